@@ -1,0 +1,300 @@
+#!/usr/bin/env python
+"""
+Generate the golden vectors under tests/golden/*.npz by running the REAL Python
+reference (LiberTEM, /root/reference/src) in this container.
+
+* The reference cannot be imported as-is here because third-party packages are absent
+  (opentelemetry, numba, sparse, sparseconverter, jsonschema, autopep8 -- SURVEY.md §8c).
+  `tests/golden/refshim/` holds throw-away stand-ins for THOSE THIRD-PARTY packages only
+  (no-op tracing, identity `njit`, NumPy-only sparseconverter); every line of LiberTEM
+  itself that runs below is the unmodified reference.
+* Inputs are produced by the seeded recipes in `tests/golden/recipes.py` (shared with the
+  parity tests), so only outputs + an input checksum are stored.
+* This script is skipped (exit 0) if /root/reference is absent (e.g. on the GPU box).
+
+Usage:  python tests/golden/generate_golden.py
+"""
+import os
+import sys
+import hashlib
+import json
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = '/root/reference/src'
+
+if not os.path.isdir(REF):
+    print("reference not present, nothing to do")
+    sys.exit(0)
+
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(HERE, 'refshim'))
+sys.path.insert(0, HERE)
+
+import numpy as np  # noqa: E402
+import scipy.sparse as sp  # noqa: E402
+
+import recipes  # noqa: E402
+
+from libertem.udf.base import UDFRunner  # noqa: E402
+from libertem.udf.masks import ApplyMasksUDF  # noqa: E402
+from libertem.udf.sum import SumUDF  # noqa: E402
+from libertem.udf.sumsigudf import SumSigUDF  # noqa: E402
+from libertem.udf.com import (  # noqa: E402
+    CoMUDF, center_shifts, apply_correction, divergence, curl_2d, magnitude,
+)
+from libertem.io.dataset.memory import MemoryDataSet  # noqa: E402
+from libertem.executor.inline import InlineJobExecutor  # noqa: E402
+from libertem.analysis.com import COMAnalysis  # noqa: E402
+from libertem.analysis.radialfourier import RadialFourierAnalysis, radial_mask_factory  # noqa: E402
+from libertem.analysis.sum import SumAnalysis  # noqa: E402
+from libertem.analysis.masks import MasksAnalysis  # noqa: E402
+from libertem.analysis.disk import DiskMaskAnalysis  # noqa: E402
+from libertem.analysis.ring import RingMaskAnalysis  # noqa: E402
+from libertem.analysis.point import PointMaskAnalysis  # noqa: E402
+from libertem.common.numba import rmatmul  # noqa: E402
+from libertem.corrections import coordinates  # noqa: E402
+from libertem import masks as ref_masks  # noqa: E402
+
+
+EX = InlineJobExecutor(inline_threads=1)
+MANIFEST = {}
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def run(ds, udf, roi=None):
+    res = UDFRunner([udf]).run_for_dataset(ds, EX, roi=roi)
+    return res.buffers[0]
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    MANIFEST[name] = {k: [list(np.shape(v)), str(np.asarray(v).dtype)] for k, v in arrays.items()}
+    print(f"wrote {path} ({os.path.getsize(path)} bytes)")
+
+
+# ---------------------------------------------------------------------------
+# 1. ApplyMasksUDF, dense masks: dtype matrix, tile shapes, partition counts
+# ---------------------------------------------------------------------------
+def gen_apply_masks_dense():
+    out = {}
+    for case in recipes.DENSE_CASES:
+        data, masks = recipes.make_dense_case(case)
+        ds = MemoryDataSet(
+            data=data, num_partitions=case['num_partitions'], sig_dims=2,
+            tileshape=case.get('tileshape'),
+        )
+        kwargs = dict(case.get('udf_kwargs', {}))
+        udf = ApplyMasksUDF(mask_factories=lambda: masks, **kwargs)
+        res = run(ds, udf)['intensity']
+        arr = np.array(res.data)
+        out[case['name']] = arr
+        out[case['name'] + '__sha_data'] = np.frombuffer(
+            bytes.fromhex(sha(data)), dtype=np.uint8)
+        out[case['name'] + '__sha_masks'] = np.frombuffer(
+            bytes.fromhex(sha(masks)), dtype=np.uint8)
+        print(case['name'], arr.shape, arr.dtype)
+    save('apply_masks_dense', **out)
+
+
+# ---------------------------------------------------------------------------
+# 2. SumUDF / SumSigUDF (config C1 shape on a reduced nav)
+# ---------------------------------------------------------------------------
+def gen_sums():
+    out = {}
+    for case in recipes.SUM_CASES:
+        data = recipes.make_sum_case(case)
+        ds = MemoryDataSet(
+            data=data, num_partitions=case['num_partitions'], sig_dims=2,
+            tileshape=case.get('tileshape'),
+        )
+        s = run(ds, SumUDF(**case.get('sum_kwargs', {})))['intensity']
+        ss = run(ds, SumSigUDF())['intensity']
+        out[case['name'] + '__sum'] = np.array(s.data)
+        out[case['name'] + '__sumsig'] = np.array(ss.data)
+        out[case['name'] + '__sha_data'] = np.frombuffer(bytes.fromhex(sha(data)), dtype=np.uint8)
+        print(case['name'], s.data.dtype, ss.data.dtype)
+    # SumAnalysis dtype rule (analysis/sum.py:94-98)
+    data = recipes.make_sum_case(recipes.SUM_CASES[1])
+    ds = MemoryDataSet(data=data, num_partitions=2, sig_dims=2)
+    udf = SumAnalysis(ds, {}).get_udf()
+    out['sum_analysis_u16__sum'] = np.array(run(ds, udf)['intensity'].data)
+    save('sums', **out)
+
+
+# ---------------------------------------------------------------------------
+# 3. CoM: CoMUDF (all result buffers) and COMAnalysis (udf + post-processing)
+# ---------------------------------------------------------------------------
+def gen_com():
+    out = {}
+    for case in recipes.COM_CASES:
+        data = recipes.make_com_case(case)
+        ds = MemoryDataSet(data=data, num_partitions=case['num_partitions'], sig_dims=2)
+        udf = CoMUDF.with_params(**case['params'])
+        res = run(ds, udf)
+        for k, v in res.items():
+            out[f"{case['name']}__udf__{k}"] = np.array(v.data)
+        # the analysis flavour
+        ap = dict(case['analysis_params'])
+        analysis = COMAnalysis(ds, ap)
+        ares = run(ds, analysis.get_udf())['intensity']
+        inten = np.array(ares.data)
+        out[f"{case['name']}__analysis__intensity"] = inten
+        p = analysis.parameters
+        yc_raw, xc_raw = center_shifts(inten[..., 0], inten[..., 1], inten[..., 2], p['cy'], p['cx'])
+        yc, xc = apply_correction(yc_raw, xc_raw, scan_rotation=p['scan_rotation'],
+                                  flip_y=p['flip_y'])
+        out[f"{case['name']}__analysis__x"] = xc
+        out[f"{case['name']}__analysis__y"] = yc
+        out[f"{case['name']}__analysis__magnitude"] = magnitude(yc, xc)
+        out[f"{case['name']}__analysis__divergence"] = divergence(yc, xc)
+        out[f"{case['name']}__analysis__curl"] = curl_2d(yc, xc)
+        out[f"{case['name']}__sha_data"] = np.frombuffer(bytes.fromhex(sha(data)), dtype=np.uint8)
+        print(case['name'], {k: (v.data.shape, str(v.data.dtype)) for k, v in res.items()})
+    # coordinate helpers (corrections/coordinates.py:11-54)
+    out['rotate_deg_33'] = coordinates.rotate_deg(33.)
+    out['rotate_deg_m90'] = coordinates.rotate_deg(-90.)
+    out['flip_y'] = coordinates.flip_y()
+    out['identity'] = coordinates.identity()
+    save('com', **out)
+
+
+# ---------------------------------------------------------------------------
+# 4. Radial Fourier analysis (dense complex64 masks)
+# ---------------------------------------------------------------------------
+def gen_radial_fourier():
+    out = {}
+    for case in recipes.RF_CASES:
+        data = recipes.make_rf_case(case)
+        ds = MemoryDataSet(data=data, num_partitions=case['num_partitions'], sig_dims=2)
+        analysis = RadialFourierAnalysis(ds, dict(case['params']))
+        p = analysis.parameters
+        out[f"{case['name']}__params"] = np.array(
+            [p['cx'], p['cy'], p['ri'], p['ro'], p['n_bins'], p['max_order'], p['mask_count'],
+             0 if p['use_sparse'] is False else 1], dtype=np.float64)
+        if p['use_sparse'] is not False:
+            print(case['name'], 'resolves to sparse -> parameters only')
+            continue
+        udf_res = run(ds, analysis.get_udf())
+        inten = np.array(udf_res['intensity'].data)
+        out[f"{case['name']}__intensity"] = inten
+        rs = analysis.get_udf_results(udf_res, None, damage=True)
+        out[f"{case['name']}__raw_results"] = np.array(rs.raw_results)
+        out[f"{case['name']}__sha_data"] = np.frombuffer(bytes.fromhex(sha(data)), dtype=np.uint8)
+        print(case['name'], inten.shape, inten.dtype)
+    save('radial_fourier', **out)
+
+
+# ---------------------------------------------------------------------------
+# 5. Mask factories, bit for bit
+# ---------------------------------------------------------------------------
+def gen_mask_factories():
+    out = {}
+    for i, kw in enumerate(recipes.CIRCULAR_CASES):
+        out[f'circular_{i}'] = ref_masks.circular(**kw)
+    for i, kw in enumerate(recipes.RING_CASES):
+        out[f'ring_{i}'] = ref_masks.ring(**kw)
+    for i, kw in enumerate(recipes.RADIAL_BINS_CASES):
+        out[f'radial_bins_{i}'] = ref_masks.radial_bins(use_sparse=False, **kw)
+    for i, kw in enumerate(recipes.POLAR_MAP_CASES):
+        r, phi = ref_masks.polar_map(**kw)
+        out[f'polar_map_{i}__r'] = r
+        out[f'polar_map_{i}__phi'] = phi
+    for i, (x, y) in enumerate(recipes.GRADIENT_CASES):
+        out[f'gradient_x_{i}'] = ref_masks.gradient_x(x, y)
+        out[f'gradient_y_{i}'] = ref_masks.gradient_y(x, y)
+    for i, args in enumerate(recipes.BOUNDING_RADIUS_CASES):
+        out[f'bounding_radius_{i}'] = np.array(ref_masks.bounding_radius(*args))
+    for i, kw in enumerate(recipes.RADIAL_MASK_FACTORY_CASES):
+        out[f'radial_mask_factory_{i}'] = radial_mask_factory(use_sparse=False, **kw)()
+    for i, kw in enumerate(recipes.RECT_CASES):
+        out[f'rectangular_{i}'] = ref_masks.rectangular(**kw)
+    for i, kw in enumerate(recipes.BGSUB_CASES):
+        out[f'background_subtraction_{i}'] = ref_masks.background_subtraction(**kw)
+    for i, kw in enumerate(recipes.RADIAL_GRADIENT_CASES):
+        out[f'radial_gradient_{i}'] = ref_masks.radial_gradient(**kw)
+    save('mask_factories', **out)
+
+
+# ---------------------------------------------------------------------------
+# 6. rmatmul (dense x CSR / CSC), the reference's own sparse kernel, run as Python
+# ---------------------------------------------------------------------------
+def gen_rmatmul():
+    out = {}
+    for case in recipes.RMATMUL_CASES:
+        left, dense_right = recipes.make_rmatmul_case(case)
+        csr = sp.csr_matrix(dense_right)
+        csc = sp.csc_matrix(dense_right)
+        r1 = rmatmul(left, csr)
+        r2 = rmatmul(left, csc)
+        out[case['name'] + '__csr'] = r1
+        out[case['name'] + '__csc'] = r2
+        print(case['name'], r1.dtype, r1.shape, np.abs(r1 - r2).max())
+    save('rmatmul', **out)
+
+
+# ---------------------------------------------------------------------------
+# 7. Partitioning + tiling negotiation for the BASELINE.json config shapes
+# ---------------------------------------------------------------------------
+def gen_tiling():
+    out = {}
+    for case in recipes.TILING_CASES:
+        shape = tuple(case['shape'])
+        # np.zeros is lazily committed; nothing below touches the pages
+        data = np.zeros(shape, dtype=case['dtype'])
+        ds = MemoryDataSet(
+            data=data, num_partitions=case['num_partitions'], sig_dims=2,
+            tileshape=case.get('tileshape'),
+        )
+        if case['udf'] == 'masks':
+            nm = case.get('n_masks', 16)
+            udf = ApplyMasksUDF(
+                mask_factories=lambda: np.zeros((nm,) + shape[2:], dtype=np.float32),
+                mask_count=nm, mask_dtype=np.float32, use_sparse=False)
+        else:
+            udf = SumUDF()
+        runner = UDFRunner([udf])
+        tasks, params = runner._prepare_run_for_dataset(
+            ds, EX, EX._get_local_env(), None, None, None, False)
+        ts = params.tiling_scheme
+        out[case['name'] + '__tileshape'] = np.array(tuple(ts.shape), dtype=np.int64)
+        out[case['name'] + '__n_sig_slices'] = np.array(len(ts), dtype=np.int64)
+        out[case['name'] + '__sig_slices'] = np.array(
+            [list(s.origin) + list(s.shape) for _, s in ts.slices], dtype=np.int64)
+        out[case['name'] + '__partitions'] = np.array(
+            [[t.partition.slice.origin[0], t.partition.slice.shape[0]] for t in tasks],
+            dtype=np.int64)
+        print(case['name'], tuple(ts.shape), len(ts), len(tasks))
+    save('tiling', **out)
+
+
+# ---------------------------------------------------------------------------
+# 8. one-mask analyses (disk / ring / point) and MasksAnalysis wiring
+# ---------------------------------------------------------------------------
+def gen_single_mask_analyses():
+    out = {}
+    data = recipes.make_com_case(recipes.COM_CASES[0])
+    ds = MemoryDataSet(data=data, num_partitions=2, sig_dims=2)
+    for name, cls, params in recipes.single_mask_analyses():
+        a = {'disk': DiskMaskAnalysis, 'ring': RingMaskAnalysis, 'point': PointMaskAnalysis,
+             'masks': MasksAnalysis}[cls](ds, dict(params))
+        res = run(ds, a.get_udf())['intensity']
+        out[name] = np.array(res.data)
+        print(name, res.data.shape, res.data.dtype)
+    save('single_mask_analyses', **out)
+
+
+if __name__ == '__main__':
+    gen_apply_masks_dense()
+    gen_sums()
+    gen_com()
+    gen_radial_fourier()
+    gen_mask_factories()
+    gen_rmatmul()
+    gen_tiling()
+    gen_single_mask_analyses()
+    with open(os.path.join(HERE, 'MANIFEST.json'), 'w') as f:
+        json.dump(MANIFEST, f, indent=1, sort_keys=True)

@@ -1,0 +1,323 @@
+"""
+Seeded input recipes shared by `generate_golden.py` (runs the real reference) and the
+parity tests (run the oracle / the HIP path on the same inputs).  Data only, no reference code.
+
+Value ranges are chosen like the reference's `_mk_random` idea (tests/utils.py:48-78):
+mostly small values plus a few large outliers, so that errors do not average out.
+"""
+import numpy as np
+
+
+def _outliers(rng, arr, n=4, val=None):
+    flat = arr.reshape(-1)
+    idx = rng.integers(0, flat.size, n)
+    if val is None:
+        if arr.dtype.kind in 'iu':
+            val = min(np.iinfo(arr.dtype).max, 60000)
+        else:
+            val = 3.0e4
+    flat[idx] = val
+    return arr
+
+
+# ---------------------------------------------------------------------------
+# dense ApplyMasksUDF cases
+# ---------------------------------------------------------------------------
+DENSE_CASES = [
+    # C2 shape on a reduced nav: real reference tile shape (32, 32, 256), 8 sig slices,
+    # ragged last frame group (72 = 2*32 + 8), uneven partitions
+    dict(name='c2_u16_16masks', nav=(3, 24), sig=(256, 256), dtype='uint16', n_masks=16,
+         mask_dtype='float32', num_partitions=2, seed=101,
+         udf_kwargs=dict(use_sparse=False, mask_count=16, mask_dtype=np.float32)),
+    # C3 shape (CoM-like 3 masks) reduced nav; tiles (32, 16, 512)
+    dict(name='c3_u16_3masks', nav=(2, 20), sig=(512, 512), dtype='uint16', n_masks=3,
+         mask_dtype='float32', num_partitions=3, seed=102,
+         udf_kwargs=dict(use_sparse=False)),
+    # float32 data: whole-partition tiles
+    dict(name='f32_5masks', nav=(5, 7), sig=(64, 48), dtype='float32', n_masks=5,
+         mask_dtype='float32', num_partitions=4, seed=103, udf_kwargs={}),
+    # odd sig shape + forced sub-frame tiling (tests/analysis/test_analysis_masks.py:141-148)
+    dict(name='odd_tiles_f32', nav=(4, 9), sig=(17, 23), dtype='float32', n_masks=4,
+         mask_dtype='float32', num_partitions=2, seed=104, tileshape=(8, 4, 23), udf_kwargs={}),
+    dict(name='u8_2masks', nav=(4, 4), sig=(32, 32), dtype='uint8', n_masks=2,
+         mask_dtype='float32', num_partitions=2, seed=105, udf_kwargs={}),
+    dict(name='i16_bool_masks', nav=(4, 4), sig=(32, 32), dtype='int16', n_masks=3,
+         mask_dtype='bool', num_partitions=2, seed=106, udf_kwargs={}),
+    # int16 data x bool masks with dtype=int32 -> exact int32 (test_analysis_masks.py:568-597)
+    dict(name='i16_int32_exact', nav=(4, 4), sig=(32, 32), dtype='int16', n_masks=3,
+         mask_dtype='bool', num_partitions=2, seed=107,
+         udf_kwargs=dict(preferred_dtype=np.int32, mask_dtype=np.int32)),
+    # int32 / int64 data -> float64 (test_analysis_masks.py:499-519)
+    dict(name='i32_f64', nav=(3, 5), sig=(24, 40), dtype='int32', n_masks=3,
+         mask_dtype='float32', num_partitions=2, seed=108, udf_kwargs={}),
+    dict(name='i64_f64', nav=(3, 5), sig=(24, 40), dtype='int64', n_masks=3,
+         mask_dtype='float32', num_partitions=2, seed=109, udf_kwargs={}),
+    dict(name='f64_f64masks', nav=(3, 5), sig=(24, 40), dtype='float64', n_masks=3,
+         mask_dtype='float64', num_partitions=2, seed=110, udf_kwargs={}),
+    # float64 masks forced down (test_analysis_masks.py:625-646)
+    dict(name='u16_f64masks_forced_f32', nav=(3, 5), sig=(24, 40), dtype='uint16', n_masks=3,
+         mask_dtype='float64', num_partitions=2, seed=111,
+         udf_kwargs=dict(mask_dtype=np.float32)),
+    # complex masks on real data (radial-Fourier style) and complex data
+    dict(name='u16_c64masks', nav=(3, 5), sig=(24, 40), dtype='uint16', n_masks=4,
+         mask_dtype='complex64', num_partitions=2, seed=112, udf_kwargs={}),
+    dict(name='c64_data', nav=(3, 5), sig=(24, 40), dtype='complex64', n_masks=3,
+         mask_dtype='float32', num_partitions=2, seed=113, udf_kwargs={}),
+    # many masks (more than one 16-column group, not a multiple of 16)
+    dict(name='u16_37masks', nav=(2, 9), sig=(64, 64), dtype='uint16', n_masks=37,
+         mask_dtype='float32', num_partitions=2, seed=114, udf_kwargs={}),
+    # single frame / single partition edge
+    dict(name='single_frame', nav=(1, 1), sig=(32, 32), dtype='uint16', n_masks=2,
+         mask_dtype='float32', num_partitions=1, seed=115, udf_kwargs={}),
+]
+
+
+def make_dense_case(case):
+    rng = np.random.default_rng(case['seed'])
+    shape = tuple(case['nav']) + tuple(case['sig'])
+    dt = np.dtype(case['dtype'])
+    if dt.kind == 'u':
+        data = rng.integers(0, 4096 if dt.itemsize > 1 else 200, shape).astype(dt)
+        _outliers(rng, data)
+    elif dt.kind == 'i':
+        data = rng.integers(-2000, 2000, shape).astype(dt)
+        _outliers(rng, data, val=30000)
+    elif dt.kind == 'f':
+        data = rng.random(shape).astype(dt)
+        _outliers(rng, data)
+    else:
+        data = (rng.random(shape) + 1j * rng.random(shape)).astype(dt)
+    mdt = np.dtype(case['mask_dtype'])
+    mshape = (case['n_masks'],) + tuple(case['sig'])
+    if mdt.kind == 'b':
+        masks = rng.random(mshape) > 0.5
+    elif mdt.kind == 'c':
+        masks = (rng.random(mshape) - 0.5 + 1j * (rng.random(mshape) - 0.5)).astype(mdt)
+    else:
+        masks = (rng.random(mshape) - 0.25).astype(mdt)
+    return data, masks
+
+
+# ---------------------------------------------------------------------------
+# Sum / SumSig
+# ---------------------------------------------------------------------------
+SUM_CASES = [
+    # config C1 sig shape, reduced nav
+    dict(name='c1_f32', nav=(4, 8), sig=(128, 128), dtype='float32', num_partitions=4, seed=201),
+    dict(name='u16', nav=(5, 7), sig=(64, 48), dtype='uint16', num_partitions=3, seed=202),
+    # tests/udf/test_sum.py:12-36
+    dict(name='odd_tiles', nav=(16, 8), sig=(17, 23), dtype='float32', num_partitions=2,
+         seed=203, tileshape=(8, 17, 23)),
+    dict(name='u8', nav=(3, 3), sig=(32, 32), dtype='uint8', num_partitions=2, seed=204),
+    dict(name='f64', nav=(3, 3), sig=(32, 32), dtype='float64', num_partitions=2, seed=205),
+    dict(name='i32', nav=(3, 3), sig=(32, 32), dtype='int32', num_partitions=2, seed=206),
+]
+
+
+def make_sum_case(case):
+    rng = np.random.default_rng(case['seed'])
+    shape = tuple(case['nav']) + tuple(case['sig'])
+    dt = np.dtype(case['dtype'])
+    if dt.kind == 'u':
+        data = rng.integers(0, 200, shape).astype(dt)
+    elif dt.kind == 'i':
+        data = rng.integers(-2000, 2000, shape).astype(dt)
+    else:
+        data = rng.random(shape).astype(dt)
+    return data
+
+
+# ---------------------------------------------------------------------------
+# CoM
+# ---------------------------------------------------------------------------
+COM_CASES = [
+    dict(name='default', nav=(8, 6), sig=(32, 32), dtype='uint16', num_partitions=2, seed=301,
+         params=dict(), analysis_params=dict()),
+    dict(name='disk', nav=(8, 6), sig=(32, 48), dtype='float32', num_partitions=3, seed=302,
+         params=dict(cy=15.2, cx=22.8, r=9.),
+         analysis_params=dict(cy=15.2, cx=22.8, r=9.)),
+    dict(name='annular_rot_flip', nav=(7, 9), sig=(40, 40), dtype='uint16', num_partitions=2,
+         seed=303,
+         params=dict(cy=19., cx=21., r=15., ri=4., scan_rotation=33., flip_y=True),
+         analysis_params=dict(cy=19., cx=21., r=15., ri=4., scan_rotation=33., flip_y=True)),
+    dict(name='regression_lin', nav=(6, 6), sig=(32, 32), dtype='float32', num_partitions=2,
+         seed=304, params=dict(regression=1), analysis_params=dict()),
+    dict(name='regression_mean', nav=(6, 6), sig=(32, 32), dtype='float32', num_partitions=2,
+         seed=305, params=dict(regression=0), analysis_params=dict()),
+    # some all-zero frames (tests/analysis/test_analysis_com.py:36-52)
+    dict(name='zero_frames', nav=(4, 4), sig=(16, 16), dtype='float32', num_partitions=2,
+         seed=306, params=dict(), analysis_params=dict(), zero_frames=[0, 5, 15]),
+]
+
+
+def make_com_case(case):
+    rng = np.random.default_rng(case['seed'])
+    nav, sig = tuple(case['nav']), tuple(case['sig'])
+    dt = np.dtype(case['dtype'])
+    # a blob whose position moves with the scan position + noise
+    yy, xx = np.mgrid[0:sig[0], 0:sig[1]]
+    data = np.zeros(nav + sig, dtype=np.float64)
+    for i in range(nav[0]):
+        for j in range(nav[1]):
+            cy = sig[0] / 2 + 3 * np.sin(i / 2.) + rng.normal() * 0.3
+            cx = sig[1] / 2 + 2 * np.cos(j / 3.) + rng.normal() * 0.3
+            data[i, j] = 1000 * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / 18.)
+    data += rng.random(nav + sig) * 5
+    for f in case.get('zero_frames', []):
+        data.reshape((-1,) + sig)[f] = 0
+    if dt.kind in 'iu':
+        return np.round(data).astype(dt)
+    return data.astype(dt)
+
+
+# ---------------------------------------------------------------------------
+# Radial Fourier
+# ---------------------------------------------------------------------------
+RF_CASES = [
+    dict(name='dense_2x4', nav=(4, 4), sig=(64, 64), dtype='uint16', num_partitions=2, seed=401,
+         params=dict(n_bins=2, max_order=4, use_sparse=False)),
+    dict(name='dense_default_small', nav=(3, 3), sig=(48, 40), dtype='float32',
+         num_partitions=2, seed=402, params=dict(use_sparse=False)),
+    dict(name='offcenter', nav=(3, 3), sig=(48, 40), dtype='float32', num_partitions=2,
+         seed=403, params=dict(cx=17.3, cy=25.9, ri=3., ro=14., n_bins=3, max_order=6,
+                               use_sparse=False)),
+    # parameter heuristics only (C5 / C4' shapes): (analysis/radialfourier.py:316-354)
+    dict(name='heuristic_c5', nav=(1, 2), sig=(1024, 1024), dtype='float32', num_partitions=1,
+         seed=404, params=dict()),
+    dict(name='heuristic_16bins', nav=(1, 2), sig=(256, 256), dtype='float32',
+         num_partitions=1, seed=405, params=dict(n_bins=16, max_order=24)),
+]
+
+
+def make_rf_case(case):
+    rng = np.random.default_rng(case['seed'])
+    shape = tuple(case['nav']) + tuple(case['sig'])
+    dt = np.dtype(case['dtype'])
+    if case['name'].startswith('heuristic'):
+        return np.zeros(shape, dtype=dt)
+    if dt.kind == 'u':
+        return rng.integers(0, 1000, shape).astype(dt)
+    return rng.random(shape).astype(dt)
+
+
+# ---------------------------------------------------------------------------
+# mask factories
+# ---------------------------------------------------------------------------
+CIRCULAR_CASES = [
+    dict(centerX=16, centerY=16, imageSizeX=32, imageSizeY=32, radius=6),
+    dict(centerX=10.5, centerY=20.25, imageSizeX=40, imageSizeY=24, radius=7.5),
+    dict(centerX=5, centerY=5, imageSizeX=16, imageSizeY=16, radius=float('inf')),
+    dict(centerX=16, centerY=16, imageSizeX=32, imageSizeY=32, radius=6, antialiased=True),
+]
+RING_CASES = [
+    dict(centerX=16, centerY=16, imageSizeX=32, imageSizeY=32, radius=10, radius_inner=4),
+    dict(centerX=10.5, centerY=20.25, imageSizeX=40, imageSizeY=24, radius=9.5, radius_inner=3.2),
+    dict(centerX=16, centerY=16, imageSizeX=32, imageSizeY=32, radius=10, radius_inner=4,
+         antialiased=True),
+]
+RADIAL_BINS_CASES = [
+    dict(centerX=16, centerY=16, imageSizeX=32, imageSizeY=32, n_bins=4, dtype=np.float32),
+    dict(centerX=10.5, centerY=20.25, imageSizeX=40, imageSizeY=24, radius=12.,
+         radius_inner=2., n_bins=5, dtype=np.float32),
+    dict(centerX=16, centerY=16, imageSizeX=32, imageSizeY=32, radius=8, n_bins=3,
+         normalize=True, dtype=np.float64),
+    dict(centerX=16, centerY=16, imageSizeX=32, imageSizeY=32, dtype=np.float32),
+    dict(centerX=20, centerY=12, imageSizeX=40, imageSizeY=24, n_bins=64, dtype=np.float32),
+]
+POLAR_MAP_CASES = [
+    dict(centerX=16, centerY=16, imageSizeX=32, imageSizeY=32),
+    dict(centerX=10.5, centerY=20.25, imageSizeX=40, imageSizeY=24),
+    dict(centerX=10.5, centerY=20.25, imageSizeX=40, imageSizeY=24, stretchY=1.3, angle=0.4),
+]
+GRADIENT_CASES = [(32, 32), (40, 24), (7, 13)]
+BOUNDING_RADIUS_CASES = [(16, 16, 32, 32), (10.5, 20.25, 40, 24), (128, 128, 256, 256),
+                         (512, 512, 1024, 1024)]
+RADIAL_MASK_FACTORY_CASES = [
+    dict(detector_y=32, detector_x=32, cx=16, cy=16, ri=0, ro=12, n_bins=2, max_order=3),
+    dict(detector_y=24, detector_x=40, cx=17.3, cy=11.9, ri=2, ro=10, n_bins=3, max_order=5),
+]
+RECT_CASES = [
+    dict(X=3, Y=4, Width=10, Height=6, imageSizeX=32, imageSizeY=24),
+    dict(X=20, Y=15, Width=-8, Height=5, imageSizeX=32, imageSizeY=24),
+    dict(X=20, Y=15, Width=8, Height=-5, imageSizeX=32, imageSizeY=24),
+    dict(X=20, Y=15, Width=-8, Height=-5, imageSizeX=32, imageSizeY=24),
+]
+BGSUB_CASES = [
+    dict(centerX=16, centerY=16, imageSizeX=32, imageSizeY=32, radius=10, radius_inner=5),
+    dict(centerX=16, centerY=16, imageSizeX=32, imageSizeY=32, radius=10, radius_inner=5,
+         antialiased=True),
+]
+RADIAL_GRADIENT_CASES = [
+    dict(centerX=16, centerY=16, imageSizeX=32, imageSizeY=32, radius=10),
+    dict(centerX=16, centerY=16, imageSizeX=32, imageSizeY=32, radius=10, antialiased=True),
+]
+
+
+# ---------------------------------------------------------------------------
+# rmatmul
+# ---------------------------------------------------------------------------
+RMATMUL_CASES = [
+    dict(name='f32', rows=13, k=97, cols=11, density=0.1, ldtype='float32', rdtype='float32',
+         seed=501),
+    dict(name='u16_f32', rows=32, k=256, cols=20, density=0.05, ldtype='uint16',
+         rdtype='float32', seed=502),
+    dict(name='f32_c64', rows=8, k=64, cols=6, density=0.2, ldtype='float32',
+         rdtype='complex64', seed=503),
+    dict(name='f64', rows=5, k=33, cols=4, density=0.3, ldtype='float64', rdtype='float64',
+         seed=504),
+    dict(name='empty_rows', rows=6, k=40, cols=5, density=0.02, ldtype='float32',
+         rdtype='float32', seed=505),
+]
+
+
+def make_rmatmul_case(case):
+    rng = np.random.default_rng(case['seed'])
+    ld = np.dtype(case['ldtype'])
+    if ld.kind == 'u':
+        left = rng.integers(0, 4096, (case['rows'], case['k'])).astype(ld)
+    else:
+        left = rng.random((case['rows'], case['k'])).astype(ld)
+    rd = np.dtype(case['rdtype'])
+    dense = rng.random((case['k'], case['cols']))
+    sel = rng.random((case['k'], case['cols'])) < case['density']
+    if rd.kind == 'c':
+        dense = dense + 1j * rng.random((case['k'], case['cols']))
+    right = np.where(sel, dense, 0).astype(rd)
+    return left, right
+
+
+# ---------------------------------------------------------------------------
+# partitioning / tiling negotiation
+# ---------------------------------------------------------------------------
+TILING_CASES = [
+    dict(name='c1', shape=(32, 32, 128, 128), dtype='float32', num_partitions=4, udf='sum'),
+    dict(name='c2', shape=(16, 256, 256, 256), dtype='uint16', num_partitions=8, udf='masks'),
+    dict(name='c2_ragged', shape=(3, 24, 256, 256), dtype='uint16', num_partitions=2,
+         udf='masks'),
+    dict(name='c3', shape=(4, 128, 512, 512), dtype='uint16', num_partitions=4, udf='masks',
+         n_masks=3),
+    dict(name='c5', shape=(2, 16, 1024, 1024), dtype='float32', num_partitions=4, udf='masks',
+         n_masks=25),
+    dict(name='u8_64', shape=(8, 64, 64, 64), dtype='uint8', num_partitions=3, udf='masks'),
+    dict(name='odd_sig', shape=(5, 7, 17, 23), dtype='uint16', num_partitions=2, udf='masks',
+         n_masks=2),
+    dict(name='forced', shape=(4, 9, 17, 23), dtype='float32', num_partitions=2, udf='masks',
+         n_masks=2, tileshape=(8, 4, 23)),
+    dict(name='more_parts_than_frames', shape=(1, 3, 16, 16), dtype='float32',
+         num_partitions=3, udf='sum'),
+]
+
+
+def single_mask_analyses():
+    masks2 = [
+        lambda: np.ones((32, 32), dtype=np.float32),
+        lambda: np.arange(32 * 32, dtype=np.float64).reshape((32, 32)) / 1024.,
+    ]
+    return [
+        ('disk_default', 'disk', {}),
+        ('disk_params', 'disk', dict(cx=10, cy=20, r=5)),
+        ('ring_default', 'ring', {}),
+        ('ring_params', 'ring', dict(cx=10, cy=20, ri=3, ro=8)),
+        ('masks_two', 'masks', dict(factories=masks2)),
+        ('masks_two_f32', 'masks', dict(factories=masks2, mask_dtype=np.float32)),
+    ]

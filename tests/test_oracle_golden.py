@@ -1,0 +1,243 @@
+"""
+Pin the oracle (oracle/) against golden vectors produced by the REAL reference
+(tests/golden/generate_golden.py).  CPU only.
+"""
+import os
+import hashlib
+
+import numpy as np
+import scipy.sparse as sp
+import pytest
+
+import recipes
+from oracle import masks as omasks, tiling as otiling, path as opath
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + '.npz'))
+
+
+def _sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+def _tol(dtype):
+    dtype = np.dtype(dtype)
+    if dtype.kind in 'iub':
+        return dict(rtol=0, atol=0)
+    if dtype in (np.float32, np.complex64):
+        # same algorithm, same BLAS: differences only from thread-count dependent blocking
+        return dict(rtol=2e-6, atol=0)
+    return dict(rtol=1e-13, atol=0)
+
+
+@pytest.mark.parametrize('case', recipes.DENSE_CASES, ids=lambda c: c['name'])
+def test_apply_masks_dense(golden_dir, case):
+    g = _load(golden_dir, 'apply_masks_dense')
+    data, masks = recipes.make_dense_case(case)
+    # the seeded recipe must reproduce the generator's inputs bit for bit
+    assert np.array_equal(_sha(data), g[case['name'] + '__sha_data'])
+    assert np.array_equal(_sha(masks), g[case['name'] + '__sha_masks'])
+    kw = case.get('udf_kwargs', {})
+    res = opath.apply_masks(
+        data, masks, num_partitions=case['num_partitions'], tileshape=case.get('tileshape'),
+        mask_dtype=kw.get('mask_dtype'), preferred_dtype=kw.get('preferred_dtype'),
+    )
+    ref = g[case['name']]
+    assert res.dtype == ref.dtype
+    assert res.shape == ref.shape
+    scale = np.abs(ref).max()
+    t = _tol(ref.dtype)
+    assert np.allclose(res, ref, rtol=t['rtol'], atol=t['rtol'] * scale)
+    if ref.dtype.kind in 'iu':
+        assert np.array_equal(res, ref)
+
+
+@pytest.mark.parametrize('case', recipes.SUM_CASES, ids=lambda c: c['name'])
+def test_sums(golden_dir, case):
+    g = _load(golden_dir, 'sums')
+    data = recipes.make_sum_case(case)
+    assert np.array_equal(_sha(data), g[case['name'] + '__sha_data'])
+    s = opath.sum_udf(data, num_partitions=case['num_partitions'],
+                      tileshape=case.get('tileshape'))
+    ss = opath.sumsig_udf(data, num_partitions=case['num_partitions'],
+                          tileshape=case.get('tileshape'))
+    rs, rss = g[case['name'] + '__sum'], g[case['name'] + '__sumsig']
+    assert s.dtype == rs.dtype and ss.dtype == rss.dtype
+    assert np.allclose(s, rs, rtol=1e-6)
+    assert np.allclose(ss, rss, rtol=1e-6)
+    if np.dtype(case['dtype']).kind in 'iu':
+        # integer-valued data below 2**24: every order of summation is exact
+        assert np.array_equal(s, rs)
+        assert np.array_equal(ss, rss)
+
+
+def test_sum_analysis_dtype(golden_dir):
+    g = _load(golden_dir, 'sums')
+    data = recipes.make_sum_case(recipes.SUM_CASES[1])
+    s = opath.sum_udf(data, num_partitions=2, dtype='float32')
+    assert np.array_equal(s, g['sum_analysis_u16__sum'])
+
+
+@pytest.mark.parametrize('case', recipes.COM_CASES, ids=lambda c: c['name'])
+def test_com(golden_dir, case):
+    g = _load(golden_dir, 'com')
+    data = recipes.make_com_case(case)
+    assert np.array_equal(_sha(data), g[case['name'] + '__sha_data'])
+    res = opath.com_udf(data, num_partitions=case['num_partitions'], **case['params'])
+    for k, v in res.items():
+        ref = g[f"{case['name']}__udf__{k}"]
+        assert v.dtype == ref.dtype, k
+        assert v.shape == ref.shape, k
+        assert np.allclose(v, ref, rtol=1e-5, atol=1e-5), k
+    ap = dict(case['analysis_params'])
+    ares = opath.com_analysis(data, num_partitions=case['num_partitions'], **ap)
+    for k in ('intensity', 'x', 'y', 'magnitude', 'divergence', 'curl'):
+        ref = g[f"{case['name']}__analysis__{k}"]
+        assert ares[k].shape == ref.shape
+        assert np.allclose(ares[k], ref, rtol=1e-5, atol=1e-5), k
+
+
+def test_coordinates(golden_dir):
+    g = _load(golden_dir, 'com')
+    assert np.array_equal(opath.rotate_deg(33.), g['rotate_deg_33'])
+    assert np.array_equal(opath.rotate_deg(-90.), g['rotate_deg_m90'])
+    assert np.array_equal(opath.flip_y(), g['flip_y'])
+    assert np.array_equal(opath.identity(), g['identity'])
+
+
+@pytest.mark.parametrize('case', recipes.RF_CASES, ids=lambda c: c['name'])
+def test_radial_fourier(golden_dir, case):
+    g = _load(golden_dir, 'radial_fourier')
+    data = recipes.make_rf_case(case)
+    p = opath.radial_fourier_parameters(tuple(case['sig']), **case['params'])
+    ref_p = g[f"{case['name']}__params"]
+    mine = np.array([p['cx'], p['cy'], p['ri'], p['ro'], p['n_bins'], p['max_order'],
+                     p['mask_count'], 0 if p['use_sparse'] is False else 1], dtype=np.float64)
+    assert np.array_equal(mine, ref_p)
+    if f"{case['name']}__intensity" not in g.files or case['name'].startswith('heuristic'):
+        return
+    res = opath.radial_fourier_analysis(data, num_partitions=case['num_partitions'],
+                                        **case['params'])
+    ref = g[f"{case['name']}__intensity"]
+    assert res['intensity'].dtype == ref.dtype
+    scale = np.abs(ref).max()
+    assert np.allclose(res['intensity'], ref, rtol=0, atol=3e-6 * scale)
+    assert np.allclose(res['raw_results'], g[f"{case['name']}__raw_results"], rtol=0,
+                       atol=3e-6 * scale)
+
+
+def test_radial_fourier_sparse_equals_dense():
+    # the sparse branch (not importable from the reference here) must agree with the pinned
+    # dense branch
+    case = recipes.RF_CASES[0]
+    data = recipes.make_rf_case(case)
+    a = opath.radial_fourier_analysis(data, num_partitions=2, n_bins=2, max_order=4,
+                                      use_sparse=False)
+    b = opath.radial_fourier_analysis(data, num_partitions=2, n_bins=2, max_order=4,
+                                      use_sparse='scipy.sparse')
+    scale = np.abs(a['intensity']).max()
+    assert np.allclose(a['intensity'], b['intensity'], rtol=0, atol=3e-6 * scale)
+
+
+def test_mask_factories(golden_dir):
+    g = _load(golden_dir, 'mask_factories')
+
+    def same(a, b):
+        a, b = np.asarray(a), np.asarray(b)
+        assert a.dtype == b.dtype, (a.dtype, b.dtype)
+        assert a.shape == b.shape
+        assert np.array_equal(a, b)
+
+    for i, kw in enumerate(recipes.CIRCULAR_CASES):
+        same(omasks.circular(**kw), g[f'circular_{i}'])
+    for i, kw in enumerate(recipes.RING_CASES):
+        same(omasks.ring(**kw), g[f'ring_{i}'])
+    for i, kw in enumerate(recipes.RADIAL_BINS_CASES):
+        same(omasks.radial_bins(use_sparse=False, **kw), g[f'radial_bins_{i}'])
+    for i, kw in enumerate(recipes.POLAR_MAP_CASES):
+        r, phi = omasks.polar_map(**kw)
+        same(r, g[f'polar_map_{i}__r'])
+        same(phi, g[f'polar_map_{i}__phi'])
+    for i, (x, y) in enumerate(recipes.GRADIENT_CASES):
+        same(omasks.gradient_x(x, y), g[f'gradient_x_{i}'])
+        same(omasks.gradient_y(x, y), g[f'gradient_y_{i}'])
+    for i, args in enumerate(recipes.BOUNDING_RADIUS_CASES):
+        assert omasks.bounding_radius(*args) == int(g[f'bounding_radius_{i}'])
+    for i, kw in enumerate(recipes.RADIAL_MASK_FACTORY_CASES):
+        same(omasks.radial_mask_stack(**kw), g[f'radial_mask_factory_{i}'])
+    for i, kw in enumerate(recipes.RECT_CASES):
+        same(omasks.rectangular(**kw), g[f'rectangular_{i}'])
+    for i, kw in enumerate(recipes.BGSUB_CASES):
+        same(omasks.background_subtraction(**kw), g[f'background_subtraction_{i}'])
+    for i, kw in enumerate(recipes.RADIAL_GRADIENT_CASES):
+        same(omasks.radial_gradient(**kw), g[f'radial_gradient_{i}'])
+
+
+def test_radial_bins_sparse_matches_dense():
+    # tests/test_masks.py:63-72 + consistency of the sparse branch with the pinned dense one
+    for kw in recipes.RADIAL_BINS_CASES:
+        dense = omasks.radial_bins(use_sparse=False, **kw)
+        sparse = omasks.radial_bins(use_sparse=True, **kw)
+        assert sp.issparse(sparse)
+        d2 = sparse.toarray().reshape(dense.shape)
+        # the centre patch is `+= (1 - cur - ri)` in the sparse branch vs `= 1 - ri` in the dense one
+        assert np.allclose(d2, dense, rtol=0, atol=1e-6)
+    m = omasks.radial_bins(20, 12, 40, 24, n_bins=64, use_sparse=False, dtype=np.float64)
+    assert np.allclose(m.sum(axis=0), 1)
+
+
+@pytest.mark.parametrize('case', recipes.RMATMUL_CASES, ids=lambda c: c['name'])
+def test_rmatmul(golden_dir, case):
+    g = _load(golden_dir, 'rmatmul')
+    left, right = recipes.make_rmatmul_case(case)
+    r1 = opath.rmatmul(left, sp.csr_matrix(right))
+    r2 = opath.rmatmul(left, sp.csc_matrix(right))
+    for mine, key in ((r1, '__csr'), (r2, '__csc')):
+        ref = g[case['name'] + key]
+        assert mine.dtype == ref.dtype
+        assert mine.shape == ref.shape
+        # identical loop order -> identical bits
+        assert np.array_equal(mine, ref)
+    # tests/common/test_numba.py:18-29
+    assert np.allclose(r1, left @ right, rtol=1e-5)
+
+
+def test_rmatmul_errors():
+    # tests/common/test_numba.py:32-61
+    le = np.zeros((3, 4), dtype=np.float32)
+    with pytest.raises(ValueError):
+        opath.rmatmul(le, sp.csr_matrix(np.zeros((5, 2))))
+    with pytest.raises(ValueError):
+        opath.rmatmul(le[0], sp.csr_matrix(np.zeros((4, 2))))
+    with pytest.raises(ValueError):
+        opath.rmatmul(le, sp.coo_matrix(np.zeros((4, 2))))
+
+
+@pytest.mark.parametrize('case', recipes.TILING_CASES, ids=lambda c: c['name'])
+def test_tiling(golden_dir, case):
+    g = _load(golden_dir, 'tiling')
+    shape = tuple(case['shape'])
+    n_frames = int(np.prod(shape[:2]))
+    with pytest.warns(RuntimeWarning) if case['name'] == 'more_parts_than_frames' \
+            else _nullcontext():
+        parts = otiling.partition_boundaries(n_frames, case['num_partitions'])
+    ref_parts = g[case['name'] + '__partitions']
+    assert [(int(a), int(a + b)) for a, b in ref_parts] == parts
+    in_dtype = opath.input_dtype(np.dtype(case['dtype']), np.float32)
+    ts = otiling.negotiate_tileshape(shape, 2, case['dtype'], in_dtype,
+                                     parts[0][1] - parts[0][0],
+                                     forced_tileshape=case.get('tileshape'))
+    assert ts == tuple(int(x) for x in g[case['name'] + '__tileshape'])
+    sl = otiling.sig_slices(shape[2:], ts[1:])
+    ref_sl = g[case['name'] + '__sig_slices']
+    assert len(sl) == int(g[case['name'] + '__n_sig_slices'])
+    assert [list(o) + list(s) for o, s in sl] == [list(map(int, r)) for r in ref_sl]
+
+
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
