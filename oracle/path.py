@@ -102,7 +102,8 @@ def rmatmul(left_dense, right_sparse):
         raise ValueError("Shape mismatch: left_dense.shape[1] != right_sparse.shape[0]")
     res_t = np.zeros((right_sparse.shape[1], left_dense.shape[0]),
                      dtype=np.result_type(right_sparse, left_dense))
-    data, indices, indptr = right_sparse.data, right_sparse.indices, right_sparse.indptr
+    if isinstance(right_sparse, (sp.csc_matrix, sp.csr_matrix)):
+        data, indices, indptr = right_sparse.data, right_sparse.indices, right_sparse.indptr
     if isinstance(right_sparse, sp.csc_matrix):
         for col in range(len(indptr) - 1):
             for index in range(indptr[col], indptr[col + 1]):

@@ -183,8 +183,13 @@ def test_radial_bins_sparse_matches_dense():
         d2 = sparse.toarray().reshape(dense.shape)
         # the centre patch is `+= (1 - cur - ri)` in the sparse branch vs `= 1 - ri` in the dense one
         assert np.allclose(d2, dense, rtol=0, atol=1e-6)
-    m = omasks.radial_bins(20, 12, 40, 24, n_bins=64, use_sparse=False, dtype=np.float64)
-    assert np.allclose(m.sum(axis=0), 1)
+    # reference known-answer tests, tests/test_masks.py:63-72
+    bins = omasks.radial_bins(35, 37, 80, 80, n_bins=42)
+    assert sp.issparse(bins) and bins.shape == (42, 80 * 80)
+    assert np.allclose(1, np.asarray(bins.sum(axis=0)))
+    bins = omasks.radial_bins(40, 41, 80, 80, n_bins=2)
+    assert bins.shape == (2, 80, 80)
+    assert np.allclose(1, bins.sum(axis=0))
 
 
 @pytest.mark.parametrize('case', recipes.RMATMUL_CASES, ids=lambda c: c['name'])
