@@ -224,9 +224,7 @@ def test_tiling(golden_dir, case):
     g = _load(golden_dir, 'tiling')
     shape = tuple(case['shape'])
     n_frames = int(np.prod(shape[:2]))
-    with pytest.warns(RuntimeWarning) if case['name'] == 'more_parts_than_frames' \
-            else _nullcontext():
-        parts = otiling.partition_boundaries(n_frames, case['num_partitions'])
+    parts = otiling.partition_boundaries(n_frames, case['num_partitions'])
     ref_parts = g[case['name'] + '__partitions']
     assert [(int(a), int(a + b)) for a, b in ref_parts] == parts
     in_dtype = opath.input_dtype(np.dtype(case['dtype']), np.float32)
@@ -240,9 +238,8 @@ def test_tiling(golden_dir, case):
     assert [list(o) + list(s) for o, s in sl] == [list(map(int, r)) for r in ref_sl]
 
 
-class _nullcontext:
-    def __enter__(self):
-        return None
-
-    def __exit__(self, *a):
-        return False
+def test_partition_clamp():
+    # base/partition.py:74-81
+    with pytest.warns(RuntimeWarning):
+        parts = otiling.partition_boundaries(3, 8)
+    assert parts == [(0, 1), (1, 2), (2, 3)]
