@@ -1,0 +1,123 @@
+/*
+ * ltmi.h -- C ABI of libltmi.so: MI355X (gfx950) kernels for LiberTEM's mask-application /
+ * virtual-detector hot path.
+ *
+ * The reference (LiberTEM, pure Python) has no FFI for this path; its operator boundary is the
+ * Python UDF interface (`process_tile` / `merge`, src/libertem/udf/base.py:1334-1608).  Each entry
+ * point below replaces the array-library call the reference makes *inside* that interface and
+ * cites it.  All pointers named `*_dev` / `tile` / `out` are DEVICE pointers owned by the caller
+ * (torch-ROCm tensors' data_ptr()); the library never allocates user-visible memory.  It owns only
+ * the opaque mask handles (prepared device images of the mask stack + a partial-sum workspace).
+ *
+ * Conventions
+ *   - every function returns 0 (LTMI_OK) on success, a negative LTMI_E_* code for argument errors,
+ *     or a positive hipError_t; `ltmi_last_error()` returns a thread-local message.
+ *   - nothing throws across the ABI.
+ *   - `stream` is a hipStream_t (NULL = the legacy default stream); all work is enqueued on it and
+ *     the call returns without synchronising.  A handle must be used on one stream at a time
+ *     (its workspace is reused by consecutive calls).
+ *   - `device` is the HIP device ordinal; handles remember theirs and every call on a handle
+ *     switches to it (hipSetDevice) first.
+ *   - tiles are row-major `(n_frames, n_px)` with `ld_tile` ELEMENTS between consecutive frames,
+ *     i.e. exactly the flattened C-contiguous tile `tile.reshape((n, -1))` of
+ *     src/libertem/udf/masks.py:79-83.
+ */
+#ifndef LTMI_H
+#define LTMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LTMI_VERSION 1
+
+#define LTMI_OK 0
+#define LTMI_E_INVALID (-1)      /* bad argument (null pointer, negative size, ...) */
+#define LTMI_E_DTYPE (-2)        /* dtype combination not supported */
+#define LTMI_E_SHAPE (-3)        /* shapes do not match the handle */
+#define LTMI_E_NOMEM (-4)        /* host allocation failed */
+
+/* dtype codes (numpy names) */
+enum ltmi_dtype {
+    LTMI_BOOL = 0, LTMI_U8 = 1, LTMI_I8 = 2, LTMI_U16 = 3, LTMI_I16 = 4, LTMI_U32 = 5,
+    LTMI_I32 = 6, LTMI_U64 = 7, LTMI_I64 = 8, LTMI_F32 = 9, LTMI_F64 = 10, LTMI_C64 = 11,
+    LTMI_C128 = 12
+};
+
+typedef struct ltmi_masks ltmi_masks;      /* opaque */
+
+/* ---- misc ----------------------------------------------------------------------------- */
+int ltmi_version(void);
+const char *ltmi_last_error(void);
+int ltmi_device_count(int *count);
+/* name_out: at least 256 bytes. replaces libertem.utils.devices.detect() (utils/devices.py:31-60) */
+int ltmi_device_info(int device, char *name_out, int *cu_count, int64_t *hbm_bytes, int *gfx_arch);
+
+/* ---- mask stacks ------------------------------------------------------------------------
+ * Dense stack.  Replaces MaskContainer.get_for_sig_slice(sig_slice, transpose=True) +
+ * for_backend(m, backend).astype(dtype)  (src/libertem/common/container.py:74-94, :213-217):
+ * `masks_host` is the HOST array of the sig-sliced, flattened stack, logical shape
+ * (n_masks, n_px), C-contiguous ("mask-major", which is also the reference's physical layout),
+ * already cast to `result_dtype` = np.result_type(input_dtype, mask_dtype)
+ * (src/libertem/udf/masks.py:362).  The library converts it to its own device image
+ * (see DESIGN.md "HBM layout") and keeps no reference to `masks_host`.
+ */
+int ltmi_masks_create_dense(int device, const void *masks_host, int result_dtype,
+                            int64_t n_masks, int64_t n_px, ltmi_masks **out);
+
+/* Sparse stack in CSR over pixels, exactly the matrix the reference builds in
+ * _build_sparse (src/libertem/common/container.py:53-64): shape (n_px, n_masks),
+ * indptr[n_px + 1], indices[nnz] (mask index), data[nnz] of `result_dtype` (f32/f64/c64/c128).
+ * Host pointers; canonical format (sorted, no duplicates) is not required.
+ */
+int ltmi_masks_create_csr(int device, const int64_t *indptr, const int64_t *indices,
+                          const void *data, int result_dtype, int64_t n_px, int64_t n_masks,
+                          ltmi_masks **out);
+
+int ltmi_masks_destroy(ltmi_masks *m);
+/* 0 = dense/MFMA-f32, 1 = dense/generic, 2 = csr; for tests and the bench */
+int ltmi_masks_kind(const ltmi_masks *m, int *kind);
+
+/* ---- the hot call -----------------------------------------------------------------------
+ * out[f, k] (+)= sum_p tile[f, p] * masks[k, p]
+ * Replaces ApplyMasksEngine.process_flat (torch.mm / `flat_tile @ masks` / rmatmul:
+ * src/libertem/udf/masks.py:59-77, src/libertem/common/numba/__init__.py:90-184) fused with the
+ * dtype conversion of the tile (io/dataset/memory.py:102-105) and with the accumulation
+ * `results.intensity[:] += ...` (src/libertem/udf/masks.py:389-392) when accumulate != 0.
+ *   tile       device pointer, (n_frames, n_px) of `tile_dtype` (the dataset's NATIVE dtype --
+ *              the astype(input_dtype) copy is fused), ld_tile elements between frames
+ *   out        device pointer, (n_frames, n_masks) of the handle's result dtype, ld_out elements
+ *   accumulate 0: out = product, 1: out += product
+ */
+int ltmi_apply_masks(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames,
+                     int64_t ld_tile, void *out, int64_t ld_out, int accumulate, void *stream);
+
+/* ---- reductions -------------------------------------------------------------------------
+ * SumUDF.process_tile: out[p] (+)= sum_f tile[f, p]        (src/libertem/udf/sum.py:43-48)
+ *   out: device (n_px,) of out_dtype; `workspace` device scratch of at least
+ *   ltmi_sum_frames_workspace(n_frames, n_px, out_dtype) bytes (may be NULL if that is 0).
+ */
+int64_t ltmi_sum_frames_workspace(int64_t n_frames, int64_t n_px, int out_dtype);
+int ltmi_sum_frames(int device, const void *tile, int tile_dtype, int64_t n_frames, int64_t n_px,
+                    int64_t ld_tile, void *out, int out_dtype, int accumulate, void *workspace,
+                    void *stream);
+/* SumSigUDF.process_tile: out[f] (+)= sum_p tile[f, p]   (src/libertem/udf/sumsigudf.py:30-39) */
+int ltmi_sum_sig(int device, const void *tile, int tile_dtype, int64_t n_frames, int64_t n_px,
+                 int64_t ld_tile, void *out, int out_dtype, int accumulate, void *stream);
+
+/* merge for sig-kind buffers: dest[i] += src[i]          (src/libertem/udf/sum.py:50-52) */
+int ltmi_axpy(int device, void *dest, const void *src, int dtype, int64_t n, void *stream);
+
+/* ---- tuning / introspection (bench + tests) ------------------------------------------- */
+/* force a kernel variant for the dense MFMA path: mt in {0(auto),1,2}, waves in {0,4,8},
+ * ksplit 0 = auto.  Returns LTMI_E_INVALID for unsupported values. */
+int ltmi_masks_set_tuning(ltmi_masks *m, int mt, int waves, int ksplit);
+/* name of the kernel variant the last ltmi_apply_masks on this handle launched */
+const char *ltmi_masks_last_kernel(const ltmi_masks *m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LTMI_H */

@@ -1,0 +1,76 @@
+"""
+Build libltmi.so (the C-ABI HIP library) for gfx950 with hipcc, in-tree.
+
+    python -m libertem_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  The result lands in libertem_amd/_lib/libltmi.so, which is
+git-ignored but travels to the GPU box with the repo snapshot.
+"""
+import os
+import subprocess
+import sys
+import shutil
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIBDIR = os.path.join(HERE, '_lib')
+LIB = os.path.join(LIBDIR, 'libltmi.so')
+OBJDIR = os.path.join(HERE, '_lib', 'obj')
+
+SOURCES = ['ltmi_capi.cpp', 'ltmi_dense.hip', 'ltmi_sparse.hip', 'ltmi_reduce.hip']
+ARCH = 'gfx950'
+FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function']
+
+
+def find_hipcc():
+    for cand in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', shutil.which('hipcc')):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, /opt/rocm/bin/hipcc, PATH)")
+
+
+def _deps(src):
+    deps = [os.path.join(CSRC, src), os.path.join(CSRC, 'ltmi_common.h'),
+            os.path.join(os.path.dirname(HERE), 'include', 'ltmi.h'), os.path.abspath(__file__)]
+    return [d for d in deps if os.path.exists(d)]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = find_hipcc()
+    os.makedirs(OBJDIR, exist_ok=True)
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + '.o')
+        objs.append(obj)
+        if force or _stale(obj, _deps(src)):
+            cmd = [hipcc] + FLAGS + ['-x', 'hip', '-c', os.path.join(CSRC, src), '-o', obj]
+            jobs.append(cmd)
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + r.stdout)
+        return r.stdout
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for out in ex.map(run, jobs):
+            if verbose and out.strip():
+                print(out)
+    if force or jobs or not os.path.exists(LIB):
+        run([hipcc, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', LIB] + objs)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

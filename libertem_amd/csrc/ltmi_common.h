@@ -1,0 +1,50 @@
+// Shared host-side helpers for libltmi (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string>
+#include "../../include/ltmi.h"
+
+namespace ltmi {
+
+void set_error(const char *fmt, ...);
+
+#define LTMI_HIP(expr)                                                                   \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            ltmi::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),       \
+                            __FILE__, __LINE__);                                         \
+            return (int)_e;                                                              \
+        }                                                                                \
+    } while (0)
+
+#define LTMI_FAIL(code, ...)                                                             \
+    do {                                                                                 \
+        ltmi::set_error(__VA_ARGS__);                                                    \
+        return (code);                                                                   \
+    } while (0)
+
+static inline int dtype_size(int dt) {
+    switch (dt) {
+        case LTMI_BOOL: case LTMI_U8: case LTMI_I8: return 1;
+        case LTMI_U16: case LTMI_I16: return 2;
+        case LTMI_U32: case LTMI_I32: case LTMI_F32: return 4;
+        case LTMI_U64: case LTMI_I64: case LTMI_F64: case LTMI_C64: return 8;
+        case LTMI_C128: return 16;
+    }
+    return 0;
+}
+
+static inline const char *dtype_name(int dt) {
+    static const char *n[] = {"bool", "uint8", "int8", "uint16", "int16", "uint32", "int32",
+                              "uint64", "int64", "float32", "float64", "complex64", "complex128"};
+    return (dt >= 0 && dt <= LTMI_C128) ? n[dt] : "?";
+}
+
+struct cfloat { float re, im; };
+struct cdouble { double re, im; };
+
+}  // namespace ltmi

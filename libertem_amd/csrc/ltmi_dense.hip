@@ -1,0 +1,763 @@
+// Dense mask application for gfx950 (MI355X):  out[f, k] (+)= sum_p tile[f, p] * masks[k, p]
+//
+// Replaces ApplyMasksEngine.process_flat for dense stacks (src/libertem/udf/masks.py:59-77:
+// torch.mm / `flat_tile @ masks`) fused with the tile's dtype conversion
+// (io/dataset/memory.py:102-105) and the `+=` into the result buffer (udf/masks.py:389-392).
+//
+// Two device paths:
+//   * k_dense_mfma    : f32 result (also complex64 = 2 real columns per mask) for
+//                       u8/i8/u16/i16/f32 tiles.  v_mfma_f32_16x16x4_f32 (exact f32 FMA chain),
+//                       frames on the M axis straight from HBM into VGPRs (non-temporal 16-B
+//                       loads, converted in registers), mask columns staged through LDS from a
+//                       pre-swizzled device image, pixels on the K axis.
+//   * k_dense_generic : every other dtype combination the reference supports (float64, complex,
+//                       wrap-around integers); plain VALU, correctness first.
+#include "ltmi_common.h"
+#include <vector>
+#include <cstring>
+#include <algorithm>
+#include <typeinfo>
+
+namespace ltmi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int KC = 256;                    // pixels per staged mask chunk
+constexpr int GROUP = 16;                  // mask columns per MFMA group (N of 16x16x4)
+constexpr int CHUNK_FLOATS = GROUP * KC;   // 4096 floats = 16 KiB per (group, chunk)
+
+// Position of mask value (column n of a group, pixel q of a chunk) inside the 16-KiB image
+// block.  Lane (n = lane&15, kg = lane>>4) of a wave needs, for pixel block `blk` (32 px) and
+// half h, the four pixels q = blk*32 + kg*8 + h*4 + {0..3} of its column n as ONE ds_read_b128.
+// The 16-B unit index is XOR-ed with n so that the 16 lanes of every ds_read_b128 service group
+// (which always hold 16 different n) hit 16 different 16-B slots of the 256-B LDS row:
+// conflict-free without padding, and the image can be copied into LDS linearly.
+__host__ __device__ static inline int img_index(int n, int q) {
+    const int blk = q >> 5, kg = (q >> 3) & 3, j = q & 7;
+    const int unit = (kg * 16 + blk * 2 + (j >> 2)) ^ n;
+    return n * KC + unit * 4 + (j & 3);
+}
+
+// ---- per-input-dtype loading / conversion of 8 consecutive pixels ---------------------------
+template <typename T> struct InTraits;
+
+template <> struct InTraits<uint16_t> {
+    typedef u32x4 raw_t;
+    static __device__ __forceinline__ raw_t load(const uint16_t *p) {
+        return __builtin_nontemporal_load((const u32x4 *)p);
+    }
+    static __device__ __forceinline__ void cvt(const raw_t &r, float (&f)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = (float)(r[i] & 0xffffu);
+            f[2 * i + 1] = (float)(r[i] >> 16);
+        }
+    }
+};
+template <> struct InTraits<int16_t> {
+    typedef u32x4 raw_t;
+    static __device__ __forceinline__ raw_t load(const int16_t *p) {
+        return __builtin_nontemporal_load((const u32x4 *)p);
+    }
+    static __device__ __forceinline__ void cvt(const raw_t &r, float (&f)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = (float)((int)(r[i] << 16) >> 16);
+            f[2 * i + 1] = (float)((int)r[i] >> 16);
+        }
+    }
+};
+template <> struct InTraits<uint8_t> {
+    typedef u32x2 raw_t;
+    static __device__ __forceinline__ raw_t load(const uint8_t *p) {
+        return __builtin_nontemporal_load((const u32x2 *)p);
+    }
+    static __device__ __forceinline__ void cvt(const raw_t &r, float (&f)[8]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) f[4 * i + b] = (float)((r[i] >> (8 * b)) & 0xffu);
+        }
+    }
+};
+template <> struct InTraits<int8_t> {
+    typedef u32x2 raw_t;
+    static __device__ __forceinline__ raw_t load(const int8_t *p) {
+        return __builtin_nontemporal_load((const u32x2 *)p);
+    }
+    static __device__ __forceinline__ void cvt(const raw_t &r, float (&f)[8]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                f[4 * i + b] = (float)((int)(r[i] << (24 - 8 * b)) >> 24);
+        }
+    }
+};
+template <> struct InTraits<float> {
+    struct raw_t { f32x4 a, b; };
+    static __device__ __forceinline__ raw_t load(const float *p) {
+        raw_t r;
+        r.a = __builtin_nontemporal_load((const f32x4 *)p);
+        r.b = __builtin_nontemporal_load((const f32x4 *)p + 1);
+        return r;
+    }
+    static __device__ __forceinline__ void cvt(const raw_t &r, float (&f)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f[i] = r.a[i]; f[4 + i] = r.b[i]; }
+    }
+};
+
+// ---- the MFMA kernel ---------------------------------------------------------------------------
+// grid = (frame tiles, ksplit, column-group tiles); block = WAVES*64.
+// Each wave owns MT*16 consecutive frames (M), all waves of a block share the staged mask chunk.
+template <typename T, int MT, int NG, int WAVES, bool ALIGNED>
+__global__ void __launch_bounds__(WAVES * 64)
+k_dense_mfma(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
+             const float *__restrict__ img, int n_chunks, float *__restrict__ out, int64_t ld_out,
+             int n_cols, int accumulate, float *__restrict__ partials, int ksplit) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NT = WAVES * 64;
+    constexpr int STAGE = NG * CHUNK_FLOATS;   // floats per LDS stage
+    constexpr int BUNITS = STAGE / 4 / NT;     // 16-B units each thread copies per stage
+    static_assert(STAGE % (4 * NT) == 0, "stage must divide evenly");
+    using TR = InTraits<T>;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int m = lane & 15, kg = lane >> 4;
+    const int g0 = blockIdx.z * NG;
+    const int ks = blockIdx.y;
+
+    const int n_full = ALIGNED ? (int)(n_px / KC) : 0;   // chunks readable with vector loads
+    const int per = (n_chunks + ksplit - 1) / ksplit;
+    const int c_begin = ks * per;
+    const int c_end = min(n_chunks, c_begin + per);
+    const int cf_end = min(c_end, n_full);
+
+    const int64_t f_wave = (int64_t)blockIdx.x * (WAVES * MT * 16) + wave * (MT * 16);
+    const T *rowp[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int64_t f = f_wave + mt * 16 + m;
+        if (f > n_frames - 1) f = n_frames - 1;   // clamp: loads stay valid, result discarded
+        rowp[mt] = tile + f * ld + kg * 8;
+    }
+
+    f32x4 acc[MT][NG];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[mt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // this thread's share of the linear image -> LDS copy
+    const u32x4 *img_units = (const u32x4 *)img;
+    auto img_unit_index = [&](int i, int c) -> int64_t {
+        const int u = i * NT + tid;                  // unit within the stage
+        const int g = u / (CHUNK_FLOATS / 4);
+        const int w = u % (CHUNK_FLOATS / 4);
+        return ((int64_t)(g0 + g) * n_chunks + c) * (CHUNK_FLOATS / 4) + w;
+    };
+
+    // LDS read offsets (floats) of this lane's column for (blk, h): base + ((blk*2+h)^m)*4
+    const int lds_lane_base = m * KC + kg * 64;
+
+    if (c_begin < cf_end) {
+        typename TR::raw_t raw[MT][8];
+        u32x4 breg[BUNITS];
+        // prologue: mask chunk c_begin -> stage 0, frame data of chunk c_begin -> registers
+#pragma unroll
+        for (int i = 0; i < BUNITS; ++i) breg[i] = img_units[img_unit_index(i, c_begin)];
+#pragma unroll
+        for (int blk = 0; blk < 8; ++blk)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                raw[mt][blk] = TR::load(rowp[mt] + (int64_t)c_begin * KC + blk * 32);
+#pragma unroll
+        for (int i = 0; i < BUNITS; ++i) ((u32x4 *)lds)[i * NT + tid] = breg[i];
+        __syncthreads();
+
+        for (int c = c_begin; c < cf_end; ++c) {
+            const int cn = min(c + 1, cf_end - 1);      // branch-free prefetch target
+            const int s = (c - c_begin) & 1;
+#pragma unroll
+            for (int i = 0; i < BUNITS; ++i) breg[i] = img_units[img_unit_index(i, cn)];
+            const float *ldsb = lds + s * STAGE + lds_lane_base;
+#pragma unroll
+            for (int blk = 0; blk < 8; ++blk) {
+                float a[MT][8];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) TR::cvt(raw[mt][blk], a[mt]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    raw[mt][blk] = TR::load(rowp[mt] + (int64_t)cn * KC + blk * 32);
+                f32x4 b[NG][2];
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        b[g][h] = *(const f32x4 *)(ldsb + g * CHUNK_FLOATS +
+                                                   (((blk * 2 + h) ^ m) << 2));
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+                            acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                a[mt][j], b[g][j >> 2][j & 3], acc[mt][g], 0, 0, 0);
+            }
+            u32x4 *ldsn = (u32x4 *)(lds + (s ^ 1) * STAGE);
+#pragma unroll
+            for (int i = 0; i < BUNITS; ++i) ldsn[i * NT + tid] = breg[i];
+            __syncthreads();
+        }
+    }
+
+    // chunks that need guarded element loads: the ragged last chunk (n_px % 256 != 0), or every
+    // chunk when the rows are not 16-byte aligned
+    for (int c = max(c_begin, n_full); c < c_end; ++c) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < BUNITS; ++i)
+            ((u32x4 *)lds)[i * NT + tid] = img_units[img_unit_index(i, c)];
+        __syncthreads();
+        const float *ldsb = lds + lds_lane_base;
+#pragma unroll
+        for (int blk = 0; blk < 8; ++blk) {
+            const int64_t p0 = (int64_t)c * KC + blk * 32;   // + kg*8 is folded into rowp
+            float a[MT][8];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    a[mt][j] = (p0 + kg * 8 + j < n_px) ? (float)rowp[mt][p0 + j] : 0.f;
+            f32x4 b[NG][2];
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    b[g][h] = *(const f32x4 *)(ldsb + g * CHUNK_FLOATS +
+                                               (((blk * 2 + h) ^ m) << 2));
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                        acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                            a[mt][j], b[g][j >> 2][j & 3], acc[mt][g], 0, 0, 0);
+        }
+    }
+
+    // epilogue.  C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t f = f_wave + mt * 16 + kg * 4 + r;
+                const int col = (g0 + g) * GROUP + m;
+                if (f < n_frames && col < n_cols) {
+                    const float v = acc[mt][g][r];
+                    if (ksplit == 1) {
+                        float *p = out + f * ld_out + col;
+                        *p = accumulate ? (*p + v) : v;
+                    } else {
+                        partials[((int64_t)ks * n_frames + f) * n_cols + col] = v;
+                    }
+                }
+            }
+}
+
+__global__ void k_reduce_partials(const float *__restrict__ partials, int ksplit,
+                                  int64_t n_frames, int n_cols, float *__restrict__ out,
+                                  int64_t ld_out, int accumulate) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_frames * n_cols) return;
+    const int64_t f = idx / n_cols;
+    const int col = (int)(idx % n_cols);
+    float *p = out + f * ld_out + col;
+    float s = accumulate ? *p : 0.f;
+    for (int k = 0; k < ksplit; ++k) s += partials[(int64_t)k * n_frames * n_cols + idx];
+    *p = s;
+}
+
+// ---- generic path ----------------------------------------------------------------------------
+// Acc types: float, double, cfloat, cdouble, uint64_t (wrap-around integer arithmetic)
+template <typename A> struct AccOps;
+template <> struct AccOps<float> {
+    static __device__ __forceinline__ float zero() { return 0.f; }
+    static __device__ __forceinline__ void fma(float &acc, float x, float m) { acc += x * m; }
+    static __device__ __forceinline__ float add(float a, float b) { return a + b; }
+};
+template <> struct AccOps<double> {
+    static __device__ __forceinline__ double zero() { return 0.; }
+    static __device__ __forceinline__ void fma(double &acc, double x, double m) { acc += x * m; }
+    static __device__ __forceinline__ double add(double a, double b) { return a + b; }
+};
+template <> struct AccOps<uint64_t> {
+    static __device__ __forceinline__ uint64_t zero() { return 0; }
+    static __device__ __forceinline__ void fma(uint64_t &acc, uint64_t x, uint64_t m) {
+        acc += x * m;
+    }
+    static __device__ __forceinline__ uint64_t add(uint64_t a, uint64_t b) { return a + b; }
+};
+template <> struct AccOps<cfloat> {
+    static __device__ __forceinline__ cfloat zero() { return cfloat{0.f, 0.f}; }
+    static __device__ __forceinline__ void fma(cfloat &acc, cfloat x, cfloat m) {
+        acc.re += x.re * m.re - x.im * m.im;
+        acc.im += x.re * m.im + x.im * m.re;
+    }
+    static __device__ __forceinline__ cfloat add(cfloat a, cfloat b) {
+        return cfloat{a.re + b.re, a.im + b.im};
+    }
+};
+template <> struct AccOps<cdouble> {
+    static __device__ __forceinline__ cdouble zero() { return cdouble{0., 0.}; }
+    static __device__ __forceinline__ void fma(cdouble &acc, cdouble x, cdouble m) {
+        acc.re += x.re * m.re - x.im * m.im;
+        acc.im += x.re * m.im + x.im * m.re;
+    }
+    static __device__ __forceinline__ cdouble add(cdouble a, cdouble b) {
+        return cdouble{a.re + b.re, a.im + b.im};
+    }
+};
+
+template <typename A, typename T> struct Conv {
+    static __device__ __forceinline__ A from(T v) { return (A)v; }
+};
+template <typename T> struct Conv<uint64_t, T> {   // integer: sign-extend like numpy astype
+    static __device__ __forceinline__ uint64_t from(T v) { return (uint64_t)(int64_t)v; }
+};
+template <> struct Conv<uint64_t, uint64_t> {
+    static __device__ __forceinline__ uint64_t from(uint64_t v) { return v; }
+};
+template <typename T> struct Conv<cfloat, T> {
+    static __device__ __forceinline__ cfloat from(T v) { return cfloat{(float)v, 0.f}; }
+};
+template <typename T> struct Conv<cdouble, T> {
+    static __device__ __forceinline__ cdouble from(T v) { return cdouble{(double)v, 0.}; }
+};
+template <> struct Conv<cfloat, cfloat> {
+    static __device__ __forceinline__ cfloat from(cfloat v) { return v; }
+};
+template <> struct Conv<cdouble, cfloat> {
+    static __device__ __forceinline__ cdouble from(cfloat v) { return cdouble{v.re, v.im}; }
+};
+template <> struct Conv<cdouble, cdouble> {
+    static __device__ __forceinline__ cdouble from(cdouble v) { return v; }
+};
+template <> struct Conv<cfloat, cdouble> {
+    static __device__ __forceinline__ cfloat from(cdouble v) {
+        return cfloat{(float)v.re, (float)v.im};
+    }
+};
+
+template <typename S, typename A> struct Store {
+    static __device__ __forceinline__ void put(S *p, A v, bool accumulate) {
+        *p = accumulate ? (S)(*p + (S)v) : (S)v;
+    }
+};
+template <> struct Store<cfloat, cfloat> {
+    static __device__ __forceinline__ void put(cfloat *p, cfloat v, bool accumulate) {
+        if (accumulate) { v.re += p->re; v.im += p->im; }
+        *p = v;
+    }
+};
+template <> struct Store<cdouble, cdouble> {
+    static __device__ __forceinline__ void put(cdouble *p, cdouble v, bool accumulate) {
+        if (accumulate) { v.re += p->re; v.im += p->im; }
+        *p = v;
+    }
+};
+
+constexpr int GEN_MASKS = 4;   // masks per block of the generic kernel
+
+// block (256 threads) per (frame, group of 4 masks)
+template <typename TIn, typename A, typename S>
+__global__ void __launch_bounds__(256)
+k_dense_generic(const TIn *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
+                const A *__restrict__ masks, int n_masks, S *__restrict__ out, int64_t ld_out,
+                int accumulate) {
+    __shared__ A red[GEN_MASKS][256];
+    const int64_t f = blockIdx.x;
+    const int k0 = blockIdx.y * GEN_MASKS;
+    const int nk = min(GEN_MASKS, n_masks - k0);
+    A acc[GEN_MASKS];
+#pragma unroll
+    for (int k = 0; k < GEN_MASKS; ++k) acc[k] = AccOps<A>::zero();
+    const TIn *row = tile + f * ld;
+    for (int64_t p = threadIdx.x; p < n_px; p += 256) {
+        const A x = Conv<A, TIn>::from(row[p]);
+#pragma unroll
+        for (int k = 0; k < GEN_MASKS; ++k)
+            if (k < nk) AccOps<A>::fma(acc[k], x, masks[(int64_t)(k0 + k) * n_px + p]);
+    }
+#pragma unroll
+    for (int k = 0; k < GEN_MASKS; ++k) red[k][threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+#pragma unroll
+            for (int k = 0; k < GEN_MASKS; ++k)
+                red[k][threadIdx.x] = AccOps<A>::add(red[k][threadIdx.x], red[k][threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if ((int)threadIdx.x < nk)
+        Store<S, A>::put(out + f * ld_out + k0 + threadIdx.x, red[threadIdx.x][0], accumulate != 0);
+}
+
+}  // namespace ltmi
+
+// =================================================================================================
+// host side
+// =================================================================================================
+using namespace ltmi;
+
+struct ltmi_masks {
+    int device = 0;
+    int kind = 0;            // 0 mfma-f32, 1 generic, 2 csr
+    int result_dtype = 0;
+    int64_t n_masks = 0, n_px = 0;
+    // kind 0
+    int n_cols = 0;          // real f32 columns (2 per mask for complex64)
+    int n_groups = 0;        // padded to a multiple of ng
+    int ng = 1;
+    int n_chunks = 0;
+    float *img = nullptr;
+    float *partials = nullptr;
+    size_t partials_bytes = 0;
+    int tune_mt = 0, tune_waves = 0, tune_ksplit = 0;
+    // kind 1
+    void *gmasks = nullptr;  // (n_masks, n_px) of the accumulate type
+    // kind 2 (ltmi_sparse.hip)
+    void *csr = nullptr;
+    char last_kernel[128] = {0};
+};
+
+namespace ltmi {
+int csr_destroy(ltmi_masks *m);   // ltmi_sparse.hip
+int csr_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames, int64_t ld_tile,
+              void *out, int64_t ld_out, int accumulate, hipStream_t stream);
+}
+
+static bool mfma_tile_dtype(int dt) {
+    return dt == LTMI_U8 || dt == LTMI_I8 || dt == LTMI_U16 || dt == LTMI_I16 ||
+           dt == LTMI_F32 || dt == LTMI_BOOL;
+}
+
+extern "C" int ltmi_masks_create_dense(int device, const void *masks_host, int result_dtype,
+                                       int64_t n_masks, int64_t n_px, ltmi_masks **out) {
+    if (!masks_host || !out || n_masks <= 0 || n_px <= 0)
+        LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_create_dense: bad arguments (n_masks=%lld n_px=%lld)",
+                  (long long)n_masks, (long long)n_px);
+    if (dtype_size(result_dtype) == 0)
+        LTMI_FAIL(LTMI_E_DTYPE, "ltmi_masks_create_dense: unknown dtype %d", result_dtype);
+    LTMI_HIP(hipSetDevice(device));
+    ltmi_masks *m = new (std::nothrow) ltmi_masks();
+    if (!m) LTMI_FAIL(LTMI_E_NOMEM, "out of host memory");
+    m->device = device;
+    m->result_dtype = result_dtype;
+    m->n_masks = n_masks;
+    m->n_px = n_px;
+
+    m->kind = (result_dtype == LTMI_F32 || result_dtype == LTMI_C64) ? 0 : 1;
+    if (m->kind == 0) {
+        // ---- MFMA image ----
+        const int cpm = (result_dtype == LTMI_C64) ? 2 : 1;      // real columns per mask
+        m->n_cols = (int)(n_masks * cpm);
+        int groups = (m->n_cols + GROUP - 1) / GROUP;
+        m->ng = groups == 1 ? 1 : (groups == 2 ? 2 : 4);
+        m->n_groups = (groups + m->ng - 1) / m->ng * m->ng;
+        m->n_chunks = (int)((n_px + KC - 1) / KC);
+        const size_t n_float = (size_t)m->n_groups * m->n_chunks * CHUNK_FLOATS;
+        std::vector<float> img;
+        try { img.assign(n_float, 0.f); } catch (...) {
+            delete m;
+            LTMI_FAIL(LTMI_E_NOMEM, "out of host memory for the mask image");
+        }
+        const float *src = (const float *)masks_host;   // f32, or interleaved (re, im) pairs
+        for (int64_t k = 0; k < n_masks; ++k) {
+            for (int part = 0; part < cpm; ++part) {
+                const int col = (int)(k * cpm + part);
+                const int g = col / GROUP, n = col % GROUP;
+                for (int64_t p = 0; p < n_px; ++p) {
+                    const int c = (int)(p / KC), q = (int)(p % KC);
+                    img[((size_t)g * m->n_chunks + c) * CHUNK_FLOATS + img_index(n, q)] =
+                        src[(k * n_px + p) * cpm + part];
+                }
+            }
+        }
+        hipError_t e = hipMalloc((void **)&m->img, n_float * sizeof(float));
+        if (e == hipSuccess)
+            e = hipMemcpy(m->img, img.data(), n_float * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (m->img) (void)hipFree(m->img);
+            delete m;
+            LTMI_FAIL((int)e, "uploading the mask image failed: %s", hipGetErrorString(e));
+        }
+    }
+    // the generic image is always kept too: it serves tile dtypes the MFMA path does not take
+    {
+        // accumulate type: f32 f64 c64 c128, integers -> 64-bit
+        const bool is_int = result_dtype <= LTMI_I64;
+        const size_t n = (size_t)n_masks * n_px;
+        const size_t acc_size = is_int ? 8 : (size_t)dtype_size(result_dtype);
+        std::vector<unsigned char> buf;
+        const void *upload = masks_host;
+        if (is_int && dtype_size(result_dtype) != 8) {
+            try { buf.resize(n * 8); } catch (...) {
+                ltmi_masks_destroy(m);
+                LTMI_FAIL(LTMI_E_NOMEM, "out of host memory");
+            }
+            int64_t *d = (int64_t *)buf.data();
+            for (size_t i = 0; i < n; ++i) {
+                switch (result_dtype) {
+                    case LTMI_BOOL: case LTMI_U8: d[i] = ((const uint8_t *)masks_host)[i]; break;
+                    case LTMI_I8: d[i] = ((const int8_t *)masks_host)[i]; break;
+                    case LTMI_U16: d[i] = ((const uint16_t *)masks_host)[i]; break;
+                    case LTMI_I16: d[i] = ((const int16_t *)masks_host)[i]; break;
+                    case LTMI_U32: d[i] = ((const uint32_t *)masks_host)[i]; break;
+                    case LTMI_I32: d[i] = ((const int32_t *)masks_host)[i]; break;
+                }
+            }
+            upload = buf.data();
+        }
+        hipError_t e = hipMalloc(&m->gmasks, n * acc_size);
+        if (e == hipSuccess) e = hipMemcpy(m->gmasks, upload, n * acc_size, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            ltmi_masks_destroy(m);
+            LTMI_FAIL((int)e, "uploading the mask stack failed: %s", hipGetErrorString(e));
+        }
+    }
+    *out = m;
+    return LTMI_OK;
+}
+
+extern "C" int ltmi_masks_destroy(ltmi_masks *m) {
+    if (!m) return LTMI_OK;
+    (void)hipSetDevice(m->device);
+    if (m->img) (void)hipFree(m->img);
+    if (m->partials) (void)hipFree(m->partials);
+    if (m->gmasks) (void)hipFree(m->gmasks);
+    if (m->csr) (void)ltmi::csr_destroy(m);
+    delete m;
+    return LTMI_OK;
+}
+
+extern "C" int ltmi_masks_kind(const ltmi_masks *m, int *kind) {
+    if (!m || !kind) LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_kind: null argument");
+    *kind = m->kind;
+    return LTMI_OK;
+}
+
+extern "C" int ltmi_masks_set_tuning(ltmi_masks *m, int mt, int waves, int ksplit) {
+    if (!m) LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_set_tuning: null handle");
+    if (!(mt == 0 || mt == 1 || mt == 2) || !(waves == 0 || waves == 4 || waves == 8) || ksplit < 0)
+        LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_set_tuning: unsupported (mt=%d waves=%d ksplit=%d)",
+                  mt, waves, ksplit);
+    m->tune_mt = mt;
+    m->tune_waves = waves;
+    m->tune_ksplit = ksplit;
+    return LTMI_OK;
+}
+
+extern "C" const char *ltmi_masks_last_kernel(const ltmi_masks *m) {
+    return m ? m->last_kernel : "";
+}
+
+// ---- MFMA launch ---------------------------------------------------------------------------------
+template <typename T, int MT, int NG, int WAVES, bool ALIGNED>
+static int launch_mfma_variant(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld,
+                               float *out, int64_t ld_out, int accumulate, int ksplit,
+                               hipStream_t stream) {
+    auto kern = k_dense_mfma<T, MT, NG, WAVES, ALIGNED>;
+    const size_t lds_bytes = (size_t)2 * NG * CHUNK_FLOATS * sizeof(float);
+    static bool attr_set[16] = {false};   // per device
+    if (lds_bytes > 64 * 1024 && !attr_set[m->device & 15]) {
+        LTMI_HIP(hipFuncSetAttribute((const void *)kern,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set[m->device & 15] = true;
+    }
+    dim3 grid((unsigned)((n_frames + WAVES * MT * 16 - 1) / (WAVES * MT * 16)), (unsigned)ksplit,
+              (unsigned)(m->n_groups / NG));
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds_bytes, stream, tile, ld, n_frames, m->n_px,
+                       (const float *)m->img, m->n_chunks, out, ld_out, m->n_cols, accumulate,
+                       m->partials, ksplit);
+    LTMI_HIP(hipGetLastError());
+    snprintf(m->last_kernel, sizeof(m->last_kernel),
+             "k_dense_mfma<%s,MT=%d,NG=%d,WAVES=%d,%s> grid=(%u,%u,%u)", typeid(T).name(), MT, NG,
+             WAVES, ALIGNED ? "aligned" : "unaligned", grid.x, grid.y, grid.z);
+    return LTMI_OK;
+}
+
+template <typename T>
+static int launch_mfma(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
+                       int64_t ld_out, int accumulate, hipStream_t stream) {
+    const bool aligned = (((uintptr_t)tile) % 16 == 0) && ((ld * (int64_t)sizeof(T)) % 16 == 0);
+    int waves = m->tune_waves ? m->tune_waves : 4;
+    int mt = m->tune_mt ? m->tune_mt : (n_frames >= 256 * waves * 32 ? 2 : 1);
+    if (m->ng == 4) { mt = 1; }   // keep the accumulator/LDS budget in check
+    const int64_t gx = (n_frames + waves * mt * 16 - 1) / (waves * mt * 16);
+    const int64_t gz = m->n_groups / m->ng;
+    int ksplit = m->tune_ksplit;
+    if (ksplit <= 0) {
+        ksplit = 1;
+        const int64_t wgs = gx * gz;
+        if (wgs < 1024) {
+            ksplit = (int)std::min<int64_t>((1024 + wgs - 1) / wgs, std::max(1, m->n_chunks / 8));
+        }
+    }
+    ksplit = std::max(1, std::min(ksplit, m->n_chunks));
+    // every split must own at least one chunk
+    {
+        const int per = (m->n_chunks + ksplit - 1) / ksplit;
+        ksplit = (m->n_chunks + per - 1) / per;
+    }
+    if (ksplit > 1) {
+        const size_t need = (size_t)ksplit * n_frames * m->n_cols * sizeof(float);
+        if (need > m->partials_bytes) {
+            if (m->partials) {
+                LTMI_HIP(hipStreamSynchronize(stream));
+                LTMI_HIP(hipFree(m->partials));
+                m->partials = nullptr;
+                m->partials_bytes = 0;
+            }
+            LTMI_HIP(hipMalloc((void **)&m->partials, need));
+            m->partials_bytes = need;
+        }
+    }
+    int rc;
+#define LTMI_VARIANT(MT_, NG_, W_)                                                                \
+    (aligned ? launch_mfma_variant<T, MT_, NG_, W_, true>(m, tile, n_frames, ld, out, ld_out,      \
+                                                          accumulate, ksplit, stream)              \
+             : launch_mfma_variant<T, MT_, NG_, W_, false>(m, tile, n_frames, ld, out, ld_out,     \
+                                                           accumulate, ksplit, stream))
+    if (m->ng == 1) {
+        if (waves == 4) rc = (mt == 1) ? LTMI_VARIANT(1, 1, 4) : LTMI_VARIANT(2, 1, 4);
+        else rc = (mt == 1) ? LTMI_VARIANT(1, 1, 8) : LTMI_VARIANT(2, 1, 8);
+    } else if (m->ng == 2) {
+        if (waves == 4) rc = (mt == 1) ? LTMI_VARIANT(1, 2, 4) : LTMI_VARIANT(2, 2, 4);
+        else rc = (mt == 1) ? LTMI_VARIANT(1, 2, 8) : LTMI_VARIANT(2, 2, 8);
+    } else {
+        rc = (waves == 4) ? LTMI_VARIANT(1, 4, 4) : LTMI_VARIANT(1, 4, 8);
+    }
+#undef LTMI_VARIANT
+    if (rc != LTMI_OK) return rc;
+    if (ksplit > 1) {
+        const int64_t n = n_frames * m->n_cols;
+        hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                           stream, (const float *)m->partials, ksplit, n_frames, m->n_cols, out,
+                           ld_out, accumulate);
+        LTMI_HIP(hipGetLastError());
+    }
+    return LTMI_OK;
+}
+
+// ---- generic launch ------------------------------------------------------------------------------
+template <typename TIn, typename A, typename S>
+static int launch_generic(ltmi_masks *m, const void *tile, int64_t n_frames, int64_t ld, void *out,
+                          int64_t ld_out, int accumulate, hipStream_t stream) {
+    dim3 grid((unsigned)n_frames, (unsigned)((m->n_masks + GEN_MASKS - 1) / GEN_MASKS));
+    hipLaunchKernelGGL((k_dense_generic<TIn, A, S>), grid, dim3(256), 0, stream, (const TIn *)tile,
+                       ld, n_frames, m->n_px, (const A *)m->gmasks, (int)m->n_masks, (S *)out,
+                       ld_out, accumulate);
+    LTMI_HIP(hipGetLastError());
+    snprintf(m->last_kernel, sizeof(m->last_kernel), "k_dense_generic<%s,%s> grid=(%u,%u)",
+             typeid(TIn).name(), typeid(A).name(), grid.x, grid.y);
+    return LTMI_OK;
+}
+
+template <typename A, typename S>
+static int dispatch_generic_real_in(ltmi_masks *m, const void *tile, int tile_dtype,
+                                    int64_t n_frames, int64_t ld, void *out, int64_t ld_out,
+                                    int accumulate, hipStream_t stream) {
+    switch (tile_dtype) {
+        case LTMI_BOOL:
+        case LTMI_U8: return launch_generic<uint8_t, A, S>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+        case LTMI_I8: return launch_generic<int8_t, A, S>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+        case LTMI_U16: return launch_generic<uint16_t, A, S>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+        case LTMI_I16: return launch_generic<int16_t, A, S>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+        case LTMI_U32: return launch_generic<uint32_t, A, S>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+        case LTMI_I32: return launch_generic<int32_t, A, S>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+        case LTMI_U64: return launch_generic<uint64_t, A, S>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+        case LTMI_I64: return launch_generic<int64_t, A, S>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+        case LTMI_F32: return launch_generic<float, A, S>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+        case LTMI_F64: return launch_generic<double, A, S>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+    }
+    LTMI_FAIL(LTMI_E_DTYPE, "tile dtype %s cannot be combined with result dtype %s",
+              dtype_name(tile_dtype), dtype_name(m->result_dtype));
+}
+
+template <typename A, typename S>
+static int dispatch_generic_int(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames,
+                                int64_t ld, void *out, int64_t ld_out, int accumulate,
+                                hipStream_t stream) {
+    if (tile_dtype > LTMI_I64)
+        LTMI_FAIL(LTMI_E_DTYPE, "float/complex tile (%s) with integer result dtype %s",
+                  dtype_name(tile_dtype), dtype_name(m->result_dtype));
+    return dispatch_generic_real_in<A, S>(m, tile, tile_dtype, n_frames, ld, out, ld_out,
+                                          accumulate, stream);
+}
+
+static int apply_generic(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames,
+                         int64_t ld, void *out, int64_t ld_out, int accumulate, hipStream_t stream) {
+    switch (m->result_dtype) {
+        case LTMI_F32: return dispatch_generic_real_in<float, float>(m, tile, tile_dtype, n_frames, ld, out, ld_out, accumulate, stream);
+        case LTMI_F64: return dispatch_generic_real_in<double, double>(m, tile, tile_dtype, n_frames, ld, out, ld_out, accumulate, stream);
+        case LTMI_C64:
+            if (tile_dtype == LTMI_C64) return launch_generic<cfloat, cfloat, cfloat>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+            if (tile_dtype == LTMI_C128) LTMI_FAIL(LTMI_E_DTYPE, "complex128 tile with complex64 result");
+            return dispatch_generic_real_in<cfloat, cfloat>(m, tile, tile_dtype, n_frames, ld, out, ld_out, accumulate, stream);
+        case LTMI_C128:
+            if (tile_dtype == LTMI_C64) return launch_generic<cfloat, cdouble, cdouble>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+            if (tile_dtype == LTMI_C128) return launch_generic<cdouble, cdouble, cdouble>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+            return dispatch_generic_real_in<cdouble, cdouble>(m, tile, tile_dtype, n_frames, ld, out, ld_out, accumulate, stream);
+        case LTMI_BOOL: case LTMI_U8: case LTMI_I8:
+            return dispatch_generic_int<uint64_t, uint8_t>(m, tile, tile_dtype, n_frames, ld, out, ld_out, accumulate, stream);
+        case LTMI_U16: case LTMI_I16:
+            return dispatch_generic_int<uint64_t, uint16_t>(m, tile, tile_dtype, n_frames, ld, out, ld_out, accumulate, stream);
+        case LTMI_U32: case LTMI_I32:
+            return dispatch_generic_int<uint64_t, uint32_t>(m, tile, tile_dtype, n_frames, ld, out, ld_out, accumulate, stream);
+        case LTMI_U64: case LTMI_I64:
+            return dispatch_generic_int<uint64_t, uint64_t>(m, tile, tile_dtype, n_frames, ld, out, ld_out, accumulate, stream);
+    }
+    LTMI_FAIL(LTMI_E_DTYPE, "unsupported result dtype %d", m->result_dtype);
+}
+
+extern "C" int ltmi_apply_masks(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames,
+                                int64_t ld_tile, void *out, int64_t ld_out, int accumulate,
+                                void *stream_) {
+    if (!m) LTMI_FAIL(LTMI_E_INVALID, "ltmi_apply_masks: null handle");
+    if (n_frames < 0 || ld_tile < m->n_px || ld_out < m->n_masks)
+        LTMI_FAIL(LTMI_E_SHAPE, "ltmi_apply_masks: n_frames=%lld ld_tile=%lld (n_px=%lld) "
+                  "ld_out=%lld (n_masks=%lld)", (long long)n_frames, (long long)ld_tile,
+                  (long long)m->n_px, (long long)ld_out, (long long)m->n_masks);
+    if (dtype_size(tile_dtype) == 0)
+        LTMI_FAIL(LTMI_E_DTYPE, "ltmi_apply_masks: unknown tile dtype %d", tile_dtype);
+    if (n_frames == 0) return LTMI_OK;
+    if (!tile || !out) LTMI_FAIL(LTMI_E_INVALID, "ltmi_apply_masks: null tile/out pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    LTMI_HIP(hipSetDevice(m->device));
+    if (m->kind == 2)
+        return ltmi::csr_apply(m, tile, tile_dtype, n_frames, ld_tile, out, ld_out, accumulate,
+                               stream);
+    if (m->kind == 0 && mfma_tile_dtype(tile_dtype)) {
+        float *o = (float *)out;
+        const int64_t ldo = ld_out * (m->result_dtype == LTMI_C64 ? 2 : 1);
+        switch (tile_dtype) {
+            case LTMI_BOOL:
+            case LTMI_U8: return launch_mfma<uint8_t>(m, (const uint8_t *)tile, n_frames, ld_tile, o, ldo, accumulate, stream);
+            case LTMI_I8: return launch_mfma<int8_t>(m, (const int8_t *)tile, n_frames, ld_tile, o, ldo, accumulate, stream);
+            case LTMI_U16: return launch_mfma<uint16_t>(m, (const uint16_t *)tile, n_frames, ld_tile, o, ldo, accumulate, stream);
+            case LTMI_I16: return launch_mfma<int16_t>(m, (const int16_t *)tile, n_frames, ld_tile, o, ldo, accumulate, stream);
+            case LTMI_F32: return launch_mfma<float>(m, (const float *)tile, n_frames, ld_tile, o, ldo, accumulate, stream);
+        }
+    }
+    return apply_generic(m, tile, tile_dtype, n_frames, ld_tile, out, ld_out, accumulate, stream);
+}

@@ -1,0 +1,260 @@
+// Reductions for SumUDF / SumSigUDF and the sig-buffer merge (gfx950).
+//
+//   ltmi_sum_sig    : out[f] (+)= sum_p tile[f, p]     (src/libertem/udf/sumsigudf.py:30-39)
+//   ltmi_sum_frames : out[p] (+)= sum_f tile[f, p]     (src/libertem/udf/sum.py:43-48)
+//   ltmi_axpy       : dest[i] += src[i]                (src/libertem/udf/sum.py:50-52)
+//
+// All three are pure HBM streams: 16-byte coalesced loads, conversion in registers,
+// wavefront (64-lane) shuffle reduction, no atomics (deterministic).
+#include "ltmi_common.h"
+
+namespace ltmi {
+
+template <typename A> __device__ __forceinline__ A wave_sum(A v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+template <typename T, typename A> struct Cv {
+    static __device__ __forceinline__ A from(T v) { return (A)v; }
+};
+
+// ---- per-frame sums ---------------------------------------------------------------------------
+// one 256-thread block per frame; VEC elements per thread per step (16 bytes where aligned)
+template <typename T, typename A, int VEC>
+__global__ void __launch_bounds__(256)
+k_sum_sig(const T *__restrict__ tile, int64_t ld, int64_t n_px, A *__restrict__ out,
+          int accumulate) {
+    __shared__ A red[4];
+    const int64_t f = blockIdx.x;
+    const T *row = tile + f * ld;
+    A acc0 = 0, acc1 = 0;
+    if (VEC > 1) {
+        typedef T vec_t __attribute__((ext_vector_type(VEC)));
+        const int64_t nvec = n_px / VEC;
+        const vec_t *vrow = (const vec_t *)row;
+        int64_t i = threadIdx.x;
+        for (; i + 256 < nvec; i += 512) {
+            const vec_t v0 = __builtin_nontemporal_load(vrow + i);
+            const vec_t v1 = __builtin_nontemporal_load(vrow + i + 256);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { acc0 += (A)v0[e]; acc1 += (A)v1[e]; }
+        }
+        for (; i < nvec; i += 256) {
+            const vec_t v0 = __builtin_nontemporal_load(vrow + i);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc0 += (A)v0[e];
+        }
+        for (int64_t p = nvec * VEC + threadIdx.x; p < n_px; p += 256) acc1 += (A)row[p];
+    } else {
+        for (int64_t p = threadIdx.x; p < n_px; p += 256) acc0 += (A)row[p];
+    }
+    A s = wave_sum<A>(acc0 + acc1);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = (red[0] + red[1]) + (red[2] + red[3]);
+        out[f] = accumulate ? out[f] + s : s;
+    }
+}
+
+// ---- sum over frames ----------------------------------------------------------------------------
+// grid = (pixel tiles of 256*VEC, frame splits). Each thread owns VEC consecutive pixels and walks
+// its slab of frames; partial sums per split go to the workspace and are reduced in fixed order.
+template <typename T, typename A, int VEC>
+__global__ void __launch_bounds__(256)
+k_sum_frames(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
+             A *__restrict__ dst, int64_t dst_stride_split, int fsplit, int accumulate_direct) {
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC;
+    if (p0 >= n_px) return;
+    const int64_t per = (n_frames + fsplit - 1) / fsplit;
+    const int64_t f0 = (int64_t)blockIdx.y * per;
+    const int64_t f1 = min(n_frames, f0 + per);
+    A acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0;
+    const bool full = (p0 + VEC <= n_px);
+    if (full) {
+        int64_t f = f0;
+        for (; f + 3 < f1; f += 4) {
+            vec_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                v[u] = __builtin_nontemporal_load((const vec_t *)(tile + (f + u) * ld + p0));
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] += (A)v[u][e];
+        }
+        for (; f < f1; ++f) {
+            const vec_t v = __builtin_nontemporal_load((const vec_t *)(tile + f * ld + p0));
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] += (A)v[e];
+        }
+    } else {
+        for (int64_t f = f0; f < f1; ++f)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                if (p0 + e < n_px) acc[e] += (A)tile[f * ld + p0 + e];
+    }
+    A *d = dst + (int64_t)blockIdx.y * dst_stride_split;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+        if (p0 + e < n_px) d[p0 + e] = accumulate_direct ? d[p0 + e] + acc[e] : acc[e];
+}
+
+template <typename A>
+__global__ void k_reduce_splits(const A *__restrict__ ws, int fsplit, int64_t n, A *__restrict__ out,
+                                int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    A s = accumulate ? out[i] : (A)0;
+    for (int k = 0; k < fsplit; ++k) s += ws[(int64_t)k * n + i];
+    out[i] = s;
+}
+
+template <typename A>
+__global__ void k_axpy(A *__restrict__ dest, const A *__restrict__ src, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dest[i] += src[i];
+}
+
+static int frames_split(int64_t n_frames, int64_t n_px) {
+    // independent of the tile dtype so that the workspace query and the launch always agree
+    const int64_t px_blocks = (n_px + 2047) / 2048;
+    int64_t want = (2048 + px_blocks - 1) / px_blocks;      // aim at >= 2048 workgroups
+    want = std::max<int64_t>(1, std::min<int64_t>(want, n_frames / 8));
+    return (int)std::max<int64_t>(1, std::min<int64_t>(want, 256));
+}
+
+template <typename T> constexpr int vec_for() { return sizeof(T) >= 16 ? 1 : (int)(16 / sizeof(T)); }
+
+template <typename T, typename A>
+static int run_sum_sig(const void *tile, int64_t n_frames, int64_t n_px, int64_t ld, void *out,
+                       int accumulate, hipStream_t stream) {
+    constexpr int VEC = vec_for<T>();
+    const bool aligned = ((uintptr_t)tile % 16 == 0) && ((ld * (int64_t)sizeof(T)) % 16 == 0);
+    if (aligned && VEC > 1)
+        hipLaunchKernelGGL((k_sum_sig<T, A, VEC>), dim3((unsigned)n_frames), dim3(256), 0, stream,
+                           (const T *)tile, ld, n_px, (A *)out, accumulate);
+    else
+        hipLaunchKernelGGL((k_sum_sig<T, A, 1>), dim3((unsigned)n_frames), dim3(256), 0, stream,
+                           (const T *)tile, ld, n_px, (A *)out, accumulate);
+    LTMI_HIP(hipGetLastError());
+    return LTMI_OK;
+}
+
+template <typename T, typename A>
+static int run_sum_frames(const void *tile, int64_t n_frames, int64_t n_px, int64_t ld, void *out,
+                          int accumulate, void *ws, hipStream_t stream) {
+    constexpr int VECA = vec_for<T>();
+    const bool aligned = ((uintptr_t)tile % 16 == 0) && ((ld * (int64_t)sizeof(T)) % 16 == 0);
+    const int vec = (aligned && VECA > 1) ? VECA : 1;
+    const int fsplit = frames_split(n_frames, n_px);         // matches the workspace query
+    dim3 grid((unsigned)((n_px + 256 * vec - 1) / (256 * vec)), (unsigned)fsplit);
+    A *dst = fsplit > 1 ? (A *)ws : (A *)out;
+    if (fsplit > 1 && !ws) LTMI_FAIL(LTMI_E_INVALID, "ltmi_sum_frames: workspace required");
+    const int direct_acc = (fsplit == 1) ? accumulate : 0;
+    if (vec > 1)
+        hipLaunchKernelGGL((k_sum_frames<T, A, VECA>), grid, dim3(256), 0, stream, (const T *)tile,
+                           ld, n_frames, n_px, dst, n_px, fsplit, direct_acc);
+    else
+        hipLaunchKernelGGL((k_sum_frames<T, A, 1>), grid, dim3(256), 0, stream, (const T *)tile, ld,
+                           n_frames, n_px, dst, n_px, fsplit, direct_acc);
+    LTMI_HIP(hipGetLastError());
+    if (fsplit > 1) {
+        hipLaunchKernelGGL((k_reduce_splits<A>), dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0,
+                           stream, (const A *)ws, fsplit, n_px, (A *)out, accumulate);
+        LTMI_HIP(hipGetLastError());
+    }
+    return LTMI_OK;
+}
+
+static int tile_vec(int dt) {
+    const int s = dtype_size(dt);
+    return s >= 16 ? 1 : 16 / s;
+}
+
+}  // namespace ltmi
+
+using namespace ltmi;
+
+#define LTMI_DISPATCH_TILE(FN, A, ...)                                                          \
+    switch (tile_dtype) {                                                                        \
+        case LTMI_BOOL:                                                                          \
+        case LTMI_U8: return FN<uint8_t, A>(__VA_ARGS__);                                       \
+        case LTMI_I8: return FN<int8_t, A>(__VA_ARGS__);                                        \
+        case LTMI_U16: return FN<uint16_t, A>(__VA_ARGS__);                                     \
+        case LTMI_I16: return FN<int16_t, A>(__VA_ARGS__);                                      \
+        case LTMI_U32: return FN<uint32_t, A>(__VA_ARGS__);                                     \
+        case LTMI_I32: return FN<int32_t, A>(__VA_ARGS__);                                      \
+        case LTMI_U64: return FN<uint64_t, A>(__VA_ARGS__);                                     \
+        case LTMI_I64: return FN<int64_t, A>(__VA_ARGS__);                                      \
+        case LTMI_F32: return FN<float, A>(__VA_ARGS__);                                        \
+        case LTMI_F64: return FN<double, A>(__VA_ARGS__);                                       \
+    }
+
+extern "C" int ltmi_sum_sig(int device, const void *tile, int tile_dtype, int64_t n_frames,
+                            int64_t n_px, int64_t ld_tile, void *out, int out_dtype, int accumulate,
+                            void *stream_) {
+    if (n_frames < 0 || n_px < 0 || ld_tile < n_px)
+        LTMI_FAIL(LTMI_E_SHAPE, "ltmi_sum_sig: bad shape");
+    if (n_frames == 0) return LTMI_OK;
+    if (!tile || !out) LTMI_FAIL(LTMI_E_INVALID, "ltmi_sum_sig: null pointer");
+    LTMI_HIP(hipSetDevice(device));
+    hipStream_t stream = (hipStream_t)stream_;
+    if (out_dtype == LTMI_F32) {
+        LTMI_DISPATCH_TILE(run_sum_sig, float, tile, n_frames, n_px, ld_tile, out, accumulate, stream)
+    } else if (out_dtype == LTMI_F64) {
+        LTMI_DISPATCH_TILE(run_sum_sig, double, tile, n_frames, n_px, ld_tile, out, accumulate, stream)
+    }
+    LTMI_FAIL(LTMI_E_DTYPE, "ltmi_sum_sig: unsupported dtypes tile=%s out=%s", dtype_name(tile_dtype),
+              dtype_name(out_dtype));
+}
+
+extern "C" int64_t ltmi_sum_frames_workspace(int64_t n_frames, int64_t n_px, int out_dtype) {
+    const int fsplit = frames_split(n_frames, n_px);
+    if (fsplit <= 1) return 0;
+    return (int64_t)fsplit * n_px * dtype_size(out_dtype);
+}
+
+extern "C" int ltmi_sum_frames(int device, const void *tile, int tile_dtype, int64_t n_frames,
+                               int64_t n_px, int64_t ld_tile, void *out, int out_dtype,
+                               int accumulate, void *workspace, void *stream_) {
+    if (n_frames < 0 || n_px < 0 || ld_tile < n_px)
+        LTMI_FAIL(LTMI_E_SHAPE, "ltmi_sum_frames: bad shape");
+    if (n_frames == 0 || n_px == 0) return LTMI_OK;
+    if (!tile || !out) LTMI_FAIL(LTMI_E_INVALID, "ltmi_sum_frames: null pointer");
+    LTMI_HIP(hipSetDevice(device));
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)tile_vec;
+    if (out_dtype == LTMI_F32) {
+        LTMI_DISPATCH_TILE(run_sum_frames, float, tile, n_frames, n_px, ld_tile, out, accumulate, workspace, stream)
+    } else if (out_dtype == LTMI_F64) {
+        LTMI_DISPATCH_TILE(run_sum_frames, double, tile, n_frames, n_px, ld_tile, out, accumulate, workspace, stream)
+    }
+    LTMI_FAIL(LTMI_E_DTYPE, "ltmi_sum_frames: unsupported dtypes tile=%s out=%s",
+              dtype_name(tile_dtype), dtype_name(out_dtype));
+}
+
+extern "C" int ltmi_axpy(int device, void *dest, const void *src, int dtype, int64_t n,
+                         void *stream_) {
+    if (n < 0) LTMI_FAIL(LTMI_E_SHAPE, "ltmi_axpy: negative size");
+    if (n == 0) return LTMI_OK;
+    if (!dest || !src) LTMI_FAIL(LTMI_E_INVALID, "ltmi_axpy: null pointer");
+    LTMI_HIP(hipSetDevice(device));
+    hipStream_t stream = (hipStream_t)stream_;
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (dtype == LTMI_F32)
+        hipLaunchKernelGGL((k_axpy<float>), grid, dim3(256), 0, stream, (float *)dest,
+                           (const float *)src, n);
+    else if (dtype == LTMI_F64)
+        hipLaunchKernelGGL((k_axpy<double>), grid, dim3(256), 0, stream, (double *)dest,
+                           (const double *)src, n);
+    else
+        LTMI_FAIL(LTMI_E_DTYPE, "ltmi_axpy: unsupported dtype %s", dtype_name(dtype));
+    LTMI_HIP(hipGetLastError());
+    return LTMI_OK;
+}

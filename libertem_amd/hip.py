@@ -1,0 +1,219 @@
+"""
+ctypes binding of libltmi.so (include/ltmi.h) -- the only way the product reaches the GPU.
+
+There is deliberately NO CPU fallback anywhere in this module: if the shared library is
+missing or a call fails, a `RuntimeError` / `ValueError` is raised.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, '_lib', 'libltmi.so')
+
+_lib = None
+_lock = threading.Lock()
+
+# numpy dtype -> enum ltmi_dtype (include/ltmi.h)
+_DTYPES = {
+    np.dtype('bool'): 0, np.dtype('uint8'): 1, np.dtype('int8'): 2, np.dtype('uint16'): 3,
+    np.dtype('int16'): 4, np.dtype('uint32'): 5, np.dtype('int32'): 6, np.dtype('uint64'): 7,
+    np.dtype('int64'): 8, np.dtype('float32'): 9, np.dtype('float64'): 10,
+    np.dtype('complex64'): 11, np.dtype('complex128'): 12,
+}
+
+EXPORTS = (
+    'ltmi_version', 'ltmi_last_error', 'ltmi_device_count', 'ltmi_device_info',
+    'ltmi_masks_create_dense', 'ltmi_masks_create_csr', 'ltmi_masks_destroy', 'ltmi_masks_kind',
+    'ltmi_apply_masks', 'ltmi_sum_frames_workspace', 'ltmi_sum_frames', 'ltmi_sum_sig',
+    'ltmi_axpy', 'ltmi_masks_set_tuning', 'ltmi_masks_last_kernel',
+)
+
+
+class LtmiError(RuntimeError):
+    pass
+
+
+def dtype_code(dtype):
+    try:
+        return _DTYPES[np.dtype(dtype)]
+    except KeyError:
+        raise ValueError(f"dtype {dtype!r} is not supported by libltmi")
+
+
+def lib():
+    """Load libltmi.so once.  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP library has not been built. "
+                "Run `python -m libertem_amd.build` (needs hipcc). There is no CPU fallback."
+            )
+        L = ctypes.CDLL(LIB_PATH)
+        c = ctypes
+        vp, i64, i32 = c.c_void_p, c.c_int64, c.c_int
+        L.ltmi_version.restype = i32
+        L.ltmi_last_error.restype = c.c_char_p
+        L.ltmi_device_count.argtypes = [c.POINTER(i32)]
+        L.ltmi_device_info.argtypes = [i32, c.c_char_p, c.POINTER(i32), c.POINTER(i64),
+                                       c.POINTER(i32)]
+        L.ltmi_masks_create_dense.argtypes = [i32, vp, i32, i64, i64, c.POINTER(vp)]
+        L.ltmi_masks_create_csr.argtypes = [i32, vp, vp, vp, i32, i64, i64, c.POINTER(vp)]
+        L.ltmi_masks_destroy.argtypes = [vp]
+        L.ltmi_masks_kind.argtypes = [vp, c.POINTER(i32)]
+        L.ltmi_apply_masks.argtypes = [vp, vp, i32, i64, i64, vp, i64, i32, vp]
+        L.ltmi_sum_frames_workspace.argtypes = [i64, i64, i32]
+        L.ltmi_sum_frames_workspace.restype = i64
+        L.ltmi_sum_frames.argtypes = [i32, vp, i32, i64, i64, i64, vp, i32, i32, vp, vp]
+        L.ltmi_sum_sig.argtypes = [i32, vp, i32, i64, i64, i64, vp, i32, i32, vp]
+        L.ltmi_axpy.argtypes = [i32, vp, vp, i32, i64, vp]
+        L.ltmi_masks_set_tuning.argtypes = [vp, i32, i32, i32]
+        L.ltmi_masks_last_kernel.argtypes = [vp]
+        L.ltmi_masks_last_kernel.restype = c.c_char_p
+        for name in EXPORTS:
+            fn = getattr(L, name)
+            if fn.restype is c.c_int and name not in ('ltmi_version',):
+                fn.restype = i32
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    msg = lib().ltmi_last_error().decode('utf8', 'replace')
+    if rc in (-1, -2, -3):
+        raise ValueError(f"{what}: {msg} (code {rc})")
+    raise LtmiError(f"{what}: {msg} (code {rc})")
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    check(lib().ltmi_device_count(ctypes.byref(n)), 'ltmi_device_count')
+    return n.value
+
+
+def device_info(device):
+    name = ctypes.create_string_buffer(256)
+    cu = ctypes.c_int(0)
+    mem = ctypes.c_int64(0)
+    arch = ctypes.c_int(0)
+    check(lib().ltmi_device_info(device, name, ctypes.byref(cu), ctypes.byref(mem),
+                                 ctypes.byref(arch)), 'ltmi_device_info')
+    return {'name': name.value.decode(), 'cu_count': cu.value, 'hbm_bytes': mem.value,
+            'gfx_arch': hex(arch.value)}
+
+
+def _stream_ptr(stream):
+    """torch.cuda.Stream | int | None -> hipStream_t value"""
+    if stream is None:
+        import torch
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if isinstance(stream, int):
+        return ctypes.c_void_p(stream)
+    return ctypes.c_void_p(stream.cuda_stream)
+
+
+class MaskHandle:
+    """Owns one `ltmi_masks*` (device image of a sig-sliced, flattened mask stack)."""
+
+    def __init__(self, ptr, device, n_masks, n_px, result_dtype, sparse):
+        self._ptr = ptr
+        self.device = device
+        self.n_masks = n_masks
+        self.n_px = n_px
+        self.result_dtype = np.dtype(result_dtype)
+        self.sparse = sparse
+
+    @classmethod
+    def dense(cls, device, masks, result_dtype):
+        """
+        masks: host array (n_masks, n_px); cast to result_dtype here, like
+        `for_backend(m, backend).astype(dtype)` (reference common/container.py:90-91).
+        """
+        result_dtype = np.dtype(result_dtype)
+        m = np.ascontiguousarray(np.asarray(masks).astype(result_dtype, copy=False))
+        if m.ndim != 2:
+            raise ValueError("dense mask stack must be 2D (n_masks, n_px)")
+        out = ctypes.c_void_p()
+        check(lib().ltmi_masks_create_dense(
+            int(device), m.ctypes.data_as(ctypes.c_void_p), dtype_code(result_dtype),
+            m.shape[0], m.shape[1], ctypes.byref(out)), 'ltmi_masks_create_dense')
+        return cls(out, device, m.shape[0], m.shape[1], result_dtype, False)
+
+    @classmethod
+    def csr(cls, device, csr_px_by_masks, result_dtype):
+        """csr_px_by_masks: scipy.sparse CSR (n_px, n_masks) as built by the reference's
+        `_build_sparse` (common/container.py:53-64)."""
+        result_dtype = np.dtype(result_dtype)
+        indptr = np.ascontiguousarray(csr_px_by_masks.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(csr_px_by_masks.indices, dtype=np.int64)
+        data = np.ascontiguousarray(csr_px_by_masks.data.astype(result_dtype, copy=False))
+        n_px, n_masks = csr_px_by_masks.shape
+        out = ctypes.c_void_p()
+        check(lib().ltmi_masks_create_csr(
+            int(device), indptr.ctypes.data_as(ctypes.c_void_p),
+            indices.ctypes.data_as(ctypes.c_void_p), data.ctypes.data_as(ctypes.c_void_p),
+            dtype_code(result_dtype), n_px, n_masks, ctypes.byref(out)), 'ltmi_masks_create_csr')
+        return cls(out, device, n_masks, n_px, result_dtype, True)
+
+    def kind(self):
+        k = ctypes.c_int(-1)
+        check(lib().ltmi_masks_kind(self._ptr, ctypes.byref(k)), 'ltmi_masks_kind')
+        return k.value
+
+    def set_tuning(self, mt=0, waves=0, ksplit=0):
+        check(lib().ltmi_masks_set_tuning(self._ptr, mt, waves, ksplit), 'ltmi_masks_set_tuning')
+
+    def last_kernel(self):
+        return lib().ltmi_masks_last_kernel(self._ptr).decode()
+
+    def apply(self, tile_ptr, tile_dtype, n_frames, ld_tile, out_ptr, ld_out, accumulate,
+              stream=None):
+        check(lib().ltmi_apply_masks(
+            self._ptr, ctypes.c_void_p(tile_ptr), dtype_code(tile_dtype), n_frames, ld_tile,
+            ctypes.c_void_p(out_ptr), ld_out, 1 if accumulate else 0, _stream_ptr(stream)),
+            'ltmi_apply_masks')
+
+    def close(self):
+        if self._ptr is not None and self._ptr.value:
+            lib().ltmi_masks_destroy(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def sum_frames_workspace(n_frames, n_px, out_dtype):
+    return int(lib().ltmi_sum_frames_workspace(n_frames, n_px, dtype_code(out_dtype)))
+
+
+def sum_frames(device, tile_ptr, tile_dtype, n_frames, n_px, ld_tile, out_ptr, out_dtype,
+               accumulate, workspace_ptr, stream=None):
+    check(lib().ltmi_sum_frames(
+        int(device), ctypes.c_void_p(tile_ptr), dtype_code(tile_dtype), n_frames, n_px, ld_tile,
+        ctypes.c_void_p(out_ptr), dtype_code(out_dtype), 1 if accumulate else 0,
+        ctypes.c_void_p(workspace_ptr), _stream_ptr(stream)), 'ltmi_sum_frames')
+
+
+def sum_sig(device, tile_ptr, tile_dtype, n_frames, n_px, ld_tile, out_ptr, out_dtype,
+            accumulate, stream=None):
+    check(lib().ltmi_sum_sig(
+        int(device), ctypes.c_void_p(tile_ptr), dtype_code(tile_dtype), n_frames, n_px, ld_tile,
+        ctypes.c_void_p(out_ptr), dtype_code(out_dtype), 1 if accumulate else 0,
+        _stream_ptr(stream)), 'ltmi_sum_sig')
+
+
+def axpy(device, dest_ptr, src_ptr, dtype, n, stream=None):
+    check(lib().ltmi_axpy(int(device), ctypes.c_void_p(dest_ptr), ctypes.c_void_p(src_ptr),
+                          dtype_code(dtype), n, _stream_ptr(stream)), 'ltmi_axpy')

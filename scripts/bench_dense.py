@@ -1,0 +1,59 @@
+"""Micro-benchmark of ltmi_apply_masks on device-resident frames (kernel-level, no UDF runtime)."""
+import argparse
+import time
+import numpy as np
+import torch
+from libertem_amd import hip
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--frames', type=int, default=65536)
+ap.add_argument('--sig', type=int, default=256)
+ap.add_argument('--masks', type=int, default=16)
+ap.add_argument('--dtype', default='uint16')
+ap.add_argument('--mask-dtype', default='float32')
+ap.add_argument('--reps', type=int, default=20)
+ap.add_argument('--variants', default='auto')
+args = ap.parse_args()
+
+n_px = args.sig * args.sig
+dt = np.dtype(args.dtype)
+g = torch.Generator(device='cuda').manual_seed(1)
+if dt.kind in 'iu':
+    tdt = {1: torch.uint8, 2: torch.int16}[dt.itemsize]
+    tile = torch.randint(0, 4096 if dt.itemsize > 1 else 200, (args.frames, n_px), generator=g,
+                         device='cuda', dtype=torch.int32).to(tdt)
+else:
+    tile = torch.rand((args.frames, n_px), generator=g, device='cuda', dtype=torch.float32)
+rng = np.random.default_rng(2)
+md = np.dtype(args.mask_dtype)
+if md.kind == 'c':
+    masks = (rng.random((args.masks, n_px)) + 1j * rng.random((args.masks, n_px))).astype(md)
+else:
+    masks = rng.random((args.masks, n_px)).astype(md)
+h = hip.MaskHandle.dense(0, masks, md)
+out = torch.zeros((args.frames, args.masks), device='cuda',
+                  dtype=torch.complex64 if md.kind == 'c' else torch.float32)
+frame_bytes = n_px * dt.itemsize + args.masks * md.itemsize
+
+if args.variants == 'auto':
+    variants = [dict(mt=0, waves=0, ksplit=0)]
+else:
+    variants = [dict(mt=m, waves=w, ksplit=k) for m in (1, 2) for w in (4, 8) for k in (1, 2)]
+for v in variants:
+    h.set_tuning(**v)
+    for _ in range(3):
+        h.apply(tile.data_ptr(), dt, args.frames, n_px, out.data_ptr(), args.masks, False)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(args.reps)]
+    for a, b in evs:
+        a.record()
+        h.apply(tile.data_ptr(), dt, args.frames, n_px, out.data_ptr(), args.masks, False)
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    med = ts[len(ts) // 2]
+    gbs = args.frames * frame_bytes / (med * 1e-3) / 1e9
+    print(f"{v} {h.last_kernel()}  median {med:.3f} ms  min {ts[0]:.3f} ms  "
+          f"{args.frames / (med * 1e-3) / 1e6:.2f} Mframes/s  {gbs:.0f} GB/s "
+          f"({gbs / 8000 * 100:.1f}% of 8 TB/s)", flush=True)

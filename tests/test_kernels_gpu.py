@@ -1,0 +1,245 @@
+"""
+GPU parity of the C-ABI kernels (through ctypes) against the oracle / float64 NumPy on the same
+seeded inputs.  `-m gpu` only.
+"""
+import numpy as np
+import pytest
+
+import recipes
+from oracle import path as opath
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from libertem_amd import hip as _hip
+    _hip.lib()
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    assert _hip.device_count() >= 1
+    return _hip
+
+
+def _dev(arr):
+    if arr.dtype == np.uint16:
+        return torch.from_numpy(arr.view(np.int16)).cuda()
+    if arr.dtype == np.uint32:
+        return torch.from_numpy(arr.view(np.int32)).cuda()
+    if arr.dtype == np.uint64:
+        return torch.from_numpy(arr.view(np.int64)).cuda()
+    return torch.from_numpy(arr).cuda()
+
+
+def _apply(hip, data2d, masks2d, result_dtype, accumulate_into=None, tuning=None):
+    h = hip.MaskHandle.dense(0, masks2d, result_dtype)
+    if tuning:
+        h.set_tuning(**tuning)
+    t = _dev(np.ascontiguousarray(data2d))
+    n_frames, n_px = data2d.shape
+    rd = np.dtype(result_dtype)
+    if accumulate_into is None:
+        out_np = np.full((n_frames, masks2d.shape[0]), 7, dtype=rd)   # poison
+        acc = False
+    else:
+        out_np = accumulate_into.astype(rd).copy()
+        acc = True
+    out = _dev(out_np)
+    h.apply(t.data_ptr(), data2d.dtype, n_frames, n_px, out.data_ptr(), masks2d.shape[0], acc)
+    torch.cuda.synchronize()
+    res = out.cpu().numpy()
+    if res.dtype != rd:
+        res = res.view(rd)
+    kern = h.last_kernel()
+    h.close()
+    return res, kern
+
+
+def _ref64(data2d, masks2d):
+    if np.iscomplexobj(data2d) or np.iscomplexobj(masks2d):
+        return data2d.astype(np.complex128) @ masks2d.astype(np.complex128).T
+    return data2d.astype(np.float64) @ masks2d.astype(np.float64).T
+
+
+@pytest.mark.parametrize('tile_dtype', ['uint8', 'int8', 'uint16', 'int16', 'float32'])
+@pytest.mark.parametrize('shape', [
+    (72, 256 * 4, 16),      # ragged frames (72 = 64 + 8), 4 full chunks
+    (5, 300, 3),            # ragged tail chunk, few frames, 3 masks
+    (130, 17 * 23, 4),      # unaligned rows for 2-byte types (391 px)
+    (64, 2048, 37),         # 3 column groups -> NG=4 path
+    (33, 512, 20),          # 2 column groups -> NG=2 path
+    (1, 256, 1),
+])
+def test_mfma_f32(hip, tile_dtype, shape):
+    n_frames, n_px, n_masks = shape
+    rng = np.random.default_rng(hash((tile_dtype,) + shape) % (2**32))
+    dt = np.dtype(tile_dtype)
+    if dt.kind == 'u':
+        data = rng.integers(0, min(4096, np.iinfo(dt).max), (n_frames, n_px)).astype(dt)
+    elif dt.kind == 'i':
+        data = rng.integers(max(-2000, np.iinfo(dt).min), min(2000, np.iinfo(dt).max),
+                            (n_frames, n_px)).astype(dt)
+    else:
+        data = (rng.random((n_frames, n_px)) - 0.3).astype(dt)
+    masks = (rng.random((n_masks, n_px)) - 0.25).astype(np.float32)
+    res, kern = _apply(hip, data, masks, np.float32)
+    assert 'k_dense_mfma' in kern, kern
+    ref = _ref64(data, masks)
+    scale = np.abs(data.astype(np.float64)) @ np.abs(masks.astype(np.float64)).T
+    # f32 accumulation error bound relative to sum |a||b|: 1e-5 rel (north_star tolerance)
+    assert np.all(np.abs(res - ref) <= 1e-5 * scale + 1e-30)
+    # accumulate=1
+    base = rng.random((n_frames, n_masks)).astype(np.float32)
+    res2, _ = _apply(hip, data, masks, np.float32, accumulate_into=base)
+    assert np.all(np.abs(res2 - (ref + base)) <= 1e-5 * (scale + 1))
+
+
+@pytest.mark.parametrize('tuning', [
+    dict(mt=1, waves=4, ksplit=1), dict(mt=2, waves=4, ksplit=1), dict(mt=1, waves=8, ksplit=1),
+    dict(mt=2, waves=8, ksplit=1), dict(mt=1, waves=4, ksplit=3), dict(mt=2, waves=8, ksplit=5),
+])
+def test_mfma_variants_agree(hip, tuning):
+    rng = np.random.default_rng(7)
+    data = rng.integers(0, 4096, (200, 256 * 9 + 40)).astype(np.uint16)
+    masks = (rng.random((16, data.shape[1])) - 0.25).astype(np.float32)
+    res, kern = _apply(hip, data, masks, np.float32, tuning=tuning)
+    ref = _ref64(data, masks)
+    scale = np.abs(data.astype(np.float64)) @ np.abs(masks.astype(np.float64)).T
+    assert np.all(np.abs(res - ref) <= 1e-5 * scale)
+    base = rng.random((200, 16)).astype(np.float32)
+    res2, _ = _apply(hip, data, masks, np.float32, accumulate_into=base, tuning=tuning)
+    assert np.all(np.abs(res2 - (ref + base)) <= 1e-5 * (scale + 1))
+
+
+def test_mfma_integer_exact(hip):
+    # 0/1 masks on low-count data: every partial sum is an integer < 2**24 -> any order exact
+    rng = np.random.default_rng(11)
+    data = rng.integers(0, 50, (100, 4096)).astype(np.uint16)
+    masks = (rng.random((16, 4096)) > 0.5).astype(np.float32)
+    res, _ = _apply(hip, data, masks, np.float32)
+    ref = data.astype(np.int64) @ masks.astype(np.int64).T
+    assert ref.max() < 2**24
+    assert np.array_equal(res.astype(np.int64), ref)
+
+
+def test_mfma_complex_masks(hip):
+    rng = np.random.default_rng(12)
+    data = rng.integers(0, 1000, (40, 1000)).astype(np.uint16)
+    masks = (rng.random((5, 1000)) - 0.5 + 1j * (rng.random((5, 1000)) - 0.5)).astype(np.complex64)
+    res, kern = _apply(hip, data, masks, np.complex64)
+    assert 'k_dense_mfma' in kern
+    ref = _ref64(data, masks)
+    scale = np.abs(data.astype(np.float64)) @ np.abs(masks).astype(np.float64).T
+    assert np.all(np.abs(res - ref) <= 1e-5 * scale)
+
+
+@pytest.mark.parametrize('combo', [
+    ('int32', 'float64'), ('int64', 'float64'), ('float64', 'float64'), ('uint16', 'float64'),
+    ('uint32', 'float64'), ('float32', 'complex128'), ('complex64', 'complex64'),
+    ('complex128', 'complex128'), ('int16', 'int32'), ('uint8', 'uint8'), ('int16', 'int64'),
+    ('uint16', 'int32'),
+])
+def test_generic(hip, combo):
+    tile_dtype, result_dtype = map(np.dtype, combo)
+    rng = np.random.default_rng(13)
+    n_frames, n_px, n_masks = 9, 333, 6
+    if tile_dtype.kind in 'iu':
+        lo = 0 if tile_dtype.kind == 'u' else -100
+        data = rng.integers(lo, 100, (n_frames, n_px)).astype(tile_dtype)
+    elif tile_dtype.kind == 'f':
+        data = rng.random((n_frames, n_px)).astype(tile_dtype)
+    else:
+        data = (rng.random((n_frames, n_px)) + 1j * rng.random((n_frames, n_px))).astype(tile_dtype)
+    if result_dtype.kind in 'iu':
+        masks = rng.integers(0, 3, (n_masks, n_px)).astype(result_dtype)
+    elif result_dtype.kind == 'c':
+        masks = (rng.random((n_masks, n_px)) + 1j * rng.random((n_masks, n_px))).astype(result_dtype)
+    else:
+        masks = rng.random((n_masks, n_px)).astype(result_dtype)
+    res, kern = _apply(hip, data, masks, result_dtype)
+    assert 'generic' in kern
+    ref = data.astype(result_dtype) @ masks.T      # NumPy's own product in the result dtype
+    if result_dtype.kind in 'iu':
+        assert np.array_equal(res, ref)            # wrap-around integer arithmetic, bit exact
+    else:
+        assert np.allclose(res, ref, rtol=1e-12 if result_dtype.itemsize >= 8 and
+                           result_dtype != np.complex64 else 1e-5)
+
+
+@pytest.mark.parametrize('case', recipes.DENSE_CASES, ids=lambda c: c['name'])
+def test_whole_dataset_vs_oracle(hip, case):
+    """one kernel call per dataset (whole nav, full frames) == the oracle's tiled CPU loop"""
+    data, masks = recipes.make_dense_case(case)
+    kw = case.get('udf_kwargs', {})
+    ref = opath.apply_masks(data, masks, num_partitions=case['num_partitions'],
+                            tileshape=case.get('tileshape'), mask_dtype=kw.get('mask_dtype'),
+                            preferred_dtype=kw.get('preferred_dtype'))
+    n_masks = masks.shape[0]
+    flat = data.reshape((-1, int(np.prod(data.shape[2:]))))
+    res, kern = _apply(hip, flat, masks.reshape((n_masks, -1)), ref.dtype)
+    res = res.reshape(ref.shape)
+    if ref.dtype.kind in 'iu':
+        assert np.array_equal(res, ref)
+    else:
+        scale = np.abs(ref).max()
+        tol = 1e-5 if ref.dtype in (np.float32, np.complex64) else 1e-12
+        assert np.allclose(res, ref, rtol=tol, atol=tol * scale)
+
+
+@pytest.mark.parametrize('tile_dtype,out_dtype', [
+    ('uint8', 'float32'), ('uint16', 'float32'), ('int16', 'float32'), ('float32', 'float32'),
+    ('int32', 'float64'), ('float64', 'float64'), ('uint16', 'float64'),
+])
+@pytest.mark.parametrize('shape', [(37, 1000), (300, 128 * 128), (5, 391), (1, 8)])
+def test_sums(hip, tile_dtype, out_dtype, shape):
+    rng = np.random.default_rng(21)
+    dt = np.dtype(tile_dtype)
+    if dt.kind in 'iu':
+        data = rng.integers(0, 100, shape).astype(dt)
+    else:
+        data = rng.random(shape).astype(dt)
+    n_frames, n_px = shape
+    t = _dev(data)
+    od = np.dtype(out_dtype)
+    tod = torch.float32 if od == np.float32 else torch.float64
+    # sum_sig
+    out = torch.full((n_frames,), 3.0, dtype=tod, device='cuda')
+    hip.sum_sig(0, t.data_ptr(), dt, n_frames, n_px, n_px, out.data_ptr(), od, False)
+    ref = data.astype(np.float64).sum(axis=1)
+    assert np.allclose(out.cpu().numpy(), ref, rtol=1e-6 if od == np.float32 else 1e-13)
+    hip.sum_sig(0, t.data_ptr(), dt, n_frames, n_px, n_px, out.data_ptr(), od, True)
+    assert np.allclose(out.cpu().numpy(), 2 * ref, rtol=1e-6 if od == np.float32 else 1e-13)
+    # sum_frames
+    ws_bytes = hip.sum_frames_workspace(n_frames, n_px, od)
+    ws = torch.empty((max(ws_bytes, 8),), dtype=torch.uint8, device='cuda')
+    out2 = torch.full((n_px,), 3.0, dtype=tod, device='cuda')
+    hip.sum_frames(0, t.data_ptr(), dt, n_frames, n_px, n_px, out2.data_ptr(), od, False,
+                   ws.data_ptr())
+    ref2 = data.astype(np.float64).sum(axis=0)
+    assert np.allclose(out2.cpu().numpy(), ref2, rtol=1e-6 if od == np.float32 else 1e-13)
+    hip.sum_frames(0, t.data_ptr(), dt, n_frames, n_px, n_px, out2.data_ptr(), od, True,
+                   ws.data_ptr())
+    assert np.allclose(out2.cpu().numpy(), 2 * ref2, rtol=1e-6 if od == np.float32 else 1e-13)
+    if dt.kind in 'iu':
+        # integer-valued sums below 2**24 are exact in any order
+        assert np.array_equal(out2.cpu().numpy(), 2 * ref2)
+    # axpy
+    hip.axpy(0, out2.data_ptr(), out2.data_ptr(), od, n_px)
+    assert np.allclose(out2.cpu().numpy(), 4 * ref2, rtol=1e-6 if od == np.float32 else 1e-13)
+
+
+def test_error_paths(hip):
+    masks = np.ones((2, 64), dtype=np.float32)
+    h = hip.MaskHandle.dense(0, masks, np.float32)
+    t = torch.zeros((4, 64), dtype=torch.float32, device='cuda')
+    o = torch.zeros((4, 2), dtype=torch.float32, device='cuda')
+    with pytest.raises(ValueError):
+        h.apply(t.data_ptr(), np.float32, 4, 32, o.data_ptr(), 2, False)     # ld < n_px
+    with pytest.raises(ValueError):
+        h.apply(t.data_ptr(), np.float32, 4, 64, o.data_ptr(), 1, False)     # ld_out < n_masks
+    with pytest.raises(ValueError):
+        h.apply(0, np.float32, 4, 64, o.data_ptr(), 2, False)                # null tile
+    with pytest.raises(ValueError):
+        hip.MaskHandle.dense(0, np.ones((0, 4), dtype=np.float32), np.float32)
+    h.apply(t.data_ptr(), np.float32, 0, 64, o.data_ptr(), 2, False)         # empty tile: no-op
+    h.close()
