@@ -1,0 +1,221 @@
+"""
+`Context`: the user-facing entry point.
+
+Mirrors the part of the reference's libertem.api.Context (api.py:177-1720) that sits on top of the
+mask / sum / CoM / radial-Fourier path: `load`, `run_udf`, `run_udf_iter`, `run`, `map`,
+`create_mask_analysis`, `create_com_analysis`, `create_radial_fourier_analysis`,
+`create_sum_analysis`, `create_disk_analysis`, `create_ring_analysis`, `create_point_analysis`
+with the same argument names and return types (`dict[str, BufferWrapper]` for one UDF, a tuple of
+dicts for a list, api.py:1330-1334).
+
+Executors: 'hip' (default when a GPU is visible: one MI355X per process, sharded over ranks if
+torch.distributed is initialised) and 'inline' (CPU plumbing for user UDFs written against NumPy).
+The reference's dask / pipelined / delayed executors are out of scope.
+"""
+import numpy as np
+
+from libertem_amd.common.exceptions import ExecutorSpecException
+from libertem_amd.io.dataset import load as _load_dataset, MemoryDataSet
+from libertem_amd.udf.base import UDFRunner, UDF
+from libertem_amd.analysis import (
+    MasksAnalysis, COMAnalysis, RadialFourierAnalysis, SumAnalysis, DiskMaskAnalysis,
+    RingMaskAnalysis, PointMaskAnalysis,
+)
+
+
+def _gpu_available():
+    try:
+        from libertem_amd import hip
+        return hip.device_count() > 0
+    except Exception:
+        return False
+
+
+class Context:
+    def __init__(self, executor=None, plot_class=None):
+        if executor is None:
+            executor = self._create_local_executor()
+        self.executor = executor
+
+    @classmethod
+    def make_with(cls, executor_spec=None, *args, cpus=None, gpus=None, plot_class=None,
+                  **kwargs):
+        """
+        executor_spec : 'hip' | 'inline' | None (= 'hip' when a GPU is visible, else 'inline').
+        gpus : for 'hip': int or iterable with ONE device ordinal (one GPU per process; use
+            torchrun + torch.distributed for several GPUs).
+        """
+        if executor_spec is None:
+            executor_spec = 'hip' if _gpu_available() else 'inline'
+        if executor_spec == 'inline':
+            from libertem_amd.executor.inline import InlineJobExecutor
+            return cls(executor=InlineJobExecutor(*args, **kwargs))
+        if executor_spec == 'hip':
+            from libertem_amd.executor.hip import HipJobExecutor
+            gpu_id = None
+            if gpus is not None:
+                ids = [gpus] if isinstance(gpus, int) else list(gpus)
+                if len(ids) != 1:
+                    raise ExecutorSpecException(
+                        "the 'hip' executor drives one GPU per process; launch one process per "
+                        "GPU (torchrun) and initialise torch.distributed for multi-GPU runs")
+                gpu_id = ids[0]
+            return cls(executor=HipJobExecutor(gpu_id=gpu_id, **kwargs))
+        raise ExecutorSpecException(
+            f"executor_spec {executor_spec!r} is not available in libertem_amd "
+            "(available: 'hip', 'inline')")
+
+    def _create_local_executor(self):
+        if _gpu_available():
+            from libertem_amd.executor.hip import HipJobExecutor
+            return HipJobExecutor()
+        from libertem_amd.executor.inline import InlineJobExecutor
+        return InlineJobExecutor()
+
+    # --- datasets ------------------------------------------------------------------------------
+    def load(self, filetype, *args, io_backend=None, **kwargs):
+        ds = _load_dataset(filetype, *args, **kwargs)
+        return ds.initialize(self.executor)
+
+    # --- analyses (reference api.py:514-811) -----------------------------------------------------
+    def create_mask_analysis(self, factories, dataset, use_sparse=None, mask_count=None,
+                             mask_dtype=None, dtype=None):
+        return MasksAnalysis(dataset=dataset, parameters={
+            "factories": factories, "use_sparse": use_sparse, "mask_count": mask_count,
+            "mask_dtype": mask_dtype, "dtype": dtype})
+
+    def create_com_analysis(self, dataset, cx=None, cy=None, mask_radius=None, flip_y=False,
+                            mask_radius_inner=None, scan_rotation=0.0):
+        if dataset.shape.nav.dims != 2:
+            raise ValueError("incompatible dataset: need two navigation dimensions")
+        if dataset.shape.sig.dims != 2:
+            raise ValueError("incompatible dataset: need two signal dimensions")
+        loc = locals()
+        parameters = {name: loc[name] for name in ['cx', 'cy', 'flip_y', 'scan_rotation']
+                      if loc[name] is not None}
+        if mask_radius is not None:
+            parameters['r'] = mask_radius
+        if mask_radius_inner is not None:
+            if mask_radius is None:
+                raise ValueError("incompatible parameters: must pass both `mask_radius` and "
+                                 "`mask_radius_inner` for annular CoM")
+            parameters['ri'] = mask_radius_inner
+        return COMAnalysis(dataset=dataset, parameters=parameters)
+
+    def create_radial_fourier_analysis(self, dataset, cx=None, cy=None, ri=None, ro=None,
+                                       n_bins=None, max_order=None, use_sparse=None):
+        if dataset.shape.sig.dims != 2:
+            raise ValueError("incompatible dataset: need two signal dimensions")
+        loc = locals()
+        parameters = {name: loc[name]
+                      for name in ['cx', 'cy', 'ri', 'ro', 'n_bins', 'max_order', 'use_sparse']
+                      if loc[name] is not None}
+        return RadialFourierAnalysis(dataset=dataset, parameters=parameters)
+
+    def create_disk_analysis(self, dataset, cx=None, cy=None, r=None):
+        if dataset.shape.sig.dims != 2:
+            raise ValueError("incompatible dataset: need two signal dimensions")
+        loc = locals()
+        return DiskMaskAnalysis(dataset=dataset, parameters={
+            name: loc[name] for name in ['cx', 'cy', 'r'] if loc[name] is not None})
+
+    def create_ring_analysis(self, dataset, cx=None, cy=None, ri=None, ro=None):
+        if dataset.shape.sig.dims != 2:
+            raise ValueError("incompatible dataset: need two signal dimensions")
+        loc = locals()
+        return RingMaskAnalysis(dataset=dataset, parameters={
+            name: loc[name] for name in ['cx', 'cy', 'ri', 'ro'] if loc[name] is not None})
+
+    def create_point_analysis(self, dataset, x=None, y=None):
+        if dataset.shape.nav.dims > 2:
+            raise ValueError("incompatible dataset: need at most two navigation dimensions")
+        parameters = {k: v for k, v in {'cx': x, 'cy': y}.items() if v is not None}
+        return PointMaskAnalysis(dataset=dataset, parameters=parameters)
+
+    def create_sum_analysis(self, dataset):
+        return SumAnalysis(dataset=dataset, parameters={})
+
+    # --- running -------------------------------------------------------------------------------
+    def run(self, job, roi=None, progress=False, corrections=None):
+        """Run an Analysis and post-process its UDF results (reference api.py:854-912)."""
+        analysis = job
+        if roi is None:
+            roi = analysis.get_roi()
+        udf_results = self.run_udf(dataset=analysis.dataset, udf=analysis.get_udf(), roi=roi,
+                                   corrections=corrections, progress=progress)
+        damage = True if roi is None else np.asarray(roi, dtype=bool)
+        return analysis.get_udf_results(udf_results, roi, damage=damage)
+
+    def run_udf(self, dataset, udf, roi=None, corrections=None, progress=False, backends=None,
+                plots=None, sync=True):
+        """
+        Run `udf` (a UDF or a list of UDFs) on `dataset`, restricted to `roi`
+        (reference api.py:914-1051).  Returns dict[str, BufferWrapper] (tuple of dicts for a list).
+        """
+        if not sync:
+            raise NotImplementedError("only sync=True is available in libertem_amd")
+        if corrections is not None and getattr(corrections, 'have_corrections', lambda: False)():
+            raise NotImplementedError("detector corrections are out of scope of libertem_amd")
+        udf_is_list = isinstance(udf, (tuple, list))
+        udfs = list(udf) if udf_is_list else [udf]
+        if roi is not None:
+            roi = self._normalize_roi(roi, dataset)
+        runner = UDFRunner(udfs)
+        res = runner.run_for_dataset(dataset=dataset, executor=self.executor, roi=roi,
+                                     progress=progress, corrections=None, backends=backends)
+        buffers = res.buffers
+        return tuple(buffers) if udf_is_list else buffers[0]
+
+    def run_udf_iter(self, dataset, udf, roi=None, corrections=None, progress=False,
+                     backends=None, plots=None, sync=True):
+        """Generator of partial results after each merged partition (api.py:1053-1152)."""
+        udf_is_list = isinstance(udf, (tuple, list))
+        udfs = list(udf) if udf_is_list else [udf]
+        if roi is not None:
+            roi = self._normalize_roi(roi, dataset)
+        runner = UDFRunner(udfs)
+        for part in runner.run_for_dataset_sync(dataset=dataset, executor=self.executor, roi=roi,
+                                                progress=progress, corrections=None,
+                                                backends=backends, iterate=True):
+            if not udf_is_list:
+                part.buffers  # noqa: B018  (materialise lazily built result)
+            yield part
+
+    @staticmethod
+    def _normalize_roi(roi, dataset):
+        import scipy.sparse as sp
+        nav = tuple(dataset.shape.nav)
+        if sp.issparse(roi):
+            roi = roi.toarray()
+        if isinstance(roi, (tuple, list)):
+            # coordinate tuple(s): ((y, x), ...) or a single (y, x) (api.py:1280-1288)
+            coords = roi
+            if all(isinstance(c, (int, np.integer)) for c in coords):
+                coords = (coords,)
+            arr = np.zeros(nav, dtype=bool)
+            for c in coords:
+                c = tuple(c)
+                if len(c) == len(nav) + 1:
+                    arr[c[:-1]] = bool(c[-1])
+                else:
+                    arr[c] = True
+            roi = arr
+        roi = np.asarray(roi, dtype=bool)
+        if roi.shape != nav:
+            raise ValueError(f"roi: incompatible shapes: {roi.shape} (roi) vs {nav} (dataset)")
+        return roi
+
+    def map(self, dataset, f, roi=None, progress=False, corrections=None, backends=None):
+        """Apply `f` to every frame; result is kind='nav' (reference api.py:1617-1670)."""
+        from libertem_amd.udf.auto import AutoUDF
+        return self.run_udf(dataset=dataset, udf=AutoUDF(f=f), roi=roi, progress=progress,
+                            backends=backends)
+
+    def close(self):
+        self.executor.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc_val, exc_tb):
+        self.close()

@@ -1,0 +1,388 @@
+"""
+Result / aux buffers of the UDF runtime.
+
+Own implementation of the subset of the reference's libertem.common.buffers.BufferWrapper
+(common/buffers.py:326-946) that the mask / sum / CoM path exercises:
+
+* kinds 'nav' | 'sig' | 'single', `extra_shape`, dtype, `where='device'`, `use`
+* worker-side shape = (frames in partition after ROI,) + extra for nav buffers (:419-431),
+  main-process shape = (prod(nav) or roi count,) + extra (:433-443)
+* `.data` reshapes to nav + extra and embeds ROI results into a NaN/0/False filled array
+  (:470-505); `.raw_data` is the flat array (:516-522)
+* views for dataset / partition / tile / frame (:720-821)
+* `allocate(lib)`: host (NumPy) or device (`HipArray`) memory, zero-initialised (:668-686);
+  `export()` copies device buffers back to NumPy once per partition (:901-907)
+"""
+import numpy as np
+
+from .math import prod
+from .shape import Shape
+from .hiparray import HipArray
+
+
+def _fill_value(dtype):
+    kind = np.dtype(dtype).kind
+    if kind in 'fc':
+        return np.nan
+    if kind == 'b':
+        return False
+    return 0
+
+
+def to_numpy(a):
+    if isinstance(a, HipArray):
+        return a.cpu()
+    return np.asarray(a)
+
+
+class BufferWrapper:
+    def __init__(self, kind, extra_shape=(), dtype="float32", where=None, use=None):
+        if kind not in ('nav', 'sig', 'single'):
+            raise ValueError(f"invalid buffer kind {kind!r}")
+        if use not in (None, 'private', 'result_only'):
+            raise ValueError(f"invalid use {use!r}")
+        self._kind = kind
+        self._extra_shape = tuple(int(x) for x in extra_shape)
+        self._dtype = np.dtype(dtype)
+        self._where = where
+        self.use = use
+        self._data = None            # np.ndarray | HipArray
+        self._shape = None
+        self._ds_shape = None
+        self._roi = None
+        self._roi_is_zero = None
+        self._valid_mask = None
+        self._ds_partitions = None
+        self._contiguous_cache = {}
+
+    # --- declaration properties --------------------------------------------------------------
+    @property
+    def kind(self):
+        return self._kind
+
+    @property
+    def extra_shape(self):
+        return self._extra_shape
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    @property
+    def where(self):
+        return self._where
+
+    @property
+    def shape(self):
+        return self._shape
+
+    def result_buffer_type(self):
+        return BufferWrapper
+
+    # --- roi / shape -------------------------------------------------------------------------
+    def set_roi(self, roi):
+        if roi is not None:
+            roi = np.asarray(roi, dtype=bool).reshape(-1)
+        self._roi = roi
+        self._roi_is_zero = None if roi is None else (np.count_nonzero(roi) == 0)
+
+    @property
+    def roi_is_zero(self):
+        return bool(self._roi_is_zero)
+
+    def _shape_for_kind(self, kind, orig_shape, roi_count=None):
+        if kind == 'nav':
+            n = prod(orig_shape.nav) if roi_count is None else roi_count
+            return (n,) + self._extra_shape
+        if kind == 'sig':
+            return tuple(orig_shape.sig) + self._extra_shape
+        if kind == 'single':
+            return self._extra_shape if self._extra_shape else (1,)
+        raise ValueError(kind)
+
+    def set_shape_partition(self, partition, roi=None):
+        roi_count = None
+        if roi is not None:
+            roi_part = np.asarray(roi).reshape(-1)[partition.slice.get(nav_only=True)]
+            roi_count = int(np.count_nonzero(roi_part))
+        assert partition.shape.nav.dims == 1
+        self._shape = self._shape_for_kind(self._kind, partition.shape, roi_count)
+
+    def set_shape_ds(self, dataset_shape, roi=None):
+        roi_count = None if roi is None else int(np.count_nonzero(roi))
+        self._shape = self._shape_for_kind(self._kind, dataset_shape.flatten_nav(), roi_count)
+        self._ds_shape = dataset_shape
+
+    # --- allocation ---------------------------------------------------------------------------
+    def allocate(self, lib=None):
+        """lib: None/'numpy' -> host zeros; ('hip', device) -> HipArray zeros when this buffer
+        was declared where='device', host zeros otherwise (reference :668-686)."""
+        if self._shape is None:
+            raise RuntimeError("shape must be set before allocate()")
+        if isinstance(lib, tuple) and lib[0] == 'hip' and self._where == 'device':
+            self._data = HipArray.zeros(self._shape, self._dtype, lib[1])
+        else:
+            self._data = np.zeros(self._shape, dtype=self._dtype)
+
+    def has_data(self):
+        return self._data is not None
+
+    @property
+    def on_device(self):
+        return isinstance(self._data, HipArray)
+
+    def export(self):
+        """D2H once per partition (reference :901-907)."""
+        if isinstance(self._data, HipArray):
+            self._data = self._data.cpu()
+
+    def replace_array(self, data):
+        data = np.asarray(data) if not isinstance(data, HipArray) else data
+        if tuple(data.shape) != tuple(self._shape) and data.size == prod(self._shape):
+            data = data.reshape(self._shape)
+        if tuple(data.shape) != tuple(self._shape):
+            raise ValueError(f"shape mismatch: buffer {self._shape}, new data {data.shape}")
+        self._data = data
+
+    # --- user-facing data ---------------------------------------------------------------------
+    @property
+    def raw_data(self):
+        return None if self._data is None else to_numpy(self._data)
+
+    @property
+    def data(self):
+        """nav + extra (or sig + extra) shaped NumPy array; ROI results are embedded into a
+        fill-valued full array (reference :470-505)."""
+        arr = self.raw_data
+        if arr is None:
+            return None
+        if self._kind != 'nav' or self._ds_shape is None:
+            return arr
+        shape = tuple(self._ds_shape.nav) + self._extra_shape
+        if self._roi is None:
+            return arr.reshape(shape)
+        if self._roi_is_zero:
+            return np.full(shape, _fill_value(self._dtype), dtype=self._dtype)
+        wrapper = np.full((prod(self._ds_shape.nav),) + self._extra_shape,
+                          _fill_value(self._dtype), dtype=self._dtype)
+        wrapper[self._roi] = arr
+        return wrapper.reshape(shape)
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.data
+        return a if dtype is None else a.astype(dtype)
+
+    # --- valid masks (reference :524-633) -----------------------------------------------------
+    def make_default_mask(self, valid_nav_mask):
+        if self._kind == 'nav':
+            m = np.asarray(valid_nav_mask, dtype=bool).reshape(-1)
+            if self._roi is not None:
+                m = m[self._roi] if m.size == self._roi.size else m
+            return m
+        return bool(np.any(valid_nav_mask))
+
+    @property
+    def valid_mask(self):
+        vm = self._valid_mask
+        if vm is None:
+            vm = True
+        if self._kind == 'nav' and self._ds_shape is not None:
+            full_shape = tuple(self._ds_shape.nav) + self._extra_shape
+            if np.ndim(vm) == 0:
+                base = np.full(full_shape, bool(vm), dtype=bool)
+                if self._roi is not None:
+                    nav = np.zeros(prod(self._ds_shape.nav), dtype=bool)
+                    nav[self._roi] = bool(vm)
+                    base = np.broadcast_to(
+                        nav.reshape(tuple(self._ds_shape.nav) + (1,) * len(self._extra_shape)),
+                        full_shape).copy()
+                return base
+            vm = np.asarray(vm, dtype=bool).reshape(-1)
+            nav = np.zeros(prod(self._ds_shape.nav), dtype=bool)
+            if self._roi is not None and vm.size == int(np.count_nonzero(self._roi)):
+                nav[self._roi] = vm
+            else:
+                nav[:] = vm
+            return np.broadcast_to(
+                nav.reshape(tuple(self._ds_shape.nav) + (1,) * len(self._extra_shape)),
+                full_shape).copy()
+        shape = self.data.shape if self.data is not None else ()
+        return np.full(shape, bool(np.all(vm)), dtype=bool)
+
+    @valid_mask.setter
+    def valid_mask(self, value):
+        self._valid_mask = value
+
+    @property
+    def masked_data(self):
+        return np.ma.MaskedArray(self.data, mask=~self.valid_mask)
+
+    # --- views --------------------------------------------------------------------------------
+    def _slice_for_partition(self, partition):
+        """Rows of the dataset-wide (roi-compressed) nav buffer that belong to `partition`."""
+        if self._roi is None:
+            return partition.slice.origin[0], partition.slice.origin[0] + partition.slice.shape[0]
+        s = partition.slice.adjust_for_roi(self._roi)
+        return s.origin[0], s.origin[0] + s.shape[0]
+
+    def _rows(self, start, stop):
+        if isinstance(self._data, HipArray):
+            return self._data.rows(start, stop)
+        return self._data[start:stop]
+
+    def get_view_for_dataset(self, dataset):
+        if self._kind == 'nav' and isinstance(self._data, np.ndarray) and self._roi is None:
+            return self._data.reshape(tuple(dataset.shape.nav) + self._extra_shape)
+        return self._data
+
+    def get_view_for_partition(self, partition):
+        """Main-process buffer: the part that `partition` fills (reference :746-759)."""
+        if self._kind == 'nav':
+            start, stop = self._slice_for_partition(partition)
+            return self._rows(start, stop)
+        return self._data
+
+    def _tile_rows(self, partition, tile):
+        """Worker buffer rows of a tile: tile origin relative to the partition origin, both in
+        the roi-compressed numbering (reference :792-821)."""
+        p0 = partition.slice.adjust_for_roi(self._roi).origin[0] if self._roi is not None \
+            else partition.slice.origin[0]
+        t0 = tile.tile_slice.origin[0]
+        start = t0 - p0
+        return start, start + tile.tile_slice.shape[0]
+
+    def get_view_for_tile(self, partition, tile):
+        if self._kind == 'nav':
+            start, stop = self._tile_rows(partition, tile)
+            return self._rows(start, stop)
+        if self._kind == 'sig':
+            if isinstance(self._data, HipArray):
+                return HipSigView(self._data, tile.tile_slice, self._extra_shape)
+            sl = tile.tile_slice.get(sig_only=True)
+            return self._data[sl]
+        return self._data
+
+    get_contiguous_view_for_tile = get_view_for_tile
+
+    def get_view_for_frame(self, partition, tile, frame_idx):
+        if self._kind == 'nav':
+            start, _ = self._tile_rows(partition, tile)
+            if isinstance(self._data, HipArray):
+                v = self._data.rows(start + frame_idx, start + frame_idx + 1)
+                return v
+            if len(self._extra_shape) == 0:
+                return self._data[start + frame_idx:start + frame_idx + 1]
+            return self._data[start + frame_idx]
+        return self.get_view_for_tile(partition, tile)
+
+    def flush(self, debug=False):
+        self._contiguous_cache.clear()
+
+    def __repr__(self):
+        return (f"<{type(self).__name__} kind={self._kind} dtype={self._dtype} "
+                f"extra_shape={self._extra_shape} shape={self._shape}>")
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        if isinstance(d.get('_data'), HipArray):
+            d['_data'] = d['_data'].cpu()
+        d['_contiguous_cache'] = {}
+        return d
+
+
+class HipSigView:
+    """Sig-kind device buffer restricted to a tile's sig slice (whole buffer + the slice)."""
+    __slots__ = ('array', 'tile_slice', 'extra_shape')
+
+    def __init__(self, array, tile_slice, extra_shape):
+        self.array = array
+        self.tile_slice = tile_slice
+        self.extra_shape = extra_shape
+
+
+class PlaceholderBufferWrapper(BufferWrapper):
+    """Declared with use='result_only': only filled in get_results (reference :949-986)."""
+
+    def allocate(self, lib=None):
+        self._data = None
+
+    def has_data(self):
+        return False
+
+    def export(self):
+        pass
+
+    def _err(self, *a, **k):
+        raise RuntimeError("result_only buffers are only available in get_results()")
+
+    get_view_for_partition = _err
+    get_view_for_tile = _err
+    get_view_for_frame = _err
+    get_contiguous_view_for_tile = _err
+
+    @property
+    def data(self):
+        self._err()
+
+    @property
+    def raw_data(self):
+        self._err()
+
+    def result_buffer_type(self):
+        return BufferWrapper
+
+
+class PreallocBufferWrapper(BufferWrapper):
+    def __init__(self, data, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._data = data
+        self._shape = tuple(data.shape)
+
+
+class AuxBufferWrapper(BufferWrapper):
+    """Read-only per-nav (or sig/single) input data handed to a UDF (reference :995-1048)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._data_coords_global = True
+
+    def set_buffer(self, buf, is_global=True):
+        buf = np.asarray(buf)
+        self._data = buf.reshape((-1,) + self._extra_shape) if self._kind == 'nav' else buf
+        self._shape = self._data.shape
+        self._data_coords_global = is_global
+
+    def new_for_partition(self, partition, roi):
+        if self._kind != 'nav':
+            return self
+        assert self._data_coords_global
+        new = AuxBufferWrapper(self._kind, self._extra_shape, self._dtype)
+        data = self._data
+        part = data[partition.slice.origin[0]:partition.slice.origin[0] + partition.slice.shape[0]]
+        if roi is not None:
+            roi_part = np.asarray(roi).reshape(-1)[partition.slice.get(nav_only=True)]
+            part = part[roi_part]
+        new.set_buffer(part, is_global=False)
+        new.set_roi(roi)
+        assert np.allclose(new._data.shape[1:], self._extra_shape) or not self._extra_shape
+        return new
+
+    def get_view_for_dataset(self, dataset):
+        return self._data
+
+    def get_view_for_partition(self, partition):
+        return self._data
+
+    def get_view_for_tile(self, partition, tile):
+        if self._kind == 'nav':
+            start, stop = self._tile_rows(partition, tile)
+            return self._data[start:stop]
+        return self._data
+
+    get_contiguous_view_for_tile = get_view_for_tile
+
+    def get_view_for_frame(self, partition, tile, frame_idx):
+        if self._kind == 'nav':
+            start, _ = self._tile_rows(partition, tile)
+            return self._data[start + frame_idx]
+        return self._data

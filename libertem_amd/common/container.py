@@ -1,0 +1,189 @@
+"""
+MaskContainer: lazily evaluated, cached, sig-sliced mask stacks.
+
+Same role and constructor surface as the reference's libertem.common.container.MaskContainer
+(common/container.py:97-339): evaluates the factories once per worker, decides dense vs sparse
+(:150-177, :245-258, :295-301), and serves the per-sig-slice matrix `(px_in_slice, n_masks)`
+cached per slice (:74-94).
+
+What is different here: besides the host matrix (`get_for_sig_slice`) the container serves a
+*device handle* (`get_handle_for_sig_slice`) -- the libltmi image of that slice, cast to the result
+dtype, resident in HBM for the lifetime of the worker's task.
+"""
+import logging
+
+import numpy as np
+import scipy.sparse as sp
+import cloudpickle
+
+from libertem_amd.common.sparse import SparseStack, is_sparse, to_dense, to_sparse_stack
+from libertem_amd.common.slice import Slice
+
+log = logging.getLogger(__name__)
+
+_SPARSE_NAMES = ('scipy.sparse', 'scipy.sparse.csc', 'scipy.sparse.csr', 'sparse.pydata',
+                 'sparse.pydata.GCXS')
+
+
+class MaskContainer:
+    def __init__(self, mask_factories, dtype=None, use_sparse=None, count=None, backend=None,
+                 default_sparse='scipy.sparse'):
+        self.mask_factories = mask_factories
+        self._length = count
+        self._dtype = dtype
+        self._computed_masks = None
+        self.backend = backend or 'numpy'
+        self._default_sparse = default_sparse
+        self._host_cache = {}
+        self._handle_cache = {}
+        if use_sparse is True:
+            self._use_sparse = default_sparse
+        elif use_sparse is False:
+            self._use_sparse = False
+        elif isinstance(use_sparse, str) and (
+                use_sparse.lower().startswith('scipy.sparse')
+                or use_sparse.lower().startswith('sparse.pydata')):
+            self._use_sparse = use_sparse
+        elif use_sparse is None:
+            self._use_sparse = None          # resolved once the masks exist
+        else:
+            raise ValueError(f'use_sparse not an allowed value: {use_sparse}')
+        self.validate_mask_functions()
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state['_host_cache'] = {}
+        state['_handle_cache'] = {}
+        return state
+
+    def validate_mask_functions(self):
+        fns = self.mask_factories
+        limit = 2**20
+        if callable(fns):
+            fns = [fns]
+        for fn in fns:
+            s = len(cloudpickle.dumps(fn))
+            if s > limit:
+                log.warning('Mask factory size %s larger than warning limit %s, may be inefficient'
+                            % (s, limit))
+
+    def __len__(self):
+        if self._length is not None:
+            return self._length
+        if not callable(self.mask_factories):
+            return len(self.mask_factories)
+        return len(self.computed_masks)
+
+    @property
+    def dtype(self):
+        if self._dtype is None:
+            return self.computed_masks.dtype
+        return np.dtype(self._dtype)
+
+    @property
+    def use_sparse(self):
+        if self._use_sparse is None:
+            self._use_sparse = self._default_sparse if is_sparse(self.computed_masks) else False
+        return self._use_sparse
+
+    @property
+    def computed_masks(self):
+        if self._computed_masks is None:
+            self._computed_masks = self._compute_masks()
+        return self._computed_masks
+
+    def _compute_masks(self):
+        """Call the factories and stack the results (common/container.py:260-314)."""
+        pieces = []
+        if callable(self.mask_factories):
+            raw = self.mask_factories()
+            if isinstance(raw, (list, tuple)):
+                # the reference's sparse.concatenate / np.concatenate accept a list of masks
+                raw = [r if is_sparse(r) else np.asarray(r) for r in raw]
+                if all(not is_sparse(r) for r in raw):
+                    raw = np.stack(raw)
+                else:
+                    raw = SparseStack.concatenate([
+                        SparseStack.from_scipy(r) if sp.issparse(r) else
+                        (r if isinstance(r, SparseStack) else to_sparse_stack(r[np.newaxis]))
+                        for r in raw])
+            pieces.append(raw)
+        else:
+            for f in self.mask_factories:
+                m = f()
+                if sp.issparse(m):
+                    m = SparseStack.from_scipy(m)            # one mask
+                elif isinstance(m, SparseStack):
+                    pass
+                else:
+                    m = np.asarray(m)
+                    m = m.reshape((1,) + m.shape)
+                pieces.append(m)
+        masks_are_sparse = all(is_sparse(m) for m in pieces)
+        use_sparse = self._use_sparse
+        if use_sparse is None:
+            use_sparse = self._default_sparse if masks_are_sparse else False
+        if use_sparse is not False:
+            return SparseStack.concatenate([to_sparse_stack(m) for m in pieces])
+        return np.concatenate([to_dense(m) for m in pieces])
+
+    # --- host matrices ---------------------------------------------------------------------------
+    def get_for_sig_slice(self, sig_slice, dtype=None, sparse_backend=None, transpose=True,
+                          backend=None):
+        """(px_in_slice, n_masks) [transpose=True] host matrix of the slice: dense ndarray or
+        scipy CSR/CSC (common/container.py:74-94, :213-217)."""
+        if dtype is None:
+            dtype = self.dtype
+        if sparse_backend is None:
+            sparse_backend = self.use_sparse
+        key = (sig_slice, np.dtype(dtype).str, sparse_backend, transpose)
+        if key not in self._host_cache:
+            self._host_cache[key] = self._build_host(sig_slice, dtype, sparse_backend, transpose)
+        return self._host_cache[key]
+
+    def get(self, key, dtype=None, sparse_backend=None, transpose=True, backend=None):
+        if not isinstance(key, Slice):
+            raise TypeError("MaskContainer.get() can only be called with "
+                            "DataTile/Slice/Partition instances")
+        return self.get_for_sig_slice(key.discard_nav(), dtype, sparse_backend, transpose)
+
+    def get_for_idx(self, scheme, idx, *args, **kwargs):
+        return self.get_for_sig_slice(scheme[idx], *args, **kwargs)
+
+    def _build_host(self, sig_slice, dtype, sparse_backend, transpose):
+        masks = self.computed_masks
+        if sparse_backend is False:
+            m = sig_slice.get(to_dense(masks), sig_only=True)
+            m = m.reshape((m.shape[0], -1))
+            if transpose:
+                m = m.T
+            return m.astype(dtype)
+        stack = to_sparse_stack(masks)
+        fmt = 'csc' if 'csc' in sparse_backend else 'csr'
+        mat = stack.to_px_by_masks(sig_slice=sig_slice, dtype=dtype, fmt=fmt)
+        if not transpose:
+            mat = mat.T
+        return mat
+
+    # --- device handles --------------------------------------------------------------------------
+    def get_handle_for_sig_slice(self, sig_slice, result_dtype, device):
+        """libltmi handle of the slice's stack, cast to `result_dtype`, on GPU `device`."""
+        from libertem_amd import hip
+        key = (sig_slice, np.dtype(result_dtype).str, int(device))
+        h = self._handle_cache.get(key)
+        if h is None:
+            if self.use_sparse is False:
+                m = self.get_for_sig_slice(sig_slice, dtype=result_dtype, sparse_backend=False,
+                                           transpose=False)            # (n_masks, px), C order
+                h = hip.MaskHandle.dense(device, np.ascontiguousarray(m), result_dtype)
+            else:
+                m = self.get_for_sig_slice(sig_slice, dtype=result_dtype,
+                                           sparse_backend='scipy.sparse.csr', transpose=True)
+                h = hip.MaskHandle.csr(device, sp.csr_matrix(m), result_dtype)
+            self._handle_cache[key] = h
+        return h
+
+    def close(self):
+        for h in self._handle_cache.values():
+            h.close()
+        self._handle_cache = {}

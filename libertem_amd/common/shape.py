@@ -1,0 +1,108 @@
+"""
+`Shape`: an n-d shape split into navigation and signal parts.
+API subset of the reference's libertem.common.shape.Shape (common/shape.py:7-213).
+"""
+from .math import prod
+
+
+class Shape:
+    __slots__ = ('_t', '_sig_dims')
+
+    def __init__(self, shape, sig_dims):
+        self._t = tuple(int(s) for s in shape)
+        self._sig_dims = int(sig_dims)
+        if self._sig_dims < 0 or self._sig_dims > len(self._t):
+            raise ValueError(f"invalid sig_dims {sig_dims} for shape {self._t}")
+
+    # --- parts -------------------------------------------------------------------------------
+    @property
+    def nav(self):
+        return NavOnlyShape(self._t[:len(self._t) - self._sig_dims])
+
+    @property
+    def sig(self):
+        return SigOnlyShape(self._t[len(self._t) - self._sig_dims:])
+
+    @property
+    def sig_dims(self):
+        return self._sig_dims
+
+    @property
+    def nav_dims(self):
+        return len(self._t) - self._sig_dims
+
+    @property
+    def dims(self):
+        return len(self._t)
+
+    @property
+    def size(self):
+        return prod(self._t)
+
+    def to_tuple(self):
+        return self._t
+
+    def flatten_nav(self):
+        nav = self._t[:self.nav_dims]
+        return Shape((prod(nav),) + self._t[self.nav_dims:], sig_dims=self._sig_dims)
+
+    def flatten_sig(self):
+        sig = self._t[self.nav_dims:]
+        return Shape(self._t[:self.nav_dims] + (prod(sig),), sig_dims=1)
+
+    # --- container protocol --------------------------------------------------------------------
+    def __iter__(self):
+        return iter(self._t)
+
+    def __len__(self):
+        return len(self._t)
+
+    def __getitem__(self, k):
+        return self._t[k]
+
+    def __eq__(self, other):
+        if isinstance(other, Shape):
+            return self._t == other._t and self._sig_dims == other._sig_dims
+        if isinstance(other, (tuple, list)):
+            return self._t == tuple(other)
+        return NotImplemented
+
+    def __hash__(self):
+        return hash((self._t, self._sig_dims))
+
+    def __add__(self, other):
+        return self._t + tuple(other)
+
+    def __radd__(self, other):
+        return tuple(other) + self._t
+
+    def __repr__(self):
+        return f"{tuple(self.nav._t)!r}+{tuple(self.sig._t)!r}" if type(self) is Shape \
+            else repr(self._t)
+
+    def __getstate__(self):
+        return {'_t': self._t, '_sig_dims': self._sig_dims}
+
+    def __setstate__(self, state):
+        self._t = state['_t']
+        self._sig_dims = state['_sig_dims']
+
+
+class SigOnlyShape(Shape):
+    __slots__ = ()
+
+    def __init__(self, shape):
+        super().__init__(shape, sig_dims=len(tuple(shape)))
+
+    def flatten_nav(self):
+        raise ValueError("a sig-only shape has no nav part")
+
+
+class NavOnlyShape(Shape):
+    __slots__ = ()
+
+    def __init__(self, shape):
+        super().__init__(shape, sig_dims=0)
+
+    def flatten_sig(self):
+        raise ValueError("a nav-only shape has no sig part")

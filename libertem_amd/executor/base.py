@@ -1,0 +1,105 @@
+"""
+Executor protocol: `Environment`, `JobExecutor` (subset of the reference's common/executor.py:
+52-432 and executor/base.py).
+"""
+import contextlib
+import os
+
+from libertem_amd.common.backend import set_use_cpu, set_use_hip
+
+
+class Environment:
+    """
+    What a task may assume about its worker (common/executor.py:52-140): thread budget and the
+    device it drives.  `device_class` is 'hip' iff `gpu_id` is not None.
+    """
+
+    def __init__(self, threads_per_worker=None, threaded_executor=False, gpu_id=None,
+                 keep_results_on_device=False, stream=None):
+        self._threads_per_worker = threads_per_worker
+        self._threaded_executor = threaded_executor
+        self._gpu_id = gpu_id
+        self.keep_results_on_device = keep_results_on_device
+        self.stream = stream
+
+    @property
+    def threads_per_worker(self):
+        return self._threads_per_worker
+
+    @property
+    def threaded_executor(self):
+        return self._threaded_executor
+
+    @property
+    def gpu_id(self):
+        return self._gpu_id
+
+    @property
+    def device_class(self):
+        return 'hip' if self._gpu_id is not None else 'cpu'
+
+    @contextlib.contextmanager
+    def enter(self, enable_gpu=False):
+        """Select the device and limit BLAS threads for the duration of a task
+        (common/executor.py:111-129)."""
+        ctxs = contextlib.ExitStack()
+        with ctxs:
+            if self._threads_per_worker is not None:
+                try:
+                    from threadpoolctl import threadpool_limits
+                    ctxs.enter_context(threadpool_limits(limits=self._threads_per_worker))
+                except Exception:
+                    pass
+            if enable_gpu and self._gpu_id is not None:
+                import torch
+                ctxs.enter_context(torch.cuda.device(self._gpu_id))
+                if self.stream is not None:
+                    ctxs.enter_context(torch.cuda.stream(self.stream))
+            yield
+
+
+class JobExecutor:
+    device_class = 'cpu'
+    gpu_id = None
+
+    def run_tasks(self, tasks, params_handle, cancel_id, task_comm_handler=None):
+        raise NotImplementedError()
+
+    def run_function(self, fn, *args, **kwargs):
+        raise NotImplementedError()
+
+    def map(self, fn, iterable):
+        return [fn(x) for x in iterable]
+
+    def run_each_host(self, fn, *args, **kwargs):
+        return {"localhost": fn(*args, **kwargs)}
+
+    def run_each_worker(self, fn, *args, **kwargs):
+        return {"inline": fn(*args, **kwargs)}
+
+    def run_process_local(self, task, args=(), kwargs=None):
+        return task(*args, **(kwargs or {}))
+
+    def scatter(self, obj):
+        raise NotImplementedError()
+
+    def scatter_release(self, handle):
+        pass
+
+    def get_available_workers(self):
+        raise NotImplementedError()
+
+    def get_local_env(self):
+        raise NotImplementedError()
+
+    def close(self):
+        pass
+
+    def ensure_sync(self):
+        return self
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

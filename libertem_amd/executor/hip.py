@@ -1,0 +1,291 @@
+"""
+HipJobExecutor: runs UDF tasks on ONE MI355X from the calling process; with torch.distributed
+initialised (one process per GPU, backend "nccl" = RCCL over xGMI, or "gloo" in CPU tests) the
+partitions are sharded over the ranks and the per-rank results are combined with collectives.
+
+Replaces, for this path, the reference's process/device boundary `executor.run_tasks`
+(executor/dask.py:581-646: pickled tasks over TCP, one worker process per GPU with
+LIBERTEM_USE_CUDA, results pickled back, serial merge on the main process udf/base.py:2340-2358):
+
+* no pickling: tasks run in-process on a dedicated HIP stream of the worker's GPU;
+* device-side merge: UDFs that declare how their buffers combine (`get_dist_merge()`:
+  'disjoint' nav rows or 'sum') are merged in HBM -- slice copies / axpy -- and copied to the host
+  ONCE per run instead of once per partition (reference: buffers.py:901-907 per partition);
+* multi-GPU: rank r owns the contiguous block of partitions  [r*P/W, (r+1)*P/W)  -- the same
+  np.linspace nav sharding as the reference's partitioning -- then ONE all_gather (nav-kind,
+  disjoint) or all_reduce(sum) (sig-kind) per buffer; every rank ends up with the full result.
+  UDFs without a declaration fall back to gathering exported per-partition results and merging
+  them in partition order on every rank (reference semantics, slower).
+"""
+import uuid
+
+import numpy as np
+
+from libertem_amd.common.hiparray import HipArray, torch_dtype_for
+from libertem_amd.common.buffers import BufferWrapper, PlaceholderBufferWrapper
+from libertem_amd.common.backend import get_use_hip
+from .base import JobExecutor, Environment
+
+
+def _dist():
+    try:
+        import torch.distributed as dist
+    except Exception:
+        return None
+    if dist.is_available() and dist.is_initialized():
+        return dist
+    return None
+
+
+class HipJobExecutor(JobExecutor):
+    device_class = 'hip'
+
+    def __init__(self, gpu_id=None, distributed=None, require_gpu=True):
+        """
+        gpu_id : HIP device ordinal; default LIBERTEM_USE_HIP, else LOCAL_RANK, else 0.
+        distributed : None = use torch.distributed iff it is initialised; False = never.
+        require_gpu : False lets CPU-only tests drive the sharding/merge logic with NumPy UDFs
+            (device class stays 'cpu' then; the native UDFs still refuse to run).
+        """
+        import os
+        if gpu_id is None:
+            gpu_id = get_use_hip()
+        if gpu_id is None:
+            gpu_id = int(os.environ.get('LOCAL_RANK', 0))
+        self._require_gpu = require_gpu
+        self._stream = None
+        if require_gpu:
+            from libertem_amd import hip
+            hip.lib()                                   # fail loudly without the HIP library
+            import torch
+            if not torch.cuda.is_available() or hip.device_count() <= gpu_id:
+                raise RuntimeError(
+                    f"HipJobExecutor: GPU {gpu_id} not available "
+                    f"({hip.device_count()} HIP device(s) visible). There is no CPU fallback.")
+            self._stream = torch.cuda.Stream(device=gpu_id)
+            self.gpu_id = gpu_id
+            self.device_class = 'hip'
+        else:
+            self.gpu_id = None
+            self.device_class = 'cpu'
+        self._distributed = distributed
+        self._scattered = {}
+
+    # --- distributed helpers -----------------------------------------------------------------------
+    def _dist(self):
+        if self._distributed is False:
+            return None
+        return _dist()
+
+    @property
+    def rank(self):
+        d = self._dist()
+        return d.get_rank() if d else 0
+
+    @property
+    def world_size(self):
+        d = self._dist()
+        return d.get_world_size() if d else 1
+
+    def my_tasks(self, tasks):
+        """Contiguous block of the task list for this rank (nav sharding)."""
+        W, r = self.world_size, self.rank
+        P = len(tasks)
+        b = np.linspace(0, P, W + 1, dtype=int)
+        return tasks[b[r]:b[r + 1]]
+
+    # --- executor protocol -----------------------------------------------------------------------------
+    def get_local_env(self):
+        return Environment(threads_per_worker=None, threaded_executor=False, gpu_id=self.gpu_id,
+                           keep_results_on_device=(self.gpu_id is not None), stream=self._stream)
+
+    def scatter(self, obj):
+        handle = str(uuid.uuid4())
+        self._scattered[handle] = obj
+        return handle
+
+    def scatter_release(self, handle):
+        self._scattered.pop(handle, None)
+
+    def run_tasks(self, tasks, params_handle, cancel_id, task_comm_handler=None):
+        params = self._scattered[params_handle]
+        env = self.get_local_env()
+        self._all_tasks = list(tasks)
+        for task in self.my_tasks(self._all_tasks):
+            result = task(env=env, params=params)
+            yield result, task
+
+    def run_function(self, fn, *args, **kwargs):
+        return fn(*args, **kwargs)
+
+    def get_available_workers(self):
+        from .workers import Worker, WorkerSet
+        res = {'HIP': 1, 'compute': 1} if self.gpu_id is not None else \
+            {'CPU': 1, 'compute': 1, 'ndarray': 1}
+        return WorkerSet([Worker(name=f'hip-{self.gpu_id}', host='localhost', resources=res,
+                                 nthreads=1)])
+
+    def close(self):
+        self._scattered = {}
+
+    # --- merging ------------------------------------------------------------------------------------
+    def merge_results(self, udfs, damage, result_iter, apply_part_result):
+        """
+        Consume (part_results, task) pairs of THIS rank, merge, combine across ranks and leave the
+        complete result in every udf.results (host buffers) and `damage`.
+        """
+        plans = []
+        for udf in udfs:
+            decl = getattr(udf, 'get_dist_merge', lambda: None)()
+            names = [k for k, b in udf.results.items()
+                     if not isinstance(b, PlaceholderBufferWrapper)]
+            if decl is not None and set(names) <= set(decl) and self.gpu_id is not None:
+                plans.append(('device', decl))
+            elif decl is not None and set(names) <= set(decl):
+                plans.append(('host-declared', decl))
+            else:
+                plans.append(('generic', None))
+
+        dev_full = [dict() for _ in udfs]       # per udf: name -> torch tensor (full size)
+        generic_parts = []                      # (task idx, [exported results of generic udfs])
+        torch = None
+        if self.gpu_id is not None:
+            import torch
+
+        for part_results, task in result_iter:
+            gen_entry = {}
+            for i, (udf, results, (mode, decl)) in enumerate(zip(udfs, part_results, plans)):
+                if mode == 'device':
+                    self._merge_on_device(udf, results, task, decl, dev_full[i])
+                else:
+                    results.export()
+                    gen_entry[i] = results
+            if gen_entry:
+                generic_parts.append((task, gen_entry))
+            damage.get_view_for_partition(task.partition)[:] = True
+
+        d = self._dist()
+        # ---- declared buffers: collectives on flat tensors ----
+        for i, (udf, (mode, decl)) in enumerate(zip(udfs, plans)):
+            if mode == 'device':
+                for name, how in decl.items():
+                    buf = udf.results.get_buffer(name)
+                    if isinstance(buf, PlaceholderBufferWrapper):
+                        continue
+                    full = dev_full[i].get(name)
+                    if full is None:
+                        full = torch.zeros(buf.shape, dtype=torch_dtype_for(buf.dtype),
+                                           device=f'cuda:{self.gpu_id}')
+                    if d is not None and self.world_size > 1:
+                        full = self._combine(d, full, how)
+                    host = full.cpu().numpy()
+                    if host.dtype != buf.dtype:
+                        host = host.view(buf.dtype)
+                    buf.replace_array(host)
+            elif mode == 'host-declared':
+                # CPU rank (gloo tests / NumPy UDFs that declare their merge): merge locally with
+                # the UDF's own merge(), then combine the full-size host buffers
+                for task, entry in generic_parts:
+                    if i in entry:
+                        self._apply_one(udf, entry[i], task)
+                if d is not None and self.world_size > 1:
+                    import torch as _t
+                    for name, how in decl.items():
+                        buf = udf.results.get_buffer(name)
+                        if isinstance(buf, PlaceholderBufferWrapper):
+                            continue
+                        t = _t.from_numpy(np.ascontiguousarray(buf.raw_data))
+                        t = self._combine(d, t, how)
+                        buf.replace_array(t.numpy())
+        # ---- generic UDFs: ship exported partition results, merge in partition order ----
+        gen_idx = [i for i, (mode, _) in enumerate(plans) if mode == 'generic']
+        if gen_idx:
+            mine = [(task.idx, {i: entry[i] for i in gen_idx if i in entry})
+                    for task, entry in generic_parts]
+            if d is not None and self.world_size > 1:
+                gathered = [None] * self.world_size
+                d.all_gather_object(gathered, mine)
+                allparts = [p for chunk in gathered for p in chunk]
+            else:
+                allparts = mine
+            by_idx = {t.idx: t for t in self._all_tasks}
+            for tidx, entry in sorted(allparts, key=lambda x: x[0]):
+                task = by_idx[tidx]
+                for i in gen_idx:
+                    if i in entry:
+                        self._apply_one(udfs[i], entry[i], task)
+        # damage: with sharding every partition was processed by some rank
+        if d is not None and self.world_size > 1:
+            for task in self._all_tasks:
+                damage.get_view_for_partition(task.partition)[:] = True
+        if self._stream is not None:
+            self._stream.synchronize()
+
+    @staticmethod
+    def _apply_one(udf, results, task):
+        udf.set_views_for_partition(task.partition)
+        udf.merge(dest=udf.results.get_proxy(), src=results.get_proxy())
+        udf.clear_views()
+
+    def _merge_on_device(self, udf, results, task, decl, full):
+        import torch
+        with torch.cuda.device(self.gpu_id), torch.cuda.stream(self._stream):
+            for name, how in decl.items():
+                buf_main = udf.results.get_buffer(name)
+                if isinstance(buf_main, PlaceholderBufferWrapper):
+                    continue
+                part = results.get_buffer(name)._data
+                if not isinstance(part, HipArray):
+                    part = HipArray.from_numpy(np.asarray(part), self.gpu_id)
+                if name not in full:
+                    full[name] = torch.zeros(buf_main.shape, dtype=torch_dtype_for(buf_main.dtype),
+                                             device=f'cuda:{self.gpu_id}')
+                pt = part.torch.reshape(part.shape)
+                if how == 'disjoint':
+                    start, stop = buf_main._slice_for_partition(task.partition)
+                    full[name][start:stop].copy_(pt.reshape(full[name][start:stop].shape))
+                elif how == 'sum':
+                    full[name] += pt.reshape(full[name].shape)
+                else:
+                    raise ValueError(f"unknown dist merge {how!r} for buffer {name!r}")
+
+    def _combine(self, d, full, how):
+        """all ranks: disjoint -> every rank's rows are zero outside its own partitions, so a SUM
+        all-reduce is an exact concatenation (x + 0 == x); sum -> all-reduce."""
+        import torch
+        if full.dtype == torch.bool:
+            t = full.to(torch.uint8)
+            d.all_reduce(t, op=d.ReduceOp.MAX)
+            return t.to(torch.bool)
+        if how == 'disjoint' and full.dim() >= 1 and full.shape[0] >= self.world_size \
+                and d.get_backend() == 'nccl' and self._equal_rows(full.shape[0]):
+            # equal contiguous shards: cheaper all_gather of 1/W of the buffer per rank
+            W, r = self.world_size, self.rank
+            rows = full.shape[0] // W
+            shard = full[r * rows:(r + 1) * rows].contiguous()
+            out = torch.empty_like(full)
+            d.all_gather_into_tensor(out.reshape(-1), shard.reshape(-1))
+            return out
+        d.all_reduce(full, op=d.ReduceOp.SUM)
+        return full
+
+    def _equal_rows(self, n_rows):
+        """True iff every rank owns exactly rows [r*n/W, (r+1)*n/W) of a nav buffer."""
+        W = self.world_size
+        tasks = getattr(self, '_all_tasks', None)
+        if not tasks or n_rows % W != 0:
+            return False
+        if n_rows != sum(t.partition.slice.shape[0] for t in tasks):
+            return False                 # ROI-compressed buffer or skipped partitions
+        rows = n_rows // W
+        P = len(tasks)
+        b = np.linspace(0, P, W + 1, dtype=int)
+        for r in range(W):
+            mine = tasks[b[r]:b[r + 1]]
+            if not mine:
+                return False
+            start = mine[0].partition.slice.origin[0]
+            stop = mine[-1].partition.slice.origin[0] + mine[-1].partition.slice.shape[0]
+            if start != r * rows or stop != (r + 1) * rows:
+                return False
+        return True

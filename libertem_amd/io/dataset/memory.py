@@ -1,0 +1,390 @@
+"""
+MemoryDataSet: frames held in host memory (NumPy) or directly in HBM (torch-ROCm tensor /
+HipArray).  Same constructor surface as the reference's MemoryDataSet
+(io/dataset/memory.py:202-406): `MemoryDataSet(data=..., tileshape=None, num_partitions=None,
+sig_dims=2, ...)`.
+
+Tile delivery:
+* BACKEND_NUMPY: host tiles in the negotiated shape, converted with `astype(dest_dtype)` when
+  the dtype differs (memory.py:102-105), frame groups outermost, sig slices innermost.
+* BACKEND_HIP, device-resident data: zero-copy views of HBM, native dtype (the conversion is fused
+  into the kernels).
+* BACKEND_HIP, host data: full-frame chunks staged through two pinned host buffers and two device
+  buffers; `hipMemcpyAsync` on a copy stream overlaps the upload of chunk i+1 with the kernels of
+  chunk i (events order the two streams; no host synchronisation inside the loop).
+"""
+import numpy as np
+import psutil
+
+from libertem_amd.common.math import prod
+from libertem_amd.common.shape import Shape
+from libertem_amd.common.slice import Slice
+from libertem_amd.common.udf import NUMPY, HIP
+from libertem_amd.common.hiparray import HipArray, torch_dtype_for
+from .base import DataSet, DataSetException, DataSetMeta, Partition, DataTile, TilingScheme
+
+
+def _is_torch_tensor(x):
+    return type(x).__module__.startswith('torch') and hasattr(x, 'is_cuda')
+
+
+class MemoryDataSet(DataSet):
+    def __init__(self, tileshape=None, num_partitions=None, data=None, sig_dims=None,
+                 check_cast=True, tiledelay=None, datashape=None, base_shape=None,
+                 force_need_decode=False, io_backend=None, nav_shape=None, sig_shape=None,
+                 sync_offset=0, array_backends=None, dtype=None):
+        super().__init__()
+        if data is None:
+            raise DataSetException("MemoryDataSet needs data")
+        if io_backend is not None:
+            raise ValueError("MemoryDataSet currently doesn't support alternative I/O backends")
+        self._device_array = None
+        if isinstance(data, HipArray):
+            self._device_array = data
+            self._data = None
+        elif _is_torch_tensor(data):
+            if not data.is_cuda:
+                data = data.numpy()
+                self._data = data
+            else:
+                # `dtype` lets the caller declare unsigned data held in a signed tensor
+                self._device_array = HipArray.from_torch(data.contiguous(), dtype=dtype)
+                self._data = None
+        else:
+            self._data = np.asarray(data)
+        full_shape = tuple(self._device_array.shape if self._device_array is not None
+                           else self._data.shape)
+        if sig_dims is None and sig_shape is None:
+            sig_dims = 2
+        if sig_shape is not None:
+            sig_shape = tuple(sig_shape)
+            sig_dims = len(sig_shape)
+        if nav_shape is not None or sig_shape is not None:
+            sig_s = sig_shape if sig_shape is not None else full_shape[-sig_dims:]
+            n_sig = prod(sig_s)
+            total = prod(full_shape)
+            nav_s = tuple(nav_shape) if nav_shape is not None else (total // n_sig,)
+            if prod(nav_s) * n_sig != total:
+                raise DataSetException("nav_shape/sig_shape do not match the data size")
+            full_shape = tuple(nav_s) + tuple(sig_s)
+        if len(full_shape) <= sig_dims:
+            raise DataSetException("data must have at least one navigation dimension")
+        self._shape = Shape(full_shape, sig_dims=sig_dims)
+        if tileshape is not None:
+            tileshape = tuple(tileshape)
+            if len(tileshape) != sig_dims + 1:
+                raise DataSetException("tileshape must have one nav dim + the sig dims")
+        self.tileshape = tileshape
+        self._base_shape = base_shape
+        self._force_need_decode = force_need_decode
+        if num_partitions is None:
+            if self._device_array is not None:
+                num_partitions = 1
+            else:
+                num_partitions = psutil.cpu_count(logical=False) or 1
+        self.num_partitions = int(num_partitions)
+        self._tiledelay = tiledelay
+        self._check_cast = check_cast
+        self._sync_offset = sync_offset
+        raw_dtype = self._device_array.dtype if self._device_array is not None \
+            else self._data.dtype
+        self._meta = DataSetMeta(shape=self._shape, raw_dtype=raw_dtype,
+                                 image_count=prod(self._shape.nav))
+
+    # --- properties -----------------------------------------------------------------------------
+    @property
+    def data(self):
+        return self._data if self._data is not None else self._device_array
+
+    @property
+    def dtype(self):
+        return self._meta.raw_dtype
+
+    @property
+    def shape(self):
+        return self._shape
+
+    @property
+    def is_device_resident(self):
+        return self._device_array is not None
+
+    @property
+    def array_backends(self):
+        if self._device_array is not None:
+            return (HIP,)
+        return (NUMPY, HIP)
+
+    def initialize(self, executor):
+        return self
+
+    def get_num_partitions(self):
+        return self.num_partitions
+
+    def get_base_shape(self, roi):
+        if self.tileshape is not None:
+            return self.tileshape
+        if self._base_shape is not None:
+            return self._base_shape
+        return super().get_base_shape(roi)
+
+    def get_forced_tileshape(self):
+        return self.tileshape
+
+    def adjust_tileshape(self, tileshape, roi):
+        if self.tileshape is not None:
+            return tuple(self.tileshape)
+        return tileshape
+
+    def need_decode(self, read_dtype, roi):
+        if self._force_need_decode:
+            return True
+        return super().need_decode(read_dtype, roi)
+
+    def flat_host(self):
+        return self._data.reshape((prod(self._shape.nav),) + tuple(self._shape.sig))
+
+    def flat_device(self):
+        return self._device_array.reshape((prod(self._shape.nav),) + tuple(self._shape.sig))
+
+    def get_partitions(self):
+        for idx, (part_slice, start, stop) in enumerate(self.get_slices()):
+            yield MemPartition(dataset=self, meta=self._meta, partition_slice=part_slice, idx=idx,
+                               start_frame=start, num_frames=stop - start)
+
+    def __repr__(self):
+        where = 'HBM' if self.is_device_resident else 'host'
+        return f"<MemoryDataSet of {self.dtype} shape={self.shape} ({where})>"
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        if d.get('_device_array') is not None:
+            raise TypeError("a device-resident MemoryDataSet cannot be pickled")
+        return d
+
+
+class _HipStager:
+    """
+    Double-buffered H2D upload of full-frame chunks (see module docstring).
+
+    If the host array can be page-locked in place (hipHostRegister through torch's runtime
+    binding) chunks are DMA-ed straight out of the user's memory; otherwise they are staged
+    through two pinned bounce buffers.
+    """
+
+    def __init__(self, device, chunk_frames, sig, dtype, host_array=None):
+        import torch
+        self.torch = torch
+        self.device = device
+        self.sig = tuple(sig)
+        self.dtype = np.dtype(dtype)
+        self.tdt = torch_dtype_for(dtype)
+        self.np_storage_dtype = np.dtype(str(self.tdt).replace('torch.', ''))
+        shape = (chunk_frames,) + self.sig
+        self.dev = [torch.empty(shape, dtype=self.tdt, device=f'cuda:{device}') for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.uploaded = [torch.cuda.Event() for _ in range(2)]
+        self.consumed = [None, None]
+        self.host_done = [None, None]
+        self.registered = None
+        self.pinned = None
+        if host_array is not None and host_array.flags.c_contiguous and host_array.nbytes > 0:
+            try:
+                ptr = host_array.ctypes.data
+                rc = torch.cuda.cudart().cudaHostRegister(ptr, host_array.nbytes, 0)
+                if int(rc) == 0:
+                    self.registered = (ptr, host_array.nbytes)
+            except Exception:
+                self.registered = None
+        if self.registered is None:
+            self.pinned = [torch.empty(shape, dtype=self.tdt).pin_memory() for _ in range(2)]
+
+    def _in_registered(self, arr):
+        if self.registered is None or not arr.flags.c_contiguous:
+            return False
+        ptr, nbytes = self.registered
+        return ptr <= arr.ctypes.data and arr.ctypes.data + arr.nbytes <= ptr + nbytes
+
+    def upload(self, slot, host_chunk):
+        """host (numpy, native dtype) -> device, asynchronously on the copy stream."""
+        torch = self.torch
+        n = host_chunk.shape[0]
+        src_np = host_chunk
+        if src_np.dtype != self.np_storage_dtype:
+            src_np = src_np.view(self.np_storage_dtype)        # bit reinterpretation only
+        if self._in_registered(src_np):
+            src = torch.from_numpy(src_np)
+        else:
+            if self.pinned is None:
+                shape = (self.dev[0].shape[0],) + self.sig
+                self.pinned = [torch.empty(shape, dtype=self.tdt).pin_memory() for _ in range(2)]
+            if self.host_done[slot] is not None:
+                self.host_done[slot].synchronize()               # bounce buffer free again?
+            self.pinned[slot][:n].numpy()[...] = src_np
+            src = self.pinned[slot][:n]
+        with torch.cuda.stream(self.copy_stream):
+            if self.consumed[slot] is not None:
+                self.copy_stream.wait_event(self.consumed[slot])  # kernels done with the buffer
+            self.dev[slot][:n].copy_(src, non_blocking=True)
+            self.uploaded[slot].record(self.copy_stream)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+            self.host_done[slot] = ev
+        return n
+
+    def get(self, slot, n):
+        """Make the compute stream wait for the upload; return the device chunk."""
+        self.torch.cuda.current_stream(self.device).wait_event(self.uploaded[slot])
+        return HipArray(self.dev[slot], (n,) + self.sig, self.dtype)
+
+    def release(self, slot):
+        ev = self.torch.cuda.Event()
+        ev.record(self.torch.cuda.current_stream(self.device))
+        self.consumed[slot] = ev
+
+    def close(self):
+        self.torch.cuda.current_stream(self.device).synchronize()
+        self.copy_stream.synchronize()
+        if self.registered is not None:
+            try:
+                self.torch.cuda.cudart().cudaHostUnregister(self.registered[0])
+            except Exception:
+                pass
+            self.registered = None
+
+
+class MemPartition(Partition):
+    def __init__(self, dataset, meta, partition_slice, idx, start_frame, num_frames):
+        super().__init__(meta=meta, partition_slice=partition_slice, idx=idx)
+        self._ds = dataset
+        self._start_frame = start_frame
+        self._num_frames = num_frames
+
+    def _roi_indices(self, roi):
+        if roi is None:
+            return None
+        roi_part = np.asarray(roi).reshape(-1)[self._start_frame:
+                                               self._start_frame + self._num_frames]
+        return np.flatnonzero(roi_part) + self._start_frame
+
+    def get_tiles(self, tiling_scheme, dest_dtype="float32", roi=None, array_backend=NUMPY,
+                  env=None):
+        ds = self._ds
+        if ds.tileshape is not None:
+            # a forced tileshape always wins (reference memory.py:427-445)
+            tiling_scheme = TilingScheme.make_for_shape(
+                tileshape=Shape(ds.tileshape, sig_dims=ds.shape.sig.dims),
+                dataset_shape=ds.shape, intent=tiling_scheme.intent)
+        if array_backend == HIP:
+            yield from self._get_tiles_hip(tiling_scheme, roi, env)
+        elif array_backend == NUMPY:
+            if ds.is_device_resident:
+                raise RuntimeError("a device-resident MemoryDataSet only serves BACKEND_HIP")
+            yield from self._get_tiles_numpy(tiling_scheme, np.dtype(dest_dtype), roi)
+        else:
+            raise ValueError(f"unsupported array backend {array_backend!r}")
+
+    # --- host tiles ---------------------------------------------------------------------------------
+    def _get_tiles_numpy(self, tiling_scheme, dest_dtype, roi):
+        flat = self._ds.flat_host()
+        sig_dims = self._ds.shape.sig.dims
+        idxs = self._roi_indices(roi)
+        depth = int(tiling_scheme.depth)
+        if idxs is None:
+            n = self._num_frames
+            compressed_origin = self._start_frame
+        else:
+            n = len(idxs)
+            compressed_origin = self.slice.adjust_for_roi(roi).origin[0]
+        for g0 in range(0, n, depth):
+            g1 = min(n, g0 + depth)
+            for scheme_idx, sig_slice in tiling_scheme.slices:
+                sig_sl = sig_slice.get(sig_only=True)
+                if idxs is None:
+                    block = flat[(slice(self._start_frame + g0, self._start_frame + g1),) + sig_sl]
+                else:
+                    block = flat[idxs[g0:g1]][(slice(None),) + sig_sl]
+                if block.dtype != dest_dtype or not block.flags.c_contiguous:
+                    block = block.astype(dest_dtype)
+                tile_slice = Slice(
+                    origin=(compressed_origin + g0,) + tuple(sig_slice.origin[-sig_dims:]),
+                    shape=Shape((g1 - g0,) + tuple(sig_slice.shape.sig), sig_dims=sig_dims))
+                yield DataTile(block, tile_slice, scheme_idx)
+
+    # --- device tiles -------------------------------------------------------------------------------
+    def _sub_tiles(self, chunk, origin_frame, tiling_scheme):
+        """Split a full-frame device chunk (n, *sig) into the scheme's sig slices."""
+        sig_dims = self._ds.shape.sig.dims
+        ds_sig = tuple(self._ds.shape.sig)
+        for scheme_idx, sig_slice in tiling_scheme.slices:
+            s_shape = tuple(sig_slice.shape.sig)
+            s_origin = tuple(sig_slice.origin[-sig_dims:])
+            if s_shape == ds_sig:
+                data = chunk
+            elif s_shape[1:] == ds_sig[1:] and all(o == 0 for o in s_origin[1:]):
+                # whole sig rows: a row-strided view, no copy
+                data = chunk.sig_rows(s_origin[0], s_origin[0] + s_shape[0])
+            else:
+                import torch
+                t = torch.as_strided(
+                    chunk.torch.reshape(-1), (chunk.shape[0], prod(ds_sig)), (chunk.ld, 1)
+                ).reshape((chunk.shape[0],) + ds_sig)
+                sl = (slice(None),) + tuple(slice(o, o + s) for o, s in zip(s_origin, s_shape))
+                data = HipArray(t[sl].contiguous(), (chunk.shape[0],) + s_shape, chunk.dtype)
+            tile_slice = Slice(origin=(origin_frame,) + s_origin,
+                               shape=Shape((chunk.shape[0],) + s_shape, sig_dims=sig_dims))
+            yield DataTile(data, tile_slice, scheme_idx)
+
+    def _get_tiles_hip(self, tiling_scheme, roi, env):
+        ds = self._ds
+        device = env.gpu_id if env is not None and env.gpu_id is not None else 0
+        idxs = self._roi_indices(roi)
+        depth = int(tiling_scheme.depth)
+        n = self._num_frames if idxs is None else len(idxs)
+        compressed_origin = self._start_frame if idxs is None \
+            else self.slice.adjust_for_roi(roi).origin[0]
+        if n == 0:
+            return
+        if ds.is_device_resident:
+            flat = ds.flat_device()
+            if flat.device != device:
+                raise RuntimeError(f"dataset lives on GPU {flat.device}, worker drives GPU {device}")
+            if idxs is not None:
+                import torch
+                sel = torch.as_tensor(idxs, device=flat.torch.device)
+                gathered = flat.torch.reshape((flat.shape[0], -1)).index_select(0, sel)
+                flat = HipArray(gathered, (n,) + tuple(ds.shape.sig), flat.dtype)
+                base = 0
+            else:
+                base = self._start_frame
+            for g0 in range(0, n, depth):
+                g1 = min(n, g0 + depth)
+                chunk = flat.rows(base + g0, base + g1)
+                yield from self._sub_tiles(chunk, compressed_origin + g0, tiling_scheme)
+            return
+        # host data: double-buffered upload, chunk i+1 in flight while chunk i is processed
+        host = ds.flat_host()
+        part_host = host[self._start_frame:self._start_frame + self._num_frames]
+        stager = _HipStager(device, min(depth, n), ds.shape.sig, ds.dtype,
+                            host_array=part_host if idxs is None else None)
+
+        def host_chunk(g0, g1):
+            if idxs is None:
+                return part_host[g0:g1]
+            return host[idxs[g0:g1]]
+
+        groups = [(g0, min(n, g0 + depth)) for g0 in range(0, n, depth)]
+        try:
+            stager.upload(0, host_chunk(*groups[0]))
+            for i, (g0, g1) in enumerate(groups):
+                slot = i & 1
+                chunk = stager.get(slot, g1 - g0)
+                if i + 1 < len(groups) and stager.registered is not None:
+                    # DMA straight from user memory: enqueue the next upload before the kernels
+                    stager.upload(slot ^ 1, host_chunk(*groups[i + 1]))
+                yield from self._sub_tiles(chunk, compressed_origin + g0, tiling_scheme)
+                stager.release(slot)
+                if i + 1 < len(groups) and stager.registered is None:
+                    # bounce-buffer mode: the host memcpy overlaps the kernels just enqueued
+                    stager.upload(slot ^ 1, host_chunk(*groups[i + 1]))
+        finally:
+            stager.close()
