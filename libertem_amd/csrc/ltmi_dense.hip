@@ -607,9 +607,11 @@ static int launch_mfma(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t l
     const int64_t gz = m->n_groups / m->ng;
     int ksplit = m->tune_ksplit;
     if (ksplit <= 0) {
+        // split K only when the frame/column tiling alone leaves CUs idle (< 2 workgroups per CU):
+        // measured on C2, 512 workgroups without a split beat 1024 with one (profiles/r01_*)
         ksplit = 1;
         const int64_t wgs = gx * gz;
-        if (wgs < 1024) {
+        if (wgs < 512) {
             ksplit = (int)std::min<int64_t>((1024 + wgs - 1) / wgs, std::max(1, m->n_chunks / 8));
         }
     }

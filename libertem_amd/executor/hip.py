@@ -174,11 +174,14 @@ class HipJobExecutor(JobExecutor):
                         continue
                     full = dev_full[i].get(name)
                     if full is None:
-                        full = torch.zeros(buf.shape, dtype=torch_dtype_for(buf.dtype),
-                                           device=f'cuda:{self.gpu_id}')
+                        with torch.cuda.device(self.gpu_id), torch.cuda.stream(self._stream):
+                            full = torch.zeros(buf.shape, dtype=torch_dtype_for(buf.dtype),
+                                               device=f'cuda:{self.gpu_id}')
                     if d is not None and self.world_size > 1:
-                        full = self._combine(d, full, how)
-                    host = full.cpu().numpy()
+                        # collectives are ordered after the kernels of the executor stream
+                        with torch.cuda.device(self.gpu_id), torch.cuda.stream(self._stream):
+                            full = self._combine(d, full, how)
+                    host = self._to_host(full)
                     if host.dtype != buf.dtype:
                         host = host.view(buf.dtype)
                     buf.replace_array(host)
@@ -220,6 +223,15 @@ class HipJobExecutor(JobExecutor):
                 damage.get_view_for_partition(task.partition)[:] = True
         if self._stream is not None:
             self._stream.synchronize()
+
+    def _to_host(self, t):
+        """ONE D2H per buffer and run, through a pinned bounce buffer, on the executor stream."""
+        import torch
+        with torch.cuda.device(self.gpu_id), torch.cuda.stream(self._stream):
+            host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            host.copy_(t, non_blocking=True)
+            self._stream.synchronize()
+        return host.numpy()
 
     @staticmethod
     def _apply_one(udf, results, task):

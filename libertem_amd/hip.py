@@ -36,6 +36,30 @@ class LtmiError(RuntimeError):
     pass
 
 
+class KernelTimer:
+    """
+    Optional HIP-event timing of every `ltmi_apply_masks` launch, on the stream the kernel is
+    launched on (bench.py's `roofline.achieved`).  Off by default: zero overhead.
+    """
+    enabled = False
+    events = []
+
+    @classmethod
+    def start(cls):
+        cls.enabled = True
+        cls.events = []
+
+    @classmethod
+    def stop(cls):
+        """-> list of (milliseconds, n_frames, kernel name); synchronises."""
+        import torch
+        cls.enabled = False
+        torch.cuda.synchronize()
+        out = [(a.elapsed_time(b), n, k) for a, b, n, k in cls.events]
+        cls.events = []
+        return out
+
+
 def dtype_code(dtype):
     try:
         return _DTYPES[np.dtype(dtype)]
@@ -56,6 +80,11 @@ def lib():
                 f"{LIB_PATH} not found: the HIP library has not been built. "
                 "Run `python -m libertem_amd.build` (needs hipcc). There is no CPU fallback."
             )
+        # torch bundles its own libamdhip64 (soname libamdhip64.so.7, NEEDED by torch under the
+        # unversioned name).  It has to be in the process BEFORE libltmi so that libltmi's
+        # DT_NEEDED libamdhip64.so.7 binds to the same runtime instance; two HIP runtimes in one
+        # process cannot share device pointers (and the second one sees no devices).
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         c = ctypes
         vp, i64, i32 = c.c_void_p, c.c_int64, c.c_int
@@ -177,10 +206,19 @@ class MaskHandle:
 
     def apply(self, tile_ptr, tile_dtype, n_frames, ld_tile, out_ptr, ld_out, accumulate,
               stream=None):
+        if KernelTimer.enabled:
+            import torch
+            st = torch.cuda.current_stream() if stream is None else stream
+            a = torch.cuda.Event(enable_timing=True)
+            b = torch.cuda.Event(enable_timing=True)
+            a.record(st)
         check(lib().ltmi_apply_masks(
             self._ptr, ctypes.c_void_p(tile_ptr), dtype_code(tile_dtype), n_frames, ld_tile,
             ctypes.c_void_p(out_ptr), ld_out, 1 if accumulate else 0, _stream_ptr(stream)),
             'ltmi_apply_masks')
+        if KernelTimer.enabled:
+            b.record(st)
+            KernelTimer.events.append((a, b, n_frames, self.last_kernel()))
 
     def close(self):
         if self._ptr is not None and self._ptr.value:

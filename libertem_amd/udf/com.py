@@ -143,6 +143,9 @@ def guess_corrections(y_centers, x_centers, roi=None) -> GuessResult:
                        cx=np.mean(x_centers[roi]))
 
 
+_COM_CONTAINERS = {}
+
+
 class CoMUDF(UDF):
     """
     Centre-of-mass analysis as a UDF.  Result buffers (all kind 'nav' unless noted):
@@ -207,20 +210,22 @@ class CoMUDF(UDF):
                 base_mask_factory=lambda: masks.ring(
                     imageSizeY=sig_shape[0], imageSizeX=sig_shape[1], centerY=cp.cy,
                     centerX=cp.cx, radius=cp.r, radius_inner=cp.ri))
-        container = MaskContainer(mask_factories=mask_factory, dtype=np.float32, use_sparse=False,
-                                  count=3, backend=self.BACKEND_HIP)
-        self._container = container
+        # the three CoM masks depend only on the geometry: keep their HBM image across tasks / runs
+        key = (sig_shape, float(cp.cy), float(cp.cx), float(cp.r),
+               None if cp.ri is None else float(cp.ri))
+        container = _COM_CONTAINERS.get(key)
+        if container is None:
+            container = MaskContainer(mask_factories=mask_factory, dtype=np.float32,
+                                      use_sparse=False, count=3, backend=self.BACKEND_HIP)
+            _COM_CONTAINERS[key] = container
+            while len(_COM_CONTAINERS) > 4:
+                _COM_CONTAINERS.pop(next(iter(_COM_CONTAINERS))).close()
         return {'com_params': cp,
                 'engine': ApplyMasksEngine(masks=container, meta=self.meta, use_torch=True)}
 
     def process_tile(self, tile):
         self.task_data.engine.process_tile(tile, out=self.results.raw_mask_result,
                                            accumulate=True)
-
-    def cleanup(self):
-        c = getattr(self, '_container', None)
-        if c is not None:
-            c.close()
 
     def get_dist_merge(self):
         return {'raw_mask_result': 'disjoint'}

@@ -10,6 +10,8 @@ into the result view are fused into a HIP kernel (see libertem_amd/csrc/ltmi_den
 
 This operator runs on BACKEND_HIP only.  There is no NumPy path in the product.
 """
+from collections import OrderedDict
+
 import numpy as np
 
 from libertem_amd.common.math import prod
@@ -19,6 +21,38 @@ from libertem_amd.common.buffers import AuxBufferWrapper
 from libertem_amd.common.hiparray import HipArray
 from libertem_amd.common.exceptions import HipRequiredError
 from libertem_amd.udf.base import UDF
+
+
+# Device mask images survive across tasks and across `run_udf` calls: every task re-instantiates the
+# UDF from its kwargs (udf/base.py `new_for_partition`), but the kwargs -- in particular the
+# `mask_factories` object -- are shared.  Factories must be pure (the reference re-evaluates them on
+# every worker, common/container.py:260-314), so "same factories object + same options" means
+# "same stack" and the MaskContainer (host stack + HBM images) can be reused.  The cache pins the
+# factories object so its id() stays unique.
+_CONTAINER_CACHE = OrderedDict()
+_CONTAINER_CACHE_SIZE = 4
+
+
+def _cached_container(mask_factories, dtype, use_sparse, count, default_sparse):
+    key = (id(mask_factories), None if dtype is None else np.dtype(dtype).str, str(use_sparse),
+           count, default_sparse)
+    hit = _CONTAINER_CACHE.get(key)
+    if hit is not None and hit[0] is mask_factories:
+        _CONTAINER_CACHE.move_to_end(key)
+        return hit[1]
+    container = MaskContainer(mask_factories, dtype=dtype, use_sparse=use_sparse, count=count,
+                              backend=UDF.BACKEND_HIP, default_sparse=default_sparse)
+    _CONTAINER_CACHE[key] = (mask_factories, container)
+    while len(_CONTAINER_CACHE) > _CONTAINER_CACHE_SIZE:
+        _, (_, old) = _CONTAINER_CACHE.popitem(last=False)
+        old.close()
+    return container
+
+
+def clear_mask_cache():
+    while _CONTAINER_CACHE:
+        _, (_, old) = _CONTAINER_CACHE.popitem(last=False)
+        old.close()
 
 
 class ApplyMasksEngine:
@@ -125,9 +159,8 @@ class ApplyMasksUDF(UDF):
 
     def _make_mask_container(self):
         p = self.params
-        return MaskContainer(p.mask_factories, dtype=p.mask_dtype, use_sparse=p.use_sparse,
-                             count=p.mask_count, backend=self.BACKEND_HIP,
-                             default_sparse='scipy.sparse')
+        return _cached_container(p.mask_factories, p.mask_dtype, p.use_sparse, p.mask_count,
+                                 'scipy.sparse')
 
     def get_task_data(self):
         return {'engine': ApplyMasksEngine(self.masks, self.meta, self.params.use_torch)}
@@ -152,6 +185,3 @@ class ApplyMasksUDF(UDF):
         # fused: results.intensity[:] += tile.reshape(n, -1).astype(input_dtype) @ masks
         self.task_data.engine.process_tile(tile, out=self.results.intensity, accumulate=True)
 
-    def cleanup(self):
-        if self._mask_container is not None:
-            self._mask_container.close()
