@@ -38,35 +38,55 @@ CONFIGS = {
 }
 
 
-def cpu_baseline(cfg, masks, budget_s=12.0):
-    """The oracle's tiled CPU loop (reference semantics) on a bounded nav sample."""
+def _cpu_worker(job):
+    """One CPU worker = one process with ONE BLAS thread (reference: executor/dask.py:251),
+    running the oracle's tiled loop over its own nav slice, `passes` times."""
+    cfg, n_frames, passes, seed = job
     import torch
-    from oracle import path as opath
-    cores = os.cpu_count() or 1
+    torch.set_num_threads(1)
     try:
-        import psutil
-        cores = psutil.cpu_count(logical=False) or cores
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
     except Exception:
         pass
-    torch.set_num_threads(cores)                      # InlineJobExecutor default: physical cores
-    rng = np.random.default_rng(1)
-    det = cfg['det']
+    from oracle import path as opath
+    rng = np.random.default_rng(seed)
+    data = rng.integers(0, 4096, (1, n_frames) + tuple(cfg['det'])).astype(cfg['dtype'])
+    masks = np.random.default_rng(2).random((cfg['n_masks'],) + tuple(cfg['det'])).astype(
+        np.float32)
+    opath.apply_masks(data[:, :32], masks, num_partitions=1)      # warm up
+    t0 = time.time()
+    for _ in range(passes):
+        opath.apply_masks(data, masks, num_partitions=1)
+    return n_frames * passes, t0, time.time()
 
-    def run(n_frames):
-        data = rng.integers(0, 4096, (1, n_frames) + det).astype(cfg['dtype'])
-        t0 = time.perf_counter()
-        opath.apply_masks(data, masks, num_partitions=max(1, min(cores, n_frames // 32)))
-        return time.perf_counter() - t0
 
-    run(64)                                           # warm BLAS / page in
-    t = run(256)
-    n = int(max(256, min(16384, 256 * budget_s / max(t, 1e-3))))
-    n -= n % 32
-    t = run(n)
-    return {"value": n / t, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} frames of the same workload (oracle.path.apply_masks: reference tile "
-                      f"shape (32,32,256), astype(float32) + torch.mm per tile, {cores} threads), "
-                      f"{t:.1f} s"}
+def cpu_baseline(cfg, budget_s=12.0):
+    """
+    The reference's CPU path restated (oracle.path.apply_masks: (32,32,256) tiles,
+    astype(float32) + torch.mm per tile, += per sig slice), one single-threaded worker process per
+    physical core, on a bounded sample.  MUST run before the parent touches the GPU (fork).
+    """
+    import multiprocessing as mp
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+    except Exception:
+        cores = os.cpu_count() or 1
+    n_frames = 512                                    # 64 MiB of uint16 per worker
+    ctx = mp.get_context('fork')
+    with ctx.Pool(cores) as pool:
+        # calibrate with one pass, then size the run to ~budget_s
+        res = pool.map(_cpu_worker, [(cfg, n_frames, 1, 100 + i) for i in range(cores)])
+        t1 = max(r[2] for r in res) - min(r[1] for r in res)
+        passes = int(max(1, min(200, budget_s / max(t1, 1e-3))))
+        res = pool.map(_cpu_worker, [(cfg, n_frames, passes, 100 + i) for i in range(cores)])
+    total = sum(r[0] for r in res)
+    wall = max(r[2] for r in res) - min(r[1] for r in res)
+    return {"value": total / wall, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} single-threaded worker processes x {n_frames} frames x {passes} "
+                      f"passes of the same workload (oracle.path.apply_masks: reference tile shape "
+                      f"(32,32,256), astype(float32) + torch.mm per tile), {wall:.1f} s wall"}
 
 
 def main():
@@ -79,11 +99,19 @@ def main():
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
-    import torch
-    import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    cpu_base = None
+    if world == 1 and not args.no_cpu_baseline:
+        # rank 0 at N=1 only, and BEFORE the HIP runtime is initialised (fork-safe)
+        try:
+            cpu_base = cpu_baseline(cfg)
+        except Exception as e:                        # the baseline must never sink the bench line
+            cpu_base = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port",
+                        "sample": f"failed: {e!r}"}
+    import torch
+    import torch.distributed as dist
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
@@ -185,12 +213,8 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes_per_frame * frames_per_launch,
             },
         }
-        if not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(cfg, masks)
-            except Exception as e:  # the baseline must never sink the bench line
-                out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0,
-                                       "kind": "port", "sample": f"failed: {e!r}"}
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

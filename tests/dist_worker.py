@@ -1,0 +1,89 @@
+"""
+Worker for tests/test_distributed_cpu.py: one rank of a world_size-N gloo job that drives the
+HipJobExecutor's sharding + cross-rank merge with NumPy UDFs (no GPU).
+"""
+import os
+import sys
+import json
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch.distributed as dist
+    from libertem_amd.api import Context
+    from libertem_amd.executor.hip import HipJobExecutor
+    from libertem_amd.udf.base import UDF
+
+    class MasksDeclared(UDF):          # nav-kind, declares 'disjoint'
+        def __init__(self, masks):
+            super().__init__(masks=masks)
+
+        def get_result_buffers(self):
+            return {'intensity': self.buffer(kind='nav', extra_shape=(len(self.params.masks),),
+                                             dtype=np.float32)}
+
+        def process_tile(self, tile):
+            m = self.meta.sig_slice.get(self.params.masks, sig_only=True)
+            m = m.reshape((len(self.params.masks), -1)).T
+            self.results.intensity[:] += tile.reshape((tile.shape[0], -1)) @ m
+
+        def get_dist_merge(self):
+            return {'intensity': 'disjoint'}
+
+    class SumDeclared(UDF):            # sig-kind, declares 'sum'
+        def get_result_buffers(self):
+            return {'intensity': self.buffer(kind='sig', dtype=np.float32)}
+
+        def process_tile(self, tile):
+            self.results.intensity[:] += np.sum(tile, axis=0)
+
+        def merge(self, dest, src):
+            dest.intensity[:] += src.intensity
+
+        def get_dist_merge(self):
+            return {'intensity': 'sum'}
+
+    class MaxGeneric(UDF):             # custom merge, no declaration -> generic object gather
+        def get_result_buffers(self):
+            return {'mx': self.buffer(kind='sig', dtype=np.float32),
+                    'per_frame': self.buffer(kind='nav', dtype=np.float32)}
+
+        def process_tile(self, tile):
+            self.results.mx[:] = np.maximum(self.results.mx, tile.max(axis=0))
+            self.results.per_frame[:] = np.maximum(
+                self.results.per_frame, tile.reshape((tile.shape[0], -1)).max(axis=1))
+
+        def merge(self, dest, src):
+            dest.mx[:] = np.maximum(dest.mx, src.mx)
+            dest.per_frame[:] = src.per_frame
+
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    out_dir = sys.argv[1]
+    rng = np.random.default_rng(5)
+    data = rng.integers(0, 100, (6, 7, 16, 16)).astype(np.uint16)     # same on every rank
+    masks = rng.random((3, 16, 16)).astype(np.float32)
+    ex = HipJobExecutor(require_gpu=False)
+    assert ex.world_size == world and ex.rank == rank
+    ctx = Context(executor=ex)
+    ds = ctx.load('memory', data=data, num_partitions=5, sig_dims=2)
+    roi = np.zeros((6, 7), dtype=bool)
+    roi[1:5, 2:6] = True
+    r1, r2, r3 = ctx.run_udf(dataset=ds, udf=[MasksDeclared(masks), SumDeclared(), MaxGeneric()])
+    my_parts = np.array([t.idx for t in ex.my_tasks(ex._all_tasks)])
+    r1_roi = ctx.run_udf(dataset=ds, udf=MasksDeclared(masks), roi=roi)
+    np.savez(os.path.join(out_dir, f'rank{rank}.npz'),
+             masks=r1['intensity'].data, sum=r2['intensity'].data, mx=r3['mx'].data,
+             per_frame=r3['per_frame'].data, masks_roi=r1_roi['intensity'].data,
+             my_parts=my_parts)
+    dist.barrier()
+    dist.destroy_process_group()
+    print(json.dumps({'rank': rank, 'ok': True}))
+
+
+if __name__ == '__main__':
+    main()

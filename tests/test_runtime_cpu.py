@@ -1,0 +1,338 @@
+"""
+CPU-side tests of the host runtime: Shape/Slice algebra, buffers, partitioning + tiling
+negotiation (against the reference's golden tile shapes), the UDF runner with NumPy UDFs against the
+oracle and the golden vectors (config C1 plumbing), error behaviour, and the C-ABI surface.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import recipes
+from oracle import path as opath
+from libertem_amd.api import Context
+from libertem_amd.common import Shape, Slice
+from libertem_amd.common.buffers import BufferWrapper
+from libertem_amd.common.exceptions import HipRequiredError, UDFException, ExecutorSpecException
+from libertem_amd.io.dataset import MemoryDataSet
+from libertem_amd.io.dataset.base import Negotiator, Partition
+from libertem_amd.udf.base import UDF, UDFRunner, _get_dtype
+from libertem_amd.udf.masks import ApplyMasksUDF
+from libertem_amd.udf.sum import SumUDF
+from libertem_amd.udf.sumsigudf import SumSigUDF
+from libertem_amd.udf.com import CoMUDF
+from libertem_amd.executor.inline import InlineJobExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# --- NumPy UDFs used to exercise the plumbing (what a user would write) -----------------------
+class NumpySumUDF(UDF):
+    def __init__(self, dtype='float32'):
+        super().__init__(dtype=dtype)
+
+    def get_preferred_input_dtype(self):
+        return self.params.dtype
+
+    def get_result_buffers(self):
+        return {'intensity': self.buffer(kind='sig', dtype=self.meta.input_dtype)}
+
+    def process_tile(self, tile):
+        self.results.intensity[:] += np.sum(tile, axis=0)
+
+    def merge(self, dest, src):
+        dest.intensity[:] += src.intensity
+
+
+class NumpySumSigUDF(UDF):
+    def get_result_buffers(self):
+        return {'intensity': self.buffer(
+            kind='nav', dtype=np.result_type(self.meta.input_dtype, np.float32))}
+
+    def process_tile(self, tile):
+        self.results.intensity[:] += np.sum(tile.reshape((tile.shape[0], -1)), axis=1)
+
+
+class NumpyMasksUDF(UDF):
+    def __init__(self, masks):
+        super().__init__(masks=masks)
+
+    def get_result_buffers(self):
+        dt = np.result_type(self.meta.input_dtype, self.params.masks.dtype)
+        return {'intensity': self.buffer(kind='nav', extra_shape=(len(self.params.masks),),
+                                         dtype=dt)}
+
+    def process_tile(self, tile):
+        m = self.meta.sig_slice.get(self.params.masks, sig_only=True)
+        m = m.reshape((len(self.params.masks), -1)).T
+        self.results.intensity[:] += tile.reshape((tile.shape[0], -1)) @ m
+
+
+class FrameUDF(UDF):
+    def get_result_buffers(self):
+        return {'mx': self.buffer(kind='nav', dtype=np.float32)}
+
+    def process_frame(self, frame):
+        self.results.mx[:] = frame.max()
+
+
+@pytest.fixture
+def ctx():
+    return Context(executor=InlineJobExecutor(debug=True, inline_threads=2))
+
+
+# --- Shape / Slice -------------------------------------------------------------------------------
+def test_shape():
+    s = Shape((4, 5, 6, 7), sig_dims=2)
+    assert tuple(s.nav) == (4, 5) and tuple(s.sig) == (6, 7)
+    assert s.size == 840 and s.nav.size == 20
+    assert tuple(s.flatten_nav()) == (20, 6, 7)
+    assert tuple(s.flatten_sig()) == (4, 5, 42)
+    assert s == Shape((4, 5, 6, 7), sig_dims=2) and s != Shape((4, 5, 6, 7), sig_dims=1)
+    assert s.nav.dims == 2 and s.sig.dims == 2 and s.dims == 4
+    assert s + (1,) == (4, 5, 6, 7, 1)
+
+
+def test_slice_algebra():
+    a = Slice(origin=(0, 0, 0), shape=Shape((4, 8, 8), sig_dims=2))
+    b = Slice(origin=(2, 4, 4), shape=Shape((4, 8, 8), sig_dims=2))
+    i = a.intersection_with(b)
+    assert i.origin == (2, 4, 4) and tuple(i.shape) == (2, 4, 4)
+    c = Slice(origin=(10, 0, 0), shape=Shape((1, 8, 8), sig_dims=2))
+    assert a.intersection_with(c).is_null()
+    assert b.shift(a).origin == (2, 4, 4)
+    assert a.shift_by((1, 2)).origin == (0, 1, 2)
+    arr = np.arange(6 * 8 * 8).reshape((6, 8, 8))
+    assert np.array_equal(b.intersection_with(a).get(arr), arr[2:4, 4:8, 4:8])
+    assert np.array_equal(i.get(arr, sig_only=True), arr[:, 4:8, 4:8])
+    subs = list(Slice(origin=(0, 0), shape=Shape((5, 7), sig_dims=2)).subslices((2, 4)))
+    assert [(s.origin, tuple(s.shape)) for s in subs] == [
+        ((0, 0), (2, 4)), ((0, 4), (2, 3)), ((2, 0), (2, 4)), ((2, 4), (2, 3)),
+        ((4, 0), (1, 4)), ((4, 4), (1, 3))]
+    roi = np.zeros(12, dtype=bool)
+    roi[[1, 5, 6, 11]] = True
+    p = Slice(origin=(4, 0, 0), shape=Shape((4, 2, 2), sig_dims=2))
+    adj = p.adjust_for_roi(roi)
+    assert adj.origin[0] == 1 and adj.shape[0] == 2
+    n = Slice(origin=(1, 0, 0, 0), shape=Shape((2, 3, 2, 2), sig_dims=2))
+    assert n.flatten_nav((4, 3, 2, 2)).origin == (3, 0, 0)
+
+
+# --- partitioning + tiling negotiation vs the reference ------------------------------------------
+@pytest.mark.parametrize('case', recipes.TILING_CASES, ids=lambda c: c['name'])
+def test_negotiator_matches_reference(golden_dir, case):
+    g = np.load(os.path.join(golden_dir, 'tiling.npz'))
+    data = np.zeros(tuple(case['shape']), dtype=case['dtype'])
+    ds = MemoryDataSet(data=data, num_partitions=case['num_partitions'], sig_dims=2,
+                       tileshape=case.get('tileshape'))
+    parts = list(ds.get_partitions())
+    ref_parts = g[case['name'] + '__partitions']
+    assert [(p.slice.origin[0], p.slice.shape[0]) for p in parts] == \
+        [(int(a), int(b)) for a, b in ref_parts]
+    udf = NumpySumUDF() if case['udf'] == 'sum' else NumpyMasksUDF(np.zeros((2, 4, 4), np.float32))
+    dtype = _get_dtype([udf], ds.dtype)
+    scheme = Negotiator().get_scheme(udfs=[udf], dataset=ds, read_dtype=dtype,
+                                     approx_partition_shape=parts[0].shape)
+    assert tuple(scheme.shape) == tuple(int(x) for x in g[case['name'] + '__tileshape'])
+    assert len(scheme) == int(g[case['name'] + '__n_sig_slices'])
+    mine = [list(s.origin) + list(s.shape) for _, s in scheme.slices]
+    assert mine == [list(map(int, r)) for r in g[case['name'] + '__sig_slices']]
+
+
+def test_partition_clamp_warning():
+    with pytest.warns(RuntimeWarning):
+        parts = list(Partition.make_slices(Shape((1, 3, 4, 4), sig_dims=2), 8))
+    assert len(parts) == 3
+
+
+# --- plumbing: config C1 and friends through the runtime, vs golden + oracle -----------------------
+@pytest.mark.parametrize('case', recipes.SUM_CASES, ids=lambda c: c['name'])
+def test_sum_plumbing(ctx, golden_dir, case):
+    g = np.load(os.path.join(golden_dir, 'sums.npz'))
+    data = recipes.make_sum_case(case)
+    ds = ctx.load('memory', data=data, num_partitions=case['num_partitions'], sig_dims=2,
+                  tileshape=case.get('tileshape'))
+    s = ctx.run_udf(dataset=ds, udf=NumpySumUDF())['intensity']
+    ss = ctx.run_udf(dataset=ds, udf=NumpySumSigUDF())['intensity']
+    assert s.data.dtype == g[case['name'] + '__sum'].dtype
+    assert np.allclose(s.data, g[case['name'] + '__sum'], rtol=1e-6)
+    assert np.allclose(ss.data, g[case['name'] + '__sumsig'], rtol=1e-6)
+    # identical tiles, identical order -> identical bits as the oracle's loop
+    assert np.array_equal(s.data, opath.sum_udf(data, num_partitions=case['num_partitions'],
+                                                tileshape=case.get('tileshape')))
+
+
+def test_c1_config(ctx):
+    """BASELINE.json configs[0]: SumUDF-like on 32x32 x 128x128 float32, inline CPU executor."""
+    data = np.random.default_rng(0).random((32, 32, 128, 128), dtype=np.float32)
+    ds = ctx.load('memory', data=data, num_partitions=4, sig_dims=2)
+    res = ctx.run_udf(dataset=ds, udf=NumpySumUDF())
+    assert np.array_equal(res['intensity'].data, opath.sum_udf(data, num_partitions=4))
+    assert np.allclose(res['intensity'].data, data.sum(axis=(0, 1)), rtol=1e-5)
+
+
+@pytest.mark.parametrize('name', ['c2_u16_16masks', 'odd_tiles_f32', 'f32_5masks', 'i32_f64',
+                                  'u16_c64masks', 'single_frame'])
+def test_masks_plumbing(ctx, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, 'apply_masks_dense.npz'))
+    case = next(c for c in recipes.DENSE_CASES if c['name'] == name)
+    data, masks = recipes.make_dense_case(case)
+    ds = ctx.load('memory', data=data, num_partitions=case['num_partitions'], sig_dims=2,
+                  tileshape=case.get('tileshape'))
+    res = ctx.run_udf(dataset=ds, udf=NumpyMasksUDF(masks))['intensity'].data
+    ref = g[name]
+    assert res.shape == ref.shape and res.dtype == ref.dtype
+    assert np.allclose(res, ref, rtol=2e-6, atol=2e-6 * np.abs(ref).max())
+
+
+def test_roi_iter_multi_udf_frame(ctx):
+    data = np.random.default_rng(1).integers(0, 100, (3, 8, 16, 16)).astype(np.uint16)
+    masks = np.random.default_rng(2).random((4, 16, 16)).astype(np.float32)
+    ds = ctx.load('memory', data=data, num_partitions=3, sig_dims=2)
+    roi = np.zeros((3, 8), dtype=bool)
+    roi[0, 2:5] = True
+    roi[2, 7] = True
+    res, res2 = ctx.run_udf(dataset=ds, udf=[NumpyMasksUDF(masks), FrameUDF()], roi=roi)
+    ref = opath.apply_masks(data, masks, use_torch=False)
+    d = res['intensity'].data
+    assert d.shape == (3, 8, 4) and np.isnan(d[1, 0, 0])
+    assert np.allclose(d[roi], ref[roi], rtol=1e-6)
+    assert res['intensity'].raw_data.shape == (4, 4)
+    assert np.allclose(res2['mx'].data[roi], data.max(axis=(2, 3))[roi])
+    # coordinate-tuple roi (reference api.py:1280-1288)
+    r3 = ctx.run_udf(dataset=ds, udf=NumpySumSigUDF(), roi=(1, 3))
+    assert np.count_nonzero(~np.isnan(r3['intensity'].data)) == 1
+    # partial results + damage
+    seen = [int(p.damage.data.sum()) for p in ctx.run_udf_iter(dataset=ds, udf=NumpySumSigUDF())]
+    assert seen == [8, 16, 24]
+    # empty roi
+    r4 = ctx.run_udf(dataset=ds, udf=NumpySumSigUDF(), roi=np.zeros((3, 8), dtype=bool))
+    assert np.all(np.isnan(r4['intensity'].data))
+    with pytest.raises(ValueError):
+        ctx.run_udf(dataset=ds, udf=NumpySumSigUDF(), roi=np.zeros((2, 2), dtype=bool))
+
+
+def test_buffer_wrapper_views():
+    data = np.zeros((2, 6, 4, 4), dtype=np.float32)
+    ds = MemoryDataSet(data=data, num_partitions=2, sig_dims=2)
+    parts = list(ds.get_partitions())
+    b = BufferWrapper(kind='nav', extra_shape=(3,), dtype=np.float32)
+    b.set_shape_ds(ds.shape)
+    b.allocate()
+    assert b.raw_data.shape == (12, 3) and b.data.shape == (2, 6, 3)
+    v = b.get_view_for_partition(parts[1])
+    v[:] = 1
+    assert b.raw_data[:6].sum() == 0 and b.raw_data[6:].sum() == 18
+    s = BufferWrapper(kind='sig', dtype=np.float64)
+    s.set_shape_partition(parts[0])
+    s.allocate()
+    assert s.raw_data.shape == (4, 4)
+    one = BufferWrapper(kind='single', extra_shape=(3, 2), dtype=np.float64)
+    one.set_shape_ds(ds.shape)
+    one.allocate()
+    assert one.raw_data.shape == (3, 2)
+    with pytest.raises(ValueError):
+        BufferWrapper(kind='bogus')
+
+
+def test_udf_interface_errors(ctx):
+    data = np.zeros((2, 2, 4, 4), dtype=np.float32)
+    ds = ctx.load('memory', data=data, num_partitions=1, sig_dims=2)
+
+    class NoProcess(UDF):
+        def get_result_buffers(self):
+            return {}
+
+    with pytest.raises(TypeError):
+        ctx.run_udf(dataset=ds, udf=NoProcess())
+
+    class SigNoMerge(UDF):
+        def get_result_buffers(self):
+            return {'x': self.buffer(kind='sig', dtype=np.float32)}
+
+        def process_tile(self, tile):
+            pass
+
+    with pytest.raises(NotImplementedError):
+        ctx.run_udf(dataset=ds, udf=SigNoMerge())
+
+    class BadResult(UDF):
+        def get_result_buffers(self):
+            return {'x': self.buffer(kind='nav', dtype=np.float32)}
+
+        def process_tile(self, tile):
+            pass
+
+        def get_results(self):
+            return {'x': self.results.x, 'undeclared': np.zeros(4, dtype=np.float32)}
+
+    with pytest.raises(UDFException):
+        ctx.run_udf(dataset=ds, udf=BadResult())['x'].data
+    with pytest.raises(ExecutorSpecException):
+        Context.make_with('dask')
+
+
+# --- the native operators must refuse to run without the HIP backend -------------------------------
+@pytest.mark.parametrize('make_udf', [
+    lambda: ApplyMasksUDF(mask_factories=[lambda: np.ones((4, 4))]),
+    lambda: SumUDF(), lambda: SumSigUDF(), lambda: CoMUDF.with_params(),
+], ids=['masks', 'sum', 'sumsig', 'com'])
+def test_native_udfs_fail_loudly_on_cpu(ctx, make_udf):
+    data = np.zeros((2, 2, 4, 4), dtype=np.float32)
+    ds = ctx.load('memory', data=data, num_partitions=1, sig_dims=2)
+    with pytest.raises(HipRequiredError):
+        ctx.run_udf(dataset=ds, udf=make_udf())
+
+
+def test_apply_masks_udf_argument_errors():
+    with pytest.raises(ValueError):
+        ApplyMasksUDF(mask_factories=[lambda: np.ones((4, 4))], backends=('numpy',))
+    with pytest.raises(NotImplementedError):
+        ApplyMasksUDF(mask_factories=[lambda: np.ones((4, 4))], shifts=(1, 2))
+    with pytest.raises(ValueError):
+        CoMUDF.with_params(r=3., ri=5.)
+
+
+def test_hip_executor_requires_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("box has a GPU")
+    from libertem_amd.executor.hip import HipJobExecutor
+    with pytest.raises(RuntimeError):
+        HipJobExecutor()
+
+
+# --- the C ABI: the library loads and exports every symbol include/ltmi.h declares -----------------
+def test_c_abi_exports():
+    from libertem_amd import hip
+    hdr = open(os.path.join(ROOT, 'include', 'ltmi.h')).read()
+    declared = set(re.findall(r'\b(ltmi_[a-z_0-9]+)\s*\(', hdr))
+    declared.discard('ltmi_masks')
+    assert len(declared) >= 15
+    L = hip.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/ltmi.h but not exported"
+    assert set(hip.EXPORTS) == declared
+    assert L.ltmi_version() == 1
+    n = ctypes.c_int(-1)
+    assert L.ltmi_device_count(ctypes.byref(n)) == 0 and n.value >= 0
+    # argument errors are reported, not crashed on
+    assert L.ltmi_device_count(None) == -1
+    assert b'null' in L.ltmi_last_error()
+
+
+def test_product_does_not_import_oracle():
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import libertem_amd.api, libertem_amd.udf.masks, "
+            "libertem_amd.udf.com, libertem_amd.analysis, libertem_amd.executor.hip; "
+            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), "
+            "'product imports the oracle'") % ROOT
+    subprocess.run([sys.executable, '-c', code], check=True)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'libertem_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), f

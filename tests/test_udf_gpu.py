@@ -1,0 +1,297 @@
+"""
+GPU parity of the product path: Context('hip').run_udf / run(analysis) with the native UDFs,
+against (a) the golden vectors produced by the real reference and (b) the oracle on the same seeded
+inputs.  Everything goes through the C ABI (libltmi.so); `-m gpu` only.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import recipes
+from oracle import path as opath, masks as omasks
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-5      # north_star: within 1e-5 rel for float results
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from libertem_amd.api import Context
+    assert torch.cuda.is_available()
+    c = Context.make_with('hip', gpus=0)
+    yield c
+    c.close()
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + '.npz'))
+
+
+def _device_ds(ctx, data, num_partitions, **kw):
+    from libertem_amd.common.hiparray import HipArray
+    arr = HipArray.from_numpy(data, 0)
+    return ctx.load('memory', data=arr, num_partitions=num_partitions, sig_dims=2, **kw)
+
+
+def _close(a, b, tol):
+    scale = max(np.abs(b).max(), 1e-30)
+    return np.allclose(a, b, rtol=tol, atol=tol * scale)
+
+
+@pytest.mark.parametrize('resident', ['host', 'device'])
+@pytest.mark.parametrize('case', recipes.DENSE_CASES, ids=lambda c: c['name'])
+def test_apply_masks_udf_vs_reference_golden(ctx, golden_dir, case, resident):
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    g = _load(golden_dir, 'apply_masks_dense')
+    data, masks = recipes.make_dense_case(case)
+    kw = dict(case.get('udf_kwargs', {}))
+    udf = ApplyMasksUDF(mask_factories=lambda: masks, **kw)
+    if resident == 'device':
+        ds = _device_ds(ctx, data, case['num_partitions'], tileshape=case.get('tileshape'))
+    else:
+        ds = ctx.load('memory', data=data, num_partitions=case['num_partitions'], sig_dims=2,
+                      tileshape=case.get('tileshape'))
+    res = ctx.run_udf(dataset=ds, udf=udf)['intensity']
+    ref = g[case['name']]
+    got = res.data
+    assert got.shape == ref.shape
+    assert got.dtype == ref.dtype
+    if ref.dtype.kind in 'iu':
+        assert np.array_equal(got, ref)                 # integer path: bit exact
+    else:
+        tol = F32_TOL if ref.dtype in (np.float32, np.complex64) else 1e-12
+        assert _close(got, ref, tol)
+    assert res.raw_data.shape == (int(np.prod(case['nav'])), masks.shape[0])
+
+
+def test_apply_masks_integer_sum_masks_bit_exact(ctx):
+    """0/1 masks on detector counts: every partial sum < 2**24 -> float32 result is exact and
+    must equal the reference path bit for bit (north_star: 'bit-exact for integer sum masks')."""
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    rng = np.random.default_rng(77)
+    data = rng.integers(0, 200, (5, 13, 128, 128)).astype(np.uint16)
+    masks = (rng.random((7, 128, 128)) > 0.4)
+    ref = opath.apply_masks(data, masks.astype(np.float32), num_partitions=3)
+    assert ref.max() < 2**24
+    ds = ctx.load('memory', data=data, num_partitions=3, sig_dims=2)
+    got = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(
+        mask_factories=[(lambda i=i: masks[i].astype(np.float32)) for i in range(7)]))
+    assert np.array_equal(got['intensity'].data, ref)
+    # the genuinely integer path: preferred_dtype / mask_dtype int32 (udf/masks.py:311-322)
+    got_i = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(
+        mask_factories=lambda: masks, preferred_dtype=np.int32, mask_dtype=np.int32))
+    assert got_i['intensity'].data.dtype == np.int32
+    assert np.array_equal(got_i['intensity'].data, ref.astype(np.int32))
+
+
+def test_apply_masks_mask_factory_variants(ctx):
+    """list of factories vs one stack factory vs scipy.sparse masks
+    (tests/analysis/test_analysis_masks.py:215-474 style)."""
+    import scipy.sparse as sp
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    rng = np.random.default_rng(3)
+    data = rng.integers(0, 100, (4, 6, 24, 40)).astype(np.uint16)
+    m0 = rng.random((24, 40)).astype(np.float32)
+    m1 = np.where(rng.random((24, 40)) < 0.1, rng.random((24, 40)), 0).astype(np.float32)
+    ref = opath.apply_masks(data, np.stack([m0, m1]), num_partitions=2)
+    ds = ctx.load('memory', data=data, num_partitions=2, sig_dims=2)
+    a = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=[lambda: m0, lambda: m1]))
+    b = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda: np.stack([m0, m1])))
+    c = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(
+        mask_factories=[lambda: m0, lambda: sp.csr_matrix(m1)]))        # mixed -> dense
+    for r in (a, b, c):
+        assert _close(r['intensity'].data, ref, F32_TOL)
+    assert a['intensity'].data.shape == (4, 6, 2)
+
+
+@pytest.mark.parametrize('case', recipes.SUM_CASES, ids=lambda c: c['name'])
+def test_sum_udfs_vs_reference_golden(ctx, golden_dir, case):
+    from libertem_amd.udf.sum import SumUDF
+    from libertem_amd.udf.sumsigudf import SumSigUDF
+    g = _load(golden_dir, 'sums')
+    data = recipes.make_sum_case(case)
+    for resident in ('host', 'device'):
+        if resident == 'device':
+            ds = _device_ds(ctx, data, case['num_partitions'], tileshape=case.get('tileshape'))
+        else:
+            ds = ctx.load('memory', data=data, num_partitions=case['num_partitions'], sig_dims=2,
+                          tileshape=case.get('tileshape'))
+        s = ctx.run_udf(dataset=ds, udf=SumUDF())['intensity'].data
+        ss = ctx.run_udf(dataset=ds, udf=SumSigUDF())['intensity'].data
+        rs, rss = g[case['name'] + '__sum'], g[case['name'] + '__sumsig']
+        assert s.dtype == rs.dtype and s.shape == rs.shape
+        assert ss.dtype == rss.dtype and ss.shape == rss.shape
+        assert np.allclose(s, rs, rtol=1e-6) and np.allclose(ss, rss, rtol=1e-6)
+        if np.dtype(case['dtype']).kind in 'iu':
+            assert np.array_equal(s, rs) and np.array_equal(ss, rss)    # exact below 2**24
+
+
+@pytest.mark.parametrize('case', recipes.COM_CASES, ids=lambda c: c['name'])
+def test_com_vs_reference_golden(ctx, golden_dir, case):
+    from libertem_amd.udf.com import CoMUDF
+    g = _load(golden_dir, 'com')
+    data = recipes.make_com_case(case)
+    ds = ctx.load('memory', data=data, num_partitions=case['num_partitions'], sig_dims=2)
+    res = ctx.run_udf(dataset=ds, udf=CoMUDF.with_params(**case['params']))
+    assert 'raw_mask_result' not in res                   # use='private'
+    for k, v in res.items():
+        ref = g[f"{case['name']}__udf__{k}"]
+        assert v.data.shape == ref.shape, k
+        assert v.data.dtype == ref.dtype, k
+        assert np.allclose(v.data, ref, rtol=1e-4, atol=1e-4), k
+    # the analysis flavour (x first in `field`, float defaults cx = W/2)
+    p = case['analysis_params']
+    analysis = ctx.create_com_analysis(
+        dataset=ds, cx=p.get('cx'), cy=p.get('cy'), mask_radius=p.get('r'),
+        mask_radius_inner=p.get('ri'), flip_y=p.get('flip_y', False),
+        scan_rotation=p.get('scan_rotation', 0.))
+    ares = ctx.run(analysis)
+    for k in ('x', 'y', 'magnitude', 'divergence', 'curl'):
+        assert np.allclose(ares[k].raw_data, g[f"{case['name']}__analysis__{k}"],
+                           rtol=1e-4, atol=1e-4), k
+    assert np.allclose(ares.field.raw_data[0], g[f"{case['name']}__analysis__x"],
+                       rtol=1e-4, atol=1e-4)
+
+
+def test_com_vs_scipy_center_of_mass(ctx):
+    """reference tests/analysis/test_analysis_com.py:55-89"""
+    import scipy.ndimage
+    from libertem_amd.udf.com import CoMUDF
+    data = recipes.make_com_case(recipes.COM_CASES[0]).astype(np.float32)
+    ds = ctx.load('memory', data=data, num_partitions=2, sig_dims=2)
+    res = ctx.run_udf(dataset=ds, udf=CoMUDF.with_params())
+    for i in range(data.shape[0]):
+        for j in range(data.shape[1]):
+            cy, cx = scipy.ndimage.center_of_mass(data[i, j].astype(np.float64))
+            assert np.allclose(res['raw_com'].data[i, j], (cy, cx), rtol=1e-4)
+
+
+@pytest.mark.parametrize('case', [c for c in recipes.RF_CASES
+                                  if not c['name'].startswith('heuristic')],
+                         ids=lambda c: c['name'])
+def test_radial_fourier_vs_reference_golden(ctx, golden_dir, case):
+    g = _load(golden_dir, 'radial_fourier')
+    data = recipes.make_rf_case(case)
+    ds = ctx.load('memory', data=data, num_partitions=case['num_partitions'], sig_dims=2)
+    analysis = ctx.create_radial_fourier_analysis(dataset=ds, **case['params'])
+    res = ctx.run(analysis)
+    ref = g[f"{case['name']}__raw_results"]
+    assert res.raw_results.shape == ref.shape and res.raw_results.dtype == ref.dtype
+    assert _close(res.raw_results, ref, F32_TOL)
+    assert res.complex_0_1.raw_data.shape == tuple(case['nav'])
+    assert np.array_equal(res.dominant_0.raw_data.shape, case['nav'])
+
+
+def test_single_mask_and_sum_analyses(ctx, golden_dir):
+    g = _load(golden_dir, 'single_mask_analyses')
+    data = recipes.make_com_case(recipes.COM_CASES[0])
+    ds = ctx.load('memory', data=data, num_partitions=2, sig_dims=2)
+    a = ctx.run(ctx.create_disk_analysis(dataset=ds))
+    assert _close(a.intensity.raw_data, g['disk_default'][..., 0], F32_TOL)
+    a = ctx.run(ctx.create_disk_analysis(dataset=ds, cx=10, cy=20, r=5))
+    assert _close(a.intensity.raw_data, g['disk_params'][..., 0], F32_TOL)
+    a = ctx.run(ctx.create_ring_analysis(dataset=ds))
+    assert _close(a.intensity.raw_data, g['ring_default'][..., 0], F32_TOL)
+    a = ctx.run(ctx.create_ring_analysis(dataset=ds, cx=10, cy=20, ri=3, ro=8))
+    assert _close(a.intensity.raw_data, g['ring_params'][..., 0], F32_TOL)
+    for name, factories, kw in recipes_single_masks():
+        a = ctx.run(ctx.create_mask_analysis(factories=factories, dataset=ds, **kw))
+        ref = g[name]
+        assert a.mask_0.raw_data.dtype == ref.dtype
+        assert _close(a.mask_1.raw_data, ref[..., 1], F32_TOL if ref.dtype == np.float32 else 1e-12)
+    s = ctx.run(ctx.create_sum_analysis(dataset=ds))
+    assert np.array_equal(s.intensity.raw_data, data.astype(np.float32).sum(axis=(0, 1)))
+    # point analysis = one-entry sparse mask -> picks a pixel
+    a = ctx.run(ctx.create_point_analysis(dataset=ds, x=7, y=9))
+    assert np.array_equal(a.intensity.raw_data, data[..., 9, 7].astype(np.float32))
+
+
+def recipes_single_masks():
+    out = []
+    for name, cls, params in recipes.single_mask_analyses():
+        if cls == 'masks':
+            p = dict(params)
+            out.append((name, p.pop('factories'), p))
+    return out
+
+
+def test_roi_and_multiple_udfs(ctx):
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd.udf.sumsigudf import SumSigUDF
+    from libertem_amd.udf.sum import SumUDF
+    rng = np.random.default_rng(9)
+    data = rng.integers(0, 100, (6, 7, 32, 32)).astype(np.uint16)
+    masks = rng.random((3, 32, 32)).astype(np.float32)
+    roi = np.zeros((6, 7), dtype=bool)
+    roi[1:5, 2:6] = True
+    roi[5, 6] = True
+    ref = opath.apply_masks(data, masks, num_partitions=4)
+    for ds in (ctx.load('memory', data=data, num_partitions=4, sig_dims=2),
+               _device_ds(ctx, data, 4)):
+        r1, r2, r3 = ctx.run_udf(dataset=ds, udf=[
+            ApplyMasksUDF(mask_factories=lambda: masks), SumSigUDF(), SumUDF()], roi=roi)
+        d = r1['intensity'].data
+        assert np.all(np.isnan(d[~roi]))
+        assert _close(d[roi], ref[roi], F32_TOL)
+        assert np.array_equal(r2['intensity'].data[roi], data.sum(axis=(2, 3))[roi])
+        assert np.array_equal(r3['intensity'].data, data[roi].astype(np.float32).sum(axis=0))
+
+
+def test_full_size_properties(ctx):
+    """At a size the oracle cannot finish in seconds: size-independent properties.
+    linearity apply(a*m1 + m2) == a*apply(m1) + apply(m2); all-ones mask == SumSigUDF;
+    sum over nav of SumSig == sum over sig of SumUDF (checksum of checksums)."""
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd.udf.sumsigudf import SumSigUDF
+    from libertem_amd.udf.sum import SumUDF
+    n = 64 * 64
+    g = torch.Generator(device='cuda').manual_seed(5)
+    frames = torch.randint(0, 64, (n, 256 * 256), generator=g, device='cuda',
+                           dtype=torch.int32).to(torch.int16).reshape((64, 64, 256, 256))
+    ds = ctx.load('memory', data=frames, dtype=np.uint16, sig_dims=2, num_partitions=2)
+    rng = np.random.default_rng(6)
+    m1 = (rng.random((256, 256)) > 0.5).astype(np.float32)
+    m2 = (rng.random((256, 256)) > 0.5).astype(np.float32)
+    ones = np.ones((256, 256), dtype=np.float32)
+    stack = np.stack([m1, m2, 2 * m1 + m2, ones])
+    r = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda: stack))['intensity'].data
+    # integer-valued, < 2**24: exact
+    assert r.max() < 2**24
+    assert np.array_equal(r[..., 2], 2 * r[..., 0] + r[..., 1])
+    ss = ctx.run_udf(dataset=ds, udf=SumSigUDF())['intensity'].data
+    assert np.array_equal(r[..., 3], ss)
+    s = ctx.run_udf(dataset=ds, udf=SumUDF())['intensity'].data
+    assert np.isclose(s.astype(np.float64).sum(), ss.astype(np.float64).sum(), rtol=1e-6)
+    # spot-check 32 random frames against the oracle
+    idx = rng.choice(n, 32, replace=False)
+    sub = frames.reshape((n, 256, 256))[torch.as_tensor(idx, device='cuda')].cpu().numpy()
+    ref = opath.apply_masks(sub.view(np.uint16)[None], stack)
+    assert np.array_equal(r.reshape((n, 4))[idx], ref[0])
+
+
+def test_mask_cache_reuse_and_eviction(ctx):
+    from libertem_amd.udf import masks as um
+    rng = np.random.default_rng(10)
+    data = rng.integers(0, 100, (2, 4, 32, 32)).astype(np.uint16)
+    ds = ctx.load('memory', data=data, num_partitions=2, sig_dims=2)
+    um.clear_mask_cache()
+    calls = {'n': 0}
+    m = rng.random((2, 32, 32)).astype(np.float32)
+
+    def factory():
+        calls['n'] += 1
+        return m
+    udf = um.ApplyMasksUDF(mask_factories=factory)
+    a = ctx.run_udf(dataset=ds, udf=udf)['intensity'].data
+    n_first = calls['n']
+    b = ctx.run_udf(dataset=ds, udf=udf)['intensity'].data
+    assert calls['n'] == n_first            # HBM image reused across tasks and runs
+    assert np.array_equal(a, b)
+    for i in range(6):                      # evict
+        mi = rng.random((1, 32, 32)).astype(np.float32)
+        ctx.run_udf(dataset=ds, udf=um.ApplyMasksUDF(mask_factories=lambda mi=mi: mi))
+    c = ctx.run_udf(dataset=ds, udf=udf)['intensity'].data
+    assert np.array_equal(a, c)
