@@ -172,7 +172,10 @@ class MaskContainer:
         key = (sig_slice, np.dtype(result_dtype).str, int(device))
         h = self._handle_cache.get(key)
         if h is None:
-            if self.use_sparse is False:
+            sparse_ok = np.dtype(result_dtype) in (np.dtype(np.float32), np.dtype(np.complex64))
+            if self.use_sparse is False or not sparse_ok:
+                # dense stack; also the route for sparse stacks whose result dtype (float64,
+                # complex128, integers) the SELL kernel does not cover: densified, generic kernel
                 m = self.get_for_sig_slice(sig_slice, dtype=result_dtype, sparse_backend=False,
                                            transpose=False)            # (n_masks, px), C order
                 h = hip.MaskHandle.dense(device, np.ascontiguousarray(m), result_dtype)

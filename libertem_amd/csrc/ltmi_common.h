@@ -48,3 +48,25 @@ struct cfloat { float re, im; };
 struct cdouble { double re, im; };
 
 }  // namespace ltmi
+
+// The opaque handle behind `ltmi_masks*` (shared by ltmi_dense.hip and ltmi_sparse.hip).
+struct ltmi_masks {
+    int device = 0;
+    int kind = 0;            // 0 dense/MFMA-f32, 1 dense/generic, 2 csr (SELL image)
+    int result_dtype = 0;
+    int64_t n_masks = 0, n_px = 0;
+    // kind 0
+    int n_cols = 0;          // real f32 columns (2 per mask for complex64)
+    int n_groups = 0;        // 16-column groups, padded to a multiple of ng
+    int ng = 1;
+    int n_chunks = 0;
+    float *img = nullptr;
+    float *partials = nullptr;
+    size_t partials_bytes = 0;
+    int tune_mt = 0, tune_waves = 0, tune_ksplit = 0;
+    // kind 0 and 1
+    void *gmasks = nullptr;  // (n_masks, n_px) of the accumulate type
+    // kind 2 (ltmi_sparse.hip)
+    void *csr = nullptr;
+    char last_kernel[128] = {0};
+};

@@ -419,27 +419,6 @@ k_dense_generic(const TIn *__restrict__ tile, int64_t ld, int64_t n_frames, int6
 // =================================================================================================
 using namespace ltmi;
 
-struct ltmi_masks {
-    int device = 0;
-    int kind = 0;            // 0 mfma-f32, 1 generic, 2 csr
-    int result_dtype = 0;
-    int64_t n_masks = 0, n_px = 0;
-    // kind 0
-    int n_cols = 0;          // real f32 columns (2 per mask for complex64)
-    int n_groups = 0;        // padded to a multiple of ng
-    int ng = 1;
-    int n_chunks = 0;
-    float *img = nullptr;
-    float *partials = nullptr;
-    size_t partials_bytes = 0;
-    int tune_mt = 0, tune_waves = 0, tune_ksplit = 0;
-    // kind 1
-    void *gmasks = nullptr;  // (n_masks, n_px) of the accumulate type
-    // kind 2 (ltmi_sparse.hip)
-    void *csr = nullptr;
-    char last_kernel[128] = {0};
-};
-
 namespace ltmi {
 int csr_destroy(ltmi_masks *m);   // ltmi_sparse.hip
 int csr_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames, int64_t ld_tile,

@@ -1,14 +1,361 @@
-// CSR mask stacks (placeholder until the SELL kernel lands)
+// Sparse mask application for gfx950 (MI355X):  out[f, k] (+)= sum_p tile[f, p] * M[p, k],
+// M sparse (n_px x n_masks), given as the CSR matrix the reference builds in _build_sparse
+// (src/libertem/common/container.py:53-64).
+//
+// Replaces the numba kernels _rmatmul_csr / _rmatmul_csc (src/libertem/common/numba/__init__.py:
+// 153-184), which walk the nnz of one pixel row at a time with a strided column gather of the
+// tile.  On the GPU the data movement is turned around:
+//
+//   * a workgroup owns F = 16 frames and a block of masks and sweeps the pixel axis in chunks of
+//     P = 1024 pixels.  The chunk of the 16 frames is converted to f32 and staged in LDS,
+//     pixel-major: slab[p][16 frames] (64 KiB), so one mask entry (pixel, value) needs 4
+//     ds_read_b128 to fetch that pixel of all 16 frames.
+//   * the masks are re-packed on the host into a sliced-ELL format per pixel chunk: 64 masks
+//     (one per lane) share a slice whose length is the longest of them inside the chunk; entry j
+//     of the slice is a coalesced 64-lane row of (local pixel, value).  Lanes keep 16 (x masks
+//     per thread) accumulators in registers for the whole sweep -- no atomics, deterministic.
+//   * masks are dealt to the 4 waves round-robin (mask k -> wave k % 4) so that localised stacks
+//     (rings: only a band of radii is present in any pixel chunk) load all waves evenly.
+//   * the 16-B quarter q of a slab row is stored at q ^ ((p >> 2) & 3): without it only p % 4
+//     selects the LDS slot of a ds_read_b128 and random gathers are >= 4-way conflicted.
+//
+// HBM traffic: frames once per pass over MB = 1024 (512 complex) masks; the SELL image comes from L2.
 #include "ltmi_common.h"
-struct ltmi_masks;
+#include <vector>
+#include <algorithm>
+#include <cstring>
+#include <type_traits>
+#include <typeinfo>
+
 namespace ltmi {
-int csr_destroy(ltmi_masks *) { return LTMI_OK; }
-int csr_apply(ltmi_masks *, const void *, int, int64_t, int64_t, void *, int64_t, int,
-              hipStream_t) {
-    LTMI_FAIL(LTMI_E_INVALID, "sparse path not built yet");
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int SP_F = 16;        // frames per workgroup
+constexpr int SP_P = 1024;      // pixels per chunk
+constexpr int SP_NT = 256;      // threads per workgroup
+
+struct CsrImage {
+    int cplx = 0;               // 0: f32 values, 1: complex64 values
+    int mpt = 4;                // masks per thread per pass
+    int mb = 1024;              // masks per pass = 256 * mpt
+    int n_pass = 0;
+    int n_chunks = 0;
+    uint32_t *pix = nullptr;    // [rows][64]
+    float *val = nullptr;       // [rows][64] (x2 interleaved re/im for complex)
+    int *row_off = nullptr;     // [(pass * n_chunks + chunk) * mpt * 4 + slot * 4 + wave]
+    int *row_len = nullptr;
+    size_t n_rows = 0;
+};
+
+__device__ __forceinline__ int slab_word(int p, int f) {
+    return p * SP_F + ((((f >> 2) ^ ((p >> 2) & 3)) << 2) | (f & 3));
 }
+
+// 8 consecutive pixels of one frame -> 8 floats
+template <typename T>
+__device__ __forceinline__ void load8_guarded(const T *row, int64_t p0, int64_t n_px, bool vec_ok,
+                                              float (&f)[8]) {
+    if (vec_ok && p0 + 8 <= n_px) {
+        if constexpr (sizeof(T) == 2) {
+            const u32x4 r = __builtin_nontemporal_load((const u32x4 *)(row + p0));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (std::is_signed<T>::value) {
+                    f[2 * i] = (float)((int)(r[i] << 16) >> 16);
+                    f[2 * i + 1] = (float)((int)r[i] >> 16);
+                } else {
+                    f[2 * i] = (float)(r[i] & 0xffffu);
+                    f[2 * i + 1] = (float)(r[i] >> 16);
+                }
+            }
+            return;
+        } else if constexpr (sizeof(T) == 1) {
+            const u32x2 r = __builtin_nontemporal_load((const u32x2 *)(row + p0));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if constexpr (std::is_signed<T>::value)
+                        f[4 * i + b] = (float)((int)(r[i] << (24 - 8 * b)) >> 24);
+                    else
+                        f[4 * i + b] = (float)((r[i] >> (8 * b)) & 0xffu);
+                }
+            return;
+        } else if constexpr (std::is_same<T, float>::value) {
+            const f32x4 a = __builtin_nontemporal_load((const f32x4 *)(row + p0));
+            const f32x4 b = __builtin_nontemporal_load((const f32x4 *)(row + p0) + 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = b[i]; }
+            return;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (p0 + j < n_px) ? (float)row[p0 + j] : 0.f;
+}
+
+template <typename T, int MPT, bool CPLX>
+__global__ void __launch_bounds__(SP_NT)
+k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
+             const uint32_t *__restrict__ pix, const float *__restrict__ val,
+             const int *__restrict__ row_off, const int *__restrict__ row_len, int n_chunks,
+             float *__restrict__ out, int64_t ld_out, int n_masks, int accumulate, int vec_ok) {
+    extern __shared__ __attribute__((aligned(16))) float slab[];     // [SP_P][SP_F]
+    constexpr int NC = CPLX ? 2 : 1;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int pass = blockIdx.y;
+    const int64_t f0 = (int64_t)blockIdx.x * SP_F;
+
+    // loader role: frame lf, pixel group lg (16 groups of 8 px per 128-px sweep step)
+    const int lf = tid & 15, lg = tid >> 4;
+    int64_t frame = f0 + lf;
+    if (frame > n_frames - 1) frame = n_frames - 1;
+    const T *row = tile + frame * ld;
+
+    float acc[MPT][SP_F][NC];
+#pragma unroll
+    for (int i = 0; i < MPT; ++i)
+#pragma unroll
+        for (int f = 0; f < SP_F; ++f)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[i][f][c] = 0.f;
+
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        // does any slice of this (pass, chunk) hold entries for this wave? (wave-uniform)
+        const int *lens = row_len + ((int64_t)(pass * n_chunks + ch) * MPT) * 4;
+        const int *offs = row_off + ((int64_t)(pass * n_chunks + ch) * MPT) * 4;
+        int any = 0;
+#pragma unroll
+        for (int i = 0; i < MPT * 4; ++i) any |= lens[i];
+        if (any == 0) continue;                      // nothing in this chunk for the whole block
+
+        __syncthreads();                             // previous chunk fully consumed
+#pragma unroll
+        for (int it = 0; it < SP_P / 128; ++it) {
+            const int pl = it * 128 + lg * 8;
+            float x[8];
+            load8_guarded<T>(row, (int64_t)ch * SP_P + pl, n_px, vec_ok != 0, x);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) slab[slab_word(pl + j, lf)] = x[j];
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int i = 0; i < MPT; ++i) {
+            const int len = lens[i * 4 + wave];
+            const int64_t base = (int64_t)offs[i * 4 + wave] * 64 + lane;
+            for (int j = 0; j < len; ++j) {
+                const uint32_t p = pix[base + (int64_t)j * 64];
+                float vr, vi = 0.f;
+                if (CPLX) {
+                    const float2 v2 = ((const float2 *)val)[base + (int64_t)j * 64];
+                    vr = v2.x;
+                    vi = v2.y;
+                } else {
+                    vr = val[base + (int64_t)j * 64];
+                }
+                const float *rowp = slab + p * SP_F;
+                const int s = (p >> 2) & 3;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 x = *(const f32x4 *)(rowp + ((q ^ s) << 2));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[i][q * 4 + e][0] += x[e] * vr;
+                        if (CPLX) acc[i][q * 4 + e][1] += x[e] * vi;
+                    }
+                }
+            }
+        }
+    }
+
+    // mask of (slot i, wave, lane): k = pass*MB + i*256 + lane*4 + wave
+#pragma unroll
+    for (int i = 0; i < MPT; ++i) {
+        const int k = pass * (256 * MPT) + i * 256 + lane * 4 + wave;
+        if (k >= n_masks) continue;
+#pragma unroll
+        for (int f = 0; f < SP_F; ++f) {
+            if (f0 + f >= n_frames) break;
+            float *o = out + (f0 + f) * ld_out + (int64_t)k * NC;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) o[c] = accumulate ? o[c] + acc[i][f][c] : acc[i][f][c];
+        }
+    }
+}
+
 }  // namespace ltmi
-extern "C" int ltmi_masks_create_csr(int, const int64_t *, const int64_t *, const void *, int,
-                                     int64_t, int64_t, ltmi_masks **) {
-    LTMI_FAIL(LTMI_E_INVALID, "sparse path not built yet");
+
+using namespace ltmi;
+
+namespace ltmi {
+
+int csr_destroy(ltmi_masks *m) {
+    CsrImage *c = (CsrImage *)m->csr;
+    if (!c) return LTMI_OK;
+    if (c->pix) (void)hipFree(c->pix);
+    if (c->val) (void)hipFree(c->val);
+    if (c->row_off) (void)hipFree(c->row_off);
+    if (c->row_len) (void)hipFree(c->row_len);
+    delete c;
+    m->csr = nullptr;
+    return LTMI_OK;
+}
+
+template <typename T>
+static int launch_sell(ltmi_masks *m, CsrImage *c, const T *tile, int64_t n_frames, int64_t ld,
+                       float *out, int64_t ld_out_f, int accumulate, hipStream_t stream) {
+    const int vec_ok = (((uintptr_t)tile) % 16 == 0) && ((ld * (int64_t)sizeof(T)) % 16 == 0);
+    dim3 grid((unsigned)((n_frames + SP_F - 1) / SP_F), (unsigned)c->n_pass);
+    const size_t lds = (size_t)SP_P * SP_F * sizeof(float);
+    if (c->cplx) {
+        auto kern = k_sell_apply<T, 2, true>;
+        static bool set[16] = {false};
+        if (!set[m->device & 15]) {
+            LTMI_HIP(hipFuncSetAttribute((const void *)kern,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            set[m->device & 15] = true;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(SP_NT), lds, stream, tile, ld, n_frames, m->n_px,
+                           (const uint32_t *)c->pix, (const float *)c->val, (const int *)c->row_off,
+                           (const int *)c->row_len, c->n_chunks, out, ld_out_f, (int)m->n_masks,
+                           accumulate, vec_ok);
+    } else {
+        auto kern = k_sell_apply<T, 4, false>;
+        static bool set[16] = {false};
+        if (!set[m->device & 15]) {
+            LTMI_HIP(hipFuncSetAttribute((const void *)kern,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            set[m->device & 15] = true;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(SP_NT), lds, stream, tile, ld, n_frames, m->n_px,
+                           (const uint32_t *)c->pix, (const float *)c->val, (const int *)c->row_off,
+                           (const int *)c->row_len, c->n_chunks, out, ld_out_f, (int)m->n_masks,
+                           accumulate, vec_ok);
+    }
+    LTMI_HIP(hipGetLastError());
+    snprintf(m->last_kernel, sizeof(m->last_kernel), "k_sell_apply<%s,%s> grid=(%u,%u) rows=%zu",
+             typeid(T).name(), c->cplx ? "c64" : "f32", grid.x, grid.y, c->n_rows);
+    return LTMI_OK;
+}
+
+int csr_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames, int64_t ld_tile,
+              void *out, int64_t ld_out, int accumulate, hipStream_t stream) {
+    CsrImage *c = (CsrImage *)m->csr;
+    float *o = (float *)out;
+    const int64_t ldo = ld_out * (c->cplx ? 2 : 1);
+    switch (tile_dtype) {
+        case LTMI_BOOL:
+        case LTMI_U8: return launch_sell<uint8_t>(m, c, (const uint8_t *)tile, n_frames, ld_tile, o, ldo, accumulate, stream);
+        case LTMI_I8: return launch_sell<int8_t>(m, c, (const int8_t *)tile, n_frames, ld_tile, o, ldo, accumulate, stream);
+        case LTMI_U16: return launch_sell<uint16_t>(m, c, (const uint16_t *)tile, n_frames, ld_tile, o, ldo, accumulate, stream);
+        case LTMI_I16: return launch_sell<int16_t>(m, c, (const int16_t *)tile, n_frames, ld_tile, o, ldo, accumulate, stream);
+        case LTMI_F32: return launch_sell<float>(m, c, (const float *)tile, n_frames, ld_tile, o, ldo, accumulate, stream);
+    }
+    LTMI_FAIL(LTMI_E_DTYPE, "sparse masks: tile dtype %s is not supported with result dtype %s "
+              "(supported tiles: uint8 int8 uint16 int16 float32)", dtype_name(tile_dtype),
+              dtype_name(m->result_dtype));
+}
+
+}  // namespace ltmi
+
+extern "C" int ltmi_masks_create_csr(int device, const int64_t *indptr, const int64_t *indices,
+                                     const void *data, int result_dtype, int64_t n_px,
+                                     int64_t n_masks, ltmi_masks **out) {
+    if (!indptr || !out || n_px <= 0 || n_masks <= 0)
+        LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_create_csr: bad arguments (n_px=%lld n_masks=%lld)",
+                  (long long)n_px, (long long)n_masks);
+    if (result_dtype != LTMI_F32 && result_dtype != LTMI_C64)
+        LTMI_FAIL(LTMI_E_DTYPE, "ltmi_masks_create_csr: result dtype %s not supported for sparse "
+                  "stacks (float32 / complex64 only; densify for others)",
+                  dtype_name(result_dtype));
+    const int64_t nnz = indptr[n_px];
+    if (nnz < 0 || (nnz > 0 && (!indices || !data)))
+        LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_create_csr: inconsistent CSR arrays");
+    for (int64_t e = 0; e < nnz; ++e)
+        if (indices[e] < 0 || indices[e] >= n_masks)
+            LTMI_FAIL(LTMI_E_SHAPE, "ltmi_masks_create_csr: column index %lld out of range",
+                      (long long)indices[e]);
+    LTMI_HIP(hipSetDevice(device));
+    ltmi_masks *m = new (std::nothrow) ltmi_masks();
+    CsrImage *c = new (std::nothrow) CsrImage();
+    if (!m || !c) { delete m; delete c; LTMI_FAIL(LTMI_E_NOMEM, "out of host memory"); }
+    m->device = device;
+    m->kind = 2;
+    m->result_dtype = result_dtype;
+    m->n_masks = n_masks;
+    m->n_px = n_px;
+    m->csr = c;
+    c->cplx = (result_dtype == LTMI_C64);
+    c->mpt = c->cplx ? 2 : 4;
+    c->mb = 256 * c->mpt;
+    c->n_pass = (int)((n_masks + c->mb - 1) / c->mb);
+    c->n_chunks = (int)((n_px + SP_P - 1) / SP_P);
+    const int nc = c->cplx ? 2 : 1;
+    const float *vals = (const float *)data;
+
+    // slice id of mask k: ((pass * n_chunks + chunk) * mpt + slot) * 4 + wave ; lane = (k%256)/4
+    const size_t n_slices = (size_t)c->n_pass * c->n_chunks * c->mpt * 4;
+    try {
+        // count entries per (chunk, mask)
+        std::vector<int> cnt((size_t)c->n_chunks * n_masks, 0);
+        for (int64_t p = 0; p < n_px; ++p) {
+            const int ch = (int)(p / SP_P);
+            for (int64_t e = indptr[p]; e < indptr[p + 1]; ++e)
+                cnt[(size_t)ch * n_masks + indices[e]]++;
+        }
+        std::vector<int> row_len(n_slices, 0), row_off(n_slices, 0);
+        auto slice_of = [&](int64_t k, int ch) -> size_t {
+            const int pass = (int)(k / c->mb);
+            const int r = (int)(k % c->mb);
+            const int slot = r / 256, wave = r % 4;
+            return (((size_t)pass * c->n_chunks + ch) * c->mpt + slot) * 4 + wave;
+        };
+        for (int ch = 0; ch < c->n_chunks; ++ch)
+            for (int64_t k = 0; k < n_masks; ++k) {
+                const size_t s = slice_of(k, ch);
+                row_len[s] = std::max(row_len[s], cnt[(size_t)ch * n_masks + k]);
+            }
+        size_t rows = 0;
+        for (size_t s = 0; s < n_slices; ++s) { row_off[s] = (int)rows; rows += row_len[s]; }
+        c->n_rows = rows;
+        std::vector<uint32_t> pix(std::max<size_t>(rows, 1) * 64, 0u);
+        std::vector<float> val(std::max<size_t>(rows, 1) * 64 * nc, 0.f);
+        std::vector<int> fill((size_t)c->n_chunks * n_masks, 0);
+        for (int64_t p = 0; p < n_px; ++p) {
+            const int ch = (int)(p / SP_P);
+            for (int64_t e = indptr[p]; e < indptr[p + 1]; ++e) {
+                const int64_t k = indices[e];
+                const size_t s = slice_of(k, ch);
+                const int lane = (int)((k % 256) / 4);
+                const int j = fill[(size_t)ch * n_masks + k]++;
+                const size_t pos = ((size_t)row_off[s] + j) * 64 + lane;
+                pix[pos] = (uint32_t)(p - (int64_t)ch * SP_P);
+                for (int q = 0; q < nc; ++q) val[pos * nc + q] = vals[e * nc + q];
+            }
+        }
+        hipError_t e = hipMalloc((void **)&c->pix, pix.size() * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&c->val, val.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void **)&c->row_off, n_slices * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&c->row_len, n_slices * sizeof(int));
+        if (e == hipSuccess) e = hipMemcpy(c->pix, pix.data(), pix.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(c->val, val.data(), val.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(c->row_off, row_off.data(), n_slices * sizeof(int), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(c->row_len, row_len.data(), n_slices * sizeof(int), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            ltmi::csr_destroy(m);
+            delete m;
+            LTMI_FAIL((int)e, "uploading the sparse mask image failed: %s", hipGetErrorString(e));
+        }
+    } catch (const std::bad_alloc &) {
+        ltmi::csr_destroy(m);
+        delete m;
+        LTMI_FAIL(LTMI_E_NOMEM, "out of host memory while packing the sparse mask image");
+    }
+    *out = m;
+    return LTMI_OK;
 }

@@ -295,3 +295,56 @@ def test_mask_cache_reuse_and_eviction(ctx):
         ctx.run_udf(dataset=ds, udf=um.ApplyMasksUDF(mask_factories=lambda mi=mi: mi))
     c = ctx.run_udf(dataset=ds, udf=udf)['intensity'].data
     assert np.array_equal(a, c)
+
+
+def test_sparse_masks_through_udf(ctx):
+    """use_sparse variants (reference tests/analysis/test_analysis_masks.py:278-446)."""
+    import scipy.sparse as sp
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd import masks as pm
+    rng = np.random.default_rng(40)
+    data = rng.integers(0, 1000, (4, 9, 64, 64)).astype(np.uint16)
+    dense = [np.where(rng.random((64, 64)) < 0.05, rng.random((64, 64)), 0).astype(np.float32)
+             for _ in range(5)]
+    ref = opath.apply_masks(data, np.stack(dense), num_partitions=2)
+    ref_sp = opath.apply_masks_sparse(
+        data, sp.csr_matrix(np.stack(dense).reshape((5, -1))), num_partitions=2)
+    assert _close(ref_sp, ref, F32_TOL)
+    ds = ctx.load('memory', data=data, num_partitions=2, sig_dims=2)
+    facs = [(lambda i=i: sp.csr_matrix(dense[i])) for i in range(5)]
+    for kw in (dict(), dict(use_sparse=True), dict(use_sparse='scipy.sparse'),
+               dict(use_sparse='scipy.sparse.csc'), dict(use_sparse='sparse.pydata'),
+               dict(use_sparse=False)):
+        got = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=facs, **kw))
+        assert _close(got['intensity'].data, ref, F32_TOL), kw
+    # dense factories forced sparse
+    got = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(
+        mask_factories=lambda: np.stack(dense), use_sparse=True))
+    assert _close(got['intensity'].data, ref, F32_TOL)
+    # sparse ring stack from the product factory, sub-frame tiles forced
+    rings = pm.radial_bins(32, 32, 64, 64, n_bins=40, use_sparse=True, dtype=np.float32)
+    ref_r = opath.apply_masks(data, rings.todense(), num_partitions=2)
+    ds_t = ctx.load('memory', data=data, num_partitions=2, sig_dims=2, tileshape=(7, 16, 64))
+    got = ctx.run_udf(dataset=ds_t, udf=ApplyMasksUDF(mask_factories=lambda: rings))
+    assert _close(got['intensity'].data, ref_r, F32_TOL)
+    # float64 data -> float64 result: sparse stack goes through the densified generic path
+    got = ctx.run_udf(dataset=ctx.load('memory', data=data.astype(np.float64), num_partitions=2,
+                                       sig_dims=2),
+                      udf=ApplyMasksUDF(mask_factories=facs))
+    assert got['intensity'].data.dtype == np.float64
+    assert _close(got['intensity'].data, ref, 1e-6)
+
+
+def test_radial_fourier_sparse(ctx):
+    """RadialFourierAnalysis with the sparse complex64 stack == the (pinned) dense one."""
+    case = recipes.RF_CASES[0]
+    data = recipes.make_rf_case(case)
+    ds = ctx.load('memory', data=data, num_partitions=2, sig_dims=2)
+    dense = ctx.run(ctx.create_radial_fourier_analysis(dataset=ds, n_bins=2, max_order=4,
+                                                       use_sparse=False))
+    sparse = ctx.run(ctx.create_radial_fourier_analysis(dataset=ds, n_bins=2, max_order=4,
+                                                        use_sparse=True))
+    ref = opath.radial_fourier_analysis(data, num_partitions=2, n_bins=2, max_order=4,
+                                        use_sparse='scipy.sparse')
+    assert _close(sparse.raw_results, dense.raw_results, F32_TOL)
+    assert _close(sparse.raw_results, ref['raw_results'], F32_TOL)
