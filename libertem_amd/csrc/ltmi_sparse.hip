@@ -36,6 +36,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr int SP_F = 16;        // frames per workgroup
 constexpr int SP_P = 1024;      // pixels per chunk
 constexpr int SP_NT = 256;      // threads per workgroup
+constexpr int SP_U = 4;         // SELL rows fetched per group (slices padded to a multiple)
 
 struct CsrImage {
     int cplx = 0;               // 0: f32 values, 1: complex64 values
@@ -148,25 +149,44 @@ k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
         for (int i = 0; i < MPT; ++i) {
             const int len = lens[i * 4 + wave];
             const int64_t base = (int64_t)offs[i * 4 + wave] * 64 + lane;
-            for (int j = 0; j < len; ++j) {
-                const uint32_t p = pix[base + (int64_t)j * 64];
-                float vr, vi = 0.f;
-                if (CPLX) {
-                    const float2 v2 = ((const float2 *)val)[base + (int64_t)j * 64];
-                    vr = v2.x;
-                    vi = v2.y;
-                } else {
-                    vr = val[base + (int64_t)j * 64];
+            // slices are padded to a multiple of SP_U rows (zero entries): SP_U rows of
+            // (pixel, value) are fetched together, one group ahead of the LDS gathers
+            uint32_t pn[SP_U];
+            float vrn[SP_U], vin[SP_U];
+            auto fetch = [&](int j) {
+#pragma unroll
+                for (int u = 0; u < SP_U; ++u) {
+                    const int64_t e = base + (int64_t)(j + u) * 64;
+                    pn[u] = pix[e];
+                    if (CPLX) {
+                        const float2 v2 = ((const float2 *)val)[e];
+                        vrn[u] = v2.x;
+                        vin[u] = v2.y;
+                    } else {
+                        vrn[u] = val[e];
+                        vin[u] = 0.f;
+                    }
                 }
-                const float *rowp = slab + p * SP_F;
-                const int s = (p >> 2) & 3;
+            };
+            if (len > 0) fetch(0);
+            for (int j = 0; j < len; j += SP_U) {
+                uint32_t pc[SP_U];
+                float vr[SP_U], vi[SP_U];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 x = *(const f32x4 *)(rowp + ((q ^ s) << 2));
+                for (int u = 0; u < SP_U; ++u) { pc[u] = pn[u]; vr[u] = vrn[u]; vi[u] = vin[u]; }
+                if (j + SP_U < len) fetch(j + SP_U);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc[i][q * 4 + e][0] += x[e] * vr;
-                        if (CPLX) acc[i][q * 4 + e][1] += x[e] * vi;
+                for (int u = 0; u < SP_U; ++u) {
+                    const float *rowp = slab + pc[u] * SP_F;
+                    const int s = (pc[u] >> 2) & 3;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 x = *(const f32x4 *)(rowp + ((q ^ s) << 2));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc[i][q * 4 + e][0] += x[e] * vr[u];
+                            if (CPLX) acc[i][q * 4 + e][1] += x[e] * vi[u];
+                        }
                     }
                 }
             }
@@ -320,6 +340,7 @@ extern "C" int ltmi_masks_create_csr(int device, const int64_t *indptr, const in
                 const size_t s = slice_of(k, ch);
                 row_len[s] = std::max(row_len[s], cnt[(size_t)ch * n_masks + k]);
             }
+        for (size_t s = 0; s < n_slices; ++s) row_len[s] = (row_len[s] + SP_U - 1) / SP_U * SP_U;
         size_t rows = 0;
         for (size_t s = 0; s < n_slices; ++s) { row_off[s] = (int)rows; rows += row_len[s]; }
         c->n_rows = rows;
