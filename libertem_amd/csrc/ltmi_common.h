@@ -63,7 +63,7 @@ struct ltmi_masks {
     float *img = nullptr;
     float *partials = nullptr;
     size_t partials_bytes = 0;
-    int tune_mt = 0, tune_waves = 0, tune_ksplit = 0;
+    int tune_mt = 0, tune_waves = 0, tune_ksplit = 0, tune_ksplit_ring = 0;
     // kind 0 and 1
     void *gmasks = nullptr;  // (n_masks, n_px) of the accumulate type
     // kind 2 (ltmi_sparse.hip)

@@ -279,30 +279,31 @@ k_dense_mfma(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
 // 7.0 TB/s.  Here every wave instruction is a global_load_lds_dwordx4 that moves 4 frame rows x 256 B
 // (whole 128-B lines) straight into LDS; MFMA A fragments are then ds_read_b128 from there.
 //
-//   * 4 waves, each owns 32 frames (2 M tiles); per wave a ring of 3 sub-chunk slots
-//     (32 rows x 256 B = 8 KiB each).  Sub-chunk = 256 B of every row (128 px of a 2-byte dtype).
+//   * 8 waves (2 per SIMD, so one wave's DMA issue / LDS latency hides under the other's MFMAs),
+//     each owns 16 frames; per wave a ring of 3 sub-chunk slots (16 rows x 256 B = 4 KiB each).
+//     Sub-chunk = 256 B of every row (128 px of a 2-byte dtype).
 //   * the 16 pieces (16 B) of a row are stored at piece ^ (row & 15): the 16 lanes of every
 //     ds_read_b128 service group (16 different rows, two adjacent pieces) hit 16 different slots.
 //     LDS-DMA writes lane-linear, so the permutation is applied to the per-lane SOURCE address.
-//   * mask image chunks (256 px, 16 KiB) also arrive by LDS-DMA, 2 slots, shared by the 4 waves.
-//   * counted waits: A(s+2) is issued before waiting for A(s) -> two sub-chunks (16 KiB per wave,
-//     64 KiB per CU) stay in flight across the MFMA work; one s_barrier per mask chunk.
-//   issue order per wave:  ... A(s) [B(s/2) if s even] A(s+1) [B if s+1 even] A(s+2) ...
-//   even s: vmcnt(16) leaves A(s+1), A(s+2) in flight  => A(s) and my pieces of B(s/2) landed
-//   odd  s: vmcnt(20) leaves A(s+1), B(..), A(s+2)     => A(s) landed
-constexpr int V2_WAVES = 4;
-constexpr int V2_ROWS = 32;                         // frames per wave (MT = 2)
+//   * mask image chunks (256 px, 16 KiB) also arrive by LDS-DMA, 2 slots, shared by the 8 waves.
+//   * one DMA instruction per 32-pixel block is interleaved with that block's 8 MFMAs; two
+//     accumulators (even / odd pixel of the block) cover the 40-cycle MFMA dependency.
+//   * counted waits, never vmcnt(0) in the loop.  Issue order per wave:
+//       iteration s: [wait] [barrier + B(s/2+1) if s even] A(s+2) spread over the 4 blocks
+//     even s: vmcnt(4) leaves A(s+1) in flight          => A(s) and my pieces of B(s/2) landed
+//     odd  s: vmcnt(6) leaves B(..) + A(s+1) in flight  => A(s) landed
+constexpr int V2_WAVES = 8;
+constexpr int V2_ROWS = 16;                         // frames per wave
 constexpr int V2_SUB_BYTES = 256;                   // bytes of a row per sub-chunk
-constexpr int V2_ASLOT = V2_ROWS * V2_SUB_BYTES;    // 8 KiB per wave per slot
-constexpr int V2_ARING = 3;
-constexpr int V2_A_BYTES = V2_ARING * V2_WAVES * V2_ASLOT;      // 96 KiB
+constexpr int V2_ASLOT = V2_ROWS * V2_SUB_BYTES;    // 4 KiB per wave per slot
 constexpr int V2_B_BYTES = 2 * CHUNK_FLOATS * 4;                 // 32 KiB
-constexpr int V2_LDS_BYTES = V2_A_BYTES + V2_B_BYTES;            // 128 KiB
+constexpr int v2_a_bytes(int ring) { return ring * V2_WAVES * V2_ASLOT; }   // 96 / 128 KiB
+constexpr int v2_lds_bytes(int ring) { return v2_a_bytes(ring) + V2_B_BYTES; }
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *glb_ptr_t;
 
-template <typename T>
+template <typename T, int V2_ARING>
 __global__ void __launch_bounds__(V2_WAVES * 64)
 k_dense_mfma_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
                  const float *__restrict__ img, int n_chunks, float *__restrict__ out,
@@ -314,6 +315,8 @@ k_dense_mfma_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64
     constexpr int SPX = V2_SUB_BYTES / sizeof(T);       // pixels per sub-chunk (128)
     constexpr int SUBS = KC / SPX;                      // sub-chunks per mask chunk (2)
     constexpr int BLKS = SPX / 32;                      // MFMA pixel blocks per sub-chunk (4)
+    static_assert(BLKS == 4 && V2_ROWS / 4 == BLKS, "one DMA instruction per block");
+    constexpr int NT = V2_WAVES * 64;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -330,57 +333,63 @@ k_dense_mfma_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64
     const int64_t f_wave = (int64_t)blockIdx.x * (V2_WAVES * V2_ROWS) + wave * V2_ROWS;
 
     unsigned char *a_base = lds_raw + wave * V2_ASLOT;               // + slot * (WAVES*ASLOT)
+    constexpr int V2_A_BYTES = v2_a_bytes(V2_ARING);
     unsigned char *b_base = lds_raw + V2_A_BYTES;                    // + bslot * 16 KiB
 
-    f32x4 acc[2];
+    f32x4 acc[2];                                        // [pixel parity]
     acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
     acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (c_begin < cf_end) {
         // DMA source pointers: instruction t moves rows 4t .. 4t+3; lane i -> row 4t + (i>>4),
         // LDS position i & 15, source piece (i & 15) ^ (row & 15)
-        const unsigned char *src[8];
+        const unsigned char *src[4];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
+        for (int t = 0; t < 4; ++t) {
             const int r = 4 * t + (lane >> 4);
             int64_t f = f_wave + r;
             if (f > n_frames - 1) f = n_frames - 1;
             const int piece = (lane & 15) ^ (r & 15);
             src[t] = (const unsigned char *)(tile + f * ld) + piece * 16;
         }
-        const unsigned char *bsrc = (const unsigned char *)img + wave * 4096 + lane * 16;
+        const unsigned char *bsrc = (const unsigned char *)img + wave * 2048 + lane * 16;
         const int S0 = c_begin * SUBS, S1 = cf_end * SUBS;    // sub-chunk range
 
-        auto issue_a = [&](int s) {
+        auto issue_a1 = [&](int s, int t) {                   // one DMA piece of sub-chunk s
             const int sc = min(s, S1 - 1);
             unsigned char *dst = a_base + (s % V2_ARING) * (V2_WAVES * V2_ASLOT);
-            const int64_t off = (int64_t)sc * V2_SUB_BYTES;
-#pragma unroll
-            for (int t = 0; t < 8; ++t)
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[t] + off),
-                                                 (lds_ptr_t)(dst + t * 1024), 16, 0, 2 /*nt*/);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[t] + (int64_t)sc * V2_SUB_BYTES),
+                                             (lds_ptr_t)(dst + t * 1024), 16, 0, 2 /*nt*/);
         };
         auto issue_b = [&](int c) {
             const int cc = min(c, cf_end - 1);
-            unsigned char *dst = b_base + (c & 1) * (CHUNK_FLOATS * 4) + wave * 4096;
+            unsigned char *dst = b_base + (c & 1) * (CHUNK_FLOATS * 4) + wave * 2048;
             const unsigned char *sp = bsrc + (int64_t)cc * (CHUNK_FLOATS * 4);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 2; ++u)
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)(sp + u * 1024),
                                                  (lds_ptr_t)(dst + u * 1024), 16, 0, 0);
         };
 
-        issue_a(S0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) issue_a1(S0, t);
         issue_b(c_begin);
-        issue_a(S0 + 1);
+#pragma unroll
+        for (int d = 1; d < V2_ARING - 1; ++d)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) issue_a1(S0 + d, t);
+        // DMA instructions allowed to stay in flight at the wait of iteration s (see header):
+        //   even s: the (RING-2) later sub-chunks          -> A(s) and B(s/2) landed
+        //   odd  s: those + the B issued in iteration s-1  -> A(s) landed
         for (int s = S0; s < S1; ++s) {
-            issue_a(s + 2);
             if (((s - S0) & 1) == 0) {
-                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                if (V2_ARING == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 issue_b((s - S0) / SUBS + c_begin + 1);
             } else {
-                asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                if (V2_ARING == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             }
             const unsigned char *aslot = a_base + (s % V2_ARING) * (V2_WAVES * V2_ASLOT);
             const int cb = (s - S0) / SUBS + c_begin;             // mask chunk of this sub-chunk
@@ -389,23 +398,19 @@ k_dense_mfma_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64
             const int blk0 = ((s - S0) & 1) * BLKS;               // block offset inside the chunk
 #pragma unroll
             for (int blk = 0; blk < BLKS; ++blk) {
-                float a[2][8];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const typename TR::raw_t raw = *(const typename TR::raw_t *)(
-                        aslot + (mt * 16 + m) * V2_SUB_BYTES + (((blk * 4 + kg) ^ m) << 4));
-                    TR::cvt(raw, a[mt]);
-                }
+                issue_a1(s + V2_ARING - 1, blk);
+                float a[8];
+                const typename TR::raw_t raw = *(const typename TR::raw_t *)(
+                    aslot + m * V2_SUB_BYTES + (((blk * 4 + kg) ^ m) << 4));
+                TR::cvt(raw, a);
                 f32x4 b[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
                     b[h] = *(const f32x4 *)(bslot + ((((blk0 + blk) * 2 + h) ^ m) << 2));
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                            a[mt][j], b[j >> 2][j & 3], acc[mt], 0, 0, 0);
+                    acc[j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                        a[j], b[j >> 2][j & 3], acc[j & 1], 0, 0, 0);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the clamped prefetches
@@ -418,55 +423,45 @@ k_dense_mfma_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64
         float *bl = (float *)b_base;
         const u32x4 *img_units = (const u32x4 *)img + (int64_t)c * (CHUNK_FLOATS / 4);
 #pragma unroll
-        for (int i = 0; i < CHUNK_FLOATS / 4 / (V2_WAVES * 64); ++i)
-            ((u32x4 *)bl)[i * (V2_WAVES * 64) + tid] = img_units[i * (V2_WAVES * 64) + tid];
+        for (int i = 0; i < CHUNK_FLOATS / 4 / NT; ++i)
+            ((u32x4 *)bl)[i * NT + tid] = img_units[i * NT + tid];
         __syncthreads();
-        const T *rowp[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            int64_t f = f_wave + mt * 16 + m;
-            if (f > n_frames - 1) f = n_frames - 1;
-            rowp[mt] = tile + f * ld + kg * 8;
-        }
+        int64_t f = f_wave + m;
+        if (f > n_frames - 1) f = n_frames - 1;
+        const T *rowp = tile + f * ld + kg * 8;
         const float *ldsb = bl + m * KC + kg * 64;
 #pragma unroll
         for (int blk = 0; blk < 8; ++blk) {
             const int64_t p0 = (int64_t)c * KC + blk * 32;
-            float a[2][8];
+            float a[8];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    a[mt][j] = (p0 + kg * 8 + j < n_px) ? (float)rowp[mt][p0 + j] : 0.f;
+            for (int j = 0; j < 8; ++j)
+                a[j] = (p0 + kg * 8 + j < n_px) ? (float)rowp[p0 + j] : 0.f;
             f32x4 b[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
                 b[h] = *(const f32x4 *)(ldsb + (((blk * 2 + h) ^ m) << 2));
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][j], b[j >> 2][j & 3],
-                                                                   acc[mt], 0, 0, 0);
+                acc[j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j >> 2][j & 3],
+                                                                  acc[j & 1], 0, 0, 0);
         }
     }
 
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t f = f_wave + mt * 16 + kg * 4 + r;
-            const int col = m;
-            if (f < n_frames && col < n_cols) {
-                const float v = acc[mt][r];
-                if (ksplit == 1) {
-                    float *p = out + f * ld_out + col;
-                    *p = accumulate ? (*p + v) : v;
-                } else {
-                    partials[((int64_t)ks * n_frames + f) * n_cols + col] = v;
-                }
+    for (int r = 0; r < 4; ++r) {
+        const int64_t f = f_wave + kg * 4 + r;
+        const int col = m;
+        if (f < n_frames && col < n_cols) {
+            const float v = acc[0][r] + acc[1][r];
+            if (ksplit == 1) {
+                float *p = out + f * ld_out + col;
+                *p = accumulate ? (*p + v) : v;
+            } else {
+                partials[((int64_t)ks * n_frames + f) * n_cols + col] = v;
             }
         }
+    }
 }
 
 __global__ void k_reduce_partials(const float *__restrict__ partials, int ksplit,
@@ -733,6 +728,13 @@ extern "C" int ltmi_masks_kind(const ltmi_masks *m, int *kind) {
 
 extern "C" int ltmi_masks_set_tuning(ltmi_masks *m, int mt, int waves, int ksplit) {
     if (!m) LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_set_tuning: null handle");
+    if (mt == 0 && (waves == 3 || waves == 5)) {     // v2 kernel, LDS ring depth 3 / 4 (5 -> 4)
+        m->tune_mt = 0;
+        m->tune_waves = 0;
+        m->tune_ksplit = ksplit;
+        m->tune_ksplit_ring = waves == 3 ? 3 : 4;
+        return LTMI_OK;
+    }
     if (!(mt == 0 || mt == 1 || mt == 2) || !(waves == 0 || waves == 4 || waves == 8) || ksplit < 0)
         LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_set_tuning: unsupported (mt=%d waves=%d ksplit=%d)",
                   mt, waves, ksplit);
@@ -792,13 +794,14 @@ static int launch_mfma_v2(ltmi_masks *m, const T *tile, int64_t n_frames, int64_
     if constexpr (sizeof(T) != 2) {
         LTMI_FAIL(LTMI_E_DTYPE, "v2 kernel needs 2-byte pixels");
     } else {
-        auto kern = k_dense_mfma_lds<T>;
-        static bool attr_set[16] = {false};
-        if (!attr_set[m->device & 15]) {
+        const int ring = (m->tune_ksplit_ring == 3) ? 3 : 4;
+        auto kern = ring == 3 ? k_dense_mfma_lds<T, 3> : k_dense_mfma_lds<T, 4>;
+        const int lds_bytes = v2_lds_bytes(ring);
+        static bool attr_set[16][2] = {{false}};
+        if (!attr_set[m->device & 15][ring - 3]) {
             LTMI_HIP(hipFuncSetAttribute((const void *)kern,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         V2_LDS_BYTES));
-            attr_set[m->device & 15] = true;
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+            attr_set[m->device & 15][ring - 3] = true;
         }
         const int64_t gx = (n_frames + V2_WAVES * V2_ROWS - 1) / (V2_WAVES * V2_ROWS);
         int ksplit = m->tune_ksplit;
@@ -818,12 +821,13 @@ static int launch_mfma_v2(ltmi_masks *m, const T *tile, int64_t n_frames, int64_
             if (rc != LTMI_OK) return rc;
         }
         dim3 grid((unsigned)gx, (unsigned)ksplit, 1);
-        hipLaunchKernelGGL(kern, grid, dim3(V2_WAVES * 64), V2_LDS_BYTES, stream, tile, ld, n_frames,
+        hipLaunchKernelGGL(kern, grid, dim3(V2_WAVES * 64), lds_bytes, stream, tile, ld, n_frames,
                            m->n_px, (const float *)m->img, m->n_chunks, out, ld_out, m->n_cols,
                            accumulate, m->partials, ksplit);
         LTMI_HIP(hipGetLastError());
         snprintf(m->last_kernel, sizeof(m->last_kernel),
-                 "k_dense_mfma_lds<%s> grid=(%u,%u,1)", typeid(T).name(), grid.x, grid.y);
+                 "k_dense_mfma_lds<%s,ring=%d> grid=(%u,%u,1)", typeid(T).name(), ring, grid.x,
+                 grid.y);
         if (ksplit > 1) {
             const int64_t n = n_frames * m->n_cols;
             hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
