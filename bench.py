@@ -116,8 +116,12 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get('LTMI_FORCE_COLLECTIVES') == '1'
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     from libertem_amd.api import Context
@@ -158,7 +162,7 @@ def main():
     assert np.all(np.isfinite(got))
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -172,7 +176,7 @@ def main():
     kernel_events = hip.KernelTimer.stop()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max = float(t.item())
 
@@ -216,7 +220,7 @@ def main():
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

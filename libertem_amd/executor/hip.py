@@ -70,12 +70,23 @@ class HipJobExecutor(JobExecutor):
             self.device_class = 'cpu'
         self._distributed = distributed
         self._scattered = {}
+        self._pinned = {}
 
     # --- distributed helpers -----------------------------------------------------------------------
     def _dist(self):
         if self._distributed is False:
             return None
         return _dist()
+
+    @property
+    def _collectives_on(self):
+        """True iff results have to be combined across ranks.  LTMI_FORCE_COLLECTIVES=1 runs the
+        collective code path even with a single rank (used to exercise RCCL on a 1-GPU box)."""
+        import os
+        d = self._dist()
+        if d is None:
+            return False
+        return self.world_size > 1 or os.environ.get('LTMI_FORCE_COLLECTIVES') == '1'
 
     @property
     def rank(self):
@@ -177,7 +188,7 @@ class HipJobExecutor(JobExecutor):
                         with torch.cuda.device(self.gpu_id), torch.cuda.stream(self._stream):
                             full = torch.zeros(buf.shape, dtype=torch_dtype_for(buf.dtype),
                                                device=f'cuda:{self.gpu_id}')
-                    if d is not None and self.world_size > 1:
+                    if self._collectives_on:
                         # collectives are ordered after the kernels of the executor stream
                         with torch.cuda.device(self.gpu_id), torch.cuda.stream(self._stream):
                             full = self._combine(d, full, how)
@@ -191,7 +202,7 @@ class HipJobExecutor(JobExecutor):
                 for task, entry in generic_parts:
                     if i in entry:
                         self._apply_one(udf, entry[i], task)
-                if d is not None and self.world_size > 1:
+                if self._collectives_on:
                     import torch as _t
                     for name, how in decl.items():
                         buf = udf.results.get_buffer(name)
@@ -205,7 +216,7 @@ class HipJobExecutor(JobExecutor):
         if gen_idx:
             mine = [(task.idx, {i: entry[i] for i in gen_idx if i in entry})
                     for task, entry in generic_parts]
-            if d is not None and self.world_size > 1:
+            if self._collectives_on:
                 gathered = [None] * self.world_size
                 d.all_gather_object(gathered, mine)
                 allparts = [p for chunk in gathered for p in chunk]
@@ -218,20 +229,27 @@ class HipJobExecutor(JobExecutor):
                     if i in entry:
                         self._apply_one(udfs[i], entry[i], task)
         # damage: with sharding every partition was processed by some rank
-        if d is not None and self.world_size > 1:
+        if self._collectives_on:
             for task in self._all_tasks:
                 damage.get_view_for_partition(task.partition)[:] = True
         if self._stream is not None:
             self._stream.synchronize()
 
     def _to_host(self, t):
-        """ONE D2H per buffer and run, through a pinned bounce buffer, on the executor stream."""
+        """ONE D2H per buffer and run, through a cached pinned bounce buffer, on the executor
+        stream; the result is copied out of the bounce buffer so callers own their array."""
         import torch
-        with torch.cuda.device(self.gpu_id), torch.cuda.stream(self._stream):
-            host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-            host.copy_(t, non_blocking=True)
-            self._stream.synchronize()
-        return host.numpy()
+        key = (tuple(t.shape), t.dtype)
+        pinned = self._pinned.get(key)
+        if pinned is None:
+            if len(self._pinned) > 8:
+                self._pinned.clear()
+            pinned = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            self._pinned[key] = pinned
+        with torch.cuda.stream(self._stream):
+            pinned.copy_(t, non_blocking=True)
+        self._stream.synchronize()
+        return pinned.numpy().copy()
 
     @staticmethod
     def _apply_one(udf, results, task):
@@ -249,10 +267,14 @@ class HipJobExecutor(JobExecutor):
                 part = results.get_buffer(name)._data
                 if not isinstance(part, HipArray):
                     part = HipArray.from_numpy(np.asarray(part), self.gpu_id)
+                pt = part.torch.reshape(part.shape)
                 if name not in full:
+                    if how == 'disjoint' and tuple(part.shape) == tuple(buf_main.shape):
+                        # one partition covers the whole buffer: adopt it, no zero-fill, no copy
+                        full[name] = pt
+                        continue
                     full[name] = torch.zeros(buf_main.shape, dtype=torch_dtype_for(buf_main.dtype),
                                              device=f'cuda:{self.gpu_id}')
-                pt = part.torch.reshape(part.shape)
                 if how == 'disjoint':
                     start, stop = buf_main._slice_for_partition(task.partition)
                     full[name][start:stop].copy_(pt.reshape(full[name][start:stop].shape))

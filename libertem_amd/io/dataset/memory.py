@@ -39,6 +39,7 @@ class MemoryDataSet(DataSet):
         if io_backend is not None:
             raise ValueError("MemoryDataSet currently doesn't support alternative I/O backends")
         self._device_array = None
+        self._partitions = None
         if isinstance(data, HipArray):
             self._device_array = data
             self._data = None
@@ -147,9 +148,12 @@ class MemoryDataSet(DataSet):
         return self._device_array.reshape((prod(self._shape.nav),) + tuple(self._shape.sig))
 
     def get_partitions(self):
-        for idx, (part_slice, start, stop) in enumerate(self.get_slices()):
-            yield MemPartition(dataset=self, meta=self._meta, partition_slice=part_slice, idx=idx,
-                               start_frame=start, num_frames=stop - start)
+        if self._partitions is None:
+            self._partitions = [
+                MemPartition(dataset=self, meta=self._meta, partition_slice=part_slice, idx=idx,
+                             start_frame=start, num_frames=stop - start)
+                for idx, (part_slice, start, stop) in enumerate(self.get_slices())]
+        yield from self._partitions
 
     def __repr__(self):
         where = 'HBM' if self.is_device_resident else 'host'
