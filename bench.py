@@ -145,8 +145,9 @@ def main():
     masks = np.random.default_rng(2).random((cfg['n_masks'],) + det).astype(np.float32)
 
     ctx = Context.make_with('hip', gpus=local_rank)
+    # one global dataset of world x (scan) frames; every rank holds its own contiguous block
     ds = ctx.load('memory', data=frames, dtype=np.dtype(cfg['dtype']), sig_dims=2,
-                  num_partitions=1)
+                  num_partitions=1, shard=(rank, world) if use_dist else None)
     udf = ApplyMasksUDF(mask_factories=lambda: masks, use_sparse=False,
                         mask_count=cfg['n_masks'], mask_dtype=np.float32)
 
@@ -158,7 +159,7 @@ def main():
     # size-independent property check of the full-size run: with an all-ones mask the result is
     # the per-frame sum; verify linearity  apply(m1 + m2) == apply(m1) + apply(m2)  on the fly
     got = res['intensity'].data
-    assert got.shape == scan + (cfg['n_masks'],) and got.dtype == np.float32
+    assert got.shape == (scan[0] * world, scan[1], cfg['n_masks']) and got.dtype == np.float32
     assert np.all(np.isfinite(got))
 
     def barrier():

@@ -32,7 +32,7 @@ class MemoryDataSet(DataSet):
     def __init__(self, tileshape=None, num_partitions=None, data=None, sig_dims=None,
                  check_cast=True, tiledelay=None, datashape=None, base_shape=None,
                  force_need_decode=False, io_backend=None, nav_shape=None, sig_shape=None,
-                 sync_offset=0, array_backends=None, dtype=None):
+                 sync_offset=0, array_backends=None, dtype=None, shard=None):
         super().__init__()
         if data is None:
             raise DataSetException("MemoryDataSet needs data")
@@ -55,6 +55,15 @@ class MemoryDataSet(DataSet):
             self._data = np.asarray(data)
         full_shape = tuple(self._device_array.shape if self._device_array is not None
                            else self._data.shape)
+        # shard=(rank, world): `data` is this rank's contiguous block of a larger dataset whose
+        # first nav axis is `world` times longer (one process per GPU, torch.distributed);
+        # partitions of other ranks exist (for planning / result shapes) but hold no data here.
+        self._shard = None
+        if shard is not None:
+            rank, world = int(shard[0]), int(shard[1])
+            if not (0 <= rank < world):
+                raise DataSetException(f"invalid shard {shard}")
+            self._shard = (rank, world)
         if sig_dims is None and sig_shape is None:
             sig_dims = 2
         if sig_shape is not None:
@@ -70,6 +79,9 @@ class MemoryDataSet(DataSet):
             full_shape = tuple(nav_s) + tuple(sig_s)
         if len(full_shape) <= sig_dims:
             raise DataSetException("data must have at least one navigation dimension")
+        self._local_shape = Shape(full_shape, sig_dims=sig_dims)
+        if self._shard is not None:
+            full_shape = (full_shape[0] * self._shard[1],) + tuple(full_shape[1:])
         self._shape = Shape(full_shape, sig_dims=sig_dims)
         if tileshape is not None:
             tileshape = tuple(tileshape)
@@ -119,7 +131,21 @@ class MemoryDataSet(DataSet):
         return self
 
     def get_num_partitions(self):
+        if self._shard is not None:
+            return self.num_partitions * self._shard[1]
         return self.num_partitions
+
+    @property
+    def shard(self):
+        return self._shard
+
+    @property
+    def local_frame_range(self):
+        """[start, stop) of the frames (flattened global nav) whose data this process holds."""
+        n_local = prod(self._local_shape.nav)
+        if self._shard is None:
+            return 0, n_local
+        return self._shard[0] * n_local, (self._shard[0] + 1) * n_local
 
     def get_base_shape(self, roi):
         if self.tileshape is not None:
@@ -142,10 +168,11 @@ class MemoryDataSet(DataSet):
         return super().need_decode(read_dtype, roi)
 
     def flat_host(self):
-        return self._data.reshape((prod(self._shape.nav),) + tuple(self._shape.sig))
+        return self._data.reshape((prod(self._local_shape.nav),) + tuple(self._shape.sig))
 
     def flat_device(self):
-        return self._device_array.reshape((prod(self._shape.nav),) + tuple(self._shape.sig))
+        return self._device_array.reshape((prod(self._local_shape.nav),) +
+                                          tuple(self._shape.sig))
 
     def get_partitions(self):
         if self._partitions is None:
@@ -261,6 +288,8 @@ class MemPartition(Partition):
         super().__init__(meta=meta, partition_slice=partition_slice, idx=idx)
         self._ds = dataset
         self._start_frame = start_frame
+        # index of the partition's first frame inside THIS process's data block
+        self._local0 = start_frame - dataset.local_frame_range[0]
         self._num_frames = num_frames
 
     def _roi_indices(self, roi):
@@ -268,11 +297,16 @@ class MemPartition(Partition):
             return None
         roi_part = np.asarray(roi).reshape(-1)[self._start_frame:
                                                self._start_frame + self._num_frames]
-        return np.flatnonzero(roi_part) + self._start_frame
+        return np.flatnonzero(roi_part) + self._local0
 
     def get_tiles(self, tiling_scheme, dest_dtype="float32", roi=None, array_backend=NUMPY,
                   env=None):
         ds = self._ds
+        lo, hi = ds.local_frame_range
+        if not (lo <= self._start_frame and self._start_frame + self._num_frames <= hi):
+            raise RuntimeError(
+                f"partition {self._idx} (frames {self._start_frame}..+{self._num_frames}) is not "
+                f"held by this process (shard {ds.shard} holds frames {lo}..{hi})")
         if ds.tileshape is not None:
             # a forced tileshape always wins (reference memory.py:427-445)
             tiling_scheme = TilingScheme.make_for_shape(
@@ -304,7 +338,7 @@ class MemPartition(Partition):
             for scheme_idx, sig_slice in tiling_scheme.slices:
                 sig_sl = sig_slice.get(sig_only=True)
                 if idxs is None:
-                    block = flat[(slice(self._start_frame + g0, self._start_frame + g1),) + sig_sl]
+                    block = flat[(slice(self._local0 + g0, self._local0 + g1),) + sig_sl]
                 else:
                     block = flat[idxs[g0:g1]][(slice(None),) + sig_sl]
                 if block.dtype != dest_dtype or not block.flags.c_contiguous:
@@ -359,7 +393,7 @@ class MemPartition(Partition):
                 flat = HipArray(gathered, (n,) + tuple(ds.shape.sig), flat.dtype)
                 base = 0
             else:
-                base = self._start_frame
+                base = self._local0
             for g0 in range(0, n, depth):
                 g1 = min(n, g0 + depth)
                 chunk = flat.rows(base + g0, base + g1)
@@ -367,7 +401,7 @@ class MemPartition(Partition):
             return
         # host data: double-buffered upload, chunk i+1 in flight while chunk i is processed
         host = ds.flat_host()
-        part_host = host[self._start_frame:self._start_frame + self._num_frames]
+        part_host = host[self._local0:self._local0 + self._num_frames]
         stager = _HipStager(device, min(depth, n), ds.shape.sig, ds.dtype,
                             host_array=part_host if idxs is None else None)
 

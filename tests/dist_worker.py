@@ -76,7 +76,14 @@ def main():
     r1, r2, r3 = ctx.run_udf(dataset=ds, udf=[MasksDeclared(masks), SumDeclared(), MaxGeneric()])
     my_parts = np.array([t.idx for t in ex.my_tasks(ex._all_tasks)])
     r1_roi = ctx.run_udf(dataset=ds, udf=MasksDeclared(masks), roi=roi)
+    # sharded dataset: every rank holds only its block of the first nav axis (bench.py's layout)
+    full = rng.integers(0, 100, (world * 3, 5, 16, 16)).astype(np.uint16)
+    local = full[rank * 3:(rank + 1) * 3]
+    ds_sh = ctx.load('memory', data=local, shard=(rank, world), num_partitions=2, sig_dims=2)
+    assert tuple(ds_sh.shape) == (world * 3, 5, 16, 16)
+    rs1, rs2 = ctx.run_udf(dataset=ds_sh, udf=[MasksDeclared(masks), SumDeclared()])
     np.savez(os.path.join(out_dir, f'rank{rank}.npz'),
+             sh_masks=rs1['intensity'].data, sh_sum=rs2['intensity'].data, sh_full=full,
              masks=r1['intensity'].data, sum=r2['intensity'].data, mx=r3['mx'].data,
              per_frame=r3['per_frame'].data, masks_roi=r1_roi['intensity'].data,
              my_parts=my_parts)

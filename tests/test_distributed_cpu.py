@@ -55,6 +55,11 @@ def test_gloo_sharded_run(tmp_path, world):
         assert np.allclose(o['masks_roi'][roi], exp_masks[roi], rtol=1e-6)
         assert np.all(np.isnan(o['masks_roi'][~roi]))
         all_parts.extend(o['my_parts'].tolist())
+        # sharded dataset: gathered nav result / reduced sig result == single-process values
+        full = o['sh_full']
+        exp = (full.reshape((-1, 256)).astype(np.float32) @ masks.reshape((3, -1)).T)
+        assert np.allclose(o['sh_masks'], exp.reshape(full.shape[:2] + (3,)), rtol=1e-6)
+        assert np.array_equal(o['sh_sum'], full.astype(np.float32).sum(axis=(0, 1)))
     # identical on every rank
     for o in outs[1:]:
         for k in ('masks', 'sum', 'mx', 'per_frame'):
