@@ -236,20 +236,15 @@ class HipJobExecutor(JobExecutor):
             self._stream.synchronize()
 
     def _to_host(self, t):
-        """ONE D2H per buffer and run, through a cached pinned bounce buffer, on the executor
-        stream; the result is copied out of the bounce buffer so callers own their array."""
+        """ONE D2H per buffer and run into page-locked memory, on the executor stream.  A fresh
+        pinned tensor per result (torch's caching host allocator recycles the blocks), so the
+        returned array is owned by the caller and no host-side copy is needed."""
         import torch
-        key = (tuple(t.shape), t.dtype)
-        pinned = self._pinned.get(key)
-        if pinned is None:
-            if len(self._pinned) > 8:
-                self._pinned.clear()
-            pinned = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-            self._pinned[key] = pinned
+        pinned = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
         with torch.cuda.stream(self._stream):
             pinned.copy_(t, non_blocking=True)
         self._stream.synchronize()
-        return pinned.numpy().copy()
+        return pinned.numpy()
 
     @staticmethod
     def _apply_one(udf, results, task):
