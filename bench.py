@@ -77,9 +77,10 @@ def cpu_baseline(cfg, budget_s=12.0):
     ctx = mp.get_context('fork')
     with ctx.Pool(cores) as pool:
         # calibrate with one pass, then size the run to ~budget_s
+        # (worker start-up skew -- importing torch in 100+ processes -- must not count)
         res = pool.map(_cpu_worker, [(cfg, n_frames, 1, 100 + i) for i in range(cores)])
-        t1 = max(r[2] for r in res) - min(r[1] for r in res)
-        passes = int(max(1, min(200, budget_s / max(t1, 1e-3))))
+        t1 = float(np.median([r[2] - r[1] for r in res]))
+        passes = int(max(1, min(400, budget_s / max(t1, 1e-3))))
         res = pool.map(_cpu_worker, [(cfg, n_frames, passes, 100 + i) for i in range(cores)])
     total = sum(r[0] for r in res)
     wall = max(r[2] for r in res) - min(r[1] for r in res)
