@@ -14,8 +14,9 @@
 //     (one per lane) share a slice whose length is the longest of them inside the chunk; entry j
 //     of the slice is a coalesced 64-lane row of (local pixel, value).  Lanes keep 16 (x masks
 //     per thread) accumulators in registers for the whole sweep -- no atomics, deterministic.
-//   * masks are dealt to the 4 waves round-robin (mask k -> wave k % 4) so that localised stacks
-//     (rings: only a band of radii is present in any pixel chunk) load all waves evenly.
+//   * 64 consecutive masks share a slice (one wave): neighbouring masks of localised stacks (rings)
+//     have similar entry counts inside a pixel chunk, which keeps the ELL padding low
+//     (C4: 11 368 rows vs 20 020 when masks are dealt round-robin to the waves).
 //   * the 16-B quarter q of a slab row is stored at q ^ ((p >> 2) & 3): without it only p % 4
 //     selects the LDS slot of a ds_read_b128 and random gathers are >= 4-way conflicted.
 //
@@ -24,6 +25,7 @@
 #include <vector>
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
 #include <type_traits>
 #include <typeinfo>
 
@@ -49,6 +51,8 @@ struct CsrImage {
     int *row_off = nullptr;     // [(pass * n_chunks + chunk) * mpt * 4 + slot * 4 + wave]
     int *row_len = nullptr;
     size_t n_rows = 0;
+    int *active = nullptr;      // chunks with entries, concatenated per pass
+    int *active_off = nullptr;  // [n_pass + 1]
 };
 
 __device__ __forceinline__ int slab_word(int p, int f) {
@@ -101,8 +105,10 @@ template <typename T, int MPT, bool CPLX>
 __global__ void __launch_bounds__(SP_NT)
 k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
              const uint32_t *__restrict__ pix, const float *__restrict__ val,
-             const int *__restrict__ row_off, const int *__restrict__ row_len, int n_chunks,
-             float *__restrict__ out, int64_t ld_out, int n_masks, int accumulate, int vec_ok) {
+             const int *__restrict__ row_off, const int *__restrict__ row_len,
+             const int *__restrict__ active, const int *__restrict__ active_off, int n_chunks,
+             float *__restrict__ out, int64_t ld_out, int n_masks, int accumulate, int vec_ok,
+             int ablate) {
     extern __shared__ __attribute__((aligned(16))) float slab[];     // [SP_P][SP_F]
     constexpr int NC = CPLX ? 2 : 1;
     const int tid = threadIdx.x;
@@ -125,16 +131,13 @@ k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
 #pragma unroll
             for (int c = 0; c < NC; ++c) acc[i][f][c] = 0.f;
 
-    for (int ch = 0; ch < n_chunks; ++ch) {
-        // does any slice of this (pass, chunk) hold entries for this wave? (wave-uniform)
-        const int *lens = row_len + ((int64_t)(pass * n_chunks + ch) * MPT) * 4;
-        const int *offs = row_off + ((int64_t)(pass * n_chunks + ch) * MPT) * 4;
-        int any = 0;
-#pragma unroll
-        for (int i = 0; i < MPT * 4; ++i) any |= lens[i];
-        if (any == 0) continue;                      // nothing in this chunk for the whole block
+    for (int ai = active_off[pass]; ai < active_off[pass + 1]; ++ai) {
+        const int ch = active[ai];
+        const int *lens = row_len + (int64_t)ai * (MPT * 4);
+        const int *offs = row_off + (int64_t)ai * (MPT * 4);
 
         __syncthreads();                             // previous chunk fully consumed
+        if (ablate != 2)
 #pragma unroll
         for (int it = 0; it < SP_P / 128; ++it) {
             const int pl = it * 128 + lg * 8;
@@ -145,6 +148,7 @@ k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
         }
         __syncthreads();
 
+        if (ablate != 1)
 #pragma unroll
         for (int i = 0; i < MPT; ++i) {
             const int len = lens[i * 4 + wave];
@@ -196,7 +200,7 @@ k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
     // mask of (slot i, wave, lane): k = pass*MB + i*256 + lane*4 + wave
 #pragma unroll
     for (int i = 0; i < MPT; ++i) {
-        const int k = pass * (256 * MPT) + i * 256 + lane * 4 + wave;
+        const int k = pass * (256 * MPT) + i * 256 + wave * 64 + lane;
         if (k >= n_masks) continue;
 #pragma unroll
         for (int f = 0; f < SP_F; ++f) {
@@ -204,6 +208,186 @@ k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
             float *o = out + (f0 + f) * ld_out + (int64_t)k * NC;
 #pragma unroll
             for (int c = 0; c < NC; ++c) o[c] = accumulate ? o[c] + acc[i][f][c] : acc[i][f][c];
+        }
+    }
+}
+
+// ---- v2 for 2-byte pixels: raw u16 slab, double buffered ------------------------------------------
+// Ablation of the first kernel (profiles/r01_sparse_ablation.txt): loader 0.70 ms + gathers 0.98 ms
+// = 1.60 ms total for 16384 C4 frames -- no overlap, and both phases bound by LDS instruction
+// count.  This version
+//   * keeps the slab in the frames' own 16-bit format: a pixel row is 16 frames x 2 B = 32 B, so an
+//     entry needs 2 ds_read_b128 instead of 4, and a loader lane packs the same pixel of TWO frames
+//     into one 32-bit word (half as many ds_write_b32);
+//   * pads 32 B after every 8 pixel rows so the loader's writes are conflict-free
+//     (row of pixel p at (p + p/8) * 32 B);
+//   * double-buffers the slab: while a chunk is gathered, the next chunk (already in registers) is
+//     written to the other buffer and the one after that is requested from HBM; one barrier per
+//     chunk;  chunks without entries for the block's masks are skipped through a host-built list.
+constexpr int SP2_ROWB = 32;                                   // bytes per pixel row (16 frames)
+constexpr int SP2_SLAB = (SP_P + SP_P / 8) * SP2_ROWB;         // 36 KiB
+
+// NW waves, ONE 64-mask slice per wave (masks per pass = NW * 64): a pixel chunk of a localised
+// stack touches only a few slices; with one slice per wave the critical path of a chunk is its
+// longest slice (C4: 3320 rows per 16 frames) instead of the busiest of 4 waves x 4 slices (4584).
+template <typename T, int NW, bool CPLX>
+__global__ void __launch_bounds__(NW * 64)
+k_sell_apply2(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
+              const uint32_t *__restrict__ pix, const float *__restrict__ val,
+              const int *__restrict__ row_off, const int *__restrict__ row_len,
+              const int *__restrict__ active, const int *__restrict__ active_off, int n_chunks,
+              float *__restrict__ out, int64_t ld_out, int n_masks, int accumulate) {
+    static_assert(sizeof(T) == 2, "2-byte pixels");
+    extern __shared__ __attribute__((aligned(16))) unsigned char slab_raw[];   // 2 x SP2_SLAB
+    constexpr int NC = CPLX ? 2 : 1;
+    constexpr int NT = NW * 64;
+    constexpr int STEPS = (SP_P * 8) / (NT * 8);         // (px * frame pairs) / (threads * 8 px)
+    static_assert(STEPS >= 1 && STEPS * NT * 8 == SP_P * 8, "loader tiling");
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int pass = blockIdx.y;
+    const int64_t f0 = (int64_t)blockIdx.x * SP_F;
+
+    // loader role: frame pair fp (frames 2fp, 2fp+1), pixel group g (8 px)
+    const int fp = tid & 7, g = tid >> 3;
+    const T *rowA, *rowB;
+    {
+        int64_t fa = f0 + 2 * fp, fb = f0 + 2 * fp + 1;
+        if (fa > n_frames - 1) fa = n_frames - 1;
+        if (fb > n_frames - 1) fb = n_frames - 1;
+        rowA = tile + fa * ld;
+        rowB = tile + fb * ld;
+    }
+
+    float acc[SP_F][NC];
+#pragma unroll
+    for (int f = 0; f < SP_F; ++f)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[f][c] = 0.f;
+
+    const int a0 = active_off[pass], a1 = active_off[pass + 1];      // active chunk list
+    u32x4 ra[STEPS], rb[STEPS];
+    auto fetch_chunk = [&](int ch) {
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            const int64_t p0 = (int64_t)ch * SP_P + st * (NT / 8) * 8 + g * 8;
+            if (p0 + 8 <= n_px) {
+                ra[st] = __builtin_nontemporal_load((const u32x4 *)(rowA + p0));
+                rb[st] = __builtin_nontemporal_load((const u32x4 *)(rowB + p0));
+            } else {
+                unsigned short ta[8], tb[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    ta[j] = (p0 + j < n_px) ? (unsigned short)rowA[p0 + j] : (unsigned short)0;
+                    tb[j] = (p0 + j < n_px) ? (unsigned short)rowB[p0 + j] : (unsigned short)0;
+                }
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    ra[st][w] = (unsigned)ta[2 * w] | ((unsigned)ta[2 * w + 1] << 16);
+                    rb[st][w] = (unsigned)tb[2 * w] | ((unsigned)tb[2 * w + 1] << 16);
+                }
+            }
+        }
+    };
+    auto store_chunk = [&](unsigned char *slab) {
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            const int pl = st * (NT / 8) * 8 + g * 8;        // first local pixel of this lane
+            unsigned *dst = (unsigned *)(slab + (pl + (pl >> 3)) * SP2_ROWB) + fp;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const unsigned a = ra[st][w], b = rb[st][w];
+                dst[(2 * w) * (SP2_ROWB / 4)] = (a & 0xffffu) | (b << 16);          // px 2w
+                dst[(2 * w + 1) * (SP2_ROWB / 4)] = (a >> 16) | (b & 0xffff0000u);  // px 2w+1
+            }
+        }
+    };
+
+    // this wave's entry stream: the rows of its slice over all active chunks are contiguous; three
+    // groups of SP_U rows are kept in flight (L2 latency ~ 2 groups of work)
+    uint32_t g0p[SP_U], g1p[SP_U], g2p[SP_U];
+    float g0r[SP_U], g1r[SP_U], g2r[SP_U], g0i[SP_U], g1i[SP_U], g2i[SP_U];
+    const int64_t sbase = (a0 < a1) ? (int64_t)row_off[a0 * NW + wave] * 64 + lane : lane;
+    auto fetch_group = [&](int t, uint32_t (&gp)[SP_U], float (&gr)[SP_U], float (&gi)[SP_U]) {
+        // rows past the end of the stream are zero padding of the image (host adds slack)
+#pragma unroll
+        for (int u = 0; u < SP_U; ++u) {
+            const int64_t e = sbase + (int64_t)(t + u) * 64;
+            gp[u] = pix[e];
+            if (CPLX) {
+                const float2 v2 = ((const float2 *)val)[e];
+                gr[u] = v2.x;
+                gi[u] = v2.y;
+            } else {
+                gr[u] = val[e];
+                gi[u] = 0.f;
+            }
+        }
+    };
+    int t_fetch = 2 * SP_U;
+
+    if (a0 < a1) {
+        fetch_group(0, g0p, g0r, g0i);
+        fetch_group(SP_U, g1p, g1r, g1i);
+        fetch_group(2 * SP_U, g2p, g2r, g2i);
+        fetch_chunk(active[a0]);
+        store_chunk(slab_raw);
+        if (a0 + 1 < a1) fetch_chunk(active[a0 + 1]);
+        __syncthreads();
+        for (int ai = a0; ai < a1; ++ai) {
+            unsigned char *cur = slab_raw + ((ai - a0) & 1) * SP2_SLAB;
+            unsigned char *nxt = slab_raw + (((ai - a0) & 1) ^ 1) * SP2_SLAB;
+            if (ai + 1 < a1) store_chunk(nxt);               // registers hold chunk ai+1
+            if (ai + 2 < a1) fetch_chunk(active[ai + 2]);
+            const int len = row_len[ai * NW + wave];
+            for (int j = 0; j < len; j += SP_U) {
+                // process group g0 from the current slab, rotate, fetch two groups ahead
+#pragma unroll
+                for (int u = 0; u < SP_U; ++u) {
+                    const unsigned char *rowp = cur + (g0p[u] + (g0p[u] >> 3)) * SP2_ROWB;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const u32x4 x = *(const u32x4 *)(rowp + h * 16);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float lo, hi;
+                            if (std::is_signed<T>::value) {
+                                lo = (float)((int)(x[e] << 16) >> 16);
+                                hi = (float)((int)x[e] >> 16);
+                            } else {
+                                lo = (float)(x[e] & 0xffffu);
+                                hi = (float)(x[e] >> 16);
+                            }
+                            acc[h * 8 + 2 * e][0] += lo * g0r[u];
+                            acc[h * 8 + 2 * e + 1][0] += hi * g0r[u];
+                            if (CPLX) {
+                                acc[h * 8 + 2 * e][1] += lo * g0i[u];
+                                acc[h * 8 + 2 * e + 1][1] += hi * g0i[u];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < SP_U; ++u) {
+                    g0p[u] = g1p[u]; g0r[u] = g1r[u]; g0i[u] = g1i[u];
+                    g1p[u] = g2p[u]; g1r[u] = g2r[u]; g1i[u] = g2i[u];
+                }
+                t_fetch += SP_U;
+                fetch_group(t_fetch, g2p, g2r, g2i);
+            }
+            __syncthreads();
+        }
+    }
+
+    const int k = pass * (NW * 64) + wave * 64 + lane;
+    if (k < n_masks) {
+#pragma unroll
+        for (int f = 0; f < SP_F; ++f) {
+            if (f0 + f >= n_frames) break;
+            float *o = out + (f0 + f) * ld_out + (int64_t)k * NC;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) o[c] = accumulate ? o[c] + acc[f][c] : acc[f][c];
         }
     }
 }
@@ -221,6 +405,8 @@ int csr_destroy(ltmi_masks *m) {
     if (c->val) (void)hipFree(c->val);
     if (c->row_off) (void)hipFree(c->row_off);
     if (c->row_len) (void)hipFree(c->row_len);
+    if (c->active) (void)hipFree(c->active);
+    if (c->active_off) (void)hipFree(c->active_off);
     delete c;
     m->csr = nullptr;
     return LTMI_OK;
@@ -230,7 +416,39 @@ template <typename T>
 static int launch_sell(ltmi_masks *m, CsrImage *c, const T *tile, int64_t n_frames, int64_t ld,
                        float *out, int64_t ld_out_f, int accumulate, hipStream_t stream) {
     const int vec_ok = (((uintptr_t)tile) % 16 == 0) && ((ld * (int64_t)sizeof(T)) % 16 == 0);
+    const char *abl = getenv("LTMI_SELL_ABLATE");     // 1: loader only, 2: gathers only (bench)
+    const int ablate = abl ? atoi(abl) : 0;
     dim3 grid((unsigned)((n_frames + SP_F - 1) / SP_F), (unsigned)c->n_pass);
+    if constexpr (sizeof(T) == 2) {
+        // experimental (round 1: not faster than k_sell_apply -- every wave's entry stream queues
+        // behind its own HBM frame loads on the in-order vmcnt; needs dedicated loader waves)
+        if (vec_ok && getenv("LTMI_SELL_V2")) {
+            const size_t lds2 = 2 * SP2_SLAB;
+            void (*k2)(const T *, int64_t, int64_t, int64_t, const uint32_t *, const float *,
+                       const int *, const int *, const int *, const int *, int, float *, int64_t,
+                       int, int);
+            if (c->cplx) k2 = k_sell_apply2<T, 8, true>;
+            else k2 = k_sell_apply2<T, 16, false>;
+            const int nthreads = c->cplx ? 8 * 64 : 16 * 64;
+            static bool set2[16][2] = {{false}};
+            if (!set2[m->device & 15][c->cplx]) {
+                LTMI_HIP(hipFuncSetAttribute((const void *)k2,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)lds2));
+                set2[m->device & 15][c->cplx] = true;
+            }
+            hipLaunchKernelGGL(k2, grid, dim3(nthreads), lds2, stream, tile, ld, n_frames, m->n_px,
+                               (const uint32_t *)c->pix, (const float *)c->val,
+                               (const int *)c->row_off, (const int *)c->row_len,
+                               (const int *)c->active, (const int *)c->active_off, c->n_chunks, out,
+                               ld_out_f, (int)m->n_masks, accumulate);
+            LTMI_HIP(hipGetLastError());
+            snprintf(m->last_kernel, sizeof(m->last_kernel),
+                     "k_sell_apply2<%s,%s> grid=(%u,%u) rows=%zu", typeid(T).name(),
+                     c->cplx ? "c64" : "f32", grid.x, grid.y, c->n_rows);
+            return LTMI_OK;
+        }
+    }
     const size_t lds = (size_t)SP_P * SP_F * sizeof(float);
     if (c->cplx) {
         auto kern = k_sell_apply<T, 2, true>;
@@ -242,8 +460,8 @@ static int launch_sell(ltmi_masks *m, CsrImage *c, const T *tile, int64_t n_fram
         }
         hipLaunchKernelGGL(kern, grid, dim3(SP_NT), lds, stream, tile, ld, n_frames, m->n_px,
                            (const uint32_t *)c->pix, (const float *)c->val, (const int *)c->row_off,
-                           (const int *)c->row_len, c->n_chunks, out, ld_out_f, (int)m->n_masks,
-                           accumulate, vec_ok);
+                           (const int *)c->row_len, (const int *)c->active, (const int *)c->active_off,
+                           c->n_chunks, out, ld_out_f, (int)m->n_masks, accumulate, vec_ok, ablate);
     } else {
         auto kern = k_sell_apply<T, 4, false>;
         static bool set[16] = {false};
@@ -254,8 +472,8 @@ static int launch_sell(ltmi_masks *m, CsrImage *c, const T *tile, int64_t n_fram
         }
         hipLaunchKernelGGL(kern, grid, dim3(SP_NT), lds, stream, tile, ld, n_frames, m->n_px,
                            (const uint32_t *)c->pix, (const float *)c->val, (const int *)c->row_off,
-                           (const int *)c->row_len, c->n_chunks, out, ld_out_f, (int)m->n_masks,
-                           accumulate, vec_ok);
+                           (const int *)c->row_len, (const int *)c->active, (const int *)c->active_off,
+                           c->n_chunks, out, ld_out_f, (int)m->n_masks, accumulate, vec_ok, ablate);
     }
     LTMI_HIP(hipGetLastError());
     snprintf(m->last_kernel, sizeof(m->last_kernel), "k_sell_apply<%s,%s> grid=(%u,%u) rows=%zu",
@@ -328,45 +546,78 @@ extern "C" int ltmi_masks_create_csr(int device, const int64_t *indptr, const in
             for (int64_t e = indptr[p]; e < indptr[p + 1]; ++e)
                 cnt[(size_t)ch * n_masks + indices[e]]++;
         }
-        std::vector<int> row_len(n_slices, 0), row_off(n_slices, 0);
-        auto slice_of = [&](int64_t k, int ch) -> size_t {
-            const int pass = (int)(k / c->mb);
-            const int r = (int)(k % c->mb);
-            const int slot = r / 256, wave = r % 4;
-            return (((size_t)pass * c->n_chunks + ch) * c->mpt + slot) * 4 + wave;
-        };
+        const int NWS = c->mpt * 4;                       // slices (64 masks each) per pass
+        auto slice_of = [&](int64_t k) -> int { return (int)((k % c->mb) / 64); };
+        // padded slice lengths per (pass, chunk, slice)
+        std::vector<int> len_full(n_slices, 0);
         for (int ch = 0; ch < c->n_chunks; ++ch)
             for (int64_t k = 0; k < n_masks; ++k) {
-                const size_t s = slice_of(k, ch);
-                row_len[s] = std::max(row_len[s], cnt[(size_t)ch * n_masks + k]);
+                const size_t s = ((size_t)(k / c->mb) * c->n_chunks + ch) * NWS + slice_of(k);
+                len_full[s] = std::max(len_full[s], cnt[(size_t)ch * n_masks + k]);
             }
-        for (size_t s = 0; s < n_slices; ++s) row_len[s] = (row_len[s] + SP_U - 1) / SP_U * SP_U;
+        for (size_t s = 0; s < n_slices; ++s) len_full[s] = (len_full[s] + SP_U - 1) / SP_U * SP_U;
+        // active chunks per pass
+        std::vector<int> active, active_off(c->n_pass + 1, 0);
+        for (int ps = 0; ps < c->n_pass; ++ps) {
+            for (int ch = 0; ch < c->n_chunks; ++ch) {
+                int any = 0;
+                for (int q = 0; q < NWS; ++q)
+                    any |= len_full[((size_t)ps * c->n_chunks + ch) * NWS + q];
+                if (any) active.push_back(ch);
+            }
+            active_off[ps + 1] = (int)active.size();
+        }
+        // row tables indexed by (active index, slice); a slice's rows of consecutive active
+        // chunks are CONTIGUOUS in the row arrays (one stream per (pass, slice)), so a wave can
+        // prefetch entries across chunk boundaries
+        const size_t n_tab = std::max<size_t>(active.size(), 1) * NWS;
+        std::vector<int> row_len(n_tab, 0), row_off(n_tab, 0);
         size_t rows = 0;
-        for (size_t s = 0; s < n_slices; ++s) { row_off[s] = (int)rows; rows += row_len[s]; }
+        for (int ps = 0; ps < c->n_pass; ++ps)
+            for (int q = 0; q < NWS; ++q)
+                for (int ai = active_off[ps]; ai < active_off[ps + 1]; ++ai) {
+                    const int ch = active[ai];
+                    const int l = len_full[((size_t)ps * c->n_chunks + ch) * NWS + q];
+                    row_len[(size_t)ai * NWS + q] = l;
+                    row_off[(size_t)ai * NWS + q] = (int)rows;
+                    rows += l;
+                }
         c->n_rows = rows;
-        std::vector<uint32_t> pix(std::max<size_t>(rows, 1) * 64, 0u);
-        std::vector<float> val(std::max<size_t>(rows, 1) * 64 * nc, 0.f);
+        // chunk -> active index (per pass)
+        std::vector<int> ai_of((size_t)c->n_pass * c->n_chunks, -1);
+        for (int ps = 0; ps < c->n_pass; ++ps)
+            for (int ai = active_off[ps]; ai < active_off[ps + 1]; ++ai)
+                ai_of[(size_t)ps * c->n_chunks + active[ai]] = ai;
+        if (active.empty()) active.push_back(0);
+        std::vector<uint32_t> pix((rows + 4 * SP_U) * 64, 0u);     // + slack for clamped prefetch
+        std::vector<float> val((rows + 4 * SP_U) * 64 * nc, 0.f);
         std::vector<int> fill((size_t)c->n_chunks * n_masks, 0);
         for (int64_t p = 0; p < n_px; ++p) {
             const int ch = (int)(p / SP_P);
             for (int64_t e = indptr[p]; e < indptr[p + 1]; ++e) {
                 const int64_t k = indices[e];
-                const size_t s = slice_of(k, ch);
-                const int lane = (int)((k % 256) / 4);
+                const int ps = (int)(k / c->mb);
+                const int ai = ai_of[(size_t)ps * c->n_chunks + ch];
+                const int lane = (int)(k % 64);
                 const int j = fill[(size_t)ch * n_masks + k]++;
-                const size_t pos = ((size_t)row_off[s] + j) * 64 + lane;
+                const size_t pos = ((size_t)row_off[(size_t)ai * NWS + slice_of(k)] + j) * 64 + lane;
                 pix[pos] = (uint32_t)(p - (int64_t)ch * SP_P);
                 for (int q = 0; q < nc; ++q) val[pos * nc + q] = vals[e * nc + q];
             }
         }
+        const size_t n_slices_dev = n_tab;
         hipError_t e = hipMalloc((void **)&c->pix, pix.size() * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc((void **)&c->val, val.size() * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void **)&c->row_off, n_slices * sizeof(int));
-        if (e == hipSuccess) e = hipMalloc((void **)&c->row_len, n_slices * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&c->row_off, n_slices_dev * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&c->row_len, n_slices_dev * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&c->active, active.size() * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&c->active_off, active_off.size() * sizeof(int));
+        if (e == hipSuccess) e = hipMemcpy(c->active, active.data(), active.size() * sizeof(int), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(c->active_off, active_off.data(), active_off.size() * sizeof(int), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(c->pix, pix.data(), pix.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(c->val, val.data(), val.size() * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(c->row_off, row_off.data(), n_slices * sizeof(int), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(c->row_len, row_len.data(), n_slices * sizeof(int), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(c->row_off, row_off.data(), n_slices_dev * sizeof(int), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(c->row_len, row_len.data(), n_slices_dev * sizeof(int), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             ltmi::csr_destroy(m);
             delete m;
