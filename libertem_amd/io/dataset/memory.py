@@ -53,6 +53,10 @@ class MemoryDataSet(DataSet):
                 self._data = None
         else:
             self._data = np.asarray(data)
+        if self._data is not None and not self._data.dtype.isnative:
+            # device kernels read native byte order: swap once on the host (the reference converts
+            # per tile with astype(), io/dataset/memory.py:102-105)
+            self._data = self._data.astype(self._data.dtype.newbyteorder('='))
         full_shape = tuple(self._device_array.shape if self._device_array is not None
                            else self._data.shape)
         # shard=(rank, world): `data` is this rank's contiguous block of a larger dataset whose

@@ -348,3 +348,89 @@ def test_radial_fourier_sparse(ctx):
                                         use_sparse='scipy.sparse')
     assert _close(sparse.raw_results, dense.raw_results, F32_TOL)
     assert _close(sparse.raw_results, ref['raw_results'], F32_TOL)
+
+
+# --- mirrors of the reference's own mask tests (tests/analysis/test_analysis_masks.py) -----------
+def _naive_mask_apply(masks, data):
+    """per-frame dot products in float64/complex128 (idea of tests/utils.py:25-45)"""
+    out_dtype = np.result_type(*[m.dtype for m in masks], data.dtype, np.float64)
+    res = np.zeros((len(masks),) + tuple(data.shape[:2]), dtype=out_dtype)
+    for n, m in enumerate(masks):
+        res[n] = np.tensordot(data.astype(out_dtype), m.astype(out_dtype), axes=([2, 3], [0, 1]))
+    return res
+
+
+def _mk_random(size, dtype='float32', seed=0):
+    """0/1 valued data with two large outliers (tests/utils.py:48-78)"""
+    rng = np.random.default_rng(seed)
+    dtype = np.dtype(dtype)
+    data = (rng.random(size) > 0.5).astype(dtype)
+    flat = data.reshape(-1)
+    if dtype.kind in 'iu':
+        flat[rng.integers(0, flat.size, 2)] = min(np.iinfo(dtype).max, 2**15)
+    else:
+        flat[rng.integers(0, flat.size, 2)] = 2.0**20
+    return data
+
+
+@pytest.mark.parametrize('data_dtype,mask_dtype', [
+    ('<u2', 'uint16'),        # test_mask_uint  (:151-173)
+    ('>u2', 'float32'),       # test_endian     (:176-193)
+    ('<i4', 'float32'),       # test_signed     (:196-214)
+    ('>f4', 'float32'),
+])
+def test_reference_dtype_cases(ctx, data_dtype, mask_dtype):
+    rng = np.random.default_rng(3)
+    if np.dtype(data_dtype).kind == 'f':
+        data = rng.random((16, 16, 16, 16)).astype(data_dtype)
+    else:
+        data = rng.choice(a=0xFFFF, size=(16, 16, 16, 16)).astype(data_dtype)
+    mask = _mk_random((16, 16), seed=1).astype(mask_dtype)
+    expected = _naive_mask_apply([mask], data)
+    ds = ctx.load('memory', data=data, tileshape=(4 * 4, 4, 4), num_partitions=2, sig_dims=2)
+    analysis = ctx.create_mask_analysis(dataset=ds, factories=[lambda: mask])
+    res = ctx.run(analysis)
+    assert res.mask_0.raw_data.shape == (16, 16)
+    assert np.allclose(res.mask_0.raw_data, expected[0], rtol=1e-5)
+    # sparse flavour of the same program (reference _run_mask_test_program, do_sparse=True)
+    import scipy.sparse as sp
+    if np.dtype(mask_dtype).kind == 'f':
+        analysis = ctx.create_mask_analysis(dataset=ds, factories=[lambda: sp.csr_matrix(mask)],
+                                            use_sparse=True)
+        res = ctx.run(analysis)
+        assert np.allclose(res.mask_0.raw_data, expected[0], rtol=1e-5)
+
+
+def test_numerics_succeed(ctx):
+    """float64 mask_dtype on the highest expected resolution / dynamic range (:948-978)"""
+    RESOLUTION, RANGE, VAL = 4096, 1e6, 1.1
+    data = np.full((2, 1, RESOLUTION, RESOLUTION), VAL, dtype=np.float32)
+    data[0, 0, 0, 0] += VAL * RANGE
+    ds = ctx.load('memory', data=data, tileshape=(2, RESOLUTION, RESOLUTION), num_partitions=1,
+                  sig_dims=2)
+    mask0 = np.ones((RESOLUTION, RESOLUTION), dtype=np.float32)
+    analysis = ctx.create_mask_analysis(dataset=ds, factories=[lambda: mask0], mask_count=1,
+                                        mask_dtype='float64')
+    results = ctx.run(analysis)
+    expected = np.array([[[VAL * RESOLUTION**2 + VAL * RANGE], [VAL * RESOLUTION**2]]])
+    assert results.mask_0.raw_data.dtype == np.float64
+    assert np.allclose(expected[0], results.mask_0.raw_data)
+
+
+def test_numerics_float32_close_to_reference_path(ctx):
+    """float32 masks on the same data: the HIP result has to agree with the oracle's float32
+    CPU path to the north-star tolerance (both lose precision against the exact value; the
+    reference documents that in test_numerics_fail :909-945)."""
+    RESOLUTION, RANGE, VAL = 1024, 1e6, 1.1
+    data = np.full((2, 1, RESOLUTION, RESOLUTION), VAL, dtype=np.float32)
+    data[0, 0, 0, 0] += VAL * RANGE
+    mask0 = np.ones((RESOLUTION, RESOLUTION), dtype=np.float64)
+    ds = ctx.load('memory', data=data, num_partitions=1, sig_dims=2)
+    analysis = ctx.create_mask_analysis(dataset=ds, factories=[lambda: mask0], mask_count=1,
+                                        mask_dtype='float32')
+    got = ctx.run(analysis).mask_0.raw_data
+    ref = opath.apply_masks(data, mask0[np.newaxis], mask_dtype=np.float32)[..., 0]
+    exact = np.array([[VAL * RESOLUTION**2 + VAL * RANGE], [VAL * RESOLUTION**2]])
+    assert got.dtype == np.float32
+    assert np.allclose(got, ref, rtol=1e-5)
+    assert np.allclose(got, exact, rtol=1e-4)
