@@ -94,6 +94,16 @@ int ltmi_masks_kind(const ltmi_masks *m, int *kind);
 int ltmi_apply_masks(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames,
                      int64_t ld_tile, void *out, int64_t ld_out, int accumulate, void *stream);
 
+/* Shifted masks: out[f, k] (+)= sum over the overlap of frame[f][y, x] * mask_k[y - dy_f, x - dx_f]
+ * Replaces ApplyMasksEngine.process_frame_shifted (src/libertem/udf/masks.py:85-124), one call per
+ * tile instead of one per frame.  Dense handles only.  `shifts` is a DEVICE array of n_frames
+ * (dy, dx) int32 pairs; frames are (sig_h, sig_w) row-major, sig_h * sig_w == the handle's n_px.
+ * A positive dy moves the mask down relative to the frame; no overlap contributes 0.
+ */
+int ltmi_apply_masks_shifted(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames,
+                             int64_t ld_tile, int sig_h, int sig_w, const int32_t *shifts,
+                             void *out, int64_t ld_out, int accumulate, void *stream);
+
 /* ---- reductions -------------------------------------------------------------------------
  * SumUDF.process_tile: out[p] (+)= sum_f tile[f, p]        (src/libertem/udf/sum.py:43-48)
  *   out: device (n_px,) of out_dtype; `workspace` device scratch of at least

@@ -812,6 +812,49 @@ k_dense_generic(const TIn *__restrict__ tile, int64_t ld, int64_t n_frames, int6
         Store<S, A>::put(out + f * ld_out + k0 + threadIdx.x, red[threadIdx.x][0], accumulate != 0);
 }
 
+// shifted masks: block (256 threads) per (frame, group of 4 masks); threads walk the overlap region
+template <typename TIn, typename A, typename S>
+__global__ void __launch_bounds__(256)
+k_dense_shifted(const TIn *__restrict__ tile, int64_t ld, int sig_h, int sig_w,
+                const int32_t *__restrict__ shifts, const A *__restrict__ masks, int n_masks,
+                S *__restrict__ out, int64_t ld_out, int accumulate) {
+    __shared__ A red[GEN_MASKS][256];
+    const int64_t f = blockIdx.x;
+    const int k0 = blockIdx.y * GEN_MASKS;
+    const int nk = min(GEN_MASKS, n_masks - k0);
+    const int dy = shifts[2 * f], dx = shifts[2 * f + 1];
+    // frame rows [y0, y1) x cols [x0, x1) overlap the mask shifted by (dy, dx)
+    const int y0 = max(0, dy), y1 = min(sig_h, sig_h + dy);
+    const int x0 = max(0, dx), x1 = min(sig_w, sig_w + dx);
+    const int ow = max(0, x1 - x0), oh = max(0, y1 - y0);
+    const int64_t n_px = (int64_t)sig_h * sig_w;
+    A acc[GEN_MASKS];
+#pragma unroll
+    for (int k = 0; k < GEN_MASKS; ++k) acc[k] = AccOps<A>::zero();
+    const TIn *row = tile + f * ld;
+    for (int64_t i = threadIdx.x; i < (int64_t)ow * oh; i += 256) {
+        const int y = y0 + (int)(i / ow), x = x0 + (int)(i % ow);
+        const A v = Conv<A, TIn>::from(row[(int64_t)y * sig_w + x]);
+        const int64_t mp = (int64_t)(y - dy) * sig_w + (x - dx);
+#pragma unroll
+        for (int k = 0; k < GEN_MASKS; ++k)
+            if (k < nk) AccOps<A>::fma(acc[k], v, masks[(int64_t)(k0 + k) * n_px + mp]);
+    }
+#pragma unroll
+    for (int k = 0; k < GEN_MASKS; ++k) red[k][threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+#pragma unroll
+            for (int k = 0; k < GEN_MASKS; ++k)
+                red[k][threadIdx.x] = AccOps<A>::add(red[k][threadIdx.x], red[k][threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if ((int)threadIdx.x < nk)
+        Store<S, A>::put(out + f * ld_out + k0 + threadIdx.x, red[threadIdx.x][0], accumulate != 0);
+}
+
 }  // namespace ltmi
 
 // =================================================================================================
@@ -1137,10 +1180,23 @@ static int launch_mfma(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t l
 }
 
 // ---- generic launch ------------------------------------------------------------------------------
+// set by ltmi_apply_masks_shifted around the generic dispatch (per thread)
+struct ShiftCtx { const int32_t *shifts = nullptr; int sig_h = 0, sig_w = 0; };
+static thread_local ShiftCtx g_shift;
+
 template <typename TIn, typename A, typename S>
 static int launch_generic(ltmi_masks *m, const void *tile, int64_t n_frames, int64_t ld, void *out,
                           int64_t ld_out, int accumulate, hipStream_t stream) {
     dim3 grid((unsigned)n_frames, (unsigned)((m->n_masks + GEN_MASKS - 1) / GEN_MASKS));
+    if (g_shift.shifts) {
+        hipLaunchKernelGGL((k_dense_shifted<TIn, A, S>), grid, dim3(256), 0, stream,
+                           (const TIn *)tile, ld, g_shift.sig_h, g_shift.sig_w, g_shift.shifts,
+                           (const A *)m->gmasks, (int)m->n_masks, (S *)out, ld_out, accumulate);
+        LTMI_HIP(hipGetLastError());
+        snprintf(m->last_kernel, sizeof(m->last_kernel), "k_dense_shifted<%s,%s> grid=(%u,%u)",
+                 typeid(TIn).name(), typeid(A).name(), grid.x, grid.y);
+        return LTMI_OK;
+    }
     hipLaunchKernelGGL((k_dense_generic<TIn, A, S>), grid, dim3(256), 0, stream, (const TIn *)tile,
                        ld, n_frames, m->n_px, (const A *)m->gmasks, (int)m->n_masks, (S *)out,
                        ld_out, accumulate);
@@ -1237,4 +1293,31 @@ extern "C" int ltmi_apply_masks(ltmi_masks *m, const void *tile, int tile_dtype,
         }
     }
     return apply_generic(m, tile, tile_dtype, n_frames, ld_tile, out, ld_out, accumulate, stream);
+}
+
+extern "C" int ltmi_apply_masks_shifted(ltmi_masks *m, const void *tile, int tile_dtype,
+                                        int64_t n_frames, int64_t ld_tile, int sig_h, int sig_w,
+                                        const int32_t *shifts, void *out, int64_t ld_out,
+                                        int accumulate, void *stream_) {
+    if (!m) LTMI_FAIL(LTMI_E_INVALID, "ltmi_apply_masks_shifted: null handle");
+    if (m->kind == 2 || !m->gmasks)
+        LTMI_FAIL(LTMI_E_INVALID, "ltmi_apply_masks_shifted: needs a dense mask handle");
+    if (sig_h <= 0 || sig_w <= 0 || (int64_t)sig_h * sig_w != m->n_px)
+        LTMI_FAIL(LTMI_E_SHAPE, "ltmi_apply_masks_shifted: sig shape (%d, %d) does not match "
+                  "n_px=%lld", sig_h, sig_w, (long long)m->n_px);
+    if (n_frames < 0 || ld_tile < m->n_px || ld_out < m->n_masks)
+        LTMI_FAIL(LTMI_E_SHAPE, "ltmi_apply_masks_shifted: bad leading dimensions");
+    if (dtype_size(tile_dtype) == 0)
+        LTMI_FAIL(LTMI_E_DTYPE, "ltmi_apply_masks_shifted: unknown tile dtype %d", tile_dtype);
+    if (n_frames == 0) return LTMI_OK;
+    if (!tile || !out || !shifts)
+        LTMI_FAIL(LTMI_E_INVALID, "ltmi_apply_masks_shifted: null pointer");
+    LTMI_HIP(hipSetDevice(m->device));
+    g_shift.shifts = shifts;
+    g_shift.sig_h = sig_h;
+    g_shift.sig_w = sig_w;
+    const int rc = apply_generic(m, tile, tile_dtype, n_frames, ld_tile, out, ld_out, accumulate,
+                                 (hipStream_t)stream_);
+    g_shift.shifts = nullptr;
+    return rc;
 }

@@ -94,6 +94,28 @@ class ApplyMasksEngine:
         handle.apply(tile.data_ptr(), tile.dtype, n, tile.ld, out.data_ptr(), out.ld, accumulate)
         return out
 
+    def process_tile_shifted(self, tile, shifts, out, accumulate=True):
+        """
+        Shifted masks for a whole tile of FULL frames (reference: process_frame_shifted, one call
+        per frame, udf/masks.py:85-124).  `shifts`: host int array (n, 2) of (dy, dx).
+        """
+        import torch
+        if not isinstance(tile, HipArray):
+            raise HipRequiredError("process_tile_shifted expects a device tile (HipArray)")
+        sig = tuple(self.meta.dataset_shape.sig)
+        if len(sig) != 2 or tuple(tile.shape[1:]) != sig:
+            raise ValueError(
+                f"shifted masks need tiles of full 2D frames {sig}, got {tile.shape[1:]} "
+                "(do not force a sub-frame tileshape together with shifts=)")
+        n = tile.shape[0]
+        shifts = np.ascontiguousarray(np.asarray(shifts).reshape((n, 2)).astype(np.int32))
+        handle = self._get_handle()
+        dev_shifts = torch.from_numpy(shifts).to(f'cuda:{tile.device}', non_blocking=False)
+        handle.apply_shifted(tile.data_ptr(), tile.dtype, n, tile.ld, sig[0], sig[1],
+                             dev_shifts.data_ptr(), out.data_ptr(), out.ld, accumulate)
+        self._keep = dev_shifts          # keep alive until the stream has consumed it
+        return out
+
 
 class ApplyMasksUDF(UDF):
     '''
@@ -111,7 +133,11 @@ class ApplyMasksUDF(UDF):
         CSR device kernel.
     mask_count, mask_dtype, preferred_dtype : as in the reference.
     backends : restrict the backends; must contain 'hip' (default).
-    shifts : not supported yet.
+    shifts : (y, x) tuple for a constant shift of all masks, or
+        `ApplyMasksUDF.aux_data(..., kind='nav', extra_shape=(2,))` for per-frame shifts
+        (reference udf/masks.py:207-233).  Float values are cast to int.  With shifts the stack is
+        always applied densely, one kernel launch per tile of full frames (the reference goes frame
+        by frame).
     '''
 
     def __init__(self, mask_factories, use_torch=True, use_sparse=None, mask_count=None,
@@ -127,9 +153,11 @@ class ApplyMasksUDF(UDF):
             raise ValueError(f'No compatible backend found in {_backends}; '
                              f'ApplyMasksUDF runs on {supported} only')
         if shifts is not None:
-            raise NotImplementedError(
-                "ApplyMasksUDF(shifts=...) (per-frame shifted masks, reference udf/masks.py:85-124) "
-                "is not part of this build yet")
+            if isinstance(use_sparse, str) and use_sparse.startswith('scipy.sparse'):
+                raise ValueError(f'Sparse backend {use_sparse} not supported for '
+                                 'shifts, use sparse.pydata instead.')
+            if not isinstance(shifts, AuxBufferWrapper):
+                shifts = np.asarray(shifts)
         self._mask_container = None
         super().__init__(
             mask_factories=mask_factories, use_torch=use_torch, use_sparse=use_sparse,
@@ -159,7 +187,10 @@ class ApplyMasksUDF(UDF):
 
     def _make_mask_container(self):
         p = self.params
-        return _cached_container(p.mask_factories, p.mask_dtype, p.use_sparse, p.mask_count,
+        use_sparse = p.use_sparse
+        if p.get('shifts') is not None:
+            use_sparse = False               # shifted application slices the dense stack
+        return _cached_container(p.mask_factories, p.mask_dtype, use_sparse, p.mask_count,
                                  'scipy.sparse')
 
     def get_task_data(self):
@@ -182,6 +213,15 @@ class ApplyMasksUDF(UDF):
         return {'intensity': 'disjoint'}
 
     def process_tile(self, tile):
-        # fused: results.intensity[:] += tile.reshape(n, -1).astype(input_dtype) @ masks
-        self.task_data.engine.process_tile(tile, out=self.results.intensity, accumulate=True)
+        shifts = self.params.get('shifts')
+        if shifts is None:
+            # fused: results.intensity[:] += tile.reshape(n, -1).astype(input_dtype) @ masks
+            self.task_data.engine.process_tile(tile, out=self.results.intensity, accumulate=True)
+            return
+        n = tile.shape[0]
+        sh = np.asarray(shifts)
+        if sh.ndim == 1:                       # constant (y, x) shift
+            sh = np.broadcast_to(sh.astype(int), (n, 2))
+        self.task_data.engine.process_tile_shifted(tile, sh.astype(int),
+                                                   out=self.results.intensity, accumulate=True)
 

@@ -88,6 +88,40 @@ def apply_masks(data, masks_stack, sig_dims=2, num_partitions=1, tileshape=None,
     return out.reshape(nav + (n_masks,))
 
 
+def apply_masks_shifted(data, masks_stack, shifts, sig_dims=2):
+    """
+    ApplyMasksUDF(shifts=...) on the CPU path: frame by frame (udf/masks.py:85-124, :394-404).
+    `shifts`: (2,) constant (y, x) or nav + (2,) per frame.  A positive y shift moves the mask
+    down relative to the frame; non-overlapping parts are discarded.
+    """
+    masks_stack = np.asarray(masks_stack)
+    in_dtype = input_dtype(data.dtype)
+    res_dtype = np.result_type(in_dtype, masks_stack.dtype)
+    nav = data.shape[:-sig_dims]
+    sig = tuple(data.shape[-sig_dims:])
+    n_frames = prod(nav)
+    n_masks = masks_stack.shape[0]
+    flat = data.reshape((n_frames,) + sig)
+    shifts = np.asarray(shifts)
+    if shifts.ndim == 1:
+        shifts = np.broadcast_to(shifts, (n_frames, 2))
+    else:
+        shifts = shifts.reshape((n_frames, 2))
+    out = np.zeros((n_frames, n_masks), dtype=res_dtype)
+    H, W = sig
+    for f in range(n_frames):
+        dy, dx = (int(v) for v in shifts[f].astype(int))
+        # left = sig_slice & sig_slice.shift_by(shifts): frame region; right: mask region
+        y0, y1 = max(0, dy), min(H, H + dy)
+        x0, x1 = max(0, dx), min(W, W + dx)
+        if y1 <= y0 or x1 <= x0:
+            continue                                  # zero overlap -> contributes 0
+        frame = flat[f].astype(in_dtype)[y0:y1, x0:x1].reshape((1, -1))
+        m = masks_stack[:, y0 - dy:y1 - dy, x0 - dx:x1 - dx].reshape((n_masks, -1)).T
+        out[f] += (frame @ m.astype(masks_stack.dtype)).reshape((n_masks,))
+    return out.reshape(nav + (n_masks,))
+
+
 def rmatmul(left_dense, right_sparse):
     """
     common/numba/__init__.py:90-184, restated with identical loop order

@@ -287,7 +287,29 @@ def gen_single_mask_analyses():
     save('single_mask_analyses', **out)
 
 
+# ---------------------------------------------------------------------------
+# 9. shifted masks
+# ---------------------------------------------------------------------------
+def gen_shifts():
+    out = {}
+    for case in recipes.SHIFT_CASES:
+        data, masks, shifts = recipes.make_shift_case(case)
+        ds = MemoryDataSet(data=data, num_partitions=case['num_partitions'], sig_dims=2)
+        if case['shifts'] == 'aux':
+            sh = ApplyMasksUDF.aux_data(shifts.reshape((-1, 2)).ravel(), kind='nav',
+                                        extra_shape=(2,), dtype=shifts.dtype)
+        else:
+            sh = tuple(int(x) for x in shifts)
+        udf = ApplyMasksUDF(mask_factories=lambda: masks, shifts=sh, use_sparse=False)
+        res = run(ds, udf)['intensity']
+        out[case['name']] = np.array(res.data)
+        out[case['name'] + '__sha_data'] = np.frombuffer(bytes.fromhex(sha(data)), dtype=np.uint8)
+        print(case['name'], res.data.shape, res.data.dtype)
+    save('shifts', **out)
+
+
 if __name__ == '__main__':
+    gen_shifts()
     gen_apply_masks_dense()
     gen_sums()
     gen_com()

@@ -321,3 +321,32 @@ def single_mask_analyses():
         ('masks_two', 'masks', dict(factories=masks2)),
         ('masks_two_f32', 'masks', dict(factories=masks2, mask_dtype=np.float32)),
     ]
+
+
+# ---------------------------------------------------------------------------
+# shifted masks (ApplyMasksUDF(shifts=...), reference udf/masks.py:85-124)
+# ---------------------------------------------------------------------------
+SHIFT_CASES = [
+    dict(name='const', nav=(4, 5), sig=(24, 32), dtype='uint16', n_masks=3, num_partitions=2,
+         seed=601, shifts=(2, -5)),
+    dict(name='const_big', nav=(3, 3), sig=(16, 16), dtype='float32', n_masks=2,
+         num_partitions=1, seed=602, shifts=(-20, 3)),           # no overlap at all
+    dict(name='per_frame', nav=(4, 5), sig=(24, 32), dtype='uint16', n_masks=3,
+         num_partitions=3, seed=603, shifts='aux'),
+]
+
+
+def make_shift_case(case):
+    rng = np.random.default_rng(case['seed'])
+    shape = tuple(case['nav']) + tuple(case['sig'])
+    dt = np.dtype(case['dtype'])
+    if dt.kind == 'u':
+        data = rng.integers(0, 1000, shape).astype(dt)
+    else:
+        data = rng.random(shape).astype(dt)
+    masks = (rng.random((case['n_masks'],) + tuple(case['sig'])) - 0.25).astype(np.float32)
+    if case['shifts'] == 'aux':
+        shifts = rng.integers(-8, 9, tuple(case['nav']) + (2,))
+    else:
+        shifts = np.array(case['shifts'])
+    return data, masks, shifts

@@ -140,6 +140,19 @@ def test_radial_fourier_sparse_equals_dense():
     assert np.allclose(a['intensity'], b['intensity'], rtol=0, atol=3e-6 * scale)
 
 
+@pytest.mark.parametrize('case', recipes.SHIFT_CASES, ids=lambda c: c['name'])
+def test_shifted_masks(golden_dir, case):
+    g = _load(golden_dir, 'shifts')
+    data, masks, shifts = recipes.make_shift_case(case)
+    assert np.array_equal(_sha(data), g[case['name'] + '__sha_data'])
+    res = opath.apply_masks_shifted(data, masks, shifts)
+    ref = g[case['name']]
+    assert res.dtype == ref.dtype and res.shape == ref.shape
+    assert np.allclose(res, ref, rtol=2e-6, atol=2e-6 * max(np.abs(ref).max(), 1e-30))
+    if case['name'] == 'const_big':
+        assert np.all(ref == 0)
+
+
 def test_mask_factories(golden_dir):
     g = _load(golden_dir, 'mask_factories')
 

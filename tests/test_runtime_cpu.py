@@ -289,8 +289,10 @@ def test_native_udfs_fail_loudly_on_cpu(ctx, make_udf):
 def test_apply_masks_udf_argument_errors():
     with pytest.raises(ValueError):
         ApplyMasksUDF(mask_factories=[lambda: np.ones((4, 4))], backends=('numpy',))
-    with pytest.raises(NotImplementedError):
-        ApplyMasksUDF(mask_factories=[lambda: np.ones((4, 4))], shifts=(1, 2))
+    with pytest.raises(ValueError):      # reference udf/masks.py:268-277
+        ApplyMasksUDF(mask_factories=[lambda: np.ones((4, 4))], shifts=(1, 2),
+                      use_sparse='scipy.sparse')
+    ApplyMasksUDF(mask_factories=[lambda: np.ones((4, 4))], shifts=(1, 2))
     with pytest.raises(ValueError):
         CoMUDF.with_params(r=3., ri=5.)
 

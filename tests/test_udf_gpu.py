@@ -440,3 +440,34 @@ def test_numerics_float32_vs_exact(ctx):
     err_ref = np.abs(ref - exact) / exact
     assert np.all(err_hip <= 1e-4)
     assert np.all(err_hip <= err_ref + 1e-6)
+
+
+@pytest.mark.parametrize('case', recipes.SHIFT_CASES, ids=lambda c: c['name'])
+def test_shifted_masks_vs_reference_golden(ctx, golden_dir, case):
+    """ApplyMasksUDF(shifts=...): constant and per-frame (aux data) shifts"""
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    g = _load(golden_dir, 'shifts')
+    data, masks, shifts = recipes.make_shift_case(case)
+    if case['shifts'] == 'aux':
+        sh = ApplyMasksUDF.aux_data(shifts.reshape((-1, 2)).ravel(), kind='nav',
+                                    extra_shape=(2,), dtype=shifts.dtype)
+    else:
+        sh = tuple(int(x) for x in shifts)
+    ref = g[case['name']]
+    for ds in (ctx.load('memory', data=data, num_partitions=case['num_partitions'], sig_dims=2),
+               _device_ds(ctx, data, case['num_partitions'])):
+        got = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda: masks, shifts=sh))
+        d = got['intensity'].data
+        assert d.shape == ref.shape and d.dtype == ref.dtype
+        assert np.allclose(d, ref, rtol=F32_TOL, atol=F32_TOL * max(np.abs(ref).max(), 1e-30))
+    assert np.allclose(opath.apply_masks_shifted(data, masks, shifts), ref, rtol=1e-5, atol=1e-3)
+    # ROI + per-frame shifts: aux data follows the ROI
+    if case['shifts'] == 'aux':
+        roi = np.zeros(case['nav'], dtype=bool)
+        roi[1, 1:4] = True
+        roi[3, 0] = True
+        ds = ctx.load('memory', data=data, num_partitions=2, sig_dims=2)
+        got = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda: masks, shifts=sh),
+                          roi=roi)['intensity'].data
+        assert np.allclose(got[roi], ref[roi], rtol=F32_TOL, atol=F32_TOL * np.abs(ref).max())
+        assert np.all(np.isnan(got[~roi]))
