@@ -38,7 +38,7 @@ frame_bytes = n_px * dt.itemsize + args.masks * md.itemsize
 if args.variants == 'auto':
     variants = [dict(mt=0, waves=0, ksplit=0)]
 else:
-    variants = [dict(mt=0, waves=6, ksplit=0), dict(mt=0, waves=3, ksplit=0),
+    variants = [dict(mt=0, waves=9, ksplit=0), dict(mt=0, waves=3, ksplit=0),
                 dict(mt=0, waves=5, ksplit=0), dict(mt=0, waves=6, ksplit=0),
                 dict(mt=2, waves=4, ksplit=1), dict(mt=1, waves=4, ksplit=1)]
 for v in variants:
