@@ -17,6 +17,7 @@
 #include <cstring>
 #include <algorithm>
 #include <typeinfo>
+#include <type_traits>
 
 namespace ltmi {
 
@@ -357,10 +358,11 @@ k_dense_mfma_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64
         const unsigned char *bsrc = (const unsigned char *)img + wave * BPW + lane * 16;
         const int S0 = c_begin * SUBS, S1 = cf_end * SUBS;    // sub-chunk range
 
-        auto issue_a1 = [&](int s, int t) {                   // one DMA piece of sub-chunk s
+        // one DMA piece (rows 4t..4t+3) of sub-chunk s into ring slot `slot`
+        auto issue_a1 = [&](int s, int slot, int t) {
             if (ABL == 2) return;
             const int sc = min(s, S1 - 1);
-            unsigned char *dst = a_base + (s % V2_ARING) * (V2_WAVES * V2_ASLOT);
+            unsigned char *dst = a_base + slot * (V2_WAVES * V2_ASLOT);
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[t] + (int64_t)sc * V2_SUB_BYTES),
                                              (lds_ptr_t)(dst + t * 1024), 16, 0, 2 /*nt*/);
         };
@@ -381,47 +383,52 @@ k_dense_mfma_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64
         };
 
 #pragma unroll
-        for (int t = 0; t < 4; ++t) issue_a1(S0, t);
+        for (int t = 0; t < 4; ++t) issue_a1(S0, 0, t);
         issue_b(0);
 #pragma unroll
         for (int d = 1; d < V2_ARING - 1; ++d)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) issue_a1(S0 + d, t);
-        // DMA instructions allowed to stay in flight at the wait of iteration s (see header):
-        //   even s: the (RING-2) later sub-chunks          -> A(s) and B(s/2) landed
-        //   odd  s: those + the B issued in iteration s-1  -> A(s) landed
-        for (int s = S0; s < S1; ++s) {
-            // i = iteration since the start; a mask slot spans PER sub-chunks.
-            //   i % PER == 0: wait for my pieces of the slot (and A(s)), barrier, issue next slot
-            //   otherwise   : wait for A(s); B instructions issued after A(s) may stay in flight
-            constexpr int PER = SUBS * BCH;
-            constexpr int NBI = BCH * BPW / 1024;                       // B instructions per wave
-            constexpr int A_N = 4 * (V2_ARING - 2);                     // later A sub-chunks
-            static_assert(PER >= 2 && V2_ARING - 2 <= PER, "wait counts assume this");
+            for (int t = 0; t < 4; ++t) issue_a1(S0 + d, d, t);
+
+        constexpr int PER = SUBS * BCH;                             // sub-chunks per mask slot
+        constexpr int NBI = BCH * BPW / 1024;                       // B instructions per wave
+        constexpr int A_N = 4 * (V2_ARING - 2);                     // later A sub-chunks
+        static_assert(PER >= 2 && V2_ARING - 2 <= PER, "wait counts assume this");
+        // lane-constant parts of the fragment addresses (bytes / floats inside a slot)
+        const int a_lane = m * V2_SUB_BYTES;
+        const int b_lane = m * KC + kg * 64;
+
+        // One sub-chunk.  `ph` carries i % UNROLL as a compile-time constant in the unrolled main
+        // loop (ring slot, mask slot and block offset become immediates of the ds_read / DMA
+        // instructions: no per-block address arithmetic), or -1 for the generic tail.
+        auto iteration = [&](int s, auto ph) {
+            constexpr int PH = decltype(ph)::value;
             const int i = s - S0;
-            if (i % PER == 0) {
-                // the slot was issued PER iterations ago; everything younger than it may fly,
-                // but A(s) (issued RING-1 iterations ago) must have landed as well
+            const int ip = PH >= 0 ? PH % PER : i % PER;            // position inside a mask slot
+            // DMA instructions allowed to stay in flight at this wait (issue order in the header):
+            //   ip == 0      : the slot was issued PER iterations ago; wait for it and A(s), barrier
+            //   ip <= RING-2 : a B slot was issued after A(s) and may stay in flight
+            if (ip == 0) {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_N) : "memory");
                 __builtin_amdgcn_s_barrier();
                 issue_b(i / PER + 1);
-            } else if ((i % PER) <= V2_ARING - 2) {
-                // a B slot was issued after A(s) (at iteration s - i%PER, i%PER <= RING-2)
+            } else if (ip <= V2_ARING - 2) {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_N + NBI) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_N) : "memory");
             }
-            const unsigned char *aslot = a_base + (s % V2_ARING) * (V2_WAVES * V2_ASLOT);
-            const int ci = (s - S0) / SUBS;                       // mask chunk since c_begin
-            const float *bslot = (const float *)(b_base + ((((ci / BCH) & 1) * BCH + ci % BCH) *
-                                                           (CHUNK_FLOATS * 4))) +
-                                 m * KC + kg * 64;
-            const int blk0 = ((s - S0) & 1) * BLKS;               // block offset inside the chunk
+            const int slot = PH >= 0 ? PH % V2_ARING : i % V2_ARING;
+            const int nslot = PH >= 0 ? (PH + V2_ARING - 1) % V2_ARING
+                                      : (i + V2_ARING - 1) % V2_ARING;
+            const int ci = PH >= 0 ? PH / SUBS : i / SUBS;          // mask chunk (mod 2*BCH)
+            const int bsl = ((ci / BCH) & 1) * BCH + ci % BCH;
+            const int blk0 = (PH >= 0 ? (PH & 1) : (i & 1)) * BLKS; // block offset inside the chunk
+            const unsigned char *aslot = a_base + slot * (V2_WAVES * V2_ASLOT) + a_lane;
+            const float *bslot = (const float *)(b_base + bsl * (CHUNK_FLOATS * 4)) + b_lane;
             // fragments are double-buffered in registers: the ds_reads of block blk+1 are issued
             // before the MFMAs of block blk, so LDS latency hides behind 8 MFMAs (256 cycles)
             auto rd_a = [&](int blk) {
-                return *(const typename TR::raw_t *)(
-                    aslot + m * V2_SUB_BYTES + (((blk * 4 + kg) ^ m) << 4));
+                return *(const typename TR::raw_t *)(aslot + (((blk * 4 + kg) ^ m) << 4));
             };
             auto rd_b = [&](int blk, int h) {
                 return *(const f32x4 *)(bslot + ((((blk0 + blk) * 2 + h) ^ m) << 2));
@@ -437,7 +444,7 @@ k_dense_mfma_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64
                     b_n0 = rd_b(blk + 1, 0);
                     b_n1 = rd_b(blk + 1, 1);
                 }
-                issue_a1(s + V2_ARING - 1, blk);
+                issue_a1(s + V2_ARING - 1, nslot, blk);
                 // keep the prefetch reads ABOVE this block's MFMAs (hipcc otherwise sinks them
                 // next to their use to save registers and the LDS latency is exposed again)
                 __builtin_amdgcn_sched_barrier(0);
@@ -463,7 +470,19 @@ k_dense_mfma_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64
                 b_c0 = b_n0;
                 b_c1 = b_n1;
             }
+        };
+
+        int s = S0;
+        if constexpr (V2_ARING == 4 && BCH == 1) {
+            // (i % 4) fixes ring slot (i % 4), mask slot ((i / 2) & 1) and block offset (i & 1)
+            for (; s + 4 <= S1; s += 4) {
+                iteration(s, std::integral_constant<int, 0>{});
+                iteration(s + 1, std::integral_constant<int, 1>{});
+                iteration(s + 2, std::integral_constant<int, 2>{});
+                iteration(s + 3, std::integral_constant<int, 3>{});
+            }
         }
+        for (; s < S1; ++s) iteration(s, std::integral_constant<int, -1>{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the clamped prefetches
     }
 
