@@ -46,7 +46,8 @@ class BufferWrapper:
         self._dtype = np.dtype(dtype)
         self._where = where
         self.use = use
-        self._data = None            # np.ndarray | HipArray
+        self._arr = None             # np.ndarray | HipArray (see the `_data` property)
+        self._lazy = False           # zeros of `_shape` are materialised on first access
         self._shape = None
         self._ds_shape = None
         self._roi = None
@@ -54,6 +55,18 @@ class BufferWrapper:
         self._valid_mask = None
         self._ds_partitions = None
         self._contiguous_cache = {}
+
+    @property
+    def _data(self):
+        if self._lazy:
+            self._lazy = False
+            self._arr = np.zeros(self._shape, dtype=self._dtype)
+        return self._arr
+
+    @_data.setter
+    def _data(self, value):
+        self._lazy = False
+        self._arr = value
 
     # --- declaration properties --------------------------------------------------------------
     @property
@@ -114,22 +127,27 @@ class BufferWrapper:
         self._ds_shape = dataset_shape
 
     # --- allocation ---------------------------------------------------------------------------
-    def allocate(self, lib=None):
+    def allocate(self, lib=None, lazy=False):
         """lib: None/'numpy' -> host zeros; ('hip', device) -> HipArray zeros when this buffer
-        was declared where='device', host zeros otherwise (reference :668-686)."""
+        was declared where='device', host zeros otherwise (reference :668-686).
+        lazy: host zeros are only materialised when somebody looks at them (the main-process
+        buffers of a run whose executor replaces them with the merged device result)."""
         if self._shape is None:
             raise RuntimeError("shape must be set before allocate()")
         if isinstance(lib, tuple) and lib[0] == 'hip' and self._where == 'device':
             self._data = HipArray.zeros(self._shape, self._dtype, lib[1])
+        elif lazy:
+            self._arr = None
+            self._lazy = True
         else:
             self._data = np.zeros(self._shape, dtype=self._dtype)
 
     def has_data(self):
-        return self._data is not None
+        return self._lazy or self._arr is not None
 
     @property
     def on_device(self):
-        return isinstance(self._data, HipArray)
+        return isinstance(self._arr, HipArray)
 
     def export(self):
         """D2H once per partition (reference :901-907)."""
@@ -303,7 +321,7 @@ class HipSigView:
 class PlaceholderBufferWrapper(BufferWrapper):
     """Declared with use='result_only': only filled in get_results (reference :949-986)."""
 
-    def allocate(self, lib=None):
+    def allocate(self, lib=None, lazy=False):
         self._data = None
 
     def has_data(self):

@@ -8,6 +8,9 @@ import os
 from libertem_amd.common.backend import set_use_cpu, set_use_hip
 
 
+_NULL_CONTEXT = contextlib.nullcontext()
+
+
 class Environment:
     """
     What a task may assume about its worker (common/executor.py:52-140): thread budget and the
@@ -15,12 +18,17 @@ class Environment:
     """
 
     def __init__(self, threads_per_worker=None, threaded_executor=False, gpu_id=None,
-                 keep_results_on_device=False, stream=None):
+                 keep_results_on_device=False, stream=None, ensure_current=None):
         self._threads_per_worker = threads_per_worker
         self._threaded_executor = threaded_executor
         self._gpu_id = gpu_id
         self.keep_results_on_device = keep_results_on_device
         self.stream = stream
+        # hipStream_t value handed to libltmi (None: torch's current stream at call time)
+        self.stream_ptr = None if stream is None else int(stream.cuda_stream)
+        # callable that makes (gpu_id, stream) torch's current device/stream WITHOUT a context
+        # manager (the HIP executor owns the process's device: one process per GPU)
+        self._ensure_current = ensure_current
 
     @property
     def threads_per_worker(self):
@@ -38,10 +46,18 @@ class Environment:
     def device_class(self):
         return 'hip' if self._gpu_id is not None else 'cpu'
 
-    @contextlib.contextmanager
     def enter(self, enable_gpu=False):
         """Select the device and limit BLAS threads for the duration of a task
         (common/executor.py:111-129)."""
+        if self._threads_per_worker is None and (
+                not enable_gpu or self._gpu_id is None or self._ensure_current is not None):
+            if enable_gpu and self._ensure_current is not None:
+                self._ensure_current()
+            return _NULL_CONTEXT
+        return self._enter_ctx(enable_gpu)
+
+    @contextlib.contextmanager
+    def _enter_ctx(self, enable_gpu):
         ctxs = contextlib.ExitStack()
         with ctxs:
             if self._threads_per_worker is not None:

@@ -17,6 +17,7 @@ LIBERTEM_USE_CUDA, results pickled back, serial merge on the main process udf/ba
   UDFs without a declaration fall back to gathering exported per-partition results and merging
   them in partition order on every rank (reference semantics, slower).
 """
+import os
 import uuid
 
 import numpy as np
@@ -27,14 +28,25 @@ from libertem_amd.common.backend import get_use_hip
 from .base import JobExecutor, Environment
 
 
+_DIST_MODULE = False          # False: not imported yet; None: torch.distributed unavailable
+
+
 def _dist():
-    try:
-        import torch.distributed as dist
-    except Exception:
-        return None
-    if dist.is_available() and dist.is_initialized():
+    global _DIST_MODULE
+    if _DIST_MODULE is False:
+        try:
+            import torch.distributed as dist
+            _DIST_MODULE = dist if dist.is_available() else None
+        except Exception:
+            _DIST_MODULE = None
+    dist = _DIST_MODULE
+    if dist is not None and dist.is_initialized():
         return dist
     return None
+
+
+#: the executor whose device + stream were last installed as torch's current ones
+_CURRENT_OWNER = None
 
 
 class HipJobExecutor(JobExecutor):
@@ -47,7 +59,6 @@ class HipJobExecutor(JobExecutor):
         require_gpu : False lets CPU-only tests drive the sharding/merge logic with NumPy UDFs
             (device class stays 'cpu' then; the native UDFs still refuse to run).
         """
-        import os
         if gpu_id is None:
             gpu_id = get_use_hip()
         if gpu_id is None:
@@ -63,6 +74,8 @@ class HipJobExecutor(JobExecutor):
                     f"HipJobExecutor: GPU {gpu_id} not available "
                     f"({hip.device_count()} HIP device(s) visible). There is no CPU fallback.")
             self._stream = torch.cuda.Stream(device=gpu_id)
+            self._stream_ptr = int(self._stream.cuda_stream)
+            self._torch = torch
             self.gpu_id = gpu_id
             self.device_class = 'hip'
         else:
@@ -82,11 +95,23 @@ class HipJobExecutor(JobExecutor):
     def _collectives_on(self):
         """True iff results have to be combined across ranks.  LTMI_FORCE_COLLECTIVES=1 runs the
         collective code path even with a single rank (used to exercise RCCL on a 1-GPU box)."""
-        import os
         d = self._dist()
         if d is None:
             return False
-        return self.world_size > 1 or os.environ.get('LTMI_FORCE_COLLECTIVES') == '1'
+        return d.get_world_size() > 1 or os.environ.get('LTMI_FORCE_COLLECTIVES') == '1'
+
+    def _make_current(self):
+        """Install this executor's GPU and stream as torch's current device / stream (no context
+        manager: one process drives one GPU, the executor owns both).  Cheap when nothing changed:
+        one raw-stream query guards against user code that switched streams in between."""
+        global _CURRENT_OWNER
+        torch = self._torch
+        if _CURRENT_OWNER is self and \
+                torch._C._cuda_getCurrentRawStream(self.gpu_id) == self._stream_ptr:
+            return
+        torch.cuda.set_device(self.gpu_id)
+        torch.cuda.set_stream(self._stream)
+        _CURRENT_OWNER = self
 
     @property
     def rank(self):
@@ -101,6 +126,8 @@ class HipJobExecutor(JobExecutor):
     def my_tasks(self, tasks):
         """Contiguous block of the task list for this rank (nav sharding)."""
         W, r = self.world_size, self.rank
+        if W == 1:
+            return tasks
         P = len(tasks)
         b = np.linspace(0, P, W + 1, dtype=int)
         return tasks[b[r]:b[r + 1]]
@@ -108,7 +135,9 @@ class HipJobExecutor(JobExecutor):
     # --- executor protocol -----------------------------------------------------------------------------
     def get_local_env(self):
         return Environment(threads_per_worker=None, threaded_executor=False, gpu_id=self.gpu_id,
-                           keep_results_on_device=(self.gpu_id is not None), stream=self._stream)
+                           keep_results_on_device=(self.gpu_id is not None), stream=self._stream,
+                           ensure_current=(self._make_current if self.gpu_id is not None
+                                           else None))
 
     def scatter(self, obj):
         handle = str(uuid.uuid4())
@@ -184,14 +213,13 @@ class HipJobExecutor(JobExecutor):
                     if isinstance(buf, PlaceholderBufferWrapper):
                         continue
                     full = dev_full[i].get(name)
+                    self._make_current()
                     if full is None:
-                        with torch.cuda.device(self.gpu_id), torch.cuda.stream(self._stream):
-                            full = torch.zeros(buf.shape, dtype=torch_dtype_for(buf.dtype),
-                                               device=f'cuda:{self.gpu_id}')
+                        full = torch.zeros(buf.shape, dtype=torch_dtype_for(buf.dtype),
+                                           device=f'cuda:{self.gpu_id}')
                     if self._collectives_on:
                         # collectives are ordered after the kernels of the executor stream
-                        with torch.cuda.device(self.gpu_id), torch.cuda.stream(self._stream):
-                            full = self._combine(d, full, how)
+                        full = self._combine(d, full, how)
                     host = self._to_host(full)
                     if host.dtype != buf.dtype:
                         host = host.view(buf.dtype)
@@ -241,8 +269,8 @@ class HipJobExecutor(JobExecutor):
         returned array is owned by the caller and no host-side copy is needed."""
         import torch
         pinned = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-        with torch.cuda.stream(self._stream):
-            pinned.copy_(t, non_blocking=True)
+        self._make_current()
+        pinned.copy_(t, non_blocking=True)
         self._stream.synchronize()
         return pinned.numpy()
 
@@ -254,7 +282,8 @@ class HipJobExecutor(JobExecutor):
 
     def _merge_on_device(self, udf, results, task, decl, full):
         import torch
-        with torch.cuda.device(self.gpu_id), torch.cuda.stream(self._stream):
+        self._make_current()
+        if True:
             for name, how in decl.items():
                 buf_main = udf.results.get_buffer(name)
                 if isinstance(buf_main, PlaceholderBufferWrapper):

@@ -209,14 +209,19 @@ class MaskHandle:
               stream=None):
         if KernelTimer.enabled:
             import torch
-            st = torch.cuda.current_stream() if stream is None else stream
+            st = torch.cuda.current_stream() if stream is None or isinstance(stream, int) \
+                else stream
+            if isinstance(stream, int) and st.cuda_stream != stream:
+                st = torch.cuda.ExternalStream(stream)
             a = torch.cuda.Event(enable_timing=True)
             b = torch.cuda.Event(enable_timing=True)
             a.record(st)
-        check(lib().ltmi_apply_masks(
-            self._ptr, ctypes.c_void_p(tile_ptr), dtype_code(tile_dtype), n_frames, ld_tile,
-            ctypes.c_void_p(out_ptr), ld_out, 1 if accumulate else 0, _stream_ptr(stream)),
-            'ltmi_apply_masks')
+        # argtypes are declared: plain ints marshal as pointers
+        rc = _lib.ltmi_apply_masks(
+            self._ptr, tile_ptr, _DTYPES.get(tile_dtype) or dtype_code(tile_dtype), n_frames, ld_tile, out_ptr, ld_out,
+            1 if accumulate else 0, stream if isinstance(stream, int) else _stream_ptr(stream))
+        if rc:
+            check(rc, 'ltmi_apply_masks')
         if KernelTimer.enabled:
             b.record(st)
             KernelTimer.events.append((a, b, n_frames, self.last_kernel()))

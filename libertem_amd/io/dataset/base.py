@@ -139,9 +139,27 @@ class Negotiator:
         return self._get_scheme_numpy(udfs, dataset, read_dtype, approx_partition_shape, roi)
 
     # --- MI355X policy ---------------------------------------------------------------------------
+    #: the HIP policy is a pure function of these few values; a run over the same dataset re-uses
+    #: the (immutable) scheme instead of re-building its slices
+    _hip_scheme_cache = {}
+
     def _get_scheme_hip(self, udfs, dataset, approx_partition_shape):
         intent = self._get_intent(udfs)
         forced = dataset.get_forced_tileshape()
+        ds_shape = dataset.shape
+        key = (intent, None if forced is None else tuple(forced), tuple(ds_shape),
+               ds_shape.sig_dims, np.dtype(dataset.dtype).itemsize,
+               bool(dataset.is_device_resident), int(approx_partition_shape[0]),
+               self.HIP_TILE_BUDGET, self.HIP_STAGING_CHUNK)
+        hit = self._hip_scheme_cache.get(key)
+        if hit is None:
+            if len(self._hip_scheme_cache) > 64:
+                self._hip_scheme_cache.clear()
+            hit = self._hip_scheme_cache[key] = self._make_scheme_hip(
+                intent, forced, dataset, approx_partition_shape)
+        return hit
+
+    def _make_scheme_hip(self, intent, forced, dataset, approx_partition_shape):
         ds_sig = tuple(dataset.shape.sig)
         if forced is not None and intent == 'tile':
             tileshape = tuple(forced)

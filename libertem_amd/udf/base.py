@@ -57,8 +57,11 @@ class UDFMeta:
 
     def __init__(self, partition_slice, dataset_shape, roi, dataset_dtype, input_dtype,
                  tiling_scheme=None, tiling_index=0, corrections=None, device_class=None,
-                 threads_per_worker=None, array_backend=None, valid_nav_mask=None, gpu_id=None):
+                 threads_per_worker=None, array_backend=None, valid_nav_mask=None, gpu_id=None,
+                 stream_ptr=None):
         self._partition_slice = partition_slice
+        #: hipStream_t (int) the worker enqueues on; None = torch's current stream
+        self.stream_ptr = stream_ptr
         self._dataset_shape = dataset_shape
         self._dataset_dtype = dataset_dtype
         self._input_dtype = input_dtype
@@ -281,13 +284,13 @@ class UDFData:
             if not isinstance(buf, AuxBufferWrapper):
                 buf.allocate(lib=lib)
 
-    def allocate_for_full(self, dataset, roi):
+    def allocate_for_full(self, dataset, roi, lazy=False):
         for k, buf in self._get_buffers():
             buf.set_roi(roi)
             buf.set_shape_ds(dataset.shape, roi)
         for k, buf in self._get_buffers():
             if not isinstance(buf, AuxBufferWrapper):
-                buf.allocate()
+                buf.allocate(lazy=lazy)
 
     def set_view_for_dataset(self, dataset):
         for k, buf in self._get_buffers(filter_allocated=True):
@@ -353,8 +356,9 @@ class UDFBase(UDFProtocol):
             ns.allocate_for_part(partition, roi, lib=self.xp)
 
     def allocate_for_full(self, dataset, roi):
-        for ns in [self.params, self.results]:
-            ns.allocate_for_full(dataset, roi)
+        self.params.allocate_for_full(dataset, roi)
+        # result buffers: zeros on first touch (a device-merging executor replaces them unseen)
+        self.results.allocate_for_full(dataset, roi, lazy=True)
 
     def set_views_for_dataset(self, dataset):
         for ns in [self.params]:
@@ -739,7 +743,7 @@ class UDFPartRunner:
             input_dtype=dtype, tiling_scheme=params.tiling_scheme,
             corrections=params.corrections, device_class=env.device_class,
             threads_per_worker=env.threads_per_worker, array_backend=backend,
-            gpu_id=env.gpu_id,
+            gpu_id=env.gpu_id, stream_ptr=getattr(env, 'stream_ptr', None),
         )
         for udf in self._udfs:
             udf.set_backend(backend)

@@ -67,6 +67,7 @@ class ApplyMasksEngine:
                 f"{meta.array_backend!r} on device class {meta.device_class!r}")
         self.result_dtype = np.result_type(meta.input_dtype, masks.dtype)
         self.device = meta.gpu_id if meta.gpu_id is not None else 0
+        self.stream_ptr = getattr(meta, 'stream_ptr', None)
 
     def _get_handle(self):
         return self.masks.get_handle_for_sig_slice(self.meta.sig_slice, self.result_dtype,
@@ -91,7 +92,8 @@ class ApplyMasksEngine:
         if out.shape[0] != n or prod(out.shape[1:]) != handle.n_masks:
             raise ValueError(f"result view {out.shape} does not fit {n} frames x "
                              f"{handle.n_masks} masks")
-        handle.apply(tile.data_ptr(), tile.dtype, n, tile.ld, out.data_ptr(), out.ld, accumulate)
+        handle.apply(tile.data_ptr(), tile.dtype, n, tile.ld, out.data_ptr(), out.ld, accumulate,
+                     stream=self.stream_ptr)
         return out
 
     def process_tile_shifted(self, tile, shifts, out, accumulate=True):
@@ -112,7 +114,8 @@ class ApplyMasksEngine:
         handle = self._get_handle()
         dev_shifts = torch.from_numpy(shifts).to(f'cuda:{tile.device}', non_blocking=False)
         handle.apply_shifted(tile.data_ptr(), tile.dtype, n, tile.ld, sig[0], sig[1],
-                             dev_shifts.data_ptr(), out.data_ptr(), out.ld, accumulate)
+                             dev_shifts.data_ptr(), out.data_ptr(), out.ld, accumulate,
+                             stream=self.stream_ptr)
         self._keep = dev_shifts          # keep alive until the stream has consumed it
         return out
 

@@ -31,4 +31,4 @@ for _ in range(N):
     ctx.run_udf(dataset=ds, udf=udf)
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats('cumulative').print_stats(45)
+st.sort_stats('tottime').print_stats(60)
