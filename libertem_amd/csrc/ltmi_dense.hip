@@ -360,7 +360,7 @@ k_dense_mfma_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64
 
         // one DMA piece (rows 4t..4t+3) of sub-chunk s into ring slot `slot`
         auto issue_a1 = [&](int s, int slot, int t) {
-            if (ABL == 2) return;
+            if (ABL >= 2) return;
             const int sc = min(s, S1 - 1);
             unsigned char *dst = a_base + slot * (V2_WAVES * V2_ASLOT);
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[t] + (int64_t)sc * V2_SUB_BYTES),
@@ -368,7 +368,7 @@ k_dense_mfma_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64
         };
         // B slot = BCH consecutive 16-KiB image chunks; group index gidx counts slots from c_begin
         auto issue_b = [&](int gidx) {
-            if (ABL == 2) return;
+            if (ABL >= 2) return;
 #pragma unroll
             for (int q = 0; q < BCH; ++q) {
                 const int cc = min(c_begin + gidx * BCH + q, cf_end - 1);
@@ -410,7 +410,7 @@ k_dense_mfma_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64
             //   ip <= RING-2 : a B slot was issued after A(s) and may stay in flight
             if (ip == 0) {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_N) : "memory");
-                __builtin_amdgcn_s_barrier();
+                if (ABL < 3) __builtin_amdgcn_s_barrier();
                 issue_b(i / PER + 1);
             } else if (ip <= V2_ARING - 2) {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_N + NBI) : "memory");
@@ -427,10 +427,21 @@ k_dense_mfma_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64
             const float *bslot = (const float *)(b_base + bsl * (CHUNK_FLOATS * 4)) + b_lane;
             // fragments are double-buffered in registers: the ds_reads of block blk+1 are issued
             // before the MFMAs of block blk, so LDS latency hides behind 8 MFMAs (256 cycles)
+            // ablations >= 4 (bench only): operands from registers instead of LDS
+            typename TR::raw_t raw_fake = {};
+            f32x4 b_fake = {1.f, 2.f, 3.f, 4.f};
             auto rd_a = [&](int blk) {
+                if (ABL >= 4) {
+                    asm volatile("" : "+v"(raw_fake));
+                    return raw_fake;
+                }
                 return *(const typename TR::raw_t *)(aslot + (((blk * 4 + kg) ^ m) << 4));
             };
             auto rd_b = [&](int blk, int h) {
+                if (ABL >= 4) {
+                    asm volatile("" : "+v"(b_fake));
+                    return b_fake;
+                }
                 return *(const f32x4 *)(bslot + ((((blk0 + blk) * 2 + h) ^ m) << 2));
             };
             typename TR::raw_t raw_c = rd_a(0);
@@ -449,7 +460,12 @@ k_dense_mfma_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64
                 // next to their use to save registers and the LDS latency is exposed again)
                 __builtin_amdgcn_sched_barrier(0);
                 float a[8];
-                TR::cvt(raw_c, a);
+                if (ABL >= 5) {       // ablation: no conversion, reinterpret the raw dwords
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a[j] = __builtin_bit_cast(float, raw_c[j >> 1]);
+                } else {
+                    TR::cvt(raw_c, a);
+                }
                 f32x4 b[2] = {b_c0, b_c1};
                 if (ABL == 1) {       // ablation: keep the operands live, no matrix work
 #pragma unroll
@@ -463,7 +479,7 @@ k_dense_mfma_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64
                     // MFMA costs ~15 % of the matrix pipe (134 vs 156 TF).  Convert the 8 pixels
                     // first, then issue the 8 MFMAs back to back; the conversions of one wave then
                     // overlap the MFMAs of the other wave on the SIMD.
-                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);     // 8 VALU (v_cvt)
+                    if (ABL < 5) __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // 8 v_cvt
                     __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);     // 8 MFMA
                 }
                 raw_c = raw_n;
@@ -1006,7 +1022,7 @@ extern "C" int ltmi_masks_kind(const ltmi_masks *m, int *kind) {
 extern "C" int ltmi_masks_set_tuning(ltmi_masks *m, int mt, int waves, int ksplit) {
     if (!m) LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_set_tuning: null handle");
     if (mt == 0 && (waves == 3 || waves == 5 || (waves >= 6 && waves <= 9) ||
-                    (waves >= 11 && waves <= 13))) {
+                    (waves >= 11 && waves <= 13) || (waves >= 23 && waves <= 25))) {
         // 2-byte fast kernels: waves = 3 / 5 -> v2 (LDS-DMA ring 3 / 4); 11..13 -> v3 (register
         // prefetch depth 1..3)
         m->tune_mt = 0;
@@ -1021,6 +1037,7 @@ extern "C" int ltmi_masks_set_tuning(ltmi_masks *m, int mt, int waves, int kspli
     m->tune_mt = mt;
     m->tune_waves = waves;
     m->tune_ksplit = ksplit;
+    m->tune_ksplit_ring = 0;
     return LTMI_OK;
 }
 
@@ -1078,7 +1095,7 @@ static int launch_mfma_v2(ltmi_masks *m, const T *tile, int64_t n_frames, int64_
         // CU); 11 / 12 / 13 = v3 with 1 / 2 / 3 chunks of register prefetch.
         int variant = m->tune_ksplit_ring;
         if (variant == 0) variant = 4;
-        const bool is_v3 = variant > 10;
+        const bool is_v3 = variant > 10 && variant < 20;
         const int ring = is_v3 ? variant - 10
                                : ((variant == 7 || variant == 6) ? 3 : (variant >= 8 ? 4 : variant));
         int waves = is_v3 ? V3_WAVES : (variant == 7 ? 4 : 8);
@@ -1098,15 +1115,20 @@ static int launch_mfma_v2(ltmi_masks *m, const T *tile, int64_t n_frames, int64_
         } else if (variant == 8 || variant == 9) {          // ablations of the default variant
             kern = variant == 8 ? k_dense_mfma_lds<T, 4, 8, 1> : k_dense_mfma_lds<T, 4, 8, 2>;
             lds_bytes = v2_lds_bytes(4, 8);
+        } else if (variant >= 23) {                         // 23..25: deeper ablations (bench only)
+            kern = variant == 23 ? k_dense_mfma_lds<T, 4, 8, 3>
+                                 : (variant == 24 ? k_dense_mfma_lds<T, 4, 8, 4>
+                                                  : k_dense_mfma_lds<T, 4, 8, 5>);
+            lds_bytes = v2_lds_bytes(4, 8);
         } else {
             kern = ring == 3 ? k_dense_mfma_lds<T, 3, 8> : k_dense_mfma_lds<T, 4, 8>;
             lds_bytes = v2_lds_bytes(ring, 8);
         }
-        static bool attr_set[16][16] = {{false}};
-        if (!attr_set[m->device & 15][variant & 15]) {
+        static bool attr_set[16][32] = {{false}};
+        if (!attr_set[m->device & 15][variant & 31]) {
             LTMI_HIP(hipFuncSetAttribute((const void *)kern,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-            attr_set[m->device & 15][variant & 15] = true;
+            attr_set[m->device & 15][variant & 31] = true;
         }
         const int64_t gx = (n_frames + waves * V2_ROWS - 1) / (waves * V2_ROWS);
         int ksplit = m->tune_ksplit;

@@ -3,6 +3,8 @@ import argparse
 import time
 import numpy as np
 import torch
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from libertem_amd import hip
 
 ap = argparse.ArgumentParser()
@@ -37,6 +39,8 @@ frame_bytes = n_px * dt.itemsize + args.masks * md.itemsize
 
 if args.variants == 'auto':
     variants = [dict(mt=0, waves=0, ksplit=0)]
+elif args.variants.startswith('w='):        # explicit list of `waves` codes, e.g. w=0,8,9,23,24,25
+    variants = [dict(mt=0, waves=int(w), ksplit=0) for w in args.variants[2:].split(',')]
 else:
     variants = [dict(mt=0, waves=9, ksplit=0), dict(mt=0, waves=3, ksplit=0),
                 dict(mt=0, waves=5, ksplit=0), dict(mt=0, waves=6, ksplit=0),
