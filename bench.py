@@ -192,6 +192,13 @@ def main():
         frames_per_launch = n_frames / launches_per_step
         avg_ms = float(np.mean(kms)) if kms else float('nan')
         achieved = alg_bytes_per_frame * frames_per_launch / (avg_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC passes (FETCH_SIZE x 1024 x 2 [gfx950 read correction]
+        # + WRITE_SIZE x 1024); cannot be collected from inside the timed process, so the
+        # committed profile of exactly this kernel and shape is quoted, scaled by the frame count.
+        traffic, traffic_src = None, None
+        if 'k_dense_mfma_lds' in kname and args.config == 'c2':
+            traffic = (8.7039e9 + 4.2e6) * frames_per_launch / 65536.0
+            traffic_src = "profiles/r01_final_bench_rocprof.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
         out = {
             "metric": "frames/sec, ApplyMasksUDF 16 dense f32 masks (+ GB/s vs HBM roofline)",
             "value": value,
@@ -214,7 +221,8 @@ def main():
             "input_GBps_whole_job": value * n_px * itemsize / 1e9,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel": kname, "avg_launch_ms": avg_ms, "launches_timed": len(kms),
                 "algorithmic_bytes_per_launch": alg_bytes_per_frame * frames_per_launch,
             },
