@@ -5,8 +5,14 @@ from libertem_amd.udf.masks import ApplyMasksUDF
 
 class BaseMasksAnalysis(BaseAnalysis):
     def get_udf(self):
+        # the parameters of an analysis are fixed at construction: build the factories once, so
+        # that repeated runs of the same analysis hand ApplyMasksUDF the same object and re-use
+        # the cached device image of the stack (udf/masks.py `_cached_container`)
+        factories = getattr(self, '_mask_factories_memo', None)
+        if factories is None:
+            factories = self._mask_factories_memo = self.get_mask_factories()
         return ApplyMasksUDF(
-            mask_factories=self.get_mask_factories(),
+            mask_factories=factories,
             use_sparse=self.get_use_sparse(),
             mask_count=self.get_preset_mask_count(),
             mask_dtype=self.get_preset_mask_dtype(),

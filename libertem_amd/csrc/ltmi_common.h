@@ -61,6 +61,8 @@ struct ltmi_masks {
     int ng = 1;
     int n_chunks = 0;
     float *img = nullptr;
+    float *img2 = nullptr;   // slot-major image for k_dense_lds with ng > 1 (KB = 128)
+    int n_slots2 = 0;
     float *partials = nullptr;
     size_t partials_bytes = 0;
     int tune_mt = 0, tune_waves = 0, tune_ksplit = 0, tune_ksplit_ring = 0;

@@ -41,6 +41,23 @@ __host__ __device__ static inline int img_index(int n, int q) {
     return n * KC + unit * 4 + (j & 3);
 }
 
+// raw stack (n_masks, n_px) of f32 [cpm = 1] or interleaved complex64 [cpm = 2]  ->  image
+__global__ void k_build_image(const float *__restrict__ src, float *__restrict__ img,
+                              int64_t n_masks, int cpm, int64_t n_px, int n_chunks) {
+    const int64_t total = n_masks * cpm * n_px;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        // i enumerates the source linearly: ((k * n_px + p) * cpm + part)
+        const int part = (int)(i % cpm);
+        const int64_t kp = i / cpm;
+        const int64_t k = kp / n_px, p = kp % n_px;
+        const int col = (int)(k * cpm + part);
+        const int g = col / GROUP, n = col % GROUP;
+        const int c = (int)(p / KC), q = (int)(p % KC);
+        img[((size_t)g * n_chunks + c) * CHUNK_FLOATS + img_index(n, q)] = src[i];
+    }
+}
+
 // ---- per-input-dtype loading / conversion of 8 consecutive pixels ---------------------------
 template <typename T> struct InTraits;
 
@@ -550,6 +567,310 @@ k_dense_mfma_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64
     }
 }
 
+// ---- v2g: the LDS-DMA kernel for every pixel width and 1 / 2 / 4 column groups -----------------
+// Same pipeline as k_dense_mfma_lds (wave-private frame ring filled by global_load_lds, counted vmcnt,
+// one barrier per mask slot, fragments double-buffered in registers, conversions batched ahead of
+// the MFMAs), generalised over
+//   * T: a sub-chunk is always 256 B of a row = 256 / sizeof(T) pixels (u8 256, u16 128, f32 64);
+//   * NG column groups per wave (C5: 25 complex masks = 50 real columns = 4 groups): the frame
+//     fragment of a block is converted once and used for NG x 8 MFMAs.
+// The mask image for NG > 1 ("image 2") is slot-major: slot k = pixels [k*KB, (k+1)*KB), KB = 128,
+// holds its NG groups back to back (NG x 8 KiB), so one slot is a linear DMA copy:
+//   float offset = (((gt * n_slots + k) * NG + g) * 16 + n) * KB + ((kg*(KB/16) + blk*2 + h) ^ n)*4 + (q&3)
+// with blk = q >> 5, kg = (q >> 3) & 3, h = (q >> 2) & 1 inside the slot; NG = 1 uses the standard
+// image (KB = 256, which this formula reproduces).
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int NG> struct LdsCfg {
+    static constexpr int KB = NG == 1 ? KC : 128;               // pixels per mask slot
+    static constexpr int BSLOT = NG * GROUP * KB * 4;           // bytes per mask slot: 16 / 16 / 32 KiB
+    static constexpr int RING = BSLOT > 16384 ? 3 : 4;          // frame ring depth (sub-chunks)
+    static constexpr int WAVES = 8;
+    static constexpr int LDS_BYTES = RING * WAVES * V2_ASLOT + 2 * BSLOT;      // 160 KiB
+};
+
+__host__ __device__ static inline int img2_index(int n, int q, int kb) {
+    const int blk = q >> 5, kg = (q >> 3) & 3, j = q & 7;
+    const int unit = (kg * (kb / 16) + blk * 2 + (j >> 2)) ^ n;
+    return n * kb + unit * 4 + (j & 3);
+}
+
+// raw stack -> image 2 (see above); ng = groups per tile, n_gt = group tiles
+__global__ void k_build_image2(const float *__restrict__ src, float *__restrict__ img,
+                               int64_t n_masks, int cpm, int64_t n_px, int n_slots, int ng, int kb) {
+    const int64_t total = n_masks * cpm * n_px;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int part = (int)(i % cpm);
+        const int64_t kp = i / cpm;
+        const int64_t k = kp / n_px, p = kp % n_px;
+        const int col = (int)(k * cpm + part);
+        const int g = col / GROUP, n = col % GROUP;
+        const int gt = g / ng, gl = g % ng;
+        const int slot = (int)(p / kb), q = (int)(p % kb);
+        img[((((size_t)gt * n_slots + slot) * ng + gl) * GROUP) * kb + img2_index(n, q, kb)] = src[i];
+    }
+}
+
+template <typename T, int NG, int ABL = 0>
+__global__ void __launch_bounds__(LdsCfg<NG>::WAVES * 64)
+k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
+            const float *__restrict__ img, int n_slots, float *__restrict__ out, int64_t ld_out,
+            int n_cols, int accumulate, float *__restrict__ partials, int ksplit) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    using TR = InTraits<T>;
+    using CFG = LdsCfg<NG>;
+    constexpr int WAVES = CFG::WAVES, RING = CFG::RING, KB = CFG::KB, BSLOT = CFG::BSLOT;
+    constexpr int SPX = V2_SUB_BYTES / (int)sizeof(T);  // pixels per sub-chunk
+    static_assert(SPX <= KB && KB % SPX == 0, "a sub-chunk must not straddle mask slots");
+    constexpr int PER = KB / SPX;                       // sub-chunks per mask slot
+    constexpr int BLKS = SPX / 32;                      // MFMA pixel blocks per sub-chunk (2/4/8)
+    constexpr int NT = WAVES * 64;
+    constexpr int A_BYTES = RING * WAVES * V2_ASLOT;
+    constexpr int BPW = BSLOT / WAVES;                  // mask-slot bytes each wave copies
+    constexpr int NBI = BPW / 1024;                     // ... in this many DMA instructions
+    constexpr int A_N = 4 * (RING - 2);                 // DMA instructions of the later sub-chunks
+    constexpr int NACC = NG == 1 ? 2 : 1;               // accumulators per group
+    constexpr int SLOT_FLOATS = BSLOT / 4;
+    constexpr bool CVT = !std::is_same<T, float>::value;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int m = lane & 15, kg = lane >> 4;
+    const int ks = blockIdx.y;
+    const int gt = blockIdx.z;
+
+    const int n_full = (int)(n_px / KB);                 // slots readable by DMA
+    const int per = (n_slots + ksplit - 1) / ksplit;
+    const int k_begin = ks * per;
+    const int k_end = min(n_slots, k_begin + per);
+    const int kf_end = min(k_end, n_full);
+    const float *img_t = img + (size_t)gt * n_slots * SLOT_FLOATS;
+
+    const int64_t f_wave = (int64_t)blockIdx.x * (WAVES * V2_ROWS) + wave * V2_ROWS;
+    unsigned char *a_base = lds_raw + wave * V2_ASLOT;   // + slot * (WAVES * V2_ASLOT)
+    unsigned char *b_base = lds_raw + A_BYTES;           // + bslot * BSLOT
+
+    f32x4 acc[NG][NACC];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int x = 0; x < NACC; ++x) acc[g][x] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // lane-constant parts of the fragment addresses
+    const int a_lane = m * V2_SUB_BYTES;                 // bytes inside a frame slot
+    const int b_lane = m * KB;                           // floats inside a group of a mask slot
+    auto b_unit = [&](int blk_in_slot, int h) {          // swizzled 16-B unit of (blk, h) for this lane
+        return ((kg * (KB / 16) + blk_in_slot * 2 + h) ^ m) << 2;
+    };
+
+    if (k_begin < kf_end) {
+        const unsigned char *src[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int r = 4 * t + (lane >> 4);
+            int64_t f = f_wave + r;
+            if (f > n_frames - 1) f = n_frames - 1;
+            const int piece = (lane & 15) ^ (r & 15);
+            src[t] = (const unsigned char *)(tile + f * ld) + piece * 16;
+        }
+        const unsigned char *bsrc = (const unsigned char *)img_t + wave * BPW + lane * 16;
+        const int S0 = k_begin * PER, S1 = kf_end * PER;      // sub-chunk range
+
+        auto issue_a1 = [&](int s, int slot, int t) {
+            if (ABL >= 2) return;
+            const int sc = min(s, S1 - 1);
+            unsigned char *dst = a_base + slot * (WAVES * V2_ASLOT);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[t] + (int64_t)sc * V2_SUB_BYTES),
+                                             (lds_ptr_t)(dst + t * 1024), 16, 0, 2 /*nt*/);
+        };
+        auto issue_b = [&](int gidx) {                  // mask slot k_begin + gidx -> LDS slot gidx & 1
+            if (ABL >= 2) return;
+            const int kk = min(k_begin + gidx, kf_end - 1);
+            unsigned char *dst = b_base + (gidx & 1) * BSLOT + wave * BPW;
+            const unsigned char *sp = bsrc + (int64_t)kk * BSLOT;
+#pragma unroll
+            for (int u = 0; u < NBI; ++u)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(sp + u * 1024),
+                                                 (lds_ptr_t)(dst + u * 1024), 16, 0, 0);
+        };
+
+#pragma unroll
+        for (int t = 0; t < 4; ++t) issue_a1(S0, 0, t);
+        issue_b(0);
+#pragma unroll
+        for (int d = 1; d < RING - 1; ++d)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) issue_a1(S0 + d, d, t);
+
+        // One sub-chunk.  ph = i % UNROLL as a compile-time constant in the unrolled main loop
+        // (ring slot, mask slot and block offsets become immediates) or -1 in the generic tail.
+        auto iteration = [&](int s, auto ph) {
+            constexpr int PH = decltype(ph)::value;
+            const int i = s - S0;
+            const int ip = PH >= 0 ? PH % PER : i % PER;           // position inside the mask slot
+            // DMA issue order per wave: ... A(s) | [B at the start of every PER-th iteration]
+            // A(s+1) ... A(s+RING-2).  ip == 0: the slot issued PER iterations ago and A(s) must
+            // have landed -> at most min(PER, RING-2) later sub-chunks may stay in flight.
+            // ip > 0: A(s) must have landed; later sub-chunks and every mask slot issued after
+            // A(s) (iterations i-ip-k*PER >= i-RING+2) may stay in flight.
+            if (ip == 0) {
+                constexpr int N0 = 4 * (PER < RING - 2 ? PER : RING - 2);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N0) : "memory");
+                if (ABL < 3) __builtin_amdgcn_s_barrier();
+                issue_b(i / PER + 1);
+            } else {
+                int nb = 0;
+#pragma unroll
+                for (int k = 0; k < RING; ++k) nb += (ip + k * PER <= RING - 2) ? 1 : 0;
+                if (nb == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_N) : "memory");
+                else if (nb == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_N + NBI) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_N + 2 * NBI) : "memory");
+            }
+            const int slot = PH >= 0 ? PH % RING : i % RING;
+            const int nslot = PH >= 0 ? (PH + RING - 1) % RING : (i + RING - 1) % RING;
+            const int bsl = PH >= 0 ? (PH / PER) & 1 : (i / PER) & 1;
+            const int blk0 = ip * BLKS;                             // block offset inside the mask slot
+            const unsigned char *aslot = a_base + slot * (WAVES * V2_ASLOT) + a_lane;
+            const float *bslot = (const float *)(b_base + bsl * BSLOT) + b_lane;
+            auto rd_a = [&](int blk) {
+                const int u = blk * 4 + kg;             // 8-pixel unit of this lane inside the sub-chunk
+                if constexpr (sizeof(T) == 2) {
+                    return *(const typename TR::raw_t *)(aslot + ((u ^ m) << 4));
+                } else if constexpr (sizeof(T) == 4) {
+                    typename TR::raw_t r;
+                    r.a = *(const f32x4 *)(aslot + (((2 * u) ^ m) << 4));
+                    r.b = *(const f32x4 *)(aslot + (((2 * u + 1) ^ m) << 4));
+                    return r;
+                } else {
+                    return *(const typename TR::raw_t *)(aslot + (((u >> 1) ^ m) << 4) + (u & 1) * 8);
+                }
+            };
+            auto rd_b = [&](int blk, int g, int h) {
+                return *(const f32x4 *)(bslot + g * (GROUP * KB) + b_unit(blk0 + blk, h));
+            };
+            typename TR::raw_t raw_c = rd_a(0);
+            f32x4 b_c[NG][2];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) { b_c[g][0] = rd_b(0, g, 0); b_c[g][1] = rd_b(0, g, 1); }
+#pragma unroll
+            for (int blk = 0; blk < BLKS; ++blk) {
+                typename TR::raw_t raw_n = raw_c;
+                f32x4 b_n[NG][2];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) { b_n[g][0] = b_c[g][0]; b_n[g][1] = b_c[g][1]; }
+                if (blk + 1 < BLKS) {
+                    raw_n = rd_a(blk + 1);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        b_n[g][0] = rd_b(blk + 1, g, 0);
+                        b_n[g][1] = rd_b(blk + 1, g, 1);
+                    }
+                }
+                // the 4 DMA instructions of sub-chunk s+RING-1 are spread over the BLKS blocks
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if ((t * BLKS) / 4 == blk) issue_a1(s + RING - 1, nslot, t);
+                __builtin_amdgcn_sched_barrier(0);      // keep the prefetch reads above the MFMAs
+                float a[8];
+                TR::cvt(raw_c, a);
+                if (ABL == 1) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+                            acc[g][j & (NACC - 1)][j & 3] += a[j] + b_c[g][j >> 2][j & 3];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+                            acc[g][j & (NACC - 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                a[j], b_c[g][j >> 2][j & 3], acc[g][j & (NACC - 1)], 0, 0, 0);
+                    if (CVT) __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);     // 8 conversions
+                    __builtin_amdgcn_sched_group_barrier(0x008, 8 * NG, 0);         // then the MFMAs
+                }
+                raw_c = raw_n;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) { b_c[g][0] = b_n[g][0]; b_c[g][1] = b_n[g][1]; }
+            }
+        };
+
+        // unroll period: ring slot (i % RING) and mask-slot parity ((i / PER) & 1) both static
+        constexpr int U2 = 2 * PER;
+        constexpr int UNROLL = (RING % U2 == 0) ? RING : ((U2 % RING == 0) ? U2 : RING * U2 /
+                               ((RING % 2 == 0 && U2 % 2 == 0) ? 2 : 1));
+        static_assert(UNROLL % RING == 0 && UNROLL % U2 == 0, "unroll period");
+        int s = S0;
+        if constexpr (UNROLL <= 12) {
+            for (; s + UNROLL <= S1; s += UNROLL) {
+                static_for<0, UNROLL>([&](auto I) { iteration(s + decltype(I)::value, I); });
+            }
+        }
+        for (; s < S1; ++s) iteration(s, std::integral_constant<int, -1>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the clamped prefetches
+    }
+
+    // ragged last slot (n_px % KB != 0): guarded element loads, mask slot staged by plain copies
+    if (k_end > n_full) {
+        const int k = n_full;
+        __syncthreads();
+        float *bl = (float *)b_base;
+        const u32x4 *img_units = (const u32x4 *)(img_t + (size_t)k * SLOT_FLOATS);
+#pragma unroll
+        for (int i = 0; i < SLOT_FLOATS / 4 / NT; ++i)
+            ((u32x4 *)bl)[i * NT + tid] = img_units[i * NT + tid];
+        __syncthreads();
+        int64_t f = f_wave + m;
+        if (f > n_frames - 1) f = n_frames - 1;
+        const T *rowp = tile + f * ld + kg * 8;
+        const float *ldsb = bl + b_lane;
+#pragma unroll
+        for (int blk = 0; blk < KB / 32; ++blk) {
+            const int64_t p0 = (int64_t)k * KB + blk * 32;
+            float a[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                a[j] = (p0 + kg * 8 + j < n_px) ? (float)rowp[p0 + j] : 0.f;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                f32x4 b[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    b[h] = *(const f32x4 *)(ldsb + g * (GROUP * KB) + b_unit(blk, h));
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    acc[g][j & (NACC - 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                        a[j], b[j >> 2][j & 3], acc[g][j & (NACC - 1)], 0, 0, 0);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t f = f_wave + kg * 4 + r;
+            const int col = (gt * NG + g) * GROUP + m;
+            if (f < n_frames && col < n_cols) {
+                float v = acc[g][0][r];
+                if (NACC == 2) v += acc[g][NACC - 1][r];
+                if (ksplit == 1) {
+                    float *p = out + f * ld_out + col;
+                    *p = accumulate ? (*p + v) : v;
+                } else {
+                    partials[((int64_t)ks * n_frames + f) * n_cols + col] = v;
+                }
+            }
+        }
+}
+
 // ---- v3: full-line loads into registers, wave-private LDS transpose ------------------------------
 // The LDS ring of v2 caps the bytes in flight at ~80 KiB per CU (160 KiB LDS); the register file is
 // 512 KiB per CU.  v3 streams frames with full-line loads (one instruction = 2 frame rows x 512 B
@@ -938,32 +1259,6 @@ extern "C" int ltmi_masks_create_dense(int device, const void *masks_host, int r
         m->ng = groups == 1 ? 1 : (groups == 2 ? 2 : 4);
         m->n_groups = (groups + m->ng - 1) / m->ng * m->ng;
         m->n_chunks = (int)((n_px + KC - 1) / KC);
-        const size_t n_float = (size_t)m->n_groups * m->n_chunks * CHUNK_FLOATS;
-        std::vector<float> img;
-        try { img.assign(n_float, 0.f); } catch (...) {
-            delete m;
-            LTMI_FAIL(LTMI_E_NOMEM, "out of host memory for the mask image");
-        }
-        const float *src = (const float *)masks_host;   // f32, or interleaved (re, im) pairs
-        for (int64_t k = 0; k < n_masks; ++k) {
-            for (int part = 0; part < cpm; ++part) {
-                const int col = (int)(k * cpm + part);
-                const int g = col / GROUP, n = col % GROUP;
-                for (int64_t p = 0; p < n_px; ++p) {
-                    const int c = (int)(p / KC), q = (int)(p % KC);
-                    img[((size_t)g * m->n_chunks + c) * CHUNK_FLOATS + img_index(n, q)] =
-                        src[(k * n_px + p) * cpm + part];
-                }
-            }
-        }
-        hipError_t e = hipMalloc((void **)&m->img, n_float * sizeof(float));
-        if (e == hipSuccess)
-            e = hipMemcpy(m->img, img.data(), n_float * sizeof(float), hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            if (m->img) (void)hipFree(m->img);
-            delete m;
-            LTMI_FAIL((int)e, "uploading the mask image failed: %s", hipGetErrorString(e));
-        }
     }
     // the generic image is always kept too: it serves tile dtypes the MFMA path does not take
     {
@@ -998,6 +1293,43 @@ extern "C" int ltmi_masks_create_dense(int device, const void *masks_host, int r
             LTMI_FAIL((int)e, "uploading the mask stack failed: %s", hipGetErrorString(e));
         }
     }
+    if (m->kind == 0) {
+        // MFMA image: swizzled on the device from the raw stack uploaded above (f32, or
+        // interleaved (re, im) pairs) -- no host-side transform, no second upload
+        const int cpm = (result_dtype == LTMI_C64) ? 2 : 1;
+        const size_t n_float = (size_t)m->n_groups * m->n_chunks * CHUNK_FLOATS;
+        hipError_t e = hipMalloc((void **)&m->img, n_float * sizeof(float));
+        if (e == hipSuccess) e = hipMemset(m->img, 0, n_float * sizeof(float));
+        if (e == hipSuccess) {
+            const int64_t total = n_masks * cpm * n_px;
+            const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 65535 * 16);
+            hipLaunchKernelGGL(ltmi::k_build_image, dim3(blocks), dim3(256), 0, 0,
+                               (const float *)m->gmasks, m->img, n_masks, cpm, n_px, m->n_chunks);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+        }
+        if (e == hipSuccess && m->ng > 1) {
+            // slot-major image for the LDS-DMA kernel with several column groups (k_dense_lds)
+            constexpr int kb = 128;
+            m->n_slots2 = (int)((n_px + kb - 1) / kb);
+            const size_t n2 = (size_t)m->n_groups * m->n_slots2 * GROUP * kb;
+            e = hipMalloc((void **)&m->img2, n2 * sizeof(float));
+            if (e == hipSuccess) e = hipMemset(m->img2, 0, n2 * sizeof(float));
+            if (e == hipSuccess) {
+                const int64_t total = n_masks * cpm * n_px;
+                const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 65535 * 16);
+                hipLaunchKernelGGL(ltmi::k_build_image2, dim3(blocks), dim3(256), 0, 0,
+                                   (const float *)m->gmasks, m->img2, n_masks, cpm, n_px,
+                                   m->n_slots2, m->ng, kb);
+                e = hipGetLastError();
+                if (e == hipSuccess) e = hipDeviceSynchronize();
+            }
+        }
+        if (e != hipSuccess) {
+            ltmi_masks_destroy(m);
+            LTMI_FAIL((int)e, "building the mask image failed: %s", hipGetErrorString(e));
+        }
+    }
     *out = m;
     return LTMI_OK;
 }
@@ -1006,6 +1338,7 @@ extern "C" int ltmi_masks_destroy(ltmi_masks *m) {
     if (!m) return LTMI_OK;
     (void)hipSetDevice(m->device);
     if (m->img) (void)hipFree(m->img);
+    if (m->img2) (void)hipFree(m->img2);
     if (m->partials) (void)hipFree(m->partials);
     if (m->gmasks) (void)hipFree(m->gmasks);
     if (m->csr) (void)ltmi::csr_destroy(m);
@@ -1022,7 +1355,8 @@ extern "C" int ltmi_masks_kind(const ltmi_masks *m, int *kind) {
 extern "C" int ltmi_masks_set_tuning(ltmi_masks *m, int mt, int waves, int ksplit) {
     if (!m) LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_set_tuning: null handle");
     if (mt == 0 && (waves == 3 || waves == 5 || (waves >= 6 && waves <= 9) ||
-                    (waves >= 11 && waves <= 13) || (waves >= 23 && waves <= 25))) {
+                    (waves >= 11 && waves <= 13) || (waves >= 23 && waves <= 25) ||
+                    (waves >= 30 && waves <= 32))) {
         // 2-byte fast kernels: waves = 3 / 5 -> v2 (LDS-DMA ring 3 / 4); 11..13 -> v3 (register
         // prefetch depth 1..3)
         m->tune_mt = 0;
@@ -1167,13 +1501,89 @@ static int launch_mfma_v2(ltmi_masks *m, const T *tile, int64_t n_frames, int64_
     }
 }
 
+// generalised LDS-DMA kernel (k_dense_lds): any pixel width, 1 / 2 / 4 column groups per wave
+template <typename T, int NG>
+static int launch_lds_ng(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
+                         int64_t ld_out, int accumulate, hipStream_t stream) {
+    using CFG = LdsCfg<NG>;
+    const int abl = m->tune_ksplit_ring == 31 ? 2 : (m->tune_ksplit_ring == 32 ? 1 : 0);
+    void (*kern)(const T *, int64_t, int64_t, int64_t, const float *, int, float *, int64_t, int,
+                 int, float *, int) =
+        abl == 2 ? k_dense_lds<T, NG, 2> : (abl == 1 ? k_dense_lds<T, NG, 1> : k_dense_lds<T, NG, 0>);
+    static bool attr_set[16][3] = {{false}};
+    if (!attr_set[m->device & 15][abl]) {
+        LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     CFG::LDS_BYTES));
+        attr_set[m->device & 15][abl] = true;
+    }
+    const float *img = NG == 1 ? m->img : m->img2;
+    const int n_slots = NG == 1 ? m->n_chunks : m->n_slots2;
+    const int64_t gx = (n_frames + CFG::WAVES * V2_ROWS - 1) / (CFG::WAVES * V2_ROWS);
+    const int64_t gz = m->n_groups / NG;
+    int ksplit = m->tune_ksplit;
+    if (ksplit <= 0) {
+        ksplit = 1;
+        if (gx * gz < 256)      // fewer workgroups than CUs: split the pixel axis
+            ksplit = (int)std::min<int64_t>((512 + gx * gz - 1) / (gx * gz),
+                                            std::max(1, n_slots / 16));
+    }
+    ksplit = std::max(1, std::min(ksplit, n_slots));
+    {
+        const int per = (n_slots + ksplit - 1) / ksplit;
+        ksplit = (n_slots + per - 1) / per;
+    }
+    if (ksplit > 1) {
+        int rc = ensure_partials(m, (size_t)ksplit * n_frames * m->n_cols * sizeof(float), stream);
+        if (rc != LTMI_OK) return rc;
+    }
+    dim3 grid((unsigned)gx, (unsigned)ksplit, (unsigned)gz);
+    hipLaunchKernelGGL(kern, grid, dim3(CFG::WAVES * 64), CFG::LDS_BYTES, stream, tile, ld, n_frames,
+                       m->n_px, img, n_slots, out, ld_out, m->n_cols, accumulate, m->partials,
+                       ksplit);
+    LTMI_HIP(hipGetLastError());
+    snprintf(m->last_kernel, sizeof(m->last_kernel), "k_dense_lds<%s,NG=%d,ring=%d%s> grid=(%u,%u,%u)",
+             typeid(T).name(), NG, CFG::RING, abl ? (abl == 2 ? ",noDMA" : ",noMFMA") : "", grid.x,
+             grid.y, grid.z);
+    if (ksplit > 1) {
+        const int64_t n = n_frames * m->n_cols;
+        hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                           stream, (const float *)m->partials, ksplit, n_frames, m->n_cols, out,
+                           ld_out, accumulate);
+        LTMI_HIP(hipGetLastError());
+    }
+    return LTMI_OK;
+}
+
+template <typename T>
+static bool lds_kernel_applies(const ltmi_masks *m) {
+    if (sizeof(T) == 1 && m->ng > 1) return false;            // 256-px sub-chunks need NG == 1
+    return m->n_px >= (m->ng == 1 ? KC : 128);
+}
+
+template <typename T>
+static int launch_lds(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
+                      int64_t ld_out, int accumulate, hipStream_t stream) {
+    if (m->ng == 1)
+        return launch_lds_ng<T, 1>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+    if constexpr (sizeof(T) > 1) {
+        if (m->ng == 2)
+            return launch_lds_ng<T, 2>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+        return launch_lds_ng<T, 4>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+    }
+    LTMI_FAIL(LTMI_E_DTYPE, "k_dense_lds: 1-byte pixels need a single column group");
+}
+
 template <typename T>
 static int launch_mfma(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
                        int64_t ld_out, int accumulate, hipStream_t stream) {
     const bool aligned = (((uintptr_t)tile) % 16 == 0) && ((ld * (int64_t)sizeof(T)) % 16 == 0);
-    if (sizeof(T) == 2 && aligned && m->n_groups == 1 && m->n_px >= KC && m->tune_mt == 0 &&
-        m->tune_waves == 0)
-        return launch_mfma_v2<T>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+    if (aligned && m->tune_mt == 0 && m->tune_waves == 0) {
+        const bool force_general = m->tune_ksplit_ring >= 30;
+        if (sizeof(T) == 2 && m->n_groups == 1 && m->n_px >= KC && !force_general)
+            return launch_mfma_v2<T>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+        if (lds_kernel_applies<T>(m) && (force_general || m->tune_ksplit_ring == 0))
+            return launch_lds<T>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+    }
     int waves = m->tune_waves ? m->tune_waves : 4;
     int mt = m->tune_mt ? m->tune_mt : (n_frames >= 256 * waves * 32 ? 2 : 1);
     if (m->ng == 4) { mt = 1; }   // keep the accumulator/LDS budget in check

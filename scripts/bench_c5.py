@@ -2,15 +2,17 @@ import sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from libertem_amd import hip
-frames, sig, nm = 2048, 1024, 25
+frames, sig, nm = int(os.environ.get('FRAMES', 8192)), 1024, 25
 n_px = sig * sig
 tile = torch.rand((frames, n_px), device='cuda', dtype=torch.float32)
 rng = np.random.default_rng(2)
 masks = (rng.random((nm, n_px)) + 1j * rng.random((nm, n_px))).astype(np.complex64)
 h = hip.MaskHandle.dense(0, masks, np.complex64)
 out = torch.zeros((frames, nm), device='cuda', dtype=torch.complex64)
-for v in [dict(mt=0, waves=0, ksplit=0), dict(mt=1, waves=8, ksplit=0), dict(mt=1, waves=8, ksplit=8),
-          dict(mt=1, waves=4, ksplit=8), dict(mt=1, waves=8, ksplit=16)]:
+for v in [dict(mt=0, waves=0, ksplit=0), dict(mt=1, waves=8, ksplit=0), dict(mt=1, waves=8, ksplit=4),
+          dict(mt=1, waves=8, ksplit=8), dict(mt=1, waves=4, ksplit=4), dict(mt=1, waves=4, ksplit=8),
+          dict(mt=2, waves=4, ksplit=4), dict(mt=2, waves=4, ksplit=8), dict(mt=2, waves=8, ksplit=8),
+          dict(mt=2, waves=8, ksplit=16)]:
     h.set_tuning(**v)
     for _ in range(2):
         h.apply(tile.data_ptr(), np.float32, frames, n_px, out.data_ptr(), nm, False)

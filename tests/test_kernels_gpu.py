@@ -83,7 +83,7 @@ def test_mfma_f32(hip, tile_dtype, shape):
         data = (rng.random((n_frames, n_px)) - 0.3).astype(dt)
     masks = (rng.random((n_masks, n_px)) - 0.25).astype(np.float32)
     res, kern = _apply(hip, data, masks, np.float32)
-    assert 'k_dense_mfma' in kern, kern
+    assert 'k_dense_mfma' in kern or 'k_dense_lds' in kern, kern
     ref = _ref64(data, masks)
     scale = np.abs(data.astype(np.float64)) @ np.abs(masks.astype(np.float64)).T
     # f32 accumulation error bound relative to sum |a||b|: 1e-5 rel (north_star tolerance)
@@ -111,6 +111,43 @@ def test_mfma_variants_agree(hip, tuning):
     assert np.all(np.abs(res2 - (ref + base)) <= 1e-5 * (scale + 1))
 
 
+@pytest.mark.parametrize('tile_dtype', ['uint8', 'int8', 'uint16', 'int16', 'float32'])
+@pytest.mark.parametrize('shape,ksplit', [
+    ((300, 256 * 41 + 112, 16), 0),     # NG=1: unrolled main loop + generic tail + ragged slot
+    ((300, 256 * 41 + 112, 16), 3),     # ... with a K split
+    ((129, 128 * 53 + 16, 24), 0),       # NG=2
+    ((77, 128 * 61 + 48, 50), 0),       # NG=4 (C5-like: 50 real columns)
+    ((77, 128 * 61 + 48, 50), 4),
+    ((40, 128 * 30, 70), 0),            # 5 groups -> two group tiles of NG=4
+])
+def test_lds_dma_kernel_all_widths(hip, tile_dtype, shape, ksplit):
+    """k_dense_lds (frames through LDS by DMA) for every pixel width and group count; forced with
+    tuning code 30 where the default dispatch would pick another kernel."""
+    n_frames, n_px, n_masks = shape
+    rng = np.random.default_rng(hash((tile_dtype,) + shape) % (2**32))
+    dt = np.dtype(tile_dtype)
+    if dt.kind == 'u':
+        data = rng.integers(0, min(4096, np.iinfo(dt).max), (n_frames, n_px)).astype(dt)
+    elif dt.kind == 'i':
+        data = rng.integers(max(-2000, np.iinfo(dt).min), min(2000, np.iinfo(dt).max),
+                            (n_frames, n_px)).astype(dt)
+    else:
+        data = (rng.random((n_frames, n_px)) - 0.3).astype(dt)
+    masks = (rng.random((n_masks, n_px)) - 0.25).astype(np.float32)
+    res, kern = _apply(hip, data, masks, np.float32, tuning=dict(mt=0, waves=30, ksplit=ksplit))
+    if dt.itemsize == 1 and n_masks > 16:
+        assert 'k_dense_mfma<' in kern, kern       # 1-byte pixels with several groups: direct-load kernel
+    else:
+        assert 'k_dense_lds' in kern, kern
+    ref = _ref64(data, masks)
+    scale = np.abs(data.astype(np.float64)) @ np.abs(masks.astype(np.float64)).T
+    assert np.all(np.abs(res - ref) <= 1e-5 * scale + 1e-30)
+    base = rng.random((n_frames, n_masks)).astype(np.float32)
+    res2, _ = _apply(hip, data, masks, np.float32, accumulate_into=base,
+                     tuning=dict(mt=0, waves=30, ksplit=ksplit))
+    assert np.all(np.abs(res2 - (ref + base)) <= 1e-5 * (scale + 1))
+
+
 def test_mfma_integer_exact(hip):
     # 0/1 masks on low-count data: every partial sum is an integer < 2**24 -> any order exact
     rng = np.random.default_rng(11)
@@ -127,7 +164,7 @@ def test_mfma_complex_masks(hip):
     data = rng.integers(0, 1000, (40, 1000)).astype(np.uint16)
     masks = (rng.random((5, 1000)) - 0.5 + 1j * (rng.random((5, 1000)) - 0.5)).astype(np.complex64)
     res, kern = _apply(hip, data, masks, np.complex64)
-    assert 'k_dense_mfma' in kern
+    assert 'k_dense_mfma' in kern or 'k_dense_lds' in kern
     ref = _ref64(data, masks)
     scale = np.abs(data.astype(np.float64)) @ np.abs(masks).astype(np.float64).T
     assert np.all(np.abs(res - ref) <= 1e-5 * scale)
