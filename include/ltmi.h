@@ -120,6 +120,23 @@ int ltmi_sum_sig(int device, const void *tile, int tile_dtype, int64_t n_frames,
 /* merge for sig-kind buffers: dest[i] += src[i]          (src/libertem/udf/sum.py:50-52) */
 int ltmi_axpy(int device, void *dest, const void *src, int dtype, int64_t n, void *stream);
 
+/* ---- detector corrections -------------------------------------------------------------------
+ * Replaces CorrectionSet.apply -> detector.correct on a tile (src/libertem/io/corrections/
+ * corrset.py:140-166, detector.py:17-101, called from io/dataset/base/backend.py:121-124) fused
+ * with the astype(read_dtype) copy of io/dataset/memory.py:102-105:
+ *   out[f, p] = ((double)tile[f, p] - dark[p]) * gain[p]      (dark / gain may be NULL)
+ * `dark`, `gain`: DEVICE float64 arrays of n_px.  out: device (n_frames, n_px) of F32 or F64.
+ */
+int ltmi_correct(int device, const void *tile, int tile_dtype, int64_t n_frames, int64_t n_px,
+                 int64_t ld_tile, const double *dark, const double *gain, void *out, int out_dtype,
+                 int64_t ld_out, void *stream);
+/* dead-pixel repair, in place: buf[f, excl[e]] = mean(buf[f, env[e][0..cnt[e])]) for all frames.
+ * Tables as built by RepairDescriptor (detector.py:278-312): DEVICE int32 arrays excl[n_excl],
+ * env[n_excl][max_env] (flat pixel indices of the good neighbours), cnt[n_excl]. */
+int ltmi_repair_pixels(int device, void *buf, int dtype, int64_t n_frames, int64_t ld,
+                       const int32_t *excl, const int32_t *env, const int32_t *cnt, int n_excl,
+                       int max_env, void *stream);
+
 /* ---- tuning / introspection (bench + tests) ------------------------------------------- */
 /* force a kernel variant for the dense MFMA path (bench / tests only; (0,0,0) = automatic):
  *   mt in {1,2}, waves in {4,8}: the direct-load kernel k_dense_mfma with that tile shape;

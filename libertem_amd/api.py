@@ -154,15 +154,16 @@ class Context:
         """
         if not sync:
             raise NotImplementedError("only sync=True is available in libertem_amd")
-        if corrections is not None and getattr(corrections, 'have_corrections', lambda: False)():
-            raise NotImplementedError("detector corrections are out of scope of libertem_amd")
+        if corrections is not None and not corrections.have_corrections():
+            corrections = None
         udf_is_list = isinstance(udf, (tuple, list))
         udfs = list(udf) if udf_is_list else [udf]
         if roi is not None:
             roi = self._normalize_roi(roi, dataset)
         runner = UDFRunner(udfs)
         res = runner.run_for_dataset(dataset=dataset, executor=self.executor, roi=roi,
-                                     progress=progress, corrections=None, backends=backends)
+                                     progress=progress, corrections=corrections,
+                                     backends=backends)
         buffers = res.buffers
         return tuple(buffers) if udf_is_list else buffers[0]
 
@@ -174,8 +175,10 @@ class Context:
         if roi is not None:
             roi = self._normalize_roi(roi, dataset)
         runner = UDFRunner(udfs)
+        if corrections is not None and not corrections.have_corrections():
+            corrections = None
         for part in runner.run_for_dataset_sync(dataset=dataset, executor=self.executor, roi=roi,
-                                                progress=progress, corrections=None,
+                                                progress=progress, corrections=corrections,
                                                 backends=backends, iterate=True):
             if not udf_is_list:
                 part.buffers  # noqa: B018  (materialise lazily built result)

@@ -239,6 +239,110 @@ extern "C" int ltmi_sum_frames(int device, const void *tile, int tile_dtype, int
               dtype_name(tile_dtype), dtype_name(out_dtype));
 }
 
+// ---- detector corrections (reference io/corrections/detector.py:17-101) -----------------------------
+// out[f, p] = ((double)tile[f, p] - dark[p]) * gain[p], rounded once to the output type: a float32
+// buffer corrected with float64 dark / gain arrays is computed in float64 by the reference's loop too.
+// One thread owns 4 consecutive pixels (dark / gain live in registers) and walks a slab of frames.
+template <typename TIn, typename TOut>
+__global__ void __launch_bounds__(256)
+k_correct(const TIn *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
+          const double *__restrict__ dark, const double *__restrict__ gain, TOut *__restrict__ out,
+          int64_t ld_out, int frames_per_block) {
+    const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p0 >= n_px) return;
+    const int np = (int)min<int64_t>(4, n_px - p0);
+    double d[4], g[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        d[j] = (dark && j < np) ? dark[p0 + j] : 0.0;
+        g[j] = (gain && j < np) ? gain[p0 + j] : 1.0;
+    }
+    const int64_t f0 = (int64_t)blockIdx.y * frames_per_block;
+    const int64_t f1 = min<int64_t>(n_frames, f0 + frames_per_block);
+    for (int64_t f = f0; f < f1; ++f) {
+        const TIn *src = tile + f * ld + p0;
+        TOut *dst = out + f * ld_out + p0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < np) dst[j] = (TOut)(((double)src[j] - d[j]) * g[j]);
+    }
+}
+
+// buf[f, excl[e]] = mean of buf[f, env[e][0 .. cnt[e])] in float64 (environments hold good pixels
+// only, so the patches are independent of each other)
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_repair_pixels(T *__restrict__ buf, int64_t ld, int64_t n_frames, const int32_t *__restrict__ excl,
+                const int32_t *__restrict__ env, const int32_t *__restrict__ cnt, int n_excl,
+                int max_env) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_frames * n_excl) return;
+    const int64_t f = i / n_excl;
+    const int e = (int)(i % n_excl);
+    const int c = cnt[e];
+    if (c <= 0) return;
+    T *row = buf + f * ld;
+    double acc = 0.0;
+    for (int j = 0; j < c; ++j) acc += (double)row[env[(int64_t)e * max_env + j]];
+    row[excl[e]] = (T)(acc / (double)c);
+}
+
+template <typename TIn, typename TOut>
+static int run_correct(const void *tile, int64_t n_frames, int64_t n_px, int64_t ld,
+                       const double *dark, const double *gain, void *out, int64_t ld_out,
+                       hipStream_t stream) {
+    const int64_t gx = (n_px + 1023) / 1024;
+    // enough blocks to fill the chip, frames slabs of at least 16
+    int64_t gy = std::max<int64_t>(1, std::min<int64_t>((n_frames + 15) / 16, (4096 + gx - 1) / gx));
+    gy = std::min<int64_t>(gy, 65535);
+    const int fpb = (int)((n_frames + gy - 1) / gy);
+    gy = (n_frames + fpb - 1) / fpb;
+    hipLaunchKernelGGL((k_correct<TIn, TOut>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, stream,
+                       (const TIn *)tile, ld, n_frames, n_px, dark, gain, (TOut *)out, ld_out, fpb);
+    LTMI_HIP(hipGetLastError());
+    return LTMI_OK;
+}
+
+extern "C" int ltmi_correct(int device, const void *tile, int tile_dtype, int64_t n_frames,
+                            int64_t n_px, int64_t ld_tile, const double *dark, const double *gain,
+                            void *out, int out_dtype, int64_t ld_out, void *stream_) {
+    if (n_frames < 0 || n_px < 0 || ld_tile < n_px || ld_out < n_px)
+        LTMI_FAIL(LTMI_E_SHAPE, "ltmi_correct: bad shape");
+    if (n_frames == 0 || n_px == 0) return LTMI_OK;
+    if (!tile || !out) LTMI_FAIL(LTMI_E_INVALID, "ltmi_correct: null pointer");
+    LTMI_HIP(hipSetDevice(device));
+    hipStream_t stream = (hipStream_t)stream_;
+    if (out_dtype == LTMI_F32) {
+        LTMI_DISPATCH_TILE(run_correct, float, tile, n_frames, n_px, ld_tile, dark, gain, out, ld_out, stream)
+    } else if (out_dtype == LTMI_F64) {
+        LTMI_DISPATCH_TILE(run_correct, double, tile, n_frames, n_px, ld_tile, dark, gain, out, ld_out, stream)
+    }
+    LTMI_FAIL(LTMI_E_DTYPE, "ltmi_correct: unsupported dtypes tile=%s out=%s", dtype_name(tile_dtype),
+              dtype_name(out_dtype));
+}
+
+extern "C" int ltmi_repair_pixels(int device, void *buf, int dtype, int64_t n_frames, int64_t ld,
+                                  const int32_t *excl, const int32_t *env, const int32_t *cnt,
+                                  int n_excl, int max_env, void *stream_) {
+    if (n_frames < 0 || n_excl < 0 || max_env < 0) LTMI_FAIL(LTMI_E_SHAPE, "ltmi_repair_pixels: bad shape");
+    if (n_frames == 0 || n_excl == 0) return LTMI_OK;
+    if (!buf || !excl || !env || !cnt) LTMI_FAIL(LTMI_E_INVALID, "ltmi_repair_pixels: null pointer");
+    LTMI_HIP(hipSetDevice(device));
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t n = n_frames * n_excl;
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (dtype == LTMI_F32)
+        hipLaunchKernelGGL((k_repair_pixels<float>), grid, dim3(256), 0, stream, (float *)buf, ld,
+                           n_frames, excl, env, cnt, n_excl, max_env);
+    else if (dtype == LTMI_F64)
+        hipLaunchKernelGGL((k_repair_pixels<double>), grid, dim3(256), 0, stream, (double *)buf, ld,
+                           n_frames, excl, env, cnt, n_excl, max_env);
+    else
+        LTMI_FAIL(LTMI_E_DTYPE, "ltmi_repair_pixels: unsupported dtype %s", dtype_name(dtype));
+    LTMI_HIP(hipGetLastError());
+    return LTMI_OK;
+}
+
 extern "C" int ltmi_axpy(int device, void *dest, const void *src, int dtype, int64_t n,
                          void *stream_) {
     if (n < 0) LTMI_FAIL(LTMI_E_SHAPE, "ltmi_axpy: negative size");

@@ -28,7 +28,8 @@ EXPORTS = (
     'ltmi_version', 'ltmi_last_error', 'ltmi_device_count', 'ltmi_device_info',
     'ltmi_masks_create_dense', 'ltmi_masks_create_csr', 'ltmi_masks_destroy', 'ltmi_masks_kind',
     'ltmi_apply_masks', 'ltmi_apply_masks_shifted', 'ltmi_sum_frames_workspace', 'ltmi_sum_frames', 'ltmi_sum_sig',
-    'ltmi_axpy', 'ltmi_masks_set_tuning', 'ltmi_masks_last_kernel',
+    'ltmi_axpy', 'ltmi_correct', 'ltmi_repair_pixels', 'ltmi_masks_set_tuning',
+    'ltmi_masks_last_kernel',
 )
 
 
@@ -104,6 +105,8 @@ def lib():
         L.ltmi_sum_frames.argtypes = [i32, vp, i32, i64, i64, i64, vp, i32, i32, vp, vp]
         L.ltmi_sum_sig.argtypes = [i32, vp, i32, i64, i64, i64, vp, i32, i32, vp]
         L.ltmi_axpy.argtypes = [i32, vp, vp, i32, i64, vp]
+        L.ltmi_correct.argtypes = [i32, vp, i32, i64, i64, i64, vp, vp, vp, i32, i64, vp]
+        L.ltmi_repair_pixels.argtypes = [i32, vp, i32, i64, i64, vp, vp, vp, i32, i32, vp]
         L.ltmi_masks_set_tuning.argtypes = [vp, i32, i32, i32]
         L.ltmi_masks_last_kernel.argtypes = [vp]
         L.ltmi_masks_last_kernel.restype = c.c_char_p
@@ -268,3 +271,20 @@ def sum_sig(device, tile_ptr, tile_dtype, n_frames, n_px, ld_tile, out_ptr, out_
 def axpy(device, dest_ptr, src_ptr, dtype, n, stream=None):
     check(lib().ltmi_axpy(int(device), ctypes.c_void_p(dest_ptr), ctypes.c_void_p(src_ptr),
                           dtype_code(dtype), n, _stream_ptr(stream)), 'ltmi_axpy')
+
+
+def correct(device, tile_ptr, tile_dtype, n_frames, n_px, ld_tile, dark_ptr, gain_ptr, out_ptr,
+            out_dtype, ld_out, stream=None):
+    """out = ((double)tile - dark) * gain; dark_ptr / gain_ptr: device float64 arrays or None."""
+    check(lib().ltmi_correct(
+        int(device), tile_ptr, dtype_code(tile_dtype), n_frames, n_px, ld_tile, dark_ptr or None,
+        gain_ptr or None, out_ptr, dtype_code(out_dtype), ld_out,
+        stream if isinstance(stream, int) else _stream_ptr(stream)), 'ltmi_correct')
+
+
+def repair_pixels(device, buf_ptr, dtype, n_frames, ld, excl_ptr, env_ptr, cnt_ptr, n_excl, max_env,
+                  stream=None):
+    check(lib().ltmi_repair_pixels(
+        int(device), buf_ptr, dtype_code(dtype), n_frames, ld, excl_ptr, env_ptr, cnt_ptr,
+        int(n_excl), int(max_env), stream if isinstance(stream, int) else _stream_ptr(stream)),
+        'ltmi_repair_pixels')

@@ -135,31 +135,41 @@ class Negotiator:
     def get_scheme(self, udfs, dataset, read_dtype, approx_partition_shape, roi=None,
                    corrections=None, backend=NUMPY):
         if backend == HIP:
-            return self._get_scheme_hip(udfs, dataset, approx_partition_shape)
-        return self._get_scheme_numpy(udfs, dataset, read_dtype, approx_partition_shape, roi)
+            return self._get_scheme_hip(udfs, dataset, approx_partition_shape, read_dtype,
+                                        corrections)
+        return self._get_scheme_numpy(udfs, dataset, read_dtype, approx_partition_shape, roi,
+                                      corrections)
 
     # --- MI355X policy ---------------------------------------------------------------------------
     #: the HIP policy is a pure function of these few values; a run over the same dataset re-uses
     #: the (immutable) scheme instead of re-building its slices
     _hip_scheme_cache = {}
 
-    def _get_scheme_hip(self, udfs, dataset, approx_partition_shape):
+    #: corrected tiles are written to a device scratch buffer of at most this many bytes
+    HIP_CORRECTED_CHUNK = 1 * 2**30
+
+    def _get_scheme_hip(self, udfs, dataset, approx_partition_shape, read_dtype=None,
+                        corrections=None):
         intent = self._get_intent(udfs)
+        corrected = corrections is not None and corrections.have_corrections()
         forced = dataset.get_forced_tileshape()
         ds_shape = dataset.shape
         key = (intent, None if forced is None else tuple(forced), tuple(ds_shape),
                ds_shape.sig_dims, np.dtype(dataset.dtype).itemsize,
                bool(dataset.is_device_resident), int(approx_partition_shape[0]),
-               self.HIP_TILE_BUDGET, self.HIP_STAGING_CHUNK)
+               self.HIP_TILE_BUDGET, self.HIP_STAGING_CHUNK,
+               np.dtype(read_dtype).itemsize if corrected else 0, self.HIP_CORRECTED_CHUNK)
         hit = self._hip_scheme_cache.get(key)
         if hit is None:
             if len(self._hip_scheme_cache) > 64:
                 self._hip_scheme_cache.clear()
             hit = self._hip_scheme_cache[key] = self._make_scheme_hip(
-                intent, forced, dataset, approx_partition_shape)
+                intent, forced, dataset, approx_partition_shape,
+                np.dtype(read_dtype).itemsize if corrected else 0)
         return hit
 
-    def _make_scheme_hip(self, intent, forced, dataset, approx_partition_shape):
+    def _make_scheme_hip(self, intent, forced, dataset, approx_partition_shape,
+                         corrected_itemsize=0):
         ds_sig = tuple(dataset.shape.sig)
         if forced is not None and intent == 'tile':
             tileshape = tuple(forced)
@@ -168,6 +178,10 @@ class Negotiator:
             budget = self.HIP_TILE_BUDGET if dataset.is_device_resident \
                 else self.HIP_STAGING_CHUNK
             depth = max(1, min(int(approx_partition_shape[0]), budget // max(1, frame_bytes)))
+            if corrected_itemsize:
+                # corrected frames (float) go through a bounded scratch buffer
+                depth = max(1, min(depth, self.HIP_CORRECTED_CHUNK //
+                                   (prod(ds_sig) * corrected_itemsize)))
             if intent == 'frame':
                 depth = 1
             elif intent == 'partition':
@@ -178,7 +192,8 @@ class Negotiator:
             intent=intent, debug={'backend': HIP})
 
     # --- reference algorithm ----------------------------------------------------------------------
-    def _get_scheme_numpy(self, udfs, dataset, read_dtype, approx_partition_shape, roi):
+    def _get_scheme_numpy(self, udfs, dataset, read_dtype, approx_partition_shape, roi,
+                          corrections=None):
         itemsize = np.dtype(read_dtype).itemsize
         min_sig_size = dataset.get_min_sig_size()
         ds_sig_shape = tuple(dataset.shape.sig)
@@ -198,6 +213,10 @@ class Negotiator:
                  for udf in udfs]
         size = max(sizes) if intent == 'partition' else min(sizes)
         size_px = int(size // itemsize)
+        if corrections is not None and corrections.have_corrections():
+            # no excluded pixel may touch a tile boundary (tiling_scheme.py:294-301)
+            base_shape = tuple(corrections.adjust_tileshape(
+                tile_shape=base_shape, sig_shape=tuple(ds_sig_shape), base_shape=base_shape))
         min_factors = self._get_scale_factors(base_shape, ds_sig_shape, min_sig_size)
         min_base_shape = self._scale(base_shape, min_factors)
         max_depth = max(1, size_px // prod(min_base_shape))
@@ -319,7 +338,7 @@ class Partition:
         return None
 
     def get_tiles(self, tiling_scheme, dest_dtype="float32", roi=None, array_backend=NUMPY,
-                  env=None):
+                  env=None, corrections=None):
         raise NotImplementedError()
 
     def __repr__(self):

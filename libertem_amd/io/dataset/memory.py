@@ -304,8 +304,10 @@ class MemPartition(Partition):
         return np.flatnonzero(roi_part) + self._local0
 
     def get_tiles(self, tiling_scheme, dest_dtype="float32", roi=None, array_backend=NUMPY,
-                  env=None):
+                  env=None, corrections=None):
         ds = self._ds
+        if corrections is not None and not corrections.have_corrections():
+            corrections = None
         lo, hi = ds.local_frame_range
         if not (lo <= self._start_frame and self._start_frame + self._num_frames <= hi):
             raise RuntimeError(
@@ -317,16 +319,18 @@ class MemPartition(Partition):
                 tileshape=Shape(ds.tileshape, sig_dims=ds.shape.sig.dims),
                 dataset_shape=ds.shape, intent=tiling_scheme.intent)
         if array_backend == HIP:
-            yield from self._get_tiles_hip(tiling_scheme, roi, env)
+            yield from self._get_tiles_hip(tiling_scheme, roi, env, np.dtype(dest_dtype),
+                                           corrections)
         elif array_backend == NUMPY:
             if ds.is_device_resident:
                 raise RuntimeError("a device-resident MemoryDataSet only serves BACKEND_HIP")
-            yield from self._get_tiles_numpy(tiling_scheme, np.dtype(dest_dtype), roi)
+            yield from self._get_tiles_numpy(tiling_scheme, np.dtype(dest_dtype), roi,
+                                             corrections)
         else:
             raise ValueError(f"unsupported array backend {array_backend!r}")
 
     # --- host tiles ---------------------------------------------------------------------------------
-    def _get_tiles_numpy(self, tiling_scheme, dest_dtype, roi):
+    def _get_tiles_numpy(self, tiling_scheme, dest_dtype, roi, corrections=None):
         flat = self._ds.flat_host()
         sig_dims = self._ds.shape.sig.dims
         idxs = self._roi_indices(roi)
@@ -345,11 +349,14 @@ class MemPartition(Partition):
                     block = flat[(slice(self._local0 + g0, self._local0 + g1),) + sig_sl]
                 else:
                     block = flat[idxs[g0:g1]][(slice(None),) + sig_sl]
-                if block.dtype != dest_dtype or not block.flags.c_contiguous:
-                    block = block.astype(dest_dtype)
+                if block.dtype != dest_dtype or not block.flags.c_contiguous \
+                        or corrections is not None:
+                    block = block.astype(dest_dtype)          # corrections need a private copy
                 tile_slice = Slice(
                     origin=(compressed_origin + g0,) + tuple(sig_slice.origin[-sig_dims:]),
                     shape=Shape((g1 - g0,) + tuple(sig_slice.shape.sig), sig_dims=sig_dims))
+                if corrections is not None:
+                    corrections.apply(block, tile_slice)      # backend.py:121-124
                 yield DataTile(block, tile_slice, scheme_idx)
 
     # --- device tiles -------------------------------------------------------------------------------
@@ -376,7 +383,36 @@ class MemPartition(Partition):
                                shape=Shape((chunk.shape[0],) + s_shape, sig_dims=sig_dims))
             yield DataTile(data, tile_slice, scheme_idx)
 
-    def _get_tiles_hip(self, tiling_scheme, roi, env):
+    def _corrector(self, corrections, device, dest_dtype, depth, env):
+        """-> callable(chunk HipArray native) -> corrected HipArray (dest_dtype) in a scratch buffer
+        that is re-used for every chunk (all work is ordered on the executor stream)."""
+        from libertem_amd import hip
+        ds = self._ds
+        if dest_dtype not in (np.dtype('float32'), np.dtype('float64')):
+            raise ValueError(f"device corrections produce float32 / float64 tiles, not {dest_dtype}")
+        sig = tuple(ds.shape.sig)
+        n_px = prod(sig)
+        tables = corrections.device_tables(device, sig)
+        scratch = HipArray.empty((depth,) + sig, dest_dtype, device)
+        stream = getattr(env, 'stream_ptr', None)
+
+        def ptr(t):
+            return None if t is None else t.data_ptr()
+
+        def run(chunk):
+            n = chunk.shape[0]
+            out = scratch.rows(0, n)
+            hip.correct(device, chunk.data_ptr(), chunk.dtype, n, n_px, chunk.ld,
+                        ptr(tables['dark']), ptr(tables['gain']), out.data_ptr(), dest_dtype,
+                        out.ld, stream=stream)
+            if tables['n_excl']:
+                hip.repair_pixels(device, out.data_ptr(), dest_dtype, n, out.ld,
+                                  ptr(tables['excl']), ptr(tables['env']), ptr(tables['cnt']),
+                                  tables['n_excl'], tables['max_env'], stream=stream)
+            return out
+        return run
+
+    def _get_tiles_hip(self, tiling_scheme, roi, env, dest_dtype=None, corrections=None):
         ds = self._ds
         device = env.gpu_id if env is not None and env.gpu_id is not None else 0
         idxs = self._roi_indices(roi)
@@ -386,6 +422,8 @@ class MemPartition(Partition):
             else self.slice.adjust_for_roi(roi).origin[0]
         if n == 0:
             return
+        fix = (lambda chunk: chunk) if corrections is None else \
+            self._corrector(corrections, device, np.dtype(dest_dtype), min(depth, n), env)
         if ds.is_device_resident:
             flat = ds.flat_device()
             if flat.device != device:
@@ -400,7 +438,7 @@ class MemPartition(Partition):
                 base = self._local0
             for g0 in range(0, n, depth):
                 g1 = min(n, g0 + depth)
-                chunk = flat.rows(base + g0, base + g1)
+                chunk = fix(flat.rows(base + g0, base + g1))
                 yield from self._sub_tiles(chunk, compressed_origin + g0, tiling_scheme)
             return
         # host data: double-buffered upload, chunk i+1 in flight while chunk i is processed
@@ -423,7 +461,7 @@ class MemPartition(Partition):
                 if i + 1 < len(groups) and stager.registered is not None:
                     # DMA straight from user memory: enqueue the next upload before the kernels
                     stager.upload(slot ^ 1, host_chunk(*groups[i + 1]))
-                yield from self._sub_tiles(chunk, compressed_origin + g0, tiling_scheme)
+                yield from self._sub_tiles(fix(chunk), compressed_origin + g0, tiling_scheme)
                 stager.release(slot)
                 if i + 1 < len(groups) and stager.registered is None:
                     # bounce-buffer mode: the host memcpy overlaps the kernels just enqueued

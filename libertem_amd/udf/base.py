@@ -764,11 +764,12 @@ class UDFPartRunner:
             # the scheme was negotiated for NumPy on the main process; re-negotiate for the device
             tiling_scheme = Negotiator().get_scheme(
                 udfs=self._udfs, dataset=partition._ds, read_dtype=meta.input_dtype,
-                approx_partition_shape=partition.shape, roi=params.roi, backend=HIP)
+                approx_partition_shape=partition.shape, roi=params.roi,
+                corrections=params.corrections, backend=HIP)
             meta._tiling_scheme = tiling_scheme
         tiles = partition.get_tiles(
             tiling_scheme=tiling_scheme, roi=params.roi, dest_dtype=meta.input_dtype,
-            array_backend=backend, env=env)
+            array_backend=backend, env=env, corrections=params.corrections)
         methods = [udf.get_method() for udf in self._udfs]
         partition_udfs = [u for u, m in zip(self._udfs, methods) if m == UDFMethod.PARTITION]
         for tile in tiles:

@@ -308,7 +308,57 @@ def gen_shifts():
     save('shifts', **out)
 
 
+# ---------------------------------------------------------------------------
+# 10. detector corrections
+# ---------------------------------------------------------------------------
+def gen_corrections():
+    import sparse
+    from libertem.io.corrections import CorrectionSet
+    from libertem.io.corrections import detector
+    out = {}
+    for case in recipes.CORR_CASES:
+        data, dark, gain, excluded, masks = recipes.make_corr_case(case)
+        sig = tuple(case['sig'])
+        excl = None if excluded is None else sparse.COO(coords=excluded, shape=sig, data=True)
+        corr = CorrectionSet(dark=dark, gain=gain, excluded_pixels=excl)
+        for uname, udf in (('sum', SumUDF()), ('sumsig', SumSigUDF()),
+                           ('masks', ApplyMasksUDF(mask_factories=lambda: masks,
+                                                   use_sparse=False))):
+            # a fresh copy per run: for float32 data the reference's MemoryDataSet corrects the
+            # tiles IN PLACE in the user's array (memory.py:102-106 hands out views when dtype and
+            # layout already match), so a second run would see corrected-twice data
+            ds = MemoryDataSet(data=data.copy(), num_partitions=case['num_partitions'],
+                               sig_dims=len(sig))
+            res = UDFRunner([udf]).run_for_dataset(ds, EX, corrections=corr).buffers[0]
+            arr = np.array(res['intensity'].data)
+            out[f"{case['name']}__{uname}"] = arr
+            print(case['name'], uname, arr.shape, arr.dtype)
+        # the corrected frames themselves (detector.correct, not in place)
+        out[f"{case['name']}__corrected"] = detector.correct(
+            buffer=data, dark_image=dark, gain_map=gain, excluded_pixels=excluded,
+            sig_shape=sig, inplace=False)
+        # masks with gain + repair folded in (dark-free linear equivalence)
+        if gain is not None:
+            out[f"{case['name']}__dot_masks"] = detector.correct_dot_masks(
+                masks.astype(np.float64), gain, excluded)
+        out[case['name'] + '__sha_data'] = np.frombuffer(bytes.fromhex(sha(data)), dtype=np.uint8)
+    for i, (sig, coords) in enumerate(recipes.REPAIR_CASES):
+        ex = np.array(coords, dtype=np.int64).T.reshape((len(sig), -1))
+        d = detector.RepairDescriptor(sig_shape=sig, excluded_pixels=ex, allow_empty=True)
+        out[f"repair{i}__exclude_flat"] = np.asarray(d.exclude_flat)
+        out[f"repair{i}__repair_flat"] = np.asarray(d.repair_flat)
+        out[f"repair{i}__repair_counts"] = np.asarray(d.repair_counts)
+    for i, (tile_shape, sig_shape, base_shape, coords) in enumerate(recipes.ADJUST_CASES):
+        excl = sparse.COO(coords=np.array(coords, dtype=np.int64), shape=sig_shape, data=True)
+        corr = CorrectionSet(excluded_pixels=excl, allow_empty=True)
+        out[f"adjust{i}"] = np.array(corr.adjust_tileshape(
+            tile_shape=tile_shape, sig_shape=sig_shape, base_shape=base_shape))
+        print('adjust', i, out[f"adjust{i}"])
+    save('corrections', **out)
+
+
 if __name__ == '__main__':
+    gen_corrections()
     gen_shifts()
     gen_apply_masks_dense()
     gen_sums()

@@ -350,3 +350,64 @@ def make_shift_case(case):
     else:
         shifts = np.array(case['shifts'])
     return data, masks, shifts
+
+
+# ---------------------------------------------------------------------------
+# detector corrections (reference io/corrections: CorrectionSet, detector.correct,
+# RepairDescriptor, correct_dot_masks, tile-shape adjustment)
+# ---------------------------------------------------------------------------
+CORR_CASES = [
+    dict(name='u16_all', nav=(3, 5), sig=(16, 24), dtype='uint16', num_partitions=2, seed=701,
+         dark=True, gain=True, excluded=[(0, 0), (5, 7), (5, 8), (15, 23), (9, 0)]),
+    dict(name='u16_dark_only', nav=(2, 4), sig=(16, 16), dtype='uint16', num_partitions=1,
+         seed=702, dark=True, gain=False, excluded=None),
+    dict(name='f32_gain_excl', nav=(7,), sig=(12, 20), dtype='float32', num_partitions=3,
+         seed=703, dark=False, gain=True, excluded=[(3, 3), (4, 4), (11, 19)]),
+    dict(name='i32_all', nav=(2, 3), sig=(8, 8), dtype='int32', num_partitions=1, seed=704,
+         dark=True, gain=True, excluded=[(2, 2)]),
+    dict(name='u8_excl_only', nav=(4, 4), sig=(16, 16), dtype='uint8', num_partitions=2,
+         seed=705, dark=False, gain=False, excluded=[(7, 7), (7, 8), (8, 7), (8, 8)]),
+]
+
+
+def make_corr_case(case):
+    """-> data, dark (float64 | None), gain (float64 | None), excluded coords (ndim, k) | None,
+    masks (3, *sig) float32"""
+    rng = np.random.default_rng(case['seed'])
+    shape = tuple(case['nav']) + tuple(case['sig'])
+    dt = np.dtype(case['dtype'])
+    if dt.kind in 'ui':
+        data = rng.integers(0, 200 if dt.itemsize == 1 else 3000, shape).astype(dt)
+    else:
+        data = (rng.random(shape) * 100).astype(dt)
+    dark = rng.random(case['sig']) * 10 if case['dark'] else None
+    gain = rng.random(case['sig']) + 0.5 if case['gain'] else None
+    excluded = None
+    if case['excluded'] is not None:
+        excluded = np.array(case['excluded'], dtype=np.int64).T.reshape((len(case['sig']), -1))
+    masks = (rng.random((3,) + tuple(case['sig'])) - 0.25).astype(np.float32)
+    return data, dark, gain, excluded, masks
+
+
+# RepairDescriptor tables: (sig_shape, excluded coords as list of tuples)
+REPAIR_CASES = [
+    ((16, 24), [(0, 0), (5, 7), (5, 8), (15, 23), (9, 0)]),
+    ((19,), [(1,), (2,), (3,), (18,)]),
+    ((5, 6, 7), [(2, 3, 4), (0, 0, 0), (4, 5, 6), (2, 3, 5)]),
+    ((8, 8), []),
+]
+
+# tile-shape adjustment: (tile_shape, sig_shape, base_shape, excluded coords (ndim, k))
+# -- the known-answer cases of the reference's tests/corrections/test_corrset.py:140-380
+ADJUST_CASES = [
+    ((1, 1), (123, 456), (1, 1), [[3], [8]]),
+    ((7, 1), (123, 456), (1, 1), [[8], [3]]),
+    ((2, 2), (123, 456), (2, 2), [[3, 5], [8, 9]]),
+    ((2, 1), (123, 456), (2, 1), [[122], [455]]),
+    ((123, 1), (123, 456), (1, 1), [[3], [8]]),
+    ((1, 1), (123, 456), (1, 1), [[0, 1, 2], [0, 1, 2]]),
+    ((8, 1), (1024, 1024), (8, 1), [[7, 8, 16, 24], [5, 6, 7, 8]]),
+    ((8, 8), (64, 64), (8, 8), [list(range(0, 64, 2)), list(range(0, 64, 2))]),
+    ((16, 16), (128, 128), (4, 4), [[17, 33, 95], [3, 64, 127]]),
+    ((3, 5), (30, 50), (3, 5), [[2, 3, 29], [4, 5, 49]]),
+]

@@ -49,7 +49,17 @@ def get_backend(arr):
 
 
 def for_backend(arr, backend, strict=True):
+    if backend == SPARSE_COO:
+        import sparse
+        if isinstance(arr, sparse.COO):
+            return arr
+        if sp.issparse(arr):
+            arr = arr.toarray()
+        return sparse.COO(np.asarray(arr))
     if backend in (NUMPY, CUDA):
+        import sparse
+        if isinstance(arr, sparse.COO):
+            return arr.todense()
         if sp.issparse(arr):
             return arr.toarray()
         return np.asarray(arr)

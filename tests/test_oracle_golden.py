@@ -256,3 +256,51 @@ def test_partition_clamp():
     with pytest.warns(RuntimeWarning):
         parts = otiling.partition_boundaries(3, 8)
     assert parts == [(0, 1), (1, 2), (2, 3)]
+
+
+# ---- detector corrections -----------------------------------------------------------------------
+def _corr_golden():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden',
+                                'corrections.npz'))
+
+
+@pytest.mark.parametrize('case', recipes.CORR_CASES, ids=lambda c: c['name'])
+def test_corrections_oracle_vs_reference(case):
+    from oracle import corrections as oc
+    g = _corr_golden()
+    data, dark, gain, excluded, masks = recipes.make_corr_case(case)
+    sig = tuple(case['sig'])
+    coords = None if excluded is None else [tuple(c) for c in excluded.T]
+    corrected = oc.correct(data, sig, dark=dark, gain=gain, coords=coords)
+    ref = g[f"{case['name']}__corrected"]
+    assert corrected.dtype == ref.dtype
+    np.testing.assert_allclose(corrected, ref, rtol=2e-6, atol=1e-6)
+    # the UDF results of the reference = the plain UDFs on corrected frames
+    nd = len(sig)
+    s = opath.sum_udf(corrected, sig_dims=nd, num_partitions=case['num_partitions'],
+                     dtype=corrected.dtype)
+    np.testing.assert_allclose(s, g[f"{case['name']}__sum"], rtol=1e-5)
+    ss = opath.sumsig_udf(corrected, sig_dims=nd, num_partitions=case['num_partitions'])
+    np.testing.assert_allclose(ss, g[f"{case['name']}__sumsig"], rtol=1e-5)
+    mres = opath.apply_masks(corrected, masks, sig_dims=nd, num_partitions=case['num_partitions'])
+    refm = g[f"{case['name']}__masks"]
+    assert mres.dtype == refm.dtype
+    np.testing.assert_allclose(mres, refm, rtol=1e-5, atol=1e-5 * np.abs(refm).max())
+    if gain is not None:
+        dm = oc.dot_masks(masks.astype(np.float64), gain, coords)
+        np.testing.assert_allclose(dm, g[f"{case['name']}__dot_masks"], rtol=1e-12, atol=1e-12)
+
+
+def test_repair_tables_and_tileshape_adjustment_vs_reference():
+    from oracle import corrections as oc
+    g = _corr_golden()
+    for i, (sig, coords) in enumerate(recipes.REPAIR_CASES):
+        ex, env, cnt = oc.repair_tables(sig, coords)
+        assert np.array_equal(ex, g[f"repair{i}__exclude_flat"])
+        assert np.array_equal(cnt, g[f"repair{i}__repair_counts"])
+        ref_env = g[f"repair{i}__repair_flat"]
+        for k in range(len(ex)):
+            assert np.array_equal(env[k, :cnt[k]], ref_env[k, :cnt[k]])
+    for i, (tile_shape, sig_shape, base_shape, coords) in enumerate(recipes.ADJUST_CASES):
+        got = oc.adjust_tileshape(tile_shape, sig_shape, base_shape, coords)
+        assert tuple(got) == tuple(g[f"adjust{i}"]), (i, got, g[f"adjust{i}"])

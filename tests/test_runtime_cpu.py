@@ -338,3 +338,107 @@ def test_product_does_not_import_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), f
+
+
+# --- detector corrections (host path) -------------------------------------------------------------
+def _excluded(case, excluded):
+    from libertem_amd.io.corrections.corrset import ExcludedPixels
+    return None if excluded is None else ExcludedPixels(excluded, tuple(case['sig']))
+
+
+@pytest.mark.parametrize('case', recipes.CORR_CASES, ids=lambda c: c['name'])
+def test_corrections_host_path_vs_reference_golden(ctx, golden_dir, case):
+    """CorrectionSet through Context.run_udf with NumPy UDFs on the inline executor, against the
+    reference's results (tests/corrections/test_corrset.py drives SumUDF the same way)."""
+    from libertem_amd.io.corrections import CorrectionSet
+    from libertem_amd.io.corrections import detector
+    g = np.load(os.path.join(golden_dir, 'corrections.npz'))
+    data, dark, gain, excluded, masks = recipes.make_corr_case(case)
+    sig = tuple(case['sig'])
+    corr = CorrectionSet(dark=dark, gain=gain, excluded_pixels=_excluded(case, excluded))
+    ds = ctx.load('memory', data=data.copy(), num_partitions=case['num_partitions'],
+                  sig_dims=len(sig))
+    keep = data.copy()
+    s = ctx.run_udf(dataset=ds, udf=NumpySumUDF(), corrections=corr)['intensity'].data
+    assert np.array_equal(ds.flat_host().reshape(data.shape), keep), "dataset must stay untouched"
+    ss = ctx.run_udf(dataset=ds, udf=NumpySumSigUDF(), corrections=corr)['intensity'].data
+    mm = ctx.run_udf(dataset=ds, udf=NumpyMasksUDF(masks), corrections=corr)['intensity'].data
+    for got, name in ((s, 'sum'), (ss, 'sumsig'), (mm, 'masks')):
+        ref = g[f"{case['name']}__{name}"]
+        assert got.shape == ref.shape and got.dtype == ref.dtype, name
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+    out = detector.correct(buffer=data, dark_image=dark, gain_map=gain, excluded_pixels=excluded,
+                           sig_shape=sig, inplace=False)
+    np.testing.assert_allclose(out, g[f"{case['name']}__corrected"], rtol=2e-6, atol=1e-6)
+    if gain is not None:
+        dm = detector.correct_dot_masks(masks.astype(np.float64), gain, excluded)
+        np.testing.assert_allclose(dm, g[f"{case['name']}__dot_masks"], rtol=1e-12, atol=1e-12)
+
+
+def test_repair_descriptor_and_tileshape_adjustment_vs_reference(golden_dir):
+    from libertem_amd.io.corrections import CorrectionSet
+    from libertem_amd.io.corrections.corrset import ExcludedPixels
+    from libertem_amd.io.corrections.detector import RepairDescriptor
+    g = np.load(os.path.join(golden_dir, 'corrections.npz'))
+    for i, (sig, coords) in enumerate(recipes.REPAIR_CASES):
+        ex = np.array(coords, dtype=np.int64).T.reshape((len(sig), -1))
+        d = RepairDescriptor(sig_shape=sig, excluded_pixels=ex, allow_empty=True)
+        assert np.array_equal(d.exclude_flat, g[f"repair{i}__exclude_flat"])
+        assert np.array_equal(d.repair_counts, g[f"repair{i}__repair_counts"])
+        assert np.array_equal(d.repair_flat, g[f"repair{i}__repair_flat"])
+    for i, (tile_shape, sig_shape, base_shape, coords) in enumerate(recipes.ADJUST_CASES):
+        corr = CorrectionSet(excluded_pixels=ExcludedPixels(np.array(coords), sig_shape),
+                             allow_empty=True)
+        got = corr.adjust_tileshape(tile_shape=tile_shape, sig_shape=sig_shape,
+                                    base_shape=base_shape)
+        assert tuple(got) == tuple(g[f"adjust{i}"]), (i, got)
+
+
+def test_correction_set_semantics(ctx):
+    """Behaviour cases of the reference's tests/corrections/test_corrset.py:27-137 and
+    test_detector.py:558-580."""
+    from libertem_amd.io.corrections import CorrectionSet
+    from libertem_amd.io.corrections.detector import RepairValueError, correct, CorrectError
+    rng = np.random.default_rng(5)
+    data = rng.random((4, 4, 16, 16)).astype(np.float32)
+    ds = ctx.load('memory', data=data, sig_dims=2, num_partitions=2)
+    # zero gain -> zero result, with and without dark
+    for dark in (np.ones((16, 16)), None):
+        r = ctx.run_udf(dataset=ds, udf=NumpySumUDF(),
+                        corrections=CorrectionSet(dark=dark, gain=np.zeros((16, 16))))
+        assert np.allclose(r['intensity'].data, 0)
+    # dark of ones, with and without unit gain
+    for gain in (np.ones((16, 16)), None):
+        r = ctx.run_udf(dataset=ds, udf=NumpySumUDF(),
+                        corrections=CorrectionSet(dark=np.ones((16, 16)), gain=gain))
+        assert np.allclose(r['intensity'].data, np.sum(data - 1, axis=(0, 1)), rtol=1e-5)
+    # empty excluded-pixel lists are no-ops
+    for excl in (np.zeros((2, 0), dtype=np.int64), np.zeros((16, 16))):
+        r = ctx.run_udf(dataset=ds, udf=NumpySumUDF(),
+                        corrections=CorrectionSet(excluded_pixels=excl, gain=np.ones((16, 16))))
+        assert np.allclose(r['intensity'].data, np.sum(data, axis=(0, 1)), rtol=1e-5)
+    # no good neighbour: raises at construction unless allow_empty
+    from libertem_amd.io.corrections.corrset import ExcludedPixels
+    line = ExcludedPixels(np.array([[1, 2, 3]]), (19,))     # pixel 2 has only bad neighbours
+    CorrectionSet(excluded_pixels=ExcludedPixels(np.array([[1, 2]]), (19,)))    # fine
+    with pytest.raises(RepairValueError):
+        CorrectionSet(excluded_pixels=line, gain=np.ones(19), dark=np.ones(19))
+    corr = CorrectionSet(excluded_pixels=line, gain=np.ones(19), dark=np.ones(19),
+                         allow_empty=True)
+    ds1 = ctx.load('memory', data=np.ones((5, 6, 19)), sig_dims=1)
+    r = ctx.run_udf(dataset=ds1, udf=NumpySumUDF(), corrections=corr)
+    assert np.allclose(r['intensity'].data, 0)              # unpatched, (1 - 1) * 1
+    # in-place needs float data and C order
+    with pytest.raises(TypeError):
+        correct(np.ones((2, 4, 4), dtype=np.uint8), gain_map=np.ones((4, 4)), inplace=True)
+    with pytest.raises(CorrectError):
+        correct(np.asfortranarray(np.ones((3, 4, 4), dtype=np.float32)),
+                gain_map=np.ones((4, 4)), inplace=True)
+    # odd 3D signal shape, pixel patched from its 26 neighbours (test_corrset.py:70-91)
+    d3 = np.ones((2, 3, 5, 7, 9))
+    ex3 = ExcludedPixels(np.array([[2, 4], [2, 5], [2, 5]]), (5, 7, 9))
+    ds3 = ctx.load('memory', data=d3, sig_dims=3)
+    r = ctx.run_udf(dataset=ds3, udf=NumpySumUDF(dtype='float64'),
+                    corrections=CorrectionSet(excluded_pixels=ex3, gain=np.ones((5, 7, 9)),
+                                              dark=np.ones((5, 7, 9))))
+    assert np.allclose(r['intensity'].data, 0)
