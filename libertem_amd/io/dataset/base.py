@@ -152,6 +152,10 @@ class Negotiator:
                         corrections=None):
         intent = self._get_intent(udfs)
         corrected = corrections is not None and corrections.have_corrections()
+        if corrected and all(getattr(u, 'folds_corrections', None) is not None
+                             and getattr(u, 'meta', None) is not None
+                             and u.folds_corrections(corrections, u.meta) for u in udfs):
+            corrected = False        # linear UDFs read the raw frames (udf/masks.py): no scratch
         forced = dataset.get_forced_tileshape()
         ds_shape = dataset.shape
         key = (intent, None if forced is None else tuple(forced), tuple(ds_shape),

@@ -62,6 +62,8 @@ class UDFMeta:
         self._partition_slice = partition_slice
         #: hipStream_t (int) the worker enqueues on; None = torch's current stream
         self.stream_ptr = stream_ptr
+        #: True: the dataset hands out RAW tiles and the UDFs apply `corrections` themselves
+        self.corrections_folded = False
         self._dataset_shape = dataset_shape
         self._dataset_dtype = dataset_dtype
         self._input_dtype = input_dtype
@@ -745,6 +747,16 @@ class UDFPartRunner:
             threads_per_worker=env.threads_per_worker, array_backend=backend,
             gpu_id=env.gpu_id, stream_ptr=getattr(env, 'stream_ptr', None),
         )
+        # Linear UDFs can absorb the corrections into their own operands (masks' = R^T m * gain,
+        # a per-mask constant for the dark frame) and read the raw frames: no corrected copy of
+        # the data is ever written.  Only if EVERY udf of the run does so and tiles are full frames.
+        corr = params.corrections
+        ts = params.tiling_scheme
+        meta.corrections_folded = bool(
+            corr is not None and corr.have_corrections() and backend == HIP
+            and ts is not None and (ts._debug or {}).get('backend') == HIP and len(ts) == 1
+            and all(getattr(u, 'folds_corrections', None) is not None
+                    and u.folds_corrections(corr, meta) for u in self._udfs))
         for udf in self._udfs:
             udf.set_backend(backend)
             udf.set_meta(meta)
@@ -769,7 +781,9 @@ class UDFPartRunner:
             meta._tiling_scheme = tiling_scheme
         tiles = partition.get_tiles(
             tiling_scheme=tiling_scheme, roi=params.roi, dest_dtype=meta.input_dtype,
-            array_backend=backend, env=env, corrections=params.corrections)
+            array_backend=backend, env=env,
+            corrections=None if getattr(meta, 'corrections_folded', False)
+            else params.corrections)
         methods = [udf.get_method() for udf in self._udfs]
         partition_udfs = [u for u, m in zip(self._udfs, methods) if m == UDFMethod.PARTITION]
         for tile in tiles:

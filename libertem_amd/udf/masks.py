@@ -49,6 +49,75 @@ def _cached_container(mask_factories, dtype, use_sparse, count, default_sparse):
     return container
 
 
+#: fold detector corrections into the mask stack of dense ApplyMasksUDF runs (see
+#: `fold_corrections_into_masks`); set to False to always correct the frames instead
+FOLD_CORRECTIONS = True
+
+
+def fold_corrections_into_masks(masks, corrections, sig_shape):
+    """
+    masks: dense (n_masks, *sig) array.  Returns (masks' float64 (n_masks, *sig), const float64
+    (n_masks,) or None) such that for every frame x
+        sum_p masks[k, p] * corrected(x)[p]  ==  sum_p masks'[k, p] * x[p]  -  const[k]
+    where corrected() is CorrectionSet.apply: (x - dark) * gain, then every excluded pixel e := mean
+    over its good neighbours env(e).  The repair is linear, so its transpose moves mask weight
+    from e to env(e):  masks'[r] = (masks[r] + sum_{e: r in env(e)} masks[e] / |env(e)|) * gain[r],
+    masks'[e] = 0  (what the reference offers as detector.correct_dot_masks, :315-338; excluded
+    pixels WITHOUT good neighbours stay unpatched here, as in `correct`), and
+    const = masks' . dark.
+    """
+    sig_shape = tuple(int(s) for s in sig_shape)
+    n_px = int(np.prod(sig_shape))
+    flat = np.asarray(masks, dtype=np.result_type(np.float64, np.asarray(masks).dtype))
+    flat = flat.reshape((-1, n_px)).copy()
+    desc = corrections.full_frame_descriptor(sig_shape)
+    if len(desc.exclude_flat):
+        src = flat.copy()
+        for e, env, c in zip(desc.exclude_flat, desc.repair_flat, desc.repair_counts):
+            if c == 0:
+                continue
+            flat[:, e] = 0
+            share = src[:, e] / c
+            for r in env[:c]:
+                flat[:, r] += share
+    gain = corrections.get_gain_map()
+    if gain is not None:
+        flat *= np.asarray(gain, dtype=np.float64).reshape(-1)[None, :]
+    dark = corrections.get_dark_frame()
+    const = None
+    if dark is not None:
+        const = flat @ np.asarray(dark, dtype=np.float64).reshape(-1)
+    return flat.reshape((-1,) + sig_shape), const
+
+
+def _folded_plan(corrections, masks_container, mask_factories, sig_shape, count):
+    """(container of the folded stack, const | None), cached on the CorrectionSet so that the
+    derived factory keeps its identity across tasks and runs (-> `_cached_container` hits)."""
+    cache = corrections.__dict__.setdefault('_folded_masks', {})
+    key = (id(mask_factories), tuple(sig_shape), np.dtype(masks_container.dtype).str)
+    hit = cache.get(key)
+    if hit is None or hit[0] is not mask_factories:
+        state = {}
+
+        def folded_factory():
+            if 'masks' not in state:
+                state['masks'], state['const'] = fold_corrections_into_masks(
+                    np.asarray(masks_container.computed_masks), corrections, sig_shape)
+            return state['masks']
+
+        folded_factory()
+        if len(cache) > 8:
+            cache.clear()
+        hit = cache[key] = (mask_factories, folded_factory, state)
+    _, factory, state = hit
+    # complex stays complex, everything else is carried in the mask dtype of the plain run
+    dtype = masks_container.dtype
+    if np.dtype(dtype).kind not in 'fc':
+        dtype = np.result_type(dtype, np.float32)
+    container = _cached_container(factory, dtype, False, count, 'scipy.sparse')
+    return container, state
+
+
 def clear_mask_cache():
     while _CONTAINER_CACHE:
         _, (_, old) = _CONTAINER_CACHE.popitem(last=False)
@@ -65,9 +134,26 @@ class ApplyMasksEngine:
             raise HipRequiredError(
                 "ApplyMasksEngine needs BACKEND_HIP (an MI355X worker); got array backend "
                 f"{meta.array_backend!r} on device class {meta.device_class!r}")
-        self.result_dtype = np.result_type(meta.input_dtype, masks.dtype)
+        self.result_dtype = np.dtype(np.result_type(meta.input_dtype, masks.dtype))
         self.device = meta.gpu_id if meta.gpu_id is not None else 0
         self.stream_ptr = getattr(meta, 'stream_ptr', None)
+        self._const = None           # device tensor (n_masks,): folded dark-frame contribution
+
+    def fold(self, folded_container, plan_state):
+        """Switch to the stack with the corrections folded in (the result dtype is unchanged).
+        plan_state: dict with 'const' (host float64 | None); the device copy is cached in it."""
+        self.masks = folded_container
+        const = plan_state['const']
+        if const is not None:
+            key = ('const_dev', self.device, self.result_dtype.str)
+            dev = plan_state.get(key)
+            if dev is None:
+                import torch
+                c = np.ascontiguousarray(np.asarray(const).astype(self.result_dtype))
+                if c.dtype.kind == 'c':
+                    raise ValueError("folding a dark frame needs a real result dtype")
+                dev = plan_state[key] = torch.from_numpy(c).to(f'cuda:{self.device}')
+            self._const = dev
 
     def _get_handle(self):
         return self.masks.get_handle_for_sig_slice(self.meta.sig_slice, self.result_dtype,
@@ -94,6 +180,11 @@ class ApplyMasksEngine:
                              f"{handle.n_masks} masks")
         handle.apply(tile.data_ptr(), tile.dtype, n, tile.ld, out.data_ptr(), out.ld, accumulate,
                      stream=self.stream_ptr)
+        if self._const is not None:
+            # dark frame of folded corrections: out[f, k] -= sum_p masks'[k, p] * dark[p]
+            import torch
+            view = torch.as_strided(out.torch.reshape(-1), (n, handle.n_masks), (out.ld, 1))
+            view.sub_(self._const)
         return out
 
     def process_tile_shifted(self, tile, shifts, out, accumulate=True):
@@ -196,8 +287,24 @@ class ApplyMasksUDF(UDF):
         return _cached_container(p.mask_factories, p.mask_dtype, use_sparse, p.mask_count,
                                  'scipy.sparse')
 
+    def folds_corrections(self, corrections, meta):
+        """True iff this UDF can take RAW frames and apply `corrections` through its masks."""
+        if not FOLD_CORRECTIONS or self.params.get('shifts') is not None:
+            return False
+        if self.masks.use_sparse is not False:
+            return False
+        if np.dtype(np.result_type(meta.input_dtype, self.get_mask_dtype())).kind != 'f':
+            return False
+        return True
+
     def get_task_data(self):
-        return {'engine': ApplyMasksEngine(self.masks, self.meta, self.params.use_torch)}
+        engine = ApplyMasksEngine(self.masks, self.meta, self.params.use_torch)
+        if getattr(self.meta, 'corrections_folded', False):
+            container, plan_state = _folded_plan(
+                self.meta.corrections, self.masks, self.params.mask_factories,
+                tuple(self.meta.dataset_shape.sig), self.get_mask_count())
+            engine.fold(container, plan_state)
+        return {'engine': engine}
 
     def get_result_buffers(self):
         dtype = np.result_type(self.meta.input_dtype, self.get_mask_dtype())

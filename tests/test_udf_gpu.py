@@ -493,13 +493,25 @@ def test_corrections_vs_reference_golden(ctx, golden_dir, case, resident):
         ds = _device_ds(ctx, data, case['num_partitions'])
     else:
         ds = ctx.load('memory', data=data, num_partitions=case['num_partitions'], sig_dims=2)
+    import libertem_amd.udf.masks as um
+    from libertem_amd import hip
     udfs = {'sum': SumUDF(), 'sumsig': SumSigUDF(),
             'masks': ApplyMasksUDF(mask_factories=lambda: masks, use_sparse=False)}
     for name, udf in udfs.items():
-        got = ctx.run_udf(dataset=ds, udf=udf, corrections=corr)['intensity'].data
-        ref = g[f"{case['name']}__{name}"]
-        assert got.shape == ref.shape and got.dtype == ref.dtype, (name, got.dtype, ref.dtype)
-        assert _close(got, ref, F32_TOL), (name, np.abs(got - ref).max(), np.abs(ref).max())
+        for fold in ((True, False) if name == 'masks' else (True,)):
+            um.FOLD_CORRECTIONS = fold
+            hip.KernelTimer.start()
+            try:
+                got = ctx.run_udf(dataset=ds, udf=udf, corrections=corr)['intensity'].data
+            finally:
+                um.FOLD_CORRECTIONS = True
+                launches = hip.KernelTimer.stop()
+            ref = g[f"{case['name']}__{name}"]
+            assert got.shape == ref.shape and got.dtype == ref.dtype, (name, got.dtype, ref.dtype)
+            assert _close(got, ref, F32_TOL), (name, fold, np.abs(got - ref).max(),
+                                               np.abs(ref).max())
+            if name == 'masks':
+                assert len(launches) >= 1
     # without corrections the same dataset still gives the uncorrected result (nothing was
     # modified in place, no stale scratch)
     plain = ctx.run_udf(dataset=ds, udf=SumSigUDF())['intensity'].data
