@@ -196,7 +196,7 @@ def main():
         # + WRITE_SIZE x 1024); cannot be collected from inside the timed process, so the
         # committed profile of exactly this kernel and shape is quoted, scaled by the frame count.
         traffic, traffic_src = None, None
-        if 'k_dense_mfma_lds' in kname and args.config == 'c2':
+        if 'k_dense_lds' in kname and args.config == 'c2':
             traffic = (8.7039e9 + 4.2e6) * frames_per_launch / 65536.0
             traffic_src = "profiles/r01_final_bench_rocprof.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
         out = {

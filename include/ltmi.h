@@ -140,10 +140,8 @@ int ltmi_repair_pixels(int device, void *buf, int dtype, int64_t n_frames, int64
 /* ---- tuning / introspection (bench + tests) ------------------------------------------- */
 /* force a kernel variant for the dense MFMA path (bench / tests only; (0,0,0) = automatic):
  *   mt in {1,2}, waves in {4,8}: the direct-load kernel k_dense_mfma with that tile shape;
- *   mt = 0 and waves = 3 | 5 | 6 | 7: the LDS-DMA kernel k_dense_mfma_lds with ring 3 | ring 4 |
- *     ring 3 + 2-chunk mask slots | 4 waves ring 3; 8, 9, 23..25: its ablations (no MFMA, no DMA,
- *     no barrier, no LDS reads, no conversion -- results are garbage, timing only);
- *     11..13: the register-ring kernel k_dense_mfma_t with prefetch depth 1..3;
+ *   mt = 0, waves = 30: the LDS-DMA kernel k_dense_lds as dispatched; 31 / 32: its timing-only
+ *     ablations without DMA / without MFMA (results are garbage);
  *   ksplit 0 = auto.  Returns LTMI_E_INVALID for unsupported values. */
 int ltmi_masks_set_tuning(ltmi_masks *m, int mt, int waves, int ksplit);
 /* name of the kernel variant the last ltmi_apply_masks on this handle launched */

@@ -291,286 +291,29 @@ k_dense_mfma(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
             }
 }
 
-// ---- v2: frames through LDS with full-line LDS-DMA -----------------------------------------------
+// ---- frames through LDS with full-line LDS-DMA (k_dense_lds) ---------------------------------------
 // probes/stream_probe.hip: the fragment-shaped loads of k_dense_mfma (16 frame rows x 64 B per wave
 // instruction) top out at ~5.8 TB/s with no compute; 1-KiB-contiguous non-temporal reads reach
 // 7.0 TB/s.  Here every wave instruction is a global_load_lds_dwordx4 that moves 4 frame rows x 256 B
-// (whole 128-B lines) straight into LDS; MFMA A fragments are then ds_read_b128 from there.
+// (whole 128-B lines) straight into LDS; MFMA A fragments are then ds_read from there.
 //
 //   * 8 waves (2 per SIMD, so one wave's DMA issue / LDS latency hides under the other's MFMAs),
-//     each owns 16 frames; per wave a ring of 3 sub-chunk slots (16 rows x 256 B = 4 KiB each).
-//     Sub-chunk = 256 B of every row (128 px of a 2-byte dtype).
+//     each owns 16 frames; per wave a ring of sub-chunk slots (16 rows x 256 B = 4 KiB each).
 //   * the 16 pieces (16 B) of a row are stored at piece ^ (row & 15): the 16 lanes of every
-//     ds_read_b128 service group (16 different rows, two adjacent pieces) hit 16 different slots.
-//     LDS-DMA writes lane-linear, so the permutation is applied to the per-lane SOURCE address.
-//   * mask image chunks (256 px, 16 KiB) also arrive by LDS-DMA, 2 slots, shared by the 8 waves.
-//   * one DMA instruction per 32-pixel block is interleaved with that block's 8 MFMAs; two
-//     accumulators (even / odd pixel of the block) cover the 40-cycle MFMA dependency.
-//   * counted waits, never vmcnt(0) in the loop.  Issue order per wave:
-//       iteration s: [wait] [barrier + B(s/2+1) if s even] A(s+2) spread over the 4 blocks
-//     even s: vmcnt(4) leaves A(s+1) in flight          => A(s) and my pieces of B(s/2) landed
-//     odd  s: vmcnt(6) leaves B(..) + A(s+1) in flight  => A(s) landed
+//     ds_read_b128 service group (16 different rows) hit 16 different slots.  LDS-DMA writes
+//     lane-linear, so the permutation is applied to the per-lane SOURCE address.
+//   * mask slots also arrive by LDS-DMA (linear copies of the pre-swizzled image), 2 slots, shared
+//     by the 8 waves, one s_barrier per slot.
+//   * counted waits, never vmcnt(0) in the loop (DMA completes in order per wave).
 constexpr int V2_ROWS = 16;                         // frames per wave
 constexpr int V2_SUB_BYTES = 256;                   // bytes of a row per sub-chunk
 constexpr int V2_ASLOT = V2_ROWS * V2_SUB_BYTES;    // 4 KiB per wave per slot
-constexpr int V2_B_BYTES = 2 * CHUNK_FLOATS * 4;                 // 32 KiB
-constexpr int v2_a_bytes(int ring, int waves) { return ring * waves * V2_ASLOT; }
-constexpr int v2_lds_bytes(int ring, int waves, int bch = 1) {
-    return v2_a_bytes(ring, waves) + V2_B_BYTES * bch;
-}
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *glb_ptr_t;
 
-template <typename T, int V2_ARING, int V2_WAVES, int ABL = 0, int BCH = 1>
-__global__ void __launch_bounds__(V2_WAVES * 64)
-k_dense_mfma_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
-                 const float *__restrict__ img, int n_chunks, float *__restrict__ out,
-                 int64_t ld_out, int n_cols, int accumulate, float *__restrict__ partials,
-                 int ksplit) {
-    static_assert(sizeof(T) == 2, "v2 handles 2-byte pixels");
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    using TR = InTraits<T>;
-    constexpr int SPX = V2_SUB_BYTES / sizeof(T);       // pixels per sub-chunk (128)
-    constexpr int SUBS = KC / SPX;                      // sub-chunks per mask chunk (2)
-    constexpr int BLKS = SPX / 32;                      // MFMA pixel blocks per sub-chunk (4)
-    static_assert(BLKS == 4 && V2_ROWS / 4 == BLKS, "one DMA instruction per block");
-    constexpr int NT = V2_WAVES * 64;
-
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int m = lane & 15, kg = lane >> 4;
-    const int ks = blockIdx.y;
-
-    const int n_full = (int)(n_px / KC);
-    const int per = (n_chunks + ksplit - 1) / ksplit;
-    const int c_begin = ks * per;
-    const int c_end = min(n_chunks, c_begin + per);
-    const int cf_end = min(c_end, n_full);               // full mask chunks [c_begin, cf_end)
-
-    const int64_t f_wave = (int64_t)blockIdx.x * (V2_WAVES * V2_ROWS) + wave * V2_ROWS;
-
-    unsigned char *a_base = lds_raw + wave * V2_ASLOT;               // + slot * (WAVES*ASLOT)
-    constexpr int V2_A_BYTES = v2_a_bytes(V2_ARING, V2_WAVES);
-    constexpr int BPW = CHUNK_FLOATS * 4 / V2_WAVES;     // mask-chunk bytes each wave copies
-    unsigned char *b_base = lds_raw + V2_A_BYTES;                    // + bslot * 16 KiB
-
-    f32x4 acc[2];                                        // [pixel parity]
-    acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    if (c_begin < cf_end) {
-        // DMA source pointers: instruction t moves rows 4t .. 4t+3; lane i -> row 4t + (i>>4),
-        // LDS position i & 15, source piece (i & 15) ^ (row & 15)
-        const unsigned char *src[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int r = 4 * t + (lane >> 4);
-            int64_t f = f_wave + r;
-            if (f > n_frames - 1) f = n_frames - 1;
-            const int piece = (lane & 15) ^ (r & 15);
-            src[t] = (const unsigned char *)(tile + f * ld) + piece * 16;
-        }
-        const unsigned char *bsrc = (const unsigned char *)img + wave * BPW + lane * 16;
-        const int S0 = c_begin * SUBS, S1 = cf_end * SUBS;    // sub-chunk range
-
-        // one DMA piece (rows 4t..4t+3) of sub-chunk s into ring slot `slot`
-        auto issue_a1 = [&](int s, int slot, int t) {
-            if (ABL >= 2) return;
-            const int sc = min(s, S1 - 1);
-            unsigned char *dst = a_base + slot * (V2_WAVES * V2_ASLOT);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[t] + (int64_t)sc * V2_SUB_BYTES),
-                                             (lds_ptr_t)(dst + t * 1024), 16, 0, 2 /*nt*/);
-        };
-        // B slot = BCH consecutive 16-KiB image chunks; group index gidx counts slots from c_begin
-        auto issue_b = [&](int gidx) {
-            if (ABL >= 2) return;
-#pragma unroll
-            for (int q = 0; q < BCH; ++q) {
-                const int cc = min(c_begin + gidx * BCH + q, cf_end - 1);
-                unsigned char *dst = b_base + ((gidx & 1) * BCH + q) * (CHUNK_FLOATS * 4) +
-                                     wave * BPW;
-                const unsigned char *sp = bsrc + (int64_t)cc * (CHUNK_FLOATS * 4);
-#pragma unroll
-                for (int u = 0; u < BPW / 1024; ++u)
-                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(sp + u * 1024),
-                                                     (lds_ptr_t)(dst + u * 1024), 16, 0, 0);
-            }
-        };
-
-#pragma unroll
-        for (int t = 0; t < 4; ++t) issue_a1(S0, 0, t);
-        issue_b(0);
-#pragma unroll
-        for (int d = 1; d < V2_ARING - 1; ++d)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) issue_a1(S0 + d, d, t);
-
-        constexpr int PER = SUBS * BCH;                             // sub-chunks per mask slot
-        constexpr int NBI = BCH * BPW / 1024;                       // B instructions per wave
-        constexpr int A_N = 4 * (V2_ARING - 2);                     // later A sub-chunks
-        static_assert(PER >= 2 && V2_ARING - 2 <= PER, "wait counts assume this");
-        // lane-constant parts of the fragment addresses (bytes / floats inside a slot)
-        const int a_lane = m * V2_SUB_BYTES;
-        const int b_lane = m * KC + kg * 64;
-
-        // One sub-chunk.  `ph` carries i % UNROLL as a compile-time constant in the unrolled main
-        // loop (ring slot, mask slot and block offset become immediates of the ds_read / DMA
-        // instructions: no per-block address arithmetic), or -1 for the generic tail.
-        auto iteration = [&](int s, auto ph) {
-            constexpr int PH = decltype(ph)::value;
-            const int i = s - S0;
-            const int ip = PH >= 0 ? PH % PER : i % PER;            // position inside a mask slot
-            // DMA instructions allowed to stay in flight at this wait (issue order in the header):
-            //   ip == 0      : the slot was issued PER iterations ago; wait for it and A(s), barrier
-            //   ip <= RING-2 : a B slot was issued after A(s) and may stay in flight
-            if (ip == 0) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_N) : "memory");
-                if (ABL < 3) __builtin_amdgcn_s_barrier();
-                issue_b(i / PER + 1);
-            } else if (ip <= V2_ARING - 2) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_N + NBI) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_N) : "memory");
-            }
-            const int slot = PH >= 0 ? PH % V2_ARING : i % V2_ARING;
-            const int nslot = PH >= 0 ? (PH + V2_ARING - 1) % V2_ARING
-                                      : (i + V2_ARING - 1) % V2_ARING;
-            const int ci = PH >= 0 ? PH / SUBS : i / SUBS;          // mask chunk (mod 2*BCH)
-            const int bsl = ((ci / BCH) & 1) * BCH + ci % BCH;
-            const int blk0 = (PH >= 0 ? (PH & 1) : (i & 1)) * BLKS; // block offset inside the chunk
-            const unsigned char *aslot = a_base + slot * (V2_WAVES * V2_ASLOT) + a_lane;
-            const float *bslot = (const float *)(b_base + bsl * (CHUNK_FLOATS * 4)) + b_lane;
-            // fragments are double-buffered in registers: the ds_reads of block blk+1 are issued
-            // before the MFMAs of block blk, so LDS latency hides behind 8 MFMAs (256 cycles)
-            // ablations >= 4 (bench only): operands from registers instead of LDS
-            typename TR::raw_t raw_fake = {};
-            f32x4 b_fake = {1.f, 2.f, 3.f, 4.f};
-            auto rd_a = [&](int blk) {
-                if (ABL >= 4) {
-                    asm volatile("" : "+v"(raw_fake));
-                    return raw_fake;
-                }
-                return *(const typename TR::raw_t *)(aslot + (((blk * 4 + kg) ^ m) << 4));
-            };
-            auto rd_b = [&](int blk, int h) {
-                if (ABL >= 4) {
-                    asm volatile("" : "+v"(b_fake));
-                    return b_fake;
-                }
-                return *(const f32x4 *)(bslot + ((((blk0 + blk) * 2 + h) ^ m) << 2));
-            };
-            typename TR::raw_t raw_c = rd_a(0);
-            f32x4 b_c0 = rd_b(0, 0), b_c1 = rd_b(0, 1);
-#pragma unroll
-            for (int blk = 0; blk < BLKS; ++blk) {
-                typename TR::raw_t raw_n = raw_c;
-                f32x4 b_n0 = b_c0, b_n1 = b_c1;
-                if (blk + 1 < BLKS) {
-                    raw_n = rd_a(blk + 1);
-                    b_n0 = rd_b(blk + 1, 0);
-                    b_n1 = rd_b(blk + 1, 1);
-                }
-                issue_a1(s + V2_ARING - 1, nslot, blk);
-                // keep the prefetch reads ABOVE this block's MFMAs (hipcc otherwise sinks them
-                // next to their use to save registers and the LDS latency is exposed again)
-                __builtin_amdgcn_sched_barrier(0);
-                float a[8];
-                if (ABL >= 5) {       // ablation: no conversion, reinterpret the raw dwords
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) a[j] = __builtin_bit_cast(float, raw_c[j >> 1]);
-                } else {
-                    TR::cvt(raw_c, a);
-                }
-                f32x4 b[2] = {b_c0, b_c1};
-                if (ABL == 1) {       // ablation: keep the operands live, no matrix work
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j & 1][j & 3] += a[j] + b[j >> 2][j & 3];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        acc[j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                            a[j], b[j >> 2][j & 3], acc[j & 1], 0, 0, 0);
-                    // probes/mfma_probe.hip: a VALU op (+ its s_nop hazard pad) in front of every
-                    // MFMA costs ~15 % of the matrix pipe (134 vs 156 TF).  Convert the 8 pixels
-                    // first, then issue the 8 MFMAs back to back; the conversions of one wave then
-                    // overlap the MFMAs of the other wave on the SIMD.
-                    if (ABL < 5) __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // 8 v_cvt
-                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);     // 8 MFMA
-                }
-                raw_c = raw_n;
-                b_c0 = b_n0;
-                b_c1 = b_n1;
-            }
-        };
-
-        int s = S0;
-        if constexpr (V2_ARING == 4 && BCH == 1) {
-            // (i % 4) fixes ring slot (i % 4), mask slot ((i / 2) & 1) and block offset (i & 1)
-            for (; s + 4 <= S1; s += 4) {
-                iteration(s, std::integral_constant<int, 0>{});
-                iteration(s + 1, std::integral_constant<int, 1>{});
-                iteration(s + 2, std::integral_constant<int, 2>{});
-                iteration(s + 3, std::integral_constant<int, 3>{});
-            }
-        }
-        for (; s < S1; ++s) iteration(s, std::integral_constant<int, -1>{});
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the clamped prefetches
-    }
-
-    // ragged last chunk (n_px % 256 != 0): guarded element loads, mask chunk staged by plain copies
-    if (c_end > n_full) {
-        const int c = n_full;
-        __syncthreads();
-        float *bl = (float *)b_base;
-        const u32x4 *img_units = (const u32x4 *)img + (int64_t)c * (CHUNK_FLOATS / 4);
-#pragma unroll
-        for (int i = 0; i < CHUNK_FLOATS / 4 / NT; ++i)
-            ((u32x4 *)bl)[i * NT + tid] = img_units[i * NT + tid];
-        __syncthreads();
-        int64_t f = f_wave + m;
-        if (f > n_frames - 1) f = n_frames - 1;
-        const T *rowp = tile + f * ld + kg * 8;
-        const float *ldsb = bl + m * KC + kg * 64;
-#pragma unroll
-        for (int blk = 0; blk < 8; ++blk) {
-            const int64_t p0 = (int64_t)c * KC + blk * 32;
-            float a[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                a[j] = (p0 + kg * 8 + j < n_px) ? (float)rowp[p0 + j] : 0.f;
-            f32x4 b[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                b[h] = *(const f32x4 *)(ldsb + (((blk * 2 + h) ^ m) << 2));
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                acc[j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j >> 2][j & 3],
-                                                                  acc[j & 1], 0, 0, 0);
-        }
-    }
-
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int64_t f = f_wave + kg * 4 + r;
-        const int col = m;
-        if (f < n_frames && col < n_cols) {
-            const float v = acc[0][r] + acc[1][r];
-            if (ksplit == 1) {
-                float *p = out + f * ld_out + col;
-                *p = accumulate ? (*p + v) : v;
-            } else {
-                partials[((int64_t)ks * n_frames + f) * n_cols + col] = v;
-            }
-        }
-    }
-}
-
-// ---- v2g: the LDS-DMA kernel for every pixel width and 1 / 2 / 4 column groups -----------------
-// Same pipeline as k_dense_mfma_lds (wave-private frame ring filled by global_load_lds, counted vmcnt,
-// one barrier per mask slot, fragments double-buffered in registers, conversions batched ahead of
-// the MFMAs), generalised over
+// The kernel: wave-private frame ring filled by global_load_lds, counted vmcnt, one barrier per mask
+// slot, fragments double-buffered in registers, conversions batched ahead of the MFMAs; generic over
 //   * T: a sub-chunk is always 256 B of a row = 256 / sizeof(T) pixels (u8 256, u16 128, f32 64);
 //   * NG column groups per wave (C5: 25 complex masks = 50 real columns = 4 groups): the frame
 //     fragment of a block is converted once and used for NG x 8 MFMAs.
@@ -869,170 +612,6 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                 }
             }
         }
-}
-
-// ---- v3: full-line loads into registers, wave-private LDS transpose ------------------------------
-// The LDS ring of v2 caps the bytes in flight at ~80 KiB per CU (160 KiB LDS); the register file is
-// 512 KiB per CU.  v3 streams frames with full-line loads (one instruction = 2 frame rows x 512 B
-// contiguous, non-temporal) into a two-chunk-deep VGPR ring, and uses LDS only as a short-lived,
-// wave-private transpose buffer: ds_write_b128 the 8 pieces of a chunk (XOR-swizzled), then
-// ds_read_b128 the MFMA A fragments.  Mask chunks go global->VGPR->LDS as in v1, shared by the
-// block, one barrier per chunk.  All waits are compiler-counted (plain loads survive s_barrier).
-constexpr int V3_WAVES = 8;
-constexpr int V3_ROWS = 16;
-constexpr int V3_ABYTES = V3_ROWS * KC * 2;                      // 8 KiB per wave (2-byte pixels)
-constexpr int V3_LDS_BYTES = V3_WAVES * V3_ABYTES + 2 * CHUNK_FLOATS * 4;   // 64 + 32 KiB
-
-template <typename T, int DEPTH>
-__global__ void __launch_bounds__(V3_WAVES * 64)
-k_dense_mfma_t(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
-               const float *__restrict__ img, int n_chunks, float *__restrict__ out,
-               int64_t ld_out, int n_cols, int accumulate, float *__restrict__ partials,
-               int ksplit) {
-    static_assert(sizeof(T) == 2, "v3 handles 2-byte pixels");
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    using TR = InTraits<T>;
-    constexpr int NT = V3_WAVES * 64;
-    constexpr int BUNITS = CHUNK_FLOATS / 4 / NT;        // 16-B units per thread per mask chunk (2)
-
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int m = lane & 15, kg = lane >> 4;
-    const int ks = blockIdx.y;
-
-    const int n_full = (int)(n_px / KC);
-    const int per = (n_chunks + ksplit - 1) / ksplit;
-    const int c_begin = ks * per;
-    const int c_end = min(n_chunks, c_begin + per);
-    const int cf_end = min(c_end, n_full);
-
-    const int64_t f_wave = (int64_t)blockIdx.x * (V3_WAVES * V3_ROWS) + wave * V3_ROWS;
-    unsigned char *a_lds = lds_raw + wave * V3_ABYTES;
-    float *b_lds = (float *)(lds_raw + V3_WAVES * V3_ABYTES);
-
-    f32x4 acc[2];
-    acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    if (c_begin < cf_end) {
-        // load piece t: rows 2t, 2t+1; lane i -> row 2t + (i >> 5), 16-B piece i & 31 of the
-        // chunk's 512 B.  LDS position of (row r, piece c): r*512 + (c ^ (r & 15))*16.
-        const unsigned char *src[8];
-        int wr_off[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int r = 2 * t + (lane >> 5);
-            int64_t f = f_wave + r;
-            if (f > n_frames - 1) f = n_frames - 1;
-            src[t] = (const unsigned char *)(tile + f * ld) + (lane & 31) * 16;
-            wr_off[t] = r * 512 + (((lane & 31) ^ (r & 15)) << 4);
-        }
-        const u32x4 *img_units = (const u32x4 *)img;
-        u32x4 raw[DEPTH][8];
-        u32x4 breg[BUNITS];
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            const int c = min(c_begin + d, cf_end - 1);
-#pragma unroll
-            for (int t = 0; t < 8; ++t)
-                raw[d][t] = __builtin_nontemporal_load(
-                    (const u32x4 *)(src[t] + (int64_t)c * (KC * 2)));
-        }
-#pragma unroll
-        for (int i = 0; i < BUNITS; ++i)
-            breg[i] = img_units[(int64_t)c_begin * (CHUNK_FLOATS / 4) + i * NT + tid];
-#pragma unroll
-        for (int i = 0; i < BUNITS; ++i) ((u32x4 *)b_lds)[i * NT + tid] = breg[i];
-        __syncthreads();
-
-        const int rd_base = m * 512;
-        for (int c0 = c_begin; c0 < cf_end; c0 += DEPTH) {
-#pragma unroll
-            for (int d = 0; d < DEPTH; ++d) {
-                const int c = c0 + d;
-                if (c < cf_end) {                         // block-uniform
-                    const int cn = min(c + 1, cf_end - 1);
-                    const int cp = min(c + DEPTH, cf_end - 1);
-                    const int sb = (c - c_begin) & 1;
-#pragma unroll
-                    for (int i = 0; i < BUNITS; ++i)
-                        breg[i] = img_units[(int64_t)cn * (CHUNK_FLOATS / 4) + i * NT + tid];
-                    // transpose: registers -> LDS (wave private), refill the ring slot
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        *(u32x4 *)(a_lds + wr_off[t]) = raw[d][t];
-                        raw[d][t] = __builtin_nontemporal_load(
-                            (const u32x4 *)(src[t] + (int64_t)cp * (KC * 2)));
-                    }
-                    const float *ldsb = b_lds + sb * CHUNK_FLOATS + m * KC + kg * 64;
-#pragma unroll
-                    for (int blk = 0; blk < 8; ++blk) {
-                        float a[8];
-                        const u32x4 r4 = *(const u32x4 *)(
-                            a_lds + rd_base + (((blk * 4 + kg) ^ m) << 4));
-                        TR::cvt(r4, a);
-                        f32x4 b[2];
-#pragma unroll
-                        for (int h = 0; h < 2; ++h)
-                            b[h] = *(const f32x4 *)(ldsb + (((blk * 2 + h) ^ m) << 2));
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            acc[j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                a[j], b[j >> 2][j & 3], acc[j & 1], 0, 0, 0);
-                    }
-                    u32x4 *ldsn = (u32x4 *)(b_lds + (sb ^ 1) * CHUNK_FLOATS);
-#pragma unroll
-                    for (int i = 0; i < BUNITS; ++i) ldsn[i * NT + tid] = breg[i];
-                    __syncthreads();
-                }
-            }
-        }
-    }
-
-    if (c_end > n_full) {                                 // ragged last chunk: guarded loads
-        const int c = n_full;
-        __syncthreads();
-        const u32x4 *img_units = (const u32x4 *)img + (int64_t)c * (CHUNK_FLOATS / 4);
-#pragma unroll
-        for (int i = 0; i < BUNITS; ++i) ((u32x4 *)b_lds)[i * NT + tid] = img_units[i * NT + tid];
-        __syncthreads();
-        int64_t f = f_wave + m;
-        if (f > n_frames - 1) f = n_frames - 1;
-        const T *rowp = tile + f * ld + kg * 8;
-        const float *ldsb = b_lds + m * KC + kg * 64;
-#pragma unroll
-        for (int blk = 0; blk < 8; ++blk) {
-            const int64_t p0 = (int64_t)c * KC + blk * 32;
-            float a[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                a[j] = (p0 + kg * 8 + j < n_px) ? (float)rowp[p0 + j] : 0.f;
-            f32x4 b[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                b[h] = *(const f32x4 *)(ldsb + (((blk * 2 + h) ^ m) << 2));
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                acc[j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j >> 2][j & 3],
-                                                                  acc[j & 1], 0, 0, 0);
-        }
-    }
-
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int64_t f = f_wave + kg * 4 + r;
-        const int col = m;
-        if (f < n_frames && col < n_cols) {
-            const float v = acc[0][r] + acc[1][r];
-            if (ksplit == 1) {
-                float *p = out + f * ld_out + col;
-                *p = accumulate ? (*p + v) : v;
-            } else {
-                partials[((int64_t)ks * n_frames + f) * n_cols + col] = v;
-            }
-        }
-    }
 }
 
 __global__ void k_reduce_partials(const float *__restrict__ partials, int ksplit,
@@ -1354,15 +933,12 @@ extern "C" int ltmi_masks_kind(const ltmi_masks *m, int *kind) {
 
 extern "C" int ltmi_masks_set_tuning(ltmi_masks *m, int mt, int waves, int ksplit) {
     if (!m) LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_set_tuning: null handle");
-    if (mt == 0 && (waves == 3 || waves == 5 || (waves >= 6 && waves <= 9) ||
-                    (waves >= 11 && waves <= 13) || (waves >= 23 && waves <= 25) ||
-                    (waves >= 30 && waves <= 32))) {
-        // 2-byte fast kernels: waves = 3 / 5 -> v2 (LDS-DMA ring 3 / 4); 11..13 -> v3 (register
-        // prefetch depth 1..3)
+    if (mt == 0 && waves >= 30 && waves <= 32) {
+        // k_dense_lds: 30 = as dispatched, 31 / 32 = timing-only ablations (no DMA / no MFMA)
         m->tune_mt = 0;
         m->tune_waves = 0;
         m->tune_ksplit = ksplit;
-        m->tune_ksplit_ring = waves == 3 ? 3 : (waves == 5 ? 4 : waves);   // 7: 4 waves, ring 3
+        m->tune_ksplit_ring = waves;
         return LTMI_OK;
     }
     if (!(mt == 0 || mt == 1 || mt == 2) || !(waves == 0 || waves == 4 || waves == 8) || ksplit < 0)
@@ -1416,89 +992,6 @@ static int ensure_partials(ltmi_masks *m, size_t need, hipStream_t stream) {
         m->partials_bytes = need;
     }
     return LTMI_OK;
-}
-
-// v2 (frames staged through LDS by LDS-DMA): 2-byte pixels, one 16-column group, 16-B aligned rows
-template <typename T>
-static int launch_mfma_v2(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
-                          int64_t ld_out, int accumulate, hipStream_t stream) {
-    if constexpr (sizeof(T) != 2) {
-        LTMI_FAIL(LTMI_E_DTYPE, "v2 kernel needs 2-byte pixels");
-    } else {
-        // variant: 3 / 4 = v2, 8 waves, that LDS ring depth; 7 = v2, 4 waves, ring 3 (2 blocks per
-        // CU); 11 / 12 / 13 = v3 with 1 / 2 / 3 chunks of register prefetch.
-        int variant = m->tune_ksplit_ring;
-        if (variant == 0) variant = 4;
-        const bool is_v3 = variant > 10 && variant < 20;
-        const int ring = is_v3 ? variant - 10
-                               : ((variant == 7 || variant == 6) ? 3 : (variant >= 8 ? 4 : variant));
-        int waves = is_v3 ? V3_WAVES : (variant == 7 ? 4 : 8);
-        void (*kern)(const T *, int64_t, int64_t, int64_t, const float *, int, float *, int64_t,
-                     int, int, float *, int);
-        int lds_bytes;
-        if (is_v3) {
-            kern = ring == 1 ? k_dense_mfma_t<T, 1> : (ring == 2 ? k_dense_mfma_t<T, 2>
-                                                                : k_dense_mfma_t<T, 3>);
-            lds_bytes = V3_LDS_BYTES;
-        } else if (variant == 7) {
-            kern = k_dense_mfma_lds<T, 3, 4>;
-            lds_bytes = v2_lds_bytes(3, 4);
-        } else if (variant == 6) {                          // ring 3, mask slot = 2 chunks
-            kern = k_dense_mfma_lds<T, 3, 8, 0, 2>;
-            lds_bytes = v2_lds_bytes(3, 8, 2);
-        } else if (variant == 8 || variant == 9) {          // ablations of the default variant
-            kern = variant == 8 ? k_dense_mfma_lds<T, 4, 8, 1> : k_dense_mfma_lds<T, 4, 8, 2>;
-            lds_bytes = v2_lds_bytes(4, 8);
-        } else if (variant >= 23) {                         // 23..25: deeper ablations (bench only)
-            kern = variant == 23 ? k_dense_mfma_lds<T, 4, 8, 3>
-                                 : (variant == 24 ? k_dense_mfma_lds<T, 4, 8, 4>
-                                                  : k_dense_mfma_lds<T, 4, 8, 5>);
-            lds_bytes = v2_lds_bytes(4, 8);
-        } else {
-            kern = ring == 3 ? k_dense_mfma_lds<T, 3, 8> : k_dense_mfma_lds<T, 4, 8>;
-            lds_bytes = v2_lds_bytes(ring, 8);
-        }
-        static bool attr_set[16][32] = {{false}};
-        if (!attr_set[m->device & 15][variant & 31]) {
-            LTMI_HIP(hipFuncSetAttribute((const void *)kern,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-            attr_set[m->device & 15][variant & 31] = true;
-        }
-        const int64_t gx = (n_frames + waves * V2_ROWS - 1) / (waves * V2_ROWS);
-        int ksplit = m->tune_ksplit;
-        if (ksplit <= 0) {
-            ksplit = 1;
-            if (gx < 256)       // fewer workgroups than CUs: split the pixel axis
-                ksplit = (int)std::min<int64_t>((512 + gx - 1) / gx, std::max(1, m->n_chunks / 8));
-        }
-        ksplit = std::max(1, std::min(ksplit, m->n_chunks));
-        {
-            const int per = (m->n_chunks + ksplit - 1) / ksplit;
-            ksplit = (m->n_chunks + per - 1) / per;
-        }
-        if (ksplit > 1) {
-            int rc = ensure_partials(m, (size_t)ksplit * n_frames * m->n_cols * sizeof(float),
-                                     stream);
-            if (rc != LTMI_OK) return rc;
-        }
-        dim3 grid((unsigned)gx, (unsigned)ksplit, 1);
-        hipLaunchKernelGGL(kern, grid, dim3(waves * 64), lds_bytes, stream, tile, ld, n_frames,
-                           m->n_px, (const float *)m->img, m->n_chunks, out, ld_out, m->n_cols,
-                           accumulate, m->partials, ksplit);
-        LTMI_HIP(hipGetLastError());
-        snprintf(m->last_kernel, sizeof(m->last_kernel),
-                 "%s<%s,%s=%d,waves=%d> grid=(%u,%u,1)",
-                 is_v3 ? "k_dense_mfma_t" : "k_dense_mfma_lds", typeid(T).name(),
-                 is_v3 ? "depth" : "ring", ring, waves, grid.x, grid.y);
-        if (ksplit > 1) {
-            const int64_t n = n_frames * m->n_cols;
-            hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                               stream, (const float *)m->partials, ksplit, n_frames, m->n_cols, out,
-                               ld_out, accumulate);
-            LTMI_HIP(hipGetLastError());
-        }
-        return LTMI_OK;
-    }
 }
 
 // generalised LDS-DMA kernel (k_dense_lds): any pixel width, 1 / 2 / 4 column groups per wave
@@ -1577,13 +1070,8 @@ template <typename T>
 static int launch_mfma(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
                        int64_t ld_out, int accumulate, hipStream_t stream) {
     const bool aligned = (((uintptr_t)tile) % 16 == 0) && ((ld * (int64_t)sizeof(T)) % 16 == 0);
-    if (aligned && m->tune_mt == 0 && m->tune_waves == 0) {
-        const bool force_general = m->tune_ksplit_ring >= 30;
-        if (sizeof(T) == 2 && m->n_groups == 1 && m->n_px >= KC && !force_general)
-            return launch_mfma_v2<T>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
-        if (lds_kernel_applies<T>(m) && (force_general || m->tune_ksplit_ring == 0))
-            return launch_lds<T>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
-    }
+    if (aligned && m->tune_mt == 0 && m->tune_waves == 0 && lds_kernel_applies<T>(m))
+        return launch_lds<T>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
     int waves = m->tune_waves ? m->tune_waves : 4;
     int mt = m->tune_mt ? m->tune_mt : (n_frames >= 256 * waves * 32 ? 2 : 1);
     if (m->ng == 4) { mt = 1; }   // keep the accumulator/LDS budget in check

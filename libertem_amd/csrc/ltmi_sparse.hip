@@ -212,185 +212,9 @@ k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
     }
 }
 
-// ---- v2 for 2-byte pixels: raw u16 slab, double buffered ------------------------------------------
-// Ablation of the first kernel (profiles/r01_sparse_ablation.txt): loader 0.70 ms + gathers 0.98 ms
-// = 1.60 ms total for 16384 C4 frames -- no overlap, and both phases bound by LDS instruction
-// count.  This version
-//   * keeps the slab in the frames' own 16-bit format: a pixel row is 16 frames x 2 B = 32 B, so an
-//     entry needs 2 ds_read_b128 instead of 4, and a loader lane packs the same pixel of TWO frames
-//     into one 32-bit word (half as many ds_write_b32);
-//   * pads 32 B after every 8 pixel rows so the loader's writes are conflict-free
-//     (row of pixel p at (p + p/8) * 32 B);
-//   * double-buffers the slab: while a chunk is gathered, the next chunk (already in registers) is
-//     written to the other buffer and the one after that is requested from HBM; one barrier per
-//     chunk;  chunks without entries for the block's masks are skipped through a host-built list.
-constexpr int SP2_ROWB = 32;                                   // bytes per pixel row (16 frames)
-constexpr int SP2_SLAB = (SP_P + SP_P / 8) * SP2_ROWB;         // 36 KiB
-
-// NW waves, ONE 64-mask slice per wave (masks per pass = NW * 64): a pixel chunk of a localised
-// stack touches only a few slices; with one slice per wave the critical path of a chunk is its
-// longest slice (C4: 3320 rows per 16 frames) instead of the busiest of 4 waves x 4 slices (4584).
-template <typename T, int NW, bool CPLX>
-__global__ void __launch_bounds__(NW * 64)
-k_sell_apply2(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
-              const uint32_t *__restrict__ pix, const float *__restrict__ val,
-              const int *__restrict__ row_off, const int *__restrict__ row_len,
-              const int *__restrict__ active, const int *__restrict__ active_off, int n_chunks,
-              float *__restrict__ out, int64_t ld_out, int n_masks, int accumulate) {
-    static_assert(sizeof(T) == 2, "2-byte pixels");
-    extern __shared__ __attribute__((aligned(16))) unsigned char slab_raw[];   // 2 x SP2_SLAB
-    constexpr int NC = CPLX ? 2 : 1;
-    constexpr int NT = NW * 64;
-    constexpr int STEPS = (SP_P * 8) / (NT * 8);         // (px * frame pairs) / (threads * 8 px)
-    static_assert(STEPS >= 1 && STEPS * NT * 8 == SP_P * 8, "loader tiling");
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int pass = blockIdx.y;
-    const int64_t f0 = (int64_t)blockIdx.x * SP_F;
-
-    // loader role: frame pair fp (frames 2fp, 2fp+1), pixel group g (8 px)
-    const int fp = tid & 7, g = tid >> 3;
-    const T *rowA, *rowB;
-    {
-        int64_t fa = f0 + 2 * fp, fb = f0 + 2 * fp + 1;
-        if (fa > n_frames - 1) fa = n_frames - 1;
-        if (fb > n_frames - 1) fb = n_frames - 1;
-        rowA = tile + fa * ld;
-        rowB = tile + fb * ld;
-    }
-
-    float acc[SP_F][NC];
-#pragma unroll
-    for (int f = 0; f < SP_F; ++f)
-#pragma unroll
-        for (int c = 0; c < NC; ++c) acc[f][c] = 0.f;
-
-    const int a0 = active_off[pass], a1 = active_off[pass + 1];      // active chunk list
-    u32x4 ra[STEPS], rb[STEPS];
-    auto fetch_chunk = [&](int ch) {
-#pragma unroll
-        for (int st = 0; st < STEPS; ++st) {
-            const int64_t p0 = (int64_t)ch * SP_P + st * (NT / 8) * 8 + g * 8;
-            if (p0 + 8 <= n_px) {
-                ra[st] = __builtin_nontemporal_load((const u32x4 *)(rowA + p0));
-                rb[st] = __builtin_nontemporal_load((const u32x4 *)(rowB + p0));
-            } else {
-                unsigned short ta[8], tb[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    ta[j] = (p0 + j < n_px) ? (unsigned short)rowA[p0 + j] : (unsigned short)0;
-                    tb[j] = (p0 + j < n_px) ? (unsigned short)rowB[p0 + j] : (unsigned short)0;
-                }
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    ra[st][w] = (unsigned)ta[2 * w] | ((unsigned)ta[2 * w + 1] << 16);
-                    rb[st][w] = (unsigned)tb[2 * w] | ((unsigned)tb[2 * w + 1] << 16);
-                }
-            }
-        }
-    };
-    auto store_chunk = [&](unsigned char *slab) {
-#pragma unroll
-        for (int st = 0; st < STEPS; ++st) {
-            const int pl = st * (NT / 8) * 8 + g * 8;        // first local pixel of this lane
-            unsigned *dst = (unsigned *)(slab + (pl + (pl >> 3)) * SP2_ROWB) + fp;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const unsigned a = ra[st][w], b = rb[st][w];
-                dst[(2 * w) * (SP2_ROWB / 4)] = (a & 0xffffu) | (b << 16);          // px 2w
-                dst[(2 * w + 1) * (SP2_ROWB / 4)] = (a >> 16) | (b & 0xffff0000u);  // px 2w+1
-            }
-        }
-    };
-
-    // this wave's entry stream: the rows of its slice over all active chunks are contiguous; three
-    // groups of SP_U rows are kept in flight (L2 latency ~ 2 groups of work)
-    uint32_t g0p[SP_U], g1p[SP_U], g2p[SP_U];
-    float g0r[SP_U], g1r[SP_U], g2r[SP_U], g0i[SP_U], g1i[SP_U], g2i[SP_U];
-    const int64_t sbase = (a0 < a1) ? (int64_t)row_off[a0 * NW + wave] * 64 + lane : lane;
-    auto fetch_group = [&](int t, uint32_t (&gp)[SP_U], float (&gr)[SP_U], float (&gi)[SP_U]) {
-        // rows past the end of the stream are zero padding of the image (host adds slack)
-#pragma unroll
-        for (int u = 0; u < SP_U; ++u) {
-            const int64_t e = sbase + (int64_t)(t + u) * 64;
-            gp[u] = pix[e];
-            if (CPLX) {
-                const float2 v2 = ((const float2 *)val)[e];
-                gr[u] = v2.x;
-                gi[u] = v2.y;
-            } else {
-                gr[u] = val[e];
-                gi[u] = 0.f;
-            }
-        }
-    };
-    int t_fetch = 2 * SP_U;
-
-    if (a0 < a1) {
-        fetch_group(0, g0p, g0r, g0i);
-        fetch_group(SP_U, g1p, g1r, g1i);
-        fetch_group(2 * SP_U, g2p, g2r, g2i);
-        fetch_chunk(active[a0]);
-        store_chunk(slab_raw);
-        if (a0 + 1 < a1) fetch_chunk(active[a0 + 1]);
-        __syncthreads();
-        for (int ai = a0; ai < a1; ++ai) {
-            unsigned char *cur = slab_raw + ((ai - a0) & 1) * SP2_SLAB;
-            unsigned char *nxt = slab_raw + (((ai - a0) & 1) ^ 1) * SP2_SLAB;
-            if (ai + 1 < a1) store_chunk(nxt);               // registers hold chunk ai+1
-            if (ai + 2 < a1) fetch_chunk(active[ai + 2]);
-            const int len = row_len[ai * NW + wave];
-            for (int j = 0; j < len; j += SP_U) {
-                // process group g0 from the current slab, rotate, fetch two groups ahead
-#pragma unroll
-                for (int u = 0; u < SP_U; ++u) {
-                    const unsigned char *rowp = cur + (g0p[u] + (g0p[u] >> 3)) * SP2_ROWB;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const u32x4 x = *(const u32x4 *)(rowp + h * 16);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float lo, hi;
-                            if (std::is_signed<T>::value) {
-                                lo = (float)((int)(x[e] << 16) >> 16);
-                                hi = (float)((int)x[e] >> 16);
-                            } else {
-                                lo = (float)(x[e] & 0xffffu);
-                                hi = (float)(x[e] >> 16);
-                            }
-                            acc[h * 8 + 2 * e][0] += lo * g0r[u];
-                            acc[h * 8 + 2 * e + 1][0] += hi * g0r[u];
-                            if (CPLX) {
-                                acc[h * 8 + 2 * e][1] += lo * g0i[u];
-                                acc[h * 8 + 2 * e + 1][1] += hi * g0i[u];
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < SP_U; ++u) {
-                    g0p[u] = g1p[u]; g0r[u] = g1r[u]; g0i[u] = g1i[u];
-                    g1p[u] = g2p[u]; g1r[u] = g2r[u]; g1i[u] = g2i[u];
-                }
-                t_fetch += SP_U;
-                fetch_group(t_fetch, g2p, g2r, g2i);
-            }
-            __syncthreads();
-        }
-    }
-
-    const int k = pass * (NW * 64) + wave * 64 + lane;
-    if (k < n_masks) {
-#pragma unroll
-        for (int f = 0; f < SP_F; ++f) {
-            if (f0 + f >= n_frames) break;
-            float *o = out + (f0 + f) * ld_out + (int64_t)k * NC;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) o[c] = accumulate ? o[c] + acc[f][c] : acc[f][c];
-        }
-    }
-}
+// A u16-slab, double-buffered variant with one slice per wave was tried and removed: it did not
+// beat this kernel (profiles/r01_sparse_ablation.txt) -- the gather loop is latency bound, see
+// DESIGN.md section 4.3 for the analysis and the planned redesign.
 
 }  // namespace ltmi
 
@@ -422,32 +246,6 @@ static int launch_sell(ltmi_masks *m, CsrImage *c, const T *tile, int64_t n_fram
     if constexpr (sizeof(T) == 2) {
         // experimental (round 1: not faster than k_sell_apply -- every wave's entry stream queues
         // behind its own HBM frame loads on the in-order vmcnt; needs dedicated loader waves)
-        if (vec_ok && getenv("LTMI_SELL_V2")) {
-            const size_t lds2 = 2 * SP2_SLAB;
-            void (*k2)(const T *, int64_t, int64_t, int64_t, const uint32_t *, const float *,
-                       const int *, const int *, const int *, const int *, int, float *, int64_t,
-                       int, int);
-            if (c->cplx) k2 = k_sell_apply2<T, 8, true>;
-            else k2 = k_sell_apply2<T, 16, false>;
-            const int nthreads = c->cplx ? 8 * 64 : 16 * 64;
-            static bool set2[16][2] = {{false}};
-            if (!set2[m->device & 15][c->cplx]) {
-                LTMI_HIP(hipFuncSetAttribute((const void *)k2,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)lds2));
-                set2[m->device & 15][c->cplx] = true;
-            }
-            hipLaunchKernelGGL(k2, grid, dim3(nthreads), lds2, stream, tile, ld, n_frames, m->n_px,
-                               (const uint32_t *)c->pix, (const float *)c->val,
-                               (const int *)c->row_off, (const int *)c->row_len,
-                               (const int *)c->active, (const int *)c->active_off, c->n_chunks, out,
-                               ld_out_f, (int)m->n_masks, accumulate);
-            LTMI_HIP(hipGetLastError());
-            snprintf(m->last_kernel, sizeof(m->last_kernel),
-                     "k_sell_apply2<%s,%s> grid=(%u,%u) rows=%zu", typeid(T).name(),
-                     c->cplx ? "c64" : "f32", grid.x, grid.y, c->n_rows);
-            return LTMI_OK;
-        }
     }
     const size_t lds = (size_t)SP_P * SP_F * sizeof(float);
     if (c->cplx) {

@@ -39,11 +39,11 @@ frame_bytes = n_px * dt.itemsize + args.masks * md.itemsize
 
 if args.variants == 'auto':
     variants = [dict(mt=0, waves=0, ksplit=0)]
-elif args.variants.startswith('w='):        # explicit list of `waves` codes, e.g. w=0,8,9,23,24,25
+elif args.variants.startswith('w='):        # explicit list of `waves` codes, e.g. w=0,31,32
     variants = [dict(mt=0, waves=int(w), ksplit=0) for w in args.variants[2:].split(',')]
 else:
-    variants = [dict(mt=0, waves=9, ksplit=0), dict(mt=0, waves=3, ksplit=0),
-                dict(mt=0, waves=5, ksplit=0), dict(mt=0, waves=6, ksplit=0),
+    variants = [dict(mt=0, waves=0, ksplit=0), dict(mt=0, waves=31, ksplit=0),
+                dict(mt=0, waves=32, ksplit=0),
                 dict(mt=2, waves=4, ksplit=1), dict(mt=1, waves=4, ksplit=1)]
 for v in variants:
     h.set_tuning(**v)
