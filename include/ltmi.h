@@ -137,6 +137,25 @@ int ltmi_repair_pixels(int device, void *buf, int dtype, int64_t n_frames, int64
                        const int32_t *excl, const int32_t *env, const int32_t *cnt, int n_excl,
                        int max_env, void *stream);
 
+/* ---- Fourier-space operators (hipFFT) ----------------------------------------------------------
+ * A plan owns a batched 2D real-to-complex hipFFT (frames of sig_h x sig_w float32, `max_batch`
+ * per execution) and its workspace (f32 input + complex64 half spectra).
+ */
+typedef struct ltmi_fft_plan ltmi_fft_plan;   /* opaque */
+int ltmi_fft_plan_create(int device, int sig_h, int sig_w, int max_batch, ltmi_fft_plan **out);
+int ltmi_fft_plan_destroy(ltmi_fft_plan *p);
+/* CrystallinityUDF.process_frame (src/libertem/udf/crystallinity.py:73-79) for a whole tile:
+ *   out[f] (+)= sum( abs(rfft2(tile[f] * real_mask)) * half_mask )
+ * tile: device (n_frames, sig_h*sig_w) of tile_dtype, ld_tile elements apart (native dtype, the
+ * astype is fused); real_mask: device float32 (sig_h*sig_w) or NULL; half_mask: device float32
+ * (sig_h, sig_w/2+1) = fftshift(ring)[:, :w/2+1] (crystallinity.py:64-65); its non-zeros lie in the
+ * rows [0, row_lo) and [row_hi, sig_h) and in the columns [0, n_cols): only that box of the
+ * spectrum is read (row_lo = row_hi = sig_h, n_cols = sig_w/2+1 reads everything);
+ * out: device float32 (n_frames). */
+int ltmi_crystallinity(ltmi_fft_plan *p, const void *tile, int tile_dtype, int64_t n_frames,
+                       int64_t ld_tile, const float *real_mask, const float *half_mask, int row_lo,
+                       int row_hi, int n_cols, float *out, int accumulate, void *stream);
+
 /* ---- tuning / introspection (bench + tests) ------------------------------------------- */
 /* force a kernel variant for the dense MFMA path (bench / tests only; (0,0,0) = automatic):
  *   mt in {1,2}, waves in {4,8}: the direct-load kernel k_dense_mfma with that tile shape;

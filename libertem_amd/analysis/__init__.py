@@ -7,8 +7,9 @@ from .sum import SumAnalysis
 from .sumsig import SumSigAnalysis
 from .com import COMAnalysis
 from .radialfourier import RadialFourierAnalysis
+from .fft import ApplyFFTMask, SumfftAnalysis
 
 __all__ = ['Analysis', 'AnalysisResult', 'AnalysisResultSet', 'MasksAnalysis',
            'BaseMasksAnalysis', 'SingleMaskAnalysis', 'DiskMaskAnalysis', 'RingMaskAnalysis',
            'PointMaskAnalysis', 'SumAnalysis', 'SumSigAnalysis', 'COMAnalysis',
-           'RadialFourierAnalysis']
+           'RadialFourierAnalysis', 'ApplyFFTMask', 'SumfftAnalysis']

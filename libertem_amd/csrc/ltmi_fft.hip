@@ -1,0 +1,223 @@
+// ltmi_fft.hip -- per-frame Fourier-space operators.
+//
+// CrystallinityUDF.process_frame (reference udf/crystallinity.py:73-79):
+//     intensity[f] = sum( abs(rfft2(frame * real_mask)) * half_fourier_mask )
+// for a whole tile per call: a conversion kernel (native pixels -> f32, times the real-space mask),
+// ONE batched 2D real-to-complex hipFFT per batch of frames, and a fused |F| * mask reduction that
+// reads the half spectrum once and writes one float per frame.  The spectrum never leaves the
+// plan's workspace.
+#include "ltmi_common.h"
+#include <hipfft/hipfft.h>
+#include <algorithm>
+#include <new>
+
+struct ltmi_fft_plan {
+    int device = 0;
+    int h = 0, w = 0, wc = 0;          // frame shape, complex columns w/2+1
+    int batch = 0;                     // frames per hipFFT execution
+    hipfftHandle plan = 0;
+    bool have_plan = false;
+    float *real_buf = nullptr;         // (batch, h, w) f32
+    hipfftComplex *spec = nullptr;     // (batch, h, wc) c64
+    hipStream_t bound_stream = nullptr;
+    bool stream_bound = false;
+};
+
+namespace ltmi {
+
+static const char *fft_err(hipfftResult r) {
+    switch (r) {
+        case HIPFFT_SUCCESS: return "success";
+        case HIPFFT_INVALID_PLAN: return "invalid plan";
+        case HIPFFT_ALLOC_FAILED: return "allocation failed";
+        case HIPFFT_INVALID_VALUE: return "invalid value";
+        case HIPFFT_INTERNAL_ERROR: return "internal error";
+        case HIPFFT_EXEC_FAILED: return "exec failed";
+        case HIPFFT_SETUP_FAILED: return "setup failed";
+        case HIPFFT_INVALID_SIZE: return "invalid size";
+        default: return "hipfft error";
+    }
+}
+
+// frames (native dtype, ld elements apart) -> contiguous f32, times the optional real-space mask.
+// A thread converts 8 consecutive pixels (one 16-B load for 2-byte pixels, two 16-B stores).
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_fft_prepare(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
+              const float *__restrict__ real_mask, float *__restrict__ out, int vec_ok) {
+    const int64_t f = blockIdx.y;
+    const T *src = tile + f * ld;
+    float *dst = out + f * n_px;
+    const int64_t n8 = vec_ok ? n_px / 8 : 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        T raw[8];
+        typedef T __attribute__((ext_vector_type(8))) vec_t;
+        *(vec_t *)raw = __builtin_nontemporal_load((const vec_t *)(src + i * 8));
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)raw[j];
+        if (real_mask) {
+            const float4 m0 = *(const float4 *)(real_mask + i * 8);
+            const float4 m1 = *(const float4 *)(real_mask + i * 8 + 4);
+            v[0] *= m0.x; v[1] *= m0.y; v[2] *= m0.z; v[3] *= m0.w;
+            v[4] *= m1.x; v[5] *= m1.y; v[6] *= m1.z; v[7] *= m1.w;
+        }
+        *(float4 *)(dst + i * 8) = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4 *)(dst + i * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    for (int64_t p = n8 * 8 + (int64_t)blockIdx.x * 256 + threadIdx.x; p < n_px;
+         p += (int64_t)gridDim.x * 256) {
+        float v = (float)src[p];
+        if (real_mask) v *= real_mask[p];
+        dst[p] = v;
+    }
+}
+
+// out[f] (+)= sum_k |spec[f, k]| * mask[k] over the rows [0, row_lo) and [row_hi, h) and the columns
+// [0, n_cols) of the half spectrum: the bounding box of the (fft-shifted) ring -- everything else
+// of the mask is zero and is never read.  One block per frame.
+__global__ void __launch_bounds__(256)
+k_abs_dot(const hipfftComplex *__restrict__ spec, int h, int wc, const float *__restrict__ mask,
+          int row_lo, int row_hi, int n_cols, float *__restrict__ out, int accumulate) {
+    const int64_t f = blockIdx.x;
+    const hipfftComplex *s = spec + f * (int64_t)h * wc;
+    const int n_box = (row_lo + (h - row_hi)) * n_cols;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n_box; i += 256) {
+        const int r = i / n_cols, kx = i - r * n_cols;
+        const int ky = r < row_lo ? r : row_hi + (r - row_lo);
+        const float m = mask[(int64_t)ky * wc + kx];
+        if (m != 0.f) {
+            const hipfftComplex c = s[(int64_t)ky * wc + kx];
+            acc += sqrtf(c.x * c.x + c.y * c.y) * m;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = part[0] + part[1] + part[2] + part[3];
+        out[f] = accumulate ? out[f] + v : v;
+    }
+}
+
+template <typename T>
+static int run_prepare(const void *tile, int64_t ld, int64_t n, int64_t n_px, const float *real_mask,
+                       float *out, hipStream_t stream) {
+    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_px / 8 + 255) / 256, 32));
+    const int vec_ok = (sizeof(T) <= 4) && ((uintptr_t)tile % 16 == 0) &&
+                       ((ld * (int64_t)sizeof(T)) % 16 == 0) && (n_px % 8 == 0);
+    hipLaunchKernelGGL((k_fft_prepare<T>), dim3(gx, (unsigned)n), dim3(256), 0, stream,
+                       (const T *)tile, ld, n, n_px, real_mask, out, vec_ok);
+    LTMI_HIP(hipGetLastError());
+    return LTMI_OK;
+}
+
+}  // namespace ltmi
+
+using namespace ltmi;
+
+extern "C" int ltmi_fft_plan_create(int device, int sig_h, int sig_w, int max_batch,
+                                    ltmi_fft_plan **out) {
+    if (!out || sig_h <= 0 || sig_w <= 0 || max_batch <= 0)
+        LTMI_FAIL(LTMI_E_INVALID, "ltmi_fft_plan_create: bad arguments (%d x %d, batch %d)", sig_h,
+                  sig_w, max_batch);
+    LTMI_HIP(hipSetDevice(device));
+    ltmi_fft_plan *p = new (std::nothrow) ltmi_fft_plan();
+    if (!p) LTMI_FAIL(LTMI_E_NOMEM, "out of host memory");
+    p->device = device;
+    p->h = sig_h;
+    p->w = sig_w;
+    p->wc = sig_w / 2 + 1;
+    p->batch = max_batch;
+    int n[2] = {sig_h, sig_w};
+    hipfftResult r = hipfftPlanMany(&p->plan, 2, n, nullptr, 1, sig_h * sig_w, nullptr, 1,
+                                    sig_h * p->wc, HIPFFT_R2C, max_batch);
+    if (r != HIPFFT_SUCCESS) {
+        delete p;
+        LTMI_FAIL(LTMI_E_INVALID, "hipfftPlanMany(%d x %d, batch %d) failed: %s", sig_h, sig_w,
+                  max_batch, fft_err(r));
+    }
+    p->have_plan = true;
+    hipError_t e = hipMalloc((void **)&p->real_buf, (size_t)max_batch * sig_h * sig_w * sizeof(float));
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&p->spec, (size_t)max_batch * sig_h * p->wc * sizeof(hipfftComplex));
+    if (e != hipSuccess) {
+        if (p->real_buf) (void)hipFree(p->real_buf);
+        (void)hipfftDestroy(p->plan);
+        delete p;
+        LTMI_FAIL((int)e, "ltmi_fft_plan_create: workspace allocation failed: %s",
+                  hipGetErrorString(e));
+    }
+    *out = p;
+    return LTMI_OK;
+}
+
+extern "C" int ltmi_fft_plan_destroy(ltmi_fft_plan *p) {
+    if (!p) return LTMI_OK;
+    (void)hipSetDevice(p->device);
+    if (p->have_plan) (void)hipfftDestroy(p->plan);
+    if (p->real_buf) (void)hipFree(p->real_buf);
+    if (p->spec) (void)hipFree(p->spec);
+    delete p;
+    return LTMI_OK;
+}
+
+extern "C" int ltmi_crystallinity(ltmi_fft_plan *p, const void *tile, int tile_dtype,
+                                  int64_t n_frames, int64_t ld_tile, const float *real_mask,
+                                  const float *half_mask, int row_lo, int row_hi, int n_cols,
+                                  float *out, int accumulate, void *stream_) {
+    if (!p) LTMI_FAIL(LTMI_E_INVALID, "ltmi_crystallinity: null plan");
+    if (n_frames < 0) LTMI_FAIL(LTMI_E_SHAPE, "ltmi_crystallinity: negative frame count");
+    if (n_frames == 0) return LTMI_OK;
+    const int64_t n_px = (int64_t)p->h * p->w;
+    if (ld_tile < n_px) LTMI_FAIL(LTMI_E_SHAPE, "ltmi_crystallinity: ld_tile < frame size");
+    if (!tile || !half_mask || !out) LTMI_FAIL(LTMI_E_INVALID, "ltmi_crystallinity: null pointer");
+    LTMI_HIP(hipSetDevice(p->device));
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!p->stream_bound || p->bound_stream != stream) {
+        hipfftResult r = hipfftSetStream(p->plan, stream);
+        if (r != HIPFFT_SUCCESS) LTMI_FAIL(LTMI_E_INVALID, "hipfftSetStream failed: %s", fft_err(r));
+        p->bound_stream = stream;
+        p->stream_bound = true;
+    }
+    const size_t esz = (size_t)dtype_size(tile_dtype);
+    if (row_lo < 0 || row_hi < row_lo || row_hi > p->h || n_cols < 0 || n_cols > p->wc)
+        LTMI_FAIL(LTMI_E_SHAPE, "ltmi_crystallinity: bad mask bounding box (%d, %d, %d)", row_lo,
+                  row_hi, n_cols);
+    for (int64_t f0 = 0; f0 < n_frames; f0 += p->batch) {
+        const int64_t n = std::min<int64_t>(p->batch, n_frames - f0);
+        const void *src = (const char *)tile + (size_t)f0 * ld_tile * esz;
+        int rc = LTMI_E_DTYPE;
+        switch (tile_dtype) {
+            case LTMI_BOOL:
+            case LTMI_U8: rc = run_prepare<uint8_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream); break;
+            case LTMI_I8: rc = run_prepare<int8_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream); break;
+            case LTMI_U16: rc = run_prepare<uint16_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream); break;
+            case LTMI_I16: rc = run_prepare<int16_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream); break;
+            case LTMI_U32: rc = run_prepare<uint32_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream); break;
+            case LTMI_I32: rc = run_prepare<int32_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream); break;
+            case LTMI_F32: rc = run_prepare<float>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream); break;
+            case LTMI_F64: rc = run_prepare<double>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream); break;
+            default:
+                LTMI_FAIL(LTMI_E_DTYPE, "ltmi_crystallinity: unsupported tile dtype %s",
+                          dtype_name(tile_dtype));
+        }
+        if (rc != LTMI_OK) return rc;
+        if (n < p->batch) {
+            // the plan always transforms `batch` frames: clear the unused tail once so that it
+            // holds finite numbers (its spectra are never read)
+            LTMI_HIP(hipMemsetAsync(p->real_buf + n * n_px, 0,
+                                    (size_t)(p->batch - n) * n_px * sizeof(float), stream));
+        }
+        hipfftResult r = hipfftExecR2C(p->plan, p->real_buf, p->spec);
+        if (r != HIPFFT_SUCCESS) LTMI_FAIL(LTMI_E_INVALID, "hipfftExecR2C failed: %s", fft_err(r));
+        hipLaunchKernelGGL(k_abs_dot, dim3((unsigned)n), dim3(256), 0, stream,
+                           (const hipfftComplex *)p->spec, p->h, p->wc, half_mask, row_lo, row_hi,
+                           n_cols, out + f0, accumulate);
+        LTMI_HIP(hipGetLastError());
+    }
+    return LTMI_OK;
+}

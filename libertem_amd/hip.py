@@ -28,7 +28,8 @@ EXPORTS = (
     'ltmi_version', 'ltmi_last_error', 'ltmi_device_count', 'ltmi_device_info',
     'ltmi_masks_create_dense', 'ltmi_masks_create_csr', 'ltmi_masks_destroy', 'ltmi_masks_kind',
     'ltmi_apply_masks', 'ltmi_apply_masks_shifted', 'ltmi_sum_frames_workspace', 'ltmi_sum_frames', 'ltmi_sum_sig',
-    'ltmi_axpy', 'ltmi_correct', 'ltmi_repair_pixels', 'ltmi_masks_set_tuning',
+    'ltmi_axpy', 'ltmi_correct', 'ltmi_repair_pixels', 'ltmi_fft_plan_create',
+    'ltmi_fft_plan_destroy', 'ltmi_crystallinity', 'ltmi_masks_set_tuning',
     'ltmi_masks_last_kernel',
 )
 
@@ -107,6 +108,9 @@ def lib():
         L.ltmi_axpy.argtypes = [i32, vp, vp, i32, i64, vp]
         L.ltmi_correct.argtypes = [i32, vp, i32, i64, i64, i64, vp, vp, vp, i32, i64, vp]
         L.ltmi_repair_pixels.argtypes = [i32, vp, i32, i64, i64, vp, vp, vp, i32, i32, vp]
+        L.ltmi_fft_plan_create.argtypes = [i32, i32, i32, i32, c.POINTER(vp)]
+        L.ltmi_fft_plan_destroy.argtypes = [vp]
+        L.ltmi_crystallinity.argtypes = [vp, vp, i32, i64, i64, vp, vp, i32, i32, i32, vp, i32, vp]
         L.ltmi_masks_set_tuning.argtypes = [vp, i32, i32, i32]
         L.ltmi_masks_last_kernel.argtypes = [vp]
         L.ltmi_masks_last_kernel.restype = c.c_char_p
@@ -288,3 +292,33 @@ def repair_pixels(device, buf_ptr, dtype, n_frames, ld, excl_ptr, env_ptr, cnt_p
         int(device), buf_ptr, dtype_code(dtype), n_frames, ld, excl_ptr, env_ptr, cnt_ptr,
         int(n_excl), int(max_env), stream if isinstance(stream, int) else _stream_ptr(stream)),
         'ltmi_repair_pixels')
+
+
+class FFTPlan:
+    """Owns one `ltmi_fft_plan*`: batched 2D R2C hipFFT + workspace for frames of (sig_h, sig_w)."""
+
+    def __init__(self, device, sig_h, sig_w, max_batch):
+        out = ctypes.c_void_p()
+        check(lib().ltmi_fft_plan_create(int(device), int(sig_h), int(sig_w), int(max_batch),
+                                         ctypes.byref(out)), 'ltmi_fft_plan_create')
+        self._ptr = out
+        self.device, self.sig, self.max_batch = int(device), (int(sig_h), int(sig_w)), int(max_batch)
+
+    def crystallinity(self, tile_ptr, tile_dtype, n_frames, ld_tile, real_mask_ptr, half_mask_ptr,
+                      box, out_ptr, accumulate, stream=None):
+        """box = (row_lo, row_hi, n_cols): bounding box of the non-zeros of the half mask."""
+        check(lib().ltmi_crystallinity(
+            self._ptr, tile_ptr, dtype_code(tile_dtype), n_frames, ld_tile, real_mask_ptr or None,
+            half_mask_ptr, int(box[0]), int(box[1]), int(box[2]), out_ptr, 1 if accumulate else 0,
+            stream if isinstance(stream, int) else _stream_ptr(stream)), 'ltmi_crystallinity')
+
+    def close(self):
+        if self._ptr is not None and self._ptr.value:
+            lib().ltmi_fft_plan_destroy(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -417,3 +417,31 @@ def radial_fourier_analysis(data, num_partitions=1, **params):
     raw = inten.reshape((prod(nav), -1)).T
     raw = raw.reshape((p['n_bins'], p['max_order'] + 1) + nav)
     return {'intensity': inten, 'raw_results': raw, 'parameters': p}
+
+
+# ---------------------------------------------------------------------------------------------------
+# CrystallinityUDF  (udf/crystallinity.py:47-79)
+# ---------------------------------------------------------------------------------------------------
+def crystallinity_udf(data, rad_in, rad_out, real_center=None, real_rad=None):
+    """data (*nav, sy, sx).  Per frame, in the reference's arithmetic: the frame arrives as
+    input dtype = result_type(float32, ds dtype) (udf/base.py:106-123); with a real-space mask
+    (an int array) the product is float64 and so is the transform, without it the float32 frame
+    is transformed in single precision; the sum is stored into a float32 nav buffer."""
+    sig = data.shape[-2:]
+    sy, sx = sig
+
+    def disk(cx, cy, r):                                # masks.py:50-52 (_make_circular_mask)
+        x, y = np.ogrid[-cy:sy - cy, -cx:sx - cx]
+        return x * x + y * y <= r * r
+
+    real_mask = None
+    if not (real_center is None or real_rad is None):
+        real_mask = 1 - 1 * disk(real_center[1], real_center[0], real_rad)
+    ring = np.fft.fftshift(1 * disk(sx * 0.5, sy * 0.5, rad_out) - 1 * disk(sx * 0.5, sy * 0.5, rad_in))
+    half = ring[:, :int(ring.shape[1] * 0.5) + 1]
+    frames = data.reshape((-1,) + sig).astype(input_dtype(data.dtype))
+    out = np.zeros(len(frames), dtype=np.float32)
+    for i, frame in enumerate(frames):
+        masked = frame * real_mask if real_mask is not None else frame
+        out[i] = np.sum(abs(np.fft.rfft2(masked)) * half)
+    return out.reshape(data.shape[:-2])

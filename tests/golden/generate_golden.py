@@ -357,7 +357,26 @@ def gen_corrections():
     save('corrections', **out)
 
 
+# ---------------------------------------------------------------------------
+# 11. CrystallinityUDF
+# ---------------------------------------------------------------------------
+def gen_crystallinity():
+    from libertem.udf.crystallinity import CrystallinityUDF
+    out = {}
+    for case in recipes.CRYST_CASES:
+        data = recipes.make_cryst_case(case)
+        ds = MemoryDataSet(data=data, num_partitions=case['num_partitions'], sig_dims=2)
+        udf = CrystallinityUDF(rad_in=case['rad_in'], rad_out=case['rad_out'],
+                               real_center=case['real_center'], real_rad=case['real_rad'])
+        res = run(ds, udf)['intensity']
+        out[case['name']] = np.array(res.data)
+        out[case['name'] + '__sha_data'] = np.frombuffer(bytes.fromhex(sha(data)), dtype=np.uint8)
+        print(case['name'], res.data.shape, res.data.dtype, float(np.abs(res.data).max()))
+    save('crystallinity', **out)
+
+
 if __name__ == '__main__':
+    gen_crystallinity()
     gen_corrections()
     gen_shifts()
     gen_apply_masks_dense()

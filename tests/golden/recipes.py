@@ -411,3 +411,32 @@ ADJUST_CASES = [
     ((16, 16), (128, 128), (4, 4), [[17, 33, 95], [3, 64, 127]]),
     ((3, 5), (30, 50), (3, 5), [[2, 3, 29], [4, 5, 49]]),
 ]
+
+
+# ---------------------------------------------------------------------------
+# CrystallinityUDF (reference udf/crystallinity.py)
+# ---------------------------------------------------------------------------
+CRYST_CASES = [
+    dict(name='u16_masked', nav=(4, 5), sig=(32, 32), dtype='uint16', num_partitions=2, seed=801,
+         rad_in=4, rad_out=9, real_center=(16, 16), real_rad=5),
+    dict(name='f32_plain', nav=(6,), sig=(24, 40), dtype='float32', num_partitions=1, seed=802,
+         rad_in=3, rad_out=8, real_center=None, real_rad=None),
+    dict(name='u8_odd', nav=(3, 3), sig=(33, 31), dtype='uint8', num_partitions=3, seed=803,
+         rad_in=2.5, rad_out=11.5, real_center=(10.5, 20.25), real_rad=4),
+    dict(name='u16_64', nav=(2, 8), sig=(64, 64), dtype='uint16', num_partitions=1, seed=804,
+         rad_in=6, rad_out=20, real_center=(32, 32), real_rad=8),
+]
+
+
+def make_cryst_case(case):
+    rng = np.random.default_rng(case['seed'])
+    shape = tuple(case['nav']) + tuple(case['sig'])
+    dt = np.dtype(case['dtype'])
+    if dt.kind == 'u':
+        base = rng.integers(0, 200 if dt.itemsize == 1 else 2000, shape)
+    else:
+        base = rng.random(shape) * 50
+    # a lattice so that the ring actually catches peaks
+    yy, xx = np.mgrid[0:case['sig'][0], 0:case['sig'][1]]
+    lattice = 40 * (1 + np.cos(2 * np.pi * xx / 4.0)) * (1 + np.cos(2 * np.pi * yy / 5.0))
+    return (base + lattice).astype(dt)

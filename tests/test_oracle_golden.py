@@ -304,3 +304,17 @@ def test_repair_tables_and_tileshape_adjustment_vs_reference():
     for i, (tile_shape, sig_shape, base_shape, coords) in enumerate(recipes.ADJUST_CASES):
         got = oc.adjust_tileshape(tile_shape, sig_shape, base_shape, coords)
         assert tuple(got) == tuple(g[f"adjust{i}"]), (i, got, g[f"adjust{i}"])
+
+
+# ---- CrystallinityUDF ------------------------------------------------------------------------------
+@pytest.mark.parametrize('case', recipes.CRYST_CASES, ids=lambda c: c['name'])
+def test_crystallinity_oracle_vs_reference(case):
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden',
+                             'crystallinity.npz'))
+    data = recipes.make_cryst_case(case)
+    assert np.array_equal(_sha(data), g[case['name'] + '__sha_data'])
+    res = opath.crystallinity_udf(data, case['rad_in'], case['rad_out'], case['real_center'],
+                                  case['real_rad'])
+    ref = g[case['name']]
+    assert res.shape == ref.shape and res.dtype == ref.dtype
+    np.testing.assert_allclose(res, ref, rtol=2e-6)

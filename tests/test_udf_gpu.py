@@ -546,3 +546,62 @@ def test_corrections_chunked_scratch(ctx):
     coords = [tuple(c) for c in np.argwhere(bad)]
     ref = oc.correct(data, (32, 32), dark=dark, gain=gain, coords=coords).astype(np.float64)
     assert np.allclose(got, ref.reshape((37, -1)).sum(axis=1), rtol=1e-5)
+
+
+# --- Fourier-space operators -------------------------------------------------
+@pytest.mark.parametrize('resident', ['host', 'device'])
+@pytest.mark.parametrize('case', recipes.CRYST_CASES, ids=lambda c: c['name'])
+def test_crystallinity_vs_reference_golden(ctx, golden_dir, case, resident):
+    from libertem_amd.udf.crystallinity import CrystallinityUDF, run_analysis_crystall
+    g = _load(golden_dir, 'crystallinity')
+    data = recipes.make_cryst_case(case)
+    if resident == 'device':
+        ds = _device_ds(ctx, data, case['num_partitions'])
+    else:
+        ds = ctx.load('memory', data=data, num_partitions=case['num_partitions'], sig_dims=2)
+    udf = CrystallinityUDF(rad_in=case['rad_in'], rad_out=case['rad_out'],
+                           real_center=case['real_center'], real_rad=case['real_rad'])
+    got = ctx.run_udf(dataset=ds, udf=udf)['intensity'].data
+    ref = g[case['name']]
+    assert got.shape == ref.shape and got.dtype == ref.dtype
+    assert _close(got, ref, F32_TOL), (np.abs(got - ref).max(), np.abs(ref).max())
+    again = run_analysis_crystall(ctx, ds, case['rad_in'], case['rad_out'], case['real_center'],
+                                  case['real_rad'])['intensity'].data
+    assert np.array_equal(again, got)                       # deterministic, plan re-used
+
+
+def test_crystallinity_roi_batches_and_analysis(ctx):
+    """More frames than one FFT batch, a ragged last batch, an ROI, and the ApplyFFTMask /
+    SumfftAnalysis wrappers (reference tests/udf/test_crystallinity.py, analysis/sumfft.py)."""
+    import libertem_amd.udf.crystallinity as cr
+    from libertem_amd.analysis import ApplyFFTMask, SumfftAnalysis
+    rng = np.random.default_rng(9)
+    data = rng.integers(0, 500, (5, 7, 32, 32)).astype(np.uint16)
+    ref = opath.crystallinity_udf(data, 3, 9, (16, 16), 4)
+    old = cr.FFT_WORKSPACE_BYTES
+    cr.FFT_WORKSPACE_BYTES = 8 * (32 * 32 * 4 + 32 * 17 * 8)        # 8 frames per batch
+    try:
+        ds = _device_ds(ctx, data, 1)
+        udf = cr.CrystallinityUDF(rad_in=3, rad_out=9, real_center=(16, 16), real_rad=4)
+        got = ctx.run_udf(dataset=ds, udf=udf)['intensity'].data
+        assert _close(got, ref, F32_TOL)
+        roi = np.zeros((5, 7), dtype=bool)
+        roi[1, 2:6] = True
+        roi[4, 6] = True
+        part = ctx.run_udf(dataset=ds, udf=udf, roi=roi)['intensity']
+        assert _close(part.raw_data, ref[roi], F32_TOL)
+        assert np.all(np.isnan(part.data[~roi]))
+    finally:
+        cr.FFT_WORKSPACE_BYTES = old
+    an = ApplyFFTMask(dataset=ds, parameters=dict(rad_in=3, rad_out=9, real_centery=16,
+                                                  real_centerx=16, real_rad=4))
+    res = ctx.run(an)
+    assert _close(res.intensity.raw_data, ref, F32_TOL)
+    sf = ctx.run(SumfftAnalysis(dataset=ds, parameters=dict(real_centery=16, real_centerx=16,
+                                                            real_rad=4)))
+    total = data.astype(np.float64).sum(axis=(0, 1))
+    assert np.allclose(sf.intensity.raw_data, total, rtol=1e-6)
+    yy, xx = np.ogrid[-16:16, -16:16]
+    mask = 1 - 1 * (yy * yy + xx * xx <= 16)
+    expect = np.log(abs(np.fft.fftshift(np.fft.fft2(total * mask))) + 1)
+    assert np.allclose(sf.intensity_fft.raw_data, expect, rtol=1e-4, atol=1e-4)
