@@ -63,6 +63,7 @@ struct ltmi_masks {
     float *img = nullptr;
     float *img2 = nullptr;   // slot-major image for k_dense_lds with ng > 1 (KB = 128)
     int n_slots2 = 0;
+    void *shift_cache = nullptr;   // ltmi_dense.hip: images of the stack shifted by (dy, dx)
     float *partials = nullptr;
     size_t partials_bytes = 0;
     int tune_mt = 0, tune_waves = 0, tune_ksplit = 0, tune_ksplit_ring = 0;

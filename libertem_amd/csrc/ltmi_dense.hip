@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <typeinfo>
 #include <type_traits>
+#include <unordered_map>
 
 namespace ltmi {
 
@@ -360,11 +361,39 @@ __global__ void k_build_image2(const float *__restrict__ src, float *__restrict_
     }
 }
 
-template <typename T, int NG, int ABL = 0>
+// IND (indirect rows, used for shifted masks): workgroup b processes the 128 frames
+// rows[128 b .. 128 b + 127] (-1 = padding) against its own mask image wg_img[b].
+// standard image (img_index layout, one group tile) of the stack shifted by (dy, dx):
+// mask'[k](y, x) = mask[k](y - dy, x - dx) inside the frame, 0 outside (udf/masks.py:85-124)
+__global__ void k_build_image_shifted(const float *__restrict__ src, float *__restrict__ img,
+                                      int64_t n_masks, int cpm, int sig_h, int sig_w, int dy, int dx,
+                                      int n_chunks) {
+    const int64_t n_px = (int64_t)sig_h * sig_w;
+    const int64_t total = n_masks * cpm * n_px;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int part = (int)(i % cpm);
+        const int64_t kp = i / cpm;
+        const int64_t k = kp / n_px, p = kp % n_px;            // destination pixel
+        const int y = (int)(p / sig_w), x = (int)(p % sig_w);
+        const int ys = y - dy, xs = x - dx;
+        float v = 0.f;
+        if (ys >= 0 && ys < sig_h && xs >= 0 && xs < sig_w)
+            v = src[((k * n_px) + (int64_t)ys * sig_w + xs) * cpm + part];
+        const int col = (int)(k * cpm + part);
+        const int g = col / GROUP, n = col % GROUP;
+        const int c = (int)(p / KC), q = (int)(p % KC);
+        img[((size_t)g * n_chunks + c) * CHUNK_FLOATS + img_index(n, q)] = v;
+    }
+}
+
+template <typename T, int NG, int ABL = 0, bool IND = false>
 __global__ void __launch_bounds__(LdsCfg<NG>::WAVES * 64)
 k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
             const float *__restrict__ img, int n_slots, float *__restrict__ out, int64_t ld_out,
-            int n_cols, int accumulate, float *__restrict__ partials, int ksplit) {
+            int n_cols, int accumulate, float *__restrict__ partials, int ksplit,
+            const int32_t *__restrict__ rows = nullptr,
+            const float *const *__restrict__ wg_img = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     using TR = InTraits<T>;
     using CFG = LdsCfg<NG>;
@@ -394,9 +423,15 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
     const int k_begin = ks * per;
     const int k_end = min(n_slots, k_begin + per);
     const int kf_end = min(k_end, n_full);
-    const float *img_t = img + (size_t)gt * n_slots * SLOT_FLOATS;
+    const float *img_t = IND ? wg_img[blockIdx.x] : img + (size_t)gt * n_slots * SLOT_FLOATS;
 
     const int64_t f_wave = (int64_t)blockIdx.x * (WAVES * V2_ROWS) + wave * V2_ROWS;
+    // frame behind row r of this wave (IND: through the row list; -1 = nothing there)
+    auto frame_of = [&](int r) -> int64_t {
+        if (IND) return rows[f_wave + r];
+        const int64_t f = f_wave + r;
+        return f < n_frames ? f : -1;
+    };
     unsigned char *a_base = lds_raw + wave * V2_ASLOT;   // + slot * (WAVES * V2_ASLOT)
     unsigned char *b_base = lds_raw + A_BYTES;           // + bslot * BSLOT
 
@@ -418,8 +453,8 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int r = 4 * t + (lane >> 4);
-            int64_t f = f_wave + r;
-            if (f > n_frames - 1) f = n_frames - 1;
+            int64_t f = frame_of(r);
+            if (f < 0) f = IND ? 0 : n_frames - 1;      // clamp: loads stay valid, result discarded
             const int piece = (lane & 15) ^ (r & 15);
             src[t] = (const unsigned char *)(tile + f * ld) + piece * 16;
         }
@@ -570,8 +605,8 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
         for (int i = 0; i < SLOT_FLOATS / 4 / NT; ++i)
             ((u32x4 *)bl)[i * NT + tid] = img_units[i * NT + tid];
         __syncthreads();
-        int64_t f = f_wave + m;
-        if (f > n_frames - 1) f = n_frames - 1;
+        int64_t f = frame_of(m);
+        if (f < 0) f = IND ? 0 : n_frames - 1;
         const T *rowp = tile + f * ld + kg * 8;
         const float *ldsb = bl + b_lane;
 #pragma unroll
@@ -599,9 +634,9 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
     for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int64_t f = f_wave + kg * 4 + r;
+            const int64_t f = frame_of(kg * 4 + r);
             const int col = (gt * NG + g) * GROUP + m;
-            if (f < n_frames && col < n_cols) {
+            if (f >= 0 && col < n_cols) {
                 float v = acc[g][0][r];
                 if (NACC == 2) v += acc[g][NACC - 1][r];
                 if (ksplit == 1) {
@@ -913,11 +948,14 @@ extern "C" int ltmi_masks_create_dense(int device, const void *masks_host, int r
     return LTMI_OK;
 }
 
+static void shift_cache_destroy(ltmi_masks *m);
+
 extern "C" int ltmi_masks_destroy(ltmi_masks *m) {
     if (!m) return LTMI_OK;
     (void)hipSetDevice(m->device);
     if (m->img) (void)hipFree(m->img);
     if (m->img2) (void)hipFree(m->img2);
+    shift_cache_destroy(m);
     if (m->partials) (void)hipFree(m->partials);
     if (m->gmasks) (void)hipFree(m->gmasks);
     if (m->csr) (void)ltmi::csr_destroy(m);
@@ -1001,7 +1039,7 @@ static int launch_lds_ng(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t
     using CFG = LdsCfg<NG>;
     const int abl = m->tune_ksplit_ring == 31 ? 2 : (m->tune_ksplit_ring == 32 ? 1 : 0);
     void (*kern)(const T *, int64_t, int64_t, int64_t, const float *, int, float *, int64_t, int,
-                 int, float *, int) =
+                 int, float *, int, const int32_t *, const float *const *) =
         abl == 2 ? k_dense_lds<T, NG, 2> : (abl == 1 ? k_dense_lds<T, NG, 1> : k_dense_lds<T, NG, 0>);
     static bool attr_set[16][3] = {{false}};
     if (!attr_set[m->device & 15][abl]) {
@@ -1032,7 +1070,7 @@ static int launch_lds_ng(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t
     dim3 grid((unsigned)gx, (unsigned)ksplit, (unsigned)gz);
     hipLaunchKernelGGL(kern, grid, dim3(CFG::WAVES * 64), CFG::LDS_BYTES, stream, tile, ld, n_frames,
                        m->n_px, img, n_slots, out, ld_out, m->n_cols, accumulate, m->partials,
-                       ksplit);
+                       ksplit, (const int32_t *)nullptr, (const float *const *)nullptr);
     LTMI_HIP(hipGetLastError());
     snprintf(m->last_kernel, sizeof(m->last_kernel), "k_dense_lds<%s,NG=%d,ring=%d%s> grid=(%u,%u,%u)",
              typeid(T).name(), NG, CFG::RING, abl ? (abl == 2 ? ",noDMA" : ",noMFMA") : "", grid.x,
@@ -1064,6 +1102,143 @@ static int launch_lds(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld
         return launch_lds_ng<T, 4>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
     }
     LTMI_FAIL(LTMI_E_DTYPE, "k_dense_lds: 1-byte pixels need a single column group");
+}
+
+// ---- shifted masks through the MFMA kernel -----------------------------------------------------------
+// Frames are grouped by their (dy, dx); every group gets the image of the stack shifted by that
+// amount (built on the device from the raw stack, cached in the handle) and whole workgroups of
+// 128 frames (row lists padded with -1).  ONE launch of k_dense_lds<.., IND> for the tile.
+struct ShiftCache {
+    std::unordered_map<uint64_t, float *> images;       // key (dy, dx) -> device image
+    size_t image_bytes = 0;
+    int sig_h = 0, sig_w = 0;
+    int32_t *rows_dev = nullptr;
+    const float **wg_img_dev = nullptr;
+    size_t rows_cap = 0, wg_cap = 0;
+    std::vector<int32_t> rows_host;
+    std::vector<const float *> wg_host;
+};
+constexpr size_t SHIFT_CACHE_BYTES = (size_t)4 << 30;   // at most 4 GiB of shifted images per handle
+
+static void shift_cache_destroy(ltmi_masks *m) {
+    ShiftCache *c = (ShiftCache *)m->shift_cache;
+    if (!c) return;
+    for (auto &kv : c->images) (void)hipFree(kv.second);
+    if (c->rows_dev) (void)hipFree(c->rows_dev);
+    if (c->wg_img_dev) (void)hipFree((void *)c->wg_img_dev);
+    delete c;
+    m->shift_cache = nullptr;
+}
+
+template <typename T>
+static int launch_lds_shifted(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, int sig_h,
+                              int sig_w, const int32_t *shifts_host, float *out, int64_t ld_out,
+                              int accumulate, hipStream_t stream, bool *handled) {
+    *handled = false;
+    using CFG = LdsCfg<1>;
+    ShiftCache *c = (ShiftCache *)m->shift_cache;
+    if (!c) {
+        c = new (std::nothrow) ShiftCache();
+        if (!c) LTMI_FAIL(LTMI_E_NOMEM, "out of host memory");
+        m->shift_cache = c;
+    }
+    const size_t img_bytes = (size_t)m->n_groups * m->n_chunks * CHUNK_FLOATS * sizeof(float);
+    if (c->sig_h != sig_h || c->sig_w != sig_w || c->image_bytes != img_bytes) {
+        for (auto &kv : c->images) (void)hipFree(kv.second);
+        c->images.clear();
+        c->sig_h = sig_h;
+        c->sig_w = sig_w;
+        c->image_bytes = img_bytes;
+    }
+    // group the frames by shift (order of first appearance)
+    std::unordered_map<uint64_t, int> group_of;
+    std::vector<uint64_t> keys;
+    std::vector<std::vector<int32_t>> members;
+    for (int64_t f = 0; f < n_frames; ++f) {
+        const uint64_t key = ((uint64_t)(uint32_t)shifts_host[2 * f] << 32) |
+                             (uint32_t)shifts_host[2 * f + 1];
+        auto it = group_of.find(key);
+        int g;
+        if (it == group_of.end()) {
+            g = (int)keys.size();
+            group_of.emplace(key, g);
+            keys.push_back(key);
+            members.emplace_back();
+        } else {
+            g = it->second;
+        }
+        members[g].push_back((int32_t)f);
+    }
+    // images: build the missing ones; give up (generic kernel) if the budget does not hold them
+    size_t missing = 0;
+    for (uint64_t key : keys) missing += c->images.count(key) ? 0 : 1;
+    if ((c->images.size() + missing) * img_bytes > SHIFT_CACHE_BYTES) {
+        if (keys.size() * img_bytes > SHIFT_CACHE_BYTES) return LTMI_OK;      // not handled
+        for (auto &kv : c->images) (void)hipFree(kv.second);                  // start over
+        c->images.clear();
+    }
+    const int cpm = (m->result_dtype == LTMI_C64) ? 2 : 1;
+    for (uint64_t key : keys) {
+        if (c->images.count(key)) continue;
+        float *img = nullptr;
+        LTMI_HIP(hipMalloc((void **)&img, img_bytes));
+        c->images.emplace(key, img);
+        LTMI_HIP(hipMemsetAsync(img, 0, img_bytes, stream));
+        const int dy = (int)(int32_t)(key >> 32), dx = (int)(int32_t)(key & 0xffffffffu);
+        const int64_t total = m->n_masks * cpm * m->n_px;
+        const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 65535 * 16);
+        hipLaunchKernelGGL(k_build_image_shifted, dim3(blocks), dim3(256), 0, stream,
+                           (const float *)m->gmasks, img, m->n_masks, cpm, sig_h, sig_w, dy, dx,
+                           m->n_chunks);
+        LTMI_HIP(hipGetLastError());
+    }
+    // row lists, padded per group to whole workgroups
+    constexpr int WG_ROWS = CFG::WAVES * V2_ROWS;
+    c->rows_host.clear();
+    c->wg_host.clear();
+    for (size_t g = 0; g < keys.size(); ++g) {
+        const float *img = c->images[keys[g]];
+        const size_t n = members[g].size();
+        const size_t n_wg = (n + WG_ROWS - 1) / WG_ROWS;
+        c->rows_host.insert(c->rows_host.end(), members[g].begin(), members[g].end());
+        c->rows_host.resize(c->rows_host.size() + (n_wg * WG_ROWS - n), -1);
+        for (size_t b = 0; b < n_wg; ++b) c->wg_host.push_back(img);
+    }
+    const size_t n_wg = c->wg_host.size();
+    if (c->rows_cap < c->rows_host.size()) {
+        if (c->rows_dev) LTMI_HIP(hipFree(c->rows_dev));
+        c->rows_dev = nullptr;
+        c->rows_cap = c->rows_host.size() * 2;
+        LTMI_HIP(hipMalloc((void **)&c->rows_dev, c->rows_cap * sizeof(int32_t)));
+    }
+    if (c->wg_cap < n_wg) {
+        if (c->wg_img_dev) LTMI_HIP(hipFree((void *)c->wg_img_dev));
+        c->wg_img_dev = nullptr;
+        c->wg_cap = n_wg * 2;
+        LTMI_HIP(hipMalloc((void **)&c->wg_img_dev, c->wg_cap * sizeof(float *)));
+    }
+    // the host vectors live in the cache until the next call: safe for an asynchronous copy
+    LTMI_HIP(hipMemcpyAsync(c->rows_dev, c->rows_host.data(), c->rows_host.size() * sizeof(int32_t),
+                            hipMemcpyHostToDevice, stream));
+    LTMI_HIP(hipMemcpyAsync((void *)c->wg_img_dev, c->wg_host.data(), n_wg * sizeof(float *),
+                            hipMemcpyHostToDevice, stream));
+    auto kern = k_dense_lds<T, 1, 0, true>;
+    static bool attr_set[16] = {false};
+    if (!attr_set[m->device & 15]) {
+        LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     CFG::LDS_BYTES));
+        attr_set[m->device & 15] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(CFG::WAVES * 64), CFG::LDS_BYTES, stream, tile,
+                       ld, n_frames, m->n_px, (const float *)nullptr, m->n_chunks, out, ld_out,
+                       m->n_cols, accumulate, (float *)nullptr, 1, (const int32_t *)c->rows_dev,
+                       (const float *const *)c->wg_img_dev);
+    LTMI_HIP(hipGetLastError());
+    snprintf(m->last_kernel, sizeof(m->last_kernel),
+             "k_dense_lds<%s,NG=1,shifted> grid=(%zu,1,1) shift groups=%zu", typeid(T).name(), n_wg,
+             keys.size());
+    *handled = true;
+    return LTMI_OK;
 }
 
 template <typename T>
@@ -1266,3 +1441,61 @@ extern "C" int ltmi_apply_masks_shifted(ltmi_masks *m, const void *tile, int til
     g_shift.shifts = nullptr;
     return rc;
 }
+
+extern "C" int ltmi_apply_masks_shifted_host(ltmi_masks *m, const void *tile, int tile_dtype,
+                                             int64_t n_frames, int64_t ld_tile, int sig_h,
+                                             int sig_w, const int32_t *shifts_host, void *out,
+                                             int64_t ld_out, int accumulate, void *stream_) {
+    if (!m) LTMI_FAIL(LTMI_E_INVALID, "ltmi_apply_masks_shifted_host: null handle");
+    if (m->kind == 2 || !m->gmasks)
+        LTMI_FAIL(LTMI_E_INVALID, "ltmi_apply_masks_shifted_host: needs a dense mask handle");
+    if (sig_h <= 0 || sig_w <= 0 || (int64_t)sig_h * sig_w != m->n_px)
+        LTMI_FAIL(LTMI_E_SHAPE, "ltmi_apply_masks_shifted_host: sig shape (%d, %d) does not match "
+                  "n_px=%lld", sig_h, sig_w, (long long)m->n_px);
+    if (n_frames < 0 || ld_tile < m->n_px || ld_out < m->n_masks)
+        LTMI_FAIL(LTMI_E_SHAPE, "ltmi_apply_masks_shifted_host: bad leading dimensions");
+    if (dtype_size(tile_dtype) == 0)
+        LTMI_FAIL(LTMI_E_DTYPE, "ltmi_apply_masks_shifted_host: unknown tile dtype %d", tile_dtype);
+    if (n_frames == 0) return LTMI_OK;
+    if (!tile || !out || !shifts_host)
+        LTMI_FAIL(LTMI_E_INVALID, "ltmi_apply_masks_shifted_host: null pointer");
+    LTMI_HIP(hipSetDevice(m->device));
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t esz = (size_t)dtype_size(tile_dtype);
+    const bool aligned = (((uintptr_t)tile) % 16 == 0) && ((ld_tile * (int64_t)esz) % 16 == 0);
+    if (m->kind == 0 && m->n_groups == 1 && aligned && m->n_px >= KC && n_frames < (1ll << 31)) {
+        bool handled = false;
+        int rc = LTMI_OK;
+        const int64_t ldo = (m->result_dtype == LTMI_C64) ? 2 * ld_out : ld_out;
+        switch (tile_dtype) {
+            case LTMI_U8: rc = launch_lds_shifted<uint8_t>(m, (const uint8_t *)tile, n_frames, ld_tile, sig_h, sig_w, shifts_host, (float *)out, ldo, accumulate, stream, &handled); break;
+            case LTMI_I8: rc = launch_lds_shifted<int8_t>(m, (const int8_t *)tile, n_frames, ld_tile, sig_h, sig_w, shifts_host, (float *)out, ldo, accumulate, stream, &handled); break;
+            case LTMI_U16: rc = launch_lds_shifted<uint16_t>(m, (const uint16_t *)tile, n_frames, ld_tile, sig_h, sig_w, shifts_host, (float *)out, ldo, accumulate, stream, &handled); break;
+            case LTMI_I16: rc = launch_lds_shifted<int16_t>(m, (const int16_t *)tile, n_frames, ld_tile, sig_h, sig_w, shifts_host, (float *)out, ldo, accumulate, stream, &handled); break;
+            case LTMI_F32: rc = launch_lds_shifted<float>(m, (const float *)tile, n_frames, ld_tile, sig_h, sig_w, shifts_host, (float *)out, ldo, accumulate, stream, &handled); break;
+            default: break;
+        }
+        if (rc != LTMI_OK) return rc;
+        if (handled) return LTMI_OK;
+    }
+    // everything else: per-frame kernel with the shifts uploaded to the handle's scratch
+    ShiftCache *c = (ShiftCache *)m->shift_cache;
+    if (!c) {
+        c = new (std::nothrow) ShiftCache();
+        if (!c) LTMI_FAIL(LTMI_E_NOMEM, "out of host memory");
+        m->shift_cache = c;
+    }
+    const size_t need = (size_t)n_frames * 2;
+    if (c->rows_cap < need) {
+        if (c->rows_dev) LTMI_HIP(hipFree(c->rows_dev));
+        c->rows_dev = nullptr;
+        c->rows_cap = need * 2;
+        LTMI_HIP(hipMalloc((void **)&c->rows_dev, c->rows_cap * sizeof(int32_t)));
+    }
+    c->rows_host.assign(shifts_host, shifts_host + need);
+    LTMI_HIP(hipMemcpyAsync(c->rows_dev, c->rows_host.data(), need * sizeof(int32_t),
+                            hipMemcpyHostToDevice, stream));
+    return ltmi_apply_masks_shifted(m, tile, tile_dtype, n_frames, ld_tile, sig_h, sig_w, c->rows_dev,
+                                    out, ld_out, accumulate, stream_);
+}
+

@@ -27,7 +27,7 @@ _DTYPES = {
 EXPORTS = (
     'ltmi_version', 'ltmi_last_error', 'ltmi_device_count', 'ltmi_device_info',
     'ltmi_masks_create_dense', 'ltmi_masks_create_csr', 'ltmi_masks_destroy', 'ltmi_masks_kind',
-    'ltmi_apply_masks', 'ltmi_apply_masks_shifted', 'ltmi_sum_frames_workspace', 'ltmi_sum_frames', 'ltmi_sum_sig',
+    'ltmi_apply_masks', 'ltmi_apply_masks_shifted', 'ltmi_apply_masks_shifted_host', 'ltmi_sum_frames_workspace', 'ltmi_sum_frames', 'ltmi_sum_sig',
     'ltmi_axpy', 'ltmi_correct', 'ltmi_repair_pixels', 'ltmi_fft_plan_create',
     'ltmi_fft_plan_destroy', 'ltmi_crystallinity', 'ltmi_masks_set_tuning',
     'ltmi_masks_last_kernel',
@@ -101,6 +101,7 @@ def lib():
         L.ltmi_masks_kind.argtypes = [vp, c.POINTER(i32)]
         L.ltmi_apply_masks.argtypes = [vp, vp, i32, i64, i64, vp, i64, i32, vp]
         L.ltmi_apply_masks_shifted.argtypes = [vp, vp, i32, i64, i64, i32, i32, vp, vp, i64, i32, vp]
+        L.ltmi_apply_masks_shifted_host.argtypes = [vp, vp, i32, i64, i64, i32, i32, vp, vp, i64, i32, vp]
         L.ltmi_sum_frames_workspace.argtypes = [i64, i64, i32]
         L.ltmi_sum_frames_workspace.restype = i64
         L.ltmi_sum_frames.argtypes = [i32, vp, i32, i64, i64, i64, vp, i32, i32, vp, vp]
@@ -239,6 +240,18 @@ class MaskHandle:
             self._ptr, ctypes.c_void_p(tile_ptr), dtype_code(tile_dtype), n_frames, ld_tile,
             int(sig_h), int(sig_w), ctypes.c_void_p(shifts_ptr), ctypes.c_void_p(out_ptr), ld_out,
             1 if accumulate else 0, _stream_ptr(stream)), 'ltmi_apply_masks_shifted')
+
+    def apply_shifted_host(self, tile_ptr, tile_dtype, n_frames, ld_tile, sig_h, sig_w, shifts,
+                           out_ptr, ld_out, accumulate, stream=None):
+        """shifts: host int32 array (n_frames, 2) of (dy, dx), C-contiguous."""
+        shifts = np.ascontiguousarray(shifts, dtype=np.int32)
+        if shifts.shape != (n_frames, 2):
+            raise ValueError(f"shifts must have shape ({n_frames}, 2), got {shifts.shape}")
+        check(lib().ltmi_apply_masks_shifted_host(
+            self._ptr, ctypes.c_void_p(tile_ptr), dtype_code(tile_dtype), n_frames, ld_tile,
+            int(sig_h), int(sig_w), shifts.ctypes.data_as(ctypes.c_void_p),
+            ctypes.c_void_p(out_ptr), ld_out, 1 if accumulate else 0, _stream_ptr(stream)),
+            'ltmi_apply_masks_shifted_host')
 
     def close(self):
         if self._ptr is not None and self._ptr.value:

@@ -203,11 +203,8 @@ class ApplyMasksEngine:
         n = tile.shape[0]
         shifts = np.ascontiguousarray(np.asarray(shifts).reshape((n, 2)).astype(np.int32))
         handle = self._get_handle()
-        dev_shifts = torch.from_numpy(shifts).to(f'cuda:{tile.device}', non_blocking=False)
-        handle.apply_shifted(tile.data_ptr(), tile.dtype, n, tile.ld, sig[0], sig[1],
-                             dev_shifts.data_ptr(), out.data_ptr(), out.ld, accumulate,
-                             stream=self.stream_ptr)
-        self._keep = dev_shifts          # keep alive until the stream has consumed it
+        handle.apply_shifted_host(tile.data_ptr(), tile.dtype, n, tile.ld, sig[0], sig[1], shifts,
+                                  out.data_ptr(), out.ld, accumulate, stream=self.stream_ptr)
         return out
 
 

@@ -369,3 +369,80 @@ def test_sell_ring_stack_vs_oracle(hip):
     assert np.allclose(res[:8], ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
     ref64 = data.astype(np.float64) @ rings.T.astype(np.float64)
     assert np.allclose(res, np.asarray(ref64), rtol=1e-5, atol=1e-5 * np.abs(ref64).max())
+
+
+# ---- shifted masks ------------------------------------------------------------------------------------
+def _shift_ref(data3d, masks3d, shifts):
+    """out[f, k] = sum over the overlap of frame[f][y, x] * mask_k[y - dy, x - dx] in float64
+    (reference udf/masks.py:85-124 semantics)."""
+    n, h, w = data3d.shape
+    out = np.zeros((n, len(masks3d)), dtype=np.complex128 if np.iscomplexobj(masks3d) else np.float64)
+    scale = np.zeros((n, len(masks3d)))
+    for f in range(n):
+        dy, dx = int(shifts[f, 0]), int(shifts[f, 1])
+        shifted = np.zeros_like(masks3d)
+        ys0, ys1 = max(0, dy), min(h, h + dy)
+        xs0, xs1 = max(0, dx), min(w, w + dx)
+        if ys0 < ys1 and xs0 < xs1:
+            shifted[:, ys0:ys1, xs0:xs1] = masks3d[:, ys0 - dy:ys1 - dy, xs0 - dx:xs1 - dx]
+        fr = data3d[f].astype(np.float64)
+        out[f] = np.tensordot(shifted.astype(out.dtype), fr, axes=([1, 2], [0, 1]))
+        scale[f] = np.tensordot(np.abs(shifted).astype(np.float64), np.abs(fr), axes=([1, 2], [0, 1]))
+    return out, scale
+
+
+@pytest.mark.parametrize('tile_dtype,sig,n_masks,mask_dtype,expect', [
+    ('uint16', (40, 48), 5, 'float32', 'k_dense_lds'),       # MFMA path, many shift groups
+    ('float32', (32, 32), 16, 'float32', 'k_dense_lds'),
+    ('uint8', (32, 64), 3, 'complex64', 'k_dense_lds'),
+    ('uint16', (17, 23), 4, 'float32', 'k_dense_shifted'),   # unaligned rows -> per-frame kernel
+    ('uint16', (32, 32), 20, 'float32', 'k_dense_shifted'),  # two column groups -> per-frame kernel
+    ('int32', (16, 32), 2, 'float64', 'k_dense_shifted'),    # float64 result -> generic
+])
+def test_shifted_masks_host_shifts(hip, tile_dtype, sig, n_masks, mask_dtype, expect):
+    rng = np.random.default_rng(hash((tile_dtype, sig, n_masks)) % (2**32))
+    n = 300
+    dt = np.dtype(tile_dtype)
+    if dt.kind in 'ui':
+        data = rng.integers(0, 200 if dt.itemsize == 1 else 3000, (n,) + sig).astype(dt)
+    else:
+        data = (rng.random((n,) + sig) - 0.3).astype(dt)
+    md = np.dtype(mask_dtype)
+    masks = (rng.random((n_masks,) + sig) - 0.25)
+    if md.kind == 'c':
+        masks = masks + 1j * (rng.random((n_masks,) + sig) - 0.5)
+    masks = masks.astype(md)
+    shifts = rng.integers(-5, 6, (n, 2)).astype(np.int32)
+    shifts[7] = (sig[0] + 3, 0)                  # no overlap at all
+    shifts[8] = (0, -(sig[1] - 1))               # one column of overlap
+    rd = np.result_type(np.float32, dt, md)
+    h = hip.MaskHandle.dense(0, masks.reshape((n_masks, -1)), rd)
+    t = _dev(np.ascontiguousarray(data.reshape((n, -1))))
+    base = rng.random((n, n_masks)).astype(rd)
+    for acc in (False, True):
+        out = _dev(base.copy() if acc else np.full((n, n_masks), 7, dtype=rd))
+        h.apply_shifted_host(t.data_ptr(), dt, n, data[0].size, sig[0], sig[1], shifts,
+                             out.data_ptr(), n_masks, acc)
+        torch.cuda.synchronize()
+        res = out.cpu().numpy()
+        if res.dtype != rd:
+            res = res.view(rd)
+        assert expect in h.last_kernel(), h.last_kernel()
+        ref, scale = _shift_ref(data, masks, shifts)
+        if acc:
+            ref = ref + base
+        tol = 1e-5 if rd in (np.float32, np.complex64) else 1e-12
+        assert np.all(np.abs(res - ref) <= tol * (scale + 1)), np.abs(res - ref).max()
+    # a second call re-uses the cached shifted images and handles a different grouping
+    shifts2 = np.roll(shifts, 11, axis=0)
+    out = _dev(np.zeros((n, n_masks), dtype=rd))
+    h.apply_shifted_host(t.data_ptr(), dt, n, data[0].size, sig[0], sig[1], shifts2, out.data_ptr(),
+                         n_masks, False)
+    torch.cuda.synchronize()
+    res = out.cpu().numpy()
+    if res.dtype != rd:
+        res = res.view(rd)
+    ref, scale = _shift_ref(data, masks, shifts2)
+    assert np.all(np.abs(res - ref) <= (1e-5 if rd in (np.float32, np.complex64) else 1e-12)
+                  * (scale + 1))
+    h.close()
