@@ -12,7 +12,7 @@ dataset (planning + kernels + device-side merge + [N>1: RCCL all-gather of the n
 one D2H of the result), i.e. the whole hot path, not just the kernel.  Weak scaling: every rank
 holds its own 256x256-scan shard (65536 frames, 8 GiB); the nav grid of the job is N x that.
 
-Rank 0 prints ONE JSON line.  `roofline` is the dominant kernel (k_dense_mfma) timed with HIP
+Rank 0 prints ONE JSON line.  `roofline` is the dominant kernel (k_dense_lds) timed with HIP
 events on its own stream inside the timed region; `cpu_baseline` is the oracle (the CPU
 restatement of the reference path) timed on this box's host cores on a bounded sample.
 """
@@ -185,12 +185,15 @@ def main():
     if rank == 0:
         total_frames = n_frames * world * args.steps
         value = total_frames / elapsed_max
-        kms = [ms for ms, n, k in kernel_events if 'k_dense_mfma' in k]
-        kname = next((k for ms, n, k in kernel_events if 'k_dense_mfma' in k), '')
+        kms = [ms for ms, n, k in kernel_events if 'k_dense' in k]
+        kname = next((k for ms, n, k in kernel_events if 'k_dense' in k), '')
         alg_bytes_per_frame = n_px * itemsize + cfg['n_masks'] * 4
         launches_per_step = max(1, len(kms) // max(1, args.steps))
         frames_per_launch = n_frames / launches_per_step
-        avg_ms = float(np.mean(kms)) if kms else float('nan')
+        if not kms:
+            raise SystemExit("bench.py: no ltmi_apply_masks launch was timed -- kernel name filter "
+                             "out of date? events: %r" % (kernel_events[:3],))
+        avg_ms = float(np.mean(kms))
         achieved = alg_bytes_per_frame * frames_per_launch / (avg_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC passes (FETCH_SIZE x 1024 x 2 [gfx950 read correction]
         # + WRITE_SIZE x 1024); cannot be collected from inside the timed process, so the
