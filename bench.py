@@ -125,6 +125,8 @@ def main():
         os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
+    import logging
+    logging.getLogger('libertem_amd').setLevel(logging.ERROR)     # stdout carries ONE JSON line
     from libertem_amd.api import Context
     from libertem_amd.udf.masks import ApplyMasksUDF
     from libertem_amd import hip
