@@ -1,5 +1,5 @@
 """BASELINE.json configs C1/C3/C4/C5 through the public API (Context.run / run_udf) on one MI355X,
-device-resident frames, plus a spot check of a few frames against the oracle.
+device-resident frames, plus a spot check of a few frames against float64 NumPy.
 
     python scripts/bench_configs.py c3 [--scan 512] [--reps 5]
 """
