@@ -220,8 +220,18 @@ class CoMUDF(UDF):
             _COM_CONTAINERS[key] = container
             while len(_COM_CONTAINERS) > 4:
                 _COM_CONTAINERS.pop(next(iter(_COM_CONTAINERS))).close()
-        return {'com_params': cp,
-                'engine': ApplyMasksEngine(masks=container, meta=self.meta, use_torch=True)}
+        engine = ApplyMasksEngine(masks=container, meta=self.meta, use_torch=True)
+        if getattr(self.meta, 'corrections_folded', False):
+            # detector corrections absorbed by the three masks (udf/masks.py): raw frames are read
+            from libertem_amd.udf.masks import _folded_plan
+            folded, plan_state = _folded_plan(self.meta.corrections, container,
+                                              container.mask_factories, sig_shape, 3)
+            engine.fold(folded, plan_state)
+        return {'com_params': cp, 'engine': engine}
+
+    def folds_corrections(self, corrections, meta):
+        import libertem_amd.udf.masks as um
+        return bool(um.FOLD_CORRECTIONS)
 
     def process_tile(self, tile):
         self.task_data.engine.process_tile(tile, out=self.results.raw_mask_result,

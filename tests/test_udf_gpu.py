@@ -605,3 +605,43 @@ def test_crystallinity_roi_batches_and_analysis(ctx):
     mask = 1 - 1 * (yy * yy + xx * xx <= 16)
     expect = np.log(abs(np.fft.fftshift(np.fft.fft2(total * mask))) + 1)
     assert np.allclose(sf.intensity_fft.raw_data, expect, rtol=1e-4, atol=1e-4)
+
+
+def test_com_with_corrections_folded_and_generic(ctx):
+    """CoMUDF under CorrectionSet: the folded path (raw frames, corrected masks) and the generic
+    path (corrected frames) agree with the oracle's CoM of oracle-corrected frames."""
+    import libertem_amd.udf.masks as um
+    from libertem_amd.io.corrections import CorrectionSet
+    from libertem_amd.udf.com import CoMUDF
+    from oracle import corrections as oc
+    rng = np.random.default_rng(31)
+    data = rng.integers(0, 2000, (6, 7, 32, 32)).astype(np.uint16)
+    yy, xx = np.mgrid[0:32, 0:32]
+    data = (data * np.exp(-((yy - 15) ** 2 + (xx - 17) ** 2) / 60.0)).astype(np.uint16)
+    dark = rng.random((32, 32)) * 3
+    gain = rng.random((32, 32)) * 0.4 + 0.8
+    bad = np.zeros((32, 32), dtype=bool)
+    bad[14, 16] = bad[3, 3] = bad[20, 21] = True
+    corr = CorrectionSet(dark=dark, gain=gain, excluded_pixels=bad)
+    coords = [tuple(c) for c in np.argwhere(bad)]
+    corrected = oc.correct(data, (32, 32), dark=dark, gain=gain, coords=coords)
+    ref = opath.com_udf(corrected, num_partitions=2, cy=15., cx=17., r=12.)
+    ds = _device_ds(ctx, data, 2)
+    udf = CoMUDF.with_params(cy=15., cx=17., r=12.)
+    out = {}
+    for fold in (True, False):
+        um.FOLD_CORRECTIONS = fold
+        try:
+            res = ctx.run_udf(dataset=ds, udf=udf, corrections=corr)
+        finally:
+            um.FOLD_CORRECTIONS = True
+        out[fold] = res
+        # shifts = com - centre: small differences of numbers ~ the centre coordinates, so the
+        # float32 tolerance is relative to |raw_com|, as for the reference's own float32 path
+        atol = 2e-5 * np.abs(ref['raw_com']).max()
+        for name in ('raw_com', 'raw_shifts', 'field', 'magnitude'):
+            got = res[name].data
+            assert np.allclose(got, ref[name], rtol=2e-5, atol=atol), \
+                (fold, name, np.abs(got - ref[name]).max())
+    assert np.allclose(out[True]['field'].data, out[False]['field'].data, rtol=2e-5,
+                       atol=2e-5 * np.abs(ref['raw_com']).max())
