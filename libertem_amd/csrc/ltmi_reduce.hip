@@ -243,28 +243,48 @@ extern "C" int ltmi_sum_frames(int device, const void *tile, int tile_dtype, int
 // out[f, p] = ((double)tile[f, p] - dark[p]) * gain[p], rounded once to the output type: a float32
 // buffer corrected with float64 dark / gain arrays is computed in float64 by the reference's loop too.
 // One thread owns 4 consecutive pixels (dark / gain live in registers) and walks a slab of frames.
-template <typename TIn, typename TOut>
+template <typename TIn, typename TOut, bool VEC>
 __global__ void __launch_bounds__(256)
 k_correct(const TIn *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
           const double *__restrict__ dark, const double *__restrict__ gain, TOut *__restrict__ out,
           int64_t ld_out, int frames_per_block) {
-    const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    constexpr int PX = VEC ? 8 : 4;                     // pixels per thread
+    const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * PX;
     if (p0 >= n_px) return;
-    const int np = (int)min<int64_t>(4, n_px - p0);
-    double d[4], g[4];
+    const int np = (int)min<int64_t>(PX, n_px - p0);
+    double d[PX], g[PX];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < PX; ++j) {
         d[j] = (dark && j < np) ? dark[p0 + j] : 0.0;
         g[j] = (gain && j < np) ? gain[p0 + j] : 1.0;
     }
     const int64_t f0 = (int64_t)blockIdx.y * frames_per_block;
     const int64_t f1 = min<int64_t>(n_frames, f0 + frames_per_block);
-    for (int64_t f = f0; f < f1; ++f) {
-        const TIn *src = tile + f * ld + p0;
-        TOut *dst = out + f * ld_out + p0;
+    if (VEC) {
+        // whole 8-pixel units, 16-B aligned rows: one vector load, two/four vector stores per frame
+        typedef TIn __attribute__((ext_vector_type(8))) vin_t;
+        typedef TOut __attribute__((ext_vector_type(4))) vout_t;
+#pragma unroll 4
+        for (int64_t f = f0; f < f1; ++f) {
+            const vin_t x = __builtin_nontemporal_load((const vin_t *)(tile + f * ld + p0));
+            vout_t lo, hi;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (j < np) dst[j] = (TOut)(((double)src[j] - d[j]) * g[j]);
+            for (int j = 0; j < 4; ++j) {
+                lo[j] = (TOut)(((double)x[j] - d[j]) * g[j]);
+                hi[j] = (TOut)(((double)x[j + 4] - d[j + 4]) * g[j + 4]);
+            }
+            TOut *dst = out + f * ld_out + p0;
+            *(vout_t *)dst = lo;
+            *(vout_t *)(dst + 4) = hi;
+        }
+    } else {
+        for (int64_t f = f0; f < f1; ++f) {
+            const TIn *src = tile + f * ld + p0;
+            TOut *dst = out + f * ld_out + p0;
+#pragma unroll
+            for (int j = 0; j < PX; ++j)
+                if (j < np) dst[j] = (TOut)(((double)src[j] - d[j]) * g[j]);
+        }
     }
 }
 
@@ -291,14 +311,23 @@ template <typename TIn, typename TOut>
 static int run_correct(const void *tile, int64_t n_frames, int64_t n_px, int64_t ld,
                        const double *dark, const double *gain, void *out, int64_t ld_out,
                        hipStream_t stream) {
-    const int64_t gx = (n_px + 1023) / 1024;
-    // enough blocks to fill the chip, frames slabs of at least 16
+    const bool vec = (n_px % 8 == 0) && ((uintptr_t)tile % (8 * sizeof(TIn)) == 0) &&
+                     (ld % 8 == 0) && ((uintptr_t)out % (4 * sizeof(TOut)) == 0) && (ld_out % 4 == 0);
+    const int px = vec ? 8 : 4;
+    const int64_t gx = (n_px + 256 * px - 1) / (256 * px);
+    // enough blocks to fill the chip, frame slabs of at least 16
     int64_t gy = std::max<int64_t>(1, std::min<int64_t>((n_frames + 15) / 16, (4096 + gx - 1) / gx));
     gy = std::min<int64_t>(gy, 65535);
     const int fpb = (int)((n_frames + gy - 1) / gy);
     gy = (n_frames + fpb - 1) / fpb;
-    hipLaunchKernelGGL((k_correct<TIn, TOut>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, stream,
-                       (const TIn *)tile, ld, n_frames, n_px, dark, gain, (TOut *)out, ld_out, fpb);
+    if (vec)
+        hipLaunchKernelGGL((k_correct<TIn, TOut, true>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0,
+                           stream, (const TIn *)tile, ld, n_frames, n_px, dark, gain, (TOut *)out,
+                           ld_out, fpb);
+    else
+        hipLaunchKernelGGL((k_correct<TIn, TOut, false>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0,
+                           stream, (const TIn *)tile, ld, n_frames, n_px, dark, gain, (TOut *)out,
+                           ld_out, fpb);
     LTMI_HIP(hipGetLastError());
     return LTMI_OK;
 }
