@@ -174,6 +174,17 @@ class HipJobExecutor(JobExecutor):
         Consume (part_results, task) pairs of THIS rank, merge, combine across ranks and leave the
         complete result in every udf.results (host buffers) and `damage`.
         """
+        for _ in self._merge(udfs, damage, result_iter, partial=False):
+            pass
+
+    def merge_results_iter(self, udfs, damage, result_iter, apply_part_result):
+        """Generator form for `run_udf_iter` (reference udf/base.py:2657-2733): yields after every
+        merged partition with the current state published to the host buffers (one D2H per
+        buffer and partition -- opt-in cost of watching partial results).  With several ranks the
+        partial state of one rank is not a result, so it yields once, after the collectives."""
+        yield from self._merge(udfs, damage, result_iter, partial=not self._collectives_on)
+
+    def _merge(self, udfs, damage, result_iter, partial):
         plans = []
         for udf in udfs:
             decl = getattr(udf, 'get_dist_merge', lambda: None)()
@@ -187,27 +198,17 @@ class HipJobExecutor(JobExecutor):
                 plans.append(('generic', None))
 
         dev_full = [dict() for _ in udfs]       # per udf: name -> torch tensor (full size)
-        generic_parts = []                      # (task idx, [exported results of generic udfs])
+        generic_parts = []                      # (task, {udf idx: exported results})
         torch = None
         if self.gpu_id is not None:
             import torch
-
-        for part_results, task in result_iter:
-            gen_entry = {}
-            for i, (udf, results, (mode, decl)) in enumerate(zip(udfs, part_results, plans)):
-                if mode == 'device':
-                    self._merge_on_device(udf, results, task, decl, dev_full[i])
-                else:
-                    results.export()
-                    gen_entry[i] = results
-            if gen_entry:
-                generic_parts.append((task, gen_entry))
-            damage.get_view_for_partition(task.partition)[:] = True
-
         d = self._dist()
-        # ---- declared buffers: collectives on flat tensors ----
-        for i, (udf, (mode, decl)) in enumerate(zip(udfs, plans)):
-            if mode == 'device':
+
+        def publish_device(final):
+            """declared device buffers -> host arrays of the main-process udfs"""
+            for i, (udf, (mode, decl)) in enumerate(zip(udfs, plans)):
+                if mode != 'device':
+                    continue
                 for name, how in decl.items():
                     buf = udf.results.get_buffer(name)
                     if isinstance(buf, PlaceholderBufferWrapper):
@@ -217,14 +218,46 @@ class HipJobExecutor(JobExecutor):
                     if full is None:
                         full = torch.zeros(buf.shape, dtype=torch_dtype_for(buf.dtype),
                                            device=f'cuda:{self.gpu_id}')
-                    if self._collectives_on:
+                    if final and self._collectives_on:
                         # collectives are ordered after the kernels of the executor stream
                         full = self._combine(d, full, how)
                     host = self._to_host(full)
                     if host.dtype != buf.dtype:
                         host = host.view(buf.dtype)
                     buf.replace_array(host)
-            elif mode == 'host-declared':
+
+        n_done = 0
+        for part_results, task in result_iter:
+            gen_entry = {}
+            for i, (udf, results, (mode, decl)) in enumerate(zip(udfs, part_results, plans)):
+                if mode == 'device':
+                    self._merge_on_device(udf, results, task, decl, dev_full[i],
+                                          may_adopt=not partial)
+                else:
+                    results.export()
+                    gen_entry[i] = results
+            damage.get_view_for_partition(task.partition)[:] = True
+            n_done += 1
+            if partial:
+                # merge the host-side UDFs right away (tasks arrive in partition order here)
+                for i, results in gen_entry.items():
+                    self._apply_one(udfs[i], results, task)
+                publish_device(final=False)
+                yield n_done
+            elif gen_entry:
+                generic_parts.append((task, gen_entry))
+        if partial:
+            if n_done == 0:
+                publish_device(final=True)
+                yield 0
+            if self._stream is not None:
+                self._stream.synchronize()
+            return
+
+        # ---- declared buffers: collectives on flat tensors ----
+        publish_device(final=True)
+        for i, (udf, (mode, decl)) in enumerate(zip(udfs, plans)):
+            if mode == 'host-declared':
                 # CPU rank (gloo tests / NumPy UDFs that declare their merge): merge locally with
                 # the UDF's own merge(), then combine the full-size host buffers
                 for task, entry in generic_parts:
@@ -262,6 +295,7 @@ class HipJobExecutor(JobExecutor):
                 damage.get_view_for_partition(task.partition)[:] = True
         if self._stream is not None:
             self._stream.synchronize()
+        yield n_done
 
     def _to_host(self, t):
         """ONE D2H per buffer and run into page-locked memory, on the executor stream.  A fresh
@@ -280,7 +314,7 @@ class HipJobExecutor(JobExecutor):
         udf.merge(dest=udf.results.get_proxy(), src=results.get_proxy())
         udf.clear_views()
 
-    def _merge_on_device(self, udf, results, task, decl, full):
+    def _merge_on_device(self, udf, results, task, decl, full, may_adopt=True):
         import torch
         self._make_current()
         if True:
@@ -293,7 +327,8 @@ class HipJobExecutor(JobExecutor):
                     part = HipArray.from_numpy(np.asarray(part), self.gpu_id)
                 pt = part.torch.reshape(part.shape)
                 if name not in full:
-                    if how == 'disjoint' and tuple(part.shape) == tuple(buf_main.shape):
+                    if may_adopt and how == 'disjoint' and \
+                            tuple(part.shape) == tuple(buf_main.shape):
                         # one partition covers the whole buffer: adopt it, no zero-fill, no copy
                         full[name] = pt
                         continue

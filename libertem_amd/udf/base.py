@@ -954,7 +954,11 @@ class UDFRunner:
                 try:
                     # hook for executors that merge on the device / across ranks
                     result_iter = executor.run_tasks(tasks, params_handle, cancel_id)
-                    if hasattr(executor, 'merge_results'):
+                    if iterate and hasattr(executor, 'merge_results_iter'):
+                        for _ in executor.merge_results_iter(self._udfs, damage, result_iter,
+                                                             self._apply_part_result):
+                            yield self._make_udf_result(self._udfs, damage)
+                    elif hasattr(executor, 'merge_results'):
                         executor.merge_results(self._udfs, damage, result_iter,
                                                self._apply_part_result)
                         if iterate:

@@ -645,3 +645,25 @@ def test_com_with_corrections_folded_and_generic(ctx):
                 (fold, name, np.abs(got - ref[name]).max())
     assert np.allclose(out[True]['field'].data, out[False]['field'].data, rtol=2e-5,
                        atol=2e-5 * np.abs(ref['raw_com']).max())
+
+
+def test_run_udf_iter_partial_results_on_device(ctx):
+    """run_udf_iter on the HIP executor: one partial result per merged partition, damage grows,
+    the valid rows of every partial result are already final (reference api.py:1053-1152)."""
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd.udf.sum import SumUDF
+    rng = np.random.default_rng(3)
+    data = rng.integers(0, 500, (8, 6, 32, 32)).astype(np.uint16)
+    masks = rng.random((3, 32, 32)).astype(np.float32)
+    ds = _device_ds(ctx, data, 4)
+    udfs = [ApplyMasksUDF(mask_factories=lambda: masks, use_sparse=False), SumUDF()]
+    final = ctx.run_udf(dataset=ds, udf=udfs)
+    seen = []
+    for part in ctx.run_udf_iter(dataset=ds, udf=udfs):
+        dmg = np.array(part.damage.data)
+        seen.append(int(dmg.sum()))
+        inten = part.buffers[0]['intensity'].data
+        assert np.array_equal(inten[dmg], final[0]['intensity'].data[dmg])
+        assert np.all(inten[~dmg] == 0)
+    assert seen == [12, 24, 36, 48]
+    assert np.allclose(part.buffers[1]['intensity'].data, final[1]['intensity'].data, rtol=1e-6)
