@@ -30,7 +30,38 @@ class SumUDF(UDF):
         return (self.BACKEND_HIP,)
 
     def get_result_buffers(self):
-        return {'intensity': self.buffer(kind='sig', dtype=self.meta.input_dtype, where='device')}
+        return {
+            'intensity': self.buffer(kind='sig', dtype=self.meta.input_dtype, where='device'),
+            # number of RAW frames in `intensity` when detector corrections are folded (see
+            # folds_corrections); 0 if the tiles arrived corrected
+            'n_raw': self.buffer(kind='single', dtype='float64', use='private'),
+        }
+
+    def folds_corrections(self, corrections, meta):
+        """The correction is linear and identical for every frame, so it commutes with the sum:
+        sum_f corrected(x_f) = repair((sum_f x_f - N dark) * gain).  The frames are summed raw (one
+        pass over the native data) and the single summed image is corrected in get_results."""
+        import libertem_amd.udf.masks as um
+        return bool(um.FOLD_CORRECTIONS) and np.dtype(meta.input_dtype).kind == 'f'
+
+    def get_results(self):
+        img = self.results.intensity
+        n = float(np.asarray(self.results.n_raw).reshape(-1)[0])
+        corr = self.meta.corrections if self.meta is not None else None
+        if n > 0 and corr is not None and corr.have_corrections():
+            sig = tuple(img.shape)
+            work = np.asarray(img, dtype=np.float64).reshape(-1).copy()
+            dark, gain = corr.get_dark_frame(), corr.get_gain_map()
+            if dark is not None:
+                work -= n * np.asarray(dark, dtype=np.float64).reshape(-1)
+            if gain is not None:
+                work *= np.asarray(gain, dtype=np.float64).reshape(-1)
+            desc = corr.full_frame_descriptor(sig)
+            for e, env, c in zip(desc.exclude_flat, desc.repair_flat, desc.repair_counts):
+                if c > 0:
+                    work[e] = work[env[:c]].sum() / c
+            img = work.reshape(sig).astype(img.dtype)
+        return {'intensity': img}
 
     def get_task_data(self):
         if self.meta.array_backend != self.BACKEND_HIP:
@@ -63,6 +94,8 @@ class SumUDF(UDF):
         s_shape = tuple(view.tile_slice.shape.sig)
         n_px = prod(s_shape)
         device = tile.device
+        if getattr(self.meta, 'corrections_folded', False) and self.meta.tiling_scheme_idx == 0:
+            self.results.n_raw[:] += n                  # once per group of frames (first sig slice)
         ws = self._workspace(device, hip.sum_frames_workspace(n, n_px, odt))
         whole_rows = s_shape[1:] == sig_full[1:] and all(o == 0 for o in s_origin[1:])
         if whole_rows:
@@ -80,10 +113,12 @@ class SumUDF(UDF):
 
     def merge(self, dest, src):
         dest.intensity[:] += src.intensity                     # udf/sum.py:50-52
+        dest.n_raw[:] += src.n_raw
 
     def merge_all(self, ordered_results):
         chunks = [b.intensity for b in ordered_results.values()]
-        return {'intensity': np.stack(chunks, axis=0).sum(axis=0)}
+        return {'intensity': np.stack(chunks, axis=0).sum(axis=0),
+                'n_raw': np.sum([b.n_raw for b in ordered_results.values()], axis=0)}
 
     def get_dist_merge(self):
-        return {'intensity': 'sum'}
+        return {'intensity': 'sum', 'n_raw': 'sum'}
