@@ -63,6 +63,8 @@ struct ltmi_masks {
     float *img = nullptr;
     float *img2 = nullptr;   // slot-major image for k_dense_lds with ng > 1 (KB = 128)
     int n_slots2 = 0;
+    float *img3 = nullptr;   // 3 groups + ne3 VALU columns (49..52 columns), 32-KiB slots of 128 px
+    int n_slots3 = 0, ne3 = 0;
     void *shift_cache = nullptr;   // ltmi_dense.hip: images of the stack shifted by (dy, dx)
     float *partials = nullptr;
     size_t partials_bytes = 0;

@@ -330,9 +330,15 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
     }
 }
 
-template <int NG> struct LdsCfg {
-    static constexpr int KB = NG == 1 ? KC : 128;               // pixels per mask slot
-    static constexpr int BSLOT = NG * GROUP * KB * 4;           // bytes per mask slot: 16 / 16 / 32 KiB
+// NE > 0 ("extras"): NG groups go through the matrix cores and NE further columns (the remainder
+// of a stack with 16 NG + NE columns, e.g. 25 complex masks = 48 + 2) are accumulated on the VALU
+// from the already converted frame fragments -- instead of a whole extra MFMA group of padding.
+// Their slot is 32 KiB: NG x 8 KiB of groups, then NE x 512 B of plain (column, pixel) floats.
+template <int NG, int NE = 0> struct LdsCfg {
+    static constexpr int KB = (NG == 1 && NE == 0) ? KC : 128;  // pixels per mask slot
+    static constexpr int BSLOT = NE > 0 ? 32768 : NG * GROUP * KB * 4;   // bytes per mask slot
+    static constexpr int EXTRA_OFF = NG * GROUP * KB;           // float offset of the extras in a slot
+    static_assert(NE == 0 || (NG * GROUP * KB * 4 + NE * KB * 4 <= 32768), "extras must fit the slot");
     static constexpr int RING = BSLOT > 16384 ? 3 : 4;          // frame ring depth (sub-chunks)
     static constexpr int WAVES = 8;
     static constexpr int LDS_BYTES = RING * WAVES * V2_ASLOT + 2 * BSLOT;      // 160 KiB
@@ -387,8 +393,31 @@ __global__ void k_build_image_shifted(const float *__restrict__ src, float *__re
     }
 }
 
-template <typename T, int NG, int ABL = 0, bool IND = false>
-__global__ void __launch_bounds__(LdsCfg<NG>::WAVES * 64)
+// raw stack -> image 3 (NG groups + extras, 32-KiB slots of 128 pixels): groups as in image 2, then
+// the columns >= 16 NG as plain [column][pixel] floats
+__global__ void k_build_image3(const float *__restrict__ src, float *__restrict__ img,
+                               int64_t n_masks, int cpm, int64_t n_px, int n_slots, int ng) {
+    constexpr int kb = 128, slot_floats = 8192;
+    const int64_t total = n_masks * cpm * n_px;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int part = (int)(i % cpm);
+        const int64_t kp = i / cpm;
+        const int64_t k = kp / n_px, p = kp % n_px;
+        const int col = (int)(k * cpm + part);
+        const int slot = (int)(p / kb), q = (int)(p % kb);
+        float *base = img + (size_t)slot * slot_floats;
+        if (col < ng * GROUP) {
+            const int g = col / GROUP, n = col % GROUP;
+            base[(size_t)g * GROUP * kb + img2_index(n, q, kb)] = src[i];
+        } else {
+            base[(size_t)ng * GROUP * kb + (col - ng * GROUP) * kb + q] = src[i];
+        }
+    }
+}
+
+template <typename T, int NG, int ABL = 0, bool IND = false, int NE = 0>
+__global__ void __launch_bounds__(512)                          // LdsCfg::WAVES * 64
 k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
             const float *__restrict__ img, int n_slots, float *__restrict__ out, int64_t ld_out,
             int n_cols, int accumulate, float *__restrict__ partials, int ksplit,
@@ -396,7 +425,7 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             const float *const *__restrict__ wg_img = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     using TR = InTraits<T>;
-    using CFG = LdsCfg<NG>;
+    using CFG = LdsCfg<NG, NE>;
     constexpr int WAVES = CFG::WAVES, RING = CFG::RING, KB = CFG::KB, BSLOT = CFG::BSLOT;
     constexpr int SPX = V2_SUB_BYTES / (int)sizeof(T);  // pixels per sub-chunk
     static_assert(SPX <= KB && KB % SPX == 0, "a sub-chunk must not straddle mask slots");
@@ -440,6 +469,9 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
     for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int x = 0; x < NACC; ++x) acc[g][x] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float acc_e[NE > 0 ? NE : 1];                        // VALU columns: partial over this lane's pixels
+#pragma unroll
+    for (int c = 0; c < (NE > 0 ? NE : 1); ++c) acc_e[c] = 0.f;
 
     // lane-constant parts of the fragment addresses
     const int a_lane = m * V2_SUB_BYTES;                 // bytes inside a frame slot
@@ -533,22 +565,39 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             auto rd_b = [&](int blk, int g, int h) {
                 return *(const f32x4 *)(bslot + g * (GROUP * KB) + b_unit(blk0 + blk, h));
             };
+            // extras: column c, this lane's 8 pixels of the block (same address for the 16 lanes of
+            // a kg group: LDS broadcast)
+            auto rd_e = [&](int blk, int c, int h) {
+                return *(const f32x4 *)(bslot - b_lane + CFG::EXTRA_OFF + c * KB +
+                                        (blk0 + blk) * 32 + kg * 8 + h * 4);
+            };
             typename TR::raw_t raw_c = rd_a(0);
             f32x4 b_c[NG][2];
 #pragma unroll
             for (int g = 0; g < NG; ++g) { b_c[g][0] = rd_b(0, g, 0); b_c[g][1] = rd_b(0, g, 1); }
+            f32x4 e_c[NE > 0 ? NE : 1][2];
+#pragma unroll
+            for (int c = 0; c < NE; ++c) { e_c[c][0] = rd_e(0, c, 0); e_c[c][1] = rd_e(0, c, 1); }
 #pragma unroll
             for (int blk = 0; blk < BLKS; ++blk) {
                 typename TR::raw_t raw_n = raw_c;
                 f32x4 b_n[NG][2];
 #pragma unroll
                 for (int g = 0; g < NG; ++g) { b_n[g][0] = b_c[g][0]; b_n[g][1] = b_c[g][1]; }
+                f32x4 e_n[NE > 0 ? NE : 1][2];
+#pragma unroll
+                for (int c = 0; c < NE; ++c) { e_n[c][0] = e_c[c][0]; e_n[c][1] = e_c[c][1]; }
                 if (blk + 1 < BLKS) {
                     raw_n = rd_a(blk + 1);
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
                         b_n[g][0] = rd_b(blk + 1, g, 0);
                         b_n[g][1] = rd_b(blk + 1, g, 1);
+                    }
+#pragma unroll
+                    for (int c = 0; c < NE; ++c) {
+                        e_n[c][0] = rd_e(blk + 1, c, 0);
+                        e_n[c][1] = rd_e(blk + 1, c, 1);
                     }
                 }
                 // the 4 DMA instructions of sub-chunk s+RING-1 are spread over the BLKS blocks
@@ -574,9 +623,15 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                     if (CVT) __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);     // 8 conversions
                     __builtin_amdgcn_sched_group_barrier(0x008, 8 * NG, 0);         // then the MFMAs
                 }
+#pragma unroll
+                for (int c = 0; c < NE; ++c)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc_e[c] += a[j] * e_c[c][j >> 2][j & 3];
                 raw_c = raw_n;
 #pragma unroll
                 for (int g = 0; g < NG; ++g) { b_c[g][0] = b_n[g][0]; b_c[g][1] = b_n[g][1]; }
+#pragma unroll
+                for (int c = 0; c < NE; ++c) { e_c[c][0] = e_n[c][0]; e_c[c][1] = e_n[c][1]; }
             }
         };
 
@@ -627,6 +682,11 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                     acc[g][j & (NACC - 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                         a[j], b[j >> 2][j & 3], acc[g][j & (NACC - 1)], 0, 0, 0);
             }
+#pragma unroll
+            for (int c = 0; c < NE; ++c)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    acc_e[c] += a[j] * bl[CFG::EXTRA_OFF + c * KB + blk * 32 + kg * 8 + j];
         }
     }
 
@@ -647,6 +707,25 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                 }
             }
         }
+    if constexpr (NE > 0) {
+        // lane (m, kg) holds frame m's partial over its own pixels: sum the 4 kg lanes
+        const int64_t f = frame_of(m);
+#pragma unroll
+        for (int c = 0; c < NE; ++c) {
+            float v = acc_e[c];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int col = NG * GROUP + c;
+            if (kg == 0 && f >= 0 && col < n_cols) {
+                if (ksplit == 1) {
+                    float *p = out + f * ld_out + col;
+                    *p = accumulate ? (*p + v) : v;
+                } else {
+                    partials[((int64_t)ks * n_frames + f) * n_cols + col] = v;
+                }
+            }
+        }
+    }
 }
 
 __global__ void k_reduce_partials(const float *__restrict__ partials, int ksplit,
@@ -939,6 +1018,25 @@ extern "C" int ltmi_masks_create_dense(int device, const void *masks_host, int r
                 if (e == hipSuccess) e = hipDeviceSynchronize();
             }
         }
+        if (e == hipSuccess && m->n_cols > 3 * GROUP && m->n_cols <= 3 * GROUP + 4) {
+            // 49..52 columns (25 complex masks = 50): three MFMA groups + the rest on the VALU
+            // instead of a fourth group that is mostly padding (k_dense_lds<T, 3, .., NE>)
+            constexpr int kb = 128;
+            m->n_slots3 = (int)((n_px + kb - 1) / kb);
+            m->ne3 = (m->n_cols - 3 * GROUP <= 2) ? 2 : 4;
+            const size_t n3 = (size_t)m->n_slots3 * 8192;
+            e = hipMalloc((void **)&m->img3, n3 * sizeof(float));
+            if (e == hipSuccess) e = hipMemset(m->img3, 0, n3 * sizeof(float));
+            if (e == hipSuccess) {
+                const int64_t total = n_masks * cpm * n_px;
+                const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 65535 * 16);
+                hipLaunchKernelGGL(ltmi::k_build_image3, dim3(blocks), dim3(256), 0, 0,
+                                   (const float *)m->gmasks, m->img3, n_masks, cpm, n_px,
+                                   m->n_slots3, 3);
+                e = hipGetLastError();
+                if (e == hipSuccess) e = hipDeviceSynchronize();
+            }
+        }
         if (e != hipSuccess) {
             ltmi_masks_destroy(m);
             LTMI_FAIL((int)e, "building the mask image failed: %s", hipGetErrorString(e));
@@ -955,6 +1053,7 @@ extern "C" int ltmi_masks_destroy(ltmi_masks *m) {
     (void)hipSetDevice(m->device);
     if (m->img) (void)hipFree(m->img);
     if (m->img2) (void)hipFree(m->img2);
+    if (m->img3) (void)hipFree(m->img3);
     shift_cache_destroy(m);
     if (m->partials) (void)hipFree(m->partials);
     if (m->gmasks) (void)hipFree(m->gmasks);
@@ -971,7 +1070,7 @@ extern "C" int ltmi_masks_kind(const ltmi_masks *m, int *kind) {
 
 extern "C" int ltmi_masks_set_tuning(ltmi_masks *m, int mt, int waves, int ksplit) {
     if (!m) LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_set_tuning: null handle");
-    if (mt == 0 && waves >= 30 && waves <= 32) {
+    if (mt == 0 && waves >= 30 && waves <= 33) {
         // k_dense_lds: 30 = as dispatched, 31 / 32 = timing-only ablations (no DMA / no MFMA)
         m->tune_mt = 0;
         m->tune_waves = 0;
@@ -1085,6 +1184,53 @@ static int launch_lds_ng(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t
     return LTMI_OK;
 }
 
+// 3 MFMA groups + NE VALU columns (stacks of 49..52 columns)
+template <typename T, int NE>
+static int launch_lds_extras(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
+                             int64_t ld_out, int accumulate, hipStream_t stream) {
+    using CFG = LdsCfg<3, NE>;
+    auto kern = k_dense_lds<T, 3, 0, false, NE>;
+    static bool attr_set[16] = {false};
+    if (!attr_set[m->device & 15]) {
+        LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     CFG::LDS_BYTES));
+        attr_set[m->device & 15] = true;
+    }
+    const int n_slots = m->n_slots3;
+    const int64_t gx = (n_frames + CFG::WAVES * V2_ROWS - 1) / (CFG::WAVES * V2_ROWS);
+    int ksplit = m->tune_ksplit;
+    if (ksplit <= 0) {
+        ksplit = 1;
+        if (gx < 256)
+            ksplit = (int)std::min<int64_t>((512 + gx - 1) / gx, std::max(1, n_slots / 16));
+    }
+    ksplit = std::max(1, std::min(ksplit, n_slots));
+    {
+        const int per = (n_slots + ksplit - 1) / ksplit;
+        ksplit = (n_slots + per - 1) / per;
+    }
+    if (ksplit > 1) {
+        int rc = ensure_partials(m, (size_t)ksplit * n_frames * m->n_cols * sizeof(float), stream);
+        if (rc != LTMI_OK) return rc;
+    }
+    dim3 grid((unsigned)gx, (unsigned)ksplit, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(CFG::WAVES * 64), CFG::LDS_BYTES, stream, tile, ld, n_frames,
+                       m->n_px, (const float *)m->img3, n_slots, out, ld_out, m->n_cols, accumulate,
+                       m->partials, ksplit, (const int32_t *)nullptr, (const float *const *)nullptr);
+    LTMI_HIP(hipGetLastError());
+    snprintf(m->last_kernel, sizeof(m->last_kernel),
+             "k_dense_lds<%s,NG=3+%d VALU columns,ring=%d> grid=(%u,%u,1)", typeid(T).name(), NE,
+             CFG::RING, grid.x, grid.y);
+    if (ksplit > 1) {
+        const int64_t n = n_frames * m->n_cols;
+        hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                           stream, (const float *)m->partials, ksplit, n_frames, m->n_cols, out,
+                           ld_out, accumulate);
+        LTMI_HIP(hipGetLastError());
+    }
+    return LTMI_OK;
+}
+
 template <typename T>
 static bool lds_kernel_applies(const ltmi_masks *m) {
     if (sizeof(T) == 1 && m->ng > 1) return false;            // 256-px sub-chunks need NG == 1
@@ -1097,6 +1243,11 @@ static int launch_lds(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld
     if (m->ng == 1)
         return launch_lds_ng<T, 1>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
     if constexpr (sizeof(T) > 1) {
+        if (m->img3 && m->tune_ksplit_ring != 33) {          // 33: force the 4-group kernel (bench)
+            if (m->ne3 == 2)
+                return launch_lds_extras<T, 2>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+            return launch_lds_extras<T, 4>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+        }
         if (m->ng == 2)
             return launch_lds_ng<T, 2>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
         return launch_lds_ng<T, 4>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);

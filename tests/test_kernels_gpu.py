@@ -446,3 +446,41 @@ def test_shifted_masks_host_shifts(hip, tile_dtype, sig, n_masks, mask_dtype, ex
     assert np.all(np.abs(res - ref) <= (1e-5 if rd in (np.float32, np.complex64) else 1e-12)
                   * (scale + 1))
     h.close()
+
+
+@pytest.mark.parametrize('tile_dtype', ['uint16', 'int16', 'float32'])
+@pytest.mark.parametrize('n_masks,mask_dtype,ksplit', [
+    (25, 'complex64', 0),       # C5: 25 complex masks = 48 + 2 real columns
+    (25, 'complex64', 3),
+    (49, 'float32', 0), (50, 'float32', 2), (51, 'float32', 0), (52, 'float32', 0),
+])
+def test_three_groups_plus_valu_columns(hip, tile_dtype, n_masks, mask_dtype, ksplit):
+    """Stacks of 49..52 real columns: 3 MFMA groups + the remainder on the VALU (k_dense_lds with
+    extras) must agree with float64 and with the 4-group kernel (tuning code 33)."""
+    rng = np.random.default_rng(hash((tile_dtype, n_masks, mask_dtype)) % (2**32))
+    n_frames, n_px = 150, 128 * 37 + 48
+    dt = np.dtype(tile_dtype)
+    if dt.kind == 'u':
+        data = rng.integers(0, 3000, (n_frames, n_px)).astype(dt)
+    elif dt.kind == 'i':
+        data = rng.integers(-2000, 2000, (n_frames, n_px)).astype(dt)
+    else:
+        data = (rng.random((n_frames, n_px)) - 0.3).astype(dt)
+    md = np.dtype(mask_dtype)
+    masks = rng.random((n_masks, n_px)) - 0.25
+    if md.kind == 'c':
+        masks = masks + 1j * (rng.random((n_masks, n_px)) - 0.5)
+    masks = masks.astype(md)
+    ref = _ref64(data, masks)
+    scale = np.abs(data.astype(np.float64)) @ np.abs(masks).astype(np.float64).T
+    res, kern = _apply(hip, data, masks, md, tuning=dict(mt=0, waves=30, ksplit=ksplit))
+    assert 'VALU columns' in kern, kern
+    assert np.all(np.abs(res - ref) <= 1e-5 * scale + 1e-30)
+    base = (rng.random((n_frames, n_masks)) + (1j * rng.random((n_frames, n_masks))
+                                               if md.kind == 'c' else 0)).astype(md)
+    res2, _ = _apply(hip, data, masks, md, accumulate_into=base,
+                     tuning=dict(mt=0, waves=30, ksplit=ksplit))
+    assert np.all(np.abs(res2 - (ref + base)) <= 1e-5 * (scale + 1))
+    res4, kern4 = _apply(hip, data, masks, md, tuning=dict(mt=0, waves=33, ksplit=ksplit))
+    assert 'NG=4' in kern4, kern4
+    assert np.all(np.abs(res4 - res) <= 2e-5 * scale + 1e-30)
