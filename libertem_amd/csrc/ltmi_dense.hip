@@ -1266,8 +1266,12 @@ struct ShiftCache {
     int32_t *rows_dev = nullptr;
     const float **wg_img_dev = nullptr;
     size_t rows_cap = 0, wg_cap = 0;
-    std::vector<int32_t> rows_host;
-    std::vector<const float *> wg_host;
+    // host staging of the row lists / image pointers: a small ring, so that a list is not rewritten
+    // while an asynchronous copy of an earlier call may still be reading it
+    static constexpr int STAGES = 4;
+    std::vector<int32_t> rows_stage[STAGES];
+    std::vector<const float *> wg_stage[STAGES];
+    int stage = 0;
 };
 constexpr size_t SHIFT_CACHE_BYTES = (size_t)4 << 30;   // at most 4 GiB of shifted images per handle
 
@@ -1345,21 +1349,24 @@ static int launch_lds_shifted(ltmi_masks *m, const T *tile, int64_t n_frames, in
     }
     // row lists, padded per group to whole workgroups
     constexpr int WG_ROWS = CFG::WAVES * V2_ROWS;
-    c->rows_host.clear();
-    c->wg_host.clear();
+    c->stage = (c->stage + 1) % ShiftCache::STAGES;
+    std::vector<int32_t> &rows_host = c->rows_stage[c->stage];
+    std::vector<const float *> &wg_host = c->wg_stage[c->stage];
+    rows_host.clear();
+    wg_host.clear();
     for (size_t g = 0; g < keys.size(); ++g) {
         const float *img = c->images[keys[g]];
         const size_t n = members[g].size();
         const size_t n_wg = (n + WG_ROWS - 1) / WG_ROWS;
-        c->rows_host.insert(c->rows_host.end(), members[g].begin(), members[g].end());
-        c->rows_host.resize(c->rows_host.size() + (n_wg * WG_ROWS - n), -1);
-        for (size_t b = 0; b < n_wg; ++b) c->wg_host.push_back(img);
+        rows_host.insert(rows_host.end(), members[g].begin(), members[g].end());
+        rows_host.resize(rows_host.size() + (n_wg * WG_ROWS - n), -1);
+        for (size_t b = 0; b < n_wg; ++b) wg_host.push_back(img);
     }
-    const size_t n_wg = c->wg_host.size();
-    if (c->rows_cap < c->rows_host.size()) {
+    const size_t n_wg = wg_host.size();
+    if (c->rows_cap < rows_host.size()) {
         if (c->rows_dev) LTMI_HIP(hipFree(c->rows_dev));
         c->rows_dev = nullptr;
-        c->rows_cap = c->rows_host.size() * 2;
+        c->rows_cap = rows_host.size() * 2;
         LTMI_HIP(hipMalloc((void **)&c->rows_dev, c->rows_cap * sizeof(int32_t)));
     }
     if (c->wg_cap < n_wg) {
@@ -1368,10 +1375,9 @@ static int launch_lds_shifted(ltmi_masks *m, const T *tile, int64_t n_frames, in
         c->wg_cap = n_wg * 2;
         LTMI_HIP(hipMalloc((void **)&c->wg_img_dev, c->wg_cap * sizeof(float *)));
     }
-    // the host vectors live in the cache until the next call: safe for an asynchronous copy
-    LTMI_HIP(hipMemcpyAsync(c->rows_dev, c->rows_host.data(), c->rows_host.size() * sizeof(int32_t),
+    LTMI_HIP(hipMemcpyAsync(c->rows_dev, rows_host.data(), rows_host.size() * sizeof(int32_t),
                             hipMemcpyHostToDevice, stream));
-    LTMI_HIP(hipMemcpyAsync((void *)c->wg_img_dev, c->wg_host.data(), n_wg * sizeof(float *),
+    LTMI_HIP(hipMemcpyAsync((void *)c->wg_img_dev, wg_host.data(), n_wg * sizeof(float *),
                             hipMemcpyHostToDevice, stream));
     auto kern = k_dense_lds<T, 1, 0, true>;
     static bool attr_set[16] = {false};
@@ -1643,8 +1649,9 @@ extern "C" int ltmi_apply_masks_shifted_host(ltmi_masks *m, const void *tile, in
         c->rows_cap = need * 2;
         LTMI_HIP(hipMalloc((void **)&c->rows_dev, c->rows_cap * sizeof(int32_t)));
     }
-    c->rows_host.assign(shifts_host, shifts_host + need);
-    LTMI_HIP(hipMemcpyAsync(c->rows_dev, c->rows_host.data(), need * sizeof(int32_t),
+    c->stage = (c->stage + 1) % ShiftCache::STAGES;
+    c->rows_stage[c->stage].assign(shifts_host, shifts_host + need);
+    LTMI_HIP(hipMemcpyAsync(c->rows_dev, c->rows_stage[c->stage].data(), need * sizeof(int32_t),
                             hipMemcpyHostToDevice, stream));
     return ltmi_apply_masks_shifted(m, tile, tile_dtype, n_frames, ld_tile, sig_h, sig_w, c->rows_dev,
                                     out, ld_out, accumulate, stream_);
