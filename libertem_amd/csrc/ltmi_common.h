@@ -49,6 +49,14 @@ struct cdouble { double re, im; };
 
 }  // namespace ltmi
 
+struct ltmi_masks;
+namespace ltmi {
+int dense64_create(ltmi_masks *m);
+void dense64_destroy(ltmi_masks *m);
+int dense64_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames, int64_t ld,
+                  void *out, int64_t ld_out, int accumulate, hipStream_t stream, bool *handled);
+}  // namespace ltmi
+
 // The opaque handle behind `ltmi_masks*` (shared by ltmi_dense.hip and ltmi_sparse.hip).
 struct ltmi_masks {
     int device = 0;
@@ -65,6 +73,11 @@ struct ltmi_masks {
     int n_slots2 = 0;
     float *img3 = nullptr;   // 3 groups + ne3 VALU columns (49..52 columns), 32-KiB slots of 128 px
     int n_slots3 = 0, ne3 = 0;
+    // float64 results on the f64 matrix cores (ltmi_dense64.hip)
+    double *img64 = nullptr;
+    int n_groups64 = 0, n_chunks64 = 0;
+    void *ws64 = nullptr;
+    size_t ws64_bytes = 0;
     void *shift_cache = nullptr;   // ltmi_dense.hip: images of the stack shifted by (dy, dx)
     float *partials = nullptr;
     size_t partials_bytes = 0;

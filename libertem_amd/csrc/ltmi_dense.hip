@@ -986,6 +986,13 @@ extern "C" int ltmi_masks_create_dense(int device, const void *masks_host, int r
             LTMI_FAIL((int)e, "uploading the mask stack failed: %s", hipGetErrorString(e));
         }
     }
+    if (result_dtype == LTMI_F64) {
+        const int rc64 = ltmi::dense64_create(m);
+        if (rc64 != LTMI_OK) {
+            ltmi_masks_destroy(m);
+            return rc64;
+        }
+    }
     if (m->kind == 0) {
         // MFMA image: swizzled on the device from the raw stack uploaded above (f32, or
         // interleaved (re, im) pairs) -- no host-side transform, no second upload
@@ -1054,6 +1061,7 @@ extern "C" int ltmi_masks_destroy(ltmi_masks *m) {
     if (m->img) (void)hipFree(m->img);
     if (m->img2) (void)hipFree(m->img2);
     if (m->img3) (void)hipFree(m->img3);
+    ltmi::dense64_destroy(m);
     shift_cache_destroy(m);
     if (m->partials) (void)hipFree(m->partials);
     if (m->gmasks) (void)hipFree(m->gmasks);
@@ -1568,6 +1576,12 @@ extern "C" int ltmi_apply_masks(ltmi_masks *m, const void *tile, int tile_dtype,
             case LTMI_I16: return launch_mfma<int16_t>(m, (const int16_t *)tile, n_frames, ld_tile, o, ldo, accumulate, stream);
             case LTMI_F32: return launch_mfma<float>(m, (const float *)tile, n_frames, ld_tile, o, ldo, accumulate, stream);
         }
+    }
+    if (m->result_dtype == LTMI_F64) {
+        bool handled = false;
+        const int rc = ltmi::dense64_apply(m, tile, tile_dtype, n_frames, ld_tile, out, ld_out,
+                                           accumulate, stream, &handled);
+        if (rc != LTMI_OK || handled) return rc;
     }
     return apply_generic(m, tile, tile_dtype, n_frames, ld_tile, out, ld_out, accumulate, stream);
 }

@@ -1,0 +1,271 @@
+// ltmi_dense64.hip -- dense mask stacks with FLOAT64 results on the f64 matrix cores.
+//
+// np.result_type(input_dtype, mask_dtype) is float64 for int32 / uint32 / int64 / float64 data
+// (reference udf/base.py:106-123, udf/masks.py:362) and for float64 masks; the reference then runs
+// a dgemm.  Here: v_mfma_f64_16x16x4_f64 (16 frames x 16 masks x 4 pixels per instruction, exact
+// f64 FMA chain).  Structure of the direct-load f32 kernel (k_dense_mfma): a wave owns 16 frames,
+// lane (m, kg) loads 4 consecutive pixels of frame m straight from HBM into a rolling register ring
+// (16 blocks ahead), converts them to f64 in registers; the 32-KiB mask chunk (256 px x 16 columns,
+// f64, XOR-swizzled like the f32 image) is shared by the workgroup through LDS, double buffered.
+#include "ltmi_common.h"
+#include <algorithm>
+#include <typeinfo>
+
+namespace ltmi {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+
+constexpr int KC64 = 256;                       // pixels per mask chunk
+constexpr int CH64 = 16 * KC64;                 // doubles per (group, chunk) = 32 KiB
+
+// double index of (column n, pixel q) inside a chunk block: a lane's 4 pixels are two 16-B units;
+// XOR with n spreads the 16 lanes of a read over 16 different units (conflict-free)
+__host__ __device__ static inline int img64_index(int n, int q) {
+    const int blk = q >> 4, kg = (q >> 2) & 3, j = q & 3;
+    const int v = (blk * 8 + kg * 2 + (j >> 1)) ^ n;
+    return n * KC64 + v * 2 + (j & 1);
+}
+
+__global__ void k_build_image64(const double *__restrict__ src, double *__restrict__ img,
+                                int64_t n_masks, int64_t n_px, int n_chunks) {
+    const int64_t total = n_masks * n_px;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = i / n_px, p = i % n_px;
+        const int g = (int)(k / 16), n = (int)(k % 16);
+        const int c = (int)(p / KC64), q = (int)(p % KC64);
+        img[((size_t)g * n_chunks + c) * CH64 + img64_index(n, q)] = src[i];
+    }
+}
+
+template <typename T, int WAVES, bool VEC>
+__global__ void __launch_bounds__(WAVES * 64)
+k_dense_mfma_f64(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
+                 const double *__restrict__ img, int n_chunks, double *__restrict__ out,
+                 int64_t ld_out, int n_cols, int accumulate, double *__restrict__ partials,
+                 int ksplit) {
+    extern __shared__ __attribute__((aligned(16))) double lds64[];     // 2 stages x CH64
+    constexpr int NT = WAVES * 64;
+    constexpr int BUNITS = CH64 * 8 / 16 / NT;          // 16-B units per thread per chunk
+    constexpr int DEPTH = sizeof(T) == 8 ? 8 : 16;      // blocks (of 16 px) in the register ring
+    typedef T __attribute__((ext_vector_type(4))) raw_t;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int m = lane & 15, kg = lane >> 4;
+    const int ks = blockIdx.y, g0 = blockIdx.z;
+
+    const int n_full = VEC ? (int)(n_px / KC64) : 0;
+    const int per = (n_chunks + ksplit - 1) / ksplit;
+    const int c_begin = ks * per;
+    const int c_end = min(n_chunks, c_begin + per);
+    const int cf_end = min(c_end, n_full);
+
+    const int64_t f_wave = (int64_t)blockIdx.x * (WAVES * 16) + wave * 16;
+    int64_t f = f_wave + m;
+    if (f > n_frames - 1) f = n_frames - 1;             // clamp: loads stay valid, result discarded
+    const T *rowp = tile + f * ld + kg * 4;
+
+    f64x4 acc = {0., 0., 0., 0.};
+    const u32x4_ *img_units = (const u32x4_ *)img;
+    auto unit = [&](int i, int c) -> int64_t {
+        return ((int64_t)g0 * n_chunks + c) * (CH64 / 2) + i * NT + tid;
+    };
+    const int lds_lane = m * KC64;
+    auto rd_b = [&](const double *stage, int blk, int h) {
+        return *(const f64x2 *)(stage + lds_lane + (((blk * 8 + kg * 2 + h) ^ m) << 1));
+    };
+
+    if (c_begin < cf_end) {
+        raw_t raw[DEPTH];
+        u32x4_ breg[BUNITS];
+        const int64_t px0 = (int64_t)c_begin * KC64;
+        const int n_blocks = (cf_end - c_begin) * 16;
+#pragma unroll
+        for (int i = 0; i < BUNITS; ++i) breg[i] = img_units[unit(i, c_begin)];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i)
+            raw[i] = __builtin_nontemporal_load((const raw_t *)(rowp + px0 + min(i, n_blocks - 1) * 16));
+#pragma unroll
+        for (int i = 0; i < BUNITS; ++i) ((u32x4_ *)lds64)[i * NT + tid] = breg[i];
+        __syncthreads();
+
+        for (int c = c_begin; c < cf_end; ++c) {
+            const int cn = min(c + 1, cf_end - 1);
+            const int s = (c - c_begin) & 1;
+#pragma unroll
+            for (int i = 0; i < BUNITS; ++i) breg[i] = img_units[unit(i, cn)];
+            const double *stage = lds64 + s * CH64;
+#pragma unroll
+            for (int blk = 0; blk < 16; ++blk) {
+                const raw_t r = raw[blk % DEPTH];
+                const int nb = min((c - c_begin) * 16 + blk + DEPTH, n_blocks - 1);
+                raw[blk % DEPTH] = __builtin_nontemporal_load((const raw_t *)(rowp + px0 + (int64_t)nb * 16));
+                const f64x2 b0 = rd_b(stage, blk, 0), b1 = rd_b(stage, blk, 1);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)r[0], b0[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)r[1], b0[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)r[2], b1[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)r[3], b1[1], acc, 0, 0, 0);
+            }
+            u32x4_ *ldsn = (u32x4_ *)(lds64 + (s ^ 1) * CH64);
+#pragma unroll
+            for (int i = 0; i < BUNITS; ++i) ldsn[i * NT + tid] = breg[i];
+            __syncthreads();
+        }
+    }
+
+    // chunks that need guarded element loads: the ragged last chunk, or everything if unaligned
+    for (int c = max(c_begin, n_full); c < c_end; ++c) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < BUNITS; ++i) ((u32x4_ *)lds64)[i * NT + tid] = img_units[unit(i, c)];
+        __syncthreads();
+#pragma unroll
+        for (int blk = 0; blk < 16; ++blk) {
+            const int64_t p0 = (int64_t)c * KC64 + blk * 16;          // + kg*4 is folded into rowp
+            double a[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = (p0 + kg * 4 + j < n_px) ? (double)rowp[p0 + j] : 0.;
+            const f64x2 b0 = rd_b(lds64, blk, 0), b1 = rd_b(lds64, blk, 1);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b0[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b0[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b1[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b1[1], acc, 0, 0, 0);
+        }
+    }
+
+    // C/D layout of 16x16x4 f64 (differs from the f32 instruction): col = lane & 15,
+    // row = reg * 4 + (lane >> 4)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t fr = f_wave + r * 4 + kg;
+        const int col = g0 * 16 + m;
+        if (fr < n_frames && col < n_cols) {
+            if (ksplit == 1) {
+                double *p = out + fr * ld_out + col;
+                *p = accumulate ? (*p + acc[r]) : acc[r];
+            } else {
+                partials[((int64_t)ks * n_frames + fr) * n_cols + col] = acc[r];
+            }
+        }
+    }
+}
+
+__global__ void k_reduce_partials64(const double *__restrict__ partials, int ksplit,
+                                    int64_t n_frames, int n_cols, double *__restrict__ out,
+                                    int64_t ld_out, int accumulate) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_frames * n_cols) return;
+    const int64_t f = idx / n_cols;
+    const int col = (int)(idx % n_cols);
+    double *p = out + f * ld_out + col;
+    double s = accumulate ? *p : 0.;
+    for (int k = 0; k < ksplit; ++k) s += partials[(int64_t)k * n_frames * n_cols + idx];
+    *p = s;
+}
+
+// ---- host side ---------------------------------------------------------------------------------------
+int dense64_create(ltmi_masks *m) {
+    // m->gmasks holds the (n_masks, n_px) float64 stack on the device
+    m->n_groups64 = (int)((m->n_masks + 15) / 16);
+    m->n_chunks64 = (int)((m->n_px + KC64 - 1) / KC64);
+    const size_t n = (size_t)m->n_groups64 * m->n_chunks64 * CH64;
+    LTMI_HIP(hipMalloc((void **)&m->img64, n * sizeof(double)));
+    LTMI_HIP(hipMemset(m->img64, 0, n * sizeof(double)));
+    const int64_t total = m->n_masks * m->n_px;
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 65535 * 16);
+    hipLaunchKernelGGL(k_build_image64, dim3(blocks), dim3(256), 0, 0, (const double *)m->gmasks,
+                       m->img64, m->n_masks, m->n_px, m->n_chunks64);
+    LTMI_HIP(hipGetLastError());
+    LTMI_HIP(hipDeviceSynchronize());
+    return LTMI_OK;
+}
+
+void dense64_destroy(ltmi_masks *m) {
+    if (m->img64) (void)hipFree(m->img64);
+    if (m->ws64) (void)hipFree(m->ws64);
+    m->img64 = nullptr;
+    m->ws64 = nullptr;
+}
+
+template <typename T>
+static int launch64(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, double *out,
+                    int64_t ld_out, int accumulate, hipStream_t stream) {
+    constexpr int WAVES = 4;
+    const bool vec = (((uintptr_t)tile) % (4 * sizeof(T)) == 0) && (ld % 4 == 0);
+    const int64_t gx = (n_frames + WAVES * 16 - 1) / (WAVES * 16);
+    const int64_t gz = m->n_groups64;
+    int ksplit = m->tune_ksplit;
+    if (ksplit <= 0) {
+        ksplit = 1;
+        if (gx * gz < 512)
+            ksplit = (int)std::min<int64_t>((1024 + gx * gz - 1) / (gx * gz),
+                                            std::max(1, m->n_chunks64 / 8));
+    }
+    ksplit = std::max(1, std::min(ksplit, m->n_chunks64));
+    {
+        const int per = (m->n_chunks64 + ksplit - 1) / ksplit;
+        ksplit = (m->n_chunks64 + per - 1) / per;
+    }
+    if (ksplit > 1) {
+        const size_t need = (size_t)ksplit * n_frames * m->n_masks * sizeof(double);
+        if (m->ws64_bytes < need) {
+            if (m->ws64) {
+                LTMI_HIP(hipStreamSynchronize(stream));
+                LTMI_HIP(hipFree(m->ws64));
+                m->ws64 = nullptr;
+                m->ws64_bytes = 0;
+            }
+            LTMI_HIP(hipMalloc(&m->ws64, need));
+            m->ws64_bytes = need;
+        }
+    }
+    const size_t lds = 2 * (size_t)CH64 * sizeof(double);          // 64 KiB
+    auto kern = vec ? k_dense_mfma_f64<T, WAVES, true> : k_dense_mfma_f64<T, WAVES, false>;
+    LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
+    dim3 grid((unsigned)gx, (unsigned)ksplit, (unsigned)gz);
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, stream, tile, ld, n_frames, m->n_px,
+                       (const double *)m->img64, m->n_chunks64, out, ld_out, (int)m->n_masks,
+                       accumulate, (double *)m->ws64, ksplit);
+    LTMI_HIP(hipGetLastError());
+    snprintf(m->last_kernel, sizeof(m->last_kernel), "k_dense_mfma_f64<%s,%s> grid=(%u,%u,%u)",
+             typeid(T).name(), vec ? "vec" : "guarded", grid.x, grid.y, grid.z);
+    if (ksplit > 1) {
+        const int64_t n = n_frames * m->n_masks;
+        hipLaunchKernelGGL(k_reduce_partials64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                           stream, (const double *)m->ws64, ksplit, n_frames, (int)m->n_masks, out,
+                           ld_out, accumulate);
+        LTMI_HIP(hipGetLastError());
+    }
+    return LTMI_OK;
+}
+
+// -> LTMI_OK and *handled = true if the tile went through the f64 matrix kernel
+int dense64_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames, int64_t ld,
+                  void *out, int64_t ld_out, int accumulate, hipStream_t stream, bool *handled) {
+    *handled = false;
+    if (!m->img64 || m->result_dtype != LTMI_F64) return LTMI_OK;
+    double *o = (double *)out;
+    int rc;
+    switch (tile_dtype) {
+        case LTMI_BOOL:
+        case LTMI_U8: rc = launch64<uint8_t>(m, (const uint8_t *)tile, n_frames, ld, o, ld_out, accumulate, stream); break;
+        case LTMI_I8: rc = launch64<int8_t>(m, (const int8_t *)tile, n_frames, ld, o, ld_out, accumulate, stream); break;
+        case LTMI_U16: rc = launch64<uint16_t>(m, (const uint16_t *)tile, n_frames, ld, o, ld_out, accumulate, stream); break;
+        case LTMI_I16: rc = launch64<int16_t>(m, (const int16_t *)tile, n_frames, ld, o, ld_out, accumulate, stream); break;
+        case LTMI_U32: rc = launch64<uint32_t>(m, (const uint32_t *)tile, n_frames, ld, o, ld_out, accumulate, stream); break;
+        case LTMI_I32: rc = launch64<int32_t>(m, (const int32_t *)tile, n_frames, ld, o, ld_out, accumulate, stream); break;
+        case LTMI_U64: rc = launch64<uint64_t>(m, (const uint64_t *)tile, n_frames, ld, o, ld_out, accumulate, stream); break;
+        case LTMI_I64: rc = launch64<int64_t>(m, (const int64_t *)tile, n_frames, ld, o, ld_out, accumulate, stream); break;
+        case LTMI_F32: rc = launch64<float>(m, (const float *)tile, n_frames, ld, o, ld_out, accumulate, stream); break;
+        case LTMI_F64: rc = launch64<double>(m, (const double *)tile, n_frames, ld, o, ld_out, accumulate, stream); break;
+        default: return LTMI_OK;           // complex tiles: generic kernel
+    }
+    if (rc == LTMI_OK) *handled = true;
+    return rc;
+}
+
+}  // namespace ltmi

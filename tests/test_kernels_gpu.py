@@ -194,13 +194,47 @@ def test_generic(hip, combo):
     else:
         masks = rng.random((n_masks, n_px)).astype(result_dtype)
     res, kern = _apply(hip, data, masks, result_dtype)
-    assert 'generic' in kern
+    if result_dtype == np.float64:
+        assert 'k_dense_mfma_f64' in kern, kern    # float64 results: f64 matrix cores
+    else:
+        assert 'generic' in kern, kern
     ref = data.astype(result_dtype) @ masks.T      # NumPy's own product in the result dtype
     if result_dtype.kind in 'iu':
         assert np.array_equal(res, ref)            # wrap-around integer arithmetic, bit exact
     else:
         assert np.allclose(res, ref, rtol=1e-12 if result_dtype.itemsize >= 8 and
                            result_dtype != np.complex64 else 1e-5)
+
+
+@pytest.mark.parametrize('tile_dtype', ['int32', 'uint32', 'int64', 'float64', 'float32', 'uint16'])
+@pytest.mark.parametrize('shape,ksplit', [
+    ((300, 256 * 9 + 100, 16), 0),      # aligned rows, ragged last chunk
+    ((300, 256 * 9 + 100, 16), 3),      # K split + reduce
+    ((70, 17 * 23, 5), 0),              # odd row length -> guarded loads
+    ((45, 256 * 5, 37), 0),             # three column groups (grid.z)
+    ((1, 256, 1), 0),
+])
+def test_float64_results_on_matrix_cores(hip, tile_dtype, shape, ksplit):
+    """k_dense_mfma_f64: float64 results (int32 / int64 / float64 data, or float64 masks)."""
+    n_frames, n_px, n_masks = shape
+    rng = np.random.default_rng(hash((tile_dtype,) + shape) % (2**32))
+    dt = np.dtype(tile_dtype)
+    if dt.kind == 'u':
+        data = rng.integers(0, 100000 if dt.itemsize >= 4 else 4000, (n_frames, n_px)).astype(dt)
+    elif dt.kind == 'i':
+        data = rng.integers(-100000, 100000, (n_frames, n_px)).astype(dt)
+    else:
+        data = (rng.random((n_frames, n_px)) - 0.3).astype(dt)
+    masks = rng.random((n_masks, n_px)) - 0.25
+    tuning = dict(mt=0, waves=0, ksplit=ksplit) if ksplit else None
+    res, kern = _apply(hip, data, masks, np.float64, tuning=tuning)
+    assert 'k_dense_mfma_f64' in kern, kern
+    ref = data.astype(np.float64) @ masks.T
+    scale = np.abs(data.astype(np.float64)) @ np.abs(masks).T
+    assert np.all(np.abs(res - ref) <= 1e-13 * scale + 1e-300), np.abs(res - ref).max()
+    base = rng.random((n_frames, n_masks))
+    res2, _ = _apply(hip, data, masks, np.float64, accumulate_into=base, tuning=tuning)
+    assert np.all(np.abs(res2 - (ref + base)) <= 1e-13 * (scale + 1))
 
 
 @pytest.mark.parametrize('case', recipes.DENSE_CASES, ids=lambda c: c['name'])
