@@ -77,7 +77,8 @@ int ltmi_masks_create_csr(int device, const int64_t *indptr, const int64_t *indi
                           ltmi_masks **out);
 
 int ltmi_masks_destroy(ltmi_masks *m);
-/* 0 = dense/MFMA-f32, 1 = dense/generic, 2 = csr; for tests and the bench */
+/* 0 = dense with float32 / complex64 results (f32 matrix cores), 1 = dense with any other result
+ * dtype (float64: f64 matrix cores; complex128 / integers: VALU kernel), 2 = csr */
 int ltmi_masks_kind(const ltmi_masks *m, int *kind);
 
 /* ---- the hot call -----------------------------------------------------------------------
