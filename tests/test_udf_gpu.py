@@ -667,3 +667,97 @@ def test_run_udf_iter_partial_results_on_device(ctx):
         assert np.all(inten[~dmg] == 0)
     assert seen == [12, 24, 36, 48]
     assert np.allclose(part.buffers[1]['intensity'].data, final[1]['intensity'].data, rtol=1e-6)
+
+
+# --- reference test cases re-expressed (tests/analysis/test_analysis_masks.py:818-907, 1181-1257) ------
+def _shift_naive(masks, data, shifts):
+    """Known-answer construction of the reference's tests (`naive_shifted_mask_apply`, re-derived):
+    intersect frame and shifted mask explicitly; shifts are truncated to int."""
+    n, h, w = data.shape
+    shifts = np.asarray(shifts)
+    if shifts.shape == (2,):
+        shifts = np.repeat(shifts[None], n, axis=0)
+    out = np.zeros((n, len(masks)))
+    for f, (dy, dx) in enumerate(shifts.astype(int)):
+        fy0, fy1 = max(0, dy), min(h, h + dy)
+        fx0, fx1 = max(0, dx), min(w, w + dx)
+        if fy0 >= fy1 or fx0 >= fx1:
+            continue
+        for k, mk in enumerate(masks):
+            out[f, k] = (mk[fy0 - dy:fy1 - dy, fx0 - dx:fx1 - dx] * data[f, fy0:fy1, fx0:fx1]).sum()
+    return out
+
+
+def test_masks_on_1d_3d_signals_and_1d_scans(ctx):
+    """time series of 2D frames, spectra (sig_dims=1, line scan and 2D scan), hyperspectral
+    (sig_dims=3): result shapes and values."""
+    rng = np.random.default_rng(1)
+    # (data shape, sig_dims, expected nav shape, forced tileshape of the reference test)
+    cases = [((256, 16, 16), 2, (256,), (2, 16, 16)),
+             ((256, 256), 1, (256,), (2, 256)),
+             ((16, 16, 256), 1, (16, 16), (2, 256)),
+             ((6, 5, 8, 16, 16), 3, (6, 5), (1, 8, 16, 16))]
+    for shape, sig_dims, nav, tileshape in cases:
+        data = rng.integers(0, 1000, shape).astype('<u2')
+        mask0 = rng.random(shape[len(shape) - sig_dims:])
+        for ts in (None, tileshape):
+            ds = ctx.load('memory', data=data, tileshape=ts, num_partitions=2, sig_dims=sig_dims)
+            an = ctx.create_mask_analysis(dataset=ds, factories=[lambda: mask0])
+            res = ctx.run(an)
+            assert res.mask_0.raw_data.shape == nav
+            ref = np.tensordot(data.astype(np.float64), mask0,
+                               axes=(list(range(len(nav), len(shape))), list(range(sig_dims))))
+            assert _close(res.mask_0.raw_data, ref, F32_TOL)
+
+
+def test_masks_complex_dataset_and_masks(ctx):
+    rng = np.random.default_rng(2)
+    data = (rng.random((16, 16, 16, 16)) + 1j * rng.random((16, 16, 16, 16))).astype(np.complex64)
+    ds = ctx.load('memory', data=data, num_partitions=2, sig_dims=2)
+    mask_r = rng.random((16, 16))
+    res = ctx.run(ctx.create_mask_analysis(dataset=ds, factories=[lambda: mask_r]))
+    assert res.mask_0_complex.raw_data.shape == (16, 16)
+    ref = np.tensordot(data.astype(np.complex128), mask_r, axes=([2, 3], [0, 1]))
+    assert _close(res.mask_0_complex.raw_data, ref, F32_TOL)
+    mask_c = (rng.random((16, 16)) + 1j * rng.random((16, 16))).astype(np.complex64)
+    res = ctx.run(ctx.create_mask_analysis(dataset=ds, factories=[lambda: mask_c]))
+    ref = np.tensordot(data.astype(np.complex128), mask_c.astype(np.complex128),
+                       axes=([2, 3], [0, 1]))
+    assert _close(res.mask_0_complex.raw_data, ref, F32_TOL)
+    assert _close(res.mask_0.raw_data, np.abs(ref), F32_TOL)
+
+
+def test_shifted_masks_reference_cases(ctx):
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd.masks import circular
+    rng = np.random.default_rng(5)
+    # zero overlap (test_shifted_masks_zero_overlap)
+    data = rng.random((2, 18, 12)).astype(np.float32)
+    ds = ctx.load('memory', data=data, sig_dims=2)
+    m1 = rng.random((18, 12))
+    res = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=[lambda: m1], shifts=(-20, 15)))
+    assert np.allclose(res['intensity'].data, 0.)
+    # stacked masks, float shifts per frame, non-square frames (test_shifted_masks_stacked)
+    shifts = rng.uniform(-5., 5., (2, 2))
+    masks = rng.random((3, 18, 12))
+    udf = ApplyMasksUDF(mask_factories=lambda: masks,
+                        shifts=ApplyMasksUDF.aux_data(data=shifts.ravel(), kind='nav',
+                                                      extra_shape=(2,), dtype=float))
+    res = ctx.run_udf(dataset=ds, udf=udf)
+    assert _close(res['intensity'].data, _shift_naive(masks, data.astype(np.float64), shifts),
+                  F32_TOL)
+    # descan error on a constant frame (test_shifted_masks_descan)
+    h = w = 9
+    frame = circular(4, 4, w, h, 1)
+    frame_sum = frame.sum()
+    sh = np.moveaxis(np.mgrid[-2:4:2, -2:4:2], 0, -1)
+    frames = np.stack([np.roll(frame, (y, x), axis=(0, 1)) for y, x in sh.reshape(-1, 2)])
+    ds9 = ctx.load('memory', data=frames.astype(np.uint8), sig_dims=2)
+    mask = circular(4, 4, w, h, 2)
+    plain = ctx.run_udf(dataset=ds9, udf=ApplyMasksUDF(mask_factories=[lambda: mask]))
+    assert not (plain['intensity'].data == frame_sum).all()
+    assert plain['intensity'].data.reshape(3, 3)[1, 1] == frame_sum
+    fixed = ctx.run_udf(dataset=ds9, udf=ApplyMasksUDF(
+        mask_factories=[lambda: mask],
+        shifts=ApplyMasksUDF.aux_data(data=sh.ravel(), kind='nav', extra_shape=(2,), dtype=int)))
+    assert (fixed['intensity'].data == frame_sum).all()
