@@ -1,14 +1,18 @@
 from .memory import MemoryDataSet
+from .raw import RawFileDataSet
 from .base import DataSet, DataSetException, Partition, DataTile, TilingScheme, Negotiator
 
 
 def load(filetype, *args, **kwargs):
-    """Only the in-memory dataset is part of this build (file formats are out of scope)."""
+    """In-memory arrays (host or HBM) and flat binary files; the other file formats of the
+    reference are out of scope of this build."""
     if filetype in ('memory', 'mem'):
         return MemoryDataSet(*args, **kwargs)
+    if filetype == 'raw':
+        return RawFileDataSet(*args, **kwargs)
     raise DataSetException(
-        f"dataset type {filetype!r} is not available: only 'memory' is in scope of this build")
+        f"dataset type {filetype!r} is not available: 'memory' and 'raw' are in scope of this build")
 
 
-__all__ = ['MemoryDataSet', 'DataSet', 'DataSetException', 'Partition', 'DataTile',
+__all__ = ['MemoryDataSet', 'RawFileDataSet', 'DataSet', 'DataSetException', 'Partition', 'DataTile',
            'TilingScheme', 'Negotiator', 'load']

@@ -247,7 +247,11 @@ class _HipStager:
         if src_np.dtype != self.np_storage_dtype:
             src_np = src_np.view(self.np_storage_dtype)        # bit reinterpretation only
         if self._in_registered(src_np):
-            src = torch.from_numpy(src_np)
+            import warnings
+            with warnings.catch_warnings():
+                # read-only sources (memory-mapped files) are only ever read through this tensor
+                warnings.filterwarnings('ignore', message='The given NumPy array is not writable')
+                src = torch.from_numpy(src_np)
         else:
             if self.pinned is None:
                 shape = (self.dev[0].shape[0],) + self.sig

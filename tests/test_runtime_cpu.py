@@ -442,3 +442,41 @@ def test_correction_set_semantics(ctx):
                     corrections=CorrectionSet(excluded_pixels=ex3, gain=np.ones((5, 7, 9)),
                                               dark=np.ones((5, 7, 9))))
     assert np.allclose(r['intensity'].data, 0)
+
+
+# --- raw files -----------------------------------------------------------------------------------------
+def test_raw_file_dataset(ctx, tmp_path):
+    """ctx.load('raw', ...): memory-mapped flat file, sync_offset semantics of the reference
+    (io/dataset/raw.py; tests/io/datasets/test_raw.py: positive offsets skip frames, negative ones
+    insert blank frames, frames missing at the end are blank)."""
+    rng = np.random.default_rng(0)
+    data = rng.integers(0, 1000, (4, 6, 8, 8)).astype(np.uint16)
+    path = str(tmp_path / "scan.raw")
+    data.tofile(path)
+    ds = ctx.load('raw', path=path, dtype='uint16', nav_shape=(4, 6), sig_shape=(8, 8))
+    assert tuple(ds.shape) == (4, 6, 8, 8) and ds.dtype == np.uint16
+    res = ctx.run_udf(dataset=ds, udf=NumpySumSigUDF())['intensity'].data
+    assert np.array_equal(res, data.reshape((4, 6, -1)).sum(axis=-1).astype(np.float32))
+    flat = data.reshape((24, 8, 8))
+    ds2 = ctx.load('raw', path=path, dtype='uint16', nav_shape=(4, 6), sig_shape=(8, 8),
+                   sync_offset=5)
+    res2 = ctx.run_udf(dataset=ds2, udf=NumpySumSigUDF())['intensity'].data.reshape(-1)
+    assert np.array_equal(res2[:19], flat[5:].reshape((19, -1)).sum(axis=1)) and np.all(res2[19:] == 0)
+    ds3 = ctx.load('raw', path=path, dtype='uint16', nav_shape=(4, 6), sig_shape=(8, 8),
+                   sync_offset=-3)
+    res3 = ctx.run_udf(dataset=ds3, udf=NumpySumSigUDF())['intensity'].data.reshape(-1)
+    assert np.all(res3[:3] == 0) and np.array_equal(res3[3:], flat[:21].reshape((21, -1)).sum(axis=1))
+    be = str(tmp_path / "be.raw")
+    data.astype('>u2').tofile(be)
+    ds4 = ctx.load('raw', path=be, dtype='>u2', nav_shape=(24,), sig_shape=(8, 8))
+    res4 = ctx.run_udf(dataset=ds4, udf=NumpySumSigUDF())['intensity'].data
+    assert np.array_equal(res4, flat.reshape((24, -1)).sum(axis=1))
+    from libertem_amd.io.dataset import DataSetException
+    with pytest.raises(DataSetException):
+        ctx.load('raw', path=path, dtype='uint16', nav_shape=(4, 6), sig_shape=(8, 8),
+                 sync_offset=24)
+    with pytest.raises(DataSetException):
+        ctx.load('raw', path=str(tmp_path / "nope.raw"), dtype='uint16', nav_shape=(4, 6),
+                 sig_shape=(8, 8))
+    with pytest.raises(DataSetException):
+        ctx.load('hdf5', path=path)

@@ -761,3 +761,18 @@ def test_shifted_masks_reference_cases(ctx):
         mask_factories=[lambda: mask],
         shifts=ApplyMasksUDF.aux_data(data=sh.ravel(), kind='nav', extra_shape=(2,), dtype=int)))
     assert (fixed['intensity'].data == frame_sum).all()
+
+
+def test_raw_file_dataset_on_device(ctx, tmp_path):
+    """Frames of a memory-mapped raw file streamed to the GPU in their native dtype."""
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    rng = np.random.default_rng(0)
+    data = rng.integers(0, 4000, (7, 9, 32, 32)).astype(np.uint16)
+    path = str(tmp_path / "scan.raw")
+    data.tofile(path)
+    masks = rng.random((3, 32, 32)).astype(np.float32)
+    ds = ctx.load('raw', path=path, dtype='uint16', nav_shape=(7, 9), sig_shape=(32, 32),
+                  num_partitions=3)
+    res = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda: masks))
+    ref = opath.apply_masks(data, masks, num_partitions=3)
+    assert _close(res['intensity'].data, ref, F32_TOL)
