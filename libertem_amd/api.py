@@ -15,8 +15,8 @@ The reference's dask / pipelined / delayed executors are out of scope (SURVEY.md
 import numpy as np
 
 from libertem_amd.common.exceptions import ExecutorSpecException
-from libertem_amd.io.dataset import load as _load_dataset, MemoryDataSet
-from libertem_amd.udf.base import UDFRunner, UDF
+from libertem_amd.io.dataset import load as _load_dataset
+from libertem_amd.udf.base import UDFRunner
 from libertem_amd.analysis import (
     MasksAnalysis, COMAnalysis, RadialFourierAnalysis, SumAnalysis, DiskMaskAnalysis,
     RingMaskAnalysis, PointMaskAnalysis,

@@ -16,7 +16,6 @@ Own implementation of the subset of the reference's libertem.common.buffers.Buff
 import numpy as np
 
 from .math import prod
-from .shape import Shape
 from .hiparray import HipArray
 
 

@@ -3,9 +3,6 @@ Executor protocol: `Environment`, `JobExecutor` (subset of the reference's commo
 52-432 and executor/base.py).
 """
 import contextlib
-import os
-
-from libertem_amd.common.backend import set_use_cpu, set_use_hip
 
 
 _NULL_CONTEXT = contextlib.nullcontext()

@@ -23,7 +23,7 @@ import uuid
 import numpy as np
 
 from libertem_amd.common.hiparray import HipArray, torch_dtype_for
-from libertem_amd.common.buffers import BufferWrapper, PlaceholderBufferWrapper
+from libertem_amd.common.buffers import PlaceholderBufferWrapper
 from libertem_amd.common.backend import get_use_hip
 from .base import JobExecutor, Environment
 

@@ -23,7 +23,6 @@ from libertem_amd.common.shape import Shape
 from libertem_amd.common.slice import Slice
 from libertem_amd.common.udf import UDFMethod, UDFProtocol, NUMPY, HIP
 from libertem_amd.common.exceptions import UDFException
-from libertem_amd.common.hiparray import HipArray
 
 
 class DataSetException(Exception):

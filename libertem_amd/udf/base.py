@@ -20,7 +20,6 @@ there is no silent fallback: a HIP-only UDF on a CPU worker raises `HipRequiredE
 """
 import uuid
 import threading
-from collections import OrderedDict
 
 import numpy as np
 
@@ -31,10 +30,10 @@ from libertem_amd.common.buffers import (
     BufferWrapper, AuxBufferWrapper, PlaceholderBufferWrapper, PreallocBufferWrapper, HipSigView,
 )
 from libertem_amd.common.hiparray import HipArray
-from libertem_amd.common.udf import UDFProtocol, UDFMethod, NUMPY, HIP, CUPY, CUDA
+from libertem_amd.common.udf import UDFProtocol, UDFMethod, NUMPY, HIP
 from libertem_amd.common.exceptions import UDFException, UDFRunCancelled, JobCancelledError, \
     HipRequiredError
-from libertem_amd.io.dataset.base import Negotiator, TilingScheme
+from libertem_amd.io.dataset.base import Negotiator
 
 
 def check_cast(fromvar, tovar):
