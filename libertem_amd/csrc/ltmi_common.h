@@ -78,6 +78,9 @@ struct ltmi_masks {
     int n_groups64 = 0, n_chunks64 = 0;
     void *ws64 = nullptr;
     size_t ws64_bytes = 0;
+    void *res64 = nullptr;   // f64 scratch result of the exact-integer path
+    size_t res64_bytes = 0;
+    int mask_bits = 64;      // integer stacks: bits needed for max |mask value|
     void *shift_cache = nullptr;   // ltmi_dense.hip: images of the stack shifted by (dy, dx)
     float *partials = nullptr;
     size_t partials_bytes = 0;

@@ -979,6 +979,20 @@ extern "C" int ltmi_masks_create_dense(int device, const void *masks_host, int r
             }
             upload = buf.data();
         }
+        if (is_int) {
+            // largest |mask value|: decides whether sums stay exactly representable in f64
+            uint64_t absmax = 0;
+            const int64_t *d = (const int64_t *)upload;
+            const bool is_u64 = result_dtype == LTMI_U64;
+            for (size_t i = 0; i < n; ++i) {
+                const uint64_t a = is_u64 ? (uint64_t)d[i]
+                                          : (uint64_t)(d[i] < 0 ? -(d[i] + 1) + 1ull : d[i]);
+                absmax = std::max(absmax, a);
+            }
+            int bits = 0;
+            while (bits < 64 && (absmax >> bits) != 0) ++bits;
+            m->mask_bits = bits;
+        }
         hipError_t e = hipMalloc(&m->gmasks, n * acc_size);
         if (e == hipSuccess) e = hipMemcpy(m->gmasks, upload, n * acc_size, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
@@ -986,7 +1000,7 @@ extern "C" int ltmi_masks_create_dense(int device, const void *masks_host, int r
             LTMI_FAIL((int)e, "uploading the mask stack failed: %s", hipGetErrorString(e));
         }
     }
-    if (result_dtype == LTMI_F64) {
+    if (result_dtype == LTMI_F64 || (result_dtype >= LTMI_U8 && result_dtype <= LTMI_I64 && m->mask_bits <= 20)) {
         const int rc64 = ltmi::dense64_create(m);
         if (rc64 != LTMI_OK) {
             ltmi_masks_destroy(m);
@@ -1577,7 +1591,8 @@ extern "C" int ltmi_apply_masks(ltmi_masks *m, const void *tile, int tile_dtype,
             case LTMI_F32: return launch_mfma<float>(m, (const float *)tile, n_frames, ld_tile, o, ldo, accumulate, stream);
         }
     }
-    if (m->result_dtype == LTMI_F64) {
+    if (m->result_dtype == LTMI_F64 ||
+        (m->result_dtype >= LTMI_U8 && m->result_dtype <= LTMI_I64)) {
         bool handled = false;
         const int rc = ltmi::dense64_apply(m, tile, tile_dtype, n_frames, ld_tile, out, ld_out,
                                            accumulate, stream, &handled);

@@ -9,6 +9,7 @@
 // f64, XOR-swizzled like the f32 image) is shared by the workgroup through LDS, double buffered.
 #include "ltmi_common.h"
 #include <algorithm>
+#include <cstring>
 #include <typeinfo>
 
 namespace ltmi {
@@ -28,7 +29,8 @@ __host__ __device__ static inline int img64_index(int n, int q) {
     return n * KC64 + v * 2 + (j & 1);
 }
 
-__global__ void k_build_image64(const double *__restrict__ src, double *__restrict__ img,
+template <typename SRC>
+__global__ void k_build_image64(const SRC *__restrict__ src, double *__restrict__ img,
                                 int64_t n_masks, int64_t n_px, int n_chunks) {
     const int64_t total = n_masks * n_px;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -36,7 +38,7 @@ __global__ void k_build_image64(const double *__restrict__ src, double *__restri
         const int64_t k = i / n_px, p = i % n_px;
         const int g = (int)(k / 16), n = (int)(k % 16);
         const int c = (int)(p / KC64), q = (int)(p % KC64);
-        img[((size_t)g * n_chunks + c) * CH64 + img64_index(n, q)] = src[i];
+        img[((size_t)g * n_chunks + c) * CH64 + img64_index(n, q)] = (double)src[i];
     }
 }
 
@@ -167,8 +169,23 @@ __global__ void k_reduce_partials64(const double *__restrict__ partials, int ksp
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
+// exact integer sum (held in a double, |v| < 2^53) -> wrap-around integer of the result width,
+// the arithmetic NumPy's integer matmul performs (two's complement truncation)
+template <typename S>
+__global__ void k_f64_to_int(const double *__restrict__ src, int64_t n_frames, int n_masks,
+                             S *__restrict__ out, int64_t ld_out, int accumulate) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_frames * n_masks) return;
+    const int64_t f = idx / n_masks;
+    const int k = (int)(idx % n_masks);
+    const S v = (S)(uint64_t)(int64_t)src[idx];
+    S *p = out + f * ld_out + k;
+    *p = accumulate ? (S)(*p + v) : v;
+}
+
 int dense64_create(ltmi_masks *m) {
-    // m->gmasks holds the (n_masks, n_px) float64 stack on the device
+    // m->gmasks holds the (n_masks, n_px) stack on the device: float64, or int64 for integer
+    // result dtypes (then the image is only built if the masks are small, see dense64_apply)
     m->n_groups64 = (int)((m->n_masks + 15) / 16);
     m->n_chunks64 = (int)((m->n_px + KC64 - 1) / KC64);
     const size_t n = (size_t)m->n_groups64 * m->n_chunks64 * CH64;
@@ -176,8 +193,13 @@ int dense64_create(ltmi_masks *m) {
     LTMI_HIP(hipMemset(m->img64, 0, n * sizeof(double)));
     const int64_t total = m->n_masks * m->n_px;
     const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 65535 * 16);
-    hipLaunchKernelGGL(k_build_image64, dim3(blocks), dim3(256), 0, 0, (const double *)m->gmasks,
-                       m->img64, m->n_masks, m->n_px, m->n_chunks64);
+    if (m->result_dtype == LTMI_F64)
+        hipLaunchKernelGGL(k_build_image64<double>, dim3(blocks), dim3(256), 0, 0,
+                           (const double *)m->gmasks, m->img64, m->n_masks, m->n_px, m->n_chunks64);
+    else
+        hipLaunchKernelGGL(k_build_image64<int64_t>, dim3(blocks), dim3(256), 0, 0,
+                           (const int64_t *)m->gmasks, m->img64, m->n_masks, m->n_px,
+                           m->n_chunks64);
     LTMI_HIP(hipGetLastError());
     LTMI_HIP(hipDeviceSynchronize());
     return LTMI_OK;
@@ -186,8 +208,10 @@ int dense64_create(ltmi_masks *m) {
 void dense64_destroy(ltmi_masks *m) {
     if (m->img64) (void)hipFree(m->img64);
     if (m->ws64) (void)hipFree(m->ws64);
+    if (m->res64) (void)hipFree(m->res64);
     m->img64 = nullptr;
     m->ws64 = nullptr;
+    m->res64 = nullptr;
 }
 
 template <typename T>
@@ -247,25 +271,74 @@ static int launch64(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, 
 int dense64_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames, int64_t ld,
                   void *out, int64_t ld_out, int accumulate, hipStream_t stream, bool *handled) {
     *handled = false;
-    if (!m->img64 || m->result_dtype != LTMI_F64) return LTMI_OK;
+    if (!m->img64) return LTMI_OK;
+    const bool int_result = m->result_dtype >= LTMI_U8 && m->result_dtype <= LTMI_I64;
+    if (!int_result && m->result_dtype != LTMI_F64) return LTMI_OK;
     double *o = (double *)out;
+    int64_t ld_o = ld_out;
+    if (int_result) {
+        // Integer masks x integer frames (preferred_dtype / mask_dtype integer: NumPy integer matmul,
+        // wrap-around).  If every possible partial sum fits 2^52 the f64 FMA chain is EXACT, so the
+        // product runs on the f64 matrix cores into a scratch buffer and is then truncated to the
+        // result width -- bit-identical to integer arithmetic.  Otherwise: the integer VALU kernel.
+        int data_bits;
+        switch (tile_dtype) {
+            case LTMI_BOOL: data_bits = 1; break;
+            case LTMI_U8: case LTMI_I8: data_bits = 8; break;
+            case LTMI_U16: case LTMI_I16: data_bits = 16; break;
+            case LTMI_U32: case LTMI_I32: data_bits = 32; break;
+            default: return LTMI_OK;                      // 64-bit or non-integer tiles
+        }
+        int k_bits = 0;
+        while (((int64_t)1 << k_bits) < m->n_px) ++k_bits;
+        if (data_bits + m->mask_bits + k_bits > 52) return LTMI_OK;
+        const size_t need = (size_t)n_frames * m->n_masks * sizeof(double);
+        if (m->res64_bytes < need) {
+            if (m->res64) {
+                LTMI_HIP(hipStreamSynchronize(stream));
+                LTMI_HIP(hipFree(m->res64));
+                m->res64 = nullptr;
+                m->res64_bytes = 0;
+            }
+            LTMI_HIP(hipMalloc(&m->res64, need));
+            m->res64_bytes = need;
+        }
+        o = (double *)m->res64;
+        ld_o = m->n_masks;
+    }
+    const int acc64 = int_result ? 0 : accumulate;
     int rc;
     switch (tile_dtype) {
         case LTMI_BOOL:
-        case LTMI_U8: rc = launch64<uint8_t>(m, (const uint8_t *)tile, n_frames, ld, o, ld_out, accumulate, stream); break;
-        case LTMI_I8: rc = launch64<int8_t>(m, (const int8_t *)tile, n_frames, ld, o, ld_out, accumulate, stream); break;
-        case LTMI_U16: rc = launch64<uint16_t>(m, (const uint16_t *)tile, n_frames, ld, o, ld_out, accumulate, stream); break;
-        case LTMI_I16: rc = launch64<int16_t>(m, (const int16_t *)tile, n_frames, ld, o, ld_out, accumulate, stream); break;
-        case LTMI_U32: rc = launch64<uint32_t>(m, (const uint32_t *)tile, n_frames, ld, o, ld_out, accumulate, stream); break;
-        case LTMI_I32: rc = launch64<int32_t>(m, (const int32_t *)tile, n_frames, ld, o, ld_out, accumulate, stream); break;
-        case LTMI_U64: rc = launch64<uint64_t>(m, (const uint64_t *)tile, n_frames, ld, o, ld_out, accumulate, stream); break;
-        case LTMI_I64: rc = launch64<int64_t>(m, (const int64_t *)tile, n_frames, ld, o, ld_out, accumulate, stream); break;
-        case LTMI_F32: rc = launch64<float>(m, (const float *)tile, n_frames, ld, o, ld_out, accumulate, stream); break;
-        case LTMI_F64: rc = launch64<double>(m, (const double *)tile, n_frames, ld, o, ld_out, accumulate, stream); break;
+        case LTMI_U8: rc = launch64<uint8_t>(m, (const uint8_t *)tile, n_frames, ld, o, ld_o, acc64, stream); break;
+        case LTMI_I8: rc = launch64<int8_t>(m, (const int8_t *)tile, n_frames, ld, o, ld_o, acc64, stream); break;
+        case LTMI_U16: rc = launch64<uint16_t>(m, (const uint16_t *)tile, n_frames, ld, o, ld_o, acc64, stream); break;
+        case LTMI_I16: rc = launch64<int16_t>(m, (const int16_t *)tile, n_frames, ld, o, ld_o, acc64, stream); break;
+        case LTMI_U32: rc = launch64<uint32_t>(m, (const uint32_t *)tile, n_frames, ld, o, ld_o, acc64, stream); break;
+        case LTMI_I32: rc = launch64<int32_t>(m, (const int32_t *)tile, n_frames, ld, o, ld_o, acc64, stream); break;
+        case LTMI_U64: rc = launch64<uint64_t>(m, (const uint64_t *)tile, n_frames, ld, o, ld_o, acc64, stream); break;
+        case LTMI_I64: rc = launch64<int64_t>(m, (const int64_t *)tile, n_frames, ld, o, ld_o, acc64, stream); break;
+        case LTMI_F32: rc = launch64<float>(m, (const float *)tile, n_frames, ld, o, ld_o, acc64, stream); break;
+        case LTMI_F64: rc = launch64<double>(m, (const double *)tile, n_frames, ld, o, ld_o, acc64, stream); break;
         default: return LTMI_OK;           // complex tiles: generic kernel
     }
-    if (rc == LTMI_OK) *handled = true;
-    return rc;
+    if (rc != LTMI_OK) return rc;
+    if (int_result) {
+        const int64_t n = n_frames * m->n_masks;
+        const dim3 grid((unsigned)((n + 255) / 256));
+        const double *src = (const double *)m->res64;
+        switch (dtype_size(m->result_dtype)) {
+            case 1: hipLaunchKernelGGL(k_f64_to_int<uint8_t>, grid, dim3(256), 0, stream, src, n_frames, (int)m->n_masks, (uint8_t *)out, ld_out, accumulate); break;
+            case 2: hipLaunchKernelGGL(k_f64_to_int<uint16_t>, grid, dim3(256), 0, stream, src, n_frames, (int)m->n_masks, (uint16_t *)out, ld_out, accumulate); break;
+            case 4: hipLaunchKernelGGL(k_f64_to_int<uint32_t>, grid, dim3(256), 0, stream, src, n_frames, (int)m->n_masks, (uint32_t *)out, ld_out, accumulate); break;
+            default: hipLaunchKernelGGL(k_f64_to_int<uint64_t>, grid, dim3(256), 0, stream, src, n_frames, (int)m->n_masks, (uint64_t *)out, ld_out, accumulate); break;
+        }
+        LTMI_HIP(hipGetLastError());
+        const size_t len = strlen(m->last_kernel);
+        snprintf(m->last_kernel + len, sizeof(m->last_kernel) - len, " exact-int");
+    }
+    *handled = true;
+    return LTMI_OK;
 }
 
 }  // namespace ltmi

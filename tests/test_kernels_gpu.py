@@ -196,6 +196,8 @@ def test_generic(hip, combo):
     res, kern = _apply(hip, data, masks, result_dtype)
     if result_dtype == np.float64:
         assert 'k_dense_mfma_f64' in kern, kern    # float64 results: f64 matrix cores
+    elif result_dtype.kind in 'iu' and tile_dtype.itemsize <= 4:
+        assert 'exact-int' in kern, kern           # integer results, sums < 2^52: same cores, exact
     else:
         assert 'generic' in kern, kern
     ref = data.astype(result_dtype) @ masks.T      # NumPy's own product in the result dtype
@@ -235,6 +237,35 @@ def test_float64_results_on_matrix_cores(hip, tile_dtype, shape, ksplit):
     base = rng.random((n_frames, n_masks))
     res2, _ = _apply(hip, data, masks, np.float64, accumulate_into=base, tuning=tuning)
     assert np.all(np.abs(res2 - (ref + base)) <= 1e-13 * (scale + 1))
+
+
+@pytest.mark.parametrize('tile_dtype,result_dtype,mask_max,expect', [
+    ('int16', 'int32', 1, 'exact-int'),         # the reference's integer-sum case (0/1 masks)
+    ('uint16', 'int32', 200, 'exact-int'),
+    ('int32', 'int32', 1, 'exact-int'),         # wraps around in int32, still exact in f64
+    ('uint8', 'uint8', 3, 'exact-int'),         # wraps around in uint8
+    ('int32', 'int64', 100, 'exact-int'),
+    ('int32', 'int32', 2**30, 'generic'),       # sums beyond 2^52: integer VALU kernel
+    ('int64', 'int64', 1, 'generic'),           # 64-bit pixels: no bound on the products
+])
+def test_integer_results_bit_exact(hip, tile_dtype, result_dtype, mask_max, expect):
+    """Integer masks x integer frames = NumPy integer matmul with wrap-around, bit for bit; on the
+    f64 matrix cores whenever every partial sum is exactly representable."""
+    rng = np.random.default_rng(hash((tile_dtype, result_dtype, mask_max)) % (2**32))
+    n_frames, n_px, n_masks = 90, 256 * 11 + 64, 7
+    dt, rd = np.dtype(tile_dtype), np.dtype(result_dtype)
+    info = np.iinfo(dt)
+    data = rng.integers(max(info.min, -2**31), min(info.max, 2**31 - 1), (n_frames, n_px),
+                        endpoint=True).astype(dt)
+    lo = 0 if rd.kind == 'u' else -mask_max
+    masks = rng.integers(lo, mask_max, (n_masks, n_px), endpoint=True).astype(rd)
+    res, kern = _apply(hip, data, masks, rd)
+    assert expect in kern, kern
+    ref = data.astype(rd) @ masks.T                  # NumPy's integer arithmetic in the result dtype
+    assert res.dtype == ref.dtype and np.array_equal(res, ref)
+    base = rng.integers(0, 100, (n_frames, n_masks)).astype(rd)
+    res2, _ = _apply(hip, data, masks, rd, accumulate_into=base)
+    assert np.array_equal(res2, ref + base)
 
 
 @pytest.mark.parametrize('case', recipes.DENSE_CASES, ids=lambda c: c['name'])
