@@ -18,10 +18,26 @@ class SumSigUDF(UDF):
         dtype = np.result_type(self.meta.input_dtype, np.float32)
         return {'intensity': self.buffer(kind="nav", dtype=dtype, where='device')}
 
+    def folds_corrections(self, corrections, meta):
+        """Per-frame sum of CORRECTED pixels = one weighted sum of the RAW pixels: the corrections
+        fold into a single mask w = R^T(1) * gain and a constant w . dark (see udf/masks.py)."""
+        import libertem_amd.udf.masks as um
+        return bool(um.FOLD_CORRECTIONS) and \
+            np.dtype(np.result_type(meta.input_dtype, np.float32)) == np.float32
+
     def get_task_data(self):
         if self.meta.array_backend != self.BACKEND_HIP:
             raise HipRequiredError("SumSigUDF needs BACKEND_HIP (an MI355X worker)")
-        return {}
+        if getattr(self.meta, 'corrections_folded', False):
+            from libertem_amd.udf.masks import ApplyMasksEngine, _cached_container, _folded_plan
+            sig = tuple(self.meta.dataset_shape.sig)
+            ones = _ones_factory(sig)
+            plain = _cached_container(ones, np.float32, False, 1, 'scipy.sparse')
+            folded, plan_state = _folded_plan(self.meta.corrections, plain, ones, sig, 1)
+            engine = ApplyMasksEngine(plain, self.meta, True)
+            engine.fold(folded, plan_state)
+            return {'engine': engine}
+        return {'engine': None}
 
     def process_tile(self, tile):
         # results.intensity[:] += tile.reshape(n, -1).sum(axis=1)   (udf/sumsigudf.py:30-39)
@@ -32,11 +48,28 @@ class SumSigUDF(UDF):
         if out.dtype.kind != 'f':
             raise NotImplementedError(f"SumSigUDF: result dtype {out.dtype} not supported yet")
         n = tile.shape[0]
+        if self.task_data.engine is not None:
+            self.task_data.engine.process_tile(tile, out=out.reshape((n, 1)), accumulate=True)
+            return
         hip.sum_sig(tile.device, tile.data_ptr(), tile.dtype, n, prod(tile.shape[1:]), tile.ld,
                     out.data_ptr(), out.dtype, True)
 
     def get_dist_merge(self):
         return {'intensity': 'disjoint'}
+
+
+_ONES = {}
+
+
+def _ones_factory(sig):
+    """One all-ones mask of the signal shape; the factory object is kept so that the mask-stack
+    caches (keyed by factory identity) hit across tasks and runs."""
+    f = _ONES.get(sig)
+    if f is None:
+        def f():
+            return np.ones((1,) + tuple(sig), dtype=np.float32)
+        _ONES[sig] = f
+    return f
 
 
 def run_sumsig(ctx, dataset):

@@ -498,7 +498,7 @@ def test_corrections_vs_reference_golden(ctx, golden_dir, case, resident):
     udfs = {'sum': SumUDF(), 'sumsig': SumSigUDF(),
             'masks': ApplyMasksUDF(mask_factories=lambda: masks, use_sparse=False)}
     for name, udf in udfs.items():
-        for fold in ((True, False) if name in ('masks', 'sum') else (True,)):
+        for fold in (True, False):
             um.FOLD_CORRECTIONS = fold
             hip.KernelTimer.start()
             try:
