@@ -549,3 +549,15 @@ def test_three_groups_plus_valu_columns(hip, tile_dtype, n_masks, mask_dtype, ks
     res4, kern4 = _apply(hip, data, masks, md, tuning=dict(mt=0, waves=33, ksplit=ksplit))
     assert 'NG=4' in kern4, kern4
     assert np.all(np.abs(res4 - res) <= 2e-5 * scale + 1e-30)
+
+
+@pytest.mark.parametrize('seed', [101, 202])
+def test_randomised_differential(seed):
+    """scripts/fuzz_kernels.py: random shapes / dtypes / leading dimensions / accumulate / K split /
+    shifts / sparse stacks through every kernel family, against NumPy."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'fuzz_kernels.py'), '250',
+                        str(seed)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
