@@ -2,6 +2,8 @@
 GPU parity of the C-ABI kernels (through ctypes) against the oracle / float64 NumPy on the same
 seeded inputs.  `-m gpu` only.
 """
+import os
+
 import numpy as np
 import pytest
 
