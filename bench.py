@@ -215,11 +215,13 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (uint16 frames converted in-kernel, f32 MFMA accumulate)",
+            "dtype": "f32",
             "data": "synthetic (device-generated uint16 counts in [0,4096), resident in HBM)",
             "config": {
                 "workload": cfg['desc'] + f", per GPU; {world} GPU(s), nav-sharded (weak)",
                 "frames_per_gpu": n_frames, "frame_bytes": n_px * itemsize,
+                "arithmetic": "uint16 frames converted to f32 in-kernel, exact f32 FMA chain on the "
+                              "matrix cores (v_mfma_f32_16x16x4_f32), f32 masks and results",
                 "step": "Context.run_udf (plan + kernel + device merge + gather + D2H)",
                 "parallelism": f"nav-shard x{world}" + (" + RCCL all-gather" if world > 1 else ""),
             },
