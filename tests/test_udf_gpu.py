@@ -776,3 +776,28 @@ def test_raw_file_dataset_on_device(ctx, tmp_path):
     res = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda: masks))
     ref = opath.apply_masks(data, masks, num_partitions=3)
     assert _close(res['intensity'].data, ref, F32_TOL)
+
+
+def test_shifted_masks_with_roi_and_partitions(ctx):
+    """per-frame shifts (aux data) are re-sliced per partition and compressed by the ROI"""
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    rng = np.random.default_rng(77)
+    nav, sig = (5, 6), (16, 32)
+    data = rng.integers(0, 900, nav + sig).astype(np.uint16)
+    masks = rng.random((4,) + sig).astype(np.float32)
+    shifts = rng.integers(-5, 6, nav + (2,))
+    roi = rng.random(nav) < 0.6
+    roi[0, 0] = True
+    ref_all = _shift_naive(masks.astype(np.float64), data.reshape((-1,) + sig).astype(np.float64),
+                           shifts.reshape((-1, 2)))
+    for resident in ('host', 'device'):
+        ds = _device_ds(ctx, data, 3) if resident == 'device' else \
+            ctx.load('memory', data=data, num_partitions=3, sig_dims=2)
+        udf = ApplyMasksUDF(mask_factories=lambda: masks,
+                            shifts=ApplyMasksUDF.aux_data(shifts.reshape((-1, 2)).ravel(),
+                                                          kind='nav', extra_shape=(2,), dtype=int))
+        full = ctx.run_udf(dataset=ds, udf=udf)['intensity'].data
+        assert _close(full.reshape((-1, 4)), ref_all, F32_TOL)
+        part = ctx.run_udf(dataset=ds, udf=udf, roi=roi)['intensity']
+        assert _close(part.raw_data, ref_all[roi.reshape(-1)], F32_TOL)
+        assert np.all(np.isnan(part.data[~roi]))
