@@ -9,19 +9,27 @@ class Shape:
     __slots__ = ('_t', '_sig_dims')
 
     def __init__(self, shape, sig_dims):
-        self._t = tuple(int(s) for s in shape)
+        self._t = tuple(map(int, shape))
         self._sig_dims = int(sig_dims)
         if self._sig_dims < 0 or self._sig_dims > len(self._t):
             raise ValueError(f"invalid sig_dims {sig_dims} for shape {self._t}")
 
+    @classmethod
+    def _trusted(cls, t, sig_dims):
+        """internal: `t` is already a tuple of Python ints, `sig_dims` is valid"""
+        obj = cls.__new__(cls)
+        obj._t = t
+        obj._sig_dims = sig_dims
+        return obj
+
     # --- parts -------------------------------------------------------------------------------
     @property
     def nav(self):
-        return NavOnlyShape(self._t[:len(self._t) - self._sig_dims])
+        return NavOnlyShape._trusted(self._t[:len(self._t) - self._sig_dims], 0)
 
     @property
     def sig(self):
-        return SigOnlyShape(self._t[len(self._t) - self._sig_dims:])
+        return SigOnlyShape._trusted(self._t[len(self._t) - self._sig_dims:], self._sig_dims)
 
     @property
     def sig_dims(self):
@@ -43,12 +51,12 @@ class Shape:
         return self._t
 
     def flatten_nav(self):
-        nav = self._t[:self.nav_dims]
-        return Shape((prod(nav),) + self._t[self.nav_dims:], sig_dims=self._sig_dims)
+        nd = len(self._t) - self._sig_dims
+        return Shape._trusted((prod(self._t[:nd]),) + self._t[nd:], self._sig_dims)
 
     def flatten_sig(self):
-        sig = self._t[self.nav_dims:]
-        return Shape(self._t[:self.nav_dims] + (prod(sig),), sig_dims=1)
+        nd = len(self._t) - self._sig_dims
+        return Shape._trusted(self._t[:nd] + (prod(self._t[nd:]),), 1)
 
     # --- container protocol --------------------------------------------------------------------
     def __iter__(self):

@@ -6,6 +6,19 @@ import contextlib
 
 
 _NULL_CONTEXT = contextlib.nullcontext()
+_THREADPOOL_CTL = [False]          # False: not looked up yet; None: threadpoolctl unavailable
+
+
+def _threadpool_controller():
+    """One ThreadpoolController for the process: discovering the loaded BLAS / OpenMP libraries
+    costs ~1 ms, limiting them through a known controller a few microseconds."""
+    if _THREADPOOL_CTL[0] is False:
+        try:
+            from threadpoolctl import ThreadpoolController
+            _THREADPOOL_CTL[0] = ThreadpoolController()
+        except Exception:
+            _THREADPOOL_CTL[0] = None
+    return _THREADPOOL_CTL[0]
 
 
 class Environment:
@@ -58,11 +71,9 @@ class Environment:
         ctxs = contextlib.ExitStack()
         with ctxs:
             if self._threads_per_worker is not None:
-                try:
-                    from threadpoolctl import threadpool_limits
-                    ctxs.enter_context(threadpool_limits(limits=self._threads_per_worker))
-                except Exception:
-                    pass
+                ctl = _threadpool_controller()
+                if ctl is not None:
+                    ctxs.enter_context(ctl.limit(limits=self._threads_per_worker))
             if enable_gpu and self._gpu_id is not None:
                 import torch
                 ctxs.enter_context(torch.cuda.device(self._gpu_id))

@@ -12,6 +12,15 @@ import psutil
 from .base import JobExecutor, Environment
 
 
+_CORES = []
+
+
+def _physical_cores():
+    if not _CORES:
+        _CORES.append(psutil.cpu_count(logical=False) or 1)
+    return _CORES[0]
+
+
 class InlineJobExecutor(JobExecutor):
     device_class = 'cpu'
 
@@ -23,7 +32,7 @@ class InlineJobExecutor(JobExecutor):
     def get_local_env(self):
         threads = self._inline_threads
         if threads is None:
-            threads = psutil.cpu_count(logical=False) or 1
+            threads = _physical_cores()
         return Environment(threads_per_worker=threads, threaded_executor=False, gpu_id=None)
 
     def scatter(self, obj):
