@@ -480,3 +480,76 @@ def test_raw_file_dataset(ctx, tmp_path):
                  sig_shape=(8, 8))
     with pytest.raises(DataSetException):
         ctx.load('hdf5', path=path)
+
+
+# --- crystallinity host helpers ---------------------------------------------------------------------
+@pytest.mark.parametrize('sig,rad_in,rad_out,center,rad', [
+    ((32, 32), 4, 9, (16, 16), 5), ((24, 40), 3, 8, None, None), ((33, 31), 2.5, 11.5, (10.5, 20.25), 4),
+])
+def test_crystallinity_masks_and_bounding_box(sig, rad_in, rad_out, center, rad):
+    """The masks CrystallinityUDF uploads (reference udf/crystallinity.py:47-71) and the bounding
+    box the reduction kernel is restricted to."""
+    from libertem_amd.udf.crystallinity import crystallinity_masks, mask_box
+    real_mask, half = crystallinity_masks(sig, rad_in, rad_out, center, rad)
+    sy, sx = sig
+    yy, xx = np.ogrid[-sy * 0.5:sy - sy * 0.5, -sx * 0.5:sx - sx * 0.5]
+    ring = 1 * (yy * yy + xx * xx <= rad_out ** 2) - 1 * (yy * yy + xx * xx <= rad_in ** 2)
+    expect = np.fft.fftshift(ring)[:, :int(sx * 0.5) + 1]
+    assert half.shape == (sy, sx // 2 + 1) and np.array_equal(half, expect)
+    if center is None:
+        assert real_mask is None
+    else:
+        y, x = np.ogrid[-center[0]:sy - center[0], -center[1]:sx - center[1]]
+        assert np.array_equal(real_mask, 1 - 1 * (y * y + x * x <= rad * rad))
+    lo, hi, nc = mask_box(half)
+    boxed = np.zeros_like(half)
+    boxed[:lo, :nc] = half[:lo, :nc]
+    boxed[hi:, :nc] = half[hi:, :nc]
+    assert np.array_equal(boxed, half)                 # nothing outside the box
+    assert 0 <= lo <= hi <= sy and 0 < nc <= sx // 2 + 1
+    assert mask_box(np.ones((6, 4))) == (6, 6, 4)      # no structure: every row, every column
+    assert mask_box(np.zeros((6, 4))) == (0, 6, 0)
+
+
+def test_fold_corrections_into_masks_identity():
+    """masks' . x - const == masks . corrected(x) for random frames (the linear-algebra identity
+    behind the folded corrections of ApplyMasksUDF / CoMUDF / SumSigUDF), incl. dead pixels on the
+    border, adjacent dead pixels and one without any good neighbour (allow_empty)."""
+    from oracle import corrections as oc
+    from libertem_amd.io.corrections import CorrectionSet
+    from libertem_amd.udf.masks import fold_corrections_into_masks
+    rng = np.random.default_rng(8)
+    sig = (9, 11)
+    bad = np.zeros(sig, dtype=bool)
+    for y, x in [(0, 0), (4, 5), (4, 6), (8, 10), (2, 0)]:
+        bad[y, x] = True
+    dark = rng.random(sig) * 5
+    gain = rng.random(sig) + 0.5
+    masks = rng.random((4,) + sig) - 0.3
+    frames = rng.random((6,) + sig) * 100
+    coords = [tuple(c) for c in np.argwhere(bad)]
+    for kw in (dict(dark=dark, gain=gain, excluded_pixels=bad), dict(gain=gain), dict(dark=dark),
+               dict(excluded_pixels=bad)):
+        corr = CorrectionSet(**kw)
+        folded, const = fold_corrections_into_masks(masks, corr, sig)
+        corrected = oc.correct(frames, sig, dark=kw.get('dark'), gain=kw.get('gain'),
+                               coords=coords if 'excluded_pixels' in kw else None,
+                               out_dtype=np.float64)
+        want = np.tensordot(corrected, masks, axes=([1, 2], [1, 2]))
+        got = np.tensordot(frames, folded, axes=([1, 2], [1, 2]))
+        if const is not None:
+            got = got - const[None, :]
+        else:
+            assert 'dark' not in kw
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-9)
+    # 1-D signal where pixel 2 has no good neighbour: it stays unpatched (as in `correct`)
+    line = np.zeros(7, dtype=bool)
+    line[1:4] = True
+    corr = CorrectionSet(excluded_pixels=line, gain=np.full(7, 2.0), allow_empty=True)
+    m = rng.random((2, 7))
+    folded, const = fold_corrections_into_masks(m, corr, (7,))
+    x = rng.random((3, 7))
+    corrected = oc.correct(x, (7,), gain=np.full(7, 2.0), coords=[(1,), (2,), (3,)],
+                           out_dtype=np.float64)
+    np.testing.assert_allclose(x @ folded.T, corrected @ m.T, rtol=1e-12)
+    assert const is None
