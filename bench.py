@@ -202,7 +202,7 @@ def main():
         # committed profile of exactly this kernel and shape is quoted, scaled by the frame count.
         traffic, traffic_src = None, None
         if 'k_dense_lds' in kname and args.config == 'c2':
-            traffic = (8.7039e9 + 4.2e6) * frames_per_launch / 65536.0
+            traffic = (4.3522e9 + 2.1e6) * frames_per_launch / 32768.0
             traffic_src = "profiles/r01_final_bench_rocprof.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
         out = {
             "metric": "frames/sec, ApplyMasksUDF 16 dense f32 masks (+ GB/s vs HBM roofline)",

@@ -28,7 +28,7 @@ class Environment:
     """
 
     def __init__(self, threads_per_worker=None, threaded_executor=False, gpu_id=None,
-                 keep_results_on_device=False, stream=None, ensure_current=None):
+                 keep_results_on_device=False, stream=None, ensure_current=None, row_sink=None):
         self._threads_per_worker = threads_per_worker
         self._threaded_executor = threaded_executor
         self._gpu_id = gpu_id
@@ -39,6 +39,9 @@ class Environment:
         # callable that makes (gpu_id, stream) torch's current device/stream WITHOUT a context
         # manager (the HIP executor owns the process's device: one process per GPU)
         self._ensure_current = ensure_current
+        # callable(udf_index, buffer name, rows: HipArray, global_row_start) or None: finished rows
+        # of disjoint nav buffers are copied to the host while later tiles are still computing
+        self.row_sink = row_sink
 
     @property
     def threads_per_worker(self):

@@ -137,7 +137,8 @@ class HipJobExecutor(JobExecutor):
         return Environment(threads_per_worker=None, threaded_executor=False, gpu_id=self.gpu_id,
                            keep_results_on_device=(self.gpu_id is not None), stream=self._stream,
                            ensure_current=(self._make_current if self.gpu_id is not None
-                                           else None))
+                                           else None),
+                           row_sink=getattr(self, '_row_sink', None))
 
     def scatter(self, obj):
         handle = str(uuid.uuid4())
@@ -197,6 +198,39 @@ class HipJobExecutor(JobExecutor):
             else:
                 plans.append(('generic', None))
 
+        # Streamed export (single rank): rows of 'disjoint' nav buffers go to their final place in
+        # page-locked host memory on a copy stream while later tiles / partitions still compute.
+        streamed = {}                           # (udf index, name) -> [pinned tensor, rows covered]
+        self._row_sink = None
+        if self.gpu_id is not None and not self._collectives_on and not partial:
+            import torch as _torch
+            if getattr(self, '_copy_stream', None) is None:
+                self._copy_stream = _torch.cuda.Stream(device=self.gpu_id)
+            copy_stream = self._copy_stream
+
+            def row_sink(i, name, rows, g0):
+                mode, decl = plans[i]
+                buf = udfs[i].results.get_buffer(name)
+                if mode != 'device' or decl.get(name) != 'disjoint' or rows.shape[0] == 0:
+                    return
+                key = (i, name)
+                if key not in streamed:
+                    streamed[key] = [_torch.empty(buf.shape, dtype=torch_dtype_for(buf.dtype),
+                                                  pin_memory=True), 0]
+                host, _ = streamed[key]
+                n = rows.shape[0]
+                inner = int(np.prod(buf.shape[1:])) if len(buf.shape) > 1 else 1
+                if not rows.is_contiguous:
+                    return
+                src = rows.torch.reshape(-1)[:n * inner].reshape((n,) + tuple(buf.shape[1:]))
+                ev = _torch.cuda.Event()
+                ev.record(self._stream)
+                with _torch.cuda.stream(copy_stream):
+                    copy_stream.wait_event(ev)
+                    host[g0:g0 + n].copy_(src, non_blocking=True)
+                streamed[key][1] += n
+            self._row_sink = row_sink
+
         dev_full = [dict() for _ in udfs]       # per udf: name -> torch tensor (full size)
         generic_parts = []                      # (task, {udf idx: exported results})
         torch = None
@@ -212,6 +246,15 @@ class HipJobExecutor(JobExecutor):
                 for name, how in decl.items():
                     buf = udf.results.get_buffer(name)
                     if isinstance(buf, PlaceholderBufferWrapper):
+                        continue
+                    st = streamed.get((i, name))
+                    if st is not None and final and st[1] == buf.shape[0]:
+                        # every row already went out through the copy stream
+                        self._copy_stream.synchronize()
+                        host = st[0].numpy()
+                        if host.dtype != buf.dtype:
+                            host = host.view(buf.dtype)
+                        buf.replace_array(host)
                         continue
                     full = dev_full[i].get(name)
                     self._make_current()
@@ -295,6 +338,7 @@ class HipJobExecutor(JobExecutor):
                 damage.get_view_for_partition(task.partition)[:] = True
         if self._stream is not None:
             self._stream.synchronize()
+        self._row_sink = None
         yield n_done
 
     def _to_host(self, t):

@@ -144,6 +144,9 @@ class Negotiator:
     #: the (immutable) scheme instead of re-building its slices
     _hip_scheme_cache = {}
 
+    #: streamed result export: tiles per device-resident partition and frames a tile must keep
+    HIP_PIPELINE_TILES = 2
+    HIP_PIPELINE_MIN_FRAMES = 32768
     #: corrected tiles are written to a device scratch buffer of at most this many bytes
     HIP_CORRECTED_CHUNK = 1 * 2**30
 
@@ -161,7 +164,8 @@ class Negotiator:
                ds_shape.sig_dims, np.dtype(dataset.dtype).itemsize,
                bool(dataset.is_device_resident), int(approx_partition_shape[0]),
                self.HIP_TILE_BUDGET, self.HIP_STAGING_CHUNK,
-               np.dtype(read_dtype).itemsize if corrected else 0, self.HIP_CORRECTED_CHUNK)
+               np.dtype(read_dtype).itemsize if corrected else 0, self.HIP_CORRECTED_CHUNK,
+               self.HIP_PIPELINE_TILES, self.HIP_PIPELINE_MIN_FRAMES)
         hit = self._hip_scheme_cache.get(key)
         if hit is None:
             if len(self._hip_scheme_cache) > 64:
@@ -181,6 +185,12 @@ class Negotiator:
             budget = self.HIP_TILE_BUDGET if dataset.is_device_resident \
                 else self.HIP_STAGING_CHUNK
             depth = max(1, min(int(approx_partition_shape[0]), budget // max(1, frame_bytes)))
+            if dataset.is_device_resident and depth >= 2 * self.HIP_PIPELINE_MIN_FRAMES:
+                # a few tiles per partition so that the D2H of finished result rows overlaps the
+                # kernels of the next tile; never fewer frames than fill the chip twice over
+                n_tiles = min(self.HIP_PIPELINE_TILES, depth // self.HIP_PIPELINE_MIN_FRAMES)
+                depth = -(-depth // n_tiles)
+                depth = -(-depth // 128) * 128
             if corrected_itemsize:
                 # corrected frames (float) go through a bounded scratch buffer
                 depth = max(1, min(depth, self.HIP_CORRECTED_CHUNK //

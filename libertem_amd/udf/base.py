@@ -785,9 +785,33 @@ class UDFPartRunner:
             else params.corrections)
         methods = [udf.get_method() for udf in self._udfs]
         partition_udfs = [u for u, m in zip(self._udfs, methods) if m == UDFMethod.PARTITION]
+        sink = getattr(env, 'row_sink', None)
+        sinkable = None
+        if sink is not None and backend == HIP and len(tiling_scheme) == 1:
+            # tiles are whole frames: the rows of a tile in a 'disjoint' nav buffer are final as
+            # soon as its kernels are enqueued -> start their D2H now (UDFs that touch their
+            # buffers again in postprocess() are left to the normal export)
+            sinkable = []
+            for i, (udf, method) in enumerate(zip(self._udfs, methods)):
+                decl = getattr(udf, 'get_dist_merge', lambda: None)()
+                if decl is None or method != UDFMethod.TILE or hasattr(udf, 'postprocess'):
+                    continue
+                names = [k for k, how in decl.items() if how == 'disjoint']
+                names = [k for k in names if isinstance(udf.results.get_buffer(k), BufferWrapper)
+                         and udf.results.get_buffer(k).on_device
+                         and udf.results.get_buffer(k).kind == 'nav']
+                if names:
+                    sinkable.append((i, udf, names))
         for tile in tiles:
             for udf, method in zip(self._udfs, methods):
                 self._run_tile(udf, method, partition, tile)
+            if sinkable:
+                for i, udf, names in sinkable:
+                    for name in names:
+                        buf = udf.results.get_buffer(name)
+                        start, stop = buf._tile_rows(partition, tile)
+                        g0, _ = buf._slice_for_partition(partition)
+                        sink(i, name, buf._rows(start, stop), g0 + start)
         for udf in self._udfs:
             udf.flush(self._debug)
 
