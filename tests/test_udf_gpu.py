@@ -801,3 +801,35 @@ def test_shifted_masks_with_roi_and_partitions(ctx):
         part = ctx.run_udf(dataset=ds, udf=udf, roi=roi)['intensity']
         assert _close(part.raw_data, ref_all[roi.reshape(-1)], F32_TOL)
         assert np.all(np.isnan(part.data[~roi]))
+
+
+def test_streamed_export_with_several_tiles(ctx):
+    """Device-resident partitions split into tiles (pipelining policy) with the finished rows
+    exported through the copy stream: dense, sparse and per-frame-sum results, ROI, 2 partitions."""
+    from libertem_amd.io.dataset.base import Negotiator
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd.udf.sumsigudf import SumSigUDF
+    from libertem_amd import hip
+    rng = np.random.default_rng(21)
+    data = rng.integers(0, 2000, (30, 25, 16, 16)).astype(np.uint16)        # 750 frames
+    masks = rng.random((5, 16, 16)).astype(np.float32)
+    old = (Negotiator.HIP_PIPELINE_MIN_FRAMES, Negotiator.HIP_PIPELINE_TILES)
+    Negotiator.HIP_PIPELINE_MIN_FRAMES, Negotiator.HIP_PIPELINE_TILES = 64, 3
+    Negotiator._hip_scheme_cache.clear()
+    try:
+        ds = _device_ds(ctx, data, 2)
+        hip.KernelTimer.start()
+        res = ctx.run_udf(dataset=ds, udf=[ApplyMasksUDF(mask_factories=lambda: masks),
+                                           SumSigUDF()])
+        launches = hip.KernelTimer.stop()
+        assert len(launches) >= 4, launches            # 2 partitions x >= 2 tiles
+        ref = opath.apply_masks(data, masks, num_partitions=2)
+        assert _close(res[0]['intensity'].data, ref, F32_TOL)
+        assert np.array_equal(res[1]['intensity'].data,
+                              data.reshape((30, 25, -1)).sum(axis=-1).astype(np.float32))
+        roi = rng.random((30, 25)) < 0.5
+        part = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda: masks), roi=roi)
+        assert _close(part['intensity'].raw_data, ref[roi], F32_TOL)
+    finally:
+        Negotiator.HIP_PIPELINE_MIN_FRAMES, Negotiator.HIP_PIPELINE_TILES = old
+        Negotiator._hip_scheme_cache.clear()
