@@ -165,18 +165,19 @@ class Negotiator:
                bool(dataset.is_device_resident), int(approx_partition_shape[0]),
                self.HIP_TILE_BUDGET, self.HIP_STAGING_CHUNK,
                np.dtype(read_dtype).itemsize if corrected else 0, self.HIP_CORRECTED_CHUNK,
-               self.HIP_PIPELINE_TILES, self.HIP_PIPELINE_MIN_FRAMES)
+               self.HIP_PIPELINE_TILES, self.HIP_PIPELINE_MIN_FRAMES,
+               tuple(getattr(u, 'get_hip_tile_frames', lambda: None)() for u in udfs))
         hit = self._hip_scheme_cache.get(key)
         if hit is None:
             if len(self._hip_scheme_cache) > 64:
                 self._hip_scheme_cache.clear()
             hit = self._hip_scheme_cache[key] = self._make_scheme_hip(
                 intent, forced, dataset, approx_partition_shape,
-                np.dtype(read_dtype).itemsize if corrected else 0)
+                np.dtype(read_dtype).itemsize if corrected else 0, udfs)
         return hit
 
     def _make_scheme_hip(self, intent, forced, dataset, approx_partition_shape,
-                         corrected_itemsize=0):
+                         corrected_itemsize=0, udfs=()):
         ds_sig = tuple(dataset.shape.sig)
         if forced is not None and intent == 'tile':
             tileshape = tuple(forced)
@@ -185,7 +186,12 @@ class Negotiator:
             budget = self.HIP_TILE_BUDGET if dataset.is_device_resident \
                 else self.HIP_STAGING_CHUNK
             depth = max(1, min(int(approx_partition_shape[0]), budget // max(1, frame_bytes)))
-            if dataset.is_device_resident and depth >= 2 * self.HIP_PIPELINE_MIN_FRAMES:
+            hints = [h for h in (getattr(u, 'get_hip_tile_frames', lambda: None)() for u in udfs)
+                     if h]
+            if dataset.is_device_resident and hints and depth > min(hints):
+                # a UDF with large result rows asks for smaller tiles (more D2H / compute overlap)
+                depth = max(1024, -(-min(hints) // 128) * 128)
+            elif dataset.is_device_resident and depth >= 2 * self.HIP_PIPELINE_MIN_FRAMES:
                 # a few tiles per partition so that the D2H of finished result rows overlaps the
                 # kernels of the next tile; never fewer frames than fill the chip twice over
                 n_tiles = min(self.HIP_PIPELINE_TILES, depth // self.HIP_PIPELINE_MIN_FRAMES)

@@ -294,6 +294,17 @@ class ApplyMasksUDF(UDF):
             return False
         return True
 
+    def get_hip_tile_frames(self):
+        """Tiling hint for the MI355X policy: sparse stacks with wide result rows (>= 1 KiB per
+        frame, e.g. 1024 ring masks = 4 KiB) are run in tiles of 16384 frames so that the D2H of
+        finished result rows overlaps the next tile's kernel (io/dataset/base.py)."""
+        try:
+            count = int(self.get_mask_count())
+            sparse = self.masks.use_sparse is not False
+        except Exception:
+            return None
+        return 16384 if sparse and count * 4 >= 1024 else None
+
     def get_task_data(self):
         engine = ApplyMasksEngine(self.masks, self.meta, self.params.use_torch)
         if getattr(self.meta, 'corrections_folded', False):
