@@ -1,0 +1,531 @@
+// Sparse mask stacks on the matrix cores of gfx950 (MI355X): blocked-ELL image + v_mfma_f32_16x16x4_f32.
+//
+//   out[f, k] (+)= sum_p tile[f, p] * M[p, k],   M sparse (n_px x n_masks)
+//
+// Same job as k_sell_apply in ltmi_sparse.hip (the replacement of the numba kernels _rmatmul_csr /
+// _rmatmul_csc, src/libertem/common/numba/__init__.py:153-184, reached from
+// MaskContainer/ApplyMasksUDF, src/libertem/udf/masks.py:296-338), for stacks whose masks are
+// LOCALISED: neighbouring masks share pixels (ring / radial-bin stacks, src/libertem/masks.py
+// radial_bins; BASELINE.json config C4).  There a group of 16 consecutive masks touches few
+// pixels of a pixel chunk and those pixels are used by several masks of the group, so the
+// (16 masks x touched pixels) block is worth multiplying densely:
+//
+//   * image: for every (pixel chunk of 512 px, group of 16 masks) the sorted list of touched pixels,
+//     padded to a multiple of 8, and the dense 16 x n block of mask values.  Two MFMA steps
+//     (2 x 4 pixels) form one 768-byte "block record": lane l holds A[mask l&15][pixel l>>4] of
+//     both steps and the two pixel numbers of its l>>4.  C4: 3.65 multiply-adds per stored mask
+//     value, but on the matrix pipe and with ONE LDS read per 16 multiply-adds (the SELL kernel
+//     needs an LDS gather per multiply-add and is bound by that).
+//   * a workgroup = 4 waves owns 16*TILES frames (TILES = 2 for 1/2-byte pixels, 1 for float32) and
+//     1024 masks: wave j owns the groups g with g % 4 == j (16 of them -> 16 x TILES accumulator
+//     tiles in registers for the whole sweep; interleaving the groups balances ring stacks, where
+//     the groups touching a pixel chunk are consecutive).  The frames' chunk is copied
+//     global -> LDS by the LDS-DMA (global_load_lds_dwordx4), raw pixel type, double buffered; the
+//     B operand of a step is one ds_read of the pixel type + conversion.
+//   * the block records of a wave are ONE linear stream in execution order (chunk, group, step), so
+//     the wave prefetches them through a register ring that runs ahead across group and chunk
+//     boundaries; L2 serves the stream (every workgroup reads the same one).
+//   * two workgroups per CU: the record loads of a wave queue behind its own frame DMA (vmcnt
+//     retires in order) once per chunk, the other workgroup computes meanwhile.
+//
+// Complex masks are stored as 2 real masks (re, im interleaved) -- the result row is the
+// interleaved complex64 row.  Results are float32 sums in a different order than the SELL kernel;
+// both are within the 1e-5 relative tolerance of the float64 oracle.
+#include "ltmi_common.h"
+#include <vector>
+#include <algorithm>
+#include <cstring>
+#include <cstdlib>
+#include <type_traits>
+#include <typeinfo>
+
+namespace ltmi {
+
+typedef float bf32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int bu32x3 __attribute__((ext_vector_type(3)));
+typedef __attribute__((address_space(3))) void *b_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *b_glb_ptr_t;
+
+#ifndef BE_P_
+#define BE_P_ 512
+#endif
+#ifndef BE_OCC
+#define BE_OCC 2
+#endif
+constexpr int BE_P = BE_P_;          // pixels per chunk
+constexpr int BE_SETS = 4;           // waves per workgroup = interleaved group sets
+constexpr int BE_SLOTS = 16;         // groups per wave
+constexpr int BE_PASS = BE_SETS * BE_SLOTS * 16;     // real masks per pass (1024)
+#ifndef BE_D_
+#define BE_D_ 3
+#endif
+#ifndef BE_PIPE
+#define BE_PIPE 0
+#endif
+#ifndef BE_PAD
+#define BE_PAD 16
+#endif
+constexpr int BE_D = BE_D_;          // block records in flight per wave
+constexpr int BE_REC = 192;          // dwords per block record (64 lanes x 3)
+
+struct BellImage {
+    uint32_t *stream = nullptr;      // [blocks][64 lanes][A step 0, A step 1, pixels]
+    int64_t *stream_off = nullptr;   // [n_pass * 4 + set] first record of the stream
+    int *nblk = nullptr;             // [(active index * 4 + set) * 16 + slot] records of the pair
+    int *ntot = nullptr;             // [active index * 4 + set] records of the set in the chunk
+    int *active = nullptr;           // chunks with entries, concatenated per pass
+    int *active_off = nullptr;       // [n_pass + 1]
+    int n_pass = 0;
+    size_t n_blocks = 0;
+    double mac_ratio = 0.;           // multiply-adds incl. padding / stored values
+};
+
+template <int I, int N, typename F> __device__ __forceinline__ void bstatic_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        bstatic_for<I + 1, N>(f);
+    }
+}
+
+template <typename T> struct BeCfg {
+    static constexpr int SZ = (int)sizeof(T);
+    static constexpr int TILES = SZ == 4 ? 1 : 2;          // 16-frame tiles per workgroup
+    static constexpr int FB = 16 * TILES;
+    static constexpr int ROW = BE_P * SZ;                  // bytes of a frame's chunk
+    static constexpr int RPD = ROW >= 1024 ? 1 : 1024 / ROW;   // frame rows per DMA instruction
+    static constexpr int DPR = ROW >= 1024 ? ROW / 1024 : 1;   // DMA instructions per row
+    static constexpr int NDMA_WG = FB * ROW / 1024;
+    static constexpr int NDMA = NDMA_WG / BE_SETS;         // per wave and chunk
+    // a padded unit = RPD rows (>= 1 KiB) + 16 B, so the 16 frames of a tile spread over banks
+    static constexpr int UNIT_BYTES = (ROW >= 1024 ? ROW : 1024) + BE_PAD;
+    static constexpr int BUF = (FB / RPD) * UNIT_BYTES;
+    static constexpr int LDS_BYTES = 2 * BUF;
+    __host__ __device__ static constexpr int frame_base(int f) {
+        return (f / RPD) * UNIT_BYTES + (f % RPD) * ROW;
+    }
+    static constexpr int TILE_OFF = (16 / RPD) * UNIT_BYTES;
+};
+
+template <typename T> __device__ __forceinline__ float be_lds_value(const unsigned char *p) {
+    if constexpr (std::is_same<T, float>::value) return *(const float *)p;
+    else return (float)(*(const T *)p);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(BE_SETS * 64, BE_OCC)
+k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
+             const uint32_t *__restrict__ stream, const int64_t *__restrict__ stream_off,
+             const int *__restrict__ nblk, const int *__restrict__ ntot,
+             const int *__restrict__ active, const int *__restrict__ active_off,
+             float *__restrict__ out, int64_t ld_out,
+             int n_cols, int accumulate, int ablate) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char be_lds[];
+    using C = BeCfg<T>;
+    constexpr int TILES = C::TILES, NDMA = C::NDMA;
+    // one tile: the two steps of a record go to two accumulators (no back-to-back dependent MFMAs)
+    constexpr int NACC = TILES == 1 ? 2 : 1;
+    const int tid = threadIdx.x;
+    const int j = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave = group set
+    const int lane = tid & 63;
+    const int m16 = lane & 15, kg = lane >> 4;
+    const int pass = blockIdx.y;
+    const int64_t f0 = (int64_t)blockIdx.x * C::FB;
+    const int a0 = active_off[pass], a1 = active_off[pass + 1];
+
+    bf32x4 acc[BE_SLOTS][TILES * NACC];
+#pragma unroll
+    for (int s = 0; s < BE_SLOTS; ++s)
+#pragma unroll
+        for (int t = 0; t < TILES * NACC; ++t) acc[s][t] = bf32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- frame DMA: instruction q of the workgroup's chunk copy; wave j issues q = j*NDMA + i
+    auto issue_dma = [&](int ai, int buf) {
+        if (ablate == 1 || ablate == 3) return;  // timing experiments only (LTMI_BELL_ABLATE)
+        const int ch = active[ai];
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int q = j * NDMA + i;
+            int64_t fr;
+            int64_t byte_in_row;
+            int dst;
+            if constexpr (C::RPD > 1) {          // several rows per instruction (1-byte pixels)
+                constexpr int LPR = 64 / C::RPD;  // lanes per row
+                fr = f0 + q * C::RPD + lane / LPR;
+                byte_in_row = (int64_t)ch * C::ROW + (lane % LPR) * 16;
+                dst = q * C::UNIT_BYTES;
+            } else {
+                fr = f0 + q / C::DPR;
+                byte_in_row = (int64_t)ch * C::ROW + (q % C::DPR) * 1024 + lane * 16;
+                dst = (q / C::DPR) * C::UNIT_BYTES + (q % C::DPR) * 1024;
+            }
+            if (fr > n_frames - 1) fr = n_frames - 1;
+            // the last chunk may be partial: pieces past the row are not referenced by any record
+            if (byte_in_row + 16 > n_px * C::SZ) byte_in_row = 0;
+            const unsigned char *src = (const unsigned char *)(tile + fr * ld) + byte_in_row;
+            __builtin_amdgcn_global_load_lds((b_glb_ptr_t)src,
+                                             (b_lds_ptr_t)(be_lds + buf * C::BUF + dst), 16, 0, 0);
+        }
+    };
+
+    // ---- record ring (asm loads: the waits are counted by hand, see below)
+    const uint32_t *sp = stream + stream_off[pass * BE_SETS + j] * BE_REC + lane * 3;
+    bu32x3 ring[BE_D];
+    // asm loads + hand-counted waits: with plain loads the compiler turns the ring into register
+    // copies behind vmcnt(0).  A ring entry is refilled AFTER the MFMAs that read it (no copy needed)
+    // and its wait asm takes the entry as in/out operand, so nothing reads it early.
+    auto load_rec = [&](bu32x3 &r) {
+        asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(r) : "v"(sp) : "memory");
+        sp += BE_REC;
+    };
+#pragma unroll
+    for (int u = 0; u < BE_D; ++u) load_rec(ring[u]);
+
+    const int lane_base = C::frame_base(m16);
+    int phase = 0;                      // ring entry holding the next record
+    int since_dma = BE_D;               // records consumed since the last DMA issue (saturating)
+
+    if (a0 < a1) issue_dma(a0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (the ring was issued before the DMA: all landed) -- refilled below as it is consumed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // (not __syncthreads: its fence drains vmcnt, i.e. the record ring)
+    asm volatile("" ::: "memory");
+
+    // B operands (raw pixel type) of the record about to be multiplied / of the one after it
+    T bcur[2][TILES], bnxt[2][TILES];
+    const unsigned char *bbase = be_lds + lane_base;
+    // read the B operands of ring entry PH into bnxt; WAIT = younger records allowed in flight
+    auto preread = [&](auto PH, auto WAIT) {
+        bu32x3 &r = ring[decltype(PH)::value];
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(decltype(WAIT)::value) : "memory");
+        const unsigned o = r[2];
+        const unsigned char *p0 = bbase + (o & 0xffffu) * C::SZ;
+        const unsigned char *p1 = bbase + (o >> 16) * C::SZ;
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            bnxt[0][t] = *(const T *)(p0 + t * C::TILE_OFF);
+            bnxt[1][t] = *(const T *)(p1 + t * C::TILE_OFF);
+        }
+    };
+
+    for (int ai = a0; ai < a1; ++ai) {
+        const int buf = (ai - a0) & 1;
+        if (ai + 1 < a1) {
+            issue_dma(ai + 1, buf ^ 1);
+            since_dma = 0;
+        }
+        bbase = be_lds + buf * C::BUF + lane_base;
+        const int *nb_row = nblk + ((int64_t)ai * BE_SETS + j) * BE_SLOTS;
+        int nbs[BE_SLOTS];                            // one 64-byte scalar load
+#pragma unroll
+        for (int s = 0; s < BE_SLOTS; ++s) nbs[s] = nb_row[s];
+        int left = ablate == 2 ? 0 : ntot[ai * BE_SETS + j];   // records of this wave in the chunk
+        if (BE_PIPE && left > 0) {
+            // first record of the chunk: the oldest ring entry, BE_D - 1 younger ones (and, right
+            // after the issue, most of the frame DMA: record loads retire behind it anyway)
+            bstatic_for<0, BE_D>([&](auto PH) {
+                if (phase == decltype(PH)::value)
+                    preread(PH, std::integral_constant<int, BE_D - 1>{});
+            });
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) { bcur[0][t] = bnxt[0][t]; bcur[1][t] = bnxt[1][t]; }
+        }
+
+        bstatic_for<0, BE_SLOTS>([&](auto S) {
+            constexpr int s = decltype(S)::value;
+            const int nb = ablate == 2 ? 0 : nbs[s];
+            for (int b = 0; b < nb; ++b) {
+                auto consume = [&](auto PH) {
+                    constexpr int ph = decltype(PH)::value;
+                    bu32x3 &r = ring[ph];                      // landed: waited for in its preread
+                    // LDS reads of the NEXT record go out before this record's MFMAs
+                    if constexpr (BE_PIPE) {
+                        if (left > 1)
+                            preread(std::integral_constant<int, (ph + 1) % BE_D>{},
+                                    std::integral_constant<int, BE_D - 2>{});
+                    } else {
+                        preread(PH, std::integral_constant<int, BE_D - 1>{});
+#pragma unroll
+                        for (int t = 0; t < TILES; ++t) { bcur[0][t] = bnxt[0][t]; bcur[1][t] = bnxt[1][t]; }
+                    }
+                    // (copies first: __builtin_bit_cast on a vector ELEMENT reads element 0)
+                    const unsigned x0 = r[0], x1 = r[1];
+                    const float a_0 = __uint_as_float(x0);
+                    const float a_1 = __uint_as_float(x1);
+#ifndef BE_NOMFMA
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t)
+                        acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_0, (float)bcur[0][t], acc[s][t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t)
+                        acc[s][t + (NACC - 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                            a_1, (float)bcur[1][t], acc[s][t + (NACC - 1)], 0, 0, 0);
+#else                   // timing experiment: the same operands through one VALU op each
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t) {
+                        acc[s][t][0] += a_0 * (float)bcur[0][t];
+                        acc[s][t][1] += a_1 * (float)bcur[1][t];
+                    }
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_rec(r);                                   // refill this ring entry
+                    if constexpr (BE_PIPE) {
+#pragma unroll
+                        for (int t = 0; t < TILES; ++t) { bcur[0][t] = bnxt[0][t]; bcur[1][t] = bnxt[1][t]; }
+                    }
+                };
+                bstatic_for<0, BE_D>([&](auto PH) {
+                    if (phase == decltype(PH)::value) consume(PH);
+                });
+                phase = phase == BE_D - 1 ? 0 : phase + 1;
+                since_dma = since_dma < BE_D ? since_dma + 1 : since_dma;
+                --left;
+            }
+        });
+        // The next chunk must have landed before anyone reads it.  BE_D records consumed since the
+        // issue imply it (their refills were issued after the DMA and at most BE_D - 1 loads are
+        // outstanding at a consumption... of a record that is itself younger than the DMA);
+        // otherwise drain.
+        if (since_dma < BE_D) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_D) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (ablate != 3) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    // Drain the run-ahead record loads.  The ring entries are operands of the wait so that they stay
+    // live up to here: otherwise the compiler reuses their registers for the result addresses and
+    // the loads still in flight land on top of them (seen on cold caches only).
+    bstatic_for<0, BE_D>([&](auto U) {
+        bu32x3 &r = ring[decltype(U)::value];
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(r) : : "memory");
+    });
+
+    // ---- results: lane holds columns g*16 + kg*4 .. +3 of frame (tile t, m16)
+    if constexpr (NACC == 2) {
+#pragma unroll
+        for (int s = 0; s < BE_SLOTS; ++s) acc[s][0] += acc[s][1];
+    }
+#pragma unroll
+    for (int s = 0; s < BE_SLOTS; ++s) {
+        const int col0 = pass * BE_PASS + (s * BE_SETS + j) * 16 + kg * 4;
+        if (col0 >= n_cols) continue;
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            const int64_t f = f0 + t * 16 + m16;
+            if (f >= n_frames) continue;
+            float *o = out + f * ld_out + col0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (col0 + r < n_cols) o[r] = accumulate ? o[r] + acc[s][t][r] : acc[s][t][r];
+        }
+    }
+}
+
+void bell_destroy(void *image) {
+    BellImage *b = (BellImage *)image;
+    if (!b) return;
+    if (b->stream) (void)hipFree(b->stream);
+    if (b->stream_off) (void)hipFree(b->stream_off);
+    if (b->nblk) (void)hipFree(b->nblk);
+    if (b->ntot) (void)hipFree(b->ntot);
+    if (b->active) (void)hipFree(b->active);
+    if (b->active_off) (void)hipFree(b->active_off);
+    delete b;
+}
+
+// Multiply-adds of the blocked image per stored value (the padding factor that decides between
+// this kernel and the SELL kernel); columns = real columns (2 per complex mask).
+double bell_mac_ratio(const int64_t *indptr, const int64_t *indices, int nc, int64_t n_px,
+                      int64_t n_masks) {
+    const int64_t n_cols = n_masks * nc;
+    const int64_t n_groups = (n_cols + 15) / 16;
+    const int64_t nnz = indptr[n_px] * nc;
+    if (nnz <= 0) return 1e30;
+    std::vector<int64_t> last(n_groups, -1);          // last pixel counted for the group
+    std::vector<int> cols(n_groups, 0);               // touched pixels of the group in this chunk
+    int64_t steps = 0;
+    auto flush = [&]() {
+        for (int64_t g = 0; g < n_groups; ++g)
+            if (cols[g]) { steps += (cols[g] + 7) / 8 * 2; cols[g] = 0; }
+    };
+    for (int64_t p = 0; p < n_px; ++p) {
+        if (p % BE_P == 0 && p) flush();
+        for (int64_t e = indptr[p]; e < indptr[p + 1]; ++e)
+            for (int c = 0; c < nc; ++c) {
+                const int64_t g = (indices[e] * nc + c) / 16;
+                if (last[g] != p) { last[g] = p; cols[g]++; }
+            }
+    }
+    flush();
+    return (double)steps * 64.0 / (double)nnz;
+}
+
+// Build the blocked image from the CSR matrix (n_px x n_masks).  Returns nullptr + error set on
+// failure.
+void *bell_build(const int64_t *indptr, const int64_t *indices, const float *vals, int nc,
+                 int64_t n_px, int64_t n_masks, int *err) {
+    *err = LTMI_OK;
+    BellImage *b = new (std::nothrow) BellImage();
+    if (!b) { *err = LTMI_E_NOMEM; return nullptr; }
+    try {
+        const int64_t n_cols = n_masks * nc;
+        const int64_t n_groups = (n_cols + 15) / 16;
+        const int n_pass = (int)((n_groups + BE_SETS * BE_SLOTS - 1) / (BE_SETS * BE_SLOTS));
+        const int n_chunks = (int)((n_px + BE_P - 1) / BE_P);
+        b->n_pass = n_pass;
+        struct Ent { uint16_t px; uint16_t m; float v; };
+        // entries per (chunk, group), pixels ascending because the CSR rows are walked in order
+        std::vector<std::vector<Ent>> bucket((size_t)n_chunks * n_groups);
+        for (int64_t p = 0; p < n_px; ++p) {
+            const int ch = (int)(p / BE_P);
+            for (int64_t e = indptr[p]; e < indptr[p + 1]; ++e)
+                for (int c = 0; c < nc; ++c) {
+                    const int64_t col = indices[e] * nc + c;
+                    bucket[(size_t)ch * n_groups + col / 16].push_back(
+                        Ent{(uint16_t)(p - (int64_t)ch * BE_P), (uint16_t)(col % 16), vals[e * nc + c]});
+                }
+        }
+        std::vector<int> active, active_off(n_pass + 1, 0);
+        for (int ps = 0; ps < n_pass; ++ps) {
+            const int64_t g_lo = (int64_t)ps * BE_SETS * BE_SLOTS;
+            const int64_t g_hi = std::min<int64_t>(n_groups, g_lo + BE_SETS * BE_SLOTS);
+            for (int ch = 0; ch < n_chunks; ++ch) {
+                bool any = false;
+                for (int64_t g = g_lo; g < g_hi && !any; ++g)
+                    any = !bucket[(size_t)ch * n_groups + g].empty();
+                if (any) active.push_back(ch);
+            }
+            active_off[ps + 1] = (int)active.size();
+        }
+        const size_t n_act = std::max<size_t>(active.size(), 1);
+        std::vector<int> nblk(n_act * BE_SETS * BE_SLOTS, 0), ntot(n_act * BE_SETS, 0);
+        std::vector<int64_t> stream_off((size_t)n_pass * BE_SETS, 0);
+        std::vector<uint32_t> stream;
+        size_t blocks = 0;
+        std::vector<uint16_t> cols;
+        for (int ps = 0; ps < n_pass; ++ps)
+            for (int j = 0; j < BE_SETS; ++j) {
+                stream_off[(size_t)ps * BE_SETS + j] = (int64_t)blocks;
+                for (int ai = active_off[ps]; ai < active_off[ps + 1]; ++ai) {
+                    const int ch = active[ai];
+                    for (int s = 0; s < BE_SLOTS; ++s) {
+                        const int64_t g = (int64_t)ps * BE_SETS * BE_SLOTS + s * BE_SETS + j;
+                        if (g >= n_groups) continue;
+                        const std::vector<Ent> &ents = bucket[(size_t)ch * n_groups + g];
+                        if (ents.empty()) continue;
+                        cols.clear();
+                        for (const Ent &en : ents)
+                            if (cols.empty() || cols.back() != en.px) cols.push_back(en.px);
+                        const int nb = ((int)cols.size() + 7) / 8;
+                        nblk[((size_t)ai * BE_SETS + j) * BE_SLOTS + s] = nb;
+                        ntot[(size_t)ai * BE_SETS + j] += nb;
+                        const size_t base = stream.size();
+                        stream.resize(base + (size_t)nb * BE_REC, 0u);
+                        // pixel numbers: lane l -> columns 8*blk + (l >> 4) and + 4
+                        for (int blk = 0; blk < nb; ++blk)
+                            for (int l = 0; l < 64; ++l) {
+                                const int c0 = blk * 8 + (l >> 4), c1 = c0 + 4;
+                                const uint32_t p0 = c0 < (int)cols.size() ? cols[c0] : 0;
+                                const uint32_t p1 = c1 < (int)cols.size() ? cols[c1] : 0;
+                                stream[base + (size_t)blk * BE_REC + l * 3 + 2] = p0 | (p1 << 16);
+                            }
+                        size_t ci = 0;
+                        for (const Ent &en : ents) {
+                            while (cols[ci] != en.px) ++ci;
+                            const int blk = (int)(ci / 8), step = (int)((ci % 8) / 4), kk = (int)(ci % 4);
+                            const int l = kk * 16 + en.m;
+                            uint32_t bits;
+                            memcpy(&bits, &en.v, 4);
+                            stream[base + (size_t)blk * BE_REC + l * 3 + step] = bits;
+                        }
+                        blocks += nb;
+                    }
+                }
+                // slack for the run-ahead loads of the last records
+                stream.resize(stream.size() + (size_t)BE_D * BE_REC, 0u);
+                blocks += BE_D;
+            }
+        b->n_blocks = blocks;
+        int64_t nnz = indptr[n_px] * nc;
+        b->mac_ratio = nnz > 0 ? (double)(blocks - (size_t)BE_D * n_pass * BE_SETS) * 128.0 / (double)nnz : 0.;
+        if (active.empty()) active.push_back(0);
+        hipError_t e = hipMalloc((void **)&b->stream, std::max<size_t>(stream.size(), 1) * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&b->stream_off, stream_off.size() * 8);
+        if (e == hipSuccess) e = hipMalloc((void **)&b->nblk, nblk.size() * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&b->ntot, ntot.size() * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&b->active, active.size() * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&b->active_off, active_off.size() * 4);
+        if (e == hipSuccess && !stream.empty())
+            e = hipMemcpy(b->stream, stream.data(), stream.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(b->stream_off, stream_off.data(), stream_off.size() * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(b->nblk, nblk.data(), nblk.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(b->ntot, ntot.data(), ntot.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(b->active, active.data(), active.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(b->active_off, active_off.data(), active_off.size() * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            set_error("uploading the blocked sparse mask image failed: %s", hipGetErrorString(e));
+            *err = (int)e;
+            bell_destroy(b);
+            return nullptr;
+        }
+    } catch (const std::bad_alloc &) {
+        set_error("out of host memory while packing the blocked sparse mask image");
+        *err = LTMI_E_NOMEM;
+        bell_destroy(b);
+        return nullptr;
+    }
+    return b;
+}
+
+template <typename T>
+static int launch_bell(ltmi_masks *m, BellImage *b, const T *tile, int64_t n_frames, int64_t ld,
+                       float *out, int64_t ld_out_f, int n_cols, int accumulate, hipStream_t stream) {
+    using C = BeCfg<T>;
+    auto kern = k_bell_apply<T>;
+    static bool set[16] = {false};
+    if (!set[m->device & 15]) {
+        LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     C::LDS_BYTES));
+        set[m->device & 15] = true;
+    }
+    dim3 grid((unsigned)((n_frames + C::FB - 1) / C::FB), (unsigned)b->n_pass);
+    const char *abl = getenv("LTMI_BELL_ABLATE");    // 1: no frame DMA, 2: no records (bench only)
+    const int ablate = abl ? atoi(abl) : 0;
+    hipLaunchKernelGGL(kern, grid, dim3(BE_SETS * 64), C::LDS_BYTES, stream, tile, ld, n_frames,
+                       m->n_px, (const uint32_t *)b->stream, (const int64_t *)b->stream_off,
+                       (const int *)b->nblk, (const int *)b->ntot, (const int *)b->active,
+                       (const int *)b->active_off, out,
+                       ld_out_f, n_cols, accumulate, ablate);
+    LTMI_HIP(hipGetLastError());
+    snprintf(m->last_kernel, sizeof(m->last_kernel), "k_bell_apply<%s> grid=(%u,%u) blocks=%zu x%.2f",
+             typeid(T).name(), grid.x, grid.y, b->n_blocks, b->mac_ratio);
+    return LTMI_OK;
+}
+
+// handled = false: the tile does not meet the kernel's alignment rules (caller uses the SELL kernel)
+int bell_apply(ltmi_masks *m, void *image, int cplx, const void *tile, int tile_dtype,
+               int64_t n_frames, int64_t ld_tile, void *out, int64_t ld_out, int accumulate,
+               hipStream_t stream, bool *handled) {
+    BellImage *b = (BellImage *)image;
+    const int sz = dtype_size(tile_dtype);
+    *handled = false;
+    if (!b || n_frames <= 0) return LTMI_OK;
+    if (((uintptr_t)tile) % 16 || (ld_tile * sz) % 16 || (m->n_px * sz) % 16) return LTMI_OK;
+    const int nc = cplx ? 2 : 1;
+    const int n_cols = (int)(m->n_masks * nc);
+    float *o = (float *)out;
+    const int64_t ldo = ld_out * nc;
+    *handled = true;
+    switch (tile_dtype) {
+        case LTMI_BOOL:
+        case LTMI_U8: return launch_bell<uint8_t>(m, b, (const uint8_t *)tile, n_frames, ld_tile, o, ldo, n_cols, accumulate, stream);
+        case LTMI_I8: return launch_bell<int8_t>(m, b, (const int8_t *)tile, n_frames, ld_tile, o, ldo, n_cols, accumulate, stream);
+        case LTMI_U16: return launch_bell<uint16_t>(m, b, (const uint16_t *)tile, n_frames, ld_tile, o, ldo, n_cols, accumulate, stream);
+        case LTMI_I16: return launch_bell<int16_t>(m, b, (const int16_t *)tile, n_frames, ld_tile, o, ldo, n_cols, accumulate, stream);
+        case LTMI_F32: return launch_bell<float>(m, b, (const float *)tile, n_frames, ld_tile, o, ldo, n_cols, accumulate, stream);
+    }
+    *handled = false;
+    return LTMI_OK;
+}
+
+}  // namespace ltmi

@@ -55,6 +55,15 @@ int dense64_create(ltmi_masks *m);
 void dense64_destroy(ltmi_masks *m);
 int dense64_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames, int64_t ld,
                   void *out, int64_t ld_out, int accumulate, hipStream_t stream, bool *handled);
+// blocked-ELL sparse image on the matrix cores (ltmi_bell.hip)
+double bell_mac_ratio(const int64_t *indptr, const int64_t *indices, int nc, int64_t n_px,
+                      int64_t n_masks);
+void *bell_build(const int64_t *indptr, const int64_t *indices, const float *vals, int nc,
+                 int64_t n_px, int64_t n_masks, int *err);
+void bell_destroy(void *image);
+int bell_apply(ltmi_masks *m, void *image, int cplx, const void *tile, int tile_dtype,
+               int64_t n_frames, int64_t ld_tile, void *out, int64_t ld_out, int accumulate,
+               hipStream_t stream, bool *handled);
 }  // namespace ltmi
 
 // The opaque handle behind `ltmi_masks*` (shared by ltmi_dense.hip and ltmi_sparse.hip).

@@ -1092,8 +1092,9 @@ extern "C" int ltmi_masks_kind(const ltmi_masks *m, int *kind) {
 
 extern "C" int ltmi_masks_set_tuning(ltmi_masks *m, int mt, int waves, int ksplit) {
     if (!m) LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_set_tuning: null handle");
-    if (mt == 0 && waves >= 30 && waves <= 33) {
-        // k_dense_lds: 30 = as dispatched, 31 / 32 = timing-only ablations (no DMA / no MFMA)
+    if (mt == 0 && ((waves >= 30 && waves <= 33) || (waves >= 40 && waves <= 41))) {
+        // k_dense_lds: 30 = as dispatched, 31 / 32 = timing-only ablations (no DMA / no MFMA);
+        // sparse stacks: 40 = as dispatched, 41 = SELL kernel even if a blocked image exists
         m->tune_mt = 0;
         m->tune_waves = 0;
         m->tune_ksplit = ksplit;

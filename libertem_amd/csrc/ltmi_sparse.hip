@@ -53,6 +53,7 @@ struct CsrImage {
     size_t n_rows = 0;
     int *active = nullptr;      // chunks with entries, concatenated per pass
     int *active_off = nullptr;  // [n_pass + 1]
+    void *bell = nullptr;       // blocked image for the matrix-core kernel (ltmi_bell.hip) or null
 };
 
 __device__ __forceinline__ int slab_word(int p, int f) {
@@ -231,6 +232,7 @@ int csr_destroy(ltmi_masks *m) {
     if (c->row_len) (void)hipFree(c->row_len);
     if (c->active) (void)hipFree(c->active);
     if (c->active_off) (void)hipFree(c->active_off);
+    bell_destroy(c->bell);
     delete c;
     m->csr = nullptr;
     return LTMI_OK;
@@ -282,6 +284,13 @@ static int launch_sell(ltmi_masks *m, CsrImage *c, const T *tile, int64_t n_fram
 int csr_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames, int64_t ld_tile,
               void *out, int64_t ld_out, int accumulate, hipStream_t stream) {
     CsrImage *c = (CsrImage *)m->csr;
+    // localised stacks: blocked image on the matrix cores (set_tuning 41 forces the SELL kernel)
+    if (c->bell && m->tune_ksplit_ring != 41) {
+        bool handled = false;
+        const int rc = bell_apply(m, c->bell, c->cplx, tile, tile_dtype, n_frames, ld_tile, out,
+                                  ld_out, accumulate, stream, &handled);
+        if (rc != LTMI_OK || handled) return rc;
+    }
     float *o = (float *)out;
     const int64_t ldo = ld_out * (c->cplx ? 2 : 1);
     switch (tile_dtype) {
@@ -425,6 +434,27 @@ extern "C" int ltmi_masks_create_csr(int device, const int64_t *indptr, const in
         ltmi::csr_destroy(m);
         delete m;
         LTMI_FAIL(LTMI_E_NOMEM, "out of host memory while packing the sparse mask image");
+    }
+    // Localised stacks (neighbouring masks share pixels: rings, radial bins) also get the blocked
+    // image of ltmi_bell.hip; the padding factor decides.  LTMI_SPARSE_BELL=0 / 1 forces never /
+    // always (tests), LTMI_BELL_MAX_RATIO moves the threshold.
+    {
+        const char *force = getenv("LTMI_SPARSE_BELL");
+        const char *thr = getenv("LTMI_BELL_MAX_RATIO");
+        const double max_ratio = thr ? atof(thr) : 8.0;
+        bool build = nnz > 0;
+        if (force && force[0] == '0') build = false;
+        else if (!(force && force[0] == '1') && build)
+            build = ltmi::bell_mac_ratio(indptr, indices, nc, n_px, n_masks) <= max_ratio;
+        if (build) {
+            int err = LTMI_OK;
+            c->bell = ltmi::bell_build(indptr, indices, vals, nc, n_px, n_masks, &err);
+            if (!c->bell) {
+                ltmi::csr_destroy(m);
+                delete m;
+                return err;
+            }
+        }
     }
     *out = m;
     return LTMI_OK;

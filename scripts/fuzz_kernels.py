@@ -65,7 +65,10 @@ for case in range(n_cases):
                 dense = dense * (1 + 1j * rng.random((n_px, n_masks)))
             dense = dense.astype(mdt)
             rd = np.result_type(np.float32, mdt)
+            # either sparse kernel: the blocked image (matrix cores) or the SELL gather kernel
+            os.environ['LTMI_SPARSE_BELL'] = str(rng.choice(['0', '1']))
             handle = hip.MaskHandle.csr(0, sp.csr_matrix(dense), rd)
+            del os.environ['LTMI_SPARSE_BELL']
             ref = data[:, :n_px].astype(np.complex128 if mdt.kind == 'c' else np.float64) @ \
                 dense.astype(np.complex128 if mdt.kind == 'c' else np.float64)
             scale = np.abs(data[:, :n_px].astype(np.float64)) @ np.abs(dense).astype(np.float64)

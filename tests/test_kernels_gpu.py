@@ -349,7 +349,22 @@ def test_error_paths(hip):
     h.close()
 
 
-# --- sparse (CSR -> SELL) kernel ------------------------------------------------------------------
+# --- sparse kernels: SELL gather kernel and blocked image on the matrix cores -----------------------
+@pytest.fixture(params=['sell', 'bell'])
+def sparse_kernel(request, monkeypatch):
+    """Force one of the two sparse kernels at handle creation (libltmi reads LTMI_SPARSE_BELL there);
+    the blocked kernel still hands tiles it cannot DMA (unaligned rows) to the SELL kernel."""
+    monkeypatch.setenv('LTMI_SPARSE_BELL', '1' if request.param == 'bell' else '0')
+    return request.param
+
+
+def _check_sparse_kernel(kern, which, n_px, itemsize, n_nonzero=1):
+    if which == 'bell' and (n_px * itemsize) % 16 == 0 and n_nonzero:
+        assert 'k_bell_apply' in kern, kern
+    else:
+        assert 'k_sell_apply' in kern, kern
+
+
 def _apply_csr(hip, data2d, csr_px_by_masks, result_dtype, accumulate_into=None):
     h = hip.MaskHandle.csr(0, csr_px_by_masks, result_dtype)
     assert h.kind() == 2
@@ -373,7 +388,7 @@ def _apply_csr(hip, data2d, csr_px_by_masks, result_dtype, accumulate_into=None)
 
 
 @pytest.mark.parametrize('case', recipes.RMATMUL_CASES, ids=lambda c: c['name'])
-def test_sell_vs_reference_rmatmul_golden(hip, golden_dir, case):
+def test_sell_vs_reference_rmatmul_golden(hip, golden_dir, case, sparse_kernel):
     import os
     import scipy.sparse as sp
     g = np.load(os.path.join(golden_dir, 'rmatmul.npz'))
@@ -382,7 +397,7 @@ def test_sell_vs_reference_rmatmul_golden(hip, golden_dir, case):
     if ref.dtype not in (np.float32, np.complex64):
         pytest.skip("float64 sparse goes through the densified generic path (tested via the UDF)")
     res, kern = _apply_csr(hip, left, sp.csr_matrix(right), ref.dtype)
-    assert 'k_sell_apply' in kern
+    _check_sparse_kernel(kern, sparse_kernel, left.shape[1], left.dtype.itemsize)
     assert res.dtype == ref.dtype and res.shape == ref.shape
     assert np.allclose(res, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
 
@@ -395,7 +410,7 @@ def test_sell_vs_reference_rmatmul_golden(hip, golden_dir, case):
     (20, 2048, 300, 0.0),       # all-zero stack
 ])
 @pytest.mark.parametrize('tile_dtype', ['uint8', 'uint16', 'int16', 'float32'])
-def test_sell_random(hip, shape, tile_dtype):
+def test_sell_random(hip, shape, tile_dtype, sparse_kernel):
     import scipy.sparse as sp
     n_frames, n_px, n_masks, density = shape
     rng = np.random.default_rng(31)
@@ -407,6 +422,7 @@ def test_sell_random(hip, shape, tile_dtype):
     m = sp.random(n_px, n_masks, density=density, format='csr', dtype=np.float32,
                   random_state=np.random.RandomState(1))
     res, kern = _apply_csr(hip, data, m, np.float32)
+    _check_sparse_kernel(kern, sparse_kernel, n_px, dt.itemsize, m.nnz)
     ref = data.astype(np.float64) @ m.astype(np.float64).toarray()
     scale = np.abs(data.astype(np.float64)) @ np.abs(m.toarray().astype(np.float64))
     assert np.all(np.abs(res - ref) <= 1e-5 * scale + 1e-30)
@@ -421,7 +437,7 @@ def test_sell_random(hip, shape, tile_dtype):
     assert np.all(np.abs(resc.view(np.complex64).reshape(refc.shape) - refc) <= 2e-5 * scale + 1e-30)
 
 
-def test_sell_ring_stack_vs_oracle(hip):
+def test_sell_ring_stack_vs_oracle(hip, sparse_kernel):
     """C4-style stack: anti-aliased ring masks as CSR, on real-size frames (reduced nav)."""
     import scipy.sparse as sp
     from oracle import masks as omasks
@@ -432,10 +448,35 @@ def test_sell_ring_stack_vs_oracle(hip):
     rng = np.random.default_rng(32)
     data = rng.integers(0, 4096, (40, 65536)).astype(np.uint16)
     res, kern = _apply_csr(hip, data, csr, np.float32)
+    _check_sparse_kernel(kern, sparse_kernel, 65536, 2)
     ref = opath.rmatmul(data[:8].astype(np.float32), csr)          # the reference's own loop
     assert np.allclose(res[:8], ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
     ref64 = data.astype(np.float64) @ rings.T.astype(np.float64)
     assert np.allclose(res, np.asarray(ref64), rtol=1e-5, atol=1e-5 * np.abs(ref64).max())
+
+
+def test_sparse_dispatch_by_padding_factor(hip, monkeypatch):
+    """Without forcing: localised stacks (rings) take the blocked image, scattered ones the SELL kernel."""
+    import scipy.sparse as sp
+    from oracle import masks as omasks
+    monkeypatch.delenv('LTMI_SPARSE_BELL', raising=False)
+    rings = omasks.radial_bins(32, 32, 64, 64, n_bins=64, use_sparse=True, dtype=np.float32)
+    data = np.random.default_rng(5).integers(0, 100, (20, 4096)).astype(np.uint16)
+    _, kern = _apply_csr(hip, data, sp.csr_matrix(rings.T.astype(np.float32)), np.float32)
+    assert 'k_bell_apply' in kern
+    scattered = sp.random(4096, 512, density=0.002, format='csr', dtype=np.float32,
+                          random_state=np.random.RandomState(3))
+    res, kern = _apply_csr(hip, data, scattered, np.float32)
+    assert 'k_sell_apply' in kern
+    h = hip.MaskHandle.csr(0, sp.csr_matrix(rings.T.astype(np.float32)), np.float32)
+    h.set_tuning(0, 41, 0)                                          # 41: SELL kernel on request
+    t, out = _dev(data), _dev(np.zeros((20, 64), dtype=np.float32))
+    h.apply(t.data_ptr(), data.dtype, 20, 4096, out.data_ptr(), 64, False)
+    torch.cuda.synchronize()
+    assert 'k_sell_apply' in h.last_kernel()
+    ref = data.astype(np.float64) @ np.asarray(rings.T.astype(np.float64).todense())
+    assert np.allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+    h.close()
 
 
 # ---- shifted masks ------------------------------------------------------------------------------------
