@@ -71,6 +71,11 @@ int ltmi_masks_create_dense(int device, const void *masks_host, int result_dtype
  * _build_sparse (src/libertem/common/container.py:53-64): shape (n_px, n_masks),
  * indptr[n_px + 1], indices[nnz] (mask index), data[nnz] of `result_dtype` (f32/f64/c64/c128).
  * Host pointers; canonical format (sorted, no duplicates) is not required.
+ * Two device images may be built: the sliced-ELL image of the gather kernel (always) and, for stacks
+ * whose neighbouring masks share pixels (rings, radial bins), the blocked image that runs on the
+ * matrix cores; ltmi_apply_masks picks the blocked one when it exists and the tile rows are 16-byte
+ * aligned.  Environment (read here): LTMI_SPARSE_BELL=0 / 1 never / always builds the blocked image,
+ * LTMI_BELL_MAX_RATIO moves the padding-factor threshold (default 8).
  */
 int ltmi_masks_create_csr(int device, const int64_t *indptr, const int64_t *indices,
                           const void *data, int result_dtype, int64_t n_px, int64_t n_masks,
@@ -171,6 +176,8 @@ int ltmi_crystallinity(ltmi_fft_plan *p, const void *tile, int tile_dtype, int64
  *   mt in {1,2}, waves in {4,8}: the direct-load kernel k_dense_mfma with that tile shape;
  *   mt = 0, waves = 30: the LDS-DMA kernel k_dense_lds as dispatched; 31 / 32: its timing-only
  *     ablations without DMA / without MFMA (results are garbage);
+ *   mt = 0, waves = 40 / 41 (sparse handles): as dispatched / the gather kernel k_sell_apply even
+ *     if the blocked image exists;
  *   ksplit 0 = auto.  Returns LTMI_E_INVALID for unsupported values. */
 int ltmi_masks_set_tuning(ltmi_masks *m, int mt, int waves, int ksplit);
 /* name of the kernel variant the last ltmi_apply_masks on this handle launched */
