@@ -12,6 +12,7 @@ dtype, resident in HBM for the lifetime of the worker's task.
 """
 import logging
 
+import os
 import numpy as np
 import scipy.sparse as sp
 import cloudpickle
@@ -23,6 +24,29 @@ log = logging.getLogger(__name__)
 
 _SPARSE_NAMES = ('scipy.sparse', 'scipy.sparse.csc', 'scipy.sparse.csr', 'sparse.pydata',
                  'sparse.pydata.GCXS')
+
+
+DENSIFY_FILL = float(os.environ.get('LTMI_DENSIFY_FILL', '0.125'))   # 0 disables
+DENSIFY_MAX_BYTES = 2 << 30
+
+
+def _worth_densifying(csr_px_by_masks, result_dtype):
+    """HIP backend: multiply a sparse stack as a dense one when that is the faster kernel:
+    * its fill, counted in the 16-column groups the dense kernel works in, exceeds DENSIFY_FILL (the
+      blocked sparse kernel spends ~3.5 multiply-adds per stored value at less than half the dense
+      kernel's matrix-pipe efficiency), or
+    * it has at most 32 columns -- where the dense kernel streams frames at the HBM rate whatever the
+      fill -- and touches most pixels, so that skipping untouched pixel chunks (which only the sparse
+      kernels do) would save little."""
+    n_px, n_masks = csr_px_by_masks.shape
+    nc = 2 if np.dtype(result_dtype).kind == 'c' else 1
+    cols16 = -(-n_masks * nc // 16) * 16
+    if DENSIFY_FILL <= 0 or n_px * n_masks * np.dtype(result_dtype).itemsize > DENSIFY_MAX_BYTES:
+        return False
+    if csr_px_by_masks.nnz * nc > DENSIFY_FILL * n_px * cols16:
+        return True
+    touched = np.count_nonzero(np.diff(csr_px_by_masks.indptr))
+    return cols16 <= 32 and touched > 0.5 * n_px
 
 
 class MaskContainer:
@@ -180,9 +204,17 @@ class MaskContainer:
                                            transpose=False)            # (n_masks, px), C order
                 h = hip.MaskHandle.dense(device, np.ascontiguousarray(m), result_dtype)
             else:
-                m = self.get_for_sig_slice(sig_slice, dtype=result_dtype,
-                                           sparse_backend='scipy.sparse.csr', transpose=True)
-                h = hip.MaskHandle.csr(device, sp.csr_matrix(m), result_dtype)
+                m = sp.csr_matrix(self.get_for_sig_slice(
+                    sig_slice, dtype=result_dtype, sparse_backend='scipy.sparse.csr',
+                    transpose=True))                                     # (px, n_masks)
+                if _worth_densifying(m, result_dtype):
+                    # a "sparse" stack that is mostly filled (e.g. the radial Fourier orders of one
+                    # wide ring): the dense matrix-core kernel multiplies fewer zeros than the
+                    # blocked sparse image pads, and streams the stack instead of gathering
+                    dense = np.ascontiguousarray(m.T.toarray().astype(result_dtype, copy=False))
+                    h = hip.MaskHandle.dense(device, dense, result_dtype)
+                else:
+                    h = hip.MaskHandle.csr(device, m, result_dtype)
             self._handle_cache[key] = h
         return h
 

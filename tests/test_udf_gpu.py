@@ -335,6 +335,35 @@ def test_sparse_masks_through_udf(ctx):
     assert _close(got['intensity'].data, ref, 1e-6)
 
 
+def test_sparse_stack_densified_when_mostly_filled(ctx):
+    """HIP backend: a 'sparse' stack with filled 16-column groups runs on the dense matrix-core kernel,
+    a localised ring stack stays sparse (blocked image); results agree with the oracle either way."""
+    from libertem_amd.common.container import MaskContainer
+    from libertem_amd.common.slice import Slice
+    from libertem_amd.common.shape import Shape
+    from libertem_amd.udf.base import UDF
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd import masks as pm
+    rng = np.random.default_rng(41)
+    data = rng.integers(0, 1000, (3, 8, 64, 64)).astype(np.uint16)
+    filled = pm.radial_bins(32, 32, 64, 64, n_bins=2, use_sparse=True, dtype=np.float32)     # 2 wide rings
+    rings = pm.radial_bins(32, 32, 64, 64, n_bins=64, use_sparse=True, dtype=np.float32)
+    kinds = {}
+    for name, stack in (('filled', filled), ('rings', rings)):
+        mc = MaskContainer(lambda stack=stack: stack, dtype=np.float32, use_sparse=True,
+                           backend=UDF.BACKEND_HIP)
+        full = Slice(origin=(0, 0, 0), shape=Shape((1, 64, 64), sig_dims=2))
+        h = mc.get_handle_for_sig_slice(full.discard_nav(), np.float32, 0)
+        kinds[name] = h.kind()
+        mc.close()
+    assert kinds == {'filled': 0, 'rings': 2}
+    ds = ctx.load('memory', data=data, num_partitions=2, sig_dims=2)
+    for stack in (filled, rings):
+        got = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda stack=stack: stack))
+        ref = opath.apply_masks(data, stack.todense(), num_partitions=2)
+        assert _close(got['intensity'].data, ref, F32_TOL)
+
+
 def test_radial_fourier_sparse(ctx):
     """RadialFourierAnalysis with the sparse complex64 stack == the (pinned) dense one."""
     case = recipes.RF_CASES[0]
