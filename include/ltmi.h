@@ -152,6 +152,14 @@ int ltmi_repair_pixels(int device, void *buf, int dtype, int64_t n_frames, int64
                        const int32_t *excl, const int32_t *env, const int32_t *cnt, int n_excl,
                        int max_env, void *stream);
 
+/* Byte-order decode on the device: dst[i] = src[i] with its `itemsize` (1, 2, 4, 8) bytes reversed,
+ * n_items items; src == dst (in place) is allowed.  Replaces the byte-swapping decoders of
+ * DtypeConversionDecoder (src/libertem/io/dataset/base/decode.py:8-66, 74-100, 123-158), which run
+ * on the host for every tile of a non-native-endian dataset; the dtype conversion those decoders
+ * fuse (decode_swap_N) happens in the consuming kernels, which take every native dtype. */
+int ltmi_byteswap(int device, const void *src, void *dst, int itemsize, int64_t n_items,
+                  void *stream);
+
 /* ---- Fourier-space operators (hipFFT) ----------------------------------------------------------
  * A plan owns a batched 2D real-to-complex hipFFT (frames of sig_h x sig_w float32, `max_batch`
  * per execution) and its workspace (f32 input + complex64 half spectra).

@@ -28,7 +28,7 @@ EXPORTS = (
     'ltmi_version', 'ltmi_last_error', 'ltmi_device_count', 'ltmi_device_info',
     'ltmi_masks_create_dense', 'ltmi_masks_create_csr', 'ltmi_masks_destroy', 'ltmi_masks_kind',
     'ltmi_apply_masks', 'ltmi_apply_masks_shifted', 'ltmi_apply_masks_shifted_host', 'ltmi_sum_frames_workspace', 'ltmi_sum_frames', 'ltmi_sum_sig',
-    'ltmi_axpy', 'ltmi_correct', 'ltmi_repair_pixels', 'ltmi_fft_plan_create',
+    'ltmi_axpy', 'ltmi_correct', 'ltmi_repair_pixels', 'ltmi_byteswap', 'ltmi_fft_plan_create',
     'ltmi_fft_plan_destroy', 'ltmi_crystallinity', 'ltmi_masks_set_tuning',
     'ltmi_masks_last_kernel',
 )
@@ -109,6 +109,7 @@ def lib():
         L.ltmi_axpy.argtypes = [i32, vp, vp, i32, i64, vp]
         L.ltmi_correct.argtypes = [i32, vp, i32, i64, i64, i64, vp, vp, vp, i32, i64, vp]
         L.ltmi_repair_pixels.argtypes = [i32, vp, i32, i64, i64, vp, vp, vp, i32, i32, vp]
+        L.ltmi_byteswap.argtypes = [i32, vp, vp, i32, i64, vp]
         L.ltmi_fft_plan_create.argtypes = [i32, i32, i32, i32, c.POINTER(vp)]
         L.ltmi_fft_plan_destroy.argtypes = [vp]
         L.ltmi_crystallinity.argtypes = [vp, vp, i32, i64, i64, vp, vp, i32, i32, i32, vp, i32, vp]
@@ -305,6 +306,13 @@ def repair_pixels(device, buf_ptr, dtype, n_frames, ld, excl_ptr, env_ptr, cnt_p
         int(device), buf_ptr, dtype_code(dtype), n_frames, ld, excl_ptr, env_ptr, cnt_ptr,
         int(n_excl), int(max_env), stream if isinstance(stream, int) else _stream_ptr(stream)),
         'ltmi_repair_pixels')
+
+
+def byteswap(device, src_ptr, dst_ptr, itemsize, n_items, stream=None):
+    """Reverse the bytes of every `itemsize`-byte item (device pointers; in place if equal)."""
+    check(lib().ltmi_byteswap(
+        int(device), src_ptr, dst_ptr, int(itemsize), int(n_items),
+        stream if isinstance(stream, int) else _stream_ptr(stream)), 'ltmi_byteswap')
 
 
 class FFTPlan:

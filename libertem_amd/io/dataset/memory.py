@@ -53,10 +53,18 @@ class MemoryDataSet(DataSet):
                 self._data = None
         else:
             self._data = np.asarray(data)
+        self._swap_itemsize = 0
         if self._data is not None and not self._data.dtype.isnative:
-            # device kernels read native byte order: swap once on the host (the reference converts
-            # per tile with astype(), io/dataset/memory.py:102-105)
-            self._data = self._data.astype(self._data.dtype.newbyteorder('='))
+            if self._data.dtype.kind in 'iu':
+                # Integers in the other byte order (big-endian detector files) stay as they are: the
+                # NumPy path converts per tile with astype() like the reference
+                # (io/dataset/memory.py:102-105), the HIP path uploads the raw bytes and swaps them on
+                # the device (ltmi_byteswap; reference io/dataset/base/decode.py:123-158 does it on the
+                # host for every tile).
+                self._swap_itemsize = self._data.dtype.itemsize
+            else:
+                # floats: one host copy (the reference's decoder has no float byte swapping at all)
+                self._data = self._data.astype(self._data.dtype.newbyteorder('='))
         full_shape = tuple(self._device_array.shape if self._device_array is not None
                            else self._data.shape)
         # shard=(rank, world): `data` is this rank's contiguous block of a larger dataset whose
@@ -104,7 +112,7 @@ class MemoryDataSet(DataSet):
         self._check_cast = check_cast
         self._sync_offset = sync_offset
         raw_dtype = self._device_array.dtype if self._device_array is not None \
-            else self._data.dtype
+            else self._data.dtype.newbyteorder('=')
         self._meta = DataSetMeta(shape=self._shape, raw_dtype=raw_dtype,
                                  image_count=prod(self._shape.nav))
 
@@ -206,10 +214,11 @@ class _HipStager:
     through two pinned bounce buffers.
     """
 
-    def __init__(self, device, chunk_frames, sig, dtype, host_array=None):
+    def __init__(self, device, chunk_frames, sig, dtype, host_array=None, swap_itemsize=0):
         import torch
         self.torch = torch
         self.device = device
+        self.swap_itemsize = int(swap_itemsize)     # > 0: host data is in the other byte order
         self.sig = tuple(sig)
         self.dtype = np.dtype(dtype)
         self.tdt = torch_dtype_for(dtype)
@@ -264,6 +273,13 @@ class _HipStager:
             if self.consumed[slot] is not None:
                 self.copy_stream.wait_event(self.consumed[slot])  # kernels done with the buffer
             self.dev[slot][:n].copy_(src, non_blocking=True)
+            if self.swap_itemsize > 1:
+                # decode on the device, in place, behind the copy on the same stream
+                from libertem_amd import hip
+                d = self.dev[slot]
+                hip.byteswap(self.device, d.data_ptr(), d.data_ptr(), self.swap_itemsize,
+                             n * int(np.prod(self.sig, dtype=np.int64)),
+                             stream=self.copy_stream.cuda_stream)
             self.uploaded[slot].record(self.copy_stream)
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
@@ -449,7 +465,8 @@ class MemPartition(Partition):
         host = ds.flat_host()
         part_host = host[self._local0:self._local0 + self._num_frames]
         stager = _HipStager(device, min(depth, n), ds.shape.sig, ds.dtype,
-                            host_array=part_host if idxs is None else None)
+                            host_array=part_host if idxs is None else None,
+                            swap_itemsize=ds._swap_itemsize)
 
         def host_chunk(g0, g1):
             if idxs is None:

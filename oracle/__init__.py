@@ -14,8 +14,9 @@ tests/golden/*.npz) in `tests/test_oracle_golden.py`.  Parity is therefore PINNE
 ApplyMasksUDF (dtype matrix, tile shapes, partitioning), SumUDF, SumSigUDF, CoMUDF, COMAnalysis
 post-processing, RadialFourierAnalysis (dense complex64), all mask factories, `rmatmul`
 (CSR/CSC), the tiling negotiation and detector corrections (CorrectionSet on Sum/SumSig/
-ApplyMasks UDFs, RepairDescriptor tables, correct_dot_masks, tile-shape adjustment).  Not pinned through the import (third-party pydata
+ApplyMasks UDFs, RepairDescriptor tables, correct_dot_masks, tile-shape adjustment) and the
+byte-order decoders (io/dataset/base/decode.py, unsigned dtype pairs of the reference's own test).  Not pinned through the import (third-party pydata
 `sparse` is absent): construction of *sparse* mask stacks; there the oracle follows
 common/container.py:33-71 + masks.py:290-353 and is anchored on `rmatmul` + dense radial_bins.
 """
-from . import masks, tiling, path, corrections  # noqa: F401
+from . import masks, tiling, path, corrections, decode  # noqa: F401

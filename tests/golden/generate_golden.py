@@ -375,7 +375,61 @@ def gen_crystallinity():
     save('crystallinity', **out)
 
 
+# ---------------------------------------------------------------------------
+# 12. byte-order decoders (io/dataset/base/decode.py)
+# ---------------------------------------------------------------------------
+def gen_decode():
+    from libertem.io.dataset.base import decode as ref_decode
+    out = {}
+    dec = ref_decode.DtypeConversionDecoder()
+    for case in recipes.DECODE_CASES:
+        vals, raw = recipes.make_decode_case(case)
+        in_full = np.dtype(case['in_dtype']).newbyteorder(case['order'])
+        read = np.dtype(case['out_dtype'])
+        need = bool(dec._need_byteswap(in_full, read))
+        native = dec.get_native_dtype(in_full, read)
+        fn = dec.get_decode(native_dtype=in_full, read_dtype=read)
+        res = np.zeros((1, vals.size), dtype=read)
+        n = np.array(case['shape'])
+        fn(inp=raw if need else raw.view(np.dtype(case['in_dtype'])), out=res, idx=0,
+           native_dtype=np.dtype(case['in_dtype']), rr=np.array([0, 0, raw.nbytes]),
+           origin=np.zeros(3, dtype=np.int64), shape=n, ds_shape=n)
+        out[case['name']] = res
+        out[case['name'] + '__need_swap'] = np.array(need)
+        out[case['name'] + '__native'] = np.array(str(np.dtype(native)))
+        out[case['name'] + '__sha_raw'] = np.frombuffer(bytes.fromhex(sha(raw)), dtype=np.uint8)
+        if need:
+            only = {2: ref_decode.decode_swap_only_2, 4: ref_decode.decode_swap_only_4,
+                    8: ref_decode.decode_swap_only_8}[in_full.itemsize]
+            res2 = np.zeros((1, vals.size), dtype=np.dtype(case['in_dtype']))
+            only(inp=raw, out=res2, idx=0, native_dtype=np.dtype(case['in_dtype']),
+                 rr=np.array([0, 0, raw.nbytes]), origin=np.zeros(3, dtype=np.int64), shape=n,
+                 ds_shape=n)
+            out[case['name'] + '__swap_only'] = res2
+        print(case['name'], need, native, res.dtype)
+    # floats in the other byte order are refused by the reference
+    try:
+        dec.get_decode(native_dtype=np.dtype('>f4'), read_dtype=np.dtype('float32'))
+        out['float_swap_error'] = np.array('')
+    except NotImplementedError as e:
+        out['float_swap_error'] = np.array(str(e))
+    save('decode', **out)
+
+
+GENERATORS = {}
+
 if __name__ == '__main__':
+    GENERATORS.update({k[4:]: v for k, v in list(globals().items()) if k.startswith('gen_')})
+    if len(sys.argv) > 1:
+        # regenerate only the named fixtures, keep the other manifest entries
+        with open(os.path.join(HERE, 'MANIFEST.json')) as f:
+            MANIFEST.update(json.load(f))
+        for name in sys.argv[1:]:
+            GENERATORS[name]()
+        with open(os.path.join(HERE, 'MANIFEST.json'), 'w') as f:
+            json.dump(MANIFEST, f, indent=1, sort_keys=True)
+        sys.exit(0)
+    gen_decode()
     gen_crystallinity()
     gen_corrections()
     gen_shifts()

@@ -440,3 +440,27 @@ def make_cryst_case(case):
     yy, xx = np.mgrid[0:case['sig'][0], 0:case['sig'][1]]
     lattice = 40 * (1 + np.cos(2 * np.pi * xx / 4.0)) * (1 + np.cos(2 * np.pi * yy / 5.0))
     return (base + lattice).astype(dt)
+
+
+# ---- byte-order decoders (reference io/dataset/base/decode.py; its test tests/io/test_decode_swap.py:166-245)
+DECODE_PAIRS = [
+    ('uint8', 'uint16'), ('uint8', 'uint32'), ('uint8', 'uint64'), ('uint16', 'uint16'),
+    ('uint16', 'uint32'), ('uint16', 'uint64'), ('uint32', 'uint32'), ('uint32', 'uint64'),
+    ('uint8', 'float32'), ('uint16', 'float32'), ('uint32', 'float32'),
+    ('uint8', 'float64'), ('uint16', 'float64'), ('uint32', 'float64'),
+    ('uint64', 'uint64'),
+]   # unsigned only, as in the reference's test: its decoders compose UNSIGNED words and rely on numba's
+#     wrap-around when storing them into signed outputs, which the identity-njit stand-in cannot show
+DECODE_CASES = [dict(name=f"{a}_to_{b}_{'be' if order == '>' else 'le'}", in_dtype=a, out_dtype=b,
+                     order=order, seed=900 + i * 2 + (order == '>'), shape=(1, 16, 16))
+                for i, (a, b) in enumerate(DECODE_PAIRS) for order in ('<', '>')]
+
+
+def make_decode_case(case):
+    """values (native order) and the raw bytes as they sit in a file of byte order case['order']"""
+    rng = np.random.default_rng(case['seed'])
+    dt = np.dtype(case['in_dtype'])
+    info = np.iinfo(dt)
+    vals = rng.integers(info.min, info.max, size=case['shape'], dtype=dt, endpoint=True)
+    stored = vals.astype(dt.newbyteorder(case['order']))
+    return vals, stored.reshape(-1).view(np.uint8).copy()

@@ -604,3 +604,34 @@ def test_randomised_differential(seed):
     r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'fuzz_kernels.py'), '250',
                         str(seed)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+# ---- byte-order decode -----------------------------------------------------------------------------
+@pytest.mark.parametrize('itemsize', [1, 2, 4, 8])
+@pytest.mark.parametrize('n_items,offset', [(1, 0), (7, 0), (4096, 0), (100003, 0), (5000, 3)])
+def test_byteswap_vs_oracle(hip, itemsize, n_items, offset):
+    """ltmi_byteswap == byteswap_N_straight of the reference (oracle.decode), out of place and in
+    place, aligned and unaligned buffers."""
+    from oracle import decode as od
+    rng = np.random.default_rng(itemsize * 1000 + n_items)
+    raw = rng.integers(0, 256, n_items * itemsize + offset * itemsize, dtype=np.uint8)
+    src = _dev(raw)
+    dst = torch.zeros_like(src)
+    o = offset * itemsize
+    hip.byteswap(0, src.data_ptr() + o, dst.data_ptr() + o, itemsize, n_items)
+    torch.cuda.synchronize()
+    ref = od.byteswap_straight(raw[o:], itemsize) if itemsize > 1 else raw[o:]
+    assert np.array_equal(dst.cpu().numpy()[o:], ref)
+    assert np.all(dst.cpu().numpy()[:o] == 0)
+    hip.byteswap(0, src.data_ptr() + o, src.data_ptr() + o, itemsize, n_items)     # in place
+    torch.cuda.synchronize()
+    assert np.array_equal(src.cpu().numpy()[o:], ref)
+    assert np.array_equal(src.cpu().numpy()[:o], raw[:o])
+
+
+def test_byteswap_rejects_bad_arguments(hip):
+    t = _dev(np.zeros(64, dtype=np.uint8))
+    with pytest.raises((RuntimeError, ValueError)):
+        hip.byteswap(0, t.data_ptr(), t.data_ptr(), 3, 4)
+    with pytest.raises((RuntimeError, ValueError)):
+        hip.byteswap(0, t.data_ptr(), t.data_ptr(), 2, -1)

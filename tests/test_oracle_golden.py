@@ -318,3 +318,35 @@ def test_crystallinity_oracle_vs_reference(case):
     ref = g[case['name']]
     assert res.shape == ref.shape and res.dtype == ref.dtype
     np.testing.assert_allclose(res, ref, rtol=2e-6)
+
+
+# ---- byte-order decoders (reference io/dataset/base/decode.py) --------------------------------------
+@pytest.mark.parametrize('case', recipes.DECODE_CASES, ids=lambda c: c['name'])
+def test_decode_oracle_vs_reference(golden_dir, case):
+    """oracle.decode == the reference's DtypeConversionDecoder on the same bytes (golden vectors of
+    the reference's own functions; dtype pairs of its tests/io/test_decode_swap.py:166-245)."""
+    from oracle import decode as od
+    g = _load(golden_dir, 'decode')
+    vals, raw = recipes.make_decode_case(case)
+    assert hashlib.sha256(raw.tobytes()).digest() == g[case['name'] + '__sha_raw'].tobytes()
+    in_full = np.dtype(case['in_dtype']).newbyteorder(case['order'])
+    need = od.need_byteswap(in_full, case['out_dtype'])
+    assert need == bool(g[case['name'] + '__need_swap'])
+    assert str(od.get_native_dtype(in_full, case['out_dtype'])) == str(g[case['name'] + '__native'])
+    got = od.decode(raw if need else raw.view(case['in_dtype']), in_full, case['out_dtype'])
+    ref = g[case['name']].reshape(-1)
+    assert got.dtype == ref.dtype and np.array_equal(got, ref)
+    # the reference test's own expectation: swap back, then convert
+    assert np.array_equal(ref, vals.reshape(-1).astype(case['out_dtype']))
+    if need:
+        item = np.dtype(case['in_dtype']).itemsize
+        assert np.array_equal(od.byteswap_straight(raw, item).view(case['in_dtype']),
+                              g[case['name'] + '__swap_only'].reshape(-1))
+
+
+def test_decode_float_swap_refused_like_reference(golden_dir):
+    from oracle import decode as od
+    g = _load(golden_dir, 'decode')
+    with pytest.raises(NotImplementedError) as e:
+        od.decode(np.zeros(8, dtype=np.uint8), np.dtype('>f4'), np.float32)
+    assert str(e.value) == str(g['float_swap_error'])

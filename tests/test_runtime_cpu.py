@@ -483,6 +483,38 @@ def test_raw_file_dataset(ctx, tmp_path):
 
 
 # --- crystallinity host helpers ---------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', ['>u2', '>i2', '>u4', '<u2', '>f4'])
+def test_other_byte_order_datasets(ctx, tmp_path, dtype):
+    """Raw files / arrays in the other byte order give the same results as native ones (reference:
+    DtypeConversionDecoder, io/dataset/base/decode.py:123-158; tests/io/test_decode_swap.py)."""
+    rng = np.random.default_rng(11)
+    dt = np.dtype(dtype)
+    native = dt.newbyteorder('=')
+    if dt.kind == 'f':
+        vals = rng.random((3, 5, 16, 16)).astype(native)
+    else:
+        info = np.iinfo(native)
+        vals = rng.integers(max(info.min, -3000), min(info.max, 3000), (3, 5, 16, 16)).astype(native)
+    path = str(tmp_path / "scan.raw")
+    vals.astype(dt).tofile(path)
+    masks = rng.random((2, 16, 16)).astype(np.float32)
+    ds = ctx.load('raw', path=path, dtype=dtype, nav_shape=(3, 5), sig_shape=(16, 16),
+                  num_partitions=2)
+    assert ds.dtype == native and ds.dtype.isnative
+    if dt.kind in 'iu' and not dt.isnative:
+        assert isinstance(ds.data.base if ds.data.base is not None else ds.data, np.memmap) or \
+            not ds.data.flags.owndata                      # still the file mapping: no host copy
+    res = ctx.run_udf(dataset=ds, udf=NumpyMasksUDF(masks))
+    ds_n = ctx.load('memory', data=vals, sig_dims=2, num_partitions=2)
+    ref = ctx.run_udf(dataset=ds_n, udf=NumpyMasksUDF(masks))
+    assert res['intensity'].data.dtype == ref['intensity'].data.dtype
+    assert np.array_equal(res['intensity'].data, ref['intensity'].data)
+    # ... and an in-memory array in the other byte order
+    ds_m = ctx.load('memory', data=vals.astype(dt), sig_dims=2, num_partitions=2)
+    res_m = ctx.run_udf(dataset=ds_m, udf=NumpyMasksUDF(masks))
+    assert np.array_equal(res_m['intensity'].data, ref['intensity'].data)
+
+
 @pytest.mark.parametrize('sig,rad_in,rad_out,center,rad', [
     ((32, 32), 4, 9, (16, 16), 5), ((24, 40), 3, 8, None, None), ((33, 31), 2.5, 11.5, (10.5, 20.25), 4),
 ])

@@ -807,6 +807,37 @@ def test_raw_file_dataset_on_device(ctx, tmp_path):
     assert _close(res['intensity'].data, ref, F32_TOL)
 
 
+@pytest.mark.parametrize('dtype', ['>u2', '>i2', '>u4'])
+def test_big_endian_raw_file_decoded_on_device(ctx, tmp_path, dtype):
+    """A raw file in the other byte order: the mapping is uploaded as it is and decoded on the GPU
+    (ltmi_byteswap behind the H2D copy); results equal those of the same values in native order."""
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd.udf.sum import SumUDF
+    rng = np.random.default_rng(21)
+    dt = np.dtype(dtype)
+    native = dt.newbyteorder('=')
+    info = np.iinfo(native)
+    vals = rng.integers(max(info.min, -3000), min(info.max, 3000), (6, 7, 32, 32)).astype(native)
+    path = str(tmp_path / "scan_be.raw")
+    vals.astype(dt).tofile(path)
+    masks = rng.random((3, 32, 32)).astype(np.float32)
+    ds = ctx.load('raw', path=path, dtype=dtype, nav_shape=(6, 7), sig_shape=(32, 32),
+                  num_partitions=3)
+    assert ds._swap_itemsize == dt.itemsize and ds.dtype == native
+    res = ctx.run_udf(dataset=ds, udf=[ApplyMasksUDF(mask_factories=lambda: masks), SumUDF()])
+    ds_n = ctx.load('memory', data=vals, num_partitions=3, sig_dims=2)
+    ref = ctx.run_udf(dataset=ds_n, udf=[ApplyMasksUDF(mask_factories=lambda: masks), SumUDF()])
+    assert np.array_equal(res[0]['intensity'].data, ref[0]['intensity'].data)
+    assert np.array_equal(res[1]['intensity'].data, ref[1]['intensity'].data)
+    assert _close(res[0]['intensity'].data, opath.apply_masks(vals, masks, num_partitions=3),
+                  F32_TOL if native.itemsize < 4 else 1e-6)
+    # ROI: frames gathered on the host (bounce buffers), still decoded on the device
+    roi = rng.random((6, 7)) < 0.5
+    part = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda: masks), roi=roi)
+    ref_p = ctx.run_udf(dataset=ds_n, udf=ApplyMasksUDF(mask_factories=lambda: masks), roi=roi)
+    assert np.array_equal(part['intensity'].raw_data, ref_p['intensity'].raw_data)
+
+
 def test_shifted_masks_with_roi_and_partitions(ctx):
     """per-frame shifts (aux data) are re-sliced per partition and compressed by the ROI"""
     from libertem_amd.udf.masks import ApplyMasksUDF
