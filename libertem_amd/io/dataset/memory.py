@@ -186,6 +186,12 @@ class MemoryDataSet(DataSet):
         return self._device_array.reshape((prod(self._local_shape.nav),) +
                                           tuple(self._shape.sig))
 
+    eager_upload = True     # HIP path: enqueue the upload of chunk i+1 before the kernels of chunk i
+
+    def wait_for_frames(self, upto):
+        """Hook for datasets whose frames are still arriving (io/dataset/stream.py): returns once
+        the first `upto` frames of the scan are readable.  Everything is there already here."""
+
     def get_partitions(self):
         if self._partitions is None:
             self._partitions = [
@@ -344,6 +350,7 @@ class MemPartition(Partition):
         elif array_backend == NUMPY:
             if ds.is_device_resident:
                 raise RuntimeError("a device-resident MemoryDataSet only serves BACKEND_HIP")
+            ds.wait_for_frames(self._start_frame + self._num_frames)
             yield from self._get_tiles_numpy(tiling_scheme, np.dtype(dest_dtype), roi,
                                              corrections)
         else:
@@ -470,7 +477,9 @@ class MemPartition(Partition):
 
         def host_chunk(g0, g1):
             if idxs is None:
+                ds.wait_for_frames(self._start_frame + g1)     # (a stream: frames up to here)
                 return part_host[g0:g1]
+            ds.wait_for_frames(self._start_frame + self._num_frames)
             return host[idxs[g0:g1]]
 
         groups = [(g0, min(n, g0 + depth)) for g0 in range(0, n, depth)]
@@ -479,13 +488,16 @@ class MemPartition(Partition):
             for i, (g0, g1) in enumerate(groups):
                 slot = i & 1
                 chunk = stager.get(slot, g1 - g0)
-                if i + 1 < len(groups) and stager.registered is not None:
+                eager = stager.registered is not None and ds.eager_upload
+                if i + 1 < len(groups) and eager:
                     # DMA straight from user memory: enqueue the next upload before the kernels
                     stager.upload(slot ^ 1, host_chunk(*groups[i + 1]))
                 yield from self._sub_tiles(fix(chunk), compressed_origin + g0, tiling_scheme)
                 stager.release(slot)
-                if i + 1 < len(groups) and stager.registered is None:
+                if i + 1 < len(groups) and not eager:
                     # bounce-buffer mode: the host memcpy overlaps the kernels just enqueued
+                    # (streams: the frames of the next chunk may not have arrived yet -- wait for
+                    # them only after this chunk's kernels are on their way)
                     stager.upload(slot ^ 1, host_chunk(*groups[i + 1]))
         finally:
             stager.close()

@@ -1,0 +1,126 @@
+"""
+StreamDataSet: frames that are still arriving (`ctx.load("stream", frames=..., nav_shape=...,
+sig_shape=..., dtype=...)`), the data side of row f4 of SURVEY.md section 8: the reference feeds
+partitions of a running acquisition to its workers through queues (executor/pipelined.py:789-1253)
+and publishes partial results with `run_udf_iter` (api.py:1053-1152, udf/base.py:2657-2733).
+
+Here one process drives one GPU, so the feed is a thread: it copies the chunks the acquisition
+yields into one host buffer and publishes how many frames have landed; a partition's chunks are
+uploaded (double-buffered H2D, io/dataset/memory.py) as soon as THEIR frames are there, i.e. the GPU
+works on the scan while it is being recorded, and `Context.run_udf_iter` hands out the result after
+every partition.  Everything else (tiling, corrections, ROI, sharding) is MemoryDataSet.
+"""
+import threading
+
+import numpy as np
+
+from libertem_amd.common.math import prod
+from .base import DataSetException
+from .memory import MemoryDataSet
+
+
+class StreamDataSet(MemoryDataSet):
+    """
+    Parameters
+    ----------
+    frames : iterable of array-like
+        Each item holds one or more whole frames, in scan order: shape `sig_shape` or
+        `(n,) + sig_shape`.  Consumed by a background thread, once.
+    nav_shape, sig_shape : tuple of int
+    dtype : numpy dtype of the frames (items are cast to it)
+    num_partitions : int, optional
+        Partial results are published per partition (default: about 16, at least one frame each).
+    timeout : float, optional
+        Seconds to wait for missing frames before giving up (default: wait for ever).
+    """
+
+    eager_upload = False    # never wait for the next chunk's frames before launching this chunk
+
+    def __init__(self, frames, nav_shape, sig_shape, dtype, num_partitions=None, timeout=None,
+                 tileshape=None):
+        nav_shape = tuple(int(x) for x in nav_shape)
+        sig_shape = tuple(int(x) for x in sig_shape)
+        n_frames = prod(nav_shape)
+        if n_frames <= 0 or prod(sig_shape) <= 0:
+            raise DataSetException(f"empty stream shape {nav_shape} x {sig_shape}")
+        dt = np.dtype(dtype)
+        if not dt.isnative:
+            raise DataSetException("a stream delivers frames in the native byte order")
+        buf = np.zeros((n_frames,) + sig_shape, dtype=dt)
+        if num_partitions is None:
+            num_partitions = max(1, min(16, n_frames))
+        super().__init__(data=buf.reshape(nav_shape + sig_shape), sig_dims=len(sig_shape),
+                         num_partitions=num_partitions, tileshape=tileshape)
+        self._buf = buf
+        self._n_frames = n_frames
+        self._timeout = timeout
+        self._arrived = 0
+        self._finished = False
+        self._error = None
+        self._cond = threading.Condition()
+        self._thread = threading.Thread(target=self._pump, args=(iter(frames),), daemon=True,
+                                        name='ltmi-stream-feed')
+        self._thread.start()
+
+    # --- feed ------------------------------------------------------------------------------------
+    def _pump(self, it):
+        sig = self._buf.shape[1:]
+        try:
+            for item in it:
+                chunk = np.asarray(item)
+                if chunk.shape == sig:
+                    chunk = chunk[None]
+                if chunk.shape[1:] != sig:
+                    raise DataSetException(
+                        f"stream item of shape {chunk.shape} does not hold frames of {sig}")
+                n = chunk.shape[0]
+                with self._cond:
+                    start = self._arrived
+                if start + n > self._n_frames:
+                    raise DataSetException(
+                        f"stream delivered more than the {self._n_frames} frames of the scan")
+                self._buf[start:start + n] = chunk            # cast + copy outside the lock
+                with self._cond:
+                    self._arrived = start + n
+                    self._cond.notify_all()
+                if start + n == self._n_frames:
+                    break
+        except BaseException as e:      # noqa: B036  (handed to the consumer, never swallowed)
+            with self._cond:
+                self._error = e
+                self._cond.notify_all()
+            return
+        with self._cond:
+            self._finished = True
+            self._cond.notify_all()
+
+    @property
+    def frames_arrived(self):
+        with self._cond:
+            return self._arrived
+
+    def wait_for_frames(self, upto):
+        """Block until the first `upto` frames of the scan are in the buffer."""
+        upto = min(int(upto), self._n_frames)
+        with self._cond:
+            ok = self._cond.wait_for(
+                lambda: self._arrived >= upto or self._error is not None or self._finished,
+                timeout=self._timeout)
+            if self._error is not None:
+                raise DataSetException(f"the frame stream failed: {self._error!r}") from self._error
+            if self._arrived >= upto:
+                return
+            if self._finished:
+                raise DataSetException(
+                    f"the frame stream ended after {self._arrived} of {self._n_frames} frames")
+            if not ok:
+                raise DataSetException(
+                    f"timed out after {self._timeout} s waiting for frame {upto} "
+                    f"({self._arrived} arrived)")
+
+    def __repr__(self):
+        return (f"<StreamDataSet of {self.dtype} shape={self.shape} "
+                f"({self.frames_arrived}/{self._n_frames} frames arrived)>")
+
+    def __getstate__(self):
+        raise TypeError("a StreamDataSet is bound to its feeding thread and cannot be pickled")

@@ -515,6 +515,76 @@ def test_other_byte_order_datasets(ctx, tmp_path, dtype):
     assert np.array_equal(res_m['intensity'].data, ref['intensity'].data)
 
 
+def _feed(flat, step, delay=0.005, stop_at=None):
+    import time
+    for i in range(0, len(flat) if stop_at is None else stop_at, step):
+        time.sleep(delay)
+        yield flat[i:i + step]
+
+
+@pytest.fixture
+def live_ctx():
+    # (no debug round trip through pickle: a stream is bound to its feeding thread, like a
+    # device-resident dataset is bound to its GPU)
+    return Context(executor=InlineJobExecutor(debug=False, inline_threads=2))
+
+
+def test_stream_dataset_partial_results(live_ctx):
+    """Row f4: frames of a running acquisition (an iterator) are processed while they arrive and
+    `run_udf_iter` publishes the result after every partition (reference api.py:1053-1152)."""
+    rng = np.random.default_rng(3)
+    data = rng.integers(0, 100, (6, 8, 16, 16)).astype(np.uint16)
+    flat = data.reshape((-1, 16, 16))
+    masks = rng.random((2, 16, 16)).astype(np.float32)
+    ds = live_ctx.load('stream', frames=_feed(flat, 5), nav_shape=(6, 8), sig_shape=(16, 16),
+                  dtype=np.uint16, num_partitions=6)
+    assert tuple(ds.shape) == (6, 8, 16, 16) and ds.dtype == np.uint16
+    done = []
+    for part in live_ctx.run_udf_iter(dataset=ds, udf=NumpyMasksUDF(masks)):
+        res = part.buffers[0]['intensity'].data.reshape((48, 2))
+        done.append(int(np.count_nonzero(res[:, 0])))
+        assert ds.frames_arrived >= done[-1]              # only frames that arrived are in
+    assert done == [8, 16, 24, 32, 40, 48]
+    ref = flat.reshape((48, -1)).astype(np.float32) @ masks.reshape((2, -1)).T
+    assert np.allclose(res, ref, rtol=1e-5)
+    # single frames as items, ROI, a second UDF on the finished stream object
+    ds = live_ctx.load('stream', frames=iter(flat), nav_shape=(6, 8), sig_shape=(16, 16), dtype=np.uint16)
+    roi = rng.random((6, 8)) < 0.5
+    r = live_ctx.run_udf(dataset=ds, udf=NumpySumUDF(), roi=roi)
+    assert np.array_equal(r['intensity'].data, flat[roi.reshape(-1)].astype(np.float32).sum(axis=0))
+    r = live_ctx.run_udf(dataset=ds, udf=NumpySumUDF())
+    assert np.array_equal(r['intensity'].data, flat.astype(np.float32).sum(axis=0))
+
+
+def test_stream_dataset_failures(live_ctx, ctx):
+    from libertem_amd.io.dataset import DataSetException
+    ds = ctx.load('stream', frames=[np.ones((4, 4))], nav_shape=(1,), sig_shape=(4, 4),
+                  dtype=np.float32)
+    with pytest.raises(TypeError, match='cannot be pickled'):       # debug executors pickle tasks
+        ctx.run_udf(dataset=ds, udf=NumpySumUDF())
+    ctx = live_ctx
+    flat = np.ones((12, 4, 4), dtype=np.float32)
+    ds = ctx.load('stream', frames=_feed(flat, 4, stop_at=8), nav_shape=(12,), sig_shape=(4, 4),
+                  dtype=np.float32, num_partitions=3)
+    with pytest.raises(DataSetException, match='ended after 8 of 12 frames'):
+        ctx.run_udf(dataset=ds, udf=NumpySumUDF())
+    ds = ctx.load('stream', frames=[np.ones((2, 5, 4))], nav_shape=(12,), sig_shape=(4, 4),
+                  dtype=np.float32)
+    with pytest.raises(DataSetException, match='does not hold frames'):
+        ctx.run_udf(dataset=ds, udf=NumpySumUDF())
+
+    def never():
+        import time
+        yield flat[:4]
+        time.sleep(5)
+    ds = ctx.load('stream', frames=never(), nav_shape=(12,), sig_shape=(4, 4), dtype=np.float32,
+                  num_partitions=3, timeout=0.2)
+    with pytest.raises(DataSetException, match='timed out'):
+        ctx.run_udf(dataset=ds, udf=NumpySumUDF())
+    with pytest.raises(DataSetException):
+        ctx.load('stream', frames=[], nav_shape=(0,), sig_shape=(4, 4), dtype=np.float32)
+
+
 @pytest.mark.parametrize('sig,rad_in,rad_out,center,rad', [
     ((32, 32), 4, 9, (16, 16), 5), ((24, 40), 3, 8, None, None), ((33, 31), 2.5, 11.5, (10.5, 20.25), 4),
 ])

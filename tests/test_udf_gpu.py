@@ -838,6 +838,34 @@ def test_big_endian_raw_file_decoded_on_device(ctx, tmp_path, dtype):
     assert np.array_equal(part['intensity'].raw_data, ref_p['intensity'].raw_data)
 
 
+def test_stream_dataset_on_device(ctx):
+    """Row f4: frames arriving from an iterator are uploaded chunk by chunk as they land and go
+    through the HIP kernels; partial results after every partition, final result == MemoryDataSet."""
+    import time
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    rng = np.random.default_rng(8)
+    data = rng.integers(0, 4000, (8, 16, 32, 32)).astype(np.uint16)
+    flat = data.reshape((-1, 32, 32))
+    masks = rng.random((3, 32, 32)).astype(np.float32)
+
+    def feed():
+        for i in range(0, len(flat), 16):
+            time.sleep(0.005)
+            yield flat[i:i + 16]
+
+    ds = ctx.load('stream', frames=feed(), nav_shape=(8, 16), sig_shape=(32, 32), dtype=np.uint16,
+                  num_partitions=4)
+    counts = []
+    for part in ctx.run_udf_iter(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda: masks)):
+        res = part.buffers[0]['intensity'].data.reshape((128, 3))
+        counts.append(int(np.count_nonzero(res[:, 0])))
+    assert counts == [32, 64, 96, 128]
+    ref = ctx.run_udf(dataset=ctx.load('memory', data=data, num_partitions=4, sig_dims=2),
+                      udf=ApplyMasksUDF(mask_factories=lambda: masks))
+    assert np.array_equal(res, ref['intensity'].data.reshape((128, 3)))
+    assert _close(res, opath.apply_masks(data, masks, num_partitions=4).reshape((128, 3)), F32_TOL)
+
+
 def test_shifted_masks_with_roi_and_partitions(ctx):
     """per-frame shifts (aux data) are re-sliced per partition and compressed by the ROI"""
     from libertem_amd.udf.masks import ApplyMasksUDF
