@@ -59,9 +59,6 @@ constexpr int BE_PASS = BE_SETS * BE_SLOTS * 16;     // real masks per pass (102
 #ifndef BE_D_
 #define BE_D_ 3
 #endif
-#ifndef BE_PIPE
-#define BE_PIPE 0
-#endif
 #ifndef BE_PAD
 #define BE_PAD 16
 #endif
@@ -72,7 +69,6 @@ struct BellImage {
     uint32_t *stream = nullptr;      // [blocks][64 lanes][A step 0, A step 1, pixels]
     int64_t *stream_off = nullptr;   // [n_pass * 4 + set] first record of the stream
     int *nblk = nullptr;             // [(active index * 4 + set) * 16 + slot] records of the pair
-    int *ntot = nullptr;             // [active index * 4 + set] records of the set in the chunk
     int *active = nullptr;           // chunks with entries, concatenated per pass
     int *active_off = nullptr;       // [n_pass + 1]
     int n_pass = 0;
@@ -115,7 +111,7 @@ template <typename T>
 __global__ void __launch_bounds__(BE_SETS * 64, BE_OCC)
 k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
              const uint32_t *__restrict__ stream, const int64_t *__restrict__ stream_off,
-             const int *__restrict__ nblk, const int *__restrict__ ntot,
+             const int *__restrict__ nblk,
              const int *__restrict__ active, const int *__restrict__ active_off,
              float *__restrict__ out, int64_t ld_out,
              int n_cols, int accumulate, int ablate) {
@@ -191,20 +187,21 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
     __builtin_amdgcn_s_barrier();          // (not __syncthreads: its fence drains vmcnt, i.e. the record ring)
     asm volatile("" ::: "memory");
 
-    // B operands (raw pixel type) of the record about to be multiplied / of the one after it
-    T bcur[2][TILES], bnxt[2][TILES];
+    // B operands (raw pixel type) of the record about to be multiplied
+    T bcur[2][TILES];
     const unsigned char *bbase = be_lds + lane_base;
-    // read the B operands of ring entry PH into bnxt; WAIT = younger records allowed in flight
-    auto preread = [&](auto PH, auto WAIT) {
+    // wait for ring entry PH and read its B operands (one LDS read of the pixel type per step
+    // and frame tile)
+    auto read_b = [&](auto PH) {
         bu32x3 &r = ring[decltype(PH)::value];
-        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(decltype(WAIT)::value) : "memory");
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(BE_D - 1) : "memory");
         const unsigned o = r[2];
         const unsigned char *p0 = bbase + (o & 0xffffu) * C::SZ;
         const unsigned char *p1 = bbase + (o >> 16) * C::SZ;
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
-            bnxt[0][t] = *(const T *)(p0 + t * C::TILE_OFF);
-            bnxt[1][t] = *(const T *)(p1 + t * C::TILE_OFF);
+            bcur[0][t] = *(const T *)(p0 + t * C::TILE_OFF);
+            bcur[1][t] = *(const T *)(p1 + t * C::TILE_OFF);
         }
     };
 
@@ -219,17 +216,6 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
         int nbs[BE_SLOTS];                            // one 64-byte scalar load
 #pragma unroll
         for (int s = 0; s < BE_SLOTS; ++s) nbs[s] = nb_row[s];
-        int left = ablate == 2 ? 0 : ntot[ai * BE_SETS + j];   // records of this wave in the chunk
-        if (BE_PIPE && left > 0) {
-            // first record of the chunk: the oldest ring entry, BE_D - 1 younger ones (and, right
-            // after the issue, most of the frame DMA: record loads retire behind it anyway)
-            bstatic_for<0, BE_D>([&](auto PH) {
-                if (phase == decltype(PH)::value)
-                    preread(PH, std::integral_constant<int, BE_D - 1>{});
-            });
-#pragma unroll
-            for (int t = 0; t < TILES; ++t) { bcur[0][t] = bnxt[0][t]; bcur[1][t] = bnxt[1][t]; }
-        }
 
         bstatic_for<0, BE_SLOTS>([&](auto S) {
             constexpr int s = decltype(S)::value;
@@ -237,17 +223,11 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
             for (int b = 0; b < nb; ++b) {
                 auto consume = [&](auto PH) {
                     constexpr int ph = decltype(PH)::value;
-                    bu32x3 &r = ring[ph];                      // landed: waited for in its preread
-                    // LDS reads of the NEXT record go out before this record's MFMAs
-                    if constexpr (BE_PIPE) {
-                        if (left > 1)
-                            preread(std::integral_constant<int, (ph + 1) % BE_D>{},
-                                    std::integral_constant<int, BE_D - 2>{});
-                    } else {
-                        preread(PH, std::integral_constant<int, BE_D - 1>{});
-#pragma unroll
-                        for (int t = 0; t < TILES; ++t) { bcur[0][t] = bnxt[0][t]; bcur[1][t] = bnxt[1][t]; }
-                    }
+                    bu32x3 &r = ring[ph];
+                    // the oldest record of the ring: BE_D - 1 younger ones stay in flight.  (Right
+                    // after a DMA issue this also waits for most of the DMA -- record loads retire
+                    // behind it anyway, the stall would come BE_D records later.)
+                    read_b(PH);
                     // (copies first: __builtin_bit_cast on a vector ELEMENT reads element 0)
                     const unsigned x0 = r[0], x1 = r[1];
                     const float a_0 = __uint_as_float(x0);
@@ -269,17 +249,12 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
 #endif
                     __builtin_amdgcn_sched_barrier(0);
                     load_rec(r);                                   // refill this ring entry
-                    if constexpr (BE_PIPE) {
-#pragma unroll
-                        for (int t = 0; t < TILES; ++t) { bcur[0][t] = bnxt[0][t]; bcur[1][t] = bnxt[1][t]; }
-                    }
                 };
                 bstatic_for<0, BE_D>([&](auto PH) {
                     if (phase == decltype(PH)::value) consume(PH);
                 });
                 phase = phase == BE_D - 1 ? 0 : phase + 1;
                 since_dma = since_dma < BE_D ? since_dma + 1 : since_dma;
-                --left;
             }
         });
         // The next chunk must have landed before anyone reads it.  BE_D records consumed since the
@@ -327,7 +302,6 @@ void bell_destroy(void *image) {
     if (b->stream) (void)hipFree(b->stream);
     if (b->stream_off) (void)hipFree(b->stream_off);
     if (b->nblk) (void)hipFree(b->nblk);
-    if (b->ntot) (void)hipFree(b->ntot);
     if (b->active) (void)hipFree(b->active);
     if (b->active_off) (void)hipFree(b->active_off);
     delete b;
@@ -398,7 +372,7 @@ void *bell_build(const int64_t *indptr, const int64_t *indices, const float *val
             active_off[ps + 1] = (int)active.size();
         }
         const size_t n_act = std::max<size_t>(active.size(), 1);
-        std::vector<int> nblk(n_act * BE_SETS * BE_SLOTS, 0), ntot(n_act * BE_SETS, 0);
+        std::vector<int> nblk(n_act * BE_SETS * BE_SLOTS, 0);
         std::vector<int64_t> stream_off((size_t)n_pass * BE_SETS, 0);
         std::vector<uint32_t> stream;
         size_t blocks = 0;
@@ -418,7 +392,6 @@ void *bell_build(const int64_t *indptr, const int64_t *indices, const float *val
                             if (cols.empty() || cols.back() != en.px) cols.push_back(en.px);
                         const int nb = ((int)cols.size() + 7) / 8;
                         nblk[((size_t)ai * BE_SETS + j) * BE_SLOTS + s] = nb;
-                        ntot[(size_t)ai * BE_SETS + j] += nb;
                         const size_t base = stream.size();
                         stream.resize(base + (size_t)nb * BE_REC, 0u);
                         // pixel numbers: lane l -> columns 8*blk + (l >> 4) and + 4
@@ -452,14 +425,12 @@ void *bell_build(const int64_t *indptr, const int64_t *indices, const float *val
         hipError_t e = hipMalloc((void **)&b->stream, std::max<size_t>(stream.size(), 1) * 4);
         if (e == hipSuccess) e = hipMalloc((void **)&b->stream_off, stream_off.size() * 8);
         if (e == hipSuccess) e = hipMalloc((void **)&b->nblk, nblk.size() * 4);
-        if (e == hipSuccess) e = hipMalloc((void **)&b->ntot, ntot.size() * 4);
         if (e == hipSuccess) e = hipMalloc((void **)&b->active, active.size() * 4);
         if (e == hipSuccess) e = hipMalloc((void **)&b->active_off, active_off.size() * 4);
         if (e == hipSuccess && !stream.empty())
             e = hipMemcpy(b->stream, stream.data(), stream.size() * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(b->stream_off, stream_off.data(), stream_off.size() * 8, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(b->nblk, nblk.data(), nblk.size() * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(b->ntot, ntot.data(), ntot.size() * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(b->active, active.data(), active.size() * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(b->active_off, active_off.data(), active_off.size() * 4, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
@@ -493,7 +464,7 @@ static int launch_bell(ltmi_masks *m, BellImage *b, const T *tile, int64_t n_fra
     const int ablate = abl ? atoi(abl) : 0;
     hipLaunchKernelGGL(kern, grid, dim3(BE_SETS * 64), C::LDS_BYTES, stream, tile, ld, n_frames,
                        m->n_px, (const uint32_t *)b->stream, (const int64_t *)b->stream_off,
-                       (const int *)b->nblk, (const int *)b->ntot, (const int *)b->active,
+                       (const int *)b->nblk, (const int *)b->active,
                        (const int *)b->active_off, out,
                        ld_out_f, n_cols, accumulate, ablate);
     LTMI_HIP(hipGetLastError());
