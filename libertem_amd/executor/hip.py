@@ -100,6 +100,27 @@ class HipJobExecutor(JobExecutor):
             return False
         return d.get_world_size() > 1 or os.environ.get('LTMI_FORCE_COLLECTIVES') == '1'
 
+    def _node_shared(self):
+        """The shared, page-locked host ring of this node's ranks (executor/nodeshared.py), or None
+        when the ranks span several nodes / LTMI_RESULT_VIA=rccl asks for the device collectives."""
+        if self.gpu_id is None or not self._collectives_on or getattr(self, '_shared_off', False):
+            return None
+        via = os.environ.get('LTMI_RESULT_VIA', 'auto')
+        if via == 'rccl':
+            return None
+        if via != 'shm' and int(os.environ.get('LOCAL_WORLD_SIZE', '0')) != self.world_size:
+            return None
+        if getattr(self, '_shared', None) is None:
+            from .nodeshared import NodeShared, NodeSharedUnavailable
+            try:
+                self._shared = NodeShared(self._dist(), self._torch, self.gpu_id)
+            except NodeSharedUnavailable as e:
+                self._shared_off = True                  # same on every rank: device collectives
+                import logging
+                logging.getLogger(__name__).warning("%s -- results go through RCCL", e)
+                return None
+        return self._shared
+
     def _make_current(self):
         """Install this executor's GPU and stream as torch's current device / stream (no context
         manager: one process drives one GPU, the executor owns both).  Cheap when nothing changed:
@@ -168,6 +189,9 @@ class HipJobExecutor(JobExecutor):
 
     def close(self):
         self._scattered = {}
+        if getattr(self, '_shared', None) is not None:
+            self._shared.close()
+            self._shared = None
 
     # --- merging ------------------------------------------------------------------------------------
     def merge_results(self, udfs, damage, result_iter, apply_part_result):
@@ -198,11 +222,47 @@ class HipJobExecutor(JobExecutor):
             else:
                 plans.append(('generic', None))
 
-        # Streamed export (single rank): rows of 'disjoint' nav buffers go to their final place in
-        # page-locked host memory on a copy stream while later tiles / partitions still compute.
-        streamed = {}                           # (udf index, name) -> [pinned tensor, rows covered]
+        # Streamed export: rows of 'disjoint' nav buffers go to their final place in page-locked host
+        # memory on a copy stream while later tiles / partitions still compute.  Single rank: a
+        # fresh pinned buffer.  Several ranks on one node: a host segment shared by the ranks, every
+        # rank writes ITS rows (no data-path collective, executor/nodeshared.py).
+        streamed = {}                           # (udf index, name) -> [host tensor, rows covered]
+        expected = {}                           # shared mode: rows this rank has to deliver
+        shared_np = {}
+        shared = self._node_shared() if not partial else None
+        shared_slot = None
         self._row_sink = None
-        if self.gpu_id is not None and not self._collectives_on and not partial:
+        if shared is not None:
+            layout, total = [], 0
+            for i, (udf, (mode, decl)) in enumerate(zip(udfs, plans)):
+                if mode != 'device':
+                    continue
+                for name, how in decl.items():
+                    buf = udf.results.get_buffer(name)
+                    if how != 'disjoint' or isinstance(buf, PlaceholderBufferWrapper):
+                        continue
+                    nb = int(np.prod(buf.shape, dtype=np.int64)) * np.dtype(buf.dtype).itemsize
+                    layout.append((i, name, tuple(buf.shape), np.dtype(buf.dtype), total, nb))
+                    total += (nb + 4095) // 4096 * 4096
+            if layout:
+                from .nodeshared import NodeSharedUnavailable
+                try:
+                    shared_slot, tens, arr = shared.begin_run(total)
+                except NodeSharedUnavailable as e:
+                    self._shared_off = True
+                    import logging
+                    logging.getLogger(__name__).warning("%s -- results go through RCCL", e)
+                    shared, layout = None, []
+                for i, name, shape, dt, off, nb in layout:
+                    tdt = torch_dtype_for(dt)
+                    streamed[(i, name)] = [tens[off:off + nb].view(tdt).reshape(shape), 0]
+                    shared_np[(i, name)] = arr[off:off + nb].view(
+                        np.dtype(str(tdt).replace('torch.', ''))).reshape(shape)
+                    expected[(i, name)] = 0
+            else:
+                shared = None
+        if self.gpu_id is not None and not partial and \
+                (shared is not None or not self._collectives_on):
             import torch as _torch
             if getattr(self, '_copy_stream', None) is None:
                 self._copy_stream = _torch.cuda.Stream(device=self.gpu_id)
@@ -215,6 +275,8 @@ class HipJobExecutor(JobExecutor):
                     return
                 key = (i, name)
                 if key not in streamed:
+                    if shared is not None:
+                        return
                     streamed[key] = [_torch.empty(buf.shape, dtype=torch_dtype_for(buf.dtype),
                                                   pin_memory=True), 0]
                 host, _ = streamed[key]
@@ -232,6 +294,7 @@ class HipJobExecutor(JobExecutor):
             self._row_sink = row_sink
 
         dev_full = [dict() for _ in udfs]       # per udf: name -> torch tensor (full size)
+        deferred = {}                           # shared mode: (udf idx, name) -> [(start, stop, rows)]
         generic_parts = []                      # (task, {udf idx: exported results})
         torch = None
         if self.gpu_id is not None:
@@ -240,6 +303,13 @@ class HipJobExecutor(JobExecutor):
 
         def publish_device(final):
             """declared device buffers -> host arrays of the main-process udfs"""
+            shared_ok = False
+            if shared is not None and final:
+                # my rows are out once the copy stream is idle; then every rank of the node says
+                # whether all of ITS rows went through the sink (same answer on every rank)
+                self._copy_stream.synchronize()
+                mine = all(streamed[k][1] == expected[k] for k in expected)
+                shared_ok = shared.all_ok(mine)
             for i, (udf, (mode, decl)) in enumerate(zip(udfs, plans)):
                 if mode != 'device':
                     continue
@@ -248,6 +318,16 @@ class HipJobExecutor(JobExecutor):
                     if isinstance(buf, PlaceholderBufferWrapper):
                         continue
                     st = streamed.get((i, name))
+                    if shared is not None:
+                        if shared_ok and (i, name) in shared_np:
+                            host = shared_np[(i, name)]
+                            if host.dtype != buf.dtype:
+                                host = host.view(buf.dtype)
+                            buf.replace_array(host)
+                            shared.occupy(shared_slot, buf)
+                            continue
+                        st = None                      # fall back to the device collectives
+                        self._flush_deferred(udf, i, name, dev_full[i], deferred)
                     if st is not None and final and st[1] == buf.shape[0]:
                         # every row already went out through the copy stream
                         self._copy_stream.synchronize()
@@ -275,7 +355,9 @@ class HipJobExecutor(JobExecutor):
             for i, (udf, results, (mode, decl)) in enumerate(zip(udfs, part_results, plans)):
                 if mode == 'device':
                     self._merge_on_device(udf, results, task, decl, dev_full[i],
-                                          may_adopt=not partial)
+                                          may_adopt=not partial,
+                                          defer=(deferred, i, expected) if shared is not None
+                                          else None)
                 else:
                     results.export()
                     gen_entry[i] = results
@@ -358,7 +440,21 @@ class HipJobExecutor(JobExecutor):
         udf.merge(dest=udf.results.get_proxy(), src=results.get_proxy())
         udf.clear_views()
 
-    def _merge_on_device(self, udf, results, task, decl, full, may_adopt=True):
+    def _flush_deferred(self, udf, i, name, full, deferred):
+        """shared-memory delivery was not possible for this run: build the full-size device
+        buffer from the partition results kept aside, for the collectives"""
+        import torch
+        items = deferred.pop((i, name), None)
+        if items is None:
+            return
+        buf_main = udf.results.get_buffer(name)
+        self._make_current()
+        full[name] = torch.zeros(buf_main.shape, dtype=torch_dtype_for(buf_main.dtype),
+                                 device=f'cuda:{self.gpu_id}')
+        for start, stop, pt in items:
+            full[name][start:stop].copy_(pt.reshape(full[name][start:stop].shape))
+
+    def _merge_on_device(self, udf, results, task, decl, full, may_adopt=True, defer=None):
         import torch
         self._make_current()
         if True:
@@ -370,6 +466,13 @@ class HipJobExecutor(JobExecutor):
                 if not isinstance(part, HipArray):
                     part = HipArray.from_numpy(np.asarray(part), self.gpu_id)
                 pt = part.torch.reshape(part.shape)
+                if defer is not None and how == 'disjoint' and (defer[1], name) in defer[2]:
+                    # rows travel through the shared host segment; keep the partition result only
+                    # as the fallback source
+                    start, stop = buf_main._slice_for_partition(task.partition)
+                    defer[0].setdefault((defer[1], name), []).append((start, stop, pt))
+                    defer[2][(defer[1], name)] += stop - start
+                    continue
                 if name not in full:
                     if may_adopt and how == 'disjoint' and \
                             tuple(part.shape) == tuple(buf_main.shape):

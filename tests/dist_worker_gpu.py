@@ -1,0 +1,73 @@
+"""
+Worker for tests/test_udf_gpu.py::test_two_ranks_*: one rank of a 2-rank job on a ONE-GPU box.
+Both ranks drive GPU 0 (LIBERTEM_USE_HIP=0) and rendezvous over gloo -- RCCL refuses two ranks on one
+device -- which is enough for the result delivery through the node-shared host segment
+(executor/nodeshared.py: no data-path collective); 'sum' buffers go through gloo's all_reduce.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    from libertem_amd.api import Context
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd.udf.sum import SumUDF
+    from libertem_amd.udf.sumsigudf import SumSigUDF
+
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    out_dir = sys.argv[1]
+    ctx = Context.make_with('hip', gpus=0)
+    ex = ctx.executor
+    assert ex.world_size == world and ex.rank == rank and ex._node_shared() is not None
+    rng = np.random.default_rng(9)
+    masks = rng.random((5, 32, 32)).astype(np.float32)
+    out = {}
+    # (1) sharded, device-resident (bench.py's layout): every rank holds its block of the scan
+    full = rng.integers(0, 4000, (world * 6, 8, 32, 32)).astype(np.uint16)
+    mine = full[rank * 6:(rank + 1) * 6]
+    dev = torch.from_numpy(mine.view(np.int16)).to('cuda:0')
+    ds = ctx.load('memory', data=dev, dtype=np.uint16, sig_dims=2, num_partitions=2,
+                  shard=(rank, world))
+    for rep in range(7):                  # more runs than ring slots: slots are recycled
+        res = ctx.run_udf(dataset=ds, udf=[ApplyMasksUDF(mask_factories=lambda: masks), SumUDF(),
+                                           SumSigUDF()])
+        if rep == 0:
+            first = res[0]['intensity']           # kept alive across the recycling of its slot
+            first_copy = np.array(first.data)
+    out['sh_masks'] = res[0]['intensity'].data
+    out['sh_sum'] = res[1]['intensity'].data
+    out['sh_sumsig'] = res[2]['intensity'].data
+    out['sh_first_still_valid'] = np.array(np.array_equal(first.data, first_copy))
+    out['sh_full'] = full
+    # (2) replicated host dataset, 5 partitions over 2 ranks, with and without ROI
+    data = rng.integers(0, 4000, (5, 9, 32, 32)).astype(np.uint16)
+    ds2 = ctx.load('memory', data=data, sig_dims=2, num_partitions=5)
+    out['rep_masks'] = ctx.run_udf(dataset=ds2, udf=ApplyMasksUDF(
+        mask_factories=lambda: masks))['intensity'].data
+    roi = rng.random((5, 9)) < 0.5
+    part = ctx.run_udf(dataset=ds2, udf=ApplyMasksUDF(mask_factories=lambda: masks), roi=roi)
+    out['rep_roi_raw'] = part['intensity'].raw_data
+    out['rep_data'] = data
+    out['rep_roi'] = roi
+    # (3) the device collectives on request (gloo moves the device tensors through the host)
+    os.environ['LTMI_RESULT_VIA'] = 'rccl'
+    out['coll_masks'] = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(
+        mask_factories=lambda: masks))['intensity'].data
+    del os.environ['LTMI_RESULT_VIA']
+    out['masks'] = masks
+    np.savez(os.path.join(out_dir, f'rank{rank}.npz'), **out)
+    dist.barrier()
+    ctx.close() if hasattr(ctx, 'close') else None
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
