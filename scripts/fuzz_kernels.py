@@ -60,7 +60,16 @@ for case in range(n_cases):
             if str(tdt) not in ('uint8', 'int8', 'uint16', 'int16', 'float32'):
                 tdt = np.dtype('uint16'); data = gen(tdt, (n_frames, ld))   # what result_type allows
             mdt = np.dtype(rng.choice(['float32', 'complex64']))
-            dense = (rng.random((n_px, n_masks)) < 0.1) * (rng.random((n_px, n_masks)) - 0.3)
+            if rng.random() < 0.3:
+                n_masks = int(rng.choice([130, 300, 1030, 1100]))      # many groups, two passes
+            if rng.random() < 0.5:
+                # localised stack: mask k touches the pixels around k * n_px / n_masks (long pairs)
+                centre = (np.arange(n_masks) + 0.5) * n_px / n_masks
+                width = float(rng.choice([2., 8., 40.])) * max(1., n_px / n_masks)
+                dist = np.abs(np.arange(n_px)[:, None] - centre[None, :])
+                dense = (dist < width) * (rng.random((n_px, n_masks)) - 0.3)
+            else:
+                dense = (rng.random((n_px, n_masks)) < 0.1) * (rng.random((n_px, n_masks)) - 0.3)
             if mdt.kind == 'c':
                 dense = dense * (1 + 1j * rng.random((n_px, n_masks)))
             dense = dense.astype(mdt)
