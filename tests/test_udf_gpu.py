@@ -335,6 +335,56 @@ def test_sparse_masks_through_udf(ctx):
     assert _close(got['intensity'].data, ref, 1e-6)
 
 
+def _spots_frame(sig, centre, offsets, radius=3.0):
+    """disks of equal intensity at centre + offsets"""
+    yy, xx = np.mgrid[0:sig[0], 0:sig[1]]
+    f = np.zeros(sig, dtype=np.float32)
+    for dy, dx in offsets:
+        f += ((yy - centre[0] - dy) ** 2 + (xx - centre[1] - dx) ** 2 <= radius ** 2)
+    return f
+
+
+@pytest.mark.parametrize('use_sparse', [False, True])
+def test_radial_fourier_symmetry_selection_rules(ctx, use_sparse):
+    """The selection rules the reference checks in tests/analysis/test_analysis_radialfourier.py:
+    76-188, on own frames: one spot (all orders, phase follows the azimuth), two opposite spots (odd
+    orders vanish), four spots at 90 degrees (only multiples of 4 survive); nothing in the inner bin;
+    order 0 of the outer bin is the summed intensity."""
+    sig, c, d = (64, 64), (32, 32), 12
+    frames = np.stack([
+        _spots_frame(sig, c, [(0, d)]),                                   # +x
+        _spots_frame(sig, c, [(0, -d)]),                                  # -x
+        _spots_frame(sig, c, [(0, d), (0, -d)]),                          # 2-fold
+        _spots_frame(sig, c, [(0, d), (0, -d), (d, 0), (-d, 0)]),         # 4-fold
+    ]).reshape((2, 2) + sig)
+    ds = ctx.load('memory', data=frames, sig_dims=2, num_partitions=2)
+    res = ctx.run(ctx.create_radial_fourier_analysis(
+        dataset=ds, cy=c[0], cx=c[1], ri=0, ro=d + 4, n_bins=2, max_order=8,
+        use_sparse=use_sparse))
+    total = frames.sum(axis=(2, 3))
+
+    def ch(b, o):
+        return getattr(res, f'complex_{b}_{o}').raw_data
+
+    tol = 2e-5 * total.max()
+    for o in range(9):
+        assert np.all(np.abs(ch(0, o)) <= tol), o                # inner bin is empty
+    assert np.allclose(np.abs(ch(1, 0)), total, rtol=1e-5)
+    for o in (1, 3, 5, 7):                                        # odd orders: 2-fold kills them
+        assert np.all(np.abs(ch(1, o))[1] <= tol), o
+        assert np.all(np.abs(ch(1, o))[0] > 0.1 * total[0]), o
+    for o in (2, 6):                                              # 4-fold kills 2 and 6
+        assert abs(ch(1, o)[1, 1]) <= tol
+        assert abs(ch(1, o)[1, 0]) > 0.1 * total[1, 0]
+    for o in (4, 8):                                              # everything passes, in phase
+        assert np.all(np.abs(ch(1, o)) > 0.1 * total)
+        assert np.allclose(np.angle(ch(1, o)), 0, atol=1e-4)
+    # a single spot at azimuth 0 / pi: order 1 has phase 0 / pi (the factor is exp(i * o * phi))
+    assert abs(np.angle(ch(1, 1)[0, 0])) < 1e-4
+    assert abs(abs(np.angle(ch(1, 1)[0, 1])) - np.pi) < 1e-4
+    assert res.dominant_0.raw_data.shape == (2, 2)
+
+
 def test_sparse_stack_densified_when_mostly_filled(ctx):
     """HIP backend: a 'sparse' stack with filled 16-column groups runs on the dense matrix-core kernel,
     a localised ring stack stays sparse (blocked image); results agree with the oracle either way."""
