@@ -114,7 +114,7 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
              const int *__restrict__ nblk,
              const int *__restrict__ active, const int *__restrict__ active_off,
              float *__restrict__ out, int64_t ld_out,
-             int n_cols, int accumulate, int ablate) {
+             int n_cols, int accumulate, int ablate, unsigned long long *prof) {
     extern __shared__ __attribute__((aligned(16))) unsigned char be_lds[];
     using C = BeCfg<T>;
     constexpr int TILES = C::TILES, NDMA = C::NDMA;
@@ -187,6 +187,20 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
     __builtin_amdgcn_s_barrier();          // (not __syncthreads: its fence drains vmcnt, i.e. the record ring)
     asm volatile("" ::: "memory");
 
+#ifdef BE_PROF
+    // cycle attribution (-DBE_PROF builds only, scripts/bell_variants.sh): s_memtime stamps around
+    // the phases of a record; every stamp costs ~60 cycles itself
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
+    const unsigned long long t_begin = t_prev;
+#define BE_STAMP(cat)                                                  \
+    do {                                                               \
+        const unsigned long long t_now = __builtin_readcyclecounter(); \
+        pt[cat] += t_now - t_prev;                                     \
+        t_prev = t_now;                                                \
+    } while (0)
+#else
+#define BE_STAMP(cat) do { } while (0)
+#endif
     // B operands (raw pixel type) of the record about to be multiplied
     T bcur[2][TILES];
     const unsigned char *bbase = be_lds + lane_base;
@@ -194,7 +208,9 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
     // and frame tile)
     auto read_b = [&](auto PH) {
         bu32x3 &r = ring[decltype(PH)::value];
+        BE_STAMP(3);                                   // loop control / ring dispatch since the last record
         asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(BE_D - 1) : "memory");
+        BE_STAMP(0);                                   // waiting for the record
         const unsigned o = r[2];
         const unsigned char *p0 = bbase + (o & 0xffffu) * C::SZ;
         const unsigned char *p1 = bbase + (o >> 16) * C::SZ;
@@ -203,6 +219,10 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
             bcur[0][t] = *(const T *)(p0 + t * C::TILE_OFF);
             bcur[1][t] = *(const T *)(p1 + t * C::TILE_OFF);
         }
+#ifdef BE_PROF
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        BE_STAMP(1);                                   // address arithmetic + LDS reads
+#endif
     };
 
     for (int ai = a0; ai < a1; ++ai) {
@@ -249,6 +269,7 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
 #endif
                     __builtin_amdgcn_sched_barrier(0);
                     load_rec(r);                                   // refill this ring entry
+                    BE_STAMP(2);                                   // conversions + MFMAs + refill issue
                 };
                 bstatic_for<0, BE_D>([&](auto PH) {
                     if (phase == decltype(PH)::value) consume(PH);
@@ -261,12 +282,23 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
         // issue imply it (their refills were issued after the DMA and at most BE_D - 1 loads are
         // outstanding at a consumption... of a record that is itself younger than the DMA);
         // otherwise drain.
+        BE_STAMP(3);
         if (since_dma < BE_D) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_D) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        BE_STAMP(4);                                   // waiting for the next chunk's DMA
         if (ablate != 3) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        BE_STAMP(5);                                   // waiting for the other waves
     }
+#ifdef BE_PROF
+    if (prof && lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) atomicAdd(prof + c, pt[c]);
+        atomicAdd(prof + 6, __builtin_readcyclecounter() - t_begin);
+        atomicAdd(prof + 7, 1ull);
+    }
+#endif
     // Drain the run-ahead record loads.  The ring entries are operands of the wait so that they stay
     // live up to here: otherwise the compiler reuses their registers for the result addresses and
     // the loads still in flight land on top of them (seen on cold caches only).
@@ -462,12 +494,31 @@ static int launch_bell(ltmi_masks *m, BellImage *b, const T *tile, int64_t n_fra
     dim3 grid((unsigned)((n_frames + C::FB - 1) / C::FB), (unsigned)b->n_pass);
     const char *abl = getenv("LTMI_BELL_ABLATE");    // 1: no frame DMA, 2: no records (bench only)
     const int ablate = abl ? atoi(abl) : 0;
+    unsigned long long *prof = nullptr;
+#ifdef BE_PROF
+    static unsigned long long *prof_dev = nullptr;
+    if (!prof_dev) LTMI_HIP(hipMalloc((void **)&prof_dev, 8 * sizeof(unsigned long long)));
+    LTMI_HIP(hipMemsetAsync(prof_dev, 0, 8 * sizeof(unsigned long long), stream));
+    prof = prof_dev;
+#endif
     hipLaunchKernelGGL(kern, grid, dim3(BE_SETS * 64), C::LDS_BYTES, stream, tile, ld, n_frames,
                        m->n_px, (const uint32_t *)b->stream, (const int64_t *)b->stream_off,
                        (const int *)b->nblk, (const int *)b->active,
                        (const int *)b->active_off, out,
-                       ld_out_f, n_cols, accumulate, ablate);
+                       ld_out_f, n_cols, accumulate, ablate, prof);
     LTMI_HIP(hipGetLastError());
+#ifdef BE_PROF
+    {
+        unsigned long long h[8];
+        LTMI_HIP(hipStreamSynchronize(stream));
+        LTMI_HIP(hipMemcpy(h, prof_dev, sizeof(h), hipMemcpyDeviceToHost));
+        const double w = (double)h[7];
+        fprintf(stderr, "BE_PROF cycles per wave (%.0f waves, ~%.0f records each): record-wait %.0f  "
+                "lds %.0f  mfma+refill %.0f  loop %.0f  dma-wait %.0f  barrier %.0f  total %.0f\n",
+                w, (double)b->n_blocks / BE_SETS, h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w,
+                h[5] / w, h[6] / w);
+    }
+#endif
     snprintf(m->last_kernel, sizeof(m->last_kernel), "k_bell_apply<%s> grid=(%u,%u) blocks=%zu x%.2f",
              typeid(T).name(), grid.x, grid.y, b->n_blocks, b->mac_ratio);
     return LTMI_OK;
