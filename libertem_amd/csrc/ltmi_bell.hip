@@ -57,10 +57,10 @@ constexpr int BE_SETS = 4;           // waves per workgroup = interleaved group 
 constexpr int BE_SLOTS = 16;         // groups per wave
 constexpr int BE_PASS = BE_SETS * BE_SLOTS * 16;     // real masks per pass (1024)
 #ifndef BE_D_
-#define BE_D_ 3
+#define BE_D_ 4
 #endif
 #ifndef BE_PAD
-#define BE_PAD 16
+#define BE_PAD 0
 #endif
 constexpr int BE_D = BE_D_;          // block records in flight per wave
 constexpr int BE_REC = 192;          // dwords per block record (64 lanes x 3)
@@ -92,10 +92,11 @@ template <typename T> struct BeCfg {
     static constexpr int DPR = ROW >= 1024 ? ROW / 1024 : 1;   // DMA instructions per row
     static constexpr int NDMA_WG = FB * ROW / 1024;
     static constexpr int NDMA = NDMA_WG / BE_SETS;         // per wave and chunk
-    // a padded unit = RPD rows (>= 1 KiB) + 16 B, so the 16 frames of a tile spread over banks
+    // a unit = RPD rows (>= 1 KiB) + BE_PAD bytes of padding (0: XOR-swizzled pieces instead)
     static constexpr int UNIT_BYTES = (ROW >= 1024 ? ROW : 1024) + BE_PAD;
     static constexpr int BUF = (FB / RPD) * UNIT_BYTES;
-    static constexpr int LDS_BYTES = 2 * BUF;
+    static constexpr int RING_OFF = 2 * BUF;                // record rings of the waves behind the slabs
+    static constexpr int LDS_BYTES = 2 * BUF + BE_SETS * BE_D * 1024;
     __host__ __device__ static constexpr int frame_base(int f) {
         return (f / RPD) * UNIT_BYTES + (f % RPD) * ROW;
     }
@@ -146,13 +147,16 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
             int dst;
             if constexpr (C::RPD > 1) {          // several rows per instruction (1-byte pixels)
                 constexpr int LPR = 64 / C::RPD;  // lanes per row
-                fr = f0 + q * C::RPD + lane / LPR;
-                byte_in_row = (int64_t)ch * C::ROW + (lane % LPR) * 16;
+                const int r = q * C::RPD + lane / LPR;             // frame of the workgroup
+                fr = f0 + r;
+                byte_in_row = (int64_t)ch * C::ROW + ((lane % LPR) ^ (BE_PAD ? 0 : (r & 7))) * 16;
                 dst = q * C::UNIT_BYTES;
             } else {
-                fr = f0 + q / C::DPR;
-                byte_in_row = (int64_t)ch * C::ROW + (q % C::DPR) * 1024 + lane * 16;
-                dst = (q / C::DPR) * C::UNIT_BYTES + (q % C::DPR) * 1024;
+                const int r = q / C::DPR;
+                fr = f0 + r;
+                byte_in_row = (int64_t)ch * C::ROW + (q % C::DPR) * 1024
+                              + (lane ^ (BE_PAD ? 0 : (r & 7))) * 16;
+                dst = r * C::UNIT_BYTES + (q % C::DPR) * 1024;
             }
             if (fr > n_frames - 1) fr = n_frames - 1;
             // the last chunk may be partial: pieces past the row are not referenced by any record
@@ -163,28 +167,37 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
         }
     };
 
-    // ---- record ring (asm loads: the waits are counted by hand, see below)
-    const uint32_t *sp = stream + stream_off[pass * BE_SETS + j] * BE_REC + lane * 3;
-    bu32x3 ring[BE_D];
-    // asm loads + hand-counted waits: with plain loads the compiler turns the ring into register
-    // copies behind vmcnt(0).  A ring entry is refilled AFTER the MFMAs that read it (no copy needed)
-    // and its wait asm takes the entry as in/out operand, so nothing reads it early.
-    auto load_rec = [&](bu32x3 &r) {
-        asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(r) : "v"(sp) : "memory");
-        sp += BE_REC;
+    // ---- record ring: BE_D slots per wave in LDS, filled by LDS-DMA (dwordx3: 12 bytes per lane),
+    // read back with ds_read when the record's turn comes.  All loads of the kernel are
+    // DMA and retire in order, so the waits are counted by hand; what lands in REGISTERS is ordinary
+    // compiler-tracked LDS data (an earlier version kept the ring in registers behind asm loads: the
+    // compiler may copy such registers while they are still in flight).
+    // (global_load_lds_dwordx3 puts the 12 bytes of lane l at l * 16: a slot is 1 KiB,
+    // probes/dma3_probe.hip)
+    constexpr int REC_BYTES = BE_REC * 4, SLOT_BYTES = 1024;
+    unsigned char *ring_lds = be_lds + C::RING_OFF + j * (BE_D * SLOT_BYTES);
+    const unsigned char *sp = (const unsigned char *)(stream + stream_off[pass * BE_SETS + j] * BE_REC)
+                              + lane * 12;
+    auto issue_rec = [&](int slot) {
+        __builtin_amdgcn_global_load_lds((b_glb_ptr_t)sp, (b_lds_ptr_t)(ring_lds + slot * SLOT_BYTES),
+                                         12, 0, 0);
+        sp += REC_BYTES;
     };
 #pragma unroll
-    for (int u = 0; u < BE_D; ++u) load_rec(ring[u]);
+    for (int u = 0; u < BE_D; ++u) issue_rec(u);
+    int slot = 0;                       // ring slot holding the next record
 
     const int lane_base = C::frame_base(m16);
-    int phase = 0;                      // ring entry holding the next record
-    int since_dma = BE_D;               // records consumed since the last DMA issue (saturating)
+    // BE_PAD == 0: instead of padding the rows, the 16-byte pieces of frame f sit at piece ^ (f & 7)
+    // (the DMA lanes fetch the permuted source piece) -- the 16 frames of a tile spread over the
+    // banks like with 16 bytes of padding, and the LDS holds a fourth ring slot per wave instead
+    const unsigned swz = BE_PAD ? 0u : (unsigned)((m16 & 7) << 4);
+    int since_dma = BE_D;               // records consumed since the last frame-DMA issue (saturating)
 
     if (a0 < a1) issue_dma(a0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // (the ring was issued before the DMA: all landed) -- refilled below as it is consumed
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();          // (not __syncthreads: its fence drains vmcnt, i.e. the record ring)
+    __builtin_amdgcn_s_barrier();          // (not __syncthreads: its fence would drain the record ring)
     asm volatile("" ::: "memory");
 
 #ifdef BE_PROF
@@ -201,29 +214,6 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
 #else
 #define BE_STAMP(cat) do { } while (0)
 #endif
-    // B operands (raw pixel type) of the record about to be multiplied
-    T bcur[2][TILES];
-    const unsigned char *bbase = be_lds + lane_base;
-    // wait for ring entry PH and read its B operands (one LDS read of the pixel type per step
-    // and frame tile)
-    auto read_b = [&](auto PH) {
-        bu32x3 &r = ring[decltype(PH)::value];
-        BE_STAMP(3);                                   // loop control / ring dispatch since the last record
-        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(BE_D - 1) : "memory");
-        BE_STAMP(0);                                   // waiting for the record
-        const unsigned o = r[2];
-        const unsigned char *p0 = bbase + (o & 0xffffu) * C::SZ;
-        const unsigned char *p1 = bbase + (o >> 16) * C::SZ;
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) {
-            bcur[0][t] = *(const T *)(p0 + t * C::TILE_OFF);
-            bcur[1][t] = *(const T *)(p1 + t * C::TILE_OFF);
-        }
-#ifdef BE_PROF
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        BE_STAMP(1);                                   // address arithmetic + LDS reads
-#endif
-    };
 
     for (int ai = a0; ai < a1; ++ai) {
         const int buf = (ai - a0) & 1;
@@ -231,7 +221,7 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
             issue_dma(ai + 1, buf ^ 1);
             since_dma = 0;
         }
-        bbase = be_lds + buf * C::BUF + lane_base;
+        const unsigned char *bbase = be_lds + buf * C::BUF + lane_base;
         const int *nb_row = nblk + ((int64_t)ai * BE_SETS + j) * BE_SLOTS;
         int nbs[BE_SLOTS];                            // one 64-byte scalar load
 #pragma unroll
@@ -241,47 +231,52 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
             constexpr int s = decltype(S)::value;
             const int nb = ablate == 2 ? 0 : nbs[s];
             for (int b = 0; b < nb; ++b) {
-                auto consume = [&](auto PH) {
-                    constexpr int ph = decltype(PH)::value;
-                    bu32x3 &r = ring[ph];
-                    // the oldest record of the ring: BE_D - 1 younger ones stay in flight.  (Right
-                    // after a DMA issue this also waits for most of the DMA -- record loads retire
-                    // behind it anyway, the stall would come BE_D records later.)
-                    read_b(PH);
-                    // (copies first: __builtin_bit_cast on a vector ELEMENT reads element 0)
-                    const unsigned x0 = r[0], x1 = r[1];
-                    const float a_0 = __uint_as_float(x0);
-                    const float a_1 = __uint_as_float(x1);
+                BE_STAMP(3);                           // loop control since the last record
+                // the oldest record of the ring: BE_D - 1 younger ones stay in flight.  (Right after
+                // a frame-DMA issue this also waits for most of that DMA -- record loads retire
+                // behind it anyway, the stall would come BE_D records later.)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_D - 1) : "memory");
+                BE_STAMP(0);
+                const unsigned *rp = (const unsigned *)(ring_lds + slot * SLOT_BYTES) + lane * 4;
+                const unsigned x0 = rp[0], x1 = rp[1], o = rp[2];
+                const float a_0 = __uint_as_float(x0);
+                const float a_1 = __uint_as_float(x1);
+                const unsigned char *p0 = bbase + (((o & 0xffffu) * C::SZ) ^ swz);
+                const unsigned char *p1 = bbase + (((o >> 16) * C::SZ) ^ swz);
+                T b0[TILES], b1[TILES];
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) {
+                    b0[t] = *(const T *)(p0 + t * C::TILE_OFF);
+                    b1[t] = *(const T *)(p1 + t * C::TILE_OFF);
+                }
+#ifdef BE_PROF
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                BE_STAMP(1);
+#endif
 #ifndef BE_NOMFMA
 #pragma unroll
-                    for (int t = 0; t < TILES; ++t)
-                        acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_0, (float)bcur[0][t], acc[s][t], 0, 0, 0);
+                for (int t = 0; t < TILES; ++t)
+                    acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_0, (float)b0[t], acc[s][t], 0, 0, 0);
 #pragma unroll
-                    for (int t = 0; t < TILES; ++t)
-                        acc[s][t + (NACC - 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                            a_1, (float)bcur[1][t], acc[s][t + (NACC - 1)], 0, 0, 0);
-#else                   // timing experiment: the same operands through one VALU op each
+                for (int t = 0; t < TILES; ++t)
+                    acc[s][t + (NACC - 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                        a_1, (float)b1[t], acc[s][t + (NACC - 1)], 0, 0, 0);
+#else               // timing experiment: the same operands through one VALU op each
 #pragma unroll
-                    for (int t = 0; t < TILES; ++t) {
-                        acc[s][t][0] += a_0 * (float)bcur[0][t];
-                        acc[s][t][1] += a_1 * (float)bcur[1][t];
-                    }
+                for (int t = 0; t < TILES; ++t) {
+                    acc[s][t][0] += a_0 * (float)b0[t];
+                    acc[s][t][1] += a_1 * (float)b1[t];
+                }
 #endif
-                    __builtin_amdgcn_sched_barrier(0);
-                    load_rec(r);                                   // refill this ring entry
-                    BE_STAMP(2);                                   // conversions + MFMAs + refill issue
-                };
-                bstatic_for<0, BE_D>([&](auto PH) {
-                    if (phase == decltype(PH)::value) consume(PH);
-                });
-                phase = phase == BE_D - 1 ? 0 : phase + 1;
+                // refill the slot (its three words are in registers: the MFMAs above used them)
+                issue_rec(slot);
+                slot = slot + 1 == BE_D ? 0 : slot + 1;
                 since_dma = since_dma < BE_D ? since_dma + 1 : since_dma;
+                BE_STAMP(2);
             }
         });
-        // The next chunk must have landed before anyone reads it.  BE_D records consumed since the
-        // issue imply it (their refills were issued after the DMA and at most BE_D - 1 loads are
-        // outstanding at a consumption... of a record that is itself younger than the DMA);
-        // otherwise drain.
+        // The next chunk must have landed before anyone reads it.  BE_D records consumed since its
+        // issue imply it: their refills were issued after it and at most BE_D loads are in flight.
         BE_STAMP(3);
         if (since_dma < BE_D) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_D) : "memory");
@@ -291,6 +286,7 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
         asm volatile("" ::: "memory");
         BE_STAMP(5);                                   // waiting for the other waves
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the run-ahead record loads
 #ifdef BE_PROF
     if (prof && lane == 0) {
 #pragma unroll
@@ -299,13 +295,6 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
         atomicAdd(prof + 7, 1ull);
     }
 #endif
-    // Drain the run-ahead record loads.  The ring entries are operands of the wait so that they stay
-    // live up to here: otherwise the compiler reuses their registers for the result addresses and
-    // the loads still in flight land on top of them (seen on cold caches only).
-    bstatic_for<0, BE_D>([&](auto U) {
-        bu32x3 &r = ring[decltype(U)::value];
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(r) : : "memory");
-    });
 
     // ---- results: lane holds columns g*16 + kg*4 .. +3 of frame (tile t, m16)
     if constexpr (NACC == 2) {
