@@ -973,7 +973,8 @@ def test_streamed_export_with_several_tiles(ctx):
         Negotiator._hip_scheme_cache.clear()
 
 
-def test_two_ranks_share_results_through_host_segment(tmp_path):
+@pytest.mark.parametrize('world', [2, 3])
+def test_two_ranks_share_results_through_host_segment(tmp_path, world):
     """The N>1 result path on the GPU (one-GPU box: two gloo ranks driving GPU 0): every rank
     writes the rows of its nav shard into the node-shared page-locked segment, no data-path
     collective; each rank ends up with the complete result == single-process values."""
@@ -989,16 +990,16 @@ def test_two_ranks_share_results_through_host_segment(tmp_path):
     env['PYTHONPATH'] = root + os.pathsep + env.get('PYTHONPATH', '')
     env['LIBERTEM_USE_HIP'] = '0'
     env['OMP_NUM_THREADS'] = '1'
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}',
            '--master-addr', '127.0.0.1', '--master-port', str(port),
            os.path.join(root, 'tests', 'dist_worker_gpu.py'), str(tmp_path)]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stdout[-4000:]
-    outs = [np.load(os.path.join(tmp_path, f'rank{k}.npz')) for k in range(2)]
+    outs = [np.load(os.path.join(tmp_path, f'rank{k}.npz')) for k in range(world)]
     for o in outs:
         masks, full = o['masks'], o['sh_full']
-        exp = opath.apply_masks(full, masks, num_partitions=4)
+        exp = opath.apply_masks(full, masks, num_partitions=2 * world)
         assert _close(o['sh_masks'], exp, F32_TOL)
         assert _close(o['coll_masks'], exp, F32_TOL)
         assert np.array_equal(o['sh_sum'], full.astype(np.float32).sum(axis=(0, 1)))
@@ -1009,5 +1010,6 @@ def test_two_ranks_share_results_through_host_segment(tmp_path):
         assert _close(o['rep_masks'], exp2, F32_TOL)
         assert _close(o['rep_roi_raw'], exp2.reshape((45, -1))[roi.reshape(-1)], F32_TOL)
     for k in ('sh_masks', 'sh_sum', 'sh_sumsig', 'rep_masks', 'rep_roi_raw', 'coll_masks'):
-        assert np.array_equal(outs[0][k], outs[1][k]), k
+        for o in outs[1:]:
+            assert np.array_equal(outs[0][k], o[k]), k
     assert not [f for f in os.listdir('/dev/shm') if f.startswith(f'ltmi_{os.getuid()}_{port}')]
