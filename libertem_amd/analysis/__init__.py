@@ -8,8 +8,9 @@ from .sumsig import SumSigAnalysis
 from .com import COMAnalysis
 from .radialfourier import RadialFourierAnalysis
 from .fft import ApplyFFTMask, SumfftAnalysis
+from .raw import PickFrameAnalysis, PickFFTFrameAnalysis
 
-__all__ = ['Analysis', 'AnalysisResult', 'AnalysisResultSet', 'MasksAnalysis',
+__all__ = ['PickFrameAnalysis', 'PickFFTFrameAnalysis', 'Analysis', 'AnalysisResult', 'AnalysisResultSet', 'MasksAnalysis',
            'BaseMasksAnalysis', 'SingleMaskAnalysis', 'DiskMaskAnalysis', 'RingMaskAnalysis',
            'PointMaskAnalysis', 'SumAnalysis', 'SumSigAnalysis', 'COMAnalysis',
            'RadialFourierAnalysis', 'ApplyFFTMask', 'SumfftAnalysis']

@@ -132,6 +132,16 @@ class Context:
         parameters = {k: v for k, v in {'cx': x, 'cy': y}.items() if v is not None}
         return PointMaskAnalysis(dataset=dataset, parameters=parameters)
 
+    def create_pick_analysis(self, dataset, x, y=None, z=None):
+        """Pick the frame at (z, y, x) -- as many coordinates as nav dimensions (api.py:813-850)."""
+        from libertem_amd.analysis.raw import PickFrameAnalysis
+        parameters = {'x': x}
+        if y is not None:
+            parameters['y'] = y
+        if z is not None:
+            parameters['z'] = z
+        return PickFrameAnalysis(dataset=dataset, parameters=parameters)
+
     def create_sum_analysis(self, dataset):
         return SumAnalysis(dataset=dataset, parameters={})
 

@@ -416,6 +416,43 @@ def gen_decode():
     save('decode', **out)
 
 
+# ---------------------------------------------------------------------------
+# 13. PickUDF and the pick analyses
+# ---------------------------------------------------------------------------
+def gen_pick():
+    from libertem.udf.raw import PickUDF
+    from libertem.analysis.raw import PickFrameAnalysis
+    from libertem.analysis.rawfft import PickFFTFrameAnalysis
+    out = {}
+    for case in recipes.PICK_CASES:
+        data = recipes.make_pick_case(case)
+        ds = MemoryDataSet(data=data, num_partitions=case['num_partitions'],
+                           sig_dims=len(case['sig']))
+        roi = np.zeros(case['nav'], dtype=bool)
+        for c in case['roi_frames']:
+            roi[c] = True
+        res = run(ds, PickUDF(), roi=roi)['intensity']
+        out[case['name'] + '__picked'] = np.array(res.data)
+        for cls, tag in ((PickFrameAnalysis, 'frame'), (PickFFTFrameAnalysis, 'fft')):
+            params = dict(case['pick'])
+            if tag == 'fft' and case['real'] is not None:
+                params.update(real_rad=case['real']['rad'], real_centerx=case['real']['cx'],
+                              real_centery=case['real']['cy'])
+            # the result sets of the reference render through matplotlib / colorcet (absent here):
+            # capture the array its get_udf_results() hands to get_generic_results() instead
+            capture = type('Capture' + tag, (cls,), {
+                'get_generic_results': lambda self, data, damage: np.array(data)})
+            a = capture(dataset=ds, parameters=params)
+            aroi = a.get_roi()
+            aroi = np.asarray(aroi.todense()) if hasattr(aroi, 'todense') else np.asarray(aroi)
+            out[f"{case['name']}__{tag}__roi"] = aroi
+            ures = run(ds, a.get_udf(), roi=aroi)
+            out[f"{case['name']}__{tag}"] = a.get_udf_results(ures, aroi, damage=True)
+        out[case['name'] + '__sha_data'] = np.frombuffer(bytes.fromhex(sha(data)), dtype=np.uint8)
+        print(case['name'], res.data.shape, res.data.dtype)
+    save('pick', **out)
+
+
 GENERATORS = {}
 
 if __name__ == '__main__':

@@ -464,3 +464,25 @@ def make_decode_case(case):
     vals = rng.integers(info.min, info.max, size=case['shape'], dtype=dt, endpoint=True)
     stored = vals.astype(dt.newbyteorder(case['order']))
     return vals, stored.reshape(-1).view(np.uint8).copy()
+
+
+# ---- PickUDF / PickFrameAnalysis / PickFFTFrameAnalysis (udf/raw.py, analysis/raw.py, analysis/rawfft.py)
+PICK_CASES = [
+    dict(name='u16_2d', nav=(5, 6), sig=(16, 16), dtype='uint16', num_partitions=3, seed=950,
+         roi_frames=[(1, 2), (4, 5), (0, 0)], pick=dict(x=2, y=1), real=dict(rad=3, cx=8, cy=8)),
+    dict(name='f32_1d', nav=(9,), sig=(12, 20), dtype='float32', num_partitions=2, seed=951,
+         roi_frames=[(7,)], pick=dict(x=7), real=None),
+    dict(name='c64_3d', nav=(2, 3, 4), sig=(8, 8), dtype='complex64', num_partitions=4, seed=952,
+         roi_frames=[(1, 2, 3), (0, 0, 1)], pick=dict(x=3, y=2, z=1), real=None),
+]
+
+
+def make_pick_case(case):
+    rng = np.random.default_rng(case['seed'])
+    shape = tuple(case['nav']) + tuple(case['sig'])
+    dt = np.dtype(case['dtype'])
+    if dt.kind == 'c':
+        return (rng.random(shape) + 1j * rng.random(shape)).astype(dt)
+    if dt.kind == 'f':
+        return rng.random(shape).astype(dt)
+    return rng.integers(0, 1000, shape).astype(dt)

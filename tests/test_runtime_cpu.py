@@ -515,6 +515,47 @@ def test_other_byte_order_datasets(ctx, tmp_path, dtype):
     assert np.array_equal(res_m['intensity'].data, ref['intensity'].data)
 
 
+def _pick_check(ctx, golden_dir, case):
+    from libertem_amd.udf.raw import PickUDF
+    from libertem_amd.analysis.raw import PickFrameAnalysis, PickFFTFrameAnalysis
+    g = np.load(os.path.join(golden_dir, 'pick.npz'))
+    data = recipes.make_pick_case(case)
+    ds = ctx.load('memory', data=data, num_partitions=case['num_partitions'],
+                  sig_dims=len(case['sig']))
+    roi = np.zeros(case['nav'], dtype=bool)
+    for c in case['roi_frames']:
+        roi[c] = True
+    res = ctx.run_udf(dataset=ds, udf=PickUDF(), roi=roi)['intensity'].data
+    ref = g[case['name'] + '__picked']
+    assert res.dtype == ref.dtype and np.array_equal(res, ref)
+    for cls, tag in ((PickFrameAnalysis, 'frame'), (PickFFTFrameAnalysis, 'fft')):
+        params = dict(case['pick'])
+        if tag == 'fft' and case['real'] is not None:
+            params.update(real_rad=case['real']['rad'], real_centerx=case['real']['cx'],
+                          real_centery=case['real']['cy'])
+        a = cls(dataset=ds, parameters=params)
+        assert np.array_equal(a.get_roi(), g[f"{case['name']}__{tag}__roi"])
+        rs = ctx.run(a)
+        ref = g[f"{case['name']}__{tag}"]
+        got = rs.intensity_complex.raw_data if ref.dtype.kind == 'c' else rs.intensity.raw_data
+        assert got.dtype == ref.dtype
+        assert np.allclose(got, ref, rtol=1e-6, atol=1e-6 * np.abs(ref).max())
+        if ref.dtype.kind != 'c':
+            assert np.array_equal(rs.intensity_lin.raw_data, got)
+
+
+@pytest.mark.parametrize('case', recipes.PICK_CASES, ids=lambda c: c['name'])
+def test_pick_udf_and_analyses_vs_reference(ctx, golden_dir, case):
+    """PickUDF / PickFrameAnalysis / PickFFTFrameAnalysis on the NumPy backend == the reference
+    (udf/raw.py:12-76, analysis/raw.py:83-165, analysis/rawfft.py:38-57)."""
+    _pick_check(ctx, golden_dir, case)
+    ds = ctx.load('memory', data=np.zeros((2, 3, 4, 4)), sig_dims=2)
+    for bad in (dict(x=1), dict(x=1, y=1, z=0)):
+        with pytest.raises(ValueError):
+            ctx.run(ctx.create_pick_analysis(dataset=ds, **bad))
+    assert ctx.run(ctx.create_pick_analysis(dataset=ds, x=2, y=1)).intensity.raw_data.shape == (4, 4)
+
+
 def _feed(flat, step, delay=0.005, stop_at=None):
     import time
     for i in range(0, len(flat) if stop_at is None else stop_at, step):

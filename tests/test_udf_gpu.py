@@ -30,10 +30,10 @@ def _load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name + '.npz'))
 
 
-def _device_ds(ctx, data, num_partitions, **kw):
+def _device_ds(ctx, data, num_partitions, sig_dims=2, **kw):
     from libertem_amd.common.hiparray import HipArray
     arr = HipArray.from_numpy(data, 0)
-    return ctx.load('memory', data=arr, num_partitions=num_partitions, sig_dims=2, **kw)
+    return ctx.load('memory', data=arr, num_partitions=num_partitions, sig_dims=sig_dims, **kw)
 
 
 def _close(a, b, tol):
@@ -886,6 +886,39 @@ def test_big_endian_raw_file_decoded_on_device(ctx, tmp_path, dtype):
     part = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda: masks), roi=roi)
     ref_p = ctx.run_udf(dataset=ds_n, udf=ApplyMasksUDF(mask_factories=lambda: masks), roi=roi)
     assert np.array_equal(part['intensity'].raw_data, ref_p['intensity'].raw_data)
+
+
+@pytest.mark.parametrize('resident', ['host', 'device'])
+@pytest.mark.parametrize('case', recipes.PICK_CASES, ids=lambda c: c['name'])
+def test_pick_udf_and_analyses_on_device(ctx, golden_dir, case, resident):
+    """PickUDF on the HIP worker (rows copied inside HBM) and the pick analyses == the reference."""
+    from libertem_amd.udf.raw import PickUDF
+    from libertem_amd.analysis.raw import PickFrameAnalysis, PickFFTFrameAnalysis
+    g = np.load(os.path.join(golden_dir, 'pick.npz'))
+    data = recipes.make_pick_case(case)
+    if resident == 'device':
+        if data.dtype.kind == 'c':
+            pytest.skip("device-resident datasets hold real pixel types")
+        ds = _device_ds(ctx, data, case['num_partitions'], sig_dims=len(case['sig']))
+    else:
+        ds = ctx.load('memory', data=data, num_partitions=case['num_partitions'],
+                      sig_dims=len(case['sig']))
+    roi = np.zeros(case['nav'], dtype=bool)
+    for c in case['roi_frames']:
+        roi[c] = True
+    res = ctx.run_udf(dataset=ds, udf=PickUDF(), roi=roi)['intensity'].data
+    ref = g[case['name'] + '__picked']
+    assert res.dtype == ref.dtype and np.array_equal(res, ref)
+    for cls, tag in ((PickFrameAnalysis, 'frame'), (PickFFTFrameAnalysis, 'fft')):
+        params = dict(case['pick'])
+        if tag == 'fft' and case['real'] is not None:
+            params.update(real_rad=case['real']['rad'], real_centerx=case['real']['cx'],
+                          real_centery=case['real']['cy'])
+        rs = ctx.run(cls(dataset=ds, parameters=params))
+        ref = g[f"{case['name']}__{tag}"]
+        got = rs.intensity_complex.raw_data if ref.dtype.kind == 'c' else rs.intensity.raw_data
+        assert got.dtype == ref.dtype
+        assert np.allclose(got, ref, rtol=1e-6, atol=1e-6 * np.abs(ref).max())
 
 
 def test_stream_dataset_on_device(ctx):
