@@ -103,6 +103,9 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # test hooks (one-GPU box: several gloo ranks on one device exercise the N>1 flow end to end)
+    device_id = int(os.environ.get('LTMI_BENCH_DEVICE', local_rank))
+    backend = os.environ.get('LTMI_BENCH_BACKEND', 'nccl')
     cpu_base = None
     if world == 1 and not args.no_cpu_baseline:
         # rank 0 at N=1 only, and BEFORE the HIP runtime is initialised (fork-safe)
@@ -116,14 +119,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(device_id)
     use_dist = world > 1 or os.environ.get('LTMI_FORCE_COLLECTIVES') == '1'
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', device_id))
+        else:
+            dist.init_process_group(backend)
 
     import logging
     logging.getLogger('libertem_amd').setLevel(logging.ERROR)     # stdout carries ONE JSON line
@@ -147,7 +153,7 @@ def main():
     frames = frames.reshape(scan + det)
     masks = np.random.default_rng(2).random((cfg['n_masks'],) + det).astype(np.float32)
 
-    ctx = Context.make_with('hip', gpus=local_rank)
+    ctx = Context.make_with('hip', gpus=device_id)
     # one global dataset of world x (scan) frames; every rank holds its own contiguous block
     ds = ctx.load('memory', data=frames, dtype=np.dtype(cfg['dtype']), sig_dims=2,
                   num_partitions=1, shard=(rank, world) if use_dist else None)

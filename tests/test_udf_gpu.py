@@ -1046,3 +1046,31 @@ def test_two_ranks_share_results_through_host_segment(tmp_path, world):
         for o in outs[1:]:
             assert np.array_equal(outs[0][k], o[k]), k
     assert not [f for f in os.listdir('/dev/shm') if f.startswith(f'ltmi_{os.getuid()}_{port}')]
+
+
+def test_bench_contract_with_two_ranks_on_one_gpu():
+    """bench.py end to end on the N>1 path (sharded dataset, shared-segment delivery, max-over-ranks
+    timing, one JSON line from rank 0) -- two gloo ranks on GPU 0 stand in for two GPUs."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, LTMI_BENCH_DEVICE='0', LTMI_BENCH_BACKEND='gloo', OMP_NUM_THREADS='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1']
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 3 and d['warmup'] == 1 and d['scaling'] == 'weak'
+    assert d['value'] > 0 and d['unit'] == 'frames/s' and d['vs_baseline'] is None
+    assert d['roofline']['bound'] == 'hbm' and 0 < d['roofline']['frac'] < 1.2
+    assert 'cpu_baseline' not in d or d['cpu_baseline'] is None or d['n_gpus'] == 1
