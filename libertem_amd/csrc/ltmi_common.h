@@ -80,8 +80,8 @@ struct ltmi_masks {
     float *img = nullptr;
     float *img2 = nullptr;   // slot-major image for k_dense_lds with ng > 1 (KB = 128)
     int n_slots2 = 0;
-    float *img3 = nullptr;   // 3 groups + ne3 VALU columns (49..52 columns), 32-KiB slots of 128 px
-    int n_slots3 = 0, ne3 = 0;
+    float *img3 = nullptr;   // ng3 groups + ne3 VALU columns (16 ng3 + 1..4 columns), slots of 128 px
+    int n_slots3 = 0, ne3 = 0, ng3 = 0;   // ng3 full groups + ne3 VALU columns
     // float64 results on the f64 matrix cores (ltmi_dense64.hip)
     double *img64 = nullptr;
     int n_groups64 = 0, n_chunks64 = 0;

@@ -336,9 +336,12 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 // Their slot is 32 KiB: NG x 8 KiB of groups, then NE x 512 B of plain (column, pixel) floats.
 template <int NG, int NE = 0> struct LdsCfg {
     static constexpr int KB = (NG == 1 && NE == 0) ? KC : 128;  // pixels per mask slot
-    static constexpr int BSLOT = NE > 0 ? 32768 : NG * GROUP * KB * 4;   // bytes per mask slot
+    // bytes per mask slot; with extras: the NG groups + NE plain columns, rounded up to 8 KiB (each of
+    // the 8 waves copies 1/8 of a slot in whole 1-KiB DMA instructions): 16 / 24 / 32 KiB
+    static constexpr int BSLOT = NE > 0 ? (NG * GROUP * KB * 4 + NE * KB * 4 + 8191) / 8192 * 8192
+                                        : NG * GROUP * KB * 4;
     static constexpr int EXTRA_OFF = NG * GROUP * KB;           // float offset of the extras in a slot
-    static_assert(NE == 0 || (NG * GROUP * KB * 4 + NE * KB * 4 <= 32768), "extras must fit the slot");
+    static_assert(NE == 0 || (NG * GROUP * KB * 4 + NE * KB * 4 <= BSLOT), "extras must fit the slot");
     static constexpr int RING = BSLOT > 16384 ? 3 : 4;          // frame ring depth (sub-chunks)
     static constexpr int WAVES = 8;
     static constexpr int LDS_BYTES = RING * WAVES * V2_ASLOT + 2 * BSLOT;      // 160 KiB
@@ -396,8 +399,9 @@ __global__ void k_build_image_shifted(const float *__restrict__ src, float *__re
 // raw stack -> image 3 (NG groups + extras, 32-KiB slots of 128 pixels): groups as in image 2, then
 // the columns >= 16 NG as plain [column][pixel] floats
 __global__ void k_build_image3(const float *__restrict__ src, float *__restrict__ img,
-                               int64_t n_masks, int cpm, int64_t n_px, int n_slots, int ng) {
-    constexpr int kb = 128, slot_floats = 8192;
+                               int64_t n_masks, int cpm, int64_t n_px, int n_slots, int ng,
+                               int slot_floats) {
+    constexpr int kb = 128;
     const int64_t total = n_masks * cpm * n_px;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -1039,13 +1043,26 @@ extern "C" int ltmi_masks_create_dense(int device, const void *masks_host, int r
                 if (e == hipSuccess) e = hipDeviceSynchronize();
             }
         }
-        if (e == hipSuccess && m->n_cols > 3 * GROUP && m->n_cols <= 3 * GROUP + 4) {
-            // 49..52 columns (25 complex masks = 50): three MFMA groups + the rest on the VALU
-            // instead of a fourth group that is mostly padding (k_dense_lds<T, 3, .., NE>)
+        // Column counts the 1 / 2 / 4-group tiles serve badly get their own slot-major image
+        // ("image 3"): ng3 MFMA groups + ne3 columns on the VALU instead of a group that is mostly
+        // padding (k_dense_lds<T, NG, .., NE>; measured in scripts/bench_extras.py):
+        //   17..18 -> 1 + 2    33..34 -> 2 + 2    35..36 -> 2 + 4    37..48 -> 3 (no padded 4th group)
+        //   49..50 -> 3 + 2    51..52 -> 3 + 4    (19..20: the padded 2-group kernel is faster)
+        int ng3 = 0, ne3 = 0;
+        {
+            const int nc = m->n_cols;
+            if (nc >= 17 && nc <= 18) { ng3 = 1; ne3 = 2; }
+            else if (nc >= 33 && nc <= 36) { ng3 = 2; ne3 = nc <= 34 ? 2 : 4; }
+            else if (nc >= 37 && nc <= 48) { ng3 = 3; ne3 = 0; }
+            else if (nc >= 49 && nc <= 52) { ng3 = 3; ne3 = nc <= 50 ? 2 : 4; }
+        }
+        if (e == hipSuccess && ng3 > 0) {
             constexpr int kb = 128;
+            m->ng3 = ng3;
             m->n_slots3 = (int)((n_px + kb - 1) / kb);
-            m->ne3 = (m->n_cols - 3 * GROUP <= 2) ? 2 : 4;
-            const size_t n3 = (size_t)m->n_slots3 * 8192;
+            m->ne3 = ne3;
+            const int slot_floats = (ng3 * GROUP * kb * 4 + m->ne3 * kb * 4 + 8191) / 8192 * 8192 / 4;
+            const size_t n3 = (size_t)m->n_slots3 * slot_floats;
             e = hipMalloc((void **)&m->img3, n3 * sizeof(float));
             if (e == hipSuccess) e = hipMemset(m->img3, 0, n3 * sizeof(float));
             if (e == hipSuccess) {
@@ -1053,7 +1070,7 @@ extern "C" int ltmi_masks_create_dense(int device, const void *masks_host, int r
                 const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 65535 * 16);
                 hipLaunchKernelGGL(ltmi::k_build_image3, dim3(blocks), dim3(256), 0, 0,
                                    (const float *)m->gmasks, m->img3, n_masks, cpm, n_px,
-                                   m->n_slots3, 3);
+                                   m->n_slots3, ng3, slot_floats);
                 e = hipGetLastError();
                 if (e == hipSuccess) e = hipDeviceSynchronize();
             }
@@ -1207,12 +1224,12 @@ static int launch_lds_ng(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t
     return LTMI_OK;
 }
 
-// 3 MFMA groups + NE VALU columns (stacks of 49..52 columns)
-template <typename T, int NE>
+// NG MFMA groups + NE VALU columns (stacks of 16 NG + 1..4 columns)
+template <typename T, int NG, int NE>
 static int launch_lds_extras(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
                              int64_t ld_out, int accumulate, hipStream_t stream) {
-    using CFG = LdsCfg<3, NE>;
-    auto kern = k_dense_lds<T, 3, 0, false, NE>;
+    using CFG = LdsCfg<NG, NE>;
+    auto kern = k_dense_lds<T, NG, 0, false, NE>;
     static bool attr_set[16] = {false};
     if (!attr_set[m->device & 15]) {
         LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1241,9 +1258,13 @@ static int launch_lds_extras(ltmi_masks *m, const T *tile, int64_t n_frames, int
                        m->n_px, (const float *)m->img3, n_slots, out, ld_out, m->n_cols, accumulate,
                        m->partials, ksplit, (const int32_t *)nullptr, (const float *const *)nullptr);
     LTMI_HIP(hipGetLastError());
-    snprintf(m->last_kernel, sizeof(m->last_kernel),
-             "k_dense_lds<%s,NG=3+%d VALU columns,ring=%d> grid=(%u,%u,1)", typeid(T).name(), NE,
-             CFG::RING, grid.x, grid.y);
+    if (NE > 0)
+        snprintf(m->last_kernel, sizeof(m->last_kernel),
+                 "k_dense_lds<%s,NG=%d+%d VALU columns,ring=%d> grid=(%u,%u,1)", typeid(T).name(), NG,
+                 NE, CFG::RING, grid.x, grid.y);
+    else
+        snprintf(m->last_kernel, sizeof(m->last_kernel), "k_dense_lds<%s,NG=%d,ring=%d> grid=(%u,%u,1)",
+                 typeid(T).name(), NG, CFG::RING, grid.x, grid.y);
     if (ksplit > 1) {
         const int64_t n = n_frames * m->n_cols;
         hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
@@ -1266,10 +1287,17 @@ static int launch_lds(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld
     if (m->ng == 1)
         return launch_lds_ng<T, 1>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
     if constexpr (sizeof(T) > 1) {
-        if (m->img3 && m->tune_ksplit_ring != 33) {          // 33: force the 4-group kernel (bench)
-            if (m->ne3 == 2)
-                return launch_lds_extras<T, 2>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
-            return launch_lds_extras<T, 4>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+        if (m->img3 && m->tune_ksplit_ring != 33) {          // 33: force the padded-group kernel (bench)
+#define LTMI_EXTRAS(NG_, NE_)                                                                     \
+    if (m->ng3 == NG_ && m->ne3 == NE_)                                                           \
+        return launch_lds_extras<T, NG_, NE_>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+            LTMI_EXTRAS(1, 2)
+            LTMI_EXTRAS(2, 2)
+            LTMI_EXTRAS(2, 4)
+            LTMI_EXTRAS(3, 0)
+            LTMI_EXTRAS(3, 2)
+            LTMI_EXTRAS(3, 4)
+#undef LTMI_EXTRAS
         }
         if (m->ng == 2)
             return launch_lds_ng<T, 2>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);

@@ -561,10 +561,14 @@ def test_shifted_masks_host_shifts(hip, tile_dtype, sig, n_masks, mask_dtype, ex
     (25, 'complex64', 0),       # C5: 25 complex masks = 48 + 2 real columns
     (25, 'complex64', 3),
     (49, 'float32', 0), (50, 'float32', 2), (51, 'float32', 0), (52, 'float32', 0),
+    (17, 'float32', 0), (18, 'float32', 3), (9, 'complex64', 0),                          # 1 group + 2
+    (33, 'float32', 0), (35, 'float32', 2), (36, 'float32', 0), (18, 'complex64', 0),    # 2 groups + rest
+    (37, 'float32', 0), (48, 'float32', 2), (20, 'complex64', 0), (24, 'complex64', 0),  # 3 groups
 ])
 def test_three_groups_plus_valu_columns(hip, tile_dtype, n_masks, mask_dtype, ksplit):
-    """Stacks of 49..52 real columns: 3 MFMA groups + the remainder on the VALU (k_dense_lds with
-    extras) must agree with float64 and with the 4-group kernel (tuning code 33)."""
+    """Column counts between the 1 / 2 / 4-group tiles: g MFMA groups + 2 or 4 columns on the VALU
+    (17..18, 33..36, 49..52) or exactly 3 groups (37..48) must agree with float64 and with the
+    padded-group kernel (tuning 33)."""
     rng = np.random.default_rng(hash((tile_dtype, n_masks, mask_dtype)) % (2**32))
     n_frames, n_px = 150, 128 * 37 + 48
     dt = np.dtype(tile_dtype)
@@ -582,7 +586,11 @@ def test_three_groups_plus_valu_columns(hip, tile_dtype, n_masks, mask_dtype, ks
     ref = _ref64(data, masks)
     scale = np.abs(data.astype(np.float64)) @ np.abs(masks).astype(np.float64).T
     res, kern = _apply(hip, data, masks, md, tuning=dict(mt=0, waves=30, ksplit=ksplit))
-    assert 'VALU columns' in kern, kern
+    n_cols = n_masks * (2 if md.kind == 'c' else 1)
+    expect = {17: 'NG=1+2 VALU', 18: 'NG=1+2 VALU', 33: 'NG=2+2 VALU', 34: 'NG=2+2 VALU',
+              35: 'NG=2+4 VALU', 36: 'NG=2+4 VALU', 49: 'NG=3+2 VALU', 50: 'NG=3+2 VALU',
+              51: 'NG=3+4 VALU', 52: 'NG=3+4 VALU'}.get(n_cols, 'NG=3,')
+    assert expect in kern, kern
     assert np.all(np.abs(res - ref) <= 1e-5 * scale + 1e-30)
     base = (rng.random((n_frames, n_masks)) + (1j * rng.random((n_frames, n_masks))
                                                if md.kind == 'c' else 0)).astype(md)
@@ -590,7 +598,7 @@ def test_three_groups_plus_valu_columns(hip, tile_dtype, n_masks, mask_dtype, ks
                      tuning=dict(mt=0, waves=30, ksplit=ksplit))
     assert np.all(np.abs(res2 - (ref + base)) <= 1e-5 * (scale + 1))
     res4, kern4 = _apply(hip, data, masks, md, tuning=dict(mt=0, waves=33, ksplit=ksplit))
-    assert 'NG=4' in kern4, kern4
+    assert ('NG=4' if n_cols > 32 else 'NG=2') in kern4 and 'VALU' not in kern4, kern4
     assert np.all(np.abs(res4 - res) <= 2e-5 * scale + 1e-30)
 
 
