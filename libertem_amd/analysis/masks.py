@@ -1,4 +1,6 @@
 """Mask-based analyses -> ApplyMasksUDF (reference analysis/masks.py:6-184)."""
+import numpy as np
+
 from .base import BaseAnalysis, AnalysisResultSet, AnalysisResult
 from libertem_amd.udf.masks import ApplyMasksUDF
 
@@ -44,12 +46,45 @@ class MasksResultSet(AnalysisResultSet):
 
 
 class SingleMaskAnalysis(BaseMasksAnalysis):
+    """One mask on a 2D detector.  Subclasses are declarative: `WHAT` (text of the result),
+    `geometry(det_y, det_x, given)` -> the geometric parameters with their defaults filled in, and
+    `mask(p, det_y, det_x)` -> the mask (anything a mask factory may return); `SPARSE` fixes
+    `use_sparse` for masks that are sparse by nature."""
+    WHAT = None
+    SPARSE = None
+
+    def geometry(self, det_y, det_x, given):
+        raise NotImplementedError
+
+    def mask(self, p, det_y, det_x):
+        raise NotImplementedError
+
     def get_udf_results(self, udf_results, roi, damage):
         data = udf_results['intensity'].data
         return self.get_generic_results(data[..., 0], damage=damage)
 
     def get_description(self):
-        raise NotImplementedError
+        return "intensity of the integration over the selected %s" % self.WHAT
+
+    def get_use_sparse(self):
+        return self.SPARSE if self.SPARSE is not None else super().get_use_sparse()
+
+    def get_mask_factories(self):
+        sig = self.dataset.shape.sig
+        if sig.dims != 2:
+            raise ValueError("can only handle 2D signals currently")
+        det_y, det_x = tuple(sig)
+        p = dict(self.parameters)
+        return [lambda: self.mask(p, det_y, det_x)]
+
+    def get_parameters(self, parameters):
+        det_y, det_x = tuple(self.dataset.shape.sig)
+        out = dict(self.geometry(det_y, det_x, parameters))
+        if self.SPARSE is None:
+            out['use_sparse'] = parameters.get('use_sparse', False)
+        out['mask_count'] = 1
+        out['mask_dtype'] = np.float32
+        return out
 
     def get_generic_results(self, data, damage):
         if data.dtype.kind == 'c':

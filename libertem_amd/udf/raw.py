@@ -1,10 +1,10 @@
 """
-PickUDF: hand the frames selected by a (small) ROI back unchanged, in the dataset's native dtype.
-Drop-in for the reference's libertem.udf.raw.PickUDF (udf/raw.py:12-76): a 'single' buffer of shape
-(frames in the ROI,) + sig; every partition fills the rows of its own frames, the merge adds the
-otherwise-zero buffers.  No arithmetic: on a HIP worker the tile's rows are copied inside HBM into
-the result buffer (one D2H per partition with the export), on a NumPy worker it is the reference's
-slice assignment.
+PickUDF -- frames selected by a (small) ROI come back unchanged, in the dataset's native dtype.
+
+Same contract as the reference's PickUDF (src/libertem/udf/raw.py:12-76): ONE 'single' buffer of shape
+(number of selected frames,) + sig_shape; each partition writes the rows of its own frames into an
+otherwise zero buffer and the merge adds the buffers up.  Nothing is computed: a HIP worker copies
+the tile's rows inside HBM (one D2H per partition at export), a NumPy worker assigns the slice.
 """
 import logging
 
@@ -16,6 +16,9 @@ from libertem_amd.udf.base import UDF
 
 log = logging.getLogger(__name__)
 
+#: picking is meant for a handful of frames; beyond this many bytes a warning points to real UDFs
+PICK_WARN_BYTES = 1 << 28
+
 
 class PickUDF(UDF):
     def __init__(self):
@@ -25,42 +28,44 @@ class PickUDF(UDF):
         return (self.BACKEND_HIP, self.BACKEND_NUMPY)
 
     def get_preferred_input_dtype(self):
-        return self.USE_NATIVE_DTYPE
+        return self.USE_NATIVE_DTYPE            # hand the pixels back as they are stored
+
+    def _n_selected(self):
+        roi = self.meta.roi
+        return prod(self.meta.dataset_shape.nav) if roi is None else int(np.count_nonzero(roi))
 
     def get_result_buffers(self):
-        dtype = self.meta.input_dtype
-        sigshape = tuple(self.meta.dataset_shape.sig)
-        if self.meta.roi is not None:
-            navsize = int(np.count_nonzero(self.meta.roi))
-        else:
-            navsize = prod(self.meta.dataset_shape.nav)
-        warn_limit = 2**28
-        loaded_size = prod(sigshape) * navsize * np.dtype(dtype).itemsize
-        if loaded_size > warn_limit:
-            log.warning("PickUDF is loading %s bytes, exceeding warning limit %s. "
-                        "Consider using or implementing an UDF to process data on the worker "
-                        "nodes instead." % (loaded_size, warn_limit))
-        return {'intensity': self.buffer(kind='single', extra_shape=(navsize,) + sigshape,
-                                         dtype=dtype, where='device')}
+        sig = tuple(self.meta.dataset_shape.sig)
+        n_sel = self._n_selected()
+        dtype = np.dtype(self.meta.input_dtype)
+        n_bytes = n_sel * prod(sig) * dtype.itemsize
+        if n_bytes > PICK_WARN_BYTES:
+            log.warning("PickUDF is loading %d bytes, exceeding warning limit %d. Consider using or "
+                        "implementing an UDF to process data on the worker nodes instead.",
+                        n_bytes, PICK_WARN_BYTES)
+        # 'single' (not 'nav'): a nav buffer would span the whole scan, NaN-filled outside the ROI
+        return {'intensity': self.buffer(kind='single', extra_shape=(n_sel,) + sig, dtype=dtype,
+                                         where='device')}
 
     def process_tile(self, tile):
-        # flattened nav space with the ROI applied (udf/raw.py:56-60)
-        out = self.results.intensity
-        sl = self.meta.slice
-        if isinstance(tile, HipArray):
-            start = sl.origin[0]
-            n = tile.shape[0]
-            dst = out.torch.reshape(-1)[:prod(out.shape)].reshape(tuple(out.shape))
-            idx = (slice(start, start + n),) + tuple(
-                slice(o, o + s) for o, s in zip(sl.origin[1:], tuple(sl.shape)[1:]))
-            dst[idx].copy_(tile.torch.reshape(-1)[:prod(tile.shape)].reshape(tuple(tile.shape)))
+        target = self.results.intensity
+        where = self.meta.slice                 # flat nav (ROI-compressed) + sig coordinates
+        if not isinstance(tile, HipArray):
+            target[where.get()] = tile
             return
-        out[sl.get()] = tile
+        first = where.origin[0]
+        window = (slice(first, first + tile.shape[0]),) + tuple(
+            slice(o, o + n) for o, n in zip(where.origin[1:], tuple(where.shape)[1:]))
+        dst = target.torch.reshape(-1)[:prod(target.shape)].reshape(tuple(target.shape))
+        src = tile.torch.reshape(-1)[:prod(tile.shape)].reshape(tuple(tile.shape))
+        dst[window].copy_(src)
 
     def merge(self, dest, src):
-        # full-size buffers from every partition, zero outside its own frames
+        # every partition delivers a full-size buffer that is zero outside its own frames
         dest.intensity[:] += src.intensity
 
     def merge_all(self, ordered_results):
-        chunks = [b.intensity for b in ordered_results.values()]
-        return {'intensity': np.stack(chunks, axis=0).sum(axis=0)}
+        total = None
+        for part in ordered_results.values():
+            total = np.array(part.intensity) if total is None else total + part.intensity
+        return {'intensity': total}
