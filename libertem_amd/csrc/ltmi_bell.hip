@@ -134,6 +134,14 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
     for (int s = 0; s < BE_SLOTS; ++s)
 #pragma unroll
         for (int t = 0; t < TILES * NACC; ++t) acc[s][t] = bf32x4{0.f, 0.f, 0.f, 0.f};
+    // One tile per wave (float32 frames, often large detectors): the running sums are handed to a
+    // second level every BE_L2 chunks, which keeps the float32 chains short (the registers are there:
+    // 16 more tiles).  Two tiles per wave have no room for it.
+    constexpr bool TWO_LEVEL = TILES == 1;
+    constexpr int BE_L2 = 32;
+    bf32x4 acc2[TWO_LEVEL ? BE_SLOTS : 1];
+#pragma unroll
+    for (int s = 0; s < (TWO_LEVEL ? BE_SLOTS : 1); ++s) acc2[s] = bf32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- frame DMA: instruction q of the workgroup's chunk copy; wave j issues q = j*NDMA + i
     auto issue_dma = [&](int ai, int buf) {
@@ -275,6 +283,15 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
                 BE_STAMP(2);
             }
         });
+        if constexpr (TWO_LEVEL) {
+            if (((ai - a0) & (BE_L2 - 1)) == BE_L2 - 1) {
+#pragma unroll
+                for (int s = 0; s < BE_SLOTS; ++s) {
+                    acc2[s] += acc[s][0] + acc[s][1];
+                    acc[s][0] = acc[s][1] = bf32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
         // The next chunk must have landed before anyone reads it.  BE_D records consumed since its
         // issue imply it: their refills were issued after it and at most BE_D loads are in flight.
         BE_STAMP(3);
@@ -299,7 +316,7 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
     // ---- results: lane holds columns g*16 + kg*4 .. +3 of frame (tile t, m16)
     if constexpr (NACC == 2) {
 #pragma unroll
-        for (int s = 0; s < BE_SLOTS; ++s) acc[s][0] += acc[s][1];
+        for (int s = 0; s < BE_SLOTS; ++s) acc[s][0] += acc[s][1] + (TWO_LEVEL ? acc2[s] : bf32x4{0.f, 0.f, 0.f, 0.f});
     }
 #pragma unroll
     for (int s = 0; s < BE_SLOTS; ++s) {
