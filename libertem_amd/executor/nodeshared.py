@@ -121,13 +121,22 @@ class NodeShared:
             if bw is not None:
                 bw.replace_array(np.array(bw.raw_data, copy=True))
         self.occupants[s] = []
-        seg = self.slots[s]
-        if seg is None or seg['cap'] < nbytes:
-            self._unmap(seg)
-            self.gen += 1
+        if self.slots[s] is None or self.slots[s]['cap'] < nbytes:
+            # (re)create ALL slots of the ring at the new size now: mapping + page-locking costs
+            # milliseconds, better in one (warm-up) run than spread over the next K
             cap = _round_up(max(nbytes, 1 << 21), 1 << 21)
-            seg = self._map(f"{self.key}_s{s}_g{self.gen}", cap)
-            self.slots[s] = seg
+            self.gen += 1
+            for k in range(self.K):
+                if self.slots[k] is None or self.slots[k]['cap'] < cap:
+                    if k != s:
+                        for ref in self.occupants[k]:
+                            bw = ref()
+                            if bw is not None:
+                                bw.replace_array(np.array(bw.raw_data, copy=True))
+                        self.occupants[k] = []
+                    self._unmap(self.slots[k])
+                    self.slots[k] = self._map(f"{self.key}_s{k}_g{self.gen}", cap)
+        seg = self.slots[s]
         return s, seg['tensor'], seg['np']
 
     def occupy(self, slot, buffer_wrapper):
