@@ -160,6 +160,20 @@ int ltmi_repair_pixels(int device, void *buf, int dtype, int64_t n_frames, int64
 int ltmi_byteswap(int device, const void *src, void *dst, int itemsize, int64_t n_items,
                   void *stream);
 
+/* Centre-of-mass post-processing on a 2D scan of ny x nx positions: from the rows (sum, sum*y, sum*x)
+ * of the 3-mask product to the shift field and its derived maps, float64.  Replaces the NumPy chain
+ * center_shifts -> apply_correction -> magnitude / divergence / curl_2d of src/libertem/udf/com.py:
+ * 100-142 (run by COMAnalysis.get_generic_results, src/libertem/analysis/com.py:191-284):
+ *   yc = (sum != 0 ? sum*y / sum : ref_y) - ref_y   (float32, like NumPy on float32 arrays), same for x;
+ *   (y, x) = transform (2x2 row-major float64: rotation / flip, HOST pointer) . (yc, xc);
+ *   magnitude = sqrt(y^2 + x^2); divergence = d y/dy + d x/dx; curl = d y/dx - d x/dy with
+ *   np.gradient's stencils (central inside, one-sided at the edges, unit spacing).
+ * raw: device float32, row i = scan position i, ld_raw floats between rows (>= 3); outputs: device
+ * float64 (ny*nx each); out_mag / out_div / out_curl may be NULL. */
+int ltmi_com_fields(int device, const float *raw, int64_t ld_raw, int ny, int nx, double ref_y,
+                    double ref_x, const double *transform, double *out_y, double *out_x,
+                    double *out_mag, double *out_div, double *out_curl, void *stream);
+
 /* ---- Fourier-space operators (hipFFT) ----------------------------------------------------------
  * A plan owns a batched 2D real-to-complex hipFFT (frames of sig_h x sig_w float32, `max_batch`
  * per execution) and its workspace (f32 input + complex64 half spectra).

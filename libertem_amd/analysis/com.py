@@ -21,15 +21,49 @@ class COMResultSet(AnalysisResultSet):
 class COMAnalysis(BaseMasksAnalysis, id_="CENTER_OF_MASS"):
     def get_udf_results(self, udf_results, roi, damage):
         data = udf_results['intensity'].data
-        return self.get_generic_results(data[..., 0], data[..., 1], data[..., 2], damage=damage)
+        fields = self._fields_on_device(data)
+        return self.get_generic_results(data[..., 0], data[..., 1], data[..., 2], damage=damage,
+                                        fields=fields)
 
-    def get_generic_results(self, img_sum, img_y, img_x, damage):
+    def _fields_on_device(self, data):
+        """2D scans of real float32 sums: shift field, magnitude, divergence and curl in one pass on
+        the GPU (ltmi_com_fields) instead of ~10 NumPy passes over the scan (3 ms of a 26 ms C3
+        run).  Other cases (complex data, 1D / 3D scans) keep the NumPy chain of the reference."""
+        if data.dtype != np.float32 or data.ndim != 3 or data.shape[-1] != 3 \
+                or min(data.shape[:2]) < 2:
+            return None
+        try:
+            import torch
+            from libertem_amd import hip
+            if not torch.cuda.is_available():
+                return None
+        except Exception:
+            return None
+        from libertem_amd.corrections import coordinates
+        p = self.parameters
+        transform = coordinates.flip_y() if p["flip_y"] else coordinates.identity()
+        transform = coordinates.rotate_deg(p["scan_rotation"]) @ transform
+        ny, nx = data.shape[:2]
+        dev = torch.cuda.current_device()
+        raw = torch.from_numpy(np.ascontiguousarray(data).reshape(-1, 3)).to(f'cuda:{dev}')
+        out = torch.empty((5, ny * nx), dtype=torch.float64, device=raw.device)
+        ptr = [out[i].data_ptr() for i in range(5)]
+        hip.com_fields(dev, raw.data_ptr(), 3, ny, nx, p["cy"], p["cx"], transform, ptr[0], ptr[1],
+                       ptr[2], ptr[3], ptr[4], stream=torch.cuda.current_stream(dev))
+        host = out.cpu().numpy().reshape((5, ny, nx))
+        return dict(y=host[0], x=host[1], magnitude=host[2], divergence=host[3], curl=host[4])
+
+    def get_generic_results(self, img_sum, img_y, img_x, damage, fields=None):
         ref_x, ref_y = self.parameters["cx"], self.parameters["cy"]
-        y_raw, x_raw = center_shifts(img_sum, img_y, img_x, ref_y, ref_x)
-        shape = y_raw.shape
-        y_centers, x_centers = apply_correction(
-            y_raw, x_raw, scan_rotation=self.parameters["scan_rotation"],
-            flip_y=self.parameters["flip_y"])
+        if fields is not None:
+            y_centers, x_centers = fields['y'], fields['x']
+            shape = y_centers.shape
+        else:
+            y_raw, x_raw = center_shifts(img_sum, img_y, img_x, ref_y, ref_x)
+            shape = y_raw.shape
+            y_centers, x_centers = apply_correction(
+                y_raw, x_raw, scan_rotation=self.parameters["scan_rotation"],
+                flip_y=self.parameters["flip_y"])
         if img_sum.dtype.kind == 'c':
             return COMResultSet([
                 AnalysisResult(raw_data=np.real(x_centers), key="x_real", title="x [real]"),
@@ -37,7 +71,7 @@ class COMAnalysis(BaseMasksAnalysis, id_="CENTER_OF_MASS"):
                 AnalysisResult(raw_data=np.imag(x_centers), key="x_imag", title="x [imag]"),
                 AnalysisResult(raw_data=np.imag(y_centers), key="y_imag", title="y [imag]"),
             ])
-        m = magnitude(y_centers, x_centers)
+        m = fields['magnitude'] if fields is not None else magnitude(y_centers, x_centers)
         results = [
             AnalysisResult(raw_data=(x_centers, y_centers), key="field", title="field",
                            desc="cubehelix colorwheel visualization", include_in_download=False),
@@ -50,9 +84,11 @@ class COMAnalysis(BaseMasksAnalysis, id_="CENTER_OF_MASS"):
         ]
         if all(s > 1 for s in shape):
             extra = [
-                AnalysisResult(raw_data=divergence(y_centers, x_centers), key="divergence",
+                AnalysisResult(raw_data=fields['divergence'] if fields is not None
+                               else divergence(y_centers, x_centers), key="divergence",
                                title="divergence", desc="divergence of the vector field"),
-                AnalysisResult(raw_data=curl_2d(y_centers, x_centers), key="curl", title="curl",
+                AnalysisResult(raw_data=fields['curl'] if fields is not None
+                               else curl_2d(y_centers, x_centers), key="curl", title="curl",
                                desc="curl of the 2D vector field"),
             ]
             results[2:2] = extra

@@ -437,6 +437,75 @@ extern "C" int ltmi_repair_pixels(int device, void *buf, int dtype, int64_t n_fr
     return LTMI_OK;
 }
 
+// ---- centre-of-mass post-processing on a 2D scan (reference udf/com.py:100-142) ------------------
+// raw rows (sum, sum*y, sum*x) float32 -> shift vectors: float32 division and reference subtraction as
+// NumPy does on float32 arrays, then the 2x2 float64 transform (rotation / flip), magnitude,
+// divergence and curl with np.gradient's stencils (central inside, one-sided at the edges).
+__global__ void __launch_bounds__(256)
+k_com_shifts(const float *__restrict__ raw, int64_t ld_raw, int64_t n, float ref_y, float ref_x,
+             double tyy, double tyx, double txy, double txx, double *__restrict__ out_y,
+             double *__restrict__ out_x, double *__restrict__ out_mag) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float s = raw[i * ld_raw], sy = raw[i * ld_raw + 1], sx = raw[i * ld_raw + 2];
+    float yc = ref_y, xc = ref_x;
+    if (s != 0.f) {
+        yc = __fdiv_rn(sy, s);
+        xc = __fdiv_rn(sx, s);
+    }
+    yc = __fsub_rn(yc, ref_y);
+    xc = __fsub_rn(xc, ref_x);
+    const double y = (double)yc, x = (double)xc;
+    const double yt = __dadd_rn(__dmul_rn(tyy, y), __dmul_rn(tyx, x));
+    const double xt = __dadd_rn(__dmul_rn(txy, y), __dmul_rn(txx, x));
+    out_y[i] = yt;
+    out_x[i] = xt;
+    if (out_mag) out_mag[i] = sqrt(__dadd_rn(__dmul_rn(yt, yt), __dmul_rn(xt, xt)));
+}
+
+__device__ __forceinline__ double grad_at(const double *f, int64_t idx, int64_t stride, int pos, int n) {
+    if (n < 2) return 0.0;
+    if (pos == 0) return f[idx + stride] - f[idx];
+    if (pos == n - 1) return f[idx] - f[idx - stride];
+    return (f[idx + stride] - f[idx - stride]) / 2.0;
+}
+
+__global__ void __launch_bounds__(256)
+k_com_div_curl(const double *__restrict__ fy, const double *__restrict__ fx, int ny, int nx,
+               double *__restrict__ out_div, double *__restrict__ out_curl) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)ny * nx) return;
+    const int yy = (int)(i / nx), xx = (int)(i % nx);
+    // axis 0 = y (stride nx), axis 1 = x (stride 1)
+    if (out_div) out_div[i] = grad_at(fy, i, nx, yy, ny) + grad_at(fx, i, 1, xx, nx);
+    if (out_curl) out_curl[i] = grad_at(fy, i, 1, xx, nx) - grad_at(fx, i, nx, yy, ny);
+}
+
+extern "C" int ltmi_com_fields(int device, const float *raw, int64_t ld_raw, int ny, int nx,
+                               double ref_y, double ref_x, const double *transform,
+                               double *out_y, double *out_x, double *out_mag, double *out_div,
+                               double *out_curl, void *stream_) {
+    if (ny <= 0 || nx <= 0 || ld_raw < 3)
+        LTMI_FAIL(LTMI_E_SHAPE, "ltmi_com_fields: bad shape (ny=%d nx=%d ld=%lld)", ny, nx,
+                  (long long)ld_raw);
+    if (!raw || !transform || !out_y || !out_x)
+        LTMI_FAIL(LTMI_E_INVALID, "ltmi_com_fields: null pointer");
+    LTMI_HIP(hipSetDevice(device));
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t n = (int64_t)ny * nx;
+    dim3 grid((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL(k_com_shifts, grid, dim3(256), 0, stream, raw, ld_raw, n, (float)ref_y,
+                       (float)ref_x, transform[0], transform[1], transform[2], transform[3], out_y,
+                       out_x, out_mag);
+    LTMI_HIP(hipGetLastError());
+    if (out_div || out_curl) {
+        hipLaunchKernelGGL(k_com_div_curl, grid, dim3(256), 0, stream, (const double *)out_y,
+                           (const double *)out_x, ny, nx, out_div, out_curl);
+        LTMI_HIP(hipGetLastError());
+    }
+    return LTMI_OK;
+}
+
 extern "C" int ltmi_axpy(int device, void *dest, const void *src, int dtype, int64_t n,
                          void *stream_) {
     if (n < 0) LTMI_FAIL(LTMI_E_SHAPE, "ltmi_axpy: negative size");

@@ -28,7 +28,7 @@ EXPORTS = (
     'ltmi_version', 'ltmi_last_error', 'ltmi_device_count', 'ltmi_device_info',
     'ltmi_masks_create_dense', 'ltmi_masks_create_csr', 'ltmi_masks_destroy', 'ltmi_masks_kind',
     'ltmi_apply_masks', 'ltmi_apply_masks_shifted', 'ltmi_apply_masks_shifted_host', 'ltmi_sum_frames_workspace', 'ltmi_sum_frames', 'ltmi_sum_sig',
-    'ltmi_axpy', 'ltmi_correct', 'ltmi_repair_pixels', 'ltmi_byteswap', 'ltmi_fft_plan_create',
+    'ltmi_axpy', 'ltmi_correct', 'ltmi_repair_pixels', 'ltmi_byteswap', 'ltmi_com_fields', 'ltmi_fft_plan_create',
     'ltmi_fft_plan_destroy', 'ltmi_crystallinity', 'ltmi_masks_set_tuning',
     'ltmi_masks_last_kernel',
 )
@@ -110,6 +110,8 @@ def lib():
         L.ltmi_correct.argtypes = [i32, vp, i32, i64, i64, i64, vp, vp, vp, i32, i64, vp]
         L.ltmi_repair_pixels.argtypes = [i32, vp, i32, i64, i64, vp, vp, vp, i32, i32, vp]
         L.ltmi_byteswap.argtypes = [i32, vp, vp, i32, i64, vp]
+        L.ltmi_com_fields.argtypes = [i32, vp, i64, i32, i32, ctypes.c_double, ctypes.c_double, vp, vp,
+                                      vp, vp, vp, vp, vp]
         L.ltmi_fft_plan_create.argtypes = [i32, i32, i32, i32, c.POINTER(vp)]
         L.ltmi_fft_plan_destroy.argtypes = [vp]
         L.ltmi_crystallinity.argtypes = [vp, vp, i32, i64, i64, vp, vp, i32, i32, i32, vp, i32, vp]
@@ -313,6 +315,18 @@ def byteswap(device, src_ptr, dst_ptr, itemsize, n_items, stream=None):
     check(lib().ltmi_byteswap(
         int(device), src_ptr, dst_ptr, int(itemsize), int(n_items),
         stream if isinstance(stream, int) else _stream_ptr(stream)), 'ltmi_byteswap')
+
+
+def com_fields(device, raw_ptr, ld_raw, ny, nx, ref_y, ref_x, transform, out_y, out_x, out_mag=None,
+               out_div=None, out_curl=None, stream=None):
+    """Shift field + magnitude / divergence / curl of a 2D scan from the raw CoM rows (device
+    pointers; `transform`: 2x2 float64, host)."""
+    t = np.ascontiguousarray(transform, dtype=np.float64).reshape(4)
+    check(lib().ltmi_com_fields(
+        int(device), raw_ptr, int(ld_raw), int(ny), int(nx), float(ref_y), float(ref_x),
+        t.ctypes.data_as(ctypes.c_void_p), out_y, out_x, out_mag or None, out_div or None,
+        out_curl or None, stream if isinstance(stream, int) else _stream_ptr(stream)),
+        'ltmi_com_fields')
 
 
 class FFTPlan:

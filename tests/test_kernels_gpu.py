@@ -643,3 +643,33 @@ def test_byteswap_rejects_bad_arguments(hip):
         hip.byteswap(0, t.data_ptr(), t.data_ptr(), 3, 4)
     with pytest.raises((RuntimeError, ValueError)):
         hip.byteswap(0, t.data_ptr(), t.data_ptr(), 2, -1)
+
+
+# ---- centre-of-mass post-processing ---------------------------------------------------------------------
+@pytest.mark.parametrize('ny,nx,rot,flip', [(7, 9, 0.0, False), (16, 5, 33.0, True), (2, 2, 90.0, False),
+                                            (64, 64, -120.5, True), (3, 40, 0.0, True)])
+def test_com_fields_vs_oracle(hip, ny, nx, rot, flip):
+    """ltmi_com_fields == the NumPy chain center_shifts -> apply_correction -> magnitude /
+    divergence / curl_2d of the reference (oracle.path restatement, pinned by com.npz)."""
+    from libertem_amd.corrections import coordinates
+    rng = np.random.default_rng(ny * 100 + nx)
+    raw = rng.random((ny, nx, 3)).astype(np.float32) * np.array([50, 900, 1100], dtype=np.float32)
+    raw[0, 0] = 0                                          # empty frame: zero shift
+    if ny > 2:
+        raw[ny // 2, nx // 2, 0] = 0
+    cy, cx = 17.25, 21.5
+    y_raw, x_raw = opath.center_shifts(raw[..., 0], raw[..., 1], raw[..., 2], cy, cx)
+    y_ref, x_ref = opath.apply_correction(y_raw, x_raw, scan_rotation=rot, flip_y_=flip)
+    transform = coordinates.flip_y() if flip else coordinates.identity()
+    transform = coordinates.rotate_deg(rot) @ transform
+    t = _dev(raw.reshape(-1, 3))
+    out = torch.zeros((5, ny * nx), dtype=torch.float64, device='cuda')
+    hip.com_fields(0, t.data_ptr(), 3, ny, nx, cy, cx, transform, *[out[i].data_ptr() for i in range(5)])
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape((5, ny, nx))
+    tol = dict(rtol=1e-12, atol=1e-12)
+    assert np.allclose(got[0], y_ref, **tol) and np.allclose(got[1], x_ref, **tol)
+    assert np.allclose(got[2], opath.magnitude(y_ref, x_ref), **tol)
+    assert np.allclose(got[3], opath.divergence(y_ref, x_ref), **tol)
+    assert np.allclose(got[4], opath.curl_2d(y_ref, x_ref), **tol)
+    assert got[0][0, 0] == 0 and got[1][0, 0] == 0
