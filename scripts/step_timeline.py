@@ -46,6 +46,16 @@ wrap(ubase.UDF, 'allocate_for_part')
 wrap(ubase.UDF, 'allocate_for_full')
 wrap(ubase.UDF, 'init_result_buffers')
 wrap(ubase.UDF, 'init_task_data')
+from libertem_amd.io.dataset import memory as dsmem
+from libertem_amd.udf import masks as umasks
+wrap(umasks.ApplyMasksUDF, 'process_tile', 'udf.process_tile')
+wrap(umasks.ApplyMasksUDF, 'get_task_data')
+wrap(umasks.ApplyMasksUDF, 'get_result_buffers')
+wrap(ubase.UDFPartRunner, '_run_tile')
+wrap(hexec.HipJobExecutor, 'run_tasks', 'run_tasks (generator creation)')
+wrap(hexec.HipJobExecutor, '_merge_on_device')
+wrap(ubase.UDFRunner, '_make_udf_tasks') if hasattr(ubase.UDFRunner, '_make_udf_tasks') else None
+wrap(dsbase.DataSet, 'get_partitions') if hasattr(dsbase.DataSet, 'get_partitions') else None
 for _ in range(5):
     ctx.run_udf(dataset=ds, udf=udf)
 runs = []
