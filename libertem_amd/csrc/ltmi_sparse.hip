@@ -214,8 +214,9 @@ k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
 }
 
 // A u16-slab, double-buffered variant with one slice per wave was tried and removed: it did not
-// beat this kernel (profiles/r01_sparse_ablation.txt) -- the gather loop is latency bound, see
-// DESIGN.md section 4.3 for the analysis and the planned redesign.
+// beat this kernel (profiles/r01_sparse_ablation.txt) -- the gather loop is bound by its LDS gathers
+// and their latency, see DESIGN.md section 4.3.  Localised stacks go to the blocked image on the
+// matrix cores instead (ltmi_bell.hip).
 
 }  // namespace ltmi
 
@@ -245,10 +246,6 @@ static int launch_sell(ltmi_masks *m, CsrImage *c, const T *tile, int64_t n_fram
     const char *abl = getenv("LTMI_SELL_ABLATE");     // 1: loader only, 2: gathers only (bench)
     const int ablate = abl ? atoi(abl) : 0;
     dim3 grid((unsigned)((n_frames + SP_F - 1) / SP_F), (unsigned)c->n_pass);
-    if constexpr (sizeof(T) == 2) {
-        // experimental (round 1: not faster than k_sell_apply -- every wave's entry stream queues
-        // behind its own HBM frame loads on the in-order vmcnt; needs dedicated loader waves)
-    }
     const size_t lds = (size_t)SP_P * SP_F * sizeof(float);
     if (c->cplx) {
         auto kern = k_sell_apply<T, 2, true>;
