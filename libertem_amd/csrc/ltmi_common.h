@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include <string>
+#include <vector>
 #include "../../include/ltmi.h"
 
 namespace ltmi {
@@ -98,5 +99,9 @@ struct ltmi_masks {
     void *gmasks = nullptr;  // (n_masks, n_px) of the accumulate type
     // kind 2 (ltmi_sparse.hip)
     void *csr = nullptr;
+    // kind 0 with more than 64 real columns: the stack again as column blocks of <= 64 columns,
+    // each with the tile width that fits it (ltmi_apply_masks walks them; tuning code 33 does not)
+    std::vector<ltmi_masks *> blocks;
+    std::vector<int64_t> block_first;        // first mask of every block
     char last_kernel[128] = {0};
 };

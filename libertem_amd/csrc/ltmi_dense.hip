@@ -1080,6 +1080,26 @@ extern "C" int ltmi_masks_create_dense(int device, const void *masks_host, int r
             LTMI_FAIL((int)e, "building the mask image failed: %s", hipGetErrorString(e));
         }
     }
+    if (m->kind == 0 && m->n_cols > 4 * GROUP) {
+        // wide stacks: 4-group tiles over ALL columns would pad the last tile to 64 columns; blocks
+        // of 64 columns + a last block with the tile width that fits it compute less (70 columns:
+        // 64 + 16 instead of 128)
+        const int cpm = (result_dtype == LTMI_C64) ? 2 : 1;
+        const int64_t per = 4 * GROUP / cpm;
+        const size_t row_bytes = (size_t)n_px * dtype_size(result_dtype);
+        for (int64_t k0 = 0; k0 < n_masks; k0 += per) {
+            ltmi_masks *child = nullptr;
+            const int rc = ltmi_masks_create_dense(
+                device, (const unsigned char *)masks_host + (size_t)k0 * row_bytes, result_dtype,
+                std::min<int64_t>(per, n_masks - k0), n_px, &child);
+            if (rc != LTMI_OK) {
+                ltmi_masks_destroy(m);
+                return rc;
+            }
+            m->blocks.push_back(child);
+            m->block_first.push_back(k0);
+        }
+    }
     *out = m;
     return LTMI_OK;
 }
@@ -1088,6 +1108,8 @@ static void shift_cache_destroy(ltmi_masks *m);
 
 extern "C" int ltmi_masks_destroy(ltmi_masks *m) {
     if (!m) return LTMI_OK;
+    for (ltmi_masks *b : m->blocks) (void)ltmi_masks_destroy(b);
+    m->blocks.clear();
     (void)hipSetDevice(m->device);
     if (m->img) (void)hipFree(m->img);
     if (m->img2) (void)hipFree(m->img2);
@@ -1608,6 +1630,22 @@ extern "C" int ltmi_apply_masks(ltmi_masks *m, const void *tile, int tile_dtype,
     if (m->kind == 2)
         return ltmi::csr_apply(m, tile, tile_dtype, n_frames, ld_tile, out, ld_out, accumulate,
                                stream);
+    if (m->kind == 0 && mfma_tile_dtype(tile_dtype) && !m->blocks.empty() &&
+        m->tune_mt == 0 && m->tune_waves == 0 && m->tune_ksplit_ring != 33) {
+        const size_t elem = (size_t)dtype_size(m->result_dtype);
+        for (size_t b = 0; b < m->blocks.size(); ++b) {
+            ltmi_masks *c = m->blocks[b];
+            c->tune_ksplit = m->tune_ksplit;
+            c->tune_ksplit_ring = m->tune_ksplit_ring;
+            const int rc = ltmi_apply_masks(c, tile, tile_dtype, n_frames, ld_tile,
+                                            (unsigned char *)out + (size_t)m->block_first[b] * elem,
+                                            ld_out, accumulate, stream_);
+            if (rc != LTMI_OK) return rc;
+        }
+        snprintf(m->last_kernel, sizeof(m->last_kernel), "%zu column blocks, last: %.90s",
+                 m->blocks.size(), m->blocks.back()->last_kernel);
+        return LTMI_OK;
+    }
     if (m->kind == 0 && mfma_tile_dtype(tile_dtype)) {
         float *o = (float *)out;
         const int64_t ldo = ld_out * (m->result_dtype == LTMI_C64 ? 2 : 1);

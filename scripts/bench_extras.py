@@ -9,7 +9,7 @@ rng = np.random.default_rng(0)
 for dt, n_frames, n_px in ((np.uint16, 65536, 65536), (np.float32, 8192, 1 << 20)):
     tdt = torch.int16 if dt == np.uint16 else torch.float32
     tile = (torch.rand((n_frames, n_px), device='cuda') * 4000).to(tdt)
-    for n_masks in (16, 18, 20, 32, 34, 36, 48, 50):
+    for n_masks in (16, 18, 20, 32, 34, 36, 48, 50, 70, 100, 128):
         masks = rng.random((n_masks, n_px), dtype=np.float32)
         h = hip.MaskHandle.dense(0, masks, np.float32)
         out = torch.zeros((n_frames, n_masks), device='cuda')

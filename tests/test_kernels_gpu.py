@@ -120,7 +120,8 @@ def test_mfma_variants_agree(hip, tuning):
     ((129, 128 * 53 + 16, 24), 0),       # NG=2
     ((77, 128 * 61 + 48, 50), 0),       # NG=4 (C5-like: 50 real columns)
     ((77, 128 * 61 + 48, 50), 4),
-    ((40, 128 * 30, 70), 0),            # 5 groups -> two group tiles of NG=4
+    ((40, 128 * 30, 70), 0),            # 5 groups -> a block of 64 columns + one of 6
+    ((40, 128 * 30, 70), 2),
 ])
 def test_lds_dma_kernel_all_widths(hip, tile_dtype, shape, ksplit):
     """k_dense_lds (frames through LDS by DMA) for every pixel width and group count; forced with
@@ -137,10 +138,12 @@ def test_lds_dma_kernel_all_widths(hip, tile_dtype, shape, ksplit):
         data = (rng.random((n_frames, n_px)) - 0.3).astype(dt)
     masks = (rng.random((n_masks, n_px)) - 0.25).astype(np.float32)
     res, kern = _apply(hip, data, masks, np.float32, tuning=dict(mt=0, waves=30, ksplit=ksplit))
-    if dt.itemsize == 1 and n_masks > 16:
+    if dt.itemsize == 1 and 16 < n_masks <= 64:
         assert 'k_dense_mfma<' in kern, kern       # 1-byte pixels with several groups: direct-load kernel
     else:
         assert 'k_dense_lds' in kern, kern
+    if n_masks > 64:
+        assert kern.startswith('2 column blocks'), kern   # 64 + the rest, each with its own tile width
     ref = _ref64(data, masks)
     scale = np.abs(data.astype(np.float64)) @ np.abs(masks.astype(np.float64)).T
     assert np.all(np.abs(res - ref) <= 1e-5 * scale + 1e-30)
