@@ -1,20 +1,38 @@
 #!/usr/bin/env python
 """
 bench.py -- headline benchmark: ApplyMasksUDF, 16 dense float32 masks, 256x256 scan x 256x256
-detector uint16 (BASELINE.json configs[1]), frames resident in HBM, through Context.run_udf.
+detector uint16 (BASELINE.json configs[1], "C2"), frames resident in HBM, through Context.run_udf.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is ONE complete `Context.run_udf(dataset, ApplyMasksUDF(...))` job over the per-GPU
-dataset (planning + kernels + device-side merge + [N>1: RCCL all-gather of the nav results] +
-one D2H of the result), i.e. the whole hot path, not just the kernel.  Weak scaling: every rank
-holds its own 256x256-scan shard (65536 frames, 8 GiB); the nav grid of the job is N x that.
+dataset (planning + kernels + delivery of the complete nav result to the host of EVERY rank), i.e.
+the whole hot path, not just the kernel.  Weak scaling: every rank holds its own 256x256-scan shard
+(65536 frames, 8 GiB); the nav grid of the job is N x that.
 
-Rank 0 prints ONE JSON line.  `roofline` is the dominant kernel (k_dense_lds) timed with HIP
-events on its own stream inside the timed region; `cpu_baseline` is the oracle (the CPU
-restatement of the reference path) timed on this box's host cores on a bounded sample.
+Rank 0 prints ONE JSON line.  `value` / `roofline` / `cpu_baseline` are the C2 figures the contract
+asks for.  The same line carries, as extra keys (all configs, both timing modes):
+
+  N = 1:  "configs": {"c3": ..., "c4": ..., "c5": ...}   whole job + dominant kernel + roofline each
+          "host_streamed": frames in host memory, double-buffered hipMemcpyAsync, vs measured H2D peak
+  N > 1:  "result_via", "per_rank" (kernel / step time of every rank),
+          "rccl_path": the same steps with the results gathered by RCCL (all_gather over xGMI)
+                       instead of the node-shared host segment,
+          "strong_c3": CoM analysis on a FIXED 512x512 scan x 512x512 uint16 (128 GiB) nav-split
+                       over the N ranks (strong scaling).
+
+`--config c3|c4|c5` makes that config the measured one (`value` then is ITS frames/s; used by
+scripts/profile_round.sh for per-config rocprofv3 passes); `--no-extras` skips the extra keys.
+
+`roofline.achieved` = algorithmic bytes (or flops) per launch / average launch duration from HIP
+events on the kernel's own stream inside the timed region; `roofline.traffic` = HBM bytes per launch
+from the tracked PMC profile (profiles/traffic.json, written by scripts/traffic_from_rocprof.py from
+separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over exactly this command), matched on
+config, kernel label and frames per launch -- null if the kernel changed since the profile was taken.
+`cpu_baseline` is the oracle (the CPU restatement of the reference path) timed on this box's host
+cores on a bounded sample; it is the checker and the baseline, never the thing measured.
 """
 import argparse
 import json
@@ -27,17 +45,33 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E (guides/MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TF = 157.3         # dense f32 matrix peak (same guide)
 
 CONFIGS = {
-    # name: (scan, detector, dtype, n_masks)
-    'c2': dict(scan=(256, 256), det=(256, 256), dtype='uint16', n_masks=16,
+    'c2': dict(scan=(256, 256), det=(256, 256), dtype='uint16', n_masks=16, result_bytes=64,
+               flops=2 * 65536 * 16, bound='hbm', kernel='k_dense',
                desc='ApplyMasksUDF 16 dense f32 masks, 256x256 scan x 256x256 uint16'),
-    'c2-small': dict(scan=(64, 64), det=(256, 256), dtype='uint16', n_masks=16,
+    'c2-small': dict(scan=(64, 64), det=(256, 256), dtype='uint16', n_masks=16, result_bytes=64,
+                     flops=2 * 65536 * 16, bound='hbm', kernel='k_dense',
                      desc='ApplyMasksUDF 16 dense f32 masks, 64x64 scan x 256x256 uint16'),
+    'c3': dict(scan=(512, 512), det=(512, 512), dtype='uint16', n_masks=3, result_bytes=12,
+               flops=2 * 262144 * 3, bound='hbm', kernel='k_dense',
+               desc='COMAnalysis (3 masks + post-processing), 512x512 scan x 512x512 uint16'),
+    'c4': dict(scan=(256, 256), det=(256, 256), dtype='uint16', n_masks=1024, result_bytes=4096,
+               flops=2 * 432407, bound='hbm', kernel='k_bell|k_sell',
+               desc='ApplyMasksUDF 1024 sparse ring masks (CSR, nnz 432407), 256x256 scan x '
+                    '256x256 uint16'),
+    'c5': dict(scan=(128, 128), det=(1024, 1024), dtype='float32', n_masks=25, result_bytes=200,
+               flops=4 * 1048576 * 25, bound='mfma', kernel='k_dense',
+               desc='RadialFourierAnalysis defaults (25 dense complex64 masks), 128x128 scan x '
+                    '1024x1024 float32'),
 }
 
 
+# --------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle = the checker; forked BEFORE the HIP runtime is initialised)
+# --------------------------------------------------------------------------------------------------
 def _cpu_worker(job):
     """One CPU worker = one process with ONE BLAS thread (reference: executor/dask.py:251),
     running the oracle's tiled loop over its own nav slice, `passes` times."""
@@ -86,8 +120,237 @@ def cpu_baseline(cfg, budget_s=12.0):
     wall = max(r[2] for r in res) - min(r[1] for r in res)
     return {"value": total / wall, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{cores} single-threaded worker processes x {n_frames} frames x {passes} "
-                      f"passes of the same workload (oracle.path.apply_masks: reference tile shape "
+                      f"passes of the C2 workload (oracle.path.apply_masks: reference tile shape "
                       f"(32,32,256), astype(float32) + torch.mm per tile), {wall:.1f} s wall"}
+
+
+# --------------------------------------------------------------------------------------------------
+# workloads
+# --------------------------------------------------------------------------------------------------
+def device_frames(torch, n_frames, det, dtype, seed):
+    """synthetic frames generated ON the device (not timed): uint16 counts in [0, 4096) /
+    float32 in [0, 1)"""
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    n_px = det[0] * det[1]
+    if np.dtype(dtype) == np.uint16:
+        t = torch.empty((n_frames, n_px), dtype=torch.int16, device='cuda')
+        step = max(1, (1 << 30) // (n_px * 2))
+        for i in range(0, n_frames, step):
+            j = min(n_frames, i + step)
+            t[i:j] = torch.randint(0, 4096, (j - i, n_px), generator=g, device='cuda',
+                                   dtype=torch.int16)
+        return t
+    t = torch.empty((n_frames, n_px), dtype=torch.float32, device='cuda')
+    step = max(1, (1 << 30) // (n_px * 4))
+    for i in range(0, n_frames, step):
+        j = min(n_frames, i + step)
+        t[i:j] = torch.rand((j - i, n_px), generator=g, device='cuda')
+    return t
+
+
+class Workload:
+    """One BASELINE.json config on this rank's shard: .step() runs the whole job once through the
+    public API, .check(result) compares a few frames with float64 NumPy."""
+
+    def __init__(self, name, ctx, torch, rank, world, sharded, frames_per_rank=None):
+        from libertem_amd.udf.masks import ApplyMasksUDF
+        from libertem_amd import masks as M
+        cfg = CONFIGS[name]
+        self.name, self.cfg, self.ctx, self.torch = name, cfg, ctx, torch
+        scan, det = cfg['scan'], cfg['det']
+        self.det = det
+        self.n_px = det[0] * det[1]
+        self.itemsize = np.dtype(cfg['dtype']).itemsize
+        self.n_local = frames_per_rank if frames_per_rank is not None else scan[0] * scan[1]
+        self.world, self.rank = world, rank
+        self.use_oracle = False
+        self.frames = device_frames(torch, self.n_local, det, cfg['dtype'], 1 + rank + 17 * len(name))
+        rows = self.n_local // scan[1]
+        assert rows * scan[1] == self.n_local
+        data = self.frames.reshape((rows, scan[1]) + det)
+        self.ds = ctx.load('memory', data=data, dtype=np.dtype(cfg['dtype']), sig_dims=2,
+                           num_partitions=1, shard=(rank, world) if sharded else None)
+        self.nav = (rows * (world if sharded else 1), scan[1])
+        if name in ('c2', 'c2-small'):
+            self.masks = np.random.default_rng(2).random((16,) + det).astype(np.float32)
+            udf = ApplyMasksUDF(mask_factories=lambda: self.masks, use_sparse=False,
+                                mask_count=16, mask_dtype=np.float32)
+            self.step = lambda: ctx.run_udf(dataset=self.ds, udf=udf)
+        elif name == 'c3':
+            an = ctx.create_com_analysis(dataset=self.ds, cx=256, cy=256)
+            self.step = lambda: ctx.run(an)
+        elif name == 'c4':
+            def rings():
+                return M.radial_bins(centerX=128, centerY=128, imageSizeX=256, imageSizeY=256,
+                                     n_bins=1024, use_sparse=True, dtype=np.float32)
+            udf = ApplyMasksUDF(mask_factories=rings, use_sparse='scipy.sparse', mask_count=1024,
+                                mask_dtype=np.float32)
+            self.step = lambda: ctx.run_udf(dataset=self.ds, udf=udf)
+        elif name == 'c5':
+            self.analysis = ctx.create_radial_fourier_analysis(dataset=self.ds)
+            assert self.analysis.parameters['use_sparse'] is False
+            self.step = lambda: ctx.run(self.analysis)
+        else:
+            raise ValueError(name)
+
+    def _frame(self, local_idx):
+        f = self.frames[local_idx].cpu().numpy()
+        if self.cfg['dtype'] == 'uint16':
+            f = f.view(np.uint16)
+        return f.astype(np.float64)
+
+    def check(self, res, n_check=32):
+        """float64 NumPy on `n_check` of THIS rank's frames against the job's result; raises on a
+        relative error > 1e-5 (a kernel that skipped pixels or frames does not post a number)."""
+        from libertem_amd import masks as M
+        rng = np.random.default_rng(1234 + self.rank)
+        idx = np.unique(np.concatenate([[0, self.n_local - 1],
+                                        rng.integers(0, self.n_local, n_check)]))
+        g0 = self.rank * self.n_local if self.ds.shard is not None else 0
+        name = self.name
+        worst = 0.0
+        if name in ('c2', 'c2-small'):
+            got = res['intensity'].data
+            assert got.shape == self.nav + (16,) and got.dtype == np.float32
+            assert np.all(np.isfinite(got))
+            got = got.reshape((-1, 16))
+            m64 = self.masks.reshape((16, -1)).astype(np.float64)
+            for i in idx:
+                ref = m64 @ self._frame(i).reshape(-1)
+                worst = max(worst, np.abs(got[g0 + i] - ref).max() / np.abs(ref).max())
+            if self.use_oracle:
+                # the oracle (CPU restatement of the reference's tiled loop) as the checker, on the
+                # same frames -- cpu_baseline leg only
+                from oracle import path as opath
+                sub = np.stack([self.frames[int(i)].cpu().numpy().view(np.uint16) for i in idx])
+                ref = opath.apply_masks(sub.reshape((1, len(idx)) + self.det), self.masks)[0]
+                worst = max(worst, float(np.abs(got[g0 + idx] - ref).max() / np.abs(ref).max()))
+        elif name == 'c3':
+            yy, xx = np.mgrid[0:self.det[0], 0:self.det[1]]
+            gy = res.y.raw_data.reshape(-1)
+            gx = res.x.raw_data.reshape(-1)
+            assert res.y.raw_data.shape == self.nav
+            for i in idx[:8]:
+                f = self._frame(i).reshape(self.det)
+                cy, cx = (f * yy).sum() / f.sum() - 256, (f * xx).sum() / f.sum() - 256
+                # the shifts are differences of ~256-sized quotients: absolute floor 1e-5 x 256
+                worst = max(worst, abs(gy[g0 + i] - cy) / 256., abs(gx[g0 + i] - cx) / 256.)
+        elif name == 'c4':
+            dense = M.radial_bins(centerX=128, centerY=128, imageSizeX=256, imageSizeY=256,
+                                  n_bins=1024, use_sparse=False,
+                                  dtype=np.float32).reshape((1024, -1)).astype(np.float64)
+            got = res['intensity'].raw_data
+            assert got.shape == (self.nav[0] * self.nav[1], 1024)
+            for i in idx[:8]:
+                ref = dense @ self._frame(i).reshape(-1)
+                worst = max(worst, np.abs(got[g0 + i] - ref).max() / np.abs(ref).max())
+        elif name == 'c5':
+            stack = np.asarray(self.analysis.get_mask_factories()()).reshape((25, -1))
+            raw = res.raw_results.reshape((25, -1))
+            assert res.raw_results.shape == (1, 25) + self.nav
+            for i in idx[:3]:
+                ref = stack.astype(np.complex128) @ self._frame(i).reshape(-1)
+                worst = max(worst, np.abs(raw[:, g0 + i] - ref).max() / np.abs(ref).max())
+        if not worst < 1e-5:
+            raise SystemExit(f"bench.py: {name} result check failed: rel err {worst:.3e} vs "
+                             f"float64 NumPy")
+        return float(worst)
+
+
+def load_traffic(name, kname, frames_per_launch):
+    """HBM bytes per launch from the tracked PMC profile, only if it was taken for exactly this
+    config, kernel (label incl. grid) and launch size."""
+    path = os.path.join(ROOT, 'profiles', 'traffic.json')
+    try:
+        with open(path) as f:
+            entries = json.load(f)['entries']
+    except Exception:
+        return None, None
+    for e in entries:
+        if e.get('config') == name and e.get('kernel') == kname and \
+                int(e.get('frames_per_launch', -1)) == int(frames_per_launch):
+            return float(e['hbm_bytes_per_launch']), e.get('source')
+    return None, None
+
+
+def measure(wl, steps, warmup, barrier, hip, n_check=32):
+    """W untimed + K timed steps of a workload; returns whole-job and dominant-kernel figures."""
+    import re
+    cfg = wl.cfg
+    res = wl.step()
+    err = wl.check(res, n_check=n_check)
+    del res
+    for _ in range(max(0, warmup - 1)):
+        wl.step()
+    hip.KernelTimer.start()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    events = hip.KernelTimer.stop()
+    pat = re.compile(cfg['kernel'])
+    kms = [ms for ms, n, k in events if pat.search(k)]
+    kname = next((k for ms, n, k in events if pat.search(k)), '')
+    if not kms:
+        raise SystemExit(f"bench.py: no {cfg['kernel']} launch was timed for {wl.name} -- kernel "
+                         f"name filter out of date? events: {events[:3]!r}")
+    launches_per_step = max(1, len(kms) // max(1, steps))
+    frames_per_launch = wl.n_local / launches_per_step
+    avg_ms = float(np.mean(kms))
+    alg_bytes = (wl.n_px * wl.itemsize + cfg['result_bytes']) * frames_per_launch   # SURVEY.md 8(d)
+    gbs = alg_bytes / (avg_ms * 1e-3) / 1e9
+    tfs = cfg['flops'] * frames_per_launch / (avg_ms * 1e-3) / 1e12
+    traffic, traffic_src = load_traffic(wl.name, kname, frames_per_launch)
+    roof = {"bound": cfg['bound']}
+    if cfg['bound'] == 'hbm':
+        roof.update(achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS)
+    else:
+        roof.update(achieved=tfs, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                    frac=tfs / MFMA_F32_PEAK_TF, hbm_GBps=gbs, hbm_frac=gbs / HBM_PEAK_GBS)
+    roof.update(traffic=traffic, traffic_source=traffic_src, kernel=kname, avg_launch_ms=avg_ms,
+                launches_timed=len(kms), frames_per_launch=frames_per_launch,
+                algorithmic_bytes_per_launch=alg_bytes,
+                algorithmic_flops_per_launch=cfg['flops'] * frames_per_launch,
+                mfma_f32_TFLOPs=tfs)
+    return dict(elapsed=elapsed, ms_per_step=elapsed / steps * 1e3, roofline=roof,
+                kernel_ms_per_step=float(np.sum(kms)) / steps, check_rel_err=err)
+
+
+def host_streamed(ctx, torch, hip, rows=64):
+    """Timing mode (ii) of SURVEY.md 8(d): C2 frames in HOST memory (page-locked in place),
+    double-buffered hipMemcpyAsync overlapping the kernels; against the measured H2D peak."""
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    rng = np.random.default_rng(1)
+    data = rng.integers(0, 4096, (rows, 256, 256, 256), dtype=np.uint16)
+    masks = np.random.default_rng(2).random((16, 256, 256)).astype(np.float32)
+    ds = ctx.load('memory', data=data, sig_dims=2, num_partitions=1)
+    udf = ApplyMasksUDF(mask_factories=lambda: masks, use_sparse=False, mask_count=16,
+                        mask_dtype=np.float32)
+    for _ in range(2):
+        ctx.run_udf(dataset=ds, udf=udf)
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        ctx.run_udf(dataset=ds, udf=udf)
+        ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    # the link's own ceiling: one pinned 1 GiB buffer, plain hipMemcpyAsync
+    pinned = torch.empty((1 << 30,), dtype=torch.uint8, pin_memory=True)
+    dev = torch.empty((1 << 30,), dtype=torch.uint8, device='cuda')
+    dev.copy_(pinned, non_blocking=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        dev.copy_(pinned, non_blocking=True)
+    torch.cuda.synchronize()
+    peak = 4 * (1 << 30) / (time.perf_counter() - t0) / 1e9
+    gbs = data.nbytes / t / 1e9
+    return {"workload": f"C2 masks, {rows * 256} frames ({data.nbytes / 2**30:.0f} GiB) in host "
+                        f"memory, hipHostRegister + double-buffered hipMemcpyAsync",
+            "frames_per_s": rows * 256 / t, "GBps": gbs, "h2d_peak_GBps": peak,
+            "frac_of_h2d_peak": gbs / peak, "ms_per_run": t * 1e3}
 
 
 def main():
@@ -97,6 +360,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true')
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
@@ -106,11 +370,13 @@ def main():
     # test hooks (one-GPU box: several gloo ranks on one device exercise the N>1 flow end to end)
     device_id = int(os.environ.get('LTMI_BENCH_DEVICE', local_rank))
     backend = os.environ.get('LTMI_BENCH_BACKEND', 'nccl')
+    extras = not args.no_extras and os.environ.get('LTMI_BENCH_EXTRAS', '1') != '0' \
+        and args.config == 'c2'
     cpu_base = None
     if world == 1 and not args.no_cpu_baseline:
         # rank 0 at N=1 only, and BEFORE the HIP runtime is initialised (fork-safe)
         try:
-            cpu_base = cpu_baseline(cfg)
+            cpu_base = cpu_baseline(CONFIGS['c2'])
         except Exception as e:                        # the baseline must never sink the bench line
             cpu_base = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port",
                         "sample": f"failed: {e!r}"}
@@ -122,98 +388,140 @@ def main():
     torch.cuda.set_device(device_id)
     use_dist = world > 1 or os.environ.get('LTMI_FORCE_COLLECTIVES') == '1'
     if use_dist:
+        import datetime
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
+        # a rank that dies must take the job down within minutes, not hang it
+        tmo = datetime.timedelta(seconds=int(os.environ.get('LTMI_BENCH_TIMEOUT_S', '300')))
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', device_id))
+            dist.init_process_group('nccl', device_id=torch.device('cuda', device_id), timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
 
     import logging
     logging.getLogger('libertem_amd').setLevel(logging.ERROR)     # stdout carries ONE JSON line
     from libertem_amd.api import Context
-    from libertem_amd.udf.masks import ApplyMasksUDF
     from libertem_amd import hip
 
-    scan, det = cfg['scan'], cfg['det']
-    n_frames = scan[0] * scan[1]
-    n_px = det[0] * det[1]
-    itemsize = np.dtype(cfg['dtype']).itemsize
-
-    # synthetic frames generated ON the device (not timed): counts in [0, 4096), seed per rank
-    g = torch.Generator(device='cuda').manual_seed(1 + rank)
-    frames = torch.empty((n_frames, n_px), dtype=torch.int16, device='cuda')
-    chunk = 4096
-    for i in range(0, n_frames, chunk):
-        j = min(n_frames, i + chunk)
-        frames[i:j] = torch.randint(0, 4096, (j - i, n_px), generator=g, device='cuda',
-                                    dtype=torch.int32).to(torch.int16)
-    frames = frames.reshape(scan + det)
-    masks = np.random.default_rng(2).random((cfg['n_masks'],) + det).astype(np.float32)
-
     ctx = Context.make_with('hip', gpus=device_id)
-    # one global dataset of world x (scan) frames; every rank holds its own contiguous block
-    ds = ctx.load('memory', data=frames, dtype=np.dtype(cfg['dtype']), sig_dims=2,
-                  num_partitions=1, shard=(rank, world) if use_dist else None)
-    udf = ApplyMasksUDF(mask_factories=lambda: masks, use_sparse=False,
-                        mask_count=cfg['n_masks'], mask_dtype=np.float32)
-
-    def step():
-        return ctx.run_udf(dataset=ds, udf=udf)
-
-    res = step()                        # untimed: result check below (also with --warmup 0)
-    for _ in range(args.warmup - 1):
-        res = step()
-    # shape / dtype / finiteness of the full-size result (parity itself: tests/, smoke())
-    got = res['intensity'].data
-    assert got.shape == (scan[0] * world, scan[1], cfg['n_masks']) and got.dtype == np.float32
-    assert np.all(np.isfinite(got))
-    del res, got        # (multi-rank: results are views of a recycled shared host segment; a live
-    #                      one would be given a private copy when its slot comes round again)
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    hip.KernelTimer.start()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_events = hip.KernelTimer.stop()
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device='cuda')
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-    if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed_max = float(t.item())
+    def gather_list(x):
+        if not use_dist:
+            return [x]
+        out = [None] * world
+        dist.all_gather_object(out, x)
+        return out
+
+    # ---- the measured config: one global dataset of world x (scan) frames, every rank holds its
+    # ---- own contiguous block (weak scaling)
+    wl = Workload(args.config, ctx, torch, rank, world, sharded=use_dist)
+    wl.use_oracle = cpu_base is not None           # N = 1: the oracle also checks 32 result rows
+    m = measure(wl, args.steps, args.warmup, barrier, hip)
+    result_via = getattr(ctx.executor, 'last_result_via', 'local')
+    elapsed_max = max_over_ranks(m['elapsed'])
+    per_rank = gather_list({"rank": rank, "ms_per_step": m['ms_per_step'],
+                            "kernel_ms_per_step": m['kernel_ms_per_step'],
+                            "kernel_avg_launch_ms": m['roofline']['avg_launch_ms']})
+    n_frames, n_px, itemsize = wl.n_local, wl.n_px, wl.itemsize
+    total_frames = n_frames * world * args.steps
+    value = total_frames / elapsed_max
+
+    extra = {}
+
+    def guarded(key, fn):
+        """extras never sink the line; every rank takes the same path (the code below is
+        deterministic and symmetric), an exception is recorded instead of raised"""
+        try:
+            extra[key] = fn()
+        except BaseException as e:                    # noqa: BLE001  (SystemExit of a failed check too)
+            extra[key] = {"error": repr(e)[:300]}
+
+    if extras and world > 1:
+        # (a) the same steps with the nav results gathered by RCCL over xGMI (north star) instead of
+        #     the node-shared host segment
+        def rccl_path():
+            if result_via != 'shm':
+                return {"skipped": f"default delivery already is {result_via!r}"}
+            os.environ['LTMI_RESULT_VIA'] = 'rccl'
+            try:
+                k = max(3, args.steps // 2)
+                mm = measure(wl, k, 2, barrier, hip, n_check=4)
+                el = max_over_ranks(mm['elapsed'])
+                return {"result_via": getattr(ctx.executor, 'last_result_via', None),
+                        "steps": k, "ms_per_step": el / k * 1e3,
+                        "value": n_frames * world * k / el, "unit": "frames/s"}
+            finally:
+                del os.environ['LTMI_RESULT_VIA']
+        guarded('rccl_path', rccl_path)
+
+    if extras and use_dist:
+        # (b) strong scaling: C3 (CoM analysis, 512x512 scan x 512x512 uint16 = 128 GiB in total)
+        #     nav-split over the ranks; value = the FIXED 262144 frames / max-over-ranks time
+        def strong_c3():
+            c3 = CONFIGS['c3']
+            total = c3['scan'][0] * c3['scan'][1]
+            if total % (world * c3['scan'][1]) != 0:
+                return {"skipped": f"512 scan rows do not split over {world} ranks"}
+            w3 = Workload('c3', ctx, torch, rank, world, sharded=True,
+                          frames_per_rank=total // world)
+            k = 5
+            mm = measure(w3, k, 2, barrier, hip, n_check=4)
+            el = max_over_ranks(mm['elapsed'])
+            return {"workload": c3['desc'] + f", nav-split over {world} GPU(s)",
+                    "scaling": "strong", "frames_total": total, "steps": k,
+                    "ms_per_step": el / k * 1e3, "value": total * k / el, "unit": "frames/s",
+                    "input_GBps": total * k / el * 512 * 512 * 2 / 1e9,
+                    "result_via": getattr(ctx.executor, 'last_result_via', None),
+                    "kernel_avg_launch_ms_rank0": mm['roofline']['avg_launch_ms']}
+        del wl
+        torch.cuda.empty_cache()
+        guarded('strong_c3', strong_c3)
+    elif extras:
+        del wl
+        torch.cuda.empty_cache()
+
+    if extras and world == 1 and not use_dist:
+        # (c) the other BASELINE.json configs, whole job + dominant kernel, device-resident
+        def one_config(name):
+            def run():
+                w = Workload(name, ctx, torch, 0, 1, sharded=False)
+                k = 5
+                mm = measure(w, k, 2, barrier, hip, n_check=8)
+                fps = w.n_local * k / mm['elapsed']
+                return {"workload": CONFIGS[name]['desc'], "steps": k,
+                        "ms_per_step": mm['ms_per_step'], "value": fps, "unit": "frames/s",
+                        "input_GBps_whole_job": fps * w.n_px * w.itemsize / 1e9,
+                        "kernel_ms_per_step": mm['kernel_ms_per_step'],
+                        "check_rel_err_vs_float64": mm['check_rel_err'],
+                        "roofline": mm['roofline']}
+            return run
+        cfgs = {}
+        for name in ('c3', 'c4', 'c5'):
+            try:
+                cfgs[name] = one_config(name)()
+            except BaseException as e:                # noqa: BLE001
+                cfgs[name] = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
+        extra['configs'] = cfgs
+        guarded('host_streamed', lambda: host_streamed(ctx, torch, hip))
 
     if rank == 0:
-        total_frames = n_frames * world * args.steps
-        value = total_frames / elapsed_max
-        kms = [ms for ms, n, k in kernel_events if 'k_dense' in k]
-        kname = next((k for ms, n, k in kernel_events if 'k_dense' in k), '')
-        alg_bytes_per_frame = n_px * itemsize + cfg['n_masks'] * 4
-        launches_per_step = max(1, len(kms) // max(1, args.steps))
-        frames_per_launch = n_frames / launches_per_step
-        if not kms:
-            raise SystemExit("bench.py: no ltmi_apply_masks launch was timed -- kernel name filter "
-                             "out of date? events: %r" % (kernel_events[:3],))
-        avg_ms = float(np.mean(kms))
-        achieved = alg_bytes_per_frame * frames_per_launch / (avg_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC passes (FETCH_SIZE x 1024 x 2 [gfx950 read correction]
-        # + WRITE_SIZE x 1024); cannot be collected from inside the timed process, so the
-        # committed profile of exactly this kernel and shape is quoted, scaled by the frame count.
-        traffic, traffic_src = None, None
-        if 'k_dense_lds' in kname and args.config == 'c2':
-            traffic = (4.3522e9 + 2.1e6) * frames_per_launch / 32768.0
-            traffic_src = "profiles/r01_final_bench_rocprof.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
         out = {
-            "metric": "frames/sec, ApplyMasksUDF 16 dense f32 masks (+ GB/s vs HBM roofline)",
+            "metric": "frames/sec, ApplyMasksUDF 16 dense f32 masks (+ GB/s vs HBM roofline)"
+                      if args.config.startswith('c2') else f"frames/sec, {cfg['desc']}",
             "value": value,
             "unit": "frames/s",
             "n_gpus": world,
@@ -224,24 +532,25 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (device-generated uint16 counts in [0,4096), resident in HBM)",
+            "data": "synthetic (device-generated, resident in HBM: uint16 counts in [0,4096) / "
+                    "float32 in [0,1))",
             "config": {
                 "workload": cfg['desc'] + f", per GPU; {world} GPU(s), nav-sharded (weak)",
                 "frames_per_gpu": n_frames, "frame_bytes": n_px * itemsize,
-                "arithmetic": "uint16 frames converted to f32 in-kernel, exact f32 FMA chain on the "
-                              "matrix cores (v_mfma_f32_16x16x4_f32), f32 masks and results",
-                "step": "Context.run_udf (plan + kernel + device merge + gather + D2H)",
-                "parallelism": f"nav-shard x{world}" + (" + RCCL all-gather" if world > 1 else ""),
+                "arithmetic": "frames converted to f32 in-kernel, exact f32 FMA chain on the "
+                              "matrix cores (v_mfma_f32_16x16x4_f32), f32 / complex64 masks and "
+                              "results",
+                "step": "Context.run_udf / Context.run (plan + kernels + delivery of the complete "
+                        "result to every rank's host)",
+                "parallelism": f"nav-shard x{world}; results via {result_via}",
             },
             "input_GBps_whole_job": value * n_px * itemsize / 1e9,
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": traffic_src,
-                "kernel": kname, "avg_launch_ms": avg_ms, "launches_timed": len(kms),
-                "algorithmic_bytes_per_launch": alg_bytes_per_frame * frames_per_launch,
-            },
+            "result_check_rel_err_vs_float64": m['check_rel_err'],
+            "roofline": m['roofline'],
+            "result_via": result_via,
+            "per_rank": per_rank,
         }
+        out.update(extra)
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         print(json.dumps(out), flush=True)

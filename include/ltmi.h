@@ -132,8 +132,22 @@ int ltmi_sum_frames(int device, const void *tile, int tile_dtype, int64_t n_fram
 int ltmi_sum_sig(int device, const void *tile, int tile_dtype, int64_t n_frames, int64_t n_px,
                  int64_t ld_tile, void *out, int out_dtype, int accumulate, void *stream);
 
-/* merge for sig-kind buffers: dest[i] += src[i]          (src/libertem/udf/sum.py:50-52) */
+/* merge for sig-kind buffers: dest[i] += src[i]          (src/libertem/udf/sum.py:50-52);
+ * every dtype of enum ltmi_dtype, integers wrap around like NumPy's `+=` */
 int ltmi_axpy(int device, void *dest, const void *src, int dtype, int64_t n, void *stream);
+/* dest[r, c] (+|-)= src[r, c] for r < rows, c < cols; leading dimensions in ELEMENTS; ld_src == 0
+ * broadcasts one row.  Replaces the NumPy in-place arithmetic around the kernels:
+ *   `results.intensity[sig slice] += partial`  of a partial-width sig slice (src/libertem/udf/sum.py:43-48),
+ *   the per-mask dark-frame constant of folded corrections (negate = 1, ld_src = 0;
+ *   src/libertem/io/corrections/detector.py:315-338),
+ *   `dest.intensity[:] += src.intensity`  (src/libertem/udf/sum.py:50-52). */
+int ltmi_add2d(int device, void *dest, int64_t ld_dest, const void *src, int64_t ld_src, int dtype,
+               int64_t rows, int64_t cols, int negate, void *stream);
+/* dest[i, :] = src[idx[i], :]  -- the frames an ROI selects, gathered inside HBM (the reference
+ * reads them frame by frame on the host, src/libertem/io/dataset/memory.py:107-131).
+ * idx: DEVICE int64 (n_rows,); rows of row_bytes bytes, ld_src_bytes between source rows. */
+int ltmi_gather_rows(int device, const void *src, int64_t ld_src_bytes, const int64_t *idx,
+                     int64_t n_rows, int64_t row_bytes, void *dest, void *stream);
 
 /* ---- detector corrections -------------------------------------------------------------------
  * Replaces CorrectionSet.apply -> detector.correct on a tile (src/libertem/io/corrections/

@@ -222,7 +222,7 @@ class Context:
         """Apply `f` to every frame; result is kind='nav' (reference api.py:1617-1670)."""
         from libertem_amd.udf.auto import AutoUDF
         return self.run_udf(dataset=dataset, udf=AutoUDF(f=f), roi=roi, progress=progress,
-                            backends=backends)
+                            corrections=corrections, backends=backends)
 
     def close(self):
         self.executor.close()

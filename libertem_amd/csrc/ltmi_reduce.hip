@@ -115,10 +115,31 @@ __global__ void k_reduce_splits(const A *__restrict__ ws, int fsplit, int64_t n,
     out[i] = s;
 }
 
+// dest[r * ld_dest + c] += sign * src[r * ld_src + c]; ld_src == 0 broadcasts one row of `src`
 template <typename A>
-__global__ void k_axpy(A *__restrict__ dest, const A *__restrict__ src, int64_t n) {
+__global__ void k_add2d(A *__restrict__ dest, int64_t ld_dest, const A *__restrict__ src,
+                        int64_t ld_src, int64_t rows, int64_t cols, int negate) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dest[i] += src[i];
+    if (i >= rows * cols) return;
+    const int64_t r = i / cols, c = i - r * cols;
+    const A v = src[r * ld_src + c];
+    A &d = dest[r * ld_dest + c];
+    d = negate ? (A)(d - v) : (A)(d + v);
+}
+
+typedef unsigned int gu32x4 __attribute__((ext_vector_type(4)));
+
+// dest[i, :] = src[idx[i], :], rows of `row_bytes` bytes (a multiple of sizeof(V))
+template <typename V>
+__global__ void __launch_bounds__(256)
+k_gather_rows(const V *__restrict__ src, int64_t ld_src_v, const int64_t *__restrict__ idx,
+              V *__restrict__ dest, int64_t row_v) {
+    const int64_t r = blockIdx.y;
+    const V *s = src + idx[r] * ld_src_v;
+    V *d = dest + r * row_v;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_v;
+         i += (int64_t)gridDim.x * blockDim.x)
+        d[i] = __builtin_nontemporal_load(s + i);
 }
 
 static int frames_split(int64_t n_frames, int64_t n_px) {
@@ -506,22 +527,87 @@ extern "C" int ltmi_com_fields(int device, const float *raw, int64_t ld_raw, int
     return LTMI_OK;
 }
 
+template <typename A>
+static void launch_add2d(void *dest, int64_t ld_dest, const void *src, int64_t ld_src, int64_t rows,
+                         int64_t cols, int negate, hipStream_t stream) {
+    dim3 grid((unsigned)((rows * cols + 255) / 256));
+    hipLaunchKernelGGL((k_add2d<A>), grid, dim3(256), 0, stream, (A *)dest, ld_dest, (const A *)src,
+                       ld_src, rows, cols, negate);
+}
+
+extern "C" int ltmi_add2d(int device, void *dest, int64_t ld_dest, const void *src, int64_t ld_src,
+                          int dtype, int64_t rows, int64_t cols, int negate, void *stream_) {
+    if (rows < 0 || cols < 0 || ld_dest < 0 || ld_src < 0)
+        LTMI_FAIL(LTMI_E_SHAPE, "ltmi_add2d: negative size");
+    if (rows == 0 || cols == 0) return LTMI_OK;
+    if (!dest || !src) LTMI_FAIL(LTMI_E_INVALID, "ltmi_add2d: null pointer");
+    if (rows * cols > ((int64_t)1 << 39)) LTMI_FAIL(LTMI_E_SHAPE, "ltmi_add2d: too many elements");
+    LTMI_HIP(hipSetDevice(device));
+    hipStream_t stream = (hipStream_t)stream_;
+    switch (dtype) {                    // integers wrap around like NumPy's `+=`
+        case LTMI_BOOL: case LTMI_U8: case LTMI_I8:
+            launch_add2d<uint8_t>(dest, ld_dest, src, ld_src, rows, cols, negate, stream); break;
+        case LTMI_U16: case LTMI_I16:
+            launch_add2d<uint16_t>(dest, ld_dest, src, ld_src, rows, cols, negate, stream); break;
+        case LTMI_U32: case LTMI_I32:
+            launch_add2d<uint32_t>(dest, ld_dest, src, ld_src, rows, cols, negate, stream); break;
+        case LTMI_U64: case LTMI_I64:
+            launch_add2d<uint64_t>(dest, ld_dest, src, ld_src, rows, cols, negate, stream); break;
+        case LTMI_F32:
+            launch_add2d<float>(dest, ld_dest, src, ld_src, rows, cols, negate, stream); break;
+        case LTMI_F64:
+            launch_add2d<double>(dest, ld_dest, src, ld_src, rows, cols, negate, stream); break;
+        case LTMI_C64:                  // complex = pairs of reals
+            launch_add2d<float>(dest, 2 * ld_dest, src, 2 * ld_src, rows, 2 * cols, negate, stream);
+            break;
+        case LTMI_C128:
+            launch_add2d<double>(dest, 2 * ld_dest, src, 2 * ld_src, rows, 2 * cols, negate, stream);
+            break;
+        default:
+            LTMI_FAIL(LTMI_E_DTYPE, "ltmi_add2d: unsupported dtype %d", dtype);
+    }
+    LTMI_HIP(hipGetLastError());
+    return LTMI_OK;
+}
+
 extern "C" int ltmi_axpy(int device, void *dest, const void *src, int dtype, int64_t n,
                          void *stream_) {
     if (n < 0) LTMI_FAIL(LTMI_E_SHAPE, "ltmi_axpy: negative size");
-    if (n == 0) return LTMI_OK;
-    if (!dest || !src) LTMI_FAIL(LTMI_E_INVALID, "ltmi_axpy: null pointer");
+    return ltmi_add2d(device, dest, n, src, n, dtype, 1, n, 0, stream_);
+}
+
+extern "C" int ltmi_gather_rows(int device, const void *src, int64_t ld_src_bytes,
+                                const int64_t *idx, int64_t n_rows, int64_t row_bytes, void *dest,
+                                void *stream_) {
+    if (n_rows < 0 || row_bytes < 0 || ld_src_bytes < row_bytes)
+        LTMI_FAIL(LTMI_E_SHAPE, "ltmi_gather_rows: bad sizes");
+    if (n_rows == 0 || row_bytes == 0) return LTMI_OK;
+    if (!src || !idx || !dest) LTMI_FAIL(LTMI_E_INVALID, "ltmi_gather_rows: null pointer");
+    if (n_rows > 65535 * (int64_t)65535) LTMI_FAIL(LTMI_E_SHAPE, "ltmi_gather_rows: too many rows");
     LTMI_HIP(hipSetDevice(device));
     hipStream_t stream = (hipStream_t)stream_;
-    dim3 grid((unsigned)((n + 255) / 256));
-    if (dtype == LTMI_F32)
-        hipLaunchKernelGGL((k_axpy<float>), grid, dim3(256), 0, stream, (float *)dest,
-                           (const float *)src, n);
-    else if (dtype == LTMI_F64)
-        hipLaunchKernelGGL((k_axpy<double>), grid, dim3(256), 0, stream, (double *)dest,
-                           (const double *)src, n);
-    else
-        LTMI_FAIL(LTMI_E_DTYPE, "ltmi_axpy: unsupported dtype %s", dtype_name(dtype));
+    const uintptr_t al = (uintptr_t)src | (uintptr_t)dest | (uintptr_t)ld_src_bytes |
+                         (uintptr_t)row_bytes;
+    // the grid's y extent is limited to 65535: walk the rows in slabs
+    for (int64_t r0 = 0; r0 < n_rows; r0 += 65535) {
+        const int64_t nr = std::min<int64_t>(65535, n_rows - r0);
+        char *d = (char *)dest + r0 * row_bytes;
+        if ((al & 15) == 0) {
+            const int64_t rv = row_bytes / 16;
+            dim3 grid((unsigned)std::min<int64_t>((rv + 255) / 256, 64), (unsigned)nr);
+            hipLaunchKernelGGL((k_gather_rows<gu32x4>), grid, dim3(256), 0, stream,
+                               (const gu32x4 *)src, ld_src_bytes / 16, idx + r0, (gu32x4 *)d, rv);
+        } else if ((al & 3) == 0) {
+            const int64_t rv = row_bytes / 4;
+            dim3 grid((unsigned)std::min<int64_t>((rv + 255) / 256, 64), (unsigned)nr);
+            hipLaunchKernelGGL((k_gather_rows<uint32_t>), grid, dim3(256), 0, stream,
+                               (const uint32_t *)src, ld_src_bytes / 4, idx + r0, (uint32_t *)d, rv);
+        } else {
+            dim3 grid((unsigned)std::min<int64_t>((row_bytes + 255) / 256, 64), (unsigned)nr);
+            hipLaunchKernelGGL((k_gather_rows<uint8_t>), grid, dim3(256), 0, stream,
+                               (const uint8_t *)src, ld_src_bytes, idx + r0, (uint8_t *)d, row_bytes);
+        }
+    }
     LTMI_HIP(hipGetLastError());
     return LTMI_OK;
 }

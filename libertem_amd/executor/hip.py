@@ -144,14 +144,37 @@ class HipJobExecutor(JobExecutor):
         d = self._dist()
         return d.get_world_size() if d else 1
 
-    def my_tasks(self, tasks):
-        """Contiguous block of the task list for this rank (nav sharding)."""
-        W, r = self.world_size, self.rank
+    def task_owners(self, tasks):
+        """rank of every task, the same list on every rank.  Sharded datasets: the rank that HOLDS
+        the partition's frames (an ROI may remove whole partitions of one shard, so the position in
+        the filtered task list says nothing).  Replicated data: contiguous blocks of the task list,
+        the np.linspace nav sharding of the reference's partitioning."""
+        W = self.world_size
         if W == 1:
+            return [0] * len(tasks)
+        owners = []
+        for t in tasks:
+            ds = getattr(t.partition, '_ds', None)
+            own = getattr(ds, 'owner_of_frames', None)
+            sl = t.partition.slice
+            r = own(sl.origin[0], sl.origin[0] + sl.shape[0]) if own is not None else None
+            owners.append(r)
+        if all(r is None for r in owners):
+            P = len(tasks)
+            b = np.linspace(0, P, W + 1, dtype=int)
+            owners = [0] * P
+            for r in range(W):
+                owners[b[r]:b[r + 1]] = [r] * int(b[r + 1] - b[r])
+        elif any(r is None for r in owners):
+            raise RuntimeError("tasks of sharded and replicated datasets in one run")
+        return owners
+
+    def my_tasks(self, tasks):
+        """The tasks this rank runs (nav sharding)."""
+        if self.world_size == 1:
             return tasks
-        P = len(tasks)
-        b = np.linspace(0, P, W + 1, dtype=int)
-        return tasks[b[r]:b[r + 1]]
+        r = self.rank
+        return [t for t, o in zip(tasks, self.task_owners(tasks)) if o == r]
 
     # --- executor protocol -----------------------------------------------------------------------------
     def get_local_env(self):
@@ -231,6 +254,7 @@ class HipJobExecutor(JobExecutor):
         shared_np = {}
         shared = self._node_shared() if not partial else None
         shared_slot = None
+        busy_shared = None
         self._row_sink = None
         if shared is not None:
             layout, total = [], 0
@@ -245,9 +269,13 @@ class HipJobExecutor(JobExecutor):
                     layout.append((i, name, tuple(buf.shape), np.dtype(buf.dtype), total, nb))
                     total += (nb + 4095) // 4096 * 4096
             if layout:
-                from .nodeshared import NodeSharedUnavailable
+                from .nodeshared import NodeSharedUnavailable, NodeSharedBusy
                 try:
                     shared_slot, tens, arr = shared.begin_run(total)
+                except NodeSharedBusy:
+                    # this run only: device collectives (the end-of-run barrier still runs, it
+                    # refreshes the set of free slots)
+                    busy_shared, shared, layout = shared, None, []
                 except NodeSharedUnavailable as e:
                     self._shared_off = True
                     import logging
@@ -256,17 +284,34 @@ class HipJobExecutor(JobExecutor):
                 for i, name, shape, dt, off, nb in layout:
                     tdt = torch_dtype_for(dt)
                     streamed[(i, name)] = [tens[off:off + nb].view(tdt).reshape(shape), 0]
-                    shared_np[(i, name)] = arr[off:off + nb].view(
+                    # views of the run's owner object: they keep the slot reserved, on every rank,
+                    # for as long as the caller references any of them (executor/nodeshared.py)
+                    shared_np[(i, name)] = arr[off:off + nb].view(np.ndarray).view(
                         np.dtype(str(tdt).replace('torch.', ''))).reshape(shape)
                     expected[(i, name)] = 0
+                del arr
             else:
                 shared = None
-        if self.gpu_id is not None and not partial and \
-                (shared is not None or not self._collectives_on):
+        self.last_result_via = 'shm' if shared is not None else \
+            ('collective' if self._collectives_on else 'local')
+        sink_on = self.gpu_id is not None and not partial and \
+            (shared is not None or not self._collectives_on)
+        keepalive = []                          # device rows with a D2H in flight on the copy stream
+        if sink_on:
             import torch as _torch
             if getattr(self, '_copy_stream', None) is None:
                 self._copy_stream = _torch.cuda.Stream(device=self.gpu_id)
             copy_stream = self._copy_stream
+            if shared is None:
+                # single rank: every 'disjoint' device buffer may be streamed; what the sink does
+                # not deliver is built from the partition results kept aside (`deferred`)
+                for i, (udf, (mode, decl)) in enumerate(zip(udfs, plans)):
+                    if mode != 'device':
+                        continue
+                    for name, how in decl.items():
+                        buf = udf.results.get_buffer(name)
+                        if how == 'disjoint' and not isinstance(buf, PlaceholderBufferWrapper):
+                            expected[(i, name)] = 0
 
             def row_sink(i, name, rows, g0):
                 mode, decl = plans[i]
@@ -274,22 +319,24 @@ class HipJobExecutor(JobExecutor):
                 if mode != 'device' or decl.get(name) != 'disjoint' or rows.shape[0] == 0:
                     return
                 key = (i, name)
+                if key not in expected or not rows.is_contiguous:
+                    return
                 if key not in streamed:
-                    if shared is not None:
-                        return
                     streamed[key] = [_torch.empty(buf.shape, dtype=torch_dtype_for(buf.dtype),
                                                   pin_memory=True), 0]
                 host, _ = streamed[key]
                 n = rows.shape[0]
                 inner = int(np.prod(buf.shape[1:])) if len(buf.shape) > 1 else 1
-                if not rows.is_contiguous:
-                    return
                 src = rows.torch.reshape(-1)[:n * inner].reshape((n,) + tuple(buf.shape[1:]))
                 ev = _torch.cuda.Event()
                 ev.record(self._stream)
                 with _torch.cuda.stream(copy_stream):
                     copy_stream.wait_event(ev)
                     host[g0:g0 + n].copy_(src, non_blocking=True)
+                # the source block was allocated on the executor stream: keep it referenced until
+                # the copy stream has been synchronised, or the caching allocator may hand it to the
+                # next partition while the D2H still reads it
+                keepalive.append(src)
                 streamed[key][1] += n
             self._row_sink = row_sink
 
@@ -304,12 +351,17 @@ class HipJobExecutor(JobExecutor):
         def publish_device(final):
             """declared device buffers -> host arrays of the main-process udfs"""
             shared_ok = False
-            if shared is not None and final:
-                # my rows are out once the copy stream is idle; then every rank of the node says
-                # whether all of ITS rows went through the sink (same answer on every rank)
+            if sink_on and final:
+                # my rows are out once the copy stream is idle
                 self._copy_stream.synchronize()
+                keepalive.clear()
+            if shared is not None and final:
+                # every rank of the node says whether all of ITS rows went through the sink
+                # (same answer on every rank)
                 mine = all(streamed[k][1] == expected[k] for k in expected)
                 shared_ok = shared.all_ok(mine)
+            elif busy_shared is not None and final:
+                busy_shared.all_ok(True)
             for i, (udf, (mode, decl)) in enumerate(zip(udfs, plans)):
                 if mode != 'device':
                     continue
@@ -324,18 +376,18 @@ class HipJobExecutor(JobExecutor):
                             if host.dtype != buf.dtype:
                                 host = host.view(buf.dtype)
                             buf.replace_array(host)
-                            shared.occupy(shared_slot, buf)
                             continue
                         st = None                      # fall back to the device collectives
-                        self._flush_deferred(udf, i, name, dev_full[i], deferred)
-                    if st is not None and final and st[1] == buf.shape[0]:
+                    elif st is not None and final and st[1] == buf.shape[0] \
+                            and st[1] == expected.get((i, name)):
                         # every row already went out through the copy stream
-                        self._copy_stream.synchronize()
                         host = st[0].numpy()
                         if host.dtype != buf.dtype:
                             host = host.view(buf.dtype)
                         buf.replace_array(host)
+                        deferred.pop((i, name), None)
                         continue
+                    self._flush_deferred(udf, i, name, dev_full[i], deferred, keep=not final)
                     full = dev_full[i].get(name)
                     self._make_current()
                     if full is None:
@@ -348,6 +400,7 @@ class HipJobExecutor(JobExecutor):
                     if host.dtype != buf.dtype:
                         host = host.view(buf.dtype)
                     buf.replace_array(host)
+            shared_np.clear()
 
         n_done = 0
         for part_results, task in result_iter:
@@ -356,8 +409,7 @@ class HipJobExecutor(JobExecutor):
                 if mode == 'device':
                     self._merge_on_device(udf, results, task, decl, dev_full[i],
                                           may_adopt=not partial,
-                                          defer=(deferred, i, expected) if shared is not None
-                                          else None)
+                                          defer=(deferred, i, expected) if sink_on else None)
                 else:
                     results.export()
                     gen_entry[i] = results
@@ -440,54 +492,64 @@ class HipJobExecutor(JobExecutor):
         udf.merge(dest=udf.results.get_proxy(), src=results.get_proxy())
         udf.clear_views()
 
-    def _flush_deferred(self, udf, i, name, full, deferred):
-        """shared-memory delivery was not possible for this run: build the full-size device
-        buffer from the partition results kept aside, for the collectives"""
+    def _flush_deferred(self, udf, i, name, full, deferred, keep=False):
+        """Rows that were (or could have been) streamed to the host were not merged on the device;
+        if the streamed delivery did not cover the buffer, build the full-size device buffer from
+        the partition results kept aside."""
         import torch
-        items = deferred.pop((i, name), None)
-        if items is None:
+        items = deferred.get((i, name)) if keep else deferred.pop((i, name), None)
+        if not items:
             return
         buf_main = udf.results.get_buffer(name)
         self._make_current()
-        full[name] = torch.zeros(buf_main.shape, dtype=torch_dtype_for(buf_main.dtype),
-                                 device=f'cuda:{self.gpu_id}')
+        if name not in full:
+            full[name] = torch.zeros(buf_main.shape, dtype=torch_dtype_for(buf_main.dtype),
+                                     device=f'cuda:{self.gpu_id}')
         for start, stop, pt in items:
             full[name][start:stop].copy_(pt.reshape(full[name][start:stop].shape))
 
     def _merge_on_device(self, udf, results, task, decl, full, may_adopt=True, defer=None):
         import torch
+        from libertem_amd import hip
         self._make_current()
-        if True:
-            for name, how in decl.items():
-                buf_main = udf.results.get_buffer(name)
-                if isinstance(buf_main, PlaceholderBufferWrapper):
+        for name, how in decl.items():
+            buf_main = udf.results.get_buffer(name)
+            if isinstance(buf_main, PlaceholderBufferWrapper):
+                continue
+            part = results.get_buffer(name)._data
+            if not isinstance(part, HipArray):
+                part = HipArray.from_numpy(np.asarray(part), self.gpu_id)
+            pt = part.torch.reshape(part.shape)
+            if defer is not None and how == 'disjoint' and (defer[1], name) in defer[2]:
+                # rows travel to the host on the copy stream (shared host segment / pinned
+                # buffer); keep the partition result only as the fallback source
+                start, stop = buf_main._slice_for_partition(task.partition)
+                defer[0].setdefault((defer[1], name), []).append((start, stop, pt))
+                defer[2][(defer[1], name)] += stop - start
+                continue
+            if name not in full:
+                if may_adopt and tuple(part.shape) == tuple(buf_main.shape) and \
+                        (how == 'disjoint' or how == 'sum'):
+                    # first partition covers the whole buffer (always true for 'sum' buffers):
+                    # adopt it, no zero-fill, no copy / add
+                    full[name] = pt
                     continue
-                part = results.get_buffer(name)._data
-                if not isinstance(part, HipArray):
-                    part = HipArray.from_numpy(np.asarray(part), self.gpu_id)
-                pt = part.torch.reshape(part.shape)
-                if defer is not None and how == 'disjoint' and (defer[1], name) in defer[2]:
-                    # rows travel through the shared host segment; keep the partition result only
-                    # as the fallback source
-                    start, stop = buf_main._slice_for_partition(task.partition)
-                    defer[0].setdefault((defer[1], name), []).append((start, stop, pt))
-                    defer[2][(defer[1], name)] += stop - start
-                    continue
-                if name not in full:
-                    if may_adopt and how == 'disjoint' and \
-                            tuple(part.shape) == tuple(buf_main.shape):
-                        # one partition covers the whole buffer: adopt it, no zero-fill, no copy
-                        full[name] = pt
-                        continue
-                    full[name] = torch.zeros(buf_main.shape, dtype=torch_dtype_for(buf_main.dtype),
-                                             device=f'cuda:{self.gpu_id}')
-                if how == 'disjoint':
-                    start, stop = buf_main._slice_for_partition(task.partition)
-                    full[name][start:stop].copy_(pt.reshape(full[name][start:stop].shape))
-                elif how == 'sum':
-                    full[name] += pt.reshape(full[name].shape)
+                full[name] = torch.zeros(buf_main.shape, dtype=torch_dtype_for(buf_main.dtype),
+                                         device=f'cuda:{self.gpu_id}')
+            if how == 'disjoint':
+                start, stop = buf_main._slice_for_partition(task.partition)
+                full[name][start:stop].copy_(pt.reshape(full[name][start:stop].shape))
+            elif how == 'sum':
+                dst = full[name]
+                if np.dtype(buf_main.dtype) in hip.AXPY_DTYPES and dst.is_contiguous() \
+                        and pt.is_contiguous():
+                    # dest += src in HBM with the library's own kernel (ltmi_axpy)
+                    hip.axpy(self.gpu_id, dst.data_ptr(), pt.data_ptr(), buf_main.dtype,
+                             dst.numel(), stream=self._stream_ptr)
                 else:
-                    raise ValueError(f"unknown dist merge {how!r} for buffer {name!r}")
+                    dst += pt.reshape(dst.shape)
+            else:
+                raise ValueError(f"unknown dist merge {how!r} for buffer {name!r}")
 
     def _combine(self, d, full, how):
         """all ranks: disjoint -> every rank's rows are zero outside its own partitions, so a SUM
@@ -518,10 +580,9 @@ class HipJobExecutor(JobExecutor):
         if n_rows != sum(t.partition.slice.shape[0] for t in tasks):
             return False                 # ROI-compressed buffer or skipped partitions
         rows = n_rows // W
-        P = len(tasks)
-        b = np.linspace(0, P, W + 1, dtype=int)
+        owners = self.task_owners(tasks)
         for r in range(W):
-            mine = tasks[b[r]:b[r + 1]]
+            mine = [t for t, o in zip(tasks, owners) if o == r]
             if not mine:
                 return False
             start = mine[0].partition.slice.origin[0]

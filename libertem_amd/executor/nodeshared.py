@@ -9,11 +9,16 @@ rows straight into a page-locked host segment that all ranks of the node map (`/
 in parallel, each byte once; a flag barrier in the same segment publishes completion.  The buffers
 the caller gets are views of that segment.
 
-Segments are a ring of `LTMI_SHM_SLOTS` (default 4) slots per executor, reused run after run (mapping
-and page-locking a fresh segment costs milliseconds).  Before a slot is reused, result buffers of
-the run that used it last and that are still alive are given a private copy -- arrays obtained
-through `BufferWrapper.data` stay valid; a raw ndarray reference taken out of one is only good for
-LTMI_SHM_SLOTS - 1 further runs (documented in DESIGN.md section 5).
+Lifetime: the arrays handed to the caller behave like caller-owned arrays -- they stay valid for as
+long as ANY view of them is referenced, on every rank.  Segments form a ring of slots (4 to begin
+with, `LTMI_SHM_SLOTS`; mapping and page-locking a fresh one costs milliseconds, so they are reused).
+Every run hands out its results as views of a per-run owner object (`_Owner`, an ndarray subclass:
+NumPy's base-collapsing stops at it, so every derived view keeps it alive, and it can be weakly
+referenced).  A slot is written again only after its owner has died on EVERY rank: each rank
+publishes the set of slots whose owner is dead in the end-of-run barrier, the AND of those sets is
+the set the next run may choose from -- the same choice on every rank, and no rank can start writing
+into memory another rank's caller still looks at.  If all slots are held the ring grows (up to
+`LTMI_SHM_MAX_SLOTS`, 16); beyond that a run delivers through the device collectives instead.
 """
 import atexit
 import mmap
@@ -32,6 +37,17 @@ def _round_up(n, m):
     return (n + m - 1) // m * m
 
 
+class NodeSharedBusy(RuntimeError):
+    """every slot of the ring is still referenced by earlier results (same answer on every rank):
+    this run has to deliver through the device collectives."""
+
+
+class _Owner(np.ndarray):
+    """The array all result views of ONE run derive from.  A subclass so that (a) NumPy does not
+    collapse `view.base` past it -- a view of a view of ... keeps it alive -- and (b) it can be
+    weakly referenced: `weakref(owner)` dead <=> nobody in this process can see the slot."""
+
+
 class NodeShared:
     CTRL_BYTES = 4096
 
@@ -40,9 +56,10 @@ class NodeShared:
         self.rank, self.W = dist.get_rank(), dist.get_world_size()
         self.key = f"ltmi_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}"
         self.K = max(2, int(os.environ.get('LTMI_SHM_SLOTS', '4')))
+        self.K_max = max(self.K, min(60, int(os.environ.get('LTMI_SHM_MAX_SLOTS', '16'))))
         self.slots = [None] * self.K           # dict(path, mm, np, tensor, cap)
-        self.occupants = [[] for _ in range(self.K)]
-        self.seq = 0
+        self.owners = [None] * self.K          # weakref to the _Owner of the run that used the slot
+        self.common_free = (1 << self.K) - 1   # slots that were free on EVERY rank at the last barrier
         self.gen = 0
         self.epoch = 0
         self._closed = False
@@ -111,44 +128,50 @@ class NodeShared:
         # the mapping itself stays alive as long as result views reference it (np.frombuffer)
 
     # --- per run -----------------------------------------------------------------------------------
+    def _local_free(self):
+        m = 0
+        for k in range(len(self.slots)):
+            ref = self.owners[k]
+            if ref is None or ref() is None:
+                m |= 1 << k
+        return m
+
     def begin_run(self, nbytes):
-        """Collective.  Returns (slot index, uint8 torch tensor over the slot, numpy view)."""
-        s = self.seq % self.K
-        self.seq += 1
-        # results of the run that used this slot last: hand out private copies before overwriting
-        for ref in self.occupants[s]:
-            bw = ref()
-            if bw is not None:
-                bw.replace_array(np.array(bw.raw_data, copy=True))
-        self.occupants[s] = []
+        """Collective (every rank takes the same decisions: they only depend on `common_free`, the
+        slot sizes and `nbytes`, which are the same everywhere).  Returns (slot index, uint8 torch
+        tensor over the slot, numpy `_Owner` view of it); raises NodeSharedBusy if no slot is free."""
+        free = [k for k in range(len(self.slots)) if self.common_free >> k & 1]
+        if not free:
+            if len(self.slots) >= self.K_max:
+                raise NodeSharedBusy(
+                    f"all {len(self.slots)} shared result slots are still referenced")
+            self.slots.append(None)
+            self.owners.append(None)
+            free = [len(self.slots) - 1]
+        s = free[0]
         if self.slots[s] is None or self.slots[s]['cap'] < nbytes:
-            # (re)create ALL slots of the ring at the new size now: mapping + page-locking costs
-            # milliseconds, better in one (warm-up) run than spread over the next K
+            # (re)create all free slots at the new size now: mapping + page-locking costs
+            # milliseconds, better in one (warm-up) run than spread over the next ones
             cap = _round_up(max(nbytes, 1 << 21), 1 << 21)
             self.gen += 1
-            for k in range(self.K):
+            for k in free:
                 if self.slots[k] is None or self.slots[k]['cap'] < cap:
-                    if k != s:
-                        for ref in self.occupants[k]:
-                            bw = ref()
-                            if bw is not None:
-                                bw.replace_array(np.array(bw.raw_data, copy=True))
-                        self.occupants[k] = []
                     self._unmap(self.slots[k])
                     self.slots[k] = self._map(f"{self.key}_s{k}_g{self.gen}", cap)
         seg = self.slots[s]
-        return s, seg['tensor'], seg['np']
-
-    def occupy(self, slot, buffer_wrapper):
-        self.occupants[slot].append(weakref.ref(buffer_wrapper))
+        owner = seg['np'].view(_Owner)
+        self.owners[s] = weakref.ref(owner)
+        self.common_free &= ~(1 << s)
+        return s, seg['tensor'], owner
 
     def all_ok(self, ok, timeout=120.0):
-        """Barrier over the node's ranks that also ANDs a flag.  The flag banks alternate with the
-        epoch parity: a rank can be at most one epoch ahead of the slowest one."""
+        """Barrier over the node's ranks that ANDs a flag -- and the sets of slots that nobody
+        references any more (-> `common_free` for the next run).  The banks alternate with the epoch
+        parity: a rank can be at most one epoch ahead of the slowest one."""
         self.epoch += 1
         W, c = self.W, self.ctrl
         bank = W * (1 + (self.epoch & 1))
-        c[bank + self.rank] = 1 if ok else 0
+        c[bank + self.rank] = (self._local_free() << 1) | (1 if ok else 0)
         c[self.rank] = self.epoch
         t0 = time.perf_counter()
         spins = 0
@@ -162,7 +185,9 @@ class NodeShared:
                         f"rank {self.rank}: timed out waiting for the other ranks of the node "
                         f"(epochs {c[:W].tolist()}, want {self.epoch})")
                 time.sleep(0)
-        return bool(np.all(c[bank:bank + W] == 1))
+        both = int(np.bitwise_and.reduce(c[bank:bank + W]))
+        self.common_free = both >> 1
+        return bool(both & 1)
 
     def close(self):
         if self._closed:
@@ -170,7 +195,7 @@ class NodeShared:
         self._closed = True
         for seg in self.slots:
             self._unmap(seg)
-        self.slots = [None] * self.K
+        self.slots = [None] * len(self.slots)
         seg = self._ctrl_seg
         if seg is not None and self.rank == 0:
             try:

@@ -28,7 +28,7 @@ EXPORTS = (
     'ltmi_version', 'ltmi_last_error', 'ltmi_device_count', 'ltmi_device_info',
     'ltmi_masks_create_dense', 'ltmi_masks_create_csr', 'ltmi_masks_destroy', 'ltmi_masks_kind',
     'ltmi_apply_masks', 'ltmi_apply_masks_shifted', 'ltmi_apply_masks_shifted_host', 'ltmi_sum_frames_workspace', 'ltmi_sum_frames', 'ltmi_sum_sig',
-    'ltmi_axpy', 'ltmi_correct', 'ltmi_repair_pixels', 'ltmi_byteswap', 'ltmi_com_fields', 'ltmi_fft_plan_create',
+    'ltmi_axpy', 'ltmi_add2d', 'ltmi_gather_rows', 'ltmi_correct', 'ltmi_repair_pixels', 'ltmi_byteswap', 'ltmi_com_fields', 'ltmi_fft_plan_create',
     'ltmi_fft_plan_destroy', 'ltmi_crystallinity', 'ltmi_masks_set_tuning',
     'ltmi_masks_last_kernel',
 )
@@ -107,6 +107,8 @@ def lib():
         L.ltmi_sum_frames.argtypes = [i32, vp, i32, i64, i64, i64, vp, i32, i32, vp, vp]
         L.ltmi_sum_sig.argtypes = [i32, vp, i32, i64, i64, i64, vp, i32, i32, vp]
         L.ltmi_axpy.argtypes = [i32, vp, vp, i32, i64, vp]
+        L.ltmi_add2d.argtypes = [i32, vp, i64, vp, i64, i32, i64, i64, i32, vp]
+        L.ltmi_gather_rows.argtypes = [i32, vp, i64, vp, i64, i64, vp, vp]
         L.ltmi_correct.argtypes = [i32, vp, i32, i64, i64, i64, vp, vp, vp, i32, i64, vp]
         L.ltmi_repair_pixels.argtypes = [i32, vp, i32, i64, i64, vp, vp, vp, i32, i32, vp]
         L.ltmi_byteswap.argtypes = [i32, vp, vp, i32, i64, vp]
@@ -288,9 +290,27 @@ def sum_sig(device, tile_ptr, tile_dtype, n_frames, n_px, ld_tile, out_ptr, out_
         _stream_ptr(stream)), 'ltmi_sum_sig')
 
 
+#: dtypes ltmi_axpy / ltmi_add2d take (every dtype of the enum)
+AXPY_DTYPES = frozenset(np.dtype(t) for t in (
+    'bool', 'u1', 'i1', 'u2', 'i2', 'u4', 'i4', 'u8', 'i8', 'f4', 'f8', 'c8', 'c16'))
+
+
 def axpy(device, dest_ptr, src_ptr, dtype, n, stream=None):
     check(lib().ltmi_axpy(int(device), ctypes.c_void_p(dest_ptr), ctypes.c_void_p(src_ptr),
                           dtype_code(dtype), n, _stream_ptr(stream)), 'ltmi_axpy')
+
+
+def add2d(device, dest_ptr, ld_dest, src_ptr, ld_src, dtype, rows, cols, negate=False, stream=None):
+    """dest[r, c] (+|-)= src[r, c]; leading dimensions in elements, ld_src = 0 broadcasts a row."""
+    check(lib().ltmi_add2d(int(device), dest_ptr, int(ld_dest), src_ptr, int(ld_src),
+                           dtype_code(dtype), int(rows), int(cols), 1 if negate else 0,
+                           _stream_ptr(stream)), 'ltmi_add2d')
+
+
+def gather_rows(device, src_ptr, ld_src_bytes, idx_ptr, n_rows, row_bytes, dest_ptr, stream=None):
+    """dest[i, :] = src[idx[i], :] inside HBM; idx: device int64."""
+    check(lib().ltmi_gather_rows(int(device), src_ptr, int(ld_src_bytes), idx_ptr, int(n_rows),
+                                 int(row_bytes), dest_ptr, _stream_ptr(stream)), 'ltmi_gather_rows')
 
 
 def correct(device, tile_ptr, tile_dtype, n_frames, n_px, ld_tile, dark_ptr, gain_ptr, out_ptr,

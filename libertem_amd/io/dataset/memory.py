@@ -144,7 +144,8 @@ class MemoryDataSet(DataSet):
 
     def get_num_partitions(self):
         if self._shard is not None:
-            return self.num_partitions * self._shard[1]
+            n_local = prod(self._local_shape.nav)
+            return max(1, min(self.num_partitions, n_local)) * self._shard[1]
         return self.num_partitions
 
     @property
@@ -191,6 +192,34 @@ class MemoryDataSet(DataSet):
     def wait_for_frames(self, upto):
         """Hook for datasets whose frames are still arriving (io/dataset/stream.py): returns once
         the first `upto` frames of the scan are readable.  Everything is there already here."""
+
+    def get_slices(self):
+        """Sharded data: every rank's block [r*n_local, (r+1)*n_local) is cut into `num_partitions`
+        partitions with the reference's np.linspace rule applied INSIDE the block -- integer
+        boundaries that never straddle two ranks' data (a global linspace over world*P partitions
+        rounds some boundaries to k*n_local - 1)."""
+        if self._shard is None:
+            yield from super().get_slices()
+            return
+        n_local = prod(self._local_shape.nav)
+        sig = tuple(self._shape.sig)
+        P = max(1, min(self.num_partitions, n_local))
+        local = tuple(int(b) for b in np.linspace(0, n_local, num=P + 1, endpoint=True, dtype=int))
+        for r in range(self._shard[1]):
+            for a, b in zip(local[:-1], local[1:]):
+                start, stop = r * n_local + a, r * n_local + b
+                yield (Slice(origin=(start,) + (0,) * len(sig),
+                             shape=Shape((stop - start,) + sig, sig_dims=len(sig))), start, stop)
+
+    def owner_of_frames(self, start, stop):
+        """rank that holds frames [start, stop) of the global nav axis, None if replicated."""
+        if self._shard is None:
+            return None
+        n_local = prod(self._local_shape.nav)
+        r = start // n_local
+        if stop > (r + 1) * n_local:
+            raise DataSetException(f"frames {start}..{stop} straddle two shards of {n_local} frames")
+        return int(r)
 
     def get_partitions(self):
         if self._partitions is None:
@@ -456,10 +485,15 @@ class MemPartition(Partition):
             if flat.device != device:
                 raise RuntimeError(f"dataset lives on GPU {flat.device}, worker drives GPU {device}")
             if idxs is not None:
-                import torch
-                sel = torch.as_tensor(idxs, device=flat.torch.device)
-                gathered = flat.torch.reshape((flat.shape[0], -1)).index_select(0, sel)
-                flat = HipArray(gathered, (n,) + tuple(ds.shape.sig), flat.dtype)
+                # the frames the ROI selects, gathered inside HBM (ltmi_gather_rows)
+                from libertem_amd import hip
+                sel = HipArray.from_numpy(np.ascontiguousarray(idxs, dtype=np.int64), device)
+                gathered = HipArray.empty((n,) + tuple(ds.shape.sig), flat.dtype, device)
+                isz = np.dtype(flat.dtype).itemsize
+                hip.gather_rows(device, flat.data_ptr(), flat.ld * isz, sel.data_ptr(), n,
+                                prod(ds.shape.sig) * isz, gathered.data_ptr(),
+                                stream=getattr(env, 'stream_ptr', None))
+                flat = gathered
                 base = 0
             else:
                 base = self._local0

@@ -33,19 +33,32 @@ _CONTAINER_CACHE = OrderedDict()
 _CONTAINER_CACHE_SIZE = 4
 
 
+def _factories_key(mask_factories):
+    """Identity of the factories AND of the list that holds them: a list that the user mutates in
+    place (append / replace a factory) between runs is a different stack (the reference re-evaluates
+    the factories on every run, common/container.py:260-314)."""
+    if isinstance(mask_factories, (list, tuple)):
+        return (id(mask_factories), len(mask_factories), tuple(id(f) for f in mask_factories))
+    return (id(mask_factories),)
+
+
 def _cached_container(mask_factories, dtype, use_sparse, count, default_sparse):
-    key = (id(mask_factories), None if dtype is None else np.dtype(dtype).str, str(use_sparse),
-           count, default_sparse)
+    key = (_factories_key(mask_factories), None if dtype is None else np.dtype(dtype).str,
+           str(use_sparse), count, default_sparse)
     hit = _CONTAINER_CACHE.get(key)
     if hit is not None and hit[0] is mask_factories:
         _CONTAINER_CACHE.move_to_end(key)
         return hit[1]
     container = MaskContainer(mask_factories, dtype=dtype, use_sparse=use_sparse, count=count,
                               backend=UDF.BACKEND_HIP, default_sparse=default_sparse)
-    _CONTAINER_CACHE[key] = (mask_factories, container)
+    # pin the factories (and a snapshot of a list's members) so that their id()s stay unique
+    pinned = list(mask_factories) if isinstance(mask_factories, (list, tuple)) else None
+    _CONTAINER_CACHE[key] = (mask_factories, container, pinned)
     while len(_CONTAINER_CACHE) > _CONTAINER_CACHE_SIZE:
-        _, (_, old) = _CONTAINER_CACHE.popitem(last=False)
-        old.close()
+        # evicted containers are NOT closed: a UDF of the current run may still hold them (5+
+        # ApplyMasksUDFs in one run_udf); their device images go when the last reference does
+        # (MaskHandle.__del__)
+        _CONTAINER_CACHE.popitem(last=False)
     return container
 
 
@@ -120,8 +133,8 @@ def _folded_plan(corrections, masks_container, mask_factories, sig_shape, count)
 
 def clear_mask_cache():
     while _CONTAINER_CACHE:
-        _, (_, old) = _CONTAINER_CACHE.popitem(last=False)
-        old.close()
+        _, entry = _CONTAINER_CACHE.popitem(last=False)
+        entry[1].close()
 
 
 class ApplyMasksEngine:
@@ -182,9 +195,9 @@ class ApplyMasksEngine:
                      stream=self.stream_ptr)
         if self._const is not None:
             # dark frame of folded corrections: out[f, k] -= sum_p masks'[k, p] * dark[p]
-            import torch
-            view = torch.as_strided(out.torch.reshape(-1), (n, handle.n_masks), (out.ld, 1))
-            view.sub_(self._const)
+            from libertem_amd import hip
+            hip.add2d(tile.device, out.data_ptr(), out.ld, self._const.data_ptr(), 0,
+                      self.result_dtype, n, handle.n_masks, negate=True, stream=self.stream_ptr)
         return out
 
     def process_tile_shifted(self, tile, shifts, out, accumulate=True):

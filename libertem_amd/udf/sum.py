@@ -108,8 +108,21 @@ class SumUDF(UDF):
             tmp = HipArray.zeros(s_shape, odt, device)
             hip.sum_frames(device, tile.data_ptr(), tile.dtype, n, n_px, tile.ld, tmp.data_ptr(),
                            odt, False, ws)
-            sl = tuple(slice(o, o + s) for o, s in zip(s_origin, s_shape))
-            out.torch.reshape(sig_full)[sl] += tmp.torch.reshape(s_shape)
+            # out[sig slice] += tmp: rows of the innermost axis, one strided add per block of the
+            # outer sig axes (2D detectors: ONE call)
+            isz = odt.itemsize
+            strides = [prod(sig_full[k + 1:]) for k in range(len(sig_full))]
+            if len(sig_full) == 1:
+                hip.add2d(device, out.data_ptr() + s_origin[0] * isz, sig_full[0], tmp.data_ptr(),
+                          s_shape[0], odt, 1, s_shape[0])
+            else:
+                rows, cols = s_shape[-2], s_shape[-1]
+                for outer in np.ndindex(*s_shape[:-2]):
+                    off = sum((o + i) * st for o, i, st in zip(s_origin[:-2], outer, strides[:-2]))
+                    off += s_origin[-2] * strides[-2] + s_origin[-1]
+                    toff = sum(i * prod(s_shape[k + 1:]) for k, i in enumerate(outer))
+                    hip.add2d(device, out.data_ptr() + off * isz, sig_full[-1],
+                              tmp.data_ptr() + toff * isz, cols, odt, rows, cols)
 
     def merge(self, dest, src):
         dest.intensity[:] += src.intensity                     # udf/sum.py:50-52

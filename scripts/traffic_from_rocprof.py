@@ -1,0 +1,140 @@
+"""Turn the per-config rocprofv3 passes of scripts/profile_round.sh into
+
+  * profiles/traffic.json -- HBM bytes per launch of the dominant kernel of every config, keyed by
+    (config, bench.py's kernel label, frames per launch); bench.py quotes `roofline.traffic` from it
+    only when all three match what it just ran;
+  * a text summary on stdout (per-kernel duration statistics + raw counters + the bench line).
+
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts wide streaming reads at half
+their size, so reads are doubled (guides/MI355X_MICROARCH.md, HBM / rocprofv3 section).
+
+    python scripts/traffic_from_rocprof.py <tag> <dir with <cfg>_{stats,fetch,write,sq}/> c2 c3 ...
+"""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DOMINANT = ('k_dense', 'k_bell', 'k_sell')
+
+
+def find_db(d):
+    hits = sorted(glob.glob(os.path.join(d, '**', '*results.db'), recursive=True))
+    return hits[0] if hits else None
+
+
+def _table(c, prefix):
+    names = [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')")]
+    exact = [n for n in names if n == prefix]
+    return (exact or [n for n in names if n.startswith(prefix)] or [None])[0]
+
+
+def kernel_stats(db):
+    c = sqlite3.connect(db)
+    t = _table(c, 'kernels')
+    rows = c.execute(f"select name, count(*), avg(end-start), min(end-start), max(end-start), "
+                     f"sum(end-start) from {t} group by name order by sum(end-start) desc").fetchall()
+    return rows
+
+
+def counters(db):
+    c = sqlite3.connect(db)
+    for q in ("select k.name, p.counter_name, count(*), avg(p.value) from pmc_events p "
+              "join kernels k on k.dispatch_id = p.dispatch_id group by k.name, p.counter_name",
+              "select kernel_name, counter_name, count(*), avg(value) from counters_collection "
+              "group by kernel_name, counter_name",
+              "select name, counter_name, count(*), avg(value) from counters_collection "
+              "group by name, counter_name"):
+        try:
+            return c.execute(q).fetchall()
+        except Exception:
+            continue
+    return []
+
+
+def dominant(rows):
+    for name, n, avg, mn, mx, tot in rows:
+        if any(k in name for k in DOMINANT):
+            return name, n, avg, mn, mx
+    return None
+
+
+def bench_line(log):
+    try:
+        for ln in open(log):
+            if ln.startswith('{') and '"roofline"' in ln:
+                return json.loads(ln)
+    except OSError:
+        pass
+    return None
+
+
+def main():
+    tag, d, cfgs = sys.argv[1], sys.argv[2], sys.argv[3:]
+    entries = []
+    for cfg in cfgs:
+        print(f"## config {cfg}")
+        line = bench_line(os.path.join(d, f'{cfg}_stats.log'))
+        if line is None:
+            print("   no bench line in the stats pass log")
+            continue
+        roof = line['roofline']
+        print(f"   bench.py (stats pass): value {line['value']:.4g} frames/s, ms_per_step "
+              f"{line['ms_per_step']:.3f}; roofline {json.dumps(roof)}")
+        per = {}
+        for p in ('stats', 'fetch', 'write', 'sq'):
+            db = find_db(os.path.join(d, f'{cfg}_{p}'))
+            if db is None:
+                print(f"   pass {p}: no database")
+                continue
+            rows = kernel_stats(db)
+            print(f"   pass {p}: {'kernel':88s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} "
+                  f"{'max_us':>10s}")
+            for name, n, avg, mn, mx, tot in rows[:4]:
+                print(f"      {name[:96]:96s} {n:6d} {avg/1e3:10.2f} {mn/1e3:10.2f} {mx/1e3:10.2f}")
+            dom = dominant(rows)
+            per[p] = dict(dom=dom, counters=counters(db))
+            for name, ctr, n, v in per[p]['counters']:
+                if dom and name == dom[0]:
+                    print(f"      counter {ctr:28s} n={n:4d} avg per dispatch {v:18.1f}")
+        try:
+            dom = per['stats']['dom']
+            fetch = [v for name, ctr, n, v in per['fetch']['counters']
+                     if name == per['fetch']['dom'][0] and ctr == 'FETCH_SIZE'][0]
+            write = [v for name, ctr, n, v in per['write']['counters']
+                     if name == per['write']['dom'][0] and ctr == 'WRITE_SIZE'][0]
+        except (KeyError, IndexError, TypeError) as e:
+            print(f"   no traffic entry: {e!r}")
+            continue
+        hbm = fetch * 1024 * 2 + write * 1024
+        alg = roof['algorithmic_bytes_per_launch']
+        print(f"   => {dom[0][:60]}: rocprof avg {dom[2]/1e3:.1f} us vs HIP events "
+              f"{roof['avg_launch_ms']*1e3:.1f} us; FETCH_SIZE {fetch:.1f} KiB x 1024 x 2 (gfx950) + "
+              f"WRITE_SIZE {write:.1f} KiB x 1024 = {hbm:.4g} B = {hbm/alg:.3f} x algorithmic "
+              f"({alg:.4g} B)")
+        entries.append({
+            "config": cfg, "kernel": roof['kernel'],
+            "frames_per_launch": roof['frames_per_launch'],
+            "hbm_bytes_per_launch": hbm, "fetch_size_kib": fetch, "write_size_kib": write,
+            "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": hbm / alg,
+            "rocprof_kernel": dom[0], "rocprof_avg_us": dom[2] / 1e3, "rocprof_calls": dom[1],
+            "hip_event_avg_us": roof['avg_launch_ms'] * 1e3,
+            "source": f"profiles/{tag}_configs_rocprof.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                      f"separate passes over bench.py --config {cfg})",
+        })
+        print()
+    path = os.path.join(ROOT, 'profiles', 'traffic.json')
+    old = []
+    try:
+        old = json.load(open(path))['entries']
+    except Exception:
+        pass
+    keep = [e for e in old if e.get('config') not in {x['config'] for x in entries}]
+    json.dump({"tag": tag, "entries": keep + entries}, open(path, 'w'), indent=1)
+    print(f"wrote {path}: {len(entries)} new entr(y/ies), {len(keep)} kept")
+
+
+if __name__ == '__main__':
+    main()

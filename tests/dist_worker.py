@@ -82,7 +82,18 @@ def main():
     ds_sh = ctx.load('memory', data=local, shard=(rank, world), num_partitions=2, sig_dims=2)
     assert tuple(ds_sh.shape) == (world * 3, 5, 16, 16)
     rs1, rs2 = ctx.run_udf(dataset=ds_sh, udf=[MasksDeclared(masks), SumDeclared()])
+    # sizes where a global np.linspace truncates a boundary to k*n_local - 1 (61 frames per rank,
+    # 7 partitions per rank), and an ROI that removes every partition of rank 0's shard
+    full2 = rng.integers(0, 100, (world * 61, 16, 16)).astype(np.uint16)
+    ds_sh2 = ctx.load('memory', data=full2[rank * 61:(rank + 1) * 61], shard=(rank, world),
+                      num_partitions=7, sig_dims=2)
+    rs3 = ctx.run_udf(dataset=ds_sh2, udf=MasksDeclared(masks))
+    roi2 = np.zeros((world * 61,), dtype=bool)
+    roi2[61 + 5:61 + 40] = True
+    rs4 = ctx.run_udf(dataset=ds_sh2, udf=[MasksDeclared(masks), SumDeclared()], roi=roi2)
     np.savez(os.path.join(out_dir, f'rank{rank}.npz'),
+             sh2_masks=rs3['intensity'].data, sh2_roi_raw=rs4[0]['intensity'].raw_data,
+             sh2_roi_sum=rs4[1]['intensity'].data, sh2_full=full2,
              sh_masks=rs1['intensity'].data, sh_sum=rs2['intensity'].data, sh_full=full,
              masks=r1['intensity'].data, sum=r2['intensity'].data, mx=r3['mx'].data,
              per_frame=r3['per_frame'].data, masks_roi=r1_roi['intensity'].data,

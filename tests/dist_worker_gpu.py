@@ -40,12 +40,25 @@ def main():
         res = ctx.run_udf(dataset=ds, udf=[ApplyMasksUDF(mask_factories=lambda: masks), SumUDF(),
                                            SumSigUDF()])
         if rep == 0:
-            first = res[0]['intensity']           # kept alive across the recycling of its slot
+            first = res[0]['intensity']           # a BufferWrapper kept alive across the recycling
             first_copy = np.array(first.data)
+        if rep == 1 and rank == 0:
+            # a BARE ndarray view, held on ONE rank only: the slot must not be rewritten by the
+            # other rank either (results are caller-owned for as long as they are referenced)
+            bare = res[2]['intensity'].data[1:3]
+            bare_copy = np.array(bare)
     out['sh_masks'] = res[0]['intensity'].data
     out['sh_sum'] = res[1]['intensity'].data
     out['sh_sumsig'] = res[2]['intensity'].data
     out['sh_first_still_valid'] = np.array(np.array_equal(first.data, first_copy))
+    out['sh_bare_still_valid'] = np.array(rank != 0 or np.array_equal(bare, bare_copy))
+    out['sh_slots'] = np.array(len(ex._node_shared().slots))
+    # every slot held (ring limit 6 in this test): the run falls back to the collectives and the
+    # held results stay untouched
+    held = [ctx.run_udf(dataset=ds, udf=SumSigUDF())['intensity'].data for _ in range(8)]
+    out['sh_held_equal'] = np.array(all(np.array_equal(h, held[0]) for h in held))
+    out['sh_via_when_full'] = np.array(ex.last_result_via)
+    del held
     out['sh_full'] = full
     # (2) replicated host dataset, 5 partitions over 2 ranks, with and without ROI
     data = rng.integers(0, 4000, (5, 9, 32, 32)).astype(np.uint16)

@@ -452,6 +452,47 @@ def gen_pick():
         print(case['name'], res.data.shape, res.data.dtype)
     save('pick', **out)
 
+# ---------------------------------------------------------------------------
+# 14. the BASELINE.json config workloads at their real detector size (reduced nav)
+# ---------------------------------------------------------------------------
+def gen_config_workloads():
+    out = {}
+    for case in recipes.WORKLOAD_CASES:
+        data = recipes.make_workload_case(case)
+        ds = MemoryDataSet(data=data, num_partitions=case['num_partitions'], sig_dims=2)
+        name = case['name']
+        out[f"{name}__sha_data"] = np.frombuffer(bytes.fromhex(sha(data)), dtype=np.uint8)
+        if case['kind'] == 'rf':
+            analysis = RadialFourierAnalysis(ds, dict(case['params']))
+            p = analysis.parameters
+            assert p['use_sparse'] is False, p
+            udf_res = run(ds, analysis.get_udf())
+            out[f"{name}__intensity"] = np.array(udf_res['intensity'].data)
+            rs = analysis.get_udf_results(udf_res, None, damage=True)
+            out[f"{name}__raw_results"] = np.array(rs.raw_results)
+            print(name, out[f"{name}__intensity"].shape, out[f"{name}__intensity"].dtype)
+            continue
+        for i, ap in enumerate(case['analysis_params']):
+            analysis = COMAnalysis(ds, dict(ap))
+            inten = np.array(run(ds, analysis.get_udf())['intensity'].data)
+            p = analysis.parameters
+            yc_raw, xc_raw = center_shifts(inten[..., 0], inten[..., 1], inten[..., 2],
+                                           p['cy'], p['cx'])
+            yc, xc = apply_correction(yc_raw, xc_raw, scan_rotation=p['scan_rotation'],
+                                      flip_y=p['flip_y'])
+            out[f"{name}__analysis{i}__intensity"] = inten
+            out[f"{name}__analysis{i}__x"] = xc
+            out[f"{name}__analysis{i}__y"] = yc
+            out[f"{name}__analysis{i}__magnitude"] = magnitude(yc, xc)
+            out[f"{name}__analysis{i}__divergence"] = divergence(yc, xc)
+            out[f"{name}__analysis{i}__curl"] = curl_2d(yc, xc)
+        for i, up in enumerate(case['udf_params']):
+            res = run(ds, CoMUDF.with_params(**up))
+            for k, v in res.items():
+                out[f"{name}__udf{i}__{k}"] = np.array(v.data)
+        print(name, inten.shape, inten.dtype)
+    save('config_workloads', **out)
+
 
 GENERATORS = {}
 
@@ -478,5 +519,7 @@ if __name__ == '__main__':
     gen_rmatmul()
     gen_tiling()
     gen_single_mask_analyses()
+    gen_pick()
+    gen_config_workloads()
     with open(os.path.join(HERE, 'MANIFEST.json'), 'w') as f:
         json.dump(MANIFEST, f, indent=1, sort_keys=True)

@@ -201,6 +201,40 @@ def make_rf_case(case):
 
 
 # ---------------------------------------------------------------------------
+# Config workloads at their real detector size (BASELINE.json C3 / C5), reduced nav
+# ---------------------------------------------------------------------------
+WORKLOAD_CASES = [
+    # C5: RadialFourierAnalysis defaults (n_bins=1, max_order=24 -> 25 dense complex64 masks)
+    # on 1024x1024 float32 frames, rng(5).random like SURVEY.md 8(d)
+    dict(name='c5_rf_1024', kind='rf', nav=(2, 4), sig=(1024, 1024), dtype='float32',
+         num_partitions=2, seed=5, params=dict()),
+    # C3: COMAnalysis / CoMUDF on 512x512 uint16 counts in [0, 4096): default (r=inf) and
+    # mask_radius=200, plus an off-centre CoMUDF
+    dict(name='c3_com_512', kind='com', nav=(2, 4), sig=(512, 512), dtype='uint16',
+         num_partitions=2, seed=3,
+         analysis_params=[dict(cx=256, cy=256), dict(cx=256, cy=256, r=200)],
+         udf_params=[dict(), dict(cy=250.5, cx=260.25, r=200.)]),
+]
+
+
+def make_workload_case(case):
+    rng = np.random.default_rng(case['seed'])
+    shape = tuple(case['nav']) + tuple(case['sig'])
+    if case['kind'] == 'rf':
+        return rng.random(shape, dtype=np.float32)
+    data = rng.integers(0, 4096, shape).astype(case['dtype'])
+    # a brighter disk that wanders with the scan position, so that the centre of mass is not
+    # just the noise around the detector centre
+    yy, xx = np.mgrid[0:shape[2], 0:shape[3]]
+    flat = data.reshape((-1,) + shape[2:])
+    for f in range(flat.shape[0]):
+        cy, cx = shape[2] / 2 + 11.5 * np.sin(f), shape[3] / 2 + 17.25 * np.cos(f)
+        disk = (yy - cy) ** 2 + (xx - cx) ** 2 < 60 ** 2
+        flat[f][disk] = np.minimum(flat[f][disk].astype(np.int64) + 2000, 4095).astype(data.dtype)
+    return data
+
+
+# ---------------------------------------------------------------------------
 # mask factories
 # ---------------------------------------------------------------------------
 CIRCULAR_CASES = [

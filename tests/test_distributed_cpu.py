@@ -60,6 +60,12 @@ def test_gloo_sharded_run(tmp_path, world):
         exp = (full.reshape((-1, 256)).astype(np.float32) @ masks.reshape((3, -1)).T)
         assert np.allclose(o['sh_masks'], exp.reshape(full.shape[:2] + (3,)), rtol=1e-6)
         assert np.array_equal(o['sh_sum'], full.astype(np.float32).sum(axis=(0, 1)))
+        # partition boundaries of sharded data never straddle two ranks; ROI that empties a shard
+        full2 = o['sh2_full']
+        exp2 = full2.reshape((-1, 256)).astype(np.float32) @ masks.reshape((3, -1)).T
+        assert np.allclose(o['sh2_masks'], exp2, rtol=1e-6)
+        assert np.allclose(o['sh2_roi_raw'], exp2[61 + 5:61 + 40], rtol=1e-6)
+        assert np.array_equal(o['sh2_roi_sum'], full2[61 + 5:61 + 40].astype(np.float32).sum(axis=0))
     # identical on every rank
     for o in outs[1:]:
         for k in ('masks', 'sum', 'mx', 'per_frame'):

@@ -98,6 +98,38 @@ def test_com(golden_dir, case):
         assert np.allclose(ares[k], ref, rtol=1e-5, atol=1e-5), k
 
 
+@pytest.mark.parametrize('case', recipes.WORKLOAD_CASES, ids=lambda c: c['name'])
+def test_config_workloads_full_detector_size(golden_dir, case):
+    """C3 (CoM, 512x512 uint16) and C5 (radial Fourier defaults, 1024x1024 float32) at the real
+    detector sizes, reduced nav: the oracle against what the reference produced."""
+    g = _load(golden_dir, 'config_workloads')
+    data = recipes.make_workload_case(case)
+    name = case['name']
+    assert np.array_equal(_sha(data), g[name + '__sha_data'])
+    if case['kind'] == 'rf':
+        res = opath.radial_fourier_analysis(data, num_partitions=case['num_partitions'],
+                                            **case['params'])
+        ref = g[name + '__intensity']
+        assert res['intensity'].dtype == ref.dtype and res['intensity'].shape == ref.shape
+        scale = np.abs(ref).max()
+        assert np.allclose(res['intensity'], ref, rtol=0, atol=1e-5 * scale)
+        assert np.allclose(res['raw_results'], g[name + '__raw_results'], rtol=0,
+                           atol=1e-5 * scale)
+        return
+    for i, ap in enumerate(case['analysis_params']):
+        ares = opath.com_analysis(data, num_partitions=case['num_partitions'], **ap)
+        for k in ('intensity', 'x', 'y', 'magnitude', 'divergence', 'curl'):
+            ref = g[f"{name}__analysis{i}__{k}"]
+            assert ares[k].shape == ref.shape and ares[k].dtype == ref.dtype, k
+            assert np.allclose(ares[k], ref, rtol=1e-5, atol=1e-5), k
+    for i, up in enumerate(case['udf_params']):
+        res = opath.com_udf(data, num_partitions=case['num_partitions'], **up)
+        for k, v in res.items():
+            ref = g[f"{name}__udf{i}__{k}"]
+            assert v.dtype == ref.dtype and v.shape == ref.shape, k
+            assert np.allclose(v, ref, rtol=1e-5, atol=1e-5), k
+
+
 def test_coordinates(golden_dir):
     g = _load(golden_dir, 'com')
     assert np.array_equal(opath.rotate_deg(33.), g['rotate_deg_33'])

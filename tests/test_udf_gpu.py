@@ -41,6 +41,15 @@ def _close(a, b, tol):
     return np.allclose(a, b, rtol=tol, atol=tol * scale)
 
 
+def _com_close(got, ref, scale, tol=F32_TOL):
+    """CoM tolerance (north star: 1e-5 rel).  `raw_com` = img_y/img_sum is a plain quotient of two
+    f32 sums: 1e-5 relative.  Everything downstream (`raw_shifts`, `field`, x / y, magnitude,
+    regression coefficients) is `raw_com - centre` or linear in it, and divergence / curl are
+    np.gradient differences of neighbouring shifts with weights <= 1: the subtraction cancels the
+    leading digits, so the error they inherit is ABSOLUTE, 1e-5 x |raw_com| (`scale`)."""
+    return np.allclose(got, ref, rtol=tol, atol=tol * scale)
+
+
 @pytest.mark.parametrize('resident', ['host', 'device'])
 @pytest.mark.parametrize('case', recipes.DENSE_CASES, ids=lambda c: c['name'])
 def test_apply_masks_udf_vs_reference_golden(ctx, golden_dir, case, resident):
@@ -137,11 +146,15 @@ def test_com_vs_reference_golden(ctx, golden_dir, case):
     ds = ctx.load('memory', data=data, num_partitions=case['num_partitions'], sig_dims=2)
     res = ctx.run_udf(dataset=ds, udf=CoMUDF.with_params(**case['params']))
     assert 'raw_mask_result' not in res                   # use='private'
+    scale = np.abs(g[f"{case['name']}__udf__raw_com"]).max()
     for k, v in res.items():
         ref = g[f"{case['name']}__udf__{k}"]
         assert v.data.shape == ref.shape, k
         assert v.data.dtype == ref.dtype, k
-        assert np.allclose(v.data, ref, rtol=1e-4, atol=1e-4), k
+        if k == 'raw_com':
+            assert np.allclose(v.data, ref, rtol=F32_TOL, atol=0), k
+        else:
+            assert _com_close(v.data, ref, scale), k
     # the analysis flavour (x first in `field`, float defaults cx = W/2)
     p = case['analysis_params']
     analysis = ctx.create_com_analysis(
@@ -150,10 +163,8 @@ def test_com_vs_reference_golden(ctx, golden_dir, case):
         scan_rotation=p.get('scan_rotation', 0.))
     ares = ctx.run(analysis)
     for k in ('x', 'y', 'magnitude', 'divergence', 'curl'):
-        assert np.allclose(ares[k].raw_data, g[f"{case['name']}__analysis__{k}"],
-                           rtol=1e-4, atol=1e-4), k
-    assert np.allclose(ares.field.raw_data[0], g[f"{case['name']}__analysis__x"],
-                       rtol=1e-4, atol=1e-4)
+        assert _com_close(ares[k].raw_data, g[f"{case['name']}__analysis__{k}"], scale), k
+    assert _com_close(ares.field.raw_data[0], g[f"{case['name']}__analysis__x"], scale)
 
 
 def test_com_vs_scipy_center_of_mass(ctx):
@@ -166,7 +177,7 @@ def test_com_vs_scipy_center_of_mass(ctx):
     for i in range(data.shape[0]):
         for j in range(data.shape[1]):
             cy, cx = scipy.ndimage.center_of_mass(data[i, j].astype(np.float64))
-            assert np.allclose(res['raw_com'].data[i, j], (cy, cx), rtol=1e-4)
+            assert np.allclose(res['raw_com'].data[i, j], (cy, cx), rtol=F32_TOL)
 
 
 @pytest.mark.parametrize('case', [c for c in recipes.RF_CASES
@@ -183,6 +194,73 @@ def test_radial_fourier_vs_reference_golden(ctx, golden_dir, case):
     assert _close(res.raw_results, ref, F32_TOL)
     assert res.complex_0_1.raw_data.shape == tuple(case['nav'])
     assert np.array_equal(res.dominant_0.raw_data.shape, case['nav'])
+
+
+@pytest.mark.parametrize('resident', ['host', 'device'])
+def test_c5_workload_radial_fourier_1024(ctx, golden_dir, resident):
+    """BASELINE.json C5 at its real detector size: create_radial_fourier_analysis DEFAULTS
+    (n_bins=1, max_order=24 -> 25 dense complex64 masks = 50 real columns: the 3 MFMA groups + 2
+    VALU columns kernel over the 256 MiB image) on 1024x1024 float32 frames, reduced nav; against
+    the reference's output (golden) and the oracle, 1e-5 of max|ref|."""
+    case = next(c for c in recipes.WORKLOAD_CASES if c['name'] == 'c5_rf_1024')
+    g = _load(golden_dir, 'config_workloads')
+    data = recipes.make_workload_case(case)
+    if resident == 'device':
+        ds = _device_ds(ctx, data, case['num_partitions'])
+    else:
+        ds = ctx.load('memory', data=data, num_partitions=case['num_partitions'], sig_dims=2)
+    analysis = ctx.create_radial_fourier_analysis(dataset=ds)
+    assert analysis.parameters['use_sparse'] is False
+    res = ctx.run(analysis)
+    ref = g['c5_rf_1024__raw_results']
+    assert res.raw_results.shape == ref.shape == (1, 25, 2, 4)
+    assert res.raw_results.dtype == ref.dtype == np.complex64
+    assert _close(res.raw_results, ref, F32_TOL)
+    ora = opath.radial_fourier_analysis(data, num_partitions=case['num_partitions'])
+    assert _close(res.raw_results, ora['raw_results'], F32_TOL)
+    udf_res = ctx.run_udf(dataset=ds, udf=analysis.get_udf())['intensity'].data
+    assert _close(udf_res, g['c5_rf_1024__intensity'], F32_TOL)
+
+
+@pytest.mark.parametrize('resident', ['host', 'device'])
+def test_c3_workload_com_512(ctx, golden_dir, resident):
+    """BASELINE.json C3 at its real detector size: COMAnalysis (default and mask_radius=200) and
+    CoMUDF on 512x512 uint16 counts in [0, 4096) -- gradient ramps x 262 144 pixels, sums ~1e11 in
+    float32 -- against the reference's output (golden) and the oracle."""
+    from libertem_amd.udf.com import CoMUDF
+    case = next(c for c in recipes.WORKLOAD_CASES if c['name'] == 'c3_com_512')
+    g = _load(golden_dir, 'config_workloads')
+    data = recipes.make_workload_case(case)
+    if resident == 'device':
+        ds = _device_ds(ctx, data, case['num_partitions'])
+    else:
+        ds = ctx.load('memory', data=data, num_partitions=case['num_partitions'], sig_dims=2)
+    scale = 512.
+    for i, ap in enumerate(case['analysis_params']):
+        analysis = ctx.create_com_analysis(dataset=ds, cx=ap['cx'], cy=ap['cy'],
+                                           mask_radius=ap.get('r'))
+        inten = ctx.run_udf(dataset=ds, udf=analysis.get_udf())['intensity'].data
+        ref_i = g[f'c3_com_512__analysis{i}__intensity']
+        assert inten.dtype == ref_i.dtype and inten.shape == ref_i.shape
+        for c in range(3):                  # the three raw sums, each relative to its own maximum
+            assert _close(inten[..., c], ref_i[..., c], F32_TOL), (i, c)
+        ares = ctx.run(analysis)
+        ora = opath.com_analysis(data, num_partitions=case['num_partitions'], **ap)
+        for k in ('x', 'y', 'magnitude', 'divergence', 'curl'):
+            assert _com_close(ares[k].raw_data, g[f'c3_com_512__analysis{i}__{k}'], scale), (i, k)
+            assert _com_close(ares[k].raw_data, ora[k], scale), (i, k)
+    for i, up in enumerate(case['udf_params']):
+        res = ctx.run_udf(dataset=ds, udf=CoMUDF.with_params(**up))
+        ora = opath.com_udf(data, num_partitions=case['num_partitions'], **up)
+        for k, v in res.items():
+            ref = g[f'c3_com_512__udf{i}__{k}']
+            assert v.data.shape == ref.shape and v.data.dtype == ref.dtype, k
+            if k == 'raw_com':
+                assert np.allclose(v.data, ref, rtol=F32_TOL, atol=0), k
+                assert np.allclose(v.data, ora[k], rtol=F32_TOL, atol=0), k
+            else:
+                assert _com_close(v.data, ref, scale), (i, k)
+                assert _com_close(v.data, ora[k], scale), (i, k)
 
 
 def test_single_mask_and_sum_analyses(ctx, golden_dir):
@@ -241,16 +319,19 @@ def test_roi_and_multiple_udfs(ctx):
 
 
 def test_full_size_properties(ctx):
-    """At a size the oracle cannot finish in seconds: size-independent properties.
+    """At the full C2 size (the oracle cannot finish that in seconds): size-independent properties.
     linearity apply(a*m1 + m2) == a*apply(m1) + apply(m2); all-ones mask == SumSigUDF;
     sum over nav of SumSig == sum over sig of SumUDF (checksum of checksums)."""
     from libertem_amd.udf.masks import ApplyMasksUDF
     from libertem_amd.udf.sumsigudf import SumSigUDF
     from libertem_amd.udf.sum import SumUDF
-    n = 64 * 64
+    n = 256 * 256                       # BASELINE.json C2: 65 536 frames of 256x256 uint16 (8 GiB)
     g = torch.Generator(device='cuda').manual_seed(5)
-    frames = torch.randint(0, 64, (n, 256 * 256), generator=g, device='cuda',
-                           dtype=torch.int32).to(torch.int16).reshape((64, 64, 256, 256))
+    frames = torch.empty((n, 256 * 256), dtype=torch.int16, device='cuda')
+    for i in range(0, n, 4096):
+        frames[i:i + 4096] = torch.randint(0, 64, (4096, 256 * 256), generator=g, device='cuda',
+                                           dtype=torch.int32).to(torch.int16)
+    frames = frames.reshape((256, 256, 256, 256))
     ds = ctx.load('memory', data=frames, dtype=np.uint16, sig_dims=2, num_partitions=2)
     rng = np.random.default_rng(6)
     m1 = (rng.random((256, 256)) > 0.5).astype(np.float32)
@@ -1023,6 +1104,7 @@ def test_two_ranks_share_results_through_host_segment(tmp_path, world):
     env['PYTHONPATH'] = root + os.pathsep + env.get('PYTHONPATH', '')
     env['LIBERTEM_USE_HIP'] = '0'
     env['OMP_NUM_THREADS'] = '1'
+    env['LTMI_SHM_MAX_SLOTS'] = '6'
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}',
            '--master-addr', '127.0.0.1', '--master-port', str(port),
            os.path.join(root, 'tests', 'dist_worker_gpu.py'), str(tmp_path)]
@@ -1037,7 +1119,9 @@ def test_two_ranks_share_results_through_host_segment(tmp_path, world):
         assert _close(o['coll_masks'], exp, F32_TOL)
         assert np.array_equal(o['sh_sum'], full.astype(np.float32).sum(axis=(0, 1)))
         assert np.array_equal(o['sh_sumsig'], full.astype(np.float32).sum(axis=(2, 3)))
-        assert bool(o['sh_first_still_valid'])
+        assert bool(o['sh_first_still_valid']) and bool(o['sh_bare_still_valid'])
+        assert bool(o['sh_held_equal']) and str(o['sh_via_when_full']) == 'collective'
+        assert 4 <= int(o['sh_slots']) <= 6
         data, roi = o['rep_data'], o['rep_roi']
         exp2 = opath.apply_masks(data, masks, num_partitions=5)
         assert _close(o['rep_masks'], exp2, F32_TOL)
@@ -1074,3 +1158,11 @@ def test_bench_contract_with_two_ranks_on_one_gpu():
     assert d['value'] > 0 and d['unit'] == 'frames/s' and d['vs_baseline'] is None
     assert d['roofline']['bound'] == 'hbm' and 0 < d['roofline']['frac'] < 1.2
     assert 'cpu_baseline' not in d or d['cpu_baseline'] is None or d['n_gpus'] == 1
+    # the N>1 extras: delivery path, per-rank times, the RCCL-style gather of the same steps, and
+    # strong scaling on C3 (128 GiB nav-split over the ranks)
+    assert d['result_via'] == 'shm' and len(d['per_rank']) == 2
+    assert all(p['kernel_ms_per_step'] > 0 for p in d['per_rank'])
+    assert 'error' not in d['rccl_path'], d['rccl_path']
+    assert d['rccl_path']['result_via'] == 'collective' and d['rccl_path']['value'] > 0
+    assert 'error' not in d['strong_c3'], d['strong_c3']
+    assert d['strong_c3']['frames_total'] == 512 * 512 and d['strong_c3']['scaling'] == 'strong'
