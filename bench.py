@@ -172,10 +172,13 @@ class Workload:
                            num_partitions=1, shard=(rank, world) if sharded else None)
         self.nav = (rows * (world if sharded else 1), scan[1])
         if name in ('c2', 'c2-small'):
-            self.masks = np.random.default_rng(2).random((16,) + det).astype(np.float32)
-            udf = ApplyMasksUDF(mask_factories=lambda: self.masks, use_sparse=False,
+            masks = self.masks = np.random.default_rng(2).random((16,) + det).astype(np.float32)
+            # (the factory must not close over `self`: factories are pickled for their size check,
+            # like in the reference, common/container.py)
+            udf = ApplyMasksUDF(mask_factories=lambda: masks, use_sparse=False,
                                 mask_count=16, mask_dtype=np.float32)
-            self.step = lambda: ctx.run_udf(dataset=self.ds, udf=udf)
+            ds = self.ds
+            self.step = lambda: ctx.run_udf(dataset=ds, udf=udf)
         elif name == 'c3':
             an = ctx.create_com_analysis(dataset=self.ds, cx=256, cy=256)
             self.step = lambda: ctx.run(an)
@@ -185,7 +188,8 @@ class Workload:
                                      n_bins=1024, use_sparse=True, dtype=np.float32)
             udf = ApplyMasksUDF(mask_factories=rings, use_sparse='scipy.sparse', mask_count=1024,
                                 mask_dtype=np.float32)
-            self.step = lambda: ctx.run_udf(dataset=self.ds, udf=udf)
+            ds = self.ds
+            self.step = lambda: ctx.run_udf(dataset=ds, udf=udf)
         elif name == 'c5':
             self.analysis = ctx.create_radial_fourier_analysis(dataset=self.ds)
             assert self.analysis.parameters['use_sparse'] is False
@@ -499,7 +503,7 @@ def main():
             def run():
                 w = Workload(name, ctx, torch, 0, 1, sharded=False)
                 k = 5
-                mm = measure(w, k, 2, barrier, hip, n_check=8)
+                mm = measure(w, k, 3, barrier, hip, n_check=8)
                 fps = w.n_local * k / mm['elapsed']
                 return {"workload": CONFIGS[name]['desc'], "steps": k,
                         "ms_per_step": mm['ms_per_step'], "value": fps, "unit": "frames/s",

@@ -149,6 +149,11 @@ int ltmi_add2d(int device, void *dest, int64_t ld_dest, const void *src, int64_t
 int ltmi_gather_rows(int device, const void *src, int64_t ld_src_bytes, const int64_t *idx,
                      int64_t n_rows, int64_t row_bytes, void *dest, void *stream);
 
+/* Device address of page-locked host memory (hipHostMalloc / hipHostRegister): the place where the
+ * kernels above may write small write-once result rows directly (`out` = this address), instead of
+ * the reference's per-partition D2H export of device buffers (src/libertem/common/buffers.py:901-907). */
+int ltmi_host_device_pointer(int device, void *host, void **dev_out);
+
 /* ---- detector corrections -------------------------------------------------------------------
  * Replaces CorrectionSet.apply -> detector.correct on a tile (src/libertem/io/corrections/
  * corrset.py:140-166, detector.py:17-101, called from io/dataset/base/backend.py:121-124) fused

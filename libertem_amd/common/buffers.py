@@ -47,6 +47,7 @@ class BufferWrapper:
         self.use = use
         self._arr = None             # np.ndarray | HipArray (see the `_data` property)
         self._lazy = False           # zeros of `_shape` are materialised on first access
+        self.write_once = False      # allocated without zero fill: the UDF writes, never adds
         self._shape = None
         self._ds_shape = None
         self._roi = None
@@ -126,15 +127,25 @@ class BufferWrapper:
         self._ds_shape = dataset_shape
 
     # --- allocation ---------------------------------------------------------------------------
-    def allocate(self, lib=None, lazy=False):
+    def allocate(self, lib=None, lazy=False, write_once=False, target=None):
         """lib: None/'numpy' -> host zeros; ('hip', device) -> HipArray zeros when this buffer
         was declared where='device', host zeros otherwise (reference :668-686).
         lazy: host zeros are only materialised when somebody looks at them (the main-process
-        buffers of a run whose executor replaces them with the merged device result)."""
+        buffers of a run whose executor replaces them with the merged device result).
+        write_once: the UDF promises to WRITE every element exactly once (no `+=`): the device
+        buffer is not zero-filled, and `target` -- a callable(shape, dtype) -> HipArray | None of
+        the executor -- may place it straight into the run's final host buffer."""
         if self._shape is None:
             raise RuntimeError("shape must be set before allocate()")
         if isinstance(lib, tuple) and lib[0] == 'hip' and self._where == 'device':
-            self._data = HipArray.zeros(self._shape, self._dtype, lib[1])
+            arr = None
+            if write_once and target is not None:
+                arr = target(self._shape, self._dtype)
+            if arr is None:
+                arr = (HipArray.empty if write_once else HipArray.zeros)(
+                    self._shape, self._dtype, lib[1])
+            self._data = arr
+            self.write_once = bool(write_once)
         elif lazy:
             self._arr = None
             self._lazy = True
@@ -147,6 +158,12 @@ class BufferWrapper:
     @property
     def on_device(self):
         return isinstance(self._arr, HipArray)
+
+    @property
+    def host_mapped(self):
+        """True iff the kernels write this buffer straight into page-locked host memory."""
+        from .hiparray import HostMappedArray
+        return isinstance(self._arr, HostMappedArray)
 
     def export(self):
         """D2H once per partition (reference :901-907)."""

@@ -86,7 +86,12 @@ class MaskContainer:
         if callable(fns):
             fns = [fns]
         for fn in fns:
-            s = len(cloudpickle.dumps(fn))
+            try:
+                s = len(cloudpickle.dumps(fn))
+            except Exception:
+                # tasks never leave the process here (no pickling on the HIP executor): a factory
+                # that closes over something unpicklable only loses the size warning
+                continue
             if s > limit:
                 log.warning('Mask factory size %s larger than warning limit %s, may be inefficient'
                             % (s, limit))

@@ -185,3 +185,80 @@ class HipArray:
 
     def __repr__(self):
         return f"<HipArray shape={self.shape} dtype={self.dtype} ld={self.ld} dev={self.device}>"
+
+
+class HostMappedArray(HipArray):
+    """
+    Rows of a page-locked HOST buffer that the kernels write directly over the host link
+    (zero-copy): the final place of small write-once result rows -- no device buffer, no D2H copy,
+    no copy stream; a stream synchronisation makes them readable on the host.
+    `host` is the NumPy view of the rows (storage dtype may be the signed twin of an unsigned
+    dtype), `dev_ptr` the device address of its first byte.
+    """
+    __slots__ = ('_host', '_dev_ptr', '_dev')
+
+    def __init__(self, host, dev_ptr, device, shape, dtype, ld=None):
+        self._t = None
+        self._host = host
+        self._dev_ptr = int(dev_ptr)
+        self._dev = int(device)
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        inner = prod(self.shape[1:]) if len(self.shape) > 0 else 1
+        self.ld = inner if ld is None else int(ld)
+
+    @property
+    def device(self):
+        return self._dev
+
+    def data_ptr(self):
+        return self._dev_ptr
+
+    @property
+    def torch(self):
+        raise TypeError("a host-mapped result array has no device tensor")
+
+    def rows(self, start, stop):
+        start, stop = int(start), int(stop)
+        if not (0 <= start <= stop <= self.shape[0]):
+            raise IndexError(f"rows [{start}, {stop}) out of range for {self.shape}")
+        flat = self._host.reshape(-1)
+        return HostMappedArray(flat[start * self.ld:], self._dev_ptr + start * self.ld *
+                               self.dtype.itemsize, self._dev, (stop - start,) + self.shape[1:],
+                               self.dtype, ld=self.ld)
+
+    def reshape(self, shape):
+        shape = tuple(int(s) for s in shape)
+        if -1 in shape:
+            known = prod(s for s in shape if s != -1)
+            shape = tuple(self.size // known if s == -1 else s for s in shape)
+        if prod(shape) != self.size:
+            raise ValueError(f"cannot reshape {self.shape} to {shape}")
+        if self.is_contiguous or (shape and shape[0] == self.shape[0]):
+            return HostMappedArray(self._host, self._dev_ptr, self._dev, shape, self.dtype,
+                                   ld=None if self.is_contiguous else self.ld)
+        raise ValueError("cannot reshape a row-strided array across its first axis")
+
+    def sig_rows(self, row_start, row_stop):
+        raise TypeError("host-mapped arrays hold result rows, not frames")
+
+    def contiguous(self):
+        if self.is_contiguous:
+            return self
+        raise TypeError("host-mapped result rows are contiguous by construction")
+
+    def cpu(self):
+        """The rows as a NumPy array (a VIEW of the page-locked buffer; the caller must have
+        synchronised the stream the kernels ran on)."""
+        n = self.size
+        host = self._host.reshape(-1)[:n]
+        if host.dtype != self.dtype:
+            host = host.view(self.dtype)
+        return host.reshape(self.shape)
+
+    def fill_(self, value):
+        self.cpu()[...] = value
+        return self
+
+    def __repr__(self):
+        return f"<HostMappedArray shape={self.shape} dtype={self.dtype} ld={self.ld} dev={self._dev}>"

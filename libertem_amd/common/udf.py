@@ -26,8 +26,13 @@ class UDFMethod(Enum):
     PARTITION = 'partition'
 
 
+import os
+
 NUMPY = 'numpy'
 HIP = 'hip'
+#: nav result rows of at most this many bytes are written by the kernels straight into the run's
+#: final (page-locked) host buffer; wider rows are copied out on a copy stream (0: always copy)
+HIP_DIRECT_ROW_MAX = int(os.environ.get('LTMI_DIRECT_ROW_MAX', '512'))
 # names of reference backends that are accepted in `backends=` arguments and ignored
 # (there is no CuPy / sparse-tile support in this build)
 CUPY = 'cupy'

@@ -42,3 +42,12 @@ extern "C" int ltmi_device_info(int device, char *name_out, int *cu_count, int64
     }
     return LTMI_OK;
 }
+
+extern "C" int ltmi_host_device_pointer(int device, void *host, void **dev_out) {
+    if (!host || !dev_out) LTMI_FAIL(LTMI_E_INVALID, "ltmi_host_device_pointer: null argument");
+    LTMI_HIP(hipSetDevice(device));
+    void *d = nullptr;
+    LTMI_HIP(hipHostGetDevicePointer(&d, host, 0));
+    *dev_out = d;
+    return LTMI_OK;
+}

@@ -28,7 +28,8 @@ class Environment:
     """
 
     def __init__(self, threads_per_worker=None, threaded_executor=False, gpu_id=None,
-                 keep_results_on_device=False, stream=None, ensure_current=None, row_sink=None):
+                 keep_results_on_device=False, stream=None, ensure_current=None, row_sink=None,
+                 result_target=None):
         self._threads_per_worker = threads_per_worker
         self._threaded_executor = threaded_executor
         self._gpu_id = gpu_id
@@ -42,6 +43,9 @@ class Environment:
         # callable(udf_index, buffer name, rows: HipArray, global_row_start) or None: finished rows
         # of disjoint nav buffers are copied to the host while later tiles are still computing
         self.row_sink = row_sink
+        # callable(udf_index, buffer name, global_row_start, shape, dtype) -> HipArray | None: rows of
+        # the run's final host buffer that the kernels of a partition may write directly
+        self.result_target = result_target
 
     @property
     def threads_per_worker(self):

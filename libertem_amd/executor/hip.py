@@ -22,13 +22,15 @@ import uuid
 
 import numpy as np
 
-from libertem_amd.common.hiparray import HipArray, torch_dtype_for
+from libertem_amd.common.hiparray import HipArray, HostMappedArray, torch_dtype_for
 from libertem_amd.common.buffers import PlaceholderBufferWrapper
 from libertem_amd.common.backend import get_use_hip
 from .base import JobExecutor, Environment
 
 
 _DIST_MODULE = False          # False: not imported yet; None: torch.distributed unavailable
+
+from libertem_amd.common import udf as _udf_common     # noqa: E402  (HIP_DIRECT_ROW_MAX, read per run)
 
 
 def _dist():
@@ -182,7 +184,8 @@ class HipJobExecutor(JobExecutor):
                            keep_results_on_device=(self.gpu_id is not None), stream=self._stream,
                            ensure_current=(self._make_current if self.gpu_id is not None
                                            else None),
-                           row_sink=getattr(self, '_row_sink', None))
+                           row_sink=getattr(self, '_row_sink', None),
+                           result_target=getattr(self, '_result_target', None))
 
     def scatter(self, obj):
         handle = str(uuid.uuid4())
@@ -245,19 +248,26 @@ class HipJobExecutor(JobExecutor):
             else:
                 plans.append(('generic', None))
 
-        # Streamed export: rows of 'disjoint' nav buffers go to their final place in page-locked host
-        # memory on a copy stream while later tiles / partitions still compute.  Single rank: a
-        # fresh pinned buffer.  Several ranks on one node: a host segment shared by the ranks, every
-        # rank writes ITS rows (no data-path collective, executor/nodeshared.py).
-        streamed = {}                           # (udf index, name) -> [host tensor, rows covered]
-        expected = {}                           # shared mode: rows this rank has to deliver
-        shared_np = {}
+        # Delivery of 'disjoint' nav buffers: every row goes to its final place in page-locked host
+        # memory while the run is still computing -- small write-once rows are written there by the
+        # kernels themselves (zero-copy over the host link: no device buffer, no D2H, no copy
+        # stream), wide rows are copied out tile by tile on a copy stream while later tiles compute.
+        # Single rank: a buffer of the executor's pinned ring.  Several ranks on one node: a host
+        # segment shared by the ranks, every rank delivers ITS rows (no data-path collective,
+        # executor/nodeshared.py).
+        streamed = {}                           # (udf index, name) -> [host tensor, rows copied out]
+        expected = {}                           # rows this rank has to deliver
+        direct = {}                             # (udf index, name) -> rows the kernels wrote directly
+        host_np = {}                            # (udf index, name) -> NumPy view of the final buffer
+        dev_ptrs = {}
         shared = self._node_shared() if not partial else None
-        shared_slot = None
         busy_shared = None
         self._row_sink = None
-        if shared is not None:
-            layout, total = [], 0
+        self._result_target = None
+        sink_on = self.gpu_id is not None and not partial and \
+            (shared is not None or not self._collectives_on)
+        layout, total = [], 0
+        if sink_on:
             for i, (udf, (mode, decl)) in enumerate(zip(udfs, plans)):
                 if mode != 'device':
                     continue
@@ -268,63 +278,64 @@ class HipJobExecutor(JobExecutor):
                     nb = int(np.prod(buf.shape, dtype=np.int64)) * np.dtype(buf.dtype).itemsize
                     layout.append((i, name, tuple(buf.shape), np.dtype(buf.dtype), total, nb))
                     total += (nb + 4095) // 4096 * 4096
-            if layout:
-                from .nodeshared import NodeSharedUnavailable, NodeSharedBusy
-                try:
-                    shared_slot, tens, arr = shared.begin_run(total)
-                except NodeSharedBusy:
-                    # this run only: device collectives (the end-of-run barrier still runs, it
-                    # refreshes the set of free slots)
-                    busy_shared, shared, layout = shared, None, []
-                except NodeSharedUnavailable as e:
-                    self._shared_off = True
-                    import logging
-                    logging.getLogger(__name__).warning("%s -- results go through RCCL", e)
-                    shared, layout = None, []
-                for i, name, shape, dt, off, nb in layout:
-                    tdt = torch_dtype_for(dt)
-                    streamed[(i, name)] = [tens[off:off + nb].view(tdt).reshape(shape), 0]
-                    # views of the run's owner object: they keep the slot reserved, on every rank,
-                    # for as long as the caller references any of them (executor/nodeshared.py)
-                    shared_np[(i, name)] = arr[off:off + nb].view(np.ndarray).view(
-                        np.dtype(str(tdt).replace('torch.', ''))).reshape(shape)
-                    expected[(i, name)] = 0
-                del arr
-            else:
-                shared = None
+        tens = arr = base_dev = None
+        if layout and shared is not None:
+            from .nodeshared import NodeSharedUnavailable, NodeSharedBusy
+            try:
+                _, tens, arr, base_dev = shared.begin_run(total)
+            except NodeSharedBusy:
+                # this run only: device collectives (the end-of-run barrier still runs, it
+                # refreshes the set of free slots)
+                busy_shared, shared, layout = shared, None, []
+            except NodeSharedUnavailable as e:
+                self._shared_off = True
+                import logging
+                logging.getLogger(__name__).warning("%s -- results go through RCCL", e)
+                shared, layout = None, []
+            if shared is None:
+                sink_on = False
+        elif layout:
+            if getattr(self, '_pinned_ring', None) is None:
+                from .pinned import PinnedRing
+                from libertem_amd import hip as _hip
+                self._pinned_ring = PinnedRing(
+                    self._torch, lambda ptr: _hip.host_device_pointer(self.gpu_id, ptr))
+            tens, arr, base_dev = self._pinned_ring.get(total)
+        else:
+            shared = None
+        if layout:
+            DIRECT_ROW_MAX = _udf_common.HIP_DIRECT_ROW_MAX
+            if DIRECT_ROW_MAX <= 0:
+                base_dev = None
+            for i, name, shape, dt, off, nb in layout:
+                tdt = torch_dtype_for(dt)
+                streamed[(i, name)] = [tens[off:off + nb].view(tdt).reshape(shape), 0]
+                # views of the run's owner object: they keep the buffer reserved (on every rank)
+                # for as long as the caller references any of them
+                host_np[(i, name)] = arr[off:off + nb].view(np.ndarray).view(
+                    np.dtype(str(tdt).replace('torch.', ''))).reshape(shape)
+                expected[(i, name)] = 0
+                row_bytes = nb // max(1, shape[0])
+                if base_dev is not None and row_bytes <= DIRECT_ROW_MAX:
+                    direct[(i, name)] = 0
+                    dev_ptrs[(i, name)] = base_dev + off
+            del arr, tens
         self.last_result_via = 'shm' if shared is not None else \
             ('collective' if self._collectives_on else 'local')
-        sink_on = self.gpu_id is not None and not partial and \
-            (shared is not None or not self._collectives_on)
         keepalive = []                          # device rows with a D2H in flight on the copy stream
-        if sink_on:
+        if sink_on and layout:
             import torch as _torch
             if getattr(self, '_copy_stream', None) is None:
                 self._copy_stream = _torch.cuda.Stream(device=self.gpu_id)
             copy_stream = self._copy_stream
-            if shared is None:
-                # single rank: every 'disjoint' device buffer may be streamed; what the sink does
-                # not deliver is built from the partition results kept aside (`deferred`)
-                for i, (udf, (mode, decl)) in enumerate(zip(udfs, plans)):
-                    if mode != 'device':
-                        continue
-                    for name, how in decl.items():
-                        buf = udf.results.get_buffer(name)
-                        if how == 'disjoint' and not isinstance(buf, PlaceholderBufferWrapper):
-                            expected[(i, name)] = 0
 
             def row_sink(i, name, rows, g0):
-                mode, decl = plans[i]
-                buf = udfs[i].results.get_buffer(name)
-                if mode != 'device' or decl.get(name) != 'disjoint' or rows.shape[0] == 0:
-                    return
                 key = (i, name)
-                if key not in expected or not rows.is_contiguous:
+                if key not in expected or key in direct or rows.shape[0] == 0 \
+                        or not rows.is_contiguous:
                     return
-                if key not in streamed:
-                    streamed[key] = [_torch.empty(buf.shape, dtype=torch_dtype_for(buf.dtype),
-                                                  pin_memory=True), 0]
-                host, _ = streamed[key]
+                buf = udfs[i].results.get_buffer(name)
+                host = streamed[key][0]
                 n = rows.shape[0]
                 inner = int(np.prod(buf.shape[1:])) if len(buf.shape) > 1 else 1
                 src = rows.torch.reshape(-1)[:n * inner].reshape((n,) + tuple(buf.shape[1:]))
@@ -338,7 +349,20 @@ class HipJobExecutor(JobExecutor):
                 # next partition while the D2H still reads it
                 keepalive.append(src)
                 streamed[key][1] += n
-            self._row_sink = row_sink
+
+            def result_target(i, name, g0, shape, dtype):
+                key = (i, name)
+                if key not in direct:
+                    return None
+                full = host_np[key]
+                if np.dtype(dtype) != udfs[i].results.get_buffer(name).dtype or \
+                        tuple(shape[1:]) != tuple(full.shape[1:]) or g0 + shape[0] > full.shape[0]:
+                    return None
+                row_bytes = full.strides[0] if full.ndim else full.itemsize
+                return HostMappedArray(full[g0:g0 + shape[0]], dev_ptrs[key] + g0 * row_bytes,
+                                       self.gpu_id, shape, dtype)
+            self._row_sink = row_sink if any(k not in direct for k in expected) else None
+            self._result_target = result_target if direct else None
 
         dev_full = [dict() for _ in udfs]       # per udf: name -> torch tensor (full size)
         deferred = {}                           # shared mode: (udf idx, name) -> [(start, stop, rows)]
@@ -348,17 +372,23 @@ class HipJobExecutor(JobExecutor):
             import torch
         d = self._dist()
 
+        def delivered(key):
+            return streamed[key][1] + direct.get(key, 0)
+
         def publish_device(final):
             """declared device buffers -> host arrays of the main-process udfs"""
             shared_ok = False
-            if sink_on and final:
-                # my rows are out once the copy stream is idle
+            if sink_on and layout and final:
+                # my rows are out once the copy stream (copied rows) and the executor stream (rows
+                # the kernels wrote into the host buffer themselves) are idle
                 self._copy_stream.synchronize()
+                if direct:
+                    self._stream.synchronize()
                 keepalive.clear()
             if shared is not None and final:
-                # every rank of the node says whether all of ITS rows went through the sink
+                # every rank of the node says whether all of ITS rows were delivered
                 # (same answer on every rank)
-                mine = all(streamed[k][1] == expected[k] for k in expected)
+                mine = all(delivered(k) == expected[k] for k in expected)
                 shared_ok = shared.all_ok(mine)
             elif busy_shared is not None and final:
                 busy_shared.all_ok(True)
@@ -369,23 +399,16 @@ class HipJobExecutor(JobExecutor):
                     buf = udf.results.get_buffer(name)
                     if isinstance(buf, PlaceholderBufferWrapper):
                         continue
-                    st = streamed.get((i, name))
-                    if shared is not None:
-                        if shared_ok and (i, name) in shared_np:
-                            host = shared_np[(i, name)]
-                            if host.dtype != buf.dtype:
-                                host = host.view(buf.dtype)
-                            buf.replace_array(host)
-                            continue
-                        st = None                      # fall back to the device collectives
-                    elif st is not None and final and st[1] == buf.shape[0] \
-                            and st[1] == expected.get((i, name)):
-                        # every row already went out through the copy stream
-                        host = st[0].numpy()
+                    key = (i, name)
+                    if key in host_np and final and (
+                            shared_ok if shared is not None else
+                            (delivered(key) == buf.shape[0] == expected.get(key))):
+                        # every row is in its final place already
+                        host = host_np[key]
                         if host.dtype != buf.dtype:
                             host = host.view(buf.dtype)
                         buf.replace_array(host)
-                        deferred.pop((i, name), None)
+                        deferred.pop(key, None)
                         continue
                     self._flush_deferred(udf, i, name, dev_full[i], deferred, keep=not final)
                     full = dev_full[i].get(name)
@@ -400,7 +423,9 @@ class HipJobExecutor(JobExecutor):
                     if host.dtype != buf.dtype:
                         host = host.view(buf.dtype)
                     buf.replace_array(host)
-            shared_np.clear()
+            if final:
+                host_np.clear()
+                streamed.clear()
 
         n_done = 0
         for part_results, task in result_iter:
@@ -409,7 +434,8 @@ class HipJobExecutor(JobExecutor):
                 if mode == 'device':
                     self._merge_on_device(udf, results, task, decl, dev_full[i],
                                           may_adopt=not partial,
-                                          defer=(deferred, i, expected) if sink_on else None)
+                                          defer=(deferred, i, expected, direct)
+                                          if sink_on and layout else None)
                 else:
                     results.export()
                     gen_entry[i] = results
@@ -473,6 +499,7 @@ class HipJobExecutor(JobExecutor):
         if self._stream is not None:
             self._stream.synchronize()
         self._row_sink = None
+        self._result_target = None
         yield n_done
 
     def _to_host(self, t):
@@ -519,28 +546,36 @@ class HipJobExecutor(JobExecutor):
             part = results.get_buffer(name)._data
             if not isinstance(part, HipArray):
                 part = HipArray.from_numpy(np.asarray(part), self.gpu_id)
-            pt = part.torch.reshape(part.shape)
             if defer is not None and how == 'disjoint' and (defer[1], name) in defer[2]:
+                start, stop = buf_main._slice_for_partition(task.partition)
+                defer[2][(defer[1], name)] += stop - start
+                if isinstance(part, HostMappedArray):
+                    # the kernels wrote these rows into the final host buffer themselves
+                    defer[3][(defer[1], name)] += stop - start
+                    continue
                 # rows travel to the host on the copy stream (shared host segment / pinned
                 # buffer); keep the partition result only as the fallback source
-                start, stop = buf_main._slice_for_partition(task.partition)
-                defer[0].setdefault((defer[1], name), []).append((start, stop, pt))
-                defer[2][(defer[1], name)] += stop - start
+                defer[0].setdefault((defer[1], name), []).append(
+                    (start, stop, part.torch.reshape(part.shape)))
                 continue
+            if isinstance(part, HostMappedArray):
+                raise RuntimeError(f"host-mapped result rows of {name!r} outside a streamed delivery")
             if name not in full:
                 if may_adopt and tuple(part.shape) == tuple(buf_main.shape) and \
                         (how == 'disjoint' or how == 'sum'):
                     # first partition covers the whole buffer (always true for 'sum' buffers):
                     # adopt it, no zero-fill, no copy / add
-                    full[name] = pt
+                    full[name] = part.torch.reshape(part.shape)
                     continue
                 full[name] = torch.zeros(buf_main.shape, dtype=torch_dtype_for(buf_main.dtype),
                                          device=f'cuda:{self.gpu_id}')
             if how == 'disjoint':
                 start, stop = buf_main._slice_for_partition(task.partition)
-                full[name][start:stop].copy_(pt.reshape(full[name][start:stop].shape))
+                full[name][start:stop].copy_(
+                    part.torch.reshape(part.shape).reshape(full[name][start:stop].shape))
             elif how == 'sum':
                 dst = full[name]
+                pt = part.torch.reshape(part.shape)
                 if np.dtype(buf_main.dtype) in hip.AXPY_DTYPES and dst.is_contiguous() \
                         and pt.is_contiguous():
                     # dest += src in HBM with the library's own kernel (ltmi_axpy)

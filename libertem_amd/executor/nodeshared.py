@@ -103,12 +103,18 @@ class NodeShared:
         if self.rank == 0:
             arr[:] = 0                                     # also faults the pages in
         self.d.barrier()
-        seg = dict(path=path, mm=mm, np=arr, cap=nbytes, tensor=None, registered=False)
+        seg = dict(path=path, mm=mm, np=arr, cap=nbytes, tensor=None, registered=False, dev=None)
         if register:
             ptr = arr.ctypes.data
             rc = self.torch.cuda.cudart().cudaHostRegister(ptr, nbytes, 0)
             seg['registered'] = int(rc) == 0
             seg['tensor'] = self.torch.from_numpy(arr)
+            if seg['registered']:
+                try:
+                    from libertem_amd import hip
+                    seg['dev'] = hip.host_device_pointer(self.gpu_id, ptr)
+                except Exception:
+                    seg['dev'] = None           # kernels cannot write it: rows are copied out
         return seg
 
     def _unmap(self, seg):
@@ -139,7 +145,8 @@ class NodeShared:
     def begin_run(self, nbytes):
         """Collective (every rank takes the same decisions: they only depend on `common_free`, the
         slot sizes and `nbytes`, which are the same everywhere).  Returns (slot index, uint8 torch
-        tensor over the slot, numpy `_Owner` view of it); raises NodeSharedBusy if no slot is free."""
+        tensor over the slot, numpy `_Owner` view of it, device address of the slot | None);
+        raises NodeSharedBusy if no slot is free."""
         free = [k for k in range(len(self.slots)) if self.common_free >> k & 1]
         if not free:
             if len(self.slots) >= self.K_max:
@@ -162,7 +169,7 @@ class NodeShared:
         owner = seg['np'].view(_Owner)
         self.owners[s] = weakref.ref(owner)
         self.common_free &= ~(1 << s)
-        return s, seg['tensor'], owner
+        return s, seg['tensor'], owner, seg['dev']
 
     def all_ok(self, ok, timeout=120.0):
         """Barrier over the node's ranks that ANDs a flag -- and the sets of slots that nobody

@@ -28,7 +28,7 @@ EXPORTS = (
     'ltmi_version', 'ltmi_last_error', 'ltmi_device_count', 'ltmi_device_info',
     'ltmi_masks_create_dense', 'ltmi_masks_create_csr', 'ltmi_masks_destroy', 'ltmi_masks_kind',
     'ltmi_apply_masks', 'ltmi_apply_masks_shifted', 'ltmi_apply_masks_shifted_host', 'ltmi_sum_frames_workspace', 'ltmi_sum_frames', 'ltmi_sum_sig',
-    'ltmi_axpy', 'ltmi_add2d', 'ltmi_gather_rows', 'ltmi_correct', 'ltmi_repair_pixels', 'ltmi_byteswap', 'ltmi_com_fields', 'ltmi_fft_plan_create',
+    'ltmi_axpy', 'ltmi_add2d', 'ltmi_gather_rows', 'ltmi_host_device_pointer', 'ltmi_correct', 'ltmi_repair_pixels', 'ltmi_byteswap', 'ltmi_com_fields', 'ltmi_fft_plan_create',
     'ltmi_fft_plan_destroy', 'ltmi_crystallinity', 'ltmi_masks_set_tuning',
     'ltmi_masks_last_kernel',
 )
@@ -109,6 +109,7 @@ def lib():
         L.ltmi_axpy.argtypes = [i32, vp, vp, i32, i64, vp]
         L.ltmi_add2d.argtypes = [i32, vp, i64, vp, i64, i32, i64, i64, i32, vp]
         L.ltmi_gather_rows.argtypes = [i32, vp, i64, vp, i64, i64, vp, vp]
+        L.ltmi_host_device_pointer.argtypes = [i32, vp, c.POINTER(vp)]
         L.ltmi_correct.argtypes = [i32, vp, i32, i64, i64, i64, vp, vp, vp, i32, i64, vp]
         L.ltmi_repair_pixels.argtypes = [i32, vp, i32, i64, i64, vp, vp, vp, i32, i32, vp]
         L.ltmi_byteswap.argtypes = [i32, vp, vp, i32, i64, vp]
@@ -305,6 +306,14 @@ def add2d(device, dest_ptr, ld_dest, src_ptr, ld_src, dtype, rows, cols, negate=
     check(lib().ltmi_add2d(int(device), dest_ptr, int(ld_dest), src_ptr, int(ld_src),
                            dtype_code(dtype), int(rows), int(cols), 1 if negate else 0,
                            _stream_ptr(stream)), 'ltmi_add2d')
+
+
+def host_device_pointer(device, host_ptr):
+    """device address of page-locked host memory (raises if it is not device-accessible)"""
+    out = ctypes.c_void_p()
+    check(lib().ltmi_host_device_pointer(int(device), host_ptr, ctypes.byref(out)),
+          'ltmi_host_device_pointer')
+    return int(out.value)
 
 
 def gather_rows(device, src_ptr, ld_src_bytes, idx_ptr, n_rows, row_bytes, dest_ptr, stream=None):

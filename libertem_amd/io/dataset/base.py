@@ -16,6 +16,8 @@ launch per ~1 MiB tile would cost more than the kernel itself (SURVEY.md §7 "la
 import math
 import warnings
 
+import os
+
 import numpy as np
 
 from libertem_amd.common.math import prod
@@ -166,7 +168,8 @@ class Negotiator:
                self.HIP_TILE_BUDGET, self.HIP_STAGING_CHUNK,
                np.dtype(read_dtype).itemsize if corrected else 0, self.HIP_CORRECTED_CHUNK,
                self.HIP_PIPELINE_TILES, self.HIP_PIPELINE_MIN_FRAMES,
-               tuple(getattr(u, 'get_hip_tile_frames', lambda: None)() for u in udfs))
+               tuple(getattr(u, 'get_hip_tile_frames', lambda: None)() for u in udfs),
+               self._results_direct(udfs))
         hit = self._hip_scheme_cache.get(key)
         if hit is None:
             if len(self._hip_scheme_cache) > 64:
@@ -175,6 +178,15 @@ class Negotiator:
                 intent, forced, dataset, approx_partition_shape,
                 np.dtype(read_dtype).itemsize if corrected else 0, udfs)
         return hit
+
+    @staticmethod
+    def _results_direct(udfs):
+        """True iff every UDF of the run has its nav rows written by the kernels straight into
+        the final host buffer (small write-once rows): there is no D2H to overlap, so the
+        partition is NOT split into pipelined tiles -- one launch fills the chip more evenly."""
+        if os.environ.get('LTMI_HIP_PIPELINE_ALWAYS') == '1':       # experiments
+            return False
+        return all(bool(getattr(u, 'get_hip_direct_results', lambda: False)()) for u in udfs)
 
     def _make_scheme_hip(self, intent, forced, dataset, approx_partition_shape,
                          corrected_itemsize=0, udfs=()):
@@ -191,7 +203,8 @@ class Negotiator:
             if dataset.is_device_resident and hints and depth > min(hints):
                 # a UDF with large result rows asks for smaller tiles (more D2H / compute overlap)
                 depth = max(1024, -(-min(hints) // 128) * 128)
-            elif dataset.is_device_resident and depth >= 2 * self.HIP_PIPELINE_MIN_FRAMES:
+            elif dataset.is_device_resident and depth >= 2 * self.HIP_PIPELINE_MIN_FRAMES \
+                    and not self._results_direct(udfs):
                 # a few tiles per partition so that the D2H of finished result rows overlaps the
                 # kernels of the next tile; never fewer frames than fill the chip twice over
                 n_tiles = min(self.HIP_PIPELINE_TILES, depth // self.HIP_PIPELINE_MIN_FRAMES)
@@ -367,6 +380,11 @@ class Partition:
 class DataSet:
     def __init__(self):
         self._meta = None
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop('_udf_plans', None)       # cached run plans (udf/base.py) stay in this process
+        return d
 
     def initialize(self, executor):
         return self

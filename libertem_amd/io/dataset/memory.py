@@ -234,7 +234,7 @@ class MemoryDataSet(DataSet):
         return f"<MemoryDataSet of {self.dtype} shape={self.shape} ({where})>"
 
     def __getstate__(self):
-        d = dict(self.__dict__)
+        d = super().__getstate__()
         if d.get('_device_array') is not None:
             raise TypeError("a device-resident MemoryDataSet cannot be pickled")
         return d

@@ -18,8 +18,11 @@ New relative to the reference: the execution plan knows BACKEND_HIP.  On a HIP w
 lists BACKEND_HIP gets device-resident tiles (`HipArray`, native dtype) and device result buffers;
 there is no silent fallback: a HIP-only UDF on a CPU worker raises `HipRequiredError`.
 """
+import copy
 import uuid
 import threading
+import weakref
+from collections import OrderedDict
 
 import numpy as np
 
@@ -277,13 +280,18 @@ class UDFData:
                     continue
                 yield k, buf
 
-    def allocate_for_part(self, partition, roi, lib=None):
+    def allocate_for_part(self, partition, roi, lib=None, write_once=(), target=None):
         for k, buf in self._get_buffers():
             buf.set_roi(roi)
             buf.set_shape_partition(partition, roi)
         for k, buf in self._get_buffers():
             if not isinstance(buf, AuxBufferWrapper):
-                buf.allocate(lib=lib)
+                if k in write_once:
+                    buf.allocate(lib=lib, write_once=True,
+                                 target=None if target is None else
+                                 (lambda shape, dtype, k=k, buf=buf: target(k, buf, shape, dtype)))
+                else:
+                    buf.allocate(lib=lib)
 
     def allocate_for_full(self, dataset, roi, lazy=False):
         for k, buf in self._get_buffers():
@@ -352,9 +360,18 @@ class UDFBase(UDFProtocol):
     def get_result_buffers(self):
         raise NotImplementedError()
 
-    def allocate_for_part(self, partition, roi):
+    def allocate_for_part(self, partition, roi, target=None):
+        """target: callable(name, buffer, shape, dtype) -> HipArray | None of the executor: where
+        the rows of a write-once nav buffer of THIS partition may be written directly."""
+        once = self.get_write_once_buffers() if self._backend == HIP else ()
         for ns in [self.results]:
-            ns.allocate_for_part(partition, roi, lib=self.xp)
+            ns.allocate_for_part(partition, roi, lib=self.xp, write_once=once, target=target)
+
+    def get_write_once_buffers(self):
+        """Names of where='device' result buffers whose every element process_tile WRITES exactly
+        once in this run (no accumulation over sig slices, untouched by postprocess): they need
+        no zero fill and may live in the run's final host buffer.  Known after set_meta()."""
+        return ()
 
     def allocate_for_full(self, dataset, roi):
         self.params.allocate_for_full(dataset, roi)
@@ -489,6 +506,12 @@ class UDFBase(UDFProtocol):
 
 class UDF(UDFBase):
     """The user-facing base class (udf/base.py:1270-1732)."""
+
+    #: True: the per-partition instance of this UDF (params, meta, task data) may be kept and re-used
+    #: when the SAME udf object runs again on the same dataset (`run_udf` in a loop); every run
+    #: still gets fresh result buffers.  The reference creates a new instance per task
+    #: (udf/base.py:1997-2003); user UDFs keep that behaviour, the native operators opt in.
+    REUSE_TASK_INSTANCES = False
 
     def __init__(self, **kwargs):
         super().__init__()
@@ -690,12 +713,19 @@ class UDFTask:
         self._udf_classes = udf_classes
         self._udf_backends = udf_backends
         self._runner_cls = runner_cls or UDFPartRunner
+        #: per-task state kept between runs of a cached plan (see UDFRunner._plan_for): the
+        #: partition's UDF instances with meta / task data, its device tiles, the sink set-up
+        self._keep = None
 
     def __call__(self, params, env):
+        keep = self._keep
+        if keep is not None and keep.get('udfs') is not None:
+            return self._runner_cls(keep['udfs']).run_for_partition(
+                self.partition, params, env, backend_choice=params.backends, keep=keep)
         udfs = [cls.new_for_partition(kwargs, self.partition, params.roi)
                 for cls, kwargs in zip(self._udf_classes, params.kwargs)]
         return self._runner_cls(udfs).run_for_partition(
-            self.partition, params, env, backend_choice=params.backends)
+            self.partition, params, env, backend_choice=params.backends, keep=keep)
 
     def get_partition(self):
         return self.partition
@@ -724,16 +754,46 @@ class UDFPartRunner:
         self._udfs = udfs
         self._debug = debug
 
-    def run_for_partition(self, partition, params, env, backend_choice=None):
+    def run_for_partition(self, partition, params, env, backend_choice=None, keep=None):
+        """keep: None, or the task's dict of state that survives between runs of a cached plan
+        (only filled when every UDF allows it, `UDF.REUSE_TASK_INSTANCES`)."""
+        if keep is not None and keep.get('udfs') is not None:
+            # same udf objects, dataset, executor as the run that filled `keep`: only the result
+            # buffers are new
+            backend, meta = keep['backend'], keep['meta']
+            with env.enter(enable_gpu=(backend == HIP)):
+                roi = params.roi
+                for i, udf in enumerate(self._udfs):
+                    udf.init_result_buffers()
+                    udf.allocate_for_part(partition, roi,
+                                          target=self._result_target(env, i, partition))
+                    if hasattr(udf, 'preprocess'):
+                        udf.set_views_for_partition(partition)
+                        udf.preprocess()
+                        udf.clear_views()
+                self._run_udfs(partition, params, env, backend, meta, keep=keep)
+                self._wrapup_udfs(partition, backend, env)
+            return self._hand_over_results(kept=True)
         roi = params.roi
         device_class = env.device_class
         ds_backends = partition._ds.array_backends if hasattr(partition, '_ds') else (NUMPY,)
         backend = _execution_plan(self._udfs, ds_backends, device_class, restrict=backend_choice)
         with env.enter(enable_gpu=(backend == HIP)):
             meta = self._init_udfs(partition, params, env, backend)
-            self._run_udfs(partition, params, env, backend, meta)
+            if keep is not None and all(u.REUSE_TASK_INSTANCES for u in self._udfs):
+                keep.update(udfs=self._udfs, backend=backend, meta=meta)
+            self._run_udfs(partition, params, env, backend, meta, keep=keep)
             self._wrapup_udfs(partition, backend, env)
-        return tuple(udf.results for udf in self._udfs)
+        return self._hand_over_results(kept=keep is not None and keep.get('udfs') is not None)
+
+    def _hand_over_results(self, kept):
+        res = tuple(udf.results for udf in self._udfs)
+        if kept:
+            # instances that outlive the run must not keep its result memory alive (rows in the
+            # executor's page-locked ring / the node-shared segment are reserved by references)
+            for udf in self._udfs:
+                udf.results = None
+        return res
 
     def _init_udfs(self, partition, params, env, backend):
         roi = params.roi
@@ -756,11 +816,11 @@ class UDFPartRunner:
             and ts is not None and (ts._debug or {}).get('backend') == HIP and len(ts) == 1
             and all(getattr(u, 'folds_corrections', None) is not None
                     and u.folds_corrections(corr, meta) for u in self._udfs))
-        for udf in self._udfs:
+        for i, udf in enumerate(self._udfs):
             udf.set_backend(backend)
             udf.set_meta(meta)
             udf.init_result_buffers()
-            udf.allocate_for_part(partition, roi)
+            udf.allocate_for_part(partition, roi, target=self._result_target(env, i, partition))
             udf.init_task_data()
             if hasattr(udf, 'preprocess'):
                 udf.set_views_for_partition(partition)
@@ -768,23 +828,52 @@ class UDFPartRunner:
                 udf.clear_views()
         return meta
 
-    def _run_udfs(self, partition, params, env, backend, meta):
+    @staticmethod
+    def _result_target(env, i, partition):
+        rt = getattr(env, 'result_target', None)
+        if rt is None:
+            return None
+
+        def target(name, buf, shape, dtype):
+            if buf.kind != 'nav':
+                return None
+            g0, g1 = buf._slice_for_partition(partition)
+            if g1 - g0 != shape[0]:
+                return None
+            return rt(i, name, g0, tuple(shape), dtype)
+        return target
+
+    def _run_udfs(self, partition, params, env, backend, meta, keep=None):
         tiling_scheme = params.tiling_scheme
-        if backend == HIP and tiling_scheme.intent is not None \
-                and (tiling_scheme._debug or {}).get('backend') != HIP:
-            # the scheme was negotiated for NumPy on the main process; re-negotiate for the device
-            tiling_scheme = Negotiator().get_scheme(
-                udfs=self._udfs, dataset=partition._ds, read_dtype=meta.input_dtype,
-                approx_partition_shape=partition.shape, roi=params.roi,
-                corrections=params.corrections, backend=HIP)
-            meta._tiling_scheme = tiling_scheme
-        tiles = partition.get_tiles(
-            tiling_scheme=tiling_scheme, roi=params.roi, dest_dtype=meta.input_dtype,
-            array_backend=backend, env=env,
-            corrections=None if getattr(meta, 'corrections_folded', False)
-            else params.corrections)
-        methods = [udf.get_method() for udf in self._udfs]
-        partition_udfs = [u for u, m in zip(self._udfs, methods) if m == UDFMethod.PARTITION]
+        methods = keep.get('methods') if keep is not None else None
+        if methods is None:
+            if backend == HIP and tiling_scheme.intent is not None \
+                    and (tiling_scheme._debug or {}).get('backend') != HIP:
+                # the scheme was negotiated for NumPy on the main process; re-negotiate for the device
+                tiling_scheme = Negotiator().get_scheme(
+                    udfs=self._udfs, dataset=partition._ds, read_dtype=meta.input_dtype,
+                    approx_partition_shape=partition.shape, roi=params.roi,
+                    corrections=params.corrections, backend=HIP)
+                meta._tiling_scheme = tiling_scheme
+            methods = [udf.get_method() for udf in self._udfs]
+            if keep is not None and keep.get('udfs') is not None:
+                keep['methods'] = methods
+                keep['scheme'] = tiling_scheme
+        else:
+            tiling_scheme = keep['scheme']
+        tiles = keep.get('tiles') if keep is not None else None
+        if tiles is None:
+            tiles = partition.get_tiles(
+                tiling_scheme=tiling_scheme, roi=params.roi, dest_dtype=meta.input_dtype,
+                array_backend=backend, env=env,
+                corrections=None if getattr(meta, 'corrections_folded', False)
+                else params.corrections)
+            ds = getattr(partition, '_ds', None)
+            if keep is not None and keep.get('udfs') is not None and backend == HIP \
+                    and params.roi is None and params.corrections is None \
+                    and getattr(ds, 'is_device_resident', False):
+                # device-resident frames: the tiles are zero-copy views of HBM, the same every run
+                tiles = keep['tiles'] = list(tiles)
         sink = getattr(env, 'row_sink', None)
         sinkable = None
         if sink is not None and backend == HIP and len(tiling_scheme) == 1:
@@ -799,6 +888,7 @@ class UDFPartRunner:
                 names = [k for k, how in decl.items() if how == 'disjoint']
                 names = [k for k in names if isinstance(udf.results.get_buffer(k), BufferWrapper)
                          and udf.results.get_buffer(k).on_device
+                         and not udf.results.get_buffer(k).host_mapped
                          and udf.results.get_buffer(k).kind == 'nav']
                 if names:
                     sinkable.append((i, udf, names))
@@ -906,10 +996,71 @@ class UDFRunner:
             raise ValueError("roi: incompatible shapes: %s (roi) vs %s (dataset)" % (
                 roi.shape, dataset.shape.nav))
 
+    #: plans kept per dataset (`run_udf` in a loop with the same udf objects)
+    PLAN_CACHE_SIZE = 8
+
+    def _plan_key(self, executor, roi, corrections, backends, dry):
+        """Identity of a run that may re-use the plan of an earlier one: the SAME udf objects with
+        the same parameter objects, on the same executor, no ROI, no corrections.  None: plan afresh."""
+        if roi is not None or corrections is not None or dry:
+            return None
+        parts = []
+        for u in self._udfs:
+            kw = getattr(u, '_kwargs', None)
+            if kw is None:
+                return None
+            vals = []
+            for k, v in kw.items():
+                if isinstance(v, (list, tuple)):
+                    # a list that is mutated in place between runs (mask factories appended or
+                    # replaced) is a different parameter
+                    vals.append((k, id(v), len(v), tuple(id(x) for x in v)))
+                else:
+                    vals.append((k, id(v)))
+            parts.append((id(u), tuple(vals)))
+        return (id(executor), _canonical_backends(backends), tuple(parts))
+
     def _prepare_run_for_dataset(self, dataset, executor, roi, corrections, backends, dry):
+        key = self._plan_key(executor, roi, corrections, backends, dry)
+        plans = None
+        if key is not None:
+            try:
+                plans = dataset.__dict__.setdefault('_udf_plans', OrderedDict())
+            except AttributeError:
+                plans = None
+        hit = plans.get(key) if plans is not None else None
+        if hit is not None and all(a() is b for a, b in zip(hit['udfs'], self._udfs)) \
+                and hit['executor'] is executor:
+            # same udf objects (and parameter objects) as before: planning, negotiation and task
+            # creation are pure functions of them -- only the result buffers are per run
+            plans.move_to_end(key)
+            meta = copy.copy(hit['meta'])
+            for udf in self._udfs:
+                udf.set_meta(meta)
+                udf.init_result_buffers()
+                udf.allocate_for_full(dataset, roi)
+                if hasattr(udf, 'preprocess'):
+                    udf.set_views_for_dataset(dataset)
+                    udf.preprocess()
+            return hit['tasks'], hit['params']
+        tasks, params, meta = self._plan_run(dataset, executor, roi, corrections, backends, dry)
+        if plans is not None:
+            for t in tasks:
+                t._keep = {}
+            # The udf objects are only weakly referenced (they carry the results of their last
+            # run, which must be free to go when the caller drops them); a dead reference never
+            # matches, so a recycled id() cannot produce a false hit.  The parameter objects are
+            # pinned: their id()s are part of the key.
+            plans[key] = dict(udfs=[weakref.ref(u) for u in self._udfs], executor=executor,
+                              tasks=tasks, params=params, meta=meta,
+                              kwargs=[dict(u._kwargs) for u in self._udfs])
+            while len(plans) > self.PLAN_CACHE_SIZE:
+                plans.popitem(last=False)
+        return tasks, params
+
+    def _plan_run(self, dataset, executor, roi, corrections, backends, dry):
         self._check_preconditions(dataset, roi)
         backends = _canonical_backends(backends)
-        env = executor.get_local_env() if hasattr(executor, 'get_local_env') else None
         device_class = executor.device_class
         chosen = _execution_plan(self._udfs, dataset.array_backends, device_class,
                                  restrict=backends)
@@ -936,7 +1087,7 @@ class UDFRunner:
         params = UDFParams.from_udfs(udfs=self._udfs, roi=roi, corrections=corrections,
                                      tiling_scheme=tiling_scheme, backends=backends)
         tasks = [] if dry else list(self._make_udf_tasks(dataset, roi, backends))
-        return tasks, params
+        return tasks, params, meta
 
     def _roi_for_partition(self, roi, partition):
         return roi.reshape(-1)[partition.slice.get(nav_only=True)]

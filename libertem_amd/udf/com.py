@@ -153,6 +153,8 @@ class CoMUDF(UDF):
     curl and regression (kind 'single', (3, 2)).  See udf/com.py:298-376 of the reference.
     """
 
+    REUSE_TASK_INSTANCES = True      # (udf/base.py: per-partition instances kept between runs)
+
     def __init__(self, com_params: CoMParams = CoMParams()):
         super().__init__(com_params=com_params)
 

@@ -78,6 +78,8 @@ class CrystallinityUDF(UDF):
         is None no real-space mask is applied.
     """
 
+    REUSE_TASK_INSTANCES = True      # (udf/base.py: per-partition instances kept between runs)
+
     def __init__(self, rad_in, rad_out, real_center, real_rad, **kwargs):
         super().__init__(rad_in=rad_in, rad_out=rad_out, real_center=real_center,
                          real_rad=real_rad, **kwargs)

@@ -244,6 +244,8 @@ class ApplyMasksUDF(UDF):
         by frame).
     '''
 
+    REUSE_TASK_INSTANCES = True      # (udf/base.py: per-partition instances kept between runs)
+
     def __init__(self, mask_factories, use_torch=True, use_sparse=None, mask_count=None,
                  mask_dtype=None, preferred_dtype=None, backends=None, shifts=None, **kwargs):
         _backends = backends
@@ -318,6 +320,17 @@ class ApplyMasksUDF(UDF):
             return None
         return 16384 if sparse and count * 4 >= 1024 else None
 
+    def get_hip_direct_results(self):
+        """Tiling hint: result rows small enough to be written straight into the final host buffer
+        (common/udf.py HIP_DIRECT_ROW_MAX) -> no pipelined tiles needed (io/dataset/base.py)."""
+        from libertem_amd.common import udf as udf_common
+        try:
+            dtype = np.result_type(self.meta.input_dtype, self.get_mask_dtype())
+            return int(self.get_mask_count()) * np.dtype(dtype).itemsize <= \
+                udf_common.HIP_DIRECT_ROW_MAX
+        except Exception:
+            return False
+
     def get_task_data(self):
         engine = ApplyMasksEngine(self.masks, self.meta, self.params.use_torch)
         if getattr(self.meta, 'corrections_folded', False):
@@ -343,16 +356,29 @@ class ApplyMasksUDF(UDF):
         """nav-kind, default merge: disjoint row ranges per partition."""
         return {'intensity': 'disjoint'}
 
+    def get_write_once_buffers(self):
+        """Tiles of whole frames (the MI355X tiling policy): every result row is produced by ONE
+        kernel call, `=` instead of `+=` -- no zero fill, and the rows may be written straight
+        into the run's final host buffer.  (Not with a folded dark frame: its constant is
+        subtracted in a second pass over the rows.)"""
+        ts = self.meta.tiling_scheme if self.meta is not None else None
+        if ts is None or len(ts) != 1 or getattr(self.meta, 'corrections_folded', False):
+            return ()
+        return ('intensity',)
+
     def process_tile(self, tile):
         shifts = self.params.get('shifts')
+        accumulate = not self.results.get_buffer('intensity').write_once
         if shifts is None:
-            # fused: results.intensity[:] += tile.reshape(n, -1).astype(input_dtype) @ masks
-            self.task_data.engine.process_tile(tile, out=self.results.intensity, accumulate=True)
+            # fused: results.intensity[:] (+)= tile.reshape(n, -1).astype(input_dtype) @ masks
+            self.task_data.engine.process_tile(tile, out=self.results.intensity,
+                                               accumulate=accumulate)
             return
         n = tile.shape[0]
         sh = np.asarray(shifts)
         if sh.ndim == 1:                       # constant (y, x) shift
             sh = np.broadcast_to(sh.astype(int), (n, 2))
         self.task_data.engine.process_tile_shifted(tile, sh.astype(int),
-                                                   out=self.results.intensity, accumulate=True)
+                                                   out=self.results.intensity,
+                                                   accumulate=accumulate)
 

@@ -20,6 +20,8 @@ class SumUDF(UDF):
         `numpy.result_type(dtype, dataset dtype)` (udf/sum.py:11-17, :38-40).
     """
 
+    REUSE_TASK_INSTANCES = True      # (udf/base.py: per-partition instances kept between runs)
+
     def __init__(self, dtype='float32'):
         super().__init__(dtype=dtype)
 

@@ -11,6 +11,8 @@ from libertem_amd.udf.base import UDF
 
 
 class SumSigUDF(UDF):
+    REUSE_TASK_INSTANCES = True      # (udf/base.py: per-partition instances kept between runs)
+
     def get_backends(self):
         return (self.BACKEND_HIP,)
 
@@ -48,14 +50,26 @@ class SumSigUDF(UDF):
         if out.dtype.kind != 'f':
             raise NotImplementedError(f"SumSigUDF: result dtype {out.dtype} not supported yet")
         n = tile.shape[0]
+        accumulate = not self.results.get_buffer('intensity').write_once
         if self.task_data.engine is not None:
-            self.task_data.engine.process_tile(tile, out=out.reshape((n, 1)), accumulate=True)
+            self.task_data.engine.process_tile(tile, out=out.reshape((n, 1)), accumulate=accumulate)
             return
         hip.sum_sig(tile.device, tile.data_ptr(), tile.dtype, n, prod(tile.shape[1:]), tile.ld,
-                    out.data_ptr(), out.dtype, True)
+                    out.data_ptr(), out.dtype, accumulate, stream=self.meta.stream_ptr)
+
+    def get_write_once_buffers(self):
+        """whole-frame tiles: one kernel call per row (see ApplyMasksUDF.get_write_once_buffers)"""
+        ts = self.meta.tiling_scheme if self.meta is not None else None
+        if ts is None or len(ts) != 1 or getattr(self.meta, 'corrections_folded', False):
+            return ()
+        return ('intensity',)
 
     def get_dist_merge(self):
         return {'intensity': 'disjoint'}
+
+    def get_hip_direct_results(self):
+        from libertem_amd.common import udf as udf_common
+        return udf_common.HIP_DIRECT_ROW_MAX >= 8
 
 
 _ONES = {}

@@ -55,7 +55,14 @@ def main():
     out['sh_slots'] = np.array(len(ex._node_shared().slots))
     # every slot held (ring limit 6 in this test): the run falls back to the collectives and the
     # held results stay untouched
-    held = [ctx.run_udf(dataset=ds, udf=SumSigUDF())['intensity'].data for _ in range(8)]
+    held = []
+    for _ in range(8):
+        held.append(ctx.run_udf(dataset=ds, udf=SumSigUDF())['intensity'].data)
+        if os.environ.get('LTMI_TEST_DEBUG'):
+            sh = ex._node_shared()
+            print(rank, 'held', len(held), 'via', ex.last_result_via, 'slots', len(sh.slots),
+                  'common_free', bin(sh.common_free), 'local_free', bin(sh._local_free()),
+                  'base', type(held[-1].base), flush=True)
     out['sh_held_equal'] = np.array(all(np.array_equal(h, held[0]) for h in held))
     out['sh_via_when_full'] = np.array(ex.last_result_via)
     del held

@@ -696,3 +696,49 @@ def test_fold_corrections_into_masks_identity():
                            out_dtype=np.float64)
     np.testing.assert_allclose(x @ folded.T, corrected @ m.T, rtol=1e-12)
     assert const is None
+
+
+_COUNT_UDF_MADE = []
+
+
+class CountUDF(UDF):
+    def __init__(self, scale=1.0, tags=None):
+        super().__init__(scale=scale, tags=tags)
+        _COUNT_UDF_MADE.append(self)
+
+    def get_result_buffers(self):
+        return {'s': self.buffer(kind='nav', dtype=np.float64)}
+
+    def process_tile(self, tile):
+        self.results.s[:] += self.params.scale * tile.reshape((tile.shape[0], -1)).sum(axis=1) \
+            + (len(self.params.tags) if self.params.tags is not None else 0)
+
+
+def test_plan_cache_reuses_planning_not_user_udf_instances(ctx):
+    """`run_udf` in a loop with the same udf object re-uses the plan (tasks, tiling scheme) kept on
+    the dataset; user UDFs still get a NEW instance per task (reference udf/base.py:1997-2003), and
+    mutated parameters / a different udf object plan afresh."""
+    made = _COUNT_UDF_MADE
+    del made[:]
+    data = np.random.default_rng(1).random((4, 5, 8, 8)).astype(np.float32)
+    ds = ctx.load('memory', data=data, num_partitions=3, sig_dims=2)
+    tags = [1, 2]
+    udf = CountUDF(scale=2.0, tags=tags)
+    expect = 2.0 * data.reshape((4, 5, -1)).sum(axis=-1, dtype=np.float64)
+    a = ctx.run_udf(dataset=ds, udf=udf)['s'].data
+    n_after_first = len(made)
+    plans = ds.__dict__['_udf_plans']
+    assert len(plans) == 1
+    tasks_first = next(iter(plans.values()))['tasks']
+    b = ctx.run_udf(dataset=ds, udf=udf)['s'].data
+    assert len(plans) == 1 and next(iter(plans.values()))['tasks'] is tasks_first     # plan hit
+    assert len(made) == n_after_first + 3                 # ... but 3 new task instances
+    assert np.allclose(a, expect + 2) and np.array_equal(a, b)
+    tags.append(3)                                        # list parameter mutated in place
+    c = ctx.run_udf(dataset=ds, udf=udf)['s'].data
+    assert len(plans) == 2 and np.allclose(c, expect + 3)
+    roi = np.zeros((4, 5), dtype=bool)
+    roi[1] = True
+    d = ctx.run_udf(dataset=ds, udf=udf, roi=roi)['s']
+    assert len(plans) == 2                                # ROI runs are never cached
+    assert np.allclose(d.raw_data, (expect + 3)[roi])

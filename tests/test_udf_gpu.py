@@ -378,6 +378,33 @@ def test_mask_cache_reuse_and_eviction(ctx):
     assert np.array_equal(a, c)
 
 
+def test_run_udf_loop_reuses_plan_and_follows_mutated_factories(ctx):
+    """The same ApplyMasksUDF object run again re-uses plan, per-partition instances and device
+    tiles; a factories LIST mutated in place is a new stack (the reference re-evaluates the
+    factories every run, common/container.py:260-314); results stay caller-owned arrays."""
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    rng = np.random.default_rng(31)
+    data = rng.integers(0, 500, (6, 7, 32, 32)).astype(np.uint16)
+    m = [rng.random((32, 32)).astype(np.float32) for _ in range(3)]
+    factories = [lambda: m[0], lambda: m[1]]
+    ds = _device_ds(ctx, data, 2)
+    udf = ApplyMasksUDF(mask_factories=factories)
+    keep = []
+    for rep in range(4):
+        r = ctx.run_udf(dataset=ds, udf=udf)['intensity'].data
+        keep.append(r)
+        assert r.shape == (6, 7, 2)
+        assert _close(r, opath.apply_masks(data, np.stack(m[:2]), num_partitions=2), F32_TOL)
+    assert all(np.array_equal(k, keep[0]) for k in keep)          # earlier results untouched
+    assert len({k.ctypes.data for k in keep}) == 4                # ... and in their own memory
+    plans = ds.__dict__['_udf_plans']
+    assert len(plans) == 1 and next(iter(plans.values()))['tasks'][0]._keep.get('tiles')
+    factories.append(lambda: m[2])
+    r3 = ctx.run_udf(dataset=ds, udf=udf)['intensity'].data
+    assert r3.shape == (6, 7, 3)
+    assert _close(r3, opath.apply_masks(data, np.stack(m), num_partitions=2), F32_TOL)
+
+
 def test_sparse_masks_through_udf(ctx):
     """use_sparse variants (reference tests/analysis/test_analysis_masks.py:278-446)."""
     import scipy.sparse as sp
@@ -1055,10 +1082,15 @@ def test_shifted_masks_with_roi_and_partitions(ctx):
         assert np.all(np.isnan(part.data[~roi]))
 
 
-def test_streamed_export_with_several_tiles(ctx):
+@pytest.mark.parametrize('direct_row_max', [0, 512])
+def test_streamed_export_with_several_tiles(ctx, direct_row_max, monkeypatch):
     """Device-resident partitions split into tiles (pipelining policy) with the finished rows
-    exported through the copy stream: dense, sparse and per-frame-sum results, ROI, 2 partitions."""
+    exported through the copy stream (direct_row_max = 0), or -- small write-once rows -- written by
+    the kernels straight into the final page-locked host buffer, one launch per partition
+    (direct_row_max = 512): dense and per-frame-sum results, ROI, 2 partitions."""
     from libertem_amd.io.dataset.base import Negotiator
+    from libertem_amd.common import udf as udf_common
+    monkeypatch.setattr(udf_common, 'HIP_DIRECT_ROW_MAX', direct_row_max)
     from libertem_amd.udf.masks import ApplyMasksUDF
     from libertem_amd.udf.sumsigudf import SumSigUDF
     from libertem_amd import hip
@@ -1074,7 +1106,10 @@ def test_streamed_export_with_several_tiles(ctx):
         res = ctx.run_udf(dataset=ds, udf=[ApplyMasksUDF(mask_factories=lambda: masks),
                                            SumSigUDF()])
         launches = hip.KernelTimer.stop()
-        assert len(launches) >= 4, launches            # 2 partitions x >= 2 tiles
+        if direct_row_max == 0:
+            assert len(launches) >= 4, launches        # 2 partitions x >= 2 tiles
+        else:
+            assert len(launches) == 2, launches        # no D2H to overlap: one launch per partition
         ref = opath.apply_masks(data, masks, num_partitions=2)
         assert _close(res[0]['intensity'].data, ref, F32_TOL)
         assert np.array_equal(res[1]['intensity'].data,
