@@ -436,8 +436,11 @@ void *bell_build(const int64_t *indptr, const int64_t *indices, const float *val
                         for (int blk = 0; blk < nb; ++blk)
                             for (int l = 0; l < 64; ++l) {
                                 const int c0 = blk * 8 + (l >> 4), c1 = c0 + 4;
-                                const uint32_t p0 = c0 < (int)cols.size() ? cols[c0] : 0;
-                                const uint32_t p1 = c1 < (int)cols.size() ? cols[c1] : 0;
+                                // padding columns (value 0) repeat the block's first pixel rather
+                                // than pixel 0 of the chunk: a non-finite pixel then only reaches
+                                // blocks that really contain it (0 * NaN = NaN)
+                                const uint32_t p0 = c0 < (int)cols.size() ? cols[c0] : cols[blk * 8];
+                                const uint32_t p1 = c1 < (int)cols.size() ? cols[c1] : cols[blk * 8];
                                 stream[base + (size_t)blk * BE_REC + l * 3 + 2] = p0 | (p1 << 16);
                             }
                         size_t ci = 0;

@@ -124,6 +124,11 @@ k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
     if (frame > n_frames - 1) frame = n_frames - 1;
     const T *row = tile + frame * ld;
 
+    // padding entries of the image (value 0) point at pixel row SP_P, which is all zeros: a
+    // non-finite pixel of a frame only reaches the masks that really contain it, like in the
+    // reference's CSR loop (0 * NaN would be NaN)
+    if (tid < SP_F) slab[SP_P * SP_F + tid] = 0.f;
+
     float acc[MPT][SP_F][NC];
 #pragma unroll
     for (int i = 0; i < MPT; ++i)
@@ -246,7 +251,8 @@ static int launch_sell(ltmi_masks *m, CsrImage *c, const T *tile, int64_t n_fram
     const char *abl = getenv("LTMI_SELL_ABLATE");     // 1: loader only, 2: gathers only (bench)
     const int ablate = abl ? atoi(abl) : 0;
     dim3 grid((unsigned)((n_frames + SP_F - 1) / SP_F), (unsigned)c->n_pass);
-    const size_t lds = (size_t)SP_P * SP_F * sizeof(float);
+    // + one all-zero pixel row (index SP_P) for the padding entries of the image
+    const size_t lds = (size_t)(SP_P + 1) * SP_F * sizeof(float);
     if (c->cplx) {
         auto kern = k_sell_apply<T, 2, true>;
         static bool set[16] = {false};
@@ -393,7 +399,8 @@ extern "C" int ltmi_masks_create_csr(int device, const int64_t *indptr, const in
             for (int ai = active_off[ps]; ai < active_off[ps + 1]; ++ai)
                 ai_of[(size_t)ps * c->n_chunks + active[ai]] = ai;
         if (active.empty()) active.push_back(0);
-        std::vector<uint32_t> pix((rows + 4 * SP_U) * 64, 0u);     // + slack for clamped prefetch
+        // (padding entries and the prefetch slack: the zero pixel row SP_P, value 0)
+        std::vector<uint32_t> pix((rows + 4 * SP_U) * 64, (uint32_t)SP_P);
         std::vector<float> val((rows + 4 * SP_U) * 64 * nc, 0.f);
         std::vector<int> fill((size_t)c->n_chunks * n_masks, 0);
         for (int64_t p = 0; p < n_px; ++p) {

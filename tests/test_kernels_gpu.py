@@ -458,6 +458,55 @@ def test_sell_ring_stack_vs_oracle(hip, sparse_kernel):
     assert np.allclose(res, np.asarray(ref64), rtol=1e-5, atol=1e-5 * np.abs(ref64).max())
 
 
+def test_sparse_non_finite_pixels(hip, sparse_kernel):
+    """NaN / Inf pixels (float32 frames) and the zero entries the device images are padded with.
+    The reference's CSR loop only touches stored entries (common/numba/__init__.py:153-184): a
+    non-finite pixel reaches exactly the masks that contain it.
+    * pixels NO mask contains: no effect at all -- both kernels (the padding entries used to
+      multiply pixel 0 of a chunk; now the gather kernel's padding reads an all-zero LDS row and the
+      blocked image pads a block with one of its own pixels);
+    * a pixel some masks contain: those masks are NaN like in the reference; the gather kernel
+      leaves every other mask finite, the blocked image (dense 16-mask x 8-pixel blocks on the
+      matrix cores) may also poison the other masks of the 16-mask groups whose blocks hold that
+      pixel -- documented divergence."""
+    import scipy.sparse as sp
+    from oracle import masks as omasks
+    rings = omasks.radial_bins(32, 32, 64, 64, radius=20, n_bins=64, use_sparse=True,
+                               dtype=np.float32)                  # (64, 4096) csr, r <= 20 px only
+    csr = sp.csr_matrix(rings.T.astype(np.float32))
+    touched = np.asarray((rings != 0).sum(axis=0)).reshape(-1) > 0
+    assert touched.sum() < 2000 and not touched[0] and not touched[1024]
+    rng = np.random.default_rng(77)
+    clean = rng.random((24, 4096)).astype(np.float32)
+    ref = opath.rmatmul(clean, csr)
+    base, kern = _apply_csr(hip, clean, csr, np.float32)
+    _check_sparse_kernel(kern, sparse_kernel, 4096, 4)
+    assert np.allclose(base, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+    dirty = clean.copy()
+    dirty[:, ~touched] = np.nan                 # incl. pixel 0 of every chunk
+    dirty[3, ~touched] = np.inf
+    res, _ = _apply_csr(hip, dirty, csr, np.float32)
+    assert np.all(np.isfinite(res)) and np.array_equal(res, base)
+    # one touched pixel of frame 5
+    p = int(np.flatnonzero(touched)[200])
+    dirty = clean.copy()
+    dirty[5, p] = np.nan
+    ref2 = opath.rmatmul(dirty, csr)
+    res2, _ = _apply_csr(hip, dirty, csr, np.float32)
+    has_p = np.asarray(rings[:, p].todense()).reshape(-1) != 0
+    assert np.all(np.isnan(ref2[5, has_p])) and np.all(np.isfinite(ref2[5, ~has_p]))
+    assert np.all(np.isnan(res2[5, has_p]))
+    other = np.arange(24) != 5
+    assert np.array_equal(res2[other], base[other])              # other frames untouched
+    if sparse_kernel == 'sell':
+        assert np.array_equal(np.isnan(res2), np.isnan(ref2))    # exactly the reference's NaNs
+    else:
+        groups = np.unique(np.flatnonzero(has_p) // 16)           # 16-mask groups holding p
+        allowed = np.isin(np.arange(64) // 16, groups)
+        assert np.all(np.isfinite(res2[5, ~allowed]))
+        assert np.allclose(res2[5, ~allowed], base[5, ~allowed], rtol=1e-6)
+
+
 def test_sparse_dispatch_by_padding_factor(hip, monkeypatch):
     """Without forcing: localised stacks (rings) take the blocked image, scattered ones the SELL kernel."""
     import scipy.sparse as sp
