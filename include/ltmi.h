@@ -211,6 +211,18 @@ int ltmi_fft_plan_destroy(ltmi_fft_plan *p);
 int ltmi_crystallinity(ltmi_fft_plan *p, const void *tile, int tile_dtype, int64_t n_frames,
                        int64_t ld_tile, const float *real_mask, const float *half_mask, int row_lo,
                        int row_hi, int n_cols, float *out, int accumulate, void *stream);
+/* The same on RAW frames with the detector corrections fused into the conversion pass (reference:
+ * CorrectionSet.apply inside the tile read, src/libertem/io/corrections/detector.py:17-101, then
+ * udf/crystallinity.py:73-79): v = (float)(((double)x - dark) * gain), every excluded pixel = mean
+ * of its good neighbours' corrected values; no corrected copy of the tile is written.
+ * dark / gain: device float64 (sig_h*sig_w) or NULL; excl (n_excl), env (n_excl, max_env),
+ * cnt (n_excl): device int32 repair tables as for ltmi_repair_pixels (n_excl = 0: none). */
+int ltmi_crystallinity_corrected(ltmi_fft_plan *p, const void *tile, int tile_dtype,
+                                 int64_t n_frames, int64_t ld_tile, const double *dark,
+                                 const double *gain, const int32_t *excl, const int32_t *env,
+                                 const int32_t *cnt, int n_excl, int max_env,
+                                 const float *real_mask, const float *half_mask, int row_lo,
+                                 int row_hi, int n_cols, float *out, int accumulate, void *stream);
 
 /* ---- tuning / introspection (bench + tests) ------------------------------------------- */
 /* force a kernel variant for the dense MFMA path (bench / tests only; (0,0,0) = automatic):

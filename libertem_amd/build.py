@@ -2,6 +2,8 @@
 Build libltmi.so (the C-ABI HIP library) for gfx950 with hipcc, in-tree.
 
     python -m libertem_amd.build [--force]
+    python -m libertem_amd.build --asan      # host side instrumented with AddressSanitizer ->
+                                             # libertem_amd/_lib/libltmi_asan.so
 
 hipcc cross-compiles without a GPU.  The result lands in libertem_amd/_lib/libltmi.so, which is
 git-ignored but travels to the GPU box with the repo snapshot.
@@ -46,16 +48,24 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, asan=False):
+    """asan=True: the HOST code of the library (image builders, argument checks, the C ABI) compiled
+    with -fsanitize=address into libltmi_asan.so (device code unchanged).  Load it with
+    LTMI_LIB=<path> and LD_PRELOAD=$(hipcc -print-file-name=libclang_rt.asan-x86_64.so), e.g.
+        LTMI_LIB=libertem_amd/_lib/libltmi_asan.so LD_PRELOAD=... ASAN_OPTIONS=detect_leaks=0 \
+            python -m pytest tests -m gpu -k kernels"""
     hipcc = find_hipcc()
-    os.makedirs(OBJDIR, exist_ok=True)
+    objdir = OBJDIR + ('_asan' if asan else '')
+    lib = LIB.replace('libltmi.so', 'libltmi_asan.so') if asan else LIB
+    extra = ['-fsanitize=address', '-fno-omit-frame-pointer', '-g', '-shared-libsan'] if asan else []
+    os.makedirs(objdir, exist_ok=True)
     jobs = []
     objs = []
     for src in SOURCES:
-        obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + '.o')
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + '.o')
         objs.append(obj)
         if force or _stale(obj, _deps(src)):
-            cmd = [hipcc] + FLAGS + ['-x', 'hip', '-c', os.path.join(CSRC, src), '-o', obj]
+            cmd = [hipcc] + FLAGS + extra + ['-x', 'hip', '-c', os.path.join(CSRC, src), '-o', obj]
             jobs.append(cmd)
 
     def run(cmd):
@@ -70,10 +80,11 @@ def build(force=False, verbose=True):
         for out in ex.map(run, jobs):
             if verbose and out.strip():
                 print(out)
-    if force or jobs or not os.path.exists(LIB):
-        run([hipcc, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', LIB] + objs + LINK_LIBS)
-    return LIB
+    if force or jobs or not os.path.exists(lib):
+        run([hipcc, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', lib] + extra + objs
+            + LINK_LIBS)
+    return lib
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv))
+    print(build(force='--force' in sys.argv, asan='--asan' in sys.argv))

@@ -41,10 +41,14 @@ static const char *fft_err(hipfftResult r) {
 
 // frames (native dtype, ld elements apart) -> contiguous f32, times the optional real-space mask.
 // A thread converts 8 consecutive pixels (one 16-B load for 2-byte pixels, two 16-B stores).
+// With dark / gain (detector corrections fused, reference io/corrections/detector.py:17-101):
+// v = (float)(((double)x - dark) * gain), the arithmetic of ltmi_correct with a float32 result, in
+// the same pass; the dead-pixel patches follow in k_fft_repair.
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_fft_prepare(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
-              const float *__restrict__ real_mask, float *__restrict__ out, int vec_ok) {
+              const float *__restrict__ real_mask, float *__restrict__ out, int vec_ok,
+              const double *__restrict__ dark, const double *__restrict__ gain) {
     const int64_t f = blockIdx.y;
     const T *src = tile + f * ld;
     float *dst = out + f * n_px;
@@ -54,8 +58,17 @@ k_fft_prepare(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t 
         typedef T __attribute__((ext_vector_type(8))) vec_t;
         *(vec_t *)raw = __builtin_nontemporal_load((const vec_t *)(src + i * 8));
         float v[8];
+        if (dark || gain) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (float)raw[j];
+            for (int j = 0; j < 8; ++j) {
+                const double d = dark ? dark[i * 8 + j] : 0.0;
+                const double g = gain ? gain[i * 8 + j] : 1.0;
+                v[j] = (float)(((double)raw[j] - d) * g);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)raw[j];
+        }
         if (real_mask) {
             const float4 m0 = *(const float4 *)(real_mask + i * 8);
             const float4 m1 = *(const float4 *)(real_mask + i * 8 + 4);
@@ -67,10 +80,41 @@ k_fft_prepare(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t 
     }
     for (int64_t p = n8 * 8 + (int64_t)blockIdx.x * 256 + threadIdx.x; p < n_px;
          p += (int64_t)gridDim.x * 256) {
-        float v = (float)src[p];
+        float v = (dark || gain)
+                      ? (float)(((double)src[p] - (dark ? dark[p] : 0.0)) * (gain ? gain[p] : 1.0))
+                      : (float)src[p];
         if (real_mask) v *= real_mask[p];
         dst[p] = v;
     }
+}
+
+// Dead pixels: buf[f, e] = mean over the good neighbours of e of the CORRECTED pixel, times the
+// real-space mask at e -- recomputed from the raw tile (<= max_env pixels per patch), so that the
+// prepare pass needs no second sweep over the frames.  One thread per (frame, excluded pixel).
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_fft_repair(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
+             const double *__restrict__ dark, const double *__restrict__ gain,
+             const float *__restrict__ real_mask, const int32_t *__restrict__ excl,
+             const int32_t *__restrict__ env, const int32_t *__restrict__ cnt, int n_excl,
+             int max_env, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_frames * n_excl) return;
+    const int64_t f = i / n_excl;
+    const int e = (int)(i % n_excl);
+    const int c = cnt[e];
+    if (c <= 0) return;
+    const T *src = tile + f * ld;
+    double acc = 0.0;
+    for (int j = 0; j < c; ++j) {
+        const int r = env[(int64_t)e * max_env + j];
+        // the neighbour as the float32 value the corrected tile holds (ltmi_correct rounds once)
+        acc += (double)(float)(((double)src[r] - (dark ? dark[r] : 0.0)) * (gain ? gain[r] : 1.0));
+    }
+    float v = (float)(acc / (double)c);
+    const int p = excl[e];
+    if (real_mask) v *= real_mask[p];
+    out[f * n_px + p] = v;
 }
 
 // out[f] (+)= sum_k |spec[f, k]| * mask[k] over the rows [0, row_lo) and [row_hi, h) and the columns
@@ -103,14 +147,26 @@ k_abs_dot(const hipfftComplex *__restrict__ spec, int h, int wc, const float *__
     }
 }
 
+struct FftCorr {                   // detector corrections fused into the prepare pass (all optional)
+    const double *dark = nullptr, *gain = nullptr;
+    const int32_t *excl = nullptr, *env = nullptr, *cnt = nullptr;
+    int n_excl = 0, max_env = 0;
+};
+
 template <typename T>
 static int run_prepare(const void *tile, int64_t ld, int64_t n, int64_t n_px, const float *real_mask,
-                       float *out, hipStream_t stream) {
+                       float *out, hipStream_t stream, const FftCorr &corr) {
     const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_px / 8 + 255) / 256, 32));
     const int vec_ok = (sizeof(T) <= 4) && ((uintptr_t)tile % 16 == 0) &&
                        ((ld * (int64_t)sizeof(T)) % 16 == 0) && (n_px % 8 == 0);
     hipLaunchKernelGGL((k_fft_prepare<T>), dim3(gx, (unsigned)n), dim3(256), 0, stream,
-                       (const T *)tile, ld, n, n_px, real_mask, out, vec_ok);
+                       (const T *)tile, ld, n, n_px, real_mask, out, vec_ok, corr.dark, corr.gain);
+    if (corr.n_excl > 0) {
+        const int64_t nt = n * corr.n_excl;
+        hipLaunchKernelGGL((k_fft_repair<T>), dim3((unsigned)((nt + 255) / 256)), dim3(256), 0,
+                           stream, (const T *)tile, ld, n, n_px, corr.dark, corr.gain, real_mask,
+                           corr.excl, corr.env, corr.cnt, corr.n_excl, corr.max_env, out);
+    }
     LTMI_HIP(hipGetLastError());
     return LTMI_OK;
 }
@@ -165,10 +221,42 @@ extern "C" int ltmi_fft_plan_destroy(ltmi_fft_plan *p) {
     return LTMI_OK;
 }
 
+static int crystallinity_impl(ltmi_fft_plan *p, const void *tile, int tile_dtype,
+                              int64_t n_frames, int64_t ld_tile, const float *real_mask,
+                              const float *half_mask, int row_lo, int row_hi, int n_cols,
+                              float *out, int accumulate, void *stream_, const FftCorr &corr);
+
 extern "C" int ltmi_crystallinity(ltmi_fft_plan *p, const void *tile, int tile_dtype,
                                   int64_t n_frames, int64_t ld_tile, const float *real_mask,
                                   const float *half_mask, int row_lo, int row_hi, int n_cols,
                                   float *out, int accumulate, void *stream_) {
+    return crystallinity_impl(p, tile, tile_dtype, n_frames, ld_tile, real_mask, half_mask, row_lo,
+                              row_hi, n_cols, out, accumulate, stream_, FftCorr());
+}
+
+extern "C" int ltmi_crystallinity_corrected(
+    ltmi_fft_plan *p, const void *tile, int tile_dtype, int64_t n_frames, int64_t ld_tile,
+    const double *dark, const double *gain, const int32_t *excl, const int32_t *env,
+    const int32_t *cnt, int n_excl, int max_env, const float *real_mask, const float *half_mask,
+    int row_lo, int row_hi, int n_cols, float *out, int accumulate, void *stream_) {
+    if (n_excl < 0 || max_env < 0 || (n_excl > 0 && (!excl || !env || !cnt)))
+        LTMI_FAIL(LTMI_E_INVALID, "ltmi_crystallinity_corrected: bad repair tables");
+    FftCorr corr;
+    corr.dark = dark;
+    corr.gain = gain;
+    corr.excl = excl;
+    corr.env = env;
+    corr.cnt = cnt;
+    corr.n_excl = n_excl;
+    corr.max_env = max_env;
+    return crystallinity_impl(p, tile, tile_dtype, n_frames, ld_tile, real_mask, half_mask, row_lo,
+                              row_hi, n_cols, out, accumulate, stream_, corr);
+}
+
+static int crystallinity_impl(ltmi_fft_plan *p, const void *tile, int tile_dtype,
+                              int64_t n_frames, int64_t ld_tile, const float *real_mask,
+                              const float *half_mask, int row_lo, int row_hi, int n_cols,
+                              float *out, int accumulate, void *stream_, const FftCorr &corr) {
     if (!p) LTMI_FAIL(LTMI_E_INVALID, "ltmi_crystallinity: null plan");
     if (n_frames < 0) LTMI_FAIL(LTMI_E_SHAPE, "ltmi_crystallinity: negative frame count");
     if (n_frames == 0) return LTMI_OK;
@@ -193,14 +281,14 @@ extern "C" int ltmi_crystallinity(ltmi_fft_plan *p, const void *tile, int tile_d
         int rc = LTMI_E_DTYPE;
         switch (tile_dtype) {
             case LTMI_BOOL:
-            case LTMI_U8: rc = run_prepare<uint8_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream); break;
-            case LTMI_I8: rc = run_prepare<int8_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream); break;
-            case LTMI_U16: rc = run_prepare<uint16_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream); break;
-            case LTMI_I16: rc = run_prepare<int16_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream); break;
-            case LTMI_U32: rc = run_prepare<uint32_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream); break;
-            case LTMI_I32: rc = run_prepare<int32_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream); break;
-            case LTMI_F32: rc = run_prepare<float>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream); break;
-            case LTMI_F64: rc = run_prepare<double>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream); break;
+            case LTMI_U8: rc = run_prepare<uint8_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream, corr); break;
+            case LTMI_I8: rc = run_prepare<int8_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream, corr); break;
+            case LTMI_U16: rc = run_prepare<uint16_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream, corr); break;
+            case LTMI_I16: rc = run_prepare<int16_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream, corr); break;
+            case LTMI_U32: rc = run_prepare<uint32_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream, corr); break;
+            case LTMI_I32: rc = run_prepare<int32_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream, corr); break;
+            case LTMI_F32: rc = run_prepare<float>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream, corr); break;
+            case LTMI_F64: rc = run_prepare<double>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream, corr); break;
             default:
                 LTMI_FAIL(LTMI_E_DTYPE, "ltmi_crystallinity: unsupported tile dtype %s",
                           dtype_name(tile_dtype));

@@ -11,7 +11,9 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, '_lib', 'libltmi.so')
+#: LTMI_LIB selects another build of the same library (the AddressSanitizer host build of
+#: `python -m libertem_amd.build --asan`); there is no other implementation to select
+LIB_PATH = os.environ.get('LTMI_LIB') or os.path.join(_HERE, '_lib', 'libltmi.so')
 
 _lib = None
 _lock = threading.Lock()
@@ -29,7 +31,8 @@ EXPORTS = (
     'ltmi_masks_create_dense', 'ltmi_masks_create_csr', 'ltmi_masks_destroy', 'ltmi_masks_kind',
     'ltmi_apply_masks', 'ltmi_apply_masks_shifted', 'ltmi_apply_masks_shifted_host', 'ltmi_sum_frames_workspace', 'ltmi_sum_frames', 'ltmi_sum_sig',
     'ltmi_axpy', 'ltmi_add2d', 'ltmi_gather_rows', 'ltmi_host_device_pointer', 'ltmi_correct', 'ltmi_repair_pixels', 'ltmi_byteswap', 'ltmi_com_fields', 'ltmi_fft_plan_create',
-    'ltmi_fft_plan_destroy', 'ltmi_crystallinity', 'ltmi_masks_set_tuning',
+    'ltmi_fft_plan_destroy', 'ltmi_crystallinity', 'ltmi_crystallinity_corrected',
+    'ltmi_masks_set_tuning',
     'ltmi_masks_last_kernel',
 )
 
@@ -118,6 +121,8 @@ def lib():
         L.ltmi_fft_plan_create.argtypes = [i32, i32, i32, i32, c.POINTER(vp)]
         L.ltmi_fft_plan_destroy.argtypes = [vp]
         L.ltmi_crystallinity.argtypes = [vp, vp, i32, i64, i64, vp, vp, i32, i32, i32, vp, i32, vp]
+        L.ltmi_crystallinity_corrected.argtypes = [vp, vp, i32, i64, i64, vp, vp, vp, vp, vp, i32, i32,
+                                                   vp, vp, i32, i32, i32, vp, i32, vp]
         L.ltmi_masks_set_tuning.argtypes = [vp, i32, i32, i32]
         L.ltmi_masks_last_kernel.argtypes = [vp]
         L.ltmi_masks_last_kernel.restype = c.c_char_p
@@ -375,6 +380,21 @@ class FFTPlan:
             self._ptr, tile_ptr, dtype_code(tile_dtype), n_frames, ld_tile, real_mask_ptr or None,
             half_mask_ptr, int(box[0]), int(box[1]), int(box[2]), out_ptr, 1 if accumulate else 0,
             stream if isinstance(stream, int) else _stream_ptr(stream)), 'ltmi_crystallinity')
+
+    def crystallinity_corrected(self, tile_ptr, tile_dtype, n_frames, ld_tile, tables,
+                                real_mask_ptr, half_mask_ptr, box, out_ptr, accumulate,
+                                stream=None):
+        """The same on RAW frames; `tables` = CorrectionSet.device_tables(...): dark / gain (float64
+        device tensors or None) and the int32 repair tables."""
+        def ptr(t):
+            return None if t is None else t.data_ptr()
+        check(lib().ltmi_crystallinity_corrected(
+            self._ptr, tile_ptr, dtype_code(tile_dtype), n_frames, ld_tile, ptr(tables['dark']),
+            ptr(tables['gain']), ptr(tables['excl']), ptr(tables['env']), ptr(tables['cnt']),
+            int(tables['n_excl']), int(tables['max_env']), real_mask_ptr or None, half_mask_ptr,
+            int(box[0]), int(box[1]), int(box[2]), out_ptr, 1 if accumulate else 0,
+            stream if isinstance(stream, int) else _stream_ptr(stream)),
+            'ltmi_crystallinity_corrected')
 
     def close(self):
         if self._ptr is not None and self._ptr.value:

@@ -136,9 +136,24 @@ class CrystallinityUDF(UDF):
                 f"CrystallinityUDF transforms whole frames {td.sig}, got tiles of {tile.shape[1:]} "
                 "(do not force a sub-frame tileshape)")
         rm = td.real_mask
+        if getattr(self.meta, 'corrections_folded', False):
+            # RAW tile: (x - dark) * gain and the dead-pixel patches happen inside the conversion
+            # pass of the transform (no corrected copy of the frames)
+            tables = self.meta.corrections.device_tables(tile.device, td.sig)
+            td.plan.crystallinity_corrected(
+                tile.data_ptr(), tile.dtype, tile.shape[0], tile.ld, tables,
+                None if rm is None else rm.data_ptr(), td.half_mask.data_ptr(), td.box,
+                out.data_ptr(), False, stream=self.meta.stream_ptr)
+            return
         td.plan.crystallinity(tile.data_ptr(), tile.dtype, tile.shape[0], tile.ld,
                               None if rm is None else rm.data_ptr(), td.half_mask.data_ptr(),
                               td.box, out.data_ptr(), False, stream=self.meta.stream_ptr)
+
+    def folds_corrections(self, corrections, meta):
+        """Detector corrections are applied inside the transform's conversion pass
+        (ltmi_crystallinity_corrected): the dataset hands out raw tiles."""
+        import libertem_amd.udf.masks as um
+        return bool(um.FOLD_CORRECTIONS)
 
 
 def run_analysis_crystall(ctx, dataset, rad_in, rad_out, real_center=None, real_rad=None, roi=None,

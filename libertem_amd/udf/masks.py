@@ -103,6 +103,50 @@ def fold_corrections_into_masks(masks, corrections, sig_shape):
     return flat.reshape((-1,) + sig_shape), const
 
 
+def fold_corrections_into_sparse_masks(stack, corrections, sig_shape):
+    """
+    The same fold for a SPARSE stack (SparseStack / anything `to_sparse_stack` takes):
+        masks' = (masks . R) . diag(gain),   const = masks' . dark
+    with R the (sparse, n_px x n_px) dead-pixel repair operator of CorrectionSet.apply -- identity
+    rows, except row e of an excluded pixel: 1/|env(e)| at its good neighbours.  The folded stack
+    stays sparse (an excluded pixel's weight moves to <= 8 neighbours).  Returns (SparseStack of
+    float64 / complex128 values, const | None).
+    """
+    import scipy.sparse as sp
+    from libertem_amd.common.sparse import SparseStack, to_sparse_stack
+    sig_shape = tuple(int(x) for x in sig_shape)
+    n_px = int(np.prod(sig_shape))
+    st = to_sparse_stack(stack)
+    wide = np.result_type(np.float64, st.data.dtype)
+    m = sp.csr_matrix((st.data.astype(wide), (st.mask_idx, st.px_idx)), shape=(st.n_masks, n_px))
+    desc = corrections.full_frame_descriptor(sig_shape)
+    if len(desc.exclude_flat):
+        rows, cols, vals = [], [], []
+        keep = np.ones(n_px, dtype=bool)
+        for e, env, c in zip(desc.exclude_flat, desc.repair_flat, desc.repair_counts):
+            if c == 0:
+                continue                     # no good neighbour: stays unpatched, as in `correct`
+            keep[e] = False
+            rows.extend([int(e)] * int(c))
+            cols.extend(int(r) for r in env[:c])
+            vals.extend([1.0 / c] * int(c))
+        ident = np.flatnonzero(keep)
+        r_op = sp.csr_matrix(
+            (np.concatenate([np.ones(len(ident)), np.asarray(vals, dtype=np.float64)]),
+             (np.concatenate([ident, np.asarray(rows, dtype=np.int64)]),
+              np.concatenate([ident, np.asarray(cols, dtype=np.int64)]))), shape=(n_px, n_px))
+        m = sp.csr_matrix(m @ r_op)
+    gain = corrections.get_gain_map()
+    if gain is not None:
+        m = sp.csr_matrix(m @ sp.diags(np.asarray(gain, dtype=np.float64).reshape(-1)))
+    dark = corrections.get_dark_frame()
+    const = None
+    if dark is not None:
+        const = np.asarray(m @ np.asarray(dark, dtype=np.float64).reshape(-1)).reshape(-1)
+    m.eliminate_zeros()
+    return SparseStack.from_csr_masks_by_px(m, sig_shape), const
+
+
 def _folded_plan(corrections, masks_container, mask_factories, sig_shape, count):
     """(container of the folded stack, const | None), cached on the CorrectionSet so that the
     derived factory keeps its identity across tasks and runs (-> `_cached_container` hits)."""
@@ -112,10 +156,16 @@ def _folded_plan(corrections, masks_container, mask_factories, sig_shape, count)
     if hit is None or hit[0] is not mask_factories:
         state = {}
 
+        sparse = masks_container.use_sparse is not False
+
         def folded_factory():
             if 'masks' not in state:
-                state['masks'], state['const'] = fold_corrections_into_masks(
-                    np.asarray(masks_container.computed_masks), corrections, sig_shape)
+                if sparse:
+                    state['masks'], state['const'] = fold_corrections_into_sparse_masks(
+                        masks_container.computed_masks, corrections, sig_shape)
+                else:
+                    state['masks'], state['const'] = fold_corrections_into_masks(
+                        np.asarray(masks_container.computed_masks), corrections, sig_shape)
             return state['masks']
 
         folded_factory()
@@ -127,7 +177,9 @@ def _folded_plan(corrections, masks_container, mask_factories, sig_shape, count)
     dtype = masks_container.dtype
     if np.dtype(dtype).kind not in 'fc':
         dtype = np.result_type(dtype, np.float32)
-    container = _cached_container(factory, dtype, False, count, 'scipy.sparse')
+    container = _cached_container(
+        factory, dtype, masks_container.use_sparse if masks_container.use_sparse is not False
+        else False, count, 'scipy.sparse')
     return container, state
 
 
@@ -302,8 +354,6 @@ class ApplyMasksUDF(UDF):
     def folds_corrections(self, corrections, meta):
         """True iff this UDF can take RAW frames and apply `corrections` through its masks."""
         if not FOLD_CORRECTIONS or self.params.get('shifts') is not None:
-            return False
-        if self.masks.use_sparse is not False:
             return False
         if np.dtype(np.result_type(meta.input_dtype, self.get_mask_dtype())).kind != 'f':
             return False

@@ -698,6 +698,36 @@ def test_fold_corrections_into_masks_identity():
     assert const is None
 
 
+def test_fold_corrections_into_sparse_masks_identity():
+    """the same identity for sparse stacks: masks' = (masks . R) . diag(gain) stays sparse and
+    equals the dense fold"""
+    from libertem_amd.io.corrections import CorrectionSet
+    from libertem_amd.udf.masks import fold_corrections_into_masks, \
+        fold_corrections_into_sparse_masks
+    from libertem_amd.common.sparse import SparseStack
+    rng = np.random.default_rng(9)
+    sig = (9, 11)
+    bad = np.zeros(sig, dtype=bool)
+    for y, x in [(0, 0), (4, 5), (4, 6), (8, 10), (2, 0)]:
+        bad[y, x] = True
+    dark = rng.random(sig) * 5
+    gain = rng.random(sig) + 0.5
+    dense = (rng.random((5,) + sig) - 0.3) * (rng.random((5,) + sig) < 0.2)
+    dense[1, 4, 5] = 0.7                                  # weight on a dead pixel
+    stack = SparseStack.from_dense(dense)
+    for kw in (dict(dark=dark, gain=gain, excluded_pixels=bad), dict(gain=gain), dict(dark=dark),
+               dict(excluded_pixels=bad)):
+        corr = CorrectionSet(**kw)
+        want, want_c = fold_corrections_into_masks(dense, corr, sig)
+        got, got_c = fold_corrections_into_sparse_masks(stack, corr, sig)
+        assert isinstance(got, SparseStack) and got.nnz <= stack.nnz + 8 * int(bad.sum()) * 5
+        np.testing.assert_allclose(got.todense(), want, rtol=1e-12, atol=1e-12)
+        if want_c is None:
+            assert got_c is None
+        else:
+            np.testing.assert_allclose(got_c, want_c, rtol=1e-12, atol=1e-12)
+
+
 _COUNT_UDF_MADE = []
 
 

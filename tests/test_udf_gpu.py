@@ -757,6 +757,45 @@ def test_crystallinity_vs_reference_golden(ctx, golden_dir, case, resident):
     assert np.array_equal(again, got)                       # deterministic, plan re-used
 
 
+def test_crystallinity_with_corrections_fused(ctx):
+    """CrystallinityUDF under CorrectionSet: dark / gain / dead-pixel patches fused into the
+    transform's conversion pass (raw tiles) == the generic route (corrected copy of the frames) ==
+    the oracle on oracle-corrected frames."""
+    import libertem_amd.udf.masks as um
+    from libertem_amd.io.corrections import CorrectionSet
+    from libertem_amd.udf.crystallinity import CrystallinityUDF
+    from oracle import corrections as oc
+    rng = np.random.default_rng(51)
+    data = rng.integers(0, 3000, (4, 6, 32, 48)).astype(np.uint16)
+    dark = rng.random((32, 48)) * 6
+    gain = rng.random((32, 48)) * 0.6 + 0.7
+    bad = np.zeros((32, 48), dtype=bool)
+    bad[16, 24] = bad[0, 0] = bad[10, 40] = bad[10, 41] = bad[31, 47] = True
+    coords = [tuple(c) for c in np.argwhere(bad)]
+    for kw in (dict(dark=dark, gain=gain, excluded_pixels=bad), dict(gain=gain),
+               dict(excluded_pixels=bad)):
+        corr = CorrectionSet(**kw)
+        corrected = oc.correct(data, (32, 48), dark=kw.get('dark'), gain=kw.get('gain'),
+                               coords=coords if 'excluded_pixels' in kw else None)
+        for real in ((16, 24), None):
+            ref = opath.crystallinity_udf(corrected, 3, 9, real, 4 if real else None)
+            out = {}
+            for fold in (True, False):
+                um.FOLD_CORRECTIONS = fold
+                try:
+                    for resident in ('device', 'host'):
+                        ds = _device_ds(ctx, data, 2) if resident == 'device' else \
+                            ctx.load('memory', data=data, num_partitions=2, sig_dims=2)
+                        udf = CrystallinityUDF(rad_in=3, rad_out=9, real_center=real,
+                                               real_rad=4 if real else None)
+                        got = ctx.run_udf(dataset=ds, udf=udf, corrections=corr)['intensity'].data
+                        assert _close(got, ref, F32_TOL), (sorted(kw), real, fold, resident)
+                        out[(fold, resident)] = got
+                finally:
+                    um.FOLD_CORRECTIONS = True
+            assert _close(out[(True, "device")], out[(False, "device")], F32_TOL)
+
+
 def test_crystallinity_roi_batches_and_analysis(ctx):
     """More frames than one FFT batch, a ragged last batch, an ROI, and the ApplyFFTMask /
     SumfftAnalysis wrappers (reference tests/udf/test_crystallinity.py, analysis/sumfft.py)."""
@@ -832,6 +871,48 @@ def test_com_with_corrections_folded_and_generic(ctx):
                 (fold, name, np.abs(got - ref[name]).max())
     assert np.allclose(out[True]['field'].data, out[False]['field'].data, rtol=2e-5,
                        atol=2e-5 * np.abs(ref['raw_com']).max())
+
+
+def test_sparse_masks_with_corrections_folded(ctx):
+    """Sparse stacks take the folded route too: RAW frames, (masks . R) . diag(gain) as the sparse
+    stack and the dark constant subtracted -- equal to applying the stack to oracle-corrected frames,
+    and to the generic route (corrected copy of the frames)."""
+    import libertem_amd.udf.masks as um
+    from libertem_amd.io.corrections import CorrectionSet
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd import masks as M, hip
+    from oracle import corrections as oc
+    rng = np.random.default_rng(41)
+    data = rng.integers(0, 3000, (5, 8, 64, 64)).astype(np.uint16)
+    dark = rng.random((64, 64)) * 4
+    gain = rng.random((64, 64)) * 0.5 + 0.75
+    bad = np.zeros((64, 64), dtype=bool)
+    bad[30, 33] = bad[0, 0] = bad[40, 12] = bad[40, 13] = True
+    corr = CorrectionSet(dark=dark, gain=gain, excluded_pixels=bad)
+    coords = [tuple(c) for c in np.argwhere(bad)]
+    corrected = oc.correct(data, (64, 64), dark=dark, gain=gain, coords=coords)
+
+    def rings():
+        return M.radial_bins(centerX=32, centerY=32, imageSizeX=64, imageSizeY=64, n_bins=48,
+                             use_sparse=True, dtype=np.float32)
+    dense = M.radial_bins(centerX=32, centerY=32, imageSizeX=64, imageSizeY=64, n_bins=48,
+                          use_sparse=False, dtype=np.float32)
+    ref = np.tensordot(corrected.astype(np.float64), dense.astype(np.float64),
+                       axes=([2, 3], [1, 2]))
+    ds = _device_ds(ctx, data, 2)
+    udf = ApplyMasksUDF(mask_factories=rings, use_sparse='scipy.sparse', mask_count=48,
+                        mask_dtype=np.float32)
+    out = {}
+    for fold in (True, False):
+        um.FOLD_CORRECTIONS = fold
+        try:
+            hip.KernelTimer.start()
+            out[fold] = ctx.run_udf(dataset=ds, udf=udf, corrections=corr)['intensity'].data
+            kernels = [k for _, _, k in hip.KernelTimer.stop()]
+        finally:
+            um.FOLD_CORRECTIONS = True
+        assert all('k_bell' in k or 'k_sell' in k for k in kernels) and kernels, kernels
+        assert _close(out[fold], ref, F32_TOL), fold
 
 
 def test_run_udf_iter_partial_results_on_device(ctx):
