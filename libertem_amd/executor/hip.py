@@ -232,10 +232,14 @@ class HipJobExecutor(JobExecutor):
         """Generator form for `run_udf_iter` (reference udf/base.py:2657-2733): yields after every
         merged partition with the current state published to the host buffers (one D2H per
         buffer and partition -- opt-in cost of watching partial results).  With several ranks the
-        partial state of one rank is not a result, so it yields once, after the collectives."""
-        yield from self._merge(udfs, damage, result_iter, partial=not self._collectives_on)
+        ranks advance in lockstep -- one step = the next partition of EVERY rank, then one
+        collective per buffer -- and every rank yields the same partial result after each step."""
+        if self._collectives_on:
+            yield from self._merge_partial_dist(udfs, damage, result_iter)
+        else:
+            yield from self._merge(udfs, damage, result_iter, partial=True)
 
-    def _merge(self, udfs, damage, result_iter, partial):
+    def _merge_plans(self, udfs):
         plans = []
         for udf in udfs:
             decl = getattr(udf, 'get_dist_merge', lambda: None)()
@@ -247,6 +251,101 @@ class HipJobExecutor(JobExecutor):
                 plans.append(('host-declared', decl))
             else:
                 plans.append(('generic', None))
+        return plans
+
+    def _merge_partial_dist(self, udfs, damage, result_iter):
+        """Partial results across ranks (live acquisitions fed to several GPUs, one feeder per rank:
+        io/dataset/stream.py with shard=; reference executor/pipelined.py:789-1253 +
+        udf/base.py:2657-2733).  After step k every rank holds the merge of the first k + 1
+        partitions of every rank; the damage map says which rows that is."""
+        import torch
+        d = self._dist()
+        plans = self._merge_plans(udfs)
+        self._row_sink = None
+        self._result_target = None
+        self.last_result_via = 'collective'
+        it = iter(result_iter)
+        first = next(it, None)                  # (runs the executor's task set-up: _all_tasks)
+        tasks = self._all_tasks
+        owners = self.task_owners(tasks)
+        per_rank = [[t for t, o in zip(tasks, owners) if o == r] for r in range(self.world_size)]
+        n_steps = max((len(x) for x in per_rank), default=0)
+        dev_full = [dict() for _ in udfs]
+        local_host = {}                         # (udf idx, name) -> this rank's own merged array
+        by_idx = {t.idx: t for t in tasks}
+
+        def publish():
+            for i, (udf, (mode, decl)) in enumerate(zip(udfs, plans)):
+                if mode == 'generic':
+                    continue
+                for name, how in decl.items():
+                    buf = udf.results.get_buffer(name)
+                    if isinstance(buf, PlaceholderBufferWrapper):
+                        continue
+                    if mode == 'device':
+                        self._make_current()
+                        full = dev_full[i].get(name)
+                        t = torch.zeros(buf.shape, dtype=torch_dtype_for(buf.dtype),
+                                        device=f'cuda:{self.gpu_id}') if full is None \
+                            else full.clone()
+                        host = self._to_host(self._combine(d, t, how))
+                    else:
+                        mine = local_host.get((i, name))
+                        if mine is None:
+                            mine = local_host[(i, name)] = np.array(buf.raw_data, copy=True)
+                        t = torch.from_numpy(np.array(mine, copy=True))
+                        host = self._combine(d, t, how).numpy()
+                    if host.dtype != buf.dtype:
+                        host = host.view(buf.dtype)
+                    buf.replace_array(host)
+
+        pending = first
+        for step in range(n_steps):
+            new_generic = []
+            if pending is not None:
+                part_results, task = pending
+                entry = {}
+                for i, (udf, results, (mode, decl)) in enumerate(zip(udfs, part_results, plans)):
+                    if mode == 'device':
+                        self._merge_on_device(udf, results, task, decl, dev_full[i],
+                                              may_adopt=False)
+                    elif mode == 'host-declared':
+                        results.export()
+                        for name in decl:           # merge into THIS rank's own state
+                            buf = udf.results.get_buffer(name)
+                            if (i, name) in local_host and \
+                                    not isinstance(buf, PlaceholderBufferWrapper):
+                                buf.replace_array(local_host[(i, name)])
+                        self._apply_one(udf, results, task)
+                        for name in decl:
+                            buf = udf.results.get_buffer(name)
+                            if not isinstance(buf, PlaceholderBufferWrapper):
+                                local_host[(i, name)] = buf.raw_data
+                    else:
+                        results.export()
+                        entry[i] = results
+                if entry:
+                    new_generic.append((task.idx, entry))
+                pending = next(it, None)
+            publish()
+            if any(mode == 'generic' for mode, _ in plans):
+                gathered = [None] * self.world_size
+                d.all_gather_object(gathered, new_generic)
+                for tidx, entry in sorted((p for chunk in gathered for p in chunk),
+                                          key=lambda x: x[0]):
+                    for i, results in entry.items():
+                        self._apply_one(udfs[i], results, by_idx[tidx])
+            for r in range(self.world_size):
+                for t in per_rank[r][:step + 1]:
+                    damage.get_view_for_partition(t.partition)[:] = True
+            yield step + 1
+        if n_steps == 0:
+            yield 0
+        if self._stream is not None:
+            self._stream.synchronize()
+
+    def _merge(self, udfs, damage, result_iter, partial):
+        plans = self._merge_plans(udfs)
 
         # Delivery of 'disjoint' nav buffers: every row goes to its final place in page-locked host
         # memory while the run is still computing -- small write-once rows are written there by the

@@ -9,6 +9,11 @@ yields into one host buffer and publishes how many frames have landed; a partiti
 uploaded (double-buffered H2D, io/dataset/memory.py) as soon as THEIR frames are there, i.e. the GPU
 works on the scan while it is being recorded, and `Context.run_udf_iter` hands out the result after
 every partition.  Everything else (tiling, corrections, ROI, sharding) is MemoryDataSet.
+
+Several GPUs: one feeder per rank.  With `shard=(rank, world)` the iterator of a rank delivers ITS
+block of the scan (frames [rank * n / world, (rank + 1) * n / world) of the flattened nav axis, the
+nav sharding of MemoryDataSet); `run_udf_iter` then advances the ranks in lockstep and every rank
+yields the merged partial result after each step (executor/hip.py `_merge_partial_dist`).
 """
 import threading
 
@@ -32,25 +37,37 @@ class StreamDataSet(MemoryDataSet):
         Partial results are published per partition (default: about 16, at least one frame each).
     timeout : float, optional
         Seconds to wait for missing frames before giving up (default: wait for ever).
+    shard : (rank, world), optional
+        `frames` delivers only this rank's block of the scan; `nav_shape` is the shape of the WHOLE
+        scan, its first axis must be divisible by `world`.
     """
 
     eager_upload = False    # never wait for the next chunk's frames before launching this chunk
 
     def __init__(self, frames, nav_shape, sig_shape, dtype, num_partitions=None, timeout=None,
-                 tileshape=None):
+                 tileshape=None, shard=None):
         nav_shape = tuple(int(x) for x in nav_shape)
         sig_shape = tuple(int(x) for x in sig_shape)
-        n_frames = prod(nav_shape)
-        if n_frames <= 0 or prod(sig_shape) <= 0:
+        if prod(nav_shape) <= 0 or prod(sig_shape) <= 0:
             raise DataSetException(f"empty stream shape {nav_shape} x {sig_shape}")
+        local_nav = nav_shape
+        self._frame0 = 0                    # global number of this process's first frame
+        if shard is not None:
+            rank, world = int(shard[0]), int(shard[1])
+            if not (0 <= rank < world) or nav_shape[0] % world != 0:
+                raise DataSetException(
+                    f"cannot shard a scan of {nav_shape} over {world} ranks (shard {shard})")
+            local_nav = (nav_shape[0] // world,) + nav_shape[1:]
+            self._frame0 = rank * prod(local_nav)
+        n_frames = prod(local_nav)
         dt = np.dtype(dtype)
         if not dt.isnative:
             raise DataSetException("a stream delivers frames in the native byte order")
         buf = np.zeros((n_frames,) + sig_shape, dtype=dt)
         if num_partitions is None:
             num_partitions = max(1, min(16, n_frames))
-        super().__init__(data=buf.reshape(nav_shape + sig_shape), sig_dims=len(sig_shape),
-                         num_partitions=num_partitions, tileshape=tileshape)
+        super().__init__(data=buf.reshape(local_nav + sig_shape), sig_dims=len(sig_shape),
+                         num_partitions=num_partitions, tileshape=tileshape, shard=shard)
         self._buf = buf
         self._n_frames = n_frames
         self._timeout = timeout
@@ -100,8 +117,9 @@ class StreamDataSet(MemoryDataSet):
             return self._arrived
 
     def wait_for_frames(self, upto):
-        """Block until the first `upto` frames of the scan are in the buffer."""
-        upto = min(int(upto), self._n_frames)
+        """Block until the frames of the scan up to (global) number `upto` that THIS process is
+        fed with are in the buffer."""
+        upto = max(0, min(int(upto) - self._frame0, self._n_frames))
         with self._cond:
             ok = self._cond.wait_for(
                 lambda: self._arrived >= upto or self._error is not None or self._finished,

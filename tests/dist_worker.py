@@ -91,7 +91,29 @@ def main():
     roi2 = np.zeros((world * 61,), dtype=bool)
     roi2[61 + 5:61 + 40] = True
     rs4 = ctx.run_udf(dataset=ds_sh2, udf=[MasksDeclared(masks), SumDeclared()], roi=roi2)
+    # live feed, one feeder per rank (StreamDataSet(shard=...)) + run_udf_iter across the ranks:
+    # the ranks advance in lockstep, every rank yields the same partial result after each step
+    import time as _time
+    live = rng.integers(0, 100, (world * 4, 3, 16, 16)).astype(np.uint16)
+    mine = live[rank * 4:(rank + 1) * 4].reshape((-1, 16, 16))
+
+    def feed():
+        for i in range(0, len(mine), 3):
+            _time.sleep(0.002 * (rank + 1))          # the ranks' feeds are not in step
+            yield mine[i:i + 3]
+
+    ds_live = ctx.load('stream', frames=feed(), nav_shape=(world * 4, 3), sig_shape=(16, 16),
+                       dtype=np.uint16, num_partitions=3, shard=(rank, world))
+    steps_masks, steps_sum, steps_mx, steps_damage = [], [], [], []
+    for part in ctx.run_udf_iter(dataset=ds_live, udf=[MasksDeclared(masks), SumDeclared(),
+                                                        MaxGeneric()]):
+        steps_masks.append(np.array(part.buffers[0]['intensity'].data))
+        steps_sum.append(np.array(part.buffers[1]['intensity'].data))
+        steps_mx.append(np.array(part.buffers[2]['mx'].data))
+        steps_damage.append(np.array(part.damage.data))
     np.savez(os.path.join(out_dir, f'rank{rank}.npz'),
+             live=live, live_masks=np.stack(steps_masks), live_sum=np.stack(steps_sum),
+             live_mx=np.stack(steps_mx), live_damage=np.stack(steps_damage),
              sh2_masks=rs3['intensity'].data, sh2_roi_raw=rs4[0]['intensity'].raw_data,
              sh2_roi_sum=rs4[1]['intensity'].data, sh2_full=full2,
              sh_masks=rs1['intensity'].data, sh_sum=rs2['intensity'].data, sh_full=full,

@@ -82,6 +82,18 @@ def main():
     out['coll_masks'] = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(
         mask_factories=lambda: masks))['intensity'].data
     del os.environ['LTMI_RESULT_VIA']
+    # (4) live feed, one feeder per rank, partial results across the ranks on the device path
+    live = rng.integers(0, 4000, (world * 4, 5, 32, 32)).astype(np.uint16)
+    mine_live = live[rank * 4:(rank + 1) * 4].reshape((-1, 32, 32))
+    ds_live = ctx.load('stream', frames=(mine_live[i:i + 4] for i in range(0, 20, 4)),
+                       nav_shape=(world * 4, 5), sig_shape=(32, 32), dtype=np.uint16,
+                       num_partitions=2, shard=(rank, world))
+    steps = []
+    for part in ctx.run_udf_iter(dataset=ds_live, udf=ApplyMasksUDF(mask_factories=lambda: masks)):
+        steps.append((np.array(part.buffers[0]['intensity'].data), np.array(part.damage.data)))
+    out['live'] = live
+    out['live_step_masks'] = np.stack([a for a, _ in steps])
+    out['live_step_damage'] = np.stack([b for _, b in steps])
     out['masks'] = masks
     np.savez(os.path.join(out_dir, f'rank{rank}.npz'), **out)
     dist.barrier()

@@ -66,8 +66,28 @@ def test_gloo_sharded_run(tmp_path, world):
         assert np.allclose(o['sh2_masks'], exp2, rtol=1e-6)
         assert np.allclose(o['sh2_roi_raw'], exp2[61 + 5:61 + 40], rtol=1e-6)
         assert np.array_equal(o['sh2_roi_sum'], full2[61 + 5:61 + 40].astype(np.float32).sum(axis=0))
+        # live feed per rank + run_udf_iter: 3 steps (3 partitions per rank); after step k the
+        # frames of the first k + 1 partitions of EVERY rank are merged and marked in the damage map
+        live = o['live']
+        flat_live = live.reshape((world, 12, 256)).astype(np.float32)      # (rank, local frame, px)
+        bounds = np.linspace(0, 12, 4, dtype=int)
+        assert o['live_masks'].shape[0] == 3
+        for k in range(3):
+            done = np.zeros((world, 12), dtype=bool)
+            done[:, :bounds[k + 1]] = True
+            dmg = o['live_damage'][k].reshape((world, 12))
+            assert np.array_equal(dmg, done), k
+            part_masks = o['live_masks'][k].reshape((world, 12, 3))
+            exp_m = flat_live @ masks.reshape((3, -1)).T
+            assert np.allclose(part_masks[done], exp_m[done], rtol=1e-6)
+            assert np.all(part_masks[~done] == 0)
+            assert np.array_equal(o['live_sum'][k],
+                                  flat_live[done].sum(axis=0).reshape((16, 16)))
+            assert np.array_equal(o['live_mx'][k], flat_live[done].max(axis=0).reshape((16, 16)))
     # identical on every rank
     for o in outs[1:]:
+        for k in ('live_masks', 'live_sum', 'live_mx', 'live_damage'):
+            assert np.array_equal(o[k], outs[0][k]), k
         for k in ('masks', 'sum', 'mx', 'per_frame'):
             assert np.array_equal(o[k], outs[0][k])
     # every partition processed exactly once, in contiguous blocks

@@ -1238,6 +1238,17 @@ def test_two_ranks_share_results_through_host_segment(tmp_path, world):
         assert bool(o['sh_first_still_valid']) and bool(o['sh_bare_still_valid'])
         assert bool(o['sh_held_equal']) and str(o['sh_via_when_full']) == 'collective'
         assert 4 <= int(o['sh_slots']) <= 6
+        # live feed per rank + run_udf_iter: 2 steps, after step k the first k + 1 partitions of
+        # every rank are merged (device merge + collective) and marked in the damage map
+        live = o['live']
+        exp_live = opath.apply_masks(live, masks).reshape((world, 20, -1))
+        assert o['live_step_masks'].shape[0] == 2
+        for k, n_done in enumerate((10, 20)):
+            got = o['live_step_masks'][k].reshape((world, 20, -1))
+            dmg = o['live_step_damage'][k].reshape((world, 20))
+            assert np.all(dmg[:, :n_done]) and not np.any(dmg[:, n_done:])
+            assert _close(got[:, :n_done], exp_live[:, :n_done], F32_TOL)
+            assert np.all(got[:, n_done:] == 0)
         data, roi = o['rep_data'], o['rep_roi']
         exp2 = opath.apply_masks(data, masks, num_partitions=5)
         assert _close(o['rep_masks'], exp2, F32_TOL)
