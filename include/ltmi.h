@@ -11,7 +11,8 @@
  *
  * Conventions
  *   - every function returns 0 (LTMI_OK) on success, a negative LTMI_E_* code for argument errors,
- *     or a positive hipError_t; `ltmi_last_error()` returns a thread-local message.
+ *     or a positive code: a hipError_t, or LTMI_E_RCCL_BASE + ncclResult_t from the ltmi_comm_*
+ *     functions; `ltmi_last_error()` returns a thread-local message.
  *   - nothing throws across the ABI.
  *   - `stream` is a hipStream_t (NULL = the legacy default stream); all work is enqueued on it and
  *     the call returns without synchronising.  A handle must be used on one stream at a time
@@ -38,6 +39,7 @@ extern "C" {
 #define LTMI_E_DTYPE (-2)        /* dtype combination not supported */
 #define LTMI_E_SHAPE (-3)        /* shapes do not match the handle */
 #define LTMI_E_NOMEM (-4)        /* host allocation failed */
+#define LTMI_E_RCCL_BASE 10000   /* a failing RCCL call returns LTMI_E_RCCL_BASE + ncclResult_t */
 
 /* dtype codes (numpy names) */
 enum ltmi_dtype {
@@ -223,6 +225,26 @@ int ltmi_crystallinity_corrected(ltmi_fft_plan *p, const void *tile, int tile_dt
                                  const int32_t *cnt, int n_excl, int max_env,
                                  const float *real_mask, const float *half_mask, int row_lo,
                                  int row_hi, int n_cols, float *out, int accumulate, void *stream);
+
+/* ---- multi-GPU: RCCL (over xGMI) behind the C ABI ---------------------------------------------
+ * One process per GPU; the path shards over scan positions, the ranks exchange per-partition nav-grid
+ * results only.  Replaces, for a reference-side binding, the transport of partition results through
+ * the executor (pickled over TCP, src/libertem/executor/dask.py:581-646) and the serial merge on the
+ * main process (src/libertem/udf/base.py:2340-2358, udf/sum.py:50-52):
+ *   'disjoint' nav buffers (ApplyMasksUDF, SumSigUDF, CoM) -> ltmi_comm_all_gather of equal row blocks,
+ *   sig buffers (SumUDF)                                    -> ltmi_comm_all_reduce_sum.
+ * The 128-byte id comes from ltmi_comm_unique_id on ONE rank and reaches the others through the
+ * launcher's own channel (environment, file, torch.distributed store).  librccl is opened lazily. */
+typedef struct ltmi_comm ltmi_comm;   /* opaque */
+int ltmi_comm_unique_id(void *id_out /* 128 bytes */);
+int ltmi_comm_create(int device, int rank, int world, const void *id /* 128 bytes */,
+                     ltmi_comm **out);
+int ltmi_comm_destroy(ltmi_comm *c);
+/* recv[r * bytes_per_rank ...] = send of rank r, device pointers, on `stream` */
+int ltmi_comm_all_gather(ltmi_comm *c, const void *send, void *recv, int64_t bytes_per_rank,
+                         void *stream);
+/* buf[i] = sum over ranks, in place; dtype: enum ltmi_dtype without the 16-bit integers */
+int ltmi_comm_all_reduce_sum(ltmi_comm *c, void *buf, int dtype, int64_t n, void *stream);
 
 /* ---- tuning / introspection (bench + tests) ------------------------------------------- */
 /* force a kernel variant for the dense MFMA path (bench / tests only; (0,0,0) = automatic):

@@ -20,10 +20,10 @@ LIBDIR = os.path.join(HERE, '_lib')
 LIB = os.path.join(LIBDIR, 'libltmi.so')
 OBJDIR = os.path.join(HERE, '_lib', 'obj')
 
-SOURCES = ['ltmi_capi.cpp', 'ltmi_dense.hip', 'ltmi_sparse.hip', 'ltmi_reduce.hip', 'ltmi_fft.hip', 'ltmi_dense64.hip', 'ltmi_bell.hip']
+SOURCES = ['ltmi_capi.cpp', 'ltmi_comm.cpp', 'ltmi_dense.hip', 'ltmi_sparse.hip', 'ltmi_reduce.hip', 'ltmi_fft.hip', 'ltmi_dense64.hip', 'ltmi_bell.hip']
 # hipFFT for the Fourier-space operators (ltmi_fft.hip).  The loader binds libhipfft.so.0 to the copy
 # torch already has in the process (same soname), i.e. the one that matches torch's HIP runtime.
-LINK_LIBS = ['-L/opt/rocm/lib', '-lhipfft']
+LINK_LIBS = ['-L/opt/rocm/lib', '-lhipfft', '-ldl']
 ARCH = 'gfx950'
 FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function']
 

@@ -88,6 +88,43 @@ k_fft_prepare(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t 
     }
 }
 
+// The corrected conversion with dark / gain held in registers across frames: a thread owns 8
+// consecutive pixels and walks `frames_per_block` frames (the per-pixel float64 dark and gain values
+// would otherwise be re-read from L2 for every frame: 16 B per 2-byte pixel).
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_fft_prepare_corr(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
+                   const float *__restrict__ real_mask, float *__restrict__ out,
+                   const double *__restrict__ dark, const double *__restrict__ gain,
+                   int frames_per_block) {
+    const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (p0 >= n_px) return;                  // (n_px % 8 == 0 on this path)
+    double d[8], g[8];
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        d[j] = dark ? dark[p0 + j] : 0.0;
+        g[j] = gain ? gain[p0 + j] : 1.0;
+        m[j] = real_mask ? real_mask[p0 + j] : 1.f;
+    }
+    const int64_t f0 = (int64_t)blockIdx.y * frames_per_block;
+    const int64_t f1 = min<int64_t>(n_frames, f0 + frames_per_block);
+    typedef T __attribute__((ext_vector_type(8))) vec_t;
+#pragma unroll 2
+    for (int64_t f = f0; f < f1; ++f) {
+        const vec_t x = __builtin_nontemporal_load((const vec_t *)(tile + f * ld + p0));
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = (float)(((double)x[j] - d[j]) * g[j]);
+            if (real_mask) v[j] *= m[j];
+        }
+        float *dst = out + f * n_px + p0;
+        *(float4 *)dst = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4 *)(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
 // Dead pixels: buf[f, e] = mean over the good neighbours of e of the CORRECTED pixel, times the
 // real-space mask at e -- recomputed from the raw tile (<= max_env pixels per patch), so that the
 // prepare pass needs no second sweep over the frames.  One thread per (frame, excluded pixel).
@@ -159,8 +196,17 @@ static int run_prepare(const void *tile, int64_t ld, int64_t n, int64_t n_px, co
     const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_px / 8 + 255) / 256, 32));
     const int vec_ok = (sizeof(T) <= 4) && ((uintptr_t)tile % 16 == 0) &&
                        ((ld * (int64_t)sizeof(T)) % 16 == 0) && (n_px % 8 == 0);
-    hipLaunchKernelGGL((k_fft_prepare<T>), dim3(gx, (unsigned)n), dim3(256), 0, stream,
-                       (const T *)tile, ld, n, n_px, real_mask, out, vec_ok, corr.dark, corr.gain);
+    if ((corr.dark || corr.gain) && vec_ok) {
+        const int fpb = 16;
+        const unsigned bx = (unsigned)((n_px / 8 + 255) / 256);
+        hipLaunchKernelGGL((k_fft_prepare_corr<T>), dim3(bx, (unsigned)((n + fpb - 1) / fpb)),
+                           dim3(256), 0, stream, (const T *)tile, ld, n, n_px, real_mask, out,
+                           corr.dark, corr.gain, fpb);
+    } else {
+        hipLaunchKernelGGL((k_fft_prepare<T>), dim3(gx, (unsigned)n), dim3(256), 0, stream,
+                           (const T *)tile, ld, n, n_px, real_mask, out, vec_ok, corr.dark,
+                           corr.gain);
+    }
     if (corr.n_excl > 0) {
         const int64_t nt = n * corr.n_excl;
         hipLaunchKernelGGL((k_fft_repair<T>), dim3((unsigned)((nt + 255) / 256)), dim3(256), 0,

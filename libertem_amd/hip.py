@@ -33,7 +33,8 @@ EXPORTS = (
     'ltmi_axpy', 'ltmi_add2d', 'ltmi_gather_rows', 'ltmi_host_device_pointer', 'ltmi_correct', 'ltmi_repair_pixels', 'ltmi_byteswap', 'ltmi_com_fields', 'ltmi_fft_plan_create',
     'ltmi_fft_plan_destroy', 'ltmi_crystallinity', 'ltmi_crystallinity_corrected',
     'ltmi_masks_set_tuning',
-    'ltmi_masks_last_kernel',
+    'ltmi_masks_last_kernel', 'ltmi_comm_unique_id', 'ltmi_comm_create', 'ltmi_comm_destroy',
+    'ltmi_comm_all_gather', 'ltmi_comm_all_reduce_sum',
 )
 
 
@@ -125,6 +126,11 @@ def lib():
                                                    vp, vp, i32, i32, i32, vp, i32, vp]
         L.ltmi_masks_set_tuning.argtypes = [vp, i32, i32, i32]
         L.ltmi_masks_last_kernel.argtypes = [vp]
+        L.ltmi_comm_unique_id.argtypes = [vp]
+        L.ltmi_comm_create.argtypes = [i32, i32, i32, vp, c.POINTER(vp)]
+        L.ltmi_comm_destroy.argtypes = [vp]
+        L.ltmi_comm_all_gather.argtypes = [vp, vp, vp, i64, vp]
+        L.ltmi_comm_all_reduce_sum.argtypes = [vp, vp, i32, i64, vp]
         L.ltmi_masks_last_kernel.restype = c.c_char_p
         for name in EXPORTS:
             fn = getattr(L, name)
@@ -399,6 +405,48 @@ class FFTPlan:
     def close(self):
         if self._ptr is not None and self._ptr.value:
             lib().ltmi_fft_plan_destroy(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm:
+    """RCCL communicator behind the C ABI (`ltmi_comm*`): what a reference-side binding uses to
+    gather nav results / reduce sig results across the GPUs of a node without torch.distributed."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(Comm.ID_BYTES)
+        check(lib().ltmi_comm_unique_id(buf), 'ltmi_comm_unique_id')
+        return buf.raw
+
+    def __init__(self, device, rank, world, unique_id):
+        if len(unique_id) != self.ID_BYTES:
+            raise ValueError(f"the RCCL unique id has {self.ID_BYTES} bytes")
+        out = ctypes.c_void_p()
+        check(lib().ltmi_comm_create(int(device), int(rank), int(world),
+                                     ctypes.c_char_p(bytes(unique_id)), ctypes.byref(out)),
+              'ltmi_comm_create')
+        self._ptr = out
+        self.rank, self.world = int(rank), int(world)
+
+    def all_gather(self, send_ptr, recv_ptr, bytes_per_rank, stream=None):
+        check(lib().ltmi_comm_all_gather(self._ptr, send_ptr, recv_ptr, int(bytes_per_rank),
+                                         _stream_ptr(stream)), 'ltmi_comm_all_gather')
+
+    def all_reduce_sum(self, buf_ptr, dtype, n, stream=None):
+        check(lib().ltmi_comm_all_reduce_sum(self._ptr, buf_ptr, dtype_code(dtype), int(n),
+                                             _stream_ptr(stream)), 'ltmi_comm_all_reduce_sum')
+
+    def close(self):
+        if self._ptr is not None and self._ptr.value:
+            lib().ltmi_comm_destroy(self._ptr)
             self._ptr = None
 
     def __del__(self):

@@ -38,3 +38,39 @@ for label, fold, c in (('no corrections', True, None), ('folded into masks', Tru
           f"{65536 / np.median(ts) / 1e6:6.2f} Mframes/s")
 a, b = res['folded into masks'], res['corrected frames (scratch)']
 print("folded vs corrected-frames: max rel diff", np.abs(a - b).max() / np.abs(b).max())
+
+# ---- the same for the other consumers: sparse ring stack (C4 masks) and CrystallinityUDF --------------
+from libertem_amd import masks as M
+from libertem_amd.udf.crystallinity import CrystallinityUDF
+
+
+def rings():
+    return M.radial_bins(centerX=128, centerY=128, imageSizeX=256, imageSizeY=256, n_bins=1024,
+                         use_sparse=True, dtype=np.float32)
+
+
+def timed(udf, c, fold, n=5):
+    um.FOLD_CORRECTIONS = fold
+    try:
+        for _ in range(3):
+            ctx.run_udf(dataset=ds, udf=udf, corrections=c)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            ctx.run_udf(dataset=ds, udf=udf, corrections=c)
+            ts.append(time.perf_counter() - t0)
+    finally:
+        um.FOLD_CORRECTIONS = True
+    return float(np.median(ts)) * 1e3
+
+
+sparse_udf = ApplyMasksUDF(mask_factories=rings, use_sparse='scipy.sparse', mask_count=1024,
+                           mask_dtype=np.float32)
+cryst = CrystallinityUDF(rad_in=20, rad_out=60, real_center=(128, 128), real_rad=10)
+for name, udf in (('1024 sparse ring masks', sparse_udf), ('CrystallinityUDF', cryst)):
+    t0 = timed(udf, None, True)
+    t1 = timed(udf, corr, True)
+    t2 = timed(udf, corr, False)
+    print(f"{name:28s} no corrections {t0:7.2f} ms | fused / folded {t1:7.2f} ms ({t1 / t0:.2f}x) | "
+          f"corrected copy of the frames {t2:7.2f} ms ({t2 / t0:.2f}x)")

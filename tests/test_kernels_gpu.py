@@ -725,3 +725,32 @@ def test_com_fields_vs_oracle(hip, ny, nx, rot, flip):
     assert np.allclose(got[3], opath.divergence(y_ref, x_ref), **tol)
     assert np.allclose(got[4], opath.curl_2d(y_ref, x_ref), **tol)
     assert got[0][0, 0] == 0 and got[1][0, 0] == 0
+
+
+def test_rccl_comm_behind_the_c_abi(hip):
+    """ltmi_comm_*: RCCL through the C ABI (what a reference-side binding gathers nav results /
+    reduces sig results with).  One GPU here, so a one-rank communicator: all_gather is the
+    identity into the receive buffer, all_reduce(sum) leaves the buffer unchanged; the error path
+    (16-bit integers have no RCCL sum) raises."""
+    uid = hip.Comm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = hip.Comm(0, 0, 1, uid)
+    rng = np.random.default_rng(3)
+    rows = rng.random((96, 16)).astype(np.float32)
+    send = _dev(rows)
+    recv = torch.zeros_like(send)
+    comm.all_gather(send.data_ptr(), recv.data_ptr(), rows.nbytes)
+    torch.cuda.synchronize()
+    assert np.array_equal(recv.cpu().numpy(), rows)
+    sig = rng.random((64, 64)).astype(np.float64)
+    buf = _dev(sig)
+    comm.all_reduce_sum(buf.data_ptr(), np.float64, sig.size)
+    c64 = (rng.random(100) + 1j * rng.random(100)).astype(np.complex64)
+    cbuf = _dev(c64.view(np.float32))
+    comm.all_reduce_sum(cbuf.data_ptr(), np.complex64, c64.size)
+    torch.cuda.synchronize()
+    assert np.array_equal(buf.cpu().numpy(), sig)
+    assert np.array_equal(cbuf.cpu().numpy().view(np.complex64), c64)
+    with pytest.raises(ValueError):
+        comm.all_reduce_sum(buf.data_ptr(), np.uint16, 4)
+    comm.close()
