@@ -189,6 +189,23 @@ class MemoryDataSet(DataSet):
 
     eager_upload = True     # HIP path: enqueue the upload of chunk i+1 before the kernels of chunk i
 
+    #: SIGNED integers stored in the other byte order, read into a float or a wider integer dtype:
+    #: 'reference' -- the reference's decoders compose the UNSIGNED word from the file's bytes and
+    #: store that (io/dataset/base/decode.py:15-66; pinned by tests/golden/decode_signed.npz): -1
+    #: stored big-endian reads as 65535.0.  Same-width signed reads wrap back to the signed value.
+    #: 'signed' -- the arithmetic value (what NumPy's astype gives).  Results are identical for
+    #: non-negative data.
+    signed_other_order = 'reference'
+
+    def decoded_dtype(self, dest_dtype):
+        """dtype the (byte-swapped) pixels are INTERPRETED as before conversion to `dest_dtype`."""
+        dt = np.dtype(self.dtype)
+        dest = np.dtype(dest_dtype)
+        if self._swap_itemsize > 1 and dt.kind == 'i' and self.signed_other_order == 'reference' \
+                and not (dest.kind == 'i' and dest.itemsize == dt.itemsize):
+            return np.dtype(f'u{dt.itemsize}')
+        return dt
+
     def wait_for_frames(self, upto):
         """Hook for datasets whose frames are still arriving (io/dataset/stream.py): returns once
         the first `upto` frames of the scan are readable.  Everything is there already here."""
@@ -391,6 +408,9 @@ class MemPartition(Partition):
         sig_dims = self._ds.shape.sig.dims
         idxs = self._roi_indices(roi)
         depth = int(tiling_scheme.depth)
+        src_view = None
+        if self._ds.decoded_dtype(dest_dtype) != np.dtype(self._ds.dtype):
+            src_view = self._ds.decoded_dtype(dest_dtype).newbyteorder(flat.dtype.byteorder)
         if idxs is None:
             n = self._num_frames
             compressed_origin = self._start_frame
@@ -407,6 +427,10 @@ class MemPartition(Partition):
                     block = flat[idxs[g0:g1]][(slice(None),) + sig_sl]
                 if block.dtype != dest_dtype or not block.flags.c_contiguous \
                         or corrections is not None:
+                    if src_view is not None:
+                        # signed integers in the other byte order, read like the reference does:
+                        # the unsigned word (see `signed_other_order`)
+                        block = block.view(src_view)
                     block = block.astype(dest_dtype)          # corrections need a private copy
                 tile_slice = Slice(
                     origin=(compressed_origin + g0,) + tuple(sig_slice.origin[-sig_dims:]),
@@ -505,7 +529,8 @@ class MemPartition(Partition):
         # host data: double-buffered upload, chunk i+1 in flight while chunk i is processed
         host = ds.flat_host()
         part_host = host[self._local0:self._local0 + self._num_frames]
-        stager = _HipStager(device, min(depth, n), ds.shape.sig, ds.dtype,
+        stager = _HipStager(device, min(depth, n), ds.shape.sig,
+                            ds.decoded_dtype(dest_dtype if dest_dtype is not None else ds.dtype),
                             host_array=part_host if idxs is None else None,
                             swap_itemsize=ds._swap_itemsize)
 

@@ -20,4 +20,6 @@ cd $R
 python scripts/traffic_from_rocprof.py $tag $out $cfgs > $out/summary.txt 2>&1
 cp $out/summary.txt $R/gpurun_out/${tag}_configs_rocprof.txt
 cp $R/profiles/traffic.json $R/gpurun_out/${tag}_traffic.json 2>/dev/null
+# the rocpd databases are large (gpurun copies back <= 64 MiB): keep logs + summaries only
+for c in $cfgs; do rm -rf $out/${c}_stats $out/${c}_fetch $out/${c}_write $out/${c}_sq; done
 tail -5 $out/summary.txt

@@ -416,6 +416,31 @@ def gen_decode():
     save('decode', **out)
 
 
+def gen_decode_signed():
+    """signed integers through the reference's decoders (run as plain Python: the stand-in njit is the
+    identity, NumPy's scalar-into-array assignment wraps like numba's)"""
+    from libertem.io.dataset.base import decode as ref_decode
+    out = {}
+    dec = ref_decode.DtypeConversionDecoder()
+    for case in recipes.DECODE_SIGNED_CASES:
+        vals, raw = recipes.make_decode_case(case)
+        in_full = np.dtype(case['in_dtype']).newbyteorder(case['order'])
+        read = np.dtype(case['out_dtype'])
+        need = bool(dec._need_byteswap(in_full, read))
+        fn = dec.get_decode(native_dtype=in_full, read_dtype=read)
+        res = np.zeros((1, vals.size), dtype=read)
+        n = np.array(case['shape'])
+        with np.errstate(over='ignore'):
+            fn(inp=raw if need else raw.view(np.dtype(case['in_dtype'])), out=res, idx=0,
+               native_dtype=np.dtype(case['in_dtype']), rr=np.array([0, 0, raw.nbytes]),
+               origin=np.zeros(3, dtype=np.int64), shape=n, ds_shape=n)
+        out[case['name']] = res
+        out[case['name'] + '__need_swap'] = np.array(need)
+        out[case['name'] + '__sha_raw'] = np.frombuffer(bytes.fromhex(sha(raw)), dtype=np.uint8)
+        print(case['name'], need, res.dtype, int((vals < 0).sum()), 'negative inputs')
+    save('decode_signed', **out)
+
+
 # ---------------------------------------------------------------------------
 # 13. PickUDF and the pick analyses
 # ---------------------------------------------------------------------------
@@ -508,6 +533,7 @@ if __name__ == '__main__':
             json.dump(MANIFEST, f, indent=1, sort_keys=True)
         sys.exit(0)
     gen_decode()
+    gen_decode_signed()
     gen_crystallinity()
     gen_corrections()
     gen_shifts()

@@ -490,6 +490,22 @@ DECODE_CASES = [dict(name=f"{a}_to_{b}_{'be' if order == '>' else 'le'}", in_dty
                 for i, (a, b) in enumerate(DECODE_PAIRS) for order in ('<', '>')]
 
 
+# Signed integers in the other byte order: the reference composes the UNSIGNED word and stores it into
+# the read dtype (decode.py:15-66).  Same-width signed outputs wrap back to the signed value, but wider
+# integer and float outputs get the unsigned value (-1 stored big-endian reads as 65535.0).  Pinned in
+# its own fixture (decode_signed.npz) with the decoders run as plain Python.
+# (Same-width signed outputs -- int16 -> int16 ... -- cannot be run without numba: `out[i] = word`
+# raises OverflowError in plain NumPy where compiled code wraps around to the signed value.)
+DECODE_SIGNED_PAIRS = [
+    ('int16', 'int32'), ('int16', 'float32'), ('int16', 'float64'),
+    ('int32', 'int64'), ('int32', 'float64'),
+]
+DECODE_SIGNED_CASES = [
+    dict(name=f"{a}_to_{b}_{'be' if order == '>' else 'le'}", in_dtype=a, out_dtype=b, order=order,
+         seed=980 + i * 2 + (order == '>'), shape=(1, 16, 16))
+    for i, (a, b) in enumerate(DECODE_SIGNED_PAIRS) for order in ('<', '>')]
+
+
 def make_decode_case(case):
     """values (native order) and the raw bytes as they sit in a file of byte order case['order']"""
     rng = np.random.default_rng(case['seed'])

@@ -382,3 +382,25 @@ def test_decode_float_swap_refused_like_reference(golden_dir):
     with pytest.raises(NotImplementedError) as e:
         od.decode(np.zeros(8, dtype=np.uint8), np.dtype('>f4'), np.float32)
     assert str(e.value) == str(g['float_swap_error'])
+
+
+@pytest.mark.parametrize('case', recipes.DECODE_SIGNED_CASES, ids=lambda c: c['name'])
+def test_decode_signed_other_byte_order(golden_dir, case):
+    """Signed integers through the reference's byte-swapping decoders: the UNSIGNED word lands in
+    wider integer / float read dtypes (decode.py:15-66) -- the oracle and the product's NumPy tile
+    path reproduce it."""
+    from oracle import decode as odec
+    from libertem_amd.io.dataset.memory import MemoryDataSet
+    g = _load(golden_dir, 'decode_signed')
+    vals, raw = recipes.make_decode_case(case)
+    assert np.array_equal(_sha(raw), g[case['name'] + '__sha_raw'])
+    in_full = np.dtype(case['in_dtype']).newbyteorder(case['order'])
+    ref = g[case['name']].reshape(-1)
+    got = odec.decode(raw, in_full, case['out_dtype'])
+    assert got.dtype == ref.dtype and np.array_equal(got.reshape(-1), ref)
+    # product: what a tile of this data converts to for a UDF that reads `out_dtype`
+    stored = raw.view(in_full).reshape((1,) + tuple(case['shape'][1:]))
+    ds = MemoryDataSet(data=stored, sig_dims=2, num_partitions=1)
+    interp = ds.decoded_dtype(case['out_dtype'])
+    tile = stored.view(interp.newbyteorder(stored.dtype.byteorder)).astype(case['out_dtype'])
+    assert np.array_equal(tile.reshape(-1), ref)
