@@ -1436,21 +1436,30 @@ static int launch_lds_shifted(ltmi_masks *m, const T *tile, int64_t n_frames, in
         for (size_t b = 0; b < n_wg; ++b) wg_host.push_back(img);
     }
     const size_t n_wg = wg_host.size();
+    // Stacks with more than 16 real columns: one launch per 16-column group, every launch with the
+    // image pointers of ITS group (the shifted image is group-major like the standard one) and its
+    // own 16 result columns.  The frames are read once per group -- still one matrix-core launch per
+    // group and tile instead of one VALU block per frame.
+    const int n_col_groups = (m->n_cols + GROUP - 1) / GROUP;
+    const size_t group_floats = (size_t)m->n_chunks * CHUNK_FLOATS;
+    wg_host.resize(n_wg * n_col_groups);
+    for (int gi = 1; gi < n_col_groups; ++gi)
+        for (size_t b = 0; b < n_wg; ++b) wg_host[gi * n_wg + b] = wg_host[b] + gi * group_floats;
     if (c->rows_cap < rows_host.size()) {
         if (c->rows_dev) LTMI_HIP(hipFree(c->rows_dev));
         c->rows_dev = nullptr;
         c->rows_cap = rows_host.size() * 2;
         LTMI_HIP(hipMalloc((void **)&c->rows_dev, c->rows_cap * sizeof(int32_t)));
     }
-    if (c->wg_cap < n_wg) {
+    if (c->wg_cap < wg_host.size()) {
         if (c->wg_img_dev) LTMI_HIP(hipFree((void *)c->wg_img_dev));
         c->wg_img_dev = nullptr;
-        c->wg_cap = n_wg * 2;
+        c->wg_cap = wg_host.size() * 2;
         LTMI_HIP(hipMalloc((void **)&c->wg_img_dev, c->wg_cap * sizeof(float *)));
     }
     LTMI_HIP(hipMemcpyAsync(c->rows_dev, rows_host.data(), rows_host.size() * sizeof(int32_t),
                             hipMemcpyHostToDevice, stream));
-    LTMI_HIP(hipMemcpyAsync((void *)c->wg_img_dev, wg_host.data(), n_wg * sizeof(float *),
+    LTMI_HIP(hipMemcpyAsync((void *)c->wg_img_dev, wg_host.data(), wg_host.size() * sizeof(float *),
                             hipMemcpyHostToDevice, stream));
     auto kern = k_dense_lds<T, 1, 0, true>;
     static bool attr_set[16] = {false};
@@ -1459,14 +1468,16 @@ static int launch_lds_shifted(ltmi_masks *m, const T *tile, int64_t n_frames, in
                                      CFG::LDS_BYTES));
         attr_set[m->device & 15] = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(CFG::WAVES * 64), CFG::LDS_BYTES, stream, tile,
-                       ld, n_frames, m->n_px, (const float *)nullptr, m->n_chunks, out, ld_out,
-                       m->n_cols, accumulate, (float *)nullptr, 1, (const int32_t *)c->rows_dev,
-                       (const float *const *)c->wg_img_dev);
+    for (int gi = 0; gi < n_col_groups; ++gi)
+        hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(CFG::WAVES * 64), CFG::LDS_BYTES, stream,
+                           tile, ld, n_frames, m->n_px, (const float *)nullptr, m->n_chunks,
+                           out + gi * GROUP, ld_out, std::min(GROUP, m->n_cols - gi * GROUP),
+                           accumulate, (float *)nullptr, 1, (const int32_t *)c->rows_dev,
+                           (const float *const *)c->wg_img_dev + (size_t)gi * n_wg);
     LTMI_HIP(hipGetLastError());
     snprintf(m->last_kernel, sizeof(m->last_kernel),
-             "k_dense_lds<%s,NG=1,shifted> grid=(%zu,1,1) shift groups=%zu", typeid(T).name(), n_wg,
-             keys.size());
+             "k_dense_lds<%s,NG=1,shifted> grid=(%zu,1,1) x %d column group(s), shift groups=%zu",
+             typeid(T).name(), n_wg, n_col_groups, keys.size());
     *handled = true;
     return LTMI_OK;
 }
@@ -1716,7 +1727,7 @@ extern "C" int ltmi_apply_masks_shifted_host(ltmi_masks *m, const void *tile, in
     hipStream_t stream = (hipStream_t)stream_;
     const size_t esz = (size_t)dtype_size(tile_dtype);
     const bool aligned = (((uintptr_t)tile) % 16 == 0) && ((ld_tile * (int64_t)esz) % 16 == 0);
-    if (m->kind == 0 && m->n_groups == 1 && aligned && m->n_px >= KC && n_frames < (1ll << 31)) {
+    if (m->kind == 0 && aligned && m->n_px >= KC && n_frames < (1ll << 31)) {
         bool handled = false;
         int rc = LTMI_OK;
         const int64_t ldo = (m->result_dtype == LTMI_C64) ? 2 * ld_out : ld_out;

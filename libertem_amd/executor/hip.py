@@ -188,7 +188,8 @@ class HipJobExecutor(JobExecutor):
                            result_target=getattr(self, '_result_target', None))
 
     def scatter(self, obj):
-        handle = str(uuid.uuid4())
+        self._scatter_seq = getattr(self, '_scatter_seq', 0) + 1
+        handle = f"params-{self._scatter_seq}"
         self._scattered[handle] = obj
         return handle
 

@@ -19,6 +19,7 @@ lists BACKEND_HIP gets device-resident tiles (`HipArray`, native dtype) and devi
 there is no silent fallback: a HIP-only UDF on a CPU worker raises `HipRequiredError`.
 """
 import copy
+import itertools
 import uuid
 import threading
 import weakref
@@ -37,6 +38,9 @@ from libertem_amd.common.udf import UDFProtocol, UDFMethod, NUMPY, HIP
 from libertem_amd.common.exceptions import UDFException, UDFRunCancelled, JobCancelledError, \
     HipRequiredError
 from libertem_amd.io.dataset.base import Negotiator
+
+
+_RUN_IDS = itertools.count()
 
 
 def check_cast(fromvar, tovar):
@@ -468,7 +472,8 @@ class UDFBase(UDFProtocol):
         """Run get_results, wrap arrays into buffers, attach valid masks (udf/base.py:1226-1267)."""
         from libertem_amd.common.buffers import to_numpy
         results_tmp = dict(self.get_results())
-        decl = self.get_result_buffers()
+        # the declarations of this run (made by init_result_buffers from get_result_buffers())
+        decl = self.results.as_dict() if self.results is not None else self.get_result_buffers()
         # buffers with use=None that get_results did not mention are included as they are
         for k, v in decl.items():
             if k not in results_tmp and v.use is None:
@@ -494,6 +499,9 @@ class UDFBase(UDFProtocol):
         return results
 
     def _result_shape(self, buf_decl, arr):
+        shape = getattr(buf_decl, 'shape', None)
+        if shape is not None and prod(shape) == arr.size and buf_decl._ds_shape is not None:
+            return shape                     # the run's own (dataset-shaped) buffer
         tmp = BufferWrapper(buf_decl.kind, buf_decl.extra_shape, buf_decl.dtype)
         tmp.set_roi(self.meta.roi)
         tmp.set_shape_ds(self.meta.dataset_shape, self.meta.roi)
@@ -1117,7 +1125,7 @@ class UDFRunner:
             roi = np.asarray(roi, dtype=bool)
         tasks, params = self._prepare_run_for_dataset(dataset, executor, roi, corrections,
                                                       backends, dry)
-        cancel_id = str(uuid.uuid4())
+        cancel_id = f"run-{next(_RUN_IDS)}"
         damage = BufferWrapper(kind='nav', dtype=bool)
         damage.set_roi(roi)
         damage.set_shape_ds(dataset.shape, roi)

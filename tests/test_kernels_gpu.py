@@ -556,7 +556,9 @@ def _shift_ref(data3d, masks3d, shifts):
     ('float32', (32, 32), 16, 'float32', 'k_dense_lds'),
     ('uint8', (32, 64), 3, 'complex64', 'k_dense_lds'),
     ('uint16', (17, 23), 4, 'float32', 'k_dense_shifted'),   # unaligned rows -> per-frame kernel
-    ('uint16', (32, 32), 20, 'float32', 'k_dense_shifted'),  # two column groups -> per-frame kernel
+    ('uint16', (32, 32), 20, 'float32', 'x 2 column group'),  # two column groups: MFMA path, two launches
+    ('uint16', (32, 32), 70, 'float32', 'x 5 column group'),  # > 64 columns (column blocks of the handle)
+    ('float32', (32, 32), 13, 'complex64', 'x 2 column group'),   # 26 real columns
     ('int32', (16, 32), 2, 'float64', 'k_dense_shifted'),    # float64 result -> generic
 ])
 def test_shifted_masks_host_shifts(hip, tile_dtype, sig, n_masks, mask_dtype, expect):
