@@ -257,6 +257,20 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
                     b0[t] = *(const T *)(p0 + t * C::TILE_OFF);
                     b1[t] = *(const T *)(p1 + t * C::TILE_OFF);
                 }
+#ifndef BE_NO_GATHER_GROUP
+                // all gathers of the record in flight together: left alone the compiler reuses one
+                // register and issues the last gather behind the first MFMAs -- a third dependent LDS
+                // round trip per record
+                {
+                    float g0f[TILES], g1f[TILES];       // (the conversions follow the gathers anyway)
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t) { g0f[t] = (float)b0[t]; g1f[t] = (float)b1[t]; }
+                    if constexpr (TILES == 2)
+                        asm volatile("" ::"v"(g0f[0]), "v"(g0f[1]), "v"(g1f[0]), "v"(g1f[1]));
+                    else
+                        asm volatile("" ::"v"(g0f[0]), "v"(g1f[0]));
+                }
+#endif
 #ifdef BE_PROF
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 BE_STAMP(1);
