@@ -2,6 +2,8 @@
 Build libltmi.so (the C-ABI HIP library) for gfx950 with hipcc, in-tree.
 
     python -m libertem_amd.build [--force]
+    python -m libertem_amd.build --hardened  # host side with checked std:: containers ->
+                                             # libertem_amd/_lib/libltmi_hardened.so
     python -m libertem_amd.build --asan      # host side instrumented with AddressSanitizer ->
                                              # libertem_amd/_lib/libltmi_asan.so
 
@@ -48,16 +50,28 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True, asan=False):
-    """asan=True: the HOST code of the library (image builders, argument checks, the C ABI) compiled
-    with -fsanitize=address into libltmi_asan.so (device code unchanged).  Load it with
-    LTMI_LIB=<path> and LD_PRELOAD=$(hipcc -print-file-name=libclang_rt.asan-x86_64.so), e.g.
-        LTMI_LIB=libertem_amd/_lib/libltmi_asan.so LD_PRELOAD=... ASAN_OPTIONS=detect_leaks=0 \
-            python -m pytest tests -m gpu -k kernels"""
+def build(force=False, verbose=True, asan=False, hardened=False):
+    """Sanitizer builds of the HOST code of the library (image builders, argument checks, the C ABI;
+    device code unchanged), selected at run time with LTMI_LIB=<path>:
+
+    hardened=True -> libltmi_hardened.so: -D_GLIBCXX_ASSERTIONS (every std::vector / std::string
+        index of the image builders is bounds-checked and aborts with a message) + stack protector;
+        no sanitizer runtime, so it coexists with the stock torch wheel (host-side -fsanitize=undefined
+        was tried too: hipcc then mis-launches the unaligned-row kernel variants, so it is left out):
+            LTMI_LIB=libertem_amd/_lib/libltmi_hardened.so python -m pytest tests -m gpu
+    asan=True -> libltmi_asan.so (-fsanitize=address).  Needs an ASAN-enabled ROCm stack: ROCm's ASAN
+        runtime intercepts the HSA allocator and aborts inside the un-instrumented HIP runtime that the
+        torch wheel bundles (observed on this image), so with stock torch use the hardened build.
+            LTMI_LIB=.../libltmi_asan.so LD_PRELOAD=$(clang -print-file-name=libclang_rt.asan-x86_64.so)"""
     hipcc = find_hipcc()
-    objdir = OBJDIR + ('_asan' if asan else '')
-    lib = LIB.replace('libltmi.so', 'libltmi_asan.so') if asan else LIB
-    extra = ['-fsanitize=address', '-fno-omit-frame-pointer', '-g', '-shared-libsan'] if asan else []
+    tag = '_asan' if asan else ('_hardened' if hardened else '')
+    objdir = OBJDIR + tag
+    lib = LIB.replace('libltmi.so', f'libltmi{tag}.so')
+    extra = []
+    if asan:
+        extra = ['-fsanitize=address', '-fno-omit-frame-pointer', '-g', '-shared-libsan']
+    elif hardened:
+        extra = ['-D_GLIBCXX_ASSERTIONS', '-Xarch_host', '-fstack-protector-strong']
     os.makedirs(objdir, exist_ok=True)
     jobs = []
     objs = []
@@ -87,4 +101,5 @@ def build(force=False, verbose=True, asan=False):
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, asan='--asan' in sys.argv))
+    print(build(force='--force' in sys.argv, asan='--asan' in sys.argv,
+                hardened='--hardened' in sys.argv))
