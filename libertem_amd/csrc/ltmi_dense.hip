@@ -298,17 +298,20 @@ k_dense_mfma(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
 // 7.0 TB/s.  Here every wave instruction is a global_load_lds_dwordx4 that moves 4 frame rows x 256 B
 // (whole 128-B lines) straight into LDS; MFMA A fragments are then ds_read from there.
 //
-//   * 8 waves (2 per SIMD, so one wave's DMA issue / LDS latency hides under the other's MFMAs),
-//     each owns 16 frames; per wave a ring of sub-chunk slots (16 rows x 256 B = 4 KiB each).
+//   * a workgroup is 128 frames: 4 waves (one per SIMD) of 32 frames = two 16-frame MFMA tiles each
+//     (TILES = 2; the first version had 8 waves of 16 frames: bit-identical results, but every mask
+//     fragment read from LDS fed only one tile -- twice the mask-fragment LDS traffic per MFMA, and
+//     these kernels sit at the board's power cap: profiles/r02_tiles.txt, 5-11 % slower on C2);
+//     per wave a ring of sub-chunk slots (32 rows x 256 B = 8 KiB each).
 //   * the 16 pieces (16 B) of a row are stored at piece ^ (row & 15): the 16 lanes of every
 //     ds_read_b128 service group (16 different rows) hit 16 different slots.  LDS-DMA writes
 //     lane-linear, so the permutation is applied to the per-lane SOURCE address.
 //   * mask slots also arrive by LDS-DMA (linear copies of the pre-swizzled image), 2 slots, shared
 //     by the 8 waves, one s_barrier per slot.
 //   * counted waits, never vmcnt(0) in the loop (DMA completes in order per wave).
-constexpr int V2_ROWS = 16;                         // frames per wave
+constexpr int V2_ROWS = 16;                         // frames per MFMA tile
 constexpr int V2_SUB_BYTES = 256;                   // bytes of a row per sub-chunk
-constexpr int V2_ASLOT = V2_ROWS * V2_SUB_BYTES;    // 4 KiB per wave per slot
+constexpr int V2_ASLOT = V2_ROWS * V2_SUB_BYTES;    // 4 KiB per frame tile and ring slot
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *glb_ptr_t;
@@ -334,17 +337,23 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 // of a stack with 16 NG + NE columns, e.g. 25 complex masks = 48 + 2) are accumulated on the VALU
 // from the already converted frame fragments -- instead of a whole extra MFMA group of padding.
 // Their slot is 32 KiB: NG x 8 KiB of groups, then NE x 512 B of plain (column, pixel) floats.
-template <int NG, int NE = 0> struct LdsCfg {
+// TILES: 16-frame tiles per wave.  With 2, a workgroup is 4 waves of 32 frames (same 128 frames, same
+// LDS): one mask fragment read from LDS feeds the MFMAs of two frame tiles, i.e. half the mask-fragment
+// LDS traffic per MFMA -- these kernels run into the board's power cap, so energy per frame is time.
+template <int NG, int NE = 0, int TILES = 1> struct LdsCfg {
     static constexpr int KB = (NG == 1 && NE == 0) ? KC : 128;  // pixels per mask slot
-    // bytes per mask slot; with extras: the NG groups + NE plain columns, rounded up to 8 KiB (each of
-    // the 8 waves copies 1/8 of a slot in whole 1-KiB DMA instructions): 16 / 24 / 32 KiB
+    // bytes per mask slot; with extras: the NG groups + NE plain columns, rounded up to 8 KiB (every
+    // wave copies an equal share of a slot in whole 1-KiB DMA instructions): 16 / 24 / 32 KiB
     static constexpr int BSLOT = NE > 0 ? (NG * GROUP * KB * 4 + NE * KB * 4 + 8191) / 8192 * 8192
                                         : NG * GROUP * KB * 4;
     static constexpr int EXTRA_OFF = NG * GROUP * KB;           // float offset of the extras in a slot
     static_assert(NE == 0 || (NG * GROUP * KB * 4 + NE * KB * 4 <= BSLOT), "extras must fit the slot");
     static constexpr int RING = BSLOT > 16384 ? 3 : 4;          // frame ring depth (sub-chunks)
-    static constexpr int WAVES = 8;
-    static constexpr int LDS_BYTES = RING * WAVES * V2_ASLOT + 2 * BSLOT;      // 160 KiB
+    static constexpr int WAVES = 8 / TILES;
+    static constexpr int ROWS = V2_ROWS * TILES;                // frames per wave
+    static constexpr int ASLOT = ROWS * V2_SUB_BYTES;           // bytes per wave and ring slot
+    static constexpr int WG_ROWS = WAVES * ROWS;                // 128 frames per workgroup
+    static constexpr int LDS_BYTES = RING * WAVES * ASLOT + 2 * BSLOT;         // 160 KiB
 };
 
 __host__ __device__ static inline int img2_index(int n, int q, int kb) {
@@ -420,8 +429,8 @@ __global__ void k_build_image3(const float *__restrict__ src, float *__restrict_
     }
 }
 
-template <typename T, int NG, int ABL = 0, bool IND = false, int NE = 0>
-__global__ void __launch_bounds__(512)                          // LdsCfg::WAVES * 64
+template <typename T, int NG, int ABL = 0, bool IND = false, int NE = 0, int TILES = 1>
+__global__ void __launch_bounds__(512 / TILES)                  // LdsCfg::WAVES * 64
 k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
             const float *__restrict__ img, int n_slots, float *__restrict__ out, int64_t ld_out,
             int n_cols, int accumulate, float *__restrict__ partials, int ksplit,
@@ -429,18 +438,21 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             const float *const *__restrict__ wg_img = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     using TR = InTraits<T>;
-    using CFG = LdsCfg<NG, NE>;
+    using CFG = LdsCfg<NG, NE, TILES>;
     constexpr int WAVES = CFG::WAVES, RING = CFG::RING, KB = CFG::KB, BSLOT = CFG::BSLOT;
+    constexpr int ROWS = CFG::ROWS, ASLOT = CFG::ASLOT;
+    constexpr int ND = 4 * TILES;                       // DMA instructions per sub-chunk (4 rows each)
     constexpr int SPX = V2_SUB_BYTES / (int)sizeof(T);  // pixels per sub-chunk
     static_assert(SPX <= KB && KB % SPX == 0, "a sub-chunk must not straddle mask slots");
     constexpr int PER = KB / SPX;                       // sub-chunks per mask slot
     constexpr int BLKS = SPX / 32;                      // MFMA pixel blocks per sub-chunk (2/4/8)
     constexpr int NT = WAVES * 64;
-    constexpr int A_BYTES = RING * WAVES * V2_ASLOT;
+    constexpr int A_BYTES = RING * WAVES * ASLOT;
     constexpr int BPW = BSLOT / WAVES;                  // mask-slot bytes each wave copies
     constexpr int NBI = BPW / 1024;                     // ... in this many DMA instructions
-    constexpr int A_N = 4 * (RING - 2);                 // DMA instructions of the later sub-chunks
-    constexpr int NACC = NG == 1 ? 2 : 1;               // accumulators per group
+    constexpr int A_N = ND * (RING - 2);                // DMA instructions of the later sub-chunks
+    static_assert(A_N + 2 * NBI < 64, "vmcnt is a 6-bit counter");
+    constexpr int NACC = NG == 1 ? 2 : 1;               // accumulators per group and frame tile
     constexpr int SLOT_FLOATS = BSLOT / 4;
     constexpr bool CVT = !std::is_same<T, float>::value;
 
@@ -458,36 +470,40 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
     const int kf_end = min(k_end, n_full);
     const float *img_t = IND ? wg_img[blockIdx.x] : img + (size_t)gt * n_slots * SLOT_FLOATS;
 
-    const int64_t f_wave = (int64_t)blockIdx.x * (WAVES * V2_ROWS) + wave * V2_ROWS;
+    const int64_t f_wave = (int64_t)blockIdx.x * (WAVES * ROWS) + wave * ROWS;
     // frame behind row r of this wave (IND: through the row list; -1 = nothing there)
     auto frame_of = [&](int r) -> int64_t {
         if (IND) return rows[f_wave + r];
         const int64_t f = f_wave + r;
         return f < n_frames ? f : -1;
     };
-    unsigned char *a_base = lds_raw + wave * V2_ASLOT;   // + slot * (WAVES * V2_ASLOT)
+    unsigned char *a_base = lds_raw + wave * ASLOT;      // + slot * (WAVES * ASLOT)
     unsigned char *b_base = lds_raw + A_BYTES;           // + bslot * BSLOT
 
-    f32x4 acc[NG][NACC];
+    f32x4 acc[TILES][NG][NACC];
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
+    for (int tl = 0; tl < TILES; ++tl)
 #pragma unroll
-        for (int x = 0; x < NACC; ++x) acc[g][x] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float acc_e[NE > 0 ? NE : 1];                        // VALU columns: partial over this lane's pixels
+        for (int g = 0; g < NG; ++g)
 #pragma unroll
-    for (int c = 0; c < (NE > 0 ? NE : 1); ++c) acc_e[c] = 0.f;
+            for (int x = 0; x < NACC; ++x) acc[tl][g][x] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float acc_e[TILES][NE > 0 ? NE : 1];                 // VALU columns: partial over this lane's pixels
+#pragma unroll
+    for (int tl = 0; tl < TILES; ++tl)
+#pragma unroll
+        for (int c = 0; c < (NE > 0 ? NE : 1); ++c) acc_e[tl][c] = 0.f;
 
     // lane-constant parts of the fragment addresses
-    const int a_lane = m * V2_SUB_BYTES;                 // bytes inside a frame slot
+    const int a_lane = m * V2_SUB_BYTES;                 // bytes inside a frame tile of a ring slot
     const int b_lane = m * KB;                           // floats inside a group of a mask slot
     auto b_unit = [&](int blk_in_slot, int h) {          // swizzled 16-B unit of (blk, h) for this lane
         return ((kg * (KB / 16) + blk_in_slot * 2 + h) ^ m) << 2;
     };
 
     if (k_begin < kf_end) {
-        const unsigned char *src[4];
+        const unsigned char *src[ND];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < ND; ++t) {
             const int r = 4 * t + (lane >> 4);
             int64_t f = frame_of(r);
             if (f < 0) f = IND ? 0 : n_frames - 1;      // clamp: loads stay valid, result discarded
@@ -500,7 +516,7 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
         auto issue_a1 = [&](int s, int slot, int t) {
             if (ABL >= 2) return;
             const int sc = min(s, S1 - 1);
-            unsigned char *dst = a_base + slot * (WAVES * V2_ASLOT);
+            unsigned char *dst = a_base + slot * (WAVES * ASLOT);
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[t] + (int64_t)sc * V2_SUB_BYTES),
                                              (lds_ptr_t)(dst + t * 1024), 16, 0, 2 /*nt*/);
         };
@@ -516,12 +532,12 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
         };
 
 #pragma unroll
-        for (int t = 0; t < 4; ++t) issue_a1(S0, 0, t);
+        for (int t = 0; t < ND; ++t) issue_a1(S0, 0, t);
         issue_b(0);
 #pragma unroll
         for (int d = 1; d < RING - 1; ++d)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) issue_a1(S0 + d, d, t);
+            for (int t = 0; t < ND; ++t) issue_a1(S0 + d, d, t);
 
         // One sub-chunk.  ph = i % UNROLL as a compile-time constant in the unrolled main loop
         // (ring slot, mask slot and block offsets become immediates) or -1 in the generic tail.
@@ -535,7 +551,7 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             // ip > 0: A(s) must have landed; later sub-chunks and every mask slot issued after
             // A(s) (iterations i-ip-k*PER >= i-RING+2) may stay in flight.
             if (ip == 0) {
-                constexpr int N0 = 4 * (PER < RING - 2 ? PER : RING - 2);
+                constexpr int N0 = ND * (PER < RING - 2 ? PER : RING - 2);
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N0) : "memory");
                 if (ABL < 3) __builtin_amdgcn_s_barrier();
                 issue_b(i / PER + 1);
@@ -551,19 +567,20 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             const int nslot = PH >= 0 ? (PH + RING - 1) % RING : (i + RING - 1) % RING;
             const int bsl = PH >= 0 ? (PH / PER) & 1 : (i / PER) & 1;
             const int blk0 = ip * BLKS;                             // block offset inside the mask slot
-            const unsigned char *aslot = a_base + slot * (WAVES * V2_ASLOT) + a_lane;
+            const unsigned char *aslot = a_base + slot * (WAVES * ASLOT) + a_lane;
             const float *bslot = (const float *)(b_base + bsl * BSLOT) + b_lane;
-            auto rd_a = [&](int blk) {
+            auto rd_a = [&](int tl, int blk) {
+                const unsigned char *at = aslot + tl * V2_ASLOT;
                 const int u = blk * 4 + kg;             // 8-pixel unit of this lane inside the sub-chunk
                 if constexpr (sizeof(T) == 2) {
-                    return *(const typename TR::raw_t *)(aslot + ((u ^ m) << 4));
+                    return *(const typename TR::raw_t *)(at + ((u ^ m) << 4));
                 } else if constexpr (sizeof(T) == 4) {
                     typename TR::raw_t r;
-                    r.a = *(const f32x4 *)(aslot + (((2 * u) ^ m) << 4));
-                    r.b = *(const f32x4 *)(aslot + (((2 * u + 1) ^ m) << 4));
+                    r.a = *(const f32x4 *)(at + (((2 * u) ^ m) << 4));
+                    r.b = *(const f32x4 *)(at + (((2 * u + 1) ^ m) << 4));
                     return r;
                 } else {
-                    return *(const typename TR::raw_t *)(aslot + (((u >> 1) ^ m) << 4) + (u & 1) * 8);
+                    return *(const typename TR::raw_t *)(at + (((u >> 1) ^ m) << 4) + (u & 1) * 8);
                 }
             };
             auto rd_b = [&](int blk, int g, int h) {
@@ -575,7 +592,9 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                 return *(const f32x4 *)(bslot - b_lane + CFG::EXTRA_OFF + c * KB +
                                         (blk0 + blk) * 32 + kg * 8 + h * 4);
             };
-            typename TR::raw_t raw_c = rd_a(0);
+            typename TR::raw_t raw_c[TILES];
+#pragma unroll
+            for (int tl = 0; tl < TILES; ++tl) raw_c[tl] = rd_a(tl, 0);
             f32x4 b_c[NG][2];
 #pragma unroll
             for (int g = 0; g < NG; ++g) { b_c[g][0] = rd_b(0, g, 0); b_c[g][1] = rd_b(0, g, 1); }
@@ -584,7 +603,9 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             for (int c = 0; c < NE; ++c) { e_c[c][0] = rd_e(0, c, 0); e_c[c][1] = rd_e(0, c, 1); }
 #pragma unroll
             for (int blk = 0; blk < BLKS; ++blk) {
-                typename TR::raw_t raw_n = raw_c;
+                typename TR::raw_t raw_n[TILES];
+#pragma unroll
+                for (int tl = 0; tl < TILES; ++tl) raw_n[tl] = raw_c[tl];
                 f32x4 b_n[NG][2];
 #pragma unroll
                 for (int g = 0; g < NG; ++g) { b_n[g][0] = b_c[g][0]; b_n[g][1] = b_c[g][1]; }
@@ -592,7 +613,8 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
 #pragma unroll
                 for (int c = 0; c < NE; ++c) { e_n[c][0] = e_c[c][0]; e_n[c][1] = e_c[c][1]; }
                 if (blk + 1 < BLKS) {
-                    raw_n = rd_a(blk + 1);
+#pragma unroll
+                    for (int tl = 0; tl < TILES; ++tl) raw_n[tl] = rd_a(tl, blk + 1);
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
                         b_n[g][0] = rd_b(blk + 1, g, 0);
@@ -604,34 +626,42 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                         e_n[c][1] = rd_e(blk + 1, c, 1);
                     }
                 }
-                // the 4 DMA instructions of sub-chunk s+RING-1 are spread over the BLKS blocks
+                // the DMA instructions of sub-chunk s+RING-1 are spread over the BLKS blocks
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    if ((t * BLKS) / 4 == blk) issue_a1(s + RING - 1, nslot, t);
+                for (int t = 0; t < ND; ++t)
+                    if ((t * BLKS) / ND == blk) issue_a1(s + RING - 1, nslot, t);
                 __builtin_amdgcn_sched_barrier(0);      // keep the prefetch reads above the MFMAs
-                float a[8];
-                TR::cvt(raw_c, a);
+                float a[TILES][8];
+#pragma unroll
+                for (int tl = 0; tl < TILES; ++tl) TR::cvt(raw_c[tl], a[tl]);
                 if (ABL == 1) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
 #pragma unroll
-                        for (int g = 0; g < NG; ++g)
-                            acc[g][j & (NACC - 1)][j & 3] += a[j] + b_c[g][j >> 2][j & 3];
+                        for (int tl = 0; tl < TILES; ++tl)
+#pragma unroll
+                            for (int g = 0; g < NG; ++g)
+                                acc[tl][g][j & (NACC - 1)][j & 3] += a[tl][j] + b_c[g][j >> 2][j & 3];
                 } else {
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
 #pragma unroll
-                        for (int g = 0; g < NG; ++g)
-                            acc[g][j & (NACC - 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                a[j], b_c[g][j >> 2][j & 3], acc[g][j & (NACC - 1)], 0, 0, 0);
-                    if (CVT) __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);     // 8 conversions
-                    __builtin_amdgcn_sched_group_barrier(0x008, 8 * NG, 0);         // then the MFMAs
+                        for (int tl = 0; tl < TILES; ++tl)
+#pragma unroll
+                            for (int g = 0; g < NG; ++g)
+                                acc[tl][g][j & (NACC - 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                    a[tl][j], b_c[g][j >> 2][j & 3], acc[tl][g][j & (NACC - 1)], 0, 0, 0);
+                    if (CVT) __builtin_amdgcn_sched_group_barrier(0x002, 8 * TILES, 0);  // conversions
+                    __builtin_amdgcn_sched_group_barrier(0x008, 8 * NG * TILES, 0);      // then the MFMAs
                 }
 #pragma unroll
-                for (int c = 0; c < NE; ++c)
+                for (int tl = 0; tl < TILES; ++tl)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc_e[c] += a[j] * e_c[c][j >> 2][j & 3];
-                raw_c = raw_n;
+                    for (int c = 0; c < NE; ++c)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc_e[tl][c] += a[tl][j] * e_c[c][j >> 2][j & 3];
+#pragma unroll
+                for (int tl = 0; tl < TILES; ++tl) raw_c[tl] = raw_n[tl];
 #pragma unroll
                 for (int g = 0; g < NG; ++g) { b_c[g][0] = b_n[g][0]; b_c[g][1] = b_n[g][1]; }
 #pragma unroll
@@ -664,68 +694,76 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
         for (int i = 0; i < SLOT_FLOATS / 4 / NT; ++i)
             ((u32x4 *)bl)[i * NT + tid] = img_units[i * NT + tid];
         __syncthreads();
-        int64_t f = frame_of(m);
-        if (f < 0) f = IND ? 0 : n_frames - 1;
-        const T *rowp = tile + f * ld + kg * 8;
         const float *ldsb = bl + b_lane;
 #pragma unroll
-        for (int blk = 0; blk < KB / 32; ++blk) {
-            const int64_t p0 = (int64_t)k * KB + blk * 32;
-            float a[8];
+        for (int tl = 0; tl < TILES; ++tl) {
+            int64_t f = frame_of(tl * 16 + m);
+            if (f < 0) f = IND ? 0 : n_frames - 1;
+            const T *rowp = tile + f * ld + kg * 8;
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                a[j] = (p0 + kg * 8 + j < n_px) ? (float)rowp[p0 + j] : 0.f;
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                f32x4 b[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    b[h] = *(const f32x4 *)(ldsb + g * (GROUP * KB) + b_unit(blk, h));
+            for (int blk = 0; blk < KB / 32; ++blk) {
+                const int64_t p0 = (int64_t)k * KB + blk * 32;
+                float a[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    acc[g][j & (NACC - 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                        a[j], b[j >> 2][j & 3], acc[g][j & (NACC - 1)], 0, 0, 0);
+                    a[j] = (p0 + kg * 8 + j < n_px) ? (float)rowp[p0 + j] : 0.f;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    f32x4 b[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        b[h] = *(const f32x4 *)(ldsb + g * (GROUP * KB) + b_unit(blk, h));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        acc[tl][g][j & (NACC - 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                            a[j], b[j >> 2][j & 3], acc[tl][g][j & (NACC - 1)], 0, 0, 0);
+                }
+#pragma unroll
+                for (int c = 0; c < NE; ++c)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        acc_e[tl][c] += a[j] * bl[CFG::EXTRA_OFF + c * KB + blk * 32 + kg * 8 + j];
             }
-#pragma unroll
-            for (int c = 0; c < NE; ++c)
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    acc_e[c] += a[j] * bl[CFG::EXTRA_OFF + c * KB + blk * 32 + kg * 8 + j];
         }
     }
 
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
+    for (int tl = 0; tl < TILES; ++tl)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t f = frame_of(kg * 4 + r);
-            const int col = (gt * NG + g) * GROUP + m;
-            if (f >= 0 && col < n_cols) {
-                float v = acc[g][0][r];
-                if (NACC == 2) v += acc[g][NACC - 1][r];
-                if (ksplit == 1) {
-                    float *p = out + f * ld_out + col;
-                    *p = accumulate ? (*p + v) : v;
-                } else {
-                    partials[((int64_t)ks * n_frames + f) * n_cols + col] = v;
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t f = frame_of(tl * 16 + kg * 4 + r);
+                const int col = (gt * NG + g) * GROUP + m;
+                if (f >= 0 && col < n_cols) {
+                    float v = acc[tl][g][0][r];
+                    if (NACC == 2) v += acc[tl][g][NACC - 1][r];
+                    if (ksplit == 1) {
+                        float *p = out + f * ld_out + col;
+                        *p = accumulate ? (*p + v) : v;
+                    } else {
+                        partials[((int64_t)ks * n_frames + f) * n_cols + col] = v;
+                    }
                 }
             }
-        }
     if constexpr (NE > 0) {
         // lane (m, kg) holds frame m's partial over its own pixels: sum the 4 kg lanes
-        const int64_t f = frame_of(m);
 #pragma unroll
-        for (int c = 0; c < NE; ++c) {
-            float v = acc_e[c];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            const int col = NG * GROUP + c;
-            if (kg == 0 && f >= 0 && col < n_cols) {
-                if (ksplit == 1) {
-                    float *p = out + f * ld_out + col;
-                    *p = accumulate ? (*p + v) : v;
-                } else {
-                    partials[((int64_t)ks * n_frames + f) * n_cols + col] = v;
+        for (int tl = 0; tl < TILES; ++tl) {
+            const int64_t f = frame_of(tl * 16 + m);
+#pragma unroll
+            for (int c = 0; c < NE; ++c) {
+                float v = acc_e[tl][c];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                const int col = NG * GROUP + c;
+                if (kg == 0 && f >= 0 && col < n_cols) {
+                    if (ksplit == 1) {
+                        float *p = out + f * ld_out + col;
+                        *p = accumulate ? (*p + v) : v;
+                    } else {
+                        partials[((int64_t)ks * n_frames + f) * n_cols + col] = v;
+                    }
                 }
             }
         }
@@ -1131,8 +1169,9 @@ extern "C" int ltmi_masks_kind(const ltmi_masks *m, int *kind) {
 
 extern "C" int ltmi_masks_set_tuning(ltmi_masks *m, int mt, int waves, int ksplit) {
     if (!m) LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_set_tuning: null handle");
-    if (mt == 0 && ((waves >= 30 && waves <= 33) || (waves >= 40 && waves <= 41))) {
-        // k_dense_lds: 30 = as dispatched, 31 / 32 = timing-only ablations (no DMA / no MFMA);
+    if (mt == 0 && ((waves >= 30 && waves <= 35) || (waves >= 40 && waves <= 41))) {
+        // k_dense_lds: 30 = as dispatched, 31 / 32 = timing-only ablations (no DMA / no MFMA),
+        // 34 / 35 = one / two frame tiles per wave;
         // sparse stacks: 40 = as dispatched, 41 = SELL kernel even if a blocked image exists
         m->tune_mt = 0;
         m->tune_waves = 0;
@@ -1193,15 +1232,23 @@ static int ensure_partials(ltmi_masks *m, size_t need, hipStream_t stream) {
     return LTMI_OK;
 }
 
+// frame tiles per wave (LdsCfg): 2 unless a bench run forces one of them
+// (ltmi_masks_set_tuning waves code 34 = one tile / 8 waves, 35 = two tiles / 4 waves)
+static inline int lds_tiles(const ltmi_masks *m) {
+    return m->tune_ksplit_ring == 34 ? 1 : 2;
+}
+
 // generalised LDS-DMA kernel (k_dense_lds): any pixel width, 1 / 2 / 4 column groups per wave
-template <typename T, int NG>
-static int launch_lds_ng(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
-                         int64_t ld_out, int accumulate, hipStream_t stream) {
-    using CFG = LdsCfg<NG>;
+template <typename T, int NG, int TILES>
+static int launch_lds_ng_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
+                           int64_t ld_out, int accumulate, hipStream_t stream) {
+    using CFG = LdsCfg<NG, 0, TILES>;
     const int abl = m->tune_ksplit_ring == 31 ? 2 : (m->tune_ksplit_ring == 32 ? 1 : 0);
     void (*kern)(const T *, int64_t, int64_t, int64_t, const float *, int, float *, int64_t, int,
                  int, float *, int, const int32_t *, const float *const *) =
-        abl == 2 ? k_dense_lds<T, NG, 2> : (abl == 1 ? k_dense_lds<T, NG, 1> : k_dense_lds<T, NG, 0>);
+        abl == 2 ? k_dense_lds<T, NG, 2, false, 0, TILES>
+                 : (abl == 1 ? k_dense_lds<T, NG, 1, false, 0, TILES>
+                             : k_dense_lds<T, NG, 0, false, 0, TILES>);
     static bool attr_set[16][3] = {{false}};
     if (!attr_set[m->device & 15][abl]) {
         LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1210,7 +1257,7 @@ static int launch_lds_ng(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t
     }
     const float *img = NG == 1 ? m->img : m->img2;
     const int n_slots = NG == 1 ? m->n_chunks : m->n_slots2;
-    const int64_t gx = (n_frames + CFG::WAVES * V2_ROWS - 1) / (CFG::WAVES * V2_ROWS);
+    const int64_t gx = (n_frames + CFG::WG_ROWS - 1) / CFG::WG_ROWS;
     const int64_t gz = m->n_groups / NG;
     int ksplit = m->tune_ksplit;
     if (ksplit <= 0) {
@@ -1233,9 +1280,9 @@ static int launch_lds_ng(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t
                        m->n_px, img, n_slots, out, ld_out, m->n_cols, accumulate, m->partials,
                        ksplit, (const int32_t *)nullptr, (const float *const *)nullptr);
     LTMI_HIP(hipGetLastError());
-    snprintf(m->last_kernel, sizeof(m->last_kernel), "k_dense_lds<%s,NG=%d,ring=%d%s> grid=(%u,%u,%u)",
-             typeid(T).name(), NG, CFG::RING, abl ? (abl == 2 ? ",noDMA" : ",noMFMA") : "", grid.x,
-             grid.y, grid.z);
+    snprintf(m->last_kernel, sizeof(m->last_kernel),
+             "k_dense_lds<%s,NG=%d,ring=%d,tiles=%d%s> grid=(%u,%u,%u)", typeid(T).name(), NG,
+             CFG::RING, TILES, abl ? (abl == 2 ? ",noDMA" : ",noMFMA") : "", grid.x, grid.y, grid.z);
     if (ksplit > 1) {
         const int64_t n = n_frames * m->n_cols;
         hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
@@ -1246,12 +1293,20 @@ static int launch_lds_ng(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t
     return LTMI_OK;
 }
 
+template <typename T, int NG>
+static int launch_lds_ng(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
+                         int64_t ld_out, int accumulate, hipStream_t stream) {
+    if (lds_tiles(m) == 2)
+        return launch_lds_ng_t<T, NG, 2>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+    return launch_lds_ng_t<T, NG, 1>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+}
+
 // NG MFMA groups + NE VALU columns (stacks of 16 NG + 1..4 columns)
-template <typename T, int NG, int NE>
-static int launch_lds_extras(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
-                             int64_t ld_out, int accumulate, hipStream_t stream) {
-    using CFG = LdsCfg<NG, NE>;
-    auto kern = k_dense_lds<T, NG, 0, false, NE>;
+template <typename T, int NG, int NE, int TILES>
+static int launch_lds_extras_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
+                               int64_t ld_out, int accumulate, hipStream_t stream) {
+    using CFG = LdsCfg<NG, NE, TILES>;
+    auto kern = k_dense_lds<T, NG, 0, false, NE, TILES>;
     static bool attr_set[16] = {false};
     if (!attr_set[m->device & 15]) {
         LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1259,7 +1314,7 @@ static int launch_lds_extras(ltmi_masks *m, const T *tile, int64_t n_frames, int
         attr_set[m->device & 15] = true;
     }
     const int n_slots = m->n_slots3;
-    const int64_t gx = (n_frames + CFG::WAVES * V2_ROWS - 1) / (CFG::WAVES * V2_ROWS);
+    const int64_t gx = (n_frames + CFG::WG_ROWS - 1) / CFG::WG_ROWS;
     int ksplit = m->tune_ksplit;
     if (ksplit <= 0) {
         ksplit = 1;
@@ -1282,11 +1337,12 @@ static int launch_lds_extras(ltmi_masks *m, const T *tile, int64_t n_frames, int
     LTMI_HIP(hipGetLastError());
     if (NE > 0)
         snprintf(m->last_kernel, sizeof(m->last_kernel),
-                 "k_dense_lds<%s,NG=%d+%d VALU columns,ring=%d> grid=(%u,%u,1)", typeid(T).name(), NG,
-                 NE, CFG::RING, grid.x, grid.y);
+                 "k_dense_lds<%s,NG=%d+%d VALU columns,ring=%d,tiles=%d> grid=(%u,%u,1)",
+                 typeid(T).name(), NG, NE, CFG::RING, TILES, grid.x, grid.y);
     else
-        snprintf(m->last_kernel, sizeof(m->last_kernel), "k_dense_lds<%s,NG=%d,ring=%d> grid=(%u,%u,1)",
-                 typeid(T).name(), NG, CFG::RING, grid.x, grid.y);
+        snprintf(m->last_kernel, sizeof(m->last_kernel),
+                 "k_dense_lds<%s,NG=%d,ring=%d,tiles=%d> grid=(%u,%u,1)", typeid(T).name(), NG,
+                 CFG::RING, TILES, grid.x, grid.y);
     if (ksplit > 1) {
         const int64_t n = n_frames * m->n_cols;
         hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
@@ -1295,6 +1351,15 @@ static int launch_lds_extras(ltmi_masks *m, const T *tile, int64_t n_frames, int
         LTMI_HIP(hipGetLastError());
     }
     return LTMI_OK;
+}
+
+template <typename T, int NG, int NE>
+static int launch_lds_extras(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
+                             int64_t ld_out, int accumulate, hipStream_t stream) {
+    if (lds_tiles(m) == 2)
+        return launch_lds_extras_t<T, NG, NE, 2>(m, tile, n_frames, ld, out, ld_out, accumulate,
+                                                 stream);
+    return launch_lds_extras_t<T, NG, NE, 1>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
 }
 
 template <typename T>
@@ -1363,7 +1428,7 @@ static int launch_lds_shifted(ltmi_masks *m, const T *tile, int64_t n_frames, in
                               int sig_w, const int32_t *shifts_host, float *out, int64_t ld_out,
                               int accumulate, hipStream_t stream, bool *handled) {
     *handled = false;
-    using CFG = LdsCfg<1>;
+    using CFG = LdsCfg<1, 0, 2>;
     ShiftCache *c = (ShiftCache *)m->shift_cache;
     if (!c) {
         c = new (std::nothrow) ShiftCache();
@@ -1421,7 +1486,7 @@ static int launch_lds_shifted(ltmi_masks *m, const T *tile, int64_t n_frames, in
         LTMI_HIP(hipGetLastError());
     }
     // row lists, padded per group to whole workgroups
-    constexpr int WG_ROWS = CFG::WAVES * V2_ROWS;
+    constexpr int WG_ROWS = CFG::WG_ROWS;
     c->stage = (c->stage + 1) % ShiftCache::STAGES;
     std::vector<int32_t> &rows_host = c->rows_stage[c->stage];
     std::vector<const float *> &wg_host = c->wg_stage[c->stage];
@@ -1461,7 +1526,7 @@ static int launch_lds_shifted(ltmi_masks *m, const T *tile, int64_t n_frames, in
                             hipMemcpyHostToDevice, stream));
     LTMI_HIP(hipMemcpyAsync((void *)c->wg_img_dev, wg_host.data(), wg_host.size() * sizeof(float *),
                             hipMemcpyHostToDevice, stream));
-    auto kern = k_dense_lds<T, 1, 0, true>;
+    auto kern = k_dense_lds<T, 1, 0, true, 0, 2>;
     static bool attr_set[16] = {false};
     if (!attr_set[m->device & 15]) {
         LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -472,6 +472,8 @@ class HipJobExecutor(JobExecutor):
             import torch
         d = self._dist()
 
+        idle = [False]                          # executor stream known to be drained
+
         def delivered(key):
             return streamed[key][1] + direct.get(key, 0)
 
@@ -481,10 +483,12 @@ class HipJobExecutor(JobExecutor):
             if sink_on and layout and final:
                 # my rows are out once the copy stream (copied rows) and the executor stream (rows
                 # the kernels wrote into the host buffer themselves) are idle
-                self._copy_stream.synchronize()
+                if keepalive:
+                    self._copy_stream.synchronize()
+                    keepalive.clear()
                 if direct:
                     self._stream.synchronize()
-                keepalive.clear()
+                    idle[0] = True
             if shared is not None and final:
                 # every rank of the node says whether all of ITS rows were delivered
                 # (same answer on every rank)
@@ -510,6 +514,7 @@ class HipJobExecutor(JobExecutor):
                         buf.replace_array(host)
                         deferred.pop(key, None)
                         continue
+                    idle[0] = False
                     self._flush_deferred(udf, i, name, dev_full[i], deferred, keep=not final)
                     full = dev_full[i].get(name)
                     self._make_current()
@@ -596,7 +601,7 @@ class HipJobExecutor(JobExecutor):
         if self._collectives_on:
             for task in self._all_tasks:
                 damage.get_view_for_partition(task.partition)[:] = True
-        if self._stream is not None:
+        if self._stream is not None and not idle[0]:
             self._stream.synchronize()
         self._row_sink = None
         self._result_target = None

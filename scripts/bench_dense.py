@@ -45,6 +45,7 @@ else:
     variants = [dict(mt=0, waves=0, ksplit=0), dict(mt=0, waves=31, ksplit=0),
                 dict(mt=0, waves=32, ksplit=0),
                 dict(mt=2, waves=4, ksplit=1), dict(mt=1, waves=4, ksplit=1)]
+ref_out = None
 for v in variants:
     h.set_tuning(**v)
     for _ in range(3):
@@ -59,6 +60,12 @@ for v in variants:
     torch.cuda.synchronize()
     ts = sorted(a.elapsed_time(b) for a, b in evs)
     med = ts[len(ts) // 2]
+    if ref_out is None:
+        ref_out = out.clone()
+    else:
+        err = float((torch.view_as_real(out) if out.is_complex() else out).sub(
+            torch.view_as_real(ref_out) if out.is_complex() else ref_out).abs().max())
+        print(f"   max |diff| to the first variant: {err:.3e} (scale {float(ref_out.abs().max()):.3e})")
     gbs = args.frames * frame_bytes / (med * 1e-3) / 1e9
     print(f"{v} {h.last_kernel()}  median {med:.3f} ms  min {ts[0]:.3f} ms  "
           f"{args.frames / (med * 1e-3) / 1e6:.2f} Mframes/s  {gbs:.0f} GB/s "

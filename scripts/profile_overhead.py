@@ -32,3 +32,4 @@ for _ in range(N):
 pr.disable()
 st = pstats.Stats(pr)
 st.sort_stats('tottime').print_stats(60)
+st.sort_stats('cumulative').print_stats(45)
