@@ -23,6 +23,7 @@
 namespace ltmi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -336,7 +337,8 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 // NE > 0 ("extras"): NG groups go through the matrix cores and NE further columns (the remainder
 // of a stack with 16 NG + NE columns, e.g. 25 complex masks = 48 + 2) are accumulated on the VALU
 // from the already converted frame fragments -- instead of a whole extra MFMA group of padding.
-// Their slot is 32 KiB: NG x 8 KiB of groups, then NE x 512 B of plain (column, pixel) floats.
+// Their slot is 32 KiB: NG x 8 KiB of groups, then NE / 2 column pairs of 1 KiB, (pixel, column of the
+// pair) floats: one v_pk_fma_f32 per pixel and pair.
 // TILES: 16-frame tiles per wave.  With 2, a workgroup is 4 waves of 32 frames (same 128 frames, same
 // LDS): one mask fragment read from LDS feeds the MFMAs of two frame tiles, i.e. half the mask-fragment
 // LDS traffic per MFMA -- these kernels run into the board's power cap, so energy per frame is time.
@@ -406,7 +408,7 @@ __global__ void k_build_image_shifted(const float *__restrict__ src, float *__re
 }
 
 // raw stack -> image 3 (NG groups + extras, 32-KiB slots of 128 pixels): groups as in image 2, then
-// the columns >= 16 NG as plain [column][pixel] floats
+// the columns >= 16 NG in pairs, [pair][pixel][2] floats
 __global__ void k_build_image3(const float *__restrict__ src, float *__restrict__ img,
                                int64_t n_masks, int cpm, int64_t n_px, int n_slots, int ng,
                                int slot_floats) {
@@ -424,7 +426,8 @@ __global__ void k_build_image3(const float *__restrict__ src, float *__restrict_
             const int g = col / GROUP, n = col % GROUP;
             base[(size_t)g * GROUP * kb + img2_index(n, q, kb)] = src[i];
         } else {
-            base[(size_t)ng * GROUP * kb + (col - ng * GROUP) * kb + q] = src[i];
+            const int e = col - ng * GROUP;             // column pairs: (pair, pixel, column of the pair)
+            base[(size_t)ng * GROUP * kb + (e / 2) * (2 * kb) + q * 2 + (e & 1)] = src[i];
         }
     }
 }
@@ -487,11 +490,12 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
         for (int g = 0; g < NG; ++g)
 #pragma unroll
             for (int x = 0; x < NACC; ++x) acc[tl][g][x] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float acc_e[TILES][NE > 0 ? NE : 1];                 // VALU columns: partial over this lane's pixels
+    static_assert(NE % 2 == 0, "VALU columns come in pairs");
+    f32x2 acc_e[TILES][NE > 0 ? NE / 2 : 1];             // VALU column pairs: partial over this lane's pixels
 #pragma unroll
     for (int tl = 0; tl < TILES; ++tl)
 #pragma unroll
-        for (int c = 0; c < (NE > 0 ? NE : 1); ++c) acc_e[tl][c] = 0.f;
+        for (int c = 0; c < (NE > 0 ? NE / 2 : 1); ++c) acc_e[tl][c] = f32x2{0.f, 0.f};
 
     // lane-constant parts of the fragment addresses
     const int a_lane = m * V2_SUB_BYTES;                 // bytes inside a frame tile of a ring slot
@@ -586,11 +590,12 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             auto rd_b = [&](int blk, int g, int h) {
                 return *(const f32x4 *)(bslot + g * (GROUP * KB) + b_unit(blk0 + blk, h));
             };
-            // extras: column c, this lane's 8 pixels of the block (same address for the 16 lanes of
-            // a kg group: LDS broadcast)
-            auto rd_e = [&](int blk, int c, int h) {
-                return *(const f32x4 *)(bslot - b_lane + CFG::EXTRA_OFF + c * KB +
-                                        (blk0 + blk) * 32 + kg * 8 + h * 4);
+            // extras: column pair c2, pixels 2h, 2h+1 of this lane's 8 pixels of the block, as
+            // (col 2 c2, col 2 c2 + 1) per pixel (same address for the 16 lanes of a kg group: LDS
+            // broadcast)
+            auto rd_e = [&](int blk, int c2, int h) {
+                return *(const f32x4 *)(bslot - b_lane + CFG::EXTRA_OFF + c2 * (2 * KB) +
+                                        ((blk0 + blk) * 32 + kg * 8) * 2 + h * 4);
             };
             typename TR::raw_t raw_c[TILES];
 #pragma unroll
@@ -598,9 +603,11 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             f32x4 b_c[NG][2];
 #pragma unroll
             for (int g = 0; g < NG; ++g) { b_c[g][0] = rd_b(0, g, 0); b_c[g][1] = rd_b(0, g, 1); }
-            f32x4 e_c[NE > 0 ? NE : 1][2];
+            f32x4 e_c[NE > 0 ? NE / 2 : 1][4];
 #pragma unroll
-            for (int c = 0; c < NE; ++c) { e_c[c][0] = rd_e(0, c, 0); e_c[c][1] = rd_e(0, c, 1); }
+            for (int c = 0; c < NE / 2; ++c)
+#pragma unroll
+                for (int h = 0; h < 4; ++h) e_c[c][h] = rd_e(0, c, h);
 #pragma unroll
             for (int blk = 0; blk < BLKS; ++blk) {
                 typename TR::raw_t raw_n[TILES];
@@ -609,9 +616,11 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                 f32x4 b_n[NG][2];
 #pragma unroll
                 for (int g = 0; g < NG; ++g) { b_n[g][0] = b_c[g][0]; b_n[g][1] = b_c[g][1]; }
-                f32x4 e_n[NE > 0 ? NE : 1][2];
+                f32x4 e_n[NE > 0 ? NE / 2 : 1][4];
 #pragma unroll
-                for (int c = 0; c < NE; ++c) { e_n[c][0] = e_c[c][0]; e_n[c][1] = e_c[c][1]; }
+                for (int c = 0; c < NE / 2; ++c)
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) e_n[c][h] = e_c[c][h];
                 if (blk + 1 < BLKS) {
 #pragma unroll
                     for (int tl = 0; tl < TILES; ++tl) raw_n[tl] = rd_a(tl, blk + 1);
@@ -621,10 +630,9 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                         b_n[g][1] = rd_b(blk + 1, g, 1);
                     }
 #pragma unroll
-                    for (int c = 0; c < NE; ++c) {
-                        e_n[c][0] = rd_e(blk + 1, c, 0);
-                        e_n[c][1] = rd_e(blk + 1, c, 1);
-                    }
+                    for (int c = 0; c < NE / 2; ++c)
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) e_n[c][h] = rd_e(blk + 1, c, h);
                 }
                 // the DMA instructions of sub-chunk s+RING-1 are spread over the BLKS blocks
 #pragma unroll
@@ -654,18 +662,27 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                     if (CVT) __builtin_amdgcn_sched_group_barrier(0x002, 8 * TILES, 0);  // conversions
                     __builtin_amdgcn_sched_group_barrier(0x008, 8 * NG * TILES, 0);      // then the MFMAs
                 }
+                // VALU columns, two at a time (v_pk_fma_f32: the pixel value is broadcast, the two
+                // columns' mask values sit next to each other in the slot)
 #pragma unroll
                 for (int tl = 0; tl < TILES; ++tl)
 #pragma unroll
-                    for (int c = 0; c < NE; ++c)
+                    for (int c2 = 0; c2 < NE / 2; ++c2)
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) acc_e[tl][c] += a[tl][j] * e_c[c][j >> 2][j & 3];
+                        for (int j = 0; j < 8; ++j) {
+                            const f32x4 ev = e_c[c2][j >> 1];
+                            const f32x2 e2 = (j & 1) ? f32x2{ev[2], ev[3]} : f32x2{ev[0], ev[1]};
+                            acc_e[tl][c2] = __builtin_elementwise_fma(f32x2{a[tl][j], a[tl][j]}, e2,
+                                                                      acc_e[tl][c2]);
+                        }
 #pragma unroll
                 for (int tl = 0; tl < TILES; ++tl) raw_c[tl] = raw_n[tl];
 #pragma unroll
                 for (int g = 0; g < NG; ++g) { b_c[g][0] = b_n[g][0]; b_c[g][1] = b_n[g][1]; }
 #pragma unroll
-                for (int c = 0; c < NE; ++c) { e_c[c][0] = e_n[c][0]; e_c[c][1] = e_n[c][1]; }
+                for (int c = 0; c < NE / 2; ++c)
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) e_c[c][h] = e_n[c][h];
             }
         };
 
@@ -722,7 +739,8 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                 for (int c = 0; c < NE; ++c)
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
-                        acc_e[tl][c] += a[j] * bl[CFG::EXTRA_OFF + c * KB + blk * 32 + kg * 8 + j];
+                        acc_e[tl][c / 2][c & 1] += a[j] * bl[CFG::EXTRA_OFF + (c / 2) * (2 * KB) +
+                                                            (blk * 32 + kg * 8 + j) * 2 + (c & 1)];
             }
         }
     }
@@ -753,7 +771,7 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             const int64_t f = frame_of(tl * 16 + m);
 #pragma unroll
             for (int c = 0; c < NE; ++c) {
-                float v = acc_e[tl][c];
+                float v = acc_e[tl][c / 2][c & 1];
                 v += __shfl_xor(v, 16, 64);
                 v += __shfl_xor(v, 32, 64);
                 const int col = NG * GROUP + c;

@@ -30,6 +30,9 @@ h = hip.MaskHandle.dense(0, masks, np.float32)
 out = torch.zeros((frames, 16), device='cuda')
 dt = np.dtype('uint16')
 for name, v in [('idle', None), ('default', dict(mt=0, waves=0, ksplit=0)),
+                ('tiles=1 (8 waves x 16 frames)', dict(mt=0, waves=34, ksplit=0)),
+                ('tiles=2 (4 waves x 32 frames)', dict(mt=0, waves=35, ksplit=0)),
+                ('tiles=1 again', dict(mt=0, waves=34, ksplit=0)),
                 ('no-MFMA (memory stream only)', dict(mt=0, waves=32, ksplit=0)),
                 ('no-DMA (compute stream only)', dict(mt=0, waves=31, ksplit=0)),
                 ('default again', dict(mt=0, waves=0, ksplit=0))]:
