@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <cstring>
 #include <typeinfo>
+#include <type_traits>
+#include <utility>
 
 namespace ltmi {
 
@@ -155,6 +157,264 @@ k_dense_mfma_f64(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64
     }
 }
 
+// ---- frames through LDS with full-line LDS-DMA (k_dense_lds64) ---------------------------------------
+// The f64 twin of k_dense_lds (ltmi_dense.hip) for 4- and 8-byte pixels (int32 / uint32 / float32 /
+// int64 / uint64 / float64 -- the data types whose results are float64 in the reference): 4 waves of
+// 32 frames (two 16-frame tiles), per wave a ring of 3 sub-chunk slots (32 rows x 256 B) filled by
+// global_load_lds_dwordx4 with the 16-B pieces of a row stored at piece ^ (row & 15); the 32-KiB mask
+// chunks (the image of the direct-load kernel above: 256 px x 16 columns of f64) arrive by LDS-DMA
+// too, double buffered, one s_barrier per chunk; counted vmcnt waits.  160 KiB of LDS.
+typedef __attribute__((address_space(3))) void *lds_ptr64_t;
+typedef const __attribute__((address_space(1))) void *glb_ptr64_t;
+
+template <int I, int N, typename F> __device__ __forceinline__ void static_for64(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for64<I + 1, N>(f);
+    }
+}
+
+struct Lds64Cfg {
+    static constexpr int TILES = 2, WAVES = 4, RING = 3;
+    static constexpr int SUB_BYTES = 256;                       // bytes of a row per sub-chunk
+    static constexpr int ROWS = 16 * TILES;
+    static constexpr int TSLOT = 16 * SUB_BYTES;                // one tile of a ring slot
+    static constexpr int ASLOT = ROWS * SUB_BYTES;              // 8 KiB per wave and ring slot
+    static constexpr int BSLOT = CH64 * 8;                      // 32 KiB per mask chunk
+    static constexpr int WG_ROWS = WAVES * ROWS;                // 128 frames per workgroup
+    static constexpr int LDS_BYTES = RING * WAVES * ASLOT + 2 * BSLOT;     // 160 KiB
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_dense_lds64(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
+              const double *__restrict__ img, int n_chunks, double *__restrict__ out,
+              int64_t ld_out, int n_cols, int accumulate, double *__restrict__ partials,
+              int ksplit) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw64[];
+    using CFG = Lds64Cfg;
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "4- or 8-byte pixels");
+    constexpr int TILES = CFG::TILES, WAVES = CFG::WAVES, RING = CFG::RING;
+    constexpr int ASLOT = CFG::ASLOT, BSLOT = CFG::BSLOT, SUB = CFG::SUB_BYTES;
+    constexpr int ND = 4 * TILES;                       // DMA instructions per sub-chunk
+    constexpr int SPX = SUB / (int)sizeof(T);           // pixels per sub-chunk (64 / 32)
+    constexpr int PER = KC64 / SPX;                     // sub-chunks per mask chunk (4 / 8)
+    constexpr int BLKS = SPX / 16;                      // 16-pixel MFMA blocks per sub-chunk (4 / 2)
+    constexpr int NT = WAVES * 64;
+    constexpr int A_BYTES = RING * WAVES * ASLOT;
+    constexpr int BPW = BSLOT / WAVES;
+    constexpr int NBI = BPW / 1024;
+    constexpr int A_N = ND * (RING - 2);
+    static_assert(A_N + 2 * NBI < 64, "vmcnt is a 6-bit counter");
+    typedef T __attribute__((ext_vector_type(16 / sizeof(T)))) unit_t;      // one 16-B piece
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int m = lane & 15, kg = lane >> 4;
+    const int ks = blockIdx.y, g0 = blockIdx.z;
+
+    const int n_full = (int)(n_px / KC64);
+    const int per = (n_chunks + ksplit - 1) / ksplit;
+    const int c_begin = ks * per;
+    const int c_end = min(n_chunks, c_begin + per);
+    const int cf_end = min(c_end, n_full);
+    const double *img_t = img + (size_t)g0 * n_chunks * CH64;
+
+    const int64_t f_wave = (int64_t)blockIdx.x * CFG::WG_ROWS + wave * CFG::ROWS;
+    unsigned char *a_base = lds_raw64 + wave * ASLOT;
+    unsigned char *b_base = lds_raw64 + A_BYTES;
+
+    f64x4 acc[TILES][2];
+#pragma unroll
+    for (int tl = 0; tl < TILES; ++tl)
+#pragma unroll
+        for (int x = 0; x < 2; ++x) acc[tl][x] = f64x4{0., 0., 0., 0.};
+
+    const int a_lane = m * SUB;
+    const int b_lane = m * KC64;                         // doubles inside a mask chunk
+    auto b_unit = [&](int blk_in_chunk, int h) {         // double offset of the swizzled 16-B unit
+        return ((blk_in_chunk * 8 + kg * 2 + h) ^ m) << 1;
+    };
+
+    if (c_begin < cf_end) {
+        const unsigned char *src[ND];
+#pragma unroll
+        for (int t = 0; t < ND; ++t) {
+            const int r = 4 * t + (lane >> 4);
+            int64_t f = f_wave + r;
+            if (f > n_frames - 1) f = n_frames - 1;      // clamp: loads stay valid, result discarded
+            const int piece = (lane & 15) ^ (r & 15);
+            src[t] = (const unsigned char *)(tile + f * ld) + piece * 16;
+        }
+        const unsigned char *bsrc = (const unsigned char *)img_t + wave * BPW + lane * 16;
+        const int S0 = c_begin * PER, S1 = cf_end * PER;
+
+        auto issue_a1 = [&](int s, int slot, int t) {
+            const int sc = min(s, S1 - 1);
+            unsigned char *dst = a_base + slot * (WAVES * ASLOT);
+            __builtin_amdgcn_global_load_lds((glb_ptr64_t)(src[t] + (int64_t)sc * SUB),
+                                             (lds_ptr64_t)(dst + t * 1024), 16, 0, 2 /*nt*/);
+        };
+        auto issue_b = [&](int gidx) {
+            const int cc = min(c_begin + gidx, cf_end - 1);
+            unsigned char *dst = b_base + (gidx & 1) * BSLOT + wave * BPW;
+            const unsigned char *sp = bsrc + (int64_t)cc * BSLOT;
+#pragma unroll
+            for (int u = 0; u < NBI; ++u)
+                __builtin_amdgcn_global_load_lds((glb_ptr64_t)(sp + u * 1024),
+                                                 (lds_ptr64_t)(dst + u * 1024), 16, 0, 0);
+        };
+
+#pragma unroll
+        for (int t = 0; t < ND; ++t) issue_a1(S0, 0, t);
+        issue_b(0);
+#pragma unroll
+        for (int d = 1; d < RING - 1; ++d)
+#pragma unroll
+            for (int t = 0; t < ND; ++t) issue_a1(S0 + d, d, t);
+
+        // one sub-chunk; the waits follow the DMA issue order exactly as in k_dense_lds
+        auto iteration = [&](int s, auto ph) {
+            constexpr int PH = decltype(ph)::value;
+            const int i = s - S0;
+            const int ip = PH >= 0 ? PH % PER : i % PER;
+            if (ip == 0) {
+                constexpr int N0 = ND * (PER < RING - 2 ? PER : RING - 2);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N0) : "memory");
+                __builtin_amdgcn_s_barrier();
+                issue_b(i / PER + 1);
+            } else {
+                int nb = 0;
+#pragma unroll
+                for (int k = 0; k < RING; ++k) nb += (ip + k * PER <= RING - 2) ? 1 : 0;
+                if (nb == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_N) : "memory");
+                else if (nb == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_N + NBI) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_N + 2 * NBI) : "memory");
+            }
+            const int slot = PH >= 0 ? PH % RING : i % RING;
+            const int nslot = PH >= 0 ? (PH + RING - 1) % RING : (i + RING - 1) % RING;
+            const int bsl = PH >= 0 ? (PH / PER) & 1 : (i / PER) & 1;
+            const int blk0 = ip * BLKS;                 // 16-px block offset inside the mask chunk
+            const unsigned char *aslot = a_base + slot * (WAVES * ASLOT) + a_lane;
+            const double *bslot = (const double *)(b_base + bsl * BSLOT) + b_lane;
+            // this lane's 4 pixels (kg*4 .. kg*4+3) of block blk, tile tl, as doubles
+            auto rd_a = [&](int tl, int blk, double (&a)[4]) {
+                const unsigned char *at = aslot + tl * CFG::TSLOT;
+                const int u = blk * 4 + kg;
+                if constexpr (sizeof(T) == 4) {
+                    const unit_t r = *(const unit_t *)(at + ((u ^ m) << 4));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] = (double)r[j];
+                } else {
+                    const unit_t r0 = *(const unit_t *)(at + (((2 * u) ^ m) << 4));
+                    const unit_t r1 = *(const unit_t *)(at + (((2 * u + 1) ^ m) << 4));
+                    a[0] = (double)r0[0]; a[1] = (double)r0[1];
+                    a[2] = (double)r1[0]; a[3] = (double)r1[1];
+                }
+            };
+            auto rd_b = [&](int blk, int h) {
+                return *(const f64x2 *)(bslot + b_unit(blk0 + blk, h));
+            };
+            double a_c[TILES][4];
+#pragma unroll
+            for (int tl = 0; tl < TILES; ++tl) rd_a(tl, 0, a_c[tl]);
+            f64x2 b_c[2] = {rd_b(0, 0), rd_b(0, 1)};
+#pragma unroll
+            for (int blk = 0; blk < BLKS; ++blk) {
+                double a_n[TILES][4];
+                f64x2 b_n[2] = {b_c[0], b_c[1]};
+#pragma unroll
+                for (int tl = 0; tl < TILES; ++tl)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a_n[tl][j] = a_c[tl][j];
+                if (blk + 1 < BLKS) {
+#pragma unroll
+                    for (int tl = 0; tl < TILES; ++tl) rd_a(tl, blk + 1, a_n[tl]);
+                    b_n[0] = rd_b(blk + 1, 0);
+                    b_n[1] = rd_b(blk + 1, 1);
+                }
+#pragma unroll
+                for (int t = 0; t < ND; ++t)
+                    if ((t * BLKS) / ND == blk) issue_a1(s + RING - 1, nslot, t);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int tl = 0; tl < TILES; ++tl)
+                        acc[tl][j & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                            a_c[tl][j], b_c[j >> 1][j & 1], acc[tl][j & 1], 0, 0, 0);
+#pragma unroll
+                for (int tl = 0; tl < TILES; ++tl)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a_c[tl][j] = a_n[tl][j];
+                b_c[0] = b_n[0];
+                b_c[1] = b_n[1];
+            }
+        };
+
+        constexpr int U2 = 2 * PER;
+        constexpr int UNROLL = (U2 % RING == 0) ? U2 : RING * U2;
+        int s = S0;
+        if constexpr (UNROLL <= 48) {
+            for (; s + UNROLL <= S1; s += UNROLL) {
+                static_for64<0, UNROLL>([&](auto I) { iteration(s + decltype(I)::value, I); });
+            }
+        }
+        for (; s < S1; ++s) iteration(s, std::integral_constant<int, -1>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+
+    // ragged last chunk (n_px % 256 != 0): guarded element loads, mask chunk staged by plain copies
+    if (c_end > n_full) {
+        const int c = n_full;
+        __syncthreads();
+        double *bl = (double *)b_base;
+        const u32x4_ *img_units = (const u32x4_ *)(img_t + (size_t)c * CH64);
+#pragma unroll
+        for (int i = 0; i < BSLOT / 16 / NT; ++i)
+            ((u32x4_ *)bl)[i * NT + tid] = img_units[i * NT + tid];
+        __syncthreads();
+        const double *ldsb = bl + b_lane;
+#pragma unroll
+        for (int tl = 0; tl < TILES; ++tl) {
+            int64_t f = f_wave + tl * 16 + m;
+            if (f > n_frames - 1) f = n_frames - 1;
+            const T *rowp = tile + f * ld + kg * 4;
+#pragma unroll
+            for (int blk = 0; blk < KC64 / 16; ++blk) {
+                const int64_t p0 = (int64_t)c * KC64 + blk * 16;
+                double a[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] = (p0 + kg * 4 + j < n_px) ? (double)rowp[p0 + j] : 0.;
+                const f64x2 b0 = *(const f64x2 *)(ldsb + b_unit(blk, 0));
+                const f64x2 b1 = *(const f64x2 *)(ldsb + b_unit(blk, 1));
+                acc[tl][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b0[0], acc[tl][0], 0, 0, 0);
+                acc[tl][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b0[1], acc[tl][1], 0, 0, 0);
+                acc[tl][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b1[0], acc[tl][0], 0, 0, 0);
+                acc[tl][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b1[1], acc[tl][1], 0, 0, 0);
+            }
+        }
+    }
+
+    // C/D layout of 16x16x4 f64: col = lane & 15, row = reg * 4 + (lane >> 4)
+#pragma unroll
+    for (int tl = 0; tl < TILES; ++tl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t fr = f_wave + tl * 16 + r * 4 + kg;
+            const int col = g0 * 16 + m;
+            if (fr < n_frames && col < n_cols) {
+                const double v = acc[tl][0][r] + acc[tl][1][r];
+                if (ksplit == 1) {
+                    double *p = out + fr * ld_out + col;
+                    *p = accumulate ? (*p + v) : v;
+                } else {
+                    partials[((int64_t)ks * n_frames + fr) * n_cols + col] = v;
+                }
+            }
+        }
+}
+
 __global__ void k_reduce_partials64(const double *__restrict__ partials, int ksplit,
                                     int64_t n_frames, int n_cols, double *__restrict__ out,
                                     int64_t ld_out, int accumulate) {
@@ -214,9 +474,76 @@ void dense64_destroy(ltmi_masks *m) {
     m->res64 = nullptr;
 }
 
+static int ensure_ws64(ltmi_masks *m, size_t need, hipStream_t stream) {
+    if (m->ws64_bytes < need) {
+        if (m->ws64) {
+            LTMI_HIP(hipStreamSynchronize(stream));
+            LTMI_HIP(hipFree(m->ws64));
+            m->ws64 = nullptr;
+            m->ws64_bytes = 0;
+        }
+        LTMI_HIP(hipMalloc(&m->ws64, need));
+        m->ws64_bytes = need;
+    }
+    return LTMI_OK;
+}
+
+// 4- / 8-byte pixels, 16-B aligned rows, at least one full mask chunk: the LDS-DMA kernel
+template <typename T>
+static int launch64_lds(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, double *out,
+                        int64_t ld_out, int accumulate, hipStream_t stream) {
+    using CFG = Lds64Cfg;
+    auto kern = k_dense_lds64<T>;
+    static bool attr_set[16] = {false};
+    if (!attr_set[m->device & 15]) {
+        LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     CFG::LDS_BYTES));
+        attr_set[m->device & 15] = true;
+    }
+    const int64_t gx = (n_frames + CFG::WG_ROWS - 1) / CFG::WG_ROWS;
+    const int64_t gz = m->n_groups64;
+    int ksplit = m->tune_ksplit;
+    if (ksplit <= 0) {
+        ksplit = 1;
+        if (gx * gz < 256)
+            ksplit = (int)std::min<int64_t>((512 + gx * gz - 1) / (gx * gz),
+                                            std::max(1, m->n_chunks64 / 8));
+    }
+    ksplit = std::max(1, std::min(ksplit, m->n_chunks64));
+    {
+        const int per = (m->n_chunks64 + ksplit - 1) / ksplit;
+        ksplit = (m->n_chunks64 + per - 1) / per;
+    }
+    if (ksplit > 1) {
+        int rc = ensure_ws64(m, (size_t)ksplit * n_frames * m->n_masks * sizeof(double), stream);
+        if (rc != LTMI_OK) return rc;
+    }
+    dim3 grid((unsigned)gx, (unsigned)ksplit, (unsigned)gz);
+    hipLaunchKernelGGL(kern, grid, dim3(CFG::WAVES * 64), CFG::LDS_BYTES, stream, tile, ld, n_frames,
+                       m->n_px, (const double *)m->img64, m->n_chunks64, out, ld_out,
+                       (int)m->n_masks, accumulate, (double *)m->ws64, ksplit);
+    LTMI_HIP(hipGetLastError());
+    snprintf(m->last_kernel, sizeof(m->last_kernel), "k_dense_lds64<%s> grid=(%u,%u,%u)",
+             typeid(T).name(), grid.x, grid.y, grid.z);
+    if (ksplit > 1) {
+        const int64_t n = n_frames * m->n_masks;
+        hipLaunchKernelGGL(k_reduce_partials64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                           stream, (const double *)m->ws64, ksplit, n_frames, (int)m->n_masks, out,
+                           ld_out, accumulate);
+        LTMI_HIP(hipGetLastError());
+    }
+    return LTMI_OK;
+}
+
 template <typename T>
 static int launch64(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, double *out,
                     int64_t ld_out, int accumulate, hipStream_t stream) {
+    if constexpr (sizeof(T) >= 4) {
+        // tune_mt == 1 (ltmi_masks_set_tuning): force the direct-load kernel (bench comparison)
+        if (m->tune_mt != 1 && m->n_px >= KC64 && ((uintptr_t)tile) % 16 == 0 &&
+            (ld * sizeof(T)) % 16 == 0)
+            return launch64_lds<T>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+    }
     constexpr int WAVES = 4;
     const bool vec = (((uintptr_t)tile) % (4 * sizeof(T)) == 0) && (ld % 4 == 0);
     const int64_t gx = (n_frames + WAVES * 16 - 1) / (WAVES * 16);

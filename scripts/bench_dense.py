@@ -21,24 +21,29 @@ n_px = args.sig * args.sig
 dt = np.dtype(args.dtype)
 g = torch.Generator(device='cuda').manual_seed(1)
 if dt.kind in 'iu':
-    tdt = {1: torch.uint8, 2: torch.int16}[dt.itemsize]
+    tdt = {1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[dt.itemsize]
     tile = torch.randint(0, 4096 if dt.itemsize > 1 else 200, (args.frames, n_px), generator=g,
                          device='cuda', dtype=torch.int32).to(tdt)
 else:
-    tile = torch.rand((args.frames, n_px), generator=g, device='cuda', dtype=torch.float32)
+    tile = torch.rand((args.frames, n_px), generator=g, device='cuda',
+                      dtype=torch.float64 if dt.itemsize == 8 else torch.float32)
 rng = np.random.default_rng(2)
 md = np.dtype(args.mask_dtype)
 if md.kind == 'c':
     masks = (rng.random((args.masks, n_px)) + 1j * rng.random((args.masks, n_px))).astype(md)
 else:
     masks = rng.random((args.masks, n_px)).astype(md)
-h = hip.MaskHandle.dense(0, masks, md)
+res_dt = np.result_type(dt, md)
+h = hip.MaskHandle.dense(0, masks, res_dt)
 out = torch.zeros((args.frames, args.masks), device='cuda',
-                  dtype=torch.complex64 if md.kind == 'c' else torch.float32)
-frame_bytes = n_px * dt.itemsize + args.masks * md.itemsize
+                  dtype={'complex64': torch.complex64, 'float32': torch.float32,
+                         'float64': torch.float64}[res_dt.name])
+frame_bytes = n_px * dt.itemsize + args.masks * res_dt.itemsize
 
 if args.variants == 'auto':
     variants = [dict(mt=0, waves=0, ksplit=0)]
+elif args.variants.startswith('mt='):       # explicit list of `mt` codes (f64 results: 1 = direct-load kernel)
+    variants = [dict(mt=int(w), waves=0, ksplit=0) for w in args.variants[3:].split(',')]
 elif args.variants.startswith('w='):        # explicit list of `waves` codes, e.g. w=0,31,32
     variants = [dict(mt=0, waves=int(w), ksplit=0) for w in args.variants[2:].split(',')]
 else:

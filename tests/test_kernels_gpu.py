@@ -200,7 +200,7 @@ def test_generic(hip, combo):
         masks = rng.random((n_masks, n_px)).astype(result_dtype)
     res, kern = _apply(hip, data, masks, result_dtype)
     if result_dtype == np.float64:
-        assert 'k_dense_mfma_f64' in kern, kern    # float64 results: f64 matrix cores
+        assert 'k_dense_mfma_f64' in kern, kern    # float64 results: f64 matrix cores (333 px: odd rows)
     elif result_dtype.kind in 'iu' and tile_dtype.itemsize <= 4:
         assert 'exact-int' in kern, kern           # integer results, sums < 2^52: same cores, exact
     else:
@@ -220,9 +220,13 @@ def test_generic(hip, combo):
     ((70, 17 * 23, 5), 0),              # odd row length -> guarded loads
     ((45, 256 * 5, 37), 0),             # three column groups (grid.z)
     ((1, 256, 1), 0),
+    ((1000, 256 * 20, 16), 0),          # several workgroups, the unrolled steady state
+    ((130, 256 * 3 + 4, 16), 2),        # K split with a ragged tail of 4 pixels
 ])
 def test_float64_results_on_matrix_cores(hip, tile_dtype, shape, ksplit):
-    """k_dense_mfma_f64: float64 results (int32 / int64 / float64 data, or float64 masks)."""
+    """float64 results (int32 / int64 / float64 data, or float64 masks) on the f64 matrix cores:
+    k_dense_lds64 (LDS-DMA) for 4- / 8-byte pixels with 16-B aligned rows, k_dense_mfma_f64
+    (direct loads) otherwise."""
     n_frames, n_px, n_masks = shape
     rng = np.random.default_rng(hash((tile_dtype,) + shape) % (2**32))
     dt = np.dtype(tile_dtype)
@@ -235,7 +239,13 @@ def test_float64_results_on_matrix_cores(hip, tile_dtype, shape, ksplit):
     masks = rng.random((n_masks, n_px)) - 0.25
     tuning = dict(mt=0, waves=0, ksplit=ksplit) if ksplit else None
     res, kern = _apply(hip, data, masks, np.float64, tuning=tuning)
-    assert 'k_dense_mfma_f64' in kern, kern
+    lds = dt.itemsize >= 4 and (n_px * dt.itemsize) % 16 == 0 and n_px >= 256
+    assert ('k_dense_lds64' if lds else 'k_dense_mfma_f64') in kern, kern
+    if lds:
+        # the direct-load kernel on the same input (tuning mt=1) agrees to rounding
+        res_d, kern_d = _apply(hip, data, masks, np.float64, tuning=dict(mt=1, waves=0, ksplit=ksplit))
+        assert 'k_dense_mfma_f64' in kern_d, kern_d
+        assert np.allclose(res, res_d, rtol=1e-12, atol=1e-12 * np.abs(res_d).max())
     ref = data.astype(np.float64) @ masks.T
     scale = np.abs(data.astype(np.float64)) @ np.abs(masks).T
     assert np.all(np.abs(res - ref) <= 1e-13 * scale + 1e-300), np.abs(res - ref).max()
