@@ -53,8 +53,14 @@ typedef const __attribute__((address_space(1))) void *b_glb_ptr_t;
 #define BE_OCC 2
 #endif
 constexpr int BE_P = BE_P_;          // pixels per chunk
-constexpr int BE_SETS = 4;           // waves per workgroup = interleaved group sets
-constexpr int BE_SLOTS = 16;         // groups per wave
+#ifndef BE_SETS_
+#define BE_SETS_ 4
+#endif
+#ifndef BE_SLOTS_
+#define BE_SLOTS_ 16
+#endif
+constexpr int BE_SETS = BE_SETS_;    // waves per workgroup = interleaved group sets
+constexpr int BE_SLOTS = BE_SLOTS_;  // groups per wave
 constexpr int BE_PASS = BE_SETS * BE_SLOTS * 16;     // real masks per pass (1024)
 #ifndef BE_D_
 #define BE_D_ 4
