@@ -180,6 +180,17 @@ class BufferWrapper:
 
     # --- user-facing data ---------------------------------------------------------------------
     @property
+    def device_data(self):
+        """The HipArray holding the result in HBM (runs with result_where='device'), else None.
+        `.data` / `.raw_data` of such a buffer download it on access."""
+        return self._data if isinstance(self._data, HipArray) else None
+
+    @property
+    def result_array(self):
+        """raw_data, except that a result kept in HBM (result_where='device') is NOT downloaded."""
+        return self._data if isinstance(self._data, HipArray) else self.raw_data
+
+    @property
     def raw_data(self):
         return None if self._data is None else to_numpy(self._data)
 

@@ -360,11 +360,17 @@ class HipJobExecutor(JobExecutor):
         direct = {}                             # (udf index, name) -> rows the kernels wrote directly
         host_np = {}                            # (udf index, name) -> NumPy view of the final buffer
         dev_ptrs = {}
-        shared = self._node_shared() if not partial else None
+        # result_where='device' (Context.run_udf): the declared buffers stay in HBM as HipArrays
+        # (for a follow-up computation on the device); nothing is delivered to the host
+        dev_mode = getattr(self, 'result_where', None) == 'device'
+        if dev_mode and (self.gpu_id is None or partial or self._collectives_on):
+            raise NotImplementedError(
+                "result_where='device' needs a single-rank HIP executor and run_udf (not run_udf_iter)")
+        shared = self._node_shared() if not partial and not dev_mode else None
         busy_shared = None
         self._row_sink = None
         self._result_target = None
-        sink_on = self.gpu_id is not None and not partial and \
+        sink_on = self.gpu_id is not None and not partial and not dev_mode and \
             (shared is not None or not self._collectives_on)
         layout, total = [], 0
         if sink_on:
@@ -465,6 +471,23 @@ class HipJobExecutor(JobExecutor):
             self._result_target = result_target if direct else None
 
         dev_full = [dict() for _ in udfs]       # per udf: name -> torch tensor (full size)
+        if dev_mode:
+            import torch as _torch
+
+            def device_target(i, name, g0, shape, dtype):
+                # write-once nav rows of a partition go straight into the full-size device buffer
+                buf = udfs[i].results.get_buffer(name)
+                if np.dtype(dtype) != buf.dtype or tuple(shape[1:]) != tuple(buf.shape[1:]) or \
+                        g0 + shape[0] > buf.shape[0]:
+                    return None
+                t = dev_full[i].get(name)
+                if t is None:
+                    self._make_current()
+                    t = _torch.zeros(tuple(buf.shape), dtype=torch_dtype_for(buf.dtype),
+                                     device=f'cuda:{self.gpu_id}')
+                    dev_full[i][name] = t
+                return HipArray(t[g0:g0 + shape[0]], shape, dtype)
+            self._result_target = device_target
         deferred = {}                           # shared mode: (udf idx, name) -> [(start, stop, rows)]
         generic_parts = []                      # (task, {udf idx: exported results})
         torch = None
@@ -521,6 +544,9 @@ class HipJobExecutor(JobExecutor):
                     if full is None:
                         full = torch.zeros(buf.shape, dtype=torch_dtype_for(buf.dtype),
                                            device=f'cuda:{self.gpu_id}')
+                    if dev_mode:
+                        buf.replace_array(HipArray(full, tuple(buf.shape), buf.dtype))
+                        continue
                     if final and self._collectives_on:
                         # collectives are ordered after the kernels of the executor stream
                         full = self._combine(d, full, how)
@@ -676,6 +702,8 @@ class HipJobExecutor(JobExecutor):
                                          device=f'cuda:{self.gpu_id}')
             if how == 'disjoint':
                 start, stop = buf_main._slice_for_partition(task.partition)
+                if stop > start and part.data_ptr() == full[name][start:stop].data_ptr():
+                    continue            # the kernels wrote the rows into the full buffer (device_target)
                 full[name][start:stop].copy_(
                     part.torch.reshape(part.shape).reshape(full[name][start:stop].shape))
             elif how == 'sum':

@@ -477,13 +477,14 @@ class UDFBase(UDFProtocol):
         # buffers with use=None that get_results did not mention are included as they are
         for k, v in decl.items():
             if k not in results_tmp and v.use is None:
-                results_tmp[k] = self.results.get_buffer(k).raw_data
+                results_tmp[k] = self.results.get_buffer(k).result_array
         results = {}
         for name, arr in results_tmp.items():
             mask = None
             if hasattr(arr, 'arr') and hasattr(arr, 'mask'):      # ArrayWithMask
                 arr, mask = arr.arr, arr.mask
-            arr = to_numpy(arr)
+            if not isinstance(arr, HipArray):   # (HipArray: a run with result_where='device')
+                arr = to_numpy(arr)
             self._check_results(decl, arr, name)
             buf_decl = decl[name]
             buf = PreallocBufferWrapper(
@@ -571,7 +572,7 @@ class UDF(UDFBase):
             if buf.use == 'result_only':
                 raise NotImplementedError(
                     "Default get_results doesn't handle use='result_only' buffers")
-        return {k: self.results.get_buffer(k).raw_data for k, buf in self.results.items()
+        return {k: self.results.get_buffer(k).result_array for k, buf in self.results.items()
                 if buf.use != 'private'}
 
     def get_preferred_input_dtype(self):

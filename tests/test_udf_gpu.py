@@ -1213,6 +1213,56 @@ def test_streamed_export_with_several_tiles(ctx, direct_row_max, monkeypatch):
         Negotiator._hip_scheme_cache.clear()
 
 
+def test_results_kept_on_device(ctx):
+    """run_udf(result_where='device'): declared buffers stay in HBM (HipArray behind
+    `buffer.device_data`), `.data` downloads on access; several partitions, a 'sum' buffer, a
+    sparse stack and an ROI."""
+    import scipy.sparse as sp
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd.udf.sumsigudf import SumSigUDF
+    from libertem_amd.udf.sum import SumUDF
+    from libertem_amd.common.hiparray import HipArray, HostMappedArray
+
+    rng = np.random.default_rng(33)
+    data = rng.integers(0, 3000, (12, 11, 32, 32)).astype(np.uint16)
+    masks = rng.random((7, 32, 32)).astype(np.float32)
+    sparse = [sp.random(32, 32, density=0.05, random_state=k, dtype=np.float32).tocsr()
+              for k in range(5)]
+    ref = opath.apply_masks(data, masks, num_partitions=3)
+    dense_sparse = np.stack([m.toarray() for m in sparse])
+    ref_sp = opath.apply_masks(data, dense_sparse, num_partitions=3)
+    ds = _device_ds(ctx, data, 3)
+    r1, r2, r3, r4 = ctx.run_udf(dataset=ds, udf=[
+        ApplyMasksUDF(mask_factories=lambda: masks), SumSigUDF(), SumUDF(),
+        ApplyMasksUDF(mask_factories=[(lambda m=m: m) for m in sparse], use_sparse=True)],
+        result_where='device')
+    for r in (r1, r2, r4):              # (SumUDF post-processes its sig-sized sum on the host)
+        dev = r['intensity'].device_data
+        assert isinstance(dev, HipArray) and not isinstance(dev, HostMappedArray), type(dev)
+        assert dev.torch.is_cuda
+    assert tuple(r1['intensity'].device_data.shape) == (12 * 11, 7)
+    # usable on the device without a copy ...
+    on_dev = r1['intensity'].device_data.torch.reshape(12 * 11, 7).sum(dim=0).cpu().numpy()
+    assert np.allclose(on_dev, ref.reshape(-1, 7).sum(axis=0), rtol=1e-4)
+    # ... and downloaded on access
+    assert _close(r1['intensity'].data, ref, F32_TOL)
+    assert np.array_equal(r2['intensity'].data, data.reshape((12, 11, -1)).sum(axis=-1).astype(np.float32))
+    assert np.array_equal(r3['intensity'].data, data.astype(np.float32).sum(axis=(0, 1)))
+    assert _close(r4['intensity'].data, ref_sp, F32_TOL)
+    # the next run without the option delivers host arrays again
+    host = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda: masks))
+    assert host['intensity'].device_data is None
+    assert _close(host['intensity'].data, ref, F32_TOL)
+    # ROI
+    roi = rng.random((12, 11)) < 0.4
+    part = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda: masks), roi=roi,
+                       result_where='device')
+    assert isinstance(part['intensity'].device_data, HipArray)
+    assert _close(part['intensity'].raw_data, ref[roi], F32_TOL)
+    with pytest.raises(ValueError):
+        ctx.run_udf(dataset=ds, udf=SumSigUDF(), result_where='hbm')
+
+
 @pytest.mark.parametrize('world', [2, 3])
 def test_two_ranks_share_results_through_host_segment(tmp_path, world):
     """The N>1 result path on the GPU (one-GPU box: two gloo ranks driving GPU 0): every rank
