@@ -327,6 +327,28 @@ def host_device_pointer(device, host_ptr):
     return int(out.value)
 
 
+def map_or_upload(device, arr):
+    """-> (device pointer, keep-alive object) for a C-contiguous host array: zero-copy if the array
+    lives in page-locked, device-mapped memory (the result buffers of a run do), else an H2D copy."""
+    import torch
+    arr = np.ascontiguousarray(arr)
+    try:
+        return host_device_pointer(device, arr.ctypes.data), arr
+    except Exception:
+        t = torch.from_numpy(arr).to(f'cuda:{int(device)}')
+        return t.data_ptr(), t
+
+
+def download_pinned(tensor):
+    """Device tensor -> NumPy array in page-locked memory (one D2H at link speed; a pageable
+    destination is staged by the runtime at a fraction of it).  The array owns its memory."""
+    import torch
+    host = torch.empty(tensor.shape, dtype=tensor.dtype, pin_memory=True)
+    host.copy_(tensor, non_blocking=True)
+    torch.cuda.current_stream(tensor.device).synchronize()
+    return host.numpy()
+
+
 def gather_rows(device, src_ptr, ld_src_bytes, idx_ptr, n_rows, row_bytes, dest_ptr, stream=None):
     """dest[i, :] = src[idx[i], :] inside HBM; idx: device int64."""
     check(lib().ltmi_gather_rows(int(device), src_ptr, int(ld_src_bytes), idx_ptr, int(n_rows),

@@ -310,12 +310,13 @@ class CoMUDF(UDF):
         transform = coordinates.rotate_deg(cp.scan_rotation) @ transform
         ny, nx = data.shape[:2]
         dev = torch.cuda.current_device()
-        raw = torch.from_numpy(np.ascontiguousarray(data).reshape(-1, 3)).to(f'cuda:{dev}')
-        out = torch.empty((5, ny * nx), dtype=torch.float64, device=raw.device)
-        hip.com_fields(dev, raw.data_ptr(), 3, ny, nx, cp.cy, cp.cx, transform,
+        raw_ptr, keep = hip.map_or_upload(dev, data.reshape(-1, 3))
+        out = torch.empty((5, ny * nx), dtype=torch.float64, device=f'cuda:{dev}')
+        hip.com_fields(dev, raw_ptr, 3, ny, nx, cp.cy, cp.cx, transform,
                        *[out[i].data_ptr() for i in range(5)],
                        stream=torch.cuda.current_stream(dev))
-        f = out.cpu().numpy()
+        f = hip.download_pinned(out)
+        del keep
         raw_shifts = center_shifts(img_sum=data[..., 0], img_y=data[..., 1], img_x=data[..., 2],
                                    ref_y=cp.cy, ref_x=cp.cx)
         n = ny * nx
