@@ -35,6 +35,7 @@ class HipArray:
     contiguous) -- i.e. exactly the (n_frames, n_px, ld) triple libltmi takes.
     """
     __slots__ = ('_t', 'shape', 'dtype', 'ld')
+    PINNED_DOWNLOAD_MIN = 256 * 1024        # bytes: larger downloads go through page-locked memory
 
     def __init__(self, tensor, shape, dtype, ld=None):
         self._t = tensor                    # torch tensor whose data_ptr() is element [0, ...]
@@ -165,10 +166,17 @@ class HipArray:
         inner = prod(self.shape[1:]) if self.shape else 1
         n0 = self.shape[0] if self.shape else 1
         flat = self._t.reshape(-1)
-        if self.is_contiguous:
-            host = flat[:n0 * inner].cpu().numpy()
+        src = flat[:n0 * inner] if self.is_contiguous else \
+            torch.as_strided(flat, (n0, inner), (self.ld, 1))
+        if src.numel() * src.element_size() >= self.PINNED_DOWNLOAD_MIN and src.is_contiguous():
+            # one D2H at link speed into page-locked memory (the runtime stages a pageable
+            # destination at ~1/8 of it; page-locking costs less than that even for a single use)
+            pinned = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+            pinned.copy_(src, non_blocking=True)
+            torch.cuda.current_stream(src.device).synchronize()
+            host = pinned.numpy()
         else:
-            host = torch.as_strided(flat, (n0, inner), (self.ld, 1)).cpu().numpy()
+            host = src.cpu().numpy()
         if host.dtype != self.dtype:
             host = host.view(self.dtype)
         return host.reshape(self.shape)

@@ -337,17 +337,22 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 // NE > 0 ("extras"): NG groups go through the matrix cores and NE further columns (the remainder
 // of a stack with 16 NG + NE columns, e.g. 25 complex masks = 48 + 2) are accumulated on the VALU
 // from the already converted frame fragments -- instead of a whole extra MFMA group of padding.
-// Their slot is 32 KiB: NG x 8 KiB of groups, then NE / 2 column pairs of 1 KiB, (pixel, column of the
-// pair) floats: one v_pk_fma_f32 per pixel and pair.
+// Their slot: NG x 8 KiB of groups, then NE / 2 column pairs of 1 KiB, (pixel, column of the pair)
+// floats -- one v_pk_fma_f32 per pixel and pair --, rounded up to 4 KiB.
+// bytes of a mask slot of 128 pixels with ng MFMA groups + ne VALU columns (kernel and image builder)
+__host__ __device__ constexpr int ext_slot_bytes(int ng, int ne) {
+    return (ng * GROUP * 128 * 4 + ne * 128 * 4 + 4095) / 4096 * 4096;
+}
+
 // TILES: 16-frame tiles per wave.  With 2, a workgroup is 4 waves of 32 frames (same 128 frames, same
 // LDS): one mask fragment read from LDS feeds the MFMAs of two frame tiles, i.e. half the mask-fragment
 // LDS traffic per MFMA -- these kernels run into the board's power cap, so energy per frame is time.
 template <int NG, int NE = 0, int TILES = 1> struct LdsCfg {
     static constexpr int KB = (NG == 1 && NE == 0) ? KC : 128;  // pixels per mask slot
-    // bytes per mask slot; with extras: the NG groups + NE plain columns, rounded up to 8 KiB (every
-    // wave copies an equal share of a slot in whole 1-KiB DMA instructions): 16 / 24 / 32 KiB
-    static constexpr int BSLOT = NE > 0 ? (NG * GROUP * KB * 4 + NE * KB * 4 + 8191) / 8192 * 8192
-                                        : NG * GROUP * KB * 4;
+    // bytes per mask slot; with extras: the NG groups + NE / 2 column pairs, rounded up to 4 KiB (each
+    // of the 4 waves copies an equal share of a slot in whole 1-KiB DMA instructions): 12 / 20 / 28 KiB
+    static_assert(NE == 0 || TILES == 2, "the VALU-column image is laid out for 4-wave workgroups");
+    static constexpr int BSLOT = NE > 0 ? ext_slot_bytes(NG, NE) : NG * GROUP * KB * 4;
     static constexpr int EXTRA_OFF = NG * GROUP * KB;           // float offset of the extras in a slot
     static_assert(NE == 0 || (NG * GROUP * KB * 4 + NE * KB * 4 <= BSLOT), "extras must fit the slot");
     static constexpr int RING = BSLOT > 16384 ? 3 : 4;          // frame ring depth (sub-chunks)
@@ -1117,7 +1122,8 @@ extern "C" int ltmi_masks_create_dense(int device, const void *masks_host, int r
             m->ng3 = ng3;
             m->n_slots3 = (int)((n_px + kb - 1) / kb);
             m->ne3 = ne3;
-            const int slot_floats = (ng3 * GROUP * kb * 4 + m->ne3 * kb * 4 + 8191) / 8192 * 8192 / 4;
+            const int slot_floats = (m->ne3 > 0 ? ltmi::ext_slot_bytes(ng3, m->ne3)
+                                                : ng3 * GROUP * kb * 4) / 4;
             const size_t n3 = (size_t)m->n_slots3 * slot_floats;
             e = hipMalloc((void **)&m->img3, n3 * sizeof(float));
             if (e == hipSuccess) e = hipMemset(m->img3, 0, n3 * sizeof(float));
@@ -1374,10 +1380,12 @@ static int launch_lds_extras_t(ltmi_masks *m, const T *tile, int64_t n_frames, i
 template <typename T, int NG, int NE>
 static int launch_lds_extras(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
                              int64_t ld_out, int accumulate, hipStream_t stream) {
-    if (lds_tiles(m) == 2)
-        return launch_lds_extras_t<T, NG, NE, 2>(m, tile, n_frames, ld, out, ld_out, accumulate,
-                                                 stream);
-    return launch_lds_extras_t<T, NG, NE, 1>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+    if constexpr (NE == 0) {
+        if (lds_tiles(m) != 2)
+            return launch_lds_extras_t<T, NG, NE, 1>(m, tile, n_frames, ld, out, ld_out, accumulate,
+                                                     stream);
+    }
+    return launch_lds_extras_t<T, NG, NE, 2>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
 }
 
 template <typename T>
