@@ -10,6 +10,7 @@
 #include "ltmi_common.h"
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
 #include <typeinfo>
 #include <type_traits>
 #include <utility>
@@ -488,7 +489,7 @@ static int ensure_ws64(ltmi_masks *m, size_t need, hipStream_t stream) {
     return LTMI_OK;
 }
 
-// 4- / 8-byte pixels, 16-B aligned rows, at least one full mask chunk: the LDS-DMA kernel
+// 4- / 8-byte pixels, at least one full mask chunk: the LDS-DMA kernel
 template <typename T>
 static int launch64_lds(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, double *out,
                         int64_t ld_out, int accumulate, hipStream_t stream) {
@@ -540,8 +541,11 @@ static int launch64(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, 
                     int64_t ld_out, int accumulate, hipStream_t stream) {
     if constexpr (sizeof(T) >= 4) {
         // tune_mt == 1 (ltmi_masks_set_tuning): force the direct-load kernel (bench comparison)
-        if (m->tune_mt != 1 && m->n_px >= KC64 && ((uintptr_t)tile) % 16 == 0 &&
-            (ld * sizeof(T)) % 16 == 0)
+        // (rows need not be 16-B aligned: LDS-DMA reads from any element-aligned address)
+        static const bool aligned_only = getenv("LTMI_ALIGNED_DMA_ONLY") != nullptr;
+        const bool aligned = ((uintptr_t)tile) % 16 == 0 && (ld * sizeof(T)) % 16 == 0;
+        if (m->tune_mt != 1 && m->n_px >= KC64 &&
+            (aligned || (!aligned_only && ((uintptr_t)tile) % sizeof(T) == 0)))
             return launch64_lds<T>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
     }
     constexpr int WAVES = 4;

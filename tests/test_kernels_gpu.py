@@ -175,6 +175,46 @@ def test_mfma_complex_masks(hip):
     assert np.all(np.abs(res - ref) <= 1e-5 * scale)
 
 
+@pytest.mark.parametrize('tile_dtype,result_dtype', [
+    ('uint8', 'float32'), ('uint16', 'float32'), ('int16', 'float32'), ('float32', 'float32'),
+    ('float32', 'complex64'), ('int32', 'float64'), ('float64', 'float64'),
+])
+@pytest.mark.parametrize('n_px,pad,offset', [
+    (515 * 5, 0, 0),        # odd row length (a 515-wide detector): rows at every element alignment
+    (515 * 5, 3, 1),        # odd leading dimension AND a tile pointer that is only element-aligned
+    (256 * 3, 0, 1),        # aligned row length, misaligned base
+])
+def test_rows_of_any_alignment_through_lds_dma(hip, tile_dtype, result_dtype, n_px, pad, offset):
+    """Detectors with odd row lengths: the LDS-DMA kernels (k_dense_lds / k_dense_lds64) take rows
+    at any element alignment (global_load_lds_dwordx4 does not need 16-B aligned addresses)."""
+    dt, rd = np.dtype(tile_dtype), np.dtype(result_dtype)
+    rng = np.random.default_rng(n_px + pad * 7 + offset)
+    n_frames, n_masks, ld = 150, 7, n_px + pad
+    flat = (rng.integers(0, 200, offset + n_frames * ld).astype(dt) if dt.kind in 'iu'
+            else (rng.random(offset + n_frames * ld) - 0.3).astype(dt))
+    data = flat[offset:].reshape(n_frames, ld)[:, :n_px]
+    if rd.kind == 'c':
+        masks = (rng.random((n_masks, n_px)) + 1j * rng.random((n_masks, n_px))).astype(rd)
+    else:
+        masks = (rng.random((n_masks, n_px)) - 0.25).astype(rd)
+    h = hip.MaskHandle.dense(0, masks, rd)
+    t = _dev(flat)
+    ptr = t.data_ptr() + offset * dt.itemsize
+    assert (ptr % 16 != 0) or (ld * dt.itemsize) % 16 != 0 or offset == 0
+    out = torch.full((n_frames, n_masks), 7, dtype={'float32': torch.float32, 'float64': torch.float64,
+                                                    'complex64': torch.complex64}[rd.name], device='cuda')
+    h.apply(ptr, dt, n_frames, ld, out.data_ptr(), n_masks, False)
+    torch.cuda.synchronize()
+    kern = h.last_kernel()
+    h.close()
+    assert ('k_dense_lds64' if rd == np.float64 else 'k_dense_lds<') in kern, kern
+    res = out.cpu().numpy()
+    ref = _ref64(data, masks)
+    scale = np.abs(data.astype(np.float64)) @ np.abs(masks).astype(np.float64).T
+    tol = 1e-13 if rd == np.float64 else 1e-5
+    assert np.all(np.abs(res - ref) <= tol * scale + 1e-30), np.abs(res - ref).max()
+
+
 @pytest.mark.parametrize('combo', [
     ('int32', 'float64'), ('int64', 'float64'), ('float64', 'float64'), ('uint16', 'float64'),
     ('uint32', 'float64'), ('float32', 'complex128'), ('complex64', 'complex64'),
@@ -200,7 +240,8 @@ def test_generic(hip, combo):
         masks = rng.random((n_masks, n_px)).astype(result_dtype)
     res, kern = _apply(hip, data, masks, result_dtype)
     if result_dtype == np.float64:
-        assert 'k_dense_mfma_f64' in kern, kern    # float64 results: f64 matrix cores (333 px: odd rows)
+        # float64 results: f64 matrix cores (LDS-DMA for 4- / 8-byte pixels, also with odd rows)
+        assert ('k_dense_lds64' if tile_dtype.itemsize >= 4 else 'k_dense_mfma_f64') in kern, kern
     elif result_dtype.kind in 'iu' and tile_dtype.itemsize <= 4:
         assert 'exact-int' in kern, kern           # integer results, sums < 2^52: same cores, exact
     else:
@@ -217,7 +258,8 @@ def test_generic(hip, combo):
 @pytest.mark.parametrize('shape,ksplit', [
     ((300, 256 * 9 + 100, 16), 0),      # aligned rows, ragged last chunk
     ((300, 256 * 9 + 100, 16), 3),      # K split + reduce
-    ((70, 17 * 23, 5), 0),              # odd row length -> guarded loads
+    ((70, 17 * 23, 5), 0),              # odd row length: unaligned DMA / guarded loads (2-byte pixels)
+    ((70, 15 * 13, 5), 0),              # fewer pixels than a mask chunk -> guarded loads
     ((45, 256 * 5, 37), 0),             # three column groups (grid.z)
     ((1, 256, 1), 0),
     ((1000, 256 * 20, 16), 0),          # several workgroups, the unrolled steady state
@@ -239,7 +281,7 @@ def test_float64_results_on_matrix_cores(hip, tile_dtype, shape, ksplit):
     masks = rng.random((n_masks, n_px)) - 0.25
     tuning = dict(mt=0, waves=0, ksplit=ksplit) if ksplit else None
     res, kern = _apply(hip, data, masks, np.float64, tuning=tuning)
-    lds = dt.itemsize >= 4 and (n_px * dt.itemsize) % 16 == 0 and n_px >= 256
+    lds = dt.itemsize >= 4 and n_px >= 256          # (rows need not be 16-B aligned)
     assert ('k_dense_lds64' if lds else 'k_dense_mfma_f64') in kern, kern
     if lds:
         # the direct-load kernel on the same input (tuning mt=1) agrees to rounding
@@ -565,7 +607,8 @@ def _shift_ref(data3d, masks3d, shifts):
     ('uint16', (40, 48), 5, 'float32', 'k_dense_lds'),       # MFMA path, many shift groups
     ('float32', (32, 32), 16, 'float32', 'k_dense_lds'),
     ('uint8', (32, 64), 3, 'complex64', 'k_dense_lds'),
-    ('uint16', (17, 23), 4, 'float32', 'k_dense_shifted'),   # unaligned rows -> per-frame kernel
+    ('uint16', (17, 23), 4, 'float32', 'k_dense_lds'),       # unaligned rows (391 px): LDS-DMA all the same
+    ('uint16', (15, 15), 4, 'float32', 'k_dense_shifted'),   # fewer pixels than a mask slot -> per-frame kernel
     ('uint16', (32, 32), 20, 'float32', 'x 2 column group'),  # two column groups: MFMA path, two launches
     ('uint16', (32, 32), 70, 'float32', 'x 5 column group'),  # > 64 columns (column blocks of the handle)
     ('float32', (32, 32), 13, 'complex64', 'x 2 column group'),   # 26 real columns
