@@ -78,6 +78,12 @@ struct BellImage {
     int *active = nullptr;           // chunks with entries, concatenated per pass
     int *active_off = nullptr;       // [n_pass + 1]
     int n_pass = 0;
+    // entries of the last n_px % 16 pixels of a frame (at most 15): when a row is not a multiple of 16
+    // bytes its last 16-byte piece is partial and is not fetched by the frame DMA; these few entries are
+    // applied by k_bell_tail after the main kernel
+    int32_t *tail_px = nullptr, *tail_col = nullptr;
+    float *tail_val = nullptr;
+    int n_tail = 0;
     size_t n_blocks = 0;
     double mac_ratio = 0.;           // multiply-adds incl. padding / stored values
 };
@@ -362,6 +368,9 @@ void bell_destroy(void *image) {
     if (b->nblk) (void)hipFree(b->nblk);
     if (b->active) (void)hipFree(b->active);
     if (b->active_off) (void)hipFree(b->active_off);
+    if (b->tail_px) (void)hipFree(b->tail_px);
+    if (b->tail_col) (void)hipFree(b->tail_col);
+    if (b->tail_val) (void)hipFree(b->tail_val);
     delete b;
 }
 
@@ -408,15 +417,25 @@ void *bell_build(const int64_t *indptr, const int64_t *indices, const float *val
         struct Ent { uint16_t px; uint16_t m; float v; };
         // entries per (chunk, group), pixels ascending because the CSR rows are walked in order
         std::vector<std::vector<Ent>> bucket((size_t)n_chunks * n_groups);
+        const int64_t p_tail0 = n_px - n_px % 16;       // pixels from here on: k_bell_tail
+        std::vector<int32_t> tail_px, tail_col;
+        std::vector<float> tail_val;
         for (int64_t p = 0; p < n_px; ++p) {
             const int ch = (int)(p / BE_P);
             for (int64_t e = indptr[p]; e < indptr[p + 1]; ++e)
                 for (int c = 0; c < nc; ++c) {
                     const int64_t col = indices[e] * nc + c;
+                    if (p >= p_tail0) {
+                        tail_px.push_back((int32_t)p);
+                        tail_col.push_back((int32_t)col);
+                        tail_val.push_back(vals[e * nc + c]);
+                        continue;
+                    }
                     bucket[(size_t)ch * n_groups + col / 16].push_back(
                         Ent{(uint16_t)(p - (int64_t)ch * BE_P), (uint16_t)(col % 16), vals[e * nc + c]});
                 }
         }
+        b->n_tail = (int)tail_px.size();
         std::vector<int> active, active_off(n_pass + 1, 0);
         for (int ps = 0; ps < n_pass; ++ps) {
             const int64_t g_lo = (int64_t)ps * BE_SETS * BE_SLOTS;
@@ -494,6 +513,15 @@ void *bell_build(const int64_t *indptr, const int64_t *indices, const float *val
         if (e == hipSuccess) e = hipMemcpy(b->nblk, nblk.data(), nblk.size() * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(b->active, active.data(), active.size() * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(b->active_off, active_off.data(), active_off.size() * 4, hipMemcpyHostToDevice);
+        if (b->n_tail > 0) {
+            const size_t nt = (size_t)b->n_tail;
+            if (e == hipSuccess) e = hipMalloc((void **)&b->tail_px, nt * 4);
+            if (e == hipSuccess) e = hipMalloc((void **)&b->tail_col, nt * 4);
+            if (e == hipSuccess) e = hipMalloc((void **)&b->tail_val, nt * 4);
+            if (e == hipSuccess) e = hipMemcpy(b->tail_px, tail_px.data(), nt * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(b->tail_col, tail_col.data(), nt * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(b->tail_val, tail_val.data(), nt * 4, hipMemcpyHostToDevice);
+        }
         if (e != hipSuccess) {
             set_error("uploading the blocked sparse mask image failed: %s", hipGetErrorString(e));
             *err = (int)e;
@@ -507,6 +535,20 @@ void *bell_build(const int64_t *indptr, const int64_t *indices, const float *val
         return nullptr;
     }
     return b;
+}
+
+// the entries of the last n_px % 16 pixels (see BellImage::tail_*): one thread per frame, entries in
+// CSR order (a frame's sums are updated by one thread only: no atomics)
+template <typename T>
+__global__ void k_bell_tail(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
+                            const int32_t *__restrict__ px, const int32_t *__restrict__ col,
+                            const float *__restrict__ val, int n_tail, float *__restrict__ out,
+                            int64_t ld_out) {
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames) return;
+    const T *row = tile + f * ld;
+    float *o = out + f * ld_out;
+    for (int e = 0; e < n_tail; ++e) o[col[e]] += val[e] * (float)row[px[e]];
 }
 
 template <typename T>
@@ -548,12 +590,19 @@ static int launch_bell(ltmi_masks *m, BellImage *b, const T *tile, int64_t n_fra
                 h[5] / w, h[6] / w);
     }
 #endif
+    if (b->n_tail > 0) {
+        hipLaunchKernelGGL(k_bell_tail<T>, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0,
+                           stream, tile, ld, n_frames, (const int32_t *)b->tail_px,
+                           (const int32_t *)b->tail_col, (const float *)b->tail_val, b->n_tail, out,
+                           ld_out_f);
+        LTMI_HIP(hipGetLastError());
+    }
     snprintf(m->last_kernel, sizeof(m->last_kernel), "k_bell_apply<%s> grid=(%u,%u) blocks=%zu x%.2f",
              typeid(T).name(), grid.x, grid.y, b->n_blocks, b->mac_ratio);
     return LTMI_OK;
 }
 
-// handled = false: the tile does not meet the kernel's alignment rules (caller uses the SELL kernel)
+// handled = false: the tile does not meet the kernel's rules (caller uses the SELL kernel)
 int bell_apply(ltmi_masks *m, void *image, int cplx, const void *tile, int tile_dtype,
                int64_t n_frames, int64_t ld_tile, void *out, int64_t ld_out, int accumulate,
                hipStream_t stream, bool *handled) {
@@ -561,7 +610,9 @@ int bell_apply(ltmi_masks *m, void *image, int cplx, const void *tile, int tile_
     const int sz = dtype_size(tile_dtype);
     *handled = false;
     if (!b || n_frames <= 0) return LTMI_OK;
-    if (((uintptr_t)tile) % 16 || (ld_tile * sz) % 16 || (m->n_px * sz) % 16) return LTMI_OK;
+    // rows of any element alignment (LDS-DMA reads them); a partial last 16-byte piece of a row is not
+    // fetched -- its pixels (< 16) are k_bell_tail's
+    if (sz <= 0 || !vector_loads_ok(tile, ld_tile, (size_t)sz)) return LTMI_OK;
     const int nc = cplx ? 2 : 1;
     const int n_cols = (int)(m->n_masks * nc);
     float *o = (float *)out;

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 #include "../../include/ltmi.h"
@@ -27,6 +28,16 @@ void set_error(const char *fmt, ...);
         ltmi::set_error(__VA_ARGS__);                                                    \
         return (code);                                                                   \
     } while (0)
+
+// gfx950 serves 16-byte vector loads and LDS-DMA loads from any element-aligned address at the speed
+// of aligned ones (profiles/r02_unaligned.txt), so tiles whose rows are not 16-B aligned (odd pixel
+// counts, e.g. 515 x 515 detectors) take the same vectorised kernels.  LTMI_ALIGNED_DMA_ONLY=1 in the
+// environment restores the conservative dispatch (vector paths for 16-B aligned rows only).
+static inline bool vector_loads_ok(const void *tile, int64_t ld_elems, size_t elem) {
+    static const bool aligned_only = getenv("LTMI_ALIGNED_DMA_ONLY") != nullptr;
+    if ((((uintptr_t)tile) % 16 == 0) && ((ld_elems * (int64_t)elem) % 16 == 0)) return true;
+    return !aligned_only && ((uintptr_t)tile) % elem == 0;
+}
 
 static inline int dtype_size(int dt) {
     switch (dt) {

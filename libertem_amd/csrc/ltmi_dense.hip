@@ -1574,12 +1574,6 @@ static int launch_lds_shifted(ltmi_masks *m, const T *tile, int64_t n_frames, in
     return LTMI_OK;
 }
 
-// element-aligned tile pointer and the escape hatch not set
-static inline bool lds_dma_any_alignment(const void *tile, size_t elem) {
-    static const bool aligned_only = getenv("LTMI_ALIGNED_DMA_ONLY") != nullptr;
-    return !aligned_only && ((uintptr_t)tile) % elem == 0;
-}
-
 template <typename T>
 static int launch_mfma(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
                        int64_t ld_out, int accumulate, hipStream_t stream) {
@@ -1588,8 +1582,8 @@ static int launch_mfma(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t l
     // any element-aligned address (detectors with odd row lengths -- 515 x 515 uint16 -- run at the
     // speed of 516 x 516: profiles/r02_unaligned.txt; the direct-load fallback with guarded element
     // loads was 5.5x slower).  LTMI_ALIGNED_DMA_ONLY=1 restores the old dispatch.
-    if ((aligned || lds_dma_any_alignment(tile, sizeof(T))) && m->tune_mt == 0 &&
-        m->tune_waves == 0 && lds_kernel_applies<T>(m))
+    if (vector_loads_ok(tile, ld, sizeof(T)) && m->tune_mt == 0 && m->tune_waves == 0 &&
+        lds_kernel_applies<T>(m))
         return launch_lds<T>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
     int waves = m->tune_waves ? m->tune_waves : 4;
     int mt = m->tune_mt ? m->tune_mt : (n_frames >= 256 * waves * 32 ? 2 : 1);
@@ -1829,8 +1823,7 @@ extern "C" int ltmi_apply_masks_shifted_host(ltmi_masks *m, const void *tile, in
     LTMI_HIP(hipSetDevice(m->device));
     hipStream_t stream = (hipStream_t)stream_;
     const size_t esz = (size_t)dtype_size(tile_dtype);
-    const bool aligned = ((((uintptr_t)tile) % 16 == 0) && ((ld_tile * (int64_t)esz) % 16 == 0)) ||
-                         lds_dma_any_alignment(tile, esz);
+    const bool aligned = vector_loads_ok(tile, ld_tile, esz);
     if (m->kind == 0 && aligned && m->n_px >= KC && n_frames < (1ll << 31)) {
         bool handled = false;
         int rc = LTMI_OK;

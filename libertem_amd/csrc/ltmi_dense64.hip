@@ -542,10 +542,7 @@ static int launch64(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, 
     if constexpr (sizeof(T) >= 4) {
         // tune_mt == 1 (ltmi_masks_set_tuning): force the direct-load kernel (bench comparison)
         // (rows need not be 16-B aligned: LDS-DMA reads from any element-aligned address)
-        static const bool aligned_only = getenv("LTMI_ALIGNED_DMA_ONLY") != nullptr;
-        const bool aligned = ((uintptr_t)tile) % 16 == 0 && (ld * sizeof(T)) % 16 == 0;
-        if (m->tune_mt != 1 && m->n_px >= KC64 &&
-            (aligned || (!aligned_only && ((uintptr_t)tile) % sizeof(T) == 0)))
+        if (m->tune_mt != 1 && m->n_px >= KC64 && vector_loads_ok(tile, ld, sizeof(T)))
             return launch64_lds<T>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
     }
     constexpr int WAVES = 4;

@@ -156,7 +156,7 @@ template <typename T, typename A>
 static int run_sum_sig(const void *tile, int64_t n_frames, int64_t n_px, int64_t ld, void *out,
                        int accumulate, hipStream_t stream) {
     constexpr int VEC = vec_for<T>();
-    const bool aligned = ((uintptr_t)tile % 16 == 0) && ((ld * (int64_t)sizeof(T)) % 16 == 0);
+    const bool aligned = vector_loads_ok(tile, ld, sizeof(T));
     if (aligned && VEC > 1)
         hipLaunchKernelGGL((k_sum_sig<T, A, VEC>), dim3((unsigned)n_frames), dim3(256), 0, stream,
                            (const T *)tile, ld, n_px, (A *)out, accumulate);
@@ -171,7 +171,7 @@ template <typename T, typename A>
 static int run_sum_frames(const void *tile, int64_t n_frames, int64_t n_px, int64_t ld, void *out,
                           int accumulate, void *ws, hipStream_t stream) {
     constexpr int VECA = vec_for<T>();
-    const bool aligned = ((uintptr_t)tile % 16 == 0) && ((ld * (int64_t)sizeof(T)) % 16 == 0);
+    const bool aligned = vector_loads_ok(tile, ld, sizeof(T));
     const int vec = (aligned && VECA > 1) ? VECA : 1;
     const int fsplit = frames_split(n_frames, n_px);         // matches the workspace query
     dim3 grid((unsigned)((n_px + 256 * vec - 1) / (256 * vec)), (unsigned)fsplit);

@@ -247,7 +247,7 @@ int csr_destroy(ltmi_masks *m) {
 template <typename T>
 static int launch_sell(ltmi_masks *m, CsrImage *c, const T *tile, int64_t n_frames, int64_t ld,
                        float *out, int64_t ld_out_f, int accumulate, hipStream_t stream) {
-    const int vec_ok = (((uintptr_t)tile) % 16 == 0) && ((ld * (int64_t)sizeof(T)) % 16 == 0);
+    const int vec_ok = vector_loads_ok(tile, ld, sizeof(T)) ? 1 : 0;
     const char *abl = getenv("LTMI_SELL_ABLATE");     // 1: loader only, 2: gathers only (bench)
     const int ablate = abl ? atoi(abl) : 0;
     dim3 grid((unsigned)((n_frames + SP_F - 1) / SP_F), (unsigned)c->n_pass);
