@@ -31,7 +31,10 @@ k_sum_sig(const T *__restrict__ tile, int64_t ld, int64_t n_px, A *__restrict__ 
     const T *row = tile + f * ld;
     A acc0 = 0, acc1 = 0;
     if (VEC > 1) {
-        typedef T vec_t __attribute__((ext_vector_type(VEC)));
+        // (element-aligned only: rows of odd length start at any element boundary; the target has
+        // unaligned access enabled, the load stays one global_load_dwordx4)
+        typedef T vec_a __attribute__((ext_vector_type(VEC)));
+        typedef vec_a vec_t __attribute__((aligned(sizeof(T))));
         const int64_t nvec = n_px / VEC;
         const vec_t *vrow = (const vec_t *)row;
         int64_t i = threadIdx.x;
@@ -66,7 +69,8 @@ template <typename T, typename A, int VEC>
 __global__ void __launch_bounds__(256)
 k_sum_frames(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
              A *__restrict__ dst, int64_t dst_stride_split, int fsplit, int accumulate_direct) {
-    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    typedef T vec_a __attribute__((ext_vector_type(VEC)));
+    typedef vec_a vec_t __attribute__((aligned(sizeof(T))));     // rows at any element alignment
     const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC;
     if (p0 >= n_px) return;
     const int64_t per = (n_frames + fsplit - 1) / fsplit;

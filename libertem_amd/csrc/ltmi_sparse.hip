@@ -66,7 +66,8 @@ __device__ __forceinline__ void load8_guarded(const T *row, int64_t p0, int64_t 
                                               float (&f)[8]) {
     if (vec_ok && p0 + 8 <= n_px) {
         if constexpr (sizeof(T) == 2) {
-            const u32x4 r = __builtin_nontemporal_load((const u32x4 *)(row + p0));
+            typedef u32x4 u32x4_u __attribute__((aligned(2)));   // rows at any element alignment
+            const u32x4 r = __builtin_nontemporal_load((const u32x4_u *)(row + p0));
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if constexpr (std::is_signed<T>::value) {
@@ -79,7 +80,8 @@ __device__ __forceinline__ void load8_guarded(const T *row, int64_t p0, int64_t 
             }
             return;
         } else if constexpr (sizeof(T) == 1) {
-            const u32x2 r = __builtin_nontemporal_load((const u32x2 *)(row + p0));
+            typedef u32x2 u32x2_u __attribute__((aligned(1)));
+            const u32x2 r = __builtin_nontemporal_load((const u32x2_u *)(row + p0));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -91,8 +93,9 @@ __device__ __forceinline__ void load8_guarded(const T *row, int64_t p0, int64_t 
                 }
             return;
         } else if constexpr (std::is_same<T, float>::value) {
-            const f32x4 a = __builtin_nontemporal_load((const f32x4 *)(row + p0));
-            const f32x4 b = __builtin_nontemporal_load((const f32x4 *)(row + p0) + 1);
+            typedef f32x4 f32x4_u __attribute__((aligned(4)));
+            const f32x4 a = __builtin_nontemporal_load((const f32x4_u *)(row + p0));
+            const f32x4 b = __builtin_nontemporal_load((const f32x4_u *)(row + p0) + 1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = b[i]; }
             return;
