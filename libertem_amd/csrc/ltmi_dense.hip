@@ -489,7 +489,18 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
     unsigned char *a_base = lds_raw + wave * ASLOT;      // + slot * (WAVES * ASLOT)
     unsigned char *b_base = lds_raw + A_BYTES;           // + bslot * BSLOT
 
-    f32x4 acc[TILES][NG][NACC];
+    constexpr int NGA = NG > 0 ? NG : 1;                // (array dimensions; NG = 0: VALU columns only)
+    f32x4 acc[TILES][NGA][NACC];
+    // second accumulation level: every FLUSH_PX pixels the running tiles are added to acc2 and start
+    // again from zero.  One float32 chain over a whole 512 x 512 (1024 x 1024) frame drifts by 1.5e-5
+    // (6e-5) of the sum on all-positive data -- round-off random walk over 32 768 (131 072) MFMA steps;
+    // with chains of 128 steps + at most a few thousand second-level additions it stays below 2e-6.
+    constexpr int FLUSH_PX = 1024;
+    f32x4 acc2[TILES][NGA];
+#pragma unroll
+    for (int tl = 0; tl < TILES; ++tl)
+#pragma unroll
+        for (int g = 0; g < NGA; ++g) acc2[tl][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int tl = 0; tl < TILES; ++tl)
 #pragma unroll
@@ -497,11 +508,16 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
 #pragma unroll
             for (int x = 0; x < NACC; ++x) acc[tl][g][x] = f32x4{0.f, 0.f, 0.f, 0.f};
     static_assert(NE % 2 == 0, "VALU columns come in pairs");
-    f32x2 acc_e[TILES][NE > 0 ? NE / 2 : 1];             // VALU column pairs: partial over this lane's pixels
+    // VALU column pairs: partial over this lane's pixels -- two levels: the running sum of ONE sub-chunk
+    // (16 / 32 / 64 products per lane) is added to the long sum at the end of the sub-chunk, so the
+    // float32 chains stay short (a single chain over 65 536 products of a 512 x 512 frame drifts by
+    // ~2e-5 relative)
+    f32x2 acc_e[TILES][NE > 0 ? NE / 2 : 1], acc_e2[TILES][NE > 0 ? NE / 2 : 1];
 #pragma unroll
     for (int tl = 0; tl < TILES; ++tl)
 #pragma unroll
-        for (int c = 0; c < (NE > 0 ? NE / 2 : 1); ++c) acc_e[tl][c] = f32x2{0.f, 0.f};
+        for (int c = 0; c < (NE > 0 ? NE / 2 : 1); ++c)
+            acc_e[tl][c] = acc_e2[tl][c] = f32x2{0.f, 0.f};
 
     // lane-constant parts of the fragment addresses
     const int a_lane = m * V2_SUB_BYTES;                 // bytes inside a frame tile of a ring slot
@@ -606,7 +622,7 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             typename TR::raw_t raw_c[TILES];
 #pragma unroll
             for (int tl = 0; tl < TILES; ++tl) raw_c[tl] = rd_a(tl, 0);
-            f32x4 b_c[NG][2];
+            f32x4 b_c[NGA][2];
 #pragma unroll
             for (int g = 0; g < NG; ++g) { b_c[g][0] = rd_b(0, g, 0); b_c[g][1] = rd_b(0, g, 1); }
             f32x4 e_c[NE > 0 ? NE / 2 : 1][4];
@@ -619,7 +635,7 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                 typename TR::raw_t raw_n[TILES];
 #pragma unroll
                 for (int tl = 0; tl < TILES; ++tl) raw_n[tl] = raw_c[tl];
-                f32x4 b_n[NG][2];
+                f32x4 b_n[NGA][2];
 #pragma unroll
                 for (int g = 0; g < NG; ++g) { b_n[g][0] = b_c[g][0]; b_n[g][1] = b_c[g][1]; }
                 f32x4 e_n[NE > 0 ? NE / 2 : 1][4];
@@ -665,8 +681,10 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                             for (int g = 0; g < NG; ++g)
                                 acc[tl][g][j & (NACC - 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                                     a[tl][j], b_c[g][j >> 2][j & 3], acc[tl][g][j & (NACC - 1)], 0, 0, 0);
-                    if (CVT) __builtin_amdgcn_sched_group_barrier(0x002, 8 * TILES, 0);  // conversions
-                    __builtin_amdgcn_sched_group_barrier(0x008, 8 * NG * TILES, 0);      // then the MFMAs
+                    if constexpr (NG > 0) {
+                        if (CVT) __builtin_amdgcn_sched_group_barrier(0x002, 8 * TILES, 0);  // conversions
+                        __builtin_amdgcn_sched_group_barrier(0x008, 8 * NG * TILES, 0);      // then the MFMAs
+                    }
                 }
                 // VALU columns, two at a time (v_pk_fma_f32: the pixel value is broadcast, the two
                 // columns' mask values sit next to each other in the slot)
@@ -690,6 +708,13 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
 #pragma unroll
                     for (int h = 0; h < 4; ++h) e_c[c][h] = e_n[c][h];
             }
+#pragma unroll
+            for (int tl = 0; tl < TILES; ++tl)
+#pragma unroll
+                for (int c = 0; c < NE / 2; ++c) {
+                    acc_e2[tl][c] += acc_e[tl][c];
+                    acc_e[tl][c] = f32x2{0.f, 0.f};
+                }
         };
 
         // unroll period: ring slot (i % RING) and mask-slot parity ((i / PER) & 1) both static
@@ -699,7 +724,23 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
         static_assert(UNROLL % RING == 0 && UNROLL % U2 == 0, "unroll period");
         int s = S0;
         if constexpr (UNROLL <= 12) {
+            // (the second-level flush sits between the unrolled blocks, not inside them)
+            constexpr int FLUSH_BLOCKS = FLUSH_PX / (UNROLL * SPX) > 1 ? FLUSH_PX / (UNROLL * SPX) : 1;
+            int blocks_done = 0;
             for (; s + UNROLL <= S1; s += UNROLL) {
+                if (NG > 0 && blocks_done == FLUSH_BLOCKS) {
+                    blocks_done = 0;
+#pragma unroll
+                    for (int tl = 0; tl < TILES; ++tl)
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+#pragma unroll
+                            for (int x = 0; x < NACC; ++x) {
+                                acc2[tl][g] += acc[tl][g][x];
+                                acc[tl][g][x] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            }
+                }
+                ++blocks_done;
                 static_for<0, UNROLL>([&](auto I) { iteration(s + decltype(I)::value, I); });
             }
         }
@@ -762,6 +803,7 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                 if (f >= 0 && col < n_cols) {
                     float v = acc[tl][g][0][r];
                     if (NACC == 2) v += acc[tl][g][NACC - 1][r];
+                    v += acc2[tl][g][r];
                     if (ksplit == 1) {
                         float *p = out + f * ld_out + col;
                         *p = accumulate ? (*p + v) : v;
@@ -777,7 +819,7 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             const int64_t f = frame_of(tl * 16 + m);
 #pragma unroll
             for (int c = 0; c < NE; ++c) {
-                float v = acc_e[tl][c / 2][c & 1];
+                float v = acc_e2[tl][c / 2][c & 1] + acc_e[tl][c / 2][c & 1];   // (+ the ragged tail)
                 v += __shfl_xor(v, 16, 64);
                 v += __shfl_xor(v, 32, 64);
                 const int col = NG * GROUP + c;
@@ -1110,15 +1152,17 @@ extern "C" int ltmi_masks_create_dense(int device, const void *masks_host, int r
         // padding (k_dense_lds<T, NG, .., NE>; measured in scripts/bench_extras.py):
         //   17..18 -> 1 + 2    33..34 -> 2 + 2    35..36 -> 2 + 4    37..48 -> 3 (no padded 4th group)
         //   49..50 -> 3 + 2    51..52 -> 3 + 4    (19..20: the padded 2-group kernel is faster)
+        //   1..2 -> 0 + 2      3..4 -> 0 + 4      (no matrix cores at all)
         int ng3 = 0, ne3 = 0;
         {
             const int nc = m->n_cols;
-            if (nc >= 17 && nc <= 18) { ng3 = 1; ne3 = 2; }
+            if (nc <= 4) { ng3 = 0; ne3 = nc <= 2 ? 2 : 4; }        // VALU only
+            else if (nc >= 17 && nc <= 18) { ng3 = 1; ne3 = 2; }
             else if (nc >= 33 && nc <= 36) { ng3 = 2; ne3 = nc <= 34 ? 2 : 4; }
             else if (nc >= 37 && nc <= 48) { ng3 = 3; ne3 = 0; }
             else if (nc >= 49 && nc <= 52) { ng3 = 3; ne3 = nc <= 50 ? 2 : 4; }
         }
-        if (e == hipSuccess && ng3 > 0) {
+        if (e == hipSuccess && (ng3 > 0 || ne3 > 0)) {
             constexpr int kb = 128;
             m->ng3 = ng3;
             m->n_slots3 = (int)((n_px + kb - 1) / kb);
@@ -1398,10 +1442,22 @@ static bool lds_kernel_applies(const ltmi_masks *m) {
 template <typename T>
 static int launch_lds(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
                       int64_t ld_out, int accumulate, hipStream_t stream) {
-    if (m->ng == 1)
+    if (m->ng == 1) {
+        if constexpr (sizeof(T) > 1) {
+            // at most 4 columns (CoM: 3, single-mask analyses: 1 or 2): all of them on the VALU -- a
+            // 16-column MFMA tile would be >= 75 % padding that still costs matrix-pipe power
+            if (m->img3 && m->ng3 == 0 && m->tune_ksplit_ring != 33) {
+                if (m->ne3 == 2)
+                    return launch_lds_extras<T, 0, 2>(m, tile, n_frames, ld, out, ld_out, accumulate,
+                                                      stream);
+                return launch_lds_extras<T, 0, 4>(m, tile, n_frames, ld, out, ld_out, accumulate,
+                                                  stream);
+            }
+        }
         return launch_lds_ng<T, 1>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+    }
     if constexpr (sizeof(T) > 1) {
-        if (m->img3 && m->tune_ksplit_ring != 33) {          // 33: force the padded-group kernel (bench)
+        if (m->img3 && m->ng3 > 0 && m->tune_ksplit_ring != 33) {   // 33: force the padded-group kernel (bench)
 #define LTMI_EXTRAS(NG_, NE_)                                                                     \
     if (m->ng3 == NG_ && m->ne3 == NE_)                                                           \
         return launch_lds_extras<T, NG_, NE_>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);

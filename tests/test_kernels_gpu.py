@@ -215,6 +215,33 @@ def test_rows_of_any_alignment_through_lds_dma(hip, tile_dtype, result_dtype, n_
     assert np.all(np.abs(res - ref) <= tol * scale + 1e-30), np.abs(res - ref).max()
 
 
+@pytest.mark.parametrize('n_px,tile_dtype,n_masks', [
+    (512 * 512, 'uint16', 16),      # MFMA path, one column group
+    (512 * 512, 'uint16', 3),       # <= 4 columns: the VALU-only variant (CoM)
+    (1024 * 1024, 'float32', 3),
+    (1024 * 1024, 'float32', 50),   # 3 groups + 2 VALU columns (the radial Fourier default)
+])
+def test_long_rows_keep_float32_accuracy(hip, n_px, tile_dtype, n_masks):
+    """All-positive data, large frames, NO split of the pixel axis (what a full partition gets):
+    one float32 accumulation chain over a whole frame would drift by 1e-5 ... 6e-5 of the sum (the
+    round-off random walk of 32 768 ... 131 072 MFMA steps); the kernels fold their running tiles into
+    a second accumulation level every <= 1024 pixels instead and stay an order of magnitude below
+    the 1e-5 tolerance against float64."""
+    dt = np.dtype(tile_dtype)
+    rng = np.random.default_rng(n_px % 1000 + n_masks)
+    n_frames = 130
+    data = (rng.integers(0, 4096, (n_frames, n_px)).astype(dt) if dt.kind == 'u'
+            else rng.random((n_frames, n_px)).astype(dt))
+    masks = rng.random((n_masks, n_px)).astype(np.float32)
+    res, kern = _apply(hip, data, masks, np.float32, tuning=dict(mt=0, waves=0, ksplit=1))
+    assert 'k_dense_lds' in kern and ',1,1)' in kern.replace(' ', ''), kern      # grid.y == 1: no K split
+    if n_masks <= 4:
+        assert 'NG=0+' in kern, kern
+    ref = data.astype(np.float64) @ masks.astype(np.float64).T
+    err = np.abs(res - ref).max() / np.abs(ref).max()
+    assert err < 4e-6, err
+
+
 @pytest.mark.parametrize('combo', [
     ('int32', 'float64'), ('int64', 'float64'), ('float64', 'float64'), ('uint16', 'float64'),
     ('uint32', 'float64'), ('float32', 'complex128'), ('complex64', 'complex64'),
