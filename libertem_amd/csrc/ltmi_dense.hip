@@ -167,11 +167,22 @@ k_dense_mfma(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
         rowp[mt] = tile + f * ld + kg * 8;
     }
 
-    f32x4 acc[MT][NG];
+    // acc: the running tiles of at most 4 chunks (1024 pixels); acc2: the long sums (two accumulation
+    // levels keep the float32 chains short on large frames, see k_dense_lds)
+    f32x4 acc[MT][NG], acc2[MT][NG];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int g = 0; g < NG; ++g) acc[mt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < NG; ++g) acc[mt][g] = acc2[mt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto flush_acc = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                acc2[mt][g] += acc[mt][g];
+                acc[mt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    };
 
     // this thread's share of the linear image -> LDS copy
     const u32x4 *img_units = (const u32x4 *)img;
@@ -203,6 +214,7 @@ k_dense_mfma(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
         for (int c = c_begin; c < cf_end; ++c) {
             const int cn = min(c + 1, cf_end - 1);      // branch-free prefetch target
             const int s = (c - c_begin) & 1;
+            if (((c - c_begin) & 3) == 3) flush_acc();
 #pragma unroll
             for (int i = 0; i < BUNITS; ++i) breg[i] = img_units[img_unit_index(i, cn)];
             const float *ldsb = lds + s * STAGE + lds_lane_base;
@@ -241,6 +253,7 @@ k_dense_mfma(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
     // chunk when the rows are not 16-byte aligned
     for (int c = max(c_begin, n_full); c < c_end; ++c) {
         __syncthreads();
+        if (((c - c_begin) & 3) == 3) flush_acc();
 #pragma unroll
         for (int i = 0; i < BUNITS; ++i)
             ((u32x4 *)lds)[i * NT + tid] = img_units[img_unit_index(i, c)];
@@ -283,7 +296,7 @@ k_dense_mfma(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
                 const int64_t f = f_wave + mt * 16 + kg * 4 + r;
                 const int col = (g0 + g) * GROUP + m;
                 if (f < n_frames && col < n_cols) {
-                    const float v = acc[mt][g][r];
+                    const float v = acc[mt][g][r] + acc2[mt][g][r];
                     if (ksplit == 1) {
                         float *p = out + f * ld_out + col;
                         *p = accumulate ? (*p + v) : v;

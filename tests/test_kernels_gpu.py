@@ -220,6 +220,7 @@ def test_rows_of_any_alignment_through_lds_dma(hip, tile_dtype, result_dtype, n_
     (512 * 512, 'uint16', 3),       # <= 4 columns: the VALU-only variant (CoM)
     (1024 * 1024, 'float32', 3),
     (1024 * 1024, 'float32', 50),   # 3 groups + 2 VALU columns (the radial Fourier default)
+    (512 * 512, 'uint8', 20),       # 1-byte pixels, two column groups: the direct-load kernel
 ])
 def test_long_rows_keep_float32_accuracy(hip, n_px, tile_dtype, n_masks):
     """All-positive data, large frames, NO split of the pixel axis (what a full partition gets):
@@ -230,11 +231,12 @@ def test_long_rows_keep_float32_accuracy(hip, n_px, tile_dtype, n_masks):
     dt = np.dtype(tile_dtype)
     rng = np.random.default_rng(n_px % 1000 + n_masks)
     n_frames = 130
-    data = (rng.integers(0, 4096, (n_frames, n_px)).astype(dt) if dt.kind == 'u'
+    data = (rng.integers(0, min(4096, np.iinfo(dt).max), (n_frames, n_px)).astype(dt) if dt.kind == 'u'
             else rng.random((n_frames, n_px)).astype(dt))
     masks = rng.random((n_masks, n_px)).astype(np.float32)
     res, kern = _apply(hip, data, masks, np.float32, tuning=dict(mt=0, waves=0, ksplit=1))
-    assert 'k_dense_lds' in kern and ',1,1)' in kern.replace(' ', ''), kern      # grid.y == 1: no K split
+    assert ('k_dense_mfma' if dt.itemsize == 1 else 'k_dense_lds') in kern, kern
+    assert ',1,1)' in kern.replace(' ', ''), kern                                # grid.y == 1: no K split
     if n_masks <= 4:
         assert 'NG=0+' in kern, kern
     ref = data.astype(np.float64) @ masks.astype(np.float64).T
