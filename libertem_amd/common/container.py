@@ -43,6 +43,9 @@ def _worth_densifying(csr_px_by_masks, result_dtype):
     cols16 = -(-n_masks * nc // 16) * 16
     if DENSIFY_FILL <= 0 or n_px * n_masks * np.dtype(result_dtype).itemsize > DENSIFY_MAX_BYTES:
         return False
+    if np.dtype(result_dtype) == np.float64 and cols16 > 16:
+        # the float64 matrix kernel reads the frames once per 16-column group
+        return False
     if csr_px_by_masks.nnz * nc > DENSIFY_FILL * n_px * cols16:
         return True
     touched = np.count_nonzero(np.diff(csr_px_by_masks.indptr))
@@ -201,10 +204,11 @@ class MaskContainer:
         key = (sig_slice, np.dtype(result_dtype).str, int(device))
         h = self._handle_cache.get(key)
         if h is None:
-            sparse_ok = np.dtype(result_dtype) in (np.dtype(np.float32), np.dtype(np.complex64))
+            sparse_ok = np.dtype(result_dtype) in (np.dtype(np.float32), np.dtype(np.complex64),
+                                                   np.dtype(np.float64))
             if self.use_sparse is False or not sparse_ok:
-                # dense stack; also the route for sparse stacks whose result dtype (float64,
-                # complex128, integers) the SELL kernel does not cover: densified, generic kernel
+                # dense stack; also the route for sparse stacks whose result dtype (complex128,
+                # integers) the sparse kernels do not cover: densified
                 m = self.get_for_sig_slice(sig_slice, dtype=result_dtype, sparse_backend=False,
                                            transpose=False)            # (n_masks, px), C order
                 h = hip.MaskHandle.dense(device, np.ascontiguousarray(m), result_dtype)

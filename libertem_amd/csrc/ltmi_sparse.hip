@@ -48,6 +48,8 @@ struct CsrImage {
     int n_chunks = 0;
     uint32_t *pix = nullptr;    // [rows][64]
     float *val = nullptr;       // [rows][64] (x2 interleaved re/im for complex)
+    double *val64 = nullptr;    // float64 results: the values as doubles instead (f64 != 0)
+    int f64 = 0;
     int *row_off = nullptr;     // [(pass * n_chunks + chunk) * mpt * 4 + slot * 4 + wave]
     int *row_len = nullptr;
     size_t n_rows = 0;
@@ -105,15 +107,49 @@ __device__ __forceinline__ void load8_guarded(const T *row, int64_t p0, int64_t 
     for (int j = 0; j < 8; ++j) f[j] = (p0 + j < n_px) ? (float)row[p0 + j] : 0.f;
 }
 
-template <typename T, int MPT, bool CPLX>
+// the same for an accumulation type A: float (above) or double (float64 results: int32 / uint32 /
+// int64 / float64 frames, or float64 mask values -- np.result_type, reference udf/masks.py:362)
+template <typename T, typename A>
+__device__ __forceinline__ void load8_as(const T *row, int64_t p0, int64_t n_px, bool vec_ok,
+                                         A (&f)[8]) {
+    if constexpr (std::is_same<A, float>::value) {
+        load8_guarded<T>(row, p0, n_px, vec_ok, f);
+    } else if constexpr (sizeof(T) <= 2 || std::is_same<T, float>::value) {
+        float t[8];
+        load8_guarded<T>(row, p0, n_px, vec_ok, t);      // exact in float32, then widened
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (A)t[j];
+    } else {
+        if (vec_ok && p0 + 8 <= n_px) {
+            constexpr int VE = 16 / (int)sizeof(T);      // elements per 16-byte load
+            typedef T v_a __attribute__((ext_vector_type(VE)));
+            typedef v_a v_t __attribute__((aligned(sizeof(T))));
+            const v_t *vp = (const v_t *)(row + p0);
+#pragma unroll
+            for (int i = 0; i < 8 / VE; ++i) {
+                const v_a v = __builtin_nontemporal_load(vp + i);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) f[i * VE + e] = (A)v[e];
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (p0 + j < n_px) ? (A)row[p0 + j] : (A)0;
+    }
+}
+
+template <typename T, int MPT, bool CPLX, typename A = float>
 __global__ void __launch_bounds__(SP_NT)
 k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
-             const uint32_t *__restrict__ pix, const float *__restrict__ val,
+             const uint32_t *__restrict__ pix, const A *__restrict__ val,
              const int *__restrict__ row_off, const int *__restrict__ row_len,
              const int *__restrict__ active, const int *__restrict__ active_off, int n_chunks,
-             float *__restrict__ out, int64_t ld_out, int n_masks, int accumulate, int vec_ok,
+             A *__restrict__ out, int64_t ld_out, int n_masks, int accumulate, int vec_ok,
              int ablate) {
-    extern __shared__ __attribute__((aligned(16))) float slab[];     // [SP_P][SP_F]
+    extern __shared__ __attribute__((aligned(16))) unsigned char slab_raw[];
+    A *slab = (A *)slab_raw;                                          // [SP_P][SP_F]
+    typedef A ax4 __attribute__((ext_vector_type(4)));
+    typedef A ax2 __attribute__((ext_vector_type(2)));
     constexpr int NC = CPLX ? 2 : 1;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -130,15 +166,15 @@ k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
     // padding entries of the image (value 0) point at pixel row SP_P, which is all zeros: a
     // non-finite pixel of a frame only reaches the masks that really contain it, like in the
     // reference's CSR loop (0 * NaN would be NaN)
-    if (tid < SP_F) slab[SP_P * SP_F + tid] = 0.f;
+    if (tid < SP_F) slab[SP_P * SP_F + tid] = (A)0;
 
-    float acc[MPT][SP_F][NC];
+    A acc[MPT][SP_F][NC];
 #pragma unroll
     for (int i = 0; i < MPT; ++i)
 #pragma unroll
         for (int f = 0; f < SP_F; ++f)
 #pragma unroll
-            for (int c = 0; c < NC; ++c) acc[i][f][c] = 0.f;
+            for (int c = 0; c < NC; ++c) acc[i][f][c] = (A)0;
 
     for (int ai = active_off[pass]; ai < active_off[pass + 1]; ++ai) {
         const int ch = active[ai];
@@ -150,8 +186,8 @@ k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
 #pragma unroll
         for (int it = 0; it < SP_P / 128; ++it) {
             const int pl = it * 128 + lg * 8;
-            float x[8];
-            load8_guarded<T>(row, (int64_t)ch * SP_P + pl, n_px, vec_ok != 0, x);
+            A x[8];
+            load8_as<T, A>(row, (int64_t)ch * SP_P + pl, n_px, vec_ok != 0, x);
 #pragma unroll
             for (int j = 0; j < 8; ++j) slab[slab_word(pl + j, lf)] = x[j];
         }
@@ -165,36 +201,36 @@ k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
             // slices are padded to a multiple of SP_U rows (zero entries): SP_U rows of
             // (pixel, value) are fetched together, one group ahead of the LDS gathers
             uint32_t pn[SP_U];
-            float vrn[SP_U], vin[SP_U];
+            A vrn[SP_U], vin[SP_U];
             auto fetch = [&](int j) {
 #pragma unroll
                 for (int u = 0; u < SP_U; ++u) {
                     const int64_t e = base + (int64_t)(j + u) * 64;
                     pn[u] = pix[e];
                     if (CPLX) {
-                        const float2 v2 = ((const float2 *)val)[e];
-                        vrn[u] = v2.x;
-                        vin[u] = v2.y;
+                        const ax2 v2 = ((const ax2 *)val)[e];
+                        vrn[u] = v2[0];
+                        vin[u] = v2[1];
                     } else {
                         vrn[u] = val[e];
-                        vin[u] = 0.f;
+                        vin[u] = (A)0;
                     }
                 }
             };
             if (len > 0) fetch(0);
             for (int j = 0; j < len; j += SP_U) {
                 uint32_t pc[SP_U];
-                float vr[SP_U], vi[SP_U];
+                A vr[SP_U], vi[SP_U];
 #pragma unroll
                 for (int u = 0; u < SP_U; ++u) { pc[u] = pn[u]; vr[u] = vrn[u]; vi[u] = vin[u]; }
                 if (j + SP_U < len) fetch(j + SP_U);
 #pragma unroll
                 for (int u = 0; u < SP_U; ++u) {
-                    const float *rowp = slab + pc[u] * SP_F;
+                    const A *rowp = slab + pc[u] * SP_F;
                     const int s = (pc[u] >> 2) & 3;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const f32x4 x = *(const f32x4 *)(rowp + ((q ^ s) << 2));
+                        const ax4 x = *(const ax4 *)(rowp + ((q ^ s) << 2));
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             acc[i][q * 4 + e][0] += x[e] * vr[u];
@@ -214,7 +250,7 @@ k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
 #pragma unroll
         for (int f = 0; f < SP_F; ++f) {
             if (f0 + f >= n_frames) break;
-            float *o = out + (f0 + f) * ld_out + (int64_t)k * NC;
+            A *o = out + (f0 + f) * ld_out + (int64_t)k * NC;
 #pragma unroll
             for (int c = 0; c < NC; ++c) o[c] = accumulate ? o[c] + acc[i][f][c] : acc[i][f][c];
         }
@@ -237,6 +273,7 @@ int csr_destroy(ltmi_masks *m) {
     if (!c) return LTMI_OK;
     if (c->pix) (void)hipFree(c->pix);
     if (c->val) (void)hipFree(c->val);
+    if (c->val64) (void)hipFree(c->val64);
     if (c->row_off) (void)hipFree(c->row_off);
     if (c->row_len) (void)hipFree(c->row_len);
     if (c->active) (void)hipFree(c->active);
@@ -287,9 +324,51 @@ static int launch_sell(ltmi_masks *m, CsrImage *c, const T *tile, int64_t n_fram
     return LTMI_OK;
 }
 
+// float64 results: the same kernel with double slab / accumulators / values (128 KiB of LDS)
+template <typename T>
+static int launch_sell64(ltmi_masks *m, CsrImage *c, const T *tile, int64_t n_frames, int64_t ld,
+                         double *out, int64_t ld_out, int accumulate, hipStream_t stream) {
+    const int vec_ok = vector_loads_ok(tile, ld, sizeof(T)) ? 1 : 0;
+    dim3 grid((unsigned)((n_frames + SP_F - 1) / SP_F), (unsigned)c->n_pass);
+    const size_t lds = (size_t)(SP_P + 1) * SP_F * sizeof(double);
+    auto kern = k_sell_apply<T, 4, false, double>;
+    static bool set[16] = {false};
+    if (!set[m->device & 15]) {
+        LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
+        set[m->device & 15] = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(SP_NT), lds, stream, tile, ld, n_frames, m->n_px,
+                       (const uint32_t *)c->pix, (const double *)c->val64, (const int *)c->row_off,
+                       (const int *)c->row_len, (const int *)c->active, (const int *)c->active_off,
+                       c->n_chunks, out, ld_out, (int)m->n_masks, accumulate, vec_ok, 0);
+    LTMI_HIP(hipGetLastError());
+    snprintf(m->last_kernel, sizeof(m->last_kernel), "k_sell_apply<%s,f64> grid=(%u,%u) rows=%zu",
+             typeid(T).name(), grid.x, grid.y, c->n_rows);
+    return LTMI_OK;
+}
+
 int csr_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames, int64_t ld_tile,
               void *out, int64_t ld_out, int accumulate, hipStream_t stream) {
     CsrImage *c = (CsrImage *)m->csr;
+    if (c->f64) {
+        double *o = (double *)out;
+        switch (tile_dtype) {
+            case LTMI_BOOL:
+            case LTMI_U8: return launch_sell64<uint8_t>(m, c, (const uint8_t *)tile, n_frames, ld_tile, o, ld_out, accumulate, stream);
+            case LTMI_I8: return launch_sell64<int8_t>(m, c, (const int8_t *)tile, n_frames, ld_tile, o, ld_out, accumulate, stream);
+            case LTMI_U16: return launch_sell64<uint16_t>(m, c, (const uint16_t *)tile, n_frames, ld_tile, o, ld_out, accumulate, stream);
+            case LTMI_I16: return launch_sell64<int16_t>(m, c, (const int16_t *)tile, n_frames, ld_tile, o, ld_out, accumulate, stream);
+            case LTMI_U32: return launch_sell64<uint32_t>(m, c, (const uint32_t *)tile, n_frames, ld_tile, o, ld_out, accumulate, stream);
+            case LTMI_I32: return launch_sell64<int32_t>(m, c, (const int32_t *)tile, n_frames, ld_tile, o, ld_out, accumulate, stream);
+            case LTMI_U64: return launch_sell64<uint64_t>(m, c, (const uint64_t *)tile, n_frames, ld_tile, o, ld_out, accumulate, stream);
+            case LTMI_I64: return launch_sell64<int64_t>(m, c, (const int64_t *)tile, n_frames, ld_tile, o, ld_out, accumulate, stream);
+            case LTMI_F32: return launch_sell64<float>(m, c, (const float *)tile, n_frames, ld_tile, o, ld_out, accumulate, stream);
+            case LTMI_F64: return launch_sell64<double>(m, c, (const double *)tile, n_frames, ld_tile, o, ld_out, accumulate, stream);
+        }
+        LTMI_FAIL(LTMI_E_DTYPE, "sparse masks with float64 results: tile dtype %s is not supported",
+                  dtype_name(tile_dtype));
+    }
     // localised stacks: blocked image on the matrix cores (set_tuning 41 forces the SELL kernel)
     if (c->bell && m->tune_ksplit_ring != 41) {
         bool handled = false;
@@ -320,9 +399,9 @@ extern "C" int ltmi_masks_create_csr(int device, const int64_t *indptr, const in
     if (!indptr || !out || n_px <= 0 || n_masks <= 0)
         LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_create_csr: bad arguments (n_px=%lld n_masks=%lld)",
                   (long long)n_px, (long long)n_masks);
-    if (result_dtype != LTMI_F32 && result_dtype != LTMI_C64)
+    if (result_dtype != LTMI_F32 && result_dtype != LTMI_C64 && result_dtype != LTMI_F64)
         LTMI_FAIL(LTMI_E_DTYPE, "ltmi_masks_create_csr: result dtype %s not supported for sparse "
-                  "stacks (float32 / complex64 only; densify for others)",
+                  "stacks (float32 / complex64 / float64 only; densify for others)",
                   dtype_name(result_dtype));
     const int64_t nnz = indptr[n_px];
     if (nnz < 0 || (nnz > 0 && (!indices || !data)))
@@ -347,7 +426,9 @@ extern "C" int ltmi_masks_create_csr(int device, const int64_t *indptr, const in
     c->n_pass = (int)((n_masks + c->mb - 1) / c->mb);
     c->n_chunks = (int)((n_px + SP_P - 1) / SP_P);
     const int nc = c->cplx ? 2 : 1;
-    const float *vals = (const float *)data;
+    c->f64 = (result_dtype == LTMI_F64);
+    const float *vals = (const float *)data;              // (f64: `data` holds doubles, see below)
+    const double *vals64 = (const double *)data;
 
     // slice id of mask k: ((pass * n_chunks + chunk) * mpt + slot) * 4 + wave ; lane = (k%256)/4
     const size_t n_slices = (size_t)c->n_pass * c->n_chunks * c->mpt * 4;
@@ -404,7 +485,8 @@ extern "C" int ltmi_masks_create_csr(int device, const int64_t *indptr, const in
         if (active.empty()) active.push_back(0);
         // (padding entries and the prefetch slack: the zero pixel row SP_P, value 0)
         std::vector<uint32_t> pix((rows + 4 * SP_U) * 64, (uint32_t)SP_P);
-        std::vector<float> val((rows + 4 * SP_U) * 64 * nc, 0.f);
+        std::vector<float> val(c->f64 ? 0 : (rows + 4 * SP_U) * 64 * nc, 0.f);
+        std::vector<double> val64(c->f64 ? (rows + 4 * SP_U) * 64 : 0, 0.);
         std::vector<int> fill((size_t)c->n_chunks * n_masks, 0);
         for (int64_t p = 0; p < n_px; ++p) {
             const int ch = (int)(p / SP_P);
@@ -416,12 +498,15 @@ extern "C" int ltmi_masks_create_csr(int device, const int64_t *indptr, const in
                 const int j = fill[(size_t)ch * n_masks + k]++;
                 const size_t pos = ((size_t)row_off[(size_t)ai * NWS + slice_of(k)] + j) * 64 + lane;
                 pix[pos] = (uint32_t)(p - (int64_t)ch * SP_P);
-                for (int q = 0; q < nc; ++q) val[pos * nc + q] = vals[e * nc + q];
+                if (c->f64) val64[pos] = vals64[e];
+                else
+                    for (int q = 0; q < nc; ++q) val[pos * nc + q] = vals[e * nc + q];
             }
         }
         const size_t n_slices_dev = n_tab;
         hipError_t e = hipMalloc((void **)&c->pix, pix.size() * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc((void **)&c->val, val.size() * sizeof(float));
+        if (e == hipSuccess && !c->f64) e = hipMalloc((void **)&c->val, val.size() * sizeof(float));
+        if (e == hipSuccess && c->f64) e = hipMalloc((void **)&c->val64, val64.size() * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&c->row_off, n_slices_dev * sizeof(int));
         if (e == hipSuccess) e = hipMalloc((void **)&c->row_len, n_slices_dev * sizeof(int));
         if (e == hipSuccess) e = hipMalloc((void **)&c->active, active.size() * sizeof(int));
@@ -429,7 +514,8 @@ extern "C" int ltmi_masks_create_csr(int device, const int64_t *indptr, const in
         if (e == hipSuccess) e = hipMemcpy(c->active, active.data(), active.size() * sizeof(int), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(c->active_off, active_off.data(), active_off.size() * sizeof(int), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(c->pix, pix.data(), pix.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(c->val, val.data(), val.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess && !c->f64) e = hipMemcpy(c->val, val.data(), val.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess && c->f64) e = hipMemcpy(c->val64, val64.data(), val64.size() * sizeof(double), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(c->row_off, row_off.data(), n_slices_dev * sizeof(int), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(c->row_len, row_len.data(), n_slices_dev * sizeof(int), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
@@ -449,7 +535,7 @@ extern "C" int ltmi_masks_create_csr(int device, const int64_t *indptr, const in
         const char *force = getenv("LTMI_SPARSE_BELL");
         const char *thr = getenv("LTMI_BELL_MAX_RATIO");
         const double max_ratio = thr ? atof(thr) : 8.0;
-        bool build = nnz > 0;
+        bool build = nnz > 0 && !c->f64;                  // (the blocked image is float32 only)
         if (force && force[0] == '0') build = false;
         else if (!(force && force[0] == '1') && build)
             build = ltmi::bell_mac_ratio(indptr, indices, nc, n_px, n_masks) <= max_ratio;

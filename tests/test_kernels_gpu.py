@@ -480,12 +480,49 @@ def test_sell_vs_reference_rmatmul_golden(hip, golden_dir, case, sparse_kernel):
     g = np.load(os.path.join(golden_dir, 'rmatmul.npz'))
     left, right = recipes.make_rmatmul_case(case)
     ref = g[case['name'] + '__csr']
-    if ref.dtype not in (np.float32, np.complex64):
-        pytest.skip("float64 sparse goes through the densified generic path (tested via the UDF)")
+    if ref.dtype not in (np.float32, np.complex64, np.float64):
+        pytest.skip("complex128 / integer sparse stacks are densified (tested via the UDF)")
     res, kern = _apply_csr(hip, left, sp.csr_matrix(right), ref.dtype)
-    _check_sparse_kernel(kern, sparse_kernel, left.shape[1], left.dtype.itemsize)
+    if ref.dtype == np.float64:
+        assert 'k_sell_apply' in kern and 'f64' in kern, kern       # float64: the gather kernel in double
+    else:
+        _check_sparse_kernel(kern, sparse_kernel, left.shape[1], left.dtype.itemsize)
     assert res.dtype == ref.dtype and res.shape == ref.shape
-    assert np.allclose(res, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+    tol = 1e-12 if ref.dtype == np.float64 else 1e-5
+    assert np.allclose(res, ref, rtol=tol, atol=tol * np.abs(ref).max())
+
+
+@pytest.mark.parametrize('tile_dtype', ['int32', 'uint32', 'int64', 'float64', 'float32', 'uint16'])
+@pytest.mark.parametrize('shape', [
+    (37, 3000, 70, 0.02),       # ragged frames, 3 chunks
+    (16, 1024, 1300, 0.01),     # two passes of 1024 masks
+    (70, 515 * 7, 40, 0.05),    # odd row length
+    (20, 2048, 300, 0.0),       # all-zero stack
+])
+def test_sparse_float64_results(hip, shape, tile_dtype):
+    """Sparse stacks with float64 results (int32 / uint32 / int64 / float64 frames, or float64 mask
+    values): the gather kernel with double slab, values and accumulators -- not a densified stack."""
+    import scipy.sparse as sp
+    n_frames, n_px, n_masks, density = shape
+    rng = np.random.default_rng(41)
+    dt = np.dtype(tile_dtype)
+    if dt.kind == 'u':
+        data = rng.integers(0, 2**31 if dt.itemsize >= 4 else 4000, (n_frames, n_px)).astype(dt)
+    elif dt.kind == 'i':
+        data = rng.integers(-2**30, 2**30, (n_frames, n_px)).astype(dt)
+    else:
+        data = (rng.random((n_frames, n_px)) - 0.3).astype(dt)
+    m = sp.random(n_px, n_masks, density=density, format='csr', dtype=np.float64,
+                  random_state=np.random.RandomState(2))
+    res, kern = _apply_csr(hip, data, m, np.float64)
+    assert 'k_sell_apply' in kern and 'f64' in kern, kern
+    dense = m.toarray()
+    ref = data.astype(np.float64) @ dense
+    scale = np.abs(data.astype(np.float64)) @ np.abs(dense)
+    assert np.all(np.abs(res - ref) <= 1e-13 * scale + 1e-300), np.abs(res - ref).max()
+    base = rng.random((n_frames, n_masks))
+    res2, _ = _apply_csr(hip, data, m, np.float64, accumulate_into=base)
+    assert np.all(np.abs(res2 - (ref + base)) <= 1e-13 * (scale + 1))
 
 
 @pytest.mark.parametrize('shape', [
