@@ -97,6 +97,7 @@ struct ltmi_masks {
     // float64 results on the f64 matrix cores (ltmi_dense64.hip)
     double *img64 = nullptr;
     int n_groups64 = 0, n_chunks64 = 0;
+    int cpm64 = 1;              // real columns per mask in the f64 image (2: complex128 masks)
     void *ws64 = nullptr;
     size_t ws64_bytes = 0;
     void *res64 = nullptr;   // f64 scratch result of the exact-integer path

@@ -1121,7 +1121,8 @@ extern "C" int ltmi_masks_create_dense(int device, const void *masks_host, int r
             LTMI_FAIL((int)e, "uploading the mask stack failed: %s", hipGetErrorString(e));
         }
     }
-    if (result_dtype == LTMI_F64 || (result_dtype >= LTMI_U8 && result_dtype <= LTMI_I64 && m->mask_bits <= 20)) {
+    if (result_dtype == LTMI_F64 || result_dtype == LTMI_C128 ||
+        (result_dtype >= LTMI_U8 && result_dtype <= LTMI_I64 && m->mask_bits <= 20)) {
         const int rc64 = ltmi::dense64_create(m);
         if (rc64 != LTMI_OK) {
             ltmi_masks_destroy(m);
@@ -1835,7 +1836,7 @@ extern "C" int ltmi_apply_masks(ltmi_masks *m, const void *tile, int tile_dtype,
             case LTMI_F32: return launch_mfma<float>(m, (const float *)tile, n_frames, ld_tile, o, ldo, accumulate, stream);
         }
     }
-    if (m->result_dtype == LTMI_F64 ||
+    if (m->result_dtype == LTMI_F64 || m->result_dtype == LTMI_C128 ||
         (m->result_dtype >= LTMI_U8 && m->result_dtype <= LTMI_I64)) {
         bool handled = false;
         const int rc = ltmi::dense64_apply(m, tile, tile_dtype, n_frames, ld_tile, out, ld_out,

@@ -32,13 +32,17 @@ __host__ __device__ static inline int img64_index(int n, int q) {
     return n * KC64 + v * 2 + (j & 1);
 }
 
+// cpm: real columns per mask (2 for complex128 stacks: interleaved (re, im) like the f32 image)
 template <typename SRC>
 __global__ void k_build_image64(const SRC *__restrict__ src, double *__restrict__ img,
-                                int64_t n_masks, int64_t n_px, int n_chunks) {
-    const int64_t total = n_masks * n_px;
+                                int64_t n_masks, int64_t n_px, int n_chunks, int cpm) {
+    const int64_t total = n_masks * n_px * cpm;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t k = i / n_px, p = i % n_px;
+        const int part = (int)(i % cpm);
+        const int64_t kp = i / cpm;
+        const int64_t p = kp % n_px;
+        const int64_t k = (kp / n_px) * cpm + part;           // real column
         const int g = (int)(k / 16), n = (int)(k % 16);
         const int c = (int)(p / KC64), q = (int)(p % KC64);
         img[((size_t)g * n_chunks + c) * CH64 + img64_index(n, q)] = (double)src[i];
@@ -447,20 +451,22 @@ __global__ void k_f64_to_int(const double *__restrict__ src, int64_t n_frames, i
 int dense64_create(ltmi_masks *m) {
     // m->gmasks holds the (n_masks, n_px) stack on the device: float64, or int64 for integer
     // result dtypes (then the image is only built if the masks are small, see dense64_apply)
-    m->n_groups64 = (int)((m->n_masks + 15) / 16);
+    m->cpm64 = (m->result_dtype == LTMI_C128) ? 2 : 1;
+    m->n_groups64 = (int)((m->n_masks * m->cpm64 + 15) / 16);
     m->n_chunks64 = (int)((m->n_px + KC64 - 1) / KC64);
     const size_t n = (size_t)m->n_groups64 * m->n_chunks64 * CH64;
     LTMI_HIP(hipMalloc((void **)&m->img64, n * sizeof(double)));
     LTMI_HIP(hipMemset(m->img64, 0, n * sizeof(double)));
-    const int64_t total = m->n_masks * m->n_px;
+    const int64_t total = m->n_masks * m->n_px * m->cpm64;
     const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 65535 * 16);
-    if (m->result_dtype == LTMI_F64)
+    if (m->result_dtype == LTMI_F64 || m->result_dtype == LTMI_C128)
         hipLaunchKernelGGL(k_build_image64<double>, dim3(blocks), dim3(256), 0, 0,
-                           (const double *)m->gmasks, m->img64, m->n_masks, m->n_px, m->n_chunks64);
+                           (const double *)m->gmasks, m->img64, m->n_masks, m->n_px, m->n_chunks64,
+                           m->cpm64);
     else
         hipLaunchKernelGGL(k_build_image64<int64_t>, dim3(blocks), dim3(256), 0, 0,
                            (const int64_t *)m->gmasks, m->img64, m->n_masks, m->n_px,
-                           m->n_chunks64);
+                           m->n_chunks64, 1);
     LTMI_HIP(hipGetLastError());
     LTMI_HIP(hipDeviceSynchronize());
     return LTMI_OK;
@@ -474,6 +480,8 @@ void dense64_destroy(ltmi_masks *m) {
     m->ws64 = nullptr;
     m->res64 = nullptr;
 }
+
+static inline int64_t n_cols64(const ltmi_masks *m) { return m->n_masks * m->cpm64; }
 
 static int ensure_ws64(ltmi_masks *m, size_t need, hipStream_t stream) {
     if (m->ws64_bytes < need) {
@@ -516,20 +524,20 @@ static int launch64_lds(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t 
         ksplit = (m->n_chunks64 + per - 1) / per;
     }
     if (ksplit > 1) {
-        int rc = ensure_ws64(m, (size_t)ksplit * n_frames * m->n_masks * sizeof(double), stream);
+        int rc = ensure_ws64(m, (size_t)ksplit * n_frames * n_cols64(m) * sizeof(double), stream);
         if (rc != LTMI_OK) return rc;
     }
     dim3 grid((unsigned)gx, (unsigned)ksplit, (unsigned)gz);
     hipLaunchKernelGGL(kern, grid, dim3(CFG::WAVES * 64), CFG::LDS_BYTES, stream, tile, ld, n_frames,
                        m->n_px, (const double *)m->img64, m->n_chunks64, out, ld_out,
-                       (int)m->n_masks, accumulate, (double *)m->ws64, ksplit);
+                       (int)n_cols64(m), accumulate, (double *)m->ws64, ksplit);
     LTMI_HIP(hipGetLastError());
     snprintf(m->last_kernel, sizeof(m->last_kernel), "k_dense_lds64<%s> grid=(%u,%u,%u)",
              typeid(T).name(), grid.x, grid.y, grid.z);
     if (ksplit > 1) {
-        const int64_t n = n_frames * m->n_masks;
+        const int64_t n = n_frames * n_cols64(m);
         hipLaunchKernelGGL(k_reduce_partials64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                           stream, (const double *)m->ws64, ksplit, n_frames, (int)m->n_masks, out,
+                           stream, (const double *)m->ws64, ksplit, n_frames, (int)n_cols64(m), out,
                            ld_out, accumulate);
         LTMI_HIP(hipGetLastError());
     }
@@ -562,7 +570,7 @@ static int launch64(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, 
         ksplit = (m->n_chunks64 + per - 1) / per;
     }
     if (ksplit > 1) {
-        const size_t need = (size_t)ksplit * n_frames * m->n_masks * sizeof(double);
+        const size_t need = (size_t)ksplit * n_frames * n_cols64(m) * sizeof(double);
         if (m->ws64_bytes < need) {
             if (m->ws64) {
                 LTMI_HIP(hipStreamSynchronize(stream));
@@ -580,15 +588,15 @@ static int launch64(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, 
                                  (int)lds));
     dim3 grid((unsigned)gx, (unsigned)ksplit, (unsigned)gz);
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, stream, tile, ld, n_frames, m->n_px,
-                       (const double *)m->img64, m->n_chunks64, out, ld_out, (int)m->n_masks,
+                       (const double *)m->img64, m->n_chunks64, out, ld_out, (int)n_cols64(m),
                        accumulate, (double *)m->ws64, ksplit);
     LTMI_HIP(hipGetLastError());
     snprintf(m->last_kernel, sizeof(m->last_kernel), "k_dense_mfma_f64<%s,%s> grid=(%u,%u,%u)",
              typeid(T).name(), vec ? "vec" : "guarded", grid.x, grid.y, grid.z);
     if (ksplit > 1) {
-        const int64_t n = n_frames * m->n_masks;
+        const int64_t n = n_frames * n_cols64(m);
         hipLaunchKernelGGL(k_reduce_partials64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                           stream, (const double *)m->ws64, ksplit, n_frames, (int)m->n_masks, out,
+                           stream, (const double *)m->ws64, ksplit, n_frames, (int)n_cols64(m), out,
                            ld_out, accumulate);
         LTMI_HIP(hipGetLastError());
     }
@@ -601,9 +609,11 @@ int dense64_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_fra
     *handled = false;
     if (!m->img64) return LTMI_OK;
     const bool int_result = m->result_dtype >= LTMI_U8 && m->result_dtype <= LTMI_I64;
-    if (!int_result && m->result_dtype != LTMI_F64) return LTMI_OK;
+    if (!int_result && m->result_dtype != LTMI_F64 && m->result_dtype != LTMI_C128) return LTMI_OK;
+    // complex128 masks on REAL frames: 2 real f64 columns per mask, the result row is the interleaved
+    // complex128 row (complex frames stay with the generic kernel: `default` below)
     double *o = (double *)out;
-    int64_t ld_o = ld_out;
+    int64_t ld_o = ld_out * m->cpm64;
     if (int_result) {
         // Integer masks x integer frames (preferred_dtype / mask_dtype integer: NumPy integer matmul,
         // wrap-around).  If every possible partial sum fits 2^52 the f64 FMA chain is EXACT, so the

@@ -37,7 +37,7 @@ res_dt = np.result_type(dt, md)
 h = hip.MaskHandle.dense(0, masks, res_dt)
 out = torch.zeros((args.frames, args.masks), device='cuda',
                   dtype={'complex64': torch.complex64, 'float32': torch.float32,
-                         'float64': torch.float64}[res_dt.name])
+                         'float64': torch.float64, 'complex128': torch.complex128}[res_dt.name])
 frame_bytes = n_px * dt.itemsize + args.masks * res_dt.itemsize
 
 if args.variants == 'auto':

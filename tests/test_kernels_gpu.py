@@ -246,7 +246,8 @@ def test_long_rows_keep_float32_accuracy(hip, n_px, tile_dtype, n_masks):
 
 @pytest.mark.parametrize('combo', [
     ('int32', 'float64'), ('int64', 'float64'), ('float64', 'float64'), ('uint16', 'float64'),
-    ('uint32', 'float64'), ('float32', 'complex128'), ('complex64', 'complex64'),
+    ('uint32', 'float64'), ('float32', 'complex128'), ('int32', 'complex128'),
+    ('uint16', 'complex128'), ('complex64', 'complex64'),
     ('complex128', 'complex128'), ('int16', 'int32'), ('uint8', 'uint8'), ('int16', 'int64'),
     ('uint16', 'int32'),
 ])
@@ -268,8 +269,9 @@ def test_generic(hip, combo):
     else:
         masks = rng.random((n_masks, n_px)).astype(result_dtype)
     res, kern = _apply(hip, data, masks, result_dtype)
-    if result_dtype == np.float64:
-        # float64 results: f64 matrix cores (LDS-DMA for 4- / 8-byte pixels, also with odd rows)
+    if result_dtype == np.float64 or (result_dtype == np.complex128 and tile_dtype.kind != 'c'):
+        # float64 results: f64 matrix cores (LDS-DMA for 4- / 8-byte pixels, also with odd rows);
+        # complex128 masks on real frames: the same kernels with 2 real columns per mask
         assert ('k_dense_lds64' if tile_dtype.itemsize >= 4 else 'k_dense_mfma_f64') in kern, kern
     elif result_dtype.kind in 'iu' and tile_dtype.itemsize <= 4:
         assert 'exact-int' in kern, kern           # integer results, sums < 2^52: same cores, exact
@@ -322,6 +324,32 @@ def test_float64_results_on_matrix_cores(hip, tile_dtype, shape, ksplit):
     assert np.all(np.abs(res - ref) <= 1e-13 * scale + 1e-300), np.abs(res - ref).max()
     base = rng.random((n_frames, n_masks))
     res2, _ = _apply(hip, data, masks, np.float64, accumulate_into=base, tuning=tuning)
+    assert np.all(np.abs(res2 - (ref + base)) <= 1e-13 * (scale + 1))
+
+
+@pytest.mark.parametrize('tile_dtype', ['int32', 'uint16', 'float32', 'float64'])
+@pytest.mark.parametrize('shape', [
+    (300, 256 * 9 + 100, 16),           # 32 real columns: two column groups, ragged last chunk
+    (70, 17 * 23, 5),                   # odd row length
+    (45, 256 * 5, 25),                  # the radial Fourier default stack (50 real columns)
+])
+def test_complex128_masks_on_real_frames(hip, tile_dtype, shape):
+    """complex128 results (int32 / float64 frames x complex64 masks, or complex128 masks) on REAL frames:
+    the f64 matrix kernels with (re, im) as two real columns per mask -- not the generic VALU kernel."""
+    n_frames, n_px, n_masks = shape
+    rng = np.random.default_rng(hash((tile_dtype,) + shape) % (2**32))
+    dt = np.dtype(tile_dtype)
+    data = (rng.integers(-1000 if dt.kind == 'i' else 0, 100000 if dt.itemsize >= 4 else 4000,
+                         (n_frames, n_px)).astype(dt) if dt.kind in 'iu'
+            else (rng.random((n_frames, n_px)) - 0.3).astype(dt))
+    masks = (rng.random((n_masks, n_px)) - 0.25) + 1j * (rng.random((n_masks, n_px)) - 0.5)
+    res, kern = _apply(hip, data, masks, np.complex128)
+    assert 'k_dense_lds64' in kern or 'k_dense_mfma_f64' in kern, kern
+    ref = data.astype(np.complex128) @ masks.T
+    scale = np.abs(data.astype(np.float64)) @ np.abs(masks).T
+    assert np.all(np.abs(res - ref) <= 1e-13 * scale + 1e-300), np.abs(res - ref).max()
+    base = rng.random((n_frames, n_masks)) + 1j * rng.random((n_frames, n_masks))
+    res2, _ = _apply(hip, data, masks, np.complex128, accumulate_into=base)
     assert np.all(np.abs(res2 - (ref + base)) <= 1e-13 * (scale + 1))
 
 
