@@ -57,9 +57,15 @@ for case in range(n_cases):
         n_masks = int(rng.choice([1, 2, 5, 16, 17, 25, 33, 49, 50, 52, 64, 70]))
         data = gen(tdt, (n_frames, ld))
         if kind == 'sparse':
+            wide_result = False
             if str(tdt) not in ('uint8', 'int8', 'uint16', 'int16', 'float32'):
-                tdt = np.dtype('uint16'); data = gen(tdt, (n_frames, ld))   # what result_type allows
-            mdt = np.dtype(rng.choice(['float32', 'complex64']))
+                if rng.random() < 0.5:
+                    wide_result = True          # float64 result: the gather kernel in double
+                else:
+                    tdt = np.dtype('uint16'); data = gen(tdt, (n_frames, ld))
+            elif rng.random() < 0.15:
+                wide_result = True              # float64 mask values on narrow pixels
+            mdt = np.dtype('float64') if wide_result else np.dtype(rng.choice(['float32', 'complex64']))
             if rng.random() < 0.3:
                 n_masks = int(rng.choice([130, 300, 1030, 1100]))      # many groups, two passes
             if rng.random() < 0.5:
@@ -73,7 +79,7 @@ for case in range(n_cases):
             if mdt.kind == 'c':
                 dense = dense * (1 + 1j * rng.random((n_px, n_masks)))
             dense = dense.astype(mdt)
-            rd = np.result_type(np.float32, mdt)
+            rd = np.dtype(np.float64) if wide_result else np.result_type(np.float32, mdt)
             # either sparse kernel: the blocked image (matrix cores) or the SELL gather kernel
             os.environ['LTMI_SPARSE_BELL'] = str(rng.choice(['0', '1']))
             handle = hip.MaskHandle.csr(0, sp.csr_matrix(dense), rd)
@@ -134,6 +140,7 @@ for case in range(n_cases):
             res = res.view(rd)
         lk = handle.last_kernel()
         kern = lk.split('<')[0] + ('+exact-int' if 'exact-int' in lk else '') + \
+            ('+f64' if ',f64>' in lk else '') + \
             ('+shifted' if 'shifted>' in lk else '') + ('+valu' if 'VALU' in lk else '') + \
             ('+NG' + lk.split('NG=')[1][0] if 'NG=' in lk else '')
         kernels_seen[kern] = kernels_seen.get(kern, 0) + 1
