@@ -322,8 +322,11 @@ k_dense_mfma(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
 //     ds_read_b128 service group (16 different rows) hit 16 different slots.  LDS-DMA writes
 //     lane-linear, so the permutation is applied to the per-lane SOURCE address.
 //   * mask slots also arrive by LDS-DMA (linear copies of the pre-swizzled image), 2 slots, shared
-//     by the 8 waves, one s_barrier per slot.
+//     by the waves of the workgroup, one s_barrier per slot.
 //   * counted waits, never vmcnt(0) in the loop (DMA completes in order per wave).
+//   * rows need not be 16-B aligned: the DMA reads from any element-aligned address (ltmi_common.h
+//     vector_loads_ok), the piece permutation is relative to the row start.
+//   * two accumulation levels (see acc2 in the kernel): the float32 chains stay <= 1024 pixels long.
 constexpr int V2_ROWS = 16;                         // frames per MFMA tile
 constexpr int V2_SUB_BYTES = 256;                   // bytes of a row per sub-chunk
 constexpr int V2_ASLOT = V2_ROWS * V2_SUB_BYTES;    // 4 KiB per frame tile and ring slot
@@ -351,6 +354,7 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 // NE > 0 ("extras"): NG groups go through the matrix cores and NE further columns (the remainder
 // of a stack with 16 NG + NE columns, e.g. 25 complex masks = 48 + 2) are accumulated on the VALU
 // from the already converted frame fragments -- instead of a whole extra MFMA group of padding.
+// NG = 0: stacks of at most 4 columns (CoM, single-mask analyses) use the VALU columns ONLY.
 // Their slot: NG x 8 KiB of groups, then NE / 2 column pairs of 1 KiB, (pixel, column of the pair)
 // floats -- one v_pk_fma_f32 per pixel and pair --, rounded up to 4 KiB.
 // bytes of a mask slot of 128 pixels with ng MFMA groups + ne VALU columns (kernel and image builder)
