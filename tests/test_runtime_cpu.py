@@ -785,3 +785,32 @@ def test_plan_cache_reuses_planning_not_user_udf_instances(ctx):
     d = ctx.run_udf(dataset=ds, udf=udf, roi=roi)['s']
     assert len(plans) == 2                                # ROI runs are never cached
     assert np.allclose(d.raw_data, (expect + 3)[roi])
+
+
+def test_result_where_option_and_float64_densify_rule(ctx):
+    """`run_udf(result_where=...)`: only None / 'host' / 'device' are accepted and 'device' needs the
+    HIP executor; float64 sparse stacks with more than one 16-column group are not densified (the
+    float64 matrix kernel would read the frames once per group)."""
+    import scipy.sparse as sp
+    from libertem_amd.common.container import _worth_densifying
+
+    class Count(UDF):
+        def get_result_buffers(self):
+            return {'n': self.buffer(kind='nav', dtype=np.float32)}
+
+        def process_frame(self, frame):
+            self.results.n[:] = frame.sum()
+
+    data = np.ones((2, 3, 4, 4), dtype=np.float32)
+    ds = ctx.load('memory', data=data, sig_dims=2, num_partitions=2)
+    with pytest.raises(ValueError):
+        ctx.run_udf(dataset=ds, udf=Count(), result_where='hbm')
+    with pytest.raises(NotImplementedError):
+        ctx.run_udf(dataset=ds, udf=Count(), result_where='device')
+    res = ctx.run_udf(dataset=ds, udf=Count(), result_where='host')
+    assert np.all(res['n'].data == 16) and res['n'].device_data is None
+
+    full = sp.csr_matrix(np.ones((64, 40), dtype=np.float64))        # completely filled, 40 columns
+    assert _worth_densifying(full.astype(np.float32), np.float32)
+    assert not _worth_densifying(full, np.float64)
+    assert _worth_densifying(sp.csr_matrix(np.ones((64, 12))), np.float64)     # one column group
