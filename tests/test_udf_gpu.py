@@ -1213,6 +1213,27 @@ def test_streamed_export_with_several_tiles(ctx, direct_row_max, monkeypatch):
         Negotiator._hip_scheme_cache.clear()
 
 
+def test_default_partition_count_on_the_gpu_executor(ctx):
+    """`num_partitions` not given: the reference's default is one partition per CPU core (a worker
+    count); the GPU executor streams host data through one device, so the default is one partition
+    per GiB there (device-resident arrays: one)."""
+    from libertem_amd.udf.sumsigudf import SumSigUDF
+    data = np.arange(8 * 9 * 16 * 16, dtype=np.uint16).reshape((8, 9, 16, 16))
+    ds = ctx.load('memory', data=data, sig_dims=2)
+    assert ds.get_num_partitions() == 1
+    explicit = ctx.load('memory', data=data, sig_dims=2, num_partitions=5)
+    assert explicit.get_num_partitions() == 5
+    old = type(ds).HIP_DEFAULT_PARTITION_BYTES
+    type(ds).HIP_DEFAULT_PARTITION_BYTES = 8192          # 16 frames per partition
+    try:
+        small = ctx.load('memory', data=data, sig_dims=2)
+        assert small.get_num_partitions() == 5           # 72 frames of 512 B = 36 864 B -> 5
+        res = ctx.run_udf(dataset=small, udf=SumSigUDF())
+        assert np.array_equal(res['intensity'].data, data.sum(axis=(2, 3)).astype(np.float32))
+    finally:
+        type(ds).HIP_DEFAULT_PARTITION_BYTES = old
+
+
 def test_results_kept_on_device(ctx):
     """run_udf(result_where='device'): declared buffers stay in HBM (HipArray behind
     `buffer.device_data`), `.data` downloads on access; several partitions, a 'sum' buffer, a
