@@ -17,6 +17,7 @@ LIBERTEM_USE_CUDA, results pickled back, serial merge on the main process udf/ba
   UDFs without a declaration fall back to gathering exported per-partition results and merging
   them in partition order on every rank (reference semantics, slower).
 """
+import math
 import os
 import uuid
 
@@ -31,6 +32,10 @@ from .base import JobExecutor, Environment
 _DIST_MODULE = False          # False: not imported yet; None: torch.distributed unavailable
 
 from libertem_amd.common import udf as _udf_common     # noqa: E402  (HIP_DIRECT_ROW_MAX, read per run)
+
+# NumPy dtype of the bytes as torch stores them (torch has no unsigned 16 / 32 / 64-bit tensors)
+_STORAGE_DTYPE = {np.dtype('uint16'): np.dtype('int16'), np.dtype('uint32'): np.dtype('int32'),
+                  np.dtype('uint64'): np.dtype('int64')}
 
 
 def _dist():
@@ -381,8 +386,9 @@ class HipJobExecutor(JobExecutor):
                     buf = udf.results.get_buffer(name)
                     if how != 'disjoint' or isinstance(buf, PlaceholderBufferWrapper):
                         continue
-                    nb = int(np.prod(buf.shape, dtype=np.int64)) * np.dtype(buf.dtype).itemsize
-                    layout.append((i, name, tuple(buf.shape), np.dtype(buf.dtype), total, nb))
+                    dt = np.dtype(buf.dtype)
+                    nb = math.prod(buf.shape) * dt.itemsize
+                    layout.append((i, name, tuple(buf.shape), dt, total, nb))
                     total += (nb + 4095) // 4096 * 4096
         tens = arr = base_dev = None
         if layout and shared is not None:
@@ -414,18 +420,18 @@ class HipJobExecutor(JobExecutor):
             if DIRECT_ROW_MAX <= 0:
                 base_dev = None
             for i, name, shape, dt, off, nb in layout:
-                tdt = torch_dtype_for(dt)
-                streamed[(i, name)] = [tens[off:off + nb].view(tdt).reshape(shape), 0]
+                # [torch view of the buffer (made when the first rows are copied out), rows copied]
+                streamed[(i, name)] = [None, 0, off, nb, shape, dt]
                 # views of the run's owner object: they keep the buffer reserved (on every rank)
                 # for as long as the caller references any of them
                 host_np[(i, name)] = arr[off:off + nb].view(np.ndarray).view(
-                    np.dtype(str(tdt).replace('torch.', ''))).reshape(shape)
+                    _STORAGE_DTYPE.get(dt, dt)).reshape(shape)
                 expected[(i, name)] = 0
                 row_bytes = nb // max(1, shape[0])
                 if base_dev is not None and row_bytes <= DIRECT_ROW_MAX:
                     direct[(i, name)] = 0
                     dev_ptrs[(i, name)] = base_dev + off
-            del arr, tens
+            del arr
         self.last_result_via = 'shm' if shared is not None else \
             ('collective' if self._collectives_on else 'local')
         keepalive = []                          # device rows with a D2H in flight on the copy stream
@@ -441,7 +447,10 @@ class HipJobExecutor(JobExecutor):
                         or not rows.is_contiguous:
                     return
                 buf = udfs[i].results.get_buffer(name)
-                host = streamed[key][0]
+                ent = streamed[key]
+                if ent[0] is None:
+                    ent[0] = tens[ent[2]:ent[2] + ent[3]].view(torch_dtype_for(ent[5])).reshape(ent[4])
+                host = ent[0]
                 n = rows.shape[0]
                 inner = int(np.prod(buf.shape[1:])) if len(buf.shape) > 1 else 1
                 src = rows.torch.reshape(-1)[:n * inner].reshape((n,) + tuple(buf.shape[1:]))
