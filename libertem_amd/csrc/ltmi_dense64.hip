@@ -163,8 +163,9 @@ k_dense_mfma_f64(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64
 }
 
 // ---- frames through LDS with full-line LDS-DMA (k_dense_lds64) ---------------------------------------
-// The f64 twin of k_dense_lds (ltmi_dense.hip) for 4- and 8-byte pixels (int32 / uint32 / float32 /
-// int64 / uint64 / float64 -- the data types whose results are float64 in the reference): 4 waves of
+// The f64 twin of k_dense_lds (ltmi_dense.hip) for every pixel size (int32 / uint32 / float32 /
+// int64 / uint64 / float64 -- whose results are float64 in the reference -- and 1- / 2-byte pixels
+// with float64 masks): 4 waves of
 // 32 frames (two 16-frame tiles), per wave a ring of 3 sub-chunk slots (32 rows x 256 B) filled by
 // global_load_lds_dwordx4 with the 16-B pieces of a row stored at piece ^ (row & 15); the 32-KiB mask
 // chunks (the image of the direct-load kernel above: 256 px x 16 columns of f64) arrive by LDS-DMA
@@ -198,7 +199,7 @@ k_dense_lds64(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t 
               int ksplit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw64[];
     using CFG = Lds64Cfg;
-    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "4- or 8-byte pixels");
+    static_assert(sizeof(T) == 1 || sizeof(T) == 2 || sizeof(T) == 4 || sizeof(T) == 8, "pixel size");
     constexpr int TILES = CFG::TILES, WAVES = CFG::WAVES, RING = CFG::RING;
     constexpr int ASLOT = CFG::ASLOT, BSLOT = CFG::BSLOT, SUB = CFG::SUB_BYTES;
     constexpr int ND = 4 * TILES;                       // DMA instructions per sub-chunk
@@ -211,7 +212,8 @@ k_dense_lds64(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t 
     constexpr int NBI = BPW / 1024;
     constexpr int A_N = ND * (RING - 2);
     static_assert(A_N + 2 * NBI < 64, "vmcnt is a 6-bit counter");
-    typedef T __attribute__((ext_vector_type(16 / sizeof(T)))) unit_t;      // one 16-B piece
+    typedef T __attribute__((ext_vector_type(sizeof(T) >= 4 ? 16 / sizeof(T) : 4))) unit_t;
+    // (4- / 8-byte pixels: one 16-B piece; 1- / 2-byte pixels: this lane's 4 pixels)
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -309,6 +311,15 @@ k_dense_lds64(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t 
                 const int u = blk * 4 + kg;
                 if constexpr (sizeof(T) == 4) {
                     const unit_t r = *(const unit_t *)(at + ((u ^ m) << 4));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] = (double)r[j];
+                } else if constexpr (sizeof(T) == 2) {
+                    // 8 bytes of piece u / 2 (two lanes of a kg pair share a piece)
+                    const unit_t r = *(const unit_t *)(at + (((u >> 1) ^ m) << 4) + (u & 1) * 8);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] = (double)r[j];
+                } else if constexpr (sizeof(T) == 1) {
+                    const unit_t r = *(const unit_t *)(at + (((u >> 2) ^ m) << 4) + (u & 3) * 4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) a[j] = (double)r[j];
                 } else {
@@ -497,7 +508,7 @@ static int ensure_ws64(ltmi_masks *m, size_t need, hipStream_t stream) {
     return LTMI_OK;
 }
 
-// 4- / 8-byte pixels, at least one full mask chunk: the LDS-DMA kernel
+// at least one full mask chunk: the LDS-DMA kernel
 template <typename T>
 static int launch64_lds(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, double *out,
                         int64_t ld_out, int accumulate, hipStream_t stream) {
@@ -547,7 +558,7 @@ static int launch64_lds(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t 
 template <typename T>
 static int launch64(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, double *out,
                     int64_t ld_out, int accumulate, hipStream_t stream) {
-    if constexpr (sizeof(T) >= 4) {
+    {
         // tune_mt == 1 (ltmi_masks_set_tuning): force the direct-load kernel (bench comparison)
         // (rows need not be 16-B aligned: LDS-DMA reads from any element-aligned address)
         if (m->tune_mt != 1 && m->n_px >= KC64 && vector_loads_ok(tile, ld, sizeof(T)))

@@ -272,7 +272,7 @@ def test_generic(hip, combo):
     if result_dtype == np.float64 or (result_dtype == np.complex128 and tile_dtype.kind != 'c'):
         # float64 results: f64 matrix cores (LDS-DMA for 4- / 8-byte pixels, also with odd rows);
         # complex128 masks on real frames: the same kernels with 2 real columns per mask
-        assert ('k_dense_lds64' if tile_dtype.itemsize >= 4 else 'k_dense_mfma_f64') in kern, kern
+        assert 'k_dense_lds64' in kern, kern       # (333 pixels >= one mask chunk)
     elif result_dtype.kind in 'iu' and tile_dtype.itemsize <= 4:
         assert 'exact-int' in kern, kern           # integer results, sums < 2^52: same cores, exact
     else:
@@ -285,7 +285,8 @@ def test_generic(hip, combo):
                            result_dtype != np.complex64 else 1e-5)
 
 
-@pytest.mark.parametrize('tile_dtype', ['int32', 'uint32', 'int64', 'float64', 'float32', 'uint16'])
+@pytest.mark.parametrize('tile_dtype', ['int32', 'uint32', 'int64', 'float64', 'float32', 'uint16',
+                                        'int16', 'uint8', 'int8'])
 @pytest.mark.parametrize('shape,ksplit', [
     ((300, 256 * 9 + 100, 16), 0),      # aligned rows, ragged last chunk
     ((300, 256 * 9 + 100, 16), 3),      # K split + reduce
@@ -297,22 +298,23 @@ def test_generic(hip, combo):
     ((130, 256 * 3 + 4, 16), 2),        # K split with a ragged tail of 4 pixels
 ])
 def test_float64_results_on_matrix_cores(hip, tile_dtype, shape, ksplit):
-    """float64 results (int32 / int64 / float64 data, or float64 masks) on the f64 matrix cores:
-    k_dense_lds64 (LDS-DMA) for 4- / 8-byte pixels with 16-B aligned rows, k_dense_mfma_f64
+    """float64 results (int32 / int64 / float64 data, or float64 masks on any pixel type) on the f64
+    matrix cores: k_dense_lds64 (LDS-DMA) for rows of at least one mask chunk, k_dense_mfma_f64
     (direct loads) otherwise."""
     n_frames, n_px, n_masks = shape
     rng = np.random.default_rng(hash((tile_dtype,) + shape) % (2**32))
     dt = np.dtype(tile_dtype)
     if dt.kind == 'u':
-        data = rng.integers(0, 100000 if dt.itemsize >= 4 else 4000, (n_frames, n_px)).astype(dt)
+        data = rng.integers(0, min(100000, np.iinfo(dt).max), (n_frames, n_px)).astype(dt)
     elif dt.kind == 'i':
-        data = rng.integers(-100000, 100000, (n_frames, n_px)).astype(dt)
+        data = rng.integers(max(-100000, np.iinfo(dt).min), min(100000, np.iinfo(dt).max),
+                            (n_frames, n_px)).astype(dt)
     else:
         data = (rng.random((n_frames, n_px)) - 0.3).astype(dt)
     masks = rng.random((n_masks, n_px)) - 0.25
     tuning = dict(mt=0, waves=0, ksplit=ksplit) if ksplit else None
     res, kern = _apply(hip, data, masks, np.float64, tuning=tuning)
-    lds = dt.itemsize >= 4 and n_px >= 256          # (rows need not be 16-B aligned)
+    lds = n_px >= 256                               # (any pixel size; rows need not be 16-B aligned)
     assert ('k_dense_lds64' if lds else 'k_dense_mfma_f64') in kern, kern
     if lds:
         # the direct-load kernel on the same input (tuning mt=1) agrees to rounding
