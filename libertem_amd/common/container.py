@@ -227,6 +227,32 @@ class MaskContainer:
             self._handle_cache[key] = h
         return h
 
+    def get_handle_for_complex_frames(self, sig_slice, result_dtype, device):
+        """Complex frames (complex64 / complex128 datasets) on the real matrix kernels:
+        sum_p (xr + i xi)(mr + i mi) = [xr, xi] . [mr, -mi] + i [xr, xi] . [mi, mr], i.e. the frame
+        read as 2 n_px real pixels against a REAL stack of 2 n_masks rows over 2 n_px pixels; the
+        result row (re_0, im_0, re_1, ...) is the interleaved complex row.  Returns a dense handle
+        with n_px' = 2 n_px and n_masks' = 2 n_masks in the real dtype of `result_dtype`."""
+        from libertem_amd import hip
+        rd = np.dtype(result_dtype)
+        if rd.kind != 'c':
+            raise ValueError("complex frames have a complex result dtype")
+        real = np.dtype(np.float32 if rd == np.complex64 else np.float64)
+        key = ('complex-frames', sig_slice, rd.str, int(device))
+        h = self._handle_cache.get(key)
+        if h is None:
+            m = np.asarray(self.get_for_sig_slice(sig_slice, dtype=rd, sparse_backend=False,
+                                                  transpose=False))        # (n_masks, px) complex
+            n_masks, n_px = m.shape
+            stack = np.empty((2 * n_masks, 2 * n_px), dtype=real)
+            stack[0::2, 0::2] = m.real
+            stack[0::2, 1::2] = -m.imag
+            stack[1::2, 0::2] = m.imag
+            stack[1::2, 1::2] = m.real
+            h = hip.MaskHandle.dense(device, stack, real)
+            self._handle_cache[key] = h
+        return h, real
+
     def close(self):
         for h in self._handle_cache.values():
             h.close()

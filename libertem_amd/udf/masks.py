@@ -234,6 +234,25 @@ class ApplyMasksEngine:
             raise HipRequiredError("ApplyMasksEngine.process_tile expects a device tile (HipArray)")
         n = tile.shape[0]
         n_px = prod(tile.shape[1:])
+        if np.dtype(tile.dtype).kind == 'c' and self.result_dtype.kind == 'c' \
+                and self.masks.use_sparse is False and self._const is None \
+                and np.dtype(tile.dtype) == self.result_dtype:
+            # complex frames: the frame as 2 n_px real pixels against the real expansion of the stack
+            # -- the matrix kernels instead of the generic one (container.get_handle_for_complex_frames)
+            handle, real = self.masks.get_handle_for_complex_frames(
+                self.meta.sig_slice, self.result_dtype, self.device)
+            if handle.n_px != 2 * n_px:
+                raise ValueError(f"tile has {n_px} px per frame, mask slice has {handle.n_px // 2}")
+            n_masks = handle.n_masks // 2
+            if out is None:
+                out = HipArray.empty((n, n_masks), self.result_dtype, tile.device)
+                accumulate = False
+            if out.shape[0] != n or prod(out.shape[1:]) != n_masks:
+                raise ValueError(f"result view {out.shape} does not fit {n} frames x "
+                                 f"{n_masks} masks")
+            handle.apply(tile.data_ptr(), real, n, 2 * tile.ld, out.data_ptr(), 2 * out.ld,
+                         accumulate, stream=self.stream_ptr)
+            return out
         handle = self._get_handle()
         if handle.n_px != n_px:
             raise ValueError(f"tile has {n_px} px per frame, mask slice has {handle.n_px}")

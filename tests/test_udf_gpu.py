@@ -995,6 +995,33 @@ def test_masks_complex_dataset_and_masks(ctx):
     assert _close(res.mask_0.raw_data, np.abs(ref), F32_TOL)
 
 
+@pytest.mark.parametrize('dtype', ['complex64', 'complex128'])
+def test_complex_frames_run_on_the_matrix_kernels(ctx, dtype):
+    """complex datasets: the frame is read as 2 n_px real pixels against the real expansion of the
+    stack ([mr, -mi] / [mi, mr] rows), so the dense matrix kernels do the work -- several
+    partitions, 20 complex masks (40 real columns), accumulate over ROI-free tiles."""
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd import hip
+    rng = np.random.default_rng(12)
+    data = ((rng.random((6, 9, 24, 24)) - 0.4) + 1j * (rng.random((6, 9, 24, 24)) - 0.6)).astype(dtype)
+    masks = ((rng.random((20, 24, 24)) - 0.5) + 1j * (rng.random((20, 24, 24)) - 0.5)).astype(dtype)
+    ds = _device_ds(ctx, data, 3)
+    hip.KernelTimer.start()
+    res = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda: masks, use_sparse=False,
+                                                    mask_count=20, mask_dtype=np.dtype(dtype)))
+    kernels = {k.split('<')[0] for _, _, k in hip.KernelTimer.stop()}
+    assert kernels and all(k.startswith('k_dense_lds') for k in kernels), kernels
+    got = res['intensity'].data
+    assert got.dtype == np.dtype(dtype) and got.shape == (6, 9, 20)
+    ref = np.tensordot(data.astype(np.complex128), masks.astype(np.complex128), axes=([2, 3], [1, 2]))
+    assert _close(got, ref, F32_TOL if dtype == 'complex64' else 1e-12)
+    # real masks on complex frames
+    mr = rng.random((3, 24, 24)).astype(np.float32 if dtype == 'complex64' else np.float64)
+    res = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda: mr, use_sparse=False))
+    ref = np.tensordot(data.astype(np.complex128), mr.astype(np.float64), axes=([2, 3], [1, 2]))
+    assert _close(res['intensity'].data, ref, F32_TOL if dtype == 'complex64' else 1e-12)
+
+
 def test_shifted_masks_reference_cases(ctx):
     from libertem_amd.udf.masks import ApplyMasksUDF
     from libertem_amd.masks import circular
