@@ -69,6 +69,18 @@ DENSE_CASES = [
     # single frame / single partition edge
     dict(name='single_frame', nav=(1, 1), sig=(32, 32), dtype='uint16', n_masks=2,
          mask_dtype='float32', num_partitions=1, seed=115, udf_kwargs={}),
+    # round 2: the remaining rows of the reference's dtype rule (np.result_type of input and masks)
+    # float64 masks -- NumPy's default -- on uint16 frames without mask_dtype: float64 results
+    dict(name='u16_f64masks', nav=(3, 5), sig=(24, 40), dtype='uint16', n_masks=3,
+         mask_dtype='float64', num_partitions=2, seed=116, udf_kwargs={}),
+    # complex64 masks on int32 frames (radial Fourier on a counting detector): complex128
+    dict(name='i32_c64masks', nav=(3, 5), sig=(24, 40), dtype='int32', n_masks=4,
+         mask_dtype='complex64', num_partitions=2, seed=117, udf_kwargs={}),
+    # complex frames x complex masks
+    dict(name='c64_data_c64masks', nav=(3, 5), sig=(24, 40), dtype='complex64', n_masks=3,
+         mask_dtype='complex64', num_partitions=2, seed=118, udf_kwargs={}),
+    dict(name='u32_f32masks', nav=(3, 5), sig=(24, 40), dtype='uint32', n_masks=3,
+         mask_dtype='float32', num_partitions=2, seed=119, udf_kwargs={}),
 ]
 
 
