@@ -435,12 +435,18 @@ def test_sparse_masks_through_udf(ctx):
     ds_t = ctx.load('memory', data=data, num_partitions=2, sig_dims=2, tileshape=(7, 16, 64))
     got = ctx.run_udf(dataset=ds_t, udf=ApplyMasksUDF(mask_factories=lambda: rings))
     assert _close(got['intensity'].data, ref_r, F32_TOL)
-    # float64 data -> float64 result: sparse stack goes through the densified generic path
-    got = ctx.run_udf(dataset=ctx.load('memory', data=data.astype(np.float64), num_partitions=2,
-                                       sig_dims=2),
-                      udf=ApplyMasksUDF(mask_factories=facs))
-    assert got['intensity'].data.dtype == np.float64
-    assert _close(got['intensity'].data, ref, 1e-6)
+    # float64 / uint32 data -> float64 result: the sparse gather kernel in double (not densified)
+    from libertem_amd import hip
+    ref64 = np.tensordot(data.astype(np.float64), np.stack(dense).astype(np.float64),
+                         axes=([2, 3], [1, 2]))
+    for wide in (np.float64, np.uint32, np.int32):
+        ds_w = ctx.load('memory', data=data.astype(wide), num_partitions=2, sig_dims=2)
+        hip.KernelTimer.start()
+        got = ctx.run_udf(dataset=ds_w, udf=ApplyMasksUDF(mask_factories=facs))
+        kernels = {k.split(' ')[0] for _, _, k in hip.KernelTimer.stop()}
+        assert kernels and all('k_sell_apply' in k and 'f64' in k for k in kernels), kernels
+        assert got['intensity'].data.dtype == np.float64
+        assert _close(got['intensity'].data, ref64, 1e-12)
 
 
 def _spots_frame(sig, centre, offsets, radius=3.0):
