@@ -71,12 +71,12 @@ int ltmi_masks_create_dense(int device, const void *masks_host, int result_dtype
 
 /* Sparse stack in CSR over pixels, exactly the matrix the reference builds in
  * _build_sparse (src/libertem/common/container.py:53-64): shape (n_px, n_masks),
- * indptr[n_px + 1], indices[nnz] (mask index), data[nnz] of `result_dtype` (f32/f64/c64/c128).
+ * indptr[n_px + 1], indices[nnz] (mask index), data[nnz] of `result_dtype`: float32, complex64 or
+ * float64 (complex128 / integer results: densify and use ltmi_masks_create_dense).
  * Host pointers; canonical format (sorted, no duplicates) is not required.
- * Two device images may be built: the sliced-ELL image of the gather kernel (always) and, for stacks
- * whose neighbouring masks share pixels (rings, radial bins), the blocked image that runs on the
- * matrix cores; ltmi_apply_masks picks the blocked one when it exists and the tile rows are 16-byte
- * aligned.  Environment (read here): LTMI_SPARSE_BELL=0 / 1 never / always builds the blocked image,
+ * Two device images may be built: the sliced-ELL image of the gather kernel (always) and, for float32 /
+ * complex64 stacks whose neighbouring masks share pixels (rings, radial bins), the blocked image that
+ * runs on the matrix cores; ltmi_apply_masks picks the blocked one when it exists.  Environment (read here): LTMI_SPARSE_BELL=0 / 1 never / always builds the blocked image,
  * LTMI_BELL_MAX_RATIO moves the padding-factor threshold (default 8).
  */
 int ltmi_masks_create_csr(int device, const int64_t *indptr, const int64_t *indices,
@@ -85,7 +85,8 @@ int ltmi_masks_create_csr(int device, const int64_t *indptr, const int64_t *indi
 
 int ltmi_masks_destroy(ltmi_masks *m);
 /* 0 = dense with float32 / complex64 results (f32 matrix cores), 1 = dense with any other result
- * dtype (float64: f64 matrix cores; complex128 / integers: VALU kernel), 2 = csr */
+ * dtype (float64, complex128 on real tiles, exactly representable integer sums: f64 matrix cores;
+ * complex tiles and wider integers: VALU kernel), 2 = csr */
 int ltmi_masks_kind(const ltmi_masks *m, int *kind);
 
 /* ---- the hot call -----------------------------------------------------------------------
@@ -95,7 +96,10 @@ int ltmi_masks_kind(const ltmi_masks *m, int *kind);
  * dtype conversion of the tile (io/dataset/memory.py:102-105) and with the accumulation
  * `results.intensity[:] += ...` (src/libertem/udf/masks.py:389-392) when accumulate != 0.
  *   tile       device pointer, (n_frames, n_px) of `tile_dtype` (the dataset's NATIVE dtype --
- *              the astype(input_dtype) copy is fused), ld_tile elements between frames
+ *              the astype(input_dtype) copy is fused), ld_tile elements between frames; element
+ *              alignment is enough (rows of odd length: the 16-byte loads / LDS-DMA of gfx950 take
+ *              any address; LTMI_ALIGNED_DMA_ONLY=1 in the environment keeps the vector paths to
+ *              16-byte aligned rows)
  *   out        device pointer, (n_frames, n_masks) of the handle's result dtype, ld_out elements
  *   accumulate 0: out = product, 1: out += product
  */
