@@ -39,6 +39,31 @@ static inline bool vector_loads_ok(const void *tile, int64_t ld_elems, size_t el
     return !aligned_only && ((uintptr_t)tile) % elem == 0;
 }
 
+// K split of the LDS-DMA kernels (one workgroup per CU at a time, 256 CUs): `wgs` workgroups at
+// ksplit = 1, each walking `n_slots` mask slots.  A split by ks makes ks x wgs workgroups of n_slots / ks
+// slots; the launch takes ceil(ks wgs / 256) rounds of (n_slots / ks + start-up) plus, for ks > 1, the
+// reduction of the partials.  Picks the ks with the shortest modelled time: fills the chip when there
+// are fewer workgroups than CUs AND trims the last, partly filled round of awkward frame counts (313
+// workgroups: 2 rounds unsplit = 2.0, ks = 4: 5 rounds of a quarter = 1.25 of one workgroup's time).
+static inline int choose_ksplit(int64_t wgs, int n_slots) {
+    const double START = 1.5, REDUCE = 6.0;             // in slot times (~3 us / ~14 us on C2)
+    const int max_ks = n_slots / 8 > 1 ? (n_slots / 8 < 64 ? n_slots / 8 : 64) : 1;
+    double best = 1e300;
+    int best_ks = 1;
+    for (int ks = 1; ks <= max_ks; ++ks) {
+        if (wgs * ks > 16384 && ks > 1) break;
+        const double rounds = (double)((wgs * ks + 255) / 256);
+        // (a launch of few rounds runs at the pace of its slowest CUs: ~8 % on a single round)
+        const double t = rounds * ((double)n_slots / ks + START) * (1.0 + 0.08 / rounds) +
+                         (ks > 1 ? REDUCE : 0.0);
+        if (t < best * 0.98) {                          // a larger split has to be worth >= 2 %
+            best = t;
+            best_ks = ks;
+        }
+    }
+    return best_ks;
+}
+
 static inline int dtype_size(int dt) {
     switch (dt) {
         case LTMI_BOOL: case LTMI_U8: case LTMI_I8: return 1;

@@ -1347,12 +1347,7 @@ static int launch_lds_ng_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64
     const int64_t gx = (n_frames + CFG::WG_ROWS - 1) / CFG::WG_ROWS;
     const int64_t gz = m->n_groups / NG;
     int ksplit = m->tune_ksplit;
-    if (ksplit <= 0) {
-        ksplit = 1;
-        if (gx * gz < 256)      // fewer workgroups than CUs: split the pixel axis
-            ksplit = (int)std::min<int64_t>((512 + gx * gz - 1) / (gx * gz),
-                                            std::max(1, n_slots / 16));
-    }
+    if (ksplit <= 0) ksplit = choose_ksplit(gx * gz, n_slots);
     ksplit = std::max(1, std::min(ksplit, n_slots));
     {
         const int per = (n_slots + ksplit - 1) / ksplit;
@@ -1403,11 +1398,7 @@ static int launch_lds_extras_t(ltmi_masks *m, const T *tile, int64_t n_frames, i
     const int n_slots = m->n_slots3;
     const int64_t gx = (n_frames + CFG::WG_ROWS - 1) / CFG::WG_ROWS;
     int ksplit = m->tune_ksplit;
-    if (ksplit <= 0) {
-        ksplit = 1;
-        if (gx < 256)
-            ksplit = (int)std::min<int64_t>((512 + gx - 1) / gx, std::max(1, n_slots / 16));
-    }
+    if (ksplit <= 0) ksplit = choose_ksplit(gx, n_slots);
     ksplit = std::max(1, std::min(ksplit, n_slots));
     {
         const int per = (n_slots + ksplit - 1) / ksplit;

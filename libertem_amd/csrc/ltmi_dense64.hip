@@ -523,12 +523,7 @@ static int launch64_lds(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t 
     const int64_t gx = (n_frames + CFG::WG_ROWS - 1) / CFG::WG_ROWS;
     const int64_t gz = m->n_groups64;
     int ksplit = m->tune_ksplit;
-    if (ksplit <= 0) {
-        ksplit = 1;
-        if (gx * gz < 256)
-            ksplit = (int)std::min<int64_t>((512 + gx * gz - 1) / (gx * gz),
-                                            std::max(1, m->n_chunks64 / 8));
-    }
+    if (ksplit <= 0) ksplit = choose_ksplit(gx * gz, m->n_chunks64);
     ksplit = std::max(1, std::min(ksplit, m->n_chunks64));
     {
         const int per = (m->n_chunks64 + ksplit - 1) / ksplit;
