@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string>
+#include <algorithm>
 #include <vector>
 #include "../../include/ltmi.h"
 
@@ -47,7 +48,16 @@ static inline bool vector_loads_ok(const void *tile, int64_t ld_elems, size_t el
 // workgroups: 2 rounds unsplit = 2.0, ks = 4: 5 rounds of a quarter = 1.25 of one workgroup's time).
 static inline int choose_ksplit(int64_t wgs, int n_slots) {
     const double START = 1.5, REDUCE = 6.0;             // in slot times (~3 us / ~14 us on C2)
-    const int max_ks = n_slots / 8 > 1 ? (n_slots / 8 < 64 ? n_slots / 8 : 64) : 1;
+    int max_ks = n_slots / 8 > 1 ? (n_slots / 8 < 64 ? n_slots / 8 : 64) : 1;
+    if (wgs < 256) {
+        // fewer workgroups than CUs: up to ~4 rounds' worth of workgroups
+        max_ks = (int)std::min<int64_t>(max_ks, (1024 + wgs - 1) / wgs);
+    } else {
+        // whole rounds, or a last round that is at least 3/4 full: nothing to trim
+        const int64_t tail = wgs % 256;
+        if (tail == 0 || tail >= 192 || wgs > 4 * 256) return 1;
+        max_ks = std::min(max_ks, 8);
+    }
     double best = 1e300;
     int best_ks = 1;
     for (int ks = 1; ks <= max_ks; ++ks) {
