@@ -106,6 +106,19 @@ int ltmi_masks_kind(const ltmi_masks *m, int *kind);
 int ltmi_apply_masks(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames,
                      int64_t ld_tile, void *out, int64_t ld_out, int accumulate, void *stream);
 
+/* The same product for SELECTED frames of a tile, through a device list of frame numbers -- a region
+ * of interest without the gathered copy of its frames (reference: the ROI is applied while reading,
+ * frame by frame, io/dataset/memory.py:107-131; buffers are ROI-compressed, common/buffers.py:419-505):
+ *   out[i, k] (+)= sum_p tile[rows[i], p] * masks[k, p],   0 <= i < n_rows
+ * `rows`: DEVICE array of n_rows int32 frame numbers relative to `tile`.  *handled = 0 and nothing is
+ * done when the handle / tile combination has no row-list kernel (then gather with ltmi_gather_rows and
+ * call ltmi_apply_masks): row lists are served for dense float32 / complex64 stacks of at most 64 real
+ * columns on uint8 / int8 / uint16 / int16 / float32 tiles of at least one mask slot per frame.
+ */
+int ltmi_apply_masks_rows(ltmi_masks *m, const void *tile, int tile_dtype, const int32_t *rows,
+                          int64_t n_rows, int64_t ld_tile, void *out, int64_t ld_out, int accumulate,
+                          void *stream, int *handled);
+
 /* Shifted masks: out[f, k] (+)= sum over the overlap of frame[f][y, x] * mask_k[y - dy_f, x - dx_f]
  * Replaces ApplyMasksEngine.process_frame_shifted (src/libertem/udf/masks.py:85-124), one call per
  * tile instead of one per frame.  Dense handles only.  `shifts` is a DEVICE array of n_frames

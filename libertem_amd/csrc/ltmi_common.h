@@ -142,6 +142,9 @@ struct ltmi_masks {
     float *partials = nullptr;
     size_t partials_bytes = 0;
     int tune_mt = 0, tune_waves = 0, tune_ksplit = 0, tune_ksplit_ring = 0;
+    // ltmi_apply_masks_rows: device list of the tile's frames to multiply (result row i = frame rows[i]);
+    // set for the duration of that call only
+    const int32_t *roi_rows = nullptr;
     // kind 0 and 1
     void *gmasks = nullptr;  // (n_masks, n_px) of the accumulate type
     // kind 2 (ltmi_sparse.hip)

@@ -455,7 +455,7 @@ __global__ void k_build_image3(const float *__restrict__ src, float *__restrict_
     }
 }
 
-template <typename T, int NG, int ABL = 0, bool IND = false, int NE = 0, int TILES = 1>
+template <typename T, int NG, int ABL = 0, int IND = 0, int NE = 0, int TILES = 1>
 __global__ void __launch_bounds__(512 / TILES)                  // LdsCfg::WAVES * 64
 k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
             const float *__restrict__ img, int n_slots, float *__restrict__ out, int64_t ld_out,
@@ -494,14 +494,22 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
     const int k_begin = ks * per;
     const int k_end = min(n_slots, k_begin + per);
     const int kf_end = min(k_end, n_full);
-    const float *img_t = IND ? wg_img[blockIdx.x] : img + (size_t)gt * n_slots * SLOT_FLOATS;
+    const float *img_t = IND == 1 ? wg_img[blockIdx.x] : img + (size_t)gt * n_slots * SLOT_FLOATS;
 
     const int64_t f_wave = (int64_t)blockIdx.x * (WAVES * ROWS) + wave * ROWS;
-    // frame behind row r of this wave (IND: through the row list; -1 = nothing there)
-    auto frame_of = [&](int r) -> int64_t {
-        if (IND) return rows[f_wave + r];
+    // IND == 1 (shifted masks): row r of this wave is frame rows[...] of the tile, read AND written
+    // there (-1 = nothing).  IND == 2 (a region of interest without a gathered copy): result row i is
+    // the product of frame rows[i] of the tile, i < n_frames.
+    auto frame_of = [&](int r) -> int64_t {                 // result row
+        if (IND == 1) return rows[f_wave + r];
         const int64_t f = f_wave + r;
         return f < n_frames ? f : -1;
+    };
+    auto src_frame_of = [&](int r) -> int64_t {             // frame to read (clamped: loads stay valid)
+        int64_t f = frame_of(r);
+        if (IND == 2) return f < 0 ? (int64_t)rows[0] : (int64_t)rows[f];
+        if (f < 0) f = IND ? 0 : n_frames - 1;
+        return f;
     };
     unsigned char *a_base = lds_raw + wave * ASLOT;      // + slot * (WAVES * ASLOT)
     unsigned char *b_base = lds_raw + A_BYTES;           // + bslot * BSLOT
@@ -548,8 +556,7 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
 #pragma unroll
         for (int t = 0; t < ND; ++t) {
             const int r = 4 * t + (lane >> 4);
-            int64_t f = frame_of(r);
-            if (f < 0) f = IND ? 0 : n_frames - 1;      // clamp: loads stay valid, result discarded
+            const int64_t f = src_frame_of(r);          // (clamped; such results are discarded)
             const int piece = (lane & 15) ^ (r & 15);
             src[t] = (const unsigned char *)(tile + f * ld) + piece * 16;
         }
@@ -778,8 +785,7 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
         const float *ldsb = bl + b_lane;
 #pragma unroll
         for (int tl = 0; tl < TILES; ++tl) {
-            int64_t f = frame_of(tl * 16 + m);
-            if (f < 0) f = IND ? 0 : n_frames - 1;
+            const int64_t f = src_frame_of(tl * 16 + m);
             const T *rowp = tile + f * ld + kg * 8;
 #pragma unroll
             for (int blk = 0; blk < KB / 32; ++blk) {
@@ -1333,14 +1339,17 @@ static int launch_lds_ng_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64
     const int abl = m->tune_ksplit_ring == 31 ? 2 : (m->tune_ksplit_ring == 32 ? 1 : 0);
     void (*kern)(const T *, int64_t, int64_t, int64_t, const float *, int, float *, int64_t, int,
                  int, float *, int, const int32_t *, const float *const *) =
-        abl == 2 ? k_dense_lds<T, NG, 2, false, 0, TILES>
-                 : (abl == 1 ? k_dense_lds<T, NG, 1, false, 0, TILES>
-                             : k_dense_lds<T, NG, 0, false, 0, TILES>);
-    static bool attr_set[16][3] = {{false}};
-    if (!attr_set[m->device & 15][abl]) {
+        abl == 2 ? k_dense_lds<T, NG, 2, 0, 0, TILES>
+                 : (abl == 1 ? k_dense_lds<T, NG, 1, 0, 0, TILES>
+                             : k_dense_lds<T, NG, 0, 0, 0, TILES>);
+    const int32_t *rows = m->roi_rows;                  // ltmi_apply_masks_rows: frames through a row list
+    if (rows) kern = k_dense_lds<T, NG, 0, 2, 0, TILES>;
+    static bool attr_set[16][4] = {{false}};
+    const int variant = rows ? 3 : abl;
+    if (!attr_set[m->device & 15][variant]) {
         LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      CFG::LDS_BYTES));
-        attr_set[m->device & 15][abl] = true;
+        attr_set[m->device & 15][variant] = true;
     }
     const float *img = NG == 1 ? m->img : m->img2;
     const int n_slots = NG == 1 ? m->n_chunks : m->n_slots2;
@@ -1360,11 +1369,12 @@ static int launch_lds_ng_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64
     dim3 grid((unsigned)gx, (unsigned)ksplit, (unsigned)gz);
     hipLaunchKernelGGL(kern, grid, dim3(CFG::WAVES * 64), CFG::LDS_BYTES, stream, tile, ld, n_frames,
                        m->n_px, img, n_slots, out, ld_out, m->n_cols, accumulate, m->partials,
-                       ksplit, (const int32_t *)nullptr, (const float *const *)nullptr);
+                       ksplit, rows, (const float *const *)nullptr);
     LTMI_HIP(hipGetLastError());
     snprintf(m->last_kernel, sizeof(m->last_kernel),
              "k_dense_lds<%s,NG=%d,ring=%d,tiles=%d%s> grid=(%u,%u,%u)", typeid(T).name(), NG,
-             CFG::RING, TILES, abl ? (abl == 2 ? ",noDMA" : ",noMFMA") : "", grid.x, grid.y, grid.z);
+             CFG::RING, TILES, rows ? ",rows" : (abl ? (abl == 2 ? ",noDMA" : ",noMFMA") : ""),
+             grid.x, grid.y, grid.z);
     if (ksplit > 1) {
         const int64_t n = n_frames * m->n_cols;
         hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
@@ -1378,7 +1388,7 @@ static int launch_lds_ng_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64
 template <typename T, int NG>
 static int launch_lds_ng(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
                          int64_t ld_out, int accumulate, hipStream_t stream) {
-    if (lds_tiles(m) == 2)
+    if (lds_tiles(m) == 2 || m->roi_rows)
         return launch_lds_ng_t<T, NG, 2>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
     return launch_lds_ng_t<T, NG, 1>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
 }
@@ -1388,12 +1398,14 @@ template <typename T, int NG, int NE, int TILES>
 static int launch_lds_extras_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
                                int64_t ld_out, int accumulate, hipStream_t stream) {
     using CFG = LdsCfg<NG, NE, TILES>;
-    auto kern = k_dense_lds<T, NG, 0, false, NE, TILES>;
-    static bool attr_set[16] = {false};
-    if (!attr_set[m->device & 15]) {
+    auto kern = k_dense_lds<T, NG, 0, 0, NE, TILES>;
+    const int32_t *rows = m->roi_rows;
+    if (rows) kern = k_dense_lds<T, NG, 0, 2, NE, TILES>;
+    static bool attr_set[16][2] = {{false}};
+    if (!attr_set[m->device & 15][rows ? 1 : 0]) {
         LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      CFG::LDS_BYTES));
-        attr_set[m->device & 15] = true;
+        attr_set[m->device & 15][rows ? 1 : 0] = true;
     }
     const int n_slots = m->n_slots3;
     const int64_t gx = (n_frames + CFG::WG_ROWS - 1) / CFG::WG_ROWS;
@@ -1411,16 +1423,16 @@ static int launch_lds_extras_t(ltmi_masks *m, const T *tile, int64_t n_frames, i
     dim3 grid((unsigned)gx, (unsigned)ksplit, 1);
     hipLaunchKernelGGL(kern, grid, dim3(CFG::WAVES * 64), CFG::LDS_BYTES, stream, tile, ld, n_frames,
                        m->n_px, (const float *)m->img3, n_slots, out, ld_out, m->n_cols, accumulate,
-                       m->partials, ksplit, (const int32_t *)nullptr, (const float *const *)nullptr);
+                       m->partials, ksplit, rows, (const float *const *)nullptr);
     LTMI_HIP(hipGetLastError());
     if (NE > 0)
         snprintf(m->last_kernel, sizeof(m->last_kernel),
-                 "k_dense_lds<%s,NG=%d+%d VALU columns,ring=%d,tiles=%d> grid=(%u,%u,1)",
-                 typeid(T).name(), NG, NE, CFG::RING, TILES, grid.x, grid.y);
+                 "k_dense_lds<%s,NG=%d+%d VALU columns,ring=%d,tiles=%d%s> grid=(%u,%u,1)",
+                 typeid(T).name(), NG, NE, CFG::RING, TILES, rows ? ",rows" : "", grid.x, grid.y);
     else
         snprintf(m->last_kernel, sizeof(m->last_kernel),
-                 "k_dense_lds<%s,NG=%d,ring=%d,tiles=%d> grid=(%u,%u,1)", typeid(T).name(), NG,
-                 CFG::RING, TILES, grid.x, grid.y);
+                 "k_dense_lds<%s,NG=%d,ring=%d,tiles=%d%s> grid=(%u,%u,1)", typeid(T).name(), NG,
+                 CFG::RING, TILES, rows ? ",rows" : "", grid.x, grid.y);
     if (ksplit > 1) {
         const int64_t n = n_frames * m->n_cols;
         hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
@@ -1435,7 +1447,7 @@ template <typename T, int NG, int NE>
 static int launch_lds_extras(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
                              int64_t ld_out, int accumulate, hipStream_t stream) {
     if constexpr (NE == 0) {
-        if (lds_tiles(m) != 2)
+        if (lds_tiles(m) != 2 && !m->roi_rows)
             return launch_lds_extras_t<T, NG, NE, 1>(m, tile, n_frames, ld, out, ld_out, accumulate,
                                                      stream);
     }
@@ -1618,7 +1630,7 @@ static int launch_lds_shifted(ltmi_masks *m, const T *tile, int64_t n_frames, in
                             hipMemcpyHostToDevice, stream));
     LTMI_HIP(hipMemcpyAsync((void *)c->wg_img_dev, wg_host.data(), wg_host.size() * sizeof(float *),
                             hipMemcpyHostToDevice, stream));
-    auto kern = k_dense_lds<T, 1, 0, true, 0, 2>;
+    auto kern = k_dense_lds<T, 1, 0, 1, 0, 2>;
     static bool attr_set[16] = {false};
     if (!attr_set[m->device & 15]) {
         LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1839,6 +1851,42 @@ extern "C" int ltmi_apply_masks(ltmi_masks *m, const void *tile, int tile_dtype,
         if (rc != LTMI_OK || handled) return rc;
     }
     return apply_generic(m, tile, tile_dtype, n_frames, ld_tile, out, ld_out, accumulate, stream);
+}
+
+// Frames of a tile through a row list (a region of interest without a gathered copy):
+//   out[i, k] (+)= sum_p tile[rows[i], p] * masks[k, p],   i < n_rows
+// *handled = 0 (and nothing done) when the handle / tile has no row-list kernel: dense stacks with
+// float32 / complex64 results of at most 64 real columns on the LDS-DMA kernels only.
+extern "C" int ltmi_apply_masks_rows(ltmi_masks *m, const void *tile, int tile_dtype,
+                                     const int32_t *rows, int64_t n_rows, int64_t ld_tile, void *out,
+                                     int64_t ld_out, int accumulate, void *stream_, int *handled) {
+    if (!m || !handled) LTMI_FAIL(LTMI_E_INVALID, "ltmi_apply_masks_rows: null handle / handled");
+    *handled = 0;
+    if (n_rows < 0 || ld_tile < m->n_px || ld_out < m->n_masks)
+        LTMI_FAIL(LTMI_E_SHAPE, "ltmi_apply_masks_rows: n_rows=%lld ld_tile=%lld (n_px=%lld) "
+                  "ld_out=%lld (n_masks=%lld)", (long long)n_rows, (long long)ld_tile,
+                  (long long)m->n_px, (long long)ld_out, (long long)m->n_masks);
+    if (dtype_size(tile_dtype) == 0)
+        LTMI_FAIL(LTMI_E_DTYPE, "ltmi_apply_masks_rows: unknown tile dtype %d", tile_dtype);
+    if (n_rows == 0) { *handled = 1; return LTMI_OK; }
+    if (!tile || !out || !rows) LTMI_FAIL(LTMI_E_INVALID, "ltmi_apply_masks_rows: null pointer");
+    if (m->kind != 0 || !mfma_tile_dtype(tile_dtype) || !m->blocks.empty() || m->tune_mt != 0 ||
+        m->tune_waves != 0 || n_rows >= (1ll << 31) ||
+        !vector_loads_ok(tile, ld_tile, (size_t)dtype_size(tile_dtype)))
+        return LTMI_OK;
+    bool lds = false;
+    switch (tile_dtype) {
+        case LTMI_BOOL: case LTMI_U8: case LTMI_I8: lds = lds_kernel_applies<uint8_t>(m); break;
+        case LTMI_U16: case LTMI_I16: lds = lds_kernel_applies<uint16_t>(m); break;
+        case LTMI_F32: lds = lds_kernel_applies<float>(m); break;
+    }
+    if (!lds) return LTMI_OK;
+    m->roi_rows = rows;
+    const int rc = ltmi_apply_masks(m, tile, tile_dtype, n_rows, ld_tile, out, ld_out, accumulate,
+                                    stream_);
+    m->roi_rows = nullptr;
+    *handled = 1;
+    return rc;
 }
 
 extern "C" int ltmi_apply_masks_shifted(ltmi_masks *m, const void *tile, int tile_dtype,

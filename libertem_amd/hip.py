@@ -102,6 +102,8 @@ def lib():
         L.ltmi_masks_create_dense.argtypes = [i32, vp, i32, i64, i64, c.POINTER(vp)]
         L.ltmi_masks_create_csr.argtypes = [i32, vp, vp, vp, i32, i64, i64, c.POINTER(vp)]
         L.ltmi_masks_destroy.argtypes = [vp]
+        L.ltmi_apply_masks_rows.argtypes = [vp, vp, i32, vp, i64, i64, vp, i64, i32, vp,
+                                            c.POINTER(i32)]
         L.ltmi_masks_kind.argtypes = [vp, c.POINTER(i32)]
         L.ltmi_apply_masks.argtypes = [vp, vp, i32, i64, i64, vp, i64, i32, vp]
         L.ltmi_apply_masks_shifted.argtypes = [vp, vp, i32, i64, i64, i32, i32, vp, vp, i64, i32, vp]
@@ -250,6 +252,30 @@ class MaskHandle:
         if KernelTimer.enabled:
             b.record(st)
             KernelTimer.events.append((a, b, n_frames, self.last_kernel()))
+
+    def apply_rows(self, tile_ptr, tile_dtype, rows_ptr, n_rows, ld_tile, out_ptr, ld_out, accumulate,
+                   stream=None):
+        """out[i] (+)= product of frame rows[i] of the tile (rows: device int32).  Returns False --
+        nothing done -- when this handle / tile has no row-list kernel (gather the frames instead)."""
+        handled = ctypes.c_int(0)
+        if KernelTimer.enabled:
+            import torch
+            st = torch.cuda.current_stream() if stream is None or isinstance(stream, int) \
+                else stream
+            if isinstance(stream, int) and st.cuda_stream != stream:
+                st = torch.cuda.ExternalStream(stream)
+            a = torch.cuda.Event(enable_timing=True)
+            b = torch.cuda.Event(enable_timing=True)
+            a.record(st)
+        check(lib().ltmi_apply_masks_rows(
+            self._ptr, ctypes.c_void_p(tile_ptr), dtype_code(tile_dtype), ctypes.c_void_p(rows_ptr),
+            int(n_rows), int(ld_tile), ctypes.c_void_p(out_ptr), int(ld_out), 1 if accumulate else 0,
+            stream if isinstance(stream, int) else _stream_ptr(stream), ctypes.byref(handled)),
+            'ltmi_apply_masks_rows')
+        if KernelTimer.enabled and handled.value:
+            b.record(st)
+            KernelTimer.events.append((a, b, n_rows, self.last_kernel()))
+        return bool(handled.value)
 
     def apply_shifted(self, tile_ptr, tile_dtype, n_frames, ld_tile, sig_h, sig_w, shifts_ptr,
                       out_ptr, ld_out, accumulate, stream=None):

@@ -1,0 +1,20 @@
+import sys, os, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from libertem_amd.api import Context
+from libertem_amd.udf.masks import ApplyMasksUDF
+from libertem_amd.common.hiparray import HipArray
+ctx = Context.make_with('hip', gpus=0)
+frames = torch.randint(0, 4096, (256, 256, 256, 256), device='cuda', dtype=torch.int32).to(torch.int16)
+ds = ctx.load('memory', data=HipArray.from_torch(frames, np.uint16), sig_dims=2, num_partitions=1)
+masks = np.random.default_rng(2).random((16, 256, 256)).astype(np.float32)
+udf = ApplyMasksUDF(mask_factories=lambda: masks, use_sparse=False, mask_count=16, mask_dtype=np.float32)
+rng = np.random.default_rng(0)
+for name, roi in (('none', None), ('random 50 %', rng.random((256, 256)) < 0.5), ('block 50 %', np.arange(65536).reshape(256, 256) < 32768), ('random 10 %', rng.random((256, 256)) < 0.1)):
+    for _ in range(3):
+        ctx.run_udf(dataset=ds, udf=udf, roi=roi)
+    ts = []
+    for _ in range(8):
+        t0 = time.perf_counter(); ctx.run_udf(dataset=ds, udf=udf, roi=roi); ts.append(time.perf_counter() - t0)
+    n = 65536 if roi is None else int(roi.sum())
+    t = float(np.median(ts))
+    print(f"roi {name:12s}: {n:6d} frames {t*1e3:7.2f} ms  {n / t / 1e6:6.1f} M frames/s", flush=True)

@@ -244,6 +244,48 @@ def test_long_rows_keep_float32_accuracy(hip, n_px, tile_dtype, n_masks):
     assert err < 4e-6, err
 
 
+@pytest.mark.parametrize('tile_dtype,n_masks,mask_dtype', [
+    ('uint16', 16, 'float32'), ('uint16', 3, 'float32'), ('float32', 25, 'complex64'),
+    ('uint8', 5, 'float32'), ('int16', 40, 'float32'), ('uint16', 70, 'float32'),
+    ('int32', 4, 'float32'),
+])
+def test_row_lists_instead_of_gathered_frames(hip, tile_dtype, n_masks, mask_dtype):
+    """ltmi_apply_masks_rows: out[i] = product of frame rows[i] of the tile -- a region of interest
+    without the gathered copy.  Served for the float32 / complex64 LDS-DMA kernels (every column
+    tiling up to 64 real columns); other handles report handled = 0 and the caller gathers."""
+    dt, md = np.dtype(tile_dtype), np.dtype(mask_dtype)
+    rng = np.random.default_rng(n_masks)
+    n_frames, n_px = 700, 256 * 5 + 24
+    data = (rng.integers(0, 200, (n_frames, n_px)).astype(dt) if dt.kind in 'iu'
+            else rng.random((n_frames, n_px)).astype(dt))
+    masks = rng.random((n_masks, n_px)) - 0.25
+    if md.kind == 'c':
+        masks = masks + 1j * (rng.random((n_masks, n_px)) - 0.5)
+    masks = masks.astype(md)
+    rd = np.result_type(dt, md)
+    rows = np.sort(rng.choice(n_frames, 333, replace=False)).astype(np.int32)
+    rows[7], rows[8] = rows[8], rows[7]                      # (any order, repeats allowed)
+    rows[100] = rows[99]
+    h = hip.MaskHandle.dense(0, masks, rd)
+    t = _dev(data)
+    r = torch.from_numpy(rows).cuda()
+    tout = {'float32': torch.float32, 'float64': torch.float64, 'complex64': torch.complex64}[rd.name]
+    base = torch.full((len(rows), n_masks), 2.0, dtype=tout, device='cuda')
+    for acc in (False, True):
+        out = base.clone()
+        handled = h.apply_rows(t.data_ptr(), dt, r.data_ptr(), len(rows), n_px, out.data_ptr(),
+                               n_masks, acc)
+        torch.cuda.synchronize()
+        if dt.itemsize == 4 and dt.kind == 'i' or n_masks > 64:
+            assert not handled                                # float64 results / column blocks: gather
+            continue
+        assert handled and ',rows' in h.last_kernel(), h.last_kernel()
+        ref = _ref64(data[rows], masks) + (2.0 if acc else 0.0)
+        scale = np.abs(data[rows].astype(np.float64)) @ np.abs(masks).astype(np.float64).T + 2.0
+        assert np.all(np.abs(out.cpu().numpy() - ref) <= 1e-5 * scale), h.last_kernel()
+    h.close()
+
+
 @pytest.mark.parametrize('combo', [
     ('int32', 'float64'), ('int64', 'float64'), ('float64', 'float64'), ('uint16', 'float64'),
     ('uint32', 'float64'), ('float32', 'complex128'), ('int32', 'complex128'),
