@@ -29,7 +29,7 @@ _DTYPES = {
 EXPORTS = (
     'ltmi_version', 'ltmi_last_error', 'ltmi_device_count', 'ltmi_device_info',
     'ltmi_masks_create_dense', 'ltmi_masks_create_csr', 'ltmi_masks_destroy', 'ltmi_masks_kind',
-    'ltmi_apply_masks', 'ltmi_apply_masks_shifted', 'ltmi_apply_masks_shifted_host', 'ltmi_sum_frames_workspace', 'ltmi_sum_frames', 'ltmi_sum_sig',
+    'ltmi_apply_masks', 'ltmi_apply_masks_rows', 'ltmi_apply_masks_shifted', 'ltmi_apply_masks_shifted_host', 'ltmi_sum_frames_workspace', 'ltmi_sum_frames', 'ltmi_sum_sig',
     'ltmi_axpy', 'ltmi_add2d', 'ltmi_gather_rows', 'ltmi_host_device_pointer', 'ltmi_correct', 'ltmi_repair_pixels', 'ltmi_byteswap', 'ltmi_com_fields', 'ltmi_fft_plan_create',
     'ltmi_fft_plan_destroy', 'ltmi_crystallinity', 'ltmi_crystallinity_corrected',
     'ltmi_masks_set_tuning',
