@@ -195,6 +195,63 @@ class HipArray:
         return f"<HipArray shape={self.shape} dtype={self.dtype} ld={self.ld} dev={self.device}>"
 
 
+class HipRowsArray(HipArray):
+    """
+    Frames of a flat device array selected by a row list -- logical shape (n, *sig), NO copy: what a
+    region of interest of a device-resident dataset looks like to the kernels that can read frames
+    through a row list (`ltmi_apply_masks_rows`).  Everything else calls `materialize()` (the frames
+    gathered into a contiguous HipArray with `ltmi_gather_rows`, cached).
+    `base`: HipArray (n_total, ...) whose rows are frames; `idx64` / `rows32`: device tensors with the
+    same frame numbers (int64 for the gather kernel, int32 for the row-list kernels).
+    """
+    __slots__ = ('_base', '_idx64', '_rows32', '_mat')
+
+    def __init__(self, base, idx64, rows32, sig):
+        HipArray.__init__(self, base._t, (int(idx64.shape[0]),) + tuple(sig), base.dtype,
+                          ld=base.ld)
+        self._base, self._idx64, self._rows32, self._mat = base, idx64, rows32, None
+
+    @property
+    def base(self):
+        return self._base
+
+    def rows_ptr(self):
+        return self._rows32.data_ptr()
+
+    def data_ptr(self):
+        raise TypeError("HipRowsArray has no contiguous data: use materialize() or a row-list kernel")
+
+    @property
+    def torch(self):
+        raise TypeError("HipRowsArray has no contiguous data: use materialize()")
+
+    def rows(self, start, stop):
+        start, stop = int(start), int(stop)
+        if not (0 <= start <= stop <= self.shape[0]):
+            raise IndexError(f"rows [{start}, {stop}) out of range for {self.shape}")
+        return HipRowsArray(self._base, self._idx64[start:stop], self._rows32[start:stop],
+                            self.shape[1:])
+
+    def reshape(self, shape):
+        return self.materialize().reshape(shape)
+
+    def cpu(self):
+        return self.materialize().cpu()
+
+    def materialize(self, stream=None):
+        if self._mat is None:
+            from libertem_amd import hip
+            n = self.shape[0]
+            out = HipArray.empty(self.shape, self.dtype, self._base.device)
+            if n:
+                isz = self.dtype.itemsize
+                hip.gather_rows(self._base.device, self._base.data_ptr(), self._base.ld * isz,
+                                self._idx64.data_ptr(), n, prod(self.shape[1:]) * isz,
+                                out.data_ptr(), stream=stream)
+            self._mat = out
+        return self._mat
+
+
 class HostMappedArray(HipArray):
     """
     Rows of a page-locked HOST buffer that the kernels write directly over the host link

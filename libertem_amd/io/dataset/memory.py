@@ -461,6 +461,8 @@ class MemPartition(Partition):
         for scheme_idx, sig_slice in tiling_scheme.slices:
             s_shape = tuple(sig_slice.shape.sig)
             s_origin = tuple(sig_slice.origin[-sig_dims:])
+            if s_shape != ds_sig and hasattr(chunk, 'materialize'):
+                chunk = chunk.materialize()         # (a row list only stands for whole frames)
             if s_shape == ds_sig:
                 data = chunk
             elif s_shape[1:] == ds_sig[1:] and all(o == 0 for o in s_origin[1:]):
@@ -522,7 +524,17 @@ class MemPartition(Partition):
             flat = ds.flat_device()
             if flat.device != device:
                 raise RuntimeError(f"dataset lives on GPU {flat.device}, worker drives GPU {device}")
-            if idxs is not None:
+            if idxs is not None and corrections is None and \
+                    int(idxs.max()) < 2 ** 31 - 1 and flat.is_contiguous:
+                # the frames the ROI selects as a ROW LIST over the resident array: the mask kernels
+                # read them in place (ltmi_apply_masks_rows), other consumers gather on demand
+                import torch
+                from libertem_amd.common.hiparray import HipRowsArray
+                i64 = torch.from_numpy(np.ascontiguousarray(idxs, dtype=np.int64)).to(
+                    f'cuda:{device}')
+                flat = HipRowsArray(flat, i64, i64.to(torch.int32), tuple(ds.shape.sig))
+                base = 0
+            elif idxs is not None:
                 # the frames the ROI selects, gathered inside HBM (ltmi_gather_rows)
                 from libertem_amd import hip
                 sel = HipArray.from_numpy(np.ascontiguousarray(idxs, dtype=np.int64), device)

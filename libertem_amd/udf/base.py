@@ -522,6 +522,10 @@ class UDF(UDFBase):
     #: (udf/base.py:1997-2003); user UDFs keep that behaviour, the native operators opt in.
     REUSE_TASK_INSTANCES = False
 
+    #: True: `process_tile` accepts a `HipRowsArray` (the frames of a region of interest as a row list
+    #: over the resident array) -- other UDFs are handed the gathered frames.
+    ACCEPTS_ROW_VIEWS = False
+
     def __init__(self, **kwargs):
         super().__init__()
         self._kwargs = kwargs
@@ -915,14 +919,19 @@ class UDFPartRunner:
             udf.flush(self._debug)
 
     def _run_tile(self, udf, method, partition, tile):
+        data = tile.data
+        if hasattr(data, 'materialize') and not (
+                method == UDFMethod.TILE and getattr(udf, 'ACCEPTS_ROW_VIEWS', False)):
+            # a region of interest as a row list over the resident frames: only the mask operators
+            # read through it, everyone else gets the gathered frames (gathered once per tile)
+            data = data.materialize()
         if method == UDFMethod.TILE:
             udf.set_contiguous_views_for_tile(partition, tile)
             udf.set_slice(tile.tile_slice)
             udf.set_tile_idx(tile.scheme_idx)
-            udf.process_tile(tile.data)
+            udf.process_tile(data)
         elif method == UDFMethod.FRAME:
             tile_slice = tile.tile_slice
-            data = tile.data
             for frame_idx in range(data.shape[0]):
                 frame_slice = Slice(
                     origin=(tile_slice.origin[0] + frame_idx,) + tile_slice.origin[1:],
@@ -936,7 +945,7 @@ class UDFPartRunner:
         elif method == UDFMethod.PARTITION:
             udf.set_views_for_tile(partition, tile)
             udf.set_slice(tile.tile_slice)
-            udf.process_partition(tile.data)
+            udf.process_partition(data)
 
     def _wrapup_udfs(self, partition, backend, env):
         for udf in self._udfs:

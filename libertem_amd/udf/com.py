@@ -154,6 +154,7 @@ class CoMUDF(UDF):
     """
 
     REUSE_TASK_INSTANCES = True      # (udf/base.py: per-partition instances kept between runs)
+    ACCEPTS_ROW_VIEWS = True         # process_tile reads an ROI's frames through a row list (no gather)
 
     def __init__(self, com_params: CoMParams = CoMParams()):
         super().__init__(com_params=com_params)

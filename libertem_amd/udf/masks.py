@@ -18,7 +18,7 @@ from libertem_amd.common.math import prod
 from libertem_amd.common.udf import UDFMethod
 from libertem_amd.common.container import MaskContainer
 from libertem_amd.common.buffers import AuxBufferWrapper
-from libertem_amd.common.hiparray import HipArray
+from libertem_amd.common.hiparray import HipArray, HipRowsArray
 from libertem_amd.common.exceptions import HipRequiredError
 from libertem_amd.udf.base import UDF
 
@@ -234,6 +234,18 @@ class ApplyMasksEngine:
             raise HipRequiredError("ApplyMasksEngine.process_tile expects a device tile (HipArray)")
         n = tile.shape[0]
         n_px = prod(tile.shape[1:])
+        if isinstance(tile, HipRowsArray):
+            # a region of interest as a row list over the resident frames: the dense float32 kernels
+            # read the selected frames in place; anything else gets them gathered
+            if out is not None and self._const is None and np.dtype(tile.dtype).kind != 'c':
+                handle = self._get_handle()
+                if handle.n_px == n_px and out.shape[0] == n and \
+                        prod(out.shape[1:]) == handle.n_masks and \
+                        handle.apply_rows(tile.base.data_ptr(), tile.dtype, tile.rows_ptr(), n,
+                                          tile.base.ld, out.data_ptr(), out.ld, accumulate,
+                                          stream=self.stream_ptr):
+                    return out
+            tile = tile.materialize(stream=self.stream_ptr)
         if np.dtype(tile.dtype).kind == 'c' and self.result_dtype.kind == 'c' \
                 and self.masks.use_sparse is False and self._const is None \
                 and np.dtype(tile.dtype) == self.result_dtype:
@@ -279,6 +291,8 @@ class ApplyMasksEngine:
         import torch
         if not isinstance(tile, HipArray):
             raise HipRequiredError("process_tile_shifted expects a device tile (HipArray)")
+        if isinstance(tile, HipRowsArray):
+            tile = tile.materialize(stream=self.stream_ptr)
         sig = tuple(self.meta.dataset_shape.sig)
         if len(sig) != 2 or tuple(tile.shape[1:]) != sig:
             raise ValueError(
@@ -316,6 +330,7 @@ class ApplyMasksUDF(UDF):
     '''
 
     REUSE_TASK_INSTANCES = True      # (udf/base.py: per-partition instances kept between runs)
+    ACCEPTS_ROW_VIEWS = True         # process_tile reads an ROI's frames through a row list (no gather)
 
     def __init__(self, mask_factories, use_torch=True, use_sparse=None, mask_count=None,
                  mask_dtype=None, preferred_dtype=None, backends=None, shifts=None, **kwargs):

@@ -1,3 +1,5 @@
+"""ROI runs of ApplyMasksUDF on a device-resident C2 dataset: whole job per run (Context.run_udf(roi=...)).
+The mask kernels read the selected frames through a row list (ltmi_apply_masks_rows), no gathered copy."""
 import sys, os, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from libertem_amd.api import Context

@@ -1246,6 +1246,46 @@ def test_streamed_export_with_several_tiles(ctx, direct_row_max, monkeypatch):
         Negotiator._hip_scheme_cache.clear()
 
 
+def test_roi_runs_read_frames_through_a_row_list(ctx):
+    """Device-resident data + ROI: the mask operators (ApplyMasksUDF, CoMUDF) read the selected frames
+    in place through a row list (`ltmi_apply_masks_rows`, kernel label ',rows'), no gathered copy;
+    UDFs that do not take row lists (SumSigUDF) get the gathered frames in the same run."""
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd.udf.sumsigudf import SumSigUDF
+    from libertem_amd.udf.com import CoMUDF
+    from libertem_amd import hip
+    rng = np.random.default_rng(77)
+    data = rng.integers(0, 3000, (13, 17, 32, 32)).astype(np.uint16)
+    masks = rng.random((5, 32, 32)).astype(np.float32)
+    roi = rng.random((13, 17)) < 0.4
+    roi[0, :5] = True
+    ref = opath.apply_masks(data, masks, num_partitions=3)
+    ds = _device_ds(ctx, data, 3)
+    hip.KernelTimer.start()
+    res = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda: masks), roi=roi)
+    kernels = [k for _, _, k in hip.KernelTimer.stop()]
+    assert kernels and all(',rows' in k for k in kernels), kernels
+    assert _close(res['intensity'].raw_data, ref[roi], F32_TOL)
+    assert np.all(np.isnan(res['intensity'].data[~roi]))
+    # mixed run: SumSigUDF works on the gathered frames, the masks still through the row list
+    hip.KernelTimer.start()
+    r1, r2 = ctx.run_udf(dataset=ds, udf=[ApplyMasksUDF(mask_factories=lambda: masks), SumSigUDF()],
+                         roi=roi)
+    kernels = [k for _, _, k in hip.KernelTimer.stop()]
+    assert any(',rows' in k for k in kernels), kernels
+    assert _close(r1['intensity'].raw_data, ref[roi], F32_TOL)
+    assert np.array_equal(r2['intensity'].raw_data, data.sum(axis=(2, 3))[roi].astype(np.float32))
+    # CoM on the ROI (its 3-column stack: the VALU-only kernel, also through the row list)
+    com = ctx.run_udf(dataset=ds, udf=CoMUDF.with_params(cy=16, cx=16), roi=roi)
+    full = ctx.run_udf(dataset=ds, udf=CoMUDF.with_params(cy=16, cx=16))
+    assert np.allclose(com['raw_com'].raw_data, full['raw_com'].data[roi], rtol=1e-6)
+    # float64 results (int32 frames): no row-list kernel -> gathered, same numbers
+    ds32 = _device_ds(ctx, data.astype(np.int32), 3)
+    r64 = ctx.run_udf(dataset=ds32, udf=ApplyMasksUDF(mask_factories=lambda: masks), roi=roi)
+    assert r64['intensity'].raw_data.dtype == np.float64
+    assert _close(r64['intensity'].raw_data, ref[roi], 1e-6)
+
+
 def test_default_partition_count_on_the_gpu_executor(ctx):
     """`num_partitions` not given: the reference's default is one partition per CPU core (a worker
     count); the GPU executor streams host data through one device, so the default is one partition
