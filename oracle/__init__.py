@@ -19,4 +19,4 @@ byte-order decoders (io/dataset/base/decode.py, unsigned dtype pairs of the refe
 `sparse` is absent): construction of *sparse* mask stacks; there the oracle follows
 common/container.py:33-71 + masks.py:290-353 and is anchored on `rmatmul` + dense radial_bins.
 """
-from . import masks, tiling, path, corrections, decode  # noqa: F401
+from . import masks, tiling, path, corrections, decode, mib  # noqa: F401

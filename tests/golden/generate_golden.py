@@ -519,6 +519,61 @@ def gen_config_workloads():
     save('config_workloads', **out)
 
 
+# ---------------------------------------------------------------------------
+# 15. Merlin .mib files: the reference's own encoders, decoders and MIBDataSet
+# ---------------------------------------------------------------------------
+def gen_mib():
+    import tempfile
+    from libertem.io.dataset import mib as ref_mib
+    from libertem.io.dataset.mib import MIBDataSet
+    from libertem.udf.raw import PickUDF
+    out = {}
+    enc = {1: ref_mib.encode_r1, 6: ref_mib.encode_r6, 12: ref_mib.encode_r12}
+    for case in recipes.MIB_CASES:
+        frames, files, hdr = recipes.make_mib_case(case)
+        name = case['name']
+        # the recipe's payload bytes against the reference's encoders (single chip, 1 / 6 / 12 bit)
+        if case['kind'] == 'r' and case['bits'] in enc and not case.get('quad'):
+            h, w = case['sig']
+            ref_rows = np.zeros((h, w * {1: 1, 6: 8, 12: 16}[case['bits']] // 8), dtype=np.uint8)
+            enc[case['bits']](inp=frames[0], out=ref_rows)
+            assert ref_rows.tobytes() == recipes.mib_frame_payload(frames[0], case), name
+        with tempfile.TemporaryDirectory() as d:
+            for fn, blob in files.items():
+                with open(os.path.join(d, fn), 'wb') as f:
+                    f.write(blob)
+            hdr_path = os.path.join(d, name + '.hdr')
+            with open(hdr_path, 'w') as f:
+                f.write(hdr)
+            ds = MIBDataSet(path=hdr_path, sync_offset=case.get('sync_offset', 0))
+            ds = ds.initialize(EX)
+            assert tuple(ds.shape.nav) == tuple(case['nav']), (ds.shape, case['nav'])
+            roi = np.ones(tuple(ds.shape.nav), dtype=bool)
+            picked = run(ds, PickUDF(), roi=roi)['intensity'].data
+            so = case.get('sync_offset', 0)
+            n_nav = int(np.prod(case['nav']))
+            expect = np.zeros((n_nav,) + tuple(case['sig']), dtype=frames.dtype)
+            src = frames[max(so, 0):max(so, 0) + n_nav - max(-so, 0)]
+            expect[max(-so, 0):max(-so, 0) + len(src)] = src
+            # (24 bit: the reference declares uint16 and PickUDF reads into that: values wrap)
+            same = np.array_equal(np.asarray(picked).reshape(expect.shape),
+                                  expect.astype(picked.dtype))
+            print(name, 'reference reads back the recipe frames:', same)
+            assert same, name
+            sums = run(ds, SumSigUDF())['intensity'].data
+            rng = np.random.default_rng(case['seed'] + 5000)
+            masks = rng.random((3,) + tuple(ds.shape.sig)).astype(np.float32)
+            applied = run(ds, ApplyMasksUDF(mask_factories=lambda: masks))['intensity'].data
+            out[name + '__dtype'] = np.array(str(np.dtype(ds.dtype)))
+            out[name + '__frames'] = np.asarray(picked)
+            out[name + '__sumsig'] = np.asarray(sums)
+            out[name + '__masks'] = np.asarray(applied)
+            out[name + '__sha_files'] = np.frombuffer(bytes.fromhex(hashlib.sha256(
+                b''.join(files[k] for k in sorted(files))).hexdigest()), dtype=np.uint8)
+            print(name, ds.dtype, picked.dtype, picked.shape, sums.dtype, applied.dtype)
+    save('mib', **out)
+
+
 GENERATORS = {}
 
 if __name__ == '__main__':
@@ -547,5 +602,6 @@ if __name__ == '__main__':
     gen_single_mask_analyses()
     gen_pick()
     gen_config_workloads()
+    gen_mib()
     with open(os.path.join(HERE, 'MANIFEST.json'), 'w') as f:
         json.dump(MANIFEST, f, indent=1, sort_keys=True)

@@ -548,3 +548,120 @@ def make_pick_case(case):
     if dt.kind == 'f':
         return rng.random(shape).astype(dt)
     return rng.integers(0, 1000, shape).astype(dt)
+
+
+# ---------------------------------------------------------------------------
+# Merlin / Medipix .mib files (reference io/dataset/mib.py): per-frame ASCII header + payload.
+# kind 'u': big-endian unsigned integers; kind 'r' ("R64"): 64-bit words whose bytes are stored most
+# significant first -- 64 one-bit, 8 six-bit (one byte each) or 4 twelve-bit (two bytes each) pixels
+# per word, first pixel in the LEAST significant position; 24 bit = two 12-bit images, high half first.
+# Quad (2x2 chips): a raw row is [chip 4 | chip 3 | chip 2 | chip 1], chips 3 and 4 rotated by 180 degrees.
+# ---------------------------------------------------------------------------
+MIB_CASES = [
+    dict(name='u08', kind='u', bits=8, sig=(32, 64), frames=(5,), nav=(1, 5), seed=1301),
+    dict(name='u16', kind='u', bits=16, sig=(32, 64), frames=(3, 2), nav=(1, 5), seed=1302),
+    dict(name='u32', kind='u', bits=32, sig=(16, 64), frames=(4,), nav=(2, 2), seed=1303),
+    # (1-bit files: the reference needs file size % pixels per frame == 0, base/file.py:121-127)
+    dict(name='r1', kind='r', bits=1, sig=(32, 128), frames=(32,), nav=(4, 8), seed=1304),
+    dict(name='r6', kind='r', bits=6, sig=(32, 64), frames=(3, 3), nav=(2, 3), seed=1305),
+    dict(name='r12', kind='r', bits=12, sig=(32, 64), frames=(6,), nav=(2, 3), seed=1306),
+    # (24 bit: one frame per file -- the reference's read ranges step over later frames of a file by the
+    #  size of ONE 12-bit image, mib.py:224-252, so only single-frame files read back correctly there)
+    dict(name='r24', kind='r', bits=24, sig=(32, 64), frames=(1, 1, 1, 1), nav=(2, 2), seed=1307),
+    dict(name='r1_quad', kind='r', bits=1, sig=(128, 128), frames=(64,), nav=(8, 8), quad=True,
+         seed=1308),
+    dict(name='r6_quad', kind='r', bits=6, sig=(128, 128), frames=(2, 2), nav=(2, 2), quad=True,
+         seed=1309),
+    dict(name='r12_quad', kind='r', bits=12, sig=(128, 128), frames=(4,), nav=(2, 2), quad=True,
+         seed=1310),
+    # fewer frames in the files than the scan has positions + a sync offset
+    dict(name='r12_offset', kind='r', bits=12, sig=(32, 64), frames=(7,), nav=(2, 3), seed=1311,
+         sync_offset=2),
+    dict(name='u16_neg_offset', kind='u', bits=16, sig=(32, 64), frames=(5,), nav=(2, 3), seed=1312,
+         sync_offset=-2),
+]
+
+
+def _mib_words(px, per_word):
+    """(rows, W) pixel values -> (rows, W) with every group of `per_word` pixels reversed (the first
+    pixel of a word sits in its least significant position, the word is stored big-endian)"""
+    rows, w = px.shape
+    return px.reshape(rows, w // per_word, per_word)[:, :, ::-1].reshape(rows, w)
+
+
+def mib_encode_rows(px, bits):
+    """(rows, W) pixel values -> (rows, bytes) payload of raw ('R64') data"""
+    if bits == 1:
+        return np.packbits(_mib_words(px.astype(np.uint8) & 1, 64), axis=1, bitorder='big')
+    if bits == 6:
+        return _mib_words(px.astype(np.uint8), 8)
+    if bits == 12:
+        return _mib_words(px.astype(np.uint16), 4).astype('>u2').view(np.uint8)
+    raise ValueError(bits)
+
+
+def mib_frame_payload(frame, case):
+    kind, bits = case['kind'], case['bits']
+    if kind == 'u':
+        return frame.astype(f'>u{bits // 8}').tobytes()
+    if bits == 24:
+        hi = mib_encode_rows((frame >> 12).astype(np.uint16), 12)
+        lo = mib_encode_rows((frame & 0xFFF).astype(np.uint16), 12)
+        return hi.tobytes() + lo.tobytes()
+    if case.get('quad'):
+        h, w = frame.shape
+        q1, q2 = frame[:h // 2, :w // 2], frame[:h // 2, w // 2:]
+        q3, q4 = frame[h // 2:, :w // 2][::-1, ::-1], frame[h // 2:, w // 2:][::-1, ::-1]
+        return np.concatenate([mib_encode_rows(np.ascontiguousarray(q), bits)
+                               for q in (q4, q3, q2, q1)], axis=1).tobytes()
+    return mib_encode_rows(frame, bits).tobytes()
+
+
+def mib_header(case, seq):
+    """per-frame header as the Merlin software writes it (384 bytes per chip, comma separated)"""
+    h, w = case['sig']
+    quad = bool(case.get('quad'))
+    n_chips = 4 if quad else 1
+    size = 384 * n_chips
+    if case['kind'] == 'u':
+        dt = 'U%02d' % case['bits']
+        hw, hh = w, h
+    else:
+        dt = 'R64'
+        if quad:
+            hw, hh = 2 * w, h // 2          # raw rows of all four chips side by side
+        elif case['bits'] == 24:
+            hw, hh = 2 * w, h               # two 12-bit images
+        else:
+            hw, hh = w, h
+    layout = '   2x2' if quad else '   1x1'
+    chips = '0F' if quad else '01'
+    text = (f"MQ1,{seq:06d},{size:05d},{n_chips:02d},{hw:04d},{hh:04d},{dt},{layout},{chips},"
+            f"2020-05-18 16:51:49.971626,0.000555,0,0,0,1.200000E+2,5.110000E+2,0.000000E+0,"
+            f"0.000000E+0,3RX,175,511,000,000,125,255,MQ1A,2020-05-18T14:51:49.971626178Z,555000ns,"
+            f"{case['bits']}")
+    raw = text.encode('ascii') + b','
+    assert len(raw) <= size
+    return raw + b'\x00' * (size - len(raw))
+
+
+def make_mib_case(case):
+    """-> (frames (n, H, W) in file order, {file name: bytes}, hdr text)"""
+    rng = np.random.default_rng(case['seed'])
+    n = sum(case['frames'])
+    bits = case['bits']
+    dt = np.uint8 if bits <= 8 else (np.uint16 if bits <= 16 else np.uint32)
+    frames = rng.integers(0, 2 ** bits, size=(n,) + tuple(case['sig']), dtype=np.uint64).astype(dt)
+    frames[0].reshape(-1)[:3] = [2 ** bits - 1, 0, 2 ** bits - 1]
+    files = {}
+    seq = 1
+    for i, cnt in enumerate(case['frames']):
+        blob = b''.join(mib_header(case, seq + k) + mib_frame_payload(frames[seq - 1 + k], case)
+                        for k in range(cnt))
+        files[f"{case['name']}{i + 1:06d}.mib"] = blob
+        seq += cnt
+    nav = case['nav']
+    hdr = ("HDR,\t\nTime and Date Stamp (day, mnth, yr, hr, min, s):\t18/05/2020 16:51:48\n"
+           f"Frames in Acquisition (Number):\t{int(np.prod(nav))}\n"
+           f"Frames per Trigger (Number):\t{nav[-1]}\nEnd\t")
+    return frames, files, hdr

@@ -404,3 +404,27 @@ def test_decode_signed_other_byte_order(golden_dir, case):
     interp = ds.decoded_dtype(case['out_dtype'])
     tile = stored.view(interp.newbyteorder(stored.dtype.byteorder)).astype(case['out_dtype'])
     assert np.array_equal(tile.reshape(-1), ref)
+
+
+# ---- Merlin .mib files (oracle/mib.py vs the reference's MIBDataSet) ------------------------------
+@pytest.mark.parametrize('case', recipes.MIB_CASES, ids=lambda c: c['name'])
+def test_mib_oracle_vs_reference(golden_dir, case):
+    from oracle import mib as omib
+    g = _load(golden_dir, 'mib')
+    frames, files, hdr = recipes.make_mib_case(case)
+    name = case['name']
+    assert np.array_equal(_sha(b''.join(files[k] for k in sorted(files))), g[name + '__sha_files'])
+    got, fields = omib.read_files(files, case['nav'], case.get('sync_offset', 0))
+    assert str(omib.declared_dtype(fields)) == str(g[name + '__dtype'])
+    assert tuple(fields['image_size']) == tuple(case['sig'])
+    ref = g[name + '__frames']
+    # (24 bit: the reference reads into its declared uint16 and wraps; the oracle keeps all 24 bits)
+    assert np.array_equal(got.astype(ref.dtype).reshape(ref.shape), ref)
+    sums = g[name + '__sumsig']
+    assert np.allclose(got.reshape(got.shape[0], -1).sum(axis=1, dtype=np.float64),
+                       sums.reshape(-1), rtol=1e-6)
+    rng = np.random.default_rng(case['seed'] + 5000)
+    masks = rng.random((3,) + tuple(case['sig'])).astype(np.float32)
+    ref_m = g[name + '__masks']
+    mine = got.reshape(got.shape[0], -1).astype(np.float64) @ masks.reshape(3, -1).T.astype(np.float64)
+    assert np.allclose(mine, ref_m.reshape(-1, 3), rtol=2e-5 if ref_m.dtype == np.float32 else 1e-12)
