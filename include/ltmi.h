@@ -198,6 +198,19 @@ int ltmi_repair_pixels(int device, void *buf, int dtype, int64_t n_frames, int64
 int ltmi_byteswap(int device, const void *src, void *dst, int itemsize, int64_t n_items,
                   void *stream);
 
+/* Merlin / Medipix .mib frames decoded on the device.  `src`: DEVICE copy of (part of) a .mib file starting
+ * at a frame header; frame f = src + f * frame_stride: `header_bytes` of ASCII header, then the payload.
+ * kind 'u' (bits 8 / 16 / 32): big-endian unsigned integers -> native LTMI_U8 / U16 / U32.
+ * kind 'r' (bits 1 / 6 / 12 / 24, the detector's raw "R64" words): -> LTMI_U8 / U8 / U16 / U32 (24 bit
+ * also LTMI_F32, exact); `quad` != 0: raw rows of a 2x2 detector ([chip 4 | chip 3 | chip 2 | chip 1],
+ * chips 3 / 4 rotated by 180 degrees) assembled into height x width frames.  dst: (n_frames, height, width)
+ * contiguous, `dst_dtype` must be the dtype named above.  Replaces MIBDecoder and its numba decoders
+ * decode_r{1,6,12,24}_swap / decode_r{1,6,12}_swap_2x2 plus the per-row read ranges that feed them
+ * (src/libertem/io/dataset/mib.py:224-398, 401-735), which the reference runs on the host per tile. */
+int ltmi_mib_decode(int device, const void *src, int64_t frame_stride, int64_t header_bytes, int kind,
+                    int bits, int quad, int64_t n_frames, int height, int width, void *dst,
+                    int dst_dtype, void *stream);
+
 /* Centre-of-mass post-processing on a 2D scan of ny x nx positions: from the rows (sum, sum*y, sum*x)
  * of the 3-mask product to the shift field and its derived maps, float64.  Replaces the NumPy chain
  * center_shifts -> apply_correction -> magnitude / divergence / curl_2d of src/libertem/udf/com.py:

@@ -30,7 +30,7 @@ EXPORTS = (
     'ltmi_version', 'ltmi_last_error', 'ltmi_device_count', 'ltmi_device_info',
     'ltmi_masks_create_dense', 'ltmi_masks_create_csr', 'ltmi_masks_destroy', 'ltmi_masks_kind',
     'ltmi_apply_masks', 'ltmi_apply_masks_rows', 'ltmi_apply_masks_shifted', 'ltmi_apply_masks_shifted_host', 'ltmi_sum_frames_workspace', 'ltmi_sum_frames', 'ltmi_sum_sig',
-    'ltmi_axpy', 'ltmi_add2d', 'ltmi_gather_rows', 'ltmi_host_device_pointer', 'ltmi_correct', 'ltmi_repair_pixels', 'ltmi_byteswap', 'ltmi_com_fields', 'ltmi_fft_plan_create',
+    'ltmi_axpy', 'ltmi_add2d', 'ltmi_gather_rows', 'ltmi_host_device_pointer', 'ltmi_correct', 'ltmi_repair_pixels', 'ltmi_byteswap', 'ltmi_mib_decode', 'ltmi_com_fields', 'ltmi_fft_plan_create',
     'ltmi_fft_plan_destroy', 'ltmi_crystallinity', 'ltmi_crystallinity_corrected',
     'ltmi_masks_set_tuning',
     'ltmi_masks_last_kernel', 'ltmi_comm_unique_id', 'ltmi_comm_create', 'ltmi_comm_destroy',
@@ -119,6 +119,7 @@ def lib():
         L.ltmi_correct.argtypes = [i32, vp, i32, i64, i64, i64, vp, vp, vp, i32, i64, vp]
         L.ltmi_repair_pixels.argtypes = [i32, vp, i32, i64, i64, vp, vp, vp, i32, i32, vp]
         L.ltmi_byteswap.argtypes = [i32, vp, vp, i32, i64, vp]
+        L.ltmi_mib_decode.argtypes = [i32, vp, i64, i64, i32, i32, i32, i64, i32, i32, vp, i32, vp]
         L.ltmi_com_fields.argtypes = [i32, vp, i64, i32, i32, ctypes.c_double, ctypes.c_double, vp, vp,
                                       vp, vp, vp, vp, vp]
         L.ltmi_fft_plan_create.argtypes = [i32, i32, i32, i32, c.POINTER(vp)]
@@ -403,6 +404,15 @@ def byteswap(device, src_ptr, dst_ptr, itemsize, n_items, stream=None):
     check(lib().ltmi_byteswap(
         int(device), src_ptr, dst_ptr, int(itemsize), int(n_items),
         stream if isinstance(stream, int) else _stream_ptr(stream)), 'ltmi_byteswap')
+
+
+def mib_decode(device, src_ptr, frame_stride, header_bytes, kind, bits, quad, n_frames, height, width,
+               dst_ptr, dst_dtype, stream=None):
+    """Frames of a .mib file (device copy of the file bytes) -> (n_frames, height, width) of `dst_dtype`."""
+    check(lib().ltmi_mib_decode(
+        int(device), src_ptr, int(frame_stride), int(header_bytes), ord(kind), int(bits), int(bool(quad)),
+        int(n_frames), int(height), int(width), dst_ptr, dtype_code(dst_dtype),
+        stream if isinstance(stream, int) else _stream_ptr(stream)), 'ltmi_mib_decode')
 
 
 def com_fields(device, raw_ptr, ld_raw, ny, nx, ref_y, ref_x, transform, out_y, out_x, out_mag=None,

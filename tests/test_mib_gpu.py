@@ -1,0 +1,173 @@
+"""
+Merlin .mib files on the GPU (-m gpu): `ltmi_mib_decode` through the C ABI against the oracle
+(oracle/mib.py) and the golden vectors the REAL reference's MIBDataSet produced from the same files
+(tests/golden/mib.npz), then MIBDataSet end to end (frames, SumSigUDF, ApplyMasksUDF, ROI).
+Integer work: bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import recipes
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from libertem_amd.api import Context
+    assert torch.cuda.is_available()
+    c = Context.make_with('hip', gpus=0)
+    yield c
+    c.close()
+
+
+def _golden(golden_dir):
+    return np.load(os.path.join(golden_dir, 'mib.npz'))
+
+
+def _write(tmp_path, case):
+    frames, files, hdr = recipes.make_mib_case(case)
+    d = tmp_path / case['name']
+    d.mkdir()
+    for fn, blob in files.items():
+        (d / fn).write_bytes(blob)
+    (d / (case['name'] + '.hdr')).write_text(hdr)
+    return frames, files, str(d / (case['name'] + '.hdr'))
+
+
+@pytest.mark.parametrize('case', recipes.MIB_CASES, ids=lambda c: c['name'])
+def test_decode_kernel_vs_oracle(case):
+    """one file's bytes on the device -> frames, through the C ABI"""
+    from libertem_amd import hip
+    from libertem_amd.common.hiparray import HipArray
+    from libertem_amd.io.dataset.mib import parse_frame_header
+    from oracle import mib as omib
+    frames, files, _ = recipes.make_mib_case(case)
+    name, blob = sorted(files.items())[0]
+    f = parse_frame_header(blob[:1024], len(blob))
+    assert f == {**f, **{k: v for k, v in omib.parse_header(blob[:1024], len(blob)).items()}}
+    h, w = f['image_size']
+    stride = f['header_size_bytes'] + f['image_size_bytes']
+    n = f['num_images']
+    ref = np.stack([omib.decode_frame(blob[i * stride + f['header_size_bytes']:(i + 1) * stride],
+                                      omib.parse_header(blob[:1024], len(blob))) for i in range(n)])
+    quad = f['mib_kind'] == 'r' and f['num_chips'] > 1
+    storages = [f['storage_dtype']] + ([np.dtype('uint32')] if f['bits_per_pixel'] == 24 else [])
+    for storage in storages:
+        for shift in (0, 3):                       # file bytes at an odd device address as well
+            raw = torch.zeros(len(blob) + 16, dtype=torch.uint8, device='cuda:0')
+            raw[shift:shift + len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
+            out = HipArray.empty((n, h, w), storage, 0)
+            hip.mib_decode(0, raw.data_ptr() + shift, stride, f['header_size_bytes'], f['mib_kind'],
+                           f['bits_per_pixel'], quad, n, h, w, out.data_ptr(), storage)
+            got = out.cpu()
+            assert got.dtype == storage
+            assert np.array_equal(got.astype(np.uint32), ref), (case['name'], storage, shift)
+
+
+def test_decode_kernel_refuses_what_is_not_a_format():
+    from libertem_amd import hip
+    from libertem_amd.common.hiparray import HipArray
+    raw = torch.zeros(4096, dtype=torch.uint8, device='cuda:0')
+    out = HipArray.empty((1, 8, 64), np.uint8, 0)
+    with pytest.raises(ValueError, match='not a .mib format'):
+        hip.mib_decode(0, raw.data_ptr(), 1024, 384, 'r', 7, False, 1, 8, 64, out.data_ptr(), np.uint8)
+    with pytest.raises(ValueError, match='decode to uint16'):
+        hip.mib_decode(0, raw.data_ptr(), 2048, 384, 'r', 12, False, 1, 8, 64, out.data_ptr(), np.uint8)
+    with pytest.raises(ValueError, match='whole 64-bit words'):
+        hip.mib_decode(0, raw.data_ptr(), 1024, 384, 'r', 1, False, 1, 8, 32, out.data_ptr(), np.uint8)
+    with pytest.raises(ValueError, match='exceed the frame stride'):
+        hip.mib_decode(0, raw.data_ptr(), 500, 384, 'r', 6, False, 1, 8, 64, out.data_ptr(), np.uint8)
+
+
+@pytest.mark.parametrize('case', recipes.MIB_CASES, ids=lambda c: c['name'])
+def test_dataset_vs_reference_golden(ctx, golden_dir, tmp_path, case):
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd.udf.sumsigudf import SumSigUDF
+    from libertem_amd.udf.raw import PickUDF
+    g = _golden(golden_dir)
+    name = case['name']
+    frames, files, hdr_path = _write(tmp_path, case)
+    ds = ctx.load('mib', path=hdr_path, sync_offset=case.get('sync_offset', 0))
+    assert tuple(ds.shape) == tuple(case['nav']) + tuple(case['sig'])
+    assert str(np.dtype(ds.dtype)) == str(np.dtype(str(g[name + '__dtype'])).newbyteorder('='))
+    assert ds.is_device_resident
+    ref_frames = g[name + '__frames']
+    roi = np.ones(tuple(case['nav']), dtype=bool)
+    picked = ctx.run_udf(dataset=ds, udf=PickUDF(), roi=roi)['intensity'].data
+    if case['bits'] == 24:
+        # the reference reads 24-bit pixels into its declared uint16 and wraps; here they are exact
+        assert np.array_equal(np.asarray(picked).astype(np.uint32).astype(np.uint16).reshape(
+            ref_frames.shape), ref_frames)
+    else:
+        assert np.array_equal(np.asarray(picked).reshape(ref_frames.shape).astype(ref_frames.dtype),
+                              ref_frames)
+    sums = ctx.run_udf(dataset=ds, udf=SumSigUDF())['intensity'].data
+    ref_s = g[name + '__sumsig']
+    assert sums.dtype == ref_s.dtype and np.allclose(sums, ref_s, rtol=1e-6)
+    rng = np.random.default_rng(case['seed'] + 5000)
+    masks = rng.random((3,) + tuple(case['sig'])).astype(np.float32)
+    res = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda: masks))['intensity'].data
+    ref_m = g[name + '__masks']
+    assert res.dtype == ref_m.dtype, (res.dtype, ref_m.dtype)
+    tol = 1e-5 if ref_m.dtype == np.float32 else 1e-12
+    assert np.allclose(res, ref_m, rtol=tol, atol=tol * np.abs(ref_m).max())
+    # a region of interest reads the resident frames in place
+    roi = np.zeros(tuple(case['nav']), dtype=bool)
+    roi.reshape(-1)[::2] = True
+    res_roi = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda: masks), roi=roi)
+    assert np.allclose(res_roi['intensity'].raw_data, ref_m[roi], rtol=tol,
+                       atol=tol * np.abs(ref_m).max())
+
+
+def test_dataset_parameters_like_the_reference(ctx, tmp_path):
+    from libertem_amd.io.dataset.mib import MIBDataSet
+    from libertem_amd.io.dataset.base import DataSetException
+    case = [c for c in recipes.MIB_CASES if c['name'] == 'r12'][0]
+    frames, files, hdr_path = _write(tmp_path, case)
+    mib_path = os.path.join(os.path.dirname(hdr_path), sorted(files)[0])
+    with pytest.raises(ValueError, match='either nav_shape needs to be passed'):
+        MIBDataSet(path=mib_path)
+    # a .mib path + nav_shape; other sig_shape with the same number of pixels; 1D / 3D nav
+    ds = ctx.load('mib', path=mib_path, nav_shape=(6,), sig_shape=(64, 32))
+    assert tuple(ds.shape) == (6, 64, 32)
+    with pytest.raises(DataSetException, match='sig_shape must be of size'):
+        ctx.load('mib', path=mib_path, nav_shape=(6,), sig_shape=(64, 33))
+    with pytest.raises(DataSetException, match='offset should be in'):
+        ctx.load('mib', path=mib_path, nav_shape=(2, 3), sync_offset=6)
+    d = MIBDataSet.detect_params(hdr_path)
+    assert d['parameters']['nav_shape'] == (2, 3) and d['parameters']['sig_shape'] == (32, 64)
+    assert d['info']['image_count'] == 6
+    assert MIBDataSet.detect_params(mib_path)['parameters']['nav_shape'] == (6,)
+    assert MIBDataSet.get_supported_extensions() == {'mib', 'hdr'}
+    diag = {x['name']: x['value'] for x in ctx.load('mib', path=hdr_path).get_diagnostics()}
+    assert diag == {'Bits per pixel': '12', 'Data kind': 'r', 'Layout': '(1, 1)'}
+    # more scan positions than frames: the rest is blank, as in the reference
+    ds = ctx.load('mib', path=hdr_path, nav_shape=(2, 4))
+    from libertem_amd.udf.sumsigudf import SumSigUDF
+    s = ctx.run_udf(dataset=ds, udf=SumSigUDF())['intensity'].data.reshape(-1)
+    assert np.array_equal(s[:6], frames.reshape(6, -1).sum(axis=1).astype(np.float32))
+    assert np.all(s[6:] == 0)
+
+
+def test_many_frames_over_several_chunks(ctx, tmp_path):
+    """chunked copy + decode (two buffers in flight), files that end inside a chunk"""
+    from libertem_amd.io.dataset.mib import MIBDataSet
+    from libertem_amd.udf.sumsigudf import SumSigUDF
+    case = dict(name='chunks', kind='r', bits=12, sig=(64, 64), frames=(37, 50, 13), nav=(10, 10),
+                seed=4242)
+    frames, files, hdr_path = _write(tmp_path, case)
+    old = MIBDataSet.CHUNK_BYTES
+    MIBDataSet.CHUNK_BYTES = 11 * (384 + 64 * 64 * 2)          # 11 frames per step
+    try:
+        ds = ctx.load('mib', path=hdr_path)
+    finally:
+        MIBDataSet.CHUNK_BYTES = old
+    assert ds.decode_bytes == 100 * (384 + 64 * 64 * 2) and ds.decode_seconds > 0
+    s = ctx.run_udf(dataset=ds, udf=SumSigUDF())['intensity'].data.reshape(-1)
+    assert np.array_equal(s, frames.reshape(100, -1).sum(axis=1).astype(np.float32))
+    got = ds.data.cpu().reshape(frames.shape)
+    assert np.array_equal(got, frames)
