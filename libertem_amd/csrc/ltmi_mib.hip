@@ -107,6 +107,90 @@ k_mib_decode(const unsigned char *__restrict__ src, int64_t frame_stride, unsign
     }
 }
 
+// The same with 16 bytes of OUTPUT per thread (one dwordx4 store per lane, a wave writes 1 KiB in a row):
+// the common shapes -- payload a multiple of 16 bytes, an even number of words per (chip) row.
+typedef uint64_t u64x2_u __attribute__((ext_vector_type(2), aligned(1)));
+
+template <int MODE, bool QUAD>
+__global__ void __launch_bounds__(256)
+k_mib_decode16(const unsigned char *__restrict__ src, int64_t frame_stride, unsigned char *__restrict__ dst,
+               int64_t n_frames, int cpf, int blocks_per_frame, int wpf24, int height, int width) {
+    const unsigned frame = blockIdx.x / (unsigned)blocks_per_frame;
+    const int c = (int)(blockIdx.x - frame * (unsigned)blocks_per_frame) * 256 + (int)threadIdx.x;
+    if (frame >= n_frames || c >= cpf) return;
+    const unsigned char *in = src + (int64_t)frame * frame_stride;
+    constexpr int OUT = MODE == M_U8 || MODE == M_R1 || MODE == M_R6 ? 1
+                        : MODE == M_U16 || MODE == M_R12 ? 2 : 4;
+    const int64_t n_px = (int64_t)height * width;
+    unsigned char *frame_out = dst + (int64_t)frame * n_px * OUT;
+    constexpr int PPC = 16 / OUT;                           // pixels per 16-byte chunk of output
+
+    if (MODE == M_R1) {
+        // chunk c: pixels 16 q ... 16 q + 15 of word k
+        const int k = c >> 2, q = c & 3;
+        int64_t px0 = (int64_t)k * 64 + 16 * q;
+        uint64_t w = __builtin_bswap64(*(const u64_u *)(in + (int64_t)k * 8));
+        if (QUAD) {
+            const int xh = width / 2, wps = xh / 64;
+            const int j = k % wps, seg = (k / wps) & 3, r = k / (4 * wps);
+            const bool flip = seg < 2;
+            const int y = flip ? height - 1 - r : r;
+            const int x_half = (seg == 3 || seg == 1) ? 0 : xh;
+            if (flip) w = __builtin_bitreverse64(w);
+            px0 = (int64_t)y * width + x_half + (flip ? xh - (j + 1) * 64 : j * 64) + 16 * q;
+        }
+        const uint32_t bits16 = (uint32_t)(w >> (16 * q)) & 0xFFFFu;
+        u32x4_u o;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            o[d] = (((bits16 >> (4 * d)) & 0xFu) * 0x00204081u) & 0x01010101u;
+        *(u32x4_u *)(frame_out + px0) = o;
+        return;
+    }
+    if (MODE == M_R24 || MODE == M_R24F) {
+        const uint64_t hi = __builtin_bswap64(*(const u64_u *)(in + (int64_t)c * 8));
+        const uint64_t lo = __builtin_bswap64(*(const u64_u *)(in + (int64_t)(c + wpf24) * 8));
+        uint32_t v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            v[t] = ((uint32_t)((hi >> (16 * t)) & 0xFFFFu) << 12) + (uint32_t)((lo >> (16 * t)) & 0xFFFFu);
+        if (MODE == M_R24) {
+            u32x4_u o = {v[0], v[1], v[2], v[3]};
+            *(u32x4_u *)(frame_out + (int64_t)c * 16) = o;
+        } else {
+            f32x4_u o = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+            *(f32x4_u *)(frame_out + (int64_t)c * 16) = o;
+        }
+        return;
+    }
+    // 16 bytes in -> 16 bytes out (two words)
+    const u64x2_u v = *(const u64x2_u *)(in + (int64_t)c * 16);
+    u64x2_u o;
+    int64_t px0 = (int64_t)c * PPC;
+    if (MODE == M_U8) { o = v; }
+    else if (MODE == M_U16) { o[0] = swap_lanes16(v[0]); o[1] = swap_lanes16(v[1]); }
+    else if (MODE == M_U32) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            o[i] = ((uint64_t)__builtin_bswap32((uint32_t)(v[i] >> 32)) << 32) |
+                   __builtin_bswap32((uint32_t)v[i]);
+    } else {                                                // M_R6 / M_R12
+        bool flip = false;
+        if (QUAD) {
+            const int xh = width / 2, cps = xh / PPC;       // chunks per chip row
+            const int j = c % cps, seg = (c / cps) & 3, r = c / (4 * cps);
+            flip = seg < 2;
+            const int y = flip ? height - 1 - r : r;
+            const int x_half = (seg == 3 || seg == 1) ? 0 : xh;
+            px0 = (int64_t)y * width + x_half + (flip ? xh - (j + 1) * PPC : j * PPC);
+        }
+        if (!flip) { o[0] = __builtin_bswap64(v[0]); o[1] = __builtin_bswap64(v[1]); }
+        else if (MODE == M_R6) { o[0] = v[1]; o[1] = v[0]; }
+        else { o[0] = swap_lanes16(v[1]); o[1] = swap_lanes16(v[0]); }
+    }
+    *(u64x2_u *)(frame_out + px0 * OUT) = o;
+}
+
 }  // namespace
 
 extern "C" int ltmi_mib_decode(int device, const void *src, int64_t frame_stride, int64_t header_bytes,
@@ -157,6 +241,42 @@ extern "C" int ltmi_mib_decode(int device, const void *src, int64_t frame_stride
     }
     LTMI_HIP(hipSetDevice(device));
     hipStream_t stream = (hipStream_t)stream_;
+    // 16 bytes of output per thread when the shape allows (env LTMI_MIB_WORDS=1: the per-word kernel)
+    static const bool words_only = getenv("LTMI_MIB_WORDS") != nullptr;
+    const int ppc = 16 / ltmi::dtype_size(want);
+    const bool wide = !words_only && (payload % 16 == 0 || mode == M_R1) &&
+                      (!quad || mode == M_R1 || ((width / 2) % ppc == 0));
+    if (wide) {
+        const int64_t chunks = mode == M_R1 ? payload / 2 : (mode == M_R24 || mode == M_R24F) ? payload / 16
+                                                                                             : payload / 16;
+        if (chunks > (1ll << 30)) LTMI_FAIL(LTMI_E_SHAPE, "ltmi_mib_decode: frame too large");
+        const int cpf = (int)chunks, bpf = (cpf + 255) / 256, wpf24 = (int)(payload / 16);
+        const unsigned char *s = (const unsigned char *)src + header_bytes;
+        const int64_t out_frame = n_px * ltmi::dtype_size(want);
+        const int64_t max_frames = std::max<int64_t>(1, (int64_t)0x7FFFFFFF / bpf);
+        for (int64_t f0 = 0; f0 < n_frames; f0 += max_frames) {
+            const int64_t nf = std::min(max_frames, n_frames - f0);
+            dim3 grid((unsigned)(nf * bpf));
+            const unsigned char *sp = s + f0 * frame_stride;
+            unsigned char *dp = (unsigned char *)dst + f0 * out_frame;
+#define LTMI_MIB_LAUNCH16(MODE, QUAD)                                                               \
+            hipLaunchKernelGGL((k_mib_decode16<MODE, QUAD>), grid, dim3(256), 0, stream, sp,        \
+                               frame_stride, dp, nf, cpf, bpf, wpf24, height, width)
+            switch (mode) {
+                case M_U8: LTMI_MIB_LAUNCH16(M_U8, false); break;
+                case M_U16: LTMI_MIB_LAUNCH16(M_U16, false); break;
+                case M_U32: LTMI_MIB_LAUNCH16(M_U32, false); break;
+                case M_R1: if (quad) LTMI_MIB_LAUNCH16(M_R1, true); else LTMI_MIB_LAUNCH16(M_R1, false); break;
+                case M_R6: if (quad) LTMI_MIB_LAUNCH16(M_R6, true); else LTMI_MIB_LAUNCH16(M_R6, false); break;
+                case M_R12: if (quad) LTMI_MIB_LAUNCH16(M_R12, true); else LTMI_MIB_LAUNCH16(M_R12, false); break;
+                case M_R24: LTMI_MIB_LAUNCH16(M_R24, false); break;
+                default: LTMI_MIB_LAUNCH16(M_R24F, false); break;
+            }
+#undef LTMI_MIB_LAUNCH16
+            LTMI_HIP(hipGetLastError());
+        }
+        return LTMI_OK;
+    }
     const int64_t words = (mode == M_R24 || mode == M_R24F) ? payload / 16 : (payload + 7) / 8;
     if (words > (1ll << 30)) LTMI_FAIL(LTMI_E_SHAPE, "ltmi_mib_decode: frame too large");
     const int wpf = (int)words, bpf = (wpf + 255) / 256;

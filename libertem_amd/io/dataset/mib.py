@@ -154,6 +154,7 @@ class MIBDataSet(MemoryDataSet):
         one process per GPU: decode and hold only this rank's block of the first nav axis
     """
     CHUNK_BYTES = 256 << 20          # file bytes per copy + decode step (two in flight)
+    COPY_THREADS = 8
 
     def __init__(self, path, tileshape=None, scan_size=None, disable_glob=False, nav_shape=None,
                  sig_shape=None, sync_offset=0, io_backend=None, num_partitions=None, shard=None):
@@ -283,6 +284,8 @@ class MIBDataSet(MemoryDataSet):
             copy_stream.wait_stream(torch.cuda.current_stream(device))     # (the zero fill)
             starts = np.cumsum([0] + [fl['num_images'] for _, fl in self._files_sorted])
             maps = {}
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(self.COPY_THREADS)
             for i, c0 in enumerate(range(g0, g1, chunk)):
                 c1 = min(g1, c0 + chunk)
                 slot = i & 1
@@ -299,8 +302,8 @@ class MIBDataSet(MemoryDataSet):
                     if fi not in maps:
                         maps.clear()                                       # one mapping at a time
                         maps[fi] = np.memmap(fn, dtype=np.uint8, mode='r')
-                    host[(g - c0) * stride:(g - c0 + b - a) * stride] = \
-                        maps[fi][a * stride:b * stride]
+                    self._host_copy(pool, host, (g - c0) * stride, maps[fi], a * stride,
+                                    (b - a) * stride)
                     g += b - a
                     fi += 1
                 nb = (c1 - c0) * stride
@@ -314,10 +317,24 @@ class MIBDataSet(MemoryDataSet):
                     ev.record(copy_stream)
                     free[slot] = ev
             copy_stream.synchronize()
+            pool.shutdown()
         torch.cuda.current_stream(device).synchronize()
         self.decode_seconds = time.perf_counter() - t0
         self.decode_bytes = n_src * stride
         return out
+
+    @staticmethod
+    def _host_copy(pool, dst, dst_off, src, src_off, nbytes, piece=16 << 20):
+        """file mapping -> pinned buffer on several threads (one memcpy stream reads the page cache at
+        ~12 GB/s, a fifth of what the host link takes)"""
+        if nbytes <= piece:
+            dst[dst_off:dst_off + nbytes] = src[src_off:src_off + nbytes]
+            return
+
+        def run(o):
+            n = min(piece, nbytes - o)
+            dst[dst_off + o:dst_off + o + n] = src[src_off + o:src_off + o + n]
+        list(pool.map(run, range(0, nbytes, piece)))
 
     # --- the reference's descriptive surface --------------------------------------------------------
     @property
