@@ -171,3 +171,18 @@ def test_many_frames_over_several_chunks(ctx, tmp_path):
     assert np.array_equal(s, frames.reshape(100, -1).sum(axis=1).astype(np.float32))
     got = ds.data.cpu().reshape(frames.shape)
     assert np.array_equal(got, frames)
+
+
+def test_one_rank_decodes_only_its_block(ctx, tmp_path):
+    """shard=(rank, world): one process per GPU holds its block of the first nav axis (sync offset applied
+    to the whole series first)"""
+    case = [c for c in recipes.MIB_CASES if c['name'] == 'r12_offset'][0]
+    frames, files, hdr_path = _write(tmp_path, case)
+    for rank in (0, 1):
+        ds = ctx.load('mib', path=hdr_path, sync_offset=2, shard=(rank, 2))
+        assert tuple(ds.shape) == (2, 3, 32, 64) and ds.shard == (rank, 2)
+        local = ds.data.cpu().reshape(3, 32, 64)
+        expect = np.zeros((6, 32, 64), dtype=np.uint16)
+        expect[:5] = frames[2:7]
+        assert np.array_equal(local, expect[rank * 3:rank * 3 + 3])
+        assert ds.decode_bytes == (3 if rank == 0 else 2) * (384 + 32 * 64 * 2)
