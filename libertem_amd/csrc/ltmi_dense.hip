@@ -329,7 +329,6 @@ k_dense_mfma(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
 //   * two accumulation levels (see acc2 in the kernel): the float32 chains stay <= 1024 pixels long.
 constexpr int V2_ROWS = 16;                         // frames per MFMA tile
 constexpr int V2_SUB_BYTES = 256;                   // bytes of a row per sub-chunk
-constexpr int V2_ASLOT = V2_ROWS * V2_SUB_BYTES;    // 4 KiB per frame tile and ring slot
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *glb_ptr_t;
@@ -467,8 +466,14 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
     using CFG = LdsCfg<NG, NE, TILES>;
     constexpr int WAVES = CFG::WAVES, RING = CFG::RING, KB = CFG::KB, BSLOT = CFG::BSLOT;
     constexpr int ROWS = CFG::ROWS, ASLOT = CFG::ASLOT;
-    constexpr int ND = 4 * TILES;                       // DMA instructions per sub-chunk (4 rows each)
-    constexpr int SPX = V2_SUB_BYTES / (int)sizeof(T);  // pixels per sub-chunk
+    // bytes of a frame row per sub-chunk: 256, or 128 for 1-byte pixels against 128-pixel mask slots
+    // (a sub-chunk must not straddle mask slots); rows sit SUBB bytes apart in a ring slot
+    constexpr int SUBB = (sizeof(T) == 1 && KB < V2_SUB_BYTES) ? 128 : V2_SUB_BYTES;
+    constexpr int PPR = SUBB / 16;                      // 16-byte pieces per row
+    constexpr int RPI = 64 / PPR;                       // rows one DMA instruction (64 x 16 B) covers
+    constexpr int TILE_BYTES = V2_ROWS * SUBB;          // one 16-frame tile of a ring slot
+    constexpr int ND = (V2_ROWS / RPI) * TILES;         // DMA instructions per sub-chunk
+    constexpr int SPX = SUBB / (int)sizeof(T);          // pixels per sub-chunk
     static_assert(SPX <= KB && KB % SPX == 0, "a sub-chunk must not straddle mask slots");
     constexpr int PER = KB / SPX;                       // sub-chunks per mask slot
     constexpr int BLKS = SPX / 32;                      // MFMA pixel blocks per sub-chunk (2/4/8)
@@ -545,7 +550,7 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             acc_e[tl][c] = acc_e2[tl][c] = f32x2{0.f, 0.f};
 
     // lane-constant parts of the fragment addresses
-    const int a_lane = m * V2_SUB_BYTES;                 // bytes inside a frame tile of a ring slot
+    const int a_lane = m * SUBB;                         // bytes inside a frame tile of a ring slot
     const int b_lane = m * KB;                           // floats inside a group of a mask slot
     auto b_unit = [&](int blk_in_slot, int h) {          // swizzled 16-B unit of (blk, h) for this lane
         return ((kg * (KB / 16) + blk_in_slot * 2 + h) ^ m) << 2;
@@ -555,9 +560,9 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
         const unsigned char *src[ND];
 #pragma unroll
         for (int t = 0; t < ND; ++t) {
-            const int r = 4 * t + (lane >> 4);
+            const int r = RPI * t + lane / PPR;
             const int64_t f = src_frame_of(r);          // (clamped; such results are discarded)
-            const int piece = (lane & 15) ^ (r & 15);
+            const int piece = (lane & (PPR - 1)) ^ (r & (PPR - 1));
             src[t] = (const unsigned char *)(tile + f * ld) + piece * 16;
         }
         const unsigned char *bsrc = (const unsigned char *)img_t + wave * BPW + lane * 16;
@@ -567,7 +572,7 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             if (ABL >= 2) return;
             const int sc = min(s, S1 - 1);
             unsigned char *dst = a_base + slot * (WAVES * ASLOT);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[t] + (int64_t)sc * V2_SUB_BYTES),
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[t] + (int64_t)sc * SUBB),
                                              (lds_ptr_t)(dst + t * 1024), 16, 0, 2 /*nt*/);
         };
         auto issue_b = [&](int gidx) {                  // mask slot k_begin + gidx -> LDS slot gidx & 1
@@ -620,7 +625,7 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             const unsigned char *aslot = a_base + slot * (WAVES * ASLOT) + a_lane;
             const float *bslot = (const float *)(b_base + bsl * BSLOT) + b_lane;
             auto rd_a = [&](int tl, int blk) {
-                const unsigned char *at = aslot + tl * V2_ASLOT;
+                const unsigned char *at = aslot + tl * TILE_BYTES;
                 const int u = blk * 4 + kg;             // 8-pixel unit of this lane inside the sub-chunk
                 if constexpr (sizeof(T) == 2) {
                     return *(const typename TR::raw_t *)(at + ((u ^ m) << 4));
@@ -630,7 +635,7 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                     r.b = *(const f32x4 *)(at + (((2 * u + 1) ^ m) << 4));
                     return r;
                 } else {
-                    return *(const typename TR::raw_t *)(at + (((u >> 1) ^ m) << 4) + (u & 1) * 8);
+                    return *(const typename TR::raw_t *)(at + (((u >> 1) ^ (m & (PPR - 1))) << 4) + (u & 1) * 8);
                 }
             };
             auto rd_b = [&](int blk, int g, int h) {
@@ -1456,7 +1461,6 @@ static int launch_lds_extras(ltmi_masks *m, const T *tile, int64_t n_frames, int
 
 template <typename T>
 static bool lds_kernel_applies(const ltmi_masks *m) {
-    if (sizeof(T) == 1 && m->ng > 1) return false;            // 256-px sub-chunks need NG == 1
     return m->n_px >= (m->ng == 1 ? KC : 128);
 }
 
@@ -1464,37 +1468,32 @@ template <typename T>
 static int launch_lds(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
                       int64_t ld_out, int accumulate, hipStream_t stream) {
     if (m->ng == 1) {
-        if constexpr (sizeof(T) > 1) {
-            // at most 4 columns (CoM: 3, single-mask analyses: 1 or 2): all of them on the VALU -- a
-            // 16-column MFMA tile would be >= 75 % padding that still costs matrix-pipe power
-            if (m->img3 && m->ng3 == 0 && m->tune_ksplit_ring != 33) {
-                if (m->ne3 == 2)
-                    return launch_lds_extras<T, 0, 2>(m, tile, n_frames, ld, out, ld_out, accumulate,
-                                                      stream);
-                return launch_lds_extras<T, 0, 4>(m, tile, n_frames, ld, out, ld_out, accumulate,
+        // at most 4 columns (CoM: 3, single-mask analyses: 1 or 2): all of them on the VALU -- a
+        // 16-column MFMA tile would be >= 75 % padding that still costs matrix-pipe power
+        if (m->img3 && m->ng3 == 0 && m->tune_ksplit_ring != 33) {
+            if (m->ne3 == 2)
+                return launch_lds_extras<T, 0, 2>(m, tile, n_frames, ld, out, ld_out, accumulate,
                                                   stream);
-            }
+            return launch_lds_extras<T, 0, 4>(m, tile, n_frames, ld, out, ld_out, accumulate,
+                                              stream);
         }
         return launch_lds_ng<T, 1>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
     }
-    if constexpr (sizeof(T) > 1) {
-        if (m->img3 && m->ng3 > 0 && m->tune_ksplit_ring != 33) {   // 33: force the padded-group kernel (bench)
+    if (m->img3 && m->ng3 > 0 && m->tune_ksplit_ring != 33) {   // 33: force the padded-group kernel (bench)
 #define LTMI_EXTRAS(NG_, NE_)                                                                     \
     if (m->ng3 == NG_ && m->ne3 == NE_)                                                           \
         return launch_lds_extras<T, NG_, NE_>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
-            LTMI_EXTRAS(1, 2)
-            LTMI_EXTRAS(2, 2)
-            LTMI_EXTRAS(2, 4)
-            LTMI_EXTRAS(3, 0)
-            LTMI_EXTRAS(3, 2)
-            LTMI_EXTRAS(3, 4)
+        LTMI_EXTRAS(1, 2)
+        LTMI_EXTRAS(2, 2)
+        LTMI_EXTRAS(2, 4)
+        LTMI_EXTRAS(3, 0)
+        LTMI_EXTRAS(3, 2)
+        LTMI_EXTRAS(3, 4)
 #undef LTMI_EXTRAS
-        }
-        if (m->ng == 2)
-            return launch_lds_ng<T, 2>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
-        return launch_lds_ng<T, 4>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
     }
-    LTMI_FAIL(LTMI_E_DTYPE, "k_dense_lds: 1-byte pixels need a single column group");
+    if (m->ng == 2)
+        return launch_lds_ng<T, 2>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+    return launch_lds_ng<T, 4>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
 }
 
 // ---- shifted masks through the MFMA kernel -----------------------------------------------------------

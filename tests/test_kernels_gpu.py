@@ -138,10 +138,7 @@ def test_lds_dma_kernel_all_widths(hip, tile_dtype, shape, ksplit):
         data = (rng.random((n_frames, n_px)) - 0.3).astype(dt)
     masks = (rng.random((n_masks, n_px)) - 0.25).astype(np.float32)
     res, kern = _apply(hip, data, masks, np.float32, tuning=dict(mt=0, waves=30, ksplit=ksplit))
-    if dt.itemsize == 1 and 16 < n_masks <= 64:
-        assert 'k_dense_mfma<' in kern, kern       # 1-byte pixels with several groups: direct-load kernel
-    else:
-        assert 'k_dense_lds' in kern, kern
+    assert 'k_dense_lds' in kern, kern          # (1-byte pixels with several groups: 128-byte sub-chunks)
     if n_masks > 64:
         assert kern.startswith('2 column blocks'), kern   # 64 + the rest, each with its own tile width
     ref = _ref64(data, masks)
@@ -220,7 +217,9 @@ def test_rows_of_any_alignment_through_lds_dma(hip, tile_dtype, result_dtype, n_
     (512 * 512, 'uint16', 3),       # <= 4 columns: the VALU-only variant (CoM)
     (1024 * 1024, 'float32', 3),
     (1024 * 1024, 'float32', 50),   # 3 groups + 2 VALU columns (the radial Fourier default)
-    (512 * 512, 'uint8', 20),       # 1-byte pixels, two column groups: the direct-load kernel
+    (512 * 512, 'uint8', 20),       # 1-byte pixels, two column groups: 128-byte sub-chunks
+    (512 * 512, 'uint8', 50),       # ... 3 groups + 2 VALU columns
+    (512 * 512, 'uint8', 3),        # ... VALU-only
 ])
 def test_long_rows_keep_float32_accuracy(hip, n_px, tile_dtype, n_masks):
     """All-positive data, large frames, NO split of the pixel axis (what a full partition gets):
@@ -235,7 +234,7 @@ def test_long_rows_keep_float32_accuracy(hip, n_px, tile_dtype, n_masks):
             else rng.random((n_frames, n_px)).astype(dt))
     masks = rng.random((n_masks, n_px)).astype(np.float32)
     res, kern = _apply(hip, data, masks, np.float32, tuning=dict(mt=0, waves=0, ksplit=1))
-    assert ('k_dense_mfma' if dt.itemsize == 1 else 'k_dense_lds') in kern, kern
+    assert 'k_dense_lds' in kern, kern
     assert ',1,1)' in kern.replace(' ', ''), kern                                # grid.y == 1: no K split
     if n_masks <= 4:
         assert 'NG=0+' in kern, kern
