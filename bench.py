@@ -384,6 +384,43 @@ def host_streamed(ctx, torch, hip, rows=64):
             "frac_of_h2d_peak": gbs / peak, "ms_per_run": t * 1e3}
 
 
+def mib_decode(torch, hip, n=16384, reps=10):
+    """Row f2: .mib frames (12-bit raw words, 256 x 256, 384-byte headers) -> uint16 frames, file bytes
+    already in HBM; rate = (payload read + frames written) / kernel time (HIP events on its stream)."""
+    from libertem_amd.common.hiparray import HipArray
+    h = w = 256
+    header, payload = 384, h * w * 2
+    stride = header + payload
+    raw = torch.randint(0, 256, (n * stride,), dtype=torch.uint8, device='cuda')
+    out = HipArray.empty((n, h, w), np.uint16, 0)
+    s = torch.cuda.current_stream()
+
+    def run():
+        hip.mib_decode(0, raw.data_ptr(), stride, header, 'r', 12, False, n, h, w, out.data_ptr(),
+                       np.uint16, stream=s.cuda_stream)
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for _ in range(reps):
+        run()
+    e1.record(s)
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    # spot check of the last frame against the format's definition (big-endian words, pixels of a
+    # word in reverse order)
+    last = raw[(n - 1) * stride + header:(n - 1) * stride + stride].cpu().numpy()
+    expect = last.view('>u2').astype(np.uint16).reshape(-1, 4)[:, ::-1].reshape(h, w)
+    ok = bool(np.array_equal(out.rows(n - 1, n).cpu().reshape(h, w), expect))
+    nbytes = n * (payload + h * w * 2)
+    return {"workload": f"{n} raw 12-bit .mib frames of 256x256 -> uint16 (ltmi_mib_decode)",
+            "kernel": "k_mib_decode16", "avg_launch_ms": ms, "frames_per_s": n / ms * 1e3,
+            "check_last_frame": ok,
+            "roofline": {"bound": "hbm", "achieved": nbytes / ms / 1e6, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": nbytes / ms / 1e6 / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": float(nbytes), "traffic": None}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -569,6 +606,7 @@ def main():
             torch.cuda.empty_cache()
         extra['configs'] = cfgs
         guarded('host_streamed', lambda: host_streamed(ctx, torch, hip))
+        guarded('mib_decode', lambda: mib_decode(torch, hip))
 
     if rank == 0:
         out = {
