@@ -418,7 +418,11 @@ def mib_decode(torch, hip, n=16384, reps=10):
             "check_last_frame": ok,
             "roofline": {"bound": "hbm", "achieved": nbytes / ms / 1e6, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": nbytes / ms / 1e6 / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_launch": float(nbytes), "traffic": None}}
+                         "algorithmic_bytes_per_launch": float(nbytes),
+                         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this launch (profiles/r02_mib.txt):
+                         # 1048586 KiB x 1024 x 2 (gfx950) + 2097152 KiB x 1024
+                         "traffic": 4294988390.4 * n / 16384,
+                         "traffic_source": "profiles/r02_mib.txt"}}
 
 
 def main():
