@@ -413,16 +413,14 @@ def mib_decode(torch, hip, n=16384, reps=10):
     expect = last.view('>u2').astype(np.uint16).reshape(-1, 4)[:, ::-1].reshape(h, w)
     ok = bool(np.array_equal(out.rows(n - 1, n).cpu().reshape(h, w), expect))
     nbytes = n * (payload + h * w * 2)
+    traffic, source = load_traffic('mib_decode', 'k_mib_decode16', n)
     return {"workload": f"{n} raw 12-bit .mib frames of 256x256 -> uint16 (ltmi_mib_decode)",
             "kernel": "k_mib_decode16", "avg_launch_ms": ms, "frames_per_s": n / ms * 1e3,
             "check_last_frame": ok,
             "roofline": {"bound": "hbm", "achieved": nbytes / ms / 1e6, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": nbytes / ms / 1e6 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": float(nbytes),
-                         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this launch (profiles/r02_mib.txt):
-                         # 1048586 KiB x 1024 x 2 (gfx950) + 2097152 KiB x 1024
-                         "traffic": 4294988390.4 * n / 16384,
-                         "traffic_source": "profiles/r02_mib.txt"}}
+                         "traffic": traffic, "traffic_source": source}}
 
 
 def main():
