@@ -271,6 +271,13 @@ class MIBDataSet(MemoryDataSet):
         n_src = max(0, g1 - g0)
         if getattr(executor, '_make_current', None) is not None:
             executor._make_current()
+        need = n * h * w * storage.itemsize
+        free_bytes, _ = torch.cuda.mem_get_info(device)
+        if need + 2 * min(self.CHUNK_BYTES, max(n_src, 1) * stride) > free_bytes:
+            raise DataSetException(
+                f"{n} decoded frames of {h}x{w} {storage} need {need / 2**30:.1f} GiB of HBM, "
+                f"{free_bytes / 2**30:.1f} GiB are free on GPU {device}: load a part of the scan "
+                "(nav_shape + sync_offset) or shard it over several GPUs (shard=(rank, world))")
         t0 = time.perf_counter()
         out = HipArray.empty((n, h, w), storage, device) if n_src == n else \
             HipArray.zeros((n, h, w), storage, device)          # blank frames stay zero

@@ -186,3 +186,12 @@ def test_one_rank_decodes_only_its_block(ctx, tmp_path):
         expect[:5] = frames[2:7]
         assert np.array_equal(local, expect[rank * 3:rank * 3 + 3])
         assert ds.decode_bytes == (3 if rank == 0 else 2) * (384 + 32 * 64 * 2)
+
+
+def test_series_larger_than_hbm_is_refused_with_advice(ctx, tmp_path, monkeypatch):
+    from libertem_amd.io.dataset.base import DataSetException
+    case = [c for c in recipes.MIB_CASES if c['name'] == 'u08'][0]
+    _, _, hdr_path = _write(tmp_path, case)
+    monkeypatch.setattr(torch.cuda, 'mem_get_info', lambda device=None: (1000, 1 << 38))
+    with pytest.raises(DataSetException, match='shard it over several GPUs'):
+        ctx.load('mib', path=hdr_path)
