@@ -16,17 +16,20 @@
 //     both steps and the two pixel numbers of its l>>4.  C4: 3.65 multiply-adds per stored mask
 //     value, but on the matrix pipe and with ONE LDS read per 16 multiply-adds (the SELL kernel
 //     needs an LDS gather per multiply-add and is bound by that).
-//   * a workgroup = 4 waves owns 16*TILES frames (TILES = 2 for 1/2-byte pixels, 1 for float32) and
-//     1024 masks: wave j owns the groups g with g % 4 == j (16 of them -> 16 x TILES accumulator
-//     tiles in registers for the whole sweep; interleaving the groups balances ring stacks, where
-//     the groups touching a pixel chunk are consecutive).  The frames' chunk is copied
-//     global -> LDS by the LDS-DMA (global_load_lds_dwordx4), raw pixel type, double buffered; the
-//     B operand of a step is one ds_read of the pixel type + conversion.
+//   * a workgroup = 16 waves (the whole CU, one workgroup at a time) owns 16*TILES frames and 1024
+//     masks: wave j owns the groups g with g % 16 == j (4 of them -> 4 x TILES accumulator tiles in
+//     registers for the whole sweep; interleaving the groups balances ring stacks, where the groups
+//     touching a pixel chunk are consecutive).  TILES = 2 or 4 for 1/2-byte pixels, 1 or 2 for
+//     float32, chosen per launch (launch_bell): a record's fixed cost -- ring read, gather
+//     addresses, refill -- is paid once for all tiles, so 64 frames per workgroup cost 1.7x of 32,
+//     but small launches need the many short workgroups.  (Round 1 / early round 2: 4 waves x 16
+//     groups, two workgroups per CU, 32 frames: 0.95 ms per 16 384 frames of C4; now 0.84 ms.)
+//     The frames' chunk is copied global -> LDS by the LDS-DMA (global_load_lds_dwordx4), raw pixel
+//     type, double buffered; the B operand of a step is one ds_read of the pixel type + conversion.
 //   * the block records of a wave are ONE linear stream in execution order (chunk, group, step), so
-//     the wave prefetches them through a register ring that runs ahead across group and chunk
-//     boundaries; L2 serves the stream (every workgroup reads the same one).
-//   * two workgroups per CU: the record loads of a wave queue behind its own frame DMA (vmcnt
-//     retires in order) once per chunk, the other workgroup computes meanwhile.
+//     the wave prefetches them through an LDS ring (depth 2 ... 4: what the slabs leave of the
+//     160 KiB) that runs ahead across group and chunk boundaries; L2 serves the stream (every
+//     workgroup reads the same one).
 //
 // Complex masks are stored as 2 real masks (re, im interleaved) -- the result row is the
 // interleaved complex64 row.  Results are float32 sums in a different order than the SELL kernel;
@@ -50,14 +53,14 @@ typedef const __attribute__((address_space(1))) void *b_glb_ptr_t;
 #define BE_P_ 512
 #endif
 #ifndef BE_OCC
-#define BE_OCC 2
+#define BE_OCC 1
 #endif
 constexpr int BE_P = BE_P_;          // pixels per chunk
 #ifndef BE_SETS_
-#define BE_SETS_ 4
+#define BE_SETS_ 16
 #endif
 #ifndef BE_SLOTS_
-#define BE_SLOTS_ 16
+#define BE_SLOTS_ 4
 #endif
 constexpr int BE_SETS = BE_SETS_;    // waves per workgroup = interleaved group sets
 constexpr int BE_SLOTS = BE_SLOTS_;  // groups per wave
@@ -68,7 +71,7 @@ constexpr int BE_PASS = BE_SETS * BE_SLOTS * 16;     // real masks per pass (102
 #ifndef BE_PAD
 #define BE_PAD 0
 #endif
-constexpr int BE_D = BE_D_;          // block records in flight per wave
+constexpr int BE_D_MAX = BE_D_;      // block records in flight per wave, at most (LDS permitting)
 constexpr int BE_REC = 192;          // dwords per block record (64 lanes x 3)
 
 struct BellImage {
@@ -95,9 +98,9 @@ template <int I, int N, typename F> __device__ __forceinline__ void bstatic_for(
     }
 }
 
-template <typename T> struct BeCfg {
+template <typename T, int TL> struct BeCfg {
     static constexpr int SZ = (int)sizeof(T);
-    static constexpr int TILES = SZ == 4 ? 1 : 2;          // 16-frame tiles per workgroup
+    static constexpr int TILES = TL;                       // 16-frame tiles per workgroup
     static constexpr int FB = 16 * TILES;
     static constexpr int ROW = BE_P * SZ;                  // bytes of a frame's chunk
     static constexpr int RPD = ROW >= 1024 ? 1 : 1024 / ROW;   // frame rows per DMA instruction
@@ -108,7 +111,11 @@ template <typename T> struct BeCfg {
     static constexpr int UNIT_BYTES = (ROW >= 1024 ? ROW : 1024) + BE_PAD;
     static constexpr int BUF = (FB / RPD) * UNIT_BYTES;
     static constexpr int RING_OFF = 2 * BUF;                // record rings of the waves behind the slabs
-    static constexpr int LDS_BYTES = 2 * BUF + BE_SETS * BE_D * 1024;
+    // ring depth: what the 160 KiB leave next to the two slabs (2 with 64-frame slabs of 1 KiB rows)
+    static constexpr int D_FIT = (160 * 1024 - 2 * BUF) / (BE_SETS * 1024);
+    static constexpr int D = D_FIT < BE_D_MAX ? D_FIT : BE_D_MAX;
+    static_assert(D >= 2, "two slabs + a record ring of depth 2 must fit the LDS");
+    static constexpr int LDS_BYTES = 2 * BUF + BE_SETS * D * 1024;
     __host__ __device__ static constexpr int frame_base(int f) {
         return (f / RPD) * UNIT_BYTES + (f % RPD) * ROW;
     }
@@ -120,7 +127,7 @@ template <typename T> __device__ __forceinline__ float be_lds_value(const unsign
     else return (float)(*(const T *)p);
 }
 
-template <typename T>
+template <typename T, int TL>
 __global__ void __launch_bounds__(BE_SETS * 64, BE_OCC)
 k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
              const uint32_t *__restrict__ stream, const int64_t *__restrict__ stream_off,
@@ -129,8 +136,8 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
              float *__restrict__ out, int64_t ld_out,
              int n_cols, int accumulate, int ablate, unsigned long long *prof) {
     extern __shared__ __attribute__((aligned(16))) unsigned char be_lds[];
-    using C = BeCfg<T>;
-    constexpr int TILES = C::TILES, NDMA = C::NDMA;
+    using C = BeCfg<T, TL>;
+    constexpr int TILES = C::TILES, NDMA = C::NDMA, BE_D = C::D;
     // one tile: the two steps of a record go to two accumulators (no back-to-back dependent MFMAs)
     constexpr int NACC = TILES == 1 ? 2 : 1;
     const int tid = threadIdx.x;
@@ -149,11 +156,13 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
     // One tile per wave (float32 frames, often large detectors): the running sums are handed to a
     // second level every BE_L2 chunks, which keeps the float32 chains short (the registers are there:
     // 16 more tiles).  Two tiles per wave have no room for it.
-    constexpr bool TWO_LEVEL = TILES == 1;
+    constexpr bool TWO_LEVEL = C::SZ == 4;
     constexpr int BE_L2 = 32;
-    bf32x4 acc2[TWO_LEVEL ? BE_SLOTS : 1];
+    bf32x4 acc2[TWO_LEVEL ? BE_SLOTS : 1][TWO_LEVEL ? TILES : 1];
 #pragma unroll
-    for (int s = 0; s < (TWO_LEVEL ? BE_SLOTS : 1); ++s) acc2[s] = bf32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < (TWO_LEVEL ? BE_SLOTS : 1); ++s)
+#pragma unroll
+        for (int t = 0; t < (TWO_LEVEL ? TILES : 1); ++t) acc2[s][t] = bf32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- frame DMA: instruction q of the workgroup's chunk copy; wave j issues q = j*NDMA + i
     auto issue_dma = [&](int ai, int buf) {
@@ -277,7 +286,10 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
                     float g0f[TILES], g1f[TILES];       // (the conversions follow the gathers anyway)
 #pragma unroll
                     for (int t = 0; t < TILES; ++t) { g0f[t] = (float)b0[t]; g1f[t] = (float)b1[t]; }
-                    if constexpr (TILES == 2)
+                    if constexpr (TILES == 4)
+                        asm volatile("" ::"v"(g0f[0]), "v"(g0f[1]), "v"(g0f[2]), "v"(g0f[3]),
+                                     "v"(g1f[0]), "v"(g1f[1]), "v"(g1f[2]), "v"(g1f[3]));
+                    else if constexpr (TILES == 2)
                         asm volatile("" ::"v"(g0f[0]), "v"(g0f[1]), "v"(g1f[0]), "v"(g1f[1]));
                     else
                         asm volatile("" ::"v"(g0f[0]), "v"(g1f[0]));
@@ -312,10 +324,16 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
         if constexpr (TWO_LEVEL) {
             if (((ai - a0) & (BE_L2 - 1)) == BE_L2 - 1) {
 #pragma unroll
-                for (int s = 0; s < BE_SLOTS; ++s) {
-                    acc2[s] += acc[s][0] + acc[s][1];
-                    acc[s][0] = acc[s][1] = bf32x4{0.f, 0.f, 0.f, 0.f};
-                }
+                for (int s = 0; s < BE_SLOTS; ++s)
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t) {
+                        acc2[s][t] += acc[s][t];
+                        acc[s][t] = bf32x4{0.f, 0.f, 0.f, 0.f};
+                        if constexpr (NACC == 2) {
+                            acc2[s][t] += acc[s][t + 1];
+                            acc[s][t + 1] = bf32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                    }
             }
         }
         // The next chunk must have landed before anyone reads it.  BE_D records consumed since its
@@ -342,7 +360,13 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
     // ---- results: lane holds columns g*16 + kg*4 .. +3 of frame (tile t, m16)
     if constexpr (NACC == 2) {
 #pragma unroll
-        for (int s = 0; s < BE_SLOTS; ++s) acc[s][0] += acc[s][1] + (TWO_LEVEL ? acc2[s] : bf32x4{0.f, 0.f, 0.f, 0.f});
+        for (int s = 0; s < BE_SLOTS; ++s) acc[s][0] += acc[s][1];
+    }
+    if constexpr (TWO_LEVEL) {
+#pragma unroll
+        for (int s = 0; s < BE_SLOTS; ++s)
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) acc[s][t] += acc2[s][t];
     }
 #pragma unroll
     for (int s = 0; s < BE_SLOTS; ++s) {
@@ -495,12 +519,12 @@ void *bell_build(const int64_t *indptr, const int64_t *indices, const float *val
                     }
                 }
                 // slack for the run-ahead loads of the last records
-                stream.resize(stream.size() + (size_t)BE_D * BE_REC, 0u);
-                blocks += BE_D;
+                stream.resize(stream.size() + (size_t)BE_D_MAX * BE_REC, 0u);
+                blocks += BE_D_MAX;
             }
         b->n_blocks = blocks;
         int64_t nnz = indptr[n_px] * nc;
-        b->mac_ratio = nnz > 0 ? (double)(blocks - (size_t)BE_D * n_pass * BE_SETS) * 128.0 / (double)nnz : 0.;
+        b->mac_ratio = nnz > 0 ? (double)(blocks - (size_t)BE_D_MAX * n_pass * BE_SETS) * 128.0 / (double)nnz : 0.;
         if (active.empty()) active.push_back(0);
         hipError_t e = hipMalloc((void **)&b->stream, std::max<size_t>(stream.size(), 1) * 4);
         if (e == hipSuccess) e = hipMalloc((void **)&b->stream_off, stream_off.size() * 8);
@@ -551,11 +575,11 @@ __global__ void k_bell_tail(const T *__restrict__ tile, int64_t ld, int64_t n_fr
     for (int e = 0; e < n_tail; ++e) o[col[e]] += val[e] * (float)row[px[e]];
 }
 
-template <typename T>
-static int launch_bell(ltmi_masks *m, BellImage *b, const T *tile, int64_t n_frames, int64_t ld,
-                       float *out, int64_t ld_out_f, int n_cols, int accumulate, hipStream_t stream) {
-    using C = BeCfg<T>;
-    auto kern = k_bell_apply<T>;
+template <typename T, int TL>
+static int launch_bell_t(ltmi_masks *m, BellImage *b, const T *tile, int64_t n_frames, int64_t ld,
+                         float *out, int64_t ld_out_f, int n_cols, int accumulate, hipStream_t stream) {
+    using C = BeCfg<T, TL>;
+    auto kern = k_bell_apply<T, TL>;
     static bool set[16] = {false};
     if (!set[m->device & 15]) {
         LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -597,9 +621,26 @@ static int launch_bell(ltmi_masks *m, BellImage *b, const T *tile, int64_t n_fra
                            ld_out_f);
         LTMI_HIP(hipGetLastError());
     }
-    snprintf(m->last_kernel, sizeof(m->last_kernel), "k_bell_apply<%s> grid=(%u,%u) blocks=%zu x%.2f",
-             typeid(T).name(), grid.x, grid.y, b->n_blocks, b->mac_ratio);
+    snprintf(m->last_kernel, sizeof(m->last_kernel),
+             "k_bell_apply<%s,tiles=%d> grid=(%u,%u) blocks=%zu x%.2f", typeid(T).name(), TL, grid.x,
+             grid.y, b->n_blocks, b->mac_ratio);
     return LTMI_OK;
+}
+
+// Frames per workgroup: one workgroup (16 waves) per CU at a time.  More 16-frame tiles per wave spread
+// the fixed cost of a block record (ring read, gather addresses, refill) over more MFMAs -- 64 frames
+// per workgroup take 1.65 - 1.8x the time of 32 (profiles/r02_sparse_experiments.txt) -- but make fewer, longer workgroups: whichever needs the
+// shorter sequence of rounds on the 256 CUs (LTMI_BELL_TILES forces one).
+template <typename T>
+static int launch_bell(ltmi_masks *m, BellImage *b, const T *tile, int64_t n_frames, int64_t ld,
+                       float *out, int64_t ld_out_f, int n_cols, int accumulate, hipStream_t stream) {
+    constexpr int LO = sizeof(T) == 4 ? 1 : 2, HI = 2 * LO;
+    static const int forced = getenv("LTMI_BELL_TILES") ? atoi(getenv("LTMI_BELL_TILES")) : 0;
+    auto rounds = [&](int tl) { return (double)(((n_frames + 16 * tl - 1) / (16 * tl) + 255) / 256); };
+    const bool hi = forced ? forced == HI : rounds(HI) * 1.7 < rounds(LO);
+    if (hi)
+        return launch_bell_t<T, HI>(m, b, tile, n_frames, ld, out, ld_out_f, n_cols, accumulate, stream);
+    return launch_bell_t<T, LO>(m, b, tile, n_frames, ld, out, ld_out_f, n_cols, accumulate, stream);
 }
 
 // handled = false: the tile does not meet the kernel's rules (caller uses the SELL kernel)
