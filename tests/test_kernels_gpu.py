@@ -950,3 +950,28 @@ def test_rccl_comm_behind_the_c_abi(hip):
     with pytest.raises(ValueError):
         comm.all_reduce_sum(buf.data_ptr(), np.uint16, 4)
     comm.close()
+
+
+@pytest.mark.parametrize('tile_dtype,n_frames,tiles', [
+    ('uint16', 9000, 4), ('uint8', 9000, 4), ('float32', 6000, 2),     # one round of 64 / 32-frame workgroups
+    ('uint16', 24576, 2), ('float32', 9000, 1),                        # ... would be coarser than the small ones
+])
+def test_blocked_sparse_kernel_frames_per_workgroup(hip, tile_dtype, n_frames, tiles):
+    """k_bell_apply runs 2 or 4 (float32: 1 or 2) frame tiles per wave, whichever needs the shorter
+    sequence of workgroup rounds; both instantiations against float64, ragged last workgroup included"""
+    from oracle import masks as omasks
+    if os.environ.get('LTMI_SPARSE_BELL') == '0' or os.environ.get('LTMI_BELL_TILES'):
+        pytest.skip("kernel choice forced by the environment")
+    dt = np.dtype(tile_dtype)
+    n_frames -= 7                                   # ragged
+    rng = np.random.default_rng(n_frames)
+    import scipy.sparse as sp
+    rings = omasks.radial_bins(32, 32, 64, 64, n_bins=300, use_sparse=True, dtype=np.float32)
+    csr = sp.csr_matrix(rings.T.astype(np.float32))              # (px, 300)
+    data = (rng.integers(0, 200, (n_frames, 64 * 64)).astype(dt) if dt.kind == 'u'
+            else rng.random((n_frames, 64 * 64)).astype(dt))
+    res, kern = _apply_csr(hip, data, csr, np.float32)
+    assert f'k_bell_apply<' in kern and f'tiles={tiles}>' in kern, kern
+    ref = data.astype(np.float64) @ csr.astype(np.float64).toarray()
+    scale = np.abs(data.astype(np.float64)) @ np.abs(csr.astype(np.float64).toarray())
+    assert np.all(np.abs(res - ref) <= 1e-5 * scale + 1e-30)
