@@ -1513,6 +1513,16 @@ struct ShiftCache {
     std::vector<int32_t> rows_stage[STAGES];
     std::vector<const float *> wg_stage[STAGES];
     int stage = 0;
+    // float64 / complex128 / exact-integer results (shifted64): images in the f64 layout, scratch for
+    // the frames and results of one shift group, frame numbers of the groups
+    std::unordered_map<uint64_t, double *> images64;
+    size_t image64_bytes = 0;
+    int sig_h64 = 0, sig_w64 = 0;
+    void *gather = nullptr, *res = nullptr;
+    size_t gather_bytes = 0, res_bytes = 0;
+    int64_t *idx_dev = nullptr;
+    size_t idx_cap = 0;
+    std::vector<int64_t> idx_stage[STAGES];
 };
 constexpr size_t SHIFT_CACHE_BYTES = (size_t)4 << 30;   // at most 4 GiB of shifted images per handle
 
@@ -1520,6 +1530,10 @@ static void shift_cache_destroy(ltmi_masks *m) {
     ShiftCache *c = (ShiftCache *)m->shift_cache;
     if (!c) return;
     for (auto &kv : c->images) (void)hipFree(kv.second);
+    for (auto &kv : c->images64) (void)hipFree(kv.second);
+    if (c->gather) (void)hipFree(c->gather);
+    if (c->res) (void)hipFree(c->res);
+    if (c->idx_dev) (void)hipFree(c->idx_dev);
     if (c->rows_dev) (void)hipFree(c->rows_dev);
     if (c->wg_img_dev) (void)hipFree((void *)c->wg_img_dev);
     delete c;
@@ -1888,6 +1902,181 @@ extern "C" int ltmi_apply_masks_rows(ltmi_masks *m, const void *tile, int tile_d
     return rc;
 }
 
+// ---- shifted masks, float64 / complex128 / exact-integer results ---------------------------------------
+// The f64 matrix-core path (ltmi_dense64.hip) works off m->img64.  Frames are grouped by their shift;
+// every distinct shift gets the image of the shifted stack (built on the device, cached) and the group
+// runs through dense64_apply with that image in place of the unshifted one: a whole tile directly when
+// it has ONE shift (a constant descan correction), otherwise group by group on gathered frames, the
+// result rows scattered back.  More than SHIFT64_MAX_GROUPS distinct shifts in a tile: not handled
+// (per-frame kernel).
+constexpr size_t SHIFT64_MAX_GROUPS = 256;
+
+template <typename R>
+__global__ void k_scatter_rows(const R *__restrict__ src, int64_t n_rows, int n_cols,
+                               const int64_t *__restrict__ rows, R *__restrict__ out, int64_t ld_out,
+                               int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * n_cols) return;
+    const int64_t r = i / n_cols;
+    const int col = (int)(i % n_cols);
+    R *p = out + rows[r] * ld_out + col;
+    *p = accumulate ? (R)(*p + src[i]) : src[i];
+}
+
+static int ensure_bytes(void **buf, size_t *have, size_t need, hipStream_t stream) {
+    if (*have >= need) return LTMI_OK;
+    if (*buf) {
+        LTMI_HIP(hipStreamSynchronize(stream));
+        LTMI_HIP(hipFree(*buf));
+        *buf = nullptr;
+        *have = 0;
+    }
+    LTMI_HIP(hipMalloc(buf, need));
+    *have = need;
+    return LTMI_OK;
+}
+
+static int shifted64(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames, int64_t ld_tile,
+                     int sig_h, int sig_w, const int32_t *shifts_host, void *out, int64_t ld_out,
+                     int accumulate, hipStream_t stream, bool *handled) {
+    *handled = false;
+    ShiftCache *c = (ShiftCache *)m->shift_cache;
+    if (!c) {
+        c = new (std::nothrow) ShiftCache();
+        if (!c) LTMI_FAIL(LTMI_E_NOMEM, "out of host memory");
+        m->shift_cache = c;
+    }
+    // group the frames by shift (order of first appearance)
+    std::unordered_map<uint64_t, int> group_of;
+    std::vector<uint64_t> keys;
+    std::vector<std::vector<int64_t>> members;
+    for (int64_t f = 0; f < n_frames; ++f) {
+        const uint64_t key = ((uint64_t)(uint32_t)shifts_host[2 * f] << 32) |
+                             (uint32_t)shifts_host[2 * f + 1];
+        auto it = group_of.find(key);
+        int g;
+        if (it == group_of.end()) {
+            if (keys.size() == SHIFT64_MAX_GROUPS) return LTMI_OK;       // not handled
+            g = (int)keys.size();
+            group_of.emplace(key, g);
+            keys.push_back(key);
+            members.emplace_back();
+        } else {
+            g = it->second;
+        }
+        members[g].push_back(f);
+    }
+    const size_t img_bytes = ltmi::dense64_image_bytes(m);
+    if (c->sig_h64 != sig_h || c->sig_w64 != sig_w || c->image64_bytes != img_bytes) {
+        LTMI_HIP(hipStreamSynchronize(stream));
+        for (auto &kv : c->images64) (void)hipFree(kv.second);
+        c->images64.clear();
+        c->sig_h64 = sig_h;
+        c->sig_w64 = sig_w;
+        c->image64_bytes = img_bytes;
+    }
+    size_t missing = 0;
+    for (uint64_t key : keys) missing += c->images64.count(key) ? 0 : 1;
+    if ((c->images64.size() + missing) * img_bytes > SHIFT_CACHE_BYTES) {
+        if (keys.size() * img_bytes > SHIFT_CACHE_BYTES) return LTMI_OK;         // not handled
+        LTMI_HIP(hipStreamSynchronize(stream));
+        for (auto &kv : c->images64) (void)hipFree(kv.second);
+        c->images64.clear();
+    }
+    for (uint64_t key : keys) {
+        if (c->images64.count(key)) continue;
+        double *img = nullptr;
+        LTMI_HIP(hipMalloc((void **)&img, img_bytes));
+        c->images64.emplace(key, img);
+        LTMI_HIP(hipMemsetAsync(img, 0, img_bytes, stream));                      // the padding
+        const int rc = ltmi::dense64_build_shifted(m, sig_h, sig_w, (int)(int32_t)(key >> 32),
+                                                   (int)(int32_t)(key & 0xffffffffu), img, stream);
+        if (rc != LTMI_OK) return rc;
+    }
+    double *const img_plain = m->img64;
+    auto run = [&](double *img, const void *frames, int64_t n, int64_t ld, void *dst, int64_t ld_dst,
+                   int acc, bool *ok) {
+        m->img64 = img;
+        const int rc = ltmi::dense64_apply(m, frames, tile_dtype, n, ld, dst, ld_dst, acc, stream, ok);
+        m->img64 = img_plain;
+        return rc;
+    };
+    if (keys.size() == 1) {                      // one shift for the whole tile: no gather, no scatter
+        bool ok = false;
+        const int rc = run(c->images64[keys[0]], tile, n_frames, ld_tile, out, ld_out, accumulate, &ok);
+        if (rc != LTMI_OK) return rc;
+        if (ok) {
+            const size_t len = strlen(m->last_kernel);
+            snprintf(m->last_kernel + len, sizeof(m->last_kernel) - len, " shifted, 1 group");
+        }
+        *handled = ok;
+        return LTMI_OK;
+    }
+    // several shifts: frame numbers of all groups to the device, then group by group
+    const size_t esz = (size_t)dtype_size(tile_dtype), rsz = (size_t)dtype_size(m->result_dtype);
+    size_t largest = 0;
+    c->stage = (c->stage + 1) % ShiftCache::STAGES;
+    std::vector<int64_t> &idx_host = c->idx_stage[c->stage];
+    idx_host.clear();
+    for (auto &mem : members) {
+        largest = std::max(largest, mem.size());
+        idx_host.insert(idx_host.end(), mem.begin(), mem.end());
+    }
+    int rc = ensure_bytes(&c->gather, &c->gather_bytes, largest * (size_t)m->n_px * esz, stream);
+    if (rc != LTMI_OK) return rc;
+    rc = ensure_bytes(&c->res, &c->res_bytes, largest * (size_t)m->n_masks * rsz, stream);
+    if (rc != LTMI_OK) return rc;
+    if (c->idx_cap < idx_host.size()) {
+        if (c->idx_dev) {
+            LTMI_HIP(hipStreamSynchronize(stream));
+            LTMI_HIP(hipFree(c->idx_dev));
+        }
+        c->idx_dev = nullptr;
+        c->idx_cap = idx_host.size() * 2;
+        LTMI_HIP(hipMalloc((void **)&c->idx_dev, c->idx_cap * sizeof(int64_t)));
+    }
+    LTMI_HIP(hipMemcpyAsync(c->idx_dev, idx_host.data(), idx_host.size() * sizeof(int64_t),
+                            hipMemcpyHostToDevice, stream));
+    size_t first = 0;
+    for (size_t g = 0; g < keys.size(); ++g) {
+        const int64_t n = (int64_t)members[g].size();
+        const int64_t *idx = c->idx_dev + first;
+        first += (size_t)n;
+        rc = ltmi_gather_rows(m->device, tile, ld_tile * (int64_t)esz, idx, n, m->n_px * (int64_t)esz,
+                              c->gather, stream);
+        if (rc != LTMI_OK) return rc;
+        bool ok = false;
+        rc = run(c->images64[keys[g]], c->gather, n, m->n_px, c->res, m->n_masks, 0, &ok);
+        if (rc != LTMI_OK) return rc;
+        if (!ok) {
+            if (g == 0) return LTMI_OK;          // (nothing written yet: the per-frame kernel takes over)
+            LTMI_FAIL(LTMI_E_DTYPE, "ltmi_apply_masks_shifted_host: the float64 path stopped midway");
+        }
+        // result rows back to their frames (complex128 rows as 2 doubles per mask)
+        const int n_cols = (int)(m->n_masks * (m->result_dtype == LTMI_C128 ? 2 : 1));
+        const int64_t ldo = ld_out * (m->result_dtype == LTMI_C128 ? 2 : 1);
+        const dim3 grid((unsigned)((n * n_cols + 255) / 256));
+        switch (m->result_dtype == LTMI_C128 ? 8 : (int)rsz) {
+            case 1: hipLaunchKernelGGL(k_scatter_rows<uint8_t>, grid, dim3(256), 0, stream, (const uint8_t *)c->res, n, n_cols, idx, (uint8_t *)out, ldo, accumulate); break;
+            case 2: hipLaunchKernelGGL(k_scatter_rows<uint16_t>, grid, dim3(256), 0, stream, (const uint16_t *)c->res, n, n_cols, idx, (uint16_t *)out, ldo, accumulate); break;
+            case 4: hipLaunchKernelGGL(k_scatter_rows<uint32_t>, grid, dim3(256), 0, stream, (const uint32_t *)c->res, n, n_cols, idx, (uint32_t *)out, ldo, accumulate); break;
+            default:
+                if (m->result_dtype == LTMI_F64 || m->result_dtype == LTMI_C128)
+                    hipLaunchKernelGGL(k_scatter_rows<double>, grid, dim3(256), 0, stream, (const double *)c->res, n, n_cols, idx, (double *)out, ldo, accumulate);
+                else
+                    hipLaunchKernelGGL(k_scatter_rows<uint64_t>, grid, dim3(256), 0, stream, (const uint64_t *)c->res, n, n_cols, idx, (uint64_t *)out, ldo, accumulate);
+                break;
+        }
+        LTMI_HIP(hipGetLastError());
+    }
+    {
+        const size_t len = strlen(m->last_kernel);
+        snprintf(m->last_kernel + len, sizeof(m->last_kernel) - len, " shifted, %zu groups", keys.size());
+    }
+    *handled = true;
+    return LTMI_OK;
+}
+
 extern "C" int ltmi_apply_masks_shifted(ltmi_masks *m, const void *tile, int tile_dtype,
                                         int64_t n_frames, int64_t ld_tile, int sig_h, int sig_w,
                                         const int32_t *shifts, void *out, int64_t ld_out,
@@ -1948,6 +2137,13 @@ extern "C" int ltmi_apply_masks_shifted_host(ltmi_masks *m, const void *tile, in
             case LTMI_F32: rc = launch_lds_shifted<float>(m, (const float *)tile, n_frames, ld_tile, sig_h, sig_w, shifts_host, (float *)out, ldo, accumulate, stream, &handled); break;
             default: break;
         }
+        if (rc != LTMI_OK) return rc;
+        if (handled) return LTMI_OK;
+    }
+    if (m->img64 && tile_dtype != LTMI_C64 && tile_dtype != LTMI_C128 && n_frames < (1ll << 31)) {
+        bool handled = false;
+        const int rc = shifted64(m, tile, tile_dtype, n_frames, ld_tile, sig_h, sig_w, shifts_host, out,
+                                 ld_out, accumulate, stream, &handled);
         if (rc != LTMI_OK) return rc;
         if (handled) return LTMI_OK;
     }

@@ -49,6 +49,29 @@ __global__ void k_build_image64(const SRC *__restrict__ src, double *__restrict_
     }
 }
 
+// the image of the stack shifted by (dy, dx): mask'[k](y, x) = mask[k](y - dy, x - dx) inside the frame,
+// 0 outside (udf/masks.py:85-124); every element of the unpadded image is written
+template <typename SRC>
+__global__ void k_build_image64_shifted(const SRC *__restrict__ src, double *__restrict__ img,
+                                        int64_t n_masks, int64_t n_px, int n_chunks, int cpm, int sig_h,
+                                        int sig_w, int dy, int dx) {
+    const int64_t total = n_masks * n_px * cpm;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int part = (int)(i % cpm);
+        const int64_t kp = i / cpm;
+        const int64_t p = kp % n_px, mask = kp / n_px;
+        const int y = (int)(p / sig_w) - dy, x = (int)(p % sig_w) - dx;
+        double v = 0.;
+        if (y >= 0 && y < sig_h && x >= 0 && x < sig_w)
+            v = (double)src[(mask * n_px + (int64_t)y * sig_w + x) * cpm + part];
+        const int64_t k = mask * cpm + part;
+        const int g = (int)(k / 16), n = (int)(k % 16);
+        const int c = (int)(p / KC64), q = (int)(p % KC64);
+        img[((size_t)g * n_chunks + c) * CH64 + img64_index(n, q)] = v;
+    }
+}
+
 template <typename T, int WAVES, bool VEC>
 __global__ void __launch_bounds__(WAVES * 64)
 k_dense_mfma_f64(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
@@ -480,6 +503,28 @@ int dense64_create(ltmi_masks *m) {
                            m->n_chunks64, 1);
     LTMI_HIP(hipGetLastError());
     LTMI_HIP(hipDeviceSynchronize());
+    return LTMI_OK;
+}
+
+size_t dense64_image_bytes(const ltmi_masks *m) {
+    return (size_t)m->n_groups64 * m->n_chunks64 * CH64 * sizeof(double);
+}
+
+// `img`: dense64_image_bytes(m) of device memory whose padding (columns past the stack, pixels past the
+// frame) is zero; asynchronous on `stream`
+int dense64_build_shifted(ltmi_masks *m, int sig_h, int sig_w, int dy, int dx, double *img,
+                          hipStream_t stream) {
+    const int64_t total = m->n_masks * m->n_px * m->cpm64;
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 65535 * 16);
+    if (m->result_dtype == LTMI_F64 || m->result_dtype == LTMI_C128)
+        hipLaunchKernelGGL(k_build_image64_shifted<double>, dim3(blocks), dim3(256), 0, stream,
+                           (const double *)m->gmasks, img, m->n_masks, m->n_px, m->n_chunks64, m->cpm64,
+                           sig_h, sig_w, dy, dx);
+    else
+        hipLaunchKernelGGL(k_build_image64_shifted<int64_t>, dim3(blocks), dim3(256), 0, stream,
+                           (const int64_t *)m->gmasks, img, m->n_masks, m->n_px, m->n_chunks64, 1, sig_h,
+                           sig_w, dy, dx);
+    LTMI_HIP(hipGetLastError());
     return LTMI_OK;
 }
 

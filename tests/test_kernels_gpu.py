@@ -753,7 +753,8 @@ def _shift_ref(data3d, masks3d, shifts):
     ('uint16', (32, 32), 20, 'float32', 'x 2 column group'),  # two column groups: MFMA path, two launches
     ('uint16', (32, 32), 70, 'float32', 'x 5 column group'),  # > 64 columns (column blocks of the handle)
     ('float32', (32, 32), 13, 'complex64', 'x 2 column group'),   # 26 real columns
-    ('int32', (16, 32), 2, 'float64', 'k_dense_shifted'),    # float64 result -> generic
+    ('int32', (16, 32), 2, 'float64', 'k_dense_lds64'),      # float64 result: the f64 kernel per shift group
+    ('int32', (8, 16), 2, 'float64', 'k_dense_mfma_f64'),    # ... fewer than 256 pixels: its direct-load variant
 ])
 def test_shifted_masks_host_shifts(hip, tile_dtype, sig, n_masks, mask_dtype, expect):
     rng = np.random.default_rng(hash((tile_dtype, sig, n_masks)) % (2**32))
@@ -975,3 +976,48 @@ def test_blocked_sparse_kernel_frames_per_workgroup(hip, tile_dtype, n_frames, t
     ref = data.astype(np.float64) @ csr.astype(np.float64).toarray()
     scale = np.abs(data.astype(np.float64)) @ np.abs(csr.astype(np.float64).toarray())
     assert np.all(np.abs(res - ref) <= 1e-5 * scale + 1e-30)
+
+
+@pytest.mark.parametrize('tile_dtype,mask_dtype,result_dtype', [
+    ('uint16', 'float64', 'float64'), ('int32', 'float32', 'float64'), ('uint8', 'float64', 'float64'),
+    ('uint16', 'complex128', 'complex128'), ('int16', 'int32', 'int32'), ('uint8', 'int64', 'int64'),
+])
+@pytest.mark.parametrize('spread', [0, 1, 2])
+def test_shifted_masks_float64_and_integer_results(hip, tile_dtype, mask_dtype, result_dtype, spread):
+    """Shifted masks whose result is float64 / complex128 / an exact integer: the f64 matrix-core kernel
+    with the image of the SHIFTED stack -- a whole tile at once for one constant shift (spread 0), group
+    by group on gathered frames for a few distinct shifts (spread 1: up to 9, spread 2: up to 25)."""
+    rng = np.random.default_rng(hash((tile_dtype, mask_dtype, spread)) % (2**32))
+    n, sig, n_masks = 200, (24, 32), 5
+    dt, md, rd = np.dtype(tile_dtype), np.dtype(mask_dtype), np.dtype(result_dtype)
+    data = rng.integers(0, 200 if dt.itemsize == 1 else 3000, (n,) + sig).astype(dt)
+    if md.kind in 'iu':
+        masks = rng.integers(-3, 9, (n_masks,) + sig).astype(md)
+    else:
+        masks = rng.random((n_masks,) + sig) - 0.25
+        if md.kind == 'c':
+            masks = masks + 1j * (rng.random((n_masks,) + sig) - 0.5)
+        masks = masks.astype(md)
+    shifts = (rng.integers(-spread, spread + 1, (n, 2)) if spread else
+              np.tile(np.array([[3, -2]]), (n, 1))).astype(np.int32)
+    h = hip.MaskHandle.dense(0, masks.reshape((n_masks, -1)), rd)
+    t = _dev(np.ascontiguousarray(data.reshape((n, -1))))
+    base = (rng.integers(0, 50, (n, n_masks)) if rd.kind in 'iu' else rng.random((n, n_masks))).astype(rd)
+    ref, scale = _shift_ref(data, masks, shifts)
+    for acc in (False, True):
+        out = _dev(base.copy() if acc else np.full((n, n_masks), 7, dtype=rd))
+        h.apply_shifted_host(t.data_ptr(), dt, n, data[0].size, sig[0], sig[1], shifts,
+                             out.data_ptr(), n_masks, acc)
+        torch.cuda.synchronize()
+        res = out.cpu().numpy()
+        if res.dtype != rd:
+            res = res.view(rd)
+        kern = h.last_kernel()
+        assert 'k_dense_lds64' in kern and 'shifted, ' in kern, kern
+        assert ('1 group' in kern) == (spread == 0), kern
+        want = ref + base if acc else ref
+        if rd.kind in 'iu':
+            assert np.array_equal(res, np.real(want).astype(np.int64).astype(rd))
+        else:
+            assert np.all(np.abs(res - want) <= 1e-12 * (scale + 1)), np.abs(res - want).max()
+    h.close()
