@@ -132,8 +132,10 @@ int ltmi_apply_masks_shifted(ltmi_masks *m, const void *tile, int tile_dtype, in
 /* Same operation with the shifts on the HOST (n_frames (dy, dx) int32 pairs): lets the library
  * group the frames by shift and run them through the MFMA kernel against shifted copies of the
  * mask image (built on the device, cached in the handle, <= 4 GiB) -- one launch per tile at
- * close to the unshifted rate.  Falls back to the per-frame kernel above (after uploading the
- * shifts) for handles / tiles the MFMA path does not take. */
+ * close to the unshifted rate (float32 / complex64 results); float64 / complex128 / exact-integer
+ * results: the f64 matrix-core kernel per group of frames with the same shift (one call for a tile
+ * with a constant shift, up to 256 distinct shifts per tile).  Falls back to the per-frame kernel
+ * above (after uploading the shifts) for handles / tiles these paths do not take. */
 int ltmi_apply_masks_shifted_host(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames,
                                   int64_t ld_tile, int sig_h, int sig_w, const int32_t *shifts_host,
                                   void *out, int64_t ld_out, int accumulate, void *stream);
