@@ -134,7 +134,8 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
              const int *__restrict__ nblk,
              const int *__restrict__ active, const int *__restrict__ active_off,
              float *__restrict__ out, int64_t ld_out,
-             int n_cols, int accumulate, int ablate, unsigned long long *prof) {
+             int n_cols, int accumulate, int ablate, unsigned long long *prof,
+             const int32_t *__restrict__ rows) {
     extern __shared__ __attribute__((aligned(16))) unsigned char be_lds[];
     using C = BeCfg<T, TL>;
     constexpr int TILES = C::TILES, NDMA = C::NDMA, BE_D = C::D;
@@ -188,6 +189,7 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
                 dst = r * C::UNIT_BYTES + (q % C::DPR) * 1024;
             }
             if (fr > n_frames - 1) fr = n_frames - 1;
+            if (rows) fr = rows[fr];                  // a region of interest: result row i = frame rows[i]
             // the last chunk may be partial: pieces past the row are not referenced by any record
             if (byte_in_row + 16 > n_px * C::SZ) byte_in_row = 0;
             const unsigned char *src = (const unsigned char *)(tile + fr * ld) + byte_in_row;
@@ -567,10 +569,10 @@ template <typename T>
 __global__ void k_bell_tail(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
                             const int32_t *__restrict__ px, const int32_t *__restrict__ col,
                             const float *__restrict__ val, int n_tail, float *__restrict__ out,
-                            int64_t ld_out) {
+                            int64_t ld_out, const int32_t *__restrict__ rows) {
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n_frames) return;
-    const T *row = tile + f * ld;
+    const T *row = tile + (rows ? (int64_t)rows[f] : f) * ld;
     float *o = out + f * ld_out;
     for (int e = 0; e < n_tail; ++e) o[col[e]] += val[e] * (float)row[px[e]];
 }
@@ -600,7 +602,7 @@ static int launch_bell_t(ltmi_masks *m, BellImage *b, const T *tile, int64_t n_f
                        m->n_px, (const uint32_t *)b->stream, (const int64_t *)b->stream_off,
                        (const int *)b->nblk, (const int *)b->active,
                        (const int *)b->active_off, out,
-                       ld_out_f, n_cols, accumulate, ablate, prof);
+                       ld_out_f, n_cols, accumulate, ablate, prof, m->roi_rows);
     LTMI_HIP(hipGetLastError());
 #ifdef BE_PROF
     {
@@ -618,12 +620,12 @@ static int launch_bell_t(ltmi_masks *m, BellImage *b, const T *tile, int64_t n_f
         hipLaunchKernelGGL(k_bell_tail<T>, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0,
                            stream, tile, ld, n_frames, (const int32_t *)b->tail_px,
                            (const int32_t *)b->tail_col, (const float *)b->tail_val, b->n_tail, out,
-                           ld_out_f);
+                           ld_out_f, m->roi_rows);
         LTMI_HIP(hipGetLastError());
     }
     snprintf(m->last_kernel, sizeof(m->last_kernel),
-             "k_bell_apply<%s,tiles=%d> grid=(%u,%u) blocks=%zu x%.2f", typeid(T).name(), TL, grid.x,
-             grid.y, b->n_blocks, b->mac_ratio);
+             "k_bell_apply<%s,tiles=%d%s> grid=(%u,%u) blocks=%zu x%.2f", typeid(T).name(), TL,
+             m->roi_rows ? ",rows" : "", grid.x, grid.y, b->n_blocks, b->mac_ratio);
     return LTMI_OK;
 }
 

@@ -1055,6 +1055,7 @@ using namespace ltmi;
 
 namespace ltmi {
 int csr_destroy(ltmi_masks *m);   // ltmi_sparse.hip
+bool csr_rows_ok(const ltmi_masks *m, const void *tile, int tile_dtype, int64_t ld_tile);
 int csr_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames, int64_t ld_tile,
               void *out, int64_t ld_out, int accumulate, hipStream_t stream);
 }
@@ -1883,6 +1884,16 @@ extern "C" int ltmi_apply_masks_rows(ltmi_masks *m, const void *tile, int tile_d
         LTMI_FAIL(LTMI_E_DTYPE, "ltmi_apply_masks_rows: unknown tile dtype %d", tile_dtype);
     if (n_rows == 0) { *handled = 1; return LTMI_OK; }
     if (!tile || !out || !rows) LTMI_FAIL(LTMI_E_INVALID, "ltmi_apply_masks_rows: null pointer");
+    if (m->kind == 2) {
+        // sparse stacks: the blocked image's kernel reads frames through the row list as well
+        if (n_rows >= (1ll << 31) || !ltmi::csr_rows_ok(m, tile, tile_dtype, ld_tile)) return LTMI_OK;
+        m->roi_rows = rows;
+        const int rc = ltmi_apply_masks(m, tile, tile_dtype, n_rows, ld_tile, out, ld_out, accumulate,
+                                        stream_);
+        m->roi_rows = nullptr;
+        *handled = 1;
+        return rc;
+    }
     if (m->kind != 0 || !mfma_tile_dtype(tile_dtype) || !m->blocks.empty() || m->tune_mt != 0 ||
         m->tune_waves != 0 || n_rows >= (1ll << 31) ||
         !vector_loads_ok(tile, ld_tile, (size_t)dtype_size(tile_dtype)))

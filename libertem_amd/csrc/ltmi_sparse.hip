@@ -348,9 +348,23 @@ static int launch_sell64(ltmi_masks *m, CsrImage *c, const T *tile, int64_t n_fr
     return LTMI_OK;
 }
 
+// can this handle read the frames of a region of interest through a row list (ltmi_apply_masks_rows)?
+// Only the blocked image's kernel does: its frame DMA takes any row address.
+bool csr_rows_ok(const ltmi_masks *m, const void *tile, int tile_dtype, int64_t ld_tile) {
+    const CsrImage *c = (const CsrImage *)m->csr;
+    if (!c || c->f64 || !c->bell || m->tune_ksplit_ring == 41) return false;
+    switch (tile_dtype) {
+        case LTMI_BOOL: case LTMI_U8: case LTMI_I8: case LTMI_U16: case LTMI_I16: case LTMI_F32: break;
+        default: return false;
+    }
+    return vector_loads_ok(tile, ld_tile, (size_t)dtype_size(tile_dtype));
+}
+
 int csr_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames, int64_t ld_tile,
               void *out, int64_t ld_out, int accumulate, hipStream_t stream) {
     CsrImage *c = (CsrImage *)m->csr;
+    if (m->roi_rows && !csr_rows_ok(m, tile, tile_dtype, ld_tile))
+        LTMI_FAIL(LTMI_E_INVALID, "sparse masks: this handle / tile cannot take a row list");
     if (c->f64) {
         double *o = (double *)out;
         switch (tile_dtype) {

@@ -92,15 +92,19 @@ def radial_bins(centerX, centerY, imageSizeX, imageSizeY, radius=None, radius_in
         vals = vals.astype(dtype)
         px = all_px[sel]
         if b == 0 and patch_centre:
-            # the reference adds a one-entry float64 COO with (1 - current - radius_inner)
+            # the reference adds a one-entry COO `np.array([1 - slices[0][index] - radius_inner])`
+            # (masks.py:338-349): the scalar read from the slice has the slice's dtype, the patch the
+            # dtype NumPy's scalar promotion gives the expression (float32 slices stay float32 for
+            # Python numbers under NumPy >= 2), the sum promotes like arrays of the two dtypes
             target = cy_i * imageSizeX + cx_i
             hit = np.flatnonzero(px == target)
-            cur = vals[hit[0]] if len(hit) else 0
-            vals = vals.astype(np.result_type(vals.dtype, np.float64))
+            cur = vals[hit[0]] if len(hit) else vals.dtype.type(0)
+            patch = np.array([1 - cur - radius_inner])
+            vals = vals.astype(np.result_type(vals.dtype, patch.dtype))
             if len(hit):
-                vals[hit[0]] = cur + (1 - cur - radius_inner)
+                vals[hit[0]] = vals[hit[0]] + patch[0]
             else:
-                vals = np.concatenate([vals, [1 - cur - radius_inner]])
+                vals = np.concatenate([vals, patch.astype(vals.dtype)])
                 px = np.concatenate([px, [target]])
         datas.append(vals)
         mask_idx.append(np.full(len(vals), b, dtype=np.int64))

@@ -74,15 +74,17 @@ def radial_bins_coo(centerX, centerY, imageSizeX, imageSizeY, radius=None, radiu
             if 0 <= yy < imageSizeY and 0 <= xx < imageSizeX:
                 index = yy * imageSizeX + xx
                 pos = np.nonzero(idx == index)[0]
-                cur = vals[pos[0]] if len(pos) else 0
-                d = 1 - cur - radius_inner
+                # `slices[0][index]` is a scalar of the slice's dtype (the stored value or the fill value
+                # 0); `np.array([diff])` then has whatever dtype NumPy's scalar promotion gives
+                # `1 - scalar - radius_inner` (float32 slices stay float32 for Python numbers under
+                # NumPy >= 2), and COO + COO promotes like arrays of those dtypes
+                cur = vals[pos[0]] if len(pos) else vals.dtype.type(0)
+                patch = np.array([1 - cur - radius_inner])
+                vals = vals.astype(np.result_type(vals.dtype, patch.dtype))
                 if len(pos):
-                    # COO + COO promotes like numpy (patch data is float64)
-                    vals = vals.astype(np.result_type(vals.dtype, np.float64))
-                    vals[pos[0]] = cur + d
+                    vals[pos[0]] = vals[pos[0]] + patch[0]
                 else:
-                    vals = np.concatenate([vals.astype(np.result_type(vals.dtype, np.float64)),
-                                           [d]])
+                    vals = np.concatenate([vals, patch.astype(vals.dtype)])
                     idx = np.concatenate([idx, [index]])
         datas.append(vals)
         bins.append(np.full(len(vals), b, dtype=np.int64))

@@ -1021,3 +1021,46 @@ def test_shifted_masks_float64_and_integer_results(hip, tile_dtype, mask_dtype, 
         else:
             assert np.all(np.abs(res - want) <= 1e-12 * (scale + 1)), np.abs(res - want).max()
     h.close()
+
+
+@pytest.mark.parametrize('tile_dtype,n_frames', [('uint16', 700), ('float32', 300), ('uint8', 9000)])
+def test_row_lists_for_the_blocked_sparse_kernel(hip, tile_dtype, n_frames):
+    """ltmi_apply_masks_rows on a sparse handle: the blocked image's frame DMA reads frame rows[i] for
+    result row i (both workgroup sizes, pixel counts with a tail); the gather kernel does not take row
+    lists (handled = 0, the caller gathers)."""
+    import scipy.sparse as sp
+    from oracle import masks as omasks
+    if os.environ.get('LTMI_SPARSE_BELL') == '0':
+        pytest.skip("blocked image switched off by the environment")
+    dt = np.dtype(tile_dtype)
+    rng = np.random.default_rng(n_frames)
+    rings = omasks.radial_bins(31, 33, 67, 61, n_bins=90, use_sparse=True, dtype=np.float32)
+    csr = sp.csr_matrix(rings.T.astype(np.float32))              # (61 * 67 px, 90): 4087 px, 7 in the tail
+    n_px = csr.shape[0]
+    data = (rng.integers(0, 200, (n_frames, n_px)).astype(dt) if dt.kind == 'u'
+            else rng.random((n_frames, n_px)).astype(dt))
+    rows = np.sort(rng.choice(n_frames, n_frames * 2 // 3, replace=False)).astype(np.int32)
+    rows[3], rows[4] = rows[4], rows[3]
+    h = hip.MaskHandle.csr(0, csr, np.float32)
+    t = _dev(data)
+    r = torch.from_numpy(rows).cuda()
+    dense = csr.astype(np.float64).toarray()
+    for acc in (False, True):
+        out = torch.full((len(rows), 90), 2.0, dtype=torch.float32, device='cuda')
+        handled = h.apply_rows(t.data_ptr(), dt, r.data_ptr(), len(rows), n_px, out.data_ptr(), 90, acc)
+        torch.cuda.synchronize()
+        assert handled and 'k_bell_apply' in h.last_kernel() and ',rows' in h.last_kernel(), h.last_kernel()
+        ref = data[rows].astype(np.float64) @ dense + (2.0 if acc else 0.0)
+        scale = np.abs(data[rows].astype(np.float64)) @ np.abs(dense) + 2.0
+        assert np.all(np.abs(out.cpu().numpy() - ref) <= 1e-5 * scale), h.last_kernel()
+    h.close()
+    # a stack without a blocked image (random pattern: padding factor too high) declines
+    m = sp.random(n_px, 40, density=0.02, format='csr', dtype=np.float32, random_state=np.random.RandomState(3))
+    h = hip.MaskHandle.csr(0, m, np.float32)
+    out = torch.zeros((len(rows), 40), dtype=torch.float32, device='cuda')
+    handled = h.apply_rows(t.data_ptr(), dt, r.data_ptr(), len(rows), n_px, out.data_ptr(), 40, False)
+    h.apply(t.data_ptr(), dt, 4, n_px, out.data_ptr(), 40, False)
+    torch.cuda.synchronize()
+    if 'k_bell_apply' not in h.last_kernel():
+        assert not handled
+    h.close()

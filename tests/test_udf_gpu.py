@@ -1279,6 +1279,18 @@ def test_roi_runs_read_frames_through_a_row_list(ctx):
     com = ctx.run_udf(dataset=ds, udf=CoMUDF.with_params(cy=16, cx=16), roi=roi)
     full = ctx.run_udf(dataset=ds, udf=CoMUDF.with_params(cy=16, cx=16))
     assert np.allclose(com['raw_com'].raw_data, full['raw_com'].data[roi], rtol=1e-6)
+    # sparse ring masks: the blocked image's kernel through the row list as well
+    from libertem_amd import masks as pm
+    rings = pm.radial_bins(16, 16, 32, 32, n_bins=40, use_sparse=True, dtype=np.float32)
+    hip.KernelTimer.start()
+    rs = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda: rings), roi=roi)
+    kernels = [k for _, _, k in hip.KernelTimer.stop()]
+    assert kernels
+    if any('k_bell_apply' in k for k in kernels):
+        assert all(',rows' in k for k in kernels if 'k_bell_apply' in k), kernels
+    ref_s = data.reshape(13 * 17, -1).astype(np.float64) @ \
+        np.asarray(rings.todense()).reshape(40, -1).T.astype(np.float64)
+    assert _close(rs['intensity'].raw_data, ref_s.reshape(13, 17, 40)[roi], F32_TOL)
     # float64 results (int32 frames): no row-list kernel -> gathered, same numbers
     ds32 = _device_ds(ctx, data.astype(np.int32), 3)
     r64 = ctx.run_udf(dataset=ds32, udf=ApplyMasksUDF(mask_factories=lambda: masks), roi=roi)
