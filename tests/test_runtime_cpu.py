@@ -865,3 +865,22 @@ def test_mib_file_series_and_parameters(tmp_path):
         gpu_id = None
     with pytest.raises(DataSetException, match='decodes the files on the GPU'):
         mib.MIBDataSet(path=str(tmp_path / 'r6.hdr')).initialize(NoGpu())
+
+
+def test_sparse_radial_bins_keep_the_requested_dtype():
+    """masks.py:290-353, sparse branch: the slices are `vals.astype(dtype)` and the one-entry centre patch is
+    np.array([1 - slices[0][index] - radius_inner]) -- a float32 scalar read from the slice stays float32
+    against Python numbers (NumPy >= 2), so the stack is float32 and ApplyMasksUDF's result is too; a
+    float64 NumPy scalar for radius_inner promotes, as it would in the reference."""
+    from libertem_amd import masks as pm
+    from oracle import masks as omasks
+    r32 = pm.radial_bins(16, 16, 32, 32, n_bins=10, use_sparse=True, dtype=np.float32)
+    assert r32.dtype == np.float32
+    o32 = omasks.radial_bins(16, 16, 32, 32, n_bins=10, use_sparse=True, dtype=np.float32)
+    assert o32.dtype == np.float32
+    assert np.array_equal(np.asarray(r32.todense()).reshape(10, -1), np.asarray(o32.todense()))
+    dense = pm.radial_bins(16, 16, 32, 32, n_bins=10, use_sparse=False, dtype=np.float32)
+    assert np.allclose(np.asarray(r32.todense()).reshape(dense.shape), dense, rtol=0, atol=1e-7)
+    assert pm.radial_bins(16, 16, 32, 32, n_bins=10, use_sparse=True).dtype == np.float64
+    assert pm.radial_bins(16, 16, 32, 32, n_bins=10, use_sparse=True, dtype=np.float32,
+                          radius_inner=np.float64(0.25)).dtype == np.float64
