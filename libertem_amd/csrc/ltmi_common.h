@@ -102,6 +102,7 @@ int dense64_create(ltmi_masks *m);
 void dense64_destroy(ltmi_masks *m);
 int dense64_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames, int64_t ld,
                   void *out, int64_t ld_out, int accumulate, hipStream_t stream, bool *handled);
+bool dense64_rows_ok(const ltmi_masks *m, const void *tile, int tile_dtype, int64_t ld);
 size_t dense64_image_bytes(const ltmi_masks *m);
 int dense64_build_shifted(ltmi_masks *m, int sig_h, int sig_w, int dy, int dx, double *img,
                           hipStream_t stream);

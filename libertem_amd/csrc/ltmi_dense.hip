@@ -1864,6 +1864,7 @@ extern "C" int ltmi_apply_masks(ltmi_masks *m, const void *tile, int tile_dtype,
                                            accumulate, stream, &handled);
         if (rc != LTMI_OK || handled) return rc;
     }
+    if (m->roi_rows) LTMI_FAIL(LTMI_E_INVALID, "ltmi_apply_masks: the generic kernel does not take a row list");
     return apply_generic(m, tile, tile_dtype, n_frames, ld_tile, out, ld_out, accumulate, stream);
 }
 
@@ -1887,6 +1888,16 @@ extern "C" int ltmi_apply_masks_rows(ltmi_masks *m, const void *tile, int tile_d
     if (m->kind == 2) {
         // sparse stacks: the blocked image's kernel reads frames through the row list as well
         if (n_rows >= (1ll << 31) || !ltmi::csr_rows_ok(m, tile, tile_dtype, ld_tile)) return LTMI_OK;
+        m->roi_rows = rows;
+        const int rc = ltmi_apply_masks(m, tile, tile_dtype, n_rows, ld_tile, out, ld_out, accumulate,
+                                        stream_);
+        m->roi_rows = nullptr;
+        *handled = 1;
+        return rc;
+    }
+    if (m->kind != 2 && m->img64 && m->blocks.empty() && n_rows < (1ll << 31) &&
+        ltmi::dense64_rows_ok(m, tile, tile_dtype, ld_tile)) {
+        // float64 / complex128 results: the f64 LDS-DMA kernel reads frames through the row list
         m->roi_rows = rows;
         const int rc = ltmi_apply_masks(m, tile, tile_dtype, n_rows, ld_tile, out, ld_out, accumulate,
                                         stream_);

@@ -219,7 +219,8 @@ __global__ void __launch_bounds__(256)
 k_dense_lds64(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
               const double *__restrict__ img, int n_chunks, double *__restrict__ out,
               int64_t ld_out, int n_cols, int accumulate, double *__restrict__ partials,
-              int ksplit) {
+              int ksplit,
+              const int32_t *__restrict__ rows = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw64[];
     using CFG = Lds64Cfg;
     static_assert(sizeof(T) == 1 || sizeof(T) == 2 || sizeof(T) == 4 || sizeof(T) == 8, "pixel size");
@@ -274,6 +275,7 @@ k_dense_lds64(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t 
             const int r = 4 * t + (lane >> 4);
             int64_t f = f_wave + r;
             if (f > n_frames - 1) f = n_frames - 1;      // clamp: loads stay valid, result discarded
+            if (rows) f = rows[f];                       // a region of interest: result row i = frame rows[i]
             const int piece = (lane & 15) ^ (r & 15);
             src[t] = (const unsigned char *)(tile + f * ld) + piece * 16;
         }
@@ -418,6 +420,7 @@ k_dense_lds64(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t 
         for (int tl = 0; tl < TILES; ++tl) {
             int64_t f = f_wave + tl * 16 + m;
             if (f > n_frames - 1) f = n_frames - 1;
+            if (rows) f = rows[f];
             const T *rowp = tile + f * ld + kg * 4;
 #pragma unroll
             for (int blk = 0; blk < KC64 / 16; ++blk) {
@@ -581,10 +584,10 @@ static int launch64_lds(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t 
     dim3 grid((unsigned)gx, (unsigned)ksplit, (unsigned)gz);
     hipLaunchKernelGGL(kern, grid, dim3(CFG::WAVES * 64), CFG::LDS_BYTES, stream, tile, ld, n_frames,
                        m->n_px, (const double *)m->img64, m->n_chunks64, out, ld_out,
-                       (int)n_cols64(m), accumulate, (double *)m->ws64, ksplit);
+                       (int)n_cols64(m), accumulate, (double *)m->ws64, ksplit, m->roi_rows);
     LTMI_HIP(hipGetLastError());
-    snprintf(m->last_kernel, sizeof(m->last_kernel), "k_dense_lds64<%s> grid=(%u,%u,%u)",
-             typeid(T).name(), grid.x, grid.y, grid.z);
+    snprintf(m->last_kernel, sizeof(m->last_kernel), "k_dense_lds64<%s%s> grid=(%u,%u,%u)",
+             typeid(T).name(), m->roi_rows ? ",rows" : "", grid.x, grid.y, grid.z);
     if (ksplit > 1) {
         const int64_t n = n_frames * n_cols64(m);
         hipLaunchKernelGGL(k_reduce_partials64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
@@ -593,6 +596,15 @@ static int launch64_lds(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t 
         LTMI_HIP(hipGetLastError());
     }
     return LTMI_OK;
+}
+
+// can this handle read the frames of a region of interest through a row list (ltmi_apply_masks_rows)?
+// float64 / complex128 results through the LDS-DMA kernel (mirrors the dispatch of launch64)
+bool dense64_rows_ok(const ltmi_masks *m, const void *tile, int tile_dtype, int64_t ld) {
+    if (!m->img64 || (m->result_dtype != LTMI_F64 && m->result_dtype != LTMI_C128)) return false;
+    if (tile_dtype == LTMI_C64 || tile_dtype == LTMI_C128 || dtype_size(tile_dtype) == 0) return false;
+    return m->tune_mt != 1 && m->n_px >= KC64 &&
+           vector_loads_ok(tile, ld, (size_t)dtype_size(tile_dtype));
 }
 
 template <typename T>
@@ -604,6 +616,7 @@ static int launch64(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, 
         if (m->tune_mt != 1 && m->n_px >= KC64 && vector_loads_ok(tile, ld, sizeof(T)))
             return launch64_lds<T>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
     }
+    if (m->roi_rows) LTMI_FAIL(LTMI_E_INVALID, "k_dense_mfma_f64 does not take a row list");
     constexpr int WAVES = 4;
     const bool vec = (((uintptr_t)tile) % (4 * sizeof(T)) == 0) && (ld % 4 == 0);
     const int64_t gx = (n_frames + WAVES * 16 - 1) / (WAVES * 16);

@@ -246,12 +246,13 @@ def test_long_rows_keep_float32_accuracy(hip, n_px, tile_dtype, n_masks):
 @pytest.mark.parametrize('tile_dtype,n_masks,mask_dtype', [
     ('uint16', 16, 'float32'), ('uint16', 3, 'float32'), ('float32', 25, 'complex64'),
     ('uint8', 5, 'float32'), ('int16', 40, 'float32'), ('uint16', 70, 'float32'),
-    ('int32', 4, 'float32'),
+    ('int32', 4, 'float32'), ('uint16', 20, 'float64'), ('uint8', 70, 'float64'),
 ])
 def test_row_lists_instead_of_gathered_frames(hip, tile_dtype, n_masks, mask_dtype):
     """ltmi_apply_masks_rows: out[i] = product of frame rows[i] of the tile -- a region of interest
     without the gathered copy.  Served for the float32 / complex64 LDS-DMA kernels (every column
-    tiling up to 64 real columns); other handles report handled = 0 and the caller gathers."""
+    tiling up to 64 real columns) and the float64 one; other handles report handled = 0 and the caller
+    gathers."""
     dt, md = np.dtype(tile_dtype), np.dtype(mask_dtype)
     rng = np.random.default_rng(n_masks)
     n_frames, n_px = 700, 256 * 5 + 24
@@ -275,13 +276,15 @@ def test_row_lists_instead_of_gathered_frames(hip, tile_dtype, n_masks, mask_dty
         handled = h.apply_rows(t.data_ptr(), dt, r.data_ptr(), len(rows), n_px, out.data_ptr(),
                                n_masks, acc)
         torch.cuda.synchronize()
-        if dt.itemsize == 4 and dt.kind == 'i' or n_masks > 64:
-            assert not handled                                # float64 results / column blocks: gather
+        if n_masks > 64 and rd != np.float64:
+            assert not handled                                # column blocks: gather
             continue
         assert handled and ',rows' in h.last_kernel(), h.last_kernel()
+        assert ('k_dense_lds64' in h.last_kernel()) == (rd == np.float64)
         ref = _ref64(data[rows], masks) + (2.0 if acc else 0.0)
         scale = np.abs(data[rows].astype(np.float64)) @ np.abs(masks).astype(np.float64).T + 2.0
-        assert np.all(np.abs(out.cpu().numpy() - ref) <= 1e-5 * scale), h.last_kernel()
+        tol = 1e-12 if rd == np.float64 else 1e-5
+        assert np.all(np.abs(out.cpu().numpy() - ref) <= tol * scale), h.last_kernel()
     h.close()
 
 

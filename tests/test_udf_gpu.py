@@ -1291,7 +1291,7 @@ def test_roi_runs_read_frames_through_a_row_list(ctx):
     ref_s = data.reshape(13 * 17, -1).astype(np.float64) @ \
         np.asarray(rings.todense()).reshape(40, -1).T.astype(np.float64)
     assert _close(rs['intensity'].raw_data, ref_s.reshape(13, 17, 40)[roi], F32_TOL)
-    # float64 results (int32 frames): no row-list kernel -> gathered, same numbers
+    # float64 results (int32 frames): the f64 LDS-DMA kernel through the row list
     ds32 = _device_ds(ctx, data.astype(np.int32), 3)
     r64 = ctx.run_udf(dataset=ds32, udf=ApplyMasksUDF(mask_factories=lambda: masks), roi=roi)
     assert r64['intensity'].raw_data.dtype == np.float64
