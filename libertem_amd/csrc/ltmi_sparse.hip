@@ -145,7 +145,7 @@ k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
              const int *__restrict__ row_off, const int *__restrict__ row_len,
              const int *__restrict__ active, const int *__restrict__ active_off, int n_chunks,
              A *__restrict__ out, int64_t ld_out, int n_masks, int accumulate, int vec_ok,
-             int ablate) {
+             int ablate, const int32_t *__restrict__ rows) {
     extern __shared__ __attribute__((aligned(16))) unsigned char slab_raw[];
     A *slab = (A *)slab_raw;                                          // [SP_P][SP_F]
     typedef A ax4 __attribute__((ext_vector_type(4)));
@@ -161,6 +161,7 @@ k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
     const int lf = tid & 15, lg = tid >> 4;
     int64_t frame = f0 + lf;
     if (frame > n_frames - 1) frame = n_frames - 1;
+    if (rows) frame = rows[frame];                    // a region of interest: result row i = frame rows[i]
     const T *row = tile + frame * ld;
 
     // padding entries of the image (value 0) point at pixel row SP_P, which is all zeros: a
@@ -304,7 +305,7 @@ static int launch_sell(ltmi_masks *m, CsrImage *c, const T *tile, int64_t n_fram
         hipLaunchKernelGGL(kern, grid, dim3(SP_NT), lds, stream, tile, ld, n_frames, m->n_px,
                            (const uint32_t *)c->pix, (const float *)c->val, (const int *)c->row_off,
                            (const int *)c->row_len, (const int *)c->active, (const int *)c->active_off,
-                           c->n_chunks, out, ld_out_f, (int)m->n_masks, accumulate, vec_ok, ablate);
+                           c->n_chunks, out, ld_out_f, (int)m->n_masks, accumulate, vec_ok, ablate, m->roi_rows);
     } else {
         auto kern = k_sell_apply<T, 4, false>;
         static bool set[16] = {false};
@@ -316,11 +317,12 @@ static int launch_sell(ltmi_masks *m, CsrImage *c, const T *tile, int64_t n_fram
         hipLaunchKernelGGL(kern, grid, dim3(SP_NT), lds, stream, tile, ld, n_frames, m->n_px,
                            (const uint32_t *)c->pix, (const float *)c->val, (const int *)c->row_off,
                            (const int *)c->row_len, (const int *)c->active, (const int *)c->active_off,
-                           c->n_chunks, out, ld_out_f, (int)m->n_masks, accumulate, vec_ok, ablate);
+                           c->n_chunks, out, ld_out_f, (int)m->n_masks, accumulate, vec_ok, ablate, m->roi_rows);
     }
     LTMI_HIP(hipGetLastError());
-    snprintf(m->last_kernel, sizeof(m->last_kernel), "k_sell_apply<%s,%s> grid=(%u,%u) rows=%zu",
-             typeid(T).name(), c->cplx ? "c64" : "f32", grid.x, grid.y, c->n_rows);
+    snprintf(m->last_kernel, sizeof(m->last_kernel), "k_sell_apply<%s,%s%s> grid=(%u,%u) rows=%zu",
+             typeid(T).name(), c->cplx ? "c64" : "f32", m->roi_rows ? ",rows" : "", grid.x, grid.y,
+             c->n_rows);
     return LTMI_OK;
 }
 
@@ -341,23 +343,25 @@ static int launch_sell64(ltmi_masks *m, CsrImage *c, const T *tile, int64_t n_fr
     hipLaunchKernelGGL(kern, grid, dim3(SP_NT), lds, stream, tile, ld, n_frames, m->n_px,
                        (const uint32_t *)c->pix, (const double *)c->val64, (const int *)c->row_off,
                        (const int *)c->row_len, (const int *)c->active, (const int *)c->active_off,
-                       c->n_chunks, out, ld_out, (int)m->n_masks, accumulate, vec_ok, 0);
+                       c->n_chunks, out, ld_out, (int)m->n_masks, accumulate, vec_ok, 0, m->roi_rows);
     LTMI_HIP(hipGetLastError());
-    snprintf(m->last_kernel, sizeof(m->last_kernel), "k_sell_apply<%s,f64> grid=(%u,%u) rows=%zu",
-             typeid(T).name(), grid.x, grid.y, c->n_rows);
+    snprintf(m->last_kernel, sizeof(m->last_kernel), "k_sell_apply<%s,f64%s> grid=(%u,%u) rows=%zu",
+             typeid(T).name(), m->roi_rows ? ",rows" : "", grid.x, grid.y, c->n_rows);
     return LTMI_OK;
 }
 
 // can this handle read the frames of a region of interest through a row list (ltmi_apply_masks_rows)?
-// Only the blocked image's kernel does: its frame DMA takes any row address.
+// Both sparse kernels do (the tile dtypes csr_apply dispatches).
 bool csr_rows_ok(const ltmi_masks *m, const void *tile, int tile_dtype, int64_t ld_tile) {
     const CsrImage *c = (const CsrImage *)m->csr;
-    if (!c || c->f64 || !c->bell || m->tune_ksplit_ring == 41) return false;
+    if (!c || !tile) return false;
     switch (tile_dtype) {
-        case LTMI_BOOL: case LTMI_U8: case LTMI_I8: case LTMI_U16: case LTMI_I16: case LTMI_F32: break;
-        default: return false;
+        case LTMI_BOOL: case LTMI_U8: case LTMI_I8: case LTMI_U16: case LTMI_I16: case LTMI_F32:
+            return true;
+        case LTMI_U32: case LTMI_I32: case LTMI_U64: case LTMI_I64: case LTMI_F64:
+            return c->f64 != 0;
     }
-    return vector_loads_ok(tile, ld_tile, (size_t)dtype_size(tile_dtype));
+    return false;
 }
 
 int csr_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames, int64_t ld_tile,

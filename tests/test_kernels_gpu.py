@@ -1029,8 +1029,7 @@ def test_shifted_masks_float64_and_integer_results(hip, tile_dtype, mask_dtype, 
 @pytest.mark.parametrize('tile_dtype,n_frames', [('uint16', 700), ('float32', 300), ('uint8', 9000)])
 def test_row_lists_for_the_blocked_sparse_kernel(hip, tile_dtype, n_frames):
     """ltmi_apply_masks_rows on a sparse handle: the blocked image's frame DMA reads frame rows[i] for
-    result row i (both workgroup sizes, pixel counts with a tail); the gather kernel does not take row
-    lists (handled = 0, the caller gathers)."""
+    result row i (both workgroup sizes, pixel counts with a tail), and so does the gather kernel's loader."""
     import scipy.sparse as sp
     from oracle import masks as omasks
     if os.environ.get('LTMI_SPARSE_BELL') == '0':
@@ -1057,13 +1056,23 @@ def test_row_lists_for_the_blocked_sparse_kernel(hip, tile_dtype, n_frames):
         scale = np.abs(data[rows].astype(np.float64)) @ np.abs(dense) + 2.0
         assert np.all(np.abs(out.cpu().numpy() - ref) <= 1e-5 * scale), h.last_kernel()
     h.close()
-    # a stack without a blocked image (random pattern: padding factor too high) declines
+    # a stack without a blocked image (random pattern: padding factor too high): the gather kernel takes
+    # the row list as well; float64 results (int32 frames) through its double variant
     m = sp.random(n_px, 40, density=0.02, format='csr', dtype=np.float32, random_state=np.random.RandomState(3))
-    h = hip.MaskHandle.csr(0, m, np.float32)
-    out = torch.zeros((len(rows), 40), dtype=torch.float32, device='cuda')
-    handled = h.apply_rows(t.data_ptr(), dt, r.data_ptr(), len(rows), n_px, out.data_ptr(), 40, False)
-    h.apply(t.data_ptr(), dt, 4, n_px, out.data_ptr(), 40, False)
-    torch.cuda.synchronize()
-    if 'k_bell_apply' not in h.last_kernel():
-        assert not handled
-    h.close()
+    for res_dt, frames in ((np.float32, data), (np.float64, data.astype(np.int32) if dt.kind == 'u' else None)):
+        if frames is None:
+            continue
+        h = hip.MaskHandle.csr(0, m.astype(res_dt), res_dt)
+        tt = _dev(frames)
+        out = torch.zeros((len(rows), 40), dtype=torch.float32 if res_dt == np.float32 else torch.float64,
+                          device='cuda')
+        handled = h.apply_rows(tt.data_ptr(), frames.dtype, r.data_ptr(), len(rows), n_px, out.data_ptr(),
+                               40, False)
+        torch.cuda.synchronize()
+        assert handled and ',rows' in h.last_kernel(), h.last_kernel()
+        dm = m.astype(np.float64).toarray()
+        ref = frames[rows].astype(np.float64) @ dm
+        scale = np.abs(frames[rows].astype(np.float64)) @ np.abs(dm) + 1e-30
+        tol = 1e-5 if res_dt == np.float32 else 1e-12
+        assert np.all(np.abs(out.cpu().numpy() - ref) <= tol * scale), h.last_kernel()
+        h.close()
