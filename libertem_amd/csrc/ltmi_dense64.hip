@@ -598,10 +598,29 @@ static int launch64_lds(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t 
     return LTMI_OK;
 }
 
+// integer masks x integer frames: every possible partial sum fits 2^52, the f64 FMA chain is exact
+static bool int_product_is_exact(const ltmi_masks *m, int tile_dtype) {
+    int data_bits;
+    switch (tile_dtype) {
+        case LTMI_BOOL: data_bits = 1; break;
+        case LTMI_U8: case LTMI_I8: data_bits = 8; break;
+        case LTMI_U16: case LTMI_I16: data_bits = 16; break;
+        case LTMI_U32: case LTMI_I32: data_bits = 32; break;
+        default: return false;                            // 64-bit or non-integer tiles
+    }
+    int k_bits = 0;
+    while (((int64_t)1 << k_bits) < m->n_px) ++k_bits;
+    return data_bits + m->mask_bits + k_bits <= 52;
+}
+
 // can this handle read the frames of a region of interest through a row list (ltmi_apply_masks_rows)?
-// float64 / complex128 results through the LDS-DMA kernel (mirrors the dispatch of launch64)
+// float64 / complex128 / exact-integer results through the LDS-DMA kernel (mirrors the dispatch of
+// dense64_apply and launch64)
 bool dense64_rows_ok(const ltmi_masks *m, const void *tile, int tile_dtype, int64_t ld) {
-    if (!m->img64 || (m->result_dtype != LTMI_F64 && m->result_dtype != LTMI_C128)) return false;
+    if (!m->img64) return false;
+    const bool int_result = m->result_dtype >= LTMI_U8 && m->result_dtype <= LTMI_I64;
+    if (int_result ? !int_product_is_exact(m, tile_dtype)
+                   : (m->result_dtype != LTMI_F64 && m->result_dtype != LTMI_C128)) return false;
     if (tile_dtype == LTMI_C64 || tile_dtype == LTMI_C128 || dtype_size(tile_dtype) == 0) return false;
     return m->tune_mt != 1 && m->n_px >= KC64 &&
            vector_loads_ok(tile, ld, (size_t)dtype_size(tile_dtype));
@@ -683,17 +702,7 @@ int dense64_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_fra
         // wrap-around).  If every possible partial sum fits 2^52 the f64 FMA chain is EXACT, so the
         // product runs on the f64 matrix cores into a scratch buffer and is then truncated to the
         // result width -- bit-identical to integer arithmetic.  Otherwise: the integer VALU kernel.
-        int data_bits;
-        switch (tile_dtype) {
-            case LTMI_BOOL: data_bits = 1; break;
-            case LTMI_U8: case LTMI_I8: data_bits = 8; break;
-            case LTMI_U16: case LTMI_I16: data_bits = 16; break;
-            case LTMI_U32: case LTMI_I32: data_bits = 32; break;
-            default: return LTMI_OK;                      // 64-bit or non-integer tiles
-        }
-        int k_bits = 0;
-        while (((int64_t)1 << k_bits) < m->n_px) ++k_bits;
-        if (data_bits + m->mask_bits + k_bits > 52) return LTMI_OK;
+        if (!int_product_is_exact(m, tile_dtype)) return LTMI_OK;
         const size_t need = (size_t)n_frames * m->n_masks * sizeof(double);
         if (m->res64_bytes < need) {
             if (m->res64) {

@@ -246,7 +246,7 @@ def test_long_rows_keep_float32_accuracy(hip, n_px, tile_dtype, n_masks):
 @pytest.mark.parametrize('tile_dtype,n_masks,mask_dtype', [
     ('uint16', 16, 'float32'), ('uint16', 3, 'float32'), ('float32', 25, 'complex64'),
     ('uint8', 5, 'float32'), ('int16', 40, 'float32'), ('uint16', 70, 'float32'),
-    ('int32', 4, 'float32'), ('uint16', 20, 'float64'), ('uint8', 70, 'float64'),
+    ('int32', 4, 'float32'), ('uint16', 20, 'float64'), ('uint8', 70, 'float64'), ('int16', 6, 'int32'),
 ])
 def test_row_lists_instead_of_gathered_frames(hip, tile_dtype, n_masks, mask_dtype):
     """ltmi_apply_masks_rows: out[i] = product of frame rows[i] of the tile -- a region of interest
@@ -261,7 +261,7 @@ def test_row_lists_instead_of_gathered_frames(hip, tile_dtype, n_masks, mask_dty
     masks = rng.random((n_masks, n_px)) - 0.25
     if md.kind == 'c':
         masks = masks + 1j * (rng.random((n_masks, n_px)) - 0.5)
-    masks = masks.astype(md)
+    masks = masks.astype(md) if md.kind != 'i' else rng.integers(-3, 9, (n_masks, n_px)).astype(md)
     rd = np.result_type(dt, md)
     rows = np.sort(rng.choice(n_frames, 333, replace=False)).astype(np.int32)
     rows[7], rows[8] = rows[8], rows[7]                      # (any order, repeats allowed)
@@ -269,8 +269,9 @@ def test_row_lists_instead_of_gathered_frames(hip, tile_dtype, n_masks, mask_dty
     h = hip.MaskHandle.dense(0, masks, rd)
     t = _dev(data)
     r = torch.from_numpy(rows).cuda()
-    tout = {'float32': torch.float32, 'float64': torch.float64, 'complex64': torch.complex64}[rd.name]
-    base = torch.full((len(rows), n_masks), 2.0, dtype=tout, device='cuda')
+    tout = {'float32': torch.float32, 'float64': torch.float64, 'complex64': torch.complex64,
+            'int32': torch.int32}[rd.name]
+    base = torch.full((len(rows), n_masks), 2, dtype=tout, device='cuda')
     for acc in (False, True):
         out = base.clone()
         handled = h.apply_rows(t.data_ptr(), dt, r.data_ptr(), len(rows), n_px, out.data_ptr(),
@@ -280,7 +281,11 @@ def test_row_lists_instead_of_gathered_frames(hip, tile_dtype, n_masks, mask_dty
             assert not handled                                # column blocks: gather
             continue
         assert handled and ',rows' in h.last_kernel(), h.last_kernel()
-        assert ('k_dense_lds64' in h.last_kernel()) == (rd == np.float64)
+        assert ('k_dense_lds64' in h.last_kernel()) == (rd in (np.float64, np.int32))
+        if rd.kind == 'i':                                    # exact integer arithmetic
+            want = data[rows].astype(np.int64) @ masks.astype(np.int64).T + (2 if acc else 0)
+            assert np.array_equal(out.cpu().numpy(), want.astype(np.int32)), h.last_kernel()
+            continue
         ref = _ref64(data[rows], masks) + (2.0 if acc else 0.0)
         scale = np.abs(data[rows].astype(np.float64)) @ np.abs(masks).astype(np.float64).T + 2.0
         tol = 1e-12 if rd == np.float64 else 1e-5
