@@ -1836,9 +1836,11 @@ extern "C" int ltmi_apply_masks(ltmi_masks *m, const void *tile, int tile_dtype,
             ltmi_masks *c = m->blocks[b];
             c->tune_ksplit = m->tune_ksplit;
             c->tune_ksplit_ring = m->tune_ksplit_ring;
+            c->roi_rows = m->roi_rows;                      // (ltmi_apply_masks_rows: every block reads them)
             const int rc = ltmi_apply_masks(c, tile, tile_dtype, n_frames, ld_tile,
                                             (unsigned char *)out + (size_t)m->block_first[b] * elem,
                                             ld_out, accumulate, stream_);
+            c->roi_rows = nullptr;
             if (rc != LTMI_OK) return rc;
         }
         snprintf(m->last_kernel, sizeof(m->last_kernel), "%zu column blocks, last: %.90s",
@@ -1905,16 +1907,21 @@ extern "C" int ltmi_apply_masks_rows(ltmi_masks *m, const void *tile, int tile_d
         *handled = 1;
         return rc;
     }
-    if (m->kind != 0 || !mfma_tile_dtype(tile_dtype) || !m->blocks.empty() || m->tune_mt != 0 ||
-        m->tune_waves != 0 || n_rows >= (1ll << 31) ||
+    if (m->kind != 0 || !mfma_tile_dtype(tile_dtype) || m->tune_mt != 0 ||
+        m->tune_waves != 0 || m->tune_ksplit_ring == 33 || n_rows >= (1ll << 31) ||
         !vector_loads_ok(tile, ld_tile, (size_t)dtype_size(tile_dtype)))
         return LTMI_OK;
-    bool lds = false;
-    switch (tile_dtype) {
-        case LTMI_BOOL: case LTMI_U8: case LTMI_I8: lds = lds_kernel_applies<uint8_t>(m); break;
-        case LTMI_U16: case LTMI_I16: lds = lds_kernel_applies<uint16_t>(m); break;
-        case LTMI_F32: lds = lds_kernel_applies<float>(m); break;
-    }
+    auto lds_ok = [&](const ltmi_masks *h) {
+        switch (tile_dtype) {
+            case LTMI_BOOL: case LTMI_U8: case LTMI_I8: return lds_kernel_applies<uint8_t>(h);
+            case LTMI_U16: case LTMI_I16: return lds_kernel_applies<uint16_t>(h);
+            case LTMI_F32: return lds_kernel_applies<float>(h);
+        }
+        return false;
+    };
+    // (stacks of more than 64 real columns: every column block must take the row list)
+    bool lds = m->blocks.empty() ? lds_ok(m) : true;
+    for (const ltmi_masks *b : m->blocks) lds = lds && lds_ok(b);
     if (!lds) return LTMI_OK;
     m->roi_rows = rows;
     const int rc = ltmi_apply_masks(m, tile, tile_dtype, n_rows, ld_tile, out, ld_out, accumulate,

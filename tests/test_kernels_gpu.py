@@ -277,10 +277,9 @@ def test_row_lists_instead_of_gathered_frames(hip, tile_dtype, n_masks, mask_dty
         handled = h.apply_rows(t.data_ptr(), dt, r.data_ptr(), len(rows), n_px, out.data_ptr(),
                                n_masks, acc)
         torch.cuda.synchronize()
-        if n_masks > 64 and rd != np.float64:
-            assert not handled                                # column blocks: gather
-            continue
         assert handled and ',rows' in h.last_kernel(), h.last_kernel()
+        if n_masks > 64 and rd != np.float64:
+            assert 'column blocks' in h.last_kernel(), h.last_kernel()
         assert ('k_dense_lds64' in h.last_kernel()) == (rd in (np.float64, np.int32))
         if rd.kind == 'i':                                    # exact integer arithmetic
             want = data[rows].astype(np.int64) @ masks.astype(np.int64).T + (2 if acc else 0)
