@@ -112,10 +112,10 @@ int ltmi_apply_masks(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_
  *   out[i, k] (+)= sum_p tile[rows[i], p] * masks[k, p],   0 <= i < n_rows
  * `rows`: DEVICE array of n_rows int32 frame numbers relative to `tile`.  *handled = 0 and nothing is
  * done when the handle / tile combination has no row-list kernel (then gather with ltmi_gather_rows and
- * call ltmi_apply_masks): row lists are served for dense float32 / complex64 stacks of at most 64 real
- * columns on uint8 / int8 / uint16 / int16 / float32 tiles of at least one mask slot per frame, for
- * dense float64 / complex128 results of real tiles (>= 256 pixels per frame), and for sparse (CSR)
- * stacks (both sparse kernels, float32 / complex64 / float64 results).
+ * call ltmi_apply_masks): row lists are served for dense float32 / complex64 stacks on uint8 / int8 /
+ * uint16 / int16 / float32 tiles of at least one mask slot per frame, for dense float64 / complex128 /
+ * exact-integer results of real tiles (>= 256 pixels per frame), and for sparse (CSR) stacks (both
+ * sparse kernels, float32 / complex64 / float64 results).
  */
 int ltmi_apply_masks_rows(ltmi_masks *m, const void *tile, int tile_dtype, const int32_t *rows,
                           int64_t n_rows, int64_t ld_tile, void *out, int64_t ld_out, int accumulate,
