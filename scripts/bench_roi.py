@@ -7,7 +7,10 @@ from libertem_amd.udf.masks import ApplyMasksUDF
 from libertem_amd.common.hiparray import HipArray
 ctx = Context.make_with('hip', gpus=0)
 frames = torch.randint(0, 4096, (256, 256, 256, 256), device='cuda', dtype=torch.int32).to(torch.int16)
-ds = ctx.load('memory', data=HipArray.from_torch(frames, np.uint16), sig_dims=2, num_partitions=1)
+if '--f64' in sys.argv:            # int32 detector: float64 results (k_dense_lds64)
+    frames = frames.to(torch.int32)
+ds = ctx.load('memory', data=HipArray.from_torch(frames, np.int32 if '--f64' in sys.argv else np.uint16),
+              sig_dims=2, num_partitions=1)
 masks = np.random.default_rng(2).random((16, 256, 256)).astype(np.float32)
 udf = ApplyMasksUDF(mask_factories=lambda: masks, use_sparse=False, mask_count=16, mask_dtype=np.float32)
 if '--sparse' in sys.argv:          # C4: 1024 sparse ring masks (256 MiB result: kept in HBM here)
