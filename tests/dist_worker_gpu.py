@@ -94,6 +94,32 @@ def main():
     out['live'] = live
     out['live_step_masks'] = np.stack([a for a, _ in steps])
     out['live_step_damage'] = np.stack([b for _, b in steps])
+    # (5) a Merlin .mib series: every rank unpacks and holds its block of the scan (shard), ROI run
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    import recipes
+    case = [c for c in recipes.MIB_CASES if c['name'] == 'r12'][0]           # 6 frames of 32 x 64, 12 bit
+    mib_frames, mib_files, mib_hdr = recipes.make_mib_case(case)
+    mib_dir = os.path.join(out_dir, 'mib')
+    if rank == 0:
+        os.makedirs(mib_dir, exist_ok=True)
+        for fn, blob in mib_files.items():
+            with open(os.path.join(mib_dir, fn), 'wb') as f:
+                f.write(blob)
+        with open(os.path.join(mib_dir, 'r12.hdr'), 'w') as f:
+            f.write(mib_hdr)
+    dist.barrier()
+    ds_mib = ctx.load('mib', path=os.path.join(mib_dir, 'r12.hdr'), nav_shape=(world, 6 // world),
+                      shard=(rank, world))
+    mib_masks = rng.random((4, 32, 64)).astype(np.float32)
+    mib_roi = np.array([True, False, True, True, True, False]).reshape((world, 6 // world))
+    out['mib_full'] = ctx.run_udf(dataset=ds_mib, udf=ApplyMasksUDF(
+        mask_factories=lambda: mib_masks))['intensity'].data
+    out['mib_roi_raw'] = ctx.run_udf(dataset=ds_mib, udf=ApplyMasksUDF(
+        mask_factories=lambda: mib_masks), roi=mib_roi)['intensity'].raw_data
+    out['mib_masks'] = mib_masks
+    out['mib_frames'] = mib_frames
+    out['mib_roi'] = mib_roi
+    out['mib_local_frames'] = np.array(ds_mib.decode_bytes // (384 + 32 * 64 * 2))
     out['masks'] = masks
     np.savez(os.path.join(out_dir, f'rank{rank}.npz'), **out)
     dist.barrier()

@@ -1419,7 +1419,14 @@ def test_two_ranks_share_results_through_host_segment(tmp_path, world):
         exp2 = opath.apply_masks(data, masks, num_partitions=5)
         assert _close(o['rep_masks'], exp2, F32_TOL)
         assert _close(o['rep_roi_raw'], exp2.reshape((45, -1))[roi.reshape(-1)], F32_TOL)
-    for k in ('sh_masks', 'sh_sum', 'sh_sumsig', 'rep_masks', 'rep_roi_raw', 'coll_masks'):
+        # the .mib series: each rank decoded only its 3 frames, everybody has the complete result
+        fr = o['mib_frames'].reshape(6, -1).astype(np.float64)
+        exp_m = (fr @ o['mib_masks'].reshape(4, -1).T.astype(np.float64)).reshape(world, 6 // world, 4)
+        assert int(o['mib_local_frames']) == 6 // world
+        assert _close(o['mib_full'], exp_m, F32_TOL)
+        assert _close(o['mib_roi_raw'], exp_m[o['mib_roi']], F32_TOL)
+    for k in ('sh_masks', 'sh_sum', 'sh_sumsig', 'rep_masks', 'rep_roi_raw', 'coll_masks', 'mib_full',
+              'mib_roi_raw'):
         for o in outs[1:]:
             assert np.array_equal(outs[0][k], o[k]), k
     assert not [f for f in os.listdir('/dev/shm') if f.startswith(f'ltmi_{os.getuid()}_{port}')]
