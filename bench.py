@@ -423,6 +423,27 @@ def mib_decode(torch, hip, n=16384, reps=10):
                          "traffic": traffic, "traffic_source": source}}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-exec this command line under
+    torch.distributed.run (N ranks on this node, rendezvous on 127.0.0.1 at a free port); the ranks
+    inherit stdout / stderr, so the ONE JSON line of rank 0 is this process's output.  Returns the
+    launcher's exit code."""
+    import socket
+    import subprocess
+    port = os.environ.get('MASTER_PORT')
+    if port is None:
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', port,
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -433,6 +454,11 @@ def main():
     ap.add_argument('--no-extras', action='store_true')
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks (one per GPU) and let
+        # rank 0's JSON line through on the inherited stdout
+        raise SystemExit(self_launch(args.gpus))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -453,8 +479,7 @@ def main():
     import torch
     import torch.distributed as dist
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(device_id)
     use_dist = world > 1 or os.environ.get('LTMI_FORCE_COLLECTIVES') == '1'
     if use_dist:

@@ -32,6 +32,13 @@
 extern "C" {
 #endif
 
+/* libltmi.so is built with -fvisibility=hidden: the functions declared between this push and the pop
+ * at the end of the header are the WHOLE dynamic symbol table of the library (tests/test_runtime_cpu.py
+ * compares `nm -D` with this header). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
+
 #define LTMI_VERSION 1
 
 #define LTMI_OK 0
@@ -291,6 +298,10 @@ int ltmi_comm_all_reduce_sum(ltmi_comm *c, void *buf, int dtype, int64_t n, void
 int ltmi_masks_set_tuning(ltmi_masks *m, int mt, int waves, int ksplit);
 /* name of the kernel variant the last ltmi_apply_masks on this handle launched */
 const char *ltmi_masks_last_kernel(const ltmi_masks *m);
+
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,8 @@ SOURCES = ['ltmi_capi.cpp', 'ltmi_comm.cpp', 'ltmi_dense.hip', 'ltmi_sparse.hip'
 # torch already has in the process (same soname), i.e. the one that matches torch's HIP runtime.
 LINK_LIBS = ['-L/opt/rocm/lib', '-lhipfft', '-ldl']
 ARCH = 'gfx950'
-FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function']
+FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function',
+         '-fvisibility=hidden']   # exported: what include/ltmi.h declares, nothing else
 
 
 def find_hipcc():
@@ -94,10 +95,26 @@ def build(force=False, verbose=True, asan=False, hardened=False):
         for out in ex.map(run, jobs):
             if verbose and out.strip():
                 print(out)
-    if force or jobs or not os.path.exists(lib):
-        run([hipcc, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', lib] + extra + objs
-            + LINK_LIBS)
+    if force or jobs or not os.path.exists(lib) or _stale(lib, [os.path.abspath(__file__)]):
+        # the dynamic symbol table = the functions include/ltmi.h declares: -fvisibility=hidden covers
+        # the host code, the version script also hides the kernels' host-side launch stubs (hipcc
+        # gives every __global__ function default visibility)
+        vmap = os.path.join(objdir, 'ltmi.map')
+        with open(vmap, 'w') as f:
+            f.write('{\n  global:\n' + ''.join(f'    {n};\n' for n in header_exports())
+                    + '  local:\n    *;\n};\n')
+        run([hipcc, '-shared', '-fPIC', f'--offload-arch={ARCH}', f'-Wl,--version-script={vmap}',
+             '-o', lib] + extra + objs + LINK_LIBS)
     return lib
+
+
+def header_exports():
+    """names of the functions include/ltmi.h declares"""
+    import re
+    with open(os.path.join(os.path.dirname(HERE), 'include', 'ltmi.h')) as f:
+        hdr = f.read()
+    names = set(re.findall(r'\b(ltmi_[a-z_0-9]+)\s*\(', hdr))
+    return sorted(names)
 
 
 if __name__ == '__main__':

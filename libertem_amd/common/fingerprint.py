@@ -1,0 +1,110 @@
+"""
+Cheap content fingerprints of UDF parameters.
+
+The reference evaluates the mask factories on every run and on every task
+(src/libertem/udf/masks.py:331-351, common/container.py:260-314), so an array that a factory closes
+over may be modified in place between two `run_udf` calls and the next run sees the new values.
+This implementation keeps evaluated stacks (device images) and whole run plans across runs; what
+identifies "the same parameters" therefore has to look INTO the objects: the identity of a factory
+plus a fingerprint of every array it can see (closure cells, defaults, functools.partial arguments,
+module globals it names).  A fingerprint hashes a bounded sample of the bytes -- 4096 pieces of 64
+bytes spread evenly over the buffer, everything for buffers up to 256 KiB -- so that it costs tens
+of microseconds for a 200 MiB stack: any in-place change that touches a contiguous run of more than
+1/4096 of the array (`m *= 2`, `m[3] = ...`, `m[:, 10:20] = 0`) is seen; a single changed element of
+a large array may not be (documented contract: DESIGN.md section 3).
+"""
+import functools
+
+import numpy as np
+
+try:
+    import xxhash
+
+    def _hash(b):
+        return xxhash.xxh3_64_intdigest(b)
+except Exception:                                            # pragma: no cover
+    import hashlib
+
+    def _hash(b):
+        return int.from_bytes(hashlib.blake2b(b, digest_size=8).digest(), 'little')
+
+FULL_BYTES = 256 * 1024
+PIECES = 4096
+PIECE_BYTES = 64
+
+
+def array_fingerprint(a):
+    a = np.asarray(a)
+    head = (a.shape, a.dtype.str)
+    if a.dtype.hasobject:
+        return head + (id(a),)
+    nbytes = a.nbytes
+    if nbytes == 0:
+        return head + (0,)
+    if not a.flags.c_contiguous:
+        if nbytes <= FULL_BYTES:
+            return head + (_hash(np.ascontiguousarray(a).view(np.uint8).data),)
+        # strided sample, at most ~64 Ki elements
+        per_axis = max(1, int(round((a.size / 65536.0) ** (1.0 / max(1, a.ndim)))))
+        sub = a[tuple(slice(None, None, per_axis) for _ in range(a.ndim))]
+        return head + (a.strides, _hash(np.ascontiguousarray(sub).view(np.uint8).data))
+    flat = a.reshape(-1).view(np.uint8)
+    if nbytes <= FULL_BYTES:
+        return head + (_hash(flat.data),)
+    step = nbytes // PIECES
+    sample = np.lib.stride_tricks.as_strided(flat, shape=(PIECES, PIECE_BYTES), strides=(step, 1))
+    tail = flat[-PIECE_BYTES:]
+    return head + (_hash(np.ascontiguousarray(sample).data), _hash(tail.data))
+
+
+def _sparse_parts(obj):
+    """arrays of a scipy.sparse matrix (or anything that looks like one)"""
+    parts = []
+    for name in ('data', 'indices', 'indptr', 'row', 'col', 'coords'):
+        v = getattr(obj, name, None)
+        if isinstance(v, np.ndarray):
+            parts.append(v)
+    return parts
+
+
+def fingerprint(obj, _depth=0):
+    """hashable value that changes when `obj`, or an array `obj` can reach, changes"""
+    if isinstance(obj, np.ndarray):
+        return ('nd', id(obj)) + array_fingerprint(obj)
+    if obj is None or isinstance(obj, (bool, int, float, complex, str, bytes, np.generic)):
+        return ('v', obj)
+    if _depth > 3:
+        return ('id', id(obj))
+    if isinstance(obj, (list, tuple)):
+        return ('seq', id(obj), len(obj)) + tuple(fingerprint(x, _depth + 1) for x in obj)
+    if isinstance(obj, dict):
+        return ('map', id(obj)) + tuple((k, fingerprint(v, _depth + 1)) for k, v in obj.items())
+    if isinstance(obj, functools.partial):
+        return ('partial', id(obj), fingerprint(obj.func, _depth + 1),
+                fingerprint(obj.args, _depth + 1), fingerprint(obj.keywords, _depth + 1))
+    sp_parts = _sparse_parts(obj) if hasattr(obj, 'shape') and hasattr(obj, 'dtype') else None
+    if sp_parts:
+        return ('sp', id(obj)) + tuple(array_fingerprint(p) for p in sp_parts)
+    if callable(obj):
+        out = ['fn', id(obj)]
+        fn = getattr(obj, '__func__', obj)
+        for cell in (getattr(fn, '__closure__', None) or ()):
+            try:
+                out.append(fingerprint(cell.cell_contents, _depth + 1))
+            except ValueError:                                  # empty cell
+                out.append(None)
+        for d in (getattr(fn, '__defaults__', None) or ()):
+            out.append(fingerprint(d, _depth + 1))
+        for k, d in (getattr(fn, '__kwdefaults__', None) or {}).items():
+            out.append((k, fingerprint(d, _depth + 1)))
+        code, glob = getattr(fn, '__code__', None), getattr(fn, '__globals__', None)
+        if code is not None and glob is not None:
+            for name in code.co_names:
+                v = glob.get(name)
+                if isinstance(v, np.ndarray):
+                    out.append((name, fingerprint(v, _depth + 1)))
+        bound = getattr(obj, '__self__', None)
+        if bound is not None and not isinstance(bound, type(np)):
+            out.append(('self', id(bound)))
+        return tuple(out)
+    return ('id', id(obj))

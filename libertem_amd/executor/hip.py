@@ -498,6 +498,7 @@ class HipJobExecutor(JobExecutor):
                 return HipArray(t[g0:g0 + shape[0]], shape, dtype)
             self._result_target = device_target
         deferred = {}                           # shared mode: (udf idx, name) -> [(start, stop, rows)]
+        direct_rows = {}                        # (udf idx, name) -> [(start, stop)] written by kernels
         generic_parts = []                      # (task, {udf idx: exported results})
         torch = None
         if self.gpu_id is not None:
@@ -548,6 +549,22 @@ class HipJobExecutor(JobExecutor):
                         continue
                     idle[0] = False
                     self._flush_deferred(udf, i, name, dev_full[i], deferred, keep=not final)
+                    if direct_rows.get(key) and key in host_np:
+                        # rows the kernels wrote straight into the host buffer exist nowhere on the
+                        # device: bring THIS rank's rows back before the buffers are combined (the
+                        # streamed delivery was called off, e.g. another buffer of the run was not
+                        # fully delivered on some rank)
+                        self._make_current()
+                        if name not in dev_full[i]:
+                            dev_full[i][name] = torch.zeros(
+                                buf.shape, dtype=torch_dtype_for(buf.dtype),
+                                device=f'cuda:{self.gpu_id}')
+                        src = host_np[key]
+                        for start, stop in direct_rows.pop(key):
+                            dev_full[i][name][start:stop].copy_(
+                                torch.from_numpy(np.array(src[start:stop], copy=True)).view(
+                                    dev_full[i][name].dtype).reshape(
+                                        dev_full[i][name][start:stop].shape))
                     full = dev_full[i].get(name)
                     self._make_current()
                     if full is None:
@@ -574,7 +591,7 @@ class HipJobExecutor(JobExecutor):
                 if mode == 'device':
                     self._merge_on_device(udf, results, task, decl, dev_full[i],
                                           may_adopt=not partial,
-                                          defer=(deferred, i, expected, direct)
+                                          defer=(deferred, i, expected, direct, direct_rows)
                                           if sink_on and layout else None)
                 else:
                     results.export()
@@ -692,6 +709,8 @@ class HipJobExecutor(JobExecutor):
                 if isinstance(part, HostMappedArray):
                     # the kernels wrote these rows into the final host buffer themselves
                     defer[3][(defer[1], name)] += stop - start
+                    if len(defer) > 4:
+                        defer[4].setdefault((defer[1], name), []).append((start, stop))
                     continue
                 # rows travel to the host on the copy stream (shared host segment / pinned
                 # buffer); keep the partition result only as the fallback source
@@ -719,7 +738,9 @@ class HipJobExecutor(JobExecutor):
                 dst = full[name]
                 pt = part.torch.reshape(part.shape)
                 if np.dtype(buf_main.dtype) in hip.AXPY_DTYPES and dst.is_contiguous() \
-                        and pt.is_contiguous():
+                        and pt.is_contiguous() and np.dtype(buf_main.dtype) != np.bool_:
+                    # (bool: `+=` is a logical OR in NumPy and in the reference's merge; adding the
+                    # bytes would leave 2 in a bool -- torch's in-place add below keeps the OR)
                     # dest += src in HBM with the library's own kernel (ltmi_axpy)
                     hip.axpy(self.gpu_id, dst.data_ptr(), pt.data_ptr(), buf_main.dtype,
                              dst.numel(), stream=self._stream_ptr)

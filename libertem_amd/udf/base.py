@@ -829,6 +829,14 @@ class UDFPartRunner:
             and ts is not None and (ts._debug or {}).get('backend') == HIP and len(ts) == 1
             and all(getattr(u, 'folds_corrections', None) is not None
                     and u.folds_corrections(corr, meta) for u in self._udfs))
+        # a tileshape forced on the dataset replaces whatever scheme was negotiated when the tiles
+        # are read (MemPartition.get_tiles) or the scheme is re-negotiated for the device: if it cuts
+        # the frames, result rows are accumulated over several tiles -- no write-once buffers then
+        ds = getattr(partition, '_ds', None)
+        forced = ds.get_forced_tileshape() if hasattr(ds, 'get_forced_tileshape') else None
+        meta.sig_sliced_tiles = bool(
+            forced is not None and tuple(forced)[-len(tuple(partition.meta.shape.sig)):]
+            != tuple(partition.meta.shape.sig))
         for i, udf in enumerate(self._udfs):
             udf.set_backend(backend)
             udf.set_meta(meta)

@@ -446,7 +446,8 @@ class ApplyMasksUDF(UDF):
         into the run's final host buffer.  (Not with a folded dark frame: its constant is
         subtracted in a second pass over the rows.)"""
         ts = self.meta.tiling_scheme if self.meta is not None else None
-        if ts is None or len(ts) != 1 or getattr(self.meta, 'corrections_folded', False):
+        if ts is None or len(ts) != 1 or getattr(self.meta, 'corrections_folded', False) \
+                or getattr(self.meta, 'sig_sliced_tiles', False):
             return ()
         return ('intensity',)
 

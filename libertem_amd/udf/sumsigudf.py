@@ -60,7 +60,8 @@ class SumSigUDF(UDF):
     def get_write_once_buffers(self):
         """whole-frame tiles: one kernel call per row (see ApplyMasksUDF.get_write_once_buffers)"""
         ts = self.meta.tiling_scheme if self.meta is not None else None
-        if ts is None or len(ts) != 1 or getattr(self.meta, 'corrections_folded', False):
+        if ts is None or len(ts) != 1 or getattr(self.meta, 'corrections_folded', False) \
+                or getattr(self.meta, 'sig_sliced_tiles', False):
             return ()
         return ('intensity',)
 

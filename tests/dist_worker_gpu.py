@@ -120,6 +120,22 @@ def main():
     out['mib_frames'] = mib_frames
     out['mib_roi'] = mib_roi
     out['mib_local_frames'] = np.array(ds_mib.decode_bytes // (384 + 32 * 64 * 2))
+    # (6) a run whose shared delivery is called off: one UDF declares a 'disjoint' device buffer but
+    #     keeps it out of the streamed delivery (postprocess(), no write-once rows) -> all_ok() is
+    #     False on every rank and EVERY buffer goes through the collectives -- also the rows of
+    #     ApplyMasksUDF / SumSigUDF that the kernels had already written into the host segment
+    class LateSumSig(SumSigUDF):
+        def get_write_once_buffers(self):
+            return ()
+
+        def postprocess(self):
+            pass
+    res6 = ctx.run_udf(dataset=ds, udf=[ApplyMasksUDF(mask_factories=lambda: masks), LateSumSig(),
+                                        SumSigUDF()])
+    out['mix_via'] = np.array(ex.last_result_via)
+    out['mix_masks'] = np.array(res6[0]['intensity'].data)
+    out['mix_late'] = np.array(res6[1]['intensity'].data)
+    out['mix_sumsig'] = np.array(res6[2]['intensity'].data)
     out['masks'] = masks
     np.savez(os.path.join(out_dir, f'rank{rank}.npz'), **out)
     dist.barrier()

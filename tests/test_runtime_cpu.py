@@ -317,6 +317,13 @@ def test_c_abi_exports():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/ltmi.h but not exported"
     assert set(hip.EXPORTS) == declared
+    # ... and nothing else: the dynamic symbol table of the library IS the header
+    # (-fvisibility=hidden + version script, libertem_amd/build.py)
+    import subprocess
+    nm = subprocess.run(['nm', '-D', '--defined-only', L._name], stdout=subprocess.PIPE, text=True,
+                        check=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if ln.strip()}
+    assert exported == declared, sorted(exported ^ declared)
     assert L.ltmi_version() == 1
     n = ctypes.c_int(-1)
     assert L.ltmi_device_count(ctypes.byref(n)) == 0 and n.value >= 0

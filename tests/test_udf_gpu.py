@@ -353,6 +353,139 @@ def test_full_size_properties(ctx):
     assert np.array_equal(r.reshape((n, 4))[idx], ref[0])
 
 
+def test_c2_full_size_16_masks_benchmarked_kernel(ctx):
+    """BASELINE.json C2 exactly as bench.py runs it: 65 536 frames of 256x256 uint16 in [0, 4096),
+    the 16-mask float32 stack of rng(2), ONE partition -> the matrix-core kernel
+    k_dense_lds<NG=1, 2 tiles> on a 512-workgroup grid (not the VALU-column variant a 4-mask stack
+    selects).  Checks: the kernel that ran; 32 frames against the oracle ELEMENT-wise (all data
+    positive: rtol 1e-5, no norm-wise slack); exact linearity under a power-of-two scaling of the
+    stack; linearity in the masks to 1e-5."""
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd import hip
+    n = 256 * 256
+    g = torch.Generator(device='cuda').manual_seed(11)
+    frames = torch.empty((n, 256 * 256), dtype=torch.int16, device='cuda')
+    for i in range(0, n, 4096):
+        frames[i:i + 4096] = torch.randint(0, 4096, (4096, 256 * 256), generator=g, device='cuda',
+                                           dtype=torch.int16)
+    ds = ctx.load('memory', data=frames.reshape((256, 256, 256, 256)), dtype=np.uint16, sig_dims=2,
+                  num_partitions=1)
+    masks = np.random.default_rng(2).random((16, 256, 256)).astype(np.float32)
+    udf = ApplyMasksUDF(mask_factories=lambda: masks, use_sparse=False, mask_count=16,
+                        mask_dtype=np.float32)
+    hip.KernelTimer.start()
+    r = ctx.run_udf(dataset=ds, udf=udf)['intensity'].data
+    kernels = [k for _, _, k in hip.KernelTimer.stop()]
+    assert len(kernels) == 1, kernels
+    assert 'k_dense_lds' in kernels[0] and 'NG=1' in kernels[0] and 'grid=(512' in kernels[0], kernels
+    assert r.shape == (256, 256, 16) and r.dtype == np.float32
+    flat = r.reshape((n, 16))
+    rng = np.random.default_rng(12)
+    idx = np.unique(np.concatenate([[0, n - 1], rng.choice(n, 32, replace=False)]))
+    sub = frames[torch.as_tensor(idx, device='cuda')].cpu().numpy().view(np.uint16)
+    ref = opath.apply_masks(sub.reshape((1, len(idx), 256, 256)), masks)[0]
+    assert np.allclose(flat[idx], ref, rtol=F32_TOL, atol=0)
+    ref64 = sub.astype(np.float64) @ masks.reshape((16, -1)).T.astype(np.float64)
+    assert np.allclose(flat[idx], ref64, rtol=F32_TOL, atol=0)
+    # a power-of-two scaling of the stack is exact in float32
+    masks4 = masks * np.float32(4)
+    r4 = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda: masks4, use_sparse=False,
+                                                   mask_count=16))['intensity'].data
+    assert np.array_equal(r4, 4 * r)
+    # linearity in the masks: column 15 := 0.5 * m0 + m1 - 0.25 * m2
+    mixed = masks.copy()
+    mixed[15] = 0.5 * masks[0] + masks[1] - 0.25 * masks[2]
+    rm = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda: mixed, use_sparse=False,
+                                                   mask_count=16))['intensity'].data
+    assert np.array_equal(rm[..., :15], r[..., :15])
+    assert np.allclose(rm[..., 15], 0.5 * r[..., 0] + r[..., 1] - 0.25 * r[..., 2], rtol=F32_TOL,
+                       atol=0)
+
+
+@pytest.mark.parametrize('resident', ['host', 'device'])
+def test_c4_workload_through_run_udf(ctx, resident):
+    """BASELINE.json C4 through the product wiring: radial_bins(n_bins=1024, use_sparse=True) ->
+    MaskContainer -> CSR -> blocked device image -> k_bell_apply -> delivery of the wide
+    (frames x 1024) result, on 4096 frames of 256x256 uint16, host- and device-resident, and with
+    result_where='device'.  Against the oracle's restatement of the reference's CSR loop
+    (oracle.path.apply_masks_sparse) on 24 frames and float64 scipy on all of them."""
+    import scipy.sparse as sp
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd import masks as M
+    from libertem_amd import hip
+    from libertem_amd.common.hiparray import HipArray
+    rng = np.random.default_rng(44)
+    data = rng.integers(0, 4096, (16, 256, 256, 256), dtype=np.uint16)
+    if resident == 'device':
+        ds = _device_ds(ctx, data, 2)
+    else:
+        ds = ctx.load('memory', data=data, sig_dims=2, num_partitions=2)
+
+    def rings():
+        return M.radial_bins(centerX=128, centerY=128, imageSizeX=256, imageSizeY=256,
+                             n_bins=1024, use_sparse=True, dtype=np.float32)
+    udf = ApplyMasksUDF(mask_factories=rings, use_sparse='scipy.sparse', mask_count=1024,
+                        mask_dtype=np.float32)
+    hip.KernelTimer.start()
+    res = ctx.run_udf(dataset=ds, udf=udf)
+    kernels = {k.split(' ')[0] for _, _, k in hip.KernelTimer.stop()}
+    assert kernels and all(k.startswith('k_bell_apply') for k in kernels), kernels
+    got = res['intensity'].data
+    assert got.shape == (16, 256, 1024) and got.dtype == np.float32
+    stack = sp.csr_matrix(omasks.radial_bins(128, 128, 256, 256, n_bins=1024, use_sparse=True,
+                                             dtype=np.float32))
+    assert stack.shape == (1024, 65536) and stack.nnz == 432407
+    flat = data.reshape((4096, 65536))
+    ref64 = np.asarray(flat.astype(np.float64) @ stack.T.astype(np.float64))
+    scale = np.abs(ref64).max()
+    g = got.reshape((4096, 1024))
+    assert np.allclose(g, ref64, rtol=F32_TOL, atol=F32_TOL * scale)
+    # element-wise where the rings hold enough pixels for a relative statement (all data >= 0)
+    big = ref64 > 1e-3 * scale
+    assert big.mean() > 0.5 and np.allclose(g[big], ref64[big], rtol=F32_TOL, atol=0)
+    idx = np.concatenate([[0, 4095], rng.choice(4096, 22, replace=False)])
+    ref = opath.apply_masks_sparse(flat[idx].reshape((1, 24, 256, 256)), stack)[0]
+    assert ref.dtype == np.float32
+    assert np.allclose(g[idx], ref, rtol=F32_TOL, atol=F32_TOL * scale)
+    # the 16 MiB result kept in HBM
+    dev = ctx.run_udf(dataset=ds, udf=udf, result_where='device')
+    assert isinstance(dev['intensity'].device_data, HipArray)
+    assert np.array_equal(dev['intensity'].data, got)
+
+
+def test_write_once_rows_not_with_frame_cutting_tileshape(ctx):
+    """A tileshape forced on the dataset that cuts the frames replaces the negotiated scheme when the
+    tiles are read (intent 'frame': ApplyMasksUDF next to a process_frame UDF): result rows then are
+    sums over several tiles -- the write-once shortcut (`=` into an un-zeroed buffer) must be off."""
+    from libertem_amd.udf.base import UDF
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd.udf.sumsigudf import SumSigUDF
+
+    class FrameSeen(UDF):
+        def get_backends(self):
+            return (UDF.BACKEND_HIP,)
+
+        def get_result_buffers(self):
+            return {'seen': self.buffer(kind='nav', dtype=np.float32)}
+
+        def process_frame(self, frame):
+            self.results.seen[:] += 1
+
+    rng = np.random.default_rng(71)
+    data = rng.integers(0, 1000, (3, 7, 32, 64)).astype(np.uint16)
+    masks = rng.random((4, 32, 64)).astype(np.float32)
+    ref = opath.apply_masks(data, masks, num_partitions=2)
+    for tileshape in ((5, 8, 64), (3, 32, 64)):
+        ds = ctx.load('memory', data=data, num_partitions=2, sig_dims=2, tileshape=tileshape)
+        res = ctx.run_udf(dataset=ds, udf=[ApplyMasksUDF(mask_factories=lambda: masks),
+                                           SumSigUDF(), FrameSeen()])
+        assert _close(res[0]['intensity'].data, ref, F32_TOL), tileshape
+        assert np.array_equal(res[1]['intensity'].data, data.astype(np.float32).sum(axis=(2, 3)))
+        assert np.all(res[2]['seen'].data >= 1)
+        alone = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda: masks))
+        assert _close(alone['intensity'].data, ref, F32_TOL), tileshape
+
+
 def test_mask_cache_reuse_and_eviction(ctx):
     from libertem_amd.udf import masks as um
     rng = np.random.default_rng(10)
@@ -1403,6 +1536,11 @@ def test_two_ranks_share_results_through_host_segment(tmp_path, world):
         assert np.array_equal(o['sh_sumsig'], full.astype(np.float32).sum(axis=(2, 3)))
         assert bool(o['sh_first_still_valid']) and bool(o['sh_bare_still_valid'])
         assert bool(o['sh_held_equal']) and str(o['sh_via_when_full']) == 'collective'
+        # delivery through the shared segment called off by ONE buffer: the rows the kernels wrote
+        # directly into it still reach every rank (through the collectives)
+        assert _close(o['mix_masks'], exp, F32_TOL)
+        assert np.array_equal(o['mix_late'], o['sh_sumsig'])
+        assert np.array_equal(o['mix_sumsig'], o['sh_sumsig'])
         assert 4 <= int(o['sh_slots']) <= 6
         # live feed per rank + run_udf_iter: 2 steps, after step k the first k + 1 partitions of
         # every rank are merged (device merge + collective) and marked in the damage map
@@ -1432,9 +1570,12 @@ def test_two_ranks_share_results_through_host_segment(tmp_path, world):
     assert not [f for f in os.listdir('/dev/shm') if f.startswith(f'ltmi_{os.getuid()}_{port}')]
 
 
-def test_bench_contract_with_two_ranks_on_one_gpu():
+@pytest.mark.parametrize('launcher', ['torchrun', 'self'])
+def test_bench_contract_with_two_ranks_on_one_gpu(launcher):
     """bench.py end to end on the N>1 path (sharded dataset, shared-segment delivery, max-over-ranks
-    timing, one JSON line from rank 0) -- two gloo ranks on GPU 0 stand in for two GPUs."""
+    timing, one JSON line from rank 0) -- two gloo ranks on GPU 0 stand in for two GPUs.
+    'torchrun': started the way the driver's contract describes; 'self': plain
+    `python bench.py --gpus 2`, bench.py spawns its own ranks."""
     import json
     import socket
     import subprocess
@@ -1445,9 +1586,15 @@ def test_bench_contract_with_two_ranks_on_one_gpu():
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, LTMI_BENCH_DEVICE='0', LTMI_BENCH_BACKEND='gloo', OMP_NUM_THREADS='1')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
-           '--master-addr', '127.0.0.1', '--master-port', str(port),
-           os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1']
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR'):
+        env.pop(k, None)
+    if launcher == 'torchrun':
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+               '--master-addr', '127.0.0.1', '--master-port', str(port),
+               os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1']
+    else:
+        cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3',
+               '--warmup', '1']
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                        timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
