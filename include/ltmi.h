@@ -153,12 +153,19 @@ int ltmi_apply_masks_shifted_host(ltmi_masks *m, const void *tile, int tile_dtyp
  * SumUDF.process_tile: out[p] (+)= sum_f tile[f, p]        (src/libertem/udf/sum.py:43-48)
  *   out: device (n_px,) of out_dtype; `workspace` device scratch of at least
  *   ltmi_sum_frames_workspace(n_frames, n_px, out_dtype) bytes (may be NULL if that is 0).
+ *   out_dtype follows the reference's rule "result dtype = input dtype" (udf/sum.py:38-40):
+ *   float32 / float64 for any real tile; complex64 / complex128 for complex (or real) tiles; an
+ *   integer dtype for integer tiles (SumUDF(dtype=<integer>)): exact int64 accumulation, stored
+ *   truncated = NumPy's wrap-around in the narrower type
+ *   (reference tests/analysis/test_analysis_sum.py:157-163 `test_sum_complex`).
  */
 int64_t ltmi_sum_frames_workspace(int64_t n_frames, int64_t n_px, int out_dtype);
 int ltmi_sum_frames(int device, const void *tile, int tile_dtype, int64_t n_frames, int64_t n_px,
                     int64_t ld_tile, void *out, int out_dtype, int accumulate, void *workspace,
                     void *stream);
-/* SumSigUDF.process_tile: out[f] (+)= sum_p tile[f, p]   (src/libertem/udf/sumsigudf.py:30-39) */
+/* SumSigUDF.process_tile: out[f] (+)= sum_p tile[f, p]   (src/libertem/udf/sumsigudf.py:30-39);
+ * out_dtype float32 / float64 for real tiles, complex64 / complex128 for complex tiles
+ * (result_type(input, float32), udf/sumsigudf.py:23) */
 int ltmi_sum_sig(int device, const void *tile, int tile_dtype, int64_t n_frames, int64_t n_px,
                  int64_t ld_tile, void *out, int out_dtype, int accumulate, void *stream);
 

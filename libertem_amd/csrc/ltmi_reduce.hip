@@ -62,6 +62,43 @@ k_sum_sig(const T *__restrict__ tile, int64_t ld, int64_t n_px, A *__restrict__ 
     }
 }
 
+// complex frames: tile rows are (re, im) pairs of R; one block per frame, two sums (even / odd elements)
+template <typename R, typename A>
+__global__ void __launch_bounds__(256)
+k_sum_sig_cplx(const R *__restrict__ tile, int64_t ld_r, int64_t n_px, A *__restrict__ out,
+               int accumulate) {
+    __shared__ A red[8];
+    const int64_t f = blockIdx.x;
+    const R *row = tile + f * ld_r;
+    A re = 0, im = 0;
+    for (int64_t p = threadIdx.x; p < n_px; p += 256) {
+        re += (A)__builtin_nontemporal_load(row + 2 * p);
+        im += (A)__builtin_nontemporal_load(row + 2 * p + 1);
+    }
+    re = wave_sum<A>(re);
+    im = wave_sum<A>(im);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = re; red[4 + (threadIdx.x >> 6)] = im; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const A *r = red + 4 * threadIdx.x;
+        const A s = (r[0] + r[1]) + (r[2] + r[3]);
+        A &o = out[2 * f + threadIdx.x];
+        o = accumulate ? o + s : s;
+    }
+}
+
+// out[i * stride] (+)= (O)src[i]   (integers: two's complement truncation = NumPy's wrap-around);
+// stride 2 = the real parts of a complex buffer, whose imaginary parts are zeroed unless accumulating
+template <typename S, typename O>
+__global__ void k_store_cast(const S *__restrict__ src, int64_t n, O *__restrict__ out, int stride,
+                             int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    O &o = out[i * stride];
+    o = accumulate ? (O)(o + (O)src[i]) : (O)src[i];
+    if (stride == 2 && !accumulate) out[i * 2 + 1] = (O)0;
+}
+
 // ---- sum over frames ----------------------------------------------------------------------------
 // grid = (pixel tiles of 256*VEC, frame splits). Each thread owns VEC consecutive pixels and walks
 // its slab of frames; partial sums per split go to the workspace and are reduced in fixed order.
@@ -230,6 +267,25 @@ extern "C" int ltmi_sum_sig(int device, const void *tile, int tile_dtype, int64_
     if (!tile || !out) LTMI_FAIL(LTMI_E_INVALID, "ltmi_sum_sig: null pointer");
     LTMI_HIP(hipSetDevice(device));
     hipStream_t stream = (hipStream_t)stream_;
+    if (tile_dtype == LTMI_C64 || tile_dtype == LTMI_C128) {
+        // complex frames -> complex sums (udf/sumsigudf.py:23: result_type(input, float32) keeps
+        // complex64 / complex128): real and imaginary parts are summed separately
+        const dim3 grid((unsigned)n_frames);
+        if (tile_dtype == LTMI_C64 && out_dtype == LTMI_C64)
+            hipLaunchKernelGGL((k_sum_sig_cplx<float, float>), grid, dim3(256), 0, stream,
+                               (const float *)tile, 2 * ld_tile, n_px, (float *)out, accumulate);
+        else if (tile_dtype == LTMI_C64 && out_dtype == LTMI_C128)
+            hipLaunchKernelGGL((k_sum_sig_cplx<float, double>), grid, dim3(256), 0, stream,
+                               (const float *)tile, 2 * ld_tile, n_px, (double *)out, accumulate);
+        else if (tile_dtype == LTMI_C128 && out_dtype == LTMI_C128)
+            hipLaunchKernelGGL((k_sum_sig_cplx<double, double>), grid, dim3(256), 0, stream,
+                               (const double *)tile, 2 * ld_tile, n_px, (double *)out, accumulate);
+        else
+            LTMI_FAIL(LTMI_E_DTYPE, "ltmi_sum_sig: unsupported dtypes tile=%s out=%s",
+                      dtype_name(tile_dtype), dtype_name(out_dtype));
+        LTMI_HIP(hipGetLastError());
+        return LTMI_OK;
+    }
     if (out_dtype == LTMI_F32) {
         LTMI_DISPATCH_TILE(run_sum_sig, float, tile, n_frames, n_px, ld_tile, out, accumulate, stream)
     } else if (out_dtype == LTMI_F64) {
@@ -239,10 +295,60 @@ extern "C" int ltmi_sum_sig(int device, const void *tile, int tile_dtype, int64_
               dtype_name(out_dtype));
 }
 
+// How ltmi_sum_frames computes for an output dtype (the tile dtype only selects between the two
+// complex layouts, so the workspace query -- which does not know it -- takes the larger one):
+//   float32 / float64 out : accumulate in that type, straight into `out`
+//   complex out, complex tile : the same on 2 * n_px real columns
+//   complex out, real tile    : real sums into a temporary, stored into the real parts
+//   integer out  : accumulate in int64 (exact), store truncated = NumPy's wrap-around in the narrower
+//                  type (udf/sum.py:38-48 with SumUDF(dtype=<integer>) on integer frames)
+static bool is_int_dtype(int dt) { return dt >= LTMI_BOOL && dt <= LTMI_I64; }
+static bool is_cplx_dtype(int dt) { return dt == LTMI_C64 || dt == LTMI_C128; }
+
+static int64_t split_bytes(int64_t n_frames, int64_t n_cols, int acc_size) {
+    const int fsplit = frames_split(n_frames, n_cols);
+    return fsplit <= 1 ? 0 : (int64_t)fsplit * n_cols * acc_size;
+}
+
 extern "C" int64_t ltmi_sum_frames_workspace(int64_t n_frames, int64_t n_px, int out_dtype) {
-    const int fsplit = frames_split(n_frames, n_px);
-    if (fsplit <= 1) return 0;
-    return (int64_t)fsplit * n_px * dtype_size(out_dtype);
+    if (is_cplx_dtype(out_dtype)) {
+        const int rs = dtype_size(out_dtype) / 2;
+        return std::max(split_bytes(n_frames, 2 * n_px, rs),
+                        split_bytes(n_frames, n_px, rs) + n_px * rs);
+    }
+    if (is_int_dtype(out_dtype)) return split_bytes(n_frames, n_px, 8) + n_px * 8;
+    return split_bytes(n_frames, n_px, dtype_size(out_dtype));
+}
+
+template <typename S>
+static int store_cast(const S *src, int64_t n, void *out, int out_dtype, int stride, int accumulate,
+                      hipStream_t stream) {
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+#define LTMI_CAST_CASE(DT, O)                                                                       \
+    case DT: hipLaunchKernelGGL((k_store_cast<S, O>), grid, block, 0, stream, src, n, (O *)out,     \
+                                stride, accumulate); break;
+    switch (out_dtype) {
+        LTMI_CAST_CASE(LTMI_U8, uint8_t) LTMI_CAST_CASE(LTMI_I8, int8_t)
+        LTMI_CAST_CASE(LTMI_U16, uint16_t) LTMI_CAST_CASE(LTMI_I16, int16_t)
+        LTMI_CAST_CASE(LTMI_U32, uint32_t) LTMI_CAST_CASE(LTMI_I32, int32_t)
+        LTMI_CAST_CASE(LTMI_U64, uint64_t) LTMI_CAST_CASE(LTMI_I64, int64_t)
+        LTMI_CAST_CASE(LTMI_F32, float) LTMI_CAST_CASE(LTMI_F64, double)
+        default: LTMI_FAIL(LTMI_E_DTYPE, "store_cast: output dtype %s", dtype_name(out_dtype));
+    }
+#undef LTMI_CAST_CASE
+    LTMI_HIP(hipGetLastError());
+    return LTMI_OK;
+}
+
+template <typename T, typename A>
+static int run_sum_frames_cast(const void *tile, int64_t n_frames, int64_t n_px, int64_t ld,
+                               void *out, int out_dtype, int stride, int accumulate, void *ws,
+                               hipStream_t stream) {
+    if (!ws) LTMI_FAIL(LTMI_E_INVALID, "ltmi_sum_frames: workspace required");
+    A *tmp = (A *)((char *)ws + split_bytes(n_frames, n_px, sizeof(A)));
+    int rc = run_sum_frames<T, A>(tile, n_frames, n_px, ld, tmp, 0, ws, stream);
+    if (rc != LTMI_OK) return rc;
+    return store_cast<A>(tmp, n_px, out, out_dtype, stride, accumulate, stream);
 }
 
 extern "C" int ltmi_sum_frames(int device, const void *tile, int tile_dtype, int64_t n_frames,
@@ -255,10 +361,41 @@ extern "C" int ltmi_sum_frames(int device, const void *tile, int tile_dtype, int
     LTMI_HIP(hipSetDevice(device));
     hipStream_t stream = (hipStream_t)stream_;
     (void)tile_vec;
+    if (is_cplx_dtype(tile_dtype)) {
+        // complex frames are 2 * n_px real columns (udf/sum.py:38-40: the result keeps the complex dtype)
+        const int rt = tile_dtype == LTMI_C64 ? LTMI_F32 : LTMI_F64;
+        if (out_dtype == LTMI_C64 && rt == LTMI_F32)
+            return run_sum_frames<float, float>(tile, n_frames, 2 * n_px, 2 * ld_tile, out, accumulate,
+                                                workspace, stream);
+        if (out_dtype == LTMI_C128 && rt == LTMI_F32)
+            return run_sum_frames<float, double>(tile, n_frames, 2 * n_px, 2 * ld_tile, out, accumulate,
+                                                 workspace, stream);
+        if (out_dtype == LTMI_C128 && rt == LTMI_F64)
+            return run_sum_frames<double, double>(tile, n_frames, 2 * n_px, 2 * ld_tile, out,
+                                                  accumulate, workspace, stream);
+        LTMI_FAIL(LTMI_E_DTYPE, "ltmi_sum_frames: unsupported dtypes tile=%s out=%s",
+                  dtype_name(tile_dtype), dtype_name(out_dtype));
+    }
     if (out_dtype == LTMI_F32) {
         LTMI_DISPATCH_TILE(run_sum_frames, float, tile, n_frames, n_px, ld_tile, out, accumulate, workspace, stream)
     } else if (out_dtype == LTMI_F64) {
         LTMI_DISPATCH_TILE(run_sum_frames, double, tile, n_frames, n_px, ld_tile, out, accumulate, workspace, stream)
+    } else if (out_dtype == LTMI_C64) {
+        LTMI_DISPATCH_TILE(run_sum_frames_cast, float, tile, n_frames, n_px, ld_tile, out, LTMI_F32, 2, accumulate, workspace, stream)
+    } else if (out_dtype == LTMI_C128) {
+        LTMI_DISPATCH_TILE(run_sum_frames_cast, double, tile, n_frames, n_px, ld_tile, out, LTMI_F64, 2, accumulate, workspace, stream)
+    } else if (is_int_dtype(out_dtype) && out_dtype != LTMI_BOOL && is_int_dtype(tile_dtype)) {
+        switch (tile_dtype) {
+            case LTMI_BOOL:
+            case LTMI_U8: return run_sum_frames_cast<uint8_t, int64_t>(tile, n_frames, n_px, ld_tile, out, out_dtype, 1, accumulate, workspace, stream);
+            case LTMI_I8: return run_sum_frames_cast<int8_t, int64_t>(tile, n_frames, n_px, ld_tile, out, out_dtype, 1, accumulate, workspace, stream);
+            case LTMI_U16: return run_sum_frames_cast<uint16_t, int64_t>(tile, n_frames, n_px, ld_tile, out, out_dtype, 1, accumulate, workspace, stream);
+            case LTMI_I16: return run_sum_frames_cast<int16_t, int64_t>(tile, n_frames, n_px, ld_tile, out, out_dtype, 1, accumulate, workspace, stream);
+            case LTMI_U32: return run_sum_frames_cast<uint32_t, int64_t>(tile, n_frames, n_px, ld_tile, out, out_dtype, 1, accumulate, workspace, stream);
+            case LTMI_I32: return run_sum_frames_cast<int32_t, int64_t>(tile, n_frames, n_px, ld_tile, out, out_dtype, 1, accumulate, workspace, stream);
+            case LTMI_U64: return run_sum_frames_cast<uint64_t, int64_t>(tile, n_frames, n_px, ld_tile, out, out_dtype, 1, accumulate, workspace, stream);
+            case LTMI_I64: return run_sum_frames_cast<int64_t, int64_t>(tile, n_frames, n_px, ld_tile, out, out_dtype, 1, accumulate, workspace, stream);
+        }
     }
     LTMI_FAIL(LTMI_E_DTYPE, "ltmi_sum_frames: unsupported dtypes tile=%s out=%s",
               dtype_name(tile_dtype), dtype_name(out_dtype));

@@ -399,8 +399,11 @@ class MemPartition(Partition):
             raise RuntimeError(
                 f"partition {self._idx} (frames {self._start_frame}..+{self._num_frames}) is not "
                 f"held by this process (shard {ds.shard} holds frames {lo}..{hi})")
-        if ds.tileshape is not None:
-            # a forced tileshape always wins (reference memory.py:427-445)
+        if ds.tileshape is not None and (array_backend != HIP or tiling_scheme.intent == 'tile'):
+            # a forced tileshape always wins (reference memory.py:427-445).  On the device only for
+            # runs of process_tile UDFs, like the scheme negotiated for it (Negotiator._make_scheme_hip):
+            # next to a process_frame / process_partition UDF the tiles stay whole frames -- the scheme
+            # the UDFs' meta holds -- instead of handing frame pieces to process_frame
             tiling_scheme = TilingScheme.make_for_shape(
                 tileshape=Shape(ds.tileshape, sig_dims=ds.shape.sig.dims),
                 dataset_shape=ds.shape, intent=tiling_scheme.intent)

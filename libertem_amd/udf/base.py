@@ -20,6 +20,7 @@ there is no silent fallback: a HIP-only UDF on a CPU worker raises `HipRequiredE
 """
 import copy
 import itertools
+import sys
 import uuid
 import threading
 import weakref
@@ -34,6 +35,7 @@ from libertem_amd.common.buffers import (
     BufferWrapper, AuxBufferWrapper, PlaceholderBufferWrapper, PreallocBufferWrapper, HipSigView,
 )
 from libertem_amd.common.hiparray import HipArray
+from libertem_amd.common.fingerprint import fingerprint
 from libertem_amd.common.udf import UDFProtocol, UDFMethod, NUMPY, HIP
 from libertem_amd.common.exceptions import UDFException, UDFRunCancelled, JobCancelledError, \
     HipRequiredError
@@ -1035,16 +1037,17 @@ class UDFRunner:
             kw = getattr(u, '_kwargs', None)
             if kw is None:
                 return None
-            vals = []
-            for k, v in kw.items():
-                if isinstance(v, (list, tuple)):
-                    # a list that is mutated in place between runs (mask factories appended or
-                    # replaced) is a different parameter
-                    vals.append((k, id(v), len(v), tuple(id(x) for x in v)))
-                else:
-                    vals.append((k, id(v)))
+            # identity AND a content fingerprint: a list that is mutated in place between runs (mask
+            # factories appended or replaced), an ndarray parameter or an array captured by a mask
+            # factory that is modified in place, is a different parameter (the reference
+            # re-instantiates the UDFs and re-evaluates the factories on every run)
+            vals = [(k, fingerprint(v)) for k, v in kw.items()]
             parts.append((id(u), tuple(vals)))
-        return (id(executor), _canonical_backends(backends), tuple(parts))
+        from libertem_amd.common import udf as udf_common
+        knobs = (udf_common.HIP_DIRECT_ROW_MAX,) + tuple(
+            getattr(sys.modules.get(type(u).__module__), 'FOLD_CORRECTIONS', None)
+            for u in self._udfs)
+        return (id(executor), _canonical_backends(backends), tuple(parts), knobs)
 
     def _prepare_run_for_dataset(self, dataset, executor, roi, corrections, backends, dry):
         key = self._plan_key(executor, roi, corrections, backends, dry)

@@ -20,6 +20,7 @@ from libertem_amd.common.container import MaskContainer
 from libertem_amd.common.buffers import AuxBufferWrapper
 from libertem_amd.common.hiparray import HipArray, HipRowsArray
 from libertem_amd.common.exceptions import HipRequiredError
+from libertem_amd.common.fingerprint import fingerprint
 from libertem_amd.udf.base import UDF
 
 
@@ -34,12 +35,12 @@ _CONTAINER_CACHE_SIZE = 4
 
 
 def _factories_key(mask_factories):
-    """Identity of the factories AND of the list that holds them: a list that the user mutates in
-    place (append / replace a factory) between runs is a different stack (the reference re-evaluates
-    the factories on every run, common/container.py:260-314)."""
-    if isinstance(mask_factories, (list, tuple)):
-        return (id(mask_factories), len(mask_factories), tuple(id(f) for f in mask_factories))
-    return (id(mask_factories),)
+    """Identity of the factories AND of the list that holds them AND a content fingerprint of every
+    array the factories can see (closure cells, defaults, partial arguments, module globals): a list
+    that the user mutates in place (append / replace a factory), or a captured array that is modified
+    in place between runs, is a different stack (the reference re-evaluates the factories on every
+    run, udf/masks.py:331-351, common/container.py:260-314)."""
+    return fingerprint(mask_factories)
 
 
 def _cached_container(mask_factories, dtype, use_sparse, count, default_sparse):

@@ -68,10 +68,11 @@ class SumUDF(UDF):
     def get_task_data(self):
         if self.meta.array_backend != self.BACKEND_HIP:
             raise HipRequiredError("SumUDF needs BACKEND_HIP (an MI355X worker)")
-        if np.dtype(self.meta.input_dtype).kind not in 'f':
+        # result dtype = input dtype (udf/sum.py:38-40): float, complex, or -- SumUDF(dtype=<integer>)
+        # on integer frames -- an integer with NumPy's wrap-around
+        if np.dtype(self.meta.input_dtype).kind not in 'fciu':
             raise NotImplementedError(
-                f"SumUDF on MI355X accumulates in float32/float64; input dtype "
-                f"{self.meta.input_dtype} is not supported yet")
+                f"SumUDF on MI355X: input dtype {self.meta.input_dtype} is not supported")
         return {'workspace': {}}
 
     def _workspace(self, device, nbytes):

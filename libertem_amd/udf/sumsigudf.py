@@ -47,8 +47,8 @@ class SumSigUDF(UDF):
         out = self.results.intensity
         if not isinstance(tile, HipArray) or not isinstance(out, HipArray):
             raise HipRequiredError("SumSigUDF.process_tile expects device tiles and buffers")
-        if out.dtype.kind != 'f':
-            raise NotImplementedError(f"SumSigUDF: result dtype {out.dtype} not supported yet")
+        if out.dtype.kind not in 'fc':
+            raise NotImplementedError(f"SumSigUDF: result dtype {out.dtype} not supported")
         n = tile.shape[0]
         accumulate = not self.results.get_buffer('intensity').write_once
         if self.task_data.engine is not None:

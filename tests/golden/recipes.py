@@ -123,6 +123,21 @@ SUM_CASES = [
     dict(name='u8', nav=(3, 3), sig=(32, 32), dtype='uint8', num_partitions=2, seed=204),
     dict(name='f64', nav=(3, 3), sig=(32, 32), dtype='float64', num_partitions=2, seed=205),
     dict(name='i32', nav=(3, 3), sig=(32, 32), dtype='int32', num_partitions=2, seed=206),
+    # complex frames keep their dtype (reference tests/analysis/test_analysis_sum.py:157-163
+    # `test_sum_complex`; udf/sum.py:38-40, udf/sumsigudf.py:23)
+    dict(name='c64', nav=(4, 5), sig=(32, 24), dtype='complex64', num_partitions=3, seed=207),
+    dict(name='c128', nav=(3, 3), sig=(16, 16), dtype='complex128', num_partitions=2, seed=208),
+    dict(name='c64_tiles', nav=(6, 4), sig=(16, 32), dtype='complex64', num_partitions=2, seed=209,
+         tileshape=(5, 8, 32)),
+    dict(name='c64_as_c128', nav=(3, 4), sig=(16, 16), dtype='complex64', num_partitions=2,
+         seed=210, sum_kwargs=dict(dtype='float64')),
+    # SumUDF(dtype=<integer>) on integer frames: integer result, NumPy wrap-around
+    dict(name='i16_as_i32', nav=(4, 4), sig=(32, 32), dtype='int16', num_partitions=2, seed=211,
+         sum_kwargs=dict(dtype='int32')),
+    dict(name='u8_wraps', nav=(5, 5), sig=(16, 16), dtype='uint8', num_partitions=2, seed=212,
+         sum_kwargs=dict(dtype='uint8')),
+    dict(name='u16_as_i64', nav=(3, 5), sig=(24, 16), dtype='uint16', num_partitions=3, seed=213,
+         sum_kwargs=dict(dtype='int64'), tileshape=(4, 8, 16)),
 ]
 
 
@@ -134,6 +149,8 @@ def make_sum_case(case):
         data = rng.integers(0, 200, shape).astype(dt)
     elif dt.kind == 'i':
         data = rng.integers(-2000, 2000, shape).astype(dt)
+    elif dt.kind == 'c':
+        data = (rng.random(shape) - 0.5 + 1j * (rng.random(shape) - 0.25)).astype(dt)
     else:
         data = rng.random(shape).astype(dt)
     return data

@@ -59,7 +59,7 @@ def test_sums(golden_dir, case):
     data = recipes.make_sum_case(case)
     assert np.array_equal(_sha(data), g[case['name'] + '__sha_data'])
     s = opath.sum_udf(data, num_partitions=case['num_partitions'],
-                      tileshape=case.get('tileshape'))
+                      tileshape=case.get('tileshape'), **case.get('sum_kwargs', {}))
     ss = opath.sumsig_udf(data, num_partitions=case['num_partitions'],
                           tileshape=case.get('tileshape'))
     rs, rss = g[case['name'] + '__sum'], g[case['name'] + '__sumsig']
@@ -67,7 +67,8 @@ def test_sums(golden_dir, case):
     assert np.allclose(s, rs, rtol=1e-6)
     assert np.allclose(ss, rss, rtol=1e-6)
     if np.dtype(case['dtype']).kind in 'iu':
-        # integer-valued data below 2**24: every order of summation is exact
+        # integer-valued data below 2**24 (or integer arithmetic with wrap-around): every order of
+        # summation is exact
         assert np.array_equal(s, rs)
         assert np.array_equal(ss, rss)
 

@@ -154,14 +154,17 @@ def test_sum_plumbing(ctx, golden_dir, case):
     data = recipes.make_sum_case(case)
     ds = ctx.load('memory', data=data, num_partitions=case['num_partitions'], sig_dims=2,
                   tileshape=case.get('tileshape'))
-    s = ctx.run_udf(dataset=ds, udf=NumpySumUDF())['intensity']
+    kw = case.get('sum_kwargs', {})
+    s = ctx.run_udf(dataset=ds, udf=NumpySumUDF(**kw))['intensity']
     ss = ctx.run_udf(dataset=ds, udf=NumpySumSigUDF())['intensity']
     assert s.data.dtype == g[case['name'] + '__sum'].dtype
-    assert np.allclose(s.data, g[case['name'] + '__sum'], rtol=1e-6)
-    assert np.allclose(ss.data, g[case['name'] + '__sumsig'], rtol=1e-6)
+    assert ss.data.dtype == g[case['name'] + '__sumsig'].dtype
+    atol = 1e-6 * np.abs(data).sum(axis=(0, 1)).max() if data.dtype.kind == 'c' else 0
+    assert np.allclose(s.data, g[case['name'] + '__sum'], rtol=1e-6, atol=atol)
+    assert np.allclose(ss.data, g[case['name'] + '__sumsig'], rtol=1e-6, atol=atol)
     # identical tiles, identical order -> identical bits as the oracle's loop
     assert np.array_equal(s.data, opath.sum_udf(data, num_partitions=case['num_partitions'],
-                                                tileshape=case.get('tileshape')))
+                                                tileshape=case.get('tileshape'), **kw))
 
 
 def test_c1_config(ctx):
