@@ -27,7 +27,7 @@ SOURCES = ['ltmi_capi.cpp', 'ltmi_comm.cpp', 'ltmi_dense.hip', 'ltmi_sparse.hip'
 # torch already has in the process (same soname), i.e. the one that matches torch's HIP runtime.
 LINK_LIBS = ['-L/opt/rocm/lib', '-lhipfft', '-ldl']
 ARCH = 'gfx950'
-FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function',
+FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function', '-Wno-inline-asm',
          '-fvisibility=hidden']   # exported: what include/ltmi.h declares, nothing else
 
 
@@ -95,7 +95,7 @@ def build(force=False, verbose=True, asan=False, hardened=False):
         for out in ex.map(run, jobs):
             if verbose and out.strip():
                 print(out)
-    if force or jobs or not os.path.exists(lib) or _stale(lib, [os.path.abspath(__file__)]):
+    if force or jobs or not os.path.exists(lib) or _stale(lib, [os.path.abspath(__file__)] + objs):
         # the dynamic symbol table = the functions include/ltmi.h declares: -fvisibility=hidden covers
         # the host code, the version script also hides the kernels' host-side launch stubs (hipcc
         # gives every __global__ function default visibility)

@@ -10,7 +10,9 @@
 // pixels of a pixel chunk and those pixels are used by several masks of the group, so the
 // (16 masks x touched pixels) block is worth multiplying densely:
 //
-//   * image: for every (pixel chunk of 512 px, group of 16 masks) the sorted list of touched pixels,
+//   * image: a chunk is 512 pixels of a frame -- 8 segments of 64 consecutive pixels that the builder
+//     picks so that the work of a chunk is spread evenly over the waves (ChunkPlanner below); for
+//     every (chunk, group of 16 masks) the sorted list of touched pixels,
 //     padded to a multiple of 8, and the dense 16 x n block of mask values.  Two MFMA steps
 //     (2 x 4 pixels) form one 768-byte "block record": lane l holds A[mask l&15][pixel l>>4] of
 //     both steps and the two pixel numbers of its l>>4.  C4: 3.65 multiply-adds per stored mask
@@ -39,12 +41,15 @@
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
+#include <cmath>
 #include <type_traits>
 #include <typeinfo>
 
 namespace ltmi {
 
 typedef float bf32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 bh16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 bh16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int bu32x3 __attribute__((ext_vector_type(3)));
 typedef __attribute__((address_space(3))) void *b_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *b_glb_ptr_t;
@@ -56,6 +61,12 @@ typedef const __attribute__((address_space(1))) void *b_glb_ptr_t;
 #define BE_OCC 1
 #endif
 constexpr int BE_P = BE_P_;          // pixels per chunk
+#ifndef BE_SEG_
+#define BE_SEG_ 64
+#endif
+constexpr int BE_SEG = BE_SEG_;      // a chunk = BE_NSEG runs ("segments") of BE_SEG consecutive pixels
+constexpr int BE_NSEG = BE_P / BE_SEG;
+static_assert(BE_NSEG >= 2 && BE_NSEG <= 64 && (BE_NSEG & (BE_NSEG - 1)) == 0, "segments per chunk");
 #ifndef BE_SETS_
 #define BE_SETS_ 16
 #endif
@@ -78,8 +89,17 @@ struct BellImage {
     uint32_t *stream = nullptr;      // [blocks][64 lanes][A step 0, A step 1, pixels]
     int64_t *stream_off = nullptr;   // [n_pass * 4 + set] first record of the stream
     int *nblk = nullptr;             // [(active index * 4 + set) * 16 + slot] records of the pair
-    int *active = nullptr;           // chunks with entries, concatenated per pass
-    int *active_off = nullptr;       // [n_pass + 1]
+    int *active = nullptr;           // [chunk][BE_NSEG] first pixel of the chunk's segments; the chunks
+                                     // of the passes are concatenated
+    int *active_off = nullptr;       // [n_pass + 1] first chunk of a pass
+    long crit_records = 0;           // sum over the chunks of the busiest wave's records
+    bool f16 = false;                // records of 4 pixel pairs with float16 weights (k_bell_apply<.., true>)
+    float *inv_scale = nullptr;      // f16: [n_cols] 1 / power-of-two scale of the column's weights
+    BellImage *h16 = nullptr;        // the float16 image of the same stack (1- and 2-byte unsigned pixels)
+    // f16 images: flat streams of k_bell_flat, one per (pass, wave)
+    uint32_t *ctrl = nullptr;        // control word per record (slot | BE_C_SKIP | BE_C_END)
+    int64_t *ctrl_off = nullptr;     // [n_pass * BE_SETS] first control word of the stream
+    int *n_rec = nullptr;            // [n_pass * BE_SETS] records of the stream (a multiple of BE_FD)
     int n_pass = 0;
     // entries of the last n_px % 16 pixels of a frame (at most 15): when a row is not a multiple of 16
     // bytes its last 16-byte piece is partial and is not fetched by the frame DMA; these few entries are
@@ -168,26 +188,30 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
     // ---- frame DMA: instruction q of the workgroup's chunk copy; wave j issues q = j*NDMA + i
     auto issue_dma = [&](int ai, int buf) {
         if (ablate == 1 || ablate == 3) return;  // timing experiments only (LTMI_BELL_ABLATE)
-        const int ch = active[ai];
+        // the chunk's BE_NSEG segments (runs of BE_SEG pixels anywhere in the frame, chosen by the
+        // image builder): lanes 0 .. BE_NSEG-1 hold their first pixel, the others fetch it by bpermute
+        const int segv = active[(int64_t)ai * BE_NSEG + (lane & (BE_NSEG - 1))];
+        constexpr int PPS = BE_SEG * C::SZ / 16;      // 16-byte pieces per segment
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) {
             const int q = j * NDMA + i;
             int64_t fr;
-            int64_t byte_in_row;
+            int piece;                            // 16-byte piece of the frame's chunk this lane fetches
             int dst;
             if constexpr (C::RPD > 1) {          // several rows per instruction (1-byte pixels)
                 constexpr int LPR = 64 / C::RPD;  // lanes per row
                 const int r = q * C::RPD + lane / LPR;             // frame of the workgroup
                 fr = f0 + r;
-                byte_in_row = (int64_t)ch * C::ROW + ((lane % LPR) ^ (BE_PAD ? 0 : (r & 7))) * 16;
+                piece = (lane % LPR) ^ (BE_PAD ? 0 : (r & 7));
                 dst = q * C::UNIT_BYTES;
             } else {
                 const int r = q / C::DPR;
                 fr = f0 + r;
-                byte_in_row = (int64_t)ch * C::ROW + (q % C::DPR) * 1024
-                              + (lane ^ (BE_PAD ? 0 : (r & 7))) * 16;
+                piece = (q % C::DPR) * 64 + (lane ^ (BE_PAD ? 0 : (r & 7)));
                 dst = r * C::UNIT_BYTES + (q % C::DPR) * 1024;
             }
+            const int seg_px = __builtin_amdgcn_ds_bpermute((piece / PPS) * 4, segv);
+            int64_t byte_in_row = (int64_t)seg_px * C::SZ + (piece % PPS) * 16;
             if (fr > n_frames - 1) fr = n_frames - 1;
             if (rows) fr = rows[fr];                  // a region of interest: result row i = frame rows[i]
             // the last chunk may be partial: pieces past the row are not referenced by any record
@@ -250,7 +274,7 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
         const int buf = (ai - a0) & 1;
         if (ai + 1 < a1) {
             issue_dma(ai + 1, buf ^ 1);
-            since_dma = 0;
+            if (ablate != 1 && ablate != 3) since_dma = 0;
         }
         const unsigned char *bbase = be_lds + buf * C::BUF + lane_base;
         const int *nb_row = nblk + ((int64_t)ai * BE_SETS + j) * BE_SLOTS;
@@ -266,17 +290,37 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
                 // the oldest record of the ring: BE_D - 1 younger ones stay in flight.  (Right after
                 // a frame-DMA issue this also waits for most of that DMA -- record loads retire
                 // behind it anyway, the stall would come BE_D records later.)
+#ifndef BE_OLD_WAIT
+                // ... unless the frame DMA of the next chunk was issued less than BE_D records ago: then
+                // the record is OLDER than that DMA (loads retire in order) and the NDMA copies may stay
+                // in flight too -- waiting them out here would stall every wave for an HBM round trip
+                // per chunk
+                if (since_dma < BE_D) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_D - 1 + NDMA) : "memory");
+                else
+#endif
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_D - 1) : "memory");
                 BE_STAMP(0);
                 const unsigned *rp = (const unsigned *)(ring_lds + slot * SLOT_BYTES) + lane * 4;
+#ifdef BE_X_NORING      // timing experiments (wrong results): no ring read
+                const unsigned x0 = 0x3f800000u + lane + b, x1 = 0x3f000000u + lane, o = ((lane >> 4) * 9 + b) | (((lane >> 4) * 5 + 300) << 16);
+#else
                 const unsigned x0 = rp[0], x1 = rp[1], o = rp[2];
+#endif
                 const float a_0 = __uint_as_float(x0);
                 const float a_1 = __uint_as_float(x1);
                 const unsigned char *p0 = bbase + (((o & 0xffffu) * C::SZ) ^ swz);
                 const unsigned char *p1 = bbase + (((o >> 16) * C::SZ) ^ swz);
+#ifdef BE_EXP_READY
+                // timing experiment (wrong results): the record's words taken as ready-made byte offsets
+                p0 = bbase + (o & 0x3feu);
+                p1 = bbase + ((o >> 16) & 0x3feu);
+#endif
                 T b0[TILES], b1[TILES];
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
+#ifdef BE_X_GATHER1     // timing experiment (wrong results): two gathers per record instead of 2 * TILES
+                    if (t > 0) { b0[t] = b0[0]; b1[t] = b1[0]; continue; }
+#endif
                     b0[t] = *(const T *)(p0 + t * C::TILE_OFF);
                     b1[t] = *(const T *)(p1 + t * C::TILE_OFF);
                 }
@@ -386,6 +430,341 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
     }
 }
 
+
+// ==== float16 path, flat record loop (1- and 2-byte unsigned pixels) ==================================
+// The frame copies (HBM, ~3 us round trip under load) and the record stream (L2) share the CU's
+// in-order vector-memory return path: a record requested after a chunk's frame copy comes back behind
+// it.  With the two-record LDS ring of the kernel above a wave works through the records it already
+// holds and then idles until the frames of the NEXT chunk have landed -- once per chunk, 128 times per
+// workgroup, ~0.25 ms of a 0.70 ms launch (profiles/r03_sparse.txt).  The cure is a record ring deep
+// enough to cover that shadow (BE_FD = 8 records, ~4 us of work), which the LDS cannot hold next to
+// the two 64 KiB frame slabs -- but registers can: 3 words per record and lane.  Registers cannot be
+// indexed by a ring position, so the loop is FLAT: one stream of records per wave for the whole sweep,
+// unrolled BE_FD times (ring position = position in the unrolled body), with a control word per
+// record -- which of the wave's 4 accumulator sets it feeds, whether the wave's work on the chunk
+// ends with it (then: wait for the next chunk's frames, barrier, start the copy of the chunk after
+// next) -- read through the scalar cache, which is a separate path.
+constexpr int BE_FD = 8;
+constexpr unsigned BE_C_SKIP = 4u, BE_C_END = 8u;
+struct BeRec3 { uint32_t w1, w2, px; };       // a lane's 12 bytes of a float16 record
+
+#define BE_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63"
+#define BE_ACC_ZERO() asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tv_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0\n\tv_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\tv_accvgpr_write_b32 a10, 0\n\tv_accvgpr_write_b32 a11, 0\n\tv_accvgpr_write_b32 a12, 0\n\tv_accvgpr_write_b32 a13, 0\n\tv_accvgpr_write_b32 a14, 0\n\tv_accvgpr_write_b32 a15, 0\n\tv_accvgpr_write_b32 a16, 0\n\tv_accvgpr_write_b32 a17, 0\n\tv_accvgpr_write_b32 a18, 0\n\tv_accvgpr_write_b32 a19, 0\n\tv_accvgpr_write_b32 a20, 0\n\tv_accvgpr_write_b32 a21, 0\n\tv_accvgpr_write_b32 a22, 0\n\tv_accvgpr_write_b32 a23, 0\n\tv_accvgpr_write_b32 a24, 0\n\tv_accvgpr_write_b32 a25, 0\n\tv_accvgpr_write_b32 a26, 0\n\tv_accvgpr_write_b32 a27, 0\n\tv_accvgpr_write_b32 a28, 0\n\tv_accvgpr_write_b32 a29, 0\n\tv_accvgpr_write_b32 a30, 0\n\tv_accvgpr_write_b32 a31, 0\n\tv_accvgpr_write_b32 a32, 0\n\tv_accvgpr_write_b32 a33, 0\n\tv_accvgpr_write_b32 a34, 0\n\tv_accvgpr_write_b32 a35, 0\n\tv_accvgpr_write_b32 a36, 0\n\tv_accvgpr_write_b32 a37, 0\n\tv_accvgpr_write_b32 a38, 0\n\tv_accvgpr_write_b32 a39, 0\n\tv_accvgpr_write_b32 a40, 0\n\tv_accvgpr_write_b32 a41, 0\n\tv_accvgpr_write_b32 a42, 0\n\tv_accvgpr_write_b32 a43, 0\n\tv_accvgpr_write_b32 a44, 0\n\tv_accvgpr_write_b32 a45, 0\n\tv_accvgpr_write_b32 a46, 0\n\tv_accvgpr_write_b32 a47, 0\n\tv_accvgpr_write_b32 a48, 0\n\tv_accvgpr_write_b32 a49, 0\n\tv_accvgpr_write_b32 a50, 0\n\tv_accvgpr_write_b32 a51, 0\n\tv_accvgpr_write_b32 a52, 0\n\tv_accvgpr_write_b32 a53, 0\n\tv_accvgpr_write_b32 a54, 0\n\tv_accvgpr_write_b32 a55, 0\n\tv_accvgpr_write_b32 a56, 0\n\tv_accvgpr_write_b32 a57, 0\n\tv_accvgpr_write_b32 a58, 0\n\tv_accvgpr_write_b32 a59, 0\n\tv_accvgpr_write_b32 a60, 0\n\tv_accvgpr_write_b32 a61, 0\n\tv_accvgpr_write_b32 a62, 0\n\tv_accvgpr_write_b32 a63, 0" ::: BE_AGPRS)
+#define BE_MFMA_0_0(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[0:3], %0, %1, a[0:3]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_0_1(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[4:7], %0, %1, a[4:7]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_0_2(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[8:11], %0, %1, a[8:11]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_0_3(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[12:15], %0, %1, a[12:15]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_1_0(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[16:19], %0, %1, a[16:19]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_1_1(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[20:23], %0, %1, a[20:23]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_1_2(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[24:27], %0, %1, a[24:27]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_1_3(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[28:31], %0, %1, a[28:31]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_2_0(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[32:35], %0, %1, a[32:35]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_2_1(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[36:39], %0, %1, a[36:39]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_2_2(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[40:43], %0, %1, a[40:43]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_2_3(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[44:47], %0, %1, a[44:47]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_3_0(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[48:51], %0, %1, a[48:51]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_3_1(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[52:55], %0, %1, a[52:55]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_3_2(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[56:59], %0, %1, a[56:59]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_3_3(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[60:63], %0, %1, a[60:63]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_ARM(S_)                                                         \
+    asm volatile("s_nop 1");                                               \
+    BE_MFMA_##S_##_0(a1v, bv[0]); BE_MFMA_##S_##_1(a1v, bv[1]);              \
+    if constexpr (TILES == 4) { BE_MFMA_##S_##_2(a1v, bv[2]); BE_MFMA_##S_##_3(a1v, bv[3]); } \
+    BE_MFMA_##S_##_0(a2v, bv[0]); BE_MFMA_##S_##_1(a2v, bv[1]);              \
+    if constexpr (TILES == 4) { BE_MFMA_##S_##_2(a2v, bv[2]); BE_MFMA_##S_##_3(a2v, bv[3]); }
+
+#define BE_ACC_READ_0_0(V0, V1, V2, V3) asm volatile("v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\tv_accvgpr_read_b32 %3, a3" : "=v"(V0), "=v"(V1), "=v"(V2), "=v"(V3) :: BE_AGPRS)
+#define BE_ACC_READ_0_1(V0, V1, V2, V3) asm volatile("v_accvgpr_read_b32 %0, a4\n\tv_accvgpr_read_b32 %1, a5\n\tv_accvgpr_read_b32 %2, a6\n\tv_accvgpr_read_b32 %3, a7" : "=v"(V0), "=v"(V1), "=v"(V2), "=v"(V3) :: BE_AGPRS)
+#define BE_ACC_READ_0_2(V0, V1, V2, V3) asm volatile("v_accvgpr_read_b32 %0, a8\n\tv_accvgpr_read_b32 %1, a9\n\tv_accvgpr_read_b32 %2, a10\n\tv_accvgpr_read_b32 %3, a11" : "=v"(V0), "=v"(V1), "=v"(V2), "=v"(V3) :: BE_AGPRS)
+#define BE_ACC_READ_0_3(V0, V1, V2, V3) asm volatile("v_accvgpr_read_b32 %0, a12\n\tv_accvgpr_read_b32 %1, a13\n\tv_accvgpr_read_b32 %2, a14\n\tv_accvgpr_read_b32 %3, a15" : "=v"(V0), "=v"(V1), "=v"(V2), "=v"(V3) :: BE_AGPRS)
+#define BE_ACC_READ_1_0(V0, V1, V2, V3) asm volatile("v_accvgpr_read_b32 %0, a16\n\tv_accvgpr_read_b32 %1, a17\n\tv_accvgpr_read_b32 %2, a18\n\tv_accvgpr_read_b32 %3, a19" : "=v"(V0), "=v"(V1), "=v"(V2), "=v"(V3) :: BE_AGPRS)
+#define BE_ACC_READ_1_1(V0, V1, V2, V3) asm volatile("v_accvgpr_read_b32 %0, a20\n\tv_accvgpr_read_b32 %1, a21\n\tv_accvgpr_read_b32 %2, a22\n\tv_accvgpr_read_b32 %3, a23" : "=v"(V0), "=v"(V1), "=v"(V2), "=v"(V3) :: BE_AGPRS)
+#define BE_ACC_READ_1_2(V0, V1, V2, V3) asm volatile("v_accvgpr_read_b32 %0, a24\n\tv_accvgpr_read_b32 %1, a25\n\tv_accvgpr_read_b32 %2, a26\n\tv_accvgpr_read_b32 %3, a27" : "=v"(V0), "=v"(V1), "=v"(V2), "=v"(V3) :: BE_AGPRS)
+#define BE_ACC_READ_1_3(V0, V1, V2, V3) asm volatile("v_accvgpr_read_b32 %0, a28\n\tv_accvgpr_read_b32 %1, a29\n\tv_accvgpr_read_b32 %2, a30\n\tv_accvgpr_read_b32 %3, a31" : "=v"(V0), "=v"(V1), "=v"(V2), "=v"(V3) :: BE_AGPRS)
+#define BE_ACC_READ_2_0(V0, V1, V2, V3) asm volatile("v_accvgpr_read_b32 %0, a32\n\tv_accvgpr_read_b32 %1, a33\n\tv_accvgpr_read_b32 %2, a34\n\tv_accvgpr_read_b32 %3, a35" : "=v"(V0), "=v"(V1), "=v"(V2), "=v"(V3) :: BE_AGPRS)
+#define BE_ACC_READ_2_1(V0, V1, V2, V3) asm volatile("v_accvgpr_read_b32 %0, a36\n\tv_accvgpr_read_b32 %1, a37\n\tv_accvgpr_read_b32 %2, a38\n\tv_accvgpr_read_b32 %3, a39" : "=v"(V0), "=v"(V1), "=v"(V2), "=v"(V3) :: BE_AGPRS)
+#define BE_ACC_READ_2_2(V0, V1, V2, V3) asm volatile("v_accvgpr_read_b32 %0, a40\n\tv_accvgpr_read_b32 %1, a41\n\tv_accvgpr_read_b32 %2, a42\n\tv_accvgpr_read_b32 %3, a43" : "=v"(V0), "=v"(V1), "=v"(V2), "=v"(V3) :: BE_AGPRS)
+#define BE_ACC_READ_2_3(V0, V1, V2, V3) asm volatile("v_accvgpr_read_b32 %0, a44\n\tv_accvgpr_read_b32 %1, a45\n\tv_accvgpr_read_b32 %2, a46\n\tv_accvgpr_read_b32 %3, a47" : "=v"(V0), "=v"(V1), "=v"(V2), "=v"(V3) :: BE_AGPRS)
+#define BE_ACC_READ_3_0(V0, V1, V2, V3) asm volatile("v_accvgpr_read_b32 %0, a48\n\tv_accvgpr_read_b32 %1, a49\n\tv_accvgpr_read_b32 %2, a50\n\tv_accvgpr_read_b32 %3, a51" : "=v"(V0), "=v"(V1), "=v"(V2), "=v"(V3) :: BE_AGPRS)
+#define BE_ACC_READ_3_1(V0, V1, V2, V3) asm volatile("v_accvgpr_read_b32 %0, a52\n\tv_accvgpr_read_b32 %1, a53\n\tv_accvgpr_read_b32 %2, a54\n\tv_accvgpr_read_b32 %3, a55" : "=v"(V0), "=v"(V1), "=v"(V2), "=v"(V3) :: BE_AGPRS)
+#define BE_ACC_READ_3_2(V0, V1, V2, V3) asm volatile("v_accvgpr_read_b32 %0, a56\n\tv_accvgpr_read_b32 %1, a57\n\tv_accvgpr_read_b32 %2, a58\n\tv_accvgpr_read_b32 %3, a59" : "=v"(V0), "=v"(V1), "=v"(V2), "=v"(V3) :: BE_AGPRS)
+#define BE_ACC_READ_3_3(V0, V1, V2, V3) asm volatile("v_accvgpr_read_b32 %0, a60\n\tv_accvgpr_read_b32 %1, a61\n\tv_accvgpr_read_b32 %2, a62\n\tv_accvgpr_read_b32 %3, a63" : "=v"(V0), "=v"(V1), "=v"(V2), "=v"(V3) :: BE_AGPRS)
+#define BE_ACC_STORE(S_)                                                   \
+    if (TILES > 0) {                                                    \
+        float v0_, v1_, v2_, v3_;                                         \
+        BE_ACC_READ_##S_##_0(v0_, v1_, v2_, v3_);                            \
+        store_tile(S_, 0, v0_, v1_, v2_, v3_);                           \
+    }                                                                  \
+    if (TILES > 1) {                                                    \
+        float v0_, v1_, v2_, v3_;                                         \
+        BE_ACC_READ_##S_##_1(v0_, v1_, v2_, v3_);                            \
+        store_tile(S_, 1, v0_, v1_, v2_, v3_);                           \
+    }                                                                  \
+    if (TILES > 2) {                                                    \
+        float v0_, v1_, v2_, v3_;                                         \
+        BE_ACC_READ_##S_##_2(v0_, v1_, v2_, v3_);                            \
+        store_tile(S_, 2, v0_, v1_, v2_, v3_);                           \
+    }                                                                  \
+    if (TILES > 3) {                                                    \
+        float v0_, v1_, v2_, v3_;                                         \
+        BE_ACC_READ_##S_##_3(v0_, v1_, v2_, v3_);                            \
+        store_tile(S_, 3, v0_, v1_, v2_, v3_);                           \
+    }
+
+
+// the record ring of k_bell_flat: ring position u = a[64 + 4 u .. + 2] (register tuples start at even numbers), loaded by asm (the compiler neither
+// sees the loads nor the registers, so it cannot move a register whose load is still in flight) and
+// waited for with hand-counted vmcnt
+#define BE_RING_LOAD_0(VOFF, SBASE) asm volatile("global_load_dwordx3 a[64:66], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
+#define BE_RING_READ_0(W1, W2, PX) asm volatile("v_accvgpr_read_b32 %0, a64\n\tv_accvgpr_read_b32 %1, a65\n\tv_accvgpr_read_b32 %2, a66" : "=v"(W1), "=v"(W2), "=v"(PX) :: BE_RING_AGPRS)
+#define BE_RING_LOAD_1(VOFF, SBASE) asm volatile("global_load_dwordx3 a[68:70], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
+#define BE_RING_READ_1(W1, W2, PX) asm volatile("v_accvgpr_read_b32 %0, a68\n\tv_accvgpr_read_b32 %1, a69\n\tv_accvgpr_read_b32 %2, a70" : "=v"(W1), "=v"(W2), "=v"(PX) :: BE_RING_AGPRS)
+#define BE_RING_LOAD_2(VOFF, SBASE) asm volatile("global_load_dwordx3 a[72:74], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
+#define BE_RING_READ_2(W1, W2, PX) asm volatile("v_accvgpr_read_b32 %0, a72\n\tv_accvgpr_read_b32 %1, a73\n\tv_accvgpr_read_b32 %2, a74" : "=v"(W1), "=v"(W2), "=v"(PX) :: BE_RING_AGPRS)
+#define BE_RING_LOAD_3(VOFF, SBASE) asm volatile("global_load_dwordx3 a[76:78], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
+#define BE_RING_READ_3(W1, W2, PX) asm volatile("v_accvgpr_read_b32 %0, a76\n\tv_accvgpr_read_b32 %1, a77\n\tv_accvgpr_read_b32 %2, a78" : "=v"(W1), "=v"(W2), "=v"(PX) :: BE_RING_AGPRS)
+#define BE_RING_LOAD_4(VOFF, SBASE) asm volatile("global_load_dwordx3 a[80:82], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
+#define BE_RING_READ_4(W1, W2, PX) asm volatile("v_accvgpr_read_b32 %0, a80\n\tv_accvgpr_read_b32 %1, a81\n\tv_accvgpr_read_b32 %2, a82" : "=v"(W1), "=v"(W2), "=v"(PX) :: BE_RING_AGPRS)
+#define BE_RING_LOAD_5(VOFF, SBASE) asm volatile("global_load_dwordx3 a[84:86], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
+#define BE_RING_READ_5(W1, W2, PX) asm volatile("v_accvgpr_read_b32 %0, a84\n\tv_accvgpr_read_b32 %1, a85\n\tv_accvgpr_read_b32 %2, a86" : "=v"(W1), "=v"(W2), "=v"(PX) :: BE_RING_AGPRS)
+#define BE_RING_LOAD_6(VOFF, SBASE) asm volatile("global_load_dwordx3 a[88:90], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
+#define BE_RING_READ_6(W1, W2, PX) asm volatile("v_accvgpr_read_b32 %0, a88\n\tv_accvgpr_read_b32 %1, a89\n\tv_accvgpr_read_b32 %2, a90" : "=v"(W1), "=v"(W2), "=v"(PX) :: BE_RING_AGPRS)
+#define BE_RING_LOAD_7(VOFF, SBASE) asm volatile("global_load_dwordx3 a[92:94], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
+#define BE_RING_READ_7(W1, W2, PX) asm volatile("v_accvgpr_read_b32 %0, a92\n\tv_accvgpr_read_b32 %1, a93\n\tv_accvgpr_read_b32 %2, a94" : "=v"(W1), "=v"(W2), "=v"(PX) :: BE_RING_AGPRS)
+#define BE_RING_AGPRS "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95"
+
+template <typename T, int TL>
+// (a[0:95] are named by hand and not in the compiler's budget: 32 registers are left for it)
+__global__ void __launch_bounds__(BE_SETS * 64, 1) __attribute__((amdgpu_num_vgpr(32)))
+k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
+            const uint32_t *__restrict__ stream, const int64_t *__restrict__ stream_off,
+            const uint32_t *__restrict__ ctrl, const int64_t *__restrict__ ctrl_off,
+            const int *__restrict__ n_rec,
+            const int *__restrict__ active, const int *__restrict__ active_off,
+            float *__restrict__ out, int64_t ld_out, int n_cols, int accumulate, int ablate,
+            const int32_t *__restrict__ rows, const float *__restrict__ inv_scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char be_lds[];
+    using C = BeCfg<T, TL>;
+    static_assert(C::SZ <= 2, "float16 path: 1- and 2-byte pixels");
+    constexpr int TILES = C::TILES, NDMA = C::NDMA;
+    const int tid = threadIdx.x;
+    const int j = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int m16 = lane & 15, kg = lane >> 4;
+    const int pass = blockIdx.y;
+    const int64_t f0 = (int64_t)blockIdx.x * C::FB;
+    const int a0 = active_off[pass], a1 = active_off[pass + 1];
+
+    // The 4 x TILES accumulator tiles live in a[0:63] under fixed names (slot s, tile t: a[16 s + 4 t ..
+    // + 3]), outside the compiler's view: which set a record feeds is decided at run time, and through
+    // compiler-visible accumulators every merge of the four arms copies whole register tuples (and
+    // spills).  Every asm statement that touches them lists all 64 as clobbered, so the compiler
+    // keeps nothing of its own there.
+    BE_ACC_ZERO();
+
+    auto issue_dma = [&](int ai, int buf, int i_lo = 0, int i_hi = 64) {
+        if (ablate == 1 || ablate == 3) return;
+        const int segv = active[(int64_t)ai * BE_NSEG + (lane & (BE_NSEG - 1))];
+        constexpr int PPS = BE_SEG * C::SZ / 16;
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            if (i < i_lo || i >= i_hi) continue;
+            const int q = j * NDMA + i;
+            int64_t fr;
+            int piece, dst;
+            if constexpr (C::RPD > 1) {
+                constexpr int LPR = 64 / C::RPD;
+                const int r = q * C::RPD + lane / LPR;
+                fr = f0 + r;
+                piece = (lane % LPR) ^ (r & 7);
+                dst = q * C::UNIT_BYTES;
+            } else {
+                const int r = q / C::DPR;
+                fr = f0 + r;
+                piece = (q % C::DPR) * 64 + (lane ^ (r & 7));
+                dst = r * C::UNIT_BYTES + (q % C::DPR) * 1024;
+            }
+            const int seg_px = __builtin_amdgcn_ds_bpermute((piece / PPS) * 4, segv);
+            int64_t byte_in_row = (int64_t)seg_px * C::SZ + (piece % PPS) * 16;
+            if (fr > n_frames - 1) fr = n_frames - 1;
+            if (rows) fr = rows[fr];
+            if (byte_in_row + 16 > n_px * C::SZ) byte_in_row = 0;
+            const unsigned char *src = (const unsigned char *)(tile + fr * ld) + byte_in_row;
+            __builtin_amdgcn_global_load_lds((b_glb_ptr_t)src,
+                                             (b_lds_ptr_t)(be_lds + buf * C::BUF + dst), 16, 0, 0);
+        }
+    };
+
+    const int wj = pass * BE_SETS + j;
+    const unsigned char *rec_base = (const unsigned char *)(stream + stream_off[wj] * BE_REC);   // uniform
+    const unsigned lane12 = (unsigned)lane * 12u;
+    const uint32_t *ctl = ctrl + ctrl_off[wj];
+    const int n = n_rec[wj];                       // a multiple of BE_FD; BE_FD more records follow
+    constexpr int REC_BYTES = BE_REC * 4;
+
+    auto ring_load = [&](auto U, int64_t rec) {
+        constexpr int u = decltype(U)::value;
+        const uint64_t sb = (uint64_t)(rec_base + rec * REC_BYTES);
+        if constexpr (u == 0) BE_RING_LOAD_0(lane12, sb);
+        else if constexpr (u == 1) BE_RING_LOAD_1(lane12, sb);
+        else if constexpr (u == 2) BE_RING_LOAD_2(lane12, sb);
+        else if constexpr (u == 3) BE_RING_LOAD_3(lane12, sb);
+        else if constexpr (u == 4) BE_RING_LOAD_4(lane12, sb);
+        else if constexpr (u == 5) BE_RING_LOAD_5(lane12, sb);
+        else if constexpr (u == 6) BE_RING_LOAD_6(lane12, sb);
+        else BE_RING_LOAD_7(lane12, sb);
+    };
+    auto ring_read = [&](auto U, unsigned &w1, unsigned &w2, unsigned &px) {
+        constexpr int u = decltype(U)::value;
+        if constexpr (u == 0) BE_RING_READ_0(w1, w2, px);
+        else if constexpr (u == 1) BE_RING_READ_1(w1, w2, px);
+        else if constexpr (u == 2) BE_RING_READ_2(w1, w2, px);
+        else if constexpr (u == 3) BE_RING_READ_3(w1, w2, px);
+        else if constexpr (u == 4) BE_RING_READ_4(w1, w2, px);
+        else if constexpr (u == 5) BE_RING_READ_5(w1, w2, px);
+        else if constexpr (u == 6) BE_RING_READ_6(w1, w2, px);
+        else BE_RING_READ_7(w1, w2, px);
+    };
+    static_assert(BE_FD <= 8, "ring registers a[64:95]");
+
+    const int lane_base = C::frame_base(m16);
+    const unsigned swz = (unsigned)((m16 & 7) << 4);
+    int ai = a0, buf = 0, since = 63;
+#ifdef BE_STAGGER
+    int pend = 0;
+#endif
+    // vector-memory operations retire in order: `win` remembers which of the last records' turns ended
+    // with the issue of a chunk's frame copy (bit k: k + 1 records ago) -- those NDMA operations are
+    // YOUNGER than the load of the record a turn is about to use and may stay in flight with the
+    // BE_FD - 1 younger record loads
+    unsigned win = 0;
+    if (a0 < a1) issue_dma(a0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    bstatic_for<0, BE_FD>([&](auto U) { ring_load(U, (int64_t) decltype(U)::value); });
+    if (a0 + 1 < a1) {
+        issue_dma(a0 + 1, 1);
+        if (ablate != 1 && ablate != 3) { since = 0; win = 1; }
+    }
+    const unsigned char *bbase = be_lds + lane_base;
+
+    const bh16x2 k256 = {(_Float16)256.0f, (_Float16)256.0f};
+    const bh16x2 kbias = {(_Float16)1024.0f, (_Float16)1024.0f};
+
+    for (int i = 0; i < n; i += BE_FD) {
+        unsigned cw[BE_FD];
+#pragma unroll
+        for (int u = 0; u < BE_FD; ++u) cw[u] = ctl[i + u];
+        bstatic_for<0, BE_FD>([&](auto U) {
+            constexpr int u = decltype(U)::value;
+            const unsigned c = cw[u];
+            {
+                const int nb = __builtin_popcount(win & ((1u << BE_FD) - 1u));
+#ifdef BE_STAGGER
+                if (nb == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD - 1) : "memory");
+                else if (nb == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD) : "memory");
+                else if (nb == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD + 1) : "memory");
+                else if (nb == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD + 2) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD + 3) : "memory");
+#else
+                if (nb == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD - 1) : "memory");
+                else if (nb == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD - 1 + NDMA) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD - 1 + 2 * NDMA) : "memory");
+#endif
+            }
+            if (!(c & BE_C_SKIP)) {
+                unsigned rw1, rw2, rpx;
+                ring_read(U, rw1, rw2, rpx);
+                bh16x2 w1l = __builtin_bit_cast(bh16x2, rw1), w2l = __builtin_bit_cast(bh16x2, rw2);
+                bh16x2 w1h = w1l * k256, w2h = w2l * k256;
+                bh16x4 a1v = {w1l[0], w1l[1], w1h[0], w1h[1]};
+                bh16x4 a2v = {w2l[0], w2l[1], w2h[0], w2h[1]};
+                const unsigned char *pq = bbase + buf * C::BUF + (((rpx & 0xffffu) * C::SZ) ^ swz);
+                unsigned raw[TILES];
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) {
+                    if constexpr (C::SZ == 2) raw[t] = *(const unsigned *)(pq + t * C::TILE_OFF);
+                    else raw[t] = *(const unsigned short *)(pq + t * C::TILE_OFF);
+                }
+                bh16x4 bv[TILES];
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) {
+                    bh16x2 lo, hi;
+                    if constexpr (C::SZ == 2) {
+                        lo = __builtin_bit_cast(bh16x2, __builtin_amdgcn_perm(0x64646464u, raw[t], 0x04020400u)) - kbias;
+                        hi = __builtin_bit_cast(bh16x2, __builtin_amdgcn_perm(0x64646464u, raw[t], 0x04030401u)) - kbias;
+                    } else {
+                        lo = __builtin_bit_cast(bh16x2, __builtin_amdgcn_perm(0x64646464u, raw[t], 0x04010400u)) - kbias;
+                        hi = bh16x2{(_Float16)0.0f, (_Float16)0.0f};
+                    }
+                    bv[t] = bh16x4{lo[0], lo[1], hi[0], hi[1]};
+                }
+                static_assert(BE_SLOTS == 4 && (TILES == 2 || TILES == 4), "accumulator naming");
+                const unsigned sl = c & 3u;
+                if (sl == 0u) { BE_ARM(0) } else if (sl == 1u) { BE_ARM(1) }
+                else if (sl == 2u) { BE_ARM(2) } else { BE_ARM(3) }
+            }
+            ring_load(U, (int64_t)(i + u + BE_FD));
+            since = since < 63 ? since + 1 : since;
+            win <<= 1;
+#ifdef BE_STAGGER
+            // (experiment) the copy of the next chunk one instruction per record instead of a burst
+            if (pend > 0) {
+                issue_dma(ai + 1, buf ^ 1, NDMA - pend, NDMA - pend + 1);
+                --pend;
+                if (ablate != 1 && ablate != 3) { since = 0; win |= 1u; }
+            }
+            if ((c & BE_C_END) && pend > 0) {
+                issue_dma(ai + 1, buf ^ 1, NDMA - pend, NDMA);
+                pend = 0;
+                if (ablate != 1 && ablate != 3) { since = 0; win |= 1u; }
+            }
+#endif
+            if (c & BE_C_END) {
+                // this wave is through with chunk ai: the next chunk's frames must have landed -- their
+                // copy is older than the last `since` record loads, and nothing else is younger --
+                // then everybody meets
+                if (since >= BE_FD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD) : "memory");
+                else if (since >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if (since >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (ablate != 3) __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                ++ai;
+                buf ^= 1;
+#ifdef BE_STAGGER
+                if (ai + 1 < a1) pend = NDMA;
+#else
+                if (ai + 1 < a1) {
+                    issue_dma(ai + 1, buf ^ 1);
+                    if (ablate != 1 && ablate != 3) { since = 0; win |= 1u; }
+                }
+#endif
+            }
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (the run-ahead loads)
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");              // the last MFMAs have retired
+
+    auto store_tile = [&](int s, int t, float v0, float v1, float v2, float v3) {
+        const int col0 = pass * BE_PASS + (s * BE_SETS + j) * 16 + kg * 4;
+        const int64_t f = f0 + t * 16 + m16;
+        if (col0 >= n_cols || f >= n_frames) return;
+        const float v[4] = {v0, v1, v2, v3};
+        float *o = out + f * ld_out + col0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (col0 + r < n_cols) {
+                const float x = v[r] * inv_scale[col0 + r];       // undo the column's power-of-two scale
+                o[r] = accumulate ? o[r] + x : x;
+            }
+    };
+    BE_ACC_STORE(0) BE_ACC_STORE(1) BE_ACC_STORE(2) BE_ACC_STORE(3)
+}
+
 void bell_destroy(void *image) {
     BellImage *b = (BellImage *)image;
     if (!b) return;
@@ -397,6 +776,11 @@ void bell_destroy(void *image) {
     if (b->tail_px) (void)hipFree(b->tail_px);
     if (b->tail_col) (void)hipFree(b->tail_col);
     if (b->tail_val) (void)hipFree(b->tail_val);
+    if (b->inv_scale) (void)hipFree(b->inv_scale);
+    if (b->ctrl) (void)hipFree(b->ctrl);
+    if (b->ctrl_off) (void)hipFree(b->ctrl_off);
+    if (b->n_rec) (void)hipFree(b->n_rec);
+    if (b->h16) bell_destroy(b->h16);
     delete b;
 }
 
@@ -427,107 +811,348 @@ double bell_mac_ratio(const int64_t *indptr, const int64_t *indices, int nc, int
     return (double)steps * 64.0 / (double)nnz;
 }
 
-// Build the blocked image from the CSR matrix (n_px x n_masks).  Returns nullptr + error set on
-// failure.
-void *bell_build(const int64_t *indptr, const int64_t *indices, const float *vals, int nc,
-                 int64_t n_px, int64_t n_masks, int *err) {
+// ---- chunk composition ----------------------------------------------------------------------------
+// A workgroup's waves meet at a barrier after every chunk, so a chunk costs what its BUSIEST wave
+// does.  With chunks of consecutive pixels that is far from the mean: in a ring stack the ring that is
+// tangent to the chunk's detector rows puts ~100 pixels into ONE 16-mask group -- one wave works
+// through a dozen records while the others hold two or three (C4: the busiest waves add up to 2.06x the
+// mean; the matrix pipes idle at the barriers for the difference).  A chunk is therefore a SET of
+// BE_NSEG segments (runs of BE_SEG pixels = one or two cache lines of a frame row) that the builder is
+// free to choose: segments whose heavy groups belong to different waves go together.  The choice is a
+// small annealing run (deterministic: fixed seed) over swaps of segments between chunks, minimising
+// sum over chunks of max over waves of the records (+ a little of the total, which grows when segments
+// that share groups are separated); it starts from the better of the natural order and a strided
+// interleave.  C4: busiest-wave records 1589 -> ~960 for 4 % more records.
+struct ChunkPlanner {
+    int n_local;                                    // groups of the pass (<= BE_SETS * BE_SLOTS)
+    const std::vector<uint16_t> &cnt;               // [segment][n_local] touched pixels (f16: pixel pairs)
+    int upr;                                        // of them per record: 8 pixels / 4 pairs
+    std::vector<int> tmp;
+    ChunkPlanner(int nl, const std::vector<uint16_t> &c, int u) : n_local(nl), cnt(c), upr(u), tmp((size_t)nl) {}
+    // (records of the busiest wave, records of all waves) of a chunk made of `segs`
+    void cost(const int *segs, int n, int *crit, int *total) {
+        std::fill(tmp.begin(), tmp.end(), 0);
+        for (int i = 0; i < n; ++i) {
+            if (segs[i] < 0) continue;
+            const uint16_t *row = cnt.data() + (size_t)segs[i] * n_local;
+            for (int g = 0; g < n_local; ++g) tmp[g] += row[g];
+        }
+        int load[BE_SETS] = {0}, tot = 0;
+        for (int g = 0; g < n_local; ++g) {
+            const int rec = (tmp[g] + upr - 1) / upr;
+            load[g % BE_SETS] += rec;                 // group g of the pass: wave g % BE_SETS
+            tot += rec;
+        }
+        int mx = 0;
+        for (int w = 0; w < BE_SETS; ++w) mx = std::max(mx, load[w]);
+        *crit = mx;
+        *total = tot;
+    }
+    // segs: n_chunks * BE_NSEG segment numbers (index into cnt), -1 = empty slot; optimised in place
+    long plan(std::vector<int> &segs, long *total_out) {
+        const int n_chunks = (int)(segs.size() / BE_NSEG);
+        std::vector<int> cc((size_t)n_chunks), ct((size_t)n_chunks);
+        auto eval_all = [&](const std::vector<int> &a, long *tot) {
+            long c = 0, t = 0;
+            for (int k = 0; k < n_chunks; ++k) {
+                int x, y;
+                cost(a.data() + (size_t)k * BE_NSEG, BE_NSEG, &x, &y);
+                c += x; t += y;
+            }
+            *tot = t;
+            return c;
+        };
+        constexpr double W_TOTAL = 0.05;             // weight of a record anywhere vs on the critical wave
+        // start: natural order or strided interleave (segment k * n_chunks + c -> chunk c), whichever is
+        // better
+        std::vector<int> inter(segs.size(), -1);
+        {
+            std::vector<int> fill((size_t)n_chunks, 0);
+            int k = 0;
+            for (int v : segs) {
+                if (v < 0) continue;
+                const int c = k % n_chunks;
+                inter[(size_t)c * BE_NSEG + fill[c]++] = v;
+                ++k;
+            }
+        }
+        long t_nat, t_int;
+        const long c_nat = eval_all(segs, &t_nat), c_int = eval_all(inter, &t_int);
+        if (c_int + W_TOTAL * t_int < c_nat + W_TOTAL * t_nat) segs = inter;
+        for (int k = 0; k < n_chunks; ++k) cost(segs.data() + (size_t)k * BE_NSEG, BE_NSEG, &cc[k], &ct[k]);
+        if (n_chunks >= 2) {
+            uint64_t rng = 0x9E3779B97F4A7C15ull;
+            auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+            const long iters = std::min<long>(400000, 150L * (long)segs.size() + 2000);
+            for (long it = 0; it < iters; ++it) {
+                const int A = (int)(next() % n_chunks), B = (int)(next() % n_chunks);
+                if (A == B) continue;
+                const size_t ia = (size_t)A * BE_NSEG + next() % BE_NSEG, ib = (size_t)B * BE_NSEG + next() % BE_NSEG;
+                if (segs[ia] < 0 && segs[ib] < 0) continue;
+                std::swap(segs[ia], segs[ib]);
+                int ca, ta, cb, tb;
+                cost(segs.data() + (size_t)A * BE_NSEG, BE_NSEG, &ca, &ta);
+                cost(segs.data() + (size_t)B * BE_NSEG, BE_NSEG, &cb, &tb);
+                const double d = (ca + cb - cc[A] - cc[B]) + W_TOTAL * (ta + tb - ct[A] - ct[B]);
+                const double T = std::max(0.02, 1.0 - (double)it / (double)iters);
+                const double u = (double)(next() >> 11) * (1.0 / 9007199254740992.0);
+                if (d <= 0 || u < std::exp(-d / T)) {
+                    cc[A] = ca; ct[A] = ta; cc[B] = cb; ct[B] = tb;
+                } else {
+                    std::swap(segs[ia], segs[ib]);
+                }
+            }
+        }
+        long c = 0, t = 0;
+        for (int k = 0; k < n_chunks; ++k) { c += cc[k]; t += ct[k]; }
+        *total_out = t;
+        return c;
+    }
+};
+
+static uint16_t half_bits(double x) {
+    const _Float16 h = (_Float16)x;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+static double half_value(uint16_t u) {
+    _Float16 h;
+    memcpy(&h, &u, 2);
+    return (double)h;
+}
+
+// Build a blocked image from the CSR matrix (n_px x n_masks): f16 = false -> records of 8 pixels with
+// float32 weights (any pixel type), f16 = true -> records of 4 aligned pixel pairs with split float16
+// weights (k_bell_flat; `col_scale`: the columns' power-of-two scales).
+static BellImage *build_image(const int64_t *indptr, const int64_t *indices, const float *vals, int nc,
+                              int64_t n_px, int64_t n_masks, bool f16,
+                              const std::vector<float> &col_scale, int *err) {
     *err = LTMI_OK;
     BellImage *b = new (std::nothrow) BellImage();
     if (!b) { *err = LTMI_E_NOMEM; return nullptr; }
+    b->f16 = f16;
+    const int UPR = f16 ? 4 : 8;                        // units (pixels / pixel pairs) per record
     try {
         const int64_t n_cols = n_masks * nc;
         const int64_t n_groups = (n_cols + 15) / 16;
-        const int n_pass = (int)((n_groups + BE_SETS * BE_SLOTS - 1) / (BE_SETS * BE_SLOTS));
-        const int n_chunks = (int)((n_px + BE_P - 1) / BE_P);
+        constexpr int GPP = BE_SETS * BE_SLOTS;         // groups per pass
+        const int n_pass = (int)((n_groups + GPP - 1) / GPP);
         b->n_pass = n_pass;
         struct Ent { uint16_t px; uint16_t m; float v; };
-        // entries per (chunk, group), pixels ascending because the CSR rows are walked in order
-        std::vector<std::vector<Ent>> bucket((size_t)n_chunks * n_groups);
         const int64_t p_tail0 = n_px - n_px % 16;       // pixels from here on: k_bell_tail
+        const int64_t n_seg = (p_tail0 + BE_SEG - 1) / BE_SEG;
         std::vector<int32_t> tail_px, tail_col;
         std::vector<float> tail_val;
-        for (int64_t p = 0; p < n_px; ++p) {
-            const int ch = (int)(p / BE_P);
+        for (int64_t p = p_tail0; p < n_px; ++p)
+            for (int64_t e = indptr[p]; e < indptr[p + 1]; ++e)
+                for (int c = 0; c < nc; ++c) {
+                    tail_px.push_back((int32_t)p);
+                    tail_col.push_back((int32_t)(indices[e] * nc + c));
+                    tail_val.push_back(vals[e * nc + c]);
+                }
+        b->n_tail = (int)tail_px.size();
+
+        // ---- per pass: which segments hold entries, how they are grouped into chunks
+        std::vector<int> active, active_off(n_pass + 1, 0);     // active: [chunk][BE_NSEG] segment numbers
+        std::vector<int> chunk_of_seg((size_t)n_pass * n_seg, -1), slot_of_seg((size_t)n_pass * n_seg, 0);
+        const bool natural = getenv("LTMI_BELL_NATURAL_CHUNKS") != nullptr;     // experiments: no planning
+        for (int ps = 0; ps < n_pass; ++ps) {
+            const int64_t g_lo = (int64_t)ps * GPP;
+            const int n_local = (int)std::min<int64_t>(GPP, n_groups - g_lo);
+            // touched pixels per (segment, group of the pass)
+            std::vector<int> seg_id((size_t)n_seg, -1);          // segment -> row of `cnt`
+            std::vector<int> seg_list;
+            std::vector<uint16_t> cnt;
+            std::vector<int64_t> last((size_t)n_local, -1);
+            for (int64_t p = 0; p < p_tail0; ++p) {
+                const int64_t sg = p / BE_SEG;
+                const int64_t unit = f16 ? p >> 1 : p;
+                for (int64_t e = indptr[p]; e < indptr[p + 1]; ++e)
+                    for (int c = 0; c < nc; ++c) {
+                        const int64_t g = (indices[e] * nc + c) / 16 - g_lo;
+                        if (g < 0 || g >= n_local || last[g] == unit) continue;
+                        last[g] = unit;
+                        if (seg_id[sg] < 0) {
+                            seg_id[sg] = (int)seg_list.size();
+                            seg_list.push_back((int)sg);
+                            cnt.resize(cnt.size() + (size_t)n_local, 0);
+                        }
+                        cnt[(size_t)seg_id[sg] * n_local + g]++;
+                    }
+            }
+            const int n_act = (int)seg_list.size();
+            const int n_chunks = (n_act + BE_NSEG - 1) / BE_NSEG;
+            std::vector<int> segs((size_t)n_chunks * BE_NSEG, -1);
+            for (int k = 0; k < n_act; ++k) segs[k] = k;
+            ChunkPlanner planner(n_local, cnt, UPR);
+            long total = 0;
+            if (natural) {
+                for (int k = 0; k < n_chunks; ++k) {
+                    int x, y;
+                    planner.cost(segs.data() + (size_t)k * BE_NSEG, BE_NSEG, &x, &y);
+                    b->crit_records += x;
+                }
+            } else {
+                b->crit_records += planner.plan(segs, &total);
+            }
+            const int chunk0 = (int)(active.size() / BE_NSEG);
+            for (int k = 0; k < n_chunks; ++k)
+                for (int i = 0; i < BE_NSEG; ++i) {
+                    const int v = segs[(size_t)k * BE_NSEG + i];
+                    // (an empty slot fetches the frame's first pixels: never referenced by a record)
+                    active.push_back(v < 0 ? 0 : seg_list[v] * BE_SEG);
+                    if (v >= 0) {
+                        chunk_of_seg[(size_t)ps * n_seg + seg_list[v]] = chunk0 + k;
+                        slot_of_seg[(size_t)ps * n_seg + seg_list[v]] = i;
+                    }
+                }
+            active_off[ps + 1] = (int)(active.size() / BE_NSEG);
+        }
+        const int n_chunks_all = active_off[n_pass];
+
+        // ---- entries per (chunk, group); pixel numbers are positions in the chunk's LDS image
+        // (segment slot * BE_SEG + pixel in the segment), ascending within a (chunk, group) only per
+        // segment -- the records do not care
+        std::vector<std::vector<Ent>> bucket((size_t)std::max(n_chunks_all, 1) * GPP);
+        for (int64_t p = 0; p < p_tail0; ++p) {
+            const int64_t sg = p / BE_SEG;
             for (int64_t e = indptr[p]; e < indptr[p + 1]; ++e)
                 for (int c = 0; c < nc; ++c) {
                     const int64_t col = indices[e] * nc + c;
-                    if (p >= p_tail0) {
-                        tail_px.push_back((int32_t)p);
-                        tail_col.push_back((int32_t)col);
-                        tail_val.push_back(vals[e * nc + c]);
-                        continue;
-                    }
-                    bucket[(size_t)ch * n_groups + col / 16].push_back(
-                        Ent{(uint16_t)(p - (int64_t)ch * BE_P), (uint16_t)(col % 16), vals[e * nc + c]});
+                    const int64_t g = col / 16;
+                    const int ps = (int)(g / GPP);
+                    const int ch = chunk_of_seg[(size_t)ps * n_seg + sg];
+                    const int local = slot_of_seg[(size_t)ps * n_seg + sg] * BE_SEG + (int)(p % BE_SEG);
+                    bucket[(size_t)ch * GPP + (g - (int64_t)ps * GPP)].push_back(
+                        Ent{(uint16_t)local, (uint16_t)(col % 16), vals[e * nc + c]});
                 }
         }
-        b->n_tail = (int)tail_px.size();
-        std::vector<int> active, active_off(n_pass + 1, 0);
-        for (int ps = 0; ps < n_pass; ++ps) {
-            const int64_t g_lo = (int64_t)ps * BE_SETS * BE_SLOTS;
-            const int64_t g_hi = std::min<int64_t>(n_groups, g_lo + BE_SETS * BE_SLOTS);
-            for (int ch = 0; ch < n_chunks; ++ch) {
-                bool any = false;
-                for (int64_t g = g_lo; g < g_hi && !any; ++g)
-                    any = !bucket[(size_t)ch * n_groups + g].empty();
-                if (any) active.push_back(ch);
-            }
-            active_off[ps + 1] = (int)active.size();
-        }
-        const size_t n_act = std::max<size_t>(active.size(), 1);
+        // a (chunk, group) list in ascending position (entries of one pixel stay adjacent)
+        for (auto &v : bucket)
+            std::stable_sort(v.begin(), v.end(), [](const Ent &a, const Ent &c) { return a.px < c.px; });
+
+        const size_t n_act = (size_t)std::max(n_chunks_all, 1);
         std::vector<int> nblk(n_act * BE_SETS * BE_SLOTS, 0);
         std::vector<int64_t> stream_off((size_t)n_pass * BE_SETS, 0);
         std::vector<uint32_t> stream;
-        size_t blocks = 0;
+        // f16 (k_bell_flat): a control word per record, one flat stream per (pass, wave)
+        std::vector<uint32_t> ctrl;
+        std::vector<int64_t> ctrl_off((size_t)n_pass * BE_SETS, 0);
+        std::vector<int> n_rec((size_t)n_pass * BE_SETS, 0);
+        size_t blocks = 0, pad_blocks = 0;
         std::vector<uint16_t> cols;
         for (int ps = 0; ps < n_pass; ++ps)
             for (int j = 0; j < BE_SETS; ++j) {
                 stream_off[(size_t)ps * BE_SETS + j] = (int64_t)blocks;
+                ctrl.resize((ctrl.size() + 7) / 8 * 8, BE_C_SKIP);            // 32-byte aligned streams
+                ctrl_off[(size_t)ps * BE_SETS + j] = (int64_t)ctrl.size();
+                const size_t ctrl0 = ctrl.size();
                 for (int ai = active_off[ps]; ai < active_off[ps + 1]; ++ai) {
-                    const int ch = active[ai];
-                    for (int s = 0; s < BE_SLOTS; ++s) {
-                        const int64_t g = (int64_t)ps * BE_SETS * BE_SLOTS + s * BE_SETS + j;
-                        if (g >= n_groups) continue;
-                        const std::vector<Ent> &ents = bucket[(size_t)ch * n_groups + g];
+                    const size_t ctrl_chunk0 = ctrl.size();
+                    for (int s = 0; s <= BE_SLOTS; ++s) {
+                        if (s == BE_SLOTS) {
+                            // end of the wave's work on this chunk
+                            if (f16) {
+                                if (ctrl.size() == ctrl_chunk0) {       // nothing: a record to carry the flag
+                                    stream.resize(stream.size() + BE_REC, 0u);
+                                    ctrl.push_back(BE_C_SKIP);
+                                    ++blocks;
+                                    ++pad_blocks;
+                                }
+                                ctrl.back() |= BE_C_END;
+                            }
+                            break;
+                        }
+                        const int gl = s * BE_SETS + j;            // group of the pass
+                        if ((int64_t)ps * GPP + gl >= n_groups) continue;
+                        const std::vector<Ent> &ents = bucket[(size_t)ai * GPP + gl];
                         if (ents.empty()) continue;
                         cols.clear();
-                        for (const Ent &en : ents)
-                            if (cols.empty() || cols.back() != en.px) cols.push_back(en.px);
-                        const int nb = ((int)cols.size() + 7) / 8;
+                        // units of the pair list: pixels, or (f16) aligned pixel pairs named by their
+                        // even pixel
+                        for (const Ent &en : ents) {
+                            const uint16_t u = f16 ? (uint16_t)(en.px & ~1u) : en.px;
+                            if (cols.empty() || cols.back() != u) cols.push_back(u);
+                        }
+                        const int nb = ((int)cols.size() + UPR - 1) / UPR;
                         nblk[((size_t)ai * BE_SETS + j) * BE_SLOTS + s] = nb;
                         const size_t base = stream.size();
                         stream.resize(base + (size_t)nb * BE_REC, 0u);
-                        // pixel numbers: lane l -> columns 8*blk + (l >> 4) and + 4
-                        for (int blk = 0; blk < nb; ++blk)
-                            for (int l = 0; l < 64; ++l) {
-                                const int c0 = blk * 8 + (l >> 4), c1 = c0 + 4;
-                                // padding columns (value 0) repeat the block's first pixel rather
-                                // than pixel 0 of the chunk: a non-finite pixel then only reaches
-                                // blocks that really contain it (0 * NaN = NaN)
-                                const uint32_t p0 = c0 < (int)cols.size() ? cols[c0] : cols[blk * 8];
-                                const uint32_t p1 = c1 < (int)cols.size() ? cols[c1] : cols[blk * 8];
-                                stream[base + (size_t)blk * BE_REC + l * 3 + 2] = p0 | (p1 << 16);
+                        if (!f16) {
+                            // pixel numbers: lane l -> columns 8*blk + (l >> 4) and + 4
+                            for (int blk = 0; blk < nb; ++blk)
+                                for (int l = 0; l < 64; ++l) {
+                                    const int c0 = blk * 8 + (l >> 4), c1 = c0 + 4;
+                                    // padding columns (value 0) repeat the block's first pixel rather
+                                    // than pixel 0 of the chunk: a non-finite pixel then only reaches
+                                    // blocks that really contain it (0 * NaN = NaN)
+                                    const uint32_t p0 = c0 < (int)cols.size() ? cols[c0] : cols[blk * 8];
+                                    const uint32_t p1 = c1 < (int)cols.size() ? cols[c1] : cols[blk * 8];
+                                    stream[base + (size_t)blk * BE_REC + l * 3 + 2] = p0 | (p1 << 16);
+                                }
+                            size_t ci = 0;
+                            for (const Ent &en : ents) {
+                                while (cols[ci] != en.px) ++ci;
+                                const int blk = (int)(ci / 8), step = (int)((ci % 8) / 4), kk = (int)(ci % 4);
+                                const int l = kk * 16 + en.m;
+                                uint32_t bits;
+                                memcpy(&bits, &en.v, 4);
+                                stream[base + (size_t)blk * BE_REC + l * 3 + step] = bits;
                             }
-                        size_t ci = 0;
-                        for (const Ent &en : ents) {
-                            while (cols[ci] != en.px) ++ci;
-                            const int blk = (int)(ci / 8), step = (int)((ci % 8) / 4), kk = (int)(ci % 4);
-                            const int l = kk * 16 + en.m;
-                            uint32_t bits;
-                            memcpy(&bits, &en.v, 4);
-                            stream[base + (size_t)blk * BE_REC + l * 3 + step] = bits;
+                        } else {
+                            // lane l = (mask l & 15, pair l >> 4 of the record): words
+                            // [w1(q) | w1(q+1) << 16, w2(q) | w2(q+1) << 16, q]
+                            for (int blk = 0; blk < nb; ++blk)
+                                for (int l = 0; l < 64; ++l) {
+                                    const int c0 = blk * 4 + (l >> 4);
+                                    stream[base + (size_t)blk * BE_REC + l * 3 + 2] =
+                                        c0 < (int)cols.size() ? cols[c0] : cols[blk * 4];
+                                }
+                            size_t ci = 0;
+                            const int64_t col_base = ((int64_t)ps * GPP + gl) * 16;
+                            for (const Ent &en : ents) {
+                                while (cols[ci] != (uint16_t)(en.px & ~1u)) ++ci;
+                                const int blk = (int)(ci / 4), kk = (int)(ci % 4);
+                                const int l = kk * 16 + en.m;
+                                const double ws = (double)en.v * (double)col_scale[(size_t)(col_base + en.m)];
+                                const uint16_t h1 = half_bits(ws);
+                                const uint16_t h2 = half_bits(ws - half_value(h1));
+                                const int sh = (en.px & 1) ? 16 : 0;
+                                uint32_t *rec = &stream[base + (size_t)blk * BE_REC + l * 3];
+                                rec[0] |= (uint32_t)h1 << sh;
+                                rec[1] |= (uint32_t)h2 << sh;
+                            }
                         }
                         blocks += nb;
+                        if (f16) ctrl.insert(ctrl.end(), (size_t)nb, (uint32_t)s);
                     }
                 }
-                // slack for the run-ahead loads of the last records
-                stream.resize(stream.size() + (size_t)BE_D_MAX * BE_REC, 0u);
-                blocks += BE_D_MAX;
+                if (f16) {
+                    // whole turns of the unrolled loop, then BE_FD records of slack for its run-ahead loads
+                    while ((ctrl.size() - ctrl0) % BE_FD) {
+                        stream.resize(stream.size() + BE_REC, 0u);
+                        ctrl.push_back(BE_C_SKIP);
+                        ++blocks;
+                        ++pad_blocks;
+                    }
+                    n_rec[(size_t)ps * BE_SETS + j] = (int)(ctrl.size() - ctrl0);
+                    stream.resize(stream.size() + (size_t)BE_FD * BE_REC, 0u);
+                    ctrl.insert(ctrl.end(), (size_t)BE_FD, BE_C_SKIP);
+                    blocks += BE_FD;
+                    pad_blocks += BE_FD;
+                } else {
+                    // slack for the run-ahead loads of the last records
+                    stream.resize(stream.size() + (size_t)BE_D_MAX * BE_REC, 0u);
+                    blocks += BE_D_MAX;
+                    pad_blocks += BE_D_MAX;
+                }
             }
+        ctrl.resize(ctrl.size() + 2 * BE_FD, BE_C_SKIP);          // (the control words are read one turn ahead)
         b->n_blocks = blocks;
         int64_t nnz = indptr[n_px] * nc;
-        b->mac_ratio = nnz > 0 ? (double)(blocks - (size_t)BE_D_MAX * n_pass * BE_SETS) * 128.0 / (double)nnz : 0.;
-        if (active.empty()) active.push_back(0);
+        b->mac_ratio = nnz > 0 ? (double)(blocks - pad_blocks) * 128.0 / (double)nnz : 0.;
+        if (active.empty()) active.resize(BE_NSEG, 0);
         hipError_t e = hipMalloc((void **)&b->stream, std::max<size_t>(stream.size(), 1) * 4);
         if (e == hipSuccess) e = hipMalloc((void **)&b->stream_off, stream_off.size() * 8);
         if (e == hipSuccess) e = hipMalloc((void **)&b->nblk, nblk.size() * 4);
@@ -548,6 +1173,21 @@ void *bell_build(const int64_t *indptr, const int64_t *indices, const float *val
             if (e == hipSuccess) e = hipMemcpy(b->tail_col, tail_col.data(), nt * 4, hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipMemcpy(b->tail_val, tail_val.data(), nt * 4, hipMemcpyHostToDevice);
         }
+        if (f16 && e == hipSuccess) {
+            e = hipMalloc((void **)&b->ctrl, ctrl.size() * 4);
+            if (e == hipSuccess) e = hipMalloc((void **)&b->ctrl_off, ctrl_off.size() * 8);
+            if (e == hipSuccess) e = hipMalloc((void **)&b->n_rec, n_rec.size() * 4);
+            if (e == hipSuccess) e = hipMemcpy(b->ctrl, ctrl.data(), ctrl.size() * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(b->ctrl_off, ctrl_off.data(), ctrl_off.size() * 8, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(b->n_rec, n_rec.data(), n_rec.size() * 4, hipMemcpyHostToDevice);
+        }
+        if (f16 && e == hipSuccess) {
+            std::vector<float> inv(col_scale.size());
+            for (size_t k = 0; k < inv.size(); ++k) inv[k] = 1.0f / col_scale[k];
+            e = hipMalloc((void **)&b->inv_scale, std::max<size_t>(inv.size(), 1) * 4);
+            if (e == hipSuccess && !inv.empty())
+                e = hipMemcpy(b->inv_scale, inv.data(), inv.size() * 4, hipMemcpyHostToDevice);
+        }
         if (e != hipSuccess) {
             set_error("uploading the blocked sparse mask image failed: %s", hipGetErrorString(e));
             *err = (int)e;
@@ -560,6 +1200,43 @@ void *bell_build(const int64_t *indptr, const int64_t *indices, const float *val
         bell_destroy(b);
         return nullptr;
     }
+    return b;
+}
+
+// The image(s) of a stack: the float32 one (any pixel type) and -- when every weight is finite -- the
+// float16 one for 1- and 2-byte unsigned pixels.  Column scale of the float16 image: the power of two
+// S with max |w| S in (64, 128], so that 256 w S stays below the float16 maximum and small weights
+// stay clear of its subnormals; the kernel multiplies the column by 1 / S at the end (exact).
+void *bell_build(const int64_t *indptr, const int64_t *indices, const float *vals, int nc,
+                 int64_t n_px, int64_t n_masks, int *err) {
+    const std::vector<float> none;
+    BellImage *b = build_image(indptr, indices, vals, nc, n_px, n_masks, false, none, err);
+    if (!b) return nullptr;
+    const char *off = getenv("LTMI_BELL_F16");
+    if (off && atoi(off) == 0) return b;
+    const int64_t n_cols = n_masks * nc;
+    std::vector<float> amax((size_t)n_cols, 0.f);
+    bool finite = true;
+    const int64_t nnz = indptr[n_px];
+    for (int64_t e = 0; e < nnz && finite; ++e)
+        for (int c = 0; c < nc; ++c) {
+            const float v = vals[e * nc + c];
+            if (!std::isfinite(v)) { finite = false; break; }
+            float &m = amax[(size_t)(indices[e] * nc + c)];
+            m = std::max(m, std::fabs(v));
+        }
+    if (!finite) return b;
+    std::vector<float> scale((size_t)n_cols, 1.f);
+    for (int64_t k = 0; k < n_cols; ++k)
+        if (amax[(size_t)k] > 0.f) {
+            int ex;
+            (void)std::frexp(amax[(size_t)k], &ex);          // amax = f * 2^ex, f in [0.5, 1)
+            const int sh = std::max(-120, std::min(120, 7 - ex));   // amax * 2^sh in [64, 128)
+            scale[(size_t)k] = std::ldexp(1.0f, sh);
+        }
+    int err16 = LTMI_OK;
+    b->h16 = build_image(indptr, indices, vals, nc, n_px, n_masks, true, scale, &err16);
+    // (a failure here -- memory -- leaves the float32 image in charge)
     return b;
 }
 
@@ -624,8 +1301,41 @@ static int launch_bell_t(ltmi_masks *m, BellImage *b, const T *tile, int64_t n_f
         LTMI_HIP(hipGetLastError());
     }
     snprintf(m->last_kernel, sizeof(m->last_kernel),
-             "k_bell_apply<%s,tiles=%d%s> grid=(%u,%u) blocks=%zu x%.2f", typeid(T).name(), TL,
-             m->roi_rows ? ",rows" : "", grid.x, grid.y, b->n_blocks, b->mac_ratio);
+             "k_bell_apply<%s,tiles=%d%s> grid=(%u,%u) blocks=%zu x%.2f crit=%ld", typeid(T).name(), TL,
+             m->roi_rows ? ",rows" : "", grid.x, grid.y, b->n_blocks, b->mac_ratio, b->crit_records);
+    return LTMI_OK;
+}
+
+template <typename T, int TL>
+static int launch_bell_flat(ltmi_masks *m, BellImage *b, const T *tile, int64_t n_frames, int64_t ld,
+                            float *out, int64_t ld_out_f, int n_cols, int accumulate, hipStream_t stream) {
+    using C = BeCfg<T, TL>;
+    auto kern = k_bell_flat<T, TL>;
+    constexpr int LDS = 2 * C::BUF;
+    static bool set[16] = {false};
+    if (!set[m->device & 15]) {
+        LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        set[m->device & 15] = true;
+    }
+    dim3 grid((unsigned)((n_frames + C::FB - 1) / C::FB), (unsigned)b->n_pass);
+    const char *abl = getenv("LTMI_BELL_ABLATE");
+    const int ablate = abl ? atoi(abl) : 0;
+    hipLaunchKernelGGL(kern, grid, dim3(BE_SETS * 64), LDS, stream, tile, ld, n_frames, m->n_px,
+                       (const uint32_t *)b->stream, (const int64_t *)b->stream_off,
+                       (const uint32_t *)b->ctrl, (const int64_t *)b->ctrl_off, (const int *)b->n_rec,
+                       (const int *)b->active, (const int *)b->active_off, out, ld_out_f, n_cols,
+                       accumulate, ablate, m->roi_rows, (const float *)b->inv_scale);
+    LTMI_HIP(hipGetLastError());
+    if (b->n_tail > 0) {
+        hipLaunchKernelGGL(k_bell_tail<T>, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0,
+                           stream, tile, ld, n_frames, (const int32_t *)b->tail_px,
+                           (const int32_t *)b->tail_col, (const float *)b->tail_val, b->n_tail, out,
+                           ld_out_f, m->roi_rows);
+        LTMI_HIP(hipGetLastError());
+    }
+    snprintf(m->last_kernel, sizeof(m->last_kernel),
+             "k_bell_flat<%s,tiles=%d,f16%s> grid=(%u,%u) blocks=%zu x%.2f crit=%ld", typeid(T).name(), TL,
+             m->roi_rows ? ",rows" : "", grid.x, grid.y, b->n_blocks, b->mac_ratio, b->crit_records);
     return LTMI_OK;
 }
 
@@ -640,6 +1350,15 @@ static int launch_bell(ltmi_masks *m, BellImage *b, const T *tile, int64_t n_fra
     static const int forced = getenv("LTMI_BELL_TILES") ? atoi(getenv("LTMI_BELL_TILES")) : 0;
     auto rounds = [&](int tl) { return (double)(((n_frames + 16 * tl - 1) / (16 * tl) + 255) / 256); };
     const bool hi = forced ? forced == HI : rounds(HI) * 1.7 < rounds(LO);
+    if constexpr (std::is_same<T, uint8_t>::value || std::is_same<T, uint16_t>::value) {
+        if (b->h16) {               // unsigned 1- / 2-byte pixels: the float16 image
+            if (hi)
+                return launch_bell_flat<T, HI>(m, b->h16, tile, n_frames, ld, out, ld_out_f, n_cols,
+                                               accumulate, stream);
+            return launch_bell_flat<T, LO>(m, b->h16, tile, n_frames, ld, out, ld_out_f, n_cols,
+                                           accumulate, stream);
+        }
+    }
     if (hi)
         return launch_bell_t<T, HI>(m, b, tile, n_frames, ld, out, ld_out_f, n_cols, accumulate, stream);
     return launch_bell_t<T, LO>(m, b, tile, n_frames, ld, out, ld_out_f, n_cols, accumulate, stream);
