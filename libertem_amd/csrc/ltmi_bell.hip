@@ -67,6 +67,17 @@ constexpr int BE_P = BE_P_;          // pixels per chunk
 constexpr int BE_SEG = BE_SEG_;      // a chunk = BE_NSEG runs ("segments") of BE_SEG consecutive pixels
 constexpr int BE_NSEG = BE_P / BE_SEG;
 static_assert(BE_NSEG >= 2 && BE_NSEG <= 64 && (BE_NSEG & (BE_NSEG - 1)) == 0, "segments per chunk");
+// the float16 image / k_bell_flat has its own chunk size and more frame buffers (see k_bell_flat)
+#ifndef BE_FP_
+#define BE_FP_ 512
+#endif
+#ifndef BE_FNBUF_
+#define BE_FNBUF_ 2
+#endif
+constexpr int BE_FP = BE_FP_;
+constexpr int BE_FNSEG = BE_FP / BE_SEG;
+constexpr int BE_FNBUF = BE_FNBUF_;
+static_assert(BE_FNSEG >= 2 && (BE_FNSEG & (BE_FNSEG - 1)) == 0 && BE_FNBUF >= 2, "float16 chunks");
 #ifndef BE_SETS_
 #define BE_SETS_ 16
 #endif
@@ -84,6 +95,7 @@ constexpr int BE_PASS = BE_SETS * BE_SLOTS * 16;     // real masks per pass (102
 #endif
 constexpr int BE_D_MAX = BE_D_;      // block records in flight per wave, at most (LDS permitting)
 constexpr int BE_REC = 192;          // dwords per block record (64 lanes x 3)
+constexpr int BE_REC16 = 128;        // ... of a float16 record (64 lanes x 2; pixel numbers in the control words)
 
 struct BellImage {
     uint32_t *stream = nullptr;      // [blocks][64 lanes][A step 0, A step 1, pixels]
@@ -118,11 +130,11 @@ template <int I, int N, typename F> __device__ __forceinline__ void bstatic_for(
     }
 }
 
-template <typename T, int TL> struct BeCfg {
+template <typename T, int TL, int P = BE_P> struct BeCfg {
     static constexpr int SZ = (int)sizeof(T);
     static constexpr int TILES = TL;                       // 16-frame tiles per workgroup
     static constexpr int FB = 16 * TILES;
-    static constexpr int ROW = BE_P * SZ;                  // bytes of a frame's chunk
+    static constexpr int ROW = P * SZ;                     // bytes of a frame's chunk
     static constexpr int RPD = ROW >= 1024 ? 1 : 1024 / ROW;   // frame rows per DMA instruction
     static constexpr int DPR = ROW >= 1024 ? ROW / 1024 : 1;   // DMA instructions per row
     static constexpr int NDMA_WG = FB * ROW / 1024;
@@ -134,7 +146,6 @@ template <typename T, int TL> struct BeCfg {
     // ring depth: what the 160 KiB leave next to the two slabs (2 with 64-frame slabs of 1 KiB rows)
     static constexpr int D_FIT = (160 * 1024 - 2 * BUF) / (BE_SETS * 1024);
     static constexpr int D = D_FIT < BE_D_MAX ? D_FIT : BE_D_MAX;
-    static_assert(D >= 2, "two slabs + a record ring of depth 2 must fit the LDS");
     static constexpr int LDS_BYTES = 2 * BUF + BE_SETS * D * 1024;
     __host__ __device__ static constexpr int frame_base(int f) {
         return (f / RPD) * UNIT_BYTES + (f % RPD) * ROW;
@@ -159,6 +170,7 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
     extern __shared__ __attribute__((aligned(16))) unsigned char be_lds[];
     using C = BeCfg<T, TL>;
     constexpr int TILES = C::TILES, NDMA = C::NDMA, BE_D = C::D;
+    static_assert(BE_D >= 2, "two slabs + a record ring of depth 2 must fit the LDS");
     // one tile: the two steps of a record go to two accumulators (no back-to-back dependent MFMAs)
     constexpr int NACC = TILES == 1 ? 2 : 1;
     const int tid = threadIdx.x;
@@ -444,9 +456,11 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
 // record -- which of the wave's 4 accumulator sets it feeds, whether the wave's work on the chunk
 // ends with it (then: wait for the next chunk's frames, barrier, start the copy of the chunk after
 // next) -- read through the scalar cache, which is a separate path.
+#ifndef BE_PHASE_SLEEP
+#define BE_PHASE_SLEEP 8            // s_sleep units (64 cycles) per phase step, 16 steps
+#endif
 constexpr int BE_FD = 8;
 constexpr unsigned BE_C_SKIP = 4u, BE_C_END = 8u;
-struct BeRec3 { uint32_t w1, w2, px; };       // a lane's 12 bytes of a float16 record
 
 #define BE_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63"
 #define BE_ACC_ZERO() asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tv_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0\n\tv_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\tv_accvgpr_write_b32 a10, 0\n\tv_accvgpr_write_b32 a11, 0\n\tv_accvgpr_write_b32 a12, 0\n\tv_accvgpr_write_b32 a13, 0\n\tv_accvgpr_write_b32 a14, 0\n\tv_accvgpr_write_b32 a15, 0\n\tv_accvgpr_write_b32 a16, 0\n\tv_accvgpr_write_b32 a17, 0\n\tv_accvgpr_write_b32 a18, 0\n\tv_accvgpr_write_b32 a19, 0\n\tv_accvgpr_write_b32 a20, 0\n\tv_accvgpr_write_b32 a21, 0\n\tv_accvgpr_write_b32 a22, 0\n\tv_accvgpr_write_b32 a23, 0\n\tv_accvgpr_write_b32 a24, 0\n\tv_accvgpr_write_b32 a25, 0\n\tv_accvgpr_write_b32 a26, 0\n\tv_accvgpr_write_b32 a27, 0\n\tv_accvgpr_write_b32 a28, 0\n\tv_accvgpr_write_b32 a29, 0\n\tv_accvgpr_write_b32 a30, 0\n\tv_accvgpr_write_b32 a31, 0\n\tv_accvgpr_write_b32 a32, 0\n\tv_accvgpr_write_b32 a33, 0\n\tv_accvgpr_write_b32 a34, 0\n\tv_accvgpr_write_b32 a35, 0\n\tv_accvgpr_write_b32 a36, 0\n\tv_accvgpr_write_b32 a37, 0\n\tv_accvgpr_write_b32 a38, 0\n\tv_accvgpr_write_b32 a39, 0\n\tv_accvgpr_write_b32 a40, 0\n\tv_accvgpr_write_b32 a41, 0\n\tv_accvgpr_write_b32 a42, 0\n\tv_accvgpr_write_b32 a43, 0\n\tv_accvgpr_write_b32 a44, 0\n\tv_accvgpr_write_b32 a45, 0\n\tv_accvgpr_write_b32 a46, 0\n\tv_accvgpr_write_b32 a47, 0\n\tv_accvgpr_write_b32 a48, 0\n\tv_accvgpr_write_b32 a49, 0\n\tv_accvgpr_write_b32 a50, 0\n\tv_accvgpr_write_b32 a51, 0\n\tv_accvgpr_write_b32 a52, 0\n\tv_accvgpr_write_b32 a53, 0\n\tv_accvgpr_write_b32 a54, 0\n\tv_accvgpr_write_b32 a55, 0\n\tv_accvgpr_write_b32 a56, 0\n\tv_accvgpr_write_b32 a57, 0\n\tv_accvgpr_write_b32 a58, 0\n\tv_accvgpr_write_b32 a59, 0\n\tv_accvgpr_write_b32 a60, 0\n\tv_accvgpr_write_b32 a61, 0\n\tv_accvgpr_write_b32 a62, 0\n\tv_accvgpr_write_b32 a63, 0" ::: BE_AGPRS)
@@ -512,30 +526,30 @@ struct BeRec3 { uint32_t w1, w2, px; };       // a lane's 12 bytes of a float16 
     }
 
 
-// the record ring of k_bell_flat: ring position u = a[64 + 4 u .. + 2] (register tuples start at even numbers), loaded by asm (the compiler neither
+// the record ring of k_bell_flat: ring position u = a[64 + 2 u], a[65 + 2 u], loaded by asm (the compiler neither
 // sees the loads nor the registers, so it cannot move a register whose load is still in flight) and
 // waited for with hand-counted vmcnt
-#define BE_RING_LOAD_0(VOFF, SBASE) asm volatile("global_load_dwordx3 a[64:66], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
-#define BE_RING_READ_0(W1, W2, PX) asm volatile("v_accvgpr_read_b32 %0, a64\n\tv_accvgpr_read_b32 %1, a65\n\tv_accvgpr_read_b32 %2, a66" : "=v"(W1), "=v"(W2), "=v"(PX) :: BE_RING_AGPRS)
-#define BE_RING_LOAD_1(VOFF, SBASE) asm volatile("global_load_dwordx3 a[68:70], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
-#define BE_RING_READ_1(W1, W2, PX) asm volatile("v_accvgpr_read_b32 %0, a68\n\tv_accvgpr_read_b32 %1, a69\n\tv_accvgpr_read_b32 %2, a70" : "=v"(W1), "=v"(W2), "=v"(PX) :: BE_RING_AGPRS)
-#define BE_RING_LOAD_2(VOFF, SBASE) asm volatile("global_load_dwordx3 a[72:74], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
-#define BE_RING_READ_2(W1, W2, PX) asm volatile("v_accvgpr_read_b32 %0, a72\n\tv_accvgpr_read_b32 %1, a73\n\tv_accvgpr_read_b32 %2, a74" : "=v"(W1), "=v"(W2), "=v"(PX) :: BE_RING_AGPRS)
-#define BE_RING_LOAD_3(VOFF, SBASE) asm volatile("global_load_dwordx3 a[76:78], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
-#define BE_RING_READ_3(W1, W2, PX) asm volatile("v_accvgpr_read_b32 %0, a76\n\tv_accvgpr_read_b32 %1, a77\n\tv_accvgpr_read_b32 %2, a78" : "=v"(W1), "=v"(W2), "=v"(PX) :: BE_RING_AGPRS)
-#define BE_RING_LOAD_4(VOFF, SBASE) asm volatile("global_load_dwordx3 a[80:82], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
-#define BE_RING_READ_4(W1, W2, PX) asm volatile("v_accvgpr_read_b32 %0, a80\n\tv_accvgpr_read_b32 %1, a81\n\tv_accvgpr_read_b32 %2, a82" : "=v"(W1), "=v"(W2), "=v"(PX) :: BE_RING_AGPRS)
-#define BE_RING_LOAD_5(VOFF, SBASE) asm volatile("global_load_dwordx3 a[84:86], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
-#define BE_RING_READ_5(W1, W2, PX) asm volatile("v_accvgpr_read_b32 %0, a84\n\tv_accvgpr_read_b32 %1, a85\n\tv_accvgpr_read_b32 %2, a86" : "=v"(W1), "=v"(W2), "=v"(PX) :: BE_RING_AGPRS)
-#define BE_RING_LOAD_6(VOFF, SBASE) asm volatile("global_load_dwordx3 a[88:90], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
-#define BE_RING_READ_6(W1, W2, PX) asm volatile("v_accvgpr_read_b32 %0, a88\n\tv_accvgpr_read_b32 %1, a89\n\tv_accvgpr_read_b32 %2, a90" : "=v"(W1), "=v"(W2), "=v"(PX) :: BE_RING_AGPRS)
-#define BE_RING_LOAD_7(VOFF, SBASE) asm volatile("global_load_dwordx3 a[92:94], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
-#define BE_RING_READ_7(W1, W2, PX) asm volatile("v_accvgpr_read_b32 %0, a92\n\tv_accvgpr_read_b32 %1, a93\n\tv_accvgpr_read_b32 %2, a94" : "=v"(W1), "=v"(W2), "=v"(PX) :: BE_RING_AGPRS)
-#define BE_RING_AGPRS "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95"
+#define BE_RING_LOAD_0(VOFF, SBASE) asm volatile("global_load_dwordx2 a[64:65], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
+#define BE_RING_READ_0(W1, W2) asm volatile("v_accvgpr_read_b32 %0, a64\n\tv_accvgpr_read_b32 %1, a65" : "=v"(W1), "=v"(W2) :: BE_RING_AGPRS)
+#define BE_RING_LOAD_1(VOFF, SBASE) asm volatile("global_load_dwordx2 a[66:67], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
+#define BE_RING_READ_1(W1, W2) asm volatile("v_accvgpr_read_b32 %0, a66\n\tv_accvgpr_read_b32 %1, a67" : "=v"(W1), "=v"(W2) :: BE_RING_AGPRS)
+#define BE_RING_LOAD_2(VOFF, SBASE) asm volatile("global_load_dwordx2 a[68:69], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
+#define BE_RING_READ_2(W1, W2) asm volatile("v_accvgpr_read_b32 %0, a68\n\tv_accvgpr_read_b32 %1, a69" : "=v"(W1), "=v"(W2) :: BE_RING_AGPRS)
+#define BE_RING_LOAD_3(VOFF, SBASE) asm volatile("global_load_dwordx2 a[70:71], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
+#define BE_RING_READ_3(W1, W2) asm volatile("v_accvgpr_read_b32 %0, a70\n\tv_accvgpr_read_b32 %1, a71" : "=v"(W1), "=v"(W2) :: BE_RING_AGPRS)
+#define BE_RING_LOAD_4(VOFF, SBASE) asm volatile("global_load_dwordx2 a[72:73], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
+#define BE_RING_READ_4(W1, W2) asm volatile("v_accvgpr_read_b32 %0, a72\n\tv_accvgpr_read_b32 %1, a73" : "=v"(W1), "=v"(W2) :: BE_RING_AGPRS)
+#define BE_RING_LOAD_5(VOFF, SBASE) asm volatile("global_load_dwordx2 a[74:75], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
+#define BE_RING_READ_5(W1, W2) asm volatile("v_accvgpr_read_b32 %0, a74\n\tv_accvgpr_read_b32 %1, a75" : "=v"(W1), "=v"(W2) :: BE_RING_AGPRS)
+#define BE_RING_LOAD_6(VOFF, SBASE) asm volatile("global_load_dwordx2 a[76:77], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
+#define BE_RING_READ_6(W1, W2) asm volatile("v_accvgpr_read_b32 %0, a76\n\tv_accvgpr_read_b32 %1, a77" : "=v"(W1), "=v"(W2) :: BE_RING_AGPRS)
+#define BE_RING_LOAD_7(VOFF, SBASE) asm volatile("global_load_dwordx2 a[78:79], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
+#define BE_RING_READ_7(W1, W2) asm volatile("v_accvgpr_read_b32 %0, a78\n\tv_accvgpr_read_b32 %1, a79" : "=v"(W1), "=v"(W2) :: BE_RING_AGPRS)
+#define BE_RING_AGPRS "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79"
 
 template <typename T, int TL>
-// (a[0:95] are named by hand and not in the compiler's budget: 32 registers are left for it)
-__global__ void __launch_bounds__(BE_SETS * 64, 1) __attribute__((amdgpu_num_vgpr(32)))
+// (a[0:79] are named by hand and not in the compiler's budget: 48 registers are left for it)
+__global__ void __launch_bounds__(BE_SETS * 64, 1) __attribute__((amdgpu_num_vgpr(48)))
 k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
             const uint32_t *__restrict__ stream, const int64_t *__restrict__ stream_off,
             const uint32_t *__restrict__ ctrl, const int64_t *__restrict__ ctrl_off,
@@ -544,7 +558,8 @@ k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             float *__restrict__ out, int64_t ld_out, int n_cols, int accumulate, int ablate,
             const int32_t *__restrict__ rows, const float *__restrict__ inv_scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char be_lds[];
-    using C = BeCfg<T, TL>;
+    using C = BeCfg<T, TL, BE_FP>;
+    constexpr int NBUF = BE_FNBUF, DIST = NBUF >= 3 ? NBUF - 1 : 1;
     static_assert(C::SZ <= 2, "float16 path: 1- and 2-byte pixels");
     constexpr int TILES = C::TILES, NDMA = C::NDMA;
     const int tid = threadIdx.x;
@@ -564,7 +579,7 @@ k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
 
     auto issue_dma = [&](int ai, int buf, int i_lo = 0, int i_hi = 64) {
         if (ablate == 1 || ablate == 3) return;
-        const int segv = active[(int64_t)ai * BE_NSEG + (lane & (BE_NSEG - 1))];
+        const int segv = active[(int64_t)ai * BE_FNSEG + (lane & (BE_FNSEG - 1))];
         constexpr int PPS = BE_SEG * C::SZ / 16;
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) {
@@ -596,11 +611,11 @@ k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
     };
 
     const int wj = pass * BE_SETS + j;
-    const unsigned char *rec_base = (const unsigned char *)(stream + stream_off[wj] * BE_REC);   // uniform
-    const unsigned lane12 = (unsigned)lane * 12u;
+    const unsigned char *rec_base = (const unsigned char *)(stream + stream_off[wj] * BE_REC16);   // uniform
+    const unsigned lane12 = (unsigned)lane * 8u;           // a lane's 8 bytes of a record
     const uint32_t *ctl = ctrl + ctrl_off[wj];
     const int n = n_rec[wj];                       // a multiple of BE_FD; BE_FD more records follow
-    constexpr int REC_BYTES = BE_REC * 4;
+    constexpr int REC_BYTES = BE_REC16 * 4;
 
     auto ring_load = [&](auto U, int64_t rec) {
         constexpr int u = decltype(U)::value;
@@ -614,18 +629,19 @@ k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
         else if constexpr (u == 6) BE_RING_LOAD_6(lane12, sb);
         else BE_RING_LOAD_7(lane12, sb);
     };
-    auto ring_read = [&](auto U, unsigned &w1, unsigned &w2, unsigned &px) {
+    auto ring_read = [&](auto U, unsigned &w1, unsigned &w2) {
         constexpr int u = decltype(U)::value;
-        if constexpr (u == 0) BE_RING_READ_0(w1, w2, px);
-        else if constexpr (u == 1) BE_RING_READ_1(w1, w2, px);
-        else if constexpr (u == 2) BE_RING_READ_2(w1, w2, px);
-        else if constexpr (u == 3) BE_RING_READ_3(w1, w2, px);
-        else if constexpr (u == 4) BE_RING_READ_4(w1, w2, px);
-        else if constexpr (u == 5) BE_RING_READ_5(w1, w2, px);
-        else if constexpr (u == 6) BE_RING_READ_6(w1, w2, px);
-        else BE_RING_READ_7(w1, w2, px);
+        if constexpr (u == 0) BE_RING_READ_0(w1, w2);
+        else if constexpr (u == 1) BE_RING_READ_1(w1, w2);
+        else if constexpr (u == 2) BE_RING_READ_2(w1, w2);
+        else if constexpr (u == 3) BE_RING_READ_3(w1, w2);
+        else if constexpr (u == 4) BE_RING_READ_4(w1, w2);
+        else if constexpr (u == 5) BE_RING_READ_5(w1, w2);
+        else if constexpr (u == 6) BE_RING_READ_6(w1, w2);
+        else BE_RING_READ_7(w1, w2);
     };
-    static_assert(BE_FD <= 8, "ring registers a[64:95]");
+    const unsigned kg8 = (unsigned)kg * 8u;
+    static_assert(BE_FD <= 8 && BE_FP <= 512, "ring registers a[64:79]; pair numbers are bytes");
 
     const int lane_base = C::frame_base(m16);
     const unsigned swz = (unsigned)((m16 & 7) << 4);
@@ -638,15 +654,40 @@ k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
     // YOUNGER than the load of the record a turn is about to use and may stay in flight with the
     // BE_FD - 1 younger record loads
     unsigned win = 0;
-    if (a0 < a1) issue_dma(a0, 0);
+    // Frame copies.  NBUF = 2: the copy of chunk c + 1 starts when everybody has left chunk c - 1, i.e.
+    // right after the barrier -- all waves issue at once and the copy has one chunk's time to land.
+    // NBUF >= 3: a wave issues its part of chunk c + NBUF - 1 when IT is through with chunk c (that
+    // buffer was chunk c - 1's, which everybody left before this wave entered chunk c): the issues
+    // are spread over the waves' arrival times -- the early ones do it while they wait at the
+    // barrier anyway -- and a copy has NBUF - 2 chunks' time to land.
+    int r_cur = 0, r_prev = 63;                    // record loads issued during this / the previous chunk
+#ifndef BE_NO_PHASE
+    // A launch that fills the chip once starts all workgroups together, and they stay in step: every CU
+    // asks for its next chunk at the same moment and computes at the same moment -- the HBM sees
+    // bursts and idles in between, and the copies take the longer for it.  Spread the workgroups over one
+    // chunk period (~5 us) once, at the start.
+    {
+        const int steps = (int)((blockIdx.x * 7u + blockIdx.y) & 15u);
+        for (int k = 0; k < steps; ++k) __builtin_amdgcn_s_sleep(BE_PHASE_SLEEP);
+    }
+#endif
+    if constexpr (NBUF >= 3) {
+#pragma unroll
+        for (int d = 0; d < DIST; ++d)
+            if (a0 + d < a1) issue_dma(a0 + d, d);
+    } else {
+        if (a0 < a1) issue_dma(a0, 0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     bstatic_for<0, BE_FD>([&](auto U) { ring_load(U, (int64_t) decltype(U)::value); });
-    if (a0 + 1 < a1) {
-        issue_dma(a0 + 1, 1);
-        if (ablate != 1 && ablate != 3) { since = 0; win = 1; }
+    if constexpr (NBUF < 3) {
+        if (a0 + 1 < a1) {
+            issue_dma(a0 + 1, 1);
+            if (ablate != 1 && ablate != 3) { since = 0; win = 1; }
+        }
     }
     const unsigned char *bbase = be_lds + lane_base;
 
@@ -654,9 +695,9 @@ k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
     const bh16x2 kbias = {(_Float16)1024.0f, (_Float16)1024.0f};
 
     for (int i = 0; i < n; i += BE_FD) {
-        unsigned cw[BE_FD];
+        unsigned cw[BE_FD], cpx[BE_FD];
 #pragma unroll
-        for (int u = 0; u < BE_FD; ++u) cw[u] = ctl[i + u];
+        for (int u = 0; u < BE_FD; ++u) { cw[u] = ctl[2 * (i + u)]; cpx[u] = ctl[2 * (i + u) + 1]; }
         bstatic_for<0, BE_FD>([&](auto U) {
             constexpr int u = decltype(U)::value;
             const unsigned c = cw[u];
@@ -671,17 +712,19 @@ k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
 #else
                 if (nb == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD - 1) : "memory");
                 else if (nb == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD - 1 + NDMA) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD - 1 + 2 * NDMA) : "memory");
+                else if (nb == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD - 1 + 2 * NDMA) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD - 1 + 3 * NDMA) : "memory");
 #endif
             }
             if (!(c & BE_C_SKIP)) {
-                unsigned rw1, rw2, rpx;
-                ring_read(U, rw1, rw2, rpx);
+                unsigned rw1, rw2;
+                ring_read(U, rw1, rw2);
+                const unsigned rpair = __builtin_amdgcn_ubfe(cpx[u], kg8, 8u);    // this lane group's pair
                 bh16x2 w1l = __builtin_bit_cast(bh16x2, rw1), w2l = __builtin_bit_cast(bh16x2, rw2);
                 bh16x2 w1h = w1l * k256, w2h = w2l * k256;
                 bh16x4 a1v = {w1l[0], w1l[1], w1h[0], w1h[1]};
                 bh16x4 a2v = {w2l[0], w2l[1], w2h[0], w2h[1]};
-                const unsigned char *pq = bbase + buf * C::BUF + (((rpx & 0xffffu) * C::SZ) ^ swz);
+                const unsigned char *pq = bbase + buf * C::BUF + ((rpair * (2 * C::SZ)) ^ swz);
                 unsigned raw[TILES];
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
@@ -722,6 +765,31 @@ k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                 if (ablate != 1 && ablate != 3) { since = 0; win |= 1u; }
             }
 #endif
+            ++r_cur;
+            if ((c & BE_C_END) && NBUF >= 3) {
+                // this wave is through with chunk ai: start its part of the copy of chunk ai + DIST, make
+                // sure its part of chunk ai + 1 has landed -- younger than that are the record loads of
+                // this and the previous chunk (at most BE_FD in flight) and (NBUF - 2) later copies --
+                // then everybody meets
+                const bool more = ai + DIST < a1;
+                if (more) issue_dma(ai + DIST, (buf + DIST) % NBUF);
+                const int r2 = r_cur + r_prev;
+                constexpr int YOUNGER = (NBUF - 2) * NDMA;
+                if (ablate == 1 || ablate == 3) asm volatile("" ::: "memory");
+                else if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the last chunks)
+                else if (r2 >= BE_FD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD + YOUNGER) : "memory");
+                else if (r2 >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + YOUNGER) : "memory");
+                else if (r2 >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + YOUNGER) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (ablate != 3) __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                ++ai;
+                buf = buf + 1 == NBUF ? 0 : buf + 1;
+                r_prev = r_cur;
+                r_cur = 0;
+                if (more && ablate != 1 && ablate != 3) win |= 1u;
+            } else
             if (c & BE_C_END) {
                 // this wave is through with chunk ai: the next chunk's frames must have landed -- their
                 // copy is older than the last `since` record loads, and nothing else is younger --
@@ -827,8 +895,10 @@ struct ChunkPlanner {
     int n_local;                                    // groups of the pass (<= BE_SETS * BE_SLOTS)
     const std::vector<uint16_t> &cnt;               // [segment][n_local] touched pixels (f16: pixel pairs)
     int upr;                                        // of them per record: 8 pixels / 4 pairs
+    int nseg;                                       // segments per chunk
     std::vector<int> tmp;
-    ChunkPlanner(int nl, const std::vector<uint16_t> &c, int u) : n_local(nl), cnt(c), upr(u), tmp((size_t)nl) {}
+    ChunkPlanner(int nl, const std::vector<uint16_t> &c, int u, int ns)
+        : n_local(nl), cnt(c), upr(u), nseg(ns), tmp((size_t)nl) {}
     // (records of the busiest wave, records of all waves) of a chunk made of `segs`
     void cost(const int *segs, int n, int *crit, int *total) {
         std::fill(tmp.begin(), tmp.end(), 0);
@@ -848,15 +918,15 @@ struct ChunkPlanner {
         *crit = mx;
         *total = tot;
     }
-    // segs: n_chunks * BE_NSEG segment numbers (index into cnt), -1 = empty slot; optimised in place
+    // segs: n_chunks * nseg segment numbers (index into cnt), -1 = empty slot; optimised in place
     long plan(std::vector<int> &segs, long *total_out) {
-        const int n_chunks = (int)(segs.size() / BE_NSEG);
+        const int n_chunks = (int)(segs.size() / nseg);
         std::vector<int> cc((size_t)n_chunks), ct((size_t)n_chunks);
         auto eval_all = [&](const std::vector<int> &a, long *tot) {
             long c = 0, t = 0;
             for (int k = 0; k < n_chunks; ++k) {
                 int x, y;
-                cost(a.data() + (size_t)k * BE_NSEG, BE_NSEG, &x, &y);
+                cost(a.data() + (size_t)k * nseg, nseg, &x, &y);
                 c += x; t += y;
             }
             *tot = t;
@@ -872,14 +942,14 @@ struct ChunkPlanner {
             for (int v : segs) {
                 if (v < 0) continue;
                 const int c = k % n_chunks;
-                inter[(size_t)c * BE_NSEG + fill[c]++] = v;
+                inter[(size_t)c * nseg + fill[c]++] = v;
                 ++k;
             }
         }
         long t_nat, t_int;
         const long c_nat = eval_all(segs, &t_nat), c_int = eval_all(inter, &t_int);
         if (c_int + W_TOTAL * t_int < c_nat + W_TOTAL * t_nat) segs = inter;
-        for (int k = 0; k < n_chunks; ++k) cost(segs.data() + (size_t)k * BE_NSEG, BE_NSEG, &cc[k], &ct[k]);
+        for (int k = 0; k < n_chunks; ++k) cost(segs.data() + (size_t)k * nseg, nseg, &cc[k], &ct[k]);
         if (n_chunks >= 2) {
             uint64_t rng = 0x9E3779B97F4A7C15ull;
             auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
@@ -887,12 +957,12 @@ struct ChunkPlanner {
             for (long it = 0; it < iters; ++it) {
                 const int A = (int)(next() % n_chunks), B = (int)(next() % n_chunks);
                 if (A == B) continue;
-                const size_t ia = (size_t)A * BE_NSEG + next() % BE_NSEG, ib = (size_t)B * BE_NSEG + next() % BE_NSEG;
+                const size_t ia = (size_t)A * nseg + next() % nseg, ib = (size_t)B * nseg + next() % nseg;
                 if (segs[ia] < 0 && segs[ib] < 0) continue;
                 std::swap(segs[ia], segs[ib]);
                 int ca, ta, cb, tb;
-                cost(segs.data() + (size_t)A * BE_NSEG, BE_NSEG, &ca, &ta);
-                cost(segs.data() + (size_t)B * BE_NSEG, BE_NSEG, &cb, &tb);
+                cost(segs.data() + (size_t)A * nseg, nseg, &ca, &ta);
+                cost(segs.data() + (size_t)B * nseg, nseg, &cb, &tb);
                 const double d = (ca + cb - cc[A] - cc[B]) + W_TOTAL * (ta + tb - ct[A] - ct[B]);
                 const double T = std::max(0.02, 1.0 - (double)it / (double)iters);
                 const double u = (double)(next() >> 11) * (1.0 / 9007199254740992.0);
@@ -933,6 +1003,8 @@ static BellImage *build_image(const int64_t *indptr, const int64_t *indices, con
     if (!b) { *err = LTMI_E_NOMEM; return nullptr; }
     b->f16 = f16;
     const int UPR = f16 ? 4 : 8;                        // units (pixels / pixel pairs) per record
+    const int REC = f16 ? BE_REC16 : BE_REC;          // dwords per record
+    const int NSEG = f16 ? BE_FNSEG : BE_NSEG;        // segments per chunk
     try {
         const int64_t n_cols = n_masks * nc;
         const int64_t n_groups = (n_cols + 15) / 16;
@@ -954,7 +1026,7 @@ static BellImage *build_image(const int64_t *indptr, const int64_t *indices, con
         b->n_tail = (int)tail_px.size();
 
         // ---- per pass: which segments hold entries, how they are grouped into chunks
-        std::vector<int> active, active_off(n_pass + 1, 0);     // active: [chunk][BE_NSEG] segment numbers
+        std::vector<int> active, active_off(n_pass + 1, 0);     // active: [chunk][NSEG] segment numbers
         std::vector<int> chunk_of_seg((size_t)n_pass * n_seg, -1), slot_of_seg((size_t)n_pass * n_seg, 0);
         const bool natural = getenv("LTMI_BELL_NATURAL_CHUNKS") != nullptr;     // experiments: no planning
         for (int ps = 0; ps < n_pass; ++ps) {
@@ -982,24 +1054,24 @@ static BellImage *build_image(const int64_t *indptr, const int64_t *indices, con
                     }
             }
             const int n_act = (int)seg_list.size();
-            const int n_chunks = (n_act + BE_NSEG - 1) / BE_NSEG;
-            std::vector<int> segs((size_t)n_chunks * BE_NSEG, -1);
+            const int n_chunks = (n_act + NSEG - 1) / NSEG;
+            std::vector<int> segs((size_t)n_chunks * NSEG, -1);
             for (int k = 0; k < n_act; ++k) segs[k] = k;
-            ChunkPlanner planner(n_local, cnt, UPR);
+            ChunkPlanner planner(n_local, cnt, UPR, NSEG);
             long total = 0;
             if (natural) {
                 for (int k = 0; k < n_chunks; ++k) {
                     int x, y;
-                    planner.cost(segs.data() + (size_t)k * BE_NSEG, BE_NSEG, &x, &y);
+                    planner.cost(segs.data() + (size_t)k * NSEG, NSEG, &x, &y);
                     b->crit_records += x;
                 }
             } else {
                 b->crit_records += planner.plan(segs, &total);
             }
-            const int chunk0 = (int)(active.size() / BE_NSEG);
+            const int chunk0 = (int)(active.size() / NSEG);
             for (int k = 0; k < n_chunks; ++k)
-                for (int i = 0; i < BE_NSEG; ++i) {
-                    const int v = segs[(size_t)k * BE_NSEG + i];
+                for (int i = 0; i < NSEG; ++i) {
+                    const int v = segs[(size_t)k * NSEG + i];
                     // (an empty slot fetches the frame's first pixels: never referenced by a record)
                     active.push_back(v < 0 ? 0 : seg_list[v] * BE_SEG);
                     if (v >= 0) {
@@ -1007,7 +1079,7 @@ static BellImage *build_image(const int64_t *indptr, const int64_t *indices, con
                         slot_of_seg[(size_t)ps * n_seg + seg_list[v]] = i;
                     }
                 }
-            active_off[ps + 1] = (int)(active.size() / BE_NSEG);
+            active_off[ps + 1] = (int)(active.size() / NSEG);
         }
         const int n_chunks_all = active_off[n_pass];
 
@@ -1042,10 +1114,11 @@ static BellImage *build_image(const int64_t *indptr, const int64_t *indices, con
         std::vector<int> n_rec((size_t)n_pass * BE_SETS, 0);
         size_t blocks = 0, pad_blocks = 0;
         std::vector<uint16_t> cols;
+        std::vector<uint32_t> pxws;
         for (int ps = 0; ps < n_pass; ++ps)
             for (int j = 0; j < BE_SETS; ++j) {
                 stream_off[(size_t)ps * BE_SETS + j] = (int64_t)blocks;
-                ctrl.resize((ctrl.size() + 7) / 8 * 8, BE_C_SKIP);            // 32-byte aligned streams
+                ctrl.resize((ctrl.size() + 15) / 16 * 16, BE_C_SKIP);         // 64-byte aligned streams
                 ctrl_off[(size_t)ps * BE_SETS + j] = (int64_t)ctrl.size();
                 const size_t ctrl0 = ctrl.size();
                 for (int ai = active_off[ps]; ai < active_off[ps + 1]; ++ai) {
@@ -1055,12 +1128,13 @@ static BellImage *build_image(const int64_t *indptr, const int64_t *indices, con
                             // end of the wave's work on this chunk
                             if (f16) {
                                 if (ctrl.size() == ctrl_chunk0) {       // nothing: a record to carry the flag
-                                    stream.resize(stream.size() + BE_REC, 0u);
+                                    stream.resize(stream.size() + REC, 0u);
                                     ctrl.push_back(BE_C_SKIP);
+                                    ctrl.push_back(0u);
                                     ++blocks;
                                     ++pad_blocks;
                                 }
-                                ctrl.back() |= BE_C_END;
+                                ctrl[ctrl.size() - 2] |= BE_C_END;
                             }
                             break;
                         }
@@ -1078,7 +1152,7 @@ static BellImage *build_image(const int64_t *indptr, const int64_t *indices, con
                         const int nb = ((int)cols.size() + UPR - 1) / UPR;
                         nblk[((size_t)ai * BE_SETS + j) * BE_SLOTS + s] = nb;
                         const size_t base = stream.size();
-                        stream.resize(base + (size_t)nb * BE_REC, 0u);
+                        stream.resize(base + (size_t)nb * REC, 0u);
                         if (!f16) {
                             // pixel numbers: lane l -> columns 8*blk + (l >> 4) and + 4
                             for (int blk = 0; blk < nb; ++blk)
@@ -1089,7 +1163,7 @@ static BellImage *build_image(const int64_t *indptr, const int64_t *indices, con
                                     // blocks that really contain it (0 * NaN = NaN)
                                     const uint32_t p0 = c0 < (int)cols.size() ? cols[c0] : cols[blk * 8];
                                     const uint32_t p1 = c1 < (int)cols.size() ? cols[c1] : cols[blk * 8];
-                                    stream[base + (size_t)blk * BE_REC + l * 3 + 2] = p0 | (p1 << 16);
+                                    stream[base + (size_t)blk * REC + l * 3 + 2] = p0 | (p1 << 16);
                                 }
                             size_t ci = 0;
                             for (const Ent &en : ents) {
@@ -1098,17 +1172,21 @@ static BellImage *build_image(const int64_t *indptr, const int64_t *indices, con
                                 const int l = kk * 16 + en.m;
                                 uint32_t bits;
                                 memcpy(&bits, &en.v, 4);
-                                stream[base + (size_t)blk * BE_REC + l * 3 + step] = bits;
+                                stream[base + (size_t)blk * REC + l * 3 + step] = bits;
                             }
                         } else {
                             // lane l = (mask l & 15, pair l >> 4 of the record): words
-                            // [w1(q) | w1(q+1) << 16, w2(q) | w2(q+1) << 16, q]
-                            for (int blk = 0; blk < nb; ++blk)
-                                for (int l = 0; l < 64; ++l) {
-                                    const int c0 = blk * 4 + (l >> 4);
-                                    stream[base + (size_t)blk * BE_REC + l * 3 + 2] =
-                                        c0 < (int)cols.size() ? cols[c0] : cols[blk * 4];
+                            // [w1(q) | w1(q+1) << 16, w2(q) | w2(q+1) << 16]; the four pairs' numbers q / 2
+                            // are the bytes of the record's second control word
+                            for (int blk = 0; blk < nb; ++blk) {
+                                uint32_t pxw = 0;
+                                for (int kk = 0; kk < 4; ++kk) {
+                                    const int c0 = blk * 4 + kk;
+                                    const uint32_t q = c0 < (int)cols.size() ? cols[c0] : cols[blk * 4];
+                                    pxw |= (q >> 1) << (8 * kk);
                                 }
+                                pxws.push_back(pxw);
+                            }
                             size_t ci = 0;
                             const int64_t col_base = ((int64_t)ps * GPP + gl) * 16;
                             for (const Ent &en : ents) {
@@ -1119,40 +1197,46 @@ static BellImage *build_image(const int64_t *indptr, const int64_t *indices, con
                                 const uint16_t h1 = half_bits(ws);
                                 const uint16_t h2 = half_bits(ws - half_value(h1));
                                 const int sh = (en.px & 1) ? 16 : 0;
-                                uint32_t *rec = &stream[base + (size_t)blk * BE_REC + l * 3];
+                                uint32_t *rec = &stream[base + (size_t)blk * REC + l * 2];
                                 rec[0] |= (uint32_t)h1 << sh;
                                 rec[1] |= (uint32_t)h2 << sh;
                             }
                         }
                         blocks += nb;
-                        if (f16) ctrl.insert(ctrl.end(), (size_t)nb, (uint32_t)s);
+                        if (f16)
+                            for (int blk = 0; blk < nb; ++blk) {
+                                ctrl.push_back((uint32_t)s);
+                                ctrl.push_back(pxws[(size_t)blk]);
+                            }
+                        pxws.clear();
                     }
                 }
                 if (f16) {
                     // whole turns of the unrolled loop, then BE_FD records of slack for its run-ahead loads
-                    while ((ctrl.size() - ctrl0) % BE_FD) {
-                        stream.resize(stream.size() + BE_REC, 0u);
+                    while (((ctrl.size() - ctrl0) / 2) % BE_FD) {
+                        stream.resize(stream.size() + REC, 0u);
                         ctrl.push_back(BE_C_SKIP);
+                        ctrl.push_back(0u);
                         ++blocks;
                         ++pad_blocks;
                     }
-                    n_rec[(size_t)ps * BE_SETS + j] = (int)(ctrl.size() - ctrl0);
-                    stream.resize(stream.size() + (size_t)BE_FD * BE_REC, 0u);
-                    ctrl.insert(ctrl.end(), (size_t)BE_FD, BE_C_SKIP);
+                    n_rec[(size_t)ps * BE_SETS + j] = (int)((ctrl.size() - ctrl0) / 2);
+                    stream.resize(stream.size() + (size_t)BE_FD * REC, 0u);
+                    for (int k = 0; k < BE_FD; ++k) { ctrl.push_back(BE_C_SKIP); ctrl.push_back(0u); }
                     blocks += BE_FD;
                     pad_blocks += BE_FD;
                 } else {
                     // slack for the run-ahead loads of the last records
-                    stream.resize(stream.size() + (size_t)BE_D_MAX * BE_REC, 0u);
+                    stream.resize(stream.size() + (size_t)BE_D_MAX * REC, 0u);
                     blocks += BE_D_MAX;
                     pad_blocks += BE_D_MAX;
                 }
             }
-        ctrl.resize(ctrl.size() + 2 * BE_FD, BE_C_SKIP);          // (the control words are read one turn ahead)
+        ctrl.resize(ctrl.size() + 4 * BE_FD, BE_C_SKIP);          // (the control words are read one turn ahead)
         b->n_blocks = blocks;
         int64_t nnz = indptr[n_px] * nc;
         b->mac_ratio = nnz > 0 ? (double)(blocks - pad_blocks) * 128.0 / (double)nnz : 0.;
-        if (active.empty()) active.resize(BE_NSEG, 0);
+        if (active.empty()) active.resize(NSEG, 0);
         hipError_t e = hipMalloc((void **)&b->stream, std::max<size_t>(stream.size(), 1) * 4);
         if (e == hipSuccess) e = hipMalloc((void **)&b->stream_off, stream_off.size() * 8);
         if (e == hipSuccess) e = hipMalloc((void **)&b->nblk, nblk.size() * 4);
@@ -1309,9 +1393,9 @@ static int launch_bell_t(ltmi_masks *m, BellImage *b, const T *tile, int64_t n_f
 template <typename T, int TL>
 static int launch_bell_flat(ltmi_masks *m, BellImage *b, const T *tile, int64_t n_frames, int64_t ld,
                             float *out, int64_t ld_out_f, int n_cols, int accumulate, hipStream_t stream) {
-    using C = BeCfg<T, TL>;
+    using C = BeCfg<T, TL, BE_FP>;
     auto kern = k_bell_flat<T, TL>;
-    constexpr int LDS = 2 * C::BUF;
+    constexpr int LDS = BE_FNBUF * C::BUF;
     static bool set[16] = {false};
     if (!set[m->device & 15]) {
         LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
