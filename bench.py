@@ -556,6 +556,7 @@ def main():
                 mm = measure(wl, k, 2, barrier, hip, n_check=4)
                 el = max_over_ranks(mm['elapsed'])
                 return {"result_via": getattr(ctx.executor, 'last_result_via', None),
+                        "collective": getattr(ctx.executor, 'last_collective', None),
                         "steps": k, "ms_per_step": el / k * 1e3,
                         "value": n_frames * world * k / el, "unit": "frames/s"}
             finally:

@@ -56,6 +56,22 @@ def _dist():
 _CURRENT_OWNER = None
 
 
+class _LazyTorchDtypes(dict):
+    """torch dtype -> NumPy dtype for the dtypes ltmi_comm_all_reduce_sum takes (torch imported late)"""
+
+    def get(self, key, default=None):
+        if not self:
+            import torch
+            self.update({torch.float32: np.float32, torch.float64: np.float64,
+                         torch.complex64: np.complex64, torch.complex128: np.complex128,
+                         torch.int32: np.int32, torch.int64: np.int64, torch.uint8: np.uint8,
+                         torch.int8: np.int8})
+        return dict.get(self, key, default)
+
+
+_NP_OF_TORCH = _LazyTorchDtypes()
+
+
 class HipJobExecutor(JobExecutor):
     device_class = 'hip'
 
@@ -221,6 +237,9 @@ class HipJobExecutor(JobExecutor):
 
     def close(self):
         self._scattered = {}
+        if getattr(self, '_comm_state', None):
+            self._comm_state.close()
+            self._comm_state = None
         if getattr(self, '_shared', None) is not None:
             self._shared.close()
             self._shared = None
@@ -749,10 +768,74 @@ class HipJobExecutor(JobExecutor):
             else:
                 raise ValueError(f"unknown dist merge {how!r} for buffer {name!r}")
 
+    def _rccl(self, d):
+        """The library's own RCCL communicator (`ltmi_comm_*`, csrc/ltmi_comm.cpp) over the ranks of the
+        job, or None: created once -- rank 0 draws the unique id, the control plane (torch.distributed's
+        store / object broadcast) carries its 128 bytes to the others, then ncclCommInitRank on every
+        rank -- and only for device tensors on the "nccl" backend (gloo test ranks share one GPU, which
+        RCCL refuses).  Whether everybody has a communicator is agreed on collectively, so all ranks
+        take the same path.  LTMI_COMM=torch keeps the data plane in torch.distributed."""
+        if getattr(self, '_comm_state', None) is not None:
+            return self._comm_state or None
+        self._comm_state = False
+        if self.gpu_id is None or os.environ.get('LTMI_COMM', 'ltmi') == 'torch' \
+                or d.get_backend() != 'nccl':
+            return None
+        import torch
+        from libertem_amd import hip
+        comm, err = None, None
+        try:
+            box = [hip.Comm.unique_id() if self.rank == 0 else None]
+            d.broadcast_object_list(box, src=0)
+            self._make_current()
+            comm = hip.Comm(self.gpu_id, self.rank, self.world_size, box[0])
+        except Exception as e:                       # noqa: BLE001  (decided collectively below)
+            err = e
+        ok = torch.tensor([0 if comm is None else 1], dtype=torch.int32,
+                          device=f'cuda:{self.gpu_id}')
+        d.all_reduce(ok, op=d.ReduceOp.MIN)
+        if int(ok.item()) != 1:
+            import logging
+            logging.getLogger(__name__).warning(
+                "ltmi_comm could not be set up on every rank (%r here) -- results are combined "
+                "through torch.distributed", err)
+            if comm is not None:
+                comm.close()
+            return None
+        self._comm_state = comm
+        return comm
+
     def _combine(self, d, full, how):
         """all ranks: disjoint -> every rank's rows are zero outside its own partitions, so a SUM
-        all-reduce is an exact concatenation (x + 0 == x); sum -> all-reduce."""
+        all-reduce is an exact concatenation (x + 0 == x); sum -> all-reduce.  Device tensors on the
+        nccl backend go through the library's own communicator (`_rccl`): all-gather of equal row
+        blocks / all-reduce(sum) on the executor's stream, torch only owns the buffers."""
         import torch
+        comm = self._rccl(d) if full.is_cuda else None
+        if comm is not None:
+            self._make_current()
+            self.last_collective = 'ltmi_comm'
+            if full.dtype == torch.bool:
+                t = full.to(torch.uint8).contiguous()
+                comm.all_reduce_sum(t.data_ptr(), np.uint8, t.numel(), stream=self._stream_ptr)
+                return t != 0
+            if not full.is_contiguous():
+                full = full.contiguous()
+            if how == 'disjoint' and full.dim() >= 1 and full.shape[0] >= self.world_size \
+                    and self._equal_rows(full.shape[0]):
+                W, r = self.world_size, self.rank
+                rows = full.shape[0] // W
+                out = torch.empty_like(full)
+                nbytes = rows * (full.numel() // full.shape[0]) * full.element_size()
+                comm.all_gather(full[r * rows:(r + 1) * rows].data_ptr(), out.data_ptr(), nbytes,
+                                stream=self._stream_ptr)
+                return out
+            np_dtype = _NP_OF_TORCH.get(full.dtype)
+            if np_dtype is not None:
+                comm.all_reduce_sum(full.data_ptr(), np_dtype, full.numel(), stream=self._stream_ptr)
+                return full
+            # (16-bit integers: RCCL has no sum for them) -> torch below
+        self.last_collective = 'torch.distributed'
         if full.dtype == torch.bool:
             t = full.to(torch.uint8)
             d.all_reduce(t, op=d.ReduceOp.MAX)

@@ -1608,6 +1608,42 @@ def test_two_ranks_share_results_through_host_segment(tmp_path, world):
     assert not [f for f in os.listdir('/dev/shm') if f.startswith(f'ltmi_{os.getuid()}_{port}')]
 
 
+def test_nccl_backend_collectives_through_ltmi_comm(tmp_path):
+    """The multi-GPU result path on the real backend: one "nccl" (RCCL) rank with
+    LTMI_FORCE_COLLECTIVES=1 -- RCCL initialises, the executor builds the library's own communicator
+    (ltmi_comm_unique_id / _create) and combines device buffers with ltmi_comm_all_gather /
+    _all_reduce_sum on its stream (torch.distributed only carries the 128-byte id and barriers).
+    With one rank the collectives are identities, so the results must equal the oracle's."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1',
+               LOCAL_RANK='0', LOCAL_WORLD_SIZE='1', LTMI_FORCE_COLLECTIVES='1',
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('LTMI_COMM', None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'tests', 'dist_worker_nccl1.py'),
+                        str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-4000:]
+    o = np.load(os.path.join(tmp_path, 'nccl1.npz'))
+    data, masks = o['data'], o['masks']
+    exp = opath.apply_masks(data, masks, num_partitions=3)
+    for via in ('rccl', 'auto'):
+        assert _close(o[f'{via}_masks'], exp, F32_TOL)
+        assert np.array_equal(o[f'{via}_sum'], data.astype(np.float32).sum(axis=(0, 1)))
+        assert np.array_equal(o[f'{via}_sumsig'], data.astype(np.float32).sum(axis=(2, 3)))
+    # the device collectives went through the library's communicator, not torch.distributed
+    assert str(o['rccl_via']) == 'collective' and str(o['rccl_collective']) == 'ltmi_comm'
+    assert int(o['iter_steps']) == 3 and _close(o['iter_last'], exp, F32_TOL)
+    assert str(o['c_collective']) == 'ltmi_comm'
+    assert np.allclose(o['c_sum'], o['c_data'].sum(axis=(0, 1)), rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize('launcher', ['torchrun', 'self'])
 def test_bench_contract_with_two_ranks_on_one_gpu(launcher):
     """bench.py end to end on the N>1 path (sharded dataset, shared-segment delivery, max-over-ranks
