@@ -16,7 +16,10 @@ Rank 0 prints ONE JSON line.  `value` / `roofline` / `cpu_baseline` are the C2 f
 asks for.  The same line carries, as extra keys (all configs, both timing modes):
 
   N = 1:  "configs": {"c3": ..., "c4": ..., "c5": ...}   whole job + dominant kernel + roofline each
-          "host_streamed": frames in host memory, double-buffered hipMemcpyAsync, vs measured H2D peak
+          "host_streamed": {"c2" .. "c5"}: frames in host memory, double-buffered hipMemcpyAsync, vs
+                           the H2D peak measured in the same run
+          "small_tiles": C2 launches of 1 024 / 4 096 / 8 192 frames; "live_feed": run_udf_iter on a
+                         StreamDataSet
   N > 1:  "result_via", "per_rank" (kernel / step time of every rank),
           "rccl_path": the same steps with the results gathered by RCCL (all_gather over xGMI)
                        instead of the node-shared host segment,
@@ -271,12 +274,12 @@ def load_traffic(name, kname, frames_per_launch):
         with open(path) as f:
             entries = json.load(f)['entries']
     except Exception:
-        return None, None
+        return None, None, None
     for e in entries:
         if e.get('config') == name and e.get('kernel') == kname and \
                 int(e.get('frames_per_launch', -1)) == int(frames_per_launch):
-            return float(e['hbm_bytes_per_launch']), e.get('source')
-    return None, None
+            return float(e['hbm_bytes_per_launch']), e.get('source'), e.get('rocprof_avg_us')
+    return None, None, None
 
 
 def measure(wl, steps, warmup, barrier, hip, n_check=32):
@@ -332,13 +335,21 @@ def measure(wl, steps, warmup, barrier, hip, n_check=32):
     alg_bytes = (wl.n_px * wl.itemsize + cfg['result_bytes']) * frames_per_launch
     gbs = alg_bytes / (avg_ms * 1e-3) / 1e9
     tfs = cfg['flops'] * frames_per_launch / (avg_ms * 1e-3) / 1e12
-    traffic, traffic_src = load_traffic(wl.name, kname, frames_per_launch)
+    traffic, traffic_src, prof_us = load_traffic(wl.name, kname, frames_per_launch)
     roof = {"bound": cfg['bound']}
     if cfg['bound'] == 'hbm':
         roof.update(achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS)
     else:
         roof.update(achieved=tfs, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
                     frac=tfs / MFMA_F32_PEAK_TF, hbm_GBps=gbs, hbm_frac=gbs / HBM_PEAK_GBS)
+    # the same fraction from the tracked rocprofv3 --kernel-trace average of this kernel (all launches
+    # of the profiled run, cold ones included), so that the two can be compared without arithmetic
+    if prof_us:
+        per_s = (alg_bytes / 1e9 / HBM_PEAK_GBS if cfg['bound'] == 'hbm'
+                 else cfg['flops'] * frames_per_launch / 1e12 / MFMA_F32_PEAK_TF)
+        roof.update(profile_avg_launch_ms=prof_us / 1e3, frac_from_profile=per_s / (prof_us * 1e-6))
+    else:
+        roof.update(profile_avg_launch_ms=None, frac_from_profile=None)
     roof.update(traffic=traffic, traffic_source=traffic_src, kernel=kname, avg_launch_ms=avg_ms,
                 launches_timed=len(kms), frames_per_launch=frames_per_launch,
                 algorithmic_bytes_per_launch=alg_bytes,
@@ -349,25 +360,15 @@ def measure(wl, steps, warmup, barrier, hip, n_check=32):
                 preheat_steps=preheat)
 
 
-def host_streamed(ctx, torch, hip, rows=64):
-    """Timing mode (ii) of SURVEY.md 8(d): C2 frames in HOST memory (page-locked in place),
-    double-buffered hipMemcpyAsync overlapping the kernels; against the measured H2D peak."""
+def host_streamed(ctx, torch, hip, gib=2):
+    """Timing mode (ii) of SURVEY.md 8(d) for every config: frames in HOST memory (page-locked in
+    place), double-buffered hipMemcpyAsync overlapping the kernels, `gib` GiB per config; against the
+    H2D peak measured in the same process (one pinned 1 GiB buffer, plain hipMemcpyAsync)."""
     from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd import masks as M
+    nbytes = gib << 30
     rng = np.random.default_rng(1)
-    data = rng.integers(0, 4096, (rows, 256, 256, 256), dtype=np.uint16)
-    masks = np.random.default_rng(2).random((16, 256, 256)).astype(np.float32)
-    ds = ctx.load('memory', data=data, sig_dims=2, num_partitions=1)
-    udf = ApplyMasksUDF(mask_factories=lambda: masks, use_sparse=False, mask_count=16,
-                        mask_dtype=np.float32)
-    for _ in range(2):
-        ctx.run_udf(dataset=ds, udf=udf)
-    ts = []
-    for _ in range(5):
-        t0 = time.perf_counter()
-        ctx.run_udf(dataset=ds, udf=udf)
-        ts.append(time.perf_counter() - t0)
-    t = float(np.median(ts))
-    # the link's own ceiling: one pinned 1 GiB buffer, plain hipMemcpyAsync
+    u16 = rng.integers(0, 4096, nbytes // 2, dtype=np.uint16)
     pinned = torch.empty((1 << 30,), dtype=torch.uint8, pin_memory=True)
     dev = torch.empty((1 << 30,), dtype=torch.uint8, device='cuda')
     dev.copy_(pinned, non_blocking=True)
@@ -377,11 +378,118 @@ def host_streamed(ctx, torch, hip, rows=64):
         dev.copy_(pinned, non_blocking=True)
     torch.cuda.synchronize()
     peak = 4 * (1 << 30) / (time.perf_counter() - t0) / 1e9
-    gbs = data.nbytes / t / 1e9
-    return {"workload": f"C2 masks, {rows * 256} frames ({data.nbytes / 2**30:.0f} GiB) in host "
-                        f"memory, hipHostRegister + double-buffered hipMemcpyAsync",
-            "frames_per_s": rows * 256 / t, "GBps": gbs, "h2d_peak_GBps": peak,
-            "frac_of_h2d_peak": gbs / peak, "ms_per_run": t * 1e3}
+    del pinned, dev
+
+    def timed(step, n_frames, data_bytes, what):
+        for _ in range(2):
+            step()
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            step()
+            ts.append(time.perf_counter() - t0)
+        t = float(np.median(ts))
+        gbs = data_bytes / t / 1e9
+        return {"workload": what, "frames_per_s": n_frames / t, "GBps": gbs,
+                "h2d_peak_GBps": peak, "frac_of_h2d_peak": gbs / peak, "ms_per_run": t * 1e3}
+
+    out = {}
+    masks = np.random.default_rng(2).random((16, 256, 256)).astype(np.float32)
+    n2 = nbytes // (256 * 256 * 2)
+    ds2 = ctx.load('memory', data=u16.reshape((n2 // 256, 256, 256, 256)), sig_dims=2, num_partitions=1)
+    udf2 = ApplyMasksUDF(mask_factories=lambda: masks, use_sparse=False, mask_count=16,
+                         mask_dtype=np.float32)
+    out['c2'] = timed(lambda: ctx.run_udf(dataset=ds2, udf=udf2), n2, nbytes,
+                      f"C2 masks, {n2} frames ({gib} GiB) in host memory, hipHostRegister + "
+                      f"double-buffered hipMemcpyAsync")
+    n3 = nbytes // (512 * 512 * 2)
+    ds3 = ctx.load('memory', data=u16.reshape((n3 // 512, 512, 512, 512)), sig_dims=2, num_partitions=1)
+    an3 = ctx.create_com_analysis(dataset=ds3, cx=256, cy=256)
+    out['c3'] = timed(lambda: ctx.run(an3), n3, nbytes,
+                      f"C3 CoM analysis, {n3} frames of 512x512 uint16 ({gib} GiB) in host memory")
+
+    def rings():
+        return M.radial_bins(centerX=128, centerY=128, imageSizeX=256, imageSizeY=256,
+                             n_bins=1024, use_sparse=True, dtype=np.float32)
+    udf4 = ApplyMasksUDF(mask_factories=rings, use_sparse='scipy.sparse', mask_count=1024,
+                         mask_dtype=np.float32)
+    out['c4'] = timed(lambda: ctx.run_udf(dataset=ds2, udf=udf4), n2, nbytes,
+                      f"C4 ring stack, {n2} frames of 256x256 uint16 ({gib} GiB) in host memory "
+                      f"(+ {n2 * 4096 / 2**20:.0f} MiB of results back)")
+    del ds2, ds3, u16
+    f32 = rng.random(nbytes // 4, dtype=np.float32)
+    n5 = nbytes // (1024 * 1024 * 4)
+    ds5 = ctx.load('memory', data=f32.reshape((n5 // 128, 128, 1024, 1024)) if n5 >= 128 else
+                   f32.reshape((1, n5, 1024, 1024)), sig_dims=2, num_partitions=1)
+    an5 = ctx.create_radial_fourier_analysis(dataset=ds5)
+    out['c5'] = timed(lambda: ctx.run(an5), n5, nbytes,
+                      f"C5 radial Fourier analysis, {n5} frames of 1024x1024 float32 ({gib} GiB) in "
+                      f"host memory")
+    return out
+
+
+def small_tiles(torch, hip, sizes=(1024, 4096, 8192)):
+    """What a live feed produces: C2 launches of a few thousand frames (ltmi_apply_masks on resident
+    tiles, HIP events on the launch stream around back-to-back launches)."""
+    masks = np.random.default_rng(2).random((16, 65536)).astype(np.float32)
+    h = hip.MaskHandle.dense(0, masks, np.float32)
+    g = torch.Generator(device='cuda').manual_seed(3)
+    tile = torch.randint(0, 4096, (max(sizes), 65536), generator=g, device='cuda', dtype=torch.int16)
+    out_t = torch.zeros((max(sizes), 16), device='cuda', dtype=torch.float32)
+    res = {}
+    for n in sizes:
+        for _ in range(3):
+            h.apply(tile.data_ptr(), np.uint16, n, 65536, out_t.data_ptr(), 16, False)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        e0.record()
+        for _ in range(reps):
+            h.apply(tile.data_ptr(), np.uint16, n, 65536, out_t.data_ptr(), 16, False)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        gbs = n * (131072 + 64) / ms / 1e6
+        res[str(n)] = {"kernel": h.last_kernel(), "avg_launch_ms": ms, "frames_per_s": n / ms * 1e3,
+                       "GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
+    ref = tile[:4].cpu().numpy().view(np.uint16).astype(np.float64) @ masks.T.astype(np.float64)
+    err = float(np.abs(out_t[:4].cpu().numpy() - ref).max() / np.abs(ref).max())
+    if not err < 1e-5:
+        raise SystemExit(f"bench.py: small-tile check failed: {err:.3e}")
+    res["check_rel_err_vs_float64"] = err
+    return res
+
+
+def live_feed(ctx, n_frames=16384, chunk=1024):
+    """Row f4: a running acquisition -- frames arrive in chunks of `chunk` from a feeder thread
+    (StreamDataSet), partial results after every partition (Context.run_udf_iter); rate over the whole
+    scan incl. the uploads."""
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    rng = np.random.default_rng(7)
+    frames = rng.integers(0, 4096, (n_frames, 256, 256), dtype=np.uint16)
+    masks = np.random.default_rng(2).random((16, 256, 256)).astype(np.float32)
+    udf = ApplyMasksUDF(mask_factories=lambda: masks, use_sparse=False, mask_count=16,
+                        mask_dtype=np.float32)
+    ts, n_parts = [], 0
+    for rep in range(3):
+        ds = ctx.load('stream', frames=(frames[i:i + chunk] for i in range(0, n_frames, chunk)),
+                      nav_shape=(n_frames // 256, 256), sig_shape=(256, 256), dtype=np.uint16,
+                      num_partitions=n_frames // chunk)
+        t0 = time.perf_counter()
+        n_parts = 0
+        for part in ctx.run_udf_iter(dataset=ds, udf=udf):
+            n_parts += 1
+        ts.append(time.perf_counter() - t0)
+        last = np.array(part.buffers[0]['intensity'].data)
+    t = float(np.median(ts[1:]))
+    ref = frames[-1].reshape(-1).astype(np.float64) @ masks.reshape((16, -1)).T.astype(np.float64)
+    err = float(np.abs(last.reshape((-1, 16))[-1] - ref).max() / np.abs(ref).max())
+    if not err < 1e-5:
+        raise SystemExit(f"bench.py: live-feed check failed: {err:.3e}")
+    return {"workload": f"C2 masks on {n_frames} frames arriving in chunks of {chunk} "
+                        f"(StreamDataSet + run_udf_iter, {n_parts} partial results)",
+            "frames_per_s": n_frames / t, "GBps": frames.nbytes / t / 1e9, "ms_per_scan": t * 1e3,
+            "check_rel_err_vs_float64": err}
 
 
 def mib_decode(torch, hip, n=16384, reps=10):
@@ -413,7 +521,7 @@ def mib_decode(torch, hip, n=16384, reps=10):
     expect = last.view('>u2').astype(np.uint16).reshape(-1, 4)[:, ::-1].reshape(h, w)
     ok = bool(np.array_equal(out.rows(n - 1, n).cpu().reshape(h, w), expect))
     nbytes = n * (payload + h * w * 2)
-    traffic, source = load_traffic('mib_decode', 'k_mib_decode16', n)
+    traffic, source, _ = load_traffic('mib_decode', 'k_mib_decode16', n)
     return {"workload": f"{n} raw 12-bit .mib frames of 256x256 -> uint16 (ltmi_mib_decode)",
             "kernel": "k_mib_decode16", "avg_launch_ms": ms, "frames_per_s": n / ms * 1e3,
             "check_last_frame": ok,
@@ -634,6 +742,8 @@ def main():
             torch.cuda.empty_cache()
         extra['configs'] = cfgs
         guarded('host_streamed', lambda: host_streamed(ctx, torch, hip))
+        guarded('small_tiles', lambda: small_tiles(torch, hip))
+        guarded('live_feed', lambda: live_feed(ctx))
         guarded('mib_decode', lambda: mib_decode(torch, hip))
 
     if rank == 0:

@@ -67,18 +67,22 @@ def _sparse_parts(obj):
     return parts
 
 
-def fingerprint(obj, _depth=0):
-    """hashable value that changes when `obj`, or an array `obj` can reach, changes"""
+def fingerprint(obj, _depth=0, _inside=False):
+    """hashable value that changes when `obj`, or an array `obj` can reach, changes.  Plain numbers
+    and strings count by value where a factory captures them directly (closure cell, default,
+    partial argument), not inside a captured list / dict -- those are followed for the arrays they
+    hold; a counter a factory keeps in a dict is not a mask parameter."""
     if isinstance(obj, np.ndarray):
         return ('nd', id(obj)) + array_fingerprint(obj)
     if obj is None or isinstance(obj, (bool, int, float, complex, str, bytes, np.generic)):
-        return ('v', obj)
+        return ('s',) if _inside else ('v', obj)
     if _depth > 3:
         return ('id', id(obj))
     if isinstance(obj, (list, tuple)):
-        return ('seq', id(obj), len(obj)) + tuple(fingerprint(x, _depth + 1) for x in obj)
+        return ('seq', id(obj), len(obj)) + tuple(fingerprint(x, _depth + 1, True) for x in obj)
     if isinstance(obj, dict):
-        return ('map', id(obj)) + tuple((k, fingerprint(v, _depth + 1)) for k, v in obj.items())
+        return ('map', id(obj), len(obj)) + tuple(fingerprint(v, _depth + 1, True)
+                                                  for v in obj.values())
     if isinstance(obj, functools.partial):
         return ('partial', id(obj), fingerprint(obj.func, _depth + 1),
                 fingerprint(obj.args, _depth + 1), fingerprint(obj.keywords, _depth + 1))

@@ -460,7 +460,7 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             const float *__restrict__ img, int n_slots, float *__restrict__ out, int64_t ld_out,
             int n_cols, int accumulate, float *__restrict__ partials, int ksplit,
             const int32_t *__restrict__ rows = nullptr,
-            const float *const *__restrict__ wg_img = nullptr) {
+            const float *const *__restrict__ wg_img = nullptr, int *__restrict__ kcount = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     using TR = InTraits<T>;
     using CFG = LdsCfg<NG, NE, TILES>;
@@ -860,6 +860,49 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                     }
                 }
             }
+        }
+    }
+    // ---- pixel axis split over `ksplit` workgroups, optional (kcount != nullptr): the LAST of them to
+    // finish a block of frames adds the partial sums up -- in the fixed order k = 0 .. ksplit - 1,
+    // whoever is last, so the result does not depend on the arrival order -- instead of a second
+    // launch.  Measured slower than the second launch (see partial_counters) and off by default.
+    if (IND != 1 && kcount != nullptr && ksplit > 1) {
+        volatile int *last_flag = (volatile int *)lds_raw;  // (the LDS is full; its buffers are dead now)
+        __threadfence();                                    // this workgroup's partials are visible
+        __syncthreads();
+        int *cnt = kcount + (int64_t)blockIdx.z * gridDim.x + blockIdx.x;
+        if (tid == 0) *last_flag = atomicAdd(cnt, 1) == ksplit - 1;
+        __syncthreads();
+        if (*last_flag) {
+            __threadfence();
+            const int64_t fb0 = (int64_t)blockIdx.x * (WAVES * ROWS);
+            const int nf = (int)min<int64_t>(WAVES * ROWS, n_frames - fb0);
+            const int c0 = gt * NG * GROUP;
+            const int nc = min(n_cols - c0, NG * GROUP + NE);
+            // (device-scope loads: the other workgroups' partials come from the L2, never from a line
+            // this CU's L1 kept from an earlier launch; 8 independent loads in flight per thread)
+            const int64_t kstride = n_frames * n_cols;
+            for (int idx = tid; idx < nf * nc; idx += NT) {
+                const int64_t f = fb0 + idx / nc;
+                const int col = c0 + idx % nc;
+                float *p = out + f * ld_out + col;
+                const float *src = partials + f * n_cols + col;
+                float acc_s = accumulate ? *p : 0.f;
+                for (int k0 = 0; k0 < ksplit; k0 += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        v[u] = k0 + u < ksplit
+                                   ? __hip_atomic_load(src + (k0 + u) * kstride, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT)
+                                   : 0.f;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (k0 + u < ksplit) acc_s += v[u];
+                }
+                *p = acc_s;
+            }
+            if (tid == 0) *cnt = 0;                         // ready for the next launch
         }
     }
 }
@@ -1293,6 +1336,37 @@ extern "C" const char *ltmi_masks_last_kernel(const ltmi_masks *m) {
 }
 
 // ---- MFMA launch ---------------------------------------------------------------------------------
+// the workspace of a handle: KCOUNT_BYTES of arrival counters (zero between launches: the last workgroup
+// of a frame block resets its counter) followed by the partial sums
+constexpr size_t KCOUNT_BYTES = 64 * 1024;
+static int ensure_partials(ltmi_masks *m, size_t need, hipStream_t stream) {
+    need += KCOUNT_BYTES;
+    if (need > m->partials_bytes) {
+        if (m->partials) {
+            LTMI_HIP(hipStreamSynchronize(stream));
+            LTMI_HIP(hipFree(m->partials));
+            m->partials = nullptr;
+            m->partials_bytes = 0;
+        }
+        LTMI_HIP(hipMalloc((void **)&m->partials, need));
+        LTMI_HIP(hipMemsetAsync(m->partials, 0, KCOUNT_BYTES, stream));
+        m->partials_bytes = need;
+    }
+    return LTMI_OK;
+}
+static inline float *partial_sums(const ltmi_masks *m) {
+    return m->partials ? (float *)((char *)m->partials + KCOUNT_BYTES) : nullptr;
+}
+static inline int *partial_counters(const ltmi_masks *m, int64_t n_blocks) {
+    // Off unless LTMI_KSPLIT_FUSED is set: measured on MI355X (profiles/r03_small_tiles.txt) the last
+    // workgroup's reduction is a serial tail on ONE CU and loses to the second launch, which spreads the
+    // same additions over the chip: 1 024 frames 78 vs 48 us, 4 096 frames 151 vs 121 us, 16 384 frames
+    // 477 vs 440 us.
+    static const bool off = getenv("LTMI_KSPLIT_FUSED") == nullptr;
+    return (m->partials && !off && n_blocks * (int64_t)sizeof(int) <= (int64_t)KCOUNT_BYTES)
+               ? (int *)m->partials : nullptr;
+}
+
 template <typename T, int MT, int NG, int WAVES, bool ALIGNED>
 static int launch_mfma_variant(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld,
                                float *out, int64_t ld_out, int accumulate, int ksplit,
@@ -1309,25 +1383,11 @@ static int launch_mfma_variant(ltmi_masks *m, const T *tile, int64_t n_frames, i
               (unsigned)(m->n_groups / NG));
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds_bytes, stream, tile, ld, n_frames, m->n_px,
                        (const float *)m->img, m->n_chunks, out, ld_out, m->n_cols, accumulate,
-                       m->partials, ksplit);
+                       partial_sums(m), ksplit);
     LTMI_HIP(hipGetLastError());
     snprintf(m->last_kernel, sizeof(m->last_kernel),
              "k_dense_mfma<%s,MT=%d,NG=%d,WAVES=%d,%s> grid=(%u,%u,%u)", typeid(T).name(), MT, NG,
              WAVES, ALIGNED ? "aligned" : "unaligned", grid.x, grid.y, grid.z);
-    return LTMI_OK;
-}
-
-static int ensure_partials(ltmi_masks *m, size_t need, hipStream_t stream) {
-    if (need > m->partials_bytes) {
-        if (m->partials) {
-            LTMI_HIP(hipStreamSynchronize(stream));
-            LTMI_HIP(hipFree(m->partials));
-            m->partials = nullptr;
-            m->partials_bytes = 0;
-        }
-        LTMI_HIP(hipMalloc((void **)&m->partials, need));
-        m->partials_bytes = need;
-    }
     return LTMI_OK;
 }
 
@@ -1344,7 +1404,7 @@ static int launch_lds_ng_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64
     using CFG = LdsCfg<NG, 0, TILES>;
     const int abl = m->tune_ksplit_ring == 31 ? 2 : (m->tune_ksplit_ring == 32 ? 1 : 0);
     void (*kern)(const T *, int64_t, int64_t, int64_t, const float *, int, float *, int64_t, int,
-                 int, float *, int, const int32_t *, const float *const *) =
+                 int, float *, int, const int32_t *, const float *const *, int *) =
         abl == 2 ? k_dense_lds<T, NG, 2, 0, 0, TILES>
                  : (abl == 1 ? k_dense_lds<T, NG, 1, 0, 0, TILES>
                              : k_dense_lds<T, NG, 0, 0, 0, TILES>);
@@ -1373,18 +1433,19 @@ static int launch_lds_ng_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64
         if (rc != LTMI_OK) return rc;
     }
     dim3 grid((unsigned)gx, (unsigned)ksplit, (unsigned)gz);
+    int *kcount = ksplit > 1 ? partial_counters(m, gx * gz) : nullptr;
     hipLaunchKernelGGL(kern, grid, dim3(CFG::WAVES * 64), CFG::LDS_BYTES, stream, tile, ld, n_frames,
-                       m->n_px, img, n_slots, out, ld_out, m->n_cols, accumulate, m->partials,
-                       ksplit, rows, (const float *const *)nullptr);
+                       m->n_px, img, n_slots, out, ld_out, m->n_cols, accumulate, partial_sums(m),
+                       ksplit, rows, (const float *const *)nullptr, kcount);
     LTMI_HIP(hipGetLastError());
     snprintf(m->last_kernel, sizeof(m->last_kernel),
              "k_dense_lds<%s,NG=%d,ring=%d,tiles=%d%s> grid=(%u,%u,%u)", typeid(T).name(), NG,
              CFG::RING, TILES, rows ? ",rows" : (abl ? (abl == 2 ? ",noDMA" : ",noMFMA") : ""),
              grid.x, grid.y, grid.z);
-    if (ksplit > 1) {
+    if (ksplit > 1 && !kcount) {
         const int64_t n = n_frames * m->n_cols;
         hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                           stream, (const float *)m->partials, ksplit, n_frames, m->n_cols, out,
+                           stream, (const float *)partial_sums(m), ksplit, n_frames, m->n_cols, out,
                            ld_out, accumulate);
         LTMI_HIP(hipGetLastError());
     }
@@ -1427,9 +1488,10 @@ static int launch_lds_extras_t(ltmi_masks *m, const T *tile, int64_t n_frames, i
         if (rc != LTMI_OK) return rc;
     }
     dim3 grid((unsigned)gx, (unsigned)ksplit, 1);
+    int *kcount = ksplit > 1 ? partial_counters(m, gx) : nullptr;
     hipLaunchKernelGGL(kern, grid, dim3(CFG::WAVES * 64), CFG::LDS_BYTES, stream, tile, ld, n_frames,
                        m->n_px, (const float *)m->img3, n_slots, out, ld_out, m->n_cols, accumulate,
-                       m->partials, ksplit, rows, (const float *const *)nullptr);
+                       partial_sums(m), ksplit, rows, (const float *const *)nullptr, kcount);
     LTMI_HIP(hipGetLastError());
     if (NE > 0)
         snprintf(m->last_kernel, sizeof(m->last_kernel),
@@ -1439,10 +1501,10 @@ static int launch_lds_extras_t(ltmi_masks *m, const T *tile, int64_t n_frames, i
         snprintf(m->last_kernel, sizeof(m->last_kernel),
                  "k_dense_lds<%s,NG=%d,ring=%d,tiles=%d%s> grid=(%u,%u,1)", typeid(T).name(), NG,
                  CFG::RING, TILES, rows ? ",rows" : "", grid.x, grid.y);
-    if (ksplit > 1) {
+    if (ksplit > 1 && !kcount) {
         const int64_t n = n_frames * m->n_cols;
         hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                           stream, (const float *)m->partials, ksplit, n_frames, m->n_cols, out,
+                           stream, (const float *)partial_sums(m), ksplit, n_frames, m->n_cols, out,
                            ld_out, accumulate);
         LTMI_HIP(hipGetLastError());
     }
@@ -1656,7 +1718,7 @@ static int launch_lds_shifted(ltmi_masks *m, const T *tile, int64_t n_frames, in
                            tile, ld, n_frames, m->n_px, (const float *)nullptr, m->n_chunks,
                            out + gi * GROUP, ld_out, std::min(GROUP, m->n_cols - gi * GROUP),
                            accumulate, (float *)nullptr, 1, (const int32_t *)c->rows_dev,
-                           (const float *const *)c->wg_img_dev + (size_t)gi * n_wg);
+                           (const float *const *)c->wg_img_dev + (size_t)gi * n_wg, (int *)nullptr);
     LTMI_HIP(hipGetLastError());
     snprintf(m->last_kernel, sizeof(m->last_kernel),
              "k_dense_lds<%s,NG=1,shifted> grid=(%zu,1,1) x %d column group(s), shift groups=%zu",
@@ -1721,7 +1783,7 @@ static int launch_mfma(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t l
     if (ksplit > 1) {
         const int64_t n = n_frames * m->n_cols;
         hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                           stream, (const float *)m->partials, ksplit, n_frames, m->n_cols, out,
+                           stream, (const float *)partial_sums(m), ksplit, n_frames, m->n_cols, out,
                            ld_out, accumulate);
         LTMI_HIP(hipGetLastError());
     }
