@@ -198,15 +198,27 @@ class MaskContainer:
         return mat
 
     # --- device handles --------------------------------------------------------------------------
-    def get_handle_for_sig_slice(self, sig_slice, result_dtype, device):
-        """libltmi handle of the slice's stack, cast to `result_dtype`, on GPU `device`."""
+    def get_handle_for_sig_slice(self, sig_slice, result_dtype, device, real_frames=True):
+        """libltmi handle of the slice's stack, cast to `result_dtype`, on GPU `device`.
+        real_frames: the tiles are real numbers (a complex128 sparse stack may then stay sparse)."""
         from libertem_amd import hip
-        key = (sig_slice, np.dtype(result_dtype).str, int(device))
+        key = (sig_slice, np.dtype(result_dtype).str, int(device), bool(real_frames))
         h = self._handle_cache.get(key)
         if h is None:
             sparse_ok = np.dtype(result_dtype) in (np.dtype(np.float32), np.dtype(np.complex64),
                                                    np.dtype(np.float64))
-            if self.use_sparse is False or not sparse_ok:
+            if self.use_sparse is not False and np.dtype(result_dtype) == np.complex128 \
+                    and real_frames:
+                # complex128 stack on real frames: the float64 gather kernel on (re, im) column pairs
+                m = sp.csr_matrix(self.get_for_sig_slice(
+                    sig_slice, dtype=result_dtype, sparse_backend='scipy.sparse.csr',
+                    transpose=True))
+                if _worth_densifying(m, result_dtype):
+                    dense = np.ascontiguousarray(m.T.toarray().astype(result_dtype, copy=False))
+                    h = hip.MaskHandle.dense(device, dense, result_dtype)
+                else:
+                    h = hip.MaskHandle.csr_complex128(device, m)
+            elif self.use_sparse is False or not sparse_ok:
                 # dense stack; also the route for sparse stacks whose result dtype (complex128,
                 # integers) the sparse kernels do not cover: densified
                 m = self.get_for_sig_slice(sig_slice, dtype=result_dtype, sparse_backend=False,

@@ -189,6 +189,8 @@ class MaskHandle:
         self.n_px = n_px
         self.result_dtype = np.dtype(result_dtype)
         self.sparse = sparse
+        #: result words per mask the library writes (2: a complex stack held as real column pairs)
+        self._out_words = 1
 
     @classmethod
     def dense(cls, device, masks, result_dtype):
@@ -222,6 +224,31 @@ class MaskHandle:
             dtype_code(result_dtype), n_px, n_masks, ctypes.byref(out)), 'ltmi_masks_create_csr')
         return cls(out, device, n_masks, n_px, result_dtype, True)
 
+    @classmethod
+    def csr_complex128(cls, device, csr_px_by_masks):
+        """A complex128 sparse stack for REAL frames, without densifying it: (re, im) of mask k are the
+        float64 columns 2k, 2k + 1 of the image (the float64 gather kernel), and the result row of a
+        frame -- 2 n_masks doubles -- is its complex128 row.  (complex64 stacks do the same inside the
+        library.)"""
+        import scipy.sparse as sp
+        m = sp.csr_matrix(csr_px_by_masks)
+        m.sum_duplicates()
+        m.sort_indices()
+        n_px, n_masks = m.shape
+        vals = np.ascontiguousarray(m.data.astype(np.complex128, copy=False))
+        counts = np.diff(m.indptr)
+        data = np.empty(2 * vals.size, dtype=np.float64)
+        indices = np.empty(2 * vals.size, dtype=np.int64)
+        data[0::2], data[1::2] = vals.real, vals.imag
+        indices[0::2], indices[1::2] = 2 * m.indices.astype(np.int64), 2 * m.indices.astype(np.int64) + 1
+        indptr = np.concatenate([[0], np.cumsum(2 * counts)]).astype(np.int64)
+        real = sp.csr_matrix((data, indices, indptr), shape=(n_px, 2 * n_masks))
+        h = cls.csr(device, real, np.float64)
+        h.n_masks = n_masks
+        h.result_dtype = np.dtype(np.complex128)
+        h._out_words = 2
+        return h
+
     def kind(self):
         k = ctypes.c_int(-1)
         check(lib().ltmi_masks_kind(self._ptr, ctypes.byref(k)), 'ltmi_masks_kind')
@@ -246,7 +273,8 @@ class MaskHandle:
             a.record(st)
         # argtypes are declared: plain ints marshal as pointers
         rc = _lib.ltmi_apply_masks(
-            self._ptr, tile_ptr, _DTYPES.get(tile_dtype) or dtype_code(tile_dtype), n_frames, ld_tile, out_ptr, ld_out,
+            self._ptr, tile_ptr, _DTYPES.get(tile_dtype) or dtype_code(tile_dtype), n_frames, ld_tile, out_ptr,
+            ld_out * self._out_words,
             1 if accumulate else 0, stream if isinstance(stream, int) else _stream_ptr(stream))
         if rc:
             check(rc, 'ltmi_apply_masks')
@@ -270,7 +298,8 @@ class MaskHandle:
             a.record(st)
         check(lib().ltmi_apply_masks_rows(
             self._ptr, ctypes.c_void_p(tile_ptr), dtype_code(tile_dtype), ctypes.c_void_p(rows_ptr),
-            int(n_rows), int(ld_tile), ctypes.c_void_p(out_ptr), int(ld_out), 1 if accumulate else 0,
+            int(n_rows), int(ld_tile), ctypes.c_void_p(out_ptr), int(ld_out) * self._out_words,
+            1 if accumulate else 0,
             stream if isinstance(stream, int) else _stream_ptr(stream), ctypes.byref(handled)),
             'ltmi_apply_masks_rows')
         if KernelTimer.enabled and handled.value:

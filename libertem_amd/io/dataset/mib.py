@@ -243,9 +243,11 @@ class MIBDataSet(MemoryDataSet):
         n_nav = int(prod(nav_shape))
         self._image_count = sum(f['num_images'] for _, f in files)
         so = self._sync_offset_arg
-        if not (-n_nav < so < max(self._image_count, 1)):
+        # (reference io/dataset/base/dataset.py:74: the offset lies in (-image_count, image_count); a
+        # negative one of n_nav or more frames simply leaves every scan position blank)
+        if not (-max(self._image_count, 1) < so < max(self._image_count, 1)):
             raise DataSetException(
-                f"offset should be in ({-n_nav}, {self._image_count}), which is "
+                f"offset should be in ({-self._image_count}, {self._image_count}), which is "
                 "(-image_count, image_count)")
         # this process's block of scan positions [p0, p1)
         local_nav = tuple(nav_shape)

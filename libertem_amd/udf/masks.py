@@ -222,8 +222,9 @@ class ApplyMasksEngine:
             self._const = dev
 
     def _get_handle(self):
-        return self.masks.get_handle_for_sig_slice(self.meta.sig_slice, self.result_dtype,
-                                                   self.device)
+        return self.masks.get_handle_for_sig_slice(
+            self.meta.sig_slice, self.result_dtype, self.device,
+            real_frames=np.dtype(self.meta.input_dtype).kind != 'c')
 
     def process_tile(self, tile, out=None, accumulate=False):
         """

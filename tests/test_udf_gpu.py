@@ -491,6 +491,40 @@ def test_write_once_rows_not_with_frame_cutting_tileshape(ctx):
         assert _close(alone['intensity'].data, ref, F32_TOL), tileshape
 
 
+def test_sparse_complex128_stack_stays_sparse(ctx):
+    """A sparse complex128 stack on real frames (float64 / uint32 data, or complex128 mask values):
+    the float64 gather kernel on (re, im) column pairs instead of a densified stack -- result dtype
+    complex128 like the reference's rmatmul (common/numba/__init__.py:126: result_type of both)."""
+    import scipy.sparse as sp
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd import hip
+    rng = np.random.default_rng(53)
+    data = rng.integers(0, 5000, (3, 5, 64, 64)).astype(np.uint32)
+    dense = []
+    for _ in range(6):
+        keep = rng.random((64, 64)) < 0.02
+        dense.append(np.where(keep, rng.random((64, 64)) - 0.5 + 1j * (rng.random((64, 64)) - 0.5), 0))
+    facs = [(lambda d=d: sp.csr_matrix(d.astype(np.complex128))) for d in dense]
+    ref = np.tensordot(data.astype(np.complex128), np.stack(dense), axes=([2, 3], [1, 2]))
+    for ds in (_device_ds(ctx, data, 2), ctx.load('memory', data=data, num_partitions=2, sig_dims=2)):
+        hip.KernelTimer.start()
+        got = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=facs,
+                                                        use_sparse='scipy.sparse'))
+        kernels = {k.split(' ')[0] for _, _, k in hip.KernelTimer.stop()}
+        assert kernels and all('k_sell_apply' in k and 'f64' in k for k in kernels), kernels
+        r = got['intensity'].data
+        assert r.dtype == np.complex128 and r.shape == (3, 5, 6)
+        assert np.allclose(r, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+    # float32 frames with a complex128 mask dtype: same route
+    dataf = rng.random((2, 4, 64, 64)).astype(np.float32)
+    got = ctx.run_udf(dataset=ctx.load('memory', data=dataf, num_partitions=2, sig_dims=2),
+                      udf=ApplyMasksUDF(mask_factories=facs, use_sparse='scipy.sparse',
+                                        mask_dtype=np.complex128))['intensity'].data
+    reff = np.tensordot(dataf.astype(np.complex128), np.stack(dense), axes=([2, 3], [1, 2]))
+    assert got.dtype == np.complex128
+    assert np.allclose(got, reff, rtol=1e-12, atol=1e-12 * np.abs(reff).max())
+
+
 def test_masks_modified_in_place_between_runs(ctx):
     """The reference evaluates the mask factories on every run (udf/masks.py:331-351): an array the
     factory closes over may change between two run_udf calls.  The cached device image / the cached
