@@ -51,6 +51,7 @@ typedef float bf32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 bh16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 bh16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int bu32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned int bu32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void *b_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *b_glb_ptr_t;
 
@@ -646,9 +647,6 @@ k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
     const int lane_base = C::frame_base(m16);
     const unsigned swz = (unsigned)((m16 & 7) << 4);
     int ai = a0, buf = 0, since = 63;
-#ifdef BE_STAGGER
-    int pend = 0;
-#endif
     // vector-memory operations retire in order: `win` remembers which of the last records' turns ended
     // with the issue of a chunk's frame copy (bit k: k + 1 records ago) -- those NDMA operations are
     // YOUNGER than the load of the record a turn is about to use and may stay in flight with the
@@ -703,18 +701,10 @@ k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             const unsigned c = cw[u];
             {
                 const int nb = __builtin_popcount(win & ((1u << BE_FD) - 1u));
-#ifdef BE_STAGGER
-                if (nb == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD - 1) : "memory");
-                else if (nb == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD) : "memory");
-                else if (nb == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD + 1) : "memory");
-                else if (nb == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD + 2) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD + 3) : "memory");
-#else
                 if (nb == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD - 1) : "memory");
                 else if (nb == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD - 1 + NDMA) : "memory");
                 else if (nb == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD - 1 + 2 * NDMA) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD - 1 + 3 * NDMA) : "memory");
-#endif
             }
             if (!(c & BE_C_SKIP)) {
                 unsigned rw1, rw2;
@@ -752,19 +742,6 @@ k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             ring_load(U, (int64_t)(i + u + BE_FD));
             since = since < 63 ? since + 1 : since;
             win <<= 1;
-#ifdef BE_STAGGER
-            // (experiment) the copy of the next chunk one instruction per record instead of a burst
-            if (pend > 0) {
-                issue_dma(ai + 1, buf ^ 1, NDMA - pend, NDMA - pend + 1);
-                --pend;
-                if (ablate != 1 && ablate != 3) { since = 0; win |= 1u; }
-            }
-            if ((c & BE_C_END) && pend > 0) {
-                issue_dma(ai + 1, buf ^ 1, NDMA - pend, NDMA);
-                pend = 0;
-                if (ablate != 1 && ablate != 3) { since = 0; win |= 1u; }
-            }
-#endif
             ++r_cur;
             if ((c & BE_C_END) && NBUF >= 3) {
                 // this wave is through with chunk ai: start its part of the copy of chunk ai + DIST, make
@@ -803,14 +780,10 @@ k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                 asm volatile("" ::: "memory");
                 ++ai;
                 buf ^= 1;
-#ifdef BE_STAGGER
-                if (ai + 1 < a1) pend = NDMA;
-#else
                 if (ai + 1 < a1) {
                     issue_dma(ai + 1, buf ^ 1);
                     if (ablate != 1 && ablate != 3) { since = 0; win |= 1u; }
                 }
-#endif
             }
         });
     }
