@@ -50,6 +50,7 @@ namespace ltmi {
 typedef float bf32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 bh16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 bh16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 bh16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int bu32x3 __attribute__((ext_vector_type(3)));
 typedef unsigned int bu32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void *b_lds_ptr_t;
@@ -96,7 +97,8 @@ constexpr int BE_PASS = BE_SETS * BE_SLOTS * 16;     // real masks per pass (102
 #endif
 constexpr int BE_D_MAX = BE_D_;      // block records in flight per wave, at most (LDS permitting)
 constexpr int BE_REC = 192;          // dwords per block record (64 lanes x 3)
-constexpr int BE_REC16 = 128;        // ... of a float16 record (64 lanes x 2; pixel numbers in the control words)
+constexpr int BE_REC16 = 256;        // ... of a float16 record (64 lanes x 4; pixel numbers in the control words)
+constexpr int BE_CTL = 4;            // control words per float16 record: flags, pairs a, pairs b, -
 
 struct BellImage {
     uint32_t *stream = nullptr;      // [blocks][64 lanes][A step 0, A step 1, pixels]
@@ -460,27 +462,30 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
 #ifndef BE_PHASE_SLEEP
 #define BE_PHASE_SLEEP 8            // s_sleep units (64 cycles) per phase step, 16 steps
 #endif
-constexpr int BE_FD = 8;
+#ifndef BE_FD_
+#define BE_FD_ 6
+#endif
+constexpr int BE_FD = BE_FD_;
 constexpr unsigned BE_C_SKIP = 4u, BE_C_END = 8u;
 
 #define BE_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63"
 #define BE_ACC_ZERO() asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tv_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0\n\tv_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\tv_accvgpr_write_b32 a10, 0\n\tv_accvgpr_write_b32 a11, 0\n\tv_accvgpr_write_b32 a12, 0\n\tv_accvgpr_write_b32 a13, 0\n\tv_accvgpr_write_b32 a14, 0\n\tv_accvgpr_write_b32 a15, 0\n\tv_accvgpr_write_b32 a16, 0\n\tv_accvgpr_write_b32 a17, 0\n\tv_accvgpr_write_b32 a18, 0\n\tv_accvgpr_write_b32 a19, 0\n\tv_accvgpr_write_b32 a20, 0\n\tv_accvgpr_write_b32 a21, 0\n\tv_accvgpr_write_b32 a22, 0\n\tv_accvgpr_write_b32 a23, 0\n\tv_accvgpr_write_b32 a24, 0\n\tv_accvgpr_write_b32 a25, 0\n\tv_accvgpr_write_b32 a26, 0\n\tv_accvgpr_write_b32 a27, 0\n\tv_accvgpr_write_b32 a28, 0\n\tv_accvgpr_write_b32 a29, 0\n\tv_accvgpr_write_b32 a30, 0\n\tv_accvgpr_write_b32 a31, 0\n\tv_accvgpr_write_b32 a32, 0\n\tv_accvgpr_write_b32 a33, 0\n\tv_accvgpr_write_b32 a34, 0\n\tv_accvgpr_write_b32 a35, 0\n\tv_accvgpr_write_b32 a36, 0\n\tv_accvgpr_write_b32 a37, 0\n\tv_accvgpr_write_b32 a38, 0\n\tv_accvgpr_write_b32 a39, 0\n\tv_accvgpr_write_b32 a40, 0\n\tv_accvgpr_write_b32 a41, 0\n\tv_accvgpr_write_b32 a42, 0\n\tv_accvgpr_write_b32 a43, 0\n\tv_accvgpr_write_b32 a44, 0\n\tv_accvgpr_write_b32 a45, 0\n\tv_accvgpr_write_b32 a46, 0\n\tv_accvgpr_write_b32 a47, 0\n\tv_accvgpr_write_b32 a48, 0\n\tv_accvgpr_write_b32 a49, 0\n\tv_accvgpr_write_b32 a50, 0\n\tv_accvgpr_write_b32 a51, 0\n\tv_accvgpr_write_b32 a52, 0\n\tv_accvgpr_write_b32 a53, 0\n\tv_accvgpr_write_b32 a54, 0\n\tv_accvgpr_write_b32 a55, 0\n\tv_accvgpr_write_b32 a56, 0\n\tv_accvgpr_write_b32 a57, 0\n\tv_accvgpr_write_b32 a58, 0\n\tv_accvgpr_write_b32 a59, 0\n\tv_accvgpr_write_b32 a60, 0\n\tv_accvgpr_write_b32 a61, 0\n\tv_accvgpr_write_b32 a62, 0\n\tv_accvgpr_write_b32 a63, 0" ::: BE_AGPRS)
-#define BE_MFMA_0_0(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[0:3], %0, %1, a[0:3]" ::"v"(A_), "v"(B_) : BE_AGPRS)
-#define BE_MFMA_0_1(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[4:7], %0, %1, a[4:7]" ::"v"(A_), "v"(B_) : BE_AGPRS)
-#define BE_MFMA_0_2(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[8:11], %0, %1, a[8:11]" ::"v"(A_), "v"(B_) : BE_AGPRS)
-#define BE_MFMA_0_3(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[12:15], %0, %1, a[12:15]" ::"v"(A_), "v"(B_) : BE_AGPRS)
-#define BE_MFMA_1_0(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[16:19], %0, %1, a[16:19]" ::"v"(A_), "v"(B_) : BE_AGPRS)
-#define BE_MFMA_1_1(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[20:23], %0, %1, a[20:23]" ::"v"(A_), "v"(B_) : BE_AGPRS)
-#define BE_MFMA_1_2(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[24:27], %0, %1, a[24:27]" ::"v"(A_), "v"(B_) : BE_AGPRS)
-#define BE_MFMA_1_3(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[28:31], %0, %1, a[28:31]" ::"v"(A_), "v"(B_) : BE_AGPRS)
-#define BE_MFMA_2_0(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[32:35], %0, %1, a[32:35]" ::"v"(A_), "v"(B_) : BE_AGPRS)
-#define BE_MFMA_2_1(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[36:39], %0, %1, a[36:39]" ::"v"(A_), "v"(B_) : BE_AGPRS)
-#define BE_MFMA_2_2(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[40:43], %0, %1, a[40:43]" ::"v"(A_), "v"(B_) : BE_AGPRS)
-#define BE_MFMA_2_3(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[44:47], %0, %1, a[44:47]" ::"v"(A_), "v"(B_) : BE_AGPRS)
-#define BE_MFMA_3_0(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[48:51], %0, %1, a[48:51]" ::"v"(A_), "v"(B_) : BE_AGPRS)
-#define BE_MFMA_3_1(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[52:55], %0, %1, a[52:55]" ::"v"(A_), "v"(B_) : BE_AGPRS)
-#define BE_MFMA_3_2(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[56:59], %0, %1, a[56:59]" ::"v"(A_), "v"(B_) : BE_AGPRS)
-#define BE_MFMA_3_3(A_, B_) asm volatile("v_mfma_f32_16x16x16_f16 a[60:63], %0, %1, a[60:63]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_0_0(A_, B_) asm volatile("v_mfma_f32_16x16x32_f16 a[0:3], %0, %1, a[0:3]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_0_1(A_, B_) asm volatile("v_mfma_f32_16x16x32_f16 a[4:7], %0, %1, a[4:7]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_0_2(A_, B_) asm volatile("v_mfma_f32_16x16x32_f16 a[8:11], %0, %1, a[8:11]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_0_3(A_, B_) asm volatile("v_mfma_f32_16x16x32_f16 a[12:15], %0, %1, a[12:15]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_1_0(A_, B_) asm volatile("v_mfma_f32_16x16x32_f16 a[16:19], %0, %1, a[16:19]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_1_1(A_, B_) asm volatile("v_mfma_f32_16x16x32_f16 a[20:23], %0, %1, a[20:23]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_1_2(A_, B_) asm volatile("v_mfma_f32_16x16x32_f16 a[24:27], %0, %1, a[24:27]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_1_3(A_, B_) asm volatile("v_mfma_f32_16x16x32_f16 a[28:31], %0, %1, a[28:31]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_2_0(A_, B_) asm volatile("v_mfma_f32_16x16x32_f16 a[32:35], %0, %1, a[32:35]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_2_1(A_, B_) asm volatile("v_mfma_f32_16x16x32_f16 a[36:39], %0, %1, a[36:39]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_2_2(A_, B_) asm volatile("v_mfma_f32_16x16x32_f16 a[40:43], %0, %1, a[40:43]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_2_3(A_, B_) asm volatile("v_mfma_f32_16x16x32_f16 a[44:47], %0, %1, a[44:47]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_3_0(A_, B_) asm volatile("v_mfma_f32_16x16x32_f16 a[48:51], %0, %1, a[48:51]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_3_1(A_, B_) asm volatile("v_mfma_f32_16x16x32_f16 a[52:55], %0, %1, a[52:55]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_3_2(A_, B_) asm volatile("v_mfma_f32_16x16x32_f16 a[56:59], %0, %1, a[56:59]" ::"v"(A_), "v"(B_) : BE_AGPRS)
+#define BE_MFMA_3_3(A_, B_) asm volatile("v_mfma_f32_16x16x32_f16 a[60:63], %0, %1, a[60:63]" ::"v"(A_), "v"(B_) : BE_AGPRS)
 #define BE_ARM(S_)                                                         \
     asm volatile("s_nop 1");                                               \
     BE_MFMA_##S_##_0(a1v, bv[0]); BE_MFMA_##S_##_1(a1v, bv[1]);              \
@@ -527,30 +532,35 @@ constexpr unsigned BE_C_SKIP = 4u, BE_C_END = 8u;
     }
 
 
-// the record ring of k_bell_flat: ring position u = a[64 + 2 u], a[65 + 2 u], loaded by asm (the compiler neither
+// the record ring of k_bell_flat: ring position u = a[64 + 4 u .. + 3], loaded by asm (the compiler neither
 // sees the loads nor the registers, so it cannot move a register whose load is still in flight) and
 // waited for with hand-counted vmcnt
-#define BE_RING_LOAD_0(VOFF, SBASE) asm volatile("global_load_dwordx2 a[64:65], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
-#define BE_RING_READ_0(W1, W2) asm volatile("v_accvgpr_read_b32 %0, a64\n\tv_accvgpr_read_b32 %1, a65" : "=v"(W1), "=v"(W2) :: BE_RING_AGPRS)
-#define BE_RING_LOAD_1(VOFF, SBASE) asm volatile("global_load_dwordx2 a[66:67], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
-#define BE_RING_READ_1(W1, W2) asm volatile("v_accvgpr_read_b32 %0, a66\n\tv_accvgpr_read_b32 %1, a67" : "=v"(W1), "=v"(W2) :: BE_RING_AGPRS)
-#define BE_RING_LOAD_2(VOFF, SBASE) asm volatile("global_load_dwordx2 a[68:69], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
-#define BE_RING_READ_2(W1, W2) asm volatile("v_accvgpr_read_b32 %0, a68\n\tv_accvgpr_read_b32 %1, a69" : "=v"(W1), "=v"(W2) :: BE_RING_AGPRS)
-#define BE_RING_LOAD_3(VOFF, SBASE) asm volatile("global_load_dwordx2 a[70:71], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
-#define BE_RING_READ_3(W1, W2) asm volatile("v_accvgpr_read_b32 %0, a70\n\tv_accvgpr_read_b32 %1, a71" : "=v"(W1), "=v"(W2) :: BE_RING_AGPRS)
-#define BE_RING_LOAD_4(VOFF, SBASE) asm volatile("global_load_dwordx2 a[72:73], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
-#define BE_RING_READ_4(W1, W2) asm volatile("v_accvgpr_read_b32 %0, a72\n\tv_accvgpr_read_b32 %1, a73" : "=v"(W1), "=v"(W2) :: BE_RING_AGPRS)
-#define BE_RING_LOAD_5(VOFF, SBASE) asm volatile("global_load_dwordx2 a[74:75], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
-#define BE_RING_READ_5(W1, W2) asm volatile("v_accvgpr_read_b32 %0, a74\n\tv_accvgpr_read_b32 %1, a75" : "=v"(W1), "=v"(W2) :: BE_RING_AGPRS)
-#define BE_RING_LOAD_6(VOFF, SBASE) asm volatile("global_load_dwordx2 a[76:77], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
-#define BE_RING_READ_6(W1, W2) asm volatile("v_accvgpr_read_b32 %0, a76\n\tv_accvgpr_read_b32 %1, a77" : "=v"(W1), "=v"(W2) :: BE_RING_AGPRS)
-#define BE_RING_LOAD_7(VOFF, SBASE) asm volatile("global_load_dwordx2 a[78:79], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
-#define BE_RING_READ_7(W1, W2) asm volatile("v_accvgpr_read_b32 %0, a78\n\tv_accvgpr_read_b32 %1, a79" : "=v"(W1), "=v"(W2) :: BE_RING_AGPRS)
-#define BE_RING_AGPRS "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79"
+#define BE_RING_LOAD_0(VOFF, SBASE) asm volatile("global_load_dwordx4 a[64:67], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
+#define BE_RING_READ_0(W) asm volatile("v_accvgpr_read_b32 %0, a64\n\tv_accvgpr_read_b32 %1, a65\n\tv_accvgpr_read_b32 %2, a66\n\tv_accvgpr_read_b32 %3, a67" : "=v"(W[0]), "=v"(W[1]), "=v"(W[2]), "=v"(W[3]) :: BE_RING_AGPRS)
+#define BE_RING_LOAD_1(VOFF, SBASE) asm volatile("global_load_dwordx4 a[68:71], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
+#define BE_RING_READ_1(W) asm volatile("v_accvgpr_read_b32 %0, a68\n\tv_accvgpr_read_b32 %1, a69\n\tv_accvgpr_read_b32 %2, a70\n\tv_accvgpr_read_b32 %3, a71" : "=v"(W[0]), "=v"(W[1]), "=v"(W[2]), "=v"(W[3]) :: BE_RING_AGPRS)
+#define BE_RING_LOAD_2(VOFF, SBASE) asm volatile("global_load_dwordx4 a[72:75], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
+#define BE_RING_READ_2(W) asm volatile("v_accvgpr_read_b32 %0, a72\n\tv_accvgpr_read_b32 %1, a73\n\tv_accvgpr_read_b32 %2, a74\n\tv_accvgpr_read_b32 %3, a75" : "=v"(W[0]), "=v"(W[1]), "=v"(W[2]), "=v"(W[3]) :: BE_RING_AGPRS)
+#define BE_RING_LOAD_3(VOFF, SBASE) asm volatile("global_load_dwordx4 a[76:79], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
+#define BE_RING_READ_3(W) asm volatile("v_accvgpr_read_b32 %0, a76\n\tv_accvgpr_read_b32 %1, a77\n\tv_accvgpr_read_b32 %2, a78\n\tv_accvgpr_read_b32 %3, a79" : "=v"(W[0]), "=v"(W[1]), "=v"(W[2]), "=v"(W[3]) :: BE_RING_AGPRS)
+#define BE_RING_LOAD_4(VOFF, SBASE) asm volatile("global_load_dwordx4 a[80:83], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
+#define BE_RING_READ_4(W) asm volatile("v_accvgpr_read_b32 %0, a80\n\tv_accvgpr_read_b32 %1, a81\n\tv_accvgpr_read_b32 %2, a82\n\tv_accvgpr_read_b32 %3, a83" : "=v"(W[0]), "=v"(W[1]), "=v"(W[2]), "=v"(W[3]) :: BE_RING_AGPRS)
+#define BE_RING_LOAD_5(VOFF, SBASE) asm volatile("global_load_dwordx4 a[84:87], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
+#define BE_RING_READ_5(W) asm volatile("v_accvgpr_read_b32 %0, a84\n\tv_accvgpr_read_b32 %1, a85\n\tv_accvgpr_read_b32 %2, a86\n\tv_accvgpr_read_b32 %3, a87" : "=v"(W[0]), "=v"(W[1]), "=v"(W[2]), "=v"(W[3]) :: BE_RING_AGPRS)
+#define BE_RING_LOAD_6(VOFF, SBASE) asm volatile("global_load_dwordx4 a[88:91], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
+#define BE_RING_READ_6(W) asm volatile("v_accvgpr_read_b32 %0, a88\n\tv_accvgpr_read_b32 %1, a89\n\tv_accvgpr_read_b32 %2, a90\n\tv_accvgpr_read_b32 %3, a91" : "=v"(W[0]), "=v"(W[1]), "=v"(W[2]), "=v"(W[3]) :: BE_RING_AGPRS)
+#define BE_RING_LOAD_7(VOFF, SBASE) asm volatile("global_load_dwordx4 a[92:95], %0, %1" ::"v"(VOFF), "s"(SBASE) : "memory", BE_RING_AGPRS)
+#define BE_RING_READ_7(W) asm volatile("v_accvgpr_read_b32 %0, a92\n\tv_accvgpr_read_b32 %1, a93\n\tv_accvgpr_read_b32 %2, a94\n\tv_accvgpr_read_b32 %3, a95" : "=v"(W[0]), "=v"(W[1]), "=v"(W[2]), "=v"(W[3]) :: BE_RING_AGPRS)
+#if BE_FD_ <= 6
+#define BE_RING_AGPRS "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87"
+#else
+#define BE_RING_AGPRS "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95"
+#endif
 
 template <typename T, int TL>
-// (a[0:79] are named by hand and not in the compiler's budget: 48 registers are left for it)
-__global__ void __launch_bounds__(BE_SETS * 64, 1) __attribute__((amdgpu_num_vgpr(48)))
+// (a[0 .. 63 + 4 BE_FD] are named by hand and not in the compiler's budget)
+#define BE_FLAT_NVGPR (128 - 64 - 4 * (BE_FD_ <= 6 ? 6 : 8))
+__global__ void __launch_bounds__(BE_SETS * 64, 1) __attribute__((amdgpu_num_vgpr(BE_FLAT_NVGPR)))
 k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
             const uint32_t *__restrict__ stream, const int64_t *__restrict__ stream_off,
             const uint32_t *__restrict__ ctrl, const int64_t *__restrict__ ctrl_off,
@@ -613,7 +623,7 @@ k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
 
     const int wj = pass * BE_SETS + j;
     const unsigned char *rec_base = (const unsigned char *)(stream + stream_off[wj] * BE_REC16);   // uniform
-    const unsigned lane12 = (unsigned)lane * 8u;           // a lane's 8 bytes of a record
+    const unsigned lane12 = (unsigned)lane * 16u;          // a lane's 16 bytes of a record
     const uint32_t *ctl = ctrl + ctrl_off[wj];
     const int n = n_rec[wj];                       // a multiple of BE_FD; BE_FD more records follow
     constexpr int REC_BYTES = BE_REC16 * 4;
@@ -630,19 +640,19 @@ k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
         else if constexpr (u == 6) BE_RING_LOAD_6(lane12, sb);
         else BE_RING_LOAD_7(lane12, sb);
     };
-    auto ring_read = [&](auto U, unsigned &w1, unsigned &w2) {
+    auto ring_read = [&](auto U, unsigned (&w)[4]) {
         constexpr int u = decltype(U)::value;
-        if constexpr (u == 0) BE_RING_READ_0(w1, w2);
-        else if constexpr (u == 1) BE_RING_READ_1(w1, w2);
-        else if constexpr (u == 2) BE_RING_READ_2(w1, w2);
-        else if constexpr (u == 3) BE_RING_READ_3(w1, w2);
-        else if constexpr (u == 4) BE_RING_READ_4(w1, w2);
-        else if constexpr (u == 5) BE_RING_READ_5(w1, w2);
-        else if constexpr (u == 6) BE_RING_READ_6(w1, w2);
-        else BE_RING_READ_7(w1, w2);
+        if constexpr (u == 0) BE_RING_READ_0(w);
+        else if constexpr (u == 1) BE_RING_READ_1(w);
+        else if constexpr (u == 2) BE_RING_READ_2(w);
+        else if constexpr (u == 3) BE_RING_READ_3(w);
+        else if constexpr (u == 4) BE_RING_READ_4(w);
+        else if constexpr (u == 5) BE_RING_READ_5(w);
+        else if constexpr (u == 6) BE_RING_READ_6(w);
+        else BE_RING_READ_7(w);
     };
     const unsigned kg8 = (unsigned)kg * 8u;
-    static_assert(BE_FD <= 8 && BE_FP <= 512, "ring registers a[64:79]; pair numbers are bytes");
+    static_assert(BE_FD <= 8 && BE_FP <= 512, "ring registers a[64:95]; pair numbers are bytes");
 
     const int lane_base = C::frame_base(m16);
     const unsigned swz = (unsigned)((m16 & 7) << 4);
@@ -693,9 +703,13 @@ k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
     const bh16x2 kbias = {(_Float16)1024.0f, (_Float16)1024.0f};
 
     for (int i = 0; i < n; i += BE_FD) {
-        unsigned cw[BE_FD], cpx[BE_FD];
+        unsigned cw[BE_FD], cpa[BE_FD], cpb[BE_FD];
 #pragma unroll
-        for (int u = 0; u < BE_FD; ++u) { cw[u] = ctl[2 * (i + u)]; cpx[u] = ctl[2 * (i + u) + 1]; }
+        for (int u = 0; u < BE_FD; ++u) {
+            cw[u] = ctl[BE_CTL * (i + u)];
+            cpa[u] = ctl[BE_CTL * (i + u) + 1];
+            cpb[u] = ctl[BE_CTL * (i + u) + 2];
+        }
         bstatic_for<0, BE_FD>([&](auto U) {
             constexpr int u = decltype(U)::value;
             const unsigned c = cw[u];
@@ -707,32 +721,46 @@ k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD - 1 + 3 * NDMA) : "memory");
             }
             if (!(c & BE_C_SKIP)) {
-                unsigned rw1, rw2;
-                ring_read(U, rw1, rw2);
-                const unsigned rpair = __builtin_amdgcn_ubfe(cpx[u], kg8, 8u);    // this lane group's pair
-                bh16x2 w1l = __builtin_bit_cast(bh16x2, rw1), w2l = __builtin_bit_cast(bh16x2, rw2);
-                bh16x2 w1h = w1l * k256, w2h = w2l * k256;
-                bh16x4 a1v = {w1l[0], w1l[1], w1h[0], w1h[1]};
-                bh16x4 a2v = {w2l[0], w2l[1], w2h[0], w2h[1]};
-                const unsigned char *pq = bbase + buf * C::BUF + ((rpair * (2 * C::SZ)) ^ swz);
-                unsigned raw[TILES];
+                // a record = 8 aligned pixel pairs x 16 masks: lane group kg holds the pairs qa, qb; the K
+                // slots of v_mfma_f32_16x16x32_f16 are [lo(qa) lo(qa+1) hi(qa) hi(qa+1) | the same of qb]
+                // against [w(qa) w(qa+1) 256 w(qa) 256 w(qa+1) | ...], one MFMA for w1, one for w2
+                unsigned rw[4];                   // w1(qa) pair, w1(qb) pair, w2(qa) pair, w2(qb) pair
+                ring_read(U, rw);
+                const bh16x2 w1a = __builtin_bit_cast(bh16x2, rw[0]), w1b = __builtin_bit_cast(bh16x2, rw[1]);
+                const bh16x2 w2a = __builtin_bit_cast(bh16x2, rw[2]), w2b = __builtin_bit_cast(bh16x2, rw[3]);
+                const bh16x2 w1ah = w1a * k256, w1bh = w1b * k256, w2ah = w2a * k256, w2bh = w2b * k256;
+                bh16x8 a1v = {w1a[0], w1a[1], w1ah[0], w1ah[1], w1b[0], w1b[1], w1bh[0], w1bh[1]};
+                bh16x8 a2v = {w2a[0], w2a[1], w2ah[0], w2ah[1], w2b[0], w2b[1], w2bh[0], w2bh[1]};
+                const unsigned pa = __builtin_amdgcn_ubfe(cpa[u], kg8, 8u), pb = __builtin_amdgcn_ubfe(cpb[u], kg8, 8u);
+                const unsigned char *qa = bbase + buf * C::BUF + ((pa * (2 * C::SZ)) ^ swz);
+                const unsigned char *qb = bbase + buf * C::BUF + ((pb * (2 * C::SZ)) ^ swz);
+                unsigned rawa[TILES], rawb[TILES];
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
-                    if constexpr (C::SZ == 2) raw[t] = *(const unsigned *)(pq + t * C::TILE_OFF);
-                    else raw[t] = *(const unsigned short *)(pq + t * C::TILE_OFF);
-                }
-                bh16x4 bv[TILES];
-#pragma unroll
-                for (int t = 0; t < TILES; ++t) {
-                    bh16x2 lo, hi;
                     if constexpr (C::SZ == 2) {
-                        lo = __builtin_bit_cast(bh16x2, __builtin_amdgcn_perm(0x64646464u, raw[t], 0x04020400u)) - kbias;
-                        hi = __builtin_bit_cast(bh16x2, __builtin_amdgcn_perm(0x64646464u, raw[t], 0x04030401u)) - kbias;
+                        rawa[t] = *(const unsigned *)(qa + t * C::TILE_OFF);
+                        rawb[t] = *(const unsigned *)(qb + t * C::TILE_OFF);
                     } else {
-                        lo = __builtin_bit_cast(bh16x2, __builtin_amdgcn_perm(0x64646464u, raw[t], 0x04010400u)) - kbias;
-                        hi = bh16x2{(_Float16)0.0f, (_Float16)0.0f};
+                        rawa[t] = *(const unsigned short *)(qa + t * C::TILE_OFF);
+                        rawb[t] = *(const unsigned short *)(qb + t * C::TILE_OFF);
                     }
-                    bv[t] = bh16x4{lo[0], lo[1], hi[0], hi[1]};
+                }
+                bh16x8 bv[TILES];
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) {
+                    // bytes -> float16 without a conversion: 0x6400 | b is 1024 + b exactly
+                    bh16x2 la, ha, lb, hb;
+                    if constexpr (C::SZ == 2) {
+                        la = __builtin_bit_cast(bh16x2, __builtin_amdgcn_perm(0x64646464u, rawa[t], 0x04020400u)) - kbias;
+                        ha = __builtin_bit_cast(bh16x2, __builtin_amdgcn_perm(0x64646464u, rawa[t], 0x04030401u)) - kbias;
+                        lb = __builtin_bit_cast(bh16x2, __builtin_amdgcn_perm(0x64646464u, rawb[t], 0x04020400u)) - kbias;
+                        hb = __builtin_bit_cast(bh16x2, __builtin_amdgcn_perm(0x64646464u, rawb[t], 0x04030401u)) - kbias;
+                    } else {
+                        la = __builtin_bit_cast(bh16x2, __builtin_amdgcn_perm(0x64646464u, rawa[t], 0x04010400u)) - kbias;
+                        lb = __builtin_bit_cast(bh16x2, __builtin_amdgcn_perm(0x64646464u, rawb[t], 0x04010400u)) - kbias;
+                        ha = hb = bh16x2{(_Float16)0.0f, (_Float16)0.0f};
+                    }
+                    bv[t] = bh16x8{la[0], la[1], ha[0], ha[1], lb[0], lb[1], hb[0], hb[1]};
                 }
                 static_assert(BE_SLOTS == 4 && (TILES == 2 || TILES == 4), "accumulator naming");
                 const unsigned sl = c & 3u;
@@ -975,7 +1003,7 @@ static BellImage *build_image(const int64_t *indptr, const int64_t *indices, con
     BellImage *b = new (std::nothrow) BellImage();
     if (!b) { *err = LTMI_E_NOMEM; return nullptr; }
     b->f16 = f16;
-    const int UPR = f16 ? 4 : 8;                        // units (pixels / pixel pairs) per record
+    const int UPR = 8;                                  // units (pixels / f16: pixel pairs) per record
     const int REC = f16 ? BE_REC16 : BE_REC;          // dwords per record
     const int NSEG = f16 ? BE_FNSEG : BE_NSEG;        // segments per chunk
     try {
@@ -1103,11 +1131,11 @@ static BellImage *build_image(const int64_t *indptr, const int64_t *indices, con
                                 if (ctrl.size() == ctrl_chunk0) {       // nothing: a record to carry the flag
                                     stream.resize(stream.size() + REC, 0u);
                                     ctrl.push_back(BE_C_SKIP);
-                                    ctrl.push_back(0u);
+                                    ctrl.insert(ctrl.end(), BE_CTL - 1, 0u);
                                     ++blocks;
                                     ++pad_blocks;
                                 }
-                                ctrl[ctrl.size() - 2] |= BE_C_END;
+                                ctrl[ctrl.size() - BE_CTL] |= BE_C_END;
                             }
                             break;
                         }
@@ -1148,54 +1176,61 @@ static BellImage *build_image(const int64_t *indptr, const int64_t *indices, con
                                 stream[base + (size_t)blk * REC + l * 3 + step] = bits;
                             }
                         } else {
-                            // lane l = (mask l & 15, pair l >> 4 of the record): words
-                            // [w1(q) | w1(q+1) << 16, w2(q) | w2(q+1) << 16]; the four pairs' numbers q / 2
-                            // are the bytes of the record's second control word
+                            // lane l = (mask l & 15, lane group kg = l >> 4): the group holds the pairs
+                            // a = 8 blk + kg and b = 8 blk + 4 + kg of the list; words
+                            // [w1(a) | w1(a+1) << 16, w1(b) .., w2(a) .., w2(b) ..]; the pairs' numbers q / 2 are
+                            // the bytes of the record's control words 1 (a) and 2 (b)
                             for (int blk = 0; blk < nb; ++blk) {
-                                uint32_t pxw = 0;
+                                uint32_t pa = 0, pb = 0;
                                 for (int kk = 0; kk < 4; ++kk) {
-                                    const int c0 = blk * 4 + kk;
-                                    const uint32_t q = c0 < (int)cols.size() ? cols[c0] : cols[blk * 4];
-                                    pxw |= (q >> 1) << (8 * kk);
+                                    const int ca = blk * 8 + kk, cb = ca + 4;
+                                    const uint32_t first = cols[blk * 8];
+                                    const uint32_t qa = ca < (int)cols.size() ? cols[ca] : first;
+                                    const uint32_t qb = cb < (int)cols.size() ? cols[cb] : first;
+                                    pa |= (qa >> 1) << (8 * kk);
+                                    pb |= (qb >> 1) << (8 * kk);
                                 }
-                                pxws.push_back(pxw);
+                                pxws.push_back(pa);
+                                pxws.push_back(pb);
                             }
                             size_t ci = 0;
                             const int64_t col_base = ((int64_t)ps * GPP + gl) * 16;
                             for (const Ent &en : ents) {
                                 while (cols[ci] != (uint16_t)(en.px & ~1u)) ++ci;
-                                const int blk = (int)(ci / 4), kk = (int)(ci % 4);
+                                const int blk = (int)(ci / 8), half = (int)((ci % 8) / 4), kk = (int)(ci % 4);
                                 const int l = kk * 16 + en.m;
                                 const double ws = (double)en.v * (double)col_scale[(size_t)(col_base + en.m)];
                                 const uint16_t h1 = half_bits(ws);
                                 const uint16_t h2 = half_bits(ws - half_value(h1));
                                 const int sh = (en.px & 1) ? 16 : 0;
-                                uint32_t *rec = &stream[base + (size_t)blk * REC + l * 2];
-                                rec[0] |= (uint32_t)h1 << sh;
-                                rec[1] |= (uint32_t)h2 << sh;
+                                uint32_t *rec = &stream[base + (size_t)blk * REC + l * 4];
+                                rec[half] |= (uint32_t)h1 << sh;
+                                rec[2 + half] |= (uint32_t)h2 << sh;
                             }
                         }
                         blocks += nb;
                         if (f16)
                             for (int blk = 0; blk < nb; ++blk) {
                                 ctrl.push_back((uint32_t)s);
-                                ctrl.push_back(pxws[(size_t)blk]);
+                                ctrl.push_back(pxws[(size_t)blk * 2]);
+                                ctrl.push_back(pxws[(size_t)blk * 2 + 1]);
+                                ctrl.push_back(0u);
                             }
                         pxws.clear();
                     }
                 }
                 if (f16) {
                     // whole turns of the unrolled loop, then BE_FD records of slack for its run-ahead loads
-                    while (((ctrl.size() - ctrl0) / 2) % BE_FD) {
+                    while (((ctrl.size() - ctrl0) / BE_CTL) % BE_FD) {
                         stream.resize(stream.size() + REC, 0u);
                         ctrl.push_back(BE_C_SKIP);
-                        ctrl.push_back(0u);
+                        ctrl.insert(ctrl.end(), BE_CTL - 1, 0u);
                         ++blocks;
                         ++pad_blocks;
                     }
-                    n_rec[(size_t)ps * BE_SETS + j] = (int)((ctrl.size() - ctrl0) / 2);
+                    n_rec[(size_t)ps * BE_SETS + j] = (int)((ctrl.size() - ctrl0) / BE_CTL);
                     stream.resize(stream.size() + (size_t)BE_FD * REC, 0u);
-                    for (int k = 0; k < BE_FD; ++k) { ctrl.push_back(BE_C_SKIP); ctrl.push_back(0u); }
+                    for (int k = 0; k < BE_FD; ++k) { ctrl.push_back(BE_C_SKIP); ctrl.insert(ctrl.end(), BE_CTL - 1, 0u); }
                     blocks += BE_FD;
                     pad_blocks += BE_FD;
                 } else {
@@ -1205,10 +1240,10 @@ static BellImage *build_image(const int64_t *indptr, const int64_t *indices, con
                     pad_blocks += BE_D_MAX;
                 }
             }
-        ctrl.resize(ctrl.size() + 4 * BE_FD, BE_C_SKIP);          // (the control words are read one turn ahead)
+        ctrl.resize(ctrl.size() + 2 * BE_CTL * BE_FD, BE_C_SKIP);          // (the control words are read one turn ahead)
         b->n_blocks = blocks;
         int64_t nnz = indptr[n_px] * nc;
-        b->mac_ratio = nnz > 0 ? (double)(blocks - pad_blocks) * 128.0 / (double)nnz : 0.;
+        b->mac_ratio = nnz > 0 ? (double)(blocks - pad_blocks) * (f16 ? 256.0 : 128.0) / (double)nnz : 0.;
         if (active.empty()) active.resize(NSEG, 0);
         hipError_t e = hipMalloc((void **)&b->stream, std::max<size_t>(stream.size(), 1) * 4);
         if (e == hipSuccess) e = hipMalloc((void **)&b->stream_off, stream_off.size() * 8);
