@@ -278,7 +278,8 @@ def load_traffic(name, kname, frames_per_launch):
     for e in entries:
         if e.get('config') == name and e.get('kernel') == kname and \
                 int(e.get('frames_per_launch', -1)) == int(frames_per_launch):
-            return float(e['hbm_bytes_per_launch']), e.get('source'), e.get('rocprof_avg_us')
+            return float(e['hbm_bytes_per_launch']), e.get('source'), \
+                (e.get('rocprof_avg_us'), e.get('rocprof_pmc_pass_avg_us'))
     return None, None, None
 
 
@@ -344,12 +345,15 @@ def measure(wl, steps, warmup, barrier, hip, n_check=32):
                     frac=tfs / MFMA_F32_PEAK_TF, hbm_GBps=gbs, hbm_frac=gbs / HBM_PEAK_GBS)
     # the same fraction from the tracked rocprofv3 --kernel-trace average of this kernel (all launches
     # of the profiled run, cold ones included), so that the two can be compared without arithmetic
-    if prof_us:
-        per_s = (alg_bytes / 1e9 / HBM_PEAK_GBS if cfg['bound'] == 'hbm'
-                 else cfg['flops'] * frames_per_launch / 1e12 / MFMA_F32_PEAK_TF)
-        roof.update(profile_avg_launch_ms=prof_us / 1e3, frac_from_profile=per_s / (prof_us * 1e-6))
-    else:
-        roof.update(profile_avg_launch_ms=None, frac_from_profile=None)
+    prof_us, pmc_us = prof_us if isinstance(prof_us, tuple) else (prof_us, None)
+    per_s = (alg_bytes / 1e9 / HBM_PEAK_GBS if cfg['bound'] == 'hbm'
+             else cfg['flops'] * frames_per_launch / 1e12 / MFMA_F32_PEAK_TF)
+    roof.update(profile_avg_launch_ms=prof_us / 1e3 if prof_us else None,
+                frac_from_profile=per_s / (prof_us * 1e-6) if prof_us else None,
+                # the kernel alone (rocprofv3 counter passes serialise the dispatches): without the
+                # result copies of the previous tile on the HBM -- differs for C4 only
+                profile_pmc_pass_avg_launch_ms=pmc_us / 1e3 if pmc_us else None,
+                frac_from_profile_pmc_passes=per_s / (pmc_us * 1e-6) if pmc_us else None)
     roof.update(traffic=traffic, traffic_source=traffic_src, kernel=kname, avg_launch_ms=avg_ms,
                 launches_timed=len(kms), frames_per_launch=frames_per_launch,
                 algorithmic_bytes_per_launch=alg_bytes,

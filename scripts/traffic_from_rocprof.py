@@ -110,6 +110,12 @@ def main():
             continue
         hbm = fetch * 1024 * 2 + write * 1024
         alg = roof['algorithmic_bytes_per_launch']
+        # the kernel's average in the counter passes (kernel-trace + --pmc serialises dispatches, so the
+        # kernel does not share the HBM with the result copies of the previous tile like in the --stats
+        # pass and in the unprofiled run)
+        pmc_avgs = [per[p_]['dom'][2] / 1e3 for p_ in ('fetch', 'write', 'sq')
+                    if p_ in per and per[p_]['dom']]
+        pmc_avg = sum(pmc_avgs) / len(pmc_avgs) if pmc_avgs else None
         print(f"   => {dom[0][:60]}: rocprof avg {dom[2]/1e3:.1f} us vs HIP events "
               f"{roof['avg_launch_ms']*1e3:.1f} us; FETCH_SIZE {fetch:.1f} KiB x 1024 x 2 (gfx950) + "
               f"WRITE_SIZE {write:.1f} KiB x 1024 = {hbm:.4g} B = {hbm/alg:.3f} x algorithmic "
@@ -120,6 +126,7 @@ def main():
             "hbm_bytes_per_launch": hbm, "fetch_size_kib": fetch, "write_size_kib": write,
             "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": hbm / alg,
             "rocprof_kernel": dom[0], "rocprof_avg_us": dom[2] / 1e3, "rocprof_calls": dom[1],
+            "rocprof_pmc_pass_avg_us": pmc_avg,
             "hip_event_avg_us": roof['avg_launch_ms'] * 1e3,
             "source": f"profiles/{tag}_configs_rocprof.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                       f"separate passes over bench.py --config {cfg})",
