@@ -1,4 +1,6 @@
-// Sparse mask stacks on the matrix cores of gfx950 (MI355X): blocked-ELL image + v_mfma_f32_16x16x4_f32.
+// Sparse mask stacks on the matrix cores of gfx950 (MI355X): blocked-ELL image + v_mfma_f32_16x16x4_f32
+// (k_bell_apply: float32 / int8 / int16 frames) or exact float16 products on v_mfma_f32_16x16x32_f16 (k_bell_flat,
+// further down: uint8 / uint16 frames).
 //
 //   out[f, k] (+)= sum_p tile[f, p] * M[p, k],   M sparse (n_px x n_masks)
 //
@@ -446,19 +448,28 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
 }
 
 
-// ==== float16 path, flat record loop (1- and 2-byte unsigned pixels) ==================================
-// The frame copies (HBM, ~3 us round trip under load) and the record stream (L2) share the CU's
-// in-order vector-memory return path: a record requested after a chunk's frame copy comes back behind
-// it.  With the two-record LDS ring of the kernel above a wave works through the records it already
-// holds and then idles until the frames of the NEXT chunk have landed -- once per chunk, 128 times per
-// workgroup, ~0.25 ms of a 0.70 ms launch (profiles/r03_sparse.txt).  The cure is a record ring deep
-// enough to cover that shadow (BE_FD = 8 records, ~4 us of work), which the LDS cannot hold next to
-// the two 64 KiB frame slabs -- but registers can: 3 words per record and lane.  Registers cannot be
-// indexed by a ring position, so the loop is FLAT: one stream of records per wave for the whole sweep,
-// unrolled BE_FD times (ring position = position in the unrolled body), with a control word per
-// record -- which of the wave's 4 accumulator sets it feeds, whether the wave's work on the chunk
-// ends with it (then: wait for the next chunk's frames, barrier, start the copy of the chunk after
-// next) -- read through the scalar cache, which is a separate path.
+// ==== float16 path, flat record loop (1- and 2-byte unsigned pixels): k_bell_flat ====================
+// What the float32 kernel above pays for is the matrix pipe: 3.8 padded multiply-adds per stored value on
+// v_mfma_f32_16x16x4_f32 are 0.4 - 0.5 ms per 16 384 frames of C4 at the clock the chip sustains.  For
+// unsigned 1- and 2-byte pixels the same products can be formed EXACTLY from float16 operands:
+//   * a pixel x = lo + 256 hi, two bytes; 0x6400 | b is the float16 number 1024 + b, so one v_perm_b32 turns two
+//     bytes into two float16 values and one v_pk_add_f16 removes the bias (no conversion instruction).  (Bytes as
+//     float16 subnormals need no arithmetic at all and the matrix cores accept them, but their accumulation
+//     truncates: measured -3e-6 relative bias, not used -- profiles/r03_sparse.txt item 9);
+//   * a weight times its column's power-of-two scale S is w1 + w2, two float16 (22 bits); S keeps 256 w S below
+//     the float16 maximum and small weights out of its subnormals, the kernel multiplies by 1 / S at the end;
+//   * w x S = w1 lo + (256 w1) hi + w2 lo + (256 w2) hi: four exact products per pixel, summed in float32 by
+//     v_mfma_f32_16x16x32_f16.  A record = 8 aligned pixel PAIRS x 16 masks; lane group kg holds the pairs qa, qb:
+//     K slots [lo(qa) lo(qa+1) hi(qa) hi(qa+1) | the same of qb] against [w(qa) w(qa+1) 256 w(qa) 256 w(qa+1) | ..],
+//     one MFMA for w1 and one for w2 per tile -- 2 x 16 pipe cycles for 16 pixels where float32 needs 4 x 32.
+// The loop is FLAT: one stream of records per wave for the whole sweep, unrolled BE_FD times, with control words
+// per record -- which of the wave's 4 accumulator sets it feeds, whether the wave's work on the chunk ends with
+// it (then: wait for the next chunk's frames, barrier, start the copy of the chunk after next), the pairs' pixel
+// numbers -- read through the scalar cache.  The record ring (BE_FD records of 4 words per lane) and the 64
+// accumulator registers live in AGPRs under fixed names: registers cannot be indexed by a ring position (hence
+// the unrolling, ring position = position in the unrolled body), compiler-visible accumulators are copied at
+// every merge of the four accumulator-set arms, and a ring behind asm loads must not be moved by the compiler
+// while a load is in flight.  What this buys and what still bounds the kernel: profiles/r03_sparse.txt, DESIGN 4.3.
 #ifndef BE_PHASE_SLEEP
 #define BE_PHASE_SLEEP 8            // s_sleep units (64 cycles) per phase step, 16 steps
 #endif
