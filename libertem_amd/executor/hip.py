@@ -245,6 +245,23 @@ class HipJobExecutor(JobExecutor):
             self._shared = None
 
     # --- merging ------------------------------------------------------------------------------------
+    _before_wait = None
+
+    def set_before_wait(self, fn):
+        """`fn()` is called once in the next `merge_results`, after the kernels of every task of this
+        rank are enqueued and before the first wait or delivery -- host work that may hide behind
+        the GPU (UDFRunner: the content comparison of a re-used plan).  If it raises, the stream is
+        drained, nothing is delivered and the exception propagates."""
+        self._before_wait = fn
+
+    def drain(self):
+        """a run was abandoned half way: wait for what it enqueued, forget its delivery targets"""
+        self._row_sink = None
+        self._result_target = None
+        for st in (self._stream, getattr(self, '_copy_stream', None)):
+            if st is not None:
+                st.synchronize()
+
     def merge_results(self, udfs, damage, result_iter, apply_part_result):
         """
         Consume (part_results, task) pairs of THIS rank, merge, combine across ranks and leave the
@@ -633,6 +650,13 @@ class HipJobExecutor(JobExecutor):
                 self._stream.synchronize()
             return
 
+        hook, self._before_wait = self._before_wait, None
+        if hook is not None:
+            try:
+                hook()
+            except BaseException:
+                self.drain()
+                raise
         # ---- declared buffers: collectives on flat tensors ----
         publish_device(final=True)
         for i, (udf, (mode, decl)) in enumerate(zip(udfs, plans)):

@@ -969,6 +969,10 @@ class UDFPartRunner:
                 udf.export_results()
 
 
+class _StalePlan(Exception):
+    """a cached plan whose parameter contents no longer match (UDFRunner._prepare_run_for_dataset)"""
+
+
 class UDFResults:
     """udf/base.py:2806-2831"""
 
@@ -1037,19 +1041,27 @@ class UDFRunner:
             kw = getattr(u, '_kwargs', None)
             if kw is None:
                 return None
-            # identity AND a content fingerprint: a list that is mutated in place between runs (mask
-            # factories appended or replaced), an ndarray parameter or an array captured by a mask
-            # factory that is modified in place, is a different parameter (the reference
-            # re-instantiates the UDFs and re-evaluates the factories on every run)
-            vals = [(k, fingerprint(v)) for k, v in kw.items()]
-            parts.append((id(u), tuple(vals)))
+            parts.append((id(u), tuple((k, id(v)) for k, v in kw.items())))
         from libertem_amd.common import udf as udf_common
         knobs = (udf_common.HIP_DIRECT_ROW_MAX,) + tuple(
             getattr(sys.modules.get(type(u).__module__), 'FOLD_CORRECTIONS', None)
             for u in self._udfs)
         return (id(executor), _canonical_backends(backends), tuple(parts), knobs)
 
-    def _prepare_run_for_dataset(self, dataset, executor, roi, corrections, backends, dry):
+    def _plan_content(self):
+        """Content fingerprints of the parameters (common/fingerprint.py): a list that is mutated in
+        place between runs (mask factories appended or replaced), an ndarray parameter or an array
+        captured by a mask factory that is modified in place, is a different parameter (the reference
+        re-instantiates the UDFs and re-evaluates the factories on every run).  Reading the sample
+        costs ~80 us for the 4 MiB C2 stack, so a run that hits the cache by identity starts on the
+        cached plan and compares the contents while the kernels run (`_prepare_run_for_dataset`)."""
+        return tuple(tuple((k, fingerprint(v)) for k, v in u._kwargs.items()) for u in self._udfs)
+
+    def _prepare_run_for_dataset(self, dataset, executor, roi, corrections, backends, dry,
+                                 defer_check=False):
+        """-> (tasks, params, verify).  `verify` (None, or a callable that raises _StalePlan) is the
+        content comparison of a cache hit that the caller asked to run late (`defer_check`): after
+        the kernels of the run are enqueued, before anything is delivered."""
         key = self._plan_key(executor, roi, corrections, backends, dry)
         plans = None
         if key is not None:
@@ -1058,8 +1070,22 @@ class UDFRunner:
             except AttributeError:
                 plans = None
         hit = plans.get(key) if plans is not None else None
+        verify = None
         if hit is not None and all(a() is b for a, b in zip(hit['udfs'], self._udfs)) \
                 and hit['executor'] is executor:
+            def verify(hit=hit, key=key):
+                if self._plan_content() != hit['content']:
+                    plans.pop(key, None)
+                    raise _StalePlan()
+            if not defer_check:
+                try:
+                    verify()
+                except _StalePlan:
+                    hit = None
+                verify = None
+        else:
+            hit = None
+        if hit is not None:
             # same udf objects (and parameter objects) as before: planning, negotiation and task
             # creation are pure functions of them -- only the result buffers are per run
             plans.move_to_end(key)
@@ -1071,7 +1097,8 @@ class UDFRunner:
                 if hasattr(udf, 'preprocess'):
                     udf.set_views_for_dataset(dataset)
                     udf.preprocess()
-            return hit['tasks'], hit['params']
+            return hit['tasks'], hit['params'], verify
+        content = self._plan_content() if plans is not None else None
         tasks, params, meta = self._plan_run(dataset, executor, roi, corrections, backends, dry)
         if plans is not None:
             for t in tasks:
@@ -1081,11 +1108,11 @@ class UDFRunner:
             # matches, so a recycled id() cannot produce a false hit.  The parameter objects are
             # pinned: their id()s are part of the key.
             plans[key] = dict(udfs=[weakref.ref(u) for u in self._udfs], executor=executor,
-                              tasks=tasks, params=params, meta=meta,
+                              tasks=tasks, params=params, meta=meta, content=content,
                               kwargs=[dict(u._kwargs) for u in self._udfs])
             while len(plans) > self.PLAN_CACHE_SIZE:
                 plans.popitem(last=False)
-        return tasks, params
+        return tasks, params, None
 
     def _plan_run(self, dataset, executor, roi, corrections, backends, dry):
         self._check_preconditions(dataset, roi)
@@ -1144,17 +1171,38 @@ class UDFRunner:
                              backends=None, dry=False, iterate=True):
         if roi is not None:
             roi = np.asarray(roi, dtype=bool)
-        tasks, params = self._prepare_run_for_dataset(dataset, executor, roi, corrections,
-                                                      backends, dry)
+        # a cache hit by identity may compare the parameter CONTENTS behind the enqueued kernels
+        # (executor hook); a partial-result iteration publishes early, so it compares up front
+        defer = (not iterate) and hasattr(executor, 'set_before_wait')
+        while True:
+            try:
+                yield from self._run_attempt(dataset, executor, roi, corrections, backends, dry,
+                                             iterate, defer)
+                return
+            except _StalePlan:
+                # the parameters changed in place since the plan was made: the plan is gone from the
+                # cache, nothing of the run was delivered -- plan afresh and run again
+                defer = False
+
+    def _run_attempt(self, dataset, executor, roi, corrections, backends, dry, iterate, defer):
+        tasks, params, verify = self._prepare_run_for_dataset(
+            dataset, executor, roi, corrections, backends, dry, defer_check=defer)
         cancel_id = f"run-{next(_RUN_IDS)}"
         damage = BufferWrapper(kind='nav', dtype=bool)
         damage.set_roi(roi)
         damage.set_shape_ds(dataset.shape, roi)
         damage.allocate()
+        checked = []
+
+        def late_check():
+            checked.append(True)
+            verify()
         try:
             if tasks:
                 params_handle = executor.scatter(params)
                 try:
+                    if verify is not None:
+                        executor.set_before_wait(late_check)
                     # hook for executors that merge on the device / across ranks
                     result_iter = executor.run_tasks(tasks, params_handle, cancel_id)
                     if iterate and hasattr(executor, 'merge_results_iter'):
@@ -1173,12 +1221,27 @@ class UDFRunner:
                             if iterate:
                                 yield self._make_udf_result(self._udfs, damage)
                 finally:
+                    if verify is not None:
+                        executor.set_before_wait(None)
                     executor.scatter_release(params_handle)
             else:
                 if iterate:
                     yield self._make_udf_result(self._udfs, damage)
+            if verify is not None and not checked:
+                late_check()
         except JobCancelledError:
             raise UDFRunCancelled(f"UDF run cancelled after {len(tasks)} tasks were created")
+        except _StalePlan:
+            raise
+        except Exception:
+            # a stale plan may fail before the comparison is reached (a factory list that grew: the
+            # kept task instances and the new result buffers disagree) -- that is a stale plan, not
+            # an error of the run
+            if verify is not None and not checked:
+                if hasattr(executor, 'drain'):
+                    executor.drain()
+                late_check()
+            raise
         if not iterate:
             yield self._make_udf_result(self._udfs, damage)
 
