@@ -112,6 +112,15 @@ double bell_mac_ratio(const int64_t *indptr, const int64_t *indices, int nc, int
 void *bell_build(const int64_t *indptr, const int64_t *indices, const float *vals, int nc,
                  int64_t n_px, int64_t n_masks, int *err);
 void bell_destroy(void *image);
+// float32 frames x multi-group float32 stacks on the bf16 matrix cores, float32-accurate (ltmi_split.hip)
+bool split_selected(bool tuned);
+bool split_wanted(int n_cols, int64_t n_px);
+int split_create(int device, const float *gmasks, int64_t n_masks, int cpm, int64_t n_px, int n_cols,
+                 void **image);
+void split_destroy(void *image);
+size_t split_image_bytes(const void *image);
+int split_apply(ltmi_masks *m, void *image, const float *tile, int64_t n_frames, int64_t ld, float *out,
+                int64_t ld_out, int accumulate, hipStream_t stream);
 int bell_apply(ltmi_masks *m, void *image, int cplx, const void *tile, int tile_dtype,
                int64_t n_frames, int64_t ld_tile, void *out, int64_t ld_out, int accumulate,
                hipStream_t stream, bool *handled);
@@ -133,6 +142,7 @@ struct ltmi_masks {
     int n_slots2 = 0;
     float *img3 = nullptr;   // ng3 groups + ne3 VALU columns (16 ng3 + 1..4 columns), slots of 128 px
     int n_slots3 = 0, ne3 = 0, ng3 = 0;   // ng3 full groups + ne3 VALU columns
+    void *split = nullptr;   // bf16 x 3 image for float32 frames (ltmi_split.hip), stacks of >= 2 groups
     // float64 results on the f64 matrix cores (ltmi_dense64.hip)
     double *img64 = nullptr;
     int n_groups64 = 0, n_chunks64 = 0;

@@ -1294,6 +1294,8 @@ extern "C" int ltmi_masks_destroy(ltmi_masks *m) {
     if (m->img) (void)hipFree(m->img);
     if (m->img2) (void)hipFree(m->img2);
     if (m->img3) (void)hipFree(m->img3);
+    ltmi::split_destroy(m->split);
+    m->split = nullptr;
     ltmi::dense64_destroy(m);
     shift_cache_destroy(m);
     if (m->partials) (void)hipFree(m->partials);
@@ -1311,9 +1313,9 @@ extern "C" int ltmi_masks_kind(const ltmi_masks *m, int *kind) {
 
 extern "C" int ltmi_masks_set_tuning(ltmi_masks *m, int mt, int waves, int ksplit) {
     if (!m) LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_set_tuning: null handle");
-    if (mt == 0 && ((waves >= 30 && waves <= 35) || (waves >= 40 && waves <= 41))) {
+    if (mt == 0 && ((waves >= 30 && waves <= 36) || (waves >= 40 && waves <= 41))) {
         // k_dense_lds: 30 = as dispatched, 31 / 32 = timing-only ablations (no DMA / no MFMA),
-        // 34 / 35 = one / two frame tiles per wave;
+        // 34 / 35 = one / two frame tiles per wave; 36 = k_dense_split (float32 frames, ltmi_split.hip);
         // sparse stacks: 40 = as dispatched, 41 = SELL kernel even if a blocked image exists
         m->tune_mt = 0;
         m->tune_waves = 0;
@@ -1393,6 +1395,20 @@ static int launch_mfma_variant(ltmi_masks *m, const T *tile, int64_t n_frames, i
 
 // frame tiles per wave (LdsCfg): 2 unless a bench run forces one of them
 // (ltmi_masks_set_tuning waves code 34 = one tile / 8 waves, 35 = two tiles / 4 waves)
+// kernel instantiation point.  -DLTMI_DENSE_EXP (experiment builds, scripts/dense_variant.sh): only the
+// C5 kernels (float frames, 3 groups + 0 / 2 VALU columns) are compiled -- a minute instead of five
+template <typename T, int NG, int ABL, int IND, int NE, int TILES>
+static auto lds_kernel() -> void (*)(const T *, int64_t, int64_t, int64_t, const float *, int, float *,
+                                     int64_t, int, int, float *, int, const int32_t *,
+                                     const float *const *, int *) {
+#ifdef LTMI_DENSE_EXP
+    if constexpr (!(std::is_same<T, float>::value && NG == 3 && ABL == 0 && IND == 0 && TILES == 2))
+        return nullptr;
+    else
+#endif
+        return k_dense_lds<T, NG, ABL, IND, NE, TILES>;
+}
+
 static inline int lds_tiles(const ltmi_masks *m) {
     return m->tune_ksplit_ring == 34 ? 1 : 2;
 }
@@ -1405,11 +1421,12 @@ static int launch_lds_ng_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64
     const int abl = m->tune_ksplit_ring == 31 ? 2 : (m->tune_ksplit_ring == 32 ? 1 : 0);
     void (*kern)(const T *, int64_t, int64_t, int64_t, const float *, int, float *, int64_t, int,
                  int, float *, int, const int32_t *, const float *const *, int *) =
-        abl == 2 ? k_dense_lds<T, NG, 2, 0, 0, TILES>
-                 : (abl == 1 ? k_dense_lds<T, NG, 1, 0, 0, TILES>
-                             : k_dense_lds<T, NG, 0, 0, 0, TILES>);
+        abl == 2 ? lds_kernel<T, NG, 2, 0, 0, TILES>()
+                 : (abl == 1 ? lds_kernel<T, NG, 1, 0, 0, TILES>()
+                             : lds_kernel<T, NG, 0, 0, 0, TILES>());
     const int32_t *rows = m->roi_rows;                  // ltmi_apply_masks_rows: frames through a row list
-    if (rows) kern = k_dense_lds<T, NG, 0, 2, 0, TILES>;
+    if (rows) kern = lds_kernel<T, NG, 0, 2, 0, TILES>();
+    if (!kern) return LTMI_E_DTYPE;
     static bool attr_set[16][4] = {{false}};
     const int variant = rows ? 3 : abl;
     if (!attr_set[m->device & 15][variant]) {
@@ -1465,9 +1482,10 @@ template <typename T, int NG, int NE, int TILES>
 static int launch_lds_extras_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
                                int64_t ld_out, int accumulate, hipStream_t stream) {
     using CFG = LdsCfg<NG, NE, TILES>;
-    auto kern = k_dense_lds<T, NG, 0, 0, NE, TILES>;
+    auto kern = lds_kernel<T, NG, 0, 0, NE, TILES>();
     const int32_t *rows = m->roi_rows;
-    if (rows) kern = k_dense_lds<T, NG, 0, 2, NE, TILES>;
+    if (rows) kern = lds_kernel<T, NG, 0, 2, NE, TILES>();
+    if (!kern) return LTMI_E_DTYPE;
     static bool attr_set[16][2] = {{false}};
     if (!attr_set[m->device & 15][rows ? 1 : 0]) {
         LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1706,7 +1724,8 @@ static int launch_lds_shifted(ltmi_masks *m, const T *tile, int64_t n_frames, in
                             hipMemcpyHostToDevice, stream));
     LTMI_HIP(hipMemcpyAsync((void *)c->wg_img_dev, wg_host.data(), wg_host.size() * sizeof(float *),
                             hipMemcpyHostToDevice, stream));
-    auto kern = k_dense_lds<T, 1, 0, 1, 0, 2>;
+    auto kern = lds_kernel<T, 1, 0, 1, 0, 2>();
+    if (!kern) return LTMI_E_DTYPE;
     static bool attr_set[16] = {false};
     if (!attr_set[m->device & 15]) {
         LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1735,6 +1754,23 @@ static int launch_mfma(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t l
     // any element-aligned address (detectors with odd row lengths -- 515 x 515 uint16 -- run at the
     // speed of 516 x 516: profiles/r02_unaligned.txt; the direct-load fallback with guarded element
     // loads was 5.5x slower).  LTMI_ALIGNED_DMA_ONLY=1 restores the old dispatch.
+    if constexpr (std::is_same<T, float>::value) {
+        // opt-in (LTMI_SPLIT=1 or tuning code 36): float32 frames against two or more column groups
+        // as bf16 pieces on the bf16 matrix cores (ltmi_split.hip; measured slower than k_dense_lds
+        // on C5, profiles/r03_split.txt, hence not the default).  The image is made on first use.
+        if (ltmi::split_selected(m->tune_ksplit_ring == 36) && m->blocks.empty() && !m->roi_rows &&
+            m->result_dtype != LTMI_F64 && ltmi::split_wanted(m->n_cols, m->n_px) &&
+            vector_loads_ok(tile, ld, sizeof(T)) && m->tune_mt == 0 && m->tune_waves == 0 &&
+            (m->tune_ksplit_ring == 0 || m->tune_ksplit_ring == 36)) {
+            if (!m->split) {
+                const int cpm = (m->result_dtype == LTMI_C64) ? 2 : 1;
+                const int rcs = ltmi::split_create(m->device, (const float *)m->gmasks, m->n_masks, cpm,
+                                                   m->n_px, m->n_cols, &m->split);
+                if (rcs != LTMI_OK) return rcs;
+            }
+            return ltmi::split_apply(m, m->split, tile, n_frames, ld, out, ld_out, accumulate, stream);
+        }
+    }
     if (vector_loads_ok(tile, ld, sizeof(T)) && m->tune_mt == 0 && m->tune_waves == 0 &&
         lds_kernel_applies<T>(m))
         return launch_lds<T>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);

@@ -858,6 +858,60 @@ def test_three_groups_plus_valu_columns(hip, tile_dtype, n_masks, mask_dtype, ks
     assert np.all(np.abs(res4 - res) <= 2e-5 * scale + 1e-30)
 
 
+@pytest.mark.parametrize('n_frames,n_px,n_masks,mask_dtype,ksplit', [
+    (150, 64 * 40, 25, 'complex64', 0),     # C5's stack: 50 real columns -> 4 groups
+    (150, 64 * 40, 25, 'complex64', 3),
+    (300, 128 * 33, 20, 'float32', 0),      # 2 groups
+    (77, 128 * 16, 32, 'float32', 2),
+    (129, 64 * 21, 48, 'float32', 0),       # 3 groups, one frame past a workgroup
+    (40, 64 * 64, 70, 'float32', 0),        # column blocks: 64 columns split, the last 6 on k_dense_lds
+])
+def test_float32_frames_on_bf16_matrix_cores(hip, n_frames, n_px, n_masks, mask_dtype, ksplit):
+    """k_dense_split (csrc/ltmi_split.hip, opt-in: tuning code 36 / LTMI_SPLIT=1): float32 frames
+    against >= 2 column groups as three bf16 pieces per factor, six exact-product matrix instructions
+    -- float32 accuracy (checked tighter than the north-star 1e-5: 2e-6 of sum |a||b|), agreement with
+    the f32-instruction kernel, accumulate and K-split paths, wide exponent range."""
+    rng = np.random.default_rng(hash((n_frames, n_px, n_masks, mask_dtype)) % (2**32))
+    md = np.dtype(mask_dtype)
+    data = (rng.random((n_frames, n_px)) - 0.3).astype(np.float32)
+    data[:, ::7] *= 1e-3
+    data[:, 5::11] *= 300.0
+    data[3 % n_frames] = 0.0
+    masks = rng.random((n_masks, n_px)) - 0.25
+    if md.kind == 'c':
+        masks = masks + 1j * (rng.random((n_masks, n_px)) - 0.5)
+    masks = masks.astype(md)
+    masks[0, :n_px // 2] = 0
+    ref = _ref64(data, masks)
+    scale = np.abs(data.astype(np.float64)) @ np.abs(masks).astype(np.float64).T
+    n_cols = n_masks * (2 if md.kind == 'c' else 1)
+    tuning = dict(mt=0, waves=36, ksplit=ksplit)
+    res, kern = _apply(hip, data, masks, md, tuning=tuning)
+    if n_cols <= 64:
+        assert 'k_dense_split' in kern and 'bf16x3' in kern, kern
+    else:
+        assert 'column blocks' in kern, kern        # 64 columns split, the last 6 on k_dense_lds
+    assert np.all(np.abs(res - ref) <= 2e-6 * scale + 1e-30), np.max(np.abs(res - ref) / (scale + 1e-30))
+    base = (rng.random((n_frames, n_masks)) + (1j * rng.random((n_frames, n_masks))
+                                               if md.kind == 'c' else 0)).astype(md)
+    res2, _ = _apply(hip, data, masks, md, accumulate_into=base, tuning=tuning)
+    assert np.all(np.abs(res2 - (ref + base)) <= 2e-6 * (scale + 1))
+    # the f32-instruction kernel (the default dispatch) agrees
+    res3, kern3 = _apply(hip, data, masks, md, tuning=dict(mt=0, waves=30, ksplit=ksplit))
+    assert 'k_dense_lds' in kern3, kern3
+    assert np.all(np.abs(res3 - res) <= 1e-5 * scale + 1e-30)
+    _, kern_default = _apply(hip, data, masks, md)
+    assert 'k_dense_split' not in kern_default, kern_default
+    # exponents far from 1: the pieces keep the float32 exponent range
+    big = (data[:16] * np.float32(1e30)).astype(np.float32)
+    small = (data[:16] * np.float32(1e-30)).astype(np.float32)
+    for d in (big, small):
+        r, k = _apply(hip, d, masks, md, tuning=tuning)
+        rf = _ref64(d, masks)
+        sc = np.abs(d.astype(np.float64)) @ np.abs(masks).astype(np.float64).T
+        assert np.all(np.isfinite(r)) and np.all(np.abs(r - rf) <= 2e-6 * sc + 1e-38)
+
+
 @pytest.mark.parametrize('seed', [101, 202])
 def test_randomised_differential(seed):
     """scripts/fuzz_kernels.py: random shapes / dtypes / leading dimensions / accumulate / K split /
