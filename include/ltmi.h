@@ -78,8 +78,12 @@ int ltmi_masks_create_dense(int device, const void *masks_host, int result_dtype
 
 /* Sparse stack in CSR over pixels, exactly the matrix the reference builds in
  * _build_sparse (src/libertem/common/container.py:53-64): shape (n_px, n_masks),
- * indptr[n_px + 1], indices[nnz] (mask index), data[nnz] of `result_dtype`: float32, complex64 or
- * float64 (complex128 / integer results: densify and use ltmi_masks_create_dense).
+ * indptr[n_px + 1], indices[nnz] (mask index), data[nnz] of `result_dtype`: float32, complex64,
+ * float64, or -- for the integer result dtypes -- int64 values: ltmi_apply_masks then computes the
+ * integer product with wrap-around (SciPy's integer matmul) through the float64 gather kernel and
+ * fails with LTMI_E_DTYPE for a tile dtype whose sums could exceed 2^52 (bits of the tile dtype + bits
+ * of the largest column sum of |values| > 52: densify and use ltmi_masks_create_dense).
+ * complex128: pass (re, im) as two float64 columns (libertem_amd/hip.py MaskHandle.csr_complex128).
  * Host pointers; canonical format (sorted, no duplicates) is not required.
  * Two device images may be built: the sliced-ELL image of the gather kernel (always) and, for float32 /
  * complex64 stacks whose neighbouring masks share pixels (rings, radial bins), the blocked image that

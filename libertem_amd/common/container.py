@@ -52,6 +52,26 @@ def _worth_densifying(csr_px_by_masks, result_dtype):
     return cols16 <= 32 and touched > 0.5 * n_px
 
 
+def _sparse_int_exact(csr_px_by_masks, tile_dtypes):
+    """Integer stack x integer frames through the float64 gather kernel: exact iff every possible
+    partial sum stays below 2^52 -- bits of the widest tile dtype + bits of the largest column sum of
+    |mask values| (csrc/ltmi_sparse.hip csr_int_exact, the same rule)."""
+    bits = 0
+    for dt in tile_dtypes:
+        dt = np.dtype(dt)
+        if dt.kind == 'b':
+            b = 1
+        elif dt.kind in 'iu' and dt.itemsize <= 4:
+            b = 8 * dt.itemsize
+        else:
+            return False
+        bits = max(bits, b)
+    if csr_px_by_masks.nnz == 0:
+        return True
+    worst = int(np.max(abs(csr_px_by_masks).sum(axis=0)))
+    return bits + worst.bit_length() <= 52
+
+
 class MaskContainer:
     def __init__(self, mask_factories, dtype=None, use_sparse=None, count=None, backend=None,
                  default_sparse='scipy.sparse'):
@@ -198,11 +218,15 @@ class MaskContainer:
         return mat
 
     # --- device handles --------------------------------------------------------------------------
-    def get_handle_for_sig_slice(self, sig_slice, result_dtype, device, real_frames=True):
+    def get_handle_for_sig_slice(self, sig_slice, result_dtype, device, real_frames=True,
+                                 tile_dtypes=()):
         """libltmi handle of the slice's stack, cast to `result_dtype`, on GPU `device`.
-        real_frames: the tiles are real numbers (a complex128 sparse stack may then stay sparse)."""
+        real_frames: the tiles are real numbers (a complex128 sparse stack may then stay sparse).
+        tile_dtypes: the dtypes the tiles can arrive in (an integer sparse stack stays sparse if the
+        product with them is exact in float64)."""
         from libertem_amd import hip
-        key = (sig_slice, np.dtype(result_dtype).str, int(device), bool(real_frames))
+        tile_dtypes = tuple(sorted({np.dtype(d).str for d in tile_dtypes}))
+        key = (sig_slice, np.dtype(result_dtype).str, int(device), bool(real_frames), tile_dtypes)
         h = self._handle_cache.get(key)
         if h is None:
             sparse_ok = np.dtype(result_dtype) in (np.dtype(np.float32), np.dtype(np.complex64),
@@ -218,9 +242,20 @@ class MaskContainer:
                     h = hip.MaskHandle.dense(device, dense, result_dtype)
                 else:
                     h = hip.MaskHandle.csr_complex128(device, m)
+            elif self.use_sparse is not False and np.dtype(result_dtype).kind in 'iu' and tile_dtypes:
+                # integer stack, integer frames (reference: SciPy integer matmul, wrap-around): the
+                # float64 gather kernel + truncation where that is exact, else the dense integer kernels
+                m = sp.csr_matrix(self.get_for_sig_slice(
+                    sig_slice, dtype=result_dtype, sparse_backend='scipy.sparse.csr',
+                    transpose=True))
+                if _sparse_int_exact(m, tile_dtypes) and not _worth_densifying(m, result_dtype):
+                    h = hip.MaskHandle.csr(device, m, result_dtype)
+                else:
+                    dense = np.ascontiguousarray(m.T.toarray().astype(result_dtype, copy=False))
+                    h = hip.MaskHandle.dense(device, dense, result_dtype)
             elif self.use_sparse is False or not sparse_ok:
-                # dense stack; also the route for sparse stacks whose result dtype (complex128,
-                # integers) the sparse kernels do not cover: densified
+                # dense stack; also the route for sparse stacks whose result dtype the sparse kernels
+                # do not cover (complex128 on complex frames, integers on wide tiles): densified
                 m = self.get_for_sig_slice(sig_slice, dtype=result_dtype, sparse_backend=False,
                                            transpose=False)            # (n_masks, px), C order
                 h = hip.MaskHandle.dense(device, np.ascontiguousarray(m), result_dtype)

@@ -25,6 +25,7 @@
 #include <vector>
 #include <algorithm>
 #include <cstring>
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 #include <typeinfo>
@@ -56,6 +57,10 @@ struct CsrImage {
     int *active = nullptr;      // chunks with entries, concatenated per pass
     int *active_off = nullptr;  // [n_pass + 1]
     void *bell = nullptr;       // blocked image for the matrix-core kernel (ltmi_bell.hip) or null
+    // integer result dtypes: the values are held as doubles (f64 = 1) and a product whose every
+    // partial sum stays below 2^52 is exact in the float64 gather kernel (see csr_apply)
+    int int_result = 0;
+    int sum_bits = 0;           // bits of the largest possible |sum of mask values| of one column
 };
 
 __device__ __forceinline__ int slab_word(int p, int f) {
@@ -364,11 +369,75 @@ bool csr_rows_ok(const ltmi_masks *m, const void *tile, int tile_dtype, int64_t 
     return false;
 }
 
+// exact integer sum (held in a double, |v| < 2^53) -> wrap-around integer of the result width: the
+// arithmetic of NumPy's / SciPy's integer matmul (the same step as ltmi_dense64.hip k_f64_to_int)
+template <typename S>
+__global__ void k_sell_f64_to_int(const double *__restrict__ src, int64_t n_frames, int n_masks,
+                                  S *__restrict__ out, int64_t ld_out, int accumulate) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_frames * n_masks) return;
+    const int64_t f = idx / n_masks;
+    const int k = (int)(idx % n_masks);
+    const S v = (S)(uint64_t)(int64_t)src[idx];
+    S *p = out + f * ld_out + k;
+    *p = accumulate ? (S)(*p + v) : v;
+}
+
+// integer stack x integer frames: is every possible partial sum below 2^52 (float64 chain exact)?
+bool csr_int_exact(const ltmi_masks *m, int tile_dtype) {
+    const CsrImage *c = (const CsrImage *)m->csr;
+    if (!c || !c->int_result) return false;
+    int data_bits;
+    switch (tile_dtype) {
+        case LTMI_BOOL: data_bits = 1; break;
+        case LTMI_U8: case LTMI_I8: data_bits = 8; break;
+        case LTMI_U16: case LTMI_I16: data_bits = 16; break;
+        case LTMI_U32: case LTMI_I32: data_bits = 32; break;
+        default: return false;                            // 64-bit or non-integer tiles
+    }
+    return data_bits + c->sum_bits <= 52;
+}
+
 int csr_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames, int64_t ld_tile,
               void *out, int64_t ld_out, int accumulate, hipStream_t stream) {
     CsrImage *c = (CsrImage *)m->csr;
     if (m->roi_rows && !csr_rows_ok(m, tile, tile_dtype, ld_tile))
         LTMI_FAIL(LTMI_E_INVALID, "sparse masks: this handle / tile cannot take a row list");
+    if (c->int_result) {
+        // exact in float64 -> gather into a float64 scratch, then truncate to the result width
+        if (!csr_int_exact(m, tile_dtype))
+            LTMI_FAIL(LTMI_E_DTYPE, "sparse integer masks: %s tiles against this stack can exceed 2^52 "
+                      "(densify the stack: the integer VALU kernel)", dtype_name(tile_dtype));
+        const size_t need = (size_t)n_frames * m->n_masks * sizeof(double);
+        if (m->res64_bytes < need) {
+            if (m->res64) {
+                LTMI_HIP(hipStreamSynchronize(stream));
+                LTMI_HIP(hipFree(m->res64));
+                m->res64 = nullptr;
+                m->res64_bytes = 0;
+            }
+            LTMI_HIP(hipMalloc(&m->res64, need));
+            m->res64_bytes = need;
+        }
+        c->int_result = 0;                                  // (the float64 branch below, once)
+        const int rc = csr_apply(m, tile, tile_dtype, n_frames, ld_tile, m->res64, m->n_masks, 0,
+                                 stream);
+        c->int_result = 1;
+        if (rc != LTMI_OK) return rc;
+        const int64_t n = n_frames * m->n_masks;
+        const dim3 grid((unsigned)((n + 255) / 256));
+        const double *src = (const double *)m->res64;
+        switch (dtype_size(m->result_dtype)) {
+            case 1: hipLaunchKernelGGL(k_sell_f64_to_int<uint8_t>, grid, dim3(256), 0, stream, src, n_frames, (int)m->n_masks, (uint8_t *)out, ld_out, accumulate); break;
+            case 2: hipLaunchKernelGGL(k_sell_f64_to_int<uint16_t>, grid, dim3(256), 0, stream, src, n_frames, (int)m->n_masks, (uint16_t *)out, ld_out, accumulate); break;
+            case 4: hipLaunchKernelGGL(k_sell_f64_to_int<uint32_t>, grid, dim3(256), 0, stream, src, n_frames, (int)m->n_masks, (uint32_t *)out, ld_out, accumulate); break;
+            default: hipLaunchKernelGGL(k_sell_f64_to_int<uint64_t>, grid, dim3(256), 0, stream, src, n_frames, (int)m->n_masks, (uint64_t *)out, ld_out, accumulate); break;
+        }
+        LTMI_HIP(hipGetLastError());
+        const size_t len = strlen(m->last_kernel);
+        snprintf(m->last_kernel + len, sizeof(m->last_kernel) - len, " exact-int");
+        return LTMI_OK;
+    }
     if (c->f64) {
         double *o = (double *)out;
         switch (tile_dtype) {
@@ -417,9 +486,10 @@ extern "C" int ltmi_masks_create_csr(int device, const int64_t *indptr, const in
     if (!indptr || !out || n_px <= 0 || n_masks <= 0)
         LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_create_csr: bad arguments (n_px=%lld n_masks=%lld)",
                   (long long)n_px, (long long)n_masks);
-    if (result_dtype != LTMI_F32 && result_dtype != LTMI_C64 && result_dtype != LTMI_F64)
+    const bool int_result = result_dtype >= LTMI_U8 && result_dtype <= LTMI_I64;
+    if (result_dtype != LTMI_F32 && result_dtype != LTMI_C64 && result_dtype != LTMI_F64 && !int_result)
         LTMI_FAIL(LTMI_E_DTYPE, "ltmi_masks_create_csr: result dtype %s not supported for sparse "
-                  "stacks (float32 / complex64 / float64 only; densify for others)",
+                  "stacks (float32 / complex64 / float64 / integers; densify for others)",
                   dtype_name(result_dtype));
     const int64_t nnz = indptr[n_px];
     if (nnz < 0 || (nnz > 0 && (!indices || !data)))
@@ -444,9 +514,22 @@ extern "C" int ltmi_masks_create_csr(int device, const int64_t *indptr, const in
     c->n_pass = (int)((n_masks + c->mb - 1) / c->mb);
     c->n_chunks = (int)((n_px + SP_P - 1) / SP_P);
     const int nc = c->cplx ? 2 : 1;
-    c->f64 = (result_dtype == LTMI_F64);
+    c->f64 = (result_dtype == LTMI_F64) || int_result;
+    c->int_result = int_result ? 1 : 0;
     const float *vals = (const float *)data;              // (f64: `data` holds doubles, see below)
     const double *vals64 = (const double *)data;
+    const int64_t *vals_i = (const int64_t *)data;        // (integer results: int64 values)
+    if (int_result) {
+        // largest possible |column sum|: decides (with the tile dtype) whether the float64 chain is exact
+        std::vector<double> col_abs((size_t)n_masks, 0.);
+        for (int64_t e = 0; e < nnz; ++e)
+            col_abs[(size_t)indices[e]] += std::fabs((double)vals_i[e]);
+        double worst = 0.;
+        for (double v : col_abs) worst = std::max(worst, v);
+        int bits = 0;
+        while (bits < 64 && std::ldexp(1.0, bits) <= worst) ++bits;
+        c->sum_bits = bits;
+    }
 
     // slice id of mask k: ((pass * n_chunks + chunk) * mpt + slot) * 4 + wave ; lane = (k%256)/4
     const size_t n_slices = (size_t)c->n_pass * c->n_chunks * c->mpt * 4;
@@ -516,7 +599,7 @@ extern "C" int ltmi_masks_create_csr(int device, const int64_t *indptr, const in
                 const int j = fill[(size_t)ch * n_masks + k]++;
                 const size_t pos = ((size_t)row_off[(size_t)ai * NWS + slice_of(k)] + j) * 64 + lane;
                 pix[pos] = (uint32_t)(p - (int64_t)ch * SP_P);
-                if (c->f64) val64[pos] = vals64[e];
+                if (c->f64) val64[pos] = int_result ? (double)vals_i[e] : vals64[e];
                 else
                     for (int q = 0; q < nc; ++q) val[pos * nc + q] = vals[e * nc + q];
             }

@@ -215,7 +215,13 @@ class MaskHandle:
         result_dtype = np.dtype(result_dtype)
         indptr = np.ascontiguousarray(csr_px_by_masks.indptr, dtype=np.int64)
         indices = np.ascontiguousarray(csr_px_by_masks.indices, dtype=np.int64)
-        data = np.ascontiguousarray(csr_px_by_masks.data.astype(result_dtype, copy=False))
+        if result_dtype.kind in 'iu':
+            # integer results: int64 values (the library keeps them as doubles: exact, see
+            # csrc/ltmi_sparse.hip csr_apply); uint64 values beyond 2^63 do not fit
+            data = np.ascontiguousarray(csr_px_by_masks.data.astype(result_dtype, copy=False)
+                                        .astype(np.int64))
+        else:
+            data = np.ascontiguousarray(csr_px_by_masks.data.astype(result_dtype, copy=False))
         n_px, n_masks = csr_px_by_masks.shape
         out = ctypes.c_void_p()
         check(lib().ltmi_masks_create_csr(

@@ -221,10 +221,14 @@ class ApplyMasksEngine:
                 dev = plan_state[key] = torch.from_numpy(c).to(f'cuda:{self.device}')
             self._const = dev
 
-    def _get_handle(self):
+    def _get_handle(self, tile_dtype=None):
+        # (tile_dtype: an integer sparse stack stays sparse where the product with tiles of that
+        # dtype is exact in float64 -- common/container.py; only asked for integer results)
+        ask = tile_dtype is not None and np.dtype(self.result_dtype).kind in 'iu'
         return self.masks.get_handle_for_sig_slice(
             self.meta.sig_slice, self.result_dtype, self.device,
-            real_frames=np.dtype(self.meta.input_dtype).kind != 'c')
+            real_frames=np.dtype(self.meta.input_dtype).kind != 'c',
+            tile_dtypes=(tile_dtype,) if ask else ())
 
     def process_tile(self, tile, out=None, accumulate=False):
         """
@@ -240,7 +244,7 @@ class ApplyMasksEngine:
             # a region of interest as a row list over the resident frames: the dense float32 kernels
             # read the selected frames in place; anything else gets them gathered
             if out is not None and self._const is None and np.dtype(tile.dtype).kind != 'c':
-                handle = self._get_handle()
+                handle = self._get_handle(tile.dtype)
                 if handle.n_px == n_px and out.shape[0] == n and \
                         prod(out.shape[1:]) == handle.n_masks and \
                         handle.apply_rows(tile.base.data_ptr(), tile.dtype, tile.rows_ptr(), n,
@@ -267,7 +271,7 @@ class ApplyMasksEngine:
             handle.apply(tile.data_ptr(), real, n, 2 * tile.ld, out.data_ptr(), 2 * out.ld,
                          accumulate, stream=self.stream_ptr)
             return out
-        handle = self._get_handle()
+        handle = self._get_handle(tile.dtype)
         if handle.n_px != n_px:
             raise ValueError(f"tile has {n_px} px per frame, mask slice has {handle.n_px}")
         if out is None:

@@ -640,6 +640,43 @@ def test_sell_random(hip, shape, tile_dtype, sparse_kernel):
     assert np.all(np.abs(resc.view(np.complex64).reshape(refc.shape) - refc) <= 2e-5 * scale + 1e-30)
 
 
+@pytest.mark.parametrize('tile_dtype,result_dtype', [
+    ('uint8', 'int64'), ('uint16', 'int64'), ('int16', 'int32'), ('uint16', 'uint16'), ('uint32', 'int64'),
+    ('int8', 'uint8'),
+])
+def test_sparse_integer_results_bit_exact(hip, tile_dtype, result_dtype):
+    """Integer sparse stacks through ltmi_masks_create_csr: float64 gather + truncation to the result
+    width = integer matmul with wrap-around, accumulate included; a product that can exceed 2^52 is
+    refused (the caller densifies)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(hash((tile_dtype, result_dtype)) % (2**32))
+    n_frames, n_px, n_masks = 70, 3000, 37
+    dt, rd = np.dtype(tile_dtype), np.dtype(result_dtype)
+    info = np.iinfo(dt)
+    data = rng.integers(max(info.min, -30000), min(info.max, 60000), (n_frames, n_px)).astype(dt)
+    dense = np.where(rng.random((n_masks, n_px)) < 0.02, rng.integers(-7, 8, (n_masks, n_px)), 0)
+    m = sp.csr_matrix(dense.T.astype(np.int64))                       # (px, masks)
+    h = hip.MaskHandle.csr(0, m, rd)
+    t = _dev(data)
+    ref = (data.astype(np.int64) @ dense.T.astype(np.int64))
+    base = rng.integers(0, 100, (n_frames, n_masks)).astype(rd)
+    for acc in (False, True):
+        out = _dev(base.copy())
+        h.apply(t.data_ptr(), dt, n_frames, n_px, out.data_ptr(), n_masks, acc)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(rd)
+        want = (ref + (base.astype(np.int64) if acc else 0)).astype(rd)
+        assert np.array_equal(got, want)
+    assert 'k_sell_apply' in h.last_kernel() and 'exact-int' in h.last_kernel(), h.last_kernel()
+    h.close()
+    big = sp.csr_matrix((dense.T.astype(np.int64)) * (1 << 44))
+    hb = hip.MaskHandle.csr(0, big, np.int64)
+    out = _dev(np.zeros((n_frames, n_masks), np.int64))
+    with pytest.raises(Exception, match='2.52'):
+        hb.apply(t.data_ptr(), dt, n_frames, n_px, out.data_ptr(), n_masks, False)
+    hb.close()
+
+
 def test_sell_ring_stack_vs_oracle(hip, sparse_kernel):
     """C4-style stack: anti-aliased ring masks as CSR, on real-size frames (reduced nav)."""
     import scipy.sparse as sp

@@ -525,6 +525,57 @@ def test_sparse_complex128_stack_stays_sparse(ctx):
     assert np.allclose(got, reff, rtol=1e-12, atol=1e-12 * np.abs(reff).max())
 
 
+def test_sparse_integer_stack_stays_sparse(ctx):
+    """Integer sparse masks on integer frames: integer result dtype with NumPy's / SciPy's wrap-around
+    (reference: mask dtype = result_type(mask, frames), common/container.py + rmatmul), bit exact --
+    through the float64 gather kernel + truncation while every partial sum stays below 2^52, without
+    densifying the stack; a stack whose sums can exceed that goes to the dense integer kernels."""
+    import scipy.sparse as sp
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd import hip
+    rng = np.random.default_rng(77)
+    data = rng.integers(0, 60000, (3, 5, 64, 64)).astype(np.uint16)
+    dense = []
+    for _ in range(6):
+        keep = rng.random((64, 64)) < 0.03
+        dense.append(np.where(keep, rng.integers(-9, 10, (64, 64)), 0).astype(np.int64))
+    stack = np.stack(dense)
+    facs = [(lambda d=d: sp.csr_matrix(d)) for d in dense]
+    ref = np.tensordot(data.astype(np.int64), stack, axes=([2, 3], [1, 2]))
+    for ds in (_device_ds(ctx, data, 2), ctx.load('memory', data=data, num_partitions=2, sig_dims=2)):
+        hip.KernelTimer.start()
+        got = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(
+            mask_factories=facs, use_sparse='scipy.sparse', preferred_dtype=np.int64,
+            mask_dtype=np.int64))
+        kernels = {k for _, _, k in hip.KernelTimer.stop()}
+        assert kernels and all('k_sell_apply' in k and 'exact-int' in k for k in kernels), kernels
+        r = got['intensity'].data
+        assert r.dtype == np.int64 and np.array_equal(r, ref)
+    # a narrower integer result dtype
+    got16 = ctx.run_udf(dataset=ctx.load('memory', data=data, num_partitions=2, sig_dims=2),
+                        udf=ApplyMasksUDF(mask_factories=facs, use_sparse='scipy.sparse',
+                                          mask_dtype=np.int16, preferred_dtype=np.int16)
+                        )['intensity'].data
+    # (result_type(int16, uint16) = int32; the wrap-around of narrow result dtypes is checked at the
+    # kernel level: test_kernels_gpu.py::test_sparse_integer_results_bit_exact)
+    assert got16.dtype == np.int32 and np.array_equal(got16, ref.astype(np.int32))
+    # with a region of interest (row list over the resident frames)
+    roi = rng.random((3, 5)) < 0.5
+    part = ctx.run_udf(dataset=_device_ds(ctx, data, 2), roi=roi,
+                       udf=ApplyMasksUDF(mask_factories=facs, use_sparse='scipy.sparse',
+                                         preferred_dtype=np.int64, mask_dtype=np.int64))
+    assert np.array_equal(part['intensity'].raw_data, ref[roi])
+    # sums that can exceed 2^52: still exact, on the dense integer kernels
+    huge = [(lambda d=d: sp.csr_matrix(d * (1 << 40))) for d in dense]
+    hip.KernelTimer.start()
+    got = ctx.run_udf(dataset=ctx.load('memory', data=data, num_partitions=2, sig_dims=2),
+                      udf=ApplyMasksUDF(mask_factories=huge, use_sparse='scipy.sparse',
+                                        preferred_dtype=np.int64, mask_dtype=np.int64))
+    kernels = {k for _, _, k in hip.KernelTimer.stop()}
+    assert kernels and not any('k_sell_apply' in k for k in kernels), kernels
+    assert np.array_equal(got['intensity'].data, ref * (1 << 40))
+
+
 def test_masks_modified_in_place_between_runs(ctx):
     """The reference evaluates the mask factories on every run (udf/masks.py:331-351): an array the
     factory closes over may change between two run_udf calls.  The cached device image / the cached
