@@ -68,7 +68,10 @@ def _sparse_int_exact(csr_px_by_masks, tile_dtypes):
         bits = max(bits, b)
     if csr_px_by_masks.nnz == 0:
         return True
-    worst = int(np.max(abs(csr_px_by_masks).sum(axis=0)))
+    from libertem_amd.hip import signed_representative
+    mags = sp.csr_matrix((np.abs(signed_representative(csr_px_by_masks.data)), csr_px_by_masks.indices,
+                          csr_px_by_masks.indptr), shape=csr_px_by_masks.shape)
+    worst = int(np.max(mags.sum(axis=0)))
     return bits + worst.bit_length() <= 52
 
 

@@ -179,6 +179,17 @@ def _stream_ptr(stream):
     return ctypes.c_void_p(stream.cuda_stream)
 
 
+def signed_representative(values):
+    """Integer mask values as int64 for an integer product that is truncated to the width of their
+    dtype afterwards: unsigned values are read as the signed numbers of the same width (65530 as uint16
+    is -6 modulo 2^16) -- the same result, the smallest magnitudes (the float64 route of the sparse
+    integer product is exact while the column sums of |values| stay small)."""
+    values = np.asarray(values)
+    if values.dtype.kind == 'u':
+        values = values.view(np.dtype(f'i{values.dtype.itemsize}'))
+    return values.astype(np.int64)
+
+
 class MaskHandle:
     """Owns one `ltmi_masks*` (device image of a sig-sliced, flattened mask stack)."""
 
@@ -218,8 +229,8 @@ class MaskHandle:
         if result_dtype.kind in 'iu':
             # integer results: int64 values (the library keeps them as doubles: exact, see
             # csrc/ltmi_sparse.hip csr_apply); uint64 values beyond 2^63 do not fit
-            data = np.ascontiguousarray(csr_px_by_masks.data.astype(result_dtype, copy=False)
-                                        .astype(np.int64))
+            data = np.ascontiguousarray(signed_representative(
+                csr_px_by_masks.data.astype(result_dtype, copy=False)))
         else:
             data = np.ascontiguousarray(csr_px_by_masks.data.astype(result_dtype, copy=False))
         n_px, n_masks = csr_px_by_masks.shape

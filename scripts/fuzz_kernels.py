@@ -35,7 +35,7 @@ def gen(dt, shape):
 
 fails = 0
 for case in range(n_cases):
-    kind = rng.choice(['dense', 'dense', 'dense', 'shift', 'sparse', 'int'])
+    kind = rng.choice(['dense', 'dense', 'dense', 'shift', 'sparse', 'int', 'sparse_int', 'split'])
     n_frames = int(rng.choice([1, 3, 15, 16, 17, 100, 129, 300, 777]))
     tdt = np.dtype(rng.choice(TILE_DTYPES))
     accumulate = bool(rng.integers(0, 2))
@@ -87,6 +87,36 @@ for case in range(n_cases):
             ref = data[:, :n_px].astype(np.complex128 if mdt.kind == 'c' else np.float64) @ \
                 dense.astype(np.complex128 if mdt.kind == 'c' else np.float64)
             scale = np.abs(data[:, :n_px].astype(np.float64)) @ np.abs(dense).astype(np.float64)
+        elif kind == 'sparse_int':
+            # integer sparse stack x integer frames: float64 gather + truncation (exact), wrap-around
+            if tdt.kind not in 'iu' or tdt.itemsize > 4:
+                tdt = np.dtype(rng.choice(['uint8', 'uint16', 'int16', 'int32'])); data = gen(tdt, (n_frames, ld))
+            rd = np.dtype(rng.choice(['int32', 'int64', 'uint16', 'uint8']))
+            if rng.random() < 0.3:
+                n_masks = int(rng.choice([130, 300]))
+            dense = ((rng.random((n_px, n_masks)) < 0.08) * rng.integers(-6, 7, (n_px, n_masks))).astype(np.int64)
+            handle = hip.MaskHandle.csr(0, sp.csr_matrix(dense), rd)
+            ref = data[:, :n_px].astype(np.int64) @ dense
+            scale = None
+        elif kind == 'split':
+            # float32 frames on the bf16 x 3 split kernel (tuning 36) where it applies, else as dispatched
+            tdt = np.dtype('float32')
+            n_px = int(rng.choice([512, 1024, 2048, 4096, 64 * 37]))
+            ld = n_px + pad
+            data = gen(tdt, (n_frames, ld))
+            data[:, ::5] *= np.float32(1e-4)
+            mdt = np.dtype(rng.choice(['float32', 'complex64']))
+            n_masks = int(rng.choice([17, 20, 25, 32, 40, 50, 64])) // (2 if mdt.kind == 'c' else 1)
+            masks = rng.random((n_masks, n_px)) - 0.25
+            if mdt.kind == 'c':
+                masks = masks + 1j * (rng.random((n_masks, n_px)) - 0.5)
+            masks = masks.astype(mdt)
+            rd = mdt
+            handle = hip.MaskHandle.dense(0, masks, rd)
+            handle.set_tuning(mt=0, waves=36, ksplit=int(rng.choice([0, 0, 3])))
+            wide = np.complex128 if rd.kind == 'c' else np.float64
+            ref = data[:, :n_px].astype(wide) @ masks.astype(wide).T
+            scale = np.abs(data[:, :n_px].astype(np.float64)) @ np.abs(masks).astype(np.float64).T
         elif kind == 'int':
             if tdt.kind not in 'iu':
                 tdt = np.dtype('int16'); data = gen(tdt, (n_frames, ld))
@@ -146,9 +176,9 @@ for case in range(n_cases):
         kernels_seen[kern] = kernels_seen.get(kern, 0) + 1
         expect = ref + base if accumulate else ref
         if rd.kind in 'iu':
-            ok = np.array_equal(res, expect.astype(rd))
+            ok = np.array_equal(res, (expect.astype(np.int64) if expect.dtype.kind in 'iu' else expect).astype(rd))
         else:
-            tol = 1e-5 if rd in (np.float32, np.complex64) else 1e-12
+            tol = (2e-6 if kind == 'split' else 1e-5) if rd in (np.float32, np.complex64) else 1e-12
             ok = bool(np.all(np.abs(res - expect) <= tol * (scale + 1)))
         if not ok:
             fails += 1
