@@ -358,7 +358,7 @@ def measure(wl, steps, warmup, barrier, hip, n_check=32):
                 launches_timed=len(kms), frames_per_launch=frames_per_launch,
                 algorithmic_bytes_per_launch=alg_bytes,
                 algorithmic_flops_per_launch=cfg['flops'] * frames_per_launch,
-                mfma_f32_TFLOPs=tfs)
+                algorithmic_TFLOPs=tfs)
     return dict(elapsed=elapsed, ms_per_step=elapsed / steps * 1e3, roofline=roof,
                 kernel_ms_per_step=float(np.sum(kms)) / steps, check_rel_err=err,
                 preheat_steps=preheat)
@@ -666,9 +666,11 @@ def main():
         "config": {
             "workload": cfg['desc'] + f", per GPU; {world} GPU(s), nav-sharded (weak)",
             "frames_per_gpu": n_frames, "frame_bytes": n_px * itemsize,
-            "arithmetic": "frames converted to f32 in-kernel, exact f32 FMA chain on the "
-                          "matrix cores (v_mfma_f32_16x16x4_f32), f32 / complex64 masks and "
-                          "results",
+            "arithmetic": "float32 sums on the matrix cores of products that are formed exactly: "
+                          "uint16 pixels as two bytes x float32 weights as two float16 pieces of "
+                          "the column-scaled value (22 bits; v_mfma_f32_16x16x32_f16, k_dense_lds "
+                          "X16) -- kernels labelled ',f16'; other pixel types: pixels converted to "
+                          "f32 in-kernel, v_mfma_f32_16x16x4_f32.  f32 / complex64 masks and results",
             "step": "Context.run_udf / Context.run (plan + kernels + delivery of the complete "
                     "result to every rank's host)",
             "parallelism": f"nav-shard x{world}; results via {result_via}",

@@ -143,6 +143,10 @@ struct ltmi_masks {
     float *img3 = nullptr;   // ng3 groups + ne3 VALU columns (16 ng3 + 1..4 columns), slots of 128 px
     int n_slots3 = 0, ne3 = 0, ng3 = 0;   // ng3 full groups + ne3 VALU columns
     void *split = nullptr;   // bf16 x 3 image for float32 frames (ltmi_split.hip), stacks of >= 2 groups
+    // float16 image of the standard (ng = 1) layout for unsigned 1- / 2-byte pixels (k_dense_lds X16):
+    // w1 / w2 of the scaled weights in the two 16-byte units of a lane's 8 pixels; 1 / scale per column
+    float *img_h = nullptr;
+    float *inv_scale = nullptr;
     // float64 results on the f64 matrix cores (ltmi_dense64.hip)
     double *img64 = nullptr;
     int n_groups64 = 0, n_chunks64 = 0;

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <typeinfo>
+#include <cmath>
 #include <type_traits>
 #include <unordered_map>
 
@@ -27,6 +28,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int KC = 256;                    // pixels per staged mask chunk
 constexpr int GROUP = 16;                  // mask columns per MFMA group (N of 16x16x4)
@@ -58,6 +61,32 @@ __global__ void k_build_image(const float *__restrict__ src, float *__restrict__
         const int g = col / GROUP, n = col % GROUP;
         const int c = (int)(p / KC), q = (int)(p % KC);
         img[((size_t)g * n_chunks + c) * CHUNK_FLOATS + img_index(n, q)] = src[i];
+    }
+}
+
+// the float16 image of the same geometry (k_dense_lds X16): pixel q = blk*32 + kg*8 + j of column n has
+// w1 at 2-byte position j of the unit (kg*16 + blk*2 + 0) ^ n and w2 at position j of the unit
+// (.. + 1) ^ n, where w * scale[column] = w1 + w2 in float16 (round to nearest, then the residual)
+__global__ void k_build_image_h16(const float *__restrict__ src, _Float16 *__restrict__ img,
+                                  int64_t n_masks, int cpm, int64_t n_px, int n_chunks,
+                                  const float *__restrict__ scale) {
+    const int64_t total = n_masks * cpm * n_px;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int part = (int)(i % cpm);
+        const int64_t kp = i / cpm;
+        const int64_t k = kp / n_px, p = kp % n_px;
+        const int col = (int)(k * cpm + part);
+        const int g = col / GROUP, n = col % GROUP;
+        const int c = (int)(p / KC), q = (int)(p % KC);
+        const int blk = q >> 5, kg = (q >> 3) & 3, j = q & 7;
+        const float ws = src[i] * scale[col];             // (power-of-two scale: exact)
+        const _Float16 w1 = (_Float16)ws;
+        const _Float16 w2 = (_Float16)(ws - (float)w1);
+        _Float16 *block = img + (((size_t)g * n_chunks + c) * CHUNK_FLOATS) * 2;
+        const int u1 = (kg * 16 + blk * 2) ^ n, u2 = (kg * 16 + blk * 2 + 1) ^ n;
+        block[(n * KC + u1 * 4) * 2 + j] = w1;
+        block[(n * KC + u2 * 4) * 2 + j] = w2;
     }
 }
 
@@ -454,13 +483,27 @@ __global__ void k_build_image3(const float *__restrict__ src, float *__restrict_
     }
 }
 
-template <typename T, int NG, int ABL = 0, int IND = 0, int NE = 0, int TILES = 1>
+// X16 (unsigned 1- and 2-byte pixels, no VALU columns): the products are formed EXACTLY from float16
+// operands on v_mfma_f32_16x16x32_f16 instead of converting the pixels to float32 -- a pixel is
+// lo + 256 hi (two bytes, each a float16 number: 0x6400 | b is 1024 + b, one v_perm_b32 and one
+// v_pk_add_f16 per pixel pair), a weight times its column's power-of-two scale is w1 + w2 (two float16,
+// 22 bits; the image holds w1 of the lane's 8 pixels in the 16-byte unit h = 0 and w2 in h = 1: same
+// bytes, same addresses as the float32 image).  lo w1 + lo w2 go to one accumulator, hi w1 + hi w2 to a
+// second one that counts 256-fold: 4 x 16 matrix-pipe cycles per 16 frames x 16 columns x 32 pixels where
+// float32 takes 8 x 32 -- these kernels run at the board's power cap with the f32 pipe 65 % busy (C2),
+// so the pipe's energy is time.  Same scheme as k_bell_flat (ltmi_bell.hip); `inv_scale`: 1 / scale
+// per column, applied to the sums.
+template <typename T, int NG, int ABL = 0, int IND = 0, int NE = 0, int TILES = 1, bool X16 = false>
 __global__ void __launch_bounds__(512 / TILES)                  // LdsCfg::WAVES * 64
 k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
             const float *__restrict__ img, int n_slots, float *__restrict__ out, int64_t ld_out,
             int n_cols, int accumulate, float *__restrict__ partials, int ksplit,
             const int32_t *__restrict__ rows = nullptr,
-            const float *const *__restrict__ wg_img = nullptr, int *__restrict__ kcount = nullptr) {
+            const float *const *__restrict__ wg_img = nullptr, int *__restrict__ kcount = nullptr,
+            const float *__restrict__ inv_scale = nullptr) {
+    static_assert(!X16 || (NE == 0 && NG >= 1 && IND != 1 && ABL == 0 &&
+                           (std::is_same<T, uint16_t>::value || std::is_same<T, uint8_t>::value)),
+                  "X16: unsigned 1- / 2-byte pixels on the matrix cores only");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     using TR = InTraits<T>;
     using CFG = LdsCfg<NG, NE, TILES>;
@@ -483,7 +526,8 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
     constexpr int NBI = BPW / 1024;                     // ... in this many DMA instructions
     constexpr int A_N = ND * (RING - 2);                // DMA instructions of the later sub-chunks
     static_assert(A_N + 2 * NBI < 64, "vmcnt is a 6-bit counter");
-    constexpr int NACC = NG == 1 ? 2 : 1;               // accumulators per group and frame tile
+    // accumulators per group and frame tile (X16: [0] the low bytes' products, [1] the high bytes')
+    constexpr int NACC = (NG == 1 || X16) ? 2 : 1;
     constexpr int SLOT_FLOATS = BSLOT / 4;
     constexpr bool CVT = !std::is_same<T, float>::value;
 
@@ -554,6 +598,38 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
     const int b_lane = m * KB;                           // floats inside a group of a mask slot
     auto b_unit = [&](int blk_in_slot, int h) {          // swizzled 16-B unit of (blk, h) for this lane
         return ((kg * (KB / 16) + blk_in_slot * 2 + h) ^ m) << 2;
+    };
+    // X16: the lane's 8 raw pixels -> float16 operands of their low and high bytes
+    auto bytes_f16 = [&](const auto &r, h16x8 &lo, h16x8 &hi) {
+        const h16x2 kbias = {(_Float16)1024.f, (_Float16)1024.f};
+        h16x2 l[4], h[4];
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                l[i] = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0x64646464u, r[i], 0x04020400u)) - kbias;
+                h[i] = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0x64646464u, r[i], 0x04030401u)) - kbias;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                l[2 * i] = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0x64646464u, r[i], 0x04010400u)) - kbias;
+                l[2 * i + 1] = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0x64646464u, r[i], 0x04030402u)) - kbias;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h[i] = h16x2{(_Float16)0.f, (_Float16)0.f};
+        }
+        lo = h16x8{l[0][0], l[0][1], l[1][0], l[1][1], l[2][0], l[2][1], l[3][0], l[3][1]};
+        hi = h16x8{h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]};
+    };
+    // (tile tl, group g) += the block's products; bw1 / bw2: the two 16-byte units of the mask fragment
+    auto mfma_x16 = [&](int tl, int g, const h16x8 &lo, const h16x8 &hi, const f32x4 &bw1, const f32x4 &bw2) {
+        const h16x8 w1 = __builtin_bit_cast(h16x8, bw1), w2 = __builtin_bit_cast(h16x8, bw2);
+        acc[tl][g][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo, w2, acc[tl][g][0], 0, 0, 0);
+        acc[tl][g][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo, w1, acc[tl][g][0], 0, 0, 0);
+        if constexpr (sizeof(T) == 2) {
+            acc[tl][g][NACC - 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, w2, acc[tl][g][NACC - 1], 0, 0, 0);
+            acc[tl][g][NACC - 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, w1, acc[tl][g][NACC - 1], 0, 0, 0);
+        }
     };
 
     if (k_begin < kf_end) {
@@ -691,6 +767,15 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                     if ((t * BLKS) / ND == blk) issue_a1(s + RING - 1, nslot, t);
                 __builtin_amdgcn_sched_barrier(0);      // keep the prefetch reads above the MFMAs
                 float a[TILES][8];
+                if constexpr (X16) {
+                    h16x8 lo[TILES], hi[TILES];
+#pragma unroll
+                    for (int tl = 0; tl < TILES; ++tl) bytes_f16(raw_c[tl], lo[tl], hi[tl]);
+#pragma unroll
+                    for (int tl = 0; tl < TILES; ++tl)
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) mfma_x16(tl, g, lo[tl], hi[tl], b_c[g][0], b_c[g][1]);
+                } else {
 #pragma unroll
                 for (int tl = 0; tl < TILES; ++tl) TR::cvt(raw_c[tl], a[tl]);
                 if (ABL == 1) {
@@ -714,6 +799,7 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                         if (CVT) __builtin_amdgcn_sched_group_barrier(0x002, 8 * TILES, 0);  // conversions
                         __builtin_amdgcn_sched_group_barrier(0x008, 8 * NG * TILES, 0);      // then the MFMAs
                     }
+                }
                 }
                 // VALU columns, two at a time (v_pk_fma_f32: the pixel value is broadcast, the two
                 // columns' mask values sit next to each other in the slot)
@@ -765,7 +851,9 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                         for (int g = 0; g < NG; ++g)
 #pragma unroll
                             for (int x = 0; x < NACC; ++x) {
-                                acc2[tl][g] += acc[tl][g][x];
+                                // (X16: [1] holds the high bytes' products)
+                                if (X16 && x == 1) acc2[tl][g] += acc[tl][g][x] * 256.f;
+                                else acc2[tl][g] += acc[tl][g][x];
                                 acc[tl][g][x] = f32x4{0.f, 0.f, 0.f, 0.f};
                             }
                 }
@@ -795,6 +883,26 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
 #pragma unroll
             for (int blk = 0; blk < KB / 32; ++blk) {
                 const int64_t p0 = (int64_t)k * KB + blk * 32;
+                if constexpr (X16) {
+                    typename TR::raw_t raw;
+#pragma unroll
+                    for (int i = 0; i < (int)(8 * sizeof(T) / 4); ++i) {
+                        unsigned w = 0;
+#pragma unroll
+                        for (int e = 0; e < (int)(4 / sizeof(T)); ++e) {
+                            const int j = i * (int)(4 / sizeof(T)) + e;
+                            const unsigned v = (p0 + kg * 8 + j < n_px) ? (unsigned)rowp[p0 + j] : 0u;
+                            w |= v << (8 * (int)sizeof(T) * e);
+                        }
+                        raw[i] = w;
+                    }
+                    h16x8 lo, hi;
+                    bytes_f16(raw, lo, hi);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                        mfma_x16(tl, g, lo, hi, *(const f32x4 *)(ldsb + g * (GROUP * KB) + b_unit(blk, 0)),
+                                 *(const f32x4 *)(ldsb + g * (GROUP * KB) + b_unit(blk, 1)));
+                } else {
                 float a[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
@@ -816,6 +924,7 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                     for (int j = 0; j < 8; ++j)
                         acc_e[tl][c / 2][c & 1] += a[j] * bl[CFG::EXTRA_OFF + (c / 2) * (2 * KB) +
                                                             (blk * 32 + kg * 8 + j) * 2 + (c & 1)];
+                }
             }
         }
     }
@@ -830,8 +939,10 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                 const int col = (gt * NG + g) * GROUP + m;
                 if (f >= 0 && col < n_cols) {
                     float v = acc[tl][g][0][r];
-                    if (NACC == 2) v += acc[tl][g][NACC - 1][r];
+                    if (X16) v += 256.f * acc[tl][g][NACC - 1][r];
+                    else if (NACC == 2) v += acc[tl][g][NACC - 1][r];
                     v += acc2[tl][g][r];
+                    if (X16) v *= inv_scale[col];             // undo the column's power-of-two scale
                     if (ksplit == 1) {
                         float *p = out + f * ld_out + col;
                         *p = accumulate ? (*p + v) : v;
@@ -1203,6 +1314,50 @@ extern "C" int ltmi_masks_create_dense(int device, const void *masks_host, int r
             e = hipGetLastError();
             if (e == hipSuccess) e = hipDeviceSynchronize();
         }
+        // one column group with 5 .. 16 columns (fewer: the VALU-only kernel), finite weights: the
+        // float16 image for unsigned 1- / 2-byte pixels (k_dense_lds X16).  LTMI_DENSE_F16=0: never.
+        if (e == hipSuccess && m->ng == 1 && m->n_groups == 1 && m->n_cols > 4) {
+            const char *off = getenv("LTMI_DENSE_F16");
+            const float *hm = (const float *)masks_host;      // (n_masks, n_px, cpm) float32 on the host
+            std::vector<float> amax((size_t)m->n_cols, 0.f);
+            bool finite = !(off && atoi(off) == 0);
+            for (int64_t k = 0; k < n_masks && finite; ++k)
+                for (int64_t p = 0; p < n_px && finite; ++p)
+                    for (int c2 = 0; c2 < cpm; ++c2) {
+                        const float v = hm[(k * n_px + p) * cpm + c2];
+                        if (!std::isfinite(v)) { finite = false; break; }
+                        float &mx = amax[(size_t)(k * cpm + c2)];
+                        mx = std::max(mx, std::fabs(v));
+                    }
+            if (finite) {
+                std::vector<float> scale((size_t)m->n_cols, 1.f), inv((size_t)m->n_cols, 1.f);
+                for (int k = 0; k < m->n_cols; ++k)
+                    if (amax[(size_t)k] > 0.f) {
+                        int ex;
+                        (void)std::frexp(amax[(size_t)k], &ex);           // amax = f 2^ex, f in [0.5, 1)
+                        const int sh = std::max(-120, std::min(120, 7 - ex));   // amax 2^sh in [64, 128)
+                        scale[(size_t)k] = std::ldexp(1.0f, sh);
+                        inv[(size_t)k] = std::ldexp(1.0f, -sh);
+                    }
+                float *scale_dev = nullptr;
+                e = hipMalloc((void **)&m->img_h, n_float * sizeof(float));
+                if (e == hipSuccess) e = hipMemset(m->img_h, 0, n_float * sizeof(float));
+                if (e == hipSuccess) e = hipMalloc((void **)&m->inv_scale, inv.size() * sizeof(float));
+                if (e == hipSuccess) e = hipMalloc((void **)&scale_dev, scale.size() * sizeof(float));
+                if (e == hipSuccess) e = hipMemcpy(m->inv_scale, inv.data(), inv.size() * sizeof(float), hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipMemcpy(scale_dev, scale.data(), scale.size() * sizeof(float), hipMemcpyHostToDevice);
+                if (e == hipSuccess) {
+                    const int64_t total = n_masks * cpm * n_px;
+                    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 65535 * 16);
+                    hipLaunchKernelGGL(ltmi::k_build_image_h16, dim3(blocks), dim3(256), 0, 0,
+                                       (const float *)m->gmasks, (_Float16 *)m->img_h, n_masks, cpm, n_px,
+                                       m->n_chunks, (const float *)scale_dev);
+                    e = hipGetLastError();
+                    if (e == hipSuccess) e = hipDeviceSynchronize();
+                }
+                if (scale_dev) (void)hipFree(scale_dev);
+            }
+        }
         if (e == hipSuccess && m->ng > 1) {
             // slot-major image for the LDS-DMA kernel with several column groups (k_dense_lds)
             constexpr int kb = 128;
@@ -1296,6 +1451,8 @@ extern "C" int ltmi_masks_destroy(ltmi_masks *m) {
     if (m->img3) (void)hipFree(m->img3);
     ltmi::split_destroy(m->split);
     m->split = nullptr;
+    if (m->img_h) (void)hipFree(m->img_h);
+    if (m->inv_scale) (void)hipFree(m->inv_scale);
     ltmi::dense64_destroy(m);
     shift_cache_destroy(m);
     if (m->partials) (void)hipFree(m->partials);
@@ -1313,9 +1470,10 @@ extern "C" int ltmi_masks_kind(const ltmi_masks *m, int *kind) {
 
 extern "C" int ltmi_masks_set_tuning(ltmi_masks *m, int mt, int waves, int ksplit) {
     if (!m) LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_set_tuning: null handle");
-    if (mt == 0 && ((waves >= 30 && waves <= 36) || (waves >= 40 && waves <= 41))) {
+    if (mt == 0 && ((waves >= 30 && waves <= 37) || (waves >= 40 && waves <= 41))) {
         // k_dense_lds: 30 = as dispatched, 31 / 32 = timing-only ablations (no DMA / no MFMA),
         // 34 / 35 = one / two frame tiles per wave; 36 = k_dense_split (float32 frames, ltmi_split.hip);
+        // 37 = the float32 matrix instruction also where the exact float16 products (X16) apply;
         // sparse stacks: 40 = as dispatched, 41 = SELL kernel even if a blocked image exists
         m->tune_mt = 0;
         m->tune_waves = 0;
@@ -1397,16 +1555,20 @@ static int launch_mfma_variant(ltmi_masks *m, const T *tile, int64_t n_frames, i
 // (ltmi_masks_set_tuning waves code 34 = one tile / 8 waves, 35 = two tiles / 4 waves)
 // kernel instantiation point.  -DLTMI_DENSE_EXP (experiment builds, scripts/dense_variant.sh): only the
 // C5 kernels (float frames, 3 groups + 0 / 2 VALU columns) are compiled -- a minute instead of five
-template <typename T, int NG, int ABL, int IND, int NE, int TILES>
+template <typename T, int NG, int ABL, int IND, int NE, int TILES, bool X16 = false>
 static auto lds_kernel() -> void (*)(const T *, int64_t, int64_t, int64_t, const float *, int, float *,
                                      int64_t, int, int, float *, int, const int32_t *,
-                                     const float *const *, int *) {
+                                     const float *const *, int *, const float *) {
 #ifdef LTMI_DENSE_EXP
-    if constexpr (!(std::is_same<T, float>::value && NG == 3 && ABL == 0 && IND == 0 && TILES == 2))
+    // (C5: float frames, 3 groups; C2 and its 1-byte sibling: one group, with and without X16)
+    if constexpr (!(ABL == 0 && IND == 0 && TILES == 2 &&
+                    ((std::is_same<T, float>::value && NG == 3) ||
+                     ((std::is_same<T, uint16_t>::value || std::is_same<T, uint8_t>::value) && NG == 1 &&
+                      NE == 0))))
         return nullptr;
     else
 #endif
-        return k_dense_lds<T, NG, ABL, IND, NE, TILES>;
+        return k_dense_lds<T, NG, ABL, IND, NE, TILES, X16>;
 }
 
 static inline int lds_tiles(const ltmi_masks *m) {
@@ -1420,21 +1582,30 @@ static int launch_lds_ng_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64
     using CFG = LdsCfg<NG, 0, TILES>;
     const int abl = m->tune_ksplit_ring == 31 ? 2 : (m->tune_ksplit_ring == 32 ? 1 : 0);
     void (*kern)(const T *, int64_t, int64_t, int64_t, const float *, int, float *, int64_t, int,
-                 int, float *, int, const int32_t *, const float *const *, int *) =
+                 int, float *, int, const int32_t *, const float *const *, int *, const float *) =
         abl == 2 ? lds_kernel<T, NG, 2, 0, 0, TILES>()
                  : (abl == 1 ? lds_kernel<T, NG, 1, 0, 0, TILES>()
                              : lds_kernel<T, NG, 0, 0, 0, TILES>());
     const int32_t *rows = m->roi_rows;                  // ltmi_apply_masks_rows: frames through a row list
     if (rows) kern = lds_kernel<T, NG, 0, 2, 0, TILES>();
+    // unsigned 1- / 2-byte pixels against one column group: exact float16 products (X16; tuning code
+    // 37 keeps the float32 instruction: tests, benches)
+    bool x16 = false;
+    if constexpr (NG == 1 && (std::is_same<T, uint16_t>::value || std::is_same<T, uint8_t>::value)) {
+        x16 = m->img_h != nullptr && abl == 0 && m->tune_ksplit_ring != 37;
+        if (x16)
+            kern = rows ? lds_kernel<T, NG, 0, 2, 0, TILES, true>()
+                        : lds_kernel<T, NG, 0, 0, 0, TILES, true>();
+    }
     if (!kern) return LTMI_E_DTYPE;
-    static bool attr_set[16][4] = {{false}};
-    const int variant = rows ? 3 : abl;
+    static bool attr_set[16][8] = {{false}};
+    const int variant = (rows ? 3 : abl) + (x16 ? 4 : 0);
     if (!attr_set[m->device & 15][variant]) {
         LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      CFG::LDS_BYTES));
         attr_set[m->device & 15][variant] = true;
     }
-    const float *img = NG == 1 ? m->img : m->img2;
+    const float *img = x16 ? m->img_h : (NG == 1 ? m->img : m->img2);
     const int n_slots = NG == 1 ? m->n_chunks : m->n_slots2;
     const int64_t gx = (n_frames + CFG::WG_ROWS - 1) / CFG::WG_ROWS;
     const int64_t gz = m->n_groups / NG;
@@ -1453,12 +1624,13 @@ static int launch_lds_ng_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64
     int *kcount = ksplit > 1 ? partial_counters(m, gx * gz) : nullptr;
     hipLaunchKernelGGL(kern, grid, dim3(CFG::WAVES * 64), CFG::LDS_BYTES, stream, tile, ld, n_frames,
                        m->n_px, img, n_slots, out, ld_out, m->n_cols, accumulate, partial_sums(m),
-                       ksplit, rows, (const float *const *)nullptr, kcount);
+                       ksplit, rows, (const float *const *)nullptr, kcount,
+                       x16 ? (const float *)m->inv_scale : (const float *)nullptr);
     LTMI_HIP(hipGetLastError());
     snprintf(m->last_kernel, sizeof(m->last_kernel),
-             "k_dense_lds<%s,NG=%d,ring=%d,tiles=%d%s> grid=(%u,%u,%u)", typeid(T).name(), NG,
-             CFG::RING, TILES, rows ? ",rows" : (abl ? (abl == 2 ? ",noDMA" : ",noMFMA") : ""),
-             grid.x, grid.y, grid.z);
+             "k_dense_lds<%s,NG=%d,ring=%d,tiles=%d%s%s> grid=(%u,%u,%u)", typeid(T).name(), NG,
+             CFG::RING, TILES, x16 ? ",f16" : "",
+             rows ? ",rows" : (abl ? (abl == 2 ? ",noDMA" : ",noMFMA") : ""), grid.x, grid.y, grid.z);
     if (ksplit > 1 && !kcount) {
         const int64_t n = n_frames * m->n_cols;
         hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
@@ -1509,7 +1681,8 @@ static int launch_lds_extras_t(ltmi_masks *m, const T *tile, int64_t n_frames, i
     int *kcount = ksplit > 1 ? partial_counters(m, gx) : nullptr;
     hipLaunchKernelGGL(kern, grid, dim3(CFG::WAVES * 64), CFG::LDS_BYTES, stream, tile, ld, n_frames,
                        m->n_px, (const float *)m->img3, n_slots, out, ld_out, m->n_cols, accumulate,
-                       partial_sums(m), ksplit, rows, (const float *const *)nullptr, kcount);
+                       partial_sums(m), ksplit, rows, (const float *const *)nullptr, kcount,
+                       (const float *)nullptr);
     LTMI_HIP(hipGetLastError());
     if (NE > 0)
         snprintf(m->last_kernel, sizeof(m->last_kernel),
@@ -1737,7 +1910,8 @@ static int launch_lds_shifted(ltmi_masks *m, const T *tile, int64_t n_frames, in
                            tile, ld, n_frames, m->n_px, (const float *)nullptr, m->n_chunks,
                            out + gi * GROUP, ld_out, std::min(GROUP, m->n_cols - gi * GROUP),
                            accumulate, (float *)nullptr, 1, (const int32_t *)c->rows_dev,
-                           (const float *const *)c->wg_img_dev + (size_t)gi * n_wg, (int *)nullptr);
+                           (const float *const *)c->wg_img_dev + (size_t)gi * n_wg, (int *)nullptr,
+                           (const float *)nullptr);
     LTMI_HIP(hipGetLastError());
     snprintf(m->last_kernel, sizeof(m->last_kernel),
              "k_dense_lds<%s,NG=1,shifted> grid=(%zu,1,1) x %d column group(s), shift groups=%zu",

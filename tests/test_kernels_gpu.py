@@ -150,6 +150,57 @@ def test_lds_dma_kernel_all_widths(hip, tile_dtype, shape, ksplit):
     assert np.all(np.abs(res2 - (ref + base)) <= 1e-5 * (scale + 1))
 
 
+@pytest.mark.parametrize('tile_dtype', ['uint8', 'uint16'])
+@pytest.mark.parametrize('shape,ksplit,mask_dtype', [
+    ((300, 256 * 41 + 112, 16), 0, 'float32'),      # unrolled loop + generic tail + ragged last slot
+    ((300, 256 * 41 + 112, 16), 3, 'float32'),      # ... with a K split
+    ((129, 256 * 8, 9), 0, 'float32'),
+    ((1000, 1024, 12), 0, 'float32'),
+    ((70, 515, 16), 0, 'float32'),                  # unaligned rows
+    ((200, 256 * 6 + 40, 8), 0, 'complex64'),       # 8 complex masks = 16 real columns
+])
+def test_exact_float16_products_for_unsigned_pixels(hip, tile_dtype, shape, ksplit, mask_dtype):
+    """k_dense_lds X16 (one column group, unsigned 1- / 2-byte pixels): pixel bytes x (w1 + w2) float16
+    pieces of the scaled weights on v_mfma_f32_16x16x32_f16 -- the default dispatch.  Float32
+    accuracy over the full pixel range and columns of very different magnitude (per-column scale),
+    agreement with the float32 instruction (tuning 37), integer-valued masks bit-exact, accumulate."""
+    n_frames, n_px, n_masks = shape
+    rng = np.random.default_rng(hash((tile_dtype,) + shape + (mask_dtype,)) % (2**32))
+    dt, md = np.dtype(tile_dtype), np.dtype(mask_dtype)
+    data = rng.integers(0, np.iinfo(dt).max, (n_frames, n_px), endpoint=True).astype(dt)
+    data[1 % n_frames] = np.iinfo(dt).max
+    data[2 % n_frames] = 0
+    masks = rng.random((n_masks, n_px)) - 0.25
+    if md.kind == 'c':
+        masks = masks + 1j * (rng.random((n_masks, n_px)) - 0.5)
+    masks[0] *= 1e-6                                  # columns of very different magnitude
+    masks[1] *= 3e4
+    masks[2 % n_masks] = 0
+    masks[3 % n_masks, ::3] *= 1e-4                   # small next to large inside one column
+    masks = masks.astype(md)
+    ref = _ref64(data, masks)
+    scale = np.abs(data.astype(np.float64)) @ np.abs(masks).astype(np.float64).T
+    tuning = dict(mt=0, waves=30, ksplit=ksplit) if ksplit else None
+    res, kern = _apply(hip, data, masks, md, tuning=tuning)
+    assert 'k_dense_lds' in kern and ',f16' in kern, kern
+    assert np.all(np.abs(res - ref) <= 2e-6 * scale + 1e-30), np.max(np.abs(res - ref) / (scale + 1e-30))
+    res32, kern32 = _apply(hip, data, masks, md, tuning=dict(mt=0, waves=37, ksplit=ksplit))
+    assert 'k_dense_lds' in kern32 and ',f16' not in kern32, kern32
+    assert np.all(np.abs(res32 - res) <= 1e-5 * scale + 1e-30)
+    base = (rng.random((n_frames, n_masks)) + (1j * rng.random((n_frames, n_masks))
+                                               if md.kind == 'c' else 0)).astype(md)
+    res2, _ = _apply(hip, data, masks, md, accumulate_into=base, tuning=tuning)
+    assert np.all(np.abs(res2 - (ref + base)) <= 2e-6 * (scale + 1))
+    if md.kind == 'f':
+        # integer-valued masks, sums below 2^24: both instructions give the exact integers
+        small = (data % 16).astype(dt)
+        imasks = rng.integers(0, 4, (n_masks, n_px)).astype(np.float32)
+        exact = small.astype(np.int64) @ imasks.astype(np.int64).T
+        assert exact.max() < 2**24
+        ri, ki = _apply(hip, small, imasks, np.float32, tuning=tuning)
+        assert ',f16' in ki and np.array_equal(ri, exact.astype(np.float32))
+
+
 def test_mfma_integer_exact(hip):
     # 0/1 masks on low-count data: every partial sum is an integer < 2**24 -> any order exact
     rng = np.random.default_rng(11)
