@@ -146,6 +146,8 @@ struct ltmi_masks {
     // float16 image of the standard (ng = 1) layout for unsigned 1- / 2-byte pixels (k_dense_lds X16):
     // w1 / w2 of the scaled weights in the two 16-byte units of a lane's 8 pixels; 1 / scale per column
     float *img_h = nullptr;
+    float *img2_h = nullptr;     // ... of image 2 (ng > 1)
+    float *img3_h = nullptr;     // ... of image 3 without VALU columns (3 groups)
     float *inv_scale = nullptr;
     // float64 results on the f64 matrix cores (ltmi_dense64.hip)
     double *img64 = nullptr;

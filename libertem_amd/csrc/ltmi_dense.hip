@@ -64,13 +64,24 @@ __global__ void k_build_image(const float *__restrict__ src, float *__restrict__
     }
 }
 
-// the float16 image of the same geometry (k_dense_lds X16): pixel q = blk*32 + kg*8 + j of column n has
-// w1 at 2-byte position j of the unit (kg*16 + blk*2 + 0) ^ n and w2 at position j of the unit
-// (.. + 1) ^ n, where w * scale[column] = w1 + w2 in float16 (round to nearest, then the residual)
+// the float16 images of the same geometries (k_dense_lds X16): where the float32 image has pixels
+// q .. q+3 of column n in the 16-byte unit (U + 0) ^ n and q+4 .. q+7 in (U + 1) ^ n (U = kg * (kb / 16)
+// + blk * 2, q = blk*32 + kg*8), the float16 image has w1 of all 8 pixels in the first unit and w2 in the
+// second, w * scale[column] = w1 + w2 (float16: round to nearest, then the residual).  Index in HALVES
+// relative to the start of the 16-column group block.
+__host__ __device__ static inline int h16_index(int n, int q, int kb, int plane) {
+    const int blk = q >> 5, kg = (q >> 3) & 3, j = q & 7;
+    const int unit = (kg * (kb / 16) + blk * 2 + plane) ^ n;
+    return (n * kb + unit * 4) * 2 + j;
+}
+
+// layout: 1 = standard image (one group tile, chunks of KC), 2 = slot-major image 2 (ng groups per slot
+// of kb = 128 pixels), 3 = image 3 without VALU columns (ng groups per slot, slot_floats floats per slot)
 __global__ void k_build_image_h16(const float *__restrict__ src, _Float16 *__restrict__ img,
-                                  int64_t n_masks, int cpm, int64_t n_px, int n_chunks,
-                                  const float *__restrict__ scale) {
+                                  int64_t n_masks, int cpm, int64_t n_px, int n_slots, int ng,
+                                  int layout, int slot_floats, const float *__restrict__ scale) {
     const int64_t total = n_masks * cpm * n_px;
+    const int kb = layout == 1 ? KC : 128;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int part = (int)(i % cpm);
@@ -78,15 +89,16 @@ __global__ void k_build_image_h16(const float *__restrict__ src, _Float16 *__res
         const int64_t k = kp / n_px, p = kp % n_px;
         const int col = (int)(k * cpm + part);
         const int g = col / GROUP, n = col % GROUP;
-        const int c = (int)(p / KC), q = (int)(p % KC);
-        const int blk = q >> 5, kg = (q >> 3) & 3, j = q & 7;
+        const int slot = (int)(p / kb), q = (int)(p % kb);
+        size_t base;                                       // floats
+        if (layout == 1) base = ((size_t)g * n_slots + slot) * CHUNK_FLOATS;
+        else if (layout == 2) base = ((((size_t)(g / ng) * n_slots + slot) * ng + g % ng) * GROUP) * kb;
+        else base = (size_t)slot * slot_floats + (size_t)g * GROUP * kb;
         const float ws = src[i] * scale[col];             // (power-of-two scale: exact)
         const _Float16 w1 = (_Float16)ws;
         const _Float16 w2 = (_Float16)(ws - (float)w1);
-        _Float16 *block = img + (((size_t)g * n_chunks + c) * CHUNK_FLOATS) * 2;
-        const int u1 = (kg * 16 + blk * 2) ^ n, u2 = (kg * 16 + blk * 2 + 1) ^ n;
-        block[(n * KC + u1 * 4) * 2 + j] = w1;
-        block[(n * KC + u2 * 4) * 2 + j] = w2;
+        img[base * 2 + h16_index(n, q, kb, 0)] = w1;
+        img[base * 2 + h16_index(n, q, kb, 1)] = w2;
     }
 }
 
@@ -501,9 +513,8 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             const int32_t *__restrict__ rows = nullptr,
             const float *const *__restrict__ wg_img = nullptr, int *__restrict__ kcount = nullptr,
             const float *__restrict__ inv_scale = nullptr) {
-    static_assert(!X16 || (NE == 0 && NG >= 1 && IND != 1 && ABL == 0 &&
-                           (std::is_same<T, uint16_t>::value || std::is_same<T, uint8_t>::value)),
-                  "X16: unsigned 1- / 2-byte pixels on the matrix cores only");
+    static_assert(!X16 || (NE == 0 && NG >= 1 && IND != 1 && ABL == 0 && sizeof(T) <= 2),
+                  "X16: 1- / 2-byte integer pixels on the matrix cores only");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     using TR = InTraits<T>;
     using CFG = LdsCfg<NG, NE, TILES>;
@@ -600,20 +611,26 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
         return ((kg * (KB / 16) + blk_in_slot * 2 + h) ^ m) << 2;
     };
     // X16: the lane's 8 raw pixels -> float16 operands of their low and high bytes
+    // (signed pixels: the top byte is a signed number -- its sign bit is flipped before the perm and
+    // 128 more are taken off: 1024 + (b ^ 0x80) - 1152 = b as int8)
     auto bytes_f16 = [&](const auto &r, h16x8 &lo, h16x8 &hi) {
+        constexpr bool SIGNED = std::is_signed<T>::value;
         const h16x2 kbias = {(_Float16)1024.f, (_Float16)1024.f};
+        const h16x2 kbias_top = SIGNED ? h16x2{(_Float16)1152.f, (_Float16)1152.f} : kbias;
         h16x2 l[4], h[4];
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                l[i] = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0x64646464u, r[i], 0x04020400u)) - kbias;
-                h[i] = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0x64646464u, r[i], 0x04030401u)) - kbias;
+                const unsigned w = SIGNED ? (r[i] ^ 0x80008000u) : r[i];
+                l[i] = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0x64646464u, w, 0x04020400u)) - kbias;
+                h[i] = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0x64646464u, w, 0x04030401u)) - kbias_top;
             }
         } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                l[2 * i] = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0x64646464u, r[i], 0x04010400u)) - kbias;
-                l[2 * i + 1] = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0x64646464u, r[i], 0x04030402u)) - kbias;
+                const unsigned w = SIGNED ? (r[i] ^ 0x80808080u) : r[i];
+                l[2 * i] = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0x64646464u, w, 0x04010400u)) - kbias_top;
+                l[2 * i + 1] = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0x64646464u, w, 0x04030402u)) - kbias_top;
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) h[i] = h16x2{(_Float16)0.f, (_Float16)0.f};
@@ -891,7 +908,9 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
 #pragma unroll
                         for (int e = 0; e < (int)(4 / sizeof(T)); ++e) {
                             const int j = i * (int)(4 / sizeof(T)) + e;
-                            const unsigned v = (p0 + kg * 8 + j < n_px) ? (unsigned)rowp[p0 + j] : 0u;
+                            const unsigned v = (p0 + kg * 8 + j < n_px)
+                                                   ? ((unsigned)rowp[p0 + j] & (sizeof(T) == 2 ? 0xffffu : 0xffu))
+                                                   : 0u;
                             w |= v << (8 * (int)sizeof(T) * e);
                         }
                         raw[i] = w;
@@ -1314,50 +1333,6 @@ extern "C" int ltmi_masks_create_dense(int device, const void *masks_host, int r
             e = hipGetLastError();
             if (e == hipSuccess) e = hipDeviceSynchronize();
         }
-        // one column group with 5 .. 16 columns (fewer: the VALU-only kernel), finite weights: the
-        // float16 image for unsigned 1- / 2-byte pixels (k_dense_lds X16).  LTMI_DENSE_F16=0: never.
-        if (e == hipSuccess && m->ng == 1 && m->n_groups == 1 && m->n_cols > 4) {
-            const char *off = getenv("LTMI_DENSE_F16");
-            const float *hm = (const float *)masks_host;      // (n_masks, n_px, cpm) float32 on the host
-            std::vector<float> amax((size_t)m->n_cols, 0.f);
-            bool finite = !(off && atoi(off) == 0);
-            for (int64_t k = 0; k < n_masks && finite; ++k)
-                for (int64_t p = 0; p < n_px && finite; ++p)
-                    for (int c2 = 0; c2 < cpm; ++c2) {
-                        const float v = hm[(k * n_px + p) * cpm + c2];
-                        if (!std::isfinite(v)) { finite = false; break; }
-                        float &mx = amax[(size_t)(k * cpm + c2)];
-                        mx = std::max(mx, std::fabs(v));
-                    }
-            if (finite) {
-                std::vector<float> scale((size_t)m->n_cols, 1.f), inv((size_t)m->n_cols, 1.f);
-                for (int k = 0; k < m->n_cols; ++k)
-                    if (amax[(size_t)k] > 0.f) {
-                        int ex;
-                        (void)std::frexp(amax[(size_t)k], &ex);           // amax = f 2^ex, f in [0.5, 1)
-                        const int sh = std::max(-120, std::min(120, 7 - ex));   // amax 2^sh in [64, 128)
-                        scale[(size_t)k] = std::ldexp(1.0f, sh);
-                        inv[(size_t)k] = std::ldexp(1.0f, -sh);
-                    }
-                float *scale_dev = nullptr;
-                e = hipMalloc((void **)&m->img_h, n_float * sizeof(float));
-                if (e == hipSuccess) e = hipMemset(m->img_h, 0, n_float * sizeof(float));
-                if (e == hipSuccess) e = hipMalloc((void **)&m->inv_scale, inv.size() * sizeof(float));
-                if (e == hipSuccess) e = hipMalloc((void **)&scale_dev, scale.size() * sizeof(float));
-                if (e == hipSuccess) e = hipMemcpy(m->inv_scale, inv.data(), inv.size() * sizeof(float), hipMemcpyHostToDevice);
-                if (e == hipSuccess) e = hipMemcpy(scale_dev, scale.data(), scale.size() * sizeof(float), hipMemcpyHostToDevice);
-                if (e == hipSuccess) {
-                    const int64_t total = n_masks * cpm * n_px;
-                    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 65535 * 16);
-                    hipLaunchKernelGGL(ltmi::k_build_image_h16, dim3(blocks), dim3(256), 0, 0,
-                                       (const float *)m->gmasks, (_Float16 *)m->img_h, n_masks, cpm, n_px,
-                                       m->n_chunks, (const float *)scale_dev);
-                    e = hipGetLastError();
-                    if (e == hipSuccess) e = hipDeviceSynchronize();
-                }
-                if (scale_dev) (void)hipFree(scale_dev);
-            }
-        }
         if (e == hipSuccess && m->ng > 1) {
             // slot-major image for the LDS-DMA kernel with several column groups (k_dense_lds)
             constexpr int kb = 128;
@@ -1410,6 +1385,63 @@ extern "C" int ltmi_masks_create_dense(int device, const void *masks_host, int r
                 if (e == hipSuccess) e = hipDeviceSynchronize();
             }
         }
+        // float16 images for 1- / 2-byte integer pixels (k_dense_lds X16) of every matrix-core layout
+        // this stack has without VALU columns: finite weights only.  LTMI_DENSE_F16=0: never.
+        const bool want_h1 = m->ng == 1 && m->n_groups == 1 && m->n_cols > 4;
+        const bool want_h2 = m->ng > 1 && m->img2 != nullptr;
+        const bool want_h3 = m->img3 != nullptr && m->ng3 == 3 && m->ne3 == 0;
+        if (e == hipSuccess && (want_h1 || want_h2 || want_h3)) {
+            const char *off = getenv("LTMI_DENSE_F16");
+            const float *hm = (const float *)masks_host;      // (n_masks, n_px, cpm) float32 on the host
+            std::vector<float> amax((size_t)m->n_cols, 0.f);
+            bool finite = !(off && atoi(off) == 0);
+            for (int64_t k = 0; k < n_masks && finite; ++k)
+                for (int64_t p = 0; p < n_px && finite; ++p)
+                    for (int c2 = 0; c2 < cpm; ++c2) {
+                        const float v = hm[(k * n_px + p) * cpm + c2];
+                        if (!std::isfinite(v)) { finite = false; break; }
+                        float &mx = amax[(size_t)(k * cpm + c2)];
+                        mx = std::max(mx, std::fabs(v));
+                    }
+            if (finite) {
+                std::vector<float> scale((size_t)m->n_cols, 1.f), inv((size_t)m->n_cols, 1.f);
+                for (int k = 0; k < m->n_cols; ++k)
+                    if (amax[(size_t)k] > 0.f) {
+                        int ex;
+                        (void)std::frexp(amax[(size_t)k], &ex);           // amax = f 2^ex, f in [0.5, 1)
+                        const int sh = std::max(-120, std::min(120, 7 - ex));   // amax 2^sh in [64, 128)
+                        scale[(size_t)k] = std::ldexp(1.0f, sh);
+                        inv[(size_t)k] = std::ldexp(1.0f, -sh);
+                    }
+                float *scale_dev = nullptr;
+                e = hipMalloc((void **)&m->inv_scale, inv.size() * sizeof(float));
+                if (e == hipSuccess) e = hipMalloc((void **)&scale_dev, scale.size() * sizeof(float));
+                if (e == hipSuccess) e = hipMemcpy(m->inv_scale, inv.data(), inv.size() * sizeof(float), hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipMemcpy(scale_dev, scale.data(), scale.size() * sizeof(float), hipMemcpyHostToDevice);
+                const int64_t total = n_masks * cpm * n_px;
+                const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 65535 * 16);
+                auto build = [&](float **dst, size_t n_floats, int n_slots, int ng, int layout,
+                                 int slot_floats) {
+                    if (e != hipSuccess) return;
+                    e = hipMalloc((void **)dst, n_floats * sizeof(float));
+                    if (e == hipSuccess) e = hipMemset(*dst, 0, n_floats * sizeof(float));
+                    if (e != hipSuccess) return;
+                    hipLaunchKernelGGL(ltmi::k_build_image_h16, dim3(blocks), dim3(256), 0, 0,
+                                       (const float *)m->gmasks, (_Float16 *)*dst, n_masks, cpm, n_px,
+                                       n_slots, ng, layout, slot_floats, (const float *)scale_dev);
+                    e = hipGetLastError();
+                };
+                if (want_h1) build(&m->img_h, n_float, m->n_chunks, 1, 1, 0);
+                if (want_h2)
+                    build(&m->img2_h, (size_t)m->n_groups * m->n_slots2 * GROUP * 128, m->n_slots2, m->ng,
+                          2, 0);
+                if (want_h3)
+                    build(&m->img3_h, (size_t)m->n_slots3 * (3 * GROUP * 128), m->n_slots3, 3, 3,
+                          3 * GROUP * 128);
+                if (e == hipSuccess) e = hipDeviceSynchronize();
+                if (scale_dev) (void)hipFree(scale_dev);
+            }
+        }
         if (e != hipSuccess) {
             ltmi_masks_destroy(m);
             LTMI_FAIL((int)e, "building the mask image failed: %s", hipGetErrorString(e));
@@ -1452,6 +1484,8 @@ extern "C" int ltmi_masks_destroy(ltmi_masks *m) {
     ltmi::split_destroy(m->split);
     m->split = nullptr;
     if (m->img_h) (void)hipFree(m->img_h);
+    if (m->img2_h) (void)hipFree(m->img2_h);
+    if (m->img3_h) (void)hipFree(m->img3_h);
     if (m->inv_scale) (void)hipFree(m->inv_scale);
     ltmi::dense64_destroy(m);
     shift_cache_destroy(m);
@@ -1588,11 +1622,11 @@ static int launch_lds_ng_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64
                              : lds_kernel<T, NG, 0, 0, 0, TILES>());
     const int32_t *rows = m->roi_rows;                  // ltmi_apply_masks_rows: frames through a row list
     if (rows) kern = lds_kernel<T, NG, 0, 2, 0, TILES>();
-    // unsigned 1- / 2-byte pixels against one column group: exact float16 products (X16; tuning code
-    // 37 keeps the float32 instruction: tests, benches)
+    // 1- / 2-byte integer pixels: exact float16 products (X16; tuning code 37 keeps the float32
+    // instruction: tests, benches)
     bool x16 = false;
-    if constexpr (NG == 1 && (std::is_same<T, uint16_t>::value || std::is_same<T, uint8_t>::value)) {
-        x16 = m->img_h != nullptr && abl == 0 && m->tune_ksplit_ring != 37;
+    if constexpr (sizeof(T) <= 2 && std::is_integral<T>::value) {
+        x16 = (NG == 1 ? m->img_h : m->img2_h) != nullptr && abl == 0 && m->tune_ksplit_ring != 37;
         if (x16)
             kern = rows ? lds_kernel<T, NG, 0, 2, 0, TILES, true>()
                         : lds_kernel<T, NG, 0, 0, 0, TILES, true>();
@@ -1605,7 +1639,7 @@ static int launch_lds_ng_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64
                                      CFG::LDS_BYTES));
         attr_set[m->device & 15][variant] = true;
     }
-    const float *img = x16 ? m->img_h : (NG == 1 ? m->img : m->img2);
+    const float *img = x16 ? (NG == 1 ? m->img_h : m->img2_h) : (NG == 1 ? m->img : m->img2);
     const int n_slots = NG == 1 ? m->n_chunks : m->n_slots2;
     const int64_t gx = (n_frames + CFG::WG_ROWS - 1) / CFG::WG_ROWS;
     const int64_t gz = m->n_groups / NG;
@@ -1657,12 +1691,21 @@ static int launch_lds_extras_t(ltmi_masks *m, const T *tile, int64_t n_frames, i
     auto kern = lds_kernel<T, NG, 0, 0, NE, TILES>();
     const int32_t *rows = m->roi_rows;
     if (rows) kern = lds_kernel<T, NG, 0, 2, NE, TILES>();
+    bool x16 = false;
+    if constexpr (NE == 0 && NG >= 1 && sizeof(T) <= 2 && std::is_integral<T>::value) {
+        // (exactly 3 groups: the float16 image of image 3, see launch_lds_ng_t)
+        x16 = m->img3_h != nullptr && m->tune_ksplit_ring != 37;
+        if (x16)
+            kern = rows ? lds_kernel<T, NG, 0, 2, NE, TILES, true>()
+                        : lds_kernel<T, NG, 0, 0, NE, TILES, true>();
+    }
     if (!kern) return LTMI_E_DTYPE;
-    static bool attr_set[16][2] = {{false}};
-    if (!attr_set[m->device & 15][rows ? 1 : 0]) {
+    static bool attr_set[16][4] = {{false}};
+    const int variant = (rows ? 1 : 0) + (x16 ? 2 : 0);
+    if (!attr_set[m->device & 15][variant]) {
         LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      CFG::LDS_BYTES));
-        attr_set[m->device & 15][rows ? 1 : 0] = true;
+        attr_set[m->device & 15][variant] = true;
     }
     const int n_slots = m->n_slots3;
     const int64_t gx = (n_frames + CFG::WG_ROWS - 1) / CFG::WG_ROWS;
@@ -1680,9 +1723,10 @@ static int launch_lds_extras_t(ltmi_masks *m, const T *tile, int64_t n_frames, i
     dim3 grid((unsigned)gx, (unsigned)ksplit, 1);
     int *kcount = ksplit > 1 ? partial_counters(m, gx) : nullptr;
     hipLaunchKernelGGL(kern, grid, dim3(CFG::WAVES * 64), CFG::LDS_BYTES, stream, tile, ld, n_frames,
-                       m->n_px, (const float *)m->img3, n_slots, out, ld_out, m->n_cols, accumulate,
-                       partial_sums(m), ksplit, rows, (const float *const *)nullptr, kcount,
-                       (const float *)nullptr);
+                       m->n_px, x16 ? (const float *)m->img3_h : (const float *)m->img3, n_slots, out,
+                       ld_out, m->n_cols, accumulate, partial_sums(m), ksplit, rows,
+                       (const float *const *)nullptr, kcount,
+                       x16 ? (const float *)m->inv_scale : (const float *)nullptr);
     LTMI_HIP(hipGetLastError());
     if (NE > 0)
         snprintf(m->last_kernel, sizeof(m->last_kernel),
@@ -1690,8 +1734,8 @@ static int launch_lds_extras_t(ltmi_masks *m, const T *tile, int64_t n_frames, i
                  typeid(T).name(), NG, NE, CFG::RING, TILES, rows ? ",rows" : "", grid.x, grid.y);
     else
         snprintf(m->last_kernel, sizeof(m->last_kernel),
-                 "k_dense_lds<%s,NG=%d,ring=%d,tiles=%d%s> grid=(%u,%u,1)", typeid(T).name(), NG,
-                 CFG::RING, TILES, rows ? ",rows" : "", grid.x, grid.y);
+                 "k_dense_lds<%s,NG=%d,ring=%d,tiles=%d%s%s> grid=(%u,%u,1)", typeid(T).name(), NG,
+                 CFG::RING, TILES, x16 ? ",f16" : "", rows ? ",rows" : "", grid.x, grid.y);
     if (ksplit > 1 && !kcount) {
         const int64_t n = n_frames * m->n_cols;
         hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
@@ -1733,7 +1777,12 @@ static int launch_lds(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld
         }
         return launch_lds_ng<T, 1>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
     }
-    if (m->img3 && m->ng3 > 0 && m->tune_ksplit_ring != 33) {   // 33: force the padded-group kernel (bench)
+    // 1- / 2-byte integer pixels: the VALU columns need float32 pixels, and with the exact float16
+    // products (X16) a padded group costs less than they do -- the padded-group kernel instead
+    bool x16_padded = false;
+    if constexpr (sizeof(T) <= 2 && std::is_integral<T>::value)
+        x16_padded = m->ne3 > 0 && m->img2_h != nullptr && m->tune_ksplit_ring != 37;
+    if (m->img3 && m->ng3 > 0 && m->tune_ksplit_ring != 33 && !x16_padded) {   // 33: force the padded-group kernel (bench)
 #define LTMI_EXTRAS(NG_, NE_)                                                                     \
     if (m->ng3 == NG_ && m->ne3 == NE_)                                                           \
         return launch_lds_extras<T, NG_, NE_>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);

@@ -150,7 +150,7 @@ def test_lds_dma_kernel_all_widths(hip, tile_dtype, shape, ksplit):
     assert np.all(np.abs(res2 - (ref + base)) <= 1e-5 * (scale + 1))
 
 
-@pytest.mark.parametrize('tile_dtype', ['uint8', 'uint16'])
+@pytest.mark.parametrize('tile_dtype', ['uint8', 'uint16', 'int16', 'int8'])
 @pytest.mark.parametrize('shape,ksplit,mask_dtype', [
     ((300, 256 * 41 + 112, 16), 0, 'float32'),      # unrolled loop + generic tail + ragged last slot
     ((300, 256 * 41 + 112, 16), 3, 'float32'),      # ... with a K split
@@ -158,18 +158,24 @@ def test_lds_dma_kernel_all_widths(hip, tile_dtype, shape, ksplit):
     ((1000, 1024, 12), 0, 'float32'),
     ((70, 515, 16), 0, 'float32'),                  # unaligned rows
     ((200, 256 * 6 + 40, 8), 0, 'complex64'),       # 8 complex masks = 16 real columns
+    ((150, 128 * 21 + 16, 24), 0, 'float32'),       # 2 groups (image 2)
+    ((150, 128 * 21 + 16, 40), 2, 'float32'),       # exactly 3 groups (image 3 without VALU columns)
+    ((90, 128 * 30, 64), 0, 'float32'),             # 4 groups
+    ((90, 128 * 30, 30), 0, 'complex64'),           # 60 real columns: 4 groups, 4 padded columns
 ])
 def test_exact_float16_products_for_unsigned_pixels(hip, tile_dtype, shape, ksplit, mask_dtype):
-    """k_dense_lds X16 (one column group, unsigned 1- / 2-byte pixels): pixel bytes x (w1 + w2) float16
-    pieces of the scaled weights on v_mfma_f32_16x16x32_f16 -- the default dispatch.  Float32
-    accuracy over the full pixel range and columns of very different magnitude (per-column scale),
-    agreement with the float32 instruction (tuning 37), integer-valued masks bit-exact, accumulate."""
+    """k_dense_lds X16 (1- / 2-byte integer pixels, 1 / 2 / 3 / 4 column groups without VALU columns):
+    pixel bytes x (w1 + w2) float16 pieces of the scaled weights on v_mfma_f32_16x16x32_f16 -- the
+    default dispatch.  Float32 accuracy over the full pixel range (signed: both signs) and columns of
+    very different magnitude (per-column scale), agreement with the float32 instruction (tuning 37),
+    integer-valued masks bit-exact, accumulate."""
     n_frames, n_px, n_masks = shape
     rng = np.random.default_rng(hash((tile_dtype,) + shape + (mask_dtype,)) % (2**32))
     dt, md = np.dtype(tile_dtype), np.dtype(mask_dtype)
-    data = rng.integers(0, np.iinfo(dt).max, (n_frames, n_px), endpoint=True).astype(dt)
+    data = rng.integers(np.iinfo(dt).min, np.iinfo(dt).max, (n_frames, n_px), endpoint=True).astype(dt)
     data[1 % n_frames] = np.iinfo(dt).max
     data[2 % n_frames] = 0
+    data[4 % n_frames] = np.iinfo(dt).min
     masks = rng.random((n_masks, n_px)) - 0.25
     if md.kind == 'c':
         masks = masks + 1j * (rng.random((n_masks, n_px)) - 0.5)
@@ -193,7 +199,7 @@ def test_exact_float16_products_for_unsigned_pixels(hip, tile_dtype, shape, kspl
     assert np.all(np.abs(res2 - (ref + base)) <= 2e-6 * (scale + 1))
     if md.kind == 'f':
         # integer-valued masks, sums below 2^24: both instructions give the exact integers
-        small = (data % 16).astype(dt)
+        small = (data.astype(np.int64) % 16).astype(dt)
         imasks = rng.integers(0, 4, (n_masks, n_px)).astype(np.float32)
         exact = small.astype(np.int64) @ imasks.astype(np.int64).T
         assert exact.max() < 2**24
