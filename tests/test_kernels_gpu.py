@@ -935,7 +935,10 @@ def test_three_groups_plus_valu_columns(hip, tile_dtype, n_masks, mask_dtype, ks
     masks = masks.astype(md)
     ref = _ref64(data, masks)
     scale = np.abs(data.astype(np.float64)) @ np.abs(masks).astype(np.float64).T
-    res, kern = _apply(hip, data, masks, md, tuning=dict(mt=0, waves=30, ksplit=ksplit))
+    # (integer pixels: tuning 37 keeps the float32 instruction -- by default they take the exact
+    # float16 products on a padded group instead of VALU columns, checked at the end)
+    code = 37 if dt.kind in 'iu' else 30
+    res, kern = _apply(hip, data, masks, md, tuning=dict(mt=0, waves=code, ksplit=ksplit))
     n_cols = n_masks * (2 if md.kind == 'c' else 1)
     expect = {17: 'NG=1+2 VALU', 18: 'NG=1+2 VALU', 33: 'NG=2+2 VALU', 34: 'NG=2+2 VALU',
               35: 'NG=2+4 VALU', 36: 'NG=2+4 VALU', 49: 'NG=3+2 VALU', 50: 'NG=3+2 VALU',
@@ -945,11 +948,15 @@ def test_three_groups_plus_valu_columns(hip, tile_dtype, n_masks, mask_dtype, ks
     base = (rng.random((n_frames, n_masks)) + (1j * rng.random((n_frames, n_masks))
                                                if md.kind == 'c' else 0)).astype(md)
     res2, _ = _apply(hip, data, masks, md, accumulate_into=base,
-                     tuning=dict(mt=0, waves=30, ksplit=ksplit))
+                     tuning=dict(mt=0, waves=code, ksplit=ksplit))
     assert np.all(np.abs(res2 - (ref + base)) <= 1e-5 * (scale + 1))
     res4, kern4 = _apply(hip, data, masks, md, tuning=dict(mt=0, waves=33, ksplit=ksplit))
     assert ('NG=4' if n_cols > 32 else 'NG=2') in kern4 and 'VALU' not in kern4, kern4
     assert np.all(np.abs(res4 - res) <= 2e-5 * scale + 1e-30)
+    if dt.kind in 'iu':
+        res5, kern5 = _apply(hip, data, masks, md, tuning=dict(mt=0, waves=30, ksplit=ksplit))
+        assert ',f16' in kern5 and 'VALU' not in kern5, kern5
+        assert np.all(np.abs(res5 - ref) <= 2e-6 * scale + 1e-30)
 
 
 @pytest.mark.parametrize('n_frames,n_px,n_masks,mask_dtype,ksplit', [
