@@ -498,8 +498,8 @@ __global__ void k_build_image3(const float *__restrict__ src, float *__restrict_
 // X16 (unsigned 1- and 2-byte pixels, no VALU columns): the products are formed EXACTLY from float16
 // operands on v_mfma_f32_16x16x32_f16 instead of converting the pixels to float32 -- a pixel is
 // lo + 256 hi (two bytes, each a float16 number: 0x6400 | b is 1024 + b, one v_perm_b32 and one
-// v_pk_add_f16 per pixel pair), a weight times its column's power-of-two scale is w1 + w2 (two float16,
-// 22 bits; the image holds w1 of the lane's 8 pixels in the 16-byte unit h = 0 and w2 in h = 1: same
+// v_pk_add_f16 per pixel pair), a weight times its column's power-of-two scale (max|w| S in [2^14, 2^15))
+// is w1 + w2 (two float16, 22 bits; the image holds w1 of the lane's 8 pixels in the 16-byte unit h = 0 and w2 in h = 1: same
 // bytes, same addresses as the float32 image).  lo w1 + lo w2 go to one accumulator, hi w1 + hi w2 to a
 // second one that counts 256-fold: 4 x 16 matrix-pipe cycles per 16 frames x 16 columns x 32 pixels where
 // float32 takes 8 x 32 -- these kernels run at the board's power cap with the f32 pipe 65 % busy (C2),
@@ -1409,7 +1409,12 @@ extern "C" int ltmi_masks_create_dense(int device, const void *masks_host, int r
                     if (amax[(size_t)k] > 0.f) {
                         int ex;
                         (void)std::frexp(amax[(size_t)k], &ex);           // amax = f 2^ex, f in [0.5, 1)
-                        const int sh = std::max(-120, std::min(120, 7 - ex));   // amax 2^sh in [64, 128)
+                        // amax 2^sh in [16384, 32768): the largest scale whose w1 stays a finite float16.
+                        // (k_bell_flat keeps 256 w S finite and scales to [64, 128); here the high bytes
+                        // have their own accumulator.)  w S = w1 + w2 then holds with relative error
+                        // 2^-22 for |w| >= 2^-19 max|w| of the column and absolute error 2^-39 max|w|
+                        // below that: every weight down to 2^-22 of its column's maximum is within 1e-5
+                        const int sh = std::max(-120, std::min(120, 15 - ex));
                         scale[(size_t)k] = std::ldexp(1.0f, sh);
                         inv[(size_t)k] = std::ldexp(1.0f, -sh);
                     }

@@ -207,6 +207,38 @@ def test_exact_float16_products_for_unsigned_pixels(hip, tile_dtype, shape, kspl
         assert ',f16' in ki and np.array_equal(ri, exact.astype(np.float32))
 
 
+@pytest.mark.parametrize('tile_dtype', ['uint16', 'uint8'])
+def test_exact_float16_products_elementwise(hip, tile_dtype):
+    """X16, element-wise: frames lit at ONE pixel pick single weights out of the stack -- a smooth mask
+    whose values span 7 orders of magnitude inside one column (Gaussian tail), every weight down to
+    2^-22 of the column maximum must come back within 1e-5 RELATIVE (the north-star tolerance applied
+    per element, not norm-wise); exactly representable weights come back exactly."""
+    n_px, n_masks = 4096, 16
+    rng = np.random.default_rng(5)
+    dt = np.dtype(tile_dtype)
+    q = np.arange(n_px)
+    masks = np.empty((n_masks, n_px), np.float32)
+    for k in range(n_masks):
+        masks[k] = (3.0 + k) * np.exp(-((q - 2048.0) / (40.0 + 9 * k)) ** 2 / 2)      # 3 .. 18 down to 0
+    masks[5] = (q % 7 == 0) * 0.75                                                       # exact weights
+    n_frames = 512
+    px = np.clip(rng.normal(2048, 260, n_frames), 0, n_px - 1).astype(np.int64)      # centre, flanks, tails
+    val = rng.integers(1, np.iinfo(dt).max, n_frames, endpoint=True)
+    data = np.zeros((n_frames, n_px), dt)
+    data[np.arange(n_frames), px] = val
+    res, kern = _apply(hip, data, masks, np.float32)
+    assert ',f16' in kern, kern
+    ref = val[:, None].astype(np.float64) * masks[:, px].T.astype(np.float64)
+    big = np.abs(masks[:, px].T) >= 2.0 ** -22 * np.abs(masks).max(axis=1)[None, :]
+    rel = np.abs(res - ref) / np.where(ref == 0, 1, np.abs(ref))
+    assert 0.3 * big.size < big.sum() < big.size
+    assert np.all(rel[big] <= 1e-5), rel[big].max()
+    # below that: absolute error 2^-39 of the column maximum (times the pixel value)
+    bound = val[:, None] * 2.0 ** -38 * np.abs(masks).max(axis=1)[None, :]
+    assert np.all(np.abs(res - ref)[~big] <= bound[~big] + 1e-30)
+    assert np.array_equal(res[:, 5], (val * masks[5, px]).astype(np.float32))
+
+
 def test_mfma_integer_exact(hip):
     # 0/1 masks on low-count data: every partial sum is an integer < 2**24 -> any order exact
     rng = np.random.default_rng(11)
