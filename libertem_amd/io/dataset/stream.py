@@ -16,6 +16,7 @@ nav sharding of MemoryDataSet); `run_udf_iter` then advances the ranks in lockst
 yields the merged partial result after each step (executor/hip.py `_merge_partial_dist`).
 """
 import threading
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -43,6 +44,11 @@ class StreamDataSet(MemoryDataSet):
     """
 
     eager_upload = False    # never wait for the next chunk's frames before launching this chunk
+
+    #: chunks of at least this many bytes are copied into the scan buffer by COPY_THREADS threads (one
+    #: thread moves ~20 GB/s, below the 55 GB/s the upload takes them away with)
+    PARALLEL_COPY_BYTES = 8 << 20
+    COPY_THREADS = 4
 
     def __init__(self, frames, nav_shape, sig_shape, dtype, num_partitions=None, timeout=None,
                  tileshape=None, shard=None):
@@ -80,8 +86,29 @@ class StreamDataSet(MemoryDataSet):
         self._thread.start()
 
     # --- feed ------------------------------------------------------------------------------------
+    def _copy_in(self, start, chunk, pool):
+        """self._buf[start:start + n] = chunk (cast + copy), large chunks in parallel slices"""
+        n = chunk.shape[0]
+        if pool is None or chunk.nbytes < self.PARALLEL_COPY_BYTES or n < 2 * self.COPY_THREADS:
+            self._buf[start:start + n] = chunk
+            return
+        step = -(-n // self.COPY_THREADS)
+
+        def part(a):
+            self._buf[start + a:start + min(n, a + step)] = chunk[a:a + step]
+        list(pool.map(part, range(0, n, step)))
+
     def _pump(self, it):
         sig = self._buf.shape[1:]
+        pool = ThreadPoolExecutor(self.COPY_THREADS, thread_name_prefix='ltmi-stream-copy') \
+            if self.COPY_THREADS > 1 else None
+        try:
+            self._pump_loop(it, sig, pool)
+        finally:
+            if pool is not None:
+                pool.shutdown(wait=False)
+
+    def _pump_loop(self, it, sig, pool):
         try:
             for item in it:
                 chunk = np.asarray(item)
@@ -96,7 +123,7 @@ class StreamDataSet(MemoryDataSet):
                 if start + n > self._n_frames:
                     raise DataSetException(
                         f"stream delivered more than the {self._n_frames} frames of the scan")
-                self._buf[start:start + n] = chunk            # cast + copy outside the lock
+                self._copy_in(start, chunk, pool)             # cast + copy outside the lock
                 with self._cond:
                     self._arrived = start + n
                     self._cond.notify_all()
