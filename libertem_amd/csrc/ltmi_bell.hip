@@ -1334,6 +1334,9 @@ void *bell_build(const int64_t *indptr, const int64_t *indices, const float *val
         if (amax[(size_t)k] > 0.f) {
             int ex;
             (void)std::frexp(amax[(size_t)k], &ex);          // amax = f * 2^ex, f in [0.5, 1)
+            // (a column beyond 2^-100 .. 2^100 cannot be scaled into float16 by a float32 power of two
+            // with room to spare: the float32 image stays in charge of such stacks)
+            if (ex < -100 || ex > 100) return b;
             const int sh = std::max(-120, std::min(120, 7 - ex));   // amax * 2^sh in [64, 128)
             scale[(size_t)k] = std::ldexp(1.0f, sh);
         }

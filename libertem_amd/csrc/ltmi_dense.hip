@@ -1403,6 +1403,14 @@ extern "C" int ltmi_masks_create_dense(int device, const void *masks_host, int r
                         float &mx = amax[(size_t)(k * cpm + c2)];
                         mx = std::max(mx, std::fabs(v));
                     }
+            // (columns whose largest weight lies outside 2^-100 .. 2^100 cannot be brought into float16 by
+            // a float32 power of two with room to spare: such stacks keep the float32 instruction)
+            for (int k = 0; k < m->n_cols && finite; ++k)
+                if (amax[(size_t)k] > 0.f) {
+                    int ex;
+                    (void)std::frexp(amax[(size_t)k], &ex);
+                    if (ex < -100 || ex > 100) finite = false;
+                }
             if (finite) {
                 std::vector<float> scale((size_t)m->n_cols, 1.f), inv((size_t)m->n_cols, 1.f);
                 for (int k = 0; k < m->n_cols; ++k)

@@ -239,6 +239,40 @@ def test_exact_float16_products_elementwise(hip, tile_dtype):
     assert np.array_equal(res[:, 5], (val * masks[5, px]).astype(np.float32))
 
 
+def test_exact_float16_products_not_for_non_finite_or_extreme_weights(hip):
+    """X16 is only built for finite weights (a stack holding inf / nan keeps the float32 instruction and
+    its IEEE behaviour); columns near the ends of the float32 range still scale into float16."""
+    rng = np.random.default_rng(3)
+    data = rng.integers(0, 60000, (200, 2048)).astype(np.uint16)
+    masks = (rng.random((16, 2048)) - 0.25).astype(np.float32)
+    bad = masks.copy()
+    bad[3, 100] = np.inf
+    bad[7, 5] = np.nan
+    res, kern = _apply(hip, data, bad, np.float32)
+    assert 'k_dense_lds' in kern and ',f16' not in kern, kern
+    with np.errstate(invalid='ignore', over='ignore'):
+        ref = data.astype(np.float64) @ bad.astype(np.float64).T
+    assert np.array_equal(np.isnan(res), np.isnan(ref)) and np.array_equal(np.isinf(res), np.isinf(ref))
+    ok = np.isfinite(ref)
+    scale = np.abs(data.astype(np.float64)) @ np.abs(np.where(np.isfinite(bad), bad, 0)).astype(np.float64).T
+    assert np.all(np.abs(res - ref)[ok] <= 1e-5 * scale[ok])
+    ext = masks.copy()
+    ext[0] *= np.float32(1e28)
+    ext[1] *= np.float32(1e-28)
+    res, kern = _apply(hip, data, ext, np.float32)
+    assert ',f16' in kern, kern
+    ref = data.astype(np.float64) @ ext.astype(np.float64).T
+    scale = np.abs(data.astype(np.float64)) @ np.abs(ext).astype(np.float64).T
+    assert np.all(np.isfinite(res)) and np.all(np.abs(res - ref) <= 2e-6 * scale + 1e-44)
+    # beyond 2^+-100 (float32 subnormal weights, 1e36): the float32 instruction
+    ext[2] = np.float32(1e-42)
+    res, kern = _apply(hip, data, ext, np.float32)
+    assert ',f16' not in kern, kern
+    ref = data.astype(np.float64) @ ext.astype(np.float64).T
+    scale = np.abs(data.astype(np.float64)) @ np.abs(ext).astype(np.float64).T
+    assert np.all(np.abs(res - ref) <= 1e-5 * scale + 1e-44)
+
+
 def test_mfma_integer_exact(hip):
     # 0/1 masks on low-count data: every partial sum is an integer < 2**24 -> any order exact
     rng = np.random.default_rng(11)
