@@ -300,10 +300,12 @@ int ltmi_comm_all_reduce_sum(ltmi_comm *c, void *buf, int dtype, int64_t n, void
 
 /* ---- tuning / introspection (bench + tests) ------------------------------------------- */
 /* force a kernel variant for the dense MFMA path (bench / tests only; (0,0,0) = automatic):
- *   mt in {1,2}, waves in {4,8}: the direct-load kernel k_dense_mfma with that tile shape;
+ *   mt in {1,2}, waves in {4,8}: the direct-load kernel k_dense_mfma with that tile shape (8 waves:
+ *     uint16 tiles only);
  *   mt = 0, waves = 30: the LDS-DMA kernel k_dense_lds as dispatched; 31 / 32: its timing-only
- *     ablations without DMA / without MFMA (results are garbage); 33: padded column groups instead
- *     of VALU columns; 34 / 35: one / two 16-frame tiles per wave; 36: float32 tiles of stacks with
+ *     ablations without DMA / without MFMA (results are garbage; uint16 tiles against one column
+ *     group only, like 34); 33: padded column groups instead of VALU columns; 34 / 35: one / two
+ *     16-frame tiles per wave; 36: float32 tiles of stacks with
  *     2 - 4 column groups on the bf16 x 3 split kernel (ltmi_split.hip); 37: the float32 matrix
  *     instruction also for 1- / 2-byte integer tiles (by default those take exact float16-piece
  *     products, kernel names ending in ",f16"; LTMI_DENSE_F16=0 in the environment: never);

@@ -1606,6 +1606,12 @@ template <typename T, int NG, int ABL, int IND, int NE, int TILES, bool X16 = fa
 static auto lds_kernel() -> void (*)(const T *, int64_t, int64_t, int64_t, const float *, int, float *,
                                      int64_t, int, int, float *, int, const int32_t *,
                                      const float *const *, int *, const float *) {
+    // the timing-only ablations (tuning codes 31 / 32) and the one-tile-per-wave shape (34) exist for the
+    // C2 kernel only -- uint16 pixels, one column group --: they are bench comparisons
+    // (scripts/clock_probe.py, profiles/r02_tiles.txt), and every variant is minutes of compile time
+    if constexpr ((ABL != 0 || TILES == 1) && !(std::is_same<T, uint16_t>::value && NG == 1 && NE == 0))
+        return nullptr;
+    else
 #ifdef LTMI_DENSE_EXP
     // (C5: float frames, 3 groups; C2 and its 1-byte sibling: one group, with and without X16)
     if constexpr (!(ABL == 0 && IND == 0 && TILES == 2 &&
@@ -1691,9 +1697,11 @@ static int launch_lds_ng_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64
 template <typename T, int NG>
 static int launch_lds_ng(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
                          int64_t ld_out, int accumulate, hipStream_t stream) {
-    if (lds_tiles(m) == 2 || m->roi_rows)
-        return launch_lds_ng_t<T, NG, 2>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
-    return launch_lds_ng_t<T, NG, 1>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+    if constexpr (std::is_same<T, uint16_t>::value && NG == 1) {
+        if (lds_tiles(m) != 2 && !m->roi_rows)
+            return launch_lds_ng_t<T, NG, 1>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+    }
+    return launch_lds_ng_t<T, NG, 2>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
 }
 
 // NG MFMA groups + NE VALU columns (stacks of 16 NG + 1..4 columns)
@@ -1762,11 +1770,6 @@ static int launch_lds_extras_t(ltmi_masks *m, const T *tile, int64_t n_frames, i
 template <typename T, int NG, int NE>
 static int launch_lds_extras(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
                              int64_t ld_out, int accumulate, hipStream_t stream) {
-    if constexpr (NE == 0) {
-        if (lds_tiles(m) != 2 && !m->roi_rows)
-            return launch_lds_extras_t<T, NG, NE, 1>(m, tile, n_frames, ld, out, ld_out, accumulate,
-                                                     stream);
-    }
     return launch_lds_extras_t<T, NG, NE, 2>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
 }
 
@@ -2041,14 +2044,23 @@ static int launch_mfma(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t l
                                                           accumulate, ksplit, stream)              \
              : launch_mfma_variant<T, MT_, NG_, W_, false>(m, tile, n_frames, ld, out, ld_out,     \
                                                            accumulate, ksplit, stream))
+    // (8-wave workgroups are a tuning choice only -- ltmi_masks_set_tuning(.., waves = 8, ..) -- and
+    // compiled for uint16 pixels, the type the comparisons were made on; default: 4 waves)
+    constexpr bool W8 = std::is_same<T, uint16_t>::value;
+    if (waves == 8 && !W8)
+        LTMI_FAIL(LTMI_E_INVALID, "k_dense_mfma with 8 waves is built for uint16 tiles only");
     if (m->ng == 1) {
         if (waves == 4) rc = (mt == 1) ? LTMI_VARIANT(1, 1, 4) : LTMI_VARIANT(2, 1, 4);
-        else rc = (mt == 1) ? LTMI_VARIANT(1, 1, 8) : LTMI_VARIANT(2, 1, 8);
+        else if constexpr (W8) rc = (mt == 1) ? LTMI_VARIANT(1, 1, 8) : LTMI_VARIANT(2, 1, 8);
+        else rc = LTMI_E_INVALID;
     } else if (m->ng == 2) {
         if (waves == 4) rc = (mt == 1) ? LTMI_VARIANT(1, 2, 4) : LTMI_VARIANT(2, 2, 4);
-        else rc = (mt == 1) ? LTMI_VARIANT(1, 2, 8) : LTMI_VARIANT(2, 2, 8);
+        else if constexpr (W8) rc = (mt == 1) ? LTMI_VARIANT(1, 2, 8) : LTMI_VARIANT(2, 2, 8);
+        else rc = LTMI_E_INVALID;
     } else {
-        rc = (waves == 4) ? LTMI_VARIANT(1, 4, 4) : LTMI_VARIANT(1, 4, 8);
+        if (waves == 4) rc = LTMI_VARIANT(1, 4, 4);
+        else if constexpr (W8) rc = LTMI_VARIANT(1, 4, 8);
+        else rc = LTMI_E_INVALID;
     }
 #undef LTMI_VARIANT
     if (rc != LTMI_OK) return rc;

@@ -9,10 +9,8 @@ rng = np.random.default_rng(2)
 masks = (rng.random((nm, n_px)) + 1j * rng.random((nm, n_px))).astype(np.complex64)
 h = hip.MaskHandle.dense(0, masks, np.complex64)
 out = torch.zeros((frames, nm), device='cuda', dtype=torch.complex64)
-variants = [dict(mt=0, waves=int(os.environ.get('TUNE', 0)), ksplit=0)] if os.environ.get('ONLY_DEFAULT') else [dict(mt=0, waves=0, ksplit=0), dict(mt=1, waves=8, ksplit=0), dict(mt=1, waves=8, ksplit=4),
-          dict(mt=1, waves=8, ksplit=8), dict(mt=1, waves=4, ksplit=4), dict(mt=1, waves=4, ksplit=8),
-          dict(mt=2, waves=4, ksplit=4), dict(mt=2, waves=4, ksplit=8), dict(mt=2, waves=8, ksplit=8),
-          dict(mt=2, waves=8, ksplit=16)]
+variants = [dict(mt=0, waves=int(os.environ.get('TUNE', 0)), ksplit=0)] if os.environ.get('ONLY_DEFAULT') else [dict(mt=0, waves=0, ksplit=0), dict(mt=1, waves=4, ksplit=4), dict(mt=1, waves=4, ksplit=8),
+          dict(mt=2, waves=4, ksplit=4), dict(mt=2, waves=4, ksplit=8)]   # (8-wave k_dense_mfma: uint16 tiles only)
 for v in variants:
     h.set_tuning(**v)
     for _ in range(2):
