@@ -470,6 +470,34 @@ __global__ void k_build_image_shifted(const float *__restrict__ src, float *__re
     }
 }
 
+// ... and its float16 image for k_dense_lds X16 (w * scale = w1 + w2, scale = 1 / inv_scale: powers of two)
+__global__ void k_build_image_shifted_h16(const float *__restrict__ src, _Float16 *__restrict__ img,
+                                          int64_t n_masks, int cpm, int sig_h, int sig_w, int dy, int dx,
+                                          int n_chunks, const float *__restrict__ inv_scale) {
+    const int64_t n_px = (int64_t)sig_h * sig_w;
+    const int64_t total = n_masks * cpm * n_px;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int part = (int)(i % cpm);
+        const int64_t kp = i / cpm;
+        const int64_t k = kp / n_px, p = kp % n_px;            // destination pixel
+        const int y = (int)(p / sig_w), x = (int)(p % sig_w);
+        const int ys = y - dy, xs = x - dx;
+        float v = 0.f;
+        if (ys >= 0 && ys < sig_h && xs >= 0 && xs < sig_w)
+            v = src[((k * n_px) + (int64_t)ys * sig_w + xs) * cpm + part];
+        const int col = (int)(k * cpm + part);
+        const int g = col / GROUP, n = col % GROUP;
+        const int c = (int)(p / KC), q = (int)(p % KC);
+        const float ws = v * (1.0f / inv_scale[col]);
+        const _Float16 w1 = (_Float16)ws;
+        const _Float16 w2 = (_Float16)(ws - (float)w1);
+        _Float16 *block = img + (((size_t)g * n_chunks + c) * CHUNK_FLOATS) * 2;
+        block[h16_index(n, q, KC, 0)] = w1;
+        block[h16_index(n, q, KC, 1)] = w2;
+    }
+}
+
 // raw stack -> image 3 (NG groups + extras, 32-KiB slots of 128 pixels): groups as in image 2, then
 // the columns >= 16 NG in pairs, [pair][pixel][2] floats
 __global__ void k_build_image3(const float *__restrict__ src, float *__restrict__ img,
@@ -513,7 +541,7 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             const int32_t *__restrict__ rows = nullptr,
             const float *const *__restrict__ wg_img = nullptr, int *__restrict__ kcount = nullptr,
             const float *__restrict__ inv_scale = nullptr) {
-    static_assert(!X16 || (NE == 0 && NG >= 1 && IND != 1 && ABL == 0 && sizeof(T) <= 2),
+    static_assert(!X16 || (NE == 0 && NG >= 1 && ABL == 0 && sizeof(T) <= 2),
                   "X16: 1- / 2-byte integer pixels on the matrix cores only");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     using TR = InTraits<T>;
@@ -1821,6 +1849,7 @@ static int launch_lds(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld
 // 128 frames (row lists padded with -1).  ONE launch of k_dense_lds<.., IND> for the tile.
 struct ShiftCache {
     std::unordered_map<uint64_t, float *> images;       // key (dy, dx) -> device image
+    bool x16 = false;                                   // the images hold float16 pieces (k_dense_lds X16)
     size_t image_bytes = 0;
     int sig_h = 0, sig_w = 0;
     int32_t *rows_dev = nullptr;
@@ -1872,7 +1901,12 @@ static int launch_lds_shifted(ltmi_masks *m, const T *tile, int64_t n_frames, in
         m->shift_cache = c;
     }
     const size_t img_bytes = (size_t)m->n_groups * m->n_chunks * CHUNK_FLOATS * sizeof(float);
-    if (c->sig_h != sig_h || c->sig_w != sig_w || c->image_bytes != img_bytes) {
+    // 1- / 2-byte integer pixels against a stack that has column scales: exact float16 products
+    bool x16 = false;
+    if constexpr (sizeof(T) <= 2 && std::is_integral<T>::value)
+        x16 = m->inv_scale != nullptr && m->tune_ksplit_ring != 37;
+    if (c->sig_h != sig_h || c->sig_w != sig_w || c->image_bytes != img_bytes || c->x16 != x16) {
+        c->x16 = x16;
         for (auto &kv : c->images) (void)hipFree(kv.second);
         c->images.clear();
         c->sig_h = sig_h;
@@ -1916,9 +1950,14 @@ static int launch_lds_shifted(ltmi_masks *m, const T *tile, int64_t n_frames, in
         const int dy = (int)(int32_t)(key >> 32), dx = (int)(int32_t)(key & 0xffffffffu);
         const int64_t total = m->n_masks * cpm * m->n_px;
         const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 65535 * 16);
-        hipLaunchKernelGGL(k_build_image_shifted, dim3(blocks), dim3(256), 0, stream,
-                           (const float *)m->gmasks, img, m->n_masks, cpm, sig_h, sig_w, dy, dx,
-                           m->n_chunks);
+        if (x16)
+            hipLaunchKernelGGL(k_build_image_shifted_h16, dim3(blocks), dim3(256), 0, stream,
+                               (const float *)m->gmasks, (_Float16 *)img, m->n_masks, cpm, sig_h, sig_w,
+                               dy, dx, m->n_chunks, (const float *)m->inv_scale);
+        else
+            hipLaunchKernelGGL(k_build_image_shifted, dim3(blocks), dim3(256), 0, stream,
+                               (const float *)m->gmasks, img, m->n_masks, cpm, sig_h, sig_w, dy, dx,
+                               m->n_chunks);
         LTMI_HIP(hipGetLastError());
     }
     // row lists, padded per group to whole workgroups
@@ -1963,12 +2002,15 @@ static int launch_lds_shifted(ltmi_masks *m, const T *tile, int64_t n_frames, in
     LTMI_HIP(hipMemcpyAsync((void *)c->wg_img_dev, wg_host.data(), wg_host.size() * sizeof(float *),
                             hipMemcpyHostToDevice, stream));
     auto kern = lds_kernel<T, 1, 0, 1, 0, 2>();
+    if constexpr (sizeof(T) <= 2 && std::is_integral<T>::value) {
+        if (x16) kern = lds_kernel<T, 1, 0, 1, 0, 2, true>();
+    }
     if (!kern) return LTMI_E_DTYPE;
-    static bool attr_set[16] = {false};
-    if (!attr_set[m->device & 15]) {
+    static bool attr_set[16][2] = {{false}};
+    if (!attr_set[m->device & 15][x16 ? 1 : 0]) {
         LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      CFG::LDS_BYTES));
-        attr_set[m->device & 15] = true;
+        attr_set[m->device & 15][x16 ? 1 : 0] = true;
     }
     for (int gi = 0; gi < n_col_groups; ++gi)
         hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(CFG::WAVES * 64), CFG::LDS_BYTES, stream,
@@ -1976,11 +2018,11 @@ static int launch_lds_shifted(ltmi_masks *m, const T *tile, int64_t n_frames, in
                            out + gi * GROUP, ld_out, std::min(GROUP, m->n_cols - gi * GROUP),
                            accumulate, (float *)nullptr, 1, (const int32_t *)c->rows_dev,
                            (const float *const *)c->wg_img_dev + (size_t)gi * n_wg, (int *)nullptr,
-                           (const float *)nullptr);
+                           x16 ? (const float *)m->inv_scale + gi * GROUP : (const float *)nullptr);
     LTMI_HIP(hipGetLastError());
     snprintf(m->last_kernel, sizeof(m->last_kernel),
-             "k_dense_lds<%s,NG=1,shifted> grid=(%zu,1,1) x %d column group(s), shift groups=%zu",
-             typeid(T).name(), n_wg, n_col_groups, keys.size());
+             "k_dense_lds<%s,NG=1,shifted%s> grid=(%zu,1,1) x %d column group(s), shift groups=%zu",
+             typeid(T).name(), x16 ? ",f16" : "", n_wg, n_col_groups, keys.size());
     *handled = true;
     return LTMI_OK;
 }

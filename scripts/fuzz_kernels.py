@@ -171,7 +171,7 @@ for case in range(n_cases):
         lk = handle.last_kernel()
         kern = lk.split('<')[0] + ('+exact-int' if 'exact-int' in lk else '') + \
             ('+f64' if ',f64>' in lk else '') + \
-            ('+shifted' if 'shifted>' in lk else '') + ('+valu' if 'VALU' in lk else '') + \
+            ('+shifted' if 'shifted' in lk else '') + ('+valu' if 'VALU' in lk else '') + \
             ('+NG' + lk.split('NG=')[1][0] if 'NG=' in lk else '')
         kernels_seen[kern] = kernels_seen.get(kern, 0) + 1
         expect = ref + base if accumulate else ref

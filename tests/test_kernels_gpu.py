@@ -969,6 +969,21 @@ def test_shifted_masks_host_shifts(hip, tile_dtype, sig, n_masks, mask_dtype, ex
     ref, scale = _shift_ref(data, masks, shifts2)
     assert np.all(np.abs(res - ref) <= (1e-5 if rd in (np.float32, np.complex64) else 1e-12)
                   * (scale + 1))
+    # 1- / 2-byte integer pixels with more than 4 columns on the matrix-core path: the shifted images
+    # hold float16 pieces (X16); tuning 37 switches the same handle to float32 images and back
+    if dt.kind in 'ui' and dt.itemsize <= 2 and 'k_dense_lds' in h.last_kernel() \
+            and n_masks * (2 if md.kind == 'c' else 1) > 4:
+        assert ',f16' in h.last_kernel(), h.last_kernel()
+        assert np.all(np.abs(res - ref) <= 2e-6 * (scale + 1))
+        h.set_tuning(mt=0, waves=37, ksplit=0)
+        out32 = _dev(np.zeros((n, n_masks), dtype=rd))
+        h.apply_shifted_host(t.data_ptr(), dt, n, data[0].size, sig[0], sig[1], shifts2,
+                             out32.data_ptr(), n_masks, False)
+        torch.cuda.synchronize()
+        assert ',f16' not in h.last_kernel(), h.last_kernel()
+        res32 = out32.cpu().numpy()
+        res32 = res32 if res32.dtype == rd else res32.view(rd)
+        assert np.all(np.abs(res32 - res) <= 1e-5 * (scale + 1))
     h.close()
 
 
