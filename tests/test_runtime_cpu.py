@@ -896,3 +896,24 @@ def test_sparse_radial_bins_keep_the_requested_dtype():
     assert pm.radial_bins(16, 16, 32, 32, n_bins=10, use_sparse=True).dtype == np.float64
     assert pm.radial_bins(16, 16, 32, 32, n_bins=10, use_sparse=True, dtype=np.float32,
                           radius_inner=np.float64(0.25)).dtype == np.float64
+
+
+def test_sparse_integer_exactness_rule():
+    """common/container.py::_sparse_int_exact and hip.signed_representative (pure NumPy): an integer
+    sparse stack stays sparse iff bits(tile dtype) + bits(largest column sum of |values|) <= 52, with
+    unsigned values read as the signed numbers of their width."""
+    import scipy.sparse as sp
+    from libertem_amd.common.container import _sparse_int_exact
+    from libertem_amd.hip import signed_representative
+    assert np.array_equal(signed_representative(np.array([65530, 3, 0], np.uint16)), [-6, 3, 0])
+    assert np.array_equal(signed_representative(np.array([-6, 3], np.int32)), [-6, 3])
+    assert signed_representative(np.array([2**64 - 1], np.uint64))[0] == -1
+    rng = np.random.default_rng(0)
+    dense = np.where(rng.random((500, 40)) < 0.1, rng.integers(-9, 10, (500, 40)), 0)
+    m = sp.csr_matrix(dense.astype(np.int64))
+    assert _sparse_int_exact(m, (np.uint16,)) and _sparse_int_exact(m, (np.uint32, np.bool_))
+    assert not _sparse_int_exact(m, (np.int64,)) and not _sparse_int_exact(m, (np.float32,))
+    assert _sparse_int_exact(sp.csr_matrix(dense.astype(np.uint16)), (np.uint16,))      # 65527 = -9
+    big = sp.csr_matrix(dense.astype(np.int64) * (1 << 30))
+    assert _sparse_int_exact(big, (np.uint8,)) and not _sparse_int_exact(big, (np.uint16,))
+    assert _sparse_int_exact(sp.csr_matrix((500, 40), dtype=np.int64), (np.uint32,))
