@@ -21,8 +21,14 @@
 // bit-identical to k_dense_lds (different summation order, like any other tile shape).  Frames holding
 // +-inf produce NaN where the f32 instruction produces +-inf (inf - inf in the split).
 //
+// STATUS: opt-in (ltmi_masks_set_tuning code 36 / LTMI_SPLIT=1), NOT the default: on C5 it takes 8.2 - 8.9 ms
+// against the 7.7 - 7.9 ms of k_dense_lds -- the matrix pipe drops to 34 % busy, but the pre-split image is
+// 6 bytes per weight in 64 padded columns and its slots, re-read by every workgroup through the LDS-DMA
+// path, cost the frames their bandwidth (profiles/r03_split.txt).  Kept as the measured experiment and as
+// a second implementation the float32 kernel is checked against (test_float32_frames_on_bf16_matrix_cores).
+//
 // Reference interface: the same `tile.reshape((n, -1)) @ masks` of udf/masks.py:79-83 as the other
-// dense kernels; dispatched from ltmi_apply_masks for float32 tiles (ltmi_dense.hip launch_mfma).
+// dense kernels; reached from ltmi_apply_masks for float32 tiles (ltmi_dense.hip launch_mfma).
 #include <type_traits>
 #include "ltmi_common.h"
 
