@@ -1040,25 +1040,41 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             // (device-scope loads: the other workgroups' partials come from the L2, never from a line
             // this CU's L1 kept from an earlier launch; 8 independent loads in flight per thread)
             const int64_t kstride = n_frames * n_cols;
-            for (int idx = tid; idx < nf * nc; idx += NT) {
-                const int64_t f = fb0 + idx / nc;
-                const int col = c0 + idx % nc;
-                float *p = out + f * ld_out + col;
-                const float *src = partials + f * n_cols + col;
-                float acc_s = accumulate ? *p : 0.f;
-                for (int k0 = 0; k0 < ksplit; k0 += 8) {
-                    float v[8];
+            // 8 outputs x 8 splits = 64 loads in flight per thread and batch: the tail is a handful of
+            // L2 round trips, not one per (output, 8 splits) -- it is what every workgroup of the frame
+            // block waits for.  Each output still adds its partials in the order k = 0 .. ksplit - 1.
+            constexpr int OB = 8, KBATCH = 8;
+            const int n_out = nf * nc;
+            for (int o0 = tid; o0 < n_out; o0 += NT * OB) {
+                float acc_s[OB];
+                const float *src[OB];
+                float *dstp[OB];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        v[u] = k0 + u < ksplit
-                                   ? __hip_atomic_load(src + (k0 + u) * kstride, __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT)
-                                   : 0.f;
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (k0 + u < ksplit) acc_s += v[u];
+                for (int j = 0; j < OB; ++j) {
+                    const int idx = min(o0 + j * NT, n_out - 1);            // (clamped: discarded below)
+                    const int64_t f = fb0 + idx / nc;
+                    const int col = c0 + idx % nc;
+                    dstp[j] = out + f * ld_out + col;
+                    src[j] = partials + f * n_cols + col;
+                    acc_s[j] = accumulate ? *dstp[j] : 0.f;
                 }
-                *p = acc_s;
+                for (int k0 = 0; k0 < ksplit; k0 += KBATCH) {
+                    float v[OB][KBATCH];
+#pragma unroll
+                    for (int j = 0; j < OB; ++j)
+#pragma unroll
+                        for (int u = 0; u < KBATCH; ++u)
+                            v[j][u] = __hip_atomic_load(src[j] + (int64_t)min(k0 + u, ksplit - 1) * kstride,
+                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int j = 0; j < OB; ++j)
+#pragma unroll
+                        for (int u = 0; u < KBATCH; ++u)
+                            if (k0 + u < ksplit) acc_s[j] += v[j][u];
+                }
+#pragma unroll
+                for (int j = 0; j < OB; ++j)
+                    if (o0 + j * NT < n_out) *dstp[j] = acc_s[j];
             }
             if (tid == 0) *cnt = 0;                         // ready for the next launch
         }
@@ -1593,10 +1609,12 @@ static inline float *partial_sums(const ltmi_masks *m) {
     return m->partials ? (float *)((char *)m->partials + KCOUNT_BYTES) : nullptr;
 }
 static inline int *partial_counters(const ltmi_masks *m, int64_t n_blocks) {
-    // Off unless LTMI_KSPLIT_FUSED is set: measured on MI355X (profiles/r03_small_tiles.txt) the last
-    // workgroup's reduction is a serial tail on ONE CU and loses to the second launch, which spreads the
-    // same additions over the chip: 1 024 frames 78 vs 48 us, 4 096 frames 151 vs 121 us, 16 384 frames
-    // 477 vs 440 us.
+    // Off unless LTMI_KSPLIT_FUSED is set: measured on MI355X (profiles/r03_small_tiles.txt) the in-kernel
+    // reduction by the last-arriving workgroup loses to the second launch at every size -- final build,
+    // tail widened to 64 loads in flight per thread: 1 024 / 4 096 / 8 192 frames 61 / 135 / 193 us against
+    // 45 / 114 / 167 us.  The ~20 us it costs whatever the split are the device-scope fences: partials
+    // written under one XCD's L2 must be made visible to a workgroup on another XCD (L2 write-back +
+    // invalidate inside the kernel), which the kernel boundary of the second launch does once for all.
     static const bool off = getenv("LTMI_KSPLIT_FUSED") == nullptr;
     return (m->partials && !off && n_blocks * (int64_t)sizeof(int) <= (int64_t)KCOUNT_BYTES)
                ? (int *)m->partials : nullptr;
