@@ -1430,8 +1430,8 @@ extern "C" int ltmi_masks_create_dense(int device, const void *masks_host, int r
             }
         }
         // float16 images for 1- / 2-byte integer pixels (k_dense_lds X16) of every matrix-core layout
-        // this stack has without VALU columns: finite weights only.  LTMI_DENSE_F16=0: never.
-        const bool want_h1 = m->ng == 1 && m->n_groups == 1 && m->n_cols > 4;
+        // this stack has without VALU columns (one group: also for <= 4 columns): finite weights only.  LTMI_DENSE_F16=0: never.
+        const bool want_h1 = m->ng == 1 && m->n_groups == 1;
         const bool want_h2 = m->ng > 1 && m->img2 != nullptr;
         const bool want_h3 = m->img3 != nullptr && m->ng3 == 3 && m->ne3 == 0;
         if (e == hipSuccess && (want_h1 || want_h2 || want_h3)) {
@@ -1830,7 +1830,13 @@ static int launch_lds(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld
     if (m->ng == 1) {
         // at most 4 columns (CoM: 3, single-mask analyses: 1 or 2): all of them on the VALU -- a
         // 16-column MFMA tile would be >= 75 % padding that still costs matrix-pipe power
-        if (m->img3 && m->ng3 == 0 && m->tune_ksplit_ring != 33) {
+        // (1- / 2-byte integer pixels: the padded group with exact float16 products instead -- 1-byte
+        // pixels are VALU bound on the column kernel (uint8, 3 masks: 0.54 -> 0.89 of HBM), 2-byte ones
+        // gain a per cent; tuning 37 keeps the VALU columns)
+        bool x16_group = false;
+        if constexpr (sizeof(T) <= 2 && std::is_integral<T>::value)
+            x16_group = m->img_h != nullptr && m->tune_ksplit_ring != 37;
+        if (m->img3 && m->ng3 == 0 && m->tune_ksplit_ring != 33 && !x16_group) {
             if (m->ne3 == 2)
                 return launch_lds_extras<T, 0, 2>(m, tile, n_frames, ld, out, ld_out, accumulate,
                                                   stream);
