@@ -273,6 +273,42 @@ def test_exact_float16_products_not_for_non_finite_or_extreme_weights(hip):
     assert np.all(np.abs(res - ref) <= 1e-5 * scale + 1e-44)
 
 
+def test_float16_switches(hip, monkeypatch):
+    """LTMI_DENSE_F16=0 / LTMI_BELL_F16=0 (read when a handle is created): 1- / 2-byte integer pixels keep
+    the float32 matrix instruction, dense and blocked sparse; results agree with the default."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(12)
+    data = rng.integers(0, 60000, (150, 2048)).astype(np.uint16)
+    masks = (rng.random((16, 2048)) - 0.25).astype(np.float32)
+    res, kern = _apply(hip, data, masks, np.float32)
+    assert ',f16' in kern, kern
+    monkeypatch.setenv('LTMI_DENSE_F16', '0')
+    res0, kern0 = _apply(hip, data, masks, np.float32)
+    assert 'k_dense_lds' in kern0 and ',f16' not in kern0, kern0
+    scale = np.abs(data.astype(np.float64)) @ np.abs(masks).astype(np.float64).T
+    assert np.all(np.abs(res0 - res) <= 1e-5 * scale)
+    monkeypatch.delenv('LTMI_DENSE_F16')
+    centre = (np.arange(64) + 0.5) * 2048 / 64
+    dense = ((np.abs(np.arange(2048)[:, None] - centre[None, :]) < 40) *
+             (rng.random((2048, 64)) + 0.1)).astype(np.float32)
+    t = _dev(data)
+    got = {}
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv('LTMI_BELL_F16', '0')
+        monkeypatch.setenv('LTMI_SPARSE_BELL', '1')
+        h = hip.MaskHandle.csr(0, sp.csr_matrix(dense), np.float32)
+        out = _dev(np.zeros((150, 64), np.float32))
+        h.apply(t.data_ptr(), np.uint16, 150, 2048, out.data_ptr(), 64, False)
+        torch.cuda.synchronize()
+        got[off] = (out.cpu().numpy(), h.last_kernel())
+        h.close()
+    assert 'k_bell_flat' in got[False][1] and 'k_bell_apply' in got[True][1], (got[False][1], got[True][1])
+    ref = data.astype(np.float64) @ dense.astype(np.float64)
+    for off in (False, True):
+        assert np.all(np.abs(got[off][0] - ref) <= 1e-5 * np.abs(ref).max())
+
+
 def test_mfma_integer_exact(hip):
     # 0/1 masks on low-count data: every partial sum is an integer < 2**24 -> any order exact
     rng = np.random.default_rng(11)
