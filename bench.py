@@ -646,6 +646,29 @@ def main():
     total_frames = n_frames * world * args.steps
     value = total_frames / elapsed_max
 
+    # the same K steps on the float32 matrix instruction only (v_mfma_f32_16x16x4_f32: the strict reading
+    # of "MFMA f32" in the north star), same handle, same plan -- every rank takes this path
+    f32_leg = None
+    if args.config.startswith('c2'):
+        os.environ['LTMI_DENSE_F32_INSTR'] = '1'
+        try:
+            mf = measure(wl, args.steps, args.warmup, barrier, hip, n_check=8)
+            el = max_over_ranks(mf['elapsed'])
+            rf = mf['roofline']
+            f32_leg = {"instruction": "v_mfma_f32_16x16x4_f32", "steps": args.steps,
+                       "ms_per_step": el / args.steps * 1e3,
+                       "value": n_frames * world * args.steps / el, "unit": "frames/s",
+                       "whole_job_frac_of_hbm": n_frames * world * args.steps / el * n_px * itemsize
+                       / 1e9 / HBM_PEAK_GBS / world,
+                       "kernel": rf['kernel'], "kernel_avg_launch_ms": rf['avg_launch_ms'],
+                       "kernel_frac": rf['frac'], "check_rel_err_vs_float64": mf['check_rel_err']}
+            if ',f16' in rf['kernel']:
+                f32_leg["error"] = "the float16-piece kernel ran"
+        except BaseException as e:                        # noqa: BLE001  (never sinks the line)
+            f32_leg = {"error": repr(e)[:300]}
+        finally:
+            del os.environ['LTMI_DENSE_F32_INSTR']
+
     extra = {}
     out = {
         "metric": "frames/sec, ApplyMasksUDF 16 dense f32 masks (+ GB/s vs HBM roofline)"
@@ -666,11 +689,15 @@ def main():
         "config": {
             "workload": cfg['desc'] + f", per GPU; {world} GPU(s), nav-sharded (weak)",
             "frames_per_gpu": n_frames, "frame_bytes": n_px * itemsize,
-            "arithmetic": "float32 sums on the matrix cores of products that are formed exactly: "
-                          "uint16 pixels as two bytes x float32 weights as two float16 pieces of "
-                          "the column-scaled value (22 bits; v_mfma_f32_16x16x32_f16, k_dense_lds "
-                          "X16) -- kernels labelled ',f16'; other pixel types: pixels converted to "
-                          "f32 in-kernel, v_mfma_f32_16x16x4_f32.  f32 / complex64 masks and results",
+            "arithmetic": "f16x2-piece products, f32 accumulate, 22-bit weights",
+            "arithmetic_detail": "headline (kernels labelled ',f16'): uint16 pixels as two bytes x "
+                                 "float32 weights as two float16 pieces of the column-scaled value; "
+                                 "every product exact, summed in float32 by v_mfma_f32_16x16x32_f16; "
+                                 "weights below 2^-21 of their column maximum are added by a float32 "
+                                 "tail kernel ('+tail(n)'), stacks with more than 64 of them keep "
+                                 "v_mfma_f32_16x16x4_f32.  The key f32_instruction holds the same "
+                                 "steps on v_mfma_f32_16x16x4_f32 only (pixels converted to f32 "
+                                 "in-kernel).  f32 / complex64 masks and results",
             "step": "Context.run_udf / Context.run (plan + kernels + delivery of the complete "
                     "result to every rank's host)",
             "parallelism": f"nav-shard x{world}; results via {result_via}",
@@ -678,6 +705,7 @@ def main():
         "input_GBps_whole_job": value * n_px * itemsize / 1e9,
         "result_check_rel_err_vs_float64": m['check_rel_err'],
         "roofline": m['roofline'],
+        "f32_instruction": f32_leg,
         "result_via": result_via,
         "per_rank": per_rank,
     }

@@ -22,7 +22,7 @@ LIBDIR = os.path.join(HERE, '_lib')
 LIB = os.path.join(LIBDIR, 'libltmi.so')
 OBJDIR = os.path.join(HERE, '_lib', 'obj')
 
-SOURCES = ['ltmi_capi.cpp', 'ltmi_comm.cpp', 'ltmi_dense.hip', 'ltmi_sparse.hip', 'ltmi_reduce.hip', 'ltmi_fft.hip', 'ltmi_dense64.hip', 'ltmi_bell.hip', 'ltmi_mib.hip', 'ltmi_split.hip']
+SOURCES = ['ltmi_capi.cpp', 'ltmi_comm.cpp', 'ltmi_dense.hip', 'ltmi_sparse.hip', 'ltmi_reduce.hip', 'ltmi_fft.hip', 'ltmi_dense64.hip', 'ltmi_bell.hip', 'ltmi_mib.hip', 'ltmi_split.hip', 'ltmi_scatter.hip']
 # hipFFT for the Fourier-space operators (ltmi_fft.hip).  The loader binds libhipfft.so.0 to the copy
 # torch already has in the process (same soname), i.e. the one that matches torch's HIP runtime.
 LINK_LIBS = ['-L/opt/rocm/lib', '-lhipfft', '-ldl']
@@ -39,8 +39,9 @@ def find_hipcc():
 
 
 def _deps(src):
-    deps = [os.path.join(CSRC, src), os.path.join(CSRC, 'ltmi_common.h'),
-            os.path.join(os.path.dirname(HERE), 'include', 'ltmi.h'), os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, src), os.path.join(CSRC, 'ltmi_common.h'), header_path(),
+            os.path.join(CSRC, 'ltmi_scatter_loop.inc'),
+            os.path.abspath(__file__)]
     return [d for d in deps if os.path.exists(d)]
 
 
@@ -108,10 +109,20 @@ def build(force=False, verbose=True, asan=False, hardened=False):
     return lib
 
 
+def header_path():
+    """include/ltmi.h of the source tree; an installed package (no repo root above it) carries a copy
+    as libertem_amd/include/ltmi.h"""
+    for cand in (os.path.join(os.path.dirname(HERE), 'include', 'ltmi.h'),
+                 os.path.join(HERE, 'include', 'ltmi.h')):
+        if os.path.exists(cand):
+            return cand
+    raise RuntimeError("ltmi.h not found (looked next to the package and in libertem_amd/include)")
+
+
 def header_exports():
     """names of the functions include/ltmi.h declares"""
     import re
-    with open(os.path.join(os.path.dirname(HERE), 'include', 'ltmi.h')) as f:
+    with open(header_path()) as f:
         hdr = f.read()
     names = set(re.findall(r'\b(ltmi_[a-z_0-9]+)\s*\(', hdr))
     return sorted(names)

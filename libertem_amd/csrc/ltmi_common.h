@@ -112,6 +112,13 @@ double bell_mac_ratio(const int64_t *indptr, const int64_t *indices, int nc, int
 void *bell_build(const int64_t *indptr, const int64_t *indices, const float *vals, int nc,
                  int64_t n_px, int64_t n_masks, int *err);
 void bell_destroy(void *image);
+// sparse stacks on the vector ALUs, one float32 FMA per stored entry (ltmi_scatter.hip)
+double scat_fill(const int64_t *indptr, const int64_t *indices, int nc, int64_t n_px, int64_t n_masks);
+void *scat_build(const int64_t *indptr, const int64_t *indices, const float *vals, int nc, int64_t n_px,
+                 int64_t n_masks, int *err);
+void scat_destroy(void *set);
+int scat_apply(ltmi_masks *m, void *set, int cplx, const void *tile, int tile_dtype, int64_t n_frames,
+               int64_t ld_tile, void *out, int64_t ld_out, int accumulate, hipStream_t stream, bool *handled);
 // float32 frames x multi-group float32 stacks on the bf16 matrix cores, float32-accurate (ltmi_split.hip)
 bool split_selected(bool tuned);
 bool split_wanted(int n_cols, int64_t n_px);
@@ -149,6 +156,15 @@ struct ltmi_masks {
     float *img2_h = nullptr;     // ... of image 2 (ng > 1)
     float *img3_h = nullptr;     // ... of image 3 without VALU columns (3 groups)
     float *inv_scale = nullptr;
+    // small weights that two float16 pieces do not carry to 2^-19 relative: left out of the float16
+    // images; k_dense_tail_pre forms their float32 products (tail_scratch: n_frames x tail_n), the
+    // epilogue of k_dense_lds X16 adds them
+    int32_t *tail_px = nullptr, *tail_col = nullptr;
+    float *tail_val = nullptr;
+    int tail_n = 0;
+    float *tail_scratch = nullptr;
+    size_t tail_scratch_bytes = 0;
+    bool x16_used = false, tail_ready = false;
     // float64 results on the f64 matrix cores (ltmi_dense64.hip)
     double *img64 = nullptr;
     int n_groups64 = 0, n_chunks64 = 0;

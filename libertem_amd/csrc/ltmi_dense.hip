@@ -75,11 +75,21 @@ __host__ __device__ static inline int h16_index(int n, int q, int kb, int plane)
     return (n * kb + unit * 4) * 2 + j;
 }
 
+// do two float16 pieces carry the (column-scaled) weight to 2^-19 relative?  (host and device: same IEEE
+// conversions, same answer -- the host lists the weights that fail, the image builder leaves them out)
+__host__ __device__ static inline bool h16_pieces_exact_enough(float ws) {
+    const _Float16 w1 = (_Float16)ws;
+    const float r = ws - (float)w1;
+    const _Float16 w2 = (_Float16)r;
+    return fabsf(r - (float)w2) <= ldexpf(fabsf(ws), -19);
+}
+
 // layout: 1 = standard image (one group tile, chunks of KC), 2 = slot-major image 2 (ng groups per slot
 // of kb = 128 pixels), 3 = image 3 without VALU columns (ng groups per slot, slot_floats floats per slot)
 __global__ void k_build_image_h16(const float *__restrict__ src, _Float16 *__restrict__ img,
                                   int64_t n_masks, int cpm, int64_t n_px, int n_slots, int ng,
-                                  int layout, int slot_floats, const float *__restrict__ scale) {
+                                  int layout, int slot_floats, const float *__restrict__ scale,
+                                  const float *__restrict__ amax) {
     const int64_t total = n_masks * cpm * n_px;
     const int kb = layout == 1 ? KC : 128;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -94,12 +104,31 @@ __global__ void k_build_image_h16(const float *__restrict__ src, _Float16 *__res
         if (layout == 1) base = ((size_t)g * n_slots + slot) * CHUNK_FLOATS;
         else if (layout == 2) base = ((((size_t)(g / ng) * n_slots + slot) * ng + g % ng) * GROUP) * kb;
         else base = (size_t)slot * slot_floats + (size_t)g * GROUP * kb;
-        const float ws = src[i] * scale[col];             // (power-of-two scale: exact)
+        // (power-of-two scale: exact; the few small weights that two float16 pieces do not carry to 2^-19
+        // relative are left out here and added in float32 (k_dense_tail_pre + the epilogue of k_dense_lds) -- same rule as the host's)
+        float ws = src[i] * scale[col];
+        if (ws != 0.f && fabsf(src[i]) < ldexpf(amax[col], -20) && !h16_pieces_exact_enough(ws)) ws = 0.f;
         const _Float16 w1 = (_Float16)ws;
         const _Float16 w2 = (_Float16)(ws - (float)w1);
         img[base * 2 + h16_index(n, q, kb, 0)] = w1;
         img[base * 2 + h16_index(n, q, kb, 1)] = w2;
     }
+}
+
+// The weights the float16 images leave out (k_build_image_h16; at most DENSE_TAIL_MAX per stack): before the
+// matrix kernel of such a stack runs, this kernel forms w * pixel for every left-out entry and result
+// row -- one float32 product per stored entry like the reference's matrix product (udf/masks.py:59-77)
+// -- into a device scratch (n_frames x n_tail); the matrix kernel's epilogue adds them to its column
+// sums (k_dense_lds X16: `tail_add`).  One thread per result row.
+constexpr int DENSE_TAIL_MAX = 64;
+template <typename T>
+__global__ void k_dense_tail_pre(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
+                                 const int32_t *__restrict__ px, const float *__restrict__ val, int n_tail,
+                                 float *__restrict__ scratch, const int32_t *__restrict__ rows) {
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames) return;
+    const T *row = tile + (rows ? (int64_t)rows[f] : f) * ld;
+    for (int e = 0; e < n_tail; ++e) scratch[f * n_tail + e] = val[e] * (float)row[px[e]];
 }
 
 // ---- per-input-dtype loading / conversion of 8 consecutive pixels ---------------------------
@@ -540,7 +569,8 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             int n_cols, int accumulate, float *__restrict__ partials, int ksplit,
             const int32_t *__restrict__ rows = nullptr,
             const float *const *__restrict__ wg_img = nullptr, int *__restrict__ kcount = nullptr,
-            const float *__restrict__ inv_scale = nullptr) {
+            const float *__restrict__ inv_scale = nullptr, const float *__restrict__ tail_add = nullptr,
+            const int32_t *__restrict__ tail_col = nullptr, int n_tail = 0) {
     static_assert(!X16 || (NE == 0 && NG >= 1 && ABL == 0 && sizeof(T) <= 2),
                   "X16: 1- / 2-byte integer pixels on the matrix cores only");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -990,6 +1020,12 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                     else if (NACC == 2) v += acc[tl][g][NACC - 1][r];
                     v += acc2[tl][g][r];
                     if (X16) v *= inv_scale[col];             // undo the column's power-of-two scale
+                    if constexpr (X16) {
+                        // the weights the float16 image leaves out: their float32 products (k_dense_tail_pre)
+                        if (n_tail > 0 && ks == 0)
+                            for (int e = 0; e < n_tail; ++e)
+                                if (tail_col[e] == col) v += tail_add[f * n_tail + e];
+                    }
                     if (ksplit == 1) {
                         float *p = out + f * ld_out + col;
                         *p = accumulate ? (*p + v) : v;
@@ -1455,24 +1491,57 @@ extern "C" int ltmi_masks_create_dense(int device, const void *masks_host, int r
                     (void)std::frexp(amax[(size_t)k], &ex);
                     if (ex < -100 || ex > 100) finite = false;
                 }
+            // Two float16 pieces of the scaled weight carry 22 bits down to 2^-19 of the column's largest
+            // weight and an absolute 2^-39 max|w| below that (the float16 subnormal grid).  A weight whose two
+            // pieces miss it by more than 2^-19 relative (only possible below 2^-20 of the maximum; weights
+            // with few significant bits -- 0/1 masks, k 2^-24 random numbers -- are exact at any size) is
+            // left out of the float16 images and added in float32 (k_dense_tail_pre, then the epilogue of the matrix kernel).  A stack with more
+            // than DENSE_TAIL_MAX of them (smooth masks with long tails: Gaussians) keeps the float32
+            // instruction altogether.
+            std::vector<float> scale((size_t)m->n_cols, 1.f), inv((size_t)m->n_cols, 1.f);
+            std::vector<int32_t> tail_px, tail_col;
+            std::vector<float> tail_val;
             if (finite) {
-                std::vector<float> scale((size_t)m->n_cols, 1.f), inv((size_t)m->n_cols, 1.f);
                 for (int k = 0; k < m->n_cols; ++k)
                     if (amax[(size_t)k] > 0.f) {
                         int ex;
                         (void)std::frexp(amax[(size_t)k], &ex);           // amax = f 2^ex, f in [0.5, 1)
                         // amax 2^sh in [16384, 32768): the largest scale whose w1 stays a finite float16.
                         // (k_bell_flat keeps 256 w S finite and scales to [64, 128); here the high bytes
-                        // have their own accumulator.)  w S = w1 + w2 then holds with relative error
-                        // 2^-22 for |w| >= 2^-19 max|w| of the column and absolute error 2^-39 max|w|
-                        // below that: every weight down to 2^-22 of its column's maximum is within 1e-5
+                        // have their own accumulator.)
                         const int sh = std::max(-120, std::min(120, 15 - ex));
                         scale[(size_t)k] = std::ldexp(1.0f, sh);
                         inv[(size_t)k] = std::ldexp(1.0f, -sh);
                     }
-                float *scale_dev = nullptr;
+                for (int64_t k = 0; k < n_masks && finite; ++k)
+                    for (int64_t p = 0; p < n_px && finite; ++p)
+                        for (int c2 = 0; c2 < cpm; ++c2) {
+                            const float v = hm[(k * n_px + p) * cpm + c2];
+                            const int col = (int)(k * cpm + c2);
+                            if (v == 0.f || std::fabs(v) >= std::ldexp(amax[(size_t)col], -20)) continue;
+                            if (ltmi::h16_pieces_exact_enough(v * scale[(size_t)col])) continue;
+                            if ((int)tail_val.size() == ltmi::DENSE_TAIL_MAX) { finite = false; break; }
+                            tail_px.push_back((int32_t)p);
+                            tail_col.push_back(col);
+                            tail_val.push_back(v);
+                        }
+            }
+            if (finite) {
+                float *scale_dev = nullptr, *amax_dev = nullptr;
                 e = hipMalloc((void **)&m->inv_scale, inv.size() * sizeof(float));
                 if (e == hipSuccess) e = hipMalloc((void **)&scale_dev, scale.size() * sizeof(float));
+                if (e == hipSuccess) e = hipMalloc((void **)&amax_dev, amax.size() * sizeof(float));
+                if (e == hipSuccess) e = hipMemcpy(amax_dev, amax.data(), amax.size() * sizeof(float), hipMemcpyHostToDevice);
+                if (e == hipSuccess && !tail_val.empty()) {
+                    const size_t nt = tail_val.size();
+                    m->tail_n = (int)nt;
+                    e = hipMalloc((void **)&m->tail_px, nt * sizeof(int32_t));
+                    if (e == hipSuccess) e = hipMalloc((void **)&m->tail_col, nt * sizeof(int32_t));
+                    if (e == hipSuccess) e = hipMalloc((void **)&m->tail_val, nt * sizeof(float));
+                    if (e == hipSuccess) e = hipMemcpy(m->tail_px, tail_px.data(), nt * sizeof(int32_t), hipMemcpyHostToDevice);
+                    if (e == hipSuccess) e = hipMemcpy(m->tail_col, tail_col.data(), nt * sizeof(int32_t), hipMemcpyHostToDevice);
+                    if (e == hipSuccess) e = hipMemcpy(m->tail_val, tail_val.data(), nt * sizeof(float), hipMemcpyHostToDevice);
+                }
                 if (e == hipSuccess) e = hipMemcpy(m->inv_scale, inv.data(), inv.size() * sizeof(float), hipMemcpyHostToDevice);
                 if (e == hipSuccess) e = hipMemcpy(scale_dev, scale.data(), scale.size() * sizeof(float), hipMemcpyHostToDevice);
                 const int64_t total = n_masks * cpm * n_px;
@@ -1485,7 +1554,8 @@ extern "C" int ltmi_masks_create_dense(int device, const void *masks_host, int r
                     if (e != hipSuccess) return;
                     hipLaunchKernelGGL(ltmi::k_build_image_h16, dim3(blocks), dim3(256), 0, 0,
                                        (const float *)m->gmasks, (_Float16 *)*dst, n_masks, cpm, n_px,
-                                       n_slots, ng, layout, slot_floats, (const float *)scale_dev);
+                                       n_slots, ng, layout, slot_floats, (const float *)scale_dev,
+                                       (const float *)amax_dev);
                     e = hipGetLastError();
                 };
                 if (want_h1) build(&m->img_h, n_float, m->n_chunks, 1, 1, 0);
@@ -1497,6 +1567,7 @@ extern "C" int ltmi_masks_create_dense(int device, const void *masks_host, int r
                           3 * GROUP * 128);
                 if (e == hipSuccess) e = hipDeviceSynchronize();
                 if (scale_dev) (void)hipFree(scale_dev);
+                if (amax_dev) (void)hipFree(amax_dev);
             }
         }
         if (e != hipSuccess) {
@@ -1544,6 +1615,10 @@ extern "C" int ltmi_masks_destroy(ltmi_masks *m) {
     if (m->img2_h) (void)hipFree(m->img2_h);
     if (m->img3_h) (void)hipFree(m->img3_h);
     if (m->inv_scale) (void)hipFree(m->inv_scale);
+    if (m->tail_px) (void)hipFree(m->tail_px);
+    if (m->tail_col) (void)hipFree(m->tail_col);
+    if (m->tail_val) (void)hipFree(m->tail_val);
+    if (m->tail_scratch) (void)hipFree(m->tail_scratch);
     ltmi::dense64_destroy(m);
     shift_cache_destroy(m);
     if (m->partials) (void)hipFree(m->partials);
@@ -1561,11 +1636,12 @@ extern "C" int ltmi_masks_kind(const ltmi_masks *m, int *kind) {
 
 extern "C" int ltmi_masks_set_tuning(ltmi_masks *m, int mt, int waves, int ksplit) {
     if (!m) LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_set_tuning: null handle");
-    if (mt == 0 && ((waves >= 30 && waves <= 37) || (waves >= 40 && waves <= 41))) {
+    if (mt == 0 && ((waves >= 30 && waves <= 37) || (waves >= 40 && waves <= 42))) {
         // k_dense_lds: 30 = as dispatched, 31 / 32 = timing-only ablations (no DMA / no MFMA),
         // 34 / 35 = one / two frame tiles per wave; 36 = k_dense_split (float32 frames, ltmi_split.hip);
         // 37 = the float32 matrix instruction also where the exact float16 products (X16) apply;
-        // sparse stacks: 40 = as dispatched, 41 = SELL kernel even if a blocked image exists
+        // sparse stacks: 40 = as dispatched, 41 = SELL kernel even if a blocked / scatter image exists,
+        // 42 = not the scatter kernel (blocked image or SELL)
         m->tune_mt = 0;
         m->tune_waves = 0;
         m->tune_ksplit = ksplit;
@@ -1651,7 +1727,8 @@ static int launch_mfma_variant(ltmi_masks *m, const T *tile, int64_t n_frames, i
 template <typename T, int NG, int ABL, int IND, int NE, int TILES, bool X16 = false>
 static auto lds_kernel() -> void (*)(const T *, int64_t, int64_t, int64_t, const float *, int, float *,
                                      int64_t, int, int, float *, int, const int32_t *,
-                                     const float *const *, int *, const float *) {
+                                     const float *const *, int *, const float *, const float *,
+                                     const int32_t *, int) {
     // the timing-only ablations (tuning codes 31 / 32) and the one-tile-per-wave shape (34) exist for the
     // C2 kernel only -- uint16 pixels, one column group --: they are bench comparisons
     // (scripts/clock_probe.py, profiles/r02_tiles.txt), and every variant is minutes of compile time
@@ -1670,6 +1747,15 @@ static auto lds_kernel() -> void (*)(const T *, int64_t, int64_t, int64_t, const
         return k_dense_lds<T, NG, ABL, IND, NE, TILES, X16>;
 }
 
+// the float32 matrix instruction also where the exact float16 products (X16) apply: tuning code 37 on the
+// handle, or LTMI_DENSE_F32_INSTR=1 in the environment (read per launch: bench.py times both arithmetics
+// through Context.run_udf with the same cached handle)
+static inline bool f32_instruction_only(const ltmi_masks *m) {
+    if (m->tune_ksplit_ring == 37) return true;
+    const char *e = getenv("LTMI_DENSE_F32_INSTR");
+    return e && e[0] == '1';
+}
+
 static inline int lds_tiles(const ltmi_masks *m) {
     return m->tune_ksplit_ring == 34 ? 1 : 2;
 }
@@ -1681,7 +1767,8 @@ static int launch_lds_ng_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64
     using CFG = LdsCfg<NG, 0, TILES>;
     const int abl = m->tune_ksplit_ring == 31 ? 2 : (m->tune_ksplit_ring == 32 ? 1 : 0);
     void (*kern)(const T *, int64_t, int64_t, int64_t, const float *, int, float *, int64_t, int,
-                 int, float *, int, const int32_t *, const float *const *, int *, const float *) =
+                 int, float *, int, const int32_t *, const float *const *, int *, const float *,
+                 const float *, const int32_t *, int) =
         abl == 2 ? lds_kernel<T, NG, 2, 0, 0, TILES>()
                  : (abl == 1 ? lds_kernel<T, NG, 1, 0, 0, TILES>()
                              : lds_kernel<T, NG, 0, 0, 0, TILES>());
@@ -1691,12 +1778,15 @@ static int launch_lds_ng_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64
     // instruction: tests, benches)
     bool x16 = false;
     if constexpr (sizeof(T) <= 2 && std::is_integral<T>::value) {
-        x16 = (NG == 1 ? m->img_h : m->img2_h) != nullptr && abl == 0 && m->tune_ksplit_ring != 37;
+        x16 = (NG == 1 ? m->img_h : m->img2_h) != nullptr && abl == 0 && !f32_instruction_only(m);
         if (x16)
             kern = rows ? lds_kernel<T, NG, 0, 2, 0, TILES, true>()
                         : lds_kernel<T, NG, 0, 0, 0, TILES, true>();
+        m->x16_used = x16;
     }
-    if (!kern) return LTMI_E_DTYPE;
+    if (!kern)
+        LTMI_FAIL(LTMI_E_DTYPE, "k_dense_lds<%s, NG=%d>: tuning code %d (ablations / one tile per wave) is built for "
+                  "uint16 tiles and one column group only", typeid(T).name(), NG, m->tune_ksplit_ring);
     static bool attr_set[16][8] = {{false}};
     const int variant = (rows ? 3 : abl) + (x16 ? 4 : 0);
     if (!attr_set[m->device & 15][variant]) {
@@ -1724,7 +1814,9 @@ static int launch_lds_ng_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64
     hipLaunchKernelGGL(kern, grid, dim3(CFG::WAVES * 64), CFG::LDS_BYTES, stream, tile, ld, n_frames,
                        m->n_px, img, n_slots, out, ld_out, m->n_cols, accumulate, partial_sums(m),
                        ksplit, rows, (const float *const *)nullptr, kcount,
-                       x16 ? (const float *)m->inv_scale : (const float *)nullptr);
+                       x16 ? (const float *)m->inv_scale : (const float *)nullptr,
+                       (const float *)m->tail_scratch, (const int32_t *)m->tail_col,
+                       x16 && m->tail_ready ? m->tail_n : 0);
     LTMI_HIP(hipGetLastError());
     snprintf(m->last_kernel, sizeof(m->last_kernel),
              "k_dense_lds<%s,NG=%d,ring=%d,tiles=%d%s%s> grid=(%u,%u,%u)", typeid(T).name(), NG,
@@ -1761,12 +1853,15 @@ static int launch_lds_extras_t(ltmi_masks *m, const T *tile, int64_t n_frames, i
     bool x16 = false;
     if constexpr (NE == 0 && NG >= 1 && sizeof(T) <= 2 && std::is_integral<T>::value) {
         // (exactly 3 groups: the float16 image of image 3, see launch_lds_ng_t)
-        x16 = m->img3_h != nullptr && m->tune_ksplit_ring != 37;
+        x16 = m->img3_h != nullptr && !f32_instruction_only(m);
         if (x16)
             kern = rows ? lds_kernel<T, NG, 0, 2, NE, TILES, true>()
                         : lds_kernel<T, NG, 0, 0, NE, TILES, true>();
+        m->x16_used = x16;
     }
-    if (!kern) return LTMI_E_DTYPE;
+    if (!kern)
+        LTMI_FAIL(LTMI_E_DTYPE, "k_dense_lds<%s, NG=%d + %d VALU columns>: variant not built (tuning code %d)",
+                  typeid(T).name(), NG, NE, m->tune_ksplit_ring);
     static bool attr_set[16][4] = {{false}};
     const int variant = (rows ? 1 : 0) + (x16 ? 2 : 0);
     if (!attr_set[m->device & 15][variant]) {
@@ -1793,7 +1888,9 @@ static int launch_lds_extras_t(ltmi_masks *m, const T *tile, int64_t n_frames, i
                        m->n_px, x16 ? (const float *)m->img3_h : (const float *)m->img3, n_slots, out,
                        ld_out, m->n_cols, accumulate, partial_sums(m), ksplit, rows,
                        (const float *const *)nullptr, kcount,
-                       x16 ? (const float *)m->inv_scale : (const float *)nullptr);
+                       x16 ? (const float *)m->inv_scale : (const float *)nullptr,
+                       (const float *)m->tail_scratch, (const int32_t *)m->tail_col,
+                       x16 && m->tail_ready ? m->tail_n : 0);
     LTMI_HIP(hipGetLastError());
     if (NE > 0)
         snprintf(m->last_kernel, sizeof(m->last_kernel),
@@ -1835,7 +1932,7 @@ static int launch_lds(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld
         // gain a per cent; tuning 37 keeps the VALU columns)
         bool x16_group = false;
         if constexpr (sizeof(T) <= 2 && std::is_integral<T>::value)
-            x16_group = m->img_h != nullptr && m->tune_ksplit_ring != 37;
+            x16_group = m->img_h != nullptr && !f32_instruction_only(m);
         if (m->img3 && m->ng3 == 0 && m->tune_ksplit_ring != 33 && !x16_group) {
             if (m->ne3 == 2)
                 return launch_lds_extras<T, 0, 2>(m, tile, n_frames, ld, out, ld_out, accumulate,
@@ -1849,7 +1946,7 @@ static int launch_lds(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld
     // products (X16) a padded group costs less than they do -- the padded-group kernel instead
     bool x16_padded = false;
     if constexpr (sizeof(T) <= 2 && std::is_integral<T>::value)
-        x16_padded = m->ne3 > 0 && m->img2_h != nullptr && m->tune_ksplit_ring != 37;
+        x16_padded = m->ne3 > 0 && m->img2_h != nullptr && !f32_instruction_only(m);
     if (m->img3 && m->ng3 > 0 && m->tune_ksplit_ring != 33 && !x16_padded) {   // 33: force the padded-group kernel (bench)
 #define LTMI_EXTRAS(NG_, NE_)                                                                     \
     if (m->ng3 == NG_ && m->ne3 == NE_)                                                           \
@@ -1928,7 +2025,7 @@ static int launch_lds_shifted(ltmi_masks *m, const T *tile, int64_t n_frames, in
     // 1- / 2-byte integer pixels against a stack that has column scales: exact float16 products
     bool x16 = false;
     if constexpr (sizeof(T) <= 2 && std::is_integral<T>::value)
-        x16 = m->inv_scale != nullptr && m->tune_ksplit_ring != 37;
+        x16 = m->inv_scale != nullptr && m->tail_n == 0 && !f32_instruction_only(m);   // (tail pixels would have to shift along)
     if (c->sig_h != sig_h || c->sig_w != sig_w || c->image_bytes != img_bytes || c->x16 != x16) {
         c->x16 = x16;
         for (auto &kv : c->images) (void)hipFree(kv.second);
@@ -2029,7 +2126,7 @@ static int launch_lds_shifted(ltmi_masks *m, const T *tile, int64_t n_frames, in
     if constexpr (sizeof(T) <= 2 && std::is_integral<T>::value) {
         if (x16) kern = lds_kernel<T, 1, 0, 1, 0, 2, true>();
     }
-    if (!kern) return LTMI_E_DTYPE;
+    if (!kern) LTMI_FAIL(LTMI_E_DTYPE, "k_dense_lds<%s, shifted>: variant not built", typeid(T).name());
     static bool attr_set[16][2] = {{false}};
     if (!attr_set[m->device & 15][x16 ? 1 : 0]) {
         LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2042,7 +2139,8 @@ static int launch_lds_shifted(ltmi_masks *m, const T *tile, int64_t n_frames, in
                            out + gi * GROUP, ld_out, std::min(GROUP, m->n_cols - gi * GROUP),
                            accumulate, (float *)nullptr, 1, (const int32_t *)c->rows_dev,
                            (const float *const *)c->wg_img_dev + (size_t)gi * n_wg, (int *)nullptr,
-                           x16 ? (const float *)m->inv_scale + gi * GROUP : (const float *)nullptr);
+                           x16 ? (const float *)m->inv_scale + gi * GROUP : (const float *)nullptr,
+                           (const float *)nullptr, (const int32_t *)nullptr, 0);
     LTMI_HIP(hipGetLastError());
     snprintf(m->last_kernel, sizeof(m->last_kernel),
              "k_dense_lds<%s,NG=1,shifted%s> grid=(%zu,1,1) x %d column group(s), shift groups=%zu",
@@ -2077,8 +2175,35 @@ static int launch_mfma(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t l
         }
     }
     if (vector_loads_ok(tile, ld, sizeof(T)) && m->tune_mt == 0 && m->tune_waves == 0 &&
-        lds_kernel_applies<T>(m))
-        return launch_lds<T>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+        lds_kernel_applies<T>(m)) {
+        // a stack with weights that its float16 images leave out: their float32 products first
+        // (k_dense_tail_pre, device scratch), the matrix kernel's epilogue adds them
+        m->tail_ready = false;
+        if constexpr (sizeof(T) <= 2 && std::is_integral<T>::value) {
+            if (m->tail_n > 0 && !f32_instruction_only(m)) {
+                const size_t need = (size_t)n_frames * m->tail_n * sizeof(float);
+                if (m->tail_scratch_bytes < need) {
+                    if (m->tail_scratch) LTMI_HIP(hipFree(m->tail_scratch));
+                    m->tail_scratch = nullptr;
+                    m->tail_scratch_bytes = 0;
+                    LTMI_HIP(hipMalloc((void **)&m->tail_scratch, need));
+                    m->tail_scratch_bytes = need;
+                }
+                hipLaunchKernelGGL(k_dense_tail_pre<T>, dim3((unsigned)((n_frames + 255) / 256)), dim3(256),
+                                   0, stream, tile, ld, n_frames, (const int32_t *)m->tail_px,
+                                   (const float *)m->tail_val, m->tail_n, m->tail_scratch, m->roi_rows);
+                LTMI_HIP(hipGetLastError());
+                m->tail_ready = true;
+            }
+        }
+        m->x16_used = false;
+        const int rc_lds = launch_lds<T>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+        if (rc_lds == LTMI_OK && m->x16_used && m->tail_ready) {
+            const size_t l = strlen(m->last_kernel);
+            snprintf(m->last_kernel + l, sizeof(m->last_kernel) - l, " +tail(%d)", m->tail_n);
+        }
+        return rc_lds;
+    }
     int waves = m->tune_waves ? m->tune_waves : 4;
     int mt = m->tune_mt ? m->tune_mt : (n_frames >= 256 * waves * 32 ? 2 : 1);
     if (m->ng == 4) { mt = 1; }   // keep the accumulator/LDS budget in check

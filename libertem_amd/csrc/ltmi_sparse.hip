@@ -54,6 +54,7 @@ struct CsrImage {
     int *row_off = nullptr;     // [(pass * n_chunks + chunk) * mpt * 4 + slot * 4 + wave]
     int *row_len = nullptr;
     size_t n_rows = 0;
+    void *scat = nullptr;       // ltmi_scatter.hip: the stack for k_scatter (images built per pixel size on first use)
     int *active = nullptr;      // chunks with entries, concatenated per pass
     int *active_off = nullptr;  // [n_pass + 1]
     void *bell = nullptr;       // blocked image for the matrix-core kernel (ltmi_bell.hip) or null
@@ -285,6 +286,7 @@ int csr_destroy(ltmi_masks *m) {
     if (c->active) (void)hipFree(c->active);
     if (c->active_off) (void)hipFree(c->active_off);
     bell_destroy(c->bell);
+    scat_destroy(c->scat);
     delete c;
     m->csr = nullptr;
     return LTMI_OK;
@@ -455,6 +457,13 @@ int csr_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames,
         }
         LTMI_FAIL(LTMI_E_DTYPE, "sparse masks with float64 results: tile dtype %s is not supported",
                   dtype_name(tile_dtype));
+    }
+    // one float32 FMA per stored entry on the vector ALUs (k_scatter; tuning 41: SELL kernel, 42: blocked image)
+    if (c->scat && m->tune_ksplit_ring != 41 && m->tune_ksplit_ring != 42) {
+        bool handled = false;
+        const int rc = scat_apply(m, c->scat, c->cplx, tile, tile_dtype, n_frames, ld_tile, out, ld_out,
+                                  accumulate, stream, &handled);
+        if (rc != LTMI_OK || handled) return rc;
     }
     // localised stacks: blocked image on the matrix cores (set_tuning 41 forces the SELL kernel)
     if (c->bell && m->tune_ksplit_ring != 41) {
@@ -644,6 +653,26 @@ extern "C" int ltmi_masks_create_csr(int device, const int64_t *indptr, const in
             int err = LTMI_OK;
             c->bell = ltmi::bell_build(indptr, indices, vals, nc, n_px, n_masks, &err);
             if (!c->bell) {
+                ltmi::csr_destroy(m);
+                delete m;
+                return err;
+            }
+        }
+    }
+    // Stacks with at least 64 columns whose entries cluster in runs of neighbouring columns (radial bins,
+    // rings, any banded stack: >= 1.2 stored entries per 8-column window) also get the scatter image
+    // (ltmi_scatter.hip: exact float32 FMAs on the vector ALUs, every 1- / 2- / 4-byte pixel type).
+    // LTMI_SPARSE_SCATTER=0 / 1 forces never / always.
+    {
+        const char *force = getenv("LTMI_SPARSE_SCATTER");
+        bool build = nnz > 0 && !c->f64 && n_masks * nc >= 64;
+        if (force && force[0] == '0') build = false;
+        else if (force && force[0] == '1') build = nnz > 0 && !c->f64;
+        else if (build) build = ltmi::scat_fill(indptr, indices, nc, n_px, n_masks) >= 0.15;
+        if (build) {
+            int err = LTMI_OK;
+            c->scat = ltmi::scat_build(indptr, indices, vals, nc, n_px, n_masks, &err);
+            if (!c->scat) {
                 ltmi::csr_destroy(m);
                 delete m;
                 return err;

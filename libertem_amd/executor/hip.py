@@ -840,8 +840,10 @@ class HipJobExecutor(JobExecutor):
             self._make_current()
             self.last_collective = 'ltmi_comm'
             if full.dtype == torch.bool:
-                t = full.to(torch.uint8).contiguous()
-                comm.all_reduce_sum(t.data_ptr(), np.uint8, t.numel(), stream=self._stream_ptr)
+                # OR as a sum of 0 / 1 in int32: cannot wrap for any world size (uint8 would at 256 ranks
+                # that all hold True); torch's path uses MAX
+                t = full.to(torch.int32).contiguous()
+                comm.all_reduce_sum(t.data_ptr(), np.int32, t.numel(), stream=self._stream_ptr)
                 return t != 0
             if not full.is_contiguous():
                 full = full.contiguous()

@@ -917,3 +917,30 @@ def test_sparse_integer_exactness_rule():
     big = sp.csr_matrix(dense.astype(np.int64) * (1 << 30))
     assert _sparse_int_exact(big, (np.uint8,)) and not _sparse_int_exact(big, (np.uint16,))
     assert _sparse_int_exact(sp.csr_matrix((500, 40), dtype=np.int64), (np.uint32,))
+
+
+def test_fingerprint_sees_column_bands_and_single_elements():
+    """Round-3 review: an evenly strided sample of a (16, 256, 256) float32 stack (step = one row) hashes
+    columns 0..15 of every row only -- a column-band edit or a small block went unseen and the cached
+    device image / plan of the old masks was used.  Buffers up to 64 MiB are hashed in full."""
+    from libertem_amd.common.fingerprint import array_fingerprint, fingerprint, FULL_BYTES
+    m = np.random.default_rng(0).random((16, 256, 256)).astype(np.float32)
+    f0 = array_fingerprint(m)
+    assert array_fingerprint(m.copy()) == f0
+    for edit in (lambda a: a.__setitem__((slice(None), slice(None), slice(100, 110)), 0),
+                 lambda a: a.__setitem__((3, slice(50, 60), slice(60, 70)), 7),
+                 lambda a: a.__setitem__((7, 123, 45), -1.0),
+                 lambda a: a.__setitem__((15, 255, 255), 2.0)):
+        m2 = m.copy()
+        edit(m2)
+        assert array_fingerprint(m2) != f0
+    # captured by a factory: the factory's fingerprint follows
+    fac = (lambda: m)
+    g0 = fingerprint(fac)
+    m[:, :, 100:110] = 0
+    assert fingerprint(fac) != g0
+    # beyond the full-hash limit: sampled, but not with a stride that divides the row length
+    big = np.zeros((FULL_BYTES // 4 // 1024 // 1024 + 1, 1024, 1024), np.float32)
+    fb = array_fingerprint(big)
+    big[:, :, 100:110] = 1
+    assert array_fingerprint(big) != fb

@@ -595,6 +595,18 @@ def test_masks_modified_in_place_between_runs(ctx):
             for _ in range(2):                      # second run of the same state: cache / plan hit
                 got = ctx.run_udf(dataset=ds, udf=udf)['intensity'].data
                 assert _close(got, opath.apply_masks(data, masks, num_partitions=2), F32_TOL)
+    # (round-3 review) a 4 MiB stack edited in a column band / a small block: an evenly strided sample saw
+    # columns 0..15 of every row only
+    data2 = rng.integers(0, 1000, (2, 3, 256, 256)).astype(np.uint16)
+    big = rng.random((16, 256, 256)).astype(np.float32)
+    ds2 = _device_ds(ctx, data2, 1)
+    udf2 = ApplyMasksUDF(mask_factories=lambda: big, use_sparse=False, mask_count=16)
+    for change in (lambda: None, lambda: big.__setitem__((slice(None), slice(None), slice(100, 110)), 0),
+                   lambda: big.__setitem__((3, slice(50, 60), slice(60, 70)), 7.0)):
+        change()
+        for _ in range(2):
+            got = ctx.run_udf(dataset=ds2, udf=udf2)['intensity'].data
+            assert _close(got, opath.apply_masks(data2, big, num_partitions=1), F32_TOL)
     # a sparse stack whose value array is scaled in place
     dense = [np.where(rng.random((64, 64)) < 0.05, rng.random((64, 64)), 0).astype(np.float32)
              for _ in range(5)]
