@@ -24,18 +24,20 @@
 //
 // The loop itself (software pipelined over two register sets, every register named by hand) is generated:
 // scripts/gen_scatter_asm.py -> ltmi_scatter_loop.inc.  REGISTER CONTRACT with that file:
-//   compiler: v0..v31, s0..s11 (+ vcc); loop: v32..v127, s12..s99, m0, scc.
-//   v32 argument lanes | v33 / v38 lane * PITCH + offset of the buffer being read / the other one | v34 lane's
-//   byte offset of its 16-byte piece in the frame row (chunk table) | v35 lane * 4 | v36 / v37 row pointers
-//   (lanes 0..3) | v39 temp | v40..v55 pixel values + address temps of the two sets | v56..v119 accumulators,
-//   v120..v127 padding slots (dummy bundles, windows that reach beyond slot 63).
-//   s12..s19 header words of the two sets (bits 0-7 accumulator slot, bit 8 of word 3: end of the wave's work on
-//   the chunk, bits 16-31 LDS row offset of the NEXT block's pixel) | s20..s25 stream / table bases |
-//   s26..s29 temps | s30 / s31 stream offsets | s32 blocks left | s33 / s34 chunk index, end | s35 buffer |
-//   s36..s99 weights of the two sets.
-// A chunk = 1 KiB of every frame row = 8 SEGMENTS of 128 bytes which the builder composes (ChunkMixer) so that
-// the waves of the workgroup -- they meet at a barrier per chunk -- carry equal work: in a ring stack the ring
-// that is tangent to a detector row puts ~70 pixels of that row into ONE 32-column range.
+//   compiler: v0..v27, s0..s11; loop: v28..v127, s12..s99, vcc, m0, scc.
+//   v28 lane's LDS offset inside a buffer | v29 offset of a row's last whole 16-byte piece | v30:31 address temp |
+//   v32 argument lanes | v33 v28 + buffer being read | v34 lane's byte offset in the frame row (chunk being
+//   copied) | v35 (lane & 7) * 16 | v36..v39 row pointers of the wave's two copy instructions | v40..v55 pixel
+//   values + address temps of the two sets | v56..v119 accumulators, v120..v127 padding slots (dummy bundles).
+//   s12..s27 header words of the two sets: 4 bundle words (bits 0-7 accumulator slot, bit 8 of word 3: end of
+//   the wave's work on the chunk, bits 16-31 LDS row offset of the NEXT block's pixel) + the 4 segment offsets
+//   of the chunk whose copy starts at that end | s28..s31 stream bases | s32 header offset | s33 chunks left |
+//   s34 buffer | s35 temp | s36..s99 weights of the two sets.
+// A chunk = 512 bytes of every frame row = 4 SEGMENTS of 128 bytes which the builder composes (ChunkMixer) so
+// that the waves of the workgroup -- they meet at a barrier per chunk -- carry equal work: in a ring stack the
+// ring that is tangent to a detector row puts ~70 pixels of that row into ONE 32-column range.  Four chunk
+// buffers: the copy of chunk c + 4 starts when everybody has left chunk c (three chunks in flight, requests
+// spread over time instead of one burst per chunk; the workgroups start out of phase).
 #include "ltmi_common.h"
 #include "ltmi_scatter_loop.inc"
 #include <cstring>
@@ -50,7 +52,7 @@ namespace ltmi {
 constexpr int SC_WAVES = 16, SC_SLOTS = 64;                         // waves, accumulators per wave
 constexpr int SC_PASS = SC_WAVES * SC_SLOTS;                        // columns per pass
 constexpr int SC_FB = 64;                                           // frames per workgroup
-constexpr int SC_ROW = 1024, SC_SEG = 128, SC_NSEG = SC_ROW / SC_SEG;   // bytes of a row per chunk / per segment
+constexpr int SC_ROW = SCAT_ROWB, SC_SEG = 128, SC_NSEG = SC_ROW / SC_SEG;   // bytes of a row per chunk / per segment
 constexpr int SC_PAD_SLOT = 64;                                     // accumulator slot of dummy bundles (v120..)
 constexpr unsigned SC_END = 1u << 8;
 // columns per RANGE (the unit that is assigned to a wave): 32 for a full pass, fewer for narrow stacks so that
@@ -61,16 +63,17 @@ static inline int range_size(int64_t cols_in_pass) {
     return rs;
 }
 constexpr int SC_EPI = SC_WAVES * 64 * 33 * 4;                          // epilogue: 64 x 33 words per wave
-constexpr int SC_LDS = 2 * SCAT_BUF > SC_EPI ? 2 * SCAT_BUF : SC_EPI;
-static_assert(SCAT_PITCH == SC_ROW + 4 && SCAT_BUF == SC_FB * SCAT_PITCH && SCAT_ACC0 == 56, "generated loop");
+constexpr int SC_LDS = SCAT_NBUF * SCAT_BUF > SC_EPI ? SCAT_NBUF * SCAT_BUF : SC_EPI;
+static_assert(SCAT_PITCH == 2 * SC_ROW + 4 && SCAT_BUF == SC_FB / 2 * SCAT_PITCH && SCAT_ACC0 == 56 && SC_NSEG == 4,
+              "generated loop");
 
 struct ScatImage {                       // the image of a stack for ONE pixel size
     int sz = 0, n_pass = 0;
-    uint32_t *hdr = nullptr;             // 4 words per block
+    uint32_t *hdr = nullptr;             // 8 words per block: 4 bundle words, 4 segment offsets
     float *wts = nullptr;                // 32 weights per block
     int64_t *stream_off = nullptr;       // [n_pass * 16 + 1] first block of a wave's stream
     int32_t *n_blk = nullptr;            // [n_pass * 16] blocks of the stream (incl. the leading dummy)
-    int32_t *dma_off = nullptr;          // [chunks of all passes][64] byte offset in the frame row
+    int32_t *seg_tab = nullptr;          // [chunks of all passes + 4][4] byte offsets of a chunk's segments in the frame row
     int32_t *active_off = nullptr;       // [n_pass + 1]
     int32_t *col_of_slot = nullptr;      // [n_pass * 16 * 64] column of an accumulator slot, -1: none
     int32_t *tail_px = nullptr, *tail_col = nullptr;   // entries of pixels behind the last full 16-byte piece
@@ -92,7 +95,7 @@ struct ScatSet {                         // host copy of the CSR matrix + the im
 
 static void image_destroy(ScatImage *b) {
     if (!b) return;
-    void *p[] = {b->hdr, b->wts, b->stream_off, b->n_blk, b->dma_off, b->active_off, b->col_of_slot,
+    void *p[] = {b->hdr, b->wts, b->stream_off, b->n_blk, b->seg_tab, b->active_off, b->col_of_slot,
                  b->tail_px, b->tail_col, b->tail_val};
     for (void *q : p)
         if (q) (void)hipFree(q);
@@ -107,7 +110,7 @@ void scat_destroy(void *set) {
 }
 
 // ---- kernel -------------------------------------------------------------------------------------------
-#define SC_V32_127 "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+#define SC_V32_127 "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
 #define SC_S12_99 "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
 
 // 8 accumulators v[A .. A + 7] into compiler-visible values
@@ -117,15 +120,15 @@ void scat_destroy(void *set) {
                  : "=v"(R[0]), "=v"(R[1]), "=v"(R[2]), "=v"(R[3]), "=v"(R[4]), "=v"(R[5]), "=v"(R[6]), "=v"(R[7]))
 
 // ABL > 0: timing-only variants of the uint16 loop (LTMI_SCATTER_ABLATE: 1 weights from one hot line, 2 no
-// frame copies, 3 no LDS reads, 4 no FMAs, 5 = 1 + 2; results are garbage)
+// frame copies, 3 no LDS reads, 4 no FMAs, 5 = 1 + 2, 6 no chunk barriers; results are garbage)
 template <typename T, int ABL = 0>
-__global__ void __launch_bounds__(SC_WAVES * 64, 1) __attribute__((amdgpu_num_vgpr(32)))
+__global__ void __launch_bounds__(SC_WAVES * 64, 1) __attribute__((amdgpu_num_vgpr(28)))
 k_scatter(const T *__restrict__ tile, int64_t ld, int64_t n_frames, const uint32_t *__restrict__ hdr,
           const float *__restrict__ wts, const int64_t *__restrict__ stream_off,
-          const int32_t *__restrict__ n_blk, const int32_t *__restrict__ dma_off,
+          const int32_t *__restrict__ n_blk, const int32_t *__restrict__ seg_tab,
           const int32_t *__restrict__ active_off, const int32_t *__restrict__ col_of_slot,
           float *__restrict__ out, int64_t ld_out, int n_cols, int accumulate,
-          const int32_t *__restrict__ rows) {
+          const int32_t *__restrict__ rows, int64_t n_px_bytes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sc_lds[];      // at LDS address 0 (the loop assumes it)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -135,31 +138,42 @@ k_scatter(const T *__restrict__ tile, int64_t ld, int64_t n_frames, const uint32
     const int a0 = active_off[pass], a1 = active_off[pass + 1];
     const int wj = pass * SC_WAVES + j;
     {
-        const uint64_t hp = (uint64_t)(hdr + stream_off[wj] * 4);
+        const uint64_t hp = (uint64_t)(hdr + stream_off[wj] * 8);
         const uint64_t wp = (uint64_t)(wts + stream_off[wj] * 32);
-        const uint64_t tp = (uint64_t)dma_off;
-        const unsigned av[10] = {(unsigned)hp, (unsigned)(hp >> 32), (unsigned)wp, (unsigned)(wp >> 32),
-                                 (unsigned)tp, (unsigned)(tp >> 32), (unsigned)n_blk[wj], (unsigned)a0,
-                                 (unsigned)a1, (unsigned)(4 * j * SCAT_PITCH)};
+        const uint64_t tp = (uint64_t)(seg_tab + (int64_t)a0 * 4);
+        const unsigned phase = (unsigned)((blockIdx.x * 7u + blockIdx.y) & 15u);
+        const unsigned av[9] = {(unsigned)hp, (unsigned)(hp >> 32), (unsigned)wp, (unsigned)(wp >> 32),
+                                (unsigned)(a1 - a0 - 1), (unsigned)(2 * j * SCAT_PITCH), (unsigned)tp,
+                                (unsigned)(tp >> 32), phase};
         unsigned args = 0;
 #pragma unroll
-        for (int i = 0; i < 10; ++i) args = lane == i ? av[i] : args;
-        // rows 4 j .. 4 j + 3 of the workgroup's frames (beyond the last frame: the last one again)
-        int64_t fr = f0 + 4 * j + (lane & 3);
-        if (fr > n_frames - 1) fr = n_frames - 1;
-        if (rows) fr = rows[fr];
-        const uint64_t rp = (uint64_t)(tile + fr * ld);
-        const unsigned rowlo = (unsigned)rp, rowhi = (unsigned)(rp >> 32);
-        const unsigned lanebase = (unsigned)lane * SCAT_PITCH, lane4 = (unsigned)lane * 4u;
+        for (int i = 0; i < 9; ++i) args = lane == i ? av[i] : args;
+        // the wave copies the rows 4 j .. 4 j + 3 of the workgroup's frames, two per instruction (lanes 0-31 /
+        // 32-63); beyond the last frame: the last one again
+        unsigned rpl[2], rph[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            int64_t fr = f0 + 4 * j + 2 * k + (lane >> 5);
+            if (fr > n_frames - 1) fr = n_frames - 1;
+            if (rows) fr = rows[fr];
+            const uint64_t rp = (uint64_t)(tile + fr * ld);
+            rpl[k] = (unsigned)rp;
+            rph[k] = (unsigned)(rp >> 32);
+        }
+        const unsigned lanebase = (unsigned)(lane >> 1) * SCAT_PITCH + (unsigned)(lane & 1) * SCAT_ROWB;
+        const unsigned piece = (unsigned)(lane & 7) * 16u;
+        const unsigned limit = (unsigned)(n_px_bytes - 16);
         if (a0 < a1) {
 #define SC_RUN(NAME)                                                                                  \
-    asm volatile(SCAT_LOOP_##NAME ::"v"(args), "v"(lanebase), "v"(lane4), "v"(rowlo), "v"(rowhi)       \
-                 : "memory", "scc", SC_V32_127, SC_S12_99)
+    asm volatile(SCAT_LOOP_##NAME ::"v"(args), "v"(lanebase), "v"(piece), "v"(rpl[0]), "v"(rph[0]),     \
+                 "v"(rpl[1]), "v"(rph[1]), "v"(limit)                                                 \
+                 : "memory", "scc", "vcc", SC_V32_127, SC_S12_99)
             if constexpr (ABL == 1) SC_RUN(u16_a1);
             else if constexpr (ABL == 2) SC_RUN(u16_a2);
             else if constexpr (ABL == 3) SC_RUN(u16_a3);
             else if constexpr (ABL == 4) SC_RUN(u16_a4);
             else if constexpr (ABL == 5) SC_RUN(u16_a5);
+            else if constexpr (ABL == 6) SC_RUN(u16_a6);
             else if constexpr (std::is_same<T, uint8_t>::value) SC_RUN(u8);
             else if constexpr (std::is_same<T, int8_t>::value) SC_RUN(i8);
             else if constexpr (std::is_same<T, uint16_t>::value) SC_RUN(u16);
@@ -236,7 +250,8 @@ __global__ void k_scatter_tail(const T *__restrict__ tile, int64_t ld, int64_t n
 // between chunks (fixed seed), started from the better of the natural order and a strided interleave.
 struct ChunkMixer {
     const std::vector<uint16_t> &cnt;
-    explicit ChunkMixer(const std::vector<uint16_t> &c) : cnt(c) {}
+    int unit;                                      // segments that move together (contiguous bytes of a row: 128 * unit)
+    explicit ChunkMixer(const std::vector<uint16_t> &c, int u = 1) : cnt(c), unit(u) {}
     void cost(const int *segs, int *crit, int *total) const {
         int load[SC_WAVES] = {0};
         for (int i = 0; i < SC_NSEG; ++i) {
@@ -264,14 +279,20 @@ struct ChunkMixer {
             }
             return c;
         };
+        // (segs comes in natural order: consecutive entries are consecutive segments; a unit = `unit` of them)
+        const int upc = SC_NSEG / unit;                       // units per chunk
         std::vector<int> inter(segs.size(), -1);
         {
             std::vector<int> fill((size_t)n_chunks, 0);
+            const size_t n_units = segs.size() / unit;
             int k = 0;
-            for (int v : segs) {
-                if (v < 0) continue;
+            for (size_t u = 0; u < n_units; ++u) {
+                bool any = false;
+                for (int q = 0; q < unit; ++q) any |= segs[u * unit + q] >= 0;
+                if (!any) continue;
                 const int c = k % n_chunks;
-                inter[(size_t)c * SC_NSEG + fill[c]++] = v;
+                for (int q = 0; q < unit; ++q) inter[((size_t)c * upc + fill[c]) * unit + q] = segs[u * unit + q];
+                ++fill[c];
                 ++k;
             }
         }
@@ -285,9 +306,9 @@ struct ChunkMixer {
             for (long it = 0; it < iters; ++it) {
                 const int A = (int)(next() % n_chunks), B = (int)(next() % n_chunks);
                 if (A == B) continue;
-                const size_t ia = (size_t)A * SC_NSEG + next() % SC_NSEG, ib = (size_t)B * SC_NSEG + next() % SC_NSEG;
-                if (segs[ia] < 0 && segs[ib] < 0) continue;
-                std::swap(segs[ia], segs[ib]);
+                const size_t ia = ((size_t)A * upc + next() % upc) * unit, ib = ((size_t)B * upc + next() % upc) * unit;
+                auto swap_units = [&]() { for (int q = 0; q < unit; ++q) std::swap(segs[ia + q], segs[ib + q]); };
+                swap_units();
                 int ca, ta, cb, tb;
                 cost(segs.data() + (size_t)A * SC_NSEG, &ca, &ta);
                 cost(segs.data() + (size_t)B * SC_NSEG, &cb, &tb);
@@ -297,7 +318,7 @@ struct ChunkMixer {
                 if (d <= 0 || u < std::exp(-d / temp)) {
                     cc[A] = ca; ct[A] = ta; cc[B] = cb; ct[B] = tb;
                 } else {
-                    std::swap(segs[ia], segs[ib]);
+                    swap_units();
                 }
             }
         }
@@ -351,7 +372,7 @@ static ScatImage *build_image(const ScatSet &s, int sz, int *err) {
         std::vector<float> wts;
         std::vector<int64_t> stream_off((size_t)b->n_pass * SC_WAVES + 1, 0);
         std::vector<int32_t> n_blk((size_t)b->n_pass * SC_WAVES, 0);
-        std::vector<int32_t> dma_off, active_off((size_t)b->n_pass + 1, 0);
+        std::vector<int32_t> seg_tab, active_off((size_t)b->n_pass + 1, 0);
         std::vector<int32_t> col_of_slot((size_t)b->n_pass * SC_WAVES * SC_SLOTS, -1);
         size_t stored = 0;
 
@@ -359,6 +380,11 @@ static ScatImage *build_image(const ScatSet &s, int sz, int *err) {
             const int64_t c_lo = (int64_t)ps * SC_PASS, c_hi = std::min<int64_t>(n_cols, c_lo + SC_PASS);
             const int SC_RS = range_size(c_hi - c_lo);
             const int n_rng = (int)((c_hi - c_lo + SC_RS - 1) / SC_RS);
+            // a range occupies a CELL of max(RS, 8) accumulator slots; a bundle's window of 8 slots never leaves
+            // the cell of its range, so the zero weights of a window only ever meet columns of the same range
+            // (a non-finite pixel reaches at most the 7 neighbouring columns of a mask that holds it) or slots
+            // no column uses
+            const int cell = std::max(SC_RS, 8);
             // (1) weight of a range = its bundles; ranges to (wave, half): heaviest first onto the lightest
             //     wave that has a half left
             auto bundles_of_pixel = [&](int64_t p, auto &&emit) {
@@ -402,9 +428,9 @@ static ScatImage *build_image(const ScatSet &s, int sz, int *err) {
             for (int r : order) {
                 int best = -1;
                 for (int w = 0; w < SC_WAVES; ++w)
-                    if (wave_n[w] < SC_SLOTS / SC_RS && (best < 0 || wave_w[w] < wave_w[best])) best = w;
+                    if (wave_n[w] < SC_SLOTS / cell && (best < 0 || wave_w[w] < wave_w[best])) best = w;
                 rng_wave[(size_t)r] = best;
-                rng_base[(size_t)r] = wave_n[best] * SC_RS;
+                rng_base[(size_t)r] = wave_n[best] * cell;
                 ++wave_n[best];
                 wave_w[best] += rng_w[(size_t)r];
             }
@@ -420,7 +446,8 @@ static ScatImage *build_image(const ScatSet &s, int sz, int *err) {
             for (int64_t p = 0; p < n_px_dma; ++p)
                 bundles_of_pixel(p, [&](const int *cols, const float *vals, int n) {
                     const int seg = (int)(p / px_seg);
-                    // the pixel's entries as (wave, slot), sorted; per wave: windows of 8 slots from an even slot
+                    // the pixel's entries as (wave, slot), sorted; per range: windows of 8 slots from an even slot,
+                    // kept inside the range's cell
                     int key[SC_PASS];
                     for (int i = 0; i < n; ++i) {
                         const int r = cols[i] / SC_RS;
@@ -429,12 +456,15 @@ static ScatImage *build_image(const ScatSet &s, int sz, int *err) {
                     std::sort(key, key + n);
                     int i = 0;
                     while (i < n) {
-                        const int w = key[i] >> 20, s0 = ((key[i] >> 12) & 0xff) & ~1;
+                        const int w = key[i] >> 20, slot = (key[i] >> 12) & 0xff;
+                        const int cell_lo = slot / cell * cell;
+                        const int s0 = std::min(slot & ~1, cell_lo + cell - 8);
                         Bundle bd;
                         bd.px = (int32_t)p;
                         bd.slot = (uint8_t)s0;
                         for (float &x : bd.w) x = 0.f;
-                        while (i < n && (key[i] >> 20) == w && ((key[i] >> 12) & 0xff) < s0 + 8) {
+                        while (i < n && (key[i] >> 20) == w && ((key[i] >> 12) & 0xff) < s0 + 8 &&
+                               ((key[i] >> 12) & 0xff) < cell_lo + cell) {
                             bd.w[((key[i] >> 12) & 0xff) - s0] += vals[key[i] & 0xfff];      // (+=: duplicate entries add up)
                             ++stored;
                             ++i;
@@ -444,29 +474,36 @@ static ScatImage *build_image(const ScatSet &s, int sz, int *err) {
                     }
                 });
             // (3) chunks: the segments that hold anything, 8 per chunk, composed for level waves
-            std::vector<int> segs;
-            for (int g = 0; g < n_seg; ++g) {
+            static const bool natural = getenv("LTMI_SCATTER_NATURAL") != nullptr;      // (bench: no mixing)
+            static const int unit = std::min(SC_NSEG, getenv("LTMI_SCATTER_SEG") ? std::max(1, atoi(getenv("LTMI_SCATTER_SEG")) / SC_SEG) : 1);
+            std::vector<int> segs;                 // groups of `unit` adjacent segments (contiguous bytes of a row)
+            for (int g0 = 0; g0 < n_seg; g0 += unit) {
                 bool any = false;
-                for (int w = 0; w < SC_WAVES; ++w) any |= cnt[(size_t)g * SC_WAVES + w] != 0;
-                if (any) segs.push_back(g);
+                for (int g = g0; g < std::min(n_seg, g0 + unit); ++g)
+                    for (int w = 0; w < SC_WAVES; ++w) any |= cnt[(size_t)g * SC_WAVES + w] != 0;
+                if (any)
+                    for (int g = g0; g < g0 + unit; ++g) segs.push_back(g < n_seg ? g : -1);
             }
             const int n_chunks = (int)((segs.size() + SC_NSEG - 1) / SC_NSEG);
             segs.resize((size_t)n_chunks * SC_NSEG, -1);
-            static const bool natural = getenv("LTMI_SCATTER_NATURAL") != nullptr;      // (bench: no mixing)
-            if (!natural && n_chunks > 0) b->crit_blocks += ChunkMixer(cnt).mix(segs);
+            if (!natural && n_chunks > 0) b->crit_blocks += ChunkMixer(cnt, unit).mix(segs);
             active_off[(size_t)ps + 1] = active_off[(size_t)ps] + n_chunks;
+            // byte offsets of a chunk's segments in the frame row (an empty slot: offset 0, never read)
+            const size_t tab0 = seg_tab.size();
             for (int k = 0; k < n_chunks; ++k)
-                for (int l = 0; l < 64; ++l) {
-                    const int g = segs[(size_t)k * SC_NSEG + l / 8];
-                    int64_t off = g < 0 ? 0 : (int64_t)g * SC_SEG + (l % 8) * 16;
-                    if (off + 16 > n_px * sz) off = 0;
-                    dma_off.push_back((int32_t)off);
+                for (int q = 0; q < SC_NSEG; ++q) {
+                    const int g = segs[(size_t)k * SC_NSEG + q];
+                    seg_tab.push_back(g < 0 ? 0 : (int32_t)((int64_t)g * SC_SEG));
                 }
+            auto seg_of = [&](int k, int q) -> uint32_t {
+                return k < n_chunks ? (uint32_t)seg_tab[tab0 + (size_t)k * SC_NSEG + q] : 0u;
+            };
             // (4) the waves' streams
             for (int w = 0; w < SC_WAVES; ++w) {
-                const size_t first = hdr.size() / 4;
+                const size_t first = hdr.size() / 8;
                 stream_off[(size_t)ps * SC_WAVES + w] = (int64_t)first;
                 std::vector<uint32_t> own;          // per bundle: slot | flags << 8 | own row offset << 16
+                std::vector<int> end_of;            // per block: the chunk it ends, or -1
                 auto push = [&](const Bundle *bd, uint32_t lds_off, uint32_t flags) {
                     own.push_back((bd ? bd->slot : (uint32_t)SC_PAD_SLOT) | flags | (lds_off << 16));
                     for (int q = 0; q < 8; ++q) wts.push_back(bd ? bd->w[q] : 0.f);
@@ -489,14 +526,23 @@ static ScatImage *build_image(const ScatSet &s, int sz, int *err) {
                     if (in_chunk == 0) { push(nullptr, 0, 0); ++in_chunk; }
                     while (in_chunk % 4 != 0) { push(nullptr, 0, 0); ++in_chunk; }
                     own[own.size() - 1] |= SC_END;                                    // word 3 of the chunk's last block
+                    end_of.resize(own.size() / 4, -1);
+                    end_of.back() = k;
                 }
                 for (int q = 0; q < 4; ++q) push(nullptr, 0, 0);                          // read-ahead slack
                 const size_t nb = own.size() / 4 - 1;                                     // blocks to process
                 n_blk[(size_t)ps * SC_WAVES + w] = (int32_t)nb;
-                // header words: own slot + flags, and the row offset of the NEXT block's bundle
-                for (size_t i = 0; i < own.size(); ++i) {
-                    const uint32_t nxt = i + 4 < own.size() ? own[i + 4] >> 16 : 0u;
-                    hdr.push_back((own[i] & 0xffffu) | (nxt << 16));
+                // header words: own slot + flags and the row offset of the NEXT block's bundle; then the segment
+                // offsets of the chunk whose copy starts when this block ends chunk k: chunk k + 4
+                end_of.resize(own.size() / 4, -1);
+                for (size_t blk = 0; blk < own.size() / 4; ++blk) {
+                    for (size_t q = 0; q < 4; ++q) {
+                        const size_t i = blk * 4 + q;
+                        const uint32_t nxt = i + 4 < own.size() ? own[i + 4] >> 16 : 0u;
+                        hdr.push_back((own[i] & 0xffffu) | (nxt << 16));
+                    }
+                    for (int q = 0; q < SC_NSEG; ++q)
+                        hdr.push_back(end_of[blk] >= 0 ? seg_of(end_of[blk] + SCAT_NBUF, q) : 0u);
                 }
                 b->n_blocks += nb;
             }
@@ -507,14 +553,14 @@ static ScatImage *build_image(const ScatSet &s, int sz, int *err) {
                     b->crit_blocks += x;
                 }
         }
-        stream_off.back() = (int64_t)(hdr.size() / 4);
-        if (dma_off.empty()) dma_off.assign(64, 0);
+        stream_off.back() = (int64_t)(hdr.size() / 8);
+        seg_tab.resize(seg_tab.size() + 4 * SC_NSEG, 0);              // (the prologue reads four chunks' worth)
         b->fill = b->n_bundles ? (double)stored / (8.0 * (double)b->n_bundles) : 0.0;
         hipError_t e = upload(&b->hdr, hdr);
         if (e == hipSuccess) e = upload(&b->wts, wts);
         if (e == hipSuccess) e = upload(&b->stream_off, stream_off);
         if (e == hipSuccess) e = upload(&b->n_blk, n_blk);
-        if (e == hipSuccess) e = upload(&b->dma_off, dma_off);
+        if (e == hipSuccess) e = upload(&b->seg_tab, seg_tab);
         if (e == hipSuccess) e = upload(&b->active_off, active_off);
         if (e == hipSuccess) e = upload(&b->col_of_slot, col_of_slot);
         if (e == hipSuccess && b->n_tail) e = upload(&b->tail_px, tail_px);
@@ -595,9 +641,10 @@ static int launch_scatter(ltmi_masks *m, ScatImage *b, const T *tile, int64_t n_
         else if (abl == 3) kern = k_scatter<T, 3>;
         else if (abl == 4) kern = k_scatter<T, 4>;
         else if (abl == 5) kern = k_scatter<T, 5>;
+        else if (abl == 6) kern = k_scatter<T, 6>;
         else abl = 0;
     }
-    static bool set[16][6] = {{false}};
+    static bool set[16][7] = {{false}};
     if (!set[m->device & 15][abl]) {
         LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SC_LDS));
         set[m->device & 15][abl] = true;
@@ -605,8 +652,9 @@ static int launch_scatter(ltmi_masks *m, ScatImage *b, const T *tile, int64_t n_
     dim3 grid((unsigned)((n_frames + SC_FB - 1) / SC_FB), (unsigned)b->n_pass);
     hipLaunchKernelGGL(kern, grid, dim3(SC_WAVES * 64), SC_LDS, stream, tile, ld, n_frames,
                        (const uint32_t *)b->hdr, (const float *)b->wts, (const int64_t *)b->stream_off,
-                       (const int32_t *)b->n_blk, (const int32_t *)b->dma_off, (const int32_t *)b->active_off,
-                       (const int32_t *)b->col_of_slot, out, ld_out_f, n_cols, accumulate, m->roi_rows);
+                       (const int32_t *)b->n_blk, (const int32_t *)b->seg_tab, (const int32_t *)b->active_off,
+                       (const int32_t *)b->col_of_slot, out, ld_out_f, n_cols, accumulate, m->roi_rows,
+                       (int64_t)(m->n_px * (int64_t)sizeof(T)));
     LTMI_HIP(hipGetLastError());
     if (b->n_tail > 0) {
         hipLaunchKernelGGL(k_scatter_tail<T>, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, stream,

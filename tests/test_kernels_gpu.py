@@ -979,9 +979,15 @@ def test_sparse_non_finite_pixels(hip, sparse_kernel):
     if sparse_kernel == 'sell':
         assert np.array_equal(np.isnan(res2), np.isnan(ref2))    # exactly the reference's NaNs
     elif sparse_kernel == 'scatter':
-        # k_scatter: a bundle is a window of 8 neighbouring accumulator slots; the zero weights of its unused
-        # slots meet the NaN too -- masks within 8 columns of one that holds the pixel may be NaN, no others
-        near = np.abs(np.arange(64)[:, None] - np.flatnonzero(has_p)[None, :]).min(axis=1) < 8
+        # k_scatter: a bundle is a window of 8 accumulator slots inside the cell of ONE range of columns
+        # (64 columns: ranges of 2); the zero weights of its unused slots meet the NaN too -- columns of the
+        # same range within 8 of one that holds the pixel may be NaN, no others
+        rs = 2
+        while rs < 32 and (64 + rs - 1) // rs > 32:
+            rs *= 2
+        hp = np.flatnonzero(has_p)
+        col = np.arange(64)
+        near = ((col[:, None] // rs == hp[None, :] // rs) & (np.abs(col[:, None] - hp[None, :]) < 8)).any(axis=1)
         assert np.all(np.isfinite(res2[5, ~near]))
         assert np.allclose(res2[5, ~near], base[5, ~near], rtol=1e-6)
     else:
