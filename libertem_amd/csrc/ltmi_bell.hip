@@ -121,9 +121,9 @@ struct BellImage {
     // entries of the last n_px % 16 pixels of a frame (at most 15): when a row is not a multiple of 16
     // bytes its last 16-byte piece is partial and is not fetched by the frame DMA; these few entries are
     // applied by k_bell_tail after the main kernel
-    int32_t *tail_px = nullptr, *tail_col = nullptr;
+    int32_t *tail_px = nullptr, *tail_col = nullptr, *tail_seg = nullptr;   // sorted by column; seg: first entry of a column
     float *tail_val = nullptr;
-    int n_tail = 0;
+    int n_tail = 0, n_tail_cols = 0;
     size_t n_blocks = 0;
     double mac_ratio = 0.;           // multiply-adds incl. padding / stored values
 };
@@ -856,6 +856,7 @@ void bell_destroy(void *image) {
     if (b->tail_px) (void)hipFree(b->tail_px);
     if (b->tail_col) (void)hipFree(b->tail_col);
     if (b->tail_val) (void)hipFree(b->tail_val);
+    if (b->tail_seg) (void)hipFree(b->tail_seg);
     if (b->inv_scale) (void)hipFree(b->inv_scale);
     if (b->ctrl) (void)hipFree(b->ctrl);
     if (b->ctrl_off) (void)hipFree(b->ctrl_off);
@@ -1007,9 +1008,15 @@ static double half_value(uint16_t u) {
 // Build a blocked image from the CSR matrix (n_px x n_masks): f16 = false -> records of 8 pixels with
 // float32 weights (any pixel type), f16 = true -> records of 4 aligned pixel pairs with split float16
 // weights (k_bell_flat; `col_scale`: the columns' power-of-two scales).
+struct ExtraTail {                                   // entries a caller wants applied by k_bell_tail as well
+    std::vector<int32_t> px, col;
+    std::vector<float> val;
+};
+
 static BellImage *build_image(const int64_t *indptr, const int64_t *indices, const float *vals, int nc,
                               int64_t n_px, int64_t n_masks, bool f16,
-                              const std::vector<float> &col_scale, int *err) {
+                              const std::vector<float> &col_scale, int *err,
+                              const ExtraTail *extra = nullptr) {
     *err = LTMI_OK;
     BellImage *b = new (std::nothrow) BellImage();
     if (!b) { *err = LTMI_E_NOMEM; return nullptr; }
@@ -1035,7 +1042,31 @@ static BellImage *build_image(const int64_t *indptr, const int64_t *indices, con
                     tail_col.push_back((int32_t)(indices[e] * nc + c));
                     tail_val.push_back(vals[e * nc + c]);
                 }
+        if (extra) {
+            tail_px.insert(tail_px.end(), extra->px.begin(), extra->px.end());
+            tail_col.insert(tail_col.end(), extra->col.begin(), extra->col.end());
+            tail_val.insert(tail_val.end(), extra->val.begin(), extra->val.end());
+        }
+        std::vector<int32_t> tail_seg;
+        {
+            std::vector<size_t> order(tail_px.size());
+            for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return tail_col[x] < tail_col[y]; });
+            std::vector<int32_t> p2(order.size()), c2(order.size());
+            std::vector<float> v2(order.size());
+            for (size_t i = 0; i < order.size(); ++i) {
+                p2[i] = tail_px[order[i]];
+                c2[i] = tail_col[order[i]];
+                v2[i] = tail_val[order[i]];
+                if (i == 0 || c2[i] != c2[i - 1]) tail_seg.push_back((int32_t)i);
+            }
+            tail_seg.push_back((int32_t)order.size());
+            tail_px.swap(p2);
+            tail_col.swap(c2);
+            tail_val.swap(v2);
+        }
         b->n_tail = (int)tail_px.size();
+        b->n_tail_cols = (int)tail_seg.size() - 1;
 
         // ---- per pass: which segments hold entries, how they are grouped into chunks
         std::vector<int> active, active_off(n_pass + 1, 0);     // active: [chunk][NSEG] segment numbers
@@ -1275,6 +1306,8 @@ static BellImage *build_image(const int64_t *indptr, const int64_t *indices, con
             if (e == hipSuccess) e = hipMemcpy(b->tail_px, tail_px.data(), nt * 4, hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipMemcpy(b->tail_col, tail_col.data(), nt * 4, hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipMemcpy(b->tail_val, tail_val.data(), nt * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMalloc((void **)&b->tail_seg, tail_seg.size() * 4);
+            if (e == hipSuccess) e = hipMemcpy(b->tail_seg, tail_seg.data(), tail_seg.size() * 4, hipMemcpyHostToDevice);
         }
         if (f16 && e == hipSuccess) {
             e = hipMalloc((void **)&b->ctrl, ctrl.size() * 4);
@@ -1340,24 +1373,53 @@ void *bell_build(const int64_t *indptr, const int64_t *indices, const float *val
             const int sh = std::max(-120, std::min(120, 7 - ex));   // amax * 2^sh in [64, 128)
             scale[(size_t)k] = std::ldexp(1.0f, sh);
         }
+    // Two float16 pieces of w S carry 22 bits while the second piece is a normal float16 number; below
+    // ~2^-10 of the column's maximum it falls on the subnormal grid (absolute error 2^-31 max|w|).  The few
+    // entries whose pieces miss them by more than 2^-19 relative (C4: 32 of 432 407) are taken out of the
+    // float16 image -- they stay stored, with weight 0 -- and are applied by k_bell_tail as ONE float32
+    // product each, the reference's arithmetic (common/numba/__init__.py:169-184).  A stack with more than
+    // BELL_TAIL_MAX of them keeps the float32 image.
+    constexpr size_t BELL_TAIL_MAX = 256;
+    ExtraTail extra;
+    std::vector<float> vals16(vals, vals + (size_t)nnz * nc);
+    for (int64_t p = 0; p < n_px - n_px % 16; ++p)
+        for (int64_t e = indptr[p]; e < indptr[p + 1]; ++e)
+            for (int c = 0; c < nc; ++c) {
+                const int64_t col = indices[e] * nc + c;
+                const float v = vals[e * nc + c];
+                if (v == 0.f) continue;
+                const float ws = v * scale[(size_t)col];
+                const _Float16 w1 = (_Float16)ws;
+                const float r = ws - (float)w1;
+                const _Float16 w2 = (_Float16)r;
+                if (std::fabs(r - (float)w2) <= std::ldexp(std::fabs(ws), -19)) continue;
+                if (extra.val.size() == BELL_TAIL_MAX) return b;
+                extra.px.push_back((int32_t)p);
+                extra.col.push_back((int32_t)col);
+                extra.val.push_back(v);
+                vals16[(size_t)(e * nc + c)] = 0.f;
+            }
     int err16 = LTMI_OK;
-    b->h16 = build_image(indptr, indices, vals, nc, n_px, n_masks, true, scale, &err16);
+    b->h16 = build_image(indptr, indices, vals16.data(), nc, n_px, n_masks, true, scale, &err16, &extra);
     // (a failure here -- memory -- leaves the float32 image in charge)
     return b;
 }
 
-// the entries of the last n_px % 16 pixels (see BellImage::tail_*): one thread per frame, entries in
-// CSR order (a frame's sums are updated by one thread only: no atomics)
+// the entries of the last n_px % 16 pixels and the entries the float16 image leaves to float32 (see
+// BellImage::tail_*): sorted by column; one thread per (frame, column) sums its column's products in float32
+// and adds them to the result -- a sum is updated by one thread only: no atomics, launches are reproducible
 template <typename T>
 __global__ void k_bell_tail(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
                             const int32_t *__restrict__ px, const int32_t *__restrict__ col,
-                            const float *__restrict__ val, int n_tail, float *__restrict__ out,
-                            int64_t ld_out, const int32_t *__restrict__ rows) {
+                            const float *__restrict__ val, const int32_t *__restrict__ seg,
+                            float *__restrict__ out, int64_t ld_out, const int32_t *__restrict__ rows) {
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n_frames) return;
+    const int e0 = seg[blockIdx.y], e1 = seg[blockIdx.y + 1];
     const T *row = tile + (rows ? (int64_t)rows[f] : f) * ld;
-    float *o = out + f * ld_out;
-    for (int e = 0; e < n_tail; ++e) o[col[e]] += val[e] * (float)row[px[e]];
+    float acc = 0.f;
+    for (int e = e0; e < e1; ++e) acc += val[e] * (float)row[px[e]];
+    out[f * ld_out + col[e0]] += acc;
 }
 
 template <typename T, int TL>
@@ -1400,10 +1462,10 @@ static int launch_bell_t(ltmi_masks *m, BellImage *b, const T *tile, int64_t n_f
     }
 #endif
     if (b->n_tail > 0) {
-        hipLaunchKernelGGL(k_bell_tail<T>, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0,
-                           stream, tile, ld, n_frames, (const int32_t *)b->tail_px,
-                           (const int32_t *)b->tail_col, (const float *)b->tail_val, b->n_tail, out,
-                           ld_out_f, m->roi_rows);
+        hipLaunchKernelGGL(k_bell_tail<T>, dim3((unsigned)((n_frames + 255) / 256), (unsigned)b->n_tail_cols),
+                           dim3(256), 0, stream, tile, ld, n_frames, (const int32_t *)b->tail_px,
+                           (const int32_t *)b->tail_col, (const float *)b->tail_val,
+                           (const int32_t *)b->tail_seg, out, ld_out_f, m->roi_rows);
         LTMI_HIP(hipGetLastError());
     }
     snprintf(m->last_kernel, sizeof(m->last_kernel),
@@ -1433,15 +1495,15 @@ static int launch_bell_flat(ltmi_masks *m, BellImage *b, const T *tile, int64_t 
                        accumulate, ablate, m->roi_rows, (const float *)b->inv_scale);
     LTMI_HIP(hipGetLastError());
     if (b->n_tail > 0) {
-        hipLaunchKernelGGL(k_bell_tail<T>, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0,
-                           stream, tile, ld, n_frames, (const int32_t *)b->tail_px,
-                           (const int32_t *)b->tail_col, (const float *)b->tail_val, b->n_tail, out,
-                           ld_out_f, m->roi_rows);
+        hipLaunchKernelGGL(k_bell_tail<T>, dim3((unsigned)((n_frames + 255) / 256), (unsigned)b->n_tail_cols),
+                           dim3(256), 0, stream, tile, ld, n_frames, (const int32_t *)b->tail_px,
+                           (const int32_t *)b->tail_col, (const float *)b->tail_val,
+                           (const int32_t *)b->tail_seg, out, ld_out_f, m->roi_rows);
         LTMI_HIP(hipGetLastError());
     }
     snprintf(m->last_kernel, sizeof(m->last_kernel),
-             "k_bell_flat<%s,tiles=%d,f16%s> grid=(%u,%u) blocks=%zu x%.2f crit=%ld", typeid(T).name(), TL,
-             m->roi_rows ? ",rows" : "", grid.x, grid.y, b->n_blocks, b->mac_ratio, b->crit_records);
+             "k_bell_flat<%s,tiles=%d,f16%s> grid=(%u,%u) blocks=%zu x%.2f crit=%ld tail=%d", typeid(T).name(), TL,
+             m->roi_rows ? ",rows" : "", grid.x, grid.y, b->n_blocks, b->mac_ratio, b->crit_records, b->n_tail);
     return LTMI_OK;
 }
 

@@ -24,20 +24,18 @@
 //
 // The loop itself (software pipelined over two register sets, every register named by hand) is generated:
 // scripts/gen_scatter_asm.py -> ltmi_scatter_loop.inc.  REGISTER CONTRACT with that file:
-//   compiler: v0..v27, s0..s11; loop: v28..v127, s12..s99, vcc, m0, scc.
-//   v28 lane's LDS offset inside a buffer | v29 offset of a row's last whole 16-byte piece | v30:31 address temp |
-//   v32 argument lanes | v33 v28 + buffer being read | v34 lane's byte offset in the frame row (chunk being
-//   copied) | v35 (lane & 7) * 16 | v36..v39 row pointers of the wave's two copy instructions | v40..v55 pixel
-//   values + address temps of the two sets | v56..v119 accumulators, v120..v127 padding slots (dummy bundles).
-//   s12..s27 header words of the two sets: 4 bundle words (bits 0-7 accumulator slot, bit 8 of word 3: end of
-//   the wave's work on the chunk, bits 16-31 LDS row offset of the NEXT block's pixel) + the 4 segment offsets
-//   of the chunk whose copy starts at that end | s28..s31 stream bases | s32 header offset | s33 chunks left |
-//   s34 buffer | s35 temp | s36..s99 weights of the two sets.
-// A chunk = 512 bytes of every frame row = 4 SEGMENTS of 128 bytes which the builder composes (ChunkMixer) so
-// that the waves of the workgroup -- they meet at a barrier per chunk -- carry equal work: in a ring stack the
-// ring that is tangent to a detector row puts ~70 pixels of that row into ONE 32-column range.  Four chunk
-// buffers: the copy of chunk c + 4 starts when everybody has left chunk c (three chunks in flight, requests
-// spread over time instead of one burst per chunk; the workgroups start out of phase).
+//   compiler: v0..v31, s0..s11 (+ vcc); loop: v32..v127, s12..s99, m0, scc.
+//   v32 argument lanes | v33 / v38 lane * PITCH + offset of the buffer being read / the other one | v34 lane's
+//   byte offset of its 16-byte piece in the frame row (chunk table) | v35 lane * 4 | v36 / v37 row pointers
+//   (lanes 0..3) | v39 temp | v40..v55 pixel values + address temps of the two sets | v56..v119 accumulators,
+//   v120..v127 padding slots (dummy bundles, windows that reach beyond slot 63).
+//   s12..s19 header words of the two sets (bits 0-7 accumulator slot, bit 8 of word 3: end of the wave's work on
+//   the chunk, bits 16-31 LDS row offset of the NEXT block's pixel) | s20..s25 stream / table bases |
+//   s26..s29 temps | s30 / s31 stream offsets | s32 blocks left | s33 / s34 chunk index, end | s35 buffer |
+//   s36..s99 weights of the two sets.
+// A chunk = 1 KiB of every frame row = 8 SEGMENTS of 128 bytes which the builder composes (ChunkMixer) so that
+// the waves of the workgroup -- they meet at a barrier per chunk -- carry equal work: in a ring stack the ring
+// that is tangent to a detector row puts ~70 pixels of that row into ONE 32-column range.
 #include "ltmi_common.h"
 #include "ltmi_scatter_loop.inc"
 #include <cstring>
@@ -52,7 +50,7 @@ namespace ltmi {
 constexpr int SC_WAVES = 16, SC_SLOTS = 64;                         // waves, accumulators per wave
 constexpr int SC_PASS = SC_WAVES * SC_SLOTS;                        // columns per pass
 constexpr int SC_FB = 64;                                           // frames per workgroup
-constexpr int SC_ROW = SCAT_ROWB, SC_SEG = 128, SC_NSEG = SC_ROW / SC_SEG;   // bytes of a row per chunk / per segment
+constexpr int SC_ROW = 1024, SC_SEG = 128, SC_NSEG = SC_ROW / SC_SEG;   // bytes of a row per chunk / per segment
 constexpr int SC_PAD_SLOT = 64;                                     // accumulator slot of dummy bundles (v120..)
 constexpr unsigned SC_END = 1u << 8;
 // columns per RANGE (the unit that is assigned to a wave): 32 for a full pass, fewer for narrow stacks so that
@@ -62,18 +60,18 @@ static inline int range_size(int64_t cols_in_pass) {
     while (rs < 32 && (cols_in_pass + rs - 1) / rs > 2 * SC_WAVES) rs *= 2;
     return rs;
 }
+
 constexpr int SC_EPI = SC_WAVES * 64 * 33 * 4;                          // epilogue: 64 x 33 words per wave
-constexpr int SC_LDS = SCAT_NBUF * SCAT_BUF > SC_EPI ? SCAT_NBUF * SCAT_BUF : SC_EPI;
-static_assert(SCAT_PITCH == 2 * SC_ROW + 4 && SCAT_BUF == SC_FB / 2 * SCAT_PITCH && SCAT_ACC0 == 56 && SC_NSEG == 4,
-              "generated loop");
+constexpr int SC_LDS = 2 * SCAT_BUF > SC_EPI ? 2 * SCAT_BUF : SC_EPI;
+static_assert(SCAT_PITCH == SC_ROW + 4 && SCAT_BUF == SC_FB * SCAT_PITCH && SCAT_ACC0 == 56, "generated loop");
 
 struct ScatImage {                       // the image of a stack for ONE pixel size
     int sz = 0, n_pass = 0;
-    uint32_t *hdr = nullptr;             // 8 words per block: 4 bundle words, 4 segment offsets
+    uint32_t *hdr = nullptr;             // 4 words per block
     float *wts = nullptr;                // 32 weights per block
     int64_t *stream_off = nullptr;       // [n_pass * 16 + 1] first block of a wave's stream
     int32_t *n_blk = nullptr;            // [n_pass * 16] blocks of the stream (incl. the leading dummy)
-    int32_t *seg_tab = nullptr;          // [chunks of all passes + 4][4] byte offsets of a chunk's segments in the frame row
+    int32_t *dma_off = nullptr;          // [chunks of all passes][64] byte offset in the frame row
     int32_t *active_off = nullptr;       // [n_pass + 1]
     int32_t *col_of_slot = nullptr;      // [n_pass * 16 * 64] column of an accumulator slot, -1: none
     int32_t *tail_px = nullptr, *tail_col = nullptr;   // entries of pixels behind the last full 16-byte piece
@@ -95,7 +93,7 @@ struct ScatSet {                         // host copy of the CSR matrix + the im
 
 static void image_destroy(ScatImage *b) {
     if (!b) return;
-    void *p[] = {b->hdr, b->wts, b->stream_off, b->n_blk, b->seg_tab, b->active_off, b->col_of_slot,
+    void *p[] = {b->hdr, b->wts, b->stream_off, b->n_blk, b->dma_off, b->active_off, b->col_of_slot,
                  b->tail_px, b->tail_col, b->tail_val};
     for (void *q : p)
         if (q) (void)hipFree(q);
@@ -110,7 +108,7 @@ void scat_destroy(void *set) {
 }
 
 // ---- kernel -------------------------------------------------------------------------------------------
-#define SC_V32_127 "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+#define SC_V32_127 "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
 #define SC_S12_99 "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
 
 // 8 accumulators v[A .. A + 7] into compiler-visible values
@@ -120,15 +118,15 @@ void scat_destroy(void *set) {
                  : "=v"(R[0]), "=v"(R[1]), "=v"(R[2]), "=v"(R[3]), "=v"(R[4]), "=v"(R[5]), "=v"(R[6]), "=v"(R[7]))
 
 // ABL > 0: timing-only variants of the uint16 loop (LTMI_SCATTER_ABLATE: 1 weights from one hot line, 2 no
-// frame copies, 3 no LDS reads, 4 no FMAs, 5 = 1 + 2, 6 no chunk barriers; results are garbage)
+// frame copies, 3 no LDS reads, 4 no FMAs, 5 = 1 + 2, 6 no chunk barriers, 7 = 1 + 6; results are garbage)
 template <typename T, int ABL = 0>
-__global__ void __launch_bounds__(SC_WAVES * 64, 1) __attribute__((amdgpu_num_vgpr(28)))
+__global__ void __launch_bounds__(SC_WAVES * 64, 1) __attribute__((amdgpu_num_vgpr(32)))
 k_scatter(const T *__restrict__ tile, int64_t ld, int64_t n_frames, const uint32_t *__restrict__ hdr,
           const float *__restrict__ wts, const int64_t *__restrict__ stream_off,
-          const int32_t *__restrict__ n_blk, const int32_t *__restrict__ seg_tab,
+          const int32_t *__restrict__ n_blk, const int32_t *__restrict__ dma_off,
           const int32_t *__restrict__ active_off, const int32_t *__restrict__ col_of_slot,
           float *__restrict__ out, int64_t ld_out, int n_cols, int accumulate,
-          const int32_t *__restrict__ rows, int64_t n_px_bytes) {
+          const int32_t *__restrict__ rows) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sc_lds[];      // at LDS address 0 (the loop assumes it)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -138,42 +136,33 @@ k_scatter(const T *__restrict__ tile, int64_t ld, int64_t n_frames, const uint32
     const int a0 = active_off[pass], a1 = active_off[pass + 1];
     const int wj = pass * SC_WAVES + j;
     {
-        const uint64_t hp = (uint64_t)(hdr + stream_off[wj] * 8);
+        const uint64_t hp = (uint64_t)(hdr + stream_off[wj] * 4);
         const uint64_t wp = (uint64_t)(wts + stream_off[wj] * 32);
-        const uint64_t tp = (uint64_t)(seg_tab + (int64_t)a0 * 4);
-        const unsigned phase = (unsigned)((blockIdx.x * 7u + blockIdx.y) & 15u);
-        const unsigned av[9] = {(unsigned)hp, (unsigned)(hp >> 32), (unsigned)wp, (unsigned)(wp >> 32),
-                                (unsigned)(a1 - a0 - 1), (unsigned)(2 * j * SCAT_PITCH), (unsigned)tp,
-                                (unsigned)(tp >> 32), phase};
+        const uint64_t tp = (uint64_t)dma_off;
+        const unsigned av[10] = {(unsigned)hp, (unsigned)(hp >> 32), (unsigned)wp, (unsigned)(wp >> 32),
+                                 (unsigned)tp, (unsigned)(tp >> 32), (unsigned)n_blk[wj], (unsigned)a0,
+                                 (unsigned)a1, (unsigned)(4 * j * SCAT_PITCH)};
         unsigned args = 0;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) args = lane == i ? av[i] : args;
-        // the wave copies the rows 4 j .. 4 j + 3 of the workgroup's frames, two per instruction (lanes 0-31 /
-        // 32-63); beyond the last frame: the last one again
-        unsigned rpl[2], rph[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            int64_t fr = f0 + 4 * j + 2 * k + (lane >> 5);
-            if (fr > n_frames - 1) fr = n_frames - 1;
-            if (rows) fr = rows[fr];
-            const uint64_t rp = (uint64_t)(tile + fr * ld);
-            rpl[k] = (unsigned)rp;
-            rph[k] = (unsigned)(rp >> 32);
-        }
-        const unsigned lanebase = (unsigned)(lane >> 1) * SCAT_PITCH + (unsigned)(lane & 1) * SCAT_ROWB;
-        const unsigned piece = (unsigned)(lane & 7) * 16u;
-        const unsigned limit = (unsigned)(n_px_bytes - 16);
+        for (int i = 0; i < 10; ++i) args = lane == i ? av[i] : args;
+        // rows 4 j .. 4 j + 3 of the workgroup's frames (beyond the last frame: the last one again)
+        int64_t fr = f0 + 4 * j + (lane & 3);
+        if (fr > n_frames - 1) fr = n_frames - 1;
+        if (rows) fr = rows[fr];
+        const uint64_t rp = (uint64_t)(tile + fr * ld);
+        const unsigned rowlo = (unsigned)rp, rowhi = (unsigned)(rp >> 32);
+        const unsigned lanebase = (unsigned)lane * SCAT_PITCH, lane4 = (unsigned)lane * 4u;
         if (a0 < a1) {
 #define SC_RUN(NAME)                                                                                  \
-    asm volatile(SCAT_LOOP_##NAME ::"v"(args), "v"(lanebase), "v"(piece), "v"(rpl[0]), "v"(rph[0]),     \
-                 "v"(rpl[1]), "v"(rph[1]), "v"(limit)                                                 \
-                 : "memory", "scc", "vcc", SC_V32_127, SC_S12_99)
+    asm volatile(SCAT_LOOP_##NAME ::"v"(args), "v"(lanebase), "v"(lane4), "v"(rowlo), "v"(rowhi)       \
+                 : "memory", "scc", SC_V32_127, SC_S12_99)
             if constexpr (ABL == 1) SC_RUN(u16_a1);
             else if constexpr (ABL == 2) SC_RUN(u16_a2);
             else if constexpr (ABL == 3) SC_RUN(u16_a3);
             else if constexpr (ABL == 4) SC_RUN(u16_a4);
             else if constexpr (ABL == 5) SC_RUN(u16_a5);
             else if constexpr (ABL == 6) SC_RUN(u16_a6);
+            else if constexpr (ABL == 7) SC_RUN(u16_a7);
             else if constexpr (std::is_same<T, uint8_t>::value) SC_RUN(u8);
             else if constexpr (std::is_same<T, int8_t>::value) SC_RUN(i8);
             else if constexpr (std::is_same<T, uint16_t>::value) SC_RUN(u16);
@@ -372,7 +361,7 @@ static ScatImage *build_image(const ScatSet &s, int sz, int *err) {
         std::vector<float> wts;
         std::vector<int64_t> stream_off((size_t)b->n_pass * SC_WAVES + 1, 0);
         std::vector<int32_t> n_blk((size_t)b->n_pass * SC_WAVES, 0);
-        std::vector<int32_t> seg_tab, active_off((size_t)b->n_pass + 1, 0);
+        std::vector<int32_t> dma_off, active_off((size_t)b->n_pass + 1, 0);
         std::vector<int32_t> col_of_slot((size_t)b->n_pass * SC_WAVES * SC_SLOTS, -1);
         size_t stored = 0;
 
@@ -488,22 +477,18 @@ static ScatImage *build_image(const ScatSet &s, int sz, int *err) {
             segs.resize((size_t)n_chunks * SC_NSEG, -1);
             if (!natural && n_chunks > 0) b->crit_blocks += ChunkMixer(cnt, unit).mix(segs);
             active_off[(size_t)ps + 1] = active_off[(size_t)ps] + n_chunks;
-            // byte offsets of a chunk's segments in the frame row (an empty slot: offset 0, never read)
-            const size_t tab0 = seg_tab.size();
             for (int k = 0; k < n_chunks; ++k)
-                for (int q = 0; q < SC_NSEG; ++q) {
-                    const int g = segs[(size_t)k * SC_NSEG + q];
-                    seg_tab.push_back(g < 0 ? 0 : (int32_t)((int64_t)g * SC_SEG));
+                for (int l = 0; l < 64; ++l) {
+                    const int g = segs[(size_t)k * SC_NSEG + l / 8];
+                    int64_t off = g < 0 ? 0 : (int64_t)g * SC_SEG + (l % 8) * 16;
+                    if (off + 16 > n_px * sz) off = 0;
+                    dma_off.push_back((int32_t)off);
                 }
-            auto seg_of = [&](int k, int q) -> uint32_t {
-                return k < n_chunks ? (uint32_t)seg_tab[tab0 + (size_t)k * SC_NSEG + q] : 0u;
-            };
             // (4) the waves' streams
             for (int w = 0; w < SC_WAVES; ++w) {
-                const size_t first = hdr.size() / 8;
+                const size_t first = hdr.size() / 4;
                 stream_off[(size_t)ps * SC_WAVES + w] = (int64_t)first;
                 std::vector<uint32_t> own;          // per bundle: slot | flags << 8 | own row offset << 16
-                std::vector<int> end_of;            // per block: the chunk it ends, or -1
                 auto push = [&](const Bundle *bd, uint32_t lds_off, uint32_t flags) {
                     own.push_back((bd ? bd->slot : (uint32_t)SC_PAD_SLOT) | flags | (lds_off << 16));
                     for (int q = 0; q < 8; ++q) wts.push_back(bd ? bd->w[q] : 0.f);
@@ -526,23 +511,14 @@ static ScatImage *build_image(const ScatSet &s, int sz, int *err) {
                     if (in_chunk == 0) { push(nullptr, 0, 0); ++in_chunk; }
                     while (in_chunk % 4 != 0) { push(nullptr, 0, 0); ++in_chunk; }
                     own[own.size() - 1] |= SC_END;                                    // word 3 of the chunk's last block
-                    end_of.resize(own.size() / 4, -1);
-                    end_of.back() = k;
                 }
                 for (int q = 0; q < 4; ++q) push(nullptr, 0, 0);                          // read-ahead slack
                 const size_t nb = own.size() / 4 - 1;                                     // blocks to process
                 n_blk[(size_t)ps * SC_WAVES + w] = (int32_t)nb;
-                // header words: own slot + flags and the row offset of the NEXT block's bundle; then the segment
-                // offsets of the chunk whose copy starts when this block ends chunk k: chunk k + 4
-                end_of.resize(own.size() / 4, -1);
-                for (size_t blk = 0; blk < own.size() / 4; ++blk) {
-                    for (size_t q = 0; q < 4; ++q) {
-                        const size_t i = blk * 4 + q;
-                        const uint32_t nxt = i + 4 < own.size() ? own[i + 4] >> 16 : 0u;
-                        hdr.push_back((own[i] & 0xffffu) | (nxt << 16));
-                    }
-                    for (int q = 0; q < SC_NSEG; ++q)
-                        hdr.push_back(end_of[blk] >= 0 ? seg_of(end_of[blk] + SCAT_NBUF, q) : 0u);
+                // header words: own slot + flags, and the row offset of the NEXT block's bundle
+                for (size_t i = 0; i < own.size(); ++i) {
+                    const uint32_t nxt = i + 4 < own.size() ? own[i + 4] >> 16 : 0u;
+                    hdr.push_back((own[i] & 0xffffu) | (nxt << 16));
                 }
                 b->n_blocks += nb;
             }
@@ -553,14 +529,14 @@ static ScatImage *build_image(const ScatSet &s, int sz, int *err) {
                     b->crit_blocks += x;
                 }
         }
-        stream_off.back() = (int64_t)(hdr.size() / 8);
-        seg_tab.resize(seg_tab.size() + 4 * SC_NSEG, 0);              // (the prologue reads four chunks' worth)
+        stream_off.back() = (int64_t)(hdr.size() / 4);
+        if (dma_off.empty()) dma_off.assign(64, 0);
         b->fill = b->n_bundles ? (double)stored / (8.0 * (double)b->n_bundles) : 0.0;
         hipError_t e = upload(&b->hdr, hdr);
         if (e == hipSuccess) e = upload(&b->wts, wts);
         if (e == hipSuccess) e = upload(&b->stream_off, stream_off);
         if (e == hipSuccess) e = upload(&b->n_blk, n_blk);
-        if (e == hipSuccess) e = upload(&b->seg_tab, seg_tab);
+        if (e == hipSuccess) e = upload(&b->dma_off, dma_off);
         if (e == hipSuccess) e = upload(&b->active_off, active_off);
         if (e == hipSuccess) e = upload(&b->col_of_slot, col_of_slot);
         if (e == hipSuccess && b->n_tail) e = upload(&b->tail_px, tail_px);
@@ -642,9 +618,10 @@ static int launch_scatter(ltmi_masks *m, ScatImage *b, const T *tile, int64_t n_
         else if (abl == 4) kern = k_scatter<T, 4>;
         else if (abl == 5) kern = k_scatter<T, 5>;
         else if (abl == 6) kern = k_scatter<T, 6>;
+        else if (abl == 7) kern = k_scatter<T, 7>;
         else abl = 0;
     }
-    static bool set[16][7] = {{false}};
+    static bool set[16][8] = {{false}};
     if (!set[m->device & 15][abl]) {
         LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SC_LDS));
         set[m->device & 15][abl] = true;
@@ -652,9 +629,8 @@ static int launch_scatter(ltmi_masks *m, ScatImage *b, const T *tile, int64_t n_
     dim3 grid((unsigned)((n_frames + SC_FB - 1) / SC_FB), (unsigned)b->n_pass);
     hipLaunchKernelGGL(kern, grid, dim3(SC_WAVES * 64), SC_LDS, stream, tile, ld, n_frames,
                        (const uint32_t *)b->hdr, (const float *)b->wts, (const int64_t *)b->stream_off,
-                       (const int32_t *)b->n_blk, (const int32_t *)b->seg_tab, (const int32_t *)b->active_off,
-                       (const int32_t *)b->col_of_slot, out, ld_out_f, n_cols, accumulate, m->roi_rows,
-                       (int64_t)(m->n_px * (int64_t)sizeof(T)));
+                       (const int32_t *)b->n_blk, (const int32_t *)b->dma_off, (const int32_t *)b->active_off,
+                       (const int32_t *)b->col_of_slot, out, ld_out_f, n_cols, accumulate, m->roi_rows);
     LTMI_HIP(hipGetLastError());
     if (b->n_tail > 0) {
         hipLaunchKernelGGL(k_scatter_tail<T>, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, stream,

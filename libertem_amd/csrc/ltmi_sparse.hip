@@ -55,6 +55,7 @@ struct CsrImage {
     int *row_len = nullptr;
     size_t n_rows = 0;
     void *scat = nullptr;       // ltmi_scatter.hip: the stack for k_scatter (images built per pixel size on first use)
+    bool scat_all = false;      // LTMI_SPARSE_SCATTER=1: k_scatter for every pixel type (default: float32 frames)
     int *active = nullptr;      // chunks with entries, concatenated per pass
     int *active_off = nullptr;  // [n_pass + 1]
     void *bell = nullptr;       // blocked image for the matrix-core kernel (ltmi_bell.hip) or null
@@ -459,7 +460,11 @@ int csr_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames,
                   dtype_name(tile_dtype));
     }
     // one float32 FMA per stored entry on the vector ALUs (k_scatter; tuning 41: SELL kernel, 42: blocked image)
-    if (c->scat && m->tune_ksplit_ring != 41 && m->tune_ksplit_ring != 42) {
+    // (float32 frames by default -- measured 7 % ahead of the float32 blocked image on C4, and a non-finite
+    // pixel reaches fewer foreign masks; 1- / 2-byte pixels stay on the blocked images, which are 15 - 30 %
+    // faster there: profiles/r04_sparse.txt.  LTMI_SPARSE_SCATTER=1: every pixel type)
+    if (c->scat && (c->scat_all || tile_dtype == LTMI_F32) && m->tune_ksplit_ring != 41 &&
+        m->tune_ksplit_ring != 42) {
         bool handled = false;
         const int rc = scat_apply(m, c->scat, c->cplx, tile, tile_dtype, n_frames, ld_tile, out, ld_out,
                                   accumulate, stream, &handled);
@@ -667,7 +672,7 @@ extern "C" int ltmi_masks_create_csr(int device, const int64_t *indptr, const in
         const char *force = getenv("LTMI_SPARSE_SCATTER");
         bool build = nnz > 0 && !c->f64 && n_masks * nc >= 64;
         if (force && force[0] == '0') build = false;
-        else if (force && force[0] == '1') build = nnz > 0 && !c->f64;
+        else if (force && force[0] == '1') { build = nnz > 0 && !c->f64; c->scat_all = true; }
         else if (build) build = ltmi::scat_fill(indptr, indices, nc, n_px, n_masks) >= 0.15;
         if (build) {
             int err = LTMI_OK;
