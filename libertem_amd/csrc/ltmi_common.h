@@ -157,14 +157,11 @@ struct ltmi_masks {
     float *img3_h = nullptr;     // ... of image 3 without VALU columns (3 groups)
     float *inv_scale = nullptr;
     // small weights that two float16 pieces do not carry to 2^-19 relative: left out of the float16
-    // images; k_dense_tail_pre forms their float32 products (tail_scratch: n_frames x tail_n), the
-    // epilogue of k_dense_lds X16 adds them
+    // images; the epilogue of k_dense_lds X16 adds their float32 products
     int32_t *tail_px = nullptr, *tail_col = nullptr;
     float *tail_val = nullptr;
     int tail_n = 0;
-    float *tail_scratch = nullptr;
-    size_t tail_scratch_bytes = 0;
-    bool x16_used = false, tail_ready = false;
+    bool x16_used = false;
     // float64 results on the f64 matrix cores (ltmi_dense64.hip)
     double *img64 = nullptr;
     int n_groups64 = 0, n_chunks64 = 0;

@@ -105,7 +105,7 @@ __global__ void k_build_image_h16(const float *__restrict__ src, _Float16 *__res
         else if (layout == 2) base = ((((size_t)(g / ng) * n_slots + slot) * ng + g % ng) * GROUP) * kb;
         else base = (size_t)slot * slot_floats + (size_t)g * GROUP * kb;
         // (power-of-two scale: exact; the few small weights that two float16 pieces do not carry to 2^-19
-        // relative are left out here and added in float32 (k_dense_tail_pre + the epilogue of k_dense_lds) -- same rule as the host's)
+        // relative are left out here and added in float32 by the epilogue of k_dense_lds -- same rule as the host's)
         float ws = src[i] * scale[col];
         if (ws != 0.f && fabsf(src[i]) < ldexpf(amax[col], -20) && !h16_pieces_exact_enough(ws)) ws = 0.f;
         const _Float16 w1 = (_Float16)ws;
@@ -115,21 +115,7 @@ __global__ void k_build_image_h16(const float *__restrict__ src, _Float16 *__res
     }
 }
 
-// The weights the float16 images leave out (k_build_image_h16; at most DENSE_TAIL_MAX per stack): before the
-// matrix kernel of such a stack runs, this kernel forms w * pixel for every left-out entry and result
-// row -- one float32 product per stored entry like the reference's matrix product (udf/masks.py:59-77)
-// -- into a device scratch (n_frames x n_tail); the matrix kernel's epilogue adds them to its column
-// sums (k_dense_lds X16: `tail_add`).  One thread per result row.
-constexpr int DENSE_TAIL_MAX = 64;
-template <typename T>
-__global__ void k_dense_tail_pre(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
-                                 const int32_t *__restrict__ px, const float *__restrict__ val, int n_tail,
-                                 float *__restrict__ scratch, const int32_t *__restrict__ rows) {
-    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n_frames) return;
-    const T *row = tile + (rows ? (int64_t)rows[f] : f) * ld;
-    for (int e = 0; e < n_tail; ++e) scratch[f * n_tail + e] = val[e] * (float)row[px[e]];
-}
+constexpr int DENSE_TAIL_MAX = 64;     // weights a stack's float16 images may leave to the float32 epilogue of k_dense_lds
 
 // ---- per-input-dtype loading / conversion of 8 consecutive pixels ---------------------------
 template <typename T> struct InTraits;
@@ -569,8 +555,9 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             int n_cols, int accumulate, float *__restrict__ partials, int ksplit,
             const int32_t *__restrict__ rows = nullptr,
             const float *const *__restrict__ wg_img = nullptr, int *__restrict__ kcount = nullptr,
-            const float *__restrict__ inv_scale = nullptr, const float *__restrict__ tail_add = nullptr,
-            const int32_t *__restrict__ tail_col = nullptr, int n_tail = 0) {
+            const float *__restrict__ inv_scale = nullptr, const float *__restrict__ tail_val = nullptr,
+            const int32_t *__restrict__ tail_col = nullptr, const int32_t *__restrict__ tail_px = nullptr,
+            int n_tail = 0) {
     static_assert(!X16 || (NE == 0 && NG >= 1 && ABL == 0 && sizeof(T) <= 2),
                   "X16: 1- / 2-byte integer pixels on the matrix cores only");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -1021,10 +1008,14 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                     v += acc2[tl][g][r];
                     if (X16) v *= inv_scale[col];             // undo the column's power-of-two scale
                     if constexpr (X16) {
-                        // the weights the float16 image leaves out: their float32 products (k_dense_tail_pre)
-                        if (n_tail > 0 && ks == 0)
+                        // the few weights the float16 image leaves out (at most DENSE_TAIL_MAX per stack): one
+                        // float32 product per stored entry, like the reference's matrix product
+                        // (udf/masks.py:59-77), added to the column's sum
+                        if (n_tail > 0 && ks == 0) {
+                            const T *src = tile + src_frame_of(tl * 16 + kg * 4 + r) * ld;
                             for (int e = 0; e < n_tail; ++e)
-                                if (tail_col[e] == col) v += tail_add[f * n_tail + e];
+                                if (tail_col[e] == col) v += tail_val[e] * (float)src[tail_px[e]];
+                        }
                     }
                     if (ksplit == 1) {
                         float *p = out + f * ld_out + col;
@@ -1495,7 +1486,7 @@ extern "C" int ltmi_masks_create_dense(int device, const void *masks_host, int r
             // weight and an absolute 2^-39 max|w| below that (the float16 subnormal grid).  A weight whose two
             // pieces miss it by more than 2^-19 relative (only possible below 2^-20 of the maximum; weights
             // with few significant bits -- 0/1 masks, k 2^-24 random numbers -- are exact at any size) is
-            // left out of the float16 images and added in float32 (k_dense_tail_pre, then the epilogue of the matrix kernel).  A stack with more
+            // left out of the float16 images and added in float32 by the epilogue of the matrix kernel.  A stack with more
             // than DENSE_TAIL_MAX of them (smooth masks with long tails: Gaussians) keeps the float32
             // instruction altogether.
             std::vector<float> scale((size_t)m->n_cols, 1.f), inv((size_t)m->n_cols, 1.f);
@@ -1618,7 +1609,6 @@ extern "C" int ltmi_masks_destroy(ltmi_masks *m) {
     if (m->tail_px) (void)hipFree(m->tail_px);
     if (m->tail_col) (void)hipFree(m->tail_col);
     if (m->tail_val) (void)hipFree(m->tail_val);
-    if (m->tail_scratch) (void)hipFree(m->tail_scratch);
     ltmi::dense64_destroy(m);
     shift_cache_destroy(m);
     if (m->partials) (void)hipFree(m->partials);
@@ -1728,7 +1718,7 @@ template <typename T, int NG, int ABL, int IND, int NE, int TILES, bool X16 = fa
 static auto lds_kernel() -> void (*)(const T *, int64_t, int64_t, int64_t, const float *, int, float *,
                                      int64_t, int, int, float *, int, const int32_t *,
                                      const float *const *, int *, const float *, const float *,
-                                     const int32_t *, int) {
+                                     const int32_t *, const int32_t *, int) {
     // the timing-only ablations (tuning codes 31 / 32) and the one-tile-per-wave shape (34) exist for the
     // C2 kernel only -- uint16 pixels, one column group --: they are bench comparisons
     // (scripts/clock_probe.py, profiles/r02_tiles.txt), and every variant is minutes of compile time
@@ -1768,7 +1758,7 @@ static int launch_lds_ng_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64
     const int abl = m->tune_ksplit_ring == 31 ? 2 : (m->tune_ksplit_ring == 32 ? 1 : 0);
     void (*kern)(const T *, int64_t, int64_t, int64_t, const float *, int, float *, int64_t, int,
                  int, float *, int, const int32_t *, const float *const *, int *, const float *,
-                 const float *, const int32_t *, int) =
+                 const float *, const int32_t *, const int32_t *, int) =
         abl == 2 ? lds_kernel<T, NG, 2, 0, 0, TILES>()
                  : (abl == 1 ? lds_kernel<T, NG, 1, 0, 0, TILES>()
                              : lds_kernel<T, NG, 0, 0, 0, TILES>());
@@ -1815,8 +1805,8 @@ static int launch_lds_ng_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64
                        m->n_px, img, n_slots, out, ld_out, m->n_cols, accumulate, partial_sums(m),
                        ksplit, rows, (const float *const *)nullptr, kcount,
                        x16 ? (const float *)m->inv_scale : (const float *)nullptr,
-                       (const float *)m->tail_scratch, (const int32_t *)m->tail_col,
-                       x16 && m->tail_ready ? m->tail_n : 0);
+                       (const float *)m->tail_val, (const int32_t *)m->tail_col, (const int32_t *)m->tail_px,
+                       x16 ? m->tail_n : 0);
     LTMI_HIP(hipGetLastError());
     snprintf(m->last_kernel, sizeof(m->last_kernel),
              "k_dense_lds<%s,NG=%d,ring=%d,tiles=%d%s%s> grid=(%u,%u,%u)", typeid(T).name(), NG,
@@ -1889,8 +1879,8 @@ static int launch_lds_extras_t(ltmi_masks *m, const T *tile, int64_t n_frames, i
                        ld_out, m->n_cols, accumulate, partial_sums(m), ksplit, rows,
                        (const float *const *)nullptr, kcount,
                        x16 ? (const float *)m->inv_scale : (const float *)nullptr,
-                       (const float *)m->tail_scratch, (const int32_t *)m->tail_col,
-                       x16 && m->tail_ready ? m->tail_n : 0);
+                       (const float *)m->tail_val, (const int32_t *)m->tail_col, (const int32_t *)m->tail_px,
+                       x16 ? m->tail_n : 0);
     LTMI_HIP(hipGetLastError());
     if (NE > 0)
         snprintf(m->last_kernel, sizeof(m->last_kernel),
@@ -2140,7 +2130,7 @@ static int launch_lds_shifted(ltmi_masks *m, const T *tile, int64_t n_frames, in
                            accumulate, (float *)nullptr, 1, (const int32_t *)c->rows_dev,
                            (const float *const *)c->wg_img_dev + (size_t)gi * n_wg, (int *)nullptr,
                            x16 ? (const float *)m->inv_scale + gi * GROUP : (const float *)nullptr,
-                           (const float *)nullptr, (const int32_t *)nullptr, 0);
+                           (const float *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, 0);
     LTMI_HIP(hipGetLastError());
     snprintf(m->last_kernel, sizeof(m->last_kernel),
              "k_dense_lds<%s,NG=1,shifted%s> grid=(%zu,1,1) x %d column group(s), shift groups=%zu",
@@ -2176,29 +2166,9 @@ static int launch_mfma(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t l
     }
     if (vector_loads_ok(tile, ld, sizeof(T)) && m->tune_mt == 0 && m->tune_waves == 0 &&
         lds_kernel_applies<T>(m)) {
-        // a stack with weights that its float16 images leave out: their float32 products first
-        // (k_dense_tail_pre, device scratch), the matrix kernel's epilogue adds them
-        m->tail_ready = false;
-        if constexpr (sizeof(T) <= 2 && std::is_integral<T>::value) {
-            if (m->tail_n > 0 && !f32_instruction_only(m)) {
-                const size_t need = (size_t)n_frames * m->tail_n * sizeof(float);
-                if (m->tail_scratch_bytes < need) {
-                    if (m->tail_scratch) LTMI_HIP(hipFree(m->tail_scratch));
-                    m->tail_scratch = nullptr;
-                    m->tail_scratch_bytes = 0;
-                    LTMI_HIP(hipMalloc((void **)&m->tail_scratch, need));
-                    m->tail_scratch_bytes = need;
-                }
-                hipLaunchKernelGGL(k_dense_tail_pre<T>, dim3((unsigned)((n_frames + 255) / 256)), dim3(256),
-                                   0, stream, tile, ld, n_frames, (const int32_t *)m->tail_px,
-                                   (const float *)m->tail_val, m->tail_n, m->tail_scratch, m->roi_rows);
-                LTMI_HIP(hipGetLastError());
-                m->tail_ready = true;
-            }
-        }
         m->x16_used = false;
         const int rc_lds = launch_lds<T>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
-        if (rc_lds == LTMI_OK && m->x16_used && m->tail_ready) {
+        if (rc_lds == LTMI_OK && m->x16_used && m->tail_n > 0) {
             const size_t l = strlen(m->last_kernel);
             snprintf(m->last_kernel + l, sizeof(m->last_kernel) - l, " +tail(%d)", m->tail_n);
         }

@@ -219,11 +219,14 @@ class HipJobExecutor(JobExecutor):
 
     def run_tasks(self, tasks, params_handle, cancel_id, task_comm_handler=None):
         params = self._scattered[params_handle]
-        env = self.get_local_env()
-        self._all_tasks = list(tasks)
-        for task in self.my_tasks(self._all_tasks):
-            result = task(env=env, params=params)
-            yield result, task
+        self._all_tasks = list(tasks)                  # (known to merge_results before the first task runs)
+
+        def run():
+            env = self.get_local_env()                 # (picks up the delivery targets merge_results has set)
+            for task in self.my_tasks(self._all_tasks):
+                result = task(env=env, params=params)
+                yield result, task
+        return run()
 
     def run_function(self, fn, *args, **kwargs):
         return fn(*args, **kwargs)
@@ -254,8 +257,51 @@ class HipJobExecutor(JobExecutor):
         drained, nothing is delivered and the exception propagates."""
         self._before_wait = fn
 
+    def launch_ahead(self, tasks):
+        """Launch first, book-keep behind the kernel: every task of a cached plan whose previous run made
+        exactly one mask launch into directly written rows of the run's host buffer (recorded by
+        merge_results) gets that launch enqueued NOW, into the buffer of the page-locked ring that
+        merge_results will adopt for this run; the tile loop's own call is then recognised and skipped
+        (hip.LaunchReplay).  Single rank, complete runs (no partial results) only."""
+        from libertem_amd import hip as _hip
+        if self.gpu_id is None or self._collectives_on or _hip.LaunchReplay.expected is not None \
+                or getattr(self, 'result_where', None) == 'device' \
+                or getattr(self, '_pinned_ring', None) is None:
+            return False
+        recs = [(getattr(t, '_keep', None) or {}).get('replay') for t in self.my_tasks(list(tasks))]
+        if not recs or not all(recs) or len({r[3] for r in recs}) != 1:
+            return False
+        total = recs[0][3]
+        slot = self._pinned_ring.get(total)
+        base_dev = slot[2]
+        if base_dev is None:
+            return False
+        self._make_current()
+        expected = []
+        for handle, sig, off, _ in recs:
+            sig = sig[:5] + (base_dev + off,) + sig[6:]
+            handle.apply(sig[1], sig[2], sig[3], sig[4], sig[5], sig[6], sig[7], stream=sig[8])
+            expected.append(sig)
+        self._ahead = dict(slot=slot, total=total)
+        _hip.LaunchReplay.expected = expected
+        _hip.LaunchReplay.n_ahead += len(expected)
+        return True
+
+    _before_final = None
+
+    def set_before_final(self, fn):
+        """`fn()` is called once in the next `merge_results` when every declared buffer was written
+        straight into its final host array: after the arrays are attached to the buffers, before the wait
+        for the kernels -- host work on the result OBJECTS (not their contents) that hides behind the GPU."""
+        self._before_final = fn
+
     def drain(self):
         """a run was abandoned half way: wait for what it enqueued, forget its delivery targets"""
+        self._ahead = None
+        self._before_final = None
+        from libertem_amd import hip as _hip
+        _hip.LaunchReplay.expected = None
+        _hip.LaunchReplay.recording = None
         self._row_sink = None
         self._result_target = None
         for st in (self._stream, getattr(self, '_copy_stream', None)):
@@ -396,6 +442,7 @@ class HipJobExecutor(JobExecutor):
         # Single rank: a buffer of the executor's pinned ring.  Several ranks on one node: a host
         # segment shared by the ranks, every rank delivers ITS rows (no data-path collective,
         # executor/nodeshared.py).
+        from libertem_amd import hip as _hip
         streamed = {}                           # (udf index, name) -> [host tensor, rows copied out]
         expected = {}                           # rows this rank has to deliver
         direct = {}                             # (udf index, name) -> rows the kernels wrote directly
@@ -448,9 +495,22 @@ class HipJobExecutor(JobExecutor):
                 from libertem_amd import hip as _hip
                 self._pinned_ring = PinnedRing(
                     self._torch, lambda ptr: _hip.host_device_pointer(self.gpu_id, ptr))
-            tens, arr, base_dev = self._pinned_ring.get(total)
+            ahead = getattr(self, '_ahead', None)
+            if ahead is not None:
+                # the run's launches were enqueued ahead into THIS buffer (launch_ahead)
+                self._ahead = None
+                if ahead['total'] != total or partial:
+                    self.drain()
+                    raise _hip.ReplayMismatch("the result layout changed since the launches were recorded")
+                tens, arr, base_dev = ahead['slot']
+            else:
+                tens, arr, base_dev = self._pinned_ring.get(total)
         else:
             shared = None
+        if getattr(self, '_ahead', None) is not None:
+            self._ahead = None
+            self.drain()
+            raise _hip.ReplayMismatch("launches were enqueued ahead for a run without a host result buffer")
         if layout:
             DIRECT_ROW_MAX = _udf_common.HIP_DIRECT_ROW_MAX
             if DIRECT_ROW_MAX <= 0:
@@ -549,6 +609,43 @@ class HipJobExecutor(JobExecutor):
         def publish_device(final):
             """declared device buffers -> host arrays of the main-process udfs"""
             shared_ok = False
+            if sink_on and layout and final and shared is None and busy_shared is None and direct \
+                    and not keepalive and not deferred:
+                # Every declared buffer written by the kernels straight into its final place?  Then the
+                # arrays can be handed over and the caller's result objects built (`set_before_final`)
+                # BEHIND the kernels; the wait for the stream comes last.
+                todo = []
+                for i, (udf, (mode, decl)) in enumerate(zip(udfs, plans)):
+                    if mode != 'device':
+                        todo = None
+                        break
+                    for name in decl:
+                        buf = udf.results.get_buffer(name)
+                        if isinstance(buf, PlaceholderBufferWrapper):
+                            continue
+                        key = (i, name)
+                        if key in host_np and key in direct and \
+                                delivered(key) == buf.shape[0] == expected.get(key):
+                            todo.append((buf, key))
+                        else:
+                            todo = None
+                            break
+                    if todo is None:
+                        break
+                if todo:
+                    for buf, key in todo:
+                        host = host_np[key]
+                        buf.replace_array(host if host.dtype == buf.dtype else host.view(buf.dtype))
+                    hook2, self._before_final = self._before_final, None
+                    try:
+                        if hook2 is not None:
+                            hook2()
+                    finally:
+                        self._stream.synchronize()
+                        idle[0] = True
+                    host_np.clear()
+                    streamed.clear()
+                    return
             if sink_on and layout and final:
                 # my rows are out once the copy stream (copied rows) and the executor stream (rows
                 # the kernels wrote into the host buffer themselves) are idle
@@ -634,6 +731,15 @@ class HipJobExecutor(JobExecutor):
                     gen_entry[i] = results
             damage.get_view_for_partition(task.partition)[:] = True
             n_done += 1
+            rec = (getattr(task, '_keep', None) or {}).pop('recorded', None)
+            if rec is not None and len(rec) == 1 and not rec[0][1][7] and len(udfs) == 1:
+                # one launch, not accumulating, into rows of a directly written buffer: launch-ahead material
+                handle, sig = rec[0]
+                for key, base in dev_ptrs.items():
+                    nb = streamed[key][3]
+                    if shared is None and base <= sig[5] < base + nb:
+                        # (offset inside the run's buffer of the page-locked ring, size of that buffer)
+                        task._keep['replay'] = (handle, sig, streamed[key][2] + sig[5] - base, total)
             if partial:
                 # merge the host-side UDFs right away (tasks arrive in partition order here)
                 for i, results in gen_entry.items():
@@ -650,6 +756,11 @@ class HipJobExecutor(JobExecutor):
                 self._stream.synchronize()
             return
 
+        if _hip.LaunchReplay.expected is not None:
+            left, _hip.LaunchReplay.expected = _hip.LaunchReplay.expected, None
+            if left:
+                self.drain()
+                raise _hip.ReplayMismatch(f"{len(left)} launch(es) enqueued ahead were not made by the run")
         hook, self._before_wait = self._before_wait, None
         if hook is not None:
             try:
@@ -700,6 +811,7 @@ class HipJobExecutor(JobExecutor):
             self._stream.synchronize()
         self._row_sink = None
         self._result_target = None
+        self._before_final = None
         yield n_done
 
     def _to_host(self, t):

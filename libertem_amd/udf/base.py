@@ -36,6 +36,7 @@ from libertem_amd.common.buffers import (
 )
 from libertem_amd.common.hiparray import HipArray
 from libertem_amd.common.fingerprint import fingerprint
+from libertem_amd.hip import ReplayMismatch as _ReplayMismatch
 from libertem_amd.common.udf import UDFProtocol, UDFMethod, NUMPY, HIP
 from libertem_amd.common.exceptions import UDFException, UDFRunCancelled, JobCancelledError, \
     HipRequiredError
@@ -786,7 +787,21 @@ class UDFPartRunner:
                         udf.set_views_for_partition(partition)
                         udf.preprocess()
                         udf.clear_views()
-                self._run_udfs(partition, params, env, backend, meta, keep=keep)
+                # the launches of this task, for the executor's launch-ahead of later runs (hip.LaunchReplay):
+                # recorded once, on the first re-run of the kept instances
+                from libertem_amd import hip as _hip
+                record = backend == HIP and 'replay' not in keep and _hip.LaunchReplay.expected is None \
+                    and _hip.LaunchReplay.recording is None and keep.get('tiles') is not None
+                if record:
+                    _hip.LaunchReplay.recording = rec = []
+                try:
+                    self._run_udfs(partition, params, env, backend, meta, keep=keep)
+                finally:
+                    if record:
+                        _hip.LaunchReplay.recording = None
+                if record:
+                    keep['replay'] = None                  # (decided by the executor: merge_results)
+                    keep['recorded'] = rec
                 self._wrapup_udfs(partition, backend, env)
             return self._hand_over_results(kept=True)
         roi = params.roi
@@ -1088,6 +1103,9 @@ class UDFRunner:
         if hit is not None:
             # same udf objects (and parameter objects) as before: planning, negotiation and task
             # creation are pure functions of them -- only the result buffers are per run
+            if defer_check and hasattr(executor, 'launch_ahead'):
+                # launch first (the recorded launches of the plan's tasks), book-keep behind the kernel
+                executor.launch_ahead(hit['tasks'])
             plans.move_to_end(key)
             meta = copy.copy(hit['meta'])
             for udf in self._udfs:
@@ -1197,10 +1215,22 @@ class UDFRunner:
         def late_check():
             checked.append(True)
             verify()
+        prebuilt = []
+
+        def prebuild():
+            # result objects of the run, built while its kernels are still running (the executor calls this
+            # once the final arrays are attached): only for UDFs whose get_results() hands the declared
+            # buffers on without reading them
+            res = self._make_udf_result(self._udfs, damage)
+            res.buffers
+            prebuilt.append(res)
         try:
             if tasks:
                 params_handle = executor.scatter(params)
                 try:
+                    if not iterate and hasattr(executor, 'set_before_final') and all(
+                            type(u).get_results is UDF.get_results for u in self._udfs):
+                        executor.set_before_final(prebuild)
                     if verify is not None:
                         executor.set_before_wait(late_check)
                     # hook for executors that merge on the device / across ranks
@@ -1233,6 +1263,19 @@ class UDFRunner:
             raise UDFRunCancelled(f"UDF run cancelled after {len(tasks)} tasks were created")
         except _StalePlan:
             raise
+        except _ReplayMismatch:
+            # the launch that was enqueued ahead is not the one this run makes: wait for it, forget the
+            # recorded launches and the plan, run again from scratch (fresh result buffers)
+            if hasattr(executor, 'drain'):
+                executor.drain()
+            for t in tasks:
+                if getattr(t, '_keep', None) is not None:
+                    t._keep['replay'] = None
+                    t._keep.pop('recorded', None)
+            plans = getattr(dataset, '__dict__', {}).get('_udf_plans')
+            if plans:
+                plans.clear()
+            raise _StalePlan()
         except Exception:
             # a stale plan may fail before the comparison is reached (a factory list that grew: the
             # kept task instances and the new result buffers disagree) -- that is a stale plan, not
@@ -1243,7 +1286,7 @@ class UDFRunner:
                 late_check()
             raise
         if not iterate:
-            yield self._make_udf_result(self._udfs, damage)
+            yield prebuilt[0] if prebuilt else self._make_udf_result(self._udfs, damage)
 
     @classmethod
     def dry_run(cls, udfs, dataset, roi=None):

@@ -622,6 +622,47 @@ def test_masks_modified_in_place_between_runs(ctx):
     assert np.array_equal(r1[..., 2], 4 * r0[..., 2]) and np.array_equal(r1[..., :2], r0[..., :2])
 
 
+def test_launch_ahead_of_the_bookkeeping(ctx):
+    """A plan that is run again and again (same udf object, device-resident frames): from the third run on
+    the mask launch of every partition is enqueued as soon as the run's result buffer exists and the tile
+    loop's own call is recognised and skipped (hip.LaunchReplay) -- same results, in caller-owned arrays; masks
+    edited in place are noticed by the deferred content comparison and the run is repeated with the new
+    stack; another udf object does not inherit anything."""
+    from libertem_amd import hip
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    rng = np.random.default_rng(17)
+    data = rng.integers(0, 1000, (6, 8, 64, 64)).astype(np.uint16)
+    masks = rng.random((16, 64, 64)).astype(np.float32)
+    ds = _device_ds(ctx, data, 2)
+    udf = ApplyMasksUDF(mask_factories=lambda: masks, use_sparse=False, mask_count=16)
+    n0 = hip.LaunchReplay.n_ahead
+    got = []
+    for rep in range(6):
+        hip.KernelTimer.start()
+        r = ctx.run_udf(dataset=ds, udf=udf)['intensity'].data
+        ev = hip.KernelTimer.stop()
+        assert len(ev) == 2, ev                           # one launch per partition, never two
+        got.append(r)
+        assert _close(r, opath.apply_masks(data, masks, num_partitions=2), F32_TOL)
+    assert hip.LaunchReplay.n_ahead - n0 == 2 * 4          # runs 3 .. 6, two partitions
+    assert all(np.array_equal(g, got[0]) for g in got) and len({g.ctypes.data for g in got}) == 6
+    masks *= np.float32(3)
+    for rep in range(4):
+        r = ctx.run_udf(dataset=ds, udf=udf)['intensity'].data
+        assert _close(r, opath.apply_masks(data, masks, num_partitions=2), F32_TOL)
+    assert hip.LaunchReplay.expected is None and hip.LaunchReplay.recording is None
+    other = ApplyMasksUDF(mask_factories=lambda: masks[:3], use_sparse=False, mask_count=3)
+    r = ctx.run_udf(dataset=ds, udf=other)['intensity'].data
+    assert _close(r, opath.apply_masks(data, masks[:3], num_partitions=2), F32_TOL)
+    # a run with a region of interest plans afresh (no launch-ahead), the next plain run uses it again
+    roi = np.zeros((6, 8), bool)
+    roi[1::2] = True
+    r = ctx.run_udf(dataset=ds, udf=udf, roi=roi)['intensity'].raw_data
+    assert _close(r, opath.apply_masks(data, masks, num_partitions=2)[roi], F32_TOL)
+    r = ctx.run_udf(dataset=ds, udf=udf)['intensity'].data
+    assert _close(r, opath.apply_masks(data, masks, num_partitions=2), F32_TOL)
+
+
 def test_mask_cache_reuse_and_eviction(ctx):
     from libertem_amd.udf import masks as um
     rng = np.random.default_rng(10)
