@@ -634,7 +634,10 @@ def main():
 
     # ---- the measured config: one global dataset of world x (scan) frames, every rank holds its
     # ---- own contiguous block (weak scaling)
-    wl = Workload(args.config, ctx, torch, rank, world, sharded=use_dist)
+    # (test hook: fewer frames per rank -- many ranks on one GPU stand in for a node; recorded in the line)
+    fpr = os.environ.get('LTMI_BENCH_FRAMES_PER_RANK')
+    fpr = int(fpr) if fpr else None
+    wl = Workload(args.config, ctx, torch, rank, world, sharded=use_dist, frames_per_rank=fpr)
     wl.use_oracle = cpu_base is not None           # N = 1: the oracle also checks 32 result rows
     m = measure(wl, args.steps, args.warmup, barrier, hip)
     result_via = getattr(ctx.executor, 'last_result_via', 'local')
@@ -707,8 +710,18 @@ def main():
         "roofline": m['roofline'],
         "f32_instruction": f32_leg,
         "result_via": result_via,
+        "value_path": {"shm": "every rank's kernels write its nav rows into a page-locked host segment all "
+                              "ranks of the node map (no data-path collective); extras.rccl_path times "
+                              "the same steps with the RCCL all-gather over xGMI",
+                       "collective": "nav rows gathered on the devices by RCCL (ltmi_comm_all_gather over "
+                                     "xGMI), one D2H per rank",
+                       "local": "single rank: kernels write into the rank's own page-locked buffer"
+                       }.get(result_via, result_via),
+        "launch_ahead": hip.LaunchReplay.n_ahead,
         "per_rank": per_rank,
     }
+    if fpr is not None:
+        out["test_hook_frames_per_rank"] = fpr
 
     # The headline figure is complete here.  The extras below run several more collectives (RCCL through
     # the library's communicator, a 128 GiB strong-scaling set-up); should one of them hang on a box this
@@ -759,8 +772,13 @@ def main():
                 k = max(3, args.steps // 2)
                 mm = measure(wl, k, 2, barrier, hip, n_check=4)
                 el = max_over_ranks(mm['elapsed'])
+                try:
+                    lib_info = hip.Comm.library_info()
+                except Exception as e:                    # noqa: BLE001
+                    lib_info = {"error": repr(e)[:200]}
                 return {"result_via": getattr(ctx.executor, 'last_result_via', None),
                         "collective": getattr(ctx.executor, 'last_collective', None),
+                        "rccl_lib": lib_info,
                         "steps": k, "ms_per_step": el / k * 1e3,
                         "value": n_frames * world * k / el, "unit": "frames/s"}
             finally:
@@ -773,6 +791,8 @@ def main():
         def strong_c3():
             c3 = CONFIGS['c3']
             total = c3['scan'][0] * c3['scan'][1]
+            if fpr is not None:
+                total = min(total, fpr * world // 4 // c3['scan'][1] * c3['scan'][1])     # (test hook)
             if total % (world * c3['scan'][1]) != 0:
                 return {"skipped": f"512 scan rows do not split over {world} ranks"}
             w3 = Workload('c3', ctx, torch, rank, world, sharded=True,

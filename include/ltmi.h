@@ -288,6 +288,11 @@ int ltmi_crystallinity_corrected(ltmi_fft_plan *p, const void *tile, int tile_dt
  * The 128-byte id comes from ltmi_comm_unique_id on ONE rank and reaches the others through the
  * launcher's own channel (environment, file, torch.distributed store).  librccl is opened lazily. */
 typedef struct ltmi_comm ltmi_comm;   /* opaque */
+/* which librccl the ltmi_comm_* functions are bound to: file path (NUL-terminated, at most path_cap bytes),
+ * ncclGetVersion() code, and whether that copy was already mapped by the process (a process that runs
+ * torch.distributed binds to torch's bundled RCCL -- never a second one; otherwise LTMI_RCCL_LIB, the
+ * loader path, /opt/rocm/lib).  Any of the output pointers may be NULL. */
+int ltmi_comm_library_info(char *path_out, int64_t path_cap, int *version, int *was_loaded);
 int ltmi_comm_unique_id(void *id_out /* 128 bytes */);
 int ltmi_comm_create(int device, int rank, int world, const void *id /* 128 bytes */,
                      ltmi_comm **out);

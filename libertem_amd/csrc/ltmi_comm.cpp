@@ -6,12 +6,21 @@
 // the same data as pickled partition results over TCP (src/libertem/executor/dask.py:581-646) and
 // merges them one by one on the main process (src/libertem/udf/base.py:2340-2358).
 //
-// librccl is opened lazily (dlopen): a process that never creates a communicator does not need it,
-// and a process that already runs torch.distributed binds to the copy that is loaded.
+// librccl is opened lazily (dlopen): a process that never creates a communicator does not need it.  A
+// process that already runs torch.distributed has an RCCL mapped -- torch bundles its own copy as
+// torch/lib/librccl.so -- and must not get a SECOND one (two RCCLs in one process: two sets of IPC
+// handles and proxy threads on the same GPUs): the loaded objects are searched first
+// (dl_iterate_phdr) and the copy that is there is bound with RTLD_NOLOAD; only a process without any
+// RCCL opens one by name (LTMI_RCCL_LIB, then the loader path, then /opt/rocm/lib).
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
 #include "ltmi_common.h"
 #include <dlfcn.h>
+#include <link.h>
 #include <string.h>
 #include <new>
+#include <string>
 
 namespace {
 
@@ -46,17 +55,39 @@ struct Rccl {
     ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
+    std::string path;            // the file the functions come from
+    bool was_loaded = false;     // bound to a copy that was already in the process
 };
+
+static int find_loaded_rccl(struct dl_phdr_info *info, size_t, void *out) {
+    const char *name = info->dlpi_name;
+    if (name && strstr(name, "librccl")) {
+        *(std::string *)out = name;
+        return 1;
+    }
+    return 0;
+}
 
 static Rccl *rccl() {
     static Rccl r;
     static bool tried = false;
     if (tried) return r.lib ? &r : nullptr;
     tried = true;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *n : names) {
-        r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (r.lib) break;
+    std::string loaded;
+    dl_iterate_phdr(find_loaded_rccl, &loaded);
+    if (!loaded.empty()) {
+        r.lib = dlopen(loaded.c_str(), RTLD_NOW | RTLD_NOLOAD);
+        r.was_loaded = r.lib != nullptr;
+    }
+    if (!r.lib) {
+        const char *env = getenv("LTMI_RCCL_LIB");
+        const char *names[] = {env ? env : "librccl.so.1", "librccl.so.1", "librccl.so",
+                               "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
     }
     if (!r.lib) return nullptr;
     r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
@@ -65,6 +96,9 @@ static Rccl *rccl() {
     r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
     r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+    r.GetVersion = (decltype(r.GetVersion))dlsym(r.lib, "ncclGetVersion");
+    Dl_info di;
+    if (r.GetUniqueId && dladdr((void *)r.GetUniqueId, &di) && di.dli_fname) r.path = di.dli_fname;
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.AllReduce) {
         dlclose(r.lib);
         r.lib = nullptr;
@@ -89,6 +123,21 @@ struct ltmi_comm {
             return LTMI_E_RCCL_BASE + (int)_r;                                                \
         }                                                                                     \
     } while (0)
+
+extern "C" int ltmi_comm_library_info(char *path_out, int64_t path_cap, int *version, int *was_loaded) {
+    Rccl *r = rccl();
+    if (!r) LTMI_FAIL(LTMI_E_INVALID, "librccl could not be loaded: %s", dlerror());
+    if (path_out && path_cap > 0) {
+        strncpy(path_out, r->path.c_str(), (size_t)path_cap - 1);
+        path_out[path_cap - 1] = 0;
+    }
+    if (version) {
+        *version = 0;
+        if (r->GetVersion) (void)r->GetVersion(version);
+    }
+    if (was_loaded) *was_loaded = r->was_loaded ? 1 : 0;
+    return LTMI_OK;
+}
 
 extern "C" int ltmi_comm_unique_id(void *id_out) {
     if (!id_out) LTMI_FAIL(LTMI_E_INVALID, "ltmi_comm_unique_id: null argument");

@@ -264,25 +264,35 @@ class HipJobExecutor(JobExecutor):
         merge_results will adopt for this run; the tile loop's own call is then recognised and skipped
         (hip.LaunchReplay).  Single rank, complete runs (no partial results) only."""
         from libertem_amd import hip as _hip
-        if self.gpu_id is None or self._collectives_on or _hip.LaunchReplay.expected is not None \
-                or getattr(self, 'result_where', None) == 'device' \
-                or getattr(self, '_pinned_ring', None) is None:
+        if self.gpu_id is None or _hip.LaunchReplay.expected is not None \
+                or getattr(self, 'result_where', None) == 'device':
             return False
         recs = [(getattr(t, '_keep', None) or {}).get('replay') for t in self.my_tasks(list(tasks))]
-        if not recs or not all(recs) or len({r[3] for r in recs}) != 1:
+        if not recs or not all(recs) or len({r[3:] for r in recs}) != 1:
             return False
-        total = recs[0][3]
-        slot = self._pinned_ring.get(total)
+        total, mode = recs[0][3], recs[0][4]
+        if mode == 'ring':
+            if self._collectives_on or getattr(self, '_pinned_ring', None) is None:
+                return False
+            slot = self._pinned_ring.get(total)
+        else:
+            # several ranks of one node: this rank's rows of the node-shared segment.  Only when the next
+            # slot exists already -- handing it out is then a local decision that every rank takes alike,
+            # whether it launches ahead or not (executor/nodeshared.py)
+            shared = self._node_shared()
+            if shared is None or not shared.ready_for(total):
+                return False
+            slot = shared.begin_run(total)[1:]
         base_dev = slot[2]
         if base_dev is None:
             return False
         self._make_current()
         expected = []
-        for handle, sig, off, _ in recs:
+        for handle, sig, off, _, _ in recs:
             sig = sig[:5] + (base_dev + off,) + sig[6:]
             handle.apply(sig[1], sig[2], sig[3], sig[4], sig[5], sig[6], sig[7], stream=sig[8])
             expected.append(sig)
-        self._ahead = dict(slot=slot, total=total)
+        self._ahead = dict(slot=slot, total=total, mode=mode)
         _hip.LaunchReplay.expected = expected
         _hip.LaunchReplay.n_ahead += len(expected)
         return True
@@ -477,7 +487,16 @@ class HipJobExecutor(JobExecutor):
         if layout and shared is not None:
             from .nodeshared import NodeSharedUnavailable, NodeSharedBusy
             try:
-                _, tens, arr, base_dev = shared.begin_run(total)
+                ahead = getattr(self, '_ahead', None)
+                if ahead is not None:
+                    # the run's launches were enqueued ahead into THIS slot (launch_ahead)
+                    self._ahead = None
+                    if ahead['total'] != total or ahead['mode'] != 'shared' or partial:
+                        self.drain()
+                        raise _hip.ReplayMismatch("the result layout changed since the launches were recorded")
+                    tens, arr, base_dev = ahead['slot']
+                else:
+                    _, tens, arr, base_dev = shared.begin_run(total)
             except NodeSharedBusy:
                 # this run only: device collectives (the end-of-run barrier still runs, it
                 # refreshes the set of free slots)
@@ -499,7 +518,7 @@ class HipJobExecutor(JobExecutor):
             if ahead is not None:
                 # the run's launches were enqueued ahead into THIS buffer (launch_ahead)
                 self._ahead = None
-                if ahead['total'] != total or partial:
+                if ahead['total'] != total or ahead['mode'] != 'ring' or partial:
                     self.drain()
                     raise _hip.ReplayMismatch("the result layout changed since the launches were recorded")
                 tens, arr, base_dev = ahead['slot']
@@ -737,9 +756,10 @@ class HipJobExecutor(JobExecutor):
                 handle, sig = rec[0]
                 for key, base in dev_ptrs.items():
                     nb = streamed[key][3]
-                    if shared is None and base <= sig[5] < base + nb:
-                        # (offset inside the run's buffer of the page-locked ring, size of that buffer)
-                        task._keep['replay'] = (handle, sig, streamed[key][2] + sig[5] - base, total)
+                    if base <= sig[5] < base + nb:
+                        # (offset inside the run's buffer -- page-locked ring / node-shared slot -- and its size)
+                        task._keep['replay'] = (handle, sig, streamed[key][2] + sig[5] - base, total,
+                                                'ring' if shared is None else 'shared')
             if partial:
                 # merge the host-side UDFs right away (tasks arrive in partition order here)
                 for i, results in gen_entry.items():

@@ -142,6 +142,15 @@ class NodeShared:
                 m |= 1 << k
         return m
 
+    def ready_for(self, nbytes):
+        """True if `begin_run(nbytes)` would hand out an existing slot -- no mapping, nothing collective: the
+        decision only depends on state that is the same on every rank (launch-ahead, executor/hip.py)."""
+        for k in range(len(self.slots)):
+            if self.common_free >> k & 1:
+                return self.slots[k] is not None and self.slots[k]['cap'] >= nbytes \
+                    and self.slots[k]['dev'] is not None
+        return False
+
     def begin_run(self, nbytes):
         """Collective (every rank takes the same decisions: they only depend on `common_free`, the
         slot sizes and `nbytes`, which are the same everywhere).  Returns (slot index, uint8 torch

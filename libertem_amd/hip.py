@@ -34,7 +34,7 @@ EXPORTS = (
     'ltmi_fft_plan_destroy', 'ltmi_crystallinity', 'ltmi_crystallinity_corrected',
     'ltmi_masks_set_tuning',
     'ltmi_masks_last_kernel', 'ltmi_comm_unique_id', 'ltmi_comm_create', 'ltmi_comm_destroy',
-    'ltmi_comm_all_gather', 'ltmi_comm_all_reduce_sum',
+    'ltmi_comm_all_gather', 'ltmi_comm_all_reduce_sum', 'ltmi_comm_library_info',
 )
 
 
@@ -158,6 +158,7 @@ def lib():
         L.ltmi_comm_destroy.argtypes = [vp]
         L.ltmi_comm_all_gather.argtypes = [vp, vp, vp, i64, vp]
         L.ltmi_comm_all_reduce_sum.argtypes = [vp, vp, i32, i64, vp]
+        L.ltmi_comm_library_info.argtypes = [ctypes.c_char_p, i64, ctypes.POINTER(i32), ctypes.POINTER(i32)]
         L.ltmi_masks_last_kernel.restype = c.c_char_p
         for name in EXPORTS:
             fn = getattr(L, name)
@@ -556,6 +557,16 @@ class Comm:
     gather nav results / reduce sig results across the GPUs of a node without torch.distributed."""
 
     ID_BYTES = 128
+
+    @staticmethod
+    def library_info():
+        """-> dict(path, version, was_loaded): the librccl the communicators are bound to (the copy torch has
+        mapped when the process runs torch.distributed -- never a second one)"""
+        path = ctypes.create_string_buffer(1024)
+        ver, was = ctypes.c_int(0), ctypes.c_int(0)
+        check(lib().ltmi_comm_library_info(path, 1024, ctypes.byref(ver), ctypes.byref(was)),
+              'ltmi_comm_library_info')
+        return dict(path=path.value.decode(), version=int(ver.value), was_loaded=bool(was.value))
 
     @staticmethod
     def unique_id():

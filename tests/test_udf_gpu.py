@@ -1826,3 +1826,37 @@ def test_bench_contract_with_two_ranks_on_one_gpu(launcher):
     assert d['rccl_path']['result_via'] == 'collective' and d['rccl_path']['value'] > 0
     assert 'error' not in d['strong_c3'], d['strong_c3']
     assert d['strong_c3']['frames_total'] == 512 * 512 and d['strong_c3']['scaling'] == 'strong'
+
+
+def test_bench_contract_with_eight_ranks_on_one_gpu():
+    """The shape of the first 8-GPU run, on one GPU: `python bench.py --gpus 8` (bench.py starts its own 8
+    ranks; gloo ranks on GPU 0 stand in for 8 GPUs, 8192 frames per rank instead of 65536): 8 nav shards,
+    the node-shared result ring with 8 owners, launch-ahead of the recorded launches in the shared segment,
+    the RCCL-style gather of the same steps, C3 nav-split 8 ways -- ONE JSON line, every extra present."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LTMI_BENCH_DEVICE='0', LTMI_BENCH_BACKEND='gloo', OMP_NUM_THREADS='1',
+               LTMI_BENCH_FRAMES_PER_RANK='8192', LTMI_BENCH_PREHEAT='4')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '6', '--warmup', '2']
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['steps'] == 6 and d['scaling'] == 'weak' and d['value'] > 0
+    assert d['config']['frames_per_gpu'] == 8192 and d['test_hook_frames_per_rank'] == 8192
+    assert d['result_via'] == 'shm' and 'segment' in d['value_path'] and len(d['per_rank']) == 8
+    assert sorted(p['rank'] for p in d['per_rank']) == list(range(8))
+    assert d['launch_ahead'] > 0                         # (rank 0's count: the steps after the second one)
+    assert 'extras_incomplete' not in d, d.get('extras_incomplete')
+    assert 'error' not in d['rccl_path'], d['rccl_path']
+    assert d['rccl_path']['result_via'] == 'collective' and d['rccl_path']['value'] > 0
+    assert 'error' not in d['strong_c3'], d['strong_c3']
+    assert d['strong_c3']['scaling'] == 'strong' and d['strong_c3']['frames_total'] == 16384
+    assert d['f32_instruction'] and 'error' not in d['f32_instruction']
+    assert not [f for f in os.listdir('/dev/shm') if f.startswith(f'ltmi_{os.getuid()}_')]
