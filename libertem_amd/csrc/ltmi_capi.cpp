@@ -19,6 +19,7 @@ extern "C" const char *ltmi_last_error(void) { return ltmi::g_err; }
 extern "C" int ltmi_device_count(int *count) {
     if (!count) LTMI_FAIL(LTMI_E_INVALID, "ltmi_device_count: null argument");
     int n = 0;
+    (void)hipGetLastError();            // (also forgets the thread's sticky last error: hip.clear_last_runtime_error)
     hipError_t e = hipGetDeviceCount(&n);
     if (e == hipErrorNoDevice) { *count = 0; return LTMI_OK; }
     if (e != hipSuccess) LTMI_FAIL((int)e, "hipGetDeviceCount failed: %s", hipGetErrorString(e));

@@ -2331,6 +2331,9 @@ extern "C" int ltmi_apply_masks(ltmi_masks *m, const void *tile, int tile_dtype,
         LTMI_FAIL(LTMI_E_DTYPE, "ltmi_apply_masks: unknown tile dtype %d", tile_dtype);
     if (n_frames == 0) return LTMI_OK;
     if (!tile || !out) LTMI_FAIL(LTMI_E_INVALID, "ltmi_apply_masks: null tile/out pointer");
+    // (a runtime call that failed OUTSIDE the library -- a refused host registration, say -- leaves its code as
+    // the thread's sticky last error; the launch checks below must not report it for these kernels)
+    (void)hipGetLastError();
     hipStream_t stream = (hipStream_t)stream_;
     LTMI_HIP(hipSetDevice(m->device));
     if (m->kind == 2)

@@ -552,6 +552,12 @@ class FFTPlan:
             pass
 
 
+def clear_last_runtime_error():
+    """forget the HIP runtime's sticky 'last error' of this thread (set by a call that failed outside the
+    library, e.g. a host registration that was refused) so that the next launch check does not report it"""
+    lib().ltmi_device_count(ctypes.byref(ctypes.c_int(0)))
+
+
 class Comm:
     """RCCL communicator behind the C ABI (`ltmi_comm*`): what a reference-side binding uses to
     gather nav results / reduce sig results across the GPUs of a node without torch.distributed."""

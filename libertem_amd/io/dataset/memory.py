@@ -224,6 +224,21 @@ class MemoryDataSet(DataSet):
         """Hook for datasets whose frames are still arriving (io/dataset/stream.py): returns once
         the first `upto` frames of the scan are readable.  Everything is there already here."""
 
+    def frames_ready(self, upto):
+        """non-blocking twin of `wait_for_frames`: are the first `upto` frames of the scan readable?"""
+        return True
+
+    def close_stagers(self):
+        """release the upload buffers kept between partitions and runs (host datasets on the HIP backend)"""
+        for st in self.__dict__.pop('_hip_stagers', {}).values():
+            st.close()
+
+    def __del__(self):
+        try:
+            self.close_stagers()
+        except Exception:
+            pass
+
     def get_slices(self):
         """Sharded data: every rank's block [r*n_local, (r+1)*n_local) is cut into `num_partitions`
         partitions with the reference's np.linspace rule applied INSIDE the block -- integer
@@ -268,7 +283,58 @@ class MemoryDataSet(DataSet):
         d = super().__getstate__()
         if d.get('_device_array') is not None:
             raise TypeError("a device-resident MemoryDataSet cannot be pickled")
+        d.pop('_hip_stagers', None)             # (device buffers of this process)
+        d.pop('_udf_plans', None)
         return d
+
+
+#: host ranges this process has page-locked for uploads: start address -> [bytes, users].  Two datasets over
+#: the same array (or a second stager of one dataset) share the registration -- registering a range twice
+#: fails, and the runtime's error would surface at the next kernel launch
+_REGISTERED = {}
+
+
+def _register_host(torch, arr):
+    """page-lock `arr` in place (or join an existing registration that covers it) -> key | None"""
+    ptr, nbytes = arr.ctypes.data, arr.nbytes
+    for p0, ent in _REGISTERED.items():
+        if p0 <= ptr and ptr + nbytes <= p0 + ent[0]:
+            ent[1] += 1
+            return p0
+    try:
+        rc = int(torch.cuda.cudart().cudaHostRegister(ptr, nbytes, 0))
+    except Exception:
+        rc = -1
+    if rc != 0:
+        _clear_runtime_error(torch)
+        return None
+    _REGISTERED[ptr] = [nbytes, 1]
+    return ptr
+
+
+def _unregister_host(torch, key):
+    ent = _REGISTERED.get(key)
+    if ent is None:
+        return
+    ent[1] -= 1
+    if ent[1] <= 0:
+        del _REGISTERED[key]
+        try:
+            rc = int(torch.cuda.cudart().cudaHostUnregister(key))
+        except Exception:
+            rc = -1
+        if rc != 0:
+            _clear_runtime_error(torch)
+
+
+def _clear_runtime_error(torch):
+    """a failed registration leaves its error code as the thread's 'last error'; the next
+    hipGetLastError() -- libltmi's launch check -- would report it for an innocent kernel"""
+    try:
+        from libertem_amd import hip
+        hip.clear_last_runtime_error()
+    except Exception:
+        pass
 
 
 class _HipStager:
@@ -280,7 +346,8 @@ class _HipStager:
     through two pinned bounce buffers.
     """
 
-    def __init__(self, device, chunk_frames, sig, dtype, host_array=None, swap_itemsize=0):
+    def __init__(self, device, chunk_frames, sig, dtype, host_array=None, swap_itemsize=0,
+                 host_is_pinned=False):
         import torch
         self.torch = torch
         self.device = device
@@ -297,14 +364,16 @@ class _HipStager:
         self.host_done = [None, None]
         self.registered = None
         self.pinned = None
-        if host_array is not None and host_array.flags.c_contiguous and host_array.nbytes > 0:
-            try:
-                ptr = host_array.ctypes.data
-                rc = torch.cuda.cudart().cudaHostRegister(ptr, host_array.nbytes, 0)
-                if int(rc) == 0:
-                    self.registered = (ptr, host_array.nbytes)
-            except Exception:
-                self.registered = None
+        self.unregister = True
+        self._reg_key = None
+        if host_is_pinned and host_array is not None and host_array.flags.c_contiguous:
+            # (the dataset allocated the array page-locked -- a stream's scan buffer: nothing to register)
+            self.registered = (host_array.ctypes.data, host_array.nbytes)
+            self.unregister = False
+        elif host_array is not None and host_array.flags.c_contiguous and host_array.nbytes > 0:
+            self._reg_key = _register_host(torch, host_array)
+            if self._reg_key is not None:
+                self.registered = (host_array.ctypes.data, host_array.nbytes)
         if self.registered is None:
             self.pinned = [torch.empty(shape, dtype=self.tdt).pin_memory() for _ in range(2)]
 
@@ -366,10 +435,8 @@ class _HipStager:
         self.torch.cuda.current_stream(self.device).synchronize()
         self.copy_stream.synchronize()
         if self.registered is not None:
-            try:
-                self.torch.cuda.cudart().cudaHostUnregister(self.registered[0])
-            except Exception:
-                pass
+            if self.unregister:
+                _unregister_host(self.torch, self._reg_key)
             self.registered = None
 
 
@@ -558,34 +625,94 @@ class MemPartition(Partition):
         # host data: double-buffered upload, chunk i+1 in flight while chunk i is processed
         host = ds.flat_host()
         part_host = host[self._local0:self._local0 + self._num_frames]
+        groups = [(g0, min(n, g0 + depth)) for g0 in range(0, n, depth)]
+        if idxs is None:
+            yield from self._tiles_through_dataset_stager(ds, host, part_host, groups, depth, device,
+                                                          dest_dtype, fix, compressed_origin,
+                                                          tiling_scheme)
+            return
         stager = _HipStager(device, min(depth, n), ds.shape.sig,
                             ds.decoded_dtype(dest_dtype if dest_dtype is not None else ds.dtype),
-                            host_array=part_host if idxs is None else None,
-                            swap_itemsize=ds._swap_itemsize)
+                            host_array=None, swap_itemsize=ds._swap_itemsize)
 
         def host_chunk(g0, g1):
-            if idxs is None:
-                ds.wait_for_frames(self._start_frame + g1)     # (a stream: frames up to here)
-                return part_host[g0:g1]
             ds.wait_for_frames(self._start_frame + self._num_frames)
             return host[idxs[g0:g1]]
 
-        groups = [(g0, min(n, g0 + depth)) for g0 in range(0, n, depth)]
         try:
             stager.upload(0, host_chunk(*groups[0]))
             for i, (g0, g1) in enumerate(groups):
                 slot = i & 1
                 chunk = stager.get(slot, g1 - g0)
-                eager = stager.registered is not None and ds.eager_upload
-                if i + 1 < len(groups) and eager:
-                    # DMA straight from user memory: enqueue the next upload before the kernels
-                    stager.upload(slot ^ 1, host_chunk(*groups[i + 1]))
                 yield from self._sub_tiles(fix(chunk), compressed_origin + g0, tiling_scheme)
                 stager.release(slot)
-                if i + 1 < len(groups) and not eager:
+                if i + 1 < len(groups):
                     # bounce-buffer mode: the host memcpy overlaps the kernels just enqueued
-                    # (streams: the frames of the next chunk may not have arrived yet -- wait for
-                    # them only after this chunk's kernels are on their way)
                     stager.upload(slot ^ 1, host_chunk(*groups[i + 1]))
         finally:
             stager.close()
+
+    def _tiles_through_dataset_stager(self, ds, host, part_host, groups, depth, device, dest_dtype, fix,
+                                      compressed_origin, tiling_scheme):
+        """Whole partitions of host data (no ROI): ONE stager per dataset and device, kept between
+        partitions and runs -- the two device buffers, the copy stream and the page-locking of the host
+        array are set up once -- and the first chunk of the NEXT partition is uploaded while this
+        partition's last kernels run and its partial result is published (a stream: only if its frames
+        have arrived).  Buffer reuse is ordered by events (`consumed` / `host_done`), no stream is
+        waited for at a partition's end."""
+        dt = ds.decoded_dtype(dest_dtype if dest_dtype is not None else ds.dtype)
+        key = (device, int(depth), np.dtype(dt).str, int(ds._swap_itemsize))
+        stagers = ds.__dict__.setdefault('_hip_stagers', {})
+        st = stagers.get(key)
+        if st is None:
+            for old in stagers.values():
+                old.close()
+            stagers.clear()
+            st = stagers[key] = _HipStager(
+                device, min(depth, host.shape[0]), ds.shape.sig, dt, host_array=host,
+                swap_itemsize=ds._swap_itemsize,
+                host_is_pinned=bool(getattr(ds, 'host_is_pinned', False)))
+            st.seq = 0                      # chunks handed out so far: slot = seq & 1
+            st.ahead = None                 # (first local frame, frames, slot) of a chunk uploaded ahead
+        eager = st.registered is not None and ds.eager_upload
+
+        def host_chunk(g0, g1):
+            ds.wait_for_frames(self._start_frame + g1)     # (a stream: frames up to here)
+            return part_host[g0:g1]
+
+        def take(g0, g1):
+            """slot that holds (or gets) the chunk [g0, g1) of this partition"""
+            a = st.ahead
+            st.ahead = None
+            if a is not None and a[0] == self._local0 + g0 and a[1] >= g1 - g0:
+                return a[2]
+            slot = st.seq & 1
+            st.upload(slot, host_chunk(g0, g1))
+            return slot
+
+        slot = take(*groups[0])
+        for i, (g0, g1) in enumerate(groups):
+            st.seq = slot + 1
+            chunk = st.get(slot, g1 - g0)
+            nxt = None
+            if i + 1 < len(groups) and eager:
+                # DMA straight from user memory: enqueue the next upload before the kernels
+                nxt = take(*groups[i + 1])
+            yield from self._sub_tiles(fix(chunk), compressed_origin + g0, tiling_scheme)
+            st.release(slot)
+            if i + 1 < len(groups):
+                if nxt is None:
+                    # bounce-buffer mode / a stream: the host memcpy overlaps the kernels just enqueued
+                    # (the frames of the next chunk may not have arrived yet -- wait for them only
+                    # after this chunk's kernels are on their way)
+                    nxt = take(*groups[i + 1])
+                slot = nxt
+        # the next partition's first chunk, if it follows in the host array and is there already
+        f_next = self._local0 + self._num_frames
+        if f_next < host.shape[0]:
+            n_next = min(depth, host.shape[0] - f_next)
+            if ds.frames_ready(self._start_frame + self._num_frames + n_next):
+                s2 = slot ^ 1
+                st.upload(s2, host[f_next:f_next + n_next])
+                st.ahead = (f_next, n_next, s2)
+                st.seq = s2

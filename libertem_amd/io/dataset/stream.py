@@ -10,6 +10,11 @@ uploaded (double-buffered H2D, io/dataset/memory.py) as soon as THEIR frames are
 works on the scan while it is being recorded, and `Context.run_udf_iter` hands out the result after
 every partition.  Everything else (tiling, corrections, ROI, sharding) is MemoryDataSet.
 
+In-place feed (`frames=None`): an acquisition that can write into memory it is given -- a detector's DMA
+engine, a receiver thread -- fills `ds.scan_buffer` (page-locked: the uploads read it without a bounce copy
+and without a feeder memcpy, which bounds the iterator feed at ~40 GB/s) and publishes its progress with
+`ds.commit(n_frames_written)`; `ds.finish()` / `ds.fail(exc)` end the acquisition.
+
 Several GPUs: one feeder per rank.  With `shard=(rank, world)` the iterator of a rank delivers ITS
 block of the scan (frames [rank * n / world, (rank + 1) * n / world) of the flattened nav axis, the
 nav sharding of MemoryDataSet); `run_udf_iter` then advances the ranks in lockstep and every rank
@@ -29,9 +34,10 @@ class StreamDataSet(MemoryDataSet):
     """
     Parameters
     ----------
-    frames : iterable of array-like
+    frames : iterable of array-like, or None
         Each item holds one or more whole frames, in scan order: shape `sig_shape` or
-        `(n,) + sig_shape`.  Consumed by a background thread, once.
+        `(n,) + sig_shape`.  Consumed by a background thread, once.  None: the producer writes the
+        frames into `scan_buffer` itself and calls `commit()` (no copy on this side).
     nav_shape, sig_shape : tuple of int
     dtype : numpy dtype of the frames (items are cast to it)
     num_partitions : int, optional
@@ -69,7 +75,7 @@ class StreamDataSet(MemoryDataSet):
         dt = np.dtype(dtype)
         if not dt.isnative:
             raise DataSetException("a stream delivers frames in the native byte order")
-        buf = np.zeros((n_frames,) + sig_shape, dtype=dt)
+        buf, self.host_is_pinned = self._scan_buffer((n_frames,) + sig_shape, dt, pinned=True)
         if num_partitions is None:
             num_partitions = max(1, min(16, n_frames))
         super().__init__(data=buf.reshape(local_nav + sig_shape), sig_dims=len(sig_shape),
@@ -81,9 +87,59 @@ class StreamDataSet(MemoryDataSet):
         self._finished = False
         self._error = None
         self._cond = threading.Condition()
-        self._thread = threading.Thread(target=self._pump, args=(iter(frames),), daemon=True,
-                                        name='ltmi-stream-feed')
-        self._thread.start()
+        self._thread = None
+        if frames is not None:
+            self._thread = threading.Thread(target=self._pump, args=(iter(frames),), daemon=True,
+                                            name='ltmi-stream-feed')
+            self._thread.start()
+
+    @staticmethod
+    def _scan_buffer(shape, dt, pinned):
+        """the host buffer of the scan; page-locked when the producer writes it in place and a GPU is there"""
+        if pinned:
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    from libertem_amd.common.hiparray import torch_dtype_for
+                    t = torch.empty(shape, dtype=torch_dtype_for(dt), pin_memory=True)
+                    arr = t.numpy().view(dt)
+                    arr[...] = 0
+                    return arr, True
+            except Exception:                              # pragma: no cover  (no torch / no GPU)
+                pass
+        return np.zeros(shape, dtype=dt), False
+
+    # --- in-place feed ---------------------------------------------------------------------------
+    @property
+    def scan_buffer(self):
+        """(n_frames of this process,) + sig_shape array the producer of an in-place feed writes into"""
+        return self._buf
+
+    def commit(self, n_frames_written):
+        """in-place feed: the first `n_frames_written` frames of this process's block are in `scan_buffer`"""
+        n = int(n_frames_written)
+        with self._cond:
+            if self._thread is not None:
+                raise DataSetException("commit() belongs to an in-place feed (frames=None)")
+            if not (self._arrived <= n <= self._n_frames):
+                raise DataSetException(f"commit({n}): {self._arrived} frames committed, the block has "
+                                       f"{self._n_frames}")
+            self._arrived = n
+            if n == self._n_frames:
+                self._finished = True
+            self._cond.notify_all()
+
+    def finish(self):
+        """in-place feed: no more frames will come (ends a scan that was cut short)"""
+        with self._cond:
+            self._finished = True
+            self._cond.notify_all()
+
+    def fail(self, exc):
+        """in-place feed: the acquisition failed; waiting consumers raise"""
+        with self._cond:
+            self._error = exc
+            self._cond.notify_all()
 
     # --- feed ------------------------------------------------------------------------------------
     def _copy_in(self, start, chunk, pool):
@@ -142,6 +198,11 @@ class StreamDataSet(MemoryDataSet):
     def frames_arrived(self):
         with self._cond:
             return self._arrived
+
+    def frames_ready(self, upto):
+        upto = max(0, min(int(upto) - self._frame0, self._n_frames))
+        with self._cond:
+            return self._arrived >= upto
 
     def wait_for_frames(self, upto):
         """Block until the frames of the scan up to (global) number `upto` that THIS process is

@@ -213,6 +213,19 @@ def test_exact_float16_products_for_unsigned_pixels(hip, tile_dtype, shape, kspl
         assert ',f16' in ki and np.array_equal(ri, exact.astype(np.float32))
 
 
+def _n_float32_tail(masks2d):
+    """entries of a dense float32 stack that the float16-piece images leave to the float32 epilogue: below 2^-20
+    of their column's maximum AND missed by two float16 pieces of the column-scaled value by more than 2^-19"""
+    m = np.asarray(masks2d, np.float32)
+    amax = np.abs(m).max(axis=1, keepdims=True)
+    scale = np.float32(2.0) ** (15 - np.frexp(np.where(amax > 0, amax, 1))[1])
+    ws = (m * scale).astype(np.float32)
+    w1 = ws.astype(np.float16).astype(np.float32)
+    r = ws - w1
+    miss = np.abs(r - r.astype(np.float16).astype(np.float32)) > np.abs(ws) * np.float32(2.0 ** -19)
+    return int(((m != 0) & (np.abs(m) < amax * np.float32(2.0 ** -20)) & miss).sum())
+
+
 def _one_pixel_frames(dt, n_px, rng):
     """frame i is lit at pixel i only: result[i, k] = value_i * masks[k, i] -- every entry of the stack"""
     dt = np.dtype(dt)
@@ -262,15 +275,8 @@ def test_exact_float16_products_every_entry_elementwise(hip, tile_dtype, n_masks
         assert np.allclose(res, ref, rtol=1e-5, atol=0), np.abs(res / np.where(ref == 0, 1, ref) - 1)[ref != 0].max()
         assert np.array_equal(res == 0, ref == 0)
         assert np.array_equal(res[:, 5], (val * masks[5]).astype(np.float32))
-    # the number of tail entries: weights below 2^-20 of their column's maximum whose two float16 pieces
-    # (of the column-scaled value) miss them by more than 2^-19 relative
-    amax = np.abs(masks).max(axis=1, keepdims=True)
-    scale = np.float32(2.0) ** (15 - np.frexp(amax)[1])
-    ws = (masks * scale).astype(np.float32)
-    w1 = ws.astype(np.float16).astype(np.float32)
-    r = ws - w1
-    miss = np.abs(r - r.astype(np.float16).astype(np.float32)) > np.abs(ws) * np.float32(2.0 ** -19)
-    want = int(((masks != 0) & (np.abs(masks) < amax * np.float32(2.0 ** -20)) & miss).sum())
+    # the number of tail entries
+    want = _n_float32_tail(masks)
     assert 0 < want <= n_tiny and f'+tail({want})' in kern, (want, kern)
 
 
@@ -1234,7 +1240,14 @@ def test_shifted_masks_host_shifts(hip, tile_dtype, sig, n_masks, mask_dtype, ex
                   * (scale + 1))
     # 1- / 2-byte integer pixels with more than 4 columns on the matrix-core path: the shifted images
     # hold float16 pieces (X16); tuning 37 switches the same handle to float32 images and back
+    # (a stack with weights that go through the float32 tail keeps float32 images for shifted frames: the tail
+    #  pixels would have to shift along)
+    real = masks.reshape((n_masks, -1))
+    real = real if md.kind != 'c' else np.concatenate([real.real, real.imag])
     if dt.kind in 'ui' and dt.itemsize <= 2 and 'k_dense_lds' in h.last_kernel() \
+            and n_masks * (2 if md.kind == 'c' else 1) > 4 and _n_float32_tail(real) > 0:
+        assert ',f16' not in h.last_kernel(), h.last_kernel()
+    elif dt.kind in 'ui' and dt.itemsize <= 2 and 'k_dense_lds' in h.last_kernel() \
             and n_masks * (2 if md.kind == 'c' else 1) > 4:
         assert ',f16' in h.last_kernel(), h.last_kernel()
         assert np.all(np.abs(res - ref) <= 2e-6 * (scale + 1))
@@ -1463,10 +1476,11 @@ def test_rccl_comm_behind_the_c_abi(hip):
     ('uint16', 9000, 4), ('uint8', 9000, 4), ('float32', 6000, 2),     # one round of 64 / 32-frame workgroups
     ('uint16', 24576, 2), ('float32', 9000, 1),                        # ... would be coarser than the small ones
 ])
-def test_blocked_sparse_kernel_frames_per_workgroup(hip, tile_dtype, n_frames, tiles):
+def test_blocked_sparse_kernel_frames_per_workgroup(hip, monkeypatch, tile_dtype, n_frames, tiles):
     """k_bell_apply runs 2 or 4 (float32: 1 or 2) frame tiles per wave, whichever needs the shorter
     sequence of workgroup rounds; both instantiations against float64, ragged last workgroup included"""
     from oracle import masks as omasks
+    monkeypatch.setenv('LTMI_SPARSE_SCATTER', '0')        # (float32 frames would take k_scatter)
     if os.environ.get('LTMI_SPARSE_BELL') == '0' or os.environ.get('LTMI_BELL_TILES'):
         pytest.skip("kernel choice forced by the environment")
     dt = np.dtype(tile_dtype)

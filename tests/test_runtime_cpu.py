@@ -620,6 +620,55 @@ def test_stream_dataset_partial_results(live_ctx):
     assert np.array_equal(r['intensity'].data, flat.astype(np.float32).sum(axis=0))
 
 
+def test_stream_dataset_in_place_feed(live_ctx):
+    """`frames=None`: the producer writes into `scan_buffer` itself and commits its progress -- no feeder
+    thread, no copy on this side (a detector's DMA target); partial results per partition as with the
+    iterator feed; commit() out of order / on an iterator feed and a failed acquisition raise."""
+    import threading
+    import time
+    from libertem_amd.io.dataset import DataSetException
+    rng = np.random.default_rng(4)
+    flat = rng.integers(0, 100, (48, 16, 16)).astype(np.uint16)
+    masks = rng.random((2, 16, 16)).astype(np.float32)
+    ds = live_ctx.load('stream', frames=None, nav_shape=(6, 8), sig_shape=(16, 16), dtype=np.uint16,
+                       num_partitions=6)
+    assert ds.scan_buffer.shape == (48, 16, 16) and ds.frames_arrived == 0
+
+    def produce():
+        for i in range(0, 48, 6):
+            ds.scan_buffer[i:i + 6] = flat[i:i + 6]
+            ds.commit(i + 6)
+            time.sleep(0.005)
+    th = threading.Thread(target=produce)
+    th.start()
+    done = []
+    for part in live_ctx.run_udf_iter(dataset=ds, udf=NumpyMasksUDF(masks)):
+        res = part.buffers[0]['intensity'].data.reshape((48, 2))
+        done.append(int(np.count_nonzero(res[:, 0])))
+        assert ds.frames_arrived >= done[-1]
+    th.join()
+    assert done == [8, 16, 24, 32, 40, 48]
+    assert np.allclose(res, flat.reshape((48, -1)).astype(np.float32) @ masks.reshape((2, -1)).T, rtol=1e-5)
+    with pytest.raises(DataSetException):
+        ds.commit(40)                                      # going backwards
+    it = live_ctx.load('stream', frames=iter(flat), nav_shape=(6, 8), sig_shape=(16, 16), dtype=np.uint16)
+    with pytest.raises(DataSetException, match='in-place'):
+        it.commit(3)
+    bad = live_ctx.load('stream', frames=None, nav_shape=(6, 8), sig_shape=(16, 16), dtype=np.uint16,
+                        num_partitions=6)
+    bad.scan_buffer[:8] = flat[:8]
+    bad.commit(8)
+    bad.fail(RuntimeError("detector lost"))
+    with pytest.raises(DataSetException, match='detector lost'):
+        live_ctx.run_udf(dataset=bad, udf=NumpySumUDF())
+    short = live_ctx.load('stream', frames=None, nav_shape=(6, 8), sig_shape=(16, 16), dtype=np.uint16,
+                          num_partitions=6)
+    short.commit(16)
+    short.finish()
+    with pytest.raises(DataSetException, match='ended after 16 of 48'):
+        live_ctx.run_udf(dataset=short, udf=NumpySumUDF())
+
+
 def test_stream_dataset_failures(live_ctx, ctx):
     from libertem_amd.io.dataset import DataSetException
     ds = ctx.load('stream', frames=[np.ones((4, 4))], nav_shape=(1,), sig_shape=(4, 4),
