@@ -993,6 +993,40 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
         }
     }
 
+    // The few weights the float16 image leaves out (at most DENSE_TAIL_MAX per stack; k_build_image_h16): one
+    // float32 product per stored entry, like the reference's matrix product (udf/masks.py:59-77), added to
+    // the column's sum.  A lane holds column m of every group and 4 * TILES frames: the pixels of an entry
+    // that falls on one of its columns are fetched for all of its frames at once (independent loads).
+    float tail_add[TILES][X16 ? NG : 1][4];
+    if constexpr (X16) {
+#pragma unroll
+        for (int tl = 0; tl < TILES; ++tl)
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tail_add[tl][g][r] = 0.f;
+        if (n_tail > 0 && ks == 0) {
+            for (int e = 0; e < n_tail; ++e) {
+                const int c = tail_col[e] - gt * NG * GROUP;
+                if (c < 0 || c >= NG * GROUP || (c & (GROUP - 1)) != m) continue;
+                const float w = tail_val[e];
+                const int64_t px = tail_px[e];
+                float x[TILES][4];
+#pragma unroll
+                for (int tl = 0; tl < TILES; ++tl)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        x[tl][r] = (float)tile[src_frame_of(tl * 16 + kg * 4 + r) * ld + px];
+#pragma unroll
+                for (int tl = 0; tl < TILES; ++tl)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (g == c / GROUP) tail_add[tl][g][r] += w * x[tl][r];
+            }
+        }
+    }
 #pragma unroll
     for (int tl = 0; tl < TILES; ++tl)
 #pragma unroll
@@ -1007,16 +1041,7 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                     else if (NACC == 2) v += acc[tl][g][NACC - 1][r];
                     v += acc2[tl][g][r];
                     if (X16) v *= inv_scale[col];             // undo the column's power-of-two scale
-                    if constexpr (X16) {
-                        // the few weights the float16 image leaves out (at most DENSE_TAIL_MAX per stack): one
-                        // float32 product per stored entry, like the reference's matrix product
-                        // (udf/masks.py:59-77), added to the column's sum
-                        if (n_tail > 0 && ks == 0) {
-                            const T *src = tile + src_frame_of(tl * 16 + kg * 4 + r) * ld;
-                            for (int e = 0; e < n_tail; ++e)
-                                if (tail_col[e] == col) v += tail_val[e] * (float)src[tail_px[e]];
-                        }
-                    }
+                    if constexpr (X16) v += tail_add[tl][g][r];
                     if (ksplit == 1) {
                         float *p = out + f * ld_out + col;
                         *p = accumulate ? (*p + v) : v;
