@@ -1280,6 +1280,14 @@ class UDFRunner:
             # a stale plan may fail before the comparison is reached (a factory list that grew: the
             # kept task instances and the new result buffers disagree) -- that is a stale plan, not
             # an error of the run
+            from libertem_amd import hip as _hip
+            if _hip.LaunchReplay.expected is not None or _hip.LaunchReplay.recording is not None:
+                # a run that enqueued launches ahead (or was recording) ended in an error: nothing of that
+                # state may leak into the next run
+                if hasattr(executor, 'drain'):
+                    executor.drain()
+                _hip.LaunchReplay.expected = None
+                _hip.LaunchReplay.recording = None
             if verify is not None and not checked:
                 if hasattr(executor, 'drain'):
                     executor.drain()

@@ -54,9 +54,17 @@ def counters(db):
     return []
 
 
-def dominant(rows):
+def dominant(rows, label=''):
+    """the kernel the bench line's roofline is about: for k_dense_lds the instantiation with / without the
+    float16-piece products (label ',f16' <-> last template argument `true`) -- bench.py times both in one run
+    (f32_instruction) -- else the first of the dominant families by total time"""
+    want_x16 = ',f16' in label if 'k_dense_lds' in label else None
     for name, n, avg, mn, mx, tot in rows:
         if any(k in name for k in DOMINANT):
+            if want_x16 is not None and 'k_dense_lds<' in name:
+                is_x16 = name.split('>(')[0].rstrip().endswith('true')
+                if is_x16 != want_x16:
+                    continue
             return name, n, avg, mn, mx
     return None
 
@@ -94,7 +102,7 @@ def main():
                   f"{'max_us':>10s}")
             for name, n, avg, mn, mx, tot in rows[:4]:
                 print(f"      {name[:96]:96s} {n:6d} {avg/1e3:10.2f} {mn/1e3:10.2f} {mx/1e3:10.2f}")
-            dom = dominant(rows)
+            dom = dominant(rows, roof.get('kernel', ''))
             per[p] = dict(dom=dom, counters=counters(db))
             for name, ctr, n, v in per[p]['counters']:
                 if dom and name == dom[0]:
