@@ -71,7 +71,7 @@ __global__ void k_build_image(const float *__restrict__ src, float *__restrict__
 // relative to the start of the 16-column group block.
 __host__ __device__ static inline int h16_index(int n, int q, int kb, int plane) {
     const int blk = q >> 5, kg = (q >> 3) & 3, j = q & 7;
-    const int unit = (kg * (kb / 16) + blk * 2 + plane) ^ n;
+    const int unit = (kg * (kb / 16) + blk * 2 + plane) ^ (n & (kb / 16 - 1));      // (see img2_index)
     return (n * kb + unit * 4) * 2 + j;
 }
 
@@ -436,9 +436,13 @@ template <int NG, int NE = 0, int TILES = 1> struct LdsCfg {
     static constexpr int LDS_BYTES = RING * WAVES * ASLOT + 2 * BSLOT;         // 160 KiB
 };
 
+// (the XOR must stay inside a lane group's kb / 16 units: with 128-pixel slots -- 8 units per group -- the
+// full 4-bit n flipped the group, lanes (n, kg) and (n ^ 8, kg ^ 1) asked for the same unit of two rows 4 KiB
+// apart: 4 conflict cycles per fragment read, SQ_LDS_BANK_CONFLICT 2^23 per column group and C5-sized launch
+// in rounds 2 and 3; profiles/r04_lds_conflicts.txt, probes/lds_b128_probe.hip)
 __host__ __device__ static inline int img2_index(int n, int q, int kb) {
     const int blk = q >> 5, kg = (q >> 3) & 3, j = q & 7;
-    const int unit = (kg * (kb / 16) + blk * 2 + (j >> 2)) ^ n;
+    const int unit = (kg * (kb / 16) + blk * 2 + (j >> 2)) ^ (n & (kb / 16 - 1));
     return n * kb + unit * 4 + (j & 3);
 }
 
@@ -653,7 +657,7 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
     const int a_lane = m * SUBB;                         // bytes inside a frame tile of a ring slot
     const int b_lane = m * KB;                           // floats inside a group of a mask slot
     auto b_unit = [&](int blk_in_slot, int h) {          // swizzled 16-B unit of (blk, h) for this lane
-        return ((kg * (KB / 16) + blk_in_slot * 2 + h) ^ m) << 2;
+        return ((kg * (KB / 16) + blk_in_slot * 2 + h) ^ (m & (KB / 16 - 1))) << 2;
     };
     // X16: the lane's 8 raw pixels -> float16 operands of their low and high bytes
     // (signed pixels: the top byte is a signed number -- its sign bit is flipped before the perm and
