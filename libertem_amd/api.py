@@ -168,7 +168,11 @@ class Context:
         (1024 masks x 65 536 frames of float32 are 256 MiB = 4.9 ms of PCIe for a 3.8 ms job).
         """
         if not sync:
-            raise NotImplementedError("only sync=True is available in libertem_amd")
+            # (reference api.py:981-1051: a coroutine that yields the same result; here the synchronous run
+            #  on the context's single worker thread -- runs of one context are serialised, the event loop
+            #  stays free while the GPU works)
+            return self._run_udf_async(dataset, udf, roi=roi, corrections=corrections, progress=progress,
+                                       backends=backends, plots=plots, result_where=result_where)
         if result_where not in (None, 'host', 'device'):
             raise ValueError("result_where must be None, 'host' or 'device'")
         if result_where == 'device':
@@ -193,9 +197,48 @@ class Context:
         buffers = res.buffers
         return tuple(buffers) if udf_is_list else buffers[0]
 
+    def _async_pool(self):
+        pool = getattr(self, '_async_worker', None)
+        if pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = self._async_worker = ThreadPoolExecutor(1, thread_name_prefix='ltmi-async-run')
+        return pool
+
+    async def _run_udf_async(self, dataset, udf, **kwargs):
+        import asyncio
+        import functools
+        loop = asyncio.get_running_loop()
+        return await loop.run_in_executor(
+            self._async_pool(), functools.partial(self.run_udf, dataset, udf, sync=True, **kwargs))
+
+    async def _run_udf_iter_async(self, dataset, udf, **kwargs):
+        """async generator twin of `run_udf_iter` (reference api.py:1105-1152, `ResultAsyncGenerator`)"""
+        import asyncio
+        loop = asyncio.get_running_loop()
+        pool = self._async_pool()
+        gen = self.run_udf_iter(dataset, udf, sync=True, **kwargs)
+        done = object()
+        try:
+            while True:
+                part = await loop.run_in_executor(pool, next, gen, done)
+                if part is done:
+                    return
+                yield part
+        finally:
+            await loop.run_in_executor(pool, gen.close)
+
     def run_udf_iter(self, dataset, udf, roi=None, corrections=None, progress=False,
                      backends=None, plots=None, sync=True):
-        """Generator of partial results after each merged partition (api.py:1053-1152)."""
+        """Generator of partial results after each merged partition (api.py:1053-1152); `sync=False`:
+        an async generator of the same partial results."""
+        if not sync:
+            return self._run_udf_iter_async(dataset, udf, roi=roi, corrections=corrections,
+                                            progress=progress, backends=backends, plots=plots)
+        return self._run_udf_iter_sync(dataset, udf, roi=roi, corrections=corrections, progress=progress,
+                                       backends=backends, plots=plots)
+
+    def _run_udf_iter_sync(self, dataset, udf, roi=None, corrections=None, progress=False,
+                           backends=None, plots=None):
         udf_is_list = isinstance(udf, (tuple, list))
         udfs = list(udf) if udf_is_list else [udf]
         if roi is not None:
@@ -241,6 +284,10 @@ class Context:
                             corrections=corrections, backends=backends)
 
     def close(self):
+        pool = getattr(self, '_async_worker', None)
+        if pool is not None:
+            pool.shutdown(wait=True)
+            self._async_worker = None
         self.executor.close()
 
     def __enter__(self):

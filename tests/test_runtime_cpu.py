@@ -620,6 +620,39 @@ def test_stream_dataset_partial_results(live_ctx):
     assert np.array_equal(r['intensity'].data, flat.astype(np.float32).sum(axis=0))
 
 
+def test_run_udf_async(ctx):
+    """`sync=False` (reference api.py:981-1051, 1105-1152): run_udf returns a coroutine of the same result,
+    run_udf_iter an async generator of the same partial results; the event loop keeps running meanwhile."""
+    import asyncio
+    rng = np.random.default_rng(9)
+    data = rng.integers(0, 100, (4, 6, 8, 8)).astype(np.uint16)
+    masks = rng.random((3, 8, 8)).astype(np.float32)
+    ds = ctx.load('memory', data=data, num_partitions=4, sig_dims=2)
+    want = ctx.run_udf(dataset=ds, udf=NumpyMasksUDF(masks))['intensity'].data
+
+    async def main():
+        ticks = []
+
+        async def ticker():
+            for _ in range(3):
+                ticks.append(1)
+                await asyncio.sleep(0)
+        coro = ctx.run_udf(dataset=ds, udf=NumpyMasksUDF(masks), sync=False)
+        assert asyncio.iscoroutine(coro)
+        res, _ = await asyncio.gather(coro, ticker())
+        both = await ctx.run_udf(dataset=ds, udf=[NumpyMasksUDF(masks), NumpySumUDF()], sync=False)
+        parts = []
+        async for part in ctx.run_udf_iter(dataset=ds, udf=NumpyMasksUDF(masks), sync=False):
+            parts.append(np.array(part.buffers[0]['intensity'].data))
+        return res, both, parts, ticks
+    res, both, parts, ticks = asyncio.run(main())
+    assert np.array_equal(res['intensity'].data, want) and len(ticks) == 3
+    assert isinstance(both, tuple) and np.array_equal(both[0]['intensity'].data, want)
+    assert np.array_equal(both[1]['intensity'].data, data.astype(np.float32).sum(axis=(0, 1)))
+    assert len(parts) == 4 and np.array_equal(parts[-1], want)
+    assert np.count_nonzero(parts[0][..., 0]) == 6
+
+
 def test_stream_dataset_in_place_feed(live_ctx):
     """`frames=None`: the producer writes into `scan_buffer` itself and commits its progress -- no feeder
     thread, no copy on this side (a detector's DMA target); partial results per partition as with the

@@ -1828,6 +1828,32 @@ def test_bench_contract_with_two_ranks_on_one_gpu(launcher):
     assert d['strong_c3']['frames_total'] == 512 * 512 and d['strong_c3']['scaling'] == 'strong'
 
 
+def test_run_udf_async_on_the_gpu(ctx):
+    """`run_udf(sync=False)` / `run_udf_iter(sync=False)` on the HIP executor: the run happens on the context's
+    worker thread (its own current device / stream), the awaited result equals the synchronous one, also with
+    the launch-ahead of a repeated plan."""
+    import asyncio
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    rng = np.random.default_rng(23)
+    data = rng.integers(0, 1000, (5, 8, 64, 64)).astype(np.uint16)
+    masks = rng.random((16, 64, 64)).astype(np.float32)
+    ds = _device_ds(ctx, data, 2)
+    udf = ApplyMasksUDF(mask_factories=lambda: masks, use_sparse=False, mask_count=16)
+    want = ctx.run_udf(dataset=ds, udf=udf)['intensity'].data
+
+    async def main():
+        outs = [await ctx.run_udf(dataset=ds, udf=udf, sync=False) for _ in range(4)]
+        parts = []
+        async for part in ctx.run_udf_iter(dataset=ds, udf=udf, sync=False):
+            parts.append(np.array(part.buffers[0]['intensity'].data))
+        return outs, parts
+    outs, parts = asyncio.run(main())
+    assert all(np.array_equal(o['intensity'].data, want) for o in outs)
+    assert len(parts) == 2 and np.array_equal(parts[-1], want)
+    assert _close(want, opath.apply_masks(data, masks, num_partitions=2), F32_TOL)
+    assert np.array_equal(ctx.run_udf(dataset=ds, udf=udf)['intensity'].data, want)      # back on the main thread
+
+
 def test_bench_contract_with_eight_ranks_on_one_gpu():
     """The shape of the first 8-GPU run, on one GPU: `python bench.py --gpus 8` (bench.py starts its own 8
     ranks; gloo ranks on GPU 0 stand in for 8 GPUs, 8192 frames per rank instead of 65536): 8 nav shards,
