@@ -21,6 +21,10 @@ struct ltmi_fft_plan {
     hipfftComplex *spec = nullptr;     // (batch, h, wc) c64
     hipStream_t bound_stream = nullptr;
     bool stream_bound = false;
+    float *mask_t = nullptr;           // (max columns, 256): the ring's columns of the half mask, transposed
+    int n_cu = 0;
+    bool fused_ok = false;             // 256 x 256 frames: k_cryst_fused (ltmi_cryst.hip) unless LTMI_FFT_FUSED=0
+    char last_kernel[96] = {0};
 };
 
 namespace ltmi {
@@ -246,8 +250,16 @@ extern "C" int ltmi_fft_plan_create(int device, int sig_h, int sig_w, int max_ba
     hipError_t e = hipMalloc((void **)&p->real_buf, (size_t)max_batch * sig_h * sig_w * sizeof(float));
     if (e == hipSuccess)
         e = hipMalloc((void **)&p->spec, (size_t)max_batch * sig_h * p->wc * sizeof(hipfftComplex));
+    if (e == hipSuccess && sig_h == 256 && sig_w == 256) {
+        const char *env = getenv("LTMI_FFT_FUSED");
+        p->fused_ok = !(env && env[0] == '0');
+        e = hipMalloc((void **)&p->mask_t, (size_t)cryst_fused_max_cols() * 256 * sizeof(float));
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&p->n_cu, hipDeviceAttributeMultiprocessorCount, device);
+    }
     if (e != hipSuccess) {
         if (p->real_buf) (void)hipFree(p->real_buf);
+        if (p->spec) (void)hipFree(p->spec);
+        if (p->mask_t) (void)hipFree(p->mask_t);
         (void)hipfftDestroy(p->plan);
         delete p;
         LTMI_FAIL((int)e, "ltmi_fft_plan_create: workspace allocation failed: %s",
@@ -263,8 +275,13 @@ extern "C" int ltmi_fft_plan_destroy(ltmi_fft_plan *p) {
     if (p->have_plan) (void)hipfftDestroy(p->plan);
     if (p->real_buf) (void)hipFree(p->real_buf);
     if (p->spec) (void)hipFree(p->spec);
+    if (p->mask_t) (void)hipFree(p->mask_t);
     delete p;
     return LTMI_OK;
+}
+
+extern "C" const char *ltmi_fft_plan_last_kernel(const ltmi_fft_plan *p) {
+    return p ? p->last_kernel : "";
 }
 
 static int crystallinity_impl(ltmi_fft_plan *p, const void *tile, int tile_dtype,
@@ -321,6 +338,19 @@ static int crystallinity_impl(ltmi_fft_plan *p, const void *tile, int tile_dtype
     if (row_lo < 0 || row_hi < row_lo || row_hi > p->h || n_cols < 0 || n_cols > p->wc)
         LTMI_FAIL(LTMI_E_SHAPE, "ltmi_crystallinity: bad mask bounding box (%d, %d, %d)", row_lo,
                   row_hi, n_cols);
+    if (p->fused_ok && !corr.dark && !corr.gain && corr.n_excl == 0) {
+        bool handled = false;
+        const int rc = cryst_fused(tile, tile_dtype, n_frames, ld_tile, p->h, p->w, real_mask, half_mask,
+                                   n_cols, p->mask_t, out, accumulate, p->n_cu, stream, &handled);
+        if (rc != LTMI_OK) return rc;
+        if (handled) {
+            snprintf(p->last_kernel, sizeof(p->last_kernel), "k_cryst_fused<%s%s> columns=%d",
+                     dtype_name(tile_dtype), real_mask ? ",mask" : "", n_cols);
+            return LTMI_OK;
+        }
+    }
+    snprintf(p->last_kernel, sizeof(p->last_kernel), "hipfft_r2c<%s> batch=%d", dtype_name(tile_dtype),
+             p->batch);
     for (int64_t f0 = 0; f0 < n_frames; f0 += p->batch) {
         const int64_t n = std::min<int64_t>(p->batch, n_frames - f0);
         const void *src = (const char *)tile + (size_t)f0 * ld_tile * esz;

@@ -31,7 +31,7 @@ EXPORTS = (
     'ltmi_masks_create_dense', 'ltmi_masks_create_csr', 'ltmi_masks_destroy', 'ltmi_masks_kind',
     'ltmi_apply_masks', 'ltmi_apply_masks_rows', 'ltmi_apply_masks_shifted', 'ltmi_apply_masks_shifted_host', 'ltmi_sum_frames_workspace', 'ltmi_sum_frames', 'ltmi_sum_sig',
     'ltmi_axpy', 'ltmi_add2d', 'ltmi_gather_rows', 'ltmi_host_device_pointer', 'ltmi_correct', 'ltmi_repair_pixels', 'ltmi_byteswap', 'ltmi_mib_decode', 'ltmi_com_fields', 'ltmi_fft_plan_create',
-    'ltmi_fft_plan_destroy', 'ltmi_crystallinity', 'ltmi_crystallinity_corrected',
+    'ltmi_fft_plan_destroy', 'ltmi_crystallinity', 'ltmi_crystallinity_corrected', 'ltmi_fft_plan_last_kernel',
     'ltmi_masks_set_tuning',
     'ltmi_masks_last_kernel', 'ltmi_comm_unique_id', 'ltmi_comm_create', 'ltmi_comm_destroy',
     'ltmi_comm_all_gather', 'ltmi_comm_all_reduce_sum', 'ltmi_comm_library_info',
@@ -160,6 +160,8 @@ def lib():
         L.ltmi_comm_all_reduce_sum.argtypes = [vp, vp, i32, i64, vp]
         L.ltmi_comm_library_info.argtypes = [ctypes.c_char_p, i64, ctypes.POINTER(i32), ctypes.POINTER(i32)]
         L.ltmi_masks_last_kernel.restype = c.c_char_p
+        L.ltmi_fft_plan_last_kernel.argtypes = [vp]
+        L.ltmi_fft_plan_last_kernel.restype = c.c_char_p
         for name in EXPORTS:
             fn = getattr(L, name)
             if fn.restype is c.c_int and name not in ('ltmi_version',):
@@ -539,6 +541,10 @@ class FFTPlan:
             int(box[0]), int(box[1]), int(box[2]), out_ptr, 1 if accumulate else 0,
             stream if isinstance(stream, int) else _stream_ptr(stream)),
             'ltmi_crystallinity_corrected')
+
+    def last_kernel(self):
+        """'k_cryst_fused<...>' or 'hipfft_r2c<...>': the route of the last crystallinity call"""
+        return lib().ltmi_fft_plan_last_kernel(self._ptr).decode()
 
     def close(self):
         if self._ptr is not None and self._ptr.value:

@@ -1594,3 +1594,102 @@ def test_row_lists_for_the_blocked_sparse_kernel(hip, tile_dtype, n_frames):
         tol = 1e-5 if res_dt == np.float32 else 1e-12
         assert np.all(np.abs(out.cpu().numpy() - ref) <= tol * scale), h.last_kernel()
         h.close()
+
+
+# --- CrystallinityUDF in one kernel (csrc/ltmi_cryst.hip) ----------------
+def _cryst_reference(frames, rad_in, rad_out, real):
+    """float64 restatement of udf/crystallinity.py:47-79 through the oracle's mask construction"""
+    from libertem_amd.udf.crystallinity import crystallinity_masks
+    sig = frames.shape[-2:]
+    real_mask, half = crystallinity_masks(sig, rad_in, rad_out, real[0] if real else None,
+                                          real[1] if real else None)
+    out = np.zeros(len(frames))
+    for i, fr in enumerate(frames.astype(np.float64)):
+        out[i] = np.sum(abs(np.fft.rfft2(fr * real_mask if real_mask is not None else fr)) * half)
+    return out, real_mask, half
+
+
+def _cryst_run(hip, frames, real_mask, half, accumulate_into=None, ld_pad=0, batch=64):
+    from libertem_amd.udf.crystallinity import mask_box
+    n, h, w = frames.shape
+    plan = hip.FFTPlan(0, h, w, batch)
+    ld = h * w + ld_pad
+    padded = np.zeros((n, ld), dtype=frames.dtype)
+    padded[:, :h * w] = frames.reshape(n, -1)
+    t = _dev(padded)
+    rm = None if real_mask is None else torch.from_numpy(
+        np.ascontiguousarray(real_mask.astype(np.float32))).cuda()
+    hm = torch.from_numpy(np.ascontiguousarray(half.astype(np.float32))).cuda()
+    out = torch.full((n,), 7.0, dtype=torch.float32, device='cuda') if accumulate_into is None \
+        else torch.from_numpy(accumulate_into.astype(np.float32)).cuda()
+    plan.crystallinity(t.data_ptr(), frames.dtype, n, ld, None if rm is None else rm.data_ptr(),
+                       hm.data_ptr(), mask_box(half), out.data_ptr(), accumulate_into is not None)
+    torch.cuda.synchronize()
+    label = plan.last_kernel()
+    plan.close()
+    return out.cpu().numpy(), label
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['uint8', 'int8', 'uint16', 'int16', 'uint32', 'int32', 'float32'])
+@pytest.mark.parametrize('rad_in,rad_out,real', [(16, 64, ((128, 128), 25)), (0, 30, None),
+                                                 (40, 70, ((100.5, 140), 31.5))])
+def test_crystallinity_fused_kernel_all_pixel_types(hip, dtype, rad_in, rad_out, real):
+    """256 x 256 frames go through k_cryst_fused: rows, columns and ring sum inside one workgroup;
+    1e-5 relative against float64 (north_star tolerance for floating point)."""
+    rng = np.random.default_rng(_seed('cryst', dtype, rad_out))
+    dt = np.dtype(dtype)
+    n = 11
+    if dt.kind == 'f':
+        frames = rng.normal(size=(n, 256, 256)).astype(dt) * 100
+    else:
+        info = np.iinfo(dt)
+        frames = rng.integers(max(info.min, -4000), min(info.max, 4000), size=(n, 256, 256),
+                              endpoint=True).astype(dt)
+    frames[3] = 0                                              # an empty frame
+    frames[4, 100:110, 50:60] += 17                            # structure on top of the noise
+    ref, real_mask, half = _cryst_reference(frames, rad_in, rad_out, real)
+    got, label = _cryst_run(hip, frames, real_mask, half)
+    assert label.startswith('k_cryst_fused<'), label
+    assert (',mask' in label) == (real is not None)
+    assert np.allclose(got, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max()), (got, ref)
+    assert got[3] == 0
+
+
+@pytest.mark.gpu
+def test_crystallinity_fused_kernel_many_frames_ragged_accumulate(hip):
+    """more frames than workgroups, a padded frame stride, accumulate; and the same numbers as the hipFFT
+    route for a ring that is too wide for the LDS (rad_out 100 -> 101 columns)."""
+    rng = np.random.default_rng(_seed('cryst-many'))
+    frames = rng.integers(0, 4096, size=(300, 256, 256)).astype(np.uint16)
+    ref, real_mask, half = _cryst_reference(frames, 16, 64, ((128, 128), 25))
+    got, label = _cryst_run(hip, frames, real_mask, half, ld_pad=8)
+    assert label == 'k_cryst_fused<uint16,mask> columns=65', label
+    assert np.allclose(got, ref, rtol=1e-5)
+    base = rng.normal(size=300).astype(np.float32) * 1e6
+    got2, _ = _cryst_run(hip, frames, real_mask, half, accumulate_into=base)
+    assert np.allclose(got2, base + got, rtol=1e-6)
+    # an odd frame stride (rows not 8-byte aligned): the hipFFT route takes it
+    got3, label3 = _cryst_run(hip, frames[:9], real_mask, half, ld_pad=1)
+    assert label3.startswith('hipfft_r2c<'), label3
+    assert np.allclose(got3, ref[:9], rtol=1e-5)
+    ref_w, rm_w, half_w = _cryst_reference(frames[:9], 16, 100, ((128, 128), 25))
+    got_w, label_w = _cryst_run(hip, frames[:9], rm_w, half_w)
+    assert label_w.startswith('hipfft_r2c<'), label_w
+    assert np.allclose(got_w, ref_w, rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_crystallinity_fused_kernel_every_bin_of_the_ring(hip):
+    """frames that are single plane waves exp(2 pi i (ky y + kx x) / 256) (real part): |F| is 256^2 / 2 in
+    exactly the bins (ky, kx) and (-ky, -kx) -- each probes whether ONE bin is inside the sum."""
+    yy, xx = np.mgrid[0:256, 0:256]
+    waves = [(0, 0), (0, 64), (0, 65), (64, 0), (192, 0), (45, 45), (46, 46), (255, 1), (16, 0), (15, 0),
+             (200, 30), (128, 128), (3, 63)]
+    frames = np.stack([np.cos(2 * np.pi * (ky * yy + kx * xx) / 256) for ky, kx in waves]).astype(np.float32)
+    ref, _, half = _cryst_reference(frames, 16, 64, None)
+    got, label = _cryst_run(hip, frames, None, half)
+    assert label.startswith('k_cryst_fused<'), label
+    assert np.allclose(got, ref, rtol=1e-5, atol=256 * 256 * 1e-4), (got, ref)   # float32 round-off of 10^4 empty bins
+    inside = ref > 1000
+    assert inside.sum() >= 5 and (~inside).sum() >= 4          # the probe set straddles the ring's edges
