@@ -7,55 +7,72 @@
 // half spectrum in HBM and reads that back: 128 KiB of pixels become 0.9 MiB of traffic and three
 // launches.  Here a workgroup keeps ONE frame in the LDS from the pixels to the single float:
 //
-//   rows     a wave takes two rows a, b as the complex sequence a + i b through a 256-point Stockham
-//            radix-4 transform (4 passes, lane t = butterfly t, data through 2 KiB of LDS per wave),
-//            separates the two spectra (Z[k], conj Z[256 - k]: one ds_bpermute pair) and stores the
-//            columns kx < K it will need -- K = the ring's outer radius + 1 -- into G[kx][y];
-//   columns  a wave transforms column kx of G in place with the same passes and sums
-//            |F[ky][kx]| * mask[ky][kx] into a register; the workgroup writes one float.
+//   rows     a wave takes two rows a, b as the complex sequence a + i b through a 256-point radix-4
+//            transform, separates the two spectra (Z[k], conj Z[256 - k]: one ds_bpermute pair) and
+//            stores the columns kx < K it will need -- K = the ring's outer radius + 1 -- into G[kx][y];
+//   columns  a wave transforms column kx of G in place and sums |F[ky][kx]| * mask[ky][kx] into a
+//            register; the workgroup writes one float per frame.
 //
-// LDS: K columns of (256 + 2) float2 + 8 x 2 KiB of row scratch = 147 KiB for K = 65 (rad_out 64);
-// rings with K > CF_KMAX columns, other frame shapes, float64 pixels and fused corrections stay on
-// the hipFFT route.  HBM traffic: the pixels once (+ the two masks from the L2).
+// The transform (cf_core; lane-level model with every index below: scripts/cryst_fft_model.py).  A wave
+// holds the 256 points as 4 registers x 64 lanes; a radix-4 pass works on the index digit that is the
+// REGISTER index, so between passes a digit held in two lane bits changes place with the register digit:
+//     n = 64 a2 + 16 a1 + 4 a0 + j        lane = (a2 a1 a0), register = j       (8 bytes of a row per lane)
+//     swap register <-> lane[5:4]        v_permlane32_swap + v_permlane16_swap: no LDS at all
+//     pass over a2 -> c0, twiddle W64^((4 a1 + a0) c0)
+//     swap register <-> lane[3:2]        through the LDS: store 64 r + (lane ^ 4 r), load base ^ 4 r
+//     pass over a1 -> c1, twiddle W16^(a0 c1)
+//     swap register <-> lane[1:0]        through the LDS: store 64 r + (lane ^ r), load base ^ r
+//     pass over a0 -> c2
+//     swap register <-> lane[5:4]        permlane swaps again
+//     twiddle W256^(j k1), pass over j -> k2:   register k2 of lane (c2 c0 c1) holds Z[k1 + 64 k2],
+//                                               k1 = c0 + 4 c1 + 16 c2 = sigma(lane)
+// Two LDS round trips per transform (a Stockham formulation needs one per pass and one more to bring the
+// row in: that version of this kernel ran 16 384 frames in 1.58 ms, LDS and vector ALUs ~55 % busy each).
+// The XORs make every 16-lane store group and every 32-lane load group a permutation of the banks
+// (SQ_LDS_BANK_CONFLICT = 0).  The column stage reads G[kx] directly in the layout after the first swap.
 //
-// Bank conflicts: a pass reads the units t + 64 r (contiguous lanes: none) and writes 4 t + r,
-// 16 (t >> 2) + (t & 3) + 4 r, 64 (t >> 4) + (t & 15) + 16 r: the first two put a 16-lane store
-// group on 4 of its 16 bank pairs.  Unit u is therefore kept at u ^ (5 * ((u >> 4) & 3)): bits
-// 5:4 XORed into bits 1:0 and 3:2 make every store group of all three passes a permutation of the
-// 16 bank pairs and leave the reads contiguous within 16 lanes (model: scripts/cryst_fft_model.py).
+// G[kx][y]: 258 float2 per column (516 dwords = 4 mod 32: 8 neighbouring columns, 16 bytes each, hit 32
+// banks), y kept at y ^ (2 ((y >> 5) & 1)) ^ (4 ((kx >> 3) & 1)): the first makes the column stage's loads
+// (lane 16 j + m reads y = 64 r + 4 m + j) conflict-free, the second the row stage's stores (a group of
+// 8 lanes holds the columns sigma(lane) = {0, 4, 8, 12, 1, 5, 9, 13} + 16 i).
+//
+// LDS: K columns + 2 KiB of row scratch per wave that transforms rows: K = 65 (rad_out 64) leaves room for
+// 14 of the 16 waves; rings with K > CF_KMAX columns, other frame shapes, float64 pixels and fused
+// corrections stay on the hipFFT route.  HBM traffic: the pixels once (+ the two masks from the L2).
 #include "ltmi_common.h"
 #include <algorithm>
 
 namespace ltmi {
 
 constexpr int CF_N = 256;                       // frame edge
-constexpr int CF_WAVES = 8;
-constexpr int CF_COL = CF_N + 2;                // float2 units per column of G: 2064 B, 16-B aligned, a
-                                                // b128 store of 8 neighbouring columns hits 32 banks
+constexpr int CF_COL = CF_N + 2;                // float2 units per column of G
 constexpr int CF_SCR = CF_N;                    // float2 units of row scratch per wave
-constexpr int CF_KMAX = (160 * 1024 - 256 - CF_WAVES * CF_SCR * 8) / (CF_COL * 8);
+constexpr int CF_LDS_MAX = 160 * 1024 - 256;    // dynamic LDS a workgroup may ask for (static: the partial sums)
+constexpr int CF_KMAX = (CF_LDS_MAX - 8 * CF_SCR * 8) / (CF_COL * 8);   // at least 8 row buffers
 
-struct CfLane {                                 // per-lane constants of the four passes
-    float2 tw[3][3];                            // passes p = 4, 16, 64: exp(-2 pi i (t & (p-1)) r / (4 p)), r = 1..3
-    int rd;                                     // phys(t): reads of the passes 2..4 (+ 64 r)
-    int wr[3][4];                               // stores of the passes 1..3
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+struct CfLane {                                 // per-lane constants of the transform
+    v2f tw[3][3];                               // passes over a2, a1, j: (re, im) of the twiddle of register 1..3
+    v2f twr[3][3];                              // (-im, re) of the same: u w = u.xx * tw + u.yy * twr, two packed FMAs
+    int wB[4], rB[4];                           // LDS addresses (float2 units) of the swap with lane[3:2]
+    int wC[4], rC[4];                           // ... with lane[1:0]
 };
 
-__device__ __forceinline__ int cf_phys(int u) { return u ^ (5 * ((u >> 4) & 3)); }
+__device__ __forceinline__ int cf_sigma(int l) { return (l & 48) | ((l & 3) << 2) | ((l >> 2) & 3); }
 
-__device__ __forceinline__ float2 cf_mul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+__device__ __forceinline__ v2f cf_mul(v2f u, v2f w, v2f wr) {
+    return __builtin_elementwise_fma(u.xx, w, u.yy * wr);
 }
 
-__device__ __forceinline__ void cf_bfly(float2 (&u)[4]) {
-    const float2 t0 = make_float2(u[0].x + u[2].x, u[0].y + u[2].y);
-    const float2 t1 = make_float2(u[0].x - u[2].x, u[0].y - u[2].y);
-    const float2 t2 = make_float2(u[1].x + u[3].x, u[1].y + u[3].y);
-    const float2 t3 = make_float2(u[1].y - u[3].y, u[3].x - u[1].x);       // -i (u1 - u3)
-    u[0] = make_float2(t0.x + t2.x, t0.y + t2.y);
-    u[1] = make_float2(t1.x + t3.x, t1.y + t3.y);
-    u[2] = make_float2(t0.x - t2.x, t0.y - t2.y);
-    u[3] = make_float2(t1.x - t3.x, t1.y - t3.y);
+__device__ __forceinline__ void cf_bfly(v2f (&u)[4]) {
+    const v2f t0 = u[0] + u[2], t1 = u[0] - u[2], t2 = u[1] + u[3], d = u[1] - u[3];
+    const v2f t3 = {d.y, -d.x};                                             // -i (u1 - u3)
+    u[0] = t0 + t2;
+    u[1] = t1 + t3;
+    u[2] = t0 - t2;
+    u[3] = t1 - t3;
 }
 
 // the wave's own stores become visible to its own loads in program order (DS operations of a wave
@@ -65,127 +82,192 @@ __device__ __forceinline__ void cf_wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// 256-point forward transform of buf (float2 units; the input at rd0 + 64 r for lane t); the result
-// stays in registers: u[r] = Z[t + 64 r].  buf is destroyed.
-__device__ __forceinline__ void cf_fft256(float2 *buf, int rd0, const CfLane &c, float2 (&u)[4]) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) u[r] = buf[rd0 + 64 * r];
-    cf_bfly(u);
-    cf_wave_sync();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) buf[c.wr[0][r]] = u[r];
-#pragma unroll
-    for (int pi = 0; pi < 3; ++pi) {
-        cf_wave_sync();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) u[r] = buf[c.rd + 64 * r];
-        u[1] = cf_mul(u[1], c.tw[pi][0]);
-        u[2] = cf_mul(u[2], c.tw[pi][1]);
-        u[3] = cf_mul(u[3], c.tw[pi][2]);
-        cf_bfly(u);
-        if (pi < 2) {
-            cf_wave_sync();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) buf[c.wr[pi + 1][r]] = u[r];
-        }
-    }
-    cf_wave_sync();
+// (__builtin_bit_cast of an ext-vector ELEMENT reads element 0 whatever the element -- clang of ROCm 7.2 --
+// so the components go through float temporaries)
+// a' = (a.lo32, b.lo32), b' = (a.hi32, b.hi32): register bit <-> lane bit 5
+__device__ __forceinline__ void cf_swap32(v2f &a, v2f &b) {
+    const float ax = a.x, ay = a.y, bx = b.x, by = b.y;
+    const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(ax), __float_as_uint(bx), false, false);
+    const auto y = __builtin_amdgcn_permlane32_swap(__float_as_uint(ay), __float_as_uint(by), false, false);
+    const unsigned x0 = x[0], x1 = x[1], y0 = y[0], y1 = y[1];
+    a = (v2f){__uint_as_float(x0), __uint_as_float(y0)};
+    b = (v2f){__uint_as_float(x1), __uint_as_float(y1)};
 }
 
+// odd rows of 16 lanes of a <-> even rows of b: register bit <-> lane bit 4
+__device__ __forceinline__ void cf_swap16(v2f &a, v2f &b) {
+    const float ax = a.x, ay = a.y, bx = b.x, by = b.y;
+    const auto x = __builtin_amdgcn_permlane16_swap(__float_as_uint(ax), __float_as_uint(bx), false, false);
+    const auto y = __builtin_amdgcn_permlane16_swap(__float_as_uint(ay), __float_as_uint(by), false, false);
+    const unsigned x0 = x[0], x1 = x[1], y0 = y[0], y1 = y[1];
+    a = (v2f){__uint_as_float(x0), __uint_as_float(y0)};
+    b = (v2f){__uint_as_float(x1), __uint_as_float(y1)};
+}
+
+// register index <-> lane[5:4]
+__device__ __forceinline__ void cf_swap_a(v2f (&u)[4]) {
+    cf_swap32(u[0], u[2]);
+    cf_swap32(u[1], u[3]);
+    cf_swap16(u[0], u[1]);
+    cf_swap16(u[2], u[3]);
+}
+
+// From the layout after the first swap (lane = 16 j + 4 a1 + a0, register = a2) to the spectrum:
+// u[k2] = Z[sigma(lane) + 64 k2].  buf: 256 float2 of LDS owned by this wave (destroyed).
+__device__ __forceinline__ void cf_core(v2f *buf, const CfLane &c, v2f (&u)[4]) {
+    cf_bfly(u);
+#pragma unroll
+    for (int r = 1; r < 4; ++r) u[r] = cf_mul(u[r], c.tw[0][r - 1], c.twr[0][r - 1]);
+    cf_wave_sync();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) buf[c.wB[r]] = u[r];
+    cf_wave_sync();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) u[r] = buf[c.rB[r]];
+    cf_bfly(u);
+#pragma unroll
+    for (int r = 1; r < 4; ++r) u[r] = cf_mul(u[r], c.tw[1][r - 1], c.twr[1][r - 1]);
+    cf_wave_sync();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) buf[c.wC[r]] = u[r];
+    cf_wave_sync();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) u[r] = buf[c.rC[r]];
+    cf_wave_sync();
+    cf_bfly(u);
+    cf_swap_a(u);
+#pragma unroll
+    for (int r = 1; r < 4; ++r) u[r] = cf_mul(u[r], c.tw[2][r - 1], c.twr[2][r - 1]);
+    cf_bfly(u);
+}
+
+template <typename T>
+struct CfPair {                                 // the pixels (and mask values) one lane holds of a row pair
+    typedef T __attribute__((ext_vector_type(4))) vec_t;
+    vec_t ra, rb;
+    v4f m01, m23;                               // (ma0, mb0, ma1, mb1), (ma2, mb2, ma3, mb3)
+};
+
 template <typename T, bool MASK>
-__global__ void __launch_bounds__(CF_WAVES * 64)
+__device__ __forceinline__ void cf_load_pair(CfPair<T> &p, const T *__restrict__ src,
+                                             const float *__restrict__ rmask_p, int yp, int t) {
+    typedef typename CfPair<T>::vec_t vec_t;
+    p.ra = __builtin_nontemporal_load((const vec_t *)(src + (2 * yp) * CF_N + 4 * t));
+    p.rb = __builtin_nontemporal_load((const vec_t *)(src + (2 * yp + 1) * CF_N + 4 * t));
+    if (MASK) {
+        p.m01 = *(const v4f *)(rmask_p + yp * (2 * CF_N) + 8 * t);
+        p.m23 = *(const v4f *)(rmask_p + yp * (2 * CF_N) + 8 * t + 4);
+    }
+}
+
+// WAVES waves per workgroup (one workgroup per CU); n_scr <= WAVES of them own 2 KiB of row scratch and
+// transform row pairs (what the LDS leaves beside the K columns of G), all of them transform columns.
+template <typename T, bool MASK, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
 k_cryst_fused(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
-              const float *__restrict__ real_mask, const float *__restrict__ mask_t, int K,
+              const float *__restrict__ rmask_p, const float *__restrict__ mask_p, int K, int n_scr,
               float *__restrict__ out, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cf_smem[];
-    __shared__ float part[CF_WAVES];
+    __shared__ float part[WAVES];
     const int t = threadIdx.x & 63, w = threadIdx.x >> 6;
-    float2 *G = (float2 *)cf_smem;
-    float2 *scr = G + K * CF_COL + w * CF_SCR;
+    v2f *G = (v2f *)cf_smem;
+    v2f *scr = G + K * CF_COL + w * CF_SCR;
+    const int sig = cf_sigma(t);
 
     CfLane c;
 #pragma unroll
-    for (int pi = 0; pi < 3; ++pi) {
-        const int p = 4 << (2 * pi);
-        const int k = t & (p - 1);
+    for (int r = 1; r < 4; ++r) {
+        double s, co;
+        sincospi(-2.0 * (double)((t & 15) * r) / 64.0, &s, &co);
+        c.tw[0][r - 1] = (v2f){(float)co, (float)s};
+        sincospi(-2.0 * (double)((t & 3) * r) / 16.0, &s, &co);
+        c.tw[1][r - 1] = (v2f){(float)co, (float)s};
+        sincospi(-2.0 * (double)(sig * r) / 256.0, &s, &co);
+        c.tw[2][r - 1] = (v2f){(float)co, (float)s};
 #pragma unroll
-        for (int r = 1; r < 4; ++r) {
-            double s, co;
-            sincospi(-2.0 * (double)(k * r) / (double)(4 * p), &s, &co);
-            c.tw[pi][r - 1] = make_float2((float)co, (float)s);
+        for (int pi = 0; pi < 3; ++pi) c.twr[pi][r - 1] = (v2f){-c.tw[pi][r - 1].y, c.tw[pi][r - 1].x};
+    }
+    {
+        const int b2 = (t >> 2) & 3, b0 = t & 3;
+        const int base_b = 64 * b2 + ((t & ~12) | (b2 << 2)), base_c = 64 * b0 + ((t & ~3) | b0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            c.wB[r] = 64 * r + (t ^ (r << 2));
+            c.rB[r] = base_b ^ (r << 2);
+            c.wC[r] = 64 * r + (t ^ r);
+            c.rC[r] = base_c ^ r;
         }
     }
-    c.rd = cf_phys(t);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        c.wr[0][r] = cf_phys(4 * t + r);
-        c.wr[1][r] = cf_phys(16 * (t >> 2) + (t & 3) + 4 * r);
-        c.wr[2][r] = cf_phys(64 * (t >> 4) + (t & 15) + 16 * r);
-    }
-    // the staged row pair: element idx at idx ^ (2 * ((idx >> 4) & 1)) (16-byte halves of a lane's 32 bytes
-    // swapped in every other group of 4 lanes: the b128 stores of 8 lanes then cover all 32 banks)
-    const int half = (t >> 2) & 1;
-    const int st0 = 4 * t + 2 * half, st1 = 4 * t + 2 - 2 * half;
-    const int rd_staged = t ^ (2 * ((t >> 4) & 1));
-    const int back = ((64 - t) & 63) * 4;           // ds_bpermute address: lane (-t) mod 64
+    // row stage: the lane's columns kx = sigma(t) (+ 64), the partner lane that holds Z[256 - kx]
+    const int back = cf_sigma((64 - sig) & 63) * 4;                 // ds_bpermute address
+    const int g_col = sig * CF_COL, g_xor = 4 * ((sig >> 3) & 1);
+    // column stage: lane 16 j + m loads y = 64 r + 4 m + j (kept at y ^ 2 (m >> 3), ^ 4 in odd groups of 8 columns)
+    const int col_rd = (4 * (t & 15) + (t >> 4)) ^ (2 * ((t >> 3) & 1));
+    const bool rows = w < n_scr;
 
-    typedef T __attribute__((ext_vector_type(4))) vec_t;
+    // the loads of a row pair are issued one pair ahead (the first pair of the NEXT frame before the column
+    // stage of this one): their latency is not on the wave's critical path
+    CfPair<T> nxt;
+    if (rows && (int64_t)blockIdx.x < n_frames)
+        cf_load_pair<T, MASK>(nxt, tile + (int64_t)blockIdx.x * ld, rmask_p, w, t);
     for (int64_t f = blockIdx.x; f < n_frames; f += gridDim.x) {
         const T *src = tile + f * ld;
-        // ---- rows: pairs (2 y', 2 y' + 1), y' = w + 8 i
-#pragma unroll 2
-        for (int i = 0; i < CF_N / 2 / CF_WAVES; ++i) {
-            const int yp = w + CF_WAVES * i;
-            const vec_t ra = __builtin_nontemporal_load((const vec_t *)(src + (2 * yp) * CF_N + 4 * t));
-            const vec_t rb = __builtin_nontemporal_load((const vec_t *)(src + (2 * yp + 1) * CF_N + 4 * t));
-            float za[4], zb[4];
+        // ---- rows: pairs (2 y', 2 y' + 1), y' = w + n_scr i
+        if (rows) {
+            for (int yp = w; yp < CF_N / 2; yp += n_scr) {
+                const CfPair<T> cur = nxt;
+                if (yp + n_scr < CF_N / 2)
+                    cf_load_pair<T, MASK>(nxt, src, rmask_p, yp + n_scr, t);
+                else if (f + gridDim.x < n_frames)
+                    cf_load_pair<T, MASK>(nxt, src + (int64_t)gridDim.x * ld, rmask_p, w, t);
+                v2f u[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                za[j] = (float)ra[j];
-                zb[j] = (float)rb[j];
-            }
-            if (MASK) {
-                const float4 ma = *(const float4 *)(real_mask + (2 * yp) * CF_N + 4 * t);
-                const float4 mb = *(const float4 *)(real_mask + (2 * yp + 1) * CF_N + 4 * t);
-                za[0] *= ma.x; za[1] *= ma.y; za[2] *= ma.z; za[3] *= ma.w;
-                zb[0] *= mb.x; zb[1] *= mb.y; zb[2] *= mb.z; zb[3] *= mb.w;
-            }
-            *(float4 *)(scr + st0) = make_float4(za[0], zb[0], za[1], zb[1]);
-            *(float4 *)(scr + st1) = make_float4(za[2], zb[2], za[3], zb[3]);
-            cf_wave_sync();
-            float2 u[4];
-            cf_fft256(scr, rd_staged, c, u);
-            // two real rows out of one complex transform: with Z[k] = (a, b), Z[256 - k] = (c, d)
-            //   2 A[k] = (a + c, b - d)        2 B[k] = (b + d, c - a)       (the 1/2 is applied at the end)
-            {
-                const float2 give = t == 0 ? u[0] : u[3];
-                const float cr = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(back, __builtin_bit_cast(int, give.x)));
-                const float ci = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(back, __builtin_bit_cast(int, give.y)));
-                if (t < K)
-                    *(float4 *)(G + t * CF_COL + 2 * yp) =
-                        make_float4(u[0].x + cr, u[0].y - ci, u[0].y + ci, cr - u[0].x);
-            }
-            if (K > 64) {
-                const float2 give = t == 0 ? u[3] : u[2];
-                const float cr = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(back, __builtin_bit_cast(int, give.x)));
-                const float ci = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(back, __builtin_bit_cast(int, give.y)));
-                if (t + 64 < K)
-                    *(float4 *)(G + (t + 64) * CF_COL + 2 * yp) =
-                        make_float4(u[1].x + cr, u[1].y - ci, u[1].y + ci, cr - u[1].x);
+                for (int j = 0; j < 4; ++j) u[j] = (v2f){(float)cur.ra[j], (float)cur.rb[j]};
+                if (MASK) {
+                    u[0] *= cur.m01.xy; u[1] *= cur.m01.zw;
+                    u[2] *= cur.m23.xy; u[3] *= cur.m23.zw;
+                }
+                cf_swap_a(u);
+                cf_core(scr, c, u);
+                // two real rows out of one complex transform: with Z[k] = (a, b), Z[256 - k] = (c, d)
+                //   2 A[k] = (a + c, b - d)     2 B[k] = (b + d, c - a)     (the 1/2 is applied at the end)
+                const int pos = (2 * (yp ^ ((yp >> 4) & 1))) ^ g_xor;
+                {
+                    const float gx = t == 0 ? u[0].x : u[3].x, gy = t == 0 ? u[0].y : u[3].y;
+                    const float cr = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(gx)));
+                    const float ci = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(gy)));
+                    if (sig < K)
+                        *(v4f *)(G + g_col + pos) = (v4f){u[0].x + cr, u[0].y - ci, u[0].y + ci, cr - u[0].x};
+                }
+                if (K > 64) {
+                    const float gx = t == 0 ? u[3].x : u[2].x, gy = t == 0 ? u[3].y : u[2].y;
+                    const float cr = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(gx)));
+                    const float ci = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(gy)));
+                    if (sig + 64 < K)
+                        *(v4f *)(G + g_col + 64 * CF_COL + pos) =
+                            (v4f){u[1].x + cr, u[1].y - ci, u[1].y + ci, cr - u[1].x};
+                }
             }
         }
         __syncthreads();
-        // ---- columns kx = w + 8 i: transform in place, |F| * mask summed per lane
+        // ---- columns kx = w + WAVES i: transform in place, |F| * mask summed per lane
         float acc = 0.f;
-        for (int kx = w; kx < K; kx += CF_WAVES) {
+        for (int kx = w; kx < K; kx += WAVES) {
             float m[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) m[r] = mask_t[kx * CF_N + t + 64 * r];
-            float2 u[4];
-            cf_fft256(G + kx * CF_COL, t, c, u);
+            for (int r = 0; r < 4; ++r) m[r] = mask_p[kx * CF_N + 64 * r + t];
+            v2f *col = G + kx * CF_COL;
+            const int rd = col_rd ^ (4 * ((kx >> 3) & 1));
+            v2f u[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u[r] = col[rd + 64 * r];
+            cf_core(col, c, u);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (m[r] != 0.f) acc += sqrtf(u[r].x * u[r].x + u[r].y * u[r].y) * m[r];
+                if (__builtin_amdgcn_ballot_w64(m[r] != 0.f)) {          // (most columns: two of the four)
+                    const float a = __builtin_amdgcn_sqrtf(u[r].x * u[r].x + u[r].y * u[r].y);
+                    acc += m[r] != 0.f ? a * m[r] : 0.f;
+                }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -194,43 +276,72 @@ k_cryst_fused(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
         if (threadIdx.x == 0) {
             float v = 0.f;
 #pragma unroll
-            for (int i = 0; i < CF_WAVES; ++i) v += part[i];
+            for (int i = 0; i < WAVES; ++i) v += part[i];
             v *= 0.5f;
             out[f] = accumulate ? out[f] + v : v;
         }
     }
 }
 
-// mask_t[kx][ky] = half_mask[ky][kx] for the K columns of the ring (lanes = ky in the column stage)
+// The two masks in the order the lanes want them (one launch per call, 0.3 MiB):
+//   mask_p[kx][64 r + l]  = half_mask[sigma(l) + 64 r][kx]         (register r of lane l in the column stage)
+//   rmask_p[y'][2 x + i]  = real_mask[2 y' + i][x]                 (rows of a pair interleaved like a + i b)
 __global__ void __launch_bounds__(256)
-k_cryst_mask_t(const float *__restrict__ half_mask, int wc, int K, float *__restrict__ mask_t) {
+k_cryst_masks(const float *__restrict__ half_mask, int wc, int K, float *__restrict__ mask_p,
+              const float *__restrict__ real_mask, float *__restrict__ rmask_p) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= K * CF_N) return;
-    const int kx = i / CF_N, ky = i - kx * CF_N;
-    mask_t[i] = half_mask[(int64_t)ky * wc + kx];
+    if (i < K * CF_N) {
+        const int kx = i / CF_N, q = i - kx * CF_N;
+        const int ky = cf_sigma(q & 63) + 64 * (q >> 6);
+        mask_p[i] = half_mask[(int64_t)ky * wc + kx];
+    }
+    if (real_mask && i < CF_N * CF_N) {
+        const int yp = i / (2 * CF_N), q = i - yp * (2 * CF_N);
+        rmask_p[i] = real_mask[(2 * yp + (q & 1)) * CF_N + (q >> 1)];
+    }
 }
 
 int cryst_fused_max_cols() { return CF_KMAX; }
+int64_t cryst_fused_workspace_floats() { return (int64_t)CF_KMAX * CF_N + CF_N * CF_N; }
 
-template <typename T>
-static int launch_fused(const void *tile, int64_t ld, int64_t n_frames, const float *real_mask,
-                        const float *mask_t, int K, float *out, int accumulate, int n_cu,
-                        hipStream_t stream) {
-    auto kern = real_mask ? k_cryst_fused<T, true> : k_cryst_fused<T, false>;
-    const int lds = K * CF_COL * 8 + CF_WAVES * CF_SCR * 8;
+template <typename T, int WAVES>
+static int launch_fused_w(const void *tile, int64_t ld, int64_t n_frames, const float *real_mask,
+                          const float *mask_t, int K, float *out, int accumulate, int n_cu,
+                          hipStream_t stream) {
+    auto kern = real_mask ? k_cryst_fused<T, true, WAVES> : k_cryst_fused<T, false, WAVES>;
+    const int n_scr = std::min(WAVES, (CF_LDS_MAX - K * CF_COL * 8) / (CF_SCR * 8));
+    const int lds = K * CF_COL * 8 + n_scr * CF_SCR * 8;
     int device = 0;
     LTMI_HIP(hipGetDevice(&device));
     static bool attr_set[16][2] = {{false}};          // per device (and per pixel type: one copy per T)
     if (!attr_set[device & 15][real_mask ? 1 : 0]) {
         LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024 - 256));
+                                     CF_LDS_MAX));
         attr_set[device & 15][real_mask ? 1 : 0] = true;
     }
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_frames, n_cu));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(CF_WAVES * 64), (size_t)lds, stream, (const T *)tile, ld,
-                       n_frames, real_mask, mask_t, K, out, accumulate);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), (size_t)lds, stream, (const T *)tile, ld,
+                       n_frames, real_mask, mask_t, K, n_scr, out, accumulate);
     LTMI_HIP(hipGetLastError());
     return LTMI_OK;
+}
+
+static int cf_waves() {                               // LTMI_CRYST_WAVES=8 / 16 (measurement switch)
+    static int v = 0;
+    if (!v) {
+        const char *env = getenv("LTMI_CRYST_WAVES");
+        v = env && atoi(env) == 8 ? 8 : 16;
+    }
+    return v;
+}
+
+template <typename T>
+static int launch_fused(const void *tile, int64_t ld, int64_t n_frames, const float *real_mask,
+                        const float *mask_t, int K, float *out, int accumulate, int n_cu,
+                        hipStream_t stream) {
+    return cf_waves() == 8
+        ? launch_fused_w<T, 8>(tile, ld, n_frames, real_mask, mask_t, K, out, accumulate, n_cu, stream)
+        : launch_fused_w<T, 16>(tile, ld, n_frames, real_mask, mask_t, K, out, accumulate, n_cu, stream);
 }
 
 // -> LTMI_OK with *handled = true when the fused kernel ran
@@ -242,9 +353,10 @@ int cryst_fused(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, 
     const size_t esz = (size_t)dtype_size(tile_dtype);
     if (esz > 4 || tile_dtype == LTMI_F64) return LTMI_OK;
     if ((uintptr_t)tile % (4 * esz) != 0 || ld % 4 != 0) return LTMI_OK;
-    if (real_mask && (uintptr_t)real_mask % 16 != 0) return LTMI_OK;
-    hipLaunchKernelGGL(k_cryst_mask_t, dim3((unsigned)((n_cols * CF_N + 255) / 256)), dim3(256), 0, stream,
-                       half_mask, sig_w / 2 + 1, n_cols, mask_t);
+        float *rmask_p = mask_t + (int64_t)CF_KMAX * CF_N;
+    hipLaunchKernelGGL(k_cryst_masks, dim3((unsigned)(CF_N * CF_N / 256)), dim3(256), 0, stream, half_mask,
+                       sig_w / 2 + 1, n_cols, mask_t, real_mask, rmask_p);
+    if (real_mask) real_mask = rmask_p;
     int rc = LTMI_E_DTYPE;
     switch (tile_dtype) {
         case LTMI_BOOL:

@@ -21,7 +21,7 @@ struct ltmi_fft_plan {
     hipfftComplex *spec = nullptr;     // (batch, h, wc) c64
     hipStream_t bound_stream = nullptr;
     bool stream_bound = false;
-    float *mask_t = nullptr;           // (max columns, 256): the ring's columns of the half mask, transposed
+    float *mask_t = nullptr;           // workspace of k_cryst_fused: both masks in lane order (ltmi_cryst.hip)
     int n_cu = 0;
     bool fused_ok = false;             // 256 x 256 frames: k_cryst_fused (ltmi_cryst.hip) unless LTMI_FFT_FUSED=0
     char last_kernel[96] = {0};
@@ -253,7 +253,7 @@ extern "C" int ltmi_fft_plan_create(int device, int sig_h, int sig_w, int max_ba
     if (e == hipSuccess && sig_h == 256 && sig_w == 256) {
         const char *env = getenv("LTMI_FFT_FUSED");
         p->fused_ok = !(env && env[0] == '0');
-        e = hipMalloc((void **)&p->mask_t, (size_t)cryst_fused_max_cols() * 256 * sizeof(float));
+        e = hipMalloc((void **)&p->mask_t, (size_t)cryst_fused_workspace_floats() * sizeof(float));
         if (e == hipSuccess) e = hipDeviceGetAttribute(&p->n_cu, hipDeviceAttributeMultiprocessorCount, device);
     }
     if (e != hipSuccess) {

@@ -1,0 +1,53 @@
+"""ltmi_crystallinity alone (no UDF machinery): N frames of 256 x 256 resident in HBM, HIP events around
+REPS calls.  N=16384 REPS=10 RAD_OUT=64 DTYPE=uint16 MASK=1; LTMI_FFT_FUSED=0 -> the hipFFT route."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from libertem_amd import hip
+from libertem_amd.udf.crystallinity import crystallinity_masks, mask_box
+
+n = int(os.environ.get('N', 16384))
+reps = int(os.environ.get('REPS', 10))
+rad_out = int(os.environ.get('RAD_OUT', 64))
+dt = np.dtype(os.environ.get('DTYPE', 'uint16'))
+use_mask = os.environ.get('MASK', '1') != '0'
+g = torch.Generator(device='cuda').manual_seed(1)
+tdt = {1: torch.uint8, 2: torch.int16, 4: torch.int32}[dt.itemsize]
+if dt.kind == 'f':
+    frames = torch.rand((n, 256, 256), generator=g, device='cuda', dtype=torch.float32) * 4096
+else:
+    frames = torch.randint(0, 200 if dt.itemsize == 1 else 4096, (n, 256, 256), generator=g, device='cuda',
+                           dtype=tdt)
+real_mask, half = crystallinity_masks((256, 256), rad_out // 4, rad_out,
+                                      (128, 128) if use_mask else None, 25 if use_mask else None)
+rm = None if real_mask is None else torch.from_numpy(np.ascontiguousarray(real_mask.astype(np.float32))).cuda()
+hm = torch.from_numpy(np.ascontiguousarray(half.astype(np.float32))).cuda()
+out = torch.zeros(n, dtype=torch.float32, device='cuda')
+plan = hip.FFTPlan(0, 256, 256, min(n, 1024))
+box = mask_box(half)
+
+
+def call():
+    plan.crystallinity(frames.data_ptr(), dt, n, 256 * 256, None if rm is None else rm.data_ptr(),
+                       hm.data_ptr(), box, out.data_ptr(), False)
+
+
+call(); call()
+torch.cuda.synchronize()
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+ev[0].record()
+for i in range(reps):
+    call()
+    ev[i + 1].record()
+torch.cuda.synchronize()
+ms = np.median([ev[i].elapsed_time(ev[i + 1]) for i in range(reps)])
+print(f"{plan.last_kernel()}: {n} frames {dt} in {ms:.3f} ms = {n / ms / 1e3:.2f} M frames/s, "
+      f"{n * 65536 * dt.itemsize / ms / 1e6:.0f} GB/s of pixels")
+i = [0, n // 2, n - 1]
+fr = frames[i].cpu().numpy()
+fr = fr.view(dt) if fr.dtype != dt else fr
+got = out[i].cpu().numpy()
+for j, fj in enumerate(fr.astype(np.float64)):
+    ref = np.sum(abs(np.fft.rfft2(fj * real_mask if real_mask is not None else fj)) * half)
+    assert abs(got[j] - ref) <= 1e-5 * abs(ref), (got[j], ref)
+print("   3 frames checked against float64: ok")
