@@ -41,6 +41,7 @@
 // corrections stay on the hipFFT route.  HBM traffic: the pixels once (+ the two masks from the L2).
 #include "ltmi_common.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace ltmi {
 
@@ -66,13 +67,25 @@ __device__ __forceinline__ v2f cf_mul(v2f u, v2f w, v2f wr) {
     return __builtin_elementwise_fma(u.xx, w, u.yy * wr);
 }
 
+// radix-4 butterfly, forward: 8 packed adds.  t1 -+ i d has a different sign in each half: the VOP3P
+// modifiers express it (op_sel swaps the halves of d, neg_lo / neg_hi negate one of them), the compiler does
+// not (it inserts v_xor + v_mov), hence two instructions of inline assembly.  PLAIN = the compiler's version:
+// for results that feed a v_permlane*_swap (the hazard recognizer must see their producer).
+template <bool PLAIN = false>
 __device__ __forceinline__ void cf_bfly(v2f (&u)[4]) {
     const v2f t0 = u[0] + u[2], t1 = u[0] - u[2], t2 = u[1] + u[3], d = u[1] - u[3];
-    const v2f t3 = {d.y, -d.x};                                             // -i (u1 - u3)
     u[0] = t0 + t2;
-    u[1] = t1 + t3;
     u[2] = t0 - t2;
-    u[3] = t1 - t3;
+    if (PLAIN) {
+        u[1] = (v2f){t1.x + d.y, t1.y - d.x};
+        u[3] = (v2f){t1.x - d.y, t1.y + d.x};
+    } else {
+        v2f a, b;
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(a) : "v"(t1), "v"(d));
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(b) : "v"(t1), "v"(d));
+        u[1] = a;
+        u[3] = b;
+    }
 }
 
 // the wave's own stores become visible to its own loads in program order (DS operations of a wave
@@ -114,27 +127,32 @@ __device__ __forceinline__ void cf_swap_a(v2f (&u)[4]) {
 
 // From the layout after the first swap (lane = 16 j + 4 a1 + a0, register = a2) to the spectrum:
 // u[k2] = Z[sigma(lane) + 64 k2].  buf: 256 float2 of LDS owned by this wave (destroyed).
+template <bool NOLDS = false>
 __device__ __forceinline__ void cf_core(v2f *buf, const CfLane &c, v2f (&u)[4]) {
     cf_bfly(u);
 #pragma unroll
     for (int r = 1; r < 4; ++r) u[r] = cf_mul(u[r], c.tw[0][r - 1], c.twr[0][r - 1]);
-    cf_wave_sync();
+    if (!NOLDS) {
+        cf_wave_sync();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) buf[c.wB[r]] = u[r];
-    cf_wave_sync();
+        for (int r = 0; r < 4; ++r) buf[c.wB[r]] = u[r];
+        cf_wave_sync();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) u[r] = buf[c.rB[r]];
+        for (int r = 0; r < 4; ++r) u[r] = buf[c.rB[r]];
+    }
     cf_bfly(u);
 #pragma unroll
     for (int r = 1; r < 4; ++r) u[r] = cf_mul(u[r], c.tw[1][r - 1], c.twr[1][r - 1]);
-    cf_wave_sync();
+    if (!NOLDS) {
+        cf_wave_sync();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) buf[c.wC[r]] = u[r];
-    cf_wave_sync();
+        for (int r = 0; r < 4; ++r) buf[c.wC[r]] = u[r];
+        cf_wave_sync();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) u[r] = buf[c.rC[r]];
-    cf_wave_sync();
-    cf_bfly(u);
+        for (int r = 0; r < 4; ++r) u[r] = buf[c.rC[r]];
+        cf_wave_sync();
+    }
+    cf_bfly<true>(u);
     cf_swap_a(u);
 #pragma unroll
     for (int r = 1; r < 4; ++r) u[r] = cf_mul(u[r], c.tw[2][r - 1], c.twr[2][r - 1]);
@@ -142,34 +160,49 @@ __device__ __forceinline__ void cf_core(v2f *buf, const CfLane &c, v2f (&u)[4]) 
 }
 
 template <typename T>
-struct CfPair {                                 // the pixels (and mask values) one lane holds of a row pair
+struct CfRaw {                                  // the pixels one lane holds of a row pair: 4 of row a, 4 of row b
     typedef T __attribute__((ext_vector_type(4))) vec_t;
     vec_t ra, rb;
-    v4f m01, m23;                               // (ma0, mb0, ma1, mb1), (ma2, mb2, ma3, mb3)
 };
+struct CfMask { v4f m01, m23; };                // (ma0, mb0, ma1, mb1), (ma2, mb2, ma3, mb3)
 
-template <typename T, bool MASK>
-__device__ __forceinline__ void cf_load_pair(CfPair<T> &p, const T *__restrict__ src,
-                                             const float *__restrict__ rmask_p, int yp, int t) {
-    typedef typename CfPair<T>::vec_t vec_t;
-    p.ra = __builtin_nontemporal_load((const vec_t *)(src + (2 * yp) * CF_N + 4 * t));
-    p.rb = __builtin_nontemporal_load((const vec_t *)(src + (2 * yp + 1) * CF_N + 4 * t));
-    if (MASK) {
-        p.m01 = *(const v4f *)(rmask_p + yp * (2 * CF_N) + 8 * t);
-        p.m23 = *(const v4f *)(rmask_p + yp * (2 * CF_N) + 8 * t + 4);
+template <typename T, int ABL = 0>
+__device__ __forceinline__ void cf_load_raw(CfRaw<T> &p, const T *__restrict__ src, int yp, int t) {
+    typedef typename CfRaw<T>::vec_t vec_t;
+    if (ABL == 1) {                                 // (timing only: no memory)
+        p.ra = (vec_t)(T)yp;
+        p.rb = (vec_t)(T)t;
+        return;
     }
+    const T *row = src + (2 * yp) * CF_N;           // (uniform: scalar base + the lane's offset)
+    p.ra = __builtin_nontemporal_load((const vec_t *)(row + 4 * t));
+    p.rb = __builtin_nontemporal_load((const vec_t *)(row + CF_N + 4 * t));
+}
+
+template <int ABL = 0>
+__device__ __forceinline__ void cf_load_mask(CfMask &p, const float *__restrict__ rmask_p, int yp, int t) {
+    if (ABL == 1) {
+        p.m01 = p.m23 = (v4f)1.f;
+        return;
+    }
+    const float *row = rmask_p + yp * (2 * CF_N);
+    p.m01 = *(const v4f *)(row + 8 * t);
+    p.m23 = *(const v4f *)(row + 8 * t + 4);
 }
 
 // WAVES waves per workgroup (one workgroup per CU); n_scr <= WAVES of them own 2 KiB of row scratch and
 // transform row pairs (what the LDS leaves beside the K columns of G), all of them transform columns.
-template <typename T, bool MASK, int WAVES>
+// ABL: timing-only ablations (LTMI_CRYST_ABLATE, uint16 + mask + 16 waves): 1 no global loads, 2 no barriers,
+// 3 no LDS transposes, 4 rows only, 5 columns only -- the results are garbage
+template <typename T, bool MASK, int WAVES, int ABL = 0>
 __global__ void __launch_bounds__(WAVES * 64)
 k_cryst_fused(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
-              const float *__restrict__ rmask_p, const float *__restrict__ mask_p, int K, int n_scr,
-              float *__restrict__ out, int accumulate) {
+              const float *__restrict__ rmask_p, const unsigned long long *__restrict__ rflags,
+              const float *__restrict__ mask_p, int K, int n_scr, float *__restrict__ out, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cf_smem[];
     __shared__ float part[WAVES];
-    const int t = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int t = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (uniform: scalar addresses and branches)
     v2f *G = (v2f *)cf_smem;
     v2f *scr = G + K * CF_COL + w * CF_SCR;
     const int sig = cf_sigma(t);
@@ -205,30 +238,53 @@ k_cryst_fused(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
     const int col_rd = (4 * (t & 15) + (t >> 4)) ^ (2 * ((t >> 3) & 1));
     const bool rows = w < n_scr;
 
-    // the loads of a row pair are issued one pair ahead (the first pair of the NEXT frame before the column
-    // stage of this one): their latency is not on the wave's critical path
-    CfPair<T> nxt;
-    if (rows && (int64_t)blockIdx.x < n_frames)
-        cf_load_pair<T, MASK>(nxt, tile + (int64_t)blockIdx.x * ld, rmask_p, w, t);
+    // Row pairs as one stream of items (frame, y') per wave.  The pixels of an item are loaded DEPTH items
+    // ahead (2 for 1- and 2-byte pixels, 8 registers; 1 for 4-byte pixels), its mask values one item ahead
+    // and only where the pair's mask is not all ones (bit y' of rflags: a disk touches ~20 % of the pairs):
+    // without memory the kernel is 21 % faster than with a single pair of lead.
+    constexpr int DEPTH = sizeof(T) <= 2 ? 2 : 1;
+    const unsigned long long fl0 = MASK ? rflags[0] : 0, fl1 = MASK ? rflags[1] : 0;
+    auto masked = [&](int yp) -> bool { return ((yp < 64 ? fl0 : fl1) >> (yp & 63)) & 1; };
+    CfRaw<T> r0, r1;
+    CfMask m0;
+    int64_t lf = blockIdx.x;                            // load cursor: the item DEPTH ahead of the one in work
+    int lyp = w;
+    auto load_next = [&](CfRaw<T> &dst) {
+        if (lf < n_frames) cf_load_raw<T, ABL>(dst, tile + lf * ld, lyp, t);
+        lyp += n_scr;
+        if (lyp >= CF_N / 2) {
+            lyp = w;
+            lf += gridDim.x;
+        }
+    };
+    if (rows) {
+        load_next(r0);
+        if (DEPTH == 2) load_next(r1);
+        if (MASK && masked(w)) cf_load_mask<ABL>(m0, rmask_p, w, t);
+    }
     for (int64_t f = blockIdx.x; f < n_frames; f += gridDim.x) {
-        const T *src = tile + f * ld;
         // ---- rows: pairs (2 y', 2 y' + 1), y' = w + n_scr i
-        if (rows) {
+        if (rows && ABL != 5) {
             for (int yp = w; yp < CF_N / 2; yp += n_scr) {
-                const CfPair<T> cur = nxt;
-                if (yp + n_scr < CF_N / 2)
-                    cf_load_pair<T, MASK>(nxt, src, rmask_p, yp + n_scr, t);
-                else if (f + gridDim.x < n_frames)
-                    cf_load_pair<T, MASK>(nxt, src + (int64_t)gridDim.x * ld, rmask_p, w, t);
+                const CfRaw<T> cur = r0;
+                const CfMask cm = m0;
+                if (DEPTH == 2) {
+                    r0 = r1;
+                    load_next(r1);
+                } else {
+                    load_next(r0);
+                }
+                const int nyp = yp + n_scr < CF_N / 2 ? yp + n_scr : w;
+                if (MASK && masked(nyp)) cf_load_mask<ABL>(m0, rmask_p, nyp, t);
                 v2f u[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) u[j] = (v2f){(float)cur.ra[j], (float)cur.rb[j]};
-                if (MASK) {
-                    u[0] *= cur.m01.xy; u[1] *= cur.m01.zw;
-                    u[2] *= cur.m23.xy; u[3] *= cur.m23.zw;
+                if (MASK && masked(yp)) {
+                    u[0] *= cm.m01.xy; u[1] *= cm.m01.zw;
+                    u[2] *= cm.m23.xy; u[3] *= cm.m23.zw;
                 }
                 cf_swap_a(u);
-                cf_core(scr, c, u);
+                cf_core<ABL == 3>(scr, c, u);
                 // two real rows out of one complex transform: with Z[k] = (a, b), Z[256 - k] = (c, d)
                 //   2 A[k] = (a + c, b - d)     2 B[k] = (b + d, c - a)     (the 1/2 is applied at the end)
                 const int pos = (2 * (yp ^ ((yp >> 4) & 1))) ^ g_xor;
@@ -249,10 +305,10 @@ k_cryst_fused(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
                 }
             }
         }
-        __syncthreads();
+        if (ABL != 2) __syncthreads();
         // ---- columns kx = w + WAVES i: transform in place, |F| * mask summed per lane
         float acc = 0.f;
-        for (int kx = w; kx < K; kx += WAVES) {
+        for (int kx = w; kx < (ABL == 4 ? 0 : K); kx += WAVES) {
             float m[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) m[r] = mask_p[kx * CF_N + 64 * r + t];
@@ -261,7 +317,7 @@ k_cryst_fused(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
             v2f u[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) u[r] = col[rd + 64 * r];
-            cf_core(col, c, u);
+            cf_core<ABL == 3>(col, c, u);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (__builtin_amdgcn_ballot_w64(m[r] != 0.f)) {          // (most columns: two of the four)
@@ -272,7 +328,7 @@ k_cryst_fused(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
         if (t == 0) part[w] = acc;
-        __syncthreads();
+        if (ABL != 2) __syncthreads();
         if (threadIdx.x == 0) {
             float v = 0.f;
 #pragma unroll
@@ -286,9 +342,11 @@ k_cryst_fused(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
 // The two masks in the order the lanes want them (one launch per call, 0.3 MiB):
 //   mask_p[kx][64 r + l]  = half_mask[sigma(l) + 64 r][kx]         (register r of lane l in the column stage)
 //   rmask_p[y'][2 x + i]  = real_mask[2 y' + i][x]                 (rows of a pair interleaved like a + i b)
+//   rflags bit y'         = the pair y' holds a mask value other than 1 (cleared by the caller)
 __global__ void __launch_bounds__(256)
 k_cryst_masks(const float *__restrict__ half_mask, int wc, int K, float *__restrict__ mask_p,
-              const float *__restrict__ real_mask, float *__restrict__ rmask_p) {
+              const float *__restrict__ real_mask, float *__restrict__ rmask_p,
+              unsigned long long *__restrict__ rflags) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < K * CF_N) {
         const int kx = i / CF_N, q = i - kx * CF_N;
@@ -297,31 +355,43 @@ k_cryst_masks(const float *__restrict__ half_mask, int wc, int K, float *__restr
     }
     if (real_mask && i < CF_N * CF_N) {
         const int yp = i / (2 * CF_N), q = i - yp * (2 * CF_N);
-        rmask_p[i] = real_mask[(2 * yp + (q & 1)) * CF_N + (q >> 1)];
+        const float v = real_mask[(2 * yp + (q & 1)) * CF_N + (q >> 1)];
+        rmask_p[i] = v;
+        // (a wave's 64 elements belong to one pair)
+        if (__builtin_amdgcn_ballot_w64(v != 1.f) && (threadIdx.x & 63) == 0)
+            atomicOr(&rflags[yp >> 6], 1ull << (yp & 63));
     }
 }
 
 int cryst_fused_max_cols() { return CF_KMAX; }
-int64_t cryst_fused_workspace_floats() { return (int64_t)CF_KMAX * CF_N + CF_N * CF_N; }
+int64_t cryst_fused_workspace_floats() { return (int64_t)CF_KMAX * CF_N + CF_N * CF_N + 4; }
 
 template <typename T, int WAVES>
 static int launch_fused_w(const void *tile, int64_t ld, int64_t n_frames, const float *real_mask,
-                          const float *mask_t, int K, float *out, int accumulate, int n_cu,
-                          hipStream_t stream) {
+                          const unsigned long long *rflags, const float *mask_t, int K, float *out,
+                          int accumulate, int n_cu, hipStream_t stream) {
     auto kern = real_mask ? k_cryst_fused<T, true, WAVES> : k_cryst_fused<T, false, WAVES>;
+    if constexpr (std::is_same<T, uint16_t>::value && WAVES == 16) {
+        static const int abl = getenv("LTMI_CRYST_ABLATE") ? atoi(getenv("LTMI_CRYST_ABLATE")) : 0;
+        if (real_mask && abl == 1) kern = k_cryst_fused<T, true, WAVES, 1>;
+        if (real_mask && abl == 2) kern = k_cryst_fused<T, true, WAVES, 2>;
+        if (real_mask && abl == 3) kern = k_cryst_fused<T, true, WAVES, 3>;
+        if (real_mask && abl == 4) kern = k_cryst_fused<T, true, WAVES, 4>;
+        if (real_mask && abl == 5) kern = k_cryst_fused<T, true, WAVES, 5>;
+    }
     const int n_scr = std::min(WAVES, (CF_LDS_MAX - K * CF_COL * 8) / (CF_SCR * 8));
     const int lds = K * CF_COL * 8 + n_scr * CF_SCR * 8;
     int device = 0;
     LTMI_HIP(hipGetDevice(&device));
     static bool attr_set[16][2] = {{false}};          // per device (and per pixel type: one copy per T)
-    if (!attr_set[device & 15][real_mask ? 1 : 0]) {
+    if (!attr_set[device & 15][real_mask ? 1 : 0] || getenv("LTMI_CRYST_ABLATE")) {
         LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      CF_LDS_MAX));
         attr_set[device & 15][real_mask ? 1 : 0] = true;
     }
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_frames, n_cu));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), (size_t)lds, stream, (const T *)tile, ld,
-                       n_frames, real_mask, mask_t, K, n_scr, out, accumulate);
+                       n_frames, real_mask, rflags, mask_t, K, n_scr, out, accumulate);
     LTMI_HIP(hipGetLastError());
     return LTMI_OK;
 }
@@ -337,11 +407,11 @@ static int cf_waves() {                               // LTMI_CRYST_WAVES=8 / 16
 
 template <typename T>
 static int launch_fused(const void *tile, int64_t ld, int64_t n_frames, const float *real_mask,
-                        const float *mask_t, int K, float *out, int accumulate, int n_cu,
-                        hipStream_t stream) {
+                        const unsigned long long *rflags, const float *mask_t, int K, float *out,
+                        int accumulate, int n_cu, hipStream_t stream) {
     return cf_waves() == 8
-        ? launch_fused_w<T, 8>(tile, ld, n_frames, real_mask, mask_t, K, out, accumulate, n_cu, stream)
-        : launch_fused_w<T, 16>(tile, ld, n_frames, real_mask, mask_t, K, out, accumulate, n_cu, stream);
+        ? launch_fused_w<T, 8>(tile, ld, n_frames, real_mask, rflags, mask_t, K, out, accumulate, n_cu, stream)
+        : launch_fused_w<T, 16>(tile, ld, n_frames, real_mask, rflags, mask_t, K, out, accumulate, n_cu, stream);
 }
 
 // -> LTMI_OK with *handled = true when the fused kernel ran
@@ -353,20 +423,22 @@ int cryst_fused(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, 
     const size_t esz = (size_t)dtype_size(tile_dtype);
     if (esz > 4 || tile_dtype == LTMI_F64) return LTMI_OK;
     if ((uintptr_t)tile % (4 * esz) != 0 || ld % 4 != 0) return LTMI_OK;
-        float *rmask_p = mask_t + (int64_t)CF_KMAX * CF_N;
+    float *rmask_p = mask_t + (int64_t)CF_KMAX * CF_N;
+    unsigned long long *rflags = (unsigned long long *)(rmask_p + CF_N * CF_N);
+    if (real_mask) LTMI_HIP(hipMemsetAsync(rflags, 0, 16, stream));
     hipLaunchKernelGGL(k_cryst_masks, dim3((unsigned)(CF_N * CF_N / 256)), dim3(256), 0, stream, half_mask,
-                       sig_w / 2 + 1, n_cols, mask_t, real_mask, rmask_p);
+                       sig_w / 2 + 1, n_cols, mask_t, real_mask, rmask_p, rflags);
     if (real_mask) real_mask = rmask_p;
     int rc = LTMI_E_DTYPE;
     switch (tile_dtype) {
         case LTMI_BOOL:
-        case LTMI_U8: rc = launch_fused<uint8_t>(tile, ld, n_frames, real_mask, mask_t, n_cols, out, accumulate, n_cu, stream); break;
-        case LTMI_I8: rc = launch_fused<int8_t>(tile, ld, n_frames, real_mask, mask_t, n_cols, out, accumulate, n_cu, stream); break;
-        case LTMI_U16: rc = launch_fused<uint16_t>(tile, ld, n_frames, real_mask, mask_t, n_cols, out, accumulate, n_cu, stream); break;
-        case LTMI_I16: rc = launch_fused<int16_t>(tile, ld, n_frames, real_mask, mask_t, n_cols, out, accumulate, n_cu, stream); break;
-        case LTMI_U32: rc = launch_fused<uint32_t>(tile, ld, n_frames, real_mask, mask_t, n_cols, out, accumulate, n_cu, stream); break;
-        case LTMI_I32: rc = launch_fused<int32_t>(tile, ld, n_frames, real_mask, mask_t, n_cols, out, accumulate, n_cu, stream); break;
-        case LTMI_F32: rc = launch_fused<float>(tile, ld, n_frames, real_mask, mask_t, n_cols, out, accumulate, n_cu, stream); break;
+        case LTMI_U8: rc = launch_fused<uint8_t>(tile, ld, n_frames, real_mask, rflags, mask_t, n_cols, out, accumulate, n_cu, stream); break;
+        case LTMI_I8: rc = launch_fused<int8_t>(tile, ld, n_frames, real_mask, rflags, mask_t, n_cols, out, accumulate, n_cu, stream); break;
+        case LTMI_U16: rc = launch_fused<uint16_t>(tile, ld, n_frames, real_mask, rflags, mask_t, n_cols, out, accumulate, n_cu, stream); break;
+        case LTMI_I16: rc = launch_fused<int16_t>(tile, ld, n_frames, real_mask, rflags, mask_t, n_cols, out, accumulate, n_cu, stream); break;
+        case LTMI_U32: rc = launch_fused<uint32_t>(tile, ld, n_frames, real_mask, rflags, mask_t, n_cols, out, accumulate, n_cu, stream); break;
+        case LTMI_I32: rc = launch_fused<int32_t>(tile, ld, n_frames, real_mask, rflags, mask_t, n_cols, out, accumulate, n_cu, stream); break;
+        case LTMI_F32: rc = launch_fused<float>(tile, ld, n_frames, real_mask, rflags, mask_t, n_cols, out, accumulate, n_cu, stream); break;
         default: return LTMI_OK;
     }
     if (rc == LTMI_OK) *handled = true;
