@@ -238,16 +238,14 @@ k_cryst_fused(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
     const int col_rd = (4 * (t & 15) + (t >> 4)) ^ (2 * ((t >> 3) & 1));
     const bool rows = w < n_scr;
 
-    // Row pairs as one stream of items (frame, y') per wave.  The pixels of an item are loaded DEPTH items
-    // ahead (2 for 1- and 2-byte pixels, 8 registers; 1 for 4-byte pixels), its mask values one item ahead
-    // and only where the pair's mask is not all ones (bit y' of rflags: a disk touches ~20 % of the pairs):
-    // without memory the kernel is 21 % faster than with a single pair of lead.
-    constexpr int DEPTH = sizeof(T) <= 2 ? 2 : 1;
+    // Row pairs as one stream of items (frame, y') per wave, two items per turn of the loop: their pixels
+    // were loaded during the previous turn (two transforms of lead: with one pair of lead the kernel ran 21 %
+    // slower than without memory), are converted, then the loads of the next two items are issued.  The mask
+    // values are fetched from the L2 where they are used, and only for pairs whose mask is not all ones (bit
+    // y' of rflags: a disk touches ~20 % of the pairs).
     const unsigned long long fl0 = MASK ? rflags[0] : 0, fl1 = MASK ? rflags[1] : 0;
-    auto masked = [&](int yp) -> bool { return ((yp < 64 ? fl0 : fl1) >> (yp & 63)) & 1; };
-    CfRaw<T> r0, r1;
-    CfMask m0;
-    int64_t lf = blockIdx.x;                            // load cursor: the item DEPTH ahead of the one in work
+    auto masked = [&](int yp) -> bool { return MASK && (((yp < 64 ? fl0 : fl1) >> (yp & 63)) & 1); };
+    int64_t lf = blockIdx.x;                            // load cursor
     int lyp = w;
     auto load_next = [&](CfRaw<T> &dst) {
         if (lf < n_frames) cf_load_raw<T, ABL>(dst, tile + lf * ld, lyp, t);
@@ -257,56 +255,47 @@ k_cryst_fused(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
             lf += gridDim.x;
         }
     };
-    if (rows) {
-        load_next(r0);
-        if (DEPTH == 2) load_next(r1);
-        if (MASK && masked(w)) cf_load_mask<ABL>(m0, rmask_p, w, t);
-    }
-    for (int64_t f = blockIdx.x; f < n_frames; f += gridDim.x) {
-        // ---- rows: pairs (2 y', 2 y' + 1), y' = w + n_scr i
-        if (rows && ABL != 5) {
-            for (int yp = w; yp < CF_N / 2; yp += n_scr) {
-                const CfRaw<T> cur = r0;
-                const CfMask cm = m0;
-                if (DEPTH == 2) {
-                    r0 = r1;
-                    load_next(r1);
-                } else {
-                    load_next(r0);
-                }
-                const int nyp = yp + n_scr < CF_N / 2 ? yp + n_scr : w;
-                if (MASK && masked(nyp)) cf_load_mask<ABL>(m0, rmask_p, nyp, t);
-                v2f u[4];
+    auto convert = [&](const CfRaw<T> &buf, int yp, v2f (&u)[4]) {
+        CfMask bm;
+        const bool mk = masked(yp);
+        if (mk) cf_load_mask<ABL>(bm, rmask_p, yp, t);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) u[j] = (v2f){(float)cur.ra[j], (float)cur.rb[j]};
-                if (MASK && masked(yp)) {
-                    u[0] *= cm.m01.xy; u[1] *= cm.m01.zw;
-                    u[2] *= cm.m23.xy; u[3] *= cm.m23.zw;
-                }
-                cf_swap_a(u);
-                cf_core<ABL == 3>(scr, c, u);
-                // two real rows out of one complex transform: with Z[k] = (a, b), Z[256 - k] = (c, d)
-                //   2 A[k] = (a + c, b - d)     2 B[k] = (b + d, c - a)     (the 1/2 is applied at the end)
-                const int pos = (2 * (yp ^ ((yp >> 4) & 1))) ^ g_xor;
-                {
-                    const float gx = t == 0 ? u[0].x : u[3].x, gy = t == 0 ? u[0].y : u[3].y;
-                    const float cr = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(gx)));
-                    const float ci = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(gy)));
-                    if (sig < K)
-                        *(v4f *)(G + g_col + pos) = (v4f){u[0].x + cr, u[0].y - ci, u[0].y + ci, cr - u[0].x};
-                }
-                if (K > 64) {
-                    const float gx = t == 0 ? u[3].x : u[2].x, gy = t == 0 ? u[3].y : u[2].y;
-                    const float cr = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(gx)));
-                    const float ci = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(gy)));
-                    if (sig + 64 < K)
-                        *(v4f *)(G + g_col + 64 * CF_COL + pos) =
-                            (v4f){u[1].x + cr, u[1].y - ci, u[1].y + ci, cr - u[1].x};
-                }
-            }
+        for (int j = 0; j < 4; ++j) u[j] = (v2f){(float)buf.ra[j], (float)buf.rb[j]};
+        if (mk) {
+            u[0] *= bm.m01.xy; u[1] *= bm.m01.zw;
+            u[2] *= bm.m23.xy; u[3] *= bm.m23.zw;
         }
+    };
+
+    // one row pair: transform, separate, store the K columns
+    auto row_pair = [&](v2f (&u)[4], int yp) {
+        if (ABL == 5) return;
+        cf_swap_a(u);
+        cf_core<ABL == 3>(scr, c, u);
+        // two real rows out of one complex transform: with Z[k] = (a, b), Z[256 - k] = (c, d)
+        //   2 A[k] = (a + c, b - d)     2 B[k] = (b + d, c - a)     (the 1/2 is applied at the end)
+        const int pos = (2 * (yp ^ ((yp >> 4) & 1))) ^ g_xor;
+        {
+            const float gx = t == 0 ? u[0].x : u[3].x, gy = t == 0 ? u[0].y : u[3].y;
+            const float cr = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(gx)));
+            const float ci = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(gy)));
+            if (sig < K)
+                *(v4f *)(G + g_col + pos) = (v4f){u[0].x + cr, u[0].y - ci, u[0].y + ci, cr - u[0].x};
+        }
+        if (K > 64) {
+            const float gx = t == 0 ? u[3].x : u[2].x, gy = t == 0 ? u[3].y : u[2].y;
+            const float cr = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(gx)));
+            const float ci = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(gy)));
+            if (sig + 64 < K)
+                *(v4f *)(G + g_col + 64 * CF_COL + pos) =
+                    (v4f){u[1].x + cr, u[1].y - ci, u[1].y + ci, cr - u[1].x};
+        }
+    };
+
+    // after the last row pair of frame f: columns kx = w + WAVES i transformed in place, |F| * mask summed
+    // per lane, one float per frame
+    auto frame_end = [&](int64_t f) {
         if (ABL != 2) __syncthreads();
-        // ---- columns kx = w + WAVES i: transform in place, |F| * mask summed per lane
         float acc = 0.f;
         for (int kx = w; kx < (ABL == 4 ? 0 : K); kx += WAVES) {
             float m[4];
@@ -335,6 +324,41 @@ k_cryst_fused(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
             for (int i = 0; i < WAVES; ++i) v += part[i];
             v *= 0.5f;
             out[f] = accumulate ? out[f] + v : v;
+        }
+    };
+
+    if (!rows) {                                        // (no row scratch left for this wave: columns only)
+        for (int64_t f = blockIdx.x; f < n_frames; f += gridDim.x) frame_end(f);
+        return;
+    }
+    CfRaw<T> ba, bb;
+    load_next(ba);
+    load_next(bb);
+    int64_t f = blockIdx.x;
+    int yp = w;
+    while (f < n_frames) {
+        v2f ua[4], ub[4];
+        const int ypa = yp;
+        int ypb = yp + n_scr;                           // (item b: the next pair of this frame or the first of the next)
+        const bool a_last = ypb >= CF_N / 2;
+        if (a_last) ypb = w;
+        const bool have_b = !a_last || f + gridDim.x < n_frames;
+        convert(ba, ypa, ua);
+        if (have_b) convert(bb, ypb, ub);
+        load_next(ba);
+        load_next(bb);
+        row_pair(ua, ypa);
+        if (a_last) {
+            frame_end(f);
+            f += gridDim.x;
+            if (!have_b) break;
+        }
+        row_pair(ub, ypb);
+        yp = ypb + n_scr;
+        if (yp >= CF_N / 2) {
+            frame_end(f);
+            f += gridDim.x;
+            yp = w;
         }
     }
 }
