@@ -225,6 +225,28 @@ static int run_prepare(const void *tile, int64_t ld, int64_t n, int64_t n_px, co
 
 using namespace ltmi;
 
+// the hipFFT plan + workspace of a plan, created on first use
+static int hipfft_route_ready(ltmi_fft_plan *p) {
+    if (p->have_plan) return LTMI_OK;
+    int n[2] = {p->h, p->w};
+    hipfftResult r = hipfftPlanMany(&p->plan, 2, n, nullptr, 1, p->h * p->w, nullptr, 1, p->h * p->wc,
+                                    HIPFFT_R2C, p->batch);
+    if (r != HIPFFT_SUCCESS)
+        LTMI_FAIL(LTMI_E_INVALID, "hipfftPlanMany(%d x %d, batch %d) failed: %s", p->h, p->w, p->batch,
+                  fft_err(r));
+    hipError_t e = hipMalloc((void **)&p->real_buf, (size_t)p->batch * p->h * p->w * sizeof(float));
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&p->spec, (size_t)p->batch * p->h * p->wc * sizeof(hipfftComplex));
+    if (e != hipSuccess) {
+        if (p->real_buf) (void)hipFree(p->real_buf);
+        p->real_buf = nullptr;
+        (void)hipfftDestroy(p->plan);
+        LTMI_FAIL((int)e, "ltmi_fft_plan: workspace allocation failed: %s", hipGetErrorString(e));
+    }
+    p->have_plan = true;
+    return LTMI_OK;
+}
+
 extern "C" int ltmi_fft_plan_create(int device, int sig_h, int sig_w, int max_batch,
                                     ltmi_fft_plan **out) {
     if (!out || sig_h <= 0 || sig_w <= 0 || max_batch <= 0)
@@ -238,32 +260,27 @@ extern "C" int ltmi_fft_plan_create(int device, int sig_h, int sig_w, int max_ba
     p->w = sig_w;
     p->wc = sig_w / 2 + 1;
     p->batch = max_batch;
-    int n[2] = {sig_h, sig_w};
-    hipfftResult r = hipfftPlanMany(&p->plan, 2, n, nullptr, 1, sig_h * sig_w, nullptr, 1,
-                                    sig_h * p->wc, HIPFFT_R2C, max_batch);
-    if (r != HIPFFT_SUCCESS) {
-        delete p;
-        LTMI_FAIL(LTMI_E_INVALID, "hipfftPlanMany(%d x %d, batch %d) failed: %s", sig_h, sig_w,
-                  max_batch, fft_err(r));
-    }
-    p->have_plan = true;
-    hipError_t e = hipMalloc((void **)&p->real_buf, (size_t)max_batch * sig_h * sig_w * sizeof(float));
-    if (e == hipSuccess)
-        e = hipMalloc((void **)&p->spec, (size_t)max_batch * sig_h * p->wc * sizeof(hipfftComplex));
-    if (e == hipSuccess && sig_h == 256 && sig_w == 256) {
+    hipError_t e = hipSuccess;
+    if (sig_h == 256 && sig_w == 256) {
         const char *env = getenv("LTMI_FFT_FUSED");
         p->fused_ok = !(env && env[0] == '0');
         e = hipMalloc((void **)&p->mask_t, (size_t)cryst_fused_workspace_floats() * sizeof(float));
         if (e == hipSuccess) e = hipDeviceGetAttribute(&p->n_cu, hipDeviceAttributeMultiprocessorCount, device);
+        if (e != hipSuccess) {
+            if (p->mask_t) (void)hipFree(p->mask_t);
+            delete p;
+            LTMI_FAIL((int)e, "ltmi_fft_plan_create: workspace allocation failed: %s", hipGetErrorString(e));
+        }
     }
-    if (e != hipSuccess) {
-        if (p->real_buf) (void)hipFree(p->real_buf);
-        if (p->spec) (void)hipFree(p->spec);
-        if (p->mask_t) (void)hipFree(p->mask_t);
-        (void)hipfftDestroy(p->plan);
-        delete p;
-        LTMI_FAIL((int)e, "ltmi_fft_plan_create: workspace allocation failed: %s",
-                  hipGetErrorString(e));
+    // frames the fused kernel takes never need the hipFFT plan and its (batch x frame) workspace: both are
+    // created by the first call that does (hipfft_route_ready)
+    if (!p->fused_ok) {
+        const int rc = hipfft_route_ready(p);
+        if (rc != LTMI_OK) {
+            if (p->mask_t) (void)hipFree(p->mask_t);
+            delete p;
+            return rc;
+        }
     }
     *out = p;
     return LTMI_OK;
@@ -328,12 +345,6 @@ static int crystallinity_impl(ltmi_fft_plan *p, const void *tile, int tile_dtype
     if (!tile || !half_mask || !out) LTMI_FAIL(LTMI_E_INVALID, "ltmi_crystallinity: null pointer");
     LTMI_HIP(hipSetDevice(p->device));
     hipStream_t stream = (hipStream_t)stream_;
-    if (!p->stream_bound || p->bound_stream != stream) {
-        hipfftResult r = hipfftSetStream(p->plan, stream);
-        if (r != HIPFFT_SUCCESS) LTMI_FAIL(LTMI_E_INVALID, "hipfftSetStream failed: %s", fft_err(r));
-        p->bound_stream = stream;
-        p->stream_bound = true;
-    }
     const size_t esz = (size_t)dtype_size(tile_dtype);
     if (row_lo < 0 || row_hi < row_lo || row_hi > p->h || n_cols < 0 || n_cols > p->wc)
         LTMI_FAIL(LTMI_E_SHAPE, "ltmi_crystallinity: bad mask bounding box (%d, %d, %d)", row_lo,
@@ -351,6 +362,16 @@ static int crystallinity_impl(ltmi_fft_plan *p, const void *tile, int tile_dtype
     }
     snprintf(p->last_kernel, sizeof(p->last_kernel), "hipfft_r2c<%s> batch=%d", dtype_name(tile_dtype),
              p->batch);
+    {
+        const int rc = hipfft_route_ready(p);
+        if (rc != LTMI_OK) return rc;
+    }
+    if (!p->stream_bound || p->bound_stream != stream) {
+        hipfftResult r = hipfftSetStream(p->plan, stream);
+        if (r != HIPFFT_SUCCESS) LTMI_FAIL(LTMI_E_INVALID, "hipfftSetStream failed: %s", fft_err(r));
+        p->bound_stream = stream;
+        p->stream_bound = true;
+    }
     for (int64_t f0 = 0; f0 < n_frames; f0 += p->batch) {
         const int64_t n = std::min<int64_t>(p->batch, n_frames - f0);
         const void *src = (const char *)tile + (size_t)f0 * ld_tile * esz;
