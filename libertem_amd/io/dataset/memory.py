@@ -201,6 +201,12 @@ class MemoryDataSet(DataSet):
         return self._device_array.reshape((prod(self._local_shape.nav),) +
                                           tuple(self._shape.sig))
 
+    def device_frames(self, local0, n):
+        """(device array, row of local frame `local0` in it) for the frames [local0, local0 + n) of this
+        process's block -- the whole resident array here; a dataset that holds a window of its frames in
+        HBM (MIBDataSet in streamed mode) brings them in now."""
+        return self.flat_device(), local0
+
     eager_upload = True     # HIP path: enqueue the upload of chunk i+1 before the kernels of chunk i
 
     #: SIGNED integers stored in the other byte order, read into a float or a wider integer dtype:
@@ -591,7 +597,9 @@ class MemPartition(Partition):
         fix = (lambda chunk: chunk) if corrections is None else \
             self._corrector(corrections, device, np.dtype(dest_dtype), min(depth, n), env)
         if ds.is_device_resident:
-            flat = ds.flat_device()
+            flat, row0 = ds.device_frames(self._local0, self._num_frames)
+            if idxs is not None:
+                idxs = idxs - self._local0 + row0           # rows of `flat`
             if flat.device != device:
                 raise RuntimeError(f"dataset lives on GPU {flat.device}, worker drives GPU {device}")
             if idxs is not None and corrections is None and \
@@ -616,7 +624,7 @@ class MemPartition(Partition):
                 flat = gathered
                 base = 0
             else:
-                base = self._local0
+                base = row0
             for g0 in range(0, n, depth):
                 g1 = min(n, g0 + depth)
                 chunk = fix(flat.rows(base + g0, base + g1))

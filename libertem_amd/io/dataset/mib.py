@@ -6,6 +6,8 @@ for every tile of every run (mib.py:401-735); here `initialize()` streams the fi
 bounce buffers into HBM, `ltmi_mib_decode` (csrc/ltmi_mib.hip) strips the per-frame headers and unpacks
 the pixels behind each copy, and the dataset is a device-resident array from then on (288 GB of HBM hold
 any single acquisition) -- every later `run_udf` starts at the kernels, ROI runs read frames in place.
+A block of the scan that does not fit is STREAMED instead: each partition decodes its frames from the files
+into one window of HBM when its tiles are asked for (`device_frames`), every run re-reads the files.
 
 Formats: integer files U08 / U16 / U32 (big-endian), raw "R64" files with 1, 6, 12 or 24 bits per pixel,
 single chip or 2x2 quad (1 / 6 / 12 bit), `.hdr` side file for the scan shape, files of a series found by
@@ -167,6 +169,11 @@ class MIBDataSet(MemoryDataSet):
     """
     CHUNK_BYTES = 256 << 20          # file bytes per copy + decode step (two in flight)
     COPY_THREADS = 8
+    #: decoded bytes this process may keep in HBM (None: what is free).  A block of the scan that needs more
+    #: is STREAMED: no frame is decoded at load time, every partition decodes its frames from the files
+    #: into a window of HBM when its tiles are asked for (partitions of at most STREAM_WINDOW_BYTES).
+    MAX_RESIDENT_BYTES = None
+    STREAM_WINDOW_BYTES = 4 << 30
 
     def __init__(self, path, tileshape=None, scan_size=None, disable_glob=False, nav_shape=None,
                  sig_shape=None, sync_offset=0, io_backend=None, num_partitions=None, shard=None):
@@ -197,6 +204,7 @@ class MIBDataSet(MemoryDataSet):
         self._image_count = None
         self.decode_seconds = None
         self.decode_bytes = None
+        self._streamed = None
 
     # --- host side: which files, which frames ------------------------------------------------------
     def _scan_files(self):
@@ -259,10 +267,34 @@ class MIBDataSet(MemoryDataSet):
             local_nav = (nav_shape[0] // world,) + tuple(nav_shape[1:])
             p0 = rank * int(prod(local_nav))
             p1 = p0 + int(prod(local_nav))
-        frames = self._decode_to_device(device, executor, p0, p1, so)
-        MemoryDataSet.__init__(
-            self, data=frames.reshape(local_nav + tuple(sig_shape)), sig_dims=len(sig_shape),
-            num_partitions=self._num_partitions_arg, shard=self._shard_arg)
+        self._streamed = None
+        n_local = p1 - p0
+        storage = np.dtype(first['storage_dtype'])
+        need = n_local * int(prod(first['image_size'])) * storage.itemsize
+        stride = first['header_size_bytes'] + first['image_size_bytes']
+        if not self._fits_in_hbm(device, executor, need, stride, n_local):
+            # a series larger than the HBM it may take: windows of it, decoded per partition
+            import torch
+            frame_bytes = int(prod(first['image_size'])) * storage.itemsize
+            free_bytes, _ = torch.cuda.mem_get_info(device)
+            window = int(min(self.STREAM_WINDOW_BYTES, max(frame_bytes, free_bytes // 4)))
+            if self.MAX_RESIDENT_BYTES is not None:
+                window = int(min(window, max(frame_bytes, self.MAX_RESIDENT_BYTES)))
+            want = -(-need // window)
+            n_parts = max(int(self._num_partitions_arg or 1), int(want))
+            self._streamed = dict(device=device, executor=executor, p0=p0, sync_offset=so, key=None,
+                                  frames=None)
+            self.decode_seconds, self.decode_bytes = 0.0, 0
+            placeholder = torch.empty(1, dtype=torch.uint8, device=f'cuda:{device}')
+            frames = HipArray(placeholder, (n_local,) + tuple(first['image_size']), storage)
+            MemoryDataSet.__init__(
+                self, data=frames.reshape(local_nav + tuple(sig_shape)), sig_dims=len(sig_shape),
+                num_partitions=min(n_parts, max(1, n_local)), shard=self._shard_arg)
+        else:
+            frames = self._decode_to_device(device, executor, p0, p1, so)
+            MemoryDataSet.__init__(
+                self, data=frames.reshape(local_nav + tuple(sig_shape)), sig_dims=len(sig_shape),
+                num_partitions=self._num_partitions_arg, shard=self._shard_arg)
         self._sync_offset = so
         self._meta = DataSetMeta(shape=self._shape, raw_dtype=np.dtype(first['dtype']),
                                  sync_offset=so, image_count=self._image_count)
@@ -290,8 +322,9 @@ class MIBDataSet(MemoryDataSet):
         if need + 2 * min(self.CHUNK_BYTES, max(n_src, 1) * stride) > free_bytes:
             raise DataSetException(
                 f"{n} decoded frames of {h}x{w} {storage} need {need / 2**30:.1f} GiB of HBM, "
-                f"{free_bytes / 2**30:.1f} GiB are free on GPU {device}: load a part of the scan "
-                "(nav_shape + sync_offset) or shard it over several GPUs (shard=(rank, world))")
+                f"{free_bytes / 2**30:.1f} GiB are free on GPU {device}: fewer frames per partition "
+                "(num_partitions), a part of the scan (nav_shape + sync_offset) or a shard per GPU "
+                "(shard=(rank, world))")
         t0 = time.perf_counter()
         out = HipArray.empty((n, h, w), storage, device) if n_src == n else \
             HipArray.zeros((n, h, w), storage, device)          # blank frames stay zero
@@ -340,9 +373,52 @@ class MIBDataSet(MemoryDataSet):
             copy_stream.synchronize()
             pool.shutdown()
         torch.cuda.current_stream(device).synchronize()
-        self.decode_seconds = time.perf_counter() - t0
-        self.decode_bytes = n_src * stride
+        if self._streamed is not None:
+            self.decode_seconds += time.perf_counter() - t0
+            self.decode_bytes += n_src * stride
+        else:
+            self.decode_seconds = time.perf_counter() - t0
+            self.decode_bytes = n_src * stride
         return out
+
+    def _fits_in_hbm(self, device, executor, need, stride, n_local):
+        import torch
+        if getattr(executor, '_make_current', None) is not None:
+            executor._make_current()
+        if self.MAX_RESIDENT_BYTES is not None and need > self.MAX_RESIDENT_BYTES:
+            return False
+        free_bytes, _ = torch.cuda.mem_get_info(device)
+        return need + 2 * min(self.CHUNK_BYTES, max(n_local, 1) * stride) <= free_bytes
+
+    @property
+    def stable_device_tiles(self):
+        return self._streamed is None
+
+    @property
+    def is_streamed(self):
+        """the decoded frames do not stay in HBM: every partition decodes its own from the files"""
+        return self._streamed is not None
+
+    @property
+    def data(self):
+        if self._streamed is not None:
+            raise DataSetException(
+                "this .mib series is streamed (larger than the HBM it may take): there is no resident "
+                "array of its frames -- run UDFs over it, or load a part (nav_shape + sync_offset)")
+        return MemoryDataSet.data.fget(self)
+
+    def device_frames(self, local0, n):
+        st = self._streamed
+        if st is None:
+            return MemoryDataSet.device_frames(self, local0, n)
+        if st['key'] != (local0, n):
+            st['frames'] = None                     # (one window at a time)
+            st['key'] = None
+            p = st['p0'] + local0
+            st['frames'] = self._decode_to_device(st['device'], st['executor'], p, p + n,
+                                                  st['sync_offset'])
+            st['key'] = (local0, n)
+        return st['frames'], 0
 
     @staticmethod
     def _host_copy(pool, dst, dst_off, src, src_off, nbytes, piece=16 << 20):

@@ -909,8 +909,10 @@ class UDFPartRunner:
             ds = getattr(partition, '_ds', None)
             if keep is not None and keep.get('udfs') is not None and backend == HIP \
                     and params.roi is None and params.corrections is None \
-                    and getattr(ds, 'is_device_resident', False):
+                    and getattr(ds, 'is_device_resident', False) \
+                    and getattr(ds, 'stable_device_tiles', True):
                 # device-resident frames: the tiles are zero-copy views of HBM, the same every run
+                # (not a streamed .mib series: its partitions share one window of HBM)
                 tiles = keep['tiles'] = list(tiles)
         sink = getattr(env, 'row_sink', None)
         sinkable = None

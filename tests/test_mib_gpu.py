@@ -188,10 +188,66 @@ def test_one_rank_decodes_only_its_block(ctx, tmp_path):
         assert ds.decode_bytes == (3 if rank == 0 else 2) * (384 + 32 * 64 * 2)
 
 
-def test_series_larger_than_hbm_is_refused_with_advice(ctx, tmp_path, monkeypatch):
+def test_series_larger_than_hbm_is_streamed(ctx, tmp_path, monkeypatch):
+    """A block of the scan that does not fit (here: may not take) the HBM is not refused: nothing is decoded at
+    load time, every partition decodes its frames from the files into a window of HBM when its tiles are asked
+    for -- same results as the resident dataset, run after run, with an ROI, with a sync offset, with a shard."""
+    from libertem_amd.io.dataset.base import DataSetException
+    from libertem_amd.io.dataset.mib import MIBDataSet
+    from libertem_amd.udf.sumsigudf import SumSigUDF
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    for name, kw in (('r1', {}), ('u16', {}), ('r12_offset', dict(sync_offset=2)), ('u16_neg_offset', dict(sync_offset=-2))):
+        case = [c for c in recipes.MIB_CASES if c['name'] == name][0]
+        frames, _, hdr_path = _write(tmp_path, case)
+        sig = tuple(case['sig'])
+        resident = ctx.load('mib', path=hdr_path, **kw)
+        assert not resident.is_streamed
+        n_nav = int(np.prod(resident.shape.nav))
+        frame_bytes = int(np.prod(sig)) * np.dtype(resident.storage_dtype).itemsize
+        monkeypatch.setattr(MIBDataSet, 'MAX_RESIDENT_BYTES', 2 * frame_bytes)
+        ds = ctx.load('mib', path=hdr_path, **kw)
+        monkeypatch.setattr(MIBDataSet, 'MAX_RESIDENT_BYTES', None)
+        assert ds.is_streamed and tuple(ds.shape) == tuple(resident.shape)
+        assert ds.get_num_partitions() >= -(-n_nav // 2) and ds.decode_bytes == 0
+        with pytest.raises(DataSetException, match='streamed'):
+            ds.data
+        masks = np.random.default_rng(5).random((3,) + sig).astype(np.float32)
+        udf = ApplyMasksUDF(mask_factories=lambda: masks, use_sparse=False, mask_count=3, mask_dtype=np.float32)
+        want_sum = ctx.run_udf(dataset=resident, udf=SumSigUDF())['intensity'].data
+        want = ctx.run_udf(dataset=resident, udf=udf)['intensity'].data
+        for _ in range(2):                                   # (the second run re-uses the plan, not the tiles)
+            assert np.array_equal(ctx.run_udf(dataset=ds, udf=SumSigUDF())['intensity'].data, want_sum)
+            assert np.array_equal(ctx.run_udf(dataset=ds, udf=udf)['intensity'].data, want)
+        assert ds.decode_bytes > 0
+        roi = np.zeros(resident.shape.nav, dtype=bool)
+        roi.reshape(-1)[[0, n_nav - 1, n_nav // 2]] = True
+        got = ctx.run_udf(dataset=ds, udf=SumSigUDF(), roi=roi)['intensity'].raw_data
+        assert np.array_equal(got, ctx.run_udf(dataset=resident, udf=SumSigUDF(), roi=roi)['intensity'].raw_data)
+    # one rank of two, streamed
+    case = [c for c in recipes.MIB_CASES if c['name'] == 'r12_offset'][0]
+    (tmp_path / 'shard').mkdir()
+    frames, _, hdr_path = _write(tmp_path / 'shard', case)
+    monkeypatch.setattr(MIBDataSet, 'MAX_RESIDENT_BYTES', 32 * 64 * 2)
+    ds = ctx.load('mib', path=hdr_path, sync_offset=2, shard=(1, 2))
+    monkeypatch.setattr(MIBDataSet, 'MAX_RESIDENT_BYTES', None)
+    assert ds.is_streamed and ds.shard == (1, 2)
+    expect = np.zeros((6, 32, 64), dtype=np.uint16)
+    expect[:5] = frames[2:7]
+    parts = [p for p in ds.get_partitions() if ds.owner_of_frames(p._start_frame, p._start_frame + p._num_frames) == 1]
+    assert len(parts) == 3
+    for p in parts:
+        arr, row0 = ds.device_frames(p._local0, p._num_frames)
+        assert np.array_equal(arr.rows(row0, row0 + p._num_frames).cpu().reshape(-1, 32, 64),
+                              expect[p._start_frame:p._start_frame + p._num_frames])
+
+
+def test_partition_that_does_not_fit_is_refused_with_advice(ctx, tmp_path, monkeypatch):
     from libertem_amd.io.dataset.base import DataSetException
     case = [c for c in recipes.MIB_CASES if c['name'] == 'u08'][0]
     _, _, hdr_path = _write(tmp_path, case)
     monkeypatch.setattr(torch.cuda, 'mem_get_info', lambda device=None: (1000, 1 << 38))
-    with pytest.raises(DataSetException, match='shard it over several GPUs'):
-        ctx.load('mib', path=hdr_path)
+    ds = ctx.load('mib', path=hdr_path)                     # (streamed: no frame decoded yet)
+    assert ds.is_streamed
+    from libertem_amd.udf.sumsigudf import SumSigUDF
+    with pytest.raises(DataSetException, match='fewer frames per partition'):
+        ctx.run_udf(dataset=ds, udf=SumSigUDF())
