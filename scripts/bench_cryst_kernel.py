@@ -8,7 +8,8 @@ from libertem_amd.udf.crystallinity import crystallinity_masks, mask_box
 
 n = int(os.environ.get('N', 16384))
 reps = int(os.environ.get('REPS', 10))
-rad_out = int(os.environ.get('RAD_OUT', 64))
+rad_out = float(os.environ.get('RAD_OUT', 64))
+rad_out = int(rad_out) if rad_out == int(rad_out) else rad_out
 dt = np.dtype(os.environ.get('DTYPE', 'uint16'))
 use_mask = os.environ.get('MASK', '1') != '0'
 g = torch.Generator(device='cuda').manual_seed(1)
@@ -18,7 +19,7 @@ if dt.kind == 'f':
 else:
     frames = torch.randint(0, 200 if dt.itemsize == 1 else 4096, (n, 256, 256), generator=g, device='cuda',
                            dtype=tdt)
-real_mask, half = crystallinity_masks((256, 256), rad_out // 4, rad_out,
+real_mask, half = crystallinity_masks((256, 256), int(rad_out) // 4, rad_out,
                                       (128, 128) if use_mask else None, 25 if use_mask else None)
 rm = None if real_mask is None else torch.from_numpy(np.ascontiguousarray(real_mask.astype(np.float32))).cuda()
 hm = torch.from_numpy(np.ascontiguousarray(half.astype(np.float32))).cuda()

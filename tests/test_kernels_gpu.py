@@ -1633,7 +1633,8 @@ def _cryst_run(hip, frames, real_mask, half, accumulate_into=None, ld_pad=0, bat
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype', ['uint8', 'int8', 'uint16', 'int16', 'uint32', 'int32', 'float32'])
 @pytest.mark.parametrize('rad_in,rad_out,real', [(16, 64, ((128, 128), 25)), (0, 30, None),
-                                                 (40, 70, ((100.5, 140), 31.5))])
+                                                 (40, 70, ((100.5, 140), 31.5)), (10, 47.5, None),
+                                                 (3.2, 64.7, ((128, 128), 25))])
 def test_crystallinity_fused_kernel_all_pixel_types(hip, dtype, rad_in, rad_out, real):
     """256 x 256 frames go through k_cryst_fused: rows, columns and ring sum inside one workgroup;
     1e-5 relative against float64 (north_star tolerance for floating point)."""
