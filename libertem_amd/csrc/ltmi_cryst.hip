@@ -388,6 +388,7 @@ k_cryst_masks(const float *__restrict__ half_mask, int wc, int K, float *__restr
 }
 
 int cryst_fused_max_cols() { return CF_KMAX; }
+bool cryst_fused_shape(int h, int w) { return (h == 256 && w == 256) || (h == 128 && w == 128); }
 int64_t cryst_fused_workspace_floats() { return (int64_t)CF_KMAX * CF_N + CF_N * CF_N + 4; }
 
 template <typename T, int WAVES>
@@ -438,12 +439,267 @@ static int launch_fused(const void *tile, int64_t ld, int64_t n_frames, const fl
         : launch_fused_w<T, 16>(tile, ld, n_frames, real_mask, rflags, mask_t, K, out, accumulate, n_cu, stream);
 }
 
-// -> LTMI_OK with *handled = true when the fused kernel ran
+// ---- 128 x 128 frames -------------------------------------------------------------------------------------
+// Two 128-point transforms as ONE 256-point transform of the interleaved sequence w[2m] = z1[m], w[2m+1] = z2[m]:
+//     W[k] = Z1[k] + w256^k Z2[k],  W[k + 128] = Z1[k] - w256^k Z2[k]      (k < 128; registers k2 and k2 + 2 of a lane)
+// so cf_core serves unchanged: a wave transforms FOUR rows 4q .. 4q+3 (z1 = row 4q + i row 4q+1, z2 = the next two;
+// lane t holds the pixels 2t, 2t+1 of each), separates Z1 / Z2 with one butterfly and one twiddle, then the two rows of
+// each as in the 256 kernel; the column stage transforms the columns c and c + 8 together and needs no twiddle at
+// all (|F2| = |W[k] - W[k+128]|).  G[kx][y]: 130 float2 per column, y kept at y ^ ((kx >> 3) & 1): conflict-free
+// b64 stores of 16 neighbouring lanes and loads of a column pair (scripts/cryst_fft_model.py, second part).  The
+// exchanges of the column stage run in the wave's row scratch (all 16 waves own one: G takes 66 KiB).
+constexpr int CG_N = 128;
+constexpr int CG_COL = CG_N + 2;                // float2 units per column of G
+constexpr int CG_K = CG_N / 2 + 1;              // columns of the half spectrum: G always holds all 65
+constexpr int CG_WAVES = 16;
+constexpr int CG_PAIRS = 33;                    // column pairs (c, c + 8) + the column 64 alone
+
+template <typename T>
+struct CgRaw {                                  // 2 pixels of each of 4 rows
+    typedef T __attribute__((ext_vector_type(2))) vec_t;
+    vec_t r[4];
+};
+
+template <typename T, bool MASK>
+__global__ void __launch_bounds__(CG_WAVES * 64)
+k_cryst_fused128(const T *__restrict__ tile, int64_t ld, int64_t n_frames, const float *__restrict__ rmask_p,
+                 const unsigned long long *__restrict__ rflags, const float *__restrict__ mask_p, int K,
+                 float *__restrict__ out, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cf_smem[];
+    __shared__ float part[CG_WAVES];
+    const int t = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    v2f *G = (v2f *)cf_smem;
+    v2f *scr = G + CG_K * CG_COL + w * CF_SCR;
+    const int sig = cf_sigma(t);
+
+    CfLane c;
+    v2f tz[2], tzr[2];                          // w256^-(sigma + 64 k2): Z2 out of W[k] - W[k + 128]
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+        double s, co;
+        sincospi(-2.0 * (double)((t & 15) * r) / 64.0, &s, &co);
+        c.tw[0][r - 1] = (v2f){(float)co, (float)s};
+        sincospi(-2.0 * (double)((t & 3) * r) / 16.0, &s, &co);
+        c.tw[1][r - 1] = (v2f){(float)co, (float)s};
+        sincospi(-2.0 * (double)(sig * r) / 256.0, &s, &co);
+        c.tw[2][r - 1] = (v2f){(float)co, (float)s};
+#pragma unroll
+        for (int pi = 0; pi < 3; ++pi) c.twr[pi][r - 1] = (v2f){-c.tw[pi][r - 1].y, c.tw[pi][r - 1].x};
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+        double s, co;
+        sincospi(2.0 * (double)(sig + 64 * k2) / 256.0, &s, &co);
+        tz[k2] = (v2f){(float)co, (float)s};
+        tzr[k2] = (v2f){-(float)s, (float)co};
+    }
+    {
+        const int b2 = (t >> 2) & 3, b0 = t & 3;
+        const int base_b = 64 * b2 + t, base_c = 64 * b0 + t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            c.wB[r] = 64 * r + (t ^ (r << 2));
+            c.rB[r] = base_b ^ (r << 2);
+            c.wC[r] = 64 * r + (t ^ r);
+            c.rC[r] = base_c ^ r;
+        }
+    }
+    const int back = cf_sigma((64 - sig) & 63) * 4;                 // ds_bpermute address: the lane of 64 - sigma
+    const int sw = (sig >> 3) & 1;
+    const int g_s = sig * CG_COL + sw, g_d = sig * CG_COL + 1 - sw; // + y (even): where 4 A[kx], 4 B[kx] of a row pair go
+    // column stage: lane 16 j + m loads y = 32 r + 2 m + (j >> 1) of the column c (j even) or c + 8 (j odd)
+    const int jj = t >> 4, mm = t & 15;
+    const int col_rd = (jj & 1) * (8 * CG_COL) + ((2 * mm + (jj >> 1)) ^ (jj & 1));
+    const int col_rd64 = 2 * mm + (jj >> 1);                        // (the pair "64, 64")
+
+    // columns the ring does not touch are never stored: zero them once, the transforms read them
+    for (int i = K * CG_COL + (int)threadIdx.x; i < CG_K * CG_COL; i += CG_WAVES * 64) G[i] = (v2f){0.f, 0.f};
+
+    const unsigned long long fl = MASK ? rflags[0] : 0;
+    auto masked = [&](int q) -> bool { return MASK && ((fl >> q) & 1); };
+    typedef typename CgRaw<T>::vec_t vec_t;
+    auto load = [&](CgRaw<T> &dst, int64_t f, int q) {
+        if (f < n_frames) {
+            const T *row = tile + f * ld + (4 * q) * CG_N;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                dst.r[i] = __builtin_nontemporal_load((const vec_t *)(row + i * CG_N + 2 * t));
+        }
+    };
+    auto convert = [&](const CgRaw<T> &b, int q, v2f (&u)[4]) {
+        CfMask bm;
+        const bool mk = masked(q);
+        if (mk) {
+            const float *row = rmask_p + q * (4 * CG_N);
+            bm.m01 = *(const v4f *)(row + 8 * t);
+            bm.m23 = *(const v4f *)(row + 8 * t + 4);
+        }
+        u[0] = (v2f){(float)b.r[0][0], (float)b.r[1][0]};
+        u[1] = (v2f){(float)b.r[2][0], (float)b.r[3][0]};
+        u[2] = (v2f){(float)b.r[0][1], (float)b.r[1][1]};
+        u[3] = (v2f){(float)b.r[2][1], (float)b.r[3][1]};
+        if (mk) {
+            u[0] *= bm.m01.xy; u[1] *= bm.m01.zw;
+            u[2] *= bm.m23.xy; u[3] *= bm.m23.zw;
+        }
+    };
+    // the two rows of one pair out of Z[k] (k2 = 0: za, k2 = 1: zb), both x 2; rows y, y + 1
+    auto store_pair = [&](v2f za, v2f zb, int y) {
+        const float gx = t == 0 ? za.x : zb.x, gy = t == 0 ? za.y : zb.y;
+        const float cr = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(gx)));
+        const float ci = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(gy)));
+        if (sig < K) {
+            G[g_s + y] = (v2f){za.x + cr, za.y - ci};
+            G[g_d + y] = (v2f){za.y + ci, cr - za.x};
+        }
+        if (K == CG_K && t == 0) {                  // kx = 64 is its own partner
+            G[64 * CG_COL + y] = (v2f){2.f * zb.x, 0.f};
+            G[64 * CG_COL + y + 1] = (v2f){2.f * zb.y, 0.f};
+        }
+    };
+    auto four_rows = [&](v2f (&u)[4], int q) {
+        cf_swap_a(u);
+        cf_core(scr, c, u);
+        const v2f d0 = u[0] - u[2], d1 = u[1] - u[3];
+        store_pair(u[0] + u[2], u[1] + u[3], 4 * q);
+        store_pair(cf_mul(d0, tz[0], tzr[0]), cf_mul(d1, tz[1], tzr[1]), 4 * q + 2);
+    };
+
+    CgRaw<T> ba, bb;
+    load(ba, blockIdx.x, w);
+    load(bb, blockIdx.x, w + CG_WAVES);
+    __syncthreads();                                // (the zeroed columns)
+    for (int64_t f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        v2f ua[4], ub[4];
+        convert(ba, w, ua);
+        convert(bb, w + CG_WAVES, ub);
+        load(ba, f + gridDim.x, w);
+        load(bb, f + gridDim.x, w + CG_WAVES);
+        four_rows(ua, w);
+        four_rows(ub, w + CG_WAVES);
+        __syncthreads();
+        // ---- column pairs p = w + 16 i
+        float acc = 0.f;
+        for (int p = w; p < CG_PAIRS; p += CG_WAVES) {
+            const int c1 = p < 32 ? (p >> 3) * 16 + (p & 7) : 64;
+            if (c1 >= K) continue;
+            float m[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) m[i] = mask_p[(p * 4 + i) * 64 + t];
+            const v2f *col = G + c1 * CG_COL + (p < 32 ? col_rd : col_rd64);
+            v2f u[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u[r] = col[32 * r];
+            cf_core(scr, c, u);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const v2f f1 = u[k2] + u[k2 + 2], f2 = u[k2] - u[k2 + 2];
+                if (__builtin_amdgcn_ballot_w64(m[k2] != 0.f)) {
+                    const float a = __builtin_amdgcn_sqrtf(f1.x * f1.x + f1.y * f1.y);
+                    acc += m[k2] != 0.f ? a * m[k2] : 0.f;
+                }
+                if (__builtin_amdgcn_ballot_w64(m[2 + k2] != 0.f)) {
+                    const float a = __builtin_amdgcn_sqrtf(f2.x * f2.x + f2.y * f2.y);
+                    acc += m[2 + k2] != 0.f ? a * m[2 + k2] : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (t == 0) part[w] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < CG_WAVES; ++i) v += part[i];
+            v *= 0.125f;
+            out[f] = accumulate ? out[f] + v : v;
+        }
+    }
+}
+
+// masks of the 128 kernel in lane order:
+//   mask_p[p][i][l]  = half_mask[sigma(l) + 64 (i & 1)][c(p) + 8 (i >> 1)]   (pair p: c = 16 (p >> 3) + (p & 7); p = 32: 64, no partner)
+//   rmask_p[q][8 t + e] = real_mask[4 q + (e & 3)][2 t + (e >> 2)];   rflags[0] bit q: a value other than 1 in rows 4q .. 4q+3
+__global__ void __launch_bounds__(256)
+k_cryst_masks128(const float *__restrict__ half_mask, float *__restrict__ mask_p,
+                 const float *__restrict__ real_mask, float *__restrict__ rmask_p,
+                 unsigned long long *__restrict__ rflags) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < CG_PAIRS * 4 * 64) {
+        const int p = i >> 8, e = (i >> 6) & 3, l = i & 63;
+        const int c1 = p < 32 ? (p >> 3) * 16 + (p & 7) : 64;
+        const int kx = c1 + 8 * (e >> 1), ky = cf_sigma(l) + 64 * (e & 1);
+        mask_p[i] = (p == 32 && (e >> 1)) ? 0.f : half_mask[ky * CG_K + kx];
+    }
+    if (real_mask && i < CG_N * CG_N) {
+        const int q = i >> 9, rem = i & 511, tt = rem >> 3, e = rem & 7;
+        const float v = real_mask[(4 * q + (e & 3)) * CG_N + 2 * tt + (e >> 2)];
+        rmask_p[i] = v;
+        if (__builtin_amdgcn_ballot_w64(v != 1.f) && (threadIdx.x & 63) == 0) atomicOr(&rflags[0], 1ull << q);
+    }
+}
+
+template <typename T>
+static int launch_fused128(const void *tile, int64_t ld, int64_t n_frames, const float *real_mask,
+                           const unsigned long long *rflags, const float *mask_p, int K, float *out,
+                           int accumulate, int n_cu, hipStream_t stream) {
+    auto kern = real_mask ? k_cryst_fused128<T, true> : k_cryst_fused128<T, false>;
+    const int lds = CG_K * CG_COL * 8 + CG_WAVES * CF_SCR * 8;
+    int device = 0;
+    LTMI_HIP(hipGetDevice(&device));
+    static bool attr_set[16][2] = {{false}};
+    if (!attr_set[device & 15][real_mask ? 1 : 0]) {
+        LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set[device & 15][real_mask ? 1 : 0] = true;
+    }
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_frames, n_cu));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(CG_WAVES * 64), (size_t)lds, stream, (const T *)tile, ld, n_frames,
+                       real_mask, rflags, mask_p, K, out, accumulate);
+    LTMI_HIP(hipGetLastError());
+    return LTMI_OK;
+}
+
+static int cryst_fused128(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, const float *real_mask,
+                          const float *half_mask, int n_cols, float *work, float *out, int accumulate, int n_cu,
+                          hipStream_t stream, bool *handled) {
+    if (n_cols < 1 || n_cols > CG_K) return LTMI_OK;
+    const size_t esz = (size_t)dtype_size(tile_dtype);
+    if (esz > 4 || tile_dtype == LTMI_F64) return LTMI_OK;
+    if ((uintptr_t)tile % (2 * esz) != 0 || ld % 2 != 0) return LTMI_OK;
+    float *mask_p = work, *rmask_p = work + CG_PAIRS * 4 * 64;
+    unsigned long long *rflags = (unsigned long long *)(rmask_p + CG_N * CG_N);
+    LTMI_HIP(hipMemsetAsync(rflags, 0, 8, stream));
+    hipLaunchKernelGGL(k_cryst_masks128, dim3((unsigned)(CG_N * CG_N / 256)), dim3(256), 0, stream, half_mask,
+                       mask_p, real_mask, rmask_p, rflags);
+    if (real_mask) real_mask = rmask_p;
+    int rc = LTMI_E_DTYPE;
+    switch (tile_dtype) {
+        case LTMI_BOOL:
+        case LTMI_U8: rc = launch_fused128<uint8_t>(tile, ld, n_frames, real_mask, rflags, mask_p, n_cols, out, accumulate, n_cu, stream); break;
+        case LTMI_I8: rc = launch_fused128<int8_t>(tile, ld, n_frames, real_mask, rflags, mask_p, n_cols, out, accumulate, n_cu, stream); break;
+        case LTMI_U16: rc = launch_fused128<uint16_t>(tile, ld, n_frames, real_mask, rflags, mask_p, n_cols, out, accumulate, n_cu, stream); break;
+        case LTMI_I16: rc = launch_fused128<int16_t>(tile, ld, n_frames, real_mask, rflags, mask_p, n_cols, out, accumulate, n_cu, stream); break;
+        case LTMI_U32: rc = launch_fused128<uint32_t>(tile, ld, n_frames, real_mask, rflags, mask_p, n_cols, out, accumulate, n_cu, stream); break;
+        case LTMI_I32: rc = launch_fused128<int32_t>(tile, ld, n_frames, real_mask, rflags, mask_p, n_cols, out, accumulate, n_cu, stream); break;
+        case LTMI_F32: rc = launch_fused128<float>(tile, ld, n_frames, real_mask, rflags, mask_p, n_cols, out, accumulate, n_cu, stream); break;
+        default: return LTMI_OK;
+    }
+    if (rc == LTMI_OK) *handled = true;
+    return rc;
+}
+
+// -> LTMI_OK with *handled = true when a fused kernel ran (256 x 256 or 128 x 128 frames)
 int cryst_fused(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, int sig_h, int sig_w,
                 const float *real_mask, const float *half_mask, int n_cols, float *mask_t, float *out,
                 int accumulate, int n_cu, hipStream_t stream, bool *handled) {
     *handled = false;
-    if (sig_h != CF_N || sig_w != CF_N || n_cols < 1 || n_cols > CF_KMAX || !mask_t) return LTMI_OK;
+    if (!mask_t) return LTMI_OK;
+    if (sig_h == CG_N && sig_w == CG_N)
+        return cryst_fused128(tile, tile_dtype, n_frames, ld, real_mask, half_mask, n_cols, mask_t, out, accumulate,
+                              n_cu, stream, handled);
+    if (sig_h != CF_N || sig_w != CF_N || n_cols < 1 || n_cols > CF_KMAX) return LTMI_OK;
     const size_t esz = (size_t)dtype_size(tile_dtype);
     if (esz > 4 || tile_dtype == LTMI_F64) return LTMI_OK;
     if ((uintptr_t)tile % (4 * esz) != 0 || ld % 4 != 0) return LTMI_OK;

@@ -261,7 +261,7 @@ extern "C" int ltmi_fft_plan_create(int device, int sig_h, int sig_w, int max_ba
     p->wc = sig_w / 2 + 1;
     p->batch = max_batch;
     hipError_t e = hipSuccess;
-    if (sig_h == 256 && sig_w == 256) {
+    if (cryst_fused_shape(sig_h, sig_w)) {
         const char *env = getenv("LTMI_FFT_FUSED");
         p->fused_ok = !(env && env[0] == '0');
         e = hipMalloc((void **)&p->mask_t, (size_t)cryst_fused_workspace_floats() * sizeof(float));
@@ -355,8 +355,8 @@ static int crystallinity_impl(ltmi_fft_plan *p, const void *tile, int tile_dtype
                                    n_cols, p->mask_t, out, accumulate, p->n_cu, stream, &handled);
         if (rc != LTMI_OK) return rc;
         if (handled) {
-            snprintf(p->last_kernel, sizeof(p->last_kernel), "k_cryst_fused<%s%s> columns=%d",
-                     dtype_name(tile_dtype), real_mask ? ",mask" : "", n_cols);
+            snprintf(p->last_kernel, sizeof(p->last_kernel), "k_cryst_fused%s<%s%s> columns=%d",
+                     p->h == 128 ? "128" : "", dtype_name(tile_dtype), real_mask ? ",mask" : "", n_cols);
             return LTMI_OK;
         }
     }

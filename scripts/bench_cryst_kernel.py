@@ -7,6 +7,7 @@ from libertem_amd import hip
 from libertem_amd.udf.crystallinity import crystallinity_masks, mask_box
 
 n = int(os.environ.get('N', 16384))
+sig = int(os.environ.get('SIG', 256))
 reps = int(os.environ.get('REPS', 10))
 rad_out = float(os.environ.get('RAD_OUT', 64))
 rad_out = int(rad_out) if rad_out == int(rad_out) else rad_out
@@ -15,21 +16,21 @@ use_mask = os.environ.get('MASK', '1') != '0'
 g = torch.Generator(device='cuda').manual_seed(1)
 tdt = {1: torch.uint8, 2: torch.int16, 4: torch.int32}[dt.itemsize]
 if dt.kind == 'f':
-    frames = torch.rand((n, 256, 256), generator=g, device='cuda', dtype=torch.float32) * 4096
+    frames = torch.rand((n, sig, sig), generator=g, device='cuda', dtype=torch.float32) * 4096
 else:
-    frames = torch.randint(0, 200 if dt.itemsize == 1 else 4096, (n, 256, 256), generator=g, device='cuda',
+    frames = torch.randint(0, 200 if dt.itemsize == 1 else 4096, (n, sig, sig), generator=g, device='cuda',
                            dtype=tdt)
-real_mask, half = crystallinity_masks((256, 256), int(rad_out) // 4, rad_out,
-                                      (128, 128) if use_mask else None, 25 if use_mask else None)
+real_mask, half = crystallinity_masks((sig, sig), int(rad_out) // 4, rad_out,
+                                      (sig // 2, sig // 2) if use_mask else None, sig // 10 if use_mask else None)
 rm = None if real_mask is None else torch.from_numpy(np.ascontiguousarray(real_mask.astype(np.float32))).cuda()
 hm = torch.from_numpy(np.ascontiguousarray(half.astype(np.float32))).cuda()
 out = torch.zeros(n, dtype=torch.float32, device='cuda')
-plan = hip.FFTPlan(0, 256, 256, min(n, 1024))
+plan = hip.FFTPlan(0, sig, sig, min(n, 1024))
 box = mask_box(half)
 
 
 def call():
-    plan.crystallinity(frames.data_ptr(), dt, n, 256 * 256, None if rm is None else rm.data_ptr(),
+    plan.crystallinity(frames.data_ptr(), dt, n, sig * sig, None if rm is None else rm.data_ptr(),
                        hm.data_ptr(), box, out.data_ptr(), False)
 
 
@@ -43,7 +44,7 @@ for i in range(reps):
 torch.cuda.synchronize()
 ms = np.median([ev[i].elapsed_time(ev[i + 1]) for i in range(reps)])
 print(f"{plan.last_kernel()}: {n} frames {dt} in {ms:.3f} ms = {n / ms / 1e3:.2f} M frames/s, "
-      f"{n * 65536 * dt.itemsize / ms / 1e6:.0f} GB/s of pixels")
+      f"{n * sig * sig * dt.itemsize / ms / 1e6:.0f} GB/s of pixels")
 if os.environ.get('LTMI_CRYST_ABLATE'):
     sys.exit(0)        # timing-only variant: garbage results
 i = [0, n // 2, n - 1]

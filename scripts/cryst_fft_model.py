@@ -95,3 +95,83 @@ for K in (10,64,65,71):
     other=supplied[back]
     assert np.allclose(other, Zf[(N-k)%N])
 print('sep ok')
+
+
+# ---- second part: 128 x 128 frames (k_cryst_fused128): two 128-point transforms as one 256-point transform of the
+# interleaved sequence; G[kx][y ^ ((kx >> 3) & 1)], column pairs (c, c + 8)
+N=128
+rng=np.random.default_rng(1)
+frame=rng.integers(0,4096,size=(N,N)).astype(float)
+mask=(rng.random((N,N))>0.1).astype(float)
+x=frame*mask
+F=np.fft.rfft2(x)            # (128, 65)
+K=65
+COL=130
+G=np.zeros((K,COL),complex)   # G[kx][y'] , y' = y ^ ((kx>>3)&1)
+back=sigma[(-sigma)%64]
+tz=[np.exp(2j*np.pi*(sigma+64*k2)/256) for k2 in (0,1)]
+for q in range(32):
+    rows=[x[4*q+i] for i in range(4)]
+    u=[rows[0][2*l]+1j*rows[1][2*l], rows[2][2*l]+1j*rows[3][2*l], rows[0][2*l+1]+1j*rows[1][2*l+1], rows[2][2*l+1]+1j*rows[3][2*l+1]]
+    U=fft_core(swapA(u))     # U[k2][l] = W[sigma+64k2]
+    Z1=[U[0]+U[2], U[1]+U[3]]                    # 2 Z1[sigma+64 k2]
+    Z2=[(U[0]-U[2])*tz[0], (U[1]-U[3])*tz[1]]    # 2 Z2[...]
+    for which,Z in enumerate((Z1,Z2)):
+        y=4*q+2*which
+        give=np.where(l==0, Z[0], Z[1])
+        other=give[back]
+        zk=Z[0]
+        S=(zk.real+other.real)+1j*(zk.imag-other.imag)      # 4 A[kx]
+        D=(zk.imag+other.imag)+1j*(other.real-zk.real)      # 4 B[kx]
+        for ln in range(64):
+            kx=sigma[ln]
+            if kx<K:
+                sw=(kx>>3)&1
+                G[kx][y^sw]=S[ln]; G[kx][(y+1)^sw]=D[ln]
+        if K==65:
+            ln=0; zk=Z[1][0]        # Z[64], partner itself
+            S64=(zk.real+zk.real)+0j*0+1j*(zk.imag-zk.imag); D64=(zk.imag+zk.imag)+1j*(zk.real-zk.real)
+            G[64][y^0]=S64; G[64][(y+1)^0]=D64
+# check G against row FFTs
+R=np.fft.fft(x,axis=1)[:,:K]   # R[y][kx]
+for kx in range(K):
+    sw=(kx>>3)&1
+    col=np.array([G[kx][y^sw] for y in range(N)])
+    assert np.allclose(col, 4*R[:,kx]), kx
+print('rows ok')
+# column stage: pairs (c, c+8)
+half=(rng.random((N,K))>0.5).astype(float)
+acc=0
+pairs=[(c,c+8) for c in range(64) if not (c>>3)&1]+[(64,64)]
+for (c1,c2) in pairs:
+    mm=l&15; j=l>>4
+    u=[]
+    for r in range(4):
+        y=32*r+2*mm+(j>>1)
+        kx=np.where(j&1, c2, c1)
+        sw=(kx>>3)&1
+        if c1==64: sw=0*sw
+        # bank check for 32-lane groups
+        units=kx*COL+(y^sw)
+        for g in range(2):
+            if c1!=c2: assert len(set(units[32*g:32*g+32]%32))==32, (c1,r,g)
+        u.append(G[kx, y^sw])
+    U=fft_core(u)
+    for k2 in (0,1):
+        ky=sigma+64*k2
+        F1=U[k2]+U[k2+2]; F2=U[k2]-U[k2+2]
+        assert np.allclose(F1, 8*F[ky,c1])
+        if c2!=c1 or True: assert np.allclose(abs(F2), 8*abs(F[ky,c2]))
+        acc+=np.sum(abs(F1)*half[ky,c1])
+        if c2!=c1: acc+=np.sum(abs(F2)*half[ky,c2])
+ref=np.sum(abs(F)*half)
+print('cols ok', acc*0.125, ref)
+# bank check of the b64 row-stage stores (16-lane groups, unit mod 16)
+for q in (0,5):
+  for which in (0,1):
+    y=4*q+2*which
+    for part in (0,1):
+      addr=sigma*COL+((y+part)^((sigma>>3)&1))
+      for g in range(4):
+        assert len(set(addr[16*g:16*g+16]%16))==16
+print('store banks ok')

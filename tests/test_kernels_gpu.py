@@ -1694,3 +1694,55 @@ def test_crystallinity_fused_kernel_every_bin_of_the_ring(hip):
     assert np.allclose(got, ref, rtol=1e-5, atol=256 * 256 * 1e-4), (got, ref)   # float32 round-off of 10^4 empty bins
     inside = ref > 1000
     assert inside.sum() >= 5 and (~inside).sum() >= 4          # the probe set straddles the ring's edges
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['uint8', 'int8', 'uint16', 'int16', 'uint32', 'int32', 'float32'])
+@pytest.mark.parametrize('rad_in,rad_out,real', [(8, 64, ((64, 64), 12)), (0, 30, None), (10, 47.5, ((50.5, 70), 9.5)),
+                                                 (60, 90, None), (0, 7, ((64, 64), 70))])
+def test_crystallinity_fused_kernel_128_all_pixel_types(hip, dtype, rad_in, rad_out, real):
+    """128 x 128 frames: k_cryst_fused128 -- four rows / two columns per 256-point transform of an interleaved
+    sequence; rings up to the full half spectrum (65 columns), 1e-5 relative against float64."""
+    rng = np.random.default_rng(_seed('cryst128', dtype, rad_out))
+    dt = np.dtype(dtype)
+    n = 9
+    if dt.kind == 'f':
+        frames = rng.normal(size=(n, 128, 128)).astype(dt) * 100
+    else:
+        info = np.iinfo(dt)
+        frames = rng.integers(max(info.min, -4000), min(info.max, 4000), size=(n, 128, 128),
+                              endpoint=True).astype(dt)
+    frames[2] = 0
+    frames[5, 40:50, 90:100] += 17
+    ref, real_mask, half = _cryst_reference(frames, rad_in, rad_out, real)
+    got, label = _cryst_run(hip, frames, real_mask, half)
+    assert label.startswith('k_cryst_fused128<'), label
+    assert np.allclose(got, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max()), (got, ref)
+    assert got[2] == 0
+
+
+@pytest.mark.gpu
+def test_crystallinity_fused_kernel_128_many_frames_and_every_bin(hip):
+    rng = np.random.default_rng(_seed('cryst128-many'))
+    frames = rng.integers(0, 4096, size=(700, 128, 128)).astype(np.uint16)
+    ref, real_mask, half = _cryst_reference(frames, 8, 32, ((64, 64), 12))
+    got, label = _cryst_run(hip, frames, real_mask, half, ld_pad=6)
+    assert label == 'k_cryst_fused128<uint16,mask> columns=33', label
+    assert np.allclose(got, ref, rtol=1e-5)
+    base = rng.normal(size=700).astype(np.float32) * 1e6
+    got2, _ = _cryst_run(hip, frames, real_mask, half, accumulate_into=base)
+    assert np.allclose(got2, base + got, rtol=1e-6)
+    got3, label3 = _cryst_run(hip, frames[:9], real_mask, half, ld_pad=1)      # odd stride: hipFFT
+    assert label3.startswith('hipfft_r2c<'), label3
+    assert np.allclose(got3, ref[:9], rtol=1e-5)
+    # single plane waves: one bin each, inside / outside the ring 8 .. 32
+    yy, xx = np.mgrid[0:128, 0:128]
+    waves = [(0, 0), (0, 32), (0, 33), (32, 0), (96, 0), (95, 0), (22, 22), (24, 24), (127, 8), (8, 0), (7, 0),
+             (100, 20), (64, 64), (3, 31)]
+    pw = np.stack([np.cos(2 * np.pi * (ky * yy + kx * xx) / 128) for ky, kx in waves]).astype(np.float32)
+    ref, _, half = _cryst_reference(pw, 8, 32, None)
+    got, label = _cryst_run(hip, pw, None, half)
+    assert label.startswith('k_cryst_fused128<'), label
+    assert np.allclose(got, ref, rtol=1e-5, atol=128 * 128 * 1e-4), (got, ref)
+    inside = ref > 1000
+    assert inside.sum() >= 5 and (~inside).sum() >= 4
