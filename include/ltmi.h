@@ -278,8 +278,8 @@ int ltmi_crystallinity_corrected(ltmi_fft_plan *p, const void *tile, int tile_dt
                                  const float *real_mask, const float *half_mask, int row_lo,
                                  int row_hi, int n_cols, float *out, int accumulate, void *stream);
 /* Which route the last ltmi_crystallinity* call of this plan took: "k_cryst_fused<...>" (256 x 256
- * frames, rings of up to 71 columns: rows, columns and the ring sum of a frame in the LDS of one
- * workgroup, csrc/ltmi_cryst.hip) or "hipfft_r2c<...>".  LTMI_FFT_FUSED=0 at plan creation keeps every
+ * frames, rings of up to 71 columns) / "k_cryst_fused128<...>" (128 x 128 frames, any ring): rows, columns
+ * and the ring sum of a frame in the LDS of one workgroup (csrc/ltmi_cryst.hip), or "hipfft_r2c<...>".  LTMI_FFT_FUSED=0 at plan creation keeps every
  * frame on hipFFT.  The string lives as long as the plan. */
 const char *ltmi_fft_plan_last_kernel(const ltmi_fft_plan *p);
 

@@ -13,6 +13,13 @@ MASK=0 python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s"
 for r in 24 48 63 64 70 71; do RAD_OUT=$r python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s" | sed "s/^/rad_out $r: /"; done
 LTMI_CRYST_WAVES=8 python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s" | sed 's/^/8 waves: /'
 LTMI_FFT_FUSED=0 python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s"
+echo "== 128 x 128 frames (k_cryst_fused128; 65 536 frames)"
+for r in 16 32 48 64; do SIG=128 N=65536 RAD_OUT=$r python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s" | sed "s/^/rad_out $r: /"; done
+for d in uint8 float32; do SIG=128 N=65536 RAD_OUT=32 DTYPE=$d python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s"; done
+SIG=128 N=65536 RAD_OUT=32 MASK=0 python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s"
+SIG=128 N=65536 RAD_OUT=32 LTMI_FFT_FUSED=0 python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s"
+SIG=128 SCAN=512 python $R/scripts/bench_crystallinity.py 2>&1 | grep "Mframes"
+SIG=128 SCAN=512 LTMI_FFT_FUSED=0 python $R/scripts/bench_crystallinity.py 2>&1 | grep "Mframes" | sed 's/^/LTMI_FFT_FUSED=0: /'
 echo "== timing-only ablations of k_cryst_fused<uint16,mask> (LTMI_CRYST_ABLATE; results are garbage)"
 for a in 1 2 3 4 5; do LTMI_CRYST_ABLATE=$a python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s" | sed "s/^/ablation $a: /"; done
 ) > $O 2>&1
