@@ -527,56 +527,63 @@ def live_feed(ctx, n_frames=16384, chunk=1024):
                          "ms_per_scan": t2 * 1e3, "check_rel_err_vs_float64": err2}}
 
 
-def crystallinity(torch, hip, n=16384, reps=10):
+def crystallinity(torch, hip, reps=10):
     """Row f3: CrystallinityUDF's kernel on frames resident in HBM -- sum(abs(rfft2(frame * real_mask)) * ring)
-    per frame (ltmi_crystallinity; 256 x 256 uint16, ring 16 .. 64, real-space disk of radius 25 masked out):
-    k_cryst_fused, and the hipFFT route of the same call beside it (LTMI_FFT_FUSED is read per plan)."""
+    per frame (ltmi_crystallinity; uint16 frames, ring sig/16 .. sig/4, real-space disk of radius sig/10 masked
+    out) for 256 x 256 frames (k_cryst_fused) and 128 x 128 frames (k_cryst_fused128), the hipFFT route of the
+    same call beside each (LTMI_FFT_FUSED is read per plan)."""
     from libertem_amd.udf.crystallinity import crystallinity_masks, mask_box
-    g = torch.Generator(device='cuda').manual_seed(1)
-    frames = torch.randint(0, 4096, (n, 256, 256), generator=g, device='cuda', dtype=torch.int16)
-    real_mask, half = crystallinity_masks((256, 256), 16, 64, (128, 128), 25)
-    rm = torch.from_numpy(np.ascontiguousarray(real_mask.astype(np.float32))).cuda()
-    hm = torch.from_numpy(np.ascontiguousarray(half.astype(np.float32))).cuda()
-    out = torch.zeros(n, dtype=torch.float32, device='cuda')
-    box = mask_box(half)
-    res = {"workload": f"{n} frames of 256x256 uint16, ring 16..64 of the half spectrum, real-space disk masked"}
-    for key, env in (("fused", None), ("hipfft_route", "0")):
-        old = os.environ.get('LTMI_FFT_FUSED')
-        if env is not None:
-            os.environ['LTMI_FFT_FUSED'] = env
-        try:
-            plan = hip.FFTPlan(0, 256, 256, 1024)
-        finally:
+    res = {"bound": "vector ALUs + LDS (profiles/r04_crystallinity.txt): the pixels are read once"}
+    for sig, n in ((256, 16384), (128, 65536)):
+        g = torch.Generator(device='cuda').manual_seed(1)
+        frames = torch.randint(0, 4096, (n, sig, sig), generator=g, device='cuda', dtype=torch.int16)
+        real_mask, half = crystallinity_masks((sig, sig), sig // 16, sig // 4, (sig // 2, sig // 2), sig // 10)
+        rm = torch.from_numpy(np.ascontiguousarray(real_mask.astype(np.float32))).cuda()
+        hm = torch.from_numpy(np.ascontiguousarray(half.astype(np.float32))).cuda()
+        out = torch.zeros(n, dtype=torch.float32, device='cuda')
+        box = mask_box(half)
+        r = {"workload": f"{n} frames of {sig}x{sig} uint16, ring {sig // 16}..{sig // 4} of the half spectrum, "
+                         "real-space disk masked"}
+        for key, env in (("fused", None), ("hipfft_route", "0")):
+            old = os.environ.get('LTMI_FFT_FUSED')
             if env is not None:
-                if old is None:
-                    os.environ.pop('LTMI_FFT_FUSED', None)
-                else:
-                    os.environ['LTMI_FFT_FUSED'] = old
+                os.environ['LTMI_FFT_FUSED'] = env
+            try:
+                plan = hip.FFTPlan(0, sig, sig, 1024)
+            finally:
+                if env is not None:
+                    if old is None:
+                        os.environ.pop('LTMI_FFT_FUSED', None)
+                    else:
+                        os.environ['LTMI_FFT_FUSED'] = old
 
-        def run():
-            plan.crystallinity(frames.data_ptr(), np.uint16, n, 65536, rm.data_ptr(), hm.data_ptr(), box,
-                               out.data_ptr(), False)
-        run(); run()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            run()
-        e1.record()
-        e1.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        got = out[[0, n - 1]].cpu().numpy()
-        fr = frames[[0, n - 1]].cpu().numpy().view(np.uint16).astype(np.float64)
-        ref = np.array([np.sum(abs(np.fft.rfft2(f * real_mask)) * half) for f in fr])
-        err = float(np.abs(got - ref).max() / np.abs(ref).max())
-        if not err < 1e-5:
-            raise SystemExit(f"bench.py: crystallinity check failed ({key}): {err:.3e}")
-        res[key] = {"kernel": plan.last_kernel(), "avg_call_ms": ms, "frames_per_s": n / ms * 1e3,
-                    "pixel_GBps": n * 131072 / ms / 1e6, "frac_of_hbm_peak": n * 131072 / ms / 1e6 / HBM_PEAK_GBS,
-                    "check_rel_err_vs_float64": err}
-        plan.close()
-    res["speedup"] = res["hipfft_route"]["avg_call_ms"] / res["fused"]["avg_call_ms"]
-    res["bound"] = "vector ALUs + LDS (profiles/r04_crystallinity.txt): the pixels are read once"
+            def run():
+                plan.crystallinity(frames.data_ptr(), np.uint16, n, sig * sig, rm.data_ptr(), hm.data_ptr(), box,
+                                   out.data_ptr(), False)
+            run(); run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                run()
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            got = out[[0, n - 1]].cpu().numpy()
+            fr = frames[[0, n - 1]].cpu().numpy().view(np.uint16).astype(np.float64)
+            ref = np.array([np.sum(abs(np.fft.rfft2(f * real_mask)) * half) for f in fr])
+            err = float(np.abs(got - ref).max() / np.abs(ref).max())
+            if not err < 1e-5:
+                raise SystemExit(f"bench.py: crystallinity check failed ({sig}, {key}): {err:.3e}")
+            nbytes = n * sig * sig * 2
+            r[key] = {"kernel": plan.last_kernel(), "avg_call_ms": ms, "frames_per_s": n / ms * 1e3,
+                      "pixel_GBps": nbytes / ms / 1e6, "frac_of_hbm_peak": nbytes / ms / 1e6 / HBM_PEAK_GBS,
+                      "check_rel_err_vs_float64": err}
+            plan.close()
+        r["speedup"] = r["hipfft_route"]["avg_call_ms"] / r["fused"]["avg_call_ms"]
+        res[f"frames_{sig}"] = r
+        del frames, out
+        torch.cuda.empty_cache()
     return res
 
 
