@@ -282,7 +282,12 @@ k_cryst_fused(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
             if (sig < K)
                 *(v4f *)(G + g_col + pos) = (v4f){u[0].x + cr, u[0].y - ci, u[0].y + ci, cr - u[0].x};
         }
-        if (K > 64) {
+        if (K == 65) {
+            // the one column kx = 64: Z[64] and Z[192] are registers 1 and 3 of lane 0, no exchange
+            if (t == 0)
+                *(v4f *)(G + 64 * CF_COL + pos) =
+                    (v4f){u[1].x + u[3].x, u[1].y - u[3].y, u[1].y + u[3].y, u[3].x - u[1].x};
+        } else if (K > 64) {
             const float gx = t == 0 ? u[3].x : u[2].x, gy = t == 0 ? u[3].y : u[2].y;
             const float cr = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(gx)));
             const float ci = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(gy)));
@@ -292,9 +297,11 @@ k_cryst_fused(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
         }
     };
 
-    // after the last row pair of frame f: columns kx = w + WAVES i transformed in place, |F| * mask summed
-    // per lane, one float per frame
-    auto frame_end = [&](int64_t f) {
+    // after the last row pair of frame f: columns kx = w + WAVES i transformed, |F| * mask summed per lane, one
+    // float per frame.  A wave that owns row scratch runs the exchanges of its column transforms THERE (fixed
+    // addresses: 16 address additions per column less), the others in place in the column.
+    auto frame_end = [&](int64_t f, auto in_place_tag) {
+        constexpr bool IN_PLACE = decltype(in_place_tag)::value;
         if (ABL != 2) __syncthreads();
         float acc = 0.f;
         for (int kx = w; kx < (ABL == 4 ? 0 : K); kx += WAVES) {
@@ -306,7 +313,7 @@ k_cryst_fused(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
             v2f u[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) u[r] = col[rd + 64 * r];
-            cf_core<ABL == 3>(col, c, u);
+            cf_core<ABL == 3>(IN_PLACE ? col : scr, c, u);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (__builtin_amdgcn_ballot_w64(m[r] != 0.f)) {          // (most columns: two of the four)
@@ -328,7 +335,7 @@ k_cryst_fused(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
     };
 
     if (!rows) {                                        // (no row scratch left for this wave: columns only)
-        for (int64_t f = blockIdx.x; f < n_frames; f += gridDim.x) frame_end(f);
+        for (int64_t f = blockIdx.x; f < n_frames; f += gridDim.x) frame_end(f, std::true_type());
         return;
     }
     CfRaw<T> ba, bb;
@@ -349,14 +356,14 @@ k_cryst_fused(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
         load_next(bb);
         row_pair(ua, ypa);
         if (a_last) {
-            frame_end(f);
+            frame_end(f, std::false_type());
             f += gridDim.x;
             if (!have_b) break;
         }
         row_pair(ub, ypb);
         yp = ypb + n_scr;
         if (yp >= CF_N / 2) {
-            frame_end(f);
+            frame_end(f, std::false_type());
             f += gridDim.x;
             yp = w;
         }
