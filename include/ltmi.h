@@ -270,7 +270,9 @@ int ltmi_crystallinity(ltmi_fft_plan *p, const void *tile, int tile_dtype, int64
  * udf/crystallinity.py:73-79): v = (float)(((double)x - dark) * gain), every excluded pixel = mean
  * of its good neighbours' corrected values; no corrected copy of the tile is written.
  * dark / gain: device float64 (sig_h*sig_w) or NULL; excl (n_excl), env (n_excl, max_env),
- * cnt (n_excl): device int32 repair tables as for ltmi_repair_pixels (n_excl = 0: none). */
+ * cnt (n_excl): device int32 repair tables as for ltmi_repair_pixels (n_excl = 0: none).
+ * 256 x 256 / 128 x 128 frames: the corrected float32 frames of a batch are written to the plan's workspace and
+ * transformed by the fused kernel (see ltmi_fft_plan_last_kernel) instead of hipFFT. */
 int ltmi_crystallinity_corrected(ltmi_fft_plan *p, const void *tile, int tile_dtype,
                                  int64_t n_frames, int64_t ld_tile, const double *dark,
                                  const double *gain, const int32_t *excl, const int32_t *env,

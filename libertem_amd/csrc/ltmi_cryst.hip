@@ -395,6 +395,11 @@ k_cryst_masks(const float *__restrict__ half_mask, int wc, int K, float *__restr
 }
 
 int cryst_fused_max_cols() { return CF_KMAX; }
+// rings the fused kernels take (given a tile they can read: see cryst_fused)
+bool cryst_fused_takes(int h, int w, int n_cols) {
+    if (h == 128 && w == 128) return n_cols >= 1 && n_cols <= 65;
+    return h == 256 && w == 256 && n_cols >= 1 && n_cols <= CF_KMAX;
+}
 bool cryst_fused_shape(int h, int w) { return (h == 256 && w == 256) || (h == 128 && w == 128); }
 int64_t cryst_fused_workspace_floats() { return (int64_t)CF_KMAX * CF_N + CF_N * CF_N + 4; }
 

@@ -225,21 +225,32 @@ static int run_prepare(const void *tile, int64_t ld, int64_t n, int64_t n_px, co
 
 using namespace ltmi;
 
+// (batch x frame) float32 workspace of a plan, created on first use
+static int real_buf_ready(ltmi_fft_plan *p) {
+    if (p->real_buf) return LTMI_OK;
+    hipError_t e = hipMalloc((void **)&p->real_buf, (size_t)p->batch * p->h * p->w * sizeof(float));
+    if (e != hipSuccess) {
+        p->real_buf = nullptr;
+        LTMI_FAIL((int)e, "ltmi_fft_plan: workspace allocation failed: %s", hipGetErrorString(e));
+    }
+    return LTMI_OK;
+}
+
 // the hipFFT plan + workspace of a plan, created on first use
 static int hipfft_route_ready(ltmi_fft_plan *p) {
     if (p->have_plan) return LTMI_OK;
+    {
+        const int rc = real_buf_ready(p);
+        if (rc != LTMI_OK) return rc;
+    }
     int n[2] = {p->h, p->w};
     hipfftResult r = hipfftPlanMany(&p->plan, 2, n, nullptr, 1, p->h * p->w, nullptr, 1, p->h * p->wc,
                                     HIPFFT_R2C, p->batch);
     if (r != HIPFFT_SUCCESS)
         LTMI_FAIL(LTMI_E_INVALID, "hipfftPlanMany(%d x %d, batch %d) failed: %s", p->h, p->w, p->batch,
                   fft_err(r));
-    hipError_t e = hipMalloc((void **)&p->real_buf, (size_t)p->batch * p->h * p->w * sizeof(float));
-    if (e == hipSuccess)
-        e = hipMalloc((void **)&p->spec, (size_t)p->batch * p->h * p->wc * sizeof(hipfftComplex));
+    hipError_t e = hipMalloc((void **)&p->spec, (size_t)p->batch * p->h * p->wc * sizeof(hipfftComplex));
     if (e != hipSuccess) {
-        if (p->real_buf) (void)hipFree(p->real_buf);
-        p->real_buf = nullptr;
         (void)hipfftDestroy(p->plan);
         LTMI_FAIL((int)e, "ltmi_fft_plan: workspace allocation failed: %s", hipGetErrorString(e));
     }
@@ -333,6 +344,24 @@ extern "C" int ltmi_crystallinity_corrected(
                               row_hi, n_cols, out, accumulate, stream_, corr);
 }
 
+// frames [0, n) of `src` -> p->real_buf: float32, corrected, times the real-space mask
+static int prepare_batch(ltmi_fft_plan *p, const void *src, int tile_dtype, int64_t ld_tile, int64_t n,
+                         int64_t n_px, const float *real_mask, hipStream_t stream, const FftCorr &corr) {
+    switch (tile_dtype) {
+        case LTMI_BOOL:
+        case LTMI_U8: return run_prepare<uint8_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream, corr);
+        case LTMI_I8: return run_prepare<int8_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream, corr);
+        case LTMI_U16: return run_prepare<uint16_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream, corr);
+        case LTMI_I16: return run_prepare<int16_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream, corr);
+        case LTMI_U32: return run_prepare<uint32_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream, corr);
+        case LTMI_I32: return run_prepare<int32_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream, corr);
+        case LTMI_F32: return run_prepare<float>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream, corr);
+        case LTMI_F64: return run_prepare<double>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream, corr);
+        default:
+            LTMI_FAIL(LTMI_E_DTYPE, "ltmi_crystallinity: unsupported tile dtype %s", dtype_name(tile_dtype));
+    }
+}
+
 static int crystallinity_impl(ltmi_fft_plan *p, const void *tile, int tile_dtype,
                               int64_t n_frames, int64_t ld_tile, const float *real_mask,
                               const float *half_mask, int row_lo, int row_hi, int n_cols,
@@ -360,6 +389,27 @@ static int crystallinity_impl(ltmi_fft_plan *p, const void *tile, int tile_dtype
             return LTMI_OK;
         }
     }
+    if (p->fused_ok && cryst_fused_takes(p->h, p->w, n_cols)) {
+        // corrected frames (and float64 pixels): the conversion pass writes them as float32 -- dark / gain /
+        // dead-pixel patches / real-space mask applied, 6 - 12 bytes of traffic per pixel -- and the fused
+        // kernel takes those instead of two rocFFT passes over a (batch x half spectrum) workspace
+        const int rc0 = real_buf_ready(p);
+        if (rc0 != LTMI_OK) return rc0;
+        for (int64_t f0 = 0; f0 < n_frames; f0 += p->batch) {
+            const int64_t n = std::min<int64_t>(p->batch, n_frames - f0);
+            const void *src = (const char *)tile + (size_t)f0 * ld_tile * esz;
+            int rc = prepare_batch(p, src, tile_dtype, ld_tile, n, n_px, real_mask, stream, corr);
+            if (rc != LTMI_OK) return rc;
+            bool handled = false;
+            rc = cryst_fused(p->real_buf, LTMI_F32, n, n_px, p->h, p->w, nullptr, half_mask, n_cols, p->mask_t,
+                             out + f0, accumulate, p->n_cu, stream, &handled);
+            if (rc != LTMI_OK) return rc;
+            if (!handled) LTMI_FAIL(LTMI_E_INVALID, "ltmi_crystallinity: the fused kernel refused its own workspace");
+        }
+        snprintf(p->last_kernel, sizeof(p->last_kernel), "k_fft_prepare<%s> + k_cryst_fused%s<float32> columns=%d",
+                 dtype_name(tile_dtype), p->h == 128 ? "128" : "", n_cols);
+        return LTMI_OK;
+    }
     snprintf(p->last_kernel, sizeof(p->last_kernel), "hipfft_r2c<%s> batch=%d", dtype_name(tile_dtype),
              p->batch);
     {
@@ -375,21 +425,7 @@ static int crystallinity_impl(ltmi_fft_plan *p, const void *tile, int tile_dtype
     for (int64_t f0 = 0; f0 < n_frames; f0 += p->batch) {
         const int64_t n = std::min<int64_t>(p->batch, n_frames - f0);
         const void *src = (const char *)tile + (size_t)f0 * ld_tile * esz;
-        int rc = LTMI_E_DTYPE;
-        switch (tile_dtype) {
-            case LTMI_BOOL:
-            case LTMI_U8: rc = run_prepare<uint8_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream, corr); break;
-            case LTMI_I8: rc = run_prepare<int8_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream, corr); break;
-            case LTMI_U16: rc = run_prepare<uint16_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream, corr); break;
-            case LTMI_I16: rc = run_prepare<int16_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream, corr); break;
-            case LTMI_U32: rc = run_prepare<uint32_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream, corr); break;
-            case LTMI_I32: rc = run_prepare<int32_t>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream, corr); break;
-            case LTMI_F32: rc = run_prepare<float>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream, corr); break;
-            case LTMI_F64: rc = run_prepare<double>(src, ld_tile, n, n_px, real_mask, p->real_buf, stream, corr); break;
-            default:
-                LTMI_FAIL(LTMI_E_DTYPE, "ltmi_crystallinity: unsupported tile dtype %s",
-                          dtype_name(tile_dtype));
-        }
+        const int rc = prepare_batch(p, src, tile_dtype, ld_tile, n, n_px, real_mask, stream, corr);
         if (rc != LTMI_OK) return rc;
         if (n < p->batch) {
             // the plan always transforms `batch` frames: clear the unused tail once so that it

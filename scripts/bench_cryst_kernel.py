@@ -14,9 +14,9 @@ rad_out = int(rad_out) if rad_out == int(rad_out) else rad_out
 dt = np.dtype(os.environ.get('DTYPE', 'uint16'))
 use_mask = os.environ.get('MASK', '1') != '0'
 g = torch.Generator(device='cuda').manual_seed(1)
-tdt = {1: torch.uint8, 2: torch.int16, 4: torch.int32}[dt.itemsize]
+tdt = {1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.float64}[dt.itemsize]
 if dt.kind == 'f':
-    frames = torch.rand((n, sig, sig), generator=g, device='cuda', dtype=torch.float32) * 4096
+    frames = torch.rand((n, sig, sig), generator=g, device='cuda', dtype=tdt if dt.itemsize == 8 else torch.float32) * 4096
 else:
     frames = torch.randint(0, 200 if dt.itemsize == 1 else 4096, (n, sig, sig), generator=g, device='cuda',
                            dtype=tdt)
@@ -29,7 +29,21 @@ plan = hip.FFTPlan(0, sig, sig, min(n, 1024))
 box = mask_box(half)
 
 
+tables = None
+if os.environ.get('CORR', '0') != '0':                      # dark + gain + 50 dead pixels, fused into the conversion pass
+    from libertem_amd.io.corrections import CorrectionSet
+    rng = np.random.default_rng(3)
+    bad = np.zeros((sig, sig), dtype=bool)
+    bad[rng.integers(0, sig, 50), rng.integers(0, sig, 50)] = True
+    corr_set = CorrectionSet(dark=rng.random((sig, sig)) * 6, gain=rng.random((sig, sig)) * 0.6 + 0.7, excluded_pixels=bad)
+    tables = corr_set.device_tables(0, (sig, sig))
+
+
 def call():
+    if tables is not None:
+        plan.crystallinity_corrected(frames.data_ptr(), dt, n, sig * sig, tables, None if rm is None else rm.data_ptr(),
+                                     hm.data_ptr(), box, out.data_ptr(), False)
+        return
     plan.crystallinity(frames.data_ptr(), dt, n, sig * sig, None if rm is None else rm.data_ptr(),
                        hm.data_ptr(), box, out.data_ptr(), False)
 
@@ -45,7 +59,7 @@ torch.cuda.synchronize()
 ms = np.median([ev[i].elapsed_time(ev[i + 1]) for i in range(reps)])
 print(f"{plan.last_kernel()}: {n} frames {dt} in {ms:.3f} ms = {n / ms / 1e3:.2f} M frames/s, "
       f"{n * sig * sig * dt.itemsize / ms / 1e6:.0f} GB/s of pixels")
-if os.environ.get('LTMI_CRYST_ABLATE'):
+if os.environ.get('LTMI_CRYST_ABLATE') or tables is not None:
     sys.exit(0)        # timing-only variant: garbage results
 i = [0, n // 2, n - 1]
 fr = frames[i].cpu().numpy()

@@ -1670,9 +1670,9 @@ def test_crystallinity_fused_kernel_many_frames_ragged_accumulate(hip):
     base = rng.normal(size=300).astype(np.float32) * 1e6
     got2, _ = _cryst_run(hip, frames, real_mask, half, accumulate_into=base)
     assert np.allclose(got2, base + got, rtol=1e-6)
-    # an odd frame stride (rows not 8-byte aligned): the hipFFT route takes it
+    # an odd frame stride (rows not 8-byte aligned): the conversion pass makes float32 frames of them first
     got3, label3 = _cryst_run(hip, frames[:9], real_mask, half, ld_pad=1)
-    assert label3.startswith('hipfft_r2c<'), label3
+    assert label3 == 'k_fft_prepare<uint16> + k_cryst_fused<float32> columns=65', label3
     assert np.allclose(got3, ref[:9], rtol=1e-5)
     ref_w, rm_w, half_w = _cryst_reference(frames[:9], 16, 100, ((128, 128), 25))
     got_w, label_w = _cryst_run(hip, frames[:9], rm_w, half_w)
@@ -1732,8 +1732,8 @@ def test_crystallinity_fused_kernel_128_many_frames_and_every_bin(hip):
     base = rng.normal(size=700).astype(np.float32) * 1e6
     got2, _ = _cryst_run(hip, frames, real_mask, half, accumulate_into=base)
     assert np.allclose(got2, base + got, rtol=1e-6)
-    got3, label3 = _cryst_run(hip, frames[:9], real_mask, half, ld_pad=1)      # odd stride: hipFFT
-    assert label3.startswith('hipfft_r2c<'), label3
+    got3, label3 = _cryst_run(hip, frames[:9], real_mask, half, ld_pad=1)      # odd stride: converted first
+    assert label3 == 'k_fft_prepare<uint16> + k_cryst_fused128<float32> columns=33', label3
     assert np.allclose(got3, ref[:9], rtol=1e-5)
     # single plane waves: one bin each, inside / outside the ring 8 .. 32
     yy, xx = np.mgrid[0:128, 0:128]
@@ -1746,3 +1746,45 @@ def test_crystallinity_fused_kernel_128_many_frames_and_every_bin(hip):
     assert np.allclose(got, ref, rtol=1e-5, atol=128 * 128 * 1e-4), (got, ref)
     inside = ref > 1000
     assert inside.sum() >= 5 and (~inside).sum() >= 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('sig', [128, 256])
+def test_crystallinity_corrected_and_float64_frames_take_the_fused_kernel(hip, sig):
+    """ltmi_crystallinity_corrected on raw frames (dark / gain / dead-pixel patches) and float64 frames: the
+    conversion pass writes corrected float32 frames, the fused kernel transforms those -- against the oracle's
+    corrections + float64 rfft2, more frames than one batch."""
+    from libertem_amd.io.corrections import CorrectionSet
+    from libertem_amd.udf.crystallinity import mask_box
+    from oracle import corrections as oc
+    rng = np.random.default_rng(_seed('cryst-corr', sig))
+    n = 21
+    data = rng.integers(0, 3000, (n, sig, sig)).astype(np.uint16)
+    dark = rng.random((sig, sig)) * 6
+    gain = rng.random((sig, sig)) * 0.6 + 0.7
+    bad = np.zeros((sig, sig), dtype=bool)
+    bad[sig // 2, sig // 2] = bad[0, 0] = bad[10, 40] = bad[10, 41] = bad[sig - 1, sig - 1] = True
+    bad[rng.integers(0, sig, 40), rng.integers(0, sig, 40)] = True
+    coords = [tuple(c) for c in np.argwhere(bad)]
+    real = ((sig // 2, sig // 2), sig // 10)
+    for kw in (dict(dark=dark, gain=gain, excluded_pixels=bad), dict(gain=gain), dict(excluded_pixels=bad)):
+        corrected = oc.correct(data, (sig, sig), dark=kw.get('dark'), gain=kw.get('gain'),
+                               coords=coords if 'excluded_pixels' in kw else None)
+        ref, real_mask, half = _cryst_reference(corrected.reshape(n, sig, sig), sig // 16, sig // 4, real)
+        tables = CorrectionSet(**kw).device_tables(0, (sig, sig))
+        plan = hip.FFTPlan(0, sig, sig, 8)                       # 8 frames per batch: 3 batches
+        t = _dev(data.reshape(n, -1))
+        rm = torch.from_numpy(np.ascontiguousarray(real_mask.astype(np.float32))).cuda()
+        hm = torch.from_numpy(np.ascontiguousarray(half.astype(np.float32))).cuda()
+        out = torch.full((n,), 7.0, dtype=torch.float32, device='cuda')
+        plan.crystallinity_corrected(t.data_ptr(), data.dtype, n, sig * sig, tables, rm.data_ptr(), hm.data_ptr(),
+                                     mask_box(half), out.data_ptr(), False)
+        torch.cuda.synchronize()
+        assert plan.last_kernel().startswith('k_fft_prepare<uint16> + k_cryst_fused'), plan.last_kernel()
+        assert np.allclose(out.cpu().numpy(), ref, rtol=1e-5), sorted(kw)
+        plan.close()
+    frames = rng.normal(size=(n, sig, sig)) * 50
+    ref, real_mask, half = _cryst_reference(frames, sig // 16, sig // 4, real)
+    got, label = _cryst_run(hip, frames, real_mask, half, batch=8)
+    assert label.startswith('k_fft_prepare<float64> + k_cryst_fused'), label
+    assert np.allclose(got, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
