@@ -1,5 +1,6 @@
-// ltmi_cryst.hip -- CrystallinityUDF.process_frame for 256 x 256 frames in ONE kernel (SURVEY.md
-// section 8, row f3; reference udf/crystallinity.py:73-79):
+// ltmi_cryst.hip -- CrystallinityUDF.process_frame for 256 x 256 (k_cryst_fused) and 128 x 128 frames
+// (k_cryst_fused128, second half of this file) in ONE kernel (reference
+// udf/crystallinity.py:73-79):
 //
 //     intensity[f] = sum( abs(rfft2(frame * real_mask)) * half_fourier_mask )
 //
@@ -28,8 +29,8 @@
 //                                               k1 = c0 + 4 c1 + 16 c2 = sigma(lane)
 // Two LDS round trips per transform (a Stockham formulation needs one per pass and one more to bring the
 // row in: that version of this kernel ran 16 384 frames in 1.58 ms, LDS and vector ALUs ~55 % busy each).
-// The XORs make every 16-lane store group and every 32-lane load group a permutation of the banks
-// (SQ_LDS_BANK_CONFLICT = 0).  The column stage reads G[kx] directly in the layout after the first swap.
+// The XORs make every 16-lane store group and every 32-lane load group a permutation of the banks (by the
+// documented bank rules; SQ_LDS_BANK_CONFLICT measures 6 % of the LDS cycles, origin open).  The column stage reads G[kx] directly in the layout after the first swap.
 //
 // G[kx][y]: 258 float2 per column (516 dwords = 4 mod 32: 8 neighbouring columns, 16 bytes each, hit 32
 // banks), y kept at y ^ (2 ((y >> 5) & 1)) ^ (4 ((kx >> 3) & 1)): the first makes the column stage's loads
@@ -37,8 +38,9 @@
 // 8 lanes holds the columns sigma(lane) = {0, 4, 8, 12, 1, 5, 9, 13} + 16 i).
 //
 // LDS: K columns + 2 KiB of row scratch per wave that transforms rows: K = 65 (rad_out 64) leaves room for
-// 14 of the 16 waves; rings with K > CF_KMAX columns, other frame shapes, float64 pixels and fused
-// corrections stay on the hipFFT route.  HBM traffic: the pixels once (+ the two masks from the L2).
+// 14 of the 16 waves; rings with K > CF_KMAX columns and other frame shapes stay on the hipFFT route; float64
+// pixels, odd strides and detector corrections reach this kernel as float32 frames written by the conversion
+// pass (ltmi_fft.hip).  HBM traffic: the pixels once (+ the two masks from the L2).
 #include "ltmi_common.h"
 #include <algorithm>
 #include <type_traits>
