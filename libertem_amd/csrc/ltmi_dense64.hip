@@ -466,7 +466,15 @@ __global__ void k_reduce_partials64(const double *__restrict__ partials, int ksp
     const int col = (int)(idx % n_cols);
     double *p = out + f * ld_out + col;
     double s = accumulate ? *p : 0.;
-    for (int k = 0; k < ksplit; ++k) s += partials[(int64_t)k * n_frames * n_cols + idx];
+    const int64_t stride = n_frames * n_cols;            // (independent loads, added in the order of k: see k_reduce_partials)
+    for (int k0 = 0; k0 < ksplit; k0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partials[(int64_t)min(k0 + u, ksplit - 1) * stride + idx];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + u < ksplit) s += v[u];
+    }
     *p = s;
 }
 
