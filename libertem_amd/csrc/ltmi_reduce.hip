@@ -152,7 +152,14 @@ __global__ void k_reduce_splits(const A *__restrict__ ws, int fsplit, int64_t n,
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     A s = accumulate ? out[i] : (A)0;
-    for (int k = 0; k < fsplit; ++k) s += ws[(int64_t)k * n + i];
+    for (int k0 = 0; k0 < fsplit; k0 += 8) {              // independent loads, added in the order of k
+        A v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ws[(int64_t)min(k0 + u, fsplit - 1) * n + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + u < fsplit) s += v[u];
+    }
     out[i] = s;
 }
 
