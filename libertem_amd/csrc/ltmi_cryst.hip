@@ -400,10 +400,13 @@ int cryst_fused_max_cols() { return CF_KMAX; }
 // rings the fused kernels take (given a tile they can read: see cryst_fused)
 bool cryst_fused_takes(int h, int w, int n_cols) {
     if (h == 128 && w == 128) return n_cols >= 1 && n_cols <= 65;
+    if (h == 512 && w == 512) return n_cols >= 1 && n_cols <= 257;
     return h == 256 && w == 256 && n_cols >= 1 && n_cols <= CF_KMAX;
 }
-bool cryst_fused_shape(int h, int w) { return (h == 256 && w == 256) || (h == 128 && w == 128); }
-int64_t cryst_fused_workspace_floats() { return (int64_t)CF_KMAX * CF_N + CF_N * CF_N + 4; }
+bool cryst_fused_shape(int h, int w) { return (h == 256 && w == 256) || (h == 128 && w == 128) || (h == 512 && w == 512); }
+// 512 x 512 frames pass the ring's columns of the row transforms through a (frames x n_cols x 512) float2 workspace
+bool cryst_fused_needs_gbuf(int h, int w) { return h == 512 && w == 512; }
+int64_t cryst_fused_workspace_floats() { return (int64_t)257 * 512 + 512 * 512 + 8; }     // (the 512 kernels' masks: the largest)
 
 template <typename T, int WAVES>
 static int launch_fused_w(const void *tile, int64_t ld, int64_t n_frames, const float *real_mask,
@@ -704,12 +707,276 @@ static int cryst_fused128(const void *tile, int tile_dtype, int64_t n_frames, in
     return rc;
 }
 
+// ---- 512 x 512 frames: two kernels, the ring's columns of the row transforms through HBM ---------------------------
+// A frame's K columns of row spectra (K <= 257) are 4 KiB each: they do not fit the LDS.  k_cryst_rows512 writes
+// them to a workspace G[frame][kx][y] (float2; K / 128 of the frame's bytes as float32 complex), k_cryst_cols512
+// transforms one column per wave and sums the ring: 2 + 2 * 8 K / 512 bytes of traffic per pixel and no spectrum
+// beyond the ring's columns, where the hipFFT route moves ~34.  A 512-point transform = the two 256-point transforms
+// of the even and the odd samples (cf_core twice: a lane's 8 consecutive samples are 4 even + 4 odd ones, the layout
+// cf_core starts from) and one butterfly:  X[k] = E[k] + w512^k O[k],  X[k + 256] = E[k] - w512^k O[k].
+constexpr int CH_N = 512;
+constexpr int CH_WAVES = 8;
+constexpr int CH_KMAX = CH_N / 2 + 1;
+constexpr int CH_STAGE = 9;                      // float4 units per column of the staging tile: 8 row pairs + 16 bytes
+
+struct ChTw { v2f w[4], wr[4]; };               // w512^(sigma + 64 k2)
+
+__device__ __forceinline__ void ch_lane_setup(int t, CfLane &c, ChTw &h) {
+    const int sig = cf_sigma(t);
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+        double s, co;
+        sincospi(-2.0 * (double)((t & 15) * r) / 64.0, &s, &co);
+        c.tw[0][r - 1] = (v2f){(float)co, (float)s};
+        sincospi(-2.0 * (double)((t & 3) * r) / 16.0, &s, &co);
+        c.tw[1][r - 1] = (v2f){(float)co, (float)s};
+        sincospi(-2.0 * (double)(sig * r) / 256.0, &s, &co);
+        c.tw[2][r - 1] = (v2f){(float)co, (float)s};
+#pragma unroll
+        for (int pi = 0; pi < 3; ++pi) c.twr[pi][r - 1] = (v2f){-c.tw[pi][r - 1].y, c.tw[pi][r - 1].x};
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+        double s, co;
+        sincospi(-2.0 * (double)(sig + 64 * k2) / 512.0, &s, &co);
+        h.w[k2] = (v2f){(float)co, (float)s};
+        h.wr[k2] = (v2f){-(float)s, (float)co};
+    }
+    const int b2 = (t >> 2) & 3, b0 = t & 3;
+    const int base_b = 64 * b2 + t, base_c = 64 * b0 + t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        c.wB[r] = 64 * r + (t ^ (r << 2));
+        c.rB[r] = base_b ^ (r << 2);
+        c.wC[r] = 64 * r + (t ^ r);
+        c.rC[r] = base_c ^ r;
+    }
+}
+
+// ue[j] = z[8 t + 2 j], uo[j] = z[8 t + 2 j + 1]  ->  ue[k2] = X[sigma + 64 k2], uo[k2] = X[sigma + 64 k2 + 256]
+__device__ __forceinline__ void ch_fft512(v2f *scr, const CfLane &c, const ChTw &h, v2f (&ue)[4], v2f (&uo)[4]) {
+    cf_swap_a(ue);
+    cf_core(scr, c, ue);
+    cf_swap_a(uo);
+    cf_core(scr, c, uo);
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+        const v2f w = cf_mul(uo[k2], h.w[k2], h.wr[k2]);
+        uo[k2] = ue[k2] - w;
+        ue[k2] = ue[k2] + w;
+    }
+}
+
+// grid: persistent over groups of 8 row pairs (frame f, pairs 8 g .. 8 g + 7: one per wave).  The 2 x K spectra of a
+// group are staged in the LDS and leave as 128 contiguous bytes per column: G[(f K + kx) 512 + 16 g ..].
+template <typename T, bool MASK>
+__global__ void __launch_bounds__(CH_WAVES * 64)
+k_cryst_rows512(const T *__restrict__ tile, int64_t ld, int64_t n_frames, const float *__restrict__ rmask_p,
+                const unsigned long long *__restrict__ rflags, int K, v2f *__restrict__ G) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cf_smem[];
+    const int t = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    v4f *stage = (v4f *)cf_smem;                                    // [K][CH_STAGE]
+    v2f *scr = (v2f *)(stage + K * CH_STAGE) + w * CF_SCR;
+    const int sig = cf_sigma(t);
+    CfLane c;
+    ChTw h;
+    ch_lane_setup(t, c, h);
+    const int back = cf_sigma((64 - sig) & 63) * 4;
+    const int st_col = sig * CH_STAGE + (w ^ (2 * ((sig >> 3) & 1)));   // + 64 k2 CH_STAGE (kx bit 3 = sigma bit 3)
+    typedef T __attribute__((ext_vector_type(8))) vec_t;
+    const int64_t n_groups = n_frames * (CH_N / 2 / CH_WAVES);
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int64_t f = grp >> 5;
+        const int g = (int)(grp & 31);
+        const int yp = CH_WAVES * g + w;
+        const T *row = tile + f * ld + (int64_t)(2 * yp) * CH_N + 8 * t;
+        const vec_t ra = __builtin_nontemporal_load((const vec_t *)row);
+        const vec_t rb = __builtin_nontemporal_load((const vec_t *)(row + CH_N));
+        v2f ue[4], uo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ue[j] = (v2f){(float)ra[2 * j], (float)rb[2 * j]};
+            uo[j] = (v2f){(float)ra[2 * j + 1], (float)rb[2 * j + 1]};
+        }
+        if (MASK && ((rflags[yp >> 6] >> (yp & 63)) & 1)) {
+            const v4f *m = (const v4f *)(rmask_p + (int64_t)yp * (2 * CH_N) + 16 * t);
+            const v4f m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3];
+            ue[0] *= m0.xy; ue[1] *= m0.zw; ue[2] *= m1.xy; ue[3] *= m1.zw;
+            uo[0] *= m2.xy; uo[1] *= m2.zw; uo[2] *= m3.xy; uo[3] *= m3.zw;
+        }
+        ch_fft512(scr, c, h, ue, uo);
+        // two real rows out of one complex transform (see k_cryst_fused): the partner X[512 - kx] of kx = sigma + 64 k2
+        // is X[256 + (64 - sigma) + 64 (3 - k2)] in the lane of 64 - sigma; sigma = 0: X[0] itself / X[256 + 64 (4 - k2)]
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) {
+            if (64 * k2 >= K) break;
+            const v2f mine = k2 == 0 ? ue[0] : uo[(4 - k2) & 3], theirs = uo[3 - k2];
+            const float gx = t == 0 ? mine.x : theirs.x, gy = t == 0 ? mine.y : theirs.y;
+            const float cr = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(gx)));
+            const float ci = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(gy)));
+            if (sig + 64 * k2 < K)
+                stage[st_col + 64 * k2 * CH_STAGE] =
+                    (v4f){ue[k2].x + cr, ue[k2].y - ci, ue[k2].y + ci, cr - ue[k2].x};
+        }
+        if (K == CH_KMAX && t == 0)                                  // kx = 256 is its own partner
+            stage[256 * CH_STAGE + w] = (v4f){2.f * uo[0].x, 0.f, 2.f * uo[0].y, 0.f};
+        __syncthreads();
+        for (int i = threadIdx.x; i < K * 8; i += CH_WAVES * 64) {
+            const int kx = i >> 3, pi = i & 7;
+            const v4f v = stage[kx * CH_STAGE + (kx < 256 ? pi ^ (2 * ((kx >> 3) & 1)) : pi)];
+            *(v4f *)(G + ((f * K + kx) * CH_N + 16 * g + 2 * pi)) = v;
+        }
+        __syncthreads();
+    }
+}
+
+// one column per wave: 512 points of G -> sum of |F[ky][kx]| * mask; one workgroup per frame (persistent)
+__global__ void __launch_bounds__(CH_WAVES * 64)
+k_cryst_cols512(const v2f *__restrict__ G, int64_t n_frames, const float *__restrict__ mask_p, int K,
+                float *__restrict__ out, int accumulate) {
+    __shared__ __attribute__((aligned(16))) v2f scr_all[CH_WAVES * CF_SCR];
+    __shared__ float part[CH_WAVES];
+    const int t = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    v2f *scr = scr_all + w * CF_SCR;
+    CfLane c;
+    ChTw h;
+    ch_lane_setup(t, c, h);
+    for (int64_t f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        float acc = 0.f;
+        for (int kx = w; kx < K; kx += CH_WAVES) {
+            const v4f *col = (const v4f *)(G + (f * K + kx) * CH_N) + 4 * t;
+            float m[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) m[q] = mask_p[(kx * 8 + q) * 64 + t];
+            v2f ue[4], uo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const v4f q = __builtin_nontemporal_load(col + j);
+                ue[j] = q.xy;
+                uo[j] = q.zw;
+            }
+            ch_fft512(scr, c, h, ue, uo);
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) {
+                if (__builtin_amdgcn_ballot_w64(m[k2] != 0.f)) {
+                    const float a = __builtin_amdgcn_sqrtf(ue[k2].x * ue[k2].x + ue[k2].y * ue[k2].y);
+                    acc += m[k2] != 0.f ? a * m[k2] : 0.f;
+                }
+                if (__builtin_amdgcn_ballot_w64(m[4 + k2] != 0.f)) {
+                    const float a = __builtin_amdgcn_sqrtf(uo[k2].x * uo[k2].x + uo[k2].y * uo[k2].y);
+                    acc += m[4 + k2] != 0.f ? a * m[4 + k2] : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (t == 0) part[w] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < CH_WAVES; ++i) v += part[i];
+            v *= 0.5f;
+            out[f] = accumulate ? out[f] + v : v;
+        }
+        __syncthreads();
+    }
+}
+
+// masks of the 512 kernels in lane order:
+//   mask_p[kx][q][l]     = half_mask[sigma(l) + 64 (q & 3) + 256 (q >> 2)][kx]
+//   rmask_p[y'][16 t + e] = real_mask[2 y' + (e & 1)][8 t + 2 ((e >> 1) & 3) + (e >> 3)]   (even samples first, a / b interleaved)
+//   rflags bit y' (4 words): the pair holds a value other than 1
+__global__ void __launch_bounds__(256)
+k_cryst_masks512(const float *__restrict__ half_mask, int K, float *__restrict__ mask_p,
+                 const float *__restrict__ real_mask, float *__restrict__ rmask_p,
+                 unsigned long long *__restrict__ rflags) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < K * 512) {
+        const int kx = i >> 9, q = (i >> 6) & 7, l = i & 63;
+        const int ky = cf_sigma(l) + 64 * (q & 3) + 256 * (q >> 2);
+        mask_p[i] = half_mask[ky * CH_KMAX + kx];
+    }
+    if (real_mask && i < CH_N * CH_N) {
+        const int yp = i >> 10, rem = i & 1023, tt = rem >> 4, e = rem & 15;
+        const float v = real_mask[(2 * yp + (e & 1)) * CH_N + 8 * tt + 2 * ((e >> 1) & 3) + (e >> 3)];
+        rmask_p[i] = v;
+        if (__builtin_amdgcn_ballot_w64(v != 1.f) && (threadIdx.x & 63) == 0)
+            atomicOr(&rflags[yp >> 6], 1ull << (yp & 63));
+    }
+}
+
+template <typename T>
+static int launch_rows512(const void *tile, int64_t ld, int64_t n_frames, const float *real_mask,
+                          const unsigned long long *rflags, int K, v2f *G, int n_cu, hipStream_t stream) {
+    auto kern = real_mask ? k_cryst_rows512<T, true> : k_cryst_rows512<T, false>;
+    const int lds = K * CH_STAGE * 16 + CH_WAVES * CF_SCR * 8;
+    int device = 0;
+    LTMI_HIP(hipGetDevice(&device));
+    static bool attr_set[16][2] = {{false}};
+    if (!attr_set[device & 15][real_mask ? 1 : 0]) {
+        LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     CH_KMAX * CH_STAGE * 16 + CH_WAVES * CF_SCR * 8));
+        attr_set[device & 15][real_mask ? 1 : 0] = true;
+    }
+    const int64_t groups = n_frames * 32;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(groups, (int64_t)n_cu * 3));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(CH_WAVES * 64), (size_t)lds, stream, (const T *)tile, ld, n_frames,
+                       real_mask, rflags, K, G);
+    LTMI_HIP(hipGetLastError());
+    return LTMI_OK;
+}
+
+// 512 x 512 frames; gbuf: workspace of gbuf_frames * n_cols * 512 float2
+static int cryst_rows_cols512(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, const float *real_mask,
+                              const float *half_mask, int n_cols, float *work, void *gbuf, int64_t gbuf_frames,
+                              float *out, int accumulate, int n_cu, hipStream_t stream, bool *handled) {
+    if (n_cols < 1 || n_cols > CH_KMAX || !gbuf || gbuf_frames < 1) return LTMI_OK;
+    const size_t esz = (size_t)dtype_size(tile_dtype);
+    if (esz > 4 || tile_dtype == LTMI_F64) return LTMI_OK;
+    if ((uintptr_t)tile % (8 * esz) != 0 || ld % 8 != 0) return LTMI_OK;
+    float *mask_p = work, *rmask_p = work + (int64_t)CH_KMAX * 512;
+    unsigned long long *rflags = (unsigned long long *)(rmask_p + CH_N * CH_N);
+    LTMI_HIP(hipMemsetAsync(rflags, 0, 32, stream));
+    hipLaunchKernelGGL(k_cryst_masks512, dim3((unsigned)(CH_N * CH_N / 256)), dim3(256), 0, stream, half_mask,
+                       n_cols, mask_p, real_mask, rmask_p, rflags);
+    const float *rm = real_mask ? rmask_p : nullptr;
+    for (int64_t f0 = 0; f0 < n_frames; f0 += gbuf_frames) {
+        const int64_t n = std::min<int64_t>(gbuf_frames, n_frames - f0);
+        const void *src = (const char *)tile + (size_t)f0 * ld * esz;
+        int rc = LTMI_E_DTYPE;
+        switch (tile_dtype) {
+            case LTMI_BOOL:
+            case LTMI_U8: rc = launch_rows512<uint8_t>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
+            case LTMI_I8: rc = launch_rows512<int8_t>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
+            case LTMI_U16: rc = launch_rows512<uint16_t>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
+            case LTMI_I16: rc = launch_rows512<int16_t>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
+            case LTMI_U32: rc = launch_rows512<uint32_t>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
+            case LTMI_I32: rc = launch_rows512<int32_t>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
+            case LTMI_F32: rc = launch_rows512<float>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
+            default: return LTMI_OK;
+        }
+        if (rc != LTMI_OK) return rc;
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)n_cu * 4));
+        hipLaunchKernelGGL(k_cryst_cols512, dim3(grid), dim3(CH_WAVES * 64), 0, stream, (const v2f *)gbuf, n,
+                           (const float *)mask_p, n_cols, out + f0, accumulate);
+        LTMI_HIP(hipGetLastError());
+    }
+    *handled = true;
+    return LTMI_OK;
+}
+
 // -> LTMI_OK with *handled = true when a fused kernel ran (256 x 256 or 128 x 128 frames)
 int cryst_fused(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, int sig_h, int sig_w,
-                const float *real_mask, const float *half_mask, int n_cols, float *mask_t, float *out,
-                int accumulate, int n_cu, hipStream_t stream, bool *handled) {
+                const float *real_mask, const float *half_mask, int n_cols, float *mask_t, void *gbuf,
+                int64_t gbuf_frames, float *out, int accumulate, int n_cu, hipStream_t stream, bool *handled) {
     *handled = false;
     if (!mask_t) return LTMI_OK;
+    if (sig_h == CH_N && sig_w == CH_N)
+        return cryst_rows_cols512(tile, tile_dtype, n_frames, ld, real_mask, half_mask, n_cols, mask_t, gbuf,
+                                  gbuf_frames, out, accumulate, n_cu, stream, handled);
     if (sig_h == CG_N && sig_w == CG_N)
         return cryst_fused128(tile, tile_dtype, n_frames, ld, real_mask, half_mask, n_cols, mask_t, out, accumulate,
                               n_cu, stream, handled);

@@ -236,6 +236,18 @@ static int real_buf_ready(ltmi_fft_plan *p) {
     return LTMI_OK;
 }
 
+// (batch x half spectrum) complex workspace of a plan, created on first use: hipFFT's output, or the columns
+// the 512 x 512 kernels pass from the row to the column transforms
+static int spec_ready(ltmi_fft_plan *p) {
+    if (p->spec) return LTMI_OK;
+    hipError_t e = hipMalloc((void **)&p->spec, (size_t)p->batch * p->h * p->wc * sizeof(hipfftComplex));
+    if (e != hipSuccess) {
+        p->spec = nullptr;
+        LTMI_FAIL((int)e, "ltmi_fft_plan: workspace allocation failed: %s", hipGetErrorString(e));
+    }
+    return LTMI_OK;
+}
+
 // the hipFFT plan + workspace of a plan, created on first use
 static int hipfft_route_ready(ltmi_fft_plan *p) {
     if (p->have_plan) return LTMI_OK;
@@ -249,10 +261,12 @@ static int hipfft_route_ready(ltmi_fft_plan *p) {
     if (r != HIPFFT_SUCCESS)
         LTMI_FAIL(LTMI_E_INVALID, "hipfftPlanMany(%d x %d, batch %d) failed: %s", p->h, p->w, p->batch,
                   fft_err(r));
-    hipError_t e = hipMalloc((void **)&p->spec, (size_t)p->batch * p->h * p->wc * sizeof(hipfftComplex));
-    if (e != hipSuccess) {
-        (void)hipfftDestroy(p->plan);
-        LTMI_FAIL((int)e, "ltmi_fft_plan: workspace allocation failed: %s", hipGetErrorString(e));
+    {
+        const int rc = spec_ready(p);
+        if (rc != LTMI_OK) {
+            (void)hipfftDestroy(p->plan);
+            return rc;
+        }
     }
     p->have_plan = true;
     return LTMI_OK;
@@ -380,12 +394,21 @@ static int crystallinity_impl(ltmi_fft_plan *p, const void *tile, int tile_dtype
                   row_hi, n_cols);
     if (p->fused_ok && !corr.dark && !corr.gain && corr.n_excl == 0) {
         bool handled = false;
+        if (cryst_fused_needs_gbuf(p->h, p->w)) {
+            const int rc1 = spec_ready(p);
+            if (rc1 != LTMI_OK) return rc1;
+        }
         const int rc = cryst_fused(tile, tile_dtype, n_frames, ld_tile, p->h, p->w, real_mask, half_mask,
-                                   n_cols, p->mask_t, out, accumulate, p->n_cu, stream, &handled);
+                                   n_cols, p->mask_t, p->spec, p->batch, out, accumulate, p->n_cu, stream,
+                                   &handled);
         if (rc != LTMI_OK) return rc;
         if (handled) {
-            snprintf(p->last_kernel, sizeof(p->last_kernel), "k_cryst_fused%s<%s%s> columns=%d",
-                     p->h == 128 ? "128" : "", dtype_name(tile_dtype), real_mask ? ",mask" : "", n_cols);
+            if (p->h == 512)
+                snprintf(p->last_kernel, sizeof(p->last_kernel), "k_cryst_rows512<%s%s> + k_cryst_cols512 columns=%d",
+                         dtype_name(tile_dtype), real_mask ? ",mask" : "", n_cols);
+            else
+                snprintf(p->last_kernel, sizeof(p->last_kernel), "k_cryst_fused%s<%s%s> columns=%d",
+                         p->h == 128 ? "128" : "", dtype_name(tile_dtype), real_mask ? ",mask" : "", n_cols);
             return LTMI_OK;
         }
     }
@@ -395,6 +418,10 @@ static int crystallinity_impl(ltmi_fft_plan *p, const void *tile, int tile_dtype
         // kernel takes those instead of two rocFFT passes over a (batch x half spectrum) workspace
         const int rc0 = real_buf_ready(p);
         if (rc0 != LTMI_OK) return rc0;
+        if (cryst_fused_needs_gbuf(p->h, p->w)) {
+            const int rc1 = spec_ready(p);
+            if (rc1 != LTMI_OK) return rc1;
+        }
         for (int64_t f0 = 0; f0 < n_frames; f0 += p->batch) {
             const int64_t n = std::min<int64_t>(p->batch, n_frames - f0);
             const void *src = (const char *)tile + (size_t)f0 * ld_tile * esz;
@@ -402,12 +429,16 @@ static int crystallinity_impl(ltmi_fft_plan *p, const void *tile, int tile_dtype
             if (rc != LTMI_OK) return rc;
             bool handled = false;
             rc = cryst_fused(p->real_buf, LTMI_F32, n, n_px, p->h, p->w, nullptr, half_mask, n_cols, p->mask_t,
-                             out + f0, accumulate, p->n_cu, stream, &handled);
+                             p->spec, p->batch, out + f0, accumulate, p->n_cu, stream, &handled);
             if (rc != LTMI_OK) return rc;
             if (!handled) LTMI_FAIL(LTMI_E_INVALID, "ltmi_crystallinity: the fused kernel refused its own workspace");
         }
-        snprintf(p->last_kernel, sizeof(p->last_kernel), "k_fft_prepare<%s> + k_cryst_fused%s<float32> columns=%d",
-                 dtype_name(tile_dtype), p->h == 128 ? "128" : "", n_cols);
+        if (p->h == 512)
+            snprintf(p->last_kernel, sizeof(p->last_kernel),
+                     "k_fft_prepare<%s> + k_cryst_rows512<float32> + k_cryst_cols512 columns=%d", dtype_name(tile_dtype), n_cols);
+        else
+            snprintf(p->last_kernel, sizeof(p->last_kernel), "k_fft_prepare<%s> + k_cryst_fused%s<float32> columns=%d",
+                     dtype_name(tile_dtype), p->h == 128 ? "128" : "", n_cols);
         return LTMI_OK;
     }
     snprintf(p->last_kernel, sizeof(p->last_kernel), "hipfft_r2c<%s> batch=%d", dtype_name(tile_dtype),

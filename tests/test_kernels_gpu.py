@@ -1749,7 +1749,7 @@ def test_crystallinity_fused_kernel_128_many_frames_and_every_bin(hip):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('sig', [128, 256])
+@pytest.mark.parametrize('sig', [128, 256, 512])
 def test_crystallinity_corrected_and_float64_frames_take_the_fused_kernel(hip, sig):
     """ltmi_crystallinity_corrected on raw frames (dark / gain / dead-pixel patches) and float64 frames: the
     conversion pass writes corrected float32 frames, the fused kernel transforms those -- against the oracle's
@@ -1780,11 +1780,67 @@ def test_crystallinity_corrected_and_float64_frames_take_the_fused_kernel(hip, s
         plan.crystallinity_corrected(t.data_ptr(), data.dtype, n, sig * sig, tables, rm.data_ptr(), hm.data_ptr(),
                                      mask_box(half), out.data_ptr(), False)
         torch.cuda.synchronize()
-        assert plan.last_kernel().startswith('k_fft_prepare<uint16> + k_cryst_fused'), plan.last_kernel()
+        assert plan.last_kernel().startswith('k_fft_prepare<uint16> + k_cryst_'), plan.last_kernel()
         assert np.allclose(out.cpu().numpy(), ref, rtol=1e-5), sorted(kw)
         plan.close()
     frames = rng.normal(size=(n, sig, sig)) * 50
     ref, real_mask, half = _cryst_reference(frames, sig // 16, sig // 4, real)
     got, label = _cryst_run(hip, frames, real_mask, half, batch=8)
-    assert label.startswith('k_fft_prepare<float64> + k_cryst_fused'), label
+    assert label.startswith('k_fft_prepare<float64> + k_cryst_'), label
     assert np.allclose(got, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['uint8', 'uint16', 'int16', 'int32', 'float32'])
+@pytest.mark.parametrize('rad_in,rad_out,real', [(32, 128, ((256, 256), 50)), (0, 40, None),
+                                                 (100, 300, ((200.5, 280), 61.5)), (10, 63.5, None)])
+def test_crystallinity_512_rows_and_columns_kernels(hip, dtype, rad_in, rad_out, real):
+    """512 x 512 frames: k_cryst_rows512 (the ring's columns of the row transforms into a workspace) +
+    k_cryst_cols512 (one column per wave); rings up to the full half spectrum (257 columns), more frames than the
+    workspace holds at once (batch 4)."""
+    rng = np.random.default_rng(_seed('cryst512', dtype, rad_out))
+    dt = np.dtype(dtype)
+    n = 7
+    if dt.kind == 'f':
+        frames = rng.normal(size=(n, 512, 512)).astype(dt) * 100
+    else:
+        info = np.iinfo(dt)
+        frames = rng.integers(max(info.min, -4000), min(info.max, 4000), size=(n, 512, 512),
+                              endpoint=True).astype(dt)
+    frames[2] = 0
+    frames[5, 140:150, 390:400] += 17
+    ref, real_mask, half = _cryst_reference(frames, rad_in, rad_out, real)
+    got, label = _cryst_run(hip, frames, real_mask, half, batch=4)
+    assert label.startswith('k_cryst_rows512<'), label
+    assert np.allclose(got, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max()), (got, ref)
+    assert got[2] == 0
+
+
+@pytest.mark.gpu
+def test_crystallinity_512_accumulate_strides_and_every_bin(hip):
+    rng = np.random.default_rng(_seed('cryst512-many'))
+    frames = rng.integers(0, 4096, size=(40, 512, 512)).astype(np.uint16)
+    ref, real_mask, half = _cryst_reference(frames, 32, 128, ((256, 256), 50))
+    got, label = _cryst_run(hip, frames, real_mask, half, ld_pad=8, batch=16)
+    assert label == 'k_cryst_rows512<uint16,mask> + k_cryst_cols512 columns=129', label
+    assert np.allclose(got, ref, rtol=1e-5)
+    base = rng.normal(size=40).astype(np.float32) * 1e6
+    got2, _ = _cryst_run(hip, frames, real_mask, half, accumulate_into=base, batch=16)
+    assert np.allclose(got2, base + got, rtol=1e-6)
+    got3, label3 = _cryst_run(hip, frames[:5], real_mask, half, ld_pad=1, batch=4)      # odd stride: converted first
+    assert label3 == 'k_fft_prepare<uint16> + k_cryst_rows512<float32> + k_cryst_cols512 columns=129', label3
+    assert np.allclose(got3, ref[:5], rtol=1e-5)
+    yy, xx = np.mgrid[0:512, 0:512]
+    waves = [(0, 0), (0, 128), (0, 129), (128, 0), (384, 0), (383, 0), (90, 90), (92, 92), (511, 32), (32, 0), (31, 0),
+             (400, 80), (256, 256), (3, 127), (0, 256), (256, 0)]
+    pw = np.stack([np.cos(2 * np.pi * (ky * yy + kx * xx) / 512) for ky, kx in waves]).astype(np.float32)
+    ref, _, half = _cryst_reference(pw, 32, 128, None)
+    got, label = _cryst_run(hip, pw, None, half)
+    assert label.startswith('k_cryst_rows512<'), label
+    assert np.allclose(got, ref, rtol=1e-5, atol=512 * 512 * 1e-4), (got, ref)
+    inside = ref > 10000
+    assert inside.sum() >= 5 and (~inside).sum() >= 5
+    ref, _, half = _cryst_reference(pw, 100, 400, None)          # all 257 columns: the bins (0, 256), (256, 256) count
+    got, label = _cryst_run(hip, pw, None, half)
+    assert label.endswith('columns=257'), label
+    assert np.allclose(got, ref, rtol=1e-5, atol=512 * 512 * 1e-4), (got, ref)
