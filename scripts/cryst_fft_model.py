@@ -175,3 +175,37 @@ for q in (0,5):
       for g in range(4):
         assert len(set(addr[16*g:16*g+16]%16))==16
 print('store banks ok')
+
+
+# ---- third part: 512-point transforms (k_cryst_rows512 / k_cryst_cols512): cf_core on the even and the odd samples +
+# one butterfly; separation of two real rows with the partner X[512 - kx] in the lane of 64 - sigma
+N=512
+rng=np.random.default_rng(2)
+def fft512(z):   # z natural (512); returns lo[k2][l] = X[sigma+64k2], hi = X[.. + 256]
+    ue=[z[8*l+2*j] for j in range(4)]; uo=[z[8*l+2*j+1] for j in range(4)]
+    Ue=fft_core(swapA(ue)); Uo=fft_core(swapA(uo))
+    lo=[];hi=[]
+    for k2 in range(4):
+        w=Uo[k2]*np.exp(-2j*np.pi*(sigma+64*k2)/512)
+        lo.append(Ue[k2]+w); hi.append(Ue[k2]-w)
+    return lo,hi
+z=rng.normal(size=N)+1j*rng.normal(size=N)
+lo,hi=fft512(z)
+X=np.fft.fft(z)
+for k2 in range(4):
+    assert np.allclose(lo[k2],X[sigma+64*k2]) and np.allclose(hi[k2],X[sigma+64*k2+256])
+print('fft512 ok')
+a=rng.normal(size=N); b=rng.normal(size=N)
+lo,hi=fft512(a+1j*b)
+A=np.fft.fft(a); B=np.fft.fft(b)
+back=sigma[(-sigma)%64]
+for k2 in range(4):
+    give=np.where(l==0, lo[0] if k2==0 else hi[(4-k2)%4], hi[3-k2])
+    other=give[back]
+    zk=lo[k2]; kx=sigma+64*k2
+    S=(zk.real+other.real)+1j*(zk.imag-other.imag); D=(zk.imag+other.imag)+1j*(other.real-zk.real)
+    assert np.allclose(S,2*A[kx]) and np.allclose(D,2*B[kx]), k2
+# kx = 256
+zk=hi[0][0]; S=2*zk.real; D=2*zk.imag
+assert np.allclose(S,2*A[256]) and np.allclose(D,2*B[256])
+print('sep512 ok')

@@ -20,6 +20,14 @@ SIG=128 N=65536 RAD_OUT=32 MASK=0 python $R/scripts/bench_cryst_kernel.py 2>&1 |
 SIG=128 N=65536 RAD_OUT=32 LTMI_FFT_FUSED=0 python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s"
 SIG=128 SCAN=512 python $R/scripts/bench_crystallinity.py 2>&1 | grep "Mframes"
 SIG=128 SCAN=512 LTMI_FFT_FUSED=0 python $R/scripts/bench_crystallinity.py 2>&1 | grep "Mframes" | sed 's/^/LTMI_FFT_FUSED=0: /'
+echo "== 512 x 512 frames (k_cryst_rows512 + k_cryst_cols512; 4 096 frames, 1 024 per pass of the workspace)"
+for r in 64 128 256; do SIG=512 N=4096 RAD_OUT=$r python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s" | sed "s/^/rad_out $r: /"; done
+for d in uint8 float32; do SIG=512 N=4096 RAD_OUT=128 DTYPE=$d python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s"; done
+SIG=512 N=4096 RAD_OUT=128 LTMI_FFT_FUSED=0 python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s"
+SIG=512 SCAN=128 python $R/scripts/bench_crystallinity.py 2>&1 | grep "Mframes"
+SIG=512 SCAN=128 LTMI_FFT_FUSED=0 python $R/scripts/bench_crystallinity.py 2>&1 | grep "Mframes" | sed 's/^/LTMI_FFT_FUSED=0: /'
+echo "== corrected frames (dark + gain + 50 dead pixels through the conversion pass, then the same kernels)"
+for sg in 128 256 512; do for fu in 1 0; do CORR=1 SIG=$sg N=$((sg == 512 ? 4096 : 16384)) LTMI_FFT_FUSED=$fu python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s" | sed "s/^/sig $sg LTMI_FFT_FUSED=$fu: /"; done; done
 echo "== timing-only ablations of k_cryst_fused<uint16,mask> (LTMI_CRYST_ABLATE; results are garbage)"
 for a in 1 2 3 4 5; do LTMI_CRYST_ABLATE=$a python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s" | sed "s/^/ablation $a: /"; done
 ) > $O 2>&1
