@@ -402,12 +402,17 @@ int cryst_fused_max_cols() { return CF_KMAX; }
 bool cryst_fused_takes(int h, int w, int n_cols) {
     if (h == 128 && w == 128) return n_cols >= 1 && n_cols <= 65;
     if (h == 512 && w == 512) return n_cols >= 1 && n_cols <= 257;
+    if (h == 1024 && w == 1024) return n_cols >= 1 && n_cols <= 513;
     return h == 256 && w == 256 && n_cols >= 1 && n_cols <= CF_KMAX;
 }
-bool cryst_fused_shape(int h, int w) { return (h == 256 && w == 256) || (h == 128 && w == 128) || (h == 512 && w == 512); }
+bool cryst_fused_shape(int h, int w) { return h == w && (h == 128 || h == 256 || h == 512 || h == 1024); }
 // 512 x 512 frames pass the ring's columns of the row transforms through a (frames x n_cols x 512) float2 workspace
-bool cryst_fused_needs_gbuf(int h, int w) { return h == 512 && w == 512; }
-int64_t cryst_fused_workspace_floats() { return (int64_t)257 * 512 + 512 * 512 + 8; }     // (the 512 kernels' masks: the largest)
+bool cryst_fused_needs_gbuf(int h, int w) { return h == w && (h == 512 || h == 1024); }
+// the masks in lane order (+ flags): what the kernels of an h x h plan need
+int64_t cryst_fused_workspace_floats(int h) {
+    if (h >= 512) return (int64_t)(h / 2 + 1) * h + (int64_t)h * h + 16;
+    return (int64_t)CF_KMAX * CF_N + CF_N * CF_N + 8;
+}
 
 template <typename T, int WAVES>
 static int launch_fused_w(const void *tile, int64_t ld, int64_t n_frames, const float *real_mask,
@@ -708,21 +713,20 @@ static int cryst_fused128(const void *tile, int tile_dtype, int64_t n_frames, in
     return rc;
 }
 
-// ---- 512 x 512 frames: two kernels, the ring's columns of the row transforms through HBM ---------------------------
-// A frame's K columns of row spectra (K <= 257) are 4 KiB each: they do not fit the LDS.  k_cryst_rows512 writes
-// them to a workspace G[frame][kx][y] (float2; K / 128 of the frame's bytes as float32 complex), k_cryst_cols512
-// transforms one column per wave and sums the ring: 2 + 2 * 8 K / 512 bytes of traffic per pixel and no spectrum
-// beyond the ring's columns, where the hipFFT route moves ~34.  A 512-point transform = the two 256-point transforms
-// of the even and the odd samples (cf_core twice: a lane's 8 consecutive samples are 4 even + 4 odd ones, the layout
-// cf_core starts from) and one butterfly:  X[k] = E[k] + w512^k O[k],  X[k + 256] = E[k] - w512^k O[k].
-constexpr int CH_N = 512;
+// ---- 512 x 512 and 1024 x 1024 frames: two kernels, the ring's columns of the row transforms through HBM -------
+// A frame's K columns of row spectra (K <= N / 2 + 1) are 8 N bytes each: they do not fit the LDS.  k_cryst_rows
+// writes them to a workspace G[frame][kx][y] (float2), k_cryst_cols transforms one column per wave and sums the
+// ring: 2 + 2 * 8 K / N bytes of traffic per pixel and no spectrum beyond the ring's columns, where the hipFFT route
+// moves ~34.  An N = 256 M point transform (M = 2, 4) = the M 256-point transforms of the samples n = q mod M
+// (cf_core M times: a lane's 4 M consecutive samples are 4 of each, the layout cf_core starts from), twiddles
+// w_N^(q k) and one radix-M butterfly over q:  X[k + 256 m] = sum_q (-i)^(q m) [for M = 4] w_N^(q k) E_q[k].
 constexpr int CH_WAVES = 8;
-constexpr int CH_KMAX = CH_N / 2 + 1;
 constexpr int CH_STAGE = 9;                      // float4 units per column of the staging tile: 8 row pairs + 16 bytes
 
-struct ChTw { v2f w[4], wr[4]; };               // w512^(sigma + 64 k2)
+template <int M> struct ChTw { v2f w[M - 1][4], wr[M - 1][4]; };   // w_N^(q (sigma + 64 k2)), q = 1 .. M - 1
 
-__device__ __forceinline__ void ch_lane_setup(int t, CfLane &c, ChTw &h) {
+template <int M>
+__device__ __forceinline__ void ch_lane_setup(int t, CfLane &c, ChTw<M> &h) {
     const int sig = cf_sigma(t);
 #pragma unroll
     for (int r = 1; r < 4; ++r) {
@@ -737,12 +741,14 @@ __device__ __forceinline__ void ch_lane_setup(int t, CfLane &c, ChTw &h) {
         for (int pi = 0; pi < 3; ++pi) c.twr[pi][r - 1] = (v2f){-c.tw[pi][r - 1].y, c.tw[pi][r - 1].x};
     }
 #pragma unroll
-    for (int k2 = 0; k2 < 4; ++k2) {
-        double s, co;
-        sincospi(-2.0 * (double)(sig + 64 * k2) / 512.0, &s, &co);
-        h.w[k2] = (v2f){(float)co, (float)s};
-        h.wr[k2] = (v2f){-(float)s, (float)co};
-    }
+    for (int q = 1; q < M; ++q)
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) {
+            double s, co;
+            sincospi(-2.0 * (double)(q * (sig + 64 * k2)) / (double)(256 * M), &s, &co);
+            h.w[q - 1][k2] = (v2f){(float)co, (float)s};
+            h.wr[q - 1][k2] = (v2f){-(float)s, (float)co};
+        }
     const int b2 = (t >> 2) & 3, b0 = t & 3;
     const int base_b = 64 * b2 + t, base_c = 64 * b0 + t;
 #pragma unroll
@@ -754,26 +760,39 @@ __device__ __forceinline__ void ch_lane_setup(int t, CfLane &c, ChTw &h) {
     }
 }
 
-// ue[j] = z[8 t + 2 j], uo[j] = z[8 t + 2 j + 1]  ->  ue[k2] = X[sigma + 64 k2], uo[k2] = X[sigma + 64 k2 + 256]
-__device__ __forceinline__ void ch_fft512(v2f *scr, const CfLane &c, const ChTw &h, v2f (&ue)[4], v2f (&uo)[4]) {
-    cf_swap_a(ue);
-    cf_core(scr, c, ue);
-    cf_swap_a(uo);
-    cf_core(scr, c, uo);
+// u[q][j] = z[4 M t + M j + q]  ->  u[m][k2] = X[sigma + 64 k2 + 256 m]
+template <int M>
+__device__ __forceinline__ void ch_fft(v2f *scr, const CfLane &c, const ChTw<M> &h, v2f (&u)[M][4]) {
+#pragma unroll
+    for (int q = 0; q < M; ++q) {
+        cf_swap_a(u[q]);
+        cf_core(scr, c, u[q]);
+    }
 #pragma unroll
     for (int k2 = 0; k2 < 4; ++k2) {
-        const v2f w = cf_mul(uo[k2], h.w[k2], h.wr[k2]);
-        uo[k2] = ue[k2] - w;
-        ue[k2] = ue[k2] + w;
+        if (M == 2) {
+            const v2f w = cf_mul(u[1][k2], h.w[0][k2], h.wr[0][k2]);
+            u[1][k2] = u[0][k2] - w;
+            u[0][k2] = u[0][k2] + w;
+        } else {
+            v2f b[4];
+            b[0] = u[0][k2];
+#pragma unroll
+            for (int q = 1; q < M; ++q) b[q] = cf_mul(u[q][k2], h.w[q - 1][k2], h.wr[q - 1][k2]);
+            cf_bfly<true>(b);
+#pragma unroll
+            for (int q = 0; q < M; ++q) u[q][k2] = b[q];
+        }
     }
 }
 
 // grid: persistent over groups of 8 row pairs (frame f, pairs 8 g .. 8 g + 7: one per wave).  The 2 x K spectra of a
-// group are staged in the LDS and leave as 128 contiguous bytes per column: G[(f K + kx) 512 + 16 g ..].
-template <typename T, bool MASK>
+// group are staged in the LDS and leave as 128 contiguous bytes per column: G[(f K + kx) N + 16 g ..].
+template <typename T, bool MASK, int M>
 __global__ void __launch_bounds__(CH_WAVES * 64)
-k_cryst_rows512(const T *__restrict__ tile, int64_t ld, int64_t n_frames, const float *__restrict__ rmask_p,
-                const unsigned long long *__restrict__ rflags, int K, v2f *__restrict__ G) {
+k_cryst_rows(const T *__restrict__ tile, int64_t ld, int64_t n_frames, const float *__restrict__ rmask_p,
+             const unsigned long long *__restrict__ rflags, int K, v2f *__restrict__ G) {
+    constexpr int N = 256 * M;
     extern __shared__ __attribute__((aligned(16))) unsigned char cf_smem[];
     const int t = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -781,95 +800,96 @@ k_cryst_rows512(const T *__restrict__ tile, int64_t ld, int64_t n_frames, const 
     v2f *scr = (v2f *)(stage + K * CH_STAGE) + w * CF_SCR;
     const int sig = cf_sigma(t);
     CfLane c;
-    ChTw h;
-    ch_lane_setup(t, c, h);
+    ChTw<M> h;
+    ch_lane_setup<M>(t, c, h);
     const int back = cf_sigma((64 - sig) & 63) * 4;
-    const int st_col = sig * CH_STAGE + (w ^ (2 * ((sig >> 3) & 1)));   // + 64 k2 CH_STAGE (kx bit 3 = sigma bit 3)
-    typedef T __attribute__((ext_vector_type(8))) vec_t;
-    const int64_t n_groups = n_frames * (CH_N / 2 / CH_WAVES);
+    const int st_col = sig * CH_STAGE + (w ^ (2 * ((sig >> 3) & 1)));   // + 64 c CH_STAGE (kx bit 3 = sigma bit 3)
+    typedef T __attribute__((ext_vector_type(4 * M))) vec_t;
+    constexpr int GROUPS = N / 2 / CH_WAVES;                        // per frame
+    const int64_t n_groups = n_frames * GROUPS;
     for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-        const int64_t f = grp >> 5;
-        const int g = (int)(grp & 31);
+        const int64_t f = grp / GROUPS;
+        const int g = (int)(grp - f * GROUPS);
         const int yp = CH_WAVES * g + w;
-        const T *row = tile + f * ld + (int64_t)(2 * yp) * CH_N + 8 * t;
+        const T *row = tile + f * ld + (int64_t)(2 * yp) * N + 4 * M * t;
         const vec_t ra = __builtin_nontemporal_load((const vec_t *)row);
-        const vec_t rb = __builtin_nontemporal_load((const vec_t *)(row + CH_N));
-        v2f ue[4], uo[4];
+        const vec_t rb = __builtin_nontemporal_load((const vec_t *)(row + N));
+        v2f u[M][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            ue[j] = (v2f){(float)ra[2 * j], (float)rb[2 * j]};
-            uo[j] = (v2f){(float)ra[2 * j + 1], (float)rb[2 * j + 1]};
-        }
+        for (int q = 0; q < M; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u[q][j] = (v2f){(float)ra[M * j + q], (float)rb[M * j + q]};
         if (MASK && ((rflags[yp >> 6] >> (yp & 63)) & 1)) {
-            const v4f *m = (const v4f *)(rmask_p + (int64_t)yp * (2 * CH_N) + 16 * t);
-            const v4f m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3];
-            ue[0] *= m0.xy; ue[1] *= m0.zw; ue[2] *= m1.xy; ue[3] *= m1.zw;
-            uo[0] *= m2.xy; uo[1] *= m2.zw; uo[2] *= m3.xy; uo[3] *= m3.zw;
-        }
-        ch_fft512(scr, c, h, ue, uo);
-        // two real rows out of one complex transform (see k_cryst_fused): the partner X[512 - kx] of kx = sigma + 64 k2
-        // is X[256 + (64 - sigma) + 64 (3 - k2)] in the lane of 64 - sigma; sigma = 0: X[0] itself / X[256 + 64 (4 - k2)]
+            const v4f *mk = (const v4f *)(rmask_p + (int64_t)yp * (2 * N) + 8 * M * t);
 #pragma unroll
-        for (int k2 = 0; k2 < 4; ++k2) {
-            if (64 * k2 >= K) break;
-            const v2f mine = k2 == 0 ? ue[0] : uo[(4 - k2) & 3], theirs = uo[3 - k2];
+            for (int q = 0; q < M; ++q) {
+                const v4f m0 = mk[2 * q], m1 = mk[2 * q + 1];
+                u[q][0] *= m0.xy; u[q][1] *= m0.zw; u[q][2] *= m1.xy; u[q][3] *= m1.zw;
+            }
+        }
+        ch_fft<M>(scr, c, h, u);
+        // two real rows out of one complex transform (see k_cryst_fused): the partner X[N - kx] of kx = sigma + 64 c
+        // (c = k2 + 4 m) is block 4 M - 1 - c of the lane of 64 - sigma; sigma = 0: X[0] itself / block 4 M - c of lane 0
+#pragma unroll
+        for (int cb = 0; cb < 2 * M; ++cb) {
+            if (64 * cb >= K) break;
+            const int k2 = cb & 3, m = cb >> 2, cp = (4 * M - cb) % (4 * M);
+            const v2f mine = u[cp >> 2][cp & 3], theirs = u[M - 1 - m][3 - k2], zk = u[m][k2];
             const float gx = t == 0 ? mine.x : theirs.x, gy = t == 0 ? mine.y : theirs.y;
             const float cr = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(gx)));
             const float ci = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(gy)));
-            if (sig + 64 * k2 < K)
-                stage[st_col + 64 * k2 * CH_STAGE] =
-                    (v4f){ue[k2].x + cr, ue[k2].y - ci, ue[k2].y + ci, cr - ue[k2].x};
+            if (sig + 64 * cb < K)
+                stage[st_col + 64 * cb * CH_STAGE] = (v4f){zk.x + cr, zk.y - ci, zk.y + ci, cr - zk.x};
         }
-        if (K == CH_KMAX && t == 0)                                  // kx = 256 is its own partner
-            stage[256 * CH_STAGE + w] = (v4f){2.f * uo[0].x, 0.f, 2.f * uo[0].y, 0.f};
+        if (K == N / 2 + 1 && t == 0)                                // kx = N / 2 is its own partner
+            stage[(N / 2) * CH_STAGE + w] = (v4f){2.f * u[M / 2][0].x, 0.f, 2.f * u[M / 2][0].y, 0.f};
         __syncthreads();
         for (int i = threadIdx.x; i < K * 8; i += CH_WAVES * 64) {
             const int kx = i >> 3, pi = i & 7;
-            const v4f v = stage[kx * CH_STAGE + (kx < 256 ? pi ^ (2 * ((kx >> 3) & 1)) : pi)];
-            *(v4f *)(G + ((f * K + kx) * CH_N + 16 * g + 2 * pi)) = v;
+            const v4f v = stage[kx * CH_STAGE + (kx < N / 2 ? pi ^ (2 * ((kx >> 3) & 1)) : pi)];
+            *(v4f *)(G + ((f * K + kx) * N + 16 * g + 2 * pi)) = v;
         }
         __syncthreads();
     }
 }
 
-// one column per wave: 512 points of G -> sum of |F[ky][kx]| * mask; one workgroup per frame (persistent)
+// one column per wave: N points of G -> sum of |F[ky][kx]| * mask; one workgroup per frame (persistent)
+template <int M>
 __global__ void __launch_bounds__(CH_WAVES * 64)
-k_cryst_cols512(const v2f *__restrict__ G, int64_t n_frames, const float *__restrict__ mask_p, int K,
-                float *__restrict__ out, int accumulate) {
+k_cryst_cols(const v2f *__restrict__ G, int64_t n_frames, const float *__restrict__ mask_p, int K,
+             float *__restrict__ out, int accumulate) {
+    constexpr int N = 256 * M;
     __shared__ __attribute__((aligned(16))) v2f scr_all[CH_WAVES * CF_SCR];
     __shared__ float part[CH_WAVES];
     const int t = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     v2f *scr = scr_all + w * CF_SCR;
     CfLane c;
-    ChTw h;
-    ch_lane_setup(t, c, h);
+    ChTw<M> h;
+    ch_lane_setup<M>(t, c, h);
     for (int64_t f = blockIdx.x; f < n_frames; f += gridDim.x) {
         float acc = 0.f;
         for (int kx = w; kx < K; kx += CH_WAVES) {
-            const v4f *col = (const v4f *)(G + (f * K + kx) * CH_N) + 4 * t;
-            float m[8];
+            const v4f *col = (const v4f *)(G + (f * K + kx) * N) + 2 * M * t;
+            v2f u[M][4];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) m[q] = mask_p[(kx * 8 + q) * 64 + t];
-            v2f ue[4], uo[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const v4f q = __builtin_nontemporal_load(col + j);
-                ue[j] = q.xy;
-                uo[j] = q.zw;
+            for (int i = 0; i < 2 * M; ++i) {                       // samples 2 i, 2 i + 1 of the lane's 4 M
+                const v4f q = __builtin_nontemporal_load(col + i);
+                u[(2 * i) % M][(2 * i) / M] = q.xy;
+                u[(2 * i + 1) % M][(2 * i + 1) / M] = q.zw;
             }
-            ch_fft512(scr, c, h, ue, uo);
+            const float *mrow = mask_p + (int64_t)kx * (4 * M * 64) + t;
+            float mk[4 * M];
 #pragma unroll
-            for (int k2 = 0; k2 < 4; ++k2) {
-                if (__builtin_amdgcn_ballot_w64(m[k2] != 0.f)) {
-                    const float a = __builtin_amdgcn_sqrtf(ue[k2].x * ue[k2].x + ue[k2].y * ue[k2].y);
-                    acc += m[k2] != 0.f ? a * m[k2] : 0.f;
+            for (int q = 0; q < 4 * M; ++q) mk[q] = mrow[q * 64];
+            ch_fft<M>(scr, c, h, u);
+#pragma unroll
+            for (int q = 0; q < 4 * M; ++q)
+                if (__builtin_amdgcn_ballot_w64(mk[q] != 0.f)) {
+                    const v2f z = u[q >> 2][q & 3];
+                    const float a = __builtin_amdgcn_sqrtf(z.x * z.x + z.y * z.y);
+                    acc += mk[q] != 0.f ? a * mk[q] : 0.f;
                 }
-                if (__builtin_amdgcn_ballot_w64(m[4 + k2] != 0.f)) {
-                    const float a = __builtin_amdgcn_sqrtf(uo[k2].x * uo[k2].x + uo[k2].y * uo[k2].y);
-                    acc += m[4 + k2] != 0.f ? a * m[4 + k2] : 0.f;
-                }
-            }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -886,62 +906,66 @@ k_cryst_cols512(const v2f *__restrict__ G, int64_t n_frames, const float *__rest
     }
 }
 
-// masks of the 512 kernels in lane order:
-//   mask_p[kx][q][l]     = half_mask[sigma(l) + 64 (q & 3) + 256 (q >> 2)][kx]
-//   rmask_p[y'][16 t + e] = real_mask[2 y' + (e & 1)][8 t + 2 ((e >> 1) & 3) + (e >> 3)]   (even samples first, a / b interleaved)
-//   rflags bit y' (4 words): the pair holds a value other than 1
+// masks of these kernels in lane order (N = 256 M):
+//   mask_p[kx][q][l]        = half_mask[sigma(l) + 64 (q & 3) + 256 (q >> 2)][kx]          (q < 4 M)
+//   rmask_p[y'][8 M t + e]  = real_mask[2 y' + (e & 1)][4 M t + M ((e >> 1) & 3) + (e >> 3)]   (sample class q = e >> 3 first,
+//                             rows a / b interleaved);  rflags bit y' (N / 128 words): the pair holds a value other than 1
 __global__ void __launch_bounds__(256)
-k_cryst_masks512(const float *__restrict__ half_mask, int K, float *__restrict__ mask_p,
-                 const float *__restrict__ real_mask, float *__restrict__ rmask_p,
-                 unsigned long long *__restrict__ rflags) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < K * 512) {
-        const int kx = i >> 9, q = (i >> 6) & 7, l = i & 63;
+k_cryst_masks_n(const float *__restrict__ half_mask, int N, int K, float *__restrict__ mask_p,
+                const float *__restrict__ real_mask, float *__restrict__ rmask_p,
+                unsigned long long *__restrict__ rflags) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int M = N / 256;
+    if (i < (int64_t)K * N) {
+        const int kx = (int)(i / N), r = (int)(i - (int64_t)kx * N), q = r >> 6, l = r & 63;
         const int ky = cf_sigma(l) + 64 * (q & 3) + 256 * (q >> 2);
-        mask_p[i] = half_mask[ky * CH_KMAX + kx];
+        mask_p[i] = half_mask[(int64_t)ky * (N / 2 + 1) + kx];
     }
-    if (real_mask && i < CH_N * CH_N) {
-        const int yp = i >> 10, rem = i & 1023, tt = rem >> 4, e = rem & 15;
-        const float v = real_mask[(2 * yp + (e & 1)) * CH_N + 8 * tt + 2 * ((e >> 1) & 3) + (e >> 3)];
+    if (real_mask && i < (int64_t)N * N) {
+        const int yp = (int)(i / (2 * N)), rem = (int)(i - (int64_t)yp * 2 * N), tt = rem / (8 * M), e = rem - tt * 8 * M;
+        const float v = real_mask[(int64_t)(2 * yp + (e & 1)) * N + 4 * M * tt + M * ((e >> 1) & 3) + (e >> 3)];
         rmask_p[i] = v;
         if (__builtin_amdgcn_ballot_w64(v != 1.f) && (threadIdx.x & 63) == 0)
             atomicOr(&rflags[yp >> 6], 1ull << (yp & 63));
     }
 }
 
-template <typename T>
-static int launch_rows512(const void *tile, int64_t ld, int64_t n_frames, const float *real_mask,
-                          const unsigned long long *rflags, int K, v2f *G, int n_cu, hipStream_t stream) {
-    auto kern = real_mask ? k_cryst_rows512<T, true> : k_cryst_rows512<T, false>;
+template <typename T, int M>
+static int launch_rows(const void *tile, int64_t ld, int64_t n_frames, const float *real_mask,
+                       const unsigned long long *rflags, int K, v2f *G, int n_cu, hipStream_t stream) {
+    auto kern = real_mask ? k_cryst_rows<T, true, M> : k_cryst_rows<T, false, M>;
+    constexpr int N = 256 * M;
     const int lds = K * CH_STAGE * 16 + CH_WAVES * CF_SCR * 8;
     int device = 0;
     LTMI_HIP(hipGetDevice(&device));
     static bool attr_set[16][2] = {{false}};
     if (!attr_set[device & 15][real_mask ? 1 : 0]) {
         LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     CH_KMAX * CH_STAGE * 16 + CH_WAVES * CF_SCR * 8));
+                                     (N / 2 + 1) * CH_STAGE * 16 + CH_WAVES * CF_SCR * 8));
         attr_set[device & 15][real_mask ? 1 : 0] = true;
     }
-    const int64_t groups = n_frames * 32;
-    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(groups, (int64_t)n_cu * 3));
+    const int64_t groups = n_frames * (N / 2 / CH_WAVES);
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(groups, (int64_t)n_cu * (M == 2 ? 3 : 2)));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(CH_WAVES * 64), (size_t)lds, stream, (const T *)tile, ld, n_frames,
                        real_mask, rflags, K, G);
     LTMI_HIP(hipGetLastError());
     return LTMI_OK;
 }
 
-// 512 x 512 frames; gbuf: workspace of gbuf_frames * n_cols * 512 float2
-static int cryst_rows_cols512(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, const float *real_mask,
-                              const float *half_mask, int n_cols, float *work, void *gbuf, int64_t gbuf_frames,
-                              float *out, int accumulate, int n_cu, hipStream_t stream, bool *handled) {
-    if (n_cols < 1 || n_cols > CH_KMAX || !gbuf || gbuf_frames < 1) return LTMI_OK;
+// N x N frames, N = 512 / 1024; gbuf: workspace of gbuf_frames * n_cols * N float2
+template <int M>
+static int cryst_rows_cols(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, const float *real_mask,
+                           const float *half_mask, int n_cols, float *work, void *gbuf, int64_t gbuf_frames,
+                           float *out, int accumulate, int n_cu, hipStream_t stream, bool *handled) {
+    constexpr int N = 256 * M;
+    if (n_cols < 1 || n_cols > N / 2 + 1 || !gbuf || gbuf_frames < 1) return LTMI_OK;
     const size_t esz = (size_t)dtype_size(tile_dtype);
     if (esz > 4 || tile_dtype == LTMI_F64) return LTMI_OK;
-    if ((uintptr_t)tile % (8 * esz) != 0 || ld % 8 != 0) return LTMI_OK;
-    float *mask_p = work, *rmask_p = work + (int64_t)CH_KMAX * 512;
-    unsigned long long *rflags = (unsigned long long *)(rmask_p + CH_N * CH_N);
-    LTMI_HIP(hipMemsetAsync(rflags, 0, 32, stream));
-    hipLaunchKernelGGL(k_cryst_masks512, dim3((unsigned)(CH_N * CH_N / 256)), dim3(256), 0, stream, half_mask,
+    if ((uintptr_t)tile % std::min<size_t>(16, 4 * M * esz) != 0 || ld % (4 * M) != 0) return LTMI_OK;
+    float *mask_p = work, *rmask_p = work + (int64_t)(N / 2 + 1) * N;
+    unsigned long long *rflags = (unsigned long long *)(rmask_p + (int64_t)N * N);
+    LTMI_HIP(hipMemsetAsync(rflags, 0, 64, stream));
+    hipLaunchKernelGGL(k_cryst_masks_n, dim3((unsigned)((int64_t)N * N / 256)), dim3(256), 0, stream, half_mask, N,
                        n_cols, mask_p, real_mask, rmask_p, rflags);
     const float *rm = real_mask ? rmask_p : nullptr;
     for (int64_t f0 = 0; f0 < n_frames; f0 += gbuf_frames) {
@@ -950,18 +974,18 @@ static int cryst_rows_cols512(const void *tile, int tile_dtype, int64_t n_frames
         int rc = LTMI_E_DTYPE;
         switch (tile_dtype) {
             case LTMI_BOOL:
-            case LTMI_U8: rc = launch_rows512<uint8_t>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
-            case LTMI_I8: rc = launch_rows512<int8_t>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
-            case LTMI_U16: rc = launch_rows512<uint16_t>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
-            case LTMI_I16: rc = launch_rows512<int16_t>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
-            case LTMI_U32: rc = launch_rows512<uint32_t>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
-            case LTMI_I32: rc = launch_rows512<int32_t>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
-            case LTMI_F32: rc = launch_rows512<float>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
+            case LTMI_U8: rc = launch_rows<uint8_t, M>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
+            case LTMI_I8: rc = launch_rows<int8_t, M>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
+            case LTMI_U16: rc = launch_rows<uint16_t, M>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
+            case LTMI_I16: rc = launch_rows<int16_t, M>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
+            case LTMI_U32: rc = launch_rows<uint32_t, M>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
+            case LTMI_I32: rc = launch_rows<int32_t, M>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
+            case LTMI_F32: rc = launch_rows<float, M>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
             default: return LTMI_OK;
         }
         if (rc != LTMI_OK) return rc;
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)n_cu * 4));
-        hipLaunchKernelGGL(k_cryst_cols512, dim3(grid), dim3(CH_WAVES * 64), 0, stream, (const v2f *)gbuf, n,
+        hipLaunchKernelGGL(k_cryst_cols<M>, dim3(grid), dim3(CH_WAVES * 64), 0, stream, (const v2f *)gbuf, n,
                            (const float *)mask_p, n_cols, out + f0, accumulate);
         LTMI_HIP(hipGetLastError());
     }
@@ -975,8 +999,11 @@ int cryst_fused(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, 
                 int64_t gbuf_frames, float *out, int accumulate, int n_cu, hipStream_t stream, bool *handled) {
     *handled = false;
     if (!mask_t) return LTMI_OK;
-    if (sig_h == CH_N && sig_w == CH_N)
-        return cryst_rows_cols512(tile, tile_dtype, n_frames, ld, real_mask, half_mask, n_cols, mask_t, gbuf,
+    if (sig_h == 512 && sig_w == 512)
+        return cryst_rows_cols<2>(tile, tile_dtype, n_frames, ld, real_mask, half_mask, n_cols, mask_t, gbuf,
+                                  gbuf_frames, out, accumulate, n_cu, stream, handled);
+    if (sig_h == 1024 && sig_w == 1024)
+        return cryst_rows_cols<4>(tile, tile_dtype, n_frames, ld, real_mask, half_mask, n_cols, mask_t, gbuf,
                                   gbuf_frames, out, accumulate, n_cu, stream, handled);
     if (sig_h == CG_N && sig_w == CG_N)
         return cryst_fused128(tile, tile_dtype, n_frames, ld, real_mask, half_mask, n_cols, mask_t, out, accumulate,

@@ -1844,3 +1844,45 @@ def test_crystallinity_512_accumulate_strides_and_every_bin(hip):
     got, label = _cryst_run(hip, pw, None, half)
     assert label.endswith('columns=257'), label
     assert np.allclose(got, ref, rtol=1e-5, atol=512 * 512 * 1e-4), (got, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['uint16', 'float32', 'uint8'])
+@pytest.mark.parametrize('rad_in,rad_out,real', [(64, 256, ((512, 512), 100)), (0, 40, None), (200, 700, None)])
+def test_crystallinity_1024_rows_and_columns_kernels(hip, dtype, rad_in, rad_out, real):
+    """1024 x 1024 frames: the same two kernels with four 256-point transforms + a radix-4 butterfly per 1024
+    points; rings up to the full half spectrum (513 columns), two passes of the workspace (batch 3)."""
+    rng = np.random.default_rng(_seed('cryst1024', dtype, rad_out))
+    dt = np.dtype(dtype)
+    n = 5
+    if dt.kind == 'f':
+        frames = rng.normal(size=(n, 1024, 1024)).astype(dt) * 100
+    else:
+        frames = rng.integers(0, min(np.iinfo(dt).max, 4000), size=(n, 1024, 1024), endpoint=True).astype(dt)
+    frames[2] = 0
+    frames[4, 140:150, 890:900] += 17
+    ref, real_mask, half = _cryst_reference(frames, rad_in, rad_out, real)
+    got, label = _cryst_run(hip, frames, real_mask, half, batch=3)
+    assert label.startswith('k_cryst_rows1024<') and 'k_cryst_cols1024' in label, label
+    assert np.allclose(got, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max()), (got, ref)
+    assert got[2] == 0
+
+
+@pytest.mark.gpu
+def test_crystallinity_1024_every_bin_and_converted_frames(hip):
+    yy, xx = np.mgrid[0:1024, 0:1024]
+    waves = [(0, 0), (0, 256), (0, 257), (256, 0), (768, 0), (767, 0), (181, 181), (182, 182), (1023, 64), (64, 0),
+             (63, 0), (800, 160), (512, 512), (3, 255), (0, 512), (512, 0), (300, 511)]
+    pw = np.stack([np.cos(2 * np.pi * (ky * yy + kx * xx) / 1024) for ky, kx in waves]).astype(np.float32)
+    for rad_in, rad_out in ((64, 256), (200, 800)):
+        ref, _, half = _cryst_reference(pw, rad_in, rad_out, None)
+        got, label = _cryst_run(hip, pw, None, half)
+        assert label.startswith('k_cryst_rows1024<'), label
+        assert np.allclose(got, ref, rtol=1e-5, atol=1024 * 1024 * 1e-4), (got, ref)
+        assert (ref > 50000).sum() >= 5 and (ref < 50000).sum() >= 4
+    rng = np.random.default_rng(_seed('cryst1024-f64'))
+    frames = rng.normal(size=(4, 1024, 1024)) * 50
+    ref, real_mask, half = _cryst_reference(frames, 64, 256, ((512, 512), 100))
+    got, label = _cryst_run(hip, frames, real_mask, half, batch=3)
+    assert label.startswith('k_fft_prepare<float64> + k_cryst_rows1024<float32>'), label
+    assert np.allclose(got, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
