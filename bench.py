@@ -530,11 +530,11 @@ def live_feed(ctx, n_frames=16384, chunk=1024):
 def crystallinity(torch, hip, reps=10):
     """Row f3: CrystallinityUDF's kernel on frames resident in HBM -- sum(abs(rfft2(frame * real_mask)) * ring)
     per frame (ltmi_crystallinity; uint16 frames, ring sig/16 .. sig/4, real-space disk of radius sig/10 masked
-    out) for 256 x 256 frames (k_cryst_fused), 128 x 128 frames (k_cryst_fused128) and 512 x 512 frames
-    (k_cryst_rows512 + k_cryst_cols512), the hipFFT route of the same call beside each (LTMI_FFT_FUSED is read per plan)."""
+    out) for 256 x 256 frames (k_cryst_fused), 128 x 128 frames (k_cryst_fused128) 512 x 512 and 1024 x 1024 frames
+    (k_cryst_rows<N> + k_cryst_cols<N>), the hipFFT route of the same call beside each (LTMI_FFT_FUSED is read per plan)."""
     from libertem_amd.udf.crystallinity import crystallinity_masks, mask_box
     res = {"bound": "vector ALUs + LDS (profiles/r04_crystallinity.txt): the pixels are read once"}
-    for sig, n in ((256, 16384), (128, 65536), (512, 4096)):
+    for sig, n in ((256, 16384), (128, 65536), (512, 4096), (1024, 1024)):
         g = torch.Generator(device='cuda').manual_seed(1)
         frames = torch.randint(0, 4096, (n, sig, sig), generator=g, device='cuda', dtype=torch.int16)
         real_mask, half = crystallinity_masks((sig, sig), sig // 16, sig // 4, (sig // 2, sig // 2), sig // 10)

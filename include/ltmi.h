@@ -271,7 +271,7 @@ int ltmi_crystallinity(ltmi_fft_plan *p, const void *tile, int tile_dtype, int64
  * of its good neighbours' corrected values; no corrected copy of the tile is written.
  * dark / gain: device float64 (sig_h*sig_w) or NULL; excl (n_excl), env (n_excl, max_env),
  * cnt (n_excl): device int32 repair tables as for ltmi_repair_pixels (n_excl = 0: none).
- * 128 x 128 / 256 x 256 / 512 x 512 frames: the corrected float32 frames of a batch are written to the plan's workspace and
+ * 128 x 128 / 256 x 256 / 512 x 512 / 1024 x 1024 frames: the corrected float32 frames of a batch are written to the plan's workspace and
  * transformed by the fused kernel (see ltmi_fft_plan_last_kernel) instead of hipFFT. */
 int ltmi_crystallinity_corrected(ltmi_fft_plan *p, const void *tile, int tile_dtype,
                                  int64_t n_frames, int64_t ld_tile, const double *dark,
@@ -281,8 +281,8 @@ int ltmi_crystallinity_corrected(ltmi_fft_plan *p, const void *tile, int tile_dt
                                  int row_hi, int n_cols, float *out, int accumulate, void *stream);
 /* Which route the last ltmi_crystallinity* call of this plan took: "k_cryst_fused<...>" (256 x 256
  * frames, rings of up to 71 columns) / "k_cryst_fused128<...>" (128 x 128 frames, any ring): rows, columns
- * and the ring sum of a frame in the LDS of one workgroup; "k_cryst_rows512<...> + k_cryst_cols512" (512 x 512
- * frames, any ring: the ring's columns of the row transforms pass through the plan's workspace)
+ * and the ring sum of a frame in the LDS of one workgroup; "k_cryst_rows512<...> + k_cryst_cols512" (512 x 512 and,
+ * with 1024 in the names, 1024 x 1024 frames, any ring: the ring's columns of the row transforms pass through the plan's workspace)
  * (csrc/ltmi_cryst.hip); or "hipfft_r2c<...>".  LTMI_FFT_FUSED=0 at plan creation keeps every
  * frame on hipFFT.  The string lives as long as the plan. */
 const char *ltmi_fft_plan_last_kernel(const ltmi_fft_plan *p);

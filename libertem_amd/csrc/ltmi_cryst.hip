@@ -1,6 +1,6 @@
 // ltmi_cryst.hip -- CrystallinityUDF.process_frame for 256 x 256 (k_cryst_fused) and 128 x 128 frames
-// (k_cryst_fused128, second part of this file) in ONE kernel, for 512 x 512 frames in two (k_cryst_rows512 +
-// k_cryst_cols512, third part) (reference
+// (k_cryst_fused128, second part of this file) in ONE kernel, for 512 x 512 and 1024 x 1024 frames in two (k_cryst_rows +
+// k_cryst_cols, third part) (reference
 // udf/crystallinity.py:73-79):
 //
 //     intensity[f] = sum( abs(rfft2(frame * real_mask)) * half_fourier_mask )

@@ -14,8 +14,10 @@ from libertem_amd.common.exceptions import HipRequiredError
 from libertem_amd.masks import _make_circular_mask
 from libertem_amd.udf.base import UDF, UDFMethod
 
-#: workspace budget of one plan (f32 frames + complex64 half spectra), bytes
-FFT_WORKSPACE_BYTES = 512 * 2**20
+#: workspace budget of one plan (f32 frames + complex64 half spectra), bytes: created only when a route needs it
+#: (hipFFT, corrected frames, the column workspace of 512 / 1024-pixel frames) -- frames of 1024 x 1024 want ~250 per
+#: pass of the workspace to fill the chip (one workgroup per frame in the column kernel)
+FFT_WORKSPACE_BYTES = 2 * 2**30
 _PLANS = {}          # (device, h, w, batch) -> hip.FFTPlan
 _MASKS = {}          # (device, sig, params) -> (real_mask tensor | None, half mask tensor)
 

@@ -209,3 +209,42 @@ for k2 in range(4):
 zk=hi[0][0]; S=2*zk.real; D=2*zk.imag
 assert np.allclose(S,2*A[256]) and np.allclose(D,2*B[256])
 print('sep512 ok')
+
+
+# ---- fourth part: N = 256 M points (M = 2, 4) as M 256-point transforms + one radix-M butterfly (ch_fft) and the
+# separation of two real rows for every block of 64 columns
+def bfly_m(us, M):
+    if M==2: return [us[0]+us[1], us[0]-us[1]]
+    return bfly(us)
+def fftN(z, M):
+    N=256*M
+    sub=[[z[4*M*l+M*j+q] for j in range(4)] for q in range(M)]
+    U=[fft_core(swapA(s)) for s in sub]
+    X=[[None]*4 for _ in range(M)]
+    for k2 in range(4):
+        k=sigma+64*k2
+        v=[U[q][k2]*np.exp(-2j*np.pi*q*k/N) for q in range(M)]
+        o=bfly_m(v,M)
+        for m in range(M): X[m][k2]=o[m]
+    return X       # X[m][k2][l] = X[sigma+64k2+256m]
+rng=np.random.default_rng(3)
+back=sigma[(-sigma)%64]
+for M in (2,4):
+    N=256*M
+    z=rng.normal(size=N)+1j*rng.normal(size=N)
+    X=fftN(z,M); ref=np.fft.fft(z)
+    for m in range(M):
+        for k2 in range(4): assert np.allclose(X[m][k2], ref[sigma+64*k2+256*m])
+    a=rng.normal(size=N); b=rng.normal(size=N)
+    X=fftN(a+1j*b,M); A=np.fft.fft(a); B=np.fft.fft(b)
+    for c in range(2*M):               # blocks kx = sigma + 64 c < N/2
+        k2,m=c&3,c>>2
+        cp=(4*M-c)%(4*M)                # sigma = 0: partner block index
+        give=np.where(l==0, X[cp>>2][cp&3], X[M-1-m][3-k2])
+        other=give[back]
+        zk=X[m][k2]; kx=sigma+64*c
+        S=(zk.real+other.real)+1j*(zk.imag-other.imag); D=(zk.imag+other.imag)+1j*(other.real-zk.real)
+        assert np.allclose(S,2*A[kx]) and np.allclose(D,2*B[kx]), (M,c)
+    zk=X[M//2][0][0]     # kx = N/2: lane 0, block c = 2M
+    assert np.allclose(2*zk.real,2*A[N//2]) and np.allclose(2*zk.imag,2*B[N//2])
+    print('M',M,'ok')

@@ -26,6 +26,12 @@ for d in uint8 float32; do SIG=512 N=4096 RAD_OUT=128 DTYPE=$d python $R/scripts
 SIG=512 N=4096 RAD_OUT=128 LTMI_FFT_FUSED=0 python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s"
 SIG=512 SCAN=128 python $R/scripts/bench_crystallinity.py 2>&1 | grep "Mframes"
 SIG=512 SCAN=128 LTMI_FFT_FUSED=0 python $R/scripts/bench_crystallinity.py 2>&1 | grep "Mframes" | sed 's/^/LTMI_FFT_FUSED=0: /'
+echo "== 1024 x 1024 frames (the same two kernels, four 256-point transforms per 1024 points; 1 024 frames)"
+for r in 128 256 512; do SIG=1024 N=1024 RAD_OUT=$r python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s" | sed "s/^/rad_out $r: /"; done
+SIG=1024 N=1024 RAD_OUT=256 DTYPE=float32 python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s"
+SIG=1024 N=1024 RAD_OUT=256 LTMI_FFT_FUSED=0 python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s"
+SIG=1024 SCAN=64 python $R/scripts/bench_crystallinity.py 2>&1 | grep "Mframes"
+SIG=1024 SCAN=64 LTMI_FFT_FUSED=0 python $R/scripts/bench_crystallinity.py 2>&1 | grep "Mframes" | sed 's/^/LTMI_FFT_FUSED=0: /'
 echo "== corrected frames (dark + gain + 50 dead pixels through the conversion pass, then the same kernels)"
 for sg in 128 256 512; do for fu in 1 0; do CORR=1 SIG=$sg N=$((sg == 512 ? 4096 : 16384)) LTMI_FFT_FUSED=$fu python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s" | sed "s/^/sig $sg LTMI_FFT_FUSED=$fu: /"; done; done
 echo "== timing-only ablations of k_cryst_fused<uint16,mask> (LTMI_CRYST_ABLATE; results are garbage)"
