@@ -811,6 +811,8 @@ k_cryst_rows(const T *__restrict__ tile, int64_t ld, int64_t n_frames, const flo
         const int64_t f = grp / GROUPS;
         const int g = (int)(grp - f * GROUPS);
         const int yp = CH_WAVES * g + w;
+        // (loading a group's pixels one group ahead changed nothing: the kernel is bound by the transforms, at the
+        // rate per 256-point transform of k_cryst_fused)
         const T *row = tile + f * ld + (int64_t)(2 * yp) * N + 4 * M * t;
         const vec_t ra = __builtin_nontemporal_load((const vec_t *)row);
         const vec_t rb = __builtin_nontemporal_load((const vec_t *)(row + N));
@@ -944,8 +946,12 @@ static int launch_rows(const void *tile, int64_t ld, int64_t n_frames, const flo
                                      (N / 2 + 1) * CH_STAGE * 16 + CH_WAVES * CF_SCR * 8));
         attr_set[device & 15][real_mask ? 1 : 0] = true;
     }
+    // persistent workgroups: exactly as many as are resident at once (a workgroup that waits for a CU would start
+    // its share of the groups when the others are done with theirs)
+    int per_cu = 1;
+    LTMI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, CH_WAVES * 64, (size_t)lds));
     const int64_t groups = n_frames * (N / 2 / CH_WAVES);
-    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(groups, (int64_t)n_cu * (M == 2 ? 3 : 2)));
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(groups, (int64_t)n_cu * std::max(1, per_cu)));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(CH_WAVES * 64), (size_t)lds, stream, (const T *)tile, ld, n_frames,
                        real_mask, rflags, K, G);
     LTMI_HIP(hipGetLastError());
@@ -984,7 +990,9 @@ static int cryst_rows_cols(const void *tile, int tile_dtype, int64_t n_frames, i
             default: return LTMI_OK;
         }
         if (rc != LTMI_OK) return rc;
-        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)n_cu * 4));
+        int per_cu = 1;
+        LTMI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_cryst_cols<M>, CH_WAVES * 64, 0));
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)n_cu * std::max(1, per_cu)));
         hipLaunchKernelGGL(k_cryst_cols<M>, dim3(grid), dim3(CH_WAVES * 64), 0, stream, (const v2f *)gbuf, n,
                            (const float *)mask_p, n_cols, out + f0, accumulate);
         LTMI_HIP(hipGetLastError());
