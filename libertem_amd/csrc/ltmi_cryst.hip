@@ -30,8 +30,8 @@
 //                                               k1 = c0 + 4 c1 + 16 c2 = sigma(lane)
 // Two LDS round trips per transform (a Stockham formulation needs one per pass and one more to bring the
 // row in: that version of this kernel ran 16 384 frames in 1.58 ms, LDS and vector ALUs ~55 % busy each).
-// The XORs make every 16-lane store group and every 32-lane load group a permutation of the banks (by the
-// documented bank rules; SQ_LDS_BANK_CONFLICT measures 6 % of the LDS cycles, origin open).  The column stage reads G[kx] directly in the layout after the first swap.
+// The XORs make every 16-lane store group and every 32-lane load group a permutation of the banks (SQ_LDS_BANK_CONFLICT
+// = 0 for the transposes: k_cryst_cols; the 8 cycles per row pair the row kernels count belong to the ds_bpermute pairs).  The column stage reads G[kx] directly in the layout after the first swap.
 //
 // G[kx][y]: 258 float2 per column (516 dwords = 4 mod 32: 8 neighbouring columns, 16 bytes each, hit 32
 // banks), y kept at y ^ (2 ((y >> 5) & 1)) ^ (4 ((kx >> 3) & 1)): the first makes the column stage's loads
