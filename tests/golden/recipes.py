@@ -488,6 +488,17 @@ CRYST_CASES = [
          rad_in=2.5, rad_out=11.5, real_center=(10.5, 20.25), real_rad=4),
     dict(name='u16_64', nav=(2, 8), sig=(64, 64), dtype='uint16', num_partitions=1, seed=804,
          rad_in=6, rad_out=20, real_center=(32, 32), real_rad=8),
+    # the frame shapes with hand-written transform kernels (csrc/ltmi_cryst.hip)
+    dict(name='u16_128', nav=(5,), sig=(128, 128), dtype='uint16', num_partitions=1, seed=805,
+         rad_in=8, rad_out=32, real_center=(64, 64), real_rad=12),
+    dict(name='u16_256', nav=(2, 3), sig=(256, 256), dtype='uint16', num_partitions=2, seed=806,
+         rad_in=16, rad_out=64, real_center=(128, 128), real_rad=25),
+    dict(name='f32_256_plain', nav=(4,), sig=(256, 256), dtype='float32', num_partitions=1, seed=807,
+         rad_in=10, rad_out=47.5, real_center=None, real_rad=None),
+    dict(name='u16_512', nav=(3,), sig=(512, 512), dtype='uint16', num_partitions=1, seed=808,
+         rad_in=32, rad_out=128, real_center=(256, 256), real_rad=50),
+    dict(name='u8_1024', nav=(2,), sig=(1024, 1024), dtype='uint8', num_partitions=1, seed=809,
+         rad_in=64, rad_out=256, real_center=None, real_rad=None),
 ]
 
 

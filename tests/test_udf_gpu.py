@@ -1068,6 +1068,11 @@ def test_crystallinity_vs_reference_golden(ctx, golden_dir, case, resident):
     ref = g[case['name']]
     assert got.shape == ref.shape and got.dtype == ref.dtype
     assert _close(got, ref, F32_TOL), (np.abs(got - ref).max(), np.abs(ref).max())
+    if tuple(case['sig']) in ((128, 128), (256, 256), (512, 512), (1024, 1024)):
+        # these shapes run the hand-written transform kernels (csrc/ltmi_cryst.hip), not hipFFT
+        import libertem_amd.udf.crystallinity as cr
+        labels = [p.last_kernel() for k, p in cr._PLANS.items() if k[1:3] == tuple(case['sig'])]
+        assert labels and all(lb.startswith('k_cryst_') for lb in labels), labels
     again = run_analysis_crystall(ctx, ds, case['rad_in'], case['rad_out'], case['real_center'],
                                   case['real_rad'])['intensity'].data
     assert np.array_equal(again, got)                       # deterministic, plan re-used
