@@ -133,7 +133,7 @@ int cryst_fused_max_cols();
 bool cryst_fused_shape(int h, int w);
 bool cryst_fused_takes(int h, int w, int n_cols);
 int64_t cryst_fused_workspace_floats(int h);
-bool cryst_fused_needs_gbuf(int h, int w);
+bool cryst_fused_needs_gbuf(int h, int w, int n_cols);
 int cryst_fused(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, int sig_h, int sig_w,
                 const float *real_mask, const float *half_mask, int n_cols, float *mask_t, void *gbuf,
                 int64_t gbuf_frames, float *out, int accumulate, int n_cu, hipStream_t stream, bool *handled);

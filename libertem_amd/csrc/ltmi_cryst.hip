@@ -39,7 +39,8 @@
 // 8 lanes holds the columns sigma(lane) = {0, 4, 8, 12, 1, 5, 9, 13} + 16 i).
 //
 // LDS: K columns + 2 KiB of row scratch per wave that transforms rows: K = 65 (rad_out 64) leaves room for
-// 14 of the 16 waves; rings with K > CF_KMAX columns and other frame shapes stay on the hipFFT route; float64
+// 14 of the 16 waves; rings with K > CF_KMAX columns run the workspace kernels of the third part (M = 1), other frame
+// shapes than the four stay on the hipFFT route; float64
 // pixels, odd strides and detector corrections reach this kernel as float32 frames written by the conversion
 // pass (ltmi_fft.hip).  HBM traffic: the pixels once (+ the two masks from the L2).
 #include "ltmi_common.h"
@@ -403,14 +404,17 @@ bool cryst_fused_takes(int h, int w, int n_cols) {
     if (h == 128 && w == 128) return n_cols >= 1 && n_cols <= 65;
     if (h == 512 && w == 512) return n_cols >= 1 && n_cols <= 257;
     if (h == 1024 && w == 1024) return n_cols >= 1 && n_cols <= 513;
-    return h == 256 && w == 256 && n_cols >= 1 && n_cols <= CF_KMAX;
+    return h == 256 && w == 256 && n_cols >= 1 && n_cols <= 129;
 }
 bool cryst_fused_shape(int h, int w) { return h == w && (h == 128 || h == 256 || h == 512 || h == 1024); }
-// 512 x 512 frames pass the ring's columns of the row transforms through a (frames x n_cols x 512) float2 workspace
-bool cryst_fused_needs_gbuf(int h, int w) { return h == w && (h == 512 || h == 1024); }
+// 512 / 1024-pixel frames (and 256-pixel frames with rings of more than 71 columns) pass the ring's columns of the row
+// transforms through a (frames x n_cols x h) float2 workspace
+bool cryst_fused_needs_gbuf(int h, int w, int n_cols) {
+    return h == w && (h == 512 || h == 1024 || (h == 256 && n_cols > CF_KMAX));
+}
 // the masks in lane order (+ flags): what the kernels of an h x h plan need
 int64_t cryst_fused_workspace_floats(int h) {
-    if (h >= 512) return (int64_t)(h / 2 + 1) * h + (int64_t)h * h + 16;
+    if (h >= 256) return (int64_t)(h / 2 + 1) * h + (int64_t)h * h + 16;         // (covers k_cryst_fused's layout too)
     return (int64_t)CF_KMAX * CF_N + CF_N * CF_N + 8;
 }
 
@@ -723,7 +727,7 @@ static int cryst_fused128(const void *tile, int tile_dtype, int64_t n_frames, in
 constexpr int CH_WAVES = 8;
 constexpr int CH_STAGE = 9;                      // float4 units per column of the staging tile: 8 row pairs + 16 bytes
 
-template <int M> struct ChTw { v2f w[M - 1][4], wr[M - 1][4]; };   // w_N^(q (sigma + 64 k2)), q = 1 .. M - 1
+template <int M> struct ChTw { v2f w[M > 1 ? M - 1 : 1][4], wr[M > 1 ? M - 1 : 1][4]; };   // w_N^(q (sigma + 64 k2)), q = 1 .. M - 1
 
 template <int M>
 __device__ __forceinline__ void ch_lane_setup(int t, CfLane &c, ChTw<M> &h) {
@@ -768,6 +772,7 @@ __device__ __forceinline__ void ch_fft(v2f *scr, const CfLane &c, const ChTw<M> 
         cf_swap_a(u[q]);
         cf_core(scr, c, u[q]);
     }
+    if (M == 1) return;                          // (256 points: one transform, nothing to combine)
 #pragma unroll
     for (int k2 = 0; k2 < 4; ++k2) {
         if (M == 2) {
@@ -844,7 +849,8 @@ k_cryst_rows(const T *__restrict__ tile, int64_t ld, int64_t n_frames, const flo
                 stage[st_col + 64 * cb * CH_STAGE] = (v4f){zk.x + cr, zk.y - ci, zk.y + ci, cr - zk.x};
         }
         if (K == N / 2 + 1 && t == 0)                                // kx = N / 2 is its own partner
-            stage[(N / 2) * CH_STAGE + w] = (v4f){2.f * u[M / 2][0].x, 0.f, 2.f * u[M / 2][0].y, 0.f};
+            stage[(N / 2) * CH_STAGE + w] =                        // X[N / 2]: block (N / 2) / 64 of lane 0
+                (v4f){2.f * u[M / 2][M == 1 ? 2 : 0].x, 0.f, 2.f * u[M / 2][M == 1 ? 2 : 0].y, 0.f};
         __syncthreads();
         for (int i = threadIdx.x; i < K * 8; i += CH_WAVES * 64) {
             const int kx = i >> 3, pi = i & 7;
@@ -1016,7 +1022,10 @@ int cryst_fused(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, 
     if (sig_h == CG_N && sig_w == CG_N)
         return cryst_fused128(tile, tile_dtype, n_frames, ld, real_mask, half_mask, n_cols, mask_t, out, accumulate,
                               n_cu, stream, handled);
-    if (sig_h != CF_N || sig_w != CF_N || n_cols < 1 || n_cols > CF_KMAX) return LTMI_OK;
+    if (sig_h != CF_N || sig_w != CF_N || n_cols < 1) return LTMI_OK;
+    if (n_cols > CF_KMAX)                        // a ring too wide for the LDS: the workspace kernels with M = 1
+        return cryst_rows_cols<1>(tile, tile_dtype, n_frames, ld, real_mask, half_mask, n_cols, mask_t, gbuf,
+                                  gbuf_frames, out, accumulate, n_cu, stream, handled);
     const size_t esz = (size_t)dtype_size(tile_dtype);
     if (esz > 4 || tile_dtype == LTMI_F64) return LTMI_OK;
     if ((uintptr_t)tile % (4 * esz) != 0 || ld % 4 != 0) return LTMI_OK;

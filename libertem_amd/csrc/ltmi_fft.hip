@@ -394,7 +394,7 @@ static int crystallinity_impl(ltmi_fft_plan *p, const void *tile, int tile_dtype
                   row_hi, n_cols);
     if (p->fused_ok && !corr.dark && !corr.gain && corr.n_excl == 0) {
         bool handled = false;
-        if (cryst_fused_needs_gbuf(p->h, p->w)) {
+        if (cryst_fused_needs_gbuf(p->h, p->w, n_cols)) {
             const int rc1 = spec_ready(p);
             if (rc1 != LTMI_OK) return rc1;
         }
@@ -403,7 +403,7 @@ static int crystallinity_impl(ltmi_fft_plan *p, const void *tile, int tile_dtype
                                    &handled);
         if (rc != LTMI_OK) return rc;
         if (handled) {
-            if (p->h >= 512)
+            if (cryst_fused_needs_gbuf(p->h, p->w, n_cols))
                 snprintf(p->last_kernel, sizeof(p->last_kernel), "k_cryst_rows%d<%s%s> + k_cryst_cols%d columns=%d", p->h,
                          dtype_name(tile_dtype), real_mask ? ",mask" : "", p->h, n_cols);
             else
@@ -418,7 +418,7 @@ static int crystallinity_impl(ltmi_fft_plan *p, const void *tile, int tile_dtype
         // kernel takes those instead of two rocFFT passes over a (batch x half spectrum) workspace
         const int rc0 = real_buf_ready(p);
         if (rc0 != LTMI_OK) return rc0;
-        if (cryst_fused_needs_gbuf(p->h, p->w)) {
+        if (cryst_fused_needs_gbuf(p->h, p->w, n_cols)) {
             const int rc1 = spec_ready(p);
             if (rc1 != LTMI_OK) return rc1;
         }
@@ -433,7 +433,7 @@ static int crystallinity_impl(ltmi_fft_plan *p, const void *tile, int tile_dtype
             if (rc != LTMI_OK) return rc;
             if (!handled) LTMI_FAIL(LTMI_E_INVALID, "ltmi_crystallinity: the fused kernel refused its own workspace");
         }
-        if (p->h >= 512)
+        if (cryst_fused_needs_gbuf(p->h, p->w, n_cols))
             snprintf(p->last_kernel, sizeof(p->last_kernel), "k_fft_prepare<%s> + k_cryst_rows%d<float32> + k_cryst_cols%d columns=%d",
                      dtype_name(tile_dtype), p->h, p->h, n_cols);
         else

@@ -10,7 +10,7 @@ LTMI_FFT_FUSED=0 python $R/scripts/bench_crystallinity.py 2>&1 | grep "Mframes" 
 echo "== kernel alone (scripts/bench_cryst_kernel.py: 16 384 frames, HIP events, median of 10)"
 for d in uint8 int8 uint16 int16 uint32 int32 float32; do DTYPE=$d python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s"; done
 MASK=0 python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s"
-for r in 24 48 63 64 70 71; do RAD_OUT=$r python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s" | sed "s/^/rad_out $r: /"; done
+for r in 24 48 63 64 70 71 100 128; do RAD_OUT=$r python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s" | sed "s/^/rad_out $r: /"; done
 LTMI_CRYST_WAVES=8 python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s" | sed 's/^/8 waves: /'
 LTMI_FFT_FUSED=0 python $R/scripts/bench_cryst_kernel.py 2>&1 | grep "frames/s"
 echo "== 128 x 128 frames (k_cryst_fused128; 65 536 frames)"

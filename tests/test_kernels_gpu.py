@@ -1659,8 +1659,7 @@ def test_crystallinity_fused_kernel_all_pixel_types(hip, dtype, rad_in, rad_out,
 
 @pytest.mark.gpu
 def test_crystallinity_fused_kernel_many_frames_ragged_accumulate(hip):
-    """more frames than workgroups, a padded frame stride, accumulate; and the same numbers as the hipFFT
-    route for a ring that is too wide for the LDS (rad_out 100 -> 101 columns)."""
+    """more frames than workgroups, a padded frame stride, accumulate; rings too wide for the LDS."""
     rng = np.random.default_rng(_seed('cryst-many'))
     frames = rng.integers(0, 4096, size=(300, 256, 256)).astype(np.uint16)
     ref, real_mask, half = _cryst_reference(frames, 16, 64, ((128, 128), 25))
@@ -1674,10 +1673,17 @@ def test_crystallinity_fused_kernel_many_frames_ragged_accumulate(hip):
     got3, label3 = _cryst_run(hip, frames[:9], real_mask, half, ld_pad=1)
     assert label3 == 'k_fft_prepare<uint16> + k_cryst_fused<float32> columns=65', label3
     assert np.allclose(got3, ref[:9], rtol=1e-5)
-    ref_w, rm_w, half_w = _cryst_reference(frames[:9], 16, 100, ((128, 128), 25))
-    got_w, label_w = _cryst_run(hip, frames[:9], rm_w, half_w)
-    assert label_w.startswith('hipfft_r2c<'), label_w
+    # a ring too wide for the LDS (rad_out 100 -> 101 columns): the row / column kernels with a workspace
+    ref_w, rm_w, half_w = _cryst_reference(frames[:40], 16, 100, ((128, 128), 25))
+    got_w, label_w = _cryst_run(hip, frames[:40], rm_w, half_w, batch=16)
+    assert label_w == 'k_cryst_rows256<uint16,mask> + k_cryst_cols256 columns=101', label_w
     assert np.allclose(got_w, ref_w, rtol=1e-5)
+    for dt, rad in ((np.float32, 200), (np.uint8, 128), (np.int16, 71)):          # up to the whole half spectrum (129 columns)
+        fr = (frames[:5] % 200).astype(dt)
+        ref_w, rm_w, half_w = _cryst_reference(fr, 30, rad, None)
+        got_w, label_w = _cryst_run(hip, fr, rm_w, half_w)
+        assert label_w.startswith('k_cryst_rows256<') and label_w.endswith(f'columns={min(rad, 128) + 1}'), label_w
+        assert np.allclose(got_w, ref_w, rtol=1e-5)
 
 
 @pytest.mark.gpu
