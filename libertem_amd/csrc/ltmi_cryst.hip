@@ -725,6 +725,7 @@ static int cryst_fused128(const void *tile, int tile_dtype, int64_t n_frames, in
 // (cf_core M times: a lane's 4 M consecutive samples are 4 of each, the layout cf_core starts from), twiddles
 // w_N^(q k) and one radix-M butterfly over q:  X[k + 256 m] = sum_q (-i)^(q m) [for M = 4] w_N^(q k) E_q[k].
 constexpr int CH_WAVES = 8;
+constexpr int CH_KMAX_ANY = 513;                 // columns of the widest half spectrum these kernels take (N = 1024)
 constexpr int CH_STAGE = 9;                      // float4 units per column of the staging tile: 8 row pairs + 16 bytes
 
 template <int M> struct ChTw { v2f w[M > 1 ? M - 1 : 1][4], wr[M > 1 ? M - 1 : 1][4]; };   // w_N^(q (sigma + 64 k2)), q = 1 .. M - 1
@@ -954,8 +955,12 @@ static int launch_rows(const void *tile, int64_t ld, int64_t n_frames, const flo
     }
     // persistent workgroups: exactly as many as are resident at once (a workgroup that waits for a CU would start
     // its share of the groups when the others are done with theirs)
-    int per_cu = 1;
-    LTMI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, CH_WAVES * 64, (size_t)lds));
+    static int resident[16][2][CH_KMAX_ANY + 2] = {{{0}}};          // per device, mask variant and K (the LDS size)
+    int &per_cu = resident[device & 15][real_mask ? 1 : 0][K];
+    if (per_cu == 0) {
+        LTMI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, CH_WAVES * 64, (size_t)lds));
+        per_cu = std::max(1, per_cu);
+    }
     const int64_t groups = n_frames * (N / 2 / CH_WAVES);
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(groups, (int64_t)n_cu * std::max(1, per_cu)));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(CH_WAVES * 64), (size_t)lds, stream, (const T *)tile, ld, n_frames,
@@ -996,8 +1001,11 @@ static int cryst_rows_cols(const void *tile, int tile_dtype, int64_t n_frames, i
             default: return LTMI_OK;
         }
         if (rc != LTMI_OK) return rc;
-        int per_cu = 1;
-        LTMI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_cryst_cols<M>, CH_WAVES * 64, 0));
+        static int per_cu = 0;                      // (one value per M: registers and static LDS only)
+        if (per_cu == 0) {
+            LTMI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_cryst_cols<M>, CH_WAVES * 64, 0));
+            per_cu = std::max(1, per_cu);
+        }
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)n_cu * std::max(1, per_cu)));
         hipLaunchKernelGGL(k_cryst_cols<M>, dim3(grid), dim3(CH_WAVES * 64), 0, stream, (const v2f *)gbuf, n,
                            (const float *)mask_p, n_cols, out + f0, accumulate);
