@@ -281,8 +281,8 @@ int ltmi_crystallinity_corrected(ltmi_fft_plan *p, const void *tile, int tile_dt
                                  int row_hi, int n_cols, float *out, int accumulate, void *stream);
 /* Which route the last ltmi_crystallinity* call of this plan took: "k_cryst_fused<...>" (256 x 256
  * frames, rings of up to 71 columns) / "k_cryst_fused128<...>" (128 x 128 frames, any ring): rows, columns
- * and the ring sum of a frame in the LDS of one workgroup; "k_cryst_rows512<...> + k_cryst_cols512" (512 x 512 and,
- * with 1024 in the names, 1024 x 1024 frames, any ring: the ring's columns of the row transforms pass through the plan's workspace)
+ * and the ring sum of a frame in the LDS of one workgroup; "k_cryst_rows<w><...> + k_cryst_cols<h>" (frames whose edges
+ * are 256 / 512 / 1024 pixels in any combination -- 256 x 256 only for rings of more than 71 columns --, any ring: the ring's columns of the row transforms pass through the plan's workspace)
  * (csrc/ltmi_cryst.hip); or "hipfft_r2c<...>".  LTMI_FFT_FUSED=0 at plan creation keeps every
  * frame on hipFFT.  The string lives as long as the plan. */
 const char *ltmi_fft_plan_last_kernel(const ltmi_fft_plan *p);

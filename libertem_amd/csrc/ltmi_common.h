@@ -132,7 +132,7 @@ int split_apply(ltmi_masks *m, void *image, const float *tile, int64_t n_frames,
 int cryst_fused_max_cols();
 bool cryst_fused_shape(int h, int w);
 bool cryst_fused_takes(int h, int w, int n_cols);
-int64_t cryst_fused_workspace_floats(int h);
+int64_t cryst_fused_workspace_floats(int h, int w);
 bool cryst_fused_needs_gbuf(int h, int w, int n_cols);
 int cryst_fused(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, int sig_h, int sig_w,
                 const float *real_mask, const float *half_mask, int n_cols, float *mask_t, void *gbuf,

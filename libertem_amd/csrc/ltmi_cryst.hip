@@ -400,21 +400,20 @@ k_cryst_masks(const float *__restrict__ half_mask, int wc, int K, float *__restr
 
 int cryst_fused_max_cols() { return CF_KMAX; }
 // rings the fused kernels take (given a tile they can read: see cryst_fused)
+static bool cf_edge(int e) { return e == 256 || e == 512 || e == 1024; }
 bool cryst_fused_takes(int h, int w, int n_cols) {
     if (h == 128 && w == 128) return n_cols >= 1 && n_cols <= 65;
-    if (h == 512 && w == 512) return n_cols >= 1 && n_cols <= 257;
-    if (h == 1024 && w == 1024) return n_cols >= 1 && n_cols <= 513;
-    return h == 256 && w == 256 && n_cols >= 1 && n_cols <= 129;
+    return cf_edge(h) && cf_edge(w) && n_cols >= 1 && n_cols <= w / 2 + 1;
 }
-bool cryst_fused_shape(int h, int w) { return h == w && (h == 128 || h == 256 || h == 512 || h == 1024); }
-// 512 / 1024-pixel frames (and 256-pixel frames with rings of more than 71 columns) pass the ring's columns of the row
-// transforms through a (frames x n_cols x h) float2 workspace
+bool cryst_fused_shape(int h, int w) { return (h == 128 && w == 128) || (cf_edge(h) && cf_edge(w)); }
+// frames other than 128 x 128 and 256 x 256 (and 256 x 256 frames with rings of more than 71 columns) pass the ring's
+// columns of the row transforms through a (frames x n_cols x h) float2 workspace
 bool cryst_fused_needs_gbuf(int h, int w, int n_cols) {
-    return h == w && (h == 512 || h == 1024 || (h == 256 && n_cols > CF_KMAX));
+    return cf_edge(h) && cf_edge(w) && !(h == 256 && w == 256 && n_cols <= CF_KMAX);
 }
-// the masks in lane order (+ flags): what the kernels of an h x h plan need
-int64_t cryst_fused_workspace_floats(int h) {
-    if (h >= 256) return (int64_t)(h / 2 + 1) * h + (int64_t)h * h + 16;         // (covers k_cryst_fused's layout too)
+// the masks in lane order (+ flags): what the kernels of an h x w plan need
+int64_t cryst_fused_workspace_floats(int h, int w) {
+    if (cf_edge(h) && cf_edge(w)) return (int64_t)(w / 2 + 1) * h + (int64_t)w * h + 16;   // (covers k_cryst_fused's layout too)
     return (int64_t)CF_KMAX * CF_N + CF_N * CF_N + 8;
 }
 
@@ -717,7 +716,8 @@ static int cryst_fused128(const void *tile, int tile_dtype, int64_t n_frames, in
     return rc;
 }
 
-// ---- 512 x 512 and 1024 x 1024 frames: two kernels, the ring's columns of the row transforms through HBM -------
+// ---- frames with edges of 256 / 512 / 1024 pixels (256 x 256: wide rings only): two kernels, the ring's columns of
+// the row transforms through HBM ------------------------------------------------------------------------------------
 // A frame's K columns of row spectra (K <= N / 2 + 1) are 8 N bytes each: they do not fit the LDS.  k_cryst_rows
 // writes them to a workspace G[frame][kx][y] (float2), k_cryst_cols transforms one column per wave and sums the
 // ring: 2 + 2 * 8 K / N bytes of traffic per pixel and no spectrum beyond the ring's columns, where the hipFFT route
@@ -797,8 +797,8 @@ __device__ __forceinline__ void ch_fft(v2f *scr, const CfLane &c, const ChTw<M> 
 template <typename T, bool MASK, int M>
 __global__ void __launch_bounds__(CH_WAVES * 64)
 k_cryst_rows(const T *__restrict__ tile, int64_t ld, int64_t n_frames, const float *__restrict__ rmask_p,
-             const unsigned long long *__restrict__ rflags, int K, v2f *__restrict__ G) {
-    constexpr int N = 256 * M;
+             const unsigned long long *__restrict__ rflags, int K, int H, v2f *__restrict__ G) {
+    constexpr int N = 256 * M;                                      // row length; H rows per frame
     extern __shared__ __attribute__((aligned(16))) unsigned char cf_smem[];
     const int t = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -811,7 +811,7 @@ k_cryst_rows(const T *__restrict__ tile, int64_t ld, int64_t n_frames, const flo
     const int back = cf_sigma((64 - sig) & 63) * 4;
     const int st_col = sig * CH_STAGE + (w ^ (2 * ((sig >> 3) & 1)));   // + 64 c CH_STAGE (kx bit 3 = sigma bit 3)
     typedef T __attribute__((ext_vector_type(4 * M))) vec_t;
-    constexpr int GROUPS = N / 2 / CH_WAVES;                        // per frame
+    const int GROUPS = H / 2 / CH_WAVES;                            // per frame
     const int64_t n_groups = n_frames * GROUPS;
     for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int64_t f = grp / GROUPS;
@@ -856,7 +856,7 @@ k_cryst_rows(const T *__restrict__ tile, int64_t ld, int64_t n_frames, const flo
         for (int i = threadIdx.x; i < K * 8; i += CH_WAVES * 64) {
             const int kx = i >> 3, pi = i & 7;
             const v4f v = stage[kx * CH_STAGE + (kx < N / 2 ? pi ^ (2 * ((kx >> 3) & 1)) : pi)];
-            *(v4f *)(G + ((f * K + kx) * N + 16 * g + 2 * pi)) = v;
+            *(v4f *)(G + ((f * K + kx) * H + 16 * g + 2 * pi)) = v;
         }
         __syncthreads();
     }
@@ -920,19 +920,20 @@ k_cryst_cols(const v2f *__restrict__ G, int64_t n_frames, const float *__restric
 //   rmask_p[y'][8 M t + e]  = real_mask[2 y' + (e & 1)][4 M t + M ((e >> 1) & 3) + (e >> 3)]   (sample class q = e >> 3 first,
 //                             rows a / b interleaved);  rflags bit y' (N / 128 words): the pair holds a value other than 1
 __global__ void __launch_bounds__(256)
-k_cryst_masks_n(const float *__restrict__ half_mask, int N, int K, float *__restrict__ mask_p,
+k_cryst_masks_n(const float *__restrict__ half_mask, int W, int H, int K, float *__restrict__ mask_p,
                 const float *__restrict__ real_mask, float *__restrict__ rmask_p,
                 unsigned long long *__restrict__ rflags) {
+    // mask_p: lane order of the COLUMN transforms (H points); rmask_p: of the ROW transforms (W points)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int M = N / 256;
-    if (i < (int64_t)K * N) {
-        const int kx = (int)(i / N), r = (int)(i - (int64_t)kx * N), q = r >> 6, l = r & 63;
+    const int M = W / 256;
+    if (i < (int64_t)K * H) {
+        const int kx = (int)(i / H), r = (int)(i - (int64_t)kx * H), q = r >> 6, l = r & 63;
         const int ky = cf_sigma(l) + 64 * (q & 3) + 256 * (q >> 2);
-        mask_p[i] = half_mask[(int64_t)ky * (N / 2 + 1) + kx];
+        mask_p[i] = half_mask[(int64_t)ky * (W / 2 + 1) + kx];
     }
-    if (real_mask && i < (int64_t)N * N) {
-        const int yp = (int)(i / (2 * N)), rem = (int)(i - (int64_t)yp * 2 * N), tt = rem / (8 * M), e = rem - tt * 8 * M;
-        const float v = real_mask[(int64_t)(2 * yp + (e & 1)) * N + 4 * M * tt + M * ((e >> 1) & 3) + (e >> 3)];
+    if (real_mask && i < (int64_t)W * H) {
+        const int yp = (int)(i / (2 * W)), rem = (int)(i - (int64_t)yp * 2 * W), tt = rem / (8 * M), e = rem - tt * 8 * M;
+        const float v = real_mask[(int64_t)(2 * yp + (e & 1)) * W + 4 * M * tt + M * ((e >> 1) & 3) + (e >> 3)];
         rmask_p[i] = v;
         if (__builtin_amdgcn_ballot_w64(v != 1.f) && (threadIdx.x & 63) == 0)
             atomicOr(&rflags[yp >> 6], 1ull << (yp & 63));
@@ -941,7 +942,7 @@ k_cryst_masks_n(const float *__restrict__ half_mask, int N, int K, float *__rest
 
 template <typename T, int M>
 static int launch_rows(const void *tile, int64_t ld, int64_t n_frames, const float *real_mask,
-                       const unsigned long long *rflags, int K, v2f *G, int n_cu, hipStream_t stream) {
+                       const unsigned long long *rflags, int K, int H, v2f *G, int n_cu, hipStream_t stream) {
     auto kern = real_mask ? k_cryst_rows<T, true, M> : k_cryst_rows<T, false, M>;
     constexpr int N = 256 * M;
     const int lds = K * CH_STAGE * 16 + CH_WAVES * CF_SCR * 8;
@@ -961,28 +962,28 @@ static int launch_rows(const void *tile, int64_t ld, int64_t n_frames, const flo
         LTMI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, CH_WAVES * 64, (size_t)lds));
         per_cu = std::max(1, per_cu);
     }
-    const int64_t groups = n_frames * (N / 2 / CH_WAVES);
+    const int64_t groups = n_frames * (H / 2 / CH_WAVES);
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(groups, (int64_t)n_cu * std::max(1, per_cu)));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(CH_WAVES * 64), (size_t)lds, stream, (const T *)tile, ld, n_frames,
-                       real_mask, rflags, K, G);
+                       real_mask, rflags, K, H, G);
     LTMI_HIP(hipGetLastError());
     return LTMI_OK;
 }
 
-// N x N frames, N = 512 / 1024; gbuf: workspace of gbuf_frames * n_cols * N float2
-template <int M>
+// H x W frames, W = 256 M, H = 256 MH (M, MH = 1, 2, 4); gbuf: workspace of gbuf_frames * n_cols * H float2
+template <int M, int MH = M>
 static int cryst_rows_cols(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, const float *real_mask,
                            const float *half_mask, int n_cols, float *work, void *gbuf, int64_t gbuf_frames,
                            float *out, int accumulate, int n_cu, hipStream_t stream, bool *handled) {
-    constexpr int N = 256 * M;
+    constexpr int N = 256 * M, H = 256 * MH;
     if (n_cols < 1 || n_cols > N / 2 + 1 || !gbuf || gbuf_frames < 1) return LTMI_OK;
     const size_t esz = (size_t)dtype_size(tile_dtype);
     if (esz > 4 || tile_dtype == LTMI_F64) return LTMI_OK;
     if ((uintptr_t)tile % std::min<size_t>(16, 4 * M * esz) != 0 || ld % (4 * M) != 0) return LTMI_OK;
-    float *mask_p = work, *rmask_p = work + (int64_t)(N / 2 + 1) * N;
-    unsigned long long *rflags = (unsigned long long *)(rmask_p + (int64_t)N * N);
+    float *mask_p = work, *rmask_p = work + (int64_t)(N / 2 + 1) * H;
+    unsigned long long *rflags = (unsigned long long *)(rmask_p + (int64_t)N * H);
     LTMI_HIP(hipMemsetAsync(rflags, 0, 64, stream));
-    hipLaunchKernelGGL(k_cryst_masks_n, dim3((unsigned)((int64_t)N * N / 256)), dim3(256), 0, stream, half_mask, N,
+    hipLaunchKernelGGL(k_cryst_masks_n, dim3((unsigned)((int64_t)N * H / 256)), dim3(256), 0, stream, half_mask, N, H,
                        n_cols, mask_p, real_mask, rmask_p, rflags);
     const float *rm = real_mask ? rmask_p : nullptr;
     for (int64_t f0 = 0; f0 < n_frames; f0 += gbuf_frames) {
@@ -991,23 +992,23 @@ static int cryst_rows_cols(const void *tile, int tile_dtype, int64_t n_frames, i
         int rc = LTMI_E_DTYPE;
         switch (tile_dtype) {
             case LTMI_BOOL:
-            case LTMI_U8: rc = launch_rows<uint8_t, M>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
-            case LTMI_I8: rc = launch_rows<int8_t, M>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
-            case LTMI_U16: rc = launch_rows<uint16_t, M>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
-            case LTMI_I16: rc = launch_rows<int16_t, M>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
-            case LTMI_U32: rc = launch_rows<uint32_t, M>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
-            case LTMI_I32: rc = launch_rows<int32_t, M>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
-            case LTMI_F32: rc = launch_rows<float, M>(src, ld, n, rm, rflags, n_cols, (v2f *)gbuf, n_cu, stream); break;
+            case LTMI_U8: rc = launch_rows<uint8_t, M>(src, ld, n, rm, rflags, n_cols, H, (v2f *)gbuf, n_cu, stream); break;
+            case LTMI_I8: rc = launch_rows<int8_t, M>(src, ld, n, rm, rflags, n_cols, H, (v2f *)gbuf, n_cu, stream); break;
+            case LTMI_U16: rc = launch_rows<uint16_t, M>(src, ld, n, rm, rflags, n_cols, H, (v2f *)gbuf, n_cu, stream); break;
+            case LTMI_I16: rc = launch_rows<int16_t, M>(src, ld, n, rm, rflags, n_cols, H, (v2f *)gbuf, n_cu, stream); break;
+            case LTMI_U32: rc = launch_rows<uint32_t, M>(src, ld, n, rm, rflags, n_cols, H, (v2f *)gbuf, n_cu, stream); break;
+            case LTMI_I32: rc = launch_rows<int32_t, M>(src, ld, n, rm, rflags, n_cols, H, (v2f *)gbuf, n_cu, stream); break;
+            case LTMI_F32: rc = launch_rows<float, M>(src, ld, n, rm, rflags, n_cols, H, (v2f *)gbuf, n_cu, stream); break;
             default: return LTMI_OK;
         }
         if (rc != LTMI_OK) return rc;
-        static int per_cu = 0;                      // (one value per M: registers and static LDS only)
+        static int per_cu = 0;                      // (one value per MH: registers and static LDS only)
         if (per_cu == 0) {
-            LTMI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_cryst_cols<M>, CH_WAVES * 64, 0));
+            LTMI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_cryst_cols<MH>, CH_WAVES * 64, 0));
             per_cu = std::max(1, per_cu);
         }
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)n_cu * std::max(1, per_cu)));
-        hipLaunchKernelGGL(k_cryst_cols<M>, dim3(grid), dim3(CH_WAVES * 64), 0, stream, (const v2f *)gbuf, n,
+        hipLaunchKernelGGL(k_cryst_cols<MH>, dim3(grid), dim3(CH_WAVES * 64), 0, stream, (const v2f *)gbuf, n,
                            (const float *)mask_p, n_cols, out + f0, accumulate);
         LTMI_HIP(hipGetLastError());
     }
@@ -1021,12 +1022,17 @@ int cryst_fused(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, 
                 int64_t gbuf_frames, float *out, int accumulate, int n_cu, hipStream_t stream, bool *handled) {
     *handled = false;
     if (!mask_t) return LTMI_OK;
-    if (sig_h == 512 && sig_w == 512)
-        return cryst_rows_cols<2>(tile, tile_dtype, n_frames, ld, real_mask, half_mask, n_cols, mask_t, gbuf,
-                                  gbuf_frames, out, accumulate, n_cu, stream, handled);
-    if (sig_h == 1024 && sig_w == 1024)
-        return cryst_rows_cols<4>(tile, tile_dtype, n_frames, ld, real_mask, half_mask, n_cols, mask_t, gbuf,
-                                  gbuf_frames, out, accumulate, n_cu, stream, handled);
+    if ((sig_h == 256 || sig_h == 512 || sig_h == 1024) && (sig_w == 256 || sig_w == 512 || sig_w == 1024) &&
+        !(sig_h == 256 && sig_w == 256)) {
+        // rows of 256 M points, columns of 256 MH points: the ring's columns through the workspace
+#define LTMI_CRYST_RC(MW_, MH_)                                                                                   \
+        if (sig_w == 256 * MW_ && sig_h == 256 * MH_)                                                            \
+            return cryst_rows_cols<MW_, MH_>(tile, tile_dtype, n_frames, ld, real_mask, half_mask, n_cols, mask_t, \
+                                             gbuf, gbuf_frames, out, accumulate, n_cu, stream, handled);
+        LTMI_CRYST_RC(1, 2) LTMI_CRYST_RC(1, 4) LTMI_CRYST_RC(2, 1) LTMI_CRYST_RC(2, 2) LTMI_CRYST_RC(2, 4)
+        LTMI_CRYST_RC(4, 1) LTMI_CRYST_RC(4, 2) LTMI_CRYST_RC(4, 4)
+#undef LTMI_CRYST_RC
+    }
     if (sig_h == CG_N && sig_w == CG_N)
         return cryst_fused128(tile, tile_dtype, n_frames, ld, real_mask, half_mask, n_cols, mask_t, out, accumulate,
                               n_cu, stream, handled);

@@ -289,7 +289,7 @@ extern "C" int ltmi_fft_plan_create(int device, int sig_h, int sig_w, int max_ba
     if (cryst_fused_shape(sig_h, sig_w)) {
         const char *env = getenv("LTMI_FFT_FUSED");
         p->fused_ok = !(env && env[0] == '0');
-        e = hipMalloc((void **)&p->mask_t, (size_t)cryst_fused_workspace_floats(sig_h) * sizeof(float));
+        e = hipMalloc((void **)&p->mask_t, (size_t)cryst_fused_workspace_floats(sig_h, sig_w) * sizeof(float));
         if (e == hipSuccess) e = hipDeviceGetAttribute(&p->n_cu, hipDeviceAttributeMultiprocessorCount, device);
         if (e != hipSuccess) {
             if (p->mask_t) (void)hipFree(p->mask_t);
@@ -404,7 +404,7 @@ static int crystallinity_impl(ltmi_fft_plan *p, const void *tile, int tile_dtype
         if (rc != LTMI_OK) return rc;
         if (handled) {
             if (cryst_fused_needs_gbuf(p->h, p->w, n_cols))
-                snprintf(p->last_kernel, sizeof(p->last_kernel), "k_cryst_rows%d<%s%s> + k_cryst_cols%d columns=%d", p->h,
+                snprintf(p->last_kernel, sizeof(p->last_kernel), "k_cryst_rows%d<%s%s> + k_cryst_cols%d columns=%d", p->w,
                          dtype_name(tile_dtype), real_mask ? ",mask" : "", p->h, n_cols);
             else
                 snprintf(p->last_kernel, sizeof(p->last_kernel), "k_cryst_fused%s<%s%s> columns=%d",
@@ -435,7 +435,7 @@ static int crystallinity_impl(ltmi_fft_plan *p, const void *tile, int tile_dtype
         }
         if (cryst_fused_needs_gbuf(p->h, p->w, n_cols))
             snprintf(p->last_kernel, sizeof(p->last_kernel), "k_fft_prepare<%s> + k_cryst_rows%d<float32> + k_cryst_cols%d columns=%d",
-                     dtype_name(tile_dtype), p->h, p->h, n_cols);
+                     dtype_name(tile_dtype), p->w, p->h, n_cols);
         else
             snprintf(p->last_kernel, sizeof(p->last_kernel), "k_fft_prepare<%s> + k_cryst_fused%s<float32> columns=%d",
                      dtype_name(tile_dtype), p->h == 128 ? "128" : "", n_cols);

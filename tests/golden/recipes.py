@@ -499,6 +499,10 @@ CRYST_CASES = [
          rad_in=32, rad_out=128, real_center=(256, 256), real_rad=50),
     dict(name='u8_1024', nav=(2,), sig=(1024, 1024), dtype='uint8', num_partitions=1, seed=809,
          rad_in=64, rad_out=256, real_center=None, real_rad=None),
+    dict(name='u16_256x512', nav=(3,), sig=(256, 512), dtype='uint16', num_partitions=1, seed=810,
+         rad_in=16, rad_out=90, real_center=(128, 256), real_rad=30),
+    dict(name='f32_512x256_wide', nav=(2,), sig=(512, 256), dtype='float32', num_partitions=1, seed=811,
+         rad_in=40, rad_out=300, real_center=None, real_rad=None),
 ]
 
 

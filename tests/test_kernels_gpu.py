@@ -1892,3 +1892,24 @@ def test_crystallinity_1024_every_bin_and_converted_frames(hip):
     got, label = _cryst_run(hip, frames, real_mask, half, batch=3)
     assert label.startswith('k_fft_prepare<float64> + k_cryst_rows1024<float32>'), label
     assert np.allclose(got, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['uint16', 'float32'])
+@pytest.mark.parametrize('sig', [(256, 512), (512, 256), (1024, 256), (256, 1024), (512, 1024), (1024, 512)])
+def test_crystallinity_rectangular_frames(hip, dtype, sig):
+    """frames whose edges are 256 / 512 / 1024 pixels in any combination: rows of 256 M points, columns of 256 MH
+    points, the ring's columns through the workspace (k_cryst_rows<w> + k_cryst_cols<h>)."""
+    rng = np.random.default_rng(_seed('cryst-rect', dtype, sig))
+    dt = np.dtype(dtype)
+    n = 5
+    h, w = sig
+    frames = (rng.normal(size=(n, h, w)) * 100).astype(dt) if dt.kind == 'f' else \
+        rng.integers(0, 4000, size=(n, h, w)).astype(dt)
+    frames[1] = 0
+    for rad_in, rad_out, real in ((min(sig) // 16, min(sig) // 4, ((h / 2, w / 2), min(sig) // 10)), (0, 2000, None)):
+        ref, real_mask, half = _cryst_reference(frames, rad_in, rad_out, real)
+        got, label = _cryst_run(hip, frames, real_mask, half, batch=3)
+        assert label.startswith(f'k_cryst_rows{w}<') and f'k_cryst_cols{h} ' in label, label
+        assert np.allclose(got, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max()), (sig, rad_out, got, ref)
+        assert got[1] == 0
