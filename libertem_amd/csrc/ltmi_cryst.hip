@@ -766,11 +766,12 @@ __device__ __forceinline__ void ch_lane_setup(int t, CfLane &c, ChTw<M> &h) {
 }
 
 // u[q][j] = z[4 M t + M j + q]  ->  u[m][k2] = X[sigma + 64 k2 + 256 m]
-template <int M>
+// SWAPPED: the input is in the layout after the first swap already: u[q][r] = z[M (64 r + 4 (t & 15) + (t >> 4)) + q]
+template <int M, bool SWAPPED = false>
 __device__ __forceinline__ void ch_fft(v2f *scr, const CfLane &c, const ChTw<M> &h, v2f (&u)[M][4]) {
 #pragma unroll
     for (int q = 0; q < M; ++q) {
-        cf_swap_a(u[q]);
+        if (!SWAPPED) cf_swap_a(u[q]);
         cf_core(scr, c, u[q]);
     }
     if (M == 1) return;                          // (256 points: one transform, nothing to combine)
@@ -879,19 +880,30 @@ k_cryst_cols(const v2f *__restrict__ G, int64_t n_frames, const float *__restric
     for (int64_t f = blockIdx.x; f < n_frames; f += gridDim.x) {
         float acc = 0.f;
         for (int kx = w; kx < K; kx += CH_WAVES) {
-            const v4f *col = (const v4f *)(G + (f * K + kx) * N) + 2 * M * t;
+            // lane t takes the samples M (64 r + 4 (t & 15) + (t >> 4)) + q -- the layout cf_core starts from, so the
+            // first lane exchange is not needed -- and a load instruction covers 64 M contiguous float2 (a lane's 4 M
+            // CONSECUTIVE samples made every instruction touch all of the column's lines: 175 us per 1 024 columns
+            // of 129 x 512 from HBM, 2.3 x the time of this order)
+            const v2f *col = G + (f * K + kx) * N + M * (4 * (t & 15) + (t >> 4));
             v2f u[M][4];
 #pragma unroll
-            for (int i = 0; i < 2 * M; ++i) {                       // samples 2 i, 2 i + 1 of the lane's 4 M
-                const v4f q = __builtin_nontemporal_load(col + i);
-                u[(2 * i) % M][(2 * i) / M] = q.xy;
-                u[(2 * i + 1) % M][(2 * i + 1) / M] = q.zw;
+            for (int r = 0; r < 4; ++r) {
+                if (M == 1) {
+                    u[0][r] = __builtin_nontemporal_load(col + 64 * r);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < M / 2; ++i) {
+                        const v4f q = __builtin_nontemporal_load((const v4f *)(col + M * 64 * r) + i);
+                        u[2 * i][r] = q.xy;
+                        u[(2 * i + 1) % M][r] = q.zw;
+                    }
+                }
             }
             const float *mrow = mask_p + (int64_t)kx * (4 * M * 64) + t;
             float mk[4 * M];
 #pragma unroll
             for (int q = 0; q < 4 * M; ++q) mk[q] = mrow[q * 64];
-            ch_fft<M>(scr, c, h, u);
+            ch_fft<M, true>(scr, c, h, u);
 #pragma unroll
             for (int q = 0; q < 4 * M; ++q)
                 if (__builtin_amdgcn_ballot_w64(mk[q] != 0.f)) {
