@@ -470,6 +470,9 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
 // the unrolling, ring position = position in the unrolled body), compiler-visible accumulators are copied at
 // every merge of the four accumulator-set arms, and a ring behind asm loads must not be moved by the compiler
 // while a load is in flight.  What this buys and what still bounds the kernel: profiles/r03_sparse.txt, DESIGN 4.3.
+#ifndef BE_DMA_AUX
+#define BE_DMA_AUX 0                // cache-policy bits of the frame copies of k_bell_flat (2 = nt)
+#endif
 #ifndef BE_PHASE_SLEEP
 #define BE_PHASE_SLEEP 8            // s_sleep units (64 cycles) per phase step, 16 steps
 #endif
@@ -628,7 +631,7 @@ k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             if (byte_in_row + 16 > n_px * C::SZ) byte_in_row = 0;
             const unsigned char *src = (const unsigned char *)(tile + fr * ld) + byte_in_row;
             __builtin_amdgcn_global_load_lds((b_glb_ptr_t)src,
-                                             (b_lds_ptr_t)(be_lds + buf * C::BUF + dst), 16, 0, 0);
+                                             (b_lds_ptr_t)(be_lds + buf * C::BUF + dst), 16, 0, BE_DMA_AUX);
         }
     };
 
@@ -731,7 +734,7 @@ k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                 else if (nb == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD - 1 + 2 * NDMA) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BE_FD - 1 + 3 * NDMA) : "memory");
             }
-            if (!(c & BE_C_SKIP)) {
+            if (!(c & BE_C_SKIP) && ablate < 4) {   // (ablate 4: frame copies + record stream only, 5: frame copies only)
                 // a record = 8 aligned pixel pairs x 16 masks: lane group kg holds the pairs qa, qb; the K
                 // slots of v_mfma_f32_16x16x32_f16 are [lo(qa) lo(qa+1) hi(qa) hi(qa+1) | the same of qb]
                 // against [w(qa) w(qa+1) 256 w(qa) 256 w(qa+1) | ...], one MFMA for w1, one for w2
@@ -778,7 +781,7 @@ k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                 if (sl == 0u) { BE_ARM(0) } else if (sl == 1u) { BE_ARM(1) }
                 else if (sl == 2u) { BE_ARM(2) } else { BE_ARM(3) }
             }
-            ring_load(U, (int64_t)(i + u + BE_FD));
+            if (ablate != 5) ring_load(U, (int64_t)(i + u + BE_FD));
             since = since < 63 ? since + 1 : since;
             win <<= 1;
             ++r_cur;

@@ -18,9 +18,19 @@ ap.add_argument('--bins', type=int, default=1024)
 ap.add_argument('--reps', type=int, default=10)
 ap.add_argument('--dtype', default='uint16')
 ap.add_argument('--only', type=int, default=0, help='tuning code of the one variant to run')
+ap.add_argument('--keep', default='all', choices=['all', 'quarter', 'half'],
+                help="timing model of a mirror-folded stack: keep only the entries of a quarter (x >= cx, y even) "
+                     "or half (y even) of the pixels -- the frames (and their copies) stay whole")
 args = ap.parse_args()
 rings = pm.radial_bins(128, 128, 256, 256, n_bins=args.bins, use_sparse=True, dtype=np.float32)
 csr = rings.to_px_by_masks(dtype=np.float32)
+if args.keep != 'all':
+    yy, xx = np.divmod(np.arange(65536), 256)
+    keep = (yy % 2 == 0) & ((xx >= 128) if args.keep == 'quarter' else True)
+    import scipy.sparse as sps
+    csr = sps.diags(keep.astype(np.float32)).dot(csr).tocsr()
+    csr.eliminate_zeros()
+    csr.sort_indices()
 print('nnz', csr.nnz)
 h = hip.MaskHandle.csr(0, csr, np.float32)
 dt = np.dtype(args.dtype)
