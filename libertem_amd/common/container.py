@@ -274,6 +274,13 @@ class MaskContainer:
                     h = hip.MaskHandle.dense(device, dense, result_dtype)
                 else:
                     h = hip.MaskHandle.csr(device, m, result_dtype)
+            # the detector shape of the slice: a dense float32 / complex64 stack that is even / odd under a
+            # mirror of the detector rows (radial Fourier, rings, centre-of-mass ramps) is then multiplied
+            # folded -- half the pixels on the matrix cores (include/ltmi.h: ltmi_masks_set_sig_shape)
+            sig = tuple(int(n) for n in sig_slice.shape.sig)
+            if len(sig) == 2 and h.n_px == sig[0] * sig[1] and np.dtype(result_dtype) in (
+                    np.dtype(np.float32), np.dtype(np.complex64)):
+                h.set_sig_shape(sig[0], sig[1])
             self._handle_cache[key] = h
         return h
 

@@ -137,6 +137,17 @@ bool cryst_fused_needs_gbuf(int h, int w, int n_cols);
 int cryst_fused(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, int sig_h, int sig_w,
                 const float *real_mask, const float *half_mask, int n_cols, float *mask_t, void *gbuf,
                 int64_t gbuf_frames, float *out, int accumulate, int n_cu, hipStream_t stream, bool *handled);
+// dense stacks folded about a mirror of the detector rows (ltmi_fold.hip)
+int fold_create(ltmi_masks *m, int sig_h, int sig_w);
+void fold_destroy(ltmi_masks *m);
+bool fold_takes(const ltmi_masks *m, const float *tile, int64_t ld);
+int launch_fold(ltmi_masks *m, const float *tile, int64_t n_frames, int64_t ld, float *out, int64_t ld_out,
+                int accumulate, hipStream_t stream);
+// the K-split workspace of a dense handle (ltmi_dense.hip)
+int dense_ensure_partials(ltmi_masks *m, size_t need, hipStream_t stream);
+float *dense_partial_sums(const ltmi_masks *m);
+int dense_reduce_partials(ltmi_masks *m, int ksplit, int64_t n_frames, float *out, int64_t ld_out, int accumulate,
+                          hipStream_t stream);
 int bell_apply(ltmi_masks *m, void *image, int cplx, const void *tile, int tile_dtype,
                int64_t n_frames, int64_t ld_tile, void *out, int64_t ld_out, int accumulate,
                hipStream_t stream, bool *handled);
@@ -181,6 +192,7 @@ struct ltmi_masks {
     size_t res64_bytes = 0;
     int mask_bits = 64;      // integer stacks: bits needed for max |mask value|
     void *shift_cache = nullptr;   // ltmi_dense.hip: images of the stack shifted by (dy, dx)
+    void *fold = nullptr;          // ltmi_fold.hip: image folded about a mirror of the detector rows (ltmi_masks_set_sig_shape)
     float *partials = nullptr;
     size_t partials_bytes = 0;
     int tune_mt = 0, tune_waves = 0, tune_ksplit = 0, tune_ksplit_ring = 0;

@@ -1636,6 +1636,7 @@ extern "C" int ltmi_masks_destroy(ltmi_masks *m) {
     for (ltmi_masks *b : m->blocks) (void)ltmi_masks_destroy(b);
     m->blocks.clear();
     (void)hipSetDevice(m->device);
+    fold_destroy(m);
     if (m->img) (void)hipFree(m->img);
     if (m->img2) (void)hipFree(m->img2);
     if (m->img3) (void)hipFree(m->img3);
@@ -1657,6 +1658,20 @@ extern "C" int ltmi_masks_destroy(ltmi_masks *m) {
     return LTMI_OK;
 }
 
+extern "C" int ltmi_masks_set_sig_shape(ltmi_masks *m, int sig_h, int sig_w) {
+    if (!m) LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_set_sig_shape: null handle");
+    if (sig_h <= 0 || sig_w <= 0 || (int64_t)sig_h * sig_w != m->n_px)
+        LTMI_FAIL(LTMI_E_SHAPE, "ltmi_masks_set_sig_shape: %d x %d is not the handle's %lld pixels", sig_h, sig_w,
+                  (long long)m->n_px);
+    LTMI_HIP(hipSetDevice(m->device));
+    for (ltmi_masks *b : m->blocks) {
+        const int rc = ltmi_masks_set_sig_shape(b, sig_h, sig_w);
+        if (rc != LTMI_OK) return rc;
+    }
+    if (m->kind != 0) return LTMI_OK;
+    return fold_create(m, sig_h, sig_w);
+}
+
 extern "C" int ltmi_masks_kind(const ltmi_masks *m, int *kind) {
     if (!m || !kind) LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_kind: null argument");
     *kind = m->kind;
@@ -1665,10 +1680,11 @@ extern "C" int ltmi_masks_kind(const ltmi_masks *m, int *kind) {
 
 extern "C" int ltmi_masks_set_tuning(ltmi_masks *m, int mt, int waves, int ksplit) {
     if (!m) LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_set_tuning: null handle");
-    if (mt == 0 && ((waves >= 30 && waves <= 37) || (waves >= 40 && waves <= 42))) {
+    if (mt == 0 && ((waves >= 30 && waves <= 38) || (waves >= 40 && waves <= 42))) {
         // k_dense_lds: 30 = as dispatched, 31 / 32 = timing-only ablations (no DMA / no MFMA),
         // 34 / 35 = one / two frame tiles per wave; 36 = k_dense_split (float32 frames, ltmi_split.hip);
         // 37 = the float32 matrix instruction also where the exact float16 products (X16) apply;
+        // 38 = the unfolded kernels for a stack that has a row-mirror image (ltmi_fold.hip);
         // sparse stacks: 40 = as dispatched, 41 = SELL kernel even if a blocked / scatter image exists,
         // 42 = not the scatter kernel (blocked image or SELL)
         m->tune_mt = 0;
@@ -1945,6 +1961,18 @@ static int launch_lds_extras(ltmi_masks *m, const T *tile, int64_t n_frames, int
     return launch_lds_extras_t<T, NG, NE, 2>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
 }
 
+// (for the kernels of other translation units that split the pixel axis: ltmi_fold.hip)
+int ltmi::dense_ensure_partials(ltmi_masks *m, size_t need, hipStream_t stream) { return ensure_partials(m, need, stream); }
+float *ltmi::dense_partial_sums(const ltmi_masks *m) { return partial_sums(m); }
+int ltmi::dense_reduce_partials(ltmi_masks *m, int ksplit, int64_t n_frames, float *out, int64_t ld_out, int accumulate,
+                                hipStream_t stream) {
+    const int64_t n = n_frames * m->n_cols;
+    hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       (const float *)partial_sums(m), ksplit, n_frames, m->n_cols, out, ld_out, accumulate);
+    LTMI_HIP(hipGetLastError());
+    return LTMI_OK;
+}
+
 template <typename T>
 static bool lds_kernel_applies(const ltmi_masks *m) {
     return m->n_px >= (m->ng == 1 ? KC : 128);
@@ -1953,6 +1981,12 @@ static bool lds_kernel_applies(const ltmi_masks *m) {
 template <typename T>
 static int launch_lds(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out,
                       int64_t ld_out, int accumulate, hipStream_t stream) {
+    // float32 frames of a stack whose columns are even / odd under a mirror of the detector rows: half the pixels
+    // on the matrix cores (ltmi_fold.hip; the handle knows the frame shape through ltmi_masks_set_sig_shape)
+    if constexpr (std::is_same<T, float>::value) {
+        if (fold_takes(m, tile, ld))
+            return launch_fold(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+    }
     if (m->ng == 1) {
         // at most 4 columns (CoM: 3, single-mask analyses: 1 or 2): all of them on the VALU -- a
         // 16-column MFMA tile would be >= 75 % padding that still costs matrix-pipe power

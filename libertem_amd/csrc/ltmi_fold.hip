@@ -1,0 +1,504 @@
+// Row-mirror fold of dense stacks: k_dense_fold and the folded image of a handle (ltmi_masks::fold).
+//
+// Virtual-detector stacks are often symmetric under the reflection of the detector rows about the centre the
+// masks were built around: radial-Fourier masks ring(r) * exp(i o phi) (src/libertem/analysis/radialfourier.py:
+// 106-146; phi = arctan2(dy, dx), utils/__init__.py:41-44) have real parts that are EVEN and imaginary parts that
+// are ODD under dy -> -dy, bit for bit (arctan2, cos and sin of the math library are exactly odd / even); rings,
+// disks and the centre-of-mass ramps (udf/com.py:47-97) likewise.  For a column c that is even (s = +1) or odd
+// (s = -1) under y -> y' = c2 - y:
+//
+//     sum_p x[p] w_c[p]  =  sum over row pairs (y < y') and x of  (x[y, x] + s x[y', x]) * w_c[y, x]   (+ unpaired rows)
+//
+// with the ORIGINAL float32 weights of the rows y -- nothing is averaged, so a frame with a single non-zero pixel
+// gives exactly pixel * weight like the unfolded product.  The matrix cores then see half of the pixels: the even
+// columns against e = a + c, the odd ones against o = a - c (two v_pk_add_f32 per pixel pair of a lane).  C5
+// (25 complex masks on 1024 x 1024 float32 frames): 2 + 2 groups of 16 columns over 513 x 1024 folded pixels
+// instead of 3 groups + 2 VALU columns over 1024 x 1024 -- the matrix work drops from 24 (+ VALU) to 16
+// v_mfma_f32_16x16x4_f32 per 32 pixels and frame tile and the kernel moves from the matrix pipe to the HBM.
+// (The reflection of the columns, dx -> -dx, is NOT exact for these masks -- arctan2(dy, -dx) = pi - arctan2(dy, dx)
+// rounds -- so only the row mirror is used; a stack in which one column is neither even nor odd is not folded.)
+//
+// Kernel: the frame layout, piece swizzle and fragment reads of k_dense_lds<float> (4 waves x 32 frames, LDS-DMA of
+// 4 rows x 256 B per instruction); a STAGE is 64 folded pixels = 256 B of detector row y ("A" part) and of row y'
+// ("C" part; unpaired rows: a zero page) of the wave's frames, and it is copied and multiplied in two HALF-stages
+// (one 16-frame tile each): the LDS holds four half-stages of 32 KiB -- one being multiplied, three on their way
+// (96 KiB per CU in flight; whole stages would leave room for one in flight only: 7.4 ms per 8192 frames of C5,
+// one 64-KiB stage per 3.6 us; HBM -> registers -> LDS with two stages in flight in the register file: 8.9 ms,
+// the stores and their waits stand in the matrix instructions' way) -- and the mask slot of a stage (NGE + NGO
+// groups x 16 columns x 64 pixels, <= 16 KiB) double buffered behind them; one s_barrier per stage, counted waits.
+#include "ltmi_common.h"
+#include <vector>
+#include <cstdlib>
+#include <type_traits>
+
+namespace ltmi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *glb_ptr_t;
+constexpr int GROUP = 16;                  // mask columns per MFMA group (N of 16x16x4)
+
+
+constexpr int FD_KB = 64;                            // folded pixels per stage / mask slot
+constexpr int FD_WAVES = 4, FD_TILES = 2;
+constexpr int FD_ROWS = 16 * FD_TILES;               // frames per wave
+constexpr int FD_TPART = 16 * 256;                   // 4 KiB: rows y (or y') of one 16-frame tile of a wave, one stage
+constexpr int FD_HALF = 2 * FD_WAVES * FD_TPART;     // 32 KiB: a half-stage = one tile of every wave, parts A and C
+constexpr int FD_RING = 4;                           // half-stages in LDS: one being multiplied, three on their way
+constexpr int FD_WG_ROWS = FD_WAVES * FD_ROWS;       // 128 frames per workgroup
+__host__ __device__ constexpr int fold_slot_bytes(int ng) { return ng * GROUP * FD_KB * 4; }
+__host__ __device__ constexpr int fold_lds_bytes(int ng) { return FD_RING * FD_HALF + 2 * fold_slot_bytes(ng); }
+
+// Position of (column n of a group, pixel q of the 64-pixel slot) inside the group's 4 KiB: rows of 256 B (one
+// per column) hold 16 units of 16 B; lane (n, kg) reads unit (kg, c = 2 blk + h).  All rows start on the same
+// bank, so the 16 lanes of a ds_read_b128 service group -- {n 0-3, 12-15 of kg} + {n 4-11 of kg ^ 1} -- must land
+// on 16 different units: the high bits are kg ^ g(n >> 2) with g = (0, 3, 2, 1), the low bits c ^ (n & 3).
+__host__ __device__ static inline int fold_index(int n, int q) {
+    const int blk = q >> 5, kg = (q >> 3) & 3, j = q & 7;
+    const int hi = kg ^ ((4 - (n >> 2)) & 3);
+    const int lo = (blk * 2 + (j >> 2)) ^ (n & 3);
+    return n * FD_KB + (hi * 4 + lo) * 4 + (j & 3);
+}
+
+// raw stack -> fold image: virtual column v of the folded stack is real column colmap[v] (-1: padding), folded
+// pixel pf = fy * sig_w + x is pixel rows[fy].x * sig_w + x of the stack
+__global__ void k_build_fold_image(const float *__restrict__ src, float *__restrict__ img, int cpm, int64_t n_px,
+                                   int sig_w, int n_fold_rows, const int2 *__restrict__ rows,
+                                   const int *__restrict__ colmap, int ng) {
+    const int64_t total = (int64_t)ng * GROUP * n_fold_rows * sig_w;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pf = i % ((int64_t)n_fold_rows * sig_w);
+        const int v = (int)(i / ((int64_t)n_fold_rows * sig_w));
+        const int col = colmap[v];
+        const int fy = (int)(pf / sig_w), x = (int)(pf % sig_w);
+        float w = 0.f;
+        if (col >= 0) {
+            const int64_t k = col / cpm, part = col % cpm;
+            w = src[(k * n_px + (int64_t)rows[fy].x * sig_w + x) * cpm + part];
+        }
+        const int64_t slot = pf / FD_KB;
+        const int q = (int)(pf % FD_KB);
+        img[(slot * ng + v / GROUP) * (GROUP * FD_KB) + fold_index(v % GROUP, q)] = w;
+    }
+}
+
+// even[col] / odd[col] (preset to 1) are cleared when the column is not even / odd under y -> c2 - y
+__global__ void k_fold_classify(const float *__restrict__ src, int cpm, int64_t n_masks, int sig_h, int sig_w,
+                                int c2, int *__restrict__ even, int *__restrict__ odd) {
+    const int64_t n_px = (int64_t)sig_h * sig_w;
+    const int64_t total = n_masks * cpm * n_px;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int part = (int)(i % cpm);
+        const int64_t kp = i / cpm;
+        const int64_t k = kp / n_px, p = kp % n_px;
+        const int y = (int)(p / sig_w), x = (int)(p % sig_w);
+        const int y2 = c2 - y;
+        if (y2 <= y || y2 >= sig_h) continue;                         // each pair once; unpaired rows: free
+        const float a = src[i], b = src[((k * n_px) + (int64_t)y2 * sig_w + x) * cpm + part];
+        const int col = (int)(k * cpm + part);
+        if (!(a == b)) even[col] = 0;                                  // (NaN: neither)
+        if (!(a == -b)) odd[col] = 0;
+    }
+}
+
+template <int NGE, int NGO, int ABL = 0>
+__global__ void __launch_bounds__(FD_WAVES * 64)
+k_dense_fold(const float *__restrict__ tile, int64_t ld, int64_t n_frames, int spr /* stages per row */,
+             const int2 *__restrict__ fold_rows, const float *__restrict__ img, int n_stages,
+             float *__restrict__ out, int64_t ld_out, int n_cols, const int *__restrict__ colmap,
+             int accumulate, float *__restrict__ partials, int ksplit,
+             const unsigned char *__restrict__ zeros, const int32_t *__restrict__ rows) {
+    constexpr int NG = NGE + NGO;
+    constexpr int BSLOT = fold_slot_bytes(NG);
+    constexpr int NBI = BSLOT / FD_WAVES / 1024;          // mask-slot DMA instructions per wave and stage
+    constexpr int NDH = 16 / 4;                           // DMA instructions per part of a half-stage (4 rows x 256 B each)
+    constexpr int NF = 2 * NDH;                           // ... per half-stage (A and C)
+    static_assert(BSLOT % (FD_WAVES * 1024) == 0, "whole DMA instructions per wave");
+    static_assert(2 * NF + NBI < 64, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int m = lane & 15, kg = lane >> 4;
+    const int ks = blockIdx.y;
+    const int per = (n_stages + ksplit - 1) / ksplit;
+    const int s_begin = ks * per;
+    const int s_end = min(n_stages, s_begin + per);
+
+    const int64_t f_wave = (int64_t)blockIdx.x * FD_WG_ROWS + wave * FD_ROWS;
+    auto frame_of = [&](int r) -> int64_t {                 // result row (-1: none)
+        const int64_t f = f_wave + r;
+        return f < n_frames ? f : -1;
+    };
+    auto src_frame_of = [&](int r) -> int64_t {             // frame to read (clamped: loads stay valid)
+        int64_t f = frame_of(r);
+        if (rows) return f < 0 ? (int64_t)rows[0] : (int64_t)rows[f];
+        return f < 0 ? n_frames - 1 : f;
+    };
+
+    // ring slot q: the wave's 16 rows of part A (4 KiB), then of part C
+    unsigned char *a_base = lds_raw + wave * (2 * FD_TPART);                // + q * FD_HALF
+    unsigned char *b_base = lds_raw + FD_RING * FD_HALF;                    // + slot * BSLOT
+
+    f32x4 acc[FD_TILES][NG], acc2[FD_TILES][NG];
+#pragma unroll
+    for (int tl = 0; tl < FD_TILES; ++tl)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[tl][g] = acc2[tl][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (s_begin < s_end) {
+        const unsigned char *src[FD_TILES][NDH];
+#pragma unroll
+        for (int tl = 0; tl < FD_TILES; ++tl)
+#pragma unroll
+            for (int t = 0; t < NDH; ++t) {
+                const int r = 4 * t + lane / 16;                            // row inside the tile
+                const int piece = (lane & 15) ^ r;
+                src[tl][t] = (const unsigned char *)(tile + src_frame_of(tl * 16 + r) * ld) + piece * 16;
+            }
+        const unsigned char *zsrc = zeros + lane * 16;
+        const unsigned char *bsrc = (const unsigned char *)img + wave * (BSLOT / FD_WAVES) + lane * 16;
+
+        // half-stages are issued in order: (stage, tile 0), (stage, tile 1), (stage + 1, tile 0) ...; past the end
+        // the last stage again (clamped prefetch: every step issues the same number of copies, the waits count them)
+        int iss = s_begin, iss_fy = s_begin / spr, iss_xs = s_begin % spr;
+        auto issue_half = [&](auto TL, auto Q) {
+            constexpr int tl = decltype(TL)::value, q = decltype(Q)::value;
+            if (ABL >= 2) return;
+            const int2 rr = fold_rows[iss_fy];
+            const int64_t off_a = ((int64_t)rr.x * spr + iss_xs) * 256;
+            const int64_t off_c = ((int64_t)rr.y * spr + iss_xs) * 256;
+            const bool pair = rr.y >= 0;
+            unsigned char *da = a_base + q * FD_HALF, *dc = da + FD_TPART;
+#pragma unroll
+            for (int t = 0; t < NDH; ++t)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[tl][t] + off_a), (lds_ptr_t)(da + t * 1024), 16, 0,
+                                                 2 /*nt*/);
+#pragma unroll
+            for (int t = 0; t < NDH; ++t) {
+                const unsigned char *p = pair ? src[tl][t] + off_c : zsrc;
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)p, (lds_ptr_t)(dc + t * 1024), 16, 0, 2 /*nt*/);
+            }
+            if (tl == FD_TILES - 1 && iss + 1 < s_end) {
+                ++iss;
+                if (++iss_xs == spr) { iss_xs = 0; ++iss_fy; }
+            }
+        };
+        auto issue_b = [&](int s, int bslot) {              // mask slot of stage s (clamped)
+            if (ABL >= 2) return;
+            unsigned char *db = b_base + bslot * BSLOT + wave * (BSLOT / FD_WAVES);
+            const unsigned char *sp = bsrc + (int64_t)min(s, s_end - 1) * BSLOT;
+#pragma unroll
+            for (int u = 0; u < NBI; ++u)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(sp + u * 1024), (lds_ptr_t)(db + u * 1024), 16, 0, 0);
+        };
+
+        // lane-constant parts of the fragment addresses
+        const int a_lane = m * 256;
+        const int b_lane = m * FD_KB;                                       // floats
+        const int b_hi = (kg ^ ((4 - (m >> 2)) & 3)) * 4;
+        auto b_unit = [&](int blk, int h) { return (b_hi + ((blk * 2 + h) ^ (m & 3))) << 2; };
+
+        // one tile (16 frames) of one stage: 2 blocks of 32 folded pixels x NG groups
+        auto compute = [&](auto TL, auto Q, auto BS) {
+            constexpr int tl = decltype(TL)::value, q = decltype(Q)::value, bslot = decltype(BS)::value;
+            const unsigned char *as = a_base + q * FD_HALF + a_lane;
+            const unsigned char *cs = as + FD_TPART;
+            const float *bs = (const float *)(b_base + bslot * BSLOT) + b_lane;
+            f32x4 ra[2][2], rc[2][2], rb[2][NG][2];
+            auto load_block = [&](int blk, int buf) {
+                const int u = blk * 4 + kg;                  // 8-pixel unit of this lane inside the part
+                ra[buf][0] = *(const f32x4 *)(as + (((2 * u) ^ m) << 4));
+                ra[buf][1] = *(const f32x4 *)(as + (((2 * u + 1) ^ m) << 4));
+                rc[buf][0] = *(const f32x4 *)(cs + (((2 * u) ^ m) << 4));
+                rc[buf][1] = *(const f32x4 *)(cs + (((2 * u + 1) ^ m) << 4));
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    rb[buf][g][0] = *(const f32x4 *)(bs + g * (GROUP * FD_KB) + b_unit(blk, 0));
+                    rb[buf][g][1] = *(const f32x4 *)(bs + g * (GROUP * FD_KB) + b_unit(blk, 1));
+                }
+            };
+            load_block(0, 0);
+#pragma unroll
+            for (int blk = 0; blk < FD_KB / 32; ++blk) {
+                const int cur = blk & 1;
+                if (blk + 1 < FD_KB / 32) load_block(blk + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);           // keep the prefetch reads above the MFMAs
+                float e[8], o[8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 ev = ra[cur][h] + rc[cur][h];
+                    const f32x4 ov = ra[cur][h] - rc[cur][h];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { e[h * 4 + i] = ev[i]; o[h * 4 + i] = ov[i]; }
+                }
+                if (ABL == 1) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+                            acc[tl][g][j & 3] += (g < NGE ? e[j] : o[j]) + rb[cur][g][j >> 2][j & 3];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+                            acc[tl][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                g < NGE ? e[j] : o[j], rb[cur][g][j >> 2][j & 3], acc[tl][g], 0, 0, 0);
+                }
+            }
+        };
+
+        // Step h (half-stage h = 2 (s - s_begin) + tl, ring slot h % 4): copies are issued in the order
+        //   step h:  [tl = 0: B(s + 1)]  F(h + 3)
+        // so at the start of step h the copies younger than F(h) and -- tl = 0 -- than B(s) (issued at step h - 2) are
+        //   tl = 0:  F(h + 1), F(h + 2)              -> vmcnt(2 NF)
+        //   tl = 1:  F(h + 1), B(s + 1), F(h + 2)    -> vmcnt(2 NF + NBI)
+        int since_flush = 0;
+        auto step = [&](auto TL, auto Q, auto BS, int s) {
+            constexpr int tl = decltype(TL)::value, q = decltype(Q)::value, bslot = decltype(BS)::value;
+            if (tl == 0) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NF) : "memory");
+                if (ABL < 3) __builtin_amdgcn_s_barrier();   // everybody's quarter of B(s) is there, B(s - 1) is free
+                issue_b(s + 1, bslot ^ 1);
+            } else {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NF + NBI) : "memory");
+            }
+            // the slot of half-stage h - 1 (this wave's rows only: it is done with them)
+            issue_half(std::integral_constant<int, (tl + 1) & 1>{}, std::integral_constant<int, (q + 3) & 3>{});
+            compute(TL, Q, BS);
+            if (tl == 1 && ++since_flush == 16) {            // second accumulation level every 1024 folded pixels
+                since_flush = 0;
+#pragma unroll
+                for (int t2 = 0; t2 < FD_TILES; ++t2)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        acc2[t2][g] += acc[t2][g];
+                        acc[t2][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>;
+        // prologue: B(s_begin), F(0), F(1), F(2)   (step 0 then issues B(s_begin + 1) and F(3))
+        issue_b(s_begin, 0);
+        issue_half(I0{}, I0{});
+        issue_half(I1{}, I1{});
+        issue_half(I0{}, I2{});
+        int s = s_begin;
+        for (; s + 2 <= s_end; s += 2) {
+            step(I0{}, I0{}, I0{}, s);
+            step(I1{}, I1{}, I0{}, s);
+            step(I0{}, I2{}, I1{}, s + 1);
+            step(I1{}, I3{}, I1{}, s + 1);
+        }
+        if (s < s_end) {
+            step(I0{}, I0{}, I0{}, s);
+            step(I1{}, I1{}, I0{}, s);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the clamped prefetches
+    }
+
+#pragma unroll
+    for (int tl = 0; tl < FD_TILES; ++tl)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int col = colmap[g * GROUP + m];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t f = frame_of(tl * 16 + kg * 4 + r);
+                if (f >= 0 && col >= 0) {
+                    const float v = acc[tl][g][r] + acc2[tl][g][r];
+                    if (ksplit == 1) {
+                        float *p = out + f * ld_out + col;
+                        *p = accumulate ? (*p + v) : v;
+                    } else {
+                        partials[((int64_t)ks * n_frames + f) * n_cols + col] = v;
+                    }
+                }
+            }
+        }
+}
+
+}  // namespace ltmi
+
+using namespace ltmi;
+
+
+// the folded image of a stack (ltmi_masks::fold)
+struct FoldImage {
+    int sig_h = 0, sig_w = 0, c2 = 0;            // rows y and c2 - y are mirror partners
+    int nge = 0, ngo = 0;                        // groups of even / odd columns
+    int n_fold_rows = 0, n_stages = 0;
+    float *img = nullptr;
+    int2 *rows = nullptr;                        // folded row -> (y, y' or -1)
+    int *colmap = nullptr;                       // virtual column -> real column or -1
+    unsigned char *zeros = nullptr;              // 1 KiB: the partner of unpaired rows
+    size_t img_bytes = 0;
+};
+
+void ltmi::fold_destroy(ltmi_masks *m) {
+    FoldImage *f = (FoldImage *)m->fold;
+    if (!f) return;
+    if (f->img) (void)hipFree(f->img);
+    if (f->rows) (void)hipFree(f->rows);
+    if (f->colmap) (void)hipFree(f->colmap);
+    if (f->zeros) (void)hipFree(f->zeros);
+    delete f;
+    m->fold = nullptr;
+}
+
+// Looks for a row mirror under which every column of the stack is even or odd and builds the folded image when
+// that saves matrix work.  Not an error when there is none (the handle then works as before).
+int ltmi::fold_create(ltmi_masks *m, int sig_h, int sig_w) {
+    fold_destroy(m);
+    const char *off = getenv("LTMI_DENSE_FOLD");
+    if (off && atoi(off) == 0) return LTMI_OK;
+    if (m->kind != 0 || !m->gmasks || (int64_t)sig_h * sig_w != m->n_px || sig_h < 4) return LTMI_OK;
+    if (sig_w % FD_KB != 0 || m->n_cols > 4 * GROUP) return LTMI_OK;
+    const int cpm = m->result_dtype == LTMI_C64 ? 2 : 1;
+    const int groups_now = (m->n_cols + GROUP - 1) / GROUP;
+    if (groups_now < 2 && !(off && atoi(off) == 2)) return LTMI_OK;     // HBM-bound already (LTMI_DENSE_FOLD=2: tests)
+    int *flags = nullptr;
+    const size_t nf = (size_t)2 * m->n_cols;
+    LTMI_HIP(hipMalloc((void **)&flags, nf * sizeof(int)));
+    std::vector<int> ones(nf, 1), got(nf);
+    const int64_t total = (int64_t)m->n_masks * cpm * m->n_px;
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 65535 * 16);
+    int best_c2 = -1;
+    std::vector<int> cls;                                               // +1 even, -1 odd per column
+    for (int c2 : {sig_h, sig_h - 1, sig_h + 1}) {                      // centres (sig_h - 1) / 2 +- 1 / 2
+        hipError_t e = hipMemcpy(flags, ones.data(), nf * sizeof(int), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(ltmi::k_fold_classify, dim3(blocks), dim3(256), 0, 0, (const float *)m->gmasks, cpm,
+                               m->n_masks, sig_h, sig_w, c2, flags, flags + m->n_cols);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpy(got.data(), flags, nf * sizeof(int), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            (void)hipFree(flags);
+            LTMI_FAIL((int)e, "classifying the stack's columns failed: %s", hipGetErrorString(e));
+        }
+        bool all = true;
+        std::vector<int> c((size_t)m->n_cols);
+        for (int k = 0; k < m->n_cols && all; ++k) {
+            if (got[(size_t)k]) c[(size_t)k] = 1;                       // (all-zero columns: even)
+            else if (got[(size_t)m->n_cols + k]) c[(size_t)k] = -1;
+            else all = false;
+        }
+        if (all) { best_c2 = c2; cls = c; break; }
+    }
+    (void)hipFree(flags);
+    if (best_c2 < 0) return LTMI_OK;
+    int n_even = 0, n_odd = 0;
+    for (int k = 0; k < m->n_cols; ++k) (cls[(size_t)k] > 0 ? n_even : n_odd)++;
+    const int nge = (n_even + GROUP - 1) / GROUP, ngo = (n_odd + GROUP - 1) / GROUP;
+    // kernels are built for 1 - 4 even groups or 1 - 2 + 1 - 2; the fold must save matrix work:
+    // (nge + ngo) groups over half of the pixels against groups_now over all of them
+    const bool built = (ngo == 0 && nge >= 1 && nge <= 4) || (nge >= 1 && nge <= 2 && ngo >= 1 && ngo <= 2);
+    if (!built || nge + ngo >= 2 * groups_now) return LTMI_OK;
+
+    FoldImage *f = new (std::nothrow) FoldImage();
+    if (!f) LTMI_FAIL(LTMI_E_NOMEM, "out of host memory");
+    m->fold = f;
+    f->sig_h = sig_h; f->sig_w = sig_w; f->c2 = best_c2; f->nge = nge; f->ngo = ngo;
+    std::vector<int2> rows;
+    for (int y = 0; y < sig_h; ++y) {
+        const int y2 = best_c2 - y;
+        if (y2 >= 0 && y2 < sig_h && y2 < y) continue;                  // the partner of an earlier row
+        rows.push_back(int2{y, (y2 > y && y2 < sig_h) ? y2 : -1});
+    }
+    f->n_fold_rows = (int)rows.size();
+    f->n_stages = f->n_fold_rows * (sig_w / FD_KB);
+    const int ng = nge + ngo;
+    std::vector<int> colmap((size_t)ng * GROUP, -1);
+    {
+        int ie = 0, io = nge * GROUP;
+        for (int k = 0; k < m->n_cols; ++k) colmap[(size_t)(cls[(size_t)k] > 0 ? ie++ : io++)] = k;
+    }
+    f->img_bytes = (size_t)f->n_stages * ltmi::fold_slot_bytes(ng);
+    hipError_t e = hipMalloc((void **)&f->img, f->img_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&f->rows, rows.size() * sizeof(int2));
+    if (e == hipSuccess) e = hipMalloc((void **)&f->colmap, colmap.size() * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&f->zeros, 1024);
+    if (e == hipSuccess) e = hipMemset(f->zeros, 0, 1024);
+    if (e == hipSuccess) e = hipMemcpy(f->rows, rows.data(), rows.size() * sizeof(int2), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(f->colmap, colmap.data(), colmap.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const int64_t tot = (int64_t)ng * GROUP * f->n_fold_rows * sig_w;
+        const unsigned bl = (unsigned)std::min<int64_t>((tot + 255) / 256, 65535 * 16);
+        hipLaunchKernelGGL(ltmi::k_build_fold_image, dim3(bl), dim3(256), 0, 0, (const float *)m->gmasks, f->img, cpm,
+                           m->n_px, sig_w, f->n_fold_rows, (const int2 *)f->rows, (const int *)f->colmap, ng);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    if (e != hipSuccess) {
+        // (no room for the image: the handle works without it)
+        fold_destroy(m);
+        (void)hipGetLastError();
+    }
+    return LTMI_OK;
+}
+
+bool ltmi::fold_takes(const ltmi_masks *m, const float *tile, int64_t ld) {
+    const FoldImage *f = (const FoldImage *)m->fold;
+    if (!f || m->tune_ksplit_ring == 38) return false;                  // tuning 38: the unfolded kernels (bench, tests)
+    return ((uintptr_t)tile % 16 == 0) && (ld * 4) % 16 == 0;
+}
+
+template <int NGE, int NGO>
+static int launch_fold_t(ltmi_masks *m, const float *tile, int64_t n_frames, int64_t ld, float *out, int64_t ld_out,
+                         int accumulate, hipStream_t stream) {
+    const FoldImage *f = (const FoldImage *)m->fold;
+    const int abl = m->tune_ksplit_ring == 31 ? 2 : (m->tune_ksplit_ring == 32 ? 1 : 0);
+    auto kern = abl == 2 ? k_dense_fold<NGE, NGO, 2> : (abl == 1 ? k_dense_fold<NGE, NGO, 1> : k_dense_fold<NGE, NGO, 0>);
+    constexpr int LDS = ltmi::fold_lds_bytes(NGE + NGO);
+    static bool attr_set[16][3] = {{false}};
+    if (!attr_set[m->device & 15][abl]) {
+        LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set[m->device & 15][abl] = true;
+    }
+    const int64_t gx = (n_frames + FD_WG_ROWS - 1) / FD_WG_ROWS;
+    int ksplit = m->tune_ksplit;
+    if (ksplit <= 0) ksplit = choose_ksplit(gx, f->n_stages);
+    ksplit = std::max(1, std::min(ksplit, f->n_stages));
+    {
+        const int per = (f->n_stages + ksplit - 1) / ksplit;
+        ksplit = (f->n_stages + per - 1) / per;
+    }
+    if (ksplit > 1) {
+        int rc = dense_ensure_partials(m, (size_t)ksplit * n_frames * m->n_cols * sizeof(float), stream);
+        if (rc != LTMI_OK) return rc;
+    }
+    dim3 grid((unsigned)gx, (unsigned)ksplit);
+    hipLaunchKernelGGL(kern, grid, dim3(FD_WAVES * 64), LDS, stream, tile, ld, n_frames, f->sig_w / FD_KB,
+                       (const int2 *)f->rows, (const float *)f->img, f->n_stages, out, ld_out, m->n_cols,
+                       (const int *)f->colmap, accumulate, dense_partial_sums(m), ksplit,
+                       (const unsigned char *)f->zeros, m->roi_rows);
+    LTMI_HIP(hipGetLastError());
+    snprintf(m->last_kernel, sizeof(m->last_kernel), "k_dense_fold<f,even=%d,odd=%d,rows %d+%d=%d%s> grid=(%u,%u)",
+             NGE, NGO, f->n_fold_rows, f->sig_h - f->n_fold_rows, f->c2, m->roi_rows ? ",rows" : "", grid.x, grid.y);
+    if (ksplit > 1) {
+        const int rc = dense_reduce_partials(m, ksplit, n_frames, out, ld_out, accumulate, stream);
+        if (rc != LTMI_OK) return rc;
+    }
+    return LTMI_OK;
+}
+
+int ltmi::launch_fold(ltmi_masks *m, const float *tile, int64_t n_frames, int64_t ld, float *out, int64_t ld_out,
+                       int accumulate, hipStream_t stream) {
+    const FoldImage *f = (const FoldImage *)m->fold;
+#define LTMI_FOLD_CASE(E_, O_)                                                                                 \
+    if (f->nge == E_ && f->ngo == O_)                                                                          \
+        return launch_fold_t<E_, O_>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+    LTMI_FOLD_CASE(1, 0) LTMI_FOLD_CASE(2, 0) LTMI_FOLD_CASE(3, 0) LTMI_FOLD_CASE(4, 0)
+    LTMI_FOLD_CASE(1, 1) LTMI_FOLD_CASE(2, 1) LTMI_FOLD_CASE(1, 2) LTMI_FOLD_CASE(2, 2)
+#undef LTMI_FOLD_CASE
+    LTMI_FAIL(LTMI_E_INVALID, "k_dense_fold: no kernel for %d + %d groups", f->nge, f->ngo);
+}
+

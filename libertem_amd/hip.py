@@ -28,7 +28,7 @@ _DTYPES = {
 
 EXPORTS = (
     'ltmi_version', 'ltmi_last_error', 'ltmi_device_count', 'ltmi_device_info',
-    'ltmi_masks_create_dense', 'ltmi_masks_create_csr', 'ltmi_masks_destroy', 'ltmi_masks_kind',
+    'ltmi_masks_create_dense', 'ltmi_masks_create_csr', 'ltmi_masks_destroy', 'ltmi_masks_kind', 'ltmi_masks_set_sig_shape',
     'ltmi_apply_masks', 'ltmi_apply_masks_rows', 'ltmi_apply_masks_shifted', 'ltmi_apply_masks_shifted_host', 'ltmi_sum_frames_workspace', 'ltmi_sum_frames', 'ltmi_sum_sig',
     'ltmi_axpy', 'ltmi_add2d', 'ltmi_gather_rows', 'ltmi_host_device_pointer', 'ltmi_correct', 'ltmi_repair_pixels', 'ltmi_byteswap', 'ltmi_mib_decode', 'ltmi_com_fields', 'ltmi_fft_plan_create',
     'ltmi_fft_plan_destroy', 'ltmi_crystallinity', 'ltmi_crystallinity_corrected', 'ltmi_fft_plan_last_kernel',
@@ -129,6 +129,7 @@ def lib():
         L.ltmi_apply_masks_rows.argtypes = [vp, vp, i32, vp, i64, i64, vp, i64, i32, vp,
                                             c.POINTER(i32)]
         L.ltmi_masks_kind.argtypes = [vp, c.POINTER(i32)]
+        L.ltmi_masks_set_sig_shape.argtypes = [vp, i32, i32]
         L.ltmi_apply_masks.argtypes = [vp, vp, i32, i64, i64, vp, i64, i32, vp]
         L.ltmi_apply_masks_shifted.argtypes = [vp, vp, i32, i64, i64, i32, i32, vp, vp, i64, i32, vp]
         L.ltmi_apply_masks_shifted_host.argtypes = [vp, vp, i32, i64, i64, i32, i32, vp, vp, i64, i32, vp]
@@ -297,6 +298,11 @@ class MaskHandle:
         k = ctypes.c_int(-1)
         check(lib().ltmi_masks_kind(self._ptr, ctypes.byref(k)), 'ltmi_masks_kind')
         return k.value
+
+    def set_sig_shape(self, sig_h, sig_w):
+        """the detector shape behind the handle's pixels: lets the library fold a stack that is even / odd under a
+        mirror of the detector rows (include/ltmi.h)"""
+        check(lib().ltmi_masks_set_sig_shape(self._ptr, int(sig_h), int(sig_w)), 'ltmi_masks_set_sig_shape')
 
     def set_tuning(self, mt=0, waves=0, ksplit=0):
         check(lib().ltmi_masks_set_tuning(self._ptr, mt, waves, ksplit), 'ltmi_masks_set_tuning')

@@ -1913,3 +1913,146 @@ def test_crystallinity_rectangular_frames(hip, dtype, sig):
         assert label.startswith(f'k_cryst_rows{w}<') and f'k_cryst_cols{h} ' in label, label
         assert np.allclose(got, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max()), (sig, rad_out, got, ref)
         assert got[1] == 0
+
+
+# ---- dense stacks folded about a mirror of the detector rows (csrc/ltmi_fold.hip) ------------------------------
+def _radial_stack(sig, n_bins, max_order, cy=None, cx=None):
+    """the reference's radial-Fourier stack (analysis/radialfourier.py:106-146, pinned bit for bit by
+    tests/golden), flattened: (n_bins * (max_order + 1), sig_h * sig_w) complex64"""
+    from libertem_amd import masks as pm
+    from libertem_amd.analysis.radialfourier import radial_mask_factory
+    h, w = sig
+    cy = h / 2 if cy is None else cy
+    cx = w / 2 if cx is None else cx
+    ro = pm.bounding_radius(cx, cy, w, h)
+    st = radial_mask_factory(h, w, cx, cy, 0, ro, n_bins, max_order, False)()
+    return np.ascontiguousarray(st.reshape(st.shape[0], -1))
+
+
+def _fold_apply(hip, data, masks, sig, result_dtype, tuning=None, accumulate_into=None, rows=None):
+    h = hip.MaskHandle.dense(0, masks, result_dtype)
+    h.set_sig_shape(*sig)
+    if tuning:
+        h.set_tuning(**tuning)
+    t = _dev(np.ascontiguousarray(data))
+    n_frames, n_px = data.shape
+    rd = np.dtype(result_dtype)
+    n_out = n_frames if rows is None else len(rows)
+    if accumulate_into is None:
+        out_np, acc = np.full((n_out, masks.shape[0]), 7, dtype=rd), False
+    else:
+        out_np, acc = accumulate_into.astype(rd).copy(), True
+    out = _dev(out_np.view(np.float32).reshape(n_out, -1) if rd.kind == 'c' else out_np)
+    if rows is None:
+        h.apply(t.data_ptr(), data.dtype, n_frames, n_px, out.data_ptr(), masks.shape[0], acc)
+    else:
+        r = torch.from_numpy(np.asarray(rows, dtype=np.int32)).cuda()
+        assert h.apply_rows(t.data_ptr(), data.dtype, r.data_ptr(), len(rows), n_px, out.data_ptr(),
+                            masks.shape[0], acc)
+    torch.cuda.synchronize()
+    res = out.cpu().numpy()
+    if rd.kind == 'c':
+        res = np.ascontiguousarray(res).view(np.complex64).reshape(n_out, -1)
+    kern = h.last_kernel()
+    h.close()
+    return res, kern
+
+
+@pytest.mark.parametrize('sig,n_bins,max_order,n_frames,ksplit', [
+    ((128, 128), 1, 24, 300, 0),        # C5's default stack (25 complex masks: 2 even + 2 odd groups), ragged frame count
+    ((128, 128), 1, 24, 300, 5),        # ... pixel axis split 5 ways
+    ((64, 256), 2, 7, 130, 0),          # 16 complex masks: 1 + 1 groups, rectangular frames
+    ((96, 64), 1, 9, 64, 3),            # 10 complex masks = 20 real columns
+    ((64, 128), 3, 6, 40, 0),           # 21 complex masks: 2 + 2 groups
+])
+def test_row_mirror_fold_radial_fourier(hip, sig, n_bins, max_order, n_frames, ksplit):
+    """k_dense_fold: float32 frames x a radial-Fourier stack (real parts even, imaginary parts odd under the mirror of
+    the detector rows about the centre): same results as the unfolded kernel (tuning 38) and the float64 product
+    within 1e-5 of sum |x||w| per entry; accumulate; the pixel axis split over workgroups."""
+    masks = _radial_stack(sig, n_bins, max_order)
+    rng = np.random.default_rng(_seed('fold', sig, n_bins, max_order))
+    data = (rng.random((n_frames, sig[0] * sig[1])) - 0.2).astype(np.float32)
+    res, kern = _fold_apply(hip, data, masks, sig, np.complex64, tuning=dict(mt=0, waves=30, ksplit=ksplit))
+    assert 'k_dense_fold' in kern, kern
+    res_u, kern_u = _fold_apply(hip, data, masks, sig, np.complex64, tuning=dict(mt=0, waves=38, ksplit=0))
+    assert 'k_dense_fold' not in kern_u, kern_u
+    ref = _ref64(data, masks)
+    scale = np.abs(data.astype(np.float64)) @ np.abs(masks).astype(np.float64).T
+    for part in (np.real, np.imag):
+        assert np.all(np.abs(part(res) - part(ref)) <= 1e-5 * scale + 1e-30)
+        assert np.all(np.abs(part(res) - part(res_u)) <= 2e-5 * scale + 1e-30)
+    base = (rng.random((n_frames, masks.shape[0])) + 1j * rng.random((n_frames, masks.shape[0]))).astype(np.complex64)
+    res2, kern2 = _fold_apply(hip, data, masks, sig, np.complex64, accumulate_into=base,
+                              tuning=dict(mt=0, waves=30, ksplit=ksplit))
+    assert 'k_dense_fold' in kern2
+    assert np.all(np.abs(res2 - (ref + base)) <= 1e-5 * (scale + 2))
+
+
+@pytest.mark.parametrize('sig,centre', [
+    ((128, 128), None),                 # centre (64, 64): rows y and 128 - y, row 0 and row 64 unpaired
+    ((128, 64), (63.5, 32.0)),          # centre between two rows: rows y and 127 - y, every row paired
+    ((64, 128), (32.5, 70.0)),          # rows y and 65 - y: rows 0 and 1 have their partner beyond the frame
+])
+def test_row_mirror_fold_every_pixel_elementwise(hip, sig, centre):
+    """One-pixel frames over EVERY pixel of the detector: the folded kernel multiplies the stack's ORIGINAL weights
+    (nothing is averaged), so pixel * weight comes back within 1e-5 RELATIVE of every single stored entry, atol 0 --
+    including the mirrored half (the partner rows), the unpaired rows and the rows whose imaginary parts are
+    sin(o pi) = tiny but not zero."""
+    cy, cx = (None, None) if centre is None else centre
+    masks = _radial_stack(sig, 1, 24, cy=cy, cx=cx)
+    n_px = sig[0] * sig[1]
+    rng = np.random.default_rng(_seed('fold-one', sig, centre))
+    vals = (rng.random(n_px) + 0.5).astype(np.float32)
+    data = np.zeros((n_px, n_px), dtype=np.float32)
+    data[np.arange(n_px), np.arange(n_px)] = vals
+    res, kern = _fold_apply(hip, data, masks, sig, np.complex64)
+    assert 'k_dense_fold' in kern, kern
+    want = masks.T.astype(np.complex128) * vals[:, None].astype(np.float64)
+    for part in (np.real, np.imag):
+        g, w = part(res).astype(np.float64), part(want)
+        assert np.all(np.abs(g - w) <= 1e-5 * np.abs(w)), np.max(np.abs(g - w) / np.maximum(np.abs(w), 1e-300))
+
+
+def test_row_mirror_fold_even_stack_and_rows(hip):
+    """A stack of even columns only (anti-aliased rings, 40 masks: 3 even groups) and a region of interest through a
+    row list (ltmi_apply_masks_rows)."""
+    from libertem_amd import masks as pm
+    sig = (128, 64)
+    rings = pm.radial_bins(32, 64, 64, 128, n_bins=40, use_sparse=False, dtype=np.float32)
+    masks = np.ascontiguousarray(np.asarray(rings).reshape(40, -1))
+    rng = np.random.default_rng(_seed('fold-even'))
+    data = rng.random((200, sig[0] * sig[1])).astype(np.float32)
+    res, kern = _fold_apply(hip, data, masks, sig, np.float32)
+    assert 'k_dense_fold<f,even=3,odd=0' in kern, kern
+    ref = _ref64(data, masks)
+    scale = np.abs(data.astype(np.float64)) @ np.abs(masks.astype(np.float64)).T
+    assert np.all(np.abs(res - ref) <= 1e-5 * scale + 1e-30)
+    rows = rng.permutation(200)[:77]
+    res_r, kern_r = _fold_apply(hip, data, masks, sig, np.float32, rows=rows)
+    assert 'k_dense_fold' in kern_r and ',rows' in kern_r, kern_r
+    assert np.all(np.abs(res_r - ref[rows]) <= 1e-5 * scale[rows] + 1e-30)
+
+
+def test_row_mirror_fold_leaves_other_stacks_alone(hip):
+    """No mirror under which every column is even or odd (random masks; a radial stack with ONE weight changed), a
+    stack of one group (nothing to save), a frame width the kernel does not take: the handle works as before."""
+    sig = (64, 128)
+    rng = np.random.default_rng(_seed('fold-none'))
+    data = rng.random((70, sig[0] * sig[1])).astype(np.float32)
+    masks = (rng.random((20, sig[0] * sig[1])) - 0.3).astype(np.float32)
+    res, kern = _fold_apply(hip, data, masks, sig, np.float32)
+    assert 'k_dense_fold' not in kern, kern
+    assert np.allclose(res, _ref64(data, masks), rtol=1e-5, atol=1e-3)
+    stack = _radial_stack(sig, 1, 24)
+    stack[7, 5 * 128 + 9] *= np.float32(1.0000002)
+    res, kern = _fold_apply(hip, data, stack, sig, np.complex64)
+    assert 'k_dense_fold' not in kern, kern
+    assert np.allclose(res, _ref64(data, stack), rtol=1e-5, atol=1e-3)
+    few = _radial_stack(sig, 1, 3)                       # 4 complex masks = 8 columns: one group
+    res, kern = _fold_apply(hip, data, few, sig, np.complex64)
+    assert 'k_dense_fold' not in kern, kern
+    odd_w = _radial_stack((64, 96), 1, 24)               # 96 pixels per row: not a multiple of the 64-pixel stage
+    d2 = rng.random((40, 64 * 96)).astype(np.float32)
+    res, kern = _fold_apply(hip, d2, odd_w, (64, 96), np.complex64)
+    assert 'k_dense_fold' not in kern, kern
+    assert np.allclose(res, _ref64(d2, odd_w), rtol=1e-5, atol=1e-3)
