@@ -175,15 +175,8 @@ class Context:
                                        backends=backends, plots=plots, result_where=result_where)
         if result_where not in (None, 'host', 'device'):
             raise ValueError("result_where must be None, 'host' or 'device'")
-        if result_where == 'device':
-            if not hasattr(self.executor, '_merge_on_device'):
-                raise NotImplementedError("result_where='device' needs the HIP executor")
-            self.executor.result_where = 'device'
-            try:
-                return self.run_udf(dataset, udf, roi=roi, corrections=corrections,
-                                    progress=progress, backends=backends, plots=plots, sync=sync)
-            finally:
-                self.executor.result_where = None
+        if result_where == 'device' and not hasattr(self.executor, '_merge_on_device'):
+            raise NotImplementedError("result_where='device' needs the HIP executor")
         if corrections is not None and not corrections.have_corrections():
             corrections = None
         udf_is_list = isinstance(udf, (tuple, list))
@@ -191,11 +184,34 @@ class Context:
         if roi is not None:
             roi = self._normalize_roi(roi, dataset)
         runner = UDFRunner(udfs)
-        res = runner.run_for_dataset(dataset=dataset, executor=self.executor, roi=roi,
-                                     progress=progress, corrections=corrections,
-                                     backends=backends)
+        # one run at a time per executor -- a sync run issued while an async one is in flight waits for it --
+        # with the executor's launch-ahead state bound to this thread for the duration (hip.LaunchReplay)
+        with self._run_scope():
+            res = runner.run_for_dataset(dataset=dataset, executor=self.executor, roi=roi,
+                                         progress=progress, corrections=corrections,
+                                         backends=backends,
+                                         **({'result_where': 'device'} if result_where == 'device' else {}))
         buffers = res.buffers
         return tuple(buffers) if udf_is_list else buffers[0]
+
+    def _run_scope(self):
+        import contextlib
+        from libertem_amd import hip as _hip
+        stack = contextlib.ExitStack()
+        stack.enter_context(self.executor.run_gate)
+        stack.enter_context(_hip.LaunchReplay.bound(self.executor.replay))
+        return stack
+
+    def invalidate_caches(self):
+        """Forget every cached mask stack / device handle and run plan of this process: the next run
+        re-evaluates the mask factories and plans afresh, like every run of the reference does
+        (common/container.py:260-314).  For factories whose output depends on something a content
+        fingerprint cannot see (files, random state, objects without a __dict__)."""
+        from libertem_amd.udf import masks as _masks
+        from libertem_amd.udf import base as _base
+        with self.executor.run_gate:
+            _masks.invalidate_cache()
+            _base.invalidate_plans()
 
     def _async_pool(self):
         pool = getattr(self, '_async_worker', None)
@@ -246,12 +262,16 @@ class Context:
         runner = UDFRunner(udfs)
         if corrections is not None and not corrections.have_corrections():
             corrections = None
-        for part in runner.run_for_dataset_sync(dataset=dataset, executor=self.executor, roi=roi,
-                                                progress=progress, corrections=corrections,
-                                                backends=backends, iterate=True):
-            if not udf_is_list:
-                part.buffers  # noqa: B018  (materialise lazily built result)
-            yield part
+        # the executor's gate is held from the first step to the end of the iteration (or close()): partial
+        # results are published from the executor's per-run state
+        scope = self._run_scope()
+        with scope:
+            for part in runner.run_for_dataset_sync(dataset=dataset, executor=self.executor, roi=roi,
+                                                    progress=progress, corrections=corrections,
+                                                    backends=backends, iterate=True):
+                if not udf_is_list:
+                    part.buffers  # noqa: B018  (materialise lazily built result)
+                yield part
 
     @staticmethod
     def _normalize_roi(roi, dataset):

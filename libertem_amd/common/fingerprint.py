@@ -1,22 +1,28 @@
 """
-Cheap content fingerprints of UDF parameters.
+Content fingerprints of UDF parameters.
 
 The reference evaluates the mask factories on every run and on every task
 (src/libertem/udf/masks.py:331-351, common/container.py:260-314), so an array that a factory closes
-over may be modified in place between two `run_udf` calls and the next run sees the new values.
-This implementation keeps evaluated stacks (device images) and whole run plans across runs; what
-identifies "the same parameters" therefore has to look INTO the objects: the identity of a factory
-plus a fingerprint of every array it can see (closure cells, defaults, functools.partial arguments,
-module globals it names).  A fingerprint hashes EVERY byte of a buffer of up to 64 MiB (xxh3: ~0.3 ms
-for the 4 MiB C2 stack, compared behind the enqueued kernels -- udf/base.py `_prepare_run_for_dataset`):
-any in-place edit is seen, also a column band (`m[:, :, 100:110] = 0`) or a single element -- an evenly
-strided sample is blind to exactly such edits when its stride shares a factor with the row length
-(round-3 review).  Larger buffers are sampled: 8192 pieces of 256 bytes at offsets taken from the
-golden-ratio sequence (no common period with any row length: a band of b bytes in rows of L bytes is
-missed with probability (1 - (b + 256) / L)^8192), plus head and tail; a single changed element of a
-buffer above 64 MiB may go unseen (documented contract: DESIGN.md section 3).
+over -- or an attribute of the object whose method the factory is -- may be modified in place between two
+`run_udf` calls and the next run sees the new values.  This implementation keeps evaluated stacks (device
+images) and whole run plans across runs; what identifies "the same parameters" therefore has to look INTO
+the objects: the identity of a factory plus a fingerprint of everything it can see -- closure cells,
+defaults, functools.partial arguments, the module globals it names, the `__dict__` of the object a bound
+method belongs to and of captured objects.  A fingerprint hashes EVERY byte of every array it reaches
+(xxh3: ~0.3 ms for the 4 MiB C2 stack, ~0.12 ms per MiB; compared behind the enqueued kernels --
+udf/base.py `_prepare_run_for_dataset`): any in-place edit is seen.  (Up to round 4 buffers above 64 MiB were
+sampled; a single changed element could go unseen.)
+
+What cannot be seen completely is NOT cached: an object without `__dict__` that is none of the known kinds
+(device tensors, file handles, random generators ...), anything nested deeper than MAX_DEPTH -- the
+fingerprint then contains an OPAQUE token that never compares equal, so the stack is evaluated and the run
+planned afresh every time, like in the reference.  Files a factory reads and global random state stay
+invisible to any fingerprint: `ApplyMasksUDF(..., cache=False)` or `Context.invalidate_caches()`.
 """
 import functools
+import itertools
+import types
+import warnings
 
 import numpy as np
 
@@ -27,41 +33,28 @@ try:
         return xxhash.xxh3_64_intdigest(b)
 except Exception:                                            # pragma: no cover
     import hashlib
+    warnings.warn("xxhash is not installed: parameter fingerprints fall back to blake2b (~10x slower per byte)")
 
     def _hash(b):
         return int.from_bytes(hashlib.blake2b(b, digest_size=8).digest(), 'little')
 
-FULL_BYTES = 64 * 1024 * 1024
-PIECES = 8192
-PIECE_BYTES = 256
-_GOLDEN = 0.6180339887498949
+MAX_DEPTH = 4
+_OPAQUE_IDS = itertools.count(1)
+_STABLE_TYPES = (types.ModuleType, type, types.BuiltinFunctionType, types.BuiltinMethodType, np.ufunc,
+                 types.MethodDescriptorType, types.WrapperDescriptorType)
 
 
 def array_fingerprint(a):
+    """(shape, dtype, hash of every byte)"""
     a = np.asarray(a)
     head = (a.shape, a.dtype.str)
     if a.dtype.hasobject:
-        return head + (id(a),)
-    nbytes = a.nbytes
-    if nbytes == 0:
+        return head + (('opaque', next(_OPAQUE_IDS)),)
+    if a.nbytes == 0:
         return head + (0,)
     if not a.flags.c_contiguous:
-        if nbytes <= FULL_BYTES:
-            return head + (_hash(np.ascontiguousarray(a).view(np.uint8).data),)
-        # strided sample, at most ~64 Ki elements
-        per_axis = max(1, int(round((a.size / 65536.0) ** (1.0 / max(1, a.ndim)))))
-        sub = a[tuple(slice(None, None, per_axis) for _ in range(a.ndim))]
-        return head + (a.strides, _hash(np.ascontiguousarray(sub).view(np.uint8).data))
-    flat = a.reshape(-1).view(np.uint8)
-    if nbytes <= FULL_BYTES:
-        return head + (_hash(flat.data),)
-    # pieces at the golden-ratio sequence of offsets (8-byte aligned, read as uint64 words)
-    words = flat[:nbytes - nbytes % 8].view(np.uint64)
-    per = PIECE_BYTES // 8
-    frac = (np.arange(1, PIECES + 1, dtype=np.float64) * _GOLDEN) % 1.0
-    start = (frac * (words.size - per)).astype(np.int64)
-    sample = words[start[:, None] + np.arange(per, dtype=np.int64)[None, :]]
-    return head + (_hash(sample.data), _hash(flat[:4096].data), _hash(flat[-4096:].data))
+        a = np.ascontiguousarray(a)
+    return head + (_hash(a.reshape(-1).view(np.uint8).data),)
 
 
 def _sparse_parts(obj):
@@ -74,19 +67,36 @@ def _sparse_parts(obj):
     return parts
 
 
+def _opaque(obj):
+    return ('opaque', id(obj), next(_OPAQUE_IDS))
+
+
+def is_opaque(fp):
+    """True iff the fingerprint contains something that could not be looked into (never equal to any other)"""
+    if isinstance(fp, tuple):
+        if len(fp) >= 1 and fp[0] == 'opaque':
+            return True
+        return any(is_opaque(x) for x in fp)
+    return False
+
+
 def fingerprint(obj, _depth=0, _inside=False):
-    """hashable value that changes when `obj`, or an array `obj` can reach, changes.  Plain numbers
+    """hashable value that changes when `obj`, or anything `obj` can reach, changes.  Plain numbers
     and strings count by value where a factory captures them directly (closure cell, default,
-    partial argument), not inside a captured list / dict -- those are followed for the arrays they
-    hold; a counter a factory keeps in a dict is not a mask parameter."""
+    partial argument, attribute of a captured object), not inside a captured list / dict -- those are
+    followed for the arrays they hold; a counter a factory keeps in a dict is not a mask parameter."""
     if isinstance(obj, np.ndarray):
         return ('nd', id(obj)) + array_fingerprint(obj)
     if obj is None or isinstance(obj, (bool, int, float, complex, str, bytes, np.generic)):
         return ('s',) if _inside else ('v', obj)
-    if _depth > 3:
-        return ('id', id(obj))
+    if isinstance(obj, _STABLE_TYPES):
+        return ('stable', id(obj))
+    if _depth > MAX_DEPTH:
+        return _opaque(obj)
     if isinstance(obj, (list, tuple)):
         return ('seq', id(obj), len(obj)) + tuple(fingerprint(x, _depth + 1, True) for x in obj)
+    if isinstance(obj, (set, frozenset)):
+        return ('set', id(obj), len(obj))
     if isinstance(obj, dict):
         return ('map', id(obj), len(obj)) + tuple(fingerprint(v, _depth + 1, True)
                                                   for v in obj.values())
@@ -96,7 +106,7 @@ def fingerprint(obj, _depth=0, _inside=False):
     sp_parts = _sparse_parts(obj) if hasattr(obj, 'shape') and hasattr(obj, 'dtype') else None
     if sp_parts:
         return ('sp', id(obj)) + tuple(array_fingerprint(p) for p in sp_parts)
-    if callable(obj):
+    if callable(obj) and (hasattr(obj, '__code__') or hasattr(obj, '__func__')):
         out = ['fn', id(obj)]
         fn = getattr(obj, '__func__', obj)
         for cell in (getattr(fn, '__closure__', None) or ()):
@@ -112,10 +122,18 @@ def fingerprint(obj, _depth=0, _inside=False):
         if code is not None and glob is not None:
             for name in code.co_names:
                 v = glob.get(name)
-                if isinstance(v, np.ndarray):
+                if isinstance(v, np.ndarray) or (
+                        v is not None and not isinstance(v, _STABLE_TYPES) and not callable(v)
+                        and hasattr(v, '__dict__')):
                     out.append((name, fingerprint(v, _depth + 1)))
         bound = getattr(obj, '__self__', None)
-        if bound is not None and not isinstance(bound, type(np)):
-            out.append(('self', id(bound)))
+        if bound is not None and not isinstance(bound, _STABLE_TYPES):
+            # a bound method: what the method can read of its object
+            out.append(('self', fingerprint(bound, _depth + 1)))
         return tuple(out)
-    return ('id', id(obj))
+    d = getattr(obj, '__dict__', None)
+    if isinstance(d, dict):
+        # an instance: its attributes, one level per depth step (scalars by value: `holder.radius = 3`)
+        return ('obj', id(obj), type(obj).__qualname__, len(d)) + tuple(
+            (k, fingerprint(v, _depth + 1)) for k, v in d.items())
+    return _opaque(obj)

@@ -93,6 +93,25 @@ class JobExecutor:
     device_class = 'cpu'
     gpu_id = None
 
+    @property
+    def run_gate(self):
+        """one run at a time per executor (Context.run_udf / run_udf_iter, sync and async alike): the delivery
+        targets, launch-ahead state and streams of an executor belong to the run in progress"""
+        gate = self.__dict__.get('_run_gate')
+        if gate is None:
+            from libertem_amd.hip import RunGate
+            gate = self.__dict__.setdefault('_run_gate', RunGate())
+        return gate
+
+    @property
+    def replay(self):
+        """launch-ahead state of this executor (hip.LaunchReplay binds it to the thread of the run)"""
+        st = self.__dict__.get('_replay_state')
+        if st is None:
+            from libertem_amd.hip import ReplayState
+            st = self.__dict__.setdefault('_replay_state', ReplayState())
+        return st
+
     def run_tasks(self, tasks, params_handle, cancel_id, task_comm_handler=None):
         raise NotImplementedError()
 

@@ -257,15 +257,14 @@ class HipJobExecutor(JobExecutor):
         drained, nothing is delivered and the exception propagates."""
         self._before_wait = fn
 
-    def launch_ahead(self, tasks):
+    def launch_ahead(self, tasks, result_where=None):
         """Launch first, book-keep behind the kernel: every task of a cached plan whose previous run made
         exactly one mask launch into directly written rows of the run's host buffer (recorded by
         merge_results) gets that launch enqueued NOW, into the buffer of the page-locked ring that
         merge_results will adopt for this run; the tile loop's own call is then recognised and skipped
         (hip.LaunchReplay).  Single rank, complete runs (no partial results) only."""
         from libertem_amd import hip as _hip
-        if self.gpu_id is None or _hip.LaunchReplay.expected is not None \
-                or getattr(self, 'result_where', None) == 'device':
+        if self.gpu_id is None or _hip.LaunchReplay.expected is not None or result_where == 'device':
             return False
         recs = [(getattr(t, '_keep', None) or {}).get('replay') for t in self.my_tasks(list(tasks))]
         if not recs or not all(recs) or len({r[3:] for r in recs}) != 1:
@@ -318,12 +317,13 @@ class HipJobExecutor(JobExecutor):
             if st is not None:
                 st.synchronize()
 
-    def merge_results(self, udfs, damage, result_iter, apply_part_result):
+    def merge_results(self, udfs, damage, result_iter, apply_part_result, result_where=None):
         """
         Consume (part_results, task) pairs of THIS rank, merge, combine across ranks and leave the
-        complete result in every udf.results (host buffers) and `damage`.
+        complete result in every udf.results (host buffers; result_where='device': HipArrays in HBM)
+        and `damage`.
         """
-        for _ in self._merge(udfs, damage, result_iter, partial=False):
+        for _ in self._merge(udfs, damage, result_iter, partial=False, result_where=result_where):
             pass
 
     def merge_results_iter(self, udfs, damage, result_iter, apply_part_result):
@@ -442,7 +442,7 @@ class HipJobExecutor(JobExecutor):
         if self._stream is not None:
             self._stream.synchronize()
 
-    def _merge(self, udfs, damage, result_iter, partial):
+    def _merge(self, udfs, damage, result_iter, partial, result_where=None):
         plans = self._merge_plans(udfs)
 
         # Delivery of 'disjoint' nav buffers: every row goes to its final place in page-locked host
@@ -460,7 +460,7 @@ class HipJobExecutor(JobExecutor):
         dev_ptrs = {}
         # result_where='device' (Context.run_udf): the declared buffers stay in HBM as HipArrays
         # (for a follow-up computation on the device); nothing is delivered to the host
-        dev_mode = getattr(self, 'result_where', None) == 'device'
+        dev_mode = result_where == 'device'
         if dev_mode and (self.gpu_id is None or partial or self._collectives_on):
             raise NotImplementedError(
                 "result_where='device' needs a single-rank HIP executor and run_udf (not run_udf_iter)")

@@ -47,18 +47,105 @@ class ReplayMismatch(RuntimeError):
     recorded launch, plans afresh and runs again -- nothing of the abandoned run is delivered"""
 
 
-class LaunchReplay:
+class ReplayState:
+    """the launch-ahead state of ONE executor (`HipJobExecutor.replay`): `expected` = the launches that were
+    enqueued ahead for the run in progress (None: none), `recording` = list that collects the launches of the
+    task that is running (None: not recording)"""
+    __slots__ = ('expected', 'recording')
+
+    def __init__(self):
+        self.expected = None
+        self.recording = None
+
+
+class RunGate:
+    """Serialises the runs of one executor (its delivery targets, launch-ahead state and streams belong to the
+    run in progress): re-entrant for the thread that holds it, and -- unlike threading.RLock -- releasable from
+    another thread (a generator of partial results that is closed by the garbage collector)."""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._owner = None
+        self._depth = 0
+
+    def acquire(self):
+        me = threading.get_ident()
+        if self._owner == me:
+            self._depth += 1
+            return
+        self._lock.acquire()
+        self._owner = me
+        self._depth = 1
+
+    def release(self):
+        self._depth -= 1
+        if self._depth <= 0:
+            self._depth = 0
+            self._owner = None
+            self._lock.release()
+
+    def __enter__(self):
+        self.acquire()
+        return self
+
+    def __exit__(self, *exc):
+        self.release()
+
+
+class _ReplayMeta(type):
+    # `LaunchReplay.expected` / `.recording` are those of the executor whose run is in progress on THIS thread
+    # (`LaunchReplay.bound(state)`, entered by Context.run_udf under the executor's gate); outside a run: a state
+    # of the thread's own, so that bare handle calls of two threads never see each other's lists
+    def _cur(cls):
+        st = getattr(cls._tls, 'state', None)
+        if st is None:
+            st = cls._tls.state = cls._tls.own = ReplayState()
+        return st
+
+    @property
+    def expected(cls):
+        return cls._cur().expected
+
+    @expected.setter
+    def expected(cls, v):
+        cls._cur().expected = v
+
+    @property
+    def recording(cls):
+        return cls._cur().recording
+
+    @recording.setter
+    def recording(cls, v):
+        cls._cur().recording = v
+
+
+class LaunchReplay(metaclass=_ReplayMeta):
     """
     Launch first, book-keep behind the kernel.  A run of a cached plan (udf/base.py `_plan_for`) whose
     previous run issued exactly ONE `ltmi_apply_masks` launch per task -- same handle, same resident tile,
     result rows written straight into the run's result buffer -- enqueues that launch as soon as the new
     result buffer exists (executor/hip.py `merge_results`), then runs the normal tile loop: the tile loop's
     own call finds itself in `expected` and returns.  A different call raises ReplayMismatch.
-    `recording`: list that collects the launches of the task that is running, or None.
+    The state (`expected`, `recording`: ReplayState) belongs to the EXECUTOR; a run binds it to its thread
+    for its duration, runs of one executor are serialised by the executor's RunGate.
     """
-    recording = None
-    expected = None
-    n_ahead = 0          # launches enqueued ahead so far (tests, bench)
+    _tls = threading.local()
+    n_ahead = 0          # launches enqueued ahead so far, all executors (tests, bench)
+
+    class bound:
+        """context manager: the calling thread's launches are matched against / recorded into `state`"""
+
+        def __init__(self, state):
+            self.state = state
+
+        def __enter__(self):
+            tls = LaunchReplay._tls
+            self.prev = getattr(tls, 'state', None)
+            tls.state = self.state
+            return self.state
+
+        def __exit__(self, *exc):
+            LaunchReplay._tls.state = self.prev
 
     @staticmethod
     def signature(handle, tile_ptr, tile_dtype, n_frames, ld_tile, out_ptr, ld_out, accumulate, stream):

@@ -35,7 +35,7 @@ from libertem_amd.common.buffers import (
     BufferWrapper, AuxBufferWrapper, PlaceholderBufferWrapper, PreallocBufferWrapper, HipSigView,
 )
 from libertem_amd.common.hiparray import HipArray
-from libertem_amd.common.fingerprint import fingerprint
+from libertem_amd.common.fingerprint import fingerprint, is_opaque
 from libertem_amd.hip import ReplayMismatch as _ReplayMismatch
 from libertem_amd.common.udf import UDFProtocol, UDFMethod, NUMPY, HIP
 from libertem_amd.common.exceptions import UDFException, UDFRunCancelled, JobCancelledError, \
@@ -44,6 +44,14 @@ from libertem_amd.io.dataset.base import Negotiator
 
 
 _RUN_IDS = itertools.count()
+_PLAN_EPOCH = [0]          # cached run plans of an earlier epoch are never re-used (invalidate_plans)
+
+
+def invalidate_plans():
+    """every cached run plan of this process is stale from now on (Context.invalidate_caches)"""
+    _PLAN_EPOCH[0] += 1
+
+
 
 
 def check_cast(fromvar, tovar):
@@ -1056,7 +1064,7 @@ class UDFRunner:
         parts = []
         for u in self._udfs:
             kw = getattr(u, '_kwargs', None)
-            if kw is None:
+            if kw is None or kw.get('cache', True) is False:      # (cache=False: planned afresh, like the reference)
                 return None
             parts.append((id(u), tuple((k, id(v)) for k, v in kw.items())))
         from libertem_amd.common import udf as udf_common
@@ -1075,7 +1083,7 @@ class UDFRunner:
         return tuple(tuple((k, fingerprint(v)) for k, v in u._kwargs.items()) for u in self._udfs)
 
     def _prepare_run_for_dataset(self, dataset, executor, roi, corrections, backends, dry,
-                                 defer_check=False):
+                                 defer_check=False, result_where=None):
         """-> (tasks, params, verify).  `verify` (None, or a callable that raises _StalePlan) is the
         content comparison of a cache hit that the caller asked to run late (`defer_check`): after
         the kernels of the run are enqueued, before anything is delivered."""
@@ -1089,7 +1097,7 @@ class UDFRunner:
         hit = plans.get(key) if plans is not None else None
         verify = None
         if hit is not None and all(a() is b for a, b in zip(hit['udfs'], self._udfs)) \
-                and hit['executor'] is executor:
+                and hit['executor'] is executor and hit.get('epoch') == _PLAN_EPOCH[0]:
             def verify(hit=hit, key=key):
                 if self._plan_content() != hit['content']:
                     plans.pop(key, None)
@@ -1107,7 +1115,7 @@ class UDFRunner:
             # creation are pure functions of them -- only the result buffers are per run
             if defer_check and hasattr(executor, 'launch_ahead'):
                 # launch first (the recorded launches of the plan's tasks), book-keep behind the kernel
-                executor.launch_ahead(hit['tasks'])
+                executor.launch_ahead(hit['tasks'], result_where)
             plans.move_to_end(key)
             meta = copy.copy(hit['meta'])
             for udf in self._udfs:
@@ -1119,6 +1127,8 @@ class UDFRunner:
                     udf.preprocess()
             return hit['tasks'], hit['params'], verify
         content = self._plan_content() if plans is not None else None
+        if content is not None and is_opaque(content):
+            plans = None            # a parameter reaches something a fingerprint cannot look into: never re-used
         tasks, params, meta = self._plan_run(dataset, executor, roi, corrections, backends, dry)
         if plans is not None:
             for t in tasks:
@@ -1128,7 +1138,7 @@ class UDFRunner:
             # matches, so a recycled id() cannot produce a false hit.  The parameter objects are
             # pinned: their id()s are part of the key.
             plans[key] = dict(udfs=[weakref.ref(u) for u in self._udfs], executor=executor,
-                              tasks=tasks, params=params, meta=meta, content=content,
+                              tasks=tasks, params=params, meta=meta, content=content, epoch=_PLAN_EPOCH[0],
                               kwargs=[dict(u._kwargs) for u in self._udfs])
             while len(plans) > self.PLAN_CACHE_SIZE:
                 plans.popitem(last=False)
@@ -1180,15 +1190,16 @@ class UDFRunner:
                           udf_backends=udf_backends)
 
     def run_for_dataset(self, dataset, executor, roi=None, progress=False, corrections=None,
-                        backends=None, dry=False):
+                        backends=None, dry=False, result_where=None):
         for res in self.run_for_dataset_sync(
                 dataset=dataset, executor=executor, roi=roi, progress=progress,
-                corrections=corrections, backends=backends, dry=dry, iterate=False):
+                corrections=corrections, backends=backends, dry=dry, iterate=False,
+                result_where=result_where):
             pass
         return UDFResults(buffers=res.buffers, damage=res.damage)
 
     def run_for_dataset_sync(self, dataset, executor, roi=None, progress=False, corrections=None,
-                             backends=None, dry=False, iterate=True):
+                             backends=None, dry=False, iterate=True, result_where=None):
         if roi is not None:
             roi = np.asarray(roi, dtype=bool)
         # a cache hit by identity may compare the parameter CONTENTS behind the enqueued kernels
@@ -1197,16 +1208,25 @@ class UDFRunner:
         while True:
             try:
                 yield from self._run_attempt(dataset, executor, roi, corrections, backends, dry,
-                                             iterate, defer)
+                                             iterate, defer, result_where)
                 return
             except _StalePlan:
                 # the parameters changed in place since the plan was made: the plan is gone from the
                 # cache, nothing of the run was delivered -- plan afresh and run again
                 defer = False
 
-    def _run_attempt(self, dataset, executor, roi, corrections, backends, dry, iterate, defer):
-        tasks, params, verify = self._prepare_run_for_dataset(
-            dataset, executor, roi, corrections, backends, dry, defer_check=defer)
+    def _run_attempt(self, dataset, executor, roi, corrections, backends, dry, iterate, defer,
+                     result_where=None):
+        try:
+            tasks, params, verify = self._prepare_run_for_dataset(
+                dataset, executor, roi, corrections, backends, dry, defer_check=defer,
+                result_where=result_where)
+        except BaseException:
+            # (launch_ahead may have enqueued kernels and set the executor's replay state before the rest of
+            # the preparation failed: nothing of it may reach the next run)
+            if hasattr(executor, 'drain'):
+                executor.drain()
+            raise
         cancel_id = f"run-{next(_RUN_IDS)}"
         damage = BufferWrapper(kind='nav', dtype=bool)
         damage.set_roi(roi)
@@ -1242,8 +1262,12 @@ class UDFRunner:
                                                              self._apply_part_result):
                             yield self._make_udf_result(self._udfs, damage)
                     elif hasattr(executor, 'merge_results'):
-                        executor.merge_results(self._udfs, damage, result_iter,
-                                               self._apply_part_result)
+                        if result_where is not None:
+                            executor.merge_results(self._udfs, damage, result_iter,
+                                                   self._apply_part_result, result_where=result_where)
+                        else:
+                            executor.merge_results(self._udfs, damage, result_iter,
+                                                   self._apply_part_result)
                         if iterate:
                             yield self._make_udf_result(self._udfs, damage)
                     else:
@@ -1278,11 +1302,16 @@ class UDFRunner:
             if plans:
                 plans.clear()
             raise _StalePlan()
-        except Exception:
+        except BaseException as exc:
             # a stale plan may fail before the comparison is reached (a factory list that grew: the
             # kept task instances and the new result buffers disagree) -- that is a stale plan, not
-            # an error of the run
+            # an error of the run.  (BaseException: a KeyboardInterrupt / GeneratorExit must not leave
+            # enqueued launches or recording state behind either.)
             from libertem_amd import hip as _hip
+            if not isinstance(exc, Exception):
+                if hasattr(executor, 'drain'):
+                    executor.drain()
+                raise
             if _hip.LaunchReplay.expected is not None or _hip.LaunchReplay.recording is not None:
                 # a run that enqueued launches ahead (or was recording) ended in an error: nothing of that
                 # state may leak into the next run

@@ -20,7 +20,7 @@ from libertem_amd.common.container import MaskContainer
 from libertem_amd.common.buffers import AuxBufferWrapper
 from libertem_amd.common.hiparray import HipArray, HipRowsArray
 from libertem_amd.common.exceptions import HipRequiredError
-from libertem_amd.common.fingerprint import fingerprint
+from libertem_amd.common.fingerprint import fingerprint, is_opaque
 from libertem_amd.udf.base import UDF
 
 
@@ -43,9 +43,14 @@ def _factories_key(mask_factories):
     return fingerprint(mask_factories)
 
 
-def _cached_container(mask_factories, dtype, use_sparse, count, default_sparse):
-    key = (_factories_key(mask_factories), None if dtype is None else np.dtype(dtype).str,
-           str(use_sparse), count, default_sparse)
+def _cached_container(mask_factories, dtype, use_sparse, count, default_sparse, cache=True):
+    fp = _factories_key(mask_factories) if cache else None
+    if fp is None or is_opaque(fp):
+        # cache=False, or the factories reach something a fingerprint cannot look into: evaluated afresh,
+        # like every run of the reference (common/container.py:260-314)
+        return MaskContainer(mask_factories, dtype=dtype, use_sparse=use_sparse, count=count,
+                             backend=UDF.BACKEND_HIP, default_sparse=default_sparse)
+    key = (fp, None if dtype is None else np.dtype(dtype).str, str(use_sparse), count, default_sparse)
     hit = _CONTAINER_CACHE.get(key)
     if hit is not None and hit[0] is mask_factories:
         _CONTAINER_CACHE.move_to_end(key)
@@ -182,6 +187,11 @@ def _folded_plan(corrections, masks_container, mask_factories, sig_shape, count)
         factory, dtype, masks_container.use_sparse if masks_container.use_sparse is not False
         else False, count, 'scipy.sparse')
     return container, state
+
+
+def invalidate_cache():
+    """forget the evaluated stacks (Context.invalidate_caches): not closed -- a UDF may still hold one"""
+    _CONTAINER_CACHE.clear()
 
 
 def clear_mask_cache():
@@ -333,13 +343,17 @@ class ApplyMasksUDF(UDF):
         (reference udf/masks.py:207-233).  Float values are cast to int.  With shifts the stack is
         always applied densely, one kernel launch per tile of full frames (the reference goes frame
         by frame).
+    cache : (not in the reference) False = evaluate the factories and plan the run afresh every time, like
+        the reference does -- for factories whose output depends on something a content fingerprint cannot
+        see (a file, random state); default True: stacks, device images and run plans are kept across runs
+        and re-used while everything the factories can reach is unchanged (common/fingerprint.py).
     '''
 
     REUSE_TASK_INSTANCES = True      # (udf/base.py: per-partition instances kept between runs)
     ACCEPTS_ROW_VIEWS = True         # process_tile reads an ROI's frames through a row list (no gather)
 
     def __init__(self, mask_factories, use_torch=True, use_sparse=None, mask_count=None,
-                 mask_dtype=None, preferred_dtype=None, backends=None, shifts=None, **kwargs):
+                 mask_dtype=None, preferred_dtype=None, backends=None, shifts=None, cache=True, **kwargs):
         _backends = backends
         supported = (self.BACKEND_HIP,)
         if backends is None:
@@ -360,7 +374,7 @@ class ApplyMasksUDF(UDF):
         super().__init__(
             mask_factories=mask_factories, use_torch=use_torch, use_sparse=use_sparse,
             mask_count=mask_count, mask_dtype=mask_dtype, preferred_dtype=preferred_dtype,
-            backends=backends, shifts=shifts, **kwargs)
+            backends=backends, shifts=shifts, cache=cache, **kwargs)
 
     def get_preferred_input_dtype(self):
         if self.params.preferred_dtype is None:
@@ -389,7 +403,7 @@ class ApplyMasksUDF(UDF):
         if p.get('shifts') is not None:
             use_sparse = False               # shifted application slices the dense stack
         return _cached_container(p.mask_factories, p.mask_dtype, use_sparse, p.mask_count,
-                                 'scipy.sparse')
+                                 'scipy.sparse', cache=p.get('cache', True) is not False)
 
     def folds_corrections(self, corrections, meta):
         """True iff this UDF can take RAW frames and apply `corrections` through its masks."""

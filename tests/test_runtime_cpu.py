@@ -1004,8 +1004,9 @@ def test_sparse_integer_exactness_rule():
 def test_fingerprint_sees_column_bands_and_single_elements():
     """Round-3 review: an evenly strided sample of a (16, 256, 256) float32 stack (step = one row) hashes
     columns 0..15 of every row only -- a column-band edit or a small block went unseen and the cached
-    device image / plan of the old masks was used.  Buffers up to 64 MiB are hashed in full."""
-    from libertem_amd.common.fingerprint import array_fingerprint, fingerprint, FULL_BYTES
+    device image / plan of the old masks was used.  Every byte of every array is hashed, whatever its size
+    (round 5: no sampling above 64 MiB any more)."""
+    from libertem_amd.common.fingerprint import array_fingerprint, fingerprint
     m = np.random.default_rng(0).random((16, 256, 256)).astype(np.float32)
     f0 = array_fingerprint(m)
     assert array_fingerprint(m.copy()) == f0
@@ -1021,8 +1022,69 @@ def test_fingerprint_sees_column_bands_and_single_elements():
     g0 = fingerprint(fac)
     m[:, :, 100:110] = 0
     assert fingerprint(fac) != g0
-    # beyond the full-hash limit: sampled, but not with a stride that divides the row length
-    big = np.zeros((FULL_BYTES // 4 // 1024 // 1024 + 1, 1024, 1024), np.float32)
+    # a large buffer: ONE changed element is seen
+    big = np.zeros((17, 1024, 1024), np.float32)
     fb = array_fingerprint(big)
-    big[:, :, 100:110] = 1
+    big[9, 777, 123] = 1
     assert array_fingerprint(big) != fb
+    # non-contiguous views
+    v = m[:, ::2, 1::3]
+    fv = array_fingerprint(v)
+    m[5, 10, 4] += 1
+    assert array_fingerprint(v) != fv
+
+
+def test_fingerprint_follows_objects_and_refuses_what_it_cannot_see():
+    """Round-4 review: a bound method's object and captured objects were taken by id() only
+    (`mask_factories=holder.make` with `holder.mask[:] = ...` between runs -> old masks).  Their __dict__ is
+    followed now; what cannot be looked into yields an OPAQUE fingerprint that never compares equal, so nothing
+    that depends on it is cached (the reference re-evaluates every run, common/container.py:260-314)."""
+    from libertem_amd.common.fingerprint import fingerprint, is_opaque
+
+    class Holder:
+        def __init__(self):
+            self.mask = np.ones((4, 4), np.float32)
+            self.radius = 3
+
+        def make(self):
+            return self.mask * self.radius
+
+    h = Holder()
+    f0 = fingerprint(h.make)
+    assert not is_opaque(f0) and fingerprint(h.make) == f0
+    h.mask[1, 2] = 5                                   # attribute array edited in place
+    f1 = fingerprint(h.make)
+    assert f1 != f0
+    h.radius = 4                                       # plain attribute changed
+    assert fingerprint(h.make) != f1
+    # closure over an object
+    h2 = Holder()
+    fac = (lambda: h2.mask)
+    g0 = fingerprint(fac)
+    h2.mask[:] = 2
+    assert fingerprint(fac) != g0
+    # a module global that is an object
+    global _FP_HOLDER
+    _FP_HOLDER = Holder()
+
+    def from_global():
+        return _FP_HOLDER.mask
+    k0 = fingerprint(from_global)
+    _FP_HOLDER.mask[0, 0] = 9
+    assert fingerprint(from_global) != k0
+
+    # things that cannot be looked into: never equal, flagged
+    class Slotted:
+        __slots__ = ('a',)
+
+        def __init__(self):
+            self.a = np.zeros(3)
+    sl = Slotted()
+    fo = fingerprint(lambda: sl.a)
+    assert is_opaque(fo) and fingerprint(lambda: sl.a) != fo
+    gen = np.random.default_rng(0)
+    assert is_opaque(fingerprint(lambda: gen.random(3)))
+    deep = [[[[[[np.zeros(2)]]]]]]
+    assert is_opaque(fingerprint(lambda: deep))
+    # modules, classes and builtins a factory names are stable, not opaque
+    assert not is_opaque(fingerprint(lambda: np.ones((2, 2)) * len(str(Holder))))

@@ -1891,3 +1891,139 @@ def test_bench_contract_with_eight_ranks_on_one_gpu():
     assert d['strong_c3']['scaling'] == 'strong' and d['strong_c3']['frames_total'] == 16384
     assert d['f32_instruction'] and 'error' not in d['f32_instruction']
     assert not [f for f in os.listdir('/dev/shm') if f.startswith(f'ltmi_{os.getuid()}_')]
+
+
+# ---- caches and launch-ahead state: staleness and concurrency (round-4 review) ---------------------------------
+class _MaskHolder:
+    """a factory that is a BOUND METHOD: what it returns depends on attributes of its object"""
+
+    def __init__(self, masks):
+        self.mask = masks
+        self.gain = np.float32(1)
+
+    def make(self):
+        return self.mask * self.gain
+
+
+def test_cached_stacks_follow_bound_methods_and_captured_objects(ctx):
+    """`mask_factories=holder.make` with `holder.mask[:] = ...` (or `holder.gain = 2`) between runs, and a closure
+    over an object whose array is edited in place: the reference re-evaluates the factories every run
+    (common/container.py:260-314); the cached stack / device image / run plan here must not survive the edit.
+    cache=False and Context.invalidate_caches() for what no fingerprint can see."""
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    rng = np.random.default_rng(77)
+    data = rng.integers(0, 1000, (4, 6, 64, 64)).astype(np.uint16)
+    ds = _device_ds(ctx, data, 2)
+    holder = _MaskHolder(rng.random((5, 64, 64)).astype(np.float32))
+    udf = ApplyMasksUDF(mask_factories=holder.make, use_sparse=False, mask_count=5)
+    for edit in (lambda: None, lambda: holder.mask.__setitem__((slice(None), slice(10, 20)), 0.25),
+                 lambda: setattr(holder, 'gain', np.float32(3)),
+                 lambda: holder.mask.__setitem__((2, 5, 7), 100.0)):
+        edit()
+        for _ in range(3):                                   # (run 3 is launched ahead of the book-keeping)
+            got = ctx.run_udf(dataset=ds, udf=udf)['intensity'].data
+            assert _close(got, opath.apply_masks(data, holder.make(), num_partitions=2), F32_TOL)
+    h2 = _MaskHolder(rng.random((3, 64, 64)).astype(np.float32))
+    udf2 = ApplyMasksUDF(mask_factories=lambda: h2.mask, use_sparse=False, mask_count=3)
+    for edit in (lambda: None, lambda: h2.mask.__imul__(np.float32(0.5)), lambda: h2.mask.__setitem__((1, 63, 63), -4.0)):
+        edit()
+        for _ in range(3):
+            got = ctx.run_udf(dataset=ds, udf=udf2)['intensity'].data
+            assert _close(got, opath.apply_masks(data, h2.mask, num_partitions=2), F32_TOL)
+    # what a fingerprint cannot see: a factory that draws from a generator.  cache=False re-evaluates every run
+    state = {'n': 0}
+    base = rng.random((2, 64, 64)).astype(np.float32)
+
+    def counting():
+        state['n'] += 1
+        return base * np.float32(state['n'])
+    n_before = state['n']
+    udf3 = ApplyMasksUDF(mask_factories=counting, use_sparse=False, mask_count=2, cache=False)
+    r1 = ctx.run_udf(dataset=ds, udf=udf3)['intensity'].data
+    r2 = ctx.run_udf(dataset=ds, udf=udf3)['intensity'].data
+    assert state['n'] > n_before + 1 and not np.array_equal(r1, r2)          # evaluated again for the second run
+    # ... and the global switch: a scalar inside a captured dict is not part of a fingerprint (a counter a factory keeps
+    # there is not a mask parameter) -- it stands in for a file the factory reads
+    files = {'scale': np.float32(1)}
+    udf4 = ApplyMasksUDF(mask_factories=lambda: base * files['scale'], use_sparse=False, mask_count=2)
+    a = ctx.run_udf(dataset=ds, udf=udf4)['intensity'].data
+    assert _close(a, opath.apply_masks(data, base, num_partitions=2), F32_TOL)
+    files['scale'] = np.float32(2)
+    ctx.invalidate_caches()
+    b = ctx.run_udf(dataset=ds, udf=udf4)['intensity'].data
+    assert _close(b, opath.apply_masks(data, base * 2, num_partitions=2), F32_TOL)
+
+
+def test_two_contexts_interleave_cached_plans(ctx):
+    """Two Contexts (two executors) in one process taking turns with plans that are launched ahead: the launch-ahead
+    state belongs to the executor, not to the process (round-4 review: one run swallowed or rejected the other's
+    launch)."""
+    from libertem_amd import hip
+    from libertem_amd.api import Context
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    rng = np.random.default_rng(78)
+    ctx2 = Context.make_with('hip', gpus=0)
+    try:
+        d1 = rng.integers(0, 1000, (4, 8, 64, 64)).astype(np.uint16)
+        d2 = rng.integers(0, 1000, (6, 4, 64, 64)).astype(np.uint16)
+        m1 = rng.random((16, 64, 64)).astype(np.float32)
+        m2 = rng.random((7, 64, 64)).astype(np.float32)
+        ds1, ds2 = _device_ds(ctx, d1, 2), _device_ds(ctx2, d2, 3)
+        u1 = ApplyMasksUDF(mask_factories=lambda: m1, use_sparse=False, mask_count=16)
+        u2 = ApplyMasksUDF(mask_factories=lambda: m2, use_sparse=False, mask_count=7)
+        ref1, ref2 = opath.apply_masks(d1, m1, num_partitions=2), opath.apply_masks(d2, m2, num_partitions=3)
+        n0 = hip.LaunchReplay.n_ahead
+        for rep in range(6):
+            assert _close(ctx.run_udf(dataset=ds1, udf=u1)['intensity'].data, ref1, F32_TOL)
+            assert _close(ctx2.run_udf(dataset=ds2, udf=u2)['intensity'].data, ref2, F32_TOL)
+        assert hip.LaunchReplay.n_ahead - n0 == 4 * (2 + 3)           # both kept launching ahead (runs 3 .. 6)
+        assert ctx.executor.replay is not ctx2.executor.replay
+        assert ctx.executor.replay.expected is None and ctx2.executor.replay.expected is None
+        # from two threads at once
+        import threading
+        errs = []
+
+        def loop(c, ds, u, ref):
+            try:
+                for _ in range(8):
+                    if not _close(c.run_udf(dataset=ds, udf=u)['intensity'].data, ref, F32_TOL):
+                        errs.append('wrong result')
+            except Exception as e:                                   # noqa: BLE001
+                errs.append(repr(e))
+        ts = [threading.Thread(target=loop, args=(ctx, ds1, u1, ref1)),
+              threading.Thread(target=loop, args=(ctx2, ds2, u2, ref2))]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errs, errs
+    finally:
+        ctx2.close()
+
+
+def test_sync_run_while_async_run_is_pending(ctx):
+    """`run_udf(sync=False)` runs on the context's worker thread; a synchronous `run_udf` issued from the event-loop
+    thread while it is in flight -- same executor, another cached plan -- waits for it (one run at a time per
+    executor) instead of sharing its delivery targets and launch-ahead state."""
+    import asyncio
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    rng = np.random.default_rng(79)
+    d1 = rng.integers(0, 1000, (16, 16, 64, 64)).astype(np.uint16)
+    d2 = rng.integers(0, 1000, (3, 5, 64, 64)).astype(np.uint16)
+    m1 = rng.random((16, 64, 64)).astype(np.float32)
+    m2 = rng.random((4, 64, 64)).astype(np.float32)
+    ds1, ds2 = _device_ds(ctx, d1, 4), _device_ds(ctx, d2, 1)
+    u1 = ApplyMasksUDF(mask_factories=lambda: m1, use_sparse=False, mask_count=16)
+    u2 = ApplyMasksUDF(mask_factories=lambda: m2, use_sparse=False, mask_count=4)
+    ref1, ref2 = opath.apply_masks(d1, m1, num_partitions=4), opath.apply_masks(d2, m2, num_partitions=1)
+    for _ in range(3):                                               # both plans cached and launched ahead
+        ctx.run_udf(dataset=ds1, udf=u1)
+        ctx.run_udf(dataset=ds2, udf=u2)
+
+    async def main():
+        for _ in range(5):
+            pending = asyncio.ensure_future(ctx.run_udf(dataset=ds1, udf=u1, sync=False))
+            await asyncio.sleep(0)                                    # the worker thread picks it up
+            got2 = ctx.run_udf(dataset=ds2, udf=u2)['intensity'].data    # sync, from the loop's thread
+            got1 = (await pending)['intensity'].data
+            assert _close(got1, ref1, F32_TOL) and _close(got2, ref2, F32_TOL)
+    asyncio.run(main())
+    assert ctx.executor.replay.expected is None and ctx.executor.replay.recording is None
