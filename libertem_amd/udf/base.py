@@ -711,6 +711,11 @@ def _execution_plan(udfs, ds_backends, device_class, restrict=None):
                 f"(udf: {u.get_backends()}, restrict: {restrict}; this build runs {(HIP, NUMPY)})")
     if device_class == 'hip' and HIP in ds_backends and all(HIP in b for b in per_udf):
         return HIP
+    if device_class == 'hip' and any(HIP in b for b in per_udf):
+        # a UDF with a device path never takes its NumPy branch on a GPU worker: no silent CPU fallback
+        raise ValueError(
+            f"no common array backend on this MI355X worker: dataset offers {ds_backends}, UDFs offer {per_udf} "
+            "(UDFs that list BACKEND_HIP run on the device or not at all here)")
     if all(NUMPY in b for b in per_udf) and NUMPY in ds_backends:
         if device_class == 'hip':
             # NumPy UDFs may run on a GPU worker's host side, like the reference runs NumPy UDFs

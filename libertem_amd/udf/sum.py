@@ -29,7 +29,11 @@ class SumUDF(UDF):
         return self.params.dtype
 
     def get_backends(self):
-        return (self.BACKEND_HIP,)
+        # BACKEND_HIP on an MI355X worker; plain NumPy on a CPU executor (BASELINE config C1:
+        # `Context(InlineJobExecutor()).run_udf(ds, SumUDF())`, the reference's udf/sum.py:43-48 runs anywhere).
+        # The executor's device class decides (udf/base.py `_execution_plan`): a GPU worker never takes the
+        # NumPy branch, there is no fallback from one to the other.
+        return (self.BACKEND_HIP, self.BACKEND_NUMPY)
 
     def get_result_buffers(self):
         return {
@@ -66,8 +70,10 @@ class SumUDF(UDF):
         return {'intensity': img}
 
     def get_task_data(self):
+        if self.meta.array_backend == self.BACKEND_NUMPY:
+            return {'workspace': None}
         if self.meta.array_backend != self.BACKEND_HIP:
-            raise HipRequiredError("SumUDF needs BACKEND_HIP (an MI355X worker)")
+            raise HipRequiredError("SumUDF needs BACKEND_HIP (an MI355X worker) or BACKEND_NUMPY (a CPU executor)")
         # result dtype = input dtype (udf/sum.py:38-40): float, complex, or -- SumUDF(dtype=<integer>)
         # on integer frames -- an integer with NumPy's wrap-around
         if np.dtype(self.meta.input_dtype).kind not in 'fciu':
@@ -85,6 +91,9 @@ class SumUDF(UDF):
 
     def process_tile(self, tile):
         # results.intensity[sig slice] += tile.sum(axis=0)      (udf/sum.py:43-48)
+        if self.meta.array_backend == self.BACKEND_NUMPY:
+            self.results.intensity[:] += np.sum(tile, axis=0)        # the reference's line, on the host
+            return
         from libertem_amd import hip
         view = self.results.intensity
         if not isinstance(tile, HipArray) or not isinstance(view, HipSigView):

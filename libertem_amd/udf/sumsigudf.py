@@ -14,7 +14,8 @@ class SumSigUDF(UDF):
     REUSE_TASK_INSTANCES = True      # (udf/base.py: per-partition instances kept between runs)
 
     def get_backends(self):
-        return (self.BACKEND_HIP,)
+        # BACKEND_HIP on an MI355X worker, plain NumPy on a CPU executor (see SumUDF.get_backends)
+        return (self.BACKEND_HIP, self.BACKEND_NUMPY)
 
     def get_result_buffers(self):
         dtype = np.result_type(self.meta.input_dtype, np.float32)
@@ -28,8 +29,10 @@ class SumSigUDF(UDF):
             np.dtype(np.result_type(meta.input_dtype, np.float32)) == np.float32
 
     def get_task_data(self):
+        if self.meta.array_backend == self.BACKEND_NUMPY:
+            return {'engine': None}
         if self.meta.array_backend != self.BACKEND_HIP:
-            raise HipRequiredError("SumSigUDF needs BACKEND_HIP (an MI355X worker)")
+            raise HipRequiredError("SumSigUDF needs BACKEND_HIP (an MI355X worker) or BACKEND_NUMPY (a CPU executor)")
         if getattr(self.meta, 'corrections_folded', False):
             from libertem_amd.udf.masks import ApplyMasksEngine, _cached_container, _folded_plan
             sig = tuple(self.meta.dataset_shape.sig)
@@ -43,6 +46,10 @@ class SumSigUDF(UDF):
 
     def process_tile(self, tile):
         # results.intensity[:] += tile.reshape(n, -1).sum(axis=1)   (udf/sumsigudf.py:30-39)
+        if self.meta.array_backend == self.BACKEND_NUMPY:
+            # the reference's line, on the host (udf/sumsigudf.py:30-39)
+            self.results.intensity[:] += np.sum(tile.reshape((tile.shape[0], -1)), axis=-1)
+            return
         from libertem_amd import hip
         out = self.results.intensity
         if not isinstance(tile, HipArray) or not isinstance(out, HipArray):
@@ -60,6 +67,8 @@ class SumSigUDF(UDF):
     def get_write_once_buffers(self):
         """whole-frame tiles: one kernel call per row (see ApplyMasksUDF.get_write_once_buffers)"""
         ts = self.meta.tiling_scheme if self.meta is not None else None
+        if self.meta is not None and self.meta.array_backend == self.BACKEND_NUMPY:
+            return ()
         if ts is None or len(ts) != 1 or getattr(self.meta, 'corrections_folded', False) \
                 or getattr(self.meta, 'sig_sliced_tiles', False):
             return ()

@@ -171,9 +171,21 @@ def test_c1_config(ctx):
     """BASELINE.json configs[0]: SumUDF-like on 32x32 x 128x128 float32, inline CPU executor."""
     data = np.random.default_rng(0).random((32, 32, 128, 128), dtype=np.float32)
     ds = ctx.load('memory', data=data, num_partitions=4, sig_dims=2)
-    res = ctx.run_udf(dataset=ds, udf=NumpySumUDF())
+    from libertem_amd.api import Context
+    from libertem_amd.executor.inline import InlineJobExecutor
+    from libertem_amd.udf.sum import SumUDF
+    from libertem_amd.udf.sumsigudf import SumSigUDF
+    # the config as written: Context(InlineJobExecutor()).run_udf(ds, SumUDF()) with the SHIPPED class
+    c1 = Context(executor=InlineJobExecutor())
+    res = c1.run_udf(dataset=ds, udf=SumUDF())
+    assert res['intensity'].data.dtype == np.float32
     assert np.array_equal(res['intensity'].data, opath.sum_udf(data, num_partitions=4))
     assert np.allclose(res['intensity'].data, data.sum(axis=(0, 1)), rtol=1e-5)
+    ss = c1.run_udf(dataset=ds, udf=SumSigUDF())
+    assert np.allclose(ss['intensity'].data, data.sum(axis=(2, 3)), rtol=1e-5)
+    # the test-local NumPy UDF of earlier rounds takes the same tiles in the same order: identical bits
+    res2 = ctx.run_udf(dataset=ds, udf=NumpySumUDF())
+    assert np.array_equal(res2['intensity'].data, res['intensity'].data)
 
 
 @pytest.mark.parametrize('name', ['c2_u16_16masks', 'odd_tiles_f32', 'f32_5masks', 'i32_f64',
@@ -280,13 +292,24 @@ def test_udf_interface_errors(ctx):
 # --- the native operators must refuse to run without the HIP backend -------------------------------
 @pytest.mark.parametrize('make_udf', [
     lambda: ApplyMasksUDF(mask_factories=[lambda: np.ones((4, 4))]),
-    lambda: SumUDF(), lambda: SumSigUDF(), lambda: CoMUDF.with_params(),
-], ids=['masks', 'sum', 'sumsig', 'com'])
+    lambda: CoMUDF.with_params(),
+], ids=['masks', 'com'])
 def test_native_udfs_fail_loudly_on_cpu(ctx, make_udf):
+    # (SumUDF / SumSigUDF list BACKEND_NUMPY too since round 5: BASELINE config C1 runs them on the inline
+    #  executor, test_c1_config; a GPU worker never takes their NumPy branch -- test_gpu_worker_never_takes_numpy_branch)
     data = np.zeros((2, 2, 4, 4), dtype=np.float32)
     ds = ctx.load('memory', data=data, num_partitions=1, sig_dims=2)
     with pytest.raises(HipRequiredError):
         ctx.run_udf(dataset=ds, udf=make_udf())
+
+
+def test_gpu_worker_never_takes_numpy_branch():
+    """_execution_plan: a UDF that lists BACKEND_HIP runs on the device or not at all on a 'hip' worker"""
+    from libertem_amd.udf.base import _execution_plan, HIP, NUMPY
+    assert _execution_plan([SumUDF()], (NUMPY, HIP), 'hip') == HIP
+    assert _execution_plan([SumUDF()], (NUMPY, HIP), 'cpu') == NUMPY
+    with pytest.raises(ValueError):
+        _execution_plan([SumUDF()], (NUMPY,), 'hip')
 
 
 def test_apply_masks_udf_argument_errors():
