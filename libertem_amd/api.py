@@ -75,7 +75,16 @@ class Context:
     # --- datasets ------------------------------------------------------------------------------
     def load(self, filetype, *args, io_backend=None, **kwargs):
         ds = _load_dataset(filetype, *args, **kwargs)
-        return ds.initialize(self.executor)
+        ds = ds.initialize(self.executor)
+        loaded = self.__dict__.get('_loaded')
+        if loaded is None:
+            import weakref
+            loaded = self.__dict__['_loaded'] = weakref.WeakSet()
+        try:
+            loaded.add(ds)                  # (close(): the datasets' upload stagers go with the context)
+        except TypeError:
+            pass
+        return ds
 
     # --- analyses (reference api.py:514-811) -----------------------------------------------------
     def create_mask_analysis(self, factories, dataset, use_sparse=None, mask_count=None,
@@ -304,6 +313,15 @@ class Context:
                             corrections=corrections, backends=backends)
 
     def close(self):
+        # the datasets this context loaded give up their upload stagers (device buffers, copy stream and the
+        # page-locking of the user's host array -- held between runs, io/dataset/memory.py)
+        for ds in list(getattr(self, '_loaded', ()) or ()):
+            closer = getattr(ds, 'close_stagers', None)
+            if closer is not None:
+                try:
+                    closer()
+                except Exception:                       # noqa: BLE001  (closing must not raise)
+                    pass
         pool = getattr(self, '_async_worker', None)
         if pool is not None:
             pool.shutdown(wait=True)

@@ -52,6 +52,24 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def check_generated():
+    """csrc/ltmi_scatter_loop.inc is generated (scripts/gen_scatter_asm.py) and tracked: a build from a tree in which
+    the two disagree -- the generator edited, the file not regenerated, or the file edited by hand -- fails.
+    (An installed package without scripts/ has nothing to compare with.)"""
+    gen = os.path.join(os.path.dirname(HERE), 'scripts', 'gen_scatter_asm.py')
+    inc = os.path.join(CSRC, 'ltmi_scatter_loop.inc')
+    if not os.path.exists(gen):
+        return
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_gen_scatter_asm', gen)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with open(inc) as f:
+        have = f.read()
+    if have != mod.render():
+        raise RuntimeError(f"{inc} is not what {gen} generates: run `python scripts/gen_scatter_asm.py`")
+
+
 def build(force=False, verbose=True, asan=False, hardened=False):
     """Sanitizer builds of the HOST code of the library (image builders, argument checks, the C ABI;
     device code unchanged), selected at run time with LTMI_LIB=<path>:
@@ -66,6 +84,7 @@ def build(force=False, verbose=True, asan=False, hardened=False):
         torch wheel bundles (observed on this image), so with stock torch use the hardened build.
             LTMI_LIB=.../libltmi_asan.so LD_PRELOAD=$(clang -print-file-name=libclang_rt.asan-x86_64.so)"""
     hipcc = find_hipcc()
+    check_generated()
     tag = '_asan' if asan else ('_hardened' if hardened else '')
     objdir = OBJDIR + tag
     lib = LIB.replace('libltmi.so', f'libltmi{tag}.so')

@@ -1414,15 +1414,18 @@ void *bell_build(const int64_t *indptr, const int64_t *indices, const float *val
 template <typename T>
 __global__ void k_bell_tail(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
                             const int32_t *__restrict__ px, const int32_t *__restrict__ col,
-                            const float *__restrict__ val, const int32_t *__restrict__ seg,
+                            const float *__restrict__ val, const int32_t *__restrict__ seg, int n_seg,
                             float *__restrict__ out, int64_t ld_out, const int32_t *__restrict__ rows) {
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n_frames) return;
-    const int e0 = seg[blockIdx.y], e1 = seg[blockIdx.y + 1];
     const T *row = tile + (rows ? (int64_t)rows[f] : f) * ld;
-    float acc = 0.f;
-    for (int e = e0; e < e1; ++e) acc += val[e] * (float)row[px[e]];
-    out[f * ld_out + col[e0]] += acc;
+    // (grid.y is capped at 65 535: a stack with more tail columns than that walks them in strides)
+    for (int c = blockIdx.y; c < n_seg; c += gridDim.y) {
+        const int e0 = seg[c], e1 = seg[c + 1];
+        float acc = 0.f;
+        for (int e = e0; e < e1; ++e) acc += val[e] * (float)row[px[e]];
+        out[f * ld_out + col[e0]] += acc;
+    }
 }
 
 template <typename T, int TL>
@@ -1465,10 +1468,10 @@ static int launch_bell_t(ltmi_masks *m, BellImage *b, const T *tile, int64_t n_f
     }
 #endif
     if (b->n_tail > 0) {
-        hipLaunchKernelGGL(k_bell_tail<T>, dim3((unsigned)((n_frames + 255) / 256), (unsigned)b->n_tail_cols),
+        hipLaunchKernelGGL(k_bell_tail<T>, dim3((unsigned)((n_frames + 255) / 256), (unsigned)std::min(b->n_tail_cols, 65535)),
                            dim3(256), 0, stream, tile, ld, n_frames, (const int32_t *)b->tail_px,
                            (const int32_t *)b->tail_col, (const float *)b->tail_val,
-                           (const int32_t *)b->tail_seg, out, ld_out_f, m->roi_rows);
+                           (const int32_t *)b->tail_seg, (int)b->n_tail_cols, out, ld_out_f, m->roi_rows);
         LTMI_HIP(hipGetLastError());
     }
     snprintf(m->last_kernel, sizeof(m->last_kernel),
@@ -1498,10 +1501,10 @@ static int launch_bell_flat(ltmi_masks *m, BellImage *b, const T *tile, int64_t 
                        accumulate, ablate, m->roi_rows, (const float *)b->inv_scale);
     LTMI_HIP(hipGetLastError());
     if (b->n_tail > 0) {
-        hipLaunchKernelGGL(k_bell_tail<T>, dim3((unsigned)((n_frames + 255) / 256), (unsigned)b->n_tail_cols),
+        hipLaunchKernelGGL(k_bell_tail<T>, dim3((unsigned)((n_frames + 255) / 256), (unsigned)std::min(b->n_tail_cols, 65535)),
                            dim3(256), 0, stream, tile, ld, n_frames, (const int32_t *)b->tail_px,
                            (const int32_t *)b->tail_col, (const float *)b->tail_val,
-                           (const int32_t *)b->tail_seg, out, ld_out_f, m->roi_rows);
+                           (const int32_t *)b->tail_seg, (int)b->n_tail_cols, out, ld_out_f, m->roi_rows);
         LTMI_HIP(hipGetLastError());
     }
     snprintf(m->last_kernel, sizeof(m->last_kernel),

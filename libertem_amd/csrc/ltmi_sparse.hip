@@ -677,11 +677,8 @@ extern "C" int ltmi_masks_create_csr(int device, const int64_t *indptr, const in
         if (build) {
             int err = LTMI_OK;
             c->scat = ltmi::scat_build(indptr, indices, vals, nc, n_px, n_masks, &err);
-            if (!c->scat) {
-                ltmi::csr_destroy(m);
-                delete m;
-                return err;
-            }
+            // (a failed build = no scatter image, like a failed float16 blocked image: the other kernels serve)
+            if (!c->scat) (void)hipGetLastError();
         }
     }
     *out = m;

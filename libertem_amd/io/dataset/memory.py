@@ -13,6 +13,8 @@ Tile delivery:
   buffers; `hipMemcpyAsync` on a copy stream overlaps the upload of chunk i+1 with the kernels of
   chunk i (events order the two streams; no host synchronisation inside the loop).
 """
+import os
+
 import numpy as np
 import psutil
 
@@ -300,6 +302,21 @@ class MemoryDataSet(DataSet):
 _REGISTERED = {}
 
 
+def pin_limit_bytes():
+    """the largest host array that is page-locked IN PLACE for uploads (hipHostRegister walks and locks every
+    page: O(size) time, counted against RLIMIT_MEMLOCK, and the pages cannot be swapped or migrated until the
+    registration goes): LTMI_PIN_MAX_BYTES, default half of the machine's memory.  Larger arrays travel through
+    the stager's two page-locked bounce buffers."""
+    env = os.environ.get('LTMI_PIN_MAX_BYTES')
+    if env:
+        return int(float(env))
+    try:
+        import psutil
+        return int(psutil.virtual_memory().total // 2)
+    except Exception:
+        return 64 << 30
+
+
 def _register_host(torch, arr):
     """page-lock `arr` in place (or join an existing registration that covers it) -> key | None"""
     ptr, nbytes = arr.ctypes.data, arr.nbytes
@@ -307,6 +324,8 @@ def _register_host(torch, arr):
         if p0 <= ptr and ptr + nbytes <= p0 + ent[0]:
             ent[1] += 1
             return p0
+    if nbytes > pin_limit_bytes():
+        return None
     try:
         rc = int(torch.cuda.cudart().cudaHostRegister(ptr, nbytes, 0))
     except Exception:

@@ -144,24 +144,30 @@ def loop(dsread, cvt):
     return out
 
 
+def render():
+    """the text of libertem_amd/csrc/ltmi_scatter_loop.inc (libertem_amd/build.py compares the tracked file with it)"""
+    out = ["// GENERATED by scripts/gen_scatter_asm.py -- do not edit.  Main loop of k_scatter per pixel type;\n"
+           "// operands: %0 argument lanes, %1 lane * PITCH, %2 lane * 4, %3 / %4 row pointers (lanes 0..3).\n",
+           f"#define SCAT_PITCH {PITCH}\n#define SCAT_BUF {BUF}\n#define SCAT_ACC0 {ACC0}\n"]
+    variants = [(name, dsread, cvt, ()) for name, (dsread, cvt) in TYPES.items()]
+    for i, abl in enumerate((('hotw',), ('nodma',), ('nolds',), ('nofma',), ('nodma', 'hotw'), ('nobar',), ('nobar', 'hotw'))):
+        variants.append((f'u16_a{i + 1}',) + TYPES['u16'] + (abl,))
+    for name, dsread, cvt, abl in variants:
+        ABL.clear()
+        ABL.update(abl)
+        out.append(f"#define SCAT_LOOP_{name} \\\n")
+        lines = loop(dsread, cvt)
+        out.append(" \\\n".join(f'    "{ln}\\n\\t"' for ln in lines))
+        out.append("\n")
+    ABL.clear()
+    return "".join(out)
+
+
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, 'libertem_amd', 'csrc', 'ltmi_scatter_loop.inc')
     with open(path, 'w') as f:
-        f.write("// GENERATED by scripts/gen_scatter_asm.py -- do not edit.  Main loop of k_scatter per pixel type;\n"
-                "// operands: %0 argument lanes, %1 lane * PITCH, %2 lane * 4, %3 / %4 row pointers (lanes 0..3).\n")
-        f.write(f"#define SCAT_PITCH {PITCH}\n#define SCAT_BUF {BUF}\n#define SCAT_ACC0 {ACC0}\n")
-        variants = [(name, dsread, cvt, ()) for name, (dsread, cvt) in TYPES.items()]
-        for i, abl in enumerate((('hotw',), ('nodma',), ('nolds',), ('nofma',), ('nodma', 'hotw'), ('nobar',), ('nobar', 'hotw'))):
-            variants.append((f'u16_a{i + 1}',) + TYPES['u16'] + (abl,))
-        for name, dsread, cvt, abl in variants:
-            ABL.clear()
-            ABL.update(abl)
-            f.write(f"#define SCAT_LOOP_{name} \\\n")
-            lines = loop(dsread, cvt)
-            f.write(" \\\n".join(f'    "{ln}\\n\\t"' for ln in lines))
-            f.write("\n")
-        ABL.clear()
+        f.write(render())
     print(path)
 
 
