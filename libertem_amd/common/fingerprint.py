@@ -13,8 +13,8 @@ method belongs to and of captured objects.  A fingerprint hashes EVERY byte of e
 udf/base.py `_prepare_run_for_dataset`): any in-place edit is seen.  (Up to round 4 buffers above 64 MiB were
 sampled; a single changed element could go unseen.)
 
-What cannot be seen completely is NOT cached: an object without `__dict__` that is none of the known kinds
-(device tensors, file handles, random generators ...), anything nested deeper than MAX_DEPTH -- the
+What cannot be seen completely is NOT cached: an object without `__dict__` / `__slots__` that is none of the known
+kinds (device tensors, file handles, random generators ...), anything nested deeper than MAX_DEPTH -- the
 fingerprint then contains an OPAQUE token that never compares equal, so the stack is evaluated and the run
 planned afresh every time, like in the reference.  Files a factory reads and global random state stay
 invisible to any fingerprint: `ApplyMasksUDF(..., cache=False)` or `Context.invalidate_caches()`.
@@ -80,29 +80,37 @@ def is_opaque(fp):
     return False
 
 
-def fingerprint(obj, _depth=0, _inside=False):
-    """hashable value that changes when `obj`, or anything `obj` can reach, changes.  Plain numbers
-    and strings count by value where a factory captures them directly (closure cell, default,
-    partial argument, attribute of a captured object), not inside a captured list / dict -- those are
-    followed for the arrays they hold; a counter a factory keeps in a dict is not a mask parameter."""
+def fingerprint(obj, _depth=0, _path=()):
+    """hashable value that changes when `obj`, or anything `obj` can reach, changes: arrays by content, numbers
+    and strings by value wherever they sit (a counter a factory keeps in a captured dict changes with every
+    evaluation -- such a factory is evaluated afresh every run, like in the reference), containers, functions,
+    bound methods and instances by what they hold."""
     if isinstance(obj, np.ndarray):
         return ('nd', id(obj)) + array_fingerprint(obj)
     if obj is None or isinstance(obj, (bool, int, float, complex, str, bytes, np.generic)):
-        return ('s',) if _inside else ('v', obj)
+        return ('v', obj)
     if isinstance(obj, _STABLE_TYPES):
         return ('stable', id(obj))
+    if isinstance(obj, np.dtype):
+        return ('v', obj.str)
+    if isinstance(obj, (range, slice)) or obj is Ellipsis:
+        return ('v', repr(obj))
+    if id(obj) in _path:
+        return ('cycle', id(obj))                           # (an object that holds the factory that holds it)
+    if _is_dataset(obj):
+        return ('ds', id(obj))                              # the frames are the data, not a mask parameter
     if _depth > MAX_DEPTH:
         return _opaque(obj)
+    path = _path + (id(obj),)
     if isinstance(obj, (list, tuple)):
-        return ('seq', id(obj), len(obj)) + tuple(fingerprint(x, _depth + 1, True) for x in obj)
+        return ('seq', id(obj), len(obj)) + tuple(fingerprint(x, _depth + 1, path) for x in obj)
     if isinstance(obj, (set, frozenset)):
         return ('set', id(obj), len(obj))
     if isinstance(obj, dict):
-        return ('map', id(obj), len(obj)) + tuple(fingerprint(v, _depth + 1, True)
-                                                  for v in obj.values())
+        return ('map', id(obj), len(obj)) + tuple(fingerprint(v, _depth + 1, path) for v in obj.values())
     if isinstance(obj, functools.partial):
-        return ('partial', id(obj), fingerprint(obj.func, _depth + 1),
-                fingerprint(obj.args, _depth + 1), fingerprint(obj.keywords, _depth + 1))
+        return ('partial', id(obj), fingerprint(obj.func, _depth + 1, path),
+                fingerprint(obj.args, _depth + 1, path), fingerprint(obj.keywords, _depth + 1, path))
     sp_parts = _sparse_parts(obj) if hasattr(obj, 'shape') and hasattr(obj, 'dtype') else None
     if sp_parts:
         return ('sp', id(obj)) + tuple(array_fingerprint(p) for p in sp_parts)
@@ -111,29 +119,40 @@ def fingerprint(obj, _depth=0, _inside=False):
         fn = getattr(obj, '__func__', obj)
         for cell in (getattr(fn, '__closure__', None) or ()):
             try:
-                out.append(fingerprint(cell.cell_contents, _depth + 1))
+                out.append(fingerprint(cell.cell_contents, _depth + 1, path))
             except ValueError:                                  # empty cell
                 out.append(None)
         for d in (getattr(fn, '__defaults__', None) or ()):
-            out.append(fingerprint(d, _depth + 1))
+            out.append(fingerprint(d, _depth + 1, path))
         for k, d in (getattr(fn, '__kwdefaults__', None) or {}).items():
-            out.append((k, fingerprint(d, _depth + 1)))
+            out.append((k, fingerprint(d, _depth + 1, path)))
         code, glob = getattr(fn, '__code__', None), getattr(fn, '__globals__', None)
         if code is not None and glob is not None:
             for name in code.co_names:
                 v = glob.get(name)
                 if isinstance(v, np.ndarray) or (
                         v is not None and not isinstance(v, _STABLE_TYPES) and not callable(v)
-                        and hasattr(v, '__dict__')):
-                    out.append((name, fingerprint(v, _depth + 1)))
+                        and (hasattr(v, '__dict__') or isinstance(v, (list, dict)))):
+                    out.append((name, fingerprint(v, _depth + 1, path)))
         bound = getattr(obj, '__self__', None)
         if bound is not None and not isinstance(bound, _STABLE_TYPES):
             # a bound method: what the method can read of its object
-            out.append(('self', fingerprint(bound, _depth + 1)))
+            out.append(('self', fingerprint(bound, _depth + 1, path)))
         return tuple(out)
     d = getattr(obj, '__dict__', None)
-    if isinstance(d, dict):
-        # an instance: its attributes, one level per depth step (scalars by value: `holder.radius = 3`)
-        return ('obj', id(obj), type(obj).__qualname__, len(d)) + tuple(
-            (k, fingerprint(v, _depth + 1)) for k, v in d.items())
+    slots = [n for klass in type(obj).__mro__ for n in getattr(klass, '__slots__', ()) if isinstance(n, str)]
+    if isinstance(d, dict) or slots:
+        # an instance: its attributes (scalars by value: `holder.radius = 3`)
+        attrs = list((d or {}).items()) + [(n, getattr(obj, n)) for n in slots
+                                           if n not in ('__dict__', '__weakref__') and hasattr(obj, n)]
+        return ('obj', id(obj), type(obj).__qualname__, len(attrs)) + tuple(
+            (k, fingerprint(v, _depth + 1, path)) for k, v in attrs)
     return _opaque(obj)
+
+
+def _is_dataset(obj):
+    try:
+        from libertem_amd.io.dataset.base import DataSet
+    except Exception:                                        # pragma: no cover
+        return False
+    return isinstance(obj, DataSet)

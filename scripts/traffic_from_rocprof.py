@@ -17,7 +17,7 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOMINANT = ('k_dense', 'k_bell', 'k_sell')
+DOMINANT = ('k_dense', 'k_bell_flat', 'k_bell_apply', 'k_sell', 'k_scatter')
 
 
 def find_db(d):
@@ -124,6 +124,21 @@ def main():
         pmc_avgs = [per[p_]['dom'][2] / 1e3 for p_ in ('fetch', 'write', 'sq')
                     if p_ in per and per[p_]['dom']]
         pmc_avg = sum(pmc_avgs) / len(pmc_avgs) if pmc_avgs else None
+        # a second kernel that belongs to every launch of the dominant one (C4: k_bell_tail, the float32 products
+        # the float16 image leaves out): its time is part of the launch bench.py's HIP events bracket
+        tail_avgs = {}
+        for p_ in ('stats', 'fetch', 'write', 'sq'):
+            db = find_db(os.path.join(d, f'{cfg}_{p_}'))
+            if db is None or 'k_bell_flat' not in dom[0]:
+                continue
+            for name, n, avg, mn, mx, tot in kernel_stats(db):
+                if 'k_bell_tail' in name:
+                    tail_avgs[p_] = avg / 1e3
+        tail_stats = tail_avgs.get('stats')
+        tail_pmc = [v for k, v in tail_avgs.items() if k != 'stats']
+        tail_pmc = sum(tail_pmc) / len(tail_pmc) if tail_pmc else None
+        if tail_stats is not None:
+            print(f"   + k_bell_tail per launch: {tail_stats:.1f} us (stats pass), {tail_pmc} us (counter passes)")
         print(f"   => {dom[0][:60]}: rocprof avg {dom[2]/1e3:.1f} us vs HIP events "
               f"{roof['avg_launch_ms']*1e3:.1f} us; FETCH_SIZE {fetch:.1f} KiB x 1024 x 2 (gfx950) + "
               f"WRITE_SIZE {write:.1f} KiB x 1024 = {hbm:.4g} B = {hbm/alg:.3f} x algorithmic "
@@ -135,10 +150,33 @@ def main():
             "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": hbm / alg,
             "rocprof_kernel": dom[0], "rocprof_avg_us": dom[2] / 1e3, "rocprof_calls": dom[1],
             "rocprof_pmc_pass_avg_us": pmc_avg,
+            "rocprof_tail_avg_us": tail_stats, "rocprof_tail_pmc_pass_avg_us": tail_pmc,
             "hip_event_avg_us": roof['avg_launch_ms'] * 1e3,
             "source": f"profiles/{tag}_configs_rocprof.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                       f"separate passes over bench.py --config {cfg})",
         })
+        f32 = line.get('roofline', {}).get('f32_instruction') or line.get('f32_instruction')
+        if cfg == 'c2' and isinstance(f32, dict) and f32.get('kernel'):
+            # the same run also timed the strict float32-instruction kernel: its own entry (config "c2_f32")
+            try:
+                lab = f32['kernel']
+                d2 = {p_: dominant(kernel_stats(find_db(os.path.join(d, f'{cfg}_{p_}'))), lab)
+                      for p_ in ('stats', 'fetch', 'write', 'sq')}
+                fe = [v for name, ctr, n, v in per['fetch']['counters'] if name == d2['fetch'][0] and ctr == 'FETCH_SIZE'][0]
+                wr = [v for name, ctr, n, v in per['write']['counters'] if name == d2['write'][0] and ctr == 'WRITE_SIZE'][0]
+                pm = [d2[p_][2] / 1e3 for p_ in ('fetch', 'write', 'sq') if d2.get(p_)]
+                entries.append({
+                    "config": "c2_f32", "kernel": lab, "frames_per_launch": roof['frames_per_launch'],
+                    "hbm_bytes_per_launch": fe * 2048 + wr * 1024, "fetch_size_kib": fe, "write_size_kib": wr,
+                    "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (fe * 2048 + wr * 1024) / alg,
+                    "rocprof_kernel": d2['stats'][0], "rocprof_avg_us": d2['stats'][2] / 1e3,
+                    "rocprof_calls": d2['stats'][1], "rocprof_pmc_pass_avg_us": sum(pm) / len(pm) if pm else None,
+                    "hip_event_avg_us": f32.get('kernel_avg_launch_ms', 0) * 1e3,
+                    "source": f"profiles/{tag}_configs_rocprof.txt (the f32_instruction leg of bench.py --config c2)"})
+                print(f"   => f32-instruction leg {d2['stats'][0][:60]}: rocprof avg {d2['stats'][2]/1e3:.1f} us "
+                      f"(counter passes {sum(pm)/len(pm):.1f} us), traffic {(fe * 2048 + wr * 1024) / alg:.3f} x algorithmic")
+            except Exception as e:                        # noqa: BLE001
+                print(f"   no entry for the f32-instruction leg: {e!r}")
         print()
     path = os.path.join(ROOT, 'profiles', 'traffic.json')
     old = []

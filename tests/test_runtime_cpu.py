@@ -1096,17 +1096,25 @@ def test_fingerprint_follows_objects_and_refuses_what_it_cannot_see():
     _FP_HOLDER.mask[0, 0] = 9
     assert fingerprint(from_global) != k0
 
-    # things that cannot be looked into: never equal, flagged
+    # objects with __slots__ are followed like those with a __dict__
     class Slotted:
         __slots__ = ('a',)
 
         def __init__(self):
             self.a = np.zeros(3)
     sl = Slotted()
-    fo = fingerprint(lambda: sl.a)
-    assert is_opaque(fo) and fingerprint(lambda: sl.a) != fo
+    fac_s = (lambda: sl.a)
+    fs = fingerprint(fac_s)
+    assert not is_opaque(fs) and fingerprint(fac_s) == fs
+    sl.a[1] = 1
+    assert fingerprint(fac_s) != fs
+    # things that cannot be looked into: never equal, flagged
     gen = np.random.default_rng(0)
-    assert is_opaque(fingerprint(lambda: gen.random(3)))
+    fo = fingerprint(lambda: gen.random(3))
+    assert is_opaque(fo) and fingerprint(lambda: gen.random(3)) != fo
+    # immutable values a factory captures: by value, not opaque
+    dt = np.dtype(np.complex64)
+    assert not is_opaque(fingerprint(lambda: np.zeros(3, dtype=dt)[slice(0, 2)]))
     deep = [[[[[[np.zeros(2)]]]]]]
     assert is_opaque(fingerprint(lambda: deep))
     # modules, classes and builtins a factory names are stable, not opaque

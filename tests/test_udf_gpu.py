@@ -669,17 +669,21 @@ def test_mask_cache_reuse_and_eviction(ctx):
     data = rng.integers(0, 100, (2, 4, 32, 32)).astype(np.uint16)
     ds = ctx.load('memory', data=data, num_partitions=2, sig_dims=2)
     um.clear_mask_cache()
-    calls = {'n': 0}
+    global _FACTORY_CALLS
+    _FACTORY_CALLS = 0
     m = rng.random((2, 32, 32)).astype(np.float32)
 
     def factory():
-        calls['n'] += 1
+        # (a module-global int: not something a factory's output can be traced to -- a counter kept in a captured
+        #  dict or list would count as a parameter that changes with every evaluation, common/fingerprint.py)
+        global _FACTORY_CALLS
+        _FACTORY_CALLS += 1
         return m
     udf = um.ApplyMasksUDF(mask_factories=factory)
     a = ctx.run_udf(dataset=ds, udf=udf)['intensity'].data
-    n_first = calls['n']
+    n_first = _FACTORY_CALLS
     b = ctx.run_udf(dataset=ds, udf=udf)['intensity'].data
-    assert calls['n'] == n_first            # HBM image reused across tasks and runs
+    assert _FACTORY_CALLS == n_first        # HBM image reused across tasks and runs
     assert np.array_equal(a, b)
     for i in range(6):                      # evict
         mi = rng.random((1, 32, 32)).astype(np.float32)
@@ -1930,28 +1934,38 @@ def test_cached_stacks_follow_bound_methods_and_captured_objects(ctx):
         for _ in range(3):
             got = ctx.run_udf(dataset=ds, udf=udf2)['intensity'].data
             assert _close(got, opath.apply_masks(data, h2.mask, num_partitions=2), F32_TOL)
-    # what a fingerprint cannot see: a factory that draws from a generator.  cache=False re-evaluates every run
+    # a counter the factory keeps in a captured dict changes with every evaluation: such a factory is evaluated
+    # afresh every run without being told to (the reference does that for every factory)
     state = {'n': 0}
     base = rng.random((2, 64, 64)).astype(np.float32)
 
     def counting():
         state['n'] += 1
         return base * np.float32(state['n'])
-    n_before = state['n']
-    udf3 = ApplyMasksUDF(mask_factories=counting, use_sparse=False, mask_count=2, cache=False)
+    udf3 = ApplyMasksUDF(mask_factories=counting, use_sparse=False, mask_count=2)
     r1 = ctx.run_udf(dataset=ds, udf=udf3)['intensity'].data
+    n1 = state['n']
     r2 = ctx.run_udf(dataset=ds, udf=udf3)['intensity'].data
-    assert state['n'] > n_before + 1 and not np.array_equal(r1, r2)          # evaluated again for the second run
-    # ... and the global switch: a scalar inside a captured dict is not part of a fingerprint (a counter a factory keeps
-    # there is not a mask parameter) -- it stands in for a file the factory reads
-    files = {'scale': np.float32(1)}
-    udf4 = ApplyMasksUDF(mask_factories=lambda: base * files['scale'], use_sparse=False, mask_count=2)
-    a = ctx.run_udf(dataset=ds, udf=udf4)['intensity'].data
-    assert _close(a, opath.apply_masks(data, base, num_partitions=2), F32_TOL)
-    files['scale'] = np.float32(2)
-    ctx.invalidate_caches()
-    b = ctx.run_udf(dataset=ds, udf=udf4)['intensity'].data
-    assert _close(b, opath.apply_masks(data, base * 2, num_partitions=2), F32_TOL)
+    assert state['n'] > n1 and not np.array_equal(r1, r2)
+    # what no fingerprint can see: a FILE the factory reads.  cache=False evaluates every run, like the reference;
+    # Context.invalidate_caches() drops what a cached udf object holds
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'masks.npy')
+        np.save(path, base)
+        from_file = (lambda: np.load(path))
+        cached = ApplyMasksUDF(mask_factories=from_file, use_sparse=False, mask_count=2)
+        fresh = ApplyMasksUDF(mask_factories=from_file, use_sparse=False, mask_count=2, cache=False)
+        for u in (cached, fresh):
+            assert _close(ctx.run_udf(dataset=ds, udf=u)['intensity'].data,
+                          opath.apply_masks(data, base, num_partitions=2), F32_TOL)
+        np.save(path, base * 2)
+        want = opath.apply_masks(data, base * 2, num_partitions=2)
+        assert _close(ctx.run_udf(dataset=ds, udf=fresh)['intensity'].data, want, F32_TOL)
+        stale = ctx.run_udf(dataset=ds, udf=cached)['intensity'].data          # (documented: the file is invisible)
+        assert not _close(stale, want, F32_TOL)
+        ctx.invalidate_caches()
+        assert _close(ctx.run_udf(dataset=ds, udf=cached)['intensity'].data, want, F32_TOL)
 
 
 def test_two_contexts_interleave_cached_plans(ctx):
