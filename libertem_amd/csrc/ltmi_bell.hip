@@ -471,7 +471,7 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
 // every merge of the four accumulator-set arms, and a ring behind asm loads must not be moved by the compiler
 // while a load is in flight.  What this buys and what still bounds the kernel: profiles/r03_sparse.txt, DESIGN 4.3.
 #ifndef BE_DMA_AUX
-#define BE_DMA_AUX 0                // cache-policy bits of the frame copies of k_bell_flat (2 = nt)
+#define BE_DMA_AUX 2                // cache-policy bits of the frame copies of k_bell_flat: nt (0.677 -> 0.655 ms on C4, copies alone 0.46 -> 0.41)
 #endif
 #ifndef BE_PHASE_SLEEP
 #define BE_PHASE_SLEEP 8            // s_sleep units (64 cycles) per phase step, 16 steps
@@ -781,7 +781,8 @@ k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                 if (sl == 0u) { BE_ARM(0) } else if (sl == 1u) { BE_ARM(1) }
                 else if (sl == 2u) { BE_ARM(2) } else { BE_ARM(3) }
             }
-            if (ablate != 5) ring_load(U, (int64_t)(i + u + BE_FD));
+            if (ablate == 6) ring_load(U, (int64_t)((i + u + BE_FD) & 15));   // (records from 16 hot KiB: timing only)
+            else if (ablate != 5) ring_load(U, (int64_t)(i + u + BE_FD));
             since = since < 63 ? since + 1 : since;
             win <<= 1;
             ++r_cur;
