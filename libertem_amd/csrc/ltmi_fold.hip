@@ -202,74 +202,96 @@ k_dense_fold(const float *__restrict__ tile, int64_t ld, int64_t n_frames, int s
         const int b_hi = (kg ^ ((4 - (m >> 2)) & 3)) * 4;
         auto b_unit = [&](int blk, int h) { return (b_hi + ((blk * 2 + h) ^ (m & 3))) << 2; };
 
-        // one tile (16 frames) of one stage: 2 blocks of 32 folded pixels x NG groups
-        auto compute = [&](auto TL, auto Q, auto BS) {
-            constexpr int tl = decltype(TL)::value, q = decltype(Q)::value, bslot = decltype(BS)::value;
+        // Fragments of one 32-pixel block of a half-stage: the lane's 8 pixels of parts A and C, its 8 weights of
+        // every group.
+        struct FragAC { f32x4 a[2], c[2]; };
+        struct FragB { f32x4 b[NG][2]; };
+        auto load_ac = [&](FragAC &fr, auto Q, int blk) {
+            constexpr int q = decltype(Q)::value;
             const unsigned char *as = a_base + q * FD_HALF + a_lane;
             const unsigned char *cs = as + FD_TPART;
+            const int u = blk * 4 + kg;                      // 8-pixel unit of this lane inside the part
+            fr.a[0] = *(const f32x4 *)(as + (((2 * u) ^ m) << 4));
+            fr.a[1] = *(const f32x4 *)(as + (((2 * u + 1) ^ m) << 4));
+            fr.c[0] = *(const f32x4 *)(cs + (((2 * u) ^ m) << 4));
+            fr.c[1] = *(const f32x4 *)(cs + (((2 * u + 1) ^ m) << 4));
+        };
+        auto load_b = [&](FragB &fr, auto BS, int blk) {
+            constexpr int bslot = decltype(BS)::value;
             const float *bs = (const float *)(b_base + bslot * BSLOT) + b_lane;
-            f32x4 ra[2][2], rc[2][2], rb[2][NG][2];
-            auto load_block = [&](int blk, int buf) {
-                const int u = blk * 4 + kg;                  // 8-pixel unit of this lane inside the part
-                ra[buf][0] = *(const f32x4 *)(as + (((2 * u) ^ m) << 4));
-                ra[buf][1] = *(const f32x4 *)(as + (((2 * u + 1) ^ m) << 4));
-                rc[buf][0] = *(const f32x4 *)(cs + (((2 * u) ^ m) << 4));
-                rc[buf][1] = *(const f32x4 *)(cs + (((2 * u + 1) ^ m) << 4));
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    rb[buf][g][0] = *(const f32x4 *)(bs + g * (GROUP * FD_KB) + b_unit(blk, 0));
-                    rb[buf][g][1] = *(const f32x4 *)(bs + g * (GROUP * FD_KB) + b_unit(blk, 1));
-                }
-            };
-            load_block(0, 0);
+            for (int g = 0; g < NG; ++g) {
+                fr.b[g][0] = *(const f32x4 *)(bs + g * (GROUP * FD_KB) + b_unit(blk, 0));
+                fr.b[g][1] = *(const f32x4 *)(bs + g * (GROUP * FD_KB) + b_unit(blk, 1));
+            }
+        };
+        auto mfma_block = [&](const FragAC &fr, const FragB &fb, auto TL) {
+            constexpr int tl = decltype(TL)::value;
+            float e[8], o[8];
 #pragma unroll
-            for (int blk = 0; blk < FD_KB / 32; ++blk) {
-                const int cur = blk & 1;
-                if (blk + 1 < FD_KB / 32) load_block(blk + 1, cur ^ 1);
-                __builtin_amdgcn_sched_barrier(0);           // keep the prefetch reads above the MFMAs
-                float e[8], o[8];
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 ev = fr.a[h] + fr.c[h];
+                const f32x4 ov = fr.a[h] - fr.c[h];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const f32x4 ev = ra[cur][h] + rc[cur][h];
-                    const f32x4 ov = ra[cur][h] - rc[cur][h];
+                for (int i = 0; i < 4; ++i) { e[h * 4 + i] = ev[i]; o[h * 4 + i] = ov[i]; }
+            }
+            if (ABL == 1) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { e[h * 4 + i] = ev[i]; o[h * 4 + i] = ov[i]; }
-                }
-                if (ABL == 1) {
+                for (int j = 0; j < 8; ++j)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
+                    for (int g = 0; g < NG; ++g)
+                        acc[tl][g][j & 3] += (g < NGE ? e[j] : o[j]) + fb.b[g][j >> 2][j & 3];
+            } else {
 #pragma unroll
-                        for (int g = 0; g < NG; ++g)
-                            acc[tl][g][j & 3] += (g < NGE ? e[j] : o[j]) + rb[cur][g][j >> 2][j & 3];
-                } else {
+                for (int j = 0; j < 8; ++j)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-#pragma unroll
-                        for (int g = 0; g < NG; ++g)
-                            acc[tl][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                g < NGE ? e[j] : o[j], rb[cur][g][j >> 2][j & 3], acc[tl][g], 0, 0, 0);
-                }
+                    for (int g = 0; g < NG; ++g)
+                        acc[tl][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                            g < NGE ? e[j] : o[j], fb.b[g][j >> 2][j & 3], acc[tl][g], 0, 0, 0);
             }
         };
 
-        // Step h (half-stage h = 2 (s - s_begin) + tl, ring slot h % 4): copies are issued in the order
-        //   step h:  [tl = 0: B(s + 1)]  F(h + 3)
-        // so at the start of step h the copies younger than F(h) and -- tl = 0 -- than B(s) (issued at step h - 2) are
-        //   tl = 0:  F(h + 1), F(h + 2)              -> vmcnt(2 NF)
-        //   tl = 1:  F(h + 1), B(s + 1), F(h + 2)    -> vmcnt(2 NF + NBI)
+        // The loop is software pipelined over half-stages h = 2 (s - s_begin) + tl (ring slot h % 4, mask slot
+        // s & 1): the fragments of block 0 of h + 1 are fetched BEFORE the matrix instructions of block 1 of h
+        // are issued, so the pipe does not wait for a half-stage's waits, barrier, copy issue and first LDS
+        // round trip (the unpipelined loop: 6.5 ms per 8192 frames of C5, 4.95 ms without the frame copies).
+        //   step h:   read block 1 of h  |  MFMA block 0 of h  |  M(h)  |  read block 0 of h + 1  |  MFMA block 1 of h
+        //   M(h):     block 1 of h is in registers -> slot h % 4 is free: issue F(h + 4);
+        //             wait for F(h + 1) [tl = 1: and for B(s + 1); then barrier; issue B(s + 2)]
+        // Copies are issued in the order  M(h), tl = 0: F(h + 4)   M(h), tl = 1: F(h + 4), B(s + 2), so the copies
+        // younger than the ones M(h) waits for are
+        //   tl = 0 (F(h + 1)):          B, F(h + 2), F(h + 3), B, F(h + 4)   -> vmcnt(3 NF + 2 NBI)
+        //   tl = 1 (F(h + 1), B(s + 1)): F(h + 3), F(h + 4)                   -> vmcnt(2 NF)
+        static_assert(3 * NF + 2 * NBI < 64, "vmcnt is a 6-bit counter");
         int since_flush = 0;
+        // fragments of block 0 / block 1 of the current half-stage; the weights of a stage's two blocks are read
+        // ONCE for both of its tiles (block 1 in the tile-0 step, block 0 ahead of it): a third fewer LDS reads
+        // per matrix instruction -- the kernel runs at the board's power cap (1380 W), energy is time
+        FragAC f0, f1;
+        FragB w0, w1;
         auto step = [&](auto TL, auto Q, auto BS, int s) {
             constexpr int tl = decltype(TL)::value, q = decltype(Q)::value, bslot = decltype(BS)::value;
+            load_ac(f1, Q, 1);
+            if (tl == 0) load_b(w1, BS, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_block(f0, w0, TL);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // block 1 is in registers
+            issue_half(TL, Q);                                                  // F(h + 4) -> slot h % 4
             if (tl == 0) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NF) : "memory");
-                if (ABL < 3) __builtin_amdgcn_s_barrier();   // everybody's quarter of B(s) is there, B(s - 1) is free
-                issue_b(s + 1, bslot ^ 1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NF + 2 * NBI) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                load_ac(f0, std::integral_constant<int, (q + 1) & 3>{}, 0);
             } else {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NF + NBI) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NF) : "memory");
+                if (ABL < 3) __builtin_amdgcn_s_barrier();   // everybody's quarter of B(s + 1) is there, B(s) is free
+                issue_b(s + 2, bslot);
+                __builtin_amdgcn_sched_barrier(0);
+                load_ac(f0, std::integral_constant<int, (q + 1) & 3>{}, 0);
+                load_b(w0, std::integral_constant<int, bslot ^ 1>{}, 0);
             }
-            // the slot of half-stage h - 1 (this wave's rows only: it is done with them)
-            issue_half(std::integral_constant<int, (tl + 1) & 1>{}, std::integral_constant<int, (q + 3) & 3>{});
-            compute(TL, Q, BS);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_block(f1, w1, TL);
             if (tl == 1 && ++since_flush == 16) {            // second accumulation level every 1024 folded pixels
                 since_flush = 0;
 #pragma unroll
@@ -285,11 +307,17 @@ k_dense_fold(const float *__restrict__ tile, int64_t ld, int64_t n_frames, int s
         using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>;
         using I3 = std::integral_constant<int, 3>;
-        // prologue: B(s_begin), F(0), F(1), F(2)   (step 0 then issues B(s_begin + 1) and F(3))
-        issue_b(s_begin, 0);
+        // prologue: F(0), F(1), B(s_begin), F(2), F(3), B(s_begin + 1); block 0 of half-stage 0
         issue_half(I0{}, I0{});
         issue_half(I1{}, I1{});
+        issue_b(s_begin, 0);
         issue_half(I0{}, I2{});
+        issue_half(I1{}, I3{});
+        issue_b(s_begin + 1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NF + NBI) : "memory");
+        if (ABL < 3) __builtin_amdgcn_s_barrier();
+        load_ac(f0, I0{}, 0);
+        load_b(w0, I0{}, 0);
         int s = s_begin;
         for (; s + 2 <= s_end; s += 2) {
             step(I0{}, I0{}, I0{}, s);
