@@ -249,6 +249,15 @@ def test_c3_workload_com_512(ctx, golden_dir, resident):
         assert inten.dtype == ref_i.dtype and inten.shape == ref_i.shape
         for c in range(3):                  # the three raw sums, each relative to its own maximum
             assert _close(inten[..., c], ref_i[..., c], F32_TOL), (i, c)
+        # ELEMENT-WISE where the data allow it (round-4 review): non-negative frames give a non-negative total and,
+        # with the centre added back, non-negative first moments sum_p y x_p, sum_p x x_p -- no cancellation, so
+        # every scan position has to agree to 1e-5 relative with the reference's numbers, no absolute term
+        assert np.allclose(inten[..., 0], ref_i[..., 0], rtol=F32_TOL, atol=0), i
+        for c, centre in ((1, ap['cy']), (2, ap['cx'])):
+            got_m = inten[..., c].astype(np.float64) + centre * inten[..., 0].astype(np.float64)
+            ref_m = ref_i[..., c].astype(np.float64) + centre * ref_i[..., 0].astype(np.float64)
+            assert (ref_m > 0).all()
+            assert np.allclose(got_m, ref_m, rtol=F32_TOL, atol=0), (i, c)
         ares = ctx.run(analysis)
         ora = opath.com_analysis(data, num_partitions=case['num_partitions'], **ap)
         for k in ('x', 'y', 'magnitude', 'divergence', 'curl'):
