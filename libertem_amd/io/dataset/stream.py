@@ -99,12 +99,14 @@ class StreamDataSet(MemoryDataSet):
         if pinned:
             try:
                 import torch
-                if torch.cuda.is_available():
+                from libertem_amd.io.dataset.memory import pin_limit_bytes
+                nbytes = int(np.prod(shape)) * dt.itemsize
+                # (page-locked memory is committed when it is allocated: no pass over it to zero it -- a frame is
+                #  read only after it has arrived; scans beyond the pin limit use pageable memory + bounce buffers)
+                if torch.cuda.is_available() and nbytes <= pin_limit_bytes():
                     from libertem_amd.common.hiparray import torch_dtype_for
                     t = torch.empty(shape, dtype=torch_dtype_for(dt), pin_memory=True)
-                    arr = t.numpy().view(dt)
-                    arr[...] = 0
-                    return arr, True
+                    return t.numpy().view(dt), True
             except Exception:                              # pragma: no cover  (no torch / no GPU)
                 pass
         return np.zeros(shape, dtype=dt), False

@@ -2056,3 +2056,22 @@ def test_row_mirror_fold_leaves_other_stacks_alone(hip):
     res, kern = _fold_apply(hip, d2, odd_w, (64, 96), np.complex64)
     assert 'k_dense_fold' not in kern, kern
     assert np.allclose(res, _ref64(d2, odd_w), rtol=1e-5, atol=1e-3)
+
+
+def test_row_mirror_fold_wide_stack_in_column_blocks(hip):
+    """More than 64 real columns: the stack is kept as blocks of <= 64 columns (ltmi_apply_masks walks them) and every
+    block is folded on its own -- 3 bins x 25 orders = 75 complex masks = 64 + 64 + 22 real columns."""
+    sig = (64, 128)
+    masks = _radial_stack(sig, 3, 24)
+    assert masks.shape[0] == 75
+    rng = np.random.default_rng(_seed('fold-wide'))
+    data = (rng.random((150, sig[0] * sig[1])) - 0.1).astype(np.float32)
+    res, kern = _fold_apply(hip, data, masks, sig, np.complex64)
+    assert kern.startswith('3 column blocks') and 'k_dense_fold<f,even=1,odd=1' in kern, kern
+    res_u, kern_u = _fold_apply(hip, data, masks, sig, np.complex64, tuning=dict(mt=0, waves=38, ksplit=0))
+    assert 'k_dense_fold' not in kern_u, kern_u
+    ref = _ref64(data, masks)
+    scale = np.abs(data.astype(np.float64)) @ np.abs(masks).astype(np.float64).T
+    for part in (np.real, np.imag):
+        assert np.all(np.abs(part(res) - part(ref)) <= 1e-5 * scale + 1e-30)
+        assert np.all(np.abs(part(res_u) - part(ref)) <= 1e-5 * scale + 1e-30)

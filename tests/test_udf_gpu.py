@@ -2050,3 +2050,29 @@ def test_sync_run_while_async_run_is_pending(ctx):
             assert _close(got1, ref1, F32_TOL) and _close(got2, ref2, F32_TOL)
     asyncio.run(main())
     assert ctx.executor.replay.expected is None and ctx.executor.replay.recording is None
+
+
+def test_radial_fourier_folded_through_run_udf_with_roi(ctx):
+    """RadialFourierAnalysis on float32 frames goes through the row-mirror fold (MaskContainer tells the handle the
+    detector shape); with a region of interest the frames are read through a row list.  Against the oracle."""
+    from libertem_amd import hip
+    rng = np.random.default_rng(91)
+    data = rng.random((6, 8, 128, 128)).astype(np.float32)
+    ds = _device_ds(ctx, data, 2)
+    analysis = ctx.create_radial_fourier_analysis(dataset=ds, n_bins=2, max_order=12)
+    hip.KernelTimer.start()
+    res = ctx.run_udf(dataset=ds, udf=analysis.get_udf())['intensity'].data
+    kernels = {k.split('<')[0] for _, _, k in hip.KernelTimer.stop()}
+    assert kernels == {'k_dense_fold'}, kernels
+    p = analysis.parameters
+    stack = np.asarray(analysis.get_mask_factories()())
+    ref = np.tensordot(data.astype(np.float64), stack.astype(np.complex128), axes=([2, 3], [1, 2]))
+    assert res.dtype == np.complex64 and _close(res, ref, F32_TOL)
+    roi = np.zeros((6, 8), bool)
+    roi[::2, 1::3] = True
+    hip.KernelTimer.start()
+    res_r = ctx.run_udf(dataset=ds, udf=analysis.get_udf(), roi=roi)['intensity'].raw_data
+    labels = [k for _, _, k in hip.KernelTimer.stop()]
+    assert labels and all('k_dense_fold' in k for k in labels), labels
+    assert _close(res_r, ref[roi], F32_TOL)
+    assert p['mask_count'] == 26
