@@ -198,11 +198,18 @@ __device__ __forceinline__ void cf_load_mask(CfMask &p, const float *__restrict_
 // transform row pairs (what the LDS leaves beside the K columns of G), all of them transform columns.
 // ABL: timing-only ablations (LTMI_CRYST_ABLATE, uint16 + mask + 16 waves): 1 no global loads, 2 no barriers,
 // 3 no LDS transposes, 4 rows only, 5 columns only -- the results are garbage
-template <typename T, bool MASK, int WAVES, int ABL = 0>
+// CORR (detector corrections inside the row stage, round 5; io/corrections/detector.py:17-101 fused with
+// udf/crystallinity.py:73-79): a pixel becomes (x - dark) * (gain * real mask) with both maps in the pairs' lane order
+// (dmap_p like rmask_p; rmask_p then holds gain * mask, 0 at the excluded pixels), and the excluded pixels of a row pair
+// (pair_ptr / pcode: lane, register, row of the pair, index into the frame's patch values) take their repaired value
+// -- the mean of the corrected good neighbours times the mask, computed per frame by k_cryst_patch_values.
+template <typename T, bool MASK, int WAVES, int ABL = 0, bool CORR = false>
 __global__ void __launch_bounds__(WAVES * 64)
 k_cryst_fused(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
               const float *__restrict__ rmask_p, const unsigned long long *__restrict__ rflags,
-              const float *__restrict__ mask_p, int K, int n_scr, float *__restrict__ out, int accumulate) {
+              const float *__restrict__ mask_p, int K, int n_scr, float *__restrict__ out, int accumulate,
+              const float *__restrict__ dmap_p = nullptr, const int *__restrict__ pair_ptr = nullptr,
+              const int *__restrict__ pcode = nullptr, const float *__restrict__ patch = nullptr, int n_excl = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cf_smem[];
     __shared__ float part[WAVES];
     const int t = threadIdx.x & 63;
@@ -259,15 +266,38 @@ k_cryst_fused(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
             lf += gridDim.x;
         }
     };
-    auto convert = [&](const CfRaw<T> &buf, int yp, v2f (&u)[4]) {
+    auto convert = [&](const CfRaw<T> &buf, int yp, int64_t fr, v2f (&u)[4]) {
         CfMask bm;
-        const bool mk = masked(yp);
+        const bool mk = CORR || masked(yp);
         if (mk) cf_load_mask<ABL>(bm, rmask_p, yp, t);
 #pragma unroll
         for (int j = 0; j < 4; ++j) u[j] = (v2f){(float)buf.ra[j], (float)buf.rb[j]};
+        if constexpr (CORR) {
+            CfMask dm;
+            cf_load_mask<ABL>(dm, dmap_p, yp, t);
+            u[0] -= dm.m01.xy; u[1] -= dm.m01.zw;
+            u[2] -= dm.m23.xy; u[3] -= dm.m23.zw;
+        }
         if (mk) {
             u[0] *= bm.m01.xy; u[1] *= bm.m01.zw;
             u[2] *= bm.m23.xy; u[3] *= bm.m23.zw;
+        }
+        if constexpr (CORR) {
+            if (n_excl > 0 && fr < n_frames) {
+                const int e1 = pair_ptr[yp + 1];
+                for (int e = pair_ptr[yp]; e < e1; ++e) {             // (uniform: usually none)
+                    const int code = pcode[e];
+                    const float v = patch[fr * n_excl + (code >> 16)];
+                    if (t == ((code >> 3) & 63)) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (j == ((code >> 1) & 3)) {
+                                if (code & 1) u[j].y = v;
+                                else u[j].x = v;
+                            }
+                    }
+                }
+            }
         }
     };
 
@@ -354,8 +384,8 @@ k_cryst_fused(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
         const bool a_last = ypb >= CF_N / 2;
         if (a_last) ypb = w;
         const bool have_b = !a_last || f + gridDim.x < n_frames;
-        convert(ba, ypa, ua);
-        if (have_b) convert(bb, ypb, ub);
+        convert(ba, ypa, f, ua);
+        if (have_b) convert(bb, ypb, a_last ? f + gridDim.x : f, ub);
         load_next(ba);
         load_next(bb);
         row_pair(ua, ypa);
@@ -396,6 +426,162 @@ k_cryst_masks(const float *__restrict__ half_mask, int wc, int K, float *__restr
         if (__builtin_amdgcn_ballot_w64(v != 1.f) && (threadIdx.x & 63) == 0)
             atomicOr(&rflags[yp >> 6], 1ull << (yp & 63));
     }
+}
+
+// ---- corrections inside the row stage of k_cryst_fused (256 x 256 frames) --------------------------------------
+constexpr int CF_MAX_EXCL = 4096;
+// gm_p[y'][2 x + i] = gain * real mask, dmap_p = dark, of pixel (2 y' + i, x) (float32; the reference corrects in
+// float64 and rounds once: (x - dark) * gain, then multiplies by the mask in float32 -- udf/crystallinity.py:73-79)
+__global__ void __launch_bounds__(256)
+k_cryst_corr_maps(const double *__restrict__ dark, const double *__restrict__ gain,
+                  const float *__restrict__ real_mask, float *__restrict__ gm_p, float *__restrict__ dmap_p) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= CF_N * CF_N) return;
+    const int yp = i / (2 * CF_N), q = i - yp * (2 * CF_N);
+    const int p = (2 * yp + (q & 1)) * CF_N + (q >> 1);
+    gm_p[i] = (float)(gain ? gain[p] : 1.0) * (real_mask ? real_mask[p] : 1.f);
+    dmap_p[i] = (float)(dark ? dark[p] : 0.0);
+}
+// one workgroup: the excluded pixels sorted by row pair (pair_ptr[129], pcode = lane << 3 | register << 1 | row of
+// the pair, index into the excluded list << 16) and their map entries cleared
+__global__ void __launch_bounds__(256)
+k_cryst_patch_index(const int32_t *__restrict__ excl, int n_excl, int *__restrict__ pair_ptr,
+                    int *__restrict__ pcode, float *__restrict__ gm_p) {
+    __shared__ int cnt[CF_N / 2 + 1], cur[CF_N / 2];
+    for (int i = threadIdx.x; i <= CF_N / 2; i += 256) cnt[i] = 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_excl; e += 256) atomicAdd(&cnt[excl[e] / (2 * CF_N)], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < CF_N / 2; ++i) {
+            const int c = cnt[i];
+            pair_ptr[i] = run;
+            cur[i] = run;
+            run += c;
+        }
+        pair_ptr[CF_N / 2] = run;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_excl; e += 256) {
+        const int p = excl[e], y = p / CF_N, x = p - y * CF_N;
+        const int slot = atomicAdd(&cur[y >> 1], 1);
+        pcode[slot] = ((x >> 2) << 3) | ((x & 3) << 1) | (y & 1) | (e << 16);
+        gm_p[(y >> 1) * (2 * CF_N) + 2 * x + (y & 1)] = 0.f;
+    }
+}
+// patch[f, e] = mean over the good neighbours of excluded pixel e of the CORRECTED pixel (as the float32 value
+// the corrected tile would hold), times the real-space mask at e (io/corrections/detector.py:60-101)
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_cryst_patch_values(const T *__restrict__ tile, int64_t ld, int64_t n_frames, const double *__restrict__ dark,
+                     const double *__restrict__ gain, const float *__restrict__ real_mask,
+                     const int32_t *__restrict__ excl, const int32_t *__restrict__ env,
+                     const int32_t *__restrict__ cnt, int n_excl, int max_env, float *__restrict__ patch) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_frames * n_excl) return;
+    const int64_t f = i / n_excl;
+    const int e = (int)(i % n_excl);
+    const int c = cnt[e];
+    float v = 0.f;
+    if (c > 0) {
+        const T *src = tile + f * ld;
+        double acc = 0.0;
+        for (int j = 0; j < c; ++j) {
+            const int r = env[(int64_t)e * max_env + j];
+            acc += (double)(float)(((double)src[r] - (dark ? dark[r] : 0.0)) * (gain ? gain[r] : 1.0));
+        }
+        v = (float)(acc / (double)c);
+        if (real_mask) v *= real_mask[excl[e]];
+    } else {
+        // no good neighbour: the pixel keeps its corrected value (detector.py: nothing to repair with)
+        const int p = excl[e];
+        v = (float)(((double)tile[f * ld + p] - (dark ? dark[p] : 0.0)) * (gain ? gain[p] : 1.0));
+        if (real_mask) v *= real_mask[p];
+    }
+    patch[i] = v;
+}
+
+int64_t cryst_corr_workspace_bytes(int64_t n_frames, int n_excl) {
+    return (int64_t)CF_N * CF_N * 4 + (CF_N / 2 + 1 + 3) / 4 * 16 + (int64_t)std::max(n_excl, 1) * 4 +
+           (int64_t)n_frames * std::max(n_excl, 1) * 4 + 64;
+}
+bool cryst_corr_takes(int h, int w, int n_cols, int tile_dtype, int n_excl) {
+    return h == CF_N && w == CF_N && n_cols >= 1 && n_cols <= CF_KMAX && n_excl <= CF_MAX_EXCL &&
+           dtype_size(tile_dtype) <= 4 && tile_dtype != LTMI_F64;
+}
+
+template <typename T>
+static int launch_fused_corr(const void *tile, int64_t ld, int64_t n_frames, const float *gm_p, const float *dmap_p,
+                             const unsigned long long *rflags, const float *mask_t, int K, const int *pair_ptr,
+                             const int *pcode, const float *patch, int n_excl, float *out, int accumulate, int n_cu,
+                             hipStream_t stream) {
+    constexpr int WAVES = 16;
+    auto kern = k_cryst_fused<T, true, WAVES, 0, true>;
+    const int n_scr = std::min(WAVES, (CF_LDS_MAX - K * CF_COL * 8) / (CF_SCR * 8));
+    const int lds = K * CF_COL * 8 + n_scr * CF_SCR * 8;
+    int device = 0;
+    LTMI_HIP(hipGetDevice(&device));
+    static bool attr_set[16] = {false};
+    if (!attr_set[device & 15]) {
+        LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CF_LDS_MAX));
+        attr_set[device & 15] = true;
+    }
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_frames, n_cu));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), (size_t)lds, stream, (const T *)tile, ld, n_frames, gm_p,
+                       rflags, mask_t, K, n_scr, out, accumulate, dmap_p, pair_ptr, pcode, patch, n_excl);
+    LTMI_HIP(hipGetLastError());
+    return LTMI_OK;
+}
+
+// RAW 256 x 256 frames with detector corrections in ONE pass over the pixels.  `ws`: cryst_corr_workspace_bytes.
+int cryst_fused_corrected(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, const double *dark,
+                          const double *gain, const int32_t *excl, const int32_t *env, const int32_t *cnt, int n_excl,
+                          int max_env, const float *real_mask, const float *half_mask, int n_cols, float *mask_t,
+                          void *ws, float *out, int accumulate, int n_cu, hipStream_t stream, bool *handled) {
+    *handled = false;
+    if (!mask_t || !ws || !cryst_corr_takes(CF_N, CF_N, n_cols, tile_dtype, n_excl)) return LTMI_OK;
+    const size_t esz = (size_t)dtype_size(tile_dtype);
+    if ((uintptr_t)tile % (4 * esz) != 0 || ld % 4 != 0) return LTMI_OK;
+    float *gm_p = mask_t + (int64_t)CF_KMAX * CF_N;                   // (the place of rmask_p)
+    unsigned long long *rflags = (unsigned long long *)(gm_p + CF_N * CF_N);
+    float *dmap_p = (float *)ws;
+    int *pair_ptr = (int *)(dmap_p + CF_N * CF_N);
+    int *pcode = pair_ptr + (CF_N / 2 + 1 + 3) / 4 * 4;
+    float *patch = (float *)(pcode + std::max(n_excl, 1));
+    hipLaunchKernelGGL(k_cryst_masks, dim3((unsigned)(CF_N * CF_N / 256)), dim3(256), 0, stream, half_mask,
+                       CF_N / 2 + 1, n_cols, mask_t, (const float *)nullptr, gm_p, rflags);
+    hipLaunchKernelGGL(k_cryst_corr_maps, dim3((unsigned)(CF_N * CF_N / 256)), dim3(256), 0, stream, dark, gain,
+                       real_mask, gm_p, dmap_p);
+    if (n_excl > 0)
+        hipLaunchKernelGGL(k_cryst_patch_index, dim3(1), dim3(256), 0, stream, excl, n_excl, pair_ptr, pcode, gm_p);
+    LTMI_HIP(hipGetLastError());
+    int rc = LTMI_E_DTYPE;
+#define LTMI_CORR_CASE(T_)                                                                                        \
+    {                                                                                                             \
+        if (n_excl > 0) {                                                                                         \
+            const int64_t nt = n_frames * n_excl;                                                                 \
+            hipLaunchKernelGGL((k_cryst_patch_values<T_>), dim3((unsigned)((nt + 255) / 256)), dim3(256), 0,      \
+                               stream, (const T_ *)tile, ld, n_frames, dark, gain, real_mask, excl, env, cnt,     \
+                               n_excl, max_env, patch);                                                           \
+        }                                                                                                         \
+        rc = launch_fused_corr<T_>(tile, ld, n_frames, gm_p, dmap_p, rflags, mask_t, n_cols, pair_ptr, pcode,     \
+                                   patch, n_excl, out, accumulate, n_cu, stream);                                 \
+    }
+    switch (tile_dtype) {
+        case LTMI_BOOL:
+        case LTMI_U8: LTMI_CORR_CASE(uint8_t) break;
+        case LTMI_I8: LTMI_CORR_CASE(int8_t) break;
+        case LTMI_U16: LTMI_CORR_CASE(uint16_t) break;
+        case LTMI_I16: LTMI_CORR_CASE(int16_t) break;
+        case LTMI_U32: LTMI_CORR_CASE(uint32_t) break;
+        case LTMI_I32: LTMI_CORR_CASE(int32_t) break;
+        case LTMI_F32: LTMI_CORR_CASE(float) break;
+        default: return LTMI_OK;
+    }
+#undef LTMI_CORR_CASE
+    if (rc == LTMI_OK) *handled = true;
+    return rc;
 }
 
 int cryst_fused_max_cols() { return CF_KMAX; }
@@ -442,7 +628,8 @@ static int launch_fused_w(const void *tile, int64_t ld, int64_t n_frames, const 
     }
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_frames, n_cu));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), (size_t)lds, stream, (const T *)tile, ld,
-                       n_frames, real_mask, rflags, mask_t, K, n_scr, out, accumulate);
+                       n_frames, real_mask, rflags, mask_t, K, n_scr, out, accumulate, (const float *)nullptr,
+                       (const int *)nullptr, (const int *)nullptr, (const float *)nullptr, 0);
     LTMI_HIP(hipGetLastError());
     return LTMI_OK;
 }

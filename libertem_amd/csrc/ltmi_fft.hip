@@ -22,6 +22,8 @@ struct ltmi_fft_plan {
     hipStream_t bound_stream = nullptr;
     bool stream_bound = false;
     float *mask_t = nullptr;           // workspace of k_cryst_fused: both masks in lane order (ltmi_cryst.hip)
+    void *corr_ws = nullptr;           // ... of the corrections inside its row stage: dark map, patch lists / values
+    size_t corr_ws_bytes = 0;
     int n_cu = 0;
     bool fused_ok = false;             // 256 x 256 frames: k_cryst_fused (ltmi_cryst.hip) unless LTMI_FFT_FUSED=0
     char last_kernel[96] = {0};
@@ -317,6 +319,7 @@ extern "C" int ltmi_fft_plan_destroy(ltmi_fft_plan *p) {
     if (p->have_plan) (void)hipfftDestroy(p->plan);
     if (p->real_buf) (void)hipFree(p->real_buf);
     if (p->spec) (void)hipFree(p->spec);
+    if (p->corr_ws) (void)hipFree(p->corr_ws);
     if (p->mask_t) (void)hipFree(p->mask_t);
     delete p;
     return LTMI_OK;
@@ -409,6 +412,43 @@ static int crystallinity_impl(ltmi_fft_plan *p, const void *tile, int tile_dtype
             else
                 snprintf(p->last_kernel, sizeof(p->last_kernel), "k_cryst_fused%s<%s%s> columns=%d",
                          p->h == 128 ? "128" : "", dtype_name(tile_dtype), real_mask ? ",mask" : "", n_cols);
+            return LTMI_OK;
+        }
+    }
+    if (p->fused_ok && (corr.dark || corr.gain || corr.n_excl > 0) &&
+        cryst_corr_takes(p->h, p->w, n_cols, tile_dtype, corr.n_excl) && !getenv("LTMI_CRYST_CORR_PASS")) {
+        // 256 x 256 frames: dark / gain / dead-pixel patches inside the row stage of the fused kernel -- ONE pass over
+        // the raw pixels (round 5; LTMI_CRYST_CORR_PASS=1 keeps the conversion pass: tests, bench).  Frames in
+        // chunks whose patch values fit 64 MiB.
+        const int64_t chunk = corr.n_excl > 0 ? std::max<int64_t>(1024, ((int64_t)64 << 20) / (4 * corr.n_excl)) : n_frames;
+        const size_t need = (size_t)cryst_corr_workspace_bytes(std::min(chunk, n_frames), corr.n_excl);
+        if (need > p->corr_ws_bytes) {
+            if (p->corr_ws) {
+                LTMI_HIP(hipStreamSynchronize(stream));
+                (void)hipFree(p->corr_ws);
+                p->corr_ws = nullptr;
+                p->corr_ws_bytes = 0;
+            }
+            LTMI_HIP(hipMalloc(&p->corr_ws, need));
+            p->corr_ws_bytes = need;
+        }
+        bool all = true;
+        for (int64_t f0 = 0; f0 < n_frames && all; f0 += chunk) {
+            const int64_t n = std::min(chunk, n_frames - f0);
+            bool handled = false;
+            const int rc = cryst_fused_corrected((const char *)tile + (size_t)f0 * ld_tile * esz, tile_dtype, n, ld_tile,
+                                                 corr.dark, corr.gain, corr.excl, corr.env, corr.cnt, corr.n_excl,
+                                                 corr.max_env, real_mask, half_mask, n_cols, p->mask_t, p->corr_ws,
+                                                 out + f0, accumulate, p->n_cu, stream, &handled);
+            if (rc != LTMI_OK) return rc;
+            if (!handled) {
+                if (f0 != 0) LTMI_FAIL(LTMI_E_INVALID, "ltmi_crystallinity: the fused kernel refused a later chunk");
+                all = false;
+            }
+        }
+        if (all) {
+            snprintf(p->last_kernel, sizeof(p->last_kernel), "k_cryst_fused<%s,corrected%s> columns=%d patches=%d",
+                     dtype_name(tile_dtype), real_mask ? ",mask" : "", n_cols, corr.n_excl);
             return LTMI_OK;
         }
     }

@@ -1786,9 +1786,52 @@ def test_crystallinity_corrected_and_float64_frames_take_the_fused_kernel(hip, s
         plan.crystallinity_corrected(t.data_ptr(), data.dtype, n, sig * sig, tables, rm.data_ptr(), hm.data_ptr(),
                                      mask_box(half), out.data_ptr(), False)
         torch.cuda.synchronize()
-        assert plan.last_kernel().startswith('k_fft_prepare<uint16> + k_cryst_'), plan.last_kernel()
+        if sig == 256:
+            # round 5: the corrections run inside the row stage of the fused kernel -- one pass over the raw pixels
+            assert plan.last_kernel().startswith('k_cryst_fused<uint16,corrected'), plan.last_kernel()
+        else:
+            assert plan.last_kernel().startswith('k_fft_prepare<uint16> + k_cryst_'), plan.last_kernel()
         assert np.allclose(out.cpu().numpy(), ref, rtol=1e-5), sorted(kw)
+        if sig == 256:
+            # ... and agrees with the conversion pass + the same kernel on corrected float32 frames
+            os.environ['LTMI_CRYST_CORR_PASS'] = '1'
+            try:
+                out2 = torch.full((n,), 7.0, dtype=torch.float32, device='cuda')
+                plan.crystallinity_corrected(t.data_ptr(), data.dtype, n, sig * sig, tables, rm.data_ptr(),
+                                             hm.data_ptr(), mask_box(half), out2.data_ptr(), False)
+                torch.cuda.synchronize()
+                assert plan.last_kernel().startswith('k_fft_prepare<uint16> + k_cryst_fused'), plan.last_kernel()
+                assert np.allclose(out2.cpu().numpy(), out.cpu().numpy(), rtol=2e-6)
+            finally:
+                del os.environ['LTMI_CRYST_CORR_PASS']
+            # accumulate, ragged frame count beyond one workgroup round, other pixel types
+            out3 = out.clone()
+            plan.crystallinity_corrected(t.data_ptr(), data.dtype, n, sig * sig, tables, rm.data_ptr(), hm.data_ptr(),
+                                         mask_box(half), out3.data_ptr(), True)
+            torch.cuda.synchronize()
+            assert np.allclose(out3.cpu().numpy(), 2 * ref, rtol=1e-5)
         plan.close()
+    if sig == 256:
+        # many frames (more than one round of workgroups), float32 / uint8 pixels, no real-space mask, many dead pixels
+        n2 = 700
+        for dt, hi in ((np.float32, None), (np.uint8, 200)):
+            d2 = (rng.random((n2, sig, sig)) * 100).astype(dt) if hi is None else \
+                rng.integers(0, hi, (n2, sig, sig)).astype(dt)
+            bad2 = rng.random((sig, sig)) < 0.01                       # ~650 dead pixels, clusters included
+            coords2 = [tuple(c) for c in np.argwhere(bad2)]
+            corrected = oc.correct(d2, (sig, sig), dark=dark, gain=gain, coords=coords2)
+            ref2, _, half2 = _cryst_reference(corrected.reshape(n2, sig, sig), sig // 16, sig // 4, None)
+            tables = CorrectionSet(dark=dark, gain=gain, excluded_pixels=bad2).device_tables(0, (sig, sig))
+            plan = hip.FFTPlan(0, sig, sig, 8)
+            t = _dev(d2.reshape(n2, -1))
+            hm = torch.from_numpy(np.ascontiguousarray(half2.astype(np.float32))).cuda()
+            out = torch.full((n2,), 7.0, dtype=torch.float32, device='cuda')
+            plan.crystallinity_corrected(t.data_ptr(), d2.dtype, n2, sig * sig, tables, None, hm.data_ptr(),
+                                         mask_box(half2), out.data_ptr(), False)
+            torch.cuda.synchronize()
+            assert plan.last_kernel().startswith('k_cryst_fused<') and 'corrected' in plan.last_kernel()
+            assert np.allclose(out.cpu().numpy(), ref2, rtol=1e-5), dt
+            plan.close()
     frames = rng.normal(size=(n, sig, sig)) * 50
     ref, real_mask, half = _cryst_reference(frames, sig // 16, sig // 4, real)
     got, label = _cryst_run(hip, frames, real_mask, half, batch=8)
