@@ -149,12 +149,13 @@ float *dense_partial_sums(const ltmi_masks *m);
 int dense_reduce_partials(ltmi_masks *m, int ksplit, int64_t n_frames, float *out, int64_t ld_out, int accumulate,
                           hipStream_t stream);
 // ... on RAW frames with the detector corrections applied inside the row stage (256 x 256 frames)
-int64_t cryst_corr_workspace_bytes(int64_t n_frames, int n_excl);
+int64_t cryst_corr_workspace_bytes(int h, int w, int64_t n_frames, int n_excl);
 bool cryst_corr_takes(int h, int w, int n_cols, int tile_dtype, int n_excl);
-int cryst_fused_corrected(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, const double *dark,
-                          const double *gain, const int32_t *excl, const int32_t *env, const int32_t *cnt, int n_excl,
-                          int max_env, const float *real_mask, const float *half_mask, int n_cols, float *mask_t,
-                          void *ws, float *out, int accumulate, int n_cu, hipStream_t stream, bool *handled);
+int cryst_fused_corrected(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, int sig_h, int sig_w,
+                          const double *dark, const double *gain, const int32_t *excl, const int32_t *env,
+                          const int32_t *cnt, int n_excl, int max_env, const float *real_mask, const float *half_mask,
+                          int n_cols, float *mask_t, void *gbuf, int64_t gbuf_frames, void *ws, float *out,
+                          int accumulate, int n_cu, hipStream_t stream, bool *handled);
 int bell_apply(ltmi_masks *m, void *image, int cplx, const void *tile, int tile_dtype,
                int64_t n_frames, int64_t ld_tile, void *out, int64_t ld_out, int accumulate,
                hipStream_t stream, bool *handled);

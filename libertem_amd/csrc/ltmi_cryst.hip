@@ -163,6 +163,36 @@ __device__ __forceinline__ void cf_core(v2f *buf, const CfLane &c, v2f (&u)[4]) 
     cf_bfly(u);
 }
 
+// Detector corrections inside the row stages (round 5): what the kernels get when a call carries them.
+struct CfCorr {
+    const float *d_px;                  // dark, pixel order (float32)
+    float *dmap_p;                      // ... in the lane order of the kernel's real-space mask (packed per call)
+    unsigned long long *dummy_flags;    // (the pack kernels write flags)
+    const int *pair_ptr, *pcode;        // excluded pixels by item (row pair / group of four rows) of the row stage
+    const float *patch;                 // [frame][excluded pixel]: the repaired values
+    int n_excl;
+};
+// pcode: row of the pair (bit 0) | register (2 bits) << 1 | lane << 3 | sub-transform q (2 bits) << 9 | index << 16
+template <int NQ>
+__device__ __forceinline__ void cf_apply_patches(v2f (&u)[NQ][4], int t, int item, int64_t fr, const int *pair_ptr,
+                                                 const int *pcode, const float *patch, int n_excl) {
+    const int e1 = pair_ptr[item + 1];
+    for (int e = pair_ptr[item]; e < e1; ++e) {                 // (uniform: usually none)
+        const int code = pcode[e];
+        const float v = patch[fr * n_excl + (code >> 16)];
+        if (t == ((code >> 3) & 63)) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (q == ((code >> 9) & 3) && j == ((code >> 1) & 3)) {
+                        if (code & 1) u[q][j].y = v;
+                        else u[q][j].x = v;
+                    }
+        }
+    }
+}
+
 template <typename T>
 struct CfRaw {                                  // the pixels one lane holds of a row pair: 4 of row a, 4 of row b
     typedef T __attribute__((ext_vector_type(4))) vec_t;
@@ -284,19 +314,8 @@ k_cryst_fused(const T *__restrict__ tile, int64_t ld, int64_t n_frames,
         }
         if constexpr (CORR) {
             if (n_excl > 0 && fr < n_frames) {
-                const int e1 = pair_ptr[yp + 1];
-                for (int e = pair_ptr[yp]; e < e1; ++e) {             // (uniform: usually none)
-                    const int code = pcode[e];
-                    const float v = patch[fr * n_excl + (code >> 16)];
-                    if (t == ((code >> 3) & 63)) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (j == ((code >> 1) & 3)) {
-                                if (code & 1) u[j].y = v;
-                                else u[j].x = v;
-                            }
-                    }
-                }
+                v2f (&uu)[1][4] = reinterpret_cast<v2f (&)[1][4]>(u);
+                cf_apply_patches<1>(uu, t, yp, fr, pair_ptr, pcode, patch, n_excl);
             }
         }
     };
@@ -428,46 +447,57 @@ k_cryst_masks(const float *__restrict__ half_mask, int wc, int K, float *__restr
     }
 }
 
-// ---- corrections inside the row stage of k_cryst_fused (256 x 256 frames) --------------------------------------
+// ---- corrections inside the row stages (round 5) -----------------------------------------------------------------
 constexpr int CF_MAX_EXCL = 4096;
-// gm_p[y'][2 x + i] = gain * real mask, dmap_p = dark, of pixel (2 y' + i, x) (float32; the reference corrects in
-// float64 and rounds once: (x - dark) * gain, then multiplies by the mask in float32 -- udf/crystallinity.py:73-79)
+// gm_px = gain * real mask, d_px = dark, pixel order (float32; the reference corrects in float64 and rounds once:
+// (x - dark) * gain, then multiplies by the mask in float32 -- io/corrections/detector.py:17-58, udf/crystallinity.py:73-79)
 __global__ void __launch_bounds__(256)
 k_cryst_corr_maps(const double *__restrict__ dark, const double *__restrict__ gain,
-                  const float *__restrict__ real_mask, float *__restrict__ gm_p, float *__restrict__ dmap_p) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= CF_N * CF_N) return;
-    const int yp = i / (2 * CF_N), q = i - yp * (2 * CF_N);
-    const int p = (2 * yp + (q & 1)) * CF_N + (q >> 1);
-    gm_p[i] = (float)(gain ? gain[p] : 1.0) * (real_mask ? real_mask[p] : 1.f);
-    dmap_p[i] = (float)(dark ? dark[p] : 0.0);
+                  const float *__restrict__ real_mask, int64_t n_px, float *__restrict__ gm_px,
+                  float *__restrict__ d_px) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_px) return;
+    gm_px[p] = (float)(gain ? gain[p] : 1.0) * (real_mask ? real_mask[p] : 1.f);
+    d_px[p] = (float)(dark ? dark[p] : 0.0);
 }
-// one workgroup: the excluded pixels sorted by row pair (pair_ptr[129], pcode = lane << 3 | register << 1 | row of
-// the pair, index into the excluded list << 16) and their map entries cleared
+// one workgroup: the excluded pixels sorted by item of the row stage (pair_ptr[n_items + 1], pcode: see CfCorr) and
+// their entries of gm_px cleared.  mode 0: row pairs, a lane holds 4 M consecutive pixels of both rows (k_cryst_fused:
+// M = 1, k_cryst_rows<M>); mode 1: groups of four rows, a lane holds 2 pixels of each (k_cryst_fused128)
 __global__ void __launch_bounds__(256)
-k_cryst_patch_index(const int32_t *__restrict__ excl, int n_excl, int *__restrict__ pair_ptr,
-                    int *__restrict__ pcode, float *__restrict__ gm_p) {
-    __shared__ int cnt[CF_N / 2 + 1], cur[CF_N / 2];
-    for (int i = threadIdx.x; i <= CF_N / 2; i += 256) cnt[i] = 0;
+k_cryst_patch_index(const int32_t *__restrict__ excl, int n_excl, int W, int n_items, int mode, int M,
+                    int *__restrict__ pair_ptr, int *__restrict__ pcode, float *__restrict__ gm_px) {
+    __shared__ int cnt[513], cur[512];
+    for (int i = threadIdx.x; i <= n_items; i += 256) cnt[i] = 0;
     __syncthreads();
-    for (int e = threadIdx.x; e < n_excl; e += 256) atomicAdd(&cnt[excl[e] / (2 * CF_N)], 1);
+    const int rows_per_item = mode == 1 ? 4 : 2;
+    for (int e = threadIdx.x; e < n_excl; e += 256) atomicAdd(&cnt[excl[e] / W / rows_per_item], 1);
     __syncthreads();
     if (threadIdx.x == 0) {
         int run = 0;
-        for (int i = 0; i < CF_N / 2; ++i) {
+        for (int i = 0; i < n_items; ++i) {
             const int c = cnt[i];
             pair_ptr[i] = run;
             cur[i] = run;
             run += c;
         }
-        pair_ptr[CF_N / 2] = run;
+        pair_ptr[n_items] = run;
     }
     __syncthreads();
     for (int e = threadIdx.x; e < n_excl; e += 256) {
-        const int p = excl[e], y = p / CF_N, x = p - y * CF_N;
-        const int slot = atomicAdd(&cur[y >> 1], 1);
-        pcode[slot] = ((x >> 2) << 3) | ((x & 3) << 1) | (y & 1) | (e << 16);
-        gm_p[(y >> 1) * (2 * CF_N) + 2 * x + (y & 1)] = 0.f;
+        const int p = excl[e], y = p / W, x = p - y * W;
+        int lane, reg, sub = 0;
+        if (mode == 1) {
+            lane = x >> 1;
+            reg = (x & 1) * 2 + ((y & 3) >> 1);
+        } else {
+            lane = x / (4 * M);
+            const int r = x - lane * 4 * M;
+            reg = r / M;
+            sub = r - reg * M;
+        }
+        const int slot = atomicAdd(&cur[y / rows_per_item], 1);
+        pcode[slot] = (y & 1) | (reg << 1) | (lane << 3) | (sub << 9) | (e << 16);
+        gm_px[p] = 0.f;
     }
 }
 // patch[f, e] = mean over the good neighbours of excluded pixel e of the CORRECTED pixel (as the float32 value
@@ -483,39 +513,38 @@ k_cryst_patch_values(const T *__restrict__ tile, int64_t ld, int64_t n_frames, c
     const int64_t f = i / n_excl;
     const int e = (int)(i % n_excl);
     const int c = cnt[e];
-    float v = 0.f;
+    const T *src = tile + f * ld;
+    float v;
     if (c > 0) {
-        const T *src = tile + f * ld;
         double acc = 0.0;
         for (int j = 0; j < c; ++j) {
             const int r = env[(int64_t)e * max_env + j];
             acc += (double)(float)(((double)src[r] - (dark ? dark[r] : 0.0)) * (gain ? gain[r] : 1.0));
         }
         v = (float)(acc / (double)c);
-        if (real_mask) v *= real_mask[excl[e]];
     } else {
-        // no good neighbour: the pixel keeps its corrected value (detector.py: nothing to repair with)
+        // no good neighbour: the pixel keeps its corrected value (nothing to repair with)
         const int p = excl[e];
-        v = (float)(((double)tile[f * ld + p] - (dark ? dark[p] : 0.0)) * (gain ? gain[p] : 1.0));
-        if (real_mask) v *= real_mask[p];
+        v = (float)(((double)src[p] - (dark ? dark[p] : 0.0)) * (gain ? gain[p] : 1.0));
     }
+    if (real_mask) v *= real_mask[excl[e]];
     patch[i] = v;
 }
 
-int64_t cryst_corr_workspace_bytes(int64_t n_frames, int n_excl) {
-    return (int64_t)CF_N * CF_N * 4 + (CF_N / 2 + 1 + 3) / 4 * 16 + (int64_t)std::max(n_excl, 1) * 4 +
+bool cryst_fused_takes(int h, int w, int n_cols);
+int64_t cryst_corr_workspace_bytes(int h, int w, int64_t n_frames, int n_excl) {
+    return (int64_t)3 * h * w * 4 + 64 + 520 * 4 + (int64_t)std::max(n_excl, 1) * 4 +
            (int64_t)n_frames * std::max(n_excl, 1) * 4 + 64;
 }
 bool cryst_corr_takes(int h, int w, int n_cols, int tile_dtype, int n_excl) {
-    return h == CF_N && w == CF_N && n_cols >= 1 && n_cols <= CF_KMAX && n_excl <= CF_MAX_EXCL &&
-           dtype_size(tile_dtype) <= 4 && tile_dtype != LTMI_F64;
+    return cryst_fused_takes(h, w, n_cols) && n_excl <= CF_MAX_EXCL && dtype_size(tile_dtype) <= 4 &&
+           tile_dtype != LTMI_F64;
 }
 
 template <typename T>
-static int launch_fused_corr(const void *tile, int64_t ld, int64_t n_frames, const float *gm_p, const float *dmap_p,
-                             const unsigned long long *rflags, const float *mask_t, int K, const int *pair_ptr,
-                             const int *pcode, const float *patch, int n_excl, float *out, int accumulate, int n_cu,
-                             hipStream_t stream) {
+static int launch_fused_corr(const void *tile, int64_t ld, int64_t n_frames, const float *gm_p,
+                             const unsigned long long *rflags, const float *mask_t, int K, const CfCorr *corr,
+                             float *out, int accumulate, int n_cu, hipStream_t stream) {
     constexpr int WAVES = 16;
     auto kern = k_cryst_fused<T, true, WAVES, 0, true>;
     const int n_scr = std::min(WAVES, (CF_LDS_MAX - K * CF_COL * 8) / (CF_SCR * 8));
@@ -529,59 +558,10 @@ static int launch_fused_corr(const void *tile, int64_t ld, int64_t n_frames, con
     }
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_frames, n_cu));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), (size_t)lds, stream, (const T *)tile, ld, n_frames, gm_p,
-                       rflags, mask_t, K, n_scr, out, accumulate, dmap_p, pair_ptr, pcode, patch, n_excl);
+                       rflags, mask_t, K, n_scr, out, accumulate, (const float *)corr->dmap_p, corr->pair_ptr,
+                       corr->pcode, corr->patch, corr->n_excl);
     LTMI_HIP(hipGetLastError());
     return LTMI_OK;
-}
-
-// RAW 256 x 256 frames with detector corrections in ONE pass over the pixels.  `ws`: cryst_corr_workspace_bytes.
-int cryst_fused_corrected(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, const double *dark,
-                          const double *gain, const int32_t *excl, const int32_t *env, const int32_t *cnt, int n_excl,
-                          int max_env, const float *real_mask, const float *half_mask, int n_cols, float *mask_t,
-                          void *ws, float *out, int accumulate, int n_cu, hipStream_t stream, bool *handled) {
-    *handled = false;
-    if (!mask_t || !ws || !cryst_corr_takes(CF_N, CF_N, n_cols, tile_dtype, n_excl)) return LTMI_OK;
-    const size_t esz = (size_t)dtype_size(tile_dtype);
-    if ((uintptr_t)tile % (4 * esz) != 0 || ld % 4 != 0) return LTMI_OK;
-    float *gm_p = mask_t + (int64_t)CF_KMAX * CF_N;                   // (the place of rmask_p)
-    unsigned long long *rflags = (unsigned long long *)(gm_p + CF_N * CF_N);
-    float *dmap_p = (float *)ws;
-    int *pair_ptr = (int *)(dmap_p + CF_N * CF_N);
-    int *pcode = pair_ptr + (CF_N / 2 + 1 + 3) / 4 * 4;
-    float *patch = (float *)(pcode + std::max(n_excl, 1));
-    hipLaunchKernelGGL(k_cryst_masks, dim3((unsigned)(CF_N * CF_N / 256)), dim3(256), 0, stream, half_mask,
-                       CF_N / 2 + 1, n_cols, mask_t, (const float *)nullptr, gm_p, rflags);
-    hipLaunchKernelGGL(k_cryst_corr_maps, dim3((unsigned)(CF_N * CF_N / 256)), dim3(256), 0, stream, dark, gain,
-                       real_mask, gm_p, dmap_p);
-    if (n_excl > 0)
-        hipLaunchKernelGGL(k_cryst_patch_index, dim3(1), dim3(256), 0, stream, excl, n_excl, pair_ptr, pcode, gm_p);
-    LTMI_HIP(hipGetLastError());
-    int rc = LTMI_E_DTYPE;
-#define LTMI_CORR_CASE(T_)                                                                                        \
-    {                                                                                                             \
-        if (n_excl > 0) {                                                                                         \
-            const int64_t nt = n_frames * n_excl;                                                                 \
-            hipLaunchKernelGGL((k_cryst_patch_values<T_>), dim3((unsigned)((nt + 255) / 256)), dim3(256), 0,      \
-                               stream, (const T_ *)tile, ld, n_frames, dark, gain, real_mask, excl, env, cnt,     \
-                               n_excl, max_env, patch);                                                           \
-        }                                                                                                         \
-        rc = launch_fused_corr<T_>(tile, ld, n_frames, gm_p, dmap_p, rflags, mask_t, n_cols, pair_ptr, pcode,     \
-                                   patch, n_excl, out, accumulate, n_cu, stream);                                 \
-    }
-    switch (tile_dtype) {
-        case LTMI_BOOL:
-        case LTMI_U8: LTMI_CORR_CASE(uint8_t) break;
-        case LTMI_I8: LTMI_CORR_CASE(int8_t) break;
-        case LTMI_U16: LTMI_CORR_CASE(uint16_t) break;
-        case LTMI_I16: LTMI_CORR_CASE(int16_t) break;
-        case LTMI_U32: LTMI_CORR_CASE(uint32_t) break;
-        case LTMI_I32: LTMI_CORR_CASE(int32_t) break;
-        case LTMI_F32: LTMI_CORR_CASE(float) break;
-        default: return LTMI_OK;
-    }
-#undef LTMI_CORR_CASE
-    if (rc == LTMI_OK) *handled = true;
-    return rc;
 }
 
 int cryst_fused_max_cols() { return CF_KMAX; }
@@ -673,11 +653,13 @@ struct CgRaw {                                  // 2 pixels of each of 4 rows
     vec_t r[4];
 };
 
-template <typename T, bool MASK>
+template <typename T, bool MASK, bool CORR = false>
 __global__ void __launch_bounds__(CG_WAVES * 64)
 k_cryst_fused128(const T *__restrict__ tile, int64_t ld, int64_t n_frames, const float *__restrict__ rmask_p,
                  const unsigned long long *__restrict__ rflags, const float *__restrict__ mask_p, int K,
-                 float *__restrict__ out, int accumulate) {
+                 float *__restrict__ out, int accumulate, const float *__restrict__ dmap_p,
+                 const int *__restrict__ pair_ptr, const int *__restrict__ pcode, const float *__restrict__ patch,
+                 int n_excl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cf_smem[];
     __shared__ float part[CG_WAVES];
     const int t = threadIdx.x & 63;
@@ -740,9 +722,9 @@ k_cryst_fused128(const T *__restrict__ tile, int64_t ld, int64_t n_frames, const
                 dst.r[i] = __builtin_nontemporal_load((const vec_t *)(row + i * CG_N + 2 * t));
         }
     };
-    auto convert = [&](const CgRaw<T> &b, int q, v2f (&u)[4]) {
+    auto convert = [&](const CgRaw<T> &b, int q, int64_t fr, v2f (&u)[4]) {
         CfMask bm;
-        const bool mk = masked(q);
+        const bool mk = CORR || masked(q);
         if (mk) {
             const float *row = rmask_p + q * (4 * CG_N);
             bm.m01 = *(const v4f *)(row + 8 * t);
@@ -752,9 +734,21 @@ k_cryst_fused128(const T *__restrict__ tile, int64_t ld, int64_t n_frames, const
         u[1] = (v2f){(float)b.r[2][0], (float)b.r[3][0]};
         u[2] = (v2f){(float)b.r[0][1], (float)b.r[1][1]};
         u[3] = (v2f){(float)b.r[2][1], (float)b.r[3][1]};
+        if constexpr (CORR) {
+            const float *row = dmap_p + q * (4 * CG_N);
+            const v4f d01 = *(const v4f *)(row + 8 * t), d23 = *(const v4f *)(row + 8 * t + 4);
+            u[0] -= d01.xy; u[1] -= d01.zw;
+            u[2] -= d23.xy; u[3] -= d23.zw;
+        }
         if (mk) {
             u[0] *= bm.m01.xy; u[1] *= bm.m01.zw;
             u[2] *= bm.m23.xy; u[3] *= bm.m23.zw;
+        }
+        if constexpr (CORR) {
+            if (n_excl > 0 && fr < n_frames) {
+                v2f (&uu)[1][4] = reinterpret_cast<v2f (&)[1][4]>(u);
+                cf_apply_patches<1>(uu, t, q, fr, pair_ptr, pcode, patch, n_excl);
+            }
         }
     };
     // the two rows of one pair out of Z[k] (k2 = 0: za, k2 = 1: zb), both x 2; rows y, y + 1
@@ -785,8 +779,8 @@ k_cryst_fused128(const T *__restrict__ tile, int64_t ld, int64_t n_frames, const
     __syncthreads();                                // (the zeroed columns)
     for (int64_t f = blockIdx.x; f < n_frames; f += gridDim.x) {
         v2f ua[4], ub[4];
-        convert(ba, w, ua);
-        convert(bb, w + CG_WAVES, ub);
+        convert(ba, w, f, ua);
+        convert(bb, w + CG_WAVES, f, ub);
         load(ba, f + gridDim.x, w);
         load(bb, f + gridDim.x, w + CG_WAVES);
         four_rows(ua, w);
@@ -857,26 +851,30 @@ k_cryst_masks128(const float *__restrict__ half_mask, float *__restrict__ mask_p
 template <typename T>
 static int launch_fused128(const void *tile, int64_t ld, int64_t n_frames, const float *real_mask,
                            const unsigned long long *rflags, const float *mask_p, int K, float *out,
-                           int accumulate, int n_cu, hipStream_t stream) {
-    auto kern = real_mask ? k_cryst_fused128<T, true> : k_cryst_fused128<T, false>;
+                           int accumulate, int n_cu, hipStream_t stream, const CfCorr *corr = nullptr) {
+    auto kern = corr ? k_cryst_fused128<T, true, true>
+                     : (real_mask ? k_cryst_fused128<T, true> : k_cryst_fused128<T, false>);
     const int lds = CG_K * CG_COL * 8 + CG_WAVES * CF_SCR * 8;
     int device = 0;
     LTMI_HIP(hipGetDevice(&device));
-    static bool attr_set[16][2] = {{false}};
-    if (!attr_set[device & 15][real_mask ? 1 : 0]) {
+    static bool attr_set[16][3] = {{false}};
+    const int variant = corr ? 2 : (real_mask ? 1 : 0);
+    if (!attr_set[device & 15][variant]) {
         LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set[device & 15][real_mask ? 1 : 0] = true;
+        attr_set[device & 15][variant] = true;
     }
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_frames, n_cu));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(CG_WAVES * 64), (size_t)lds, stream, (const T *)tile, ld, n_frames,
-                       real_mask, rflags, mask_p, K, out, accumulate);
+                       real_mask, rflags, mask_p, K, out, accumulate, corr ? (const float *)corr->dmap_p : nullptr,
+                       corr ? corr->pair_ptr : nullptr, corr ? corr->pcode : nullptr, corr ? corr->patch : nullptr,
+                       corr ? corr->n_excl : 0);
     LTMI_HIP(hipGetLastError());
     return LTMI_OK;
 }
 
 static int cryst_fused128(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, const float *real_mask,
                           const float *half_mask, int n_cols, float *work, float *out, int accumulate, int n_cu,
-                          hipStream_t stream, bool *handled) {
+                          hipStream_t stream, bool *handled, const CfCorr *corr = nullptr) {
     if (n_cols < 1 || n_cols > CG_K) return LTMI_OK;
     const size_t esz = (size_t)dtype_size(tile_dtype);
     if (esz > 4 || tile_dtype == LTMI_F64) return LTMI_OK;
@@ -886,17 +884,20 @@ static int cryst_fused128(const void *tile, int tile_dtype, int64_t n_frames, in
     LTMI_HIP(hipMemsetAsync(rflags, 0, 8, stream));
     hipLaunchKernelGGL(k_cryst_masks128, dim3((unsigned)(CG_N * CG_N / 256)), dim3(256), 0, stream, half_mask,
                        mask_p, real_mask, rmask_p, rflags);
+    if (corr)                                       // (the dark map in the same lane order)
+        hipLaunchKernelGGL(k_cryst_masks128, dim3((unsigned)(CG_N * CG_N / 256)), dim3(256), 0, stream, half_mask,
+                           mask_p, corr->d_px, corr->dmap_p, corr->dummy_flags);
     if (real_mask) real_mask = rmask_p;
     int rc = LTMI_E_DTYPE;
     switch (tile_dtype) {
         case LTMI_BOOL:
-        case LTMI_U8: rc = launch_fused128<uint8_t>(tile, ld, n_frames, real_mask, rflags, mask_p, n_cols, out, accumulate, n_cu, stream); break;
-        case LTMI_I8: rc = launch_fused128<int8_t>(tile, ld, n_frames, real_mask, rflags, mask_p, n_cols, out, accumulate, n_cu, stream); break;
-        case LTMI_U16: rc = launch_fused128<uint16_t>(tile, ld, n_frames, real_mask, rflags, mask_p, n_cols, out, accumulate, n_cu, stream); break;
-        case LTMI_I16: rc = launch_fused128<int16_t>(tile, ld, n_frames, real_mask, rflags, mask_p, n_cols, out, accumulate, n_cu, stream); break;
-        case LTMI_U32: rc = launch_fused128<uint32_t>(tile, ld, n_frames, real_mask, rflags, mask_p, n_cols, out, accumulate, n_cu, stream); break;
-        case LTMI_I32: rc = launch_fused128<int32_t>(tile, ld, n_frames, real_mask, rflags, mask_p, n_cols, out, accumulate, n_cu, stream); break;
-        case LTMI_F32: rc = launch_fused128<float>(tile, ld, n_frames, real_mask, rflags, mask_p, n_cols, out, accumulate, n_cu, stream); break;
+        case LTMI_U8: rc = launch_fused128<uint8_t>(tile, ld, n_frames, real_mask, rflags, mask_p, n_cols, out, accumulate, n_cu, stream, corr); break;
+        case LTMI_I8: rc = launch_fused128<int8_t>(tile, ld, n_frames, real_mask, rflags, mask_p, n_cols, out, accumulate, n_cu, stream, corr); break;
+        case LTMI_U16: rc = launch_fused128<uint16_t>(tile, ld, n_frames, real_mask, rflags, mask_p, n_cols, out, accumulate, n_cu, stream, corr); break;
+        case LTMI_I16: rc = launch_fused128<int16_t>(tile, ld, n_frames, real_mask, rflags, mask_p, n_cols, out, accumulate, n_cu, stream, corr); break;
+        case LTMI_U32: rc = launch_fused128<uint32_t>(tile, ld, n_frames, real_mask, rflags, mask_p, n_cols, out, accumulate, n_cu, stream, corr); break;
+        case LTMI_I32: rc = launch_fused128<int32_t>(tile, ld, n_frames, real_mask, rflags, mask_p, n_cols, out, accumulate, n_cu, stream, corr); break;
+        case LTMI_F32: rc = launch_fused128<float>(tile, ld, n_frames, real_mask, rflags, mask_p, n_cols, out, accumulate, n_cu, stream, corr); break;
         default: return LTMI_OK;
     }
     if (rc == LTMI_OK) *handled = true;
@@ -982,10 +983,12 @@ __device__ __forceinline__ void ch_fft(v2f *scr, const CfLane &c, const ChTw<M> 
 
 // grid: persistent over groups of 8 row pairs (frame f, pairs 8 g .. 8 g + 7: one per wave).  The 2 x K spectra of a
 // group are staged in the LDS and leave as 128 contiguous bytes per column: G[(f K + kx) N + 16 g ..].
-template <typename T, bool MASK, int M>
+template <typename T, bool MASK, int M, bool CORR = false>
 __global__ void __launch_bounds__(CH_WAVES * 64)
 k_cryst_rows(const T *__restrict__ tile, int64_t ld, int64_t n_frames, const float *__restrict__ rmask_p,
-             const unsigned long long *__restrict__ rflags, int K, int H, v2f *__restrict__ G) {
+             const unsigned long long *__restrict__ rflags, int K, int H, v2f *__restrict__ G,
+             const float *__restrict__ dmap_p, const int *__restrict__ pair_ptr, const int *__restrict__ pcode,
+             const float *__restrict__ patch, int n_excl) {
     constexpr int N = 256 * M;                                      // row length; H rows per frame
     extern __shared__ __attribute__((aligned(16))) unsigned char cf_smem[];
     const int t = threadIdx.x & 63;
@@ -1015,13 +1018,24 @@ k_cryst_rows(const T *__restrict__ tile, int64_t ld, int64_t n_frames, const flo
         for (int q = 0; q < M; ++q)
 #pragma unroll
             for (int j = 0; j < 4; ++j) u[q][j] = (v2f){(float)ra[M * j + q], (float)rb[M * j + q]};
-        if (MASK && ((rflags[yp >> 6] >> (yp & 63)) & 1)) {
+        if constexpr (CORR) {
+            const v4f *dk = (const v4f *)(dmap_p + (int64_t)yp * (2 * N) + 8 * M * t);
+#pragma unroll
+            for (int q = 0; q < M; ++q) {
+                const v4f d0 = dk[2 * q], d1 = dk[2 * q + 1];
+                u[q][0] -= d0.xy; u[q][1] -= d0.zw; u[q][2] -= d1.xy; u[q][3] -= d1.zw;
+            }
+        }
+        if (CORR || (MASK && ((rflags[yp >> 6] >> (yp & 63)) & 1))) {
             const v4f *mk = (const v4f *)(rmask_p + (int64_t)yp * (2 * N) + 8 * M * t);
 #pragma unroll
             for (int q = 0; q < M; ++q) {
                 const v4f m0 = mk[2 * q], m1 = mk[2 * q + 1];
                 u[q][0] *= m0.xy; u[q][1] *= m0.zw; u[q][2] *= m1.xy; u[q][3] *= m1.zw;
             }
+        }
+        if constexpr (CORR) {
+            if (n_excl > 0) cf_apply_patches<M>(u, t, yp, f, pair_ptr, pcode, patch, n_excl);
         }
         ch_fft<M>(scr, c, h, u);
         // two real rows out of one complex transform (see k_cryst_fused): the partner X[N - kx] of kx = sigma + 64 c
@@ -1141,22 +1155,25 @@ k_cryst_masks_n(const float *__restrict__ half_mask, int W, int H, int K, float 
 
 template <typename T, int M>
 static int launch_rows(const void *tile, int64_t ld, int64_t n_frames, const float *real_mask,
-                       const unsigned long long *rflags, int K, int H, v2f *G, int n_cu, hipStream_t stream) {
-    auto kern = real_mask ? k_cryst_rows<T, true, M> : k_cryst_rows<T, false, M>;
+                       const unsigned long long *rflags, int K, int H, v2f *G, int n_cu, hipStream_t stream,
+                       const CfCorr *corr = nullptr, int64_t patch_frame0 = 0) {
+    auto kern = corr ? k_cryst_rows<T, true, M, true>
+                     : (real_mask ? k_cryst_rows<T, true, M> : k_cryst_rows<T, false, M>);
     constexpr int N = 256 * M;
     const int lds = K * CH_STAGE * 16 + CH_WAVES * CF_SCR * 8;
     int device = 0;
     LTMI_HIP(hipGetDevice(&device));
-    static bool attr_set[16][2] = {{false}};
-    if (!attr_set[device & 15][real_mask ? 1 : 0]) {
+    static bool attr_set[16][3] = {{false}};
+    const int variant = corr ? 2 : (real_mask ? 1 : 0);
+    if (!attr_set[device & 15][variant]) {
         LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (N / 2 + 1) * CH_STAGE * 16 + CH_WAVES * CF_SCR * 8));
-        attr_set[device & 15][real_mask ? 1 : 0] = true;
+        attr_set[device & 15][variant] = true;
     }
     // persistent workgroups: exactly as many as are resident at once (a workgroup that waits for a CU would start
     // its share of the groups when the others are done with theirs)
-    static int resident[16][2][CH_KMAX_ANY + 2] = {{{0}}};          // per device, mask variant and K (the LDS size)
-    int &per_cu = resident[device & 15][real_mask ? 1 : 0][K];
+    static int resident[16][3][CH_KMAX_ANY + 2] = {{{0}}};          // per device, mask variant and K (the LDS size)
+    int &per_cu = resident[device & 15][variant][K];
     if (per_cu == 0) {
         LTMI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, CH_WAVES * 64, (size_t)lds));
         per_cu = std::max(1, per_cu);
@@ -1164,7 +1181,9 @@ static int launch_rows(const void *tile, int64_t ld, int64_t n_frames, const flo
     const int64_t groups = n_frames * (H / 2 / CH_WAVES);
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(groups, (int64_t)n_cu * std::max(1, per_cu)));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(CH_WAVES * 64), (size_t)lds, stream, (const T *)tile, ld, n_frames,
-                       real_mask, rflags, K, H, G);
+                       real_mask, rflags, K, H, G, corr ? (const float *)corr->dmap_p : nullptr,
+                       corr ? corr->pair_ptr : nullptr, corr ? corr->pcode : nullptr,
+                       corr ? corr->patch + patch_frame0 * corr->n_excl : nullptr, corr ? corr->n_excl : 0);
     LTMI_HIP(hipGetLastError());
     return LTMI_OK;
 }
@@ -1173,7 +1192,8 @@ static int launch_rows(const void *tile, int64_t ld, int64_t n_frames, const flo
 template <int M, int MH = M>
 static int cryst_rows_cols(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, const float *real_mask,
                            const float *half_mask, int n_cols, float *work, void *gbuf, int64_t gbuf_frames,
-                           float *out, int accumulate, int n_cu, hipStream_t stream, bool *handled) {
+                           float *out, int accumulate, int n_cu, hipStream_t stream, bool *handled,
+                           const CfCorr *corr = nullptr) {
     constexpr int N = 256 * M, H = 256 * MH;
     if (n_cols < 1 || n_cols > N / 2 + 1 || !gbuf || gbuf_frames < 1) return LTMI_OK;
     const size_t esz = (size_t)dtype_size(tile_dtype);
@@ -1184,6 +1204,9 @@ static int cryst_rows_cols(const void *tile, int tile_dtype, int64_t n_frames, i
     LTMI_HIP(hipMemsetAsync(rflags, 0, 64, stream));
     hipLaunchKernelGGL(k_cryst_masks_n, dim3((unsigned)((int64_t)N * H / 256)), dim3(256), 0, stream, half_mask, N, H,
                        n_cols, mask_p, real_mask, rmask_p, rflags);
+    if (corr)                                       // (the dark map in the same lane order)
+        hipLaunchKernelGGL(k_cryst_masks_n, dim3((unsigned)((int64_t)N * H / 256)), dim3(256), 0, stream, half_mask, N, H,
+                           0, mask_p, corr->d_px, corr->dmap_p, corr->dummy_flags);
     const float *rm = real_mask ? rmask_p : nullptr;
     for (int64_t f0 = 0; f0 < n_frames; f0 += gbuf_frames) {
         const int64_t n = std::min<int64_t>(gbuf_frames, n_frames - f0);
@@ -1191,13 +1214,13 @@ static int cryst_rows_cols(const void *tile, int tile_dtype, int64_t n_frames, i
         int rc = LTMI_E_DTYPE;
         switch (tile_dtype) {
             case LTMI_BOOL:
-            case LTMI_U8: rc = launch_rows<uint8_t, M>(src, ld, n, rm, rflags, n_cols, H, (v2f *)gbuf, n_cu, stream); break;
-            case LTMI_I8: rc = launch_rows<int8_t, M>(src, ld, n, rm, rflags, n_cols, H, (v2f *)gbuf, n_cu, stream); break;
-            case LTMI_U16: rc = launch_rows<uint16_t, M>(src, ld, n, rm, rflags, n_cols, H, (v2f *)gbuf, n_cu, stream); break;
-            case LTMI_I16: rc = launch_rows<int16_t, M>(src, ld, n, rm, rflags, n_cols, H, (v2f *)gbuf, n_cu, stream); break;
-            case LTMI_U32: rc = launch_rows<uint32_t, M>(src, ld, n, rm, rflags, n_cols, H, (v2f *)gbuf, n_cu, stream); break;
-            case LTMI_I32: rc = launch_rows<int32_t, M>(src, ld, n, rm, rflags, n_cols, H, (v2f *)gbuf, n_cu, stream); break;
-            case LTMI_F32: rc = launch_rows<float, M>(src, ld, n, rm, rflags, n_cols, H, (v2f *)gbuf, n_cu, stream); break;
+            case LTMI_U8: rc = launch_rows<uint8_t, M>(src, ld, n, rm, rflags, n_cols, H, (v2f *)gbuf, n_cu, stream, corr, f0); break;
+            case LTMI_I8: rc = launch_rows<int8_t, M>(src, ld, n, rm, rflags, n_cols, H, (v2f *)gbuf, n_cu, stream, corr, f0); break;
+            case LTMI_U16: rc = launch_rows<uint16_t, M>(src, ld, n, rm, rflags, n_cols, H, (v2f *)gbuf, n_cu, stream, corr, f0); break;
+            case LTMI_I16: rc = launch_rows<int16_t, M>(src, ld, n, rm, rflags, n_cols, H, (v2f *)gbuf, n_cu, stream, corr, f0); break;
+            case LTMI_U32: rc = launch_rows<uint32_t, M>(src, ld, n, rm, rflags, n_cols, H, (v2f *)gbuf, n_cu, stream, corr, f0); break;
+            case LTMI_I32: rc = launch_rows<int32_t, M>(src, ld, n, rm, rflags, n_cols, H, (v2f *)gbuf, n_cu, stream, corr, f0); break;
+            case LTMI_F32: rc = launch_rows<float, M>(src, ld, n, rm, rflags, n_cols, H, (v2f *)gbuf, n_cu, stream, corr, f0); break;
             default: return LTMI_OK;
         }
         if (rc != LTMI_OK) return rc;
@@ -1216,9 +1239,10 @@ static int cryst_rows_cols(const void *tile, int tile_dtype, int64_t n_frames, i
 }
 
 // -> LTMI_OK with *handled = true when a fused kernel ran (256 x 256 or 128 x 128 frames)
-int cryst_fused(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, int sig_h, int sig_w,
-                const float *real_mask, const float *half_mask, int n_cols, float *mask_t, void *gbuf,
-                int64_t gbuf_frames, float *out, int accumulate, int n_cu, hipStream_t stream, bool *handled) {
+static int cryst_fused_impl(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, int sig_h, int sig_w,
+                            const float *real_mask, const float *half_mask, int n_cols, float *mask_t, void *gbuf,
+                            int64_t gbuf_frames, float *out, int accumulate, int n_cu, hipStream_t stream, bool *handled,
+                            const CfCorr *corr) {
     *handled = false;
     if (!mask_t) return LTMI_OK;
     if ((sig_h == 256 || sig_h == 512 || sig_h == 1024) && (sig_w == 256 || sig_w == 512 || sig_w == 1024) &&
@@ -1227,18 +1251,18 @@ int cryst_fused(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, 
 #define LTMI_CRYST_RC(MW_, MH_)                                                                                   \
         if (sig_w == 256 * MW_ && sig_h == 256 * MH_)                                                            \
             return cryst_rows_cols<MW_, MH_>(tile, tile_dtype, n_frames, ld, real_mask, half_mask, n_cols, mask_t, \
-                                             gbuf, gbuf_frames, out, accumulate, n_cu, stream, handled);
+                                             gbuf, gbuf_frames, out, accumulate, n_cu, stream, handled, corr);
         LTMI_CRYST_RC(1, 2) LTMI_CRYST_RC(1, 4) LTMI_CRYST_RC(2, 1) LTMI_CRYST_RC(2, 2) LTMI_CRYST_RC(2, 4)
         LTMI_CRYST_RC(4, 1) LTMI_CRYST_RC(4, 2) LTMI_CRYST_RC(4, 4)
 #undef LTMI_CRYST_RC
     }
     if (sig_h == CG_N && sig_w == CG_N)
         return cryst_fused128(tile, tile_dtype, n_frames, ld, real_mask, half_mask, n_cols, mask_t, out, accumulate,
-                              n_cu, stream, handled);
+                              n_cu, stream, handled, corr);
     if (sig_h != CF_N || sig_w != CF_N || n_cols < 1) return LTMI_OK;
     if (n_cols > CF_KMAX)                        // a ring too wide for the LDS: the workspace kernels with M = 1
         return cryst_rows_cols<1>(tile, tile_dtype, n_frames, ld, real_mask, half_mask, n_cols, mask_t, gbuf,
-                                  gbuf_frames, out, accumulate, n_cu, stream, handled);
+                                  gbuf_frames, out, accumulate, n_cu, stream, handled, corr);
     const size_t esz = (size_t)dtype_size(tile_dtype);
     if (esz > 4 || tile_dtype == LTMI_F64) return LTMI_OK;
     if ((uintptr_t)tile % (4 * esz) != 0 || ld % 4 != 0) return LTMI_OK;
@@ -1249,6 +1273,24 @@ int cryst_fused(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, 
                        sig_w / 2 + 1, n_cols, mask_t, real_mask, rmask_p, rflags);
     if (real_mask) real_mask = rmask_p;
     int rc = LTMI_E_DTYPE;
+    if (corr) {
+        // the dark map in the same lane order (K = 0: the half mask is in place), then the CORR instantiation
+        hipLaunchKernelGGL(k_cryst_masks, dim3((unsigned)(CF_N * CF_N / 256)), dim3(256), 0, stream, half_mask,
+                           sig_w / 2 + 1, 0, mask_t, corr->d_px, corr->dmap_p, corr->dummy_flags);
+        switch (tile_dtype) {
+            case LTMI_BOOL:
+            case LTMI_U8: rc = launch_fused_corr<uint8_t>(tile, ld, n_frames, real_mask, rflags, mask_t, n_cols, corr, out, accumulate, n_cu, stream); break;
+            case LTMI_I8: rc = launch_fused_corr<int8_t>(tile, ld, n_frames, real_mask, rflags, mask_t, n_cols, corr, out, accumulate, n_cu, stream); break;
+            case LTMI_U16: rc = launch_fused_corr<uint16_t>(tile, ld, n_frames, real_mask, rflags, mask_t, n_cols, corr, out, accumulate, n_cu, stream); break;
+            case LTMI_I16: rc = launch_fused_corr<int16_t>(tile, ld, n_frames, real_mask, rflags, mask_t, n_cols, corr, out, accumulate, n_cu, stream); break;
+            case LTMI_U32: rc = launch_fused_corr<uint32_t>(tile, ld, n_frames, real_mask, rflags, mask_t, n_cols, corr, out, accumulate, n_cu, stream); break;
+            case LTMI_I32: rc = launch_fused_corr<int32_t>(tile, ld, n_frames, real_mask, rflags, mask_t, n_cols, corr, out, accumulate, n_cu, stream); break;
+            case LTMI_F32: rc = launch_fused_corr<float>(tile, ld, n_frames, real_mask, rflags, mask_t, n_cols, corr, out, accumulate, n_cu, stream); break;
+            default: return LTMI_OK;
+        }
+        if (rc == LTMI_OK) *handled = true;
+        return rc;
+    }
     switch (tile_dtype) {
         case LTMI_BOOL:
         case LTMI_U8: rc = launch_fused<uint8_t>(tile, ld, n_frames, real_mask, rflags, mask_t, n_cols, out, accumulate, n_cu, stream); break;
@@ -1262,6 +1304,69 @@ int cryst_fused(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, 
     }
     if (rc == LTMI_OK) *handled = true;
     return rc;
+}
+
+// -> LTMI_OK with *handled = true when a fused kernel ran
+int cryst_fused(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, int sig_h, int sig_w,
+                const float *real_mask, const float *half_mask, int n_cols, float *mask_t, void *gbuf,
+                int64_t gbuf_frames, float *out, int accumulate, int n_cu, hipStream_t stream, bool *handled) {
+    return cryst_fused_impl(tile, tile_dtype, n_frames, ld, sig_h, sig_w, real_mask, half_mask, n_cols, mask_t, gbuf,
+                            gbuf_frames, out, accumulate, n_cu, stream, handled, nullptr);
+}
+
+// RAW frames with detector corrections in ONE pass over the pixels (every shape the fused kernels take).
+// `ws`: cryst_corr_workspace_bytes(h, w, n_frames, n_excl).
+int cryst_fused_corrected(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, int sig_h, int sig_w,
+                          const double *dark, const double *gain, const int32_t *excl, const int32_t *env,
+                          const int32_t *cnt, int n_excl, int max_env, const float *real_mask, const float *half_mask,
+                          int n_cols, float *mask_t, void *gbuf, int64_t gbuf_frames, void *ws, float *out,
+                          int accumulate, int n_cu, hipStream_t stream, bool *handled) {
+    *handled = false;
+    if (!mask_t || !ws || !cryst_corr_takes(sig_h, sig_w, n_cols, tile_dtype, n_excl)) return LTMI_OK;
+    const int64_t n_px = (int64_t)sig_h * sig_w;
+    float *gm_px = (float *)ws, *d_px = gm_px + n_px, *dmap_p = d_px + n_px;
+    unsigned long long *dummy = (unsigned long long *)(dmap_p + n_px);
+    int *pair_ptr = (int *)(dummy + 8);
+    int *pcode = pair_ptr + 520;
+    float *patch = (float *)(pcode + std::max(n_excl, 1));
+    const bool four_rows = sig_h == CG_N && sig_w == CG_N;
+    const bool rows_cols = !four_rows && cryst_fused_needs_gbuf(sig_h, sig_w, n_cols);
+    if (rows_cols && (!gbuf || gbuf_frames < 1)) return LTMI_OK;
+    const int M = four_rows ? 1 : sig_w / 256;
+    hipLaunchKernelGGL(k_cryst_corr_maps, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, stream, dark, gain,
+                       real_mask, n_px, gm_px, d_px);
+    if (n_excl > 0) {
+        hipLaunchKernelGGL(k_cryst_patch_index, dim3(1), dim3(256), 0, stream, excl, n_excl, sig_w,
+                           four_rows ? sig_h / 4 : sig_h / 2, four_rows ? 1 : 0, M, pair_ptr, pcode, gm_px);
+        const int64_t nt = n_frames * n_excl;
+        const unsigned gb = (unsigned)((nt + 255) / 256);
+#define LTMI_PATCH_CASE(T_)                                                                                       \
+        hipLaunchKernelGGL((k_cryst_patch_values<T_>), dim3(gb), dim3(256), 0, stream, (const T_ *)tile, ld, n_frames, \
+                           dark, gain, real_mask, excl, env, cnt, n_excl, max_env, patch);
+        switch (tile_dtype) {
+            case LTMI_BOOL:
+            case LTMI_U8: LTMI_PATCH_CASE(uint8_t) break;
+            case LTMI_I8: LTMI_PATCH_CASE(int8_t) break;
+            case LTMI_U16: LTMI_PATCH_CASE(uint16_t) break;
+            case LTMI_I16: LTMI_PATCH_CASE(int16_t) break;
+            case LTMI_U32: LTMI_PATCH_CASE(uint32_t) break;
+            case LTMI_I32: LTMI_PATCH_CASE(int32_t) break;
+            case LTMI_F32: LTMI_PATCH_CASE(float) break;
+            default: return LTMI_OK;
+        }
+#undef LTMI_PATCH_CASE
+    }
+    LTMI_HIP(hipGetLastError());
+    CfCorr corr;
+    corr.d_px = d_px;
+    corr.dmap_p = dmap_p;
+    corr.dummy_flags = dummy;
+    corr.pair_ptr = pair_ptr;
+    corr.pcode = pcode;
+    corr.patch = patch;
+    corr.n_excl = n_excl;
+    return cryst_fused_impl(tile, tile_dtype, n_frames, ld, sig_h, sig_w, gm_px, half_mask, n_cols, mask_t, gbuf,
+                            gbuf_frames, out, accumulate, n_cu, stream, handled, &corr);
 }
 
 }  // namespace ltmi

@@ -26,7 +26,7 @@ struct ltmi_fft_plan {
     size_t corr_ws_bytes = 0;
     int n_cu = 0;
     bool fused_ok = false;             // 256 x 256 frames: k_cryst_fused (ltmi_cryst.hip) unless LTMI_FFT_FUSED=0
-    char last_kernel[96] = {0};
+    char last_kernel[128] = {0};
 };
 
 namespace ltmi {
@@ -417,11 +417,16 @@ static int crystallinity_impl(ltmi_fft_plan *p, const void *tile, int tile_dtype
     }
     if (p->fused_ok && (corr.dark || corr.gain || corr.n_excl > 0) &&
         cryst_corr_takes(p->h, p->w, n_cols, tile_dtype, corr.n_excl) && !getenv("LTMI_CRYST_CORR_PASS")) {
-        // 256 x 256 frames: dark / gain / dead-pixel patches inside the row stage of the fused kernel -- ONE pass over
-        // the raw pixels (round 5; LTMI_CRYST_CORR_PASS=1 keeps the conversion pass: tests, bench).  Frames in
-        // chunks whose patch values fit 64 MiB.
+        // dark / gain / dead-pixel patches inside the row stage of the fused kernels -- ONE pass over the raw pixels
+        // (round 5; LTMI_CRYST_CORR_PASS=1 keeps the conversion pass: tests, bench).  Frames in chunks whose patch
+        // values fit 64 MiB.
+        const bool need_g = cryst_fused_needs_gbuf(p->h, p->w, n_cols);
+        if (need_g) {
+            const int rc1 = spec_ready(p);
+            if (rc1 != LTMI_OK) return rc1;
+        }
         const int64_t chunk = corr.n_excl > 0 ? std::max<int64_t>(1024, ((int64_t)64 << 20) / (4 * corr.n_excl)) : n_frames;
-        const size_t need = (size_t)cryst_corr_workspace_bytes(std::min(chunk, n_frames), corr.n_excl);
+        const size_t need = (size_t)cryst_corr_workspace_bytes(p->h, p->w, std::min(chunk, n_frames), corr.n_excl);
         if (need > p->corr_ws_bytes) {
             if (p->corr_ws) {
                 LTMI_HIP(hipStreamSynchronize(stream));
@@ -437,9 +442,10 @@ static int crystallinity_impl(ltmi_fft_plan *p, const void *tile, int tile_dtype
             const int64_t n = std::min(chunk, n_frames - f0);
             bool handled = false;
             const int rc = cryst_fused_corrected((const char *)tile + (size_t)f0 * ld_tile * esz, tile_dtype, n, ld_tile,
-                                                 corr.dark, corr.gain, corr.excl, corr.env, corr.cnt, corr.n_excl,
-                                                 corr.max_env, real_mask, half_mask, n_cols, p->mask_t, p->corr_ws,
-                                                 out + f0, accumulate, p->n_cu, stream, &handled);
+                                                 p->h, p->w, corr.dark, corr.gain, corr.excl, corr.env, corr.cnt,
+                                                 corr.n_excl, corr.max_env, real_mask, half_mask, n_cols, p->mask_t,
+                                                 p->spec, p->batch, p->corr_ws, out + f0, accumulate, p->n_cu, stream,
+                                                 &handled);
             if (rc != LTMI_OK) return rc;
             if (!handled) {
                 if (f0 != 0) LTMI_FAIL(LTMI_E_INVALID, "ltmi_crystallinity: the fused kernel refused a later chunk");
@@ -447,8 +453,12 @@ static int crystallinity_impl(ltmi_fft_plan *p, const void *tile, int tile_dtype
             }
         }
         if (all) {
-            snprintf(p->last_kernel, sizeof(p->last_kernel), "k_cryst_fused<%s,corrected%s> columns=%d patches=%d",
-                     dtype_name(tile_dtype), real_mask ? ",mask" : "", n_cols, corr.n_excl);
+            if (need_g)
+                snprintf(p->last_kernel, sizeof(p->last_kernel), "k_cryst_rows%d<%s,corrected%s> + k_cryst_cols%d columns=%d patches=%d",
+                         p->w, dtype_name(tile_dtype), real_mask ? ",mask" : "", p->h, n_cols, corr.n_excl);
+            else
+                snprintf(p->last_kernel, sizeof(p->last_kernel), "k_cryst_fused%s<%s,corrected%s> columns=%d patches=%d",
+                         p->h == 128 ? "128" : "", dtype_name(tile_dtype), real_mask ? ",mask" : "", n_cols, corr.n_excl);
             return LTMI_OK;
         }
     }

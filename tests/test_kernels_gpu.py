@@ -1757,9 +1757,10 @@ def test_crystallinity_fused_kernel_128_many_frames_and_every_bin(hip):
 @pytest.mark.gpu
 @pytest.mark.parametrize('sig', [128, 256, 512])
 def test_crystallinity_corrected_and_float64_frames_take_the_fused_kernel(hip, sig):
-    """ltmi_crystallinity_corrected on raw frames (dark / gain / dead-pixel patches) and float64 frames: the
-    conversion pass writes corrected float32 frames, the fused kernel transforms those -- against the oracle's
-    corrections + float64 rfft2, more frames than one batch."""
+    """ltmi_crystallinity_corrected on raw frames (dark / gain / dead-pixel patches): the corrections run inside the
+    row stage of the fused kernels (round 5; LTMI_CRYST_CORR_PASS=1: the conversion pass writes corrected float32
+    frames first); float64 frames still take the conversion pass -- against the oracle's corrections + float64
+    rfft2, more frames than one batch / one round of workgroups."""
     from libertem_amd.io.corrections import CorrectionSet
     from libertem_amd.udf.crystallinity import mask_box
     from oracle import corrections as oc
@@ -1786,13 +1787,12 @@ def test_crystallinity_corrected_and_float64_frames_take_the_fused_kernel(hip, s
         plan.crystallinity_corrected(t.data_ptr(), data.dtype, n, sig * sig, tables, rm.data_ptr(), hm.data_ptr(),
                                      mask_box(half), out.data_ptr(), False)
         torch.cuda.synchronize()
-        if sig == 256:
-            # round 5: the corrections run inside the row stage of the fused kernel -- one pass over the raw pixels
-            assert plan.last_kernel().startswith('k_cryst_fused<uint16,corrected'), plan.last_kernel()
-        else:
-            assert plan.last_kernel().startswith('k_fft_prepare<uint16> + k_cryst_'), plan.last_kernel()
+        # round 5: the corrections run inside the row stage of the fused kernels -- one pass over the raw pixels
+        want = {128: 'k_cryst_fused128<uint16,corrected', 256: 'k_cryst_fused<uint16,corrected',
+                512: 'k_cryst_rows512<uint16,corrected'}[sig]
+        assert plan.last_kernel().startswith(want), plan.last_kernel()
         assert np.allclose(out.cpu().numpy(), ref, rtol=1e-5), sorted(kw)
-        if sig == 256:
+        if True:
             # ... and agrees with the conversion pass + the same kernel on corrected float32 frames
             os.environ['LTMI_CRYST_CORR_PASS'] = '1'
             try:
@@ -1800,7 +1800,7 @@ def test_crystallinity_corrected_and_float64_frames_take_the_fused_kernel(hip, s
                 plan.crystallinity_corrected(t.data_ptr(), data.dtype, n, sig * sig, tables, rm.data_ptr(),
                                              hm.data_ptr(), mask_box(half), out2.data_ptr(), False)
                 torch.cuda.synchronize()
-                assert plan.last_kernel().startswith('k_fft_prepare<uint16> + k_cryst_fused'), plan.last_kernel()
+                assert plan.last_kernel().startswith('k_fft_prepare<uint16> + k_cryst_'), plan.last_kernel()
                 assert np.allclose(out2.cpu().numpy(), out.cpu().numpy(), rtol=2e-6)
             finally:
                 del os.environ['LTMI_CRYST_CORR_PASS']
@@ -1811,9 +1811,9 @@ def test_crystallinity_corrected_and_float64_frames_take_the_fused_kernel(hip, s
             torch.cuda.synchronize()
             assert np.allclose(out3.cpu().numpy(), 2 * ref, rtol=1e-5)
         plan.close()
-    if sig == 256:
+    if sig in (128, 256, 512):
         # many frames (more than one round of workgroups), float32 / uint8 pixels, no real-space mask, many dead pixels
-        n2 = 700
+        n2 = {128: 1500, 256: 700, 512: 150}[sig]
         for dt, hi in ((np.float32, None), (np.uint8, 200)):
             d2 = (rng.random((n2, sig, sig)) * 100).astype(dt) if hi is None else \
                 rng.integers(0, hi, (n2, sig, sig)).astype(dt)
@@ -1829,7 +1829,7 @@ def test_crystallinity_corrected_and_float64_frames_take_the_fused_kernel(hip, s
             plan.crystallinity_corrected(t.data_ptr(), d2.dtype, n2, sig * sig, tables, None, hm.data_ptr(),
                                          mask_box(half2), out.data_ptr(), False)
             torch.cuda.synchronize()
-            assert plan.last_kernel().startswith('k_cryst_fused<') and 'corrected' in plan.last_kernel()
+            assert plan.last_kernel().startswith('k_cryst_') and 'corrected' in plan.last_kernel(), plan.last_kernel()
             assert np.allclose(out.cpu().numpy(), ref2, rtol=1e-5), dt
             plan.close()
     frames = rng.normal(size=(n, sig, sig)) * 50
