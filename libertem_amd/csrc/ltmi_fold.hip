@@ -30,6 +30,7 @@
 #include <vector>
 #include <cstdlib>
 #include <type_traits>
+#include <typeinfo>
 
 namespace ltmi {
 
@@ -248,6 +249,10 @@ k_dense_fold(const float *__restrict__ tile, int64_t ld, int64_t n_frames, int s
                     for (int g = 0; g < NG; ++g)
                         acc[tl][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                             g < NGE ? e[j] : o[j], fb.b[g][j >> 2][j & 3], acc[tl][g], 0, 0, 0);
+#ifdef FD_SCHED_GROUPS
+                __builtin_amdgcn_sched_group_barrier(0x002, FD_SCHED_GROUPS, 0);     // the folds, then the MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x008, 8 * NG, 0);
+#endif
             }
         };
 
@@ -292,7 +297,7 @@ k_dense_fold(const float *__restrict__ tile, int64_t ld, int64_t n_frames, int s
             }
             __builtin_amdgcn_sched_barrier(0);
             mfma_block(f1, w1, TL);
-            if (tl == 1 && ++since_flush == 16) {            // second accumulation level every 1024 folded pixels
+            if (tl == 1 && ++since_flush == 8) {             // second accumulation level every 512 folded pixels
                 since_flush = 0;
 #pragma unroll
                 for (int t2 = 0; t2 < FD_TILES; ++t2)
@@ -353,6 +358,258 @@ k_dense_fold(const float *__restrict__ tile, int64_t ld, int64_t n_frames, int s
         }
 }
 
+
+// ---- 2-byte integer pixels (uint16 / int16 detectors) -------------------------------------------------------------------
+// Radial-Fourier stacks keep the float32 matrix instruction for integer pixels too (their zero crossings hold more
+// weights than the float16 pieces' float32 tail takes), so uint16 frames x 50 columns ran at 0.28 - 0.31 of HBM, bound
+// by the same 24 + VALU matrix instructions per 32 pixels as C5.  The fold applies unchanged -- the pixels are
+// converted to float32 first, a + c and a - c of integers below 2^17 are exact -- with 256-byte row pieces of 128
+// pixels: a stage is 128 folded pixels, its mask slot (NG x 16 x 128 weights, the 128-pixel unit swizzle of
+// k_dense_lds) 32 KiB for four groups, the ring three half-stages (one multiplied, two on their way: half the bytes
+// per matrix instruction of the float32 case).  Plain loop (no software pipelining: the kernel is bound by its
+// matrix instructions): wait, barrier per stage, issue, four blocks with double-buffered fragments.
+constexpr int FD16_KB = 128;
+constexpr int FD16_RING = 3;
+__host__ __device__ constexpr int fold16_slot_bytes(int ng) { return ng * GROUP * FD16_KB * 4; }
+__host__ __device__ constexpr int fold16_lds_bytes(int ng) { return FD16_RING * FD_HALF + 2 * fold16_slot_bytes(ng); }
+__host__ __device__ static inline int fold16_index(int n, int q) {
+    const int blk = q >> 5, kg = (q >> 3) & 3, j = q & 7;
+    const int unit = (kg * 8 + blk * 2 + (j >> 2)) ^ (n & 7);
+    return n * FD16_KB + unit * 4 + (j & 3);
+}
+
+__global__ void k_build_fold_image16(const float *__restrict__ src, float *__restrict__ img, int cpm, int64_t n_px,
+                                     int sig_w, int n_fold_rows, const int2 *__restrict__ rows,
+                                     const int *__restrict__ colmap, int ng) {
+    const int64_t total = (int64_t)ng * GROUP * n_fold_rows * sig_w;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pf = i % ((int64_t)n_fold_rows * sig_w);
+        const int v = (int)(i / ((int64_t)n_fold_rows * sig_w));
+        const int col = colmap[v];
+        const int fy = (int)(pf / sig_w), x = (int)(pf % sig_w);
+        float w = 0.f;
+        if (col >= 0) {
+            const int64_t k = col / cpm, part = col % cpm;
+            w = src[(k * n_px + (int64_t)rows[fy].x * sig_w + x) * cpm + part];
+        }
+        const int64_t slot = pf / FD16_KB;
+        const int q = (int)(pf % FD16_KB);
+        img[(slot * ng + v / GROUP) * (GROUP * FD16_KB) + fold16_index(v % GROUP, q)] = w;
+    }
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T, int NGE, int NGO>
+__global__ void __launch_bounds__(FD_WAVES * 64)
+k_dense_fold16(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int spr /* stages (128 px) per row */,
+               const int2 *__restrict__ fold_rows, const float *__restrict__ img, int n_stages,
+               float *__restrict__ out, int64_t ld_out, int n_cols, const int *__restrict__ colmap,
+               int accumulate, float *__restrict__ partials, int ksplit,
+               const unsigned char *__restrict__ zeros, const int32_t *__restrict__ rows) {
+    static_assert(sizeof(T) == 2, "2-byte pixels");
+    constexpr int NG = NGE + NGO;
+    constexpr int BSLOT = fold16_slot_bytes(NG);
+    constexpr int NBI = BSLOT / FD_WAVES / 1024;
+    constexpr int NDH = 16 / 4, NF = 2 * NDH;
+    constexpr int NB = FD16_KB / 32;                      // 32-pixel blocks per stage
+    static_assert(NF + NBI < 64, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int m = lane & 15, kg = lane >> 4;
+    const int ks = blockIdx.y;
+    const int per = (n_stages + ksplit - 1) / ksplit;
+    const int s_begin = ks * per;
+    const int s_end = min(n_stages, s_begin + per);
+
+    const int64_t f_wave = (int64_t)blockIdx.x * FD_WG_ROWS + wave * FD_ROWS;
+    auto frame_of = [&](int r) -> int64_t {
+        const int64_t f = f_wave + r;
+        return f < n_frames ? f : -1;
+    };
+    auto src_frame_of = [&](int r) -> int64_t {
+        int64_t f = frame_of(r);
+        if (rows) return f < 0 ? (int64_t)rows[0] : (int64_t)rows[f];
+        return f < 0 ? n_frames - 1 : f;
+    };
+    unsigned char *a_base = lds_raw + wave * (2 * FD_TPART);                // + q * FD_HALF
+    unsigned char *b_base = lds_raw + FD16_RING * FD_HALF;                  // + slot * BSLOT
+
+    f32x4 acc[FD_TILES][NG], acc2[FD_TILES][NG];
+#pragma unroll
+    for (int tl = 0; tl < FD_TILES; ++tl)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[tl][g] = acc2[tl][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (s_begin < s_end) {
+        const unsigned char *src[FD_TILES][NDH];
+#pragma unroll
+        for (int tl = 0; tl < FD_TILES; ++tl)
+#pragma unroll
+            for (int t = 0; t < NDH; ++t) {
+                const int r = 4 * t + lane / 16;
+                const int piece = (lane & 15) ^ r;
+                src[tl][t] = (const unsigned char *)(tile + src_frame_of(tl * 16 + r) * ld) + piece * 16;
+            }
+        const unsigned char *zsrc = zeros + lane * 16;
+        const unsigned char *bsrc = (const unsigned char *)img + wave * (BSLOT / FD_WAVES) + lane * 16;
+
+        int iss = s_begin, iss_fy = s_begin / spr, iss_xs = s_begin % spr;
+        auto issue_half = [&](auto TL, int q) {
+            constexpr int tl = decltype(TL)::value;
+            const int2 rr = fold_rows[iss_fy];
+            const int64_t off_a = ((int64_t)rr.x * spr + iss_xs) * 256;
+            const int64_t off_c = ((int64_t)rr.y * spr + iss_xs) * 256;
+            const bool pair = rr.y >= 0;
+            unsigned char *da = a_base + q * FD_HALF, *dc = da + FD_TPART;
+#pragma unroll
+            for (int t = 0; t < NDH; ++t)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[tl][t] + off_a), (lds_ptr_t)(da + t * 1024), 16, 0,
+                                                 2 /*nt*/);
+#pragma unroll
+            for (int t = 0; t < NDH; ++t) {
+                const unsigned char *p = pair ? src[tl][t] + off_c : zsrc;
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)p, (lds_ptr_t)(dc + t * 1024), 16, 0, 2 /*nt*/);
+            }
+            if (tl == FD_TILES - 1 && iss + 1 < s_end) {
+                ++iss;
+                if (++iss_xs == spr) { iss_xs = 0; ++iss_fy; }
+            }
+        };
+        auto issue_b = [&](int s, int bslot) {
+            unsigned char *db = b_base + bslot * BSLOT + wave * (BSLOT / FD_WAVES);
+            const unsigned char *sp = bsrc + (int64_t)min(s, s_end - 1) * BSLOT;
+#pragma unroll
+            for (int u = 0; u < NBI; ++u)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(sp + u * 1024), (lds_ptr_t)(db + u * 1024), 16, 0, 0);
+        };
+
+        const int a_lane = m * 256;
+        const int b_lane = m * FD16_KB;
+        auto b_unit = [&](int blk, int h) { return ((kg * 8 + blk * 2 + h) ^ (m & 7)) << 2; };
+        auto to_float = [&](const u32x4 &r, float (&f)[8]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (std::is_signed<T>::value) {
+                    f[2 * i] = (float)(int)(short)(r[i] & 0xffffu);
+                    f[2 * i + 1] = (float)((int)r[i] >> 16);
+                } else {
+                    f[2 * i] = (float)(r[i] & 0xffffu);
+                    f[2 * i + 1] = (float)(r[i] >> 16);
+                }
+            }
+        };
+
+        // one tile (16 frames) of one stage: NB blocks of 32 folded pixels x NG groups
+        auto compute = [&](auto TL, int q, int bslot) {
+            constexpr int tl = decltype(TL)::value;
+            const unsigned char *as = a_base + q * FD_HALF + a_lane;
+            const unsigned char *cs = as + FD_TPART;
+            const float *bs = (const float *)(b_base + bslot * BSLOT) + b_lane;
+            u32x4 ra[2], rc[2];
+            f32x4 rb[2][NG][2];
+            auto load_block = [&](int blk, int buf) {
+                const int u = blk * 4 + kg;                  // 8-pixel unit (16 bytes) of this lane inside the part
+                ra[buf] = *(const u32x4 *)(as + ((u ^ m) << 4));
+                rc[buf] = *(const u32x4 *)(cs + ((u ^ m) << 4));
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    rb[buf][g][0] = *(const f32x4 *)(bs + g * (GROUP * FD16_KB) + b_unit(blk, 0));
+                    rb[buf][g][1] = *(const f32x4 *)(bs + g * (GROUP * FD16_KB) + b_unit(blk, 1));
+                }
+            };
+            load_block(0, 0);
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                const int cur = blk & 1;
+                if (blk + 1 < NB) load_block(blk + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                float fa[8], fc[8], e[8], o[8];
+                to_float(ra[cur], fa);
+                to_float(rc[cur], fc);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { e[j] = fa[j] + fc[j]; o[j] = fa[j] - fc[j]; }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                        acc[tl][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(g < NGE ? e[j] : o[j], rb[cur][g][j >> 2][j & 3],
+                                                                          acc[tl][g], 0, 0, 0);
+                // conversions and folds as one group ahead of the block's matrix instructions (a VALU operation in
+                // front of every MFMA costs 15 % of the pipe, probes/mfma_probe.hip)
+                __builtin_amdgcn_sched_group_barrier(0x002, 16 + (NGO > 0 ? 16 : 8), 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8 * NG, 0);
+            }
+        };
+
+        // Copies are issued in the order  step h, tl = 0: B(s + 1), F(h + 2)   tl = 1: F(h + 2); at the start of step h
+        // the copies younger than F(h) (and, tl = 0, than B(s)) are  tl = 0: F(h + 1)   tl = 1: B(s + 1), F(h + 1)
+        int since_flush = 0;
+        auto step = [&](auto TL, int q, int bslot, int s) {
+            constexpr int tl = decltype(TL)::value;
+            if (tl == 0) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NF) : "memory");
+                __builtin_amdgcn_s_barrier();                // everybody's quarter of B(s) is there, B(s - 1) is free
+                issue_b(s + 1, bslot ^ 1);
+            } else {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NF + NBI) : "memory");
+            }
+            issue_half(std::integral_constant<int, tl>{}, q == 0 ? FD16_RING - 1 : q - 1);   // F(h + 2) -> the slot of h - 1
+            compute(TL, q, bslot);
+            if (tl == 1 && ++since_flush == 4) {             // second accumulation level every 512 folded pixels (the folded
+                                                             // values are twice the pixels': a constant full-scale frame on an
+                                                             // all-positive column drifted to 1.0e-5 with chains of 1024)
+                since_flush = 0;
+#pragma unroll
+                for (int t2 = 0; t2 < FD_TILES; ++t2)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        acc2[t2][g] += acc[t2][g];
+                        acc[t2][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        issue_b(s_begin, 0);
+        issue_half(I0{}, 0);
+        issue_half(I1{}, 1);
+        int q = 0, bslot = 0;
+        for (int s = s_begin; s < s_end; ++s) {
+            step(I0{}, q, bslot, s);
+            q = q + 1 == FD16_RING ? 0 : q + 1;
+            step(I1{}, q, bslot, s);
+            q = q + 1 == FD16_RING ? 0 : q + 1;
+            bslot ^= 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+
+#pragma unroll
+    for (int tl = 0; tl < FD_TILES; ++tl)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int col = colmap[g * GROUP + m];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t f = frame_of(tl * 16 + kg * 4 + r);
+                if (f >= 0 && col >= 0) {
+                    const float v = acc[tl][g][r] + acc2[tl][g][r];
+                    if (ksplit == 1) {
+                        float *p = out + f * ld_out + col;
+                        *p = accumulate ? (*p + v) : v;
+                    } else {
+                        partials[((int64_t)ks * n_frames + f) * n_cols + col] = v;
+                    }
+                }
+            }
+        }
+}
+
 }  // namespace ltmi
 
 using namespace ltmi;
@@ -368,6 +625,9 @@ struct FoldImage {
     int *colmap = nullptr;                       // virtual column -> real column or -1
     unsigned char *zeros = nullptr;              // 1 KiB: the partner of unpaired rows
     size_t img_bytes = 0;
+    float *img16 = nullptr;                      // the image in 128-pixel slots (2-byte pixels), built on first use
+    int n_stages16 = 0;
+    bool img16_failed = false;
 };
 
 void ltmi::fold_destroy(ltmi_masks *m) {
@@ -377,6 +637,7 @@ void ltmi::fold_destroy(ltmi_masks *m) {
     if (f->rows) (void)hipFree(f->rows);
     if (f->colmap) (void)hipFree(f->colmap);
     if (f->zeros) (void)hipFree(f->zeros);
+    if (f->img16) (void)hipFree(f->img16);
     delete f;
     m->fold = nullptr;
 }
@@ -530,3 +791,91 @@ int ltmi::launch_fold(ltmi_masks *m, const float *tile, int64_t n_frames, int64_
     LTMI_FAIL(LTMI_E_INVALID, "k_dense_fold: no kernel for %d + %d groups", f->nge, f->ngo);
 }
 
+// ---- 2-byte pixels ------------------------------------------------------------------------------------------------
+bool ltmi::fold_takes16(ltmi_masks *m, const void *tile, int64_t ld) {
+    FoldImage *f = (FoldImage *)m->fold;
+    if (!f || m->tune_ksplit_ring == 38 || f->img16_failed) return false;
+    if (f->sig_w % FD16_KB != 0 || ((uintptr_t)tile % 16 != 0) || (ld * 2) % 16 != 0) return false;
+    if (!f->img16) {
+        // built on the first 2-byte tile (a stack that only ever sees float32 frames does not pay for it)
+        const int cpm = m->result_dtype == LTMI_C64 ? 2 : 1;
+        const int ng = f->nge + f->ngo;
+        f->n_stages16 = f->n_fold_rows * (f->sig_w / FD16_KB);
+        const size_t bytes = (size_t)f->n_stages16 * ltmi::fold16_slot_bytes(ng);
+        hipError_t e = hipMalloc((void **)&f->img16, bytes);
+        if (e == hipSuccess) {
+            const int64_t tot = (int64_t)ng * GROUP * f->n_fold_rows * f->sig_w;
+            const unsigned bl = (unsigned)std::min<int64_t>((tot + 255) / 256, 65535 * 16);
+            hipLaunchKernelGGL(ltmi::k_build_fold_image16, dim3(bl), dim3(256), 0, 0, (const float *)m->gmasks, f->img16,
+                               cpm, m->n_px, f->sig_w, f->n_fold_rows, (const int2 *)f->rows, (const int *)f->colmap, ng);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+        }
+        if (e != hipSuccess) {
+            if (f->img16) (void)hipFree(f->img16);
+            f->img16 = nullptr;
+            f->img16_failed = true;
+            (void)hipGetLastError();
+            return false;
+        }
+    }
+    return true;
+}
+
+template <typename T, int NGE, int NGO>
+static int launch_fold16_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out, int64_t ld_out,
+                           int accumulate, hipStream_t stream) {
+    const FoldImage *f = (const FoldImage *)m->fold;
+    auto kern = k_dense_fold16<T, NGE, NGO>;
+    constexpr int LDS = ltmi::fold16_lds_bytes(NGE + NGO);
+    static bool attr_set[16] = {false};
+    if (!attr_set[m->device & 15]) {
+        LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set[m->device & 15] = true;
+    }
+    const int64_t gx = (n_frames + FD_WG_ROWS - 1) / FD_WG_ROWS;
+    int ksplit = m->tune_ksplit;
+    if (ksplit <= 0) ksplit = choose_ksplit(gx, f->n_stages16);
+    ksplit = std::max(1, std::min(ksplit, f->n_stages16));
+    {
+        const int per = (f->n_stages16 + ksplit - 1) / ksplit;
+        ksplit = (f->n_stages16 + per - 1) / per;
+    }
+    if (ksplit > 1) {
+        int rc = dense_ensure_partials(m, (size_t)ksplit * n_frames * m->n_cols * sizeof(float), stream);
+        if (rc != LTMI_OK) return rc;
+    }
+    dim3 grid((unsigned)gx, (unsigned)ksplit);
+    hipLaunchKernelGGL(kern, grid, dim3(FD_WAVES * 64), LDS, stream, tile, ld, n_frames, f->sig_w / FD16_KB,
+                       (const int2 *)f->rows, (const float *)f->img16, f->n_stages16, out, ld_out, m->n_cols,
+                       (const int *)f->colmap, accumulate, dense_partial_sums(m), ksplit,
+                       (const unsigned char *)f->zeros, m->roi_rows);
+    LTMI_HIP(hipGetLastError());
+    snprintf(m->last_kernel, sizeof(m->last_kernel), "k_dense_fold16<%s,even=%d,odd=%d,rows %d+%d=%d%s> grid=(%u,%u)",
+             typeid(T).name(), NGE, NGO, f->n_fold_rows, f->sig_h - f->n_fold_rows, f->c2, m->roi_rows ? ",rows" : "",
+             grid.x, grid.y);
+    if (ksplit > 1) {
+        const int rc = dense_reduce_partials(m, ksplit, n_frames, out, ld_out, accumulate, stream);
+        if (rc != LTMI_OK) return rc;
+    }
+    return LTMI_OK;
+}
+
+template <typename T>
+static int launch_fold16_any(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out, int64_t ld_out,
+                             int accumulate, hipStream_t stream) {
+    const FoldImage *f = (const FoldImage *)m->fold;
+#define LTMI_FOLD_CASE(E_, O_)                                                                                 \
+    if (f->nge == E_ && f->ngo == O_)                                                                          \
+        return launch_fold16_t<T, E_, O_>(m, tile, n_frames, ld, out, ld_out, accumulate, stream);
+    LTMI_FOLD_CASE(1, 0) LTMI_FOLD_CASE(2, 0) LTMI_FOLD_CASE(3, 0) LTMI_FOLD_CASE(4, 0)
+    LTMI_FOLD_CASE(1, 1) LTMI_FOLD_CASE(2, 1) LTMI_FOLD_CASE(1, 2) LTMI_FOLD_CASE(2, 2)
+#undef LTMI_FOLD_CASE
+    LTMI_FAIL(LTMI_E_INVALID, "k_dense_fold16: no kernel for %d + %d groups", f->nge, f->ngo);
+}
+
+int ltmi::launch_fold16(ltmi_masks *m, const void *tile, bool is_signed, int64_t n_frames, int64_t ld, float *out,
+                        int64_t ld_out, int accumulate, hipStream_t stream) {
+    return is_signed ? launch_fold16_any<int16_t>(m, (const int16_t *)tile, n_frames, ld, out, ld_out, accumulate, stream)
+                     : launch_fold16_any<uint16_t>(m, (const uint16_t *)tile, n_frames, ld, out, ld_out, accumulate, stream);
+}

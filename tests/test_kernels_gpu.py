@@ -2118,3 +2118,46 @@ def test_row_mirror_fold_wide_stack_in_column_blocks(hip):
     for part in (np.real, np.imag):
         assert np.all(np.abs(part(res) - part(ref)) <= 1e-5 * scale + 1e-30)
         assert np.all(np.abs(part(res_u) - part(ref)) <= 1e-5 * scale + 1e-30)
+
+
+@pytest.mark.parametrize('tile_dtype', ['uint16', 'int16'])
+@pytest.mark.parametrize('sig,n_bins,max_order,n_frames,ksplit', [
+    ((128, 128), 1, 24, 300, 0),        # 25 complex masks: 2 even + 2 odd groups, one 128-pixel stage per row
+    ((64, 256), 1, 24, 130, 3),         # two stages per row, pixel axis split
+    ((96, 128), 2, 7, 70, 0),           # 16 complex masks: 1 + 1 groups
+])
+def test_row_mirror_fold_two_byte_pixels(hip, tile_dtype, sig, n_bins, max_order, n_frames, ksplit):
+    """k_dense_fold16: uint16 / int16 frames of a radial-Fourier stack (which keeps the float32 matrix instruction: its
+    zero crossings hold more small weights than the float16 pieces' tail takes) through the row-mirror fold -- against
+    float64, the unfolded kernel (tuning 38) and, one-pixel frames over every pixel, every stored weight."""
+    masks = _radial_stack(sig, n_bins, max_order)
+    rng = np.random.default_rng(_seed('fold16', tile_dtype, sig, n_bins))
+    dt = np.dtype(tile_dtype)
+    lo, hi = (0, 65535) if dt.kind == 'u' else (-32768, 32767)
+    data = rng.integers(lo, hi, (n_frames, sig[0] * sig[1]), endpoint=True).astype(dt)
+    data[1] = hi
+    data[2] = lo
+    res, kern = _fold_apply(hip, data, masks, sig, np.complex64, tuning=dict(mt=0, waves=30, ksplit=ksplit))
+    assert 'k_dense_fold16' in kern, kern
+    res_u, kern_u = _fold_apply(hip, data, masks, sig, np.complex64, tuning=dict(mt=0, waves=38, ksplit=0))
+    assert 'k_dense_fold' not in kern_u, kern_u
+    ref = _ref64(data, masks)
+    scale = np.abs(data.astype(np.float64)) @ np.abs(masks).astype(np.float64).T
+    for part in (np.real, np.imag):
+        assert np.all(np.abs(part(res) - part(ref)) <= 1e-5 * scale + 1e-30)
+        assert np.all(np.abs(part(res) - part(res_u)) <= 2e-5 * scale + 1e-30)
+    base = (rng.random((n_frames, masks.shape[0])) + 1j * rng.random((n_frames, masks.shape[0]))).astype(np.complex64)
+    res2, _ = _fold_apply(hip, data, masks, sig, np.complex64, accumulate_into=base,
+                          tuning=dict(mt=0, waves=30, ksplit=ksplit))
+    assert np.all(np.abs(res2 - (ref + base)) <= 1e-5 * (scale + 2))
+    # every stored weight: one-pixel frames (the mirrored half, the unpaired rows included), rtol 1e-5, atol 0
+    n_px = sig[0] * sig[1]
+    vals = rng.integers(1, hi, n_px, endpoint=True).astype(dt)
+    one = np.zeros((n_px, n_px), dtype=dt)
+    one[np.arange(n_px), np.arange(n_px)] = vals
+    r1, k1 = _fold_apply(hip, one, masks, sig, np.complex64)
+    assert 'k_dense_fold16' in k1, k1
+    want = masks.T.astype(np.complex128) * vals[:, None].astype(np.float64)
+    for part in (np.real, np.imag):
+        g, w = part(r1).astype(np.float64), part(want)
+        assert np.all(np.abs(g - w) <= 1e-5 * np.abs(w)), np.max(np.abs(g - w) / np.maximum(np.abs(w), 1e-300))
