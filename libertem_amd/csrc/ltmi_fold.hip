@@ -249,10 +249,9 @@ k_dense_fold(const float *__restrict__ tile, int64_t ld, int64_t n_frames, int s
                     for (int g = 0; g < NG; ++g)
                         acc[tl][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                             g < NGE ? e[j] : o[j], fb.b[g][j >> 2][j & 3], acc[tl][g], 0, 0, 0);
-#ifdef FD_SCHED_GROUPS
-                __builtin_amdgcn_sched_group_barrier(0x002, FD_SCHED_GROUPS, 0);     // the folds, then the MFMAs
+                // the folds as one group ahead of the block's matrix instructions (6.41 - 6.60 -> 6.26 - 6.48 ms on C5)
+                __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 8 * NG, 0);
-#endif
             }
         };
 
