@@ -560,7 +560,7 @@ def crystallinity(torch, hip, reps=10):
     out) for 256 x 256 frames (k_cryst_fused), 128 x 128 frames (k_cryst_fused128) 512 x 512 and 1024 x 1024 frames
     (k_cryst_rows<N> + k_cryst_cols<N>), the hipFFT route of the same call beside each (LTMI_FFT_FUSED is read per plan)."""
     from libertem_amd.udf.crystallinity import crystallinity_masks, mask_box
-    res = {"bound": "vector ALUs + LDS (profiles/r04_crystallinity.txt): the pixels are read once"}
+    res = {"bound": "vector ALUs + LDS (profiles/r04_crystallinity.txt, r05_crystallinity.txt): the pixels are read once"}
     for sig, n in ((256, 16384), (128, 65536), (512, 4096), (1024, 1024)):
         g = torch.Generator(device='cuda').manual_seed(1)
         frames = torch.randint(0, 4096, (n, sig, sig), generator=g, device='cuda', dtype=torch.int16)
@@ -608,6 +608,57 @@ def crystallinity(torch, hip, reps=10):
                       "check_rel_err_vs_float64": err}
             plan.close()
         r["speedup"] = r["hipfft_route"]["avg_call_ms"] / r["fused"]["avg_call_ms"]
+        # RAW frames with detector corrections (dark + gain + 50 dead pixels): inside the row stage of the fused
+        # kernels (round 5), through the conversion pass of round 4, through hipFFT
+        try:
+            from libertem_amd.io.corrections import CorrectionSet
+            from oracle import corrections as oc
+            crng = np.random.default_rng(3)
+            bad = np.zeros((sig, sig), dtype=bool)
+            bad[crng.integers(0, sig, 50), crng.integers(0, sig, 50)] = True
+            dark, gain = crng.random((sig, sig)) * 6, crng.random((sig, sig)) * 0.6 + 0.7
+            tables = CorrectionSet(dark=dark, gain=gain, excluded_pixels=bad).device_tables(0, (sig, sig))
+            fr2 = frames[[0, n - 1]].cpu().numpy().view(np.uint16)
+            fixed = oc.correct(fr2, (sig, sig), dark=dark, gain=gain,
+                               coords=[tuple(c) for c in np.argwhere(bad)]).reshape(2, sig, sig)
+            ref_c = np.array([np.sum(abs(np.fft.rfft2(f.astype(np.float64) * real_mask)) * half) for f in fixed])
+            corr = {}
+            for key, envs in (("row_stage", {}), ("conversion_pass", {"LTMI_CRYST_CORR_PASS": "1"}),
+                              ("hipfft_route", {"LTMI_FFT_FUSED": "0"})):
+                saved = {k: os.environ.get(k) for k in envs}
+                os.environ.update(envs)
+                try:
+                    plan = hip.FFTPlan(0, sig, sig, 1024)
+
+                    def run_c():
+                        plan.crystallinity_corrected(frames.data_ptr(), np.uint16, n, sig * sig, tables, rm.data_ptr(),
+                                                     hm.data_ptr(), box, out.data_ptr(), False)
+                    run_c(); run_c()
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(reps):
+                        run_c()
+                    e1.record()
+                    e1.synchronize()
+                    ms = e0.elapsed_time(e1) / reps
+                    got = out[[0, n - 1]].cpu().numpy()
+                    err = float(np.abs(got - ref_c).max() / np.abs(ref_c).max())
+                    if not err < 1e-5:
+                        raise SystemExit(f"bench.py: corrected crystallinity check failed ({sig}, {key}): {err:.3e}")
+                    corr[key] = {"kernel": plan.last_kernel(), "avg_call_ms": ms, "frames_per_s": n / ms * 1e3,
+                                 "check_rel_err_vs_float64": err}
+                    plan.close()
+                finally:
+                    for k, v in saved.items():
+                        if v is None:
+                            os.environ.pop(k, None)
+                        else:
+                            os.environ[k] = v
+            corr["speedup_vs_hipfft"] = corr["hipfft_route"]["avg_call_ms"] / corr["row_stage"]["avg_call_ms"]
+            r["corrected_raw_frames"] = corr
+        except BaseException as e:                    # noqa: BLE001  (never sinks the entry)
+            r["corrected_raw_frames"] = {"error": repr(e)[:300]}
         res[f"frames_{sig}"] = r
         del frames, out
         torch.cuda.empty_cache()
