@@ -143,9 +143,9 @@ void fold_destroy(ltmi_masks *m);
 bool fold_takes(const ltmi_masks *m, const float *tile, int64_t ld);
 int launch_fold(ltmi_masks *m, const float *tile, int64_t n_frames, int64_t ld, float *out, int64_t ld_out,
                 int accumulate, hipStream_t stream);
-bool fold_takes16(ltmi_masks *m, const void *tile, int64_t ld);             // uint16 / int16 frames (image built on first use)
-int launch_fold16(ltmi_masks *m, const void *tile, bool is_signed, int64_t n_frames, int64_t ld, float *out,
-                  int64_t ld_out, int accumulate, hipStream_t stream);
+bool fold_takes16(ltmi_masks *m, const void *tile, int64_t ld, int px_bytes);   // 1- / 2-byte integer frames (image built on first use)
+int launch_fold16(ltmi_masks *m, const void *tile, int px_bytes, bool is_signed, int64_t n_frames, int64_t ld,
+                  float *out, int64_t ld_out, int accumulate, hipStream_t stream);
 // the K-split workspace of a dense handle (ltmi_dense.hip)
 int dense_ensure_partials(ltmi_masks *m, size_t need, hipStream_t stream);
 float *dense_partial_sums(const ltmi_masks *m);

@@ -1989,10 +1989,11 @@ static int launch_lds(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld
     }
     // ... and 2-byte integer frames of such a stack when it keeps the float32 matrix instruction (no float16
     // images: more small weights than their float32 tail takes -- radial-Fourier stacks) or is told to
-    if constexpr (sizeof(T) == 2 && std::is_integral<T>::value) {
+    if constexpr (sizeof(T) <= 2 && std::is_integral<T>::value) {
         const bool x16 = (m->img_h || m->img2_h || m->img3_h) && !f32_instruction_only(m);
-        if (!x16 && m->fold && fold_takes16(m, tile, ld))
-            return launch_fold16(m, tile, std::is_signed<T>::value, n_frames, ld, out, ld_out, accumulate, stream);
+        if (!x16 && m->fold && fold_takes16(m, tile, ld, (int)sizeof(T)))
+            return launch_fold16(m, tile, (int)sizeof(T), std::is_signed<T>::value, n_frames, ld, out, ld_out,
+                                 accumulate, stream);
     }
     if (m->ng == 1) {
         // at most 4 columns (CoM: 3, single-mask analyses: 1 or 2): all of them on the VALU -- a

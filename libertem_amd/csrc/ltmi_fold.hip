@@ -370,7 +370,9 @@ k_dense_fold(const float *__restrict__ tile, int64_t ld, int64_t n_frames, int s
 constexpr int FD16_KB = 128;
 constexpr int FD16_RING = 3;
 __host__ __device__ constexpr int fold16_slot_bytes(int ng) { return ng * GROUP * FD16_KB * 4; }
-__host__ __device__ constexpr int fold16_lds_bytes(int ng) { return FD16_RING * FD_HALF + 2 * fold16_slot_bytes(ng); }
+__host__ __device__ constexpr int fold16_lds_bytes(int ng, int px_bytes) {
+    return FD16_RING * (2 * FD_WAVES * 16 * FD16_KB * px_bytes) + 2 * fold16_slot_bytes(ng);
+}
 __host__ __device__ static inline int fold16_index(int n, int q) {
     const int blk = q >> 5, kg = (q >> 3) & 3, j = q & 7;
     const int unit = (kg * 8 + blk * 2 + (j >> 2)) ^ (n & 7);
@@ -407,11 +409,16 @@ k_dense_fold16(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int spr
                float *__restrict__ out, int64_t ld_out, int n_cols, const int *__restrict__ colmap,
                int accumulate, float *__restrict__ partials, int ksplit,
                const unsigned char *__restrict__ zeros, const int32_t *__restrict__ rows) {
-    static_assert(sizeof(T) == 2, "2-byte pixels");
+    static_assert(sizeof(T) <= 2, "1- and 2-byte pixels");
     constexpr int NG = NGE + NGO;
     constexpr int BSLOT = fold16_slot_bytes(NG);
     constexpr int NBI = BSLOT / FD_WAVES / 1024;
-    constexpr int NDH = 16 / 4, NF = 2 * NDH;
+    // a stage is 128 pixels of a row: 256 bytes (16 pieces of 16 bytes, 4 rows per copy instruction) for 2-byte
+    // pixels, 128 bytes (8 pieces, 8 rows per instruction) for 1-byte pixels
+    constexpr int ROWB = FD16_KB * (int)sizeof(T);
+    constexpr int PPR = ROWB / 16, RPI = 64 / PPR;
+    constexpr int NDH = 16 / RPI, NF = 2 * NDH;
+    constexpr int TPART = 16 * ROWB, HALF = 2 * FD_WAVES * TPART;
     constexpr int NB = FD16_KB / 32;                      // 32-pixel blocks per stage
     static_assert(NF + NBI < 64, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -435,8 +442,8 @@ k_dense_fold16(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int spr
         if (rows) return f < 0 ? (int64_t)rows[0] : (int64_t)rows[f];
         return f < 0 ? n_frames - 1 : f;
     };
-    unsigned char *a_base = lds_raw + wave * (2 * FD_TPART);                // + q * FD_HALF
-    unsigned char *b_base = lds_raw + FD16_RING * FD_HALF;                  // + slot * BSLOT
+    unsigned char *a_base = lds_raw + wave * (2 * TPART);                   // + q * HALF
+    unsigned char *b_base = lds_raw + FD16_RING * HALF;                     // + slot * BSLOT
 
     f32x4 acc[FD_TILES][NG], acc2[FD_TILES][NG];
 #pragma unroll
@@ -450,8 +457,8 @@ k_dense_fold16(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int spr
         for (int tl = 0; tl < FD_TILES; ++tl)
 #pragma unroll
             for (int t = 0; t < NDH; ++t) {
-                const int r = 4 * t + lane / 16;
-                const int piece = (lane & 15) ^ r;
+                const int r = RPI * t + lane / PPR;
+                const int piece = (lane & (PPR - 1)) ^ (r & (PPR - 1));
                 src[tl][t] = (const unsigned char *)(tile + src_frame_of(tl * 16 + r) * ld) + piece * 16;
             }
         const unsigned char *zsrc = zeros + lane * 16;
@@ -461,10 +468,10 @@ k_dense_fold16(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int spr
         auto issue_half = [&](auto TL, int q) {
             constexpr int tl = decltype(TL)::value;
             const int2 rr = fold_rows[iss_fy];
-            const int64_t off_a = ((int64_t)rr.x * spr + iss_xs) * 256;
-            const int64_t off_c = ((int64_t)rr.y * spr + iss_xs) * 256;
+            const int64_t off_a = ((int64_t)rr.x * spr + iss_xs) * ROWB;
+            const int64_t off_c = ((int64_t)rr.y * spr + iss_xs) * ROWB;
             const bool pair = rr.y >= 0;
-            unsigned char *da = a_base + q * FD_HALF, *dc = da + FD_TPART;
+            unsigned char *da = a_base + q * HALF, *dc = da + TPART;
 #pragma unroll
             for (int t = 0; t < NDH; ++t)
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[tl][t] + off_a), (lds_ptr_t)(da + t * 1024), 16, 0,
@@ -487,34 +494,51 @@ k_dense_fold16(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int spr
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)(sp + u * 1024), (lds_ptr_t)(db + u * 1024), 16, 0, 0);
         };
 
-        const int a_lane = m * 256;
+        const int a_lane = m * ROWB;
         const int b_lane = m * FD16_KB;
         auto b_unit = [&](int blk, int h) { return ((kg * 8 + blk * 2 + h) ^ (m & 7)) << 2; };
-        auto to_float = [&](const u32x4 &r, float (&f)[8]) {
+        // the lane's 8 pixels of a block: 16 bytes (2-byte pixels) or 8 bytes
+        typedef unsigned int raw_t __attribute__((ext_vector_type(sizeof(T) == 2 ? 4 : 2)));
+        auto to_float = [&](const raw_t &r, float (&f)[8]) {
+            if constexpr (sizeof(T) == 2) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (std::is_signed<T>::value) {
-                    f[2 * i] = (float)(int)(short)(r[i] & 0xffffu);
-                    f[2 * i + 1] = (float)((int)r[i] >> 16);
-                } else {
-                    f[2 * i] = (float)(r[i] & 0xffffu);
-                    f[2 * i + 1] = (float)(r[i] >> 16);
+                for (int i = 0; i < 4; ++i) {
+                    if (std::is_signed<T>::value) {
+                        f[2 * i] = (float)(int)(short)(r[i] & 0xffffu);
+                        f[2 * i + 1] = (float)((int)r[i] >> 16);
+                    } else {
+                        f[2 * i] = (float)(r[i] & 0xffffu);
+                        f[2 * i + 1] = (float)(r[i] >> 16);
+                    }
                 }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (std::is_signed<T>::value) f[4 * i + e] = (float)(int)(signed char)((r[i] >> (8 * e)) & 0xffu);
+                        else f[4 * i + e] = (float)((r[i] >> (8 * e)) & 0xffu);
+                    }
             }
         };
 
         // one tile (16 frames) of one stage: NB blocks of 32 folded pixels x NG groups
         auto compute = [&](auto TL, int q, int bslot) {
             constexpr int tl = decltype(TL)::value;
-            const unsigned char *as = a_base + q * FD_HALF + a_lane;
-            const unsigned char *cs = as + FD_TPART;
+            const unsigned char *as = a_base + q * HALF + a_lane;
+            const unsigned char *cs = as + TPART;
             const float *bs = (const float *)(b_base + bslot * BSLOT) + b_lane;
-            u32x4 ra[2], rc[2];
+            raw_t ra[2], rc[2];
             f32x4 rb[2][NG][2];
             auto load_block = [&](int blk, int buf) {
-                const int u = blk * 4 + kg;                  // 8-pixel unit (16 bytes) of this lane inside the part
-                ra[buf] = *(const u32x4 *)(as + ((u ^ m) << 4));
-                rc[buf] = *(const u32x4 *)(cs + ((u ^ m) << 4));
+                const int u = blk * 4 + kg;                  // 8-pixel unit of this lane inside the part
+                if constexpr (sizeof(T) == 2) {
+                    ra[buf] = *(const raw_t *)(as + ((u ^ m) << 4));
+                    rc[buf] = *(const raw_t *)(cs + ((u ^ m) << 4));
+                } else {
+                    ra[buf] = *(const raw_t *)(as + (((u >> 1) ^ (m & 7)) << 4) + (u & 1) * 8);
+                    rc[buf] = *(const raw_t *)(cs + (((u >> 1) ^ (m & 7)) << 4) + (u & 1) * 8);
+                }
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     rb[buf][g][0] = *(const f32x4 *)(bs + g * (GROUP * FD16_KB) + b_unit(blk, 0));
@@ -791,10 +815,10 @@ int ltmi::launch_fold(ltmi_masks *m, const float *tile, int64_t n_frames, int64_
 }
 
 // ---- 2-byte pixels ------------------------------------------------------------------------------------------------
-bool ltmi::fold_takes16(ltmi_masks *m, const void *tile, int64_t ld) {
+bool ltmi::fold_takes16(ltmi_masks *m, const void *tile, int64_t ld, int px_bytes) {
     FoldImage *f = (FoldImage *)m->fold;
     if (!f || m->tune_ksplit_ring == 38 || f->img16_failed) return false;
-    if (f->sig_w % FD16_KB != 0 || ((uintptr_t)tile % 16 != 0) || (ld * 2) % 16 != 0) return false;
+    if (f->sig_w % FD16_KB != 0 || ((uintptr_t)tile % 16 != 0) || (ld * px_bytes) % 16 != 0) return false;
     if (!f->img16) {
         // built on the first 2-byte tile (a stack that only ever sees float32 frames does not pay for it)
         const int cpm = m->result_dtype == LTMI_C64 ? 2 : 1;
@@ -826,7 +850,7 @@ static int launch_fold16_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64
                            int accumulate, hipStream_t stream) {
     const FoldImage *f = (const FoldImage *)m->fold;
     auto kern = k_dense_fold16<T, NGE, NGO>;
-    constexpr int LDS = ltmi::fold16_lds_bytes(NGE + NGO);
+    constexpr int LDS = ltmi::fold16_lds_bytes(NGE + NGO, (int)sizeof(T));
     static bool attr_set[16] = {false};
     if (!attr_set[m->device & 15]) {
         LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -873,8 +897,11 @@ static int launch_fold16_any(ltmi_masks *m, const T *tile, int64_t n_frames, int
     LTMI_FAIL(LTMI_E_INVALID, "k_dense_fold16: no kernel for %d + %d groups", f->nge, f->ngo);
 }
 
-int ltmi::launch_fold16(ltmi_masks *m, const void *tile, bool is_signed, int64_t n_frames, int64_t ld, float *out,
-                        int64_t ld_out, int accumulate, hipStream_t stream) {
+int ltmi::launch_fold16(ltmi_masks *m, const void *tile, int px_bytes, bool is_signed, int64_t n_frames, int64_t ld,
+                        float *out, int64_t ld_out, int accumulate, hipStream_t stream) {
+    if (px_bytes == 1)
+        return is_signed ? launch_fold16_any<int8_t>(m, (const int8_t *)tile, n_frames, ld, out, ld_out, accumulate, stream)
+                         : launch_fold16_any<uint8_t>(m, (const uint8_t *)tile, n_frames, ld, out, ld_out, accumulate, stream);
     return is_signed ? launch_fold16_any<int16_t>(m, (const int16_t *)tile, n_frames, ld, out, ld_out, accumulate, stream)
                      : launch_fold16_any<uint16_t>(m, (const uint16_t *)tile, n_frames, ld, out, ld_out, accumulate, stream);
 }

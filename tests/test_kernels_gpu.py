@@ -2120,20 +2120,20 @@ def test_row_mirror_fold_wide_stack_in_column_blocks(hip):
         assert np.all(np.abs(part(res_u) - part(ref)) <= 1e-5 * scale + 1e-30)
 
 
-@pytest.mark.parametrize('tile_dtype', ['uint16', 'int16'])
+@pytest.mark.parametrize('tile_dtype', ['uint16', 'int16', 'uint8', 'int8'])
 @pytest.mark.parametrize('sig,n_bins,max_order,n_frames,ksplit', [
     ((128, 128), 1, 24, 300, 0),        # 25 complex masks: 2 even + 2 odd groups, one 128-pixel stage per row
     ((64, 256), 1, 24, 130, 3),         # two stages per row, pixel axis split
     ((96, 128), 2, 7, 70, 0),           # 16 complex masks: 1 + 1 groups
 ])
 def test_row_mirror_fold_two_byte_pixels(hip, tile_dtype, sig, n_bins, max_order, n_frames, ksplit):
-    """k_dense_fold16: uint16 / int16 frames of a radial-Fourier stack (which keeps the float32 matrix instruction: its
-    zero crossings hold more small weights than the float16 pieces' tail takes) through the row-mirror fold -- against
+    """k_dense_fold16: 1- and 2-byte integer frames of a radial-Fourier stack (which keeps the float32 matrix instruction:
+    its zero crossings hold more small weights than the float16 pieces' tail takes) through the row-mirror fold -- against
     float64, the unfolded kernel (tuning 38) and, one-pixel frames over every pixel, every stored weight."""
     masks = _radial_stack(sig, n_bins, max_order)
     rng = np.random.default_rng(_seed('fold16', tile_dtype, sig, n_bins))
     dt = np.dtype(tile_dtype)
-    lo, hi = (0, 65535) if dt.kind == 'u' else (-32768, 32767)
+    lo, hi = int(np.iinfo(dt).min), int(np.iinfo(dt).max)
     data = rng.integers(lo, hi, (n_frames, sig[0] * sig[1]), endpoint=True).astype(dt)
     data[1] = hi
     data[2] = lo
