@@ -21,6 +21,7 @@ ap.add_argument('--only', type=int, default=0, help='tuning code of the one vari
 ap.add_argument('--keep', default='all', choices=['all', 'quarter', 'half'],
                 help="timing model of a mirror-folded stack: keep only the entries of a quarter (x >= cx, y even) "
                      "or half (y even) of the pixels -- the frames (and their copies) stay whole")
+ap.add_argument('--pad', type=int, default=0, help='pixels of padding at the end of every frame row (frame stride = 65536 + pad)')
 args = ap.parse_args()
 rings = pm.radial_bins(128, 128, 256, 256, n_bins=args.bins, use_sparse=True, dtype=np.float32)
 csr = rings.to_px_by_masks(dtype=np.float32)
@@ -43,6 +44,11 @@ elif dt.itemsize == 1:
 else:
     tile = torch.randint(0, 4096, (args.frames, 65536), generator=g, device='cuda',
                          dtype=torch.int32).to(torch.int16)
+if args.pad:
+    padded = torch.zeros((args.frames, 65536 + args.pad), device='cuda', dtype=tile.dtype)
+    padded[:, :65536] = tile
+    tile = padded[:, :65536]
+LD = 65536 + args.pad
 out = torch.zeros((args.frames, args.bins), device='cuda', dtype=torch.float32)
 dense = csr.toarray().astype(np.float64)                 # (n_px, n_masks)
 check = [0, 17, args.frames - 1]
@@ -54,7 +60,7 @@ for code, name in ((40, 'as dispatched'), (42, 'blocked image (tuning 42)'), (41
     h.set_tuning(0, code, 0)
     out.zero_()
     for _ in range(2):
-        h.apply(tile.data_ptr(), dt, args.frames, 65536, out.data_ptr(), args.bins, False)
+        h.apply(tile.data_ptr(), dt, args.frames, LD, out.data_ptr(), args.bins, False)
     torch.cuda.synchronize()
     got = out[check].cpu().numpy()
     err = np.abs(got - ref).max() / np.abs(ref).max()
@@ -62,7 +68,7 @@ for code, name in ((40, 'as dispatched'), (42, 'blocked image (tuning 42)'), (41
            for _ in range(args.reps)]
     for a, b in evs:
         a.record()
-        h.apply(tile.data_ptr(), dt, args.frames, 65536, out.data_ptr(), args.bins, False)
+        h.apply(tile.data_ptr(), dt, args.frames, LD, out.data_ptr(), args.bins, False)
         b.record()
     torch.cuda.synchronize()
     ts = sorted(a.elapsed_time(b) for a, b in evs)
