@@ -56,6 +56,7 @@ struct CsrImage {
     size_t n_rows = 0;
     void *scat = nullptr;       // ltmi_scatter.hip: the stack for k_scatter (images built per pixel size on first use)
     bool scat_all = false;      // LTMI_SPARSE_SCATTER=1: k_scatter for every pixel type (default: float32 frames)
+    double bell_ratio = 0.;     // padded MACs of the blocked image per stored entry (0: not computed)
     int *active = nullptr;      // chunks with entries, concatenated per pass
     int *active_off = nullptr;  // [n_pass + 1]
     void *bell = nullptr;       // blocked image for the matrix-core kernel (ltmi_bell.hip) or null
@@ -401,6 +402,9 @@ bool csr_int_exact(const ltmi_masks *m, int tile_dtype) {
     return data_bits + c->sum_bits <= 52;
 }
 
+// float32 frames: k_scatter only where the blocked image pads at least this much (per stored entry)
+static constexpr double SCAT_MIN_BELL_RATIO = 3.0;
+
 int csr_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames, int64_t ld_tile,
               void *out, int64_t ld_out, int accumulate, hipStream_t stream) {
     CsrImage *c = (CsrImage *)m->csr;
@@ -463,7 +467,11 @@ int csr_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames,
     // (float32 frames by default -- measured 7 % ahead of the float32 blocked image on C4, and a non-finite
     // pixel reaches fewer foreign masks; 1- / 2-byte pixels stay on the blocked images, which are 15 - 30 %
     // faster there: profiles/r04_sparse.txt.  LTMI_SPARSE_SCATTER=1: every pixel type)
-    if (c->scat && (c->scat_all || tile_dtype == LTMI_F32) && m->tune_ksplit_ring != 41 &&
+    // ... unless the blocked image is well filled: a stack of dense column blocks (radial Fourier with several bins:
+    // 1.3 padded MACs per stored entry) runs 3 x faster on the matrix cores (21 ms against 62 ms per 8192 frames
+    // of 1024 x 1024, scripts/bench_second_runs.py); C4's rings (4.8) stay here
+    const bool bell_better = c->bell && c->bell_ratio > 0. && c->bell_ratio < SCAT_MIN_BELL_RATIO && !c->scat_all;
+    if (c->scat && (c->scat_all || tile_dtype == LTMI_F32) && !bell_better && m->tune_ksplit_ring != 41 &&
         m->tune_ksplit_ring != 42) {
         bool handled = false;
         const int rc = scat_apply(m, c->scat, c->cplx, tile, tile_dtype, n_frames, ld_tile, out, ld_out,
@@ -652,8 +660,10 @@ extern "C" int ltmi_masks_create_csr(int device, const int64_t *indptr, const in
         const double max_ratio = thr ? atof(thr) : 8.0;
         bool build = nnz > 0 && !c->f64;                  // (the blocked image is float32 only)
         if (force && force[0] == '0') build = false;
-        else if (!(force && force[0] == '1') && build)
-            build = ltmi::bell_mac_ratio(indptr, indices, nc, n_px, n_masks) <= max_ratio;
+        else if (build) {
+            c->bell_ratio = ltmi::bell_mac_ratio(indptr, indices, nc, n_px, n_masks);
+            if (!(force && force[0] == '1')) build = c->bell_ratio <= max_ratio;
+        }
         if (build) {
             int err = LTMI_OK;
             c->bell = ltmi::bell_build(indptr, indices, vals, nc, n_px, n_masks, &err);

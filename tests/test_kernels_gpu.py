@@ -1029,6 +1029,17 @@ def test_sparse_dispatch_by_padding_factor(hip, monkeypatch):
                           random_state=np.random.RandomState(3))
     res, kern = _apply_csr(hip, data, scattered, np.float32)
     assert 'k_sell_apply' in kern
+    # dense column blocks (radial Fourier with several bins, SURVEY.md 8(d)'s second C5 run): the blocked image pads
+    # little, float32 frames stay on the matrix cores
+    from libertem_amd.analysis.radialfourier import radial_mask_factory
+    from libertem_amd import masks as pm
+    stack = radial_mask_factory(64, 64, 32, 32, 0, pm.bounding_radius(32, 32, 64, 64), 4, 7, True)()
+    stack = stack.to_px_by_masks(dtype=np.complex64)                      # (4096, 32) CSR
+    f32 = np.random.default_rng(6).random((40, 4096)).astype(np.float32)
+    res, kern = _apply_csr(hip, f32, stack.astype(np.complex64), np.complex64)
+    assert 'k_bell_apply<f' in kern, kern
+    ref = f32.astype(np.float64) @ np.asarray(stack.todense()).astype(np.complex128)
+    assert np.all(np.abs(res - ref) <= 1e-5 * (np.abs(f32).astype(np.float64) @ np.abs(np.asarray(stack.todense()))) + 1e-30)
     h = hip.MaskHandle.csr(0, sp.csr_matrix(rings.T.astype(np.float32)), np.float32)
     h.set_tuning(0, 41, 0)                                          # 41: SELL kernel on request
     t, out = _dev(data), _dev(np.zeros((20, 64), dtype=np.float32))
