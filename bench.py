@@ -665,6 +665,84 @@ def crystallinity(torch, hip, reps=10):
     return res
 
 
+def second_runs(ctx, torch, hip, reps=3):
+    """SURVEY.md 8(d)'s second runs of C3 and C5: CoM with mask_radius=200, radial Fourier with n_bins=16, max_order=24,
+    use_sparse=True (400 complex64 masks, a stack of dense column blocks).  Whole job through Context.run on a nav
+    subset, the kernels through hip.KernelTimer, a few frames against float64 NumPy."""
+    import gc
+    out = {}
+
+    def timed(an, n, frame_bytes):
+        res = ctx.run(an)
+        for _ in range(2):
+            ctx.run(an)
+        hip.KernelTimer.start()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.run(an)
+        dt = (time.perf_counter() - t0) / reps
+        ev = hip.KernelTimer.stop()
+        by = {}
+        for ms, cnt, k in ev:
+            by.setdefault(k, []).append(ms)
+        kernels = [{"kernel": k, "launches_per_run": len(v) // reps, "avg_launch_ms": float(np.mean(v))}
+                   for k, v in by.items()]
+        return res, {"ms_per_run": dt * 1e3, "frames_per_s": n / dt, "input_GBps_whole_job": n * frame_bytes / dt / 1e9,
+                     "kernels": kernels}
+
+    # C3, mask_radius=200
+    n = 16384
+    fr = device_frames(torch, n, (512, 512), 'uint16', 31)
+    ds = ctx.load('memory', data=fr.reshape((n // 256, 256, 512, 512)), dtype=np.dtype('uint16'), sig_dims=2,
+                  num_partitions=1)
+    an = ctx.create_com_analysis(dataset=ds, cx=256, cy=256, mask_radius=200)
+    res, rec = timed(an, n, 512 * 512 * 2)
+    yy, xx = np.mgrid[0:512, 0:512]
+    disk = ((yy - 256) ** 2 + (xx - 256) ** 2) <= 200 ** 2
+    worst = 0.
+    for i in (0, 777, n - 1):
+        f = fr[i].cpu().numpy().view(np.uint16).astype(np.float64).reshape((512, 512)) * disk
+        cy, cx = (f * yy).sum() / f.sum() - 256, (f * xx).sum() / f.sum() - 256
+        worst = max(worst, abs(res.y.raw_data.reshape(-1)[i] - cy) / 256., abs(res.x.raw_data.reshape(-1)[i] - cx) / 256.)
+    if not worst < 1e-5:
+        raise SystemExit(f"bench.py: C3 mask_radius=200 check failed: {worst:.3e}")
+    rec.update(workload=f"CoM analysis, cx=cy=256, mask_radius=200, {n} frames of 512x512 uint16",
+               check_rel_err_vs_float64=float(worst),
+               frac_of_hbm_peak_kernel=n * 512 * 512 * 2 / (sum(k['avg_launch_ms'] * k['launches_per_run']
+                                                                for k in rec['kernels']) * 1e-3) / 1e9 / HBM_PEAK_GBS)
+    out['c3_mask_radius_200'] = rec
+    del fr, ds, an, res
+    gc.collect()
+    torch.cuda.empty_cache()
+
+    # C5, 16 bins x 25 orders, sparse
+    n = 4096
+    fr = device_frames(torch, n, (1024, 1024), 'float32', 32)
+    ds = ctx.load('memory', data=fr.reshape((n // 128, 128, 1024, 1024)), dtype=np.dtype('float32'), sig_dims=2,
+                  num_partitions=1)
+    an = ctx.create_radial_fourier_analysis(dataset=ds, n_bins=16, max_order=24, use_sparse=True)
+    res, rec = timed(an, n, 1024 * 1024 * 4)
+    stack = an.get_mask_factories()().to_px_by_masks(dtype=np.complex64)          # (n_px, 400) CSR
+    raw = res.raw_results.reshape((400, -1))
+    worst = 0.
+    for i in (0, n - 1):
+        f = fr[i].cpu().numpy().astype(np.float64).reshape(-1)
+        ref = np.asarray(stack.T.astype(np.complex128) @ f).reshape(-1)
+        worst = max(worst, float(np.abs(raw[:, i] - ref).max() / np.abs(ref).max()))
+    if not worst < 1e-5:
+        raise SystemExit(f"bench.py: C5 sparse radial Fourier check failed: {worst:.3e}")
+    rec.update(workload=f"radial Fourier analysis, n_bins=16, max_order=24, use_sparse=True (400 complex64 masks, "
+                        f"nnz {stack.nnz}), {n} frames of 1024x1024 float32",
+               check_rel_err_vs_float64=worst,
+               useful_TFLOPs_kernel=4 * stack.nnz * n / (sum(k['avg_launch_ms'] * k['launches_per_run']
+                                                             for k in rec['kernels']) * 1e-3) / 1e12)
+    out['c5_sparse_16_bins'] = rec
+    del fr, ds, an, res
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def mib_decode(torch, hip, n=16384, reps=10):
     """Row f2: .mib frames (12-bit raw words, 256 x 256, 384-byte headers) -> uint16 frames, file bytes
     already in HBM; rate = (payload read + frames written) / kernel time (HIP events on its stream)."""
@@ -1040,6 +1118,7 @@ def main():
         guarded('live_feed', lambda: live_feed(ctx))
         guarded('mib_decode', lambda: mib_decode(torch, hip))
         guarded('crystallinity', lambda: crystallinity(torch, hip))
+        guarded('second_runs', lambda: second_runs(ctx, torch, hip))
 
     watchdog.cancel()
     emit()
