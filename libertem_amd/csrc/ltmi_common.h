@@ -143,6 +143,16 @@ void fold_destroy(ltmi_masks *m);
 bool fold_takes(const ltmi_masks *m, const float *tile, int64_t ld);
 int launch_fold(ltmi_masks *m, const float *tile, int64_t n_frames, int64_t ld, float *out, int64_t ld_out,
                 int accumulate, hipStream_t stream);
+// banded sparse stacks (column blocks with a common support each: radial Fourier with several bins) on k_dense_fold
+struct KeptCsr;                                                             // host copy of a CSR stack, rows sorted
+KeptCsr *band_keep_csr(const int64_t *indptr, const int64_t *indices, const float *vals, int nc, int64_t n_px,
+                       int64_t n_masks);                                    // nullptr: not a candidate
+void band_free_csr(KeptCsr *k);
+void *band_build(const KeptCsr *k, int sig_h, int sig_w, double other_macs);    // nullptr: the other kernels serve
+void band_destroy(void *band);
+bool band_takes(const void *band, const ltmi_masks *m, const void *tile, int tile_dtype, int64_t ld);
+int band_apply(ltmi_masks *m, void *band, const float *tile, int64_t n_frames, int64_t ld, float *out, int64_t ld_out,
+               int n_cols, int accumulate, hipStream_t stream);
 bool fold_takes16(ltmi_masks *m, const void *tile, int64_t ld, int px_bytes);   // 1- / 2-byte integer frames (image built on first use)
 int launch_fold16(ltmi_masks *m, const void *tile, int px_bytes, bool is_signed, int64_t n_frames, int64_t ld,
                   float *out, int64_t ld_out, int accumulate, hipStream_t stream);

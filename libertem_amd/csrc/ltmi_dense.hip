@@ -1338,6 +1338,7 @@ using namespace ltmi;
 
 namespace ltmi {
 int csr_destroy(ltmi_masks *m);   // ltmi_sparse.hip
+int csr_set_sig_shape(ltmi_masks *m, int sig_h, int sig_w);
 bool csr_rows_ok(const ltmi_masks *m, const void *tile, int tile_dtype, int64_t ld_tile);
 int csr_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames, int64_t ld_tile,
               void *out, int64_t ld_out, int accumulate, hipStream_t stream);
@@ -1668,6 +1669,7 @@ extern "C" int ltmi_masks_set_sig_shape(ltmi_masks *m, int sig_h, int sig_w) {
         const int rc = ltmi_masks_set_sig_shape(b, sig_h, sig_w);
         if (rc != LTMI_OK) return rc;
     }
+    if (m->kind == 2) return ltmi::csr_set_sig_shape(m, sig_h, sig_w);
     if (m->kind != 0) return LTMI_OK;
     return fold_create(m, sig_h, sig_w);
 }

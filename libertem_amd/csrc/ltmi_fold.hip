@@ -29,6 +29,9 @@
 #include "ltmi_common.h"
 #include <vector>
 #include <cstdlib>
+#include <algorithm>
+#include <climits>
+#include <cstdint>
 #include <type_traits>
 #include <typeinfo>
 
@@ -104,13 +107,19 @@ __global__ void k_fold_classify(const float *__restrict__ src, int cpm, int64_t 
     }
 }
 
-template <int NGE, int NGO, int ABL = 0>
+// LIST (banded stacks, see band_build below): the stack is a set of column BLOCKS with a pixel support each (the
+// bins of a radial-Fourier stack with several bins); workgroup (x, y) multiplies the frames of x with block y only,
+// over the stages that touch the block's support: stage s is (row y, row y' or -1, 64-pixel slot of the rows, -)
+// = stage_list[s], s in [blk_off[y], blk_off[y + 1]), its mask slot is slot s of the image, the block's columns are
+// colmap[y * NG * 16 ...].  No pixel split (every block writes its own columns).
+template <int NGE, int NGO, int ABL = 0, bool LIST = false>
 __global__ void __launch_bounds__(FD_WAVES * 64)
 k_dense_fold(const float *__restrict__ tile, int64_t ld, int64_t n_frames, int spr /* stages per row */,
              const int2 *__restrict__ fold_rows, const float *__restrict__ img, int n_stages,
              float *__restrict__ out, int64_t ld_out, int n_cols, const int *__restrict__ colmap,
              int accumulate, float *__restrict__ partials, int ksplit,
-             const unsigned char *__restrict__ zeros, const int32_t *__restrict__ rows) {
+             const unsigned char *__restrict__ zeros, const int32_t *__restrict__ rows,
+             const int4 *__restrict__ stage_list, const int *__restrict__ blk_off) {
     constexpr int NG = NGE + NGO;
     constexpr int BSLOT = fold_slot_bytes(NG);
     constexpr int NBI = BSLOT / FD_WAVES / 1024;          // mask-slot DMA instructions per wave and stage
@@ -124,10 +133,11 @@ k_dense_fold(const float *__restrict__ tile, int64_t ld, int64_t n_frames, int s
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int m = lane & 15, kg = lane >> 4;
-    const int ks = blockIdx.y;
+    const int ks = LIST ? 0 : blockIdx.y;
     const int per = (n_stages + ksplit - 1) / ksplit;
-    const int s_begin = ks * per;
-    const int s_end = min(n_stages, s_begin + per);
+    const int s_begin = LIST ? blk_off[blockIdx.y] : ks * per;
+    const int s_end = LIST ? blk_off[blockIdx.y + 1] : min(n_stages, s_begin + per);
+    if (LIST) colmap += blockIdx.y * (NG * GROUP);
 
     const int64_t f_wave = (int64_t)blockIdx.x * FD_WG_ROWS + wave * FD_ROWS;
     auto frame_of = [&](int r) -> int64_t {                 // result row (-1: none)
@@ -165,13 +175,15 @@ k_dense_fold(const float *__restrict__ tile, int64_t ld, int64_t n_frames, int s
 
         // half-stages are issued in order: (stage, tile 0), (stage, tile 1), (stage + 1, tile 0) ...; past the end
         // the last stage again (clamped prefetch: every step issues the same number of copies, the waits count them)
-        int iss = s_begin, iss_fy = s_begin / spr, iss_xs = s_begin % spr;
+        int iss = s_begin, iss_fy = LIST ? 0 : s_begin / spr, iss_xs = LIST ? 0 : s_begin % spr;
+        int4 iss_st = LIST ? stage_list[s_begin] : int4{0, 0, 0, 0};         // (fetched one stage ahead of its use)
         auto issue_half = [&](auto TL, auto Q) {
             constexpr int tl = decltype(TL)::value, q = decltype(Q)::value;
             if (ABL >= 2) return;
-            const int2 rr = fold_rows[iss_fy];
-            const int64_t off_a = ((int64_t)rr.x * spr + iss_xs) * 256;
-            const int64_t off_c = ((int64_t)rr.y * spr + iss_xs) * 256;
+            const int2 rr = LIST ? int2{iss_st.x, iss_st.y} : fold_rows[iss_fy];
+            const int xs = LIST ? iss_st.z : iss_xs;
+            const int64_t off_a = ((int64_t)rr.x * spr + xs) * 256;
+            const int64_t off_c = ((int64_t)rr.y * spr + xs) * 256;
             const bool pair = rr.y >= 0;
             unsigned char *da = a_base + q * FD_HALF, *dc = da + FD_TPART;
 #pragma unroll
@@ -185,7 +197,8 @@ k_dense_fold(const float *__restrict__ tile, int64_t ld, int64_t n_frames, int s
             }
             if (tl == FD_TILES - 1 && iss + 1 < s_end) {
                 ++iss;
-                if (++iss_xs == spr) { iss_xs = 0; ++iss_fy; }
+                if (LIST) iss_st = stage_list[iss];
+                else if (++iss_xs == spr) { iss_xs = 0; ++iss_fy; }
             }
         };
         auto issue_b = [&](int s, int bslot) {              // mask slot of stage s (clamped)
@@ -791,7 +804,7 @@ static int launch_fold_t(ltmi_masks *m, const float *tile, int64_t n_frames, int
     hipLaunchKernelGGL(kern, grid, dim3(FD_WAVES * 64), LDS, stream, tile, ld, n_frames, f->sig_w / FD_KB,
                        (const int2 *)f->rows, (const float *)f->img, f->n_stages, out, ld_out, m->n_cols,
                        (const int *)f->colmap, accumulate, dense_partial_sums(m), ksplit,
-                       (const unsigned char *)f->zeros, m->roi_rows);
+                       (const unsigned char *)f->zeros, m->roi_rows, (const int4 *)nullptr, (const int *)nullptr);
     LTMI_HIP(hipGetLastError());
     snprintf(m->last_kernel, sizeof(m->last_kernel), "k_dense_fold<f,even=%d,odd=%d,rows %d+%d=%d%s> grid=(%u,%u)",
              NGE, NGO, f->n_fold_rows, f->sig_h - f->n_fold_rows, f->c2, m->roi_rows ? ",rows" : "", grid.x, grid.y);
@@ -904,4 +917,339 @@ int ltmi::launch_fold16(ltmi_masks *m, const void *tile, int px_bytes, bool is_s
                          : launch_fold16_any<uint8_t>(m, (const uint8_t *)tile, n_frames, ld, out, ld_out, accumulate, stream);
     return is_signed ? launch_fold16_any<int16_t>(m, (const int16_t *)tile, n_frames, ld, out, ld_out, accumulate, stream)
                      : launch_fold16_any<uint16_t>(m, (const uint16_t *)tile, n_frames, ld, out, ld_out, accumulate, stream);
+}
+
+// ---- banded stacks: column blocks with a pixel support each (k_dense_fold<.., LIST>) -----------------------------
+//
+// A radial-Fourier stack with several bins (analysis/radialfourier.py:106-146 with n_bins > 1, use_sparse=True:
+// SURVEY.md 8(d)'s second C5 run, 16 bins x 25 orders) arrives as a CSR matrix, but it is not sparse in the sense
+// of the gather / blocked kernels: the 25 complex masks of a bin share ONE support (the bin's ring) and are dense on
+// it -- a dense 50-column stack per ring.  The blocked image multiplies it record by record (8 pixels x 16 columns,
+// 0.35 - 0.44 of the float32 matrix peak, profiles/r05_sparse.txt 8); here every block of columns with a common
+// support becomes a folded dense image over the 64-pixel stages that touch the support, and k_dense_fold walks the
+// block's stage list.  Stages at a ring's edge are read by both neighbours.
+struct ltmi::KeptCsr {
+    int nc = 1;
+    int64_t n_px = 0, n_masks = 0;
+    std::vector<int64_t> indptr;
+    std::vector<int32_t> idx;                   // rows sorted by mask index, no duplicates
+    std::vector<float> val;                     // nc floats per entry
+};
+
+struct BandImage {
+    int sig_h = 0, sig_w = 0, c2 = 0, nge = 0, ngo = 0;
+    int n_blocks = 0, n_stages = 0, n_fold_rows = 0;
+    float *img = nullptr;
+    int4 *stages = nullptr;
+    int *blk_off = nullptr, *colmap = nullptr;
+    unsigned char *zeros = nullptr;
+    double reread = 0.;                         // stages per stage of the whole detector: how often a frame byte is read
+};
+
+ltmi::KeptCsr *ltmi::band_keep_csr(const int64_t *indptr, const int64_t *indices, const float *vals, int nc,
+                                   int64_t n_px, int64_t n_masks) {
+    const char *off = getenv("LTMI_SPARSE_BAND");
+    if (off && atoi(off) == 0) return nullptr;
+    const int64_t nnz = indptr[n_px];
+    if (nnz <= 0 || n_masks * nc < 2 * GROUP || n_masks >= (1 << 30)) return nullptr;
+    KeptCsr *k = new (std::nothrow) KeptCsr();
+    if (!k) return nullptr;
+    try {
+        k->nc = nc; k->n_px = n_px; k->n_masks = n_masks;
+        k->indptr.assign(indptr, indptr + n_px + 1);
+        k->idx.resize((size_t)nnz);
+        k->val.resize((size_t)nnz * nc);
+        std::vector<std::pair<int32_t, int64_t>> row;
+        for (int64_t p = 0; p < n_px; ++p) {
+            const int64_t e0 = indptr[p], e1 = indptr[p + 1];
+            bool sorted = true;
+            for (int64_t e = e0 + 1; e < e1 && sorted; ++e) sorted = indices[e - 1] < indices[e];
+            if (sorted) {
+                for (int64_t e = e0; e < e1; ++e) {
+                    k->idx[(size_t)e] = (int32_t)indices[e];
+                    for (int c = 0; c < nc; ++c) k->val[(size_t)e * nc + c] = vals[e * nc + c];
+                }
+                continue;
+            }
+            row.clear();
+            for (int64_t e = e0; e < e1; ++e) row.emplace_back((int32_t)indices[e], e);
+            std::sort(row.begin(), row.end());
+            for (size_t i = 0; i < row.size(); ++i) {
+                if (i && row[i].first == row[i - 1].first) { delete k; return nullptr; }      // duplicates: not here
+                k->idx[(size_t)e0 + i] = row[i].first;
+                for (int c = 0; c < nc; ++c) k->val[((size_t)e0 + i) * nc + c] = vals[row[i].second * nc + c];
+            }
+        }
+    } catch (const std::bad_alloc &) {
+        delete k;
+        return nullptr;
+    }
+    return k;
+}
+
+void ltmi::band_free_csr(KeptCsr *k) { delete k; }
+
+void ltmi::band_destroy(void *band) {
+    BandImage *b = (BandImage *)band;
+    if (!b) return;
+    if (b->img) (void)hipFree(b->img);
+    if (b->stages) (void)hipFree(b->stages);
+    if (b->blk_off) (void)hipFree(b->blk_off);
+    if (b->colmap) (void)hipFree(b->colmap);
+    if (b->zeros) (void)hipFree(b->zeros);
+    delete b;
+}
+
+// `other_macs`: padded multiply-adds per frame of the kernel that would run instead (blocked image), 0: unknown.
+// Returns the image or nullptr (no mirror, no common supports, not worth it, no memory: the other kernels serve).
+static void *band_no(int why) {
+    if (getenv("LTMI_BAND_DEBUG")) fprintf(stderr, "band_build: no image (exit %d)\n", why);
+    return nullptr;
+}
+
+void *ltmi::band_build(const KeptCsr *k, int sig_h, int sig_w, double other_macs) {
+    if (!k || (int64_t)sig_h * sig_w != k->n_px || sig_w % FD_KB != 0 || sig_h < 4) return band_no(1);
+    const int nc = k->nc;
+    const int64_t n_cols = k->n_masks * nc;
+    const int64_t nnz = k->indptr[(size_t)k->n_px];
+    try {
+        // ---- row mirror under which every real column is even or odd (the test of fold_create, on the CSR rows) ----
+        int best_c2 = -1;
+        std::vector<signed char> cls;
+        for (int c2 : {sig_h, sig_h - 1, sig_h + 1}) {
+            std::vector<unsigned char> even((size_t)n_cols, 1), odd((size_t)n_cols, 1);
+            for (int y = 0; y < sig_h; ++y) {
+                const int y2 = c2 - y;
+                if (y2 <= y || y2 >= sig_h) continue;
+                for (int x = 0; x < sig_w; ++x) {
+                    const int64_t p = (int64_t)y * sig_w + x, q = (int64_t)y2 * sig_w + x;
+                    int64_t a = k->indptr[(size_t)p], a1 = k->indptr[(size_t)p + 1];
+                    int64_t b = k->indptr[(size_t)q], b1 = k->indptr[(size_t)q + 1];
+                    while (a < a1 || b < b1) {
+                        const int32_t ia = a < a1 ? k->idx[(size_t)a] : INT32_MAX;
+                        const int32_t ib = b < b1 ? k->idx[(size_t)b] : INT32_MAX;
+                        const int32_t col = std::min(ia, ib);
+                        for (int c = 0; c < nc; ++c) {
+                            const float va = ia == col ? k->val[(size_t)a * nc + c] : 0.f;
+                            const float vb = ib == col ? k->val[(size_t)b * nc + c] : 0.f;
+                            if (!(va == vb)) even[(size_t)col * nc + c] = 0;
+                            if (!(va == -vb)) odd[(size_t)col * nc + c] = 0;
+                        }
+                        if (ia == col) ++a;
+                        if (ib == col) ++b;
+                    }
+                }
+            }
+            bool all = true;
+            std::vector<signed char> c((size_t)n_cols);
+            for (int64_t j = 0; j < n_cols && all; ++j) {
+                if (even[(size_t)j]) c[(size_t)j] = 1;
+                else if (odd[(size_t)j]) c[(size_t)j] = -1;
+                else all = false;
+            }
+            if (all) { best_c2 = c2; cls = c; break; }
+        }
+        if (best_c2 < 0) return band_no(2);
+
+        // ---- masks with the same support form a block ----
+        std::vector<uint64_t> hash((size_t)k->n_masks, 1469598103934665603ull);
+        std::vector<int64_t> cnt((size_t)k->n_masks, 0), first((size_t)k->n_masks, -1), last((size_t)k->n_masks, -1);
+        for (int64_t p = 0; p < k->n_px; ++p)
+            for (int64_t e = k->indptr[(size_t)p]; e < k->indptr[(size_t)p + 1]; ++e) {
+                const size_t mk = (size_t)k->idx[(size_t)e];
+                hash[mk] = (hash[mk] ^ (uint64_t)(p + 1)) * 1099511628211ull;
+                if (cnt[mk]++ == 0) first[mk] = p;
+                last[mk] = p;
+            }
+        struct Block { std::vector<int32_t> masks; int n_even = 0, n_odd = 0; };
+        std::vector<Block> blocks;
+        {
+            std::vector<int32_t> order((size_t)k->n_masks);
+            for (int64_t i = 0; i < k->n_masks; ++i) order[(size_t)i] = (int32_t)i;
+            auto key_less = [&](int32_t a, int32_t b) {
+                if (hash[(size_t)a] != hash[(size_t)b]) return hash[(size_t)a] < hash[(size_t)b];
+                if (cnt[(size_t)a] != cnt[(size_t)b]) return cnt[(size_t)a] < cnt[(size_t)b];
+                if (first[(size_t)a] != first[(size_t)b]) return first[(size_t)a] < first[(size_t)b];
+                if (last[(size_t)a] != last[(size_t)b]) return last[(size_t)a] < last[(size_t)b];
+                return a < b;
+            };
+            std::sort(order.begin(), order.end(), key_less);
+            auto same = [&](int32_t a, int32_t b) {
+                return hash[(size_t)a] == hash[(size_t)b] && cnt[(size_t)a] == cnt[(size_t)b] &&
+                       first[(size_t)a] == first[(size_t)b] && last[(size_t)a] == last[(size_t)b];
+            };
+            for (size_t i = 0; i < order.size(); ++i) {
+                const int32_t mk = order[i];
+                if (cnt[(size_t)mk] == 0) return band_no(3);          // a mask without entries: its column is nobody's
+                int ne = 0, no = 0;
+                for (int c = 0; c < nc; ++c) (cls[(size_t)mk * nc + c] > 0 ? ne : no)++;
+                const bool fresh = i == 0 || !same(order[i - 1], mk) ||
+                                   blocks.back().n_even + ne > 2 * GROUP || blocks.back().n_odd + no > 2 * GROUP;
+                if (fresh) blocks.emplace_back();
+                blocks.back().masks.push_back(mk);
+                blocks.back().n_even += ne;
+                blocks.back().n_odd += no;
+            }
+        }
+        if (blocks.size() > 4096) return band_no(4);
+        int nge = 1, ngo = 0;
+        for (const Block &b : blocks) {
+            nge = std::max(nge, (b.n_even + GROUP - 1) / GROUP);
+            ngo = std::max(ngo, (b.n_odd + GROUP - 1) / GROUP);
+        }
+        const int ng = nge + ngo;
+
+        // ---- folded rows, stages of every block ----
+        std::vector<int2> rows;
+        std::vector<int> fold_row_of((size_t)sig_h, -1);
+        for (int y = 0; y < sig_h; ++y) {
+            const int y2 = best_c2 - y;
+            if (y2 >= 0 && y2 < sig_h && y2 < y) { fold_row_of[(size_t)y] = fold_row_of[(size_t)y2]; continue; }
+            fold_row_of[(size_t)y] = (int)rows.size();
+            rows.push_back(int2{y, (y2 > y && y2 < sig_h) ? y2 : -1});
+        }
+        const int spr = sig_w / FD_KB;
+        const size_t n_slots = rows.size() * (size_t)spr;
+        std::vector<int32_t> block_of((size_t)k->n_masks), vcol((size_t)n_cols);
+        for (size_t b = 0; b < blocks.size(); ++b) {
+            int ie = 0, io = nge * GROUP;
+            for (int32_t mk : blocks[b].masks) {
+                block_of[(size_t)mk] = (int32_t)b;
+                for (int c = 0; c < nc; ++c)
+                    vcol[(size_t)mk * nc + c] = cls[(size_t)mk * nc + c] > 0 ? ie++ : io++;
+            }
+        }
+        std::vector<std::vector<unsigned char>> touched(blocks.size(), std::vector<unsigned char>(n_slots, 0));
+        for (int64_t p = 0; p < k->n_px; ++p) {
+            const size_t slot = (size_t)fold_row_of[(size_t)(p / sig_w)] * spr + (size_t)((p % sig_w) / FD_KB);
+            for (int64_t e = k->indptr[(size_t)p]; e < k->indptr[(size_t)p + 1]; ++e)
+                touched[(size_t)block_of[(size_t)k->idx[(size_t)e]]][slot] = 1;
+        }
+        std::vector<size_t> n_st(blocks.size(), 0);
+        size_t total = 0;
+        for (size_t b = 0; b < blocks.size(); ++b) {
+            for (unsigned char t : touched[b]) n_st[b] += t;
+            total += n_st[b];
+        }
+        // worth it?  per frame: matrix work at the fold kernel's rate and the frame bytes it reads (edge stages once per
+        // block) against the blocked image's record loop (0.35 - 0.44 of the matrix peak; unknown: the vector ALUs)
+        const double band_macs = (double)total * FD_KB * ng * GROUP;
+        const double reread = (double)total / (double)n_slots;
+        const double t_band = std::max(band_macs * 2. / 130e12, reread * (double)k->n_px * 4. / 6.5e12);
+        const double t_other = other_macs > 0. ? other_macs * 2. / 60e12 : (double)nnz * nc / 10e12;
+        const char *force = getenv("LTMI_SPARSE_BAND");
+        if (!(force && atoi(force) == 1) && !(t_band < 0.8 * t_other)) return band_no(5);
+        if (total == 0 || total > (size_t)INT32_MAX / 2) return band_no(6);
+
+        // blocks in the order of their length, longest first (they are dispatched in that order)
+        std::vector<int32_t> border(blocks.size());
+        for (size_t b = 0; b < blocks.size(); ++b) border[b] = (int32_t)b;
+        std::stable_sort(border.begin(), border.end(), [&](int32_t a, int32_t b) { return n_st[(size_t)a] > n_st[(size_t)b]; });
+        std::vector<int> blk_off(blocks.size() + 1, 0), colmap(blocks.size() * (size_t)ng * GROUP, -1);
+        std::vector<int4> stages(total);
+        std::vector<std::vector<int32_t>> stage_id(blocks.size());
+        {
+            size_t s = 0;
+            for (size_t bi = 0; bi < border.size(); ++bi) {
+                const size_t b = (size_t)border[bi];
+                blk_off[bi] = (int)s;
+                stage_id[b].assign(n_slots, -1);
+                for (size_t slot = 0; slot < n_slots; ++slot)
+                    if (touched[b][slot]) {
+                        const int2 rr = rows[slot / spr];
+                        stages[s] = int4{rr.x, rr.y, (int)(slot % spr), 0};
+                        stage_id[b][slot] = (int32_t)s++;
+                    }
+                for (int32_t mk : blocks[b].masks)
+                    for (int c = 0; c < nc; ++c)
+                        colmap[bi * (size_t)ng * GROUP + (size_t)vcol[(size_t)mk * nc + c]] = (int)(mk * nc + c);
+                touched[b].clear();
+                touched[b].shrink_to_fit();
+            }
+            blk_off[blocks.size()] = (int)s;
+        }
+        // image: the ORIGINAL weights of rows y (the first row of a pair)
+        const size_t slot_floats = (size_t)ng * GROUP * FD_KB;
+        std::vector<float> img(total * slot_floats, 0.f);
+        for (size_t fy = 0; fy < rows.size(); ++fy) {
+            const int y = rows[fy].x;
+            for (int x = 0; x < sig_w; ++x) {
+                const int64_t p = (int64_t)y * sig_w + x;
+                const size_t slot = fy * spr + (size_t)(x / FD_KB);
+                const int q = x % FD_KB;
+                for (int64_t e = k->indptr[(size_t)p]; e < k->indptr[(size_t)p + 1]; ++e) {
+                    const int32_t mk = k->idx[(size_t)e];
+                    const int32_t s = stage_id[(size_t)block_of[(size_t)mk]][slot];
+                    for (int c = 0; c < nc; ++c) {
+                        const int v = vcol[(size_t)mk * nc + c];
+                        img[((size_t)s * ng + (size_t)(v / GROUP)) * (GROUP * FD_KB) + fold_index(v % GROUP, q)] =
+                            k->val[(size_t)e * nc + c];
+                    }
+                }
+            }
+        }
+        BandImage *bi = new BandImage();
+        bi->sig_h = sig_h; bi->sig_w = sig_w; bi->c2 = best_c2; bi->nge = nge; bi->ngo = ngo;
+        bi->n_blocks = (int)blocks.size(); bi->n_stages = (int)total; bi->n_fold_rows = (int)rows.size();
+        bi->reread = reread;
+        hipError_t e = hipMalloc((void **)&bi->img, img.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void **)&bi->stages, stages.size() * sizeof(int4));
+        if (e == hipSuccess) e = hipMalloc((void **)&bi->blk_off, blk_off.size() * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&bi->colmap, colmap.size() * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&bi->zeros, 1024);
+        if (e == hipSuccess) e = hipMemset(bi->zeros, 0, 1024);
+        if (e == hipSuccess) e = hipMemcpy(bi->img, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(bi->stages, stages.data(), stages.size() * sizeof(int4), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(bi->blk_off, blk_off.data(), blk_off.size() * sizeof(int), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(bi->colmap, colmap.data(), colmap.size() * sizeof(int), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            band_destroy(bi);
+            (void)hipGetLastError();
+            return band_no(7);
+        }
+        return bi;
+    } catch (const std::bad_alloc &) {
+        return band_no(8);
+    }
+}
+
+bool ltmi::band_takes(const void *band, const ltmi_masks *m, const void *tile, int tile_dtype, int64_t ld) {
+    if (!band || tile_dtype != LTMI_F32 || m->tune_ksplit_ring == 41 || m->tune_ksplit_ring == 42) return false;
+    return ((uintptr_t)tile % 16 == 0) && (ld * 4) % 16 == 0;
+}
+
+template <int NGE, int NGO>
+static int launch_band_t(ltmi_masks *m, const BandImage *b, const float *tile, int64_t n_frames, int64_t ld, float *out,
+                         int64_t ld_out, int n_cols, int accumulate, hipStream_t stream) {
+    auto kern = k_dense_fold<NGE, NGO, 0, true>;
+    constexpr int LDS = ltmi::fold_lds_bytes(NGE + NGO);
+    static bool attr_set[16] = {false};
+    if (!attr_set[m->device & 15]) {
+        LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set[m->device & 15] = true;
+    }
+    const int64_t gx = (n_frames + FD_WG_ROWS - 1) / FD_WG_ROWS;
+    dim3 grid((unsigned)gx, (unsigned)b->n_blocks);
+    hipLaunchKernelGGL(kern, grid, dim3(FD_WAVES * 64), LDS, stream, tile, ld, n_frames, b->sig_w / FD_KB,
+                       (const int2 *)nullptr, (const float *)b->img, b->n_stages, out, ld_out, n_cols,
+                       (const int *)b->colmap, accumulate, (float *)nullptr, 1, (const unsigned char *)b->zeros,
+                       m->roi_rows, (const int4 *)b->stages, (const int *)b->blk_off);
+    LTMI_HIP(hipGetLastError());
+    snprintf(m->last_kernel, sizeof(m->last_kernel),
+             "k_dense_fold<f,even=%d,odd=%d,banded: %d blocks, %d stages (x%.2f), rows %d+%d=%d%s> grid=(%u,%u)", NGE, NGO,
+             b->n_blocks, b->n_stages, b->reread, b->n_fold_rows, b->sig_h - b->n_fold_rows, b->c2,
+             m->roi_rows ? ",rows" : "", grid.x, grid.y);
+    return LTMI_OK;
+}
+
+int ltmi::band_apply(ltmi_masks *m, void *band, const float *tile, int64_t n_frames, int64_t ld, float *out,
+                     int64_t ld_out, int n_cols, int accumulate, hipStream_t stream) {
+    const BandImage *b = (const BandImage *)band;
+#define LTMI_BAND_CASE(E_, O_)                                                                                 \
+    if (b->nge == E_ && b->ngo == O_)                                                                          \
+        return launch_band_t<E_, O_>(m, b, tile, n_frames, ld, out, ld_out, n_cols, accumulate, stream);
+    LTMI_BAND_CASE(1, 0) LTMI_BAND_CASE(2, 0) LTMI_BAND_CASE(1, 1) LTMI_BAND_CASE(2, 1) LTMI_BAND_CASE(1, 2)
+    LTMI_BAND_CASE(2, 2)
+#undef LTMI_BAND_CASE
+    LTMI_FAIL(LTMI_E_INVALID, "k_dense_fold (banded): no kernel for %d + %d groups", b->nge, b->ngo);
 }

@@ -57,6 +57,9 @@ struct CsrImage {
     void *scat = nullptr;       // ltmi_scatter.hip: the stack for k_scatter (images built per pixel size on first use)
     bool scat_all = false;      // LTMI_SPARSE_SCATTER=1: k_scatter for every pixel type (default: float32 frames)
     double bell_ratio = 0.;     // padded MACs of the blocked image per stored entry (0: not computed)
+    KeptCsr *kept = nullptr;    // host copy until the detector shape is known (ltmi_masks_set_sig_shape) or the first product
+    void *band = nullptr;       // ltmi_fold.hip: column blocks with a common support each, folded (float32 frames)
+    double nnz_real = 0.;
     int *active = nullptr;      // chunks with entries, concatenated per pass
     int *active_off = nullptr;  // [n_pass + 1]
     void *bell = nullptr;       // blocked image for the matrix-core kernel (ltmi_bell.hip) or null
@@ -289,6 +292,8 @@ int csr_destroy(ltmi_masks *m) {
     if (c->active_off) (void)hipFree(c->active_off);
     bell_destroy(c->bell);
     scat_destroy(c->scat);
+    band_destroy(c->band);
+    band_free_csr(c->kept);
     delete c;
     m->csr = nullptr;
     return LTMI_OK;
@@ -402,6 +407,18 @@ bool csr_int_exact(const ltmi_masks *m, int tile_dtype) {
     return data_bits + c->sum_bits <= 52;
 }
 
+// the detector shape behind the pixels (ltmi_masks_set_sig_shape): a stack of column blocks with a common support
+// each gets its folded dense image (ltmi_fold.hip, band_build); the host copy of the CSR arrays is released
+int csr_set_sig_shape(ltmi_masks *m, int sig_h, int sig_w) {
+    CsrImage *c = (CsrImage *)m->csr;
+    if (!c || !c->kept) return LTMI_OK;
+    band_destroy(c->band);
+    c->band = band_build(c->kept, sig_h, sig_w, c->bell ? c->bell_ratio * c->nnz_real : 0.);
+    band_free_csr(c->kept);
+    c->kept = nullptr;
+    return LTMI_OK;
+}
+
 // float32 frames: k_scatter only where the blocked image pads at least this much (per stored entry)
 static constexpr double SCAT_MIN_BELL_RATIO = 3.0;
 
@@ -467,6 +484,13 @@ int csr_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames,
     // (float32 frames by default -- measured 7 % ahead of the float32 blocked image on C4, and a non-finite
     // pixel reaches fewer foreign masks; 1- / 2-byte pixels stay on the blocked images, which are 15 - 30 %
     // faster there: profiles/r04_sparse.txt.  LTMI_SPARSE_SCATTER=1: every pixel type)
+    if (c->kept) {                                        // no detector shape came: the host copy is not needed
+        band_free_csr(c->kept);
+        c->kept = nullptr;
+    }
+    if (c->band && band_takes(c->band, m, tile, tile_dtype, ld_tile))
+        return band_apply(m, c->band, (const float *)tile, n_frames, ld_tile, (float *)out,
+                          ld_out * (c->cplx ? 2 : 1), (int)(m->n_masks * (c->cplx ? 2 : 1)), accumulate, stream);
     // ... unless the blocked image is well filled: a stack of dense column blocks (radial Fourier with several bins:
     // 1.3 padded MACs per stored entry) runs 3 x faster on the matrix cores (21 ms against 62 ms per 8192 frames
     // of 1024 x 1024, scripts/bench_second_runs.py); C4's rings (4.8) stay here
@@ -691,6 +715,8 @@ extern "C" int ltmi_masks_create_csr(int device, const int64_t *indptr, const in
             if (!c->scat) (void)hipGetLastError();
         }
     }
+    c->nnz_real = (double)nnz * nc;
+    if (!c->f64 && !int_result) c->kept = ltmi::band_keep_csr(indptr, indices, vals, nc, n_px, n_masks);
     *out = m;
     return LTMI_OK;
 }

@@ -782,9 +782,13 @@ def _check_sparse_kernel(kern, which, n_px, itemsize, n_nonzero=1):
         assert 'k_sell_apply' in kern, kern
 
 
-def _apply_csr(hip, data2d, csr_px_by_masks, result_dtype, accumulate_into=None):
+def _apply_csr(hip, data2d, csr_px_by_masks, result_dtype, accumulate_into=None, sig=None, tuning=None):
     h = hip.MaskHandle.csr(0, csr_px_by_masks, result_dtype)
     assert h.kind() == 2
+    if sig is not None:
+        h.set_sig_shape(sig[0], sig[1])
+    if tuning is not None:
+        h.set_tuning(0, tuning, 0)
     t = _dev(np.ascontiguousarray(data2d))
     n_frames, n_px = data2d.shape
     n_masks = csr_px_by_masks.shape[1]
@@ -2172,3 +2176,79 @@ def test_row_mirror_fold_two_byte_pixels(hip, tile_dtype, sig, n_bins, max_order
     for part in (np.real, np.imag):
         g, w = part(r1).astype(np.float64), part(want)
         assert np.all(np.abs(g - w) <= 1e-5 * np.abs(w)), np.max(np.abs(g - w) / np.maximum(np.abs(w), 1e-300))
+
+
+# ---- banded sparse stacks: column blocks with a common support each on k_dense_fold<.., LIST> (ltmi_fold.hip) --------
+
+def _radial_sparse(sig, n_bins, max_order):
+    from libertem_amd.analysis.radialfourier import radial_mask_factory
+    from libertem_amd import masks as pm
+    cy, cx = sig[0] / 2, sig[1] / 2
+    st = radial_mask_factory(sig[0], sig[1], cx, cy, 0, pm.bounding_radius(cx, cy, sig[1], sig[0]), n_bins, max_order, True)()
+    return st.to_px_by_masks(dtype=np.complex64)                          # (n_px, n_bins * (max_order + 1)) CSR
+
+
+@pytest.mark.parametrize('sig,n_bins,max_order,n_frames', [
+    ((96, 128), 3, 7, 300),             # 3 blocks of 8 complex masks: 1 even + 1 odd group
+    ((64, 192), 2, 24, 130),            # 2 blocks of 25: 2 + 2 groups
+    ((65, 64), 4, 11, 70),              # odd number of rows (an unpaired row), 1 + 1
+])
+def test_banded_stack_radial_fourier_sparse(hip, monkeypatch, sig, n_bins, max_order, n_frames):
+    """A radial-Fourier stack with several bins (second C5 run) as CSR: the masks of a bin share a
+    support and are dense on it -- one folded dense image per bin, k_dense_fold over the bin's stage list.  Against
+    float64, the blocked image (tuning 42), with accumulation, and every stored weight element-wise."""
+    monkeypatch.setenv('LTMI_SPARSE_BAND', '1')                           # (small stacks: take it whatever the estimate says)
+    csr = _radial_sparse(sig, n_bins, max_order)
+    n_px, n_masks = csr.shape
+    rng = np.random.default_rng(_seed('band', sig, n_bins, max_order))
+    data = rng.random((n_frames, n_px)).astype(np.float32)
+    data[1] = 1.0
+    res, kern = _apply_csr(hip, data, csr, np.complex64, sig=sig)
+    assert 'k_dense_fold<f' in kern and 'banded: %d blocks' % n_bins in kern, kern
+    res_b, kern_b = _apply_csr(hip, data, csr, np.complex64, sig=sig, tuning=42)
+    assert 'banded' not in kern_b, kern_b
+    dense = np.asarray(csr.todense()).astype(np.complex128)
+    ref = data.astype(np.float64) @ dense
+    scale = np.abs(data).astype(np.float64) @ np.abs(dense)
+    for part in (np.real, np.imag):
+        assert np.all(np.abs(part(res) - part(ref)) <= 1e-5 * scale + 1e-30)
+        assert np.all(np.abs(part(res) - part(res_b)) <= 2e-5 * scale + 1e-30)
+    base = (rng.random((n_frames, n_masks)) + 1j * rng.random((n_frames, n_masks))).astype(np.complex64)
+    res2, _ = _apply_csr(hip, data, csr, np.complex64, accumulate_into=base, sig=sig)
+    assert np.all(np.abs(res2 - (ref + base)) <= 1e-5 * (scale + 2))
+    # every stored weight: one-pixel frames, rtol 1e-5, atol 0 (also: exactly 0 where nothing is stored)
+    vals = (rng.random(n_px) + 0.5).astype(np.float32)
+    one = np.zeros((n_px, n_px), dtype=np.float32)
+    one[np.arange(n_px), np.arange(n_px)] = vals
+    r1, k1 = _apply_csr(hip, one, csr, np.complex64, sig=sig)
+    assert 'banded' in k1, k1
+    want = dense * vals[:, None].astype(np.float64)
+    for part in (np.real, np.imag):
+        g, w = part(r1).astype(np.float64), part(want)
+        assert np.all(np.abs(g - w) <= 1e-5 * np.abs(w)), np.max(np.abs(g - w) / np.maximum(np.abs(w), 1e-300))
+
+
+def test_banded_stack_only_where_it_applies(hip, monkeypatch):
+    """No banded image for stacks without a row mirror, for thin rings (one column per support: the estimate says no)
+    and for integer frames; LTMI_SPARSE_BAND=0 switches it off."""
+    import scipy.sparse as sp
+    from oracle import masks as omasks
+    monkeypatch.delenv('LTMI_SPARSE_BAND', raising=False)
+    sig = (64, 64)
+    data = np.random.default_rng(5).random((40, 4096)).astype(np.float32)
+    rings = sp.csr_matrix(omasks.radial_bins(32, 32, 64, 64, n_bins=64, use_sparse=True, dtype=np.float32).T.astype(np.float32))
+    _, kern = _apply_csr(hip, data, rings, np.float32, sig=sig)
+    assert 'banded' not in kern, kern
+    scattered = sp.random(4096, 96, density=0.01, format='csr', dtype=np.float32, random_state=np.random.RandomState(3))
+    _, kern = _apply_csr(hip, data, scattered, np.float32, sig=sig)
+    assert 'banded' not in kern, kern
+    monkeypatch.setenv('LTMI_SPARSE_BAND', '1')
+    csr = _radial_sparse((64, 128), 3, 7)
+    d2 = np.random.default_rng(6).integers(0, 4096, (40, 64 * 128)).astype(np.uint16)
+    _, kern = _apply_csr(hip, d2, csr, np.complex64, sig=(64, 128))
+    assert 'banded' not in kern, kern                                    # (integer frames: the blocked image)
+    _, kern = _apply_csr(hip, d2.astype(np.float32), csr, np.complex64, sig=(64, 128))
+    assert 'banded' in kern, kern
+    monkeypatch.setenv('LTMI_SPARSE_BAND', '0')
+    _, kern = _apply_csr(hip, d2.astype(np.float32), csr, np.complex64, sig=(64, 128))
+    assert 'banded' not in kern, kern
