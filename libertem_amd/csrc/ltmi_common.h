@@ -150,9 +150,9 @@ KeptCsr *band_keep_csr(const int64_t *indptr, const int64_t *indices, const floa
 void band_free_csr(KeptCsr *k);
 void *band_build(const KeptCsr *k, int sig_h, int sig_w, double other_macs);    // nullptr: the other kernels serve
 void band_destroy(void *band);
-bool band_takes(const void *band, const ltmi_masks *m, const void *tile, int tile_dtype, int64_t ld);
-int band_apply(ltmi_masks *m, void *band, const float *tile, int64_t n_frames, int64_t ld, float *out, int64_t ld_out,
-               int n_cols, int accumulate, hipStream_t stream);
+bool band_takes(void *band, const ltmi_masks *m, const void *tile, int tile_dtype, int64_t ld);   // float32, 1- / 2-byte integers
+int band_apply(ltmi_masks *m, void *band, const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, float *out,
+               int64_t ld_out, int n_cols, int accumulate, hipStream_t stream);
 bool fold_takes16(ltmi_masks *m, const void *tile, int64_t ld, int px_bytes);   // 1- / 2-byte integer frames (image built on first use)
 int launch_fold16(ltmi_masks *m, const void *tile, int px_bytes, bool is_signed, int64_t n_frames, int64_t ld,
                   float *out, int64_t ld_out, int accumulate, hipStream_t stream);

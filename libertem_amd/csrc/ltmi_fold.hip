@@ -415,13 +415,32 @@ __global__ void k_build_fold_image16(const float *__restrict__ src, float *__res
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <typename T, int NGE, int NGO>
+// the float32 banded image (64-pixel slots) -> 128-pixel slots: stage s of the new image is made of stages src[s].x
+// (pixels 0 - 63) and src[s].y (64 - 127) of the old one (-1: the block has nothing there)
+__global__ void k_build_band_image16(const float *__restrict__ img, float *__restrict__ img16,
+                                     const int2 *__restrict__ src, int ng, int64_t n_stages16) {
+    const int64_t total = n_stages16 * ng * GROUP * FD16_KB;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % FD16_KB);
+        const int n = (int)((i / FD16_KB) % GROUP);
+        const int g = (int)((i / (FD16_KB * GROUP)) % ng);
+        const int64_t s = i / ((int64_t)FD16_KB * GROUP * ng);
+        const int from = q < FD_KB ? src[s].x : src[s].y;
+        const float w = from < 0 ? 0.f : img[((int64_t)from * ng + g) * (GROUP * FD_KB) + fold_index(n, q % FD_KB)];
+        img16[(s * ng + g) * (GROUP * FD16_KB) + fold16_index(n, q)] = w;
+    }
+}
+
+// LIST: see k_dense_fold
+template <typename T, int NGE, int NGO, bool LIST = false>
 __global__ void __launch_bounds__(FD_WAVES * 64)
 k_dense_fold16(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int spr /* stages (128 px) per row */,
                const int2 *__restrict__ fold_rows, const float *__restrict__ img, int n_stages,
                float *__restrict__ out, int64_t ld_out, int n_cols, const int *__restrict__ colmap,
                int accumulate, float *__restrict__ partials, int ksplit,
-               const unsigned char *__restrict__ zeros, const int32_t *__restrict__ rows) {
+               const unsigned char *__restrict__ zeros, const int32_t *__restrict__ rows,
+               const int4 *__restrict__ stage_list, const int *__restrict__ blk_off) {
     static_assert(sizeof(T) <= 2, "1- and 2-byte pixels");
     constexpr int NG = NGE + NGO;
     constexpr int BSLOT = fold16_slot_bytes(NG);
@@ -440,10 +459,11 @@ k_dense_fold16(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int spr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int m = lane & 15, kg = lane >> 4;
-    const int ks = blockIdx.y;
+    const int ks = LIST ? 0 : blockIdx.y;
     const int per = (n_stages + ksplit - 1) / ksplit;
-    const int s_begin = ks * per;
-    const int s_end = min(n_stages, s_begin + per);
+    const int s_begin = LIST ? blk_off[blockIdx.y] : ks * per;
+    const int s_end = LIST ? blk_off[blockIdx.y + 1] : min(n_stages, s_begin + per);
+    if (LIST) colmap += blockIdx.y * (NG * GROUP);
 
     const int64_t f_wave = (int64_t)blockIdx.x * FD_WG_ROWS + wave * FD_ROWS;
     auto frame_of = [&](int r) -> int64_t {
@@ -477,12 +497,14 @@ k_dense_fold16(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int spr
         const unsigned char *zsrc = zeros + lane * 16;
         const unsigned char *bsrc = (const unsigned char *)img + wave * (BSLOT / FD_WAVES) + lane * 16;
 
-        int iss = s_begin, iss_fy = s_begin / spr, iss_xs = s_begin % spr;
+        int iss = s_begin, iss_fy = LIST ? 0 : s_begin / spr, iss_xs = LIST ? 0 : s_begin % spr;
+        int4 iss_st = LIST ? stage_list[s_begin] : int4{0, 0, 0, 0};
         auto issue_half = [&](auto TL, int q) {
             constexpr int tl = decltype(TL)::value;
-            const int2 rr = fold_rows[iss_fy];
-            const int64_t off_a = ((int64_t)rr.x * spr + iss_xs) * ROWB;
-            const int64_t off_c = ((int64_t)rr.y * spr + iss_xs) * ROWB;
+            const int2 rr = LIST ? int2{iss_st.x, iss_st.y} : fold_rows[iss_fy];
+            const int xs = LIST ? iss_st.z : iss_xs;
+            const int64_t off_a = ((int64_t)rr.x * spr + xs) * ROWB;
+            const int64_t off_c = ((int64_t)rr.y * spr + xs) * ROWB;
             const bool pair = rr.y >= 0;
             unsigned char *da = a_base + q * HALF, *dc = da + TPART;
 #pragma unroll
@@ -496,7 +518,8 @@ k_dense_fold16(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int spr
             }
             if (tl == FD_TILES - 1 && iss + 1 < s_end) {
                 ++iss;
-                if (++iss_xs == spr) { iss_xs = 0; ++iss_fy; }
+                if (LIST) iss_st = stage_list[iss];
+                else if (++iss_xs == spr) { iss_xs = 0; ++iss_fy; }
             }
         };
         auto issue_b = [&](int s, int bslot) {
@@ -862,7 +885,7 @@ template <typename T, int NGE, int NGO>
 static int launch_fold16_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64_t ld, float *out, int64_t ld_out,
                            int accumulate, hipStream_t stream) {
     const FoldImage *f = (const FoldImage *)m->fold;
-    auto kern = k_dense_fold16<T, NGE, NGO>;
+    auto kern = k_dense_fold16<T, NGE, NGO, false>;
     constexpr int LDS = ltmi::fold16_lds_bytes(NGE + NGO, (int)sizeof(T));
     static bool attr_set[16] = {false};
     if (!attr_set[m->device & 15]) {
@@ -885,7 +908,7 @@ static int launch_fold16_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64
     hipLaunchKernelGGL(kern, grid, dim3(FD_WAVES * 64), LDS, stream, tile, ld, n_frames, f->sig_w / FD16_KB,
                        (const int2 *)f->rows, (const float *)f->img16, f->n_stages16, out, ld_out, m->n_cols,
                        (const int *)f->colmap, accumulate, dense_partial_sums(m), ksplit,
-                       (const unsigned char *)f->zeros, m->roi_rows);
+                       (const unsigned char *)f->zeros, m->roi_rows, (const int4 *)nullptr, (const int *)nullptr);
     LTMI_HIP(hipGetLastError());
     snprintf(m->last_kernel, sizeof(m->last_kernel), "k_dense_fold16<%s,even=%d,odd=%d,rows %d+%d=%d%s> grid=(%u,%u)",
              typeid(T).name(), NGE, NGO, f->n_fold_rows, f->sig_h - f->n_fold_rows, f->c2, m->roi_rows ? ",rows" : "",
@@ -944,6 +967,17 @@ struct BandImage {
     int *blk_off = nullptr, *colmap = nullptr;
     unsigned char *zeros = nullptr;
     double reread = 0.;                         // stages per stage of the whole detector: how often a frame byte is read
+    // 1- / 2-byte integer frames: 128-pixel stages (k_dense_fold16); the lists are made with the float32 image, the
+    // image itself on the first integer tile (k_build_band_image16)
+    std::vector<int4> stages16_host;
+    std::vector<int2> src16_host;
+    std::vector<int> blk_off16_host;
+    float *img16 = nullptr;
+    int4 *stages16 = nullptr;
+    int *blk_off16 = nullptr;
+    int n_stages16 = 0;
+    bool img16_failed = false;
+    double reread16 = 0.;
 };
 
 ltmi::KeptCsr *ltmi::band_keep_csr(const int64_t *indptr, const int64_t *indices, const float *vals, int nc,
@@ -997,6 +1031,9 @@ void ltmi::band_destroy(void *band) {
     if (b->blk_off) (void)hipFree(b->blk_off);
     if (b->colmap) (void)hipFree(b->colmap);
     if (b->zeros) (void)hipFree(b->zeros);
+    if (b->img16) (void)hipFree(b->img16);
+    if (b->stages16) (void)hipFree(b->stages16);
+    if (b->blk_off16) (void)hipFree(b->blk_off16);
     delete b;
 }
 
@@ -1168,6 +1205,26 @@ void *ltmi::band_build(const KeptCsr *k, int sig_h, int sig_w, double other_macs
             }
             blk_off[blocks.size()] = (int)s;
         }
+        // 128-pixel stages of the same blocks (integer frames): pairs of the 64-pixel ones
+        std::vector<int4> stages16;
+        std::vector<int2> src16;
+        std::vector<int> blk_off16(blocks.size() + 1, 0);
+        if (sig_w % FD16_KB == 0) {
+            const int spr16 = sig_w / FD16_KB;
+            for (size_t bi = 0; bi < border.size(); ++bi) {
+                const size_t b = (size_t)border[bi];
+                blk_off16[bi] = (int)stages16.size();
+                for (size_t fy = 0; fy < rows.size(); ++fy)
+                    for (int x16 = 0; x16 < spr16; ++x16) {
+                        const int32_t sa = stage_id[b][fy * spr + 2 * (size_t)x16];
+                        const int32_t sb = stage_id[b][fy * spr + 2 * (size_t)x16 + 1];
+                        if (sa < 0 && sb < 0) continue;
+                        stages16.push_back(int4{rows[fy].x, rows[fy].y, x16, 0});
+                        src16.push_back(int2{sa, sb});
+                    }
+            }
+            blk_off16[blocks.size()] = (int)stages16.size();
+        }
         // image: the ORIGINAL weights of rows y (the first row of a pair)
         const size_t slot_floats = (size_t)ng * GROUP * FD_KB;
         std::vector<float> img(total * slot_floats, 0.f);
@@ -1192,6 +1249,11 @@ void *ltmi::band_build(const KeptCsr *k, int sig_h, int sig_w, double other_macs
         bi->sig_h = sig_h; bi->sig_w = sig_w; bi->c2 = best_c2; bi->nge = nge; bi->ngo = ngo;
         bi->n_blocks = (int)blocks.size(); bi->n_stages = (int)total; bi->n_fold_rows = (int)rows.size();
         bi->reread = reread;
+        bi->stages16_host.swap(stages16);
+        bi->src16_host.swap(src16);
+        bi->blk_off16_host.swap(blk_off16);
+        bi->n_stages16 = (int)bi->stages16_host.size();
+        bi->reread16 = sig_w % FD16_KB == 0 ? (double)bi->n_stages16 / (double)(rows.size() * (size_t)(sig_w / FD16_KB)) : 0.;
         hipError_t e = hipMalloc((void **)&bi->img, img.size() * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&bi->stages, stages.size() * sizeof(int4));
         if (e == hipSuccess) e = hipMalloc((void **)&bi->blk_off, blk_off.size() * sizeof(int));
@@ -1213,9 +1275,55 @@ void *ltmi::band_build(const KeptCsr *k, int sig_h, int sig_w, double other_macs
     }
 }
 
-bool ltmi::band_takes(const void *band, const ltmi_masks *m, const void *tile, int tile_dtype, int64_t ld) {
-    if (!band || tile_dtype != LTMI_F32 || m->tune_ksplit_ring == 41 || m->tune_ksplit_ring == 42) return false;
-    return ((uintptr_t)tile % 16 == 0) && (ld * 4) % 16 == 0;
+bool ltmi::band_takes(void *band, const ltmi_masks *m, const void *tile, int tile_dtype, int64_t ld) {
+    BandImage *b = (BandImage *)band;
+    if (!b || m->tune_ksplit_ring == 41 || m->tune_ksplit_ring == 42) return false;
+    if ((uintptr_t)tile % 16 != 0) return false;
+    if (tile_dtype == LTMI_F32) return (ld * 4) % 16 == 0;
+    const int px_bytes = (tile_dtype == LTMI_U8 || tile_dtype == LTMI_I8)
+                             ? 1
+                             : ((tile_dtype == LTMI_U16 || tile_dtype == LTMI_I16) ? 2 : 0);
+    if (!px_bytes || (ld * px_bytes) % 16 != 0 || b->n_stages16 == 0 || b->img16_failed) return false;
+    if (!b->img16) {
+        // first integer tile: the image in 128-pixel slots from the float32 one
+        const int ng = b->nge + b->ngo;
+        int2 *src = nullptr;
+        hipError_t e = hipMalloc((void **)&b->img16, (size_t)b->n_stages16 * ltmi::fold16_slot_bytes(ng));
+        if (e == hipSuccess) e = hipMalloc((void **)&b->stages16, b->stages16_host.size() * sizeof(int4));
+        if (e == hipSuccess) e = hipMalloc((void **)&b->blk_off16, b->blk_off16_host.size() * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&src, b->src16_host.size() * sizeof(int2));
+        if (e == hipSuccess)
+            e = hipMemcpy(b->stages16, b->stages16_host.data(), b->stages16_host.size() * sizeof(int4),
+                          hipMemcpyHostToDevice);
+        if (e == hipSuccess)
+            e = hipMemcpy(b->blk_off16, b->blk_off16_host.data(), b->blk_off16_host.size() * sizeof(int),
+                          hipMemcpyHostToDevice);
+        if (e == hipSuccess)
+            e = hipMemcpy(src, b->src16_host.data(), b->src16_host.size() * sizeof(int2), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            const int64_t tot = (int64_t)b->n_stages16 * ng * GROUP * FD16_KB;
+            const unsigned bl = (unsigned)std::min<int64_t>((tot + 255) / 256, 65535 * 16);
+            hipLaunchKernelGGL(ltmi::k_build_band_image16, dim3(bl), dim3(256), 0, 0, (const float *)b->img, b->img16,
+                               (const int2 *)src, ng, (int64_t)b->n_stages16);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+        }
+        if (src) (void)hipFree(src);
+        if (e != hipSuccess) {
+            if (b->img16) (void)hipFree(b->img16);
+            if (b->stages16) (void)hipFree(b->stages16);
+            if (b->blk_off16) (void)hipFree(b->blk_off16);
+            b->img16 = nullptr;
+            b->stages16 = nullptr;
+            b->blk_off16 = nullptr;
+            b->img16_failed = true;
+            (void)hipGetLastError();
+            return false;
+        }
+        std::vector<int4>().swap(b->stages16_host);
+        std::vector<int2>().swap(b->src16_host);
+    }
+    return true;
 }
 
 template <int NGE, int NGO>
@@ -1242,12 +1350,60 @@ static int launch_band_t(ltmi_masks *m, const BandImage *b, const float *tile, i
     return LTMI_OK;
 }
 
-int ltmi::band_apply(ltmi_masks *m, void *band, const float *tile, int64_t n_frames, int64_t ld, float *out,
-                     int64_t ld_out, int n_cols, int accumulate, hipStream_t stream) {
-    const BandImage *b = (const BandImage *)band;
+template <typename T, int NGE, int NGO>
+static int launch_band16_t(ltmi_masks *m, const BandImage *b, const T *tile, int64_t n_frames, int64_t ld, float *out,
+                           int64_t ld_out, int n_cols, int accumulate, hipStream_t stream) {
+    auto kern = k_dense_fold16<T, NGE, NGO, true>;
+    constexpr int LDS = ltmi::fold16_lds_bytes(NGE + NGO, (int)sizeof(T));
+    static bool attr_set[16] = {false};
+    if (!attr_set[m->device & 15]) {
+        LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set[m->device & 15] = true;
+    }
+    const int64_t gx = (n_frames + FD_WG_ROWS - 1) / FD_WG_ROWS;
+    dim3 grid((unsigned)gx, (unsigned)b->n_blocks);
+    hipLaunchKernelGGL(kern, grid, dim3(FD_WAVES * 64), LDS, stream, tile, ld, n_frames, b->sig_w / FD16_KB,
+                       (const int2 *)nullptr, (const float *)b->img16, b->n_stages16, out, ld_out, n_cols,
+                       (const int *)b->colmap, accumulate, (float *)nullptr, 1, (const unsigned char *)b->zeros,
+                       m->roi_rows, (const int4 *)b->stages16, (const int *)b->blk_off16);
+    LTMI_HIP(hipGetLastError());
+    snprintf(m->last_kernel, sizeof(m->last_kernel),
+             "k_dense_fold16<%s,even=%d,odd=%d,banded: %d blocks, %d stages (x%.2f), rows %d+%d=%d%s> grid=(%u,%u)",
+             typeid(T).name(), NGE, NGO, b->n_blocks, b->n_stages16, b->reread16, b->n_fold_rows,
+             b->sig_h - b->n_fold_rows, b->c2, m->roi_rows ? ",rows" : "", grid.x, grid.y);
+    return LTMI_OK;
+}
+
+template <typename T>
+static int band_apply16(ltmi_masks *m, const BandImage *b, const T *tile, int64_t n_frames, int64_t ld, float *out,
+                        int64_t ld_out, int n_cols, int accumulate, hipStream_t stream) {
 #define LTMI_BAND_CASE(E_, O_)                                                                                 \
     if (b->nge == E_ && b->ngo == O_)                                                                          \
-        return launch_band_t<E_, O_>(m, b, tile, n_frames, ld, out, ld_out, n_cols, accumulate, stream);
+        return launch_band16_t<T, E_, O_>(m, b, tile, n_frames, ld, out, ld_out, n_cols, accumulate, stream);
+    LTMI_BAND_CASE(1, 0) LTMI_BAND_CASE(2, 0) LTMI_BAND_CASE(1, 1) LTMI_BAND_CASE(2, 1) LTMI_BAND_CASE(1, 2)
+    LTMI_BAND_CASE(2, 2)
+#undef LTMI_BAND_CASE
+    LTMI_FAIL(LTMI_E_INVALID, "k_dense_fold16 (banded): no kernel for %d + %d groups", b->nge, b->ngo);
+}
+
+int ltmi::band_apply(ltmi_masks *m, void *band, const void *tile, int tile_dtype, int64_t n_frames, int64_t ld,
+                     float *out, int64_t ld_out, int n_cols, int accumulate, hipStream_t stream) {
+    const BandImage *b = (const BandImage *)band;
+    switch (tile_dtype) {
+        case LTMI_U8:
+            return band_apply16<uint8_t>(m, b, (const uint8_t *)tile, n_frames, ld, out, ld_out, n_cols, accumulate, stream);
+        case LTMI_I8:
+            return band_apply16<int8_t>(m, b, (const int8_t *)tile, n_frames, ld, out, ld_out, n_cols, accumulate, stream);
+        case LTMI_U16:
+            return band_apply16<uint16_t>(m, b, (const uint16_t *)tile, n_frames, ld, out, ld_out, n_cols, accumulate, stream);
+        case LTMI_I16:
+            return band_apply16<int16_t>(m, b, (const int16_t *)tile, n_frames, ld, out, ld_out, n_cols, accumulate, stream);
+        default: break;
+    }
+    const float *ft = (const float *)tile;
+#define LTMI_BAND_CASE(E_, O_)                                                                                 \
+    if (b->nge == E_ && b->ngo == O_)                                                                          \
+        return launch_band_t<E_, O_>(m, b, ft, n_frames, ld, out, ld_out, n_cols, accumulate, stream);
     LTMI_BAND_CASE(1, 0) LTMI_BAND_CASE(2, 0) LTMI_BAND_CASE(1, 1) LTMI_BAND_CASE(2, 1) LTMI_BAND_CASE(1, 2)
     LTMI_BAND_CASE(2, 2)
 #undef LTMI_BAND_CASE

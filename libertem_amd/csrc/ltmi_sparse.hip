@@ -489,7 +489,7 @@ int csr_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames,
         c->kept = nullptr;
     }
     if (c->band && band_takes(c->band, m, tile, tile_dtype, ld_tile))
-        return band_apply(m, c->band, (const float *)tile, n_frames, ld_tile, (float *)out,
+        return band_apply(m, c->band, tile, tile_dtype, n_frames, ld_tile, (float *)out,
                           ld_out * (c->cplx ? 2 : 1), (int)(m->n_masks * (c->cplx ? 2 : 1)), accumulate, stream);
     // ... unless the blocked image is well filled: a stack of dense column blocks (radial Fourier with several bins:
     // 1.3 padded MACs per stored entry) runs 3 x faster on the matrix cores (21 ms against 62 ms per 8192 frames
