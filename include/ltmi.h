@@ -94,7 +94,7 @@ int ltmi_masks_create_csr(int device, const int64_t *indptr, const int64_t *indi
                           const void *data, int result_dtype, int64_t n_px, int64_t n_masks,
                           ltmi_masks **out);
 
-/* Tells a dense float32 / complex64 handle the detector shape behind its n_px = sig_h * sig_w pixels (C order),
+/* Tells a float32 / complex64 handle the detector shape behind its n_px = sig_h * sig_w pixels (C order),
  * which the reference's MaskContainer knows from the mask arrays it stacks (common/container.py:260-314) and
  * flattens away before the product (udf/masks.py:79-83).  The library then looks for a mirror of the detector
  * rows, y -> c2 - y with c2 in {sig_h - 1, sig_h, sig_h + 1}, under which EVERY real column of the stack is even
@@ -103,13 +103,21 @@ int ltmi_masks_create_csr(int device, const int64_t *indptr, const int64_t *indi
  * more 16-column groups), keeps a folded image: float32 frames are then multiplied as
  * (x[y] + s x[c2 - y]) * w[y] over half of the rows with the stack's original weights (k_dense_fold).  Results
  * differ from the unfolded product by float32 round-off only; a stack without such a mirror is left as it is.
- * Optional; LTMI_DENSE_FOLD=0 in the environment disables the search. */
+ * A CSR handle (ltmi_masks_create_csr, float32 / complex64) whose masks fall into blocks with ONE pixel support each
+ * -- the orders of a bin in a radial-Fourier stack with several bins (n_bins > 1, use_sparse=True) -- and has such
+ * a mirror gets a folded DENSE image per block over the 64-pixel stages that touch the block's support
+ * (k_dense_fold / k_dense_fold16 over stage lists; float32 and 1- / 2-byte integer frames) when the cost estimate
+ * favours it over the blocked sparse image; ltmi_masks_kind then reports 3.  The handle keeps a host copy of the
+ * CSR arrays until this call or its first product.
+ * Optional; LTMI_DENSE_FOLD=0 / LTMI_SPARSE_BAND=0 in the environment disable the searches (LTMI_SPARSE_BAND=1:
+ * whatever the estimate says). */
 int ltmi_masks_set_sig_shape(ltmi_masks *m, int sig_h, int sig_w);
 
 int ltmi_masks_destroy(ltmi_masks *m);
 /* 0 = dense with float32 / complex64 results (f32 matrix cores), 1 = dense with any other result
  * dtype (float64, complex128 on real tiles, exactly representable integer sums: f64 matrix cores;
- * complex tiles and wider integers: VALU kernel), 2 = csr */
+ * complex tiles and wider integers: VALU kernel), 2 = csr, 3 = csr with a banded dense image (see
+ * ltmi_masks_set_sig_shape) */
 int ltmi_masks_kind(const ltmi_masks *m, int *kind);
 
 /* ---- the hot call -----------------------------------------------------------------------

@@ -52,6 +52,25 @@ def _worth_densifying(csr_px_by_masks, result_dtype):
     return cols16 <= 32 and touched > 0.5 * n_px
 
 
+def _maybe_banded(csr_px_by_masks, result_dtype):
+    """Cheap look at a sparse stack that `_worth_densifying` would multiply as a dense one: do its masks fall into
+    three or more groups of at least four masks with ONE pixel support each (the orders of a bin in a radial-Fourier
+    stack with several bins)?  The library then builds a dense image per group over that group's pixels only
+    (ltmi_masks_set_sig_shape, include/ltmi.h), which beats one dense pass per 32 complex masks over all pixels."""
+    n_px, n_masks = csr_px_by_masks.shape
+    nc = 2 if np.dtype(result_dtype).kind == 'c' else 1
+    if n_masks * nc <= 64 or np.dtype(result_dtype) not in (np.dtype(np.float32), np.dtype(np.complex64)):
+        return False
+    csc = csr_px_by_masks.tocsc()
+    csc.sort_indices()
+    groups = {}
+    for k in range(n_masks):
+        idx = csc.indices[csc.indptr[k]:csc.indptr[k + 1]]
+        key = (len(idx), hash(idx.tobytes()))
+        groups[key] = groups.get(key, 0) + 1
+    return len(groups) >= 3 and min(groups.values()) >= 4
+
+
 def _sparse_int_exact(csr_px_by_masks, tile_dtypes):
     """Integer stack x integer frames through the float64 gather kernel: exact iff every possible
     partial sum stays below 2^52 -- bits of the widest tile dtype + bits of the largest column sum of
@@ -266,12 +285,22 @@ class MaskContainer:
                 m = sp.csr_matrix(self.get_for_sig_slice(
                     sig_slice, dtype=result_dtype, sparse_backend='scipy.sparse.csr',
                     transpose=True))                                     # (px, n_masks)
+                sig2 = tuple(int(n) for n in sig_slice.shape.sig)
                 if _worth_densifying(m, result_dtype):
                     # a "sparse" stack that is mostly filled (e.g. the radial Fourier orders of one
                     # wide ring): the dense matrix-core kernel multiplies fewer zeros than the
-                    # blocked sparse image pads, and streams the stack instead of gathering
-                    dense = np.ascontiguousarray(m.T.toarray().astype(result_dtype, copy=False))
-                    h = hip.MaskHandle.dense(device, dense, result_dtype)
+                    # blocked sparse image pads, and streams the stack instead of gathering --
+                    # unless the library finds column blocks with a support each (a few wide bins)
+                    h = None
+                    if len(sig2) == 2 and m.shape[0] == sig2[0] * sig2[1] and _maybe_banded(m, result_dtype):
+                        h = hip.MaskHandle.csr(device, m, result_dtype)
+                        h.set_sig_shape(sig2[0], sig2[1])
+                        if h.kind() != 3:
+                            h.close()
+                            h = None
+                    if h is None:
+                        dense = np.ascontiguousarray(m.T.toarray().astype(result_dtype, copy=False))
+                        h = hip.MaskHandle.dense(device, dense, result_dtype)
                 else:
                     h = hip.MaskHandle.csr(device, m, result_dtype)
             # the detector shape of the slice: a dense float32 / complex64 stack that is even / odd under a

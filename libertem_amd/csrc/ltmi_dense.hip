@@ -1339,6 +1339,7 @@ using namespace ltmi;
 namespace ltmi {
 int csr_destroy(ltmi_masks *m);   // ltmi_sparse.hip
 int csr_set_sig_shape(ltmi_masks *m, int sig_h, int sig_w);
+bool csr_has_band(const ltmi_masks *m);
 bool csr_rows_ok(const ltmi_masks *m, const void *tile, int tile_dtype, int64_t ld_tile);
 int csr_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames, int64_t ld_tile,
               void *out, int64_t ld_out, int accumulate, hipStream_t stream);
@@ -1676,7 +1677,7 @@ extern "C" int ltmi_masks_set_sig_shape(ltmi_masks *m, int sig_h, int sig_w) {
 
 extern "C" int ltmi_masks_kind(const ltmi_masks *m, int *kind) {
     if (!m || !kind) LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_kind: null argument");
-    *kind = m->kind;
+    *kind = (m->kind == 2 && ltmi::csr_has_band(m)) ? 3 : m->kind;
     return LTMI_OK;
 }
 

@@ -419,6 +419,11 @@ int csr_set_sig_shape(ltmi_masks *m, int sig_h, int sig_w) {
     return LTMI_OK;
 }
 
+bool csr_has_band(const ltmi_masks *m) {
+    const CsrImage *c = (const CsrImage *)m->csr;
+    return c && c->band;
+}
+
 // float32 frames: k_scatter only where the blocked image pads at least this much (per stored entry)
 static constexpr double SCAT_MIN_BELL_RATIO = 3.0;
 
