@@ -54,9 +54,11 @@ def _worth_densifying(csr_px_by_masks, result_dtype):
 
 def _maybe_banded(csr_px_by_masks, result_dtype):
     """Cheap look at a sparse stack that `_worth_densifying` would multiply as a dense one: do its masks fall into
-    three or more groups of at least four masks with ONE pixel support each (the orders of a bin in a radial-Fourier
+    two or more groups of at least four masks with ONE pixel support each (the orders of a bin in a radial-Fourier
     stack with several bins)?  The library then builds a dense image per group over that group's pixels only
-    (ltmi_masks_set_sig_shape, include/ltmi.h), which beats one dense pass per 32 complex masks over all pixels."""
+    (ltmi_masks_set_sig_shape, include/ltmi.h), which beats one dense pass per 32 complex masks over all pixels
+    (4096 frames of 1024 x 1024 float32, 25 orders: 2 / 3 / 4 / 8 bins 7.4 / 11.1 / 15.2 / 27.5 ms dense,
+    3.9 / 4.1 / 4.3 / 4.8 ms banded; scripts/r5_run15.sh)."""
     n_px, n_masks = csr_px_by_masks.shape
     nc = 2 if np.dtype(result_dtype).kind == 'c' else 1
     if n_masks * nc <= 64 or np.dtype(result_dtype) not in (np.dtype(np.float32), np.dtype(np.complex64)):
@@ -68,7 +70,7 @@ def _maybe_banded(csr_px_by_masks, result_dtype):
         idx = csc.indices[csc.indptr[k]:csc.indptr[k + 1]]
         key = (len(idx), hash(idx.tobytes()))
         groups[key] = groups.get(key, 0) + 1
-    return len(groups) >= 3 and min(groups.values()) >= 4
+    return len(groups) >= 2 and min(groups.values()) >= 4
 
 
 def _sparse_int_exact(csr_px_by_masks, tile_dtypes):

@@ -160,7 +160,7 @@ int launch_fold16(ltmi_masks *m, const void *tile, int px_bytes, bool is_signed,
 int dense_ensure_partials(ltmi_masks *m, size_t need, hipStream_t stream);
 float *dense_partial_sums(const ltmi_masks *m);
 int dense_reduce_partials(ltmi_masks *m, int ksplit, int64_t n_frames, float *out, int64_t ld_out, int accumulate,
-                          hipStream_t stream);
+                          hipStream_t stream, int n_cols = -1);   // n_cols <= 0: the handle's
 // ... on RAW frames with the detector corrections applied inside the row stage (256 x 256 frames)
 int64_t cryst_corr_workspace_bytes(int h, int w, int64_t n_frames, int n_excl);
 bool cryst_corr_takes(int h, int w, int n_cols, int tile_dtype, int n_excl);

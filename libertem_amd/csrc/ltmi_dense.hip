@@ -1968,10 +1968,11 @@ static int launch_lds_extras(ltmi_masks *m, const T *tile, int64_t n_frames, int
 int ltmi::dense_ensure_partials(ltmi_masks *m, size_t need, hipStream_t stream) { return ensure_partials(m, need, stream); }
 float *ltmi::dense_partial_sums(const ltmi_masks *m) { return partial_sums(m); }
 int ltmi::dense_reduce_partials(ltmi_masks *m, int ksplit, int64_t n_frames, float *out, int64_t ld_out, int accumulate,
-                                hipStream_t stream) {
-    const int64_t n = n_frames * m->n_cols;
+                                hipStream_t stream, int n_cols) {
+    if (n_cols <= 0) n_cols = m->n_cols;
+    const int64_t n = n_frames * n_cols;
     hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                       (const float *)partial_sums(m), ksplit, n_frames, m->n_cols, out, ld_out, accumulate);
+                       (const float *)partial_sums(m), ksplit, n_frames, n_cols, out, ld_out, accumulate);
     LTMI_HIP(hipGetLastError());
     return LTMI_OK;
 }

@@ -133,11 +133,14 @@ k_dense_fold(const float *__restrict__ tile, int64_t ld, int64_t n_frames, int s
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int m = lane & 15, kg = lane >> 4;
-    const int ks = LIST ? 0 : blockIdx.y;
-    const int per = (n_stages + ksplit - 1) / ksplit;
-    const int s_begin = LIST ? blk_off[blockIdx.y] : ks * per;
-    const int s_end = LIST ? blk_off[blockIdx.y + 1] : min(n_stages, s_begin + per);
-    if (LIST) colmap += blockIdx.y * (NG * GROUP);
+    // LIST: blockIdx.y = block * ksplit + part of the block's stage list
+    const int by = LIST ? blockIdx.y / ksplit : 0;
+    const int ks = LIST ? blockIdx.y - by * ksplit : blockIdx.y;
+    const int b0 = LIST ? blk_off[by] : 0, b1 = LIST ? blk_off[by + 1] : n_stages;
+    const int per = (b1 - b0 + ksplit - 1) / ksplit;
+    const int s_begin = b0 + ks * per;
+    const int s_end = min(b1, s_begin + per);
+    if (LIST) colmap += by * (NG * GROUP);
 
     const int64_t f_wave = (int64_t)blockIdx.x * FD_WG_ROWS + wave * FD_ROWS;
     auto frame_of = [&](int r) -> int64_t {                 // result row (-1: none)
@@ -459,11 +462,14 @@ k_dense_fold16(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int spr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int m = lane & 15, kg = lane >> 4;
-    const int ks = LIST ? 0 : blockIdx.y;
-    const int per = (n_stages + ksplit - 1) / ksplit;
-    const int s_begin = LIST ? blk_off[blockIdx.y] : ks * per;
-    const int s_end = LIST ? blk_off[blockIdx.y + 1] : min(n_stages, s_begin + per);
-    if (LIST) colmap += blockIdx.y * (NG * GROUP);
+    // LIST: blockIdx.y = block * ksplit + part of the block's stage list
+    const int by = LIST ? blockIdx.y / ksplit : 0;
+    const int ks = LIST ? blockIdx.y - by * ksplit : blockIdx.y;
+    const int b0 = LIST ? blk_off[by] : 0, b1 = LIST ? blk_off[by + 1] : n_stages;
+    const int per = (b1 - b0 + ksplit - 1) / ksplit;
+    const int s_begin = b0 + ks * per;
+    const int s_end = min(b1, s_begin + per);
+    if (LIST) colmap += by * (NG * GROUP);
 
     const int64_t f_wave = (int64_t)blockIdx.x * FD_WG_ROWS + wave * FD_ROWS;
     auto frame_of = [&](int r) -> int64_t {
@@ -1326,6 +1332,16 @@ bool ltmi::band_takes(void *band, const ltmi_masks *m, const void *tile, int til
     return true;
 }
 
+// parts per block: enough workgroups for two rounds on the 256 CUs, at least 32 stages each (tuning: ksplit forced)
+static int band_ksplit(const ltmi_masks *m, int64_t gx, int n_blocks, int n_stages) {
+    if (m->tune_ksplit > 0) return std::min(m->tune_ksplit, 64);
+    const int64_t wgs = gx * n_blocks;
+    int k = (int)std::min<int64_t>(16, (512 + wgs - 1) / wgs);
+    const int avg = std::max(1, n_stages / std::max(1, n_blocks));
+    k = std::min(k, std::max(1, avg / 32));
+    return std::max(1, k);
+}
+
 template <int NGE, int NGO>
 static int launch_band_t(ltmi_masks *m, const BandImage *b, const float *tile, int64_t n_frames, int64_t ld, float *out,
                          int64_t ld_out, int n_cols, int accumulate, hipStream_t stream) {
@@ -1337,12 +1353,21 @@ static int launch_band_t(ltmi_masks *m, const BandImage *b, const float *tile, i
         attr_set[m->device & 15] = true;
     }
     const int64_t gx = (n_frames + FD_WG_ROWS - 1) / FD_WG_ROWS;
-    dim3 grid((unsigned)gx, (unsigned)b->n_blocks);
+    const int ksplit = band_ksplit(m, gx, b->n_blocks, b->n_stages);
+    if (ksplit > 1) {
+        const int rc = dense_ensure_partials(m, (size_t)ksplit * n_frames * n_cols * sizeof(float), stream);
+        if (rc != LTMI_OK) return rc;
+    }
+    dim3 grid((unsigned)gx, (unsigned)(b->n_blocks * ksplit));
     hipLaunchKernelGGL(kern, grid, dim3(FD_WAVES * 64), LDS, stream, tile, ld, n_frames, b->sig_w / FD_KB,
                        (const int2 *)nullptr, (const float *)b->img, b->n_stages, out, ld_out, n_cols,
-                       (const int *)b->colmap, accumulate, (float *)nullptr, 1, (const unsigned char *)b->zeros,
-                       m->roi_rows, (const int4 *)b->stages, (const int *)b->blk_off);
+                       (const int *)b->colmap, accumulate, dense_partial_sums(m), ksplit,
+                       (const unsigned char *)b->zeros, m->roi_rows, (const int4 *)b->stages, (const int *)b->blk_off);
     LTMI_HIP(hipGetLastError());
+    if (ksplit > 1) {
+        const int rc = dense_reduce_partials(m, ksplit, n_frames, out, ld_out, accumulate, stream, n_cols);
+        if (rc != LTMI_OK) return rc;
+    }
     snprintf(m->last_kernel, sizeof(m->last_kernel),
              "k_dense_fold<f,even=%d,odd=%d,banded: %d blocks, %d stages (x%.2f), rows %d+%d=%d%s> grid=(%u,%u)", NGE, NGO,
              b->n_blocks, b->n_stages, b->reread, b->n_fold_rows, b->sig_h - b->n_fold_rows, b->c2,
@@ -1361,12 +1386,22 @@ static int launch_band16_t(ltmi_masks *m, const BandImage *b, const T *tile, int
         attr_set[m->device & 15] = true;
     }
     const int64_t gx = (n_frames + FD_WG_ROWS - 1) / FD_WG_ROWS;
-    dim3 grid((unsigned)gx, (unsigned)b->n_blocks);
+    const int ksplit = band_ksplit(m, gx, b->n_blocks, b->n_stages16);
+    if (ksplit > 1) {
+        const int rc = dense_ensure_partials(m, (size_t)ksplit * n_frames * n_cols * sizeof(float), stream);
+        if (rc != LTMI_OK) return rc;
+    }
+    dim3 grid((unsigned)gx, (unsigned)(b->n_blocks * ksplit));
     hipLaunchKernelGGL(kern, grid, dim3(FD_WAVES * 64), LDS, stream, tile, ld, n_frames, b->sig_w / FD16_KB,
                        (const int2 *)nullptr, (const float *)b->img16, b->n_stages16, out, ld_out, n_cols,
-                       (const int *)b->colmap, accumulate, (float *)nullptr, 1, (const unsigned char *)b->zeros,
-                       m->roi_rows, (const int4 *)b->stages16, (const int *)b->blk_off16);
+                       (const int *)b->colmap, accumulate, dense_partial_sums(m), ksplit,
+                       (const unsigned char *)b->zeros, m->roi_rows, (const int4 *)b->stages16,
+                       (const int *)b->blk_off16);
     LTMI_HIP(hipGetLastError());
+    if (ksplit > 1) {
+        const int rc = dense_reduce_partials(m, ksplit, n_frames, out, ld_out, accumulate, stream, n_cols);
+        if (rc != LTMI_OK) return rc;
+    }
     snprintf(m->last_kernel, sizeof(m->last_kernel),
              "k_dense_fold16<%s,even=%d,odd=%d,banded: %d blocks, %d stages (x%.2f), rows %d+%d=%d%s> grid=(%u,%u)",
              typeid(T).name(), NGE, NGO, b->n_blocks, b->n_stages16, b->reread16, b->n_fold_rows,

@@ -54,12 +54,13 @@ for key, dtype in (('c5s', torch.float32), ('c5s_u16', torch.int16)):
         fr = torch.randint(0, 4096, (n, 1024, 1024), device='cuda', dtype=torch.int16)
         npdt = np.dtype('uint16')
     ds = ctx.load('memory', data=fr.reshape((n // 128, 128, 1024, 1024)), dtype=npdt, sig_dims=2, num_partitions=1)
-    an = ctx.create_radial_fourier_analysis(dataset=ds, n_bins=16, max_order=24, use_sparse=True)
-    res = run(f'C5, n_bins=16, max_order=24, use_sparse=True ({n} frames of 1024x1024 {npdt})', an, fr, n)
+    NB = int(os.environ.get('C5S_BINS', 16))
+    an = ctx.create_radial_fourier_analysis(dataset=ds, n_bins=NB, max_order=24, use_sparse=True)
+    res = run(f'C5, n_bins={NB}, max_order=24, use_sparse=True ({n} frames of 1024x1024 {npdt})', an, fr, n)
     stack = an.get_mask_factories()()
     stack = stack.todense() if hasattr(stack, 'todense') else np.asarray(stack)
-    stack = np.asarray(stack).reshape((400, -1)).astype(np.complex128)
-    raw = res.raw_results.reshape((400, -1))
+    stack = np.asarray(stack).reshape((25 * NB, -1)).astype(np.complex128)
+    raw = res.raw_results.reshape((25 * NB, -1))
     for i in (0, n - 1):
         f = fr[i].cpu().numpy()
         f = (f.view(np.uint16) if npdt == np.dtype('uint16') else f).astype(np.float64).reshape(-1)

@@ -782,13 +782,13 @@ def _check_sparse_kernel(kern, which, n_px, itemsize, n_nonzero=1):
         assert 'k_sell_apply' in kern, kern
 
 
-def _apply_csr(hip, data2d, csr_px_by_masks, result_dtype, accumulate_into=None, sig=None, tuning=None):
+def _apply_csr(hip, data2d, csr_px_by_masks, result_dtype, accumulate_into=None, sig=None, tuning=None, ksplit=0):
     h = hip.MaskHandle.csr(0, csr_px_by_masks, result_dtype)
     assert h.kind() == 2
     if sig is not None:
         h.set_sig_shape(sig[0], sig[1])
-    if tuning is not None:
-        h.set_tuning(0, tuning, 0)
+    if tuning is not None or ksplit:
+        h.set_tuning(0, tuning or 40, ksplit)
     t = _dev(np.ascontiguousarray(data2d))
     n_frames, n_px = data2d.shape
     n_masks = csr_px_by_masks.shape[1]
@@ -2189,13 +2189,15 @@ def _radial_sparse(sig, n_bins, max_order):
 
 
 @pytest.mark.parametrize('tile_dtype', ['float32', 'uint16', 'int16', 'uint8'])
-@pytest.mark.parametrize('sig,n_bins,max_order,n_frames', [
-    ((96, 128), 3, 7, 300),             # 3 blocks of 8 complex masks: 1 even + 1 odd group
-    ((64, 192), 2, 24, 130),            # 2 blocks of 25: 2 + 2 groups (192 is not a multiple of 128: integer frames elsewhere)
-    ((65, 64), 4, 11, 70),              # odd number of rows (an unpaired row), 1 + 1
-    ((32, 256), 2, 24, 200),            # 2 + 2 groups, two 128-pixel stages per row
+@pytest.mark.parametrize('sig,n_bins,max_order,n_frames,ksplit', [
+    ((96, 128), 3, 7, 300, 0),          # 3 blocks of 8 complex masks: 1 even + 1 odd group
+    ((64, 192), 2, 24, 130, 0),         # 2 blocks of 25: 2 + 2 groups (192 is not a multiple of 128: integer frames elsewhere)
+    ((65, 64), 4, 11, 70, 0),           # odd number of rows (an unpaired row), 1 + 1
+    ((32, 256), 2, 24, 200, 0),         # 2 + 2 groups, two 128-pixel stages per row
+    ((96, 128), 3, 7, 200, 5),          # every block's stage list in 5 parts (partial sums + reduction)
+    ((64, 128), 2, 24, 40, 64),         # more parts than some blocks have stages
 ])
-def test_banded_stack_radial_fourier_sparse(hip, monkeypatch, tile_dtype, sig, n_bins, max_order, n_frames):
+def test_banded_stack_radial_fourier_sparse(hip, monkeypatch, tile_dtype, sig, n_bins, max_order, n_frames, ksplit):
     """A radial-Fourier stack with several bins (second C5 run) as CSR: the masks of a bin share a
     support and are dense on it -- one folded dense image per bin, k_dense_fold / k_dense_fold16 over the bin's stage
     list.  Against float64, the blocked image (tuning 42), with accumulation, and every stored weight element-wise."""
@@ -2215,7 +2217,7 @@ def test_banded_stack_radial_fourier_sparse(hip, monkeypatch, tile_dtype, sig, n
         data[2] = lo
         label = 'k_dense_fold16<'
     banded = dt.kind == 'f' or sig[1] % 128 == 0
-    res, kern = _apply_csr(hip, data, csr, np.complex64, sig=sig)
+    res, kern = _apply_csr(hip, data, csr, np.complex64, sig=sig, ksplit=ksplit)
     if not banded:
         assert 'banded' not in kern, kern
         return
@@ -2231,7 +2233,7 @@ def test_banded_stack_radial_fourier_sparse(hip, monkeypatch, tile_dtype, sig, n
         # drifts to 1.4e-5 - 2.7e-5 there, measured; the folded kernels flush every 512 pixels: 1.4e-6)
         assert np.all(np.abs(part(res) - part(res_b)) <= 5e-5 * scale + 1e-30)
     base = (rng.random((n_frames, n_masks)) + 1j * rng.random((n_frames, n_masks))).astype(np.complex64)
-    res2, _ = _apply_csr(hip, data, csr, np.complex64, accumulate_into=base, sig=sig)
+    res2, _ = _apply_csr(hip, data, csr, np.complex64, accumulate_into=base, sig=sig, ksplit=ksplit)
     assert np.all(np.abs(res2 - (ref + base)) <= 1e-5 * (scale + 2))
     # every stored weight: one-pixel frames, rtol 1e-5, atol 0 (also: exactly 0 where nothing is stored)
     if dt.kind == 'f':
@@ -2240,7 +2242,7 @@ def test_banded_stack_radial_fourier_sparse(hip, monkeypatch, tile_dtype, sig, n
         vals = rng.integers(1, hi, n_px, endpoint=True).astype(dt)
     one = np.zeros((n_px, n_px), dtype=dt)
     one[np.arange(n_px), np.arange(n_px)] = vals
-    r1, k1 = _apply_csr(hip, one, csr, np.complex64, sig=sig)
+    r1, k1 = _apply_csr(hip, one, csr, np.complex64, sig=sig, ksplit=ksplit)
     assert 'banded' in k1, k1
     want = dense * vals[:, None].astype(np.float64)
     for part in (np.real, np.imag):
