@@ -30,6 +30,7 @@
 #include <vector>
 #include <cstdlib>
 #include <algorithm>
+#include <exception>
 #include <climits>
 #include <cstdint>
 #include <type_traits>
@@ -184,9 +185,10 @@ k_dense_fold(const float *__restrict__ tile, int64_t ld, int64_t n_frames, int s
             constexpr int tl = decltype(TL)::value, q = decltype(Q)::value;
             if (ABL >= 2) return;
             const int2 rr = LIST ? int2{iss_st.x, iss_st.y} : fold_rows[iss_fy];
-            const int xs = LIST ? iss_st.z : iss_xs;
-            const int64_t off_a = ((int64_t)rr.x * spr + xs) * 256;
-            const int64_t off_c = ((int64_t)rr.y * spr + xs) * 256;
+            // (LIST: a window starts at pixel iss_st.z of its row, any multiple of 16)
+            const int64_t x_px = LIST ? iss_st.z : iss_xs * FD_KB;
+            const int64_t off_a = ((int64_t)rr.x * spr * FD_KB + x_px) * 4;
+            const int64_t off_c = ((int64_t)rr.y * spr * FD_KB + x_px) * 4;
             const bool pair = rr.y >= 0;
             unsigned char *da = a_base + q * FD_HALF, *dc = da + FD_TPART;
 #pragma unroll
@@ -418,10 +420,12 @@ __global__ void k_build_fold_image16(const float *__restrict__ src, float *__res
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// the float32 banded image (64-pixel slots) -> 128-pixel slots: stage s of the new image is made of stages src[s].x
-// (pixels 0 - 63) and src[s].y (64 - 127) of the old one (-1: the block has nothing there)
+// the float32 banded image (64-pixel windows) -> 128-pixel windows: window s of the new image starts at pixel
+// st[s].z of its row and owns the pixels from st[s].w on; its weights come from the 64-pixel windows src[2 s] (stage
+// numbers, -1: none) that start at pixels src[2 s + 1] -- a pixel has a weight in exactly one of them (the others hold 0)
 __global__ void k_build_band_image16(const float *__restrict__ img, float *__restrict__ img16,
-                                     const int2 *__restrict__ src, int ng, int64_t n_stages16) {
+                                     const int4 *__restrict__ st, const int4 *__restrict__ src, int ng,
+                                     int64_t n_stages16) {
     const int64_t total = n_stages16 * ng * GROUP * FD16_KB;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -429,8 +433,18 @@ __global__ void k_build_band_image16(const float *__restrict__ img, float *__res
         const int n = (int)((i / FD16_KB) % GROUP);
         const int g = (int)((i / (FD16_KB * GROUP)) % ng);
         const int64_t s = i / ((int64_t)FD16_KB * GROUP * ng);
-        const int from = q < FD_KB ? src[s].x : src[s].y;
-        const float w = from < 0 ? 0.f : img[((int64_t)from * ng + g) * (GROUP * FD_KB) + fold_index(n, q % FD_KB)];
+        const int x = st[s].z + q;
+        float w = 0.f;
+        if (x >= st[s].w) {
+            const int4 ids = src[2 * s], x0s = src[2 * s + 1];
+            const int id[4] = {ids.x, ids.y, ids.z, ids.w}, x0[4] = {x0s.x, x0s.y, x0s.z, x0s.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q64 = x - x0[j];
+                if (id[j] >= 0 && q64 >= 0 && q64 < FD_KB)
+                    w += img[((int64_t)id[j] * ng + g) * (GROUP * FD_KB) + fold_index(n, q64)];
+            }
+        }
         img16[(s * ng + g) * (GROUP * FD16_KB) + fold16_index(n, q)] = w;
     }
 }
@@ -508,9 +522,9 @@ k_dense_fold16(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int spr
         auto issue_half = [&](auto TL, int q) {
             constexpr int tl = decltype(TL)::value;
             const int2 rr = LIST ? int2{iss_st.x, iss_st.y} : fold_rows[iss_fy];
-            const int xs = LIST ? iss_st.z : iss_xs;
-            const int64_t off_a = ((int64_t)rr.x * spr + xs) * ROWB;
-            const int64_t off_c = ((int64_t)rr.y * spr + xs) * ROWB;
+            const int64_t x_px = LIST ? iss_st.z : iss_xs * FD16_KB;
+            const int64_t off_a = ((int64_t)rr.x * spr * FD16_KB + x_px) * (int)sizeof(T);
+            const int64_t off_c = ((int64_t)rr.y * spr * FD16_KB + x_px) * (int)sizeof(T);
             const bool pair = rr.y >= 0;
             unsigned char *da = a_base + q * HALF, *dc = da + TPART;
 #pragma unroll
@@ -976,7 +990,7 @@ struct BandImage {
     // 1- / 2-byte integer frames: 128-pixel stages (k_dense_fold16); the lists are made with the float32 image, the
     // image itself on the first integer tile (k_build_band_image16)
     std::vector<int4> stages16_host;
-    std::vector<int2> src16_host;
+    std::vector<int4> src16_host;                // two per stage: the 64-pixel stages it is made of, their first pixels
     std::vector<int> blk_off16_host;
     float *img16 = nullptr;
     int4 *stages16 = nullptr;
@@ -1020,7 +1034,7 @@ ltmi::KeptCsr *ltmi::band_keep_csr(const int64_t *indptr, const int64_t *indices
                 for (int c = 0; c < nc; ++c) k->val[((size_t)e0 + i) * nc + c] = vals[row[i].second * nc + c];
             }
         }
-    } catch (const std::bad_alloc &) {
+    } catch (const std::exception &) {          // (bad_alloc, length_error: no image)
         delete k;
         return nullptr;
     }
@@ -1142,7 +1156,21 @@ void *ltmi::band_build(const KeptCsr *k, int sig_h, int sig_w, double other_macs
         }
         const int ng = nge + ngo;
 
-        // ---- folded rows, stages of every block ----
+        // ---- folded rows; per block and folded row the WINDOWS of 64 (128: integer frames) pixels that cover its support ----
+        // A window need not start on a grid of whole windows -- the copies take any 16-byte boundary -- so a run of the
+        // support that is shorter than a window can cost one stage wherever it lies; but rows that start inside a
+        // 256-byte piece cost the copy path more per stage.  Measured on 1024 x 1024 float32, 25 orders (stages, ms per
+        // 8192 frames at 16 bins / per 4096 frames below):
+        //     bins   grid of 64 px       starts at 32 px      starts at 16 px
+        //      16    15 771  12.1        14 263  11.65        12 656  11.38
+        //       8    11 897   4.82       10 835   4.64        10 508   4.86
+        //       4     9 969   4.27        9 627   4.31         9 485   4.53
+        //       2     8 942   3.59        8 783   3.67         8 783   3.90
+        // (uint16, 128-pixel windows, 16 bins: grid 11 631 15.4 ms, 64 px 9 139 12.6 ms, 16 px 8 715 12.3 ms) -- a stage
+        // costs 1.065 / 1.17 (uint16: 1.045 / 1.065) of a grid stage; the builder covers the support with all three and
+        // keeps the cheapest by that count.  Windows of one row may overlap (the start is rounded down, the last one is
+        // pushed back inside the row): a pixel belongs to the FIRST window that covers it (`own` = first pixel a window
+        // owns), the later one holds weight 0 there.
         std::vector<int2> rows;
         std::vector<int> fold_row_of((size_t)sig_h, -1);
         for (int y = 0; y < sig_h; ++y) {
@@ -1162,17 +1190,83 @@ void *ltmi::band_build(const KeptCsr *k, int sig_h, int sig_w, double other_macs
                     vcol[(size_t)mk * nc + c] = cls[(size_t)mk * nc + c] > 0 ? ie++ : io++;
             }
         }
-        std::vector<std::vector<unsigned char>> touched(blocks.size(), std::vector<unsigned char>(n_slots, 0));
-        for (int64_t p = 0; p < k->n_px; ++p) {
-            const size_t slot = (size_t)fold_row_of[(size_t)(p / sig_w)] * spr + (size_t)((p % sig_w) / FD_KB);
-            for (int64_t e = k->indptr[(size_t)p]; e < k->indptr[(size_t)p + 1]; ++e)
-                touched[(size_t)block_of[(size_t)k->idx[(size_t)e]]][slot] = 1;
+        struct Win { int fy, x0, own; };
+        // candidates: (start alignment in pixels, measured cost of a stage relative to the grid's)
+        constexpr int N_ALIGN = 3;
+        const int aligns[N_ALIGN] = {FD_KB, 32, 16}, aligns16[N_ALIGN] = {FD16_KB, 64, 16};
+        const double stage_cost[N_ALIGN] = {1.0, 1.065, 1.17}, stage_cost16[N_ALIGN] = {1.0, 1.045, 1.065};
+        const bool with16 = sig_w % FD16_KB == 0;
+        std::vector<std::vector<Win>> wins(blocks.size()), wins16(blocks.size());
+        std::vector<std::vector<int>> row_first(blocks.size());      // [fy]: first window of the row in wins[b] (+ end)
+        std::vector<std::vector<Win>> cand[N_ALIGN], cand16[N_ALIGN];
+        std::vector<std::vector<int>> cand_first[N_ALIGN];
+        for (int a = 0; a < N_ALIGN; ++a) {
+            cand[a].resize(blocks.size());
+            cand16[a].resize(blocks.size());
+            cand_first[a].resize(blocks.size());
+            for (size_t b = 0; b < blocks.size(); ++b) cand_first[a][b].assign(rows.size() + 1, 0);
         }
-        std::vector<size_t> n_st(blocks.size(), 0);
-        size_t total = 0;
-        for (size_t b = 0; b < blocks.size(); ++b) {
-            for (unsigned char t : touched[b]) n_st[b] += t;
-            total += n_st[b];
+        {
+            std::vector<std::vector<int>> xs(blocks.size());
+            std::vector<int32_t> hit;                                // blocks with pixels in the current folded row
+            auto cover = [&](const std::vector<int> &sx, int width, int align, int fy, std::vector<Win> &out) {
+                int end = -1;
+                for (int x : sx)
+                    if (x >= end) {
+                        const int x0 = std::min(x / align * align, sig_w - width);
+                        out.push_back(Win{fy, x0, std::max(x0, end)});
+                        end = x0 + width;
+                    }
+            };
+            for (size_t fy = 0; fy < rows.size(); ++fy) {
+                hit.clear();
+                for (int which = 0; which < 2; ++which) {
+                    const int y = which == 0 ? rows[fy].x : rows[fy].y;
+                    if (y < 0) continue;
+                    for (int x = 0; x < sig_w; ++x) {
+                        const int64_t p = (int64_t)y * sig_w + x;
+                        for (int64_t e = k->indptr[(size_t)p]; e < k->indptr[(size_t)p + 1]; ++e) {
+                            const int32_t b = block_of[(size_t)k->idx[(size_t)e]];
+                            std::vector<int> &v = xs[(size_t)b];
+                            if (v.empty()) hit.push_back(b);
+                            if (v.empty() || v.back() != x) v.push_back(x);
+                        }
+                    }
+                }
+                for (int32_t b : hit) {
+                    std::vector<int> &v = xs[(size_t)b];
+                    std::sort(v.begin(), v.end());
+                    v.erase(std::unique(v.begin(), v.end()), v.end());
+                    for (int a = 0; a < N_ALIGN; ++a) {
+                        cover(v, FD_KB, aligns[a], (int)fy, cand[a][(size_t)b]);
+                        if (with16) cover(v, FD16_KB, aligns16[a], (int)fy, cand16[a][(size_t)b]);
+                    }
+                    v.clear();
+                }
+                for (int a = 0; a < N_ALIGN; ++a)
+                    for (size_t b = 0; b < blocks.size(); ++b) cand_first[a][b][fy + 1] = (int)cand[a][b].size();
+            }
+        }
+        size_t total = 0, total16 = 0;
+        {
+            int best = 0, best16 = 0;
+            double c_best = 0., c_best16 = 0.;
+            for (int a = 0; a < N_ALIGN; ++a) {
+                size_t n = 0, n16 = 0;
+                for (size_t b = 0; b < blocks.size(); ++b) { n += cand[a][b].size(); n16 += cand16[a][b].size(); }
+                if (a == 0 || (double)n * stage_cost[a] < c_best) { best = a; c_best = (double)n * stage_cost[a]; total = n; }
+                if (a == 0 || (double)n16 * stage_cost16[a] < c_best16) {
+                    best16 = a; c_best16 = (double)n16 * stage_cost16[a]; total16 = n16;
+                }
+            }
+            wins.swap(cand[best]);
+            row_first.swap(cand_first[best]);
+            wins16.swap(cand16[best16]);
+            for (int a = 0; a < N_ALIGN; ++a) {
+                std::vector<std::vector<Win>>().swap(cand[a]);
+                std::vector<std::vector<Win>>().swap(cand16[a]);
+                std::vector<std::vector<int>>().swap(cand_first[a]);
+            }
         }
         // worth it?  per frame: matrix work at the fold kernel's rate and the frame bytes it reads (edge stages once per
         // block) against the blocked image's record loop (0.35 - 0.44 of the matrix peak; unknown: the vector ALUs)
@@ -1187,65 +1281,80 @@ void *ltmi::band_build(const KeptCsr *k, int sig_h, int sig_w, double other_macs
         // blocks in the order of their length, longest first (they are dispatched in that order)
         std::vector<int32_t> border(blocks.size());
         for (size_t b = 0; b < blocks.size(); ++b) border[b] = (int32_t)b;
-        std::stable_sort(border.begin(), border.end(), [&](int32_t a, int32_t b) { return n_st[(size_t)a] > n_st[(size_t)b]; });
+        std::stable_sort(border.begin(), border.end(),
+                         [&](int32_t a, int32_t b) { return wins[(size_t)a].size() > wins[(size_t)b].size(); });
         std::vector<int> blk_off(blocks.size() + 1, 0), colmap(blocks.size() * (size_t)ng * GROUP, -1);
+        std::vector<int> first_stage(blocks.size(), 0);              // block -> its first stage in the final order
         std::vector<int4> stages(total);
-        std::vector<std::vector<int32_t>> stage_id(blocks.size());
         {
             size_t s = 0;
             for (size_t bi = 0; bi < border.size(); ++bi) {
                 const size_t b = (size_t)border[bi];
                 blk_off[bi] = (int)s;
-                stage_id[b].assign(n_slots, -1);
-                for (size_t slot = 0; slot < n_slots; ++slot)
-                    if (touched[b][slot]) {
-                        const int2 rr = rows[slot / spr];
-                        stages[s] = int4{rr.x, rr.y, (int)(slot % spr), 0};
-                        stage_id[b][slot] = (int32_t)s++;
-                    }
+                first_stage[b] = (int)s;
+                for (const Win &w : wins[b]) stages[s++] = int4{rows[(size_t)w.fy].x, rows[(size_t)w.fy].y, w.x0, w.own};
                 for (int32_t mk : blocks[b].masks)
                     for (int c = 0; c < nc; ++c)
                         colmap[bi * (size_t)ng * GROUP + (size_t)vcol[(size_t)mk * nc + c]] = (int)(mk * nc + c);
-                touched[b].clear();
-                touched[b].shrink_to_fit();
             }
             blk_off[blocks.size()] = (int)s;
         }
-        // 128-pixel stages of the same blocks (integer frames): pairs of the 64-pixel ones
-        std::vector<int4> stages16;
-        std::vector<int2> src16;
+        // 128-pixel windows of the same blocks (integer frames): the image is made on the device from the float32 one,
+        // every window from the (at most four) 64-pixel windows of its block and row that reach into it
+        std::vector<int4> stages16, src16;
         std::vector<int> blk_off16(blocks.size() + 1, 0);
-        if (sig_w % FD16_KB == 0) {
-            const int spr16 = sig_w / FD16_KB;
+        bool table_ok = true;
+        if (with16) {
+            stages16.reserve(total16);
+            src16.reserve(2 * total16);
             for (size_t bi = 0; bi < border.size(); ++bi) {
                 const size_t b = (size_t)border[bi];
                 blk_off16[bi] = (int)stages16.size();
-                for (size_t fy = 0; fy < rows.size(); ++fy)
-                    for (int x16 = 0; x16 < spr16; ++x16) {
-                        const int32_t sa = stage_id[b][fy * spr + 2 * (size_t)x16];
-                        const int32_t sb = stage_id[b][fy * spr + 2 * (size_t)x16 + 1];
-                        if (sa < 0 && sb < 0) continue;
-                        stages16.push_back(int4{rows[fy].x, rows[fy].y, x16, 0});
-                        src16.push_back(int2{sa, sb});
+                for (const Win &w : wins16[b]) {
+                    stages16.push_back(int4{rows[(size_t)w.fy].x, rows[(size_t)w.fy].y, w.x0, w.own});
+                    int ids[4] = {-1, -1, -1, -1}, x0s[4] = {0, 0, 0, 0}, n = 0;
+                    for (int j = row_first[b][(size_t)w.fy]; j < row_first[b][(size_t)w.fy + 1]; ++j) {
+                        const Win &v = wins[b][(size_t)j];                 // owns [v.own, v.x0 + 64)
+                        if (v.own < w.x0 + FD16_KB && v.x0 + FD_KB > w.own) {
+                            if (n == 4) { table_ok = false; break; }       // (a support in many short runs)
+                            ids[n] = first_stage[b] + j;
+                            x0s[n++] = v.x0;
+                        }
                     }
+                    src16.push_back(int4{ids[0], ids[1], ids[2], ids[3]});
+                    src16.push_back(int4{x0s[0], x0s[1], x0s[2], x0s[3]});
+                }
             }
             blk_off16[blocks.size()] = (int)stages16.size();
+            if (!table_ok) {                                               // integer frames: the other kernels
+                stages16.clear();
+                src16.clear();
+            }
         }
-        // image: the ORIGINAL weights of rows y (the first row of a pair)
+        // image: the ORIGINAL weights of rows y (the first row of a pair), every pixel in the window that owns it
         const size_t slot_floats = (size_t)ng * GROUP * FD_KB;
         std::vector<float> img(total * slot_floats, 0.f);
         for (size_t fy = 0; fy < rows.size(); ++fy) {
             const int y = rows[fy].x;
             for (int x = 0; x < sig_w; ++x) {
                 const int64_t p = (int64_t)y * sig_w + x;
-                const size_t slot = fy * spr + (size_t)(x / FD_KB);
-                const int q = x % FD_KB;
+                int32_t last_b = -1;
+                size_t s = 0;
+                int q = 0;
                 for (int64_t e = k->indptr[(size_t)p]; e < k->indptr[(size_t)p + 1]; ++e) {
                     const int32_t mk = k->idx[(size_t)e];
-                    const int32_t s = stage_id[(size_t)block_of[(size_t)mk]][slot];
+                    const int32_t b = block_of[(size_t)mk];
+                    if (b != last_b) {
+                        // the window of (b, fy) that owns x: the last one whose `own` is <= x
+                        int j = row_first[(size_t)b][fy + 1] - 1;
+                        while (j > row_first[(size_t)b][fy] && wins[(size_t)b][(size_t)j].own > x) --j;
+                        s = (size_t)first_stage[(size_t)b] + (size_t)j;
+                        q = x - wins[(size_t)b][(size_t)j].x0;
+                        last_b = b;
+                    }
                     for (int c = 0; c < nc; ++c) {
                         const int v = vcol[(size_t)mk * nc + c];
-                        img[((size_t)s * ng + (size_t)(v / GROUP)) * (GROUP * FD_KB) + fold_index(v % GROUP, q)] =
+                        img[(s * ng + (size_t)(v / GROUP)) * (GROUP * FD_KB) + fold_index(v % GROUP, q)] =
                             k->val[(size_t)e * nc + c];
                     }
                 }
@@ -1259,7 +1368,7 @@ void *ltmi::band_build(const KeptCsr *k, int sig_h, int sig_w, double other_macs
         bi->src16_host.swap(src16);
         bi->blk_off16_host.swap(blk_off16);
         bi->n_stages16 = (int)bi->stages16_host.size();
-        bi->reread16 = sig_w % FD16_KB == 0 ? (double)bi->n_stages16 / (double)(rows.size() * (size_t)(sig_w / FD16_KB)) : 0.;
+        bi->reread16 = with16 ? (double)bi->n_stages16 / (double)(rows.size() * (size_t)(sig_w / FD16_KB)) : 0.;
         hipError_t e = hipMalloc((void **)&bi->img, img.size() * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&bi->stages, stages.size() * sizeof(int4));
         if (e == hipSuccess) e = hipMalloc((void **)&bi->blk_off, blk_off.size() * sizeof(int));
@@ -1276,7 +1385,7 @@ void *ltmi::band_build(const KeptCsr *k, int sig_h, int sig_w, double other_macs
             return band_no(7);
         }
         return bi;
-    } catch (const std::bad_alloc &) {
+    } catch (const std::exception &) {          // (bad_alloc, length_error: no image)
         return band_no(8);
     }
 }
@@ -1293,11 +1402,11 @@ bool ltmi::band_takes(void *band, const ltmi_masks *m, const void *tile, int til
     if (!b->img16) {
         // first integer tile: the image in 128-pixel slots from the float32 one
         const int ng = b->nge + b->ngo;
-        int2 *src = nullptr;
+        int4 *src = nullptr;
         hipError_t e = hipMalloc((void **)&b->img16, (size_t)b->n_stages16 * ltmi::fold16_slot_bytes(ng));
         if (e == hipSuccess) e = hipMalloc((void **)&b->stages16, b->stages16_host.size() * sizeof(int4));
         if (e == hipSuccess) e = hipMalloc((void **)&b->blk_off16, b->blk_off16_host.size() * sizeof(int));
-        if (e == hipSuccess) e = hipMalloc((void **)&src, b->src16_host.size() * sizeof(int2));
+        if (e == hipSuccess) e = hipMalloc((void **)&src, b->src16_host.size() * sizeof(int4));
         if (e == hipSuccess)
             e = hipMemcpy(b->stages16, b->stages16_host.data(), b->stages16_host.size() * sizeof(int4),
                           hipMemcpyHostToDevice);
@@ -1305,12 +1414,12 @@ bool ltmi::band_takes(void *band, const ltmi_masks *m, const void *tile, int til
             e = hipMemcpy(b->blk_off16, b->blk_off16_host.data(), b->blk_off16_host.size() * sizeof(int),
                           hipMemcpyHostToDevice);
         if (e == hipSuccess)
-            e = hipMemcpy(src, b->src16_host.data(), b->src16_host.size() * sizeof(int2), hipMemcpyHostToDevice);
+            e = hipMemcpy(src, b->src16_host.data(), b->src16_host.size() * sizeof(int4), hipMemcpyHostToDevice);
         if (e == hipSuccess) {
             const int64_t tot = (int64_t)b->n_stages16 * ng * GROUP * FD16_KB;
             const unsigned bl = (unsigned)std::min<int64_t>((tot + 255) / 256, 65535 * 16);
             hipLaunchKernelGGL(ltmi::k_build_band_image16, dim3(bl), dim3(256), 0, 0, (const float *)b->img, b->img16,
-                               (const int2 *)src, ng, (int64_t)b->n_stages16);
+                               (const int4 *)b->stages16, (const int4 *)src, ng, (int64_t)b->n_stages16);
             e = hipGetLastError();
             if (e == hipSuccess) e = hipDeviceSynchronize();
         }
@@ -1327,7 +1436,7 @@ bool ltmi::band_takes(void *band, const ltmi_masks *m, const void *tile, int til
             return false;
         }
         std::vector<int4>().swap(b->stages16_host);
-        std::vector<int2>().swap(b->src16_host);
+        std::vector<int4>().swap(b->src16_host);
     }
     return true;
 }

@@ -1119,3 +1119,25 @@ def test_fingerprint_follows_objects_and_refuses_what_it_cannot_see():
     assert is_opaque(fingerprint(lambda: deep))
     # modules, classes and builtins a factory names are stable, not opaque
     assert not is_opaque(fingerprint(lambda: np.ones((2, 2)) * len(str(Holder))))
+
+
+def test_container_looks_for_banded_stacks():
+    """MaskContainer._maybe_banded: masks in groups with ONE pixel support each (the orders of a bin of a radial-Fourier
+    stack with several bins) are offered to the library as CSR before the stack is multiplied dense; rings with a
+    support each, narrow stacks and scattered ones are not."""
+    import scipy.sparse as sp
+    from libertem_amd.common.container import _maybe_banded, _worth_densifying
+    from libertem_amd.analysis.radialfourier import radial_mask_factory
+    from libertem_amd import masks as pm
+    st = radial_mask_factory(64, 128, 64, 32, 0, pm.bounding_radius(64, 32, 128, 64), 3, 12, True)()
+    csr = st.to_px_by_masks(dtype=np.complex64)
+    assert csr.shape == (64 * 128, 39)
+    assert _worth_densifying(csr, np.complex64) and _maybe_banded(csr, np.complex64)
+    assert not _maybe_banded(csr.astype(np.complex128), np.complex128)           # (float32 / complex64 images only)
+    rings = sp.csr_matrix(pm.radial_bins(32, 32, 64, 64, n_bins=96, use_sparse=True, dtype=np.float32)
+                          .to_px_by_masks(dtype=np.float32))
+    assert not _maybe_banded(rings, np.float32)                                   # one mask per support
+    narrow = radial_mask_factory(64, 128, 64, 32, 0, pm.bounding_radius(64, 32, 128, 64), 2, 7, True)()
+    assert not _maybe_banded(narrow.to_px_by_masks(dtype=np.complex64), np.complex64)     # 32 columns: one dense pass
+    scattered = sp.random(4096, 96, density=0.01, format='csr', dtype=np.float32, random_state=np.random.RandomState(3))
+    assert not _maybe_banded(scattered, np.float32)
