@@ -55,10 +55,12 @@ for key, dtype in (('c5s', torch.float32), ('c5s_u16', torch.int16)):
         npdt = np.dtype('uint16')
     ds = ctx.load('memory', data=fr.reshape((n // 128, 128, 1024, 1024)), dtype=npdt, sig_dims=2, num_partitions=1)
     NB = int(os.environ.get('C5S_BINS', 16))
-    an = ctx.create_radial_fourier_analysis(dataset=ds, n_bins=NB, max_order=24, use_sparse=True)
+    SP = {'1': True, '0': False}.get(os.environ.get('C5S_SPARSE', '1'))
+    an = ctx.create_radial_fourier_analysis(dataset=ds, n_bins=NB, max_order=24, use_sparse=SP)
     res = run(f'C5, n_bins={NB}, max_order=24, use_sparse=True ({n} frames of 1024x1024 {npdt})', an, fr, n)
     stack = an.get_mask_factories()()
     stack = stack.todense() if hasattr(stack, 'todense') else np.asarray(stack)
+    print('    use_sparse', an.parameters['use_sparse'])
     stack = np.asarray(stack).reshape((25 * NB, -1)).astype(np.complex128)
     raw = res.raw_results.reshape((25 * NB, -1))
     for i in (0, n - 1):

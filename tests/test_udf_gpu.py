@@ -2078,8 +2078,9 @@ def test_radial_fourier_folded_through_run_udf_with_roi(ctx):
     assert p['mask_count'] == 26
 
 
+@pytest.mark.parametrize('use_sparse', [True, None])
 @pytest.mark.parametrize('dtype', ['float32', 'uint16'])
-def test_radial_fourier_sparse_bins_through_run_udf_with_roi(ctx, monkeypatch, dtype):
+def test_radial_fourier_sparse_bins_through_run_udf_with_roi(ctx, monkeypatch, dtype, use_sparse):
     """RadialFourierAnalysis with several bins and use_sparse=True (second C5 run): the CSR stack is a set
     of column blocks with one support each -- folded dense images per bin on k_dense_fold / k_dense_fold16 (the handle
     learns the detector shape from MaskContainer).  Whole scan and a region of interest, against float64."""
@@ -2091,14 +2092,23 @@ def test_radial_fourier_sparse_bins_through_run_udf_with_roi(ctx, monkeypatch, d
     else:
         data = rng.integers(0, 4096, (6, 8, 128, 128)).astype(np.uint16)
     ds = _device_ds(ctx, data, 2)
-    analysis = ctx.create_radial_fourier_analysis(dataset=ds, n_bins=3, max_order=12, use_sparse=True)
-    assert analysis.parameters['use_sparse'] is True
+    if use_sparse is None:
+        # the reference's heuristic declares a few wide bins DENSE (analysis/radialfourier.py:334-341): MaskContainer
+        # finds the blocks in the dense stack and hands it over as CSR all the same
+        analysis = ctx.create_radial_fourier_analysis(dataset=ds, n_bins=3, max_order=12)
+        assert analysis.parameters['use_sparse'] is False
+    else:
+        analysis = ctx.create_radial_fourier_analysis(dataset=ds, n_bins=3, max_order=12, use_sparse=True)
+        assert analysis.parameters['use_sparse'] is True
     hip.KernelTimer.start()
     res = ctx.run_udf(dataset=ds, udf=analysis.get_udf())['intensity'].data
     labels = [k for _, _, k in hip.KernelTimer.stop()]
     assert labels and all('k_dense_fold' in k and 'banded: 3 blocks' in k for k in labels), labels
-    stack = analysis.get_mask_factories()().to_px_by_masks(dtype=np.complex64)        # (n_px, 39) CSR
-    dense = np.asarray(stack.todense()).astype(np.complex128)
+    stack = analysis.get_mask_factories()()
+    if use_sparse is None:
+        dense = np.asarray(stack).reshape((39, -1)).T.astype(np.complex128)
+    else:
+        dense = np.asarray(stack.to_px_by_masks(dtype=np.complex64).todense()).astype(np.complex128)   # (n_px, 39)
     ref = (data.reshape((48, -1)).astype(np.float64) @ dense).reshape((6, 8, -1))
     assert res.dtype == np.complex64 and _close(res, ref, F32_TOL)
     roi = np.zeros((6, 8), bool)
