@@ -556,7 +556,7 @@ template <typename T, int NG, int ABL = 0, int IND = 0, int NE = 0, int TILES = 
 __global__ void __launch_bounds__(512 / TILES)                  // LdsCfg::WAVES * 64
 k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
             const float *__restrict__ img, int n_slots, float *__restrict__ out, int64_t ld_out,
-            int n_cols, int accumulate, float *__restrict__ partials, int ksplit,
+            int n_cols, int accumulate, float *__restrict__ partials, int ksplit_arg,
             const int32_t *__restrict__ rows = nullptr,
             const float *const *__restrict__ wg_img = nullptr, int *__restrict__ kcount = nullptr,
             const float *__restrict__ inv_scale = nullptr, const float *__restrict__ tail_val = nullptr,
@@ -598,11 +598,26 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
     const int ks = blockIdx.y;
     const int gt = blockIdx.z;
 
+    // ksplit_arg < 0: the parts of a pixel-split launch take the mask slots in turn (part ks: slots ks, ks + ksplit,
+    // ...) instead of a contiguous range each, so that at any moment the workgroups of a frame block read NEIGHBOURING
+    // 512-byte pieces of their frames, not pieces 4 - 16 KiB apart (profiles/r05_small_tiles.txt)
+    // (-ksplit_arg = ksplit | log2(run) << 16: runs of 2^.. consecutive slots in turn)
+    const bool kstr = ksplit_arg < 0;
+    const int ksplit = kstr ? ((-ksplit_arg) & 0xffff) : ksplit_arg;
+    const int run_sh = kstr ? ((-ksplit_arg) >> 16) : 0, run = 1 << run_sh;
     const int n_full = (int)(n_px / KB);                 // slots readable by DMA
     const int per = (n_slots + ksplit - 1) / ksplit;
     const int k_begin = ks * per;
     const int k_end = min(n_slots, k_begin + per);
     const int kf_end = min(k_end, n_full);
+    const int n_runs = (n_full + run - 1) >> run_sh;     // runs of the whole stack, the last one may be short
+    const int my_runs = n_runs > ks ? (n_runs - ks + ksplit - 1) / ksplit : 0;
+    const int nk = kstr ? max(0, (my_runs << run_sh) - ((my_runs > 0 && (n_runs - 1) % ksplit == ks)
+                                                         ? (n_runs << run_sh) - n_full : 0))
+                        : max(0, kf_end - k_begin);
+    const bool has_ragged = kstr ? (n_slots > n_full && ks == (n_full >> run_sh) % ksplit) : (k_end > n_full);
+    // g-th slot of this part
+    auto slot_of = [&](int g) { return kstr ? (((ks + (g >> run_sh) * ksplit) << run_sh) + (g & (run - 1))) : k_begin + g; };
     const float *img_t = IND == 1 ? wg_img[blockIdx.x] : img + (size_t)gt * n_slots * SLOT_FLOATS;
 
     const int64_t f_wave = (int64_t)blockIdx.x * (WAVES * ROWS) + wave * ROWS;
@@ -698,7 +713,7 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
         }
     };
 
-    if (k_begin < kf_end) {
+    if (nk > 0) {
         const unsigned char *src[ND];
 #pragma unroll
         for (int t = 0; t < ND; ++t) {
@@ -708,18 +723,19 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             src[t] = (const unsigned char *)(tile + f * ld) + piece * 16;
         }
         const unsigned char *bsrc = (const unsigned char *)img_t + wave * BPW + lane * 16;
-        const int S0 = k_begin * PER, S1 = kf_end * PER;      // sub-chunk range
+        const int S0 = 0, S1 = nk * PER;                // sub-chunks of this part, in the order they are taken
 
         auto issue_a1 = [&](int s, int slot, int t) {
             if (ABL >= 2) return;
-            const int sc = min(s, S1 - 1);
+            const int sl = min(s, S1 - 1);
+            const int sc = slot_of(sl / PER) * PER + sl % PER;                     // sub-chunk of the frame rows
             unsigned char *dst = a_base + slot * (WAVES * ASLOT);
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[t] + (int64_t)sc * SUBB),
                                              (lds_ptr_t)(dst + t * 1024), 16, 0, 2 /*nt*/);
         };
-        auto issue_b = [&](int gidx) {                  // mask slot k_begin + gidx -> LDS slot gidx & 1
+        auto issue_b = [&](int gidx) {                  // the part's gidx-th mask slot -> LDS slot gidx & 1
             if (ABL >= 2) return;
-            const int kk = min(k_begin + gidx, kf_end - 1);
+            const int kk = slot_of(min(gidx, nk - 1));
             unsigned char *dst = b_base + (gidx & 1) * BSLOT + wave * BPW;
             const unsigned char *sp = bsrc + (int64_t)kk * BSLOT;
 #pragma unroll
@@ -932,7 +948,7 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
     }
 
     // ragged last slot (n_px % KB != 0): guarded element loads, mask slot staged by plain copies
-    if (k_end > n_full) {
+    if (has_ragged) {
         const int k = n_full;
         __syncthreads();
         float *bl = (float *)b_base;
@@ -1804,6 +1820,19 @@ static inline bool f32_instruction_only(const ltmi_masks *m) {
     return e && e[0] == '1';
 }
 
+// the parts of a pixel-split launch: mask slots in turn (negative: k_dense_lds) or a contiguous range each
+// Measured (C2 stack, us per launch incl. the reduction, contiguous -> runs of 4 slots in turn): 1 024 frames (32 parts)
+// 39.9 -> 35.8, 2 048 (16) 62.7 -> 55.0, 4 096 (8) 114.7 -> 94.0, but 8 192 (4 parts) 167.5 -> 177.0; 512 x 512 frames
+// in 61 parts 46.6 -> 53.8 (256 frames), in 32 parts 112.9 -> 105.5; 1024 x 1024 in 64 parts 162.9 -> 150.4; float32
+// frames and 48 columns: no difference (scripts/r5_run18.sh, r5_run19.sh).  In turn for 8, 16, 32, 64 parts.
+// LTMI_KSPLIT_STRIDED = 0: never, v > 0: runs of 2^(v-1) slots whatever the number of parts.
+static inline int ksplit_order(int ksplit) {
+    static const int forced = getenv("LTMI_KSPLIT_STRIDED") ? atoi(getenv("LTMI_KSPLIT_STRIDED")) : -1;
+    if (ksplit <= 1 || forced == 0) return ksplit;
+    if (forced > 0) return -(ksplit | ((forced - 1) << 16));
+    return (ksplit >= 8 && (ksplit & (ksplit - 1)) == 0) ? -(ksplit | (2 << 16)) : ksplit;
+}
+
 static inline int lds_tiles(const ltmi_masks *m) {
     return m->tune_ksplit_ring == 34 ? 1 : 2;
 }
@@ -1861,7 +1890,7 @@ static int launch_lds_ng_t(ltmi_masks *m, const T *tile, int64_t n_frames, int64
     int *kcount = ksplit > 1 ? partial_counters(m, gx * gz) : nullptr;
     hipLaunchKernelGGL(kern, grid, dim3(CFG::WAVES * 64), CFG::LDS_BYTES, stream, tile, ld, n_frames,
                        m->n_px, img, n_slots, out, ld_out, m->n_cols, accumulate, partial_sums(m),
-                       ksplit, rows, (const float *const *)nullptr, kcount,
+                       ksplit_order(ksplit), rows, (const float *const *)nullptr, kcount,
                        x16 ? (const float *)m->inv_scale : (const float *)nullptr,
                        (const float *)m->tail_val, (const int32_t *)m->tail_col, (const int32_t *)m->tail_px,
                        x16 ? m->tail_n : 0);
@@ -1934,7 +1963,7 @@ static int launch_lds_extras_t(ltmi_masks *m, const T *tile, int64_t n_frames, i
     int *kcount = ksplit > 1 ? partial_counters(m, gx) : nullptr;
     hipLaunchKernelGGL(kern, grid, dim3(CFG::WAVES * 64), CFG::LDS_BYTES, stream, tile, ld, n_frames,
                        m->n_px, x16 ? (const float *)m->img3_h : (const float *)m->img3, n_slots, out,
-                       ld_out, m->n_cols, accumulate, partial_sums(m), ksplit, rows,
+                       ld_out, m->n_cols, accumulate, partial_sums(m), ksplit_order(ksplit), rows,
                        (const float *const *)nullptr, kcount,
                        x16 ? (const float *)m->inv_scale : (const float *)nullptr,
                        (const float *)m->tail_val, (const int32_t *)m->tail_col, (const int32_t *)m->tail_px,

@@ -128,6 +128,13 @@ def test_mfma_variants_agree(hip, tuning):
     ((77, 128 * 61 + 48, 50), 4),
     ((40, 128 * 30, 70), 0),            # 5 groups -> a block of 64 columns + one of 6
     ((40, 128 * 30, 70), 2),
+    # 8 / 16 / 32 / 64 parts take runs of 4 mask slots in turn (ksplit_order): slot counts that are no multiple of
+    # the run, a ragged last slot, more parts than runs
+    ((300, 256 * 47 + 112, 16), 8),     # 48 slots: 6 per part = a run of 4 + half a run
+    ((140, 256 * 47 + 9, 16), 16),
+    ((77, 128 * 61 + 48, 50), 8),
+    ((129, 128 * 63 + 16, 24), 32),
+    ((60, 256 * 63 + 5, 16), 64),       # one slot per part: 16 runs for 64 parts
 ])
 def test_lds_dma_kernel_all_widths(hip, tile_dtype, shape, ksplit):
     """k_dense_lds (frames through LDS by DMA) for every pixel width and group count; forced with
@@ -145,6 +152,8 @@ def test_lds_dma_kernel_all_widths(hip, tile_dtype, shape, ksplit):
     masks = (rng.random((n_masks, n_px)) - 0.25).astype(np.float32)
     res, kern = _apply(hip, data, masks, np.float32, tuning=dict(mt=0, waves=30, ksplit=ksplit))
     assert 'k_dense_lds' in kern, kern          # (1-byte pixels with several groups: 128-byte sub-chunks)
+    if ksplit >= 8:
+        assert f',{ksplit},' in kern, kern      # (the number of parts the in-turn order is used for)
     if n_masks > 64:
         assert kern.startswith('2 column blocks'), kern   # 64 + the rest, each with its own tile width
     ref = _ref64(data, masks)
@@ -160,6 +169,8 @@ def test_lds_dma_kernel_all_widths(hip, tile_dtype, shape, ksplit):
 @pytest.mark.parametrize('shape,ksplit,mask_dtype', [
     ((300, 256 * 41 + 112, 16), 0, 'float32'),      # unrolled loop + generic tail + ragged last slot
     ((300, 256 * 41 + 112, 16), 3, 'float32'),      # ... with a K split
+    ((300, 256 * 47 + 112, 16), 8, 'float32'),      # ... parts in turn (runs of 4 slots)
+    ((200, 256 * 47 + 9, 16), 16, 'float32'),
     ((129, 256 * 8, 9), 0, 'float32'),
     ((1000, 1024, 12), 0, 'float32'),
     ((70, 515, 16), 0, 'float32'),                  # unaligned rows
