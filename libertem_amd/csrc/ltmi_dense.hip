@@ -602,8 +602,8 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
     // ...) instead of a contiguous range each, so that at any moment the workgroups of a frame block read NEIGHBOURING
     // 512-byte pieces of their frames, not pieces 4 - 16 KiB apart (profiles/r05_small_tiles.txt)
     // (-ksplit_arg = ksplit | log2(run) << 16: runs of 2^.. consecutive slots in turn)
-    const bool kstr = ksplit_arg < 0;
-    const int ksplit = kstr ? ((-ksplit_arg) & 0xffff) : ksplit_arg;
+    const bool kstr = ksplit_arg < 0 && IND == 0 && ABL == 0;
+    const int ksplit = ksplit_arg < 0 ? ((-ksplit_arg) & 0xffff) : ksplit_arg;
     const int run_sh = kstr ? ((-ksplit_arg) >> 16) : 0, run = 1 << run_sh;
     const int n_full = (int)(n_px / KB);                 // slots readable by DMA
     const int per = (n_slots + ksplit - 1) / ksplit;
@@ -713,7 +713,11 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
         }
     };
 
-    if (nk > 0) {
+    // the main loop, compiled twice where a launch may be pixel-split in turn (KSTR): the contiguous order keeps its
+    // addresses as `first sub-chunk + s` -- the slot arithmetic of the in-turn order costs the full C2 launch 5 %
+    // (13 % with the float32 instruction) when it sits in the copy-issue path of every launch
+    auto main_loop = [&](auto IN_TURN) {
+        constexpr bool KSTR = decltype(IN_TURN)::value;
         const unsigned char *src[ND];
 #pragma unroll
         for (int t = 0; t < ND; ++t) {
@@ -723,19 +727,20 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
             src[t] = (const unsigned char *)(tile + f * ld) + piece * 16;
         }
         const unsigned char *bsrc = (const unsigned char *)img_t + wave * BPW + lane * 16;
-        const int S0 = 0, S1 = nk * PER;                // sub-chunks of this part, in the order they are taken
+        // sub-chunks of this part: KSTR: counted from 0 in the order they are taken; else the frame rows' own numbers
+        const int S0 = KSTR ? 0 : k_begin * PER, S1 = KSTR ? nk * PER : kf_end * PER;
 
         auto issue_a1 = [&](int s, int slot, int t) {
             if (ABL >= 2) return;
             const int sl = min(s, S1 - 1);
-            const int sc = slot_of(sl / PER) * PER + sl % PER;                     // sub-chunk of the frame rows
+            const int sc = KSTR ? slot_of(sl / PER) * PER + sl % PER : sl;         // sub-chunk of the frame rows
             unsigned char *dst = a_base + slot * (WAVES * ASLOT);
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[t] + (int64_t)sc * SUBB),
                                              (lds_ptr_t)(dst + t * 1024), 16, 0, 2 /*nt*/);
         };
         auto issue_b = [&](int gidx) {                  // the part's gidx-th mask slot -> LDS slot gidx & 1
             if (ABL >= 2) return;
-            const int kk = slot_of(min(gidx, nk - 1));
+            const int kk = KSTR ? slot_of(min(gidx, nk - 1)) : min(k_begin + gidx, kf_end - 1);
             unsigned char *dst = b_base + (gidx & 1) * BSLOT + wave * BPW;
             const unsigned char *sp = bsrc + (int64_t)kk * BSLOT;
 #pragma unroll
@@ -945,6 +950,14 @@ k_dense_lds(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
         }
         for (; s < S1; ++s) iteration(s, std::integral_constant<int, -1>{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the clamped prefetches
+    };
+    if (nk > 0) {
+        if constexpr (IND == 0 && ABL == 0) {
+            if (kstr) main_loop(std::true_type{});
+            else main_loop(std::false_type{});
+        } else {
+            main_loop(std::false_type{});
+        }
     }
 
     // ragged last slot (n_px % KB != 0): guarded element loads, mask slot staged by plain copies
