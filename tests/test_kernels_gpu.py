@@ -2285,3 +2285,44 @@ def test_banded_stack_only_where_it_applies(hip, monkeypatch):
     monkeypatch.setenv('LTMI_SPARSE_BAND', '0')
     _, kern = _apply_csr(hip, d2.astype(np.float32), csr, np.complex64, sig=(64, 128))
     assert 'banded' not in kern, kern
+
+
+@pytest.mark.parametrize('n_even,n_odd', [(20, 20), (40, 0), (5, 33)])
+def test_banded_stack_real_columns_split_blocks(hip, monkeypatch, n_even, n_odd):
+    """Real float32 stacks: three wide rings, per ring `n_even` columns that are even and `n_odd` that are odd under the
+    row mirror (built by explicit reflection: exact).  More than 32 even (odd) columns on one support are split into
+    several blocks of that support."""
+    import scipy.sparse as sp
+    monkeypatch.setenv('LTMI_SPARSE_BAND', '1')
+    sig = (64, 128)
+    cy, cx = 32, 64
+    yy, xx = np.mgrid[0:sig[0], 0:sig[1]]
+    r = np.hypot(yy - cy, xx - cx)
+    rng = np.random.default_rng(_seed('bandreal', n_even, n_odd))
+    cols = []
+    for b in range(3):
+        ring = ((r >= 20 * b) & (r < 20 * (b + 1))).astype(np.float32)
+        for k in range(n_even + n_odd):
+            w = rng.random(sig).astype(np.float32) * ring
+            top = w[1:cy]                                      # rows 1 .. cy - 1; partner of row y is 2 cy - y
+            w[cy + 1:2 * cy] = top[::-1] if k < n_even else -top[::-1]
+            if k >= n_even:
+                w[cy] = 0                                      # (an odd column vanishes on the mirror line; row 0 is unpaired)
+            cols.append(w.reshape(-1))
+    dense = np.stack(cols, axis=1)                             # (n_px, 3 * (n_even + n_odd))
+    csr = sp.csr_matrix(dense)
+    n_px, n_masks = csr.shape
+    data = rng.random((150, n_px)).astype(np.float32)
+    res, kern = _apply_csr(hip, data, csr, np.float32, sig=sig)
+    # (the odd columns vanish on the mirror line: their support is not the even columns' -> blocks of their own)
+    n_blocks = 3 * (-(-n_even // 32) + -(-n_odd // 32))
+    assert 'k_dense_fold<f' in kern and 'banded: %d blocks' % n_blocks in kern, kern
+    ref = data.astype(np.float64) @ dense.astype(np.float64)
+    scale = np.abs(data.astype(np.float64)) @ np.abs(dense.astype(np.float64))
+    assert np.all(np.abs(res - ref) <= 1e-5 * scale + 1e-30)
+    d16 = rng.integers(0, 65535, (90, n_px), endpoint=True).astype(np.uint16)
+    res16, kern16 = _apply_csr(hip, d16, csr, np.float32, sig=sig)
+    assert 'k_dense_fold16<' in kern16 and 'banded' in kern16, kern16
+    ref16 = d16.astype(np.float64) @ dense.astype(np.float64)
+    scale16 = d16.astype(np.float64) @ np.abs(dense.astype(np.float64))
+    assert np.all(np.abs(res16 - ref16) <= 1e-5 * scale16 + 1e-30)
