@@ -740,6 +740,26 @@ def second_runs(ctx, torch, hip, reps=3):
     del fr, ds, an, res
     gc.collect()
     torch.cuda.empty_cache()
+
+    # ... the same stack on uint16 frames (what a detector delivers)
+    fr = device_frames(torch, n, (1024, 1024), 'uint16', 33)
+    ds = ctx.load('memory', data=fr.reshape((n // 128, 128, 1024, 1024)), dtype=np.dtype('uint16'), sig_dims=2,
+                  num_partitions=1)
+    an = ctx.create_radial_fourier_analysis(dataset=ds, n_bins=16, max_order=24, use_sparse=True)
+    res, rec = timed(an, n, 1024 * 1024 * 2)
+    raw = res.raw_results.reshape((400, -1))
+    worst = 0.
+    for i in (0, n - 1):
+        f = fr[i].cpu().numpy().view(np.uint16).astype(np.float64).reshape(-1)
+        ref = np.asarray(stack.T.astype(np.complex128) @ f).reshape(-1)
+        worst = max(worst, float(np.abs(raw[:, i] - ref).max() / np.abs(ref).max()))
+    if not worst < 1e-5:
+        raise SystemExit(f"bench.py: C5 sparse radial Fourier (uint16) check failed: {worst:.3e}")
+    rec.update(workload=f"the same analysis on {n} frames of 1024x1024 uint16", check_rel_err_vs_float64=worst)
+    out['c5_sparse_16_bins_uint16'] = rec
+    del fr, ds, an, res
+    gc.collect()
+    torch.cuda.empty_cache()
     return out
 
 
