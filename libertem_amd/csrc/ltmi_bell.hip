@@ -126,6 +126,7 @@ struct BellImage {
     int n_tail = 0, n_tail_cols = 0;
     size_t n_blocks = 0;
     double mac_ratio = 0.;           // multiply-adds incl. padding / stored values
+    int64_t max_col_entries = 0;     // stored values of the longest real column (length of its float32 chain)
 };
 
 template <int I, int N, typename F> __device__ __forceinline__ void bstatic_for(F &&f) {
@@ -191,11 +192,16 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
     for (int s = 0; s < BE_SLOTS; ++s)
 #pragma unroll
         for (int t = 0; t < TILES * NACC; ++t) acc[s][t] = bf32x4{0.f, 0.f, 0.f, 0.f};
-    // One tile per wave (float32 frames, often large detectors): the running sums are handed to a
-    // second level every BE_L2 chunks, which keeps the float32 chains short (the registers are there:
-    // 16 more tiles).  Two tiles per wave have no room for it.
-    constexpr bool TWO_LEVEL = C::SZ == 4;
-    constexpr int BE_L2 = 32;
+    // One or two tiles per wave: the running sums are handed to a second level after every chunk (512 pixels).  One
+    // float32 chain per column over a whole frame is biased when the addends repeat -- a constant frame under the unit
+    // weights of a ring's interior: once the sum passes 2^25 every addition of 32769 (65535) loses (gains) 1 -- and
+    // reached 1.5e-5 (1.1e-5) of the sum for a ring of 2 500 pixels; per chunk the sum stays below 2^24 and the
+    // second level adds partial sums of changing size: 8e-7 (scripts/debug_band.py history in
+    // profiles/r05_banded.txt 4).  The registers are there (55 -> 89 of 128 for two tiles of 2-byte pixels); four
+    // tiles have no room for it -- the launcher does not pick them for stacks with long columns
+    // (BellImage::max_col_entries).  Cost: + 2 % on the 16-bin radial Fourier stack.
+    constexpr bool TWO_LEVEL = TILES <= 2;
+    constexpr int BE_L2 = 1;
     bf32x4 acc2[TWO_LEVEL ? BE_SLOTS : 1][TWO_LEVEL ? TILES : 1];
 #pragma unroll
     for (int s = 0; s < (TWO_LEVEL ? BE_SLOTS : 1); ++s)
@@ -1352,6 +1358,11 @@ void *bell_build(const int64_t *indptr, const int64_t *indices, const float *val
     const std::vector<float> none;
     BellImage *b = build_image(indptr, indices, vals, nc, n_px, n_masks, false, none, err);
     if (!b) return nullptr;
+    {
+        std::vector<int64_t> per_mask((size_t)n_masks, 0);
+        for (int64_t e = 0; e < indptr[n_px]; ++e) per_mask[(size_t)indices[e]]++;
+        for (int64_t v : per_mask) b->max_col_entries = std::max(b->max_col_entries, v);
+    }
     const char *off = getenv("LTMI_BELL_F16");
     if (off && atoi(off) == 0) return b;
     const int64_t n_cols = n_masks * nc;
@@ -1525,6 +1536,8 @@ static int launch_bell(ltmi_masks *m, BellImage *b, const T *tile, int64_t n_fra
     static const int forced = getenv("LTMI_BELL_TILES") ? atoi(getenv("LTMI_BELL_TILES")) : 0;
     auto rounds = [&](int tl) { return (double)(((n_frames + 16 * tl - 1) / (16 * tl) + 255) / 256); };
     const bool hi = forced ? forced == HI : rounds(HI) * 1.7 < rounds(LO);
+    // k_bell_apply with four tiles has one accumulation level only: not for columns of more than 2048 stored values
+    const bool hi_apply = forced ? hi : (hi && (HI <= 2 || b->max_col_entries <= 2048));
     if constexpr (std::is_same<T, uint8_t>::value || std::is_same<T, uint16_t>::value) {
         if (b->h16) {               // unsigned 1- / 2-byte pixels: the float16 image
             if (hi)
@@ -1534,7 +1547,7 @@ static int launch_bell(ltmi_masks *m, BellImage *b, const T *tile, int64_t n_fra
                                            accumulate, stream);
         }
     }
-    if (hi)
+    if (hi_apply)
         return launch_bell_t<T, HI>(m, b, tile, n_frames, ld, out, ld_out_f, n_cols, accumulate, stream);
     return launch_bell_t<T, LO>(m, b, tile, n_frames, ld, out, ld_out_f, n_cols, accumulate, stream);
 }
