@@ -30,14 +30,18 @@ DENSIFY_FILL = float(os.environ.get('LTMI_DENSIFY_FILL', '0.125'))   # 0 disable
 DENSIFY_MAX_BYTES = 2 << 30
 
 
-def _worth_densifying(csr_px_by_masks, result_dtype):
+def _worth_densifying(csr_px_by_masks, result_dtype, frame_dtype=None):
     """HIP backend: multiply a sparse stack as a dense one when that is the faster kernel:
     * its fill, counted in the 16-column groups the dense kernel works in, exceeds DENSIFY_FILL (the
       blocked sparse kernel spends ~3.5 multiply-adds per stored value at less than half the dense
       kernel's matrix-pipe efficiency), or
-    * it has at most 32 columns -- where the dense kernel streams frames at the HBM rate whatever the
-      fill -- and touches most pixels, so that skipping untouched pixel chunks (which only the sparse
-      kernels do) would save little."""
+    * it has few columns and touches most pixels, so that skipping untouched pixel chunks (which only the
+      sparse kernels do) would save little -- wide rings: 16 384 frames of 256 x 256 against 24 / 48 / 64 / 96 / 128
+      ring bins take 3.0 / 2.3 / 2.1 / 1.9 / 1.7 ms on the gather kernel (the blocked image pads such stacks > 8 x
+      and is not built) and 0.33 / 0.40 / 0.55 / 0.95 / 1.15 ms dense on uint16 frames, 0.65 / 0.77 / 0.96 / 1.58 /
+      1.76 ms on float32 frames (there k_scatter's 1.12 ms wins from 96 columns on; scripts/bench_wide_rings.py):
+      up to 128 real columns for 1- / 2-byte frames, up to 64 otherwise.  The dense kernels also keep two
+      accumulation levels (a constant frame under a wide ring: 1e-4 on the gather kernel's single float32 chain)."""
     n_px, n_masks = csr_px_by_masks.shape
     nc = 2 if np.dtype(result_dtype).kind == 'c' else 1
     cols16 = -(-n_masks * nc // 16) * 16
@@ -49,7 +53,9 @@ def _worth_densifying(csr_px_by_masks, result_dtype):
     if csr_px_by_masks.nnz * nc > DENSIFY_FILL * n_px * cols16:
         return True
     touched = np.count_nonzero(np.diff(csr_px_by_masks.indptr))
-    return cols16 <= 32 and touched > 0.5 * n_px
+    narrow_frames = frame_dtype is not None and np.dtype(frame_dtype).kind in 'iub' and \
+        np.dtype(frame_dtype).itemsize <= 2
+    return cols16 <= (128 if narrow_frames else 64) and touched > 0.5 * n_px
 
 
 def _maybe_banded(csr_px_by_masks, result_dtype):
@@ -243,14 +249,15 @@ class MaskContainer:
 
     # --- device handles --------------------------------------------------------------------------
     def get_handle_for_sig_slice(self, sig_slice, result_dtype, device, real_frames=True,
-                                 tile_dtypes=()):
+                                 tile_dtypes=(), frame_dtype=None):
         """libltmi handle of the slice's stack, cast to `result_dtype`, on GPU `device`.
         real_frames: the tiles are real numbers (a complex128 sparse stack may then stay sparse).
         tile_dtypes: the dtypes the tiles can arrive in (an integer sparse stack stays sparse if the
         product with them is exact in float64)."""
         from libertem_amd import hip
         tile_dtypes = tuple(sorted({np.dtype(d).str for d in tile_dtypes}))
-        key = (sig_slice, np.dtype(result_dtype).str, int(device), bool(real_frames), tile_dtypes)
+        key = (sig_slice, np.dtype(result_dtype).str, int(device), bool(real_frames), tile_dtypes,
+               None if frame_dtype is None else np.dtype(frame_dtype).str)
         h = self._handle_cache.get(key)
         if h is None:
             sparse_ok = np.dtype(result_dtype) in (np.dtype(np.float32), np.dtype(np.complex64),
@@ -290,7 +297,7 @@ class MaskContainer:
                     sig_slice, dtype=result_dtype, sparse_backend='scipy.sparse.csr',
                     transpose=True))                                     # (px, n_masks)
                 sig2 = tuple(int(n) for n in sig_slice.shape.sig)
-                if _worth_densifying(m, result_dtype):
+                if _worth_densifying(m, result_dtype, frame_dtype):
                     # a "sparse" stack that is mostly filled (e.g. the radial Fourier orders of one
                     # wide ring): the dense matrix-core kernel multiplies fewer zeros than the
                     # blocked sparse image pads, and streams the stack instead of gathering --

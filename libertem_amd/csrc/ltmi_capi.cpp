@@ -52,3 +52,23 @@ extern "C" int ltmi_host_device_pointer(int device, void *host, void **dev_out) 
     *dev_out = d;
     return LTMI_OK;
 }
+
+
+// LTMI_ABORT_BACKTRACE=1: print the native call stack when the process aborts (a runtime library calling abort(), an
+// uncaught C++ exception) -- Python's faulthandler shows the Python frames only
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+static void ltmi_abort_backtrace(int sig) {
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    const char msg[] = "\nlibltmi: SIGABRT, native frames:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+__attribute__((constructor)) static void ltmi_debug_init() {
+    const char *e = getenv("LTMI_ABORT_BACKTRACE");
+    if (e && e[0] == '1') signal(SIGABRT, ltmi_abort_backtrace);
+}

@@ -317,24 +317,37 @@ def pin_limit_bytes():
         return 64 << 30
 
 
+_PAGE = 4096
+
+
 def _register_host(torch, arr):
-    """page-lock `arr` in place (or join an existing registration that covers it) -> key | None"""
+    """page-lock `arr` in place (or join an existing registration that covers it) -> key | None.
+
+    WHOLE PAGES are registered (the range of the array rounded outwards), and a range that shares a page with a live
+    registration without lying inside it is not registered at all (bounce buffers then): the runtime pins and maps
+    pages, not bytes -- two arrays that malloc placed on one page used to be registered one after the other, and
+    unregistering the first took the shared page away from under the second one's copies ("Memory access fault by
+    GPU ... on address <heap address>", once in a few runs of the test suite)."""
     ptr, nbytes = arr.ctypes.data, arr.nbytes
+    a0 = ptr // _PAGE * _PAGE
+    a1 = -(-(ptr + nbytes) // _PAGE) * _PAGE
     for p0, ent in _REGISTERED.items():
-        if p0 <= ptr and ptr + nbytes <= p0 + ent[0]:
+        if p0 <= a0 and a1 <= p0 + ent[0]:
             ent[1] += 1
             return p0
+        if a0 < p0 + ent[0] and p0 < a1:
+            return None
     if nbytes > pin_limit_bytes():
         return None
     try:
-        rc = int(torch.cuda.cudart().cudaHostRegister(ptr, nbytes, 0))
+        rc = int(torch.cuda.cudart().cudaHostRegister(a0, a1 - a0, 0))
     except Exception:
         rc = -1
     if rc != 0:
         _clear_runtime_error(torch)
         return None
-    _REGISTERED[ptr] = [nbytes, 1]
-    return ptr
+    _REGISTERED[a0] = [a1 - a0, 1]
+    return a0
 
 
 def _unregister_host(torch, key):

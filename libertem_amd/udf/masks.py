@@ -238,7 +238,7 @@ class ApplyMasksEngine:
         return self.masks.get_handle_for_sig_slice(
             self.meta.sig_slice, self.result_dtype, self.device,
             real_frames=np.dtype(self.meta.input_dtype).kind != 'c',
-            tile_dtypes=(tile_dtype,) if ask else ())
+            tile_dtypes=(tile_dtype,) if ask else (), frame_dtype=self.meta.input_dtype)
 
     def process_tile(self, tile, out=None, accumulate=False):
         """

@@ -834,16 +834,17 @@ def test_sparse_stack_densified_when_mostly_filled(ctx):
     rng = np.random.default_rng(41)
     data = rng.integers(0, 1000, (3, 8, 64, 64)).astype(np.uint16)
     filled = pm.radial_bins(32, 32, 64, 64, n_bins=2, use_sparse=True, dtype=np.float32)     # 2 wide rings
-    rings = pm.radial_bins(32, 32, 64, 64, n_bins=64, use_sparse=True, dtype=np.float32)
+    wide = pm.radial_bins(32, 32, 64, 64, n_bins=64, use_sparse=True, dtype=np.float32)      # <= 64 columns over most pixels
+    rings = pm.radial_bins(32, 32, 64, 64, n_bins=192, use_sparse=True, dtype=np.float32)
     kinds = {}
-    for name, stack in (('filled', filled), ('rings', rings)):
+    for name, stack in (('filled', filled), ('wide', wide), ('rings', rings)):
         mc = MaskContainer(lambda stack=stack: stack, dtype=np.float32, use_sparse=True,
                            backend=UDF.BACKEND_HIP)
         full = Slice(origin=(0, 0, 0), shape=Shape((1, 64, 64), sig_dims=2))
         h = mc.get_handle_for_sig_slice(full.discard_nav(), np.float32, 0)
         kinds[name] = h.kind()
         mc.close()
-    assert kinds == {'filled': 0, 'rings': 2}
+    assert kinds == {'filled': 0, 'wide': 0, 'rings': 2}
     ds = ctx.load('memory', data=data, num_partitions=2, sig_dims=2)
     for stack in (filled, rings):
         got = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda stack=stack: stack))
@@ -1227,14 +1228,14 @@ def test_sparse_masks_with_corrections_folded(ctx):
     corrected = oc.correct(data, (64, 64), dark=dark, gain=gain, coords=coords)
 
     def rings():
-        return M.radial_bins(centerX=32, centerY=32, imageSizeX=64, imageSizeY=64, n_bins=48,
+        return M.radial_bins(centerX=32, centerY=32, imageSizeX=64, imageSizeY=64, n_bins=160,
                              use_sparse=True, dtype=np.float32)
-    dense = M.radial_bins(centerX=32, centerY=32, imageSizeX=64, imageSizeY=64, n_bins=48,
+    dense = M.radial_bins(centerX=32, centerY=32, imageSizeX=64, imageSizeY=64, n_bins=160,
                           use_sparse=False, dtype=np.float32)
     ref = np.tensordot(corrected.astype(np.float64), dense.astype(np.float64),
                        axes=([2, 3], [1, 2]))
     ds = _device_ds(ctx, data, 2)
-    udf = ApplyMasksUDF(mask_factories=rings, use_sparse='scipy.sparse', mask_count=48,
+    udf = ApplyMasksUDF(mask_factories=rings, use_sparse='scipy.sparse', mask_count=160,
                         mask_dtype=np.float32)
     out = {}
     for fold in (True, False):
@@ -1245,7 +1246,7 @@ def test_sparse_masks_with_corrections_folded(ctx):
             kernels = [k for _, _, k in hip.KernelTimer.stop()]
         finally:
             um.FOLD_CORRECTIONS = True
-        assert all('k_bell' in k or 'k_sell' in k for k in kernels) and kernels, kernels
+        assert all('k_bell' in k or 'k_sell' in k or 'k_scatter' in k for k in kernels) and kernels, kernels
         assert _close(out[fold], ref, F32_TOL), fold
 
 
