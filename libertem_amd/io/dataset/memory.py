@@ -15,6 +15,7 @@ Tile delivery:
 """
 import os
 
+import weakref
 import numpy as np
 import psutil
 
@@ -323,31 +324,62 @@ _PAGE = 4096
 def _register_host(torch, arr):
     """page-lock `arr` in place (or join an existing registration that covers it) -> key | None.
 
-    WHOLE PAGES are registered (the range of the array rounded outwards), and a range that shares a page with a live
-    registration without lying inside it is not registered at all (bounce buffers then): the runtime pins and maps
-    pages, not bytes -- two arrays that malloc placed on one page used to be registered one after the other, and
-    unregistering the first took the shared page away from under the second one's copies ("Memory access fault by
-    GPU ... on address <heap address>", once in a few runs of the test suite)."""
+    The runtime pins and maps PAGES: an array that shares its first or last page with another live registration
+    (malloc places arrays of a few MB next to each other) is not registered -- unregistering the neighbour would take
+    the shared page away from under this array's copies ("Memory access fault by GPU ... on address <heap address>",
+    once in a few runs of the test suite); it is staged through the bounce buffers instead.  The registered range
+    itself stays the array's own bytes: a range rounded outwards would make pageable copies of the NEIGHBOURS
+    straddle registered and unregistered memory, which the runtime refuses (invalid argument)."""
     ptr, nbytes = arr.ctypes.data, arr.nbytes
     a0 = ptr // _PAGE * _PAGE
     a1 = -(-(ptr + nbytes) // _PAGE) * _PAGE
     for p0, ent in _REGISTERED.items():
-        if p0 <= a0 and a1 <= p0 + ent[0]:
+        if p0 <= ptr and ptr + nbytes <= p0 + ent[0]:
             ent[1] += 1
             return p0
-        if a0 < p0 + ent[0] and p0 < a1:
+        q0 = p0 // _PAGE * _PAGE
+        q1 = -(-(p0 + ent[0]) // _PAGE) * _PAGE
+        if a0 < q1 and q0 < a1:
             return None
     if nbytes > pin_limit_bytes():
         return None
     try:
-        rc = int(torch.cuda.cudart().cudaHostRegister(a0, a1 - a0, 0))
+        rc = int(torch.cuda.cudart().cudaHostRegister(ptr, nbytes, 0))
     except Exception:
         rc = -1
     if rc != 0:
         _clear_runtime_error(torch)
         return None
-    _REGISTERED[a0] = [a1 - a0, 1]
-    return a0
+    # A registration must never outlive the memory: once the pages are unmapped (free / munmap) the runtime's
+    # mapping of them is gone, and an array that malloc later places at the same addresses would "join" the stale
+    # entry and be copied through it -- a GPU memory access fault.  The owner of the bytes takes the registration
+    # with it whatever happened to the stagers (a close() that raised, a dataset dropped without close).
+    root = arr
+    while isinstance(getattr(root, 'base', None), np.ndarray):
+        root = root.base
+    try:
+        fin = weakref.finalize(root, _owner_died, torch, ptr)
+        fin.atexit = False
+    except TypeError:
+        fin = None
+    _REGISTERED[ptr] = [nbytes, 1, fin]
+    return ptr
+
+
+def _owner_died(torch, key):
+    ent = _REGISTERED.pop(key, None)
+    if ent is None:
+        return
+    try:
+        torch.cuda.synchronize()
+    except Exception:
+        pass
+    try:
+        rc = int(torch.cuda.cudart().cudaHostUnregister(key))
+    except Exception:
+        rc = -1
+    if rc != 0:
+        _clear_runtime_error(torch)
 
 
 def _unregister_host(torch, key):
@@ -357,6 +389,8 @@ def _unregister_host(torch, key):
     ent[1] -= 1
     if ent[1] <= 0:
         del _REGISTERED[key]
+        if len(ent) > 2 and ent[2] is not None:
+            ent[2].detach()
         try:
             rc = int(torch.cuda.cudart().cudaHostUnregister(key))
         except Exception:
@@ -470,12 +504,15 @@ class _HipStager:
         self.consumed[slot] = ev
 
     def close(self):
-        self.torch.cuda.current_stream(self.device).synchronize()
-        self.copy_stream.synchronize()
-        if self.registered is not None:
-            if self.unregister:
-                _unregister_host(self.torch, self._reg_key)
-            self.registered = None
+        try:
+            self.torch.cuda.current_stream(self.device).synchronize()
+            self.copy_stream.synchronize()
+        finally:
+            # (whatever the streams say: the registration goes before the memory can)
+            if self.registered is not None:
+                if self.unregister:
+                    _unregister_host(self.torch, self._reg_key)
+                self.registered = None
 
 
 class MemPartition(Partition):
