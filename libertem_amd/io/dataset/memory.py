@@ -321,6 +321,16 @@ def pin_limit_bytes():
 _PAGE = 4096
 
 
+def pin_min_bytes():
+    """the smallest host array that is page-locked in place: LTMI_PIN_MIN_BYTES, default 32 MiB = the largest
+    value glibc's malloc lets its mmap threshold grow to.  Below it an array may sit in the process heap, on pages
+    it shares with its neighbours and that malloc trims and hands out again; the runtime pins and maps pages, and
+    a GPU copy out of such a range faulted once in ~3 (later ~13) runs of the test suite ("Memory access fault by GPU ...
+    on address <heap address>").  Small arrays go through the two bounce buffers -- a host memcpy of a few MiB."""
+    env = os.environ.get('LTMI_PIN_MIN_BYTES')
+    return int(float(env)) if env else 32 << 20
+
+
 def _register_host(torch, arr):
     """page-lock `arr` in place (or join an existing registration that covers it) -> key | None.
 
@@ -336,12 +346,13 @@ def _register_host(torch, arr):
     for p0, ent in _REGISTERED.items():
         if p0 <= ptr and ptr + nbytes <= p0 + ent[0]:
             ent[1] += 1
+            _reg_log('join', ptr, nbytes)
             return p0
         q0 = p0 // _PAGE * _PAGE
         q1 = -(-(p0 + ent[0]) // _PAGE) * _PAGE
         if a0 < q1 and q0 < a1:
             return None
-    if nbytes > pin_limit_bytes():
+    if nbytes > pin_limit_bytes() or nbytes < pin_min_bytes():
         return None
     try:
         rc = int(torch.cuda.cudart().cudaHostRegister(ptr, nbytes, 0))
@@ -363,13 +374,21 @@ def _register_host(torch, arr):
     except TypeError:
         fin = None
     _REGISTERED[ptr] = [nbytes, 1, fin]
+    _reg_log('register', ptr, nbytes)
     return ptr
+
+
+def _reg_log(what, ptr, nbytes=0):
+    if os.environ.get('LTMI_REG_LOG'):
+        import sys
+        print(f"[reg] {what} {ptr:#x} +{nbytes:#x} live={len(_REGISTERED)}", file=sys.stderr, flush=True)
 
 
 def _owner_died(torch, key):
     ent = _REGISTERED.pop(key, None)
     if ent is None:
         return
+    _reg_log('owner died: unregister', key, ent[0])
     try:
         torch.cuda.synchronize()
     except Exception:
@@ -389,6 +408,7 @@ def _unregister_host(torch, key):
     ent[1] -= 1
     if ent[1] <= 0:
         del _REGISTERED[key]
+        _reg_log('unregister', key, ent[0])
         if len(ent) > 2 and ent[2] is not None:
             ent[2].detach()
         try:
