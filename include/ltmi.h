@@ -113,6 +113,40 @@ int ltmi_masks_create_csr(int device, const int64_t *indptr, const int64_t *indi
  * whatever the estimate says). */
 int ltmi_masks_set_sig_shape(ltmi_masks *m, int sig_h, int sig_w);
 
+/* Non-finite pixels (NaN / Inf in float32 / float64 frames): which zeros of a stack meet them.
+ * The reference has two arithmetics.  A SPARSE stack is multiplied entry by stored entry
+ * (`res_t[col, :] += left[:, row] * val`, src/libertem/common/numba/__init__.py:153-184; pydata path
+ * src/libertem/udf/masks.py:71-74): a non-finite pixel reaches exactly the masks that store it.  A DENSE stack is
+ * multiplied whole (`flat_tile @ masks` / torch.mm, src/libertem/udf/masks.py:59-66, :76-77): 0 * NaN = NaN, a
+ * non-finite pixel reaches every mask.  Handles follow the arithmetic of the constructor that made them
+ * (ltmi_masks_create_dense: dense, ltmi_masks_create_csr: sparse) on EVERY kernel route: where a fast kernel of a
+ * CSR handle also multiplies padding zeros (blocked, scatter, banded images), ltmi_apply_masks[_rows] reads the
+ * result rows of float frames, lists the frames with a non-finite result on the device and computes those again
+ * on the gather kernel (stored entries only) -- one small extra kernel on clean data, no host synchronisation
+ * (csrc/ltmi_guard.hip; LTMI_NONFINITE_GUARD=0 in the environment switches it off for timing comparisons).
+ * The two calls below are for a caller that hands a stack to the OTHER constructor because that kernel is faster:
+ *
+ * ltmi_masks_set_sparse_origin: `m` (from ltmi_masks_create_dense) holds a stack that the reference multiplies
+ * SPARSE -- a well-filled CSR stack that was densified; `gather` is the handle of ltmi_masks_create_csr for the same
+ * stack (same device, n_px, result row: float32 / complex64 / float64, or float64 column pairs for a complex128
+ * stack).  `m` takes ownership of `gather` (destroyed with it) and its products then follow the sparse arithmetic as
+ * above, whichever dense kernel runs (LDS-DMA, folded, float64).
+ *
+ * ltmi_masks_set_dense_origin: `m` (from ltmi_masks_create_csr, float32 / complex64, fewer than 15 360 masks) holds
+ * the non-zeros of a stack that the reference multiplies DENSE -- column blocks with a pixel support each, which
+ * the banded image serves faster (ltmi_masks_set_sig_shape).  indptr / indices: the CSR arrays given to
+ * ltmi_masks_create_csr (host; not kept).  Frames with a non-finite result or a non-finite pixel that no mask
+ * stores are listed, and in their rows every mask that does not store ALL non-finite pixels of the frame
+ * becomes NaN (a skipped 0 * NaN); masks that store them all keep the kernel's sums, which then equal the dense
+ * product.  float32 frames only. */
+int ltmi_masks_set_sparse_origin(ltmi_masks *m, ltmi_masks *gather);
+/* ltmi_masks_create_csr with the gather kernel's image only (no blocked / scatter / banded images are tried): the
+ * handle to pass as `gather` above.  Same arguments, same result dtypes. */
+int ltmi_masks_create_csr_gather(int device, const int64_t *indptr, const int64_t *indices,
+                                 const void *data, int result_dtype, int64_t n_px, int64_t n_masks,
+                                 ltmi_masks **out);
+int ltmi_masks_set_dense_origin(ltmi_masks *m, const int64_t *indptr, const int64_t *indices);
+
 int ltmi_masks_destroy(ltmi_masks *m);
 /* 0 = dense with float32 / complex64 results (f32 matrix cores), 1 = dense with any other result
  * dtype (float64, complex128 on real tiles, exactly representable integer sums: f64 matrix cores;

@@ -280,7 +280,14 @@ class Context:
                                                     backends=backends, iterate=True):
                 if not udf_is_list:
                     part.buffers  # noqa: B018  (materialise lazily built result)
-                yield part
+                # (while the consumer holds the part, another run on this executor is refused with a clear
+                # error instead of waiting for ever or sharing the suspended run's state: hip.RunGate)
+                gate = self.executor.run_gate
+                gate.suspended = 'a run_udf_iter'
+                try:
+                    yield part
+                finally:
+                    gate.suspended = None
 
     @staticmethod
     def _normalize_roi(roi, dataset):

@@ -22,7 +22,7 @@ LIBDIR = os.path.join(HERE, '_lib')
 LIB = os.path.join(LIBDIR, 'libltmi.so')
 OBJDIR = os.path.join(HERE, '_lib', 'obj')
 
-SOURCES = ['ltmi_capi.cpp', 'ltmi_comm.cpp', 'ltmi_dense.hip', 'ltmi_sparse.hip', 'ltmi_reduce.hip', 'ltmi_fft.hip', 'ltmi_dense64.hip', 'ltmi_bell.hip', 'ltmi_mib.hip', 'ltmi_split.hip', 'ltmi_scatter.hip', 'ltmi_cryst.hip', 'ltmi_fold.hip']
+SOURCES = ['ltmi_capi.cpp', 'ltmi_comm.cpp', 'ltmi_dense.hip', 'ltmi_sparse.hip', 'ltmi_reduce.hip', 'ltmi_fft.hip', 'ltmi_dense64.hip', 'ltmi_bell.hip', 'ltmi_mib.hip', 'ltmi_split.hip', 'ltmi_scatter.hip', 'ltmi_cryst.hip', 'ltmi_fold.hip', 'ltmi_guard.hip']
 # hipFFT for the Fourier-space operators (ltmi_fft.hip).  The loader binds libhipfft.so.0 to the copy
 # torch already has in the process (same soname), i.e. the one that matches torch's HIP runtime.
 LINK_LIBS = ['-L/opt/rocm/lib', '-lhipfft', '-ldl']

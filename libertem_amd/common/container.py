@@ -249,15 +249,25 @@ class MaskContainer:
 
     # --- device handles --------------------------------------------------------------------------
     def get_handle_for_sig_slice(self, sig_slice, result_dtype, device, real_frames=True,
-                                 tile_dtypes=(), frame_dtype=None):
+                                 tile_dtypes=(), frame_dtype=None, need_dense=False):
         """libltmi handle of the slice's stack, cast to `result_dtype`, on GPU `device`.
         real_frames: the tiles are real numbers (a complex128 sparse stack may then stay sparse).
         tile_dtypes: the dtypes the tiles can arrive in (an integer sparse stack stays sparse if the
-        product with them is exact in float64)."""
+        product with them is exact in float64).
+        need_dense: the caller multiplies shifted copies of the stack (ltmi_apply_masks_shifted*), which
+        only handles of ltmi_masks_create_dense serve: no banded CSR image for a dense stack.
+
+        Non-finite pixels: whichever kernel the handle ends up on, a stack that the reference multiplies sparse
+        (use_sparse is not False: stored entries only, common/numba/__init__.py:153-184) and one it multiplies
+        dense (`flat_tile @ masks`, udf/masks.py:76-77: 0 * NaN = NaN) keep their own arithmetic -- a
+        densified sparse stack carries its gather image (`set_sparse_origin`), a dense stack held as banded
+        CSR is marked (`set_dense_origin`); csrc/ltmi_guard.hip."""
         from libertem_amd import hip
         tile_dtypes = tuple(sorted({np.dtype(d).str for d in tile_dtypes}))
         key = (sig_slice, np.dtype(result_dtype).str, int(device), bool(real_frames), tile_dtypes,
-               None if frame_dtype is None else np.dtype(frame_dtype).str)
+               None if frame_dtype is None else np.dtype(frame_dtype).str, bool(need_dense))
+        # integer frames hold no NaN / Inf: nothing to attach for them
+        float_frames = frame_dtype is None or np.dtype(frame_dtype).kind in 'fc'
         h = self._handle_cache.get(key)
         if h is None:
             sparse_ok = np.dtype(result_dtype) in (np.dtype(np.float32), np.dtype(np.complex64),
@@ -271,6 +281,8 @@ class MaskContainer:
                 if _worth_densifying(m, result_dtype):
                     dense = np.ascontiguousarray(m.T.toarray().astype(result_dtype, copy=False))
                     h = hip.MaskHandle.dense(device, dense, result_dtype)
+                    if float_frames:
+                        h.set_sparse_origin(hip.MaskHandle.csr_complex128(device, m, gather_only=True))
                 else:
                     h = hip.MaskHandle.csr_complex128(device, m)
             elif self.use_sparse is not False and np.dtype(result_dtype).kind in 'iu' and tile_dtypes:
@@ -289,7 +301,10 @@ class MaskContainer:
                 # do not cover (complex128 on complex frames, integers on wide tiles): densified
                 m = self.get_for_sig_slice(sig_slice, dtype=result_dtype, sparse_backend=False,
                                            transpose=False)            # (n_masks, px), C order
-                h = self._banded_handle_of_dense(m, sig_slice, result_dtype, device)
+                h = None
+                if not need_dense:
+                    h = self._banded_handle_of_dense(m, sig_slice, result_dtype, device,
+                                                     dense_semantics=self.use_sparse is False and float_frames)
                 if h is None:
                     h = hip.MaskHandle.dense(device, np.ascontiguousarray(m), result_dtype)
             else:
@@ -312,6 +327,10 @@ class MaskContainer:
                     if h is None:
                         dense = np.ascontiguousarray(m.T.toarray().astype(result_dtype, copy=False))
                         h = hip.MaskHandle.dense(device, dense, result_dtype)
+                        if float_frames:
+                            # the reference multiplies this stack entry by stored entry: frames whose results
+                            # come out non-finite are computed again on the gather image
+                            h.set_sparse_origin(hip.MaskHandle.csr(device, m, result_dtype, gather_only=True))
                 else:
                     h = hip.MaskHandle.csr(device, m, result_dtype)
             # the detector shape of the slice: a dense float32 / complex64 stack that is even / odd under a
@@ -324,13 +343,14 @@ class MaskContainer:
             self._handle_cache[key] = h
         return h
 
-    def _banded_handle_of_dense(self, m, sig_slice, result_dtype, device):
+    def _banded_handle_of_dense(self, m, sig_slice, result_dtype, device, dense_semantics=True):
         """A DENSE stack of more than 64 real columns that is mostly zeros in blocks -- radial Fourier with 2 - 9 wide
         bins, which the reference's heuristic declares dense (analysis/radialfourier.py:334-341) -- costs one pass over
         all pixels per 32 complex masks; as CSR the library gives it one dense image per bin over that bin's pixels
         (ltmi_masks_set_sig_shape, kind 3; 4096 frames of 1024 x 1024 float32, 4 / 8 bins: 15.2 / 27.5 -> 4.3 / 4.6 ms).
-        Returns that handle, or None (the dense kernels then).  Finite frames give the same sums; a non-finite pixel
-        reaches the masks whose support holds it, like in the reference's sparse backends, not every mask."""
+        Returns that handle, or None (the dense kernels then).  Finite frames give the same sums; with
+        `dense_semantics` the handle is told that the zeros it does not store are weights (ltmi_masks_set_dense_origin):
+        a non-finite pixel then reaches every mask, like in `flat_tile @ masks`."""
         from libertem_amd import hip
         rd = np.dtype(result_dtype)
         sig = tuple(int(n) for n in sig_slice.shape.sig)
@@ -344,11 +364,15 @@ class MaskContainer:
         csr = sp.csr_matrix(np.ascontiguousarray(m).T)                   # (px, n_masks)
         if not _maybe_banded(csr, rd):
             return None
+        if dense_semantics and m.shape[0] >= 15 * 1024:
+            return None
         h = hip.MaskHandle.csr(device, csr, rd)
         h.set_sig_shape(sig[0], sig[1])
         if h.kind() != 3:
             h.close()
             return None
+        if dense_semantics:
+            h.set_dense_origin(csr)
         return h
 
     def get_handle_for_complex_frames(self, sig_slice, result_dtype, device):

@@ -13,14 +13,19 @@ method belongs to and of captured objects.  A fingerprint hashes EVERY byte of e
 udf/base.py `_prepare_run_for_dataset`): any in-place edit is seen.  (Up to round 4 buffers above 64 MiB were
 sampled; a single changed element could go unseen.)
 
-What cannot be seen completely is NOT cached: an object without `__dict__` / `__slots__` that is none of the known
-kinds (device tensors, file handles, random generators ...), anything nested deeper than MAX_DEPTH -- the
-fingerprint then contains an OPAQUE token that never compares equal, so the stack is evaluated and the run
-planned afresh every time, like in the reference.  Files a factory reads and global random state stay
+What cannot be seen completely is NOT cached: only known-transparent kinds are looked into -- NumPy arrays,
+scipy.sparse matrices, numbers / strings, list / tuple / set / dict (keys and values), functions, bound methods,
+partials, and instances of classes DEFINED IN PYTHON (their `__dict__` / `__slots__`).  Everything else -- device
+tensors (torch.Tensor, HipArray: their bytes live in HBM), file objects, random generators (random.Random,
+numpy.random.Generator / RandomState), memoryviews, any instance of a type implemented in C whose state no
+`__dict__` shows -- and anything nested deeper than MAX_DEPTH gives an OPAQUE token that never compares equal, so
+the stack is evaluated and the run planned afresh every time, like in the reference.  Files a factory reads and global random state stay
 invisible to any fingerprint: `ApplyMasksUDF(..., cache=False)` or `Context.invalidate_caches()`.
 """
 import functools
+import io
 import itertools
+import random
 import types
 import warnings
 
@@ -71,6 +76,27 @@ def _opaque(obj):
     return ('opaque', id(obj), next(_OPAQUE_IDS))
 
 
+_HEAPTYPE = 1 << 9                                          # Py_TPFLAGS_HEAPTYPE: a class made by a `class` statement
+
+
+def _known_opaque(obj):
+    """kinds whose state a `__dict__` does not show (or that live on the device): never looked into"""
+    if isinstance(obj, (io.IOBase, random.Random, memoryview, np.random.Generator, np.random.RandomState,
+                        np.random.BitGenerator, types.GeneratorType)):
+        return True
+    mod = type(obj).__module__ or ''
+    if mod == 'torch' or mod.startswith('torch.'):
+        return True                                         # tensors, generators, streams, storages
+    try:
+        from libertem_amd.common.hiparray import HipArray
+        if isinstance(obj, HipArray):
+            return True
+    except Exception:                                       # pragma: no cover
+        pass
+    # an instance of a type implemented in C (no `class` statement made it): whatever `__dict__` it has is not its state
+    return not (type(obj).__flags__ & _HEAPTYPE)
+
+
 def is_opaque(fp):
     """True iff the fingerprint contains something that could not be looked into (never equal to any other)"""
     if isinstance(fp, tuple):
@@ -105,9 +131,16 @@ def fingerprint(obj, _depth=0, _path=()):
     if isinstance(obj, (list, tuple)):
         return ('seq', id(obj), len(obj)) + tuple(fingerprint(x, _depth + 1, path) for x in obj)
     if isinstance(obj, (set, frozenset)):
-        return ('set', id(obj), len(obj))
+        # contents, in an order that does not depend on the set's history (ids drop out of the sort key)
+        members = [fingerprint(x, _depth + 1, path) for x in obj]
+        if any(is_opaque(m) for m in members):
+            return _opaque(obj)
+        return ('set', id(obj), len(obj)) + tuple(sorted(members, key=repr))
+    if isinstance(obj, (bytearray,)):
+        return ('v', bytes(obj))
     if isinstance(obj, dict):
-        return ('map', id(obj), len(obj)) + tuple(fingerprint(v, _depth + 1, path) for v in obj.values())
+        return ('map', id(obj), len(obj)) + tuple(
+            (fingerprint(k, _depth + 1, path), fingerprint(v, _depth + 1, path)) for k, v in obj.items())
     if isinstance(obj, functools.partial):
         return ('partial', id(obj), fingerprint(obj.func, _depth + 1, path),
                 fingerprint(obj.args, _depth + 1, path), fingerprint(obj.keywords, _depth + 1, path))
@@ -129,16 +162,22 @@ def fingerprint(obj, _depth=0, _path=()):
         code, glob = getattr(fn, '__code__', None), getattr(fn, '__globals__', None)
         if code is not None and glob is not None:
             for name in code.co_names:
-                v = glob.get(name)
-                if isinstance(v, np.ndarray) or (
-                        v is not None and not isinstance(v, _STABLE_TYPES) and not callable(v)
-                        and (hasattr(v, '__dict__') or isinstance(v, (list, dict)))):
-                    out.append((name, fingerprint(v, _depth + 1, path)))
+                if name not in glob:                        # (an attribute name or a builtin)
+                    continue
+                v = glob[name]
+                # module globals the function names: modules, classes and functions are taken as fixed; every
+                # other object counts -- by value / content, or OPAQUE when it cannot be looked into
+                # (`rng = np.random.default_rng()` at module level)
+                if isinstance(v, _STABLE_TYPES) or callable(v):
+                    continue
+                out.append((name, fingerprint(v, _depth + 1, path)))
         bound = getattr(obj, '__self__', None)
         if bound is not None and not isinstance(bound, _STABLE_TYPES):
             # a bound method: what the method can read of its object
             out.append(('self', fingerprint(bound, _depth + 1, path)))
         return tuple(out)
+    if _known_opaque(obj):
+        return _opaque(obj)
     d = getattr(obj, '__dict__', None)
     slots = [n for klass in type(obj).__mro__ for n in getattr(klass, '__slots__', ()) if isinstance(n, str)]
     if isinstance(d, dict) or slots:

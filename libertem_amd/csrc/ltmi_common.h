@@ -169,6 +169,17 @@ int cryst_fused_corrected(const void *tile, int tile_dtype, int64_t n_frames, in
                           const int32_t *cnt, int n_excl, int max_env, const float *real_mask, const float *half_mask,
                           int n_cols, float *mask_t, void *gbuf, int64_t gbuf_frames, void *ws, float *out,
                           int accumulate, int n_cu, hipStream_t stream, bool *handled);
+// non-finite pixels on sparse stacks (ltmi_guard.hip; the gather-kernel redo: ltmi_sparse.hip)
+int csr_redo(ltmi_masks *m, const void *tile, int tile_dtype, int64_t max_frames, int64_t ld_tile, void *out,
+             int64_t ld_out, const int32_t *sel, const int *n_sel, const int32_t *roi_rows, hipStream_t stream);
+bool csr_is_f64(const ltmi_masks *m);
+bool guard_wanted(const ltmi_masks *m, int tile_dtype);
+int guard_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames, int64_t ld_tile, void *out,
+                int64_t ld_out, int accumulate, hipStream_t stream);
+void guard_destroy(ltmi_masks *m);
+// ltmi_apply_masks without the guard (ltmi_dense.hip)
+int apply_masks_unguarded(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames, int64_t ld_tile,
+                          void *out, int64_t ld_out, int accumulate, hipStream_t stream);
 int bell_apply(ltmi_masks *m, void *image, int cplx, const void *tile, int tile_dtype,
                int64_t n_frames, int64_t ld_tile, void *out, int64_t ld_out, int accumulate,
                hipStream_t stream, bool *handled);
@@ -228,5 +239,10 @@ struct ltmi_masks {
     // each with the tile width that fits it (ltmi_apply_masks walks them; tuning code 33 does not)
     std::vector<ltmi_masks *> blocks;
     std::vector<int64_t> block_first;        // first mask of every block
+    // non-finite pixels (ltmi_guard.hip)
+    ltmi_masks *sparse_origin = nullptr;   // a DENSE handle that stands for a sparse stack: the stack's gather image (owned)
+    void *dense_origin = nullptr;          // a CSR handle that stands for a dense stack: its by-pixel tables
+    void *guard = nullptr;                 // flagged-frame list + scratch of the guarded product
+    bool last_exact = false;               // the last product ran on a kernel that multiplies stored entries only
     char last_kernel[128] = {0};
 };

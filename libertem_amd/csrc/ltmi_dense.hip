@@ -1685,6 +1685,7 @@ extern "C" int ltmi_masks_destroy(ltmi_masks *m) {
     if (m->partials) (void)hipFree(m->partials);
     if (m->gmasks) (void)hipFree(m->gmasks);
     if (m->csr) (void)ltmi::csr_destroy(m);
+    ltmi::guard_destroy(m);
     delete m;
     return LTMI_OK;
 }
@@ -2463,6 +2464,18 @@ extern "C" int ltmi_apply_masks(ltmi_masks *m, const void *tile, int tile_dtype,
     (void)hipGetLastError();
     hipStream_t stream = (hipStream_t)stream_;
     LTMI_HIP(hipSetDevice(m->device));
+    // float frames against a stack whose fast kernels also multiply zeros the stack does not hold (or, for a dense
+    // stack held as column blocks, skip zeros it does hold): frames with non-finite results are computed again with
+    // the reference's arithmetic (ltmi_guard.hip)
+    if (ltmi::guard_wanted(m, tile_dtype))
+        return ltmi::guard_apply(m, tile, tile_dtype, n_frames, ld_tile, out, ld_out, accumulate, stream);
+    return ltmi::apply_masks_unguarded(m, tile, tile_dtype, n_frames, ld_tile, out, ld_out, accumulate, stream);
+}
+
+int ltmi::apply_masks_unguarded(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames, int64_t ld_tile,
+                                void *out, int64_t ld_out, int accumulate, hipStream_t stream) {
+    void *stream_ = (void *)stream;
+    m->last_exact = false;
     if (m->kind == 2)
         return ltmi::csr_apply(m, tile, tile_dtype, n_frames, ld_tile, out, ld_out, accumulate,
                                stream);

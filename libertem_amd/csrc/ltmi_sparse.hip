@@ -156,7 +156,8 @@ k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
              const int *__restrict__ row_off, const int *__restrict__ row_len,
              const int *__restrict__ active, const int *__restrict__ active_off, int n_chunks,
              A *__restrict__ out, int64_t ld_out, int n_masks, int accumulate, int vec_ok,
-             int ablate, const int32_t *__restrict__ rows) {
+             int ablate, const int32_t *__restrict__ rows, const int32_t *__restrict__ sel,
+             const int *__restrict__ n_sel) {
     extern __shared__ __attribute__((aligned(16))) unsigned char slab_raw[];
     A *slab = (A *)slab_raw;                                          // [SP_P][SP_F]
     typedef A ax4 __attribute__((ext_vector_type(4)));
@@ -167,11 +168,18 @@ k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
     const int lane = tid & 63;
     const int pass = blockIdx.y;
     const int64_t f0 = (int64_t)blockIdx.x * SP_F;
+    // the redo of frames with non-finite results (ltmi_guard.hip): `sel` lists the result rows to compute again,
+    // their number sits in device memory -- the launch covers every frame, workgroups beyond the list leave
+    if (n_sel) {
+        n_frames = *n_sel;
+        if (f0 >= n_frames) return;
+    }
 
     // loader role: frame lf, pixel group lg (16 groups of 8 px per 128-px sweep step)
     const int lf = tid & 15, lg = tid >> 4;
     int64_t frame = f0 + lf;
     if (frame > n_frames - 1) frame = n_frames - 1;
+    if (sel) frame = sel[frame];
     if (rows) frame = rows[frame];                    // a region of interest: result row i = frame rows[i]
     const T *row = tile + frame * ld;
 
@@ -262,7 +270,8 @@ k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
 #pragma unroll
         for (int f = 0; f < SP_F; ++f) {
             if (f0 + f >= n_frames) break;
-            A *o = out + (f0 + f) * ld_out + (int64_t)k * NC;
+            const int64_t orow = sel ? (int64_t)sel[f0 + f] : f0 + f;
+            A *o = out + orow * ld_out + (int64_t)k * NC;
 #pragma unroll
             for (int c = 0; c < NC; ++c) o[c] = accumulate ? o[c] + acc[i][f][c] : acc[i][f][c];
         }
@@ -301,7 +310,8 @@ int csr_destroy(ltmi_masks *m) {
 
 template <typename T>
 static int launch_sell(ltmi_masks *m, CsrImage *c, const T *tile, int64_t n_frames, int64_t ld,
-                       float *out, int64_t ld_out_f, int accumulate, hipStream_t stream) {
+                       float *out, int64_t ld_out_f, int accumulate, hipStream_t stream,
+                       const int32_t *sel = nullptr, const int *n_sel = nullptr) {
     const int vec_ok = vector_loads_ok(tile, ld, sizeof(T)) ? 1 : 0;
     const char *abl = getenv("LTMI_SELL_ABLATE");     // 1: loader only, 2: gathers only (bench)
     const int ablate = abl ? atoi(abl) : 0;
@@ -319,7 +329,7 @@ static int launch_sell(ltmi_masks *m, CsrImage *c, const T *tile, int64_t n_fram
         hipLaunchKernelGGL(kern, grid, dim3(SP_NT), lds, stream, tile, ld, n_frames, m->n_px,
                            (const uint32_t *)c->pix, (const float *)c->val, (const int *)c->row_off,
                            (const int *)c->row_len, (const int *)c->active, (const int *)c->active_off,
-                           c->n_chunks, out, ld_out_f, (int)m->n_masks, accumulate, vec_ok, ablate, m->roi_rows);
+                           c->n_chunks, out, ld_out_f, (int)m->n_masks, accumulate, vec_ok, ablate, m->roi_rows, sel, n_sel);
     } else {
         auto kern = k_sell_apply<T, 4, false>;
         static bool set[16] = {false};
@@ -331,9 +341,11 @@ static int launch_sell(ltmi_masks *m, CsrImage *c, const T *tile, int64_t n_fram
         hipLaunchKernelGGL(kern, grid, dim3(SP_NT), lds, stream, tile, ld, n_frames, m->n_px,
                            (const uint32_t *)c->pix, (const float *)c->val, (const int *)c->row_off,
                            (const int *)c->row_len, (const int *)c->active, (const int *)c->active_off,
-                           c->n_chunks, out, ld_out_f, (int)m->n_masks, accumulate, vec_ok, ablate, m->roi_rows);
+                           c->n_chunks, out, ld_out_f, (int)m->n_masks, accumulate, vec_ok, ablate, m->roi_rows, sel, n_sel);
     }
     LTMI_HIP(hipGetLastError());
+    if (sel) return LTMI_OK;                              // (a redo keeps the name of the kernel it follows)
+    m->last_exact = true;                                 // only stored entries were multiplied
     snprintf(m->last_kernel, sizeof(m->last_kernel), "k_sell_apply<%s,%s%s> grid=(%u,%u) rows=%zu",
              typeid(T).name(), c->cplx ? "c64" : "f32", m->roi_rows ? ",rows" : "", grid.x, grid.y,
              c->n_rows);
@@ -343,7 +355,8 @@ static int launch_sell(ltmi_masks *m, CsrImage *c, const T *tile, int64_t n_fram
 // float64 results: the same kernel with double slab / accumulators / values (128 KiB of LDS)
 template <typename T>
 static int launch_sell64(ltmi_masks *m, CsrImage *c, const T *tile, int64_t n_frames, int64_t ld,
-                         double *out, int64_t ld_out, int accumulate, hipStream_t stream) {
+                         double *out, int64_t ld_out, int accumulate, hipStream_t stream,
+                         const int32_t *sel = nullptr, const int *n_sel = nullptr) {
     const int vec_ok = vector_loads_ok(tile, ld, sizeof(T)) ? 1 : 0;
     dim3 grid((unsigned)((n_frames + SP_F - 1) / SP_F), (unsigned)c->n_pass);
     const size_t lds = (size_t)(SP_P + 1) * SP_F * sizeof(double);
@@ -357,8 +370,10 @@ static int launch_sell64(ltmi_masks *m, CsrImage *c, const T *tile, int64_t n_fr
     hipLaunchKernelGGL(kern, grid, dim3(SP_NT), lds, stream, tile, ld, n_frames, m->n_px,
                        (const uint32_t *)c->pix, (const double *)c->val64, (const int *)c->row_off,
                        (const int *)c->row_len, (const int *)c->active, (const int *)c->active_off,
-                       c->n_chunks, out, ld_out, (int)m->n_masks, accumulate, vec_ok, 0, m->roi_rows);
+                       c->n_chunks, out, ld_out, (int)m->n_masks, accumulate, vec_ok, 0, m->roi_rows, sel, n_sel);
     LTMI_HIP(hipGetLastError());
+    if (sel) return LTMI_OK;
+    m->last_exact = true;
     snprintf(m->last_kernel, sizeof(m->last_kernel), "k_sell_apply<%s,f64%s> grid=(%u,%u) rows=%zu",
              typeid(T).name(), m->roi_rows ? ",rows" : "", grid.x, grid.y, c->n_rows);
     return LTMI_OK;
@@ -529,7 +544,48 @@ int csr_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames,
               dtype_name(m->result_dtype));
 }
 
+
+// The frames `sel[0 .. *n_sel)` of a product again, on the gather kernel -- stored entries only, like the reference's
+// CSR loop (common/numba/__init__.py:153-184) -- written over their result rows (ltmi_guard.hip: frames whose
+// results came out non-finite on a kernel that also multiplies padding zeros).  The launch covers `max_frames`.
+int csr_redo(ltmi_masks *m, const void *tile, int tile_dtype, int64_t max_frames, int64_t ld_tile, void *out,
+             int64_t ld_out, const int32_t *sel, const int *n_sel, const int32_t *roi_rows, hipStream_t stream) {
+    CsrImage *c = m ? (CsrImage *)m->csr : nullptr;
+    if (!c || c->int_result) LTMI_FAIL(LTMI_E_INVALID, "csr_redo: not a float sparse handle");
+    const int32_t *keep = m->roi_rows;
+    m->roi_rows = roi_rows;
+    int rc = LTMI_E_DTYPE;
+    if (c->f64) {
+        double *o = (double *)out;
+        if (tile_dtype == LTMI_F32) rc = launch_sell64<float>(m, c, (const float *)tile, max_frames, ld_tile, o, ld_out, 0, stream, sel, n_sel);
+        else if (tile_dtype == LTMI_F64) rc = launch_sell64<double>(m, c, (const double *)tile, max_frames, ld_tile, o, ld_out, 0, stream, sel, n_sel);
+    } else if (tile_dtype == LTMI_F32) {
+        rc = launch_sell<float>(m, c, (const float *)tile, max_frames, ld_tile, (float *)out,
+                                ld_out * (c->cplx ? 2 : 1), 0, stream, sel, n_sel);
+    }
+    m->roi_rows = keep;
+    if (rc == LTMI_E_DTYPE) LTMI_FAIL(LTMI_E_DTYPE, "csr_redo: %s tiles against %s results", dtype_name(tile_dtype),
+                                      dtype_name(m->result_dtype));
+    return rc;
+}
+
+bool csr_is_f64(const ltmi_masks *m) {
+    const CsrImage *c = m ? (const CsrImage *)m->csr : nullptr;
+    return c && c->f64;
+}
+
 }  // namespace ltmi
+
+static thread_local bool g_gather_only = false;
+
+extern "C" int ltmi_masks_create_csr_gather(int device, const int64_t *indptr, const int64_t *indices,
+                                            const void *data, int result_dtype, int64_t n_px,
+                                            int64_t n_masks, ltmi_masks **out) {
+    g_gather_only = true;
+    const int rc = ltmi_masks_create_csr(device, indptr, indices, data, result_dtype, n_px, n_masks, out);
+    g_gather_only = false;
+    return rc;
+}
 
 extern "C" int ltmi_masks_create_csr(int device, const int64_t *indptr, const int64_t *indices,
                                      const void *data, int result_dtype, int64_t n_px,
@@ -687,7 +743,7 @@ extern "C" int ltmi_masks_create_csr(int device, const int64_t *indptr, const in
         const char *force = getenv("LTMI_SPARSE_BELL");
         const char *thr = getenv("LTMI_BELL_MAX_RATIO");
         const double max_ratio = thr ? atof(thr) : 8.0;
-        bool build = nnz > 0 && !c->f64;                  // (the blocked image is float32 only)
+        bool build = nnz > 0 && !c->f64 && !g_gather_only;   // (the blocked image is float32 only)
         if (force && force[0] == '0') build = false;
         else if (build) {
             c->bell_ratio = ltmi::bell_mac_ratio(indptr, indices, nc, n_px, n_masks);
@@ -710,7 +766,7 @@ extern "C" int ltmi_masks_create_csr(int device, const int64_t *indptr, const in
     {
         const char *force = getenv("LTMI_SPARSE_SCATTER");
         bool build = nnz > 0 && !c->f64 && n_masks * nc >= 64;
-        if (force && force[0] == '0') build = false;
+        if (g_gather_only || (force && force[0] == '0')) build = false;
         else if (force && force[0] == '1') { build = nnz > 0 && !c->f64; c->scat_all = true; }
         else if (build) build = ltmi::scat_fill(indptr, indices, nc, n_px, n_masks) >= 0.15;
         if (build) {
@@ -721,7 +777,7 @@ extern "C" int ltmi_masks_create_csr(int device, const int64_t *indptr, const in
         }
     }
     c->nnz_real = (double)nnz * nc;
-    if (!c->f64 && !int_result) c->kept = ltmi::band_keep_csr(indptr, indices, vals, nc, n_px, n_masks);
+    if (!c->f64 && !int_result && !g_gather_only) c->kept = ltmi::band_keep_csr(indptr, indices, vals, nc, n_px, n_masks);
     *out = m;
     return LTMI_OK;
 }

@@ -29,6 +29,7 @@ _DTYPES = {
 EXPORTS = (
     'ltmi_version', 'ltmi_last_error', 'ltmi_device_count', 'ltmi_device_info',
     'ltmi_masks_create_dense', 'ltmi_masks_create_csr', 'ltmi_masks_destroy', 'ltmi_masks_kind', 'ltmi_masks_set_sig_shape',
+    'ltmi_masks_set_sparse_origin', 'ltmi_masks_set_dense_origin', 'ltmi_masks_create_csr_gather',
     'ltmi_apply_masks', 'ltmi_apply_masks_rows', 'ltmi_apply_masks_shifted', 'ltmi_apply_masks_shifted_host', 'ltmi_sum_frames_workspace', 'ltmi_sum_frames', 'ltmi_sum_sig',
     'ltmi_axpy', 'ltmi_add2d', 'ltmi_gather_rows', 'ltmi_host_device_pointer', 'ltmi_correct', 'ltmi_repair_pixels', 'ltmi_byteswap', 'ltmi_mib_decode', 'ltmi_com_fields', 'ltmi_fft_plan_create',
     'ltmi_fft_plan_destroy', 'ltmi_crystallinity', 'ltmi_crystallinity_corrected', 'ltmi_fft_plan_last_kernel',
@@ -58,22 +59,43 @@ class ReplayState:
         self.recording = None
 
 
+class RunInProgressError(RuntimeError):
+    """a run was started on an executor whose `run_udf_iter` is suspended between two partial results"""
+
+
 class RunGate:
     """Serialises the runs of one executor (its delivery targets, launch-ahead state and streams belong to the
     run in progress): re-entrant for the thread that holds it, and -- unlike threading.RLock -- releasable from
-    another thread (a generator of partial results that is closed by the garbage collector)."""
+    another thread (a generator of partial results that is closed by the garbage collector).
+
+    A `run_udf_iter` holds the gate from its first step to its end, also while it is suspended at a `yield`
+    (`suspended` is set then): the executor's per-run state belongs to it.  Another run on the same executor in
+    that window -- from the loop body, from the event loop of an `async for`, from any thread -- can neither wait
+    (it would wait for ever: the iteration only resumes when its consumer asks for the next part) nor go ahead
+    (it would reuse the suspended run's state), so `acquire` raises RunInProgressError instead."""
 
     def __init__(self):
         self._lock = threading.Lock()
         self._owner = None
         self._depth = 0
+        self.suspended = None        # what is suspended (a string for the message) or None
+
+    def _refuse(self):
+        raise RunInProgressError(
+            f"{self.suspended} of this context is suspended between two partial results and owns the executor: "
+            "consume or close() the iterator before starting another run on the same Context "
+            "(or run it on a second Context)")
 
     def acquire(self):
         me = threading.get_ident()
         if self._owner == me:
+            if self.suspended:
+                self._refuse()
             self._depth += 1
             return
-        self._lock.acquire()
+        while not self._lock.acquire(timeout=0.05):
+            if self.suspended:
+                self._refuse()
         self._owner = me
         self._depth = 1
 
@@ -82,6 +104,7 @@ class RunGate:
         if self._depth <= 0:
             self._depth = 0
             self._owner = None
+            self.suspended = None
             self._lock.release()
 
     def __enter__(self):
@@ -212,11 +235,14 @@ def lib():
                                        c.POINTER(i32)]
         L.ltmi_masks_create_dense.argtypes = [i32, vp, i32, i64, i64, c.POINTER(vp)]
         L.ltmi_masks_create_csr.argtypes = [i32, vp, vp, vp, i32, i64, i64, c.POINTER(vp)]
+        L.ltmi_masks_create_csr_gather.argtypes = [i32, vp, vp, vp, i32, i64, i64, c.POINTER(vp)]
         L.ltmi_masks_destroy.argtypes = [vp]
         L.ltmi_apply_masks_rows.argtypes = [vp, vp, i32, vp, i64, i64, vp, i64, i32, vp,
                                             c.POINTER(i32)]
         L.ltmi_masks_kind.argtypes = [vp, c.POINTER(i32)]
         L.ltmi_masks_set_sig_shape.argtypes = [vp, i32, i32]
+        L.ltmi_masks_set_sparse_origin.argtypes = [vp, vp]
+        L.ltmi_masks_set_dense_origin.argtypes = [vp, vp, vp]
         L.ltmi_apply_masks.argtypes = [vp, vp, i32, i64, i64, vp, i64, i32, vp]
         L.ltmi_apply_masks_shifted.argtypes = [vp, vp, i32, i64, i64, i32, i32, vp, vp, i64, i32, vp]
         L.ltmi_apply_masks_shifted_host.argtypes = [vp, vp, i32, i64, i64, i32, i32, vp, vp, i64, i32, vp]
@@ -335,9 +361,10 @@ class MaskHandle:
         return cls(out, device, m.shape[0], m.shape[1], result_dtype, False)
 
     @classmethod
-    def csr(cls, device, csr_px_by_masks, result_dtype):
+    def csr(cls, device, csr_px_by_masks, result_dtype, gather_only=False):
         """csr_px_by_masks: scipy.sparse CSR (n_px, n_masks) as built by the reference's
-        `_build_sparse` (common/container.py:53-64)."""
+        `_build_sparse` (common/container.py:53-64).  gather_only: just the gather kernel's image (the
+        handle a densified stack keeps for frames with non-finite pixels, `set_sparse_origin`)."""
         result_dtype = np.dtype(result_dtype)
         indptr = np.ascontiguousarray(csr_px_by_masks.indptr, dtype=np.int64)
         indices = np.ascontiguousarray(csr_px_by_masks.indices, dtype=np.int64)
@@ -350,14 +377,15 @@ class MaskHandle:
             data = np.ascontiguousarray(csr_px_by_masks.data.astype(result_dtype, copy=False))
         n_px, n_masks = csr_px_by_masks.shape
         out = ctypes.c_void_p()
-        check(lib().ltmi_masks_create_csr(
+        create = lib().ltmi_masks_create_csr_gather if gather_only else lib().ltmi_masks_create_csr
+        check(create(
             int(device), indptr.ctypes.data_as(ctypes.c_void_p),
             indices.ctypes.data_as(ctypes.c_void_p), data.ctypes.data_as(ctypes.c_void_p),
             dtype_code(result_dtype), n_px, n_masks, ctypes.byref(out)), 'ltmi_masks_create_csr')
         return cls(out, device, n_masks, n_px, result_dtype, True)
 
     @classmethod
-    def csr_complex128(cls, device, csr_px_by_masks):
+    def csr_complex128(cls, device, csr_px_by_masks, gather_only=False):
         """A complex128 sparse stack for REAL frames, without densifying it: (re, im) of mask k are the
         float64 columns 2k, 2k + 1 of the image (the float64 gather kernel), and the result row of a
         frame -- 2 n_masks doubles -- is its complex128 row.  (complex64 stacks do the same inside the
@@ -375,7 +403,7 @@ class MaskHandle:
         indices[0::2], indices[1::2] = 2 * m.indices.astype(np.int64), 2 * m.indices.astype(np.int64) + 1
         indptr = np.concatenate([[0], np.cumsum(2 * counts)]).astype(np.int64)
         real = sp.csr_matrix((data, indices, indptr), shape=(n_px, 2 * n_masks))
-        h = cls.csr(device, real, np.float64)
+        h = cls.csr(device, real, np.float64, gather_only=gather_only)
         h.n_masks = n_masks
         h.result_dtype = np.dtype(np.complex128)
         h._out_words = 2
@@ -390,6 +418,22 @@ class MaskHandle:
         """the detector shape behind the handle's pixels: lets the library fold a stack that is even / odd under a
         mirror of the detector rows (include/ltmi.h)"""
         check(lib().ltmi_masks_set_sig_shape(self._ptr, int(sig_h), int(sig_w)), 'ltmi_masks_set_sig_shape')
+
+    def set_sparse_origin(self, gather):
+        """this DENSE handle holds a stack the reference multiplies sparse (a densified CSR stack): `gather`, the
+        MaskHandle.csr / csr_complex128 of the same stack, serves the frames whose results come out non-finite --
+        stored entries only, like the reference (include/ltmi.h).  Takes ownership of `gather`."""
+        check(lib().ltmi_masks_set_sparse_origin(self._ptr, gather._ptr), 'ltmi_masks_set_sparse_origin')
+        gather._ptr = None
+
+    def set_dense_origin(self, csr_px_by_masks):
+        """this CSR handle holds the non-zeros of a stack the reference multiplies DENSE: a non-finite pixel then
+        reaches every mask, also through the zeros the handle does not store (include/ltmi.h)"""
+        indptr = np.ascontiguousarray(csr_px_by_masks.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(csr_px_by_masks.indices, dtype=np.int64)
+        check(lib().ltmi_masks_set_dense_origin(
+            self._ptr, indptr.ctypes.data_as(ctypes.c_void_p), indices.ctypes.data_as(ctypes.c_void_p)),
+            'ltmi_masks_set_dense_origin')
 
     def set_tuning(self, mt=0, waves=0, ksplit=0):
         check(lib().ltmi_masks_set_tuning(self._ptr, mt, waves, ksplit), 'ltmi_masks_set_tuning')

@@ -231,14 +231,15 @@ class ApplyMasksEngine:
                 dev = plan_state[key] = torch.from_numpy(c).to(f'cuda:{self.device}')
             self._const = dev
 
-    def _get_handle(self, tile_dtype=None):
+    def _get_handle(self, tile_dtype=None, need_dense=False):
         # (tile_dtype: an integer sparse stack stays sparse where the product with tiles of that
         # dtype is exact in float64 -- common/container.py; only asked for integer results)
         ask = tile_dtype is not None and np.dtype(self.result_dtype).kind in 'iu'
         return self.masks.get_handle_for_sig_slice(
             self.meta.sig_slice, self.result_dtype, self.device,
             real_frames=np.dtype(self.meta.input_dtype).kind != 'c',
-            tile_dtypes=(tile_dtype,) if ask else (), frame_dtype=self.meta.input_dtype)
+            tile_dtypes=(tile_dtype,) if ask else (), frame_dtype=self.meta.input_dtype,
+            need_dense=need_dense)
 
     def process_tile(self, tile, out=None, accumulate=False):
         """
@@ -316,7 +317,7 @@ class ApplyMasksEngine:
                 "(do not force a sub-frame tileshape together with shifts=)")
         n = tile.shape[0]
         shifts = np.ascontiguousarray(np.asarray(shifts).reshape((n, 2)).astype(np.int32))
-        handle = self._get_handle()
+        handle = self._get_handle(need_dense=True)     # (shifted copies are cut out of the dense image)
         handle.apply_shifted_host(tile.data_ptr(), tile.dtype, n, tile.ld, sig[0], sig[1], shifts,
                                   out.data_ptr(), out.ld, accumulate, stream=self.stream_ptr)
         return out

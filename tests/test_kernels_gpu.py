@@ -963,17 +963,47 @@ def test_sell_ring_stack_vs_oracle(hip, sparse_kernel):
     assert np.allclose(res, np.asarray(ref64), rtol=1e-5, atol=1e-5 * np.abs(ref64).max())
 
 
+def _stored_entries_ref(data2d, csr_px_by_masks):
+    """the reference's sparse arithmetic in float64 / complex128: per mask, the stored entries only
+    (common/numba/__init__.py:153-184) -- a non-finite pixel reaches exactly the masks that store it"""
+    csc = csr_px_by_masks.tocsc()
+    csc.sort_indices()
+    wide = np.complex128 if np.iscomplexobj(csc.data) else np.float64
+    ref = np.zeros((data2d.shape[0], csc.shape[1]), dtype=wide)
+    with np.errstate(invalid='ignore', over='ignore'):
+        for k in range(csc.shape[1]):
+            idx = csc.indices[csc.indptr[k]:csc.indptr[k + 1]]
+            val = csc.data[csc.indptr[k]:csc.indptr[k + 1]].astype(wide)
+            if len(idx):
+                ref[:, k] = (data2d[:, idx].astype(np.float64) * val[None, :]).sum(axis=1)
+    return ref
+
+
+def _same_non_finite(res, ref):
+    """NaN where the reference is NaN, the same infinity where it is infinite, finite where it is finite"""
+    for part in ((np.real, np.imag) if np.iscomplexobj(ref) or np.iscomplexobj(res) else (np.asarray,)):
+        a, b = part(res), part(ref)
+        if not (np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.isposinf(a), np.isposinf(b))
+                and np.array_equal(np.isneginf(a), np.isneginf(b))):
+            return False
+    return True
+
+
+def _close_where_finite(res, ref, scale, tol=1e-5):
+    ok = np.isfinite(ref)
+    return np.all(np.abs(res[ok] - ref[ok]) <= tol * scale[ok] + 1e-30)
+
+
 def test_sparse_non_finite_pixels(hip, sparse_kernel):
     """NaN / Inf pixels (float32 frames) and the zero entries the device images are padded with.
     The reference's CSR loop only touches stored entries (common/numba/__init__.py:153-184): a
-    non-finite pixel reaches exactly the masks that contain it.
-    * pixels NO mask contains: no effect at all -- both kernels (the padding entries used to
-      multiply pixel 0 of a chunk; now the gather kernel's padding reads an all-zero LDS row and the
+    non-finite pixel reaches exactly the masks that contain it -- on EVERY kernel:
+    * pixels NO mask contains: no effect at all (the gather kernel's padding reads an all-zero LDS row, the
       blocked image pads a block with one of its own pixels);
-    * a pixel some masks contain: those masks are NaN like in the reference; the gather kernel
-      leaves every other mask finite, the blocked image (dense 16-mask x 8-pixel blocks on the
-      matrix cores) may also poison the other masks of the 16-mask groups whose blocks hold that
-      pixel -- documented divergence."""
+    * a pixel some masks contain: those masks are NaN / Inf like in the reference and no others -- the blocked
+      image (dense 16-mask x 8-pixel blocks on the matrix cores) and the scatter bundles also multiply zeros of
+      neighbouring masks; the frames whose results come out non-finite are listed on the device and computed
+      again by the gather kernel (csrc/ltmi_guard.hip)."""
     import scipy.sparse as sp
     from oracle import masks as omasks
     rings = omasks.radial_bins(32, 32, 64, 64, radius=20, n_bins=64, use_sparse=True,
@@ -992,36 +1022,199 @@ def test_sparse_non_finite_pixels(hip, sparse_kernel):
     dirty[3, ~touched] = np.inf
     res, _ = _apply_csr(hip, dirty, csr, np.float32)
     assert np.all(np.isfinite(res)) and np.array_equal(res, base)
-    # one touched pixel of frame 5
-    p = int(np.flatnonzero(touched)[200])
+    # one touched pixel of frame 5 is NaN, two of frame 9 are +Inf / -Inf, one of frame 23 (the last) +Inf
+    tp = np.flatnonzero(touched)
+    p, q1, q2, q3 = int(tp[200]), int(tp[50]), int(tp[700]), int(tp[901])
     dirty = clean.copy()
     dirty[5, p] = np.nan
-    ref2 = opath.rmatmul(dirty, csr)
-    res2, _ = _apply_csr(hip, dirty, csr, np.float32)
+    dirty[9, q1] = np.inf
+    dirty[9, q2] = -np.inf
+    dirty[23, q3] = np.inf
+    ref2 = opath.rmatmul(dirty, csr)                              # the reference's own loop
+    res2, kern2 = _apply_csr(hip, dirty, csr, np.float32)
     has_p = np.asarray(rings[:, p].todense()).reshape(-1) != 0
     assert np.all(np.isnan(ref2[5, has_p])) and np.all(np.isfinite(ref2[5, ~has_p]))
-    assert np.all(np.isnan(res2[5, has_p]))
-    other = np.arange(24) != 5
-    assert np.array_equal(res2[other], base[other])              # other frames untouched
-    if sparse_kernel == 'sell':
-        assert np.array_equal(np.isnan(res2), np.isnan(ref2))    # exactly the reference's NaNs
-    elif sparse_kernel == 'scatter':
-        # k_scatter: a bundle is a window of 8 accumulator slots inside the cell of ONE range of columns
-        # (64 columns: ranges of 2); the zero weights of its unused slots meet the NaN too -- columns of the
-        # same range within 8 of one that holds the pixel may be NaN, no others
-        rs = 2
-        while rs < 32 and (64 + rs - 1) // rs > 32:
-            rs *= 2
-        hp = np.flatnonzero(has_p)
-        col = np.arange(64)
-        near = ((col[:, None] // rs == hp[None, :] // rs) & (np.abs(col[:, None] - hp[None, :]) < 8)).any(axis=1)
-        assert np.all(np.isfinite(res2[5, ~near]))
-        assert np.allclose(res2[5, ~near], base[5, ~near], rtol=1e-6)
+    assert _same_non_finite(res2, ref2), kern2                    # exactly the reference's NaNs and infinities
+    clean_rows = np.ones(24, bool)
+    clean_rows[[5, 9, 23]] = False
+    assert np.array_equal(res2[clean_rows], base[clean_rows])     # other frames untouched
+    ok = np.isfinite(ref2)
+    assert np.allclose(res2[ok], ref2[ok], rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+    if sparse_kernel != 'sell':
+        assert kern2.endswith('+nf'), kern2
+    # `out += product`: what `out` held is not the product's business (a NaN there stays, nothing else changes)
+    held = rng.random((24, 64)).astype(np.float32)
+    held[7, 3] = np.nan
+    res3, _ = _apply_csr(hip, dirty, csr, np.float32, accumulate_into=held)
+    with np.errstate(invalid='ignore'):
+        ref3 = held + ref2
+    assert _same_non_finite(res3, ref3)
+    ok = np.isfinite(ref3)
+    assert np.allclose(res3[ok], ref3[ok], rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+    # through a row list (a region of interest): result row i = frame rows[i]
+    h = hip.MaskHandle.csr(0, csr, np.float32)
+    rows = np.array([9, 2, 5, 5, 23, 0], dtype=np.int32)
+    t, r, out = _dev(dirty), _dev(rows), _dev(np.full((len(rows), 64), 7, np.float32))
+    assert h.apply_rows(t.data_ptr(), np.float32, r.data_ptr(), len(rows), 4096, out.data_ptr(), 64, False)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    h.close()
+    assert _same_non_finite(got, ref2[rows])
+    ok = np.isfinite(ref2[rows])
+    assert np.allclose(got[ok], ref2[rows][ok], rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+
+
+def _dirty_frames(rng, n_frames, n_px, stored, unstored):
+    """float32 frames: clean ones; frame 1: NaN in a pixel no mask stores; frame 2: NaN in a stored pixel;
+    frame 3: +Inf in a stored pixel; frame 4: +Inf and -Inf in two stored pixels; the last frame: NaN in both kinds"""
+    data = (rng.random((n_frames, n_px)) + 0.1).astype(np.float32)
+    if len(unstored):
+        data[1, unstored[len(unstored) // 2]] = np.nan
+        data[n_frames - 1, unstored[0]] = np.nan
+    data[2, stored[len(stored) // 3]] = np.nan
+    data[3, stored[len(stored) // 2]] = np.inf
+    data[4, stored[len(stored) // 5]] = np.inf
+    data[4, stored[(2 * len(stored)) // 3]] = -np.inf
+    data[n_frames - 1, stored[-1]] = np.nan
+    return data
+
+
+@pytest.mark.parametrize('case', ['wide_rings_f32', 'wide_rings_folded', 'complex_blocks', 'float64', 'complex128'])
+def test_densified_sparse_stack_non_finite_pixels(hip, case):
+    """A sparse stack that MaskContainer multiplies DENSE (well filled / wide rings): the dense kernels -- LDS-DMA,
+    folded, more than 64 columns in blocks, float64 matrix cores -- multiply every zero, the reference's sparse loops
+    (common/numba/__init__.py:153-184, udf/masks.py:68-77) none.  The handle carries the stack's gather image
+    (ltmi_masks_set_sparse_origin): frames with non-finite results are computed again on it."""
+    import scipy.sparse as sp
+    from oracle import masks as omasks
+    rng = np.random.default_rng(_seed('densified', case))
+    sig = (64, 64)
+    if case in ('wide_rings_f32', 'wide_rings_folded', 'float64'):
+        rings = omasks.radial_bins(32, 32, 64, 64, radius=28, n_bins=24, use_sparse=True, dtype=np.float32)
+        csr = sp.csr_matrix(rings.T.astype(np.float64 if case == 'float64' else np.float32))   # (4096, 24)
+        rd = np.float64 if case == 'float64' else np.float32
     else:
-        groups = np.unique(np.flatnonzero(has_p) // 16)           # 16-mask groups holding p
-        allowed = np.isin(np.arange(64) // 16, groups)
-        assert np.all(np.isfinite(res2[5, ~allowed]))
-        assert np.allclose(res2[5, ~allowed], base[5, ~allowed], rtol=1e-6)
+        from libertem_amd.analysis.radialfourier import radial_mask_factory
+        stack = radial_mask_factory(64, 64, 32, 32, 0, 28, 3, 15, True)()          # 3 bins x 16 orders
+        rd = np.complex128 if case == 'complex128' else np.complex64
+        csr = sp.csr_matrix(stack.to_px_by_masks(dtype=rd))
+    n_px, n_masks = csr.shape
+    stored = np.flatnonzero(np.diff(csr.indptr) > 0)
+    unstored = np.flatnonzero(np.diff(csr.indptr) == 0)
+    assert len(unstored) > 100
+    data = _dirty_frames(rng, 40, n_px, stored, unstored)
+    dense = np.ascontiguousarray(np.asarray(csr.todense()).T.astype(rd))
+    h = hip.MaskHandle.dense(0, dense, rd)
+    if case == 'complex128':
+        h.set_sparse_origin(hip.MaskHandle.csr_complex128(0, csr, gather_only=True))
+    else:
+        h.set_sparse_origin(hip.MaskHandle.csr(0, csr, rd, gather_only=True))
+    if case in ('wide_rings_folded', 'complex_blocks'):
+        h.set_sig_shape(*sig)
+    t = _dev(data)
+    out = _dev(np.full((40, n_masks), 7, dtype=rd))
+    h.apply(t.data_ptr(), np.float32, 40, n_px, out.data_ptr(), n_masks, False)
+    torch.cuda.synchronize()
+    kern = h.last_kernel()
+    res = out.cpu().numpy()
+    assert res.dtype == rd and kern.endswith('+nf'), kern
+    if case == 'wide_rings_folded':
+        assert 'k_dense_fold' in kern, kern
+    ref = _stored_entries_ref(data, csr)
+    assert not np.all(np.isfinite(ref[2])) and np.all(np.isfinite(ref[1]))
+    assert _same_non_finite(res, ref), kern
+    scale = _stored_entries_ref(np.where(np.isfinite(data), np.abs(data), 0), abs(csr))
+    tol = 1e-5 if np.dtype(rd) in (np.dtype(np.float32), np.dtype(np.complex64)) else 1e-12
+    assert _close_where_finite(res, ref, np.abs(scale) + 1e-30, tol)
+    # out += product, and a row list
+    held = rng.random((40, n_masks)).astype(rd)
+    out2 = _dev(held)
+    h.apply(t.data_ptr(), np.float32, 40, n_px, out2.data_ptr(), n_masks, True)
+    torch.cuda.synchronize()
+    res2 = out2.cpu().numpy()
+    with np.errstate(invalid='ignore'):
+        assert _same_non_finite(res2, held + ref)
+    assert _close_where_finite(res2, held + ref, np.abs(scale) + 1, tol)
+    rows = np.array([39, 2, 0, 4, 1], dtype=np.int32)
+    r = _dev(rows)
+    out3 = _dev(np.full((5, n_masks), 7, dtype=rd))
+    if h.apply_rows(t.data_ptr(), np.float32, r.data_ptr(), 5, n_px, out3.data_ptr(), n_masks, False):
+        torch.cuda.synchronize()
+        res3 = out3.cpu().numpy()
+        assert _same_non_finite(res3, ref[rows]), h.last_kernel()
+        assert _close_where_finite(res3, ref[rows], np.abs(scale[rows]) + 1e-30, tol)
+    h.close()
+
+
+@pytest.mark.parametrize('origin', ['sparse', 'dense'])
+def test_banded_stack_non_finite_pixels(hip, monkeypatch, origin):
+    """Radial-Fourier stack with several bins as a banded image (ltmi_masks_kind 3: one folded dense image per bin).
+    origin='sparse' (use_sparse=True in the reference: stored entries only): a NaN pixel inside a bin's 64-pixel stages
+    but outside its support, or in no support at all, must not reach that bin.  origin='dense' (the reference's own
+    heuristic declares a few wide bins dense, analysis/radialfourier.py:334-341: `flat_tile @ masks`): a NaN pixel
+    reaches EVERY mask, also the bins whose image never reads it (ltmi_masks_set_dense_origin)."""
+    import scipy.sparse as sp
+    from libertem_amd.analysis.radialfourier import radial_mask_factory
+    monkeypatch.setenv('LTMI_SPARSE_BAND', '1')
+    rng = np.random.default_rng(_seed('banded-nf', origin))
+    stack = radial_mask_factory(128, 128, 64, 64, 4, 50, 3, 12, True)()               # 3 bins x 13 orders
+    csr = sp.csr_matrix(stack.to_px_by_masks(dtype=np.complex64))                      # (16384, 39)
+    n_px, n_masks = csr.shape
+    stored = np.flatnonzero(np.diff(csr.indptr) > 0)
+    unstored = np.flatnonzero(np.diff(csr.indptr) == 0)
+    assert len(unstored) > 1000
+    data = _dirty_frames(rng, 48, n_px, stored, unstored)
+    h = hip.MaskHandle.csr(0, csr, np.complex64)
+    h.set_sig_shape(128, 128)
+    assert h.kind() == 3
+    if origin == 'dense':
+        h.set_dense_origin(csr)
+    t = _dev(data)
+    out = _dev(np.full((48, n_masks), 7, np.complex64))
+    h.apply(t.data_ptr(), np.float32, 48, n_px, out.data_ptr(), n_masks, False)
+    torch.cuda.synchronize()
+    kern = h.last_kernel()
+    res = out.cpu().numpy()
+    assert 'banded' in kern and kern.endswith('+nf'), kern
+    dense = np.asarray(csr.todense()).astype(np.complex128)
+    if origin == 'sparse':
+        ref = _stored_entries_ref(data, csr)
+        assert np.all(np.isfinite(ref[1]))
+    else:
+        with np.errstate(invalid='ignore'):
+            ref = data.astype(np.complex128) @ dense                                   # every zero is a weight
+        assert np.all(np.isnan(ref[1].real)) and np.all(np.isnan(ref[2].imag))
+    if origin == 'dense':
+        # NaN pixels: exactly the reference's NaNs.  Inf pixels: the same entries are non-finite; whether a complex
+        # GEMM turns Inf * (w + 0j) into (Inf, NaN) or (NaN, NaN) is the BLAS kernel's business (OpenBLAS zgemm
+        # gives the latter, the formula re = xr wr - xi wi the former), not the stack's
+        nan_frames = np.isnan(data).any(axis=1)
+        assert _same_non_finite(res[nan_frames], ref[nan_frames]), kern
+        assert np.array_equal(np.isfinite(res.real), np.isfinite(ref.real)) and \
+            np.array_equal(np.isfinite(res.imag), np.isfinite(ref.imag)), kern
+    else:
+        assert _same_non_finite(res, ref), kern
+    scale = np.where(np.isfinite(data), np.abs(data), 0).astype(np.float64) @ np.abs(dense)
+    assert _close_where_finite(res, ref, scale)
+    rows = np.array([47, 1, 2, 0, 3, 4, 9], dtype=np.int32)
+    r, out3 = _dev(rows), _dev(np.full((7, n_masks), 7, np.complex64))
+    assert h.apply_rows(t.data_ptr(), np.float32, r.data_ptr(), 7, n_px, out3.data_ptr(), n_masks, False)
+    torch.cuda.synchronize()
+    res3 = out3.cpu().numpy()
+    assert np.array_equal(np.isfinite(res3.real), np.isfinite(ref[rows].real)) and \
+        np.array_equal(np.isfinite(res3.imag), np.isfinite(ref[rows].imag)), h.last_kernel()
+    if origin == 'sparse':
+        assert _same_non_finite(res3, ref[rows]), h.last_kernel()
+    assert _close_where_finite(res3, ref[rows], scale[rows])
+    # integer frames hold no non-finite pixel: not guarded
+    u16 = rng.integers(0, 4096, (16, n_px)).astype(np.uint16)
+    t16, out4 = _dev(u16), _dev(np.zeros((16, n_masks), np.complex64))
+    h.apply(t16.data_ptr(), np.uint16, 16, n_px, out4.data_ptr(), n_masks, False)
+    torch.cuda.synchronize()
+    assert not h.last_kernel().endswith('+nf')
+    assert _close_where_finite(out4.cpu().numpy(), u16.astype(np.float64) @ dense,
+                               u16.astype(np.float64) @ np.abs(dense))
+    h.close()
 
 
 def test_sparse_dispatch_by_padding_factor(hip, monkeypatch):

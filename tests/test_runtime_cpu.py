@@ -676,6 +676,57 @@ def test_run_udf_async(ctx):
     assert np.count_nonzero(parts[0][..., 0]) == 6
 
 
+def test_run_inside_suspended_iteration_is_refused(ctx):
+    """Round-5 advice: a `run_udf_iter` owns the executor until it ends, also between two partial results.  A run
+    started in that window -- in the loop body, from another thread, from the event loop of an `async for` -- used
+    to wait for ever (other thread) or to share the suspended run's per-run state (same thread); now it raises a
+    clear error, and the iteration goes on untouched."""
+    import asyncio
+    import threading
+    from libertem_amd.hip import RunInProgressError
+    rng = np.random.default_rng(19)
+    data = rng.integers(0, 100, (4, 6, 8, 8)).astype(np.uint16)
+    masks = rng.random((3, 8, 8)).astype(np.float32)
+    ds = ctx.load('memory', data=data, num_partitions=4, sig_dims=2)
+    want = ctx.run_udf(dataset=ds, udf=NumpyMasksUDF(masks))['intensity'].data
+    steps, errors = 0, []
+    for part in ctx.run_udf_iter(dataset=ds, udf=NumpyMasksUDF(masks)):
+        steps += 1
+        with pytest.raises(RunInProgressError, match='run_udf_iter'):
+            ctx.run_udf(dataset=ds, udf=NumpySumUDF())                     # same thread
+
+        def other():
+            try:
+                ctx.run_udf(dataset=ds, udf=NumpySumUDF())
+            except RunInProgressError as e:
+                errors.append(e)
+        th = threading.Thread(target=other)
+        th.start()
+        th.join(timeout=10)
+        assert not th.is_alive()
+    assert steps == 4 and len(errors) == 4
+    assert np.array_equal(part.buffers[0]['intensity'].data, want)
+    # the gate is free again
+    assert np.array_equal(ctx.run_udf(dataset=ds, udf=NumpyMasksUDF(masks))['intensity'].data, want)
+    # a half-consumed iterator that is closed gives the executor back
+    it = ctx.run_udf_iter(dataset=ds, udf=NumpyMasksUDF(masks))
+    next(it)
+    with pytest.raises(RunInProgressError):
+        ctx.run_udf(dataset=ds, udf=NumpySumUDF())
+    it.close()
+    assert np.array_equal(ctx.run_udf(dataset=ds, udf=NumpyMasksUDF(masks))['intensity'].data, want)
+
+    async def main():
+        seen = 0
+        async for part in ctx.run_udf_iter(dataset=ds, udf=NumpyMasksUDF(masks), sync=False):
+            seen += 1
+            with pytest.raises(RunInProgressError):
+                await ctx.run_udf(dataset=ds, udf=NumpySumUDF(), sync=False)
+        return seen, np.array(part.buffers[0]['intensity'].data)
+    seen, last = asyncio.run(main())
+    assert seen == 4 and np.array_equal(last, want)
+
+
 def test_stream_dataset_in_place_feed(live_ctx):
     """`frames=None`: the producer writes into `scan_buffer` itself and commits its progress -- no feeder
     thread, no copy on this side (a detector's DMA target); partial results per partition as with the
@@ -1119,6 +1170,51 @@ def test_fingerprint_follows_objects_and_refuses_what_it_cannot_see():
     assert is_opaque(fingerprint(lambda: deep))
     # modules, classes and builtins a factory names are stable, not opaque
     assert not is_opaque(fingerprint(lambda: np.ones((2, 2)) * len(str(Holder))))
+    # round-5 advice: objects WITH a __dict__ whose state is not in it must not pass as transparent -- device
+    # tensors, file objects, random generators, instances of C-implemented types; sets by content, dicts with keys
+    import io
+    import random
+    import functools
+    import torch
+    t = torch.zeros(3)
+    for hidden in (t, random.Random(1), io.BytesIO(b'abc'), np.random.RandomState(3), memoryview(b'xy')):
+        fp = fingerprint(lambda h=hidden: h)
+        assert is_opaque(fp), type(hidden)
+    st = {1, 2, 3}
+    fac_set = (lambda: st)
+    s0 = fingerprint(fac_set)
+    assert not is_opaque(s0) and fingerprint(fac_set) == s0
+    st.add(9)
+    st.discard(1)                                      # same id, same length, other members
+    assert fingerprint(fac_set) != s0
+    d = {'a': 1}
+    fac_d = (lambda: d)
+    d0 = fingerprint(fac_d)
+    d['b'] = d.pop('a')                                # same values, other key
+    assert fingerprint(fac_d) != d0
+    # a module global that cannot be looked into makes the factory uncacheable (it used to be skipped)
+    global _FP_RNG
+    _FP_RNG = np.random.default_rng(5)
+
+    def from_global_rng():
+        return _FP_RNG.random(3)
+    assert is_opaque(fingerprint(from_global_rng))
+    # ... a scalar global counts by value
+    global _FP_RADIUS
+    _FP_RADIUS = 3
+
+    def from_global_scalar():
+        return np.ones(4) * _FP_RADIUS
+    r0 = fingerprint(from_global_scalar)
+    assert not is_opaque(r0)
+    _FP_RADIUS = 4
+    assert fingerprint(from_global_scalar) != r0
+    # the usual factories stay cacheable
+    from libertem_amd import masks as M
+    assert not is_opaque(fingerprint(functools.partial(M.circular, 3, 3, 8, 8, 2)))
+    import scipy.sparse as sp
+    m = sp.csr_matrix(np.eye(3))
+    assert not is_opaque(fingerprint(lambda: m))
 
 
 def test_container_looks_for_banded_stacks():

@@ -2119,3 +2119,144 @@ def test_radial_fourier_sparse_bins_through_run_udf_with_roi(ctx, monkeypatch, d
     labels = [k for _, _, k in hip.KernelTimer.stop()]
     assert labels and all('banded' in k for k in labels), labels
     assert _close(res_r, ref[roi], F32_TOL)
+
+
+# --- non-finite pixels: a sparse stack multiplies stored entries only, a dense one every zero ------------------
+def zlib_seed(*what):
+    import zlib
+    return zlib.crc32(repr(what).encode())
+
+
+def _nf_scan(rng, nav, sig, stored, unstored, where):
+    """float32 scan with NaN / Inf pixels in a few frames: where='unstored': pixels no mask stores;
+    'stored': pixels some masks store; a NaN, a +Inf and a +Inf / -Inf pair"""
+    n = int(np.prod(nav))
+    data = (rng.random((n, int(np.prod(sig)))) + 0.1).astype(np.float32)
+    pool = unstored if where == 'unstored' else stored
+    assert len(pool) > 8
+    data[1, pool[len(pool) // 2]] = np.nan
+    data[n // 2, pool[len(pool) // 3]] = np.inf
+    data[n - 1, pool[0]] = np.inf
+    data[n - 1, pool[-1]] = -np.inf
+    data[n - 2, pool[len(pool) // 5]] = np.nan
+    return data.reshape(tuple(nav) + tuple(sig))
+
+
+def _same_nf(res, ref):
+    parts = (np.real, np.imag) if np.iscomplexobj(ref) else (np.asarray,)
+    return all(np.array_equal(np.isnan(f(res)), np.isnan(f(ref))) and
+               np.array_equal(np.isposinf(f(res)), np.isposinf(f(ref))) and
+               np.array_equal(np.isneginf(f(res)), np.isneginf(f(ref))) for f in parts)
+
+
+@pytest.mark.parametrize('where', ['unstored', 'stored'])
+@pytest.mark.parametrize('route', ['blocked_rings', 'densified_wide_rings', 'folded_wide_rings', 'banded_radial_fourier'])
+def test_sparse_stack_non_finite_pixels_through_run_udf(ctx, monkeypatch, route, where):
+    """ApplyMasksUDF / RadialFourierAnalysis with use_sparse='scipy.sparse' on float32 frames that hold NaN / Inf
+    pixels, through run_udf, against the oracle's restatement of the reference's CSR loop
+    (oracle.path.apply_masks_sparse -> rmatmul, common/numba/__init__.py:153-184; udf/masks.py:68-77): whichever
+    kernel MaskContainer picks -- blocked / scatter image, the stack multiplied dense, dense and folded about the
+    detector rows, banded images per radial-Fourier bin -- a non-finite pixel reaches exactly the masks that store
+    it (a) not at all when no mask stores it, (b) those masks only."""
+    import scipy.sparse as sp
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd import masks as M
+    from libertem_amd import hip
+    rng = np.random.default_rng(zlib_seed(route, where))
+    nav = (4, 6)
+    if route == 'banded_radial_fourier':
+        monkeypatch.setenv('LTMI_SPARSE_BAND', '1')
+        sig = (128, 128)
+        n_bins, max_order = 3, 12
+        csr_masks = sp.csr_matrix(omasks.radial_mask_stack_csr(128, 128, 64., 64., 4., 50., n_bins, max_order))
+    else:
+        sig = (64, 64)
+        n_bins = {'blocked_rings': 192, 'densified_wide_rings': 24, 'folded_wide_rings': 40}[route]
+        # (rings about the detector centre are even under a mirror of the rows: multiplied folded; off centre: not)
+        cx, cy = (30.3, 33.7) if route == 'densified_wide_rings' else (32, 32)
+        csr_masks = sp.csr_matrix(omasks.radial_bins(cx, cy, 64, 64, radius=28, n_bins=n_bins, use_sparse=True,
+                                                     dtype=np.float32))             # (n_masks, px)
+    counts = np.asarray((csr_masks != 0).sum(axis=0)).reshape(-1)
+    stored, unstored = np.flatnonzero(counts > 0), np.flatnonzero(counts == 0)
+    data = _nf_scan(rng, nav, sig, stored, unstored, where)
+    ds = _device_ds(ctx, data, 2)
+    if route == 'banded_radial_fourier':
+        analysis = ctx.create_radial_fourier_analysis(dataset=ds, cx=64., cy=64., ri=4., ro=50., n_bins=n_bins,
+                                                      max_order=max_order, use_sparse=True)
+        udf = analysis.get_udf()
+    else:
+        def rings():
+            return M.radial_bins(cx, cy, 64, 64, radius=28, n_bins=n_bins, use_sparse=True, dtype=np.float32)
+        udf = ApplyMasksUDF(mask_factories=rings, use_sparse='scipy.sparse', mask_count=n_bins,
+                            mask_dtype=np.float32)
+    hip.KernelTimer.start()
+    got = ctx.run_udf(dataset=ds, udf=udf)['intensity'].data
+    labels = [k for _, _, k in hip.KernelTimer.stop()]
+    want = {'blocked_rings': ('k_scatter', 'k_bell'), 'densified_wide_rings': ('k_dense_lds', 'k_dense_mfma'),
+            'folded_wide_rings': ('k_dense_fold',), 'banded_radial_fourier': ('k_dense_fold',)}[route]
+    assert labels and all(k.startswith(want) or 'column blocks' in k for k in labels), labels
+    assert all(k.endswith('+nf') for k in labels), labels                  # the guarded product ran
+    if route == 'banded_radial_fourier':
+        assert all('banded' in k for k in labels), labels
+    ref = opath.apply_masks_sparse(data, csr_masks, num_partitions=2)
+    assert got.shape == ref.shape and got.dtype == ref.dtype
+    if where == 'unstored':
+        assert np.all(np.isfinite(ref))
+    else:
+        assert not np.all(np.isfinite(ref[0, 1]))
+    assert _same_nf(got, ref), labels
+    ok = np.isfinite(ref)
+    scale = np.abs(ref[ok]).max()
+    assert np.allclose(got[ok], ref[ok], rtol=F32_TOL, atol=F32_TOL * scale)
+    # a region of interest reads the frames through a row list
+    roi = np.zeros(nav, bool)
+    roi[0, 1] = roi[3, 5] = roi[2, 0] = roi[1, 3] = True
+    got_r = ctx.run_udf(dataset=ds, udf=udf, roi=roi)['intensity'].raw_data
+    assert _same_nf(got_r, ref[roi])
+    ok = np.isfinite(ref[roi])
+    assert np.allclose(got_r[ok], ref[roi][ok], rtol=F32_TOL, atol=F32_TOL * scale)
+
+
+@pytest.mark.parametrize('where', ['unstored', 'stored'])
+def test_dense_banded_radial_fourier_non_finite_pixels_through_run_udf(ctx, monkeypatch, where):
+    """The reference's heuristic declares a radial-Fourier stack of a few wide bins DENSE
+    (analysis/radialfourier.py:334-341) and multiplies it with `flat_tile @ masks` (udf/masks.py:76-77): 0 * NaN = NaN,
+    a non-finite pixel reaches every mask.  MaskContainer hands such a stack over as banded CSR (one dense image per
+    bin, which never reads the pixels outside the bins) -- marked as dense (ltmi_masks_set_dense_origin), so the
+    results keep the dense arithmetic; against oracle.path.radial_fourier_analysis."""
+    from libertem_amd import hip
+    monkeypatch.setenv('LTMI_SPARSE_BAND', '1')
+    rng = np.random.default_rng(zlib_seed('dense-banded', where))
+    nav, sig = (4, 6), (128, 128)
+    stack = omasks.radial_mask_stack(128, 128, 64., 64., 4., 50., 3, 12)              # (39, 128, 128) complex64
+    counts = (stack != 0).sum(axis=0).reshape(-1)
+    stored, unstored = np.flatnonzero(counts > 0), np.flatnonzero(counts == 0)
+    data = _nf_scan(rng, nav, sig, stored, unstored, where)
+    ds = _device_ds(ctx, data, 2)
+    analysis = ctx.create_radial_fourier_analysis(dataset=ds, cx=64., cy=64., ri=4., ro=50., n_bins=3, max_order=12)
+    assert analysis.parameters['use_sparse'] is False
+    hip.KernelTimer.start()
+    got = ctx.run_udf(dataset=ds, udf=analysis.get_udf())['intensity'].data
+    labels = [k for _, _, k in hip.KernelTimer.stop()]
+    assert labels and all('banded' in k and k.endswith('+nf') for k in labels), labels
+    with np.errstate(invalid='ignore'):
+        ref = opath.radial_fourier_analysis(data, num_partitions=2, cx=64., cy=64., ri=4., ro=50., n_bins=3,
+                                            max_order=12)['intensity']
+    assert got.shape == ref.shape and got.dtype == ref.dtype
+    assert np.all(np.isnan(ref[0, 1].real)) and np.all(np.isnan(ref[0, 1].imag))      # the NaN frame: every mask
+    # NaN pixels: exactly the reference's NaNs; Inf pixels: the same entries are non-finite (whether Inf * (w + 0j)
+    # comes out as (Inf, NaN) or (NaN, NaN) is a property of the BLAS kernel behind `flat_tile @ masks`)
+    nan_frames = np.isnan(data).any(axis=(2, 3))
+    assert _same_nf(got[nan_frames], ref[nan_frames]), labels
+    assert np.array_equal(np.isfinite(got.real), np.isfinite(ref.real)) and \
+        np.array_equal(np.isfinite(got.imag), np.isfinite(ref.imag)), labels
+    ok = np.isfinite(ref)
+    assert np.allclose(got[ok], ref[ok], rtol=F32_TOL, atol=F32_TOL * np.abs(ref[ok]).max())
+    # shifted masks need the dense image: the banded handle is not taken for them (and results agree)
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    clean = np.where(np.isfinite(data), data, 1).astype(np.float32)
+    ds2 = _device_ds(ctx, clean, 2)
+    udf_s = ApplyMasksUDF(mask_factories=lambda: stack, mask_count=39, mask_dtype=np.complex64, shifts=(2, -3))
+    got_s = ctx.run_udf(dataset=ds2, udf=udf_s)['intensity'].data
+    ref_s = opath.apply_masks_shifted(clean, stack, np.broadcast_to(np.array([2, -3]), (24, 2)))
+    assert _close(got_s, ref_s.reshape(got_s.shape), F32_TOL)
