@@ -678,21 +678,23 @@ def test_mask_cache_reuse_and_eviction(ctx):
     data = rng.integers(0, 100, (2, 4, 32, 32)).astype(np.uint16)
     ds = ctx.load('memory', data=data, num_partitions=2, sig_dims=2)
     um.clear_mask_cache()
-    global _FACTORY_CALLS
-    _FACTORY_CALLS = 0
     m = rng.random((2, 32, 32)).astype(np.float32)
 
+    class Counter:
+        # (an attribute of the CLASS: nothing a fingerprint follows -- a counter in a module global, a captured
+        #  dict / list or an instance attribute counts as a parameter that changes with every evaluation and makes
+        #  the factory uncacheable, common/fingerprint.py)
+        calls = 0
+
     def factory():
-        # (a module-global int: not something a factory's output can be traced to -- a counter kept in a captured
-        #  dict or list would count as a parameter that changes with every evaluation, common/fingerprint.py)
-        global _FACTORY_CALLS
-        _FACTORY_CALLS += 1
+        Counter.calls += 1
         return m
     udf = um.ApplyMasksUDF(mask_factories=factory)
     a = ctx.run_udf(dataset=ds, udf=udf)['intensity'].data
-    n_first = _FACTORY_CALLS
+    n_first = Counter.calls
+    assert n_first >= 1
     b = ctx.run_udf(dataset=ds, udf=udf)['intensity'].data
-    assert _FACTORY_CALLS == n_first        # HBM image reused across tasks and runs
+    assert Counter.calls == n_first        # HBM image reused across tasks and runs
     assert np.array_equal(a, b)
     for i in range(6):                      # evict
         mi = rng.random((1, 32, 32)).astype(np.float32)
