@@ -149,7 +149,7 @@ __device__ __forceinline__ void load8_as(const T *row, int64_t p0, int64_t n_px,
     }
 }
 
-template <typename T, int MPT, bool CPLX, typename A = float>
+template <typename T, int MPT, bool CPLX, typename A = float, bool REDO = false>
 __global__ void __launch_bounds__(SP_NT)
 k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_px,
              const uint32_t *__restrict__ pix, const A *__restrict__ val,
@@ -157,7 +157,7 @@ k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
              const int *__restrict__ active, const int *__restrict__ active_off, int n_chunks,
              A *__restrict__ out, int64_t ld_out, int n_masks, int accumulate, int vec_ok,
              int ablate, const int32_t *__restrict__ rows, const int32_t *__restrict__ sel,
-             const int *__restrict__ n_sel) {
+             const int *__restrict__ n_sel, int n_pass, int n_split) {
     extern __shared__ __attribute__((aligned(16))) unsigned char slab_raw[];
     A *slab = (A *)slab_raw;                                          // [SP_P][SP_F]
     typedef A ax4 __attribute__((ext_vector_type(4)));
@@ -166,27 +166,31 @@ k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int pass = blockIdx.y;
-    const int64_t f0 = (int64_t)blockIdx.x * SP_F;
-    // the redo of frames with non-finite results (ltmi_guard.hip): `sel` lists the result rows to compute again,
-    // their number sits in device memory -- the launch covers every frame, workgroups beyond the list leave
-    if (n_sel) {
+    // REDO: the frames with non-finite results again (ltmi_guard.hip).  `sel` lists their result rows, the length
+    // of the list sits in device memory (no host synchronisation): a fixed number of workgroups walks the work items
+    // (16 listed frames, pass, a 1 / n_split share of the pass's pixel chunks) and adds its share to the rows, which
+    // k_zero_sel_rows cleared -- a handful of listed frames still spreads over the chip; none: every workgroup leaves
+    int64_t work = blockIdx.x, n_work = 1;
+    if (REDO) {
         n_frames = *n_sel;
-        if (f0 >= n_frames) return;
+        n_work = ((n_frames + SP_F - 1) / SP_F) * n_pass * n_split;
+        if (work >= n_work) return;
     }
-
-    // loader role: frame lf, pixel group lg (16 groups of 8 px per 128-px sweep step)
-    const int lf = tid & 15, lg = tid >> 4;
-    int64_t frame = f0 + lf;
-    if (frame > n_frames - 1) frame = n_frames - 1;
-    if (sel) frame = sel[frame];
-    if (rows) frame = rows[frame];                    // a region of interest: result row i = frame rows[i]
-    const T *row = tile + frame * ld;
-
     // padding entries of the image (value 0) point at pixel row SP_P, which is all zeros: a
     // non-finite pixel of a frame only reaches the masks that really contain it, like in the
     // reference's CSR loop (0 * NaN would be NaN)
     if (tid < SP_F) slab[SP_P * SP_F + tid] = (A)0;
+    // loader role: frame lf, pixel group lg (16 groups of 8 px per 128-px sweep step)
+    const int lf = tid & 15, lg = tid >> 4;
+  for (;;) {
+    const int split = REDO ? (int)(work % n_split) : 0;
+    const int pass = REDO ? (int)((work / n_split) % n_pass) : (int)blockIdx.y;
+    const int64_t f0 = (REDO ? work / ((int64_t)n_split * n_pass) : (int64_t)blockIdx.x) * SP_F;
+    int64_t frame = f0 + lf;
+    if (frame > n_frames - 1) frame = n_frames - 1;
+    if (REDO) frame = sel[frame];
+    if (rows) frame = rows[frame];                    // a region of interest: result row i = frame rows[i]
+    const T *row = tile + frame * ld;
 
     A acc[MPT][SP_F][NC];
 #pragma unroll
@@ -196,7 +200,13 @@ k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
 #pragma unroll
             for (int c = 0; c < NC; ++c) acc[i][f][c] = (A)0;
 
-    for (int ai = active_off[pass]; ai < active_off[pass + 1]; ++ai) {
+    int ai0 = active_off[pass], ai1 = active_off[pass + 1];
+    if (REDO) {
+        const int per = (ai1 - ai0 + n_split - 1) / n_split;
+        ai0 += split * per;
+        ai1 = ai0 + per < ai1 ? ai0 + per : ai1;
+    }
+    for (int ai = ai0; ai < ai1; ++ai) {
         const int ch = active[ai];
         const int *lens = row_len + (int64_t)ai * (MPT * 4);
         const int *offs = row_off + (int64_t)ai * (MPT * 4);
@@ -270,11 +280,30 @@ k_sell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
 #pragma unroll
         for (int f = 0; f < SP_F; ++f) {
             if (f0 + f >= n_frames) break;
-            const int64_t orow = sel ? (int64_t)sel[f0 + f] : f0 + f;
+            const int64_t orow = REDO ? (int64_t)sel[f0 + f] : f0 + f;
             A *o = out + orow * ld_out + (int64_t)k * NC;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) o[c] = accumulate ? o[c] + acc[i][f][c] : acc[i][f][c];
+            for (int c = 0; c < NC; ++c) {
+                if (REDO) unsafeAtomicAdd(&o[c], acc[i][f][c]);
+                else o[c] = accumulate ? o[c] + acc[i][f][c] : acc[i][f][c];
+            }
         }
+    }
+    if (!REDO) break;
+    work += gridDim.x;
+    if (work >= n_work) break;
+  }
+}
+
+// clears the result rows of the listed frames before k_sell_apply<REDO> adds their sums
+template <typename A>
+__global__ void __launch_bounds__(256)
+k_zero_sel_rows(A *__restrict__ out, int64_t ld_out, int n_cols, const int32_t *__restrict__ sel,
+                const int *__restrict__ n_sel) {
+    const int n = *n_sel;
+    for (int j = blockIdx.x; j < n; j += gridDim.x) {
+        A *o = out + (int64_t)sel[j] * ld_out;
+        for (int c = threadIdx.x; c < n_cols; c += 256) o[c] = (A)0;
     }
 }
 
@@ -308,6 +337,24 @@ int csr_destroy(ltmi_masks *m) {
     return LTMI_OK;
 }
 
+// the redo launch (ltmi_guard.hip): a fixed number of workgroups over the work items of the listed frames
+constexpr unsigned SELL_REDO_WGS = 1024;
+
+static int sell_redo_split(const CsrImage *c) {
+    // a share of at least 8 pixel chunks per work item, at most 64 shares
+    const int s = c->n_chunks / 8;
+    return s < 1 ? 1 : (s > 64 ? 64 : s);
+}
+
+template <typename KERN>
+static int sell_set_lds(KERN kern, int device, size_t lds, bool *set) {
+    if (!set[device & 15]) {
+        LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        set[device & 15] = true;
+    }
+    return LTMI_OK;
+}
+
 template <typename T>
 static int launch_sell(ltmi_masks *m, CsrImage *c, const T *tile, int64_t n_frames, int64_t ld,
                        float *out, int64_t ld_out_f, int accumulate, hipStream_t stream,
@@ -318,33 +365,57 @@ static int launch_sell(ltmi_masks *m, CsrImage *c, const T *tile, int64_t n_fram
     dim3 grid((unsigned)((n_frames + SP_F - 1) / SP_F), (unsigned)c->n_pass);
     // + one all-zero pixel row (index SP_P) for the padding entries of the image
     const size_t lds = (size_t)(SP_P + 1) * SP_F * sizeof(float);
+    const int nc = c->cplx ? 2 : 1;
+    if (sel) {
+        const int split = sell_redo_split(c);
+        hipLaunchKernelGGL(k_zero_sel_rows<float>, dim3(256), dim3(256), 0, stream, out, ld_out_f,
+                           (int)m->n_masks * nc, sel, n_sel);
+        LTMI_HIP(hipGetLastError());
+        int rc;
+        if (c->cplx) {
+            auto kern = k_sell_apply<T, 2, true, float, true>;
+            static bool set[16] = {false};
+            if ((rc = sell_set_lds(kern, m->device, lds, set)) != LTMI_OK) return rc;
+            hipLaunchKernelGGL(kern, dim3(SELL_REDO_WGS), dim3(SP_NT), lds, stream, tile, ld, n_frames, m->n_px,
+                               (const uint32_t *)c->pix, (const float *)c->val, (const int *)c->row_off,
+                               (const int *)c->row_len, (const int *)c->active, (const int *)c->active_off,
+                               c->n_chunks, out, ld_out_f, (int)m->n_masks, 0, vec_ok, 0, m->roi_rows, sel, n_sel,
+                               c->n_pass, split);
+        } else {
+            auto kern = k_sell_apply<T, 4, false, float, true>;
+            static bool set[16] = {false};
+            if ((rc = sell_set_lds(kern, m->device, lds, set)) != LTMI_OK) return rc;
+            hipLaunchKernelGGL(kern, dim3(SELL_REDO_WGS), dim3(SP_NT), lds, stream, tile, ld, n_frames, m->n_px,
+                               (const uint32_t *)c->pix, (const float *)c->val, (const int *)c->row_off,
+                               (const int *)c->row_len, (const int *)c->active, (const int *)c->active_off,
+                               c->n_chunks, out, ld_out_f, (int)m->n_masks, 0, vec_ok, 0, m->roi_rows, sel, n_sel,
+                               c->n_pass, split);
+        }
+        LTMI_HIP(hipGetLastError());
+        return LTMI_OK;                                   // (a redo keeps the name of the kernel it follows)
+    }
     if (c->cplx) {
         auto kern = k_sell_apply<T, 2, true>;
         static bool set[16] = {false};
-        if (!set[m->device & 15]) {
-            LTMI_HIP(hipFuncSetAttribute((const void *)kern,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            set[m->device & 15] = true;
-        }
+        const int rc = sell_set_lds(kern, m->device, lds, set);
+        if (rc != LTMI_OK) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(SP_NT), lds, stream, tile, ld, n_frames, m->n_px,
                            (const uint32_t *)c->pix, (const float *)c->val, (const int *)c->row_off,
                            (const int *)c->row_len, (const int *)c->active, (const int *)c->active_off,
-                           c->n_chunks, out, ld_out_f, (int)m->n_masks, accumulate, vec_ok, ablate, m->roi_rows, sel, n_sel);
+                           c->n_chunks, out, ld_out_f, (int)m->n_masks, accumulate, vec_ok, ablate, m->roi_rows,
+                           (const int32_t *)nullptr, (const int *)nullptr, c->n_pass, 1);
     } else {
         auto kern = k_sell_apply<T, 4, false>;
         static bool set[16] = {false};
-        if (!set[m->device & 15]) {
-            LTMI_HIP(hipFuncSetAttribute((const void *)kern,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            set[m->device & 15] = true;
-        }
+        const int rc = sell_set_lds(kern, m->device, lds, set);
+        if (rc != LTMI_OK) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(SP_NT), lds, stream, tile, ld, n_frames, m->n_px,
                            (const uint32_t *)c->pix, (const float *)c->val, (const int *)c->row_off,
                            (const int *)c->row_len, (const int *)c->active, (const int *)c->active_off,
-                           c->n_chunks, out, ld_out_f, (int)m->n_masks, accumulate, vec_ok, ablate, m->roi_rows, sel, n_sel);
+                           c->n_chunks, out, ld_out_f, (int)m->n_masks, accumulate, vec_ok, ablate, m->roi_rows,
+                           (const int32_t *)nullptr, (const int *)nullptr, c->n_pass, 1);
     }
     LTMI_HIP(hipGetLastError());
-    if (sel) return LTMI_OK;                              // (a redo keeps the name of the kernel it follows)
     m->last_exact = true;                                 // only stored entries were multiplied
     snprintf(m->last_kernel, sizeof(m->last_kernel), "k_sell_apply<%s,%s%s> grid=(%u,%u) rows=%zu",
              typeid(T).name(), c->cplx ? "c64" : "f32", m->roi_rows ? ",rows" : "", grid.x, grid.y,
@@ -360,19 +431,32 @@ static int launch_sell64(ltmi_masks *m, CsrImage *c, const T *tile, int64_t n_fr
     const int vec_ok = vector_loads_ok(tile, ld, sizeof(T)) ? 1 : 0;
     dim3 grid((unsigned)((n_frames + SP_F - 1) / SP_F), (unsigned)c->n_pass);
     const size_t lds = (size_t)(SP_P + 1) * SP_F * sizeof(double);
+    if (sel) {
+        hipLaunchKernelGGL(k_zero_sel_rows<double>, dim3(256), dim3(256), 0, stream, out, ld_out, (int)m->n_masks,
+                           sel, n_sel);
+        LTMI_HIP(hipGetLastError());
+        auto kern = k_sell_apply<T, 4, false, double, true>;
+        static bool set[16] = {false};
+        const int rc = sell_set_lds(kern, m->device, lds, set);
+        if (rc != LTMI_OK) return rc;
+        hipLaunchKernelGGL(kern, dim3(SELL_REDO_WGS), dim3(SP_NT), lds, stream, tile, ld, n_frames, m->n_px,
+                           (const uint32_t *)c->pix, (const double *)c->val64, (const int *)c->row_off,
+                           (const int *)c->row_len, (const int *)c->active, (const int *)c->active_off,
+                           c->n_chunks, out, ld_out, (int)m->n_masks, 0, vec_ok, 0, m->roi_rows, sel, n_sel,
+                           c->n_pass, sell_redo_split(c));
+        LTMI_HIP(hipGetLastError());
+        return LTMI_OK;
+    }
     auto kern = k_sell_apply<T, 4, false, double>;
     static bool set[16] = {false};
-    if (!set[m->device & 15]) {
-        LTMI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds));
-        set[m->device & 15] = true;
-    }
+    const int rc = sell_set_lds(kern, m->device, lds, set);
+    if (rc != LTMI_OK) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(SP_NT), lds, stream, tile, ld, n_frames, m->n_px,
                        (const uint32_t *)c->pix, (const double *)c->val64, (const int *)c->row_off,
                        (const int *)c->row_len, (const int *)c->active, (const int *)c->active_off,
-                       c->n_chunks, out, ld_out, (int)m->n_masks, accumulate, vec_ok, 0, m->roi_rows, sel, n_sel);
+                       c->n_chunks, out, ld_out, (int)m->n_masks, accumulate, vec_ok, 0, m->roi_rows,
+                       (const int32_t *)nullptr, (const int *)nullptr, c->n_pass, 1);
     LTMI_HIP(hipGetLastError());
-    if (sel) return LTMI_OK;
     m->last_exact = true;
     snprintf(m->last_kernel, sizeof(m->last_kernel), "k_sell_apply<%s,f64%s> grid=(%u,%u) rows=%zu",
              typeid(T).name(), m->roi_rows ? ",rows" : "", grid.x, grid.y, c->n_rows);
