@@ -244,6 +244,13 @@ int ltmi_add2d(int device, void *dest, int64_t ld_dest, const void *src, int64_t
 int ltmi_gather_rows(int device, const void *src, int64_t ld_src_bytes, const int64_t *idx,
                      int64_t n_rows, int64_t row_bytes, void *dest, void *stream);
 
+/* Host-to-host copy on `threads` threads (<= 0: a default from the core count, at most 16; capped at 64; at
+ * least 1 MiB per thread): the staging copy of host-resident frames into page-locked bounce buffers, which has to keep
+ * up with the H2D link.  Replaces, on the upload path of host datasets, the per-tile `astype` / slicing copies the
+ * reference makes while reading (src/libertem/io/dataset/memory.py:102-131) -- here the bytes travel unconverted and
+ * the dtype conversion happens in the kernels.  Plain memcpy semantics (no overlap); calls are serialised. */
+int ltmi_host_copy(void *dst, const void *src, int64_t bytes, int threads);
+
 /* Device address of page-locked host memory (hipHostMalloc / hipHostRegister): the place where the
  * kernels above may write small write-once result rows directly (`out` = this address), instead of
  * the reference's per-partition D2H export of device buffers (src/libertem/common/buffers.py:901-907). */

@@ -31,7 +31,7 @@ EXPORTS = (
     'ltmi_masks_create_dense', 'ltmi_masks_create_csr', 'ltmi_masks_destroy', 'ltmi_masks_kind', 'ltmi_masks_set_sig_shape',
     'ltmi_masks_set_sparse_origin', 'ltmi_masks_set_dense_origin', 'ltmi_masks_create_csr_gather',
     'ltmi_apply_masks', 'ltmi_apply_masks_rows', 'ltmi_apply_masks_shifted', 'ltmi_apply_masks_shifted_host', 'ltmi_sum_frames_workspace', 'ltmi_sum_frames', 'ltmi_sum_sig',
-    'ltmi_axpy', 'ltmi_add2d', 'ltmi_gather_rows', 'ltmi_host_device_pointer', 'ltmi_correct', 'ltmi_repair_pixels', 'ltmi_byteswap', 'ltmi_mib_decode', 'ltmi_com_fields', 'ltmi_fft_plan_create',
+    'ltmi_axpy', 'ltmi_add2d', 'ltmi_gather_rows', 'ltmi_host_device_pointer', 'ltmi_host_copy', 'ltmi_correct', 'ltmi_repair_pixels', 'ltmi_byteswap', 'ltmi_mib_decode', 'ltmi_com_fields', 'ltmi_fft_plan_create',
     'ltmi_fft_plan_destroy', 'ltmi_crystallinity', 'ltmi_crystallinity_corrected', 'ltmi_fft_plan_last_kernel',
     'ltmi_masks_set_tuning',
     'ltmi_masks_last_kernel', 'ltmi_comm_unique_id', 'ltmi_comm_create', 'ltmi_comm_destroy',
@@ -254,6 +254,7 @@ def lib():
         L.ltmi_add2d.argtypes = [i32, vp, i64, vp, i64, i32, i64, i64, i32, vp]
         L.ltmi_gather_rows.argtypes = [i32, vp, i64, vp, i64, i64, vp, vp]
         L.ltmi_host_device_pointer.argtypes = [i32, vp, c.POINTER(vp)]
+        L.ltmi_host_copy.argtypes = [vp, vp, i64, i32]
         L.ltmi_correct.argtypes = [i32, vp, i32, i64, i64, i64, vp, vp, vp, i32, i64, vp]
         L.ltmi_repair_pixels.argtypes = [i32, vp, i32, i64, i64, vp, vp, vp, i32, i32, vp]
         L.ltmi_byteswap.argtypes = [i32, vp, vp, i32, i64, vp]
@@ -571,6 +572,14 @@ def host_device_pointer(device, host_ptr):
     check(lib().ltmi_host_device_pointer(int(device), host_ptr, ctypes.byref(out)),
           'ltmi_host_device_pointer')
     return int(out.value)
+
+
+def host_copy(dst, src, threads=0):
+    """dst[...] = src for two C-contiguous host arrays of the same byte size, on several threads (the GIL is
+    released for the call): the staging copy into page-locked bounce buffers at more than the H2D link's rate"""
+    if dst.nbytes != src.nbytes or not dst.flags.c_contiguous or not src.flags.c_contiguous:
+        raise ValueError("host_copy: C-contiguous arrays of the same size")
+    check(lib().ltmi_host_copy(dst.ctypes.data, src.ctypes.data, int(src.nbytes), int(threads)), 'ltmi_host_copy')
 
 
 def map_or_upload(device, arr):

@@ -14,6 +14,7 @@ Tile delivery:
   chunk i (events order the two streams; no host synchronisation inside the loop).
 """
 import os
+import time
 
 import weakref
 import numpy as np
@@ -319,6 +320,7 @@ def pin_limit_bytes():
 
 
 _PAGE = 4096
+_STAGE_DEBUG = bool(os.environ.get('LTMI_STAGE_DEBUG'))
 
 
 def pin_min_bytes():
@@ -331,8 +333,37 @@ def pin_min_bytes():
     return int(float(env)) if env else 32 << 20
 
 
+def pin_user_arrays():
+    """LTMI_PIN_USER_ARRAYS=1: also page-lock plain user ndarrays of `pin_min_bytes()` and more in place
+    (round 5's default).  Off by default since round 6: an intermittent GPU memory access fault on copies out of
+    page-locked HEAP arrays was never traced to its cause (profiles/r05_host_fault.txt; the stand-alone reproducer
+    probes/hostreg_probe.cpp survives every heap / fork / re-registration pattern tried, profiles/r06_host_upload.txt),
+    so in-place page-locking is kept to memory whose mapping provably belongs to ONE object for its whole life --
+    `np.memmap` arrays (a file mapping of their own) and the buffers this package allocates page-locked itself (a
+    stream's scan buffer).  Everything else is staged through the two page-locked bounce buffers with a multi-threaded
+    copy (ltmi_host_copy) that outruns the host link."""
+    return os.environ.get('LTMI_PIN_USER_ARRAYS', '0') == '1'
+
+
+def _own_mapping(arr):
+    """True iff the bytes of `arr` lie in a mapping that belongs to one Python object for its whole life and shares
+    no page with anything else: an np.memmap (mmap.mmap underneath)"""
+    import mmap
+    root = arr
+    while True:
+        if isinstance(root, np.memmap) or isinstance(root, mmap.mmap):
+            return True
+        base = getattr(root, 'base', None)
+        if base is None:
+            return False
+        root = base
+
+
 def _register_host(torch, arr):
     """page-lock `arr` in place (or join an existing registration that covers it) -> key | None.
+
+    Only for memory with a mapping of its own (`_own_mapping`), or for any array of `pin_min_bytes()` and more with
+    LTMI_PIN_USER_ARRAYS=1.
 
     The runtime pins and maps PAGES: an array that shares its first or last page with another live registration
     (malloc places arrays of a few MB next to each other) is not registered -- unregistering the neighbour would take
@@ -352,7 +383,10 @@ def _register_host(torch, arr):
         q1 = -(-(p0 + ent[0]) // _PAGE) * _PAGE
         if a0 < q1 and q0 < a1:
             return None
-    if nbytes > pin_limit_bytes() or nbytes < pin_min_bytes():
+    own = _own_mapping(arr)
+    if not own and not pin_user_arrays():
+        return None
+    if nbytes > pin_limit_bytes() or (nbytes < pin_min_bytes() and not own):
         return None
     try:
         rc = int(torch.cuda.cudart().cudaHostRegister(ptr, nbytes, 0))
@@ -438,6 +472,13 @@ class _HipStager:
     through two pinned bounce buffers.
     """
 
+    #: staging copies of at least this many bytes run on several threads (ltmi_host_copy)
+    PARALLEL_COPY_MIN = 4 << 20
+    #: ... on this many threads (0: the library's default)
+    STAGE_THREADS = int(os.environ.get("LTMI_STAGE_THREADS", "0"))
+    #: ... in pieces of this size, each followed by its DMA
+    STAGE_PIECE_BYTES = int(os.environ.get("LTMI_STAGE_PIECE_MIB", "64")) << 20
+
     def __init__(self, device, chunk_frames, sig, dtype, host_array=None, swap_itemsize=0,
                  host_is_pinned=False):
         import torch
@@ -482,6 +523,7 @@ class _HipStager:
         src_np = host_chunk
         if src_np.dtype != self.np_storage_dtype:
             src_np = src_np.view(self.np_storage_dtype)        # bit reinterpretation only
+        pieces = None
         if self._in_registered(src_np):
             import warnings
             with warnings.catch_warnings():
@@ -492,14 +534,54 @@ class _HipStager:
             if self.pinned is None:
                 shape = (self.dev[0].shape[0],) + self.sig
                 self.pinned = [torch.empty(shape, dtype=self.tdt).pin_memory() for _ in range(2)]
+            t_dbg = time.perf_counter() if _STAGE_DEBUG else 0.
             if self.host_done[slot] is not None:
                 self.host_done[slot].synchronize()               # bounce buffer free again?
-            self.pinned[slot][:n].numpy()[...] = src_np
+            if _STAGE_DEBUG:
+                self._dbg_wait = time.perf_counter() - t_dbg
+            dst_np = self.pinned[slot][:n].numpy()
             src = self.pinned[slot][:n]
+            if src_np.flags.c_contiguous and src_np.nbytes >= self.PARALLEL_COPY_MIN:
+                # several threads (one thread's memcpy would cap the upload below the link), and in pieces:
+                # the DMA of piece i runs while piece i + 1 is staged, so only the first piece's copy is exposed
+                frame_bytes = max(1, src_np.nbytes // max(1, n))
+                # While an earlier chunk's DMA is still running, this chunk is staged whole behind it and travels as
+                # ONE copy (every copy costs the engine a start-up gap).  With the engine idle -- the first chunk of
+                # a run -- nothing hides the staging: pieces that grow from 1/8 of the full size, each followed by
+                # its DMA, so that only the first small copy is exposed.
+                busy = any(ev is not None and not ev.query() for ev in self.host_done)
+                if busy:
+                    pieces = [(0, n)]
+                else:
+                    pieces, a, size = [], 0, max(1 << 20, self.STAGE_PIECE_BYTES // 8)
+                    while a < n:
+                        b = min(n, a + max(1, size // frame_bytes))
+                        pieces.append((a, b))
+                        a, size = b, min(self.STAGE_PIECE_BYTES, size * 2)
+            else:
+                dst_np[...] = src_np
         with torch.cuda.stream(self.copy_stream):
             if self.consumed[slot] is not None:
                 self.copy_stream.wait_event(self.consumed[slot])  # kernels done with the buffer
-            self.dev[slot][:n].copy_(src, non_blocking=True)
+            if pieces is None:
+                self.dev[slot][:n].copy_(src, non_blocking=True)
+            else:
+                from libertem_amd import hip
+                t_dbg = time.perf_counter() if _STAGE_DEBUG else 0.
+                for a, b in pieces:
+                    t1 = time.perf_counter() if _STAGE_DEBUG else 0.
+                    hip.host_copy(dst_np[a:b], src_np[a:b], self.STAGE_THREADS)
+                    t2 = time.perf_counter() if _STAGE_DEBUG else 0.
+                    self.dev[slot][a:b].copy_(src[a:b], non_blocking=True)
+                    if _STAGE_DEBUG:
+                        import sys
+                        print(f"[stage]    piece {b - a} frames: copy {(t2 - t1) * 1e3:.3f} ms, enqueue "
+                              f"{(time.perf_counter() - t2) * 1e3:.3f} ms", file=sys.stderr)
+                if _STAGE_DEBUG:
+                    import sys
+                    now = time.perf_counter()
+                    print(f"[stage] t={now * 1e3 % 100000:9.2f} ms slot {slot} {n} frames: waited {self._dbg_wait * 1e3:.2f} ms "
+                          f"for the buffer, staged {len(pieces)} pieces in {(now - t_dbg) * 1e3:.2f} ms", file=sys.stderr)
             if self.swap_itemsize > 1:
                 # decode on the device, in place, behind the copy on the same stream
                 from libertem_amd import hip

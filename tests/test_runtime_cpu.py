@@ -1237,3 +1237,54 @@ def test_container_looks_for_banded_stacks():
     assert not _maybe_banded(narrow.to_px_by_masks(dtype=np.complex64), np.complex64)     # 32 columns: one dense pass
     scattered = sp.random(4096, 96, density=0.01, format='csr', dtype=np.float32, random_state=np.random.RandomState(3))
     assert not _maybe_banded(scattered, np.float32)
+
+
+def test_host_copy_on_several_threads():
+    """ltmi_host_copy (the staging copy into the upload path's page-locked bounce buffers): plain memcpy semantics for
+    every size / thread count, nothing written beyond the range"""
+    from libertem_amd import hip
+    rng = np.random.default_rng(3)
+    src = rng.integers(0, 255, (9 << 20) + 12345, dtype=np.uint8)
+    for nbytes in (0, 1, 4095, 1 << 20, (1 << 20) + 1, 5 << 20, src.size):
+        for threads in (0, 1, 2, 3, 7, 64, 1000):
+            dst = np.full(nbytes + 64, 7, dtype=np.uint8)
+            hip.host_copy(dst[:nbytes], src[:nbytes], threads)
+            assert np.array_equal(dst[:nbytes], src[:nbytes]) and np.all(dst[nbytes:] == 7), (nbytes, threads)
+    with pytest.raises(ValueError):
+        hip.host_copy(np.zeros(4, np.uint8), np.zeros(5, np.uint8))
+    with pytest.raises(ValueError):
+        hip.host_copy(np.zeros((4, 4), np.uint8)[:, ::2], np.zeros((4, 2), np.uint8))
+
+
+def test_in_place_page_locking_only_for_own_mappings(tmp_path, monkeypatch):
+    """Round 6: user ndarrays are no longer page-locked in place by default (the GPU memory access fault on copies out
+    of page-locked heap arrays was never root-caused, profiles/r05_host_fault.txt, r06_host_upload.txt) -- only memory
+    whose mapping belongs to one object for its whole life: np.memmap.  LTMI_PIN_USER_ARRAYS=1 restores round 5's rule."""
+    from libertem_amd.io.dataset import memory as M
+    mm = np.memmap(tmp_path / 'frames.bin', dtype=np.uint16, mode='w+', shape=(8, 16, 16))
+    assert M._own_mapping(mm) and M._own_mapping(mm[2:5]) and M._own_mapping(mm.reshape((8, 256))[1:])
+    assert M._own_mapping(np.asarray(mm))                    # an ndarray view whose base chain ends in the map
+    plain = np.zeros((40 << 20,), dtype=np.uint8)
+    assert not M._own_mapping(plain) and not M._own_mapping(plain[5:])
+    monkeypatch.delenv('LTMI_PIN_USER_ARRAYS', raising=False)
+    assert not M.pin_user_arrays()
+
+    asked = []
+
+    class FakeTorch:                                         # records registration attempts, refuses them
+        class cuda:
+            @staticmethod
+            def cudart():
+                class RT:
+                    @staticmethod
+                    def cudaHostRegister(ptr, nbytes, flags):
+                        asked.append(nbytes)
+                        return 1
+                return RT
+    assert M._register_host(FakeTorch, plain) is None and asked == []      # not even tried
+    monkeypatch.setenv('LTMI_PIN_USER_ARRAYS', '1')
+    assert M.pin_user_arrays()
+    assert M._register_host(FakeTorch, plain) is None and asked == [plain.nbytes]   # round 5's rule: >= 32 MiB is tried
+    assert M._register_host(FakeTorch, plain[:1 << 20]) is None and len(asked) == 1  # ... smaller arrays never were
+    monkeypatch.delenv('LTMI_PIN_USER_ARRAYS')
+    assert M._register_host(FakeTorch, np.asarray(mm)) is None and asked[-1] == mm.nbytes    # a map of its own: tried

@@ -2262,3 +2262,41 @@ def test_dense_banded_radial_fourier_non_finite_pixels_through_run_udf(ctx, monk
     got_s = ctx.run_udf(dataset=ds2, udf=udf_s)['intensity'].data
     ref_s = opath.apply_masks_shifted(clean, stack, np.broadcast_to(np.array([2, -3]), (24, 2)))
     assert _close(got_s, ref_s.reshape(got_s.shape), F32_TOL)
+
+
+@pytest.mark.parametrize('kind', ['plain', 'plain_pinned_by_env', 'memmap'])
+def test_host_upload_paths_staged_and_in_place(ctx, tmp_path, monkeypatch, kind):
+    """Host-resident frames: a plain ndarray is staged through the page-locked bounce buffers with the multi-threaded
+    copy (default since round 6), an np.memmap -- a mapping of its own -- is page-locked in place and DMA-ed from
+    directly, LTMI_PIN_USER_ARRAYS=1 restores in-place page-locking of large plain arrays.  Same results either way,
+    on a scan of several upload chunks (64 MiB of uint16 frames, forced 8 MiB chunks)."""
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd.io.dataset import base as dsbase
+    monkeypatch.setattr(dsbase.Negotiator, 'HIP_STAGING_CHUNK', 8 << 20)
+    if kind == 'plain_pinned_by_env':
+        monkeypatch.setenv('LTMI_PIN_USER_ARRAYS', '1')
+    else:
+        monkeypatch.delenv('LTMI_PIN_USER_ARRAYS', raising=False)
+    rng = np.random.default_rng(61)
+    shape = (16, 32, 256, 256)                                   # 64 MiB
+    if kind == 'memmap':
+        data = np.memmap(tmp_path / 'scan.bin', dtype=np.uint16, mode='w+', shape=shape)
+        data[...] = rng.integers(0, 4096, shape, dtype=np.uint16)
+    else:
+        data = rng.integers(0, 4096, shape, dtype=np.uint16)
+    masks = rng.random((5, 256, 256)).astype(np.float32)
+    ds = ctx.load('memory', data=data, sig_dims=2, num_partitions=2)
+    udf = ApplyMasksUDF(mask_factories=lambda: masks, use_sparse=False, mask_count=5, mask_dtype=np.float32)
+    got = ctx.run_udf(dataset=ds, udf=udf)['intensity'].data
+    stagers = list(ds.__dict__.get('_hip_stagers', {}).values())
+    assert len(stagers) == 1
+    in_place = stagers[0].registered is not None
+    assert in_place == (kind != 'plain'), (kind, in_place)
+    ref = np.asarray(data).reshape((512, -1)).astype(np.float64) @ masks.reshape((5, -1)).astype(np.float64).T
+    assert np.allclose(got.reshape((512, 5)), ref, rtol=F32_TOL, atol=0)
+    # the frames change in place between two runs (the reference reads the array afresh every run)
+    data[3, 7] = 0
+    got2 = ctx.run_udf(dataset=ds, udf=udf)['intensity'].data
+    ref[3 * 32 + 7] = 0
+    assert np.allclose(got2.reshape((512, 5)), ref, rtol=F32_TOL, atol=0)
+    ds.close_stagers()
