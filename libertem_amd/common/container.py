@@ -64,7 +64,7 @@ def _maybe_banded(csr_px_by_masks, result_dtype):
     stack with several bins)?  The library then builds a dense image per group over that group's pixels only
     (ltmi_masks_set_sig_shape, include/ltmi.h), which beats one dense pass per 32 complex masks over all pixels
     (4096 frames of 1024 x 1024 float32, 25 orders: 2 / 3 / 4 / 8 bins 7.4 / 11.1 / 15.2 / 27.5 ms dense,
-    3.9 / 4.1 / 4.3 / 4.8 ms banded; scripts/r5_run15.sh)."""
+    3.9 / 4.1 / 4.3 / 4.8 ms banded; C5S_BINS=2|3|4|8 C5S_FRAMES=4096 scripts/bench_second_runs.py c5s)."""
     n_px, n_masks = csr_px_by_masks.shape
     nc = 2 if np.dtype(result_dtype).kind == 'c' else 1
     if n_masks * nc <= 64 or np.dtype(result_dtype) not in (np.dtype(np.float32), np.dtype(np.complex64)):
