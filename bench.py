@@ -67,7 +67,9 @@ CONFIGS = {
                desc='ApplyMasksUDF 1024 sparse ring masks (CSR, nnz 432407), 256x256 scan x '
                     '256x256 uint16'),
     'c5': dict(scan=(128, 128), det=(1024, 1024), dtype='float32', n_masks=25, result_bytes=200,
-               flops=4 * 1048576 * 25, bound='mfma', kernel='k_dense', preheat=3,
+               flops=4 * 1048576 * 25, bound='hbm', kernel='k_dense', preheat=3,
+               # the row-mirror fold multiplies 513 of the 1024 rows against 64 padded columns
+               issued_flops=2 * 513 * 1024 * 64,
                desc='RadialFourierAnalysis defaults (25 dense complex64 masks), 128x128 scan x '
                     '1024x1024 float32'),
 }
@@ -77,9 +79,10 @@ CONFIGS = {
 # CPU baseline (the oracle = the checker; forked BEFORE the HIP runtime is initialised)
 # --------------------------------------------------------------------------------------------------
 def _cpu_worker(job):
-    """One CPU worker = one process with ONE BLAS thread (reference: executor/dask.py:251),
-    running the oracle's tiled loop over its own nav slice, `passes` times."""
-    cfg, n_frames, passes, seed = job
+    """One CPU worker = one process with ONE BLAS thread (reference: executor/dask.py:251), running the
+    oracle's restatement of the reference path for one config over its own frames, `passes` times."""
+    name, n_frames, passes, seed = job
+    cfg = CONFIGS[name]
     import torch
     torch.set_num_threads(1)
     try:
@@ -89,43 +92,103 @@ def _cpu_worker(job):
         pass
     from oracle import path as opath
     rng = np.random.default_rng(seed)
-    data = rng.integers(0, 4096, (1, n_frames) + tuple(cfg['det'])).astype(cfg['dtype'])
-    masks = np.random.default_rng(2).random((cfg['n_masks'],) + tuple(cfg['det'])).astype(
-        np.float32)
-    opath.apply_masks(data[:, :32], masks, num_partitions=1)      # warm up
+    det = tuple(cfg['det'])
+    if cfg['dtype'] == 'float32':
+        data = rng.random((1, n_frames) + det, dtype=np.float32)
+    else:
+        data = rng.integers(0, 4096, (1, n_frames) + det).astype(cfg['dtype'])
+    if name == 'c2':
+        masks = np.random.default_rng(2).random((cfg['n_masks'],) + det).astype(np.float32)
+        run = lambda d: opath.apply_masks(d, masks, num_partitions=1)                     # noqa: E731
+    elif name == 'c3':
+        run = lambda d: opath.com_analysis(d, num_partitions=1, cx=256, cy=256)           # noqa: E731
+    elif name == 'c4':
+        import scipy.sparse as sp
+        from oracle import masks as omasks
+        csr = sp.csr_matrix(omasks.radial_bins(128, 128, 256, 256, n_bins=1024, use_sparse=True, dtype=np.float32))
+        # the reference multiplies with a numba-compiled CSR loop (common/numba/__init__.py:153-184); numba is not
+        # installed here and the oracle's restatement of that loop is interpreted Python, so the TIMED product is
+        # SciPy's compiled CSR kernel on the same tiles -- the nearest compiled equivalent, same arithmetic
+        product = lambda tile, m: np.asarray((m.T @ tile.T).T)                            # noqa: E731
+        run = lambda d: opath.apply_masks_sparse(d, csr, num_partitions=1, product=product)   # noqa: E731
+    elif name == 'c5':
+        # the stack once per worker, like the reference's MaskContainer keeps it (common/container.py:260-314);
+        # timed: the product of radial_fourier_analysis (float32 whole-frame tiles @ complex64 stack)
+        from oracle import masks as omasks
+        p = opath.radial_fourier_parameters(det)
+        stack = omasks.radial_mask_stack(det[0], det[1], p['cx'], p['cy'], p['ri'], p['ro'], p['n_bins'], p['max_order'])
+        run = lambda d: opath.apply_masks(d, stack, num_partitions=1, mask_dtype=np.complex64)   # noqa: E731
+    else:
+        raise ValueError(name)
+    run(data[:, :min(n_frames, 32 if name in ('c2', 'c4') else 2)])      # warm up (mask stacks, BLAS)
     t0 = time.time()
     for _ in range(passes):
-        opath.apply_masks(data, masks, num_partitions=1)
+        run(data)
     return n_frames * passes, t0, time.time()
 
 
-def cpu_baseline(cfg, budget_s=12.0):
+#: frames per worker and pass, and what the sample line says, per config
+_CPU_SAMPLES = {
+    'c2': (512, "oracle.path.apply_masks: reference tile shape (32,32,256), astype(float32) + torch.mm per tile"),
+    'c3': (64, "oracle.path.com_analysis: 3 masks, tiles (32,16,512), torch.mm per tile + the CoM post-processing"),
+    'c4': (256, "oracle.path.apply_masks_sparse on (32,32,256) tiles with SciPy's compiled CSR product standing in "
+                "for the reference's numba loop (not installable here)"),
+    'c5': (4, "the product of oracle.path.radial_fourier_analysis: 25 dense complex64 masks of 1024x1024 built once "
+              "per worker, whole-frame tiles, float32 tile @ complex64 stack"),
+}
+
+
+def cpu_baseline(name='c2', budget_s=12.0, pool=None, cores=None):
     """
-    The reference's CPU path restated (oracle.path.apply_masks: (32,32,256) tiles,
-    astype(float32) + torch.mm per tile, += per sig slice), one single-threaded worker process per
+    The reference's CPU path restated (oracle/path.py), one single-threaded worker process per
     physical core, on a bounded sample.  MUST run before the parent touches the GPU (fork).
     """
     import multiprocessing as mp
+    if cores is None:
+        cores = physical_cores()
+    n_frames, what = _CPU_SAMPLES[name]
+    own = pool is None
+    if own:
+        pool = mp.get_context('fork').Pool(cores)
     try:
-        import psutil
-        cores = psutil.cpu_count(logical=False) or os.cpu_count() or 1
-    except Exception:
-        cores = os.cpu_count() or 1
-    n_frames = 512                                    # 64 MiB of uint16 per worker
-    ctx = mp.get_context('fork')
-    with ctx.Pool(cores) as pool:
         # calibrate with one pass, then size the run to ~budget_s
         # (worker start-up skew -- importing torch in 100+ processes -- must not count)
-        res = pool.map(_cpu_worker, [(cfg, n_frames, 1, 100 + i) for i in range(cores)])
+        res = pool.map(_cpu_worker, [(name, n_frames, 1, 100 + i) for i in range(cores)])
         t1 = float(np.median([r[2] - r[1] for r in res]))
         passes = int(max(1, min(400, budget_s / max(t1, 1e-3))))
-        res = pool.map(_cpu_worker, [(cfg, n_frames, passes, 100 + i) for i in range(cores)])
+        res = pool.map(_cpu_worker, [(name, n_frames, passes, 100 + i) for i in range(cores)])
+    finally:
+        if own:
+            pool.close()
+            pool.join()
     total = sum(r[0] for r in res)
     wall = max(r[2] for r in res) - min(r[1] for r in res)
     return {"value": total / wall, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{cores} single-threaded worker processes x {n_frames} frames x {passes} "
-                      f"passes of the C2 workload (oracle.path.apply_masks: reference tile shape "
-                      f"(32,32,256), astype(float32) + torch.mm per tile), {wall:.1f} s wall"}
+                      f"passes of the {name.upper()} workload ({what}), {wall:.1f} s wall"}
+
+
+def physical_cores():
+    try:
+        import psutil
+        return psutil.cpu_count(logical=False) or os.cpu_count() or 1
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def cpu_baselines(names, budget_s):
+    """{config: cpu_baseline dict} with ONE pool of worker processes for all of them (forked before HIP)"""
+    import multiprocessing as mp
+    cores = physical_cores()
+    out = {}
+    with mp.get_context('fork').Pool(cores) as pool:
+        for name in names:
+            try:
+                out[name] = cpu_baseline(name, budget_s[name], pool=pool, cores=cores)
+            except Exception as e:                    # the baseline must never sink the bench line
+                out[name] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port",
+                             "sample": f"failed: {e!r}"[:300]}
+    return out
 
 
 # --------------------------------------------------------------------------------------------------
@@ -357,6 +420,15 @@ def measure(wl, steps, warmup, barrier, hip, n_check=32, traffic_name=None):
     roof = {"bound": cfg['bound']}
     if cfg['bound'] == 'hbm':
         roof.update(achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS)
+        if cfg.get('issued_flops'):
+            # C5: SURVEY.md 8(d) prices it against the f32 matrix peak by its ALGORITHMIC flops; since the fold
+            # (round 5) the kernel issues half of them, the bytes are the larger fraction and the board's power
+            # cap is what binds (profiles/r05_fold.txt) -- the HBM fraction is the one to beat, the two matrix
+            # fractions ride beside it
+            issued = cfg['issued_flops'] * frames_per_launch / (avg_ms * 1e-3) / 1e12
+            roof.update(mfma_peak_TFLOPs=MFMA_F32_PEAK_TF, mfma_algorithmic_frac=tfs / MFMA_F32_PEAK_TF,
+                        mfma_issued_TFLOPs=issued, mfma_issued_frac=issued / MFMA_F32_PEAK_TF,
+                        binding_resource="board power cap (1400 W; profiles/r05_fold.txt)")
     else:
         roof.update(achieved=tfs, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
                     frac=tfs / MFMA_F32_PEAK_TF, hbm_GBps=gbs, hbm_frac=gbs / HBM_PEAK_GBS)
@@ -831,7 +903,16 @@ def main():
     ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true')
+    ap.add_argument('--result-via', default='auto', choices=['auto', 'shm', 'rccl'],
+                    help="delivery of the nav results across ranks: the node-shared page-locked host segment (shm) or "
+                         "the RCCL all-gather over xGMI (rccl); auto = the executor's default (shm on one node).  At "
+                         "--gpus 1 a value other than auto forces the multi-rank delivery path with a world of one "
+                         "(LTMI_FORCE_COLLECTIVES=1): the N = 1 anchor of that path")
     args = ap.parse_args()
+    if args.result_via != 'auto':
+        os.environ['LTMI_RESULT_VIA'] = args.result_via
+        if args.gpus == 1:
+            os.environ['LTMI_FORCE_COLLECTIVES'] = '1'
     cfg = CONFIGS[args.config]
 
     if args.gpus > 1 and 'RANK' not in os.environ:
@@ -847,14 +928,15 @@ def main():
     backend = os.environ.get('LTMI_BENCH_BACKEND', 'nccl')
     extras = not args.no_extras and os.environ.get('LTMI_BENCH_EXTRAS', '1') != '0' \
         and args.config == 'c2'
-    cpu_base = None
+    cpu_base, cpu_all = None, {}
     if world == 1 and not args.no_cpu_baseline:
-        # rank 0 at N=1 only, and BEFORE the HIP runtime is initialised (fork-safe)
-        try:
-            cpu_base = cpu_baseline(CONFIGS['c2'])
-        except Exception as e:                        # the baseline must never sink the bench line
-            cpu_base = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port",
-                        "sample": f"failed: {e!r}"}
+        # rank 0 at N=1 only, and BEFORE the HIP runtime is initialised (fork-safe): the measured config, and --
+        # with the extras -- every other config whose line rides along (the CPU path beside each)
+        names = [args.config if args.config in _CPU_SAMPLES else 'c2']
+        if extras:
+            names += [n for n in ('c3', 'c4', 'c5') if n not in names]
+        cpu_all = cpu_baselines(names, {n: (12.0 if n == names[0] else 6.0) for n in names})
+        cpu_base = cpu_all[names[0]]
     import torch
     import torch.distributed as dist
     if world != args.gpus:
@@ -964,26 +1046,25 @@ def main():
             "workload": cfg['desc'] + f", per GPU; {world} GPU(s), nav-sharded (weak)",
             "frames_per_gpu": n_frames, "frame_bytes": n_px * itemsize,
             "arithmetic": "f16x2-piece products, f32 accumulate, 22-bit weights",
-            "arithmetic_detail": "headline (kernels labelled ',f16'): uint16 pixels as two bytes x "
-                                 "float32 weights as two float16 pieces of the column-scaled value; "
-                                 "every product exact, summed in float32 by v_mfma_f32_16x16x32_f16; "
-                                 "weights below 2^-21 of their column maximum are added by a float32 "
-                                 "tail kernel ('+tail(n)'), stacks with more than 64 of them keep "
-                                 "v_mfma_f32_16x16x4_f32.  The key f32_instruction holds the same "
-                                 "steps on v_mfma_f32_16x16x4_f32 only (pixels converted to f32 "
-                                 "in-kernel).  f32 / complex64 masks and results",
+            "arithmetic_detail": "uint16 pixel bytes x two f16 pieces of each f32 weight, exact products, f32 sums "
+                                 "(v_mfma_f32_16x16x32_f16); f32_instr_* keys: same steps on v_mfma_f32_16x16x4_f32",
             "step": "Context.run_udf / Context.run (plan + kernels + delivery of the complete "
                     "result to every rank's host)",
             "parallelism": f"nav-shard x{world}; results via {result_via}",
-            "f32_instruction": ({k: f32_leg.get(k) for k in ("ms_per_step", "kernel_avg_launch_ms", "kernel_frac",
-                                                            "frac_from_profile", "whole_job_frac_of_hbm")}
-                                if isinstance(f32_leg, dict) else None),
         },
         "input_GBps_whole_job": value * n_px * itemsize / 1e9,
         "result_check_rel_err_vs_float64": m['check_rel_err'],
-        # (the strict float32-instruction leg rides INSIDE roofline and config too: a record that keeps only the
-        #  contract's keys still carries it)
-        "roofline": dict(m['roofline'], f32_instruction=f32_leg) if f32_leg else m['roofline'],
+        # (the strict float32-instruction leg as FLAT scalars inside roofline: a record that keeps only scalar values
+        #  of the contract's keys still carries it)
+        "roofline": dict(m['roofline'], **({
+            "f32_instr_kernel_frac": f32_leg.get('kernel_frac'),
+            "f32_instr_frac_from_profile": f32_leg.get('frac_from_profile'),
+            "f32_instr_frac_from_profile_pmc_passes": f32_leg.get('frac_from_profile_pmc_passes'),
+            "f32_instr_kernel_avg_launch_ms": f32_leg.get('kernel_avg_launch_ms'),
+            "f32_instr_ms_per_step": f32_leg.get('ms_per_step'),
+            "f32_instr_whole_job_frac_of_hbm": f32_leg.get('whole_job_frac_of_hbm'),
+            "f32_instr_rel_err": f32_leg.get('check_rel_err_vs_float64'),
+        } if isinstance(f32_leg, dict) and 'error' not in f32_leg else {})),
         "f32_instruction": f32_leg,
         "result_via": result_via,
         "value_path": {"shm": "every rank's kernels write its nav rows into a page-locked host segment all "
@@ -1118,6 +1199,7 @@ def main():
                         "note": "Context.run_udf(result_where='device'): the result stays in HBM as "
                                 "a HipArray, no D2H"}}
                 return {"workload": CONFIGS[name]['desc'], "steps": k, **extra_keys,
+                        "cpu_baseline": cpu_all.get(name),
                         "ms_per_step": mm['ms_per_step'], "value": fps, "unit": "frames/s",
                         "input_GBps_whole_job": fps * w.n_px * w.itemsize / 1e9,
                         "kernel_ms_per_step": mm['kernel_ms_per_step'],
@@ -1139,6 +1221,37 @@ def main():
         guarded('mib_decode', lambda: mib_decode(torch, hip))
         guarded('crystallinity', lambda: crystallinity(torch, hip))
         guarded('second_runs', lambda: second_runs(ctx, torch, hip))
+
+        # (d) the N = 1 anchors of BOTH multi-rank delivery paths: the same C2 steps with the collectives forced on a
+        #     world of one -- what the first real 2 / 4 / 8-GPU lines (shm by default, RCCL as extras.rccl_path) are to
+        #     be compared with, like for like.  Separate processes: the process group has to exist from the start.
+        def delivery_anchor():
+            import subprocess
+            out_a = {}
+            for via in ('shm', 'rccl'):
+                env = dict(os.environ, LTMI_BENCH_EXTRAS='0', MASTER_ADDR='127.0.0.1',
+                           MASTER_PORT=str(29600 + (os.getpid() + len(out_a)) % 300), RANK='0', WORLD_SIZE='1',
+                           LOCAL_RANK=str(local_rank))
+                env.pop('LTMI_RESULT_VIA', None)
+                cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', str(max(5, args.steps // 2)),
+                       '--warmup', '2', '--no-extras', '--no-cpu-baseline', '--result-via', via]
+                try:
+                    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                       timeout=240)
+                    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+                    if r.returncode != 0 or not line:
+                        out_a[via] = {"error": (r.stderr or r.stdout)[-300:]}
+                        continue
+                    j = json.loads(line[-1])
+                    out_a[via] = {"value": j['value'], "unit": j['unit'], "ms_per_step": j['ms_per_step'],
+                                  "steps": j['steps'], "result_via": j.get('result_via'),
+                                  "kernel_avg_launch_ms": j['roofline'].get('avg_launch_ms')}
+                except Exception as e:                    # noqa: BLE001
+                    out_a[via] = {"error": repr(e)[:300]}
+            out_a["note"] = ("world of one, collectives forced (bench.py --gpus 1 --result-via shm|rccl): the N = 1 point "
+                             "of each delivery path; no multi-GPU hardware figure exists yet")
+            return out_a
+        guarded('delivery_anchor_n1', delivery_anchor)
 
     watchdog.cancel()
     emit()

@@ -334,20 +334,40 @@ def pin_min_bytes():
 
 
 def pin_user_arrays():
-    """LTMI_PIN_USER_ARRAYS=1: also page-lock plain user ndarrays of `pin_min_bytes()` and more in place
-    (round 5's default).  Off by default since round 6: an intermittent GPU memory access fault on copies out of
+    """LTMI_PIN_USER_ARRAYS=1: also page-lock user ndarrays of `pin_min_bytes()` and more in place wherever they
+    live (round 5's rule).  Off by default since round 6: an intermittent GPU memory access fault on copies out of
     page-locked HEAP arrays was never traced to its cause (profiles/r05_host_fault.txt; the stand-alone reproducer
     probes/hostreg_probe.cpp survives every heap / fork / re-registration pattern tried, profiles/r06_host_upload.txt),
-    so in-place page-locking is kept to memory whose mapping provably belongs to ONE object for its whole life --
-    `np.memmap` arrays (a file mapping of their own) and the buffers this package allocates page-locked itself (a
-    stream's scan buffer).  Everything else is staged through the two page-locked bounce buffers with a multi-threaded
-    copy (ltmi_host_copy) that outruns the host link."""
+    so in-place page-locking is kept to memory whose mapping PROVABLY belongs to one object for its whole life
+    (`_own_mapping`).  Everything else is staged through the two page-locked bounce buffers with a multi-threaded
+    copy (ltmi_host_copy)."""
     return os.environ.get('LTMI_PIN_USER_ARRAYS', '0') == '1'
 
 
+def _glibc_mmapped_chunk(root):
+    """True iff `root` (an ndarray that owns its data) sits in a glibc malloc chunk that is a mapping of its own:
+    malloc serves large requests (>= its mmap threshold: 128 KiB ... 32 MiB, raised as such chunks are freed) with one
+    private anonymous mmap() per chunk and marks the chunk IS_MMAPPED (bit 1 of the size word in front of the user
+    pointer, which sits 16 bytes into the first page); free() unmaps it.  No other allocation ever shares its pages
+    and the addresses are not recycled while the array lives -- unlike chunks of the brk heap / arenas."""
+    import ctypes
+    import platform
+    if platform.libc_ver()[0] != 'glibc' or ctypes.sizeof(ctypes.c_size_t) != 8:
+        return False
+    if not (isinstance(root, np.ndarray) and root.flags.owndata and root.base is None and root.nbytes > 0):
+        return False
+    ptr = root.ctypes.data
+    if ptr % _PAGE != 16:
+        return False
+    size_word = ctypes.c_size_t.from_address(ptr - 8).value        # (same page as the data: readable)
+    chunk = size_word & ~7
+    return bool(size_word & 2) and chunk % _PAGE == 0 and chunk >= root.nbytes + 16
+
+
 def _own_mapping(arr):
-    """True iff the bytes of `arr` lie in a mapping that belongs to one Python object for its whole life and shares
-    no page with anything else: an np.memmap (mmap.mmap underneath)"""
+    """True iff the bytes of `arr` lie in a mapping that belongs to ONE object for its whole life and shares no page
+    with anything else: an np.memmap / mmap.mmap (shared memory segments included), or an ndarray that owns a glibc
+    malloc chunk with a mapping of its own (`_glibc_mmapped_chunk`: what NumPy gets for large arrays)"""
     import mmap
     root = arr
     while True:
@@ -355,15 +375,15 @@ def _own_mapping(arr):
             return True
         base = getattr(root, 'base', None)
         if base is None:
-            return False
+            return _glibc_mmapped_chunk(root)
         root = base
 
 
 def _register_host(torch, arr):
     """page-lock `arr` in place (or join an existing registration that covers it) -> key | None.
 
-    Only for memory with a mapping of its own (`_own_mapping`), or for any array of `pin_min_bytes()` and more with
-    LTMI_PIN_USER_ARRAYS=1.
+    Only for memory with a mapping of its own (`_own_mapping`: np.memmap, glibc-mmapped ndarrays), or for any array of
+    `pin_min_bytes()` and more with LTMI_PIN_USER_ARRAYS=1.
 
     The runtime pins and maps PAGES: an array that shares its first or last page with another live registration
     (malloc places arrays of a few MB next to each other) is not registered -- unregistering the neighbour would take

@@ -155,12 +155,14 @@ def rmatmul(left_dense, right_sparse):
 
 
 def apply_masks_sparse(data, masks_csr, sig_dims=2, num_partitions=1, tileshape=None,
-                       mask_dtype=None, fmt='csr'):
+                       mask_dtype=None, fmt='csr', product=None):
     """
     ApplyMasksUDF with use_sparse='scipy.sparse[.csr|.csc]' on the CPU path:
     `masks_csr` is the stack as scipy sparse (n_masks, px) (sig flattened C-order).
     Per tile the (px_in_slice, n_masks) CSR/CSC matrix is built as common/container.py:53-64
     does and multiplied with rmatmul (udf/masks.py:34-40, :68-69).
+    `product(flat_tile, matrix)`: another implementation of that product for TIMING (bench.py's cpu_baseline: the
+    reference's loop is numba-compiled, the restatement here interpreted); parity tests use rmatmul.
     """
     masks_csr = sp.csr_matrix(masks_csr)
     if mask_dtype is None:
@@ -186,7 +188,7 @@ def apply_masks_sparse(data, masks_csr, sig_dims=2, num_partitions=1, tileshape=
             sub.sort_indices()
             cache[key] = sub
         flat_tile = tile.reshape((tile.shape[0], -1))
-        out[f0:f1] += rmatmul(flat_tile, cache[key])
+        out[f0:f1] += (product or rmatmul)(flat_tile, cache[key])
     return out.reshape(nav + (n_masks,))
 
 

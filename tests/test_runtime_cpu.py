@@ -1257,18 +1257,24 @@ def test_host_copy_on_several_threads():
 
 
 def test_in_place_page_locking_only_for_own_mappings(tmp_path, monkeypatch):
-    """Round 6: user ndarrays are no longer page-locked in place by default (the GPU memory access fault on copies out
-    of page-locked heap arrays was never root-caused, profiles/r05_host_fault.txt, r06_host_upload.txt) -- only memory
-    whose mapping belongs to one object for its whole life: np.memmap.  LTMI_PIN_USER_ARRAYS=1 restores round 5's rule."""
+    """Round 6: host arrays are page-locked in place only where their mapping PROVABLY belongs to one object for its whole
+    life (the GPU memory access fault on copies out of page-locked heap arrays was never root-caused,
+    profiles/r05_host_fault.txt, r06_host_upload.txt): np.memmap / mmap objects, and ndarrays that own a glibc malloc
+    chunk with a mapping of its own (IS_MMAPPED).  Anything else -- heap chunks, foreign allocators -- is staged.
+    LTMI_PIN_USER_ARRAYS=1 restores round 5's rule (any array of 32 MiB and more)."""
+    import torch
     from libertem_amd.io.dataset import memory as M
     mm = np.memmap(tmp_path / 'frames.bin', dtype=np.uint16, mode='w+', shape=(8, 16, 16))
     assert M._own_mapping(mm) and M._own_mapping(mm[2:5]) and M._own_mapping(mm.reshape((8, 256))[1:])
     assert M._own_mapping(np.asarray(mm))                    # an ndarray view whose base chain ends in the map
-    plain = np.zeros((40 << 20,), dtype=np.uint8)
-    assert not M._own_mapping(plain) and not M._own_mapping(plain[5:])
+    big = np.zeros((40 << 20,), dtype=np.uint8)              # above malloc's largest mmap threshold: a chunk of its own
+    assert M._own_mapping(big) and M._own_mapping(big[5:]) and M._own_mapping(big.reshape((40, -1))[3:7])
+    heap = np.zeros(1000, dtype=np.uint8)                    # a heap chunk
+    assert not M._own_mapping(heap)
+    foreign = torch.zeros(40 << 20, dtype=torch.uint8).numpy()      # another allocator's memory: nothing to prove
+    assert not M._own_mapping(foreign) and not M._own_mapping(foreign[64:])
     monkeypatch.delenv('LTMI_PIN_USER_ARRAYS', raising=False)
     assert not M.pin_user_arrays()
-
     asked = []
 
     class FakeTorch:                                         # records registration attempts, refuses them
@@ -1281,10 +1287,12 @@ def test_in_place_page_locking_only_for_own_mappings(tmp_path, monkeypatch):
                         asked.append(nbytes)
                         return 1
                 return RT
-    assert M._register_host(FakeTorch, plain) is None and asked == []      # not even tried
+    assert M._register_host(FakeTorch, foreign) is None and asked == []      # not even tried
+    assert M._register_host(FakeTorch, heap) is None and asked == []
+    assert M._register_host(FakeTorch, big) is None and asked == [big.nbytes]            # a chunk of its own: tried
+    assert M._register_host(FakeTorch, np.asarray(mm)) is None and asked[-1] == mm.nbytes    # a map of its own: tried
     monkeypatch.setenv('LTMI_PIN_USER_ARRAYS', '1')
     assert M.pin_user_arrays()
-    assert M._register_host(FakeTorch, plain) is None and asked == [plain.nbytes]   # round 5's rule: >= 32 MiB is tried
-    assert M._register_host(FakeTorch, plain[:1 << 20]) is None and len(asked) == 1  # ... smaller arrays never were
-    monkeypatch.delenv('LTMI_PIN_USER_ARRAYS')
-    assert M._register_host(FakeTorch, np.asarray(mm)) is None and asked[-1] == mm.nbytes    # a map of its own: tried
+    n = len(asked)
+    assert M._register_host(FakeTorch, foreign) is None and asked[n:] == [foreign.nbytes]    # round 5's rule: >= 32 MiB
+    assert M._register_host(FakeTorch, foreign[:1 << 20]) is None and len(asked) == n + 1    # ... smaller: never

@@ -1906,6 +1906,9 @@ def test_bench_contract_with_eight_ranks_on_one_gpu():
     assert 'error' not in d['strong_c3'], d['strong_c3']
     assert d['strong_c3']['scaling'] == 'strong' and d['strong_c3']['frames_total'] == 16384
     assert d['f32_instruction'] and 'error' not in d['f32_instruction']
+    # the strict float32-instruction leg as flat scalars inside `roofline` (a record that keeps scalars only carries it)
+    assert 0 < d['roofline']['f32_instr_kernel_frac'] < 1 and d['roofline']['f32_instr_ms_per_step'] > 0
+    assert d['roofline']['f32_instr_rel_err'] < 1e-5 and len(d['config']['arithmetic_detail']) < 240
     assert not [f for f in os.listdir('/dev/shm') if f.startswith(f'ltmi_{os.getuid()}_')]
 
 
@@ -2264,16 +2267,17 @@ def test_dense_banded_radial_fourier_non_finite_pixels_through_run_udf(ctx, monk
     assert _close(got_s, ref_s.reshape(got_s.shape), F32_TOL)
 
 
-@pytest.mark.parametrize('kind', ['plain', 'plain_pinned_by_env', 'memmap'])
+@pytest.mark.parametrize('kind', ['ndarray', 'foreign', 'foreign_pinned_by_env', 'memmap'])
 def test_host_upload_paths_staged_and_in_place(ctx, tmp_path, monkeypatch, kind):
-    """Host-resident frames: a plain ndarray is staged through the page-locked bounce buffers with the multi-threaded
-    copy (default since round 6), an np.memmap -- a mapping of its own -- is page-locked in place and DMA-ed from
-    directly, LTMI_PIN_USER_ARRAYS=1 restores in-place page-locking of large plain arrays.  Same results either way,
-    on a scan of several upload chunks (64 MiB of uint16 frames, forced 8 MiB chunks)."""
+    """Host-resident frames: memory whose mapping provably belongs to one object -- an np.memmap, a large ndarray
+    (a glibc malloc chunk that is an mmap of its own) -- is page-locked in place and DMA-ed from directly; anything
+    else (here: an array over another allocator's memory) is staged through the page-locked bounce buffers with the
+    multi-threaded copy; LTMI_PIN_USER_ARRAYS=1 restores in-place page-locking of any large array.  Same results
+    either way, on a scan of several upload chunks (64 MiB of uint16 frames, forced 8 MiB chunks)."""
     from libertem_amd.udf.masks import ApplyMasksUDF
     from libertem_amd.io.dataset import base as dsbase
     monkeypatch.setattr(dsbase.Negotiator, 'HIP_STAGING_CHUNK', 8 << 20)
-    if kind == 'plain_pinned_by_env':
+    if kind == 'foreign_pinned_by_env':
         monkeypatch.setenv('LTMI_PIN_USER_ARRAYS', '1')
     else:
         monkeypatch.delenv('LTMI_PIN_USER_ARRAYS', raising=False)
@@ -2282,8 +2286,11 @@ def test_host_upload_paths_staged_and_in_place(ctx, tmp_path, monkeypatch, kind)
     if kind == 'memmap':
         data = np.memmap(tmp_path / 'scan.bin', dtype=np.uint16, mode='w+', shape=shape)
         data[...] = rng.integers(0, 4096, shape, dtype=np.uint16)
-    else:
+    elif kind == 'ndarray':
         data = rng.integers(0, 4096, shape, dtype=np.uint16)
+    else:
+        keep = torch.from_numpy(rng.integers(0, 4096, shape, dtype=np.uint16).view(np.int16)).clone()
+        data = keep.numpy().view(np.uint16)                      # torch's CPU allocator, not malloc's mmap chunks
     masks = rng.random((5, 256, 256)).astype(np.float32)
     ds = ctx.load('memory', data=data, sig_dims=2, num_partitions=2)
     udf = ApplyMasksUDF(mask_factories=lambda: masks, use_sparse=False, mask_count=5, mask_dtype=np.float32)
@@ -2291,7 +2298,7 @@ def test_host_upload_paths_staged_and_in_place(ctx, tmp_path, monkeypatch, kind)
     stagers = list(ds.__dict__.get('_hip_stagers', {}).values())
     assert len(stagers) == 1
     in_place = stagers[0].registered is not None
-    assert in_place == (kind != 'plain'), (kind, in_place)
+    assert in_place == (kind != 'foreign'), (kind, in_place)
     ref = np.asarray(data).reshape((512, -1)).astype(np.float64) @ masks.reshape((5, -1)).astype(np.float64).T
     assert np.allclose(got.reshape((512, 5)), ref, rtol=F32_TOL, atol=0)
     # the frames change in place between two runs (the reference reads the array afresh every run)
