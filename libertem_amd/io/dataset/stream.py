@@ -109,12 +109,15 @@ class StreamDataSet(MemoryDataSet):
                     return t.numpy().view(dt), True
             except Exception:                              # pragma: no cover  (no torch / no GPU)
                 pass
-        return np.zeros(shape, dtype=dt), False
+        # (the same contract in both cases: a frame's bytes mean something once it has ARRIVED -- commit() / the feeder;
+        #  readers wait for arrival, `frames_arrived` says how far that is; nothing zeroes what never came)
+        return np.empty(shape, dtype=dt), False
 
     # --- in-place feed ---------------------------------------------------------------------------
     @property
     def scan_buffer(self):
-        """(n_frames of this process,) + sig_shape array the producer of an in-place feed writes into"""
+        """(n_frames of this process,) + sig_shape array the producer of an in-place feed writes into.  Frames beyond
+        `frames_arrived` hold whatever the memory held (neither the page-locked nor the pageable buffer is zeroed)."""
         return self._buf
 
     def commit(self, n_frames_written):

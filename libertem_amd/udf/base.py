@@ -711,6 +711,20 @@ def _execution_plan(udfs, ds_backends, device_class, restrict=None):
                 f"(udf: {u.get_backends()}, restrict: {restrict}; this build runs {(HIP, NUMPY)})")
     if device_class == 'hip' and HIP in ds_backends and all(HIP in b for b in per_udf):
         return HIP
+    if device_class == 'hip' and any(HIP in b for b in per_udf) and all(NUMPY in b for b in per_udf) \
+            and NUMPY in ds_backends and not all(HIP in b for b in per_udf):
+        # a mix of UDFs with a device path and NumPy-only UDFs (`[SumUDF(), MyNumpyUDF()]`): the reference plans
+        # per UDF (udf/base.py:162-329); here one backend serves a run, and since EVERY UDF of this run offers
+        # NumPy the run happens on the host -- announced, not silent.  The native operators (ApplyMasksUDF, CoMUDF,
+        # CrystallinityUDF) do not list NumPy: a mix with those is refused below.
+        import warnings
+        hipable = [type(u).__name__ for u, b in zip(udfs, per_udf) if HIP in b]
+        others = [type(u).__name__ for u, b in zip(udfs, per_udf) if HIP not in b]
+        warnings.warn(
+            f"{', '.join(others)} run(s) on NumPy only: this run_udf executes on the host, including the NumPy "
+            f"branch of {', '.join(hipable)}; run the device-capable UDFs in a run of their own to keep them on "
+            "the MI355X", RuntimeWarning, stacklevel=3)
+        return NUMPY
     if device_class == 'hip' and any(HIP in b for b in per_udf):
         # a UDF with a device path never takes its NumPy branch on a GPU worker: no silent CPU fallback
         raise ValueError(

@@ -310,6 +310,13 @@ def test_gpu_worker_never_takes_numpy_branch():
     assert _execution_plan([SumUDF()], (NUMPY, HIP), 'cpu') == NUMPY
     with pytest.raises(ValueError):
         _execution_plan([SumUDF()], (NUMPY,), 'hip')
+    # round-5 advice: `[SumUDF(), MyNumpyOnlyUDF()]` on a GPU context raised; the reference plans per UDF and runs
+    # such mixes.  Every UDF of the run offers NumPy -> the run happens on the host, announced by a warning; a mix
+    # with a native operator that has no NumPy path (ApplyMasksUDF) is still refused
+    with pytest.warns(RuntimeWarning, match='NumpySumUDF'):
+        assert _execution_plan([SumUDF(), NumpySumUDF()], (NUMPY, HIP), 'hip') == NUMPY
+    with pytest.raises(ValueError):
+        _execution_plan([ApplyMasksUDF(mask_factories=[lambda: np.ones((4, 4))]), NumpySumUDF()], (NUMPY, HIP), 'hip')
 
 
 def test_apply_masks_udf_argument_errors():

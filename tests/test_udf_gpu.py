@@ -2307,3 +2307,36 @@ def test_host_upload_paths_staged_and_in_place(ctx, tmp_path, monkeypatch, kind)
     ref[3 * 32 + 7] = 0
     assert np.allclose(got2.reshape((512, 5)), ref, rtol=F32_TOL, atol=0)
     ds.close_stagers()
+
+
+def test_mixed_numpy_only_and_device_capable_udfs_run_on_the_host(ctx):
+    """Round-5 advice: `[SumUDF(), MyNumpyOnlyUDF()]` on a GPU context (the reference plans per UDF, udf/base.py:162-329,
+    and runs such mixes): every UDF of the run offers NumPy, so the run happens on the host -- with a RuntimeWarning that
+    names the UDFs; the device-capable UDF on its own still runs on the MI355X, and a native operator without a NumPy
+    path next to a NumPy-only UDF is refused."""
+    from libertem_amd.udf.base import UDF
+    from libertem_amd.udf.sum import SumUDF
+    from libertem_amd.udf.masks import ApplyMasksUDF
+
+    class NumpyMaxUDF(UDF):
+        def get_result_buffers(self):
+            return {'peak': self.buffer(kind='nav', dtype='float32')}
+
+        def get_backends(self):
+            return (self.BACKEND_NUMPY,)
+
+        def process_frame(self, frame):
+            self.results.peak[:] = np.max(frame)
+
+    rng = np.random.default_rng(73)
+    data = rng.random((4, 6, 16, 16)).astype(np.float32)
+    ds = ctx.load('memory', data=data, num_partitions=2, sig_dims=2)
+    with pytest.warns(RuntimeWarning, match='NumpyMaxUDF'):
+        s, m = ctx.run_udf(dataset=ds, udf=[SumUDF(), NumpyMaxUDF()])
+    assert np.allclose(s['intensity'].data, data.sum(axis=(0, 1)), rtol=1e-6)
+    assert np.array_equal(m['peak'].data, data.max(axis=(2, 3)))
+    alone = ctx.run_udf(dataset=ds, udf=SumUDF())
+    assert np.allclose(alone['intensity'].data, data.sum(axis=(0, 1)), rtol=1e-6)
+    with pytest.raises(ValueError, match='no common array backend'):
+        ctx.run_udf(dataset=ds, udf=[ApplyMasksUDF(mask_factories=lambda: np.ones((1, 16, 16), np.float32)),
+                                     NumpyMaxUDF()])
