@@ -201,7 +201,8 @@ int ltmi_apply_masks_shifted(ltmi_masks *m, const void *tile, int tile_dtype, in
  * mask image (built on the device, cached in the handle, <= 4 GiB) -- one launch per tile at
  * close to the unshifted rate (float32 / complex64 results); float64 / complex128 / exact-integer
  * results: the f64 matrix-core kernel per group of frames with the same shift (one call for a tile
- * with a constant shift, up to 256 distinct shifts per tile).  Falls back to the per-frame kernel
+ * with a constant shift; up to 256 distinct shifts per tile, up to 4096 while a shift is shared by 8 frames on
+ * average and the shifted images fit 4 GiB).  Falls back to the per-frame kernel
  * above (after uploading the shifts) for handles / tiles these paths do not take. */
 int ltmi_apply_masks_shifted_host(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frames,
                                   int64_t ld_tile, int sig_h, int sig_w, const int32_t *shifts_host,

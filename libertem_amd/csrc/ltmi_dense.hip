@@ -2586,9 +2586,13 @@ extern "C" int ltmi_apply_masks_rows(ltmi_masks *m, const void *tile, int tile_d
 // every distinct shift gets the image of the shifted stack (built on the device, cached) and the group
 // runs through dense64_apply with that image in place of the unshifted one: a whole tile directly when
 // it has ONE shift (a constant descan correction), otherwise group by group on gathered frames, the
-// result rows scattered back.  More than SHIFT64_MAX_GROUPS distinct shifts in a tile: not handled
-// (per-frame kernel).
-constexpr size_t SHIFT64_MAX_GROUPS = 256;
+// result rows scattered back.  Up to SHIFT64_SMALL_GROUPS distinct shifts whatever the tile; more -- a descan
+// correction over +- 8 pixels in both directions has 289 -- while a group averages SHIFT64_MIN_AVG frames or more
+// (three launches per group: below that the per-frame kernel's single launch wins) and the shifted images fit
+// SHIFT_CACHE_BYTES, up to SHIFT64_MAX_GROUPS.  Anything else: not handled (per-frame kernel).
+constexpr size_t SHIFT64_SMALL_GROUPS = 256;
+constexpr size_t SHIFT64_MAX_GROUPS = 4096;
+constexpr int64_t SHIFT64_MIN_AVG = 8;
 
 template <typename R>
 __global__ void k_scatter_rows(const R *__restrict__ src, int64_t n_rows, int n_cols,
@@ -2635,7 +2639,9 @@ static int shifted64(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_
         auto it = group_of.find(key);
         int g;
         if (it == group_of.end()) {
-            if (keys.size() == SHIFT64_MAX_GROUPS) return LTMI_OK;       // not handled
+            if (keys.size() == SHIFT64_MAX_GROUPS ||
+                (keys.size() >= SHIFT64_SMALL_GROUPS && (int64_t)(keys.size() + 1) * SHIFT64_MIN_AVG > n_frames))
+                return LTMI_OK;                                          // not handled
             g = (int)keys.size();
             group_of.emplace(key, g);
             keys.push_back(key);

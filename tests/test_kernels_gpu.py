@@ -1762,6 +1762,38 @@ def test_shifted_masks_float64_and_integer_results(hip, tile_dtype, mask_dtype, 
     h.close()
 
 
+def test_shifted_masks_float64_many_distinct_shifts(hip):
+    """More than 256 distinct shifts in a tile with float64 results (a descan correction over +- 10 pixels: 441): the
+    f64 matrix-core kernel group by group as long as a shift is shared by 8 frames on average (round 5: the
+    per-frame kernel took every such tile); a tile of all-different shifts still goes to the per-frame kernel."""
+    rng = np.random.default_rng(_seed('many shifts'))
+    n, sig, n_masks = 4000, (24, 32), 3
+    data = rng.integers(0, 3000, (n,) + sig).astype(np.uint16)
+    masks = (rng.random((n_masks,) + sig) - 0.25)
+    shifts = rng.integers(-10, 11, (n, 2)).astype(np.int32)
+    n_distinct = len({(int(a), int(b)) for a, b in shifts})
+    assert 400 < n_distinct <= 441
+    h = hip.MaskHandle.dense(0, masks.reshape((n_masks, -1)), np.float64)
+    t = _dev(np.ascontiguousarray(data.reshape((n, -1))))
+    ref, scale = _shift_ref(data, masks, shifts)
+    out = _dev(np.full((n, n_masks), 7, dtype=np.float64))
+    h.apply_shifted_host(t.data_ptr(), np.uint16, n, data[0].size, sig[0], sig[1], shifts, out.data_ptr(), n_masks, False)
+    torch.cuda.synchronize()
+    kern = h.last_kernel()
+    assert 'k_dense_lds64' in kern and f'shifted, {n_distinct} groups' in kern, kern
+    assert np.all(np.abs(out.cpu().numpy() - ref) <= 1e-12 * (scale + 1))
+    # 300 frames, every shift different: 3 launches per frame would lose to the per-frame kernel's single launch
+    few = 300
+    sh2 = np.stack([np.arange(few) % 23 - 11, np.arange(few) // 23 - 6], axis=1).astype(np.int32)
+    ref2, scale2 = _shift_ref(data[:few], masks, sh2)
+    out2 = _dev(np.full((few, n_masks), 7, dtype=np.float64))
+    h.apply_shifted_host(t.data_ptr(), np.uint16, few, data[0].size, sig[0], sig[1], sh2, out2.data_ptr(), n_masks, False)
+    torch.cuda.synchronize()
+    assert 'groups' not in h.last_kernel(), h.last_kernel()
+    assert np.all(np.abs(out2.cpu().numpy() - ref2) <= 1e-12 * (scale2 + 1))
+    h.close()
+
+
 @pytest.mark.parametrize('tile_dtype,n_frames', [('uint16', 700), ('float32', 300), ('uint8', 9000)])
 def test_row_lists_for_the_blocked_sparse_kernel(hip, tile_dtype, n_frames):
     """ltmi_apply_masks_rows on a sparse handle: the blocked image's frame DMA reads frame rows[i] for
