@@ -2340,3 +2340,67 @@ def test_mixed_numpy_only_and_device_capable_udfs_run_on_the_host(ctx):
     with pytest.raises(ValueError, match='no common array backend'):
         ctx.run_udf(dataset=ds, udf=[ApplyMasksUDF(mask_factories=lambda: np.ones((1, 16, 16), np.float32)),
                                      NumpyMaxUDF()])
+
+
+@pytest.mark.parametrize('route', ['dense_u16_signed', 'dense_f32_40_masks', 'radial_fourier_folded',
+                                   'radial_fourier_banded_sparse', 'sparse_rings_u16', 'sparse_rings_f32', 'com_raw_sums'])
+def test_run_udf_elementwise_error_bound(ctx, monkeypatch, route):
+    """Round-5 review: many run_udf tests compare norm-wise (`_close`: atol = 1e-5 x max |ref|), which hides an error in a
+    small entry next to a large one.  Here EVERY entry of the result of every kernel route is held to the bound that is
+    right for a float32 sum of signed terms, |got - ref64| <= 1e-5 x sum_p |x_p| |w_p| (the north star's 1e-5 relative to
+    what was added up) -- signed masks, signed frames, complex radial-Fourier stacks, sparse stacks -- through run_udf."""
+    import scipy.sparse as sp
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd import masks as M
+    monkeypatch.setenv('LTMI_SPARSE_BAND', '1')
+    rng = np.random.default_rng(zlib_seed('elementwise', route))
+    nav, sig = (4, 8), (128, 128)
+    n_px = sig[0] * sig[1]
+    u16 = rng.integers(0, 4096, nav + sig, dtype=np.uint16)
+    f32 = (rng.random(nav + sig) - 0.4).astype(np.float32)
+    stack = None
+    if route == 'dense_u16_signed':
+        data = u16
+        w = (rng.random((16,) + sig) - 0.5).astype(np.float32)
+        w[3] *= 1e-4                                             # a column five orders below its neighbours
+        udf = ApplyMasksUDF(mask_factories=lambda: w, use_sparse=False, mask_count=16, mask_dtype=np.float32)
+        stack = w.reshape((16, -1))
+    elif route == 'dense_f32_40_masks':
+        data = f32
+        w = (rng.random((40,) + sig) - 0.5).astype(np.float32)
+        udf = ApplyMasksUDF(mask_factories=lambda: w, use_sparse=False, mask_count=40, mask_dtype=np.float32)
+        stack = w.reshape((40, -1))
+    elif route in ('radial_fourier_folded', 'radial_fourier_banded_sparse'):
+        data = f32
+        ds0 = _device_ds(ctx, data, 2)
+        kw = dict(n_bins=1, max_order=12) if route == 'radial_fourier_folded' else \
+            dict(n_bins=3, max_order=12, use_sparse=True)
+        an = ctx.create_radial_fourier_analysis(dataset=ds0, **kw)
+        udf = an.get_udf()
+        st = an.get_mask_factories()()
+        stack = np.asarray(st.to_px_by_masks(dtype=np.complex64).todense()).T if hasattr(st, 'to_px_by_masks') \
+            else np.asarray(st).reshape((len(st), -1))
+    elif route in ('sparse_rings_u16', 'sparse_rings_f32'):
+        data = u16 if route.endswith('u16') else f32
+
+        def rings():
+            return M.radial_bins(64, 64, 128, 128, n_bins=200, use_sparse=True, dtype=np.float32)
+        udf = ApplyMasksUDF(mask_factories=rings, use_sparse='scipy.sparse', mask_count=200, mask_dtype=np.float32)
+        stack = np.asarray(sp.csr_matrix(omasks.radial_bins(64, 64, 128, 128, n_bins=200, use_sparse=True,
+                                                            dtype=np.float32)).todense())
+    else:
+        data = u16
+        an = ctx.create_com_analysis(dataset=_device_ds(ctx, data, 2), cx=70., cy=60., mask_radius=50.)
+        udf = an.get_udf()                                       # the three CoM sums: disk, y * disk, x * disk
+        facs = an.get_mask_factories()
+        stack = np.stack([np.asarray(f()) for f in facs]).astype(np.float32).reshape((3, -1))
+    ds = _device_ds(ctx, data, 2)
+    res = ctx.run_udf(dataset=ds, udf=udf)
+    got = res['intensity'].data
+    flat = data.reshape((-1, n_px)).astype(np.float64)
+    wide = stack.astype(np.complex128 if np.iscomplexobj(stack) else np.float64)
+    ref = (flat @ wide.T).reshape(got.shape)
+    bound = 1e-5 * (np.abs(flat) @ np.abs(wide).T).reshape(got.shape) + 1e-30
+    assert got.shape == ref.shape
+    err = np.abs(got - ref)
+    assert np.all(err <= bound), (route, float((err / bound).max()))
