@@ -51,6 +51,7 @@ constexpr int FD_TPART = 16 * 256;                   // 4 KiB: rows y (or y') of
 constexpr int FD_HALF = 2 * FD_WAVES * FD_TPART;     // 32 KiB: a half-stage = one tile of every wave, parts A and C
 constexpr int FD_RING = 4;                           // half-stages in LDS: one being multiplied, three on their way
 constexpr int FD_WG_ROWS = FD_WAVES * FD_ROWS;       // 128 frames per workgroup
+constexpr bool FOLD8_DEFAULT = false;                // k_dense_fold8 (two waves per SIMD) where it applies: see launch_fold_t
 __host__ __device__ constexpr int fold_slot_bytes(int ng) { return ng * GROUP * FD_KB * 4; }
 __host__ __device__ constexpr int fold_lds_bytes(int ng) { return FD_RING * FD_HALF + 2 * fold_slot_bytes(ng); }
 
@@ -373,6 +374,213 @@ k_dense_fold(const float *__restrict__ tile, int64_t ld, int64_t n_frames, int s
                 }
             }
         }
+}
+
+
+// ---- the same product with TWO waves per SIMD (round 6) -----------------------------------------------------------------
+// k_dense_fold keeps one wave per SIMD (4 waves x 2 frame tiles) and hides every wait by software pipelining inside the
+// wave; the matrix pipe still idles a quarter of the time without any frame copies (4.7 ms per 8192 frames of C5 where
+// the instructions alone take 3.5).  Here the two tiles of a wave become two waves on the same SIMD (8 waves x 1 tile,
+// the same 128 frames, ring, mask slots and LDS layout): while one waits for its fragments, its copies or the stage
+// barrier, the other issues.  Plain loop per wave and stage: fragments of both 32-pixel blocks, matrix instructions,
+// the copy of its half-stage two stages ahead into the ring slot just read, wait for the next half-stage and its
+// share of the next mask slot, barrier, its share of the mask slot after that.  Pays with a second read of a stage's
+// weights (each tile's wave reads them itself).  Stacks of 2 or 4 column groups (mask slot shares of whole KiB).
+template <int NGE, int NGO>
+__global__ void __launch_bounds__(8 * 64)
+k_dense_fold8(const float *__restrict__ tile, int64_t ld, int64_t n_frames, int spr /* stages per row */,
+              const int2 *__restrict__ fold_rows, const float *__restrict__ img, int n_stages,
+              float *__restrict__ out, int64_t ld_out, int n_cols, const int *__restrict__ colmap,
+              int accumulate, float *__restrict__ partials, int ksplit,
+              const unsigned char *__restrict__ zeros, const int32_t *__restrict__ rows) {
+    constexpr int NG = NGE + NGO;
+    constexpr int BSLOT = fold_slot_bytes(NG);
+    constexpr int W8 = 8;
+    constexpr int NBI = BSLOT / W8 / 1024;                // mask-slot DMA instructions per wave and stage
+    constexpr int NDH = 16 / 4;                           // DMA instructions per part of a half-stage
+    constexpr int NF = 2 * NDH;
+    static_assert(BSLOT % (W8 * 1024) == 0, "whole DMA instructions per wave");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int vw = wave >> 1, tl = wave & 1;              // the rows of "virtual wave" vw, frame tile tl
+    const int lane = tid & 63;
+    const int m = lane & 15, kg = lane >> 4;
+    const int ks = blockIdx.y;
+    const int per = (n_stages + ksplit - 1) / ksplit;
+    const int s_begin = ks * per;
+    const int s_end = min(n_stages, s_begin + per);
+
+    const int64_t f_wave = (int64_t)blockIdx.x * FD_WG_ROWS + vw * FD_ROWS + tl * 16;
+    auto frame_of = [&](int r) -> int64_t {
+        const int64_t f = f_wave + r;
+        return f < n_frames ? f : -1;
+    };
+    auto src_frame_of = [&](int r) -> int64_t {
+        int64_t f = frame_of(r);
+        if (rows) return f < 0 ? (int64_t)rows[0] : (int64_t)rows[f];
+        return f < 0 ? n_frames - 1 : f;
+    };
+    // ring slot q = 2 * (stage parity) + tl: the virtual wave's 16 rows of part A (4 KiB), then of part C
+    unsigned char *a_base = lds_raw + vw * (2 * FD_TPART);
+    unsigned char *b_base = lds_raw + FD_RING * FD_HALF;
+
+    f32x4 acc[NG], acc2[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = acc2[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (s_begin < s_end) {
+        const unsigned char *src[NDH];
+#pragma unroll
+        for (int t = 0; t < NDH; ++t) {
+            const int r = 4 * t + lane / 16;
+            const int piece = (lane & 15) ^ r;
+            src[t] = (const unsigned char *)(tile + src_frame_of(r) * ld) + piece * 16;
+        }
+        const unsigned char *zsrc = zeros + lane * 16;
+        const unsigned char *bsrc = (const unsigned char *)img + wave * (BSLOT / W8) + lane * 16;
+        int iss = s_begin, iss_fy = s_begin / spr, iss_xs = s_begin % spr;
+        auto issue_f = [&](auto Q) {                       // this wave's half-stage of stage `iss` (clamped) -> ring slot q
+            constexpr int q = decltype(Q)::value;
+            const int2 rr = fold_rows[iss_fy];
+            const int64_t x_px = (int64_t)iss_xs * FD_KB;
+            const int64_t off_a = ((int64_t)rr.x * spr * FD_KB + x_px) * 4;
+            const int64_t off_c = ((int64_t)rr.y * spr * FD_KB + x_px) * 4;
+            const bool pair = rr.y >= 0;
+            unsigned char *da = a_base + q * FD_HALF, *dc = da + FD_TPART;
+#pragma unroll
+            for (int t = 0; t < NDH; ++t)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[t] + off_a), (lds_ptr_t)(da + t * 1024), 16, 0, 2 /*nt*/);
+#pragma unroll
+            for (int t = 0; t < NDH; ++t) {
+                const unsigned char *p = pair ? src[t] + off_c : zsrc;
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)p, (lds_ptr_t)(dc + t * 1024), 16, 0, 2 /*nt*/);
+            }
+            if (iss + 1 < s_end) {
+                ++iss;
+                if (++iss_xs == spr) { iss_xs = 0; ++iss_fy; }
+            }
+        };
+        auto issue_b = [&](int s, int bslot) {
+            unsigned char *db = b_base + bslot * BSLOT + wave * (BSLOT / W8);
+            const unsigned char *sp = bsrc + (int64_t)min(s, s_end - 1) * BSLOT;
+#pragma unroll
+            for (int u = 0; u < NBI; ++u)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(sp + u * 1024), (lds_ptr_t)(db + u * 1024), 16, 0, 0);
+        };
+        const int a_lane = m * 256;
+        const int b_lane = m * FD_KB;
+        const int b_hi = (kg ^ ((4 - (m >> 2)) & 3)) * 4;
+        auto b_unit = [&](int blk, int h) { return (b_hi + ((blk * 2 + h) ^ (m & 3))) << 2; };
+        struct FragAC { f32x4 a[2], c[2]; };
+        struct FragB { f32x4 b[NG][2]; };
+        auto load_ac = [&](FragAC &fr, auto Q, int blk) {
+            constexpr int q = decltype(Q)::value;
+            const unsigned char *as = a_base + q * FD_HALF + a_lane;
+            const unsigned char *cs = as + FD_TPART;
+            const int u = blk * 4 + kg;
+            fr.a[0] = *(const f32x4 *)(as + (((2 * u) ^ m) << 4));
+            fr.a[1] = *(const f32x4 *)(as + (((2 * u + 1) ^ m) << 4));
+            fr.c[0] = *(const f32x4 *)(cs + (((2 * u) ^ m) << 4));
+            fr.c[1] = *(const f32x4 *)(cs + (((2 * u + 1) ^ m) << 4));
+        };
+        auto load_b = [&](FragB &fr, auto BS, int blk) {
+            constexpr int bslot = decltype(BS)::value;
+            const float *bs = (const float *)(b_base + bslot * BSLOT) + b_lane;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                fr.b[g][0] = *(const f32x4 *)(bs + g * (GROUP * FD_KB) + b_unit(blk, 0));
+                fr.b[g][1] = *(const f32x4 *)(bs + g * (GROUP * FD_KB) + b_unit(blk, 1));
+            }
+        };
+        auto mfma_block = [&](const FragAC &fr, const FragB &fb) {
+            float e[8], o[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 ev = fr.a[h] + fr.c[h];
+                const f32x4 ov = fr.a[h] - fr.c[h];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { e[h * 4 + i] = ev[i]; o[h * 4 + i] = ov[i]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(g < NGE ? e[j] : o[j], fb.b[g][j >> 2][j & 3], acc[g],
+                                                                  0, 0, 0);
+        };
+        int since_flush = 0;
+        auto step = [&](auto P, int s) {
+            constexpr int par = decltype(P)::value;
+            using Q = std::integral_constant<int, 2 * par>;               // + tl at run time: see below
+            FragAC f0, f1;
+            FragB w0, w1;
+            // (tl is a wave-uniform run-time value: both instantiations, one taken)
+            if (tl == 0) {
+                load_ac(f0, std::integral_constant<int, 2 * par>{}, 0);
+                load_ac(f1, std::integral_constant<int, 2 * par>{}, 1);
+            } else {
+                load_ac(f0, std::integral_constant<int, 2 * par + 1>{}, 0);
+                load_ac(f1, std::integral_constant<int, 2 * par + 1>{}, 1);
+            }
+            load_b(w0, P, 0);
+            load_b(w1, P, 1);
+            mfma_block(f0, w0);
+            mfma_block(f1, w1);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the half-stage and the slot are in registers
+            if (tl == 0) issue_f(std::integral_constant<int, 2 * par>{});  // stage s + 2 -> the ring slot just read
+            else issue_f(std::integral_constant<int, 2 * par + 1>{});
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NF) : "memory");      // F(s + 1), this wave's share of B(s + 1)
+            __builtin_amdgcn_s_barrier();                                  // everybody's share is there, slot `par` is free
+            issue_b(s + 2, par);
+            __builtin_amdgcn_sched_barrier(0);
+            (void)sizeof(Q);
+            if (++since_flush == 8) {                                      // second accumulation level every 512 folded pixels
+                since_flush = 0;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    acc2[g] += acc[g];
+                    acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        // prologue: F(s_begin), B(s_begin), F(s_begin + 1), B(s_begin + 1)
+        if (tl == 0) issue_f(std::integral_constant<int, 0>{}); else issue_f(std::integral_constant<int, 1>{});
+        issue_b(s_begin, 0);
+        if (tl == 0) issue_f(std::integral_constant<int, 2>{}); else issue_f(std::integral_constant<int, 3>{});
+        issue_b(s_begin + 1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NF + NBI) : "memory");
+        __builtin_amdgcn_s_barrier();
+        int s = s_begin;
+        for (; s + 2 <= s_end; s += 2) {
+            step(I0{}, s);
+            step(I1{}, s + 1);
+        }
+        if (s < s_end) step(I0{}, s);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // drain the clamped prefetches
+    }
+
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int col = colmap[g * GROUP + m];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t f = frame_of(kg * 4 + r);
+            if (f >= 0 && col >= 0) {
+                const float v = acc[g][r] + acc2[g][r];
+                if (ksplit == 1) {
+                    float *p = out + f * ld_out + col;
+                    *p = accumulate ? (*p + v) : v;
+                } else {
+                    partials[((int64_t)ks * n_frames + f) * n_cols + col] = v;
+                }
+            }
+        }
+    }
 }
 
 
@@ -844,13 +1052,35 @@ static int launch_fold_t(ltmi_masks *m, const float *tile, int64_t n_frames, int
         if (rc != LTMI_OK) return rc;
     }
     dim3 grid((unsigned)gx, (unsigned)ksplit);
-    hipLaunchKernelGGL(kern, grid, dim3(FD_WAVES * 64), LDS, stream, tile, ld, n_frames, f->sig_w / FD_KB,
-                       (const int2 *)f->rows, (const float *)f->img, f->n_stages, out, ld_out, m->n_cols,
-                       (const int *)f->colmap, accumulate, dense_partial_sums(m), ksplit,
-                       (const unsigned char *)f->zeros, m->roi_rows, (const int4 *)nullptr, (const int *)nullptr);
+    // two waves per SIMD (k_dense_fold8): stacks of 2 or 4 column groups; measured 3 - 5 % SLOWER than the pipelined
+    // one-wave-per-SIMD kernel on C5 (profiles/r06_fold.txt), kept as a measurement switch: LTMI_FOLD_WAVES=8
+    const char *fw = getenv("LTMI_FOLD_WAVES");               // (read per launch: tests and benches switch it)
+    const int want_waves = fw ? atoi(fw) : 0;
+    bool eight = false;
+    if constexpr ((NGE + NGO) % 2 == 0) eight = abl == 0 && (want_waves == 8 || (want_waves == 0 && FOLD8_DEFAULT));
+    if (eight) {
+        if constexpr ((NGE + NGO) % 2 == 0) {
+            auto k8 = k_dense_fold8<NGE, NGO>;
+            static bool attr8[16] = {false};
+            if (!attr8[m->device & 15]) {
+                LTMI_HIP(hipFuncSetAttribute((const void *)k8, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+                attr8[m->device & 15] = true;
+            }
+            hipLaunchKernelGGL(k8, grid, dim3(8 * 64), LDS, stream, tile, ld, n_frames, f->sig_w / FD_KB,
+                               (const int2 *)f->rows, (const float *)f->img, f->n_stages, out, ld_out, m->n_cols,
+                               (const int *)f->colmap, accumulate, dense_partial_sums(m), ksplit,
+                               (const unsigned char *)f->zeros, m->roi_rows);
+        }
+    } else {
+        hipLaunchKernelGGL(kern, grid, dim3(FD_WAVES * 64), LDS, stream, tile, ld, n_frames, f->sig_w / FD_KB,
+                           (const int2 *)f->rows, (const float *)f->img, f->n_stages, out, ld_out, m->n_cols,
+                           (const int *)f->colmap, accumulate, dense_partial_sums(m), ksplit,
+                           (const unsigned char *)f->zeros, m->roi_rows, (const int4 *)nullptr, (const int *)nullptr);
+    }
     LTMI_HIP(hipGetLastError());
-    snprintf(m->last_kernel, sizeof(m->last_kernel), "k_dense_fold<f,even=%d,odd=%d,rows %d+%d=%d%s> grid=(%u,%u)",
-             NGE, NGO, f->n_fold_rows, f->sig_h - f->n_fold_rows, f->c2, m->roi_rows ? ",rows" : "", grid.x, grid.y);
+    snprintf(m->last_kernel, sizeof(m->last_kernel), "k_dense_fold%s<f,even=%d,odd=%d,rows %d+%d=%d%s> grid=(%u,%u)",
+             eight ? "8" : "", NGE, NGO, f->n_fold_rows, f->sig_h - f->n_fold_rows, f->c2, m->roi_rows ? ",rows" : "",
+             grid.x, grid.y);
     if (ksplit > 1) {
         const int rc = dense_reduce_partials(m, ksplit, n_frames, out, ld_out, accumulate, stream);
         if (rc != LTMI_OK) return rc;

@@ -2352,6 +2352,28 @@ def test_row_mirror_fold_leaves_other_stacks_alone(hip):
     assert np.allclose(res, _ref64(d2, odd_w), rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize('sig,n_bins,max_order,n_frames,ksplit', [
+    ((128, 128), 1, 24, 300, 0), ((64, 256), 1, 24, 130, 3), ((96, 128), 2, 7, 70, 0)])
+def test_row_mirror_fold_two_waves_per_simd(hip, monkeypatch, sig, n_bins, max_order, n_frames, ksplit):
+    """k_dense_fold8 (LTMI_FOLD_WAVES=8, a measurement switch: two waves per SIMD, one frame tile each) gives the sums
+    of the shipped k_dense_fold: against float64 with the element-wise bound, ragged frame counts, a pixel split, `+=`."""
+    monkeypatch.setenv('LTMI_FOLD_WAVES', '8')
+    masks = _radial_stack(sig, n_bins, max_order)
+    rng = np.random.default_rng(_seed('fold8', sig, n_frames))
+    data = (rng.random((n_frames, sig[0] * sig[1])) - 0.2).astype(np.float32)
+    tuning = dict(mt=0, waves=30, ksplit=ksplit) if ksplit else None
+    res, kern = _fold_apply(hip, data, masks, sig, np.complex64, tuning=tuning)
+    assert 'k_dense_fold8<f' in kern, kern
+    ref = _ref64(data, masks)
+    scale = np.abs(data.astype(np.float64)) @ np.abs(masks).astype(np.float64).T
+    for part in (np.real, np.imag):
+        assert np.all(np.abs(part(res) - part(ref)) <= 1e-5 * scale + 1e-30)
+    monkeypatch.setenv('LTMI_FOLD_WAVES', '4')
+    res4, kern4 = _fold_apply(hip, data, masks, sig, np.complex64, tuning=tuning)
+    assert 'k_dense_fold<f' in kern4, kern4
+    assert np.all(np.abs(res - res4) <= 2e-6 * scale + 1e-30)
+
+
 def test_row_mirror_fold_wide_stack_in_column_blocks(hip):
     """More than 64 real columns: the stack is kept as blocks of <= 64 columns (ltmi_apply_masks walks them) and every
     block is folded on its own -- 3 bins x 25 orders = 75 complex masks = 64 + 64 + 22 real columns."""
