@@ -264,10 +264,11 @@ class ApplyMasksEngine:
                     return out
             tile = tile.materialize(stream=self.stream_ptr)
         if np.dtype(tile.dtype).kind == 'c' and self.result_dtype.kind == 'c' \
-                and self.masks.use_sparse is False and self._const is None \
-                and np.dtype(tile.dtype) == self.result_dtype:
+                and self._const is None and np.dtype(tile.dtype) == self.result_dtype:
             # complex frames: the frame as 2 n_px real pixels against the real expansion of the stack
-            # -- the matrix kernels instead of the generic one (container.get_handle_for_complex_frames)
+            # -- the matrix kernels instead of the generic one (container.get_handle_for_complex_frames).
+            # Sparse stacks too: the sparse kernels take real frames only, and the reference multiplies complex
+            # frames with them just the same (rmatmul on a complex `left_dense`, common/numba/__init__.py:153-184)
             handle, real = self.masks.get_handle_for_complex_frames(
                 self.meta.sig_slice, self.result_dtype, self.device)
             if handle.n_px != 2 * n_px:

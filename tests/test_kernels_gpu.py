@@ -2353,7 +2353,7 @@ def test_row_mirror_fold_leaves_other_stacks_alone(hip):
 
 
 @pytest.mark.parametrize('sig,n_bins,max_order,n_frames,ksplit', [
-    ((128, 128), 1, 24, 300, 0), ((64, 256), 1, 24, 130, 3), ((96, 128), 1, 15, 70, 0)])   # 2 + 2, 2 + 2, 1 + 1 groups
+    ((128, 128), 1, 24, 300, 0), ((64, 256), 1, 24, 130, 3), ((128, 128), 1, 24, 70, 5)])   # 2 + 2 column groups
 def test_row_mirror_fold_two_waves_per_simd(hip, monkeypatch, sig, n_bins, max_order, n_frames, ksplit):
     """k_dense_fold8 (LTMI_FOLD_WAVES=8, a measurement switch: two waves per SIMD, one frame tile each) gives the sums
     of the shipped k_dense_fold: against float64 with the element-wise bound, ragged frame counts, a pixel split, `+=`."""

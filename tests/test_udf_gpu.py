@@ -1352,6 +1352,16 @@ def test_complex_frames_run_on_the_matrix_kernels(ctx, dtype):
     assert got.dtype == np.dtype(dtype) and got.shape == (6, 9, 20)
     ref = np.tensordot(data.astype(np.complex128), masks.astype(np.complex128), axes=([2, 3], [1, 2]))
     assert _close(got, ref, F32_TOL if dtype == 'complex64' else 1e-12)
+    # sparse masks on complex frames (the reference: rmatmul with a complex left operand)
+    import scipy.sparse as sp
+    sparse_masks = [sp.csr_matrix(np.where(rng.random((24, 24)) < 0.1, rng.random((24, 24)), 0).astype(
+        np.float32 if dtype == 'complex64' else np.float64)) for _ in range(5)]
+    res = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=[lambda m=m: m for m in sparse_masks],
+                                                    use_sparse='scipy.sparse'))
+    dense5 = np.stack([m.toarray() for m in sparse_masks]).astype(np.float64)
+    ref = np.tensordot(data.astype(np.complex128), dense5, axes=([2, 3], [1, 2]))
+    assert res['intensity'].data.dtype == np.dtype(dtype)
+    assert _close(res['intensity'].data, ref, F32_TOL if dtype == 'complex64' else 1e-12)
     # real masks on complex frames
     mr = rng.random((3, 24, 24)).astype(np.float32 if dtype == 'complex64' else np.float64)
     res = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda: mr, use_sparse=False))
