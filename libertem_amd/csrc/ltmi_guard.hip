@@ -28,12 +28,16 @@
 
 namespace ltmi {
 
+bool csr_has_fast_image(const ltmi_masks *m);      // ltmi_sparse.hip
+
 struct NfGuard {
     int *ctl = nullptr;          // [0] = number of listed frames, [1 .. 1 + cap) = per-frame "listed" flags
     int32_t *list = nullptr;     // listed frames (result rows)
     int64_t cap = 0;
-    void *scratch = nullptr;     // accumulate != 0: the product lands here first
+    void *scratch = nullptr;     // accumulate != 0 / `out` in host memory: the product lands here first
     size_t scratch_bytes = 0;
+    const void *last_out = nullptr;   // (one-entry cache of out_is_host)
+    bool last_out_host = false;
 };
 
 struct DenseOrigin {
@@ -123,6 +127,32 @@ k_dense_fixup(const T *__restrict__ tile, int64_t ld, int64_t n_px, const int32_
     }
 }
 
+// result rows from the device scratch to their place (32-bit words: float32 / complex64 / float64 / complex128 rows)
+__global__ void __launch_bounds__(256)
+k_guard_copy_rows(const uint32_t *__restrict__ src, int64_t ld_src, uint32_t *__restrict__ dst, int64_t ld_dst,
+                  int64_t n_rows, int n_words) {
+    const int64_t total = n_rows * n_words;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / n_words;
+        const int c = (int)(i - r * n_words);
+        dst[r * ld_dst + c] = src[r * ld_src + c];
+    }
+}
+
+// Does `out` point into HOST memory?  Small write-once result rows are written by the kernels straight into the run's
+// page-locked host buffer (ltmi_host_device_pointer): the guard's second look at the rows would cross the host link and
+// the redo's atomic adds would depend on PCIe atomics -- such products are checked in the device scratch and copied.
+static bool out_is_host(NfGuard *g, const void *out) {
+    if (g->last_out == out) return g->last_out_host;
+    hipPointerAttribute_t at;
+    bool host = false;
+    if (hipPointerGetAttributes(&at, out) == hipSuccess) host = at.type == hipMemoryTypeHost;
+    else (void)hipGetLastError();
+    g->last_out = out;
+    g->last_out_host = host;
+    return host;
+}
+
 static bool guard_enabled() {
     static const bool on = [] {
         const char *e = getenv("LTMI_NONFINITE_GUARD");      // 0: the fast kernels' own patterns (timing ablation)
@@ -137,7 +167,7 @@ bool guard_wanted(const ltmi_masks *m, int tile_dtype) {
     if (m->sparse_origin || m->dense_origin) return true;
     // a CSR handle: the gather kernel of float64 results multiplies stored entries only; the float32 / complex64
     // routes (blocked, scatter, banded images) do not
-    return m->kind == 2 && !csr_is_f64(m);
+    return m->kind == 2 && !csr_is_f64(m) && csr_has_fast_image(m);
 }
 
 static void dense_origin_free(ltmi_masks *m) {
@@ -204,11 +234,17 @@ int guard_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frame
     if (n_frames >= (1ll << 31)) LTMI_FAIL(LTMI_E_SHAPE, "ltmi_apply_masks: too many frames in one call");
     const size_t elem = (size_t)dtype_size(m->result_dtype);
     NfGuard *g = nullptr;
-    int rc = guard_ensure(m, n_frames, accumulate ? (size_t)n_frames * m->n_masks * elem : 0, stream, &g);
+    int rc = guard_ensure(m, n_frames, 0, stream, &g);
     if (rc != LTMI_OK) return rc;
-    // `out += product`: a NaN already in `out` is not this product's; the product is checked on its own
-    void *target = accumulate ? g->scratch : out;
-    const int64_t ld_t = accumulate ? m->n_masks : ld_out;
+    // `out += product`: a NaN already in `out` is not this product's; the product is checked on its own.  `out` in host
+    // memory (directly written result rows): checked in the device scratch, then copied
+    const bool via_scratch = accumulate || out_is_host(g, out);
+    if (via_scratch) {
+        rc = guard_ensure(m, n_frames, (size_t)n_frames * m->n_masks * elem, stream, &g);
+        if (rc != LTMI_OK) return rc;
+    }
+    void *target = via_scratch ? g->scratch : out;
+    const int64_t ld_t = via_scratch ? m->n_masks : ld_out;
     rc = apply_masks_unguarded(m, tile, tile_dtype, n_frames, ld_tile, target, ld_t, 0, stream);
     if (rc != LTMI_OK) return rc;
     const bool exact = m->kind == 2 && m->last_exact && !m->dense_origin;   // the gather kernel ran: nothing to check
@@ -256,6 +292,14 @@ int guard_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frame
     if (accumulate)
         return ltmi_add2d(m->device, out, ld_out, g->scratch, m->n_masks, m->result_dtype, n_frames, m->n_masks, 0,
                           (void *)stream);
+    if (via_scratch) {
+        const int words = (int)(m->n_masks * elem / 4);
+        const int64_t total = n_frames * words;
+        const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_guard_copy_rows, dim3(blocks), dim3(256), 0, stream, (const uint32_t *)g->scratch,
+                           (int64_t)words, (uint32_t *)out, ld_out * (int64_t)elem / 4, n_frames, words);
+        LTMI_HIP(hipGetLastError());
+    }
     return LTMI_OK;
 }
 

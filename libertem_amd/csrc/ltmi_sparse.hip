@@ -653,6 +653,13 @@ int csr_redo(ltmi_masks *m, const void *tile, int tile_dtype, int64_t max_frames
     return rc;
 }
 
+// does the handle hold an image other than the gather kernel's (blocked, scatter, banded)?  Without one every product
+// runs on k_sell_apply, which multiplies stored entries only: nothing for ltmi_guard.hip to check
+bool csr_has_fast_image(const ltmi_masks *m) {
+    const CsrImage *c = m ? (const CsrImage *)m->csr : nullptr;
+    return c && (c->bell || c->scat || c->band || c->kept);
+}
+
 bool csr_is_f64(const ltmi_masks *m) {
     const CsrImage *c = m ? (const CsrImage *)m->csr : nullptr;
     return c && c->f64;
