@@ -150,6 +150,16 @@ class StreamDataSet(MemoryDataSet):
     def _copy_in(self, start, chunk, pool):
         """self._buf[start:start + n] = chunk (cast + copy), large chunks in parallel slices"""
         n = chunk.shape[0]
+        dst = self._buf[start:start + n]
+        if chunk.dtype == dst.dtype and chunk.flags.c_contiguous and dst.flags.c_contiguous \
+                and chunk.nbytes >= self.PARALLEL_COPY_BYTES:
+            # same dtype: the library's multi-threaded memcpy (ltmi_host_copy: ~200 GB/s on 16 threads, GIL released)
+            try:
+                from libertem_amd import hip
+                hip.host_copy(dst, chunk)
+                return
+            except Exception:                               # noqa: BLE001  (library not built: NumPy copies below)
+                pass
         if pool is None or chunk.nbytes < self.PARALLEL_COPY_BYTES or n < 2 * self.COPY_THREADS:
             self._buf[start:start + n] = chunk
             return
