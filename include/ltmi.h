@@ -146,6 +146,11 @@ int ltmi_masks_create_csr_gather(int device, const int64_t *indptr, const int64_
                                  const void *data, int result_dtype, int64_t n_px, int64_t n_masks,
                                  ltmi_masks **out);
 int ltmi_masks_set_dense_origin(ltmi_masks *m, const int64_t *indptr, const int64_t *indices);
+/* How many frames of the LAST product on this handle were listed for the redo / fix-up above (frames with a non-finite
+ * result, or -- dense stack held as CSR -- a non-finite pixel no mask stores).  Diagnostic; SYNCHRONISES `stream` (the
+ * stream of that product).  0 when the product was not checked (integer frames, a handle that is not guarded, the
+ * gather kernel).  The reference has no counterpart: its NaNs simply appear in the result. */
+int ltmi_masks_nonfinite_frames(ltmi_masks *m, void *stream, int64_t *count);
 
 int ltmi_masks_destroy(ltmi_masks *m);
 /* 0 = dense with float32 / complex64 results (f32 matrix cores), 1 = dense with any other result

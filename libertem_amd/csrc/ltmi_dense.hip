@@ -1366,6 +1366,7 @@ k_dense_shifted(const TIn *__restrict__ tile, int64_t ld, int sig_h, int sig_w,
 using namespace ltmi;
 
 namespace ltmi {
+void guard_note_unchecked(ltmi_masks *m);   // ltmi_guard.hip
 int csr_destroy(ltmi_masks *m);   // ltmi_sparse.hip
 int csr_set_sig_shape(ltmi_masks *m, int sig_h, int sig_w);
 bool csr_has_band(const ltmi_masks *m);
@@ -2469,6 +2470,7 @@ extern "C" int ltmi_apply_masks(ltmi_masks *m, const void *tile, int tile_dtype,
     // the reference's arithmetic (ltmi_guard.hip)
     if (ltmi::guard_wanted(m, tile_dtype))
         return ltmi::guard_apply(m, tile, tile_dtype, n_frames, ld_tile, out, ld_out, accumulate, stream);
+    if (m->guard) ltmi::guard_note_unchecked(m);
     return ltmi::apply_masks_unguarded(m, tile, tile_dtype, n_frames, ld_tile, out, ld_out, accumulate, stream);
 }
 

@@ -38,6 +38,7 @@ struct NfGuard {
     size_t scratch_bytes = 0;
     const void *last_out = nullptr;   // (one-entry cache of out_is_host)
     bool last_out_host = false;
+    bool last_checked = false;        // the last guarded product went through k_flag_rows (ltmi_masks_nonfinite_frames)
 };
 
 struct DenseOrigin {
@@ -180,6 +181,11 @@ static void dense_origin_free(ltmi_masks *m) {
     }
 }
 
+// a product that bypasses the guard (integer frames, guard switched off): ltmi_masks_nonfinite_frames reports 0 for it
+void guard_note_unchecked(ltmi_masks *m) {
+    if (NfGuard *g = (NfGuard *)m->guard) g->last_checked = false;
+}
+
 void guard_destroy(ltmi_masks *m) {
     if (m->sparse_origin) {
         (void)ltmi_masks_destroy(m->sparse_origin);
@@ -248,6 +254,7 @@ int guard_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frame
     rc = apply_masks_unguarded(m, tile, tile_dtype, n_frames, ld_tile, target, ld_t, 0, stream);
     if (rc != LTMI_OK) return rc;
     const bool exact = m->kind == 2 && m->last_exact && !m->dense_origin;   // the gather kernel ran: nothing to check
+    g->last_checked = !exact;
     if (!exact) {
         const bool f64 = m->result_dtype == LTMI_F64 || m->result_dtype == LTMI_C128;
         const bool cplx = m->result_dtype == LTMI_C64 || m->result_dtype == LTMI_C128;
@@ -306,6 +313,19 @@ int guard_apply(ltmi_masks *m, const void *tile, int tile_dtype, int64_t n_frame
 }  // namespace ltmi
 
 using namespace ltmi;
+
+extern "C" int ltmi_masks_nonfinite_frames(ltmi_masks *m, void *stream_, int64_t *count) {
+    if (!m || !count) LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_nonfinite_frames: null argument");
+    *count = 0;
+    const NfGuard *g = (const NfGuard *)m->guard;
+    if (!g || !g->ctl || !g->last_checked) return LTMI_OK;        // the last product was not checked: nothing listed
+    LTMI_HIP(hipSetDevice(m->device));
+    int n = 0;
+    LTMI_HIP(hipMemcpyAsync(&n, g->ctl, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream_));
+    LTMI_HIP(hipStreamSynchronize((hipStream_t)stream_));
+    *count = n;
+    return LTMI_OK;
+}
 
 extern "C" int ltmi_masks_set_sparse_origin(ltmi_masks *m, ltmi_masks *gather) {
     if (!m || !gather) LTMI_FAIL(LTMI_E_INVALID, "ltmi_masks_set_sparse_origin: null handle");

@@ -30,6 +30,7 @@ EXPORTS = (
     'ltmi_version', 'ltmi_last_error', 'ltmi_device_count', 'ltmi_device_info',
     'ltmi_masks_create_dense', 'ltmi_masks_create_csr', 'ltmi_masks_destroy', 'ltmi_masks_kind', 'ltmi_masks_set_sig_shape',
     'ltmi_masks_set_sparse_origin', 'ltmi_masks_set_dense_origin', 'ltmi_masks_create_csr_gather',
+    'ltmi_masks_nonfinite_frames',
     'ltmi_apply_masks', 'ltmi_apply_masks_rows', 'ltmi_apply_masks_shifted', 'ltmi_apply_masks_shifted_host', 'ltmi_sum_frames_workspace', 'ltmi_sum_frames', 'ltmi_sum_sig',
     'ltmi_axpy', 'ltmi_add2d', 'ltmi_gather_rows', 'ltmi_host_device_pointer', 'ltmi_host_copy', 'ltmi_correct', 'ltmi_repair_pixels', 'ltmi_byteswap', 'ltmi_mib_decode', 'ltmi_com_fields', 'ltmi_fft_plan_create',
     'ltmi_fft_plan_destroy', 'ltmi_crystallinity', 'ltmi_crystallinity_corrected', 'ltmi_fft_plan_last_kernel',
@@ -243,6 +244,7 @@ def lib():
         L.ltmi_masks_set_sig_shape.argtypes = [vp, i32, i32]
         L.ltmi_masks_set_sparse_origin.argtypes = [vp, vp]
         L.ltmi_masks_set_dense_origin.argtypes = [vp, vp, vp]
+        L.ltmi_masks_nonfinite_frames.argtypes = [vp, vp, c.POINTER(i64)]
         L.ltmi_apply_masks.argtypes = [vp, vp, i32, i64, i64, vp, i64, i32, vp]
         L.ltmi_apply_masks_shifted.argtypes = [vp, vp, i32, i64, i64, i32, i32, vp, vp, i64, i32, vp]
         L.ltmi_apply_masks_shifted_host.argtypes = [vp, vp, i32, i64, i64, i32, i32, vp, vp, i64, i32, vp]
@@ -435,6 +437,13 @@ class MaskHandle:
         check(lib().ltmi_masks_set_dense_origin(
             self._ptr, indptr.ctypes.data_as(ctypes.c_void_p), indices.ctypes.data_as(ctypes.c_void_p)),
             'ltmi_masks_set_dense_origin')
+
+    def nonfinite_frames(self, stream=None):
+        """frames of the last product that were listed for the non-finite redo / fix-up (synchronises the stream)"""
+        n = ctypes.c_int64(0)
+        check(lib().ltmi_masks_nonfinite_frames(self._ptr, stream if isinstance(stream, int) else _stream_ptr(stream),
+                                                ctypes.byref(n)), 'ltmi_masks_nonfinite_frames')
+        return int(n.value)
 
     def set_tuning(self, mt=0, waves=0, ksplit=0):
         check(lib().ltmi_masks_set_tuning(self._ptr, mt, waves, ksplit), 'ltmi_masks_set_tuning')
