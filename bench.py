@@ -13,9 +13,13 @@ the whole hot path, not just the kernel.  Weak scaling: every rank holds its own
 (65536 frames, 8 GiB); the nav grid of the job is N x that.
 
 Rank 0 prints ONE JSON line.  `value` / `roofline` / `cpu_baseline` are the C2 figures the contract
-asks for.  The same line carries, as extra keys (all configs, both timing modes):
+asks for; `roofline` also carries the strict float32-instruction leg of C2 as flat scalars (`f32_instr_*`).
+The same line carries, as extra keys (all configs, both timing modes):
 
-  N = 1:  "configs": {"c3": ..., "c4": ..., "c5": ...}   whole job + dominant kernel + roofline each
+  N = 1:  "configs": {"c3": ..., "c4": ..., "c5": ...}   whole job + dominant kernel + roofline + cpu_baseline each
+          (C5's roofline is priced against HBM; `mfma_algorithmic_frac` / `mfma_issued_frac` ride beside it)
+          "delivery_anchor_n1": the C2 steps with the multi-rank delivery forced on a world of one (shm and rccl),
+                                the like-for-like N = 1 points of the first real multi-GPU lines
           "host_streamed": {"c2" .. "c5"}: frames in host memory, double-buffered hipMemcpyAsync, vs
                            the H2D peak measured in the same run
           "crystallinity": row f3, k_cryst_fused and the hipFFT route of the same call;
@@ -28,7 +32,8 @@ asks for.  The same line carries, as extra keys (all configs, both
                        over the N ranks (strong scaling).
 
 `--config c3|c4|c5` makes that config the measured one (`value` then is ITS frames/s; used by
-scripts/profile_round.sh for per-config rocprofv3 passes); `--no-extras` skips the extra keys.
+scripts/profile_round.sh for per-config rocprofv3 passes); `--no-extras` skips the extra keys;
+`--result-via shm|rccl` picks the delivery of the nav results across ranks (default: the executor's choice).
 
 `roofline.achieved` = algorithmic bytes (or flops) per launch / average launch duration from HIP
 events on the kernel's own stream inside the timed region; `roofline.traffic` = HBM bytes per launch

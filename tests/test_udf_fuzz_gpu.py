@@ -25,7 +25,7 @@ def _close(a, b, tol=1e-5):
     return np.allclose(a, b, rtol=tol, atol=tol * scale)
 
 
-@pytest.mark.parametrize('seed', range(40))
+@pytest.mark.parametrize('seed', range(int(__import__('os').environ.get('LTMI_FUZZ_SEEDS', '40'))))
 def test_random_run(ctx, seed):
     from libertem_amd.common.hiparray import HipArray
     from libertem_amd.io.corrections import CorrectionSet
