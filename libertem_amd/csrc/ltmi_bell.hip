@@ -454,7 +454,7 @@ k_bell_apply(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n
 }
 
 
-// ==== float16 path, flat record loop (1- and 2-byte unsigned pixels): k_bell_flat ====================
+// ==== float16 path, flat record loop (1- and 2-byte integer pixels): k_bell_flat ===========================
 // What the float32 kernel above pays for is the matrix pipe: 3.8 padded multiply-adds per stored value on
 // v_mfma_f32_16x16x4_f32 are 0.4 - 0.5 ms per 16 384 frames of C4 at the clock the chip sustains.  For
 // unsigned 1- and 2-byte pixels the same products can be formed EXACTLY from float16 operands:
@@ -721,6 +721,11 @@ k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
 
     const bh16x2 k256 = {(_Float16)256.0f, (_Float16)256.0f};
     const bh16x2 kbias = {(_Float16)1024.0f, (_Float16)1024.0f};
+    // signed pixels (int8 / int16, round 6): the TOP byte counts from -128: its sign bit is flipped (b ^ 0x80 is b + 128 as
+    // an unsigned byte) and the bias taken off is 1024 + 128 -- still exact float16 integers, the same products
+    constexpr bool SIGNED = std::is_signed<T>::value;
+    const bh16x2 kbias_top = SIGNED ? bh16x2{(_Float16)1152.0f, (_Float16)1152.0f} : kbias;
+    constexpr unsigned FLIP = !SIGNED ? 0u : (C::SZ == 2 ? 0x80008000u : 0x00008080u);
 
     for (int i = 0; i < n; i += BE_FD) {
         unsigned cw[BE_FD], cpa[BE_FD], cpb[BE_FD];
@@ -758,11 +763,11 @@ k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
                     if constexpr (C::SZ == 2) {
-                        rawa[t] = *(const unsigned *)(qa + t * C::TILE_OFF);
-                        rawb[t] = *(const unsigned *)(qb + t * C::TILE_OFF);
+                        rawa[t] = *(const unsigned *)(qa + t * C::TILE_OFF) ^ FLIP;
+                        rawb[t] = *(const unsigned *)(qb + t * C::TILE_OFF) ^ FLIP;
                     } else {
-                        rawa[t] = *(const unsigned short *)(qa + t * C::TILE_OFF);
-                        rawb[t] = *(const unsigned short *)(qb + t * C::TILE_OFF);
+                        rawa[t] = *(const unsigned short *)(qa + t * C::TILE_OFF) ^ FLIP;
+                        rawb[t] = *(const unsigned short *)(qb + t * C::TILE_OFF) ^ FLIP;
                     }
                 }
                 bh16x8 bv[TILES];
@@ -772,12 +777,12 @@ k_bell_flat(const T *__restrict__ tile, int64_t ld, int64_t n_frames, int64_t n_
                     bh16x2 la, ha, lb, hb;
                     if constexpr (C::SZ == 2) {
                         la = __builtin_bit_cast(bh16x2, __builtin_amdgcn_perm(0x64646464u, rawa[t], 0x04020400u)) - kbias;
-                        ha = __builtin_bit_cast(bh16x2, __builtin_amdgcn_perm(0x64646464u, rawa[t], 0x04030401u)) - kbias;
+                        ha = __builtin_bit_cast(bh16x2, __builtin_amdgcn_perm(0x64646464u, rawa[t], 0x04030401u)) - kbias_top;
                         lb = __builtin_bit_cast(bh16x2, __builtin_amdgcn_perm(0x64646464u, rawb[t], 0x04020400u)) - kbias;
-                        hb = __builtin_bit_cast(bh16x2, __builtin_amdgcn_perm(0x64646464u, rawb[t], 0x04030401u)) - kbias;
+                        hb = __builtin_bit_cast(bh16x2, __builtin_amdgcn_perm(0x64646464u, rawb[t], 0x04030401u)) - kbias_top;
                     } else {
-                        la = __builtin_bit_cast(bh16x2, __builtin_amdgcn_perm(0x64646464u, rawa[t], 0x04010400u)) - kbias;
-                        lb = __builtin_bit_cast(bh16x2, __builtin_amdgcn_perm(0x64646464u, rawb[t], 0x04010400u)) - kbias;
+                        la = __builtin_bit_cast(bh16x2, __builtin_amdgcn_perm(0x64646464u, rawa[t], 0x04010400u)) - kbias_top;
+                        lb = __builtin_bit_cast(bh16x2, __builtin_amdgcn_perm(0x64646464u, rawb[t], 0x04010400u)) - kbias_top;
                         ha = hb = bh16x2{(_Float16)0.0f, (_Float16)0.0f};
                     }
                     bv[t] = bh16x8{la[0], la[1], ha[0], ha[1], lb[0], lb[1], hb[0], hb[1]};
@@ -1538,8 +1543,8 @@ static int launch_bell(ltmi_masks *m, BellImage *b, const T *tile, int64_t n_fra
     const bool hi = forced ? forced == HI : rounds(HI) * 1.7 < rounds(LO);
     // k_bell_apply with four tiles has one accumulation level only: not for columns of more than 2048 stored values
     const bool hi_apply = forced ? hi : (hi && (HI <= 2 || b->max_col_entries <= 2048));
-    if constexpr (std::is_same<T, uint8_t>::value || std::is_same<T, uint16_t>::value) {
-        if (b->h16) {               // unsigned 1- / 2-byte pixels: the float16 image
+    if constexpr (std::is_integral<T>::value && sizeof(T) <= 2) {
+        if (b->h16) {               // 1- / 2-byte integer pixels (signed ones since round 6): the float16 image
             if (hi)
                 return launch_bell_flat<T, HI>(m, b->h16, tile, n_frames, ld, out, ld_out_f, n_cols,
                                                accumulate, stream);
