@@ -237,6 +237,35 @@ def gen_rmatmul():
 
 
 # ---------------------------------------------------------------------------
+# 6b. non-finite pixels through the reference: its CSR / CSC loops (stored entries only) and ApplyMasksUDF with a
+#     dense stack (torch.mm and `flat_tile @ masks`)
+# ---------------------------------------------------------------------------
+def gen_nonfinite():
+    out = {}
+    for case in recipes.NONFINITE_CASES:
+        data, stack = recipes.make_nonfinite_case(case)
+        n_masks = stack.shape[0]
+        flat = data.reshape((-1, stack.shape[1] * stack.shape[2]))
+        right = stack.reshape((n_masks, -1)).T                       # (px, n_masks)
+        with np.errstate(invalid='ignore', over='ignore'):
+            out[case['name'] + '__rmatmul_csr'] = rmatmul(flat, sp.csr_matrix(right))
+            out[case['name'] + '__rmatmul_csc'] = rmatmul(flat, sp.csc_matrix(right))
+            ds = MemoryDataSet(data=data, num_partitions=2, sig_dims=2)
+            # (ApplyMasksUDF(use_sparse='scipy.sparse') itself cannot run here: MaskContainer stacks the masks as pydata
+            #  `sparse.COO` first, a third-party package that is absent -- SURVEY.md 8(c); what it then calls per tile is
+            #  exactly the rmatmul above, udf/masks.py:34-40, :68-69)
+            for use_torch in (True, False):
+                udf = ApplyMasksUDF(mask_factories=lambda: stack, use_sparse=False, use_torch=use_torch,
+                                    mask_count=n_masks, mask_dtype=stack.dtype)
+                out[case['name'] + f'__udf_dense_torch{int(use_torch)}'] = np.array(run(ds, udf)['intensity'].data)
+        out[case['name'] + '__sha_data'] = np.frombuffer(bytes.fromhex(sha(data)), dtype=np.uint8)
+        out[case['name'] + '__sha_stack'] = np.frombuffer(bytes.fromhex(sha(stack)), dtype=np.uint8)
+        a, b = out[case['name'] + '__rmatmul_csr'], out[case['name'] + '__udf_dense_torch0']
+        print(case['name'], 'sparse: non-finite entries', int((~np.isfinite(a)).sum()), 'dense:', int((~np.isfinite(b)).sum()))
+    save('nonfinite', **out)
+
+
+# ---------------------------------------------------------------------------
 # 7. Partitioning + tiling negotiation for the BASELINE.json config shapes
 # ---------------------------------------------------------------------------
 def gen_tiling():
@@ -598,6 +627,7 @@ if __name__ == '__main__':
     gen_radial_fourier()
     gen_mask_factories()
     gen_rmatmul()
+    gen_nonfinite()
     gen_tiling()
     gen_single_mask_analyses()
     gen_pick()

@@ -350,6 +350,46 @@ def make_rmatmul_case(case):
 
 
 # ---------------------------------------------------------------------------
+# non-finite pixels (round 6): which zeros of a stack meet a NaN / Inf pixel -- the reference's sparse loops touch
+# stored entries only (common/numba/__init__.py:153-184), its dense product every weight (udf/masks.py:59-77)
+# ---------------------------------------------------------------------------
+NONFINITE_CASES = [
+    dict(name='rings_f32', nav=(3, 5), sig=(32, 32), n_bins=12, mask_dtype='float32', seed=811),
+    dict(name='rings_c64', nav=(2, 6), sig=(32, 48), n_bins=7, mask_dtype='complex64', seed=812),
+]
+
+
+def make_nonfinite_case(case):
+    """-> (float32 frames with NaN / +Inf / -Inf pixels in a few frames, dense stack (n_masks, *sig) with many exact
+    zeros): frame 1: NaN in a pixel no mask stores; frame 2: NaN in a stored pixel; frame 3: +Inf in a stored pixel;
+    frame 4: +Inf and -Inf in two stored pixels; the last frame: NaN in both kinds"""
+    rng = np.random.default_rng(case['seed'])
+    sig = tuple(case['sig'])
+    yy, xx = np.mgrid[0:sig[0], 0:sig[1]]
+    r = np.hypot(yy - sig[0] / 2 + 0.25, xx - sig[1] / 2 - 0.5)
+    edges = np.linspace(2.0, 0.45 * min(sig), case['n_bins'] + 1)
+    stack = np.stack([((r >= a) & (r < b)) * (0.25 + rng.random(sig)) for a, b in zip(edges[:-1], edges[1:])])
+    mdt = np.dtype(case['mask_dtype'])
+    if mdt.kind == 'c':
+        stack = stack * np.exp(1j * rng.random(stack.shape) * 6.0)
+    stack = stack.astype(mdt)
+    n = int(np.prod(case['nav']))
+    data = (rng.random((n,) + sig) + 0.1).astype(np.float32)
+    counts = (stack != 0).sum(axis=0).reshape(-1)
+    stored, unstored = np.flatnonzero(counts > 0), np.flatnonzero(counts == 0)
+    assert len(stored) > 20 and len(unstored) > 20 and n >= 6
+    flat = data.reshape((n, -1))
+    flat[1, unstored[len(unstored) // 2]] = np.nan
+    flat[2, stored[len(stored) // 3]] = np.nan
+    flat[3, stored[len(stored) // 2]] = np.inf
+    flat[4, stored[len(stored) // 5]] = np.inf
+    flat[4, stored[(2 * len(stored)) // 3]] = -np.inf
+    flat[n - 1, unstored[0]] = np.nan
+    flat[n - 1, stored[-1]] = np.nan
+    return data.reshape(tuple(case['nav']) + sig), stack
+
+
+# ---------------------------------------------------------------------------
 # partitioning / tiling negotiation
 # ---------------------------------------------------------------------------
 TILING_CASES = [

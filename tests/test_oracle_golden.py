@@ -254,6 +254,39 @@ def test_rmatmul(golden_dir, case):
     assert np.allclose(r1, left @ right, rtol=1e-5)
 
 
+@pytest.mark.parametrize('case', recipes.NONFINITE_CASES, ids=lambda c: c['name'])
+def test_non_finite_pixels_oracle_vs_reference(golden_dir, case):
+    """NaN / Inf pixels through the imported reference (tests/golden/nonfinite.npz): its CSR / CSC loops touch stored
+    entries only -- a non-finite pixel reaches exactly the masks that store it, one no mask stores has no effect
+    (common/numba/__init__.py:153-184, called per tile by udf/masks.py:68-69) --, its dense product (torch.mm and
+    `flat_tile @ masks`, udf/masks.py:59-66, 76-77) multiplies every zero: 0 * NaN = NaN in every mask.  The oracle's
+    restatements reproduce both, bit for bit where the loop order is the reference's."""
+    g = _load(golden_dir, 'nonfinite')
+    data, stack = recipes.make_nonfinite_case(case)
+    assert hashlib.sha256(np.ascontiguousarray(data).tobytes()).hexdigest() == bytes(g[case['name'] + '__sha_data']).hex()
+    n_masks = stack.shape[0]
+    flat = data.reshape((-1, stack.shape[1] * stack.shape[2]))
+    right = stack.reshape((n_masks, -1)).T
+    with np.errstate(invalid='ignore', over='ignore'):
+        for fmt, conv in (('csr', sp.csr_matrix), ('csc', sp.csc_matrix)):
+            ref = g[case['name'] + '__rmatmul_' + fmt]
+            mine = opath.rmatmul(flat, conv(right))
+            assert mine.dtype == ref.dtype and np.array_equal(mine, ref, equal_nan=True)
+        # the frames: 1 = NaN in a pixel no mask stores (no effect), 2 = NaN in a stored pixel (only the masks that store it)
+        assert np.all(np.isfinite(ref[1])) and 0 < np.count_nonzero(~np.isfinite(ref[2])) < n_masks
+        sparse_udf = opath.apply_masks_sparse(data, sp.csr_matrix(right.T), num_partitions=2, mask_dtype=stack.dtype)
+        assert np.array_equal(sparse_udf.reshape(ref.shape), ref, equal_nan=True)
+        dense = opath.apply_masks(data, stack, num_partitions=2, mask_dtype=stack.dtype)
+    for key in ('__udf_dense_torch1', '__udf_dense_torch0'):
+        ref = g[case['name'] + key]
+        assert dense.dtype == ref.dtype and dense.shape == ref.shape
+        # NaN in ANY pixel of a frame -> every mask NaN; the pattern of NaN / Inf is the reference's
+        assert np.array_equal(np.isnan(dense.real), np.isnan(ref.real)) and np.array_equal(np.isnan(dense.imag), np.isnan(ref.imag))
+        assert np.all(np.isnan(ref.reshape((-1, n_masks))[1].real))
+        ok = np.isfinite(ref)
+        assert np.allclose(dense[ok], ref[ok], rtol=1e-5, atol=0)
+
+
 def test_rmatmul_errors():
     # tests/common/test_numba.py:32-61
     le = np.zeros((3, 4), dtype=np.float32)

@@ -2414,3 +2414,50 @@ def test_run_udf_elementwise_error_bound(ctx, monkeypatch, route):
     assert got.shape == ref.shape
     err = np.abs(got - ref)
     assert np.all(err <= bound), (route, float((err / bound).max()))
+
+
+@pytest.mark.parametrize('case', recipes.NONFINITE_CASES, ids=lambda c: c['name'])
+def test_non_finite_pixels_vs_reference_golden(ctx, golden_dir, monkeypatch, case):
+    """NaN / Inf pixels against outputs of the IMPORTED reference (tests/golden/nonfinite.npz): ApplyMasksUDF with the
+    stack given sparse must reproduce the reference's rmatmul (stored entries only) -- on the gather kernel, the
+    blocked image, the scatter kernel and the densified route --, given dense its `flat_tile @ masks` / torch.mm
+    (a NaN pixel anywhere in a frame makes every mask NaN)."""
+    import scipy.sparse as sp
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd.udf import masks as um
+    g = _load(golden_dir, 'nonfinite')
+    data, stack = recipes.make_nonfinite_case(case)
+    n_masks = stack.shape[0]
+    ds = _device_ds(ctx, data, 2)
+    ref_sparse = g[case['name'] + '__rmatmul_csr'].reshape(tuple(case['nav']) + (n_masks,))
+    mats = [sp.csr_matrix(stack[k]) for k in range(n_masks)]
+    for env in (dict(LTMI_SPARSE_BELL='0', LTMI_SPARSE_SCATTER='0', LTMI_DENSIFY_FILL='0'),    # gather kernel
+                dict(LTMI_SPARSE_BELL='1', LTMI_SPARSE_SCATTER='0', LTMI_DENSIFY_FILL='0'),    # blocked image
+                dict(LTMI_SPARSE_BELL='0', LTMI_SPARSE_SCATTER='1', LTMI_DENSIFY_FILL='0'),    # scatter kernel
+                dict()):                                                                        # as dispatched
+        for k in ('LTMI_SPARSE_BELL', 'LTMI_SPARSE_SCATTER', 'LTMI_DENSIFY_FILL'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        from libertem_amd.common import container as cont
+        monkeypatch.setattr(cont, 'DENSIFY_FILL', float(env.get('LTMI_DENSIFY_FILL', '0.125')))
+        um.clear_mask_cache()
+        got = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=[(lambda m=m: m) for m in mats],
+                                                        use_sparse='scipy.sparse', mask_dtype=stack.dtype,
+                                                        cache=False))['intensity'].data
+        assert got.dtype == ref_sparse.dtype
+        assert _same_nf(got, ref_sparse), env
+        ok = np.isfinite(ref_sparse)
+        assert np.allclose(got[ok], ref_sparse[ok], rtol=F32_TOL, atol=F32_TOL * np.abs(ref_sparse[ok]).max()), env
+    um.clear_mask_cache()
+    got_d = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=lambda: stack, use_sparse=False,
+                                                      mask_count=n_masks, mask_dtype=stack.dtype))['intensity'].data
+    for key in ('__udf_dense_torch1', '__udf_dense_torch0'):
+        ref = g[case['name'] + key]
+        assert got_d.dtype == ref.dtype and got_d.shape == ref.shape
+        nan_frames = np.isnan(data).any(axis=(2, 3))
+        assert _same_nf(got_d[nan_frames], ref[nan_frames])
+        assert np.array_equal(np.isfinite(got_d.real), np.isfinite(ref.real)) and \
+            np.array_equal(np.isfinite(got_d.imag), np.isfinite(ref.imag))
+        ok = np.isfinite(ref)
+        assert np.allclose(got_d[ok], ref[ok], rtol=F32_TOL, atol=F32_TOL * np.abs(ref[ok]).max())
