@@ -398,6 +398,23 @@ class MaskContainer:
             stack[1::2, 0::2] = m.imag
             stack[1::2, 1::2] = m.real
             h = hip.MaskHandle.dense(device, stack, real)
+            if self.use_sparse is not False:
+                # a SPARSE stack on complex frames: the reference's loops multiply stored entries only, and a complex
+                # product lets a NaN in EITHER part of a pixel reach both parts of the sum (common/numba/__init__.py:
+                # 153-184 with a complex `left_dense`) -- the gather image of the expansion holds all four real entries
+                # of every stored complex entry, zeros included, and serves the frames with non-finite results
+                coo = sp.coo_matrix(self.get_for_sig_slice(sig_slice, dtype=rd, sparse_backend='scipy.sparse.csr',
+                                                           transpose=True))            # (px, n_masks), stored entries
+                p, k, v = coo.row.astype(np.int64), coo.col.astype(np.int64), coo.data.astype(rd)
+                rows = np.concatenate([2 * p, 2 * p + 1, 2 * p, 2 * p + 1])
+                cols = np.concatenate([2 * k, 2 * k, 2 * k + 1, 2 * k + 1])
+                vals = np.concatenate([v.real, -v.imag, v.imag, v.real]).astype(real)
+                order = np.lexsort((cols, rows))
+                indptr = np.zeros(2 * n_px + 1, dtype=np.int64)
+                np.add.at(indptr, rows + 1, 1)
+                indptr = np.cumsum(indptr)
+                expanded = sp.csr_matrix((vals[order], cols[order], indptr), shape=(2 * n_px, 2 * n_masks))
+                h.set_sparse_origin(hip.MaskHandle.csr(device, expanded, real, gather_only=True))
             self._handle_cache[key] = h
         return h, real
 

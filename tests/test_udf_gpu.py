@@ -2461,3 +2461,45 @@ def test_non_finite_pixels_vs_reference_golden(ctx, golden_dir, monkeypatch, cas
             np.array_equal(np.isfinite(got_d.imag), np.isfinite(ref.imag))
         ok = np.isfinite(ref)
         assert np.allclose(got_d[ok], ref[ok], rtol=F32_TOL, atol=F32_TOL * np.abs(ref[ok]).max())
+
+
+@pytest.mark.parametrize('mask_dtype', ['float32', 'complex64'])
+def test_sparse_stack_on_complex_frames_non_finite_pixels(ctx, mask_dtype):
+    """Complex frames against a SPARSE stack run on the dense real expansion of the stack; the reference multiplies them
+    entry by stored entry (rmatmul with a complex left operand, common/numba/__init__.py:153-184): a NaN in EITHER part of
+    a pixel reaches both parts of exactly the masks that store the pixel.  The expansion's gather image (all four real
+    entries of a stored complex entry, zeros included) serves the frames with non-finite results."""
+    import scipy.sparse as sp
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    rng = np.random.default_rng(zlib_seed('complex-nf', mask_dtype))
+    nav, sig = (3, 4), (16, 24)
+    data = ((rng.random(nav + sig) - 0.3) + 1j * (rng.random(nav + sig) - 0.6)).astype(np.complex64)
+    md = np.dtype(mask_dtype)
+    dense = np.where(rng.random((6,) + sig) < 0.15, rng.random((6,) + sig) + 0.2, 0)
+    if md.kind == 'c':
+        dense = dense * np.exp(1j * rng.random((6,) + sig) * 5)
+    dense = dense.astype(md)
+    counts = (dense != 0).sum(axis=0).reshape(-1)
+    stored, unstored = np.flatnonzero(counts > 0), np.flatnonzero(counts == 0)
+    flat = data.reshape((12, -1))
+    flat[1, unstored[3]] = np.nan + 0j                       # no mask stores it: no effect
+    flat[2, stored[5]] = complex(np.nan, 0.25)               # NaN in the real part only
+    flat[7, stored[11]] = complex(0.5, np.nan)               # ... in the imaginary part only
+    flat[9, stored[2]] = complex(np.inf, 0.1)
+    ds = _device_ds(ctx, data, 2)
+    mats = [sp.csr_matrix(dense[k]) for k in range(6)]
+    got = ctx.run_udf(dataset=ds, udf=ApplyMasksUDF(mask_factories=[(lambda m=m: m) for m in mats],
+                                                    use_sparse='scipy.sparse', mask_dtype=md))['intensity'].data
+    assert got.dtype == np.complex64
+    with np.errstate(invalid='ignore', over='ignore'):
+        ref = opath.apply_masks_sparse(data, sp.csr_matrix(dense.reshape((6, -1))), num_partitions=2, mask_dtype=md)
+    assert np.all(np.isfinite(ref[0, 1])) and not np.all(np.isfinite(ref[0, 2]))
+    # NaN where the reference is NaN (both parts), finite where it is finite
+    assert np.array_equal(np.isfinite(got.real), np.isfinite(ref.real)) and \
+        np.array_equal(np.isfinite(got.imag), np.isfinite(ref.imag))
+    nan_frames = np.isnan(flat.real).any(axis=1) | np.isnan(flat.imag).any(axis=1)
+    g2, r2 = got.reshape((12, 6)), ref.reshape((12, 6))
+    assert np.array_equal(np.isnan(g2[nan_frames].real), np.isnan(r2[nan_frames].real))
+    assert np.array_equal(np.isnan(g2[nan_frames].imag), np.isnan(r2[nan_frames].imag))
+    ok = np.isfinite(ref)
+    assert np.allclose(got[ok], ref[ok], rtol=F32_TOL, atol=F32_TOL * np.abs(ref[ok]).max())
