@@ -489,7 +489,7 @@ def host_streamed(ctx, torch, hip, gib=2):
     peak = 4 * (1 << 30) / (time.perf_counter() - t0) / 1e9
     del pinned, dev
 
-    def timed(step, n_frames, data_bytes, what):
+    def timed(step, n_frames, data_bytes, what, ds=None):
         for _ in range(2):
             step()
         ts = []
@@ -499,7 +499,12 @@ def host_streamed(ctx, torch, hip, gib=2):
             ts.append(time.perf_counter() - t0)
         t = float(np.median(ts))
         gbs = data_bytes / t / 1e9
-        return {"workload": what, "frames_per_s": n_frames / t, "GBps": gbs,
+        # which way the bytes went: DMA straight out of the user's array (its memory provably is a mapping of its own,
+        # io/dataset/memory.py `_own_mapping`) or staged through the page-locked bounce buffers by ltmi_host_copy
+        st = next(iter(getattr(ds, '__dict__', {}).get('_hip_stagers', {}).values()), None) if ds is not None else None
+        upload = None if st is None else ("in place (hipHostRegister: the array is a mapping of its own)"
+                                          if st.registered is not None else "staged (bounce buffers + ltmi_host_copy)")
+        return {"workload": what, "frames_per_s": n_frames / t, "GBps": gbs, "upload": upload,
                 "h2d_peak_GBps": peak, "frac_of_h2d_peak": gbs / peak, "ms_per_run": t * 1e3}
 
     out = {}
@@ -509,13 +514,20 @@ def host_streamed(ctx, torch, hip, gib=2):
     udf2 = ApplyMasksUDF(mask_factories=lambda: masks, use_sparse=False, mask_count=16,
                          mask_dtype=np.float32)
     out['c2'] = timed(lambda: ctx.run_udf(dataset=ds2, udf=udf2), n2, nbytes,
-                      f"C2 masks, {n2} frames ({gib} GiB) in host memory, hipHostRegister + "
-                      f"double-buffered hipMemcpyAsync")
+                      f"C2 masks, {n2} frames ({gib} GiB) in host memory, double-buffered hipMemcpyAsync", ds=ds2)
+    # the same frames in memory whose mapping the library cannot vouch for (another allocator's): the staged path
+    keep = torch.from_numpy(u16.view(np.int16)).clone()
+    foreign = keep.numpy().view(np.uint16).reshape((n2 // 256, 256, 256, 256))
+    ds2s = ctx.load('memory', data=foreign, sig_dims=2, num_partitions=1)
+    out['c2_staged'] = timed(lambda: ctx.run_udf(dataset=ds2s, udf=udf2), n2, nbytes,
+                             f"C2 masks, {n2} frames ({gib} GiB) in a torch CPU tensor's memory", ds=ds2s)
+    ds2s.close_stagers()
+    del ds2s, foreign, keep
     n3 = nbytes // (512 * 512 * 2)
     ds3 = ctx.load('memory', data=u16.reshape((n3 // 512, 512, 512, 512)), sig_dims=2, num_partitions=1)
     an3 = ctx.create_com_analysis(dataset=ds3, cx=256, cy=256)
     out['c3'] = timed(lambda: ctx.run(an3), n3, nbytes,
-                      f"C3 CoM analysis, {n3} frames of 512x512 uint16 ({gib} GiB) in host memory")
+                      f"C3 CoM analysis, {n3} frames of 512x512 uint16 ({gib} GiB) in host memory", ds=ds3)
 
     def rings():
         return M.radial_bins(centerX=128, centerY=128, imageSizeX=256, imageSizeY=256,
@@ -524,7 +536,7 @@ def host_streamed(ctx, torch, hip, gib=2):
                          mask_dtype=np.float32)
     out['c4'] = timed(lambda: ctx.run_udf(dataset=ds2, udf=udf4), n2, nbytes,
                       f"C4 ring stack, {n2} frames of 256x256 uint16 ({gib} GiB) in host memory "
-                      f"(+ {n2 * 4096 / 2**20:.0f} MiB of results back)")
+                      f"(+ {n2 * 4096 / 2**20:.0f} MiB of results back)", ds=ds2)
     del ds2, ds3, u16
     f32 = rng.random(nbytes // 4, dtype=np.float32)
     n5 = nbytes // (1024 * 1024 * 4)
@@ -533,7 +545,7 @@ def host_streamed(ctx, torch, hip, gib=2):
     an5 = ctx.create_radial_fourier_analysis(dataset=ds5)
     out['c5'] = timed(lambda: ctx.run(an5), n5, nbytes,
                       f"C5 radial Fourier analysis, {n5} frames of 1024x1024 float32 ({gib} GiB) in "
-                      f"host memory")
+                      f"host memory", ds=ds5)
     return out
 
 
