@@ -148,8 +148,10 @@ def fingerprint(obj, _depth=0, _path=()):
     if sp_parts:
         return ('sp', id(obj)) + tuple(array_fingerprint(p) for p in sp_parts)
     if callable(obj) and (hasattr(obj, '__code__') or hasattr(obj, '__func__')):
-        out = ['fn', id(obj)]
+        # (a bound method object is made afresh by every attribute access `holder.make`: its own id() says nothing --
+        #  the function's and, below, the object's do)
         fn = getattr(obj, '__func__', obj)
+        out = ['fn', id(fn)]
         for cell in (getattr(fn, '__closure__', None) or ()):
             try:
                 out.append(fingerprint(cell.cell_contents, _depth + 1, path))
