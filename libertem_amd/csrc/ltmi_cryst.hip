@@ -1188,6 +1188,14 @@ static int launch_rows(const void *tile, int64_t ld, int64_t n_frames, const flo
     return LTMI_OK;
 }
 
+// frames per pass of the workspace: LTMI_CRYST_PASS_MIB (measurement switch) caps the bytes a pass writes and reads back
+static int64_t cryst_pass_frames(int64_t gbuf_frames, int64_t bytes_per_frame, int n_cu) {
+    static const long mib = [] { const char *e = getenv("LTMI_CRYST_PASS_MIB"); return e ? atol(e) : 0L; }();
+    if (mib <= 0) return gbuf_frames;
+    const int64_t n = std::max<int64_t>(1, ((int64_t)mib << 20) / bytes_per_frame);
+    return std::min(gbuf_frames, n);
+}
+
 // H x W frames, W = 256 M, H = 256 MH (M, MH = 1, 2, 4); gbuf: workspace of gbuf_frames * n_cols * H float2
 template <int M, int MH = M>
 static int cryst_rows_cols(const void *tile, int tile_dtype, int64_t n_frames, int64_t ld, const float *real_mask,
@@ -1208,6 +1216,7 @@ static int cryst_rows_cols(const void *tile, int tile_dtype, int64_t n_frames, i
         hipLaunchKernelGGL(k_cryst_masks_n, dim3((unsigned)((int64_t)N * H / 256)), dim3(256), 0, stream, half_mask, N, H,
                            0, mask_p, corr->d_px, corr->dmap_p, corr->dummy_flags);
     const float *rm = real_mask ? rmask_p : nullptr;
+    gbuf_frames = cryst_pass_frames(gbuf_frames, (int64_t)n_cols * H * (int64_t)sizeof(v2f), n_cu);
     for (int64_t f0 = 0; f0 < n_frames; f0 += gbuf_frames) {
         const int64_t n = std::min<int64_t>(gbuf_frames, n_frames - f0);
         const void *src = (const char *)tile + (size_t)f0 * ld * esz;

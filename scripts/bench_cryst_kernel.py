@@ -25,7 +25,7 @@ real_mask, half = crystallinity_masks((sig, sig), int(rad_out) // 4, rad_out,
 rm = None if real_mask is None else torch.from_numpy(np.ascontiguousarray(real_mask.astype(np.float32))).cuda()
 hm = torch.from_numpy(np.ascontiguousarray(half.astype(np.float32))).cuda()
 out = torch.zeros(n, dtype=torch.float32, device='cuda')
-plan = hip.FFTPlan(0, sig, sig, min(n, 1024))
+plan = hip.FFTPlan(0, sig, sig, min(n, int(os.environ.get("BATCH", 1024))))
 box = mask_box(half)
 
 
