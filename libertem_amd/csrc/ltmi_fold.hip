@@ -51,6 +51,7 @@ constexpr int FD_TPART = 16 * 256;                   // 4 KiB: rows y (or y') of
 constexpr int FD_HALF = 2 * FD_WAVES * FD_TPART;     // 32 KiB: a half-stage = one tile of every wave, parts A and C
 constexpr int FD_RING = 4;                           // half-stages in LDS: one being multiplied, three on their way
 constexpr int FD_WG_ROWS = FD_WAVES * FD_ROWS;       // 128 frames per workgroup
+constexpr bool FOLD_TURN_DEFAULT = false;           // stages of a pixel-split launch in turn (LTMI_FOLD_TURN=1 / 0)
 constexpr bool FOLD8_DEFAULT = false;                // k_dense_fold8 (two waves per SIMD) where it applies: see launch_fold_t
 __host__ __device__ constexpr int fold_slot_bytes(int ng) { return ng * GROUP * FD_KB * 4; }
 __host__ __device__ constexpr int fold_lds_bytes(int ng) { return FD_RING * FD_HALF + 2 * fold_slot_bytes(ng); }
@@ -136,12 +137,18 @@ k_dense_fold(const float *__restrict__ tile, int64_t ld, int64_t n_frames, int s
     const int lane = tid & 63;
     const int m = lane & 15, kg = lane >> 4;
     // LIST: blockIdx.y = block * ksplit + part of the block's stage list
+    // ksplit < 0 (not LIST): the parts of a pixel-split launch take the stages IN TURN (part ks: stages ks, ks + ksplit,
+    // ...) instead of a contiguous range each -- the workgroups of a frame group that run at the same time then read
+    // neighbouring 256-byte pieces of the same detector rows.  Stage of loop index v: p0 + v * pstride.
+    const bool turn = !LIST && ksplit < 0;
+    if (ksplit < 0) ksplit = -ksplit;
     const int by = LIST ? blockIdx.y / ksplit : 0;
     const int ks = LIST ? blockIdx.y - by * ksplit : blockIdx.y;
     const int b0 = LIST ? blk_off[by] : 0, b1 = LIST ? blk_off[by + 1] : n_stages;
     const int per = (b1 - b0 + ksplit - 1) / ksplit;
-    const int s_begin = b0 + ks * per;
-    const int s_end = min(b1, s_begin + per);
+    const int p0 = turn ? ks : 0, pstride = turn ? ksplit : 1;
+    const int s_begin = turn ? 0 : b0 + ks * per;
+    const int s_end = turn ? (n_stages - ks + ksplit - 1) / ksplit : min(b1, s_begin + per);
     if (LIST) colmap += by * (NG * GROUP);
 
     const int64_t f_wave = (int64_t)blockIdx.x * FD_WG_ROWS + wave * FD_ROWS;
@@ -180,7 +187,7 @@ k_dense_fold(const float *__restrict__ tile, int64_t ld, int64_t n_frames, int s
 
         // half-stages are issued in order: (stage, tile 0), (stage, tile 1), (stage + 1, tile 0) ...; past the end
         // the last stage again (clamped prefetch: every step issues the same number of copies, the waits count them)
-        int iss = s_begin, iss_fy = LIST ? 0 : s_begin / spr, iss_xs = LIST ? 0 : s_begin % spr;
+        int iss = s_begin, iss_fy = LIST ? 0 : (p0 + s_begin * pstride) / spr, iss_xs = LIST ? 0 : (p0 + s_begin * pstride) % spr;
         int4 iss_st = LIST ? stage_list[s_begin] : int4{0, 0, 0, 0};         // (fetched one stage ahead of its use)
         auto issue_half = [&](auto TL, auto Q) {
             constexpr int tl = decltype(TL)::value, q = decltype(Q)::value;
@@ -204,13 +211,16 @@ k_dense_fold(const float *__restrict__ tile, int64_t ld, int64_t n_frames, int s
             if (tl == FD_TILES - 1 && iss + 1 < s_end) {
                 ++iss;
                 if (LIST) iss_st = stage_list[iss];
-                else if (++iss_xs == spr) { iss_xs = 0; ++iss_fy; }
+                else {
+                    iss_xs += pstride;
+                    while (iss_xs >= spr) { iss_xs -= spr; ++iss_fy; }
+                }
             }
         };
         auto issue_b = [&](int s, int bslot) {              // mask slot of stage s (clamped)
             if (ABL >= 2) return;
             unsigned char *db = b_base + bslot * BSLOT + wave * (BSLOT / FD_WAVES);
-            const unsigned char *sp = bsrc + (int64_t)min(s, s_end - 1) * BSLOT;
+            const unsigned char *sp = bsrc + (int64_t)(p0 + min(s, s_end - 1) * pstride) * BSLOT;
 #pragma unroll
             for (int u = 0; u < NBI; ++u)
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)(sp + u * 1024), (lds_ptr_t)(db + u * 1024), 16, 0, 0);
@@ -1052,6 +1062,8 @@ static int launch_fold_t(ltmi_masks *m, const float *tile, int64_t n_frames, int
         if (rc != LTMI_OK) return rc;
     }
     dim3 grid((unsigned)gx, (unsigned)ksplit);
+    static const int turn_env = getenv("LTMI_FOLD_TURN") ? atoi(getenv("LTMI_FOLD_TURN")) : -1;
+    const bool in_turn = ksplit > 1 && (turn_env >= 0 ? turn_env != 0 : FOLD_TURN_DEFAULT);
     // two waves per SIMD (k_dense_fold8): stacks of 2 or 4 column groups; measured 3 - 5 % SLOWER than the pipelined
     // one-wave-per-SIMD kernel on C5 (profiles/r06_fold.txt), kept as a measurement switch: LTMI_FOLD_WAVES=8
     const char *fw = getenv("LTMI_FOLD_WAVES");               // (read per launch: tests and benches switch it)
@@ -1074,13 +1086,13 @@ static int launch_fold_t(ltmi_masks *m, const float *tile, int64_t n_frames, int
     } else {
         hipLaunchKernelGGL(kern, grid, dim3(FD_WAVES * 64), LDS, stream, tile, ld, n_frames, f->sig_w / FD_KB,
                            (const int2 *)f->rows, (const float *)f->img, f->n_stages, out, ld_out, m->n_cols,
-                           (const int *)f->colmap, accumulate, dense_partial_sums(m), ksplit,
+                           (const int *)f->colmap, accumulate, dense_partial_sums(m), in_turn ? -ksplit : ksplit,
                            (const unsigned char *)f->zeros, m->roi_rows, (const int4 *)nullptr, (const int *)nullptr);
     }
     LTMI_HIP(hipGetLastError());
-    snprintf(m->last_kernel, sizeof(m->last_kernel), "k_dense_fold%s<f,even=%d,odd=%d,rows %d+%d=%d%s> grid=(%u,%u)",
+    snprintf(m->last_kernel, sizeof(m->last_kernel), "k_dense_fold%s<f,even=%d,odd=%d,rows %d+%d=%d%s%s> grid=(%u,%u)",
              eight ? "8" : "", NGE, NGO, f->n_fold_rows, f->sig_h - f->n_fold_rows, f->c2, m->roi_rows ? ",rows" : "",
-             grid.x, grid.y);
+             in_turn && !eight ? ",in turn" : "", grid.x, grid.y);
     if (ksplit > 1) {
         const int rc = dense_reduce_partials(m, ksplit, n_frames, out, ld_out, accumulate, stream);
         if (rc != LTMI_OK) return rc;
