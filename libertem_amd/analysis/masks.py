@@ -2,6 +2,7 @@
 import numpy as np
 
 from .base import BaseAnalysis, AnalysisResultSet, AnalysisResult
+from .getroi import get_roi
 from libertem_amd.udf.masks import ApplyMasksUDF
 
 
@@ -116,6 +117,10 @@ class MasksAnalysis(BaseMasksAnalysis, id_="APPLY_MASKS"):
                            desc="integrated intensity for mask %d" % idx)
             for idx in range(data.shape[-1])
         ])
+
+    def get_roi(self):
+        # parameters = {'factories': ..., 'roi': {'shape': 'disk' | 'rect', ...}} (analysis/masks.py:179-180)
+        return get_roi(params=self.parameters, shape=self.dataset.shape.nav)
 
     def get_udf_results(self, udf_results, roi, damage):
         data = udf_results['intensity'].data

@@ -3,6 +3,7 @@ import numpy as np
 
 from libertem_amd.udf.sum import SumUDF
 from .base import BaseAnalysis, AnalysisResult, AnalysisResultSet
+from .getroi import get_roi
 
 
 class SumResultSet(AnalysisResultSet):
@@ -15,6 +16,10 @@ class SumAnalysis(BaseAnalysis, id_="SUM_FRAMES"):
         if dest_dtype.kind not in ('c', 'f'):
             dest_dtype = 'float32'
         return SumUDF(dtype=dest_dtype)
+
+    def get_roi(self):
+        # parameters = {'roi': {'shape': 'disk' | 'rect', ...}} (analysis/sum.py:100-101)
+        return get_roi(params=self.parameters, shape=self.dataset.shape.nav)
 
     def get_udf_results(self, udf_results, roi, damage):
         data = udf_results['intensity'].data

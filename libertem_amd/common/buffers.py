@@ -34,6 +34,78 @@ def to_numpy(a):
     return np.asarray(a)
 
 
+class InvalidMaskError(Exception):
+    """a valid-mask that cannot belong to its array: not bool, or not broadcastable to the array's shape"""
+
+
+class ArrayWithMask:
+    """A result array together with the mask of its valid entries -- what `UDF.with_mask(data, mask)` hands back from
+    `get_results` (reference common/buffers.py:195-232).  `mask`: bool array broadcastable to `arr.shape`, or a bool."""
+
+    def __init__(self, arr, mask):
+        if isinstance(mask, (bool, np.bool_)):
+            mask = np.array([bool(mask)])
+        mask = np.asarray(mask)
+        try:
+            mask = np.broadcast_to(mask, arr.shape)
+        except ValueError:
+            raise InvalidMaskError(
+                f"`arr` and `mask` must have compatible shapes (arr.shape={arr.shape} vs mask.shape={mask.shape})")
+        if mask.dtype != np.dtype(bool):
+            raise InvalidMaskError(f"`mask` should have `dtype=bool` (have {mask.dtype})")
+        self._arr = arr
+        self._mask = mask
+
+    @property
+    def mask(self):
+        return np.broadcast_to(self._mask, self._arr.shape)
+
+    @property
+    def arr(self):
+        return self._arr
+
+
+def get_inner_slice(arr, axis=0):
+    """Slice along `axis` over the FIRST run of positions at which every entry of the other axes is non-zero
+    (reference common/buffers.py:235-269); an array without such a position gives the empty slice [n:1]."""
+    arr = np.asarray(arr)
+    full = np.all(arr != 0, axis=tuple(i for i in range(arr.ndim) if i != axis))
+    hits = np.flatnonzero(full)
+    if hits.size == 0:
+        lo, hi = arr.shape[axis], 0
+    else:
+        lo = hi = int(hits[0])
+        while hi + 1 < full.shape[0] and full[hi + 1]:
+            hi += 1
+    return tuple(slice(lo, hi + 1) if d == axis else slice(None, None, None) for d in range(arr.ndim))
+
+
+def get_bbox(arr, eps=1e-8):
+    """(min_0, max_0, min_1, max_1, ...): per axis the first and last index that holds an entry with |value| >= eps
+    (reference common/buffers.py:272-312); an axis without one gives (n, 0) -- an empty slice in get_bbox_slice."""
+    arr = np.asarray(arr)
+    hit = arr if arr.dtype == bool else np.abs(arr) >= eps
+    out = []
+    for ax in range(arr.ndim):
+        idx = np.flatnonzero(np.any(hit, axis=tuple(i for i in range(arr.ndim) if i != ax)))
+        out.extend((int(idx[0]), int(idx[-1])) if idx.size else (arr.shape[ax], 0))
+    return tuple(out)
+
+
+def get_bbox_2d(arr, eps=1e-8):
+    return get_bbox(arr, eps)
+
+
+def get_bbox_slice(arr):
+    b = get_bbox(arr)
+    return tuple(slice(b[2 * i], b[2 * i + 1] + 1, None) for i in range(len(b) // 2))
+
+
+def disjoint(sl, slices):
+    """True iff `sl` overlaps none of `slices` (reference common/buffers.py:122-123)"""
+    return all(sl.intersection_with(o).is_null() for o in slices)
+
+
 class BufferWrapper:
     def __init__(self, kind, extra_shape=(), dtype="float32", where=None, use=None):
         if kind not in ('nav', 'sig', 'single'):
@@ -218,49 +290,64 @@ class BufferWrapper:
         return a if dtype is None else a.astype(dtype)
 
     # --- valid masks (reference :524-633) -----------------------------------------------------
-    def make_default_mask(self, valid_nav_mask):
+    def make_default_mask(self, valid_nav_mask, dataset_shape=None, roi=None):
+        """The valid-mask a buffer gets when `get_results` does not say otherwise, in the buffer's RAW shape: nav
+        buffers follow `valid_nav_mask` (flat, compressed to `roi`), broadcast over the extra dimensions; sig and
+        single buffers are valid everywhere (reference :524-551)."""
+        if dataset_shape is None:
+            dataset_shape = self._ds_shape
+        if roi is None and self._roi is not None:
+            roi = self._roi
+        roi_count = None if roi is None else int(np.count_nonzero(roi))
+        shape = self._shape_for_kind(self._kind, dataset_shape.flatten_nav(), roi_count)
         if self._kind == 'nav':
-            m = np.asarray(valid_nav_mask, dtype=bool).reshape(-1)
-            if self._roi is not None:
-                m = m[self._roi] if m.size == self._roi.size else m
-            return m
-        return bool(np.any(valid_nav_mask))
+            mask = np.zeros(shape, dtype=bool)
+            v = np.asarray(valid_nav_mask, dtype=bool)
+            mask[:] = v.reshape(v.shape + (1,) * len(self._extra_shape))
+            return mask
+        return np.ones(shape, dtype=bool)
 
     @property
     def valid_mask(self):
+        """bool array of the shape of `data`: which entries hold valid results (reference :553-576).  Never set
+        (a buffer outside a run's results): everything counts as valid."""
+        if self._ds_shape is None:
+            raise RuntimeError("`valid_mask` called without setting the dataset shape")
         vm = self._valid_mask
         if vm is None:
-            vm = True
-        if self._kind == 'nav' and self._ds_shape is not None:
+            vm = np.ones(self._shape, dtype=bool)
+        if self._kind == 'nav':
             full_shape = tuple(self._ds_shape.nav) + self._extra_shape
-            if np.ndim(vm) == 0:
-                base = np.full(full_shape, bool(vm), dtype=bool)
-                if self._roi is not None:
-                    nav = np.zeros(prod(self._ds_shape.nav), dtype=bool)
-                    nav[self._roi] = bool(vm)
-                    base = np.broadcast_to(
-                        nav.reshape(tuple(self._ds_shape.nav) + (1,) * len(self._extra_shape)),
-                        full_shape).copy()
-                return base
-            vm = np.asarray(vm, dtype=bool).reshape(-1)
-            nav = np.zeros(prod(self._ds_shape.nav), dtype=bool)
-            if self._roi is not None and vm.size == int(np.count_nonzero(self._roi)):
-                nav[self._roi] = vm
-            else:
-                nav[:] = vm
-            return np.broadcast_to(
-                nav.reshape(tuple(self._ds_shape.nav) + (1,) * len(self._extra_shape)),
-                full_shape).copy()
-        shape = self.data.shape if self.data is not None else ()
-        return np.full(shape, bool(np.all(vm)), dtype=bool)
+            if self._roi is not None:
+                out = np.zeros(full_shape, dtype=bool)
+                out.reshape((prod(self._ds_shape.nav),) + self._extra_shape)[self._roi] = vm
+                return out
+            return np.asarray(vm).reshape(full_shape)
+        return vm
 
     @valid_mask.setter
     def valid_mask(self, value):
         self._valid_mask = value
 
     @property
+    def valid_slice_bounding(self):
+        """slices into `data` around every valid entry -- may include invalid ones (reference :585-595)"""
+        return get_bbox_slice(self.valid_mask)
+
+    def get_valid_slice_inner(self, axis=0):
+        """slices into `data`, cut along `axis`, that select valid entries only -- may leave valid ones out
+        (reference :597-613)"""
+        return get_inner_slice(self.valid_mask, axis=axis)
+
+    @property
     def masked_data(self):
-        return np.ma.MaskedArray(self.data, mask=~self.valid_mask)
+        return np.ma.array(self.data, mask=~self.valid_mask)
+
+    @property
+    def raw_masked_data(self):
+        """`raw_data` (flat nav axis, compressed to the roi) as a masked array (reference :624-633)"""
+        vm = self._valid_mask if self._valid_mask is not None else np.ones(self._shape, dtype=bool)
+        return np.ma.array(self.raw_data, mask=~np.asarray(vm))
 
     # --- views --------------------------------------------------------------------------------
     def _slice_for_partition(self, partition):

@@ -229,6 +229,10 @@ class MaskContainer:
                             "DataTile/Slice/Partition instances")
         return self.get_for_sig_slice(key.discard_nav(), dtype, sparse_backend, transpose)
 
+    def get_masks_for_slice(self, slice_, dtype=None, sparse_backend=None, transpose=True, backend='numpy'):
+        """host matrix of a sig-only slice (common/container.py:316-333; `backend`: NumPy arrays only here)"""
+        return self.get_for_sig_slice(slice_, dtype, sparse_backend, transpose, backend)
+
     def get_for_idx(self, scheme, idx, *args, **kwargs):
         return self.get_for_sig_slice(scheme[idx], *args, **kwargs)
 

@@ -39,6 +39,10 @@ class Slice:
             and self.shape == other.shape
 
     # --- algebra -----------------------------------------------------------------------------
+    def clip_to(self, shape):
+        """the part of this slice inside an array of `shape` anchored at the origin (common/slice.py:397-399)"""
+        return self.intersection_with(Slice((0,) * shape.dims, shape))
+
     def intersection_with(self, other):
         """Overlap of two slices; an empty overlap yields a slice with zero-sized shape."""
         if self.shape.sig_dims != other.shape.sig_dims:

@@ -414,7 +414,7 @@ class HipJobExecutor(JobExecutor):
                             if (i, name) in local_host and \
                                     not isinstance(buf, PlaceholderBufferWrapper):
                                 buf.replace_array(local_host[(i, name)])
-                        self._apply_one(udf, results, task)
+                        self._apply_one(udf, results, task, damage)
                         for name in decl:
                             buf = udf.results.get_buffer(name)
                             if not isinstance(buf, PlaceholderBufferWrapper):
@@ -432,7 +432,7 @@ class HipJobExecutor(JobExecutor):
                 for tidx, entry in sorted((p for chunk in gathered for p in chunk),
                                           key=lambda x: x[0]):
                     for i, results in entry.items():
-                        self._apply_one(udfs[i], results, by_idx[tidx])
+                        self._apply_one(udfs[i], results, by_idx[tidx], damage)
             for r in range(self.world_size):
                 for t in per_rank[r][:step + 1]:
                     damage.get_view_for_partition(t.partition)[:] = True
@@ -763,7 +763,7 @@ class HipJobExecutor(JobExecutor):
             if partial:
                 # merge the host-side UDFs right away (tasks arrive in partition order here)
                 for i, results in gen_entry.items():
-                    self._apply_one(udfs[i], results, task)
+                    self._apply_one(udfs[i], results, task, damage)
                 publish_device(final=False)
                 yield n_done
             elif gen_entry:
@@ -796,7 +796,7 @@ class HipJobExecutor(JobExecutor):
                 # the UDF's own merge(), then combine the full-size host buffers
                 for task, entry in generic_parts:
                     if i in entry:
-                        self._apply_one(udf, entry[i], task)
+                        self._apply_one(udf, entry[i], task, damage)
                 if self._collectives_on:
                     import torch as _t
                     for name, how in decl.items():
@@ -822,7 +822,7 @@ class HipJobExecutor(JobExecutor):
                 task = by_idx[tidx]
                 for i in gen_idx:
                     if i in entry:
-                        self._apply_one(udfs[i], entry[i], task)
+                        self._apply_one(udfs[i], entry[i], task, damage)
         # damage: with sharding every partition was processed by some rank
         if self._collectives_on:
             for task in self._all_tasks:
@@ -846,7 +846,13 @@ class HipJobExecutor(JobExecutor):
         return pinned.numpy()
 
     @staticmethod
-    def _apply_one(udf, results, task):
+    def _apply_one(udf, results, task, damage=None):
+        if damage is not None:
+            # what is merged SO FAR (udf/base.py:2351) -- some callers mark the task's rows before merging them
+            seen = np.array(damage.raw_data, copy=True)
+            a, b = damage._slice_for_partition(task.partition)
+            seen[a:b] = False
+            udf.meta.set_valid_nav_mask(seen)
         udf.set_views_for_partition(task.partition)
         udf.merge(dest=udf.results.get_proxy(), src=results.get_proxy())
         udf.clear_views()

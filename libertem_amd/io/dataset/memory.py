@@ -39,7 +39,11 @@ class MemoryDataSet(DataSet):
                  sync_offset=0, array_backends=None, dtype=None, shard=None):
         super().__init__()
         if data is None:
-            raise DataSetException("MemoryDataSet needs data")
+            # (reference io/dataset/memory.py:222-226: float32 zeros of `datashape`)
+            if datashape is None:
+                raise DataSetException('MemoryDataSet can be created from either data [np.ndarray], or datashape '
+                                       '[tuple | Shape], both arguments are None')
+            data = np.zeros(tuple(datashape), dtype=np.float32)
         if io_backend is not None:
             raise ValueError("MemoryDataSet currently doesn't support alternative I/O backends")
         self._device_array = None

@@ -32,7 +32,7 @@ from libertem_amd.common.math import prod
 from libertem_amd.common.slice import Slice
 from libertem_amd.common.shape import Shape
 from libertem_amd.common.buffers import (
-    BufferWrapper, AuxBufferWrapper, PlaceholderBufferWrapper, PreallocBufferWrapper, HipSigView,
+    BufferWrapper, AuxBufferWrapper, PlaceholderBufferWrapper, PreallocBufferWrapper, HipSigView, ArrayWithMask,
 )
 from libertem_amd.common.hiparray import HipArray
 from libertem_amd.common.fingerprint import fingerprint, is_opaque
@@ -213,7 +213,13 @@ class MergeAttrMapping:
             raise AttributeError(k)
 
     def __setattr__(self, k, v):
-        raise TypeError(f"cannot re-assign attribute {k}, did you mean `.{k}[:] = ...`?")
+        # `dest.x = value` and `dest.x += value` write INTO the buffer (udf/base.py:609-613)
+        if k == '_dict':
+            object.__setattr__(self, k, v)
+            return
+        target = self._dict[k]
+        if target is not v:                      # (`+=` on an array already updated it in place)
+            target[:] = v
 
     def __getitem__(self, k):
         return self._dict[k]
@@ -251,9 +257,13 @@ class UDFData:
 
     def __setattr__(self, k, v):
         if not k.startswith("_"):
-            raise AttributeError(
-                "cannot re-assign attribute %s, did you mean `.%s[:] = ...`?" % (k, k))
-        super().__setattr__(k, v)
+            # `self.results.x = value` and `self.results.x += value` are slice assignments into the current view
+            # (udf/base.py:673-678)
+            target = getattr(self, k)
+            if target is not v:                  # (`+=` on an array already updated it in place)
+                target[:] = v
+        else:
+            super().__setattr__(k, v)
 
     def _get_view_or_data(self, k):
         if k in self._views:
@@ -492,7 +502,7 @@ class UDFBase(UDFProtocol):
         results = {}
         for name, arr in results_tmp.items():
             mask = None
-            if hasattr(arr, 'arr') and hasattr(arr, 'mask'):      # ArrayWithMask
+            if isinstance(arr, ArrayWithMask):
                 arr, mask = arr.arr, arr.mask
             if not isinstance(arr, HipArray):   # (HipArray: a run with result_where='device')
                 arr = to_numpy(arr)
@@ -505,7 +515,10 @@ class UDFBase(UDFProtocol):
             buf.set_shape_ds(self.meta.dataset_shape, self.meta.roi)
             if mask is None:
                 vm = self.meta.get_valid_nav_mask()
-                mask = buf.make_default_mask(vm) if vm is not None else None
+                mask = None if vm is None else buf.make_default_mask(
+                    valid_nav_mask=vm, dataset_shape=self.meta.dataset_shape, roi=self.meta.roi)
+            else:
+                mask = np.asarray(mask).reshape(buf.shape)
             buf.valid_mask = mask
             results[name] = buf
         return results
@@ -614,8 +627,9 @@ class UDF(UDFBase):
 
     @staticmethod
     def with_mask(data, mask):
-        from types import SimpleNamespace
-        return SimpleNamespace(arr=data, mask=mask)
+        """`data` with its own valid-mask, for `get_results` (udf/base.py:1611-1642): a bool array that broadcasts to
+        `data.shape`, or True / False; InvalidMaskError otherwise"""
+        return ArrayWithMask(data, mask=mask)
 
     def buffer(self, kind, extra_shape=(), dtype="float32", where=None, use=None):
         """Declare a result buffer (udf/base.py:1644-1692)."""
@@ -1051,6 +1065,7 @@ class UDFRunner:
     @staticmethod
     def _apply_part_result(udfs, damage, part_results, task):
         for results, udf in zip(part_results, udfs):
+            udf.meta.set_valid_nav_mask(damage.raw_data)        # (what is merged so far: udf/base.py:2351)
             udf.set_views_for_partition(task.partition)
             udf.merge(dest=udf.results.get_proxy(), src=results.get_proxy())
             udf.clear_views()

@@ -1303,3 +1303,34 @@ def test_in_place_page_locking_only_for_own_mappings(tmp_path, monkeypatch):
     n = len(asked)
     assert M._register_host(FakeTorch, foreign) is None and asked[n:] == [foreign.nbytes]    # round 5's rule: >= 32 MiB
     assert M._register_host(FakeTorch, foreign[:1 << 20]) is None and len(asked) == n + 1    # ... smaller: never
+
+
+def test_mask_container_get_masks_for_slice_and_getroi():
+    """MaskContainer.get_masks_for_slice (common/container.py:316-333): the host matrix of a sig-only slice, dense
+    and scipy CSR; analysis/getroi.py"""
+    import scipy.sparse as sp
+    from libertem_amd.common.container import MaskContainer
+    from libertem_amd.common import Shape, Slice
+    from libertem_amd.analysis.getroi import get_roi
+    from libertem_amd import masks as M
+    rng = np.random.default_rng(4)
+    stack = rng.random((3, 8, 8)).astype(np.float32)
+    stack[stack < 0.7] = 0
+    sl = Slice(origin=(2, 4), shape=Shape((4, 4), sig_dims=2))
+    mc = MaskContainer([lambda i=i: stack[i] for i in range(3)], dtype=np.float32, use_sparse=False, count=3)
+    dense = mc.get_masks_for_slice(sl)
+    assert isinstance(dense, np.ndarray) and dense.shape == (16, 3)
+    assert np.array_equal(dense, stack[:, 2:6, 4:8].reshape(3, 16).T)
+    assert np.array_equal(mc.get_masks_for_slice(sl, transpose=False), dense.T)
+    ms = MaskContainer([lambda i=i: sp.csr_matrix(stack[i]) for i in range(3)], dtype=np.float32,
+                       use_sparse='scipy.sparse', count=3)
+    sparse = ms.get_masks_for_slice(sl)
+    assert sp.issparse(sparse) and sparse.shape == (16, 3)
+    assert np.array_equal(sparse.toarray(), dense)
+    assert np.array_equal(mc.get(Slice(origin=(0, 2, 4), shape=Shape((5, 4, 4), sig_dims=2))), dense)
+
+    assert get_roi({}, (4, 6)) is None and get_roi({"roi": {}}, (4, 6)) is None
+    disk = get_roi({"roi": {"shape": "disk", "cx": 2, "cy": 1, "r": 1.5}}, (4, 6))
+    assert disk.shape == (4, 6) and np.array_equal(disk, M.circular(2, 1, 6, 4, 1.5))
+    rect = get_roi({"roi": {"shape": "rect", "x": 1, "y": 0, "width": 3, "height": 2}}, (4, 6))
+    assert np.array_equal(rect, M.rectangular(1, 0, 3, 2, 6, 4)) and rect.sum() == 12      # (both edges belong: masks.py:370-411)

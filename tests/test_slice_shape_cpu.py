@@ -162,3 +162,33 @@ def test_shape_algebra():
         assert str(t[0]) in repr(s)
     empty = Shape((0, 4, 4), sig_dims=2)
     assert empty.size == 0 and empty.nav.size == 0 and empty.sig.size == 16
+
+
+def test_slice_clip_to():
+    """Slice.clip_to (common/slice.py:397-399): the part inside an array of a shape anchored at the origin"""
+    from libertem_amd.common.slice import Slice
+    from libertem_amd.common.shape import Shape
+    s = Slice(origin=(2, 3, 4), shape=Shape((4, 10, 10), sig_dims=2))
+    c = s.clip_to(Shape((4, 8, 8), sig_dims=2))
+    assert tuple(c.origin) == (2, 3, 4) and tuple(c.shape) == (2, 5, 4)
+    inside = Slice(origin=(0, 1, 1), shape=Shape((2, 3, 3), sig_dims=2))
+    assert inside.clip_to(Shape((4, 8, 8), sig_dims=2)) == inside
+    assert Slice(origin=(5, 0, 0), shape=Shape((2, 3, 3), sig_dims=2)).clip_to(Shape((4, 8, 8), sig_dims=2)).is_null()
+
+
+def test_scale_rotate_flip_y_round_trip():
+    """corrections/coordinates.py:57-93: (scale, angle, flip) of scale() @ rotate() @ flip_y(); shear and unequal
+    scales are refused"""
+    import pytest
+    from libertem_amd.corrections import coordinates as c
+    for sc, ang, fl in [(2.5, 0.3, False), (1., -2.1, True), (0.7, 3.0, True), (4., 0., False), (1.5, np.pi / 2, True)]:
+        m = c.scale(sc) @ c.rotate(ang) @ (c.flip_y() if fl else c.identity())
+        s2, a2, f2 = c.scale_rotate_flip_y(m)
+        assert np.isclose(s2, sc) and f2 is fl
+        assert np.allclose((np.sin(a2), np.cos(a2)), (np.sin(ang), np.cos(ang)))
+        back = c.scale(s2) @ c.rotate(a2) @ (c.flip_y() if f2 else c.identity())
+        assert np.allclose(back, m)
+    with pytest.raises(ValueError, match='are different'):
+        c.scale_rotate_flip_y(np.array([(2., 0.), (0., 1.)]))
+    with pytest.raises(ValueError, match='shear'):
+        c.scale_rotate_flip_y(np.array([(1., 1.), (0., 1.)]) / np.array([1., np.sqrt(2.)]))

@@ -2503,3 +2503,49 @@ def test_sparse_stack_on_complex_frames_non_finite_pixels(ctx, mask_dtype):
     assert np.array_equal(np.isnan(g2[nan_frames].imag), np.isnan(r2[nan_frames].imag))
     ok = np.isfinite(ref)
     assert np.allclose(got[ok], ref[ok], rtol=F32_TOL, atol=F32_TOL * np.abs(ref[ok]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('spec', [
+    {"shape": "disk", "cx": 5, "cy": 6, "r": 7},
+    {"shape": "disk", "cx": -1, "cy": -1, "r": 0},                       # nothing selected
+    {"shape": "rect", "x": 3, "y": 2, "width": 6, "height": 9},
+])
+def test_analysis_roi_parameter(ctx, spec):
+    """`parameters={'roi': {...}}` of SumAnalysis / MasksAnalysis (analysis/sum.py:100-101, analysis/masks.py:179-180,
+    analysis/getroi.py): the reference's tests/analysis/test_analysis_sum.py:171-240 (`test_sum_with_roi`,
+    `test_sum_zero_roi`) re-expressed, plus the rectangle and the masks analysis."""
+    from libertem_amd import masks as M
+    from libertem_amd.analysis.sum import SumAnalysis
+    from libertem_amd.analysis.masks import MasksAnalysis
+    rng = np.random.default_rng(11)
+    data = rng.integers(0, 4096, (16, 16, 16, 16)).astype('<u2')
+    ds = _device_ds(ctx, data, 8)
+    if spec["shape"] == "disk":
+        mask = M.circular(spec["cx"], spec["cy"], 16, 16, spec["r"])
+    else:
+        mask = M.rectangular(spec["x"], spec["y"], spec["width"], spec["height"], 16, 16)
+    assert mask.shape == (16, 16) and mask.dtype == bool
+    analysis = SumAnalysis(dataset=ds, parameters={"roi": spec})
+    assert np.array_equal(analysis.get_roi(), mask)
+    results = ctx.run(analysis)
+    expected = data[mask, ...].astype(np.float64).sum(axis=0)
+    assert results['intensity'].raw_data.shape == (16, 16)
+    assert not np.allclose(results['intensity'].raw_data, data.astype(np.float64).sum(axis=(0, 1)))
+    assert np.allclose(results['intensity'].raw_data, expected)
+    assert np.allclose(results['intensity_lin'].raw_data, expected)
+
+    stack = rng.random((3, 16, 16)).astype(np.float32)
+    ma = MasksAnalysis(dataset=ds, parameters={"factories": [lambda i=i: stack[i] for i in range(3)], "roi": spec})
+    assert np.array_equal(ma.get_roi(), mask)
+    res = ctx.run(ma)
+    want = np.einsum('nyx,kyx->nk', data[mask].astype(np.float64), stack.astype(np.float64))
+    for k in range(3):
+        got = res[f'mask_{k}'].raw_data
+        assert got.shape == (16, 16)
+        assert np.all(np.isnan(got[~mask]))                      # outside the roi: the fill value of float buffers
+        if mask.any():
+            assert np.allclose(got[mask], want[:, k], rtol=F32_TOL)
+    assert SumAnalysis(dataset=ds, parameters={}).get_roi() is None
+    with pytest.raises(NotImplementedError, match='unknown shape'):
+        SumAnalysis(dataset=ds, parameters={"roi": {"shape": "star"}}).get_roi()
