@@ -316,8 +316,9 @@ class Context:
     def map(self, dataset, f, roi=None, progress=False, corrections=None, backends=None):
         """Apply `f` to every frame; result is kind='nav' (reference api.py:1617-1670)."""
         from libertem_amd.udf.auto import AutoUDF
-        return self.run_udf(dataset=dataset, udf=AutoUDF(f=f), roi=roi, progress=progress,
-                            corrections=corrections, backends=backends)
+        results = self.run_udf(dataset=dataset, udf=AutoUDF(f=f), roi=roi, progress=progress,
+                               corrections=corrections, backends=backends)
+        return results['result']
 
     def close(self):
         # the datasets this context loaded give up their upload stagers (device buffers, copy stream and the

@@ -1,4 +1,4 @@
 from .shape import Shape
-from .slice import Slice
+from .slice import Slice, SliceUsageError
 
-__all__ = ['Shape', 'Slice']
+__all__ = ['Shape', 'Slice', 'SliceUsageError']

@@ -101,6 +101,13 @@ def get_bbox_slice(arr):
     return tuple(slice(b[2 * i], b[2 * i + 1] + 1, None) for i in range(len(b) // 2))
 
 
+def reshaped_view(a, shape):
+    """`a` with another shape, as a VIEW: AttributeError where NumPy would have to copy (reference :94-119)"""
+    res = a.view()
+    res.shape = shape
+    return res
+
+
 def disjoint(sl, slices):
     """True iff `sl` overlaps none of `slices` (reference common/buffers.py:122-123)"""
     return all(sl.intersection_with(o).is_null() for o in slices)
@@ -444,21 +451,23 @@ class PlaceholderBufferWrapper(BufferWrapper):
     def export(self):
         pass
 
-    def _err(self, *a, **k):
-        raise RuntimeError("result_only buffers are only available in get_results()")
+    def _no_view(self, *a, **k):
+        return None
 
-    get_view_for_partition = _err
-    get_view_for_tile = _err
-    get_view_for_frame = _err
-    get_contiguous_view_for_tile = _err
+    get_view_for_partition = _no_view
+    get_view_for_tile = _no_view
+    get_view_for_frame = _no_view
+    get_contiguous_view_for_tile = _no_view
 
     @property
     def data(self):
-        self._err()
+        raise ValueError("this BufferWrapper doesn't have a value associated with it "
+                         "(use='result_only': it only exists in what get_results() returns)")
 
     @property
     def raw_data(self):
-        self._err()
+        raise ValueError("this BufferWrapper doesn't have a value associated with it "
+                         "(use='result_only': it only exists in what get_results() returns)")
 
     def result_buffer_type(self):
         return BufferWrapper
@@ -500,6 +509,9 @@ class AuxBufferWrapper(BufferWrapper):
         return new
 
     def get_view_for_dataset(self, dataset):
+        # the positions the run covers (reference :1025-1026)
+        if self._kind == 'nav' and self._roi is not None and self._data_coords_global:
+            return self._data[self._roi]
         return self._data
 
     def get_view_for_partition(self, partition):

@@ -45,7 +45,8 @@ class Shape:
 
     @property
     def size(self):
-        return prod(self._t)
+        # (a shape without dimensions covers nothing: common/shape.py:83-99)
+        return prod(self._t) if self._t else 0
 
     def to_tuple(self):
         return self._t
@@ -79,14 +80,20 @@ class Shape:
         return hash((self._t, self._sig_dims))
 
     def __add__(self, other):
-        return self._t + tuple(other)
+        """shape + tuple: more SIGNAL dimensions (common/shape.py:176-186)"""
+        if not isinstance(other, tuple):
+            return NotImplemented
+        return Shape(self._t + other, sig_dims=self._sig_dims + len(other))
 
     def __radd__(self, other):
-        return tuple(other) + self._t
+        """tuple + shape: more NAVIGATION dimensions, behind the ones it has (common/shape.py:188-198)"""
+        if not isinstance(other, tuple):
+            return NotImplemented
+        nd = len(self._t) - self._sig_dims
+        return Shape(self._t[:nd] + other + self._t[nd:], sig_dims=self._sig_dims)
 
     def __repr__(self):
-        return f"{tuple(self.nav._t)!r}+{tuple(self.sig._t)!r}" if type(self) is Shape \
-            else repr(self._t)
+        return repr(self._t)
 
     def __getstate__(self):
         return {'_t': self._t, '_sig_dims': self._sig_dims}

@@ -45,6 +45,9 @@ class Slice:
 
     def intersection_with(self, other):
         """Overlap of two slices; an empty overlap yields a slice with zero-sized shape."""
+        if len(self.origin) != len(other.origin):
+            raise SliceUsageError(
+                f"cannot intersect slices of different dimensionality ({len(self.origin)} vs {len(other.origin)})")
         if self.shape.sig_dims != other.shape.sig_dims:
             raise SliceUsageError("cannot intersect slices with different sig dims")
         lo = [max(a, b) for a, b in zip(self.origin, other.origin)]

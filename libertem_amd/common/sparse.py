@@ -76,6 +76,39 @@ class SparseStack:
     def __len__(self):
         return self.n_masks
 
+    def __getitem__(self, k):
+        """`stack[i]`: mask i as a sig-shaped stack of one -- `.todense()` gives the 2-D array, like indexing the
+        reference's `sparse.COO` stacks (tests/test_masks.py:39-60); a slice / index array: a sub-stack"""
+        if isinstance(k, (int, np.integer)):
+            i = int(k) + (self.n_masks if k < 0 else 0)
+            if not 0 <= i < self.n_masks:
+                raise IndexError(f"mask {k} of a stack of {self.n_masks}")
+            sel = self.mask_idx == i
+            return _SparseMask(self.data[sel], self.px_idx[sel], self.sig_shape)
+        idx = np.arange(self.n_masks)[k]
+        lut = np.full(self.n_masks, -1, dtype=np.int64)
+        lut[idx] = np.arange(len(idx))
+        sel = lut[self.mask_idx] >= 0
+        return SparseStack(self.data[sel], lut[self.mask_idx[sel]], self.px_idx[sel], len(idx), self.sig_shape)
+
+    def sum(self, axis=None):
+        """axis=None: the sum of all entries; axis=0: over the masks (a sig-shaped sparse result with `.todense()`);
+        the sig axes (1 ..): per mask, dense"""
+        if axis is None:
+            return self.data.sum()
+        axes = (axis,) if isinstance(axis, (int, np.integer)) else tuple(axis)
+        axes = tuple(sorted(a + (len(self.shape) if a < 0 else 0) for a in axes))
+        if axes == (0,):
+            m = sp.coo_matrix((self.data, (np.zeros(self.nnz, dtype=np.int64), self.px_idx)),
+                              shape=(1, prod(self.sig_shape))).tocsr()
+            m = m.tocoo()
+            return _SparseMask(m.data, m.col.astype(np.int64), self.sig_shape)
+        if axes == tuple(range(1, len(self.shape))):
+            out = np.zeros(self.n_masks, dtype=self.data.dtype)
+            np.add.at(out, self.mask_idx, self.data)
+            return out
+        return self.todense().sum(axis=axis)
+
     def astype(self, dtype):
         return SparseStack(self.data.astype(dtype), self.mask_idx, self.px_idx, self.n_masks,
                            self.sig_shape)
@@ -127,3 +160,30 @@ def to_sparse_stack(a):
     if isinstance(a, SparseStack):
         return a
     return SparseStack.from_dense(np.asarray(a))
+
+
+class _SparseMask:
+    """one sig-shaped sparse array (what `stack[i]` and `stack.sum(axis=0)` give)"""
+
+    def __init__(self, data, px_idx, sig_shape):
+        self.data, self.px_idx, self.shape = np.asarray(data), np.asarray(px_idx, dtype=np.int64), tuple(sig_shape)
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+    @property
+    def nnz(self):
+        return len(self.data)
+
+    def todense(self):
+        out = np.zeros(prod(self.shape), dtype=self.data.dtype)
+        np.add.at(out, self.px_idx, self.data)
+        return out.reshape(self.shape)
+
+    def sum(self):
+        return self.data.sum()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.todense()
+        return a if dtype is None else a.astype(dtype)

@@ -90,6 +90,15 @@ class TilingScheme:
         subslices = list(sig_slice.subslices(tuple(tileshape.sig)))
         return cls(subslices, tileshape, dataset_shape, intent=intent, debug=debug)
 
+    def adjust_for_partition(self, partition):
+        """process_partition takes WHOLE partitions: with that intent the depth follows the partition's number of
+        frames, whatever depth the scheme was made with (tiling_scheme.py:39-70); otherwise self"""
+        n = int(partition.slice.shape.nav.size)
+        if self._intent != 'partition' or n == self.depth:
+            return self
+        shape = Shape((n,) + tuple(self._tileshape.sig), sig_dims=self._tileshape.sig.dims)
+        return TilingScheme(self._slices, shape, self._dataset_shape, intent=self._intent, debug=self._debug)
+
     def __getitem__(self, idx):
         return self._slices[idx]
 
@@ -377,9 +386,25 @@ class Partition:
         return f"<{type(self).__name__} idx={self._idx} slice={self.slice}>"
 
 
+class RoiHelper:
+    """`ds.roi[index]`: a bool nav mask with the indexed positions set (reference base/dataset.py:21-28)"""
+
+    def __init__(self, ds):
+        self._ds = ds
+
+    def __getitem__(self, k):
+        roi = np.zeros(tuple(self._ds.shape.nav), dtype=bool)
+        roi[k] = True
+        return roi
+
+
 class DataSet:
     def __init__(self):
         self._meta = None
+
+    @property
+    def roi(self):
+        return RoiHelper(self)
 
     def __getstate__(self):
         d = dict(self.__dict__)

@@ -99,6 +99,25 @@ class MemoryDataSet(DataSet):
             full_shape = tuple(nav_s) + tuple(sig_s)
         if len(full_shape) <= sig_dims:
             raise DataSetException("data must have at least one navigation dimension")
+        sync_offset = int(sync_offset or 0)
+        if sync_offset != 0:
+            # frame g of `data` belongs to scan position g - sync_offset (reference io/dataset/memory.py:352-406 via
+            # base/partition.py): positive offsets skip frames, negative ones leave the first positions blank.
+            # Positions without a frame hold ZERO frames here (like RawFileDataSet / MIBDataSet of this package;
+            # the reference does not deliver them to the UDFs at all: the same sums, masks and CoM results).
+            if self._data is None or shard is not None:
+                raise DataSetException("sync_offset of a MemoryDataSet needs host data held by one process")
+            n_sig = prod(full_shape[-sig_dims:])
+            n_nav = prod(full_shape[:-sig_dims])
+            if not (-n_nav < sync_offset < n_nav):
+                raise DataSetException(
+                    f"offset should be in ({-n_nav}, {n_nav}), which is (-image_count, image_count)")
+            frames = self._data.reshape((n_nav, n_sig))
+            skip, lead = max(0, sync_offset), max(0, -sync_offset)
+            avail = max(0, min(n_nav - skip, n_nav - lead))
+            moved = np.zeros_like(frames)
+            moved[lead:lead + avail] = frames[skip:skip + avail]
+            self._data = moved.reshape(full_shape)
         self._local_shape = Shape(full_shape, sig_dims=sig_dims)
         if self._shard is not None:
             full_shape = (full_shape[0] * self._shard[1],) + tuple(full_shape[1:])
@@ -675,6 +694,7 @@ class MemPartition(Partition):
             tiling_scheme = TilingScheme.make_for_shape(
                 tileshape=Shape(ds.tileshape, sig_dims=ds.shape.sig.dims),
                 dataset_shape=ds.shape, intent=tiling_scheme.intent)
+        tiling_scheme = tiling_scheme.adjust_for_partition(self)
         if array_backend == HIP:
             yield from self._get_tiles_hip(tiling_scheme, roi, env, np.dtype(dest_dtype),
                                            corrections)

@@ -825,9 +825,8 @@ class UDFPartRunner:
                     udf.allocate_for_part(partition, roi,
                                           target=self._result_target(env, i, partition))
                     if hasattr(udf, 'preprocess'):
-                        udf.set_views_for_partition(partition)
+                        udf.clear_views()           # (the task's whole buffers: udf/base.py:2250-2252)
                         udf.preprocess()
-                        udf.clear_views()
                 # the launches of this task, for the executor's launch-ahead of later runs (hip.LaunchReplay):
                 # recorded once, on the first re-run of the kept instances
                 from libertem_amd import hip as _hip
@@ -895,16 +894,19 @@ class UDFPartRunner:
         meta.sig_sliced_tiles = bool(
             forced is not None and tuple(forced)[-len(tuple(partition.meta.shape.sig)):]
             != tuple(partition.meta.shape.sig))
+        # until the first tile, `meta.slice` / `meta.coordinates` describe the whole partition (compressed to the roi):
+        # get_task_data / preprocess may look at them (udf/base.py:2238-2247)
+        pslice = partition.slice if roi is None else partition.slice.adjust_for_roi(roi)
         for i, udf in enumerate(self._udfs):
             udf.set_backend(backend)
             udf.set_meta(meta)
+            udf.set_slice(pslice)
             udf.init_result_buffers()
             udf.allocate_for_part(partition, roi, target=self._result_target(env, i, partition))
             udf.init_task_data()
             if hasattr(udf, 'preprocess'):
-                udf.set_views_for_partition(partition)
+                udf.clear_views()                   # (the task's whole buffers: udf/base.py:2250-2252)
                 udf.preprocess()
-                udf.clear_views()
         return meta
 
     @staticmethod
@@ -975,7 +977,16 @@ class UDFPartRunner:
                     sinkable.append((i, udf, names))
         for tile in tiles:
             for udf, method in zip(self._udfs, methods):
-                self._run_tile(udf, method, partition, tile)
+                try:
+                    self._run_tile(udf, method, partition, tile)
+                except AttributeError as e:
+                    # tiles are plain arrays: what DataTile objects once carried is on `self.meta`
+                    # (udf/base.py:2196-2206)
+                    for old, new in (('tile_slice', 'self.meta.slice'), ('scheme_idx', 'self.meta.tiling_scheme_idx')):
+                        if e.args and isinstance(e.args[0], str) and old in e.args[0]:
+                            raise AttributeError(
+                                f'Attribute {old} for input tiles was removed. Please use {new} instead.') from e
+                    raise
             if sinkable:
                 for i, udf, names in sinkable:
                     for name in names:
@@ -1193,7 +1204,15 @@ class UDFRunner:
         )
         for udf in self._udfs:
             udf.set_meta(meta)
-            udf.get_method()          # validity check
+            method = udf.get_method()
+            # a `get_method` of the UDF's own may name what it likes: it has to be a UDFMethod whose process_*
+            # exists (udf/base.py:2515-2526)
+            if not isinstance(method, UDFMethod):
+                raise UDFException('UDF.get_method() returned unrecognized value')
+            need = {UDFMethod.TILE: 'process_tile', UDFMethod.FRAME: 'process_frame',
+                    UDFMethod.PARTITION: 'process_partition'}[method]
+            if not callable(getattr(udf, need, None)):
+                raise UDFException(f'UDF declared method {method.value} but does not implement {need}.')
             udf.init_result_buffers()
             udf.allocate_for_full(dataset, roi)
             if hasattr(udf, 'preprocess'):
@@ -1235,7 +1254,9 @@ class UDFRunner:
     def run_for_dataset_sync(self, dataset, executor, roi=None, progress=False, corrections=None,
                              backends=None, dry=False, iterate=True, result_where=None):
         if roi is not None:
-            roi = np.asarray(roi, dtype=bool)
+            # a private copy: the result buffers keep the roi, and the caller may reuse its array for the next run
+            # (reference tests/udf/test_simple_udf.py test_copy_roi)
+            roi = np.array(roi, dtype=bool, copy=True)
         # a cache hit by identity may compare the parameter CONTENTS behind the enqueued kernels
         # (executor hook); a partial-result iteration publishes early, so it compares up front
         defer = (not iterate) and hasattr(executor, 'set_before_wait')

@@ -147,7 +147,8 @@ def test_shape_algebra():
         s = Shape(t, sig_dims=min(sig_dims, dims))
         k = dims - s.sig_dims
         assert tuple(s.nav) == t[:k] and tuple(s.sig) == t[k:]
-        assert s.size == int(np.prod(t)) and s.nav.size == int(np.prod(t[:k], dtype=np.int64))
+        # (a shape without dimensions has size 0: reference tests/common/test_shape.py test_size_nav_zero)
+        assert s.size == int(np.prod(t)) and s.nav.size == (int(np.prod(t[:k], dtype=np.int64)) if k else 0)
         assert s.sig.size == int(np.prod(t[k:]))
         assert s.dims == dims and s.nav.dims == k and s.sig.dims == s.sig_dims
         if k:
@@ -157,11 +158,17 @@ def test_shape_algebra():
         assert s == Shape(t, sig_dims=s.sig_dims) and hash(s) == hash(Shape(t, sig_dims=s.sig_dims))
         if s.sig_dims != 1 and dims > 1:
             assert s != Shape(t, sig_dims=1)
-        assert s + (9,) == t + (9,) and (9,) + s == (9,) + t
+        # shape + tuple: more sig dimensions; tuple + shape: more nav dimensions, behind the existing ones
+        # (reference tests/common/test_shape.py test_shape_add_1 / _2)
+        right, left = s + (9, 8), (9, 8) + s
+        assert isinstance(right, Shape) and tuple(right) == t + (9, 8) and right.sig.dims == s.sig_dims + 2
+        assert isinstance(left, Shape) and tuple(left) == t[:k] + (9, 8) + t[k:] and left.sig.dims == s.sig_dims
+        assert repr(s) == repr(t)
         assert pickle.loads(pickle.dumps(s)) == s
         assert str(t[0]) in repr(s)
     empty = Shape((0, 4, 4), sig_dims=2)
     assert empty.size == 0 and empty.nav.size == 0 and empty.sig.size == 16
+    assert Shape((), sig_dims=0).size == 0 and Shape((128, 128), sig_dims=2).nav.size == 0
 
 
 def test_slice_clip_to():

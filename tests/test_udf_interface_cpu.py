@@ -1,0 +1,269 @@
+"""The UDF interface as user code sees it, cases of the reference's own interface tests re-expressed against this
+package (tests/udf/test_aux_data.py, test_coords.py, test_simple_udf.py, test_auto.py, tests/common/test_bufferwrapper.py,
+test_math.py, tests/test_masks.py): what `preprocess` / `get_task_data` can see, whole partitions for
+`process_partition`, the errors for outdated or impossible UDFs, `ds.roi[...]`, `Context.map` / AutoUDF, sparse
+mask stacks as arrays, `sync_offset` of a MemoryDataSet.  NumPy UDFs on the inline executor: no GPU."""
+import functools
+
+import numpy as np
+import pytest
+
+from libertem_amd.api import Context
+from libertem_amd.executor.inline import InlineJobExecutor
+from libertem_amd.udf.base import UDF
+from libertem_amd.udf.auto import AutoUDF
+from libertem_amd.common.udf import UDFMethod
+from libertem_amd.common.exceptions import UDFException
+from libertem_amd.common import Shape, Slice, SliceUsageError
+from libertem_amd.common.math import prod, make_2D_square, count_nonzero
+from libertem_amd.common.buffers import PlaceholderBufferWrapper, reshaped_view
+from libertem_amd.io.dataset.memory import MemoryDataSet
+from libertem_amd import masks as M
+
+
+@pytest.fixture
+def lt_ctx():
+    return Context(executor=InlineJobExecutor(debug=True))
+
+
+class EchoUDF(UDF):
+    """what the hooks see of a nav-kind aux buffer (test_aux_data.py:10-39)"""
+
+    def get_result_buffers(self):
+        return {k: self.buffer(kind="nav", dtype="float32", extra_shape=(2,))
+                for k in ('echo', 'echo_preprocess', 'echo_postprocess')} | \
+            {'weighted': self.buffer(kind="nav", dtype="float32")}
+
+    def preprocess(self):
+        self.results.echo_preprocess[:] = self.params.aux          # the whole task's rows, on both sides
+
+    def process_frame(self, frame):
+        assert self.params.aux.shape == (2,)
+        self.results.echo[:] = self.params.aux
+        self.results.weighted[:] = np.sum(frame) * self.params.aux[0]
+
+    def postprocess(self):
+        self.results.echo_postprocess[:] = self.params.aux
+
+
+@pytest.mark.parametrize('with_roi', [False, True])
+def test_aux_data_in_every_hook(lt_ctx, with_roi):
+    rng = np.random.default_rng(3)
+    data = rng.random((16, 16, 8, 8)).astype(np.float32)
+    aux = rng.random((16, 16, 2)).astype(np.float32)
+    ds = lt_ctx.load("memory", data=data, tileshape=(7, 8, 8), num_partitions=2, sig_dims=2)
+    roi = rng.random((16, 16)) < 0.5 if with_roi else None
+    udf = EchoUDF(aux=EchoUDF.aux_data(kind="nav", data=aux, dtype="float32", extra_shape=(2,)), other_stuff=object())
+    res = lt_ctx.run_udf(dataset=ds, udf=udf, roi=roi)
+    sel = slice(None) if roi is None else roi
+    for k in ('echo', 'echo_preprocess', 'echo_postprocess'):
+        assert np.array_equal(res[k].raw_data, aux[sel].reshape(-1, 2)), k
+    assert np.allclose(res['weighted'].raw_data, (data.sum(axis=(2, 3)) * aux[..., 0])[sel].reshape(-1), rtol=1e-5)
+
+
+class CoordsInGetTaskData(UDF):
+    """`meta.slice` / `meta.coordinates` describe the whole partition until the first tile (test_coords.py:177-213)"""
+
+    def get_result_buffers(self):
+        return {'counter': self.buffer(kind='single', dtype=np.int64),
+                'first': self.buffer(kind='nav', dtype=np.int64, extra_shape=(2,))}
+
+    def process_tile(self, tile):
+        self.results.first[:] = self.meta.coordinates
+
+    def get_task_data(self):
+        assert self.meta.slice is not None
+        c = self.meta.coordinates
+        assert c.shape == (self.meta.slice.shape[0], 2)
+        return {'ps': np.zeros((c.shape[0],), dtype=bool), 'coords': c}
+
+    def postprocess(self):
+        self.results.counter[0] += self.task_data.ps.shape[0]
+        assert np.array_equal(self.results.first, self.task_data.coords)     # the tiles' coordinates add up to it
+
+    def merge(self, dest, src):
+        dest.counter += src.counter
+        dest.first[:] = src.first
+
+
+def test_coordinates_available_before_the_first_tile(lt_ctx):
+    data = np.zeros((16, 16, 4, 4), dtype=np.float32)
+    ds = lt_ctx.load("memory", data=data, tileshape=(7, 4, 4), num_partitions=2, sig_dims=2)
+    roi = np.random.default_rng(8).choice([True, False], (16, 16))
+    res = lt_ctx.run_udf(dataset=ds, udf=CoordsInGetTaskData(), roi=roi)
+    assert res['counter'].data[0] == np.count_nonzero(roi)
+    assert np.array_equal(res['first'].raw_data, np.argwhere(roi))
+
+
+class WholePartition(UDF):
+    def get_result_buffers(self):
+        return {'sums': self.buffer(kind='nav', dtype=np.float64), 'depths': self.buffer(kind='nav', dtype=np.int64)}
+
+    def process_partition(self, partition):
+        assert self.meta.slice.shape[0] == self.meta.partition_shape[0]          # every frame of the partition
+        assert partition.shape[1:] == tuple(self.meta.sig_slice.shape)
+        self.results.sums[:] += partition.sum(axis=(1, 2))
+        self.results.depths[:] = partition.shape[0]
+
+
+@pytest.mark.parametrize('tileshape', [(3, 3, 7), (15, 3, 7), (4, 1, 7)])
+def test_process_partition_takes_whole_partitions_whatever_the_tileshape(lt_ctx, tileshape):
+    """test_simple_udf.py:661-745: a depth forced on the dataset does not cut the partitions of process_partition"""
+    data = np.random.default_rng(2).random((30, 3, 7)).astype(np.float32)
+    ds = MemoryDataSet(data=data, tileshape=tileshape, num_partitions=2, sig_dims=2).initialize(lt_ctx.executor)
+    res = lt_ctx.run_udf(dataset=ds, udf=WholePartition())
+    assert np.all(res['depths'].data == 15)
+    assert np.allclose(res['sums'].data, data.astype(np.float64).sum(axis=(1, 2)))
+
+
+def test_outdated_tile_attributes_name_their_replacement(lt_ctx):
+    class Old1(UDF):
+        def get_result_buffers(self):
+            return {}
+
+        def process_tile(self, tile):
+            tile.scheme_idx
+
+    class Old2(Old1):
+        def process_tile(self, tile):
+            tile.tile_slice
+    ds = lt_ctx.load('memory', data=np.ones((2, 2, 4, 4)))
+    with pytest.raises(AttributeError, match='self.meta.tiling_scheme_idx'):
+        lt_ctx.run_udf(dataset=ds, udf=Old1())
+    with pytest.raises(AttributeError, match='self.meta.slice'):
+        lt_ctx.run_udf(dataset=ds, udf=Old2())
+
+
+@pytest.mark.parametrize('method', [42, UDFMethod.FRAME, UDFMethod.PARTITION, UDFMethod.TILE])
+def test_get_method_must_name_an_implemented_method(lt_ctx, method):
+    class Bad(UDF):
+        def __init__(self, method):
+            super().__init__(method=method)
+
+        def get_method(self):
+            return self.params.method
+
+        def get_result_buffers(self):
+            return {}
+    ds = lt_ctx.load('memory', data=np.ones((2, 2, 4, 4)))
+    with pytest.raises(UDFException):
+        lt_ctx.run_udf(dataset=ds, udf=Bad(method=method))
+
+
+def test_dataset_roi_helper_and_private_copy(lt_ctx):
+    class PerFrame(UDF):
+        def get_result_buffers(self):
+            return {'intensity': self.buffer(kind='nav', dtype=np.float32)}
+
+        def process_frame(self, frame):
+            self.results.intensity[:] = frame.sum()
+    data = np.arange(4, dtype=np.float32).reshape(2, 2, 1, 1) * np.ones((2, 2, 4, 4), dtype=np.float32)
+    ds = lt_ctx.load('memory', data=data)
+    roi = ds.roi[0, 1]
+    assert roi.shape == (2, 2) and roi.dtype == bool and roi.sum() == 1 and roi[0, 1]
+    assert ds.roi[:, 1].sum() == 2
+    res = lt_ctx.run_udf(dataset=ds, udf=PerFrame(), roi=roi)
+    before = res['intensity'].data.copy()
+    roi[:] = ds.roi[:, :]                                   # the caller reuses its array: the result must not move
+    assert np.array_equal(np.isnan(res['intensity'].data), np.isnan(before))
+    assert res['intensity'].data[0, 1] == 16. and np.isnan(res['intensity'].data[0, 0])
+
+
+def test_map_and_auto_udf(lt_ctx):
+    rng = np.random.default_rng(6)
+    data = rng.random((16, 8, 32, 64)).astype(np.float32)
+    ds = MemoryDataSet(data=data, tileshape=(8, 32, 64), num_partitions=2, sig_dims=2).initialize(lt_ctx.executor)
+    got = lt_ctx.map(dataset=ds, f=functools.partial(np.sum, axis=-1))       # the BUFFER, not a dict (api.py:1670)
+    assert got.data.shape == (16, 8, 32) and np.allclose(got.data, data.sum(axis=-1), rtol=1e-5)
+
+    def weird(frame):
+        return ["Shape %s" % str(frame.shape), dict(shape=frame.shape, sum=frame.sum()), lambda x: x, MemoryDataSet]
+    item = lt_ctx.map(dataset=ds, f=weird).data[0, 0]
+    assert len(item) == 4 and isinstance(item[0], str) and isinstance(item[1], dict) and item[2](1) == 1
+
+    for roi in (None, rng.random((16, 8)) < 0.5):
+        udf = AutoUDF(f=functools.partial(np.sum, axis=-1), monitor=True)
+        n = 0
+        for res in lt_ctx.run_udf_iter(dataset=ds, udf=udf, roi=roi):
+            valid = np.flatnonzero(res.damage.raw_data.reshape(-1))
+            last = valid[-1] if len(valid) else 0
+            assert np.allclose(res.buffers[0]['result'].raw_data[last], res.buffers[0]['monitor'].data)
+            n += 1
+        assert n == 2
+
+
+def test_placeholder_buffers_and_reshaped_view():
+    buf = PlaceholderBufferWrapper(kind='sig', dtype=np.float32)
+    with pytest.raises(ValueError, match="doesn't have a value"):
+        np.array(buf)
+    with pytest.raises(ValueError):
+        buf.raw_data
+    assert buf.get_view_for_partition(None) is None and not buf.has_data()
+    data = np.zeros((2, 5))
+    with pytest.raises(AttributeError):
+        reshaped_view(data[:, :3], (-1,))
+    v = reshaped_view(data, (-1,))
+    v[3] = 7
+    assert data[0, 3] == 7 and v.shape == (10,)
+
+
+def test_math_helpers():
+    assert prod([]) == 1 and prod((1, 2, 3)) == 6 and prod((-11, 2, 3)) == -66
+    assert prod((2**32, 2**32, 2**32)) == 2**96
+    assert prod(np.array((2**62, 2**62, 2**62), dtype=np.int64)) == 2**186
+    assert prod(Shape((1, 2, 3), sig_dims=1).nav) == 2 and prod((3, True)) == 3
+    for bad in ((1., 2, False), np.array((1., 1 + 2j, 1))):
+        with pytest.raises(ValueError):
+            prod(bad)
+    assert make_2D_square((16,)) == (4, 4) and make_2D_square((15,)) == (15,) and make_2D_square((1,)) == (1, 1)
+    assert make_2D_square((4, 4)) == (4, 4) and make_2D_square(()) == ()
+    with pytest.raises(ValueError):
+        make_2D_square((0,))
+    assert count_nonzero(np.eye(3)) == 3 and count_nonzero(np.zeros(4)) == 0
+
+
+def test_sparse_stacks_as_arrays():
+    """tests/test_masks.py:39-66: `stack[i].todense()`, `bins.sum(axis=0).todense()` -- soft radial bins add up to 1"""
+    stack = M.sparse_template_multi_stack(mask_index=(0, 1, 2), offsetY=(13, 14, 15), offsetX=(15, 14, 13),
+                                          template=np.ones((2, 3)), imageSizeY=32, imageSizeX=32)
+    for i, (y, x) in enumerate([(13, 15), (14, 14), (15, 13)]):
+        want = np.zeros((32, 32))
+        want[y:y + 2, x:x + 3] = 1
+        assert np.array_equal(stack[i].todense(), want)
+    assert np.array_equal(stack[-1].todense(), stack[2].todense()) and stack[1:].shape == (2, 32, 32)
+    with pytest.raises(IndexError):
+        stack[3]
+    bins = M.radial_bins(35, 37, 80, 80, n_bins=42)
+    assert bins.shape == (42, 80, 80)
+    total = bins.sum(axis=0).todense()
+    inside = np.hypot(*(np.mgrid[0:80, 0:80] - np.array([37, 35]).reshape(2, 1, 1))) < 30
+    assert total.shape == (80, 80) and np.allclose(total[inside], 1)
+    assert np.allclose(bins.sum(axis=(1, 2)), bins.todense().sum(axis=(1, 2)))
+    assert np.isclose(bins.sum(), bins.todense().sum())
+
+
+def test_memory_dataset_sync_offset(lt_ctx):
+    """frame g of the data sits at scan position g - sync_offset (the reference's tests/udf/test_coords.py offsets);
+    positions without a frame hold zero frames here"""
+    class PerFrame(UDF):
+        def get_result_buffers(self):
+            return {'s': self.buffer(kind='nav', dtype=np.float32)}
+
+        def process_frame(self, frame):
+            self.results.s[:] = frame.sum()
+    data = np.arange(64, dtype=np.float32).reshape(8, 8, 1, 1) * np.ones((8, 8, 2, 2), dtype=np.float32)
+    want = {62: [248., 252.] + [0.] * 62, -62: [0.] * 62 + [0., 4.], 3: [4. * g for g in range(3, 64)] + [0.] * 3}
+    for so, w in want.items():
+        ds = MemoryDataSet(data=data, num_partitions=2, sig_dims=2, sync_offset=so).initialize(lt_ctx.executor)
+        assert np.array_equal(lt_ctx.run_udf(dataset=ds, udf=PerFrame())['s'].data.reshape(-1), np.array(w, dtype=np.float32))
+    with pytest.raises(Exception, match='offset should be in'):
+        MemoryDataSet(data=data, sig_dims=2, sync_offset=64)
+
+
+def test_slices_of_different_dimensionality_do_not_intersect():
+    s1 = Slice(origin=(1, 1, 1, 1), shape=Shape((2, 2, 2, 2), sig_dims=2))
+    s2 = Slice(origin=(1, 1, 1), shape=Shape((2, 2, 2), sig_dims=2))
+    s3 = Slice(origin=(1, 1, 1, 1), shape=Shape((2, 2, 2, 2), sig_dims=1))
+    for other in (s2, s3):
+        with pytest.raises(SliceUsageError):
+            s1.intersection_with(other)
