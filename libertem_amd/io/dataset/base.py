@@ -358,6 +358,21 @@ class Partition:
             yield (Slice(origin=(start,) + (0,) * len(sig),
                          shape=Shape((stop - start,) + sig, sig_dims=len(sig))), start, stop)
 
+    def get_macrotile(self, dest_dtype="float32", roi=None, array_backend=None):
+        """The whole partition as ONE tile -- for code that wants process_partition-style input outside a run
+        (reference base/partition.py:133-170); an empty tile if the roi leaves nothing of the partition."""
+        scheme = TilingScheme.make_for_shape(tileshape=self.shape, dataset_shape=self.meta.shape, intent='partition')
+        kw = {} if array_backend is None else {'array_backend': array_backend}
+        tiles = list(self.get_tiles(scheme, dest_dtype=dest_dtype, roi=roi, **kw))
+        if len(tiles) > 1:
+            raise RuntimeError("a macrotile is a single tile")
+        if tiles:
+            return tiles[0]
+        sig = tuple(self.slice.shape.sig)
+        tile_slice = Slice(origin=(self.slice.origin[0],) + (0,) * len(sig),
+                           shape=Shape((0,) + sig, sig_dims=len(sig)))
+        return DataTile(np.zeros(tuple(tile_slice.shape), dtype=dest_dtype), tile_slice=tile_slice, scheme_idx=0)
+
     @property
     def idx(self):
         return self._idx

@@ -267,3 +267,20 @@ def test_slices_of_different_dimensionality_do_not_intersect():
     for other in (s2, s3):
         with pytest.raises(SliceUsageError):
             s1.intersection_with(other)
+
+
+def test_partition_macrotile():
+    """Partition.get_macrotile (base/partition.py:133-170; tests/io/datasets/test_mem.py:26-43): the whole partition
+    as one tile, whatever tileshape the dataset forces; with a roi its selected frames, possibly none"""
+    data = np.random.default_rng(0).random((16, 16, 16, 16)).astype(np.float32)
+    ds = MemoryDataSet(data=data, tileshape=(16, 16, 16), num_partitions=2).initialize(None)
+    p0, p1 = list(ds.get_partitions())
+    mt = p0.get_macrotile()
+    assert tuple(mt.shape) == (128, 16, 16) and mt.data.dtype == np.float32
+    assert np.array_equal(mt.data, data.reshape(256, 16, 16)[:128]) and mt.tile_slice == p0.slice
+    roi = np.zeros((16, 16), bool)
+    roi[0, 3] = roi[15, 0] = True
+    one = p0.get_macrotile(roi=roi, dest_dtype=np.float64)
+    assert tuple(one.shape) == (1, 16, 16) and one.data.dtype == np.float64 and np.array_equal(one.data[0], data[0, 3])
+    none = p1.get_macrotile(roi=ds.roi[0, 0])
+    assert tuple(none.shape) == (0, 16, 16)
