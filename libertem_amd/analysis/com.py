@@ -6,9 +6,9 @@ Centre-of-mass analysis (reference analysis/com.py:191-334): parameters -> 3-mas
 import numpy as np
 
 from libertem_amd import masks
-from libertem_amd.udf.com import (
+from libertem_amd.udf.com import (                               # noqa: F401  (importable from here too: analysis/com.py:14-19)
     com_masks_factory, com_masks_generic, center_shifts, apply_correction, divergence, curl_2d,
-    magnitude,
+    magnitude, coordinate_check, GuessResult, guess_corrections,
 )
 from .base import AnalysisResult, AnalysisResultSet
 from .masks import BaseMasksAnalysis

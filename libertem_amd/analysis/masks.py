@@ -93,10 +93,12 @@ class SingleMaskAnalysis(BaseMasksAnalysis):
                 data, key_prefix='intensity', title='intensity', desc=self.get_description(),
                 damage=damage))
         return SingleMaskResultSet([
-            AnalysisResult(raw_data=data, key='intensity', title='intensity [log]',
-                           desc=self.get_description()),
-            AnalysisResult(raw_data=data, key='intensity_lin', title='intensity [lin]',
-                           desc=self.get_description()),
+            # (keys as in analysis/masks.py:63-76: the linear one is 'intensity', the log-scaled view 'intensity_log';
+            #  both carry the same numbers -- scaling is a matter of the plot)
+            AnalysisResult(raw_data=data, key='intensity', title='intensity [lin]',
+                           desc=f'{self.get_description()} lin-scaled'),
+            AnalysisResult(raw_data=data, key='intensity_log', title='intensity [log]',
+                           desc=f'{self.get_description()} log-scaled'),
         ])
 
 

@@ -144,15 +144,36 @@ class SparseStack:
 
 
 def is_sparse(a):
-    return isinstance(a, SparseStack) or sp.issparse(a)
+    return isinstance(a, (SparseStack, _SparseMask)) or sp.issparse(a)
 
 
 def to_dense(a):
-    if isinstance(a, SparseStack):
+    if isinstance(a, (SparseStack, _SparseMask)):
         return a.todense()
     if sp.issparse(a):
         return a.toarray()
     return np.array(a)
+
+
+def to_sparse(a, shape=None):
+    """The sparse form of a mask (reference common/sparse.py:20-32, there a pydata `sparse.COO`): a 2-D array becomes a
+    scipy CSR matrix, a stack of masks a SparseStack; sparse inputs pass through.  A list of roi coordinates
+    ((y, x), ...) or ((y, x, value), ...) with `shape`: a bool scipy matrix / array with those positions set."""
+    if isinstance(a, (tuple, list)):
+        if all(isinstance(aa, (int, np.integer)) for aa in a):
+            a = (tuple(a) + (True,),)
+        values = {bool(aa[-1]) if len(aa) == len(tuple(shape)) + 1 else True for aa in a}
+        if len(values) != 1:
+            raise ValueError(f'Cannot cast iterable roi coords with more than one truth value {values}')
+        val = values.pop()
+        out = np.full(tuple(shape), not val, dtype=bool)
+        for aa in a:
+            out[tuple(aa[:len(tuple(shape))])] = val
+        return sp.csr_matrix(out) if out.ndim == 2 else out
+    if is_sparse(a) or isinstance(a, _SparseMask):
+        return a
+    a = np.asarray(a)
+    return sp.csr_matrix(a) if a.ndim == 2 else SparseStack.from_dense(a)
 
 
 def to_sparse_stack(a):

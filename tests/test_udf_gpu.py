@@ -283,6 +283,9 @@ def test_single_mask_and_sum_analyses(ctx, golden_dir):
     ds = ctx.load('memory', data=data, num_partitions=2, sig_dims=2)
     a = ctx.run(ctx.create_disk_analysis(dataset=ds))
     assert _close(a.intensity.raw_data, g['disk_default'][..., 0], F32_TOL)
+    # the result keys of the single-mask analyses (analysis/masks.py:63-76; tests/analysis/test_analysis_shapes.py)
+    assert [r.key for r in a.results] == ['intensity', 'intensity_log']
+    assert np.array_equal(a.intensity_log.raw_data, a.intensity.raw_data) and a['intensity_log'].title == 'intensity [log]'
     a = ctx.run(ctx.create_disk_analysis(dataset=ds, cx=10, cy=20, r=5))
     assert _close(a.intensity.raw_data, g['disk_params'][..., 0], F32_TOL)
     a = ctx.run(ctx.create_ring_analysis(dataset=ds))
