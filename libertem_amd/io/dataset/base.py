@@ -482,6 +482,34 @@ class DataSet:
     def check_valid(self):
         return True
 
+    def get_diagnostics(self):
+        """format-specific [{'name': ..., 'value': ...}, ...] (reference base/dataset.py:198-204)"""
+        return []
+
     @property
     def diagnostics(self):
-        return []
+        """what every dataset can say about itself, after the format's own entries (reference base/dataset.py:177-196)"""
+        parts = list(self.get_partitions())
+        info = self.get_sync_offset_info()
+        return list(self.get_diagnostics()) + [
+            {"name": "Partition shape", "value": str(tuple(parts[0].shape)) if parts else "-"},
+            {"name": "Number of partitions", "value": str(len(parts))},
+            {"name": "Number of frames skipped at the beginning", "value": info["frames_skipped_start"]},
+            {"name": "Number of frames ignored at the end", "value": info["frames_ignored_end"]},
+            {"name": "Number of blank frames inserted at the beginning", "value": info["frames_inserted_start"]},
+            {"name": "Number of blank frames inserted at the end", "value": info["frames_inserted_end"]},
+        ]
+
+    def get_sync_offset_info(self):
+        """frames skipped / ignored / inserted by `sync_offset` (reference base/dataset.py:70-88)"""
+        so = getattr(self, '_sync_offset_arg', None)
+        so = int(so if so is not None else (getattr(self, '_sync_offset', 0) or 0))
+        n_nav = prod(self.shape.nav)
+        n_img = getattr(self, '_image_count', None)
+        n_img = int(n_img if n_img is not None else n_nav)
+        return {
+            "frames_skipped_start": max(0, so),
+            "frames_ignored_end": max(0, n_img - n_nav - so),
+            "frames_inserted_start": abs(min(0, so)),
+            "frames_inserted_end": max(0, n_nav - n_img + so),
+        }

@@ -86,5 +86,13 @@ class RawFileDataSet(MemoryDataSet):
     def path(self):
         return self._path
 
+    def get_diagnostics(self):
+        return [{"name": "dtype", "value": str(self._meta.raw_dtype)}]
+
+    def get_cache_key(self):
+        # (what identifies the data a result was computed from: reference io/dataset/raw.py:246-254)
+        return {"path": self._path, "shape": tuple(self.shape), "dtype": str(self.dtype),
+                "sync_offset": self._sync_offset_arg}
+
     def __repr__(self):
         return f"<RawFileDataSet {self._path} shape={tuple(self.shape)} dtype={self.dtype}>"

@@ -284,3 +284,27 @@ def test_partition_macrotile():
     assert tuple(one.shape) == (1, 16, 16) and one.data.dtype == np.float64 and np.array_equal(one.data[0], data[0, 3])
     none = p1.get_macrotile(roi=ds.roi[0, 0])
     assert tuple(none.shape) == (0, 16, 16)
+
+
+def test_dataset_diagnostics_and_cache_key(lt_ctx, tmp_path):
+    """`ds.diagnostics` = the format's own entries + what every dataset can say (base/dataset.py:70-88, 177-204);
+    `RawFileDataSet.get_cache_key` (io/dataset/raw.py:246-254)"""
+    import json
+    path = str(tmp_path / 'x.raw')
+    np.arange(10 * 4 * 4, dtype=np.float32).tofile(path)
+    want = {0: (0, 2, 0, 0), 2: (2, 0, 0, 0), -3: (0, 5, 3, 0)}
+    for so, (skipped, ignored, ins_start, ins_end) in want.items():
+        ds = lt_ctx.load('raw', path=path, dtype='float32', nav_shape=(2, 4), sig_shape=(4, 4), sync_offset=so)
+        info = ds.get_sync_offset_info()
+        assert (info['frames_skipped_start'], info['frames_ignored_end'], info['frames_inserted_start'],
+                info['frames_inserted_end']) == (skipped, ignored, ins_start, ins_end)
+        d = {e['name']: e['value'] for e in ds.diagnostics}
+        assert d['dtype'] == 'float32' and d['Number of partitions'] == str(len(list(ds.get_partitions())))
+        assert d['Number of frames skipped at the beginning'] == skipped
+        assert d['Number of blank frames inserted at the beginning'] == ins_start
+        key = ds.get_cache_key()
+        assert json.loads(json.dumps(key)) == {"path": path, "shape": [2, 4, 4, 4], "dtype": "float32", "sync_offset": so}
+    mem = lt_ctx.load('memory', data=np.zeros((4, 4, 2, 2)), sync_offset=3)
+    assert mem.get_sync_offset_info() == {'frames_skipped_start': 3, 'frames_ignored_end': 0,
+                                          'frames_inserted_start': 0, 'frames_inserted_end': 3}
+    assert mem.get_diagnostics() == []
