@@ -14,6 +14,10 @@ from .base import DataSetException
 from .memory import MemoryDataSet
 
 
+def _reopen(kwargs):
+    return RawFileDataSet(**kwargs)
+
+
 class RawFileDataSet(MemoryDataSet):
     """
     Parameters (reference raw.py:77-104)
@@ -31,10 +35,24 @@ class RawFileDataSet(MemoryDataSet):
     def __init__(self, path, dtype, scan_size=None, detector_size=None, enable_direct=False,
                  detector_size_raw=None, crop_detector_to=None, tileshape=None, nav_shape=None,
                  sig_shape=None, sync_offset=0, io_backend=None, num_partitions=None, shard=None):
-        if enable_direct or io_backend is not None:
-            raise ValueError("alternative I/O backends are not part of this build")
-        if detector_size_raw is not None or crop_detector_to is not None:
-            raise ValueError("detector cropping was removed from the reference API as well")
+        # `io_backend` / `enable_direct` choose HOW the reference reads the file (mmap, buffered, O_DIRECT); here the
+        # file is always memory-mapped and its frames go to the GPU through the upload stager: accepted, not used
+        if enable_direct and io_backend is not None:
+            raise ValueError("can't specify io_backend and enable_direct at the same time")
+        if enable_direct:
+            warnings.warn("enable_direct is deprecated; pass `io_backend=DirectBackend()` instead", FutureWarning)
+        if tileshape is not None:
+            warnings.warn("tileshape argument is ignored and will be removed after 0.6.0", FutureWarning)
+            tileshape = None
+        if crop_detector_to is not None:
+            warnings.warn("crop_detector_to and detector_size_raw are deprecated, and will be removed after version "
+                          "0.6.0. please specify sig_shape instead or use a more specific DataSet like EMPAD",
+                          FutureWarning)
+            if detector_size is not None:
+                raise ValueError("cannot specify both detector_size and crop_detector_to")
+            if detector_size_raw != crop_detector_to:
+                raise ValueError("RawFileDataSet can't crop detector anymore, please use EMPAD DataSet")
+            detector_size = crop_detector_to
         if scan_size is not None:
             warnings.warn("scan_size argument is deprecated. please specify nav_shape instead",
                           FutureWarning)
@@ -47,8 +65,10 @@ class RawFileDataSet(MemoryDataSet):
             if sig_shape is not None:
                 raise ValueError("cannot specify both detector_size and sig_shape")
             sig_shape = detector_size
-        if nav_shape is None or sig_shape is None:
-            raise TypeError("missing 1 required argument: 'nav_shape' / 'sig_shape'")
+        if nav_shape is None:
+            raise TypeError("missing 1 required argument: 'nav_shape'")
+        if sig_shape is None:
+            raise TypeError("missing 1 required argument: 'sig_shape'")
         nav_shape = tuple(int(x) for x in nav_shape)
         sig_shape = tuple(int(x) for x in sig_shape)
         dt = np.dtype(dtype)
@@ -58,6 +78,8 @@ class RawFileDataSet(MemoryDataSet):
         except OSError as e:
             raise DataSetException(f"could not open file {path}: {e}")
         frame_bytes = prod(sig_shape) * dt.itemsize
+        if prod(sig_shape) > filesize // dt.itemsize:
+            raise DataSetException("sig_shape must be less than size: %s" % (filesize // dt.itemsize))
         n_file = filesize // frame_bytes
         n_nav = prod(nav_shape)
         sync_offset = int(sync_offset)
@@ -81,6 +103,14 @@ class RawFileDataSet(MemoryDataSet):
         self._image_count = int(n_file)
         super().__init__(data=data.reshape(nav_shape + sig_shape), sig_dims=len(sig_shape),
                          num_partitions=num_partitions, shard=shard)
+        self._meta.image_count = int(n_file)             # (the frames in the FILE: reference raw.py:185-190)
+        self._ctor = dict(path=path, dtype=dt.str, nav_shape=nav_shape, sig_shape=sig_shape, sync_offset=sync_offset,
+                          num_partitions=num_partitions, shard=shard)
+
+    def __reduce__(self):
+        # a pickle names the file, it does not carry its frames (reference tests/io/datasets/test_raw.py
+        # test_pickle_is_small); plans and uploads are made again where it is loaded
+        return (_reopen, (self._ctor,))
 
     @property
     def path(self):

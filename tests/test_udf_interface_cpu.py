@@ -308,3 +308,39 @@ def test_dataset_diagnostics_and_cache_key(lt_ctx, tmp_path):
     assert mem.get_sync_offset_info() == {'frames_skipped_start': 3, 'frames_ignored_end': 0,
                                           'frames_inserted_start': 0, 'frames_inserted_end': 3}
     assert mem.get_diagnostics() == []
+
+
+def test_raw_file_dataset_arguments(lt_ctx, tmp_path):
+    """tests/io/datasets/test_raw.py re-expressed: frames in the FILE are `meta.image_count` (extra data at the end is
+    cut off, missing frames are blank), a sig_shape larger than the file is refused, the messages of missing
+    arguments, deprecated arguments warn, reader back-ends are accepted (the file is always mapped), small pickles"""
+    import pickle
+    from libertem_amd.io.dataset.base import DataSetException
+    path = str(tmp_path / '8x8x8x8')
+    data = np.random.default_rng(4).random((8, 8, 8, 8)).astype(np.float32)
+    data.tofile(path)
+    ds = lt_ctx.load("raw", path=path, nav_shape=(8, 8), sig_shape=(4, 4), dtype="float32")
+    assert ds._meta.image_count == 256 and tuple(ds.shape) == (8, 8, 4, 4)
+    ds = lt_ctx.load("raw", path=path, nav_shape=(8, 8), sig_shape=(3, 3), dtype="float32", io_backend=object())
+    assert ds._meta.image_count == 455
+    assert np.array_equal(np.asarray(ds.data).reshape(-1), data.reshape(-1)[:64 * 9])
+    many = lt_ctx.load("raw", path=path, nav_shape=(10, 8), sig_shape=(8, 8), dtype="float32")
+    assert many._meta.image_count == 64 and many.get_sync_offset_info()['frames_inserted_end'] == 16
+    assert not np.asarray(many.data)[8:].any()
+    with pytest.raises(DataSetException, match='sig_shape must be less than size'):
+        lt_ctx.load("raw", path=path, nav_shape=(8, 8), sig_shape=(65, 65), dtype="float32")
+    with pytest.raises(TypeError, match="missing 1 required argument: 'sig_shape'"):
+        lt_ctx.load("raw", path=path, nav_shape=(8, 8), dtype="float32")
+    with pytest.raises(TypeError, match="missing 1 required argument: 'nav_shape'"):
+        lt_ctx.load("raw", path=path, sig_shape=(8, 8), dtype="float32")
+    with pytest.warns(FutureWarning, match='scan_size'):
+        old = lt_ctx.load("raw", path=path, scan_size=(8, 8), sig_shape=(8, 8), dtype="float32")
+    with pytest.warns(FutureWarning, match='enable_direct'):
+        lt_ctx.load("raw", path=path, nav_shape=(8, 8), sig_shape=(8, 8), dtype="float32", enable_direct=True)
+    with pytest.raises(ValueError, match="can't crop"):
+        with pytest.warns(FutureWarning):
+            lt_ctx.load("raw", path=path, nav_shape=(8, 8), dtype="float32", detector_size_raw=(8, 8), crop_detector_to=(4, 4))
+    blob = pickle.dumps(old)
+    assert len(blob) < 2 * 1024
+    again = pickle.loads(blob)
+    assert tuple(again.shape) == (8, 8, 8, 8) and np.array_equal(np.asarray(again.data), data)
