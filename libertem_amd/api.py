@@ -48,6 +48,10 @@ class Context:
         if executor_spec is None:
             executor_spec = 'hip' if _gpu_available() else 'inline'
         if executor_spec == 'inline':
+            # (the inline executor has neither worker processes nor GPUs to size: api.py make_with of the reference
+            #  refuses `cpus` / `gpus` for it)
+            if cpus is not None or gpus is not None:
+                raise ExecutorSpecException("the 'inline' executor takes neither cpus nor gpus")
             from libertem_amd.executor.inline import InlineJobExecutor
             return cls(executor=InlineJobExecutor(*args, **kwargs))
         if executor_spec == 'hip':
@@ -182,6 +186,10 @@ class Context:
             #  stays free while the GPU works)
             return self._run_udf_async(dataset, udf, roi=roi, corrections=corrections, progress=progress,
                                        backends=backends, plots=plots, result_where=result_where)
+        nested = self._nested_context()
+        if nested is not None:
+            return nested.run_udf(dataset, udf, roi=roi, corrections=corrections, progress=progress, backends=backends,
+                                  plots=plots, sync=True, result_where=result_where)
         if result_where not in (None, 'host', 'device'):
             raise ValueError("result_where must be None, 'host' or 'device'")
         if result_where == 'device' and not hasattr(self.executor, '_merge_on_device'):
@@ -190,6 +198,8 @@ class Context:
             corrections = None
         udf_is_list = isinstance(udf, (tuple, list))
         udfs = list(udf) if udf_is_list else [udf]
+        if len(udfs) == 0:
+            raise ValueError("empty list of UDFs - nothing to do!")
         if roi is not None:
             roi = self._normalize_roi(roi, dataset)
         runner = UDFRunner(udfs)
@@ -202,6 +212,23 @@ class Context:
                                          **({'result_where': 'device'} if result_where == 'device' else {}))
         buffers = res.buffers
         return tuple(buffers) if udf_is_list else buffers[0]
+
+    def _nested_context(self):
+        """The reference runs UDFs from inside a `run_udf_iter` loop (tests/test_context.py test_udf_iter: a second run
+        per partial result, on the same Context).  Here an executor's delivery buffers and launch-ahead state belong
+        to the run in progress, so a run started BY THE THREAD THAT HOLDS A SUSPENDED ITERATION goes to a sibling
+        executor (same kind, same GPU, state of its own), made on first use.  Other threads are refused (RunGate)."""
+        import threading
+        gate = self.executor.run_gate
+        if not gate.suspended or gate._owner != threading.get_ident():
+            return None
+        sib = self.__dict__.get('_sibling')
+        if sib is None:
+            make = getattr(self.executor, 'sibling', None)
+            if make is None:
+                return None                                   # (the gate refuses with its message)
+            sib = self._sibling = Context(executor=make())
+        return sib
 
     def _run_scope(self):
         import contextlib
@@ -264,8 +291,15 @@ class Context:
 
     def _run_udf_iter_sync(self, dataset, udf, roi=None, corrections=None, progress=False,
                            backends=None, plots=None):
+        nested = self._nested_context()
+        if nested is not None:
+            yield from nested._run_udf_iter_sync(dataset, udf, roi=roi, corrections=corrections, progress=progress,
+                                                 backends=backends, plots=plots)
+            return
         udf_is_list = isinstance(udf, (tuple, list))
         udfs = list(udf) if udf_is_list else [udf]
+        if len(udfs) == 0:
+            raise ValueError("empty list of UDFs - nothing to do!")
         if roi is not None:
             roi = self._normalize_roi(roi, dataset)
         runner = UDFRunner(udfs)
@@ -300,15 +334,29 @@ class Context:
             coords = roi
             if all(isinstance(c, (int, np.integer)) for c in coords):
                 coords = (coords,)
-            arr = np.zeros(nav, dtype=bool)
+            # items: ((y, x), value) as in the reference (common/sparse.py:20-32), or (y, x) / (y, x, value)
+            items = []
             for c in coords:
                 c = tuple(c)
-                if len(c) == len(nav) + 1:
-                    arr[c[:-1]] = bool(c[-1])
+                if len(c) == 2 and isinstance(c[0], (tuple, list, np.ndarray)):
+                    items.append((tuple(int(i) for i in c[0]), bool(c[1])))
+                elif len(c) == len(nav) + 1:
+                    items.append((tuple(int(i) for i in c[:-1]), bool(c[-1])))
                 else:
-                    arr[c] = True
+                    items.append((tuple(int(i) for i in c), True))
+            values = {v for _, v in items}
+            if len(values) > 1:
+                raise ValueError(f'Cannot cast iterable roi coords with more than one truth value {values}')
+            val = values.pop() if values else True
+            arr = np.full(nav, not val, dtype=bool)
+            for pos, _ in items:
+                arr[pos] = val
             roi = arr
-        roi = np.asarray(roi, dtype=bool)
+        roi = np.asarray(roi)
+        if roi.dtype != np.dtype(bool):
+            import warnings
+            warnings.warn(f"ROI dtype is {roi.dtype}, expected bool. Attempting cast to bool.")
+            roi = roi.astype(bool)
         if roi.shape != nav:
             raise ValueError(f"roi: incompatible shapes: {roi.shape} (roi) vs {nav} (dataset)")
         return roi
@@ -330,6 +378,9 @@ class Context:
                     closer()
                 except Exception:                       # noqa: BLE001  (closing must not raise)
                     pass
+        sib = self.__dict__.pop('_sibling', None)
+        if sib is not None:
+            sib.close()
         pool = getattr(self, '_async_worker', None)
         if pool is not None:
             pool.shutdown(wait=True)

@@ -108,6 +108,12 @@ class HipJobExecutor(JobExecutor):
         self._scattered = {}
         self._pinned = {}
 
+    def sibling(self):
+        """an independent executor on the same GPU (a stream, delivery buffers and launch-ahead state of its own): runs
+        a UDF while a `run_udf_iter` of this one is suspended between two partial results (Context.run_udf).  With
+        several ranks every rank has to start the same nested run -- its collectives use the same process group."""
+        return HipJobExecutor(gpu_id=self.gpu_id, distributed=self._distributed, require_gpu=self._require_gpu)
+
     # --- distributed helpers -----------------------------------------------------------------------
     def _dist(self):
         if self._distributed is False:

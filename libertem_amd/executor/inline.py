@@ -29,6 +29,11 @@ class InlineJobExecutor(JobExecutor):
         self._inline_threads = inline_threads
         self._scattered = {}
 
+    def sibling(self):
+        """an independent executor of the same kind: runs a UDF while a `run_udf_iter` of this one is suspended between
+        two partial results (Context.run_udf)"""
+        return InlineJobExecutor(debug=self._debug, inline_threads=self._inline_threads)
+
     def get_local_env(self):
         threads = self._inline_threads
         if threads is None:

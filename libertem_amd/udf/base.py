@@ -537,6 +537,24 @@ class UDFBase(UDFProtocol):
         return tmp.shape
 
 
+def _mixin(method, doc):
+    """runtime-checkable protocol `has a method <method>` (udf/base.py:804-960 of the reference): user code may
+    inherit from these or ask `isinstance(udf, UDFTileMixin)`; the run itself only looks for the methods"""
+    from typing import Protocol, runtime_checkable
+    ns = {'__doc__': doc, method: lambda self, *a, **k: (_ for _ in ()).throw(NotImplementedError())}
+    ns[method].__name__ = method
+    return runtime_checkable(type(Protocol)('UDF' + ''.join(w.title() for w in method.split('_')[1:]) + 'Mixin',
+                                            (Protocol,), ns))
+
+
+UDFFrameMixin = _mixin('process_frame', "Implement `process_frame(frame)` for per-frame processing.")
+UDFTileMixin = _mixin('process_tile', "Implement `process_tile(tile)` for per-tile processing.")
+UDFPartitionMixin = _mixin('process_partition', "Implement `process_partition(partition)` for whole partitions.")
+UDFPreprocessMixin = _mixin('preprocess', "Implement `preprocess()`: runs before the tiles of every task.")
+UDFPostprocessMixin = _mixin('postprocess', "Implement `postprocess()`: runs after the tiles of every task.")
+UDFMergeAllMixin = _mixin('merge_all', "Implement `merge_all(ordered_results)` instead of `merge`.")
+
+
 class UDF(UDFBase):
     """The user-facing base class (udf/base.py:1270-1732)."""
 
@@ -1341,7 +1359,13 @@ class UDFRunner:
             if verify is not None and not checked:
                 late_check()
         except JobCancelledError:
-            raise UDFRunCancelled(f"UDF run cancelled after {len(tasks)} tasks were created")
+            # (the message of the reference, udf/base.py:2720-2721: partitions whose results were merged)
+            done = 0
+            try:
+                done = sum(1 for t in tasks if np.all(damage.get_view_for_partition(t.partition)))
+            except Exception:                               # noqa: BLE001  (cancelled before any buffer existed)
+                pass
+            raise UDFRunCancelled(f"UDF run cancelled after {done} partitions")
         except _StalePlan:
             raise
         except _ReplayMismatch:

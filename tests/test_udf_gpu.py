@@ -2552,3 +2552,39 @@ def test_analysis_roi_parameter(ctx, spec):
     assert SumAnalysis(dataset=ds, parameters={}).get_roi() is None
     with pytest.raises(NotImplementedError, match='unknown shape'):
         SumAnalysis(dataset=ds, parameters={"roi": {"shape": "star"}}).get_roi()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('resident', ['host', 'device'])
+def test_runs_inside_a_partial_result_loop(ctx, resident):
+    """The reference's tests/test_context.py test_udf_iter: inside `for res in ctx.run_udf_iter(...)` a second run on
+    the SAME context with the damage so far as roi gives the partial result.  On the HIP executor the nested run goes
+    to a sibling executor on the same GPU (Context._nested_context); host data goes through the dataset's shared
+    upload stager in both runs, the prefetched chunk of the suspended run included."""
+    from libertem_amd.udf.masks import ApplyMasksUDF
+    from libertem_amd.udf.sumsigudf import SumSigUDF
+    rng = np.random.default_rng(23)
+    data = rng.integers(0, 4096, (8, 16, 64, 64)).astype(np.uint16)
+    masks = rng.random((3, 64, 64)).astype(np.float32)
+    if resident == 'device':
+        ds = _device_ds(ctx, data, 4)
+    else:
+        ds = ctx.load('memory', data=data, num_partitions=4, sig_dims=2)
+
+    def udfs():
+        return [ApplyMasksUDF(mask_factories=lambda: masks, mask_count=3, mask_dtype=np.float32), SumSigUDF()]
+    want = np.einsum('abyx,kyx->abk', data.astype(np.float64), masks.astype(np.float64))
+    steps = 0
+    for res in ctx.run_udf_iter(dataset=ds, udf=udfs()):
+        steps += 1
+        dmg = np.array(res.damage.data)
+        ref = ctx.run_udf(dataset=ds, udf=udfs(), roi=dmg)
+        for i, key in enumerate(('intensity', 'intensity')):
+            got, again = res.buffers[i][key].data, ref[i][key].data
+            assert np.array_equal(got[dmg], again[dmg])
+        assert _close(res.buffers[0]['intensity'].data[dmg], want[dmg], F32_TOL)
+        # a whole second iteration in between
+        assert sum(1 for _ in ctx.run_udf_iter(dataset=ds, udf=SumSigUDF())) == 4
+    assert steps == 4 and dmg.all()
+    assert _close(res.buffers[0]['intensity'].data, want, F32_TOL)
+    assert np.array_equal(res.buffers[1]['intensity'].data, data.astype(np.float64).sum(axis=(2, 3)).astype(res.buffers[1]['intensity'].data.dtype))

@@ -344,3 +344,60 @@ def test_raw_file_dataset_arguments(lt_ctx, tmp_path):
     assert len(blob) < 2 * 1024
     again = pickle.loads(blob)
     assert tuple(again.shape) == (8, 8, 8, 8) and np.array_equal(np.asarray(again.data), data)
+
+
+def test_context_argument_handling(lt_ctx):
+    """tests/test_context.py re-expressed: an empty list of UDFs, ROIs that are not bool arrays (other dtypes warn
+    and are cast; coordinate lists ((y, x), value); a single position; scipy matrices), `make_with('inline')` takes no
+    resources, cancellation names the partitions merged so far, the mixin protocols of `libertem.udf`"""
+    import scipy.sparse as sp
+    from libertem_amd.common.exceptions import ExecutorSpecException
+    from libertem_amd.common.executor import JobCancelledError
+    from libertem_amd.udf import UDFRunCancelled, UDFFrameMixin, UDFTileMixin, UDFPreprocessMixin
+
+    class PerFrame(UDFFrameMixin, UDF):
+        def get_result_buffers(self):
+            return {'s': self.buffer(kind='nav', dtype=np.float32)}
+
+        def process_frame(self, frame):
+            self.results.s[:] = frame.sum()
+    data = np.random.default_rng(1).random((4, 5, 3, 3)).astype(np.float32)
+    ds = lt_ctx.load('memory', data=data, num_partitions=2)
+    with pytest.raises(ValueError, match="^empty list of UDFs - nothing to do!$"):
+        lt_ctx.run_udf(dataset=ds, udf=[])
+    with pytest.raises(ValueError, match="^empty list of UDFs - nothing to do!$"):
+        list(lt_ctx.run_udf_iter(dataset=ds, udf=[]))
+    roi = np.zeros((4, 5), dtype=bool)
+    roi[3, 2] = True
+    want = lt_ctx.run_udf(dataset=ds, udf=PerFrame(), roi=roi)['s'].raw_data
+    assert want.shape == (1,) and np.isclose(want[0], data[3, 2].sum())
+    for dtype in (int, float):
+        with pytest.warns(UserWarning, match=f"ROI dtype is {np.dtype(dtype)}, expected bool. Attempting cast to bool."):
+            got = lt_ctx.run_udf(dataset=ds, udf=PerFrame(), roi=roi.astype(dtype))['s'].raw_data
+        assert np.array_equal(got, want)
+    for roi_in in (sp.coo_matrix(roi), sp.csr_matrix(roi), (((3, 2), True),), [[[3, 2], True]], (3, 2)):
+        assert np.array_equal(lt_ctx.run_udf(dataset=ds, udf=PerFrame(), roi=roi_in)['s'].raw_data, want)
+    inverse = lt_ctx.run_udf(dataset=ds, udf=PerFrame(), roi=(((3, 2), False),))['s'].raw_data
+    assert inverse.shape == (19,)
+    with pytest.raises(ValueError, match='more than one truth value'):
+        lt_ctx.run_udf(dataset=ds, udf=PerFrame(), roi=(((3, 2), True), ((0, 0), False)))
+
+    for kw in ({'cpus': 4}, {'gpus': 4}):
+        with pytest.raises(ExecutorSpecException):
+            Context.make_with('inline', **kw)
+    with pytest.raises(ExecutorSpecException):
+        Context.make_with('not_an_executor')
+    assert isinstance(Context.make_with('inline').executor, InlineJobExecutor)
+
+    class Cancels(UDF):
+        def get_result_buffers(self):
+            return {'stuff': self.buffer(kind='nav', dtype='float32')}
+
+        def process_frame(self, frame):
+            if self.meta.coordinates[0][0] >= 2:
+                raise JobCancelledError()
+    with pytest.raises(UDFRunCancelled, match=r"^UDF run cancelled after 1 partitions$"):
+        for _ in lt_ctx.run_udf_iter(dataset=ds, udf=Cancels()):
+            pass
+    assert isinstance(PerFrame(), UDFFrameMixin) and not isinstance(PerFrame(), UDFTileMixin)
+    assert not isinstance(PerFrame(), UDFPreprocessMixin) and PerFrame().get_method() == UDFMethod.FRAME
