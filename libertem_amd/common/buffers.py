@@ -131,7 +131,7 @@ class BufferWrapper:
         self._ds_shape = None
         self._roi = None
         self._roi_is_zero = None
-        self._valid_mask = None
+        self._valid_mask_value = None        # bool array in the raw shape, or a callable that makes it on first use
         self._ds_partitions = None
         self._contiguous_cache = {}
 
@@ -313,6 +313,19 @@ class BufferWrapper:
             mask[:] = v.reshape(v.shape + (1,) * len(self._extra_shape))
             return mask
         return np.ones(shape, dtype=bool)
+
+    @property
+    def _valid_mask(self):
+        # (the default mask of a result is made when somebody asks for it: a run that only reads `.data` does not pay
+        #  for n_frames x extra bools)
+        v = self._valid_mask_value
+        if callable(v):
+            v = self._valid_mask_value = v()
+        return v
+
+    @_valid_mask.setter
+    def _valid_mask(self, value):
+        self._valid_mask_value = value
 
     @property
     def valid_mask(self):

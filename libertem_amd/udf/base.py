@@ -26,6 +26,7 @@ import threading
 import weakref
 from collections import OrderedDict
 
+import functools
 import numpy as np
 
 from libertem_amd.common.math import prod
@@ -515,8 +516,10 @@ class UDFBase(UDFProtocol):
             buf.set_shape_ds(self.meta.dataset_shape, self.meta.roi)
             if mask is None:
                 vm = self.meta.get_valid_nav_mask()
-                mask = None if vm is None else buf.make_default_mask(
-                    valid_nav_mask=vm, dataset_shape=self.meta.dataset_shape, roi=self.meta.roi)
+                if vm is not None:
+                    vm = np.array(vm, copy=True)        # (the damage map goes on changing; made into a mask lazily)
+                    mask = functools.partial(buf.make_default_mask, valid_nav_mask=vm,
+                                             dataset_shape=self.meta.dataset_shape, roi=self.meta.roi)
             else:
                 mask = np.asarray(mask).reshape(buf.shape)
             buf.valid_mask = mask
