@@ -17,9 +17,17 @@ from libertem_amd.common.buffers import (
 )
 
 
-@pytest.fixture
-def lt_ctx():
-    return Context(executor=InlineJobExecutor(debug=True))
+@pytest.fixture(params=['inline', pytest.param('hip', marks=pytest.mark.gpu)])
+def lt_ctx(request):
+    """the inline executor (CPU), and -- under `-m gpu` -- the HIP executor, whose merge / delivery code of its own
+    serves NumPy UDFs of users as well"""
+    if request.param == 'hip':
+        from libertem_amd.executor.hip import HipJobExecutor
+        ctx = Context(executor=HipJobExecutor())
+        yield ctx
+        ctx.close()
+    else:
+        yield Context(executor=InlineJobExecutor(debug=True))
 
 
 def _ds(ctx, datashape=(16, 16, 32, 32), num_partitions=4):
