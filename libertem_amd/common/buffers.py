@@ -101,6 +101,17 @@ def get_bbox_slice(arr):
     return tuple(slice(b[2 * i], b[2 * i + 1] + 1, None) for i in range(len(b) // 2))
 
 
+def default_mask(kind, shape, n_extra, valid_nav_mask):
+    """see BufferWrapper.make_default_mask; a plain function: a mask that is made lazily must not keep its buffer
+    (and the delivery slot behind it) alive through a reference cycle"""
+    if kind == 'nav':
+        mask = np.zeros(shape, dtype=bool)
+        v = np.asarray(valid_nav_mask, dtype=bool)
+        mask[:] = v.reshape(v.shape + (1,) * n_extra)
+        return mask
+    return np.ones(shape, dtype=bool)
+
+
 def reshaped_view(a, shape):
     """`a` with another shape, as a VIEW: AttributeError where NumPy would have to copy (reference :94-119)"""
     res = a.view()
@@ -307,12 +318,7 @@ class BufferWrapper:
             roi = self._roi
         roi_count = None if roi is None else int(np.count_nonzero(roi))
         shape = self._shape_for_kind(self._kind, dataset_shape.flatten_nav(), roi_count)
-        if self._kind == 'nav':
-            mask = np.zeros(shape, dtype=bool)
-            v = np.asarray(valid_nav_mask, dtype=bool)
-            mask[:] = v.reshape(v.shape + (1,) * len(self._extra_shape))
-            return mask
-        return np.ones(shape, dtype=bool)
+        return default_mask(self._kind, shape, len(self._extra_shape), valid_nav_mask)
 
     @property
     def _valid_mask(self):

@@ -34,6 +34,7 @@ from libertem_amd.common.slice import Slice
 from libertem_amd.common.shape import Shape
 from libertem_amd.common.buffers import (
     BufferWrapper, AuxBufferWrapper, PlaceholderBufferWrapper, PreallocBufferWrapper, HipSigView, ArrayWithMask,
+    default_mask,
 )
 from libertem_amd.common.hiparray import HipArray
 from libertem_amd.common.fingerprint import fingerprint, is_opaque
@@ -518,8 +519,9 @@ class UDFBase(UDFProtocol):
                 vm = self.meta.get_valid_nav_mask()
                 if vm is not None:
                     vm = np.array(vm, copy=True)        # (the damage map goes on changing; made into a mask lazily)
-                    mask = functools.partial(buf.make_default_mask, valid_nav_mask=vm,
-                                             dataset_shape=self.meta.dataset_shape, roi=self.meta.roi)
+                    # (no reference to `buf` in the callable: a cycle would keep the run's delivery slot reserved
+                    #  until the garbage collector runs)
+                    mask = functools.partial(default_mask, buf.kind, tuple(buf.shape), len(buf.extra_shape), vm)
             else:
                 mask = np.asarray(mask).reshape(buf.shape)
             buf.valid_mask = mask
