@@ -59,6 +59,9 @@ extern "C" int ltmi_host_device_pointer(int device, void *host, void **dev_out) 
 // with the host link (57.6 GB/s measured H2D); one thread's memcpy does 8 - 12 GB/s.  A small persistent pool of
 // workers, each copying a contiguous share; the caller copies a share itself and waits for the others.
 #include <atomic>
+#include <string>
+#include <sched.h>
+#include <pthread.h>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -76,7 +79,54 @@ struct CopyPool {
     int pending = 0;
     bool quit = false;
 
+    // One copy thread per L3 domain (a CCD of an EPYC host: 8 cores behind one link to the memory fabric).  Left to the
+    // scheduler, 16 threads may land on one or two CCDs and the copy runs at 50 GB/s -- below the 57 GB/s host link it
+    // has to stay ahead of -- where spread threads reach 90 - 200 (profiles/r06_host_upload.txt).  A worker may run on
+    // any core of ITS domain; LTMI_COPY_SPREAD=0 leaves the placement to the scheduler.
+    static const std::vector<cpu_set_t> &domains() {
+        static const std::vector<cpu_set_t> d = [] {
+            std::vector<cpu_set_t> out;
+            const char *e = getenv("LTMI_COPY_SPREAD");
+            if (e && e[0] == '0') return out;
+            cpu_set_t allowed;
+            CPU_ZERO(&allowed);
+            if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return out;
+            std::vector<std::string> keys;
+            for (int cpu = 0; cpu < CPU_SETSIZE; ++cpu) {
+                if (!CPU_ISSET(cpu, &allowed)) continue;
+                char path[128], buf[256] = {0};
+                snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+                FILE *f = fopen(path, "r");
+                if (!f) continue;
+                const bool ok = fgets(buf, sizeof(buf), f) != nullptr;
+                fclose(f);
+                if (!ok) continue;
+                size_t k = 0;
+                for (; k < keys.size(); ++k)
+                    if (keys[k] == buf) break;
+                if (k == keys.size()) {
+                    keys.push_back(buf);
+                    cpu_set_t s;
+                    CPU_ZERO(&s);
+                    out.push_back(s);
+                }
+                CPU_SET(cpu, &out[k]);
+            }
+            if (out.size() < 2) out.clear();
+            return out;
+        }();
+        return d;
+    }
+
     void work(int idx) {
+        const std::vector<cpu_set_t> &dom = domains();
+        if (!dom.empty()) {
+            // worker idx -> domain idx + 1, idx + 1 + n/2, ... : neighbours in the list (one socket) are filled alternately
+            const size_t n = dom.size();
+            const size_t k = (size_t)(idx + 1) % n;
+            const size_t pick = (k % 2) * (n / 2) + k / 2;
+            (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &dom[pick % n]);
+        }
         uint64_t seen = 0;
         for (;;) {
             std::unique_lock<std::mutex> lk(mu);
