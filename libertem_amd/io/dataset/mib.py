@@ -427,6 +427,13 @@ class MIBDataSet(MemoryDataSet):
         if nbytes <= piece:
             dst[dst_off:dst_off + nbytes] = src[src_off:src_off + nbytes]
             return
+        try:
+            # the library's copy pool: one thread per L3 domain of the host (csrc/ltmi_capi.cpp)
+            from libertem_amd import hip
+            hip.host_copy(dst[dst_off:dst_off + nbytes], np.asarray(src[src_off:src_off + nbytes]))
+            return
+        except Exception:                               # noqa: BLE001  (e.g. a source that is not contiguous)
+            pass
 
         def run(o):
             n = min(piece, nbytes - o)
