@@ -103,8 +103,9 @@ class MemoryDataSet(DataSet):
         if sync_offset != 0:
             # frame g of `data` belongs to scan position g - sync_offset (reference io/dataset/memory.py:352-406 via
             # base/partition.py): positive offsets skip frames, negative ones leave the first positions blank.
-            # Positions without a frame hold ZERO frames here (like RawFileDataSet / MIBDataSet of this package;
-            # the reference does not deliver them to the UDFs at all: the same sums, masks and CoM results).
+            # Positions without a frame hold zero frames in the array (like RawFileDataSet / MIBDataSet of this
+            # package): the host tile loop skips them like the reference (`_valid_frames`), the device path multiplies
+            # the zeros -- the same sums, masks and CoM results.
             if self._data is None or shard is not None:
                 raise DataSetException("sync_offset of a MemoryDataSet needs host data held by one process")
             n_sig = prod(full_shape[-sig_dims:])
@@ -118,6 +119,7 @@ class MemoryDataSet(DataSet):
             moved = np.zeros_like(frames)
             moved[lead:lead + avail] = frames[skip:skip + avail]
             self._data = moved.reshape(full_shape)
+            self._valid_frames = (lead, lead + avail)
         self._local_shape = Shape(full_shape, sig_dims=sig_dims)
         if self._shard is not None:
             full_shape = (full_shape[0] * self._shard[1],) + tuple(full_shape[1:])
@@ -722,8 +724,21 @@ class MemPartition(Partition):
         else:
             n = len(idxs)
             compressed_origin = self.slice.adjust_for_roi(roi).origin[0]
-        for g0 in range(0, n, depth):
-            g1 = min(n, g0 + depth)
+        # scan positions a `sync_offset` leaves without a frame -- before the first or after the last one -- are NOT
+        # delivered (reference base/partition.py read ranges; tests/udf/test_coords.py): host UDFs see frames that
+        # exist, their result rows elsewhere keep their initial value.  (The device path multiplies the zero frames
+        # that stand there: the same sums for every native operator, and write-once result rows stay defined.)
+        first, last = 0, n
+        valid = getattr(self._ds, '_valid_frames', None)
+        if valid is not None:
+            lo, hi = valid[0] - self._ds.local_frame_range[0], valid[1] - self._ds.local_frame_range[0]
+            if idxs is None:
+                first, last = max(0, lo - self._local0), min(n, hi - self._local0)
+            else:
+                first = int(np.searchsorted(idxs, lo, side='left'))
+                last = int(np.searchsorted(idxs, hi, side='left'))
+        for g0 in range(first, last, depth):
+            g1 = min(last, g0 + depth)
             for scheme_idx, sig_slice in tiling_scheme.slices:
                 sig_sl = sig_slice.get(sig_only=True)
                 if idxs is None:

@@ -104,6 +104,8 @@ class RawFileDataSet(MemoryDataSet):
         super().__init__(data=data.reshape(nav_shape + sig_shape), sig_dims=len(sig_shape),
                          num_partitions=num_partitions, shard=shard)
         self._meta.image_count = int(n_file)             # (the frames in the FILE: reference raw.py:185-190)
+        if lead_blank or avail < n_nav:
+            self._valid_frames = (lead_blank, lead_blank + avail)      # (positions that hold a frame of the file)
         self._ctor = dict(path=path, dtype=dt.str, nav_shape=nav_shape, sig_shape=sig_shape, sync_offset=sync_offset,
                           num_partitions=num_partitions, shard=shard)
 

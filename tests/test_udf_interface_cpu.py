@@ -251,22 +251,35 @@ def test_sparse_stacks_as_arrays():
 
 
 def test_memory_dataset_sync_offset(lt_ctx):
-    """frame g of the data sits at scan position g - sync_offset (the reference's tests/udf/test_coords.py offsets);
-    positions without a frame hold zero frames here"""
-    class PerFrame(UDF):
+    """frame g of the data sits at scan position g - sync_offset; positions a sync_offset leaves without a frame are
+    not delivered to host UDFs at all (the reference's tests/udf/test_coords.py test_tiles_positive_offset /
+    _negative_offset; io/dataset/base/partition.py read ranges) -- their result rows keep their initial value"""
+    class PerTile(UDF):
         def get_result_buffers(self):
-            return {'s': self.buffer(kind='nav', dtype=np.float32)}
+            return {'s': self.buffer(kind='nav', dtype=np.float32), 'seen': self.buffer(kind='single', dtype=np.int64)}
 
-        def process_frame(self, frame):
-            self.results.s[:] = frame.sum()
+        def process_tile(self, tile):
+            assert tile.shape[0] == len(self.meta.coordinates)
+            self.results.s[:] = tile.sum(axis=(1, 2)) + 1                 # (+ 1: a delivered zero frame would show)
+            self.results.seen[0] += tile.shape[0]
+
+        def merge(self, dest, src):
+            dest.s[:] = src.s
+            dest.seen += src.seen
     data = np.arange(64, dtype=np.float32).reshape(8, 8, 1, 1) * np.ones((8, 8, 2, 2), dtype=np.float32)
-    want = {62: [248., 252.] + [0.] * 62, -62: [0.] * 62 + [0., 4.], 3: [4. * g for g in range(3, 64)] + [0.] * 3}
+    want = {62: [249., 253.] + [0.] * 62, -62: [0.] * 62 + [1., 5.], 3: [4. * g + 1 for g in range(3, 64)] + [0.] * 3}
     for so, w in want.items():
-        ds = MemoryDataSet(data=data, num_partitions=2, sig_dims=2, sync_offset=so).initialize(lt_ctx.executor)
-        assert np.array_equal(lt_ctx.run_udf(dataset=ds, udf=PerFrame())['s'].data.reshape(-1), np.array(w, dtype=np.float32))
+        ds = MemoryDataSet(data=data, tileshape=(4, 2, 2), num_partitions=2, sig_dims=2, sync_offset=so)
+        ds = ds.initialize(lt_ctx.executor)
+        res = lt_ctx.run_udf(dataset=ds, udf=PerTile())
+        assert np.array_equal(res['s'].data.reshape(-1), np.array(w, dtype=np.float32)), so
+        assert res['seen'].data[0] == 64 - abs(so)
+    roi = np.arange(64).reshape(8, 8) % 3 == 0                            # 22 positions, the last one without a frame
+    ds = MemoryDataSet(data=data, num_partitions=2, sig_dims=2, sync_offset=3).initialize(lt_ctx.executor)
+    res = lt_ctx.run_udf(dataset=ds, udf=PerTile(), roi=roi)
+    assert res['seen'].data[0] == 21 and res['s'].raw_data[-1] == 0 and res['s'].raw_data[0] == 13.
     with pytest.raises(Exception, match='offset should be in'):
         MemoryDataSet(data=data, sig_dims=2, sync_offset=64)
-
 
 def test_slices_of_different_dimensionality_do_not_intersect():
     s1 = Slice(origin=(1, 1, 1, 1), shape=Shape((2, 2, 2, 2), sig_dims=2))
