@@ -422,3 +422,24 @@ def test_context_argument_handling(lt_ctx):
             pass
     assert isinstance(PerFrame(), UDFFrameMixin) and not isinstance(PerFrame(), UDFTileMixin)
     assert not isinstance(PerFrame(), UDFPreprocessMixin) and PerFrame().get_method() == UDFMethod.FRAME
+
+
+def test_backend_names_of_the_reference_can_be_declared(lt_ctx):
+    """common/udf.py:43-75: a UDF may name the reference's sparse / CuPy tile back-ends beside NumPy in `get_backends`
+    (docs/source/udf/advanced.rst); tiles still arrive as NumPy arrays"""
+    class Declares(UDF):
+        def get_backends(self):
+            return (self.BACKEND_SCIPY_CSR, self.BACKEND_SPARSE_GCXS, self.BACKEND_CUPY, self.BACKEND_NUMPY)
+
+        def get_result_buffers(self):
+            return {'s': self.buffer(kind='nav', dtype=np.float32)}
+
+        def process_tile(self, tile):
+            assert isinstance(tile, np.ndarray) and self.meta.array_backend == self.BACKEND_NUMPY
+            self.results.s[:] = tile.sum(axis=(1, 2))
+    data = np.random.default_rng(0).random((3, 4, 5, 5)).astype(np.float32)
+    ds = lt_ctx.load('memory', data=data)
+    assert np.allclose(lt_ctx.run_udf(dataset=ds, udf=Declares())['s'].data, data.sum(axis=(2, 3)), rtol=1e-5)
+    assert UDF.BACKEND_SCIPY_CSR in UDF.SPARSE_BACKENDS and UDF.BACKEND_NUMPY in UDF.DENSE_BACKENDS
+    assert UDF.BACKEND_SCIPY_CSC in UDF.D2_BACKENDS and UDF.BACKEND_SPARSE_COO in UDF.ND_BACKENDS
+    assert UDF.BACKEND_CUPY_SCIPY_CSR in UDF.CUDA_BACKENDS
