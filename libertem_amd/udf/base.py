@@ -848,6 +848,7 @@ class UDFPartRunner:
                     udf.allocate_for_part(partition, roi,
                                           target=self._result_target(env, i, partition))
                     if hasattr(udf, 'preprocess'):
+                        udf.set_slice(partition.slice)  # (as on the first run: the partition, until the first tile)
                         udf.clear_views()           # (the task's whole buffers: udf/base.py:2250-2252)
                         udf.preprocess()
                 # the launches of this task, for the executor's launch-ahead of later runs (hip.LaunchReplay):
