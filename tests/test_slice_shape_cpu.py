@@ -199,3 +199,21 @@ def test_scale_rotate_flip_y_round_trip():
         c.scale_rotate_flip_y(np.array([(2., 0.), (0., 1.)]))
     with pytest.raises(ValueError, match='shear'):
         c.scale_rotate_flip_y(np.array([(1., 1.), (0., 1.)]) / np.array([1., np.sqrt(2.)]))
+
+
+def test_utils_polar_and_rotations():
+    """libertem.utils (utils/__init__.py:9-132; reference tests/test_utils.py, tests/corrections/test_coordinates.py):
+    polar <-> cartesian round trip, rotations consistent with corrections.coordinates.rotate"""
+    from libertem_amd.utils import make_polar, make_cartesian, rotate_deg, rotate_rad
+    from libertem_amd.corrections import coordinates as c
+    rng = np.random.default_rng(1)
+    cart = rng.random((7, 2)) * 10 - 5
+    pol = make_polar(cart)
+    assert pol.shape == (7, 2) and np.allclose(pol[:, 0], np.hypot(cart[:, 0], cart[:, 1]))
+    assert np.allclose(pol[:, 1], np.arctan2(cart[:, 0], cart[:, 1])) and np.allclose(make_cartesian(pol), cart)
+    grid = rng.random((3, 4, 2))
+    assert np.allclose(make_cartesian(make_polar(grid)), grid)
+    y, x = rng.random((2, 7))
+    r_y, r_x = c.identity() @ c.rotate(np.pi / 180 * 23) @ (y, x)
+    assert np.allclose(rotate_deg(y, x, 23), (r_y, r_x)) and np.allclose(rotate_rad(y, x, np.pi / 180 * 23), (r_y, r_x))
+    assert np.allclose(rotate_deg(1., 0., 90), (0., -1.))        # (y down: clockwise)
