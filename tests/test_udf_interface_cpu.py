@@ -443,3 +443,51 @@ def test_backend_names_of_the_reference_can_be_declared(lt_ctx):
     assert UDF.BACKEND_SCIPY_CSR in UDF.SPARSE_BACKENDS and UDF.BACKEND_NUMPY in UDF.DENSE_BACKENDS
     assert UDF.BACKEND_SCIPY_CSC in UDF.D2_BACKENDS and UDF.BACKEND_SPARSE_COO in UDF.ND_BACKENDS
     assert UDF.BACKEND_CUPY_SCIPY_CSR in UDF.CUDA_BACKENDS
+
+
+def test_libertem_import_alias():
+    """libertem_amd.compat.install(): scripts written against the reference's module names import this package's
+    modules (the same objects), a module this package does not have is an ImportError; in a subprocess -- the alias is
+    per process"""
+    import subprocess
+    import sys
+    code = '''
+import numpy as np
+import libertem_amd.compat as compat
+assert compat.install() and compat.install()
+from libertem.api import Context
+from libertem.udf import UDF, UDFRunCancelled, UDFTileMixin
+from libertem.udf.masks import ApplyMasksUDF
+from libertem.udf.sum import SumUDF
+from libertem.common.buffers import BufferWrapper, reshaped_view
+from libertem.common import Shape, Slice
+from libertem.io.dataset.memory import MemoryDataSet
+from libertem.executor.inline import InlineJobExecutor
+from libertem.analysis.com import guess_corrections
+import libertem.masks, libertem_amd.masks, libertem_amd.api
+assert Context is libertem_amd.api.Context and libertem.masks is libertem_amd.masks
+try:
+    import libertem.web
+    raise SystemExit("libertem.web should not exist")
+except ImportError:
+    pass
+
+class PerFrame(UDF):
+    def get_result_buffers(self):
+        return {"s": self.buffer(kind="nav", dtype=np.float32)}
+    def process_frame(self, frame):
+        self.results.s += frame.sum()
+
+ctx = Context(executor=InlineJobExecutor())
+data = np.arange(2 * 3 * 4 * 4, dtype=np.float32).reshape(2, 3, 4, 4)
+ds = ctx.load("memory", data=data, num_partitions=2)
+res = ctx.run_udf(dataset=ds, udf=[PerFrame(), SumUDF()])
+assert np.array_equal(res[0]["s"].data, data.sum(axis=(2, 3))) and np.array_equal(res[1]["intensity"].data, data.sum(axis=(0, 1)))
+compat.uninstall()
+print("alias ok")
+'''
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and 'alias ok' in r.stdout, r.stderr[-2000:]
