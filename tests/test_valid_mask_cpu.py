@@ -35,12 +35,12 @@ def _ds(ctx, datashape=(16, 16, 32, 32), num_partitions=4):
     return ds.initialize(ctx.executor)
 
 
-class ValidNavMaskUDF(UDF):
+class SeesNavMask(UDF):
     def get_result_buffers(self):
         return {
-            'buf_sig': self.buffer(kind='sig', dtype=np.float32),
-            'buf_nav': self.buffer(kind='nav', dtype=np.float32),
-            'buf_single': self.buffer(kind='single', dtype=np.float32, extra_shape=(1,)),
+            'sig_sum': self.buffer(kind='sig', dtype=np.float32),
+            'per_frame': self.buffer(kind='nav', dtype=np.float32),
+            'scalar': self.buffer(kind='single', dtype=np.float32, extra_shape=(1,)),
         }
 
     def get_results(self):
@@ -59,17 +59,17 @@ class ValidNavMaskUDF(UDF):
     def process_frame(self, frame):
         assert self.meta.get_valid_nav_mask() is None
         assert self.meta.get_valid_nav_mask(full_nav=True) is None
-        self.results.buf_sig += frame
-        self.results.buf_nav[:] = frame.sum()
-        self.results.buf_single[:] = frame.sum()
+        self.results.sig_sum += frame
+        self.results.per_frame[:] = frame.sum()
+        self.results.scalar[:] = frame.sum()
 
     def merge(self, dest, src):
         vm = self.meta.get_valid_nav_mask()
         assert vm is not None
         assert not np.all(vm), "the mask during merge holds what is merged ALREADY: never everything"
-        dest.buf_sig += src.buf_sig
-        dest.buf_single += src.buf_single
-        dest.buf_nav[:] = src.buf_nav
+        dest.sig_sum += src.sig_sum
+        dest.scalar += src.scalar
+        dest.per_frame[:] = src.per_frame
 
 
 @pytest.mark.parametrize('roi_kind', [None, 'block', 'random'])
@@ -82,48 +82,48 @@ def test_valid_nav_mask_available(lt_ctx, roi_kind):
     elif roi_kind == 'random':
         roi = np.random.default_rng(5).choice([True, False], size=(16, 16))
     seen = []
-    for res in lt_ctx.run_udf_iter(dataset=ds, udf=ValidNavMaskUDF(), roi=roi):
-        nav = res.buffers[0]['buf_nav']
+    for res in lt_ctx.run_udf_iter(dataset=ds, udf=SeesNavMask(), roi=roi):
+        nav = res.buffers[0]['per_frame']
         assert np.array_equal(nav.valid_mask, res.damage.data)       # the default of a nav buffer IS the damage
         assert nav.valid_mask.shape == nav.data.shape == (16, 16)
         seen.append(int(np.count_nonzero(res.damage.data)))
     assert seen == sorted(seen) and seen[-1] == (256 if roi is None else np.count_nonzero(roi))
 
 
-class AdjustValidMaskUDF(UDF):
+class MasksOfItsOwn(UDF):
     def get_result_buffers(self):
         return {
-            'all_valid': self.buffer(kind='sig', dtype=np.float32),
-            'all_invalid': self.buffer(kind='sig', dtype=np.float32),
-            'keep': self.buffer(kind='nav', dtype=np.float32),
-            'nav_with_extra': self.buffer(kind='nav', dtype=np.float32, extra_shape=(2,)),
-            'custom_2d': self.buffer(kind='single', dtype=np.float32, extra_shape=(64, 64)),
+            'everything': self.buffer(kind='sig', dtype=np.float32),
+            'nothing': self.buffer(kind='sig', dtype=np.float32),
+            'default_nav': self.buffer(kind='nav', dtype=np.float32),
+            'default_nav_extra': self.buffer(kind='nav', dtype=np.float32, extra_shape=(2,)),
+            'half_plane': self.buffer(kind='single', dtype=np.float32, extra_shape=(64, 64)),
         }
 
     def get_results(self):
-        custom_mask = np.zeros((64, 64), dtype=bool)
-        custom_mask[:, 32:] = True
+        right_half = np.zeros((64, 64), dtype=bool)
+        right_half[:, 32:] = True
         return {
-            'all_valid': self.with_mask(self.results.all_valid, mask=True),
-            'all_invalid': self.with_mask(self.results.all_invalid, mask=False),
-            'keep': self.results.keep,
-            'nav_with_extra': self.results.nav_with_extra,
-            'custom_2d': self.with_mask(self.results.custom_2d, mask=custom_mask),
+            'everything': self.with_mask(self.results.everything, mask=True),
+            'nothing': self.with_mask(self.results.nothing, mask=False),
+            'default_nav': self.results.default_nav,
+            'default_nav_extra': self.results.default_nav_extra,
+            'half_plane': self.with_mask(self.results.half_plane, mask=right_half),
         }
 
     def process_frame(self, frame):
-        self.results.all_valid += frame
-        self.results.all_invalid += frame
-        self.results.keep[:] = frame.sum()
-        self.results.nav_with_extra[:] = frame.sum()
-        self.results.custom_2d = 42                      # (attribute assignment writes INTO the buffer: udf/base.py:673-678)
+        self.results.everything += frame
+        self.results.nothing += frame
+        self.results.default_nav[:] = frame.sum()
+        self.results.default_nav_extra[:] = frame.sum()
+        self.results.half_plane = 42                      # (attribute assignment writes INTO the buffer: udf/base.py:673-678)
 
     def merge(self, dest, src):
-        dest.all_valid += src.all_valid
-        dest.all_invalid += src.all_invalid
-        dest.custom_2d += src.custom_2d
-        dest.keep[:] = src.keep
-        dest.nav_with_extra[:] = src.nav_with_extra
+        dest.everything += src.everything
+        dest.nothing += src.nothing
+        dest.half_plane += src.half_plane
+        dest.default_nav[:] = src.default_nav
+        dest.default_nav_extra[:] = src.default_nav_extra
 
 
 @pytest.mark.parametrize('with_roi', [True, False])
@@ -131,25 +131,25 @@ def test_adjust_valid_mask(lt_ctx, with_roi):
     """`get_results` sets masks of its own; what it does not mention keeps the default (test_valid_mask.py:144-188)"""
     ds = _ds(lt_ctx)
     roi = np.random.default_rng(1).choice([True, False], size=(16, 16)) if with_roi else None
-    custom_expected = np.zeros((64, 64), dtype=bool)
-    custom_expected[:, 32:] = True
+    want_right_half = np.zeros((64, 64), dtype=bool)
+    want_right_half[:, 32:] = True
     n = 0
-    for res in lt_ctx.run_udf_iter(dataset=ds, udf=AdjustValidMaskUDF(), roi=roi):
+    for res in lt_ctx.run_udf_iter(dataset=ds, udf=MasksOfItsOwn(), roi=roi):
         b = res.buffers[0]
-        assert np.all(b['all_valid'].valid_mask) and b['all_valid'].valid_mask.shape == b['all_valid'].data.shape
-        assert not np.any(b['all_invalid'].valid_mask)
-        assert b['all_invalid'].valid_mask.shape == b['all_invalid'].data.shape == (32, 32)
-        assert np.array_equal(b['keep'].valid_mask, res.damage.data)
-        assert b['nav_with_extra'].valid_mask.shape == (16, 16, 2)
-        assert np.array_equal(b['nav_with_extra'].valid_mask,
+        assert np.all(b['everything'].valid_mask) and b['everything'].valid_mask.shape == b['everything'].data.shape
+        assert not np.any(b['nothing'].valid_mask)
+        assert b['nothing'].valid_mask.shape == b['nothing'].data.shape == (32, 32)
+        assert np.array_equal(b['default_nav'].valid_mask, res.damage.data)
+        assert b['default_nav_extra'].valid_mask.shape == (16, 16, 2)
+        assert np.array_equal(b['default_nav_extra'].valid_mask,
                               np.broadcast_to(res.damage.data.reshape((16, 16, 1)), (16, 16, 2)))
-        assert np.array_equal(b['custom_2d'].valid_mask, custom_expected)
-        assert np.all(b['custom_2d'].data == 42 * (n + 1))                      # one partition's 42 per merge
+        assert np.array_equal(b['half_plane'].valid_mask, want_right_half)
+        assert np.all(b['half_plane'].data == 42 * (n + 1))                      # one partition's 42 per merge
         n += 1
     assert n == 4
 
 
-class CustomMaskFromParams(UDF):
+class MaskGivenAsParameter(UDF):
     def __init__(self, mask):
         super().__init__(mask=mask)
 
@@ -167,44 +167,44 @@ class CustomMaskFromParams(UDF):
 
 
 @pytest.mark.parametrize("mask_shape", [(32, 32), (1, 32), (64, 64), (64, 64, 4), (1, 1, 4), (1, 1, 1, 1)])
-def test_custom_mask_invalid_shape(mask_shape, lt_ctx):
+def test_right_half_invalid_shape(mask_shape, lt_ctx):
     """shapes that do not broadcast to (64, 64, 3) (test_valid_mask.py:211-232)"""
     ds = _ds(lt_ctx, (16, 16, 4, 4))
     with pytest.raises(InvalidMaskError):
-        for res in lt_ctx.run_udf_iter(dataset=ds, udf=CustomMaskFromParams(mask=np.zeros(mask_shape, dtype=bool))):
+        for res in lt_ctx.run_udf_iter(dataset=ds, udf=MaskGivenAsParameter(mask=np.zeros(mask_shape, dtype=bool))):
             res.buffers
 
 
 @pytest.mark.parametrize("mask_dtype", [int, "float32", "complex64"])
-def test_custom_mask_invalid_dtype(mask_dtype, lt_ctx):
+def test_right_half_invalid_dtype(mask_dtype, lt_ctx):
     ds = _ds(lt_ctx, (16, 16, 4, 4))
     with pytest.raises(InvalidMaskError):
-        for res in lt_ctx.run_udf_iter(dataset=ds, udf=CustomMaskFromParams(mask=np.zeros((16, 16), dtype=mask_dtype))):
+        for res in lt_ctx.run_udf_iter(dataset=ds, udf=MaskGivenAsParameter(mask=np.zeros((16, 16), dtype=mask_dtype))):
             res.buffers
 
 
 @pytest.mark.parametrize("mask_shape", [(), (1,), (1, 1), (1, 1, 1), (64, 64, 1), (64, 64, 3)])
-def test_custom_mask_valid(mask_shape, lt_ctx):
+def test_right_half_valid(mask_shape, lt_ctx):
     ds = _ds(lt_ctx, (16, 16, 4, 4))
-    for res in lt_ctx.run_udf_iter(dataset=ds, udf=CustomMaskFromParams(mask=np.zeros(mask_shape, dtype=bool))):
+    for res in lt_ctx.run_udf_iter(dataset=ds, udf=MaskGivenAsParameter(mask=np.zeros(mask_shape, dtype=bool))):
         vm = res.buffers[0]['custom'].valid_mask
         assert vm.shape == (64, 64, 3) and not vm.any()
 
 
 def test_valid_mask_slice_bounding(lt_ctx):
     ds = _ds(lt_ctx)
-    for res in lt_ctx.run_udf_iter(dataset=ds, udf=AdjustValidMaskUDF()):
+    for res in lt_ctx.run_udf_iter(dataset=ds, udf=MasksOfItsOwn()):
         b = res.buffers[0]
-        buf = b['all_valid']
+        buf = b['everything']
         assert buf.data[buf.valid_slice_bounding].shape == buf.data.shape
-        buf = b['all_invalid']
+        buf = b['nothing']
         assert prod(buf.data[buf.valid_slice_bounding].shape) == 0
-        buf = b['keep']
+        buf = b['default_nav']
         assert prod(buf.data[buf.valid_slice_bounding].shape) >= np.count_nonzero(res.damage.data)
         # whole nav rows are valid after every partition of this 16 x 16 scan in 4 partitions
         inner = buf.get_valid_slice_inner(axis=0)
         assert np.all(buf.valid_mask[inner]) and buf.data[inner].size == np.count_nonzero(res.damage.data)
-        buf = b['custom_2d']
+        buf = b['half_plane']
         assert buf.valid_slice_bounding == np.s_[0:64, 32:64]
         assert buf.get_valid_slice_inner(axis=1) == np.s_[:, 32:64]
 
@@ -213,7 +213,7 @@ def test_valid_mask_slice_bounding(lt_ctx):
 def test_masked_data_and_raw_masked_data(lt_ctx, with_roi):
     ds = _ds(lt_ctx)
     roi = np.random.default_rng(2).choice(a=[True, False], size=(16, 16)) if with_roi else None
-    for res in lt_ctx.run_udf_iter(dataset=ds, udf=AdjustValidMaskUDF(), roi=roi):
+    for res in lt_ctx.run_udf_iter(dataset=ds, udf=MasksOfItsOwn(), roi=roi):
         for k, buf in res.buffers[0].items():
             want = np.sum(buf.data[buf.valid_mask])
             for md in (buf.masked_data, buf.raw_masked_data):
@@ -284,32 +284,32 @@ def test_default_mask_extra_shape(kind, roi, valid, want_shape):
         assert m.all()
 
 
-class CustomValidMask(UDF):
+class SingleBufferFollowsNav(UDF):
     """a kind='single' buffer whose mask follows the nav mask (test_valid_mask.py:433-462)"""
 
     def get_result_buffers(self):
         nav_shape = tuple(self.meta.dataset_shape.nav)
         if self.meta.roi is not None:
             nav_shape = (int(np.count_nonzero(self.meta.roi)),)
-        return {'custom_2d': self.buffer(kind='single', dtype=np.float32, extra_shape=nav_shape)}
+        return {'half_plane': self.buffer(kind='single', dtype=np.float32, extra_shape=nav_shape)}
 
     def process_frame(self, frame):
-        self.results.custom_2d[tuple(self.meta.coordinates[0])] = np.sum(frame)
+        self.results.half_plane[tuple(self.meta.coordinates[0])] = np.sum(frame)
 
     def get_results(self):
         vm = self.meta.get_valid_nav_mask()
-        return {'custom_2d': self.with_mask(self.results.custom_2d, mask=vm.reshape(self.results.custom_2d.shape))}
+        return {'half_plane': self.with_mask(self.results.half_plane, mask=vm.reshape(self.results.half_plane.shape))}
 
     def merge(self, dest, src):
-        dest.custom_2d += src.custom_2d
+        dest.half_plane += src.half_plane
 
 
 @pytest.mark.parametrize('with_roi', [False])
 def test_adjust_valid_mask_extra(lt_ctx, with_roi):
     data = np.random.default_rng(3).random((16, 16, 8, 8)).astype(np.float32)
     ds = MemoryDataSet(data=data, num_partitions=4).initialize(lt_ctx.executor)
-    res = lt_ctx.run_udf(dataset=ds, udf=CustomValidMask())
-    buf = res['custom_2d']
+    res = lt_ctx.run_udf(dataset=ds, udf=SingleBufferFollowsNav())
+    buf = res['half_plane']
     assert buf.valid_mask.shape == (16, 16) and buf.valid_mask.all()
     assert np.allclose(buf.data, data.sum(axis=(2, 3)), rtol=1e-5)
 
